@@ -1,0 +1,191 @@
+/*
+ * tsba.h -- C ABI of the MI355X-native bundle-adjustment / pose-optimisation back-end.
+ *
+ * Drop-in boundary for TextSLAM's optimizer:: hot path.  Every entry point replaces the
+ * numeric core of one public optimizer method of the reference (citations are relative to
+ * the TextSLAM tree):
+ *
+ *   tsba_local_ba     <- optimizer::LocalBundleAdjustment   src/optimizer.cc:197-331  (PyrBA :1330-1698)
+ *   tsba_pose_optim   <- optimizer::PoseOptim               src/optimizer.cc:135-195  (PyrPoseOptim :1060-1327)
+ *   tsba_global_ba    <- optimizer::GlobalBA                src/optimizer.cc:334-453  (PyrGlobalBA :1701-1851)
+ *   tsba_eval         <- ceres::Problem::Evaluate as used at src/optimizer.cc:1228-1231, 1609-1612
+ *
+ * The reference methods traffic in Eigen / OpenCV / keyframe* object graphs; the header-only
+ * adapter shown in INTEGRATION.md gathers those into the flat, plain-pointer description
+ * below (row B1 of SURVEY.md section 8a) and scatters the results back (rows O2/O3).
+ *
+ * Conventions
+ *   - pose[7] = (qw,qx,qy,qz, tx,ty,tz) of T_cw (world -> camera)      optimizer.cc:84-90
+ *   - scene point = host KF r + ray (mx,my,1) + inverse depth rho       mapPts.cc:49-69
+ *   - text plane  = host KF r + theta (= n/d in the host camera frame)   ModelTool.hpp:164-171
+ *   - K_l = K / 2^l with K_l(2,2) = 1                                    optimizer.cc:43-52
+ *   - all arithmetic fp64 (as the reference); images uint8, row stride == width
+ *   - every pointer is a HOST pointer owned by the caller; the library keeps device mirrors in ctx
+ *   - return 0 = OK, negative = error (the library never calls exit())
+ *   - one ctx per calling thread; calls are synchronous
+ */
+#ifndef TSBA_H
+#define TSBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSBA_MAX_LEVELS 4
+#define TSBA_NTAP 8            /* INTERVAL8 pattern, tool.cc:1550-1561 */
+
+/* error codes */
+#define TSBA_OK              0
+#define TSBA_ERR_ARG        -1
+#define TSBA_ERR_DEVICE     -2   /* no HIP device / HIP runtime error */
+#define TSBA_ERR_NUMERIC    -3   /* Cholesky breakdown, NaN */
+#define TSBA_ERR_STATE      -4   /* call order (no problem uploaded ...) */
+#define TSBA_ERR_COMM       -5   /* RCCL failure */
+
+/* BAStatus, setting.h */
+#define TSBA_STATE_NOTREACHWIN 0
+#define TSBA_STATE_LOCAL       1
+#define TSBA_STATE_GLOBAL      2
+
+typedef struct tsba_problem {
+    int32_t n_kf, n_pt, n_text;
+    int32_t n_levels;                 /* number of pyramid levels described below (1..4) */
+    double  K[4];                     /* fx, fy, cx, cy of level 0 */
+
+    /* ---- parameters (in/out) ---- */
+    double  *pose;                    /* [n_kf][7] */
+    double  *rho;                     /* [n_pt] */
+    double  *theta;                   /* [n_text][3] */
+
+    /* ---- gauge (row L4): KFs with mnId 0/1, optimizer.cc:274-275 ---- */
+    const uint8_t *kf_initial;        /* [n_kf] 1 = "InitialIdx" keyframe */
+
+    /* ---- scene points ---- */
+    const double  *pt_ray;            /* [n_pt][2] mx,my   (mapPts::GetRaydir, z == 1) */
+    const int32_t *pt_host;           /* [n_pt] KF index of the host, or -1: host outside the
+                                         window => landmark and host pose frozen (vMapPtOptim=false) */
+    const double  *pt_host_Trw;       /* [n_pt][12] row-major 3x4 T_rw of the host (RefKF->mTcw);
+                                         read only where pt_host < 0; may be NULL if none */
+    /* ---- text planes ---- */
+    const int32_t *text_host;         /* [n_text] KF index or -1 (vMapTextOptim=false) */
+    const double  *text_host_Twr;     /* [n_text][12] row-major 3x4 T_wr (RefKF->mTwc); read where text_host < 0 */
+    const double  *text_box_ray;      /* [n_text][4][2] vTextDeteRay, mapText.cc:87-90 */
+
+    /* ---- scene observations, per level, in the reference's residual order
+     *      (KF-major, then vSceneObv2d[level] order; optimizer.cc:1366-1435) ---- */
+    int32_t        n_sobs[TSBA_MAX_LEVELS];
+    const int32_t *sobs_kf[TSBA_MAX_LEVELS];    /* [n_sobs] target KF index */
+    const int32_t *sobs_pt[TSBA_MAX_LEVELS];    /* [n_sobs] point index */
+    const int32_t *sobs_flag[TSBA_MAX_LEVELS];  /* [n_sobs] index into sgood[] (KF offset + IdxToRaw) */
+    const double  *sobs_uv0[TSBA_MAX_LEVELS];   /* [n_sobs][2] LEVEL-0 pixel (SceneUse0Pyr, optimizer.cc:1336) */
+    int32_t        n_sgood;
+    uint8_t       *sgood;                       /* [n_sgood] vObvGoodPts of all KFs, concatenated; in/out */
+
+    /* ---- text reference features per level (mapText::vRefFeature[level]), grouped by text ---- */
+    int32_t        n_tfeat[TSBA_MAX_LEVELS];
+    const int32_t *tfeat_off[TSBA_MAX_LEVELS];  /* [n_text+1] CSR: features of text j are [off[j], off[j+1]) */
+    const int32_t *tfeat_raw[TSBA_MAX_LEVELS];  /* [n_tfeat] IdxToRaw (index of the level-0 feature) */
+    const double  *tfeat_uv[TSBA_MAX_LEVELS];   /* [n_tfeat][2] feature centre (u,v) in the HOST level-l image;
+                                                   the 8 tap rays are ((u+dx-cx_l)/fx_l,(v+dy-cy_l)/fy_l,1), tool.cc:1550-1566 */
+    const double  *tfeat_ref[TSBA_MAX_LEVELS];  /* [n_tfeat][8] neighbourNInten (normalised host intensities) */
+
+    /* ---- text observations: (KF, text) pairs, KF-major (GetStateTextObvs order) ---- */
+    int32_t        n_tobs;
+    const int32_t *tobs_kf;           /* [n_tobs] */
+    const int32_t *tobs_text;         /* [n_tobs] */
+    uint8_t       *tobs_good;         /* [n_tobs] vObvGoodTexts; in/out */
+    const int32_t *tobs_fgood_off;    /* [n_tobs+1] offsets into tfgood (one flag per LEVEL-0 feature of the text) */
+    uint8_t       *tfgood;            /* [tobs_fgood_off[n_tobs]] vObvGoodTextFeats; in/out */
+
+    /* ---- images: level l of KF k = img[l][k], continuous uint8, img_w[l] x img_h[l] ---- */
+    const uint8_t *const *img[TSBA_MAX_LEVELS]; /* img[l] = array of n_kf pointers (may be NULL if no text) */
+    int32_t        img_w[TSBA_MAX_LEVELS], img_h[TSBA_MAX_LEVELS];
+} tsba_problem;
+
+typedef struct tsba_options {
+    /* residual weights and robust kernels, optimizer.cc:1350-1351,1369,1454 */
+    double  w_sx, w_sy, w_t;
+    double  huber_scene, huber_text;
+    /* pyramid passes, optimizer.cc:282-289 (local), :174-186 (pose), :411-414 (global) */
+    int32_t n_passes;
+    int32_t levels[TSBA_MAX_LEVELS];
+    int32_t its[TSBA_MAX_LEVELS];
+    double  chi2_mono[TSBA_MAX_LEVELS];
+    double  chi2_text[TSBA_MAX_LEVELS];
+    double  text_bad_ratio;          /* 0.99 */
+    int32_t state;                   /* TSBA_STATE_* (gauge rule, optimizer.cc:1571-1588) */
+    int32_t outlier_scene, outlier_text;   /* O1 on/off (off when bFlag_rapid) */
+    int32_t use_text;                /* FLAG_TEXT */
+    int32_t filter_good;             /* 1: skip observations whose good-flag is 0 (local/pose); 0: global BA */
+    int32_t text_jacobian;           /* 0 analytic bilinear (HIP path), 1 Ceres CENTRAL numeric diff (oracle only) */
+    /* Levenberg-Marquardt constants = Ceres 1.x defaults */
+    double  initial_radius, max_radius, min_radius;
+    double  min_relative_decrease;
+    double  function_tolerance, gradient_tolerance, parameter_tolerance;
+    double  min_diagonal, max_diagonal;
+    /* multi-GPU (global BA): this rank's share of the landmarks is [lm_shard, n) stride lm_nshard */
+    int32_t lm_shard, lm_nshard;
+} tsba_options;
+
+typedef struct tsba_report {
+    int32_t status;
+    int32_t n_passes;
+    int32_t iters[TSBA_MAX_LEVELS];        /* LM iterations taken (incl. unsuccessful) */
+    int32_t accepted[TSBA_MAX_LEVELS];     /* successful steps */
+    int32_t termination[TSBA_MAX_LEVELS];  /* 0 max-iter, 1 function tol, 2 parameter tol, 3 gradient tol, 4 radius, 5 failure */
+    double  cost0[TSBA_MAX_LEVELS], cost1[TSBA_MAX_LEVELS];
+    int64_t n_sblock[TSBA_MAX_LEVELS], n_tblock[TSBA_MAX_LEVELS];   /* residual blocks in the problem */
+    int64_t n_resid_evals;                 /* scalar residuals evaluated, one count per LM trial step + linearisation */
+    int32_t n_bad_scene[TSBA_MAX_LEVELS], n_bad_tfeat[TSBA_MAX_LEVELS], n_bad_text[TSBA_MAX_LEVELS];
+    double  t_upload_ms, t_solve_ms, t_download_ms;
+} tsba_report;
+
+/* Reference defaults for the three public methods. */
+void tsba_default_options_local (tsba_options *o);   /* levels 2,1,0 x10, chi2 12.25 / .5 .5 .5(.95 at 0) */
+void tsba_default_options_pose  (tsba_options *o);
+void tsba_default_options_global(tsba_options *o);   /* level 0, 20 its, unweighted, scene only */
+
+/* ---- context ---- */
+int  tsba_create (void **ctx, int device);   /* TSBA_ERR_DEVICE if no gfx950 device is usable */
+int  tsba_destroy(void *ctx);
+const char *tsba_last_error(void *ctx);
+
+/* ---- one-shot calls (upload + solve + download), the optimizer:: replacements ---- */
+int  tsba_local_ba  (void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r);
+int  tsba_pose_optim(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r);  /* n_kf==1, all landmarks frozen */
+int  tsba_global_ba (void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r);
+
+/* ---- staged calls (bench / repeated solves with the problem resident in HBM) ---- */
+int  tsba_upload  (void *ctx, const tsba_problem *p, const tsba_options *o);
+int  tsba_solve   (void *ctx, tsba_report *r);        /* restarts from the uploaded parameters every call */
+int  tsba_download(void *ctx, tsba_problem *p);       /* parameters + good flags of the last solve */
+
+/* ---- test hooks ---- */
+/* Residuals (+ optional Jacobians) of every residual block of pyramid level `level`, in the
+ * reference's block order (scene blocks first, optimizer.cc:1609-1612).  Blocks are the ones the
+ * reference would add (good-flag filtering per options.filter_good).
+ *   resid    [2*ns + 8*nt]             raw residuals (no loss applied)
+ *   jac      scene block: 2 x 13 row-major  (target d_rot3,t3 | host d_rot3,t3 | rho)   tangent space of
+ *            text  block: 8 x 15 row-major  (target 6 | host 6 | theta3)                 ceres::QuaternionParameterization
+ *            frozen-host blocks fill only the target 6 columns (others 0).  May be NULL.
+ *   musigma  [n_tobs][2] mu, sigma used (may be NULL)
+ *   ns, nt   out: number of scene / text blocks
+ */
+int  tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int level,
+               double *resid, double *jac, double *musigma, int64_t *ns, int64_t *nt);
+
+/* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
+ * equation accumulation) over n launches on the library's stream, measured with HIP events.
+ * Requires an uploaded problem; `level` selects the pass.  Also returns the algorithmic bytes of one launch. */
+int  tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *algo_bytes);
+
+/* ---- multi-GPU: RCCL communicator for tsba_global_ba (one process per GPU) ---- */
+int  tsba_comm_unique_id(void *id128);                       /* rank 0: fills 128 bytes */
+int  tsba_comm_init(void *ctx, const void *id128, int rank, int world);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSBA_H */

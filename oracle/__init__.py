@@ -1,0 +1,116 @@
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+ctypes loader for the CPU oracle (oracle/tsba_oracle.c, a plain-C restatement of the reference's
+BA / pose-optimisation algorithm; PARITY UNPINNED, see tsba_oracle.h).  Importable only from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from textslam_amd.abi import TsbaProblem, TsbaOptions, TsbaReport, BAProblem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libtsba_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.tsba_oracle_eval.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, dp, dp, dp,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.tsba_oracle_eval.restype = C.c_int
+        L.tsba_oracle_solve.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.POINTER(TsbaReport)]
+        L.tsba_oracle_solve.restype = C.c_int
+        L.tsba_oracle_musigma.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, dp, dp, dp]
+        L.tsba_oracle_musigma.restype = C.c_int
+        L.tsba_oracle_fillpoly4.argtypes = [C.c_int, C.c_int, ip, C.POINTER(C.c_uint8)]
+        L.tsba_oracle_fillpoly4.restype = None
+        L.tsba_oracle_reduced_system.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, C.c_double,
+                                                 ip, dp, dp, dp, dp, dp]
+        L.tsba_oracle_reduced_system.restype = C.c_int
+        L.tsba_oracle_default_options.argtypes = [C.POINTER(TsbaOptions), C.c_int]
+        L.tsba_oracle_default_options.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def count_blocks(prob: BAProblem, opt: TsbaOptions, level: int):
+    ns, nt = C.c_int64(0), C.c_int64(0)
+    s = prob.struct()
+    rc = lib().tsba_oracle_eval(C.byref(s), C.byref(opt), level, None, None, None, C.byref(ns), C.byref(nt))
+    assert rc == 0, rc
+    return ns.value, nt.value
+
+
+def evaluate(prob: BAProblem, opt: TsbaOptions, level: int, jac=True):
+    """-> dict(resid, jac_scene [ns,2,13], jac_text [nt,8,15], musigma [n_tobs,2], ns, nt)"""
+    ns, nt = count_blocks(prob, opt, level)
+    resid = np.zeros(2 * ns + 8 * nt)
+    J = np.zeros(26 * ns + 120 * nt) if jac else None
+    ms = np.zeros((max(prob.n_tobs, 1), 2))
+    s = prob.struct()
+    a, b = C.c_int64(0), C.c_int64(0)
+    rc = lib().tsba_oracle_eval(C.byref(s), C.byref(opt), level, _dp(resid), _dp(J) if jac else None, _dp(ms),
+                                C.byref(a), C.byref(b))
+    assert rc == 0, rc
+    out = {"resid": resid, "ns": ns, "nt": nt, "musigma": ms[:prob.n_tobs]}
+    if jac:
+        out["jac_scene"] = J[:26 * ns].reshape(ns, 2, 13)
+        out["jac_text"] = J[26 * ns:].reshape(nt, 8, 15)
+    return out
+
+
+def solve(prob: BAProblem, opt: TsbaOptions):
+    """In-place solve of `prob` (parameters and good flags are overwritten). Returns the report dict."""
+    s = prob.struct()
+    rep = TsbaReport()
+    rc = lib().tsba_oracle_solve(C.byref(s), C.byref(opt), C.byref(rep))
+    assert rc == 0, rc
+    return rep.as_dict()
+
+
+def musigma(img: np.ndarray, corners: np.ndarray):
+    img = np.ascontiguousarray(img, np.uint8)
+    c = np.ascontiguousarray(corners, np.float64).reshape(-1)
+    mu, sg = C.c_double(0), C.c_double(0)
+    ok = lib().tsba_oracle_musigma(img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[1], img.shape[0], _dp(c),
+                                   C.byref(mu), C.byref(sg))
+    return ok, mu.value, sg.value
+
+
+def fillpoly4(w, h, xy):
+    xy = np.ascontiguousarray(xy, np.int32).reshape(-1)
+    m = np.zeros((h, w), np.uint8)
+    lib().tsba_oracle_fillpoly4(w, h, xy.ctypes.data_as(C.POINTER(C.c_int32)), m.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return m
+
+
+def reduced_system(prob: BAProblem, opt: TsbaOptions, level: int, radius: float):
+    n6 = 6 * prob.n_kf
+    S, g = np.zeros(n6 * n6), np.zeros(n6)
+    Hpp, bp = np.zeros(n6 * n6), np.zeros(n6)
+    free = np.zeros(prob.n_kf, np.int32)
+    cost = C.c_double(0)
+    s = prob.struct()
+    nf = lib().tsba_oracle_reduced_system(C.byref(s), C.byref(opt), level, radius,
+                                          free.ctypes.data_as(C.POINTER(C.c_int32)), _dp(S), _dp(g), _dp(Hpp), _dp(bp),
+                                          C.byref(cost))
+    assert nf >= 0, nf
+    m = 6 * nf
+    return {"nf": nf, "free_idx": free, "S": S[:m * m].reshape(m, m), "g": g[:m], "Hpp": Hpp[:m * m].reshape(m, m),
+            "bp": bp[:m], "cost": cost.value}

@@ -1,0 +1,431 @@
+"""Seeded synthetic BA problems: the workloads of bench.py and the parity tests.
+
+There is no dataset and no Ceres / OpenCV in the image, so every configuration is generated:
+camera K = yaml/GeneralMotion.yaml:12-15, 640x480; keyframes on a gentle arc; inverse-depth
+points hosted in their first observer; planar text patches with a band-limited texture rendered
+into every keyframe through the true plane-induced homography, so that photometric residuals
+vanish at ground truth.  Pure numpy, deterministic for a given seed.
+"""
+import numpy as np
+from .abi import BAProblem, MAX_LEVELS
+
+K_GENERAL_MOTION = np.array([384.396254546, 382.825746531, 315.635886103, 249.182929809])
+SEED = 20240926
+TAP_DX = np.array([0, 2, 1, 0, -1, -2, -1, 0], np.float64)      # tool.cc:1550-1557 (INTERVAL8)
+TAP_DY = np.array([0, 0, -1, -2, -1, 0, 1, 2], np.float64)
+W, H = 640, 480
+
+
+def _rot_y(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def _rodrigues(v):
+    th = np.linalg.norm(v)
+    if th < 1e-15:
+        return np.eye(3)
+    k = v / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def _R_to_q(R):
+    """Eigen's Quaternion(Matrix3) (w,x,y,z), normalised -- what optimizer.cc:84-90 feeds Ceres."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0)
+        w = 0.5 * s
+        s = 0.5 / s
+        q = np.array([w, (R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        v = np.zeros(3)
+        v[i] = 0.5 * s
+        s = 0.5 / s
+        w = (R[k, j] - R[j, k]) * s
+        v[j] = (R[j, i] + R[i, j]) * s
+        v[k] = (R[k, i] + R[i, k]) * s
+        q = np.array([w, v[0], v[1], v[2]])
+    return q / np.linalg.norm(q)
+
+
+def _cam(k, step=0.1, yaw_deg=0.35):
+    """T_cw of camera k (k may be negative: hosts that already left the window)."""
+    c = np.array([step * k, 0.02 * np.sin(0.3 * k), 0.03 * np.cos(0.2 * k)])
+    Rwc = _rot_y(np.deg2rad(yaw_deg) * k)
+    Rcw = Rwc.T
+    return Rcw, -Rcw @ c
+
+
+def _bilinear(img, u, v):
+    h, w = img.shape
+    uf, vf = np.floor(u).astype(int), np.floor(v).astype(int)
+    ok = (uf >= 0) & (vf >= 0) & (np.ceil(u) < w) & (np.ceil(v) < h)
+    uf0, vf0 = np.clip(uf, 0, w - 2), np.clip(vf, 0, h - 2)
+    a, b = u - uf, v - vf
+    I = ((1 - a) * (1 - b) * img[vf0, uf0] + a * (1 - b) * img[vf0, uf0 + 1]
+         + (1 - a) * b * img[vf0 + 1, uf0] + a * b * img[vf0 + 1, uf0 + 1])
+    return np.where(ok, I, 0.0)
+
+
+def _quad_stats(img, corners):
+    """mean / sample-std of the pixels whose centres lie inside a convex quad (host-side reference statistics)."""
+    h, w = img.shape
+    x0, x1 = int(max(0, np.floor(corners[:, 0].min()))), int(min(w - 1, np.ceil(corners[:, 0].max())))
+    y0, y1 = int(max(0, np.floor(corners[:, 1].min()))), int(min(h - 1, np.ceil(corners[:, 1].max())))
+    if x1 < x0 or y1 < y0:
+        return 0.0, 0.0
+    xs, ys = np.meshgrid(np.arange(x0, x1 + 1), np.arange(y0, y1 + 1))
+    inside = np.ones(xs.shape, bool)
+    sign = None
+    for i in range(4):
+        a, b = corners[i], corners[(i + 1) % 4]
+        cr = (b[0] - a[0]) * (ys - a[1]) - (b[1] - a[1]) * (xs - a[0])
+        if sign is None:
+            sign = 1.0 if np.sum(cr > 0) >= np.sum(cr < 0) else -1.0
+        inside &= (cr * sign >= 0)
+    vals = img[y0:y1 + 1, x0:x1 + 1][inside].astype(np.float64)
+    if vals.size < 2:
+        return 0.0, 0.0
+    return float(vals.mean()), float(vals.std(ddof=1))
+
+
+def _pyr_down(img):
+    h, w = img.shape[-2] // 2 * 2, img.shape[-1] // 2 * 2
+    a = img[..., :h, :w].astype(np.uint16)
+    s = a[..., 0::2, 0::2] + a[..., 0::2, 1::2] + a[..., 1::2, 0::2] + a[..., 1::2, 1::2]
+    return ((s + 2) // 4).astype(np.uint8)
+
+
+class _Plane:
+    pass
+
+
+def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), max_targets=5, text_targets=5,
+                 frozen_frac=0.1, outlier_frac=0.05, noise_px=0.5, perturb=True, n_levels=3,
+                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True):
+    """Build a synthetic window (local BA / pose-only / global BA depending on the arguments).
+
+    n_kf == 1 with frozen_frac == 1 gives the pose-only problem (every landmark hosted outside).
+    n_text == 0 skips image synthesis (global BA, scene points only, as the reference's GlobalBA).
+    """
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = K_GENERAL_MOTION
+    P = BAProblem()
+    P.K = K_GENERAL_MOTION.copy()
+    P.n_levels = n_levels if n_text > 0 else 1
+    band = band or n_kf
+    # cameras: window 0..n_kf-1, outside hosts -1..-n_out
+    cams = {k: _cam(k) for k in range(-n_out, n_kf)}
+    Rcw = np.stack([cams[k][0] for k in range(n_kf)])
+    tcw = np.stack([cams[k][1] for k in range(n_kf)])
+
+    def project(k, Xw):
+        R, t = cams[k]
+        Xc = Xw @ R.T + t
+        z = Xc[..., 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = fx * Xc[..., 0] / z + cx
+            v = fy * Xc[..., 1] / z + cy
+        return u, v, z
+
+    # ------------------------------------------------------------------ scene points
+    frozen = rng.random(n_pt) < frozen_frac
+    if n_kf == 1:
+        frozen[:] = True
+    host = np.where(frozen, -1 - rng.integers(0, n_out, n_pt), rng.integers(0, max(1, n_kf - 1), n_pt)).astype(np.int64)
+    u0 = rng.uniform(16, W - 16, n_pt)
+    v0 = rng.uniform(16, H - 16, n_pt)
+    rho = rng.uniform(0.125, 0.5, n_pt)
+    far = rng.random(n_pt) < far_frac
+    rho[far] = rng.uniform(0.01, 0.02, far.sum())
+    ray = np.stack([(u0 - cx) / fx, (v0 - cy) / fy], 1)
+    Xh = np.concatenate([ray, np.ones((n_pt, 1))], 1) / rho[:, None]
+    Xw = np.empty((n_pt, 3))
+    for k in np.unique(host):
+        m = host == k
+        R, t = cams[int(k)]
+        Xw[m] = (Xh[m] - t) @ R          # X_w = R^T (X_c - t)
+    per_kf = [[] for _ in range(n_kf)]    # (pt, u, v)
+    order = np.arange(n_pt)
+    for j in order:
+        h = int(host[j])
+        if far[j]:
+            cand = rng.choice(n_kf, size=min(n_kf, 3 * max_targets), replace=False)
+            cand.sort()
+        elif h >= 0:
+            cand = np.arange(h + 1, min(n_kf, h + 1 + band))
+        else:
+            cand = np.arange(0, min(n_kf, band))
+        got = 0
+        if h >= 0 and self_obs and (j % 2 == 0):
+            per_kf[h].append((j, u0[j], v0[j]))          # host observes its own point (skipped: host == target)
+        for k in cand:
+            if k == h:
+                continue
+            u, v, z = project(int(k), Xw[j])
+            if z > 0.1 and 16 <= u < W - 16 and 16 <= v < H - 16:
+                nu, nv = rng.normal(0, noise_px, 2)
+                if rng.random() < outlier_frac:
+                    nu += rng.choice([-1, 1]) * rng.uniform(8, 20)
+                    nv += rng.choice([-1, 1]) * rng.uniform(8, 20)
+                per_kf[int(k)].append((j, u + nu, v + nv))
+                got += 1
+                if got >= max_targets:
+                    break
+    kf_off = np.zeros(n_kf + 1, np.int64)
+    for k in range(n_kf):
+        kf_off[k + 1] = kf_off[k] + len(per_kf[k])
+    P.sgood = np.ones(int(kf_off[-1]), np.uint8)
+    if P.sgood.size > 10:
+        P.sgood[rng.integers(0, P.sgood.size, max(1, P.sgood.size // 100))] = 0
+    for l in range(P.n_levels):
+        kk, pp, ff, uv = [], [], [], []
+        for k in range(n_kf):
+            for i, (j, u, v) in enumerate(per_kf[k]):
+                if l > 0 and (i % (2 ** l)) != 0:      # coarser levels see a subset (tool::GetPyramidPts)
+                    continue
+                kk.append(k); pp.append(j); ff.append(kf_off[k] + i); uv.append((u, v))
+        P.sobs_kf[l], P.sobs_pt[l], P.sobs_flag[l] = np.array(kk, np.int32), np.array(pp, np.int32), np.array(ff, np.int32)
+        P.sobs_uv0[l] = np.array(uv, np.float64).reshape(-1, 2)
+    P.pt_ray = ray
+    P.pt_host = np.where(host >= 0, host, -1).astype(np.int32)
+    Trw = np.zeros((n_pt, 12))
+    for j in np.nonzero(host < 0)[0]:
+        R, t = cams[int(host[j])]
+        Trw[j] = np.concatenate([R, t[:, None]], 1).reshape(-1)
+    P.pt_host_Trw = Trw
+
+    # ------------------------------------------------------------------ text planes
+    planes = []
+    tfrozen = rng.random(n_text) < frozen_frac
+    if n_kf == 1:
+        tfrozen[:] = True
+    a_half, b_half = 0.4, 0.15                        # 0.8 m x 0.3 m text patches
+    gnx = max(1, int(np.ceil(np.sqrt(max(n_text, 1) * 4.0 / 3.0))))
+    gny = max(1, int(np.ceil(max(n_text, 1) / gnx)))
+    cells = rng.permutation(gnx * gny)
+    for j in range(n_text):
+        for _try in range(100):
+            pl = _Plane()
+            pl.host = int(-1 - rng.integers(0, n_out)) if tfrozen[j] else int(rng.integers(0, max(1, n_kf - text_targets)))
+            cxi, cyi = cells[j] % gnx, cells[j] // gnx     # jittered grid in the host image limits patch overlap
+            uc = 80 + (W - 160) * (cxi + 0.5 + rng.uniform(-0.2, 0.2)) / gnx
+            vc = 60 + (H - 120) * (cyi + 0.5 + rng.uniform(-0.2, 0.2)) / gny
+            z0 = rng.uniform(3.0, 6.0)
+            m0 = np.array([(uc - cx) / fx, (vc - cy) / fy, 1.0])
+            tilt = np.deg2rad(rng.uniform(0, 30))
+            ang = rng.uniform(0, 2 * np.pi)
+            n = _rodrigues(tilt * np.array([np.cos(ang), np.sin(ang), 0.0])) @ np.array([0, 0, -1.0])
+            X0 = m0 * z0
+            d = -float(n @ X0)
+            pl.n, pl.d, pl.X0 = n, d, X0
+            pl.theta = n / d
+            e1 = np.array([1.0, 0, 0]) - n[0] * n
+            e1 /= np.linalg.norm(e1)
+            e2 = np.cross(n, e1)
+            pl.e1, pl.e2 = e1, e2
+            cs = np.array([[-a_half, -b_half], [a_half, -b_half], [a_half, b_half], [-a_half, b_half]])
+            Xc = X0 + cs[:, :1] * e1 + cs[:, 1:] * e2
+            pl.box_ray = Xc[:, :2] / Xc[:, 2:]
+            bu, bv = fx * pl.box_ray[:, 0] + cx, fy * pl.box_ray[:, 1] + cy
+            if bu.min() < 12 or bu.max() > W - 12 or bv.min() < 12 or bv.max() > H - 12:
+                continue
+            nf = 6
+            pl.amp = rng.uniform(10, 22, nf)
+            fr = rng.uniform(2.0, 7.0, nf)
+            fa = rng.uniform(0, 2 * np.pi, nf)
+            pl.f1, pl.f2 = fr * np.cos(fa), fr * np.sin(fa)
+            pl.ph = rng.uniform(0, 2 * np.pi, nf)
+            pl.base = rng.uniform(100, 150)
+            # observers
+            Rh, th = cams[pl.host]
+            Xw_c = (Xc - th) @ Rh
+            obs = []
+            cand = range(n_kf) if pl.host < 0 else range(pl.host + 1, n_kf)
+            for k in cand:
+                u, v, z = project(k, Xw_c)
+                if np.all(z > 0.1) and u.min() >= 8 and u.max() < W - 8 and v.min() >= 8 and v.max() < H - 8:
+                    obs.append(k)
+                    if len(obs) >= text_targets:
+                        break
+            if len(obs) == 0:
+                continue
+            pl.obs = obs
+            planes.append(pl)
+            break
+        else:
+            raise RuntimeError("could not place text plane")
+
+    def texture(pl, s, t):
+        val = np.full(s.shape, pl.base)
+        for i in range(pl.amp.size):
+            val = val + pl.amp[i] * np.sin(2 * np.pi * (pl.f1[i] * s + pl.f2[i] * t) + pl.ph[i])
+        return val
+
+    if n_text > 0:
+        # ---- images: render every plane into every camera (window + outside hosts)
+        imgs = {}
+        for k in range(-n_out, n_kf):
+            img = 110.0 + rng.normal(0, 4.0, (H, W))
+            Rk, tk = cams[k]
+            for pl in planes:
+                if k != pl.host and k not in pl.obs:
+                    continue                         # a patch is painted only where the problem uses it (limits overlap)
+                Rh, th = cams[pl.host]
+                Rhk = Rh @ Rk.T                      # X_h = Rhk X_k + thk
+                thk = th - Rhk @ tk
+                ext = np.array([[-1.25 * a_half, -1.4 * b_half], [1.25 * a_half, -1.4 * b_half],
+                                [1.25 * a_half, 1.4 * b_half], [-1.25 * a_half, 1.4 * b_half]])
+                Xe = pl.X0 + ext[:, :1] * pl.e1 + ext[:, 1:] * pl.e2
+                Xk = (Xe - thk) @ Rhk                # X_k = Rhk^T (X_h - thk)
+                if np.any(Xk[:, 2] < 0.1):
+                    continue
+                uu, vv = fx * Xk[:, 0] / Xk[:, 2] + cx, fy * Xk[:, 1] / Xk[:, 2] + cy
+                x0, x1 = int(max(0, np.floor(uu.min()))), int(min(W - 1, np.ceil(uu.max())))
+                y0, y1 = int(max(0, np.floor(vv.min()))), int(min(H - 1, np.ceil(vv.max())))
+                if x1 < x0 or y1 < y0:
+                    continue
+                xs, ys = np.meshgrid(np.arange(x0, x1 + 1, dtype=np.float64), np.arange(y0, y1 + 1, dtype=np.float64))
+                m = np.stack([(xs - cx) / fx, (ys - cy) / fy, np.ones_like(xs)], -1)
+                Rm = m @ Rhk.T
+                den = Rm @ pl.n
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    z = -(pl.d + pl.n @ thk) / den
+                Xh_ = Rm * z[..., None] + thk
+                s = (Xh_ - pl.X0) @ pl.e1
+                t = (Xh_ - pl.X0) @ pl.e2
+                ins = (z > 0.1) & (np.abs(s) <= 1.25 * a_half) & (np.abs(t) <= 1.4 * b_half)
+                val = texture(pl, s, t) + rng.normal(0, 0.25, s.shape)
+                sub = img[y0:y1 + 1, x0:x1 + 1]
+                sub[ins] = val[ins]
+            imgs[k] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        pyr = {k: [imgs[k]] for k in imgs}
+        for k in imgs:
+            for l in range(1, P.n_levels):
+                pyr[k].append(_pyr_down(pyr[k][l - 1]))
+        for l in range(P.n_levels):
+            P.img[l] = np.stack([pyr[k][l] for k in range(n_kf)])
+
+        # ---- reference features (mapText::GetObjectInfo, tool::GetNeighbour)
+        P.theta = np.stack([pl.theta for pl in planes])
+        P.text_host = np.array([pl.host if pl.host >= 0 else -1 for pl in planes], np.int32)
+        P.text_box_ray = np.stack([pl.box_ray for pl in planes])
+        Twr = np.zeros((n_text, 12))
+        for j, pl in enumerate(planes):
+            if pl.host < 0:
+                R, t = cams[pl.host]
+                Twr[j] = np.concatenate([R.T, (-R.T @ t)[:, None]], 1).reshape(-1)
+        P.text_host_Twr = Twr
+        F0 = feats[0]
+        gx = int(np.ceil(np.sqrt(F0 * 4)))
+        gy = int(np.ceil(F0 / gx))
+        feat_uv0 = []
+        for pl in planes:
+            ii = np.arange(F0)
+            s = (-0.9 + 1.8 * ((ii % gx) + 0.5 + rng.uniform(-0.3, 0.3, F0)) / gx) * a_half
+            t = (-0.8 + 1.6 * ((ii // gx) + 0.5 + rng.uniform(-0.3, 0.3, F0)) / gy) * b_half
+            X = pl.X0 + s[:, None] * pl.e1 + t[:, None] * pl.e2
+            feat_uv0.append(np.stack([fx * X[:, 0] / X[:, 2] + cx, fy * X[:, 1] / X[:, 2] + cy], 1))
+        for l in range(P.n_levels):
+            sc = 0.5 ** l
+            Kl = K_GENERAL_MOTION * sc
+            off, raw, uv, ref = [0], [], [], []
+            nl = min(feats[l] if l < len(feats) else feats[-1], F0)
+            for j, pl in enumerate(planes):
+                sel = np.arange(F0) if l == 0 else np.sort(rng.choice(F0, nl, replace=False))
+                him = pyr[pl.host][l].astype(np.float64)
+                corners = np.stack([Kl[0] * pl.box_ray[:, 0] + Kl[2], Kl[1] * pl.box_ray[:, 1] + Kl[3]], 1)
+                mu, sg = _quad_stats(pyr[pl.host][l], corners)
+                if sg == 0:
+                    sg = 1.0
+                c = feat_uv0[j][sel] * sc
+                tu = c[:, :1] + TAP_DX[None, :]
+                tv = c[:, 1:] + TAP_DY[None, :]
+                I = _bilinear(him, tu, tv)
+                raw.append(sel); uv.append(c); ref.append((I - mu) / sg)
+                off.append(off[-1] + sel.size)
+            P.tfeat_off[l] = np.array(off, np.int32)
+            P.tfeat_raw[l] = np.concatenate(raw).astype(np.int32)
+            P.tfeat_uv[l] = np.concatenate(uv)
+            P.tfeat_ref[l] = np.concatenate(ref)
+        # ---- text observations, KF-major
+        tk, tt = [], []
+        for k in range(n_kf):
+            for j, pl in enumerate(planes):
+                if k in pl.obs or (self_obs and k == pl.host and j % 2 == 0):
+                    tk.append(k); tt.append(j)
+        P.tobs_kf, P.tobs_text = np.array(tk, np.int32), np.array(tt, np.int32)
+        P.tobs_good = np.ones(len(tk), np.uint8)
+        P.tobs_fgood_off = (np.arange(len(tk) + 1) * F0).astype(np.int32)
+        P.tfgood = np.ones(len(tk) * F0, np.uint8)
+        if P.tfgood.size > 100:
+            P.tfgood[rng.integers(0, P.tfgood.size, P.tfgood.size // 50)] = 0
+        if len(tk) > 20:
+            P.tobs_good[rng.integers(0, len(tk))] = 0
+    else:
+        P.theta = np.zeros((0, 3))
+        P.text_host = np.zeros(0, np.int32)
+        P.text_box_ray = np.zeros((0, 4, 2))
+        P.text_host_Twr = np.zeros((0, 12))
+
+    # ------------------------------------------------------------------ parameters: truth (+) perturbation
+    pose_true = np.zeros((n_kf, 7))
+    for k in range(n_kf):
+        pose_true[k, :4] = _R_to_q(Rcw[k])
+        pose_true[k, 4:] = tcw[k]
+    P.truth = {"pose": pose_true.copy(), "rho": rho.copy(), "theta": P.theta.copy()}
+    pose = pose_true.copy()
+    rho_i = rho.copy()
+    theta_i = P.theta.copy()
+    if perturb:
+        first_free = 0 if n_kf == 1 else min(3, n_kf)
+        for k in range(first_free, n_kf):
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            dR = _rodrigues(np.deg2rad(rot_deg) * ax)
+            pose[k, :4] = _R_to_q(dR @ Rcw[k])
+            dv = rng.normal(size=3)
+            pose[k, 4:] = tcw[k] + trans_m * dv / np.linalg.norm(dv)
+        movable = P.pt_host >= 0
+        rho_i[movable] *= 1 + rng.uniform(-lm_rel, lm_rel, movable.sum())
+        if n_text > 0:
+            mv = P.text_host >= 0
+            theta_i[mv] *= 1 + rng.uniform(-lm_rel, lm_rel, (mv.sum(), 1))
+    P.pose, P.rho, P.theta = pose, rho_i, theta_i
+    ki = np.zeros(n_kf, np.uint8)
+    ki[:min(2, n_kf)] = 1 if n_kf > 1 else 0
+    P.kf_initial = ki
+    return P.normalise()
+
+
+# ---- the named configurations of SURVEY.md 8(d) --------------------------------------------------
+def config_c1(seed=SEED):
+    """C1 plumbing: 10 KF / 2000 pts / 20 planes."""
+    return make_problem(10, 2000, 20, seed, text_targets=4)
+
+
+def config_c3(seed=SEED):
+    """C3 pose-only: 1 frame, 3000 scene blocks (frozen landmarks) + 200 text blocks (25 planes x 8 features)."""
+    return make_problem(1, 3000, 25, seed, feats=(8, 6, 4), frozen_frac=1.0, n_out=6, max_targets=1, text_targets=1)
+
+
+def config_c4(seed=SEED):
+    """C4 = the headline local-BA window: 20 KF x 5000 pts x 100 text planes (64 features each at level 0)."""
+    return make_problem(20, 5000, 100, seed)
+
+
+def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0):
+    """C5 / C6: scene-only global BA (the reference's GlobalBA ignores text, optimizer.cc:1707)."""
+    return make_problem(n_kf, n_pt, 0, seed, max_targets=max_targets, frozen_frac=0.0, band=band, far_frac=far_frac,
+                        n_levels=1, rot_deg=0.2, trans_m=0.01)
+
+
+def tiny(seed=7, n_kf=5, n_pt=60, n_text=4, **kw):
+    """Small problem for unit tests (seconds on the CPU oracle)."""
+    kw.setdefault("feats", (12, 8, 6))
+    kw.setdefault("text_targets", 3)
+    return make_problem(n_kf, n_pt, n_text, seed, **kw)
