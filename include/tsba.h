@@ -176,6 +176,11 @@ int  tsba_download(void *ctx, tsba_problem *p);       /* parameters + good flags
 int  tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int level,
                double *resid, double *jac, double *musigma, int64_t *ns, int64_t *nt);
 
+/* Debug aid: first linearisation of pass 0 of the uploaded problem and the damped reduced camera system for
+ * `radius`: S [(6 n_kf)^2] (identity rows for constant / absent poses), g [6 n_kf], cost, kf_free [n_kf], dp [6 n_kf]
+ * (the pose step S dp = -g).  Any output may be NULL. */
+int  tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, double *cost, int32_t *kf_free, double *dp);
+
 /* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
  * equation accumulation) over n launches on the library's stream, measured with HIP events.
  * Requires an uploaded problem; `level` selects the pass.  Also returns the algorithmic bytes of one launch. */

@@ -1,0 +1,74 @@
+"""GPU diagnostic (not a pytest): compares every stage of the HIP path with the oracle and prints the gaps."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from textslam_amd import synth, abi
+from textslam_amd.optimizer import Optimizer
+import oracle
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def stage_compare(P, o, opt, tag):
+    print(f"==== {tag}: n_kf={P.n_kf} n_pt={P.n_pt} n_text={P.n_text} n_tobs={P.n_tobs}", flush=True)
+    for l in sorted(set(o.levels[i] for i in range(o.n_passes))):
+        eo = oracle.evaluate(P, o, l)
+        eg = opt.evaluate(P, o, l)
+        print(f" level {l}: ns {eo['ns']}/{eg['ns']} nt {eo['nt']}/{eg['nt']}")
+        if eo['ns'] != eg['ns'] or eo['nt'] != eg['nt']:
+            print("  BLOCK COUNT MISMATCH"); continue
+        if P.n_tobs:
+            print("  musigma max abs diff", np.max(np.abs(eo['musigma'] - eg['musigma'])))
+        ns = eo['ns']
+        rs_o, rs_g = eo['resid'][:2*ns], eg['resid'][:2*ns]
+        rt_o, rt_g = eo['resid'][2*ns:], eg['resid'][2*ns:]
+        if ns: print("  scene resid max abs diff", np.max(np.abs(rs_o - rs_g)), "J rel", rel(eg['jac_scene'], eo['jac_scene']))
+        if eo['nt']: print("  text  resid max abs diff", np.max(np.abs(rt_o - rt_g)), "J rel", rel(eg['jac_text'], eo['jac_text']))
+    lvl = o.levels[0]
+    ro = oracle.reduced_system(P, o, lvl, o.initial_radius)
+    opt.upload(P, o)
+    rg = opt.reduced_system(o.initial_radius)
+    free = np.nonzero(rg['free'])[0]
+    idx = np.concatenate([np.arange(6*k, 6*k+6) for k in free]) if free.size else np.zeros(0, int)
+    print(" free poses gpu", free.tolist(), "oracle", np.nonzero(ro['free_idx'] >= 0)[0].tolist())
+    if idx.size and idx.size == ro['S'].shape[0]:
+        Sg = rg['S'][np.ix_(idx, idx)]; gg = rg['g'][idx]
+        print("  cost oracle %.10g gpu %.10g" % (ro['cost'], rg['cost']))
+        print("  S rel diff", rel(Sg, ro['S']), " g rel diff", rel(gg, ro['g']), " sym err", np.max(np.abs(Sg - Sg.T)))
+        dp_ref = -np.linalg.solve(ro['S'], ro['g'])
+        print("  dp rel diff vs numpy solve of oracle S", rel(rg['dp'][idx], dp_ref))
+    G = P.copy(); t = time.time()
+    rep_g = opt.LocalBundleAdjustment(G, options=o) if P.n_kf > 1 else opt.PoseOptim(G, options=o)
+    R = P.copy(); t = time.time(); rep_o = oracle.solve(R, o); to = time.time() - t
+    keys = ('iters', 'accepted', 'termination', 'cost0', 'cost1', 'n_sblock', 'n_tblock', 'n_bad_scene', 'n_bad_tfeat', 'n_bad_text')
+    print(" gpu   ", {k: rep_g[k] for k in keys + ('t_solve_ms', 't_upload_ms')})
+    print(" oracle", {k: rep_o[k] for k in keys}, "t %.3fs" % to)
+    print(" pose max abs diff", np.max(np.abs(G.pose - R.pose)), "rho", np.max(np.abs(G.rho - R.rho)) if P.n_pt else 0,
+          "theta", np.max(np.abs(G.theta - R.theta)) if P.n_text else 0)
+    print(" flags equal:", np.array_equal(G.sgood, R.sgood), np.array_equal(G.tobs_good, R.tobs_good), np.array_equal(G.tfgood, R.tfgood),
+          " n diff", int(np.sum(G.sgood != R.sgood)), int(np.sum(G.tfgood != R.tfgood)), flush=True)
+
+
+def main():
+    opt = Optimizer(0)
+    o = abi.options_local()
+    stage_compare(synth.tiny(), o, opt, "tiny local BA")
+    o1 = abi.options_local(); o1.use_text = 0
+    stage_compare(synth.tiny(seed=11, n_kf=6, n_pt=300, n_text=0), o1, opt, "tiny scene-only")
+    stage_compare(synth.config_c3(), abi.options_pose(), opt, "C3 pose-only")
+    P4 = synth.config_c4()
+    stage_compare(P4, o, opt, "C4 local BA")
+    opt.upload(P4, o)
+    ts = []
+    for _ in range(5):
+        t = time.time(); rep = opt.solve(); ts.append((time.time() - t) * 1e3)
+    print("C4 resident solve ms:", [round(x, 3) for x in ts], "report t_solve_ms", rep['t_solve_ms'], "resid evals", rep['n_resid_evals'])
+    for l in (0, 1, 2):
+        ms, nb = opt.time_linearize(l, 50)
+        print(f"linearize level {l}: {ms*1e3:.2f} us, algorithmic bytes {nb:.0f}, {nb/ms/1e6:.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1470 @@
+// libtsba.so -- MI355X (gfx950) bundle adjustment / pose optimisation for TextSLAM's optimizer:: hot path.
+// C ABI in include/tsba.h.  One translation unit: kernels + Levenberg-Marquardt driver + ABI.
+//
+// Kernel sequence of one LM iteration (all launched back-to-back on one stream, no host sync; the LM state machine
+// lives in device memory and every kernel starts by reading it):
+//   k_schur   one wave per 6x6 block of the reduced camera system S (gather over landmark slot pairs) + reduced gradient
+//   k_solve   one workgroup: blocked Cholesky of S in LDS, pose step
+//   k_back    landmark back-substitution, candidate parameters x (+) dx, step norm, model cost change
+//   k_linearize<COST>  candidate cost (residuals + Huber only)
+//   k_decide  step quality, trust-region update, accept / reject, convergence tests (Ceres 1.x semantics)
+//   k_linearize<FULL>  (only after an accepted step) residual + analytic Jacobian + IRLS weight + per-pair / per-group
+//                      J^T J, J^T r, J^T J_landmark sums: one wave per (target KF, host KF) pair of scene observations,
+//                      one wave per (KF, text) observation of up to 64 photometric blocks
+//   k_mid     per landmark V, b and the host-pose column of W; per pair the host-side products
+//   k_postlin pose diagonal / gradient, Jacobi scaling, cost, gradient tolerance
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <chrono>
+#include "../../include/tsba.h"
+#include "tsba_device.h"
+#include "tsba_plan.h"
+
+// ------------------------------------------------------------------------------------------------ device structs
+struct LmState {
+    double radius, decrease_factor, x_cost, x_norm, cand_cost, model_change, step_norm, gmax, cost0;
+    int cur, done, need_lin, first, it, accepted, term, invalid, max_it, step_fail, pad0, pad1;
+    int ns_active, nt_active, n_bad_scene, n_bad_tfeat, n_bad_text, pad2;
+    long long n_lin, n_cost;
+};
+
+struct LevelDev {            // device copies of HostPlan + per-level inputs
+    int level, n_sc, n_pair, n_tg, n_pslot, n_tslot, n_sb, n_tfeat;
+    double K[4];             // K_l
+    int img_w, img_h;
+    const uint8_t *const *img;      // [n_kf] device pointers
+    const int *sc_obs, *sc_kf, *sc_pt, *sc_flag, *sc_slot; const double *sc_uv;
+    const int *pair_i, *pair_h, *pair_sc_off, *pair_tg_off, *pair_tg;
+    const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot;
+    const int *pls_off, *pslot_pose, *pslot_pair, *pslot_lm, *tls_off, *tslot_pose, *tslot_pair, *tslot_lm;
+    const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_tx_off, *sb_tx_s1, *sb_tx_s2;
+    const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ts_off, *pose_ts;
+    const int *tfeat_off, *tfeat_raw; const double *tfeat_uv, *tfeat_ref;
+};
+
+struct Work {                // device work buffers (sized for the largest level)
+    int n_kf, n_pt, n_text, n_tobs, N;      // N = 6 n_kf
+    double K0[4];
+    double w_sx, w_sy, w_t, huber_s, huber_t;
+    int filter_good;
+    double min_diag, max_diag;
+    // parameters: double-buffered (x = buf[cur], candidate = buf[cur^1])
+    double *pose[2], *rho[2], *theta[2];
+    const double *pt_ray; const int *pt_host; const double *pt_Trw;
+    const int *text_host; const double *text_Twr; const double *text_box;
+    const int *tobs_kf, *tobs_text, *tobs_fgood_off;
+    uint8_t *sgood, *tobs_good, *tfgood;
+    double *musig;                      // [n_tobs][2]
+    int *kf_in, *kf_const, *act_pt, *act_tx;
+    // linearisation outputs
+    double *pairM, *pairCost, *pairR, *pairOut, *tgM, *tgCost, *pairCost2, *tgCost2;
+    double *w_pt, *vb_pt, *V_pt, *b_pt, *sig_pt, *dg_pt;
+    double *w_tx, *vb_tx, *V_tx, *b_tx, *sig_tx, *dg_tx;
+    double *Hd, *bp, *sig_p, *dg_p;
+    double *S, *g, *dp, *dl_pt, *dl_tx;
+    double *partial;                    // [nblocks_back][2]
+    LmState *st;
+};
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(c, std::string(#x) + ": " + hipGetErrorString(e_)); return TSBA_ERR_DEVICE; } } while (0)
+
+// ------------------------------------------------------------------------------------------------ kernels
+__device__ __forceinline__ double wave_sum1(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double *lds) {     // deterministic tree, NT threads, all get result
+    int t = threadIdx.x;
+    lds[t] = v; __syncthreads();
+    for (int s = NT/2; s > 0; s >>= 1) { if (t < s) lds[t] += lds[t + s]; __syncthreads(); }
+    double r = lds[0]; __syncthreads();
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ double block_max(double v, double *lds) {
+    int t = threadIdx.x;
+    lds[t] = v; __syncthreads();
+    for (int s = NT/2; s > 0; s >>= 1) { if (t < s) lds[t] = fmax(lds[t], lds[t + s]); __syncthreads(); }
+    double r = lds[0]; __syncthreads();
+    return r;
+}
+
+// ---- pass initialisation
+__global__ void k_pass_reset(Work W, double radius0, int max_it) {
+    LmState *s = W.st;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int cur = s->cur; long long nl = s->n_lin, nc = s->n_cost;
+        memset(s, 0, sizeof(LmState));
+        s->cur = cur; s->n_lin = nl; s->n_cost = nc;
+        s->radius = radius0; s->decrease_factor = 2.0; s->need_lin = 1; s->first = 1; s->max_it = max_it;
+    }
+    int t = blockIdx.x*blockDim.x + threadIdx.x, n = gridDim.x*blockDim.x;
+    for (int k = t; k < W.n_kf; k += n) { W.kf_in[k] = 0; W.kf_const[k] = 0; }
+    for (int k = t; k < W.n_pt; k += n) W.act_pt[k] = 0;
+    for (int k = t; k < W.n_text; k += n) W.act_tx[k] = 0;
+}
+
+// which candidates are active (good flags), which keyframes participate (FLAG_KFIN, optimizer.cc:1410-1411,1428,1514-1515)
+__global__ void k_participation(Work W, LevelDev L) {
+    int t = blockIdx.x*blockDim.x + threadIdx.x;
+    if (t < L.n_sc) {
+        bool act = !W.filter_good || W.sgood[L.sc_flag[t]];
+        if (act) {
+            int pt = L.sc_pt[t], h = W.pt_host[pt];
+            W.kf_in[L.sc_kf[t]] = 1;
+            if (h >= 0) { W.kf_in[h] = 1; W.act_pt[pt] = 1; }
+            atomicAdd(&W.st->ns_active, 1);
+        }
+    } else if (t < L.n_sc + L.n_tg) {
+        int g = t - L.n_sc, tb = L.tg_tobs[g], j = L.tg_text[g];
+        if (W.filter_good && !W.tobs_good[tb]) return;
+        int cnt = 0;
+        for (int f = L.tfeat_off[j]; f < L.tfeat_off[j+1]; f++)
+            if (!W.filter_good || W.tfgood[W.tobs_fgood_off[tb] + L.tfeat_raw[f]]) cnt++;
+        if (cnt > 0) {
+            int h = W.text_host[j];
+            W.kf_in[L.tg_kf[g]] = 1;
+            if (h >= 0) { W.kf_in[h] = 1; W.act_tx[j] = 1; }
+            atomicAdd(&W.st->nt_active, cnt);
+        }
+    }
+}
+// gauge fixing, optimizer.cc:1562-1588 / :1825-1830
+__global__ void k_gauge(Work W, const uint8_t *kf_initial, int state) {
+    if (threadIdx.x || blockIdx.x) return;
+    int cnt = 0;
+    for (int k = 0; k < W.n_kf; k++) { if (kf_initial[k] && W.kf_in[k]) W.kf_const[k] = 1; cnt += W.kf_in[k]; }
+    if (state == TSBA_STATE_LOCAL && cnt > 3) {
+        int fixed = 0;
+        for (int k = 0; k < W.n_kf && fixed < 3; k++) if (W.kf_in[k]) { W.kf_const[k] = 1; fixed++; }
+    }
+}
+
+// ---- mu / sigma of a projected text box: tool::GetProjText x4 + tool::CalTextinfo (src/tool.cc:1178-1262,1655-1728)
+// with cv::fillPoly's scan conversion (boundary Bresenham lines + 16.16 fixed-point scanline spans).  One workgroup per
+// (KF, text) observation; the polygon mask of the clamped bounding box lives in LDS as a bit field.
+__device__ int clip_line_dev(long long Wd, long long Hd, long long &x1, long long &y1, long long &x2, long long &y2) {
+    long long right = Wd - 1, bottom = Hd - 1;
+    int c1 = (x1 < 0) + (x1 > right)*2 + (y1 < 0)*4 + (y1 > bottom)*8;
+    int c2 = (x2 < 0) + (x2 > right)*2 + (y2 < 0)*4 + (y2 > bottom)*8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) { a = c1 < 8 ? 0 : bottom; x1 += (long long)((double)(a - y1)*(double)(x2 - x1)/(double)(y2 - y1)); y1 = a; c1 = (x1 < 0) + (x1 > right)*2; }
+        if (c2 & 12) { a = c2 < 8 ? 0 : bottom; x2 += (long long)((double)(a - y2)*(double)(x2 - x1)/(double)(y2 - y1)); y2 = a; c2 = (x2 < 0) + (x2 > right)*2; }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) { a = c1 == 1 ? 0 : right; y1 += (long long)((double)(a - x1)*(double)(y2 - y1)/(double)(x2 - x1)); x1 = a; c1 = 0; }
+            if (c2) { a = c2 == 1 ? 0 : right; y2 += (long long)((double)(a - x2)*(double)(y2 - y1)/(double)(x2 - x1)); x2 = a; c2 = 0; }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+#define MS_THREADS 256
+#define MS_MASK_WORDS 9600        /* 640*480/32 bits */
+__global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
+    __shared__ unsigned mask[MS_MASK_WORDS];
+    __shared__ unsigned hist[256];
+    __shared__ int s_xy[8], s_bb[4];
+    __shared__ double s_red[MS_THREADS];
+    int g = blockIdx.x, tid = threadIdx.x;
+    int tb = L.tg_tobs[g], kf = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
+    if (W.filter_good && !W.tobs_good[tb]) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
+    const int w = L.img_w, hh = L.img_h;
+    const double *pose = W.pose[W.st->cur], *theta = W.theta[W.st->cur];
+    if (tid == 0) {
+        Pose C; load_pose(pose + 7*kf, C);
+        PairT T;
+        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+        else pair_from_Twr(C, W.text_Twr + 12*j, T);
+        double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+        int xMin = w + 1, xMax = -1, yMin = hh + 1, yMax = -1;
+        for (int b = 0; b < 4; b++) {
+            double mx = W.text_box[(j*4 + b)*2], my = W.text_box[(j*4 + b)*2 + 1];
+            double invz = -(mx*th[0] + my*th[1] + th[2]);
+            double m[3] = { mx, my, 1.0 }, Rm[3]; mat3_vec(T.Rcr, m, Rm);
+            double X = Rm[0]/invz + T.tq[0] + C.t[0], Y = Rm[1]/invz + T.tq[1] + C.t[1], Z = Rm[2]/invz + T.tq[2] + C.t[2];
+            double cu = L.K[0]*X/Z + L.K[2], cv = L.K[1]*Y/Z + L.K[3];
+            s_xy[2*b] = (int)cu; s_xy[2*b+1] = (int)cv;
+            if (cu > xMax) xMax = (int)ceil(cu);
+            if (cu < xMin) xMin = (int)floor(cu);
+            if (cv > yMax) yMax = (int)ceil(cv);
+            if (cv < yMin) yMin = (int)floor(cv);
+        }
+        if (xMin < 0) xMin = 0;
+        if (xMin >= w) xMin = w - 1;
+        if (yMin < 0) yMin = 0;
+        if (yMin >= hh) yMin = hh - 1;
+        if (xMax >= w) xMax = w - 1;
+        if (xMax < 0) xMax = 0;
+        if (yMax >= hh) yMax = hh - 1;
+        if (yMax < 0) yMax = 0;
+        s_bb[0] = xMin; s_bb[1] = xMax; s_bb[2] = yMin; s_bb[3] = yMax;
+    }
+    for (int k = tid; k < MS_MASK_WORDS; k += MS_THREADS) mask[k] = 0;
+    hist[tid] = 0;
+    __syncthreads();
+    const int xMin = s_bb[0], xMax = s_bb[1], yMin = s_bb[2], yMax = s_bb[3];
+    // boundary lines (cv::LineIterator, 8-connected, left to right)
+    if (tid < 4) {
+        int i0 = (tid + 3) & 3, i1 = tid;
+        long long x1 = s_xy[2*i0], y1 = s_xy[2*i0+1], x2 = s_xy[2*i1], y2 = s_xy[2*i1+1];
+        bool ok = true;
+        if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+            (unsigned long long)y1 >= (unsigned long long)hh || (unsigned long long)y2 >= (unsigned long long)hh)
+            ok = clip_line_dev(w, hh, x1, y1, x2, y2);
+        if (ok) {
+            long long dx = x2 - x1, dy = y2 - y1;
+            if (dx < 0) { dx = -dx; dy = -dy; x1 = x2; y1 = y2; }
+            long long sy = dy < 0 ? -1 : 1; if (dy < 0) dy = -dy;
+            bool steep = dy > dx;
+            long long major = steep ? dy : dx, minor = steep ? dx : dy;
+            long long err = major - (minor + minor), plusDelta = major + major, minusDelta = -(minor + minor);
+            long long x = x1, y = y1;
+            for (long long i = 0; i <= major; i++) {
+                if (x >= 0 && x < w && y >= 0 && y < hh) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31));
+                bool neg = err < 0;
+                err += minusDelta + (neg ? plusDelta : 0);
+                if (steep) { y += sy; if (neg) x += 1; } else { x += 1; if (neg) y += sy; }
+            }
+        }
+    }
+    // scanline interior (FillEdgeCollection): one thread per row
+    {
+        long long ex[4], edx[4]; int ey0[4], ey1[4], ne = 0;
+        int y_min = 2147483647, y_max = -2147483647;
+        for (int i = 0; i < 4; i++) {
+            int i0 = (i + 3) & 3;
+            long long p0x = (long long)s_xy[2*i0] << 16, p0y = s_xy[2*i0+1], p1x = (long long)s_xy[2*i] << 16, p1y = s_xy[2*i+1];
+            if (p0y == p1y) continue;
+            if (p0y < p1y) { ey0[ne] = (int)p0y; ey1[ne] = (int)p1y; ex[ne] = p0x; } else { ey0[ne] = (int)p1y; ey1[ne] = (int)p0y; ex[ne] = p1x; }
+            edx[ne] = (p1x - p0x)/(p1y - p0y);
+            y_min = min(y_min, ey0[ne]); y_max = max(y_max, ey1[ne]); ne++;
+        }
+        if (ne >= 2 && !(y_max < 0 || y_min >= hh)) {
+            if (y_max > hh) y_max = hh;
+            for (int y = max(y_min, 0) + tid; y < y_max; y += MS_THREADS) {
+                long long xs[4]; int na = 0;
+                for (int i = 0; i < ne; i++) if (ey0[i] <= y && y < ey1[i]) xs[na++] = ex[i] + (long long)(y - ey0[i])*edx[i];
+                for (int i = 1; i < na; i++) { long long v = xs[i]; int k = i - 1; while (k >= 0 && xs[k] > v) { xs[k+1] = xs[k]; k--; } xs[k+1] = v; }
+                for (int i = 0; i + 1 < na; i += 2) {
+                    int xa = (int)((xs[i] + 65535) >> 16), xb = (int)(xs[i+1] >> 16);
+                    if (xa < w && xb >= 0) { if (xa < 0) xa = 0; if (xb >= w) xb = w - 1;
+                        for (int x = xa; x <= xb; x++) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31)); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // histogram of masked pixels inside the clamped bounding box (tool.cc:1217-1232)
+    const uint8_t *img = L.img[kf];
+    int bw = xMax - xMin + 1, bh = yMax - yMin + 1;
+    for (int k = tid; k < bw*bh; k += MS_THREADS) {
+        int x = xMin + k % bw, y = yMin + k / bw, bit = y*w + x;
+        if (mask[bit >> 5] & (1u << (bit & 31))) atomicAdd(&hist[img[bit]], 1u);
+    }
+    __syncthreads();
+    double cnt = (double)hist[tid], sum = (double)hist[tid]*(double)tid;
+    double n = block_sum<MS_THREADS>(cnt, s_red), sm = block_sum<MS_THREADS>(sum, s_red);
+    if (n < 2.0) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
+    double mu = sm/n;
+    double d = (double)tid - mu;
+    double ss = block_sum<MS_THREADS>((double)hist[tid]*d*d, s_red);
+    if (tid == 0) { W.musig[2*tb] = mu; W.musig[2*tb+1] = sqrt(ss/(n - 1.0)); }
+}
+
+// ---- linearisation / cost.  grid = n_pair (scene waves) + n_tg (text waves), 64 threads each.
+#define MODE_FULL 0
+#define MODE_COST 1
+template <int MODE>
+__global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L) {
+    const LmState *st = W.st;
+    if (st->done) return;
+    if (MODE == MODE_FULL && !st->need_lin) return;
+    if (MODE == MODE_COST && st->step_fail) return;
+    __shared__ double lds[55*65];
+    const int sel = MODE == MODE_FULL ? st->cur : (st->cur ^ 1);
+    const double *pose = W.pose[sel], *rho = W.rho[sel], *theta = W.theta[sel];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b < L.n_pair) {
+        // ---------------- scene observations of pair (i, h)
+        const int i = L.pair_i[b], h = L.pair_h[b];
+        Pose C; load_pose(pose + 7*i, C);
+        PairT T;
+        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+        const bool fixed = (h < 0) && W.kf_const[i];           // all parameter blocks constant: not in the reduced program
+        double acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0.0;
+        const int beg = L.pair_sc_off[b], end = L.pair_sc_off[b+1];
+        for (int c = beg + lane; c < end; c += 64) {
+            const int slot = L.sc_slot[c];
+            bool act = !fixed && (!W.filter_good || W.sgood[L.sc_flag[c]]);
+            if (!act) {
+                if (MODE == MODE_FULL && slot >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) W.w_pt[(size_t)k*L.n_pslot + slot] = 0.0;
+                    W.vb_pt[slot] = 0.0; W.vb_pt[(size_t)L.n_pslot + slot] = 0.0;
+                }
+                continue;
+            }
+            const int pt = L.sc_pt[c];
+            if (h < 0) pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+            double mx = W.pt_ray[2*pt], my = W.pt_ray[2*pt+1], rh = rho[pt];
+            double uo = L.sc_uv[2*c], vo = L.sc_uv[2*c+1];
+            double r[2];
+            if (MODE == MODE_COST) {
+                scene_residual(T, C.t, mx, my, rh, uo, vo, W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r);
+                double wgt; acc[27] += 0.5*huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
+            } else {
+                double jt[2][6], jl[2];
+                scene_block(T, C.t, mx, my, rh, uo, vo, W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r, jt, jl);
+                double wgt; acc[27] += 0.5*huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
+                int q = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int cc = a; cc < 6; cc++) { acc[q] += wgt*(jt[0][a]*jt[0][cc] + jt[1][a]*jt[1][cc]); q++; }
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[21 + a] += wgt*(jt[0][a]*r[0] + jt[1][a]*r[1]);
+                if (slot >= 0) {
+#pragma unroll
+                    for (int a = 0; a < 6; a++) W.w_pt[(size_t)a*L.n_pslot + slot] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]);
+                    W.vb_pt[slot] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
+                    W.vb_pt[(size_t)L.n_pslot + slot] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
+                }
+            }
+        }
+        if (MODE == MODE_COST) {
+            double cs = wave_sum1(acc[27]);
+            if (lane == 0) W.pairCost2[b] = cs;
+        } else {
+            double tot = wave_sum_to_lane<28>(acc, lds, lane);
+            if (lane < 27) W.pairM[(size_t)lane*L.n_pair + b] = tot;
+            else if (lane == 27) W.pairCost[b] = tot;
+            if (h >= 0 && lane < 9) W.pairR[(size_t)lane*L.n_pair + b] = T.Rcr[lane];
+        }
+    } else {
+        // ---------------- photometric blocks of one (KF, text) observation
+        const int g = b - L.n_pair;
+        const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j], slot = L.tg_slot[g];
+        const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
+        const bool act_g = (!W.filter_good || W.tobs_good[tb]) && !((h < 0) && W.kf_const[i]) && sigma != 0.0;
+        double acc[55];
+#pragma unroll
+        for (int k = 0; k < 55; k++) acc[k] = 0.0;
+        if (act_g) {
+            Pose C; load_pose(pose + 7*i, C);
+            PairT T;
+            if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+            else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
+            const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+            const uint8_t *img = L.img[i];
+            const double inv_sigma = 1.0/sigma;
+            const int f0 = L.tfeat_off[j], f1 = L.tfeat_off[j+1];
+            const int fg = W.tobs_fgood_off[tb];
+            for (int f = f0 + lane; f < f1; f += 64) {
+                if (W.filter_good && !W.tfgood[fg + L.tfeat_raw[f]]) continue;
+                const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
+                double blk[54];
+#pragma unroll
+                for (int k = 0; k < 54; k++) blk[k] = 0.0;
+                double s = 0.0;
+#pragma unroll 1
+                for (int k = 0; k < 8; k++) {
+                    double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];   // tool.cc:1561
+                    double jt[6], jl[3];
+                    double r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h,
+                                        mu, sigma, inv_sigma, L.tfeat_ref[8*(size_t)f + k], W.w_t, MODE == MODE_FULL, jt, jl);
+                    s += r*r;
+                    if (MODE == MODE_FULL) {
+                        int q = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+#pragma unroll
+                            for (int cc = a; cc < 6; cc++) { blk[q] += jt[a]*jt[cc]; q++; }
+#pragma unroll
+                        for (int a = 0; a < 6; a++) blk[21 + a] += jt[a]*r;
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+#pragma unroll
+                            for (int cc = 0; cc < 3; cc++) blk[27 + a*3 + cc] += jt[a]*jl[cc];
+                        blk[45] += jl[0]*jl[0]; blk[46] += jl[0]*jl[1]; blk[47] += jl[0]*jl[2];
+                        blk[48] += jl[1]*jl[1]; blk[49] += jl[1]*jl[2]; blk[50] += jl[2]*jl[2];
+                        blk[51] += jl[0]*r; blk[52] += jl[1]*r; blk[53] += jl[2]*r;
+                    }
+                }
+                double wgt; acc[54] += 0.5*huber(s, W.huber_t, wgt);
+                if (MODE == MODE_FULL) {
+#pragma unroll
+                    for (int k = 0; k < 54; k++) acc[k] += wgt*blk[k];
+                }
+            }
+        }
+        if (MODE == MODE_COST) {
+            double cs = wave_sum1(acc[54]);
+            if (lane == 0) W.tgCost2[g] = cs;
+        } else {
+            double tot = wave_sum_to_lane<55>(acc, lds, lane);
+            if (lane < 27) W.tgM[(size_t)lane*L.n_tg + g] = tot;
+            else if (lane < 45) { if (slot >= 0) W.w_tx[(size_t)(lane - 27)*L.n_tslot + slot] = tot; }
+            else if (lane < 54) { if (slot >= 0) W.vb_tx[(size_t)(lane - 45)*L.n_tslot + slot] = tot; }
+            else if (lane == 54) W.tgCost[g] = tot;
+        }
+    }
+}
+
+// ---- per landmark: V, b, host column of W (= -sum Q^T w);  per pair: host-side products.  256-thread blocks.
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx) {
+    const LmState *st = W.st;
+    if (st->done || !st->need_lin) return;
+    int b = blockIdx.x;
+    if (b < nb_pt) {
+        int j = b*256 + threadIdx.x; if (j >= W.n_pt) return;
+        int o = L.pls_off[j], e = L.pls_off[j+1]; if (e <= o) return;
+        double V = 0, bb = 0, wh[6] = {0,0,0,0,0,0};
+        for (int s = o; s < e - 1; s++) {
+            V += W.vb_pt[s]; bb += W.vb_pt[(size_t)L.n_pslot + s];
+            int p = L.pslot_pair[s];
+            double R[9], w[6];
+#pragma unroll
+            for (int k = 0; k < 9; k++) R[k] = W.pairR[(size_t)k*L.n_pair + p];
+#pragma unroll
+            for (int k = 0; k < 6; k++) w[k] = W.w_pt[(size_t)k*L.n_pslot + s];
+            double a[3], c[3]; mat3T_vec(R, w, a); mat3T_vec(R, w + 3, c);
+            wh[0] -= a[0]; wh[1] -= a[1]; wh[2] -= a[2]; wh[3] -= c[0]; wh[4] -= c[1]; wh[5] -= c[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) W.w_pt[(size_t)k*L.n_pslot + e - 1] = wh[k];
+        W.V_pt[j] = V; W.b_pt[j] = bb;
+        if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
+        double sg = W.sig_pt[j];
+        W.dg_pt[j] = clampd(sg*sg*V, W.min_diag, W.max_diag);
+    } else if (b < nb_pt + nb_tx) {
+        int j = (b - nb_pt)*256 + threadIdx.x; if (j >= W.n_text) return;
+        int o = L.tls_off[j], e = L.tls_off[j+1]; if (e <= o) return;
+        double V[6] = {0,0,0,0,0,0}, bb[3] = {0,0,0}, wh[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) wh[k] = 0;
+        for (int s = o; s < e - 1; s++) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) V[k] += W.vb_tx[(size_t)k*L.n_tslot + s];
+#pragma unroll
+            for (int k = 0; k < 3; k++) bb[k] += W.vb_tx[(size_t)(6 + k)*L.n_tslot + s];
+            int p = L.tslot_pair[s];
+            double R[9], w[18];
+#pragma unroll
+            for (int k = 0; k < 9; k++) R[k] = W.pairR[(size_t)k*L.n_pair + p];
+#pragma unroll
+            for (int k = 0; k < 18; k++) w[k] = W.w_tx[(size_t)k*L.n_tslot + s];
+            // W (6x3, row-major): rows 0-2 rotation, 3-5 translation.  host = -blkdiag(R,R)^T W
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++)
+                        wh[(half*3 + r)*3 + cc] -= R[0*3 + r]*w[(half*3 + 0)*3 + cc] + R[1*3 + r]*w[(half*3 + 1)*3 + cc] + R[2*3 + r]*w[(half*3 + 2)*3 + cc];
+        }
+#pragma unroll
+        for (int k = 0; k < 18; k++) W.w_tx[(size_t)k*L.n_tslot + e - 1] = wh[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) W.V_tx[(size_t)k*W.n_text + j] = V[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) W.b_tx[(size_t)k*W.n_text + j] = bb[k];
+        const double dv[3] = { V[0], V[3], V[5] };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (st->first) W.sig_tx[(size_t)k*W.n_text + j] = 1.0/(1.0 + sqrt(dv[k]));
+            double sg = W.sig_tx[(size_t)k*W.n_text + j];
+            W.dg_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag);
+        }
+    } else {
+        int p = (b - nb_pt - nb_tx)*256 + threadIdx.x; if (p >= L.n_pair) return;
+        double M[21], c[6];
+#pragma unroll
+        for (int k = 0; k < 21; k++) M[k] = W.pairM[(size_t)k*L.n_pair + p];
+#pragma unroll
+        for (int k = 0; k < 6; k++) c[k] = W.pairM[(size_t)(21 + k)*L.n_pair + p];
+        for (int q = L.pair_tg_off[p]; q < L.pair_tg_off[p+1]; q++) {
+            int g = L.pair_tg[q];
+#pragma unroll
+            for (int k = 0; k < 21; k++) M[k] += W.tgM[(size_t)k*L.n_tg + g];
+#pragma unroll
+            for (int k = 0; k < 6; k++) c[k] += W.tgM[(size_t)(21 + k)*L.n_tg + g];
+        }
+        double *out = W.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) QMQ(21) Qc(6)
+#pragma unroll
+        for (int k = 0; k < 21; k++) out[(size_t)k*L.n_pair + p] = M[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) out[(size_t)(21 + k)*L.n_pair + p] = c[k];
+        if (L.pair_h[p] >= 0) {
+            double R[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) R[k] = W.pairR[(size_t)k*L.n_pair + p];
+            double Mf[36];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) Mf[r*6 + cc] = M[sym6(r, cc)];
+            double MQ[36];                         // M * blkdiag(R,R)
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int half = 0; half < 2; half++)
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++)
+                        MQ[r*6 + half*3 + cc] = Mf[r*6 + half*3]*R[cc] + Mf[r*6 + half*3 + 1]*R[3 + cc] + Mf[r*6 + half*3 + 2]*R[6 + cc];
+#pragma unroll
+            for (int k = 0; k < 36; k++) out[(size_t)(27 + k)*L.n_pair + p] = MQ[k];
+            // Q^T M Q (symmetric) and Q^T c
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int cc = r; cc < 6; cc++) {
+                    int hr = r/3, rr = r % 3;
+                    double v = R[0*3 + rr]*MQ[(hr*3 + 0)*6 + cc] + R[1*3 + rr]*MQ[(hr*3 + 1)*6 + cc] + R[2*3 + rr]*MQ[(hr*3 + 2)*6 + cc];
+                    out[(size_t)(63 + sym6(r, cc))*L.n_pair + p] = v;
+                }
+            double a[3], d[3]; mat3T_vec(R, c, a); mat3T_vec(R, c + 3, d);
+            out[(size_t)84*L.n_pair + p] = a[0]; out[(size_t)85*L.n_pair + p] = a[1]; out[(size_t)86*L.n_pair + p] = a[2];
+            out[(size_t)87*L.n_pair + p] = d[0]; out[(size_t)88*L.n_pair + p] = d[1]; out[(size_t)89*L.n_pair + p] = d[2];
+        }
+    }
+}
+
+// ---- after a linearisation: pose diagonal / gradient, Jacobi scaling, cost, gradient tolerance.  One 256-thread block.
+__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol) {
+    LmState *st = W.st;
+    if (st->done || !st->need_lin) return;
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double gmax = 0.0, xn = 0.0, cost = 0.0;
+    const double *pose = W.pose[st->cur], *rho = W.rho[st->cur], *theta = W.theta[st->cur];
+    const double *out = W.pairOut;
+    for (int a = tid; a < W.n_kf; a += 256) {
+        double Hd[6] = {0,0,0,0,0,0}, bp[6] = {0,0,0,0,0,0};
+        for (int q = L.pose_t_off[a]; q < L.pose_t_off[a+1]; q++) { int p = L.pose_t[q];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { Hd[k] += out[(size_t)sym6(k, k)*L.n_pair + p]; bp[k] += out[(size_t)(21 + k)*L.n_pair + p]; } }
+        for (int q = L.pose_h_off[a]; q < L.pose_h_off[a+1]; q++) { int p = L.pose_h[q];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { Hd[k] += out[(size_t)(63 + sym6(k, k))*L.n_pair + p]; bp[k] -= out[(size_t)(84 + k)*L.n_pair + p]; } }
+        bool fre = W.kf_in[a] && !W.kf_const[a];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            W.Hd[6*a + k] = Hd[k]; W.bp[6*a + k] = bp[k];
+            if (st->first) W.sig_p[6*a + k] = 1.0/(1.0 + sqrt(Hd[k]));
+            double sg = W.sig_p[6*a + k];
+            W.dg_p[6*a + k] = clampd(sg*sg*Hd[k], W.min_diag, W.max_diag);
+            if (fre) gmax = fmax(gmax, fabs(bp[k]));
+        }
+        if (fre) for (int k = 0; k < 7; k++) xn += pose[7*a + k]*pose[7*a + k];
+    }
+    for (int j = tid; j < W.n_pt; j += 256) if (W.act_pt[j]) { gmax = fmax(gmax, fabs(W.b_pt[j])); xn += rho[j]*rho[j]; }
+    for (int j = tid; j < W.n_text; j += 256) if (W.act_tx[j])
+        for (int k = 0; k < 3; k++) { gmax = fmax(gmax, fabs(W.b_tx[(size_t)k*W.n_text + j])); xn += theta[3*j + k]*theta[3*j + k]; }
+    for (int p = tid; p < L.n_pair; p += 256) cost += W.pairCost[p];
+    for (int g = tid; g < L.n_tg; g += 256) cost += W.tgCost[g];
+    gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red); cost = block_sum<256>(cost, red);
+    if (tid == 0) {
+        st->x_cost = cost; st->x_norm = sqrt(xn); st->gmax = gmax;
+        if (st->first) st->cost0 = cost;
+        st->first = 0; st->need_lin = 0; st->n_lin++;
+        if (gmax <= grad_tol) { st->done = 1; st->term = 3; }
+    }
+}
+
+// ---- reduced camera system.  grid = n_sb (one wave per 6x6 block) + n_kf (reduced gradient), 64 threads.
+__global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
+    LmState *st = W.st;
+    if (st->done) return;
+    __shared__ double lds[36*65];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double radius = st->radius;
+    const int N = W.N;
+    if (b < L.n_sb) {
+        const int a = L.sb_a[b], c = L.sb_b[b];
+        const bool fa = W.kf_in[a] && !W.kf_const[a], fc = W.kf_in[c] && !W.kf_const[c];
+        if (!fa || !fc) {
+            if (lane < 36) { int r = lane/6, cc = lane % 6; double v = (a == c && r == cc) ? 1.0 : 0.0;
+                W.S[(size_t)(6*a + r)*N + 6*c + cc] = v; if (a != c) W.S[(size_t)(6*c + cc)*N + 6*a + r] = v; }
+            return;
+        }
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[k] = 0.0;
+        for (int q = L.sb_pt_off[b] + lane; q < L.sb_pt_off[b+1]; q += 64) {
+            int s1 = L.sb_pt_s1[q], s2 = L.sb_pt_s2[q], j = L.pslot_lm[s1];
+            double sg = W.sig_pt[j];
+            double vinv = 1.0/(W.V_pt[j] + W.dg_pt[j]/(radius*sg*sg));
+            double w1[6], w2[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { w1[k] = W.w_pt[(size_t)k*L.n_pslot + s1]*vinv; w2[k] = W.w_pt[(size_t)k*L.n_pslot + s2]; }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += w1[r]*w2[cc];
+        }
+        for (int q = L.sb_tx_off[b] + lane; q < L.sb_tx_off[b+1]; q += 64) {
+            int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.tslot_lm[s1];
+            double Vd[6], Vi[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Vd[k] = W.V_tx[(size_t)k*W.n_text + j];
+            { double s0 = W.sig_tx[j], s1_ = W.sig_tx[(size_t)W.n_text + j], s2_ = W.sig_tx[(size_t)2*W.n_text + j];
+              Vd[0] += W.dg_tx[j]/(radius*s0*s0); Vd[3] += W.dg_tx[(size_t)W.n_text + j]/(radius*s1_*s1_); Vd[5] += W.dg_tx[(size_t)2*W.n_text + j]/(radius*s2_*s2_); }
+            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
+            double W1[18], W2[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) { W1[k] = W.w_tx[(size_t)k*L.n_tslot + s1]; W2[k] = W.w_tx[(size_t)k*L.n_tslot + s2]; }
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                double t0 = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
+                double t1 = W1[r*3]*Vi[1] + W1[r*3+1]*Vi[3] + W1[r*3+2]*Vi[4];
+                double t2 = W1[r*3]*Vi[2] + W1[r*3+1]*Vi[4] + W1[r*3+2]*Vi[5];
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += t0*W2[cc*3] + t1*W2[cc*3+1] + t2*W2[cc*3+2];
+            }
+        }
+        double tot = wave_sum_to_lane<36>(acc, lds, lane);
+        if (lane < 36) {
+            const int r = lane/6, cc = lane % 6;
+            const double *out = W.pairOut;
+            double v = -tot;
+            if (a == c) {
+                for (int q = L.pose_t_off[a]; q < L.pose_t_off[a+1]; q++) v += out[(size_t)sym6(r, cc)*L.n_pair + L.pose_t[q]];
+                for (int q = L.pose_h_off[a]; q < L.pose_h_off[a+1]; q++) v += out[(size_t)(63 + sym6(r, cc))*L.n_pair + L.pose_h[q]];
+                if (r == cc) { double sg = W.sig_p[6*a + r]; v += W.dg_p[6*a + r]/(radius*sg*sg); }
+            } else {
+                int pab = L.sb_pab[b], pba = L.sb_pba[b];
+                if (pab >= 0) v -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
+                if (pba >= 0) v -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
+            }
+            W.S[(size_t)(6*a + r)*N + 6*c + cc] = v;
+            if (a != c) W.S[(size_t)(6*c + cc)*N + 6*a + r] = v;
+        }
+    } else {
+        const int a = b - L.n_sb;
+        const bool fa = W.kf_in[a] && !W.kf_const[a];
+        if (!fa) {      // constant / absent pose: identity row so that the dense factorisation leaves dp = 0
+            if (lane < 6) { W.g[6*a + lane] = 0.0; W.S[(size_t)(6*a + lane)*N + 6*a + lane] = 1.0; }
+            return;
+        }
+        double acc[6] = {0,0,0,0,0,0};
+        for (int q = L.pose_ps_off[a] + lane; q < L.pose_ps_off[a+1]; q += 64) {
+            int s = L.pose_ps[q], j = L.pslot_lm[s];
+            double sg = W.sig_pt[j];
+            double f = W.b_pt[j]/(W.V_pt[j] + W.dg_pt[j]/(radius*sg*sg));
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc[k] += W.w_pt[(size_t)k*L.n_pslot + s]*f;
+        }
+        for (int q = L.pose_ts_off[a] + lane; q < L.pose_ts_off[a+1]; q += 64) {
+            int s = L.pose_ts[q], j = L.tslot_lm[s];
+            double Vd[6], Vi[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Vd[k] = W.V_tx[(size_t)k*W.n_text + j];
+            { double s0 = W.sig_tx[j], s1_ = W.sig_tx[(size_t)W.n_text + j], s2_ = W.sig_tx[(size_t)2*W.n_text + j];
+              Vd[0] += W.dg_tx[j]/(radius*s0*s0); Vd[3] += W.dg_tx[(size_t)W.n_text + j]/(radius*s1_*s1_); Vd[5] += W.dg_tx[(size_t)2*W.n_text + j]/(radius*s2_*s2_); }
+            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
+            double b0 = W.b_tx[j], b1 = W.b_tx[(size_t)W.n_text + j], b2 = W.b_tx[(size_t)2*W.n_text + j];
+            double f0 = Vi[0]*b0 + Vi[1]*b1 + Vi[2]*b2, f1 = Vi[1]*b0 + Vi[3]*b1 + Vi[4]*b2, f2 = Vi[2]*b0 + Vi[4]*b1 + Vi[5]*b2;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                acc[k] += W.w_tx[(size_t)(k*3)*L.n_tslot + s]*f0 + W.w_tx[(size_t)(k*3 + 1)*L.n_tslot + s]*f1 + W.w_tx[(size_t)(k*3 + 2)*L.n_tslot + s]*f2;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[k] = wave_sum1(acc[k]);
+        if (lane < 6) {
+            double v = acc[0];
+#pragma unroll
+            for (int k = 1; k < 6; k++) if (lane == k) v = acc[k];
+            W.g[6*a + lane] = W.bp[6*a + lane] - v;
+        }
+    }
+}
+
+// ---- dense solve of S dp = -g: blocked (6x6) Cholesky in LDS, one workgroup.  A = [S; g^T] stored (N+1) x ld.
+#define SOLVE_THREADS 512
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W, int use_lds) {
+    LmState *st = W.st;
+    if (st->done) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int N = W.N, tid = threadIdx.x, nb = N/6;
+    const int ld = use_lds ? (N | 1) : N;
+    double *A = use_lds ? smem : W.S;          // global fallback factors S in place; rhs row kept in W.dp
+    double *rhs = use_lds ? (smem + (size_t)N*ld) : W.dp;
+    if (use_lds) for (int k = tid; k < N*N; k += SOLVE_THREADS) A[(size_t)(k / N)*ld + (k % N)] = W.S[k];
+    for (int k = tid; k < N; k += SOLVE_THREADS) rhs[k] = W.g[k];
+    __shared__ int fail;
+    if (tid == 0) fail = st->step_fail;
+    __syncthreads();
+    for (int jb = 0; jb < nb && !fail; jb++) {
+        const int j0 = 6*jb;
+        // every thread factors the 6x6 diagonal block redundantly in registers
+        double Ld[21];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c <= r; c++) Ld[r*(r+1)/2 + c] = A[(size_t)(j0 + r)*ld + j0 + c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double d = Ld[c*(c+1)/2 + c];
+#pragma unroll
+            for (int k = 0; k < c; k++) d -= Ld[c*(c+1)/2 + k]*Ld[c*(c+1)/2 + k];
+            if (!(d > 0.0)) { bad = true; d = 1.0; }
+            d = sqrt(d); Ld[c*(c+1)/2 + c] = d;
+#pragma unroll
+            for (int r = c + 1; r < 6; r++) {
+                double s = Ld[r*(r+1)/2 + c];
+#pragma unroll
+                for (int k = 0; k < c; k++) s -= Ld[r*(r+1)/2 + k]*Ld[c*(c+1)/2 + k];
+                Ld[r*(r+1)/2 + c] = s/d;
+            }
+        }
+        __syncthreads();                        // all reads of the diagonal block done before it is overwritten
+        if (bad) { if (tid == 0) { fail = 1; st->step_fail = 1; } }
+        if (tid < 21) { int r = 0; while ((r+1)*(r+2)/2 <= tid) r++; int c = tid - r*(r+1)/2; A[(size_t)(j0 + r)*ld + j0 + c] = Ld[tid]; }
+        // panel: rows below (and the rhs row): x * Ld^T = a
+        for (int i = j0 + 6 + tid; i <= N; i += SOLVE_THREADS) {
+            double *row = (i < N) ? (A + (size_t)i*ld + j0) : (rhs + j0);
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double s = row[c];
+#pragma unroll
+                for (int k = 0; k < c; k++) s -= x[k]*Ld[c*(c+1)/2 + k];
+                x[c] = s/Ld[c*(c+1)/2 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) row[c] = x[c];
+        }
+        __syncthreads();
+        // trailing update with the rank-6 panel
+        const int m = N - j0 - 6;               // remaining rows/cols
+        for (int idx = tid; idx < (m + 1)*m; idx += SOLVE_THREADS) {
+            int ri = idx / m, ci = idx % m;
+            if (ri < m && ci > ri) continue;    // lower triangle only (rhs row ri == m takes all columns)
+            int k = j0 + 6 + ci;
+            const double *pi = (ri < m) ? (A + (size_t)(j0 + 6 + ri)*ld + j0) : (rhs + j0);
+            const double *pk = A + (size_t)k*ld + j0;
+            double s = pi[0]*pk[0] + pi[1]*pk[1] + pi[2]*pk[2] + pi[3]*pk[3] + pi[4]*pk[4] + pi[5]*pk[5];
+            if (ri < m) A[(size_t)(j0 + 6 + ri)*ld + k] -= s; else rhs[k] -= s;
+        }
+        __syncthreads();
+    }
+    if (fail) { for (int k = tid; k < N; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
+    // back substitution L^T x = y by wave 0 (y = rhs after the forward pass folded into the factorisation)
+    if (tid < 64) {
+        for (int jb = nb - 1; jb >= 0; jb--) {
+            const int j0 = 6*jb;
+            double Ld[21], y[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c <= r; c++) Ld[r*(r+1)/2 + c] = A[(size_t)(j0 + r)*ld + j0 + c];
+#pragma unroll
+            for (int c = 0; c < 6; c++) y[c] = rhs[j0 + c];
+#pragma unroll
+            for (int c = 5; c >= 0; c--) {
+                double s = y[c];
+#pragma unroll
+                for (int k = c + 1; k < 6; k++) s -= Ld[k*(k+1)/2 + c]*y[k];
+                y[c] = s/Ld[c*(c+1)/2 + c];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (tid < 6) { double v = y[0];
+#pragma unroll
+                for (int k = 1; k < 6; k++) if (tid == k) v = y[k];
+                rhs[j0 + tid] = v; }
+            for (int k = tid; k < j0; k += 64) {
+                double s = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) s += A[(size_t)(j0 + c)*ld + k]*y[c];
+                rhs[k] -= s;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+        for (int k = tid; k < N; k += 64) W.dp[k] = -rhs[k];
+    }
+}
+
+// ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
+__global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
+    LmState *st = W.st;
+    if (st->done) return;
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x, cur = st->cur;
+    const double radius = st->radius;
+    const bool fail = st->step_fail;
+    double step2 = 0.0, mcc = 0.0;
+    if (b < nb_pt) {
+        int j = b*256 + tid;
+        if (j < W.n_pt) {
+            double rh = W.rho[cur][j], d = 0.0;
+            int o = L.pls_off[j], e = L.pls_off[j+1];
+            if (!fail && e > o && W.act_pt[j]) {
+                double acc = W.b_pt[j];
+                for (int s = o; s < e; s++) { int a = L.pslot_pose[s];
+                    if (W.kf_in[a] && !W.kf_const[a]) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) acc += W.w_pt[(size_t)k*L.n_pslot + s]*W.dp[6*a + k]; } }
+                double sg = W.sig_pt[j], lam = W.dg_pt[j]/(radius*sg*sg);
+                d = -acc/(W.V_pt[j] + lam);
+                step2 = d*d; mcc = lam*d*d - W.b_pt[j]*d;
+            }
+            W.rho[cur ^ 1][j] = rh + d;
+        }
+    } else if (b < nb_pt + nb_tx) {
+        int j = (b - nb_pt)*256 + tid;
+        if (j < W.n_text) {
+            double d[3] = {0,0,0};
+            int o = L.tls_off[j], e = L.tls_off[j+1];
+            if (!fail && e > o && W.act_tx[j]) {
+                double acc[3] = { W.b_tx[j], W.b_tx[(size_t)W.n_text + j], W.b_tx[(size_t)2*W.n_text + j] };
+                for (int s = o; s < e; s++) { int a = L.tslot_pose[s];
+                    if (W.kf_in[a] && !W.kf_const[a]) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) { double dpk = W.dp[6*a + k];
+                            acc[0] += W.w_tx[(size_t)(k*3)*L.n_tslot + s]*dpk; acc[1] += W.w_tx[(size_t)(k*3 + 1)*L.n_tslot + s]*dpk; acc[2] += W.w_tx[(size_t)(k*3 + 2)*L.n_tslot + s]*dpk; } } }
+                double Vd[6], Vi[6], lam[3];
+#pragma unroll
+                for (int k = 0; k < 6; k++) Vd[k] = W.V_tx[(size_t)k*W.n_text + j];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { double sg = W.sig_tx[(size_t)k*W.n_text + j]; lam[k] = W.dg_tx[(size_t)k*W.n_text + j]/(radius*sg*sg); }
+                Vd[0] += lam[0]; Vd[3] += lam[1]; Vd[5] += lam[2];
+                if (inv_sym3(Vd, Vi)) {
+                    d[0] = -(Vi[0]*acc[0] + Vi[1]*acc[1] + Vi[2]*acc[2]);
+                    d[1] = -(Vi[1]*acc[0] + Vi[3]*acc[1] + Vi[4]*acc[2]);
+                    d[2] = -(Vi[2]*acc[0] + Vi[4]*acc[1] + Vi[5]*acc[2]);
+                    for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - W.b_tx[(size_t)k*W.n_text + j]*d[k]; }
+                }
+            }
+            for (int k = 0; k < 3; k++) W.theta[cur ^ 1][3*j + k] = W.theta[cur][3*j + k] + d[k];
+        }
+    } else {
+        int a = (b - nb_pt - nb_tx)*256 + tid;
+        if (a < W.n_kf) {
+            const double *x = W.pose[cur] + 7*a; double *c = W.pose[cur ^ 1] + 7*a;
+            if (!fail && W.kf_in[a] && !W.kf_const[a]) {
+                double d[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) d[k] = W.dp[6*a + k];
+                double q[4] = { x[0], x[1], x[2], x[3] }, qn[4];
+                quat_plus(q, d, qn);
+                for (int k = 0; k < 4; k++) { c[k] = qn[k]; step2 += (qn[k] - q[k])*(qn[k] - q[k]); }
+                for (int k = 0; k < 3; k++) { c[4 + k] = x[4 + k] + d[3 + k]; step2 += d[3 + k]*d[3 + k]; }
+                for (int k = 0; k < 6; k++) { double sg = W.sig_p[6*a + k]; double lam = W.dg_p[6*a + k]/(radius*sg*sg); mcc += lam*d[k]*d[k] - W.bp[6*a + k]*d[k]; }
+            } else for (int k = 0; k < 7; k++) c[k] = x[k];
+        }
+    }
+    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+    if (tid == 0) { W.partial[2*b] = step2; W.partial[2*b + 1] = mcc; }
+}
+
+// ---- step quality and trust-region update (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics)
+__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, tsba_options o) {
+    LmState *st = W.st;
+    if (st->done) return;
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double cost = 0.0, step2 = 0.0, mcc = 0.0;
+    for (int p = tid; p < L.n_pair; p += 256) cost += W.pairCost2[p];
+    for (int g = tid; g < L.n_tg; g += 256) cost += W.tgCost2[g];
+    for (int k = tid; k < nb_back; k += 256) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
+    cost = block_sum<256>(cost, red); step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+    if (tid) return;
+    mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
+    st->it++;
+    st->cand_cost = cost; st->model_change = mcc; st->step_norm = sqrt(step2);
+    if (st->step_fail || !(mcc > 0.0)) {          // invalid step
+        st->step_fail = 0;
+        if (++st->invalid >= 5) { st->done = 1; st->term = 5; return; }
+        st->radius *= 0.5;
+    } else {
+        st->invalid = 0; st->n_cost++;
+        if (!(cost == cost)) cost = 1.7976931348623157e308;
+        if (st->step_norm <= o.parameter_tolerance*(st->x_norm + o.parameter_tolerance)) { st->done = 1; st->term = 2; return; }
+        double cost_change = st->x_cost - cost;
+        if (fabs(cost_change) <= o.function_tolerance*st->x_cost) { st->done = 1; st->term = 1; return; }
+        double rel = cost_change/mcc;
+        if (rel > o.min_relative_decrease) {
+            st->cur ^= 1; st->need_lin = 1; st->accepted++; st->x_cost = cost;
+            double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
+            st->radius = fmin(st->radius/f, o.max_radius);
+            st->decrease_factor = 2.0;
+        } else {
+            st->radius = st->radius/st->decrease_factor; st->decrease_factor *= 2.0;
+        }
+    }
+    if (st->it >= st->max_it) { st->done = 1; st->term = 0; }
+    else if (st->radius < o.min_radius) { st->done = 1; st->term = 4; }
+}
+
+// ---- outlier pass on loss-corrected residuals, optimizer.cc:1609-1686 / :1228-1305
+__global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_mono, double chi2_text, double bad_ratio,
+                                                int do_scene, int do_text) {
+    LmState *st = W.st;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double *pose = W.pose[st->cur], *rho = W.rho[st->cur], *theta = W.theta[st->cur];
+    if (st->nt_active < 50) chi2_mono += 4.0;
+    if (b < L.n_pair) {
+        if (!do_scene) return;
+        const int i = L.pair_i[b], h = L.pair_h[b];
+        Pose C; load_pose(pose + 7*i, C);
+        PairT T;
+        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+        int nbad = 0;
+        for (int c = L.pair_sc_off[b] + lane; c < L.pair_sc_off[b+1]; c += 64) {
+            if (W.filter_good && !W.sgood[L.sc_flag[c]]) continue;
+            const int pt = L.sc_pt[c];
+            if (h < 0) pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+            double r[2];
+            scene_residual(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1],
+                           W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r);
+            double wgt; huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
+            double sc = sqrt(wgt);
+            double ex = r[0]*sc/W.w_sx, ey = r[1]*sc/W.w_sy;
+            if (ex*ex > chi2_mono || ey*ey > chi2_mono) { W.sgood[L.sc_flag[c]] = 0; nbad++; }
+        }
+        nbad = (int)wave_sum1((double)nbad);
+        if (lane == 0 && nbad) atomicAdd(&st->n_bad_scene, nbad);
+    } else {
+        if (!do_text) return;
+        const int g = b - L.n_pair;
+        const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
+        if (W.filter_good && !W.tobs_good[tb]) return;
+        const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
+        Pose C; load_pose(pose + 7*i, C);
+        PairT T;
+        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+        else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
+        const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+        const uint8_t *img = L.img[i];
+        const int fg = W.tobs_fgood_off[tb];
+        int nblk = 0, nbad = 0;
+        for (int f = L.tfeat_off[j] + lane; f < L.tfeat_off[j+1]; f += 64) {
+            if (W.filter_good && !W.tfgood[fg + L.tfeat_raw[f]]) continue;
+            nblk++;
+            if (sigma == 0.0) continue;               // residuals are 0: never an outlier
+            const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
+            double r[8], s = 0.0, jt[6], jl[3];
+#pragma unroll 1
+            for (int k = 0; k < 8; k++) {
+                double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];
+                r[k] = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h, mu, sigma, 1.0/sigma,
+                                L.tfeat_ref[8*(size_t)f + k], W.w_t, false, jt, jl);
+                s += r[k]*r[k];
+            }
+            double wgt; huber(s, W.huber_t, wgt);
+            double sc = sqrt(wgt); bool bad = false;
+            for (int k = 0; k < 8; k++) if (fabs(r[k]*sc/W.w_t) > chi2_text) bad = true;
+            if (bad) { W.tfgood[fg + L.tfeat_raw[f]] = 0; nbad++; }
+        }
+        nblk = (int)wave_sum1((double)nblk); nbad = (int)wave_sum1((double)nbad);
+        if (lane == 0 && nblk > 0) {
+            if (nbad) atomicAdd(&st->n_bad_tfeat, nbad);
+            if ((double)nbad/(double)nblk > bad_ratio) { W.tobs_good[tb] = 0; atomicAdd(&st->n_bad_text, 1); }
+        }
+    }
+}
+
+// ---- test hook: explicit residuals and Jacobians of every block, written at the reference's block order
+__global__ void k_eval_scene(Work W, LevelDev L, const int *out_idx, double *resid, double *jac) {
+    int c = blockIdx.x*blockDim.x + threadIdx.x; if (c >= L.n_sc) return;
+    int oi = out_idx[c]; if (oi < 0) return;
+    const double *pose = W.pose[0], *rho = W.rho[0];
+    // pair of this candidate
+    int i = L.sc_kf[c], pt = L.sc_pt[c], h = W.pt_host[pt];
+    Pose C; load_pose(pose + 7*i, C);
+    PairT T;
+    if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); } else pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+    double r[2], jt[2][6], jl[2];
+    scene_block(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1], W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r, jt, jl);
+    resid[2*oi] = r[0]; resid[2*oi+1] = r[1];
+    if (jac) for (int k = 0; k < 2; k++) {
+        double *row = jac + (size_t)oi*26 + k*13;
+        for (int a = 0; a < 6; a++) row[a] = jt[k][a];
+        if (h >= 0) {
+            for (int cc = 0; cc < 3; cc++) {
+                row[6 + cc] = -(jt[k][0]*T.Rcr[cc] + jt[k][1]*T.Rcr[3 + cc] + jt[k][2]*T.Rcr[6 + cc]);
+                row[9 + cc] = -(jt[k][3]*T.Rcr[cc] + jt[k][4]*T.Rcr[3 + cc] + jt[k][5]*T.Rcr[6 + cc]);
+            }
+            row[12] = jl[k];
+        } else for (int a = 6; a < 13; a++) row[a] = 0.0;
+    }
+}
+__global__ void k_eval_text(Work W, LevelDev L, int nblk, const int *blk_g, const int *blk_f, int ns, double *resid, double *jac) {
+    int q = blockIdx.x*blockDim.x + threadIdx.x; if (q >= nblk) return;
+    int g = blk_g[q], f = blk_f[q];
+    const double *pose = W.pose[0], *theta = W.theta[0];
+    const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
+    const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
+    Pose C; load_pose(pose + 7*i, C);
+    PairT T;
+    if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); } else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
+    const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+    const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
+    double *rout = resid + 2*(size_t)ns + 8*(size_t)q;
+    double *jout = jac ? jac + 26*(size_t)ns + 120*(size_t)q : nullptr;
+    for (int k = 0; k < 8; k++) {
+        double jt[6] = {0,0,0,0,0,0}, jl[3] = {0,0,0}, r = 0.0;
+        if (sigma != 0.0) {
+            double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];
+            r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], L.img[i], L.img_w, L.img_h, mu, sigma, 1.0/sigma,
+                         L.tfeat_ref[8*(size_t)f + k], W.w_t, true, jt, jl);
+        }
+        rout[k] = r;
+        if (jout) {
+            double *row = jout + k*15;
+            for (int a = 0; a < 6; a++) row[a] = jt[a];
+            if (h >= 0) {
+                for (int cc = 0; cc < 3; cc++) {
+                    row[6 + cc] = -(jt[0]*T.Rcr[cc] + jt[1]*T.Rcr[3 + cc] + jt[2]*T.Rcr[6 + cc]);
+                    row[9 + cc] = -(jt[3]*T.Rcr[cc] + jt[4]*T.Rcr[3 + cc] + jt[5]*T.Rcr[6 + cc]);
+                }
+                row[12] = jl[0]; row[13] = jl[1]; row[14] = jl[2];
+            } else for (int a = 6; a < 15; a++) row[a] = 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+};
+struct PassRecord { LmState st; };
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;                   // everything owned by the uploaded problem
+    bool uploaded = false;
+    tsba_options opt;
+    int n_kf = 0, n_pt = 0, n_text = 0, n_tobs = 0, n_sgood = 0, n_tfgood = 0, n_levels = 0;
+    Work W;
+    std::vector<HostPlan> hplan;                  // per level (only levels used by the options are built)
+    std::vector<LevelDev> lev;
+    std::vector<int> lev_built;
+    // restart copies
+    double *pose0 = nullptr, *rho0 = nullptr, *theta0 = nullptr; uint8_t *sgood0 = nullptr, *tobs_good0 = nullptr, *tfgood0 = nullptr;
+    uint8_t *kf_initial = nullptr;
+    LmState *st_host = nullptr;                   // pinned: per-pass snapshots
+    LmState *st_log = nullptr;                    // device [MAX passes]
+    int nb_back_max = 0;
+    size_t lds_limit = 0;
+    std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static void set_err(Ctx *c, const std::string &s) { c->err = s; }
+
+template <typename T>
+static int dev_alloc(Ctx *c, T **out, size_t n) {
+    void *p = nullptr; size_t bytes = std::max<size_t>(n, 1)*sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { set_err(c, std::string("hipMalloc: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; }
+    hipMemsetAsync(p, 0, bytes, c->stream);
+    c->allocs.push_back(p); *out = (T *)p; return 0;
+}
+template <typename T>
+static int dev_upload(Ctx *c, const T **out, const T *src, size_t n) {
+    T *p = nullptr; int rc = dev_alloc(c, &p, n); if (rc) return rc;
+    if (n && src) { hipError_t e = hipMemcpyAsync(p, src, n*sizeof(T), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { set_err(c, std::string("hipMemcpy H2D: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; } }
+    *out = p; return 0;
+}
+template <typename T>
+static int dev_upload_vec(Ctx *c, const T **out, const std::vector<T> &v) { return dev_upload(c, out, v.data(), v.size()); }
+
+static void free_problem(Ctx *c) {
+    hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) hipFree(p);
+    c->allocs.clear(); c->uploaded = false; c->hplan.clear(); c->lev.clear(); c->lev_built.clear();
+    for (int l = 0; l < TSBA_MAX_LEVELS; l++) c->img_dev[l].clear();
+}
+
+extern "C" {
+
+void tsba_default_options_local(tsba_options *o) {
+    memset(o, 0, sizeof(*o));
+    o->w_sx = o->w_sy = 1.0/1.2; o->w_t = 1.0/0.2;                  // optimizer.cc:1350-1351
+    o->huber_scene = sqrt(5.991); o->huber_text = 3.0;              // :1369, :1454
+    o->n_passes = 3;
+    for (int i = 0; i < 3; i++) { o->levels[i] = 2 - i; o->its[i] = 10; o->chi2_mono[i] = 12.25; o->chi2_text[i] = i == 2 ? 0.95 : 0.5; }  // :282-289
+    o->text_bad_ratio = 0.99; o->state = TSBA_STATE_LOCAL; o->outlier_scene = o->outlier_text = 1;
+    o->use_text = 1; o->filter_good = 1; o->text_jacobian = 0;
+    o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32; o->min_relative_decrease = 1e-3;
+    o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->min_diagonal = 1e-6; o->max_diagonal = 1e32; o->lm_shard = 0; o->lm_nshard = 1;
+}
+void tsba_default_options_pose(tsba_options *o) { tsba_default_options_local(o); o->state = TSBA_STATE_NOTREACHWIN; }
+void tsba_default_options_global(tsba_options *o) {
+    tsba_default_options_local(o);
+    o->w_sx = o->w_sy = o->w_t = 1.0; o->n_passes = 1; o->levels[0] = 0; o->its[0] = 20; o->chi2_mono[0] = 18.0;   // :411-414
+    o->state = TSBA_STATE_GLOBAL; o->outlier_scene = o->outlier_text = 0; o->use_text = 0; o->filter_good = 0;
+}
+
+int tsba_create(void **ctx, int device) {
+    if (!ctx) return TSBA_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return TSBA_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TSBA_ERR_DEVICE;
+    Ctx *c = new Ctx(); c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TSBA_ERR_DEVICE; }
+    hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
+    hipHostMalloc((void **)&c->st_host, sizeof(LmState)*TSBA_MAX_LEVELS, 0);
+    hipMalloc((void **)&c->st_log, sizeof(LmState)*TSBA_MAX_LEVELS);
+    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, device);
+    c->lds_limit = prop.sharedMemPerBlock;       // 64 KiB default static limit; dynamic up to 160 KiB on gfx950
+    if (c->lds_limit < 160*1024) c->lds_limit = 160*1024;
+    *ctx = c; return TSBA_OK;
+}
+int tsba_destroy(void *ctx) {
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    hipSetDevice(c->device);
+    free_problem(c);
+    hipHostFree(c->st_host); hipFree(c->st_log);
+    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
+    delete c; return TSBA_OK;
+}
+const char *tsba_last_error(void *ctx) { return ctx ? ((Ctx *)ctx)->err.c_str() : "null ctx"; }
+
+static int check_problem(Ctx *c, const tsba_problem *p, const tsba_options *o) {
+    if (!p || !o) { set_err(c, "null problem/options"); return TSBA_ERR_ARG; }
+    if (p->n_kf <= 0 || p->n_levels < 1 || p->n_levels > TSBA_MAX_LEVELS) { set_err(c, "bad n_kf / n_levels"); return TSBA_ERR_ARG; }
+    if (o->n_passes < 1 || o->n_passes > TSBA_MAX_LEVELS) { set_err(c, "bad n_passes"); return TSBA_ERR_ARG; }
+    for (int i = 0; i < o->n_passes; i++) if (o->levels[i] < 0 || o->levels[i] >= p->n_levels) { set_err(c, "pass level out of range"); return TSBA_ERR_ARG; }
+    if (o->text_jacobian != 0) { set_err(c, "text_jacobian=1 (numeric diff) is oracle-only"); return TSBA_ERR_ARG; }
+    if (o->use_text && p->n_tobs > 0) for (int i = 0; i < o->n_passes; i++) { int l = o->levels[i];
+        if (!p->img[l] || p->img_w[l]*p->img_h[l] > MS_MASK_WORDS*32) { set_err(c, "missing image level or image larger than 640x480"); return TSBA_ERR_ARG; } }
+    return 0;
+}
+
+int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    hipSetDevice(c->device);
+    int rc = check_problem(c, p, o); if (rc) return rc;
+    free_problem(c);
+    c->opt = *o;
+    c->n_kf = p->n_kf; c->n_pt = p->n_pt; c->n_text = p->n_text; c->n_tobs = p->n_tobs; c->n_sgood = p->n_sgood; c->n_levels = p->n_levels;
+    c->n_tfgood = p->n_tobs > 0 ? p->tobs_fgood_off[p->n_tobs] : 0;
+    Work &W = c->W; memset(&W, 0, sizeof(W));
+    W.n_kf = p->n_kf; W.n_pt = p->n_pt; W.n_text = p->n_text; W.n_tobs = p->n_tobs; W.N = 6*p->n_kf;
+    for (int k = 0; k < 4; k++) W.K0[k] = p->K[k];
+    W.w_sx = o->w_sx; W.w_sy = o->w_sy; W.w_t = o->w_t; W.huber_s = o->huber_scene; W.huber_t = o->huber_text;
+    W.filter_good = o->filter_good; W.min_diag = o->min_diagonal; W.max_diag = o->max_diagonal;
+#define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
+#define AL(dst, n) do { rc = dev_alloc(c, &(dst), (size_t)(n)); if (rc) return rc; } while (0)
+    const double *cd; const uint8_t *cu;
+    UP(cd, p->pose, 7*(size_t)p->n_kf); c->pose0 = (double *)cd;
+    UP(cd, p->rho, p->n_pt); c->rho0 = (double *)cd;
+    UP(cd, p->theta, 3*(size_t)p->n_text); c->theta0 = (double *)cd;
+    UP(cu, p->sgood, p->n_sgood); c->sgood0 = (uint8_t *)cu;
+    UP(cu, p->tobs_good, p->n_tobs); c->tobs_good0 = (uint8_t *)cu;
+    UP(cu, p->tfgood, c->n_tfgood); c->tfgood0 = (uint8_t *)cu;
+    std::vector<uint8_t> ki(p->n_kf, 0); if (p->kf_initial) memcpy(ki.data(), p->kf_initial, p->n_kf);
+    UP(cu, ki.data(), p->n_kf); c->kf_initial = (uint8_t *)cu;
+    for (int b = 0; b < 2; b++) { AL(W.pose[b], 7*(size_t)p->n_kf); AL(W.rho[b], p->n_pt); AL(W.theta[b], 3*(size_t)p->n_text); }
+    AL(W.sgood, p->n_sgood); AL(W.tobs_good, p->n_tobs); AL(W.tfgood, c->n_tfgood);
+    UP(W.pt_ray, p->pt_ray, 2*(size_t)p->n_pt); UP(W.pt_host, p->pt_host, p->n_pt);
+    { std::vector<double> z; const double *src = p->pt_host_Trw; if (!src) { z.assign(12*(size_t)p->n_pt, 0.0); src = z.data(); } UP(W.pt_Trw, src, 12*(size_t)p->n_pt); }
+    UP(W.text_host, p->text_host, p->n_text);
+    { std::vector<double> z; const double *src = p->text_host_Twr; if (!src) { z.assign(12*(size_t)p->n_text, 0.0); src = z.data(); } UP(W.text_Twr, src, 12*(size_t)p->n_text); }
+    UP(W.text_box, p->text_box_ray, 8*(size_t)p->n_text);
+    UP(W.tobs_kf, p->tobs_kf, p->n_tobs); UP(W.tobs_text, p->tobs_text, p->n_tobs); UP(W.tobs_fgood_off, p->tobs_fgood_off, (size_t)p->n_tobs + 1);
+    AL(W.musig, 2*(size_t)p->n_tobs);
+    AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
+    // ---- per-level plans
+    c->hplan.resize(p->n_levels); c->lev.resize(p->n_levels); c->lev_built.assign(p->n_levels, 0);
+    size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1;
+    for (int ps = 0; ps < o->n_passes; ps++) {
+        int l = o->levels[ps]; if (c->lev_built[l]) continue; c->lev_built[l] = 1;
+        HostPlan &H = c->hplan[l]; build_plan(p, o, l, H);
+        LevelDev &D = c->lev[l]; memset(&D, 0, sizeof(D));
+        D.level = l; D.n_sc = H.n_sc(); D.n_pair = H.n_pair(); D.n_tg = H.n_tg(); D.n_pslot = H.n_pslot(); D.n_tslot = H.n_tslot(); D.n_sb = H.n_sb();
+        double sc = 1.0; for (int k = 0; k < l; k++) sc *= 0.5;
+        for (int k = 0; k < 4; k++) { double v = p->K[k]; for (int q = 0; q < l; q++) v *= 0.5; D.K[k] = v; }
+        (void)sc;
+        D.img_w = p->img_w[l]; D.img_h = p->img_h[l];
+#define UV(field) do { rc = dev_upload_vec(c, &D.field, H.field); if (rc) return rc; } while (0)
+        UV(sc_obs); UV(sc_kf); UV(sc_pt); UV(sc_flag); UV(sc_slot); UV(sc_uv);
+        UV(pair_i); UV(pair_h); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
+        UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
+        UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
+        UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2);
+        UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ts_off); UV(pose_ts);
+        if (p->n_text > 0 && p->tfeat_off[l]) {
+            D.n_tfeat = p->n_tfeat[l];
+            UP(D.tfeat_off, p->tfeat_off[l], (size_t)p->n_text + 1); UP(D.tfeat_raw, p->tfeat_raw[l], p->n_tfeat[l]);
+            UP(D.tfeat_uv, p->tfeat_uv[l], 2*(size_t)p->n_tfeat[l]); UP(D.tfeat_ref, p->tfeat_ref[l], 8*(size_t)p->n_tfeat[l]);
+        } else { std::vector<int32_t> z((size_t)p->n_text + 1, 0); UP(D.tfeat_off, z.data(), z.size()); }
+        if (o->use_text && p->n_tobs > 0 && p->img[l]) {
+            std::vector<const uint8_t *> ptrs(p->n_kf, nullptr);
+            size_t npx = (size_t)p->img_w[l]*p->img_h[l];
+            uint8_t *slab = nullptr; AL(slab, npx*p->n_kf);
+            for (int k = 0; k < p->n_kf; k++) {
+                if (!p->img[l][k]) { set_err(c, "null image pointer"); return TSBA_ERR_ARG; }
+                hipError_t e = hipMemcpyAsync(slab + npx*k, p->img[l][k], npx, hipMemcpyHostToDevice, c->stream);
+                if (e != hipSuccess) { set_err(c, "image H2D failed"); return TSBA_ERR_DEVICE; }
+                ptrs[k] = slab + npx*k;
+            }
+            uint8_t **dptr = nullptr; AL(dptr, ptrs.size());
+            CK(hipMemcpyAsync(dptr, ptrs.data(), ptrs.size()*sizeof(uint8_t *), hipMemcpyHostToDevice, c->stream));
+            CK(hipStreamSynchronize(c->stream));     // ptrs is a local
+            D.img = (const uint8_t *const *)dptr;
+        }
+        mx_pair = std::max(mx_pair, (size_t)D.n_pair); mx_tg = std::max(mx_tg, (size_t)D.n_tg);
+        mx_pslot = std::max(mx_pslot, (size_t)D.n_pslot); mx_tslot = std::max(mx_tslot, (size_t)D.n_tslot);
+    }
+    AL(W.pairM, 27*mx_pair); AL(W.pairCost, mx_pair); AL(W.pairCost2, mx_pair); AL(W.pairR, 9*mx_pair); AL(W.pairOut, 90*mx_pair);
+    AL(W.tgM, 27*mx_tg); AL(W.tgCost, mx_tg); AL(W.tgCost2, mx_tg);
+    AL(W.w_pt, 6*mx_pslot); AL(W.vb_pt, 2*mx_pslot); AL(W.V_pt, p->n_pt); AL(W.b_pt, p->n_pt); AL(W.sig_pt, p->n_pt); AL(W.dg_pt, p->n_pt);
+    AL(W.w_tx, 18*mx_tslot); AL(W.vb_tx, 9*mx_tslot); AL(W.V_tx, 6*(size_t)p->n_text); AL(W.b_tx, 3*(size_t)p->n_text); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.dg_tx, 3*(size_t)p->n_text);
+    AL(W.Hd, W.N); AL(W.bp, W.N); AL(W.sig_p, W.N); AL(W.dg_p, W.N);
+    AL(W.S, (size_t)W.N*W.N); AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
+    c->nb_back_max = (p->n_pt + 255)/256 + (p->n_text + 255)/256 + (p->n_kf + 255)/256;
+    AL(W.partial, 2*(size_t)c->nb_back_max);
+    AL(W.st, 1);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err(c, "upload sync failed"); return TSBA_ERR_DEVICE; }
+    c->uploaded = true;
+    return TSBA_OK;
+}
+
+static int reset_state(Ctx *c) {
+    Work &W = c->W;
+    CK(hipMemcpyAsync(W.pose[0], c->pose0, sizeof(double)*7*c->n_kf, hipMemcpyDeviceToDevice, c->stream));
+    CK(hipMemcpyAsync(W.pose[1], c->pose0, sizeof(double)*7*c->n_kf, hipMemcpyDeviceToDevice, c->stream));
+    if (c->n_pt) { CK(hipMemcpyAsync(W.rho[0], c->rho0, sizeof(double)*c->n_pt, hipMemcpyDeviceToDevice, c->stream));
+                   CK(hipMemcpyAsync(W.rho[1], c->rho0, sizeof(double)*c->n_pt, hipMemcpyDeviceToDevice, c->stream)); }
+    if (c->n_text) { CK(hipMemcpyAsync(W.theta[0], c->theta0, sizeof(double)*3*c->n_text, hipMemcpyDeviceToDevice, c->stream));
+                     CK(hipMemcpyAsync(W.theta[1], c->theta0, sizeof(double)*3*c->n_text, hipMemcpyDeviceToDevice, c->stream)); }
+    if (c->n_sgood) CK(hipMemcpyAsync(W.sgood, c->sgood0, c->n_sgood, hipMemcpyDeviceToDevice, c->stream));
+    if (c->n_tobs) CK(hipMemcpyAsync(W.tobs_good, c->tobs_good0, c->n_tobs, hipMemcpyDeviceToDevice, c->stream));
+    if (c->n_tfgood) CK(hipMemcpyAsync(W.tfgood, c->tfgood0, c->n_tfgood, hipMemcpyDeviceToDevice, c->stream));
+    CK(hipMemsetAsync(W.st, 0, sizeof(LmState), c->stream));
+    return 0;
+}
+
+static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
+    Work &W = c->W; const tsba_options &o = c->opt;
+    hipLaunchKernelGGL(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
+    int n = D.n_sc + D.n_tg;
+    if (n > 0) hipLaunchKernelGGL(k_participation, dim3((n + 255)/256), dim3(256), 0, c->stream, W, D);
+    hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state);
+    if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
+}
+static void launch_linearize(Ctx *c, const LevelDev &D) {
+    Work &W = c->W;
+    int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256;
+    if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D);
+    hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
+    hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance);
+}
+static int solve_lds_bytes(Ctx *c, int *use_lds) {
+    size_t N = c->W.N, ld = N | 1, bytes = (N*ld + N + 8)*sizeof(double);
+    *use_lds = bytes <= 150*1024;
+    return *use_lds ? (int)bytes : 0;
+}
+static void launch_step(Ctx *c, const LevelDev &D) {
+    Work &W = c->W;
+    int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256;
+    int use_lds; int lds = solve_lds_bytes(c, &use_lds);
+    if (D.n_sb*36 < W.N*W.N) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
+    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, use_lds);
+    hipLaunchKernelGGL(k_back, dim3(nb_pt + nb_tx + nb_kf), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
+    if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_COST>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, c->opt);
+}
+
+int tsba_solve(void *ctx, tsba_report *r) {
+    Ctx *c = (Ctx *)ctx; if (!c || !r) return TSBA_ERR_ARG;
+    if (!c->uploaded) { set_err(c, "no problem uploaded"); return TSBA_ERR_STATE; }
+    hipSetDevice(c->device);
+    memset(r, 0, sizeof(*r));
+    const tsba_options &o = c->opt;
+    int use_lds; int lds = solve_lds_bytes(c, &use_lds);
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = reset_state(c); if (rc) return rc;
+    for (int ps = 0; ps < o.n_passes; ps++) {
+        const LevelDev &D = c->lev[o.levels[ps]];
+        launch_pass_init(c, D, ps);
+        launch_linearize(c, D);
+        for (int it = 0; it < o.its[ps]; it++) { launch_step(c, D); launch_linearize(c, D); }
+        if (o.outlier_scene || o.outlier_text)
+            if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, c->W, D,
+                                                          o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
+        CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
+    }
+    CK(hipMemcpyAsync(c->st_host, c->st_log, sizeof(LmState)*o.n_passes, hipMemcpyDeviceToHost, c->stream));
+    CK(hipStreamSynchronize(c->stream));
+    CK(hipGetLastError());
+    auto t1 = std::chrono::steady_clock::now();
+    r->t_solve_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    r->n_passes = o.n_passes;
+    long long prev_lin = 0, prev_cost = 0;
+    for (int ps = 0; ps < o.n_passes; ps++) {
+        const LmState &s = c->st_host[ps];
+        r->iters[ps] = s.it; r->accepted[ps] = s.accepted; r->termination[ps] = s.term;
+        r->cost0[ps] = s.cost0; r->cost1[ps] = s.x_cost;
+        r->n_sblock[ps] = s.ns_active; r->n_tblock[ps] = s.nt_active;
+        r->n_bad_scene[ps] = s.n_bad_scene; r->n_bad_tfeat[ps] = s.n_bad_tfeat; r->n_bad_text[ps] = s.n_bad_text;
+        long long evals = (s.n_lin - prev_lin) + (s.n_cost - prev_cost);
+        r->n_resid_evals += evals*(2LL*s.ns_active + 8LL*s.nt_active);
+        prev_lin = s.n_lin; prev_cost = s.n_cost;
+        if (s.term == 5) r->status = TSBA_ERR_NUMERIC;
+    }
+    return TSBA_OK;
+}
+
+int tsba_download(void *ctx, tsba_problem *p) {
+    Ctx *c = (Ctx *)ctx; if (!c || !p) return TSBA_ERR_ARG;
+    if (!c->uploaded) { set_err(c, "no problem uploaded"); return TSBA_ERR_STATE; }
+    hipSetDevice(c->device);
+    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
+    int cur = st.cur & 1;
+    CK(hipMemcpy(p->pose, c->W.pose[cur], sizeof(double)*7*c->n_kf, hipMemcpyDeviceToHost));
+    if (c->n_pt) CK(hipMemcpy(p->rho, c->W.rho[cur], sizeof(double)*c->n_pt, hipMemcpyDeviceToHost));
+    if (c->n_text) CK(hipMemcpy(p->theta, c->W.theta[cur], sizeof(double)*3*c->n_text, hipMemcpyDeviceToHost));
+    if (c->n_sgood) CK(hipMemcpy(p->sgood, c->W.sgood, c->n_sgood, hipMemcpyDeviceToHost));
+    if (c->n_tobs) CK(hipMemcpy(p->tobs_good, c->W.tobs_good, c->n_tobs, hipMemcpyDeviceToHost));
+    if (c->n_tfgood) CK(hipMemcpy(p->tfgood, c->W.tfgood, c->n_tfgood, hipMemcpyDeviceToHost));
+    return TSBA_OK;
+}
+
+static int one_shot(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r) {
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = tsba_upload(ctx, p, o); if (rc) return rc;
+    auto t1 = std::chrono::steady_clock::now();
+    rc = tsba_solve(ctx, r); if (rc) return rc;
+    auto t2 = std::chrono::steady_clock::now();
+    rc = tsba_download(ctx, p); if (rc) return rc;
+    auto t3 = std::chrono::steady_clock::now();
+    r->t_upload_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    r->t_download_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    return r->status;
+}
+int tsba_local_ba(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r) { return one_shot(ctx, p, o, r); }
+int tsba_pose_optim(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r) {
+    if (p && p->n_kf != 1) { if (ctx) set_err((Ctx *)ctx, "tsba_pose_optim needs n_kf == 1"); return TSBA_ERR_ARG; }
+    return one_shot(ctx, p, o, r);
+}
+int tsba_global_ba(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r) { return one_shot(ctx, p, o, r); }
+
+int tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int level,
+              double *resid, double *jac, double *musigma, int64_t *ns_out, int64_t *nt_out) {
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    if (!p || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
+    tsba_options oo = *o; oo.n_passes = 1; oo.levels[0] = level;
+    int rc = tsba_upload(ctx, p, &oo); if (rc) return rc;
+    rc = reset_state(c); if (rc) return rc;
+    const LevelDev &D = c->lev[level]; const HostPlan &H = c->hplan[level];
+    launch_pass_init(c, D, 0);
+    // reference block order: scene candidates by observation index, then text blocks by (tobs, feature)
+    std::vector<int> out_idx(H.n_sc(), -1);
+    { std::vector<int> by_obs(p->n_sobs[level], -1);
+      for (int q = 0; q < H.n_sc(); q++) by_obs[H.sc_obs[q]] = q;
+      int n = 0;
+      for (int s = 0; s < p->n_sobs[level]; s++) { int q = by_obs[s]; if (q < 0) continue;
+          if (oo.filter_good && !p->sgood[H.sc_flag[q]]) continue; out_idx[q] = n++; }
+      *ns_out = n; }
+    std::vector<int> bg, bf;
+    for (int g = 0; g < H.n_tg(); g++) {
+        int tb = H.tg_tobs[g], j = H.tg_text[g];
+        if (oo.filter_good && !p->tobs_good[tb]) continue;
+        for (int f = p->tfeat_off[level][j]; f < p->tfeat_off[level][j+1]; f++) {
+            if (oo.filter_good && !p->tfgood[p->tobs_fgood_off[tb] + p->tfeat_raw[level][f]]) continue;
+            bg.push_back(g); bf.push_back(f);
+        }
+    }
+    *nt_out = (int64_t)bg.size();
+    int64_t ns = *ns_out, nt = *nt_out;
+    if (resid || jac) {
+        const int *d_oi, *d_bg, *d_bf; double *d_r, *d_j = nullptr;
+        rc = dev_upload_vec(c, &d_oi, out_idx); if (rc) return rc;
+        rc = dev_upload_vec(c, &d_bg, bg); if (rc) return rc;
+        rc = dev_upload_vec(c, &d_bf, bf); if (rc) return rc;
+        rc = dev_alloc(c, &d_r, (size_t)(2*ns + 8*nt)); if (rc) return rc;
+        if (jac) { rc = dev_alloc(c, &d_j, (size_t)(26*ns + 120*nt)); if (rc) return rc; }
+        if (H.n_sc() > 0) hipLaunchKernelGGL(k_eval_scene, dim3((H.n_sc() + 255)/256), dim3(256), 0, c->stream, c->W, D, d_oi, d_r, d_j);
+        if (nt > 0) hipLaunchKernelGGL(k_eval_text, dim3(((int)nt + 255)/256), dim3(256), 0, c->stream, c->W, D, (int)nt, d_bg, d_bf, (int)ns, d_r, d_j);
+        CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
+        if (resid) CK(hipMemcpy(resid, d_r, sizeof(double)*(size_t)(2*ns + 8*nt), hipMemcpyDeviceToHost));
+        if (jac) CK(hipMemcpy(jac, d_j, sizeof(double)*(size_t)(26*ns + 120*nt), hipMemcpyDeviceToHost));
+    }
+    CK(hipStreamSynchronize(c->stream));
+    if (musigma && p->n_tobs) CK(hipMemcpy(musigma, c->W.musig, sizeof(double)*2*p->n_tobs, hipMemcpyDeviceToHost));
+    return TSBA_OK;
+}
+
+// debug / test aid: first linearisation of pass 0 + reduced system for `radius`; copies S (N x N), g (N), cost, kf flags
+int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, double *cost, int32_t *kf_free, double *dp) {
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    if (!c->uploaded) return TSBA_ERR_STATE;
+    hipSetDevice(c->device);
+    int rc = reset_state(c); if (rc) return rc;
+    tsba_options saved = c->opt; c->opt.initial_radius = radius;
+    const LevelDev &D = c->lev[c->opt.levels[0]];
+    int use_lds; int lds = solve_lds_bytes(c, &use_lds);
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    launch_pass_init(c, D, 0);
+    launch_linearize(c, D);
+    Work &W = c->W;
+    if (D.n_sb*36 < W.N*W.N) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
+    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, use_lds);
+    c->opt = saved;
+    CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
+    if (S) CK(hipMemcpy(S, W.S, sizeof(double)*(size_t)W.N*W.N, hipMemcpyDeviceToHost));
+    if (g) CK(hipMemcpy(g, W.g, sizeof(double)*W.N, hipMemcpyDeviceToHost));
+    if (dp) CK(hipMemcpy(dp, W.dp, sizeof(double)*W.N, hipMemcpyDeviceToHost));
+    LmState st; CK(hipMemcpy(&st, W.st, sizeof(st), hipMemcpyDeviceToHost));
+    if (cost) *cost = st.x_cost;
+    if (kf_free) { std::vector<int> in(c->n_kf), cs(c->n_kf);
+        CK(hipMemcpy(in.data(), W.kf_in, sizeof(int)*c->n_kf, hipMemcpyDeviceToHost)); CK(hipMemcpy(cs.data(), W.kf_const, sizeof(int)*c->n_kf, hipMemcpyDeviceToHost));
+        for (int k = 0; k < c->n_kf; k++) kf_free[k] = in[k] && !cs[k]; }
+    return TSBA_OK;
+}
+
+int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *algo_bytes) {
+    Ctx *c = (Ctx *)ctx; if (!c || n <= 0) return TSBA_ERR_ARG;
+    if (!c->uploaded || level < 0 || level >= c->n_levels || !c->lev_built[level]) { set_err(c, "level not uploaded"); return TSBA_ERR_STATE; }
+    hipSetDevice(c->device);
+    int rc = reset_state(c); if (rc) return rc;
+    const LevelDev &D = c->lev[level];
+    int ps = 0; for (int k = 0; k < c->opt.n_passes; k++) if (c->opt.levels[k] == level) ps = k;
+    launch_pass_init(c, D, ps);
+    launch_linearize(c, D);                                    // warm-up (also leaves need_lin = 0)
+    CK(hipStreamSynchronize(c->stream));
+    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
+    st.need_lin = 1; st.done = 0; st.first = 0;
+    CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));   // k_linearize never clears need_lin itself
+    CK(hipEventRecord(c->ev0, c->stream));
+    for (int k = 0; k < n; k++) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, c->W, D);
+    CK(hipEventRecord(c->ev1, c->stream));
+    CK(hipEventSynchronize(c->ev1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (avg_ms) *avg_ms = (double)ms/n;
+    if (algo_bytes) {   // 44 B / scene block, 128 B / text block, 16 B / (KF,text) pair, parameters once
+        int npairs_text = 0; std::vector<int> kin;
+        (void)kin;
+        for (int g = 0; g < D.n_tg; g++) npairs_text++;
+        *algo_bytes = 44.0*st.ns_active + 128.0*st.nt_active + 16.0*npairs_text + 56.0*c->n_kf + 8.0*c->n_pt + 24.0*c->n_text;
+    }
+    return TSBA_OK;
+}
+
+int tsba_comm_unique_id(void *id128) { (void)id128; return TSBA_ERR_COMM; }
+int tsba_comm_init(void *ctx, const void *id128, int rank, int world) { (void)ctx; (void)id128; (void)rank; (void)world; return TSBA_ERR_COMM; }
+
+} // extern "C"

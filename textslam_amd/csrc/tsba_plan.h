@@ -1,0 +1,176 @@
+// Host-side "plan" of one pyramid pass: the static index structures the kernels walk.
+//
+// This is the flat counterpart of the reference's problem construction (row B1 of SURVEY.md 8a:
+// optimizer.cc:1366-1557 PyrBA, :1126-1207 PyrPoseOptim, :1727-1765 PyrGlobalBA).  The reference adds residual
+// blocks one by one to a ceres::Problem; here every block that COULD be added (ignoring the good flags, which
+// change between passes on the device) becomes a candidate, grouped so that each later reduction is a gather:
+//
+//   pair   p = (target KF i, host KF h | -1)   all scene candidates of a pair are contiguous; text groups hang off it
+//   group  g = one (KF, text) observation      = up to 64 photometric blocks that share (i, h, theta)
+//   slot   s = one (landmark, observing pose) entry of W = J_p^T J_l; the last slot of a landmark is its host pose
+//   sblock   = one 6x6 block (a <= b) of the reduced camera system with the slot pairs that feed it
+#pragma once
+#include <vector>
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include "../../include/tsba.h"
+
+struct HostPlan {
+    int level = 0;
+    // scene candidates (sorted by pair)
+    std::vector<int32_t> sc_obs, sc_kf, sc_pt, sc_flag, sc_slot;
+    std::vector<double>  sc_uv;                 // [n_sc][2]
+    // pairs
+    std::vector<int32_t> pair_i, pair_h, pair_sc_off, pair_tg_off, pair_tg;
+    // text groups
+    std::vector<int32_t> tg_tobs, tg_kf, tg_text, tg_pair, tg_slot;
+    // landmark slots
+    std::vector<int32_t> pls_off, pslot_pose, pslot_pair, pslot_lm;     // points
+    std::vector<int32_t> tls_off, tslot_pose, tslot_pair, tslot_lm;     // text planes
+    // reduced-system blocks
+    std::vector<int32_t> sb_a, sb_b, sb_pab, sb_pba;
+    std::vector<int32_t> sb_pt_off, sb_pt_s1, sb_pt_s2, sb_tx_off, sb_tx_s1, sb_tx_s2;
+    // per pose: pairs where it is target / host; slots it owns
+    std::vector<int32_t> pose_t_off, pose_t, pose_h_off, pose_h;
+    std::vector<int32_t> pose_ps_off, pose_ps, pose_ts_off, pose_ts;
+    // text blocks flattened (group, feature) for the eval hook / outlier pass
+    int n_sc() const { return (int)sc_obs.size(); }
+    int n_pair() const { return (int)pair_i.size(); }
+    int n_tg() const { return (int)tg_tobs.size(); }
+    int n_pslot() const { return (int)pslot_pose.size(); }
+    int n_tslot() const { return (int)tslot_pose.size(); }
+    int n_sb() const { return (int)sb_a.size(); }
+};
+
+inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P) {
+    P = HostPlan();
+    P.level = L;
+    const int n_kf = p->n_kf, n_pt = p->n_pt, n_text = p->n_text;
+    struct Cand { int obs, kf, pt, host; };
+    std::vector<Cand> cs;
+    cs.reserve(p->n_sobs[L]);
+    for (int s = 0; s < p->n_sobs[L]; s++) {
+        int kf = p->sobs_kf[L][s], pt = p->sobs_pt[L][s], host = p->pt_host[pt];
+        if (host >= 0 && host == kf) continue;                    // optimizer.cc:1393 "Host != Target"
+        if (o->lm_nshard > 1 && (pt % o->lm_nshard) != o->lm_shard) continue;   // multi-GPU: landmark shard
+        cs.push_back({ s, kf, pt, host >= 0 ? host : -1 });
+    }
+    struct Grp { int tobs, kf, text, host; };
+    std::vector<Grp> gs;
+    if (o->use_text) for (int t = 0; t < p->n_tobs; t++) {
+        int kf = p->tobs_kf[t], j = p->tobs_text[t], host = p->text_host[j];
+        if (host >= 0 && host == kf) continue;                    // optimizer.cc:1484
+        if (o->lm_nshard > 1 && ((n_pt + j) % o->lm_nshard) != o->lm_shard) continue;
+        gs.push_back({ t, kf, j, host >= 0 ? host : -1 });
+    }
+    // ---- pairs: key = kf*(n_kf+1) + (host+1)
+    std::vector<int64_t> keys;
+    keys.reserve(cs.size() + gs.size());
+    auto key_of = [&](int kf, int host) { return (int64_t)kf*(n_kf + 1) + (host + 1); };
+    for (auto &c : cs) keys.push_back(key_of(c.kf, c.host));
+    for (auto &g : gs) keys.push_back(key_of(g.kf, g.host));
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    const int n_pair = (int)keys.size();
+    auto pair_of = [&](int kf, int host) { return (int)(std::lower_bound(keys.begin(), keys.end(), key_of(kf, host)) - keys.begin()); };
+    P.pair_i.resize(n_pair); P.pair_h.resize(n_pair);
+    for (int q = 0; q < n_pair; q++) { P.pair_i[q] = (int)(keys[q]/(n_kf + 1)); P.pair_h[q] = (int)(keys[q] % (n_kf + 1)) - 1; }
+    // ---- sort scene candidates by pair (stable: keeps the reference order inside a pair)
+    std::vector<int> cpair(cs.size());
+    for (size_t i = 0; i < cs.size(); i++) cpair[i] = pair_of(cs[i].kf, cs[i].host);
+    std::vector<int> order(cs.size());
+    for (size_t i = 0; i < cs.size(); i++) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cpair[a] < cpair[b]; });
+    const int n_sc = (int)cs.size();
+    P.sc_obs.resize(n_sc); P.sc_kf.resize(n_sc); P.sc_pt.resize(n_sc); P.sc_flag.resize(n_sc); P.sc_slot.assign(n_sc, -1); P.sc_uv.resize(2*(size_t)n_sc);
+    P.pair_sc_off.assign(n_pair + 1, 0);
+    for (int c = 0; c < n_sc; c++) {
+        const Cand &k = cs[order[c]];
+        P.sc_obs[c] = k.obs; P.sc_kf[c] = k.kf; P.sc_pt[c] = k.pt; P.sc_flag[c] = p->sobs_flag[L][k.obs];
+        P.sc_uv[2*c] = p->sobs_uv0[L][2*k.obs]; P.sc_uv[2*c+1] = p->sobs_uv0[L][2*k.obs+1];
+        P.pair_sc_off[cpair[order[c]] + 1]++;
+    }
+    for (int q = 0; q < n_pair; q++) P.pair_sc_off[q+1] += P.pair_sc_off[q];
+    // ---- text groups and their pair CSR
+    const int n_tg = (int)gs.size();
+    P.tg_tobs.resize(n_tg); P.tg_kf.resize(n_tg); P.tg_text.resize(n_tg); P.tg_pair.resize(n_tg); P.tg_slot.assign(n_tg, -1);
+    P.pair_tg_off.assign(n_pair + 1, 0);
+    for (int g = 0; g < n_tg; g++) {
+        P.tg_tobs[g] = gs[g].tobs; P.tg_kf[g] = gs[g].kf; P.tg_text[g] = gs[g].text; P.tg_pair[g] = pair_of(gs[g].kf, gs[g].host);
+        P.pair_tg_off[P.tg_pair[g] + 1]++;
+    }
+    for (int q = 0; q < n_pair; q++) P.pair_tg_off[q+1] += P.pair_tg_off[q];
+    P.pair_tg.resize(n_tg);
+    { std::vector<int> cur(P.pair_tg_off.begin(), P.pair_tg_off.end() - 1);
+      for (int g = 0; g < n_tg; g++) P.pair_tg[cur[P.tg_pair[g]]++] = g; }
+    // ---- landmark slots (landmark-major; last slot of a landmark = its host pose)
+    {
+        std::vector<int> cnt(n_pt + 1, 0);
+        for (int c = 0; c < n_sc; c++) if (p->pt_host[P.sc_pt[c]] >= 0) cnt[P.sc_pt[c]]++;
+        P.pls_off.assign(n_pt + 1, 0);
+        for (int j = 0; j < n_pt; j++) P.pls_off[j+1] = P.pls_off[j] + (cnt[j] > 0 ? cnt[j] + 1 : 0);
+        int ns = P.pls_off[n_pt];
+        P.pslot_pose.assign(ns, -1); P.pslot_pair.assign(ns, -1); P.pslot_lm.assign(ns, -1);
+        std::vector<int> cur(P.pls_off.begin(), P.pls_off.end() - 1);
+        for (int c = 0; c < n_sc; c++) { int j = P.sc_pt[c]; if (p->pt_host[j] < 0) continue;
+            int s = cur[j]++; P.sc_slot[c] = s; P.pslot_pose[s] = P.sc_kf[c]; P.pslot_pair[s] = pair_of(P.sc_kf[c], p->pt_host[j]); P.pslot_lm[s] = j; }
+        for (int j = 0; j < n_pt; j++) if (cnt[j] > 0) { int s = P.pls_off[j+1] - 1; P.pslot_pose[s] = p->pt_host[j]; P.pslot_lm[s] = j; }
+    }
+    {
+        std::vector<int> cnt(n_text + 1, 0);
+        for (int g = 0; g < n_tg; g++) if (p->text_host[P.tg_text[g]] >= 0) cnt[P.tg_text[g]]++;
+        P.tls_off.assign(n_text + 1, 0);
+        for (int j = 0; j < n_text; j++) P.tls_off[j+1] = P.tls_off[j] + (cnt[j] > 0 ? cnt[j] + 1 : 0);
+        int ns = P.tls_off[n_text];
+        P.tslot_pose.assign(ns, -1); P.tslot_pair.assign(ns, -1); P.tslot_lm.assign(ns, -1);
+        std::vector<int> cur(P.tls_off.begin(), P.tls_off.end() - 1);
+        for (int g = 0; g < n_tg; g++) { int j = P.tg_text[g]; if (p->text_host[j] < 0) continue;
+            int s = cur[j]++; P.tg_slot[g] = s; P.tslot_pose[s] = P.tg_kf[g]; P.tslot_pair[s] = P.tg_pair[g]; P.tslot_lm[s] = j; }
+        for (int j = 0; j < n_text; j++) if (cnt[j] > 0) { int s = P.tls_off[j+1] - 1; P.tslot_pose[s] = p->text_host[j]; P.tslot_lm[s] = j; }
+    }
+    // ---- reduced-system blocks: key = a*n_kf + b (a <= b)
+    struct Tri { int64_t key; int s1, s2; };
+    std::vector<Tri> tp, tt;
+    std::vector<int64_t> bkeys;
+    auto bkey = [&](int a, int b) { return (int64_t)a*n_kf + b; };
+    for (int j = 0; j < n_pt; j++) for (int s1 = P.pls_off[j]; s1 < P.pls_off[j+1]; s1++) for (int s2 = P.pls_off[j]; s2 < P.pls_off[j+1]; s2++) {
+        int a = P.pslot_pose[s1], b = P.pslot_pose[s2]; if (a > b) continue; tp.push_back({ bkey(a, b), s1, s2 }); }
+    for (int j = 0; j < n_text; j++) for (int s1 = P.tls_off[j]; s1 < P.tls_off[j+1]; s1++) for (int s2 = P.tls_off[j]; s2 < P.tls_off[j+1]; s2++) {
+        int a = P.tslot_pose[s1], b = P.tslot_pose[s2]; if (a > b) continue; tt.push_back({ bkey(a, b), s1, s2 }); }
+    for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bkeys.push_back(bkey(i, i));
+        if (h >= 0) { bkeys.push_back(bkey(h, h)); bkeys.push_back(bkey(std::min(i, h), std::max(i, h))); } }
+    for (auto &t : tp) bkeys.push_back(t.key);
+    for (auto &t : tt) bkeys.push_back(t.key);
+    std::sort(bkeys.begin(), bkeys.end());
+    bkeys.erase(std::unique(bkeys.begin(), bkeys.end()), bkeys.end());
+    const int n_sb = (int)bkeys.size();
+    auto blk_of = [&](int64_t k) { return (int)(std::lower_bound(bkeys.begin(), bkeys.end(), k) - bkeys.begin()); };
+    P.sb_a.resize(n_sb); P.sb_b.resize(n_sb); P.sb_pab.assign(n_sb, -1); P.sb_pba.assign(n_sb, -1);
+    for (int q = 0; q < n_sb; q++) { P.sb_a[q] = (int)(bkeys[q]/n_kf); P.sb_b[q] = (int)(bkeys[q] % n_kf); }
+    for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; if (h < 0) continue;
+        int bl = blk_of(bkey(std::min(i, h), std::max(i, h)));
+        if (i < h) P.sb_pab[bl] = q; else P.sb_pba[bl] = q; }     // pab: target = a, host = b;  pba: target = b, host = a
+    auto fill_tri = [&](std::vector<Tri> &t, std::vector<int32_t> &off, std::vector<int32_t> &s1, std::vector<int32_t> &s2) {
+        std::stable_sort(t.begin(), t.end(), [](const Tri &x, const Tri &y) { return x.key < y.key; });
+        off.assign(n_sb + 1, 0); s1.resize(t.size()); s2.resize(t.size());
+        for (size_t k = 0; k < t.size(); k++) { off[blk_of(t[k].key) + 1]++; s1[k] = t[k].s1; s2[k] = t[k].s2; }
+        for (int q = 0; q < n_sb; q++) off[q+1] += off[q];
+    };
+    fill_tri(tp, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2);
+    fill_tri(tt, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2);
+    // ---- per-pose lists
+    auto csr = [&](int n, const std::vector<std::pair<int,int>> &items, std::vector<int32_t> &off, std::vector<int32_t> &val) {
+        off.assign(n + 1, 0); val.resize(items.size());
+        for (auto &it : items) off[it.first + 1]++;
+        for (int k = 0; k < n; k++) off[k+1] += off[k];
+        std::vector<int> cur(off.begin(), off.end() - 1);
+        for (auto &it : items) val[cur[it.first]++] = it.second;
+    };
+    std::vector<std::pair<int,int>> it_t, it_h, it_ps, it_ts;
+    for (int q = 0; q < n_pair; q++) { it_t.push_back({ P.pair_i[q], q }); if (P.pair_h[q] >= 0) it_h.push_back({ P.pair_h[q], q }); }
+    for (int s = 0; s < P.n_pslot(); s++) it_ps.push_back({ P.pslot_pose[s], s });
+    for (int s = 0; s < P.n_tslot(); s++) it_ts.push_back({ P.tslot_pose[s], s });
+    csr(n_kf, it_t, P.pose_t_off, P.pose_t); csr(n_kf, it_h, P.pose_h_off, P.pose_h);
+    csr(n_kf, it_ps, P.pose_ps_off, P.pose_ps); csr(n_kf, it_ts, P.pose_ts_off, P.pose_ts);
+}

@@ -1,0 +1,164 @@
+"""Host-side mirror of TextSLAM's `optimizer` class over the C ABI of libtsba.so (include/tsba.h).
+
+Method names, argument meaning and side effects follow src/optimizer.h:57-70 of the reference:
+the caller owns the problem, the optimiser mutates poses / rho / theta and the good-flags in place.
+All compute runs in the HIP library; there is no CPU fallback -- a missing library or device raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from .abi import (TsbaProblem, TsbaOptions, TsbaReport, BAProblem, options_local, options_pose, options_global,
+                  STATE_LOCAL, STATE_NOTREACHWIN)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libtsba.so")
+_lib = None
+
+
+class TsbaError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libtsba.so and declare the ABI of include/tsba.h. Raises if the HIP extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIBPATH):
+        raise TsbaError(f"{_LIBPATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    L = C.CDLL(_LIBPATH)
+    vp, dp = C.c_void_p, C.POINTER(C.c_double)
+    L.tsba_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.tsba_destroy.argtypes = [vp]
+    L.tsba_last_error.argtypes = [vp]
+    L.tsba_last_error.restype = C.c_char_p
+    for name in ("tsba_local_ba", "tsba_pose_optim", "tsba_global_ba"):
+        getattr(L, name).argtypes = [vp, C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.POINTER(TsbaReport)]
+    L.tsba_upload.argtypes = [vp, C.POINTER(TsbaProblem), C.POINTER(TsbaOptions)]
+    L.tsba_solve.argtypes = [vp, C.POINTER(TsbaReport)]
+    L.tsba_download.argtypes = [vp, C.POINTER(TsbaProblem)]
+    L.tsba_eval.argtypes = [vp, C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, dp, dp, dp,
+                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tsba_time_linearize.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    L.tsba_debug_reduced_system.argtypes = [vp, C.c_double, dp, dp, dp, C.POINTER(C.c_int32), dp]
+    L.tsba_comm_unique_id.argtypes = [vp]
+    L.tsba_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    for name in ("tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global"):
+        getattr(L, name).argtypes = [C.POINTER(TsbaOptions)]
+        getattr(L, name).restype = None
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global",
+    "tsba_create", "tsba_destroy", "tsba_last_error",
+    "tsba_local_ba", "tsba_pose_optim", "tsba_global_ba",
+    "tsba_upload", "tsba_solve", "tsba_download", "tsba_eval", "tsba_time_linearize",
+    "tsba_comm_unique_id", "tsba_comm_init",
+]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Optimizer:
+    """Drop-in for the numeric core of TextSLAM's optimizer (one instance per calling thread / GPU)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.lib.tsba_create(C.byref(self.ctx), device)
+        if rc != 0:
+            raise TsbaError(f"tsba_create(device={device}) failed with {rc}: no usable HIP device")
+        self._resident = None
+
+    def close(self):
+        if self.ctx:
+            self.lib.tsba_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.tsba_last_error(self.ctx)
+            raise TsbaError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")
+
+    # ---- optimizer:: replacements (src/optimizer.h:57-70)
+    def LocalBundleAdjustment(self, prob: BAProblem, state=STATE_LOCAL, options: TsbaOptions = None):
+        o = options or options_local(state)
+        return self._one_shot(self.lib.tsba_local_ba, prob, o, "tsba_local_ba")
+
+    def PoseOptim(self, prob: BAProblem, options: TsbaOptions = None):
+        o = options or options_pose()
+        return self._one_shot(self.lib.tsba_pose_optim, prob, o, "tsba_pose_optim")
+
+    def GlobalBA(self, prob: BAProblem, options: TsbaOptions = None):
+        o = options or options_global()
+        return self._one_shot(self.lib.tsba_global_ba, prob, o, "tsba_global_ba")
+
+    def _one_shot(self, fn, prob, o, what):
+        s = prob.struct()
+        rep = TsbaReport()
+        rc = fn(self.ctx, C.byref(s), C.byref(o), C.byref(rep))
+        if rc != 0 and rc != -3:
+            self._check(rc, what)
+        return rep.as_dict()
+
+    # ---- staged interface (problem resident in HBM)
+    def upload(self, prob: BAProblem, options: TsbaOptions):
+        s = prob.struct()
+        self._check(self.lib.tsba_upload(self.ctx, C.byref(s), C.byref(options)), "tsba_upload")
+        self._resident = prob
+
+    def solve(self):
+        rep = TsbaReport()
+        self._check(self.lib.tsba_solve(self.ctx, C.byref(rep)), "tsba_solve")
+        return rep.as_dict()
+
+    def download(self, prob: BAProblem = None):
+        prob = prob or self._resident
+        s = prob.struct()
+        self._check(self.lib.tsba_download(self.ctx, C.byref(s)), "tsba_download")
+        return prob
+
+    # ---- test hooks
+    def evaluate(self, prob: BAProblem, options: TsbaOptions, level: int, jac=True):
+        s = prob.struct()
+        ns, nt = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.tsba_eval(self.ctx, C.byref(s), C.byref(options), level, None, None, None,
+                                       C.byref(ns), C.byref(nt)), "tsba_eval(count)")
+        n_s, n_t = ns.value, nt.value
+        resid = np.zeros(2 * n_s + 8 * n_t)
+        J = np.zeros(26 * n_s + 120 * n_t) if jac else None
+        ms = np.zeros((max(prob.n_tobs, 1), 2))
+        self._check(self.lib.tsba_eval(self.ctx, C.byref(s), C.byref(options), level, _dp(resid),
+                                       _dp(J) if jac else None, _dp(ms), C.byref(ns), C.byref(nt)), "tsba_eval")
+        out = {"resid": resid, "ns": n_s, "nt": n_t, "musigma": ms[:prob.n_tobs]}
+        if jac:
+            out["jac_scene"] = J[:26 * n_s].reshape(n_s, 2, 13)
+            out["jac_text"] = J[26 * n_s:].reshape(n_t, 8, 15)
+        return out
+
+    def reduced_system(self, radius: float):
+        """First linearisation of pass 0 of the uploaded problem: S (6n_kf x 6n_kf, identity rows for fixed poses), g, cost."""
+        n = 6 * self._resident.n_kf
+        S, g, dpv = np.zeros((n, n)), np.zeros(n), np.zeros(n)
+        cost = C.c_double(0)
+        free = np.zeros(self._resident.n_kf, np.int32)
+        self._check(self.lib.tsba_debug_reduced_system(self.ctx, radius, _dp(S), _dp(g), C.byref(cost),
+                                                       free.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dpv)),
+                    "tsba_debug_reduced_system")
+        return {"S": S, "g": g, "cost": cost.value, "free": free, "dp": dpv}
+
+    def time_linearize(self, level: int, n: int = 50):
+        ms, nbytes = C.c_double(0), C.c_double(0)
+        self._check(self.lib.tsba_time_linearize(self.ctx, level, n, C.byref(ms), C.byref(nbytes)), "tsba_time_linearize")
+        return ms.value, nbytes.value
