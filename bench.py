@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""bench.py -- local-BA wall-time and residuals/s on the 20 KF x 5k pts x 100 text-plane window.
+
+One "step" = one complete optimizer::LocalBundleAdjustment (pyramid passes 2,1,0 x <=10 LM iterations, mu/sigma,
+outlier passes) on a synthetic window that is already resident in HBM when the timed region starts.
+residuals/s = scalar residuals evaluated (once per linearisation and once per LM trial step) / wall time.
+
+N > 1: local BA does not shard ("replicas only") -- every rank runs its own window on its own GPU,
+value = sum over ranks (weak scaling), no data-path collective.  `--workload global_ba` runs the sharded global BA.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(prob, opt_ref, budget_s=30.0):
+    """The CPU restatement of the reference path (oracle, Ceres-style central-difference text Jacobians, 1 thread),
+    timed on this host on a bounded sample of the same window."""
+    import oracle
+    from textslam_amd import abi
+    o = abi.TsbaOptions.from_buffer_copy(opt_ref)
+    o.text_jacobian = 1                       # NumericDiffCostFunction<CENTRAL>, nume_BAText.h:97-100
+    o.n_passes = 1
+    o.levels[0] = 2                           # first pass of LocalBundleAdjustment (level 2), optimizer.cc:287
+    o.its[0] = opt_ref.its[0]
+    o.chi2_mono[0], o.chi2_text[0] = opt_ref.chi2_mono[0], opt_ref.chi2_text[0]
+    q = prob.copy()
+    t0 = time.perf_counter()
+    rep = oracle.solve(q, o)
+    dt = time.perf_counter() - t0
+    sample = "pass 1 of 3 (pyramid level 2, <=%d LM its) of the same window, numeric-diff text Jacobians" % o.its[0]
+    if dt < budget_s / 6:                     # cheap enough: time the whole call instead
+        o = abi.TsbaOptions.from_buffer_copy(opt_ref)
+        o.text_jacobian = 1
+        q = prob.copy()
+        t0 = time.perf_counter()
+        rep = oracle.solve(q, o)
+        dt = time.perf_counter() - t0
+        sample = "the full LocalBundleAdjustment call (3 passes) on the same window, numeric-diff text Jacobians"
+    return {"value": rep["n_resid_evals"] / dt, "unit": "residuals/s", "cores": 1, "kind": "port",
+            "sample": sample, "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="local_ba", choices=["local_ba"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from textslam_amd import synth, abi
+    from textslam_amd.optimizer import Optimizer
+
+    prob = synth.config_c4(seed=synth.SEED + rank)        # every replica gets its own window
+    opt = abi.options_local()
+    gpu = Optimizer(local_rank)
+    gpu.upload(prob, opt)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    rep = None
+    for _ in range(args.warmup):
+        rep = gpu.solve()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rep = gpu.solve()                                  # synchronous: returns after the last kernel
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        ev = torch.tensor([float(rep["n_resid_evals"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ev, op=dist.ReduceOp.SUM)
+        evals_all = float(ev.item())
+    else:
+        evals_all = float(rep["n_resid_evals"])
+    ms_per_step = dt / args.steps * 1e3
+    value = evals_all * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # roofline of the linearisation kernel (residual + Jacobian + IRLS weight + J^T J / J^T r sums), level 0
+        lin_ms, algo_bytes = gpu.time_linearize(0, 200)
+        achieved = algo_bytes / (lin_ms * 1e-3) / 1e9
+        out = {
+            "metric": "local_ba_residuals_per_s", "value": value, "unit": "residuals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4 local BA: 20 KF x 5000 pts x 100 text planes (%d (KF,plane) pairs x 64 features), "
+                                   "passes 2,1,0 x <=10 LM its" % prob.n_tobs,
+                       "parallelism": "replicas x%d" % world if world > 1 else "1 GPU",
+                       "residual_blocks_level0": {"scene": rep["n_sblock"][-1], "text": rep["n_tblock"][-1]},
+                       "lm_iterations": rep["iters"], "resid_evals_per_call": rep["n_resid_evals"]},
+            "local_ba_wall_ms": ms_per_step,
+            "roofline": {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms * 1e3},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, opt)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

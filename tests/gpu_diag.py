@@ -34,7 +34,7 @@ def stage_compare(P, o, opt, tag):
     idx = np.concatenate([np.arange(6*k, 6*k+6) for k in free]) if free.size else np.zeros(0, int)
     print(" free poses gpu", free.tolist(), "oracle", np.nonzero(ro['free_idx'] >= 0)[0].tolist())
     if idx.size and idx.size == ro['S'].shape[0]:
-        Sg = rg['S'][np.ix_(idx, idx)]; gg = rg['g'][idx]
+        m = idx.size; Sg = rg['S'][:m, :m]; gg = rg['g'][:m]      # S / g are stored compressed to the free poses
         print("  cost oracle %.10g gpu %.10g" % (ro['cost'], rg['cost']))
         print("  S rel diff", rel(Sg, ro['S']), " g rel diff", rel(gg, ro['g']), " sym err", np.max(np.abs(Sg - Sg.T)))
         dp_ref = -np.linalg.solve(ro['S'], ro['g'])
@@ -55,7 +55,7 @@ def main():
     opt = Optimizer(0)
     o = abi.options_local()
     stage_compare(synth.tiny(), o, opt, "tiny local BA")
-    o1 = abi.options_local(); o1.use_text = 0
+    o1 = abi.options_local(); o1.use_text = 0; o1.n_passes = 1; o1.levels[0] = 0; o1.its[0] = 15
     stage_compare(synth.tiny(seed=11, n_kf=6, n_pt=300, n_text=0), o1, opt, "tiny scene-only")
     stage_compare(synth.config_c3(), abi.options_pose(), opt, "C3 pose-only")
     P4 = synth.config_c4()
@@ -65,6 +65,10 @@ def main():
     for _ in range(5):
         t = time.time(); rep = opt.solve(); ts.append((time.time() - t) * 1e3)
     print("C4 resident solve ms:", [round(x, 3) for x in ts], "report t_solve_ms", rep['t_solve_ms'], "resid evals", rep['n_resid_evals'])
+    import ctypes
+    st = (ctypes.c_longlong * 64)()
+    opt.solve(); opt.lib.tsba_debug_stamps(opt.ctx, st)
+    print("k_solve stamps (cycles): load %d factor %d backsub %d | ldl %d panel %d trailing %d nfree %d" % tuple(st[:7]))
     for l in (0, 1, 2):
         ms, nb = opt.time_linearize(l, 50)
         print(f"linearize level {l}: {ms*1e3:.2f} us, algorithmic bytes {nb:.0f}, {nb/ms/1e6:.1f} GB/s")

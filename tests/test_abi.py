@@ -1,0 +1,101 @@
+"""C-ABI checks that need no GPU: libtsba.so builds for gfx950, loads, exports every symbol include/tsba.h declares,
+its structs have the layout the ctypes mirror assumes, and the product refuses to run without a HIP device."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "tsba.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    so = os.path.join(ROOT, "textslam_amd", "libtsba.so")
+    if not os.path.exists(so):
+        ge.build()
+    return C.CDLL(so)
+
+
+def test_exports_every_declared_symbol(lib):
+    text = open(HDR).read()
+    names = sorted(set(re.findall(r"\b(tsba_[a-z_0-9]+)\s*\(", text)))
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tsba.h but not exported"
+    from textslam_amd import optimizer
+    for n in optimizer.EXPORTED_SYMBOLS:
+        assert n in names
+
+
+def test_struct_layout_matches_ctypes(tmp_path):
+    from textslam_amd import abi
+    src = tmp_path / "sz.c"
+    src.write_text('#include "tsba.h"\n#include <stddef.h>\n'
+                   'unsigned long sz_problem(void){return sizeof(tsba_problem);}\n'
+                   'unsigned long sz_options(void){return sizeof(tsba_options);}\n'
+                   'unsigned long sz_report(void){return sizeof(tsba_report);}\n'
+                   'unsigned long off_img(void){return offsetof(tsba_problem, img);}\n'
+                   'unsigned long off_its(void){return offsetof(tsba_options, its);}\n'
+                   'unsigned long off_shard(void){return offsetof(tsba_options, lm_shard);}\n'
+                   'unsigned long off_evals(void){return offsetof(tsba_report, n_resid_evals);}\n')
+    so = tmp_path / "sz.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-o", str(so), str(src)])
+    L = C.CDLL(str(so))
+    for f in ("sz_problem", "sz_options", "sz_report", "off_img", "off_its", "off_shard", "off_evals"):
+        getattr(L, f).restype = C.c_ulong
+    assert L.sz_problem() == C.sizeof(abi.TsbaProblem)
+    assert L.sz_options() == C.sizeof(abi.TsbaOptions)
+    assert L.sz_report() == C.sizeof(abi.TsbaReport)
+    assert L.off_img() == abi.TsbaProblem.img.offset
+    assert L.off_its() == abi.TsbaOptions.its.offset
+    assert L.off_shard() == abi.TsbaOptions.lm_shard.offset
+    assert L.off_evals() == abi.TsbaReport.n_resid_evals.offset
+
+
+def test_default_options_match_reference_constants(lib):
+    from textslam_amd import abi
+    for fn, py in (("tsba_default_options_local", abi.options_local()),
+                   ("tsba_default_options_pose", abi.options_pose()),
+                   ("tsba_default_options_global", abi.options_global())):
+        o = abi.TsbaOptions()
+        getattr(lib, fn).argtypes = [C.POINTER(abi.TsbaOptions)]
+        getattr(lib, fn).restype = None
+        getattr(lib, fn)(C.byref(o))
+        for name, _ in abi.TsbaOptions._fields_:
+            a, b = getattr(o, name), getattr(py, name)
+            if hasattr(a, "__len__"):
+                n = o.n_passes
+                assert list(a)[:n] == pytest.approx(list(b)[:n]), (fn, name)
+            else:
+                assert a == pytest.approx(b), (fn, name)
+    o = abi.options_local()
+    assert o.huber_scene == pytest.approx(np.sqrt(5.991)) and o.w_t == 5.0 and list(o.levels)[:3] == [2, 1, 0]
+
+
+def test_no_cpu_fallback_without_device(lib):
+    """On a box without a HIP device the product must fail loudly (never route to the oracle / a CPU path)."""
+    ctx = C.c_void_p()
+    lib.tsba_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    rc = lib.tsba_create(C.byref(ctx), 0)
+    if rc == 0:
+        lib.tsba_destroy.argtypes = [C.c_void_p]
+        lib.tsba_destroy(ctx)
+        pytest.skip("a HIP device is present here")
+    assert rc == -2
+    from textslam_amd.optimizer import Optimizer, TsbaError
+    with pytest.raises(TsbaError):
+        Optimizer(0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "textslam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "tsba_oracle" not in txt, f

@@ -1,0 +1,27 @@
+"""Oracle vs the committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py)."""
+import os
+import sys
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(make_golden.CASES))
+def test_oracle_reproduces_golden(oracle_lib, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    P, o = make_golden.make_case(name)
+    assert make_golden.input_digest(P) == str(g["digest"]), "synthetic generator drifted: regenerate fixtures deliberately"
+    ev = oracle_lib.evaluate(P, o, int(g["level"]))
+    np.testing.assert_allclose(ev["resid"], g["resid"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(ev["jac_scene"], g["jac_scene"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ev["jac_text"], g["jac_text"], rtol=1e-11, atol=1e-9)
+    Q = P.copy()
+    rep = oracle_lib.solve(Q, o)
+    assert rep["iters"] == g["iters"].tolist()
+    np.testing.assert_allclose(rep["cost1"], g["cost1"], rtol=1e-10)
+    np.testing.assert_allclose(Q.pose, g["pose"], rtol=0, atol=1e-10)
+    assert np.array_equal(Q.sgood, g["sgood"]) and np.array_equal(Q.tfgood, g["tfgood"]) and np.array_equal(Q.tobs_good, g["tobs_good"])

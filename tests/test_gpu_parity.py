@@ -1,0 +1,198 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances (fp64 on both sides; the GPU contracts FMAs and sums in a different order):
+  residuals            |d| <= 1e-10                      (pixels x weight / normalised intensity x weight)
+  analytic Jacobians   rel 1e-10 of the block scale
+  reduced system S, g  rel 1e-9
+  LM trajectory        same iteration / acceptance counts, final cost rel 1e-9
+  parameters           |d| <= 1e-8 (LM path divergence is amplified by the conditioning of the window)
+  outlier flags        identical
+"""
+import os
+import sys
+import numpy as np
+import pytest
+
+from textslam_amd import synth, abi
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from textslam_amd.optimizer import Optimizer
+    return Optimizer(0)
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def _check_eval(gpu, oracle, P, o, level):
+    eo, eg = oracle.evaluate(P, o, level), gpu.evaluate(P, o, level)
+    assert (eo["ns"], eo["nt"]) == (eg["ns"], eg["nt"])
+    np.testing.assert_allclose(eg["resid"], eo["resid"], rtol=0, atol=1e-10)
+    if P.n_tobs:
+        np.testing.assert_allclose(eg["musigma"], eo["musigma"], rtol=1e-11, atol=1e-10)
+    if eo["ns"]:
+        assert _rel(eg["jac_scene"], eo["jac_scene"]) < 1e-10
+    if eo["nt"]:
+        assert _rel(eg["jac_text"], eo["jac_text"]) < 1e-10
+    return eo
+
+
+def _check_solve(gpu, oracle, P, o, call, atol=1e-8):
+    G, R = P.copy(), P.copy()
+    rep_g = call(G, o)
+    rep_o = oracle.solve(R, o)
+    assert rep_g["iters"] == rep_o["iters"] and rep_g["accepted"] == rep_o["accepted"]
+    assert rep_g["termination"] == rep_o["termination"]
+    np.testing.assert_allclose(rep_g["cost0"], rep_o["cost0"], rtol=1e-11)
+    np.testing.assert_allclose(rep_g["cost1"], rep_o["cost1"], rtol=1e-9)
+    assert rep_g["n_sblock"] == rep_o["n_sblock"] and rep_g["n_tblock"] == rep_o["n_tblock"]
+    np.testing.assert_allclose(G.pose, R.pose, rtol=0, atol=atol)
+    np.testing.assert_allclose(G.rho, R.rho, rtol=0, atol=atol)
+    np.testing.assert_allclose(G.theta, R.theta, rtol=0, atol=atol)
+    assert np.array_equal(G.sgood, R.sgood) and np.array_equal(G.tobs_good, R.tobs_good) and np.array_equal(G.tfgood, R.tfgood)
+    assert rep_g["n_bad_scene"] == rep_o["n_bad_scene"] and rep_g["n_bad_tfeat"] == rep_o["n_bad_tfeat"]
+    return G, rep_g
+
+
+def test_eval_parity_all_levels(gpu, oracle_lib):
+    P = synth.tiny()
+    o = abi.options_local()
+    for l in range(3):
+        _check_eval(gpu, oracle_lib, P, o, l)
+    o.filter_good = 0
+    _check_eval(gpu, oracle_lib, P, o, 0)
+
+
+def test_eval_matches_reference_style_numeric_jacobian(gpu, oracle_lib):
+    """HIP analytic text Jacobian vs the oracle's Ceres CENTRAL numeric differentiation (what the reference computes)."""
+    P = synth.tiny(seed=3)
+    o = abi.options_local()
+    eg = gpu.evaluate(P, o, 0)
+    o.text_jacobian = 1
+    en = oracle_lib.evaluate(P, o, 0)
+    rel = np.abs(eg["jac_text"] - en["jac_text"]) / np.abs(en["jac_text"]).max()
+    assert np.median(rel) < 1e-9 and np.mean(rel < 1e-6) > 0.995
+
+
+def test_reduced_system_parity(gpu, oracle_lib):
+    P = synth.tiny(seed=9, n_kf=6, n_pt=120, n_text=5)
+    o = abi.options_local()
+    ro = oracle_lib.reduced_system(P, o, o.levels[0], o.initial_radius)
+    gpu.upload(P, o)
+    rg = gpu.reduced_system(o.initial_radius)
+    assert np.array_equal(np.nonzero(rg["free"])[0], np.nonzero(ro["free_idx"] >= 0)[0])
+    m = 6 * ro["nf"]
+    assert _rel(rg["S"][:m, :m], ro["S"]) < 1e-9 and _rel(rg["g"][:m], ro["g"]) < 1e-9
+    assert rg["cost"] == pytest.approx(ro["cost"], rel=1e-12)
+    dp = -np.linalg.solve(ro["S"], ro["g"])
+    free = np.nonzero(rg["free"])[0]
+    idx = np.concatenate([np.arange(6*k, 6*k + 6) for k in free])
+    assert _rel(rg["dp"][idx], dp) < 1e-8
+
+
+@pytest.mark.parametrize("seed", [7, 21, 33])
+def test_local_ba_parity(gpu, oracle_lib, seed):
+    P = synth.tiny(seed=seed, n_kf=6, n_pt=150, n_text=5)
+    _check_solve(gpu, oracle_lib, P, abi.options_local(), lambda G, o: gpu.LocalBundleAdjustment(G, options=o))
+
+
+def test_local_ba_notreachwin_gauge(gpu, oracle_lib):
+    P = synth.tiny(seed=5)
+    o = abi.options_local(abi.STATE_NOTREACHWIN)      # only the two initial keyframes are constant
+    G, _ = _check_solve(gpu, oracle_lib, P, o, lambda G, o: gpu.LocalBundleAdjustment(G, options=o))
+    assert np.array_equal(G.pose.reshape(-1, 7)[:2], P.pose.reshape(-1, 7)[:2])
+    assert not np.array_equal(G.pose.reshape(-1, 7)[2], P.pose.reshape(-1, 7)[2])
+
+
+def test_pose_optim_parity_c3(gpu, oracle_lib):
+    P = synth.config_c3()
+    G, rep = _check_solve(gpu, oracle_lib, P, abi.options_pose(), lambda G, o: gpu.PoseOptim(G, options=o))
+    assert np.array_equal(G.rho, P.rho) and np.array_equal(G.theta, P.theta)       # landmarks are frozen
+    assert np.abs(G.pose - P.truth["pose"]).max() < np.abs(P.pose - P.truth["pose"]).max()
+
+
+def test_scene_only_global_style(gpu, oracle_lib):
+    P = synth.config_global(n_kf=12, n_pt=600, band=6)
+    _check_solve(gpu, oracle_lib, P, abi.options_global(), lambda G, o: gpu.GlobalBA(G, options=o))
+
+
+def test_c1_plumbing_parity(gpu, oracle_lib):
+    P = synth.config_c1()
+    _check_solve(gpu, oracle_lib, P, abi.options_local(), lambda G, o: gpu.LocalBundleAdjustment(G, options=o), atol=1e-7)
+
+
+def test_c4_full_size_parity_and_properties(gpu, oracle_lib):
+    """The headline window (20 KF x 5000 pts x 100 planes): parity with the oracle plus size-independent properties."""
+    P = synth.config_c4()
+    o = abi.options_local()
+    G, rep = _check_solve(gpu, oracle_lib, P, o, lambda G, o: gpu.LocalBundleAdjustment(G, options=o), atol=1e-7)
+    assert all(c1 < c0 for c0, c1 in zip(rep["cost0"], rep["cost1"]))             # every pass reduces its cost
+    assert np.all(G.sgood <= P.sgood) and np.all(G.tfgood <= P.tfgood)            # flags only go good -> bad
+    assert np.array_equal(G.pose.reshape(-1, 7)[:3], P.pose.reshape(-1, 7)[:3])   # gauge: first 3 participating KFs
+    assert np.array_equal(G.rho[P.pt_host < 0], P.rho[P.pt_host < 0])             # frozen landmarks untouched
+    assert np.array_equal(G.theta[P.text_host < 0], P.theta[P.text_host < 0])
+    assert np.allclose(np.linalg.norm(G.pose.reshape(-1, 7)[:, :4], axis=1), 1.0, atol=1e-12)
+    # determinism: the resident solve restarts from the uploaded state and is bit-reproducible
+    gpu.upload(P, o)
+    gpu.solve(); A = gpu.download(P.copy())
+    gpu.solve(); B = gpu.download(P.copy())
+    assert np.array_equal(A.pose, B.pose) and np.array_equal(A.rho, B.rho) and np.array_equal(A.theta, B.theta)
+    assert np.array_equal(A.pose, G.pose)
+
+
+@pytest.mark.parametrize("name", ["tiny_local", "tiny_scene", "tiny_pose"])
+def test_against_golden_fixtures(gpu, name):
+    import make_golden
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    P, o = make_golden.make_case(name)
+    assert make_golden.input_digest(P) == str(g["digest"])
+    ev = gpu.evaluate(P, o, int(g["level"]))
+    np.testing.assert_allclose(ev["resid"], g["resid"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(ev["jac_scene"], g["jac_scene"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ev["jac_text"], g["jac_text"], rtol=1e-9, atol=1e-7)
+    G = P.copy()
+    rep = gpu.PoseOptim(G, options=o) if P.n_kf == 1 else gpu.LocalBundleAdjustment(G, options=o)
+    assert rep["iters"] == g["iters"].tolist()
+    np.testing.assert_allclose(rep["cost1"], g["cost1"], rtol=1e-9)
+    np.testing.assert_allclose(G.pose, g["pose"], rtol=0, atol=1e-8)
+    assert np.array_equal(G.sgood, g["sgood"]) and np.array_equal(G.tfgood, g["tfgood"]) and np.array_equal(G.tobs_good, g["tobs_good"])
+
+
+def test_edge_cases(gpu, oracle_lib):
+    # every observation flagged bad: nothing to optimise, zero iterations, parameters untouched
+    P = synth.tiny(seed=4)
+    P.sgood[:] = 0; P.tobs_good[:] = 0
+    G = P.copy(); rep = gpu.LocalBundleAdjustment(G)
+    assert rep["iters"] == [0, 0, 0] and np.array_equal(G.pose, P.pose) and np.array_equal(G.rho, P.rho)
+    # no text at all / text disabled (bFlag_noText)
+    P = synth.tiny(seed=6)
+    o = abi.options_local(); o.use_text = 0
+    _check_solve(gpu, oracle_lib, P, o, lambda G, o: gpu.LocalBundleAdjustment(G, options=o))
+    # outlier pass disabled (bFlag_rapid)
+    o = abi.options_local(); o.outlier_scene = o.outlier_text = 0
+    G, rep = _check_solve(gpu, oracle_lib, P, o, lambda G, o: gpu.LocalBundleAdjustment(G, options=o))
+    assert np.array_equal(G.sgood, P.sgood)
+    # a text box that projects outside the image: sigma = 0 -> its residuals vanish (nume_BAText.h:85-90)
+    P = synth.tiny(seed=8)
+    P.text_box_ray[0] += 5.0
+    _check_solve(gpu, oracle_lib, P, abi.options_local(), lambda G, o: gpu.LocalBundleAdjustment(G, options=o))
+
+
+def test_error_codes(gpu):
+    from textslam_amd.optimizer import TsbaError
+    P = synth.tiny()
+    o = abi.options_local(); o.text_jacobian = 1
+    with pytest.raises(TsbaError):
+        gpu.upload(P, o)
+    o = abi.options_local(); o.levels[0] = 3
+    with pytest.raises(TsbaError):
+        gpu.upload(P, o)
+    with pytest.raises(TsbaError):
+        gpu.PoseOptim(P)                     # n_kf != 1

@@ -1,0 +1,253 @@
+"""CPU tests of the oracle (the checker): self-consistency of the restated residual models, Ceres-LM behaviour and the
+cv::fillPoly / CalTextinfo restatement.  The reference has no tests or golden vectors, so these pin the
+oracle against independent formulations written here (finite differences, dense numpy solves, brute-force rasterisation)
+and against the committed golden fixtures."""
+import numpy as np
+import pytest
+
+from textslam_amd import synth, abi
+
+
+def _fd_jacobian(oracle, P, o, level, eps=1e-6):
+    """Central differences of the oracle's LITERAL functors w.r.t. the Ceres tangent space (Plus with half-angle)."""
+    base = oracle.evaluate(P, o, level, jac=True)
+    ns, nt = base["ns"], base["nt"]
+
+    def resid(Q):
+        return oracle.evaluate(Q, o, level, jac=False)["resid"]
+
+    def quat_plus(q, d):
+        n = np.linalg.norm(d)
+        z = np.array([1.0, 0, 0, 0]) if n == 0 else np.concatenate([[np.cos(n)], np.sin(n) / n * d])
+        return np.array([z[0]*q[0] - z[1]*q[1] - z[2]*q[2] - z[3]*q[3],
+                         z[0]*q[1] + z[1]*q[0] + z[2]*q[3] - z[3]*q[2],
+                         z[0]*q[2] - z[1]*q[3] + z[2]*q[0] + z[3]*q[1],
+                         z[0]*q[3] + z[1]*q[2] - z[2]*q[1] + z[3]*q[0]])
+
+    cols = {}
+    for k in range(P.n_kf):
+        for a in range(6):
+            out = []
+            for sgn in (+1, -1):
+                Q = P.copy()
+                pose = Q.pose.reshape(-1, 7)
+                if a < 3:
+                    d = np.zeros(3); d[a] = sgn * eps
+                    pose[k, :4] = quat_plus(pose[k, :4], d)
+                else:
+                    pose[k, 4 + a - 3] += sgn * eps
+                out.append(resid(Q))
+            cols[("pose", k, a)] = (out[0] - out[1]) / (2 * eps)
+    return base, cols
+
+
+def test_scene_jacobian_matches_finite_differences(oracle_lib):
+    P = synth.tiny(seed=5, n_kf=4, n_pt=40, n_text=0, n_levels=1)
+    o = abi.options_local(); o.use_text = 0; o.filter_good = 0; o.n_passes = 1; o.levels[0] = 0
+    base, cols = _fd_jacobian(oracle_lib, P, o, 0)
+    ns = base["ns"]
+    assert ns > 20
+    J = base["jac_scene"]
+    # map block -> (kf, host)
+    kfs, hosts = [], []
+    for s in range(P.sobs_kf[0].size):
+        kf, pt = P.sobs_kf[0][s], P.sobs_pt[0][s]
+        if P.pt_host[pt] == kf:
+            continue
+        kfs.append(kf); hosts.append(P.pt_host[pt])
+    worst = 0.0
+    for b in range(ns):
+        for a in range(6):
+            fd_t = cols[("pose", kfs[b], a)][2*b:2*b+2]
+            worst = max(worst, np.max(np.abs(fd_t - J[b, :, a])) / (1 + np.max(np.abs(J[b, :, a]))))
+            if hosts[b] >= 0:
+                fd_h = cols[("pose", hosts[b], a)][2*b:2*b+2]
+                worst = max(worst, np.max(np.abs(fd_h - J[b, :, 6 + a])) / (1 + np.max(np.abs(J[b, :, 6 + a]))))
+    assert worst < 2e-7, worst
+    # inverse depth column
+    eps = 1e-7
+    for j in range(P.n_pt):
+        if P.pt_host[j] < 0:
+            continue
+        Qp, Qm = P.copy(), P.copy()
+        Qp.rho[j] += eps; Qm.rho[j] -= eps
+        fd = (oracle_lib.evaluate(Qp, o, 0, jac=False)["resid"] - oracle_lib.evaluate(Qm, o, 0, jac=False)["resid"]) / (2 * eps)
+        for b in np.nonzero(fd[:2*ns].reshape(-1, 2).any(1))[0]:
+            assert np.allclose(fd[2*b:2*b+2], J[b, :, 12], rtol=1e-5, atol=1e-5)
+
+
+def test_text_analytic_vs_ceres_numeric_diff(oracle_lib):
+    """Analytic bilinear Jacobian (the HIP path's choice) vs the reference's NumericDiffCostFunction<CENTRAL>."""
+    P = synth.tiny()
+    o = abi.options_local()
+    oa = oracle_lib.evaluate(P, o, 0)
+    o.text_jacobian = 1
+    on = oracle_lib.evaluate(P, o, 0)
+    Ja, Jn = oa["jac_text"], on["jac_text"]
+    assert Ja.shape[0] > 50
+    scale = np.abs(Ja).max()
+    # away from pixel-edge crossings the two agree to ~1e-6 relative; edge-straddling stencils are rare
+    rel = np.abs(Ja - Jn) / scale
+    assert np.median(rel) < 1e-9
+    assert np.mean(rel < 1e-6) > 0.995
+
+
+def test_lm_converges_to_truth_noise_free(oracle_lib):
+    P = synth.make_problem(8, 400, 0, seed=3, noise_px=0.0, outlier_frac=0.0, frozen_frac=0.1, n_levels=1)
+    o = abi.options_local(); o.use_text = 0; o.n_passes = 1; o.levels[0] = 0; o.its[0] = 50
+    Q = P.copy()
+    rep = oracle_lib.solve(Q, o)
+    assert rep["cost1"][0] < 1e-12 * max(1.0, rep["cost0"][0])
+    assert np.abs(Q.pose - P.truth["pose"]).max() < 1e-8
+    used = np.zeros(P.n_pt, bool)
+    act = (P.sgood[P.sobs_flag[0]] == 1) & (P.pt_host[P.sobs_pt[0]] != P.sobs_kf[0])
+    used[P.sobs_pt[0][act]] = True
+    m = (P.pt_host >= 0) & used
+    assert np.abs(Q.rho[m] / P.truth["rho"][m] - 1).max() < 1e-6
+
+
+def test_reduced_system_matches_dense_normal_equations(oracle_lib):
+    """Schur complement of the oracle vs an independent dense numpy assembly of J^T J from the oracle's Jacobians."""
+    P = synth.tiny(seed=9, n_kf=5, n_pt=50, n_text=3)
+    o = abi.options_local(); o.n_passes = 1; o.levels[0] = 0
+    rs = oracle_lib.reduced_system(P, o, 0, 1e4)
+    ev = oracle_lib.evaluate(P, o, 0)
+    free = rs["free_idx"]
+    nf = rs["nf"]
+    # parameter layout: free poses (6 each), then rho of used points, then theta of used planes
+    blocks = []
+    for s in range(P.sobs_kf[0].size):
+        kf, pt = int(P.sobs_kf[0][s]), int(P.sobs_pt[0][s])
+        if not P.sgood[P.sobs_flag[0][s]] or P.pt_host[pt] == kf:
+            continue
+        blocks.append(("s", kf, int(P.pt_host[pt]), pt))
+    for t in range(P.n_tobs):
+        kf, j = int(P.tobs_kf[t]), int(P.tobs_text[t])
+        if not P.tobs_good[t] or P.text_host[j] == kf:
+            continue
+        for f in range(P.tfeat_off[0][j], P.tfeat_off[0][j+1]):
+            if P.tfgood[P.tobs_fgood_off[t] + P.tfeat_raw[0][f]]:
+                blocks.append(("t", kf, int(P.text_host[j]), j))
+    ns, nt = ev["ns"], ev["nt"]
+    assert len(blocks) == ns + nt
+    pts = sorted({b[3] for b in blocks if b[0] == "s" and b[2] >= 0})
+    txs = sorted({b[3] for b in blocks if b[0] == "t" and b[2] >= 0})
+    off_pt = {j: 6*nf + i for i, j in enumerate(pts)}
+    off_tx = {j: 6*nf + len(pts) + 3*i for i, j in enumerate(txs)}
+    n = 6*nf + len(pts) + 3*len(txs)
+    H = np.zeros((n, n)); g = np.zeros(n)
+    const = {k for k in range(P.n_kf) if free[k] < 0}
+    for bi, b in enumerate(blocks):
+        if b[0] == "s":
+            r = ev["resid"][2*bi:2*bi+2]; J = ev["jac_scene"][bi]; delta = o.huber_scene; nl = 1
+        else:
+            k = bi - ns
+            r = ev["resid"][2*ns + 8*k: 2*ns + 8*k + 8]; J = ev["jac_text"][k]; delta = o.huber_text; nl = 3
+        if b[2] < 0 and b[1] in const:
+            continue                                    # all parameter blocks constant
+        s2 = r @ r
+        w = np.sqrt(delta / np.sqrt(s2)) if s2 > delta**2 else 1.0
+        r = r * w; J = J * w
+        cols = []
+        if free[b[1]] >= 0:
+            cols += [(6*free[b[1]] + a, a) for a in range(6)]
+        if b[2] >= 0 and free[b[2]] >= 0:
+            cols += [(6*free[b[2]] + a, 6 + a) for a in range(6)]
+        if b[2] >= 0:
+            base = off_pt[b[3]] if b[0] == "s" else off_tx[b[3]]
+            cols += [(base + a, 12 + a) for a in range(nl)]
+        idx = np.array([c[0] for c in cols]); jc = np.array([c[1] for c in cols])
+        Jc = J[:, jc]
+        H[np.ix_(idx, idx)] += Jc.T @ Jc
+        g[idx] += Jc.T @ r
+    # Ceres LM damping in Jacobi-scaled coordinates, mapped back: Lambda_k = clamp(s^2 H_kk) / (radius s^2)
+    d = np.diag(H).copy()
+    sc = 1.0 / (1.0 + np.sqrt(d))
+    lam = np.clip(sc**2 * d, o.min_diagonal, o.max_diagonal) / (1e4 * sc**2)
+    Hd = H + np.diag(lam)
+    npz = 6*nf
+    S = Hd[:npz, :npz] - Hd[:npz, npz:] @ np.linalg.solve(Hd[npz:, npz:], Hd[npz:, :npz])
+    gr = g[:npz] - Hd[:npz, npz:] @ np.linalg.solve(Hd[npz:, npz:], g[npz:])
+    assert np.allclose(rs["S"], S, rtol=1e-9, atol=1e-9 * np.abs(S).max())
+    assert np.allclose(rs["g"], gr, rtol=1e-9, atol=1e-9 * np.abs(gr).max())
+
+
+def test_fillpoly_against_bruteforce(oracle_lib):
+    """Convex quads: the restated fillPoly mask must contain every pixel strictly inside and no pixel farther than
+    one pixel from the polygon (boundary pixels follow Bresenham / fixed-point rules)."""
+    rng = np.random.default_rng(0)
+    w, h = 64, 48
+    for _ in range(50):
+        c = np.array([rng.uniform(15, w - 15), rng.uniform(12, h - 12)])
+        ang = np.sort(rng.uniform(0, 2*np.pi, 4))
+        rad = rng.uniform(5, 11)                      # points on a circle: always a convex quad
+        if np.min(np.diff(np.concatenate([ang, [ang[0] + 2*np.pi]]))) < 0.5:
+            continue
+        pts = np.stack([c[0] + rad*np.cos(ang), c[1] + rad*np.sin(ang)], 1).astype(int)
+        m = oracle_lib.fillpoly4(w, h, pts)
+        ys, xs = np.mgrid[0:h, 0:w]
+        inside = np.ones((h, w), bool); dist_out = np.zeros((h, w))
+        sign = None
+        for i in range(4):
+            a, b = pts[i], pts[(i + 1) % 4]
+            e = b - a
+            if not e.any():
+                continue
+            cr = (e[0]*(ys - a[1]) - e[1]*(xs - a[0])) / np.hypot(*e)
+            if sign is None:
+                cen = pts.mean(0)
+                sign = 1.0 if (e[0]*(cen[1] - a[1]) - e[1]*(cen[0] - a[0])) >= 0 else -1.0
+            inside &= cr*sign > 0.75
+            dist_out = np.maximum(dist_out, -cr*sign)
+        assert np.all(m[inside] == 1)
+        assert np.all(dist_out[m == 1] <= 1.0 + 1e-9)
+        for x, y in pts:
+            assert m[y, x] == 1
+
+
+def test_musigma_matches_numpy_on_mask(oracle_lib):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (48, 64)).astype(np.uint8)
+    corners = np.array([[10.3, 8.7], [50.9, 10.2], [48.1, 35.5], [12.6, 30.0]])
+    ok, mu, sg = oracle_lib.musigma(img, corners)
+    m = oracle_lib.fillpoly4(64, 48, corners.astype(int)).astype(bool)
+    x0, x1 = int(np.floor(corners[:, 0].min())), int(np.ceil(corners[:, 0].max()))
+    y0, y1 = int(np.floor(corners[:, 1].min())), int(np.ceil(corners[:, 1].max()))
+    box = np.zeros_like(m); box[y0:y1+1, x0:x1+1] = True
+    vals = img[m & box].astype(float)
+    assert ok == 1
+    assert mu == pytest.approx(vals.mean(), rel=1e-14)
+    assert sg == pytest.approx(vals.std(ddof=1), rel=1e-13)
+    # degenerate: quad outside the image -> invalid, sigma = 0
+    ok, mu, sg = oracle_lib.musigma(img, corners + 500)
+    assert ok == 0 and sg == 0
+
+
+def test_outlier_flags_and_gauge(oracle_lib):
+    P = synth.tiny(seed=21, n_kf=6, n_pt=200, n_text=4)
+    o = abi.options_local()
+    Q = P.copy()
+    rep = oracle_lib.solve(Q, o)
+    # the first three participating keyframes are constant (STATE == LOCAL, optimizer.cc:1571-1588)
+    assert np.array_equal(Q.pose.reshape(-1, 7)[:3], P.pose.reshape(-1, 7)[:3])
+    assert not np.array_equal(Q.pose.reshape(-1, 7)[3:], P.pose.reshape(-1, 7)[3:])
+    # flags only ever go from good to bad, and gross outliers are caught
+    assert np.all(Q.sgood <= P.sgood)
+    assert sum(rep["n_bad_scene"]) > 0
+    # frozen landmarks are untouched
+    assert np.array_equal(Q.rho[P.pt_host < 0], P.rho[P.pt_host < 0])
+    assert np.array_equal(Q.theta[P.text_host < 0], P.theta[P.text_host < 0])
+
+
+def test_empty_and_ragged_inputs(oracle_lib):
+    # no text at all, one keyframe, no observations at some levels
+    P = synth.make_problem(1, 50, 0, seed=2, frozen_frac=1.0, n_levels=1)
+    o = abi.options_pose(); o.use_text = 0; o.n_passes = 1; o.levels[0] = 0
+    Q = P.copy(); rep = oracle_lib.solve(Q, o)
+    assert rep["n_tblock"] == [0] and rep["n_sblock"][0] > 0
+    # a window whose flags are all bad: nothing to optimise, parameters unchanged
+    P2 = synth.tiny(seed=4)
+    P2.sgood[:] = 0; P2.tobs_good[:] = 0
+    Q2 = P2.copy(); rep2 = oracle_lib.solve(Q2, abi.options_local())
+    assert rep2["iters"] == [0, 0, 0]
+    assert np.array_equal(Q2.pose, P2.pose)

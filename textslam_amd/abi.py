@@ -119,7 +119,7 @@ def options_global():
     o.w_sx = o.w_sy = o.w_t = 1.0
     o.huber_scene, o.huber_text = math.sqrt(5.991), 3.0
     o.n_passes = 1
-    o.levels[0], o.its[0], o.chi2_mono[0] = 0, 20, 18.0
+    o.levels[0], o.its[0], o.chi2_mono[0], o.chi2_text[0] = 0, 20, 18.0, 0.5
     o.text_bad_ratio = 0.99
     o.state = STATE_GLOBAL
     o.use_text, o.filter_good = 0, 0

@@ -61,6 +61,10 @@ struct Work {                // device work buffers (sized for the largest level
     uint8_t *sgood, *tobs_good, *tfgood;
     double *musig;                      // [n_tobs][2]
     int *kf_in, *kf_const, *act_pt, *act_tx;
+    int *fidx, *nfree;                  // compressed index of the free poses in S / g
+    double *lmpart;                     // [nblocks_mid][2] per-block (gradient max, |x|^2) of the landmarks
+    long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
+    double *LDbuf;                      // factored diagonal blocks when k_solve cannot use LDS
     // linearisation outputs
     double *pairM, *pairCost, *pairR, *pairOut, *tgM, *tgCost, *pairCost2, *tgCost2;
     double *w_pt, *vb_pt, *V_pt, *b_pt, *sig_pt, *dg_pt;
@@ -112,7 +116,10 @@ __global__ void k_pass_reset(Work W, double radius0, int max_it) {
 }
 
 // which candidates are active (good flags), which keyframes participate (FLAG_KFIN, optimizer.cc:1410-1411,1428,1514-1515)
-__global__ void k_participation(Work W, LevelDev L) {
+__global__ __launch_bounds__(256) void k_participation(Work W, LevelDev L) {
+    __shared__ int cnt_s, cnt_t;
+    if (threadIdx.x == 0) { cnt_s = 0; cnt_t = 0; }
+    __syncthreads();
     int t = blockIdx.x*blockDim.x + threadIdx.x;
     if (t < L.n_sc) {
         bool act = !W.filter_good || W.sgood[L.sc_flag[t]];
@@ -120,21 +127,24 @@ __global__ void k_participation(Work W, LevelDev L) {
             int pt = L.sc_pt[t], h = W.pt_host[pt];
             W.kf_in[L.sc_kf[t]] = 1;
             if (h >= 0) { W.kf_in[h] = 1; W.act_pt[pt] = 1; }
-            atomicAdd(&W.st->ns_active, 1);
+            atomicAdd(&cnt_s, 1);
         }
     } else if (t < L.n_sc + L.n_tg) {
         int g = t - L.n_sc, tb = L.tg_tobs[g], j = L.tg_text[g];
-        if (W.filter_good && !W.tobs_good[tb]) return;
-        int cnt = 0;
-        for (int f = L.tfeat_off[j]; f < L.tfeat_off[j+1]; f++)
-            if (!W.filter_good || W.tfgood[W.tobs_fgood_off[tb] + L.tfeat_raw[f]]) cnt++;
-        if (cnt > 0) {
-            int h = W.text_host[j];
-            W.kf_in[L.tg_kf[g]] = 1;
-            if (h >= 0) { W.kf_in[h] = 1; W.act_tx[j] = 1; }
-            atomicAdd(&W.st->nt_active, cnt);
+        if (!W.filter_good || W.tobs_good[tb]) {
+            int cnt = 0;
+            for (int f = L.tfeat_off[j]; f < L.tfeat_off[j+1]; f++)
+                if (!W.filter_good || W.tfgood[W.tobs_fgood_off[tb] + L.tfeat_raw[f]]) cnt++;
+            if (cnt > 0) {
+                int h = W.text_host[j];
+                W.kf_in[L.tg_kf[g]] = 1;
+                if (h >= 0) { W.kf_in[h] = 1; W.act_tx[j] = 1; }
+                atomicAdd(&cnt_t, cnt);
+            }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) { if (cnt_s) atomicAdd(&W.st->ns_active, cnt_s); if (cnt_t) atomicAdd(&W.st->nt_active, cnt_t); }
 }
 // gauge fixing, optimizer.cc:1562-1588 / :1825-1830
 __global__ void k_gauge(Work W, const uint8_t *kf_initial, int state) {
@@ -145,6 +155,9 @@ __global__ void k_gauge(Work W, const uint8_t *kf_initial, int state) {
         int fixed = 0;
         for (int k = 0; k < W.n_kf && fixed < 3; k++) if (W.kf_in[k]) { W.kf_const[k] = 1; fixed++; }
     }
+    int nf = 0;
+    for (int k = 0; k < W.n_kf; k++) W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? nf++ : -1;
+    *W.nfree = nf;
 }
 
 // ---- mu / sigma of a projected text box: tool::GetProjText x4 + tool::CalTextinfo (src/tool.cc:1178-1262,1655-1728)
@@ -347,7 +360,10 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L) {
             double tot = wave_sum_to_lane<28>(acc, lds, lane);
             if (lane < 27) W.pairM[(size_t)lane*L.n_pair + b] = tot;
             else if (lane == 27) W.pairCost[b] = tot;
-            if (h >= 0 && lane < 9) W.pairR[(size_t)lane*L.n_pair + b] = T.Rcr[lane];
+            if (h >= 0 && lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) W.pairR[(size_t)k*L.n_pair + b] = T.Rcr[k];
+            }
         }
     } else {
         // ---------------- photometric blocks of one (KF, text) observation
@@ -424,10 +440,15 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx) {
     const LmState *st = W.st;
     if (st->done || !st->need_lin) return;
+    __shared__ double red[256];
+    const double *rho_x = W.rho[st->cur], *theta_x = W.theta[st->cur];
+    double gm = 0.0, xn = 0.0;
     int b = blockIdx.x;
     if (b < nb_pt) {
-        int j = b*256 + threadIdx.x; if (j >= W.n_pt) return;
-        int o = L.pls_off[j], e = L.pls_off[j+1]; if (e <= o) return;
+        int j = b*256 + threadIdx.x;
+        int o = 0, e = 0;
+        if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; }
+        if (e > o) {
         double V = 0, bb = 0, wh[6] = {0,0,0,0,0,0};
         for (int s = o; s < e - 1; s++) {
             V += W.vb_pt[s]; bb += W.vb_pt[(size_t)L.n_pslot + s];
@@ -446,9 +467,13 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
         if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
         double sg = W.sig_pt[j];
         W.dg_pt[j] = clampd(sg*sg*V, W.min_diag, W.max_diag);
+        if (W.act_pt[j]) { gm = fabs(bb); xn = rho_x[j]*rho_x[j]; }
+        }
     } else if (b < nb_pt + nb_tx) {
-        int j = (b - nb_pt)*256 + threadIdx.x; if (j >= W.n_text) return;
-        int o = L.tls_off[j], e = L.tls_off[j+1]; if (e <= o) return;
+        int j = (b - nb_pt)*256 + threadIdx.x;
+        int o = 0, e = 0;
+        if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; }
+        if (e > o) {
         double V[6] = {0,0,0,0,0,0}, bb[3] = {0,0,0}, wh[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) wh[k] = 0;
@@ -485,8 +510,11 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             double sg = W.sig_tx[(size_t)k*W.n_text + j];
             W.dg_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag);
         }
+        if (W.act_tx[j]) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(bb[k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
+        }
     } else {
-        int p = (b - nb_pt - nb_tx)*256 + threadIdx.x; if (p >= L.n_pair) return;
+        int p = (b - nb_pt - nb_tx)*256 + threadIdx.x;
+        if (p < L.n_pair) {
         double M[21], c[6];
 #pragma unroll
         for (int k = 0; k < 21; k++) M[k] = W.pairM[(size_t)k*L.n_pair + p];
@@ -536,17 +564,20 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             out[(size_t)84*L.n_pair + p] = a[0]; out[(size_t)85*L.n_pair + p] = a[1]; out[(size_t)86*L.n_pair + p] = a[2];
             out[(size_t)87*L.n_pair + p] = d[0]; out[(size_t)88*L.n_pair + p] = d[1]; out[(size_t)89*L.n_pair + p] = d[2];
         }
+        }
     }
+    gm = block_max<256>(gm, red); xn = block_sum<256>(xn, red);
+    if (threadIdx.x == 0) { W.lmpart[2*b] = gm; W.lmpart[2*b + 1] = xn; }
 }
 
 // ---- after a linearisation: pose diagonal / gradient, Jacobi scaling, cost, gradient tolerance.  One 256-thread block.
-__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol) {
+__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm) {
     LmState *st = W.st;
     if (st->done || !st->need_lin) return;
     __shared__ double red[256];
     const int tid = threadIdx.x;
     double gmax = 0.0, xn = 0.0, cost = 0.0;
-    const double *pose = W.pose[st->cur], *rho = W.rho[st->cur], *theta = W.theta[st->cur];
+    const double *pose = W.pose[st->cur];
     const double *out = W.pairOut;
     for (int a = tid; a < W.n_kf; a += 256) {
         double Hd[6] = {0,0,0,0,0,0}, bp[6] = {0,0,0,0,0,0};
@@ -567,9 +598,7 @@ __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad
         }
         if (fre) for (int k = 0; k < 7; k++) xn += pose[7*a + k]*pose[7*a + k];
     }
-    for (int j = tid; j < W.n_pt; j += 256) if (W.act_pt[j]) { gmax = fmax(gmax, fabs(W.b_pt[j])); xn += rho[j]*rho[j]; }
-    for (int j = tid; j < W.n_text; j += 256) if (W.act_tx[j])
-        for (int k = 0; k < 3; k++) { gmax = fmax(gmax, fabs(W.b_tx[(size_t)k*W.n_text + j])); xn += theta[3*j + k]*theta[3*j + k]; }
+    for (int k = tid; k < nb_lm; k += 256) { gmax = fmax(gmax, W.lmpart[2*k]); xn += W.lmpart[2*k + 1]; }
     for (int p = tid; p < L.n_pair; p += 256) cost += W.pairCost[p];
     for (int g = tid; g < L.n_tg; g += 256) cost += W.tgCost[g];
     gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red); cost = block_sum<256>(cost, red);
@@ -591,12 +620,8 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
     const int N = W.N;
     if (b < L.n_sb) {
         const int a = L.sb_a[b], c = L.sb_b[b];
-        const bool fa = W.kf_in[a] && !W.kf_const[a], fc = W.kf_in[c] && !W.kf_const[c];
-        if (!fa || !fc) {
-            if (lane < 36) { int r = lane/6, cc = lane % 6; double v = (a == c && r == cc) ? 1.0 : 0.0;
-                W.S[(size_t)(6*a + r)*N + 6*c + cc] = v; if (a != c) W.S[(size_t)(6*c + cc)*N + 6*a + r] = v; }
-            return;
-        }
+        const int ia = W.fidx[a], ic = W.fidx[c];           // rows / columns of S exist for free poses only
+        if (ia < 0 || ic < 0) return;
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
@@ -646,16 +671,13 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
                 if (pab >= 0) v -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
                 if (pba >= 0) v -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
             }
-            W.S[(size_t)(6*a + r)*N + 6*c + cc] = v;
-            if (a != c) W.S[(size_t)(6*c + cc)*N + 6*a + r] = v;
+            W.S[(size_t)(6*ia + r)*N + 6*ic + cc] = v;
+            if (a != c) W.S[(size_t)(6*ic + cc)*N + 6*ia + r] = v;
         }
     } else {
         const int a = b - L.n_sb;
-        const bool fa = W.kf_in[a] && !W.kf_const[a];
-        if (!fa) {      // constant / absent pose: identity row so that the dense factorisation leaves dp = 0
-            if (lane < 6) { W.g[6*a + lane] = 0.0; W.S[(size_t)(6*a + lane)*N + 6*a + lane] = 1.0; }
-            return;
-        }
+        const int ia = W.fidx[a];
+        if (ia < 0) return;
         double acc[6] = {0,0,0,0,0,0};
         for (int q = L.pose_ps_off[a] + lane; q < L.pose_ps_off[a+1]; q += 64) {
             int s = L.pose_ps[q], j = L.pslot_lm[s];
@@ -684,115 +706,165 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
             double v = acc[0];
 #pragma unroll
             for (int k = 1; k < 6; k++) if (lane == k) v = acc[k];
-            W.g[6*a + lane] = W.bp[6*a + lane] - v;
+            W.g[6*ia + lane] = W.bp[6*a + lane] - v;
         }
     }
 }
 
-// ---- dense solve of S dp = -g: blocked (6x6) Cholesky in LDS, one workgroup.  A = [S; g^T] stored (N+1) x ld.
-#define SOLVE_THREADS 512
+// ---- dense solve of S dp = -g for the free poses: blocked (6x6) LDL^T in LDS, one workgroup of 16 waves.
+// A = [S; g^T] is held as (n+1) rows; the right-hand side rides along as an extra panel row, so the forward
+// substitution is part of the factorisation.  Per 6x6 block column: every thread factors the diagonal block redundantly
+// in registers (no division chain: one reciprocal per pivot), one thread per row solves the panel, then 6 threads per
+// 6x6 block apply the rank-6 trailing update.
+#define SOLVE_THREADS 1024
+__device__ __forceinline__ void ldl6(const double *A, int ld, double l[15], double d[6], double id[6], bool &bad) {
+    // lower 6x6 at A (row stride ld) -> unit-lower l (packed rows: (1,0) (2,0) (2,1) (3,0) ...), d, 1/d
+    double a[21];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) a[r*(r+1)/2 + c] = A[(size_t)r*ld + c];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double dc = a[c*(c+1)/2 + c];
+#pragma unroll
+        for (int k = 0; k < c; k++) dc -= l[c*(c-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
+        if (!(dc > 0.0)) { bad = true; dc = 1.0; }
+        d[c] = dc; id[c] = 1.0/dc;
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) {
+            double v = a[r*(r+1)/2 + c];
+#pragma unroll
+            for (int k = 0; k < c; k++) v -= l[r*(r-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
+            l[r*(r-1)/2 + c] = v*id[c];
+        }
+    }
+}
+typedef double v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W, int use_lds) {
     LmState *st = W.st;
     if (st->done) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int N = W.N, tid = threadIdx.x, nb = N/6;
-    const int ld = use_lds ? (N | 1) : N;
-    double *A = use_lds ? smem : W.S;          // global fallback factors S in place; rhs row kept in W.dp
-    double *rhs = use_lds ? (smem + (size_t)N*ld) : W.dp;
-    if (use_lds) for (int k = tid; k < N*N; k += SOLVE_THREADS) A[(size_t)(k / N)*ld + (k % N)] = W.S[k];
-    for (int k = tid; k < N; k += SOLVE_THREADS) rhs[k] = W.g[k];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long T0 = clock64(), Tl = 0, Tt = 0, Tx;
+    const int nfree = *W.nfree, n = 6*nfree, Nmax = W.N;
+    const int ld = use_lds ? (n | 1) : Nmax;
+    // A holds rows 0..n (row n = right-hand side g); LD = factored diagonal blocks: per block 15 l + 6 d + 6 1/d (27, padded 32)
+    double *A = use_lds ? smem : W.S;
+    double *LD = use_lds ? (smem + (size_t)(n + 1)*ld) : W.LDbuf;
+    if (use_lds) {
+        for (int r = tid >> 5; r < n; r += SOLVE_THREADS/32)                      // 32 lanes per row: coalesced row reads
+            for (int cidx = tid & 31; cidx <= r; cidx += 32) A[(size_t)r*ld + cidx] = W.S[(size_t)r*Nmax + cidx];
+        for (int k = tid; k < n; k += SOLVE_THREADS) A[(size_t)n*ld + k] = W.g[k];
+    } else {
+        for (int k = tid; k < n; k += SOLVE_THREADS) A[(size_t)n*ld + k] = W.g[k];   // needs (Nmax+1) rows in W.S
+    }
     __shared__ int fail;
     if (tid == 0) fail = st->step_fail;
     __syncthreads();
-    for (int jb = 0; jb < nb && !fail; jb++) {
-        const int j0 = 6*jb;
-        // every thread factors the 6x6 diagonal block redundantly in registers
-        double Ld[21];
-        bool bad = false;
+    long long T1 = clock64();
+    for (int jb = 0; jb < nfree; jb++) {
+        if (fail) break;
+        const int j0 = 6*jb, R0 = j0 + 6;
+        Tx = clock64();
+        if (wave < 2) {             // two waves (different SIMDs) factor the diagonal block redundantly and solve the panel
+            double l[15], d[6], id[6]; bool bad = false;
+            ldl6(A + (size_t)j0*ld + j0, ld, l, d, id, bad);
+            if (tid == 0) {
+                if (bad) { fail = 1; st->step_fail = 1; }
+                double *o = LD + 32*jb;
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+                for (int k = 0; k < 15; k++) o[k] = l[k];
 #pragma unroll
-            for (int c = 0; c <= r; c++) Ld[r*(r+1)/2 + c] = A[(size_t)(j0 + r)*ld + j0 + c];
+                for (int k = 0; k < 6; k++) { o[15 + k] = d[k]; o[21 + k] = id[k]; }
+            }
+            for (int i = R0 + tid; i <= n; i += 128) {      // panel rows incl. the rhs row: x L^T = a, l_row = x D^-1
+                double *row = A + (size_t)i*ld + j0;
+                double x[6];
 #pragma unroll
-        for (int c = 0; c < 6; c++) {
-            double d = Ld[c*(c+1)/2 + c];
+                for (int c = 0; c < 6; c++) {
+                    double v = row[c];
 #pragma unroll
-            for (int k = 0; k < c; k++) d -= Ld[c*(c+1)/2 + k]*Ld[c*(c+1)/2 + k];
-            if (!(d > 0.0)) { bad = true; d = 1.0; }
-            d = sqrt(d); Ld[c*(c+1)/2 + c] = d;
+                    for (int k = 0; k < c; k++) v -= x[k]*l[c*(c-1)/2 + k];
+                    x[c] = v;
+                }
 #pragma unroll
-            for (int r = c + 1; r < 6; r++) {
-                double s = Ld[r*(r+1)/2 + c];
-#pragma unroll
-                for (int k = 0; k < c; k++) s -= Ld[r*(r+1)/2 + k]*Ld[c*(c+1)/2 + k];
-                Ld[r*(r+1)/2 + c] = s/d;
+                for (int c = 0; c < 6; c++) row[c] = x[c]*id[c];
             }
         }
-        __syncthreads();                        // all reads of the diagonal block done before it is overwritten
-        if (bad) { if (tid == 0) { fail = 1; st->step_fail = 1; } }
-        if (tid < 21) { int r = 0; while ((r+1)*(r+2)/2 <= tid) r++; int c = tid - r*(r+1)/2; A[(size_t)(j0 + r)*ld + j0 + c] = Ld[tid]; }
-        // panel: rows below (and the rhs row): x * Ld^T = a
-        for (int i = j0 + 6 + tid; i <= N; i += SOLVE_THREADS) {
-            double *row = (i < N) ? (A + (size_t)i*ld + j0) : (rhs + j0);
+        __syncthreads();
+        Tl += clock64() - Tx; Tx = clock64();
+        // trailing update A22 -= Lp D Lp^T on the matrix cores: v_mfma_f64_16x16x4_f64, K = 6 padded to 8.
+        // rows R0..n (the rhs row rides along), columns R0..n-1, lower triangle of 16x16 tiles.
+        const int mr = n - R0 + 1, mc = n - R0;
+        if (mc > 0) {
+            const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4;
+            const int lr = lane & 15, lk = lane >> 4;
+            const double dk0 = LD[32*jb + 15 + lk], dk1 = (4 + lk < 6) ? LD[32*jb + 15 + 4 + lk] : 0.0;
+            for (int t = wave; t < ntr*ntc; t += SOLVE_THREADS/64) {
+                const int ti = t / ntc, tj = t - ti*ntc;
+                if (tj > ti) continue;
+                const int arow = R0 + 16*ti + lr, bcol = R0 + 16*tj + lr;
+                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+                if (arow <= n) { a0 = -A[(size_t)arow*ld + j0 + lk]; if (4 + lk < 6) a1 = -A[(size_t)arow*ld + j0 + 4 + lk]; }
+                if (bcol < n)  { b0 = A[(size_t)bcol*ld + j0 + lk]*dk0; if (4 + lk < 6) b1 = A[(size_t)bcol*ld + j0 + 4 + lk]*dk1; }
+                v4d c;
+                const int ccol = R0 + 16*tj + lr;
+                bool ok[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int crow = R0 + 16*ti + lk + 4*r;
+                    ok[r] = crow <= n && ccol < n && (ccol <= crow);
+                    c[r] = ok[r] ? A[(size_t)crow*ld + ccol] : 0.0;
+                }
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int crow = R0 + 16*ti + lk + 4*r;
+                    if (ok[r]) A[(size_t)crow*ld + ccol] = c[r];
+                }
+            }
+        }
+        __syncthreads();
+        Tt += clock64() - Tx;
+    }
+    __syncthreads();
+    long long T2 = clock64();
+    if (fail) { for (int k = tid; k < Nmax; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
+    // back substitution L^T x = z (z = D^-1 L^-1 g sits in row n), wave 0
+    double *rhs = A + (size_t)n*ld;
+    if (tid < 64) {
+        for (int jb = nfree - 1; jb >= 0; jb--) {
+            const int j0 = 6*jb;
+            const double *l = LD + 32*jb;
             double x[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
-                double s = row[c];
-#pragma unroll
-                for (int k = 0; k < c; k++) s -= x[k]*Ld[c*(c+1)/2 + k];
-                x[c] = s/Ld[c*(c+1)/2 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++) row[c] = x[c];
-        }
-        __syncthreads();
-        // trailing update with the rank-6 panel
-        const int m = N - j0 - 6;               // remaining rows/cols
-        for (int idx = tid; idx < (m + 1)*m; idx += SOLVE_THREADS) {
-            int ri = idx / m, ci = idx % m;
-            if (ri < m && ci > ri) continue;    // lower triangle only (rhs row ri == m takes all columns)
-            int k = j0 + 6 + ci;
-            const double *pi = (ri < m) ? (A + (size_t)(j0 + 6 + ri)*ld + j0) : (rhs + j0);
-            const double *pk = A + (size_t)k*ld + j0;
-            double s = pi[0]*pk[0] + pi[1]*pk[1] + pi[2]*pk[2] + pi[3]*pk[3] + pi[4]*pk[4] + pi[5]*pk[5];
-            if (ri < m) A[(size_t)(j0 + 6 + ri)*ld + k] -= s; else rhs[k] -= s;
-        }
-        __syncthreads();
-    }
-    if (fail) { for (int k = tid; k < N; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
-    // back substitution L^T x = y by wave 0 (y = rhs after the forward pass folded into the factorisation)
-    if (tid < 64) {
-        for (int jb = nb - 1; jb >= 0; jb--) {
-            const int j0 = 6*jb;
-            double Ld[21], y[6];
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c <= r; c++) Ld[r*(r+1)/2 + c] = A[(size_t)(j0 + r)*ld + j0 + c];
-#pragma unroll
-            for (int c = 0; c < 6; c++) y[c] = rhs[j0 + c];
-#pragma unroll
             for (int c = 5; c >= 0; c--) {
-                double s = y[c];
+                double v = rhs[j0 + c];
 #pragma unroll
-                for (int k = c + 1; k < 6; k++) s -= Ld[k*(k+1)/2 + c]*y[k];
-                y[c] = s/Ld[c*(c+1)/2 + c];
+                for (int k = c + 1; k < 6; k++) v -= l[k*(k-1)/2 + c]*x[k];
+                x[c] = v;
             }
-            __builtin_amdgcn_wave_barrier();
-            if (tid < 6) { double v = y[0];
-#pragma unroll
-                for (int k = 1; k < 6; k++) if (tid == k) v = y[k];
-                rhs[j0 + tid] = v; }
             for (int k = tid; k < j0; k += 64) {
-                double s = 0;
+                double v = 0.0;
 #pragma unroll
-                for (int c = 0; c < 6; c++) s += A[(size_t)(j0 + c)*ld + k]*y[c];
-                rhs[k] -= s;
+                for (int c = 0; c < 6; c++) v += A[(size_t)(j0 + c)*ld + k]*x[c];
+                rhs[k] -= v;
             }
-            __builtin_amdgcn_wave_barrier();
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) rhs[j0 + c] = x[c];
+            }
             __threadfence_block();
         }
-        for (int k = tid; k < N; k += 64) W.dp[k] = -rhs[k];
+    }
+    __syncthreads();
+    if (tid == 0) { long long T3 = clock64(); W.dbg[0] = T1 - T0; W.dbg[1] = T2 - T1; W.dbg[2] = T3 - T2; W.dbg[3] = Tl; W.dbg[4] = 0; W.dbg[5] = Tt; W.dbg[6] = nfree; }
+    for (int a = tid; a < W.n_kf; a += SOLVE_THREADS) {
+        int ia = W.fidx[a];
+#pragma unroll
+        for (int k = 0; k < 6; k++) W.dp[6*a + k] = ia >= 0 ? -rhs[6*ia + k] : 0.0;
     }
 }
 
@@ -1183,6 +1255,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     UP(W.tobs_kf, p->tobs_kf, p->n_tobs); UP(W.tobs_text, p->tobs_text, p->n_tobs); UP(W.tobs_fgood_off, p->tobs_fgood_off, (size_t)p->n_tobs + 1);
     AL(W.musig, 2*(size_t)p->n_tobs);
     AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
+    AL(W.fidx, p->n_kf); AL(W.nfree, 1); AL(W.dbg, 64); AL(W.LDbuf, 32*(size_t)p->n_kf);
     // ---- per-level plans
     c->hplan.resize(p->n_levels); c->lev.resize(p->n_levels); c->lev_built.assign(p->n_levels, 0);
     size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1;
@@ -1230,9 +1303,10 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     AL(W.w_pt, 6*mx_pslot); AL(W.vb_pt, 2*mx_pslot); AL(W.V_pt, p->n_pt); AL(W.b_pt, p->n_pt); AL(W.sig_pt, p->n_pt); AL(W.dg_pt, p->n_pt);
     AL(W.w_tx, 18*mx_tslot); AL(W.vb_tx, 9*mx_tslot); AL(W.V_tx, 6*(size_t)p->n_text); AL(W.b_tx, 3*(size_t)p->n_text); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.dg_tx, 3*(size_t)p->n_text);
     AL(W.Hd, W.N); AL(W.bp, W.N); AL(W.sig_p, W.N); AL(W.dg_p, W.N);
-    AL(W.S, (size_t)W.N*W.N); AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
+    AL(W.S, (size_t)(W.N + 1)*W.N); AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     c->nb_back_max = (p->n_pt + 255)/256 + (p->n_text + 255)/256 + (p->n_kf + 255)/256;
     AL(W.partial, 2*(size_t)c->nb_back_max);
+    AL(W.lmpart, 2*((size_t)c->nb_back_max + mx_pair/256 + 2));
     AL(W.st, 1);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err(c, "upload sync failed"); return TSBA_ERR_DEVICE; }
     c->uploaded = true;
@@ -1267,10 +1341,10 @@ static void launch_linearize(Ctx *c, const LevelDev &D) {
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256;
     if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D);
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
-    hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance);
+    hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx);
 }
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
-    size_t N = c->W.N, ld = N | 1, bytes = (N*ld + N + 8)*sizeof(double);
+    size_t N = c->W.N, ld = N | 1, bytes = ((N + 1)*ld + 32*(N/6) + 8)*sizeof(double);     // worst case: every pose free
     *use_lds = bytes <= 150*1024;
     return *use_lds ? (int)bytes : 0;
 }
@@ -1278,7 +1352,7 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (D.n_sb*36 < W.N*W.N) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
+    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);   // block-sparse S
     hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, use_lds);
     hipLaunchKernelGGL(k_back, dim3(nb_pt + nb_tx + nb_kf), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
@@ -1420,7 +1494,7 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     launch_pass_init(c, D, 0);
     launch_linearize(c, D);
     Work &W = c->W;
-    if (D.n_sb*36 < W.N*W.N) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
+    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
     hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, use_lds);
     c->opt = saved;
@@ -1462,6 +1536,12 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
         *algo_bytes = 44.0*st.ns_active + 128.0*st.nt_active + 16.0*npairs_text + 56.0*c->n_kf + 8.0*c->n_pt + 24.0*c->n_text;
     }
     return TSBA_OK;
+}
+
+int tsba_debug_stamps(void *ctx, long long *out64) {
+    Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded) return TSBA_ERR_STATE;
+    hipSetDevice(c->device); hipStreamSynchronize(c->stream);
+    return hipMemcpy(out64, c->W.dbg, 64*sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
 }
 
 int tsba_comm_unique_id(void *id128) { (void)id128; return TSBA_ERR_COMM; }

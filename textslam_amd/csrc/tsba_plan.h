@@ -140,6 +140,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         int a = P.tslot_pose[s1], b = P.tslot_pose[s2]; if (a > b) continue; tt.push_back({ bkey(a, b), s1, s2 }); }
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bkeys.push_back(bkey(i, i));
         if (h >= 0) { bkeys.push_back(bkey(h, h)); bkeys.push_back(bkey(std::min(i, h), std::max(i, h))); } }
+    if (n_kf <= 64) for (int a = 0; a < n_kf; a++) for (int b = a; b < n_kf; b++) bkeys.push_back(bkey(a, b));   // small windows: dense S, no memset
     for (auto &t : tp) bkeys.push_back(t.key);
     for (auto &t : tt) bkeys.push_back(t.key);
     std::sort(bkeys.begin(), bkeys.end());
