@@ -741,126 +741,216 @@ __device__ __forceinline__ void ldl6(const double *A, int ld, double l[15], doub
     }
 }
 typedef double v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W, int use_lds) {
+__device__ __forceinline__ double rcp_nr(double d) {        // v_rcp_f64 + two Newton steps (d > 0, normal range)
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0); x = fma(x, e, x);
+    e = fma(-d, x, 1.0); x = fma(x, e, x);
+    return x;
+}
+__device__ __forceinline__ double readlane_f64(double v, int src) {   // src must be wave-uniform
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// Look-ahead schedule, one barrier per block column jb:
+//   wave 0 ("F"):  LDL^T of the diagonal block jb (registers) -> panel jb (rows below + rhs row) -> barrier
+//                  -> applies panel jb to block column jb+1 only, then goes straight on to factor block jb+1
+//   waves 1..15 ("T"): after the barrier, trailing update of the columns >= jb+2 with panel jb on the matrix cores
+template <bool use_lds>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W) {
     LmState *st = W.st;
     if (st->done) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long T0 = clock64(), Tl = 0, Tt = 0, Tx;
+    long long T0 = clock64();
     const int nfree = *W.nfree, n = 6*nfree, Nmax = W.N;
     const int ld = use_lds ? (n | 1) : Nmax;
-    // A holds rows 0..n (row n = right-hand side g); LD = factored diagonal blocks: per block 15 l + 6 d + 6 1/d (27, padded 32)
-    double *A = use_lds ? smem : W.S;
-    double *LD = use_lds ? (smem + (size_t)(n + 1)*ld) : W.LDbuf;
+    // separate instantiations keep LDS accesses as ds_* instructions (a runtime-selected pointer would go through FLAT)
+    auto sel = [&](auto lds_ptr, double *glob) { if constexpr (use_lds) return lds_ptr; else return glob; };
+    auto A = sel(smem, W.S);                                            // rows 0..n, row n = right-hand side g
+    auto LD = sel(smem + (size_t)(n + 1)*ld, W.LDbuf);                  // per block: 15 l, 6 d, 6 1/d (stride 32)
     if (use_lds) {
-        for (int r = tid >> 5; r < n; r += SOLVE_THREADS/32)                      // 32 lanes per row: coalesced row reads
+        for (int r = tid >> 5; r < n; r += SOLVE_THREADS/32)
             for (int cidx = tid & 31; cidx <= r; cidx += 32) A[(size_t)r*ld + cidx] = W.S[(size_t)r*Nmax + cidx];
-        for (int k = tid; k < n; k += SOLVE_THREADS) A[(size_t)n*ld + k] = W.g[k];
-    } else {
-        for (int k = tid; k < n; k += SOLVE_THREADS) A[(size_t)n*ld + k] = W.g[k];   // needs (Nmax+1) rows in W.S
     }
+    for (int k = tid; k < n; k += SOLVE_THREADS) A[(size_t)n*ld + k] = W.g[k];
     __shared__ int fail;
     if (tid == 0) fail = st->step_fail;
     __syncthreads();
     long long T1 = clock64();
     for (int jb = 0; jb < nfree; jb++) {
-        if (fail) break;
         const int j0 = 6*jb, R0 = j0 + 6;
-        Tx = clock64();
-        if (wave < 2) {             // two waves (different SIMDs) factor the diagonal block redundantly and solve the panel
-            double l[15], d[6], id[6]; bool bad = false;
-            ldl6(A + (size_t)j0*ld + j0, ld, l, d, id, bad);
-            if (tid == 0) {
-                if (bad) { fail = 1; st->step_fail = 1; }
-                double *o = LD + 32*jb;
+        if (wave == 0) {
+            if (jb > 0) {
+                // look-ahead: apply panel jb-1 (columns j0-6..j0-1) to block column jb (columns j0..j0+5), rows j0..n
+                const int p0 = j0 - 6;
+                double dprev[6], Lk[36];
 #pragma unroll
-                for (int k = 0; k < 15; k++) o[k] = l[k];
+                for (int k = 0; k < 6; k++) dprev[k] = LD[32*(jb - 1) + 15 + k];
 #pragma unroll
-                for (int k = 0; k < 6; k++) { o[15 + k] = d[k]; o[21 + k] = id[k]; }
+                for (int c = 0; c < 6; c++)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) Lk[c*6 + k] = A[(size_t)(j0 + c)*ld + p0 + k];
+                for (int i = j0 + lane; i <= n; i += 64) {
+                    auto row = A + (size_t)i*ld;
+                    double y[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) y[k] = row[p0 + k]*dprev[k];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) v += y[k]*Lk[c*6 + k];
+                        if (i >= j0 + c) row[j0 + c] -= v;
+                    }
+                }
             }
-            for (int i = R0 + tid; i <= n; i += 128) {      // panel rows incl. the rhs row: x L^T = a, l_row = x D^-1
-                double *row = A + (size_t)i*ld + j0;
-                double x[6];
+            if (!fail) {
+                // LDL^T of the 6x6 diagonal block in registers (every lane redundantly), reciprocal pivots
+                double a[21], l[15], d[6], id[6]; bool bad = false;
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c <= r; c++) a[r*(r+1)/2 + c] = A[(size_t)(j0 + r)*ld + j0 + c];
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
-                    double v = row[c];
+                    double dc = a[c*(c+1)/2 + c];
 #pragma unroll
-                    for (int k = 0; k < c; k++) v -= x[k]*l[c*(c-1)/2 + k];
-                    x[c] = v;
+                    for (int k = 0; k < c; k++) dc -= l[c*(c-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
+                    if (!(dc > 0.0)) { bad = true; dc = 1.0; }
+                    d[c] = dc; id[c] = rcp_nr(dc);
+#pragma unroll
+                    for (int r = c + 1; r < 6; r++) {
+                        double v = a[r*(r+1)/2 + c];
+#pragma unroll
+                        for (int k = 0; k < c; k++) v -= l[r*(r-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
+                        l[r*(r-1)/2 + c] = v*id[c];
+                    }
                 }
+                if (lane == 0) {
+                    if (bad) { fail = 1; st->step_fail = 1; }
+                    auto o = LD + 32*jb;
 #pragma unroll
-                for (int c = 0; c < 6; c++) row[c] = x[c]*id[c];
-            }
-        }
-        __syncthreads();
-        Tl += clock64() - Tx; Tx = clock64();
-        // trailing update A22 -= Lp D Lp^T on the matrix cores: v_mfma_f64_16x16x4_f64, K = 6 padded to 8.
-        // rows R0..n (the rhs row rides along), columns R0..n-1, lower triangle of 16x16 tiles.
-        const int mr = n - R0 + 1, mc = n - R0;
-        if (mc > 0) {
-            const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4;
-            const int lr = lane & 15, lk = lane >> 4;
-            const double dk0 = LD[32*jb + 15 + lk], dk1 = (4 + lk < 6) ? LD[32*jb + 15 + 4 + lk] : 0.0;
-            for (int t = wave; t < ntr*ntc; t += SOLVE_THREADS/64) {
-                const int ti = t / ntc, tj = t - ti*ntc;
-                if (tj > ti) continue;
-                const int arow = R0 + 16*ti + lr, bcol = R0 + 16*tj + lr;
-                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-                if (arow <= n) { a0 = -A[(size_t)arow*ld + j0 + lk]; if (4 + lk < 6) a1 = -A[(size_t)arow*ld + j0 + 4 + lk]; }
-                if (bcol < n)  { b0 = A[(size_t)bcol*ld + j0 + lk]*dk0; if (4 + lk < 6) b1 = A[(size_t)bcol*ld + j0 + 4 + lk]*dk1; }
-                v4d c;
-                const int ccol = R0 + 16*tj + lr;
-                bool ok[4];
+                    for (int k = 0; k < 15; k++) o[k] = l[k];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int crow = R0 + 16*ti + lk + 4*r;
-                    ok[r] = crow <= n && ccol < n && (ccol <= crow);
-                    c[r] = ok[r] ? A[(size_t)crow*ld + ccol] : 0.0;
+                    for (int k = 0; k < 6; k++) { o[15 + k] = d[k]; o[21 + k] = id[k]; }
                 }
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+                for (int i = R0 + lane; i <= n; i += 64) {      // panel rows incl. the rhs row: x L^T = a, l_row = x D^-1
+                    auto row = A + (size_t)i*ld + j0;
+                    double x[6];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int crow = R0 + 16*ti + lk + 4*r;
-                    if (ok[r]) A[(size_t)crow*ld + ccol] = c[r];
+                    for (int c = 0; c < 6; c++) {
+                        double v = row[c];
+#pragma unroll
+                        for (int k = 0; k < c; k++) v -= x[k]*l[c*(c-1)/2 + k];
+                        x[c] = v;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; c++) row[c] = x[c]*id[c];
                 }
             }
         }
-        __syncthreads();
-        Tt += clock64() - Tx;
+        __syncthreads();                       // panel jb complete; trailing update jb-1 complete
+        if (fail) break;
+        if (wave > 0) {
+            // trailing update with panel jb on columns >= j0+12 (block column jb+1 is wave 0's look-ahead), rows >= j0+12 and rhs
+            const int C0 = j0 + 12;
+            const int mr = n - C0 + 1, mc = n - C0;
+            if (mc > 0) {
+                const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4;
+                const int lr = lane & 15, lk = lane >> 4;
+                const double dk0 = LD[32*jb + 15 + lk], dk1 = (4 + lk < 6) ? LD[32*jb + 15 + 4 + lk] : 0.0;
+                int t = wave - 1;
+                for (int ti = 0; ti < ntr; ti++) for (int tj = 0; tj <= ti && tj < ntc; tj++) {
+                    if (t-- != 0) continue;
+                    t = SOLVE_THREADS/64 - 2;               // next tile of this wave: 15 tiles further
+                    const int arow = C0 + 16*ti + lr, bcol = C0 + 16*tj + lr;
+                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+                    if (arow <= n) { a0 = -A[(size_t)arow*ld + j0 + lk]; if (4 + lk < 6) a1 = -A[(size_t)arow*ld + j0 + 4 + lk]; }
+                    if (bcol < n)  { b0 = A[(size_t)bcol*ld + j0 + lk]*dk0; if (4 + lk < 6) b1 = A[(size_t)bcol*ld + j0 + 4 + lk]*dk1; }
+                    v4d c;
+                    const int ccol = C0 + 16*tj + lr;
+                    bool ok[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int crow = C0 + 16*ti + lk + 4*r;
+                        ok[r] = crow <= n && ccol < n && (ccol <= crow);
+                        c[r] = ok[r] ? A[(size_t)crow*ld + ccol] : 0.0;
+                    }
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int crow = C0 + 16*ti + lk + 4*r;
+                        if (ok[r]) A[(size_t)crow*ld + ccol] = c[r];
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
     long long T2 = clock64();
     if (fail) { for (int k = tid; k < Nmax; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
-    // back substitution L^T x = z (z = D^-1 L^-1 g sits in row n), wave 0
-    double *rhs = A + (size_t)n*ld;
-    if (tid < 64) {
-        for (int jb = nfree - 1; jb >= 0; jb--) {
-            const int j0 = 6*jb;
-            const double *l = LD + 32*jb;
-            double x[6];
+    // back substitution L^T x = z (z = D^-1 L^-1 g sits in row n): wave 0, solution kept in registers (rows lane, lane+64, ...)
+    auto rhs = A + (size_t)n*ld;
+    if (wave == 0) {
+        if (n <= 128) {
+            double z0 = lane < n ? rhs[lane] : 0.0, z1 = lane + 64 < n ? rhs[lane + 64] : 0.0;
+            for (int jb = nfree - 1; jb >= 0; jb--) {
+                const int j0 = 6*jb;
+                auto l = LD + 32*jb;
+                double x[6];
 #pragma unroll
-            for (int c = 5; c >= 0; c--) {
-                double v = rhs[j0 + c];
+                for (int c = 0; c < 6; c++) { int r = j0 + c; x[c] = r < 64 ? readlane_f64(z0, r) : readlane_f64(z1, r - 64); }
 #pragma unroll
-                for (int k = c + 1; k < 6; k++) v -= l[k*(k-1)/2 + c]*x[k];
-                x[c] = v;
+                for (int c = 4; c >= 0; c--) {
+#pragma unroll
+                    for (int k = c + 1; k < 6; k++) x[c] -= l[k*(k-1)/2 + c]*x[k];
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) { if (lane == ((j0 + c) & 63)) { if (j0 + c < 64) z0 = x[c]; else z1 = x[c]; } }
+                if (lane < j0) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) v += A[(size_t)(j0 + c)*ld + lane]*x[c];
+                    z0 -= v;
+                }
+                if (lane + 64 < j0) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) v += A[(size_t)(j0 + c)*ld + lane + 64]*x[c];
+                    z1 -= v;
+                }
             }
-            for (int k = tid; k < j0; k += 64) {
-                double v = 0.0;
+            if (lane < n) rhs[lane] = z0;
+            if (lane + 64 < n) rhs[lane + 64] = z1;
+        } else {
+            for (int jb = nfree - 1; jb >= 0; jb--) {
+                const int j0 = 6*jb;
+                auto l = LD + 32*jb;
+                double x[6];
 #pragma unroll
-                for (int c = 0; c < 6; c++) v += A[(size_t)(j0 + c)*ld + k]*x[c];
-                rhs[k] -= v;
-            }
-            if (tid == 0) {
+                for (int c = 5; c >= 0; c--) {
+                    double v = rhs[j0 + c];
 #pragma unroll
-                for (int c = 0; c < 6; c++) rhs[j0 + c] = x[c];
+                    for (int k = c + 1; k < 6; k++) v -= l[k*(k-1)/2 + c]*x[k];
+                    x[c] = v;
+                }
+                for (int k = lane; k < j0; k += 64) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) v += A[(size_t)(j0 + c)*ld + k]*x[c];
+                    rhs[k] -= v;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) rhs[j0 + c] = x[c];
+                }
+                __threadfence_block();
             }
-            __threadfence_block();
         }
     }
     __syncthreads();
-    if (tid == 0) { long long T3 = clock64(); W.dbg[0] = T1 - T0; W.dbg[1] = T2 - T1; W.dbg[2] = T3 - T2; W.dbg[3] = Tl; W.dbg[4] = 0; W.dbg[5] = Tt; W.dbg[6] = nfree; }
+    if (tid == 0) { long long T3 = clock64(); W.dbg[0] = T1 - T0; W.dbg[1] = T2 - T1; W.dbg[2] = T3 - T2; W.dbg[3] = 0; W.dbg[4] = 0; W.dbg[5] = 0; W.dbg[6] = nfree; }
     for (int a = tid; a < W.n_kf; a += SOLVE_THREADS) {
         int ia = W.fidx[a];
 #pragma unroll
@@ -1354,7 +1444,8 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);   // block-sparse S
     hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, use_lds);
+    if (use_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W);
+    else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, W);
     hipLaunchKernelGGL(k_back, dim3(nb_pt + nb_tx + nb_kf), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
     if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_COST>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, c->opt);
@@ -1367,7 +1458,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
     memset(r, 0, sizeof(*r));
     const tsba_options &o = c->opt;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     auto t0 = std::chrono::steady_clock::now();
     int rc = reset_state(c); if (rc) return rc;
     for (int ps = 0; ps < o.n_passes; ps++) {
@@ -1490,13 +1581,14 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     tsba_options saved = c->opt; c->opt.initial_radius = radius;
     const LevelDev &D = c->lev[c->opt.levels[0]];
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     launch_pass_init(c, D, 0);
     launch_linearize(c, D);
     Work &W = c->W;
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
     hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, use_lds);
+    if (use_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W);
+    else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, W);
     c->opt = saved;
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
     if (S) CK(hipMemcpy(S, W.S, sizeof(double)*(size_t)W.N*W.N, hipMemcpyDeviceToHost));
