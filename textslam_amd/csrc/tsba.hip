@@ -28,7 +28,7 @@
 // ------------------------------------------------------------------------------------------------ device structs
 struct LmState {
     double radius, decrease_factor, x_cost, x_norm, cand_cost, model_change, step_norm, gmax, cost0;
-    int cur, done, need_lin, first, it, accepted, term, invalid, max_it, step_fail, pad0, pad1;
+    int cur, done, need_lin, first, it, accepted, term, invalid, max_it, step_fail, lcur, pad1;
     int ns_active, nt_active, n_bad_scene, n_bad_tfeat, n_bad_text, pad2;
     long long n_lin, n_cost;
 };
@@ -42,9 +42,19 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const int *pair_i, *pair_h, *pair_sc_off, *pair_tg_off, *pair_tg;
     const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot;
     const int *pls_off, *pslot_pose, *pslot_pair, *pslot_lm, *tls_off, *tslot_pose, *tslot_pair, *tslot_lm;
-    const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_tx_off, *sb_tx_s1, *sb_tx_s2;
-    const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ts_off, *pose_ts;
+    const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_pt_lm, *sb_tx_off, *sb_tx_s1, *sb_tx_s2, *sb_tx_lm;
+    const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ps_lm, *pose_ts_off, *pose_ts, *pose_ts_lm;
     const int *tfeat_off, *tfeat_raw; const double *tfeat_uv, *tfeat_ref;
+};
+
+struct LinBuf {              // everything one linearisation produces
+    double *pairM, *pairCost, *pairR, *pairOut, *tgM, *tgCost;
+    double *w_pt, *vb_pt;               // per point slot: w [6][n], (v, b, -Q^T w) [8][n]
+    double *V_pt, *b_pt, *dgs_pt;       // per point: V, b, clamp(sigma^2 V)/sigma^2  (lambda = dgs / radius)
+    double *w_tx, *vb_tx;               // per text slot: W [18][n], (V6, b3, -Q^T W 18) [27][n]
+    double *V_tx, *b_tx, *dgs_tx;       // per plane: V [6][n], b [3][n], dgs [3][n]
+    double *Hd, *bp, *dgs_p;            // per pose: diag(H_pp), gradient, dgs
+    double *lmpart;                     // per k_mid block: (gradient max, |x|^2) of its landmarks
 };
 
 struct Work {                // device work buffers (sized for the largest level)
@@ -62,14 +72,11 @@ struct Work {                // device work buffers (sized for the largest level
     double *musig;                      // [n_tobs][2]
     int *kf_in, *kf_const, *act_pt, *act_tx;
     int *fidx, *nfree;                  // compressed index of the free poses in S / g
-    double *lmpart;                     // [nblocks_mid][2] per-block (gradient max, |x|^2) of the landmarks
     long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
     double *LDbuf;                      // factored diagonal blocks when k_solve cannot use LDS
-    // linearisation outputs
-    double *pairM, *pairCost, *pairR, *pairOut, *tgM, *tgCost, *pairCost2, *tgCost2;
-    double *w_pt, *vb_pt, *V_pt, *b_pt, *sig_pt, *dg_pt;
-    double *w_tx, *vb_tx, *V_tx, *b_tx, *sig_tx, *dg_tx;
-    double *Hd, *bp, *sig_p, *dg_p;
+    // linearisation outputs, double-buffered: lb[lcur] belongs to x, lb[lcur^1] to the LM candidate (speculative)
+    LinBuf lb[2];
+    double *sig_pt, *sig_tx, *sig_p;    // Jacobi column scales, fixed at the first linearisation of a pass
     double *S, *g, *dp, *dl_pt, *dl_tx;
     double *partial;                    // [nblocks_back][2]
     LmState *st;
@@ -295,13 +302,15 @@ __global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
 #define MODE_FULL 0
 #define MODE_COST 1
 template <int MODE>
-__global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L) {
+__global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) {
+    // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
     const LmState *st = W.st;
     if (st->done) return;
-    if (MODE == MODE_FULL && !st->need_lin) return;
-    if (MODE == MODE_COST && st->step_fail) return;
+    if (!spec && !st->need_lin) return;
+    if (spec && st->step_fail) return;
     __shared__ double lds[55*65];
-    const int sel = MODE == MODE_FULL ? st->cur : (st->cur ^ 1);
+    const int sel = spec ? (st->cur ^ 1) : st->cur;
+    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
     const double *pose = W.pose[sel], *rho = W.rho[sel], *theta = W.theta[sel];
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b < L.n_pair) {
@@ -321,8 +330,9 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L) {
             if (!act) {
                 if (MODE == MODE_FULL && slot >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 6; k++) W.w_pt[(size_t)k*L.n_pslot + slot] = 0.0;
-                    W.vb_pt[slot] = 0.0; W.vb_pt[(size_t)L.n_pslot + slot] = 0.0;
+                    for (int k = 0; k < 6; k++) B.w_pt[(size_t)k*L.n_pslot + slot] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) B.vb_pt[(size_t)k*L.n_pslot + slot] = 0.0;
                 }
                 continue;
             }
@@ -346,23 +356,27 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L) {
 #pragma unroll
                 for (int a = 0; a < 6; a++) acc[21 + a] += wgt*(jt[0][a]*r[0] + jt[1][a]*r[1]);
                 if (slot >= 0) {
+                    double w[6];
 #pragma unroll
-                    for (int a = 0; a < 6; a++) W.w_pt[(size_t)a*L.n_pslot + slot] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]);
-                    W.vb_pt[slot] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
-                    W.vb_pt[(size_t)L.n_pslot + slot] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
+                    for (int a = 0; a < 6; a++) { w[a] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]); B.w_pt[(size_t)a*L.n_pslot + slot] = w[a]; }
+                    B.vb_pt[slot] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
+                    B.vb_pt[(size_t)L.n_pslot + slot] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
+                    double qa[3], qc[3]; mat3T_vec(T.Rcr, w, qa); mat3T_vec(T.Rcr, w + 3, qc);     // host column: -Q^T w
+#pragma unroll
+                    for (int a = 0; a < 3; a++) { B.vb_pt[(size_t)(2 + a)*L.n_pslot + slot] = -qa[a]; B.vb_pt[(size_t)(5 + a)*L.n_pslot + slot] = -qc[a]; }
                 }
             }
         }
         if (MODE == MODE_COST) {
             double cs = wave_sum1(acc[27]);
-            if (lane == 0) W.pairCost2[b] = cs;
+            if (lane == 0) B.pairCost[b] = cs;
         } else {
             double tot = wave_sum_to_lane<28>(acc, lds, lane);
-            if (lane < 27) W.pairM[(size_t)lane*L.n_pair + b] = tot;
-            else if (lane == 27) W.pairCost[b] = tot;
+            if (lane < 27) B.pairM[(size_t)lane*L.n_pair + b] = tot;
+            else if (lane == 27) B.pairCost[b] = tot;
             if (h >= 0 && lane == 0) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) W.pairR[(size_t)k*L.n_pair + b] = T.Rcr[k];
+                for (int k = 0; k < 9; k++) B.pairR[(size_t)k*L.n_pair + b] = T.Rcr[k];
             }
         }
     } else {
@@ -374,9 +388,9 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L) {
         double acc[55];
 #pragma unroll
         for (int k = 0; k < 55; k++) acc[k] = 0.0;
+        PairT T;
         if (act_g) {
             Pose C; load_pose(pose + 7*i, C);
-            PairT T;
             if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
             else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
             const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
@@ -424,161 +438,154 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L) {
         }
         if (MODE == MODE_COST) {
             double cs = wave_sum1(acc[54]);
-            if (lane == 0) W.tgCost2[g] = cs;
+            if (lane == 0) B.tgCost[g] = cs;
         } else {
             double tot = wave_sum_to_lane<55>(acc, lds, lane);
-            if (lane < 27) W.tgM[(size_t)lane*L.n_tg + g] = tot;
-            else if (lane < 45) { if (slot >= 0) W.w_tx[(size_t)(lane - 27)*L.n_tslot + slot] = tot; }
-            else if (lane < 54) { if (slot >= 0) W.vb_tx[(size_t)(lane - 45)*L.n_tslot + slot] = tot; }
-            else if (lane == 54) W.tgCost[g] = tot;
+            if (lane < 27) B.tgM[(size_t)lane*L.n_tg + g] = tot;
+            else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(lane - 27)*L.n_tslot + slot] = tot; lds[lane - 27] = tot; }
+            else if (lane < 54) { if (slot >= 0) B.vb_tx[(size_t)(lane - 45)*L.n_tslot + slot] = tot; }
+            else if (lane == 54) B.tgCost[g] = tot;
+            if (slot >= 0) {                    // host column of W: -blkdiag(R,R)^T W, rows (half, r), columns cc
+                if (lane < 9) {
+                    double rv = T.Rcr[0];
+#pragma unroll
+                    for (int q = 1; q < 9; q++) if (lane == q) rv = T.Rcr[q];
+                    lds[32 + lane] = act_g ? rv : 0.0;
+                }
+                __syncthreads();
+                if (lane < 18) {
+                    const int half = lane/9, rr = (lane % 9)/3, cc = lane % 3;
+                    double v = lds[32 + 0*3 + rr]*lds[(half*3 + 0)*3 + cc] + lds[32 + 1*3 + rr]*lds[(half*3 + 1)*3 + cc] + lds[32 + 2*3 + rr]*lds[(half*3 + 2)*3 + cc];
+                    B.vb_tx[(size_t)(9 + lane)*L.n_tslot + slot] = -v;
+                }
+            }
         }
     }
 }
 
 // ---- per landmark: V, b, host column of W (= -sum Q^T w);  per pair: host-side products.  256-thread blocks.
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx) {
+__global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int spec) {
     const LmState *st = W.st;
-    if (st->done || !st->need_lin) return;
+    if (st->done) return;
+    if (!spec && !st->need_lin) return;
+    if (spec && st->step_fail) return;
+    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
+    const int sel = spec ? (st->cur ^ 1) : st->cur;
     __shared__ double red[256];
-    const double *rho_x = W.rho[st->cur], *theta_x = W.theta[st->cur];
+    const double *rho_x = W.rho[sel], *theta_x = W.theta[sel];
     double gm = 0.0, xn = 0.0;
-    int b = blockIdx.x;
+    const int b = blockIdx.x;
     if (b < nb_pt) {
-        int j = b*256 + threadIdx.x;
+        const int j = b*256 + threadIdx.x;
         int o = 0, e = 0;
         if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; }
         if (e > o) {
-        double V = 0, bb = 0, wh[6] = {0,0,0,0,0,0};
-        for (int s = o; s < e - 1; s++) {
-            V += W.vb_pt[s]; bb += W.vb_pt[(size_t)L.n_pslot + s];
-            int p = L.pslot_pair[s];
-            double R[9], w[6];
+            double acc[8] = {0,0,0,0,0,0,0,0};
+            for (int s = o; s < e - 1; s++) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) R[k] = W.pairR[(size_t)k*L.n_pair + p];
+                for (int k = 0; k < 8; k++) acc[k] += B.vb_pt[(size_t)k*L.n_pslot + s];
+            }
 #pragma unroll
-            for (int k = 0; k < 6; k++) w[k] = W.w_pt[(size_t)k*L.n_pslot + s];
-            double a[3], c[3]; mat3T_vec(R, w, a); mat3T_vec(R, w + 3, c);
-            wh[0] -= a[0]; wh[1] -= a[1]; wh[2] -= a[2]; wh[3] -= c[0]; wh[4] -= c[1]; wh[5] -= c[2];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) W.w_pt[(size_t)k*L.n_pslot + e - 1] = wh[k];
-        W.V_pt[j] = V; W.b_pt[j] = bb;
-        if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
-        double sg = W.sig_pt[j];
-        W.dg_pt[j] = clampd(sg*sg*V, W.min_diag, W.max_diag);
-        if (W.act_pt[j]) { gm = fabs(bb); xn = rho_x[j]*rho_x[j]; }
+            for (int k = 0; k < 6; k++) B.w_pt[(size_t)k*L.n_pslot + e - 1] = acc[2 + k];
+            const double V = acc[0];
+            B.V_pt[j] = V; B.b_pt[j] = acc[1];
+            if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
+            const double sg = W.sig_pt[j];
+            B.dgs_pt[j] = clampd(sg*sg*V, W.min_diag, W.max_diag)/(sg*sg);
+            if (W.act_pt[j]) { gm = fabs(acc[1]); xn = rho_x[j]*rho_x[j]; }
         }
     } else if (b < nb_pt + nb_tx) {
-        int j = (b - nb_pt)*256 + threadIdx.x;
+        const int j = (b - nb_pt)*256 + threadIdx.x;
         int o = 0, e = 0;
         if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; }
         if (e > o) {
-        double V[6] = {0,0,0,0,0,0}, bb[3] = {0,0,0}, wh[18];
+            double acc[27];
 #pragma unroll
-        for (int k = 0; k < 18; k++) wh[k] = 0;
-        for (int s = o; s < e - 1; s++) {
+            for (int k = 0; k < 27; k++) acc[k] = 0.0;
+            for (int s = o; s < e - 1; s++) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) V[k] += W.vb_tx[(size_t)k*L.n_tslot + s];
+                for (int k = 0; k < 27; k++) acc[k] += B.vb_tx[(size_t)k*L.n_tslot + s];
+            }
 #pragma unroll
-            for (int k = 0; k < 3; k++) bb[k] += W.vb_tx[(size_t)(6 + k)*L.n_tslot + s];
-            int p = L.tslot_pair[s];
-            double R[9], w[18];
+            for (int k = 0; k < 18; k++) B.w_tx[(size_t)k*L.n_tslot + e - 1] = acc[9 + k];
 #pragma unroll
-            for (int k = 0; k < 9; k++) R[k] = W.pairR[(size_t)k*L.n_pair + p];
+            for (int k = 0; k < 6; k++) B.V_tx[(size_t)k*W.n_text + j] = acc[k];
 #pragma unroll
-            for (int k = 0; k < 18; k++) w[k] = W.w_tx[(size_t)k*L.n_tslot + s];
-            // W (6x3, row-major): rows 0-2 rotation, 3-5 translation.  host = -blkdiag(R,R)^T W
+            for (int k = 0; k < 3; k++) B.b_tx[(size_t)k*W.n_text + j] = acc[6 + k];
+            const double dv[3] = { acc[0], acc[3], acc[5] };
 #pragma unroll
-            for (int half = 0; half < 2; half++)
-#pragma unroll
-                for (int r = 0; r < 3; r++)
-#pragma unroll
-                    for (int cc = 0; cc < 3; cc++)
-                        wh[(half*3 + r)*3 + cc] -= R[0*3 + r]*w[(half*3 + 0)*3 + cc] + R[1*3 + r]*w[(half*3 + 1)*3 + cc] + R[2*3 + r]*w[(half*3 + 2)*3 + cc];
-        }
-#pragma unroll
-        for (int k = 0; k < 18; k++) W.w_tx[(size_t)k*L.n_tslot + e - 1] = wh[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) W.V_tx[(size_t)k*W.n_text + j] = V[k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) W.b_tx[(size_t)k*W.n_text + j] = bb[k];
-        const double dv[3] = { V[0], V[3], V[5] };
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if (st->first) W.sig_tx[(size_t)k*W.n_text + j] = 1.0/(1.0 + sqrt(dv[k]));
-            double sg = W.sig_tx[(size_t)k*W.n_text + j];
-            W.dg_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag);
-        }
-        if (W.act_tx[j]) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(bb[k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
+            for (int k = 0; k < 3; k++) {
+                if (st->first) W.sig_tx[(size_t)k*W.n_text + j] = 1.0/(1.0 + sqrt(dv[k]));
+                const double sg = W.sig_tx[(size_t)k*W.n_text + j];
+                B.dgs_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag)/(sg*sg);
+            }
+            if (W.act_tx[j]) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(acc[6 + k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
         }
     } else {
-        int p = (b - nb_pt - nb_tx)*256 + threadIdx.x;
+        const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x;
         if (p < L.n_pair) {
-        double M[21], c[6];
+            double M[21], c[6];
 #pragma unroll
-        for (int k = 0; k < 21; k++) M[k] = W.pairM[(size_t)k*L.n_pair + p];
+            for (int k = 0; k < 21; k++) M[k] = B.pairM[(size_t)k*L.n_pair + p];
 #pragma unroll
-        for (int k = 0; k < 6; k++) c[k] = W.pairM[(size_t)(21 + k)*L.n_pair + p];
-        for (int q = L.pair_tg_off[p]; q < L.pair_tg_off[p+1]; q++) {
-            int g = L.pair_tg[q];
+            for (int k = 0; k < 6; k++) c[k] = B.pairM[(size_t)(21 + k)*L.n_pair + p];
+            for (int q = L.pair_tg_off[p]; q < L.pair_tg_off[p+1]; q++) {
+                const int g = L.pair_tg[q];
 #pragma unroll
-            for (int k = 0; k < 21; k++) M[k] += W.tgM[(size_t)k*L.n_tg + g];
+                for (int k = 0; k < 21; k++) M[k] += B.tgM[(size_t)k*L.n_tg + g];
 #pragma unroll
-            for (int k = 0; k < 6; k++) c[k] += W.tgM[(size_t)(21 + k)*L.n_tg + g];
-        }
-        double *out = W.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) QMQ(21) Qc(6)
+                for (int k = 0; k < 6; k++) c[k] += B.tgM[(size_t)(21 + k)*L.n_tg + g];
+            }
+            double *out = B.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) QMQ(21) Qc(6)
 #pragma unroll
-        for (int k = 0; k < 21; k++) out[(size_t)k*L.n_pair + p] = M[k];
+            for (int k = 0; k < 21; k++) out[(size_t)k*L.n_pair + p] = M[k];
 #pragma unroll
-        for (int k = 0; k < 6; k++) out[(size_t)(21 + k)*L.n_pair + p] = c[k];
-        if (L.pair_h[p] >= 0) {
-            double R[9];
+            for (int k = 0; k < 6; k++) out[(size_t)(21 + k)*L.n_pair + p] = c[k];
+            if (L.pair_h[p] >= 0) {
+                double R[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) R[k] = W.pairR[(size_t)k*L.n_pair + p];
-            double Mf[36];
+                for (int k = 0; k < 9; k++) R[k] = B.pairR[(size_t)k*L.n_pair + p];
+                double Mf[36];
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+                for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int cc = 0; cc < 6; cc++) Mf[r*6 + cc] = M[sym6(r, cc)];
-            double MQ[36];                         // M * blkdiag(R,R)
+                    for (int cc = 0; cc < 6; cc++) Mf[r*6 + cc] = M[sym6(r, cc)];
+                double MQ[36];                         // M * blkdiag(R,R)
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+                for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int half = 0; half < 2; half++)
+                    for (int half = 0; half < 2; half++)
 #pragma unroll
-                    for (int cc = 0; cc < 3; cc++)
-                        MQ[r*6 + half*3 + cc] = Mf[r*6 + half*3]*R[cc] + Mf[r*6 + half*3 + 1]*R[3 + cc] + Mf[r*6 + half*3 + 2]*R[6 + cc];
+                        for (int cc = 0; cc < 3; cc++)
+                            MQ[r*6 + half*3 + cc] = Mf[r*6 + half*3]*R[cc] + Mf[r*6 + half*3 + 1]*R[3 + cc] + Mf[r*6 + half*3 + 2]*R[6 + cc];
 #pragma unroll
-            for (int k = 0; k < 36; k++) out[(size_t)(27 + k)*L.n_pair + p] = MQ[k];
-            // Q^T M Q (symmetric) and Q^T c
+                for (int k = 0; k < 36; k++) out[(size_t)(27 + k)*L.n_pair + p] = MQ[k];
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+                for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int cc = r; cc < 6; cc++) {
-                    int hr = r/3, rr = r % 3;
-                    double v = R[0*3 + rr]*MQ[(hr*3 + 0)*6 + cc] + R[1*3 + rr]*MQ[(hr*3 + 1)*6 + cc] + R[2*3 + rr]*MQ[(hr*3 + 2)*6 + cc];
-                    out[(size_t)(63 + sym6(r, cc))*L.n_pair + p] = v;
-                }
-            double a[3], d[3]; mat3T_vec(R, c, a); mat3T_vec(R, c + 3, d);
-            out[(size_t)84*L.n_pair + p] = a[0]; out[(size_t)85*L.n_pair + p] = a[1]; out[(size_t)86*L.n_pair + p] = a[2];
-            out[(size_t)87*L.n_pair + p] = d[0]; out[(size_t)88*L.n_pair + p] = d[1]; out[(size_t)89*L.n_pair + p] = d[2];
-        }
+                    for (int cc = r; cc < 6; cc++) {
+                        const int hr = r/3, rr = r % 3;
+                        double v = R[0*3 + rr]*MQ[(hr*3 + 0)*6 + cc] + R[1*3 + rr]*MQ[(hr*3 + 1)*6 + cc] + R[2*3 + rr]*MQ[(hr*3 + 2)*6 + cc];
+                        out[(size_t)(63 + sym6(r, cc))*L.n_pair + p] = v;
+                    }
+                double a[3], d[3]; mat3T_vec(R, c, a); mat3T_vec(R, c + 3, d);
+                out[(size_t)84*L.n_pair + p] = a[0]; out[(size_t)85*L.n_pair + p] = a[1]; out[(size_t)86*L.n_pair + p] = a[2];
+                out[(size_t)87*L.n_pair + p] = d[0]; out[(size_t)88*L.n_pair + p] = d[1]; out[(size_t)89*L.n_pair + p] = d[2];
+            }
         }
     }
     gm = block_max<256>(gm, red); xn = block_sum<256>(xn, red);
-    if (threadIdx.x == 0) { W.lmpart[2*b] = gm; W.lmpart[2*b + 1] = xn; }
+    if (threadIdx.x == 0) { B.lmpart[2*b] = gm; B.lmpart[2*b + 1] = xn; }
 }
 
-// ---- after a linearisation: pose diagonal / gradient, Jacobi scaling, cost, gradient tolerance.  One 256-thread block.
-__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm) {
-    LmState *st = W.st;
-    if (st->done || !st->need_lin) return;
-    __shared__ double red[256];
+// ---- after a linearisation: pose diagonal / gradient, Jacobi scaling, cost, gradient tolerance (256 threads of one block).
+// Returns (gmax, |x|^2, cost) to every thread; also writes Hd / bp / dgs_p of the LinBuf.
+__device__ void postlin_body(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm,
+                             double *red, double &gmax, double &xn, double &cost) {
     const int tid = threadIdx.x;
-    double gmax = 0.0, xn = 0.0, cost = 0.0;
-    const double *pose = W.pose[st->cur];
-    const double *out = W.pairOut;
+    gmax = 0.0; xn = 0.0; cost = 0.0;
+    const double *out = B.pairOut;
     for (int a = tid; a < W.n_kf; a += 256) {
         double Hd[6] = {0,0,0,0,0,0}, bp[6] = {0,0,0,0,0,0};
         for (int q = L.pose_t_off[a]; q < L.pose_t_off[a+1]; q++) { int p = L.pose_t[q];
@@ -587,22 +594,29 @@ __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad
         for (int q = L.pose_h_off[a]; q < L.pose_h_off[a+1]; q++) { int p = L.pose_h[q];
 #pragma unroll
             for (int k = 0; k < 6; k++) { Hd[k] += out[(size_t)(63 + sym6(k, k))*L.n_pair + p]; bp[k] -= out[(size_t)(84 + k)*L.n_pair + p]; } }
-        bool fre = W.kf_in[a] && !W.kf_const[a];
+        const bool fre = W.fidx[a] >= 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            W.Hd[6*a + k] = Hd[k]; W.bp[6*a + k] = bp[k];
-            if (st->first) W.sig_p[6*a + k] = 1.0/(1.0 + sqrt(Hd[k]));
-            double sg = W.sig_p[6*a + k];
-            W.dg_p[6*a + k] = clampd(sg*sg*Hd[k], W.min_diag, W.max_diag);
+            B.Hd[6*a + k] = Hd[k]; B.bp[6*a + k] = bp[k];
+            if (first) W.sig_p[6*a + k] = 1.0/(1.0 + sqrt(Hd[k]));
+            const double sg = W.sig_p[6*a + k];
+            B.dgs_p[6*a + k] = clampd(sg*sg*Hd[k], W.min_diag, W.max_diag)/(sg*sg);
             if (fre) gmax = fmax(gmax, fabs(bp[k]));
         }
         if (fre) for (int k = 0; k < 7; k++) xn += pose[7*a + k]*pose[7*a + k];
     }
-    for (int k = tid; k < nb_lm; k += 256) { gmax = fmax(gmax, W.lmpart[2*k]); xn += W.lmpart[2*k + 1]; }
-    for (int p = tid; p < L.n_pair; p += 256) cost += W.pairCost[p];
-    for (int g = tid; g < L.n_tg; g += 256) cost += W.tgCost[g];
+    for (int k = tid; k < nb_lm; k += 256) { gmax = fmax(gmax, B.lmpart[2*k]); xn += B.lmpart[2*k + 1]; }
+    for (int p = tid; p < L.n_pair; p += 256) cost += B.pairCost[p];
+    for (int g = tid; g < L.n_tg; g += 256) cost += B.tgCost[g];
     gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red); cost = block_sum<256>(cost, red);
-    if (tid == 0) {
+}
+__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm) {
+    LmState *st = W.st;
+    if (st->done || !st->need_lin) return;
+    __shared__ double red[256];
+    double gmax, xn, cost;
+    postlin_body(W, L, W.lb[st->lcur], W.pose[st->cur], st->first != 0, nb_lm, red, gmax, xn, cost);
+    if (threadIdx.x == 0) {
         st->x_cost = cost; st->x_norm = sqrt(xn); st->gmax = gmax;
         if (st->first) st->cost0 = cost;
         st->first = 0; st->need_lin = 0; st->n_lin++;
@@ -616,8 +630,9 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
     if (st->done) return;
     __shared__ double lds[36*65];
     const int b = blockIdx.x, lane = threadIdx.x;
-    const double radius = st->radius;
+    const double radius = st->radius, irad = 1.0/radius;
     const int N = W.N;
+    const LinBuf &B = W.lb[st->lcur];
     if (b < L.n_sb) {
         const int a = L.sb_a[b], c = L.sb_b[b];
         const int ia = W.fidx[a], ic = W.fidx[c];           // rows / columns of S exist for free poses only
@@ -626,28 +641,26 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
         for (int q = L.sb_pt_off[b] + lane; q < L.sb_pt_off[b+1]; q += 64) {
-            int s1 = L.sb_pt_s1[q], s2 = L.sb_pt_s2[q], j = L.pslot_lm[s1];
-            double sg = W.sig_pt[j];
-            double vinv = 1.0/(W.V_pt[j] + W.dg_pt[j]/(radius*sg*sg));
+            const int s1 = L.sb_pt_s1[q], s2 = L.sb_pt_s2[q], j = L.sb_pt_lm[q];
+            const double vinv = 1.0/(B.V_pt[j] + B.dgs_pt[j]*irad);
             double w1[6], w2[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { w1[k] = W.w_pt[(size_t)k*L.n_pslot + s1]*vinv; w2[k] = W.w_pt[(size_t)k*L.n_pslot + s2]; }
+            for (int k = 0; k < 6; k++) { w1[k] = B.w_pt[(size_t)k*L.n_pslot + s1]*vinv; w2[k] = B.w_pt[(size_t)k*L.n_pslot + s2]; }
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
                 for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += w1[r]*w2[cc];
         }
         for (int q = L.sb_tx_off[b] + lane; q < L.sb_tx_off[b+1]; q += 64) {
-            int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.tslot_lm[s1];
+            const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
             double Vd[6], Vi[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) Vd[k] = W.V_tx[(size_t)k*W.n_text + j];
-            { double s0 = W.sig_tx[j], s1_ = W.sig_tx[(size_t)W.n_text + j], s2_ = W.sig_tx[(size_t)2*W.n_text + j];
-              Vd[0] += W.dg_tx[j]/(radius*s0*s0); Vd[3] += W.dg_tx[(size_t)W.n_text + j]/(radius*s1_*s1_); Vd[5] += W.dg_tx[(size_t)2*W.n_text + j]/(radius*s2_*s2_); }
+            for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+            Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
             if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
             double W1[18], W2[18];
 #pragma unroll
-            for (int k = 0; k < 18; k++) { W1[k] = W.w_tx[(size_t)k*L.n_tslot + s1]; W2[k] = W.w_tx[(size_t)k*L.n_tslot + s2]; }
+            for (int k = 0; k < 18; k++) { W1[k] = B.w_tx[(size_t)k*L.n_tslot + s1]; W2[k] = B.w_tx[(size_t)k*L.n_tslot + s2]; }
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 double t0 = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
@@ -660,12 +673,12 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
         double tot = wave_sum_to_lane<36>(acc, lds, lane);
         if (lane < 36) {
             const int r = lane/6, cc = lane % 6;
-            const double *out = W.pairOut;
+            const double *out = B.pairOut;
             double v = -tot;
             if (a == c) {
                 for (int q = L.pose_t_off[a]; q < L.pose_t_off[a+1]; q++) v += out[(size_t)sym6(r, cc)*L.n_pair + L.pose_t[q]];
                 for (int q = L.pose_h_off[a]; q < L.pose_h_off[a+1]; q++) v += out[(size_t)(63 + sym6(r, cc))*L.n_pair + L.pose_h[q]];
-                if (r == cc) { double sg = W.sig_p[6*a + r]; v += W.dg_p[6*a + r]/(radius*sg*sg); }
+                if (r == cc) v += B.dgs_p[6*a + r]*irad;
             } else {
                 int pab = L.sb_pab[b], pba = L.sb_pba[b];
                 if (pab >= 0) v -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
@@ -680,25 +693,23 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
         if (ia < 0) return;
         double acc[6] = {0,0,0,0,0,0};
         for (int q = L.pose_ps_off[a] + lane; q < L.pose_ps_off[a+1]; q += 64) {
-            int s = L.pose_ps[q], j = L.pslot_lm[s];
-            double sg = W.sig_pt[j];
-            double f = W.b_pt[j]/(W.V_pt[j] + W.dg_pt[j]/(radius*sg*sg));
+            const int s = L.pose_ps[q], j = L.pose_ps_lm[q];
+            const double f = B.b_pt[j]/(B.V_pt[j] + B.dgs_pt[j]*irad);
 #pragma unroll
-            for (int k = 0; k < 6; k++) acc[k] += W.w_pt[(size_t)k*L.n_pslot + s]*f;
+            for (int k = 0; k < 6; k++) acc[k] += B.w_pt[(size_t)k*L.n_pslot + s]*f;
         }
         for (int q = L.pose_ts_off[a] + lane; q < L.pose_ts_off[a+1]; q += 64) {
-            int s = L.pose_ts[q], j = L.tslot_lm[s];
+            const int s = L.pose_ts[q], j = L.pose_ts_lm[q];
             double Vd[6], Vi[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) Vd[k] = W.V_tx[(size_t)k*W.n_text + j];
-            { double s0 = W.sig_tx[j], s1_ = W.sig_tx[(size_t)W.n_text + j], s2_ = W.sig_tx[(size_t)2*W.n_text + j];
-              Vd[0] += W.dg_tx[j]/(radius*s0*s0); Vd[3] += W.dg_tx[(size_t)W.n_text + j]/(radius*s1_*s1_); Vd[5] += W.dg_tx[(size_t)2*W.n_text + j]/(radius*s2_*s2_); }
+            for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+            Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
             if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
-            double b0 = W.b_tx[j], b1 = W.b_tx[(size_t)W.n_text + j], b2 = W.b_tx[(size_t)2*W.n_text + j];
+            double b0 = B.b_tx[j], b1 = B.b_tx[(size_t)W.n_text + j], b2 = B.b_tx[(size_t)2*W.n_text + j];
             double f0 = Vi[0]*b0 + Vi[1]*b1 + Vi[2]*b2, f1 = Vi[1]*b0 + Vi[3]*b1 + Vi[4]*b2, f2 = Vi[2]*b0 + Vi[4]*b1 + Vi[5]*b2;
 #pragma unroll
             for (int k = 0; k < 6; k++)
-                acc[k] += W.w_tx[(size_t)(k*3)*L.n_tslot + s]*f0 + W.w_tx[(size_t)(k*3 + 1)*L.n_tslot + s]*f1 + W.w_tx[(size_t)(k*3 + 2)*L.n_tslot + s]*f2;
+                acc[k] += B.w_tx[(size_t)(k*3)*L.n_tslot + s]*f0 + B.w_tx[(size_t)(k*3 + 1)*L.n_tslot + s]*f1 + B.w_tx[(size_t)(k*3 + 2)*L.n_tslot + s]*f2;
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) acc[k] = wave_sum1(acc[k]);
@@ -706,257 +717,12 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
             double v = acc[0];
 #pragma unroll
             for (int k = 1; k < 6; k++) if (lane == k) v = acc[k];
-            W.g[6*ia + lane] = W.bp[6*a + lane] - v;
+            W.g[6*ia + lane] = B.bp[6*a + lane] - v;
         }
     }
 }
 
-// ---- dense solve of S dp = -g for the free poses: blocked (6x6) LDL^T in LDS, one workgroup of 16 waves.
-// A = [S; g^T] is held as (n+1) rows; the right-hand side rides along as an extra panel row, so the forward
-// substitution is part of the factorisation.  Per 6x6 block column: every thread factors the diagonal block redundantly
-// in registers (no division chain: one reciprocal per pivot), one thread per row solves the panel, then 6 threads per
-// 6x6 block apply the rank-6 trailing update.
-#define SOLVE_THREADS 1024
-__device__ __forceinline__ void ldl6(const double *A, int ld, double l[15], double d[6], double id[6], bool &bad) {
-    // lower 6x6 at A (row stride ld) -> unit-lower l (packed rows: (1,0) (2,0) (2,1) (3,0) ...), d, 1/d
-    double a[21];
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c <= r; c++) a[r*(r+1)/2 + c] = A[(size_t)r*ld + c];
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-        double dc = a[c*(c+1)/2 + c];
-#pragma unroll
-        for (int k = 0; k < c; k++) dc -= l[c*(c-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
-        if (!(dc > 0.0)) { bad = true; dc = 1.0; }
-        d[c] = dc; id[c] = 1.0/dc;
-#pragma unroll
-        for (int r = c + 1; r < 6; r++) {
-            double v = a[r*(r+1)/2 + c];
-#pragma unroll
-            for (int k = 0; k < c; k++) v -= l[r*(r-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
-            l[r*(r-1)/2 + c] = v*id[c];
-        }
-    }
-}
-typedef double v4d __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double rcp_nr(double d) {        // v_rcp_f64 + two Newton steps (d > 0, normal range)
-    double x = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, x, 1.0); x = fma(x, e, x);
-    e = fma(-d, x, 1.0); x = fma(x, e, x);
-    return x;
-}
-__device__ __forceinline__ double readlane_f64(double v, int src) {   // src must be wave-uniform
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-// Look-ahead schedule, one barrier per block column jb:
-//   wave 0 ("F"):  LDL^T of the diagonal block jb (registers) -> panel jb (rows below + rhs row) -> barrier
-//                  -> applies panel jb to block column jb+1 only, then goes straight on to factor block jb+1
-//   waves 1..15 ("T"): after the barrier, trailing update of the columns >= jb+2 with panel jb on the matrix cores
-template <bool use_lds>
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W) {
-    LmState *st = W.st;
-    if (st->done) return;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long T0 = clock64();
-    const int nfree = *W.nfree, n = 6*nfree, Nmax = W.N;
-    const int ld = use_lds ? (n | 1) : Nmax;
-    // separate instantiations keep LDS accesses as ds_* instructions (a runtime-selected pointer would go through FLAT)
-    auto sel = [&](auto lds_ptr, double *glob) { if constexpr (use_lds) return lds_ptr; else return glob; };
-    auto A = sel(smem, W.S);                                            // rows 0..n, row n = right-hand side g
-    auto LD = sel(smem + (size_t)(n + 1)*ld, W.LDbuf);                  // per block: 15 l, 6 d, 6 1/d (stride 32)
-    if (use_lds) {
-        for (int r = tid >> 5; r < n; r += SOLVE_THREADS/32)
-            for (int cidx = tid & 31; cidx <= r; cidx += 32) A[(size_t)r*ld + cidx] = W.S[(size_t)r*Nmax + cidx];
-    }
-    for (int k = tid; k < n; k += SOLVE_THREADS) A[(size_t)n*ld + k] = W.g[k];
-    __shared__ int fail;
-    if (tid == 0) fail = st->step_fail;
-    __syncthreads();
-    long long T1 = clock64();
-    for (int jb = 0; jb < nfree; jb++) {
-        const int j0 = 6*jb, R0 = j0 + 6;
-        if (wave == 0) {
-            if (jb > 0) {
-                // look-ahead: apply panel jb-1 (columns j0-6..j0-1) to block column jb (columns j0..j0+5), rows j0..n
-                const int p0 = j0 - 6;
-                double dprev[6], Lk[36];
-#pragma unroll
-                for (int k = 0; k < 6; k++) dprev[k] = LD[32*(jb - 1) + 15 + k];
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-#pragma unroll
-                    for (int k = 0; k < 6; k++) Lk[c*6 + k] = A[(size_t)(j0 + c)*ld + p0 + k];
-                for (int i = j0 + lane; i <= n; i += 64) {
-                    auto row = A + (size_t)i*ld;
-                    double y[6];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) y[k] = row[p0 + k]*dprev[k];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int k = 0; k < 6; k++) v += y[k]*Lk[c*6 + k];
-                        if (i >= j0 + c) row[j0 + c] -= v;
-                    }
-                }
-            }
-            if (!fail) {
-                // LDL^T of the 6x6 diagonal block in registers (every lane redundantly), reciprocal pivots
-                double a[21], l[15], d[6], id[6]; bool bad = false;
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int c = 0; c <= r; c++) a[r*(r+1)/2 + c] = A[(size_t)(j0 + r)*ld + j0 + c];
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    double dc = a[c*(c+1)/2 + c];
-#pragma unroll
-                    for (int k = 0; k < c; k++) dc -= l[c*(c-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
-                    if (!(dc > 0.0)) { bad = true; dc = 1.0; }
-                    d[c] = dc; id[c] = rcp_nr(dc);
-#pragma unroll
-                    for (int r = c + 1; r < 6; r++) {
-                        double v = a[r*(r+1)/2 + c];
-#pragma unroll
-                        for (int k = 0; k < c; k++) v -= l[r*(r-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
-                        l[r*(r-1)/2 + c] = v*id[c];
-                    }
-                }
-                if (lane == 0) {
-                    if (bad) { fail = 1; st->step_fail = 1; }
-                    auto o = LD + 32*jb;
-#pragma unroll
-                    for (int k = 0; k < 15; k++) o[k] = l[k];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) { o[15 + k] = d[k]; o[21 + k] = id[k]; }
-                }
-                for (int i = R0 + lane; i <= n; i += 64) {      // panel rows incl. the rhs row: x L^T = a, l_row = x D^-1
-                    auto row = A + (size_t)i*ld + j0;
-                    double x[6];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        double v = row[c];
-#pragma unroll
-                        for (int k = 0; k < c; k++) v -= x[k]*l[c*(c-1)/2 + k];
-                        x[c] = v;
-                    }
-#pragma unroll
-                    for (int c = 0; c < 6; c++) row[c] = x[c]*id[c];
-                }
-            }
-        }
-        __syncthreads();                       // panel jb complete; trailing update jb-1 complete
-        if (fail) break;
-        if (wave > 0) {
-            // trailing update with panel jb on columns >= j0+12 (block column jb+1 is wave 0's look-ahead), rows >= j0+12 and rhs
-            const int C0 = j0 + 12;
-            const int mr = n - C0 + 1, mc = n - C0;
-            if (mc > 0) {
-                const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4;
-                const int lr = lane & 15, lk = lane >> 4;
-                const double dk0 = LD[32*jb + 15 + lk], dk1 = (4 + lk < 6) ? LD[32*jb + 15 + 4 + lk] : 0.0;
-                int t = wave - 1;
-                for (int ti = 0; ti < ntr; ti++) for (int tj = 0; tj <= ti && tj < ntc; tj++) {
-                    if (t-- != 0) continue;
-                    t = SOLVE_THREADS/64 - 2;               // next tile of this wave: 15 tiles further
-                    const int arow = C0 + 16*ti + lr, bcol = C0 + 16*tj + lr;
-                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-                    if (arow <= n) { a0 = -A[(size_t)arow*ld + j0 + lk]; if (4 + lk < 6) a1 = -A[(size_t)arow*ld + j0 + 4 + lk]; }
-                    if (bcol < n)  { b0 = A[(size_t)bcol*ld + j0 + lk]*dk0; if (4 + lk < 6) b1 = A[(size_t)bcol*ld + j0 + 4 + lk]*dk1; }
-                    v4d c;
-                    const int ccol = C0 + 16*tj + lr;
-                    bool ok[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int crow = C0 + 16*ti + lk + 4*r;
-                        ok[r] = crow <= n && ccol < n && (ccol <= crow);
-                        c[r] = ok[r] ? A[(size_t)crow*ld + ccol] : 0.0;
-                    }
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int crow = C0 + 16*ti + lk + 4*r;
-                        if (ok[r]) A[(size_t)crow*ld + ccol] = c[r];
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    long long T2 = clock64();
-    if (fail) { for (int k = tid; k < Nmax; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
-    // back substitution L^T x = z (z = D^-1 L^-1 g sits in row n): wave 0, solution kept in registers (rows lane, lane+64, ...)
-    auto rhs = A + (size_t)n*ld;
-    if (wave == 0) {
-        if (n <= 128) {
-            double z0 = lane < n ? rhs[lane] : 0.0, z1 = lane + 64 < n ? rhs[lane + 64] : 0.0;
-            for (int jb = nfree - 1; jb >= 0; jb--) {
-                const int j0 = 6*jb;
-                auto l = LD + 32*jb;
-                double x[6];
-#pragma unroll
-                for (int c = 0; c < 6; c++) { int r = j0 + c; x[c] = r < 64 ? readlane_f64(z0, r) : readlane_f64(z1, r - 64); }
-#pragma unroll
-                for (int c = 4; c >= 0; c--) {
-#pragma unroll
-                    for (int k = c + 1; k < 6; k++) x[c] -= l[k*(k-1)/2 + c]*x[k];
-                }
-#pragma unroll
-                for (int c = 0; c < 6; c++) { if (lane == ((j0 + c) & 63)) { if (j0 + c < 64) z0 = x[c]; else z1 = x[c]; } }
-                if (lane < j0) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 6; c++) v += A[(size_t)(j0 + c)*ld + lane]*x[c];
-                    z0 -= v;
-                }
-                if (lane + 64 < j0) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 6; c++) v += A[(size_t)(j0 + c)*ld + lane + 64]*x[c];
-                    z1 -= v;
-                }
-            }
-            if (lane < n) rhs[lane] = z0;
-            if (lane + 64 < n) rhs[lane + 64] = z1;
-        } else {
-            for (int jb = nfree - 1; jb >= 0; jb--) {
-                const int j0 = 6*jb;
-                auto l = LD + 32*jb;
-                double x[6];
-#pragma unroll
-                for (int c = 5; c >= 0; c--) {
-                    double v = rhs[j0 + c];
-#pragma unroll
-                    for (int k = c + 1; k < 6; k++) v -= l[k*(k-1)/2 + c]*x[k];
-                    x[c] = v;
-                }
-                for (int k = lane; k < j0; k += 64) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 6; c++) v += A[(size_t)(j0 + c)*ld + k]*x[c];
-                    rhs[k] -= v;
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int c = 0; c < 6; c++) rhs[j0 + c] = x[c];
-                }
-                __threadfence_block();
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) { long long T3 = clock64(); W.dbg[0] = T1 - T0; W.dbg[1] = T2 - T1; W.dbg[2] = T3 - T2; W.dbg[3] = 0; W.dbg[4] = 0; W.dbg[5] = 0; W.dbg[6] = nfree; }
-    for (int a = tid; a < W.n_kf; a += SOLVE_THREADS) {
-        int ia = W.fidx[a];
-#pragma unroll
-        for (int k = 0; k < 6; k++) W.dp[6*a + k] = ia >= 0 ? -rhs[6*ia + k] : 0.0;
-    }
-}
+#include "tsba_solve.h"
 
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
 __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
@@ -964,8 +730,9 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
     if (st->done) return;
     __shared__ double red[256];
     const int b = blockIdx.x, tid = threadIdx.x, cur = st->cur;
-    const double radius = st->radius;
+    const double irad = 1.0/st->radius;
     const bool fail = st->step_fail;
+    const LinBuf &B = W.lb[st->lcur];
     double step2 = 0.0, mcc = 0.0;
     if (b < nb_pt) {
         int j = b*256 + tid;
@@ -973,14 +740,13 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
             double rh = W.rho[cur][j], d = 0.0;
             int o = L.pls_off[j], e = L.pls_off[j+1];
             if (!fail && e > o && W.act_pt[j]) {
-                double acc = W.b_pt[j];
-                for (int s = o; s < e; s++) { int a = L.pslot_pose[s];
-                    if (W.kf_in[a] && !W.kf_const[a]) {
+                double acc = B.b_pt[j];
+                for (int s = o; s < e; s++) { const int a = L.pslot_pose[s];       // dp is 0 for constant / absent poses
 #pragma unroll
-                        for (int k = 0; k < 6; k++) acc += W.w_pt[(size_t)k*L.n_pslot + s]*W.dp[6*a + k]; } }
-                double sg = W.sig_pt[j], lam = W.dg_pt[j]/(radius*sg*sg);
-                d = -acc/(W.V_pt[j] + lam);
-                step2 = d*d; mcc = lam*d*d - W.b_pt[j]*d;
+                    for (int k = 0; k < 6; k++) acc += B.w_pt[(size_t)k*L.n_pslot + s]*W.dp[6*a + k]; }
+                const double lam = B.dgs_pt[j]*irad;
+                d = -acc/(B.V_pt[j] + lam);
+                step2 = d*d; mcc = lam*d*d - B.b_pt[j]*d;
             }
             W.rho[cur ^ 1][j] = rh + d;
         }
@@ -990,23 +756,22 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
             double d[3] = {0,0,0};
             int o = L.tls_off[j], e = L.tls_off[j+1];
             if (!fail && e > o && W.act_tx[j]) {
-                double acc[3] = { W.b_tx[j], W.b_tx[(size_t)W.n_text + j], W.b_tx[(size_t)2*W.n_text + j] };
-                for (int s = o; s < e; s++) { int a = L.tslot_pose[s];
-                    if (W.kf_in[a] && !W.kf_const[a]) {
+                double acc[3] = { B.b_tx[j], B.b_tx[(size_t)W.n_text + j], B.b_tx[(size_t)2*W.n_text + j] };
+                for (int s = o; s < e; s++) { const int a = L.tslot_pose[s];
 #pragma unroll
-                        for (int k = 0; k < 6; k++) { double dpk = W.dp[6*a + k];
-                            acc[0] += W.w_tx[(size_t)(k*3)*L.n_tslot + s]*dpk; acc[1] += W.w_tx[(size_t)(k*3 + 1)*L.n_tslot + s]*dpk; acc[2] += W.w_tx[(size_t)(k*3 + 2)*L.n_tslot + s]*dpk; } } }
+                    for (int k = 0; k < 6; k++) { const double dpk = W.dp[6*a + k];
+                        acc[0] += B.w_tx[(size_t)(k*3)*L.n_tslot + s]*dpk; acc[1] += B.w_tx[(size_t)(k*3 + 1)*L.n_tslot + s]*dpk; acc[2] += B.w_tx[(size_t)(k*3 + 2)*L.n_tslot + s]*dpk; } }
                 double Vd[6], Vi[6], lam[3];
 #pragma unroll
-                for (int k = 0; k < 6; k++) Vd[k] = W.V_tx[(size_t)k*W.n_text + j];
+                for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
 #pragma unroll
-                for (int k = 0; k < 3; k++) { double sg = W.sig_tx[(size_t)k*W.n_text + j]; lam[k] = W.dg_tx[(size_t)k*W.n_text + j]/(radius*sg*sg); }
+                for (int k = 0; k < 3; k++) lam[k] = B.dgs_tx[(size_t)k*W.n_text + j]*irad;
                 Vd[0] += lam[0]; Vd[3] += lam[1]; Vd[5] += lam[2];
                 if (inv_sym3(Vd, Vi)) {
                     d[0] = -(Vi[0]*acc[0] + Vi[1]*acc[1] + Vi[2]*acc[2]);
                     d[1] = -(Vi[1]*acc[0] + Vi[3]*acc[1] + Vi[4]*acc[2]);
                     d[2] = -(Vi[2]*acc[0] + Vi[4]*acc[1] + Vi[5]*acc[2]);
-                    for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - W.b_tx[(size_t)k*W.n_text + j]*d[k]; }
+                    for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - B.b_tx[(size_t)k*W.n_text + j]*d[k]; }
                 }
             }
             for (int k = 0; k < 3; k++) W.theta[cur ^ 1][3*j + k] = W.theta[cur][3*j + k] + d[k];
@@ -1015,7 +780,7 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
         int a = (b - nb_pt - nb_tx)*256 + tid;
         if (a < W.n_kf) {
             const double *x = W.pose[cur] + 7*a; double *c = W.pose[cur ^ 1] + 7*a;
-            if (!fail && W.kf_in[a] && !W.kf_const[a]) {
+            if (!fail && W.fidx[a] >= 0) {
                 double d[6];
 #pragma unroll
                 for (int k = 0; k < 6; k++) d[k] = W.dp[6*a + k];
@@ -1023,7 +788,7 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
                 quat_plus(q, d, qn);
                 for (int k = 0; k < 4; k++) { c[k] = qn[k]; step2 += (qn[k] - q[k])*(qn[k] - q[k]); }
                 for (int k = 0; k < 3; k++) { c[4 + k] = x[4 + k] + d[3 + k]; step2 += d[3 + k]*d[3 + k]; }
-                for (int k = 0; k < 6; k++) { double sg = W.sig_p[6*a + k]; double lam = W.dg_p[6*a + k]/(radius*sg*sg); mcc += lam*d[k]*d[k] - W.bp[6*a + k]*d[k]; }
+                for (int k = 0; k < 6; k++) { const double lam = B.dgs_p[6*a + k]*irad; mcc += lam*d[k]*d[k] - B.bp[6*a + k]*d[k]; }
             } else for (int k = 0; k < 7; k++) c[k] = x[k];
         }
     }
@@ -1032,21 +797,23 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
 }
 
 // ---- step quality and trust-region update (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics)
-__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, tsba_options o) {
+__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o) {
     LmState *st = W.st;
     if (st->done) return;
     __shared__ double red[256];
     const int tid = threadIdx.x;
-    double cost = 0.0, step2 = 0.0, mcc = 0.0;
-    for (int p = tid; p < L.n_pair; p += 256) cost += W.pairCost2[p];
-    for (int g = tid; g < L.n_tg; g += 256) cost += W.tgCost2[g];
+    // the candidate was linearised speculatively into lb[lcur^1]: its cost, gradient and diagonals are already there
+    const LinBuf &Bc = W.lb[st->lcur ^ 1];
+    double gmax_c, xn_c, cost;
+    postlin_body(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, red, gmax_c, xn_c, cost);
+    double step2 = 0.0, mcc = 0.0;
     for (int k = tid; k < nb_back; k += 256) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
-    cost = block_sum<256>(cost, red); step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
     if (tid) return;
     mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
     st->it++;
     st->cand_cost = cost; st->model_change = mcc; st->step_norm = sqrt(step2);
-    if (st->step_fail || !(mcc > 0.0)) {          // invalid step
+    if (st->step_fail || !(mcc > 0.0)) {          // invalid step (LevenbergMarquardtStrategy::StepIsInvalid)
         st->step_fail = 0;
         if (++st->invalid >= 5) { st->done = 1; st->term = 5; return; }
         st->radius *= 0.5;
@@ -1057,11 +824,13 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
         double cost_change = st->x_cost - cost;
         if (fabs(cost_change) <= o.function_tolerance*st->x_cost) { st->done = 1; st->term = 1; return; }
         double rel = cost_change/mcc;
-        if (rel > o.min_relative_decrease) {
-            st->cur ^= 1; st->need_lin = 1; st->accepted++; st->x_cost = cost;
+        if (rel > o.min_relative_decrease) {      // accept: the speculative linearisation becomes the current one
+            st->cur ^= 1; st->lcur ^= 1; st->accepted++; st->n_lin++;
+            st->x_cost = cost; st->x_norm = sqrt(xn_c); st->gmax = gmax_c;
             double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
             st->radius = fmin(st->radius/f, o.max_radius);
             st->decrease_factor = 2.0;
+            if (gmax_c <= o.gradient_tolerance) { st->done = 1; st->term = 3; return; }
         } else {
             st->radius = st->radius/st->decrease_factor; st->decrease_factor *= 2.0;
         }
@@ -1363,8 +1132,8 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         UV(pair_i); UV(pair_h); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
         UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
         UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
-        UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2);
-        UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ts_off); UV(pose_ts);
+        UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
+        UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ps_lm); UV(pose_ts_off); UV(pose_ts); UV(pose_ts_lm);
         if (p->n_text > 0 && p->tfeat_off[l]) {
             D.n_tfeat = p->n_tfeat[l];
             UP(D.tfeat_off, p->tfeat_off[l], (size_t)p->n_text + 1); UP(D.tfeat_raw, p->tfeat_raw[l], p->n_tfeat[l]);
@@ -1388,15 +1157,19 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         mx_pair = std::max(mx_pair, (size_t)D.n_pair); mx_tg = std::max(mx_tg, (size_t)D.n_tg);
         mx_pslot = std::max(mx_pslot, (size_t)D.n_pslot); mx_tslot = std::max(mx_tslot, (size_t)D.n_tslot);
     }
-    AL(W.pairM, 27*mx_pair); AL(W.pairCost, mx_pair); AL(W.pairCost2, mx_pair); AL(W.pairR, 9*mx_pair); AL(W.pairOut, 90*mx_pair);
-    AL(W.tgM, 27*mx_tg); AL(W.tgCost, mx_tg); AL(W.tgCost2, mx_tg);
-    AL(W.w_pt, 6*mx_pslot); AL(W.vb_pt, 2*mx_pslot); AL(W.V_pt, p->n_pt); AL(W.b_pt, p->n_pt); AL(W.sig_pt, p->n_pt); AL(W.dg_pt, p->n_pt);
-    AL(W.w_tx, 18*mx_tslot); AL(W.vb_tx, 9*mx_tslot); AL(W.V_tx, 6*(size_t)p->n_text); AL(W.b_tx, 3*(size_t)p->n_text); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.dg_tx, 3*(size_t)p->n_text);
-    AL(W.Hd, W.N); AL(W.bp, W.N); AL(W.sig_p, W.N); AL(W.dg_p, W.N);
-    AL(W.S, (size_t)(W.N + 1)*W.N); AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     c->nb_back_max = (p->n_pt + 255)/256 + (p->n_text + 255)/256 + (p->n_kf + 255)/256;
+    for (int b = 0; b < 2; b++) {
+        LinBuf &B = W.lb[b];
+        AL(B.pairM, 27*mx_pair); AL(B.pairCost, mx_pair); AL(B.pairR, 9*mx_pair); AL(B.pairOut, 90*mx_pair);
+        AL(B.tgM, 27*mx_tg); AL(B.tgCost, mx_tg);
+        AL(B.w_pt, 6*mx_pslot); AL(B.vb_pt, 8*mx_pslot); AL(B.V_pt, p->n_pt); AL(B.b_pt, p->n_pt); AL(B.dgs_pt, p->n_pt);
+        AL(B.w_tx, 18*mx_tslot); AL(B.vb_tx, 27*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
+        AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.dgs_p, W.N);
+        AL(B.lmpart, 2*((size_t)c->nb_back_max + mx_pair/256 + 2));
+    }
+    AL(W.sig_pt, p->n_pt); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.sig_p, W.N);
+    AL(W.S, (size_t)(W.N + 1)*W.N); AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
-    AL(W.lmpart, 2*((size_t)c->nb_back_max + mx_pair/256 + 2));
     AL(W.st, 1);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err(c, "upload sync failed"); return TSBA_ERR_DEVICE; }
     c->uploaded = true;
@@ -1426,29 +1199,31 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state);
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
-static void launch_linearize(Ctx *c, const LevelDev &D) {
+static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256;
-    if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D);
-    hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
-    hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx);
+    if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D, spec);
+    hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr);
 }
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
     size_t N = c->W.N, ld = N | 1, bytes = ((N + 1)*ld + 32*(N/6) + 8)*sizeof(double);     // worst case: every pose free
     *use_lds = bytes <= 150*1024;
     return *use_lds ? (int)bytes : 0;
 }
+// one LM iteration: reduced system -> pose step -> back-substitution / candidate -> speculative linearisation at the
+// candidate -> decision (on acceptance the speculative LinBuf simply becomes the current one)
 static void launch_step(Ctx *c, const LevelDev &D) {
     Work &W = c->W;
-    int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256;
+    int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);   // block-sparse S
     hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
     if (use_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W);
     else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, W);
     hipLaunchKernelGGL(k_back, dim3(nb_pt + nb_tx + nb_kf), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
-    if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_COST>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, c->opt);
+    launch_linearize(c, D, 1);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx + nb_pr, c->opt);
 }
 
 int tsba_solve(void *ctx, tsba_report *r) {
@@ -1464,8 +1239,8 @@ int tsba_solve(void *ctx, tsba_report *r) {
     for (int ps = 0; ps < o.n_passes; ps++) {
         const LevelDev &D = c->lev[o.levels[ps]];
         launch_pass_init(c, D, ps);
-        launch_linearize(c, D);
-        for (int it = 0; it < o.its[ps]; it++) { launch_step(c, D); launch_linearize(c, D); }
+        launch_linearize(c, D, 0);
+        for (int it = 0; it < o.its[ps]; it++) launch_step(c, D);
         if (o.outlier_scene || o.outlier_text)
             if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, c->W, D,
                                                           o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
@@ -1583,7 +1358,7 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     launch_pass_init(c, D, 0);
-    launch_linearize(c, D);
+    launch_linearize(c, D, 0);
     Work &W = c->W;
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
     hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
@@ -1610,13 +1385,13 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     const LevelDev &D = c->lev[level];
     int ps = 0; for (int k = 0; k < c->opt.n_passes; k++) if (c->opt.levels[k] == level) ps = k;
     launch_pass_init(c, D, ps);
-    launch_linearize(c, D);                                    // warm-up (also leaves need_lin = 0)
+    launch_linearize(c, D, 0);                                 // warm-up (also leaves need_lin = 0)
     CK(hipStreamSynchronize(c->stream));
     LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
     st.need_lin = 1; st.done = 0; st.first = 0;
     CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));   // k_linearize never clears need_lin itself
     CK(hipEventRecord(c->ev0, c->stream));
-    for (int k = 0; k < n; k++) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, c->W, D);
+    for (int k = 0; k < n; k++) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, c->W, D, 0);
     CK(hipEventRecord(c->ev1, c->stream));
     CK(hipEventSynchronize(c->ev1));
     float ms = 0; CK(hipEventElapsedTime(&ms, c->ev0, c->ev1));

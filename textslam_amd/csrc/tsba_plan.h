@@ -30,10 +30,10 @@ struct HostPlan {
     std::vector<int32_t> tls_off, tslot_pose, tslot_pair, tslot_lm;     // text planes
     // reduced-system blocks
     std::vector<int32_t> sb_a, sb_b, sb_pab, sb_pba;
-    std::vector<int32_t> sb_pt_off, sb_pt_s1, sb_pt_s2, sb_tx_off, sb_tx_s1, sb_tx_s2;
+    std::vector<int32_t> sb_pt_off, sb_pt_s1, sb_pt_s2, sb_pt_lm, sb_tx_off, sb_tx_s1, sb_tx_s2, sb_tx_lm;
     // per pose: pairs where it is target / host; slots it owns
     std::vector<int32_t> pose_t_off, pose_t, pose_h_off, pose_h;
-    std::vector<int32_t> pose_ps_off, pose_ps, pose_ts_off, pose_ts;
+    std::vector<int32_t> pose_ps_off, pose_ps, pose_ps_lm, pose_ts_off, pose_ts, pose_ts_lm;
     // text blocks flattened (group, feature) for the eval hook / outlier pass
     int n_sc() const { return (int)sc_obs.size(); }
     int n_pair() const { return (int)pair_i.size(); }
@@ -160,6 +160,9 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     };
     fill_tri(tp, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2);
     fill_tri(tt, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2);
+    P.sb_pt_lm.resize(P.sb_pt_s1.size()); P.sb_tx_lm.resize(P.sb_tx_s1.size());      // saves one dependent gather in k_schur
+    for (size_t k = 0; k < P.sb_pt_s1.size(); k++) P.sb_pt_lm[k] = P.pslot_lm[P.sb_pt_s1[k]];
+    for (size_t k = 0; k < P.sb_tx_s1.size(); k++) P.sb_tx_lm[k] = P.tslot_lm[P.sb_tx_s1[k]];
     // ---- per-pose lists
     auto csr = [&](int n, const std::vector<std::pair<int,int>> &items, std::vector<int32_t> &off, std::vector<int32_t> &val) {
         off.assign(n + 1, 0); val.resize(items.size());
@@ -174,4 +177,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     for (int s = 0; s < P.n_tslot(); s++) it_ts.push_back({ P.tslot_pose[s], s });
     csr(n_kf, it_t, P.pose_t_off, P.pose_t); csr(n_kf, it_h, P.pose_h_off, P.pose_h);
     csr(n_kf, it_ps, P.pose_ps_off, P.pose_ps); csr(n_kf, it_ts, P.pose_ts_off, P.pose_ts);
+    P.pose_ps_lm.resize(P.pose_ps.size()); P.pose_ts_lm.resize(P.pose_ts.size());
+    for (size_t k = 0; k < P.pose_ps.size(); k++) P.pose_ps_lm[k] = P.pslot_lm[P.pose_ps[k]];
+    for (size_t k = 0; k < P.pose_ts.size(); k++) P.pose_ts_lm[k] = P.tslot_lm[P.pose_ts[k]];
 }
