@@ -187,7 +187,11 @@ int  tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, d
 int  tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *algo_bytes);
 
 /* ---- multi-GPU: RCCL communicator for tsba_global_ba (one process per GPU) ---- */
-int  tsba_comm_unique_id(void *id128);                       /* rank 0: fills 128 bytes */
+/* One process per GPU.  Rank 0 calls tsba_comm_unique_id and broadcasts the 128 bytes (e.g. torch.distributed); every rank
+ * then calls tsba_comm_init.  Afterwards tsba_upload keeps only this rank's landmarks (j mod world == rank, all poses
+ * replicated) and tsba_solve all-reduces the reduced normal equations S, g (and a few scalars) once per LM trial.
+ * id128 == NULL selects the split (multi-GPU) kernel sequence without a communicator (single-process test hook). */
+int  tsba_comm_unique_id(void *ctx, void *id128);
 int  tsba_comm_init(void *ctx, const void *id128, int rank, int world);
 
 #ifdef __cplusplus

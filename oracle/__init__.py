@@ -39,6 +39,9 @@ def lib():
         L.tsba_oracle_reduced_system.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, C.c_double,
                                                  ip, dp, dp, dp, dp, dp]
         L.tsba_oracle_reduced_system.restype = C.c_int
+        L.tsba_oracle_partial_system.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, C.c_double,
+                                                 ip, dp, dp, dp, dp]
+        L.tsba_oracle_partial_system.restype = C.c_int
         L.tsba_oracle_default_options.argtypes = [C.POINTER(TsbaOptions), C.c_int]
         L.tsba_oracle_default_options.restype = None
         _LIB = L
@@ -114,3 +117,17 @@ def reduced_system(prob: BAProblem, opt: TsbaOptions, level: int, radius: float)
     m = 6 * nf
     return {"nf": nf, "free_idx": free, "S": S[:m * m].reshape(m, m), "g": g[:m], "Hpp": Hpp[:m * m].reshape(m, m),
             "bp": bp[:m], "cost": cost.value}
+
+
+def partial_system(prob: BAProblem, opt: TsbaOptions, level: int, radius: float):
+    """One rank's (opt.lm_shard of opt.lm_nshard) contribution to S, g, diag(H_pp) before the all-reduce."""
+    n6 = 6 * prob.n_kf
+    S, g, Hd = np.zeros(n6 * n6), np.zeros(n6), np.zeros(n6)
+    free = np.zeros(prob.n_kf, np.int32)
+    cost = C.c_double(0)
+    s = prob.struct()
+    nf = lib().tsba_oracle_partial_system(C.byref(s), C.byref(opt), level, radius,
+                                          free.ctypes.data_as(C.POINTER(C.c_int32)), _dp(S), _dp(g), _dp(Hd), C.byref(cost))
+    assert nf >= 0, nf
+    m = 6 * nf
+    return {"nf": nf, "free_idx": free, "S": S[:m * m].reshape(m, m), "g": g[:m], "Hd": Hd[:m], "cost": cost.value}

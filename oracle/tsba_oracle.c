@@ -845,6 +845,31 @@ int tsba_oracle_reduced_system(const tsba_problem *p, const tsba_options *o, int
     return rc ? TSBA_ERR_NUMERIC : nf;
 }
 
+/* Multi-GPU restatement: what ONE rank (options.lm_shard of lm_nshard) contributes to the reduced normal equations before the
+ * all-reduce: S_part = H_pp,part - sum_{own landmarks} W (V + Lambda_l)^-1 W^T (no pose damping, unscaled pose coordinates),
+ * g_part, diag(H_pp,part) and the partial cost.  Summing the parts over the ranks and adding the pose damping
+ * Lambda_p = clamp(s^2 Hd)/(radius s^2), s = 1/(1+sqrt(Hd)), reproduces tsba_oracle_reduced_system of the unsharded problem. */
+int tsba_oracle_partial_system(const tsba_problem *p, const tsba_options *o, int level, double radius,
+                               int32_t *free_idx, double *S, double *g, double *Hd, double *cost) {
+    if (!p || !o || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
+    pass_t P; pass_build(&P, p, o, level);
+    neq_t N; neq_alloc(&N, &P);
+    linearize(&P, p->pose, p->rho, p->theta, &N, NULL);
+    int n6 = 6*N.nf;
+    double *sp = (double *)malloc(sizeof(double)*(n6 + 1)), *dgp = (double *)calloc(n6 + 1, sizeof(double));
+    double *sl = (double *)malloc(sizeof(double)*(3*(size_t)N.nlm + 1)), *dgl = (double *)malloc(sizeof(double)*(3*(size_t)N.nlm + 1));
+    jacobi_and_diag(&N, sp, sl, 1, dgp, dgl, o);
+    for (int a = 0; a < n6; a++) { sp[a] = 1.0; dgp[a] = 0.0; }          /* poses: unscaled, undamped */
+    int rc = schur_solve(&N, sp, sl, dgp, dgl, radius, NULL, NULL, S, g);
+    if (Hd) for (int a = 0; a < n6; a++) Hd[a] = N.Hpp[(size_t)a*n6 + a];
+    if (cost) *cost = N.cost;
+    if (free_idx) for (int k = 0; k < p->n_kf; k++) free_idx[k] = P.free_idx[k];
+    int nf = N.nf;
+    free(sp); free(dgp); free(sl); free(dgl);
+    neq_free(&N); pass_free(&P);
+    return rc ? TSBA_ERR_NUMERIC : nf;
+}
+
 /* ------------------------------------------------------------------ one pyramid pass: LM + outlier pass */
 static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_report *rep) {
     int level = o->levels[pass], max_it = o->its[pass];

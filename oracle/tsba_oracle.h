@@ -45,6 +45,10 @@ void tsba_oracle_fillpoly4(int w, int h, const int *xy, uint8_t *mask);
 int tsba_oracle_reduced_system(const tsba_problem *p, const tsba_options *o, int level, double radius,
                                int32_t *free_idx, double *S, double *g, double *Hpp, double *bp, double *cost);
 
+/* One rank's contribution to the reduced normal equations of a landmark-sharded global BA (see tsba_oracle.c). */
+int tsba_oracle_partial_system(const tsba_problem *p, const tsba_options *o, int level, double radius,
+                               int32_t *free_idx, double *S, double *g, double *Hd, double *cost);
+
 /* Reference option sets: kind 0 = LocalBundleAdjustment, 1 = PoseOptim, 2 = GlobalBA. */
 void tsba_oracle_default_options(tsba_options *o, int kind);
 

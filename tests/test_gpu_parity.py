@@ -196,3 +196,28 @@ def test_error_codes(gpu):
         gpu.upload(P, o)
     with pytest.raises(TsbaError):
         gpu.PoseOptim(P)                     # n_kf != 1
+
+
+def test_global_ba_large_reduced_system(gpu, oracle_lib):
+    """40 keyframes -> 228 x 228 reduced system: the multi-workgroup MFMA Cholesky path (does not fit the LDS solver)."""
+    P = synth.config_global(n_kf=40, n_pt=2000, band=8)
+    _check_solve(gpu, oracle_lib, P, abi.options_global(), lambda G, o: gpu.GlobalBA(G, options=o))
+
+
+def test_multi_gpu_kernel_sequence_single_process(oracle_lib):
+    """The sharded (multi-GPU) kernel sequence with world size 1: split sums -> exchange buffers -> decision, damping
+    added after the (here trivial) all-reduce.  Once without a communicator, once through a 1-rank RCCL communicator."""
+    from textslam_amd.optimizer import Optimizer
+    P = synth.config_global(n_kf=30, n_pt=1500, band=6)
+    o = abi.options_global()
+    for use_rccl in (False, True):
+        g = Optimizer(0)
+        if use_rccl:
+            g.comm_init(g.comm_unique_id(), 0, 1)
+            g.lib.tsba_comm_init(g.ctx, None, 0, 1)          # world stays 1: force the split sequence on top of the communicator
+        else:
+            g.comm_init(None, 0, 1)
+        _check_solve(g, oracle_lib, P, o, lambda G, oo: g.GlobalBA(G, options=oo))
+        Q = synth.tiny(seed=7)                               # and a small local window through the same sequence
+        _check_solve(g, oracle_lib, Q, abi.options_local(), lambda G, oo: g.LocalBundleAdjustment(G, options=oo))
+        g.close()

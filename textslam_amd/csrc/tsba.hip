@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is dlopen()ed by tsba_comm_init, single-GPU use never touches RCCL
 #include "../../include/tsba.h"
 #include "tsba_device.h"
 #include "tsba_plan.h"
@@ -53,12 +55,14 @@ struct LinBuf {              // everything one linearisation produces
     double *V_pt, *b_pt, *dgs_pt;       // per point: V, b, clamp(sigma^2 V)/sigma^2  (lambda = dgs / radius)
     double *w_tx, *vb_tx;               // per text slot: W [18][n], (V6, b3, -Q^T W 18) [27][n]
     double *V_tx, *b_tx, *dgs_tx;       // per plane: V [6][n], b [3][n], dgs [3][n]
-    double *Hd, *bp, *dgs_p;            // per pose: diag(H_pp), gradient, dgs
+    double *Hd, *bp, *dgs_p;            // per pose: diag(H_pp), gradient, dgs.  Hd | bp | scal[8] are one allocation (hb):
+    double *bp_loc;                     // multi-GPU: this rank's part of bp (the reduced gradient is assembled from it)
     double *lmpart;                     // per k_mid block: (gradient max, |x|^2) of its landmarks
 };
 
 struct Work {                // device work buffers (sized for the largest level)
     int n_kf, n_pt, n_text, n_tobs, N;      // N = 6 n_kf
+    int rank, world;                        // landmark shard of this process (global BA over RCCL), 0 / 1 otherwise
     double K0[4];
     double w_sx, w_sy, w_t, huber_s, huber_t;
     int filter_good;
@@ -72,6 +76,7 @@ struct Work {                // device work buffers (sized for the largest level
     double *musig;                      // [n_tobs][2]
     int *kf_in, *kf_const, *act_pt, *act_tx;
     int *fidx, *nfree;                  // compressed index of the free poses in S / g
+    double *cb, *cbm;                   // multi-GPU exchange buffers: cb = [Hd 6n | bp 6n | cost, |x_lm|^2, step^2, mcc] (sum), cbm = gradient max (max)
     long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
     double *LDbuf;                      // factored diagonal blocks when k_solve cannot use LDS
     // linearisation outputs, double-buffered: lb[lcur] belongs to x, lb[lcur^1] to the LM candidate (speculative)
@@ -579,12 +584,13 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
     if (threadIdx.x == 0) { B.lmpart[2*b] = gm; B.lmpart[2*b + 1] = xn; }
 }
 
-// ---- after a linearisation: pose diagonal / gradient, Jacobi scaling, cost, gradient tolerance (256 threads of one block).
-// Returns (gmax, |x|^2, cost) to every thread; also writes Hd / bp / dgs_p of the LinBuf.
-__device__ void postlin_body(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm,
-                             double *red, double &gmax, double &xn, double &cost) {
+// ---- after a linearisation (256 threads of one block), in two stages so that a multi-GPU run can all-reduce in between:
+//   sums_local : pose diagonal / gradient from the pair sums (-> B.Hd, B.bp), landmark gradient max / |x|^2, cost
+//   pose_scale : Jacobi scaling, LM diagonal, gradient max and |x|^2 of the free poses (from the possibly all-reduced Hd / bp)
+__device__ void sums_local(const Work &W, const LevelDev &L, const LinBuf &B, double *dHd, double *dbp, int nb_lm, double *red,
+                           double &gmax_lm, double &xn_lm, double &cost) {
     const int tid = threadIdx.x;
-    gmax = 0.0; xn = 0.0; cost = 0.0;
+    gmax_lm = 0.0; xn_lm = 0.0; cost = 0.0;
     const double *out = B.pairOut;
     for (int a = tid; a < W.n_kf; a += 256) {
         double Hd[6] = {0,0,0,0,0,0}, bp[6] = {0,0,0,0,0,0};
@@ -594,28 +600,49 @@ __device__ void postlin_body(const Work &W, const LevelDev &L, const LinBuf &B, 
         for (int q = L.pose_h_off[a]; q < L.pose_h_off[a+1]; q++) { int p = L.pose_h[q];
 #pragma unroll
             for (int k = 0; k < 6; k++) { Hd[k] += out[(size_t)(63 + sym6(k, k))*L.n_pair + p]; bp[k] -= out[(size_t)(84 + k)*L.n_pair + p]; } }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { dHd[6*a + k] = Hd[k]; dbp[6*a + k] = bp[k]; B.bp_loc[6*a + k] = bp[k]; }
+    }
+    for (int k = tid; k < nb_lm; k += 256) { gmax_lm = fmax(gmax_lm, B.lmpart[2*k]); xn_lm += B.lmpart[2*k + 1]; }
+    for (int p = tid; p < L.n_pair; p += 256) cost += B.pairCost[p];
+    for (int g = tid; g < L.n_tg; g += 256) cost += B.tgCost[g];
+    gmax_lm = block_max<256>(gmax_lm, red); xn_lm = block_sum<256>(xn_lm, red); cost = block_sum<256>(cost, red);
+}
+__device__ void pose_scale(const Work &W, const LinBuf &B, const double *sHd, const double *sbp, const double *pose, bool first,
+                           double *red, double &gmax_p, double &xn_p) {
+    const int tid = threadIdx.x;
+    gmax_p = 0.0; xn_p = 0.0;
+    for (int a = tid; a < W.n_kf; a += 256) {          // same a -> same thread as in sums_local: reads its own writes
         const bool fre = W.fidx[a] >= 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            B.Hd[6*a + k] = Hd[k]; B.bp[6*a + k] = bp[k];
-            if (first) W.sig_p[6*a + k] = 1.0/(1.0 + sqrt(Hd[k]));
+            const double h = sHd[6*a + k], g = sbp[6*a + k];
+            B.Hd[6*a + k] = h; B.bp[6*a + k] = g;                 // (multi-GPU: the all-reduced values replace the local ones)
+            if (first) W.sig_p[6*a + k] = 1.0/(1.0 + sqrt(h));
             const double sg = W.sig_p[6*a + k];
-            B.dgs_p[6*a + k] = clampd(sg*sg*Hd[k], W.min_diag, W.max_diag)/(sg*sg);
-            if (fre) gmax = fmax(gmax, fabs(bp[k]));
+            B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
+            if (fre) gmax_p = fmax(gmax_p, fabs(g));
         }
-        if (fre) for (int k = 0; k < 7; k++) xn += pose[7*a + k]*pose[7*a + k];
+        if (fre) for (int k = 0; k < 7; k++) xn_p += pose[7*a + k]*pose[7*a + k];
     }
-    for (int k = tid; k < nb_lm; k += 256) { gmax = fmax(gmax, B.lmpart[2*k]); xn += B.lmpart[2*k + 1]; }
-    for (int p = tid; p < L.n_pair; p += 256) cost += B.pairCost[p];
-    for (int g = tid; g < L.n_tg; g += 256) cost += B.tgCost[g];
-    gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red); cost = block_sum<256>(cost, red);
+    gmax_p = block_max<256>(gmax_p, red); xn_p = block_sum<256>(xn_p, red);
 }
-__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm) {
+__device__ void postlin_body(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm,
+                             double *red, double &gmax, double &xn, double &cost) {
+    double gl, xl, gp, xp;
+    sums_local(W, L, B, B.Hd, B.bp, nb_lm, red, gl, xl, cost);
+    pose_scale(W, B, B.Hd, B.bp, pose, first, red, gp, xp);
+    gmax = fmax(gl, gp); xn = xl + xp;
+}
+__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm, int multi) {
     LmState *st = W.st;
     if (st->done || !st->need_lin) return;
     __shared__ double red[256];
     double gmax, xn, cost;
-    postlin_body(W, L, W.lb[st->lcur], W.pose[st->cur], st->first != 0, nb_lm, red, gmax, xn, cost);
+    const LinBuf &B = W.lb[st->lcur];
+    if (!multi) postlin_body(W, L, B, W.pose[st->cur], st->first != 0, nb_lm, red, gmax, xn, cost);
+    else { double gp, xp; pose_scale(W, B, W.cb, W.cb + W.N, W.pose[st->cur], st->first != 0, red, gp, xp);
+           const double *sc = W.cb + 2*(size_t)W.N; cost = sc[0]; xn = sc[1] + xp; gmax = fmax(W.cbm[0], gp); }
     if (threadIdx.x == 0) {
         st->x_cost = cost; st->x_norm = sqrt(xn); st->gmax = gmax;
         if (st->first) st->cost0 = cost;
@@ -625,7 +652,7 @@ __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad
 }
 
 // ---- reduced camera system.  grid = n_sb (one wave per 6x6 block) + n_kf (reduced gradient), 64 threads.
-__global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
+__global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
     LmState *st = W.st;
     if (st->done) return;
     __shared__ double lds[36*65];
@@ -678,7 +705,7 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
             if (a == c) {
                 for (int q = L.pose_t_off[a]; q < L.pose_t_off[a+1]; q++) v += out[(size_t)sym6(r, cc)*L.n_pair + L.pose_t[q]];
                 for (int q = L.pose_h_off[a]; q < L.pose_h_off[a+1]; q++) v += out[(size_t)(63 + sym6(r, cc))*L.n_pair + L.pose_h[q]];
-                if (r == cc) v += B.dgs_p[6*a + r]*irad;
+                if (r == cc && !multi) v += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
             } else {
                 int pab = L.sb_pab[b], pba = L.sb_pba[b];
                 if (pab >= 0) v -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
@@ -717,12 +744,13 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L) {
             double v = acc[0];
 #pragma unroll
             for (int k = 1; k < 6; k++) if (lane == k) v = acc[k];
-            W.g[6*ia + lane] = B.bp[6*a + lane] - v;
+            W.g[6*ia + lane] = (multi ? B.bp_loc[6*a + lane] : B.bp[6*a + lane]) - v;
         }
     }
 }
 
 #include "tsba_solve.h"
+#include "tsba_chol.h"
 
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
 __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
@@ -797,7 +825,7 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
 }
 
 // ---- step quality and trust-region update (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics)
-__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o) {
+__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o, int multi) {
     LmState *st = W.st;
     if (st->done) return;
     __shared__ double red[256];
@@ -805,10 +833,17 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
     // the candidate was linearised speculatively into lb[lcur^1]: its cost, gradient and diagonals are already there
     const LinBuf &Bc = W.lb[st->lcur ^ 1];
     double gmax_c, xn_c, cost;
-    postlin_body(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, red, gmax_c, xn_c, cost);
     double step2 = 0.0, mcc = 0.0;
-    for (int k = tid; k < nb_back; k += 256) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
-    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+    if (!multi) {
+        postlin_body(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, red, gmax_c, xn_c, cost);
+        for (int k = tid; k < nb_back; k += 256) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
+        step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+    } else {                                      // k_sums_multi + all-reduce already produced the global sums
+        double gp, xp;
+        pose_scale(W, Bc, W.cb, W.cb + W.N, W.pose[st->cur ^ 1], false, red, gp, xp);
+        const double *sc = W.cb + 2*(size_t)W.N;
+        cost = sc[0]; xn_c = sc[1] + xp; step2 = sc[2]; mcc = sc[3]; gmax_c = fmax(W.cbm[0], gp);
+    }
     if (tid) return;
     mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
     st->it++;
@@ -837,6 +872,52 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
     }
     if (st->it >= st->max_it) { st->done = 1; st->term = 0; }
     else if (st->radius < o.min_radius) { st->done = 1; st->term = 4; }
+}
+
+// ================================================================== multi-GPU (global BA sharded by landmark over RCCL)
+// stage A: local sums into the all-reduce buffer hb = [Hd | bp | scal] and gm.  spec: candidate LinBuf (also folds the
+// k_back partial sums: landmark blocks are owned by exactly one rank, the replicated pose blocks count on rank 0 only)
+__global__ __launch_bounds__(256) void k_sums_multi(Work W, LevelDev L, int spec, int nb_lm, int nb_back, int nb_back_lm) {
+    LmState *st = W.st;
+    if (st->done) return;
+    if (!spec && !st->need_lin) return;
+    __shared__ double red[256];
+    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
+    double gl, xl, cost;
+    sums_local(W, L, B, W.cb, W.cb + W.N, nb_lm, red, gl, xl, cost);
+    double step2 = 0.0, mcc = 0.0;
+    if (spec) for (int k = threadIdx.x; k < nb_back; k += 256)
+        if (k < nb_back_lm || W.rank == 0) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
+    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+    if (threadIdx.x == 0) { double *sc = W.cb + 2*(size_t)W.N; sc[0] = cost; sc[1] = xl; sc[2] = step2; sc[3] = mcc; W.cbm[0] = gl; }
+}
+// reduced camera system: add the pose damping once, after the all-reduce of the partial S
+__global__ void k_damp_multi(Work W) {
+    LmState *st = W.st;
+    if (st->done) return;
+    const LinBuf &B = W.lb[st->lcur];
+    const double irad = 1.0/st->radius;
+    int a = blockIdx.x*blockDim.x + threadIdx.x;
+    if (a >= W.n_kf) return;
+    int ia = W.fidx[a]; if (ia < 0) return;
+    for (int k = 0; k < 6; k++) W.S[(size_t)(6*ia + k)*W.N + 6*ia + k] += B.dgs_p[6*a + k]*irad;
+}
+// landmark parameters live on their owner: delta = x - x0 on the owner, 0 elsewhere (all-reduced, then x = x0 + delta)
+__global__ void k_delta_multi(Work W, const double *rho0, const double *theta0, int apply) {
+    const int cur = W.st->cur;
+    int j = blockIdx.x*blockDim.x + threadIdx.x;
+    if (j < W.n_pt) {
+        if (!apply) W.dl_pt[j] = (j % W.world == W.rank) ? W.rho[cur][j] - rho0[j] : 0.0;
+        else W.rho[cur][j] = rho0[j] + W.dl_pt[j];
+    } else if (j < W.n_pt + 3*W.n_text) {
+        int k = j - W.n_pt, t = k/3;
+        if (!apply) W.dl_tx[k] = ((W.n_pt + t) % W.world == W.rank) ? W.theta[cur][k] - theta0[k] : 0.0;
+        else W.theta[cur][k] = theta0[k] + W.dl_tx[k];
+    }
+}
+__global__ void k_kfin_multi(Work W) {               // kf_in was summed over ranks: back to a flag
+    int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k < W.n_kf) W.kf_in[k] = W.kf_in[k] != 0;
 }
 
 // ---- outlier pass on loss-corrected residuals, optimizer.cc:1609-1686 / :1228-1305
@@ -994,6 +1075,12 @@ struct Ctx {
     size_t lds_limit = 0;
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
+    int rank = 0, world = 1; bool force_multi = false;
+    void *rccl_so = nullptr; ncclComm_t comm = nullptr;
+    decltype(&ncclGetUniqueId) p_getid = nullptr; decltype(&ncclCommInitRank) p_init = nullptr;
+    decltype(&ncclAllReduce) p_allreduce = nullptr; decltype(&ncclCommDestroy) p_destroy = nullptr;
+    decltype(&ncclGetErrorString) p_errstr = nullptr;
 };
 
 static void set_err(Ctx *c, const std::string &s) { c->err = s; }
@@ -1063,6 +1150,7 @@ int tsba_destroy(void *ctx) {
     Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
     hipSetDevice(c->device);
     free_problem(c);
+    if (c->comm && c->p_destroy) c->p_destroy(c->comm);
     hipHostFree(c->st_host); hipFree(c->st_log);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
     delete c; return TSBA_OK;
@@ -1086,6 +1174,8 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     int rc = check_problem(c, p, o); if (rc) return rc;
     free_problem(c);
     c->opt = *o;
+    if (c->world > 1) { c->opt.lm_shard = c->rank; c->opt.lm_nshard = c->world; }
+    o = &c->opt;
     c->n_kf = p->n_kf; c->n_pt = p->n_pt; c->n_text = p->n_text; c->n_tobs = p->n_tobs; c->n_sgood = p->n_sgood; c->n_levels = p->n_levels;
     c->n_tfgood = p->n_tobs > 0 ? p->tobs_fgood_off[p->n_tobs] : 0;
     Work &W = c->W; memset(&W, 0, sizeof(W));
@@ -1093,6 +1183,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     for (int k = 0; k < 4; k++) W.K0[k] = p->K[k];
     W.w_sx = o->w_sx; W.w_sy = o->w_sy; W.w_t = o->w_t; W.huber_s = o->huber_scene; W.huber_t = o->huber_text;
     W.filter_good = o->filter_good; W.min_diag = o->min_diagonal; W.max_diag = o->max_diagonal;
+    W.rank = c->rank; W.world = c->world;
 #define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
 #define AL(dst, n) do { rc = dev_alloc(c, &(dst), (size_t)(n)); if (rc) return rc; } while (0)
     const double *cd; const uint8_t *cu;
@@ -1164,10 +1255,11 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         AL(B.tgM, 27*mx_tg); AL(B.tgCost, mx_tg);
         AL(B.w_pt, 6*mx_pslot); AL(B.vb_pt, 8*mx_pslot); AL(B.V_pt, p->n_pt); AL(B.b_pt, p->n_pt); AL(B.dgs_pt, p->n_pt);
         AL(B.w_tx, 18*mx_tslot); AL(B.vb_tx, 27*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
-        AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.dgs_p, W.N);
+        AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.bp_loc, W.N); AL(B.dgs_p, W.N);
         AL(B.lmpart, 2*((size_t)c->nb_back_max + mx_pair/256 + 2));
     }
     AL(W.sig_pt, p->n_pt); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.sig_p, W.N);
+    AL(W.cb, 2*(size_t)W.N + 8); AL(W.cbm, 1);
     AL(W.S, (size_t)(W.N + 1)*W.N); AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
     AL(W.st, 1);
@@ -1191,26 +1283,64 @@ static int reset_state(Ctx *c) {
     return 0;
 }
 
+static bool is_multi(const Ctx *c) { return c->world > 1 || c->force_multi; }
+static void allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op) {
+    if (!c->comm) return;                          // force_multi without a communicator: exercises the split kernels only
+    ncclResult_t r = c->p_allreduce(buf, buf, count, dt, op, c->comm, c->stream);
+    if (r != ncclSuccess) c->err = std::string("ncclAllReduce: ") + c->p_errstr(r);
+}
 static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     Work &W = c->W; const tsba_options &o = c->opt;
     hipLaunchKernelGGL(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
     int n = D.n_sc + D.n_tg;
     if (n > 0) hipLaunchKernelGGL(k_participation, dim3((n + 255)/256), dim3(256), 0, c->stream, W, D);
+    if (is_multi(c)) {                             // participation and block counts are global properties
+        allreduce(c, W.kf_in, c->n_kf, ncclInt32, ncclSum);
+        allreduce(c, &W.st->ns_active, 2, ncclInt32, ncclSum);
+        hipLaunchKernelGGL(k_kfin_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
+    }
     hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state);
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
 static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     Work &W = c->W;
-    int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256;
+    int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
     if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D, spec);
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
-    if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr);
+    const int multi = is_multi(c);
+    if (multi) {
+        // local sums -> exchange buffer -> all-reduce; the consumer (k_postlin / k_decide) installs them into the right LinBuf
+        hipLaunchKernelGGL(k_sums_multi, dim3(1), dim3(256), 0, c->stream, W, D, spec, nb_pt + nb_tx + nb_pr, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx);
+        allreduce(c, W.cb, 2*(size_t)W.N + 8, ncclDouble, ncclSum);
+        allreduce(c, W.cbm, 1, ncclDouble, ncclMax);
+    }
+    if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi);
 }
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
     size_t N = c->W.N, ld = N | 1, bytes = ((N + 1)*ld + 32*(N/6) + 8)*sizeof(double);     // worst case: every pose free
     *use_lds = bytes <= 150*1024;
     return *use_lds ? (int)bytes : 0;
 }
+// dense solve of the reduced camera system: LDS kernel for small windows, multi-workgroup blocked Cholesky otherwise
+static void launch_solve(Ctx *c) {
+    Work &W = c->W;
+    int use_lds; int lds = solve_lds_bytes(c, &use_lds);
+    if (use_lds) { hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W); return; }
+    const int N = W.N;                                             // worst case: every keyframe free
+    hipLaunchKernelGGL(k_chol_rhs, dim3((N + 255)/256), dim3(256), 0, c->stream, W);
+    const int lds_panel = (CH_NB*(CH_NB + 1)/2 + CH_PT*(CH_NB + 1))*(int)sizeof(double);
+    const int lds_upd = 2*64*(CH_NB + 1)*(int)sizeof(double);
+    for (int j0 = 0; j0 < N; j0 += CH_NB) {
+        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(CH_T), 0, c->stream, W, j0);
+        const int rows = N + 1 - (j0 + CH_NB);                         // the host only knows the worst case n = N; a shorter last
+        const int prow = N + 1 - (j0 + 6);                             // block (nb < NB) still has the rhs row below it
+        if (prow > 0) hipLaunchKernelGGL(k_chol_panel, dim3((prow + CH_PT - 1)/CH_PT), dim3(CH_PT), lds_panel, c->stream, W, j0);
+        const int nt = (rows + 63)/64;
+        if (rows > 1) hipLaunchKernelGGL(k_chol_update, dim3(nt*(nt + 1)/2), dim3(CH_T), lds_upd, c->stream, W, j0);
+    }
+    if (!getenv("TSBA_DEBUG_NO_BACKSUB")) hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), 0, c->stream, W);
+}
+
 // one LM iteration: reduced system -> pose step -> back-substitution / candidate -> speculative linearisation at the
 // candidate -> decision (on acceptance the speculative LinBuf simply becomes the current one)
 static void launch_step(Ctx *c, const LevelDev &D) {
@@ -1218,12 +1348,16 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);   // block-sparse S
-    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
-    if (use_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W);
-    else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, W);
+    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D, (int)is_multi(c));
+    if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
+        allreduce(c, W.S, (size_t)W.N*W.N, ncclDouble, ncclSum);
+        allreduce(c, W.g, W.N, ncclDouble, ncclSum);
+        hipLaunchKernelGGL(k_damp_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
+    }
+    launch_solve(c);
     hipLaunchKernelGGL(k_back, dim3(nb_pt + nb_tx + nb_kf), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
     launch_linearize(c, D, 1);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx + nb_pr, c->opt);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c));
 }
 
 int tsba_solve(void *ctx, tsba_report *r) {
@@ -1234,6 +1368,10 @@ int tsba_solve(void *ctx, tsba_report *r) {
     const tsba_options &o = c->opt;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    else {
+        CK(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB*(CH_NB + 1)/2 + CH_PT*(CH_NB + 1))*(int)sizeof(double)));
+        CK(hipFuncSetAttribute((const void *)k_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2*64*(CH_NB + 1)*(int)sizeof(double)));
+    }
     auto t0 = std::chrono::steady_clock::now();
     int rc = reset_state(c); if (rc) return rc;
     for (int ps = 0; ps < o.n_passes; ps++) {
@@ -1246,9 +1384,19 @@ int tsba_solve(void *ctx, tsba_report *r) {
                                                           o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
         CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
     }
+    if (c->world > 1) {                           // every landmark was optimised by its owner only
+        int nl = c->n_pt + 3*c->n_text;
+        if (nl > 0) {
+            hipLaunchKernelGGL(k_delta_multi, dim3((nl + 255)/256), dim3(256), 0, c->stream, c->W, (const double *)c->rho0, (const double *)c->theta0, 0);
+            if (c->n_pt) allreduce(c, c->W.dl_pt, c->n_pt, ncclDouble, ncclSum);
+            if (c->n_text) allreduce(c, c->W.dl_tx, 3*(size_t)c->n_text, ncclDouble, ncclSum);
+            hipLaunchKernelGGL(k_delta_multi, dim3((nl + 255)/256), dim3(256), 0, c->stream, c->W, (const double *)c->rho0, (const double *)c->theta0, 1);
+        }
+    }
     CK(hipMemcpyAsync(c->st_host, c->st_log, sizeof(LmState)*o.n_passes, hipMemcpyDeviceToHost, c->stream));
     CK(hipStreamSynchronize(c->stream));
     CK(hipGetLastError());
+    if (!c->err.empty() && c->err.rfind("ncclAllReduce", 0) == 0) return TSBA_ERR_COMM;
     auto t1 = std::chrono::steady_clock::now();
     r->t_solve_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     r->n_passes = o.n_passes;
@@ -1361,9 +1509,8 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     launch_linearize(c, D, 0);
     Work &W = c->W;
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
-    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D);
-    if (use_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W);
-    else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, W);
+    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D, 0);
+    launch_solve(c);
     c->opt = saved;
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
     if (S) CK(hipMemcpy(S, W.S, sizeof(double)*(size_t)W.N*W.N, hipMemcpyDeviceToHost));
@@ -1405,13 +1552,52 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     return TSBA_OK;
 }
 
+int tsba_debug_copy_S(void *ctx, double *out) {      // (6 n_kf + 1) x (6 n_kf): factored S and the rhs row after a solve
+    Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded) return TSBA_ERR_STATE;
+    hipSetDevice(c->device); hipStreamSynchronize(c->stream);
+    return hipMemcpy(out, c->W.S, sizeof(double)*(size_t)(c->W.N + 1)*c->W.N, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
+}
+
 int tsba_debug_stamps(void *ctx, long long *out64) {
     Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded) return TSBA_ERR_STATE;
     hipSetDevice(c->device); hipStreamSynchronize(c->stream);
     return hipMemcpy(out64, c->W.dbg, 64*sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
 }
 
-int tsba_comm_unique_id(void *id128) { (void)id128; return TSBA_ERR_COMM; }
-int tsba_comm_init(void *ctx, const void *id128, int rank, int world) { (void)ctx; (void)id128; (void)rank; (void)world; return TSBA_ERR_COMM; }
+static int load_rccl(Ctx *c) {
+    if (c->rccl_so) return 0;
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char *n : names) { c->rccl_so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (c->rccl_so) break; }
+    if (!c->rccl_so) { set_err(c, std::string("dlopen(librccl): ") + dlerror()); return TSBA_ERR_COMM; }
+    c->p_getid = (decltype(c->p_getid))dlsym(c->rccl_so, "ncclGetUniqueId");
+    c->p_init = (decltype(c->p_init))dlsym(c->rccl_so, "ncclCommInitRank");
+    c->p_allreduce = (decltype(c->p_allreduce))dlsym(c->rccl_so, "ncclAllReduce");
+    c->p_destroy = (decltype(c->p_destroy))dlsym(c->rccl_so, "ncclCommDestroy");
+    c->p_errstr = (decltype(c->p_errstr))dlsym(c->rccl_so, "ncclGetErrorString");
+    if (!c->p_getid || !c->p_init || !c->p_allreduce || !c->p_destroy || !c->p_errstr) { set_err(c, "librccl: missing symbols"); return TSBA_ERR_COMM; }
+    return 0;
+}
+int tsba_comm_unique_id(void *ctx, void *id128) {
+    Ctx *c = (Ctx *)ctx; if (!c || !id128) return TSBA_ERR_ARG;
+    int rc = load_rccl(c); if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t r = c->p_getid(&id);
+    if (r != ncclSuccess) { set_err(c, std::string("ncclGetUniqueId: ") + c->p_errstr(r)); return TSBA_ERR_COMM; }
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, 128);
+    return TSBA_OK;
+}
+int tsba_comm_init(void *ctx, const void *id128, int rank, int world) {
+    Ctx *c = (Ctx *)ctx; if (!c || world < 1 || rank < 0 || rank >= world) return TSBA_ERR_ARG;
+    hipSetDevice(c->device);
+    if (!id128) { c->force_multi = world >= 1; c->rank = 0; c->world = 1; return TSBA_OK; }   // test hook: split kernels, no communicator
+    int rc = load_rccl(c); if (rc) return rc;
+    ncclUniqueId id; memcpy(&id, id128, 128);
+    ncclResult_t r = c->p_init(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { set_err(c, std::string("ncclCommInitRank: ") + c->p_errstr(r)); return TSBA_ERR_COMM; }
+    c->rank = rank; c->world = world;
+    free_problem(c);                               // any resident problem was sharded for the old world size
+    return TSBA_OK;
+}
 
 } // extern "C"

@@ -42,7 +42,7 @@ def load_library():
                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tsba_time_linearize.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.tsba_debug_reduced_system.argtypes = [vp, C.c_double, dp, dp, dp, C.POINTER(C.c_int32), dp]
-    L.tsba_comm_unique_id.argtypes = [vp]
+    L.tsba_comm_unique_id.argtypes = [vp, vp]
     L.tsba_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     for name in ("tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global"):
         getattr(L, name).argtypes = [C.POINTER(TsbaOptions)]
@@ -157,6 +157,15 @@ class Optimizer:
                                                        free.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dpv)),
                     "tsba_debug_reduced_system")
         return {"S": S, "g": g, "cost": cost.value, "free": free, "dp": dpv}
+
+    # ---- multi-GPU (global BA): one process per GPU, RCCL communicator owned by the library
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        self._check(self.lib.tsba_comm_unique_id(self.ctx, buf), "tsba_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, id128, rank, world):
+        self._check(self.lib.tsba_comm_init(self.ctx, id128, rank, world), "tsba_comm_init")
 
     def time_linearize(self, level: int, n: int = 50):
         ms, nbytes = C.c_double(0), C.c_double(0)
