@@ -53,7 +53,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="local_ba", choices=["local_ba"])
+    ap.add_argument("--workload", default="local_ba", choices=["local_ba", "global_ba"])
+    ap.add_argument("--kf", type=int, default=1000, help="global_ba: keyframes")
+    ap.add_argument("--pts", type=int, default=100000, help="global_ba: map points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -71,9 +73,20 @@ def main():
     from textslam_amd import synth, abi
     from textslam_amd.optimizer import Optimizer
 
-    prob = synth.config_c4(seed=synth.SEED + rank)        # every replica gets its own window
-    opt = abi.options_local()
     gpu = Optimizer(local_rank)
+    if args.workload == "global_ba":
+        # one global BA sharded by landmark over the ranks: poses replicated, S and g all-reduced over RCCL
+        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=12)      # identical on every rank
+        opt = abi.options_global()
+        if world > 1:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(gpu.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            gpu.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    else:
+        prob = synth.config_c4(seed=synth.SEED + rank)    # every replica gets its own window
+        opt = abi.options_local()
     gpu.upload(prob, opt)
 
     def sync():
@@ -95,16 +108,26 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        ev = torch.tensor([float(rep["n_resid_evals"])], dtype=torch.float64, device="cuda")
-        dist.all_reduce(ev, op=dist.ReduceOp.SUM)
-        evals_all = float(ev.item())
+        if args.workload == "global_ba":
+            evals_all = float(rep["n_resid_evals"])        # block counts are already global (all-reduced in the library)
+        else:
+            ev = torch.tensor([float(rep["n_resid_evals"])], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ev, op=dist.ReduceOp.SUM)
+            evals_all = float(ev.item())
     else:
         evals_all = float(rep["n_resid_evals"])
     ms_per_step = dt / args.steps * 1e3
     value = evals_all * args.steps / dt
 
     out = None
-    if rank == 0:
+    if rank == 0 and args.workload == "global_ba":
+        out = {"metric": "global_ba_residuals_per_s", "value": value, "unit": "residuals/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "global BA %d KF x %d pts (scene only, 20 LM its, level 0), landmarks sharded over %d GPU(s)"
+                                      % (args.kf, args.pts, world), "lm_iterations": rep["iters"], "scene_blocks": rep["n_sblock"],
+                          "reduced_system_dim": 6*args.kf}}
+    elif rank == 0:
         # roofline of the linearisation kernel (residual + Jacobian + IRLS weight + J^T J / J^T r sums), level 0
         lin_ms, algo_bytes = gpu.time_linearize(0, 200)
         achieved = algo_bytes / (lin_ms * 1e-3) / 1e9

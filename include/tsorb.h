@@ -1,0 +1,53 @@
+/*
+ * tsorb.h -- C ABI of the MI355X-native ORB front-end (the ORBextractor hot path of TextSLAM).
+ *
+ *   tsorb_create         <- ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)   src/ORBextractor.cc:410-471
+ *   tsorb_extract_batch  <- ORBextractor::operator()(image, mask, keypoints, descriptors)                      src/ORBextractor.cc:1054-1116
+ *                           = ComputePyramid (:1118-1143) + ComputeKeyPointsOctTree (:766-854: per-cell cv::FAST 20 -> 7,
+ *                             DistributeOctTree :540-764, IC_Angle :77-104) + GaussianBlur 7x7 sigma 2 + computeOrbDescriptor (:108-147)
+ *
+ * The reference extracts one frame per call on one CPU thread; this ABI takes a batch of frames (frame::FeatExtraScene calls
+ * it once per frame, frame.cc:328-331 -- the adapter simply passes n = 1, or batches the two initialisation frames).
+ * Keypoints come back in the reference's order (level-major, quadtree list order inside a level) as 6 floats
+ * (x, y, size, angle, response, octave) = the cv::KeyPoint fields the reference fills; descriptors as 32 bytes each.
+ * All pointers are HOST pointers owned by the caller.  Return 0 = OK, negative = error; never exits.
+ */
+#ifndef TSORB_H
+#define TSORB_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSORB_OK          0
+#define TSORB_ERR_ARG    -1
+#define TSORB_ERR_DEVICE -2
+#define TSORB_MAX_LEVELS  8
+
+int tsorb_create(void **ctx, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device);
+int tsorb_destroy(void *ctx);
+const char *tsorb_last_error(void *ctx);
+
+/* Getters of the reference class (ORBextractor.h:63-88): scale factors / per-level feature quota. */
+int tsorb_get_levels(void *ctx);
+int tsorb_get_scale_factors(void *ctx, float *sf /*[nlevels]*/, float *inv_sf /*[nlevels]*/);
+int tsorb_get_features_per_level(void *ctx, int32_t *n /*[nlevels]*/);
+
+/* imgs: n grayscale frames, each h rows of `stride` bytes (w <= stride).
+ * kp [n][cap][6], desc [n][cap][32], count [n]: per frame at most cap keypoints (the reference returns <= ~nfeatures + a few). */
+int tsorb_extract_batch(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride,
+                        float *kp, uint8_t *desc, int32_t *count, int cap);
+
+/* Staged form for resident benchmarking: upload once, run the device pipeline any number of times, download. */
+int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride, int cap);
+int tsorb_run(void *ctx);
+int tsorb_download(void *ctx, float *kp, uint8_t *desc, int32_t *count);
+
+/* Test hook: pyramid level `level` (with its 19-px BORDER_REFLECT_101 frame) of frame f after a run: (h_l + 38) x (w_l + 38) bytes;
+ * blurred = 1 returns the 7x7 Gaussian-blurred level (no frame): h_l x w_l. */
+int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out, int32_t *w_out, int32_t *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -131,3 +131,65 @@ def partial_system(prob: BAProblem, opt: TsbaOptions, level: int, radius: float)
     assert nf >= 0, nf
     m = 6 * nf
     return {"nf": nf, "free_idx": free, "S": S[:m * m].reshape(m, m), "g": g[:m], "Hd": Hd[:m], "cost": cost.value}
+
+
+# ---------------------------------------------------------------- ORB oracle (oracle/tsorb_oracle.c)
+_ORB = None
+
+
+def orb_lib():
+    global _ORB
+    if _ORB is None:
+        so = os.path.join(_HERE, "libtsorb_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        up, fp, ip = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.tsorb_oracle_extract.argtypes = [up, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp, up, C.c_int]
+        L.tsorb_oracle_extract.restype = C.c_int
+        L.tsorb_oracle_level.argtypes = [up, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, up, ip, ip]
+        L.tsorb_oracle_fast.argtypes = [up, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int]
+        L.tsorb_oracle_params.argtypes = [C.c_int, C.c_float, C.c_int, fp, ip, ip, ip]
+        L.tsorb_oracle_params.restype = None
+        L.tsorb_oracle_atan2.argtypes = [C.c_float, C.c_float]
+        L.tsorb_oracle_atan2.restype = C.c_float
+        _ORB = L
+    return _ORB
+
+
+def orb_extract(img, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, cap=4096):
+    """ORBextractor::operator() on one uint8 image -> (kp [n,6] = x,y,size,angle,response,octave ; desc [n,32])."""
+    img = np.ascontiguousarray(img, np.uint8)
+    kp = np.zeros((cap, 6), np.float32)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = orb_lib().tsorb_oracle_extract(img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[1], img.shape[0], img.shape[1],
+                                       nfeatures, scale, nlevels, ini_th, min_th,
+                                       kp.ctypes.data_as(C.POINTER(C.c_float)), desc.ctypes.data_as(C.POINTER(C.c_uint8)), cap)
+    assert n >= 0, n
+    return kp[:n].copy(), desc[:n].copy()
+
+
+def orb_level(img, level, scale=1.2, nlevels=8, blurred=False):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros((img.shape[0] + 38) * (img.shape[1] + 38), np.uint8)
+    lw, lh = C.c_int(0), C.c_int(0)
+    orb_lib().tsorb_oracle_level(img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[1], img.shape[0], img.shape[1], scale, nlevels,
+                                 level, int(blurred), out.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(lw), C.byref(lh))
+    if blurred:
+        return out[:lw.value * lh.value].reshape(lh.value, lw.value).copy()
+    return out[:(lw.value + 38) * (lh.value + 38)].reshape(lh.value + 38, lw.value + 38).copy()
+
+
+def orb_fast(img, threshold, cap=100000):
+    img = np.ascontiguousarray(img, np.uint8)
+    kp = np.zeros((cap, 3), np.float32)
+    n = orb_lib().tsorb_oracle_fast(img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[1], img.shape[0], img.shape[1], threshold,
+                                    kp.ctypes.data_as(C.POINTER(C.c_float)), cap)
+    return kp[:n].copy()
+
+
+def orb_params(nfeatures=1000, scale=1.2, nlevels=8):
+    sf = np.zeros(nlevels, np.float32); nfl = np.zeros(nlevels, np.int32); um = np.zeros(16, np.int32); gk = np.zeros(7, np.int32)
+    orb_lib().tsorb_oracle_params(nfeatures, scale, nlevels, sf.ctypes.data_as(C.POINTER(C.c_float)), nfl.ctypes.data_as(C.POINTER(C.c_int)),
+                                  um.ctypes.data_as(C.POINTER(C.c_int)), gk.ctypes.data_as(C.POINTER(C.c_int)))
+    return sf, nfl, um, gk

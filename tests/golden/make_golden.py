@@ -58,5 +58,14 @@ def main():
         print(name, rep["iters"], rep["cost1"])
 
 
+def make_orb():
+    from textslam_amd.orbextractor import synthetic_frame
+    seed = 77
+    kp, desc = oracle.orb_extract(synthetic_frame(seed))
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "orb_frame.npz"), seed=seed, kp=kp, desc=desc)
+    print("orb_frame", kp.shape)
+
+
 if __name__ == "__main__":
     main()
+    make_orb()

@@ -99,3 +99,23 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "tsba_oracle" not in txt, f
+
+
+def test_orb_library_exports_and_refuses_without_device():
+    import __graft_entry__ as ge
+    so = os.path.join(ROOT, "textslam_amd", "libtsorb.so")
+    if not os.path.exists(so):
+        ge.build()
+    L = C.CDLL(so)
+    names = sorted(set(re.findall(r"\b(tsorb_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "tsorb.h")).read())))
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), n
+    ctx = C.c_void_p()
+    L.tsorb_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+    rc = L.tsorb_create(C.byref(ctx), 1000, 1.2, 8, 20, 7, 0)
+    if rc == 0:
+        L.tsorb_destroy.argtypes = [C.c_void_p]; L.tsorb_destroy(ctx)
+        pytest.skip("a HIP device is present here")
+    assert rc == -2
+    assert L.tsorb_create(C.byref(ctx), 1000, 0.9, 8, 20, 7, 0) == -1          # bad scale factor

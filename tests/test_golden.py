@@ -25,3 +25,10 @@ def test_oracle_reproduces_golden(oracle_lib, name):
     np.testing.assert_allclose(rep["cost1"], g["cost1"], rtol=1e-10)
     np.testing.assert_allclose(Q.pose, g["pose"], rtol=0, atol=1e-10)
     assert np.array_equal(Q.sgood, g["sgood"]) and np.array_equal(Q.tfgood, g["tfgood"]) and np.array_equal(Q.tobs_good, g["tobs_good"])
+
+
+def test_orb_oracle_reproduces_golden(oracle_lib):
+    from textslam_amd.orbextractor import synthetic_frame
+    g = np.load(os.path.join(GOLD, "orb_frame.npz"))
+    kp, desc = oracle_lib.orb_extract(synthetic_frame(int(g["seed"])))
+    assert np.array_equal(kp, g["kp"]) and np.array_equal(desc, g["desc"])

@@ -1,0 +1,80 @@
+"""GPU parity of the ORB front-end (libtsorb.so through the C ABI) against the CPU oracle: bit-exact keypoint coordinates,
+octaves, responses and 256-bit descriptors; angles identical (both sides evaluate cv::fastAtan2 with the same fp32 roundings)."""
+import os
+import numpy as np
+import pytest
+
+from textslam_amd.orbextractor import synthetic_frame
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def orb():
+    from textslam_amd.orbextractor import ORBextractor
+    return ORBextractor(1000, 1.2, 8, 20, 7, device=0)
+
+
+def _same(a, b):
+    kp_a, d_a = a; kp_b, d_b = b
+    assert kp_a.shape == kp_b.shape
+    assert np.array_equal(kp_a[:, [0, 1, 2, 4, 5]], kp_b[:, [0, 1, 2, 4, 5]])       # x, y, size, response, octave: bit-exact
+    assert np.array_equal(kp_a[:, 3], kp_b[:, 3])                                  # angle
+    assert np.array_equal(d_a, d_b)                                                # 256-bit descriptors
+
+
+def test_stages_bit_exact(orb, oracle_lib):
+    img = synthetic_frame(21)
+    orb.extract_batch(img)
+    for l in range(8):
+        assert np.array_equal(orb.debug_level(0, l), oracle_lib.orb_level(img, l))                          # S1 pyramid + border
+        assert np.array_equal(orb.debug_level(0, l, True), oracle_lib.orb_level(img, l, blurred=True))      # S5 blur
+
+
+def test_batch_matches_oracle(orb, oracle_lib):
+    imgs = np.stack([synthetic_frame(30 + s) for s in range(6)])
+    res = orb.extract_batch(imgs)
+    for f in range(len(imgs)):
+        _same(res[f], oracle_lib.orb_extract(imgs[f]))
+    # operator() form and batch independence
+    _same(orb(imgs[3]), res[3])
+
+
+def test_init_frame_extractor_3000(oracle_lib):
+    """tracking.cc:38-39 builds a second extractor with 3 x nfeatures for the two initialisation frames."""
+    from textslam_amd.orbextractor import ORBextractor
+    ex = ORBextractor(3000, 1.2, 8, 20, 7, device=0)
+    img = synthetic_frame(41)
+    _same(ex(img), oracle_lib.orb_extract(img, nfeatures=3000, cap=8192))
+    assert ex.GetFeaturesPerLevel().sum() == 3000 and ex.GetLevels() == 8
+
+
+def test_edge_cases(orb, oracle_lib):
+    flat = np.full((480, 640), 128, np.uint8)                      # no corners anywhere: empty output
+    kp, desc = orb(flat)
+    assert len(kp) == 0 and desc.shape == (0, 32)
+    low = (synthetic_frame(50).astype(np.int32) // 12 + 100).astype(np.uint8)     # low contrast: the per-cell fallback to threshold 7 fires
+    _same(orb(low), oracle_lib.orb_extract(low))
+    small = np.ascontiguousarray(synthetic_frame(51)[:240, :320])   # another resolution
+    _same(orb(small), oracle_lib.orb_extract(small))
+    noise = np.random.default_rng(5).integers(0, 256, (480, 640)).astype(np.uint8)        # corners everywhere: quadtree under load
+    _same(orb(noise), oracle_lib.orb_extract(noise, cap=8192))
+
+
+def test_against_golden_fixture(orb):
+    g = np.load(os.path.join(GOLD, "orb_frame.npz"))
+    img = synthetic_frame(int(g["seed"]))
+    kp, desc = orb(img)
+    assert np.array_equal(kp, g["kp"]) and np.array_equal(desc, g["desc"])
+
+
+def test_full_batch_properties(orb):
+    """BASELINE config 2: 64 frames 640x480 -- size-independent properties at full batch size."""
+    imgs = np.stack([synthetic_frame(200 + s) for s in range(64)])
+    res = orb.extract_batch(imgs)
+    res2 = orb.extract_batch(imgs[::-1].copy())
+    for f in (0, 17, 63):
+        _same(res[f], res2[63 - f])                                # a frame's result does not depend on its batch position
+        kp, desc = res[f]
+        assert 990 <= len(kp) <= 1040 and np.all(np.diff(kp[:, 5]) >= 0)

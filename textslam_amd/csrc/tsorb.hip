@@ -1,0 +1,556 @@
+// libtsorb.so -- MI355X (gfx950) ORB front-end for TextSLAM's ORBextractor hot path.  C ABI in include/tsorb.h.
+//
+// Batch of n frames, every stage one launch over (frame, level, ...):
+//   k_level0 / k_resize   pyramid: 8 levels x1.2, cv::resize INTER_LINEAR fixed point (11-bit weights), 19-px REFLECT_101 frame
+//                         fused in (a border pixel is the resize result at the reflected coordinate)        ORBextractor.cc:1118-1143
+//   k_fast                one workgroup per 30-px cell: ROI tile in LDS, FAST-9/16 + cornerScore + 3x3 NMS at threshold 20,
+//                         per-cell fallback to 7, row-major ordered compaction                               :766-830
+//   k_octree              one workgroup per (frame, level): DistributeOctTree (serial list surgery, thread 0)      :540-764
+//   k_orient              16 lanes per keypoint: intensity-centroid moments + fastAtan2                         :77-104
+//   k_blur                7x7 sigma-2 Gaussian, Q8 fixed point separable, LDS tiled                            :1096-1097
+//   k_describe            one wave per keypoint: 256 steered BRIEF tests, one byte per lane                     :108-147
+//   k_pack                level-major concatenation, coordinates scaled back to level 0                         :1106-1112
+// Integer / fp32 arithmetic is written so that every rounding matches the CPU oracle: no FMA contraction where the
+// reference has separate multiplies and adds (__fmul_rn / __fadd_rn / __dmul_rn ...), rintf = cvRound (half to even).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <cfloat>
+#include <string>
+#include <vector>
+#include "../../include/tsorb.h"
+#include "../../include/orb_pattern.h"
+
+#define EDGE 19
+#define HALF_PATCH 15
+#define PATCH_SIZE 31
+#define MAXL TSORB_MAX_LEVELS
+#define CELL_CAP 256            // keypoints a 30-px cell can hold after 3x3 NMS
+#define TILE_MAX 72             // cell ROI is at most (wCell + 6) < 66 pixels wide
+
+struct LevelGeo {
+    int w, h, bw, bh;           // level size, bordered size
+    int nCols, nRows, wCell, hCell, minB, maxBX, maxBY;
+    int cell0;                  // first cell index of this level in the per-frame cell table
+    int nfeat, capL;            // quadtree target, slot capacity
+    int kp0;                    // first slot of this level in the per-frame selected-keypoint table
+    float sf;
+    size_t pyr_off, blur_off;   // byte offsets of this level inside one frame's pyramid / blur slab
+};
+struct OrbDev {
+    int n, nlevels, ini_th, min_th, w, h, stride;
+    LevelGeo L[MAXL];
+    int cells_per_frame, slots_per_frame, cand_cap, node_cap, pool_cap, cap;
+    size_t pyr_frame, blur_frame;          // bytes per frame
+    const uint8_t *img; uint8_t *pyr, *blur;
+    uint32_t *cellkp; int *cellcnt;        // [n][cells][CELL_CAP] packed (x | y<<8 | score<<16), [n][cells]
+    float *cand;                           // [n][nlevels][cand_cap][3]  x, y, response (relative to minBorder)
+    int *nodes, *pool, *snbuf;             // quadtree scratch per (frame, level)
+    float *sel;                            // [n][slots][4]  x, y (level coords incl. border offset), response, angle
+    int *selcnt;                           // [n][nlevels]
+    uint8_t *seldesc;                      // [n][slots][32]
+    float *out_kp; uint8_t *out_desc; int *out_cnt;
+    int umax[16]; int gk[7];
+};
+__device__ __constant__ int8_t d_pattern[1024];
+
+__device__ __forceinline__ int reflect101(int x, int n) { if (x < 0) x = -x; if (x >= n) x = 2*(n - 1) - x; return x; }
+__device__ __forceinline__ uint8_t *lev_ptr(const OrbDev &D, uint8_t *base, int f, int l) { return base + (size_t)f*D.pyr_frame + D.L[l].pyr_off; }
+
+// ---------------------------------------------------------------- pyramid
+__global__ void k_level0(OrbDev D) {
+    const LevelGeo &G = D.L[0];
+    size_t idx = (size_t)blockIdx.x*blockDim.x + threadIdx.x, per = (size_t)G.bw*G.bh;
+    if (idx >= per*D.n) return;
+    int f = (int)(idx / per), r = (int)(idx % per), y = r / G.bw, x = r % G.bw;
+    int sx = reflect101(x - EDGE, G.w), sy = reflect101(y - EDGE, G.h);
+    D.pyr[(size_t)f*D.pyr_frame + G.pyr_off + r] = D.img[((size_t)f*D.h + sy)*D.stride + sx];
+}
+// cv::resize(8UC1, INTER_LINEAR) from level l-1 to level l, evaluated at the reflected coordinate for border pixels
+__global__ void k_resize(OrbDev D, int l) {
+    const LevelGeo &G = D.L[l], &S = D.L[l-1];
+    size_t idx = (size_t)blockIdx.x*blockDim.x + threadIdx.x, per = (size_t)G.bw*G.bh;
+    if (idx >= per*D.n) return;
+    int f = (int)(idx / per), r = (int)(idx % per), y = r / G.bw, x = r % G.bw;
+    int dx = reflect101(x - EDGE, G.w), dy = reflect101(y - EDGE, G.h);
+    const double scale_x = 1.0/((double)G.w/(double)S.w), scale_y = 1.0/((double)G.h/(double)S.h);
+    float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scale_x), 0.5);
+    int sx = (int)floorf(fx); fx = __fsub_rn(fx, (float)sx);
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
+    float fy = (float)__dsub_rn(__dmul_rn((double)dy + 0.5, scale_y), 0.5);
+    int sy = (int)floorf(fy); fy = __fsub_rn(fy, (float)sy);
+    const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f)), a1 = (int)rintf(__fmul_rn(fx, 2048.f));
+    const int b0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fy), 2048.f)), b1 = (int)rintf(__fmul_rn(fy, 2048.f));
+    int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+    int sx1 = sx + 1 < S.w ? sx + 1 : sx;
+    const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + S.pyr_off + (size_t)EDGE*S.bw + EDGE;
+    const uint8_t *r0 = src + (size_t)sy0*S.bw, *r1 = src + (size_t)sy1*S.bw;
+    int S0 = r0[sx]*a0 + r0[sx1]*a1, S1 = r1[sx]*a0 + r1[sx1]*a1;
+    D.pyr[(size_t)f*D.pyr_frame + G.pyr_off + r] = (uint8_t)((((b0*(S0 >> 4)) >> 16) + ((b1*(S1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// ---------------------------------------------------------------- FAST per cell
+__device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int threshold) {     // 0 = not a corner
+    const int cx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+    const int cy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+    const int v = p[0];
+    int d[25];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - p[cy[k]*stride + cx[k]];
+#pragma unroll
+    for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+    // 9 contiguous darker / brighter: run-length over the doubled ring, as bit masks
+    unsigned mp = 0, mn = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mp |= (d[k] > threshold ? 1u : 0u) << k; mn |= (d[k] < -threshold ? 1u : 0u) << k; }
+    mp |= mp << 16; mn |= mn << 16;
+    unsigned rp = mp, rn = mn;
+#pragma unroll
+    for (int k = 1; k < 9; k++) { rp &= mp >> k; rn &= mn >> k; }
+    if (((rp | rn) & 0xffffu) == 0) return 0;
+    int a0 = threshold;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int a = min(min(d[k+1], d[k+2]), d[k+3]);
+        if (a <= a0) continue;
+        a = min(a, min(min(d[k+4], d[k+5]), min(min(d[k+6], d[k+7]), d[k+8])));
+        a0 = max(a0, min(a, d[k]));
+        a0 = max(a0, min(a, d[k+9]));
+    }
+    int b0 = -a0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int b = max(max(max(d[k+1], d[k+2]), max(d[k+3], d[k+4])), d[k+5]);
+        if (b >= b0) continue;
+        b = max(b, max(max(d[k+6], d[k+7]), d[k+8]));
+        b0 = min(b0, max(b, d[k]));
+        b0 = min(b0, max(b, d[k+9]));
+    }
+    return -b0 - 1;
+}
+__global__ __launch_bounds__(256) void k_fast(OrbDev D) {
+    __shared__ uint8_t tile[TILE_MAX*TILE_MAX];
+    __shared__ short score[TILE_MAX*TILE_MAX];
+    __shared__ int s_cnt, s_wsum[4];
+    const int f = blockIdx.x / D.cells_per_frame, cidx = blockIdx.x % D.cells_per_frame, tid = threadIdx.x;
+    int l = 0;
+    while (l + 1 < D.nlevels && cidx >= D.L[l+1].cell0) l++;
+    const LevelGeo &G = D.L[l];
+    const int cc = cidx - G.cell0, i = cc / G.nCols, j = cc % G.nCols;
+    int *cnt_out = D.cellcnt + (size_t)f*D.cells_per_frame + cidx;
+    // cell ROI, ORBextractor.cc:790-806 (float arithmetic on small integers is exact)
+    const int iniY = G.minB + i*G.hCell, iniX = G.minB + j*G.wCell;
+    int maxY = iniY + G.hCell + 6, maxX = iniX + G.wCell + 6;
+    if (iniY >= G.maxBY - 3 || iniX >= G.maxBX - 6) { if (tid == 0) *cnt_out = 0; return; }
+    if (maxY > G.maxBY) maxY = G.maxBY;
+    if (maxX > G.maxBX) maxX = G.maxBX;
+    const int rw = maxX - iniX, rh = maxY - iniY;
+    if (rw < 7 || rh < 7) { if (tid == 0) *cnt_out = 0; return; }
+    const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)(EDGE + iniY)*G.bw + EDGE + iniX;
+    for (int k = tid; k < rw*rh; k += 256) { int y = k / rw, x = k - y*rw; tile[y*TILE_MAX + x] = src[(size_t)y*G.bw + x]; }
+    __syncthreads();
+    const int iw = rw - 6, ih = rh - 6;             // inner pixels (3-px margin)
+    uint32_t *out = D.cellkp + ((size_t)f*D.cells_per_frame + cidx)*CELL_CAP;
+    for (int pass = 0; pass < 2; pass++) {
+        const int th = pass == 0 ? D.ini_th : D.min_th;
+        for (int k = tid; k < rw*rh; k += 256) score[(k / rw)*TILE_MAX + (k % rw)] = 0;
+        __syncthreads();
+        for (int k = tid; k < iw*ih; k += 256) { int y = 3 + k / iw, x = 3 + k % iw;
+            score[y*TILE_MAX + x] = (short)fast_score(tile + y*TILE_MAX + x, TILE_MAX, th); }
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        // 3x3 non-maximum suppression + row-major ordered compaction (chunks of 256 pixels)
+        for (int base = 0; base < iw*ih; base += 256) {
+            const int k = base + tid;
+            bool keep = false; int x = 0, y = 0, s = 0;
+            if (k < iw*ih) {
+                y = 3 + k / iw; x = 3 + k % iw; s = score[y*TILE_MAX + x];
+                if (s > 0) {
+                    const short *q = score + y*TILE_MAX + x;
+                    keep = s > q[-TILE_MAX-1] && s > q[-TILE_MAX] && s > q[-TILE_MAX+1] && s > q[-1] && s > q[1] &&
+                           s > q[TILE_MAX-1] && s > q[TILE_MAX] && s > q[TILE_MAX+1];
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane == 0) s_wsum[wv] = __popcll(m);
+            __syncthreads();
+            int off = s_cnt;
+            for (int q = 0; q < wv; q++) off += s_wsum[q];
+            off += __popcll(m & ((1ull << lane) - 1ull));
+            if (keep && off < CELL_CAP) out[off] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)s << 16);
+            __syncthreads();
+            if (tid == 0) s_cnt += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+            __syncthreads();
+        }
+        if (s_cnt > 0) break;                       // uniform: s_cnt is shared
+    }
+    if (tid == 0) *cnt_out = min(s_cnt, CELL_CAP);
+}
+
+// ---------------------------------------------------------------- quadtree (DistributeOctTree), one workgroup per (frame, level)
+struct QNode { int ulx, uly, urx, ury, blx, bly, brx, bry, key0, nk, nomore, prev, next; };
+struct QList { QNode *n; int cnt, head, tail, size; int *pool; int pool_top; const float *kp; };
+__device__ int q_new(QList &L, int cap) { int i = L.cnt < cap ? L.cnt++ : cap - 1; QNode &q = L.n[i]; q.nomore = 0; q.prev = q.next = -1; q.nk = 0; q.key0 = 0; return i; }
+__device__ void q_push_back(QList &L, int i) { L.n[i].prev = L.tail; L.n[i].next = -1; if (L.tail >= 0) L.n[L.tail].next = i; else L.head = i; L.tail = i; L.size++; }
+__device__ void q_push_front(QList &L, int i) { L.n[i].next = L.head; L.n[i].prev = -1; if (L.head >= 0) L.n[L.head].prev = i; else L.tail = i; L.head = i; L.size++; }
+__device__ int q_erase(QList &L, int i) { int p = L.n[i].prev, nx = L.n[i].next; if (p >= 0) L.n[p].next = nx; else L.head = nx; if (nx >= 0) L.n[nx].prev = p; else L.tail = p; L.size--; return nx; }
+__device__ void q_divide(QList &L, int src, int c[4], int node_cap, int pool_cap) {
+    for (int k = 0; k < 4; k++) c[k] = q_new(L, node_cap);
+    const QNode s = L.n[src];
+    const int halfX = (int)ceilf((float)(s.urx - s.ulx)/2), halfY = (int)ceilf((float)(s.bry - s.uly)/2);
+    QNode &n1 = L.n[c[0]], &n2 = L.n[c[1]], &n3 = L.n[c[2]], &n4 = L.n[c[3]];
+    n1.ulx = s.ulx; n1.uly = s.uly; n1.urx = s.ulx + halfX; n1.ury = s.uly; n1.blx = s.ulx; n1.bly = s.uly + halfY; n1.brx = s.ulx + halfX; n1.bry = s.uly + halfY;
+    n2.ulx = n1.urx; n2.uly = n1.ury; n2.urx = s.urx; n2.ury = s.ury; n2.blx = n1.brx; n2.bly = n1.bry; n2.brx = s.urx; n2.bry = s.uly + halfY;
+    n3.ulx = n1.blx; n3.uly = n1.bly; n3.urx = n1.brx; n3.ury = n1.bry; n3.blx = s.blx; n3.bly = s.bly; n3.brx = n1.brx; n3.bry = s.bly;
+    n4.ulx = n3.urx; n4.uly = n3.ury; n4.urx = n2.brx; n4.ury = n2.bry; n4.blx = n3.brx; n4.bly = n3.bry; n4.brx = s.brx; n4.bry = s.bry;
+    // count, carve four order-preserving sub-arrays out of the pool, fill
+    int cn[4] = {0, 0, 0, 0};
+    const float ux = (float)n1.urx, by = (float)n1.bry;
+    for (int i = 0; i < s.nk; i++) { const float *kp = L.kp + 3*L.pool[s.key0 + i];
+        int q = (kp[0] < ux) ? ((kp[1] < by) ? 0 : 2) : ((kp[1] < by) ? 1 : 3); cn[q]++; }
+    int base = L.pool_top; if (base + s.nk > pool_cap) base = pool_cap - s.nk;     // (capacity guard; sized so that it never triggers)
+    L.pool_top = base + s.nk;
+    int st[4]; st[0] = base; st[1] = st[0] + cn[0]; st[2] = st[1] + cn[1]; st[3] = st[2] + cn[2];
+    for (int k = 0; k < 4; k++) { L.n[c[k]].key0 = st[k]; L.n[c[k]].nk = cn[k]; if (cn[k] == 1) L.n[c[k]].nomore = 1; }
+    int w[4] = { st[0], st[1], st[2], st[3] };
+    for (int i = 0; i < s.nk; i++) { int key = L.pool[s.key0 + i]; const float *kp = L.kp + 3*key;
+        int q = (kp[0] < ux) ? ((kp[1] < by) ? 0 : 2) : ((kp[1] < by) ? 1 : 3); L.pool[w[q]++] = key; }
+}
+__global__ __launch_bounds__(64) void k_octree(OrbDev D) {
+    const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, tid = threadIdx.x;
+    const LevelGeo &G = D.L[l];
+    float *cand = D.cand + ((size_t)f*D.nlevels + l)*D.cand_cap*3;
+    __shared__ int s_nc;
+    // 1. gather the cells of this level in the reference's order (rows of cells, then columns; row-major inside a cell)
+    if (tid == 0) {
+        int nc = 0;
+        const int *cnt = D.cellcnt + (size_t)f*D.cells_per_frame + G.cell0;
+        const uint32_t *ck = D.cellkp + ((size_t)f*D.cells_per_frame + G.cell0)*CELL_CAP;
+        for (int c = 0; c < G.nCols*G.nRows; c++) {
+            const int i = c / G.nCols, j = c % G.nCols;
+            for (int q = 0; q < cnt[c] && nc < D.cand_cap; q++) {
+                uint32_t p = ck[(size_t)c*CELL_CAP + q];
+                cand[3*nc] = (float)((int)(p & 255u) + j*G.wCell); cand[3*nc+1] = (float)((int)((p >> 8) & 255u) + i*G.hCell); cand[3*nc+2] = (float)(p >> 16);
+                nc++;
+            }
+        }
+        s_nc = nc;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const int nk = s_nc;
+    int *selcnt = D.selcnt + (size_t)f*D.nlevels + l;
+    float *sel = D.sel + ((size_t)f*D.slots_per_frame + G.kp0)*4;
+    if (nk == 0) { *selcnt = 0; return; }
+    QList L;
+    L.n = (QNode *)(D.nodes + ((size_t)f*D.nlevels + l)*(size_t)D.node_cap*(sizeof(QNode)/sizeof(int)));
+    L.pool = D.pool + ((size_t)f*D.nlevels + l)*(size_t)D.pool_cap;
+    int *snbuf = D.snbuf + ((size_t)f*D.nlevels + l)*(size_t)(4*D.node_cap);
+    L.cnt = 0; L.head = L.tail = -1; L.size = 0; L.pool_top = 0; L.kp = cand;
+    const int minX = G.minB, maxX = G.maxBX, minY = G.minB, maxY = G.maxBY, N = G.nfeat;
+    const int nIni = (int)roundf((float)(maxX - minX)/(float)(maxY - minY));
+    const float hX = __fdiv_rn((float)(maxX - minX), (float)nIni);
+    // initial nodes: count, carve, fill (order preserving)
+    for (int i = 0; i < nIni; i++) {
+        int q = q_new(L, D.node_cap); QNode &n = L.n[q];
+        n.ulx = (int)__fmul_rn(hX, (float)i); n.uly = 0; n.urx = (int)__fmul_rn(hX, (float)(i + 1)); n.ury = 0;
+        n.blx = n.ulx; n.bly = maxY - minY; n.brx = n.urx; n.bry = maxY - minY;
+        q_push_back(L, q);
+    }
+    for (int i = 0; i < nk; i++) { int q = (int)__fdiv_rn(cand[3*i], hX); if (q >= nIni) q = nIni - 1; L.n[q].nk++; }
+    { int top = 0; for (int i = 0; i < nIni; i++) { L.n[i].key0 = top; top += L.n[i].nk; L.n[i].nk = 0; } L.pool_top = top; }
+    for (int i = 0; i < nk; i++) { int q = (int)__fdiv_rn(cand[3*i], hX); if (q >= nIni) q = nIni - 1; L.pool[L.n[q].key0 + L.n[q].nk++] = i; }
+    for (int it = L.head; it >= 0; ) { QNode &n = L.n[it]; if (n.nk == 1) { n.nomore = 1; it = n.next; } else if (n.nk == 0) it = q_erase(L, it); else it = n.next; }
+    bool finish = false;
+    int *vs = snbuf, *vprev = snbuf + 2*D.node_cap; int nvs = 0;       // pairs (size, node)
+    while (!finish) {
+        int prevSize = L.size, nToExpand = 0; nvs = 0;
+        for (int it = L.head; it >= 0; ) {
+            if (L.n[it].nomore) { it = L.n[it].next; continue; }
+            int c[4]; q_divide(L, it, c, D.node_cap, D.pool_cap);
+            for (int k = 0; k < 4; k++) if (L.n[c[k]].nk > 0) {
+                q_push_front(L, c[k]);
+                if (L.n[c[k]].nk > 1) { nToExpand++; if (nvs < D.node_cap) { vs[2*nvs] = L.n[c[k]].nk; vs[2*nvs+1] = c[k]; nvs++; } }
+            }
+            it = q_erase(L, it);
+        }
+        if (L.size >= N || L.size == prevSize) finish = true;
+        else if (L.size + nToExpand*3 > N) {
+            while (!finish) {
+                prevSize = L.size;
+                const int np = nvs;
+                for (int k = 0; k < 2*np; k++) vprev[k] = vs[k];
+                nvs = 0;
+                // ascending sort by (size, creation order) -- insertion sort, the list is short
+                for (int a = 1; a < np; a++) { int s0 = vprev[2*a], n0 = vprev[2*a+1]; int b = a - 1;
+                    while (b >= 0 && (vprev[2*b] > s0 || (vprev[2*b] == s0 && vprev[2*b+1] > n0))) { vprev[2*b+2] = vprev[2*b]; vprev[2*b+3] = vprev[2*b+1]; b--; }
+                    vprev[2*b+2] = s0; vprev[2*b+3] = n0; }
+                for (int jq = np - 1; jq >= 0; jq--) {
+                    int c[4]; q_divide(L, vprev[2*jq+1], c, D.node_cap, D.pool_cap);
+                    for (int k = 0; k < 4; k++) if (L.n[c[k]].nk > 0) {
+                        q_push_front(L, c[k]);
+                        if (L.n[c[k]].nk > 1 && nvs < D.node_cap) { vs[2*nvs] = L.n[c[k]].nk; vs[2*nvs+1] = c[k]; nvs++; }
+                    }
+                    q_erase(L, vprev[2*jq+1]);
+                    if (L.size >= N) break;
+                }
+                if (L.size >= N || L.size == prevSize) finish = true;
+            }
+        }
+    }
+    int ns = 0;
+    for (int it = L.head; it >= 0 && ns < G.capL; it = L.n[it].next) {
+        const QNode &n = L.n[it]; int best = L.pool[n.key0]; float mr = cand[3*best+2];
+        for (int k = 1; k < n.nk; k++) { int key = L.pool[n.key0 + k]; if (cand[3*key+2] > mr) { best = key; mr = cand[3*key+2]; } }
+        sel[4*ns] = cand[3*best] + (float)minX; sel[4*ns+1] = cand[3*best+1] + (float)minY; sel[4*ns+2] = mr; sel[4*ns+3] = 0.f;
+        ns++;
+    }
+    *selcnt = ns;
+}
+
+// ---------------------------------------------------------------- orientation: 16 lanes per keypoint
+__device__ __forceinline__ float fast_atan2f_dev(float y, float x) {     // cv::fastAtan2, degrees
+    const float p1 = 0.9997878412794807f*(float)(180/3.14159265358979323846), p3 = -0.3258083974640975f*(float)(180/3.14159265358979323846);
+    const float p5 = 0.1555786518463281f*(float)(180/3.14159265358979323846), p7 = -0.04432655554792128f*(float)(180/3.14159265358979323846);
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) { c = __fdiv_rn(ay, __fadd_rn(ax, (float)DBL_EPSILON)); c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c); }
+    else { c = __fdiv_rn(ax, __fadd_rn(ay, (float)DBL_EPSILON)); c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c)); }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+__global__ __launch_bounds__(256) void k_orient(OrbDev D) {
+    const int g = (blockIdx.x*256 + threadIdx.x) >> 4, v = threadIdx.x & 15;
+    const int per = D.slots_per_frame, f = g / per, slot = g % per;
+    if (f >= D.n) return;
+    int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;
+    const LevelGeo &G = D.L[l];
+    const bool valid = (slot - G.kp0) < D.selcnt[(size_t)f*D.nlevels + l];
+    float *s = D.sel + ((size_t)f*per + slot)*4;
+    int m10 = 0, m01 = 0;
+    if (valid) {
+        const uint8_t *c = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)(EDGE + (int)rintf(s[1]))*G.bw + EDGE + (int)rintf(s[0]);
+        if (v == 0) { for (int u = -HALF_PATCH; u <= HALF_PATCH; ++u) m10 += u*c[u]; }
+        else {
+            int vs = 0, d = D.umax[v];
+            for (int u = -d; u <= d; ++u) { int vp = c[u + v*G.bw], vm = c[u - v*G.bw]; vs += (vp - vm); m10 += u*(vp + vm); }
+            m01 = v*vs;
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 16); m01 += __shfl_xor(m01, o, 16); }
+    if (valid && v == 0) s[3] = fast_atan2f_dev((float)m01, (float)m10);
+}
+
+// ---------------------------------------------------------------- Gaussian blur 7x7, Q8 separable, reflect101 at the image edge
+#define BT_W 64
+#define BT_H 16
+__global__ __launch_bounds__(256) void k_blur(OrbDev D, int l) {
+    const LevelGeo &G = D.L[l];
+    __shared__ int rowf[(BT_H + 6)*BT_W];
+    const int tx = blockIdx.x % ((G.w + BT_W - 1)/BT_W), ty = (blockIdx.x / ((G.w + BT_W - 1)/BT_W)) % ((G.h + BT_H - 1)/BT_H);
+    const int f = blockIdx.x / (((G.w + BT_W - 1)/BT_W)*((G.h + BT_H - 1)/BT_H));
+    const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)EDGE*G.bw + EDGE;
+    const int x0 = tx*BT_W, y0 = ty*BT_H, tid = threadIdx.x;
+    for (int k = tid; k < (BT_H + 6)*BT_W; k += 256) {
+        int yy = k / BT_W, xx = k % BT_W;
+        int y = reflect101(y0 + yy - 3, G.h), x = x0 + xx;
+        int s = 0;
+        if (x < G.w) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) s += D.gk[i]*src[(size_t)y*G.bw + reflect101(x + i - 3, G.w)];
+        }
+        rowf[k] = s;
+    }
+    __syncthreads();
+    uint8_t *dst = D.blur + (size_t)f*D.blur_frame + G.blur_off;
+    for (int k = tid; k < BT_H*BT_W; k += 256) {
+        int yy = k / BT_W, xx = k % BT_W, x = x0 + xx, y = y0 + yy;
+        if (x >= G.w || y >= G.h) continue;
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) s += D.gk[i]*rowf[(yy + i)*BT_W + xx];
+        int v = (s + (1 << 15)) >> 16;
+        dst[(size_t)y*G.w + x] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+// ---------------------------------------------------------------- descriptors: one wave per keypoint, lane i < 32 -> byte i
+__global__ __launch_bounds__(256) void k_describe(OrbDev D) {
+    const int g = (blockIdx.x*256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int per = D.slots_per_frame, f = g / per, slot = g % per;
+    if (f >= D.n) return;
+    int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;
+    const LevelGeo &G = D.L[l];
+    if ((slot - G.kp0) >= D.selcnt[(size_t)f*D.nlevels + l] || lane >= 32) return;
+    const float *s = D.sel + ((size_t)f*per + slot)*4;
+    const float factorPI = (float)(3.14159265358979323846/180.f);
+    const float angle = __fmul_rn(s[3], factorPI);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const uint8_t *c = D.blur + (size_t)f*D.blur_frame + G.blur_off + (size_t)(int)rintf(s[1])*G.w + (int)rintf(s[0]);
+    const int8_t *pat = d_pattern + 32*lane;
+    int val = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float x0 = pat[4*t], y0 = pat[4*t+1], x1 = pat[4*t+2], y1 = pat[4*t+3];
+        const int t0 = c[(int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)))*G.w + (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)))];
+        const int t1 = c[(int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)))*G.w + (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)))];
+        val |= (t0 < t1) << t;
+    }
+    D.seldesc[((size_t)f*per + slot)*32 + lane] = (uint8_t)val;
+}
+
+// ---------------------------------------------------------------- level-major packing, coordinates back to level 0
+__global__ __launch_bounds__(256) void k_pack(OrbDev D) {
+    const int f = blockIdx.x, tid = threadIdx.x;
+    __shared__ int off[MAXL + 1];
+    if (tid == 0) { int o = 0; for (int l = 0; l < D.nlevels; l++) { off[l] = o; o += D.selcnt[(size_t)f*D.nlevels + l]; } off[D.nlevels] = o; D.out_cnt[f] = min(o, D.cap); }
+    __syncthreads();
+    for (int l = 0; l < D.nlevels; l++) {
+        const LevelGeo &G = D.L[l];
+        const int n = D.selcnt[(size_t)f*D.nlevels + l];
+        for (int q = tid; q < n; q += 256) {
+            const int o = off[l] + q; if (o >= D.cap) continue;
+            const float *s = D.sel + ((size_t)f*D.slots_per_frame + G.kp0 + q)*4;
+            float *k = D.out_kp + ((size_t)f*D.cap + o)*6;
+            k[0] = l ? __fmul_rn(s[0], G.sf) : s[0]; k[1] = l ? __fmul_rn(s[1], G.sf) : s[1];
+            k[2] = (float)(int)__fmul_rn((float)PATCH_SIZE, G.sf); k[3] = s[3]; k[4] = s[2]; k[5] = (float)l;
+            const uint32_t *ds = (const uint32_t *)(D.seldesc + ((size_t)f*D.slots_per_frame + G.kp0 + q)*32);
+            uint32_t *dd = (uint32_t *)(D.out_desc + ((size_t)f*D.cap + o)*32);
+#pragma unroll
+            for (int w = 0; w < 8; w++) dd[w] = ds[w];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct OCtx {
+    int device = 0; hipStream_t stream = nullptr; std::string err;
+    int nfeatures = 1000, nlevels = 8, ini_th = 20, min_th = 7; float scale = 1.2f;
+    float sf[MAXL], isf[MAXL]; int nfl[MAXL], umax[16], gk[7];
+    std::vector<void *> allocs; bool uploaded = false;
+    OrbDev D;
+};
+static int cv_round_f(float v) { return (int)lrintf(v); }
+#define OCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(e_); return TSORB_ERR_DEVICE; } } while (0)
+template <typename T> static int oalloc(OCtx *c, T **p, size_t n) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(n, 1)*sizeof(T)) != hipSuccess) { c->err = "hipMalloc failed"; return TSORB_ERR_DEVICE; }
+    c->allocs.push_back(q); *p = (T *)q; return 0; }
+static void ofree(OCtx *c) { hipStreamSynchronize(c->stream); for (void *p : c->allocs) hipFree(p); c->allocs.clear(); c->uploaded = false; }
+
+extern "C" {
+
+int tsorb_create(void **ctx, int nfeatures, float scale, int nlevels, int ini_th, int min_th, int device) {
+    if (!ctx || nlevels < 1 || nlevels > MAXL || nfeatures < 1 || !(scale > 1.f)) return TSORB_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return TSORB_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TSORB_ERR_DEVICE;
+    OCtx *c = new OCtx(); c->device = device; c->nfeatures = nfeatures; c->scale = scale; c->nlevels = nlevels; c->ini_th = ini_th; c->min_th = min_th;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TSORB_ERR_DEVICE; }
+    // ORBextractor::ORBextractor, ORBextractor.cc:410-471 (fp32 arithmetic as there)
+    c->sf[0] = 1.0f; for (int i = 1; i < nlevels; i++) c->sf[i] = c->sf[i-1]*scale;
+    for (int i = 0; i < nlevels; i++) c->isf[i] = 1.0f/c->sf[i];
+    float factor = 1.0f/scale;
+    float nd = nfeatures*(1 - factor)/(1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) { c->nfl[l] = cv_round_f(nd); sum += c->nfl[l]; nd *= factor; }
+    c->nfl[nlevels-1] = std::max(nfeatures - sum, 0);
+    int v, v0, vmax = (int)floor(HALF_PATCH*sqrtf(2.f)/2 + 1), vmin = (int)ceil(HALF_PATCH*sqrtf(2.f)/2);
+    const double hp2 = HALF_PATCH*HALF_PATCH;
+    memset(c->umax, 0, sizeof(c->umax));
+    for (v = 0; v <= vmax; ++v) c->umax[v] = (int)lrint(sqrt(hp2 - v*v));
+    for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) { while (c->umax[v0] == c->umax[v0+1]) ++v0; c->umax[v] = v0; ++v0; }
+    // cv::getGaussianKernel(7, 2, CV_32F) -> Q8 (OpenCV 3.3 8-bit separable path)
+    { float cf[7]; double s = 0, s2 = -0.5/(2.0*2.0); for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(s2*x*x); s += cf[i]; }
+      s = 1./s; for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i]*s); c->gk[i] = cv_round_f(cf[i]*256.f); } }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_pattern), ORB_BIT_PATTERN_31, 1024) != hipSuccess) { delete c; return TSORB_ERR_DEVICE; }
+    *ctx = c; return TSORB_OK;
+}
+int tsorb_destroy(void *ctx) { OCtx *c = (OCtx *)ctx; if (!c) return TSORB_ERR_ARG; hipSetDevice(c->device); ofree(c); hipStreamDestroy(c->stream); delete c; return TSORB_OK; }
+const char *tsorb_last_error(void *ctx) { return ctx ? ((OCtx *)ctx)->err.c_str() : "null ctx"; }
+int tsorb_get_levels(void *ctx) { return ctx ? ((OCtx *)ctx)->nlevels : TSORB_ERR_ARG; }
+int tsorb_get_scale_factors(void *ctx, float *sf, float *isf) { OCtx *c = (OCtx *)ctx; if (!c) return TSORB_ERR_ARG;
+    for (int i = 0; i < c->nlevels; i++) { if (sf) sf[i] = c->sf[i]; if (isf) isf[i] = c->isf[i]; } return TSORB_OK; }
+int tsorb_get_features_per_level(void *ctx, int32_t *n) { OCtx *c = (OCtx *)ctx; if (!c || !n) return TSORB_ERR_ARG; for (int i = 0; i < c->nlevels; i++) n[i] = c->nfl[i]; return TSORB_OK; }
+
+int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride, int cap) {
+    OCtx *c = (OCtx *)ctx; if (!c || !imgs || n < 1 || w < 64 || h < 64 || stride < w || cap < 1) return TSORB_ERR_ARG;
+    hipSetDevice(c->device); ofree(c);
+    OrbDev &D = c->D; memset(&D, 0, sizeof(D));
+    D.n = n; D.nlevels = c->nlevels; D.ini_th = c->ini_th; D.min_th = c->min_th; D.w = w; D.h = h; D.stride = stride; D.cap = cap;
+    memcpy(D.umax, c->umax, sizeof(D.umax)); memcpy(D.gk, c->gk, sizeof(D.gk));
+    size_t po = 0, bo = 0; int cell0 = 0, kp0 = 0;
+    for (int l = 0; l < c->nlevels; l++) {
+        LevelGeo &G = D.L[l];
+        G.w = cv_round_f((float)w*c->isf[l]); G.h = cv_round_f((float)h*c->isf[l]); G.bw = G.w + 2*EDGE; G.bh = G.h + 2*EDGE;
+        G.minB = EDGE - 3; G.maxBX = G.w - EDGE + 3; G.maxBY = G.h - EDGE + 3;
+        const float width = (float)(G.maxBX - G.minB), height = (float)(G.maxBY - G.minB);
+        G.nCols = (int)(width/30.f); G.nRows = (int)(height/30.f);
+        if (G.nCols < 1 || G.nRows < 1) { c->err = "image too small for the requested pyramid"; return TSORB_ERR_ARG; }
+        G.wCell = (int)ceilf(width/G.nCols); G.hCell = (int)ceilf(height/G.nRows);
+        if (G.wCell + 6 > TILE_MAX || G.hCell + 6 > TILE_MAX) { c->err = "cell larger than the LDS tile"; return TSORB_ERR_ARG; }
+        G.cell0 = cell0; cell0 += G.nCols*G.nRows;
+        G.nfeat = c->nfl[l]; G.capL = c->nfl[l] + 8; G.kp0 = kp0; kp0 += G.capL; G.sf = c->sf[l];
+        G.pyr_off = po; po += (size_t)G.bw*G.bh; G.blur_off = bo; bo += (size_t)G.w*G.h;
+    }
+    D.cells_per_frame = cell0; D.slots_per_frame = kp0; D.pyr_frame = po; D.blur_frame = bo;
+    D.cand_cap = 16384; D.node_cap = 64*(c->nfl[0] + 64); D.pool_cap = 16*D.cand_cap;
+    int rc;
+    uint8_t *img; if ((rc = oalloc(c, &img, (size_t)n*h*stride))) return rc; D.img = img;
+    OCK(hipMemcpyAsync(img, imgs, (size_t)n*h*stride, hipMemcpyHostToDevice, c->stream));
+    if ((rc = oalloc(c, &D.pyr, (size_t)n*po)) || (rc = oalloc(c, &D.blur, (size_t)n*bo))) return rc;
+    if ((rc = oalloc(c, &D.cellkp, (size_t)n*cell0*CELL_CAP)) || (rc = oalloc(c, &D.cellcnt, (size_t)n*cell0))) return rc;
+    if ((rc = oalloc(c, &D.cand, (size_t)n*c->nlevels*D.cand_cap*3))) return rc;
+    if ((rc = oalloc(c, &D.nodes, (size_t)n*c->nlevels*D.node_cap*(sizeof(QNode)/sizeof(int)))) || (rc = oalloc(c, &D.pool, (size_t)n*c->nlevels*D.pool_cap)) ||
+        (rc = oalloc(c, &D.snbuf, (size_t)n*c->nlevels*4*D.node_cap))) return rc;
+    if ((rc = oalloc(c, &D.sel, (size_t)n*kp0*4)) || (rc = oalloc(c, &D.selcnt, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.seldesc, (size_t)n*kp0*32))) return rc;
+    if ((rc = oalloc(c, &D.out_kp, (size_t)n*cap*6)) || (rc = oalloc(c, &D.out_desc, (size_t)n*cap*32)) || (rc = oalloc(c, &D.out_cnt, (size_t)n))) return rc;
+    OCK(hipStreamSynchronize(c->stream));
+    c->uploaded = true; return TSORB_OK;
+}
+int tsorb_run(void *ctx) {
+    OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG;
+    hipSetDevice(c->device);
+    OrbDev &D = c->D;
+    { size_t tot = (size_t)D.n*D.L[0].bw*D.L[0].bh; hipLaunchKernelGGL(k_level0, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, D); }
+    for (int l = 1; l < D.nlevels; l++) { size_t tot = (size_t)D.n*D.L[l].bw*D.L[l].bh; hipLaunchKernelGGL(k_resize, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, D, l); }
+    hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
+    hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);
+    hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
+    for (int l = 0; l < D.nlevels; l++) { int nt = ((D.L[l].w + BT_W - 1)/BT_W)*((D.L[l].h + BT_H - 1)/BT_H); hipLaunchKernelGGL(k_blur, dim3(D.n*nt), dim3(256), 0, c->stream, D, l); }
+    hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*64 + 255)/256), dim3(256), 0, c->stream, D);
+    hipLaunchKernelGGL(k_pack, dim3(D.n), dim3(256), 0, c->stream, D);
+    OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
+    return TSORB_OK;
+}
+int tsorb_download(void *ctx, float *kp, uint8_t *desc, int32_t *count) {
+    OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG;
+    hipSetDevice(c->device); OrbDev &D = c->D;
+    if (kp) OCK(hipMemcpy(kp, D.out_kp, sizeof(float)*(size_t)D.n*D.cap*6, hipMemcpyDeviceToHost));
+    if (desc) OCK(hipMemcpy(desc, D.out_desc, (size_t)D.n*D.cap*32, hipMemcpyDeviceToHost));
+    if (count) OCK(hipMemcpy(count, D.out_cnt, sizeof(int)*(size_t)D.n, hipMemcpyDeviceToHost));
+    return TSORB_OK;
+}
+int tsorb_extract_batch(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride, float *kp, uint8_t *desc, int32_t *count, int cap) {
+    int rc = tsorb_upload(ctx, imgs, n, w, h, stride, cap); if (rc) return rc;
+    rc = tsorb_run(ctx); if (rc) return rc;
+    return tsorb_download(ctx, kp, desc, count);
+}
+int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out, int32_t *w_out, int32_t *h_out) {
+    OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded || !out) return TSORB_ERR_ARG;
+    OrbDev &D = c->D; if (frame < 0 || frame >= D.n || level < 0 || level >= D.nlevels) return TSORB_ERR_ARG;
+    hipSetDevice(c->device);
+    const LevelGeo &G = D.L[level];
+    if (w_out) *w_out = G.w; if (h_out) *h_out = G.h;
+    if (blurred) OCK(hipMemcpy(out, D.blur + (size_t)frame*D.blur_frame + G.blur_off, (size_t)G.w*G.h, hipMemcpyDeviceToHost));
+    else OCK(hipMemcpy(out, D.pyr + (size_t)frame*D.pyr_frame + G.pyr_off, (size_t)G.bw*G.bh, hipMemcpyDeviceToHost));
+    return TSORB_OK;
+}
+
+} // extern "C"
