@@ -48,12 +48,52 @@ def cpu_baseline(prob, opt_ref, budget_s=30.0):
             "sample": sample, "seconds": dt}
 
 
+def bench_orb(args, rank, local_rank, world, dist, torch):
+    """BASELINE config 2: ORBextractor (1000, 1.2, 8, 20, 7) on a batch of 64 frames 640x480 per GPU (replicas for N > 1)."""
+    import numpy as np
+    from textslam_amd.orbextractor import ORBextractor, synthetic_frame
+    imgs = np.stack([synthetic_frame(1000*rank + s) for s in range(64)])
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device=local_rank)
+    ex.upload(imgs)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(); torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        ex.run()
+    sync(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ex.run()
+    sync(); dt = time.perf_counter() - t0
+    nk = sum(len(k) for k, _ in ex.download())
+    if dist is not None:
+        t = torch.tensor([dt, float(nk)], dtype=torch.float64, device="cuda")
+        tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, nk = float(tm[0]), float(t[1])
+    if rank == 0:
+        out = {"metric": "orb_keypoints_per_s", "value": nk*args.steps/dt, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt/args.steps*1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "ORBextractor(1000,1.2,8,20,7), 64 frames 640x480 per GPU", "frames_per_s": 64*world*args.steps/dt}}
+        if not args.no_cpu_baseline:
+            import oracle
+            t0 = time.perf_counter(); n = 0
+            for f in range(16):
+                n += len(oracle.orb_extract(imgs[f])[0])
+            dtc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n/dtc, "unit": "keypoints/s", "cores": 1, "kind": "port", "sample": "16 of the 64 frames", "seconds": dtc}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="local_ba", choices=["local_ba", "global_ba"])
+    ap.add_argument("--workload", default="local_ba", choices=["local_ba", "global_ba", "orb"])
     ap.add_argument("--kf", type=int, default=1000, help="global_ba: keyframes")
     ap.add_argument("--pts", type=int, default=100000, help="global_ba: map points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -73,6 +113,8 @@ def main():
     from textslam_amd import synth, abi
     from textslam_amd.optimizer import Optimizer
 
+    if args.workload == "orb":
+        return bench_orb(args, rank, local_rank, world, dist, torch)
     gpu = Optimizer(local_rank)
     if args.workload == "global_ba":
         # one global BA sharded by landmark over the ranks: poses replicated, S and g all-reduced over RCCL

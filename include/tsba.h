@@ -146,6 +146,17 @@ typedef struct tsba_report {
 void tsba_default_options_local (tsba_options *o);   /* levels 2,1,0 x10, chi2 12.25 / .5 .5 .5(.95 at 0) */
 void tsba_default_options_pose  (tsba_options *o);
 void tsba_default_options_global(tsba_options *o);   /* level 0, 20 its, unweighted, scene only */
+/* The remaining optimizer:: entry points are the same solver with other constants (all poses constant = mark every
+ * keyframe in kf_initial; "no loss" = a huge Huber delta):
+ *   init        optimizer::InitBA -> PyrIniBA (optimizer.cc:960-1056): 2 KFs, the host at identity constant (kf_initial = {1,0}),
+ *               auto_IniBAScene / nume_IniBAText = unweighted R1 / R6, Huber 3 / 3, levels 3,2,1,0 x 10, no flags, no outlier pass
+ *   landmarker  optimizer::OptimizeLandmarker -> PyrLandmarkers (:456-562,1853-2168): poses constant, auto_RhoScene / nume_thetaText
+ *               = unweighted R1 / R6 with only rho / theta free, Huber sqrt(5.991) / 2, levels 3,2,1,0 x 50, scene outlier pass chi2 18
+ *   theta       optimizer::ThetaOptimMultiFs -> PyrThetaOptim (:565-624,2170-2242): theta of ONE plane, poses constant, no loss,
+ *               levels 2,1,0 x 50 (Ceres default), then the 3x3 covariance of theta */
+void tsba_default_options_init      (tsba_options *o);
+void tsba_default_options_landmarker(tsba_options *o);
+void tsba_default_options_theta     (tsba_options *o);
 
 /* ---- context ---- */
 int  tsba_create (void **ctx, int device);   /* TSBA_ERR_DEVICE if no gfx950 device is usable */
@@ -156,6 +167,10 @@ const char *tsba_last_error(void *ctx);
 int  tsba_local_ba  (void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r);
 int  tsba_pose_optim(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r);  /* n_kf==1, all landmarks frozen */
 int  tsba_global_ba (void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r);
+/* optimizer::ThetaOptimMultiFs: solve (normally with tsba_default_options_theta) and return the covariance of theta[text]
+ * = (J^T J)^-1 of its residual blocks at the solution (ceres::Covariance, optimizer.cc:2219-2238), row-major 3x3.
+ * Returns TSBA_ERR_NUMERIC when the information matrix is singular (the reference returns false). */
+int  tsba_theta_optim(void *ctx, tsba_problem *p, const tsba_options *o, int text, double cov[9], tsba_report *r);
 
 /* ---- staged calls (bench / repeated solves with the problem resident in HBM) ---- */
 int  tsba_upload  (void *ctx, const tsba_problem *p, const tsba_options *o);

@@ -42,6 +42,8 @@ def lib():
         L.tsba_oracle_partial_system.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, C.c_double,
                                                  ip, dp, dp, dp, dp]
         L.tsba_oracle_partial_system.restype = C.c_int
+        L.tsba_oracle_theta_cov.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, C.c_int, dp]
+        L.tsba_oracle_theta_cov.restype = C.c_int
         L.tsba_oracle_default_options.argtypes = [C.POINTER(TsbaOptions), C.c_int]
         L.tsba_oracle_default_options.restype = None
         _LIB = L
@@ -131,6 +133,13 @@ def partial_system(prob: BAProblem, opt: TsbaOptions, level: int, radius: float)
     assert nf >= 0, nf
     m = 6 * nf
     return {"nf": nf, "free_idx": free, "S": S[:m * m].reshape(m, m), "g": g[:m], "Hd": Hd[:m], "cost": cost.value}
+
+
+def theta_cov(prob: BAProblem, opt: TsbaOptions, level: int, text: int):
+    cov = np.zeros(9)
+    s = prob.struct()
+    rc = lib().tsba_oracle_theta_cov(C.byref(s), C.byref(opt), level, text, _dp(cov))
+    return rc, cov.reshape(3, 3)
 
 
 # ---------------------------------------------------------------- ORB oracle (oracle/tsorb_oracle.c)

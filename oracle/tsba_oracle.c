@@ -870,6 +870,25 @@ int tsba_oracle_partial_system(const tsba_problem *p, const tsba_options *o, int
     return rc ? TSBA_ERR_NUMERIC : nf;
 }
 
+/* ceres::Covariance of theta[text] with every other parameter constant (optimizer.cc:2219-2238): inverse of the loss-corrected
+ * J^T J of its residual blocks at the current parameters.  Returns 0, or TSBA_ERR_NUMERIC if singular. */
+int tsba_oracle_theta_cov(const tsba_problem *p, const tsba_options *o, int level, int text, double cov[9]) {
+    if (!p || !o || level < 0 || level >= p->n_levels || text < 0 || text >= p->n_text) return TSBA_ERR_ARG;
+    pass_t P; pass_build(&P, p, o, level);
+    double V[9] = {0};
+    for (int i = 0; i < P.nblk; i++) {
+        const blk_t *b = &P.blk[i];
+        if (b->type != BLK_TEXT_BA || b->lm != text) continue;
+        double r[8], Jt[48], Jh[48], Jl[24];
+        blk_eval(&P, b, p->pose, p->rho, p->theta, r, Jt, Jh, Jl);
+        double s = 0; for (int k = 0; k < 8; k++) s += r[k]*r[k];
+        double scale; huber(s, o->huber_text, &scale);
+        for (int k = 0; k < 8; k++) for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) V[3*a + c2] += scale*scale*Jl[3*k + a]*Jl[3*k + c2];
+    }
+    pass_free(&P);
+    return inv_sym(V, 3, cov) ? TSBA_ERR_NUMERIC : TSBA_OK;
+}
+
 /* ------------------------------------------------------------------ one pyramid pass: LM + outlier pass */
 static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_report *rep) {
     int level = o->levels[pass], max_it = o->its[pass];

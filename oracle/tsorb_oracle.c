@@ -333,7 +333,7 @@ int tsorb_oracle_extract(const uint8_t *img, int w, int h, int stride, int nfeat
         const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
         const int nCols = (int)(width/Wc), nRows = (int)(height/Wc);
         const int wCell = (int)ceilf(width/nCols), hCell = (int)ceilf(height/nRows);
-        int capc = nfeatures*10 + 4096;
+        int capc = (maxBX - minBX)*(maxBY - minBY)/4 + 64;        /* strict 3x3 NMS: at most one corner per 2x2 block */
         kp_t *cand = (kp_t *)malloc(sizeof(kp_t)*capc); int nc = 0;
         kp_t *cell = (kp_t *)malloc(sizeof(kp_t)*4096);
         for (int i = 0; i < nRows; i++) {

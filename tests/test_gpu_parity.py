@@ -221,3 +221,31 @@ def test_multi_gpu_kernel_sequence_single_process(oracle_lib):
         Q = synth.tiny(seed=7)                               # and a small local window through the same sequence
         _check_solve(g, oracle_lib, Q, abi.options_local(), lambda G, oo: g.LocalBundleAdjustment(G, options=oo))
         g.close()
+
+
+def test_init_ba_parity(gpu, oracle_lib):
+    """optimizer::InitBA (rows R4 / R8): unweighted, Huber 3, levels 3,2,1,0, host keyframe constant."""
+    P = synth.init_pair(seed=5)
+    G, rep = _check_solve(gpu, oracle_lib, P, abi.options_init(), lambda G, o: gpu.InitBA(G, options=o))
+    assert rep["n_passes"] == 4 and np.array_equal(G.pose.reshape(-1, 7)[0], P.pose.reshape(-1, 7)[0])
+
+
+def test_landmarker_parity(gpu, oracle_lib):
+    """optimizer::OptimizeLandmarker (rows R5 / R9): every pose constant, rho and theta refined, scene outlier pass."""
+    P = synth.landmark_refine(seed=9)
+    G, rep = _check_solve(gpu, oracle_lib, P, abi.options_landmarker(), lambda G, o: gpu.OptimizeLandmarker(G, options=o))
+    assert np.array_equal(G.pose, P.pose) and not np.array_equal(G.rho, P.rho)
+
+
+def test_theta_optim_parity_and_covariance(gpu, oracle_lib):
+    """optimizer::ThetaOptimMultiFs (row R9): theta only, no loss, then the 3x3 covariance of the plane."""
+    P = synth.landmark_refine(seed=3, n_pt=0, n_text=2)
+    o = abi.options_theta()
+    G, R = P.copy(), P.copy()
+    rep_g, cov_g = gpu.ThetaOptimMultiFs(G, text=1, options=o)
+    rep_o = oracle_lib.solve(R, o)
+    assert rep_g["iters"] == rep_o["iters"] and rep_g["termination"] == rep_o["termination"]
+    np.testing.assert_allclose(G.theta, R.theta, rtol=0, atol=1e-8)
+    rc, cov_o = oracle_lib.theta_cov(R, o, 0, 1)
+    assert rc == 0
+    np.testing.assert_allclose(cov_g, cov_o, rtol=1e-7)

@@ -251,3 +251,42 @@ def test_empty_and_ragged_inputs(oracle_lib):
     Q2 = P2.copy(); rep2 = oracle_lib.solve(Q2, abi.options_local())
     assert rep2["iters"] == [0, 0, 0]
     assert np.array_equal(Q2.pose, P2.pose)
+
+
+def test_landmark_only_and_theta_covariance(oracle_lib):
+    """R5 / R9: every pose constant.  theta covariance = inverse of the theta block of J^T J (ceres::Covariance)."""
+    P = synth.landmark_refine(seed=3)
+    o = abi.options_theta(); o.use_text = 1
+    Q = P.copy()
+    rep = oracle_lib.solve(Q, o)
+    assert np.array_equal(Q.pose, P.pose)                                  # nothing but landmarks moves
+    assert not np.array_equal(Q.theta, P.theta)
+    assert all(c1 <= c0 for c0, c1 in zip(rep["cost0"], rep["cost1"]))
+    rc, cov = oracle_lib.theta_cov(Q, o, 0, 1)
+    assert rc == 0
+    ev = oracle_lib.evaluate(Q, o, 0)
+    # rebuild the information matrix of plane 1 from the per-block Jacobians
+    k = 0; V = np.zeros((3, 3))
+    for t in range(Q.n_tobs):
+        kf, j = int(Q.tobs_kf[t]), int(Q.tobs_text[t])
+        if Q.text_host[j] == kf:
+            continue
+        nf = Q.tfeat_off[0][j + 1] - Q.tfeat_off[0][j]
+        for _ in range(nf):
+            if j == 1:
+                Jl = ev["jac_text"][k][:, 12:15]; V += Jl.T @ Jl
+            k += 1
+    assert k == ev["nt"]
+    assert np.allclose(cov, np.linalg.inv(V), rtol=1e-9)
+
+
+def test_init_ba_style_problem(oracle_lib):
+    """R4 / R8 (optimizer::InitBA): host keyframe constant at its pose, second keyframe + rho + theta free, 4 levels."""
+    P = synth.init_pair(seed=5)
+    o = abi.options_init()
+    Q = P.copy()
+    rep = oracle_lib.solve(Q, o)
+    assert rep["n_passes"] == 4 and np.array_equal(Q.pose.reshape(-1, 7)[0], P.pose.reshape(-1, 7)[0])
+    err0 = np.abs(P.pose.reshape(-1, 7)[1, 4:] - P.truth["pose"][1, 4:]).max()
+    err1 = np.abs(Q.pose.reshape(-1, 7)[1, 4:] - P.truth["pose"][1, 4:]).max()
+    assert rep["cost1"][-1] < rep["cost0"][0] and err1 < err0

@@ -126,6 +126,43 @@ def options_global():
     return o
 
 
+def options_init():
+    """optimizer::InitBA / PyrIniBA, src/optimizer.cc:960-1056 (mark kf_initial = [1, 0]: the host at identity is constant)."""
+    o = options_local(STATE_NOTREACHWIN)
+    o.w_sx = o.w_sy = o.w_t = 1.0
+    o.huber_scene = o.huber_text = 3.0
+    o.n_passes = 4
+    for i in range(4):
+        o.levels[i], o.its[i] = 3 - i, 10
+    o.outlier_scene = o.outlier_text = 0
+    o.filter_good = 0
+    return o
+
+
+def options_landmarker():
+    """optimizer::OptimizeLandmarker / PyrLandmarkers, src/optimizer.cc:531-541,1861,1873,1922 (every KF constant)."""
+    o = options_local(STATE_NOTREACHWIN)
+    o.w_sx = o.w_sy = o.w_t = 1.0
+    o.huber_scene, o.huber_text = math.sqrt(5.991), 2.0
+    o.n_passes = 4
+    for i in range(4):
+        o.levels[i], o.its[i], o.chi2_mono[i], o.chi2_text[i] = 3 - i, 50, 18.0, 1.5
+    o.outlier_scene, o.outlier_text = 1, 0
+    return o
+
+
+def options_theta():
+    """optimizer::ThetaOptimMultiFs / PyrThetaOptim, src/optimizer.cc:610-615,2176,2203-2209 (no loss, 50 iterations)."""
+    o = options_local(STATE_NOTREACHWIN)
+    o.w_sx = o.w_sy = o.w_t = 1.0
+    o.huber_text = 1e300
+    for i in range(3):
+        o.its[i] = 50
+    o.outlier_scene = o.outlier_text = 0
+    o.filter_good = 0
+    return o
+
+
 def _ptr(a, ctype):
     if a is None or a.size == 0:
         return C.cast(None, C.POINTER(ctype))

@@ -1131,6 +1131,25 @@ void tsba_default_options_global(tsba_options *o) {
     o->state = TSBA_STATE_GLOBAL; o->outlier_scene = o->outlier_text = 0; o->use_text = 0; o->filter_good = 0;
 }
 
+void tsba_default_options_init(tsba_options *o) {                    // optimizer.cc:960-1056
+    tsba_default_options_local(o);
+    o->w_sx = o->w_sy = o->w_t = 1.0; o->huber_scene = 3.0; o->huber_text = 3.0;
+    o->n_passes = 4; for (int i = 0; i < 4; i++) { o->levels[i] = 3 - i; o->its[i] = 10; }
+    o->state = TSBA_STATE_NOTREACHWIN; o->outlier_scene = o->outlier_text = 0; o->filter_good = 0;
+}
+void tsba_default_options_landmarker(tsba_options *o) {              // optimizer.cc:531-541,1861,1873,1922
+    tsba_default_options_local(o);
+    o->w_sx = o->w_sy = o->w_t = 1.0; o->huber_scene = sqrt(5.991); o->huber_text = 2.0;
+    o->n_passes = 4; for (int i = 0; i < 4; i++) { o->levels[i] = 3 - i; o->its[i] = 50; o->chi2_mono[i] = 18.0; o->chi2_text[i] = 1.5; }
+    o->state = TSBA_STATE_NOTREACHWIN; o->outlier_scene = 1; o->outlier_text = 0;
+}
+void tsba_default_options_theta(tsba_options *o) {                   // optimizer.cc:610-615,2176,2203-2209
+    tsba_default_options_local(o);
+    o->w_sx = o->w_sy = o->w_t = 1.0; o->huber_text = 1e300;          // LossFunction* = nullptr
+    for (int i = 0; i < 3; i++) o->its[i] = 50;
+    o->state = TSBA_STATE_NOTREACHWIN; o->outlier_scene = o->outlier_text = 0; o->filter_good = 0;
+}
+
 int tsba_create(void **ctx, int device) {
     if (!ctx) return TSBA_ERR_ARG;
     int n = 0;
@@ -1448,6 +1467,22 @@ int tsba_pose_optim(void *ctx, tsba_problem *p, const tsba_options *o, tsba_repo
     return one_shot(ctx, p, o, r);
 }
 int tsba_global_ba(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r) { return one_shot(ctx, p, o, r); }
+int tsba_theta_optim(void *ctx, tsba_problem *p, const tsba_options *o, int text, double cov[9], tsba_report *r) {
+    Ctx *c = (Ctx *)ctx;
+    if (!c || !p || !cov || text < 0 || text >= p->n_text) return TSBA_ERR_ARG;
+    int rc = one_shot(ctx, p, o, r); if (rc) return rc;
+    // information matrix of theta[text] at the solution = V of the current linearisation (undamped, loss-corrected J^T J)
+    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
+    double V[6];
+    for (int k = 0; k < 6; k++) CK(hipMemcpy(&V[k], c->W.lb[st.lcur & 1].V_tx + (size_t)k*c->n_text + text, sizeof(double), hipMemcpyDeviceToHost));
+    const double a = V[0], b = V[1], cc = V[2], e = V[3], f = V[4], i = V[5];
+    const double A = e*i - f*f, B = -(b*i - cc*f), C = b*f - cc*e, det = a*A + b*B + cc*C;
+    if (!(det > 0.0) || !(a > 0.0) || !(a*e - b*b > 0.0)) { set_err(c, "theta information matrix is singular"); return TSBA_ERR_NUMERIC; }
+    const double id = 1.0/det;
+    cov[0] = A*id; cov[1] = B*id; cov[2] = C*id; cov[3] = B*id; cov[4] = (a*i - cc*cc)*id; cov[5] = -(a*f - b*cc)*id;
+    cov[6] = C*id; cov[7] = cov[5]; cov[8] = (a*e - b*b)*id;
+    return TSBA_OK;
+}
 
 int tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int level,
               double *resid, double *jac, double *musigma, int64_t *ns_out, int64_t *nt_out) {

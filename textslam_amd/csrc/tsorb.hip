@@ -27,7 +27,7 @@
 #define HALF_PATCH 15
 #define PATCH_SIZE 31
 #define MAXL TSORB_MAX_LEVELS
-#define CELL_CAP 256            // keypoints a 30-px cell can hold after 3x3 NMS
+#define CELL_CAP 1024           // >= keypoints a cell (< 60 x 60 inner pixels) can hold after strict 3x3 NMS (one per 2x2)
 #define TILE_MAX 72             // cell ROI is at most (wCell + 6) < 66 pixels wide
 
 struct LevelGeo {
@@ -500,7 +500,8 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
         G.pyr_off = po; po += (size_t)G.bw*G.bh; G.blur_off = bo; bo += (size_t)G.w*G.h;
     }
     D.cells_per_frame = cell0; D.slots_per_frame = kp0; D.pyr_frame = po; D.blur_frame = bo;
-    D.cand_cap = 16384; D.node_cap = 64*(c->nfl[0] + 64); D.pool_cap = 16*D.cand_cap;
+    // strict 3x3 NMS leaves at most one corner per 2x2 block: the level-0 search area bounds every level's candidate count
+    D.cand_cap = ((D.L[0].maxBX - D.L[0].minB)*(D.L[0].maxBY - D.L[0].minB))/4 + 64; D.node_cap = 64*(c->nfl[0] + 64); D.pool_cap = 16*D.cand_cap;
     int rc;
     uint8_t *img; if ((rc = oalloc(c, &img, (size_t)n*h*stride))) return rc; D.img = img;
     OCK(hipMemcpyAsync(img, imgs, (size_t)n*h*stride, hipMemcpyHostToDevice, c->stream));

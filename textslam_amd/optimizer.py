@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from .abi import (TsbaProblem, TsbaOptions, TsbaReport, BAProblem, options_local, options_pose, options_global,
-                  STATE_LOCAL, STATE_NOTREACHWIN)
+                  options_init, options_landmarker, options_theta, STATE_LOCAL, STATE_NOTREACHWIN)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.path.join(_HERE, "libtsba.so")
@@ -44,7 +44,9 @@ def load_library():
     L.tsba_debug_reduced_system.argtypes = [vp, C.c_double, dp, dp, dp, C.POINTER(C.c_int32), dp]
     L.tsba_comm_unique_id.argtypes = [vp, vp]
     L.tsba_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
-    for name in ("tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global"):
+    L.tsba_theta_optim.argtypes = [vp, C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, dp, C.POINTER(TsbaReport)]
+    for name in ("tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global",
+                 "tsba_default_options_init", "tsba_default_options_landmarker", "tsba_default_options_theta"):
         getattr(L, name).argtypes = [C.POINTER(TsbaOptions)]
         getattr(L, name).restype = None
     _lib = L
@@ -54,7 +56,8 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global",
     "tsba_create", "tsba_destroy", "tsba_last_error",
-    "tsba_local_ba", "tsba_pose_optim", "tsba_global_ba",
+    "tsba_default_options_init", "tsba_default_options_landmarker", "tsba_default_options_theta",
+    "tsba_local_ba", "tsba_pose_optim", "tsba_global_ba", "tsba_theta_optim",
     "tsba_upload", "tsba_solve", "tsba_download", "tsba_eval", "tsba_time_linearize",
     "tsba_comm_unique_id", "tsba_comm_init",
 ]
@@ -103,6 +106,23 @@ class Optimizer:
     def GlobalBA(self, prob: BAProblem, options: TsbaOptions = None):
         o = options or options_global()
         return self._one_shot(self.lib.tsba_global_ba, prob, o, "tsba_global_ba")
+
+    def InitBA(self, prob: BAProblem, options: TsbaOptions = None):
+        """optimizer::InitBA(F1, F2): prob holds the two keyframes, kf_initial = [1, 0] keeps the host (identity) constant."""
+        return self._one_shot(self.lib.tsba_local_ba, prob, options or options_init(), "tsba_local_ba(init)")
+
+    def OptimizeLandmarker(self, prob: BAProblem, options: TsbaOptions = None):
+        """optimizer::OptimizeLandmarker(map): rho / theta refinement with every pose constant (kf_initial = all ones)."""
+        return self._one_shot(self.lib.tsba_local_ba, prob, options or options_landmarker(), "tsba_local_ba(landmarker)")
+
+    def ThetaOptimMultiFs(self, prob: BAProblem, text: int = 0, options: TsbaOptions = None):
+        """optimizer::ThetaOptimMultiFs(F, obj): returns (report, 3x3 covariance of theta[text]); raises if it is singular."""
+        o = options or options_theta()
+        s = prob.struct()
+        rep = TsbaReport()
+        cov = np.zeros(9)
+        self._check(self.lib.tsba_theta_optim(self.ctx, C.byref(s), C.byref(o), text, _dp(cov), C.byref(rep)), "tsba_theta_optim")
+        return rep.as_dict(), cov.reshape(3, 3)
 
     def _one_shot(self, fn, prob, o, what):
         s = prob.struct()

@@ -106,7 +106,7 @@ class _Plane:
 
 def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), max_targets=5, text_targets=5,
                  frozen_frac=0.1, outlier_frac=0.05, noise_px=0.5, perturb=True, n_levels=3,
-                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True):
+                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None):
     """Build a synthetic window (local BA / pose-only / global BA depending on the arguments).
 
     n_kf == 1 with frozen_frac == 1 gives the pose-only problem (every landmark hosted outside).
@@ -382,7 +382,7 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
     rho_i = rho.copy()
     theta_i = P.theta.copy()
     if perturb:
-        first_free = 0 if n_kf == 1 else min(3, n_kf)
+        first_free = 0 if n_kf == 1 else min(n_fixed, n_kf)
         for k in range(first_free, n_kf):
             ax = rng.normal(size=3)
             ax /= np.linalg.norm(ax)
@@ -398,7 +398,7 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
     P.pose, P.rho, P.theta = pose, rho_i, theta_i
     ki = np.zeros(n_kf, np.uint8)
     ki[:min(2, n_kf)] = 1 if n_kf > 1 else 0
-    P.kf_initial = ki
+    P.kf_initial = ki if kf_initial is None else np.asarray(kf_initial, np.uint8)
     return P.normalise()
 
 
@@ -429,3 +429,15 @@ def tiny(seed=7, n_kf=5, n_pt=60, n_text=4, **kw):
     kw.setdefault("feats", (12, 8, 6))
     kw.setdefault("text_targets", 3)
     return make_problem(n_kf, n_pt, n_text, seed, **kw)
+
+
+def init_pair(seed=SEED, n_pt=300, n_text=3):
+    """optimizer::InitBA: two keyframes, every landmark hosted in the first (constant) one, 4 pyramid levels."""
+    return make_problem(2, n_pt, n_text, seed, feats=(32, 16, 10, 6), n_levels=4, frozen_frac=0.0, max_targets=1, text_targets=1,
+                        n_fixed=1, kf_initial=[1, 0], self_obs=False)
+
+
+def landmark_refine(seed=SEED, n_kf=5, n_pt=150, n_text=4):
+    """optimizer::OptimizeLandmarker / ThetaOptimMultiFs: every pose constant (and at its true value), landmarks perturbed."""
+    return make_problem(n_kf, n_pt, n_text, seed, feats=(24, 12, 8, 6), n_levels=4, frozen_frac=0.0, text_targets=3,
+                        n_fixed=n_kf, kf_initial=np.ones(n_kf, np.uint8))
