@@ -44,6 +44,8 @@ def lib():
         L.tsba_oracle_partial_system.restype = C.c_int
         L.tsba_oracle_theta_cov.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, C.c_int, dp]
         L.tsba_oracle_theta_cov.restype = C.c_int
+        L.tsba_oracle_theta_optim.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.POINTER(TsbaReport), C.c_int, dp]
+        L.tsba_oracle_theta_optim.restype = C.c_int
         L.tsba_oracle_default_options.argtypes = [C.POINTER(TsbaOptions), C.c_int]
         L.tsba_oracle_default_options.restype = None
         _LIB = L
@@ -133,6 +135,15 @@ def partial_system(prob: BAProblem, opt: TsbaOptions, level: int, radius: float)
     assert nf >= 0, nf
     m = 6 * nf
     return {"nf": nf, "free_idx": free, "S": S[:m * m].reshape(m, m), "g": g[:m], "Hd": Hd[:m], "cost": cost.value}
+
+
+def theta_optim(prob: BAProblem, opt: TsbaOptions, text: int):
+    """ThetaOptimMultiFs: in-place solve + covariance of theta[text] from the last pass. -> (rc, report, cov 3x3)"""
+    s = prob.struct()
+    rep = TsbaReport()
+    cov = np.zeros(9)
+    rc = lib().tsba_oracle_theta_optim(C.byref(s), C.byref(opt), C.byref(rep), text, _dp(cov))
+    return rc, rep.as_dict(), cov.reshape(3, 3)
 
 
 def theta_cov(prob: BAProblem, opt: TsbaOptions, level: int, text: int):

@@ -890,7 +890,7 @@ int tsba_oracle_theta_cov(const tsba_problem *p, const tsba_options *o, int leve
 }
 
 /* ------------------------------------------------------------------ one pyramid pass: LM + outlier pass */
-static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_report *rep) {
+static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_report *rep, int cov_text, double *cov_out, int *cov_rc) {
     int level = o->levels[pass], max_it = o->its[pass];
     pass_t P; pass_build(&P, p, o, level);
     neq_t N; neq_alloc(&N, &P);
@@ -972,6 +972,10 @@ done:
     rep->n_sblock[pass] = P.ns; rep->n_tblock[pass] = P.nt;
     memcpy(p->pose, x_pose, sizeof(double)*npose); memcpy(p->rho, x_rho, sizeof(double)*nrho); memcpy(p->theta, x_th, sizeof(double)*nth);
 
+    if (cov_out && cov_text >= 0 && cov_text < p->n_text) {      /* ceres::Covariance on the same problem (mu / sigma of this pass) */
+        int li = P.tx_lm[cov_text];
+        *cov_rc = (li >= 0 && !inv_sym(N.V + 9*li, 3, cov_out)) ? TSBA_OK : TSBA_ERR_NUMERIC;
+    }
     /* outlier pass on loss-corrected residuals, optimizer.cc:1609-1686 / :1228-1305 */
     if (o->outlier_scene || o->outlier_text) {
         double chi2m = o->chi2_mono[pass]; if (P.nt < 50) chi2m += 4;
@@ -1010,9 +1014,22 @@ int tsba_oracle_solve(tsba_problem *p, const tsba_options *o, tsba_report *r) {
     r->n_passes = o->n_passes;
     for (int pass = 0; pass < o->n_passes; pass++) {
         if (o->levels[pass] < 0 || o->levels[pass] >= p->n_levels) return TSBA_ERR_ARG;
-        run_pass(p, o, pass, r);
+        run_pass(p, o, pass, r, -1, NULL, NULL);
     }
     return TSBA_OK;
+}
+
+/* optimizer::ThetaOptimMultiFs: the solve plus the covariance of theta[text] from the last pass (optimizer.cc:2219-2238) */
+int tsba_oracle_theta_optim(tsba_problem *p, const tsba_options *o, tsba_report *r, int text, double cov[9]) {
+    if (!p || !o || !r || !cov) return TSBA_ERR_ARG;
+    memset(r, 0, sizeof(*r));
+    r->n_passes = o->n_passes;
+    int crc = TSBA_ERR_NUMERIC;
+    for (int pass = 0; pass < o->n_passes; pass++) {
+        if (o->levels[pass] < 0 || o->levels[pass] >= p->n_levels) return TSBA_ERR_ARG;
+        run_pass(p, o, pass, r, text, cov, &crc);
+    }
+    return crc;
 }
 
 /* ------------------------------------------------------------------ defaults (duplicated on purpose: the oracle links nothing from the product) */

@@ -52,6 +52,8 @@ int tsba_oracle_partial_system(const tsba_problem *p, const tsba_options *o, int
 /* Covariance of theta[text] (all other parameters constant) at the current parameters, ceres::Covariance semantics. */
 int tsba_oracle_theta_cov(const tsba_problem *p, const tsba_options *o, int level, int text, double cov[9]);
 
+int tsba_oracle_theta_optim(tsba_problem *p, const tsba_options *o, tsba_report *r, int text, double cov[9]);
+
 /* Reference option sets: kind 0 = LocalBundleAdjustment, 1 = PoseOptim, 2 = GlobalBA. */
 void tsba_oracle_default_options(tsba_options *o, int kind);
 
