@@ -49,11 +49,13 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const int *tfeat_off, *tfeat_raw; const double *tfeat_uv, *tfeat_ref;
 };
 
+#define PT_REC 16
+#define TX_REC 48
 struct LinBuf {              // everything one linearisation produces
     double *pairM, *pairCost, *pairR, *pairOut, *tgM, *tgCost;
-    double *w_pt, *vb_pt;               // per point slot: w [6][n], (v, b, -Q^T w) [8][n]
+    double *w_pt;                       // per point slot, one 128-byte record: w[0..5] | v | b | -Q^T w [8..13]   (PT_REC doubles)
     double *V_pt, *b_pt, *dgs_pt;       // per point: V, b, clamp(sigma^2 V)/sigma^2  (lambda = dgs / radius)
-    double *w_tx, *vb_tx;               // per text slot: W [18][n], (V6, b3, -Q^T W 18) [27][n]
+    double *w_tx;                       // per plane slot, one 384-byte record: W[0..17] | V6 [18..23] | b3 [24..26] | -Q^T W [27..44]   (TX_REC doubles)
     double *V_tx, *b_tx, *dgs_tx;       // per plane: V [6][n], b [3][n], dgs [3][n]
     double *Hd, *bp, *dgs_p;            // per pose: diag(H_pp), gradient, dgs.  Hd | bp | scal[8] are one allocation (hb):
     double *bp_loc;                     // multi-GPU: this rank's part of bp (the reduced gradient is assembled from it)
@@ -335,9 +337,9 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
             if (!act) {
                 if (MODE == MODE_FULL && slot >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 6; k++) B.w_pt[(size_t)k*L.n_pslot + slot] = 0.0;
+                    for (int k = 0; k < 6; k++) B.w_pt[(size_t)(slot)*PT_REC + k] = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) B.vb_pt[(size_t)k*L.n_pslot + slot] = 0.0;
+                    for (int k = 0; k < 8; k++) B.w_pt[(size_t)(slot)*PT_REC + 6 + k] = 0.0;
                 }
                 continue;
             }
@@ -363,12 +365,12 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
                 if (slot >= 0) {
                     double w[6];
 #pragma unroll
-                    for (int a = 0; a < 6; a++) { w[a] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]); B.w_pt[(size_t)a*L.n_pslot + slot] = w[a]; }
-                    B.vb_pt[slot] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
-                    B.vb_pt[(size_t)L.n_pslot + slot] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
+                    for (int a = 0; a < 6; a++) { w[a] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]); B.w_pt[(size_t)(slot)*PT_REC + a] = w[a]; }
+                    B.w_pt[(size_t)slot*PT_REC + 6] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
+                    B.w_pt[(size_t)slot*PT_REC + 7] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
                     double qa[3], qc[3]; mat3T_vec(T.Rcr, w, qa); mat3T_vec(T.Rcr, w + 3, qc);     // host column: -Q^T w
 #pragma unroll
-                    for (int a = 0; a < 3; a++) { B.vb_pt[(size_t)(2 + a)*L.n_pslot + slot] = -qa[a]; B.vb_pt[(size_t)(5 + a)*L.n_pslot + slot] = -qc[a]; }
+                    for (int a = 0; a < 3; a++) { B.w_pt[(size_t)(slot)*PT_REC + 6 + (2 + a)] = -qa[a]; B.w_pt[(size_t)(slot)*PT_REC + 6 + (5 + a)] = -qc[a]; }
                 }
             }
         }
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
         } else {
             double tot = wave_sum_to_lane<55>(acc, lds, lane);
             if (lane < 27) B.tgM[(size_t)lane*L.n_tg + g] = tot;
-            else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(lane - 27)*L.n_tslot + slot] = tot; lds[lane - 27] = tot; }
-            else if (lane < 54) { if (slot >= 0) B.vb_tx[(size_t)(lane - 45)*L.n_tslot + slot] = tot; }
+            else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; lds[lane - 27] = tot; }
+            else if (lane < 54) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + 18 + (lane - 45)] = tot; }
             else if (lane == 54) B.tgCost[g] = tot;
             if (slot >= 0) {                    // host column of W: -blkdiag(R,R)^T W, rows (half, r), columns cc
                 if (lane < 9) {
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
                 if (lane < 18) {
                     const int half = lane/9, rr = (lane % 9)/3, cc = lane % 3;
                     double v = lds[32 + 0*3 + rr]*lds[(half*3 + 0)*3 + cc] + lds[32 + 1*3 + rr]*lds[(half*3 + 1)*3 + cc] + lds[32 + 2*3 + rr]*lds[(half*3 + 2)*3 + cc];
-                    B.vb_tx[(size_t)(9 + lane)*L.n_tslot + slot] = -v;
+                    B.w_tx[(size_t)(slot)*TX_REC + 18 + (9 + lane)] = -v;
                 }
             }
         }
@@ -489,10 +491,10 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             double acc[8] = {0,0,0,0,0,0,0,0};
             for (int s = o; s < e - 1; s++) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) acc[k] += B.vb_pt[(size_t)k*L.n_pslot + s];
+                for (int k = 0; k < 8; k++) acc[k] += B.w_pt[(size_t)(s)*PT_REC + 6 + k];
             }
 #pragma unroll
-            for (int k = 0; k < 6; k++) B.w_pt[(size_t)k*L.n_pslot + e - 1] = acc[2 + k];
+            for (int k = 0; k < 6; k++) B.w_pt[(size_t)(e - 1)*PT_REC + k] = acc[2 + k];
             const double V = acc[0];
             B.V_pt[j] = V; B.b_pt[j] = acc[1];
             if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
@@ -510,10 +512,10 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             for (int k = 0; k < 27; k++) acc[k] = 0.0;
             for (int s = o; s < e - 1; s++) {
 #pragma unroll
-                for (int k = 0; k < 27; k++) acc[k] += B.vb_tx[(size_t)k*L.n_tslot + s];
+                for (int k = 0; k < 27; k++) acc[k] += B.w_tx[(size_t)(s)*TX_REC + 18 + k];
             }
 #pragma unroll
-            for (int k = 0; k < 18; k++) B.w_tx[(size_t)k*L.n_tslot + e - 1] = acc[9 + k];
+            for (int k = 0; k < 18; k++) B.w_tx[(size_t)(e - 1)*TX_REC + k] = acc[9 + k];
 #pragma unroll
             for (int k = 0; k < 6; k++) B.V_tx[(size_t)k*W.n_text + j] = acc[k];
 #pragma unroll
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
             const double vinv = 1.0/(B.V_pt[j] + B.dgs_pt[j]*irad);
             double w1[6], w2[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { w1[k] = B.w_pt[(size_t)k*L.n_pslot + s1]*vinv; w2[k] = B.w_pt[(size_t)k*L.n_pslot + s2]; }
+            for (int k = 0; k < 6; k++) { w1[k] = B.w_pt[(size_t)(s1)*PT_REC + k]*vinv; w2[k] = B.w_pt[(size_t)(s2)*PT_REC + k]; }
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
             if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
             double W1[18], W2[18];
 #pragma unroll
-            for (int k = 0; k < 18; k++) { W1[k] = B.w_tx[(size_t)k*L.n_tslot + s1]; W2[k] = B.w_tx[(size_t)k*L.n_tslot + s2]; }
+            for (int k = 0; k < 18; k++) { W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k]; W2[k] = B.w_tx[(size_t)(s2)*TX_REC + k]; }
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 double t0 = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
@@ -723,7 +725,7 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
             const int s = L.pose_ps[q], j = L.pose_ps_lm[q];
             const double f = B.b_pt[j]/(B.V_pt[j] + B.dgs_pt[j]*irad);
 #pragma unroll
-            for (int k = 0; k < 6; k++) acc[k] += B.w_pt[(size_t)k*L.n_pslot + s]*f;
+            for (int k = 0; k < 6; k++) acc[k] += B.w_pt[(size_t)(s)*PT_REC + k]*f;
         }
         for (int q = L.pose_ts_off[a] + lane; q < L.pose_ts_off[a+1]; q += 64) {
             const int s = L.pose_ts[q], j = L.pose_ts_lm[q];
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
             double f0 = Vi[0]*b0 + Vi[1]*b1 + Vi[2]*b2, f1 = Vi[1]*b0 + Vi[3]*b1 + Vi[4]*b2, f2 = Vi[2]*b0 + Vi[4]*b1 + Vi[5]*b2;
 #pragma unroll
             for (int k = 0; k < 6; k++)
-                acc[k] += B.w_tx[(size_t)(k*3)*L.n_tslot + s]*f0 + B.w_tx[(size_t)(k*3 + 1)*L.n_tslot + s]*f1 + B.w_tx[(size_t)(k*3 + 2)*L.n_tslot + s]*f2;
+                acc[k] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*f0 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*f1 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*f2;
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) acc[k] = wave_sum1(acc[k]);
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
                 double acc = B.b_pt[j];
                 for (int s = o; s < e; s++) { const int a = L.pslot_pose[s];       // dp is 0 for constant / absent poses
 #pragma unroll
-                    for (int k = 0; k < 6; k++) acc += B.w_pt[(size_t)k*L.n_pslot + s]*W.dp[6*a + k]; }
+                    for (int k = 0; k < 6; k++) acc += B.w_pt[(size_t)(s)*PT_REC + k]*W.dp[6*a + k]; }
                 const double lam = B.dgs_pt[j]*irad;
                 d = -acc/(B.V_pt[j] + lam);
                 step2 = d*d; mcc = lam*d*d - B.b_pt[j]*d;
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
                 for (int s = o; s < e; s++) { const int a = L.tslot_pose[s];
 #pragma unroll
                     for (int k = 0; k < 6; k++) { const double dpk = W.dp[6*a + k];
-                        acc[0] += B.w_tx[(size_t)(k*3)*L.n_tslot + s]*dpk; acc[1] += B.w_tx[(size_t)(k*3 + 1)*L.n_tslot + s]*dpk; acc[2] += B.w_tx[(size_t)(k*3 + 2)*L.n_tslot + s]*dpk; } }
+                        acc[0] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*dpk; acc[1] += B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*dpk; acc[2] += B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*dpk; } }
                 double Vd[6], Vi[6], lam[3];
 #pragma unroll
                 for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
@@ -1272,8 +1274,8 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         LinBuf &B = W.lb[b];
         AL(B.pairM, 27*mx_pair); AL(B.pairCost, mx_pair); AL(B.pairR, 9*mx_pair); AL(B.pairOut, 90*mx_pair);
         AL(B.tgM, 27*mx_tg); AL(B.tgCost, mx_tg);
-        AL(B.w_pt, 6*mx_pslot); AL(B.vb_pt, 8*mx_pslot); AL(B.V_pt, p->n_pt); AL(B.b_pt, p->n_pt); AL(B.dgs_pt, p->n_pt);
-        AL(B.w_tx, 18*mx_tslot); AL(B.vb_tx, 27*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
+        AL(B.w_pt, PT_REC*mx_pslot); AL(B.V_pt, p->n_pt); AL(B.b_pt, p->n_pt); AL(B.dgs_pt, p->n_pt);
+        AL(B.w_tx, TX_REC*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
         AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.bp_loc, W.N); AL(B.dgs_p, W.N);
         AL(B.lmpart, 2*((size_t)c->nb_back_max + mx_pair/256 + 2));
     }

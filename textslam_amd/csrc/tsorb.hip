@@ -50,6 +50,7 @@ struct OrbDev {
     int *nodes, *pool, *snbuf;             // quadtree scratch per (frame, level)
     float *sel;                            // [n][slots][4]  x, y (level coords incl. border offset), response, angle
     int *selcnt;                           // [n][nlevels]
+    int *qfallback;                        // [n][nlevels] 1 = the LDS quadtree could not hold this level (serial kernel takes over)
     uint8_t *seldesc;                      // [n][slots][32]
     float *out_kp; uint8_t *out_desc; int *out_cnt;
     int umax[16]; int gk[7];
@@ -221,8 +222,9 @@ __device__ void q_divide(QList &L, int src, int c[4], int node_cap, int pool_cap
     for (int i = 0; i < s.nk; i++) { int key = L.pool[s.key0 + i]; const float *kp = L.kp + 3*key;
         int q = (kp[0] < ux) ? ((kp[1] < by) ? 0 : 2) : ((kp[1] < by) ? 1 : 3); L.pool[w[q]++] = key; }
 }
-__global__ __launch_bounds__(64) void k_octree(OrbDev D) {
+__global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) {
     const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, tid = threadIdx.x;
+    if (!D.qfallback[blockIdx.x]) return;
     const LevelGeo &G = D.L[l];
     float *cand = D.cand + ((size_t)f*D.nlevels + l)*D.cand_cap*3;
     __shared__ int s_nc;
@@ -311,6 +313,163 @@ __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
         ns++;
     }
     *selcnt = ns;
+}
+
+
+// ---------------------------------------------------------------- quadtree, wave-cooperative, everything in LDS.
+// One wave per (frame, level).  Candidates (x, y, response), the per-node key lists and the node pool live in LDS; the list
+// surgery is executed redundantly by all 64 lanes (uniform control flow, lane 0 writes), the 4-way stable partition of a
+// node's keys and the final arg-max are spread over the lanes.  Levels that do not fit fall back to k_octree_serial.
+#define QL_CAND 4096
+#define QL_NODES 1024
+struct LNode { short x0, y0, x1, y1; int key0, nk; short nomore, pad; short prev, next; int id; };     // 24 bytes
+__global__ __launch_bounds__(64) void k_octree(OrbDev D) {
+    const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, lane = threadIdx.x;
+    const LevelGeo &G = D.L[l];
+    __shared__ float cx[QL_CAND], cy[QL_CAND], cr[QL_CAND];
+    __shared__ unsigned short keys[QL_CAND], tmpk[QL_CAND];
+    __shared__ LNode nd[QL_NODES];
+    __shared__ short freelist[QL_NODES];
+    __shared__ int vs[2*QL_NODES], vp[2*QL_NODES];
+    __shared__ int s_off[1];
+    int *selcnt = D.selcnt + (size_t)f*D.nlevels + l;
+    float *sel = D.sel + ((size_t)f*D.slots_per_frame + G.kp0)*4;
+    // ---- gather the cells (reference order) into LDS: per-cell offsets by lane 0, copy by all lanes
+    const int ncell = G.nCols*G.nRows;
+    const int *cnt = D.cellcnt + (size_t)f*D.cells_per_frame + G.cell0;
+    const uint32_t *ck = D.cellkp + ((size_t)f*D.cells_per_frame + G.cell0)*CELL_CAP;
+    int nk = 0;
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+        const int c = c0 + lane;
+        const int n = c < ncell ? cnt[c] : 0;
+        int incl = n;                                   // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const int base = nk + incl - n;
+        if (c < ncell && base + n <= QL_CAND) {
+            const int i = c / G.nCols, j = c % G.nCols;
+            for (int q = 0; q < n; q++) { uint32_t p = ck[(size_t)c*CELL_CAP + q];
+                cx[base + q] = (float)((int)(p & 255u) + j*G.wCell); cy[base + q] = (float)((int)((p >> 8) & 255u) + i*G.hCell); cr[base + q] = (float)(p >> 16); }
+        }
+        nk += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) D.qfallback[blockIdx.x] = 0;
+    if (nk == 0) { if (lane == 0) *selcnt = 0; return; }
+    if (nk > QL_CAND) { if (lane == 0) D.qfallback[blockIdx.x] = 1; return; }
+    __syncthreads();
+    const int minX = G.minB, maxX = G.maxBX, minY = G.minB, maxY = G.maxBY, N = G.nfeat;
+    const int nIni = (int)roundf((float)(maxX - minX)/(float)(maxY - minY));
+    const float hX = (float)(maxX - minX)/(float)nIni;
+    // ---- list state (identical in every lane)
+    int head = -1, tail = -1, size = 0, nfree = 0, next_id = 0, nalloc = 0;
+    bool overflow = false;
+    auto alloc = [&]() -> int { int i; if (nfree > 0) i = freelist[--nfree]; else if (nalloc < QL_NODES) i = nalloc++; else { overflow = true; i = QL_NODES - 1; }
+        if (lane == 0) { nd[i].nomore = 0; nd[i].prev = nd[i].next = -1; nd[i].nk = 0; nd[i].key0 = 0; nd[i].id = next_id; } next_id++; return i; };
+    auto release = [&](int i) { if (lane == 0) freelist[nfree] = (short)i; nfree++; };
+    auto push_back = [&](int i) { if (lane == 0) { nd[i].prev = (short)tail; nd[i].next = -1; if (tail >= 0) nd[tail].next = (short)i; } if (tail < 0) head = i; tail = i; size++; };
+    auto push_front = [&](int i) { if (lane == 0) { nd[i].next = (short)head; nd[i].prev = -1; if (head >= 0) nd[head].prev = (short)i; } if (head < 0) tail = i; head = i; size++; };
+    auto erase = [&](int i) -> int { const int p = nd[i].prev, nx = nd[i].next;
+        if (lane == 0) { if (p >= 0) nd[p].next = (short)nx; if (nx >= 0) nd[nx].prev = (short)p; }
+        if (p < 0) head = nx; if (nx < 0) tail = p; size--; return nx; };
+    // ---- initial nodes
+    for (int i = 0; i < nIni; i++) { int q = alloc();
+        if (lane == 0) { nd[q].x0 = (short)(int)(hX*(float)i); nd[q].y0 = 0; nd[q].x1 = (short)(int)(hX*(float)(i + 1)); nd[q].y1 = (short)(maxY - minY); }
+        push_back(q); }
+    __syncthreads();
+    if (nIni == 1) { for (int k = lane; k < nk; k += 64) keys[k] = (unsigned short)k; if (lane == 0) { nd[0].key0 = 0; nd[0].nk = nk; } }
+    else {           // general case (never for 4:3 images): stable bucket by x / hX, serial on lane 0
+        if (lane == 0) { int top = 0; for (int i = 0; i < nIni; i++) { int c2 = 0; for (int k = 0; k < nk; k++) { int q = (int)(cx[k]/hX); if (q >= nIni) q = nIni - 1; if (q == i) keys[top + c2++] = (unsigned short)k; }
+            nd[i].key0 = top; nd[i].nk = c2; top += c2; } }
+    }
+    __syncthreads();
+    for (int it = head; it >= 0; ) { const int n1 = nd[it].nk; const int nx = nd[it].next;
+        if (n1 == 1) { if (lane == 0) nd[it].nomore = 1; it = nx; } else if (n1 == 0) { int e = erase(it); release(it); it = e; } else it = nx; __syncthreads(); }
+    // ---- 4-way stable partition of node `src` into four children (cooperative)
+    auto divide = [&](int src, int c[4]) {
+        const int sx0 = nd[src].x0, sy0 = nd[src].y0, sx1 = nd[src].x1, sy1 = nd[src].y1, k0 = nd[src].key0, n = nd[src].nk;
+        const int halfX = (int)ceilf((float)(sx1 - sx0)/2), halfY = (int)ceilf((float)(sy1 - sy0)/2);
+        const float ux = (float)(sx0 + halfX), by = (float)(sy0 + halfY);
+        int cn[4] = {0, 0, 0, 0};
+        for (int b = 0; b < n; b += 64) {
+            const int k = b + lane; int q = -1;
+            if (k < n) { const int key = keys[k0 + k]; tmpk[k] = (unsigned short)key; q = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
+#pragma unroll
+            for (int z = 0; z < 4; z++) cn[z] += __popcll(__ballot(q == z));
+        }
+        int st[4]; st[0] = k0; st[1] = st[0] + cn[0]; st[2] = st[1] + cn[1]; st[3] = st[2] + cn[2];
+        for (int z = 0; z < 4; z++) c[z] = alloc();
+        if (lane == 0) {
+            nd[c[0]].x0 = (short)sx0; nd[c[0]].y0 = (short)sy0; nd[c[0]].x1 = (short)(sx0 + halfX); nd[c[0]].y1 = (short)(sy0 + halfY);
+            nd[c[1]].x0 = (short)(sx0 + halfX); nd[c[1]].y0 = (short)sy0; nd[c[1]].x1 = (short)sx1; nd[c[1]].y1 = (short)(sy0 + halfY);
+            nd[c[2]].x0 = (short)sx0; nd[c[2]].y0 = (short)(sy0 + halfY); nd[c[2]].x1 = (short)(sx0 + halfX); nd[c[2]].y1 = (short)sy1;
+            nd[c[3]].x0 = (short)(sx0 + halfX); nd[c[3]].y0 = (short)(sy0 + halfY); nd[c[3]].x1 = (short)sx1; nd[c[3]].y1 = (short)sy1;
+            for (int z = 0; z < 4; z++) { nd[c[z]].key0 = st[z]; nd[c[z]].nk = cn[z]; nd[c[z]].nomore = cn[z] == 1; }
+        }
+        __syncthreads();                               // tmpk complete
+        int run[4] = { st[0], st[1], st[2], st[3] };
+        for (int b = 0; b < n; b += 64) {
+            const int k = b + lane; int q = -1, key = 0;
+            if (k < n) { key = tmpk[k]; q = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
+#pragma unroll
+            for (int z = 0; z < 4; z++) { const unsigned long long m = __ballot(q == z);
+                if (q == z) keys[run[z] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)key;
+                run[z] += __popcll(m); }
+        }
+        __syncthreads();
+    };
+    bool finish = false; int nvs = 0;
+    while (!finish && !overflow) {
+        const int prevSize = size; int nToExpand = 0; nvs = 0;
+        for (int it = head; it >= 0; ) {
+            if (nd[it].nomore) { it = nd[it].next; continue; }
+            int c[4]; divide(it, c);
+            for (int z = 0; z < 4; z++) { const int cn = nd[c[z]].nk;
+                if (cn > 0) { push_front(c[z]); if (cn > 1) { nToExpand++; if (lane == 0 && nvs < QL_NODES) { vs[2*nvs] = cn; vs[2*nvs+1] = c[z]; } nvs++; } }
+                else release(c[z]);
+                __syncthreads(); }
+            const int nx = erase(it); release(it); it = nx;
+            __syncthreads();
+        }
+        if (nvs > QL_NODES) overflow = true;
+        if (size >= N || size == prevSize) finish = true;
+        else if (size + nToExpand*3 > N) {
+            while (!finish && !overflow) {
+                const int prevSize2 = size; const int np = nvs;
+                // rank sort ascending by (size, creation order): lanes share the elements
+                for (int a = lane; a < np; a += 64) { const int s0 = vs[2*a], n0 = vs[2*a+1], i0 = nd[n0].id; int rank = 0;
+                    for (int b2 = 0; b2 < np; b2++) { const int s1 = vs[2*b2], i1 = nd[vs[2*b2+1]].id; rank += (s1 < s0 || (s1 == s0 && i1 < i0)); }
+                    vp[2*rank] = s0; vp[2*rank+1] = n0; }
+                __syncthreads();
+                nvs = 0;
+                for (int jq = np - 1; jq >= 0; jq--) {
+                    const int srcn = vp[2*jq+1];
+                    int c[4]; divide(srcn, c);
+                    for (int z = 0; z < 4; z++) { const int cn = nd[c[z]].nk;
+                        if (cn > 0) { push_front(c[z]); if (cn > 1) { if (lane == 0 && nvs < QL_NODES) { vs[2*nvs] = cn; vs[2*nvs+1] = c[z]; } nvs++; } }
+                        else release(c[z]);
+                        __syncthreads(); }
+                    erase(srcn); release(srcn);
+                    __syncthreads();
+                    if (size >= N) break;
+                }
+                if (nvs > QL_NODES) overflow = true;
+                if (size >= N || size == prevSize2) finish = true;
+            }
+        }
+    }
+    if (overflow) { if (lane == 0) D.qfallback[blockIdx.x] = 1; return; }
+    // ---- best response per node, in list order: lane 0 walks the list into vs[], lanes take nodes
+    int ns = 0;
+    if (lane == 0) { int q = 0; for (int it = head; it >= 0 && q < G.capL; it = nd[it].next) vs[q++] = it; s_off[0] = q; }
+    __syncthreads();
+    ns = s_off[0];
+    for (int q = lane; q < ns; q += 64) {
+        const LNode n = nd[vs[q]];
+        int best = keys[n.key0]; float mr = cr[best];
+        for (int k = 1; k < n.nk; k++) { const int key = keys[n.key0 + k]; if (cr[key] > mr) { best = key; mr = cr[key]; } }
+        sel[4*q] = cx[best] + (float)minX; sel[4*q+1] = cy[best] + (float)minY; sel[4*q+2] = mr; sel[4*q+3] = 0.f;
+    }
+    if (lane == 0) *selcnt = ns;
 }
 
 // ---------------------------------------------------------------- orientation: 16 lanes per keypoint
@@ -510,7 +669,7 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     if ((rc = oalloc(c, &D.cand, (size_t)n*c->nlevels*D.cand_cap*3))) return rc;
     if ((rc = oalloc(c, &D.nodes, (size_t)n*c->nlevels*D.node_cap*(sizeof(QNode)/sizeof(int)))) || (rc = oalloc(c, &D.pool, (size_t)n*c->nlevels*D.pool_cap)) ||
         (rc = oalloc(c, &D.snbuf, (size_t)n*c->nlevels*4*D.node_cap))) return rc;
-    if ((rc = oalloc(c, &D.sel, (size_t)n*kp0*4)) || (rc = oalloc(c, &D.selcnt, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.seldesc, (size_t)n*kp0*32))) return rc;
+    if ((rc = oalloc(c, &D.sel, (size_t)n*kp0*4)) || (rc = oalloc(c, &D.selcnt, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.qfallback, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.seldesc, (size_t)n*kp0*32))) return rc;
     if ((rc = oalloc(c, &D.out_kp, (size_t)n*cap*6)) || (rc = oalloc(c, &D.out_desc, (size_t)n*cap*32)) || (rc = oalloc(c, &D.out_cnt, (size_t)n))) return rc;
     OCK(hipStreamSynchronize(c->stream));
     c->uploaded = true; return TSORB_OK;
@@ -523,6 +682,7 @@ int tsorb_run(void *ctx) {
     for (int l = 1; l < D.nlevels; l++) { size_t tot = (size_t)D.n*D.L[l].bw*D.L[l].bh; hipLaunchKernelGGL(k_resize, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, D, l); }
     hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);
+    hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
     hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
     for (int l = 0; l < D.nlevels; l++) { int nt = ((D.L[l].w + BT_W - 1)/BT_W)*((D.L[l].h + BT_H - 1)/BT_H); hipLaunchKernelGGL(k_blur, dim3(D.n*nt), dim3(256), 0, c->stream, D, l); }
     hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*64 + 255)/256), dim3(256), 0, c->stream, D);
