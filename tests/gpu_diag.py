@@ -68,9 +68,9 @@ def main():
     import ctypes
     st = (ctypes.c_longlong * 64)()
     opt.solve(); opt.lib.tsba_debug_stamps(opt.ctx, st)
-    print("k_solve stamps (cycles): load %d factor %d backsub %d | ldl %d panel %d trailing %d nfree %d" % tuple(st[:7]))
-    for i, nm in enumerate(("D wave0", "P wave1", "T wave3")):
-        print("   %s: work %d  barrier1-wait %d  panel-phase %d  barrier2-wait %d" % ((nm,) + tuple(st[8+4*i:12+4*i])))
+    print("k_solve stamps (cycles, TSBA_LIB=libtsba_stamps.so only): load %d factor %d backsub %d nfree %d" % (st[0], st[1], st[2], st[6]))
+    for i, nm in enumerate(("P wave0", "T wave2", "T last")):
+        print("   %s: lookahead+scratch %d  ldl %d  solve/trailing %d  barrier-wait %d" % ((nm,) + tuple(st[8+4*i:12+4*i])))
     for l in (0, 1, 2):
         ms, nb = opt.time_linearize(l, 50)
         print(f"linearize level {l}: {ms*1e3:.2f} us, algorithmic bytes {nb:.0f}, {nb/ms/1e6:.1f} GB/s")

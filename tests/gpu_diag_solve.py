@@ -1,0 +1,21 @@
+"""GPU diagnostic (not a pytest): k_solve cycle stamps on the C4 window. Run with TSBA_LIB=textslam_amd/libtsba_stamps.so."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from textslam_amd import synth, abi
+from textslam_amd.optimizer import Optimizer
+
+opt = Optimizer(0)
+P = synth.config_c4(); o = abi.options_local()
+opt.upload(P, o)
+for _ in range(3):
+    rep = opt.solve()
+print("t_solve_ms", rep['t_solve_ms'])
+st = (ctypes.c_longlong * 64)()
+opt.lib.tsba_debug_stamps(opt.ctx, st)
+print("k_solve stamps (cycles): load %d factor %d backsub %d nfree %d" % (st[0], st[1], st[2], st[6]))
+for i, nm in enumerate(("P wave0 (look-ahead | scratch+ldl | solve | barrier)", "T wave2 (- | - | trailing | barrier)", "T last")):
+    print("   %s: lookahead+scratch %d  ldl %d  solve/trailing %d  barrier-wait %d" % ((nm,) + tuple(st[8+4*i:12+4*i])))
+ms = ctypes.c_double()
+opt.lib.tsba_debug_time_solve.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+rc = opt.lib.tsba_debug_time_solve(opt.ctx, 200, ctypes.byref(ms))
+print("k_solve back-to-back: rc %d, %.2f us per launch" % (rc, ms.value*1e3))

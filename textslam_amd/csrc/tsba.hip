@@ -1338,15 +1338,15 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi);
 }
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
-    size_t N = c->W.N, ld = N | 1, bytes = ((N + 1)*ld + 32*(N/6) + 8)*sizeof(double);     // worst case: every pose free
-    *use_lds = bytes <= 150*1024;
+    size_t bytes = solve_lds_doubles(c->W.N)*sizeof(double);                                // worst case: every pose free
+    *use_lds = bytes <= 160*1024 - 64;                                                      // gfx950: 160 KB of LDS per workgroup
     return *use_lds ? (int)bytes : 0;
 }
 // dense solve of the reduced camera system: LDS kernel for small windows, multi-workgroup blocked Cholesky otherwise
 static void launch_solve(Ctx *c) {
     Work &W = c->W;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) { hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W); return; }
+    if (use_lds) { hipLaunchKernelGGL(k_solve, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W); return; }
     const int N = W.N;                                             // worst case: every keyframe free
     hipLaunchKernelGGL(k_chol_rhs, dim3((N + 255)/256), dim3(256), 0, c->stream, W);
     const int lds_panel = (CH_NB*(CH_NB + 1)/2 + CH_PT*(CH_NB + 1))*(int)sizeof(double);
@@ -1388,7 +1388,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
     memset(r, 0, sizeof(*r));
     const tsba_options &o = c->opt;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     else {
         CK(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB*(CH_NB + 1)/2 + CH_PT*(CH_NB + 1))*(int)sizeof(double)));
         CK(hipFuncSetAttribute((const void *)k_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2*64*(CH_NB + 1)*(int)sizeof(double)));
@@ -1541,7 +1541,7 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     tsba_options saved = c->opt; c->opt.initial_radius = radius;
     const LevelDev &D = c->lev[c->opt.levels[0]];
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     launch_pass_init(c, D, 0);
     launch_linearize(c, D, 0);
     Work &W = c->W;
@@ -1586,6 +1586,23 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
         for (int g = 0; g < D.n_tg; g++) npairs_text++;
         *algo_bytes = 44.0*st.ns_active + 128.0*st.nt_active + 16.0*npairs_text + 56.0*c->n_kf + 8.0*c->n_pt + 24.0*c->n_text;
     }
+    return TSBA_OK;
+}
+
+int tsba_debug_time_solve(void *ctx, int n, double *avg_ms) {     // n back-to-back launches of the dense solve on the last S, g
+    Ctx *c = (Ctx *)ctx; if (!c || n <= 0 || !c->uploaded) return TSBA_ERR_ARG;
+    hipSetDevice(c->device);
+    CK(hipStreamSynchronize(c->stream));
+    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
+    st.done = 0; st.step_fail = 0;
+    CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));
+    launch_solve(c);
+    CK(hipEventRecord(c->ev0, c->stream));
+    for (int k = 0; k < n; k++) launch_solve(c);
+    CK(hipEventRecord(c->ev1, c->stream));
+    CK(hipEventSynchronize(c->ev1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = (double)ms/n;
     return TSBA_OK;
 }
 

@@ -1,36 +1,46 @@
 // Dense solve of the reduced camera system S dp = -g (included by tsba.hip after the device structs).
 #pragma once
 
-// ---- dense solve of S dp = -g for the free poses: blocked (6x6) LDL^T in LDS, one workgroup of 16 waves.
-// A = [S; g^T] is held as (n+1) rows; the right-hand side rides along as an extra panel row, so the forward
-// substitution is part of the factorisation.  Per 6x6 block column: every thread factors the diagonal block redundantly
-// in registers (no division chain: one reciprocal per pivot), one thread per row solves the panel, then 6 threads per
-// 6x6 block apply the rank-6 trailing update.
-#define SOLVE_THREADS 1024
-__device__ __forceinline__ void ldl6(const double *A, int ld, double l[15], double d[6], double id[6], bool &bad) {
-    // lower 6x6 at A (row stride ld) -> unit-lower l (packed rows: (1,0) (2,0) (2,1) (3,0) ...), d, 1/d
-    double a[21];
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c <= r; c++) a[r*(r+1)/2 + c] = A[(size_t)r*ld + c];
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-        double dc = a[c*(c+1)/2 + c];
-#pragma unroll
-        for (int k = 0; k < c; k++) dc -= l[c*(c-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
-        if (!(dc > 0.0)) { bad = true; dc = 1.0; }
-        d[c] = dc; id[c] = 1.0/dc;
-#pragma unroll
-        for (int r = c + 1; r < 6; r++) {
-            double v = a[r*(r+1)/2 + c];
-#pragma unroll
-            for (int k = 0; k < c; k++) v -= l[r*(r-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
-            l[r*(r-1)/2 + c] = v*id[c];
-        }
-    }
-}
+// ---- one workgroup of 12 waves, the whole system resident in LDS as a packed lower triangle (rows padded to an even length so
+// that the 6-wide pose blocks move as b128), the right-hand side g riding along as row n so that the forward substitution is
+// part of the factorisation.  Blocked (6x6 = one pose) LDL^T with ONE workgroup barrier per block column:
+//   waves 0,1 ("P")   own the latency chain.  After barrier jb every lane owns one row below the diagonal block (lanes 0..5 of
+//                     BOTH waves own the 6 rows of the diagonal block itself, redundantly): it applies panel jb-1 to its row of
+//                     block column jb (look-ahead), the 6 diagonal rows go through a wave-private scratch to all lanes, every
+//                     lane factors the 6x6 block in registers (no cross-wave hand-off) and solves its own panel row.
+//   waves 2..11 ("T") apply panel jb-1 to everything right of block column jb on the matrix cores (v_mfma_f64_16x16x4, K = 6
+//                     padded to 8), 16x16 tiles of the packed triangle; the last wave also inverts the unit-lower factor of
+//                     block jb-1 for the back-substitution.
+// Measured on MI355X (tools/lat_bench, lds_bench, branch_bench): one wave issues an instruction every ~4.2 cycles (fp64 VALU
+// ~5.5, ds_read_b128 ~12, v_mfma_f64_16x16x4 64, taken scalar branch ~10), so each phase is sized in INSTRUCTIONS, not in
+// dependent-latency terms.  Variants that keep the trailing matrix in register tiles (LDS only for the panels) or use a
+// two-barrier MFMA look-ahead were measured within 10 % of this one; this is the simplest of the three.
+// The back-substitution L^T x = z runs in wave 0 with z in registers (60 rows per register: the register a block lives in is a
+// compile-time constant), x_block = L_jj^-T z_block from the stored inverse factors, next block's operands prefetched.
+#define SOLVE_THREADS 768
+#define SOLVE_PW 2                          // panel waves
+#define SOLVE_PROWS (64 - 6)                // panel rows per wave and chunk
+#ifdef TSBA_SOLVE_STAMPS                    // make stamps: cycle stamps into W.dbg (tsba_debug_stamps), perturbs the timing
+#define STAMP(v) do { long long t_ = clock64(); v += t_ - tx; tx = t_; } while (0)
+#else
+#define STAMP(v) do { } while (0)
+#endif
+#define SOLVE_LD 48                         // per block: l[15] pad d[6] 1/d[6] inv(L)[15] pad  (16-byte aligned groups)
+#define LD_D 16
+#define LD_ID 22
+#define LD_M 28
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__host__ __device__ __forceinline__ int tri(int i) { return (i*(i + 1)) >> 1; }
+// packed lower triangle with every row padded to an even length: rows start 16-byte aligned, so the 6-wide pose blocks
+// (even column offsets) move as ds_read_b128 / ds_write_b128
+__host__ __device__ __forceinline__ int rowoff(int i) { return ((i + 1) >> 1)*((i >> 1) + 1)*2; }
+__device__ __forceinline__ int tri_row(int e) {          // largest i with tri(i) <= e   (e < 2^22)
+    int i = (int)((__fsqrt_rn(8.f*(float)e + 1.f) - 1.f)*0.5f);
+    if (tri(i) > e) i--; else if (tri(i + 1) <= e) i++;
+    return i;
+}
 __device__ __forceinline__ double rcp_nr(double d) {        // v_rcp_f64 + two Newton steps (d > 0, normal range)
     double x = __builtin_amdgcn_rcp(d);
     double e = fma(-d, x, 1.0); x = fma(x, e, x);
@@ -41,234 +51,293 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {   // src mus
     int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
-// Schedule per block column jb (two barriers):
-//   wave 0 ("D"):      applies panel jb-1 to the 6x6 diagonal block jb, factors it (LDL^T in registers)       | concurrently
-//   waves 1,2 ("P"):   apply panel jb-1 to the rest of block column jb (one row per lane)                     | with
-//   waves 3..15 ("T"): trailing update of the columns >= jb+1 with panel jb-1 on the matrix cores             | each other
-//   -- barrier --      P: panel jb (x L^T = a, l_row = x D^-1), rows below + rhs row
-//   -- barrier --
-template <bool use_lds>
+__device__ __forceinline__ void wave_lds_fence() {          // order this wave's LDS writes before its following LDS reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void ld6(const double *p, double v[6]) {      // p 16-byte aligned
+    const v2d a = ((const v2d *)p)[0], b = ((const v2d *)p)[1], c = ((const v2d *)p)[2];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+}
+__device__ __forceinline__ void st6(double *p, const double v[6]) {
+    ((v2d *)p)[0] = v2d{v[0], v[1]}; ((v2d *)p)[1] = v2d{v[2], v[3]}; ((v2d *)p)[2] = v2d{v[4], v[5]};
+}
+// lower 6x6 s (packed rows) -> unit-lower l (packed strictly-lower rows (1,0) (2,0) (2,1) ...), d, 1/d.  Right-looking; a
+// single wave issues one instruction per ~4.5 cycles, so the instruction count is what matters here, not the chain
+__device__ __forceinline__ void ldl6(double s[21], double l[15], double d[6], double id[6], bool &bad) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double dc = s[tri(c) + c];
+        if (!(dc > 0.0)) { bad = true; dc = 1.0; }
+        d[c] = dc; id[c] = rcp_nr(dc);
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) {
+            const double v = s[tri(r) + c], lr = v*id[c];
+            l[tri(r - 1) + c] = lr;
+#pragma unroll
+            for (int q = c + 1; q <= r; q++) s[tri(r) + q] = fma(-lr, s[tri(q) + c], s[tri(r) + q]);
+        }
+    }
+}
+// M = L^-1 for unit-lower L (both packed strictly-lower)
+__device__ __forceinline__ void inv_unit_lower6(const double l[15], double m[15]) {
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) {
+            double v = -l[tri(r - 1) + c];
+#pragma unroll
+            for (int k = c + 1; k < r; k++) v = fma(-l[tri(r - 1) + k], m[tri(k - 1) + c], v);
+            m[tri(r - 1) + c] = v;
+        }
+}
+
+static size_t solve_lds_doubles(int N) { return (size_t)rowoff(N + 1) + 16 + (size_t)SOLVE_LD*(N/6) + 36*SOLVE_PW + 8; }
+
+template <int w> struct IC { static constexpr int value = w; };
+
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W) {
     LmState *st = W.st;
-    if (st->done) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long T0 = clock64();
-    const int nfree = *W.nfree, n = 6*nfree, Nmax = W.N;
-    const int ld = use_lds ? (n | 1) : Nmax;
-    // separate instantiations keep LDS accesses as ds_* instructions (a runtime-selected pointer would go through FLAT)
-    auto sel = [&](auto lds_ptr, double *glob) { if constexpr (use_lds) return lds_ptr; else return glob; };
-    auto A = sel(smem, W.S);                                            // rows 0..n, row n = right-hand side g
-    auto LD = sel(smem + (n + 1)*ld, W.LDbuf);                  // per block: 15 l, 6 d, 6 1/d (stride 32)
-    if (use_lds) {
-        for (int r = tid >> 5; r < n; r += SOLVE_THREADS/32)
-            for (int cidx = tid & 31; cidx <= r; cidx += 32) A[r*ld + cidx] = W.S[r*Nmax + cidx];
-    }
-    for (int k = tid; k < n; k += SOLVE_THREADS) A[n*ld + k] = W.g[k];
     __shared__ int fail;
-    if (tid == 0) fail = st->step_fail;
-    __syncthreads();
-    long long T1 = clock64();
-    long long tw = 0, tb1 = 0, tp = 0, tb2 = 0, tx;
-    for (int jb = 0; jb < nfree; jb++) {
-        const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
-        tx = clock64();
-        if (wave == 0) {
-            if (jb > 0 && lane < 36) {       // diagonal block jb -= Lp D Lp^T of panel jb-1 (one entry per lane)
-                const int r = lane/6, c = lane - 6*r;        // full 6x6 (the upper half is never read)
-                double v = 0.0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = SOLVE_THREADS/64, NT = NW - SOLVE_PW;
+#ifdef TSBA_SOLVE_STAMPS
+    const long long Tl = clock64();
+#endif
+    const int Nmax = W.N;
+    double *A = smem;                                           // padded packed lower triangle, rows 0..n (row n = g)
+    // the element addresses do not depend on the number of free poses: the first round of loads is issued together with the
+    // loads of the solver state (one global round trip instead of two)
+    const int neMax = tri(Nmax);
+    double v[12]; int er[12], ec[12];
 #pragma unroll
-                for (int k = 0; k < 6; k++) v += A[(j0 + r)*ld + p0 + k]*LD[32*(jb - 1) + 15 + k]*A[(j0 + c)*ld + p0 + k];
-                A[(j0 + r)*ld + j0 + c] -= v;
+    for (int u = 0; u < 12; u++) {
+        const int e = min(u*SOLVE_THREADS + tid, neMax - 1);
+        er[u] = tri_row(e); ec[u] = e - tri(er[u]);
+        v[u] = W.S[(size_t)er[u]*Nmax + ec[u]];
+    }
+    const int done = st->done, nfree = *W.nfree, sfail = st->step_fail;
+    if (done) return;
+    const int n = 6*nfree, ne = tri(n);
+    double *LD = A + rowoff(n + 1) + 16;
+    double *scr = LD + SOLVE_LD*nfree;
+#pragma unroll
+    for (int u = 0; u < 12; u++) if (u*SOLVE_THREADS + tid < ne) A[rowoff(er[u]) + ec[u]] = v[u];
+    for (int base = 12*SOLVE_THREADS; base < ne; base += 12*SOLVE_THREADS) {
+#pragma unroll
+        for (int u = 0; u < 12; u++) {
+            const int e = min(base + u*SOLVE_THREADS + tid, ne - 1);
+            er[u] = tri_row(e); ec[u] = e - tri(er[u]);
+            v[u] = W.S[(size_t)er[u]*Nmax + ec[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 12; u++) if (base + u*SOLVE_THREADS + tid < ne) A[rowoff(er[u]) + ec[u]] = v[u];
+    }
+    for (int k = tid; k < n; k += SOLVE_THREADS) A[rowoff(n) + k] = W.g[k];
+    if (tid == 0) fail = sfail;
+    __syncthreads();
+#ifdef TSBA_SOLVE_STAMPS
+    if (tid == 0) W.dbg[0] = clock64() - Tl;
+    long long tx = clock64(), T0 = tx, ta = 0, tb = 0, tc = 0, td = 0;
+#endif
+    for (int jb = 0; jb < nfree && !fail; jb++) {
+        const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
+        if (wave < SOLVE_PW) {
+            double Lk[36], dprev[6];
+            if (jb > 0) {
+                ld6(LD + SOLVE_LD*(jb - 1) + LD_D, dprev);
+#pragma unroll
+                for (int c = 0; c < 6; c++) ld6(A + rowoff(j0 + c) + p0, Lk + 6*c);
             }
-            if (!fail) {
-                double a[21], l[15], d[6], id[6]; bool bad = false;
+            auto load_row = [&](int i, double a[6]) {           // row i of block column jb with panel jb-1 applied
+                const double *row = A + rowoff(i);
+                ld6(row + j0, a);
+                if (jb > 0) {
+                    double y[6];
+                    ld6(row + p0, y);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) y[k] *= dprev[k];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double v0 = y[0]*Lk[c*6], v1 = y[1]*Lk[c*6 + 1];
+                        v0 = fma(y[2], Lk[c*6 + 2], v0); v1 = fma(y[3], Lk[c*6 + 3], v1);
+                        v0 = fma(y[4], Lk[c*6 + 4], v0); v1 = fma(y[5], Lk[c*6 + 5], v1);
+                        a[c] -= v0 + v1;
+                    }
+                }
+            };
+            const int i0 = lane < 6 ? j0 + lane : R0 + wave*SOLVE_PROWS + lane - 6;
+            double a[6];
+            load_row(min(i0, n), a);
+            if (lane < 6) st6(scr + wave*36 + lane*6, a);
+            wave_lds_fence();
+            STAMP(ta);
+            double s[21], l[15], d[6], id[6]; bool bad = false;
+            {
+                double t[36];
+#pragma unroll
+                for (int r = 0; r < 6; r++) ld6(scr + wave*36 + r*6, t + 6*r);
 #pragma unroll
                 for (int r = 0; r < 6; r++)
 #pragma unroll
-                    for (int c = 0; c <= r; c++) a[r*(r+1)/2 + c] = A[(j0 + r)*ld + j0 + c];
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    double dc = a[c*(c+1)/2 + c];
-#pragma unroll
-                    for (int k = 0; k < c; k++) dc -= l[c*(c-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
-                    if (!(dc > 0.0)) { bad = true; dc = 1.0; }
-                    d[c] = dc; id[c] = rcp_nr(dc);
-#pragma unroll
-                    for (int r = c + 1; r < 6; r++) {
-                        double v = a[r*(r+1)/2 + c];
-#pragma unroll
-                        for (int k = 0; k < c; k++) v -= l[r*(r-1)/2 + k]*l[c*(c-1)/2 + k]*d[k];
-                        l[r*(r-1)/2 + c] = v*id[c];
-                    }
-                }
-                if (lane == 0) {
-                    if (bad) { fail = 1; st->step_fail = 1; }
-                    auto o = LD + 32*jb;
-#pragma unroll
-                    for (int k = 0; k < 15; k++) o[k] = l[k];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) { o[15 + k] = d[k]; o[21 + k] = id[k]; }
-                }
+                    for (int c = 0; c <= r; c++) s[tri(r) + c] = t[6*r + c];
             }
-        } else if (wave <= 2) {
-            if (jb > 0) {                    // rest of block column jb (rows j0+6..n) -= panel jb-1 contribution
-                double dprev[6], Lk[36];
+            ldl6(s, l, d, id, bad);
+            if (wave == 0 && lane == 0) {
+                double *o = LD + SOLVE_LD*jb;
 #pragma unroll
-                for (int k = 0; k < 6; k++) dprev[k] = LD[32*(jb - 1) + 15 + k];
+                for (int k = 0; k < 15; k++) o[k] = l[k];
+                st6(o + LD_D, d); st6(o + LD_ID, id);
+                if (bad) { fail = 1; st->step_fail = 1; }
+            }
+            STAMP(tb);
+            auto solve_row = [&](int i, double a[6]) {           // x L^T = a (right-looking: 5-deep chain), stored row = x D^-1
 #pragma unroll
-                for (int c = 0; c < 6; c++)
+                for (int c = 0; c < 5; c++)
 #pragma unroll
-                    for (int k = 0; k < 6; k++) Lk[c*6 + k] = A[(j0 + c)*ld + p0 + k];
-                for (int i = R0 + (wave - 1)*64 + lane; i <= n; i += 128) {
-                    auto row = A + i*ld;
-                    double y[6];
+                    for (int q = c + 1; q < 6; q++) a[q] = fma(-a[c], l[tri(q - 1) + c], a[q]);
 #pragma unroll
-                    for (int k = 0; k < 6; k++) y[k] = row[p0 + k]*dprev[k];
+                for (int c = 0; c < 6; c++) a[c] *= id[c];
+                st6(A + rowoff(i) + j0, a);
+            };
+            if (lane >= 6) {
+                if (i0 <= n) solve_row(i0, a);
+                for (int i = i0 + SOLVE_PW*SOLVE_PROWS; i <= n; i += SOLVE_PW*SOLVE_PROWS) { load_row(i, a); solve_row(i, a); }
+            }
+            if (wave == 1 && jb == nfree - 1) {                  // inverse factor of the last block (the others: last T wave)
+                double m[15];
+                inv_unit_lower6(l, m);
+                if (lane == 0) {
 #pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int k = 0; k < 6; k++) v += y[k]*Lk[c*6 + k];
-                        row[j0 + c] -= v;
-                    }
+                    for (int k = 0; k < 15; k++) LD[SOLVE_LD*jb + LD_M + k] = m[k];
                 }
             }
         } else if (jb > 0) {
-            // trailing update with panel jb-1 on columns >= j0+6, rows >= j0+6 and the rhs row (block column jb is D/P work)
-            const int C0 = j0 + 6;
-            const int mr = n - C0 + 1, mc = n - C0;
+            // trailing update with panel jb-1: rows >= R0 (incl. the rhs row n), columns R0..n-1
+            const int mr = n - R0 + 1, mc = n - R0;
+            const double *ldp = LD + SOLVE_LD*(jb - 1);
             if (mc > 0) {
-                const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4;
+                const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4, ntile = tri(ntr);
                 const int lr = lane & 15, lk = lane >> 4;
-                const double dk0 = LD[32*(jb - 1) + 15 + lk], dk1 = (4 + lk < 6) ? LD[32*(jb - 1) + 15 + 4 + lk] : 0.0;
-                int t = wave - 3;
-                for (int ti = 0; ti < ntr; ti++) for (int tj = 0; tj <= ti && tj < ntc; tj++) {
-                    if (t-- != 0) continue;
-                    t = SOLVE_THREADS/64 - 4;               // this wave's next tile: 13 tiles further
+                const int k1 = min(4 + lk, 5);
+                const double dk0 = ldp[LD_D + lk], dk1 = lk < 2 ? ldp[LD_D + 4 + lk] : 0.0;
+                for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
+                    const int ti = tri_row(t), tj = t - tri(ti);
+                    if (tj >= ntc) continue;
                     // unconditional, index-clamped loads (rows / columns past the edge only feed outputs that are never stored);
                     // only the K padding (k = 6, 7) must be exact zeros
-                    const int arow = min(C0 + 16*ti + lr, n), bcol = min(C0 + 16*tj + lr, n - 1);
-                    const int k1 = min(4 + lk, 5);
-                    double a0 = -A[arow*ld + p0 + lk], a1 = -A[arow*ld + p0 + k1];
-                    double b0 = A[bcol*ld + p0 + lk]*dk0, b1 = A[bcol*ld + p0 + k1]*dk1;
+                    const int arow = rowoff(min(R0 + 16*ti + lr, n)) + p0, brow = rowoff(min(R0 + 16*tj + lr, n - 1)) + p0;
+                    double a0 = -A[arow + lk], a1 = -A[arow + k1];
+                    double b0 = A[brow + lk]*dk0, b1 = A[brow + k1]*dk1;
                     if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
-                    v4d c;
-                    const int ccol = C0 + 16*tj + lr, ccol_c = min(ccol, n - 1);
-                    bool ok[4];
+                    const int ccol = R0 + 16*tj + lr;
+                    v4d c; int ci[4]; bool ok[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int crow = C0 + 16*ti + lk + 4*r;
-                        ok[r] = crow <= n && ccol < n && (ccol <= crow);
-                        c[r] = A[min(crow, n)*ld + ccol_c];
+                        const int crow = R0 + 16*ti + lk + 4*r;
+                        ok[r] = crow <= n && ccol <= crow && ccol < n;
+                        ci[r] = rowoff(min(crow, n)) + min(ccol, min(crow, n - 1));
+                        c[r] = A[ci[r]];
                     }
                     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int crow = C0 + 16*ti + lk + 4*r;
-                        if (ok[r]) A[crow*ld + ccol] = c[r];
-                    }
+                    for (int r = 0; r < 4; r++) if (ok[r]) A[ci[r]] = c[r];
                 }
             }
-        }
-        tw += clock64() - tx; tx = clock64();
-        __syncthreads();                       // block column jb up to date, diagonal block jb factored
-        tb1 += clock64() - tx; tx = clock64();
-        if (fail) break;
-        if (wave == 1 || wave == 2) {          // panel jb: rows below the diagonal block and the rhs row
-            double l[15], id[6];
+            if (wave == NW - 1) {                                // inverse of the unit-lower factor of block jb-1
+                double l[15], m[15];
 #pragma unroll
-            for (int k = 0; k < 15; k++) l[k] = LD[32*jb + k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) id[k] = LD[32*jb + 21 + k];
-            for (int i = R0 + (wave - 1)*64 + lane; i <= n; i += 128) {
-                auto row = A + i*ld + j0;
-                double x[6];
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    double v = row[c];
-#pragma unroll
-                    for (int k = 0; k < c; k++) v -= x[k]*l[c*(c-1)/2 + k];
-                    x[c] = v;
-                }
-#pragma unroll
-                for (int c = 0; c < 6; c++) row[c] = x[c]*id[c];
-            }
-        }
-        tp += clock64() - tx; tx = clock64();
-        __syncthreads();                       // panel jb complete
-        tb2 += clock64() - tx;
-    }
-    __syncthreads();
-    long long T2 = clock64();
-    if (fail) { for (int k = tid; k < Nmax; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
-    // back substitution L^T x = z (z = D^-1 L^-1 g sits in row n): wave 0, solution kept in registers (rows lane, lane+64, ...)
-    auto rhs = A + n*ld;
-    if (wave == 0) {
-        if (n <= 128) {
-            double z0 = lane < n ? rhs[lane] : 0.0, z1 = lane + 64 < n ? rhs[lane + 64] : 0.0;
-            for (int jb = nfree - 1; jb >= 0; jb--) {
-                const int j0 = 6*jb;
-                auto l = LD + 32*jb;
-                double x[6];
-#pragma unroll
-                for (int c = 0; c < 6; c++) { int r = j0 + c; x[c] = r < 64 ? readlane_f64(z0, r) : readlane_f64(z1, r - 64); }
-#pragma unroll
-                for (int c = 4; c >= 0; c--) {
-#pragma unroll
-                    for (int k = c + 1; k < 6; k++) x[c] -= l[k*(k-1)/2 + c]*x[k];
-                }
-#pragma unroll
-                for (int c = 0; c < 6; c++) { if (lane == ((j0 + c) & 63)) { if (j0 + c < 64) z0 = x[c]; else z1 = x[c]; } }
-                if (lane < j0) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 6; c++) v += A[(j0 + c)*ld + lane]*x[c];
-                    z0 -= v;
-                }
-                if (lane + 64 < j0) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 6; c++) v += A[(j0 + c)*ld + lane + 64]*x[c];
-                    z1 -= v;
-                }
-            }
-            if (lane < n) rhs[lane] = z0;
-            if (lane + 64 < n) rhs[lane + 64] = z1;
-        } else {
-            for (int jb = nfree - 1; jb >= 0; jb--) {
-                const int j0 = 6*jb;
-                auto l = LD + 32*jb;
-                double x[6];
-#pragma unroll
-                for (int c = 5; c >= 0; c--) {
-                    double v = rhs[j0 + c];
-#pragma unroll
-                    for (int k = c + 1; k < 6; k++) v -= l[k*(k-1)/2 + c]*x[k];
-                    x[c] = v;
-                }
-                for (int k = lane; k < j0; k += 64) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 6; c++) v += A[(j0 + c)*ld + k]*x[c];
-                    rhs[k] -= v;
-                }
+                for (int k = 0; k < 15; k++) l[k] = ldp[k];
+                inv_unit_lower6(l, m);
                 if (lane == 0) {
 #pragma unroll
-                    for (int c = 0; c < 6; c++) rhs[j0 + c] = x[c];
+                    for (int k = 0; k < 15; k++) LD[SOLVE_LD*(jb - 1) + LD_M + k] = m[k];
                 }
-                __threadfence_block();
             }
         }
+        STAMP(tc);
+        __syncthreads();                       // panel jb complete, trailing update with panel jb-1 complete
+        STAMP(td);
+    }
+#ifdef TSBA_SOLVE_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 2 || wave == NW - 1)) {
+        long long *o = W.dbg + 8 + 4*(wave == 0 ? 0 : wave == 2 ? 1 : 2); o[0] = ta; o[1] = tb; o[2] = tc; o[3] = td;
+        if (wave == 0) { W.dbg[1] = clock64() - T0; W.dbg[6] = nfree; }
+    }
+    long long T1 = clock64();
+#endif
+    if (fail || nfree == 0) { for (int k = tid; k < Nmax; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
+    double *rhs = A + rowoff(n);
+    if (wave == 0) {
+        // rows of blocks that were already consumed (and lanes 60..63) keep receiving updates: they are never read again, the
+        // solution goes to the rhs row through lane 0
+        double z[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) z[w] = rhs[min(60*w + min(lane, 59), n - 1)];
+        auto back = [&](auto WC) {
+            constexpr int w = decltype(WC)::value;
+            auto fetch = [&](int q, double col[w + 1][6], double m[15]) {      // operands independent of the running solution
+                const int j0 = 6*(10*w + q);
+#pragma unroll
+                for (int u = 0; u <= w; u++) {
+                    const int k = min(60*u + lane, j0);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) col[u][c] = A[rowoff(j0 + c) + k];
+                }
+                const double *o = LD + SOLVE_LD*(10*w + q) + LD_M;
+                double t[16];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const v2d x = ((const v2d *)o)[k]; t[2*k] = x.x; t[2*k + 1] = x.y; }
+#pragma unroll
+                for (int k = 0; k < 15; k++) m[k] = t[k];
+            };
+            auto step = [&](int q, const double col[w + 1][6], const double m[15]) {
+                double zb[6], x[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) zb[c] = readlane_f64(z[w], 6*q + c);
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double v0 = zb[c], v1 = 0.0;
+#pragma unroll
+                    for (int k = c + 1; k < 6; k++) { if ((k - c) & 1) v0 = fma(m[tri(k - 1) + c], zb[k], v0); else v1 = fma(m[tri(k - 1) + c], zb[k], v1); }
+                    x[c] = v0 + v1;
+                }
+                if (lane == 0) st6(rhs + 6*(10*w + q), x);
+#pragma unroll
+                for (int u = 0; u <= w; u++)
+                    z[u] -= fma(col[u][0], x[0], fma(col[u][1], x[1], col[u][2]*x[2])) + fma(col[u][3], x[3], fma(col[u][4], x[4], col[u][5]*x[5]));
+            };
+            int q = min(9, nfree - 1 - 10*w);
+            if constexpr (w < 2) {                               // operands of the next block prefetched (two register sets)
+                double colA[w + 1][6], mA[15], colB[w + 1][6], mB[15];
+                fetch(q, colA, mA);
+                for (; q >= 1; q -= 2) {
+                    fetch(q - 1, colB, mB);
+                    step(q, colA, mA);
+                    if (q >= 2) fetch(q - 2, colA, mA);
+                    step(q - 1, colB, mB);
+                }
+                if (q == 0) step(0, colA, mA);
+            } else {
+                double col[w + 1][6], m[15];
+                for (; q >= 0; q--) { fetch(q, col, m); step(q, col, m); }
+            }
+        };
+        if (nfree > 30) back(IC<3>{});
+        if (nfree > 20) back(IC<2>{});
+        if (nfree > 10) back(IC<1>{});
+        back(IC<0>{});
     }
     __syncthreads();
-    if (tid == 0) { long long T3 = clock64(); W.dbg[0] = T1 - T0; W.dbg[1] = T2 - T1; W.dbg[2] = T3 - T2; W.dbg[3] = 0; W.dbg[4] = 0; W.dbg[5] = 0; W.dbg[6] = nfree; }
-    if (lane == 0 && (wave == 0 || wave == 1 || wave == 3)) { int o = 8 + 4*(wave == 0 ? 0 : wave == 1 ? 1 : 2); W.dbg[o] = tw; W.dbg[o+1] = tb1; W.dbg[o+2] = tp; W.dbg[o+3] = tb2; }
+#ifdef TSBA_SOLVE_STAMPS
+    if (tid == 0) W.dbg[2] = clock64() - T1;
+#endif
     for (int a = tid; a < W.n_kf; a += SOLVE_THREADS) {
         int ia = W.fidx[a];
 #pragma unroll
         for (int k = 0; k < 6; k++) W.dp[6*a + k] = ia >= 0 ? -rhs[6*ia + k] : 0.0;
     }
 }
-

@@ -12,7 +12,7 @@ from .abi import (TsbaProblem, TsbaOptions, TsbaReport, BAProblem, options_local
                   options_init, options_landmarker, options_theta, STATE_LOCAL, STATE_NOTREACHWIN)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libtsba.so")
+_LIBPATH = os.environ.get("TSBA_LIB", os.path.join(_HERE, "libtsba.so"))     # TSBA_LIB: instrumented build for diagnostics
 _lib = None
 
 
