@@ -15,6 +15,9 @@ opt.lib.tsba_debug_stamps(opt.ctx, st)
 print("k_solve stamps (cycles): load %d factor %d backsub %d nfree %d" % (st[0], st[1], st[2], st[6]))
 for i, nm in enumerate(("P wave0 (look-ahead | scratch+ldl | solve | barrier)", "T wave2 (- | - | trailing | barrier)", "T last")):
     print("   %s: lookahead+scratch %d  ldl %d  solve/trailing %d  barrier-wait %d" % ((nm,) + tuple(st[8+4*i:12+4*i])))
+print("k_decide stamps (cycles): sums_local %d  pose_scale %d  partials %d  decision %d" % tuple(st[32:36]))
+print("   fused: partials %d  offsets+range sums %d  exchange+finalize %d  reduction %d" % tuple(st[40:44]))
+print("k_linearize text group 0 (cycles): st+record %d  level-2 loads %d  feature+tap fetch %d  tap math %d  reduce %d" % tuple(st[48:53]))
 ms = ctypes.c_double()
 opt.lib.tsba_debug_time_solve.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
 rc = opt.lib.tsba_debug_time_solve(opt.ctx, 200, ctypes.byref(ms))

@@ -41,8 +41,8 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     int img_w, img_h;
     const uint8_t *const *img;      // [n_kf] device pointers
     const int *sc_obs, *sc_kf, *sc_pt, *sc_flag, *sc_slot; const double *sc_uv;
-    const int *pair_i, *pair_h, *pair_sc_off, *pair_tg_off, *pair_tg;
-    const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot;
+    const int *pair_i, *pair_h, *pair_hpos, *pair_sc_off, *pair_tg_off, *pair_tg;
+    const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot, *tg_rec;
     const int *pls_off, *pslot_pose, *pslot_pair, *pslot_lm, *tls_off, *tslot_pose, *tslot_pair, *tslot_lm;
     const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_pt_lm, *sb_tx_off, *sb_tx_s1, *sb_tx_s2, *sb_tx_lm;
     const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ps_lm, *pose_ts_off, *pose_ts, *pose_ts_lm;
@@ -98,20 +98,66 @@ __device__ __forceinline__ double wave_sum1(double v) {
     return v;
 }
 template <int NT>
-__device__ __forceinline__ double block_sum(double v, double *lds) {     // deterministic tree, NT threads, all get result
-    int t = threadIdx.x;
+__device__ __forceinline__ double block_sum(double v, double *lds) {     // deterministic (fixed order), NT threads, all get the result
+    const int t = threadIdx.x;
     lds[t] = v; __syncthreads();
-    for (int s = NT/2; s > 0; s >>= 1) { if (t < s) lds[t] += lds[t + s]; __syncthreads(); }
-    double r = lds[0]; __syncthreads();
+    if (t < 64) {
+        double s = lds[t];
+#pragma unroll
+        for (int k = 64; k < NT; k += 64) s += lds[t + k];
+        s = wave_sum1(s);
+        if (t == 0) lds[0] = s;
+    }
+    __syncthreads();
+    const double r = lds[0]; __syncthreads();
     return r;
 }
 template <int NT>
 __device__ __forceinline__ double block_max(double v, double *lds) {
-    int t = threadIdx.x;
+    const int t = threadIdx.x;
     lds[t] = v; __syncthreads();
-    for (int s = NT/2; s > 0; s >>= 1) { if (t < s) lds[t] = fmax(lds[t], lds[t + s]); __syncthreads(); }
-    double r = lds[0]; __syncthreads();
+    if (t < 64) {
+        double s = lds[t];
+#pragma unroll
+        for (int k = 64; k < NT; k += 64) s = fmax(s, lds[t + k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+        if (t == 0) lds[0] = s;
+    }
+    __syncthreads();
+    const double r = lds[0]; __syncthreads();
     return r;
+}
+
+// Sum over a variable-length gather list with U entries (index, then value) in flight per round trip instead of one:
+// val(idx) is evaluated for clamped indices and masked, the summation order is the list order.
+template <int U, class F>
+__device__ __forceinline__ double gather_sum(const int *list, int n, F &&val) {
+    double s = 0.0;
+    for (int base = 0; base < n; base += U) {
+        int idx[U]; double v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) idx[u] = list[min(base + u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = val(idx[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) s += base + u < n ? v[u] : 0.0;
+    }
+    return s;
+}
+
+// contiguous range with U loads in flight per round trip, summed in index order
+template <int U>
+__device__ __forceinline__ double range_sum(const double *v, int i0, int i1) {
+    double s = 0.0;
+    for (int base = i0; base < i1; base += U) {
+        double x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = v[min(base + u, i1 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) s += base + u < i1 ? x[u] : 0.0;
+    }
+    return s;
 }
 
 // ---- pass initialisation
@@ -312,17 +358,22 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) {
     // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
     const LmState *st = W.st;
+    __shared__ double lds[55*65];
+    // static indices of this workgroup first: in flight together with the LM state
+    const int bq = blockIdx.x;
+    int pi = 0, ph = 0, pbeg = 0, pend = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+    if (bq < L.n_pair) { pi = L.pair_i[bq]; ph = L.pair_h[bq]; pbeg = L.pair_sc_off[bq]; pend = L.pair_sc_off[bq+1]; }
+    else { ra = ((const int4 *)L.tg_rec)[2*(bq - L.n_pair)]; rb = ((const int4 *)L.tg_rec)[2*(bq - L.n_pair) + 1]; }   // one static record per group
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
-    __shared__ double lds[55*65];
     const int sel = spec ? (st->cur ^ 1) : st->cur;
     const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
     const double *pose = W.pose[sel], *rho = W.rho[sel], *theta = W.theta[sel];
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b < L.n_pair) {
         // ---------------- scene observations of pair (i, h)
-        const int i = L.pair_i[b], h = L.pair_h[b];
+        const int i = pi, h = ph;
         Pose C; load_pose(pose + 7*i, C);
         PairT T;
         if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
@@ -330,7 +381,7 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
         double acc[28];
 #pragma unroll
         for (int k = 0; k < 28; k++) acc[k] = 0.0;
-        const int beg = L.pair_sc_off[b], end = L.pair_sc_off[b+1];
+        const int beg = pbeg, end = pend;
         for (int c = beg + lane; c < end; c += 64) {
             const int slot = L.sc_slot[c];
             bool act = !fixed && (!W.filter_good || W.sgood[L.sc_flag[c]]);
@@ -389,37 +440,57 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
     } else {
         // ---------------- photometric blocks of one (KF, text) observation
         const int g = b - L.n_pair;
-        const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j], slot = L.tg_slot[g];
+        const int tb = ra.x, i = ra.y, j = ra.z, h = ra.w, slot = rb.x, f0 = rb.y, f1 = rb.z, fg = rb.w;
         const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
         const bool act_g = (!W.filter_good || W.tobs_good[tb]) && !((h < 0) && W.kf_const[i]) && sigma != 0.0;
-        double acc[55];
+        // static data of this lane's first feature: fetched together with the level-2 operands, not after them
+        int f = f0 + lane, raw = 0; double fu = 0.0, fv = 0.0, refv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (f1 > f0) {
+            const int fc = min(f, f1 - 1);
+            raw = L.tfeat_raw[fc]; fu = L.tfeat_uv[2*fc]; fv = L.tfeat_uv[2*fc+1];
 #pragma unroll
-        for (int k = 0; k < 55; k++) acc[k] = 0.0;
+            for (int k = 0; k < 8; k++) refv[k] = L.tfeat_ref[8*(size_t)fc + k];
+        }
         PairT T;
-        if (act_g) {
-            Pose C; load_pose(pose + 7*i, C);
-            if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
-            else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
-            const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-            const uint8_t *img = L.img[i];
-            const double inv_sigma = 1.0/sigma;
-            const int f0 = L.tfeat_off[j], f1 = L.tfeat_off[j+1];
-            const int fg = W.tobs_fgood_off[tb];
-            for (int f = f0 + lane; f < f1; f += 64) {
-                if (W.filter_good && !W.tfgood[fg + L.tfeat_raw[f]]) continue;
-                const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
-                double blk[54];
+        // poses / plane / image pointer do not wait for the activity test (h is known from the record)
+        Pose C; load_pose(pose + 7*i, C);
+        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+        else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
+        const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+        const uint8_t *img = L.img[i];
+        const double inv_sigma = 1.0/sigma;
+        const double ifx = 1.0/L.K[0], ify = 1.0/L.K[1];
+        double tot = 0.0;                       // lane l < 55: running total of value l
+        {
+            // chunks of 64 features (one chunk unless the plane has more).  One accumulator set only: the weighted block of the
+            // lane's feature is reduced per chunk, so that blk + the 8 pixel quads stay inside the 256 architectural VGPRs
+            // (a second accumulator set spills into AGPRs: a fifth of the instructions were v_accvgpr moves)
+            for (int fb = f0; fb == f0 || fb < f1; fb += 64, f += 64) {
+                double blk[55];
 #pragma unroll
-                for (int k = 0; k < 54; k++) blk[k] = 0.0;
-                double s = 0.0;
-#pragma unroll 1
-                for (int k = 0; k < 8; k++) {
-                    double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];   // tool.cc:1561
-                    double jt[6], jl[3];
-                    double r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h,
-                                        mu, sigma, inv_sigma, L.tfeat_ref[8*(size_t)f + k], W.w_t, MODE == MODE_FULL, jt, jl);
-                    s += r*r;
-                    if (MODE == MODE_FULL) {
+                for (int k = 0; k < 55; k++) blk[k] = 0.0;
+                if (act_g && f < f1) {
+                    if (fb != f0) {
+                        raw = L.tfeat_raw[f]; fu = L.tfeat_uv[2*f]; fv = L.tfeat_uv[2*f+1];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) refv[k] = L.tfeat_ref[8*(size_t)f + k];
+                    }
+                    const uint8_t good = W.filter_good ? W.tfgood[fg + raw] : 1;       // in flight with the pixel fetches
+                    // all 16 pixel-pair fetches of the feature in flight before the first residual
+                    TapPx px[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const double mx = (fu + TAP_DX[k] - L.K[2])*ifx, my = (fv + TAP_DY[k] - L.K[3])*ify;   // tool.cc:1561
+                        px[k] = tap_fetch(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h);
+                    }
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const double mx = (fu + TAP_DX[k] - L.K[2])*ifx, my = (fv + TAP_DY[k] - L.K[3])*ify;
+                        double jt[6], jl[3];
+                        double r = text_tap_px(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], px[k], L.img_w, L.img_h,
+                                               mu, sigma, inv_sigma, refv[k], W.w_t, true, jt, jl);
+                        s += r*r;
                         int q = 0;
 #pragma unroll
                         for (int a = 0; a < 6; a++)
@@ -434,20 +505,16 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
                         blk[45] += jl[0]*jl[0]; blk[46] += jl[0]*jl[1]; blk[47] += jl[0]*jl[2];
                         blk[48] += jl[1]*jl[1]; blk[49] += jl[1]*jl[2]; blk[50] += jl[2]*jl[2];
                         blk[51] += jl[0]*r; blk[52] += jl[1]*r; blk[53] += jl[2]*r;
+                        __builtin_amdgcn_sched_barrier(0);              // one tap at a time: interleaved taps do not fit the register file
                     }
-                }
-                double wgt; acc[54] += 0.5*huber(s, W.huber_t, wgt);
-                if (MODE == MODE_FULL) {
+                    double wgt; const double rho_h = 0.5*huber(s, W.huber_t, wgt);
+                    const double wg = good ? wgt : 0.0;
 #pragma unroll
-                    for (int k = 0; k < 54; k++) acc[k] += wgt*blk[k];
+                    for (int k = 0; k < 54; k++) blk[k] *= wg;
+                    blk[54] = good ? rho_h : 0.0;
                 }
+                tot += wave_sum_to_lane<55>(blk, lds, lane);
             }
-        }
-        if (MODE == MODE_COST) {
-            double cs = wave_sum1(acc[54]);
-            if (lane == 0) B.tgCost[g] = cs;
-        } else {
-            double tot = wave_sum_to_lane<55>(acc, lds, lane);
             if (lane < 27) B.tgM[(size_t)lane*L.n_tg + g] = tot;
             else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; lds[lane - 27] = tot; }
             else if (lane < 54) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + 18 + (lane - 45)] = tot; }
@@ -489,9 +556,16 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
         if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; }
         if (e > o) {
             double acc[8] = {0,0,0,0,0,0,0,0};
-            for (int s = o; s < e - 1; s++) {
+            for (int s0 = o; s0 < e - 1; s0 += 6) {                  // 6 slot records in flight per round trip
+                double v[6][8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) acc[k] += B.w_pt[(size_t)(s)*PT_REC + 6 + k];
+                for (int u = 0; u < 6; u++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 2))*PT_REC + 6 + k];
+#pragma unroll
+                for (int u = 0; u < 6; u++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc[k] += s0 + u < e - 1 ? v[u][k] : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < 6; k++) B.w_pt[(size_t)(e - 1)*PT_REC + k] = acc[2 + k];
@@ -510,9 +584,16 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             double acc[27];
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = 0.0;
-            for (int s = o; s < e - 1; s++) {
+            for (int s0 = o; s0 < e - 1; s0 += 3) {                  // 3 slot records in flight per round trip
+                double v[3][27];
 #pragma unroll
-                for (int k = 0; k < 27; k++) acc[k] += B.w_tx[(size_t)(s)*TX_REC + 18 + k];
+                for (int u = 0; u < 3; u++)
+#pragma unroll
+                    for (int k = 0; k < 27; k++) v[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 2))*TX_REC + 18 + k];
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+#pragma unroll
+                    for (int k = 0; k < 27; k++) acc[k] += s0 + u < e - 1 ? v[u][k] : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < 18; k++) B.w_tx[(size_t)(e - 1)*TX_REC + k] = acc[9 + k];
@@ -544,12 +625,13 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
 #pragma unroll
                 for (int k = 0; k < 6; k++) c[k] += B.tgM[(size_t)(21 + k)*L.n_tg + g];
             }
-            double *out = B.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) QMQ(21) Qc(6)
+            double *out = B.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) by pair | QMQ(21) Qc(6) by host-major rank
 #pragma unroll
             for (int k = 0; k < 21; k++) out[(size_t)k*L.n_pair + p] = M[k];
 #pragma unroll
             for (int k = 0; k < 6; k++) out[(size_t)(21 + k)*L.n_pair + p] = c[k];
             if (L.pair_h[p] >= 0) {
+                const int hp = L.pair_hpos[p];             // rows 63..89 are stored host-major
                 double R[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) R[k] = B.pairR[(size_t)k*L.n_pair + p];
@@ -574,11 +656,11 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
                     for (int cc = r; cc < 6; cc++) {
                         const int hr = r/3, rr = r % 3;
                         double v = R[0*3 + rr]*MQ[(hr*3 + 0)*6 + cc] + R[1*3 + rr]*MQ[(hr*3 + 1)*6 + cc] + R[2*3 + rr]*MQ[(hr*3 + 2)*6 + cc];
-                        out[(size_t)(63 + sym6(r, cc))*L.n_pair + p] = v;
+                        out[(size_t)(63 + sym6(r, cc))*L.n_pair + hp] = v;
                     }
                 double a[3], d[3]; mat3T_vec(R, c, a); mat3T_vec(R, c + 3, d);
-                out[(size_t)84*L.n_pair + p] = a[0]; out[(size_t)85*L.n_pair + p] = a[1]; out[(size_t)86*L.n_pair + p] = a[2];
-                out[(size_t)87*L.n_pair + p] = d[0]; out[(size_t)88*L.n_pair + p] = d[1]; out[(size_t)89*L.n_pair + p] = d[2];
+                out[(size_t)84*L.n_pair + hp] = a[0]; out[(size_t)85*L.n_pair + hp] = a[1]; out[(size_t)86*L.n_pair + hp] = a[2];
+                out[(size_t)87*L.n_pair + hp] = d[0]; out[(size_t)88*L.n_pair + hp] = d[1]; out[(size_t)89*L.n_pair + hp] = d[2];
             }
         }
     }
@@ -594,17 +676,19 @@ __device__ void sums_local(const Work &W, const LevelDev &L, const LinBuf &B, do
     const int tid = threadIdx.x;
     gmax_lm = 0.0; xn_lm = 0.0; cost = 0.0;
     const double *out = B.pairOut;
-    for (int a = tid; a < W.n_kf; a += 256) {
-        double Hd[6] = {0,0,0,0,0,0}, bp[6] = {0,0,0,0,0,0};
-        for (int q = L.pose_t_off[a]; q < L.pose_t_off[a+1]; q++) { int p = L.pose_t[q];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { Hd[k] += out[(size_t)sym6(k, k)*L.n_pair + p]; bp[k] += out[(size_t)(21 + k)*L.n_pair + p]; } }
-        for (int q = L.pose_h_off[a]; q < L.pose_h_off[a+1]; q++) { int p = L.pose_h[q];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { Hd[k] += out[(size_t)(63 + sym6(k, k))*L.n_pair + p]; bp[k] -= out[(size_t)(84 + k)*L.n_pair + p]; } }
-#pragma unroll
-        for (int k = 0; k < 6; k++) { dHd[6*a + k] = Hd[k]; dbp[6*a + k] = bp[k]; B.bp_loc[6*a + k] = bp[k]; }
+    const size_t np = L.n_pair;
+    for (int task = tid; task < 12*W.n_kf; task += 256) {          // (pose, component): diag H (6) | b (6)
+        const int a = task/12, k = task - 12*a;
+        const int t0 = L.pose_t_off[a], t1 = L.pose_t_off[a+1], h0 = L.pose_h_off[a], h1 = L.pose_h_off[a+1];
+        if (k < 6) {
+            const double h = range_sum<24>(out + (size_t)sym6(k, k)*np, t0, t1) + range_sum<24>(out + (size_t)(63 + sym6(k, k))*np, h0, h1);
+            dHd[6*a + k] = h;
+        } else {
+            const double g = range_sum<24>(out + (size_t)(21 + k - 6)*np, t0, t1) - range_sum<24>(out + (size_t)(84 + k - 6)*np, h0, h1);
+            dbp[6*a + k - 6] = g; B.bp_loc[6*a + k - 6] = g;
+        }
     }
+    __threadfence_block();                                             // pose_scale reads these through other threads
     for (int k = tid; k < nb_lm; k += 256) { gmax_lm = fmax(gmax_lm, B.lmpart[2*k]); xn_lm += B.lmpart[2*k + 1]; }
     for (int p = tid; p < L.n_pair; p += 256) cost += B.pairCost[p];
     for (int g = tid; g < L.n_tg; g += 256) cost += B.tgCost[g];
@@ -614,7 +698,7 @@ __device__ void pose_scale(const Work &W, const LinBuf &B, const double *sHd, co
                            double *red, double &gmax_p, double &xn_p) {
     const int tid = threadIdx.x;
     gmax_p = 0.0; xn_p = 0.0;
-    for (int a = tid; a < W.n_kf; a += 256) {          // same a -> same thread as in sums_local: reads its own writes
+    for (int a = tid; a < W.n_kf; a += 256) {
         const bool fre = W.fidx[a] >= 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -629,20 +713,107 @@ __device__ void pose_scale(const Work &W, const LinBuf &B, const double *sHd, co
     }
     gmax_p = block_max<256>(gmax_p, red); xn_p = block_sum<256>(xn_p, red);
 }
-__device__ void postlin_body(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm,
-                             double *red, double &gmax, double &xn, double &cost) {
-    double gl, xl, gp, xp;
-    sums_local(W, L, B, B.Hd, B.bp, nb_lm, red, gl, xl, cost);
-    pose_scale(W, B, B.Hd, B.bp, pose, first, red, gp, xp);
-    gmax = fmax(gl, gp); xn = xl + xp;
+// Single-GPU path of k_postlin / k_decide: everything one linearisation contributes to the LM decision, with the independent
+// loads of all parts issued before the first wait and ONE five-value block reduction (a global round trip from this lone
+// workgroup costs ~0.6 us, a block reduction ~0.3 us: the old sequence had a dozen of the former and seven of the latter).
+//   out5 = { max |gradient|, |x|^2, cost, step^2 (nb_back partials), model cost change (nb_back partials) }   (thread 0)
+__device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm, int nb_back,
+                              double *red /*[5*256]*/, double *xch /*[252]*/, double out5[5]) {
+    const int tid = threadIdx.x;
+    double gmax = 0.0, xn = 0.0, cost = 0.0, step2 = 0.0, mcc = 0.0;
+#ifdef TSBA_SOLVE_STAMPS
+    long long q0_ = clock64(), q1_ = 0, q2_ = 0, q3_ = 0, q4_ = 0;
+#endif
+    {   // landmark / cost / step partials: three entries per thread in flight, the (rare) rest in a plain loop
+        double pc[3], tc[3], lg[3], lx[3], ps[3], pm[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int k = tid + 256*u;
+            pc[u] = B.pairCost[min(k, max(L.n_pair - 1, 0))]; tc[u] = B.tgCost[min(k, max(L.n_tg - 1, 0))];
+            lg[u] = B.lmpart[2*min(k, max(nb_lm - 1, 0))]; lx[u] = B.lmpart[2*min(k, max(nb_lm - 1, 0)) + 1];
+            ps[u] = W.partial[2*min(k, max(nb_back - 1, 0))]; pm[u] = W.partial[2*min(k, max(nb_back - 1, 0)) + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int k = tid + 256*u;
+            if (k < L.n_pair) cost += pc[u];
+            if (k < nb_lm) { gmax = fmax(gmax, lg[u]); xn += lx[u]; }
+            if (k < nb_back) { step2 += ps[u]; mcc += pm[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) if (tid + 256*u < L.n_tg) cost += tc[u];
+        for (int k = tid + 768; k < L.n_pair; k += 256) cost += B.pairCost[k];
+        for (int k = tid + 768; k < L.n_tg; k += 256) cost += B.tgCost[k];
+        for (int k = tid + 768; k < nb_lm; k += 256) { gmax = fmax(gmax, B.lmpart[2*k]); xn += B.lmpart[2*k + 1]; }
+        for (int k = tid + 768; k < nb_back; k += 256) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
+    }
+#ifdef TSBA_SOLVE_STAMPS
+    q1_ = clock64();
+#endif
+    // poses, 21 per round: thread (pose, component) sums one entry of diag(H_pp) (6) or of the gradient (6) over the pose's
+    // pairs -- target side by pair, host side host-major, both contiguous -- then the six diag threads finish the pose
+    const double *out = B.pairOut; const size_t np = L.n_pair;
+    for (int a0 = 0; a0 < W.n_kf; a0 += 21) {
+        const int al = tid/12, k = tid - 12*al, a = a0 + al;
+        const bool on = tid < 252 && a < W.n_kf;
+        const int ac = min(a, W.n_kf - 1);
+        const int t0 = L.pose_t_off[ac], t1 = L.pose_t_off[ac+1], h0 = L.pose_h_off[ac], h1 = L.pose_h_off[ac+1];
+        const int kk = k < 6 ? k : k - 6;
+        const double sgp = first ? 0.0 : W.sig_p[6*ac + kk]; const int fre = W.fidx[ac];
+        const double px = pose[7*ac + kk], px6 = pose[7*ac + 6];
+        const double *rt = out + (size_t)(k < 6 ? sym6(kk, kk) : 21 + kk)*np, *rh = out + (size_t)(k < 6 ? 63 + sym6(kk, kk) : 84 + kk)*np;
+        const double vt = range_sum<24>(rt, t0, t1), vh = range_sum<24>(rh, h0, h1);
+        const double val = k < 6 ? vt + vh : vt - vh;
+#ifdef TSBA_SOLVE_STAMPS
+        q2_ = clock64();
+#endif
+        if (on) xch[tid] = val;
+        __syncthreads();
+        if (on && k < 6) {
+            const double h = val, g = xch[tid + 6];
+            B.Hd[6*a + k] = h; B.bp[6*a + k] = g; B.bp_loc[6*a + k] = g;
+            double sg = sgp;
+            if (first) { sg = 1.0/(1.0 + sqrt(h)); W.sig_p[6*a + k] = sg; }
+            B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
+            if (fre >= 0) { gmax = fmax(gmax, fabs(g)); xn += px*px + (k == 0 ? px6*px6 : 0.0); }
+        }
+        __syncthreads();
+    }
+#ifdef TSBA_SOLVE_STAMPS
+    q3_ = clock64();
+#endif
+    // one reduction for the five values: wave w reduces value w, wave 0 also value 4
+    red[tid] = gmax; red[256 + tid] = xn; red[512 + tid] = cost; red[768 + tid] = step2; red[1024 + tid] = mcc;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    auto reduce_one = [&](int v) -> double {
+        const double *r = red + 256*v;
+        double x;
+        if (v == 0) {
+            x = fmax(fmax(r[lane], r[lane + 64]), fmax(r[lane + 128], r[lane + 192]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
+        } else { x = (r[lane] + r[lane + 64]) + (r[lane + 128] + r[lane + 192]); x = wave_sum1(x); }
+        return x;
+    };
+    const double x0 = reduce_one(wave), x4 = wave == 0 ? reduce_one(4) : 0.0;
+    __syncthreads();
+    if (lane == 0) { red[256*wave] = x0; if (wave == 0) red[1024] = x4; }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 5; v++) out5[v] = red[256*v];
+#ifdef TSBA_SOLVE_STAMPS
+    q4_ = clock64();
+    if (tid == 0) { W.dbg[40] = q1_ - q0_; W.dbg[41] = q2_ - q1_; W.dbg[42] = q3_ - q2_; W.dbg[43] = q4_ - q3_; }
+#endif
 }
 __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm, int multi) {
     LmState *st = W.st;
     if (st->done || !st->need_lin) return;
-    __shared__ double red[256];
+    __shared__ double red[5*256], xch[256];
     double gmax, xn, cost;
     const LinBuf &B = W.lb[st->lcur];
-    if (!multi) postlin_body(W, L, B, W.pose[st->cur], st->first != 0, nb_lm, red, gmax, xn, cost);
+    if (!multi) { double o5[5]; postlin_fused(W, L, B, W.pose[st->cur], st->first != 0, nb_lm, 0, red, xch, o5); gmax = o5[0]; xn = o5[1]; cost = o5[2]; }
     else { double gp, xp; pose_scale(W, B, W.cb, W.cb + W.N, W.pose[st->cur], st->first != 0, red, gp, xp);
            const double *sc = W.cb + 2*(size_t)W.N; cost = sc[0]; xn = sc[1] + xp; gmax = fmax(W.cbm[0], gp); }
     if (threadIdx.x == 0) {
@@ -653,12 +824,16 @@ __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad
     }
 }
 
-// ---- reduced camera system.  grid = n_sb (one wave per 6x6 block) + n_kf (reduced gradient), 64 threads.
-__global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
+// ---- reduced camera system.  grid = n_sb (one workgroup per 6x6 block) + n_kf (reduced gradient), 256 threads.
+// The (slot, slot, landmark) gather lists of a diagonal block hold ~1000 entries: four waves, and per wave the indices and
+// operands of four entries in flight before the first multiply (two dependent global round trips per 1024 entries).
+#define SCHUR_T 256
+#define SCHUR_U 4
+__global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi) {
     LmState *st = W.st;
     if (st->done) return;
-    __shared__ double lds[36*65];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ double lds[3*36*64];              // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double radius = st->radius, irad = 1.0/radius;
     const int N = W.N;
     const LinBuf &B = W.lb[st->lcur];
@@ -669,27 +844,43 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
-        for (int q = L.sb_pt_off[b] + lane; q < L.sb_pt_off[b+1]; q += 64) {
-            const int s1 = L.sb_pt_s1[q], s2 = L.sb_pt_s2[q], j = L.sb_pt_lm[q];
-            const double vinv = 1.0/(B.V_pt[j] + B.dgs_pt[j]*irad);
-            double w1[6], w2[6];
+        const int pt0 = L.sb_pt_off[b], pt1 = L.sb_pt_off[b+1];
+        for (int base = pt0; base < pt1; base += SCHUR_T*SCHUR_U) {
+            int s1[SCHUR_U], s2[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { w1[k] = B.w_pt[(size_t)(s1)*PT_REC + k]*vinv; w2[k] = B.w_pt[(size_t)(s2)*PT_REC + k]; }
+            for (int u = 0; u < SCHUR_U; u++) {
+                const int q = base + u*SCHUR_T + tid; ok[u] = q < pt1;
+                const int qc = min(q, pt1 - 1);
+                s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc];
+            }
+            double w1[SCHUR_U][6], w2[SCHUR_U][6], Vv[SCHUR_U], dg[SCHUR_U];
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+            for (int u = 0; u < SCHUR_U; u++) {
+                Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
 #pragma unroll
-                for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += w1[r]*w2[cc];
+                for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
+            }
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                const double vinv = ok[u] ? 1.0/(Vv[u] + dg[u]*irad) : 0.0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    const double wr = w1[u][r]*vinv;
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += wr*w2[u][cc];
+                }
+            }
         }
-        for (int q = L.sb_tx_off[b] + lane; q < L.sb_tx_off[b+1]; q += 64) {
+        for (int q = L.sb_tx_off[b] + tid; q < L.sb_tx_off[b+1]; q += SCHUR_T) {
             const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
             double Vd[6], Vi[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
             Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
-            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
             double W1[18], W2[18];
 #pragma unroll
             for (int k = 0; k < 18; k++) { W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k]; W2[k] = B.w_tx[(size_t)(s2)*TX_REC + k]; }
+            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 double t0 = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
@@ -699,20 +890,46 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
                 for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += t0*W2[cc*3] + t1*W2[cc*3+1] + t2*W2[cc*3+2];
             }
         }
-        double tot = wave_sum_to_lane<36>(acc, lds, lane);
-        if (lane < 36) {
+        // operands of the tail, independent of the sums: issued before the reduction
+        double tail = 0.0;
+        if (wave == 0 && lane < 36) {
             const int r = lane/6, cc = lane % 6;
             const double *out = B.pairOut;
-            double v = -tot;
             if (a == c) {
-                for (int q = L.pose_t_off[a]; q < L.pose_t_off[a+1]; q++) v += out[(size_t)sym6(r, cc)*L.n_pair + L.pose_t[q]];
-                for (int q = L.pose_h_off[a]; q < L.pose_h_off[a+1]; q++) v += out[(size_t)(63 + sym6(r, cc))*L.n_pair + L.pose_h[q]];
-                if (r == cc && !multi) v += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
+                const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
+                tail = range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
+                if (r == cc && !multi) tail += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
             } else {
                 int pab = L.sb_pab[b], pba = L.sb_pba[b];
-                if (pab >= 0) v -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
-                if (pba >= 0) v -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
+                if (pab >= 0) tail -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
+                if (pba >= 0) tail -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
             }
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int k = 0; k < 36; k++) lds[((wave - 1)*36 + k)*64 + lane] = acc[k];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 36; k++) acc[k] += (lds[k*64 + lane] + lds[(36 + k)*64 + lane]) + lds[(72 + k)*64 + lane];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 36; k++) lds[k*65 + lane] = acc[k];          // transpose: lane l < 36 sums entry l over the 64 lanes
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        double tot = 0.0;
+        if (lane < 36) {
+            const double *row = lds + lane*65;
+#pragma unroll 16
+            for (int k = 0; k < 64; k++) tot += row[k];
+        }
+        if (lane < 36) {
+            const int r = lane/6, cc = lane % 6;
+            const double v = tail - tot;
             W.S[(size_t)(6*ia + r)*N + 6*ic + cc] = v;
             if (a != c) W.S[(size_t)(6*ic + cc)*N + 6*ia + r] = v;
         }
@@ -721,13 +938,30 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
         const int ia = W.fidx[a];
         if (ia < 0) return;
         double acc[6] = {0,0,0,0,0,0};
-        for (int q = L.pose_ps_off[a] + lane; q < L.pose_ps_off[a+1]; q += 64) {
-            const int s = L.pose_ps[q], j = L.pose_ps_lm[q];
-            const double f = B.b_pt[j]/(B.V_pt[j] + B.dgs_pt[j]*irad);
+        const int ps0 = L.pose_ps_off[a], ps1 = L.pose_ps_off[a+1];
+        for (int base = ps0; base < ps1; base += SCHUR_T*SCHUR_U) {
+            int s[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
 #pragma unroll
-            for (int k = 0; k < 6; k++) acc[k] += B.w_pt[(size_t)(s)*PT_REC + k]*f;
+            for (int u = 0; u < SCHUR_U; u++) {
+                const int q = base + u*SCHUR_T + tid; ok[u] = q < ps1;
+                const int qc = min(q, ps1 - 1);
+                s[u] = L.pose_ps[qc]; j[u] = L.pose_ps_lm[qc];
+            }
+            double w[SCHUR_U][6], bb[SCHUR_U], Vv[SCHUR_U], dg[SCHUR_U];
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                bb[u] = B.b_pt[j[u]]; Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
+#pragma unroll
+                for (int k = 0; k < 6; k++) w[u][k] = B.w_pt[(size_t)(s[u])*PT_REC + k];
+            }
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                const double f = ok[u] ? bb[u]/(Vv[u] + dg[u]*irad) : 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) acc[k] += w[u][k]*f;
+            }
         }
-        for (int q = L.pose_ts_off[a] + lane; q < L.pose_ts_off[a+1]; q += 64) {
+        for (int q = L.pose_ts_off[a] + tid; q < L.pose_ts_off[a+1]; q += SCHUR_T) {
             const int s = L.pose_ts[q], j = L.pose_ts_lm[q];
             double Vd[6], Vi[6];
 #pragma unroll
@@ -740,14 +974,15 @@ __global__ __launch_bounds__(64) void k_schur(Work W, LevelDev L, int multi) {
             for (int k = 0; k < 6; k++)
                 acc[k] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*f0 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*f1 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*f2;
         }
+        const double bpv = tid < 6 ? (multi ? B.bp_loc[6*a + tid] : B.bp[6*a + tid]) : 0.0;
 #pragma unroll
         for (int k = 0; k < 6; k++) acc[k] = wave_sum1(acc[k]);
-        if (lane < 6) {
-            double v = acc[0];
+        if (lane == 0) {
 #pragma unroll
-            for (int k = 1; k < 6; k++) if (lane == k) v = acc[k];
-            W.g[6*ia + lane] = (multi ? B.bp_loc[6*a + lane] : B.bp[6*a + lane]) - v;
+            for (int k = 0; k < 6; k++) lds[wave*6 + k] = acc[k];
         }
+        __syncthreads();
+        if (tid < 6) W.g[6*ia + tid] = bpv - (((lds[tid] + lds[6 + tid]) + lds[12 + tid]) + lds[18 + tid]);
     }
 }
 
@@ -771,9 +1006,19 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
             int o = L.pls_off[j], e = L.pls_off[j+1];
             if (!fail && e > o && W.act_pt[j]) {
                 double acc = B.b_pt[j];
-                for (int s = o; s < e; s++) { const int a = L.pslot_pose[s];       // dp is 0 for constant / absent poses
+                for (int s0 = o; s0 < e; s0 += 6) {                                 // 6 slots in flight; dp is 0 for constant / absent poses
+                    int a[6]; double w[6][6], dpv[6][6];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) acc += B.w_pt[(size_t)(s)*PT_REC + k]*W.dp[6*a + k]; }
+                    for (int u = 0; u < 6; u++) a[u] = L.pslot_pose[min(s0 + u, e - 1)];
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+#pragma unroll
+                        for (int k = 0; k < 6; k++) { w[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 1))*PT_REC + k]; dpv[u][k] = W.dp[6*a[u] + k]; }
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+#pragma unroll
+                        for (int k = 0; k < 6; k++) acc += s0 + u < e ? w[u][k]*dpv[u][k] : 0.0;
+                }
                 const double lam = B.dgs_pt[j]*irad;
                 d = -acc/(B.V_pt[j] + lam);
                 step2 = d*d; mcc = lam*d*d - B.b_pt[j]*d;
@@ -787,10 +1032,23 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
             int o = L.tls_off[j], e = L.tls_off[j+1];
             if (!fail && e > o && W.act_tx[j]) {
                 double acc[3] = { B.b_tx[j], B.b_tx[(size_t)W.n_text + j], B.b_tx[(size_t)2*W.n_text + j] };
-                for (int s = o; s < e; s++) { const int a = L.tslot_pose[s];
+                for (int s0 = o; s0 < e; s0 += 3) {                                 // 3 slots in flight
+                    int a[3]; double w[3][18], dpv[3][6];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) { const double dpk = W.dp[6*a + k];
-                        acc[0] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*dpk; acc[1] += B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*dpk; acc[2] += B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*dpk; } }
+                    for (int u = 0; u < 3; u++) a[u] = L.tslot_pose[min(s0 + u, e - 1)];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+#pragma unroll
+                        for (int k = 0; k < 18; k++) w[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 1))*TX_REC + k];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) dpv[u][k] = W.dp[6*a[u] + k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) if (s0 + u < e) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) { acc[0] += w[u][k*3]*dpv[u][k]; acc[1] += w[u][k*3 + 1]*dpv[u][k]; acc[2] += w[u][k*3 + 2]*dpv[u][k]; }
+                    }
+                }
                 double Vd[6], Vi[6], lam[3];
 #pragma unroll
                 for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
@@ -830,16 +1088,22 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
 __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o, int multi) {
     LmState *st = W.st;
     if (st->done) return;
-    __shared__ double red[256];
+    __shared__ double red[5*256], xch[256];
     const int tid = threadIdx.x;
     // the candidate was linearised speculatively into lb[lcur^1]: its cost, gradient and diagonals are already there
     const LinBuf &Bc = W.lb[st->lcur ^ 1];
     double gmax_c, xn_c, cost;
     double step2 = 0.0, mcc = 0.0;
+#ifdef TSBA_SOLVE_STAMPS
+    const long long s0_ = clock64(); long long s1_ = 0, s2_ = 0, s3_ = 0;
+#endif
     if (!multi) {
-        postlin_body(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, red, gmax_c, xn_c, cost);
-        for (int k = tid; k < nb_back; k += 256) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
-        step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+        double o5[5];
+        postlin_fused(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, nb_back, red, xch, o5);
+        gmax_c = o5[0]; xn_c = o5[1]; cost = o5[2]; step2 = o5[3]; mcc = o5[4];
+#ifdef TSBA_SOLVE_STAMPS
+        s1_ = s2_ = s3_ = clock64();
+#endif
     } else {                                      // k_sums_multi + all-reduce already produced the global sums
         double gp, xp;
         pose_scale(W, Bc, W.cb, W.cb + W.N, W.pose[st->cur ^ 1], false, red, gp, xp);
@@ -874,6 +1138,9 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
     }
     if (st->it >= st->max_it) { st->done = 1; st->term = 0; }
     else if (st->radius < o.min_radius) { st->done = 1; st->term = 4; }
+#ifdef TSBA_SOLVE_STAMPS
+    W.dbg[32] = s1_ - s0_; W.dbg[33] = s2_ - s1_; W.dbg[34] = s3_ - s2_; W.dbg[35] = clock64() - s3_;
+#endif
 }
 
 // ================================================================== multi-GPU (global BA sharded by landmark over RCCL)
@@ -1078,6 +1345,7 @@ struct Ctx {
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
+    char *slab_ptr = nullptr; size_t slab_left = 0;
     int rank = 0, world = 1; bool force_multi = false;
     void *rccl_so = nullptr; ncclComm_t comm = nullptr;
     decltype(&ncclGetUniqueId) p_getid = nullptr; decltype(&ncclCommInitRank) p_init = nullptr;
@@ -1087,13 +1355,22 @@ struct Ctx {
 
 static void set_err(Ctx *c, const std::string &s) { c->err = s; }
 
+// Device memory comes from a few large slabs (bump allocation, 256-byte aligned): the ~200 work arrays of a problem share
+// 2 MB pages instead of one small hipMalloc each -- far fewer TLB misses for the latency-bound single-workgroup kernels, and a
+// much cheaper upload.
 template <typename T>
 static int dev_alloc(Ctx *c, T **out, size_t n) {
-    void *p = nullptr; size_t bytes = std::max<size_t>(n, 1)*sizeof(T);
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) { set_err(c, std::string("hipMalloc: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; }
+    const size_t bytes = (std::max<size_t>(n, 1)*sizeof(T) + 255) & ~(size_t)255;
+    if (c->slab_left < bytes) {
+        const size_t sz = std::max<size_t>(bytes, (size_t)64 << 20);
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess) { set_err(c, std::string("hipMalloc: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; }
+        c->allocs.push_back(p); c->slab_ptr = (char *)p; c->slab_left = sz;
+    }
+    void *p = c->slab_ptr; c->slab_ptr += bytes; c->slab_left -= bytes;
     hipMemsetAsync(p, 0, bytes, c->stream);
-    c->allocs.push_back(p); *out = (T *)p; return 0;
+    *out = (T *)p; return 0;
 }
 template <typename T>
 static int dev_upload(Ctx *c, const T **out, const T *src, size_t n) {
@@ -1108,7 +1385,7 @@ static int dev_upload_vec(Ctx *c, const T **out, const std::vector<T> &v) { retu
 static void free_problem(Ctx *c) {
     hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) hipFree(p);
-    c->allocs.clear(); c->uploaded = false; c->hplan.clear(); c->lev.clear(); c->lev_built.clear();
+    c->allocs.clear(); c->slab_ptr = nullptr; c->slab_left = 0; c->uploaded = false; c->hplan.clear(); c->lev.clear(); c->lev_built.clear();
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) c->img_dev[l].clear();
 }
 
@@ -1241,7 +1518,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         D.img_w = p->img_w[l]; D.img_h = p->img_h[l];
 #define UV(field) do { rc = dev_upload_vec(c, &D.field, H.field); if (rc) return rc; } while (0)
         UV(sc_obs); UV(sc_kf); UV(sc_pt); UV(sc_flag); UV(sc_slot); UV(sc_uv);
-        UV(pair_i); UV(pair_h); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
+        UV(tg_rec); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
         UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
         UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
         UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
@@ -1369,7 +1646,7 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);   // block-sparse S
-    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D, (int)is_multi(c));
+    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(SCHUR_T), 0, c->stream, W, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
         allreduce(c, W.S, (size_t)W.N*W.N, ncclDouble, ncclSum);
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
@@ -1546,7 +1823,7 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     launch_linearize(c, D, 0);
     Work &W = c->W;
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
-    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, W, D, 0);
+    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(SCHUR_T), 0, c->stream, W, D, 0);
     launch_solve(c);
     c->opt = saved;
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());

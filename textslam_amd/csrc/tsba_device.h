@@ -19,9 +19,19 @@ struct Pose {
     double t[3];
 };
 
+// 1/x: v_rcp_f64 (2^-23) + two Newton steps instead of the IEEE division sequence (v_div_scale x2, v_rcp, 6 fma, v_div_fmas,
+// v_div_fixup ~ 130 cycles of quarter-rate instructions per wave).  The linearisation is bound by instruction issue and a
+// photometric tap has four of these.  Result within 1 ulp; x = 0 / inf / nan fall back to the seed (inf / 0 / nan as IEEE).
+TS_DEV double ts_rcp(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r0, 1.0), r = fma(r0, e, r0);
+    e = fma(-x, r, 1.0); r = fma(r, e, r);
+    return r == r ? r : r0;
+}
+
 TS_DEV void quat_to_R(const double q_[4], double R[9]) {       // Eigen normalized() + toRotationMatrix()
-    double n = sqrt(q_[0]*q_[0] + q_[1]*q_[1] + q_[2]*q_[2] + q_[3]*q_[3]);
-    double w = q_[0]/n, x = q_[1]/n, y = q_[2]/n, z = q_[3]/n;
+    double in = ts_rcp(sqrt(q_[0]*q_[0] + q_[1]*q_[1] + q_[2]*q_[2] + q_[3]*q_[3]));
+    double w = q_[0]*in, x = q_[1]*in, y = q_[2]*in, z = q_[3]*in;
     double tx = 2*x, ty = 2*y, tz = 2*z;
     double twx = tx*w, twy = ty*w, twz = tz*w, txx = tx*x, txy = ty*x, txz = tz*x, tyy = ty*y, tyz = tz*y, tzz = tz*z;
     R[0] = 1-(tyy+tzz); R[1] = txy-twz;     R[2] = txz+twy;
@@ -82,7 +92,7 @@ TS_DEV void pair_from_Twr(const Pose &C, const double *__restrict__ Twr, PairT &
 // Huber (ceres::HuberLoss) on s = |r|^2: returns rho(s), *w = rho'(s) (the IRLS weight; Corrector scales r and J by sqrt(w))
 TS_DEV double huber(double s, double delta, double &w) {
     double b = delta*delta;
-    if (s > b) { double r = sqrt(s); w = delta/r; return 2.0*delta*r - b; }
+    if (s > b) { double r = sqrt(s); w = delta*ts_rcp(r); return 2.0*delta*r - b; }
     w = 1.0; return s;
 }
 
@@ -90,14 +100,14 @@ TS_DEV double huber(double s, double delta, double &w) {
 TS_DEV void scene_block(const PairT &T, const double tc[3], double mx, double my, double rho, double u_obs, double v_obs,
                         double fx, double fy, double cx, double cy, double wx, double wy,
                         double r[2], double jt[2][6], double jl[2]) {
-    double ir = 1.0/rho;
+    double ir = ts_rcp(rho);
     double X[3] = { ir*mx, ir*my, ir };
     double Pm[3]; mat3_vec(T.Rcr, X, Pm);
     Pm[0] += T.tq[0]; Pm[1] += T.tq[1]; Pm[2] += T.tq[2];
     double Px = Pm[0] + tc[0], Py = Pm[1] + tc[1], Pz = Pm[2] + tc[2];
-    r[0] = (fx*Px/Pz + cx - u_obs)*wx;
-    r[1] = (fy*Py/Pz + cy - v_obs)*wy;
-    double iz = 1.0/Pz;
+    double iz = ts_rcp(Pz);
+    r[0] = (fx*Px*iz + cx - u_obs)*wx;
+    r[1] = (fy*Py*iz + cy - v_obs)*wy;
     double a0[3] = { wx*fx*iz, 0.0, -wx*fx*Px*iz*iz };
     double a1[3] = { 0.0, wy*fy*iz, -wy*fy*Py*iz*iz };
     // J_target row = [ 2 (Pm x a)^T | a^T ]
@@ -112,12 +122,13 @@ TS_DEV void scene_block(const PairT &T, const double tc[3], double mx, double my
 }
 TS_DEV void scene_residual(const PairT &T, const double tc[3], double mx, double my, double rho, double u_obs, double v_obs,
                            double fx, double fy, double cx, double cy, double wx, double wy, double r[2]) {
-    double ir = 1.0/rho;
+    double ir = ts_rcp(rho);
     double X[3] = { ir*mx, ir*my, ir };
     double Pm[3]; mat3_vec(T.Rcr, X, Pm);
     double Px = Pm[0] + T.tq[0] + tc[0], Py = Pm[1] + T.tq[1] + tc[1], Pz = Pm[2] + T.tq[2] + tc[2];
-    r[0] = (fx*Px/Pz + cx - u_obs)*wx;
-    r[1] = (fy*Py/Pz + cy - v_obs)*wy;
+    double iz = ts_rcp(Pz);
+    r[0] = (fx*Px*iz + cx - u_obs)*wx;
+    r[1] = (fy*Py*iz + cy - v_obs)*wy;
 }
 
 // INTERVAL8 pattern, src/tool.cc:1550-1557
@@ -141,22 +152,58 @@ TS_DEV double bilinear_tap(const uint8_t *__restrict__ img, int w, int h, double
     return (1.0 - su)*(1.0 - sv)*I00 + su*(1.0 - sv)*I01 + (1.0 - su)*sv*I10 + su*sv*I11;
 }
 
-// one photometric tap: residual, target-pose row (6), theta row (3)
-TS_DEV double text_tap(const PairT &T, const double tc[3], const double th[3], double mx, double my,
-                       double fx, double fy, double cx, double cy, const uint8_t *__restrict__ img, int w, int h,
-                       double mu, double sigma, double inv_sigma, double ref, double wT, bool want_j, double jt[6], double jl[3]) {
-    double s = -(mx*th[0] + my*th[1] + th[2]);               // rho(m) = -m^T theta, ModelTool.hpp:167
-    double m[3] = { mx, my, 1.0 };
-    double Rm[3]; mat3_vec(T.Rcr, m, Rm);
-    double is = 1.0/s;
-    double Pm[3] = { Rm[0]*is + T.tq[0], Rm[1]*is + T.tq[1], Rm[2]*is + T.tq[2] };
-    double Px = Pm[0] + tc[0], Py = Pm[1] + tc[1], Pz = Pm[2] + tc[2];
-    double u = fx*Px/Pz + cx, v = fy*Py/Pz + cy;
-    double gu, gv;
-    double I = bilinear_tap(img, w, h, u, v, gu, gv);
-    double r = ((I - mu)/sigma - ref)*wT;                   // nume_BAText.h:86-87
+// one photometric tap, split so that the image fetches of all taps of a feature can be in flight together:
+//   tap_fetch   projects the tap and loads its 2x2 pixel neighbourhood (zeros outside the image: same rule as bilinear_tap)
+//   text_tap_px redoes the (cheap, bit-identical) projection and finishes residual, target-pose row (6), theta row (3)
+struct TapPx { int I00, I01, I10, I11; };
+TS_DEV void tap_project(const PairT &T, const double tc[3], const double th[3], double mx, double my,
+                        double fx, double fy, double cx, double cy, double Rm[3], double &is, double Pm[3], double P[3], double &u, double &v) {
+    const double s = -(mx*th[0] + my*th[1] + th[2]);         // rho(m) = -m^T theta, ModelTool.hpp:167
+    const double m[3] = { mx, my, 1.0 };
+    mat3_vec(T.Rcr, m, Rm);
+    is = ts_rcp(s);
+    Pm[0] = Rm[0]*is + T.tq[0]; Pm[1] = Rm[1]*is + T.tq[1]; Pm[2] = Rm[2]*is + T.tq[2];
+    P[0] = Pm[0] + tc[0]; P[1] = Pm[1] + tc[1]; P[2] = Pm[2] + tc[2];
+    const double iz = ts_rcp(P[2]);                          // one reciprocal for both coordinates (and the Jacobian)
+    u = fx*P[0]*iz + cx; v = fy*P[1]*iz + cy;
+}
+TS_DEV TapPx tap_fetch(const PairT &T, const double tc[3], const double th[3], double mx, double my,
+                       double fx, double fy, double cx, double cy, const uint8_t *__restrict__ img, int w, int h) {
+    double Rm[3], is, Pm[3], P[3], u, v;
+    tap_project(T, tc, th, mx, my, fx, fy, cx, cy, Rm, is, Pm, P, u, v);
+    TapPx px = { 0, 0, 0, 0 };
+    const double uf = floor(u), vf = floor(v);
+    const int iu = (int)uf, iv = (int)vf;
+    if (iu < 0 || iv < 0 || (int)ceil(u) >= w || (int)ceil(v) >= h) return px;
+    // two 2-byte fetches instead of four 1-byte ones (the images are one slab: the byte after a row end is mapped memory)
+    const uint8_t *p = img + (size_t)iv*w + iu;
+    typedef unsigned short u16u __attribute__((aligned(1)));
+    const unsigned r0 = *(const u16u *)p;
+    const unsigned r1 = (iv + 1 < h) ? (unsigned)*(const u16u *)(p + w) : 0u;
+    const bool in_u = iu + 1 < w;
+    px.I00 = r0 & 0xff; px.I01 = in_u ? (r0 >> 8) : 0;
+    px.I10 = r1 & 0xff; px.I11 = in_u ? (r1 >> 8) : 0;
+    return px;
+}
+TS_DEV double text_tap_px(const PairT &T, const double tc[3], const double th[3], double mx, double my,
+                          double fx, double fy, double cx, double cy, const TapPx &px, int w, int h,
+                          double mu, double sigma, double inv_sigma, double ref, double wT, bool want_j, double jt[6], double jl[3]) {
+    double Rm[3], is, Pm[3], P[3], u, v;
+    tap_project(T, tc, th, mx, my, fx, fy, cx, cy, Rm, is, Pm, P, u, v);
+    double gu = 0.0, gv = 0.0, I = 0.0;
+    const double uf = floor(u), vf = floor(v);
+    const int iu = (int)uf, iv = (int)vf;
+    if (!(iu < 0 || iv < 0 || (int)ceil(u) >= w || (int)ceil(v) >= h)) {
+        const double su = u - uf, sv = v - vf;
+        const double I00 = px.I00, I01 = px.I01, I10 = px.I10, I11 = px.I11;
+        gu = (1.0 - sv)*(I01 - I00) + sv*(I11 - I10);
+        gv = (1.0 - su)*(I10 - I00) + su*(I11 - I01);
+        I = (1.0 - su)*(1.0 - sv)*I00 + su*(1.0 - sv)*I01 + (1.0 - su)*sv*I10 + su*sv*I11;
+    }
+    const double r = ((I - mu)*inv_sigma - ref)*wT;         // nume_BAText.h:86-87
     if (want_j) {
-        double iz = 1.0/Pz;
+        const double Px = P[0], Py = P[1], Pz = P[2];
+        double iz = ts_rcp(Pz);
         double g0 = wT*inv_sigma*gu, g1 = wT*inv_sigma*gv;
         double a[3] = { g0*fx*iz, g1*fy*iz, -(g0*fx*Px + g1*fy*Py)*iz*iz };
         jt[0] = 2.0*(Pm[1]*a[2] - Pm[2]*a[1]); jt[1] = 2.0*(Pm[2]*a[0] - Pm[0]*a[2]); jt[2] = 2.0*(Pm[0]*a[1] - Pm[1]*a[0]);
@@ -165,6 +212,12 @@ TS_DEV double text_tap(const PairT &T, const double tc[3], const double th[3], d
         jl[0] = c*mx; jl[1] = c*my; jl[2] = c;
     }
     return r;
+}
+TS_DEV double text_tap(const PairT &T, const double tc[3], const double th[3], double mx, double my,
+                       double fx, double fy, double cx, double cy, const uint8_t *__restrict__ img, int w, int h,
+                       double mu, double sigma, double inv_sigma, double ref, double wT, bool want_j, double jt[6], double jl[3]) {
+    const TapPx px = tap_fetch(T, tc, th, mx, my, fx, fy, cx, cy, img, w, h);
+    return text_tap_px(T, tc, th, mx, my, fx, fy, cx, cy, px, w, h, mu, sigma, inv_sigma, ref, wT, want_j, jt, jl);
 }
 
 // ceres::QuaternionParameterization::Plus

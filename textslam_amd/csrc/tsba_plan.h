@@ -22,9 +22,10 @@ struct HostPlan {
     std::vector<int32_t> sc_obs, sc_kf, sc_pt, sc_flag, sc_slot;
     std::vector<double>  sc_uv;                 // [n_sc][2]
     // pairs
-    std::vector<int32_t> pair_i, pair_h, pair_sc_off, pair_tg_off, pair_tg;
+    std::vector<int32_t> pair_i, pair_h, pair_hpos, pair_sc_off, pair_tg_off, pair_tg;   // pair_hpos: rank of the pair in host-major order (-1: frozen host)
     // text groups
     std::vector<int32_t> tg_tobs, tg_kf, tg_text, tg_pair, tg_slot;
+    std::vector<int32_t> tg_rec;        // per group, one 32-byte record: tobs, kf, text, host, slot, f0, f1, fgood offset (all static)
     // landmark slots
     std::vector<int32_t> pls_off, pslot_pose, pslot_pair, pslot_lm;     // points
     std::vector<int32_t> tls_off, tslot_pose, tslot_pair, tslot_lm;     // text planes
@@ -171,11 +172,22 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         std::vector<int> cur(off.begin(), off.end() - 1);
         for (auto &it : items) val[cur[it.first]++] = it.second;
     };
+    P.tg_rec.resize(8*(size_t)n_tg);
+    for (int g = 0; g < n_tg; g++) {
+        const int tb = P.tg_tobs[g], j = P.tg_text[g];
+        int32_t *r = &P.tg_rec[8*(size_t)g];
+        r[0] = tb; r[1] = P.tg_kf[g]; r[2] = j; r[3] = p->text_host[j]; r[4] = P.tg_slot[g];
+        r[5] = p->tfeat_off[L] ? p->tfeat_off[L][j] : 0; r[6] = p->tfeat_off[L] ? p->tfeat_off[L][j+1] : 0; r[7] = p->tobs_fgood_off[tb];
+    }
     std::vector<std::pair<int,int>> it_t, it_h, it_ps, it_ts;
     for (int q = 0; q < n_pair; q++) { it_t.push_back({ P.pair_i[q], q }); if (P.pair_h[q] >= 0) it_h.push_back({ P.pair_h[q], q }); }
     for (int s = 0; s < P.n_pslot(); s++) it_ps.push_back({ P.pslot_pose[s], s });
     for (int s = 0; s < P.n_tslot(); s++) it_ts.push_back({ P.tslot_pose[s], s });
     csr(n_kf, it_t, P.pose_t_off, P.pose_t); csr(n_kf, it_h, P.pose_h_off, P.pose_h);
+    // pairs are sorted by (target, host): pose_t[k] == k, and the host-side products are stored host-major so that the per-pose
+    // sums of both kinds read contiguous ranges
+    P.pair_hpos.assign(n_pair, -1);
+    for (size_t k = 0; k < P.pose_h.size(); k++) P.pair_hpos[P.pose_h[k]] = (int)k;
     csr(n_kf, it_ps, P.pose_ps_off, P.pose_ps); csr(n_kf, it_ts, P.pose_ts_off, P.pose_ts);
     P.pose_ps_lm.resize(P.pose_ps.size()); P.pose_ts_lm.resize(P.pose_ts.size());
     for (size_t k = 0; k < P.pose_ps.size(); k++) P.pose_ps_lm[k] = P.pslot_lm[P.pose_ps[k]];
