@@ -36,7 +36,7 @@ struct LmState {
 };
 
 struct LevelDev {            // device copies of HostPlan + per-level inputs
-    int level, n_sc, n_pair, n_tg, n_pslot, n_tslot, n_sb, n_tfeat;
+    int level, n_sc, n_pair, n_tg, n_pslot, n_tslot, n_sb, n_tfeat, bw_rows;      // bw_rows: rows of S below a pose block that can be non-zero
     double K[4];             // K_l
     int img_w, img_h;
     const uint8_t *const *img;      // [n_kf] device pointers
@@ -1346,6 +1346,7 @@ struct Ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
     char *slab_ptr = nullptr; size_t slab_left = 0;
+    int cur_bw_rows = 1 << 30;                     // band bound of the level being solved (set by launch_pass_init)
     int rank = 0, world = 1; bool force_multi = false;
     void *rccl_so = nullptr; ncclComm_t comm = nullptr;
     decltype(&ncclGetUniqueId) p_getid = nullptr; decltype(&ncclCommInitRank) p_init = nullptr;
@@ -1511,7 +1512,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         int l = o->levels[ps]; if (c->lev_built[l]) continue; c->lev_built[l] = 1;
         HostPlan &H = c->hplan[l]; build_plan(p, o, l, H);
         LevelDev &D = c->lev[l]; memset(&D, 0, sizeof(D));
-        D.level = l; D.n_sc = H.n_sc(); D.n_pair = H.n_pair(); D.n_tg = H.n_tg(); D.n_pslot = H.n_pslot(); D.n_tslot = H.n_tslot(); D.n_sb = H.n_sb();
+        D.level = l; D.n_sc = H.n_sc(); D.n_pair = H.n_pair(); D.n_tg = H.n_tg(); D.n_pslot = H.n_pslot(); D.n_tslot = H.n_tslot(); D.n_sb = H.n_sb(); D.bw_rows = 6*H.bw_pose;
         double sc = 1.0; for (int k = 0; k < l; k++) sc *= 0.5;
         for (int k = 0; k < 4; k++) { double v = p->K[k]; for (int q = 0; q < l; q++) v *= 0.5; D.K[k] = v; }
         (void)sc;
@@ -1588,6 +1589,7 @@ static void allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRe
     if (r != ncclSuccess) c->err = std::string("ncclAllReduce: ") + c->p_errstr(r);
 }
 static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
+    c->cur_bw_rows = D.bw_rows;
     Work &W = c->W; const tsba_options &o = c->opt;
     hipLaunchKernelGGL(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
     int n = D.n_sc + D.n_tg;
@@ -1623,20 +1625,23 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
 static void launch_solve(Ctx *c) {
     Work &W = c->W;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) { hipLaunchKernelGGL(k_solve, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W); return; }
+    if (use_lds) { hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0); return; }
     const int N = W.N;                                             // worst case: every keyframe free
+    const int bw = std::min(c->cur_bw_rows, N);                    // band of the reduced camera matrix (rows below a pose block)
     hipLaunchKernelGGL(k_chol_rhs, dim3((N + 255)/256), dim3(256), 0, c->stream, W);
-    const int lds_panel = (CH_NB*(CH_NB + 1)/2 + CH_PT*(CH_NB + 1))*(int)sizeof(double);
+    const int lds_diag = (int)(solve_diag_lds_doubles()*sizeof(double));
+    const int lds_panel = (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double);
     const int lds_upd = 2*64*(CH_NB + 1)*(int)sizeof(double);
     for (int j0 = 0; j0 < N; j0 += CH_NB) {
-        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(CH_T), 0, c->stream, W, j0);
-        const int rows = N + 1 - (j0 + CH_NB);                         // the host only knows the worst case n = N; a shorter last
-        const int prow = N + 1 - (j0 + 6);                             // block (nb < NB) still has the rhs row below it
-        if (prow > 0) hipLaunchKernelGGL(k_chol_panel, dim3((prow + CH_PT - 1)/CH_PT), dim3(CH_PT), lds_panel, c->stream, W, j0);
-        const int nt = (rows + 63)/64;
-        if (rows > 1) hipLaunchKernelGGL(k_chol_update, dim3(nt*(nt + 1)/2), dim3(CH_T), lds_upd, c->stream, W, j0);
+        hipLaunchKernelGGL(k_solve_t<true>, dim3(1), dim3(SOLVE_THREADS), lds_diag, c->stream, W, j0);
+        // the host only knows the worst case n = N; a shorter last block (nb < NB) still has the rhs row below it
+        const int wr = std::max(0, std::min(bw, N - (j0 + 6)));        // band rows below the block, + 1 for the rhs row
+        hipLaunchKernelGGL(k_chol_panel, dim3(wr/64 + 1), dim3(CH_T), lds_panel, c->stream, W, j0, bw);
+        const int nt = (wr + 1 + 63)/64;
+        if (wr > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt*(nt + 1)/2), dim3(CH_T), lds_upd, c->stream, W, j0, bw);
     }
-    if (!getenv("TSBA_DEBUG_NO_BACKSUB")) hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), 0, c->stream, W);
+    const int lds_bs = (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double);
+    if (!getenv("TSBA_DEBUG_NO_BACKSUB")) hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, W, bw);
 }
 
 // one LM iteration: reduced system -> pose step -> back-substitution / candidate -> speculative linearisation at the
@@ -1665,10 +1670,12 @@ int tsba_solve(void *ctx, tsba_report *r) {
     memset(r, 0, sizeof(*r));
     const tsba_options &o = c->opt;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     else {
-        CK(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB*(CH_NB + 1)/2 + CH_PT*(CH_NB + 1))*(int)sizeof(double)));
+        CK(hipFuncSetAttribute((const void *)k_solve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solve_diag_lds_doubles()*sizeof(double))));
+        CK(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double)));
         CK(hipFuncSetAttribute((const void *)k_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2*64*(CH_NB + 1)*(int)sizeof(double)));
+        CK(hipFuncSetAttribute((const void *)k_chol_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double)));
     }
     auto t0 = std::chrono::steady_clock::now();
     int rc = reset_state(c); if (rc) return rc;
@@ -1818,7 +1825,7 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     tsba_options saved = c->opt; c->opt.initial_radius = radius;
     const LevelDev &D = c->lev[c->opt.levels[0]];
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     launch_pass_init(c, D, 0);
     launch_linearize(c, D, 0);
     Work &W = c->W;

@@ -1,87 +1,79 @@
-// Dense blocked Cholesky of a large reduced camera system (global BA: 6 n_free up to tens of thousands), multi-workgroup.
+// Blocked Cholesky of a large reduced camera system (global BA: 6 n_free up to tens of thousands), multi-workgroup,
+// profile-aware: the reduced camera matrix of a SLAM map is (block-)banded -- a keyframe is coupled to the keyframes it shares
+// landmarks with -- and Cholesky without pivoting keeps the band.  The host knows an upper bound `bw` of the number of rows
+// below a pose block that can be non-zero (tsba_plan.h: envelope of the S-block list, fill included); every step touches only
+// those rows plus the right-hand-side row, so a 1000-keyframe map with a 24-keyframe band costs ~0.1 GFLOP instead of 72.
 //
-//   S (n x n, lower triangle used, leading dimension ld) and the right-hand side g held as row n of the same array.
-//   Right-looking, block size NB = 96 (16 keyframes):
-//     k_chol_diag    1 workgroup: LDS Cholesky of the NB x NB diagonal block
-//     k_chol_panel   rows below (and the rhs row): X L^T = A  (one thread per row, L broadcast from LDS)
-//     k_chol_update  trailing matrix -= panel panel^T on the matrix cores (v_mfma_f64_16x16x4_f64), 64x64 tiles per workgroup
-//   then k_chol_backsub (1 workgroup) solves L^T x = y and scatters dp = -x to the pose order.
-// The forward substitution rides along as the extra row, exactly as in the LDS solver (tsba_solve.h).
+//   S (n x n, ld = N) and the right-hand side g held as row n of the same array (forward substitution rides along).
+//   Right-looking, block size NB = 96 (16 keyframes), per block column:
+//     k_solve_t<true>  1 workgroup: LDL^T of the NB x NB diagonal block in LDS (tsba_solve.h), written back as L D^1/2 (lower),
+//                      and its inverse transposed (strict upper triangle + W.LDbuf for the diagonal)
+//     k_chol_panel     band rows below + the rhs row:  X = A W^T  on the matrix cores (the inverse turns the triangular solve into
+//                      a GEMM), 64 rows per workgroup
+//     k_chol_update    band window -= panel panel^T (v_mfma_f64_16x16x4_f64), 64x64 tiles per workgroup; local row `wr` of the
+//                      window stands for the rhs row
+//   then k_chol_backsub (1 workgroup): per block x = W^T y (matvec with the stored inverse), band update of y; dp = -x.
 #pragma once
 
 #define CH_NB 96
 #define CH_T 256
 
-// ---- diagonal block: in-LDS Cholesky (LL^T), NB x NB, 256 threads
-__global__ __launch_bounds__(CH_T) void k_chol_diag(Work W, int j0) {
-    LmState *st = W.st;
-    if (st->done || st->step_fail) return;
-    const int n = 6 * *W.nfree;
-    if (j0 >= n) return;
-    const int nb = min(CH_NB, n - j0);
-    __shared__ double L[CH_NB*(CH_NB + 1)];
-    __shared__ int bad;
-    const int tid = threadIdx.x, ld = W.N, lds = CH_NB + 1;
-    double *A = W.S;
-    if (tid == 0) bad = 0;
-    for (int k = tid; k < nb*nb; k += CH_T) { int r = k / nb, c = k - r*nb; L[r*lds + c] = (c <= r) ? A[(size_t)(j0 + r)*ld + j0 + c] : 0.0; }
-    __syncthreads();
-    for (int j = 0; j < nb; j++) {
-        double d = L[j*lds + j];
-        if (!(d > 0.0)) { if (tid == 0) bad = 1; d = 1.0; }
-        const double s = sqrt(d), is = 1.0/s;
-        __syncthreads();
-        for (int r = j + tid; r < nb; r += CH_T) L[r*lds + j] = (r == j) ? s : L[r*lds + j]*is;
-        __syncthreads();
-        // rank-1 update of the trailing lower triangle
-        const int m = nb - j - 1;
-        for (int k = tid; k < m*m; k += CH_T) {
-            int r = k / m, c = k - r*m;
-            if (c <= r) L[(j + 1 + r)*lds + j + 1 + c] -= L[(j + 1 + r)*lds + j]*L[(j + 1 + c)*lds + j];
-        }
-        __syncthreads();
-    }
-    for (int k = tid; k < nb*nb; k += CH_T) { int r = k / nb, c = k - r*nb; if (c <= r) A[(size_t)(j0 + r)*ld + j0 + c] = L[r*lds + c]; }
-    if (tid == 0 && bad) st->step_fail = 1;
-}
-
-// ---- panel: rows i in (j0+nb .. n] (row n = rhs): x L^T = a.  One thread per row; the row is staged in LDS (stride 97 keeps
-// the lanes on distinct banks), L is held packed-lower in LDS and broadcast.
-#define CH_PT 128
-__global__ __launch_bounds__(CH_PT) void k_chol_panel(Work W, int j0) {
-    LmState *st = W.st;
-    if (st->done || st->step_fail) return;
-    const int n = 6 * *W.nfree;
-    if (j0 >= n) return;
-    const int nb = min(CH_NB, n - j0);
-    const int i0 = j0 + nb + blockIdx.x*CH_PT;
-    if (i0 > n) return;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *L = sm;                                 // packed lower, nb(nb+1)/2
-    double *X = sm + CH_NB*(CH_NB + 1)/2;           // [CH_PT][CH_NB + 1]
-    const int tid = threadIdx.x, ld = W.N, xs = CH_NB + 1;
-    double *A = W.S;
-    for (int k = tid; k < nb*nb; k += CH_PT) { int r = k / nb, c = k - r*nb; if (c <= r) L[r*(r + 1)/2 + c] = A[(size_t)(j0 + r)*ld + j0 + c]; }
-    const int nrow = min(CH_PT, n + 1 - i0);
-    for (int k = tid; k < nrow*nb; k += CH_PT) { int r = k / nb, c = k - r*nb; X[r*xs + c] = A[(size_t)(i0 + r)*ld + j0 + c]; }
-    __syncthreads();
-    if (tid < nrow) {
-        double *x = X + tid*xs;
-        for (int c = 0; c < nb; c++) {
-            const double *lc = L + c*(c + 1)/2;
-            double v = x[c];
-            for (int k = 0; k < c; k++) v -= x[k]*lc[k];
-            x[c] = v/lc[c];
-        }
-    }
-    __syncthreads();
-    for (int k = tid; k < nrow*nb; k += CH_PT) { int r = k / nb, c = k - r*nb; A[(size_t)(i0 + r)*ld + j0 + c] = X[r*xs + c]; }
-}
-
-// ---- trailing update: C[i][k] -= sum_c P[i][c] P[k][c]  for i,k >= c0 (lower triangle, 64x64 tiles) and the rhs row.
-// Workgroup = 4 waves, each a 32x32 quadrant = 2x2 MFMA 16x16 tiles; the two 64 x nb panels are staged through LDS.
+// ---- panel: X = A W^T for 64 rows per workgroup.  W (NB x NB lower, inverse of the diagonal factor) is rebuilt in LDS from
+// the strict upper triangle of the diagonal block + LDbuf; A rows are staged in LDS; 4 waves x (16 rows x 96 columns).
 typedef double v4d_c __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0) {
+__global__ __launch_bounds__(CH_T) void k_chol_panel(Work W, int j0, int bw) {
+    LmState *st = W.st;
+    if (st->done || st->step_fail) return;
+    const int n = 6 * *W.nfree;
+    if (j0 >= n) return;
+    const int nb = min(CH_NB, n - j0), c0 = j0 + nb;
+    const int wr = min(bw, n - c0);                             // band rows below the block (all < n); local row wr = rhs row n
+    const int R0 = blockIdx.x*64;
+    if (R0 > wr) return;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lds = CH_NB + 1;
+    double *Wl = sm, *X = sm + CH_NB*lds;                       // W [96][97] (zeros above the diagonal), A rows [64][97]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ld = W.N;
+    double *A = W.S;
+    const int nbp = (nb + 3) & ~3;
+    for (int k = tid; k < CH_NB*CH_NB; k += CH_T) {
+        const int c = k / CH_NB, r = k - c*CH_NB;               // W[r][c], read along r (contiguous in the upper triangle's row c)
+        double v = 0.0;
+        if (r < nb && c < nb) v = r > c ? A[(size_t)(j0 + c)*ld + j0 + r] : (r == c ? W.LDbuf[j0 + r] : 0.0);
+        Wl[r*lds + c] = v;
+    }
+    for (int k = tid; k < 64*nbp; k += CH_T) {
+        const int r = k / nbp, c = k - r*nbp, rl = R0 + r;
+        const int gi = rl < wr ? c0 + rl : n;
+        X[r*lds + c] = (c < nb && rl <= wr) ? A[(size_t)gi*ld + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    // wave w: rows 16w..16w+15, all 6 column tiles; X[i][c] = sum_{k <= c} A[i][k] W[c][k]
+    const int lr = lane & 15, lk = lane >> 4;
+    v4d_c acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) acc[t] = (v4d_c){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < nbp; k += 4) {
+        const double av = X[(16*wave + lr)*lds + k + lk];
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            if (16*t + 15 < k) continue;                        // W[c][k] = 0 for c < k: tile entirely above the diagonal
+            const double bv = Wl[(16*t + lr)*lds + k + lk];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 6; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int rl = R0 + 16*wave + lk + 4*r, c = 16*t + lr;
+            if (rl <= wr && c < nb) { const int gi = rl < wr ? c0 + rl : n; A[(size_t)gi*ld + j0 + c] = acc[t][r]; }
+        }
+}
+
+// ---- trailing update of the band window: C[i][k] -= sum_c P[i][c] P[k][c], window rows c0 .. c0+wr-1 and (local row wr) the rhs row.
+// Workgroup = 4 waves, each a 32x32 quadrant = 2x2 MFMA 16x16 tiles; the two 64 x nb panels are staged through LDS.
+__global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0, int bw) {
     LmState *st = W.st;
     if (st->done || st->step_fail) return;
     const int n = 6 * *W.nfree;
@@ -89,8 +81,9 @@ __global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0) {
     const int nb = min(CH_NB, n - j0);
     const int c0 = j0 + nb;
     if (c0 >= n + 1) return;
-    // tile (ti, tj), tj <= ti over the (n + 1 - c0) rows x (n - c0) columns
-    const int ntile = (n + 1 - c0 + 63)/64;
+    const int wr = min(bw, n - c0);
+    // tile (ti, tj), tj <= ti over local rows 0..wr x local columns 0..wr-1
+    const int ntile = (wr + 1 + 63)/64;
     int t = blockIdx.x, ti = (int)((sqrtf(8.0f*(float)t + 1.0f) - 1.0f)*0.5f);
     while (ti*(ti + 1)/2 > t) ti--;
     while ((ti + 1)*(ti + 2)/2 <= t) ti++;
@@ -100,15 +93,17 @@ __global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0) {
     double *Pa = sm, *Pb = sm + 64*(CH_NB + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ld = W.N, lds = CH_NB + 1;
     double *A = W.S;
-    const int r0 = c0 + 64*ti, q0 = c0 + 64*tj;
+    const int r0 = 64*ti, q0 = 64*tj;                           // local
     const int nbp = (nb + 3) & ~3;                              // K padded to the MFMA depth with exact zeros
     for (int k = tid; k < 64*nbp; k += CH_T) {
         int r = k / nbp, c = k - r*nbp;
-        Pa[r*lds + c] = (c < nb && r0 + r <= n) ? A[(size_t)(r0 + r)*ld + j0 + c] : 0.0;
-        Pb[r*lds + c] = (c < nb && q0 + r < n) ? A[(size_t)(q0 + r)*ld + j0 + c] : 0.0;
+        const int rl = r0 + r, ql = q0 + r;
+        const int gr = rl < wr ? c0 + rl : n;
+        Pa[r*lds + c] = (c < nb && rl <= wr) ? A[(size_t)gr*ld + j0 + c] : 0.0;
+        Pb[r*lds + c] = (c < nb && ql < wr) ? A[(size_t)(c0 + ql)*ld + j0 + c] : 0.0;
     }
     __syncthreads();
-    const int wr = (wave >> 1)*32, wc = (wave & 1)*32;          // quadrant of this wave
+    const int wrw = (wave >> 1)*32, wc = (wave & 1)*32;         // quadrant of this wave
     const int lr = lane & 15, lk = lane >> 4;
     v4d_c acc[2][2];
 #pragma unroll
@@ -118,7 +113,7 @@ __global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0) {
     for (int k = 0; k < nb; k += 4) {
         double av[2], bv[2];
 #pragma unroll
-        for (int a = 0; a < 2; a++) av[a] = Pa[(wr + 16*a + lr)*lds + k + lk];
+        for (int a = 0; a < 2; a++) av[a] = Pa[(wrw + 16*a + lr)*lds + k + lk];
 #pragma unroll
         for (int b = 0; b < 2; b++) bv[b] = Pb[(wc + 16*b + lr)*lds + k + lk];
 #pragma unroll
@@ -132,41 +127,53 @@ __global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0) {
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int row = r0 + wr + 16*a + lk + 4*r, col = q0 + wc + 16*b + lr;
-                if (row <= n && col < n && (col <= row)) A[(size_t)row*ld + col] -= acc[a][b][r];
+                const int rl = r0 + wrw + 16*a + lk + 4*r, ql = q0 + wc + 16*b + lr;
+                if (rl <= wr && ql < wr && (rl == wr || ql <= rl)) { const int gr = rl < wr ? c0 + rl : n; A[(size_t)gr*ld + c0 + ql] -= acc[a][b][r]; }
             }
 }
 
-// ---- back substitution L^T x = y (y = row n), one workgroup; dp[6a + k] = -x[6 fidx[a] + k]
-__global__ __launch_bounds__(1024) void k_chol_backsub(Work W) {
+// ---- back substitution L^T x = y (y = row n), one workgroup of 1024 threads; dp[6a + k] = -x[6 fidx[a] + k].
+// Per block from the last: x = W^T y_block with the stored inverse (staged in LDS), then the band update of the rows above.
+__global__ __launch_bounds__(1024) void k_chol_backsub(Work W, int bw) {
     LmState *st = W.st;
     if (st->done) return;
     const int n = 6 * *W.nfree;
     const int tid = threadIdx.x, ld = W.N;
     double *A = W.S, *y = W.S + (size_t)n*ld;
     if (st->step_fail) { for (int k = tid; k < W.N; k += 1024) W.dp[k] = 0.0; return; }
-    __shared__ double xs[CH_NB];
-    for (int j1 = n; j1 > 0; j1 -= CH_NB) {
-        const int j0 = max(0, j1 - CH_NB), nb = j1 - j0;
-        // triangular solve of the diagonal block by wave 0: lane c owns y[j0 + c] (two per lane when nb > 64)
-        if (tid < 64) {
-            double y0 = tid < nb ? y[j0 + tid] : 0.0, y1 = tid + 64 < nb ? y[j0 + tid + 64] : 0.0;
-            for (int c = nb - 1; c >= 0; c--) {
-                const double lcc = A[(size_t)(j0 + c)*ld + j0 + c];
-                double yc = c < 64 ? readlane_f64(y0, c) : readlane_f64(y1, c - 64);
-                const double xc = yc/lcc;
-                if (tid == (c & 63)) { if (c < 64) y0 = xc; else y1 = xc; }
-                if (tid < c) y0 -= A[(size_t)(j0 + c)*ld + j0 + tid]*xc;
-                if (tid + 64 < c) y1 -= A[(size_t)(j0 + c)*ld + j0 + tid + 64]*xc;
-            }
-            if (tid < nb) { xs[tid] = y0; y[j0 + tid] = y0; }
-            if (tid + 64 < nb) { xs[tid + 64] = y1; y[j0 + tid + 64] = y1; }
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Wt = sm, *ys = sm + CH_NB*(CH_NB + 1), *xs = ys + CH_NB, *part = xs + CH_NB;      // Wt[c][r] = W[r][c]; part [8][96]
+    const int nblk = (n + CH_NB - 1)/CH_NB;
+    for (int jb = nblk - 1; jb >= 0; jb--) {
+        const int j0 = jb*CH_NB, nb = min(CH_NB, n - j0);
+        for (int k = tid; k < nb*nb; k += 1024) {
+            const int c = k / nb, r = k - c*nb;
+            Wt[c*(CH_NB + 1) + r] = r > c ? A[(size_t)(j0 + c)*ld + j0 + r] : (r == c ? W.LDbuf[j0 + r] : 0.0);
+        }
+        if (tid < nb) ys[tid] = y[j0 + tid];
+        __syncthreads();
+        if (tid < 8*CH_NB) {                                    // x[c] = sum_{r >= c} W[r][c] y[r], 8 partial sums per entry
+            const int c = tid >> 3, p = tid & 7;
+            double v = 0.0;
+            if (c < nb) for (int r = c + p; r < nb; r += 8) v = fma(Wt[c*(CH_NB + 1) + r], ys[r], v);
+            part[p*CH_NB + c] = v;
         }
         __syncthreads();
-        for (int k = tid; k < j0; k += 1024) {
+        if (tid < nb) {
             double v = 0.0;
-            for (int c = 0; c < nb; c++) v += A[(size_t)(j0 + c)*ld + k]*xs[c];
-            y[k] -= v;
+#pragma unroll
+            for (int p = 0; p < 8; p++) v += part[p*CH_NB + tid];
+            xs[tid] = v; y[j0 + tid] = v;
+        }
+        __syncthreads();
+        // rows j0..j0+nb-1 of L reach back at most bw + 2 NB columns (column block J holds rows up to J + NB - 1 + bw)
+        const int k0 = max(0, j0 - bw - 2*CH_NB);
+        for (int k = k0 + tid; k < j0; k += 1024) {
+            double v0 = 0.0, v1 = 0.0;
+            int c = 0;
+            for (; c + 1 < nb; c += 2) { v0 = fma(A[(size_t)(j0 + c)*ld + k], xs[c], v0); v1 = fma(A[(size_t)(j0 + c + 1)*ld + k], xs[c + 1], v1); }
+            if (c < nb) v0 = fma(A[(size_t)(j0 + c)*ld + k], xs[c], v0);
+            y[k] -= v0 + v1;
         }
         __syncthreads();
     }

@@ -18,6 +18,7 @@
 
 struct HostPlan {
     int level = 0;
+    int bw_pose = 0;                            // half bandwidth of the reduced camera matrix in pose blocks, fill included
     // scene candidates (sorted by pair)
     std::vector<int32_t> sc_obs, sc_kf, sc_pt, sc_flag, sc_slot;
     std::vector<double>  sc_uv;                 // [n_sc][2]
@@ -178,6 +179,16 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         int32_t *r = &P.tg_rec[8*(size_t)g];
         r[0] = tb; r[1] = P.tg_kf[g]; r[2] = j; r[3] = p->text_host[j]; r[4] = P.tg_slot[g];
         r[5] = p->tfeat_off[L] ? p->tfeat_off[L][j] : 0; r[6] = p->tfeat_off[L] ? p->tfeat_off[L][j+1] : 0; r[7] = p->tobs_fgood_off[tb];
+    }
+    {   // envelope of S: column a reaches down to its last coupled pose; Cholesky fill closes the profile under the running
+        // maximum (a column inherits the reach of every earlier column that reaches it).  Compressing the fixed poses out
+        // (device side) only shrinks distances, so this is an upper bound for the system that is actually factored.
+        std::vector<int> cm(n_kf);
+        for (int a = 0; a < n_kf; a++) cm[a] = a;
+        for (int q = 0; q < n_sb; q++) cm[P.sb_a[q]] = std::max(cm[P.sb_a[q]], (int)P.sb_b[q]);
+        int run = -1, bw = 0;
+        for (int k = 0; k < n_kf; k++) { const int reach = (run >= k) ? std::max(cm[k], run) : cm[k]; run = std::max(run, reach); bw = std::max(bw, reach - k); }
+        P.bw_pose = bw;
     }
     std::vector<std::pair<int,int>> it_t, it_h, it_ps, it_ts;
     for (int q = 0; q < n_pair; q++) { it_t.push_back({ P.pair_i[q], q }); if (P.pair_h[q] >= 0) it_h.push_back({ P.pair_h[q], q }); }

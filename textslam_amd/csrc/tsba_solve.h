@@ -93,11 +93,18 @@ __device__ __forceinline__ void inv_unit_lower6(const double l[15], double m[15]
         }
 }
 
+#define SOLVE_DIAG_NB 96                     // diagonal block of the large-system Cholesky (tsba_chol.h)
 static size_t solve_lds_doubles(int N) { return (size_t)rowoff(N + 1) + 16 + (size_t)SOLVE_LD*(N/6) + 36*SOLVE_PW + 8; }
+static size_t solve_diag_lds_doubles() { return solve_lds_doubles(SOLVE_DIAG_NB) + rowoff(SOLVE_DIAG_NB + 1) + SOLVE_DIAG_NB + 36*(SOLVE_DIAG_NB/6) + 16; }
 
 template <int w> struct IC { static constexpr int value = w; };
 
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W) {
+// DIAG = false: the reduced system of a small window (S, g) -> pose step dp.
+// DIAG = true : the 96x96 (or shorter, last) diagonal block at (B0, B0) of a LARGE system (tsba_chol.h): same factorisation, then
+//               the inverse of the factor; written back as Cholesky factor L D^1/2 (lower triangle), its inverse transposed
+//               (strict upper triangle) and the inverse's diagonal (W.LDbuf).
+template <bool DIAG>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
     LmState *st = W.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int fail;
@@ -110,16 +117,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W) {
     double *A = smem;                                           // padded packed lower triangle, rows 0..n (row n = g)
     // the element addresses do not depend on the number of free poses: the first round of loads is issued together with the
     // loads of the solver state (one global round trip instead of two)
-    const int neMax = tri(Nmax);
+    const int neMax = DIAG ? tri(SOLVE_DIAG_NB) : tri(Nmax);
+    const double *Sb = DIAG ? W.S + (size_t)B0*Nmax + B0 : W.S;
+    const int rmax = DIAG ? Nmax - 1 - B0 : Nmax - 1;           // (the last block of a large system may be short)
     double v[12]; int er[12], ec[12];
 #pragma unroll
     for (int u = 0; u < 12; u++) {
         const int e = min(u*SOLVE_THREADS + tid, neMax - 1);
         er[u] = tri_row(e); ec[u] = e - tri(er[u]);
-        v[u] = W.S[(size_t)er[u]*Nmax + ec[u]];
+        v[u] = Sb[(size_t)min(er[u], rmax)*Nmax + min(ec[u], rmax)];
     }
-    const int done = st->done, nfree = *W.nfree, sfail = st->step_fail;
+    const int done = st->done, nfree_all = *W.nfree, sfail = st->step_fail;
     if (done) return;
+    if (DIAG && (sfail || 6*nfree_all <= B0)) return;
+    const int nfree = DIAG ? min(SOLVE_DIAG_NB, 6*nfree_all - B0)/6 : nfree_all;
     const int n = 6*nfree, ne = tri(n);
     double *LD = A + rowoff(n + 1) + 16;
     double *scr = LD + SOLVE_LD*nfree;
@@ -130,13 +141,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W) {
         for (int u = 0; u < 12; u++) {
             const int e = min(base + u*SOLVE_THREADS + tid, ne - 1);
             er[u] = tri_row(e); ec[u] = e - tri(er[u]);
-            v[u] = W.S[(size_t)er[u]*Nmax + ec[u]];
+            v[u] = Sb[(size_t)er[u]*Nmax + ec[u]];
         }
 #pragma unroll
         for (int u = 0; u < 12; u++) if (base + u*SOLVE_THREADS + tid < ne) A[rowoff(er[u]) + ec[u]] = v[u];
     }
-    for (int k = tid; k < n; k += SOLVE_THREADS) A[rowoff(n) + k] = W.g[k];
-    if (tid == 0) fail = sfail;
+    for (int k = tid; k < n; k += SOLVE_THREADS) A[rowoff(n) + k] = DIAG ? 0.0 : W.g[k];
+    if (tid == 0) fail = DIAG ? 0 : sfail;
     __syncthreads();
 #ifdef TSBA_SOLVE_STAMPS
     if (tid == 0) W.dbg[0] = clock64() - Tl;
@@ -269,6 +280,45 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(Work W) {
     }
     long long T1 = clock64();
 #endif
+    if (DIAG) {
+        if (fail) return;                                     // (st->step_fail is set: the back-substitution kernel zeroes dp)
+        // ---- inverse of the unit-lower factor, block row by block row:  M_bc = -M_bb sum_{k=c}^{b-1} L_bk M_kc   (c < b)
+        double *Mi = scr + 36*SOLVE_PW;                       // second padded packed triangle
+        double *sq = Mi + rowoff(SOLVE_DIAG_NB + 1), *tmp = sq + SOLVE_DIAG_NB;   // sqrt(d), 6 x (6 b) scratch
+        for (int t = tid; t < 21*nfree; t += SOLVE_THREADS) {                     // diagonal blocks of the inverse
+            const int b = t/21, e = t - 21*b, r = tri_row(e), q = e - tri(r);
+            Mi[rowoff(6*b + r) + 6*b + q] = r == q ? 1.0 : LD[SOLVE_LD*b + LD_M + tri(r - 1) + q];
+        }
+        for (int t = tid; t < n; t += SOLVE_THREADS) sq[t] = sqrt(LD[SOLVE_LD*(t/6) + LD_D + t % 6]);
+        __syncthreads();
+        for (int b = 1; b < nfree; b++) {
+            const int nout = 36*b;                            // (c, r, q): 6x6 block (b, c), c < b
+            for (int t = tid; t < nout; t += SOLVE_THREADS) {
+                const int c = t/36, r = (t - 36*c)/6, q = t % 6;
+                double acc = 0.0;
+                const double *lrow = A + rowoff(6*b + r);
+                for (int k = 6*c + q; k < 6*b; k++) acc = fma(lrow[k], Mi[rowoff(k) + 6*c + q], acc);   // column 6c+q of M is zero above its diagonal
+                tmp[t] = acc;
+            }
+            __syncthreads();
+            for (int t = tid; t < nout; t += SOLVE_THREADS) {
+                const int c = t/36, r = (t - 36*c)/6, q = t % 6;
+                double acc = tmp[36*c + 6*r + q];             // M_bb is unit lower: row r = e_r + strictly-lower part
+                for (int m = 0; m < r; m++) acc = fma(LD[SOLVE_LD*b + LD_M + tri(r - 1) + m], tmp[36*c + 6*m + q], acc);
+                Mi[rowoff(6*b + r) + 6*c + q] = -acc;
+            }
+            __syncthreads();
+        }
+        // ---- write back: lower triangle L D^1/2, strict upper triangle (L D^1/2)^-T, diagonal of the inverse to LDbuf
+        double *Sw = W.S + (size_t)B0*Nmax + B0;
+        for (int t = tid; t < n*n; t += SOLVE_THREADS) {
+            const int r = t/n, c = t - r*n;
+            if (c < r) Sw[(size_t)r*Nmax + c] = A[rowoff(r) + c]*sq[c];
+            else if (c == r) { Sw[(size_t)r*Nmax + c] = sq[c]; W.LDbuf[B0 + r] = 1.0/sq[r]; }
+            else Sw[(size_t)r*Nmax + c] = Mi[rowoff(c) + r]/sq[c];          // W^T[r][c] = W[c][r] = M[c][r] / sqrt(d_c)
+        }
+        return;
+    }
     if (fail || nfree == 0) { for (int k = tid; k < Nmax; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
     double *rhs = A + rowoff(n);
     if (wave == 0) {
