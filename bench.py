@@ -173,6 +173,16 @@ def main():
         # roofline of the linearisation kernel (residual + Jacobian + IRLS weight + J^T J / J^T r sums), level 0
         lin_ms, algo_bytes = gpu.time_linearize(0, 200)
         achieved = algo_bytes / (lin_ms * 1e-3) / 1e9
+        # HBM traffic of the same kernel from the PMC passes committed under profiles/ (counters cannot be read from inside
+        # the process): 2 x FETCH_SIZE (gfx950 correction of the micro-architecture guide) + WRITE_SIZE, bytes per launch
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c4_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            traffic = (2.0 * pm["fetch_size_kb_raw_max"] + pm["write_size_kb_raw_max"]) * 1024.0
+            traffic_src = pm["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "local_ba_residuals_per_s", "value": value, "unit": "residuals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -184,7 +194,7 @@ def main():
                        "lm_iterations": rep["iters"], "resid_evals_per_call": rep["n_resid_evals"]},
             "local_ba_wall_ms": ms_per_step,
             "roofline": {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms * 1e3},
         }
         if not args.no_cpu_baseline:
