@@ -42,7 +42,7 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const uint8_t *const *img;      // [n_kf] device pointers
     const int *sc_obs, *sc_kf, *sc_pt, *sc_flag, *sc_slot; const double *sc_uv;
     const int *pair_i, *pair_h, *pair_hpos, *pair_sc_off, *pair_tg_off, *pair_tg;
-    const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot, *tg_rec;
+    const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot, *tg_rec, *tg_ppos, *pt_pose6;
     const int *pls_off, *pslot_pose, *pslot_pair, *pslot_lm, *tls_off, *tslot_pose, *tslot_pair, *tslot_lm;
     const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_pt_lm, *sb_tx_off, *sb_tx_s1, *sb_tx_s2, *sb_tx_lm;
     const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ps_lm, *pose_ts_off, *pose_ts, *pose_ts_lm;
@@ -361,9 +361,9 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
     __shared__ double lds[55*65];
     // static indices of this workgroup first: in flight together with the LM state
     const int bq = blockIdx.x;
-    int pi = 0, ph = 0, pbeg = 0, pend = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+    int pi = 0, ph = 0, pbeg = 0, pend = 0, tgpp = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
     if (bq < L.n_pair) { pi = L.pair_i[bq]; ph = L.pair_h[bq]; pbeg = L.pair_sc_off[bq]; pend = L.pair_sc_off[bq+1]; }
-    else { ra = ((const int4 *)L.tg_rec)[2*(bq - L.n_pair)]; rb = ((const int4 *)L.tg_rec)[2*(bq - L.n_pair) + 1]; }   // one static record per group
+    else { ra = ((const int4 *)L.tg_rec)[2*(bq - L.n_pair)]; rb = ((const int4 *)L.tg_rec)[2*(bq - L.n_pair) + 1]; tgpp = L.tg_ppos[bq - L.n_pair]; }   // one static record per group
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
                 }
                 tot += wave_sum_to_lane<55>(blk, lds, lane);
             }
-            if (lane < 27) B.tgM[(size_t)lane*L.n_tg + g] = tot;
+            if (lane < 27) B.tgM[(size_t)lane*L.n_tg + tgpp] = tot;          // pair-major rank: k_mid sums a contiguous range
             else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; lds[lane - 27] = tot; }
             else if (lane < 54) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + 18 + (lane - 45)] = tot; }
             else if (lane == 54) B.tgCost[g] = tot;
@@ -541,6 +541,12 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int spec) {
     const LmState *st = W.st;
+    const int b = blockIdx.x;
+    // static offsets of this thread's landmark / pair first: in flight together with the LM state
+    int o = 0, e = 0, tq0 = 0, tq1 = 0, ph_ = -1, hp_ = -1, act_ = 0;
+    if (b < nb_pt) { const int j = b*256 + threadIdx.x; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j]; } }
+    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + threadIdx.x; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
+    else { const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x; if (p < L.n_pair) { tq0 = L.pair_tg_off[p]; tq1 = L.pair_tg_off[p+1]; ph_ = L.pair_h[p]; hp_ = L.pair_hpos[p]; } }
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
@@ -549,11 +555,8 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
     __shared__ double red[256];
     const double *rho_x = W.rho[sel], *theta_x = W.theta[sel];
     double gm = 0.0, xn = 0.0;
-    const int b = blockIdx.x;
     if (b < nb_pt) {
         const int j = b*256 + threadIdx.x;
-        int o = 0, e = 0;
-        if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; }
         if (e > o) {
             double acc[8] = {0,0,0,0,0,0,0,0};
             for (int s0 = o; s0 < e - 1; s0 += 6) {                  // 6 slot records in flight per round trip
@@ -574,12 +577,10 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
             const double sg = W.sig_pt[j];
             B.dgs_pt[j] = clampd(sg*sg*V, W.min_diag, W.max_diag)/(sg*sg);
-            if (W.act_pt[j]) { gm = fabs(acc[1]); xn = rho_x[j]*rho_x[j]; }
+            if (act_) { gm = fabs(acc[1]); xn = rho_x[j]*rho_x[j]; }
         }
     } else if (b < nb_pt + nb_tx) {
         const int j = (b - nb_pt)*256 + threadIdx.x;
-        int o = 0, e = 0;
-        if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; }
         if (e > o) {
             double acc[27];
 #pragma unroll
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
                 const double sg = W.sig_tx[(size_t)k*W.n_text + j];
                 B.dgs_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag)/(sg*sg);
             }
-            if (W.act_tx[j]) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(acc[6 + k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
+            if (act_) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(acc[6 + k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
         }
     } else {
         const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x;
@@ -618,20 +619,19 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             for (int k = 0; k < 21; k++) M[k] = B.pairM[(size_t)k*L.n_pair + p];
 #pragma unroll
             for (int k = 0; k < 6; k++) c[k] = B.pairM[(size_t)(21 + k)*L.n_pair + p];
-            for (int q = L.pair_tg_off[p]; q < L.pair_tg_off[p+1]; q++) {
-                const int g = L.pair_tg[q];
+            for (int q = tq0; q < tq1; q++) {          // (stored in pair-major order by k_linearize)
 #pragma unroll
-                for (int k = 0; k < 21; k++) M[k] += B.tgM[(size_t)k*L.n_tg + g];
+                for (int k = 0; k < 21; k++) M[k] += B.tgM[(size_t)k*L.n_tg + q];
 #pragma unroll
-                for (int k = 0; k < 6; k++) c[k] += B.tgM[(size_t)(21 + k)*L.n_tg + g];
+                for (int k = 0; k < 6; k++) c[k] += B.tgM[(size_t)(21 + k)*L.n_tg + q];
             }
             double *out = B.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) by pair | QMQ(21) Qc(6) by host-major rank
 #pragma unroll
             for (int k = 0; k < 21; k++) out[(size_t)k*L.n_pair + p] = M[k];
 #pragma unroll
             for (int k = 0; k < 6; k++) out[(size_t)(21 + k)*L.n_pair + p] = c[k];
-            if (L.pair_h[p] >= 0) {
-                const int hp = L.pair_hpos[p];             // rows 63..89 are stored host-major
+            if (ph_ >= 0) {
+                const int hp = hp_;                        // rows 63..89 are stored host-major
                 double R[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) R[k] = B.pairR[(size_t)k*L.n_pair + p];
@@ -992,9 +992,16 @@ __global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
 __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
     LmState *st = W.st;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // static offsets / slot poses of this thread's landmark first: in flight together with the LM state
+    int o = 0, e = 0, act_ = 0, a0[6] = {0, 0, 0, 0, 0, 0};
+    if (b < nb_pt) { const int j = b*256 + tid; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
+#pragma unroll
+        for (int u = 0; u < 6; u++) a0[u] = L.pt_pose6[6*(size_t)j + u]; } }
+    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + tid; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
     if (st->done) return;
     __shared__ double red[256];
-    const int b = blockIdx.x, tid = threadIdx.x, cur = st->cur;
+    const int cur = st->cur;
     const double irad = 1.0/st->radius;
     const bool fail = st->step_fail;
     const LinBuf &B = W.lb[st->lcur];
@@ -1003,13 +1010,12 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
         int j = b*256 + tid;
         if (j < W.n_pt) {
             double rh = W.rho[cur][j], d = 0.0;
-            int o = L.pls_off[j], e = L.pls_off[j+1];
-            if (!fail && e > o && W.act_pt[j]) {
+            if (!fail && e > o && act_) {
                 double acc = B.b_pt[j];
                 for (int s0 = o; s0 < e; s0 += 6) {                                 // 6 slots in flight; dp is 0 for constant / absent poses
                     int a[6]; double w[6][6], dpv[6][6];
 #pragma unroll
-                    for (int u = 0; u < 6; u++) a[u] = L.pslot_pose[min(s0 + u, e - 1)];
+                    for (int u = 0; u < 6; u++) a[u] = s0 == o ? a0[u] : L.pslot_pose[min(s0 + u, e - 1)];
 #pragma unroll
                     for (int u = 0; u < 6; u++)
 #pragma unroll
@@ -1029,8 +1035,7 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
         int j = (b - nb_pt)*256 + tid;
         if (j < W.n_text) {
             double d[3] = {0,0,0};
-            int o = L.tls_off[j], e = L.tls_off[j+1];
-            if (!fail && e > o && W.act_tx[j]) {
+            if (!fail && e > o && act_) {
                 double acc[3] = { B.b_tx[j], B.b_tx[(size_t)W.n_text + j], B.b_tx[(size_t)2*W.n_text + j] };
                 for (int s0 = o; s0 < e; s0 += 3) {                                 // 3 slots in flight
                     int a[3]; double w[3][18], dpv[3][6];
@@ -1327,7 +1332,6 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    std::vector<void *> allocs;                   // everything owned by the uploaded problem
     bool uploaded = false;
     tsba_options opt;
     int n_kf = 0, n_pt = 0, n_text = 0, n_tobs = 0, n_sgood = 0, n_tfgood = 0, n_levels = 0;
@@ -1345,7 +1349,8 @@ struct Ctx {
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
-    char *slab_ptr = nullptr; size_t slab_left = 0;
+    std::vector<struct Slab> slabs; int cur_slab = 0;
+    int run_slab = 0; size_t run_off = 0, run_len = 0;   // pending contiguous host-to-device range
     int cur_bw_rows = 1 << 30;                     // band bound of the level being solved (set by launch_pass_init)
     int rank = 0, world = 1; bool force_multi = false;
     void *rccl_so = nullptr; ncclComm_t comm = nullptr;
@@ -1356,37 +1361,57 @@ struct Ctx {
 
 static void set_err(Ctx *c, const std::string &s) { c->err = s; }
 
-// Device memory comes from a few large slabs (bump allocation, 256-byte aligned): the ~200 work arrays of a problem share
-// 2 MB pages instead of one small hipMalloc each -- far fewer TLB misses for the latency-bound single-workgroup kernels, and a
-// much cheaper upload.
+// Device memory comes from a few large slabs (bump allocation, 256-byte aligned) that persist across uploads: the ~200 arrays
+// of a problem cost no hipMalloc / hipFree / hipMemset each (one memset per slab and upload), and host data is staged through a
+// pinned mirror of the slab so that consecutive uploads leave as ONE host-to-device copy (a plan is ~50 arrays per level).
+struct Slab { char *dev = nullptr, *host = nullptr; size_t size = 0, used = 0; };
+static void flush_run(Ctx *c) {
+    if (c->run_len) { Slab &sl = c->slabs[c->run_slab];
+        hipMemcpyAsync(sl.dev + c->run_off, sl.host + c->run_off, c->run_len, hipMemcpyHostToDevice, c->stream); c->run_len = 0; }
+}
+static int slab_take(Ctx *c, size_t bytes, int *slab, size_t *off) {
+    for (;;) {
+        if (c->cur_slab < (int)c->slabs.size()) { Slab &sl = c->slabs[c->cur_slab];
+            if (sl.size - sl.used >= bytes) { *slab = c->cur_slab; *off = sl.used; sl.used += bytes; return 0; }
+            c->cur_slab++; continue; }
+        Slab sl; sl.size = std::max<size_t>(bytes, (size_t)64 << 20);
+        hipError_t e = hipMalloc((void **)&sl.dev, sl.size);
+        if (e != hipSuccess) { set_err(c, std::string("hipMalloc: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; }
+        hipMemsetAsync(sl.dev, 0, sl.size, c->stream);
+        c->slabs.push_back(sl);
+    }
+}
 template <typename T>
 static int dev_alloc(Ctx *c, T **out, size_t n) {
     const size_t bytes = (std::max<size_t>(n, 1)*sizeof(T) + 255) & ~(size_t)255;
-    if (c->slab_left < bytes) {
-        const size_t sz = std::max<size_t>(bytes, (size_t)64 << 20);
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, sz);
-        if (e != hipSuccess) { set_err(c, std::string("hipMalloc: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; }
-        c->allocs.push_back(p); c->slab_ptr = (char *)p; c->slab_left = sz;
-    }
-    void *p = c->slab_ptr; c->slab_ptr += bytes; c->slab_left -= bytes;
-    hipMemsetAsync(p, 0, bytes, c->stream);
-    *out = (T *)p; return 0;
+    int si; size_t off; int rc = slab_take(c, bytes, &si, &off); if (rc) return rc;
+    *out = (T *)(c->slabs[si].dev + off); return 0;
 }
 template <typename T>
 static int dev_upload(Ctx *c, const T **out, const T *src, size_t n) {
-    T *p = nullptr; int rc = dev_alloc(c, &p, n); if (rc) return rc;
-    if (n && src) { hipError_t e = hipMemcpyAsync(p, src, n*sizeof(T), hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { set_err(c, std::string("hipMemcpy H2D: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; } }
-    *out = p; return 0;
+    const size_t bytes = (std::max<size_t>(n, 1)*sizeof(T) + 255) & ~(size_t)255;
+    int si; size_t off; int rc = slab_take(c, bytes, &si, &off); if (rc) return rc;
+    Slab &sl = c->slabs[si];
+    *out = (const T *)(sl.dev + off);
+    if (!n || !src) return 0;
+    if (!sl.host) { hipError_t e = hipHostMalloc((void **)&sl.host, sl.size, hipHostMallocDefault);
+        if (e != hipSuccess) { set_err(c, std::string("hipHostMalloc: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; } }
+    if (c->run_len && (c->run_slab != si || c->run_off + c->run_len != off)) flush_run(c);
+    if (!c->run_len) { c->run_slab = si; c->run_off = off; }
+    memcpy(sl.host + off, src, n*sizeof(T));
+    if (bytes > n*sizeof(T)) memset(sl.host + off + n*sizeof(T), 0, bytes - n*sizeof(T));
+    c->run_len = off + bytes - c->run_off;
+    return 0;
 }
 template <typename T>
 static int dev_upload_vec(Ctx *c, const T **out, const std::vector<T> &v) { return dev_upload(c, out, v.data(), v.size()); }
 
 static void free_problem(Ctx *c) {
     hipStreamSynchronize(c->stream);
-    for (void *p : c->allocs) hipFree(p);
-    c->allocs.clear(); c->slab_ptr = nullptr; c->slab_left = 0; c->uploaded = false; c->hplan.clear(); c->lev.clear(); c->lev_built.clear();
+    // the slabs stay (tsba_destroy frees them): zero what the last problem used, restart the bump allocation
+    for (Slab &sl : c->slabs) { if (sl.used) hipMemsetAsync(sl.dev, 0, sl.used, c->stream); sl.used = 0; }
+    c->cur_slab = 0; c->run_len = 0;
+    c->uploaded = false; c->hplan.clear(); c->lev.clear(); c->lev_built.clear();
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) c->img_dev[l].clear();
 }
 
@@ -1449,6 +1474,9 @@ int tsba_destroy(void *ctx) {
     Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
     hipSetDevice(c->device);
     free_problem(c);
+    hipStreamSynchronize(c->stream);
+    for (Slab &sl : c->slabs) { hipFree(sl.dev); if (sl.host) hipHostFree(sl.host); }
+    c->slabs.clear();
     if (c->comm && c->p_destroy) c->p_destroy(c->comm);
     hipHostFree(c->st_host); hipFree(c->st_log);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
@@ -1471,7 +1499,10 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
     hipSetDevice(c->device);
     int rc = check_problem(c, p, o); if (rc) return rc;
+    const bool tdbg = getenv("TSBA_DEBUG_TIMING") != nullptr;
+    auto tu0 = std::chrono::steady_clock::now(); double t_plan = 0.0, t_img = 0.0;
     free_problem(c);
+    auto tu1 = std::chrono::steady_clock::now();
     c->opt = *o;
     if (c->world > 1) { c->opt.lm_shard = c->rank; c->opt.lm_nshard = c->world; }
     o = &c->opt;
@@ -1510,7 +1541,9 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1;
     for (int ps = 0; ps < o->n_passes; ps++) {
         int l = o->levels[ps]; if (c->lev_built[l]) continue; c->lev_built[l] = 1;
+        auto tp0 = std::chrono::steady_clock::now();
         HostPlan &H = c->hplan[l]; build_plan(p, o, l, H);
+        t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
         LevelDev &D = c->lev[l]; memset(&D, 0, sizeof(D));
         D.level = l; D.n_sc = H.n_sc(); D.n_pair = H.n_pair(); D.n_tg = H.n_tg(); D.n_pslot = H.n_pslot(); D.n_tslot = H.n_tslot(); D.n_sb = H.n_sb(); D.bw_rows = 6*H.bw_pose;
         double sc = 1.0; for (int k = 0; k < l; k++) sc *= 0.5;
@@ -1519,7 +1552,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         D.img_w = p->img_w[l]; D.img_h = p->img_h[l];
 #define UV(field) do { rc = dev_upload_vec(c, &D.field, H.field); if (rc) return rc; } while (0)
         UV(sc_obs); UV(sc_kf); UV(sc_pt); UV(sc_flag); UV(sc_slot); UV(sc_uv);
-        UV(tg_rec); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
+        UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
         UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
         UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
         UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
@@ -1529,21 +1562,19 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             UP(D.tfeat_off, p->tfeat_off[l], (size_t)p->n_text + 1); UP(D.tfeat_raw, p->tfeat_raw[l], p->n_tfeat[l]);
             UP(D.tfeat_uv, p->tfeat_uv[l], 2*(size_t)p->n_tfeat[l]); UP(D.tfeat_ref, p->tfeat_ref[l], 8*(size_t)p->n_tfeat[l]);
         } else { std::vector<int32_t> z((size_t)p->n_text + 1, 0); UP(D.tfeat_off, z.data(), z.size()); }
+        auto ti0 = std::chrono::steady_clock::now();
         if (o->use_text && p->n_tobs > 0 && p->img[l]) {
             std::vector<const uint8_t *> ptrs(p->n_kf, nullptr);
             size_t npx = (size_t)p->img_w[l]*p->img_h[l];
-            uint8_t *slab = nullptr; AL(slab, npx*p->n_kf);
-            for (int k = 0; k < p->n_kf; k++) {
+            for (int k = 0; k < p->n_kf; k++) {                 // through the pinned staging mirror: one copy for the whole level
                 if (!p->img[l][k]) { set_err(c, "null image pointer"); return TSBA_ERR_ARG; }
-                hipError_t e = hipMemcpyAsync(slab + npx*k, p->img[l][k], npx, hipMemcpyHostToDevice, c->stream);
-                if (e != hipSuccess) { set_err(c, "image H2D failed"); return TSBA_ERR_DEVICE; }
-                ptrs[k] = slab + npx*k;
+                rc = dev_upload(c, &ptrs[k], p->img[l][k], npx); if (rc) return rc;
             }
-            uint8_t **dptr = nullptr; AL(dptr, ptrs.size());
-            CK(hipMemcpyAsync(dptr, ptrs.data(), ptrs.size()*sizeof(uint8_t *), hipMemcpyHostToDevice, c->stream));
-            CK(hipStreamSynchronize(c->stream));     // ptrs is a local
+            const uint8_t *const *dptr = nullptr;
+            rc = dev_upload(c, &dptr, (const uint8_t *const *)ptrs.data(), ptrs.size()); if (rc) return rc;
             D.img = (const uint8_t *const *)dptr;
         }
+        t_img += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
         mx_pair = std::max(mx_pair, (size_t)D.n_pair); mx_tg = std::max(mx_tg, (size_t)D.n_tg);
         mx_pslot = std::max(mx_pslot, (size_t)D.n_pslot); mx_tslot = std::max(mx_tslot, (size_t)D.n_tslot);
     }
@@ -1562,7 +1593,11 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     AL(W.S, (size_t)(W.N + 1)*W.N); AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
     AL(W.st, 1);
+    flush_run(c);
+    auto tu2 = std::chrono::steady_clock::now();
     if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err(c, "upload sync failed"); return TSBA_ERR_DEVICE; }
+    if (tdbg) { auto tu3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[tsba_upload] free %.2f ms, host total %.2f ms (plan construction %.2f ms, image section %.2f ms), final sync %.2f ms\n", ms(tu0, tu1), ms(tu1, tu2), t_plan, t_img, ms(tu2, tu3)); }
     c->uploaded = true;
     return TSBA_OK;
 }
@@ -1805,6 +1840,7 @@ int tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int level
         rc = dev_upload_vec(c, &d_bf, bf); if (rc) return rc;
         rc = dev_alloc(c, &d_r, (size_t)(2*ns + 8*nt)); if (rc) return rc;
         if (jac) { rc = dev_alloc(c, &d_j, (size_t)(26*ns + 120*nt)); if (rc) return rc; }
+        flush_run(c);                                  // staged uploads leave as one copy
         if (H.n_sc() > 0) hipLaunchKernelGGL(k_eval_scene, dim3((H.n_sc() + 255)/256), dim3(256), 0, c->stream, c->W, D, d_oi, d_r, d_j);
         if (nt > 0) hipLaunchKernelGGL(k_eval_text, dim3(((int)nt + 255)/256), dim3(256), 0, c->stream, c->W, D, (int)nt, d_bg, d_bf, (int)ns, d_r, d_j);
         CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
@@ -1873,6 +1909,13 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     return TSBA_OK;
 }
 
+int tsba_debug_plan_time(const tsba_problem *p, const tsba_options *o, int level, int reps, double *avg_ms) {   // host only: plan construction
+    if (!p || !o || reps <= 0) return TSBA_ERR_ARG;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; k++) { HostPlan H; build_plan(p, o, level, H); }
+    *avg_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()/reps;
+    return TSBA_OK;
+}
 int tsba_debug_time_solve(void *ctx, int n, double *avg_ms) {     // n back-to-back launches of the dense solve on the last S, g
     Ctx *c = (Ctx *)ctx; if (!c || n <= 0 || !c->uploaded) return TSBA_ERR_ARG;
     hipSetDevice(c->device);

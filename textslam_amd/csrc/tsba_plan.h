@@ -26,6 +26,8 @@ struct HostPlan {
     std::vector<int32_t> pair_i, pair_h, pair_hpos, pair_sc_off, pair_tg_off, pair_tg;   // pair_hpos: rank of the pair in host-major order (-1: frozen host)
     // text groups
     std::vector<int32_t> tg_tobs, tg_kf, tg_text, tg_pair, tg_slot;
+    std::vector<int32_t> pt_pose6;      // poses of the first 6 slots of every point (clamped): k_back needs them one round trip earlier
+    std::vector<int32_t> tg_ppos;       // rank of the group in pair-major order (pair_tg is the inverse): k_mid sums contiguous ranges
     std::vector<int32_t> tg_rec;        // per group, one 32-byte record: tobs, kf, text, host, slot, f0, f1, fgood offset (all static)
     // landmark slots
     std::vector<int32_t> pls_off, pslot_pose, pslot_pair, pslot_lm;     // points
@@ -44,6 +46,29 @@ struct HostPlan {
     int n_tslot() const { return (int)tslot_pose.size(); }
     int n_sb() const { return (int)sb_a.size(); }
 };
+
+// Dense id of a sparse set of integer keys, ids in key order.  Small key ranges (a 20-keyframe window has 420 possible pairs)
+// use a direct table -- no sort, no binary search: plan construction is on the critical path of every cold tsba_local_ba call.
+struct KeyIndex {
+    int64_t range = 0; std::vector<int32_t> table; std::vector<int64_t> keys;       // table[key] = id (dense mode)
+    bool dense() const { return !table.empty(); }
+    void begin(int64_t key_range) { range = key_range; table.clear(); keys.clear(); if (range <= (int64_t)1 << 22) table.assign((size_t)range, -1); }
+    void add(int64_t k) { if (dense()) table[(size_t)k] = 0; else keys.push_back(k); }
+    int finish() {                                                                   // returns the number of distinct keys
+        if (dense()) { int n = 0; keys.clear(); for (int64_t k = 0; k < range; k++) if (table[(size_t)k] == 0) { table[(size_t)k] = n++; keys.push_back(k); } return n; }
+        std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end()); return (int)keys.size();
+    }
+    int id(int64_t k) const { return dense() ? table[(size_t)k] : (int)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin()); }
+};
+// stable counting sort: order[] = indices 0..n-1 sorted by bucket[], off[] = CSR offsets (n_bucket + 1)
+inline void bucket_order(const std::vector<int> &bucket, int n_bucket, std::vector<int> &order, std::vector<int32_t> &off) {
+    off.assign((size_t)n_bucket + 1, 0);
+    for (int b : bucket) off[(size_t)b + 1]++;
+    for (int q = 0; q < n_bucket; q++) off[q+1] += off[q];
+    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+    order.resize(bucket.size());
+    for (size_t i = 0; i < bucket.size(); i++) order[(size_t)cur[bucket[i]]++] = (int)i;
+}
 
 inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P) {
     P = HostPlan();
@@ -67,23 +92,20 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         gs.push_back({ t, kf, j, host >= 0 ? host : -1 });
     }
     // ---- pairs: key = kf*(n_kf+1) + (host+1)
-    std::vector<int64_t> keys;
-    keys.reserve(cs.size() + gs.size());
     auto key_of = [&](int kf, int host) { return (int64_t)kf*(n_kf + 1) + (host + 1); };
-    for (auto &c : cs) keys.push_back(key_of(c.kf, c.host));
-    for (auto &g : gs) keys.push_back(key_of(g.kf, g.host));
-    std::sort(keys.begin(), keys.end());
-    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-    const int n_pair = (int)keys.size();
-    auto pair_of = [&](int kf, int host) { return (int)(std::lower_bound(keys.begin(), keys.end(), key_of(kf, host)) - keys.begin()); };
+    KeyIndex pk; pk.begin((int64_t)n_kf*(n_kf + 1));
+    for (auto &c : cs) pk.add(key_of(c.kf, c.host));
+    for (auto &g : gs) pk.add(key_of(g.kf, g.host));
+    const int n_pair = pk.finish();
+    const std::vector<int64_t> &keys = pk.keys;
+    auto pair_of = [&](int kf, int host) { return pk.id(key_of(kf, host)); };
     P.pair_i.resize(n_pair); P.pair_h.resize(n_pair);
     for (int q = 0; q < n_pair; q++) { P.pair_i[q] = (int)(keys[q]/(n_kf + 1)); P.pair_h[q] = (int)(keys[q] % (n_kf + 1)) - 1; }
     // ---- sort scene candidates by pair (stable: keeps the reference order inside a pair)
     std::vector<int> cpair(cs.size());
     for (size_t i = 0; i < cs.size(); i++) cpair[i] = pair_of(cs[i].kf, cs[i].host);
-    std::vector<int> order(cs.size());
-    for (size_t i = 0; i < cs.size(); i++) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cpair[a] < cpair[b]; });
+    std::vector<int> order; std::vector<int32_t> sc_off_tmp;
+    bucket_order(cpair, n_pair, order, sc_off_tmp);
     const int n_sc = (int)cs.size();
     P.sc_obs.resize(n_sc); P.sc_kf.resize(n_sc); P.sc_pt.resize(n_sc); P.sc_flag.resize(n_sc); P.sc_slot.assign(n_sc, -1); P.sc_uv.resize(2*(size_t)n_sc);
     P.pair_sc_off.assign(n_pair + 1, 0);
@@ -132,33 +154,34 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         for (int j = 0; j < n_text; j++) if (cnt[j] > 0) { int s = P.tls_off[j+1] - 1; P.tslot_pose[s] = p->text_host[j]; P.tslot_lm[s] = j; }
     }
     // ---- reduced-system blocks: key = a*n_kf + b (a <= b)
+    auto bkey = [&](int a, int b) { return (int64_t)a*n_kf + b; };
+    KeyIndex bk; bk.begin((int64_t)n_kf*n_kf);
     struct Tri { int64_t key; int s1, s2; };
     std::vector<Tri> tp, tt;
-    std::vector<int64_t> bkeys;
-    auto bkey = [&](int a, int b) { return (int64_t)a*n_kf + b; };
+    tp.reserve(8*(size_t)n_sc); tt.reserve(8*(size_t)n_tg);
     for (int j = 0; j < n_pt; j++) for (int s1 = P.pls_off[j]; s1 < P.pls_off[j+1]; s1++) for (int s2 = P.pls_off[j]; s2 < P.pls_off[j+1]; s2++) {
         int a = P.pslot_pose[s1], b = P.pslot_pose[s2]; if (a > b) continue; tp.push_back({ bkey(a, b), s1, s2 }); }
     for (int j = 0; j < n_text; j++) for (int s1 = P.tls_off[j]; s1 < P.tls_off[j+1]; s1++) for (int s2 = P.tls_off[j]; s2 < P.tls_off[j+1]; s2++) {
         int a = P.tslot_pose[s1], b = P.tslot_pose[s2]; if (a > b) continue; tt.push_back({ bkey(a, b), s1, s2 }); }
-    for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bkeys.push_back(bkey(i, i));
-        if (h >= 0) { bkeys.push_back(bkey(h, h)); bkeys.push_back(bkey(std::min(i, h), std::max(i, h))); } }
-    if (n_kf <= 64) for (int a = 0; a < n_kf; a++) for (int b = a; b < n_kf; b++) bkeys.push_back(bkey(a, b));   // small windows: dense S, no memset
-    for (auto &t : tp) bkeys.push_back(t.key);
-    for (auto &t : tt) bkeys.push_back(t.key);
-    std::sort(bkeys.begin(), bkeys.end());
-    bkeys.erase(std::unique(bkeys.begin(), bkeys.end()), bkeys.end());
-    const int n_sb = (int)bkeys.size();
-    auto blk_of = [&](int64_t k) { return (int)(std::lower_bound(bkeys.begin(), bkeys.end(), k) - bkeys.begin()); };
+    for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bk.add(bkey(i, i));
+        if (h >= 0) { bk.add(bkey(h, h)); bk.add(bkey(std::min(i, h), std::max(i, h))); } }
+    if (n_kf <= 64) for (int a = 0; a < n_kf; a++) for (int b = a; b < n_kf; b++) bk.add(bkey(a, b));   // small windows: dense S, no memset
+    for (auto &t : tp) bk.add(t.key);
+    for (auto &t : tt) bk.add(t.key);
+    const int n_sb = bk.finish();
+    const std::vector<int64_t> &bkeys = bk.keys;
+    auto blk_of = [&](int64_t k) { return bk.id(k); };
     P.sb_a.resize(n_sb); P.sb_b.resize(n_sb); P.sb_pab.assign(n_sb, -1); P.sb_pba.assign(n_sb, -1);
     for (int q = 0; q < n_sb; q++) { P.sb_a[q] = (int)(bkeys[q]/n_kf); P.sb_b[q] = (int)(bkeys[q] % n_kf); }
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; if (h < 0) continue;
         int bl = blk_of(bkey(std::min(i, h), std::max(i, h)));
         if (i < h) P.sb_pab[bl] = q; else P.sb_pba[bl] = q; }     // pab: target = a, host = b;  pba: target = b, host = a
     auto fill_tri = [&](std::vector<Tri> &t, std::vector<int32_t> &off, std::vector<int32_t> &s1, std::vector<int32_t> &s2) {
-        std::stable_sort(t.begin(), t.end(), [](const Tri &x, const Tri &y) { return x.key < y.key; });
-        off.assign(n_sb + 1, 0); s1.resize(t.size()); s2.resize(t.size());
-        for (size_t k = 0; k < t.size(); k++) { off[blk_of(t[k].key) + 1]++; s1[k] = t[k].s1; s2[k] = t[k].s2; }
-        for (int q = 0; q < n_sb; q++) off[q+1] += off[q];
+        std::vector<int> bucket(t.size()), ord;                  // stable by block: the landmark-major generation order is kept
+        for (size_t k = 0; k < t.size(); k++) bucket[k] = blk_of(t[k].key);
+        bucket_order(bucket, n_sb, ord, off);
+        s1.resize(t.size()); s2.resize(t.size());
+        for (size_t k = 0; k < t.size(); k++) { s1[k] = t[ord[k]].s1; s2[k] = t[ord[k]].s2; }
     };
     fill_tri(tp, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2);
     fill_tri(tt, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2);
@@ -173,6 +196,11 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         std::vector<int> cur(off.begin(), off.end() - 1);
         for (auto &it : items) val[cur[it.first]++] = it.second;
     };
+    P.pt_pose6.assign(6*(size_t)n_pt, 0);
+    for (int j = 0; j < n_pt; j++) { const int o = P.pls_off[j], e = P.pls_off[j+1];
+        for (int u = 0; u < 6; u++) P.pt_pose6[6*(size_t)j + u] = e > o ? P.pslot_pose[std::min(o + u, e - 1)] : 0; }
+    P.tg_ppos.assign(n_tg, 0);
+    for (size_t k = 0; k < P.pair_tg.size(); k++) P.tg_ppos[P.pair_tg[k]] = (int)k;
     P.tg_rec.resize(8*(size_t)n_tg);
     for (int g = 0; g < n_tg; g++) {
         const int tb = P.tg_tobs[g], j = P.tg_text[g];
