@@ -170,6 +170,12 @@ def main():
                                       % (args.kf, args.pts, world), "lm_iterations": rep["iters"], "scene_blocks": rep["n_sblock"],
                           "reduced_system_dim": 6*args.kf}}
     elif rank == 0:
+        # the same window through the one-shot ABI entry point (what the TextSLAM adapter calls per keyframe)
+        cold = []
+        for _ in range(3):
+            g2 = prob.copy(); tc = time.perf_counter(); gpu.LocalBundleAdjustment(g2, options=opt); cold.append((time.perf_counter() - tc)*1e3)
+        cold_ms = min(cold)
+        gpu.upload(prob, opt)
         # roofline of the linearisation kernel (residual + Jacobian + IRLS weight + J^T J / J^T r sums), level 0
         lin_ms, algo_bytes = gpu.time_linearize(0, 200)
         achieved = algo_bytes / (lin_ms * 1e-3) / 1e9
@@ -193,6 +199,7 @@ def main():
                        "residual_blocks_level0": {"scene": rep["n_sblock"][-1], "text": rep["n_tblock"][-1]},
                        "lm_iterations": rep["iters"], "resid_evals_per_call": rep["n_resid_evals"]},
             "local_ba_wall_ms": ms_per_step,
+            "local_ba_cold_call_ms": cold_ms,          # PCIe-inclusive: plan construction + upload + solve + download (never `value`)
             "roofline": {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms * 1e3},
