@@ -596,12 +596,15 @@ struct OCtx {
     float sf[MAXL], isf[MAXL]; int nfl[MAXL], umax[16], gk[7];
     std::vector<void *> allocs; bool uploaded = false;
     OrbDev D;
+    // the SLAM front-end calls once per frame with the same geometry: buffers and pinned staging are kept between calls
+    int key[5] = {0, 0, 0, 0, 0}; uint8_t *h_img = nullptr; void *h_out = nullptr; size_t h_img_sz = 0, h_out_sz = 0;
 };
 static int cv_round_f(float v) { return (int)lrintf(v); }
 #define OCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(e_); return TSORB_ERR_DEVICE; } } while (0)
 template <typename T> static int oalloc(OCtx *c, T **p, size_t n) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(n, 1)*sizeof(T)) != hipSuccess) { c->err = "hipMalloc failed"; return TSORB_ERR_DEVICE; }
     c->allocs.push_back(q); *p = (T *)q; return 0; }
-static void ofree(OCtx *c) { hipStreamSynchronize(c->stream); for (void *p : c->allocs) hipFree(p); c->allocs.clear(); c->uploaded = false; }
+static void ofree(OCtx *c) { hipStreamSynchronize(c->stream); for (void *p : c->allocs) hipFree(p); c->allocs.clear(); c->uploaded = false; c->key[0] = 0;
+    if (c->h_img) hipHostFree(c->h_img); if (c->h_out) hipHostFree(c->h_out); c->h_img = nullptr; c->h_out = nullptr; c->h_img_sz = c->h_out_sz = 0; }
 
 extern "C" {
 
@@ -640,7 +643,14 @@ int tsorb_get_features_per_level(void *ctx, int32_t *n) { OCtx *c = (OCtx *)ctx;
 
 int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride, int cap) {
     OCtx *c = (OCtx *)ctx; if (!c || !imgs || n < 1 || w < 64 || h < 64 || stride < w || cap < 1) return TSORB_ERR_ARG;
-    hipSetDevice(c->device); ofree(c);
+    hipSetDevice(c->device);
+    if (c->uploaded && c->key[0] == n && c->key[1] == w && c->key[2] == h && c->key[3] == stride && c->key[4] == cap) {
+        // same geometry as the previous call: only the pixels travel (pinned staging, one asynchronous copy)
+        memcpy(c->h_img, imgs, (size_t)n*h*stride);
+        OCK(hipMemcpyAsync((void *)c->D.img, c->h_img, (size_t)n*h*stride, hipMemcpyHostToDevice, c->stream));
+        return TSORB_OK;
+    }
+    ofree(c);
     OrbDev &D = c->D; memset(&D, 0, sizeof(D));
     D.n = n; D.nlevels = c->nlevels; D.ini_th = c->ini_th; D.min_th = c->min_th; D.w = w; D.h = h; D.stride = stride; D.cap = cap;
     memcpy(D.umax, c->umax, sizeof(D.umax)); memcpy(D.gk, c->gk, sizeof(D.gk));
@@ -663,15 +673,22 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     D.cand_cap = ((D.L[0].maxBX - D.L[0].minB)*(D.L[0].maxBY - D.L[0].minB))/4 + 64; D.node_cap = 64*(c->nfl[0] + 64); D.pool_cap = 16*D.cand_cap;
     int rc;
     uint8_t *img; if ((rc = oalloc(c, &img, (size_t)n*h*stride))) return rc; D.img = img;
-    OCK(hipMemcpyAsync(img, imgs, (size_t)n*h*stride, hipMemcpyHostToDevice, c->stream));
+    c->h_img_sz = (size_t)n*h*stride; OCK(hipHostMalloc((void **)&c->h_img, c->h_img_sz, hipHostMallocDefault));
+    memcpy(c->h_img, imgs, c->h_img_sz);
+    OCK(hipMemcpyAsync(img, c->h_img, c->h_img_sz, hipMemcpyHostToDevice, c->stream));
     if ((rc = oalloc(c, &D.pyr, (size_t)n*po)) || (rc = oalloc(c, &D.blur, (size_t)n*bo))) return rc;
     if ((rc = oalloc(c, &D.cellkp, (size_t)n*cell0*CELL_CAP)) || (rc = oalloc(c, &D.cellcnt, (size_t)n*cell0))) return rc;
     if ((rc = oalloc(c, &D.cand, (size_t)n*c->nlevels*D.cand_cap*3))) return rc;
     if ((rc = oalloc(c, &D.nodes, (size_t)n*c->nlevels*D.node_cap*(sizeof(QNode)/sizeof(int)))) || (rc = oalloc(c, &D.pool, (size_t)n*c->nlevels*D.pool_cap)) ||
         (rc = oalloc(c, &D.snbuf, (size_t)n*c->nlevels*4*D.node_cap))) return rc;
     if ((rc = oalloc(c, &D.sel, (size_t)n*kp0*4)) || (rc = oalloc(c, &D.selcnt, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.qfallback, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.seldesc, (size_t)n*kp0*32))) return rc;
-    if ((rc = oalloc(c, &D.out_kp, (size_t)n*cap*6)) || (rc = oalloc(c, &D.out_desc, (size_t)n*cap*32)) || (rc = oalloc(c, &D.out_cnt, (size_t)n))) return rc;
-    OCK(hipStreamSynchronize(c->stream));
+    {   // the three outputs in one allocation (kp | count | desc): one device-to-host copy per call
+        const size_t bkp = sizeof(float)*(size_t)n*cap*6, bcnt = ((sizeof(int)*(size_t)n + 15)/16)*16, bdesc = (size_t)n*cap*32;
+        uint8_t *ob; if ((rc = oalloc(c, &ob, bkp + bcnt + bdesc))) return rc;
+        D.out_kp = (float *)ob; D.out_cnt = (int *)(ob + bkp); D.out_desc = ob + bkp + bcnt;
+        c->h_out_sz = bkp + bcnt + bdesc; OCK(hipHostMalloc(&c->h_out, c->h_out_sz, hipHostMallocDefault));
+    }
+    c->key[0] = n; c->key[1] = w; c->key[2] = h; c->key[3] = stride; c->key[4] = cap;
     c->uploaded = true; return TSORB_OK;
 }
 int tsorb_run(void *ctx) {
@@ -693,9 +710,14 @@ int tsorb_run(void *ctx) {
 int tsorb_download(void *ctx, float *kp, uint8_t *desc, int32_t *count) {
     OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG;
     hipSetDevice(c->device); OrbDev &D = c->D;
-    if (kp) OCK(hipMemcpy(kp, D.out_kp, sizeof(float)*(size_t)D.n*D.cap*6, hipMemcpyDeviceToHost));
-    if (desc) OCK(hipMemcpy(desc, D.out_desc, (size_t)D.n*D.cap*32, hipMemcpyDeviceToHost));
-    if (count) OCK(hipMemcpy(count, D.out_cnt, sizeof(int)*(size_t)D.n, hipMemcpyDeviceToHost));
+    const size_t bkp = sizeof(float)*(size_t)D.n*D.cap*6, bcnt = ((sizeof(int)*(size_t)D.n + 15)/16)*16, bdesc = (size_t)D.n*D.cap*32;
+    const size_t bytes = desc ? bkp + bcnt + bdesc : bkp + bcnt;
+    OCK(hipMemcpyAsync(c->h_out, D.out_kp, bytes, hipMemcpyDeviceToHost, c->stream));
+    OCK(hipStreamSynchronize(c->stream));
+    const uint8_t *hb = (const uint8_t *)c->h_out;
+    if (kp) memcpy(kp, hb, bkp);
+    if (count) memcpy(count, hb + bkp, sizeof(int)*(size_t)D.n);
+    if (desc) memcpy(desc, hb + bkp + bcnt, bdesc);
     return TSORB_OK;
 }
 int tsorb_extract_batch(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride, float *kp, uint8_t *desc, int32_t *count, int cap) {
