@@ -11,3 +11,7 @@ for k in range(4):
 for k in range(3):
     t = time.time(); opt.upload(P, o); dt = (time.time() - t)*1e3
     print("upload only %d: %.2f ms" % (k, dt))
+P3 = synth.config_c3(); o3 = abi.options_pose()
+for k in range(4):
+    G = P3.copy(); t = time.time(); rep = opt.PoseOptim(G, options=o3); dt = (time.time() - t)*1e3
+    print("pose-only C3 call %d: wall %.2f ms  t_upload_ms %.2f  t_solve_ms %.2f  iters %s" % (k, dt, rep['t_upload_ms'], rep['t_solve_ms'], rep['iters']))

@@ -80,7 +80,9 @@ struct Work {                // device work buffers (sized for the largest level
     int *fidx, *nfree;                  // compressed index of the free poses in S / g
     double *cb, *cbm;                   // multi-GPU exchange buffers: cb = [Hd 6n | bp 6n | cost, |x_lm|^2, step^2, mcc] (sum), cbm = gradient max (max)
     long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
-    double *LDbuf;                      // factored diagonal blocks when k_solve cannot use LDS
+    double *LDbuf;                      // diagonal of the inverse diagonal factors (large-system Cholesky)
+    unsigned long long *hprog;          // pinned host word (seq << 32 | it << 1 | done): lets the host stop enqueuing a converged pass
+    unsigned int pass_seq;
     // linearisation outputs, double-buffered: lb[lcur] belongs to x, lb[lcur^1] to the LM candidate (speculative)
     LinBuf lb[2];
     double *sig_pt, *sig_tx, *sig_p;    // Jacobi column scales, fixed at the first linearisation of a pass
@@ -168,6 +170,7 @@ __global__ void k_pass_reset(Work W, double radius0, int max_it) {
         memset(s, 0, sizeof(LmState));
         s->cur = cur; s->n_lin = nl; s->n_cost = nc;
         s->radius = radius0; s->decrease_factor = 2.0; s->need_lin = 1; s->first = 1; s->max_it = max_it;
+        if (W.hprog) { *W.hprog = (unsigned long long)W.pass_seq << 32; __threadfence_system(); }
     }
     int t = blockIdx.x*blockDim.x + threadIdx.x, n = gridDim.x*blockDim.x;
     for (int k = t; k < W.n_kf; k += n) { W.kf_in[k] = 0; W.kf_const[k] = 0; }
@@ -821,6 +824,7 @@ __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad
         if (st->first) st->cost0 = cost;
         st->first = 0; st->need_lin = 0; st->n_lin++;
         if (gmax <= grad_tol) { st->done = 1; st->term = 3; }
+        if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)st->it << 1) | (st->done ? 1u : 0u); __threadfence_system(); }
     }
 }
 
@@ -1116,6 +1120,7 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
         cost = sc[0]; xn_c = sc[1] + xp; step2 = sc[2]; mcc = sc[3]; gmax_c = fmax(W.cbm[0], gp);
     }
     if (tid) return;
+    [&]() {
     mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
     st->it++;
     st->cand_cost = cost; st->model_change = mcc; st->step_norm = sqrt(step2);
@@ -1143,6 +1148,8 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
     }
     if (st->it >= st->max_it) { st->done = 1; st->term = 0; }
     else if (st->radius < o.min_radius) { st->done = 1; st->term = 4; }
+    }();
+    if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)st->it << 1) | (st->done ? 1u : 0u); __threadfence_system(); }
 #ifdef TSBA_SOLVE_STAMPS
     W.dbg[32] = s1_ - s0_; W.dbg[33] = s2_ - s1_; W.dbg[34] = s3_ - s2_; W.dbg[35] = clock64() - s3_;
 #endif
@@ -1349,6 +1356,7 @@ struct Ctx {
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
+    unsigned long long *hprog = nullptr; unsigned int pass_seq = 0;   // pinned progress word written by k_postlin / k_decide
     std::vector<struct Slab> slabs; int cur_slab = 0;
     int run_slab = 0; size_t run_off = 0, run_len = 0;   // pending contiguous host-to-device range
     int cur_bw_rows = 1 << 30;                     // band bound of the level being solved (set by launch_pass_init)
@@ -1465,6 +1473,7 @@ int tsba_create(void **ctx, int device) {
     hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
     hipHostMalloc((void **)&c->st_host, sizeof(LmState)*TSBA_MAX_LEVELS, 0);
     hipMalloc((void **)&c->st_log, sizeof(LmState)*TSBA_MAX_LEVELS);
+    if (hipHostMalloc((void **)&c->hprog, 64, hipHostMallocDefault) != hipSuccess) c->hprog = nullptr; else *c->hprog = 0;
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, device);
     c->lds_limit = prop.sharedMemPerBlock;       // 64 KiB default static limit; dynamic up to 160 KiB on gfx950
     if (c->lds_limit < 160*1024) c->lds_limit = 160*1024;
@@ -1478,7 +1487,7 @@ int tsba_destroy(void *ctx) {
     for (Slab &sl : c->slabs) { hipFree(sl.dev); if (sl.host) hipHostFree(sl.host); }
     c->slabs.clear();
     if (c->comm && c->p_destroy) c->p_destroy(c->comm);
-    hipHostFree(c->st_host); hipFree(c->st_log);
+    hipHostFree(c->st_host); hipFree(c->st_log); if (c->hprog) hipHostFree(c->hprog);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
     delete c; return TSBA_OK;
 }
@@ -1625,6 +1634,7 @@ static void allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRe
 }
 static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     c->cur_bw_rows = D.bw_rows;
+    c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
     Work &W = c->W; const tsba_options &o = c->opt;
     hipLaunchKernelGGL(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
     int n = D.n_sc + D.n_tg;
@@ -1718,7 +1728,22 @@ int tsba_solve(void *ctx, tsba_report *r) {
         const LevelDev &D = c->lev[o.levels[ps]];
         launch_pass_init(c, D, ps);
         launch_linearize(c, D, 0);
-        for (int it = 0; it < o.its[ps]; it++) launch_step(c, D);
+        // The kernels of an LM iteration return at once when the pass has converged, but each still costs a launch (~4 us):
+        // the host reads the pinned progress word and stays at most two iterations ahead of the device -- no API call, no
+        // synchronisation -- so a pass that converges early wastes two iterations of empty launches instead of all the rest.
+        for (int it = 0; it < o.its[ps]; it++) {
+            if (c->hprog && !is_multi(c)) {
+                bool stop = false; const auto tw = std::chrono::steady_clock::now();
+                for (int spin = 0;; spin++) {
+                    const unsigned long long w = *(volatile unsigned long long *)c->hprog;
+                    if ((unsigned int)(w >> 32) == c->W.pass_seq) { if (w & 1) { stop = true; break; } if ((int)((w & 0xffffffffu) >> 1) + 2 > it) break; }
+                    else if (it < 2) break;                              // the device has not reached this pass yet
+                    if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(2)) break;   // never hang on it
+                }
+                if (stop) break;
+            }
+            launch_step(c, D);
+        }
         if (o.outlier_scene || o.outlier_text)
             if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, c->W, D,
                                                           o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
