@@ -172,6 +172,14 @@ int  tsba_global_ba (void *ctx, tsba_problem *p, const tsba_options *o, tsba_rep
  * Returns TSBA_ERR_NUMERIC when the information matrix is singular (the reference returns false). */
 int  tsba_theta_optim(void *ctx, tsba_problem *p, const tsba_options *o, int text, double cov[9], tsba_report *r);
 
+/* Text label image of keyframe `kf` at pyramid level `level` for the state left by the last solve on this context (one-shot
+ * entry points leave it too).  Replaces the label part of optimizer::ShowBAReproj_TextBox (src/optimizer.cc:2508-2582 ->
+ * tool::TextBoxWithFill / GetTextLabelMask, src/tool.cc:2103-2166): background -1, then every text observation of the keyframe,
+ * in the order of tobs_*, fills its projected quad (cv::Point truncation, cv::fillPoly scan conversion) with its rank among the
+ * keyframe's observations; later quads overwrite earlier ones.  out: img_h[level] * img_w[level] floats (the CV_32F Mat that
+ * optimizer::UpdateTrackedTextBA, optimizer.cc:2246-2386, reads).  The drawing of box outlines / ids stays in the host. */
+int  tsba_text_label_image(void *ctx, int kf, int level, float *out);
+
 /* ---- staged calls (bench / repeated solves with the problem resident in HBM) ---- */
 int  tsba_upload  (void *ctx, const tsba_problem *p, const tsba_options *o);
 int  tsba_solve   (void *ctx, tsba_report *r);        /* restarts from the uploaded parameters every call */

@@ -146,6 +146,17 @@ def theta_optim(prob: BAProblem, opt: TsbaOptions, text: int):
     return rc, rep.as_dict(), cov.reshape(3, 3)
 
 
+def label_image(prob: BAProblem, kf: int, level: int):
+    """Text label image of keyframe kf (float32 h x w, -1 = background) from the parameters in prob."""
+    s = prob.struct()
+    w, h = int(s.img_w[level]), int(s.img_h[level])
+    out = np.zeros((h, w), np.float32)
+    rc = lib().tsba_oracle_label_image(C.byref(s), kf, level, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc:
+        raise RuntimeError("tsba_oracle_label_image rc=%d" % rc)
+    return out
+
+
 def theta_cov(prob: BAProblem, opt: TsbaOptions, level: int, text: int):
     cov = np.zeros(9)
     s = prob.struct()

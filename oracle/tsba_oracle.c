@@ -346,6 +346,46 @@ static void pair_musigma(const pass_t *P, int t, const double *pose, const doubl
     tsba_oracle_musigma(p->img[P->level][kf], p->img_w[P->level], p->img_h[P->level], corners, mu, sigma);
 }
 
+/* Text label image of keyframe kf at pyramid level `level` from the parameters in p (optimizer::ShowBAReproj_TextBox,
+   src/optimizer.cc:2508-2582 -> tool::TextBoxWithFill / GetTextLabelMask, src/tool.cc:2103-2166): background -1, then every
+   text observation of the keyframe, in observation order, fills its projected quad (corners truncated by cv::Point, cv::fillPoly)
+   with its rank among the keyframe's observations; later quads overwrite earlier ones. */
+int tsba_oracle_label_image(const tsba_problem *p, int kf, int level, float *out) {
+    if (!p || !out || kf < 0 || kf >= p->n_kf || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
+    pass_t P; memset(&P, 0, sizeof(P)); P.p = p; P.level = level; level_K(p, level, P.Kl);
+    const int w = p->img_w[level], h = p->img_h[level];
+    for (size_t k = 0; k < (size_t)w*h; k++) out[k] = -1.0f;
+    uint8_t *mask = (uint8_t *)malloc((size_t)w*h);
+    int rank = 0;
+    for (int t = 0; t < p->n_tobs; t++) {
+        if (p->tobs_kf[t] != kf) continue;
+        const int j = p->tobs_text[t], host = p->text_host[j];
+        double Rc[9], tc[3], Rcr[9], tcr[3], tmp[3], corners[8]; int xy[8];
+        pose_Rt(p->pose + 7*kf, Rc, tc);
+        if (host >= 0) { double Rr[9], tr[3]; pose_Rt(p->pose + 7*host, Rr, tr);
+            mat3_mulT(Rc, Rr, Rcr); mat3_vec(Rcr, tr, tmp);
+            tcr[0] = tc[0] - tmp[0]; tcr[1] = tc[1] - tmp[1]; tcr[2] = tc[2] - tmp[2];
+        } else { const double *T = p->text_host_Twr + 12*j; double Rwr[9], twr[3];
+            for (int i = 0; i < 3; i++) { Rwr[i*3] = T[i*4]; Rwr[i*3+1] = T[i*4+1]; Rwr[i*3+2] = T[i*4+2]; twr[i] = T[i*4+3]; }
+            mat3_mul(Rc, Rwr, Rcr); mat3_vec(Rc, twr, tmp);
+            tcr[0] = tmp[0] + tc[0]; tcr[1] = tmp[1] + tc[1]; tcr[2] = tmp[2] + tc[2]; }
+        const double *th = p->theta + 3*j;
+        for (int b = 0; b < 4; b++) {
+            double ray[3] = { p->text_box_ray[(j*4 + b)*2], p->text_box_ray[(j*4 + b)*2 + 1], 1.0 };
+            double invz = -(ray[0]*th[0] + ray[1]*th[1] + ray[2]*th[2]);
+            double Rr[3]; mat3_vec(Rcr, ray, Rr);
+            double X = Rr[0]/invz + tcr[0], Y = Rr[1]/invz + tcr[1], Z = Rr[2]/invz + tcr[2];
+            corners[2*b] = P.Kl[0]*X/Z + P.Kl[2]; corners[2*b+1] = P.Kl[1]*Y/Z + P.Kl[3];
+            xy[2*b] = (int)corners[2*b]; xy[2*b+1] = (int)corners[2*b+1];            /* cv::Point(double, double): truncation */
+        }
+        tsba_oracle_fillpoly4(w, h, xy, mask);
+        for (size_t k = 0; k < (size_t)w*h; k++) if (mask[k]) out[k] = (float)rank;
+        rank++;
+    }
+    free(mask);
+    return TSBA_OK;
+}
+
 static int pass_build(pass_t *P, const tsba_problem *p, const tsba_options *o, int level) {
     memset(P, 0, sizeof(*P));
     P->p = p; P->o = o; P->level = level;

@@ -50,6 +50,9 @@ int tsba_oracle_partial_system(const tsba_problem *p, const tsba_options *o, int
                                int32_t *free_idx, double *S, double *g, double *Hd, double *cost);
 
 /* Covariance of theta[text] (all other parameters constant) at the current parameters, ceres::Covariance semantics. */
+/* text label image of a keyframe (optimizer::ShowBAReproj_TextBox -> tool::TextBoxWithFill); out: h*w floats */
+int tsba_oracle_label_image(const tsba_problem *p, int kf, int level, float *out);
+
 int tsba_oracle_theta_cov(const tsba_problem *p, const tsba_options *o, int level, int text, double cov[9]);
 
 int tsba_oracle_theta_optim(tsba_problem *p, const tsba_options *o, tsba_report *r, int text, double cov[9]);

@@ -252,3 +252,22 @@ def test_theta_optim_parity_and_covariance(gpu, oracle_lib):
     np.testing.assert_allclose(G.theta, R.theta, rtol=0, atol=1e-8)
     np.testing.assert_allclose(cov_g, cov_o, rtol=1e-7)
     assert np.all(np.linalg.eigvalsh(cov_g) > 0)
+
+
+@pytest.mark.gpu
+def test_text_label_image_parity(gpu, oracle_lib):
+    """tsba_text_label_image after a local BA vs the oracle's fillPoly restatement on the optimised parameters: identical images."""
+    P = synth.tiny(seed=31, n_kf=5, n_pt=80, n_text=6, text_targets=4)
+    o = abi.options_local()
+    G = P.copy()
+    gpu.LocalBundleAdjustment(G, options=o)                   # G now holds the optimised poses / planes, the context the same state
+    s = G.struct()
+    for lvl in (0, 2):
+        shape = (int(s.img_h[lvl]), int(s.img_w[lvl]))
+        for kf in (0, P.n_kf - 1):
+            lab = gpu.TextLabelImage(kf, lvl, shape)
+            ref = oracle_lib.label_image(G, kf, lvl)
+            assert lab.shape == ref.shape
+            nbad = int(np.count_nonzero(lab != ref))
+            assert nbad == 0, "level %d kf %d: %d of %d pixels differ" % (lvl, kf, nbad, lab.size)
+            assert (lab >= 0).any()

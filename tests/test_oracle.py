@@ -290,3 +290,60 @@ def test_init_ba_style_problem(oracle_lib):
     err0 = np.abs(P.pose.reshape(-1, 7)[1, 4:] - P.truth["pose"][1, 4:]).max()
     err1 = np.abs(Q.pose.reshape(-1, 7)[1, 4:] - P.truth["pose"][1, 4:]).max()
     assert rep["cost1"][-1] < rep["cost0"][0] and err1 < err0
+
+
+def test_label_image_against_point_in_polygon(oracle_lib):
+    oracle = oracle_lib
+    """oracle.label_image (ShowBAReproj_TextBox -> TextBoxWithFill): background -1, labels = rank of the text observation in
+    the keyframe, later quads on top; checked against an independent even-odd point-in-polygon test away from the edges."""
+    P = synth.tiny(seed=23, n_kf=4, n_pt=30, n_text=5, text_targets=3)
+    lvl = 0
+    s = P.struct()
+    w, h = int(s.img_w[lvl]), int(s.img_h[lvl])
+    K = np.array([s.K[0], s.K[1], s.K[2], s.K[3]])
+    for kf in range(P.n_kf):
+        lab = oracle.label_image(P, kf, lvl)
+        assert lab.shape == (h, w) and lab.dtype == np.float32
+        obs = [t for t in range(P.n_tobs) if P.tobs_kf[t] == kf]
+        assert set(np.unique(lab)).issubset({-1.0} | {float(r) for r in range(len(obs))})
+        # corners of every observed plane with plain numpy
+        quads = []
+        for t in obs:
+            j = int(P.tobs_text[t]); host = int(P.text_host[j])
+            def Rt(p):
+                q = p[:4]/np.linalg.norm(p[:4]); w_, x, y, z = q
+                R = np.array([[1-2*(y*y+z*z), 2*(x*y-w_*z), 2*(x*z+w_*y)], [2*(x*y+w_*z), 1-2*(x*x+z*z), 2*(y*z-w_*x)], [2*(x*z-w_*y), 2*(y*z+w_*x), 1-2*(x*x+y*y)]])
+                return R, p[4:7]
+            Rc, tc = Rt(P.pose[kf])
+            if host >= 0:
+                Rr, tr = Rt(P.pose[host]); Rcr = Rc @ Rr.T; tcr = tc - Rcr @ tr
+            else:
+                T = P.text_host_Twr[j].reshape(3, 4); Rcr = Rc @ T[:, :3]; tcr = Rc @ T[:, 3] + tc
+            th = P.theta[j]; c = []
+            for b in range(4):
+                m = np.array([P.text_box_ray[j, b, 0], P.text_box_ray[j, b, 1], 1.0])
+                X = Rcr @ m/(-(m @ th)) + tcr
+                c.append((K[0]*X[0]/X[2] + K[2], K[1]*X[1]/X[2] + K[3]))
+            quads.append(np.trunc(np.array(c)))
+        # sample pixels: inside quad r (even-odd) and at least 1.5 px from all its edges => label >= r; far outside all => -1
+        rng = np.random.default_rng(kf)
+        for _ in range(400):
+            x, y = int(rng.integers(0, w)), int(rng.integers(0, h))
+            def inside_margin(q):
+                inside = False; dmin = 1e9
+                for i in range(4):
+                    x0, y0 = q[i - 1]; x1, y1 = q[i]
+                    if (y0 > y) != (y1 > y) and x < (x1 - x0)*(y - y0)/(y1 - y0 + 1e-30) + x0:
+                        inside = not inside
+                    d = np.array([x1 - x0, y1 - y0]); L2 = d @ d
+                    tt = 0.0 if L2 == 0 else np.clip(((x - x0)*d[0] + (y - y0)*d[1])/L2, 0, 1)
+                    dmin = min(dmin, np.hypot(x - (x0 + tt*d[0]), y - (y0 + tt*d[1])))
+                return inside, dmin
+            top = -1
+            ambiguous = False
+            for r, q in enumerate(quads):
+                ins, dm = inside_margin(q)
+                if dm < 1.5: ambiguous = True
+                elif ins: top = r
+            if not ambiguous:
+                assert lab[y, x] == float(top), (kf, x, y, lab[y, x], top)

@@ -241,8 +241,63 @@ __device__ int clip_line_dev(long long Wd, long long Hd, long long &x1, long lon
     }
     return (c1 | c2) == 0;
 }
-#define MS_THREADS 256
 #define MS_MASK_WORDS 9600        /* 640*480/32 bits */
+// cv::fillPoly of one quad (integer corners s_xy, image w x hh) into an LDS bit mask: boundary lines with cv::LineIterator
+// (8-connected) by 4 threads, interior by FillEdgeCollection scanlines (16.16 fixed point), one thread per row.  The caller
+// clears the mask and synchronises before and after.
+__device__ void raster_quad(unsigned *mask, const int *s_xy, int w, int hh, int tid, int nthreads) {
+    // boundary lines (cv::LineIterator, 8-connected, left to right)
+    if (tid < 4) {
+        int i0 = (tid + 3) & 3, i1 = tid;
+        long long x1 = s_xy[2*i0], y1 = s_xy[2*i0+1], x2 = s_xy[2*i1], y2 = s_xy[2*i1+1];
+        bool ok = true;
+        if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+            (unsigned long long)y1 >= (unsigned long long)hh || (unsigned long long)y2 >= (unsigned long long)hh)
+            ok = clip_line_dev(w, hh, x1, y1, x2, y2);
+        if (ok) {
+            long long dx = x2 - x1, dy = y2 - y1;
+            if (dx < 0) { dx = -dx; dy = -dy; x1 = x2; y1 = y2; }
+            long long sy = dy < 0 ? -1 : 1; if (dy < 0) dy = -dy;
+            bool steep = dy > dx;
+            long long major = steep ? dy : dx, minor = steep ? dx : dy;
+            long long err = major - (minor + minor), plusDelta = major + major, minusDelta = -(minor + minor);
+            long long x = x1, y = y1;
+            for (long long i = 0; i <= major; i++) {
+                if (x >= 0 && x < w && y >= 0 && y < hh) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31));
+                bool neg = err < 0;
+                err += minusDelta + (neg ? plusDelta : 0);
+                if (steep) { y += sy; if (neg) x += 1; } else { x += 1; if (neg) y += sy; }
+            }
+        }
+    }
+    // scanline interior (FillEdgeCollection): one thread per row
+    {
+        long long ex[4], edx[4]; int ey0[4], ey1[4], ne = 0;
+        int y_min = 2147483647, y_max = -2147483647;
+        for (int i = 0; i < 4; i++) {
+            int i0 = (i + 3) & 3;
+            long long p0x = (long long)s_xy[2*i0] << 16, p0y = s_xy[2*i0+1], p1x = (long long)s_xy[2*i] << 16, p1y = s_xy[2*i+1];
+            if (p0y == p1y) continue;
+            if (p0y < p1y) { ey0[ne] = (int)p0y; ey1[ne] = (int)p1y; ex[ne] = p0x; } else { ey0[ne] = (int)p1y; ey1[ne] = (int)p0y; ex[ne] = p1x; }
+            edx[ne] = (p1x - p0x)/(p1y - p0y);
+            y_min = min(y_min, ey0[ne]); y_max = max(y_max, ey1[ne]); ne++;
+        }
+        if (ne >= 2 && !(y_max < 0 || y_min >= hh)) {
+            if (y_max > hh) y_max = hh;
+            for (int y = max(y_min, 0) + tid; y < y_max; y += nthreads) {
+                long long xs[4]; int na = 0;
+                for (int i = 0; i < ne; i++) if (ey0[i] <= y && y < ey1[i]) xs[na++] = ex[i] + (long long)(y - ey0[i])*edx[i];
+                for (int i = 1; i < na; i++) { long long v = xs[i]; int k = i - 1; while (k >= 0 && xs[k] > v) { xs[k+1] = xs[k]; k--; } xs[k+1] = v; }
+                for (int i = 0; i + 1 < na; i += 2) {
+                    int xa = (int)((xs[i] + 65535) >> 16), xb = (int)(xs[i+1] >> 16);
+                    if (xa < w && xb >= 0) { if (xa < 0) xa = 0; if (xb >= w) xb = w - 1;
+                        for (int x = xa; x <= xb; x++) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31)); }
+                }
+            }
+        }
+    }
+}
+#define MS_THREADS 256
 __global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
     __shared__ unsigned mask[MS_MASK_WORDS];
     __shared__ unsigned hist[256];
@@ -286,56 +341,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
     hist[tid] = 0;
     __syncthreads();
     const int xMin = s_bb[0], xMax = s_bb[1], yMin = s_bb[2], yMax = s_bb[3];
-    // boundary lines (cv::LineIterator, 8-connected, left to right)
-    if (tid < 4) {
-        int i0 = (tid + 3) & 3, i1 = tid;
-        long long x1 = s_xy[2*i0], y1 = s_xy[2*i0+1], x2 = s_xy[2*i1], y2 = s_xy[2*i1+1];
-        bool ok = true;
-        if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
-            (unsigned long long)y1 >= (unsigned long long)hh || (unsigned long long)y2 >= (unsigned long long)hh)
-            ok = clip_line_dev(w, hh, x1, y1, x2, y2);
-        if (ok) {
-            long long dx = x2 - x1, dy = y2 - y1;
-            if (dx < 0) { dx = -dx; dy = -dy; x1 = x2; y1 = y2; }
-            long long sy = dy < 0 ? -1 : 1; if (dy < 0) dy = -dy;
-            bool steep = dy > dx;
-            long long major = steep ? dy : dx, minor = steep ? dx : dy;
-            long long err = major - (minor + minor), plusDelta = major + major, minusDelta = -(minor + minor);
-            long long x = x1, y = y1;
-            for (long long i = 0; i <= major; i++) {
-                if (x >= 0 && x < w && y >= 0 && y < hh) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31));
-                bool neg = err < 0;
-                err += minusDelta + (neg ? plusDelta : 0);
-                if (steep) { y += sy; if (neg) x += 1; } else { x += 1; if (neg) y += sy; }
-            }
-        }
-    }
-    // scanline interior (FillEdgeCollection): one thread per row
-    {
-        long long ex[4], edx[4]; int ey0[4], ey1[4], ne = 0;
-        int y_min = 2147483647, y_max = -2147483647;
-        for (int i = 0; i < 4; i++) {
-            int i0 = (i + 3) & 3;
-            long long p0x = (long long)s_xy[2*i0] << 16, p0y = s_xy[2*i0+1], p1x = (long long)s_xy[2*i] << 16, p1y = s_xy[2*i+1];
-            if (p0y == p1y) continue;
-            if (p0y < p1y) { ey0[ne] = (int)p0y; ey1[ne] = (int)p1y; ex[ne] = p0x; } else { ey0[ne] = (int)p1y; ey1[ne] = (int)p0y; ex[ne] = p1x; }
-            edx[ne] = (p1x - p0x)/(p1y - p0y);
-            y_min = min(y_min, ey0[ne]); y_max = max(y_max, ey1[ne]); ne++;
-        }
-        if (ne >= 2 && !(y_max < 0 || y_min >= hh)) {
-            if (y_max > hh) y_max = hh;
-            for (int y = max(y_min, 0) + tid; y < y_max; y += MS_THREADS) {
-                long long xs[4]; int na = 0;
-                for (int i = 0; i < ne; i++) if (ey0[i] <= y && y < ey1[i]) xs[na++] = ex[i] + (long long)(y - ey0[i])*edx[i];
-                for (int i = 1; i < na; i++) { long long v = xs[i]; int k = i - 1; while (k >= 0 && xs[k] > v) { xs[k+1] = xs[k]; k--; } xs[k+1] = v; }
-                for (int i = 0; i + 1 < na; i += 2) {
-                    int xa = (int)((xs[i] + 65535) >> 16), xb = (int)(xs[i+1] >> 16);
-                    if (xa < w && xb >= 0) { if (xa < 0) xa = 0; if (xb >= w) xb = w - 1;
-                        for (int x = xa; x <= xb; x++) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31)); }
-                }
-            }
-        }
-    }
+    raster_quad(mask, s_xy, w, hh, tid, MS_THREADS);
     __syncthreads();
     // histogram of masked pixels inside the clamped bounding box (tool.cc:1217-1232)
     const uint8_t *img = L.img[kf];
@@ -352,6 +358,56 @@ __global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
     double d = (double)tid - mu;
     double ss = block_sum<MS_THREADS>((double)hist[tid]*d*d, s_red);
     if (tid == 0) { W.musig[2*tb] = mu; W.musig[2*tb+1] = sqrt(ss/(n - 1.0)); }
+}
+
+// ---- text label image of one keyframe (optimizer::ShowBAReproj_TextBox -> tool::TextBoxWithFill, optimizer.cc:2508-2582,
+// tool.cc:2103-2166): background -1, then every text observation of the keyframe in observation order fills its projected quad
+// with its rank; later quads overwrite earlier ones, so ONE workgroup walks the observations sequentially (a keyframe sees a few
+// dozen planes) and only the rasterisation of each quad is parallel.
+#define LBL_THREADS 1024
+__global__ __launch_bounds__(LBL_THREADS) void k_label(Work W, int kf, int w, int hh, double fx, double fy, double cx, double cy, float *out) {
+    __shared__ unsigned mask[MS_MASK_WORDS];
+    __shared__ int s_xy[8], s_bb[4];
+    const int tid = threadIdx.x;
+    const double *pose = W.pose[W.st->cur], *theta = W.theta[W.st->cur];
+    for (int k = tid; k < w*hh; k += LBL_THREADS) out[k] = -1.0f;
+    int rank = 0;
+    for (int t = 0; t < W.n_tobs; t++) {
+        if (W.tobs_kf[t] != kf) continue;                   // (uniform)
+        const int j = W.tobs_text[t], h = W.text_host[j];
+        if (tid == 0) {
+            Pose C; load_pose(pose + 7*kf, C);
+            PairT T;
+            if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+            else pair_from_Twr(C, W.text_Twr + 12*j, T);
+            const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+            int xMin = w, xMax = -1, yMin = hh, yMax = -1;
+            for (int b = 0; b < 4; b++) {
+                const double mx = W.text_box[(j*4 + b)*2], my = W.text_box[(j*4 + b)*2 + 1];
+                const double invz = -(mx*th[0] + my*th[1] + th[2]);
+                double m[3] = { mx, my, 1.0 }, Rm[3]; mat3_vec(T.Rcr, m, Rm);
+                const double X = Rm[0]/invz + T.tq[0] + C.t[0], Y = Rm[1]/invz + T.tq[1] + C.t[1], Z = Rm[2]/invz + T.tq[2] + C.t[2];
+                const double cu = fx*X/Z + cx, cv = fy*Y/Z + cy;
+                const int iu = (int)cu, iv = (int)cv;                 // cv::Point(double, double): truncation
+                s_xy[2*b] = iu; s_xy[2*b+1] = iv;
+                xMin = min(xMin, iu); xMax = max(xMax, iu); yMin = min(yMin, iv); yMax = max(yMax, iv);
+            }
+            s_bb[0] = max(xMin, 0); s_bb[1] = min(xMax, w - 1); s_bb[2] = max(yMin, 0); s_bb[3] = min(yMax, hh - 1);
+        }
+        for (int k = tid; k < MS_MASK_WORDS; k += LBL_THREADS) mask[k] = 0;
+        __syncthreads();
+        raster_quad(mask, s_xy, w, hh, tid, LBL_THREADS);
+        __syncthreads();
+        const int x0 = s_bb[0], x1 = s_bb[1], y0 = s_bb[2], y1 = s_bb[3];     // the filled set lies inside the corners' bounding box
+        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+        if (bw > 0 && bh > 0)
+            for (int k = tid; k < bw*bh; k += LBL_THREADS) {
+                const int x = x0 + k % bw, y = y0 + k / bw, bit = y*w + x;
+                if (mask[bit >> 5] & (1u << (bit & 31))) out[bit] = (float)rank;
+            }
+        rank++;
+        __syncthreads();
+    }
 }
 
 // ---- linearisation / cost.  grid = n_pair (scene waves) + n_tg (text waves), 64 threads each.
@@ -1356,6 +1412,7 @@ struct Ctx {
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
+    float *lbl_dev = nullptr, *lbl_host = nullptr; size_t lbl_cap = 0;   // text label image staging
     unsigned long long *hprog = nullptr; unsigned int pass_seq = 0;   // pinned progress word written by k_postlin / k_decide
     std::vector<struct Slab> slabs; int cur_slab = 0;
     int run_slab = 0; size_t run_off = 0, run_len = 0;   // pending contiguous host-to-device range
@@ -1488,6 +1545,7 @@ int tsba_destroy(void *ctx) {
     c->slabs.clear();
     if (c->comm && c->p_destroy) c->p_destroy(c->comm);
     hipHostFree(c->st_host); hipFree(c->st_log); if (c->hprog) hipHostFree(c->hprog);
+    if (c->lbl_dev) hipFree(c->lbl_dev); if (c->lbl_host) hipHostFree(c->lbl_host);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
     delete c; return TSBA_OK;
 }
@@ -1931,6 +1989,23 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
         for (int g = 0; g < D.n_tg; g++) npairs_text++;
         *algo_bytes = 44.0*st.ns_active + 128.0*st.nt_active + 16.0*npairs_text + 56.0*c->n_kf + 8.0*c->n_pt + 24.0*c->n_text;
     }
+    return TSBA_OK;
+}
+
+int tsba_text_label_image(void *ctx, int kf, int level, float *out) {
+    Ctx *c = (Ctx *)ctx; if (!c || !out) return TSBA_ERR_ARG;
+    if (!c->uploaded) { set_err(c, "no problem uploaded"); return TSBA_ERR_STATE; }
+    if (kf < 0 || kf >= c->n_kf || level < 0 || level >= c->n_levels || !c->lev_built[level]) { set_err(c, "keyframe / level out of range or level not uploaded"); return TSBA_ERR_ARG; }
+    hipSetDevice(c->device);
+    const LevelDev &D = c->lev[level];
+    if (D.img_w <= 0 || D.img_h <= 0 || (size_t)D.img_w*D.img_h > (size_t)MS_MASK_WORDS*32) { set_err(c, "no image geometry for this level"); return TSBA_ERR_ARG; }
+    const size_t npx = (size_t)D.img_w*D.img_h;
+    if (c->lbl_cap < npx) { if (c->lbl_dev) hipFree(c->lbl_dev); if (c->lbl_host) hipHostFree(c->lbl_host); c->lbl_cap = 0;
+        CK(hipMalloc((void **)&c->lbl_dev, npx*sizeof(float))); CK(hipHostMalloc((void **)&c->lbl_host, npx*sizeof(float), hipHostMallocDefault)); c->lbl_cap = npx; }
+    hipLaunchKernelGGL(k_label, dim3(1), dim3(LBL_THREADS), 0, c->stream, c->W, kf, D.img_w, D.img_h, D.K[0], D.K[1], D.K[2], D.K[3], c->lbl_dev);
+    CK(hipMemcpyAsync(c->lbl_host, c->lbl_dev, npx*sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
+    memcpy(out, c->lbl_host, npx*sizeof(float));
     return TSBA_OK;
 }
 

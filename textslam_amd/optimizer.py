@@ -37,6 +37,7 @@ def load_library():
         getattr(L, name).argtypes = [vp, C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.POINTER(TsbaReport)]
     L.tsba_upload.argtypes = [vp, C.POINTER(TsbaProblem), C.POINTER(TsbaOptions)]
     L.tsba_solve.argtypes = [vp, C.POINTER(TsbaReport)]
+    L.tsba_text_label_image.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.tsba_download.argtypes = [vp, C.POINTER(TsbaProblem)]
     L.tsba_eval.argtypes = [vp, C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, dp, dp, dp,
                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -57,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global",
     "tsba_create", "tsba_destroy", "tsba_last_error",
     "tsba_default_options_init", "tsba_default_options_landmarker", "tsba_default_options_theta",
-    "tsba_local_ba", "tsba_pose_optim", "tsba_global_ba", "tsba_theta_optim",
+    "tsba_local_ba", "tsba_pose_optim", "tsba_global_ba", "tsba_theta_optim", "tsba_text_label_image",
     "tsba_upload", "tsba_solve", "tsba_download", "tsba_eval", "tsba_time_linearize",
     "tsba_comm_unique_id", "tsba_comm_init",
 ]
@@ -123,6 +124,13 @@ class Optimizer:
         cov = np.zeros(9)
         self._check(self.lib.tsba_theta_optim(self.ctx, C.byref(s), C.byref(o), text, _dp(cov), C.byref(rep)), "tsba_theta_optim")
         return rep.as_dict(), cov.reshape(3, 3)
+
+    def TextLabelImage(self, kf: int, level: int, shape):
+        """Label image (float32 h x w, -1 = background) of keyframe kf for the state left by the last solve
+        (the TextLabelImg of optimizer::ShowBAReproj_TextBox)."""
+        out = np.zeros(shape, np.float32)
+        self._check(self.lib.tsba_text_label_image(self.ctx, int(kf), int(level), out.ctypes.data_as(C.POINTER(C.c_float))), "tsba_text_label_image")
+        return out
 
     def _one_shot(self, fn, prob, o, what):
         s = prob.struct()
