@@ -47,6 +47,24 @@ int tsorb_download(void *ctx, float *kp, uint8_t *desc, int32_t *count);
  * blurred = 1 returns the 7x7 Gaussian-blurred level (no frame): h_l x w_l. */
 int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out, int32_t *w_out, int32_t *h_out);
 
+/* ---- Window / projection search: the step between the extractor and PoseOptim.
+ *   tsorb_match_set_frame / _set_features  <- frame::AssignFeaturesToGrid + PosInGrid                       src/frame.cc:372-407
+ *   tsorb_match_search                     <- frame::GetFeaturesInArea (src/frame.cc:415-468; keyframe.cc:217-256 with qlev = -1,-1)
+ *                                             + tracking::DescriptorDistance (src/tracking.cc:2762-2778) + the best / second-best scan
+ *                                             of tracking::SearchFrom3D / SearchFrom3DAdd / SearchFrom3DLocalTrack (:1109-1345)
+ * The searched frame is frame `frame` of the resident batch (its keypoints and descriptors never leave the device) or an explicit
+ * feature set (kp6 [n][6] = x,y,size,angle,response,octave as the extractor returns them; desc [n][32]).  min/max x/y are the
+ * frame's mnMinX.. (frame.cc:115-125); the grid is FRAME_GRID_COLS x FRAME_GRID_ROWS = 64 x 48.
+ * Per query (x, y, radius r, octave range qlev = {minLevel, maxLevel}, NULL = no level check, 32-byte descriptor):
+ *   cand_idx / cand_dist [nq][max_cand]: the candidates in the reference's order with their Hamming distances (cand_cnt = how many
+ *   there were, possibly > max_cand), best_idx / best_dist: the first minimum (strict <, as the reference's loop; -1 / INT_MAX if
+ *   none), best_dist2: the runner-up distance.  Stateful variants (SearchForInitializ's running vMatchDist filter, the
+ *   first-come claim of a feature) stay in the caller, on the candidate lists.  Output pointers may be NULL. */
+int tsorb_match_set_frame(void *ctx, int frame, double min_x, double max_x, double min_y, double max_y);
+int tsorb_match_set_features(void *ctx, const float *kp6, const uint8_t *desc, int n, double min_x, double max_x, double min_y, double max_y);
+int tsorb_match_search(void *ctx, int nq, const float *qxy, const float *qr, const int32_t *qlev, const uint8_t *qdesc, int max_cand,
+                       int32_t *cand_idx, int32_t *cand_dist, int32_t *cand_cnt, int32_t *best_idx, int32_t *best_dist, int32_t *best_dist2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,25 @@ def orb_params(nfeatures=1000, scale=1.2, nlevels=8):
     orb_lib().tsorb_oracle_params(nfeatures, scale, nlevels, sf.ctypes.data_as(C.POINTER(C.c_float)), nfl.ctypes.data_as(C.POINTER(C.c_int)),
                                   um.ctypes.data_as(C.POINTER(C.c_int)), gk.ctypes.data_as(C.POINTER(C.c_int)))
     return sf, nfl, um, gk
+
+
+def orb_match(kp6, desc, bounds, qxy, qr, qlev, qdesc, max_cand=64):
+    """Window search + Hamming distances (frame::GetFeaturesInArea + tracking::DescriptorDistance), reference candidate order.
+    Returns dict(cand_idx [nq,max_cand], cand_dist, cand_cnt, best_idx, best_dist, best_dist2)."""
+    kp6 = np.ascontiguousarray(kp6, np.float32); desc = np.ascontiguousarray(desc, np.uint8)
+    qxy = np.ascontiguousarray(qxy, np.float32); qr = np.ascontiguousarray(qr, np.float32)
+    qlev = np.ascontiguousarray(qlev, np.int32); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    nq, n = qxy.shape[0], kp6.shape[0]
+    ci = np.full((nq, max_cand), -1, np.int32); cd = np.full((nq, max_cand), -1, np.int32)
+    cc = np.zeros(nq, np.int32); bi = np.zeros(nq, np.int32); bd = np.zeros(nq, np.int32); bd2 = np.zeros(nq, np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    L = orb_lib()
+    L.tsorb_oracle_match.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                     C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_int,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    rc = L.tsorb_oracle_match(fp(kp6), up(desc), n, *[float(b) for b in bounds], nq, fp(qxy), fp(qr), ip(qlev), up(qdesc), max_cand,
+                              ip(ci), ip(cd), ip(cc), ip(bi), ip(bd), ip(bd2))
+    assert rc == 0
+    return dict(cand_idx=ci, cand_dist=cd, cand_cnt=cc, best_idx=bi, best_dist=bd, best_dist2=bd2)

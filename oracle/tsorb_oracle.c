@@ -393,3 +393,68 @@ void tsorb_oracle_params(int nfeatures, float scale, int nlevels, float *sf, int
     gauss_kernel_q8(gk7);
 }
 float tsorb_oracle_atan2(float y, float x) { return fast_atan2f(y, x); }
+
+/* ------------------------------------------------------------------ window / projection search
+ * frame::AssignFeaturesToGrid + PosInGrid (src/frame.cc:372-407), frame::GetFeaturesInArea (src/frame.cc:415-468),
+ * tracking::DescriptorDistance (src/tracking.cc:2762-2778) and the best / second-best scan shared by tracking::SearchFrom3D,
+ * SearchFrom3DAdd, SearchFrom3DLocalTrack and (without its running vMatchDist filter) SearchForInitializ (tracking.cc:1045-1400).
+ * kp6: [n][6] = x, y, size, angle, response, octave (the extractor's output).  Per query: candidates in the reference's order
+ * (cell column ix outer, cell row iy inner, features of a cell in index order), their Hamming distances, the first minimum
+ * (strict <) and the second-best distance.  PARITY UNPINNED like the rest of this file (no OpenCV / reference build here). */
+#define GRID_COLS 64
+#define GRID_ROWS 48
+static int hamming256(const uint8_t *a, const uint8_t *b) {
+    const int32_t *pa = (const int32_t *)a, *pb = (const int32_t *)b;
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        unsigned int v = (unsigned int)(pa[i] ^ pb[i]);
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+int tsorb_oracle_match(const float *kp6, const uint8_t *desc, int n, double min_x, double max_x, double min_y, double max_y,
+                       int nq, const float *qxy, const float *qr, const int32_t *qlev, const uint8_t *qdesc, int max_cand,
+                       int32_t *cand_idx, int32_t *cand_dist, int32_t *cand_cnt, int32_t *best_idx, int32_t *best_dist, int32_t *best_dist2) {
+    const double iw = (double)GRID_COLS/(max_x - min_x), ih = (double)GRID_ROWS/(max_y - min_y);
+    /* mGrid[ix][iy]: feature indices in insertion (= index) order */
+    int *cnt = (int *)calloc(GRID_COLS*GRID_ROWS + 1, sizeof(int)), *cell = (int *)malloc(sizeof(int)*(size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        int px = (int)round(((double)kp6[6*i] - min_x)*iw), py = (int)round(((double)kp6[6*i+1] - min_y)*ih);
+        cell[i] = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px*GRID_ROWS + py;
+        if (cell[i] >= 0) cnt[cell[i] + 1]++;
+    }
+    for (int c = 0; c < GRID_COLS*GRID_ROWS; c++) cnt[c+1] += cnt[c];
+    int *list = (int *)malloc(sizeof(int)*(size_t)(n > 0 ? n : 1)), *cur = (int *)malloc(sizeof(int)*GRID_COLS*GRID_ROWS);
+    memcpy(cur, cnt, sizeof(int)*GRID_COLS*GRID_ROWS);
+    for (int i = 0; i < n; i++) if (cell[i] >= 0) list[cur[cell[i]]++] = i;
+    for (int q = 0; q < nq; q++) {
+        const float x = qxy[2*q], y = qxy[2*q+1], r = qr[q];
+        const int minLevel = qlev ? qlev[2*q] : -1, maxLevel = qlev ? qlev[2*q+1] : -1;
+        int nc = 0, bi = -1, bd = 2147483647, bd2 = 2147483647;
+        const int c0x = (int)floor(((double)x - min_x - (double)r)*iw) > 0 ? (int)floor(((double)x - min_x - (double)r)*iw) : 0;
+        const int c1x = (int)ceil(((double)x - min_x + (double)r)*iw) < GRID_COLS - 1 ? (int)ceil(((double)x - min_x + (double)r)*iw) : GRID_COLS - 1;
+        const int c0y = (int)floor(((double)y - min_y - (double)r)*ih) > 0 ? (int)floor(((double)y - min_y - (double)r)*ih) : 0;
+        const int c1y = (int)ceil(((double)y - min_y + (double)r)*ih) < GRID_ROWS - 1 ? (int)ceil(((double)y - min_y + (double)r)*ih) : GRID_ROWS - 1;
+        if (!(c0x >= GRID_COLS || c1x < 0 || c0y >= GRID_ROWS || c1y < 0)) {
+            const int check = (minLevel > 0) || (maxLevel >= 0);
+            for (int ix = c0x; ix <= c1x; ix++) for (int iy = c0y; iy <= c1y; iy++) {
+                const int c = ix*GRID_ROWS + iy;
+                for (int k = cnt[c]; k < cnt[c+1]; k++) {
+                    const int i = list[k]; const int oct = (int)kp6[6*i+5];
+                    if (check) { if (oct < minLevel) continue; if (maxLevel >= 0 && oct > maxLevel) continue; }
+                    const float dx = kp6[6*i] - x, dy = kp6[6*i+1] - y;
+                    if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+                    const int d = hamming256(qdesc + 32*(size_t)q, desc + 32*(size_t)i);
+                    if (nc < max_cand) { cand_idx[(size_t)q*max_cand + nc] = i; cand_dist[(size_t)q*max_cand + nc] = d; }
+                    nc++;
+                    if (d < bd) { bd2 = bd; bd = d; bi = i; } else if (d < bd2) bd2 = d;
+                }
+            }
+        }
+        cand_cnt[q] = nc; best_idx[q] = bi; best_dist[q] = bd; best_dist2[q] = bd2;
+    }
+    free(cnt); free(cell); free(list); free(cur);
+    return 0;
+}

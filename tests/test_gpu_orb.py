@@ -78,3 +78,31 @@ def test_full_batch_properties(orb):
         _same(res[f], res2[63 - f])                                # a frame's result does not depend on its batch position
         kp, desc = res[f]
         assert 990 <= len(kp) <= 1040 and np.all(np.diff(kp[:, 5]) >= 0)
+
+
+@pytest.mark.gpu
+def test_match_search_parity_on_resident_frames(orb, oracle_lib):
+    """tsorb_match_* vs the oracle, bit-exact: candidates in the reference's order, Hamming distances, best / second best --
+    searching in a frame of the resident batch (features never leave the device) and in an explicit feature set."""
+    oracle, ex = oracle_lib, orb
+    imgs = np.stack([synthetic_frame(40), synthetic_frame(41)])
+    (kpA, dA), (kpB, dB) = ex.extract_batch(imgs)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    rng = np.random.default_rng(9)
+    nq = kpA.shape[0]
+    qxy = (kpA[:, :2] + rng.normal(0, 3.0, (nq, 2))).astype(np.float32)
+    qr = np.where(rng.random(nq) < 0.5, 15.0, 40.0).astype(np.float32)
+    oct_ = kpA[:, 5].astype(np.int32)
+    qlev = np.stack([oct_ - 1, oct_ + 1], 1).astype(np.int32)
+    ref = oracle.orb_match(kpB, dB, bounds, qxy, qr, qlev, dA, max_cand=8)
+    ex.match_set_frame(1, bounds)
+    got = ex.match_search(qxy, qr, qlev, dA, max_cand=8)
+    for k in ("cand_cnt", "best_idx", "best_dist", "best_dist2", "cand_idx", "cand_dist"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert (ref["cand_cnt"] > 0).mean() > 0.5 and ref["cand_cnt"].max() > 8        # both the common and the truncated case occur
+    # explicit feature set, no level check (keyframe::GetFeaturesInArea)
+    ref2 = oracle.orb_match(kpA, dA, bounds, qxy, qr, np.full((nq, 2), -1, np.int32), dA, max_cand=32)
+    ex.match_set_features(kpA, dA, bounds)
+    got2 = ex.match_search(qxy, qr, None, dA, max_cand=32)
+    for k in ("cand_cnt", "best_idx", "best_dist", "best_dist2", "cand_idx", "cand_dist"):
+        assert np.array_equal(got2[k], ref2[k]), k

@@ -132,3 +132,51 @@ def test_descriptor_follows_rotation(oracle_lib):
         ham = int(np.unpackbits(desc[i] ^ desc_r[j]).sum())
         close += ham <= 40
     assert matched > 50 and close / matched > 0.9
+
+
+def test_match_oracle_against_bruteforce(oracle_lib):
+    oracle = oracle_lib
+    """orb_match (GetFeaturesInArea + DescriptorDistance restatement) vs a brute-force numpy formulation: same candidate SETS,
+    same distances, best = first minimum in the oracle's candidate order, second best = runner-up distance."""
+    rng = np.random.default_rng(5)
+    n, nq = 700, 300
+    kp = np.zeros((n, 6), np.float32)
+    kp[:, 0] = rng.uniform(-5, 645, n); kp[:, 1] = rng.uniform(-5, 485, n); kp[:, 5] = rng.integers(0, 8, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    qxy = np.stack([rng.uniform(0, 640, nq), rng.uniform(0, 480, nq)], 1).astype(np.float32)
+    qr = rng.uniform(3, 40, nq).astype(np.float32)
+    qlev = np.stack([rng.integers(-1, 3, nq), rng.integers(-1, 6, nq)], 1).astype(np.int32)
+    qdesc = desc[rng.integers(0, n, nq)] ^ (rng.integers(0, 256, (nq, 32), dtype=np.uint8) & rng.integers(0, 256, (nq, 32), dtype=np.uint8) & rng.integers(0, 256, (nq, 32), dtype=np.uint8))
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    out = oracle.orb_match(kp, desc, bounds, qxy, qr, qlev, qdesc, max_cand=256)
+    iw, ih = 64/640.0, 48/480.0
+    px = np.round((kp[:, 0].astype(np.float64) - 0.0)*iw); py = np.round((kp[:, 1].astype(np.float64))*ih)   # np.round is half-even: avoid ties
+    ingrid = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    popc = np.array([bin(v).count("1") for v in range(256)])
+    for q in range(nq):
+        x, y, r = qxy[q, 0], qxy[q, 1], qr[q]
+        c0x = max(0, int(np.floor((float(x) - float(r))*iw))); c1x = min(63, int(np.ceil((float(x) + float(r))*iw)))
+        c0y = max(0, int(np.floor((float(y) - float(r))*ih))); c1y = min(47, int(np.ceil((float(y) + float(r))*ih)))
+        m = ingrid & (px >= c0x) & (px <= c1x) & (py >= c0y) & (py <= c1y)
+        mn, mx = qlev[q]
+        if mn > 0 or mx >= 0:
+            m &= kp[:, 5] >= mn
+            if mx >= 0: m &= kp[:, 5] <= mx
+        m &= (np.abs(kp[:, 0] - x) < r) & (np.abs(kp[:, 1] - y) < r)
+        want = np.nonzero(m)[0]
+        cnt = out["cand_cnt"][q]
+        assert cnt == want.size
+        got = out["cand_idx"][q, :cnt]
+        assert sorted(got.tolist()) == want.tolist()
+        d = popc[desc[got] ^ qdesc[q]].sum(1) if cnt else np.zeros(0, int)
+        assert np.array_equal(d, out["cand_dist"][q, :cnt])
+        # reference order: cell column outer, cell row inner, index inside the cell
+        key = [(int(px[i]), int(py[i]), int(i)) for i in got]
+        assert key == sorted(key)
+        if cnt:
+            k = int(np.argmin(d))                             # first minimum
+            assert out["best_idx"][q] == got[k] and out["best_dist"][q] == d[k]
+            rest = np.delete(d, k)
+            assert out["best_dist2"][q] == (rest.min() if rest.size else 2147483647)
+        else:
+            assert out["best_idx"][q] == -1 and out["best_dist"][q] == 2147483647

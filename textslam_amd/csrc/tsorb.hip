@@ -590,6 +590,85 @@ __global__ __launch_bounds__(256) void k_pack(OrbDev D) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+
+// ================================================================== window / projection search
+// frame::AssignFeaturesToGrid / PosInGrid (frame.cc:372-407), frame::GetFeaturesInArea (frame.cc:415-468),
+// tracking::DescriptorDistance (tracking.cc:2762-2778): the feature grid of the searched frame is built on the device (stable
+// counting sort: a cell lists its features in index order, as the reference's push_back does), one thread per query walks the
+// cells in the reference's order, filters by octave and window, and scores the candidates with a 256-bit Hamming distance.
+#define MG_COLS 64
+#define MG_ROWS 48
+#define MG_CELLS (MG_COLS*MG_ROWS)
+struct MatchDev {
+    const float *kp; const uint8_t *desc; int n;      // [n][6], [n][32]
+    double min_x, min_y, iw, ih;
+    int *cell, *off, *list;                           // [n], [MG_CELLS + 1], [n]
+};
+__global__ __launch_bounds__(256) void k_mg_cell(MatchDev M) {
+    const int i = blockIdx.x*256 + threadIdx.x;
+    if (i >= M.n) return;
+    const int px = (int)round(((double)M.kp[6*i] - M.min_x)*M.iw), py = (int)round(((double)M.kp[6*i+1] - M.min_y)*M.ih);   // PosInGrid
+    const int c = (px < 0 || px >= MG_COLS || py < 0 || py >= MG_ROWS) ? -1 : px*MG_ROWS + py;
+    M.cell[i] = c;
+    if (c >= 0) atomicAdd(&M.off[c + 1], 1);
+}
+__global__ __launch_bounds__(1024) void k_mg_scan(MatchDev M) {          // inclusive scan of the 3072 cell counts, one workgroup
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    int v[3], s = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { v[k] = M.off[1 + 3*t + k]; s += v[k]; }
+    part[t] = s; __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { int a = t >= d ? part[t - d] : 0; __syncthreads(); part[t] += a; __syncthreads(); }
+    int run = part[t] - s;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { run += v[k]; M.off[1 + 3*t + k] = run; }
+}
+__global__ __launch_bounds__(256) void k_mg_place(MatchDev M) {           // rank inside the cell = features of the cell with a smaller index
+    const int i = blockIdx.x*256 + threadIdx.x;
+    if (i >= M.n) return;
+    const int c = M.cell[i];
+    if (c < 0) return;
+    int rank = 0;
+    for (int j = 0; j < i; j++) rank += M.cell[j] == c;
+    M.list[M.off[c] + rank] = i;
+}
+__global__ __launch_bounds__(128) void k_match(MatchDev M, int nq, const float *qxy, const float *qr, const int *qlev, const uint8_t *qdesc, int max_cand,
+                                               int *cand_idx, int *cand_dist, int *cand_cnt, int *best_idx, int *best_dist, int *best_dist2) {
+    const int q = blockIdx.x*128 + threadIdx.x;
+    if (q >= nq) return;
+    const float x = qxy[2*q], y = qxy[2*q+1], r = qr[q];
+    const int minLevel = qlev ? qlev[2*q] : -1, maxLevel = qlev ? qlev[2*q+1] : -1;
+    uint32_t qd[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) qd[k] = ((const uint32_t *)qdesc)[8*(size_t)q + k];
+    int nc = 0, bi = -1, bd = 2147483647, bd2 = 2147483647;
+    const int c0x = max(0, (int)floor(((double)x - M.min_x - (double)r)*M.iw)), c1x = min(MG_COLS - 1, (int)ceil(((double)x - M.min_x + (double)r)*M.iw));
+    const int c0y = max(0, (int)floor(((double)y - M.min_y - (double)r)*M.ih)), c1y = min(MG_ROWS - 1, (int)ceil(((double)y - M.min_y + (double)r)*M.ih));
+    if (!(c0x >= MG_COLS || c1x < 0 || c0y >= MG_ROWS || c1y < 0)) {
+        const bool check = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = c0x; ix <= c1x; ix++) for (int iy = c0y; iy <= c1y; iy++) {
+            const int c = ix*MG_ROWS + iy;
+            for (int k = M.off[c]; k < M.off[c+1]; k++) {
+                const int i = M.list[k];
+                const float fx = M.kp[6*i], fy = M.kp[6*i+1]; const int oct = (int)M.kp[6*i+5];
+                if (check) { if (oct < minLevel) continue; if (maxLevel >= 0 && oct > maxLevel) continue; }
+                const float dx = fx - x, dy = fy - y;
+                if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+                const uint32_t *fd = (const uint32_t *)(M.desc + 32*(size_t)i);
+                int d = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++) d += __popc(qd[w] ^ fd[w]);
+                if (nc < max_cand) { cand_idx[(size_t)q*max_cand + nc] = i; cand_dist[(size_t)q*max_cand + nc] = d; }
+                nc++;
+                if (d < bd) { bd2 = bd; bd = d; bi = i; } else if (d < bd2) bd2 = d;
+            }
+        }
+    }
+    for (int k = nc; k < max_cand; k++) { cand_idx[(size_t)q*max_cand + k] = -1; cand_dist[(size_t)q*max_cand + k] = -1; }     // unused slots
+    cand_cnt[q] = nc; best_idx[q] = bi; best_dist[q] = bd; best_dist2[q] = bd2;
+}
+
 struct OCtx {
     int device = 0; hipStream_t stream = nullptr; std::string err;
     int nfeatures = 1000, nlevels = 8, ini_th = 20, min_th = 7; float scale = 1.2f;
@@ -597,13 +676,15 @@ struct OCtx {
     std::vector<void *> allocs; bool uploaded = false;
     OrbDev D;
     // the SLAM front-end calls once per frame with the same geometry: buffers and pinned staging are kept between calls
+    MatchDev M; bool m_set = false; void *m_buf = nullptr; size_t m_cap = 0; void *m_feat = nullptr; size_t m_feat_cap = 0;   // search grid of the current frame
+    void *mq_dev = nullptr, *mq_host = nullptr; size_t mq_cap = 0;
     int key[5] = {0, 0, 0, 0, 0}; uint8_t *h_img = nullptr; void *h_out = nullptr; size_t h_img_sz = 0, h_out_sz = 0;
 };
 static int cv_round_f(float v) { return (int)lrintf(v); }
 #define OCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(e_); return TSORB_ERR_DEVICE; } } while (0)
 template <typename T> static int oalloc(OCtx *c, T **p, size_t n) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(n, 1)*sizeof(T)) != hipSuccess) { c->err = "hipMalloc failed"; return TSORB_ERR_DEVICE; }
     c->allocs.push_back(q); *p = (T *)q; return 0; }
-static void ofree(OCtx *c) { hipStreamSynchronize(c->stream); for (void *p : c->allocs) hipFree(p); c->allocs.clear(); c->uploaded = false; c->key[0] = 0;
+static void ofree(OCtx *c) { hipStreamSynchronize(c->stream); for (void *p : c->allocs) hipFree(p); c->allocs.clear(); c->uploaded = false; c->key[0] = 0; c->m_set = false;
     if (c->h_img) hipHostFree(c->h_img); if (c->h_out) hipHostFree(c->h_out); c->h_img = nullptr; c->h_out = nullptr; c->h_img_sz = c->h_out_sz = 0; }
 
 extern "C" {
@@ -634,7 +715,9 @@ int tsorb_create(void **ctx, int nfeatures, float scale, int nlevels, int ini_th
     if (hipMemcpyToSymbol(HIP_SYMBOL(d_pattern), ORB_BIT_PATTERN_31, 1024) != hipSuccess) { delete c; return TSORB_ERR_DEVICE; }
     *ctx = c; return TSORB_OK;
 }
-int tsorb_destroy(void *ctx) { OCtx *c = (OCtx *)ctx; if (!c) return TSORB_ERR_ARG; hipSetDevice(c->device); ofree(c); hipStreamDestroy(c->stream); delete c; return TSORB_OK; }
+int tsorb_destroy(void *ctx) { OCtx *c = (OCtx *)ctx; if (!c) return TSORB_ERR_ARG; hipSetDevice(c->device); ofree(c);
+    if (c->m_buf) hipFree(c->m_buf); if (c->m_feat) hipFree(c->m_feat); if (c->mq_dev) hipFree(c->mq_dev); if (c->mq_host) hipHostFree(c->mq_host);
+    hipStreamDestroy(c->stream); delete c; return TSORB_OK; }
 const char *tsorb_last_error(void *ctx) { return ctx ? ((OCtx *)ctx)->err.c_str() : "null ctx"; }
 int tsorb_get_levels(void *ctx) { return ctx ? ((OCtx *)ctx)->nlevels : TSORB_ERR_ARG; }
 int tsorb_get_scale_factors(void *ctx, float *sf, float *isf) { OCtx *c = (OCtx *)ctx; if (!c) return TSORB_ERR_ARG;
@@ -733,6 +816,68 @@ int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out
     if (w_out) *w_out = G.w; if (h_out) *h_out = G.h;
     if (blurred) OCK(hipMemcpy(out, D.blur + (size_t)frame*D.blur_frame + G.blur_off, (size_t)G.w*G.h, hipMemcpyDeviceToHost));
     else OCK(hipMemcpy(out, D.pyr + (size_t)frame*D.pyr_frame + G.pyr_off, (size_t)G.bw*G.bh, hipMemcpyDeviceToHost));
+    return TSORB_OK;
+}
+
+// ---- window / projection search
+static int match_build(OCtx *c, const float *kp_dev, const uint8_t *desc_dev, int n, double min_x, double max_x, double min_y, double max_y) {
+    if (!(max_x > min_x) || !(max_y > min_y) || n < 0) return TSORB_ERR_ARG;
+    const size_t need = sizeof(int)*((size_t)2*std::max(n, 1) + MG_CELLS + 1);
+    if (c->m_cap < need) { if (c->m_buf) hipFree(c->m_buf); c->m_cap = 0; OCK(hipMalloc(&c->m_buf, need)); c->m_cap = need; }
+    MatchDev &M = c->M;
+    M.kp = kp_dev; M.desc = desc_dev; M.n = n; M.min_x = min_x; M.min_y = min_y;
+    M.iw = (double)MG_COLS/(max_x - min_x); M.ih = (double)MG_ROWS/(max_y - min_y);          // frame.cc:124-125
+    M.off = (int *)c->m_buf; M.cell = M.off + MG_CELLS + 1; M.list = M.cell + std::max(n, 1);
+    OCK(hipMemsetAsync(M.off, 0, sizeof(int)*(MG_CELLS + 1), c->stream));
+    if (n > 0) hipLaunchKernelGGL(k_mg_cell, dim3((n + 255)/256), dim3(256), 0, c->stream, M);
+    hipLaunchKernelGGL(k_mg_scan, dim3(1), dim3(1024), 0, c->stream, M);
+    if (n > 0) hipLaunchKernelGGL(k_mg_place, dim3((n + 255)/256), dim3(256), 0, c->stream, M);
+    c->m_set = true; return TSORB_OK;
+}
+int tsorb_match_set_frame(void *ctx, int frame, double min_x, double max_x, double min_y, double max_y) {
+    OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG;
+    OrbDev &D = c->D; if (frame < 0 || frame >= D.n) return TSORB_ERR_ARG;
+    hipSetDevice(c->device);
+    int cnt = 0; OCK(hipMemcpyAsync(&cnt, D.out_cnt + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream)); OCK(hipStreamSynchronize(c->stream));
+    return match_build(c, D.out_kp + (size_t)frame*D.cap*6, D.out_desc + (size_t)frame*D.cap*32, cnt, min_x, max_x, min_y, max_y);
+}
+int tsorb_match_set_features(void *ctx, const float *kp6, const uint8_t *desc, int n, double min_x, double max_x, double min_y, double max_y) {
+    OCtx *c = (OCtx *)ctx; if (!c || n < 0 || (n > 0 && (!kp6 || !desc))) return TSORB_ERR_ARG;
+    hipSetDevice(c->device);
+    const size_t bk = sizeof(float)*6*(size_t)std::max(n, 1), need = bk + 32*(size_t)std::max(n, 1);
+    if (c->m_feat_cap < need) { if (c->m_feat) hipFree(c->m_feat); c->m_feat_cap = 0; OCK(hipMalloc(&c->m_feat, need)); c->m_feat_cap = need; }
+    if (n > 0) { OCK(hipMemcpyAsync(c->m_feat, kp6, sizeof(float)*6*(size_t)n, hipMemcpyHostToDevice, c->stream));
+                 OCK(hipMemcpyAsync((char *)c->m_feat + bk, desc, 32*(size_t)n, hipMemcpyHostToDevice, c->stream)); OCK(hipStreamSynchronize(c->stream)); }
+    return match_build(c, (const float *)c->m_feat, (const uint8_t *)c->m_feat + bk, n, min_x, max_x, min_y, max_y);
+}
+int tsorb_match_search(void *ctx, int nq, const float *qxy, const float *qr, const int32_t *qlev, const uint8_t *qdesc, int max_cand,
+                       int32_t *cand_idx, int32_t *cand_dist, int32_t *cand_cnt, int32_t *best_idx, int32_t *best_dist, int32_t *best_dist2) {
+    OCtx *c = (OCtx *)ctx; if (!c || !c->m_set || nq < 0 || max_cand < 0 || (nq > 0 && (!qxy || !qr || !qdesc))) return TSORB_ERR_ARG;
+    if (nq == 0) return TSORB_OK;
+    hipSetDevice(c->device);
+    // one pinned staging block in, one out: [qxy | qr | qlev | qdesc]  ->  [cand_idx | cand_dist | cnt | best | dist | dist2]
+    const size_t b_xy = 8*(size_t)nq, b_r = 4*(size_t)nq, b_lev = 8*(size_t)nq, b_d = 32*(size_t)nq, in_sz = b_xy + b_r + b_lev + b_d;
+    const size_t b_c = 4*(size_t)nq*max_cand, out_sz = 2*b_c + 16*(size_t)nq, tot = in_sz + out_sz;
+    if (c->mq_cap < tot) { if (c->mq_dev) hipFree(c->mq_dev); if (c->mq_host) hipHostFree(c->mq_host); c->mq_cap = 0;
+        OCK(hipMalloc(&c->mq_dev, tot)); OCK(hipHostMalloc(&c->mq_host, tot, hipHostMallocDefault)); c->mq_cap = tot; }
+    char *h = (char *)c->mq_host, *d = (char *)c->mq_dev;
+    memcpy(h, qxy, b_xy); memcpy(h + b_xy, qr, b_r);
+    if (qlev) memcpy(h + b_xy + b_r, qlev, b_lev); else for (size_t k = 0; k < 2*(size_t)nq; k++) ((int32_t *)(h + b_xy + b_r))[k] = -1;
+    memcpy(h + b_xy + b_r + b_lev, qdesc, b_d);
+    OCK(hipMemcpyAsync(d, h, in_sz, hipMemcpyHostToDevice, c->stream));
+    int *o_ci = (int *)(d + in_sz), *o_cd = o_ci + (size_t)nq*max_cand, *o_cnt = o_cd + (size_t)nq*max_cand, *o_bi = o_cnt + nq, *o_bd = o_bi + nq, *o_bd2 = o_bd + nq;
+    hipLaunchKernelGGL(k_match, dim3((nq + 127)/128), dim3(128), 0, c->stream, c->M, nq, (const float *)d, (const float *)(d + b_xy), (const int *)(d + b_xy + b_r),
+                       (const uint8_t *)(d + b_xy + b_r + b_lev), max_cand, o_ci, o_cd, o_cnt, o_bi, o_bd, o_bd2);
+    OCK(hipMemcpyAsync(h + in_sz, d + in_sz, out_sz, hipMemcpyDeviceToHost, c->stream));
+    OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
+    const char *ho = h + in_sz;
+    if (cand_idx) memcpy(cand_idx, ho, b_c);
+    if (cand_dist) memcpy(cand_dist, ho + b_c, b_c);
+    const int32_t *tail = (const int32_t *)(ho + 2*b_c);
+    if (cand_cnt) memcpy(cand_cnt, tail, 4*(size_t)nq);
+    if (best_idx) memcpy(best_idx, tail + nq, 4*(size_t)nq);
+    if (best_dist) memcpy(best_dist, tail + 2*(size_t)nq, 4*(size_t)nq);
+    if (best_dist2) memcpy(best_dist2, tail + 3*(size_t)nq, 4*(size_t)nq);
     return TSORB_OK;
 }
 

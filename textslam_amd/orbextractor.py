@@ -12,7 +12,7 @@ _lib = None
 
 EXPORTED_SYMBOLS = ["tsorb_create", "tsorb_destroy", "tsorb_last_error", "tsorb_get_levels", "tsorb_get_scale_factors",
                     "tsorb_get_features_per_level", "tsorb_extract_batch", "tsorb_upload", "tsorb_run", "tsorb_download",
-                    "tsorb_debug_level"]
+                    "tsorb_debug_level", "tsorb_match_set_frame", "tsorb_match_set_features", "tsorb_match_search"]
 
 
 class TsorbError(RuntimeError):
@@ -37,6 +37,9 @@ def load_library():
         L.tsorb_run.argtypes = [vp]
         L.tsorb_download.argtypes = [vp, fp, up, ip]
         L.tsorb_debug_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, up, ip, ip]
+        L.tsorb_match_set_frame.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.tsorb_match_set_features.argtypes = [vp, fp, up, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.tsorb_match_search.argtypes = [vp, C.c_int, fp, fp, ip, up, C.c_int, ip, ip, ip, ip, ip, ip]
         _lib = L
     return _lib
 
@@ -110,6 +113,28 @@ class ORBextractor:
     def __call__(self, image, mask=None):
         """ORBextractor::operator()(image, mask, keypoints, descriptors) -- the mask is ignored, as in the reference."""
         return self.extract_batch(image)[0]
+
+    # ---- window / projection search (frame::GetFeaturesInArea + tracking::DescriptorDistance)
+    def match_set_frame(self, frame, bounds):
+        """Search in frame `frame` of the resident batch (features stay on the device); bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+        self._check(self.lib.tsorb_match_set_frame(self.ctx, int(frame), *[float(b) for b in bounds]), "tsorb_match_set_frame")
+
+    def match_set_features(self, kp6, desc, bounds):
+        kp6 = np.ascontiguousarray(kp6, np.float32); desc = np.ascontiguousarray(desc, np.uint8)
+        self._check(self.lib.tsorb_match_set_features(self.ctx, kp6.ctypes.data_as(C.POINTER(C.c_float)), desc.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                      kp6.shape[0], *[float(b) for b in bounds]), "tsorb_match_set_features")
+
+    def match_search(self, qxy, qr, qlev, qdesc, max_cand=64):
+        qxy = np.ascontiguousarray(qxy, np.float32); qr = np.ascontiguousarray(qr, np.float32); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        nq = qxy.shape[0]
+        qlev_p = None if qlev is None else np.ascontiguousarray(qlev, np.int32)
+        ci = np.full((nq, max_cand), -1, np.int32); cd = np.full((nq, max_cand), -1, np.int32)
+        cc = np.zeros(nq, np.int32); bi = np.zeros(nq, np.int32); bd = np.zeros(nq, np.int32); bd2 = np.zeros(nq, np.int32)
+        ip_ = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        self._check(self.lib.tsorb_match_search(self.ctx, nq, qxy.ctypes.data_as(C.POINTER(C.c_float)), qr.ctypes.data_as(C.POINTER(C.c_float)),
+                                                None if qlev_p is None else ip_(qlev_p), qdesc.ctypes.data_as(C.POINTER(C.c_uint8)), max_cand,
+                                                ip_(ci), ip_(cd), ip_(cc), ip_(bi), ip_(bd), ip_(bd2)), "tsorb_match_search")
+        return dict(cand_idx=ci, cand_dist=cd, cand_cnt=cc, best_idx=bi, best_dist=bd, best_dist2=bd2)
 
     def debug_level(self, frame, level, blurred=False):
         n, h, w = self._shape
