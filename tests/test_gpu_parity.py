@@ -271,3 +271,13 @@ def test_text_label_image_parity(gpu, oracle_lib):
             nbad = int(np.count_nonzero(lab != ref))
             assert nbad == 0, "level %d kf %d: %d of %d pixels differ" % (lvl, kf, nbad, lab.size)
             assert (lab >= 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_kf,band,far", [(40, 6, 0.0), (70, 9, 0.0), (50, 5, 0.08)])
+def test_global_ba_band_cholesky_profiles(gpu, oracle_lib, n_kf, band, far):
+    """The profile-aware Cholesky on several envelopes: a narrow band over 3 / 5 block columns with a short last block, and a
+    band plus long-range (loop-closure-like) observations, which widen the host's band bound towards the dense case."""
+    P = synth.config_global(n_kf=n_kf, n_pt=50*n_kf, band=band, far_frac=far)
+    o = abi.options_global(); o.its[0] = 6
+    _check_solve(gpu, oracle_lib, P, o, lambda G, oo: gpu.GlobalBA(G, options=oo), atol=1e-7, rtol_cost=1e-8)
