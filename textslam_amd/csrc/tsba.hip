@@ -81,6 +81,8 @@ struct Work {                // device work buffers (sized for the largest level
     double *cb, *cbm;                   // multi-GPU exchange buffers: cb = [Hd 6n | bp 6n | cost, |x_lm|^2, step^2, mcc] (sum), cbm = gradient max (max)
     long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
     double *LDbuf;                      // diagonal of the inverse diagonal factors (large-system Cholesky)
+    int ldS, band;                      // S(i,j) = S[i*ldS + j]; band: S holds only the band of the reduced camera matrix (large systems)
+    double *Sy;                         // right-hand-side row of the large-system solver (row n of the small one lives in LDS)
     unsigned long long *hprog;          // pinned host word (seq << 32 | it << 1 | done): lets the host stop enqueuing a converged pass
     unsigned int pass_seq;
     // linearisation outputs, double-buffered: lb[lcur] belongs to x, lb[lcur^1] to the LM candidate (speculative)
@@ -990,8 +992,9 @@ __global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi
         if (lane < 36) {
             const int r = lane/6, cc = lane % 6;
             const double v = tail - tot;
-            W.S[(size_t)(6*ia + r)*N + 6*ic + cc] = v;
-            if (a != c) W.S[(size_t)(6*ic + cc)*N + 6*ia + r] = v;
+            const size_t ldS = (size_t)W.ldS;                // (sb_a <= sb_b: the first store is the upper triangle, which band storage does not hold)
+            if (a == c || !W.band) W.S[(size_t)(6*ia + r)*ldS + 6*ic + cc] = v;
+            if (a != c) W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r] = v;
         }
     } else {
         const int a = b - L.n_sb;
@@ -1237,7 +1240,7 @@ __global__ void k_damp_multi(Work W) {
     int a = blockIdx.x*blockDim.x + threadIdx.x;
     if (a >= W.n_kf) return;
     int ia = W.fidx[a]; if (ia < 0) return;
-    for (int k = 0; k < 6; k++) W.S[(size_t)(6*ia + k)*W.N + 6*ia + k] += B.dgs_p[6*a + k]*irad;
+    for (int k = 0; k < 6; k++) W.S[(size_t)(6*ia + k)*W.ldS + 6*ia + k] += B.dgs_p[6*a + k]*irad;
 }
 // landmark parameters live on their owner: delta = x - x0 on the owner, 0 elsewhere (all-reduced, then x = x0 + delta)
 __global__ void k_delta_multi(Work W, const double *rho0, const double *theta0, int apply) {
@@ -1412,6 +1415,7 @@ struct Ctx {
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
+    double *S_alloc = nullptr; size_t S_count = 0;     // storage behind W.S (dense or band)
     float *lbl_dev = nullptr, *lbl_host = nullptr; size_t lbl_cap = 0;   // text label image staging
     unsigned long long *hprog = nullptr; unsigned int pass_seq = 0;   // pinned progress word written by k_postlin / k_decide
     std::vector<struct Slab> slabs; int cur_slab = 0;
@@ -1657,7 +1661,17 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     }
     AL(W.sig_pt, p->n_pt); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.sig_p, W.N);
     AL(W.cb, 2*(size_t)W.N + 8); AL(W.cbm, 1);
-    AL(W.S, (size_t)(W.N + 1)*W.N); AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
+    {   // reduced camera matrix: dense for the LDS solver; for the large-system Cholesky only its band (rows overlap in a skewed
+        // view: S(i,j) = base[i*(LDB-1) + j], LDB = band + 96 columns of the diagonal block's upper triangle, where the inverse
+        // diagonal factors are kept) -- 80 MB instead of 7.2 GB at 5000 keyframes, and what the ranks all-reduce
+        const int use_lds_ = solve_lds_doubles(W.N)*sizeof(double) <= 160*1024 - 64;        // (as solve_lds_bytes)
+        int bwmax = 0; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
+        const size_t LDB = (size_t)bwmax + 2*CH_NB - 1;
+        if (use_lds_ || LDB >= (size_t)W.N) { c->S_count = (size_t)(W.N + 1)*W.N; AL(c->S_alloc, c->S_count); W.S = c->S_alloc; W.ldS = W.N; W.band = 0; }
+        else { c->S_count = (size_t)W.N*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - CH_NB); W.ldS = (int)LDB - 1; W.band = 1; }
+        AL(W.Sy, W.N);
+    }
+    AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
     AL(W.st, 1);
     flush_run(c);
@@ -1753,10 +1767,10 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);   // block-sparse S
+    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream);   // block-sparse S
     hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(SCHUR_T), 0, c->stream, W, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
-        allreduce(c, W.S, (size_t)W.N*W.N, ncclDouble, ncclSum);
+        allreduce(c, c->S_alloc, c->S_count, ncclDouble, ncclSum);
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
         hipLaunchKernelGGL(k_damp_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
@@ -1948,12 +1962,18 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     launch_pass_init(c, D, 0);
     launch_linearize(c, D, 0);
     Work &W = c->W;
-    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)W.N*W.N, c->stream);
+    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream);
     hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(SCHUR_T), 0, c->stream, W, D, 0);
     launch_solve(c);
     c->opt = saved;
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
-    if (S) CK(hipMemcpy(S, W.S, sizeof(double)*(size_t)W.N*W.N, hipMemcpyDeviceToHost));
+    if (S) {
+        if (!W.band) CK(hipMemcpy(S, W.S, sizeof(double)*(size_t)W.N*W.N, hipMemcpyDeviceToHost));
+        else { std::vector<double> hb(c->S_count); CK(hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost));
+            const long long N = W.N, LDB = W.ldS + 1, Wb = LDB - CH_NB;                  // band -> dense (entries outside the band are zero)
+            for (long long i = 0; i < N; i++) for (long long j = 0; j < N; j++)
+                S[i*N + j] = (j >= i - Wb && j <= i + CH_NB - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
+    }
     if (g) CK(hipMemcpy(g, W.g, sizeof(double)*W.N, hipMemcpyDeviceToHost));
     if (dp) CK(hipMemcpy(dp, W.dp, sizeof(double)*W.N, hipMemcpyDeviceToHost));
     LmState st; CK(hipMemcpy(&st, W.st, sizeof(st), hipMemcpyDeviceToHost));
@@ -2036,7 +2056,14 @@ int tsba_debug_time_solve(void *ctx, int n, double *avg_ms) {     // n back-to-b
 int tsba_debug_copy_S(void *ctx, double *out) {      // (6 n_kf + 1) x (6 n_kf): factored S and the rhs row after a solve
     Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded) return TSBA_ERR_STATE;
     hipSetDevice(c->device); hipStreamSynchronize(c->stream);
-    return hipMemcpy(out, c->W.S, sizeof(double)*(size_t)(c->W.N + 1)*c->W.N, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
+    const Work &W = c->W; const long long N = W.N;
+    if (!W.band) { if (hipMemcpy(out, W.S, sizeof(double)*(size_t)N*N, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE; }
+    else { std::vector<double> hb(c->S_count); if (hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE;
+        const long long LDB = W.ldS + 1, Wb = LDB - CH_NB;
+        for (long long i = 0; i < N; i++) for (long long j = 0; j < N; j++)
+            out[i*N + j] = (j >= i - Wb && j <= i + CH_NB - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
+    // row N = the rhs row: of the large-system solver if that ran, else unused (the LDS solver keeps it on chip)
+    return hipMemcpy(out + (size_t)N*N, W.Sy, sizeof(double)*(size_t)N, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
 }
 
 int tsba_debug_stamps(void *ctx, long long *out64) {

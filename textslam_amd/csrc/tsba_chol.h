@@ -4,7 +4,8 @@
 // below a pose block that can be non-zero (tsba_plan.h: envelope of the S-block list, fill included); every step touches only
 // those rows plus the right-hand-side row, so a 1000-keyframe map with a 24-keyframe band costs ~0.1 GFLOP instead of 72.
 //
-//   S (n x n, ld = N) and the right-hand side g held as row n of the same array (forward substitution rides along).
+//   S (n x n) in band storage -- S(i,j) = S[i*ldS + j] over a skewed view whose rows overlap outside the band -- and the
+//   right-hand side g as an extra row W.Sy (forward substitution rides along).
 //   Right-looking, block size NB = 96 (16 keyframes), per block column:
 //     k_solve_t<true>  1 workgroup: LDL^T of the NB x NB diagonal block in LDS (tsba_solve.h), written back as L D^1/2 (lower),
 //                      and its inverse transposed (strict upper triangle + W.LDbuf for the diagonal)
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(CH_T) void k_chol_panel(Work W, int j0, int bw) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lds = CH_NB + 1;
     double *Wl = sm, *X = sm + CH_NB*lds;                       // W [96][97] (zeros above the diagonal), A rows [64][97]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ld = W.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ld = W.ldS;
     double *A = W.S;
     const int nbp = (nb + 3) & ~3;
     for (int k = tid; k < CH_NB*CH_NB; k += CH_T) {
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(CH_T) void k_chol_panel(Work W, int j0, int bw) {
     for (int k = tid; k < 64*nbp; k += CH_T) {
         const int r = k / nbp, c = k - r*nbp, rl = R0 + r;
         const int gi = rl < wr ? c0 + rl : n;
-        X[r*lds + c] = (c < nb && rl <= wr) ? A[(size_t)gi*ld + j0 + c] : 0.0;
+        X[r*lds + c] = (c < nb && rl <= wr) ? (gi == n ? W.Sy : A + (size_t)gi*ld)[j0 + c] : 0.0;
     }
     __syncthreads();
     // wave w: rows 16w..16w+15, all 6 column tiles; X[i][c] = sum_{k <= c} A[i][k] W[c][k]
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(CH_T) void k_chol_panel(Work W, int j0, int bw) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int rl = R0 + 16*wave + lk + 4*r, c = 16*t + lr;
-            if (rl <= wr && c < nb) { const int gi = rl < wr ? c0 + rl : n; A[(size_t)gi*ld + j0 + c] = acc[t][r]; }
+            if (rl <= wr && c < nb) { const int gi = rl < wr ? c0 + rl : n; (gi == n ? W.Sy : A + (size_t)gi*ld)[j0 + c] = acc[t][r]; }
         }
 }
 
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0, int bw) {
     if (ti >= ntile) return;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Pa = sm, *Pb = sm + 64*(CH_NB + 1);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ld = W.N, lds = CH_NB + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ld = W.ldS, lds = CH_NB + 1;
     double *A = W.S;
     const int r0 = 64*ti, q0 = 64*tj;                           // local
     const int nbp = (nb + 3) & ~3;                              // K padded to the MFMA depth with exact zeros
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0, int bw) {
         int r = k / nbp, c = k - r*nbp;
         const int rl = r0 + r, ql = q0 + r;
         const int gr = rl < wr ? c0 + rl : n;
-        Pa[r*lds + c] = (c < nb && rl <= wr) ? A[(size_t)gr*ld + j0 + c] : 0.0;
+        Pa[r*lds + c] = (c < nb && rl <= wr) ? (gr == n ? W.Sy : A + (size_t)gr*ld)[j0 + c] : 0.0;
         Pb[r*lds + c] = (c < nb && ql < wr) ? A[(size_t)(c0 + ql)*ld + j0 + c] : 0.0;
     }
     __syncthreads();
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(CH_T) void k_chol_update(Work W, int j0, int bw) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int rl = r0 + wrw + 16*a + lk + 4*r, ql = q0 + wc + 16*b + lr;
-                if (rl <= wr && ql < wr && (rl == wr || ql <= rl)) { const int gr = rl < wr ? c0 + rl : n; A[(size_t)gr*ld + c0 + ql] -= acc[a][b][r]; }
+                if (rl <= wr && ql < wr && (rl == wr || ql <= rl)) { const int gr = rl < wr ? c0 + rl : n; (gr == n ? W.Sy : A + (size_t)gr*ld)[c0 + ql] -= acc[a][b][r]; }
             }
 }
 
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(Work W, int bw) {
     LmState *st = W.st;
     if (st->done) return;
     const int n = 6 * *W.nfree;
-    const int tid = threadIdx.x, ld = W.N;
-    double *A = W.S, *y = W.S + (size_t)n*ld;
+    const int tid = threadIdx.x, ld = W.ldS;
+    double *A = W.S, *y = W.Sy;
     if (st->step_fail) { for (int k = tid; k < W.N; k += 1024) W.dp[k] = 0.0; return; }
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Wt = sm, *ys = sm + CH_NB*(CH_NB + 1), *xs = ys + CH_NB, *part = xs + CH_NB;      // Wt[c][r] = W[r][c]; part [8][96]
@@ -167,12 +168,15 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(Work W, int bw) {
         }
         __syncthreads();
         // rows j0..j0+nb-1 of L reach back at most bw + 2 NB columns (column block J holds rows up to J + NB - 1 + bw)
-        const int k0 = max(0, j0 - bw - 2*CH_NB);
+        // L[i][k] is stored (and can be non-zero) only for i - k <= Wb = bw + NB - 1: with band storage anything further left
+        // aliases another row, so both the column range and, per column, the row range are cut there
+        const int Wb = bw + CH_NB - 1, k0 = max(0, j0 - Wb);
         for (int k = k0 + tid; k < j0; k += 1024) {
+            const int cmax = min(nb, k + Wb - j0 + 1);
             double v0 = 0.0, v1 = 0.0;
             int c = 0;
-            for (; c + 1 < nb; c += 2) { v0 = fma(A[(size_t)(j0 + c)*ld + k], xs[c], v0); v1 = fma(A[(size_t)(j0 + c + 1)*ld + k], xs[c + 1], v1); }
-            if (c < nb) v0 = fma(A[(size_t)(j0 + c)*ld + k], xs[c], v0);
+            for (; c + 1 < cmax; c += 2) { v0 = fma(A[(size_t)(j0 + c)*ld + k], xs[c], v0); v1 = fma(A[(size_t)(j0 + c + 1)*ld + k], xs[c + 1], v1); }
+            if (c < cmax) v0 = fma(A[(size_t)(j0 + c)*ld + k], xs[c], v0);
             y[k] -= v0 + v1;
         }
         __syncthreads();
@@ -188,5 +192,5 @@ __global__ void k_chol_rhs(Work W) {
     if (W.st->done) return;
     const int n = 6 * *W.nfree;
     int k = blockIdx.x*blockDim.x + threadIdx.x;
-    if (k < n) W.S[(size_t)n*W.N + k] = W.g[k];
+    if (k < n) W.Sy[k] = W.g[k];
 }

@@ -118,14 +118,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
     // the element addresses do not depend on the number of free poses: the first round of loads is issued together with the
     // loads of the solver state (one global round trip instead of two)
     const int neMax = DIAG ? tri(SOLVE_DIAG_NB) : tri(Nmax);
-    const double *Sb = DIAG ? W.S + (size_t)B0*Nmax + B0 : W.S;
+    const size_t ldS = (size_t)W.ldS;
+    const double *Sb = DIAG ? W.S + (size_t)B0*ldS + B0 : W.S;
     const int rmax = DIAG ? Nmax - 1 - B0 : Nmax - 1;           // (the last block of a large system may be short)
     double v[12]; int er[12], ec[12];
 #pragma unroll
     for (int u = 0; u < 12; u++) {
         const int e = min(u*SOLVE_THREADS + tid, neMax - 1);
         er[u] = tri_row(e); ec[u] = e - tri(er[u]);
-        v[u] = Sb[(size_t)min(er[u], rmax)*Nmax + min(ec[u], rmax)];
+        v[u] = Sb[(size_t)min(er[u], rmax)*ldS + min(ec[u], rmax)];
     }
     const int done = st->done, nfree_all = *W.nfree, sfail = st->step_fail;
     if (done) return;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
         for (int u = 0; u < 12; u++) {
             const int e = min(base + u*SOLVE_THREADS + tid, ne - 1);
             er[u] = tri_row(e); ec[u] = e - tri(er[u]);
-            v[u] = Sb[(size_t)er[u]*Nmax + ec[u]];
+            v[u] = Sb[(size_t)er[u]*ldS + ec[u]];
         }
 #pragma unroll
         for (int u = 0; u < 12; u++) if (base + u*SOLVE_THREADS + tid < ne) A[rowoff(er[u]) + ec[u]] = v[u];
@@ -310,12 +311,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
             __syncthreads();
         }
         // ---- write back: lower triangle L D^1/2, strict upper triangle (L D^1/2)^-T, diagonal of the inverse to LDbuf
-        double *Sw = W.S + (size_t)B0*Nmax + B0;
+        double *Sw = W.S + (size_t)B0*ldS + B0;
         for (int t = tid; t < n*n; t += SOLVE_THREADS) {
             const int r = t/n, c = t - r*n;
-            if (c < r) Sw[(size_t)r*Nmax + c] = A[rowoff(r) + c]*sq[c];
-            else if (c == r) { Sw[(size_t)r*Nmax + c] = sq[c]; W.LDbuf[B0 + r] = 1.0/sq[r]; }
-            else Sw[(size_t)r*Nmax + c] = Mi[rowoff(c) + r]/sq[c];          // W^T[r][c] = W[c][r] = M[c][r] / sqrt(d_c)
+            if (c < r) Sw[(size_t)r*ldS + c] = A[rowoff(r) + c]*sq[c];
+            else if (c == r) { Sw[(size_t)r*ldS + c] = sq[c]; W.LDbuf[B0 + r] = 1.0/sq[r]; }
+            else Sw[(size_t)r*ldS + c] = Mi[rowoff(c) + r]/sq[c];          // W^T[r][c] = W[c][r] = M[c][r] / sqrt(d_c)
         }
         return;
     }
