@@ -415,24 +415,50 @@ __global__ __launch_bounds__(LBL_THREADS) void k_label(Work W, int kf, int w, in
 // ---- linearisation / cost.  grid = n_pair (scene waves) + n_tg (text waves), 64 threads each.
 #define MODE_FULL 0
 #define MODE_COST 1
+// transpose-sum of N <= 28 per-lane values of ONE wave inside a two-wave workgroup: lane l (< N) returns the total of acc[l].
+// reg: this wave's 28*65 doubles.  Both waves of the workgroup must call it (two workgroup barriers).
+template <int N>
+__device__ __forceinline__ double wave_sum_to_lane_mw(const double *acc, double *reg, int lane) {
+#pragma unroll
+    for (int i = 0; i < N; i++) reg[i*65 + lane] = acc[i];
+    __syncthreads();
+    double s = 0.0;
+    if (lane < N) {
+        const double *row = reg + lane*65;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 64; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
+        s = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    return s;
+}
+// 128-thread workgroups: a scene workgroup takes two (target, host) pairs (one per wave); a text workgroup one (KF, text)
+// observation with every feature on TWO lanes (4 taps each): the text lanes' instruction stream (~450 instructions per tap at
+// one instruction per ~4.5 cycles) is what bounds the kernel.  <= 256 VGPRs so that all ~730 workgroups of C4 are resident at once.
+#define LIN_T 128
 template <int MODE>
-__global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) {
+__global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int spec) {
     // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
     const LmState *st = W.st;
-    __shared__ double lds[55*65];
+    __shared__ double lds[2*28*65 + 2*64];
+    __shared__ int4 s_px[4*LIN_T];                          // the text path's pixel quads: indexed by tap at run time (not registers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *reg = lds + wave*28*65, *xw = lds + 2*28*65;
     // static indices of this workgroup first: in flight together with the LM state
-    const int bq = blockIdx.x;
+    const int nb_sc = (L.n_pair + 1) >> 1;
+    const int bq = blockIdx.x, pr = 2*bq + wave, prc = min(pr, max(L.n_pair - 1, 0));
     int pi = 0, ph = 0, pbeg = 0, pend = 0, tgpp = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
-    if (bq < L.n_pair) { pi = L.pair_i[bq]; ph = L.pair_h[bq]; pbeg = L.pair_sc_off[bq]; pend = L.pair_sc_off[bq+1]; }
-    else { ra = ((const int4 *)L.tg_rec)[2*(bq - L.n_pair)]; rb = ((const int4 *)L.tg_rec)[2*(bq - L.n_pair) + 1]; tgpp = L.tg_ppos[bq - L.n_pair]; }   // one static record per group
+    if (bq < nb_sc) { pi = L.pair_i[prc]; ph = L.pair_h[prc]; pbeg = L.pair_sc_off[prc]; pend = pr < L.n_pair ? L.pair_sc_off[prc+1] : pbeg; }
+    else { ra = ((const int4 *)L.tg_rec)[2*(bq - nb_sc)]; rb = ((const int4 *)L.tg_rec)[2*(bq - nb_sc) + 1]; tgpp = L.tg_ppos[bq - nb_sc]; }   // one static record per group
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
     const int sel = spec ? (st->cur ^ 1) : st->cur;
     const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
     const double *pose = W.pose[sel], *rho = W.rho[sel], *theta = W.theta[sel];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b < L.n_pair) {
+    const int b = blockIdx.x;
+    if (b < nb_sc) {
         // ---------------- scene observations of pair (i, h)
         const int i = pi, h = ph;
         Pose C; load_pose(pose + 7*i, C);
@@ -443,28 +469,20 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
 #pragma unroll
         for (int k = 0; k < 28; k++) acc[k] = 0.0;
         const int beg = pbeg, end = pend;
+#pragma unroll 1
         for (int c = beg + lane; c < end; c += 64) {
-            const int slot = L.sc_slot[c];
-            bool act = !fixed && (!W.filter_good || W.sgood[L.sc_flag[c]]);
-            if (!act) {
-                if (MODE == MODE_FULL && slot >= 0) {
+            const int slot = L.sc_slot[c], pt = L.sc_pt[c];
+            const bool act = !fixed && (!W.filter_good || W.sgood[L.sc_flag[c]]);
+            // the slot record of an inactive candidate is zeros: one store sequence for both cases (a second, branchy one
+            // costs the kernel ~170 VGPRs of live ranges)
+            double wv[14];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) B.w_pt[(size_t)(slot)*PT_REC + k] = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) B.w_pt[(size_t)(slot)*PT_REC + 6 + k] = 0.0;
-                }
-                continue;
-            }
-            const int pt = L.sc_pt[c];
-            if (h < 0) pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
-            double mx = W.pt_ray[2*pt], my = W.pt_ray[2*pt+1], rh = rho[pt];
-            double uo = L.sc_uv[2*c], vo = L.sc_uv[2*c+1];
-            double r[2];
-            if (MODE == MODE_COST) {
-                scene_residual(T, C.t, mx, my, rh, uo, vo, W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r);
-                double wgt; acc[27] += 0.5*huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
-            } else {
-                double jt[2][6], jl[2];
+            for (int k = 0; k < 14; k++) wv[k] = 0.0;
+            if (act) {
+                if (h < 0) pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+                const double mx = W.pt_ray[2*pt], my = W.pt_ray[2*pt+1], rh = rho[pt];
+                const double uo = L.sc_uv[2*c], vo = L.sc_uv[2*c+1];
+                double r[2], jt[2][6], jl[2];
                 scene_block(T, C.t, mx, my, rh, uo, vo, W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r, jt, jl);
                 double wgt; acc[27] += 0.5*huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
                 int q = 0;
@@ -474,43 +492,47 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
                     for (int cc = a; cc < 6; cc++) { acc[q] += wgt*(jt[0][a]*jt[0][cc] + jt[1][a]*jt[1][cc]); q++; }
 #pragma unroll
                 for (int a = 0; a < 6; a++) acc[21 + a] += wgt*(jt[0][a]*r[0] + jt[1][a]*r[1]);
-                if (slot >= 0) {
-                    double w[6];
 #pragma unroll
-                    for (int a = 0; a < 6; a++) { w[a] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]); B.w_pt[(size_t)(slot)*PT_REC + a] = w[a]; }
-                    B.w_pt[(size_t)slot*PT_REC + 6] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
-                    B.w_pt[(size_t)slot*PT_REC + 7] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
-                    double qa[3], qc[3]; mat3T_vec(T.Rcr, w, qa); mat3T_vec(T.Rcr, w + 3, qc);     // host column: -Q^T w
+                for (int a = 0; a < 6; a++) wv[a] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]);
+                wv[6] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
+                wv[7] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
+                double qa[3], qc[3]; mat3T_vec(T.Rcr, wv, qa); mat3T_vec(T.Rcr, wv + 3, qc);     // host column: -Q^T w
 #pragma unroll
-                    for (int a = 0; a < 3; a++) { B.w_pt[(size_t)(slot)*PT_REC + 6 + (2 + a)] = -qa[a]; B.w_pt[(size_t)(slot)*PT_REC + 6 + (5 + a)] = -qc[a]; }
-                }
+                for (int a = 0; a < 3; a++) { wv[8 + a] = -qa[a]; wv[11 + a] = -qc[a]; }
+            }
+            if (slot >= 0) {
+#pragma unroll
+                for (int k = 0; k < 14; k++) B.w_pt[(size_t)(slot)*PT_REC + k] = wv[k];
             }
         }
         if (MODE == MODE_COST) {
             double cs = wave_sum1(acc[27]);
-            if (lane == 0) B.pairCost[b] = cs;
+            if (lane == 0 && pr < L.n_pair) B.pairCost[pr] = cs;
         } else {
-            double tot = wave_sum_to_lane<28>(acc, lds, lane);
-            if (lane < 27) B.pairM[(size_t)lane*L.n_pair + b] = tot;
-            else if (lane == 27) B.pairCost[b] = tot;
-            if (h >= 0 && lane == 0) {
+            double tot = wave_sum_to_lane_mw<28>(acc, reg, lane);
+            if (pr < L.n_pair) {
+                if (lane < 27) B.pairM[(size_t)lane*L.n_pair + pr] = tot;
+                else if (lane == 27) B.pairCost[pr] = tot;
+                if (h >= 0 && lane == 0) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) B.pairR[(size_t)k*L.n_pair + b] = T.Rcr[k];
+                    for (int k = 0; k < 9; k++) B.pairR[(size_t)k*L.n_pair + pr] = T.Rcr[k];
+                }
             }
         }
     } else {
-        // ---------------- photometric blocks of one (KF, text) observation
-        const int g = b - L.n_pair;
+        // ---------------- photometric blocks of one (KF, text) observation: thread = (feature tid >> 1, tap quad tid & 1)
+        const int g = b - nb_sc;
         const int tb = ra.x, i = ra.y, j = ra.z, h = ra.w, slot = rb.x, f0 = rb.y, f1 = rb.z, fg = rb.w;
         const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
         const bool act_g = (!W.filter_good || W.tobs_good[tb]) && !((h < 0) && W.kf_const[i]) && sigma != 0.0;
-        // static data of this lane's first feature: fetched together with the level-2 operands, not after them
-        int f = f0 + lane, raw = 0; double fu = 0.0, fv = 0.0, refv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // static data of this thread's first feature: fetched together with the level-2 operands, not after them
+        const int fl = tid >> 1, tp = tid & 1;
+        int f = f0 + fl, raw = 0; double fu = 0.0, fv = 0.0, refv[4] = {0, 0, 0, 0};
         if (f1 > f0) {
             const int fc = min(f, f1 - 1);
             raw = L.tfeat_raw[fc]; fu = L.tfeat_uv[2*fc]; fv = L.tfeat_uv[2*fc+1];
 #pragma unroll
-            for (int k = 0; k < 8; k++) refv[k] = L.tfeat_ref[8*(size_t)fc + k];
+            for (int k = 0; k < 4; k++) refv[k] = L.tfeat_ref[8*(size_t)fc + 4*tp + k];
         }
         PairT T;
         // poses / plane / image pointer do not wait for the activity test (h is known from the record)
@@ -521,78 +543,91 @@ __global__ __launch_bounds__(64) void k_linearize(Work W, LevelDev L, int spec) 
         const uint8_t *img = L.img[i];
         const double inv_sigma = 1.0/sigma;
         const double ifx = 1.0/L.K[0], ify = 1.0/L.K[1];
-        double tot = 0.0;                       // lane l < 55: running total of value l
-        {
-            // chunks of 64 features (one chunk unless the plane has more).  One accumulator set only: the weighted block of the
-            // lane's feature is reduced per chunk, so that blk + the 8 pixel quads stay inside the 256 architectural VGPRs
-            // (a second accumulator set spills into AGPRs: a fifth of the instructions were v_accvgpr moves)
-            for (int fb = f0; fb == f0 || fb < f1; fb += 64, f += 64) {
-                double blk[55];
+        double tot = 0.0;                       // lane l < 55 of wave 0: running total of value l
+        // chunks of 64 features (one chunk unless the plane has more).  One accumulator set only: the weighted block of the
+        // thread's half feature is reduced per chunk, so that it stays inside the architectural VGPRs
+        for (int fb = f0; fb == f0 || fb < f1; fb += 64, f += 64) {
+            double blk[55];
 #pragma unroll
-                for (int k = 0; k < 55; k++) blk[k] = 0.0;
-                if (act_g && f < f1) {
-                    if (fb != f0) {
-                        raw = L.tfeat_raw[f]; fu = L.tfeat_uv[2*f]; fv = L.tfeat_uv[2*f+1];
+            for (int k = 0; k < 55; k++) blk[k] = 0.0;
+            if (act_g) {                                               // (uniform; the shuffle below needs both lanes of a feature)
+                const bool in = f < f1;
+                if (fb != f0 && in) {
+                    raw = L.tfeat_raw[f]; fu = L.tfeat_uv[2*f]; fv = L.tfeat_uv[2*f+1];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) refv[k] = L.tfeat_ref[8*(size_t)f + k];
-                    }
-                    const uint8_t good = W.filter_good ? W.tfgood[fg + raw] : 1;       // in flight with the pixel fetches
-                    // all 16 pixel-pair fetches of the feature in flight before the first residual
-                    TapPx px[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const double mx = (fu + TAP_DX[k] - L.K[2])*ifx, my = (fv + TAP_DY[k] - L.K[3])*ify;   // tool.cc:1561
-                        px[k] = tap_fetch(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h);
-                    }
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const double mx = (fu + TAP_DX[k] - L.K[2])*ifx, my = (fv + TAP_DY[k] - L.K[3])*ify;
-                        double jt[6], jl[3];
-                        double r = text_tap_px(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], px[k], L.img_w, L.img_h,
-                                               mu, sigma, inv_sigma, refv[k], W.w_t, true, jt, jl);
-                        s += r*r;
-                        int q = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; a++)
-#pragma unroll
-                            for (int cc = a; cc < 6; cc++) { blk[q] += jt[a]*jt[cc]; q++; }
-#pragma unroll
-                        for (int a = 0; a < 6; a++) blk[21 + a] += jt[a]*r;
-#pragma unroll
-                        for (int a = 0; a < 6; a++)
-#pragma unroll
-                            for (int cc = 0; cc < 3; cc++) blk[27 + a*3 + cc] += jt[a]*jl[cc];
-                        blk[45] += jl[0]*jl[0]; blk[46] += jl[0]*jl[1]; blk[47] += jl[0]*jl[2];
-                        blk[48] += jl[1]*jl[1]; blk[49] += jl[1]*jl[2]; blk[50] += jl[2]*jl[2];
-                        blk[51] += jl[0]*r; blk[52] += jl[1]*r; blk[53] += jl[2]*r;
-                        __builtin_amdgcn_sched_barrier(0);              // one tap at a time: interleaved taps do not fit the register file
-                    }
-                    double wgt; const double rho_h = 0.5*huber(s, W.huber_t, wgt);
-                    const double wg = good ? wgt : 0.0;
-#pragma unroll
-                    for (int k = 0; k < 54; k++) blk[k] *= wg;
-                    blk[54] = good ? rho_h : 0.0;
+                    for (int k = 0; k < 4; k++) refv[k] = L.tfeat_ref[8*(size_t)f + 4*tp + k];
                 }
-                tot += wave_sum_to_lane<55>(blk, lds, lane);
+                const uint8_t good = in ? (W.filter_good ? W.tfgood[fg + raw] : (uint8_t)1) : (uint8_t)0;   // in flight with the pixel fetches
+                // the 8 pixel-pair fetches of the thread's 4 taps in flight before the first residual; the quads wait in LDS so that
+                // the residual loop can stay rolled (unrolled, its live state does not fit 256 VGPRs and spills to scratch)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int kt = 4*tp + k;
+                    const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;   // tool.cc:1561
+                    const TapPx q = tap_fetch(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h);
+                    s_px[k*LIN_T + tid] = make_int4(q.I00, q.I01, q.I10, q.I11);
+                }
+                double s = 0.0;
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {
+                    const int kt = 4*tp + k;
+                    const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;
+                    const int4 q4 = s_px[k*LIN_T + tid];
+                    const TapPx pxk = { q4.x, q4.y, q4.z, q4.w };
+                    const double rf = k == 0 ? refv[0] : k == 1 ? refv[1] : k == 2 ? refv[2] : refv[3];
+                    double jt[6], jl[3];
+                    double r = text_tap_px(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], pxk, L.img_w, L.img_h,
+                                           mu, sigma, inv_sigma, rf, W.w_t, true, jt, jl);
+                    s += r*r;
+                    int q = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+#pragma unroll
+                        for (int cc = a; cc < 6; cc++) { blk[q] += jt[a]*jt[cc]; q++; }
+#pragma unroll
+                    for (int a = 0; a < 6; a++) blk[21 + a] += jt[a]*r;
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+#pragma unroll
+                        for (int cc = 0; cc < 3; cc++) blk[27 + a*3 + cc] += jt[a]*jl[cc];
+                    blk[45] += jl[0]*jl[0]; blk[46] += jl[0]*jl[1]; blk[47] += jl[0]*jl[2];
+                    blk[48] += jl[1]*jl[1]; blk[49] += jl[1]*jl[2]; blk[50] += jl[2]*jl[2];
+                    blk[51] += jl[0]*r; blk[52] += jl[1]*r; blk[53] += jl[2]*r;
+                }
+                const double s8 = s + __shfl_xor(s, 1, 64);         // the block's squared norm: its 8 taps sit on 2 neighbouring lanes
+                double wgt; const double rho_h = 0.5*huber(s8, W.huber_t, wgt);
+                const double wg = good ? wgt : 0.0;
+#pragma unroll
+                for (int k = 0; k < 54; k++) blk[k] *= wg;
+                blk[54] = (good && tp == 0) ? rho_h : 0.0;
             }
-            if (lane < 27) B.tgM[(size_t)lane*L.n_tg + tgpp] = tot;          // pair-major rank: k_mid sums a contiguous range
-            else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; lds[lane - 27] = tot; }
-            else if (lane < 54) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + 18 + (lane - 45)] = tot; }
-            else if (lane == 54) B.tgCost[g] = tot;
-            if (slot >= 0) {                    // host column of W: -blkdiag(R,R)^T W, rows (half, r), columns cc
-                if (lane < 9) {
-                    double rv = T.Rcr[0];
+            // 55 sums over the 128 threads: per wave two transposes (28 + 27 values), then the two waves
+            const double t0 = wave_sum_to_lane_mw<28>(blk, reg, lane);
+            const double t1 = wave_sum_to_lane_mw<27>(blk + 28, reg, lane);
+            if (lane < 28) xw[wave*64 + lane] = t0;
+            if (lane < 27) xw[wave*64 + 28 + lane] = t1;
+            __syncthreads();
+            if (lane < 55) tot += xw[lane] + xw[64 + lane];
+            __syncthreads();
+        }
+        if (wave > 0) return;
+        // wave 0 alone from here (LDS accesses of one wave are ordered; the fence keeps the compiler honest)
+        if (lane < 27) B.tgM[(size_t)lane*L.n_tg + tgpp] = tot;          // pair-major rank: k_mid sums a contiguous range
+        else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; lds[lane - 27] = tot; }
+        else if (lane < 54) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + 18 + (lane - 45)] = tot; }
+        else if (lane == 54) B.tgCost[g] = tot;
+        if (slot >= 0) {                    // host column of W: -blkdiag(R,R)^T W, rows (half, r), columns cc
+            if (lane < 9) {
+                double rv = T.Rcr[0];
 #pragma unroll
-                    for (int q = 1; q < 9; q++) if (lane == q) rv = T.Rcr[q];
-                    lds[32 + lane] = act_g ? rv : 0.0;
-                }
-                __syncthreads();
-                if (lane < 18) {
-                    const int half = lane/9, rr = (lane % 9)/3, cc = lane % 3;
-                    double v = lds[32 + 0*3 + rr]*lds[(half*3 + 0)*3 + cc] + lds[32 + 1*3 + rr]*lds[(half*3 + 1)*3 + cc] + lds[32 + 2*3 + rr]*lds[(half*3 + 2)*3 + cc];
-                    B.w_tx[(size_t)(slot)*TX_REC + 18 + (9 + lane)] = -v;
-                }
+                for (int q = 1; q < 9; q++) if (lane == q) rv = T.Rcr[q];
+                lds[32 + lane] = act_g ? rv : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 18) {
+                const int half = lane/9, rr = (lane % 9)/3, cc = lane % 3;
+                double v = lds[32 + 0*3 + rr]*lds[(half*3 + 0)*3 + cc] + lds[32 + 1*3 + rr]*lds[(half*3 + 1)*3 + cc] + lds[32 + 2*3 + rr]*lds[(half*3 + 2)*3 + cc];
+                B.w_tx[(size_t)(slot)*TX_REC + 18 + (9 + lane)] = -v;
             }
         }
     }
@@ -1722,7 +1757,7 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
 static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
-    if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, W, D, spec);
+    if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
     if (multi) {
@@ -1998,7 +2033,7 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     st.need_lin = 1; st.done = 0; st.first = 0;
     CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));   // k_linearize never clears need_lin itself
     CK(hipEventRecord(c->ev0, c->stream));
-    for (int k = 0; k < n; k++) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, c->W, D, 0);
+    for (int k = 0; k < n; k++) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
     CK(hipEventRecord(c->ev1, c->stream));
     CK(hipEventSynchronize(c->ev1));
     float ms = 0; CK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
