@@ -94,6 +94,14 @@ __global__ void k_resize(OrbDev D, int l) {
 }
 
 // ---------------------------------------------------------------- FAST per cell
+// quick reject: 9 contiguous ring pixels always contain at least two of the four compass points
+__device__ __forceinline__ bool fast_maybe(const uint8_t *p, int stride, int threshold) {
+    const int v = p[0];
+    const int d0 = v - p[3*stride], d4 = v - p[3], d8 = v - p[-3*stride], d12 = v - p[-3];
+    const int nb = (d0 > threshold) + (d4 > threshold) + (d8 > threshold) + (d12 > threshold);
+    const int nd = (d0 < -threshold) + (d4 < -threshold) + (d8 < -threshold) + (d12 < -threshold);
+    return nb >= 2 || nd >= 2;
+}
 __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int threshold) {     // 0 = not a corner
     const int cx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
     const int cy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
@@ -132,10 +140,13 @@ __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int thre
     }
     return -b0 - 1;
 }
+#define FAST_NCH (((TILE_MAX - 6)*(TILE_MAX - 6) + 255)/256)      /* chunks of 256 inner pixels of the largest cell */
 __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     __shared__ uint8_t tile[TILE_MAX*TILE_MAX];
     __shared__ short score[TILE_MAX*TILE_MAX];
-    __shared__ int s_cnt, s_wsum[4];
+    __shared__ int s_cnt, s_ncand, s_wcnt[4*FAST_NCH];
+    __shared__ unsigned short s_cand[(TILE_MAX - 6)*(TILE_MAX - 6)];
+    __shared__ unsigned char s_below[256*FAST_NCH];
     const int f = blockIdx.x / D.cells_per_frame, cidx = blockIdx.x % D.cells_per_frame, tid = threadIdx.x;
     int l = 0;
     while (l + 1 < D.nlevels && cidx >= D.L[l+1].cell0) l++;
@@ -155,40 +166,57 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     __syncthreads();
     const int iw = rw - 6, ih = rh - 6;             // inner pixels (3-px margin)
     uint32_t *out = D.cellkp + ((size_t)f*D.cells_per_frame + cidx)*CELL_CAP;
+    // ONE scoring pass at the fallback threshold: cornerScore is the largest threshold the pixel still passes at (minus one), so
+    // "corner at iniTh" is score >= iniTh, and a corner at iniTh beats every neighbour that is not one (their score is below
+    // iniTh) -- the 3x3 maximum test on the full score map selects exactly what cv::FAST(iniTh) + NMS selects.
+    const float inv_rw = 1.0f/(float)rw, inv_iw = 1.0f/(float)iw;
+    for (int k = tid; k < rw*rh; k += 256) { const int y = (int)(((float)k + 0.5f)*inv_rw); score[y*TILE_MAX + (k - y*rw)] = 0; }
+    __syncthreads();
+    const int npx = iw*ih, nch = (npx + 255) >> 8;
+    // the full arc test + cornerScore are ~200 instructions and a wave runs them for all 64 lanes if one needs them: first a
+    // 4-pixel quick reject over all inner pixels, the survivors' tile positions compacted into a list, then the full test on the
+    // list with every lane busy (the order of the list is irrelevant: scores go to the score map by position)
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+    for (int k = tid; k < npx; k += 256) { const int yy = (int)(((float)k + 0.5f)*inv_iw), pos = (3 + yy)*TILE_MAX + 3 + k - yy*iw;
+        if (fast_maybe(tile + pos, TILE_MAX, D.min_th)) s_cand[atomicAdd(&s_ncand, 1)] = (unsigned short)pos; }
+    __syncthreads();
+    for (int k = tid; k < s_ncand; k += 256) { const int pos = s_cand[k]; score[pos] = (short)fast_score(tile + pos, TILE_MAX, D.min_th); }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
     for (int pass = 0; pass < 2; pass++) {
-        const int th = pass == 0 ? D.ini_th : D.min_th;
-        for (int k = tid; k < rw*rh; k += 256) score[(k / rw)*TILE_MAX + (k % rw)] = 0;
-        __syncthreads();
-        for (int k = tid; k < iw*ih; k += 256) { int y = 3 + k / iw, x = 3 + k % iw;
-            score[y*TILE_MAX + x] = (short)fast_score(tile + y*TILE_MAX + x, TILE_MAX, th); }
-        __syncthreads();
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        // 3x3 non-maximum suppression + row-major ordered compaction (chunks of 256 pixels)
-        for (int base = 0; base < iw*ih; base += 256) {
-            const int k = base + tid;
-            bool keep = false; int x = 0, y = 0, s = 0;
-            if (k < iw*ih) {
-                y = 3 + k / iw; x = 3 + k % iw; s = score[y*TILE_MAX + x];
-                if (s > 0) {
-                    const short *q = score + y*TILE_MAX + x;
-                    keep = s > q[-TILE_MAX-1] && s > q[-TILE_MAX] && s > q[-TILE_MAX+1] && s > q[-1] && s > q[1] &&
-                           s > q[TILE_MAX-1] && s > q[TILE_MAX] && s > q[TILE_MAX+1];
-                }
+        const int th = pass == 0 ? D.ini_th : 1;
+        // 3x3 non-maximum suppression; row-major ordered compaction: chunk c = pixels [256c, 256c + 256), one ballot per wave
+        unsigned keepm = 0;
+        for (int c = 0; c < nch; c++) {
+            const int k = (c << 8) + tid;
+            bool keep = false;
+            if (k < npx) {
+                const int yy = (int)(((float)k + 0.5f)*inv_iw), y = 3 + yy, x = 3 + k - yy*iw;
+                const short *q = score + y*TILE_MAX + x; const int sc = q[0];
+                keep = sc >= th && sc > q[-TILE_MAX-1] && sc > q[-TILE_MAX] && sc > q[-TILE_MAX+1] && sc > q[-1] && sc > q[1] &&
+                       sc > q[TILE_MAX-1] && sc > q[TILE_MAX] && sc > q[TILE_MAX+1];
             }
             const unsigned long long m = __ballot(keep);
-            const int lane = tid & 63, wv = tid >> 6;
-            if (lane == 0) s_wsum[wv] = __popcll(m);
-            __syncthreads();
-            int off = s_cnt;
-            for (int q = 0; q < wv; q++) off += s_wsum[q];
-            off += __popcll(m & ((1ull << lane) - 1ull));
-            if (keep && off < CELL_CAP) out[off] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)s << 16);
-            __syncthreads();
-            if (tid == 0) s_cnt += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-            __syncthreads();
+            if (lane == 0) s_wcnt[c*4 + wv] = __popcll(m);
+            if (keep) keepm |= (1u << c) ;
+            s_below[c*256 + tid] = (unsigned char)__popcll(m & ((1ull << lane) - 1ull));
         }
-        if (s_cnt > 0) break;                       // uniform: s_cnt is shared
+        __syncthreads();
+        int run = 0;
+        for (int c = 0; c < nch; c++) {
+            int off = run;
+            for (int q = 0; q < wv; q++) off += s_wcnt[c*4 + q];
+            if ((keepm >> c) & 1u) {
+                off += s_below[c*256 + tid];
+                const int k = (c << 8) + tid, yy = (int)(((float)k + 0.5f)*inv_iw), y = 3 + yy, x = 3 + k - yy*iw;
+                if (off < CELL_CAP) out[off] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)score[y*TILE_MAX + x] << 16);
+            }
+            run += s_wcnt[c*4] + s_wcnt[c*4 + 1] + s_wcnt[c*4 + 2] + s_wcnt[c*4 + 3];
+        }
+        if (tid == 0) s_cnt = run;
+        __syncthreads();
+        if (run > 0) break;                         // uniform: every thread computed the same total
     }
     if (tid == 0) *cnt_out = min(s_cnt, CELL_CAP);
 }
