@@ -347,3 +347,49 @@ def test_label_image_against_point_in_polygon(oracle_lib):
                 elif ins: top = r
             if not ambiguous:
                 assert lab[y, x] == float(top), (kf, x, y, lab[y, x], top)
+
+
+def test_lm_optimum_matches_scipy_least_squares(oracle_lib):
+    """Independent optimiser on the oracle's literal residual functors: scipy's trust-region least squares (a different LM
+    implementation, dense finite-difference Jacobian, ambient quaternion parameters) reaches the same minimum as the oracle's
+    Ceres-style LM with the analytic tangent-space Jacobians -- noisy scene observations, hosts inside and outside the window,
+    loss switched off (scipy's robust losses act per scalar residual, Ceres' per block).  Scene blocks only: the solver holds
+    mu / sigma of a text pair fixed within a pass (optimizer.cc:1490-1504) while a plain re-evaluation recomputes them."""
+    from scipy.optimize import least_squares
+    P = synth.tiny(seed=11, n_kf=5, n_pt=80, n_text=0)
+    o = abi.options_local(); o.use_text = 0
+    o.n_passes = 1; o.levels[0] = 0; o.its[0] = 60
+    o.huber_scene = 1e9; o.huber_text = 1e9; o.outlier_scene = 0; o.outlier_text = 0
+    o.function_tolerance = 1e-15; o.parameter_tolerance = 1e-15
+    Q = P.copy()
+    oracle_lib.solve(Q, o)
+    free = [int(k) for k in np.nonzero(oracle_lib.reduced_system(P, o, 0, 1e4)["free_idx"] >= 0)[0]]      # gauge as the solver fixes it
+    assert 1 <= len(free) < P.n_kf
+
+    pts = np.nonzero(P.pt_host >= 0)[0]; txs = np.nonzero(P.text_host >= 0)[0]       # frozen-host landmarks are constants (R3 / R7)
+
+    def unpack(x, R):
+        n = 0
+        for k in free:
+            R.pose[k] = x[n:n+7]; n += 7
+        R.rho[pts] = x[n:n+pts.size]; n += pts.size
+        R.theta[txs] = x[n:n+3*txs.size].reshape(-1, 3)
+
+    def pack(R):
+        return np.concatenate([np.concatenate([R.pose[k] for k in free]), R.rho[pts], R.theta[txs].reshape(-1)])
+
+    W = P.copy()
+
+    def resid(x):
+        unpack(x, W)
+        return oracle_lib.evaluate(W, o, 0, jac=False)["resid"].copy()
+
+    c_oracle = 0.5*np.sum(resid(pack(Q))**2)
+    sol = least_squares(resid, pack(P), method="trf", x_scale="jac", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=400)
+    c_scipy = 0.5*np.sum(sol.fun**2)
+    c0 = 0.5*np.sum(resid(pack(P))**2)
+    assert c_oracle < 0.9*c0                                             # the problem is not trivial
+    assert abs(c_oracle - c_scipy) <= 2e-6*c_scipy, (c0, c_oracle, c_scipy)
+    # and the oracle's solution is stationary for the independent optimiser
+    sol2 = least_squares(resid, pack(Q), method="trf", x_scale="jac", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=100)
+    assert 0.5*np.sum(sol2.fun**2) >= c_oracle*(1 - 1e-7)
