@@ -47,6 +47,7 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_pt_lm, *sb_tx_off, *sb_tx_s1, *sb_tx_s2, *sb_tx_lm;
     const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ps_lm, *pose_ts_off, *pose_ts, *pose_ts_lm;
     const int *tfeat_off, *tfeat_raw; const double *tfeat_uv, *tfeat_ref;
+    const int *pf_g, *pf_f; int n_pf;   // pose-only path: flat (group, feature) list of the frame's text features
 };
 
 #define PT_REC 16
@@ -62,6 +63,7 @@ struct LinBuf {              // everything one linearisation produces
     double *lmpart;                     // per k_mid block: (gradient max, |x|^2) of its landmarks
 };
 
+struct PoseState;
 struct Work {                // device work buffers (sized for the largest level)
     int n_kf, n_pt, n_text, n_tobs, N;      // N = 6 n_kf
     int rank, world;                        // landmark shard of this process (global BA over RCCL), 0 / 1 otherwise
@@ -91,6 +93,7 @@ struct Work {                // device work buffers (sized for the largest level
     double *S, *g, *dp, *dl_pt, *dl_tx;
     double *partial;                    // [nblocks_back][2]
     LmState *st;
+    PoseState *pst; double *ppart;      // pose-only path (tsba_pose.h): double-buffered state, [2][G][28] partial sums
 };
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(c, std::string(#x) + ": " + hipGetErrorString(e_)); return TSBA_ERR_DEVICE; } } while (0)
@@ -932,7 +935,6 @@ __global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi
     __shared__ double lds[3*36*64];              // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double radius = st->radius, irad = 1.0/radius;
-    const int N = W.N;
     const LinBuf &B = W.lb[st->lcur];
     if (b < L.n_sb) {
         const int a = L.sb_a[b], c = L.sb_b[b];
@@ -1086,6 +1088,7 @@ __global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi
 
 #include "tsba_solve.h"
 #include "tsba_chol.h"
+#include "tsba_pose.h"
 
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
 __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
@@ -1302,17 +1305,18 @@ __global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_
     const int b = blockIdx.x, lane = threadIdx.x;
     const double *pose = W.pose[st->cur], *rho = W.rho[st->cur], *theta = W.theta[st->cur];
     if (st->nt_active < 50) chi2_mono += 4.0;
-    if (b < L.n_pair) {
+    const int nb_sc = (L.n_sc + 63) >> 6;
+    if (b < nb_sc) {
+        // scene: one candidate per lane (a frame's single (target, frozen host) pair would otherwise be one wave's serial loop)
         if (!do_scene) return;
-        const int i = L.pair_i[b], h = L.pair_h[b];
-        Pose C; load_pose(pose + 7*i, C);
-        PairT T;
-        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+        const int c = b*64 + lane;
         int nbad = 0;
-        for (int c = L.pair_sc_off[b] + lane; c < L.pair_sc_off[b+1]; c += 64) {
-            if (W.filter_good && !W.sgood[L.sc_flag[c]]) continue;
-            const int pt = L.sc_pt[c];
-            if (h < 0) pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+        if (c < L.n_sc && (!W.filter_good || W.sgood[L.sc_flag[c]])) {
+            const int pt = L.sc_pt[c], i = L.sc_kf[c], h = W.pt_host[pt];
+            Pose C; load_pose(pose + 7*i, C);
+            PairT T;
+            if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+            else pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
             double r[2];
             scene_residual(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1],
                            W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r);
@@ -1325,7 +1329,7 @@ __global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_
         if (lane == 0 && nbad) atomicAdd(&st->n_bad_scene, nbad);
     } else {
         if (!do_text) return;
-        const int g = b - L.n_pair;
+        const int g = b - nb_sc;
         const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
         if (W.filter_good && !W.tobs_good[tb]) return;
         const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
@@ -1424,6 +1428,7 @@ __global__ void k_eval_text(Work W, LevelDev L, int nblk, const int *blk_g, cons
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+static int pose_grid(const LevelDev &D) { return std::max(1, (D.n_sc + 63)/64 + (D.n_pf + 31)/32); }    // workgroups of k_pose_iter
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
 };
@@ -1450,6 +1455,7 @@ struct Ctx {
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
+    bool pose_only = false;                       // one keyframe, every landmark frozen in its host: the fused pose-only LM kernel applies
     double *S_alloc = nullptr; size_t S_count = 0;     // storage behind W.S (dense or band)
     float *lbl_dev = nullptr, *lbl_host = nullptr; size_t lbl_cap = 0;   // text label image staging
     unsigned long long *hprog = nullptr; unsigned int pass_seq = 0;   // pinned progress word written by k_postlin / k_decide
@@ -1660,6 +1666,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         UV(sc_obs); UV(sc_kf); UV(sc_pt); UV(sc_flag); UV(sc_slot); UV(sc_uv);
         UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
         UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
+        UV(pf_g); UV(pf_f); D.n_pf = (int)H.pf_g.size();
         UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
         UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
         UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ps_lm); UV(pose_ts_off); UV(pose_ts); UV(pose_ts_lm);
@@ -1685,6 +1692,16 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         mx_pslot = std::max(mx_pslot, (size_t)D.n_pslot); mx_tslot = std::max(mx_tslot, (size_t)D.n_tslot);
     }
     c->nb_back_max = (p->n_pt + 255)/256 + (p->n_text + 255)/256 + (p->n_kf + 255)/256;
+    {   bool po = p->n_kf == 1;
+        for (int j = 0; po && j < p->n_pt; j++) po = p->pt_host[j] < 0;
+        for (int j = 0; po && j < p->n_text; j++) po = p->text_host[j] < 0;
+        c->pose_only = po && !getenv("TSBA_NO_POSE_KERNEL");
+        W.pst = nullptr; W.ppart = nullptr;
+        if (c->pose_only) {
+            size_t gmax = 1;
+            for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) gmax = std::max(gmax, (size_t)pose_grid(c->lev[l]));
+            AL(W.pst, 2); AL(W.ppart, 2*28*gmax);
+        } }
     for (int b = 0; b < 2; b++) {
         LinBuf &B = W.lb[b];
         AL(B.pairM, 27*mx_pair); AL(B.pairCost, mx_pair); AL(B.pairR, 9*mx_pair); AL(B.pairOut, 90*mx_pair);
@@ -1834,25 +1851,43 @@ int tsba_solve(void *ctx, tsba_report *r) {
     for (int ps = 0; ps < o.n_passes; ps++) {
         const LevelDev &D = c->lev[o.levels[ps]];
         launch_pass_init(c, D, ps);
-        launch_linearize(c, D, 0);
         // The kernels of an LM iteration return at once when the pass has converged, but each still costs a launch (~4 us):
         // the host reads the pinned progress word and stays at most two iterations ahead of the device -- no API call, no
         // synchronisation -- so a pass that converges early wastes two iterations of empty launches instead of all the rest.
-        for (int it = 0; it < o.its[ps]; it++) {
-            if (c->hprog && !is_multi(c)) {
-                bool stop = false; const auto tw = std::chrono::steady_clock::now();
-                for (int spin = 0;; spin++) {
-                    const unsigned long long w = *(volatile unsigned long long *)c->hprog;
-                    if ((unsigned int)(w >> 32) == c->W.pass_seq) { if (w & 1) { stop = true; break; } if ((int)((w & 0xffffffffu) >> 1) + 2 > it) break; }
-                    else if (it < 2) break;                              // the device has not reached this pass yet
-                    if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(2)) break;   // never hang on it
-                }
-                if (stop) break;
+        auto converged = [&](int it) {
+            if (!c->hprog || is_multi(c)) return false;
+            const auto tw = std::chrono::steady_clock::now();
+            for (int spin = 0;; spin++) {
+                const unsigned long long w = *(volatile unsigned long long *)c->hprog;
+                if ((unsigned int)(w >> 32) == c->W.pass_seq) { if (w & 1) return true; if ((int)((w & 0xffffffffu) >> 1) + 2 > it) break; }
+                else if (it < 2) break;                              // the device has not reached this pass yet
+                if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(2)) break;   // never hang on it
             }
+            return false;
+        };
+        if (c->pose_only && !is_multi(c)) {                  // PoseOptim: one launch per LM iteration (tsba_pose.h)
+            const int G = pose_grid(D);
+            hipLaunchKernelGGL(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, -1, G);
+            int k_last = 0;
+            for (int k = 0; k <= o.its[ps]; k++) {           // launch k decides trial k - 1 and prepares trial k
+                if (k >= 1 && converged(k - 1)) break;
+                hipLaunchKernelGGL(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, k, G);
+                k_last = k;
+            }
+            hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, c->stream, c->W, k_last);
+            if (o.outlier_scene || o.outlier_text)
+                if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
+                                                              o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
+            CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
+            continue;
+        }
+        launch_linearize(c, D, 0);
+        for (int it = 0; it < o.its[ps]; it++) {
+            if (converged(it)) break;
             launch_step(c, D);
         }
         if (o.outlier_scene || o.outlier_text)
-            if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3(D.n_pair + D.n_tg), dim3(64), 0, c->stream, c->W, D,
+            if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
                                                           o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
         CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
     }

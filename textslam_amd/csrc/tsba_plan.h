@@ -28,6 +28,7 @@ struct HostPlan {
     std::vector<int32_t> tg_tobs, tg_kf, tg_text, tg_pair, tg_slot;
     std::vector<int32_t> pt_pose6;      // poses of the first 6 slots of every point (clamped): k_back needs them one round trip earlier
     std::vector<int32_t> tg_ppos;       // rank of the group in pair-major order (pair_tg is the inverse): k_mid sums contiguous ranges
+    std::vector<int32_t> pf_g, pf_f;    // single-keyframe problems (pose-only path): flat list of (group, feature) over all groups
     std::vector<int32_t> tg_rec;        // per group, one 32-byte record: tobs, kf, text, host, slot, f0, f1, fgood offset (all static)
     // landmark slots
     std::vector<int32_t> pls_off, pslot_pose, pslot_pair, pslot_lm;     // points
@@ -208,6 +209,9 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         r[0] = tb; r[1] = P.tg_kf[g]; r[2] = j; r[3] = p->text_host[j]; r[4] = P.tg_slot[g];
         r[5] = p->tfeat_off[L] ? p->tfeat_off[L][j] : 0; r[6] = p->tfeat_off[L] ? p->tfeat_off[L][j+1] : 0; r[7] = p->tobs_fgood_off[tb];
     }
+    if (n_kf == 1)
+        for (int g = 0; g < n_tg; g++)
+            for (int f = P.tg_rec[8*(size_t)g + 5]; f < P.tg_rec[8*(size_t)g + 6]; f++) { P.pf_g.push_back(g); P.pf_f.push_back(f); }
     {   // envelope of S: column a reaches down to its last coupled pose; Cholesky fill closes the profile under the running
         // maximum (a column inherits the reach of every earlier column that reaches it).  Compressing the fixed poses out
         // (device side) only shrinks distances, so this is an upper bound for the system that is actually factored.

@@ -1,0 +1,293 @@
+// Pose-only optimisation (optimizer::PoseOptim -> PyrPoseOptim, optimizer.cc:1060-1327: one free pose, every landmark frozen in its
+// host keyframe -- residual rows R3 / R7) with ONE kernel per LM iteration.  Included by tsba.hip after tsba_solve.h.
+//
+// The general pipeline spends seven dependent launches per LM iteration (schur, solve, back, linearize, mid, decide ...) and gives
+// the single (target, host = frozen) pair of a frame to ONE wave: 3000 scene blocks = 47 serial rounds.  With 6 unknowns there is
+// nothing to schedule between the sweeps, so here every LM iteration is one launch of ~100 single-wave workgroups:
+//
+//   k_pose_iter(k):   every workgroup, redundantly and bit-identically:
+//                       state_k   <- pst[k & 1]                                      (k = 0: built from W.st / W.pose)
+//                       sums(cand) <- sum over workgroups of part[(k + 1) & 1]       (fixed order: deterministic)
+//                       Ceres decision for trial k-1 (k = 0: Jacobi scaling + gradient test of the first linearisation)
+//                       (M + D/radius) dp = -c  by 6x6 LDL^T in registers, candidate on the quaternion manifold
+//                     workgroup 0 writes state_{k+1} -> pst[(k + 1) & 1] and the pinned progress word;
+//                     every workgroup then sweeps ITS 64 scene blocks / 32 text features at the candidate -> part[k & 1].
+//
+// State and partial sums are double-buffered by the launch ordinal, so no workgroup reads what another one writes in the same
+// launch; a converged pass copies its state forward, and k_pose_finish(k_last) installs it into W.st / W.pose.  mu / sigma
+// (k_musigma), participation, gauge and the outlier pass stay the kernels of the general path.
+#pragma once
+
+#define POSE_WG 64
+
+struct PoseSums { double M[21], c[6], cost; };
+struct PoseState {
+    LmState S;
+    double M[21], c[6], sig[6], dgs[6], x[7], cand[7], mcc, step2;
+    int fail, pad;
+};
+
+// this workgroup's share of the observations at pose p7: lane l < 28 returns the workgroup total of value l
+// (0..20 = sum w J^T J upper / sym6 order, 21..26 = sum w J^T r, 27 = sum rho / 2)
+__device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L, const double *p7, const double *rho, const double *theta,
+                                                int b, int nb_sc, double *reg, int4 *s_px, int lane) {
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0.0;
+    Pose C; load_pose(p7, C);
+    if (b < nb_sc) {
+        // ---- 64 scene blocks (R3): frozen host, T_rw stored with the point
+        const int c = b*64 + lane;
+        if (c < L.n_sc && (!W.filter_good || W.sgood[L.sc_flag[c]])) {
+            const int pt = L.sc_pt[c];
+            PairT T; pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+            double r[2], jt[2][6], jl[2];
+            scene_block(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1],
+                        W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r, jt, jl);
+            double wgt; acc[27] = 0.5*huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int cc = a; cc < 6; cc++) { acc[q] = wgt*(jt[0][a]*jt[0][cc] + jt[1][a]*jt[1][cc]); q++; }
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] = wgt*(jt[0][a]*r[0] + jt[1][a]*r[1]);
+        }
+    } else {
+        // ---- 32 photometric blocks (R7), each on two lanes (4 taps per lane); (group, feature) from the flat feature list
+        const int fi = (b - nb_sc)*32 + (lane >> 1), tp = lane & 1;
+        double s = 0.0; bool good = false;
+        if (fi < L.n_pf) {
+            const int g = L.pf_g[fi], f = L.pf_f[fi];
+            const int4 ra = ((const int4 *)L.tg_rec)[2*g], rb = ((const int4 *)L.tg_rec)[2*g + 1];
+            const int tb = ra.x, j = ra.z, fg = rb.w;
+            const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
+            const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
+            double refv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) refv[k] = L.tfeat_ref[8*(size_t)f + 4*tp + k];
+            good = (!W.filter_good || (W.tobs_good[tb] && W.tfgood[fg + L.tfeat_raw[f]])) && sigma != 0.0;
+            if (good) {
+                PairT T; pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
+                const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+                const double inv_sigma = 1.0/sigma, ifx = 1.0/L.K[0], ify = 1.0/L.K[1];
+                const uint8_t *img = L.img[ra.y];
+                // the pixel fetches of the 4 taps in flight together; the quads wait in LDS so that the residual loop stays rolled
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int kt = 4*tp + k;
+                    const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;   // tool.cc:1561
+                    const TapPx q = tap_fetch(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h);
+                    s_px[k*POSE_WG + lane] = make_int4(q.I00, q.I01, q.I10, q.I11);
+                }
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {
+                    const int kt = 4*tp + k;
+                    const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;
+                    const int4 q4 = s_px[k*POSE_WG + lane];
+                    const TapPx pxk = { q4.x, q4.y, q4.z, q4.w };
+                    const double rf = k == 0 ? refv[0] : k == 1 ? refv[1] : k == 2 ? refv[2] : refv[3];
+                    double jt[6], jl[3];
+                    const double r = text_tap_px(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], pxk, L.img_w, L.img_h,
+                                                 mu, sigma, inv_sigma, rf, W.w_t, true, jt, jl);
+                    s += r*r;
+                    int q = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+#pragma unroll
+                        for (int cc = a; cc < 6; cc++) { acc[q] += jt[a]*jt[cc]; q++; }
+#pragma unroll
+                    for (int a = 0; a < 6; a++) acc[21 + a] += jt[a]*r;
+                }
+            }
+        }
+        const double s8 = s + __shfl_xor(s, 1, 64);            // the block's squared norm: its 8 taps sit on 2 neighbouring lanes
+        double wgt; const double rho_h = 0.5*huber(s8, W.huber_t, wgt);
+        const double wg = good ? wgt : 0.0;
+#pragma unroll
+        for (int k = 0; k < 27; k++) acc[k] *= wg;
+        acc[27] = (good && tp == 0) ? rho_h : 0.0;
+    }
+    return wave_sum_to_lane_mw<28>(acc, reg, lane);
+}
+
+// k = -1: linearisation at the start point (into part[1]); k >= 0: see the header
+__global__ __launch_bounds__(POSE_WG) void k_pose_iter(Work W, LevelDev L, tsba_options o, int k, int G) {
+    __shared__ double reg[28*65];
+    __shared__ int4 s_px[4*POSE_WG];
+    __shared__ double s_sum[32];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int nb_sc = (L.n_sc + 63) >> 6;
+    const bool is_free = W.fidx[0] >= 0;                    // (a constant pose leaves every block out of the reduced program)
+    if (k < 0) {
+        const LmState *st = W.st;
+        if (st->done) return;
+        const int cur = st->cur;
+        double tot = 0.0;
+        if (is_free) tot = pose_sweep_wg(W, L, W.pose[cur], W.rho[cur], W.theta[cur], b, nb_sc, reg, s_px, lane);
+        if (lane < 28) W.ppart[(size_t)(1*G + b)*28 + lane] = tot;
+        return;
+    }
+    // ---- sums of the last sweep: 28 values x G workgroups, two half sums per value in a fixed order
+    double part = 0.0;
+    {
+        const int i = lane & 31, h = lane >> 5;
+        const double *src = W.ppart + (size_t)((k + 1) & 1)*G*28;
+        if (i < 28) {
+            double s0 = 0.0, s1 = 0.0; int g = h;
+            for (; g + 2 < G; g += 4) { s0 += src[(size_t)g*28 + i]; s1 += src[(size_t)(g + 2)*28 + i]; }
+            if (g < G) s0 += src[(size_t)g*28 + i];
+            part = s0 + s1;
+        }
+    }
+    // ---- state
+    PoseState P;
+    if (k == 0) {
+        P.S = *W.st;
+#pragma unroll
+        for (int q = 0; q < 7; q++) { P.x[q] = W.pose[P.S.cur][q]; P.cand[q] = P.x[q]; }
+#pragma unroll
+        for (int q = 0; q < 21; q++) P.M[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { P.c[q] = 0.0; P.sig[q] = 1.0; P.dgs[q] = 0.0; }
+        P.mcc = 0.0; P.step2 = 0.0; P.fail = 0; P.pad = 0;
+    } else P = W.pst[k & 1];
+    PoseState *Pn = W.pst + ((k + 1) & 1);
+    LmState &S = P.S;
+    if (S.done) { if (b == 0 && lane == 0) *Pn = P; return; }
+    part += __shfl_xor(part, 32, 64);
+    if (lane < 28) s_sum[lane] = part;
+    __syncthreads();
+    PoseSums Cn;
+#pragma unroll
+    for (int q = 0; q < 21; q++) Cn.M[q] = s_sum[q];
+#pragma unroll
+    for (int q = 0; q < 6; q++) Cn.c[q] = s_sum[21 + q];
+    Cn.cost = s_sum[27];
+    auto scale = [&](bool first) {                           // k_postlin: Jacobi scaling fixed at the first linearisation of the pass
+#pragma unroll
+        for (int q = 0; q < 6; q++) { const double h = P.M[sym6(q, q)]; if (first) P.sig[q] = 1.0/(1.0 + sqrt(h));
+            P.dgs[q] = clampd(P.sig[q]*P.sig[q]*h, W.min_diag, W.max_diag)/(P.sig[q]*P.sig[q]); }
+    };
+    auto install = [&]() {                                   // the swept point becomes x
+#pragma unroll
+        for (int q = 0; q < 21; q++) P.M[q] = Cn.M[q];
+#pragma unroll
+        for (int q = 0; q < 6; q++) P.c[q] = Cn.c[q];
+        double g = 0.0, v = 0.0;
+        if (is_free) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) g = fmax(g, fabs(P.c[q]));
+#pragma unroll
+            for (int q = 0; q < 7; q++) v += P.x[q]*P.x[q];
+        }
+        S.gmax = g; S.x_norm = sqrt(v);
+    };
+    if (k == 0) {
+        install(); scale(true);
+        S.x_cost = Cn.cost; S.cost0 = Cn.cost; S.first = 0; S.need_lin = 0; S.n_lin++;
+        if (S.gmax <= o.gradient_tolerance) { S.done = 1; S.term = 3; }
+    } else {
+        // ---- k_decide for the trial the previous launch prepared
+        S.it++;
+        S.cand_cost = P.fail ? S.cand_cost : Cn.cost; S.model_change = 0.5*P.mcc; S.step_norm = sqrt(P.step2);
+        const double mcc = 0.5*P.mcc;
+        if (P.fail || !(mcc > 0.0)) {
+            S.step_fail = 0;
+            if (++S.invalid >= 5) { S.done = 1; S.term = 5; }
+            else S.radius *= 0.5;
+        } else {
+            S.invalid = 0; S.n_cost++;
+            double cost = Cn.cost; if (!(cost == cost)) cost = 1.7976931348623157e308;
+            const double cost_change = S.x_cost - cost;
+            if (S.step_norm <= o.parameter_tolerance*(S.x_norm + o.parameter_tolerance)) { S.done = 1; S.term = 2; }
+            else if (fabs(cost_change) <= o.function_tolerance*S.x_cost) { S.done = 1; S.term = 1; }
+            else {
+                const double rel = cost_change/mcc;
+                if (rel > o.min_relative_decrease) {
+#pragma unroll
+                    for (int q = 0; q < 7; q++) P.x[q] = P.cand[q];
+                    install(); scale(false); S.accepted++; S.n_lin++;
+                    S.x_cost = cost;
+                    double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
+                    S.radius = fmin(S.radius/f, o.max_radius);
+                    S.decrease_factor = 2.0;
+                    if (S.gmax <= o.gradient_tolerance) { S.done = 1; S.term = 3; }
+                } else {
+                    S.radius = S.radius/S.decrease_factor; S.decrease_factor *= 2.0;
+                }
+            }
+        }
+        if (!S.done) {
+            if (S.it >= S.max_it) { S.done = 1; S.term = 0; }
+            else if (S.radius < o.min_radius) { S.done = 1; S.term = 4; }
+        }
+    }
+    if (!S.done) {
+        // ---- k_schur + k_solve + k_back for one pose: (M + D/radius) dp = -c, candidate, step norm, model cost change
+        const double irad = 1.0/S.radius;
+        double dp[6] = {0, 0, 0, 0, 0, 0}; bool fail = S.step_fail != 0 || !is_free;
+        if (!fail) {
+            double s[21], l[15], d[6], id[6]; bool bad = false;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c <= r; c++) s[(r*(r + 1))/2 + c] = P.M[sym6(c, r)] + (r == c ? P.dgs[r]*irad : 0.0);
+            ldl6(s, l, d, id, bad);
+            if (bad) fail = true;
+            else {
+                double z[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) { double v = P.c[r];
+#pragma unroll
+                    for (int q = 0; q < r; q++) v -= l[(r*(r - 1))/2 + q]*z[q];
+                    z[r] = v; }
+#pragma unroll
+                for (int r = 0; r < 6; r++) z[r] *= id[r];
+#pragma unroll
+                for (int r = 5; r >= 0; r--) { double v = z[r];
+#pragma unroll
+                    for (int q = r + 1; q < 6; q++) v -= l[(q*(q - 1))/2 + r]*z[q];
+                    z[r] = v; }
+#pragma unroll
+                for (int r = 0; r < 6; r++) dp[r] = -z[r];
+            }
+        }
+        double step2 = 0.0, mcc = 0.0;
+        if (!fail) {
+            double q4[4] = { P.x[0], P.x[1], P.x[2], P.x[3] }, qn[4];
+            quat_plus(q4, dp, qn);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { P.cand[q] = qn[q]; step2 += (qn[q] - q4[q])*(qn[q] - q4[q]); }
+#pragma unroll
+            for (int q = 0; q < 3; q++) { P.cand[4 + q] = P.x[4 + q] + dp[3 + q]; step2 += dp[3 + q]*dp[3 + q]; }
+#pragma unroll
+            for (int q = 0; q < 6; q++) { const double lam = P.dgs[q]*irad; mcc += lam*dp[q]*dp[q] - P.c[q]*dp[q]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 7; q++) P.cand[q] = P.x[q];
+        }
+        P.mcc = mcc; P.step2 = step2; P.fail = fail ? 1 : 0;
+    }
+    if (b == 0 && lane == 0) {
+        *Pn = P;
+        if (W.hprog) *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)(unsigned)S.it << 1) | (unsigned long long)(S.done != 0);
+    }
+    if (S.done || P.fail) return;
+    // ---- speculative linearisation at the candidate (skipped after a failed step, as the general path does)
+    const double tot = pose_sweep_wg(W, L, P.cand, W.rho[S.cur], W.theta[S.cur], b, nb_sc, reg, s_px, lane);
+    if (lane < 28) W.ppart[(size_t)((k & 1)*G + b)*28 + lane] = tot;
+}
+
+// after the last launched k_pose_iter(k_last): install the state and the pose where the rest of the library expects them
+__global__ void k_pose_finish(Work W, int k_last) {
+    const PoseState &P = W.pst[(k_last + 1) & 1];
+    const int t = threadIdx.x;
+    if (t < 7) { W.pose[0][t] = P.x[t]; W.pose[1][t] = P.x[t]; }
+    if (t == 0) {
+        LmState S = P.S;
+        S.ns_active = W.st->ns_active; S.nt_active = W.st->nt_active;       // counted by k_participation
+        S.n_bad_scene = W.st->n_bad_scene; S.n_bad_tfeat = W.st->n_bad_tfeat; S.n_bad_text = W.st->n_bad_text;
+        *W.st = S;
+    }
+}
