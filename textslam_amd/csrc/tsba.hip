@@ -167,6 +167,19 @@ __device__ __forceinline__ double range_sum(const double *v, int i0, int i1) {
     return s;
 }
 
+// ---- start point of a solve: parameters (both buffers), inlier flags, LM state
+struct ResetSrc { const double *pose0, *rho0, *theta0; const uint8_t *sg0, *tg0, *tf0; long long n_pose, n_rho, n_theta, n_sg, n_tg, n_tf; };
+__global__ __launch_bounds__(256) void k_reset_state(Work W, ResetSrc A) {
+    const long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x, n = (long long)gridDim.x*blockDim.x;
+    for (long long k = t; k < A.n_pose; k += n) { const double v = A.pose0[k]; W.pose[0][k] = v; W.pose[1][k] = v; }
+    for (long long k = t; k < A.n_rho; k += n) { const double v = A.rho0[k]; W.rho[0][k] = v; W.rho[1][k] = v; }
+    for (long long k = t; k < A.n_theta; k += n) { const double v = A.theta0[k]; W.theta[0][k] = v; W.theta[1][k] = v; }
+    for (long long k = t; k < A.n_sg; k += n) W.sgood[k] = A.sg0[k];
+    for (long long k = t; k < A.n_tg; k += n) W.tobs_good[k] = A.tg0[k];
+    for (long long k = t; k < A.n_tf; k += n) W.tfgood[k] = A.tf0[k];
+    if (t == 0) memset(W.st, 0, sizeof(LmState));
+}
+
 // ---- pass initialisation
 __global__ void k_pass_reset(Work W, double radius0, int max_it) {
     LmState *s = W.st;
@@ -251,27 +264,27 @@ __device__ int clip_line_dev(long long Wd, long long Hd, long long &x1, long lon
 // (8-connected) by 4 threads, interior by FillEdgeCollection scanlines (16.16 fixed point), one thread per row.  The caller
 // clears the mask and synchronises before and after.
 __device__ void raster_quad(unsigned *mask, const int *s_xy, int w, int hh, int tid, int nthreads) {
-    // boundary lines (cv::LineIterator, 8-connected, left to right)
-    if (tid < 4) {
-        int i0 = (tid + 3) & 3, i1 = tid;
+    // boundary lines (cv::LineIterator, 8-connected, left to right), a quarter of the threads per edge.  The iterator's error
+    // recurrence  err += -2 minor + (err < 0 ? 2 major : 0)  has the closed form "minor steps taken before pixel i" =
+    // round-half-down(minor i / major) = floor((2 minor i + major - 1) / (2 major)), so the pixels of a line are independent.
+    {
+        const int per = nthreads >> 2, e = tid/per, li = tid - e*per;
+        int i0 = (e + 3) & 3, i1 = e;
         long long x1 = s_xy[2*i0], y1 = s_xy[2*i0+1], x2 = s_xy[2*i1], y2 = s_xy[2*i1+1];
-        bool ok = true;
-        if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
-            (unsigned long long)y1 >= (unsigned long long)hh || (unsigned long long)y2 >= (unsigned long long)hh)
+        bool ok = e < 4;
+        if (ok && ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+                   (unsigned long long)y1 >= (unsigned long long)hh || (unsigned long long)y2 >= (unsigned long long)hh))
             ok = clip_line_dev(w, hh, x1, y1, x2, y2);
         if (ok) {
             long long dx = x2 - x1, dy = y2 - y1;
             if (dx < 0) { dx = -dx; dy = -dy; x1 = x2; y1 = y2; }
             long long sy = dy < 0 ? -1 : 1; if (dy < 0) dy = -dy;
-            bool steep = dy > dx;
-            long long major = steep ? dy : dx, minor = steep ? dx : dy;
-            long long err = major - (minor + minor), plusDelta = major + major, minusDelta = -(minor + minor);
-            long long x = x1, y = y1;
-            for (long long i = 0; i <= major; i++) {
+            const bool steep = dy > dx;
+            const int major = (int)(steep ? dy : dx), minor = (int)(steep ? dx : dy);
+            for (int i = li; i <= major; i += per) {
+                const int ci = major > 0 ? (int)((2LL*minor*i + major - 1)/(2LL*major)) : 0;
+                const long long x = steep ? x1 + ci : x1 + i, y = steep ? y1 + sy*i : y1 + sy*ci;
                 if (x >= 0 && x < w && y >= 0 && y < hh) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31));
-                bool neg = err < 0;
-                err += minusDelta + (neg ? plusDelta : 0);
-                if (steep) { y += sy; if (neg) x += 1; } else { x += 1; if (neg) y += sy; }
             }
         }
     }
@@ -296,23 +309,30 @@ __device__ void raster_quad(unsigned *mask, const int *s_xy, int w, int hh, int 
                 for (int i = 0; i + 1 < na; i += 2) {
                     int xa = (int)((xs[i] + 65535) >> 16), xb = (int)(xs[i+1] >> 16);
                     if (xa < w && xb >= 0) { if (xa < 0) xa = 0; if (xb >= w) xb = w - 1;
-                        for (int x = xa; x <= xb; x++) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31)); }
+                        if (xa <= xb) {                                   // the span's bits are contiguous: whole words at a time
+                            const int b0 = y*w + xa, b1 = y*w + xb;
+                            for (int wd = b0 >> 5; wd <= (b1 >> 5); wd++) {
+                                unsigned m = 0xffffffffu;
+                                if (wd == (b0 >> 5)) m &= 0xffffffffu << (b0 & 31);
+                                if (wd == (b1 >> 5)) m &= 0xffffffffu >> (31 - (b1 & 31));
+                                atomicOr(&mask[wd], m);
+                            }
+                        } }
                 }
             }
         }
     }
 }
 #define MS_THREADS 256
-__global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
+__device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, const int g, const double *pose, const double *theta) {
     __shared__ unsigned mask[MS_MASK_WORDS];
     __shared__ unsigned hist[256];
     __shared__ int s_xy[8], s_bb[4];
     __shared__ double s_red[MS_THREADS];
-    int g = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     int tb = L.tg_tobs[g], kf = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
     if (W.filter_good && !W.tobs_good[tb]) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
     const int w = L.img_w, hh = L.img_h;
-    const double *pose = W.pose[W.st->cur], *theta = W.theta[W.st->cur];
     if (tid == 0) {
         Pose C; load_pose(pose + 7*kf, C);
         PairT T;
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
         if (yMax < 0) yMax = 0;
         s_bb[0] = xMin; s_bb[1] = xMax; s_bb[2] = yMin; s_bb[3] = yMax;
     }
-    for (int k = tid; k < MS_MASK_WORDS; k += MS_THREADS) mask[k] = 0;
+    for (int k = tid; k < min((w*hh + 31) >> 5, MS_MASK_WORDS); k += MS_THREADS) mask[k] = 0;
     hist[tid] = 0;
     __syncthreads();
     const int xMin = s_bb[0], xMax = s_bb[1], yMin = s_bb[2], yMax = s_bb[3];
@@ -363,6 +383,10 @@ __global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
     double d = (double)tid - mu;
     double ss = block_sum<MS_THREADS>((double)hist[tid]*d*d, s_red);
     if (tid == 0) { W.musig[2*tb] = mu; W.musig[2*tb+1] = sqrt(ss/(n - 1.0)); }
+}
+
+__global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
+    musigma_wg(W, L, blockIdx.x, W.pose[W.st->cur], W.theta[W.st->cur]);
 }
 
 // ---- text label image of one keyframe (optimizer::ShowBAReproj_TextBox -> tool::TextBoxWithFill, optimizer.cc:2508-2582,
@@ -1299,11 +1323,14 @@ __global__ void k_kfin_multi(Work W) {               // kf_in was summed over ra
 }
 
 // ---- outlier pass on loss-corrected residuals, optimizer.cc:1609-1686 / :1228-1305
+// pfin != nullptr (pose-only path): the pass's result still lives in the PoseState -- pose from there, and one extra workgroup
+// installs it into W.st / W.pose (field by field: the counters of this very kernel are being updated by atomics)
 __global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_mono, double chi2_text, double bad_ratio,
-                                                int do_scene, int do_text) {
+                                                int do_scene, int do_text, const PoseState *pfin) {
     LmState *st = W.st;
     const int b = blockIdx.x, lane = threadIdx.x;
-    const double *pose = W.pose[st->cur], *rho = W.rho[st->cur], *theta = W.theta[st->cur];
+    const int selc = pfin ? 0 : st->cur;
+    const double *pose = pfin ? pfin->x : W.pose[selc], *rho = W.rho[selc], *theta = W.theta[selc];
     if (st->nt_active < 50) chi2_mono += 4.0;
     const int nb_sc = (L.n_sc + 63) >> 6;
     if (b < nb_sc) {
@@ -1327,7 +1354,8 @@ __global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_
         }
         nbad = (int)wave_sum1((double)nbad);
         if (lane == 0 && nbad) atomicAdd(&st->n_bad_scene, nbad);
-    } else {
+    } else if (b < nb_sc + L.n_tg) {
+        // text: one (KF, text) observation per workgroup, lane = (feature lane >> 3, tap lane & 7), 8 features per round
         if (!do_text) return;
         const int g = b - nb_sc;
         const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
@@ -1340,29 +1368,41 @@ __global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_
         const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
         const uint8_t *img = L.img[i];
         const int fg = W.tobs_fgood_off[tb];
+        const int k = lane & 7, f0 = L.tfeat_off[j], f1 = L.tfeat_off[j+1];
         int nblk = 0, nbad = 0;
-        for (int f = L.tfeat_off[j] + lane; f < L.tfeat_off[j+1]; f += 64) {
-            if (W.filter_good && !W.tfgood[fg + L.tfeat_raw[f]]) continue;
-            nblk++;
-            if (sigma == 0.0) continue;               // residuals are 0: never an outlier
-            const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
-            double r[8], s = 0.0, jt[6], jl[3];
-#pragma unroll 1
-            for (int k = 0; k < 8; k++) {
+        for (int fb = f0; fb < f1; fb += 8) {                          // (uniform trip count: the shuffles need all 8 lanes of a feature)
+            const int f = fb + (lane >> 3);
+            const bool in = f < f1 && (!W.filter_good || W.tfgood[fg + L.tfeat_raw[min(f, f1 - 1)]]);
+            double r = 0.0;
+            if (in && sigma != 0.0) {                                   // sigma == 0: residuals are 0, never an outlier
+                const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
+                double jt[6], jl[3];
                 double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];
-                r[k] = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h, mu, sigma, 1.0/sigma,
-                                L.tfeat_ref[8*(size_t)f + k], W.w_t, false, jt, jl);
-                s += r[k]*r[k];
+                r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h, mu, sigma, 1.0/sigma,
+                             L.tfeat_ref[8*(size_t)f + k], W.w_t, false, jt, jl);
             }
+            double s = r*r;
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
             double wgt; huber(s, W.huber_t, wgt);
-            double sc = sqrt(wgt); bool bad = false;
-            for (int k = 0; k < 8; k++) if (fabs(r[k]*sc/W.w_t) > chi2_text) bad = true;
-            if (bad) { W.tfgood[fg + L.tfeat_raw[f]] = 0; nbad++; }
+            const double sc = sqrt(wgt);
+            int bad = (in && sigma != 0.0 && fabs(r*sc/W.w_t) > chi2_text) ? 1 : 0;
+            bad |= __shfl_xor(bad, 1, 64); bad |= __shfl_xor(bad, 2, 64); bad |= __shfl_xor(bad, 4, 64);
+            if (k == 0 && in) { nblk++; if (bad) { W.tfgood[fg + L.tfeat_raw[f]] = 0; nbad++; } }
         }
         nblk = (int)wave_sum1((double)nblk); nbad = (int)wave_sum1((double)nbad);
         if (lane == 0 && nblk > 0) {
             if (nbad) atomicAdd(&st->n_bad_tfeat, nbad);
             if ((double)nbad/(double)nblk > bad_ratio) { W.tobs_good[tb] = 0; atomicAdd(&st->n_bad_text, 1); }
+        }
+    } else if (pfin) {
+        if (lane < 7) { W.pose[0][lane] = pfin->x[lane]; W.pose[1][lane] = pfin->x[lane]; }
+        if (lane == 0) {
+            const LmState &S = pfin->S;
+            st->radius = S.radius; st->decrease_factor = S.decrease_factor; st->x_cost = S.x_cost; st->x_norm = S.x_norm;
+            st->cand_cost = S.cand_cost; st->model_change = S.model_change; st->step_norm = S.step_norm; st->gmax = S.gmax; st->cost0 = S.cost0;
+            st->done = S.done; st->need_lin = S.need_lin; st->first = S.first; st->it = S.it; st->accepted = S.accepted;
+            st->term = S.term; st->invalid = S.invalid; st->max_it = S.max_it; st->step_fail = S.step_fail; st->lcur = S.lcur;
+            st->n_lin = S.n_lin; st->n_cost = S.n_cost;
         }
     }
 }
@@ -1428,7 +1468,7 @@ __global__ void k_eval_text(Work W, LevelDev L, int nblk, const int *blk_g, cons
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int pose_grid(const LevelDev &D) { return std::max(1, (D.n_sc + 63)/64 + (D.n_pf + 31)/32); }    // workgroups of k_pose_iter
+static int pose_grid(const LevelDev &D) { return std::max(1, (D.n_sc + 255)/256 + (D.n_pf + 31)/32); }    // workgroups of k_pose_iter
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
 };
@@ -1735,18 +1775,14 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     return TSBA_OK;
 }
 
-static int reset_state(Ctx *c) {
+static int reset_state(Ctx *c) {                 // one launch instead of ten small copies (each ~2.5 us on the stream)
     Work &W = c->W;
-    CK(hipMemcpyAsync(W.pose[0], c->pose0, sizeof(double)*7*c->n_kf, hipMemcpyDeviceToDevice, c->stream));
-    CK(hipMemcpyAsync(W.pose[1], c->pose0, sizeof(double)*7*c->n_kf, hipMemcpyDeviceToDevice, c->stream));
-    if (c->n_pt) { CK(hipMemcpyAsync(W.rho[0], c->rho0, sizeof(double)*c->n_pt, hipMemcpyDeviceToDevice, c->stream));
-                   CK(hipMemcpyAsync(W.rho[1], c->rho0, sizeof(double)*c->n_pt, hipMemcpyDeviceToDevice, c->stream)); }
-    if (c->n_text) { CK(hipMemcpyAsync(W.theta[0], c->theta0, sizeof(double)*3*c->n_text, hipMemcpyDeviceToDevice, c->stream));
-                     CK(hipMemcpyAsync(W.theta[1], c->theta0, sizeof(double)*3*c->n_text, hipMemcpyDeviceToDevice, c->stream)); }
-    if (c->n_sgood) CK(hipMemcpyAsync(W.sgood, c->sgood0, c->n_sgood, hipMemcpyDeviceToDevice, c->stream));
-    if (c->n_tobs) CK(hipMemcpyAsync(W.tobs_good, c->tobs_good0, c->n_tobs, hipMemcpyDeviceToDevice, c->stream));
-    if (c->n_tfgood) CK(hipMemcpyAsync(W.tfgood, c->tfgood0, c->n_tfgood, hipMemcpyDeviceToDevice, c->stream));
-    CK(hipMemsetAsync(W.st, 0, sizeof(LmState), c->stream));
+    ResetSrc A = { (const double *)c->pose0, (const double *)c->rho0, (const double *)c->theta0,
+                   (const uint8_t *)c->sgood0, (const uint8_t *)c->tobs_good0, (const uint8_t *)c->tfgood0,
+                   (long long)7*c->n_kf, (long long)c->n_pt, (long long)3*c->n_text, (long long)c->n_sgood, (long long)c->n_tobs, (long long)c->n_tfgood };
+    long long mx = std::max(std::max(A.n_pose, A.n_rho), std::max(std::max(A.n_theta, A.n_sg), std::max(A.n_tg, A.n_tf)));
+    const int nb = (int)std::min<long long>(1024, std::max<long long>(1, (mx + 255)/256));
+    hipLaunchKernelGGL(k_reset_state, dim3(nb), dim3(256), 0, c->stream, W, A);
     return 0;
 }
 
@@ -1850,7 +1886,11 @@ int tsba_solve(void *ctx, tsba_report *r) {
     int rc = reset_state(c); if (rc) return rc;
     for (int ps = 0; ps < o.n_passes; ps++) {
         const LevelDev &D = c->lev[o.levels[ps]];
-        launch_pass_init(c, D, ps);
+        const bool pose_path = c->pose_only && !is_multi(c);
+        if (pose_path) {                                     // k_pass_reset + k_participation + k_gauge + k_musigma in one launch
+            c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
+            hipLaunchKernelGGL(k_pose_begin, dim3(D.n_tg + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial);
+        } else launch_pass_init(c, D, ps);
         // The kernels of an LM iteration return at once when the pass has converged, but each still costs a launch (~4 us):
         // the host reads the pinned progress word and stays at most two iterations ahead of the device -- no API call, no
         // synchronisation -- so a pass that converges early wastes two iterations of empty launches instead of all the rest.
@@ -1865,7 +1905,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
             }
             return false;
         };
-        if (c->pose_only && !is_multi(c)) {                  // PoseOptim: one launch per LM iteration (tsba_pose.h)
+        if (pose_path) {                                     // PoseOptim: one launch per LM iteration (tsba_pose.h)
             const int G = pose_grid(D);
             hipLaunchKernelGGL(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, -1, G);
             int k_last = 0;
@@ -1874,10 +1914,9 @@ int tsba_solve(void *ctx, tsba_report *r) {
                 hipLaunchKernelGGL(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, k, G);
                 k_last = k;
             }
-            hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, c->stream, c->W, k_last);
-            if (o.outlier_scene || o.outlier_text)
-                if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
-                                                              o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
+            // outlier pass + installation of the pass's result (one extra workgroup) in one launch
+            hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg + 1), dim3(64), 0, c->stream, c->W, D, o.chi2_mono[ps], o.chi2_text[ps],
+                               o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)(c->W.pst + ((k_last + 1) & 1)));
             CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
             continue;
         }
@@ -1888,7 +1927,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
         }
         if (o.outlier_scene || o.outlier_text)
             if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
-                                                          o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
+                                                          o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)nullptr);
         CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
     }
     if (c->world > 1) {                           // every landmark was optimised by its owner only

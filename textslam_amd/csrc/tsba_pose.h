@@ -3,7 +3,7 @@
 //
 // The general pipeline spends seven dependent launches per LM iteration (schur, solve, back, linearize, mid, decide ...) and gives
 // the single (target, host = frozen) pair of a frame to ONE wave: 3000 scene blocks = 47 serial rounds.  With 6 unknowns there is
-// nothing to schedule between the sweeps, so here every LM iteration is one launch of ~100 single-wave workgroups:
+// nothing to schedule between the sweeps, so here every LM iteration is one launch of ~60 workgroups of 256 threads:
 //
 //   k_pose_iter(k):   every workgroup, redundantly and bit-identically:
 //                       state_k   <- pst[k & 1]                                      (k = 0: built from W.st / W.pose)
@@ -11,14 +11,17 @@
 //                       Ceres decision for trial k-1 (k = 0: Jacobi scaling + gradient test of the first linearisation)
 //                       (M + D/radius) dp = -c  by 6x6 LDL^T in registers, candidate on the quaternion manifold
 //                     workgroup 0 writes state_{k+1} -> pst[(k + 1) & 1] and the pinned progress word;
-//                     every workgroup then sweeps ITS 64 scene blocks / 32 text features at the candidate -> part[k & 1].
+//                     every workgroup then sweeps ITS 256 scene blocks / 32 text features x 8 taps at the candidate -> part[k & 1].
 //
 // State and partial sums are double-buffered by the launch ordinal, so no workgroup reads what another one writes in the same
 // launch; a converged pass copies its state forward, and k_pose_finish(k_last) installs it into W.st / W.pose.  mu / sigma
 // (k_musigma), participation, gauge and the outlier pass stay the kernels of the general path.
 #pragma once
 
-#define POSE_WG 64
+#define POSE_WG 256
+#define POSE_NW (POSE_WG/64)
+#define POSE_TILE 128                   /* workgroups of partial sums staged in LDS at a time */
+#define POSE_LDS (POSE_NW*14*65 + POSE_NW*32)        /* >= POSE_TILE*28 */
 
 struct PoseSums { double M[21], c[6], cost; };
 struct PoseState {
@@ -27,17 +30,18 @@ struct PoseState {
     int fail, pad;
 };
 
-// this workgroup's share of the observations at pose p7: lane l < 28 returns the workgroup total of value l
-// (0..20 = sum w J^T J upper / sym6 order, 21..26 = sum w J^T r, 27 = sum rho / 2)
+// this workgroup's share of the observations at pose p7 -- 256 scene blocks, or 32 text features x 8 taps: thread t < 28 returns
+// the workgroup total of value t (0..20 = sum w J^T J upper / sym6 order, 21..26 = sum w J^T r, 27 = sum rho / 2)
 __device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L, const double *p7, const double *rho, const double *theta,
-                                                int b, int nb_sc, double *reg, int4 *s_px, int lane) {
+                                                int b, int nb_sc, double *lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
     Pose C; load_pose(p7, C);
     if (b < nb_sc) {
-        // ---- 64 scene blocks (R3): frozen host, T_rw stored with the point
-        const int c = b*64 + lane;
+        // ---- scene blocks (R3), one per thread: frozen host, T_rw stored with the point
+        const int c = b*POSE_WG + tid;
         if (c < L.n_sc && (!W.filter_good || W.sgood[L.sc_flag[c]])) {
             const int pt = L.sc_pt[c];
             PairT T; pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
@@ -54,91 +58,68 @@ __device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L
             for (int a = 0; a < 6; a++) acc[21 + a] = wgt*(jt[0][a]*r[0] + jt[1][a]*r[1]);
         }
     } else {
-        // ---- 32 photometric blocks (R7), each on two lanes (4 taps per lane); (group, feature) from the flat feature list
-        const int fi = (b - nb_sc)*32 + (lane >> 1), tp = lane & 1;
-        double s = 0.0; bool good = false;
+        // ---- photometric blocks (R7): thread = (feature, tap); (group, feature) from the frame's flat feature list
+        const int fi = (b - nb_sc)*(POSE_WG/8) + (tid >> 3), kt = tid & 7;
+        double r = 0.0, jt[6] = {0, 0, 0, 0, 0, 0}; bool good = false;
         if (fi < L.n_pf) {
             const int g = L.pf_g[fi], f = L.pf_f[fi];
             const int4 ra = ((const int4 *)L.tg_rec)[2*g], rb = ((const int4 *)L.tg_rec)[2*g + 1];
             const int tb = ra.x, j = ra.z, fg = rb.w;
             const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
-            const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
-            double refv[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) refv[k] = L.tfeat_ref[8*(size_t)f + 4*tp + k];
+            const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1], rf = L.tfeat_ref[8*(size_t)f + kt];
+            const uint8_t *img = L.img[ra.y];
+            PairT T; pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
+            const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
             good = (!W.filter_good || (W.tobs_good[tb] && W.tfgood[fg + L.tfeat_raw[f]])) && sigma != 0.0;
             if (good) {
-                PairT T; pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
-                const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-                const double inv_sigma = 1.0/sigma, ifx = 1.0/L.K[0], ify = 1.0/L.K[1];
-                const uint8_t *img = L.img[ra.y];
-                // the pixel fetches of the 4 taps in flight together; the quads wait in LDS so that the residual loop stays rolled
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int kt = 4*tp + k;
-                    const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;   // tool.cc:1561
-                    const TapPx q = tap_fetch(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h);
-                    s_px[k*POSE_WG + lane] = make_int4(q.I00, q.I01, q.I10, q.I11);
-                }
-#pragma unroll 1
-                for (int k = 0; k < 4; k++) {
-                    const int kt = 4*tp + k;
-                    const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;
-                    const int4 q4 = s_px[k*POSE_WG + lane];
-                    const TapPx pxk = { q4.x, q4.y, q4.z, q4.w };
-                    const double rf = k == 0 ? refv[0] : k == 1 ? refv[1] : k == 2 ? refv[2] : refv[3];
-                    double jt[6], jl[3];
-                    const double r = text_tap_px(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], pxk, L.img_w, L.img_h,
-                                                 mu, sigma, inv_sigma, rf, W.w_t, true, jt, jl);
-                    s += r*r;
-                    int q = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-#pragma unroll
-                        for (int cc = a; cc < 6; cc++) { acc[q] += jt[a]*jt[cc]; q++; }
-#pragma unroll
-                    for (int a = 0; a < 6; a++) acc[21 + a] += jt[a]*r;
-                }
+                const double mx = (fu + TAP_DX[kt] - L.K[2])/L.K[0], my = (fv + TAP_DY[kt] - L.K[3])/L.K[1];   // tool.cc:1561
+                double jl[3];
+                r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h,
+                             mu, sigma, 1.0/sigma, rf, W.w_t, true, jt, jl);
             }
         }
-        const double s8 = s + __shfl_xor(s, 1, 64);            // the block's squared norm: its 8 taps sit on 2 neighbouring lanes
+        double s8 = r*r;                                        // the block's squared norm: its 8 taps sit on 8 neighbouring lanes
+        s8 += __shfl_xor(s8, 1, 64); s8 += __shfl_xor(s8, 2, 64); s8 += __shfl_xor(s8, 4, 64);
         double wgt; const double rho_h = 0.5*huber(s8, W.huber_t, wgt);
         const double wg = good ? wgt : 0.0;
+        int q = 0;
 #pragma unroll
-        for (int k = 0; k < 27; k++) acc[k] *= wg;
-        acc[27] = (good && tp == 0) ? rho_h : 0.0;
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int cc = a; cc < 6; cc++) { acc[q] = wg*(jt[a]*jt[cc]); q++; }
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] = wg*(jt[a]*r);
+        acc[27] = (good && kt == 0) ? rho_h : 0.0;
     }
-    return wave_sum_to_lane_mw<28>(acc, reg, lane);
+    double *xw = lds + POSE_NW*14*65;                        // two transposes of 14 values per wave (LDS stays under 32 KB)
+    const double t0 = wave_sum_to_lane_mw<14>(acc, lds + wave*14*65, lane);
+    const double t1 = wave_sum_to_lane_mw<14>(acc + 14, lds + wave*14*65, lane);
+    if (lane < 14) { xw[wave*32 + lane] = t0; xw[wave*32 + 14 + lane] = t1; }
+    __syncthreads();
+    double tot = 0.0;
+    if (tid < 28) {
+#pragma unroll
+        for (int w = 0; w < POSE_NW; w++) tot += xw[w*32 + tid];
+    }
+    return tot;
 }
 
 // k = -1: linearisation at the start point (into part[1]); k >= 0: see the header
 __global__ __launch_bounds__(POSE_WG) void k_pose_iter(Work W, LevelDev L, tsba_options o, int k, int G) {
-    __shared__ double reg[28*65];
-    __shared__ int4 s_px[4*POSE_WG];
+    __shared__ double lds[POSE_LDS];                        // the sweep's transposes; before it, the staged partial sums
+    __shared__ double s_ps[8*28];
     __shared__ double s_sum[32];
-    const int lane = threadIdx.x, b = blockIdx.x;
-    const int nb_sc = (L.n_sc + 63) >> 6;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int nb_sc = (L.n_sc + POSE_WG - 1)/POSE_WG;
     const bool is_free = W.fidx[0] >= 0;                    // (a constant pose leaves every block out of the reduced program)
     if (k < 0) {
         const LmState *st = W.st;
         if (st->done) return;
         const int cur = st->cur;
         double tot = 0.0;
-        if (is_free) tot = pose_sweep_wg(W, L, W.pose[cur], W.rho[cur], W.theta[cur], b, nb_sc, reg, s_px, lane);
-        if (lane < 28) W.ppart[(size_t)(1*G + b)*28 + lane] = tot;
+        if (is_free) tot = pose_sweep_wg(W, L, W.pose[cur], W.rho[cur], W.theta[cur], b, nb_sc, lds);
+        if (tid < 28) W.ppart[(size_t)(1*G + b)*28 + tid] = tot;
         return;
-    }
-    // ---- sums of the last sweep: 28 values x G workgroups, two half sums per value in a fixed order
-    double part = 0.0;
-    {
-        const int i = lane & 31, h = lane >> 5;
-        const double *src = W.ppart + (size_t)((k + 1) & 1)*G*28;
-        if (i < 28) {
-            double s0 = 0.0, s1 = 0.0; int g = h;
-            for (; g + 2 < G; g += 4) { s0 += src[(size_t)g*28 + i]; s1 += src[(size_t)(g + 2)*28 + i]; }
-            if (g < G) s0 += src[(size_t)g*28 + i];
-            part = s0 + s1;
-        }
     }
     // ---- state
     PoseState P;
@@ -154,10 +135,29 @@ __global__ __launch_bounds__(POSE_WG) void k_pose_iter(Work W, LevelDev L, tsba_
     } else P = W.pst[k & 1];
     PoseState *Pn = W.pst + ((k + 1) & 1);
     LmState &S = P.S;
-    if (S.done) { if (b == 0 && lane == 0) *Pn = P; return; }
-    part += __shfl_xor(part, 32, 64);
-    if (lane < 28) s_sum[lane] = part;
-    __syncthreads();
+    if (S.done) { if (b == 0 && tid == 0) *Pn = P; return; }
+    // ---- sums of the last sweep: 28 values x G workgroups.  All loads in flight at once (staged through LDS), then eight
+    // partial sums per value in a fixed order
+    {
+        const double *src = W.ppart + (size_t)((k + 1) & 1)*G*28;
+        const int i = tid % 28, h = tid / 28;                // h < 8 for tid < 224
+        double part = 0.0;
+        for (int g0 = 0; g0 < G; g0 += POSE_TILE) {
+            const int ng = min(POSE_TILE, G - g0);
+            const double2 *s2 = (const double2 *)(src + (size_t)g0*28);
+            for (int e = tid; e < ng*14; e += POSE_WG) ((double2 *)lds)[e] = s2[e];
+            __syncthreads();
+            if (h < 8) for (int g = h; g < ng; g += 8) part += lds[g*28 + i];
+            __syncthreads();
+        }
+        if (h < 8) s_ps[h*28 + i] = part;
+        __syncthreads();
+        if (tid < 28) { double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) t += s_ps[q*28 + tid];
+            s_sum[tid] = t; }
+        __syncthreads();
+    }
     PoseSums Cn;
 #pragma unroll
     for (int q = 0; q < 21; q++) Cn.M[q] = s_sum[q];
@@ -269,25 +269,43 @@ __global__ __launch_bounds__(POSE_WG) void k_pose_iter(Work W, LevelDev L, tsba_
         }
         P.mcc = mcc; P.step2 = step2; P.fail = fail ? 1 : 0;
     }
-    if (b == 0 && lane == 0) {
+    if (b == 0 && tid == 0) {
         *Pn = P;
         if (W.hprog) *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)(unsigned)S.it << 1) | (unsigned long long)(S.done != 0);
     }
     if (S.done || P.fail) return;
     // ---- speculative linearisation at the candidate (skipped after a failed step, as the general path does)
-    const double tot = pose_sweep_wg(W, L, P.cand, W.rho[S.cur], W.theta[S.cur], b, nb_sc, reg, s_px, lane);
-    if (lane < 28) W.ppart[(size_t)((k & 1)*G + b)*28 + lane] = tot;
+    const double tot = pose_sweep_wg(W, L, P.cand, W.rho[S.cur], W.theta[S.cur], b, nb_sc, lds);
+    if (tid < 28) W.ppart[(size_t)((k & 1)*G + b)*28 + tid] = tot;
 }
 
-// after the last launched k_pose_iter(k_last): install the state and the pose where the rest of the library expects them
-__global__ void k_pose_finish(Work W, int k_last) {
-    const PoseState &P = W.pst[(k_last + 1) & 1];
-    const int t = threadIdx.x;
-    if (t < 7) { W.pose[0][t] = P.x[t]; W.pose[1][t] = P.x[t]; }
-    if (t == 0) {
-        LmState S = P.S;
-        S.ns_active = W.st->ns_active; S.nt_active = W.st->nt_active;       // counted by k_participation
-        S.n_bad_scene = W.st->n_bad_scene; S.n_bad_tfeat = W.st->n_bad_tfeat; S.n_bad_text = W.st->n_bad_text;
-        *W.st = S;
+// pass start of the pose-only path in one launch: workgroups 0 .. n_tg-1 = k_musigma (the pose is the same in both parameter
+// buffers here); workgroup n_tg = k_pass_reset + k_participation + k_gauge for one keyframe
+__global__ __launch_bounds__(MS_THREADS) void k_pose_begin(Work W, LevelDev L, double radius0, int max_it, const uint8_t *kf_initial) {
+    if ((int)blockIdx.x < L.n_tg) { musigma_wg(W, L, blockIdx.x, W.pose[0], W.theta[0]); return; }
+    __shared__ int cnt_s, cnt_t;
+    const int tid = threadIdx.x;
+    if (tid == 0) { cnt_s = 0; cnt_t = 0; }
+    __syncthreads();
+    int ns = 0, nt = 0;
+    for (int c = tid; c < L.n_sc; c += MS_THREADS) ns += (!W.filter_good || W.sgood[L.sc_flag[c]]) ? 1 : 0;
+    for (int fi = tid; fi < L.n_pf; fi += MS_THREADS) {
+        const int g = L.pf_g[fi], f = L.pf_f[fi], tb = L.tg_rec[8*g], fg = L.tg_rec[8*g + 7];
+        nt += (!W.filter_good || (W.tobs_good[tb] && W.tfgood[fg + L.tfeat_raw[f]])) ? 1 : 0;
+    }
+    if (ns) atomicAdd(&cnt_s, ns);
+    if (nt) atomicAdd(&cnt_t, nt);
+    __syncthreads();
+    if (tid == 0) {
+        LmState *s = W.st;                                   // (every field but cur / n_lin / n_cost, which carry over)
+        s->radius = radius0; s->decrease_factor = 2.0; s->x_cost = 0; s->x_norm = 0; s->cand_cost = 0; s->model_change = 0;
+        s->step_norm = 0; s->gmax = 0; s->cost0 = 0;
+        s->done = 0; s->need_lin = 1; s->first = 1; s->it = 0; s->accepted = 0; s->term = 0; s->invalid = 0; s->max_it = max_it;
+        s->step_fail = 0; s->lcur = 0; s->pad1 = 0; s->pad2 = 0;
+        s->ns_active = cnt_s; s->nt_active = cnt_t; s->n_bad_scene = 0; s->n_bad_tfeat = 0; s->n_bad_text = 0;
+        const int in = (cnt_s > 0 || cnt_t > 0) ? 1 : 0, cst = (kf_initial[0] && in) ? 1 : 0;    // optimizer.cc:1562-1588 for one keyframe
+        W.kf_in[0] = in; W.kf_const[0] = cst;
+        W.fidx[0] = (in && !cst) ? 0 : -1; *W.nfree = (in && !cst) ? 1 : 0;
+        if (W.hprog) { *W.hprog = (unsigned long long)W.pass_seq << 32; __threadfence_system(); }
     }
 }
