@@ -1,0 +1,46 @@
+"""GPU diagnostic (not a pytest): the streaming band solver's dp against numpy on the reduced system of the first linearisation."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+from textslam_amd import synth, abi
+from textslam_amd.optimizer import Optimizer
+opt = Optimizer(0)
+for (nkf, band) in ((40, 6), (70, 9), (120, 10), (300, 12)):
+    P = synth.config_global(n_kf=nkf, n_pt=50*nkf, band=band)
+    o = abi.options_global()
+    opt.upload(P, o)
+    rg = opt.reduced_system(o.initial_radius)
+    free = np.nonzero(rg['free'])[0]; idx = np.concatenate([np.arange(6*k, 6*k+6) for k in free])
+    m = len(idx)
+    if nkf <= 120:
+        ro = oracle.reduced_system(P, o, 0, o.initial_radius); ref = -np.linalg.solve(ro['S'], ro['g'])
+        print('   g rel', np.abs(rg['g'][:m] - ro['g']).max()/np.abs(ro['g']).max())
+    else:
+        S = rg['S'][:m, :m]; S = np.tril(S) + np.tril(S, -1).T       # S, g live in the compressed (free-pose) index space
+        ref = -np.linalg.solve(S, rg['g'][:m])
+    got = rg['dp'][idx]
+    err = np.abs(got - ref)/np.abs(ref).max()
+    bad = np.nonzero(err > 1e-8)[0]
+    import ctypes as C
+    st = (C.c_longlong*64)(); opt.lib.tsba_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]; print('   rc', opt.lib.tsba_debug_stamps(opt.ctx, st)); print('   dbg bw,CB,ntot,chunks,failbase,jb,n:', list(st[16:23]), np.array([st[23], st[24]], np.int64).view(np.float64))
+    if nkf <= 120 and st[16] > 0:
+        bw = int(st[16]); REC = bw*6; nb = m//6
+        lcol = np.zeros(nb*REC); ldb = np.zeros(32*nb)
+        opt.lib.tsba_debug_band_factor.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
+        print('   rc', opt.lib.tsba_debug_band_factor(opt.ctx, lcol.ctypes.data, lcol.size, ldb.ctypes.data, ldb.size))
+        Cc = np.linalg.cholesky(ro['S']); dd = np.diag(Cc)**2; Lr = Cc/np.diag(Cc)[None, :]
+        for q in range(nb):
+            blk = lcol[q*REC:(q+1)*REC].reshape(bw, 6)
+            rows = np.arange(6*q+6, min(6*q+6+bw, m))
+            refb = Lr[rows][:, 6*q:6*q+6]
+            e = np.abs(blk[:len(rows)] - refb).max() if len(rows) else 0.0
+            idr = 1.0/dd[6*q:6*q+6]; eid = np.abs(ldb[32*q+16:32*q+22] - idr).max()/idr.max()
+            if e > 1e-9 or eid > 1e-9:
+                bad_rows = rows[np.nonzero(np.abs(blk[:len(rows)] - refb).max(axis=1) > 1e-9)[0]]
+                print('   block', q, 'L err %.3e' % e, '1/d rel err %.3e' % eid, 'bad rows', bad_rows[:12], '(local', bad_rows[:12] - 6*q - 6, ')'); break
+        else: print('   all written blocks match')
+    print(nkf, band, "nfree", len(free), "max rel err %.3e" % err.max(), "first bad row", (bad[0] if len(bad) else -1), "n bad", len(bad), flush=True)
+    if len(bad):
+        blocks = sorted(set((bad//6).tolist()))
+        print("   bad blocks:", blocks[:20], "...", blocks[-5:])

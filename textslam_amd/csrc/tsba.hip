@@ -1112,6 +1112,7 @@ __global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi
 
 #include "tsba_solve.h"
 #include "tsba_chol.h"
+#include "tsba_band.h"
 #include "tsba_pose.h"
 
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
@@ -1496,7 +1497,8 @@ struct Ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
     bool pose_only = false;                       // one keyframe, every landmark frozen in its host: the fused pose-only LM kernel applies
-    double *S_alloc = nullptr; size_t S_count = 0;     // storage behind W.S (dense or band)
+    double *S_alloc = nullptr; size_t S_count = 0;
+    double *Lcol = nullptr; int band_stream = 0;  // streaming band solver (tsba_band.h): L by block column; 1 = every built level fits it     // storage behind W.S (dense or band)
     float *lbl_dev = nullptr, *lbl_host = nullptr; size_t lbl_cap = 0;   // text label image staging
     unsigned long long *hprog = nullptr; unsigned int pass_seq = 0;   // pinned progress word written by k_postlin / k_decide
     std::vector<struct Slab> slabs; int cur_slab = 0;
@@ -1761,6 +1763,9 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         const size_t LDB = (size_t)bwmax + 2*CH_NB - 1;
         if (use_lds_ || LDB >= (size_t)W.N) { c->S_count = (size_t)(W.N + 1)*W.N; AL(c->S_alloc, c->S_count); W.S = c->S_alloc; W.ldS = W.N; W.band = 0; }
         else { c->S_count = (size_t)W.N*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - CH_NB); W.ldS = (int)LDB - 1; W.band = 1; }
+        c->Lcol = nullptr; c->band_stream = 0;
+        if (W.band && bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !getenv("TSBA_NO_BAND_STREAM")) {
+            AL(c->Lcol, (size_t)p->n_kf*bwmax*6); c->band_stream = 1; }
         AL(W.Sy, W.N);
     }
     AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
@@ -1831,6 +1836,13 @@ static void launch_solve(Ctx *c) {
     Work &W = c->W;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) { hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0); return; }
+    if (c->band_stream) {                                          // narrow band: one workgroup streams down the band (tsba_band.h)
+        const int bws = std::max(6, c->cur_bw_rows), cb = band_chunk_blocks(bws);
+        if (getenv("TSBA_DEBUG_TIMING")) fprintf(stderr, "[launch_solve] band stream bw %d cb %d lds %zu B\n", bws, cb, band_lds_doubles(bws, cb)*sizeof(double));
+        hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(SOLVE_THREADS), (int)(band_lds_doubles(bws, cb)*sizeof(double)), c->stream, W, bws, cb, c->Lcol);
+        hipLaunchKernelGGL(k_band_backsub, dim3(1), dim3(SOLVE_THREADS), (int)(band_lds_doubles(bws, cb)*sizeof(double)), c->stream, W, bws, (const double *)c->Lcol);
+        return;
+    }
     const int N = W.N;                                             // worst case: every keyframe free
     const int bw = std::min(c->cur_bw_rows, N);                    // band of the reduced camera matrix (rows below a pose block)
     hipLaunchKernelGGL(k_chol_rhs, dim3((N + 255)/256), dim3(256), 0, c->stream, W);
@@ -1877,6 +1889,8 @@ int tsba_solve(void *ctx, tsba_report *r) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     else {
+        CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_band_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_solve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solve_diag_lds_doubles()*sizeof(double))));
         CK(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double)));
         CK(hipFuncSetAttribute((const void *)k_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2*64*(CH_NB + 1)*(int)sizeof(double)));
@@ -2175,6 +2189,12 @@ int tsba_debug_copy_S(void *ctx, double *out) {      // (6 n_kf + 1) x (6 n_kf):
     return hipMemcpy(out + (size_t)N*N, W.Sy, sizeof(double)*(size_t)N, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
 }
 
+int tsba_debug_band_factor(void *ctx, double *lcol, long long n_lcol, double *ldbuf, long long n_ld) {      // test hook: streaming band solver's factor
+    Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded || !c->Lcol) return TSBA_ERR_STATE;
+    hipSetDevice(c->device); hipStreamSynchronize(c->stream);
+    if (hipMemcpy(lcol, c->Lcol, sizeof(double)*n_lcol, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE;
+    return hipMemcpy(ldbuf, c->W.LDbuf, sizeof(double)*n_ld, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
+}
 int tsba_debug_stamps(void *ctx, long long *out64) {
     Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded) return TSBA_ERR_STATE;
     hipSetDevice(c->device); hipStreamSynchronize(c->stream);

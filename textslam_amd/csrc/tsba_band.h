@@ -1,0 +1,302 @@
+// Streaming band solver for the reduced camera system of a large map (global BA): S dp = -g with S block-banded (tsba_plan.h
+// bounds the rows below a pose block that can be non-zero, fill included: bw).  Included by tsba.hip after tsba_solve.h.
+//
+// The multi-kernel blocked Cholesky of tsba_chol.h spends three dependent launches (diagonal factor / panel / update) per 96
+// columns -- ~130 us of launch gaps and load chains per block column, 41 ms per factorisation at 5000 keyframes.  A band of 13
+// pose blocks is a 78-row problem: it fits ONE workgroup's LDS with room to spare, so here the whole factorisation is one
+// launch of one workgroup that slides a dense window down the band:
+//
+//   window   = rows [base, base + Wn) of S as a padded packed lower triangle in LDS, Wn = 6 CB + bw, + the right-hand side as the
+//              last row (forward substitution rides along), exactly the layout of the small-window solver (tsba_solve.h)
+//   chunk    = the small solver's blocked LDL^T step (2 panel waves with look-ahead, 10 MFMA trailing-update waves, one barrier
+//              per pose block) for CB pose blocks; rows further than bw below a column are zeros and stay zeros
+//   write out the finished columns: L by block column (Lcol, contiguous for the back substitution), unit-lower diagonal factor
+//              and 1/d (LDbuf), forward-substituted right-hand side (Sy)
+//   slide    = the trailing (Wn - 6 (CB - 1))^2 / 2 part moves to the top-left corner (the LAST factored block stays as local
+//              block 0: its trailing update is applied by the next chunk's first step, as inside a chunk), new rows come
+//              straight from S in HBM -- no earlier column reaches them
+//   back substitution: wave 0 walks the block columns backwards, x_j = l_j^-T (v_j - sum_r L_rj^T x_r), operands staged
+//              through LDS one chunk ahead by the other eleven waves; dp[6a + k] = -x[6 fidx[a] + k].
+#pragma once
+
+#define BAND_CK 8                           /* block columns per back-substitution chunk */
+#define BAND_RING 256                       /* ring of the last solution rows (>= bw + 6) */
+#define BAND_BW_MAX 156                     /* widest band the streaming solver takes (26 keyframes): Wn = 6 CB + bw must fit LDS */
+
+// pose blocks per chunk for a band of bw rows (0: the window does not fit)
+static int band_chunk_blocks(int bw) {
+    for (int cb = 16; cb >= 3; cb--)
+        if ((solve_lds_doubles(6*cb + bw) + 64)*sizeof(double) <= 150*1024) return cb;
+    return 0;
+}
+static size_t band_lds_doubles(int bw, int cb) {
+    const size_t fac = solve_lds_doubles(6*cb + bw) + 64;
+    const size_t bs = 2*(size_t)BAND_CK*((size_t)bw*6 + 32) + BAND_RING + 64;
+    return fac > bs ? fac : bs;
+}
+
+__device__ __forceinline__ double quad_sum(double v) {       // sum over the 4 lanes of a quad (DPP quad_perm), all 4 get it
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo1 = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true), hi1 = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);   // [1,0,3,2]
+    v += __hiloint2double(hi1, lo1);
+    lo = __double2loint(v); hi = __double2hiint(v);
+    lo1 = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi1 = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);       // [2,3,0,1]
+    return v + __hiloint2double(hi1, lo1);
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, int CB, double *Lcol) {
+    LmState *st = W.st;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = SOLVE_THREADS/64, NT = NW - SOLVE_PW;
+    if (st->done) return;
+    const int nfree_all = *W.nfree, ntot = 6*nfree_all;
+    if (st->step_fail || ntot == 0) { for (int k = tid; k < W.N; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
+    const int Wn = 6*CB + bw;
+    const size_t ld = (size_t)W.ldS;
+    const double *S = W.S;
+    double *A = smem;
+    double *LD = A + rowoff(Wn + 1) + 16;
+    double *scr = LD + SOLVE_LD*(Wn/6);
+    const int REC = bw*6;
+    if (tid == 0) fail = 0;
+
+    int base = 0, n = min(Wn, ntot);
+    // rows [r0, n) of the window from HBM: zeros left of the band, then the band entries; right-hand side columns [r0, n)
+    auto load_rows = [&](int r0) {
+        for (int r = r0 + wave; r < n; r += NW) { double *row = A + rowoff(r); for (int c = lane; c <= r; c += 64) row[c] = 0.0; }
+        __syncthreads();
+        const int nr = n - r0, per = bw + 6;                   // the band is block-aligned: row r reaches back to column 6 (r/6) - bw
+        for (int e = tid; e < nr*per; e += SOLVE_THREADS) {
+            const int rr = e/per, k = e - rr*per, r = r0 + rr, c = r - k;
+            if (c >= 0 && c >= 6*(r/6) - bw) A[rowoff(r) + c] = S[(size_t)(base + r)*ld + (base + c)];
+        }
+        for (int c = r0 + tid; c < n; c += SOLVE_THREADS) A[rowoff(n) + c] = W.g[base + c];
+        __syncthreads();
+    };
+    load_rows(0);
+    bool first = true;
+    if (tid == 0 && W.dbg) { W.dbg[16] = bw; W.dbg[17] = CB; W.dbg[18] = ntot; W.dbg[19] = 0; W.dbg[20] = -1; }
+    for (;;) {
+        const bool last = base + n == ntot;
+        const int jend = last ? n/6 : CB, jstart = first ? 0 : 1;
+        // ---------------- blocked LDL^T of block columns jstart .. jend-1 of the window (tsba_solve.h, one barrier per block)
+        for (int jb = jstart; jb < jend && !fail; jb++) {
+            const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
+            if (wave < SOLVE_PW) {
+                double Lk[36], dprev[6];
+                if (jb > 0) {
+                    ld6(LD + SOLVE_LD*(jb - 1) + LD_D, dprev);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) ld6(A + rowoff(j0 + c) + p0, Lk + 6*c);
+                }
+                auto load_row = [&](int i, double a[6]) {           // row i of block column jb with panel jb-1 applied
+                    const double *row = A + rowoff(i);
+                    ld6(row + j0, a);
+                    if (jb > 0) {
+                        double y[6];
+                        ld6(row + p0, y);
+#pragma unroll
+                        for (int k = 0; k < 6; k++) y[k] *= dprev[k];
+#pragma unroll
+                        for (int c = 0; c < 6; c++) {
+                            double v0 = y[0]*Lk[c*6], v1 = y[1]*Lk[c*6 + 1];
+                            v0 = fma(y[2], Lk[c*6 + 2], v0); v1 = fma(y[3], Lk[c*6 + 3], v1);
+                            v0 = fma(y[4], Lk[c*6 + 4], v0); v1 = fma(y[5], Lk[c*6 + 5], v1);
+                            a[c] -= v0 + v1;
+                        }
+                    }
+                };
+                // rows below the band of this block column hold zeros and stay zeros: only rows < re (and the rhs row n, which
+                // follows them as virtual row re) are touched
+                const int re = min(n, R0 + bw);
+                auto vrow = [&](int iv) { return iv < re ? iv : n; };
+                const int i0 = lane < 6 ? j0 + lane : R0 + wave*SOLVE_PROWS + lane - 6;
+                double a[6];
+                load_row(vrow(min(i0, re)), a);
+                if (lane < 6) st6(scr + wave*36 + lane*6, a);
+                wave_lds_fence();
+                double s[21], l[15], d[6], id[6]; bool bad = false;
+                {
+                    double t[36];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) ld6(scr + wave*36 + r*6, t + 6*r);
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c <= r; c++) s[tri(r) + c] = t[6*r + c];
+                }
+                ldl6(s, l, d, id, bad);
+                if (wave == 0 && lane == 0) {
+                    double *o = LD + SOLVE_LD*jb;
+#pragma unroll
+                    for (int k = 0; k < 15; k++) o[k] = l[k];
+                    st6(o + LD_D, d); st6(o + LD_ID, id);
+                    if (bad) { fail = 1; st->step_fail = 1; if (W.dbg) { W.dbg[20] = base; W.dbg[21] = jb; W.dbg[22] = n; W.dbg[23] = __double_as_longlong(d[0]); W.dbg[24] = __double_as_longlong(d[5]); } }
+                }
+                auto solve_row = [&](int i, double a[6]) {           // x L^T = a (right-looking), stored row = x D^-1
+#pragma unroll
+                    for (int c = 0; c < 5; c++)
+#pragma unroll
+                        for (int q = c + 1; q < 6; q++) a[q] = fma(-a[c], l[tri(q - 1) + c], a[q]);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) a[c] *= id[c];
+                    st6(A + rowoff(i) + j0, a);
+                };
+                if (lane >= 6) {
+                    if (i0 <= re) solve_row(vrow(i0), a);
+                    for (int i = i0 + SOLVE_PW*SOLVE_PROWS; i <= re; i += SOLVE_PW*SOLVE_PROWS) { load_row(vrow(i), a); solve_row(vrow(i), a); }
+                }
+            } else if (jb > 0) {
+                // trailing update with panel jb-1, whose band ends at row re - 1: rows R0 .. re-1 and the rhs row n (virtual row
+                // re), columns R0 .. re-1
+                const int re = min(n, j0 + bw);
+                const int mr = re - R0 + 1, mc = re - R0;
+                const double *ldp = LD + SOLVE_LD*(jb - 1);
+                if (mc > 0) {
+                    const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4, ntile = tri(ntr);
+                    const int lr = lane & 15, lk = lane >> 4;
+                    const int k1 = min(4 + lk, 5);
+                    const double dk0 = ldp[LD_D + lk], dk1 = lk < 2 ? ldp[LD_D + 4 + lk] : 0.0;
+                    for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
+                        const int ti = tri_row(t), tj = t - tri(ti);
+                        if (tj >= ntc) continue;
+                        // unconditional, index-clamped loads (rows / columns past the edge only feed outputs that are never stored);
+                        // only the K padding (k = 6, 7) must be exact zeros
+                        const int av = min(R0 + 16*ti + lr, re);
+                        const int arow = rowoff(av < re ? av : n) + p0, brow = rowoff(min(R0 + 16*tj + lr, re - 1)) + p0;
+                        double a0 = -A[arow + lk], a1 = -A[arow + k1];
+                        double b0 = A[brow + lk]*dk0, b1 = A[brow + k1]*dk1;
+                        if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
+                        const int ccol = R0 + 16*tj + lr;
+                        v4d c; int ci[4]; bool ok[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int cv = R0 + 16*ti + lk + 4*r;                         // virtual row
+                            ok[r] = cv <= re && ccol <= cv && ccol < re;
+                            const int cvc = min(cv, re), crow = cvc < re ? cvc : n;
+                            ci[r] = rowoff(crow) + min(ccol, min(cvc, re - 1));
+                            c[r] = A[ci[r]];
+                        }
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (ok[r]) A[ci[r]] = c[r];
+                    }
+                }
+            }
+            __syncthreads();                       // panel jb complete, trailing update with panel jb-1 complete
+        }
+        if (fail && !W.dbg) break;
+        // ---------------- finished columns -> HBM: L by block column, unit-lower diagonal factor + 1/d, v = D^-1 L^-1 g
+        {
+            const int nq = jend - jstart, per = REC + 32;
+            for (int e = tid; e < nq*per; e += SOLVE_THREADS) {
+                const int qq = e/per, k = e - qq*per, q = jstart + qq, gq = base/6 + q;
+                if (k < REC) { const int dr = k/6, cc = k - 6*dr, r = 6*q + 6 + dr;
+                    Lcol[(size_t)gq*REC + k] = r < n ? A[rowoff(r) + 6*q + cc] : 0.0; }
+                else { const int u = k - REC;
+                    if (u < 15) W.LDbuf[32*(size_t)gq + u] = LD[SOLVE_LD*q + u];
+                    else if (u >= 16 && u < 22) W.LDbuf[32*(size_t)gq + u] = LD[SOLVE_LD*q + LD_ID + (u - 16)];
+                    else if (u >= 24 && u < 30) W.Sy[6*gq + (u - 24)] = A[rowoff(n) + 6*q + (u - 24)]; }
+            }
+        }
+        if (tid == 0 && W.dbg) W.dbg[19] += 1;
+        if (last || fail) break;
+        // ---------------- slide by s rows: (r, c) -> (r - s, c - s) for r, c >= s, the rhs row to the new last row.  Ascending
+        // packed order, a batch of 4 per thread through registers: a destination lies below every source not yet read
+        {
+            const int s = 6*(jend - 1), m = n - s, n_new = min(Wn, ntot - (base + s)), ne = tri(m) + m;
+            __syncthreads();
+            for (int e0 = 0; e0 < ne; e0 += 4*SOLVE_THREADS) {
+                double v[4]; int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u*SOLVE_THREADS + tid;
+                    dst[u] = -1;
+                    if (e < ne) { const int r = tri_row(e), c = e - tri(r);
+                        v[u] = A[rowoff(r < m ? r + s : n) + c + s]; dst[u] = rowoff(r < m ? r : n_new) + c; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (dst[u] >= 0) A[dst[u]] = v[u];
+                __syncthreads();
+            }
+            if (tid < SOLVE_LD) LD[tid] = LD[SOLVE_LD*(jend - 1) + tid];
+            base += s; n = n_new;
+            // (the rhs row moved first: its new columns and the new rows are loaded below; load_rows starts with a barrier pair)
+            load_rows(m);
+            first = false;
+        }
+    }
+    // (a failed pivot set st->step_fail: k_band_backsub zeroes dp)
+}
+
+// back substitution (second launch: the factor kernel's registers are sized for its panel waves)
+__global__ __launch_bounds__(SOLVE_THREADS) void k_band_backsub(Work W, int bw, const double *Lcol) {
+    LmState *st = W.st;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (st->done) return;
+    const int nfree_all = *W.nfree;
+    if (st->step_fail || nfree_all == 0) { for (int k = tid; k < W.N; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
+    const int REC = bw*6;
+    // ---------------- L^T x = v, block columns nblk-1 .. 0; chunks of BAND_CK block columns double-buffered
+    const int nblk = nfree_all, RECB = REC + 32;
+    double *buf0 = smem, *buf1 = smem + (size_t)BAND_CK*RECB, *ring = buf1 + (size_t)BAND_CK*RECB;
+    for (int k = tid; k < BAND_RING; k += SOLVE_THREADS) ring[k] = 0.0;
+    auto stage = [&](int chunk, double *buf, int t0, int nt) {     // block columns [jlo, jhi) of chunk -> buf (record q = j - jlo)
+        const int jhi = nblk - chunk*BAND_CK, jlo = max(0, jhi - BAND_CK), nq = jhi - jlo;
+        for (int e = t0; e < nq*RECB; e += nt) {
+            const int q = e/RECB, k = e - q*RECB, j = jlo + q;
+            double v = 0.0;
+            if (k < REC) v = Lcol[(size_t)j*REC + k];
+            else { const int u = k - REC; if (u < 24) v = W.LDbuf[32*(size_t)j + u]; else if (u < 30) v = W.Sy[6*j + (u - 24)]; }
+            buf[(size_t)q*RECB + k] = v;
+        }
+    };
+    const int nchunk = (nblk + BAND_CK - 1)/BAND_CK;
+    stage(0, buf0, tid, SOLVE_THREADS);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ch++) {
+        double *buf = (ch & 1) ? buf1 : buf0, *nxt = (ch & 1) ? buf0 : buf1;
+        if (wave > 0) { if (ch + 1 < nchunk) stage(ch + 1, nxt, tid - 64, SOLVE_THREADS - 64); }
+        else {
+            const int jhi = nblk - ch*BAND_CK, jlo = max(0, jhi - BAND_CK);
+            const int c = min(lane >> 2, 5), p = lane & 3;
+            for (int j = jhi - 1; j >= jlo; j--) {
+                const double *rec = buf + (size_t)(j - jlo)*RECB;
+                // s_c = sum_dr L[dr][c] x[6 (j + 1) + dr], four partial sums per c on the lanes of a quad
+                double acc = 0.0;
+                for (int dr = p; dr < bw; dr += 4) acc = fma(rec[dr*6 + c], ring[(6*(j + 1) + dr) & (BAND_RING - 1)], acc);
+                acc = quad_sum(acc);
+                double t[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) t[q] = rec[REC + 24 + q] - readlane_f64(acc, 4*q);
+                // x = l^-T t: unit lower l packed (1,0) (2,0) (2,1) ...
+                double x[6];
+#pragma unroll
+                for (int r = 5; r >= 0; r--) { double v = t[r];
+#pragma unroll
+                    for (int q = r + 1; q < 6; q++) v = fma(-rec[REC + tri(q - 1) + r], x[q], v);
+                    x[r] = v; }
+                if (lane < 6) {
+                    double xv = x[0];
+#pragma unroll
+                    for (int q = 1; q < 6; q++) if (lane == q) xv = x[q];
+                    ring[(6*j + lane) & (BAND_RING - 1)] = xv; W.Sy[6*j + lane] = xv;
+                }
+                wave_lds_fence();
+            }
+        }
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    for (int a = tid; a < W.n_kf; a += SOLVE_THREADS) {
+        const int ia = W.fidx[a];
+#pragma unroll
+        for (int k = 0; k < 6; k++) W.dp[6*a + k] = ia >= 0 ? -W.Sy[6*ia + k] : 0.0;
+    }
+}
