@@ -24,22 +24,6 @@ for (nkf, band) in ((40, 6), (70, 9), (120, 10), (300, 12)):
     bad = np.nonzero(err > 1e-8)[0]
     import ctypes as C
     st = (C.c_longlong*64)(); opt.lib.tsba_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]; print('   rc', opt.lib.tsba_debug_stamps(opt.ctx, st)); print('   dbg bw,CB,ntot,chunks,failbase,jb,n:', list(st[16:23]), np.array([st[23], st[24]], np.int64).view(np.float64))
-    if nkf <= 120 and st[16] > 0:
-        bw = int(st[16]); REC = bw*6; nb = m//6
-        lcol = np.zeros(nb*REC); ldb = np.zeros(32*nb)
-        opt.lib.tsba_debug_band_factor.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
-        print('   rc', opt.lib.tsba_debug_band_factor(opt.ctx, lcol.ctypes.data, lcol.size, ldb.ctypes.data, ldb.size))
-        Cc = np.linalg.cholesky(ro['S']); dd = np.diag(Cc)**2; Lr = Cc/np.diag(Cc)[None, :]
-        for q in range(nb):
-            blk = lcol[q*REC:(q+1)*REC].reshape(bw, 6)
-            rows = np.arange(6*q+6, min(6*q+6+bw, m))
-            refb = Lr[rows][:, 6*q:6*q+6]
-            e = np.abs(blk[:len(rows)] - refb).max() if len(rows) else 0.0
-            idr = 1.0/dd[6*q:6*q+6]; eid = np.abs(ldb[32*q+16:32*q+22] - idr).max()/idr.max()
-            if e > 1e-9 or eid > 1e-9:
-                bad_rows = rows[np.nonzero(np.abs(blk[:len(rows)] - refb).max(axis=1) > 1e-9)[0]]
-                print('   block', q, 'L err %.3e' % e, '1/d rel err %.3e' % eid, 'bad rows', bad_rows[:12], '(local', bad_rows[:12] - 6*q - 6, ')'); break
-        else: print('   all written blocks match')
     print(nkf, band, "nfree", len(free), "max rel err %.3e" % err.max(), "first bad row", (bad[0] if len(bad) else -1), "n bad", len(bad), flush=True)
     if len(bad):
         blocks = sorted(set((bad//6).tolist()))

@@ -10,17 +10,16 @@
 //              last row (forward substitution rides along), exactly the layout of the small-window solver (tsba_solve.h)
 //   chunk    = the small solver's blocked LDL^T step (2 panel waves with look-ahead, 10 MFMA trailing-update waves, one barrier
 //              per pose block) for CB pose blocks; rows further than bw below a column are zeros and stay zeros
-//   write out the finished columns: L by block column (Lcol, contiguous for the back substitution), unit-lower diagonal factor
+//   write out the finished columns: L by row block (contiguous for the back substitution), unit-lower diagonal factor
 //              and 1/d (LDbuf), forward-substituted right-hand side (Sy)
 //   slide    = the trailing (Wn - 6 (CB - 1))^2 / 2 part moves to the top-left corner (the LAST factored block stays as local
 //              block 0: its trailing update is applied by the next chunk's first step, as inside a chunk), new rows come
 //              straight from S in HBM -- no earlier column reaches them
-//   back substitution: wave 0 walks the block columns backwards, x_j = l_j^-T (v_j - sum_r L_rj^T x_r), operands staged
-//              through LDS one chunk ahead by the other eleven waves; dp[6a + k] = -x[6 fidx[a] + k].
+//   back substitution (k_band_backsub): wave 0 walks the row blocks backwards, right-looking, operands staged through LDS one
+//              chunk ahead by the other eleven waves; dp[6a + k] = -x[6 fidx[a] + k].
 #pragma once
 
 #define BAND_CK 8                           /* block columns per back-substitution chunk */
-#define BAND_RING 256                       /* ring of the last solution rows (>= bw + 6) */
 #define BAND_BW_MAX 156                     /* widest band the streaming solver takes (26 keyframes): Wn = 6 CB + bw must fit LDS */
 
 // pose blocks per chunk for a band of bw rows (0: the window does not fit)
@@ -31,7 +30,7 @@ static int band_chunk_blocks(int bw) {
 }
 static size_t band_lds_doubles(int bw, int cb) {
     const size_t fac = solve_lds_doubles(6*cb + bw) + 64;
-    const size_t bs = 2*(size_t)BAND_CK*((size_t)bw*6 + 32) + BAND_RING + 64;
+    const size_t bs = 2*(size_t)BAND_CK*((size_t)bw*6 + 32) + 6*64 + 64;
     return fac > bs ? fac : bs;
 }
 
@@ -194,8 +193,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, in
             const int nq = jend - jstart, per = REC + 32;
             for (int e = tid; e < nq*per; e += SOLVE_THREADS) {
                 const int qq = e/per, k = e - qq*per, q = jstart + qq, gq = base/6 + q;
-                if (k < REC) { const int dr = k/6, cc = k - 6*dr, r = 6*q + 6 + dr;
-                    Lcol[(size_t)gq*REC + k] = r < n ? A[rowoff(r) + 6*q + cc] : 0.0; }
+                if (k < REC) {                                   // L(r, 6 q + cc) -> row block gr, block b = gr - gq - 1, [b][cc][ri]
+                    const int dr = k/6, cc = k - 6*dr, r = 6*q + 6 + dr;
+                    if (r < n) { const int b = dr/6, ri = dr - 6*b;
+                        Lcol[(size_t)(gq + 1 + b)*REC + b*36 + cc*6 + ri] = A[rowoff(r) + 6*q + cc]; } }
                 else { const int u = k - REC;
                     if (u < 15) W.LDbuf[32*(size_t)gq + u] = LD[SOLVE_LD*q + u];
                     else if (u >= 16 && u < 22) W.LDbuf[32*(size_t)gq + u] = LD[SOLVE_LD*q + LD_ID + (u - 16)];
@@ -233,68 +234,116 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, in
     // (a failed pivot set st->step_fail: k_band_backsub zeroes dp)
 }
 
-// back substitution (second launch: the factor kernel's registers are sized for its panel waves)
-__global__ __launch_bounds__(SOLVE_THREADS) void k_band_backsub(Work W, int bw, const double *Lcol) {
+// back substitution L^T x = v (second launch: the factor kernel's registers are sized for its panel waves), right-looking: as
+// soon as x_r is known, every column block j in [r - B, r) receives its term L_rj^T x_r -- only the first of them is needed by
+// the next step, so the dependent chain per step is one 6x6 back-solve and one 6-term update, not the whole band.
+//   Lrow record of row block r: [b][c][ri] = L(6 r + ri, 6 (r - 1 - b) + c), then l_r (15), 1/d (6, unused here), v_r (6)
+//   wave 0: lane = task (b, c) keeps nothing across steps; the running sums u_j live in an LDS ring (6 x 64 row blocks)
+//   waves 1..11 stage the next chunk of records from HBM into the other LDS buffer.
+#define BAND_RINGB 64
+#define BAND_BS_T 512
+template <int NU>                           // NU = tasks per lane = ceil(6 B / 64)
+__global__ __launch_bounds__(BAND_BS_T) void k_band_backsub(Work W, int bw, const double *Lrow) {
     LmState *st = W.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (st->done) return;
     const int nfree_all = *W.nfree;
-    if (st->step_fail || nfree_all == 0) { for (int k = tid; k < W.N; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
-    const int REC = bw*6;
-    // ---------------- L^T x = v, block columns nblk-1 .. 0; chunks of BAND_CK block columns double-buffered
+    if (st->step_fail || nfree_all == 0) { for (int k = tid; k < W.N; k += BAND_BS_T) W.dp[k] = 0.0; return; }
+    const int REC = bw*6, B = bw/6, NTASK = 6*B;
     const int nblk = nfree_all, RECB = REC + 32;
     double *buf0 = smem, *buf1 = smem + (size_t)BAND_CK*RECB, *ring = buf1 + (size_t)BAND_CK*RECB;
-    for (int k = tid; k < BAND_RING; k += SOLVE_THREADS) ring[k] = 0.0;
-    auto stage = [&](int chunk, double *buf, int t0, int nt) {     // block columns [jlo, jhi) of chunk -> buf (record q = j - jlo)
+    for (int k = tid; k < 6*BAND_RINGB; k += BAND_BS_T) ring[k] = 0.0;
+    // row blocks [jlo, jhi) of a chunk -> buf (record q = j - jlo).  A stager thread issues ALL its loads before the first
+    // store: one HBM latency per chunk, not one per element
+    auto stage = [&](int chunk, double *buf, int t0, int nt) {
         const int jhi = nblk - chunk*BAND_CK, jlo = max(0, jhi - BAND_CK), nq = jhi - jlo;
-        for (int e = t0; e < nq*RECB; e += nt) {
-            const int q = e/RECB, k = e - q*RECB, j = jlo + q;
-            double v = 0.0;
-            if (k < REC) v = Lcol[(size_t)j*REC + k];
-            else { const int u = k - REC; if (u < 24) v = W.LDbuf[32*(size_t)j + u]; else if (u < 30) v = W.Sy[6*j + (u - 24)]; }
-            buf[(size_t)q*RECB + k] = v;
+        const int h = REC >> 1, n2 = nq*h;                                   // the L parts are one contiguous run of double2
+        const v2d *src = (const v2d *)(Lrow + (size_t)jlo*REC);
+        const int tx = t0;                                                   // extras: 32 per record, one per thread
+        double xv = 0.0; int xd = -1;
+        if (tx < nq*32) { const int q = tx >> 5, u = tx & 31, j = jlo + q; xd = q*RECB + REC + u;
+            xv = u < 24 ? W.LDbuf[32*(size_t)j + u] : (u < 30 ? W.Sy[6*j + (u - 24)] : 0.0); }
+        for (int e0 = t0; e0 < n2; e0 += 4*nt) {
+            v2d v[4]; int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u*nt; dst[u] = -1;
+                if (e < n2) { const int q = e/h, k2 = e - q*h; dst[u] = q*RECB + 2*k2;
+                    v[u] = (jlo + q - 1 - (2*k2)/36 >= 0) ? src[e] : v2d{0.0, 0.0}; }    // (blocks left of column 0 were never written)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (dst[u] >= 0) *(v2d *)(buf + dst[u]) = v[u];
         }
+        if (xd >= 0) buf[xd] = xv;
     };
     const int nchunk = (nblk + BAND_CK - 1)/BAND_CK;
-    stage(0, buf0, tid, SOLVE_THREADS);
+    stage(0, buf0, tid, BAND_BS_T);
     __syncthreads();
+    // this lane's tasks (b, c): target row block r - 1 - b, component c
+    int tb[NU], tc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) { const int t = lane + 64*u; tb[u] = t < NTASK ? t/6 : -1; tc[u] = t - 6*(t/6); }
+    struct Ops { double Lr[NU][6], l[16], vv[6]; };
+    auto fetch = [&](const double *rec, Ops &o) {                  // the record data of one step: independent of the running solution
+#pragma unroll
+        for (int u = 0; u < NU; u++) if (tb[u] >= 0) ld6(rec + 6*(lane + 64*u), o.Lr[u]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const v2d x2 = ((const v2d *)(rec + REC))[k]; o.l[2*k] = x2.x; o.l[2*k + 1] = x2.y; }
+        ld6(rec + REC + 24, o.vv);
+    };
+    auto step = [&](int r, const Ops &o, const double *nrec, Ops &on) {
+        // the reads that depend on the previous step first, then the next step's record
+        double ur[6], uo[NU]; int slot[NU];
+        ld6(ring + 6*(r & (BAND_RINGB - 1)), ur);
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int j = r - 1 - tb[u];
+            slot[u] = (tb[u] >= 0 && j >= 0) ? 6*(j & (BAND_RINGB - 1)) + tc[u] : -1;
+            uo[u] = slot[u] >= 0 ? ring[slot[u]] : 0.0;
+        }
+        if (nrec) fetch(nrec, on);
+        // x = l^-T (v - u): unit lower l packed (1,0) (2,0) (2,1) ...
+        double x[6];
+#pragma unroll
+        for (int q = 5; q >= 0; q--) { double v = o.vv[q] - ur[q];
+#pragma unroll
+            for (int k = q + 1; k < 6; k++) v = fma(-o.l[tri(k - 1) + q], x[k], v);
+            x[q] = v; }
+#pragma unroll
+        for (int u = 0; u < NU; u++)
+            if (slot[u] >= 0) {
+                const double s0 = fma(o.Lr[u][0], x[0], fma(o.Lr[u][1], x[1], o.Lr[u][2]*x[2])), s1 = fma(o.Lr[u][3], x[3], fma(o.Lr[u][4], x[4], o.Lr[u][5]*x[5]));
+                ring[slot[u]] = uo[u] + (s0 + s1);
+            }
+        if (lane < 6) {
+            double xv = x[0];
+#pragma unroll
+            for (int q = 1; q < 6; q++) if (lane == q) xv = x[q];
+            ring[6*(r & (BAND_RINGB - 1)) + lane] = 0.0;                   // the slot is reused 64 row blocks further up
+            W.Sy[6*r + lane] = xv;
+        }
+        wave_lds_fence();
+    };
     for (int ch = 0; ch < nchunk; ch++) {
         double *buf = (ch & 1) ? buf1 : buf0, *nxt = (ch & 1) ? buf0 : buf1;
-        if (wave > 0) { if (ch + 1 < nchunk) stage(ch + 1, nxt, tid - 64, SOLVE_THREADS - 64); }
+        if (wave > 0) { if (ch + 1 < nchunk) stage(ch + 1, nxt, tid - 64, BAND_BS_T - 64); }
         else {
             const int jhi = nblk - ch*BAND_CK, jlo = max(0, jhi - BAND_CK);
-            const int c = min(lane >> 2, 5), p = lane & 3;
-            for (int j = jhi - 1; j >= jlo; j--) {
-                const double *rec = buf + (size_t)(j - jlo)*RECB;
-                // s_c = sum_dr L[dr][c] x[6 (j + 1) + dr], four partial sums per c on the lanes of a quad
-                double acc = 0.0;
-                for (int dr = p; dr < bw; dr += 4) acc = fma(rec[dr*6 + c], ring[(6*(j + 1) + dr) & (BAND_RING - 1)], acc);
-                acc = quad_sum(acc);
-                double t[6];
-#pragma unroll
-                for (int q = 0; q < 6; q++) t[q] = rec[REC + 24 + q] - readlane_f64(acc, 4*q);
-                // x = l^-T t: unit lower l packed (1,0) (2,0) (2,1) ...
-                double x[6];
-#pragma unroll
-                for (int r = 5; r >= 0; r--) { double v = t[r];
-#pragma unroll
-                    for (int q = r + 1; q < 6; q++) v = fma(-rec[REC + tri(q - 1) + r], x[q], v);
-                    x[r] = v; }
-                if (lane < 6) {
-                    double xv = x[0];
-#pragma unroll
-                    for (int q = 1; q < 6; q++) if (lane == q) xv = x[q];
-                    ring[(6*j + lane) & (BAND_RING - 1)] = xv; W.Sy[6*j + lane] = xv;
-                }
-                wave_lds_fence();
+            Ops oa, ob;
+            int r = jhi - 1;
+            fetch(buf + (size_t)(r - jlo)*RECB, oa);
+            for (; r - 1 >= jlo; r -= 2) {                                   // two steps per trip: the register sets alternate
+                step(r, oa, buf + (size_t)(r - 1 - jlo)*RECB, ob);
+                step(r - 1, ob, r - 2 >= jlo ? buf + (size_t)(r - 2 - jlo)*RECB : nullptr, oa);
             }
+            if (r >= jlo) step(r, oa, nullptr, ob);
         }
         __syncthreads();
     }
     __threadfence();
     __syncthreads();
-    for (int a = tid; a < W.n_kf; a += SOLVE_THREADS) {
+    for (int a = tid; a < W.n_kf; a += BAND_BS_T) {
         const int ia = W.fidx[a];
 #pragma unroll
         for (int k = 0; k < 6; k++) W.dp[6*a + k] = ia >= 0 ? -W.Sy[6*ia + k] : 0.0;
