@@ -12,3 +12,7 @@ t = time.time(); opt.upload(P, o); print("upload s", time.time() - t)
 for _ in range(2):
     t = time.time(); rep = opt.solve()
     print("solve ms %.1f" % ((time.time() - t)*1e3), rep['iters'], rep['accepted'], rep['termination'], rep['cost0'], rep['cost1'], rep['n_sblock'], flush=True)
+import ctypes as C
+st = (C.c_longlong*64)(); opt.lib.tsba_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]; opt.lib.tsba_debug_stamps(opt.ctx, st)
+tot = sum(st[32:36]) or 1
+print("band solve phases (clock64 ticks, last launch): factor %d  write-out %d  slide %d  load %d  -> %.1f%% / %.1f%% / %.1f%% / %.1f%%; chunks %d" % (st[32], st[33], st[34], st[35], 100*st[32]/tot, 100*st[33]/tot, 100*st[34]/tot, 100*st[35]/tot, st[19]))

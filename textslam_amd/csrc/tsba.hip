@@ -282,7 +282,7 @@ __device__ void raster_quad(unsigned *mask, const int *s_xy, int w, int hh, int 
             const bool steep = dy > dx;
             const int major = (int)(steep ? dy : dx), minor = (int)(steep ? dx : dy);
             for (int i = li; i <= major; i += per) {
-                const int ci = major > 0 ? (int)((2LL*minor*i + major - 1)/(2LL*major)) : 0;
+                const int ci = major > 0 ? (2*minor*i + major - 1)/(2*major) : 0;     // (clipped coordinates: < 2^21)
                 const long long x = steep ? x1 + ci : x1 + i, y = steep ? y1 + sy*i : y1 + sy*ci;
                 if (x >= 0 && x < w && y >= 0 && y < hh) atomicOr(&mask[(y*w + x) >> 5], 1u << ((y*w + x) & 31));
             }

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, in
         for (int c = r0 + tid; c < n; c += SOLVE_THREADS) A[rowoff(n) + c] = W.g[base + c];
         __syncthreads();
     };
+    long long tF = 0, tW = 0, tS = 0, tL = 0, tx = clock64();
     load_rows(0);
+    { const long long t_ = clock64(); tL += t_ - tx; tx = t_; }
     bool first = true;
     if (tid == 0 && W.dbg) { W.dbg[16] = bw; W.dbg[17] = CB; W.dbg[18] = ntot; W.dbg[19] = 0; W.dbg[20] = -1; }
     for (;;) {
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, in
             }
             __syncthreads();                       // panel jb complete, trailing update with panel jb-1 complete
         }
+        { const long long t_ = clock64(); tF += t_ - tx; tx = t_; }
         if (fail && !W.dbg) break;
         // ---------------- finished columns -> HBM: L by block column, unit-lower diagonal factor + 1/d, v = D^-1 L^-1 g
         {
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, in
                     else if (u >= 24 && u < 30) W.Sy[6*gq + (u - 24)] = A[rowoff(n) + 6*q + (u - 24)]; }
             }
         }
-        if (tid == 0 && W.dbg) W.dbg[19] += 1;
+        { const long long t_ = clock64(); tW += t_ - tx; tx = t_; }
+        if (tid == 0 && W.dbg) { W.dbg[19] += 1; W.dbg[32] = tF; W.dbg[33] = tW; W.dbg[34] = tS; W.dbg[35] = tL; }
         if (last || fail) break;
         // ---------------- slide by s rows: (r, c) -> (r - s, c - s) for r, c >= s, the rhs row to the new last row.  Ascending
         // packed order, a batch of 4 per thread through registers: a destination lies below every source not yet read
@@ -226,8 +230,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, in
             }
             if (tid < SOLVE_LD) LD[tid] = LD[SOLVE_LD*(jend - 1) + tid];
             base += s; n = n_new;
+            { const long long t_ = clock64(); tS += t_ - tx; tx = t_; }
             // (the rhs row moved first: its new columns and the new rows are loaded below; load_rows starts with a barrier pair)
             load_rows(m);
+            { const long long t_ = clock64(); tL += t_ - tx; tx = t_; }
             first = false;
         }
     }
