@@ -246,3 +246,61 @@ def orb_match(kp6, desc, bounds, qxy, qr, qlev, qdesc, max_cand=64):
                               ip(ci), ip(cd), ip(cc), ip(bi), ip(bd), ip(bd2))
     assert rc == 0
     return dict(cand_idx=ci, cand_dist=cd, cand_cnt=cc, best_idx=bi, best_dist=bd, best_dist2=bd2)
+
+
+# ---- BA pyramid / reference features (oracle/tsframe_oracle.c)
+_FLIB = None
+
+
+def _flib():
+    global _FLIB
+    if _FLIB is None:
+        so = os.path.join(_HERE, "libtsframe_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _FLIB = C.CDLL(so)
+    return _FLIB
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def frame_pyramid(img, n_levels):
+    """frame::GetPyrMat: returns [(img, grad, gx, gy)] per level."""
+    L = _flib(); out = []
+    cur = np.ascontiguousarray(img, np.uint8)
+    for l in range(n_levels):
+        if l > 0:
+            h, w = cur.shape
+            nxt = np.zeros(((h + 1)//2, (w + 1)//2), np.uint8)
+            L.tsframe_oracle_pyrdown(_u8p(cur), C.c_int(w), C.c_int(h), _u8p(nxt))
+            cur = nxt
+        h, w = cur.shape
+        gx, gy, g = np.zeros_like(cur), np.zeros_like(cur), np.zeros_like(cur)
+        L.tsframe_oracle_gradients(_u8p(cur), C.c_int(w), C.c_int(h), _u8p(gx), _u8p(gy), _u8p(g))
+        out.append((cur, g, gx, gy))
+    return out
+
+
+def frame_pyramid_pts(mode, xy, box, pyr, inv_scale):
+    """tool::GetPyramidPts (mode 0 text / 1 scene) on the pyramid returned by frame_pyramid."""
+    L = _flib(); n = len(xy); nl = len(pyr)
+    xy = np.ascontiguousarray(xy, np.float32); cap = max(1, n*nl)
+    imgs = (C.POINTER(C.c_uint8)*nl)(*[_u8p(p[0]) for p in pyr]); grads = (C.POINTER(C.c_uint8)*nl)(*[_u8p(p[1]) for p in pyr])
+    w = np.array([p[0].shape[1] for p in pyr], np.int32); h = np.array([p[0].shape[0] for p in pyr], np.int32)
+    inv = np.ascontiguousarray(inv_scale, np.float64); bx = np.ascontiguousarray(box if box is not None else [0, 0, 1, 1], np.float64)
+    off = np.zeros(nl + 1, np.int32); u = np.zeros(cap); v = np.zeros(cap); idx = np.zeros(cap, np.int32); I = np.zeros(cap); inn = np.zeros(cap, np.uint8)
+    ip = C.POINTER(C.c_int32)
+    L.tsframe_oracle_pyramid_pts.restype = C.c_int
+    m = L.tsframe_oracle_pyramid_pts(C.c_int(mode), xy.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(n), _dp(bx), C.c_int(nl), imgs, grads,
+                                     w.ctypes.data_as(ip), h.ctypes.data_as(ip), _dp(inv), off.ctypes.data_as(ip), _dp(u), _dp(v), idx.ctypes.data_as(ip), _dp(I), _u8p(inn))
+    return {"level_off": off, "u": u[:m], "v": v[:m], "idx": idx[:m], "inten": I[:m], "in": inn[:m]}
+
+
+def frame_neighbours(img, uv, mu, sigma):
+    """tool::CalNormvec / GetNeighbour(INTERVAL8)."""
+    L = _flib(); img = np.ascontiguousarray(img, np.uint8); uv = np.ascontiguousarray(uv, np.float64); n = len(uv)
+    I = np.zeros((n, 8)); N = np.zeros((n, 8)); inn = np.zeros(n, np.uint8)
+    L.tsframe_oracle_neighbours(_u8p(img), C.c_int(img.shape[1]), C.c_int(img.shape[0]), _dp(uv), C.c_int(n), C.c_double(mu), C.c_double(sigma), _dp(I), _dp(N), _u8p(inn))
+    return I, N, inn
