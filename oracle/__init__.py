@@ -304,3 +304,49 @@ def frame_neighbours(img, uv, mu, sigma):
     I = np.zeros((n, 8)); N = np.zeros((n, 8)); inn = np.zeros(n, np.uint8)
     L.tsframe_oracle_neighbours(_u8p(img), C.c_int(img.shape[1]), C.c_int(img.shape[0]), _dp(uv), C.c_int(n), C.c_double(mu), C.c_double(sigma), _dp(I), _dp(N), _u8p(inn))
     return I, N, inn
+
+
+# ---- loop-closure optimisers (oracle/tsloop_oracle.c)
+_LLIB = None
+
+
+def _llib():
+    global _LLIB
+    if _LLIB is None:
+        so = os.path.join(_HERE, "libtsloop_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LLIB = C.CDLL(so)
+    return _LLIB
+
+
+def sim3_default_options():
+    from textslam_amd.loop import TsloopOptions
+    o = TsloopOptions(); _llib().tsloop_oracle_default_options_sim3(C.byref(o)); return o
+
+
+def optimize_sim3(P1, uv1, P2, uv2, inliers, sim, K, options=None):
+    """optimizer::OptimizeSim3 on the CPU: returns (numInlier, Sim12, vbInliers, report)."""
+    from textslam_amd.loop import make_sim3_problem, TsloopReport, report_dict
+    L = _llib(); o = options or sim3_default_options()
+    p, keep, inl = make_sim3_problem(P1, P2, uv1, uv2, inliers, sim, K)
+    r = TsloopReport()
+    L.tsloop_oracle_optimize_sim3.restype = C.c_int
+    rc = L.tsloop_oracle_optimize_sim3(C.byref(p), C.byref(o), C.byref(r))
+    rep = report_dict(r); rep["status"] = rc
+    return r.n_inlier, np.array(list(p.sim)), inl.astype(bool), rep
+
+
+def sim3_eval(x, P1, P2, uv1, uv2, K):
+    """Residuals (4) and tangent-space Jacobian (4 x 7) of one match."""
+    L = _llib()
+    x = np.ascontiguousarray(x, np.float64); P1 = np.ascontiguousarray(P1, np.float64); P2 = np.ascontiguousarray(P2, np.float64)
+    u1 = np.ascontiguousarray(uv1, np.float32); u2 = np.ascontiguousarray(uv2, np.float32); K = np.ascontiguousarray(K, np.float64)
+    r = np.zeros(4); J = np.zeros((4, 7))
+    fp = C.POINTER(C.c_float)
+    L.tsloop_oracle_sim3_eval(_dp(x), _dp(P1), _dp(P2), u1.ctypes.data_as(fp), u2.ctypes.data_as(fp), _dp(K), _dp(r), _dp(J))
+    return r, J
+
+
+def quat_plus(x, d):
+    o = np.zeros(4); _llib().tsloop_oracle_quat_plus(_dp(np.ascontiguousarray(x, np.float64)), _dp(np.ascontiguousarray(d, np.float64)), _dp(o)); return o

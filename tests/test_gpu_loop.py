@@ -1,0 +1,48 @@
+"""GPU parity of the loop-closure optimisers (libtsloop.so through the C ABI) against the CPU oracle.  fp64 on both sides, different
+derivative routes (closed tangent-space forms on the device, chained ambient Jacobians in the oracle) and summation orders:
+converged Sim3 within 1e-8 relative, identical iteration counts / termination / inlier sets."""
+import numpy as np
+import pytest
+
+from textslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lo():
+    from textslam_amd.loop import LoopOptimizer
+    return LoopOptimizer(0)
+
+
+@pytest.mark.parametrize("seed,n,outl", [(1, 300, 0.1), (2, 60, 0.0), (3, 1500, 0.25), (4, 9, 0.0)])
+def test_optimize_sim3_parity(lo, oracle_lib, seed, n, outl):
+    m = synth.sim3_matches(seed=seed, n=n, outlier_frac=outl)
+    a = (m["P1"], m["uv1"], m["P2"], m["uv2"], m["inliers"], m["sim0"], m["K"])
+    ng, sg, ig, rg = lo.OptimizeSim3(*a)
+    no, so, io, ro = oracle_lib.optimize_sim3(*a)
+    assert (rg["iters"], rg["accepted"], rg["termination"]) == (ro["iters"], ro["accepted"], ro["termination"])
+    np.testing.assert_allclose(rg["cost0"], ro["cost0"], rtol=1e-12)
+    np.testing.assert_allclose(rg["cost1"], ro["cost1"], rtol=1e-9)
+    np.testing.assert_allclose(sg, so, rtol=0, atol=1e-8)
+    assert ng == no and np.array_equal(ig, io)
+    if outl > 0:
+        assert ng < n
+
+
+def test_optimize_sim3_edge_cases(lo, oracle_lib):
+    m = synth.sim3_matches(seed=5, n=30)
+    n, sim, inl, rep = lo.OptimizeSim3(m["P1"], m["uv1"], m["P2"], m["uv2"], np.zeros(30, np.uint8), m["sim0"], m["K"])
+    assert n == 0 and rep["termination"] == 5 and rep["status"] == -3                 # nothing to optimise
+    n, sim, inl, rep = lo.OptimizeSim3(np.zeros((0, 3)), np.zeros((0, 2)), np.zeros((0, 3)), np.zeros((0, 2)), np.zeros(0, np.uint8), m["sim0"], m["K"])
+    assert n == 0 and rep["termination"] == 5
+    # restart from the solution: converges at once (function tolerance), same answer on both sides
+    a = (m["P1"], m["uv1"], m["P2"], m["uv2"], m["inliers"], m["sim0"], m["K"])
+    n1, s1, i1, r1 = lo.OptimizeSim3(*a)
+    n2, s2, i2, r2 = lo.OptimizeSim3(m["P1"], m["uv1"], m["P2"], m["uv2"], i1.astype(np.uint8), s1, m["K"])
+    no, so, io, ro = oracle_lib.optimize_sim3(m["P1"], m["uv1"], m["P2"], m["uv2"], i1.astype(np.uint8), s1, m["K"])
+    assert r2["iters"] == ro["iters"] <= 3 and np.allclose(s2, so, atol=1e-9) and n2 == no
+    from textslam_amd.loop import LoopError
+    bad = m["sim0"].copy(); bad[7] = 0.0
+    with pytest.raises(LoopError):
+        lo.OptimizeSim3(m["P1"], m["uv1"], m["P2"], m["uv2"], m["inliers"], bad, m["K"])

@@ -1,0 +1,79 @@
+"""CPU checks of the loop-closure restatement (oracle/tsloop_oracle.c): the chained ambient Jacobians of auto_sim /
+auto_siminv against central differences on the manifold, the LM solve recovering a known Sim3, and that libtsloop.so loads and exports
+every symbol include/tsloop.h declares (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+from textslam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sim3_jacobians_against_central_differences(oracle_lib):
+    m = synth.sim3_matches(seed=3, n=40)
+    x = m["sim0"].copy(); x[:4] /= np.linalg.norm(x[:4])
+    h = 1e-6
+    for i in range(0, 40, 7):
+        args = (m["P1"][i], m["P2"][i], m["uv1"][i], m["uv2"][i], m["K"])
+        r, J = oracle_lib.sim3_eval(x, *args)
+        Jn = np.zeros((4, 7))
+        for k in range(7):
+            d = np.zeros(7); d[k] = h
+            xp = np.concatenate([oracle_lib.quat_plus(x[:4], d[:3]), x[4:] + d[3:]])
+            xm = np.concatenate([oracle_lib.quat_plus(x[:4], -d[:3]), x[4:] - d[3:]])
+            Jn[:, k] = (oracle_lib.sim3_eval(xp, *args)[0] - oracle_lib.sim3_eval(xm, *args)[0])/(2*h)
+        assert np.abs(J - Jn).max() <= 1e-8*np.abs(J).max()
+        assert abs(J[2, 6]) < 1e-9 and abs(J[3, 6]) < 1e-9          # the inverse projection does not depend on the scale
+
+
+def test_sim3_recovers_the_true_similarity(oracle_lib):
+    m = synth.sim3_matches(seed=11, n=400, noise_px=0.3)
+    n, sim, inl, rep = oracle_lib.optimize_sim3(m["P1"], m["uv1"], m["P2"], m["uv2"], m["inliers"], m["sim0"], m["K"])
+    assert rep["status"] == 0 and rep["termination"] in (1, 2, 3) and rep["cost1"] < 0.2*rep["cost0"]
+    assert abs(np.linalg.norm(sim[:4]) - 1.0) < 1e-12
+    assert abs(sim[7] - m["sim_true"][7]) < 0.01 and np.abs(sim[4:7] - m["sim_true"][4:7]).max() < 0.01
+    assert min(np.abs(sim[:4] - m["sim_true"][:4]).max(), np.abs(sim[:4] + m["sim_true"][:4]).max()) < 2e-3
+    assert 0.8*400 < n < 400 and n == inl.sum()                    # the gross outliers (10 %) fail the 4 px test
+
+
+def test_sim3_edge_cases(oracle_lib):
+    m = synth.sim3_matches(seed=5, n=30)
+    none = np.zeros(30, np.uint8)                                  # no inlier left: nothing to optimise
+    n, sim, inl, rep = oracle_lib.optimize_sim3(m["P1"], m["uv1"], m["P2"], m["uv2"], none, m["sim0"], m["K"])
+    assert n == 0 and rep["termination"] == 5 and rep["iters"] == 0
+    q = m["sim0"][:4]/np.linalg.norm(m["sim0"][:4])
+    assert np.allclose(sim[:4], q) and np.array_equal(sim[4:], m["sim0"][4:])
+
+
+def test_libtsloop_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    so = os.path.join(ROOT, "textslam_amd", "libtsloop.so")
+    if not os.path.exists(so):
+        ge.build()
+    lib = C.CDLL(so)
+    names = sorted(set(re.findall(r"\b(tsloop_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "tsloop.h")).read())))
+    assert len(names) >= 5
+    for nme in names:
+        assert hasattr(lib, nme), f"{nme} declared in include/tsloop.h but not exported"
+    from textslam_amd import loop
+    assert sorted(loop.EXPORTED_SYMBOLS) == names
+    o = loop.TsloopOptions(); lib.tsloop_default_options_sim3(C.byref(o))
+    assert o.max_it == 20 and abs(o.huber_delta - 10**0.5) < 1e-15 and o.thresh_outlier == 4.0      # optimizer.cc:629,661,676
+    oo = __import__("oracle").sim3_default_options()
+    assert bytes(o) == bytes(oo)
+
+
+def test_struct_layout_matches_header(tmp_path):
+    import subprocess
+    from textslam_amd import loop
+    src = tmp_path / "sz.c"
+    src.write_text('#include "tsloop.h"\nunsigned long a(void){return sizeof(tsloop_options);}\nunsigned long b(void){return sizeof(tsloop_report);}\n'
+                   'unsigned long c(void){return sizeof(tsloop_sim3_problem);}\n')
+    so = tmp_path / "sz.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-o", str(so), str(src)])
+    L = C.CDLL(str(so))
+    for f in "abc": getattr(L, f).restype = C.c_ulong
+    assert L.a() == C.sizeof(loop.TsloopOptions) and L.b() == C.sizeof(loop.TsloopReport) and L.c() == C.sizeof(loop.TsloopSim3Problem)

@@ -441,3 +441,32 @@ def landmark_refine(seed=SEED, n_kf=5, n_pt=150, n_text=4):
     """optimizer::OptimizeLandmarker / ThetaOptimMultiFs: every pose constant (and at its true value), landmarks perturbed."""
     return make_problem(n_kf, n_pt, n_text, seed, feats=(24, 12, 8, 6), n_levels=4, frozen_frac=0.0, text_targets=3,
                         n_fixed=n_kf, kf_initial=np.ones(n_kf, np.uint8))
+
+
+def sim3_matches(seed=SEED, n=300, outlier_frac=0.1, noise_px=0.5, scale=1.07):
+    """optimizer::OptimizeSim3 input: n 3D-2D matches between two keyframes related by a Sim3 (loop closure with scale drift).
+    Returns dict(P1, uv1, P2, uv2, inliers, sim0 (perturbed initial Sim12), sim_true, K)."""
+    rng = np.random.default_rng(seed)
+    K = np.array([384.396254546, 382.825746531, 315.635886103, 249.182929809])
+    ang = np.deg2rad(7.0); ax = np.array([0.2, 1.0, 0.1]); ax /= np.linalg.norm(ax)
+    q = np.concatenate([[np.cos(ang/2)], np.sin(ang/2)*ax]); t = np.array([0.25, -0.05, 0.1])
+
+    def R_of(qq):
+        w, x, y, z = qq/np.linalg.norm(qq)
+        return np.array([[1 - 2*(y*y + z*z), 2*(x*y - w*z), 2*(x*z + w*y)], [2*(x*y + w*z), 1 - 2*(x*x + z*z), 2*(y*z - w*x)], [2*(x*z - w*y), 2*(y*z + w*x), 1 - 2*(x*x + y*y)]])
+    R = R_of(q)
+    P2 = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.0, 1.0, n), rng.uniform(2.5, 7.0, n)], 1)
+    P1 = (scale*(R @ P2.T)).T + t
+
+    def proj(P):
+        return np.stack([K[0]*P[:, 0]/P[:, 2] + K[2], K[1]*P[:, 1]/P[:, 2] + K[3]], 1)
+    uv1 = proj(P1) + rng.normal(0, noise_px, (n, 2)); uv2 = proj(P2) + rng.normal(0, noise_px, (n, 2))
+    bad = rng.random(n) < outlier_frac
+    uv1[bad] += rng.uniform(8, 30, (int(bad.sum()), 2))*rng.choice([-1, 1], (int(bad.sum()), 2))
+    # the map points carry some depth error on each side (posObv comes from each keyframe's own map)
+    P1n = P1*(1 + rng.normal(0, 0.004, (n, 1))); P2n = P2*(1 + rng.normal(0, 0.004, (n, 1)))
+    dq = np.concatenate([[1.0], rng.normal(0, 0.01, 3)]); dq /= np.linalg.norm(dq)
+    q0 = np.array([dq[0]*q[0] - dq[1:] @ q[1:], *(dq[0]*q[1:] + q[0]*dq[1:] + np.cross(dq[1:], q[1:]))])
+    sim0 = np.concatenate([q0, t + rng.normal(0, 0.03, 3), [scale*1.04]])
+    return {"P1": P1n, "uv1": uv1.astype(np.float32), "P2": P2n, "uv2": uv2.astype(np.float32), "inliers": np.ones(n, np.uint8),
+            "sim0": sim0, "sim_true": np.concatenate([q, t, [scale]]), "K": K}
