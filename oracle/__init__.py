@@ -350,3 +350,25 @@ def sim3_eval(x, P1, P2, uv1, uv2, K):
 
 def quat_plus(x, d):
     o = np.zeros(4); _llib().tsloop_oracle_quat_plus(_dp(np.ascontiguousarray(x, np.float64)), _dp(np.ascontiguousarray(d, np.float64)), _dp(o)); return o
+
+
+def optimize_loop(pose, fixed, edge_i, edge_j, meas, options=None):
+    """optimizer::OptimizeLoop (the solve) on the CPU with dense normal equations: returns (poses, report)."""
+    from textslam_amd.loop import make_graph_problem, TsloopReport, TsloopOptions, report_dict
+    L = _llib()
+    if options is None:
+        options = sim3_default_options(); options.huber_delta = 0.0; options.thresh_outlier = 0.0
+    p, keep, x = make_graph_problem(pose, fixed, edge_i, edge_j, meas)
+    r = TsloopReport()
+    L.tsloop_oracle_optimize_loop.restype = C.c_int
+    rc = L.tsloop_oracle_optimize_loop(C.byref(p), C.byref(options), C.byref(r))
+    rep = report_dict(r); rep["status"] = rc
+    return x, rep
+
+
+def pg_eval(x1, x2, m):
+    """Residual (7) and tangent Jacobians (7 x 7 each) of one pose-graph connection."""
+    L = _llib(); r = np.zeros(7); J1 = np.zeros((7, 7)); J2 = np.zeros((7, 7))
+    a = [np.ascontiguousarray(v, np.float64) for v in (x1, x2, m)]
+    L.tsloop_oracle_pg_eval(_dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(r), _dp(J1), _dp(J2))
+    return r, J1, J2

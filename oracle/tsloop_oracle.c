@@ -238,3 +238,188 @@ void tsloop_oracle_sim3_eval(const double x[8], const double P1[3], const double
     }
 }
 void tsloop_oracle_quat_plus(const double x[4], const double d[3], double o[4]) { quat_plus(x, d, o); }
+
+/* ================================================================================================================================
+ * optimizer::OptimizeLoop (src/optimizer.cc:733-957): Sim3 pose graph over all keyframes.  Parameter blocks per keyframe q (4,
+ * QuaternionParameterization), t (3), s (1); one residual block per (i, j) connection = numer_loop_ver2 (include/numer_loop_ver2.h:
+ * 22-72): logSim3( S_ji(measured) * S_i * S_j^-1 ) (include/ModelTool.hpp:354-432), NumericDiffCostFunction<CENTRAL, 7, 4,3,1, 4,3,1>,
+ * no loss; keyframes 0, 1 and the loop keyframe constant (:861-869); LM, 20 iterations (:871-877).  The map update that follows
+ * (:884-956: SetPose, rho *= s, theta *= s) is host bookkeeping of the caller and not part of this restatement. */
+static void q_mul(const double a[4], const double b[4], double o[4]) {           /* Eigen quaternion product, (w, x, y, z) */
+    o[0] = a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3];
+    o[1] = a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2];
+    o[2] = a[0]*b[2] + a[2]*b[0] + a[3]*b[1] - a[1]*b[3];
+    o[3] = a[0]*b[3] + a[3]*b[0] + a[1]*b[2] - a[2]*b[1];
+}
+static void q_rot(const double q[4], const double v[3], double o[3]) {           /* Eigen QuaternionBase::_transformVector */
+    double uv[3] = { q[2]*v[2] - q[3]*v[1], q[3]*v[0] - q[1]*v[2], q[1]*v[1] - q[2]*v[0] };
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    o[0] = v[0] + q[0]*uv[0] + (q[2]*uv[2] - q[3]*uv[1]);
+    o[1] = v[1] + q[0]*uv[1] + (q[3]*uv[0] - q[1]*uv[2]);
+    o[2] = v[2] + q[0]*uv[2] + (q[1]*uv[1] - q[2]*uv[0]);
+}
+static void q_norm(const double q[4], double o[4]) { const double n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]); for (int k = 0; k < 4; k++) o[k] = q[k]/n; }
+static void q_to_R(const double q[4], double R[9]) {                             /* Eigen toRotationMatrix (no normalisation) */
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2*x, ty = 2*y, tz = 2*z, twx = tx*w, twy = ty*w, twz = tz*w, txx = tx*x, txy = ty*x, txz = tz*x, tyy = ty*y, tyz = tz*y, tzz = tz*z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy; R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx; R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+static int solve3_lu(const double W_[9], const double b_[3], double x[3]) {      /* 3x3 partial-pivot LU (Eigen .lu().solve) */
+    double A[9], b[3]; memcpy(A, W_, sizeof(A)); memcpy(b, b_, sizeof(b));
+    for (int c = 0; c < 3; c++) {
+        int piv = c; for (int r = c + 1; r < 3; r++) if (fabs(A[3*r + c]) > fabs(A[3*piv + c])) piv = r;
+        if (piv != c) { for (int k = 0; k < 3; k++) { double t = A[3*c + k]; A[3*c + k] = A[3*piv + k]; A[3*piv + k] = t; } double t = b[c]; b[c] = b[piv]; b[piv] = t; }
+        for (int r = c + 1; r < 3; r++) { const double f = A[3*r + c]/A[3*c + c]; for (int k = c; k < 3; k++) A[3*r + k] -= f*A[3*c + k]; b[r] -= f*b[c]; }
+    }
+    for (int r = 2; r >= 0; r--) { double v = b[r]; for (int k = r + 1; k < 3; k++) v -= A[3*r + k]*x[k]; x[r] = v/A[3*r + r]; }
+    return 0;
+}
+static void log_sim3(const double rq[4], const double t[3], double s, double res[7]) {      /* ModelTool.hpp:354-432 */
+    const double sigma = log(s), eps = 0.00001;
+    double R[9]; q_to_R(rq, R);
+    const double d = 0.5*(R[0] + R[4] + R[8] - 1);
+    const double dR[3] = { R[7] - R[5], R[2] - R[6], R[3] - R[1] };               /* deltaR */
+    double omega[3], A, B, Cc;
+    if (fabs(sigma) < eps) {
+        Cc = 1;
+        if (d > 1 - eps) { for (int k = 0; k < 3; k++) omega[k] = 0.5*dR[k]; A = 1./2.; B = 1./6.; }
+        else { const double th = acos(d), th2 = th*th, f = th/(2*sqrt(1 - d*d)); for (int k = 0; k < 3; k++) omega[k] = f*dR[k];
+               A = (1 - cos(th))/th2; B = (th - sin(th))/(th2*th); }
+    } else {
+        Cc = (s - 1)/sigma;
+        if (d > 1 - eps) { const double s2 = sigma*sigma; for (int k = 0; k < 3; k++) omega[k] = 0.5*dR[k];
+               A = ((sigma - 1)*s + 1)/s2; B = ((0.5*s2 - sigma + 1)*s)/(s2*sigma); }
+        else { const double th = acos(d), f = th/(2*sqrt(1 - d*d)); for (int k = 0; k < 3; k++) omega[k] = f*dR[k];
+               const double th2 = th*th, a = s*sin(th), b = s*cos(th), c = th2 + sigma*sigma;
+               A = (a*sigma + (1 - b)*th)/(th*c); B = (Cc - ((b - 1)*sigma + a*th)/c)*1./th2; }
+    }
+    const double O[9] = { 0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0 };
+    double O2[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double v = 0; for (int k = 0; k < 3; k++) v += O[3*i + k]*O[3*k + j]; O2[3*i + j] = v; }
+    double Wm[9]; for (int k = 0; k < 9; k++) Wm[k] = A*O[k] + B*O2[k] + ((k == 0 || k == 4 || k == 8) ? Cc : 0.0);
+    double ups[3]; solve3_lu(Wm, t, ups);
+    for (int k = 0; k < 3; k++) { res[k] = omega[k]; res[3 + k] = ups[k]; }
+    res[6] = sigma;
+}
+/* numer_loop_ver2::operator() */
+static void pg_residual(const double x1[8], const double x2[8], const double m[8], double res[7]) {
+    double q1[4], q2[4]; q_norm(x1, q1); q_norm(x2, q2);
+    const double qw2[4] = { q2[0], -q2[1], -q2[2], -q2[3] };
+    const double sc = -1./x2[7], ts[3] = { sc*x2[4], sc*x2[5], sc*x2[6] };
+    double tw2[3]; q_rot(qw2, ts, tw2);
+    const double sw2 = 1./x2[7];
+    double q12[4]; q_mul(q1, qw2, q12);
+    double rt[3]; q_rot(q1, tw2, rt);
+    const double t12[3] = { x1[7]*rt[0] + x1[4], x1[7]*rt[1] + x1[5], x1[7]*rt[2] + x1[6] }, s12 = x1[7]*sw2;
+    double rq[4]; q_mul(m, q12, rq);
+    double mt[3]; q_rot(m, t12, mt);
+    const double rtt[3] = { m[7]*mt[0] + m[4], m[7]*mt[1] + m[5], m[7]*mt[2] + m[6] };
+    log_sim3(rq, rtt, m[7]*s12, res);
+}
+/* tangent-space Jacobian blocks (7 x 7) of one edge by Ceres CENTRAL numeric differentiation of the ambient blocks, then the plus-Jacobian */
+static void pg_jacobians(const double x1_[8], const double x2_[8], const double m[8], double J1[49], double J2[49]) {
+    const double min_step = sqrt(DBL_EPSILON);
+    for (int which = 0; which < 2; which++) {
+        double x1[8], x2[8], amb[56], rp[7], rm[7], PJ[12];
+        memcpy(x1, x1_, sizeof(x1)); memcpy(x2, x2_, sizeof(x2));
+        double *x = which == 0 ? x1 : x2;
+        for (int j = 0; j < 8; j++) {
+            const double x0 = x[j]; double delta = fabs(x0)*1e-6; if (delta < min_step) delta = min_step;
+            x[j] = x0 + delta; pg_residual(x1, x2, m, rp);
+            x[j] = x0 - delta; pg_residual(x1, x2, m, rm);
+            x[j] = x0;
+            const double inv = (1.0/delta)/2;
+            for (int k = 0; k < 7; k++) amb[8*k + j] = (rp[k] - rm[k])*inv;
+        }
+        quat_plus_jacobian(which == 0 ? x1_ : x2_, PJ);
+        double *J = which == 0 ? J1 : J2;
+        for (int k = 0; k < 7; k++) {
+            for (int c = 0; c < 3; c++) { double v = 0; for (int a = 0; a < 4; a++) v += amb[8*k + a]*PJ[3*a + c]; J[7*k + c] = v; }
+            for (int c = 0; c < 4; c++) J[7*k + 3 + c] = amb[8*k + 4 + c];
+        }
+    }
+}
+void tsloop_oracle_pg_eval(const double x1[8], const double x2[8], const double m[8], double res[7], double J1[49], double J2[49]) {
+    pg_residual(x1, x2, m, res); pg_jacobians(x1, x2, m, J1, J2);
+}
+
+typedef tsloop_graph_problem tsloop_graph_problem_o;
+
+static double pg_cost(const tsloop_graph_problem_o *p, const double *x) {
+    double c = 0;
+    for (int e = 0; e < p->n_edge; e++) { double r[7]; pg_residual(x + 8*p->edge_i[e], x + 8*p->edge_j[e], p->meas + 8*e, r); for (int k = 0; k < 7; k++) c += 0.5*r[k]*r[k]; }
+    return c;
+}
+static void pg_linearize(const tsloop_graph_problem_o *p, const double *x, const int *fidx, int n, double *H, double *g, double *cost) {
+    memset(H, 0, sizeof(double)*(size_t)n*n); memset(g, 0, sizeof(double)*n); *cost = 0;
+    for (int e = 0; e < p->n_edge; e++) {
+        const int a = p->edge_i[e], b = p->edge_j[e], fa = fidx[a], fb = fidx[b];
+        double r[7], J1[49], J2[49];
+        pg_residual(x + 8*a, x + 8*b, p->meas + 8*e, r); pg_jacobians(x + 8*a, x + 8*b, p->meas + 8*e, J1, J2);
+        for (int k = 0; k < 7; k++) *cost += 0.5*r[k]*r[k];
+        const double *Js[2] = { J1, J2 }; const int fs[2] = { fa, fb };
+        for (int u = 0; u < 2; u++) { if (fs[u] < 0) continue;
+            for (int c = 0; c < 7; c++) { double v = 0; for (int k = 0; k < 7; k++) v += Js[u][7*k + c]*r[k]; g[7*fs[u] + c] += v; }
+            for (int w = 0; w < 2; w++) { if (fs[w] < 0) continue;
+                for (int c = 0; c < 7; c++) for (int d = 0; d < 7; d++) { double v = 0; for (int k = 0; k < 7; k++) v += Js[u][7*k + c]*Js[w][7*k + d]; H[(size_t)(7*fs[u] + c)*n + 7*fs[w] + d] += v; } } }
+    }
+}
+
+int tsloop_oracle_optimize_loop(tsloop_graph_problem_o *p, const tsloop_options *o, tsloop_report *rep) {
+    const int N = p->n_kf;
+    int *fidx = (int *)malloc(sizeof(int)*(N + 1)); int nf = 0;
+    for (int k = 0; k < N; k++) fidx[k] = p->fixed[k] ? -1 : nf++;
+    const int n = 7*nf;
+    double *x = (double *)malloc(sizeof(double)*8*(size_t)(N + 1)), *cand = (double *)malloc(sizeof(double)*8*(size_t)(N + 1));
+    memcpy(x, p->pose, sizeof(double)*8*(size_t)N);
+    double *H = (double *)malloc(sizeof(double)*((size_t)n*n + 1)), *A = (double *)malloc(sizeof(double)*((size_t)n*n + 1));
+    double *g = (double *)calloc(n + 1, sizeof(double)), *sc = (double *)calloc(n + 1, sizeof(double)), *y = (double *)calloc(n + 1, sizeof(double)), *d = (double *)calloc(n + 1, sizeof(double));
+    memset(rep, 0, sizeof(*rep));
+    double x_cost; pg_linearize(p, x, fidx, n, H, g, &x_cost); rep->cost0 = x_cost;
+    for (int k = 0; k < n; k++) sc[k] = 1.0/(1.0 + sqrt(H[(size_t)k*n + k]));
+    #define XNORM(xx, out) do { double v_ = 0; for (int k_ = 0; k_ < N; k_++) if (fidx[k_] >= 0) for (int c_ = 0; c_ < 8; c_++) v_ += (xx)[8*k_ + c_]*(xx)[8*k_ + c_]; out = sqrt(v_); } while (0)
+    double x_norm; XNORM(x, x_norm);
+    double radius = o->initial_radius, decrease_factor = 2.0; int invalid = 0, term = 0, it = 0, accepted = 0;
+    double gmax = 0; for (int k = 0; k < n; k++) if (fabs(g[k]) > gmax) gmax = fabs(g[k]);
+    if (n == 0 || p->n_edge == 0) { term = 5; goto done; }
+    if (gmax <= o->gradient_tolerance) { term = 3; goto done; }
+    while (1) {
+        if (it >= o->max_it) { term = 0; break; }
+        if (radius < o->min_radius) { term = 4; break; }
+        it++;
+        for (int k = 0; k < n; k++) { for (int m = 0; m < n; m++) A[(size_t)k*n + m] = sc[k]*H[(size_t)k*n + m]*sc[m];
+            A[(size_t)k*n + k] += clampd(sc[k]*sc[k]*H[(size_t)k*n + k], o->min_diagonal, o->max_diagonal)/radius; y[k] = -sc[k]*g[k]; }
+        const int rc = chol_solve_dense(A, n, y);
+        double model_change = -1;
+        if (!rc) {
+            for (int k = 0; k < n; k++) d[k] = sc[k]*y[k];
+            model_change = 0;
+            for (int k = 0; k < n; k++) { double hd = 0; for (int m = 0; m < n; m++) hd += H[(size_t)k*n + m]*d[m]; model_change -= d[k]*(g[k] + 0.5*hd); }
+        }
+        if (rc || !(model_change > 0)) { if (++invalid >= 5) { term = 5; break; } radius *= 0.5; continue; }
+        invalid = 0;
+        memcpy(cand, x, sizeof(double)*8*(size_t)N);
+        for (int k = 0; k < N; k++) if (fidx[k] >= 0) { const double *dk = d + 7*fidx[k]; quat_plus(x + 8*k, dk, cand + 8*k); for (int c = 0; c < 4; c++) cand[8*k + 4 + c] = x[8*k + 4 + c] + dk[3 + c]; }
+        double c_cost = pg_cost(p, cand); if (!(c_cost == c_cost)) c_cost = DBL_MAX;
+        double step = 0; for (int k = 0; k < N; k++) if (fidx[k] >= 0) for (int c = 0; c < 8; c++) step += (cand[8*k + c] - x[8*k + c])*(cand[8*k + c] - x[8*k + c]);
+        step = sqrt(step);
+        if (step <= o->parameter_tolerance*(x_norm + o->parameter_tolerance)) { term = 2; break; }
+        const double cost_change = x_cost - c_cost;
+        if (fabs(cost_change) <= o->function_tolerance*x_cost) { term = 1; break; }
+        const double rel = cost_change/model_change;
+        if (rel > o->min_relative_decrease) {
+            memcpy(x, cand, sizeof(double)*8*(size_t)N); accepted++;
+            XNORM(x, x_norm);
+            pg_linearize(p, x, fidx, n, H, g, &x_cost);
+            double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
+            radius = radius/f; if (radius > o->max_radius) radius = o->max_radius;
+            decrease_factor = 2.0;
+            gmax = 0; for (int k = 0; k < n; k++) if (fabs(g[k]) > gmax) gmax = fabs(g[k]);
+            if (gmax <= o->gradient_tolerance) { term = 3; break; }
+        } else { radius = radius/decrease_factor; decrease_factor *= 2.0; }
+    }
+done:
+    rep->iters = it; rep->accepted = accepted; rep->termination = term; rep->cost1 = x_cost;
+    memcpy(p->pose, x, sizeof(double)*8*(size_t)N);
+    free(fidx); free(x); free(cand); free(H); free(A); free(g); free(sc); free(y); free(d);
+    return term == 5 ? TSLOOP_ERR_NUMERIC : TSLOOP_OK;
+}

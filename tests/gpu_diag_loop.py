@@ -1,0 +1,25 @@
+"""GPU diagnostic (not a pytest): call latencies of the loop-closure optimisers next to the CPU restatement."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+from textslam_amd import synth
+from textslam_amd.loop import LoopOptimizer
+lo = LoopOptimizer(0)
+m = synth.sim3_matches(n=300)
+a = (m["P1"], m["uv1"], m["P2"], m["uv2"], m["inliers"], m["sim0"], m["K"])
+for _ in range(3): lo.OptimizeSim3(*a)
+t = time.perf_counter()
+for _ in range(50): n, s, i, rep = lo.OptimizeSim3(*a)
+tg = (time.perf_counter() - t)/50*1e3
+t = time.perf_counter(); oracle.optimize_sim3(*a); to = (time.perf_counter() - t)*1e3
+print("OptimizeSim3 300 matches: GPU call %.3f ms (%d LM its), CPU restatement %.3f ms" % (tg, rep["iters"], to))
+for n_kf in (40, 150, 400, 1000):
+    g = synth.pose_graph(seed=n_kf, n_kf=n_kf)
+    b = (g["pose"], g["fixed"], g["edge_i"], g["edge_j"], g["meas"])
+    lo.OptimizeLoop(*b)
+    t = time.perf_counter(); x, rep = lo.OptimizeLoop(*b); tg = (time.perf_counter() - t)*1e3
+    to = float("nan")
+    if n_kf <= 150:
+        t = time.perf_counter(); oracle.optimize_loop(*b); to = (time.perf_counter() - t)*1e3
+    print("OptimizeLoop %4d KF, %5d connections, %4d unknowns: GPU call %.1f ms (%d LM its, %d accepted), CPU dense restatement %.0f ms" % (n_kf, len(g["edge_i"]), 7*(n_kf - 3), tg, rep["iters"], rep["accepted"], to))

@@ -77,3 +77,36 @@ def test_struct_layout_matches_header(tmp_path):
     L = C.CDLL(str(so))
     for f in "abc": getattr(L, f).restype = C.c_ulong
     assert L.a() == C.sizeof(loop.TsloopOptions) and L.b() == C.sizeof(loop.TsloopReport) and L.c() == C.sizeof(loop.TsloopSim3Problem)
+
+
+def test_pose_graph_residual_and_numeric_jacobians(oracle_lib):
+    g = synth.pose_graph(seed=2, n_kf=14)
+    # connections measured at the current estimate hold exactly: Sji * Si * Sj^-1 = identity -> log = 0
+    r, J1, J2 = oracle_lib.pg_eval(g["pose"][4], g["pose"][5], g["meas"][list(zip(g["edge_i"], g["edge_j"])).index((4, 5))])
+    assert np.abs(r).max() < 1e-12
+    # Ceres-style CENTRAL differences of the ambient blocks x plus-Jacobian against differences taken on the manifold itself
+    rng = np.random.default_rng(0)
+    x1 = g["pose"][3] + np.concatenate([rng.normal(0, 0.02, 7), [0.03]]); x1[:4] /= np.linalg.norm(x1[:4])
+    x2 = g["pose"][6].copy(); m = g["meas"][0]
+    r, J1, J2 = oracle_lib.pg_eval(x1, x2, m)
+    h = 1e-5
+    for which, J in ((0, J1), (1, J2)):
+        Jn = np.zeros((7, 7))
+        for k in range(7):
+            d = np.zeros(7); d[k] = h
+            def moved(x, sgn):
+                return np.concatenate([oracle_lib.quat_plus(x[:4], sgn*d[:3]), x[4:] + sgn*d[3:]])
+            a = (moved(x1, 1), x2) if which == 0 else (x1, moved(x2, 1)); b = (moved(x1, -1), x2) if which == 0 else (x1, moved(x2, -1))
+            Jn[:, k] = (oracle_lib.pg_eval(a[0], a[1], m)[0] - oracle_lib.pg_eval(b[0], b[1], m)[0])/(2*h)
+        assert np.abs(J - Jn).max() < 1e-6*max(1.0, np.abs(J).max())
+
+
+def test_pose_graph_solve_distributes_the_loop_error(oracle_lib):
+    g = synth.pose_graph(seed=4, n_kf=30)
+    x, rep = oracle_lib.optimize_loop(g["pose"], g["fixed"], g["edge_i"], g["edge_j"], g["meas"])
+    assert rep["status"] == 0 and rep["cost1"] < 0.05*rep["cost0"] and rep["accepted"] >= 3
+    fx = g["fixed"].astype(bool)
+    assert np.array_equal(x[fx], g["pose"][fx])                                  # SetParameterBlockConstant
+    assert np.allclose(np.linalg.norm(x[:, :4], axis=1), 1.0, atol=1e-12)
+    s = x[:, 7]
+    assert s[-1] > 1.03 and np.all(np.diff(s[3:]) > -0.01)                       # the scale correction spreads along the trajectory

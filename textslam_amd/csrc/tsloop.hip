@@ -15,6 +15,9 @@
 #include <algorithm>
 #include "../../include/tsloop.h"
 #include "tsba_device.h"
+#include <vector>
+#include <map>
+#include "tsloop_graph.h"
 
 #define SIM_T 256
 #define SIM_NW (SIM_T/64)
@@ -313,6 +316,118 @@ int tsloop_optimize_sim3(void *ctx, tsloop_sim3_problem *p, const tsloop_options
     memcpy(p->sim, h + o_sim, 64); memcpy(r, h + o_rep, sizeof(tsloop_report)); memcpy(p->inlier, h + o_inl, n);
     r->t_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return r->termination == 5 ? TSLOOP_ERR_NUMERIC : TSLOOP_OK;
+}
+
+void tsloop_default_options_loop(tsloop_options *o) {
+    tsloop_default_options_sim3(o);
+    o->huber_delta = 0.0; o->thresh_outlier = 0.0;            // no loss function (nullptr, optimizer.cc:818,856), no inlier test
+}
+
+int tsloop_optimize_loop(void *ctx, tsloop_graph_problem *p, const tsloop_options *o, tsloop_report *r) {
+    LCtx *c = (LCtx *)ctx;
+    if (!c || !p || !o || !r || p->n_kf <= 0 || p->n_edge < 0 || !p->pose || !p->fixed || (p->n_edge > 0 && (!p->edge_i || !p->edge_j || !p->meas))) return TSLOOP_ERR_ARG;
+    for (int e = 0; e < p->n_edge; e++)
+        if (p->edge_i[e] < 0 || p->edge_i[e] >= p->n_kf || p->edge_j[e] < 0 || p->edge_j[e] >= p->n_kf || p->edge_i[e] == p->edge_j[e]) { c->err = "bad edge index"; return TSLOOP_ERR_ARG; }
+    for (int k = 0; k < p->n_kf; k++) if (!(p->pose[8*k + 7] > 0.0)) { c->err = "scale must be positive"; return TSLOOP_ERR_ARG; }
+    hipSetDevice(c->device);
+    const auto t0 = std::chrono::steady_clock::now();
+    memset(r, 0, sizeof(*r));
+    const int N = p->n_kf, E = p->n_edge;
+    // ---- host plan: compressed free keyframes, incidence lists, keyframe pairs
+    std::vector<int> fidx(N), free_kf; int nf = 0;
+    for (int k = 0; k < N; k++) { fidx[k] = p->fixed[k] ? -1 : nf++; if (!p->fixed[k]) free_kf.push_back(k); }
+    if (nf == 0 || E == 0) { r->termination = 5; return TSLOOP_ERR_NUMERIC; }
+    std::vector<int> kf_off(nf + 1, 0), kf_inc;
+    for (int e = 0; e < E; e++) { if (fidx[p->edge_i[e]] >= 0) kf_off[fidx[p->edge_i[e]] + 1]++; if (fidx[p->edge_j[e]] >= 0) kf_off[fidx[p->edge_j[e]] + 1]++; }
+    for (int k = 0; k < nf; k++) kf_off[k + 1] += kf_off[k];
+    kf_inc.resize(kf_off[nf]);
+    { std::vector<int> cur(kf_off.begin(), kf_off.end() - 1);
+      for (int e = 0; e < E; e++) { const int fa = fidx[p->edge_i[e]], fb = fidx[p->edge_j[e]];
+          if (fa >= 0) kf_inc[cur[fa]++] = e << 1; if (fb >= 0) kf_inc[cur[fb]++] = (e << 1) | 1; } }
+    std::map<std::pair<int,int>, std::vector<int>> pm;              // (a > b) -> edges (edge << 1 | side of a)
+    for (int e = 0; e < E; e++) { const int fa = fidx[p->edge_i[e]], fb = fidx[p->edge_j[e]];
+        if (fa < 0 || fb < 0) continue;
+        if (fa > fb) pm[{fa, fb}].push_back(e << 1); else pm[{fb, fa}].push_back((e << 1) | 1); }
+    std::vector<int> pair_a, pair_b, pair_off(1, 0), pair_e;
+    for (auto &kv : pm) { pair_a.push_back(kv.first.first); pair_b.push_back(kv.first.second); for (int v : kv.second) pair_e.push_back(v); pair_off.push_back((int)pair_e.size()); }
+    const int npair = (int)pair_a.size(), n = 7*nf, n6 = (n + 5)/6*6, nb6 = n6/6;
+    // ---- device buffers (one allocation)
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0; auto take = [&](size_t bytes) { const size_t o_ = off; off += al(bytes); return o_; };
+    const size_t o_x0 = take(64*(size_t)N), o_x1 = take(64*(size_t)N), o_fidx = take(4*(size_t)N), o_free = take(4*(size_t)nf), o_ei = take(4*(size_t)E), o_ej = take(4*(size_t)E),
+                 o_meas = take(64*(size_t)E), o_kfoff = take(4*(size_t)(nf + 1)), o_kfinc = take(4*kf_inc.size() + 4), o_pa = take(4*(size_t)npair + 4), o_pb = take(4*(size_t)npair + 4),
+                 o_poff = take(4*(size_t)(npair + 1)), o_pe = take(4*pair_e.size() + 4), o_sfidx = take(4*(size_t)nb6), o_nfree = take(4), o_st = take(sizeof(LmState)),
+                 o_host_end = off,                                       // everything up to here is uploaded
+                 o_r = take(56*(size_t)E), o_J1 = take(392*(size_t)E), o_J2 = take(392*(size_t)E), o_ce = take(8*(size_t)E), o_cce = take(8*(size_t)E), o_qe = take(8*(size_t)E),
+                 o_sc = take(8*(size_t)n6), o_part = take(32*(size_t)nf), o_g = take(8*(size_t)n6), o_dp = take(8*(size_t)n6), o_Sy = take(8*(size_t)n6),
+                 o_LD = take(8*(size_t)std::max(n6, 32*nb6)), o_dbg = take(8*64), o_S = take(8*((size_t)n6 + 1)*n6), tot = off;
+    if (o_host_end > c->h_cap) { if (c->h_stage) hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_cap = 0; CKL(hipHostMalloc((void **)&c->h_stage, o_host_end, hipHostMallocDefault)); c->h_cap = o_host_end; }
+    if (tot > c->d_cap) { if (c->d_buf) hipFree(c->d_buf); c->d_buf = nullptr; c->d_cap = 0; CKL(hipMalloc((void **)&c->d_buf, tot)); c->d_cap = tot; }
+    uint8_t *h = c->h_stage, *d = c->d_buf;
+    memcpy(h + o_x0, p->pose, 64*(size_t)N); memcpy(h + o_x1, p->pose, 64*(size_t)N);
+    memcpy(h + o_fidx, fidx.data(), 4*(size_t)N); memcpy(h + o_free, free_kf.data(), 4*(size_t)nf);
+    memcpy(h + o_ei, p->edge_i, 4*(size_t)E); memcpy(h + o_ej, p->edge_j, 4*(size_t)E); memcpy(h + o_meas, p->meas, 64*(size_t)E);
+    memcpy(h + o_kfoff, kf_off.data(), 4*(size_t)(nf + 1)); memcpy(h + o_kfinc, kf_inc.data(), 4*kf_inc.size());
+    memcpy(h + o_pa, pair_a.data(), 4*(size_t)npair); memcpy(h + o_pb, pair_b.data(), 4*(size_t)npair); memcpy(h + o_poff, pair_off.data(), 4*(size_t)(npair + 1)); memcpy(h + o_pe, pair_e.data(), 4*pair_e.size());
+    { int *sf = (int *)(h + o_sfidx); for (int k = 0; k < nb6; k++) sf[k] = k; *(int *)(h + o_nfree) = nb6; }
+    LmState st0; memset(&st0, 0, sizeof(st0));
+    st0.first = 1; st0.need_lin = 1; st0.max_it = o->max_it; st0.radius = o->initial_radius; st0.decrease_factor = 2.0;
+    memcpy(h + o_st, &st0, sizeof(st0));
+    CKL(hipMemcpyAsync(d, h, o_host_end, hipMemcpyHostToDevice, c->stream));
+    PgDev P; memset(&P, 0, sizeof(P));
+    P.n_kf = N; P.n_edge = E; P.nf = nf; P.n = n; P.n6 = n6; P.npair = npair;
+    P.x[0] = (double *)(d + o_x0); P.x[1] = (double *)(d + o_x1); P.fidx_kf = (const int *)(d + o_fidx); P.free_kf = (const int *)(d + o_free);
+    P.ei = (const int *)(d + o_ei); P.ej = (const int *)(d + o_ej); P.meas = (const double *)(d + o_meas);
+    P.r = (double *)(d + o_r); P.J1 = (double *)(d + o_J1); P.J2 = (double *)(d + o_J2); P.cost_e = (double *)(d + o_ce); P.ccost_e = (double *)(d + o_cce); P.q_e = (double *)(d + o_qe);
+    P.kf_off = (const int *)(d + o_kfoff); P.kf_inc = (const int *)(d + o_kfinc); P.pair_a = (const int *)(d + o_pa); P.pair_b = (const int *)(d + o_pb);
+    P.pair_off = (const int *)(d + o_poff); P.pair_e = (const int *)(d + o_pe); P.sc = (double *)(d + o_sc); P.part = (double *)(d + o_part);
+    Work &W = P.W; W.N = n6; W.n_kf = nb6; W.S = (double *)(d + o_S); W.ldS = n6; W.Sy = (double *)(d + o_Sy); W.g = (double *)(d + o_g); W.dp = (double *)(d + o_dp);
+    W.LDbuf = (double *)(d + o_LD); W.fidx = (int *)(d + o_sfidx); W.nfree = (int *)(d + o_nfree); W.dbg = (long long *)(d + o_dbg); W.st = (LmState *)(d + o_st);
+    // ---- solver selection as in the BA library
+    const size_t lds_small = solve_lds_doubles(n6)*sizeof(double);
+    const bool use_lds = lds_small <= 160*1024 - 64;
+    const int lds_diag = (int)(solve_diag_lds_doubles()*sizeof(double)), lds_panel = (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double), lds_upd = 2*64*(CH_NB + 1)*(int)sizeof(double),
+              lds_bs = (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double);
+    if (use_lds) CKL(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
+    else {
+        CKL(hipFuncSetAttribute((const void *)k_solve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_diag));
+        CKL(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_panel));
+        CKL(hipFuncSetAttribute((const void *)k_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, lds_upd));
+        CKL(hipFuncSetAttribute((const void *)k_chol_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bs));
+    }
+    auto solve = [&]() {
+        if (use_lds) { hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), (int)lds_small, c->stream, W, 0); return; }
+        const int bw = n6;                                             // dense: every row below a block can be non-zero
+        hipLaunchKernelGGL(k_chol_rhs, dim3((n6 + 255)/256), dim3(256), 0, c->stream, W);
+        for (int j0 = 0; j0 < n6; j0 += CH_NB) {
+            hipLaunchKernelGGL(k_solve_t<true>, dim3(1), dim3(SOLVE_THREADS), lds_diag, c->stream, W, j0);
+            const int wr = std::max(0, std::min(bw, n6 - (j0 + 6)));
+            hipLaunchKernelGGL(k_chol_panel, dim3(wr/64 + 1), dim3(CH_T), lds_panel, c->stream, W, j0, bw);
+            const int nt = (wr + 1 + 63)/64;
+            if (wr > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt*(nt + 1)/2), dim3(CH_T), lds_upd, c->stream, W, j0, bw);
+        }
+        hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, W, bw);
+    };
+    // ---- LM: max_it rounds + one to close the last accepted step (gradient test, iteration limit)
+    for (int it = 0; it <= o->max_it; it++) {
+        hipLaunchKernelGGL(k_pg_linearize, dim3((E + 63)/64), dim3(64), 0, c->stream, P);
+        CKL(hipMemsetAsync(W.S, 0, sizeof(double)*(size_t)n6*n6, c->stream));
+        hipLaunchKernelGGL(k_pg_assemble, dim3(nf + npair + 1), dim3(64), 0, c->stream, P, *o);
+        hipLaunchKernelGGL(k_pg_pre, dim3(1), dim3(1024), 0, c->stream, P, *o);
+        if (it == o->max_it) break;
+        solve();
+        hipLaunchKernelGGL(k_pg_candidate, dim3((nf + 255)/256), dim3(256), 0, c->stream, P);
+        hipLaunchKernelGGL(k_pg_trial, dim3((E + 63)/64), dim3(64), 0, c->stream, P);
+        hipLaunchKernelGGL(k_pg_decide, dim3(1), dim3(1024), 0, c->stream, P, *o);
+    }
+    LmState st;
+    CKL(hipMemcpyAsync(h + o_st, d + o_st, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+    CKL(hipStreamSynchronize(c->stream)); CKL(hipGetLastError());
+    memcpy(&st, h + o_st, sizeof(st));
+    CKL(hipMemcpy(p->pose, st.cur ? P.x[1] : P.x[0], 64*(size_t)N, hipMemcpyDeviceToHost));
+    r->iters = st.it; r->accepted = st.accepted; r->termination = st.term; r->cost0 = st.cost0; r->cost1 = st.x_cost;
+    r->t_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st.term == 5 ? TSLOOP_ERR_NUMERIC : TSLOOP_OK;
 }
 
 }  // extern "C"

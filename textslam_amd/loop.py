@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's loop-closure optimisers on the MI355X (libtsloop.so, include/tsloop.h).
 
   LoopOptimizer.OptimizeSim3(...)     optimizer::OptimizeSim3     /root/reference/src/optimizer.cc:626-731
+  LoopOptimizer.OptimizeLoop(...)     optimizer::OptimizeLoop     /root/reference/src/optimizer.cc:733-957 (the solve; the map update stays with the caller)
 
 No CPU fallback: without the HIP library / a GPU every call raises.
 """
@@ -10,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.path.join(_HERE, "libtsloop.so")
-EXPORTED_SYMBOLS = ["tsloop_default_options_sim3", "tsloop_create", "tsloop_destroy", "tsloop_last_error", "tsloop_optimize_sim3"]
+EXPORTED_SYMBOLS = ["tsloop_default_options_sim3", "tsloop_default_options_loop", "tsloop_create", "tsloop_destroy", "tsloop_last_error",
+                    "tsloop_optimize_sim3", "tsloop_optimize_loop"]
 
 
 class TsloopOptions(C.Structure):
@@ -29,6 +31,22 @@ class TsloopSim3Problem(C.Structure):
     _fields_ = [("n", C.c_int32), ("pad", C.c_int32), ("P1", C.POINTER(C.c_double)), ("P2", C.POINTER(C.c_double)),
                 ("uv1", C.POINTER(C.c_float)), ("uv2", C.POINTER(C.c_float)), ("inlier", C.POINTER(C.c_uint8)),
                 ("K", C.c_double*4), ("sim", C.c_double*8)]
+
+
+class TsloopGraphProblem(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("n_edge", C.c_int32), ("pose", C.POINTER(C.c_double)), ("fixed", C.POINTER(C.c_uint8)),
+                ("edge_i", C.POINTER(C.c_int32)), ("edge_j", C.POINTER(C.c_int32)), ("meas", C.POINTER(C.c_double))]
+
+
+def make_graph_problem(pose, fixed, edge_i, edge_j, meas):
+    pose = np.ascontiguousarray(pose, np.float64).reshape(-1, 8).copy(); fixed = np.ascontiguousarray(fixed, np.uint8)
+    ei = np.ascontiguousarray(edge_i, np.int32); ej = np.ascontiguousarray(edge_j, np.int32); meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 8)
+    assert len(fixed) == len(pose) and len(ei) == len(ej) == len(meas)
+    p = TsloopGraphProblem()
+    p.n_kf = len(pose); p.n_edge = len(ei)
+    p.pose = pose.ctypes.data_as(C.POINTER(C.c_double)); p.fixed = fixed.ctypes.data_as(C.POINTER(C.c_uint8))
+    p.edge_i = ei.ctypes.data_as(C.POINTER(C.c_int32)); p.edge_j = ej.ctypes.data_as(C.POINTER(C.c_int32)); p.meas = meas.ctypes.data_as(C.POINTER(C.c_double))
+    return p, (fixed, ei, ej, meas), pose
 
 
 class LoopError(RuntimeError):
@@ -65,6 +83,8 @@ class LoopOptimizer:
         L.tsloop_last_error.argtypes = [C.c_void_p]; L.tsloop_last_error.restype = C.c_char_p
         L.tsloop_default_options_sim3.argtypes = [C.POINTER(TsloopOptions)]; L.tsloop_default_options_sim3.restype = None
         L.tsloop_optimize_sim3.argtypes = [C.c_void_p, C.POINTER(TsloopSim3Problem), C.POINTER(TsloopOptions), C.POINTER(TsloopReport)]
+        L.tsloop_default_options_loop.argtypes = [C.POINTER(TsloopOptions)]; L.tsloop_default_options_loop.restype = None
+        L.tsloop_optimize_loop.argtypes = [C.c_void_p, C.POINTER(TsloopGraphProblem), C.POINTER(TsloopOptions), C.POINTER(TsloopReport)]
         self.ctx = C.c_void_p()
         rc = L.tsloop_create(device, C.byref(self.ctx))
         if rc != 0:
@@ -88,3 +108,18 @@ class LoopOptimizer:
             raise LoopError("tsloop_optimize_sim3 failed (%d): %s" % (rc, self.lib.tsloop_last_error(self.ctx).decode()))
         rep = report_dict(r); rep["status"] = rc
         return r.n_inlier, np.array(list(p.sim)), inl.astype(bool), rep
+
+    def default_options_loop(self):
+        o = TsloopOptions(); self.lib.tsloop_default_options_loop(C.byref(o)); return o
+
+    def OptimizeLoop(self, pose, fixed, edge_i, edge_j, meas, options=None):
+        """Sim3 pose graph: pose [n_kf, 8] initial (q | t | s), fixed [n_kf], connections (edge_i, edge_j, meas = Sji).
+        Returns (corrected poses [n_kf, 8], report)."""
+        o = options or self.default_options_loop()
+        p, keep, x = make_graph_problem(pose, fixed, edge_i, edge_j, meas)
+        r = TsloopReport()
+        rc = self.lib.tsloop_optimize_loop(self.ctx, C.byref(p), C.byref(o), C.byref(r))
+        if rc not in (0, -3):
+            raise LoopError("tsloop_optimize_loop failed (%d): %s" % (rc, self.lib.tsloop_last_error(self.ctx).decode()))
+        rep = report_dict(r); rep["status"] = rc
+        return x, rep

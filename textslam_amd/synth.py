@@ -470,3 +470,55 @@ def sim3_matches(seed=SEED, n=300, outlier_frac=0.1, noise_px=0.5, scale=1.07):
     sim0 = np.concatenate([q0, t + rng.normal(0, 0.03, 3), [scale*1.04]])
     return {"P1": P1n, "uv1": uv1.astype(np.float32), "P2": P2n, "uv2": uv2.astype(np.float32), "inliers": np.ones(n, np.uint8),
             "sim0": sim0, "sim_true": np.concatenate([q, t, [scale]]), "K": K}
+
+
+def _q_mul(a, b):
+    return np.array([a[0]*b[0] - a[1:] @ b[1:], *(a[0]*b[1:] + b[0]*a[1:] + np.cross(a[1:], b[1:]))])
+
+
+def _q_rot(q, v):
+    uv = 2*np.cross(q[1:], v)
+    return v + q[0]*uv + np.cross(q[1:], uv)
+
+
+def _sim_mul(A, B):
+    """(q, t, s) composition A o B: x -> sA RA (sB RB x + tB) + tA."""
+    return np.concatenate([_q_mul(A[:4], B[:4]), A[7]*_q_rot(A[:4], B[4:7]) + A[4:7], [A[7]*B[7]]])
+
+
+def _sim_inv(A):
+    qi = np.array([A[0], -A[1], -A[2], -A[3]])
+    return np.concatenate([qi, _q_rot(qi, -A[4:7]/A[7]), [1.0/A[7]]])
+
+
+def pose_graph(seed=SEED, n_kf=40, window=3, loop_at=2, scale_drift=1.06):
+    """optimizer::OptimizeLoop input: a trajectory with accumulated drift, covisibility connections that hold at the drifted
+    estimate, and loop connections between the last keyframes (corrected by the loop Sim3) and the neighbourhood of keyframe
+    `loop_at`.  Returns dict(pose [n, 8], fixed, edge_i, edge_j, meas [m, 8])."""
+    rng = np.random.default_rng(seed)
+    def pose_of(k, drift):
+        a = 2*np.pi*k/n_kf*(1.0 + drift*0.02)
+        q = np.array([np.cos(a/2), 0.0, np.sin(a/2), 0.0]); q = _q_mul(q, np.concatenate([[1.0], drift*0.002*k*np.array([0.3, 0.1, -0.2])])); q /= np.linalg.norm(q)
+        c = np.array([3*np.cos(a), 0.05*np.sin(3*a), 3*np.sin(a)])*(1.0 + drift*0.004*k)           # camera centre, drifting outwards
+        return np.concatenate([q, -_q_rot(q, c), [1.0]])                                             # T_cw
+    true = [pose_of(k, 0.0) for k in range(n_kf)]
+    est = [pose_of(k, 1.0) for k in range(n_kf)]
+    ei, ej, meas = [], [], []
+    for i in range(n_kf):                                                                             # NormConnections: both directions occur in the reference
+        for j in range(i + 1, min(n_kf, i + 1 + window)):
+            for (a, b) in ((i, j), (j, i)):
+                ei.append(a); ej.append(b); meas.append(_sim_mul(est[b], _sim_inv(est[a])))          # Sji = Sjw * Siw^-1
+    # loop: the last keyframe group gets the corrected Sim3 (vConnectKFs / mScw), connected to the loop group
+    ini = [e.copy() for e in est]
+    cur_group = list(range(n_kf - 3, n_kf)); loop_group = [loop_at, loop_at + 1, loop_at + 2]
+    corr = {}
+    for c in cur_group:
+        rel = _sim_mul(true[c], _sim_inv(true[loop_at]))                                            # what the loop detection measures
+        S = _sim_mul(rel, est[loop_at]); S = np.concatenate([S[:4], S[4:7]*scale_drift, [scale_drift]])   # Sim3 with the scale the drifted map has
+        corr[c] = S; ini[c] = S.copy()
+    for c in cur_group:
+        for l in loop_group:
+            ei.append(l); ej.append(c); meas.append(_sim_mul(corr[c], _sim_inv(ini[l])))
+    fixed = np.zeros(n_kf, np.uint8); fixed[[0, 1, loop_at]] = 1                                    # optimizer.cc:861-869
+    pose = np.array(ini) + 0.0
+    return {"pose": pose, "fixed": fixed, "edge_i": np.array(ei, np.int32), "edge_j": np.array(ej, np.int32), "meas": np.array(meas)}
