@@ -6,7 +6,7 @@ import oracle
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 opt = Optimizer(0)
-for (nkf, band) in ((40, 6), (70, 9), (120, 10), (300, 12)):
+for (nkf, band) in ((40, 6), (70, 9), (120, 10), (300, 12), (600, 10), (1500, 10)):
     P = synth.config_global(n_kf=nkf, n_pt=50*nkf, band=band)
     o = abi.options_global()
     opt.upload(P, o)

@@ -1113,6 +1113,7 @@ __global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi
 #include "tsba_solve.h"
 #include "tsba_chol.h"
 #include "tsba_band.h"
+#include "tsba_bandp.h"
 #include "tsba_pose.h"
 
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
@@ -1498,6 +1499,7 @@ struct Ctx {
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
     bool pose_only = false;                       // one keyframe, every landmark frozen in its host: the fused pose-only LM kernel applies
     double *S_alloc = nullptr; size_t S_count = 0;
+    int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
     double *Lcol = nullptr; int band_stream = 0;  // streaming band solver (tsba_band.h): L by block column; 1 = every built level fits it     // storage behind W.S (dense or band)
     float *lbl_dev = nullptr, *lbl_host = nullptr; size_t lbl_cap = 0;   // text label image staging
     unsigned long long *hprog = nullptr; unsigned int pass_seq = 0;   // pinned progress word written by k_postlin / k_decide
@@ -1765,7 +1767,23 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         else { c->S_count = (size_t)W.N*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - CH_NB); W.ldS = (int)LDB - 1; W.band = 1; }
         c->Lcol = nullptr; c->band_stream = 0;
         if (W.band && bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !getenv("TSBA_NO_BAND_STREAM")) {
-            AL(c->Lcol, (size_t)p->n_kf*bwmax*6); c->band_stream = 1; }
+            AL(c->Lcol, (size_t)p->n_kf*bwmax*6); c->band_stream = 1;
+            // substructuring: P interiors on P workgroups + a separator system (again a band, 2 bw - 6 wide)
+            int P = 16; if (const char *e = getenv("TSBA_BAND_PARTS")) P = atoi(e);
+            P = std::max(1, std::min(P, BANDP_MAXP));
+            const int Bq = bwmax/6;
+            while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < 4*Bq + 4) P--;                   // worth it only for interiors of a few bands
+            if (P > 1 && bandp_chunk_blocks(bwmax) > 0 && 2*bwmax - 6 <= BAND_BW_MAX && band_chunk_blocks(2*bwmax - 6) > 0) {
+                const int nsep = (P - 1)*bwmax, bws = 2*bwmax - 6;
+                c->nsep_ld = nsep;
+                AL(c->Lb, (size_t)p->n_kf*bwmax*6); AL(c->Tbuf, (size_t)P*((size_t)4*bwmax*bwmax + 2*bwmax));
+                AL(c->Ssep, (size_t)nsep*nsep + nsep); AL(c->Lcol_sep, (size_t)(nsep/6 + 1)*bws*6);
+                Work &Ws = c->Wsep; memset(&Ws, 0, sizeof(Ws));
+                Ws.N = nsep; Ws.n_kf = 0; Ws.S = c->Ssep; Ws.ldS = nsep; Ws.band = 1; Ws.st = nullptr;       // (st is set at launch: W.st is allocated below)
+                AL(Ws.Sy, nsep); AL(Ws.g, nsep); AL(Ws.dp, nsep); AL(Ws.LDbuf, 32*(size_t)(nsep/6 + 1)); AL(Ws.nfree, 1); AL(Ws.fidx, 1);
+                c->band_parts = P;
+            } else c->band_parts = 1;
+        }
         AL(W.Sy, W.N);
     }
     AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
@@ -1831,11 +1849,48 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
     *use_lds = bytes <= 160*1024 - 64;                                                      // gfx950: 160 KB of LDS per workgroup
     return *use_lds ? (int)bytes : 0;
 }
+// kernels with more than 64 KB of dynamic LDS need the attribute once per process
+static int set_solver_attrs(Ctx *c) {
+    int use_lds; int lds = solve_lds_bytes(c, &use_lds);
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    else {
+        CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_bandp_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_band_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_band_backsub<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_solve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solve_diag_lds_doubles()*sizeof(double))));
+        CK(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double)));
+        CK(hipFuncSetAttribute((const void *)k_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2*64*(CH_NB + 1)*(int)sizeof(double)));
+        CK(hipFuncSetAttribute((const void *)k_chol_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double)));
+    }
+    return 0;
+}
 // dense solve of the reduced camera system: LDS kernel for small windows, multi-workgroup blocked Cholesky otherwise
 static void launch_solve(Ctx *c) {
     Work &W = c->W;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) { hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0); return; }
+    if (c->band_stream && c->band_parts > 1 && !getenv("TSBA_NO_BAND_PARTS")) {      // partitioned: interiors in parallel + separator system (tsba_bandp.h)
+        const int bwp = std::max(6, c->cur_bw_rows), cbp = bandp_chunk_blocks(bwp), P = c->band_parts;
+        const int bwsep = 2*bwp - 6, cbs = band_chunk_blocks(bwsep);
+        Work &Ws = c->Wsep; Ws.st = W.st; Ws.ldS = (P - 1)*bwp; Ws.N = (P - 1)*bwp;
+        hipMemsetAsync(c->Ssep, 0, sizeof(double)*((size_t)Ws.ldS*Ws.ldS + Ws.ldS), c->stream);
+        hipLaunchKernelGGL(k_bandp_factor, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
+        hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, c->Ssep, Ws.ldS, Ws.g, Ws.nfree);
+        const int ldss = (int)(band_lds_doubles(bwsep, cbs)*sizeof(double)), nus = (bwsep + 63)/64;
+        hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(SOLVE_THREADS), ldss, c->stream, Ws, bwsep, cbs, c->Lcol_sep);
+        if (nus <= 1) hipLaunchKernelGGL(k_band_backsub<1>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
+        else if (nus == 2) hipLaunchKernelGGL(k_band_backsub<2>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
+        else hipLaunchKernelGGL(k_band_backsub<3>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
+        const int nup = (bwp + 63)/64, ldsp = (int)((2*(size_t)BAND_CK*(2*(size_t)bwp*6 + 32) + 6*BAND_RINGB + 2*bwp + 64)*sizeof(double));
+        if (nup <= 1) hipLaunchKernelGGL(k_bandp_backsub<1>, dim3(P), dim3(BAND_BS_T), ldsp, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, (const double *)Ws.Sy);
+        else hipLaunchKernelGGL(k_bandp_backsub<2>, dim3(P), dim3(BAND_BS_T), ldsp, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, (const double *)Ws.Sy);
+        hipLaunchKernelGGL(k_bandp_dp, dim3((W.n_kf + 255)/256), dim3(256), 0, c->stream, W);
+        return;
+    }
     if (c->band_stream) {                                          // narrow band: one workgroup streams down the band (tsba_band.h)
         const int bws = std::max(6, c->cur_bw_rows), cb = band_chunk_blocks(bws);
         if (getenv("TSBA_DEBUG_TIMING")) fprintf(stderr, "[launch_solve] band stream bw %d cb %d lds %zu B\n", bws, cb, band_lds_doubles(bws, cb)*sizeof(double));
@@ -1890,17 +1945,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
     memset(r, 0, sizeof(*r));
     const tsba_options &o = c->opt;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    else {
-        CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_band_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_band_backsub<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_solve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solve_diag_lds_doubles()*sizeof(double))));
-        CK(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double)));
-        CK(hipFuncSetAttribute((const void *)k_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2*64*(CH_NB + 1)*(int)sizeof(double)));
-        CK(hipFuncSetAttribute((const void *)k_chol_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double)));
-    }
+    { int rca = set_solver_attrs(c); if (rca) return rca; }
     auto t0 = std::chrono::steady_clock::now();
     int rc = reset_state(c); if (rc) return rc;
     for (int ps = 0; ps < o.n_passes; ps++) {
@@ -2085,8 +2130,7 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     int rc = reset_state(c); if (rc) return rc;
     tsba_options saved = c->opt; c->opt.initial_radius = radius;
     const LevelDev &D = c->lev[c->opt.levels[0]];
-    int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    { int rca = set_solver_attrs(c); if (rca) return rca; }
     launch_pass_init(c, D, 0);
     launch_linearize(c, D, 0);
     Work &W = c->W;

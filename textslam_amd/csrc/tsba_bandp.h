@@ -1,0 +1,416 @@
+// Partitioned streaming band solver (substructuring) for the reduced camera system of a large map.  Included by tsba.hip after
+// tsba_band.h.
+//
+// The single-workgroup streaming solver (tsba_band.h) walks the band's pose blocks one after the other: ~2 us per block, 10 ms at
+// 5000 keyframes -- 75 % of an LM iteration, and inherently sequential.  A band matrix falls apart once B = bw / 6 consecutive pose
+// blocks are set aside as a SEPARATOR: the interiors on either side do not couple.  With P - 1 separators:
+//
+//   k_bandp_factor   P workgroups, one per interior [a_p, b_p): the streaming factorisation of tsba_band.h on its own rows.  The right
+//                    separator's rows are simply the rows that follow the interior in the band (they stay behind as trailing rows);
+//                    the LEFT separator's rows ride along below the window like the right-hand-side row does ("border" rows: zero
+//                    at first except for the coupling to the first B blocks, then filling in along the whole interior).  What is
+//                    left in the window at the end -- [right separator; left separator] x the same, plus the reduced rhs -- is this
+//                    interior's Schur complement contribution T_p.
+//   k_bandp_sep      assembles the separator system (block tridiagonal, blocks of 6 B: D_s = T_s.RR + T_{s+1}.LL, off-diagonal from
+//                    T_{s+1}.LR) -- a band matrix again, solved by k_band_solve / k_band_backsub on a second Work.
+//   k_bandp_backsub  P workgroups: right-looking back substitution of each interior with both separator solutions known
+//                    (the right one enters as ordinary steps with given x, the left one through the stored border panel).
+//   k_bandp_dp       dp[6a + k] = -x[6 fidx[a] + k].
+// Every workgroup derives the same partition table from the number of free poses on the device (the host does not know it).
+#pragma once
+
+#define BANDP_MAXP 32
+
+struct BandpPart { int P, a, b, has_left, has_right; };
+// interiors of q = (nb - (P - 1) B) / P blocks (the last takes the remainder), separators of B blocks between them; P shrinks
+// until an interior holds at least 2 B + 2 blocks
+__device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax, int p) {
+    int P = Pmax;
+    while (P > 1 && (nb - (P - 1)*B)/P < 2*B + 2) P--;
+    BandpPart r; r.P = P;
+    const int q = (nb - (P - 1)*B)/P;
+    r.a = p*(q + B); r.b = (p == P - 1) ? nb : r.a + q;
+    r.has_left = p > 0; r.has_right = p < P - 1;
+    return r;
+}
+static size_t bandp_lds_doubles(int bw, int cb) {               // window + border rows + rhs row, LD table, scratch
+    const int rows = 6*cb + 2*bw;
+    return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*SOLVE_PW + 8 + 64;
+}
+static int bandp_chunk_blocks(int bw) {
+    for (int cb = 16; cb >= 4; cb--) if (bandp_lds_doubles(bw, cb)*sizeof(double) <= 152*1024) return cb;
+    return 0;
+}
+
+// T_p layout: nT = nR + nL rows ([right separator rows; left separator rows]), dense nTmax x nTmax row-major (lower used) + gT
+__global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, int CB, int Pmax, double *Lrow, double *Lb, double *Tbuf) {
+    LmState *st = W.st;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = SOLVE_THREADS/64, NT = NW - SOLVE_PW;
+    if (st->done || st->step_fail) return;
+    const int nb = *W.nfree, B = bw/6;
+    if (nb == 0) return;
+    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x);
+    if ((int)blockIdx.x >= PT.P) return;
+    const int nbr = PT.has_left ? bw : 0;                       // border rows: the left separator
+    const int row_lim = 6*(PT.has_right ? PT.b + B : PT.b);     // rows of the band this workgroup ever holds
+    const int col_end = 6*PT.b;                                 // interior columns end here
+    const int Wn = 6*CB + bw;
+    const size_t ld = (size_t)W.ldS;
+    const double *S = W.S;
+    double *A = smem;
+    double *LD = A + rowoff(Wn + bw + 2) + 16;
+    double *scr = LD + SOLVE_LD*(Wn/6);
+    const int REC = bw*6;
+    if (tid == 0) fail = 0;
+
+    int base = 6*PT.a, n = min(Wn, row_lim - base);
+    const int gl0 = 6*(PT.a - B);                               // first row of the left separator
+    // rows [r0, n) of the window from HBM; for the border / rhs rows the columns [r0, n).  first: also the border-border block
+    auto load_rows = [&](int r0, bool first) {
+        for (int r = r0 + wave; r < n; r += NW) { double *row = A + rowoff(r); for (int c = lane; c <= r; c += 64) row[c] = 0.0; }
+        for (int k = wave; k < nbr; k += NW) { double *row = A + rowoff(n + k);
+            for (int c = r0 + lane; c < n; c += 64) row[c] = 0.0;
+            if (first) for (int c = lane; c <= k; c += 64) row[n + c] = 0.0; }
+        __syncthreads();
+        const int nr = n - r0, per = bw + 6;                   // the band is block-aligned: row r reaches back to column 6 (r/6) - bw
+        for (int e = tid; e < nr*per; e += SOLVE_THREADS) {
+            const int rr = e/per, k = e - rr*per, r = r0 + rr, c = r - k, gr = base + r;
+            if (c >= 0 && c >= 6*(r/6) - bw) A[rowoff(r) + c] = S[(size_t)gr*ld + (base + c)];
+            else if (first && nbr > 0 && c < 0) {               // left of the interior: the coupling to the left separator, S(gr, gl) = border(gl, gr)
+                const int gc = base + c;                         // global column < base
+                if (gc >= gl0 && gc >= 6*(gr/6) - bw) A[rowoff(n + (gc - gl0)) + r] = S[(size_t)gr*ld + gc];
+            }
+        }
+        double *rhs = A + rowoff(n + nbr);
+        for (int c = r0 + tid; c < n; c += SOLVE_THREADS) rhs[c] = W.g[base + c];
+        if (first) for (int k = tid; k < nbr; k += SOLVE_THREADS) rhs[n + k] = 0.0;
+        __syncthreads();
+    };
+    load_rows(0, true);
+    bool first = true;
+    for (;;) {
+        const bool last = base + n == row_lim;
+        const int jend = last ? (col_end - base)/6 : CB, jstart = first ? 0 : 1;
+        const bool flush = last && (n + nbr > 6*jend);          // rows stay behind: the last panel must still be applied to them
+        const int NR = n + nbr;                                 // the rhs row
+        for (int jb = jstart; jb < jend + (flush ? 1 : 0) && !fail; jb++) {
+            const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
+            const bool fl = jb == jend;                         // flush step: no factorisation, panel jb-1 onto everything right of it
+            if (wave < SOLVE_PW) {
+                double Lk[36], dprev[6];
+                if (jb > 0) {
+                    ld6(LD + SOLVE_LD*(jb - 1) + LD_D, dprev);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) ld6(A + rowoff(min(j0 + c, n - 1)) + p0, Lk + 6*c);
+                }
+                auto load_row = [&](int i, double a[6]) {           // row i of block column jb with panel jb-1 applied
+                    const double *row = A + rowoff(i);
+                    ld6(row + j0, a);
+                    if (jb > 0) {
+                        double y[6];
+                        ld6(row + p0, y);
+#pragma unroll
+                        for (int k = 0; k < 6; k++) y[k] *= dprev[k];
+#pragma unroll
+                        for (int c = 0; c < 6; c++) {
+                            double v0 = y[0]*Lk[c*6], v1 = y[1]*Lk[c*6 + 1];
+                            v0 = fma(y[2], Lk[c*6 + 2], v0); v1 = fma(y[3], Lk[c*6 + 3], v1);
+                            v0 = fma(y[4], Lk[c*6 + 4], v0); v1 = fma(y[5], Lk[c*6 + 5], v1);
+                            a[c] -= v0 + v1;
+                        }
+                    }
+                };
+                // rows of this block column that can be non-zero: the band rows < re, then (virtual rows re ..) the border rows and the rhs row
+                const int re = min(n, R0 + bw), nx = nbr + 1;
+                auto vrow = [&](int iv) { return iv < re ? iv : n + (iv - re); };
+                if (!fl) {
+                    const int i0 = lane < 6 ? j0 + lane : R0 + wave*SOLVE_PROWS + lane - 6;
+                    double a[6];
+                    load_row(vrow(min(i0, re + nx - 1)), a);
+                    if (lane < 6) st6(scr + wave*36 + lane*6, a);
+                    wave_lds_fence();
+                    double s[21], l[15], d[6], id[6]; bool bad = false;
+                    {
+                        double t[36];
+#pragma unroll
+                        for (int r = 0; r < 6; r++) ld6(scr + wave*36 + r*6, t + 6*r);
+#pragma unroll
+                        for (int r = 0; r < 6; r++)
+#pragma unroll
+                            for (int c = 0; c <= r; c++) s[tri(r) + c] = t[6*r + c];
+                    }
+                    ldl6(s, l, d, id, bad);
+                    if (wave == 0 && lane == 0) {
+                        double *o = LD + SOLVE_LD*jb;
+#pragma unroll
+                        for (int k = 0; k < 15; k++) o[k] = l[k];
+                        st6(o + LD_D, d); st6(o + LD_ID, id);
+                        if (bad) { fail = 1; st->step_fail = 1; }
+                    }
+                    auto solve_row = [&](int i, double a[6]) {       // x L^T = a (right-looking), stored row = x D^-1
+#pragma unroll
+                        for (int c = 0; c < 5; c++)
+#pragma unroll
+                            for (int q = c + 1; q < 6; q++) a[q] = fma(-a[c], l[tri(q - 1) + c], a[q]);
+#pragma unroll
+                        for (int c = 0; c < 6; c++) a[c] *= id[c];
+                        st6(A + rowoff(i) + j0, a);
+                    };
+                    if (lane >= 6) {
+                        if (i0 < re + nx) solve_row(vrow(i0), a);
+                        for (int i = i0 + SOLVE_PW*SOLVE_PROWS; i < re + nx; i += SOLVE_PW*SOLVE_PROWS) { load_row(vrow(i), a); solve_row(vrow(i), a); }
+                    }
+                }
+            } else if (jb > 0) {
+                // trailing update with panel jb-1 (its band ends at row re - 1): virtual rows R0 .. re-1 (band), re .. re+nbr-1 (border),
+                // re+nbr (rhs); virtual columns R0 .. re+nbr-1
+                // (flush step: the last panel onto EVERYTHING that stays behind, block column jb included -- no panel wave work)
+                const int Rs = fl ? j0 : R0;
+                const int re = max(Rs, min(n, j0 + bw)), vend = re + nbr;    // vend = virtual index of the rhs row
+                const int mr = vend - Rs + 1, mc = vend - Rs;
+                const double *ldp = LD + SOLVE_LD*(jb - 1);
+                if (mc > 0) {
+                    const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4, ntile = tri(ntr);
+                    const int lr = lane & 15, lk = lane >> 4;
+                    const int k1 = min(4 + lk, 5);
+                    const double dk0 = ldp[LD_D + lk], dk1 = lk < 2 ? ldp[LD_D + 4 + lk] : 0.0;
+                    auto real = [&](int v) { return v < re ? v : n + (v - re); };
+                    for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
+                        const int ti = tri_row(t), tj = t - tri(ti);
+                        if (tj >= ntc) continue;
+                        const int arow = rowoff(real(min(Rs + 16*ti + lr, vend))) + p0, brow = rowoff(real(min(Rs + 16*tj + lr, vend - 1))) + p0;
+                        double a0 = -A[arow + lk], a1 = -A[arow + k1];
+                        double b0 = A[brow + lk]*dk0, b1 = A[brow + k1]*dk1;
+                        if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
+                        const int ccol = Rs + 16*tj + lr;                                 // virtual column
+                        v4d c; int ci[4]; bool ok[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int cv = Rs + 16*ti + lk + 4*r;                         // virtual row
+                            ok[r] = cv <= vend && ccol <= cv && ccol < vend;
+                            const int cvc = min(cv, vend);
+                            ci[r] = rowoff(real(cvc)) + real(min(ccol, min(cvc, vend - 1)));
+                            c[r] = A[ci[r]];
+                        }
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (ok[r]) A[ci[r]] = c[r];
+                    }
+                }
+            }
+            __syncthreads();                       // panel jb complete, trailing update with panel jb-1 complete
+        }
+        if (fail) break;
+        // ---------------- finished columns -> HBM: L by row block, the border panel, unit-lower diagonal factor + 1/d, v = D^-1 L^-1 g
+        {
+            const int nq = jend - jstart, per = 2*REC + 32;
+            for (int e = tid; e < nq*per; e += SOLVE_THREADS) {
+                const int qq = e/per, k = e - qq*per, q = jstart + qq, gq = base/6 + q;
+                if (k < REC) {                                   // L(r, 6 q + cc) -> row block gr, block b = gr - gq - 1, [b][cc][ri]
+                    const int dr = k/6, cc = k - 6*dr, r = 6*q + 6 + dr;
+                    if (r < n) { const int b = dr/6, ri = dr - 6*b;
+                        Lrow[(size_t)(gq + 1 + b)*REC + b*36 + cc*6 + ri] = A[rowoff(r) + 6*q + cc]; } }
+                else if (k < 2*REC) {                            // border panel of the column block: [border row][cc]
+                    const int kk = k - REC, br = kk/6, cc = kk - 6*br;
+                    Lb[(size_t)gq*REC + kk] = br < nbr ? A[rowoff(n + br) + 6*q + cc] : 0.0; }
+                else { const int u = k - 2*REC;
+                    if (u < 15) W.LDbuf[32*(size_t)gq + u] = LD[SOLVE_LD*q + u];
+                    else if (u >= 16 && u < 22) W.LDbuf[32*(size_t)gq + u] = LD[SOLVE_LD*q + LD_ID + (u - 16)];
+                    else if (u >= 24 && u < 30) W.Sy[6*gq + (u - 24)] = A[rowoff(NR) + 6*q + (u - 24)]; }
+            }
+        }
+        if (last) {
+            // ---------------- what stays behind: T_p = [right separator rows; border rows] x the same (lower), reduced rhs
+            const int nR = n - 6*jend, nT = nR + nbr, nTm = 2*bw;
+            double *T = Tbuf + (size_t)blockIdx.x*((size_t)nTm*nTm + nTm), *gT = T + (size_t)nTm*nTm;
+            __syncthreads();
+            auto realT = [&](int v) { return v < nR ? 6*jend + v : n + (v - nR); };
+            for (int e = tid; e < nT*nT; e += SOLVE_THREADS) { const int i = e/nT, j = e - i*nT; if (j <= i) T[(size_t)i*nTm + j] = A[rowoff(realT(i)) + realT(j)]; }
+            for (int i = tid; i < nT; i += SOLVE_THREADS) gT[i] = A[rowoff(NR) + realT(i)];
+            break;
+        }
+        // ---------------- slide by s rows.  Virtual index v: band rows 0 .. m-1, border rows m .. m+nbr-1, rhs row m+nbr; ascending
+        // packed order through registers: a destination lies at or below its own source and below every source not yet read
+        {
+            const int s = 6*(jend - 1), m = n - s, n_new = min(Wn, row_lim - (base + s)), mv = m + nbr, ne = tri(mv) + mv;
+            __syncthreads();
+            for (int e0 = 0; e0 < ne; e0 += 4*SOLVE_THREADS) {
+                double v[4]; int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u*SOLVE_THREADS + tid;
+                    dst[u] = -1;
+                    if (e < ne) { const int r = tri_row(e), c = e - tri(r);
+                        const int ro = r < m ? r + s : n + (r - m), co = c < m ? c + s : n + (c - m);
+                        const int rn = r < m ? r : n_new + (r - m), cn = c < m ? c : n_new + (c - m);
+                        v[u] = A[rowoff(ro) + co]; dst[u] = rowoff(rn) + cn; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (dst[u] >= 0) A[dst[u]] = v[u];
+                __syncthreads();
+            }
+            if (tid < SOLVE_LD) LD[tid] = LD[SOLVE_LD*(jend - 1) + tid];
+            base += s; n = n_new;
+            load_rows(m, false);
+            first = false;
+        }
+    }
+}
+
+// ---- separator system: dense row-major (ld = nsep_ld), rows of separator s at [6 B s, 6 B (s + 1)); number of separator pose
+// blocks -> *nfree_sep (what k_band_solve reads)
+__global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, const double *Tbuf, double *Ssep, int nsep_ld, double *gsep, int *nfree_sep) {
+    const LmState *st = W.st;
+    if (st->done || st->step_fail) return;
+    const int nb = *W.nfree, B = bw/6;
+    const BandpPart P0 = bandp_part(nb, B, Pmax, 0);
+    const int P = P0.P, nS = bw, nTm = 2*bw;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nfree_sep = (P - 1)*B;
+    const int s = blockIdx.x;                                    // separator s sits between interiors s and s + 1
+    if (s >= P - 1) return;
+    const double *Ta = Tbuf + (size_t)s*((size_t)nTm*nTm + nTm), *ga = Ta + (size_t)nTm*nTm;            // interior s: this separator is its RIGHT one (rows 0 .. nS-1 of T)
+    const double *Tb = Tbuf + (size_t)(s + 1)*((size_t)nTm*nTm + nTm), *gb = Tb + (size_t)nTm*nTm;      // interior s + 1: its LEFT one (rows nRb .. of T)
+    const int nRb = (s + 1 < P - 1) ? nS : 0;                    // interior s + 1 has a right separator unless it is the last
+    for (int e = threadIdx.x; e < nS*nS; e += 256) {
+        const int i = e/nS, j = e - i*nS;
+        if (j <= i) Ssep[(size_t)(nS*s + i)*nsep_ld + nS*s + j] = Ta[(size_t)i*nTm + j] + Tb[(size_t)(nRb + i)*nTm + nRb + j];
+        // coupling to the NEXT separator through interior s + 1: T_{s+1}(border row i, right-separator column j) = S(sep s row i, sep s+1 col j)
+        if (nRb > 0) Ssep[(size_t)(nS*(s + 1) + j)*nsep_ld + nS*s + i] = Tb[(size_t)(nRb + i)*nTm + j];
+    }
+    for (int i = threadIdx.x; i < nS; i += 256) gsep[nS*s + i] = ga[i] + gb[nRb + i];
+}
+
+// ---- back substitution of the interiors (right-looking, as k_band_backsub), both separator solutions known
+template <int NU>
+__global__ __launch_bounds__(BAND_BS_T) void k_bandp_backsub(Work W, int bw, int Pmax, const double *Lrow, const double *Lb, const double *xsep) {
+    LmState *st = W.st;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (st->done || st->step_fail) return;
+    const int nb = *W.nfree, B = bw/6;
+    if (nb == 0) return;
+    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x);
+    if ((int)blockIdx.x >= PT.P) return;
+    const int REC = bw*6, NTASK = 6*B, RECB = 2*REC + 32;
+    const int r_lo = PT.a, r_hi = PT.has_right ? PT.b + B : PT.b;          // row blocks walked: [r_lo, r_hi), the top B of them given
+    double *buf0 = smem, *buf1 = smem + (size_t)BAND_CK*RECB, *ring = buf1 + (size_t)BAND_CK*RECB, *xL = ring + 6*BAND_RINGB, *xR = xL + bw;
+    for (int k = tid; k < 6*BAND_RINGB; k += BAND_BS_T) ring[k] = 0.0;
+    for (int k = tid; k < bw; k += BAND_BS_T) {
+        xL[k] = PT.has_left ? xsep[(size_t)bw*(blockIdx.x - 1) + k] : 0.0;
+        xR[k] = PT.has_right ? xsep[(size_t)bw*blockIdx.x + k] : 0.0;
+        if (PT.has_right) W.Sy[6*PT.b + k] = xR[k];              // the separator's solution goes to its rows of x
+    }
+    const int nrows = r_hi - r_lo, nchunk = (nrows + BAND_CK - 1)/BAND_CK;
+    auto stage = [&](int chunk, double *buf, int t0, int nt) {
+        const int jhi = r_hi - chunk*BAND_CK, jlo = max(r_lo, jhi - BAND_CK), nq = jhi - jlo;
+        const int h = REC >> 1, n2 = nq*2*h;                                 // L parts and border parts, as double2
+        const int tx = t0;
+        double xv = 0.0; int xd = -1;
+        if (tx < nq*32) { const int q = tx >> 5, u = tx & 31, j = jlo + q; xd = q*RECB + 2*REC + u;
+            xv = j < PT.b ? (u < 24 ? W.LDbuf[32*(size_t)j + u] : (u < 30 ? W.Sy[6*j + (u - 24)] : 0.0)) : 0.0; }
+        for (int e0 = t0; e0 < n2; e0 += 4*nt) {
+            v2d v[4]; int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u*nt; dst[u] = -1;
+                if (e < n2) { const int q = e/(2*h), k2 = e - q*2*h, j = jlo + q; dst[u] = q*RECB + 2*k2;
+                    if (k2 < h) { const int col = j - 1 - (2*k2)/36;       // L(row block j, column block col): written only for interior columns
+                        v[u] = (col >= PT.a && col < PT.b) ? ((const v2d *)(Lrow + (size_t)j*REC))[k2] : v2d{0.0, 0.0}; }
+                    else v[u] = (j < PT.b && PT.has_left) ? ((const v2d *)(Lb + (size_t)j*REC))[k2 - h] : v2d{0.0, 0.0}; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (dst[u] >= 0) *(v2d *)(buf + dst[u]) = v[u];
+        }
+        if (xd >= 0) buf[xd] = xv;
+    };
+    stage(0, buf0, tid, BAND_BS_T);
+    __syncthreads();
+    int tb[NU], tc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) { const int t = lane + 64*u; tb[u] = t < NTASK ? t/6 : -1; tc[u] = t - 6*(t/6); }
+    struct Ops { double Lr[NU][6], l[16], vv[6]; };
+    // record data of one step; the left separator's term  sum_k Lb[k][c] xL[k]  is folded into v here (it does not depend on the
+    // running solution): four partial sums per c on the lanes of a quad
+    auto fetch = [&](const double *rec, Ops &o, bool interior) {
+#pragma unroll
+        for (int u = 0; u < NU; u++) if (tb[u] >= 0) ld6(rec + 6*(lane + 64*u), o.Lr[u]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const v2d x2 = ((const v2d *)(rec + 2*REC))[k]; o.l[2*k] = x2.x; o.l[2*k + 1] = x2.y; }
+        ld6(rec + 2*REC + 24, o.vv);
+        if (interior && PT.has_left) {
+            const int c = min(lane >> 2, 5), p = lane & 3;
+            double acc = 0.0;
+            for (int k = p; k < bw; k += 4) acc = fma(rec[REC + 6*k + c], xL[k], acc);
+            acc = quad_sum(acc);
+#pragma unroll
+            for (int q = 0; q < 6; q++) o.vv[q] -= readlane_f64(acc, 4*q);
+        }
+    };
+    auto step = [&](int r, const Ops &o, const double *nrec, Ops &on, bool ninterior) {
+        double ur[6], uo[NU]; int slot[NU];
+        ld6(ring + 6*(r & (BAND_RINGB - 1)), ur);
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int j = r - 1 - tb[u];
+            slot[u] = (tb[u] >= 0 && j >= PT.a && j < PT.b) ? 6*(j & (BAND_RINGB - 1)) + tc[u] : -1;
+            uo[u] = slot[u] >= 0 ? ring[slot[u]] : 0.0;
+        }
+        if (nrec) fetch(nrec, on, ninterior);
+        double x[6];
+        if (r >= PT.b) {                                          // a row block of the right separator: its solution is given
+#pragma unroll
+            for (int q = 0; q < 6; q++) x[q] = xR[6*(r - PT.b) + q];
+        } else {
+#pragma unroll
+            for (int q = 5; q >= 0; q--) { double v = o.vv[q] - ur[q];
+#pragma unroll
+                for (int k = q + 1; k < 6; k++) v = fma(-o.l[tri(k - 1) + q], x[k], v);
+                x[q] = v; }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++)
+            if (slot[u] >= 0) {
+                const double s0 = fma(o.Lr[u][0], x[0], fma(o.Lr[u][1], x[1], o.Lr[u][2]*x[2])), s1 = fma(o.Lr[u][3], x[3], fma(o.Lr[u][4], x[4], o.Lr[u][5]*x[5]));
+                ring[slot[u]] = uo[u] + (s0 + s1);
+            }
+        if (lane < 6) {
+            double xv = x[0];
+#pragma unroll
+            for (int q = 1; q < 6; q++) if (lane == q) xv = x[q];
+            ring[6*(r & (BAND_RINGB - 1)) + lane] = 0.0;
+            if (r < PT.b) W.Sy[6*r + lane] = xv;
+        }
+        wave_lds_fence();
+    };
+    for (int ch = 0; ch < nchunk; ch++) {
+        double *buf = (ch & 1) ? buf1 : buf0, *nxt = (ch & 1) ? buf0 : buf1;
+        if (wave > 0) { if (ch + 1 < nchunk) stage(ch + 1, nxt, tid - 64, BAND_BS_T - 64); }
+        else {
+            const int jhi = r_hi - ch*BAND_CK, jlo = max(r_lo, jhi - BAND_CK);
+            Ops oa, ob;
+            int r = jhi - 1;
+            fetch(buf + (size_t)(r - jlo)*RECB, oa, r < PT.b);
+            for (; r - 1 >= jlo; r -= 2) {
+                step(r, oa, buf + (size_t)(r - 1 - jlo)*RECB, ob, r - 1 < PT.b);
+                step(r - 1, ob, r - 2 >= jlo ? buf + (size_t)(r - 2 - jlo)*RECB : nullptr, oa, r - 2 < PT.b);
+            }
+            if (r >= jlo) step(r, oa, nullptr, ob, false);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_bandp_dp(Work W) {
+    const LmState *st = W.st;
+    if (st->done) return;
+    const int a = blockIdx.x*blockDim.x + threadIdx.x;
+    if (a >= W.n_kf) return;
+    const int ia = W.fidx[a];
+#pragma unroll
+    for (int k = 0; k < 6; k++) W.dp[6*a + k] = (ia >= 0 && !st->step_fail) ? -W.Sy[6*ia + k] : 0.0;
+}
