@@ -281,3 +281,29 @@ def test_global_ba_band_cholesky_profiles(gpu, oracle_lib, n_kf, band, far):
     P = synth.config_global(n_kf=n_kf, n_pt=50*n_kf, band=band, far_frac=far)
     o = abi.options_global(); o.its[0] = 6
     _check_solve(gpu, oracle_lib, P, o, lambda G, oo: gpu.GlobalBA(G, options=oo), atol=1e-7, rtol_cost=1e-8)
+
+
+@pytest.mark.gpu
+def test_global_ba_partitioned_band_solver(gpu):
+    """Substructured band solver (tsba_bandp.h): at 300 keyframes the host picks several interiors + separators.  The LM step of
+    the first linearisation against a dense numpy solve of the same reduced system, and the full GlobalBA against the
+    single-workgroup streaming solver (TSBA_BAND_PARTS=1): same LM trajectory, poses within 1e-9."""
+    import os
+    P = synth.config_global(n_kf=300, n_pt=15000, band=8)
+    o = abi.options_global(); o.its[0] = 6
+    gpu.upload(P, o)
+    rg = gpu.reduced_system(o.initial_radius)
+    free = np.nonzero(rg["free"])[0]; idx = np.concatenate([np.arange(6*k, 6*k + 6) for k in free]); m = len(idx)
+    S = rg["S"][:m, :m]; S = np.tril(S) + np.tril(S, -1).T
+    assert np.abs(S).sum() > 0                                     # (the band paths leave S intact)
+    ref = -np.linalg.solve(S, rg["g"][:m])
+    assert np.abs(rg["dp"][idx] - ref).max() <= 1e-8*np.abs(ref).max()
+    G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+    os.environ["TSBA_BAND_PARTS"] = "1"
+    try:
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+    finally:
+        del os.environ["TSBA_BAND_PARTS"]
+    assert rep1["iters"] == rep2["iters"] and rep1["accepted"] == rep2["accepted"] and rep1["termination"] == rep2["termination"]
+    np.testing.assert_allclose(G1.pose, G2.pose, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rep1["cost1"], rep2["cost1"], rtol=1e-9)

@@ -92,6 +92,7 @@ struct Work {                // device work buffers (sized for the largest level
     double *sig_pt, *sig_tx, *sig_p;    // Jacobi column scales, fixed at the first linearisation of a pass
     double *S, *g, *dp, *dl_pt, *dl_tx;
     double *partial;                    // [nblocks_back][2]
+    double *posepart;                   // large maps: per k_pose_sums workgroup (21 poses): gradient max, |x|^2
     LmState *st;
     PoseState *pst; double *ppart;      // pose-only path (tsba_pose.h): double-buffered state, [2][G][28] partial sums
 };
@@ -841,7 +842,7 @@ __device__ void pose_scale(const Work &W, const LinBuf &B, const double *sHd, co
 // workgroup costs ~0.6 us, a block reduction ~0.3 us: the old sequence had a dozen of the former and seven of the latter).
 //   out5 = { max |gradient|, |x|^2, cost, step^2 (nb_back partials), model cost change (nb_back partials) }   (thread 0)
 __device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm, int nb_back,
-                              double *red /*[5*256]*/, double *xch /*[252]*/, double out5[5]) {
+                              double *red /*[5*256]*/, double *xch /*[252]*/, double out5[5], int npp = 0) {
     const int tid = threadIdx.x;
     double gmax = 0.0, xn = 0.0, cost = 0.0, step2 = 0.0, mcc = 0.0;
 #ifdef TSBA_SOLVE_STAMPS
@@ -876,7 +877,9 @@ __device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B,
     // poses, 21 per round: thread (pose, component) sums one entry of diag(H_pp) (6) or of the gradient (6) over the pose's
     // pairs -- target side by pair, host side host-major, both contiguous -- then the six diag threads finish the pose
     const double *out = B.pairOut; const size_t np = L.n_pair;
-    for (int a0 = 0; a0 < W.n_kf; a0 += 21) {
+    // (large maps: k_pose_sums did the per-pose work on many workgroups; only its partials are left to add)
+    for (int k = tid; k < npp; k += 256) { gmax = fmax(gmax, W.posepart[2*k]); xn += W.posepart[2*k + 1]; }
+    for (int a0 = 0; a0 < (npp > 0 ? 0 : W.n_kf); a0 += 21) {
         const int al = tid/12, k = tid - 12*al, a = a0 + al;
         const bool on = tid < 252 && a < W.n_kf;
         const int ac = min(a, W.n_kf - 1);
@@ -930,13 +933,50 @@ __device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B,
     if (tid == 0) { W.dbg[40] = q1_ - q0_; W.dbg[41] = q2_ - q1_; W.dbg[42] = q3_ - q2_; W.dbg[43] = q4_ - q3_; }
 #endif
 }
-__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm, int multi) {
+// The pose part of postlin_fused for large maps (hundreds of keyframes and more): 21 poses per workgroup instead of 21 per ROUND of
+// the single postlin / decide workgroup (238 rounds, 1.1 ms per LM iteration at 5000 keyframes).
+__global__ __launch_bounds__(256) void k_pose_sums(Work W, LevelDev L, int spec) {
+    const LmState *st = W.st;
+    if (st->done) return;
+    if (!spec && !st->need_lin) return;
+    if (spec && st->step_fail) return;
+    __shared__ double xch[256], red[256];
+    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
+    const double *pose = W.pose[spec ? (st->cur ^ 1) : st->cur];
+    const bool first = !spec && st->first != 0;
+    const int tid = threadIdx.x;
+    const double *out = B.pairOut; const size_t np = L.n_pair;
+    const int al = tid/12, k = tid - 12*al, a = blockIdx.x*21 + al;
+    const bool on = tid < 252 && a < W.n_kf;
+    const int ac = min(a, W.n_kf - 1);
+    const int t0 = L.pose_t_off[ac], t1 = L.pose_t_off[ac+1], h0 = L.pose_h_off[ac], h1 = L.pose_h_off[ac+1];
+    const int kk = k < 6 ? k : k - 6;
+    const double sgp = first ? 0.0 : W.sig_p[6*ac + kk]; const int fre = W.fidx[ac];
+    const double px = pose[7*ac + kk], px6 = pose[7*ac + 6];
+    const double *rt = out + (size_t)(k < 6 ? sym6(kk, kk) : 21 + kk)*np, *rh = out + (size_t)(k < 6 ? 63 + sym6(kk, kk) : 84 + kk)*np;
+    const double vt = range_sum<24>(rt, t0, t1), vh = range_sum<24>(rh, h0, h1);
+    const double val = k < 6 ? vt + vh : vt - vh;
+    if (on) xch[tid] = val;
+    __syncthreads();
+    double gmax = 0.0, xn = 0.0;
+    if (on && k < 6) {
+        const double h = val, g = xch[tid + 6];
+        B.Hd[6*a + k] = h; B.bp[6*a + k] = g; B.bp_loc[6*a + k] = g;
+        double sg = sgp;
+        if (first) { sg = 1.0/(1.0 + sqrt(h)); W.sig_p[6*a + k] = sg; }
+        B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
+        if (fre >= 0) { gmax = fabs(g); xn = px*px + (k == 0 ? px6*px6 : 0.0); }
+    }
+    gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red);
+    if (tid == 0) { W.posepart[2*blockIdx.x] = gmax; W.posepart[2*blockIdx.x + 1] = xn; }
+}
+__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm, int multi, int npp) {
     LmState *st = W.st;
     if (st->done || !st->need_lin) return;
     __shared__ double red[5*256], xch[256];
     double gmax, xn, cost;
     const LinBuf &B = W.lb[st->lcur];
-    if (!multi) { double o5[5]; postlin_fused(W, L, B, W.pose[st->cur], st->first != 0, nb_lm, 0, red, xch, o5); gmax = o5[0]; xn = o5[1]; cost = o5[2]; }
+    if (!multi) { double o5[5]; postlin_fused(W, L, B, W.pose[st->cur], st->first != 0, nb_lm, 0, red, xch, o5, npp); gmax = o5[0]; xn = o5[1]; cost = o5[2]; }
     else { double gp, xp; pose_scale(W, B, W.cb, W.cb + W.N, W.pose[st->cur], st->first != 0, red, gp, xp);
            const double *sc = W.cb + 2*(size_t)W.N; cost = sc[0]; xn = sc[1] + xp; gmax = fmax(W.cbm[0], gp); }
     if (threadIdx.x == 0) {
@@ -1217,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
 }
 
 // ---- step quality and trust-region update (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics)
-__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o, int multi) {
+__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o, int multi, int npp) {
     LmState *st = W.st;
     if (st->done) return;
     __shared__ double red[5*256], xch[256];
@@ -1231,7 +1271,7 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
 #endif
     if (!multi) {
         double o5[5];
-        postlin_fused(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, nb_back, red, xch, o5);
+        postlin_fused(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, nb_back, red, xch, o5, npp);
         gmax_c = o5[0]; xn_c = o5[1]; cost = o5[2]; step2 = o5[3]; mcc = o5[4];
 #ifdef TSBA_SOLVE_STAMPS
         s1_ = s2_ = s3_ = clock64();
@@ -1788,6 +1828,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     }
     AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
+    AL(W.posepart, 2*((size_t)p->n_kf/21 + 2));
     AL(W.st, 1);
     flush_run(c);
     auto tu2 = std::chrono::steady_clock::now();
@@ -1830,6 +1871,7 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state);
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
+static int pose_parts(const Ctx *c) { return (c->n_kf > 126 && !is_multi(c)) ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
 static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
@@ -1842,7 +1884,9 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
         allreduce(c, W.cb, 2*(size_t)W.N + 8, ncclDouble, ncclSum);
         allreduce(c, W.cbm, 1, ncclDouble, ncclMax);
     }
-    if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi);
+    const int npp = pose_parts(c);
+    if (npp) hipLaunchKernelGGL(k_pose_sums, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
+    if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi, npp);
 }
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
     size_t bytes = solve_lds_doubles(c->W.N)*sizeof(double);                                // worst case: every pose free
@@ -1935,7 +1979,7 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     launch_solve(c);
     hipLaunchKernelGGL(k_back, dim3(nb_pt + nb_tx + nb_kf), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
     launch_linearize(c, D, 1);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c));
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
 }
 
 int tsba_solve(void *ctx, tsba_report *r) {
