@@ -76,6 +76,10 @@ def bench_orb(args, rank, local_rank, world, dist, torch):
                "warmup": args.warmup, "ms_per_step": dt/args.steps*1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
                "config": {"workload": "ORBextractor(1000,1.2,8,20,7), 64 frames 640x480 per GPU", "frames_per_s": 64*world*args.steps/dt}}
+        # whole pipeline against HBM: SURVEY 8d counts 4.7 MB of algorithmic traffic per frame (input + pyramid + blur planes + taps)
+        algo = 64*4.7e6
+        out["roofline"] = {"bound": "hbm", "kernel": "whole ORB pipeline (pyramid, FAST, quadtree, orientation, blur, rBRIEF)", "achieved": algo*world/(dt/args.steps)/1e9,
+                           "peak": 8000.0, "unit": "GB/s", "frac": algo/(dt/args.steps)/1e9/8000.0, "traffic": None, "algorithmic_bytes_per_launch": algo}
         if not args.no_cpu_baseline:
             import oracle
             t0 = time.perf_counter(); n = 0
