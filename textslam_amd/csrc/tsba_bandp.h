@@ -89,7 +89,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         if (first) for (int k = tid; k < nbr; k += SOLVE_THREADS) rhs[n + k] = 0.0;
         __syncthreads();
     };
+    if (tid == 0 && W.dbg && blockIdx.x == 1) { W.dbg[36] = 0; W.dbg[37] = 0; W.dbg[38] = 0; }
+    long long tF = 0, tW = 0, tS = 0, tL = 0, tx = clock64(); int nchunks = 0;       // phase stamps of interior 1 (-> W.dbg[32..36])
     load_rows(0, true);
+    { const long long t_ = clock64(); tL += t_ - tx; tx = t_; }
     bool first = true;
     for (;;) {
         const bool last = base + n == row_lim;
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         const bool flush = last && (n + nbr > 6*jend);          // rows stay behind: the last panel must still be applied to them
         const int NR = n + nbr;                                 // the rhs row
         for (int jb = jstart; jb < jend + (flush ? 1 : 0) && !fail; jb++) {
+            const long long tq0 = clock64();
             const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
             const bool fl = jb == jend;                         // flush step: no factorisation, panel jb-1 onto everything right of it
             if (wave < SOLVE_PW) {
@@ -202,8 +206,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     }
                 }
             }
+            { const long long tq1 = clock64(); if (W.dbg && blockIdx.x == 1 && lane == 0 && (wave == 0 || wave == 2 || wave == 11)) atomicAdd((unsigned long long *)&W.dbg[36 + (wave == 0 ? 0 : wave == 2 ? 1 : 2)], (unsigned long long)(tq1 - tq0)); }
             __syncthreads();                       // panel jb complete, trailing update with panel jb-1 complete
         }
+        { const long long t_ = clock64(); tF += t_ - tx; tx = t_; }
         if (fail) break;
         // ---------------- finished columns -> HBM: L by row block, the border panel, unit-lower diagonal factor + 1/d, v = D^-1 L^-1 g
         {
@@ -223,6 +229,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     else if (u >= 24 && u < 30) W.Sy[6*gq + (u - 24)] = A[rowoff(NR) + 6*q + (u - 24)]; }
             }
         }
+        { const long long t_ = clock64(); tW += t_ - tx; tx = t_; nchunks++; }
+        if (tid == 0 && W.dbg && blockIdx.x == 1) { W.dbg[32] = tF; W.dbg[33] = tW; W.dbg[34] = tS; W.dbg[35] = tL; W.dbg[19] = nchunks; }
         if (last) {
             // ---------------- what stays behind: T_p = [right separator rows; border rows] x the same (lower), reduced rhs
             const int nR = n - 6*jend, nT = nR + nbr, nTm = 2*bw;
@@ -256,7 +264,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
             }
             if (tid < SOLVE_LD) LD[tid] = LD[SOLVE_LD*(jend - 1) + tid];
             base += s; n = n_new;
+            { const long long t_ = clock64(); tS += t_ - tx; tx = t_; }
             load_rows(m, false);
+            { const long long t_ = clock64(); tL += t_ - tx; tx = t_; }
             first = false;
         }
     }

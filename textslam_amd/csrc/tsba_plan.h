@@ -14,6 +14,9 @@
 #include <algorithm>
 #include <cstdint>
 #include <map>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "../../include/tsba.h"
 
 struct HostPlan {
@@ -51,15 +54,34 @@ struct HostPlan {
 // Dense id of a sparse set of integer keys, ids in key order.  Small key ranges (a 20-keyframe window has 420 possible pairs)
 // use a direct table -- no sort, no binary search: plan construction is on the critical path of every cold tsba_local_ba call.
 struct KeyIndex {
+    // three modes by key range: direct table (<= 4 M keys: a 20-keyframe window has 420 possible pairs), bitmap + rank directory
+    // (<= 2^31 keys: 5000 keyframes have 25 M possible pose pairs -- 3 MB of bits, O(1) id by popcount, no sort and no binary search
+    // over millions of slot pairs), sorted list beyond that
     int64_t range = 0; std::vector<int32_t> table; std::vector<int64_t> keys;       // table[key] = id (dense mode)
+    std::vector<uint64_t> bits; std::vector<uint32_t> rank;                           // bitmap mode: rank[w] = set bits before word w
     bool dense() const { return !table.empty(); }
-    void begin(int64_t key_range) { range = key_range; table.clear(); keys.clear(); if (range <= (int64_t)1 << 22) table.assign((size_t)range, -1); }
-    void add(int64_t k) { if (dense()) table[(size_t)k] = 0; else keys.push_back(k); }
+    bool bitmap() const { return !bits.empty(); }
+    void begin(int64_t key_range) {
+        range = key_range; table.clear(); keys.clear(); bits.clear(); rank.clear();
+        if (range <= (int64_t)1 << 22) table.assign((size_t)range, -1);
+        else if (range <= (int64_t)1 << 31) bits.assign((size_t)((range + 63) >> 6), 0);
+    }
+    void add(int64_t k) { if (dense()) table[(size_t)k] = 0; else if (bitmap()) bits[(size_t)(k >> 6)] |= (uint64_t)1 << (k & 63); else keys.push_back(k); }
     int finish() {                                                                   // returns the number of distinct keys
         if (dense()) { int n = 0; keys.clear(); for (int64_t k = 0; k < range; k++) if (table[(size_t)k] == 0) { table[(size_t)k] = n++; keys.push_back(k); } return n; }
+        if (bitmap()) {
+            rank.resize(bits.size()); keys.clear(); uint32_t n = 0;
+            for (size_t w = 0; w < bits.size(); w++) { rank[w] = n; uint64_t b = bits[w];
+                while (b) { const int t = __builtin_ctzll(b); keys.push_back((int64_t)(w << 6) + t); b &= b - 1; n++; } }
+            return (int)n;
+        }
         std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end()); return (int)keys.size();
     }
-    int id(int64_t k) const { return dense() ? table[(size_t)k] : (int)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin()); }
+    int id(int64_t k) const {
+        if (dense()) return table[(size_t)k];
+        if (bitmap()) { const size_t w = (size_t)(k >> 6); return (int)(rank[w] + (uint32_t)__builtin_popcountll(bits[w] & (((uint64_t)1 << (k & 63)) - 1))); }
+        return (int)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin());
+    }
 };
 // stable counting sort: order[] = indices 0..n-1 sorted by bucket[], off[] = CSR offsets (n_bucket + 1)
 inline void bucket_order(const std::vector<int> &bucket, int n_bucket, std::vector<int> &order, std::vector<int32_t> &off) {
@@ -72,6 +94,9 @@ inline void bucket_order(const std::vector<int> &bucket, int n_bucket, std::vect
 }
 
 inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P) {
+    static const bool dbg_plan = getenv("TSBA_DEBUG_PLAN") != nullptr;
+    auto tp0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
     P = HostPlan();
     P.level = L;
     const int n_kf = p->n_kf, n_pt = p->n_pt, n_text = p->n_text;
@@ -102,6 +127,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     auto pair_of = [&](int kf, int host) { return pk.id(key_of(kf, host)); };
     P.pair_i.resize(n_pair); P.pair_h.resize(n_pair);
     for (int q = 0; q < n_pair; q++) { P.pair_i[q] = (int)(keys[q]/(n_kf + 1)); P.pair_h[q] = (int)(keys[q] % (n_kf + 1)) - 1; }
+    lap("candidates + pair keys");
     // ---- sort scene candidates by pair (stable: keeps the reference order inside a pair)
     std::vector<int> cpair(cs.size());
     for (size_t i = 0; i < cs.size(); i++) cpair[i] = pair_of(cs[i].kf, cs[i].host);
@@ -117,6 +143,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         P.pair_sc_off[cpair[order[c]] + 1]++;
     }
     for (int q = 0; q < n_pair; q++) P.pair_sc_off[q+1] += P.pair_sc_off[q];
+    lap("candidate order");
     // ---- text groups and their pair CSR
     const int n_tg = (int)gs.size();
     P.tg_tobs.resize(n_tg); P.tg_kf.resize(n_tg); P.tg_text.resize(n_tg); P.tg_pair.resize(n_tg); P.tg_slot.assign(n_tg, -1);
@@ -154,22 +181,24 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             int s = cur[j]++; P.tg_slot[g] = s; P.tslot_pose[s] = P.tg_kf[g]; P.tslot_pair[s] = P.tg_pair[g]; P.tslot_lm[s] = j; }
         for (int j = 0; j < n_text; j++) if (cnt[j] > 0) { int s = P.tls_off[j+1] - 1; P.tslot_pose[s] = p->text_host[j]; P.tslot_lm[s] = j; }
     }
+    lap("groups + landmark slots");
     // ---- reduced-system blocks: key = a*n_kf + b (a <= b)
     auto bkey = [&](int a, int b) { return (int64_t)a*n_kf + b; };
     KeyIndex bk; bk.begin((int64_t)n_kf*n_kf);
-    struct Tri { int64_t key; int s1, s2; };
-    std::vector<Tri> tp, tt;
-    tp.reserve(8*(size_t)n_sc); tt.reserve(8*(size_t)n_tg);
-    for (int j = 0; j < n_pt; j++) for (int s1 = P.pls_off[j]; s1 < P.pls_off[j+1]; s1++) for (int s2 = P.pls_off[j]; s2 < P.pls_off[j+1]; s2++) {
-        int a = P.pslot_pose[s1], b = P.pslot_pose[s2]; if (a > b) continue; tp.push_back({ bkey(a, b), s1, s2 }); }
-    for (int j = 0; j < n_text; j++) for (int s1 = P.tls_off[j]; s1 < P.tls_off[j+1]; s1++) for (int s2 = P.tls_off[j]; s2 < P.tls_off[j+1]; s2++) {
-        int a = P.tslot_pose[s1], b = P.tslot_pose[s2]; if (a > b) continue; tt.push_back({ bkey(a, b), s1, s2 }); }
+    // slot pairs (s1, s2) of every landmark with pose(s1) <= pose(s2), in landmark-major generation order; they are visited twice
+    // (count per block, then place) instead of being materialised and sorted: 3 M pairs at 5000 keyframes
+    auto each_pair = [&](const std::vector<int32_t> &off, const std::vector<int32_t> &pose, int n_lm, auto &&f) {
+        for (int j = 0; j < n_lm; j++) for (int s1 = off[j]; s1 < off[j+1]; s1++) for (int s2 = off[j]; s2 < off[j+1]; s2++) {
+            const int a = pose[s1], b = pose[s2]; if (a > b) continue; f(bkey(a, b), s1, s2); }
+    };
+    each_pair(P.pls_off, P.pslot_pose, n_pt, [&](int64_t k, int, int) { bk.add(k); });
+    each_pair(P.tls_off, P.tslot_pose, n_text, [&](int64_t k, int, int) { bk.add(k); });
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bk.add(bkey(i, i));
         if (h >= 0) { bk.add(bkey(h, h)); bk.add(bkey(std::min(i, h), std::max(i, h))); } }
     if (n_kf <= 64) for (int a = 0; a < n_kf; a++) for (int b = a; b < n_kf; b++) bk.add(bkey(a, b));   // small windows: dense S, no memset
-    for (auto &t : tp) bk.add(t.key);
-    for (auto &t : tt) bk.add(t.key);
+    lap("slot pair generation");
     const int n_sb = bk.finish();
+    lap("block key index");
     const std::vector<int64_t> &bkeys = bk.keys;
     auto blk_of = [&](int64_t k) { return bk.id(k); };
     P.sb_a.resize(n_sb); P.sb_b.resize(n_sb); P.sb_pab.assign(n_sb, -1); P.sb_pba.assign(n_sb, -1);
@@ -177,18 +206,19 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; if (h < 0) continue;
         int bl = blk_of(bkey(std::min(i, h), std::max(i, h)));
         if (i < h) P.sb_pab[bl] = q; else P.sb_pba[bl] = q; }     // pab: target = a, host = b;  pba: target = b, host = a
-    auto fill_tri = [&](std::vector<Tri> &t, std::vector<int32_t> &off, std::vector<int32_t> &s1, std::vector<int32_t> &s2) {
-        std::vector<int> bucket(t.size()), ord;                  // stable by block: the landmark-major generation order is kept
-        for (size_t k = 0; k < t.size(); k++) bucket[k] = blk_of(t[k].key);
-        bucket_order(bucket, n_sb, ord, off);
-        s1.resize(t.size()); s2.resize(t.size());
-        for (size_t k = 0; k < t.size(); k++) { s1[k] = t[ord[k]].s1; s2[k] = t[ord[k]].s2; }
+    auto fill_tri = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, const std::vector<int32_t> &lm_of, int n_lm,
+                        std::vector<int32_t> &off, std::vector<int32_t> &s1v, std::vector<int32_t> &s2v, std::vector<int32_t> &lmv) {
+        off.assign((size_t)n_sb + 1, 0);                          // stable by block: the landmark-major generation order is kept
+        each_pair(loff, pose, n_lm, [&](int64_t k, int, int) { off[(size_t)blk_of(k) + 1]++; });
+        for (int q = 0; q < n_sb; q++) off[q+1] += off[q];
+        const size_t tot = (size_t)off[n_sb];
+        s1v.resize(tot); s2v.resize(tot); lmv.resize(tot);
+        std::vector<int32_t> cur(off.begin(), off.end() - 1);
+        each_pair(loff, pose, n_lm, [&](int64_t k, int s1, int s2) { const int at = cur[blk_of(k)]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; });
     };
-    fill_tri(tp, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2);
-    fill_tri(tt, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2);
-    P.sb_pt_lm.resize(P.sb_pt_s1.size()); P.sb_tx_lm.resize(P.sb_tx_s1.size());      // saves one dependent gather in k_schur
-    for (size_t k = 0; k < P.sb_pt_s1.size(); k++) P.sb_pt_lm[k] = P.pslot_lm[P.sb_pt_s1[k]];
-    for (size_t k = 0; k < P.sb_tx_s1.size(); k++) P.sb_tx_lm[k] = P.tslot_lm[P.sb_tx_s1[k]];
+    fill_tri(P.pls_off, P.pslot_pose, P.pslot_lm, n_pt, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2, P.sb_pt_lm);      // (lm: saves one dependent gather in k_schur)
+    fill_tri(P.tls_off, P.tslot_pose, P.tslot_lm, n_text, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2, P.sb_tx_lm);
+    lap("slot pairs by block");
     // ---- per-pose lists
     auto csr = [&](int n, const std::vector<std::pair<int,int>> &items, std::vector<int32_t> &off, std::vector<int32_t> &val) {
         off.assign(n + 1, 0); val.resize(items.size());
@@ -235,4 +265,5 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     P.pose_ps_lm.resize(P.pose_ps.size()); P.pose_ts_lm.resize(P.pose_ts.size());
     for (size_t k = 0; k < P.pose_ps.size(); k++) P.pose_ps_lm[k] = P.pslot_lm[P.pose_ps[k]];
     for (size_t k = 0; k < P.pose_ts.size(); k++) P.pose_ts_lm[k] = P.tslot_lm[P.pose_ts[k]];
+    lap("per-pose lists");
 }
