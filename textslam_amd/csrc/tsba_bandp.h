@@ -174,30 +174,32 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                 // (flush step: the last panel onto EVERYTHING that stays behind, block column jb included -- no panel wave work)
                 const int Rs = fl ? j0 : R0;
                 const int re = max(Rs, min(n, j0 + bw)), vend = re + nbr;    // vend = virtual index of the rhs row
-                const int mr = vend - Rs + 1, mc = vend - Rs;
+                // columns: the band part only.  The border x border block and the border part of the rhs never feed back into the
+                // factorisation -- they are sums over ALL interior columns, formed afterwards from the stored border panel on many
+                // workgroups (k_bandp_border) instead of costing this workgroup 10 of its 28 MFMA tiles per step
+                const int mr = vend - Rs + 1, mcb = re - Rs;
                 const double *ldp = LD + SOLVE_LD*(jb - 1);
-                if (mc > 0) {
-                    const int ntr = (mr + 15) >> 4, ntc = (mc + 15) >> 4, ntile = tri(ntr);
+                if (mcb > 0) {
+                    const int ntr = (mr + 15) >> 4, ntcb = (mcb + 15) >> 4, ntri = tri(ntcb), ntile = ntri + (ntr - ntcb)*ntcb;
                     const int lr = lane & 15, lk = lane >> 4;
                     const int k1 = min(4 + lk, 5);
                     const double dk0 = ldp[LD_D + lk], dk1 = lk < 2 ? ldp[LD_D + 4 + lk] : 0.0;
                     auto real = [&](int v) { return v < re ? v : n + (v - re); };
                     for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
-                        const int ti = tri_row(t), tj = t - tri(ti);
-                        if (tj >= ntc) continue;
-                        const int arow = rowoff(real(min(Rs + 16*ti + lr, vend))) + p0, brow = rowoff(real(min(Rs + 16*tj + lr, vend - 1))) + p0;
+                        int ti, tj;
+                        if (t < ntri) { ti = tri_row(t); tj = t - tri(ti); } else { const int u = t - ntri; ti = ntcb + u/ntcb; tj = u - (ti - ntcb)*ntcb; }
+                        const int arow = rowoff(real(min(Rs + 16*ti + lr, vend))) + p0, brow = rowoff(min(Rs + 16*tj + lr, re - 1)) + p0;
                         double a0 = -A[arow + lk], a1 = -A[arow + k1];
                         double b0 = A[brow + lk]*dk0, b1 = A[brow + k1]*dk1;
                         if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
-                        const int ccol = Rs + 16*tj + lr;                                 // virtual column
+                        const int ccol = Rs + 16*tj + lr;                                 // band column
                         v4d c; int ci[4]; bool ok[4];
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int cv = Rs + 16*ti + lk + 4*r;                         // virtual row
-                            ok[r] = cv <= vend && ccol <= cv && ccol < vend;
-                            const int cvc = min(cv, vend);
-                            ci[r] = rowoff(real(cvc)) + real(min(ccol, min(cvc, vend - 1)));
-                            c[r] = A[ci[r]];
+                            ok[r] = cv <= vend && ccol <= cv && ccol < re;
+                            ci[r] = rowoff(real(min(cv, vend))) + ccol;
+                            c[r] = ok[r] ? A[ci[r]] : 0.0;
                         }
                         c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
@@ -272,9 +274,54 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
     }
 }
 
+// ---- the deferred part of T_p: LL = -sum_j Lb_j D_j Lb_j^T and gL = -sum_j Lb_j D_j v_j over the interior's column blocks, from the border
+// panel in HBM.  grid (P, BANDP_NS): every workgroup takes a slice of the interior's blocks and writes its partial (summed in a
+// fixed order by k_bandp_sep: deterministic).  part layout per (p, slice): [nbr x nbr] (lower used) | [nbr]
+#define BANDP_NS 8
+#define BANDP_JC 8
+__global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, const double *Lb, double *part) {
+    const LmState *st = W.st;
+    if (st->done || st->step_fail) return;
+    const int nb = *W.nfree, B = bw/6;
+    if (nb == 0) return;
+    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x);
+    if ((int)blockIdx.x >= PT.P || !PT.has_left) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int nbr = bw, REC = bw*6, tid = threadIdx.x;
+    double *sL = smem, *sLd = smem + (size_t)BANDP_JC*REC, *sv = sLd + (size_t)BANDP_JC*REC;       // Lb, Lb o d, v   per staged block
+    const int q = PT.b - PT.a, per = (q + BANDP_NS - 1)/BANDP_NS, j_lo = PT.a + blockIdx.y*per, j_hi = min(PT.b, j_lo + per);
+    const int ntask = tri(nbr) + nbr;                           // (k >= k') pairs, then the nbr entries of gL
+    int tk[8], tq[8]; double acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int t = tid + 256*u; acc[u] = 0.0; tk[u] = -1; tq[u] = 0;
+        if (t < tri(nbr)) { tk[u] = tri_row(t); tq[u] = t - tri(tk[u]); } else if (t < ntask) { tk[u] = t - tri(nbr); tq[u] = -1; } }
+    for (int j0 = j_lo; j0 < j_hi; j0 += BANDP_JC) {
+        const int nj = min(BANDP_JC, j_hi - j0);
+        __syncthreads();
+        for (int e = tid; e < nj*REC; e += 256) { const int jj = e/REC, k = e - jj*REC, a6 = k % 6;
+            const double v = Lb[(size_t)(j0 + jj)*REC + k], d = 1.0/W.LDbuf[32*(size_t)(j0 + jj) + 16 + a6];
+            sL[e] = v; sLd[e] = v*d; }
+        for (int e = tid; e < nj*6; e += 256) sv[e] = W.Sy[6*(size_t)j0 + e];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (tk[u] < 0) continue;
+            double a = 0.0;
+            if (tq[u] >= 0) for (int jj = 0; jj < nj; jj++) { const double *x = sL + jj*REC + 6*tk[u], *y = sLd + jj*REC + 6*tq[u];
+                a += x[0]*y[0] + x[1]*y[1] + x[2]*y[2] + x[3]*y[3] + x[4]*y[4] + x[5]*y[5]; }
+            else for (int jj = 0; jj < nj; jj++) { const double *x = sLd + jj*REC + 6*tk[u], *y = sv + 6*jj;
+                a += x[0]*y[0] + x[1]*y[1] + x[2]*y[2] + x[3]*y[3] + x[4]*y[4] + x[5]*y[5]; }
+            acc[u] -= a;
+        }
+    }
+    double *o = part + ((size_t)blockIdx.x*BANDP_NS + blockIdx.y)*((size_t)nbr*nbr + nbr);
+#pragma unroll
+    for (int u = 0; u < 8; u++) { if (tk[u] < 0) continue; if (tq[u] >= 0) o[(size_t)tk[u]*nbr + tq[u]] = acc[u]; else o[(size_t)nbr*nbr + tk[u]] = acc[u]; }
+}
+
 // ---- separator system: dense row-major (ld = nsep_ld), rows of separator s at [6 B s, 6 B (s + 1)); number of separator pose
 // blocks -> *nfree_sep (what k_band_solve reads)
-__global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, const double *Tbuf, double *Ssep, int nsep_ld, double *gsep, int *nfree_sep) {
+__global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, const double *Tbuf, const double *part, double *Ssep, int nsep_ld, double *gsep, int *nfree_sep) {
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
     const int nb = *W.nfree, B = bw/6;
@@ -288,11 +335,16 @@ __global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, con
     const int nRb = (s + 1 < P - 1) ? nS : 0;                    // interior s + 1 has a right separator unless it is the last
     for (int e = threadIdx.x; e < nS*nS; e += 256) {
         const int i = e/nS, j = e - i*nS;
-        if (j <= i) Ssep[(size_t)(nS*s + i)*nsep_ld + nS*s + j] = Ta[(size_t)i*nTm + j] + Tb[(size_t)(nRb + i)*nTm + nRb + j];
+        if (j <= i) { double v = Ta[(size_t)i*nTm + j];          // RR of interior s (from its window) + LL of interior s + 1 (k_bandp_border partials)
+            for (int sl = 0; sl < BANDP_NS; sl++) v += part[((size_t)(s + 1)*BANDP_NS + sl)*((size_t)nS*nS + nS) + (size_t)i*nS + j];
+            Ssep[(size_t)(nS*s + i)*nsep_ld + nS*s + j] = v; }
         // coupling to the NEXT separator through interior s + 1: T_{s+1}(border row i, right-separator column j) = S(sep s row i, sep s+1 col j)
         if (nRb > 0) Ssep[(size_t)(nS*(s + 1) + j)*nsep_ld + nS*s + i] = Tb[(size_t)(nRb + i)*nTm + j];
     }
-    for (int i = threadIdx.x; i < nS; i += 256) gsep[nS*s + i] = ga[i] + gb[nRb + i];
+    for (int i = threadIdx.x; i < nS; i += 256) { double v = ga[i];
+        for (int sl = 0; sl < BANDP_NS; sl++) v += part[((size_t)(s + 1)*BANDP_NS + sl)*((size_t)nS*nS + nS) + (size_t)nS*nS + i];
+        gsep[nS*s + i] = v; }
+    (void)gb;
 }
 
 // ---- back substitution of the interiors (right-looking, as k_band_backsub), both separator solutions known
