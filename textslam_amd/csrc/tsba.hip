@@ -991,12 +991,15 @@ __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad
 // ---- reduced camera system.  grid = n_sb (one workgroup per 6x6 block) + n_kf (reduced gradient), 256 threads.
 // The (slot, slot, landmark) gather lists of a diagonal block hold ~1000 entries: four waves, and per wave the indices and
 // operands of four entries in flight before the first multiply (two dependent global round trips per 1024 entries).
-#define SCHUR_T 256
 #define SCHUR_U 4
-__global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi) {
+// SCHUR_NW waves per workgroup: 4 for windows (a diagonal block gathers ~1000 slot pairs), 1 for large maps (54 k blocks of ~60 slot
+// pairs each at 5000 keyframes: three idle waves per block and their hand-off were most of the 0.64 ms)
+template <int SCHUR_NW>
+__global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int multi) {
+    constexpr int SCHUR_T = 64*SCHUR_NW;
     LmState *st = W.st;
     if (st->done) return;
-    __shared__ double lds[3*36*64];              // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
+    __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double radius = st->radius, irad = 1.0/radius;
     const LinBuf &B = W.lb[st->lcur];
@@ -1068,16 +1071,18 @@ __global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi
                 if (pba >= 0) tail -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
             }
         }
-        if (wave > 0) {
+        if (SCHUR_NW > 1) {
+            if (wave > 0) {
 #pragma unroll
-            for (int k = 0; k < 36; k++) lds[((wave - 1)*36 + k)*64 + lane] = acc[k];
-        }
-        __syncthreads();
-        if (wave == 0) {
+                for (int k = 0; k < 36; k++) lds[((wave - 1)*36 + k)*64 + lane] = acc[k];
+            }
+            __syncthreads();
+            if (wave == 0) {
 #pragma unroll
-            for (int k = 0; k < 36; k++) acc[k] += (lds[k*64 + lane] + lds[(36 + k)*64 + lane]) + lds[(72 + k)*64 + lane];
+                for (int k = 0; k < 36; k++) acc[k] += (lds[k*64 + lane] + lds[(36 + k)*64 + lane]) + lds[(72 + k)*64 + lane];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (wave == 0) {
 #pragma unroll
             for (int k = 0; k < 36; k++) lds[k*65 + lane] = acc[k];          // transpose: lane l < 36 sums entry l over the 64 lanes
@@ -1146,7 +1151,7 @@ __global__ __launch_bounds__(SCHUR_T) void k_schur(Work W, LevelDev L, int multi
             for (int k = 0; k < 6; k++) lds[wave*6 + k] = acc[k];
         }
         __syncthreads();
-        if (tid < 6) W.g[6*ia + tid] = bpv - (((lds[tid] + lds[6 + tid]) + lds[12 + tid]) + lds[18 + tid]);
+        if (tid < 6) W.g[6*ia + tid] = bpv - (SCHUR_NW > 1 ? (((lds[tid] + lds[6 + tid]) + lds[12 + tid]) + lds[18 + tid]) : lds[tid]);
     }
 }
 
@@ -1894,6 +1899,10 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
     *use_lds = bytes <= 160*1024 - 64;                                                      // gfx950: 160 KB of LDS per workgroup
     return *use_lds ? (int)bytes : 0;
 }
+static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
+    if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi);      // large maps: one wave per block
+    else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi);
+}
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
 static int set_solver_attrs(Ctx *c) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
@@ -1973,7 +1982,7 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream);   // block-sparse S
-    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(SCHUR_T), 0, c->stream, W, D, (int)is_multi(c));
+    launch_schur(c, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
         allreduce(c, c->S_alloc, c->S_count, ncclDouble, ncclSum);
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
@@ -2182,7 +2191,7 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     launch_linearize(c, D, 0);
     Work &W = c->W;
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream);
-    hipLaunchKernelGGL(k_schur, dim3(D.n_sb + c->n_kf), dim3(SCHUR_T), 0, c->stream, W, D, 0);
+    launch_schur(c, D, 0);
     launch_solve(c);
     c->opt = saved;
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
