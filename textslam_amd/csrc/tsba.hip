@@ -92,6 +92,7 @@ struct Work {                // device work buffers (sized for the largest level
     double *sig_pt, *sig_tx, *sig_p;    // Jacobi column scales, fixed at the first linearisation of a pass
     double *S, *g, *dp, *dl_pt, *dl_tx;
     double *partial;                    // [nblocks_back][2]
+    int *cntpart;                       // per k_participation workgroup: active scene blocks, active text blocks
     double *posepart;                   // large maps: per k_pose_sums workgroup (21 poses): gradient max, |x|^2
     LmState *st;
     PoseState *pst; double *ppart;      // pose-only path (tsba_pose.h): double-buffered state, [2][G][28] partial sums
@@ -198,38 +199,65 @@ __global__ void k_pass_reset(Work W, double radius0, int max_it) {
 }
 
 // which candidates are active (good flags), which keyframes participate (FLAG_KFIN, optimizer.cc:1410-1411,1428,1514-1515)
-__global__ __launch_bounds__(256) void k_participation(Work W, LevelDev L) {
+__global__ __launch_bounds__(256) void k_participation(Work W, LevelDev L, int partials) {
+    // workgroups 0 .. nb_sc-1: one scene candidate per thread; the rest: one (KF, text) group per WAVE, its features on the lanes
+    // (a thread walking the 64 features of a group alone was most of this kernel's 14 us)
     __shared__ int cnt_s, cnt_t;
     if (threadIdx.x == 0) { cnt_s = 0; cnt_t = 0; }
     __syncthreads();
-    int t = blockIdx.x*blockDim.x + threadIdx.x;
-    if (t < L.n_sc) {
-        bool act = !W.filter_good || W.sgood[L.sc_flag[t]];
-        if (act) {
-            int pt = L.sc_pt[t], h = W.pt_host[pt];
-            W.kf_in[L.sc_kf[t]] = 1;
-            if (h >= 0) { W.kf_in[h] = 1; W.act_pt[pt] = 1; }
-            atomicAdd(&cnt_s, 1);
+    const int nb_sc = (L.n_sc + 255) >> 8, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x < nb_sc) {
+        const int t = blockIdx.x*256 + threadIdx.x;
+        bool act = false;
+        if (t < L.n_sc) {
+            act = !W.filter_good || W.sgood[L.sc_flag[t]];
+            if (act) {
+                int pt = L.sc_pt[t], h = W.pt_host[pt];
+                W.kf_in[L.sc_kf[t]] = 1;
+                if (h >= 0) { W.kf_in[h] = 1; W.act_pt[pt] = 1; }
+            }
         }
-    } else if (t < L.n_sc + L.n_tg) {
-        int g = t - L.n_sc, tb = L.tg_tobs[g], j = L.tg_text[g];
-        if (!W.filter_good || W.tobs_good[tb]) {
-            int cnt = 0;
-            for (int f = L.tfeat_off[j]; f < L.tfeat_off[j+1]; f++)
-                if (!W.filter_good || W.tfgood[W.tobs_fgood_off[tb] + L.tfeat_raw[f]]) cnt++;
-            if (cnt > 0) {
-                int h = W.text_host[j];
-                W.kf_in[L.tg_kf[g]] = 1;
-                if (h >= 0) { W.kf_in[h] = 1; W.act_tx[j] = 1; }
-                atomicAdd(&cnt_t, cnt);
+        const int nw = __popcll(__ballot(act));
+        if (lane == 0 && nw) atomicAdd(&cnt_s, nw);
+    } else {
+        const int g = (blockIdx.x - nb_sc)*4 + (threadIdx.x >> 6);
+        if (g < L.n_tg) {
+            const int tb = L.tg_tobs[g], j = L.tg_text[g];
+            if (!W.filter_good || W.tobs_good[tb]) {
+                const int f0 = L.tfeat_off[j], f1 = L.tfeat_off[j+1], fg = W.tobs_fgood_off[tb];
+                int cnt = 0;
+                for (int f = f0 + lane; f < f1; f += 64) if (!W.filter_good || W.tfgood[fg + L.tfeat_raw[f]]) cnt++;
+                cnt = (int)wave_sum1((double)cnt);
+                if (lane == 0 && cnt > 0) {
+                    const int h = W.text_host[j];
+                    W.kf_in[L.tg_kf[g]] = 1;
+                    if (h >= 0) { W.kf_in[h] = 1; W.act_tx[j] = 1; }
+                    atomicAdd(&cnt_t, cnt);
+                }
             }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { if (cnt_s) atomicAdd(&W.st->ns_active, cnt_s); if (cnt_t) atomicAdd(&W.st->nt_active, cnt_t); }
+    if (threadIdx.x == 0) {
+        // single GPU: per-workgroup partials, summed by the gauge kernel; multi-GPU: the counts are all-reduced before the gauge
+        // kernel runs, so they go straight to the state
+        if (partials) { W.cntpart[2*blockIdx.x] = cnt_s; W.cntpart[2*blockIdx.x + 1] = cnt_t; }
+        else { if (cnt_s) atomicAdd(&W.st->ns_active, cnt_s); if (cnt_t) atomicAdd(&W.st->nt_active, cnt_t); }
+    }
+}
+// block counts of k_participation -> LM state (called by the gauge kernels' first wave / all threads)
+__device__ __forceinline__ void sum_counts(const Work &W, int ncp, int tid, int nthreads, int *lds2 /* [2] zeroed */) {
+    int a = 0, b = 0;
+    for (int k = tid; k < ncp; k += nthreads) { a += W.cntpart[2*k]; b += W.cntpart[2*k + 1]; }
+    if (a) atomicAdd(&lds2[0], a);
+    if (b) atomicAdd(&lds2[1], b);
 }
 // gauge fixing, optimizer.cc:1562-1588 / :1825-1830
-__global__ void k_gauge(Work W, const uint8_t *kf_initial, int state) {
+__global__ void k_gauge(Work W, const uint8_t *kf_initial, int state, int ncp) {
+    __shared__ int s_cnt2[2];
+    if (threadIdx.x == 0) { s_cnt2[0] = 0; s_cnt2[1] = 0; }
+    __syncthreads();
+    if (ncp) { sum_counts(W, ncp, threadIdx.x, blockDim.x, s_cnt2); __syncthreads(); if (threadIdx.x == 0) { W.st->ns_active = s_cnt2[0]; W.st->nt_active = s_cnt2[1]; } }
     if (threadIdx.x || blockIdx.x) return;
     int cnt = 0;
     for (int k = 0; k < W.n_kf; k++) { if (kf_initial[k] && W.kf_in[k]) W.kf_const[k] = 1; cnt += W.kf_in[k]; }
@@ -242,10 +270,33 @@ __global__ void k_gauge(Work W, const uint8_t *kf_initial, int state) {
     *W.nfree = nf;
 }
 
+// windows of up to 64 keyframes: one lane per keyframe, ballots instead of the serial walk (7.8 -> ~2 us per pass)
+__global__ __launch_bounds__(64) void k_gauge_wave(Work W, const uint8_t *kf_initial, int state, int ncp) {
+    __shared__ int s_cnt2[2];
+    const int k = threadIdx.x;
+    if (k == 0) { s_cnt2[0] = 0; s_cnt2[1] = 0; }
+    __syncthreads();
+    if (ncp) { sum_counts(W, ncp, k, 64, s_cnt2); __syncthreads(); if (k == 0) { W.st->ns_active = s_cnt2[0]; W.st->nt_active = s_cnt2[1]; } }
+    const bool on = k < W.n_kf;
+    const int in = on ? W.kf_in[k] : 0, ini = on ? kf_initial[k] : 0;
+    const unsigned long long m_in = __ballot(in != 0);
+    int cst = (ini && in) ? 1 : 0;
+    if (state == TSBA_STATE_LOCAL && __popcll(m_in) > 3) {
+        const int before = __popcll(m_in & ((1ull << k) - 1));      // participating keyframes with a smaller index
+        if (in && before < 3) cst = 1;                               // the first three of them are held constant
+    }
+    const bool fre = in && !cst;
+    const unsigned long long m_free = __ballot(fre);
+    if (on) { W.kf_const[k] = cst; W.fidx[k] = fre ? __popcll(m_free & ((1ull << k) - 1)) : -1; }
+    if (k == 0) *W.nfree = __popcll(m_free);
+}
 // the same for large maps: 1024 threads, consecutive keyframes per thread, one block-wide exclusive scan for the compressed indices
 // (the single-thread walk above costs 1.4 ms at 5000 keyframes)
-__global__ __launch_bounds__(1024) void k_gauge_par(Work W, const uint8_t *kf_initial, int state) {
-    __shared__ int s_scan[1024]; __shared__ int s_first[3]; __shared__ int s_cnt;
+__global__ __launch_bounds__(1024) void k_gauge_par(Work W, const uint8_t *kf_initial, int state, int ncp) {
+    __shared__ int s_scan[1024]; __shared__ int s_first[3]; __shared__ int s_cnt; __shared__ int s_cnt2[2];
+    if (threadIdx.x == 0) { s_cnt2[0] = 0; s_cnt2[1] = 0; }
+    __syncthreads();
+    if (ncp) { sum_counts(W, ncp, threadIdx.x, 1024, s_cnt2); __syncthreads(); if (threadIdx.x == 0) { W.st->ns_active = s_cnt2[0]; W.st->nt_active = s_cnt2[1]; } }
     const int tid = threadIdx.x, per = (W.n_kf + 1023)/1024, k0 = tid*per, k1 = min(W.n_kf, k0 + per);
     if (tid == 0) {                                           // STATE_LOCAL: the first three participating keyframes are held constant
         int f = 0; s_first[0] = s_first[1] = s_first[2] = -1;
@@ -1866,6 +1917,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
     AL(W.posepart, 2*((size_t)p->n_kf/21 + 2));
+    { size_t mxn = 1; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) mxn = std::max(mxn, (size_t)c->lev[l].n_sc + c->lev[l].n_tg); AL(W.cntpart, 2*(mxn/4 + mxn/256 + 4)); }
     AL(W.st, 1);
     flush_run(c);
     auto tu2 = std::chrono::steady_clock::now();
@@ -1899,14 +1951,17 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     Work &W = c->W; const tsba_options &o = c->opt;
     hipLaunchKernelGGL(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
     int n = D.n_sc + D.n_tg;
-    if (n > 0) hipLaunchKernelGGL(k_participation, dim3((n + 255)/256), dim3(256), 0, c->stream, W, D);
+    const int npb = (D.n_sc + 255)/256 + (D.n_tg + 3)/4;                    // k_participation workgroups: scene candidates | text groups
+    const int ncp = (n > 0 && !is_multi(c)) ? npb : 0;                      // count partials (single GPU)
+    if (n > 0) hipLaunchKernelGGL(k_participation, dim3(npb), dim3(256), 0, c->stream, W, D, ncp ? 1 : 0);
     if (is_multi(c)) {                             // participation and block counts are global properties
         allreduce(c, W.kf_in, c->n_kf, ncclInt32, ncclSum);
         allreduce(c, &W.st->ns_active, 2, ncclInt32, ncclSum);
         hipLaunchKernelGGL(k_kfin_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
-    if (c->n_kf > 256) hipLaunchKernelGGL(k_gauge_par, dim3(1), dim3(1024), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state);
-    else hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state);
+    if (c->n_kf <= 64) hipLaunchKernelGGL(k_gauge_wave, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
+    else if (c->n_kf > 256) hipLaunchKernelGGL(k_gauge_par, dim3(1), dim3(1024), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
+    else hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
 static int pose_parts(const Ctx *c) { return (c->n_kf > 126 && !is_multi(c)) ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
