@@ -416,25 +416,31 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
     int tb = L.tg_tobs[g], kf = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
     if (W.filter_good && !W.tobs_good[tb]) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
     const int w = L.img_w, hh = L.img_h;
-    if (tid == 0) {
+    __shared__ int s_c[16];
+    if (tid < 4) {                                            // one box corner per lane (the serial walk over the four cost ~1.5 us of divisions)
+        const int b = tid;
         Pose C; load_pose(pose + 7*kf, C);
         PairT T;
         if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
         else pair_from_Twr(C, W.text_Twr + 12*j, T);
         double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-        int xMin = w + 1, xMax = -1, yMin = hh + 1, yMax = -1;
-        for (int b = 0; b < 4; b++) {
-            double mx = W.text_box[(j*4 + b)*2], my = W.text_box[(j*4 + b)*2 + 1];
-            double invz = -(mx*th[0] + my*th[1] + th[2]);
-            double m[3] = { mx, my, 1.0 }, Rm[3]; mat3_vec(T.Rcr, m, Rm);
-            double X = Rm[0]/invz + T.tq[0] + C.t[0], Y = Rm[1]/invz + T.tq[1] + C.t[1], Z = Rm[2]/invz + T.tq[2] + C.t[2];
-            double cu = L.K[0]*X/Z + L.K[2], cv = L.K[1]*Y/Z + L.K[3];
-            s_xy[2*b] = (int)cu; s_xy[2*b+1] = (int)cv;
-            if (cu > xMax) xMax = (int)ceil(cu);
-            if (cu < xMin) xMin = (int)floor(cu);
-            if (cv > yMax) yMax = (int)ceil(cv);
-            if (cv < yMin) yMin = (int)floor(cv);
-        }
+        double mx = W.text_box[(j*4 + b)*2], my = W.text_box[(j*4 + b)*2 + 1];
+        double invz = -(mx*th[0] + my*th[1] + th[2]);
+        double m[3] = { mx, my, 1.0 }, Rm[3]; mat3_vec(T.Rcr, m, Rm);
+        double X = Rm[0]/invz + T.tq[0] + C.t[0], Y = Rm[1]/invz + T.tq[1] + C.t[1], Z = Rm[2]/invz + T.tq[2] + C.t[2];
+        double cu = L.K[0]*X/Z + L.K[2], cv = L.K[1]*Y/Z + L.K[3];
+        s_xy[2*b] = (int)cu; s_xy[2*b+1] = (int)cv;
+        // the reference updates xMax / xMin only on strict improvement, starting from -1 / w + 1: a corner that does not improve
+        // contributes nothing -- the same as taking max / min over the corners that do
+        s_c[4*b] = cu > -1.0 ? (int)ceil(cu) : -1;            // candidate for xMax (initial value -1)
+        s_c[4*b + 1] = cu < (double)(w + 1) ? (int)floor(cu) : w + 1;
+        s_c[4*b + 2] = cv > -1.0 ? (int)ceil(cv) : -1;
+        s_c[4*b + 3] = cv < (double)(hh + 1) ? (int)floor(cv) : hh + 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int xMax = max(max(s_c[0], s_c[4]), max(s_c[8], s_c[12])), xMin = min(min(s_c[1], s_c[5]), min(s_c[9], s_c[13]));
+        int yMax = max(max(s_c[2], s_c[6]), max(s_c[10], s_c[14])), yMin = min(min(s_c[3], s_c[7]), min(s_c[11], s_c[15]));
         if (xMin < 0) xMin = 0;
         if (xMin >= w) xMin = w - 1;
         if (yMin < 0) yMin = 0;
@@ -454,9 +460,22 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
     // histogram of masked pixels inside the clamped bounding box (tool.cc:1217-1232)
     const uint8_t *img = L.img[kf];
     int bw = xMax - xMin + 1, bh = yMax - yMin + 1;
-    for (int k = tid; k < bw*bh; k += MS_THREADS) {
-        int x = xMin + k % bw, y = yMin + k / bw, bit = y*w + x;
-        if (mask[bit >> 5] & (1u << (bit & 31))) atomicAdd(&hist[img[bit]], 1u);
+    {   // four pixels per thread and round with their loads in flight together; (x, y) advance without a division per pixel
+        const int npx = bw*bh, dx = MS_THREADS % bw, dy = MS_THREADS / bw;
+        int x = tid % bw, y = tid / bw;
+        for (int k0 = tid; k0 < npx; k0 += 4*MS_THREADS) {
+            int bit[4]; bool in[4]; unsigned px[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                bit[u] = (yMin + y)*w + xMin + x;
+                in[u] = k0 + u*MS_THREADS < npx && (mask[bit[u] >> 5] & (1u << (bit[u] & 31)));
+                x += dx; y += dy; if (x >= bw) { x -= bw; y++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) px[u] = in[u] ? img[bit[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (in[u]) atomicAdd(&hist[px[u]], 1u);
+        }
     }
     __syncthreads();
     double cnt = (double)hist[tid], sum = (double)hist[tid]*(double)tid;
