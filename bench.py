@@ -173,6 +173,18 @@ def main():
                "config": {"workload": "global BA %d KF x %d pts (scene only, 20 LM its, level 0), landmarks sharded over %d GPU(s)"
                                       % (args.kf, args.pts, world), "lm_iterations": rep["iters"], "scene_blocks": rep["n_sblock"],
                           "reduced_system_dim": 6*args.kf}}
+        # roofline of the linearisation kernel on this rank's shard (HBM-bound stream of scene blocks, SURVEY 8d: 44 B per block)
+        lin_ms, algo_bytes = gpu.time_linearize(0, 50)
+        achieved = algo_bytes/(lin_ms*1e-3)/1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0, this rank's landmark shard)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                           "frac": achieved/8000.0, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3}
+        if not args.no_cpu_baseline:
+            # the oracle's dense Schur solve is cubic in the keyframes: a bounded instance of the same generator stands in
+            import oracle
+            small = synth.config_global(n_kf=300, n_pt=30000, band=12)
+            t0 = time.perf_counter(); rep_o = oracle.solve(small.copy(), opt); dtc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": rep_o["n_resid_evals"]/dtc, "unit": "residuals/s", "cores": 1, "kind": "port",
+                                   "sample": "the same generator at 300 KF x 30000 pts (the CPU restatement factors the reduced system densely)", "seconds": dtc}
     elif rank == 0:
         # the same window through the one-shot ABI entry point (what the TextSLAM adapter calls per keyframe)
         cold = []

@@ -16,4 +16,3 @@ import ctypes as C
 st = (C.c_longlong*64)(); opt.lib.tsba_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]; opt.lib.tsba_debug_stamps(opt.ctx, st)
 tot = sum(st[32:36]) or 1
 print("band solve phases (clock64 ticks, last launch): factor %d  write-out %d  slide %d  load %d  -> %.1f%% / %.1f%% / %.1f%% / %.1f%%; chunks %d" % (st[32], st[33], st[34], st[35], 100*st[32]/tot, 100*st[33]/tot, 100*st[34]/tot, 100*st[35]/tot, st[19]))
-print("per-launch work cycles inside the factor loop: panel wave 0 %d, update wave 2 %d, update wave 11 %d" % (st[36], st[37], st[38]))

@@ -89,7 +89,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         if (first) for (int k = tid; k < nbr; k += SOLVE_THREADS) rhs[n + k] = 0.0;
         __syncthreads();
     };
-    if (tid == 0 && W.dbg && blockIdx.x == 1) { W.dbg[36] = 0; W.dbg[37] = 0; W.dbg[38] = 0; }
     long long tF = 0, tW = 0, tS = 0, tL = 0, tx = clock64(); int nchunks = 0;       // phase stamps of interior 1 (-> W.dbg[32..36])
     load_rows(0, true);
     { const long long t_ = clock64(); tL += t_ - tx; tx = t_; }
@@ -100,7 +99,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         const bool flush = last && (n + nbr > 6*jend);          // rows stay behind: the last panel must still be applied to them
         const int NR = n + nbr;                                 // the rhs row
         for (int jb = jstart; jb < jend + (flush ? 1 : 0) && !fail; jb++) {
-            const long long tq0 = clock64();
             const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
             const bool fl = jb == jend;                         // flush step: no factorisation, panel jb-1 onto everything right of it
             if (wave < SOLVE_PW) {
@@ -208,7 +206,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     }
                 }
             }
-            { const long long tq1 = clock64(); if (W.dbg && blockIdx.x == 1 && lane == 0 && (wave == 0 || wave == 2 || wave == 11)) atomicAdd((unsigned long long *)&W.dbg[36 + (wave == 0 ? 0 : wave == 2 ? 1 : 2)], (unsigned long long)(tq1 - tq0)); }
             __syncthreads();                       // panel jb complete, trailing update with panel jb-1 complete
         }
         { const long long t_ = clock64(); tF += t_ - tx; tx = t_; }
