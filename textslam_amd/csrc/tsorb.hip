@@ -69,12 +69,12 @@ __global__ void k_level0(OrbDev D) {
     int sx = reflect101(x - EDGE, G.w), sy = reflect101(y - EDGE, G.h);
     D.pyr[(size_t)f*D.pyr_frame + G.pyr_off + r] = D.img[((size_t)f*D.h + sy)*D.stride + sx];
 }
-// cv::resize(8UC1, INTER_LINEAR) from level l-1 to level l, evaluated at the reflected coordinate for border pixels
-__global__ void k_resize(OrbDev D, int l) {
+// cv::resize(8UC1, INTER_LINEAR) from level l-1 to level l, evaluated at the reflected coordinate for border pixels.
+// grid (x chunks of 128, bordered rows, frames): the row terms (source rows, vertical weights) are uniform per workgroup.
+__global__ __launch_bounds__(128) void k_resize(OrbDev D, int l) {
     const LevelGeo &G = D.L[l], &S = D.L[l-1];
-    size_t idx = (size_t)blockIdx.x*blockDim.x + threadIdx.x, per = (size_t)G.bw*G.bh;
-    if (idx >= per*D.n) return;
-    int f = (int)(idx / per), r = (int)(idx % per), y = r / G.bw, x = r % G.bw;
+    const int x = blockIdx.x*128 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= G.bw) return;
     int dx = reflect101(x - EDGE, G.w), dy = reflect101(y - EDGE, G.h);
     const double scale_x = 1.0/((double)G.w/(double)S.w), scale_y = 1.0/((double)G.h/(double)S.h);
     float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scale_x), 0.5);
@@ -90,7 +90,7 @@ __global__ void k_resize(OrbDev D, int l) {
     const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + S.pyr_off + (size_t)EDGE*S.bw + EDGE;
     const uint8_t *r0 = src + (size_t)sy0*S.bw, *r1 = src + (size_t)sy1*S.bw;
     int S0 = r0[sx]*a0 + r0[sx1]*a1, S1 = r1[sx]*a0 + r1[sx1]*a1;
-    D.pyr[(size_t)f*D.pyr_frame + G.pyr_off + r] = (uint8_t)((((b0*(S0 >> 4)) >> 16) + ((b1*(S1 >> 4)) >> 16) + 2) >> 2);
+    D.pyr[(size_t)f*D.pyr_frame + G.pyr_off + (size_t)y*G.bw + x] = (uint8_t)((((b0*(S0 >> 4)) >> 16) + ((b1*(S1 >> 4)) >> 16) + 2) >> 2);
 }
 
 // ---------------------------------------------------------------- FAST per cell
@@ -807,7 +807,7 @@ int tsorb_run(void *ctx) {
     hipSetDevice(c->device);
     OrbDev &D = c->D;
     { size_t tot = (size_t)D.n*D.L[0].bw*D.L[0].bh; hipLaunchKernelGGL(k_level0, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, D); }
-    for (int l = 1; l < D.nlevels; l++) { size_t tot = (size_t)D.n*D.L[l].bw*D.L[l].bh; hipLaunchKernelGGL(k_resize, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, D, l); }
+    for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 127)/128, D.L[l].bh, D.n), dim3(128), 0, c->stream, D, l);
     hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
