@@ -6,7 +6,8 @@ import oracle
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 opt = Optimizer(0)
-for (nkf, band) in ((40, 6), (70, 9), (120, 10), (300, 12), (600, 10), (1500, 10)):
+cfgs = ((40, 6), (70, 9), (120, 10), (300, 12), (600, 10), (1500, 10)) if len(sys.argv) < 2 else tuple((int(a.split(',')[0]), int(a.split(',')[1])) for a in sys.argv[1:])
+for (nkf, band) in cfgs:
     P = synth.config_global(n_kf=nkf, n_pt=50*nkf, band=band)
     o = abi.options_global()
     opt.upload(P, o)

@@ -288,9 +288,10 @@ __global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, 
     double *sL = smem, *sLd = smem + (size_t)BANDP_JC*REC, *sv = sLd + (size_t)BANDP_JC*REC;       // Lb, Lb o d, v   per staged block
     const int q = PT.b - PT.a, per = (q + BANDP_NS - 1)/BANDP_NS, j_lo = PT.a + blockIdx.y*per, j_hi = min(PT.b, j_lo + per);
     const int ntask = tri(nbr) + nbr;                           // (k >= k') pairs, then the nbr entries of gL
-    int tk[8], tq[8]; double acc[8];
+    constexpr int NU = (BAND_BW_MAX/2*(BAND_BW_MAX/2 + 1)/2 + BAND_BW_MAX/2 + 255)/256;       // tasks per thread at the widest border (78 rows: 3159 tasks)
+    int tk[NU], tq[NU]; double acc[NU];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { const int t = tid + 256*u; acc[u] = 0.0; tk[u] = -1; tq[u] = 0;
+    for (int u = 0; u < NU; u++) { const int t = tid + 256*u; acc[u] = 0.0; tk[u] = -1; tq[u] = 0;
         if (t < tri(nbr)) { tk[u] = tri_row(t); tq[u] = t - tri(tk[u]); } else if (t < ntask) { tk[u] = t - tri(nbr); tq[u] = -1; } }
     for (int j0 = j_lo; j0 < j_hi; j0 += BANDP_JC) {
         const int nj = min(BANDP_JC, j_hi - j0);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, 
         for (int e = tid; e < nj*6; e += 256) sv[e] = W.Sy[6*(size_t)j0 + e];
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < NU; u++) {
             if (tk[u] < 0) continue;
             double a = 0.0;
             if (tq[u] >= 0) for (int jj = 0; jj < nj; jj++) { const double *x = sL + jj*REC + 6*tk[u], *y = sLd + jj*REC + 6*tq[u];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, 
     }
     double *o = part + ((size_t)blockIdx.x*BANDP_NS + blockIdx.y)*((size_t)nbr*nbr + nbr);
 #pragma unroll
-    for (int u = 0; u < 8; u++) { if (tk[u] < 0) continue; if (tq[u] >= 0) o[(size_t)tk[u]*nbr + tq[u]] = acc[u]; else o[(size_t)nbr*nbr + tk[u]] = acc[u]; }
+    for (int u = 0; u < NU; u++) { if (tk[u] < 0) continue; if (tq[u] >= 0) o[(size_t)tk[u]*nbr + tq[u]] = acc[u]; else o[(size_t)nbr*nbr + tk[u]] = acc[u]; }
 }
 
 // ---- separator system: dense row-major (ld = nsep_ld), rows of separator s at [6 B s, 6 B (s + 1)); number of separator pose
