@@ -1915,9 +1915,14 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         if (W.band && bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !getenv("TSBA_NO_BAND_STREAM")) {
             AL(c->Lcol, (size_t)p->n_kf*bwmax*6); c->band_stream = 1;
             // substructuring: P interiors on P workgroups + a separator system (again a band, 2 bw - 6 wide)
-            int P = 24; if (const char *e = getenv("TSBA_BAND_PARTS")) P = atoi(e);
-            P = std::max(1, std::min(P, BANDP_MAXP));
+            // number of interiors: the interiors run in parallel (n_kf / P blocks each, ~3.5 us per block, 5 us once the border makes the
+            // panel waves take two rounds), the separator system is sequential again ((P - 1) B blocks at ~4.5 us, 5.5 us when its band
+            // exceeds 115 rows): the sum is smallest near sqrt(n_kf t_f / (B t_s))
             const int Bq = bwmax/6;
+            const double t_f = bwmax > 57 ? 5.0 : 3.5, t_s = 2*bwmax - 6 > 115 ? 5.5 : 4.5;
+            int P = (int)lround(sqrt((double)p->n_kf*t_f/((double)std::max(Bq, 1)*t_s)));
+            if (const char *e = getenv("TSBA_BAND_PARTS")) P = atoi(e);
+            P = std::max(1, std::min(P, BANDP_MAXP));
             while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < 4*Bq + 4) P--;                   // worth it only for interiors of a few bands
             if (P > 1 && bandp_chunk_blocks(bwmax) > 0 && 2*bwmax - 6 <= BAND_BW_MAX && band_chunk_blocks(2*bwmax - 6) > 0) {
                 const int nsep = (P - 1)*bwmax, bws = 2*bwmax - 6;
