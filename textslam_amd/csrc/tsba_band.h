@@ -160,30 +160,49 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, in
                     const int lr = lane & 15, lk = lane >> 4;
                     const int k1 = min(4 + lk, 5);
                     const double dk0 = ldp[LD_D + lk], dk1 = lk < 2 ? ldp[LD_D + 4 + lk] : 0.0;
-                    for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
-                        const int ti = tri_row(t), tj = t - tri(ti);
-                        if (tj >= ntc) continue;
-                        // unconditional, index-clamped loads (rows / columns past the edge only feed outputs that are never stored);
-                        // only the K padding (k = 6, 7) must be exact zeros
-                        const int av = min(R0 + 16*ti + lr, re);
-                        const int arow = rowoff(av < re ? av : n) + p0, brow = rowoff(min(R0 + 16*tj + lr, re - 1)) + p0;
-                        double a0 = -A[arow + lk], a1 = -A[arow + k1];
-                        double b0 = A[brow + lk]*dk0, b1 = A[brow + k1]*dk1;
-                        if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
-                        const int ccol = R0 + 16*tj + lr;
-                        v4d c; int ci[4]; bool ok[4];
+                    // (the tiles of a wave: decode the first, then step -- no square root per tile)
+                    int t = wave - SOLVE_PW, ti = 0, tj = 0;
+                    if (t < ntile) { ti = tri_row(t); tj = t - tri(ti); }
+                    for (; t < ntile; t += NT) {
+                        if (tj < ntc) {
+                            const int r0v = R0 + 16*ti, c0v = R0 + 16*tj;
+                            double a0, a1, b0, b1;
+                            if (ti > tj && r0v + 15 < re) {
+                                // a tile strictly below the diagonal and entirely inside the band rows: nothing to mask, nothing to
+                                // clamp, row offsets by recurrence (rowoff(i + 4) = rowoff(i) + 4 i + 12) -- half the instructions
+                                const int arow = rowoff(r0v + lr) + p0, brow = rowoff(c0v + lr) + p0;
+                                a0 = -A[arow + lk]; a1 = -A[arow + k1]; b0 = A[brow + lk]*dk0; b1 = A[brow + k1]*dk1;
+                                if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
+                                const int cv0 = r0v + lk, ccol = c0v + lr;
+                                int ci0 = rowoff(cv0) + ccol; const int ci1 = ci0 + 4*cv0 + 12, ci2 = ci1 + 4*cv0 + 28, ci3 = ci2 + 4*cv0 + 44;
+                                v4d c = { A[ci0], A[ci1], A[ci2], A[ci3] };
+                                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+                                A[ci0] = c[0]; A[ci1] = c[1]; A[ci2] = c[2]; A[ci3] = c[3];
+                            } else {
+                                // unconditional, index-clamped loads (rows / columns past the edge only feed outputs that are never stored);
+                                // only the K padding (k = 6, 7) must be exact zeros
+                                const int av = min(r0v + lr, re);
+                                const int arow = rowoff(av < re ? av : n) + p0, brow = rowoff(min(c0v + lr, re - 1)) + p0;
+                                a0 = -A[arow + lk]; a1 = -A[arow + k1]; b0 = A[brow + lk]*dk0; b1 = A[brow + k1]*dk1;
+                                if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
+                                const int ccol = c0v + lr;
+                                v4d c; int ci[4]; bool ok[4];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int cv = R0 + 16*ti + lk + 4*r;                         // virtual row
-                            ok[r] = cv <= re && ccol <= cv && ccol < re;
-                            const int cvc = min(cv, re), crow = cvc < re ? cvc : n;
-                            ci[r] = rowoff(crow) + min(ccol, min(cvc, re - 1));
-                            c[r] = A[ci[r]];
+                                for (int r = 0; r < 4; r++) {
+                                    const int cv = r0v + lk + 4*r;                                // virtual row
+                                    ok[r] = cv <= re && ccol <= cv && ccol < re;
+                                    const int cvc = min(cv, re), crow = cvc < re ? cvc : n;
+                                    ci[r] = rowoff(crow) + min(ccol, min(cvc, re - 1));
+                                    c[r] = A[ci[r]];
+                                }
+                                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+#pragma unroll
+                                for (int r = 0; r < 4; r++) if (ok[r]) A[ci[r]] = c[r];
+                            }
                         }
-                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) if (ok[r]) A[ci[r]] = c[r];
+                        tj += NT; while (tj > ti) { tj -= ti + 1; ti++; }                         // next tile of this wave
                     }
                 }
             }

@@ -186,15 +186,32 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
                         int ti, tj;
                         if (t < ntri) { ti = tri_row(t); tj = t - tri(ti); } else { const int u = t - ntri; ti = ntcb + u/ntcb; tj = u - (ti - ntcb)*ntcb; }
-                        const int arow = rowoff(real(min(Rs + 16*ti + lr, vend))) + p0, brow = rowoff(min(Rs + 16*tj + lr, re - 1)) + p0;
-                        double a0 = -A[arow + lk], a1 = -A[arow + k1];
-                        double b0 = A[brow + lk]*dk0, b1 = A[brow + k1]*dk1;
+                        const int r0v = Rs + 16*ti, c0v = Rs + 16*tj;
+                        double a0, a1, b0, b1;
+                        const bool rows_band = r0v + 15 < re, rows_border = r0v >= re && r0v + 15 < vend;
+                        if (ti > tj && c0v + 15 < re && (rows_band || rows_border)) {
+                            // nothing to mask or clamp: the 16 rows are all band rows or all border rows (consecutive real rows either
+                            // way), the columns all band columns left of them; row offsets by recurrence (rowoff(i + 4) = rowoff(i) + 4 i + 12)
+                            const int rr0 = rows_band ? r0v : n + (r0v - re);                    // real row of the tile's first row
+                            const int arow = rowoff(rr0 + lr) + p0, brow = rowoff(c0v + lr) + p0;
+                            a0 = -A[arow + lk]; a1 = -A[arow + k1]; b0 = A[brow + lk]*dk0; b1 = A[brow + k1]*dk1;
+                            if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
+                            const int cv0 = rr0 + lk, ccol = c0v + lr;
+                            const int ci0 = rowoff(cv0) + ccol, ci1 = ci0 + 4*cv0 + 12, ci2 = ci1 + 4*cv0 + 28, ci3 = ci2 + 4*cv0 + 44;
+                            v4d c = { A[ci0], A[ci1], A[ci2], A[ci3] };
+                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+                            A[ci0] = c[0]; A[ci1] = c[1]; A[ci2] = c[2]; A[ci3] = c[3];
+                            continue;
+                        }
+                        const int arow = rowoff(real(min(r0v + lr, vend))) + p0, brow = rowoff(min(c0v + lr, re - 1)) + p0;
+                        a0 = -A[arow + lk]; a1 = -A[arow + k1]; b0 = A[brow + lk]*dk0; b1 = A[brow + k1]*dk1;
                         if (lk >= 2) { a1 = 0.0; b1 = 0.0; }
-                        const int ccol = Rs + 16*tj + lr;                                 // band column
+                        const int ccol = c0v + lr;                                        // band column
                         v4d c; int ci[4]; bool ok[4];
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const int cv = Rs + 16*ti + lk + 4*r;                         // virtual row
+                            const int cv = r0v + lk + 4*r;                                // virtual row
                             ok[r] = cv <= vend && ccol <= cv && ccol < re;
                             ci[r] = rowoff(real(min(cv, vend))) + ccol;
                             c[r] = ok[r] ? A[ci[r]] : 0.0;
