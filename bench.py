@@ -174,10 +174,11 @@ def main():
                                       % (args.kf, args.pts, world), "lm_iterations": rep["iters"], "scene_blocks": rep["n_sblock"],
                           "reduced_system_dim": 6*args.kf}}
         # roofline of the linearisation kernel on this rank's shard (HBM-bound stream of scene blocks, SURVEY 8d: 44 B per block)
-        lin_ms, algo_bytes = gpu.time_linearize(0, 50)
-        achieved = algo_bytes/(lin_ms*1e-3)/1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0, this rank's landmark shard)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                           "frac": achieved/8000.0, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3}
+        if world == 1:                                     # (with a communicator the pass set-up all-reduces: every rank would have to take part)
+            lin_ms, algo_bytes = gpu.time_linearize(0, 50)
+            achieved = algo_bytes/(lin_ms*1e-3)/1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                               "frac": achieved/8000.0, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3}
         if not args.no_cpu_baseline:
             # the oracle's dense Schur solve is cubic in the keyframes: a bounded instance of the same generator stands in
             import oracle
