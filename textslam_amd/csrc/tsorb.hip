@@ -354,11 +354,13 @@ struct LNode { short x0, y0, x1, y1; int key0, nk; short nomore, pad; short prev
 __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
     const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, lane = threadIdx.x;
     const LevelGeo &G = D.L[l];
-    __shared__ float cx[QL_CAND], cy[QL_CAND], cr[QL_CAND];
+    // candidates as 16-bit integers (pixel coordinates and FAST scores are small integers): with 32-bit floats the workgroup needed 106 KB
+    // of LDS -- ONE workgroup per CU, so the 512 (frame, level) workgroups of a 64-frame batch ran in two rounds; 74 KB lets two share a CU
+    __shared__ unsigned short cx[QL_CAND], cy[QL_CAND], cr[QL_CAND];
     __shared__ unsigned short keys[QL_CAND], tmpk[QL_CAND];
     __shared__ LNode nd[QL_NODES];
     __shared__ short freelist[QL_NODES];
-    __shared__ int vs[2*QL_NODES], vp[2*QL_NODES];
+    __shared__ unsigned short vs[2*QL_NODES], vp[2*QL_NODES];      // (size <= QL_CAND, node index < QL_NODES)
     __shared__ int s_off[1];
     int *selcnt = D.selcnt + (size_t)f*D.nlevels + l;
     float *sel = D.sel + ((size_t)f*D.slots_per_frame + G.kp0)*4;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
         if (c < ncell && base + n <= QL_CAND) {
             const int i = c / G.nCols, j = c % G.nCols;
             for (int q = 0; q < n; q++) { uint32_t p = ck[(size_t)c*CELL_CAP + q];
-                cx[base + q] = (float)((int)(p & 255u) + j*G.wCell); cy[base + q] = (float)((int)((p >> 8) & 255u) + i*G.hCell); cr[base + q] = (float)(p >> 16); }
+                cx[base + q] = (unsigned short)((int)(p & 255u) + j*G.wCell); cy[base + q] = (unsigned short)((int)((p >> 8) & 255u) + i*G.hCell); cr[base + q] = (unsigned short)(p >> 16); }
         }
         nk += __shfl(incl, 63, 64);
     }
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
     __syncthreads();
     if (nIni == 1) { for (int k = lane; k < nk; k += 64) keys[k] = (unsigned short)k; if (lane == 0) { nd[0].key0 = 0; nd[0].nk = nk; } }
     else {           // general case (never for 4:3 images): stable bucket by x / hX, serial on lane 0
-        if (lane == 0) { int top = 0; for (int i = 0; i < nIni; i++) { int c2 = 0; for (int k = 0; k < nk; k++) { int q = (int)(cx[k]/hX); if (q >= nIni) q = nIni - 1; if (q == i) keys[top + c2++] = (unsigned short)k; }
+        if (lane == 0) { int top = 0; for (int i = 0; i < nIni; i++) { int c2 = 0; for (int k = 0; k < nk; k++) { int q = (int)((float)cx[k]/hX); if (q >= nIni) q = nIni - 1; if (q == i) keys[top + c2++] = (unsigned short)k; }
             nd[i].key0 = top; nd[i].nk = c2; top += c2; } }
     }
     __syncthreads();
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
         int cn[4] = {0, 0, 0, 0};
         for (int b = 0; b < n; b += 64) {
             const int k = b + lane; int q = -1;
-            if (k < n) { const int key = keys[k0 + k]; tmpk[k] = (unsigned short)key; q = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
+            if (k < n) { const int key = keys[k0 + k]; tmpk[k] = (unsigned short)key; q = ((float)cx[key] < ux) ? (((float)cy[key] < by) ? 0 : 2) : (((float)cy[key] < by) ? 1 : 3); }
 #pragma unroll
             for (int z = 0; z < 4; z++) cn[z] += __popcll(__ballot(q == z));
         }
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
         int run[4] = { st[0], st[1], st[2], st[3] };
         for (int b = 0; b < n; b += 64) {
             const int k = b + lane; int q = -1, key = 0;
-            if (k < n) { key = tmpk[k]; q = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
+            if (k < n) { key = tmpk[k]; q = ((float)cx[key] < ux) ? (((float)cy[key] < by) ? 0 : 2) : (((float)cy[key] < by) ? 1 : 3); }
 #pragma unroll
             for (int z = 0; z < 4; z++) { const unsigned long long m = __ballot(q == z);
                 if (q == z) keys[run[z] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)key;
@@ -451,10 +453,12 @@ __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
         for (int it = head; it >= 0; ) {
             if (nd[it].nomore) { it = nd[it].next; continue; }
             int c[4]; divide(it, c);
+            // (no barrier between the four children: only lane 0 touches the links and the list state is replicated in registers;
+            // one barrier before the parent's erase reads its links, one before the next split reuses released slots)
             for (int z = 0; z < 4; z++) { const int cn = nd[c[z]].nk;
-                if (cn > 0) { push_front(c[z]); if (cn > 1) { nToExpand++; if (lane == 0 && nvs < QL_NODES) { vs[2*nvs] = cn; vs[2*nvs+1] = c[z]; } nvs++; } }
-                else release(c[z]);
-                __syncthreads(); }
+                if (cn > 0) { push_front(c[z]); if (cn > 1) { nToExpand++; if (lane == 0 && nvs < QL_NODES) { vs[2*nvs] = (unsigned short)cn; vs[2*nvs+1] = (unsigned short)c[z]; } nvs++; } }
+                else release(c[z]); }
+            __syncthreads();
             const int nx = erase(it); release(it); it = nx;
             __syncthreads();
         }
@@ -466,16 +470,16 @@ __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
                 // rank sort ascending by (size, creation order): lanes share the elements
                 for (int a = lane; a < np; a += 64) { const int s0 = vs[2*a], n0 = vs[2*a+1], i0 = nd[n0].id; int rank = 0;
                     for (int b2 = 0; b2 < np; b2++) { const int s1 = vs[2*b2], i1 = nd[vs[2*b2+1]].id; rank += (s1 < s0 || (s1 == s0 && i1 < i0)); }
-                    vp[2*rank] = s0; vp[2*rank+1] = n0; }
+                    vp[2*rank] = (unsigned short)s0; vp[2*rank+1] = (unsigned short)n0; }
                 __syncthreads();
                 nvs = 0;
                 for (int jq = np - 1; jq >= 0; jq--) {
                     const int srcn = vp[2*jq+1];
                     int c[4]; divide(srcn, c);
                     for (int z = 0; z < 4; z++) { const int cn = nd[c[z]].nk;
-                        if (cn > 0) { push_front(c[z]); if (cn > 1) { if (lane == 0 && nvs < QL_NODES) { vs[2*nvs] = cn; vs[2*nvs+1] = c[z]; } nvs++; } }
-                        else release(c[z]);
-                        __syncthreads(); }
+                        if (cn > 0) { push_front(c[z]); if (cn > 1) { if (lane == 0 && nvs < QL_NODES) { vs[2*nvs] = (unsigned short)cn; vs[2*nvs+1] = (unsigned short)c[z]; } nvs++; } }
+                        else release(c[z]); }
+                    __syncthreads();
                     erase(srcn); release(srcn);
                     __syncthreads();
                     if (size >= N) break;
@@ -488,14 +492,14 @@ __global__ __launch_bounds__(64) void k_octree(OrbDev D) {
     if (overflow) { if (lane == 0) D.qfallback[blockIdx.x] = 1; return; }
     // ---- best response per node, in list order: lane 0 walks the list into vs[], lanes take nodes
     int ns = 0;
-    if (lane == 0) { int q = 0; for (int it = head; it >= 0 && q < G.capL; it = nd[it].next) vs[q++] = it; s_off[0] = q; }
+    if (lane == 0) { int q = 0; for (int it = head; it >= 0 && q < G.capL; it = nd[it].next) vs[q++] = (unsigned short)it; s_off[0] = q; }
     __syncthreads();
     ns = s_off[0];
     for (int q = lane; q < ns; q += 64) {
         const LNode n = nd[vs[q]];
-        int best = keys[n.key0]; float mr = cr[best];
-        for (int k = 1; k < n.nk; k++) { const int key = keys[n.key0 + k]; if (cr[key] > mr) { best = key; mr = cr[key]; } }
-        sel[4*q] = cx[best] + (float)minX; sel[4*q+1] = cy[best] + (float)minY; sel[4*q+2] = mr; sel[4*q+3] = 0.f;
+        int best = keys[n.key0]; float mr = (float)cr[best];
+        for (int k = 1; k < n.nk; k++) { const int key = keys[n.key0 + k]; if ((float)cr[key] > mr) { best = key; mr = (float)cr[key]; } }
+        sel[4*q] = (float)cx[best] + (float)minX; sel[4*q+1] = (float)cy[best] + (float)minY; sel[4*q+2] = mr; sel[4*q+3] = 0.f;
     }
     if (lane == 0) *selcnt = ns;
 }
