@@ -127,6 +127,10 @@ typedef struct tsba_options {
     double  min_diagonal, max_diagonal;
     /* multi-GPU (global BA): this rank's share of the landmarks is [lm_shard, n) stride lm_nshard */
     int32_t lm_shard, lm_nshard;
+    /* 1: the pointers in tsba_problem.img are DEVICE pointers on this context's GPU (tsframe_level_ptr planes, include/tsframe.h:
+     * the pyramid frame::GetPyrMat left in HBM) -- the upload reads them in place, no host round trip; they must stay valid and
+     * unchanged until the last solve on the upload.  0: host pointers, copied. */
+    int32_t img_on_device, reserved_;
 } tsba_options;
 
 typedef struct tsba_report {

@@ -4,6 +4,7 @@
  *   frame::GetPyrMat                    /root/reference/src/frame.cc:178-204     -> tsframe_set_image
  *   tool::GetPyramidPts (text, scene)   /root/reference/src/tool.cc:564-710,862-980 -> tsframe_pyramid_pts
  *   tool::CalNormvec / GetNeighbour     /root/reference/src/tool.cc:1342-1364,1540-1566 (INTERVAL8) -> tsframe_neighbours
+ *   tool::GetBoxAllPixs                 /root/reference/src/tool.cc:1264-1337     -> tsframe_box_pixels
  * The pyramid stays resident in HBM: tsframe_level_ptr hands the device pointers to the BA library, so the four levels of a
  * keyframe need no host round trip between GetPyrMat and the photometric residuals.
  * All functions return 0 on success, a negative TSFRAME_ERR_* otherwise; tsframe_last_error gives the text. */
@@ -46,6 +47,14 @@ int tsframe_pyramid_pts(void *ctx, int mode, const float *xy, int n, const doubl
  * sigma == 0: TSFRAME_ERR_ARG (the reference's CalNormvec returns false). */
 int tsframe_neighbours(void *ctx, int level, const double *uv, int n, double mu, double sigma,
                        double *inten8, double *ninten8, uint8_t *in);
+
+/* tool::GetBoxAllPixs (called for level 0 by mapText's constructor, mapText.cc:103): every pixel of the level image inside the filled
+ * detection quad (4 corners x, y in level pixels; cv::Point truncation + cv::fillPoly scan conversion, boundary included), in row-major
+ * order of the clamped bounding box; entry i is the TextFeature with IdxToRaw = i: u, v = pixel, inten = I(v, u), ninten = (I - mu) / sigma
+ * (the ray ((u - cx) / fx, (v - cy) / fy, 1) is left to the caller).  *n_out = number of pixels; cap = capacity of the four output
+ * arrays, cap == 0 only counts (outputs may be NULL); n_out > cap: TSFRAME_ERR_ARG with *n_out set. */
+int tsframe_box_pixels(void *ctx, int level, const double *quad, double mu, double sigma, int cap, int32_t *n_out,
+                       int32_t *u, int32_t *v, double *inten, double *ninten);
 
 #ifdef __cplusplus
 }

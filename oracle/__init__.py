@@ -306,6 +306,37 @@ def frame_neighbours(img, uv, mu, sigma):
     return I, N, inn
 
 
+def frame_box_pixels(img, quad, mu, sigma):
+    """tool::GetBoxAllPixs (/root/reference/src/tool.cc:1264-1337): all pixels inside the filled detection quad, row-major over the
+    clamped bounding box.  Returns (u, v, inten, ninten); entry i is the TextFeature with IdxToRaw = i."""
+    import math
+    img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+    xMin, xMax, yMin, yMax = w + 1, -1, h + 1, -1
+    xy = np.zeros(8, np.int32)
+    for i in range(4):                                              # tool.cc:1269-1280 (cv::Point(double, double) truncates)
+        x, y = float(quad[i][0]), float(quad[i][1])
+        xy[2*i], xy[2*i + 1] = int(x), int(y)
+        if x > xMax: xMax = math.ceil(x)
+        if x < xMin: xMin = math.floor(x)
+        if y > yMax: yMax = math.ceil(y)
+        if y < yMin: yMin = math.floor(y)
+    if xMin < 0: xMin = 0                                           # tool.cc:1282-1297, same order
+    if xMin >= w: xMin = w - 1
+    if yMin < 0: yMin = 0
+    if yMin >= h: yMin = h - 1
+    if xMax >= w: xMax = w - 1
+    if xMax < 0: xMax = 0
+    if yMax >= h: yMax = h - 1
+    if yMax < 0: yMax = 0
+    mask = fillpoly4(w, h, xy)                                      # cv::fillPoly(TemplateImg, ..., -1), tool.cc:1299-1302
+    ys, xs = np.nonzero(mask[yMin:yMax + 1, xMin:xMax + 1])         # row-major scan, tool.cc:1305-1335
+    u = (xs + xMin).astype(np.int32); v = (ys + yMin).astype(np.int32)
+    inten = img[v, u].astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ninten = (inten - mu)/sigma
+    return u, v, inten, ninten
+
+
 # ---- loop-closure optimisers (oracle/tsloop_oracle.c; SURVEY 8f rank 4)
 _LLIB = None
 

@@ -125,3 +125,27 @@ def test_frame_refuses_to_run_without_gpu():
     from textslam_amd.frame import Frame, FrameError
     with pytest.raises(FrameError):
         Frame(0)
+
+
+def test_box_pixels_oracle_properties(oracle_lib):
+    """tool::GetBoxAllPixs restatement: an integer rectangle is filled inclusively, the order is row-major, a quad outside the image
+    yields what the clamped bounding box still sees of it (nothing), a convex quad agrees with a half-plane test away from its boundary."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 255, (120, 160), dtype=np.uint8)
+    u, v, I, N = oracle_lib.frame_box_pixels(img, [(20, 30), (60, 30), (60, 50), (20, 50)], 100.0, 20.0)
+    assert len(u) == 41*21 and u.min() == 20 and u.max() == 60 and v.min() == 30 and v.max() == 50
+    key = v.astype(np.int64)*160 + u
+    assert np.all(np.diff(key) > 0)                                     # row-major, no duplicates
+    assert np.array_equal(I, img[v, u].astype(np.float64)) and np.array_equal(N, (I - 100.0)/20.0)
+    assert len(oracle_lib.frame_box_pixels(img, [(-50, -60), (-10, -60), (-10, -20), (-50, -20)], 0.0, 1.0)[0]) == 0
+    quad = np.array([(20.3, 30.7), (90.2, 25.1), (95.9, 60.0), (18.0, 66.5)])
+    u, v, _, _ = oracle_lib.frame_box_pixels(img, quad, 0.0, 1.0)
+    got = np.zeros(img.shape, bool); got[v, u] = True
+    q = np.trunc(quad)                                                  # cv::Point truncation
+    yy, xx = np.mgrid[0:120, 0:160]
+    d = np.full(img.shape, np.inf)
+    for i in range(4):                                                  # signed distance to each edge (clockwise in image coordinates)
+        a, b = q[i], q[(i + 1) % 4]
+        e = b - a
+        d = np.minimum(d, ((xx - a[0])*e[1] - (yy - a[1])*e[0])/np.hypot(*e)*-1.0)
+    assert got[d > 1.5].all() and not got[d < -1.5].any()

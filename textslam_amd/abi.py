@@ -56,6 +56,7 @@ class TsbaOptions(C.Structure):
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("min_diagonal", C.c_double), ("max_diagonal", C.c_double),
         ("lm_shard", C.c_int32), ("lm_nshard", C.c_int32),
+        ("img_on_device", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -195,6 +196,8 @@ class BAProblem:
         self.tfeat_uv = [np.zeros((0, 2), np.float64) for _ in range(MAX_LEVELS)]
         self.tfeat_ref = [np.zeros((0, 8), np.float64) for _ in range(MAX_LEVELS)]
         self.img = [None] * MAX_LEVELS          # per level: uint8 array [n_kf, h, w]
+        self.img_dev = [None] * MAX_LEVELS      # optional, per level: n_kf device addresses (Frame.level_device_ptr) -- handed over instead
+                                                # of the host arrays; pair with TsbaOptions.img_on_device = 1 (self.img keeps the shapes)
         self.truth = {}                          # ground truth (synthetic problems only)
         self._keep = []
 
@@ -270,7 +273,7 @@ class BAProblem:
                 im = self.img[l]
                 arr = (c_up * self.n_kf)()
                 for k in range(self.n_kf):
-                    arr[k] = im[k].ctypes.data_as(c_up)
+                    arr[k] = im[k].ctypes.data_as(c_up) if self.img_dev[l] is None else C.cast(C.c_void_p(int(self.img_dev[l][k])), c_up)
                 keep.append(arr)
                 s.img[l] = C.cast(arr, c_upp)
                 s.img_h[l], s.img_w[l] = im.shape[1], im.shape[2]

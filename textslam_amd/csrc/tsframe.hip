@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "../../include/tsframe.h"
+#include "tsraster.h"
 
 struct FCtx {
     int device = 0; hipStream_t stream = nullptr; std::string err;
@@ -143,6 +144,41 @@ __global__ __launch_bounds__(256) void k_neighbours(const uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// ---- tool::GetBoxAllPixs (tool.cc:1264-1337): every pixel of the level image inside the filled detection quad, in row-major order
+// of the clamped bounding box.  One workgroup: scan conversion of the quad into a bit mask (cv::fillPoly semantics, tsraster.h), then an
+// ordered compaction of the box in tiles of 1024 pixels (ballot + wave counts).
+struct BoxDev { int xy[8]; int x0, x1, y0, y1; };
+__global__ __launch_bounds__(1024) void k_box_pixels(const uint8_t *__restrict__ img, int w, int h, BoxDev B, double mu, double sigma, unsigned *mask,
+                                                     int *cnt, int *__restrict__ u, int *__restrict__ v, double *__restrict__ inten, double *__restrict__ ninten) {
+    __shared__ int s_xy[8], s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 8) s_xy[tid] = B.xy[tid];
+    for (int k = tid; k < (w*h + 31) >> 5; k += 1024) mask[k] = 0;
+    __syncthreads();
+    raster_quad(mask, s_xy, w, h, tid, 1024);
+    __syncthreads();
+    const int bw = B.x1 - B.x0 + 1, bh = B.y1 - B.y0 + 1, npx = bw*bh;
+    int base = 0;
+    for (int k0 = 0; k0 < npx; k0 += 1024) {
+        const int k = k0 + tid;
+        int x = 0, y = 0; bool in = false;
+        if (k < npx) { x = B.x0 + k % bw; y = B.y0 + k / bw; const int bit = y*w + x; in = (mask[bit >> 5] >> (bit & 31)) & 1u; }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base, tot = 0;
+        for (int q = 0; q < 16; q++) { const int c = s_w[q]; if (q < wave) off += c; tot += c; }
+        if (in) {
+            const int at = off + __popcll(bal & ((1ull << lane) - 1ull));
+            const double I = (double)img[y*w + x];
+            u[at] = x; v[at] = y; inten[at] = I; ninten[at] = (I - mu)/sigma;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *cnt = base;
+}
+
 static int ensure_host(FCtx *c, size_t bytes) {
     if (bytes <= c->h_cap) return 0;
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -297,6 +333,60 @@ int tsframe_neighbours(void *ctx, int level, const double *uv, int n, double mu,
     CKF(hipMemcpyAsync(c->h_stage + o_I, d + o_I, tot - o_I, hipMemcpyDeviceToHost, c->stream));
     CKF(hipStreamSynchronize(c->stream)); CKF(hipGetLastError());
     memcpy(inten8, c->h_stage + o_I, 64*(size_t)n); memcpy(ninten8, c->h_stage + o_N, 64*(size_t)n); memcpy(in, c->h_stage + o_in, n);
+    return TSFRAME_OK;
+}
+
+int tsframe_box_pixels(void *ctx, int level, const double *quad, double mu, double sigma, int cap, int32_t *n_out,
+                       int32_t *u, int32_t *v, double *inten, double *ninten) {
+    FCtx *c = (FCtx *)ctx;
+    if (!c || !quad || !n_out || cap < 0 || (cap > 0 && (!u || !v || !inten || !ninten)) || level < 0) return TSFRAME_ERR_ARG;
+    if (level >= c->n_levels) { c->err = "level not built"; return TSFRAME_ERR_STATE; }
+    for (int i = 0; i < 8; i++) if (!(fabs(quad[i]) < 1e9)) { c->err = "quad corner not finite"; return TSFRAME_ERR_ARG; }
+    hipSetDevice(c->device);
+    const int w = c->w[level], h = c->h[level];
+    // corners (cv::Point(double, double): truncation) and the clamped bounding box, statement by statement as tool.cc:1269-1298
+    BoxDev B;
+    int xMin = w + 1, xMax = -1, yMin = h + 1, yMax = -1;
+    for (int i = 0; i < 4; i++) {
+        const double x = quad[2*i], y = quad[2*i + 1];
+        B.xy[2*i] = (int)x; B.xy[2*i + 1] = (int)y;
+        if (x > xMax) xMax = (int)ceil(x);
+        if (x < xMin) xMin = (int)floor(x);
+        if (y > yMax) yMax = (int)ceil(y);
+        if (y < yMin) yMin = (int)floor(y);
+    }
+    if (xMin < 0) xMin = 0;
+    if (xMin >= w) xMin = w - 1;
+    if (yMin < 0) yMin = 0;
+    if (yMin >= h) yMin = h - 1;
+    if (xMax >= w) xMax = w - 1;
+    if (xMax < 0) xMax = 0;
+    if (yMax >= h) yMax = h - 1;
+    if (yMax < 0) yMax = 0;
+    B.x0 = xMin; B.x1 = xMax; B.y0 = yMin; B.y1 = yMax;
+    *n_out = 0;
+    if (xMax < xMin || yMax < yMin) return TSFRAME_OK;
+    const size_t npx = (size_t)(xMax - xMin + 1)*(size_t)(yMax - yMin + 1);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_cnt = 0, o_mask = 256, o_u = o_mask + al(4*(((size_t)w*h + 31) >> 5)), o_v = o_u + al(4*npx), o_I = o_v + al(4*npx), o_N = o_I + al(8*npx), tot = o_N + al(8*npx);
+    int rc = ensure_work(c, tot); if (rc) return rc;
+    rc = ensure_host(c, std::max(tot, (size_t)c->w[0]*c->h[0])); if (rc) return rc;
+    uint8_t *d = c->d_work;
+    hipLaunchKernelGGL(k_box_pixels, dim3(1), dim3(1024), 0, c->stream, (const uint8_t *)c->plane[TSFRAME_IMG][level], w, h, B, mu, sigma, (unsigned *)(d + o_mask),
+                       (int *)(d + o_cnt), (int *)(d + o_u), (int *)(d + o_v), (double *)(d + o_I), (double *)(d + o_N));
+    CKF(hipMemcpyAsync(c->h_stage, d + o_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CKF(hipStreamSynchronize(c->stream)); CKF(hipGetLastError());
+    const int n = *(const int *)c->h_stage;
+    *n_out = n;
+    if (cap == 0 || n == 0) return TSFRAME_OK;                      // cap == 0: count only
+    if (n > cap) { c->err = "tsframe_box_pixels: capacity too small (n_out holds the count)"; return TSFRAME_ERR_ARG; }
+    CKF(hipMemcpyAsync(c->h_stage + o_u, d + o_u, 4*(size_t)n, hipMemcpyDeviceToHost, c->stream));
+    CKF(hipMemcpyAsync(c->h_stage + o_v, d + o_v, 4*(size_t)n, hipMemcpyDeviceToHost, c->stream));
+    CKF(hipMemcpyAsync(c->h_stage + o_I, d + o_I, 8*(size_t)n, hipMemcpyDeviceToHost, c->stream));
+    CKF(hipMemcpyAsync(c->h_stage + o_N, d + o_N, 8*(size_t)n, hipMemcpyDeviceToHost, c->stream));
+    CKF(hipStreamSynchronize(c->stream));
+    memcpy(u, c->h_stage + o_u, 4*(size_t)n); memcpy(v, c->h_stage + o_v, 4*(size_t)n);
+    memcpy(inten, c->h_stage + o_I, 8*(size_t)n); memcpy(ninten, c->h_stage + o_N, 8*(size_t)n);
     return TSFRAME_OK;
 }
 

@@ -3,6 +3,7 @@
   Frame.GetPyrMat(img, iScaleLevels)                  frame::GetPyrMat          /root/reference/src/frame.cc:178-204
   Frame.GetPyramidPts(...) / GetPyramidPtsScene(...)  tool::GetPyramidPts       /root/reference/src/tool.cc:564-710, 862-980
   Frame.CalNormvec(level, uv, mu, std)                tool::CalNormvec          /root/reference/src/tool.cc:1342-1364 (GetNeighbour INTERVAL8)
+  Frame.GetBoxAllPixs(level, vTextDete, mu, std, K)   tool::GetBoxAllPixs       /root/reference/src/tool.cc:1264-1337
 
 No CPU fallback: without the HIP library / a GPU every call raises.
 """
@@ -13,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.path.join(_HERE, "libtsframe.so")
 EXPORTED_SYMBOLS = ["tsframe_create", "tsframe_destroy", "tsframe_last_error", "tsframe_set_image", "tsframe_level_size", "tsframe_level_ptr",
-                    "tsframe_get_level", "tsframe_pyramid_pts", "tsframe_neighbours"]
+                    "tsframe_get_level", "tsframe_pyramid_pts", "tsframe_neighbours", "tsframe_box_pixels"]
 IMG, GRAD, GRADX, GRADY = 0, 1, 2, 3
 
 
@@ -35,6 +36,7 @@ def _load():
     L.tsframe_get_level.argtypes = [vp, C.c_int, C.c_int, up]
     L.tsframe_pyramid_pts.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int, dp, dp, ip, dp, dp, ip, dp, up]
     L.tsframe_neighbours.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_double, dp, dp, up]
+    L.tsframe_box_pixels.argtypes = [vp, C.c_int, dp, C.c_double, C.c_double, C.c_int, ip, ip, ip, dp, dp]
     return L
 
 
@@ -105,3 +107,20 @@ class Frame:
         I = np.zeros((n, 8)); N = np.zeros((n, 8)); inn = np.zeros(n, np.uint8)
         self._check(self.lib.tsframe_neighbours(self.ctx, level, _dp(uv), n, float(mu), float(std), _dp(I), _dp(N), _up(inn)), "tsframe_neighbours")
         return I, N, inn
+
+    def GetBoxAllPixs(self, level, vTextDete, mu, std, K=None):
+        """All pixels of the level image inside the detection quad vTextDete (4 x (x, y)); returns a dict with u, v (int32), featureInten,
+        featureNInten and -- when K = (fx, fy, cx, cy) is given -- ray [n, 3]; entry i has IdxToRaw = i, level 0, IN = True."""
+        quad = np.ascontiguousarray(vTextDete, np.float64).reshape(4, 2)
+        ip = C.POINTER(C.c_int32); n = C.c_int32(0)
+        self._check(self.lib.tsframe_box_pixels(self.ctx, level, _dp(quad), float(mu), float(std), 0, C.byref(n), None, None, None, None), "tsframe_box_pixels")
+        m = n.value; cap = max(1, m)
+        u = np.zeros(cap, np.int32); v = np.zeros(cap, np.int32); I = np.zeros(cap); N = np.zeros(cap)
+        if m > 0:
+            self._check(self.lib.tsframe_box_pixels(self.ctx, level, _dp(quad), float(mu), float(std), cap, C.byref(n), u.ctypes.data_as(ip), v.ctypes.data_as(ip),
+                                                    _dp(I), _dp(N)), "tsframe_box_pixels")
+        out = {"u": u[:m], "v": v[:m], "featureInten": I[:m], "featureNInten": N[:m]}
+        if K is not None:
+            fx, fy, cx, cy = K
+            out["ray"] = np.stack([(out["u"] - cx)/fx, (out["v"] - cy)/fy, np.ones(m)], 1)
+        return out
