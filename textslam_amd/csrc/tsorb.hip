@@ -38,6 +38,7 @@ struct LevelGeo {
     int kp0;                    // first slot of this level in the per-frame selected-keypoint table
     float sf;
     size_t pyr_off, blur_off;   // byte offsets of this level inside one frame's pyramid / blur slab
+    int rx_off, ry_off;         // this level's resize tables inside OrbDev::rtab (ints): per bordered column int2, per bordered row int4
 };
 struct OrbDev {
     int n, nlevels, ini_th, min_th, w, h, stride;
@@ -45,6 +46,7 @@ struct OrbDev {
     int cells_per_frame, slots_per_frame, cand_cap, node_cap, pool_cap, cap;
     size_t pyr_frame, blur_frame;          // bytes per frame
     const uint8_t *img; uint8_t *pyr, *blur;
+    int *rtab;                             // cv::resize coordinate / weight tables of levels 1.. (k_resize_tab, once per geometry)
     uint32_t *cellkp; int *cellcnt;        // [n][cells][CELL_CAP] packed (x | y<<8 | score<<16), [n][cells]
     float *cand;                           // [n][nlevels][cand_cap][3]  x, y, response (relative to minBorder)
     int *nodes, *pool, *snbuf;             // quadtree scratch per (frame, level)
@@ -61,36 +63,83 @@ __device__ __forceinline__ int reflect101(int x, int n) { if (x < 0) x = -x; if 
 __device__ __forceinline__ uint8_t *lev_ptr(const OrbDev &D, uint8_t *base, int f, int l) { return base + (size_t)f*D.pyr_frame + D.L[l].pyr_off; }
 
 // ---------------------------------------------------------------- pyramid
-__global__ void k_level0(OrbDev D) {
+// level 0 = the input inside its REFLECT_101 frame.  grid (x chunks of 4 x 128 pixels, groups of L0_ROWS bordered rows, frames); a thread
+// moves four neighbouring pixels as one (unaligned) dword where they do not touch the reflected columns.
+#define L0_ROWS 8
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__global__ __launch_bounds__(128) void k_level0(OrbDev D) {
     const LevelGeo &G = D.L[0];
-    size_t idx = (size_t)blockIdx.x*blockDim.x + threadIdx.x, per = (size_t)G.bw*G.bh;
-    if (idx >= per*D.n) return;
-    int f = (int)(idx / per), r = (int)(idx % per), y = r / G.bw, x = r % G.bw;
-    int sx = reflect101(x - EDGE, G.w), sy = reflect101(y - EDGE, G.h);
-    D.pyr[(size_t)f*D.pyr_frame + G.pyr_off + r] = D.img[((size_t)f*D.h + sy)*D.stride + sx];
+    const int x = 4*(blockIdx.x*128 + threadIdx.x), y0 = blockIdx.y*L0_ROWS, f = blockIdx.z;
+    if (x >= G.bw) return;
+    const uint8_t *src = D.img + (size_t)f*D.h*D.stride;
+    uint8_t *dst = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + x;
+    const int ny = min(L0_ROWS, G.bh - y0);
+    if (x >= EDGE && x + 3 < EDGE + G.w) {
+        uint32_t v[L0_ROWS];
+#pragma unroll
+        for (int r = 0; r < L0_ROWS; r++) v[r] = *(const u32_unaligned *)(src + (size_t)reflect101(y0 + min(r, ny - 1) - EDGE, G.h)*D.stride + (x - EDGE));
+#pragma unroll
+        for (int r = 0; r < L0_ROWS; r++) { if (r >= ny) break; *(u32_unaligned *)(dst + (size_t)(y0 + r)*G.bw) = v[r]; }
+    } else {
+        for (int r = 0; r < ny; r++) {
+            const uint8_t *row = src + (size_t)reflect101(y0 + r - EDGE, G.h)*D.stride;
+            for (int i = 0; i < 4 && x + i < G.bw; i++) dst[(size_t)(y0 + r)*G.bw + i] = row[reflect101(x + i - EDGE, G.w)];
+        }
+    }
 }
 // cv::resize(8UC1, INTER_LINEAR) from level l-1 to level l, evaluated at the reflected coordinate for border pixels.
-// grid (x chunks of 128, bordered rows, frames): the row terms (source rows, vertical weights) are uniform per workgroup.
+// The source coordinates and the 11-bit weights depend on the geometry only: k_resize_tab fills them once per upload (the per-pixel
+// version spent ~150 instructions per pixel on fp64 coordinate arithmetic, conversions and 64-bit index products).
+//   column x: { sx | sx1 << 16, a0 | a1 << 16 }     row y: { sy0, sy1, b0, b1 }
+__global__ __launch_bounds__(256) void k_resize_tab(OrbDev D) {
+    const int l = blockIdx.x + 1;
+    const LevelGeo &G = D.L[l], &S = D.L[l-1];
+    const double scale_x = 1.0/((double)G.w/(double)S.w), scale_y = 1.0/((double)G.h/(double)S.h);
+    int2 *xt = (int2 *)(D.rtab + G.rx_off); int4 *yt = (int4 *)(D.rtab + G.ry_off);
+    for (int x = threadIdx.x; x < G.bw; x += 256) {
+        const int dx = reflect101(x - EDGE, G.w);
+        float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scale_x), 0.5);
+        int sx = (int)floorf(fx); fx = __fsub_rn(fx, (float)sx);
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
+        const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f)), a1 = (int)rintf(__fmul_rn(fx, 2048.f));
+        const int sx1 = sx + 1 < S.w ? sx + 1 : sx;
+        xt[x] = make_int2(sx | (sx1 << 16), a0 | (a1 << 16));
+    }
+    for (int y = threadIdx.x; y < G.bh; y += 256) {
+        const int dy = reflect101(y - EDGE, G.h);
+        float fy = (float)__dsub_rn(__dmul_rn((double)dy + 0.5, scale_y), 0.5);
+        int sy = (int)floorf(fy); fy = __fsub_rn(fy, (float)sy);
+        const int b0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fy), 2048.f)), b1 = (int)rintf(__fmul_rn(fy, 2048.f));
+        yt[y] = make_int4(min(max(sy, 0), S.h - 1), min(max(sy + 1, 0), S.h - 1), b0, b1);
+    }
+}
+// grid (x chunks of 128, groups of RS_ROWS bordered rows, frames): a workgroup keeps its column terms in registers for RS_ROWS rows (one
+// row per workgroup meant 165 k two-wave workgroups for level 1 of a 64-frame batch: dispatch-bound); the row terms are uniform.
+#define RS_ROWS 8
 __global__ __launch_bounds__(128) void k_resize(OrbDev D, int l) {
     const LevelGeo &G = D.L[l], &S = D.L[l-1];
-    const int x = blockIdx.x*128 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    const int x = blockIdx.x*128 + threadIdx.x, y0 = blockIdx.y*RS_ROWS, f = blockIdx.z;
     if (x >= G.bw) return;
-    int dx = reflect101(x - EDGE, G.w), dy = reflect101(y - EDGE, G.h);
-    const double scale_x = 1.0/((double)G.w/(double)S.w), scale_y = 1.0/((double)G.h/(double)S.h);
-    float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scale_x), 0.5);
-    int sx = (int)floorf(fx); fx = __fsub_rn(fx, (float)sx);
-    if (sx < 0) { fx = 0.f; sx = 0; }
-    if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
-    float fy = (float)__dsub_rn(__dmul_rn((double)dy + 0.5, scale_y), 0.5);
-    int sy = (int)floorf(fy); fy = __fsub_rn(fy, (float)sy);
-    const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f)), a1 = (int)rintf(__fmul_rn(fx, 2048.f));
-    const int b0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fy), 2048.f)), b1 = (int)rintf(__fmul_rn(fy, 2048.f));
-    int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
-    int sx1 = sx + 1 < S.w ? sx + 1 : sx;
+    const int2 xt = ((const int2 *)(D.rtab + G.rx_off))[x];
+    const int4 *ytab = (const int4 *)(D.rtab + G.ry_off);
+    const int sx = xt.x & 0xffff, sx1 = xt.x >> 16, a0 = xt.y & 0xffff, a1 = xt.y >> 16;
     const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + S.pyr_off + (size_t)EDGE*S.bw + EDGE;
-    const uint8_t *r0 = src + (size_t)sy0*S.bw, *r1 = src + (size_t)sy1*S.bw;
-    int S0 = r0[sx]*a0 + r0[sx1]*a1, S1 = r1[sx]*a0 + r1[sx1]*a1;
-    D.pyr[(size_t)f*D.pyr_frame + G.pyr_off + (size_t)y*G.bw + x] = (uint8_t)((((b0*(S0 >> 4)) >> 16) + ((b1*(S1 >> 4)) >> 16) + 2) >> 2);
+    uint8_t *dst = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + x;
+    const int ny = min(RS_ROWS, G.bh - y0);
+    int p00[RS_ROWS], p01[RS_ROWS], p10[RS_ROWS], p11[RS_ROWS]; int4 yt[RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {                          // all gathers of the row group in flight together
+        yt[r] = ytab[y0 + min(r, ny - 1)];
+        const uint8_t *r0 = src + yt[r].x*S.bw, *r1 = src + yt[r].y*S.bw;
+        p00[r] = r0[sx]; p01[r] = r0[sx1]; p10[r] = r1[sx]; p11[r] = r1[sx1];
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        if (r >= ny) break;
+        const int S0 = p00[r]*a0 + p01[r]*a1, S1 = p10[r]*a0 + p11[r]*a1;
+        dst[(size_t)(y0 + r)*G.bw] = (uint8_t)((((yt[r].z*(S0 >> 4)) >> 16) + ((yt[r].w*(S1 >> 4)) >> 16) + 2) >> 2);
+    }
 }
 
 // ---------------------------------------------------------------- FAST per cell
@@ -545,31 +594,44 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
 #define BT_H 16
 __global__ __launch_bounds__(256) void k_blur(OrbDev D, int l) {
     const LevelGeo &G = D.L[l];
-    __shared__ int rowf[(BT_H + 6)*BT_W];
+    __shared__ __attribute__((aligned(8))) int rowf[(BT_H + 6)*BT_W];
     const int tx = blockIdx.x % ((G.w + BT_W - 1)/BT_W), ty = (blockIdx.x / ((G.w + BT_W - 1)/BT_W)) % ((G.h + BT_H - 1)/BT_H);
     const int f = blockIdx.x / (((G.w + BT_W - 1)/BT_W)*((G.h + BT_H - 1)/BT_H));
     const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)EDGE*G.bw + EDGE;
     const int x0 = tx*BT_W, y0 = ty*BT_H, tid = threadIdx.x;
-    for (int k = tid; k < (BT_H + 6)*BT_W; k += 256) {
-        int yy = k / BT_W, xx = k % BT_W;
-        int y = reflect101(y0 + yy - 3, G.h), x = x0 + xx;
-        int s = 0;
-        if (x < G.w) {
+    int gk[7];
 #pragma unroll
-            for (int i = 0; i < 7; i++) s += D.gk[i]*src[(size_t)y*G.bw + reflect101(x + i - 3, G.w)];
+    for (int i = 0; i < 7; i++) gk[i] = D.gk[i];
+    // horizontal pass, two neighbouring outputs per thread (8 loads instead of 14).  The level sits in a 19-px REFLECT_101 frame
+    // (ComputePyramid's copyMakeBorder) -- the blur's own border rule: the 3-px apron is read straight from the frame, no index reflection
+    for (int k = tid; k < (BT_H + 6)*(BT_W/2); k += 256) {
+        const int yy = k / (BT_W/2), xx = 2*(k % (BT_W/2));
+        const int y = min(y0 + yy - 3, G.h + 2), x = x0 + xx;
+        int s0 = 0, s1 = 0;
+        if (x < G.w) {
+            const uint8_t *r = src + (ptrdiff_t)y*G.bw + x - 3;
+            int p[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) p[i] = r[i];
+#pragma unroll
+            for (int i = 0; i < 7; i++) { s0 += gk[i]*p[i]; s1 += gk[i]*p[i + 1]; }
         }
-        rowf[k] = s;
+        *(int2 *)&rowf[yy*BT_W + xx] = make_int2(s0, s1);
     }
     __syncthreads();
     uint8_t *dst = D.blur + (size_t)f*D.blur_frame + G.blur_off;
-    for (int k = tid; k < BT_H*BT_W; k += 256) {
-        int yy = k / BT_W, xx = k % BT_W, x = x0 + xx, y = y0 + yy;
+    for (int k = tid; k < (BT_H/2)*BT_W; k += 256) {              // vertical pass, two rows per thread
+        const int yy = 2*(k / BT_W), xx = k % BT_W, x = x0 + xx, y = y0 + yy;
         if (x >= G.w || y >= G.h) continue;
-        int s = 0;
+        int q[8];
 #pragma unroll
-        for (int i = 0; i < 7; i++) s += D.gk[i]*rowf[(yy + i)*BT_W + xx];
-        int v = (s + (1 << 15)) >> 16;
-        dst[(size_t)y*G.w + x] = (uint8_t)min(max(v, 0), 255);
+        for (int i = 0; i < 8; i++) q[i] = rowf[(yy + i)*BT_W + xx];
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) { s0 += gk[i]*q[i]; s1 += gk[i]*q[i + 1]; }
+        const int v0 = (s0 + (1 << 15)) >> 16, v1 = (s1 + (1 << 15)) >> 16;
+        dst[(size_t)y*G.w + x] = (uint8_t)min(max(v0, 0), 255);
+        if (y + 1 < G.h) dst[(size_t)(y + 1)*G.w + x] = (uint8_t)min(max(v1, 0), 255);
     }
 }
 
@@ -784,6 +846,8 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
         G.pyr_off = po; po += (size_t)G.bw*G.bh; G.blur_off = bo; bo += (size_t)G.w*G.h;
     }
     D.cells_per_frame = cell0; D.slots_per_frame = kp0; D.pyr_frame = po; D.blur_frame = bo;
+    int rt = 0;
+    for (int l = 1; l < c->nlevels; l++) { LevelGeo &G = D.L[l]; G.rx_off = rt; rt += 2*((G.bw + 1) & ~1); G.ry_off = rt; rt += 4*G.bh; }
     // strict 3x3 NMS leaves at most one corner per 2x2 block: the level-0 search area bounds every level's candidate count
     D.cand_cap = ((D.L[0].maxBX - D.L[0].minB)*(D.L[0].maxBY - D.L[0].minB))/4 + 64; D.node_cap = 64*(c->nfl[0] + 64); D.pool_cap = 16*D.cand_cap;
     int rc;
@@ -792,6 +856,7 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     memcpy(c->h_img, imgs, c->h_img_sz);
     OCK(hipMemcpyAsync(img, c->h_img, c->h_img_sz, hipMemcpyHostToDevice, c->stream));
     if ((rc = oalloc(c, &D.pyr, (size_t)n*po)) || (rc = oalloc(c, &D.blur, (size_t)n*bo))) return rc;
+    if ((rc = oalloc(c, &D.rtab, (size_t)std::max(rt, 4)))) return rc;
     if ((rc = oalloc(c, &D.cellkp, (size_t)n*cell0*CELL_CAP)) || (rc = oalloc(c, &D.cellcnt, (size_t)n*cell0))) return rc;
     if ((rc = oalloc(c, &D.cand, (size_t)n*c->nlevels*D.cand_cap*3))) return rc;
     if ((rc = oalloc(c, &D.nodes, (size_t)n*c->nlevels*D.node_cap*(sizeof(QNode)/sizeof(int)))) || (rc = oalloc(c, &D.pool, (size_t)n*c->nlevels*D.pool_cap)) ||
@@ -804,14 +869,15 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
         c->h_out_sz = bkp + bcnt + bdesc; OCK(hipHostMalloc(&c->h_out, c->h_out_sz, hipHostMallocDefault));
     }
     c->key[0] = n; c->key[1] = w; c->key[2] = h; c->key[3] = stride; c->key[4] = cap;
+    if (c->nlevels > 1) hipLaunchKernelGGL(k_resize_tab, dim3(c->nlevels - 1), dim3(256), 0, c->stream, D);
     c->uploaded = true; return TSORB_OK;
 }
 int tsorb_run(void *ctx) {
     OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG;
     hipSetDevice(c->device);
     OrbDev &D = c->D;
-    { size_t tot = (size_t)D.n*D.L[0].bw*D.L[0].bh; hipLaunchKernelGGL(k_level0, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, D); }
-    for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 127)/128, D.L[l].bh, D.n), dim3(128), 0, c->stream, D, l);
+    hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
+    for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 127)/128, (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(128), 0, c->stream, D, l);
     hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
