@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
 #define BT_H 16
 __global__ __launch_bounds__(256) void k_blur(OrbDev D, int l) {
     const LevelGeo &G = D.L[l];
-    __shared__ __attribute__((aligned(8))) int rowf[(BT_H + 6)*BT_W];
+    __shared__ __attribute__((aligned(16))) int rowf[(BT_H + 6)*BT_W];
     const int tx = blockIdx.x % ((G.w + BT_W - 1)/BT_W), ty = (blockIdx.x / ((G.w + BT_W - 1)/BT_W)) % ((G.h + BT_H - 1)/BT_H);
     const int f = blockIdx.x / (((G.w + BT_W - 1)/BT_W)*((G.h + BT_H - 1)/BT_H));
     const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)EDGE*G.bw + EDGE;
@@ -602,36 +602,40 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev D, int l) {
     int gk[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) gk[i] = D.gk[i];
-    // horizontal pass, two neighbouring outputs per thread (8 loads instead of 14).  The level sits in a 19-px REFLECT_101 frame
-    // (ComputePyramid's copyMakeBorder) -- the blur's own border rule: the 3-px apron is read straight from the frame, no index reflection
-    for (int k = tid; k < (BT_H + 6)*(BT_W/2); k += 256) {
-        const int yy = k / (BT_W/2), xx = 2*(k % (BT_W/2));
+    // horizontal pass, four neighbouring outputs per thread from three (unaligned) dword loads.  The level sits in a 19-px REFLECT_101
+    // frame (ComputePyramid's copyMakeBorder) -- the blur's own border rule: the 3-px apron is read straight from the frame
+    for (int k = tid; k < (BT_H + 6)*(BT_W/4); k += 256) {
+        const int yy = k / (BT_W/4), xx = 4*(k % (BT_W/4));
         const int y = min(y0 + yy - 3, G.h + 2), x = x0 + xx;
-        int s0 = 0, s1 = 0;
+        int4 s4 = make_int4(0, 0, 0, 0);
         if (x < G.w) {
-            const uint8_t *r = src + (ptrdiff_t)y*G.bw + x - 3;
-            int p[8];
+            const uint8_t *r = src + (ptrdiff_t)y*G.bw + x - 3;         // bytes x-3 .. x+8 (x+6 is the last one used): inside the frame
+            const uint32_t w0 = *(const u32_unaligned *)r, w1 = *(const u32_unaligned *)(r + 4), w2 = *(const u32_unaligned *)(r + 8);
+            int p[12];
 #pragma unroll
-            for (int i = 0; i < 8; i++) p[i] = r[i];
+            for (int i = 0; i < 4; i++) { p[i] = (w0 >> (8*i)) & 255; p[4 + i] = (w1 >> (8*i)) & 255; p[8 + i] = (w2 >> (8*i)) & 255; }
 #pragma unroll
-            for (int i = 0; i < 7; i++) { s0 += gk[i]*p[i]; s1 += gk[i]*p[i + 1]; }
+            for (int i = 0; i < 7; i++) { s4.x += gk[i]*p[i]; s4.y += gk[i]*p[i + 1]; s4.z += gk[i]*p[i + 2]; s4.w += gk[i]*p[i + 3]; }
         }
-        *(int2 *)&rowf[yy*BT_W + xx] = make_int2(s0, s1);
+        *(int4 *)&rowf[yy*BT_W + xx] = s4;
     }
     __syncthreads();
     uint8_t *dst = D.blur + (size_t)f*D.blur_frame + G.blur_off;
-    for (int k = tid; k < (BT_H/2)*BT_W; k += 256) {              // vertical pass, two rows per thread
-        const int yy = 2*(k / BT_W), xx = k % BT_W, x = x0 + xx, y = y0 + yy;
-        if (x >= G.w || y >= G.h) continue;
-        int q[8];
+    {   // vertical pass: thread = (row, four neighbouring columns), one dword store where the four columns exist
+        const int yy = tid / (BT_W/4), xx = 4*(tid % (BT_W/4)), x = x0 + xx, y = y0 + yy;
+        if (x < G.w && y < G.h) {
+            int4 q[7];
 #pragma unroll
-        for (int i = 0; i < 8; i++) q[i] = rowf[(yy + i)*BT_W + xx];
-        int s0 = 0, s1 = 0;
+            for (int i = 0; i < 7; i++) q[i] = *(const int4 *)&rowf[(yy + i)*BT_W + xx];
+            int4 s4 = make_int4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 7; i++) { s0 += gk[i]*q[i]; s1 += gk[i]*q[i + 1]; }
-        const int v0 = (s0 + (1 << 15)) >> 16, v1 = (s1 + (1 << 15)) >> 16;
-        dst[(size_t)y*G.w + x] = (uint8_t)min(max(v0, 0), 255);
-        if (y + 1 < G.h) dst[(size_t)(y + 1)*G.w + x] = (uint8_t)min(max(v1, 0), 255);
+            for (int i = 0; i < 7; i++) { s4.x += gk[i]*q[i].x; s4.y += gk[i]*q[i].y; s4.z += gk[i]*q[i].z; s4.w += gk[i]*q[i].w; }
+            const int v0 = min(max((s4.x + (1 << 15)) >> 16, 0), 255), v1 = min(max((s4.y + (1 << 15)) >> 16, 0), 255);
+            const int v2 = min(max((s4.z + (1 << 15)) >> 16, 0), 255), v3 = min(max((s4.w + (1 << 15)) >> 16, 0), 255);
+            uint8_t *o = dst + (size_t)y*G.w + x;
+            if (x + 3 < G.w) *(u32_unaligned *)o = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+            else { o[0] = (uint8_t)v0; if (x + 1 < G.w) o[1] = (uint8_t)v1; if (x + 2 < G.w) o[2] = (uint8_t)v2; }
+        }
     }
 }
 
