@@ -399,158 +399,230 @@ __global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) {
 // node's keys and the final arg-max are spread over the lanes.  Levels that do not fit fall back to k_octree_serial.
 #define QL_CAND 4096
 #define QL_NODES 1024
-struct LNode { short x0, y0, x1, y1; int key0, nk; short nomore, pad; short prev, next; int id; };     // 24 bytes
-__global__ __launch_bounds__(64) void k_octree(OrbDev D) {
-    const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, lane = threadIdx.x;
+struct QN { short x0, y0, x1, y1; unsigned short key0, nk, id, pad; };     // 16 bytes: box, key range, creation number
+#define QT 256
+// exclusive block scan of 4 values per thread (thread t owns elements 4t .. 4t+3): ex[j] = sum of everything before element 4t+j
+__device__ __forceinline__ void qscan4(const int v[4], int *s_w, int tid, int ex[4], int &total) {
+    const int lane = tid & 63, wv = tid >> 6, t = v[0] + v[1] + v[2] + v[3];
+    int incl = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    int base = 0; total = 0;
+#pragma unroll
+    for (int q = 0; q < QT/64; q++) { const int c = s_w[q]; if (q < wv) base += c; total += c; }
+    __syncthreads();
+    ex[0] = base + incl - t; ex[1] = ex[0] + v[0]; ex[2] = ex[1] + v[1]; ex[3] = ex[2] + v[2];
+}
+// DistributeOctTree (ORBextractor.cc:537-753) for one (frame, level), one generation of splits at a time.  The reference walks a
+// std::list and splits node after node; what a pass does to the list is nevertheless a function of the pass's processing order only:
+//   * phase 1 (a full pass): every expandable node (more than one key) of the list, in list order, is split; children are pushed to the
+//     FRONT (so they are not visited in the same pass) and the parent is erased;
+//   * phase 2 (once size + 3 nToExpand > N): the expandable nodes sorted by (size, creation order), largest first, are split until the list
+//     holds N nodes -- the cut is a prefix sum over "non-empty children - 1", found before any key moves (a node that is not split must
+//     keep its key order: ties in the final arg-max go to the first key).
+// New list = reverse(non-empty children in processing order) ++ (old list without the split nodes); creation numbers = 4 per split in
+// processing order (they break the ties of phase 2's sort, as the node addresses do in the reference).  So a pass is: processing order
+// (compaction / rank sort) -> child counts (one wave per node) -> scan + cut -> stable 4-way partition of the keys (one wave per node)
+// -> child records + new list (scans).  Nodes live in a pool indexed by the list: the first non-empty child takes its parent's slot, so
+// the pool never holds more than the list.  Levels that do not fit (candidates, nodes) fall back to k_octree_serial.
+__global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
+    const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const LevelGeo &G = D.L[l];
-    // candidates as 16-bit integers (pixel coordinates and FAST scores are small integers): with 32-bit floats the workgroup needed 106 KB
-    // of LDS -- ONE workgroup per CU, so the 512 (frame, level) workgroups of a 64-frame batch ran in two rounds; 74 KB lets two share a CU
+    // 16-bit candidates / keys (pixel coordinates and FAST scores are small integers): 78 KB of LDS, two workgroups per CU
     __shared__ unsigned short cx[QL_CAND], cy[QL_CAND], cr[QL_CAND];
-    __shared__ unsigned short keys[QL_CAND], tmpk[QL_CAND];
-    __shared__ LNode nd[QL_NODES];
-    __shared__ short freelist[QL_NODES];
-    __shared__ unsigned short vs[2*QL_NODES], vp[2*QL_NODES];      // (size <= QL_CAND, node index < QL_NODES)
-    __shared__ int s_off[1];
+    __shared__ __attribute__((aligned(4))) unsigned short keys[QL_CAND], tmpk[QL_CAND];
+    __shared__ QN nd[QL_NODES];
+    __shared__ unsigned short lst[2][QL_NODES], proc[QL_NODES];
+    __shared__ __attribute__((aligned(4))) unsigned short cnt4[4*QL_NODES];
+    __shared__ unsigned char fsplit[QL_NODES];
+    __shared__ int s_w[QT/64], s_cut, s_front, s_nexp;
     int *selcnt = D.selcnt + (size_t)f*D.nlevels + l;
     float *sel = D.sel + ((size_t)f*D.slots_per_frame + G.kp0)*4;
-    // ---- gather the cells (reference order) into LDS: per-cell offsets by lane 0, copy by all lanes
+    // ---- gather the cells (reference order) into LDS: one cell per thread, offsets by a block scan
     const int ncell = G.nCols*G.nRows;
     const int *cnt = D.cellcnt + (size_t)f*D.cells_per_frame + G.cell0;
     const uint32_t *ck = D.cellkp + ((size_t)f*D.cells_per_frame + G.cell0)*CELL_CAP;
     int nk = 0;
-    for (int c0 = 0; c0 < ncell; c0 += 64) {
-        const int c = c0 + lane;
-        const int n = c < ncell ? cnt[c] : 0;
-        int incl = n;                                   // inclusive scan over the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        const int base = nk + incl - n;
+    for (int c0 = 0; c0 < ncell; c0 += QT) {
+        const int c = c0 + tid;
+        int v[4] = { c < ncell ? cnt[c] : 0, 0, 0, 0 }, ex[4], tot;
+        // (thread t's single value sits at element 4t: the scan order is the thread order)
+        qscan4(v, s_w, tid, ex, tot);
+        const int base = nk + ex[0], n = v[0];
         if (c < ncell && base + n <= QL_CAND) {
             const int i = c / G.nCols, j = c % G.nCols;
-            for (int q = 0; q < n; q++) { uint32_t p = ck[(size_t)c*CELL_CAP + q];
+            for (int q = 0; q < n; q++) { const uint32_t p = ck[(size_t)c*CELL_CAP + q];
                 cx[base + q] = (unsigned short)((int)(p & 255u) + j*G.wCell); cy[base + q] = (unsigned short)((int)((p >> 8) & 255u) + i*G.hCell); cr[base + q] = (unsigned short)(p >> 16); }
         }
-        nk += __shfl(incl, 63, 64);
+        nk += tot;
     }
-    if (lane == 0) D.qfallback[blockIdx.x] = 0;
-    if (nk == 0) { if (lane == 0) *selcnt = 0; return; }
-    if (nk > QL_CAND) { if (lane == 0) D.qfallback[blockIdx.x] = 1; return; }
-    __syncthreads();
+    if (tid == 0) D.qfallback[blockIdx.x] = 0;
+    if (nk == 0) { if (tid == 0) *selcnt = 0; return; }
+    if (nk > QL_CAND) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
     const int minX = G.minB, maxX = G.maxBX, minY = G.minB, maxY = G.maxBY, N = G.nfeat;
     const int nIni = (int)roundf((float)(maxX - minX)/(float)(maxY - minY));
     const float hX = (float)(maxX - minX)/(float)nIni;
-    // ---- list state (identical in every lane)
-    int head = -1, tail = -1, size = 0, nfree = 0, next_id = 0, nalloc = 0;
-    bool overflow = false;
-    auto alloc = [&]() -> int { int i; if (nfree > 0) i = freelist[--nfree]; else if (nalloc < QL_NODES) i = nalloc++; else { overflow = true; i = QL_NODES - 1; }
-        if (lane == 0) { nd[i].nomore = 0; nd[i].prev = nd[i].next = -1; nd[i].nk = 0; nd[i].key0 = 0; nd[i].id = next_id; } next_id++; return i; };
-    auto release = [&](int i) { if (lane == 0) freelist[nfree] = (short)i; nfree++; };
-    auto push_back = [&](int i) { if (lane == 0) { nd[i].prev = (short)tail; nd[i].next = -1; if (tail >= 0) nd[tail].next = (short)i; } if (tail < 0) head = i; tail = i; size++; };
-    auto push_front = [&](int i) { if (lane == 0) { nd[i].next = (short)head; nd[i].prev = -1; if (head >= 0) nd[head].prev = (short)i; } if (head < 0) tail = i; head = i; size++; };
-    auto erase = [&](int i) -> int { const int p = nd[i].prev, nx = nd[i].next;
-        if (lane == 0) { if (p >= 0) nd[p].next = (short)nx; if (nx >= 0) nd[nx].prev = (short)p; }
-        if (p < 0) head = nx; if (nx < 0) tail = p; size--; return nx; };
-    // ---- initial nodes
-    for (int i = 0; i < nIni; i++) { int q = alloc();
-        if (lane == 0) { nd[q].x0 = (short)(int)(hX*(float)i); nd[q].y0 = 0; nd[q].x1 = (short)(int)(hX*(float)(i + 1)); nd[q].y1 = (short)(maxY - minY); }
-        push_back(q); }
+    if (nIni < 1 || nIni > 16) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
+    // ---- initial nodes (ORBextractor.cc:544-573): empty ones are dropped, the list keeps the rest in order
+    for (int k = tid; k < nk; k += QT) keys[k] = (unsigned short)k;
     __syncthreads();
-    if (nIni == 1) { for (int k = lane; k < nk; k += 64) keys[k] = (unsigned short)k; if (lane == 0) { nd[0].key0 = 0; nd[0].nk = nk; } }
-    else {           // general case (never for 4:3 images): stable bucket by x / hX, serial on lane 0
-        if (lane == 0) { int top = 0; for (int i = 0; i < nIni; i++) { int c2 = 0; for (int k = 0; k < nk; k++) { int q = (int)((float)cx[k]/hX); if (q >= nIni) q = nIni - 1; if (q == i) keys[top + c2++] = (unsigned short)k; }
-            nd[i].key0 = top; nd[i].nk = c2; top += c2; } }
+    if (tid == 0) {
+        int top = 0, sz = 0;
+        for (int i = 0; i < nIni; i++) {
+            int c2 = nk;
+            if (nIni > 1) {          // (never for 4:3 images) stable bucket by x / hX, serial
+                c2 = 0;
+                for (int k = 0; k < nk; k++) { int q = (int)((float)cx[k]/hX); if (q >= nIni) q = nIni - 1; if (q == i) tmpk[top + c2++] = (unsigned short)k; }
+            }
+            if (c2 > 0) { QN q; q.x0 = (short)(int)(hX*(float)i); q.y0 = 0; q.x1 = (short)(int)(hX*(float)(i + 1)); q.y1 = (short)(maxY - minY);
+                q.key0 = (unsigned short)top; q.nk = (unsigned short)c2; q.id = (unsigned short)i; q.pad = 0; nd[sz] = q; lst[0][sz] = (unsigned short)sz; sz++; }
+            top += c2;
+        }
+        s_front = sz;
     }
     __syncthreads();
-    for (int it = head; it >= 0; ) { const int n1 = nd[it].nk; const int nx = nd[it].next;
-        if (n1 == 1) { if (lane == 0) nd[it].nomore = 1; it = nx; } else if (n1 == 0) { int e = erase(it); release(it); it = e; } else it = nx; __syncthreads(); }
-    // ---- 4-way stable partition of node `src` into four children (cooperative)
-    auto divide = [&](int src, int c[4]) {
-        const int sx0 = nd[src].x0, sy0 = nd[src].y0, sx1 = nd[src].x1, sy1 = nd[src].y1, k0 = nd[src].key0, n = nd[src].nk;
-        const int halfX = (int)ceilf((float)(sx1 - sx0)/2), halfY = (int)ceilf((float)(sy1 - sy0)/2);
-        const float ux = (float)(sx0 + halfX), by = (float)(sy0 + halfY);
-        int cn[4] = {0, 0, 0, 0};
-        for (int b = 0; b < n; b += 64) {
-            const int k = b + lane; int q = -1;
-            if (k < n) { const int key = keys[k0 + k]; tmpk[k] = (unsigned short)key; q = ((float)cx[key] < ux) ? (((float)cy[key] < by) ? 0 : 2) : (((float)cy[key] < by) ? 1 : 3); }
+    if (nIni > 1) { for (int k = tid; k < nk; k += QT) keys[k] = tmpk[k]; __syncthreads(); }
+    int size = s_front, next_id = nIni, cur = 0;
+    bool phase2 = false, overflow = false;
+    __syncthreads();
+    for (;;) {
+        const int prevSize = size;
+        unsigned short *L = lst[cur], *Ln = lst[cur ^ 1];
+        // ---- 1. processing order: list positions of the expandable nodes
+        int np;
+        {
+            int v[4], ex[4];
 #pragma unroll
-            for (int z = 0; z < 4; z++) cn[z] += __popcll(__ballot(q == z));
-        }
-        int st[4]; st[0] = k0; st[1] = st[0] + cn[0]; st[2] = st[1] + cn[1]; st[3] = st[2] + cn[2];
-        for (int z = 0; z < 4; z++) c[z] = alloc();
-        if (lane == 0) {
-            nd[c[0]].x0 = (short)sx0; nd[c[0]].y0 = (short)sy0; nd[c[0]].x1 = (short)(sx0 + halfX); nd[c[0]].y1 = (short)(sy0 + halfY);
-            nd[c[1]].x0 = (short)(sx0 + halfX); nd[c[1]].y0 = (short)sy0; nd[c[1]].x1 = (short)sx1; nd[c[1]].y1 = (short)(sy0 + halfY);
-            nd[c[2]].x0 = (short)sx0; nd[c[2]].y0 = (short)(sy0 + halfY); nd[c[2]].x1 = (short)(sx0 + halfX); nd[c[2]].y1 = (short)sy1;
-            nd[c[3]].x0 = (short)(sx0 + halfX); nd[c[3]].y0 = (short)(sy0 + halfY); nd[c[3]].x1 = (short)sx1; nd[c[3]].y1 = (short)sy1;
-            for (int z = 0; z < 4; z++) { nd[c[z]].key0 = st[z]; nd[c[z]].nk = cn[z]; nd[c[z]].nomore = cn[z] == 1; }
-        }
-        __syncthreads();                               // tmpk complete
-        int run[4] = { st[0], st[1], st[2], st[3] };
-        for (int b = 0; b < n; b += 64) {
-            const int k = b + lane; int q = -1, key = 0;
-            if (k < n) { key = tmpk[k]; q = ((float)cx[key] < ux) ? (((float)cy[key] < by) ? 0 : 2) : (((float)cy[key] < by) ? 1 : 3); }
+            for (int j = 0; j < 4; j++) { const int p = 4*tid + j; v[j] = (p < size && nd[L[p]].nk > 1) ? 1 : 0; }
+            qscan4(v, s_w, tid, ex, np);
+            if (!phase2) {
 #pragma unroll
-            for (int z = 0; z < 4; z++) { const unsigned long long m = __ballot(q == z);
-                if (q == z) keys[run[z] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)key;
-                run[z] += __popcll(m); }
-        }
-        __syncthreads();
-    };
-    bool finish = false; int nvs = 0;
-    while (!finish && !overflow) {
-        const int prevSize = size; int nToExpand = 0; nvs = 0;
-        for (int it = head; it >= 0; ) {
-            if (nd[it].nomore) { it = nd[it].next; continue; }
-            int c[4]; divide(it, c);
-            // (no barrier between the four children: only lane 0 touches the links and the list state is replicated in registers;
-            // one barrier before the parent's erase reads its links, one before the next split reuses released slots)
-            for (int z = 0; z < 4; z++) { const int cn = nd[c[z]].nk;
-                if (cn > 0) { push_front(c[z]); if (cn > 1) { nToExpand++; if (lane == 0 && nvs < QL_NODES) { vs[2*nvs] = (unsigned short)cn; vs[2*nvs+1] = (unsigned short)c[z]; } nvs++; } }
-                else release(c[z]); }
+                for (int j = 0; j < 4; j++) if (v[j]) proc[ex[j]] = (unsigned short)(4*tid + j);
+            } else {         // candidates (position | (size, creation number) key), then rank sort, largest first
+                unsigned int *ckey = (unsigned int *)tmpk;                   // np <= QL_NODES u32 keys fit the 8 KB of tmpk
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (v[j]) { const int p = 4*tid + j; const QN q = nd[L[p]]; cnt4[ex[j]] = (unsigned short)p; ckey[ex[j]] = ((unsigned int)q.nk << 16) | q.id; }
+            }
             __syncthreads();
-            const int nx = erase(it); release(it); it = nx;
-            __syncthreads();
-        }
-        if (nvs > QL_NODES) overflow = true;
-        if (size >= N || size == prevSize) finish = true;
-        else if (size + nToExpand*3 > N) {
-            while (!finish && !overflow) {
-                const int prevSize2 = size; const int np = nvs;
-                // rank sort ascending by (size, creation order): lanes share the elements
-                for (int a = lane; a < np; a += 64) { const int s0 = vs[2*a], n0 = vs[2*a+1], i0 = nd[n0].id; int rank = 0;
-                    for (int b2 = 0; b2 < np; b2++) { const int s1 = vs[2*b2], i1 = nd[vs[2*b2+1]].id; rank += (s1 < s0 || (s1 == s0 && i1 < i0)); }
-                    vp[2*rank] = (unsigned short)s0; vp[2*rank+1] = (unsigned short)n0; }
+            if (phase2) {
+                const unsigned int *ckey = (const unsigned int *)tmpk;
+                for (int a0 = tid; a0 < np; a0 += QT) { const unsigned int ka = ckey[a0]; int rank = 0;
+                    for (int b2 = 0; b2 < np; b2++) rank += ckey[b2] > ka;
+                    proc[rank] = cnt4[a0]; }
                 __syncthreads();
-                nvs = 0;
-                for (int jq = np - 1; jq >= 0; jq--) {
-                    const int srcn = vp[2*jq+1];
-                    int c[4]; divide(srcn, c);
-                    for (int z = 0; z < 4; z++) { const int cn = nd[c[z]].nk;
-                        if (cn > 0) { push_front(c[z]); if (cn > 1) { if (lane == 0 && nvs < QL_NODES) { vs[2*nvs] = (unsigned short)cn; vs[2*nvs+1] = (unsigned short)c[z]; } nvs++; } }
-                        else release(c[z]); }
-                    __syncthreads();
-                    erase(srcn); release(srcn);
-                    __syncthreads();
-                    if (size >= N) break;
-                }
-                if (nvs > QL_NODES) overflow = true;
-                if (size >= N || size == prevSize2) finish = true;
             }
         }
+        if (np == 0) break;                                                   // nothing left to split: size == prevSize
+        // ---- 2. child counts, one wave per node
+        for (int r = wv; r < np; r += QT/64) {
+            const QN q = nd[L[proc[r]]];
+            const int ux = q.x0 + ((q.x1 - q.x0 + 1) >> 1), by = q.y0 + ((q.y1 - q.y0 + 1) >> 1);     // ceil(half extent), ORBextractor.cc:496-497
+            int c0 = 0, c1 = 0, c2 = 0;
+            for (int b2 = 0; b2 < q.nk; b2 += 64) {
+                const int k = b2 + lane; int z = -1;
+                if (k < q.nk) { const int key = keys[q.key0 + k]; z = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
+                c0 += __popcll(__ballot(z == 0)); c1 += __popcll(__ballot(z == 1)); c2 += __popcll(__ballot(z == 2));
+            }
+            if (lane == 0) { cnt4[4*r] = (unsigned short)c0; cnt4[4*r+1] = (unsigned short)c1; cnt4[4*r+2] = (unsigned short)c2; cnt4[4*r+3] = (unsigned short)(q.nk - c0 - c1 - c2); }
+        }
+        if (tid == 0) { s_cut = np; s_nexp = 0; }
+        for (int p = tid; p < size; p += QT) fsplit[p] = 0;
+        __syncthreads();
+        // ---- 3. cut (phase 2) and offsets: thread t owns processing ranks 4t .. 4t+3
+        int m[4], mex[4], mtot;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int r = 4*tid + j; m[j] = 0;
+            if (r < np) m[j] = (cnt4[4*r] > 0) + (cnt4[4*r+1] > 0) + (cnt4[4*r+2] > 0) + (cnt4[4*r+3] > 0); }
+        qscan4(m, s_w, tid, mex, mtot);
+        if (phase2) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int r = 4*tid + j; if (r < np && size + mex[j] + m[j] - (r + 1) >= N) atomicMin(&s_cut, r + 1); }
+            __syncthreads();
+        }
+        const int S = s_cut;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int r = 4*tid + j; if (r < S) fsplit[proc[r]] = 1; if (r == S - 1) s_front = mex[j] + m[j]; }
+        __syncthreads();
+        const int front = s_front, newSize = front + size - S;
+        if (newSize > QL_NODES || next_id + 4*S > 65000) { overflow = true; break; }
+        // ---- 4. stable 4-way partition of the split nodes' keys, one wave per node (tmpk at the node's own key positions)
+        for (int r = wv; r < S; r += QT/64) {
+            const QN q = nd[L[proc[r]]];
+            const int ux = q.x0 + ((q.x1 - q.x0 + 1) >> 1), by = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
+            for (int b2 = lane; b2 < q.nk; b2 += 64) tmpk[q.key0 + b2] = keys[q.key0 + b2];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // one wave: LDS accesses are ordered
+            int run0 = q.key0, run1 = run0 + cnt4[4*r], run2 = run1 + cnt4[4*r+1], run3 = run2 + cnt4[4*r+2];
+            for (int b2 = 0; b2 < q.nk; b2 += 64) {
+                const int k = b2 + lane; int z = -1, key = 0;
+                if (k < q.nk) { key = tmpk[q.key0 + k]; z = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const unsigned long long m0 = __ballot(z == 0), m1 = __ballot(z == 1), m2 = __ballot(z == 2), m3 = __ballot(z == 3);
+                if (z == 0) keys[run0 + __popcll(m0 & lt)] = (unsigned short)key;
+                if (z == 1) keys[run1 + __popcll(m1 & lt)] = (unsigned short)key;
+                if (z == 2) keys[run2 + __popcll(m2 & lt)] = (unsigned short)key;
+                if (z == 3) keys[run3 + __popcll(m3 & lt)] = (unsigned short)key;
+                run0 += __popcll(m0); run1 += __popcll(m1); run2 += __popcll(m2); run3 += __popcll(m3);
+            }
+        }
+        // ---- 5. the kept part of the list (order preserved) behind the new front
+        {
+            int v[4], ex[4], tot;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int p = 4*tid + j; v[j] = (p < size && !fsplit[p]) ? 1 : 0; }
+            qscan4(v, s_w, tid, ex, tot);                   // (its barriers also order step 4's reads of nd before step 6's writes)
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (v[j]) Ln[front + ex[j]] = L[4*tid + j];
+        }
+        // ---- 6. child records: the first non-empty child takes the parent's pool slot, the others fresh ones (the pool holds `size` nodes)
+        {
+            int nexp = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 4*tid + j;
+                if (r >= S) continue;
+                const int slot = L[proc[r]];
+                const QN q = nd[slot];
+                const int hx = (q.x1 - q.x0 + 1) >> 1, hy = (q.y1 - q.y0 + 1) >> 1;
+                int st = q.key0, jj = 0;
+                const int fresh = size + (mex[j] - r);      // slots taken by the extra children of the nodes before r
+#pragma unroll
+                for (int z = 0; z < 4; z++) {
+                    const int cn = cnt4[4*r + z];
+                    if (cn > 0) {
+                        QN c;
+                        c.x0 = (short)((z & 1) ? q.x0 + hx : q.x0); c.x1 = (short)((z & 1) ? q.x1 : q.x0 + hx);
+                        c.y0 = (short)((z & 2) ? q.y0 + hy : q.y0); c.y1 = (short)((z & 2) ? q.y1 : q.y0 + hy);
+                        c.key0 = (unsigned short)st; c.nk = (unsigned short)cn; c.id = (unsigned short)(next_id + 4*r + z); c.pad = 0;
+                        const int sl = jj == 0 ? slot : fresh + jj - 1;
+                        nd[sl] = c;
+                        Ln[front - 1 - (mex[j] + jj)] = (unsigned short)sl;
+                        nexp += cn > 1; jj++;
+                    }
+                    st += cn;
+                }
+            }
+            if (nexp) atomicAdd(&s_nexp, nexp);
+        }
+        __syncthreads();
+        size = newSize; next_id += 4*S; cur ^= 1;
+        const int nToExpand = s_nexp;
+        __syncthreads();                                     // (s_nexp / s_cut are reset by the next pass)
+        if (size >= N || size == prevSize) break;
+        if (!phase2 && size + nToExpand*3 > N) phase2 = true;
     }
-    if (overflow) { if (lane == 0) D.qfallback[blockIdx.x] = 1; return; }
-    // ---- best response per node, in list order: lane 0 walks the list into vs[], lanes take nodes
-    int ns = 0;
-    if (lane == 0) { int q = 0; for (int it = head; it >= 0 && q < G.capL; it = nd[it].next) vs[q++] = (unsigned short)it; s_off[0] = q; }
-    __syncthreads();
-    ns = s_off[0];
-    for (int q = lane; q < ns; q += 64) {
-        const LNode n = nd[vs[q]];
-        int best = keys[n.key0]; float mr = (float)cr[best];
-        for (int k = 1; k < n.nk; k++) { const int key = keys[n.key0 + k]; if ((float)cr[key] > mr) { best = key; mr = (float)cr[key]; } }
-        sel[4*q] = (float)cx[best] + (float)minX; sel[4*q+1] = (float)cy[best] + (float)minY; sel[4*q+2] = mr; sel[4*q+3] = 0.f;
+    if (overflow) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
+    // ---- best response per node, in list order
+    const unsigned short *L = lst[cur];
+    const int ns = min(size, G.capL);
+    for (int q = tid; q < ns; q += QT) {
+        const QN n = nd[L[q]];
+        int best = keys[n.key0]; int mr = cr[best];
+        for (int k = 1; k < n.nk; k++) { const int key = keys[n.key0 + k]; if ((int)cr[key] > mr) { best = key; mr = cr[key]; } }
+        sel[4*q] = (float)cx[best] + (float)minX; sel[4*q+1] = (float)cy[best] + (float)minY; sel[4*q+2] = (float)mr; sel[4*q+3] = 0.f;
     }
-    if (lane == 0) *selcnt = ns;
+    if (tid == 0) *selcnt = ns;
 }
 
 // ---------------------------------------------------------------- orientation: 16 lanes per keypoint
@@ -883,7 +955,7 @@ int tsorb_run(void *ctx) {
     hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
     for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 127)/128, (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(128), 0, c->stream, D, l);
     hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
-    hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);
+    hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
     hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
     for (int l = 0; l < D.nlevels; l++) { int nt = ((D.L[l].w + BT_W - 1)/BT_W)*((D.L[l].h + BT_H - 1)/BT_H); hipLaunchKernelGGL(k_blur, dim3(D.n*nt), dim3(256), 0, c->stream, D, l); }
