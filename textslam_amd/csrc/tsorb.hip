@@ -401,6 +401,7 @@ __global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) {
 #define QL_NODES 1024
 struct QN { short x0, y0, x1, y1; unsigned short key0, nk, id, pad; };     // 16 bytes: box, key range, creation number
 #define QT 256
+#define QL_CELLS (4*QT)
 // exclusive block scan of 4 values per thread (thread t owns elements 4t .. 4t+3): ex[j] = sum of everything before element 4t+j
 __device__ __forceinline__ void qscan4(const int v[4], int *s_w, int tid, int ex[4], int &total) {
     const int lane = tid & 63, wv = tid >> 6, t = v[0] + v[1] + v[2] + v[3];
@@ -437,30 +438,47 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     __shared__ unsigned short lst[2][QL_NODES], proc[QL_NODES];
     __shared__ __attribute__((aligned(4))) unsigned short cnt4[4*QL_NODES];
     __shared__ unsigned char fsplit[QL_NODES];
-    __shared__ int s_w[QT/64], s_cut, s_front, s_nexp;
+    __shared__ unsigned short coff[QL_CELLS], mexs[QL_NODES];
+    __shared__ int s_w[QT/64], s_cut, s_front, s_nexp, s_seg[QT/64][4];
     int *selcnt = D.selcnt + (size_t)f*D.nlevels + l;
     float *sel = D.sel + ((size_t)f*D.slots_per_frame + G.kp0)*4;
-    // ---- gather the cells (reference order) into LDS: one cell per thread, offsets by a block scan
+    // ---- gather the cells (reference order) into LDS: cell offsets by a block scan, then one thread per ENTRY (the cell by binary search)
+    // so that all loads of a round are in flight together (one thread per cell walked its ~20 entries one load after the other)
     const int ncell = G.nCols*G.nRows;
     const int *cnt = D.cellcnt + (size_t)f*D.cells_per_frame + G.cell0;
     const uint32_t *ck = D.cellkp + ((size_t)f*D.cells_per_frame + G.cell0)*CELL_CAP;
+    if (ncell > QL_CELLS) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
     int nk = 0;
-    for (int c0 = 0; c0 < ncell; c0 += QT) {
-        const int c = c0 + tid;
-        int v[4] = { c < ncell ? cnt[c] : 0, 0, 0, 0 }, ex[4], tot;
-        // (thread t's single value sits at element 4t: the scan order is the thread order)
-        qscan4(v, s_w, tid, ex, tot);
-        const int base = nk + ex[0], n = v[0];
-        if (c < ncell && base + n <= QL_CAND) {
-            const int i = c / G.nCols, j = c % G.nCols;
-            for (int q = 0; q < n; q++) { const uint32_t p = ck[(size_t)c*CELL_CAP + q];
-                cx[base + q] = (unsigned short)((int)(p & 255u) + j*G.wCell); cy[base + q] = (unsigned short)((int)((p >> 8) & 255u) + i*G.hCell); cr[base + q] = (unsigned short)(p >> 16); }
-        }
-        nk += tot;
+    {   // thread t owns cells 4t .. 4t+3 (QL_CELLS = 4 QT): one scan, the four counts in flight together
+        int v[4], ex[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = 4*tid + j < ncell ? cnt[4*tid + j] : 0;
+        qscan4(v, s_w, tid, ex, nk);
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (4*tid + j < ncell) coff[4*tid + j] = (unsigned short)min(ex[j], 65535);
     }
     if (tid == 0) D.qfallback[blockIdx.x] = 0;
     if (nk == 0) { if (tid == 0) *selcnt = 0; return; }
     if (nk > QL_CAND) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
+    __syncthreads();
+    for (int k0 = tid; k0 < nk; k0 += 8*QT) {            // eight entries per thread and round: their loads are in flight together
+        int cell[8]; uint32_t p[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = min(k0 + u*QT, nk - 1);
+            int lo = 0, hi = ncell;                      // the last cell whose offset is <= k (an empty cell shares its successor's offset)
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= k) lo = mid; else hi = mid; }
+            cell[u] = lo;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int k = min(k0 + u*QT, nk - 1); p[u] = ck[(size_t)cell[u]*CELL_CAP + (k - coff[cell[u]])]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + u*QT; if (k >= nk) break;
+            const int i = cell[u] / G.nCols, j = cell[u] - i*G.nCols;
+            cx[k] = (unsigned short)((int)(p[u] & 255u) + j*G.wCell); cy[k] = (unsigned short)((int)((p[u] >> 8) & 255u) + i*G.hCell); cr[k] = (unsigned short)(p[u] >> 16);
+        }
+    }
     const int minX = G.minB, maxX = G.maxBX, minY = G.minB, maxY = G.maxBY, N = G.nfeat;
     const int nIni = (int)roundf((float)(maxX - minX)/(float)(maxY - minY));
     const float hX = (float)(maxX - minX)/(float)nIni;
@@ -516,17 +534,28 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         }
         if (np == 0) break;                                                   // nothing left to split: size == prevSize
         // ---- 2. child counts, one wave per node
-        for (int r = wv; r < np; r += QT/64) {
-            const QN q = nd[L[proc[r]]];
+        // (a pass with ONE node -- the first generation: all candidates of the level -- is shared by the waves: wave w takes the w-th
+        // contiguous segment of the keys; counts per segment, so that the partition below stays stable)
+        // small nodes (later passes: tens of nodes with a handful of keys) share a wave: lpn lanes per node, 64 / lpn nodes per wave at a time
+        const bool one = np == 1;
+        int lpn = 64; { const int avg = nk/np; while (lpn > 8 && lpn >= 2*avg) lpn >>= 1; }
+        const int gpw = 64/lpn, grp = lane/lpn, sub = lane - grp*lpn;
+        const unsigned long long gmask = (lpn == 64 ? ~0ull : ((1ull << lpn) - 1ull)) << (grp*lpn);
+        for (int r0 = one ? 0 : wv*gpw; r0 < np; r0 += (QT/64)*gpw) {
+            const int r = r0 + grp; const bool act = r < np;
+            QN q = nd[L[proc[act ? r : r0]]]; if (!act) q.nk = 0;
             const int ux = q.x0 + ((q.x1 - q.x0 + 1) >> 1), by = q.y0 + ((q.y1 - q.y0 + 1) >> 1);     // ceil(half extent), ORBextractor.cc:496-497
+            const int seg = one ? (((q.nk + QT/64 - 1)/(QT/64) + 63) & ~63) : q.nk, k_lo = one ? min(wv*seg, (int)q.nk) : 0, k_hi = one ? min(k_lo + seg, (int)q.nk) : q.nk;
             int c0 = 0, c1 = 0, c2 = 0;
-            for (int b2 = 0; b2 < q.nk; b2 += 64) {
-                const int k = b2 + lane; int z = -1;
-                if (k < q.nk) { const int key = keys[q.key0 + k]; z = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
-                c0 += __popcll(__ballot(z == 0)); c1 += __popcll(__ballot(z == 1)); c2 += __popcll(__ballot(z == 2));
+            for (int b2 = k_lo; __any(b2 < k_hi); b2 += lpn) {
+                const int k = b2 + sub; int z = -1;
+                if (k < k_hi) { const int key = keys[q.key0 + k]; z = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
+                c0 += __popcll(__ballot(z == 0) & gmask); c1 += __popcll(__ballot(z == 1) & gmask); c2 += __popcll(__ballot(z == 2) & gmask);
             }
-            if (lane == 0) { cnt4[4*r] = (unsigned short)c0; cnt4[4*r+1] = (unsigned short)c1; cnt4[4*r+2] = (unsigned short)c2; cnt4[4*r+3] = (unsigned short)(q.nk - c0 - c1 - c2); }
+            if (one) { if (lane == 0) { s_seg[wv][0] = c0; s_seg[wv][1] = c1; s_seg[wv][2] = c2; s_seg[wv][3] = (k_hi - k_lo) - c0 - c1 - c2; } }
+            else if (sub == 0 && act) { cnt4[4*r] = (unsigned short)c0; cnt4[4*r+1] = (unsigned short)c1; cnt4[4*r+2] = (unsigned short)c2; cnt4[4*r+3] = (unsigned short)(q.nk - c0 - c1 - c2); }
         }
+        if (one) { __syncthreads(); if (tid < 4) { int t = 0; for (int w = 0; w < QT/64; w++) t += s_seg[w][tid]; cnt4[tid] = (unsigned short)t; } }
         if (tid == 0) { s_cut = np; s_nexp = 0; }
         for (int p = tid; p < size; p += QT) fsplit[p] = 0;
         __syncthreads();
@@ -543,22 +572,27 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         }
         const int S = s_cut;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { const int r = 4*tid + j; if (r < S) fsplit[proc[r]] = 1; if (r == S - 1) s_front = mex[j] + m[j]; }
+        for (int j = 0; j < 4; j++) { const int r = 4*tid + j; if (r < S) { fsplit[proc[r]] = 1; mexs[r] = (unsigned short)mex[j]; } if (r == S - 1) s_front = mex[j] + m[j]; }
         __syncthreads();
         const int front = s_front, newSize = front + size - S;
         if (newSize > QL_NODES || next_id + 4*S > 65000) { overflow = true; break; }
         // ---- 4. stable 4-way partition of the split nodes' keys, one wave per node (tmpk at the node's own key positions)
-        for (int r = wv; r < S; r += QT/64) {
-            const QN q = nd[L[proc[r]]];
+        for (int r0 = one ? 0 : wv*gpw; r0 < S; r0 += (QT/64)*gpw) {
+            const int r = r0 + grp; const bool act = r < S;
+            QN q = nd[L[proc[act ? r : r0]]]; if (!act) q.nk = 0;
             const int ux = q.x0 + ((q.x1 - q.x0 + 1) >> 1), by = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
-            for (int b2 = lane; b2 < q.nk; b2 += 64) tmpk[q.key0 + b2] = keys[q.key0 + b2];
+            const int seg = one ? (((q.nk + QT/64 - 1)/(QT/64) + 63) & ~63) : q.nk, k_lo = one ? min(wv*seg, (int)q.nk) : 0, k_hi = one ? min(k_lo + seg, (int)q.nk) : q.nk;
+            for (int b2 = k_lo + sub; b2 < k_hi; b2 += lpn) tmpk[q.key0 + b2] = keys[q.key0 + b2];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // one wave: LDS accesses are ordered
-            int run0 = q.key0, run1 = run0 + cnt4[4*r], run2 = run1 + cnt4[4*r+1], run3 = run2 + cnt4[4*r+2];
-            for (int b2 = 0; b2 < q.nk; b2 += 64) {
-                const int k = b2 + lane; int z = -1, key = 0;
-                if (k < q.nk) { key = tmpk[q.key0 + k]; z = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
+            const int rc = act ? r : r0;
+            int run0 = q.key0, run1 = run0 + cnt4[4*rc], run2 = run1 + cnt4[4*rc+1], run3 = run2 + cnt4[4*rc+2];
+            if (one) for (int w = 0; w < wv; w++) { run0 += s_seg[w][0]; run1 += s_seg[w][1]; run2 += s_seg[w][2]; run3 += s_seg[w][3]; }
+            if (one) __syncthreads();                    // every wave has copied its segment before any wave scatters into it
+            for (int b2 = k_lo; __any(b2 < k_hi); b2 += lpn) {
+                const int k = b2 + sub; int z = -1, key = 0;
+                if (k < k_hi) { key = tmpk[q.key0 + k]; z = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
                 const unsigned long long lt = (1ull << lane) - 1ull;
-                const unsigned long long m0 = __ballot(z == 0), m1 = __ballot(z == 1), m2 = __ballot(z == 2), m3 = __ballot(z == 3);
+                const unsigned long long m0 = __ballot(z == 0) & gmask, m1 = __ballot(z == 1) & gmask, m2 = __ballot(z == 2) & gmask, m3 = __ballot(z == 3) & gmask;
                 if (z == 0) keys[run0 + __popcll(m0 & lt)] = (unsigned short)key;
                 if (z == 1) keys[run1 + __popcll(m1 & lt)] = (unsigned short)key;
                 if (z == 2) keys[run2 + __popcll(m2 & lt)] = (unsigned short)key;
@@ -578,15 +612,12 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         // ---- 6. child records: the first non-empty child takes the parent's pool slot, the others fresh ones (the pool holds `size` nodes)
         {
             int nexp = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = 4*tid + j;
-                if (r >= S) continue;
-                const int slot = L[proc[r]];
+            for (int r = tid; r < S; r += QT) {              // (one split node per thread: S rarely exceeds QT)
+                const int slot = L[proc[r]], mexr = mexs[r];
                 const QN q = nd[slot];
                 const int hx = (q.x1 - q.x0 + 1) >> 1, hy = (q.y1 - q.y0 + 1) >> 1;
                 int st = q.key0, jj = 0;
-                const int fresh = size + (mex[j] - r);      // slots taken by the extra children of the nodes before r
+                const int fresh = size + (mexr - r);        // slots taken by the extra children of the nodes before r
 #pragma unroll
                 for (int z = 0; z < 4; z++) {
                     const int cn = cnt4[4*r + z];
@@ -597,7 +628,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
                         c.key0 = (unsigned short)st; c.nk = (unsigned short)cn; c.id = (unsigned short)(next_id + 4*r + z); c.pad = 0;
                         const int sl = jj == 0 ? slot : fresh + jj - 1;
                         nd[sl] = c;
-                        Ln[front - 1 - (mex[j] + jj)] = (unsigned short)sl;
+                        Ln[front - 1 - (mexr + jj)] = (unsigned short)sl;
                         nexp += cn > 1; jj++;
                     }
                     st += cn;
