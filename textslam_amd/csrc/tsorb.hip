@@ -679,13 +679,23 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
     float *s = D.sel + ((size_t)f*per + slot)*4;
     int m10 = 0, m01 = 0;
     if (valid) {
+        // rows +v / -v of the circular patch as 8 + 8 unaligned dwords (columns -16 .. 15; a keypoint is >= 16 px inside the level, the level
+        // sits in a 19-px frame), the columns beyond umax[v] masked out: 16 loads in flight instead of up to 62 dependent byte loads
         const uint8_t *c = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)(EDGE + (int)rintf(s[1]))*G.bw + EDGE + (int)rintf(s[0]);
-        if (v == 0) { for (int u = -HALF_PATCH; u <= HALF_PATCH; ++u) m10 += u*c[u]; }
-        else {
-            int vs = 0, d = D.umax[v];
-            for (int u = -d; u <= d; ++u) { int vp = c[u + v*G.bw], vm = c[u - v*G.bw]; vs += (vp - vm); m10 += u*(vp + vm); }
-            m01 = v*vs;
-        }
+        const int d = v == 0 ? HALF_PATCH : D.umax[v];
+        const uint8_t *rp = c + (ptrdiff_t)v*G.bw - 16, *rm = c - (ptrdiff_t)v*G.bw - 16;
+        uint32_t wp[8], wm[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) { wp[w] = *(const u32_unaligned *)(rp + 4*w); wm[w] = *(const u32_unaligned *)(rm + 4*w); }
+        int vs = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int u = 4*w + b - 16;
+                if (u >= -d && u <= d) { const int vp = (wp[w] >> (8*b)) & 255, vm = (wm[w] >> (8*b)) & 255; vs += vp - vm; m10 += u*(v == 0 ? vp : vp + vm); }
+            }
+        m01 = v*vs;
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 16); m01 += __shfl_xor(m01, o, 16); }
@@ -742,14 +752,14 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev D, int l) {
     }
 }
 
-// ---------------------------------------------------------------- descriptors: one wave per keypoint, lane i < 32 -> byte i
+// ---------------------------------------------------------------- descriptors: 32 lanes per keypoint, lane i -> byte i
 __global__ __launch_bounds__(256) void k_describe(OrbDev D) {
-    const int g = (blockIdx.x*256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int g = (blockIdx.x*256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;      // 32 lanes per keypoint: two keypoints per wave
     const int per = D.slots_per_frame, f = g / per, slot = g % per;
     if (f >= D.n) return;
     int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;
     const LevelGeo &G = D.L[l];
-    if ((slot - G.kp0) >= D.selcnt[(size_t)f*D.nlevels + l] || lane >= 32) return;
+    if ((slot - G.kp0) >= D.selcnt[(size_t)f*D.nlevels + l]) return;
     const float *s = D.sel + ((size_t)f*per + slot)*4;
     const float factorPI = (float)(3.14159265358979323846/180.f);
     const float angle = __fmul_rn(s[3], factorPI);
@@ -990,7 +1000,7 @@ int tsorb_run(void *ctx) {
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
     hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
     for (int l = 0; l < D.nlevels; l++) { int nt = ((D.L[l].w + BT_W - 1)/BT_W)*((D.L[l].h + BT_H - 1)/BT_H); hipLaunchKernelGGL(k_blur, dim3(D.n*nt), dim3(256), 0, c->stream, D, l); }
-    hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*64 + 255)/256), dim3(256), 0, c->stream, D);
+    hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_pack, dim3(D.n), dim3(256), 0, c->stream, D);
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
     return TSORB_OK;
