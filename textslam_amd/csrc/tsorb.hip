@@ -191,11 +191,11 @@ __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int thre
 }
 #define FAST_NCH (((TILE_MAX - 6)*(TILE_MAX - 6) + 255)/256)      /* chunks of 256 inner pixels of the largest cell */
 __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
-    __shared__ uint8_t tile[TILE_MAX*TILE_MAX];
-    __shared__ short score[TILE_MAX*TILE_MAX];
-    __shared__ int s_cnt, s_ncand, s_wcnt[4*FAST_NCH];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_MAX*TILE_MAX];
+    __shared__ __attribute__((aligned(16))) short score[TILE_MAX*TILE_MAX];
+    __shared__ int s_ncand, s_nkeep;
     __shared__ unsigned short s_cand[(TILE_MAX - 6)*(TILE_MAX - 6)];
-    __shared__ unsigned char s_below[256*FAST_NCH];
+    __shared__ unsigned int s_keep[CELL_CAP];
     const int f = blockIdx.x / D.cells_per_frame, cidx = blockIdx.x % D.cells_per_frame, tid = threadIdx.x;
     int l = 0;
     while (l + 1 < D.nlevels && cidx >= D.L[l+1].cell0) l++;
@@ -211,63 +211,57 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     const int rw = maxX - iniX, rh = maxY - iniY;
     if (rw < 7 || rh < 7) { if (tid == 0) *cnt_out = 0; return; }
     const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)(EDGE + iniY)*G.bw + EDGE + iniX;
-    for (int k = tid; k < rw*rh; k += 256) { int y = k / rw, x = k - y*rw; tile[y*TILE_MAX + x] = src[(size_t)y*G.bw + x]; }
-    __syncthreads();
+    // the tile as (unaligned) dwords, two per thread in flight -- a byte per thread and iteration was five dependent round trips --, the score
+    // map cleared on the way (a row may be read up to 3 bytes past the ROI: still inside the level's frame)
     const int iw = rw - 6, ih = rh - 6;             // inner pixels (3-px margin)
+    {
+        const int rw4 = (rw + 3) >> 2, n4 = rw4*rh; const float inv_rw4 = 1.0f/(float)rw4;
+        for (int k0 = tid; k0 < n4; k0 += 512) {
+            const int ka = k0, kb = min(k0 + 256, n4 - 1);
+            const int ya = (int)(((float)ka + 0.5f)*inv_rw4), xa = 4*(ka - ya*rw4), yb = (int)(((float)kb + 0.5f)*inv_rw4), xb = 4*(kb - yb*rw4);
+            const uint32_t va = *(const u32_unaligned *)(src + (size_t)ya*G.bw + xa), vb = *(const u32_unaligned *)(src + (size_t)yb*G.bw + xb);
+            *(uint32_t *)&tile[ya*TILE_MAX + xa] = va; *(uint2 *)&score[ya*TILE_MAX + xa] = make_uint2(0u, 0u);
+            if (k0 + 256 < n4) { *(uint32_t *)&tile[yb*TILE_MAX + xb] = vb; *(uint2 *)&score[yb*TILE_MAX + xb] = make_uint2(0u, 0u); }
+        }
+        if (tid == 0) { s_ncand = 0; s_nkeep = 0; }
+    }
+    __syncthreads();
     uint32_t *out = D.cellkp + ((size_t)f*D.cells_per_frame + cidx)*CELL_CAP;
     // ONE scoring pass at the fallback threshold: cornerScore is the largest threshold the pixel still passes at (minus one), so
     // "corner at iniTh" is score >= iniTh, and a corner at iniTh beats every neighbour that is not one (their score is below
     // iniTh) -- the 3x3 maximum test on the full score map selects exactly what cv::FAST(iniTh) + NMS selects.
-    const float inv_rw = 1.0f/(float)rw, inv_iw = 1.0f/(float)iw;
-    for (int k = tid; k < rw*rh; k += 256) { const int y = (int)(((float)k + 0.5f)*inv_rw); score[y*TILE_MAX + (k - y*rw)] = 0; }
-    __syncthreads();
-    const int npx = iw*ih, nch = (npx + 255) >> 8;
+    const float inv_iw = 1.0f/(float)iw;
+    const int npx = iw*ih;
     // the full arc test + cornerScore are ~200 instructions and a wave runs them for all 64 lanes if one needs them: first a
     // 4-pixel quick reject over all inner pixels, the survivors' tile positions compacted into a list, then the full test on the
     // list with every lane busy (the order of the list is irrelevant: scores go to the score map by position)
-    if (tid == 0) s_ncand = 0;
-    __syncthreads();
     for (int k = tid; k < npx; k += 256) { const int yy = (int)(((float)k + 0.5f)*inv_iw), pos = (3 + yy)*TILE_MAX + 3 + k - yy*iw;
         if (fast_maybe(tile + pos, TILE_MAX, D.min_th)) s_cand[atomicAdd(&s_ncand, 1)] = (unsigned short)pos; }
     __syncthreads();
     for (int k = tid; k < s_ncand; k += 256) { const int pos = s_cand[k]; score[pos] = (short)fast_score(tile + pos, TILE_MAX, D.min_th); }
     __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
+    // 3x3 non-maximum suppression.  The survivors are few (a handful per cell): appended in any order, then put into the reference's
+    // row-major order by a rank sort on the pixel index -- two barriers per pass instead of a ballot scan over every 256-pixel chunk
+    int n = 0;
     for (int pass = 0; pass < 2; pass++) {
         const int th = pass == 0 ? D.ini_th : 1;
-        // 3x3 non-maximum suppression; row-major ordered compaction: chunk c = pixels [256c, 256c + 256), one ballot per wave
-        unsigned keepm = 0;
-        for (int c = 0; c < nch; c++) {
-            const int k = (c << 8) + tid;
-            bool keep = false;
-            if (k < npx) {
-                const int yy = (int)(((float)k + 0.5f)*inv_iw), y = 3 + yy, x = 3 + k - yy*iw;
-                const short *q = score + y*TILE_MAX + x; const int sc = q[0];
-                keep = sc >= th && sc > q[-TILE_MAX-1] && sc > q[-TILE_MAX] && sc > q[-TILE_MAX+1] && sc > q[-1] && sc > q[1] &&
-                       sc > q[TILE_MAX-1] && sc > q[TILE_MAX] && sc > q[TILE_MAX+1];
-            }
-            const unsigned long long m = __ballot(keep);
-            if (lane == 0) s_wcnt[c*4 + wv] = __popcll(m);
-            if (keep) keepm |= (1u << c) ;
-            s_below[c*256 + tid] = (unsigned char)__popcll(m & ((1ull << lane) - 1ull));
+        for (int k = tid; k < npx; k += 256) {
+            const int yy = (int)(((float)k + 0.5f)*inv_iw), y = 3 + yy, x = 3 + k - yy*iw;
+            const short *q = score + y*TILE_MAX + x; const int sc = q[0];
+            if (sc >= th && sc > q[-TILE_MAX-1] && sc > q[-TILE_MAX] && sc > q[-TILE_MAX+1] && sc > q[-1] && sc > q[1] &&
+                sc > q[TILE_MAX-1] && sc > q[TILE_MAX] && sc > q[TILE_MAX+1]) { const int i = atomicAdd(&s_nkeep, 1); if (i < CELL_CAP) s_keep[i] = (unsigned int)k | ((unsigned int)sc << 16); }
         }
         __syncthreads();
-        int run = 0;
-        for (int c = 0; c < nch; c++) {
-            int off = run;
-            for (int q = 0; q < wv; q++) off += s_wcnt[c*4 + q];
-            if ((keepm >> c) & 1u) {
-                off += s_below[c*256 + tid];
-                const int k = (c << 8) + tid, yy = (int)(((float)k + 0.5f)*inv_iw), y = 3 + yy, x = 3 + k - yy*iw;
-                if (off < CELL_CAP) out[off] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)score[y*TILE_MAX + x] << 16);
-            }
-            run += s_wcnt[c*4] + s_wcnt[c*4 + 1] + s_wcnt[c*4 + 2] + s_wcnt[c*4 + 3];
-        }
-        if (tid == 0) s_cnt = run;
-        __syncthreads();
-        if (run > 0) break;                         // uniform: every thread computed the same total
+        n = min(s_nkeep, CELL_CAP);
+        if (n > 0) break;                           // uniform (nothing at iniTh: the cell is searched again at the fallback threshold)
     }
-    if (tid == 0) *cnt_out = min(s_cnt, CELL_CAP);
+    for (int a = tid; a < n; a += 256) {
+        const unsigned int e = s_keep[a]; const int ka = (int)(e & 0xffffu); int rank = 0;
+        for (int b2 = 0; b2 < n; b2++) rank += (int)(s_keep[b2] & 0xffffu) < ka;
+        const int yy = (int)(((float)ka + 0.5f)*inv_iw), y = 3 + yy, x = 3 + ka - yy*iw;
+        out[rank] = (uint32_t)x | ((uint32_t)y << 8) | ((e >> 16) << 16);
+    }
+    if (tid == 0) *cnt_out = n;
 }
 
 // ---------------------------------------------------------------- quadtree (DistributeOctTree), one workgroup per (frame, level)
