@@ -189,12 +189,12 @@ __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int thre
     }
     return -b0 - 1;
 }
-#define FAST_NCH (((TILE_MAX - 6)*(TILE_MAX - 6) + 255)/256)      /* chunks of 256 inner pixels of the largest cell */
+#define FAST_CAND 2048          // quick-reject survivors listed per cell (a typical cell has ~1000 inner pixels, 10-30 % survive); the rest are scored in place
 __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_MAX*TILE_MAX];
-    __shared__ __attribute__((aligned(16))) short score[TILE_MAX*TILE_MAX];
+    __shared__ __attribute__((aligned(16))) uint8_t score[TILE_MAX*TILE_MAX];      // cornerScore <= 255
     __shared__ int s_ncand, s_nkeep;
-    __shared__ unsigned short s_cand[(TILE_MAX - 6)*(TILE_MAX - 6)];
+    __shared__ unsigned short s_cand[FAST_CAND];     // 18 KB of LDS per workgroup: eight workgroups (all 32 wave slots) per CU
     __shared__ unsigned int s_keep[CELL_CAP];
     const int f = blockIdx.x / D.cells_per_frame, cidx = blockIdx.x % D.cells_per_frame, tid = threadIdx.x;
     int l = 0;
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
             const int ka = k0, kb = min(k0 + 256, n4 - 1);
             const int ya = (int)(((float)ka + 0.5f)*inv_rw4), xa = 4*(ka - ya*rw4), yb = (int)(((float)kb + 0.5f)*inv_rw4), xb = 4*(kb - yb*rw4);
             const uint32_t va = *(const u32_unaligned *)(src + (size_t)ya*G.bw + xa), vb = *(const u32_unaligned *)(src + (size_t)yb*G.bw + xb);
-            *(uint32_t *)&tile[ya*TILE_MAX + xa] = va; *(uint2 *)&score[ya*TILE_MAX + xa] = make_uint2(0u, 0u);
-            if (k0 + 256 < n4) { *(uint32_t *)&tile[yb*TILE_MAX + xb] = vb; *(uint2 *)&score[yb*TILE_MAX + xb] = make_uint2(0u, 0u); }
+            *(uint32_t *)&tile[ya*TILE_MAX + xa] = va; *(uint32_t *)&score[ya*TILE_MAX + xa] = 0u;
+            if (k0 + 256 < n4) { *(uint32_t *)&tile[yb*TILE_MAX + xb] = vb; *(uint32_t *)&score[yb*TILE_MAX + xb] = 0u; }
         }
         if (tid == 0) { s_ncand = 0; s_nkeep = 0; }
     }
@@ -236,9 +236,10 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     // 4-pixel quick reject over all inner pixels, the survivors' tile positions compacted into a list, then the full test on the
     // list with every lane busy (the order of the list is irrelevant: scores go to the score map by position)
     for (int k = tid; k < npx; k += 256) { const int yy = (int)(((float)k + 0.5f)*inv_iw), pos = (3 + yy)*TILE_MAX + 3 + k - yy*iw;
-        if (fast_maybe(tile + pos, TILE_MAX, D.min_th)) s_cand[atomicAdd(&s_ncand, 1)] = (unsigned short)pos; }
+        if (fast_maybe(tile + pos, TILE_MAX, D.min_th)) { const int i = atomicAdd(&s_ncand, 1);
+            if (i < FAST_CAND) s_cand[i] = (unsigned short)pos; else score[pos] = (uint8_t)fast_score(tile + pos, TILE_MAX, D.min_th); } }   // (list full: scored in place)
     __syncthreads();
-    for (int k = tid; k < s_ncand; k += 256) { const int pos = s_cand[k]; score[pos] = (short)fast_score(tile + pos, TILE_MAX, D.min_th); }
+    for (int k = tid; k < min(s_ncand, FAST_CAND); k += 256) { const int pos = s_cand[k]; score[pos] = (uint8_t)fast_score(tile + pos, TILE_MAX, D.min_th); }
     __syncthreads();
     // 3x3 non-maximum suppression.  The survivors are few (a handful per cell): appended in any order, then put into the reference's
     // row-major order by a rank sort on the pixel index -- two barriers per pass instead of a ballot scan over every 256-pixel chunk
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
         const int th = pass == 0 ? D.ini_th : 1;
         for (int k = tid; k < npx; k += 256) {
             const int yy = (int)(((float)k + 0.5f)*inv_iw), y = 3 + yy, x = 3 + k - yy*iw;
-            const short *q = score + y*TILE_MAX + x; const int sc = q[0];
+            const uint8_t *q = score + y*TILE_MAX + x; const int sc = q[0];
             if (sc >= th && sc > q[-TILE_MAX-1] && sc > q[-TILE_MAX] && sc > q[-TILE_MAX+1] && sc > q[-1] && sc > q[1] &&
                 sc > q[TILE_MAX-1] && sc > q[TILE_MAX] && sc > q[TILE_MAX+1]) { const int i = atomicAdd(&s_nkeep, 1); if (i < CELL_CAP) s_keep[i] = (unsigned int)k | ((unsigned int)sc << 16); }
         }
