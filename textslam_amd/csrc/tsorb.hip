@@ -38,12 +38,13 @@ struct LevelGeo {
     int kp0;                    // first slot of this level in the per-frame selected-keypoint table
     float sf;
     size_t pyr_off, blur_off;   // byte offsets of this level inside one frame's pyramid / blur slab
+    int bt0;                    // first blur tile of this level in the per-frame tile table
     int rx_off, ry_off;         // this level's resize tables inside OrbDev::rtab (ints): per bordered column int2, per bordered row int4
 };
 struct OrbDev {
     int n, nlevels, ini_th, min_th, w, h, stride;
     LevelGeo L[MAXL];
-    int cells_per_frame, slots_per_frame, cand_cap, node_cap, pool_cap, cap;
+    int cells_per_frame, slots_per_frame, btiles_per_frame, cand_cap, node_cap, pool_cap, cap;
     size_t pyr_frame, blur_frame;          // bytes per frame
     const uint8_t *img; uint8_t *pyr, *blur;
     int *rtab;                             // cv::resize coordinate / weight tables of levels 1.. (k_resize_tab, once per geometry)
@@ -700,11 +701,14 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
 // ---------------------------------------------------------------- Gaussian blur 7x7, Q8 separable, reflect101 at the image edge
 #define BT_W 64
 #define BT_H 16
-__global__ __launch_bounds__(256) void k_blur(OrbDev D, int l) {
+__global__ __launch_bounds__(256) void k_blur(OrbDev D) {
+    // one launch for all levels (the small levels do not fill the chip on their own): block -> (frame, level, tile)
+    const int f = blockIdx.x / D.btiles_per_frame, bt = blockIdx.x % D.btiles_per_frame;
+    int l = 0;
+    while (l + 1 < D.nlevels && bt >= D.L[l+1].bt0) l++;
     const LevelGeo &G = D.L[l];
     __shared__ __attribute__((aligned(16))) int rowf[(BT_H + 6)*BT_W];
-    const int tx = blockIdx.x % ((G.w + BT_W - 1)/BT_W), ty = (blockIdx.x / ((G.w + BT_W - 1)/BT_W)) % ((G.h + BT_H - 1)/BT_H);
-    const int f = blockIdx.x / (((G.w + BT_W - 1)/BT_W)*((G.h + BT_H - 1)/BT_H));
+    const int t = bt - G.bt0, ntx = (G.w + BT_W - 1)/BT_W, tx = t % ntx, ty = t / ntx;
     const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)EDGE*G.bw + EDGE;
     const int x0 = tx*BT_W, y0 = ty*BT_H, tid = threadIdx.x;
     int gk[7];
@@ -958,6 +962,7 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
         G.pyr_off = po; po += (size_t)G.bw*G.bh; G.blur_off = bo; bo += (size_t)G.w*G.h;
     }
     D.cells_per_frame = cell0; D.slots_per_frame = kp0; D.pyr_frame = po; D.blur_frame = bo;
+    { int bt = 0; for (int l = 0; l < c->nlevels; l++) { LevelGeo &G = D.L[l]; G.bt0 = bt; bt += ((G.w + BT_W - 1)/BT_W)*((G.h + BT_H - 1)/BT_H); } D.btiles_per_frame = bt; }
     int rt = 0;
     for (int l = 1; l < c->nlevels; l++) { LevelGeo &G = D.L[l]; G.rx_off = rt; rt += 2*((G.bw + 1) & ~1); G.ry_off = rt; rt += 4*G.bh; }
     // strict 3x3 NMS leaves at most one corner per 2x2 block: the level-0 search area bounds every level's candidate count
@@ -994,7 +999,7 @@ int tsorb_run(void *ctx) {
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
     hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
-    for (int l = 0; l < D.nlevels; l++) { int nt = ((D.L[l].w + BT_W - 1)/BT_W)*((D.L[l].h + BT_H - 1)/BT_H); hipLaunchKernelGGL(k_blur, dim3(D.n*nt), dim3(256), 0, c->stream, D, l); }
+    hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_pack, dim3(D.n), dim3(256), 0, c->stream, D);
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
