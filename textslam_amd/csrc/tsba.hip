@@ -1742,13 +1742,13 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     // the per-level plans are independent of each other and of the uploads below: one host thread per level builds them while this
     // thread stages the parameter / observation arrays (C4: 1.6 ms of plan construction in sequence -> the largest level, overlapped)
     c->hplan.resize(p->n_levels); c->lev.resize(p->n_levels); c->lev_built.assign(p->n_levels, 0);
-    std::vector<std::thread> planners;
+    std::vector<std::thread> planners(p->n_levels);                 // planners[l]: the thread that builds level l's plan
     struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{planners};   // also on the error returns
     {   auto tp0 = std::chrono::steady_clock::now();
         std::vector<char> seen(p->n_levels, 0);
         for (int ps = 0; ps < o->n_passes; ps++) { const int l = o->levels[ps]; if (seen[l]) continue; seen[l] = 1;
             HostPlan *H = &c->hplan[l];
-            planners.emplace_back([p, o, l, H]() { build_plan(p, o, l, *H); }); }
+            planners[l] = std::thread([p, o, l, H]() { build_plan(p, o, l, *H); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
 #define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
@@ -1774,12 +1774,12 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
     AL(W.fidx, p->n_kf); AL(W.nfree, 1); AL(W.dbg, 64); AL(W.LDbuf, 32*(size_t)p->n_kf);
     // ---- per-level plans
-    {   auto tp0 = std::chrono::steady_clock::now();
-        for (auto &t : planners) t.join();
-        t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); }
     size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1;
     for (int ps = 0; ps < o->n_passes; ps++) {
         int l = o->levels[ps]; if (c->lev_built[l]) continue; c->lev_built[l] = 1;
+        {   auto tp0 = std::chrono::steady_clock::now();            // in pass order: the coarse levels are ready first and are staged while level 0 is still being built
+            if (planners[l].joinable()) planners[l].join();
+            t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); }
         HostPlan &H = c->hplan[l];
         LevelDev &D = c->lev[l]; memset(&D, 0, sizeof(D));
         D.level = l; D.n_sc = H.n_sc(); D.n_pair = H.n_pair(); D.n_tg = H.n_tg(); D.n_pslot = H.n_pslot(); D.n_tslot = H.n_tslot(); D.n_sb = H.n_sb(); D.bw_rows = 6*H.bw_pose;
