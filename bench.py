@@ -98,8 +98,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="local_ba", choices=["local_ba", "global_ba", "orb"])
-    ap.add_argument("--kf", type=int, default=1000, help="global_ba: keyframes")
-    ap.add_argument("--pts", type=int, default=100000, help="global_ba: map points")
+    ap.add_argument("--kf", type=int, default=5000, help="global_ba: keyframes (BASELINE configs[4]: 5k KF / 500k observations)")
+    ap.add_argument("--pts", type=int, default=70000, help="global_ba: map points (70k points -> ~500k observations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,7 +122,7 @@ def main():
     gpu = Optimizer(local_rank)
     if args.workload == "global_ba":
         # one global BA sharded by landmark over the ranks: poses replicated, S and g all-reduced over RCCL
-        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=12)      # identical on every rank
+        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=10)      # identical on every rank
         opt = abi.options_global()
         if world > 1:
             idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
