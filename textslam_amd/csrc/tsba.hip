@@ -485,11 +485,37 @@ __device__ __forceinline__ double wave_sum_to_lane_mw(const double *acc, double 
     __syncthreads();
     return s;
 }
-// 128-thread workgroups: a scene workgroup takes two (target, host) pairs (one per wave); a text workgroup one (KF, text)
+// the same for FOUR 16-lane groups per wave (small pairs share a wave): lane (group g, sub s) returns the group totals of acc[s] and
+// acc[s + 16] (the latter only for s + 16 < N).  Both waves of the workgroup must call it.
+template <int N>
+__device__ __forceinline__ void wave_sum_groups16_mw(const double *acc, double *reg, int lane, double &t0, double &t1) {
+#pragma unroll
+    for (int i = 0; i < N; i++) reg[i*65 + lane] = acc[i];
+    __syncthreads();
+    const int g16 = lane & 48, sub = lane & 15;
+    {
+        const double *row = reg + sub*65 + g16;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
+        t0 = (s0 + s1) + (s2 + s3);
+    }
+    t1 = 0.0;
+    if (sub + 16 < N) {
+        const double *row = reg + (sub + 16)*65 + g16;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
+        t1 = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+}
+// 128-thread workgroups: a scene workgroup takes two (target, host) pairs (one per wave) -- or, PPW = 4 for maps whose pairs hold a
+// dozen scene blocks (thousands of keyframes: a 64-lane wave per pair was 85 % idle), eight pairs, one per 16-lane group; a text workgroup one (KF, text)
 // observation with every feature on TWO lanes (4 taps each): the text lanes' instruction stream (~450 instructions per tap at
 // one instruction per ~4.5 cycles) is what bounds the kernel.  <= 256 VGPRs so that all ~730 workgroups of C4 are resident at once.
 #define LIN_T 128
-template <int MODE>
+template <int MODE, int PPW = 1>
 __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int spec) {
     // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
     const LmState *st = W.st;
@@ -498,8 +524,10 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *reg = lds + wave*28*65, *xw = lds + 2*28*65;
     // static indices of this workgroup first: in flight together with the LM state
-    const int nb_sc = (L.n_pair + 1) >> 1;
-    const int bq = blockIdx.x, pr = 2*bq + wave, prc = min(pr, max(L.n_pair - 1, 0));
+    constexpr int LPP = 64/PPW;                              // lanes per pair
+    const int nb_sc = (L.n_pair + 2*PPW - 1)/(2*PPW);
+    const int sub = PPW == 1 ? lane : (lane & (LPP - 1));
+    const int bq = blockIdx.x, pr = (2*bq + wave)*PPW + (PPW == 1 ? 0 : lane/LPP), prc = min(pr, max(L.n_pair - 1, 0));
     int pi = 0, ph = 0, pbeg = 0, pend = 0, tgpp = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
     if (bq < nb_sc) { pi = L.pair_i[prc]; ph = L.pair_h[prc]; pbeg = L.pair_sc_off[prc]; pend = pr < L.n_pair ? L.pair_sc_off[prc+1] : pbeg; }
     else { ra = ((const int4 *)L.tg_rec)[2*(bq - nb_sc)]; rb = ((const int4 *)L.tg_rec)[2*(bq - nb_sc) + 1]; tgpp = L.tg_ppos[bq - nb_sc]; }   // one static record per group
@@ -522,7 +550,7 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
         for (int k = 0; k < 28; k++) acc[k] = 0.0;
         const int beg = pbeg, end = pend;
 #pragma unroll 1
-        for (int c = beg + lane; c < end; c += 64) {
+        for (int c = beg + sub; c < end; c += LPP) {
             const int slot = L.sc_slot[c], pt = L.sc_pt[c];
             const bool act = !fixed && (!W.filter_good || W.sgood[L.sc_flag[c]]);
             // the slot record of an inactive candidate is zeros: one store sequence for both cases (a second, branchy one
@@ -558,8 +586,25 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
             }
         }
         if (MODE == MODE_COST) {
-            double cs = wave_sum1(acc[27]);
-            if (lane == 0 && pr < L.n_pair) B.pairCost[pr] = cs;
+            double cs = acc[27];
+            if (PPW == 1) cs = wave_sum1(cs);
+            else {
+#pragma unroll
+                for (int o = LPP/2; o > 0; o >>= 1) cs += __shfl_xor(cs, o, LPP);
+            }
+            if (sub == 0 && pr < L.n_pair) B.pairCost[pr] = cs;
+        } else if (PPW > 1) {
+            double t0, t1;
+            wave_sum_groups16_mw<28>(acc, reg, lane, t0, t1);
+            if (pr < L.n_pair) {
+                B.pairM[(size_t)sub*L.n_pair + pr] = t0;                       // values 0 .. 15
+                if (sub + 16 < 27) B.pairM[(size_t)(sub + 16)*L.n_pair + pr] = t1;
+                else if (sub + 16 == 27) B.pairCost[pr] = t1;
+                if (h >= 0 && sub == 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) B.pairR[(size_t)k*L.n_pair + pr] = T.Rcr[k];
+                }
+            }
         } else {
             double tot = wave_sum_to_lane_mw<28>(acc, reg, lane);
             if (pr < L.n_pair) {
@@ -1925,10 +1970,15 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
 static int pose_parts(const Ctx *c) { return (c->n_kf > 126 && !is_multi(c)) ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
+// pairs with a dozen scene blocks (large maps): four pairs per wave
+static bool lin_small_pairs(const LevelDev &D) { static const bool off = getenv("TSBA_NO_SMALL_PAIRS") != nullptr; return !off && D.n_pair > 0 && (long long)D.n_sc <= 24LL*D.n_pair; }
 static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
-    if (D.n_pair + D.n_tg > 0) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
+    if (D.n_pair + D.n_tg > 0) {
+        if (lin_small_pairs(D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 7)/8 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
+        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
+    }
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
     if (multi) {
@@ -2273,7 +2323,10 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     st.need_lin = 1; st.done = 0; st.first = 0;
     CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));   // k_linearize never clears need_lin itself
     CK(hipEventRecord(c->ev0, c->stream));
-    for (int k = 0; k < n; k++) hipLaunchKernelGGL(k_linearize<MODE_FULL>, dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+    for (int k = 0; k < n; k++) {
+        if (lin_small_pairs(D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 7)/8 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+    }
     CK(hipEventRecord(c->ev1, c->stream));
     CK(hipEventSynchronize(c->ev1));
     float ms = 0; CK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
