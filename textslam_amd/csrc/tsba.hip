@@ -1228,6 +1228,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
 #include "tsba_chol.h"
 #include "tsba_band.h"
 #include "tsba_bandp.h"
+#include "tsba_bandcr.h"
 #include "tsba_pose.h"
 
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
@@ -1902,6 +1903,18 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             const int Bq = bwmax/6;
             const double t_f = bwmax > 57 ? 5.0 : 3.5, t_s = 2*bwmax - 6 > 115 ? 5.5 : 4.5;
             int P = (int)lround(sqrt((double)p->n_kf*t_f/((double)std::max(Bq, 1)*t_s)));
+            if (bwmax <= CR_SMAX && !getenv("TSBA_NO_CR")) {
+                // separator system by cyclic reduction (tsba_bandcr.h): its cost grows with log2(P) only (~110 us per level: pivot + update +
+                // back-substitution launches) plus the zeroing of its dense storage, so many more, shorter interiors pay
+                double best = 1e300; int bestP = P;
+                for (int q = 4; q <= BANDP_MAXP; q++) {
+                    if ((p->n_kf - (q - 1)*Bq)/q < 4*Bq + 4) break;
+                    int lev = 1; for (int hh = 1; hh < q - 1; hh <<= 1) lev++;
+                    const double nsep = (double)(q - 1)*bwmax, cost = (double)p->n_kf/q*t_f + 110.0*lev + nsep*nsep*8.0/2.5e6;
+                    if (cost < best) { best = cost; bestP = q; }
+                }
+                if (best < 1e300) P = bestP;
+            }
             if (const char *e = getenv("TSBA_BAND_PARTS")) P = atoi(e);
             P = std::max(1, std::min(P, BANDP_MAXP));
             while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < 4*Bq + 4) P--;                   // worth it only for interiors of a few bands
@@ -2007,6 +2020,9 @@ static int set_solver_attrs(Ctx *c) {
     else {
         CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_cr_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_cr_update, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_cr_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -2033,11 +2049,28 @@ static void launch_solve(Ctx *c) {
         hipMemsetAsync(c->Bpart, 0, sizeof(double)*(size_t)P*BANDP_NS*((size_t)bwp*bwp + bwp), c->stream);        // (slices of short interiors stay empty)
         hipLaunchKernelGGL(k_bandp_border, dim3(P, BANDP_NS), dim3(256), (int)((2*(size_t)BANDP_JC*bwp*6 + 6*BANDP_JC)*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Lb, c->Bpart);
         hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree);
+        static const bool no_cr = getenv("TSBA_NO_CR") != nullptr;
+        if (bwp <= CR_SMAX && P >= 4 && !no_cr) {                  // separator system by block cyclic reduction (tsba_bandcr.h): log2(P - 1) levels
+            const int mmax = P - 1;
+            const int lp = (int)(cr_pivot_lds_doubles(bwp)*sizeof(double)), lu = (int)(cr_update_lds_doubles(bwp)*sizeof(double)), lb = (int)(cr_back_lds_doubles(bwp)*sizeof(double));
+            int htop = 1;
+            for (int h = 1; h < mmax; h <<= 1) {
+                const int npiv = (mmax + 2*h - 1)/(2*h);           // >= the pivots (2k + 1) h < m; workgroups past the end return
+                hipLaunchKernelGGL(k_cr_pivot, dim3(npiv), dim3(CR_T), lp, c->stream, W, Ws, bwp, P, h, 0);
+                hipLaunchKernelGGL(k_cr_update, dim3(2*npiv + 1), dim3(CR_T), lu, c->stream, W, Ws, bwp, P, h, npiv);
+                htop = h;
+            }
+            hipLaunchKernelGGL(k_cr_pivot, dim3(1), dim3(CR_T), lp, c->stream, W, Ws, bwp, P, 0, 1);
+            hipLaunchKernelGGL(k_cr_back, dim3(1), dim3(CR_T), lb, c->stream, W, Ws, bwp, P, 0, 1);
+            for (int h = htop; h >= 1; h >>= 1)
+                hipLaunchKernelGGL(k_cr_back, dim3((mmax + 2*h - 1)/(2*h)), dim3(CR_T), lb, c->stream, W, Ws, bwp, P, h, 0);
+        } else {
         const int ldss = (int)(band_lds_doubles(bwsep, cbs)*sizeof(double)), nus = (bwsep + 63)/64;
         hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(SOLVE_THREADS), ldss, c->stream, Ws, bwsep, cbs, c->Lcol_sep);
         if (nus <= 1) hipLaunchKernelGGL(k_band_backsub<1>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
         else if (nus == 2) hipLaunchKernelGGL(k_band_backsub<2>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
         else hipLaunchKernelGGL(k_band_backsub<3>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
+        }
         const int nup = (bwp + 63)/64, ldsp = (int)((2*(size_t)BAND_CK*(2*(size_t)bwp*6 + 32) + 6*BAND_RINGB + 2*bwp + 64)*sizeof(double));
         if (nup <= 1) hipLaunchKernelGGL(k_bandp_backsub<1>, dim3(P), dim3(BAND_BS_T), ldsp, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, (const double *)Ws.Sy);
         else hipLaunchKernelGGL(k_bandp_backsub<2>, dim3(P), dim3(BAND_BS_T), ldsp, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, (const double *)Ws.Sy);

@@ -19,7 +19,7 @@
 // Every workgroup derives the same partition table from the number of free poses on the device (the host does not know it).
 #pragma once
 
-#define BANDP_MAXP 32
+#define BANDP_MAXP 96
 
 struct BandpPart { int P, a, b, has_left, has_right; };
 // interiors of q = (nb - (P - 1) B) / P blocks (the last takes the remainder), separators of B blocks between them; P shrinks
