@@ -1614,6 +1614,7 @@ struct Ctx {
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
     bool pose_only = false;                       // one keyframe, every landmark frozen in its host: the fused pose-only LM kernel applies
     double *S_alloc = nullptr; size_t S_count = 0;
+    bool sep_cr = false;                  // separator system by cyclic reduction on the compact block pool (tsba_bandcr.h)
     int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Bpart = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
     double *Lcol = nullptr; int band_stream = 0;  // streaming band solver (tsba_band.h): L by block column; 1 = every built level fits it     // storage behind W.S (dense or band)
     float *lbl_dev = nullptr, *lbl_host = nullptr; size_t lbl_cap = 0;   // text label image staging
@@ -1893,7 +1894,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         const size_t LDB = (size_t)bwmax + 2*CH_NB - 1;
         if (use_lds_ || LDB >= (size_t)W.N) { c->S_count = (size_t)(W.N + 1)*W.N; AL(c->S_alloc, c->S_count); W.S = c->S_alloc; W.ldS = W.N; W.band = 0; }
         else { c->S_count = (size_t)W.N*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - CH_NB); W.ldS = (int)LDB - 1; W.band = 1; }
-        c->Lcol = nullptr; c->band_stream = 0;
+        c->Lcol = nullptr; c->band_stream = 0; c->sep_cr = false;
         if (W.band && bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !getenv("TSBA_NO_BAND_STREAM")) {
             AL(c->Lcol, (size_t)p->n_kf*bwmax*6); c->band_stream = 1;
             // substructuring: P interiors on P workgroups + a separator system (again a band, 2 bw - 6 wide)
@@ -1904,13 +1905,13 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             const double t_f = bwmax > 57 ? 5.0 : 3.5, t_s = 2*bwmax - 6 > 115 ? 5.5 : 4.5;
             int P = (int)lround(sqrt((double)p->n_kf*t_f/((double)std::max(Bq, 1)*t_s)));
             if (bwmax <= CR_SMAX && !getenv("TSBA_NO_CR")) {
-                // separator system by cyclic reduction (tsba_bandcr.h): its cost grows with log2(P) only (~110 us per level: pivot + update +
-                // back-substitution launches) plus the zeroing of its dense storage, so many more, shorter interiors pay
+                // separator system by cyclic reduction (tsba_bandcr.h): its cost grows with log2(P) only (~130 us per level: pivot + update +
+                // back-substitution launches), so many more, shorter interiors pay
                 double best = 1e300; int bestP = P;
                 for (int q = 4; q <= BANDP_MAXP; q++) {
-                    if ((p->n_kf - (q - 1)*Bq)/q < 4*Bq + 4) break;
+                    if ((p->n_kf - (q - 1)*Bq)/q < 6*Bq + 8) break;          // (shorter interiors no longer amortise a workgroup's fixed cost: measured)
                     int lev = 1; for (int hh = 1; hh < q - 1; hh <<= 1) lev++;
-                    const double nsep = (double)(q - 1)*bwmax, cost = (double)p->n_kf/q*t_f + 110.0*lev + nsep*nsep*8.0/2.5e6;
+                    const double cost = (double)p->n_kf/q*t_f + 130.0*lev;
                     if (cost < best) { best = cost; bestP = q; }
                 }
                 if (best < 1e300) P = bestP;
@@ -1923,7 +1924,9 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
                 c->nsep_ld = nsep;
                 AL(c->Lb, (size_t)p->n_kf*bwmax*6); AL(c->Tbuf, (size_t)P*((size_t)4*bwmax*bwmax + 2*bwmax));
                 AL(c->Bpart, (size_t)P*BANDP_NS*((size_t)bwmax*bwmax + bwmax));
-                AL(c->Ssep, (size_t)nsep*nsep + nsep); AL(c->Lcol_sep, (size_t)(nsep/6 + 1)*bws*6);
+                c->sep_cr = bwmax <= CR_SMAX && P >= 4 && !getenv("TSBA_NO_CR");
+                if (c->sep_cr) AL(c->Ssep, cr_pool_blocks(P - 1)*(size_t)bwmax*bwmax); else AL(c->Ssep, (size_t)nsep*nsep + nsep);
+                AL(c->Lcol_sep, (size_t)(nsep/6 + 1)*bws*6);
                 Work &Ws = c->Wsep; memset(&Ws, 0, sizeof(Ws));
                 Ws.N = nsep; Ws.n_kf = 0; Ws.S = c->Ssep; Ws.ldS = nsep; Ws.band = 1; Ws.st = nullptr;       // (st is set at launch: W.st is allocated below)
                 AL(Ws.Sy, nsep); AL(Ws.g, nsep); AL(Ws.dp, nsep); AL(Ws.LDbuf, 32*(size_t)(nsep/6 + 1)); AL(Ws.nfree, 1); AL(Ws.fidx, 1);
@@ -2044,13 +2047,12 @@ static void launch_solve(Ctx *c) {
         const int bwp = std::max(6, c->cur_bw_rows), cbp = bandp_chunk_blocks(bwp), P = c->band_parts;
         const int bwsep = 2*bwp - 6, cbs = band_chunk_blocks(bwsep);
         Work &Ws = c->Wsep; Ws.st = W.st; Ws.ldS = (P - 1)*bwp; Ws.N = (P - 1)*bwp;
-        hipMemsetAsync(c->Ssep, 0, sizeof(double)*((size_t)Ws.ldS*Ws.ldS + Ws.ldS), c->stream);
+        if (!c->sep_cr) hipMemsetAsync(c->Ssep, 0, sizeof(double)*((size_t)Ws.ldS*Ws.ldS + Ws.ldS), c->stream);
         hipLaunchKernelGGL(k_bandp_factor, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
         hipMemsetAsync(c->Bpart, 0, sizeof(double)*(size_t)P*BANDP_NS*((size_t)bwp*bwp + bwp), c->stream);        // (slices of short interiors stay empty)
         hipLaunchKernelGGL(k_bandp_border, dim3(P, BANDP_NS), dim3(256), (int)((2*(size_t)BANDP_JC*bwp*6 + 6*BANDP_JC)*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Lb, c->Bpart);
-        hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree);
-        static const bool no_cr = getenv("TSBA_NO_CR") != nullptr;
-        if (bwp <= CR_SMAX && P >= 4 && !no_cr) {                  // separator system by block cyclic reduction (tsba_bandcr.h): log2(P - 1) levels
+        hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
+        if (c->sep_cr) {                  // separator system by block cyclic reduction (tsba_bandcr.h): log2(P - 1) levels
             const int mmax = P - 1;
             const int lp = (int)(cr_pivot_lds_doubles(bwp)*sizeof(double)), lu = (int)(cr_update_lds_doubles(bwp)*sizeof(double)), lb = (int)(cr_back_lds_doubles(bwp)*sizeof(double));
             int htop = 1;

@@ -23,14 +23,14 @@ __device__ __forceinline__ int cr_nsep(const Work &W, int bw, int Pmax) { const 
 
 // n elements through f(index) -> value and st(index, value), 16 per thread in flight (a plain copy loop waits for every load before it
 // issues the next: ~0.6 us each)
-template <class F, class G>
+template <int U = 16, class F, class G>
 __device__ __forceinline__ void cr_batched(int n, int tid, F f, G st) {
-    for (int e0 = tid; e0 < n; e0 += 16*CR_T) {
-        double v[16];
+    for (int e0 = tid; e0 < n; e0 += U*CR_T) {
+        double v[U];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int e = e0 + u*CR_T; v[u] = e < n ? f(e) : 0.0; }
+        for (int u = 0; u < U; u++) { const int e = e0 + u*CR_T; v[u] = e < n ? f(e) : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int e = e0 + u*CR_T; if (e < n) st(e, v[u]); }
+        for (int u = 0; u < U; u++) { const int e = e0 + u*CR_T; if (e < n) st(e, v[u]); }
     }
 }
 
@@ -43,15 +43,19 @@ __global__ __launch_bounds__(CR_T) void k_cr_pivot(Work W, Work Ws, int bw, int 
     if (root) { if (blockIdx.x > 0 || m <= 0) return; i = 0; a = -1; c = -1; }
     else { i = (2*(int)blockIdx.x + 1)*h; if (i >= m) return; a = i - h; c = i + h < m ? i + h : -1; }
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int ncol = 2*s + 1, tid = threadIdx.x, ld = Ws.ldS;
+    const int ncol = 2*s + 1, tid = threadIdx.x, mmax = Pmax - 1;
     double *Ls = smem, *R = smem + (size_t)s*(s + 1);           // R[r][t]: columns [0, s) S(i, a)(:, t), [s, 2s) S(c, i)(t - s, :)^T, 2s: g_i
-    double *S = Ws.S, *g = Ws.g;
-    cr_batched(s*s, tid, [&](int e) { const int r = e/s, q = e - r*s; return q <= r ? S[(size_t)(i*s + r)*ld + i*s + q] : 0.0; },
-               [&](int e, double v) { const int r = e/s, q = e - r*s; Ls[r*(s + 1) + q] = v; });
-    if (a >= 0) cr_batched(s*s, tid, [&](int e) { const int r = e/s, t = e - r*s; return S[(size_t)(i*s + r)*ld + a*s + t]; },
-                           [&](int e, double v) { const int r = e/s, t = e - r*s; R[r*ncol + t] = v; });
-    if (c >= 0) cr_batched(s*s, tid, [&](int e) { const int j = e/s, r = e - j*s; return S[(size_t)(c*s + j)*ld + i*s + r]; },
-                           [&](int e, double v) { const int j = e/s, r = e - j*s; R[r*ncol + s + j] = v; });
+    double *g = Ws.g;
+    double *Bii = cr_blk(Ws.S, s, mmax, i, i), *Bia = a >= 0 ? cr_blk(Ws.S, s, mmax, i, a) : nullptr, *Bci = c >= 0 ? cr_blk(Ws.S, s, mmax, c, i) : nullptr;
+    // (e -> (row, column) by a float reciprocal: an integer division by the run-time s costs ~30 instructions, twice per element)
+    const float inv_s = 1.0f/(float)s;
+    auto rowof = [&](int e) { return (int)(((float)e + 0.5f)*inv_s); };
+    cr_batched(s*s, tid, [&](int e) { const int r = rowof(e), q = e - r*s; return q <= r ? Bii[e] : 0.0; },
+               [&](int e, double v) { const int r = rowof(e), q = e - r*s; Ls[r*(s + 1) + q] = v; });
+    if (a >= 0) cr_batched(s*s, tid, [&](int e) { return Bia[e]; },
+                           [&](int e, double v) { const int r = rowof(e), t = e - r*s; R[r*ncol + t] = v; });
+    if (c >= 0) cr_batched(s*s, tid, [&](int e) { return Bci[e]; },
+                           [&](int e, double v) { const int j = rowof(e), r = e - j*s; R[r*ncol + s + j] = v; });
     for (int r = tid; r < s; r += CR_T) R[r*ncol + 2*s] = g[i*s + r];
     // blocked (6 columns = one pose) right-looking Cholesky in LDS: every thread factors the 6x6 diagonal block in registers (no
     // broadcast), the threads of the rows below solve their panel row, then the rank-6 trailing update: two barriers per block
@@ -102,29 +106,68 @@ __global__ __launch_bounds__(CR_T) void k_cr_pivot(Work W, Work Ws, int bw, int 
         }
         __syncthreads();
         const int nt = s - k0 - 6;
-        for (int e = tid; e < tri(nt); e += CR_T) { const int rr = tri_row(e), cc = e - tri(rr);
-            const double *x = Ls + (k0 + 6 + rr)*(s + 1) + k0, *y = Ls + (k0 + 6 + cc)*(s + 1) + k0;
-            Ls[(k0 + 6 + rr)*(s + 1) + k0 + 6 + cc] -= x[0]*y[0] + x[1]*y[1] + x[2]*y[2] + x[3]*y[3] + x[4]*y[4] + x[5]*y[5]; }
-    }
-    __syncthreads();
-    cr_batched(s*s, tid, [&](int e) { const int r = e/s, q = e - r*s; return Ls[r*(s + 1) + q]; },
-               [&](int e, double v) { const int r = e/s, q = e - r*s; if (q <= r) S[(size_t)(i*s + r)*ld + i*s + q] = v; });
-    // forward substitution, one right-hand-side column per thread (ncol <= 157)
-    if (tid < ncol && (tid == 2*s || (tid < s ? a >= 0 : c >= 0))) {
-        for (int r = 0; r < s; r++) {
-            const double *lr = Ls + r*(s + 1);
-            double a0 = R[r*ncol + tid], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            int q = 0;
-            for (; q + 3 < r; q += 4) { a0 -= lr[q]*R[q*ncol + tid]; a1 -= lr[q + 1]*R[(q + 1)*ncol + tid]; a2 -= lr[q + 2]*R[(q + 2)*ncol + tid]; a3 -= lr[q + 3]*R[(q + 3)*ncol + tid]; }
-            for (; q < r; q++) a0 -= lr[q]*R[q*ncol + tid];
-            R[r*ncol + tid] = ((a0 + a1) + (a2 + a3))/lr[r];
+        for (int e0 = tid; e0 < tri(nt); e0 += 3*CR_T) {           // three elements per thread in flight (the reads of one are ~13 LDS round trips)
+            double xv[3][6], yv[3][6], cv[3]; int ci[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int e = min(e0 + u*CR_T, tri(nt) - 1), rr = tri_row(e), cc = e - tri(rr);
+                const double *x = Ls + (k0 + 6 + rr)*(s + 1) + k0, *y = Ls + (k0 + 6 + cc)*(s + 1) + k0;
+                ci[u] = (k0 + 6 + rr)*(s + 1) + k0 + 6 + cc; cv[u] = Ls[ci[u]];
+#pragma unroll
+                for (int q = 0; q < 6; q++) { xv[u][q] = x[q]; yv[u][q] = y[q]; } }
+#pragma unroll
+            for (int u = 0; u < 3; u++) if (e0 + u*CR_T < tri(nt))
+                Ls[ci[u]] = cv[u] - ((xv[u][0]*yv[u][0] + xv[u][1]*yv[u][1] + xv[u][2]*yv[u][2]) + (xv[u][3]*yv[u][3] + xv[u][4]*yv[u][4] + xv[u][5]*yv[u][5]));
         }
     }
     __syncthreads();
-    if (a >= 0) cr_batched(s*s, tid, [&](int e) { const int r = e/s, t = e - r*s; return R[r*ncol + t]; },
-                           [&](int e, double v) { const int r = e/s, t = e - r*s; S[(size_t)(i*s + r)*ld + a*s + t] = v; });
-    if (c >= 0) cr_batched(s*s, tid, [&](int e) { const int j = e/s, r = e - j*s; return R[r*ncol + s + j]; },
-                           [&](int e, double v) { const int j = e/s, r = e - j*s; S[(size_t)(c*s + j)*ld + i*s + r] = v; });
+    cr_batched(s*s, tid, [&](int e) { const int r = rowof(e), q = e - r*s; return Ls[r*(s + 1) + q]; },
+               [&](int e, double v) { const int r = rowof(e), q = e - r*s; if (q <= r) Bii[e] = v; });
+    // forward substitution L^-1 [S(i, a) | S(c, i)^T | g], blocked by 6 rows: the columns' 6x6 triangular solves (one column per thread),
+    // then the rank-6 update of the rows below on all threads (wave -> column half and row parity: the six solved values of the column
+    // stay in registers, the L row is a broadcast).  (One column per thread over all 60 rows was a 1770-step chain of dependent LDS
+    // reads on two waves: 35 us.)
+    {
+        const int lane = tid & 63, wave = tid >> 6, col = (wave & 1)*64 + lane, rg = wave >> 1;
+        const bool con = col < ncol && (col == 2*s || (col < s ? a >= 0 : c >= 0));
+        for (int kb = 0; kb < s; kb += 6) {
+            __syncthreads();
+            double x[6] = {0, 0, 0, 0, 0, 0};
+            if (con) {
+                double l6[21], rv[6];                              // operands first, then the dependent chain
+#pragma unroll
+                for (int q = 0; q < 6; q++) { rv[q] = R[(kb + q)*ncol + col];
+#pragma unroll
+                    for (int k = 0; k <= q; k++) l6[tri(q) + k] = Ls[(kb + q)*(s + 1) + kb + k]; }
+#pragma unroll
+                for (int q = 0; q < 6; q++) { double v = rv[q];
+#pragma unroll
+                    for (int k = 0; k < q; k++) v -= l6[tri(q) + k]*x[k];
+                    x[q] = v/l6[tri(q) + q]; }
+            }
+            __syncthreads();                                       // both row groups have read the block's rows (solved redundantly); one stores them
+            if (con) {
+                if (rg == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) R[(kb + q)*ncol + col] = x[q];
+                }
+                for (int r0 = kb + 6 + rg; r0 < s; r0 += 8) {          // four rows per round in flight
+                    double lv[4][6], cv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int r = min(r0 + 2*u, s - 1); const double *lr = Ls + r*(s + 1) + kb; cv[u] = R[r*ncol + col];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) lv[u][q] = lr[q]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (r0 + 2*u < s)
+                        R[(r0 + 2*u)*ncol + col] = cv[u] - ((lv[u][0]*x[0] + lv[u][1]*x[1] + lv[u][2]*x[2]) + (lv[u][3]*x[3] + lv[u][4]*x[4] + lv[u][5]*x[5]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (a >= 0) cr_batched(s*s, tid, [&](int e) { const int r = rowof(e), t = e - r*s; return R[r*ncol + t]; },
+                           [&](int e, double v) { Bia[e] = v; });
+    if (c >= 0) cr_batched(s*s, tid, [&](int e) { const int j = rowof(e), r = e - j*s; return R[r*ncol + s + j]; },
+                           [&](int e, double v) { Bci[e] = v; });
     for (int r = tid; r < s; r += CR_T) g[i*s + r] = R[r*ncol + 2*s];
 }
 
@@ -139,28 +182,31 @@ static size_t cr_update_lds_doubles(int s) { const int rows = (s + 15) & ~15, st
 __global__ __launch_bounds__(CR_T) void k_cr_update(Work W, Work Ws, int bw, int Pmax, int h, int npiv) {
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
-    const int m = cr_nsep(W, bw, Pmax), s = bw, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ld = Ws.ldS;
+    const int m = cr_nsep(W, bw, Pmax), s = bw, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mmax = Pmax - 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int rows = (s + 15) & ~15, kn = (s + 3) & ~3, stride = kn + 1, nt = rows >> 4;
     double *X = smem, *Yt = smem + (size_t)rows*stride;
+    const float inv_s = 1.0f/(float)s;
     double *S = Ws.S, *g = Ws.g;
     for (int e = tid; e < 2*rows*stride; e += CR_T) smem[e] = 0.0;
     __syncthreads();
     auto load_block = [&](double *dst, int br, int bc, bool transpose) {
-        cr_batched(s*s, tid, [&](int e) { const int r = e/s, q = e - r*s; return S[(size_t)(br*s + r)*ld + bc*s + q]; },
-                   [&](int e, double v) { const int r = e/s, q = e - r*s; if (transpose) dst[q*stride + r] = v; else dst[r*stride + q] = v; }); };
+        const double *Bk = cr_blk(S, s, mmax, br, bc);
+        cr_batched(s*s, tid, [&](int e) { return Bk[e]; },
+                   [&](int e, double v) { const int r = (int)(((float)e + 0.5f)*inv_s), q = e - r*s; if (transpose) dst[q*stride + r] = v; else dst[r*stride + q] = v; }); };
     const int lr = lane & 15, lk = lane >> 4;
     if ((int)blockIdx.x < npiv) {
         const int i = (2*(int)blockIdx.x + 1)*h, a = i - h, c = i + h;
         if (i >= m || c >= m) return;
-        load_block(X, c, i, false); load_block(Yt, i, a, true);   // X = W_c^T (rows of c), Yt = W_a^T:  S(c, a) -= X Yt^T
+        load_block(X, c, i, false); load_block(Yt, i, a, true);   // X = W_c^T (rows of c), Yt = W_a^T:  S(c, a) = -X Yt^T
+        double *Bca = cr_blk(S, s, mmax, c, a);
         __syncthreads();
         for (int t = wave; t < nt*nt; t += CR_T/64) {
             const int ti = t/nt, tj = t - ti*nt;
             v4d acc = {0.0, 0.0, 0.0, 0.0};
             cr_tile_acc(X, Yt, stride, kn, ti, tj, lr, lk, acc);
 #pragma unroll
-            for (int r = 0; r < 4; r++) { const int j = 16*ti + lk + 4*r, q = 16*tj + lr; if (j < s && q < s) S[(size_t)(c*s + j)*ld + a*s + q] -= acc[r]; }
+            for (int r = 0; r < 4; r++) { const int j = 16*ti + lk + 4*r, q = 16*tj + lr; if (j < s && q < s) Bca[j*s + q] = -acc[r]; }        // (a fresh block: nothing to add to)
         }
         return;
     }
@@ -169,6 +215,7 @@ __global__ __launch_bounds__(CR_T) void k_cr_update(Work W, Work Ws, int bw, int
     const int il = e0 - h, ir = e0 + h < m ? e0 + h : -1;
     const bool hl = il >= 0, hr = ir >= 0;
     if (!hl && !hr) return;
+    double *Bee = cr_blk(S, s, mmax, e0, e0);
     if (hl) load_block(X, e0, il, false);                         // W_c^T of the left pivot:  D -= X X^T,    g -= X y_l
     if (hr) load_block(Yt, ir, e0, true);                         // W_a^T of the right pivot: D -= Yt Yt^T,  g -= Yt y_r
     __syncthreads();
@@ -179,7 +226,7 @@ __global__ __launch_bounds__(CR_T) void k_cr_update(Work W, Work Ws, int bw, int
         if (hl) cr_tile_acc(X, X, stride, kn, ti, tj, lr, lk, acc);
         if (hr) cr_tile_acc(Yt, Yt, stride, kn, ti, tj, lr, lk, acc);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const int j = 16*ti + lk + 4*r, q = 16*tj + lr; if (j < s && q <= j) S[(size_t)(e0*s + j)*ld + e0*s + q] -= acc[r]; }
+        for (int r = 0; r < 4; r++) { const int j = 16*ti + lk + 4*r, q = 16*tj + lr; if (j < s && q <= j) Bee[j*s + q] -= acc[r]; }
     }
     for (int j = tid; j < s; j += CR_T) { double acc = 0.0;
         if (hl) for (int r = 0; r < s; r++) acc += X[j*stride + r]*g[il*s + r];
@@ -191,16 +238,18 @@ __global__ __launch_bounds__(CR_T) void k_cr_update(Work W, Work Ws, int bw, int
 __global__ __launch_bounds__(CR_T) void k_cr_back(Work W, Work Ws, int bw, int Pmax, int h, int root) {
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
-    const int m = cr_nsep(W, bw, Pmax), s = bw, tid = threadIdx.x, lane = tid & 63, ld = Ws.ldS;
+    const int m = cr_nsep(W, bw, Pmax), s = bw, tid = threadIdx.x, lane = tid & 63, mmax = Pmax - 1;
     int i, a, c;
     if (root) { if (blockIdx.x > 0 || m <= 0) return; i = 0; a = -1; c = -1; }
     else { i = (2*(int)blockIdx.x + 1)*h; if (i >= m) return; a = i - h; c = i + h < m ? i + h : -1; }
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *Ls = smem, *X = Ls + (size_t)s*(s + 1), *Y = X + (size_t)s*(s + 1), *t = Y + (size_t)s*(s + 1), *xn = t + s, *xa = xn + s, *xc = xa + s;
     const double *S = Ws.S, *g = Ws.g; double *x = Ws.Sy;
+    const float inv_s = 1.0f/(float)s;
     auto load_block = [&](double *dst, int br, int bc) {
-        cr_batched(s*s, tid, [&](int e) { const int r = e/s, q = e - r*s; return S[(size_t)(br*s + r)*ld + bc*s + q]; },
-                   [&](int e, double v) { const int r = e/s, q = e - r*s; dst[r*(s + 1) + q] = v; }); };
+        const double *Bk = cr_blk(S, s, mmax, br, bc);
+        cr_batched(s*s, tid, [&](int e) { return Bk[e]; },
+                   [&](int e, double v) { const int r = (int)(((float)e + 0.5f)*inv_s), q = e - r*s; dst[r*(s + 1) + q] = v; }); };
     load_block(Ls, i, i);
     if (a >= 0) load_block(X, i, a);                              // W_a
     if (c >= 0) load_block(Y, c, i);                              // W_c^T

@@ -334,9 +334,22 @@ __global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, 
     for (int u = 0; u < NU; u++) { if (tk[u] < 0) continue; if (tq[u] >= 0) o[(size_t)tk[u]*nbr + tq[u]] = acc[u]; else o[(size_t)nbr*nbr + tk[u]] = acc[u]; }
 }
 
-// ---- separator system: dense row-major (ld = nsep_ld), rows of separator s at [6 B s, 6 B (s + 1)); number of separator pose
+// Compact block pool of the separator system for the cyclic-reduction solver (tsba_bandcr.h): only the blocks it ever touches --
+// [D_0 .. D_{mmax-1}] [stride-1 couplings (k + 1, k)] [stride-2 couplings (2 (k + 1), 2 k)] ... each s x s row-major.  (The dense
+// (P - 1) s square was 114 MB at P = 64 with rows 30 KB apart: every block row in another page.)
+__device__ __host__ __forceinline__ size_t cr_blk_index(int mmax, int br, int bc) {
+    if (br == bc) return (size_t)br;
+    const int h = br - bc; size_t base = (size_t)mmax;
+    for (int hh = 1; hh < h; hh <<= 1) base += (size_t)(mmax + hh - 1)/hh;
+    return base + (size_t)(bc/h);
+}
+__device__ __forceinline__ double *cr_blk(double *pool, int s, int mmax, int br, int bc) { return pool + cr_blk_index(mmax, br, bc)*(size_t)s*s; }
+__device__ __forceinline__ const double *cr_blk(const double *pool, int s, int mmax, int br, int bc) { return pool + cr_blk_index(mmax, br, bc)*(size_t)s*s; }
+static size_t cr_pool_blocks(int mmax) { size_t n = (size_t)mmax; for (int hh = 1; hh < 2*mmax; hh <<= 1) n += (size_t)(mmax + hh - 1)/hh; return n + 2; }
+
+// ---- separator system: dense row-major (ld = nsep_ld) or, blocked = 1, the block pool above; rows of separator s at [6 B s, 6 B (s + 1)); number of separator pose
 // blocks -> *nfree_sep (what k_band_solve reads)
-__global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, const double *Tbuf, const double *part, double *Ssep, int nsep_ld, double *gsep, int *nfree_sep) {
+__global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, const double *Tbuf, const double *part, double *Ssep, int nsep_ld, double *gsep, int *nfree_sep, int blocked) {
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
     const int nb = *W.nfree, B = bw/6;
@@ -352,9 +365,10 @@ __global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, con
         const int i = e/nS, j = e - i*nS;
         if (j <= i) { double v = Ta[(size_t)i*nTm + j];          // RR of interior s (from its window) + LL of interior s + 1 (k_bandp_border partials)
             for (int sl = 0; sl < BANDP_NS; sl++) v += part[((size_t)(s + 1)*BANDP_NS + sl)*((size_t)nS*nS + nS) + (size_t)i*nS + j];
-            Ssep[(size_t)(nS*s + i)*nsep_ld + nS*s + j] = v; }
+            if (blocked) cr_blk(Ssep, nS, Pmax - 1, s, s)[(size_t)i*nS + j] = v; else Ssep[(size_t)(nS*s + i)*nsep_ld + nS*s + j] = v; }
         // coupling to the NEXT separator through interior s + 1: T_{s+1}(border row i, right-separator column j) = S(sep s row i, sep s+1 col j)
-        if (nRb > 0) Ssep[(size_t)(nS*(s + 1) + j)*nsep_ld + nS*s + i] = Tb[(size_t)(nRb + i)*nTm + j];
+        if (nRb > 0) { const double v = Tb[(size_t)(nRb + i)*nTm + j];
+            if (blocked) cr_blk(Ssep, nS, Pmax - 1, s + 1, s)[(size_t)j*nS + i] = v; else Ssep[(size_t)(nS*(s + 1) + j)*nsep_ld + nS*s + i] = v; }
     }
     for (int i = threadIdx.x; i < nS; i += 256) { double v = ga[i];
         for (int sl = 0; sl < BANDP_NS; sl++) v += part[((size_t)(s + 1)*BANDP_NS + sl)*((size_t)nS*nS + nS) + (size_t)nS*nS + i];
