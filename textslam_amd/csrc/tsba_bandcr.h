@@ -127,7 +127,9 @@ __global__ __launch_bounds__(CR_T) void k_cr_pivot(Work W, Work Ws, int bw, int 
     // stay in registers, the L row is a broadcast).  (One column per thread over all 60 rows was a 1770-step chain of dependent LDS
     // reads on two waves: 35 us.)
     {
-        const int lane = tid & 63, wave = tid >> 6, col = (wave & 1)*64 + lane, rg = wave >> 1;
+        // (up to 128 columns: two waves per column half, the rows below split by parity; more -- separators of 11+ pose blocks --: one column per thread)
+        const int lane = tid & 63, wave = tid >> 6; const bool wide = ncol > 128;
+        const int col = wide ? tid : (wave & 1)*64 + lane, rg = wide ? 0 : wave >> 1, rstep = wide ? 1 : 2;
         const bool con = col < ncol && (col == 2*s || (col < s ? a >= 0 : c >= 0));
         for (int kb = 0; kb < s; kb += 6) {
             __syncthreads();
@@ -150,15 +152,15 @@ __global__ __launch_bounds__(CR_T) void k_cr_pivot(Work W, Work Ws, int bw, int 
 #pragma unroll
                     for (int q = 0; q < 6; q++) R[(kb + q)*ncol + col] = x[q];
                 }
-                for (int r0 = kb + 6 + rg; r0 < s; r0 += 8) {          // four rows per round in flight
+                for (int r0 = kb + 6 + rg; r0 < s; r0 += 4*rstep) {    // four rows per round in flight
                     double lv[4][6], cv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { const int r = min(r0 + 2*u, s - 1); const double *lr = Ls + r*(s + 1) + kb; cv[u] = R[r*ncol + col];
+                    for (int u = 0; u < 4; u++) { const int r = min(r0 + rstep*u, s - 1); const double *lr = Ls + r*(s + 1) + kb; cv[u] = R[r*ncol + col];
 #pragma unroll
                         for (int q = 0; q < 6; q++) lv[u][q] = lr[q]; }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) if (r0 + 2*u < s)
-                        R[(r0 + 2*u)*ncol + col] = cv[u] - ((lv[u][0]*x[0] + lv[u][1]*x[1] + lv[u][2]*x[2]) + (lv[u][3]*x[3] + lv[u][4]*x[4] + lv[u][5]*x[5]));
+                    for (int u = 0; u < 4; u++) if (r0 + rstep*u < s)
+                        R[(r0 + rstep*u)*ncol + col] = cv[u] - ((lv[u][0]*x[0] + lv[u][1]*x[1] + lv[u][2]*x[2]) + (lv[u][3]*x[3] + lv[u][4]*x[4] + lv[u][5]*x[5]));
                 }
             }
         }
