@@ -1904,6 +1904,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             const int Bq = bwmax/6;
             const double t_f = bwmax > 57 ? 5.0 : 3.5, t_s = 2*bwmax - 6 > 115 ? 5.5 : 4.5;
             int P = (int)lround(sqrt((double)p->n_kf*t_f/((double)std::max(Bq, 1)*t_s)));
+            bool want_cr = false;
             if (bwmax <= CR_SMAX && !getenv("TSBA_NO_CR")) {
                 // separator system by cyclic reduction (tsba_bandcr.h): its cost grows with log2(P) only (~130 us per level: pivot + update +
                 // back-substitution launches), so many more, shorter interiors pay
@@ -1914,8 +1915,12 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
                     const double cost = (double)p->n_kf/q*t_f + 130.0*lev;
                     if (cost < best) { best = cost; bestP = q; }
                 }
-                if (best < 1e300) P = bestP;
+                // (few, long interiors -- some hundred keyframes -- are still cheaper with the sequential separator solve: compare)
+                const int Ps = std::max(1, std::min(P, BANDP_MAXP));
+                const double cost_seq = (double)p->n_kf/Ps*t_f + (double)(Ps - 1)*Bq*t_s;
+                if (best < cost_seq) { P = bestP; want_cr = true; }
             }
+            if (getenv("TSBA_BAND_PARTS") && bwmax <= CR_SMAX && !getenv("TSBA_NO_CR")) want_cr = true;
             if (const char *e = getenv("TSBA_BAND_PARTS")) P = atoi(e);
             P = std::max(1, std::min(P, BANDP_MAXP));
             while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < 4*Bq + 4) P--;                   // worth it only for interiors of a few bands
@@ -1924,7 +1929,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
                 c->nsep_ld = nsep;
                 AL(c->Lb, (size_t)p->n_kf*bwmax*6); AL(c->Tbuf, (size_t)P*((size_t)4*bwmax*bwmax + 2*bwmax));
                 AL(c->Bpart, (size_t)P*BANDP_NS*((size_t)bwmax*bwmax + bwmax));
-                c->sep_cr = bwmax <= CR_SMAX && P >= 4 && !getenv("TSBA_NO_CR");
+                c->sep_cr = want_cr && P >= 4;
                 if (c->sep_cr) AL(c->Ssep, cr_pool_blocks(P - 1)*(size_t)bwmax*bwmax); else AL(c->Ssep, (size_t)nsep*nsep + nsep);
                 AL(c->Lcol_sep, (size_t)(nsep/6 + 1)*bws*6);
                 Work &Ws = c->Wsep; memset(&Ws, 0, sizeof(Ws));
