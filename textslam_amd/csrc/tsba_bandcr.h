@@ -6,8 +6,8 @@
 //   level h = 1, 2, 4, ...: pivots i = (2k + 1) h, neighbours a = i - h, c = i + h (if < m)
 //     k_cr_pivot   D_i = L L^T (in LDS), W_a = L^-1 S(i, a), W_c = L^-1 S(c, i)^T, y_i = L^-1 g_i -- all in place (L over D_i, W_a over S(i, a),
 //                  W_c^T over S(c, i), y over g)
-//     k_cr_update  every remaining block e: D_e -= W^T W of the pivots next to it, g_e -= W^T y; every pivot: S(c, a) -= W_c^T W_a (the new
-//                  coupling of the next level; the system matrix is dense storage, zeroed per iteration, so the block is there)
+//     k_cr_update  every remaining block e: D_e -= W^T W of the pivots next to it, g_e -= W^T y; every pivot: S(c, a) = -W_c^T W_a (the new
+//                  coupling of the next level: a fresh block of the compact pool, cr_blk in tsba_bandp.h) -- 16x16 MFMA tiles
 //   root: block 0 alone; then back substitution level by level: x_i = L^-T (y_i - W_a x_a - W_c x_c)          (k_cr_back)
 // log2(m) levels of small dense kernels on m / 2h workgroups instead of m B sequential pose-block steps.  The number of separators is only
 // known on the device (bandp_part): the host launches the worst case, workgroups without a pivot return.
