@@ -2440,6 +2440,11 @@ int tsba_debug_band_factor(void *ctx, double *lcol, long long n_lcol, double *ld
     if (hipMemcpy(lcol, c->Lcol, sizeof(double)*n_lcol, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE;
     return hipMemcpy(ldbuf, c->W.LDbuf, sizeof(double)*n_ld, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
 }
+// host-side index arithmetic of the partitioned band solver, for the CPU test-suite (no device needed):
+// out5 = { P, a, b, has_left, has_right } of interior p;  block index of (br, bc) in the cyclic-reduction pool and the pool size
+void tsba_debug_bandp_part(int nb, int B, int Pmax, int p, int *out5) { const BandpPart r = bandp_part(nb, B, Pmax, p); out5[0] = r.P; out5[1] = r.a; out5[2] = r.b; out5[3] = r.has_left; out5[4] = r.has_right; }
+long long tsba_debug_cr_blk_index(int mmax, int br, int bc) { return (long long)cr_blk_index(mmax, br, bc); }
+long long tsba_debug_cr_pool_blocks(int mmax) { return (long long)cr_pool_blocks(mmax); }
 int tsba_debug_stamps(void *ctx, long long *out64) {
     Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded) return TSBA_ERR_STATE;
     hipSetDevice(c->device); hipStreamSynchronize(c->stream);
