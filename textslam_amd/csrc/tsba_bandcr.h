@@ -16,8 +16,8 @@
 #define CR_T 256
 #define CR_SMAX 78                           // separator rows (13 pose blocks): L + all right-hand sides (pivot), three blocks (back) fit the LDS
 
-static size_t cr_pivot_lds_doubles(int s) { return (size_t)s*(s + 1) + (size_t)s*(2*s + 1); }
-static size_t cr_back_lds_doubles(int s) { return 3*(size_t)s*(s + 1) + 4*(size_t)s; }
+static size_t cr_pivot_lds_doubles(int s) { return (size_t)s*(s + 1) + (size_t)s*(2*s + 1) + s; }
+static size_t cr_back_lds_doubles(int s) { return 3*(size_t)s*(s + 1) + 5*(size_t)s; }
 
 __device__ __forceinline__ int cr_nsep(const Work &W, int bw, int Pmax) { const int nb = *W.nfree; return nb > 0 ? bandp_part(nb, bw/6, Pmax, 0).P - 1 : 0; }
 
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(CR_T) void k_cr_pivot(Work W, Work Ws, int bw, int 
     else { i = (2*(int)blockIdx.x + 1)*h; if (i >= m) return; a = i - h; c = i + h < m ? i + h : -1; }
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int ncol = 2*s + 1, tid = threadIdx.x, mmax = Pmax - 1;
-    double *Ls = smem, *R = smem + (size_t)s*(s + 1);           // R[r][t]: columns [0, s) S(i, a)(:, t), [s, 2s) S(c, i)(t - s, :)^T, 2s: g_i
+    double *Ls = smem, *R = smem + (size_t)s*(s + 1), *invd = R + (size_t)s*ncol;   // invd: 1 / L(r, r) (a division is ~35 instructions: once per row, in parallel)
+    // R[r][t]: columns [0, s) S(i, a)(:, t), [s, 2s) S(c, i)(t - s, :)^T, 2s: g_i
     double *g = Ws.g;
     double *Bii = cr_blk(Ws.S, s, mmax, i, i), *Bia = a >= 0 ? cr_blk(Ws.S, s, mmax, i, a) : nullptr, *Bci = c >= 0 ? cr_blk(Ws.S, s, mmax, c, i) : nullptr;
     // (e -> (row, column) by a float reciprocal: an integer division by the run-time s costs ~30 instructions, twice per element)
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(CR_T) void k_cr_pivot(Work W, Work Ws, int bw, int 
         }
     }
     __syncthreads();
+    for (int r = tid; r < s; r += CR_T) invd[r] = 1.0/Ls[r*(s + 1) + r];
     cr_batched(s*s, tid, [&](int e) { const int r = rowof(e), q = e - r*s; return Ls[r*(s + 1) + q]; },
                [&](int e, double v) { const int r = rowof(e), q = e - r*s; if (q <= r) Bii[e] = v; });
     // forward substitution L^-1 [S(i, a) | S(c, i)^T | g], blocked by 6 rows: the columns' 6x6 triangular solves (one column per thread),
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(CR_T) void k_cr_pivot(Work W, Work Ws, int bw, int 
                 for (int q = 0; q < 6; q++) { double v = rv[q];
 #pragma unroll
                     for (int k = 0; k < q; k++) v -= l6[tri(q) + k]*x[k];
-                    x[q] = v/l6[tri(q) + q]; }
+                    x[q] = v*invd[kb + q]; }
             }
             __syncthreads();                                       // both row groups have read the block's rows (solved redundantly); one stores them
             if (con) {
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(CR_T) void k_cr_back(Work W, Work Ws, int bw, int P
     if (root) { if (blockIdx.x > 0 || m <= 0) return; i = 0; a = -1; c = -1; }
     else { i = (2*(int)blockIdx.x + 1)*h; if (i >= m) return; a = i - h; c = i + h < m ? i + h : -1; }
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *Ls = smem, *X = Ls + (size_t)s*(s + 1), *Y = X + (size_t)s*(s + 1), *t = Y + (size_t)s*(s + 1), *xn = t + s, *xa = xn + s, *xc = xa + s;
+    double *Ls = smem, *X = Ls + (size_t)s*(s + 1), *Y = X + (size_t)s*(s + 1), *t = Y + (size_t)s*(s + 1), *xn = t + s, *xa = xn + s, *xc = xa + s, *invd = xc + s;
     const double *S = Ws.S, *g = Ws.g; double *x = Ws.Sy;
     const float inv_s = 1.0f/(float)s;
     auto load_block = [&](double *dst, int br, int bc) {
@@ -260,14 +262,14 @@ __global__ __launch_bounds__(CR_T) void k_cr_back(Work W, Work Ws, int bw, int P
     for (int r = tid; r < s; r += CR_T) { double acc = t[r];
         if (a >= 0) for (int j = 0; j < s; j++) acc -= X[r*(s + 1) + j]*xa[j];
         if (c >= 0) for (int j = 0; j < s; j++) acc -= Y[j*(s + 1) + r]*xc[j];
-        t[r] = acc; }
+        t[r] = acc; invd[r] = 1.0/Ls[r*(s + 1) + r]; }
     __syncthreads();
     if (tid >= 64) return;
     // one wave, right-looking: lane owns rows lane and lane + 64
     double t0 = lane < s ? t[lane] : 0.0, t1 = lane + 64 < s ? t[lane + 64] : 0.0;
     for (int r = s - 1; r >= 0; r--) {
         const double tr = r < 64 ? readlane_f64(t0, r) : readlane_f64(t1, r - 64);
-        const double xr = tr/Ls[r*(s + 1) + r];
+        const double xr = tr*invd[r];
         if (lane == 0) xn[r] = xr;
         if (lane < r) t0 -= Ls[r*(s + 1) + lane]*xr;
         if (lane + 64 < r) t1 -= Ls[r*(s + 1) + lane + 64]*xr;
