@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             }
 #pragma unroll
             for (int u = 0; u < SCHUR_U; u++) {
-                const double vinv = ok[u] ? 1.0/(Vv[u] + dg[u]*irad) : 0.0;
+                const double vinv = ok[u] ? ts_rcp(Vv[u] + dg[u]*irad) : 0.0;     // (v_rcp + Newton: an IEEE division is ~35 instructions per slot pair)
 #pragma unroll
                 for (int r = 0; r < 6; r++) {
                     const double wr = w1[u][r]*vinv;
@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             }
 #pragma unroll
             for (int u = 0; u < SCHUR_U; u++) {
-                const double f = ok[u] ? bb[u]/(Vv[u] + dg[u]*irad) : 0.0;
+                const double f = ok[u] ? bb[u]*ts_rcp(Vv[u] + dg[u]*irad) : 0.0;
 #pragma unroll
                 for (int k = 0; k < 6; k++) acc[k] += w[u][k]*f;
             }
