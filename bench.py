@@ -80,7 +80,7 @@ def bench_orb(args, rank, local_rank, world, dist, torch):
         algo = 64*4.7e6
         out["roofline"] = {"bound": "hbm", "kernel": "whole ORB pipeline (pyramid, FAST, quadtree, orientation, blur, rBRIEF)", "achieved": algo*world/(dt/args.steps)/1e9,
                            "peak": 8000.0, "unit": "GB/s", "frac": algo/(dt/args.steps)/1e9/8000.0, "traffic": None, "algorithmic_bytes_per_launch": algo}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             import oracle
             t0 = time.perf_counter(); n = 0
             for f in range(16):
@@ -179,7 +179,7 @@ def main():
             achieved = algo_bytes/(lin_ms*1e-3)/1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                                "frac": achieved/8000.0, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             # the oracle's dense Schur solve is cubic in the keyframes: a bounded instance of the same generator stands in
             import oracle
             small = synth.config_global(n_kf=300, n_pt=30000, band=12)
@@ -221,7 +221,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms * 1e3},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # (the CPU baseline is reported at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(prob, opt)
     if dist is not None:
         dist.barrier()
