@@ -1,51 +1,84 @@
 #!/usr/bin/env python3
-"""bench.py -- local-BA wall-time and residuals/s on the 20 KF x 5k pts x 100 text-plane window.
+"""bench.py -- the two north-star measurements of BASELINE.json, one JSON line on rank 0.
 
-One "step" = one complete optimizer::LocalBundleAdjustment (pyramid passes 2,1,0 x <=10 LM iterations, mu/sigma,
-outlier passes) on a synthetic window that is already resident in HBM when the timed region starts.
+  N = 1 (default)   local BA: wall time and residuals/s of one complete optimizer::LocalBundleAdjustment (pyramid passes
+                    2,1,0 x <= 10 LM iterations, mu/sigma, outlier passes) on the 20 KF x 5000 pts x 100 text-plane window
+                    (SURVEY.md 8d, config C4), the window resident in HBM when the timed region starts.
+  N > 1 (default)   global BA: residuals/s of one complete optimizer::GlobalBA on the synthetic 5000-KF / ~500 k-observation map
+                    (config C6) sharded over the N GPUs (strong scaling: the map is fixed); the line carries the 1-GPU time of
+                    the same map measured in the same run (`scaling_reference`), the RCCL rank count and the bytes every rank
+                    exchanges per LM trial.
+  --workload local_ba | global_ba | orb selects explicitly (local BA and ORB at N > 1 are independent replicas).
+
 residuals/s = scalar residuals evaluated (once per linearisation and once per LM trial step) / wall time.
 
-N > 1: local BA does not shard ("replicas only") -- every rank runs its own window on its own GPU,
-value = sum over ranks (weak scaling), no data-path collective.  `--workload global_ba` runs the sharded global BA.
-
-Prints ONE JSON line on rank 0.
+Launch: `python bench.py --gpus N` spawns the N ranks itself (one process per GPU, RCCL over xGMI); under a launcher that already
+set RANK / LOCAL_RANK / WORLD_SIZE (torch.distributed.run) it is one of the ranks -- --gpus must then agree with WORLD_SIZE.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F64_MFMA_PEAK_TFLOPS = 78.6      # dense fp64 matrix rate (= the fp64 vector rate on this part)
 
-def cpu_baseline(prob, opt_ref, budget_s=30.0):
-    """The CPU restatement of the reference path (oracle, Ceres-style central-difference text Jacobians, 1 thread),
-    timed on this host on a bounded sample of the same window."""
+
+def _pmc_traffic(name):
+    """HBM bytes per launch of a kernel from the PMC passes committed under profiles/ (counters cannot be read from inside the
+    process): 2 x FETCH_SIZE (gfx950 correction of the micro-architecture guide) + WRITE_SIZE."""
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, name))) as f:
+                pm = json.load(f)
+            return (2.0*pm["fetch_size_kb_raw_max"] + pm["write_size_kb_raw_max"])*1024.0, pm["source"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def cpu_baseline_local(prob, opt_ref):
+    """The CPU restatement of the reference path (oracle source, Ceres-style central-difference text Jacobians) timed on this host:
+    the full LocalBundleAdjustment call on the same window, once with the reference's own setting (1 thread: num_threads = 1,
+    optimizer.cc:1600) and once with every host core (OpenMP over the residual blocks).  Built here with -O3 -march=native."""
     import oracle
     from textslam_amd import abi
+    L = oracle.baseline_lib()
     o = abi.TsbaOptions.from_buffer_copy(opt_ref)
     o.text_jacobian = 1                       # NumericDiffCostFunction<CENTRAL>, nume_BAText.h:97-100
-    o.n_passes = 1
-    o.levels[0] = 2                           # first pass of LocalBundleAdjustment (level 2), optimizer.cc:287
-    o.its[0] = opt_ref.its[0]
-    o.chi2_mono[0], o.chi2_text[0] = opt_ref.chi2_mono[0], opt_ref.chi2_text[0]
-    q = prob.copy()
-    t0 = time.perf_counter()
-    rep = oracle.solve(q, o)
-    dt = time.perf_counter() - t0
-    sample = "pass 1 of 3 (pyramid level 2, <=%d LM its) of the same window, numeric-diff text Jacobians" % o.its[0]
-    if dt < budget_s / 6:                     # cheap enough: time the whole call instead
-        o = abi.TsbaOptions.from_buffer_copy(opt_ref)
-        o.text_jacobian = 1
+    cores = os.cpu_count() or 1
+    res = {}
+    for nt in (1, cores):
+        oracle.omp_set_threads(nt)
         q = prob.copy()
-        t0 = time.perf_counter()
-        rep = oracle.solve(q, o)
-        dt = time.perf_counter() - t0
-        sample = "the full LocalBundleAdjustment call (3 passes) on the same window, numeric-diff text Jacobians"
-    return {"value": rep["n_resid_evals"] / dt, "unit": "residuals/s", "cores": 1, "kind": "port",
-            "sample": sample, "seconds": dt}
+        t0 = time.perf_counter(); rep = oracle.solve(q, o, library=L); dt = time.perf_counter() - t0
+        res[nt] = (rep["n_resid_evals"]/dt, dt)
+    return {"value": res[cores][0], "unit": "residuals/s", "cores": cores, "kind": "port",
+            "sample": "the full LocalBundleAdjustment call (3 passes) on the same window, numeric-diff text Jacobians, gcc -O3 -march=native -fopenmp",
+            "seconds": res[cores][1], "single_thread_value": res[1][0], "single_thread_seconds": res[1][1]}
+
+
+def cpu_baseline_global(prob, opt):
+    """The same 5000-keyframe map through the CPU restatement (band storage of H_pp / S + band Cholesky), 1 thread and all cores."""
+    import oracle
+    L = oracle.baseline_lib()
+    cores = os.cpu_count() or 1
+    res = {}
+    for nt in (1, cores):
+        oracle.omp_set_threads(nt)
+        t0 = time.perf_counter(); rep = oracle.solve(prob.copy(), opt, library=L); dt = time.perf_counter() - t0
+        res[nt] = (rep["n_resid_evals"]/dt, dt)
+    best = max(res, key=lambda k: res[k][0])
+    return {"value": res[best][0], "unit": "residuals/s", "cores": best, "kind": "port",
+            "sample": "the complete GlobalBA call (20 LM iterations) on the SAME map; OpenMP parallelises the block evaluation only -- the "
+                      "normal-equation accumulation and the Schur complement of the restatement are serial, so all cores gain little",
+            "seconds": res[best][1], "single_thread_value": res[1][0], "single_thread_seconds": res[1][1],
+            "all_core_value": res[cores][0], "all_cores": cores}
 
 
 def bench_orb(args, rank, local_rank, world, dist, torch):
@@ -78,8 +111,10 @@ def bench_orb(args, rank, local_rank, world, dist, torch):
                "config": {"workload": "ORBextractor(1000,1.2,8,20,7), 64 frames 640x480 per GPU", "frames_per_s": 64*world*args.steps/dt}}
         # whole pipeline against HBM: SURVEY 8d counts 4.7 MB of algorithmic traffic per frame (input + pyramid + blur planes + taps)
         algo = 64*4.7e6
+        traffic, src = _pmc_traffic("orb")
         out["roofline"] = {"bound": "hbm", "kernel": "whole ORB pipeline (pyramid, FAST, quadtree, orientation, blur, rBRIEF)", "achieved": algo*world/(dt/args.steps)/1e9,
-                           "peak": 8000.0, "unit": "GB/s", "frac": algo/(dt/args.steps)/1e9/8000.0, "traffic": None, "algorithmic_bytes_per_launch": algo}
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo/(dt/args.steps)/1e9/HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                           "algorithmic_bytes_per_launch": algo}
         if not args.no_cpu_baseline and world == 1:
             import oracle
             t0 = time.perf_counter(); n = 0
@@ -92,20 +127,47 @@ def bench_orb(args, rank, local_rank, world, dist, torch):
         dist.barrier(); dist.destroy_process_group()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: one child process per GPU; rank 0's JSON line is passed through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0); sys.stdout.flush()
+    if any(rcs):
+        sys.exit("bench.py: rank exit codes %s" % rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="local_ba", choices=["local_ba", "global_ba", "orb"])
+    ap.add_argument("--workload", default=None, choices=["local_ba", "global_ba", "orb"],
+                    help="default: local_ba at 1 GPU, global_ba (the sharded 5000-keyframe map) at N > 1")
     ap.add_argument("--kf", type=int, default=5000, help="global_ba: keyframes (BASELINE configs[4]: 5k KF / 500k observations)")
     ap.add_argument("--pts", type=int, default=70000, help="global_ba: map points (70k points -> ~500k observations)")
+    ap.add_argument("--far", type=float, default=0.0, help="global_ba: fraction of loop-closure-like long-range observations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-single", action="store_true", help="global_ba, N > 1: compare the N-rank result with the 1-rank solve")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return spawn_ranks(args)
+        rank, local_rank, world = 0, 0, 1
+    else:
+        rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            sys.exit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
+    workload = args.workload or ("local_ba" if world == 1 else "global_ba")
     dist = None
     import torch
     if world > 1:
@@ -114,17 +176,45 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    import numpy as np
     from textslam_amd import synth, abi
     from textslam_amd.optimizer import Optimizer
 
-    if args.workload == "orb":
+    if workload == "orb":
         return bench_orb(args, rank, local_rank, world, dist, torch)
     gpu = Optimizer(local_rank)
-    if args.workload == "global_ba":
-        # one global BA sharded by landmark over the ranks: poses replicated, S and g all-reduced over RCCL
-        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=10)      # identical on every rank
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(opt_ctx, steps, warmup, barrier=True):
+        rep = None
+        for _ in range(warmup):
+            rep = opt_ctx.solve()
+        if barrier:
+            sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rep = opt_ctx.solve()                          # synchronous: returns after the last kernel
+        if barrier:
+            sync()
+        return rep, time.perf_counter() - t0
+
+    reference, check = None, None
+    if workload == "global_ba":
+        # one global BA sharded by landmark over the ranks: poses replicated, reduced normal equations exchanged over RCCL
+        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=10, far_frac=args.far)      # identical on every rank
         opt = abi.options_global()
         if world > 1:
+            if rank == 0:                                  # the 1-GPU time of the SAME map, same run: the strong-scaling reference
+                gpu.upload(prob, opt)
+                rep1, dt1 = timed(gpu, args.steps, args.warmup, barrier=False)
+                reference = {"n_gpus": 1, "ms_per_step": dt1/args.steps*1e3, "value": float(rep1["n_resid_evals"])*args.steps/dt1}
+                if args.check_single:
+                    check = gpu.download(prob.copy())
             idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(gpu.comm_unique_id()), dtype=torch.uint8))
@@ -134,27 +224,12 @@ def main():
         prob = synth.config_c4(seed=synth.SEED + rank)    # every replica gets its own window
         opt = abi.options_local()
     gpu.upload(prob, opt)
-
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    rep = None
-    for _ in range(args.warmup):
-        rep = gpu.solve()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rep = gpu.solve()                                  # synchronous: returns after the last kernel
-    sync()
-    dt = time.perf_counter() - t0
+    rep, dt = timed(gpu, args.steps, args.warmup)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        if args.workload == "global_ba":
+        if workload == "global_ba":
             evals_all = float(rep["n_resid_evals"])        # block counts are already global (all-reduced in the library)
         else:
             ev = torch.tensor([float(rep["n_resid_evals"])], dtype=torch.float64, device="cuda")
@@ -162,30 +237,49 @@ def main():
             evals_all = float(ev.item())
     else:
         evals_all = float(rep["n_resid_evals"])
-    ms_per_step = dt / args.steps * 1e3
-    value = evals_all * args.steps / dt
+    ms_per_step = dt/args.steps*1e3
+    value = evals_all*args.steps/dt
+    info = gpu.solver_info()
 
     out = None
-    if rank == 0 and args.workload == "global_ba":
-        out = {"metric": "global_ba_residuals_per_s", "value": value, "unit": "residuals/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "global BA %d KF x %d pts (scene only, 20 LM its, level 0), landmarks sharded over %d GPU(s)"
-                                      % (args.kf, args.pts, world), "lm_iterations": rep["iters"], "scene_blocks": rep["n_sblock"],
-                          "reduced_system_dim": 6*args.kf}}
-        # roofline of the linearisation kernel on this rank's shard (HBM-bound stream of scene blocks, SURVEY 8d: 44 B per block)
-        if world == 1:                                     # (with a communicator the pass set-up all-reduces: every rank would have to take part)
-            lin_ms, algo_bytes = gpu.time_linearize(0, 50)
+    if workload == "global_ba":
+        # every rank takes part in the timed launches of the linearisation (the pass set-up all-reduces in a sharded run)
+        lin_ms, algo_bytes = gpu.time_linearize(0, 50)
+        sol_ms = gpu.time_solve(20) if world == 1 else None
+        ex = gpu.exchange_bytes()
+        if rank == 0:
+            n6 = 6*args.kf
+            out = {"metric": "global_ba_residuals_per_s", "value": value, "unit": "residuals/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                   "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": "C6 global BA: %d KF x %d pts (scene only, 20 LM its, level 0), landmarks sharded over %d GPU(s)"
+                                          % (args.kf, args.pts, world), "lm_iterations": rep["iters"], "scene_blocks": rep["n_sblock"],
+                              "reduced_system_dim": n6, "band_rows": info["band_rows"], "interiors": info["interiors"],
+                              "separator_solver": "cyclic reduction" if info["sep_cr"] else "streaming", "far_frac": args.far,
+                              "rccl_ranks": ex["ranks"], "allreduce_bytes_per_lm_trial": ex["per_trial"],
+                              "allreduce_bytes_per_linearisation": ex["per_linearisation"]}}
+            if reference:
+                out["scaling_reference"] = reference
+                out["config"]["speedup_vs_1gpu_same_run"] = reference["ms_per_step"]/ms_per_step
+            traffic, src = _pmc_traffic("c6_linearize")
             achieved = algo_bytes/(lin_ms*1e-3)/1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                               "frac": achieved/8000.0, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3}
-        if not args.no_cpu_baseline and world == 1:
-            # the oracle's dense Schur solve is cubic in the keyframes: a bounded instance of the same generator stands in
-            import oracle
-            small = synth.config_global(n_kf=300, n_pt=30000, band=12)
-            t0 = time.perf_counter(); rep_o = oracle.solve(small.copy(), opt); dtc = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": rep_o["n_resid_evals"]/dtc, "unit": "residuals/s", "cores": 1, "kind": "port",
-                                   "sample": "the same generator at 300 KF x 30000 pts (the CPU restatement factors the reduced system densely)", "seconds": dtc}
+            out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL,4> (level 0, this rank's shard)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic if world == 1 else None, "traffic_source": src if world == 1 else None,
+                               "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3}
+            if sol_ms is not None:
+                # the dominant phase of an LM trial: the band solve of the reduced camera system -- LDL^T of an n x n band of half width
+                # bw: n (bw^2 + 3 bw) flops + two triangular sweeps 4 n bw
+                bw = info["band_rows"] + 5
+                flops = n6*(bw*bw + 3.0*bw) + 4.0*n6*bw
+                out["roofline_dominant"] = {"bound": "mfma", "kernel": "reduced-system solve (k_bandp_factor + separator solve + back-substitution)",
+                                            "achieved": flops/(sol_ms*1e-3)/1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": flops/(sol_ms*1e-3)/1e12/F64_MFMA_PEAK_TFLOPS, "flops_per_launch": flops, "avg_launch_us": sol_ms*1e3,
+                                            "note": "latency-bound chain (interior factorisation + log2(P) cyclic-reduction levels), not a throughput kernel"}
+            if check is not None:
+                got = gpu.download(prob.copy())
+                out["config"]["max_pose_diff_vs_single_rank"] = float(np.abs(got.pose - check.pose).max())
+            if not args.no_cpu_baseline and world == 1:
+                out["cpu_baseline"] = cpu_baseline_global(prob, opt)
     elif rank == 0:
         # the same window through the one-shot ABI entry point (what the TextSLAM adapter calls per keyframe)
         cold = []
@@ -193,19 +287,15 @@ def main():
             g2 = prob.copy(); tc = time.perf_counter(); gpu.LocalBundleAdjustment(g2, options=opt); cold.append((time.perf_counter() - tc)*1e3)
         cold_ms = min(cold)
         gpu.upload(prob, opt)
+        gpu.solve()
         # roofline of the linearisation kernel (residual + Jacobian + IRLS weight + J^T J / J^T r sums), level 0
         lin_ms, algo_bytes = gpu.time_linearize(0, 200)
-        achieved = algo_bytes / (lin_ms * 1e-3) / 1e9
-        # HBM traffic of the same kernel from the PMC passes committed under profiles/ (counters cannot be read from inside
-        # the process): 2 x FETCH_SIZE (gfx950 correction of the micro-architecture guide) + WRITE_SIZE, bytes per launch
-        traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c4_pmc_traffic.json")) as f:
-                pm = json.load(f)
-            traffic = (2.0 * pm["fetch_size_kb_raw_max"] + pm["write_size_kb_raw_max"]) * 1024.0
-            traffic_src = pm["source"]
-        except (OSError, KeyError, ValueError):
-            pass
+        achieved = algo_bytes/(lin_ms*1e-3)/1e9
+        traffic, traffic_src = _pmc_traffic("c4")
+        gpu.solve()
+        sol_ms = gpu.time_solve(200)
+        n = 6*(prob.n_kf - 3)                                      # 17 free poses: the first three keyframes of the window are the gauge
+        flops = n**3/3.0 + 4.0*n*n                                 # LDL^T + forward / backward substitution
         out = {
             "metric": "local_ba_residuals_per_s", "value": value, "unit": "residuals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -217,12 +307,16 @@ def main():
                        "lm_iterations": rep["iters"], "resid_evals_per_call": rep["n_resid_evals"]},
             "local_ba_wall_ms": ms_per_step,
             "local_ba_cold_call_ms": cold_ms,          # PCIe-inclusive: plan construction + upload + solve + download (never `value`)
-            "roofline": {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms * 1e3},
+            "roofline": {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3},
+            "roofline_dominant": {"bound": "mfma", "kernel": "reduced-system solve (%d x %d LDL^T in LDS), the largest share of an LM iteration" % (n, n),
+                                  "achieved": flops/(sol_ms*1e-3)/1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": flops/(sol_ms*1e-3)/1e12/F64_MFMA_PEAK_TFLOPS, "flops_per_launch": flops, "avg_launch_us": sol_ms*1e3,
+                                  "note": "a dependent chain of %d pivots inside one workgroup: latency-bound, the FLOP fraction is not its figure of merit" % n},
         }
         if not args.no_cpu_baseline and world == 1:        # (the CPU baseline is reported at N = 1 only)
-            out["cpu_baseline"] = cpu_baseline(prob, opt)
+            out["cpu_baseline"] = cpu_baseline_local(prob, opt)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

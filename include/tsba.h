@@ -144,6 +144,8 @@ typedef struct tsba_report {
     int64_t n_resid_evals;                 /* scalar residuals evaluated, one count per LM trial step + linearisation */
     int32_t n_bad_scene[TSBA_MAX_LEVELS], n_bad_tfeat[TSBA_MAX_LEVELS], n_bad_text[TSBA_MAX_LEVELS];
     double  t_upload_ms, t_solve_ms, t_download_ms;
+    int32_t cov_valid;                     /* tsba_theta_optim: 1 = cov[] was written, 0 = singular information matrix (cov untouched) */
+    int32_t reserved_;
 } tsba_report;
 
 /* Reference defaults for the three public methods. */
@@ -173,7 +175,9 @@ int  tsba_pose_optim(void *ctx, tsba_problem *p, const tsba_options *o, tsba_rep
 int  tsba_global_ba (void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r);
 /* optimizer::ThetaOptimMultiFs: solve (normally with tsba_default_options_theta) and return the covariance of theta[text]
  * = (J^T J)^-1 of its residual blocks at the solution (ceres::Covariance, optimizer.cc:2219-2238), row-major 3x3.
- * Returns TSBA_ERR_NUMERIC when the information matrix is singular (the reference returns false). */
+ * A singular information matrix is NOT an error, as in the reference: PyrThetaOptim returns true and leaves thetaVariance
+ * as it was when Covariance::Compute fails (optimizer.cc:2224-2241) -- the call returns TSBA_OK, cov[] is left untouched and
+ * r->cov_valid = 0 (1 when cov[] was written). */
 int  tsba_theta_optim(void *ctx, tsba_problem *p, const tsba_options *o, int text, double cov[9], tsba_report *r);
 
 /* Text label image of keyframe `kf` at pyramid level `level` for the state left by the last solve on this context (one-shot
@@ -208,10 +212,39 @@ int  tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int leve
  * (the pose step S dp = -g).  Any output may be NULL. */
 int  tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, double *cost, int32_t *kf_free, double *dp);
 
+/* The same for large maps (band storage of the reduced system; the dense copy would be 7.2 GB at 5000 keyframes): n = 6 x free poses,
+ * bw = sub-diagonals kept, ab[(i - j)*n + j] = S(i, j) for j <= i <= j + bw (LAPACK lower band, rows of the COMPRESSED free-pose
+ * system), g [n], dp [6 n_kf] (by keyframe, 0 for constant poses).  ab / g / dp may be NULL (first call: sizes only). */
+int  tsba_debug_reduced_band(void *ctx, double radius, int32_t *n, int32_t *bw, double *ab, double *g, double *dp);
+
+/* Which kernels the uploaded problem runs through, so that a test can assert it exercises the path it means to.  out[11]:
+ * [0] reduced system solved in LDS  [1] band storage of S  [2] streaming band solver  [3] interiors P of the partitioned solver
+ * [4] separator system by cyclic reduction  [5] band rows  [6] four (target, host) pairs per wave in the linearisation
+ * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] small-system solver variant */
+int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
+
 /* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
  * equation accumulation) over n launches on the library's stream, measured with HIP events.
  * Requires an uploaded problem; `level` selects the pass.  Also returns the algorithmic bytes of one launch. */
 int  tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *algo_bytes);
+
+/* Average duration (ms) of the reduced-system solve (every kernel between the Schur complement and the landmark back-substitution)
+ * over n repetitions on the S, g left by the last solve / tsba_debug_reduced_system; HIP events on the library's stream. */
+int  tsba_debug_time_solve(void *ctx, int n, double *avg_ms);
+
+/* Test / diagnostics switches of one context (never read from the environment; all zero = production behaviour).  They select
+ * between solver paths that are all exact -- none of them changes what is computed, only by which kernels. */
+typedef struct tsba_debug_options {
+    int32_t band_parts;        /* > 0: number of interiors of the partitioned band solver (1 = single-workgroup streaming solver) */
+    int32_t sep_solver;        /* separator system: 0 cost model, 1 sequential streaming solver, 2 block cyclic reduction */
+    int32_t no_band_stream;    /* 1: large systems through the wide-band multi-workgroup Cholesky even when the band is narrow */
+    int32_t no_pose_kernel;    /* 1: PoseOptim through the general pipeline instead of the fused pose-only kernel */
+    int32_t no_small_pairs;    /* 1: never put four (target, host) pairs on one wave of the linearisation */
+    int32_t small_solver;      /* reduced systems that fit the LDS: 0 default, 1 blocked 6x6 LDL^T (k_solve_t), 2 column LDL^T (k_solve_col) */
+    int32_t verbose;           /* 1: host-side timing of upload / plan construction on stderr */
+    int32_t reserved[9];
+} tsba_debug_options;
+int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 
 /* ---- multi-GPU: RCCL communicator for tsba_global_ba (one process per GPU) ---- */
 /* One process per GPU.  Rank 0 calls tsba_comm_unique_id and broadcasts the 128 bytes (e.g. torch.distributed); every rank
@@ -220,6 +253,16 @@ int  tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *al
  * id128 == NULL selects the split (multi-GPU) kernel sequence without a communicator (single-process test hook). */
 int  tsba_comm_unique_id(void *ctx, void *id128);
 int  tsba_comm_init(void *ctx, const void *id128, int rank, int world);
+/* What the last solve handed to collectives on this rank: ranks = size of the communicator (ncclCommCount; 1 without one),
+ * bytes[0] per LM trial (reduced normal equations + the sums of the speculative linearisation), bytes[1] per linearisation,
+ * bytes[2] per pass set-up. */
+int  tsba_comm_stats(void *ctx, int32_t *ranks, int64_t bytes[3]);
+/* The same rank / world protocol WITHOUT RCCL, for `world` contexts of ONE process (one host thread per context, on the same or on
+ * different GPUs): the collectives go through host memory, summed in rank order.  Test hook: the N > 1 code path on a one-GPU box.
+ * group: from tsba_local_group_create(world); every member thread calls tsba_comm_init_local, then upload / solve in lockstep. */
+void *tsba_local_group_create(int world);
+void  tsba_local_group_destroy(void *group);
+int  tsba_comm_init_local(void *ctx, void *group, int rank, int world);
 
 #ifdef __cplusplus
 }

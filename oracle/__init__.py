@@ -82,13 +82,50 @@ def evaluate(prob: BAProblem, opt: TsbaOptions, level: int, jac=True):
     return out
 
 
-def solve(prob: BAProblem, opt: TsbaOptions):
-    """In-place solve of `prob` (parameters and good flags are overwritten). Returns the report dict."""
+def solve(prob: BAProblem, opt: TsbaOptions, library=None):
+    """In-place solve of `prob` (parameters and good flags are overwritten). Returns the report dict.
+    library: another build of the same source (baseline_lib()); default = the parity build."""
     s = prob.struct()
     rep = TsbaReport()
-    rc = lib().tsba_oracle_solve(C.byref(s), C.byref(opt), C.byref(rep))
+    rc = (library or lib()).tsba_oracle_solve(C.byref(s), C.byref(opt), C.byref(rep))
     assert rc == 0, rc
     return rep.as_dict()
+
+
+def set_band_threshold(nf, library=None):
+    """Keyframe count from which the solver keeps H_pp / S as a band instead of dense (default 400); tests force either mode."""
+    L = library or lib()
+    L.tsba_oracle_set_band_threshold.argtypes = [C.c_int]
+    L.tsba_oracle_set_band_threshold.restype = None
+    L.tsba_oracle_set_band_threshold(int(nf))
+
+
+_FAST = None
+
+
+def baseline_lib():
+    """bench.py's cpu_baseline leg only: the SAME source compiled for speed on the host it runs on (-O3 -march=native -fopenmp,
+    FMA contraction allowed), into oracle/_fast/ (git-ignored, built where it is used: -march=native code must not travel).
+    OpenMP parallelises the residual / Jacobian evaluation over the blocks; OMP_NUM_THREADS=1 gives the reference's own
+    single-thread setting (num_threads = 1, optimizer.cc:1600).  Never used as a parity checker."""
+    global _FAST
+    if _FAST is None:
+        d = os.path.join(_HERE, "_fast")
+        os.makedirs(d, exist_ok=True)
+        so = os.path.join(d, "libtsba_oracle_omp.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=c11", "-shared", "-o", so,
+                               os.path.join(_HERE, "tsba_oracle.c"), "-lm"])
+        L = C.CDLL(so)
+        L.tsba_oracle_solve.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.POINTER(TsbaReport)]
+        L.tsba_oracle_solve.restype = C.c_int
+        _FAST = L
+    return _FAST
+
+
+def omp_set_threads(n):
+    """Thread count of the baseline build's OpenMP runtime (libgomp is loaded with it)."""
+    g = C.CDLL("libgomp.so.1")
+    g.omp_set_num_threads(int(n))
 
 
 def musigma(img: np.ndarray, corners: np.ndarray):

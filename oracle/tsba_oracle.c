@@ -658,7 +658,9 @@ int tsba_oracle_eval(const tsba_problem *p, const tsba_options *o, int level,
 typedef struct { int col; double W[18]; } lm_entry;     /* 6 x d block of J_pose^T J_lm, row-major 6 x 3 */
 typedef struct {
     int nf, nlm;
-    double *Hpp, *bp;                  /* (6nf)^2, 6nf */
+    int bw;                            /* -1: Hpp dense (6nf)^2; >= 0: lower band, Hpp[a*(bw+1) + (a-c)] = H(a, c) for a-bw <= c <= a
+                                          (maps of thousands of keyframes: the dense matrix would be 7 GB at 5000 keyframes) */
+    double *Hpp, *bp;                  /* (6nf)^2 or 6nf x (bw+1), 6nf */
     double *V, *bl; int *dim;          /* per landmark: 3x3, 3, d */
     lm_entry *ent; int *ent_off, *ent_cnt;
     double cost;
@@ -670,10 +672,34 @@ static lm_entry *lm_find(neq_t *N, int li, int col) {
     e += N->ent_cnt[li]++; e->col = col; memset(e->W, 0, sizeof(e->W)); return e;
 }
 
-static void neq_alloc(neq_t *N, const pass_t *P) {
+/* keyframe count from which run_pass keeps H_pp / S as a band (tsba_oracle_set_band_threshold: tests force either mode) */
+static int g_band_min_nf = 400;
+void tsba_oracle_set_band_threshold(int nf) { g_band_min_nf = nf; }
+
+static inline void hpp_add(neq_t *N, int n6, int r, int c, double v) {
+    if (N->bw < 0) N->Hpp[(size_t)r*n6 + c] += v;
+    else if (r >= c) N->Hpp[(size_t)r*(N->bw + 1) + (r - c)] += v;        /* band: the lower triangle only */
+}
+static inline double hpp_diag(const neq_t *N, int n6, int a) { return N->bw < 0 ? N->Hpp[(size_t)a*n6 + a] : N->Hpp[(size_t)a*(N->bw + 1)]; }
+
+static void neq_alloc(neq_t *N, const pass_t *P, int band) {
     memset(N, 0, sizeof(*N));
     N->nf = P->nf; N->nlm = P->nlm; int n6 = 6*N->nf;
-    N->Hpp = (double *)calloc((size_t)n6*n6 + 1, sizeof(double)); N->bp = (double *)calloc((size_t)n6 + 1, sizeof(double));
+    N->bw = -1;
+    if (band) {      /* half bandwidth: a landmark couples every pair of its free poses (Cholesky without pivoting keeps the band) */
+        int *lo = (int *)malloc(sizeof(int)*((size_t)N->nlm + 1)), *hi = (int *)malloc(sizeof(int)*((size_t)N->nlm + 1)), bwb = 0;
+        for (int i = 0; i < N->nlm; i++) { lo[i] = N->nf; hi[i] = -1; }
+        for (int i = 0; i < P->nblk; i++) { const blk_t *b = &P->blk[i];
+            int ct = P->free_idx[b->kf], ch = b->host >= 0 ? P->free_idx[b->host] : -1;
+            int li = b->type == BLK_SCENE_BA ? P->pt_lm[b->lm] : (b->type == BLK_TEXT_BA ? P->tx_lm[b->lm] : -1);
+            if (ct >= 0 && ch >= 0 && abs(ct - ch) > bwb) bwb = abs(ct - ch);
+            if (li >= 0) { if (ct >= 0) { if (ct < lo[li]) lo[li] = ct; if (ct > hi[li]) hi[li] = ct; }
+                           if (ch >= 0) { if (ch < lo[li]) lo[li] = ch; if (ch > hi[li]) hi[li] = ch; } } }
+        for (int i = 0; i < N->nlm; i++) if (hi[i] >= 0 && hi[i] - lo[i] > bwb) bwb = hi[i] - lo[i];
+        free(lo); free(hi);
+        N->bw = 6*bwb + 5;
+    }
+    N->Hpp = (double *)calloc((N->bw < 0 ? (size_t)n6*n6 : (size_t)n6*(N->bw + 1)) + 1, sizeof(double)); N->bp = (double *)calloc((size_t)n6 + 1, sizeof(double));
     N->V = (double *)calloc((size_t)9*N->nlm + 1, sizeof(double)); N->bl = (double *)calloc((size_t)3*N->nlm + 1, sizeof(double));
     N->dim = (int *)calloc((size_t)N->nlm + 1, sizeof(int));
     N->ent_off = (int *)calloc((size_t)N->nlm + 1, sizeof(int)); N->ent_cnt = (int *)calloc((size_t)N->nlm + 1, sizeof(int));
@@ -698,21 +724,52 @@ static int blk_in_shard(const pass_t *P, const blk_t *b) {
 /* linearise at (pose,rho,theta): loss-corrected J^T J, J^T r.  Optionally keep corrected (r,J) per block for the model-cost test. */
 static void linearize(const pass_t *P, const double *pose, const double *rho, const double *theta, neq_t *N, double *keep) {
     int n6 = 6*N->nf;
-    memset(N->Hpp, 0, sizeof(double)*(size_t)n6*n6); memset(N->bp, 0, sizeof(double)*(size_t)n6);
+    memset(N->Hpp, 0, sizeof(double)*(N->bw < 0 ? (size_t)n6*n6 : (size_t)n6*(N->bw + 1))); memset(N->bp, 0, sizeof(double)*(size_t)n6);
     memset(N->V, 0, sizeof(double)*9*(size_t)N->nlm); memset(N->bl, 0, sizeof(double)*3*(size_t)N->nlm);
     memset(N->ent_cnt, 0, sizeof(int)*(size_t)N->nlm);
     N->cost = 0;
+#ifdef _OPENMP
+    /* all-core CPU baseline build only (bench.py: gcc -fopenmp): the residual / Jacobian evaluation of the blocks -- the expensive
+     * part, numeric differentiation of the text blocks above all -- in parallel into `keep`; the accumulation below stays serial
+     * and in block order, so the sums are those of the single-thread build */
+    double *bcost = NULL;
+    if (keep) {
+        bcost = (double *)malloc(sizeof(double)*((size_t)P->nblk + 1));
+        #pragma omp parallel for schedule(dynamic, 64)
+        for (int i = 0; i < P->nblk; i++) {
+            const blk_t *b = &P->blk[i];
+            double *kp = keep + (size_t)i*128; bcost[i] = 0;
+            if (b->fixed || !blk_in_shard(P, b)) { memset(kp, 0, sizeof(double)*128); continue; }
+            double r[8], Jt[48], Jh[48], Jl[24];
+            blk_eval(P, b, pose, rho, theta, r, Jt, Jh, Jl);
+            double s = 0; for (int k = 0; k < b->nres; k++) s += r[k]*r[k];
+            double scale, delta = b->nres == 2 ? P->o->huber_scene : P->o->huber_text;
+            bcost[i] = 0.5*huber(s, delta, &scale);
+            for (int k = 0; k < b->nres; k++) { r[k] *= scale; for (int c = 0; c < 6; c++) { Jt[k*6+c] *= scale; Jh[k*6+c] *= scale; } for (int c = 0; c < 3; c++) Jl[k*3+c] *= scale; }
+            memcpy(kp, r, 64); memcpy(kp + 8, Jt, 384); memcpy(kp + 56, Jh, 384); memcpy(kp + 104, Jl, 192);
+        }
+    }
+#endif
     for (int i = 0; i < P->nblk; i++) {
         const blk_t *b = &P->blk[i];
         double *kp = keep ? keep + (size_t)i*(8 + 48 + 48 + 24) : NULL;
-        if (b->fixed || !blk_in_shard(P, b)) { if (kp) memset(kp, 0, sizeof(double)*128); continue; }
         double r[8], Jt[48], Jh[48], Jl[24];
+#ifdef _OPENMP
+        if (bcost) {
+            if (b->fixed || !blk_in_shard(P, b)) continue;
+            N->cost += bcost[i];
+            memcpy(r, kp, 64); memcpy(Jt, kp + 8, 384); memcpy(Jh, kp + 56, 384); memcpy(Jl, kp + 104, 192);
+        } else
+#endif
+        {
+        if (b->fixed || !blk_in_shard(P, b)) { if (kp) memset(kp, 0, sizeof(double)*128); continue; }
         blk_eval(P, b, pose, rho, theta, r, Jt, Jh, Jl);
         double s = 0; for (int k = 0; k < b->nres; k++) s += r[k]*r[k];
         double scale, delta = b->nres == 2 ? P->o->huber_scene : P->o->huber_text;
         N->cost += 0.5*huber(s, delta, &scale);
         for (int k = 0; k < b->nres; k++) { r[k] *= scale; for (int c = 0; c < 6; c++) { Jt[k*6+c] *= scale; Jh[k*6+c] *= scale; } for (int c = 0; c < 3; c++) Jl[k*3+c] *= scale; }
         if (kp) { memcpy(kp, r, 64); memcpy(kp + 8, Jt, 384); memcpy(kp + 56, Jh, 384); memcpy(kp + 104, Jl, 192); }
+        }
         int ct = P->free_idx[b->kf], ch = b->host >= 0 ? P->free_idx[b->host] : -1;
         int has_lm = (b->type == BLK_SCENE_BA || b->type == BLK_TEXT_BA);
         int d = b->nres == 2 ? 1 : 3;
@@ -720,11 +777,11 @@ static void linearize(const pass_t *P, const double *pose, const double *rho, co
         for (int k = 0; k < b->nres; k++) {
             const double *jt = Jt + 6*k, *jh = Jh + 6*k, *jl = Jl + 3*k;
             if (ct >= 0) {
-                for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) N->Hpp[(size_t)(6*ct + a)*n6 + 6*ct + c] += jt[a]*jt[c]; N->bp[6*ct + a] += jt[a]*r[k]; }
+                for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) hpp_add(N, n6, 6*ct + a, 6*ct + c, jt[a]*jt[c]); N->bp[6*ct + a] += jt[a]*r[k]; }
                 if (ch >= 0) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
-                    N->Hpp[(size_t)(6*ct + a)*n6 + 6*ch + c] += jt[a]*jh[c]; N->Hpp[(size_t)(6*ch + c)*n6 + 6*ct + a] += jt[a]*jh[c]; }
+                    hpp_add(N, n6, 6*ct + a, 6*ch + c, jt[a]*jh[c]); hpp_add(N, n6, 6*ch + c, 6*ct + a, jt[a]*jh[c]); }
             }
-            if (ch >= 0) for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) N->Hpp[(size_t)(6*ch + a)*n6 + 6*ch + c] += jh[a]*jh[c]; N->bp[6*ch + a] += jh[a]*r[k]; }
+            if (ch >= 0) for (int a = 0; a < 6; a++) { for (int c = 0; c < 6; c++) hpp_add(N, n6, 6*ch + a, 6*ch + c, jh[a]*jh[c]); N->bp[6*ch + a] += jh[a]*r[k]; }
             if (has_lm) {
                 for (int a = 0; a < d; a++) { for (int c = 0; c < d; c++) N->V[9*li + 3*a + c] += jl[a]*jl[c]; N->bl[3*li + a] += jl[a]*r[k]; }
                 if (ct >= 0) { lm_entry *e = lm_find(N, li, ct); for (int a = 0; a < 6; a++) for (int c = 0; c < d; c++) e->W[3*a + c] += jt[a]*jl[c]; }
@@ -732,11 +789,17 @@ static void linearize(const pass_t *P, const double *pose, const double *rho, co
             }
         }
     }
+#ifdef _OPENMP
+    free(bcost);
+#endif
 }
 
 /* cost only (EvaluateCost at a candidate) */
 static double eval_cost(const pass_t *P, const double *pose, const double *rho, const double *theta) {
     double cost = 0;
+#ifdef _OPENMP
+    #pragma omp parallel for schedule(static) reduction(+:cost)     /* (baseline build only: the summation order differs from the serial build) */
+#endif
     for (int i = 0; i < P->nblk; i++) {
         const blk_t *b = &P->blk[i]; if (b->fixed || !blk_in_shard(P, b)) continue;
         double r[8]; blk_residual(P, b, pose, rho, theta, r);
@@ -825,6 +888,63 @@ static int schur_solve(const neq_t *N, const double *sp, const double *sl, const
     return rc;
 }
 
+/* The same for a band H_pp (N->bw >= 0): S as a lower band, band Cholesky (no fill outside the band), the sums over exactly the
+ * structurally non-zero terms of the dense variant in the same order -- the two variants agree to the last bit up to signed zeros. */
+static int schur_solve_band(const neq_t *N, const double *sp, const double *sl, const double *dgp, const double *dgl, double radius,
+                            double *yp, double *yl) {
+    const int n6 = 6*N->nf, bw = N->bw, ld = bw + 1;
+    double *S = (double *)calloc((size_t)n6*ld + 1, sizeof(double)), *g = (double *)malloc(sizeof(double)*((size_t)n6 + 1));
+    #define SB(a, c) S[(size_t)(a)*ld + ((a) - (c))]
+    for (int a = 0; a < n6; a++) { for (int c = a - bw < 0 ? 0 : a - bw; c <= a; c++) SB(a, c) = sp[a]*sp[c]*N->Hpp[(size_t)a*ld + (a - c)]; SB(a, a) += dgp[a]/radius; g[a] = sp[a]*N->bp[a]; }
+    double *Vinv = (double *)malloc(sizeof(double)*(9*(size_t)N->nlm + 1));
+    int rc = 0;
+    for (int li = 0; li < N->nlm && !rc; li++) {
+        int d = N->dim[li]; if (d == 0) continue;
+        double Vs[9] = {0}, bs[3];
+        for (int a = 0; a < d; a++) { for (int c = 0; c < d; c++) Vs[3*a + c] = sl[3*li + a]*sl[3*li + c]*N->V[9*li + 3*a + c]; Vs[3*a + a] += dgl[3*li + a]/radius; bs[a] = sl[3*li + a]*N->bl[3*li + a]; }
+        if (inv_sym(Vs, d, Vinv + 9*li)) { rc = -1; break; }
+        const double *Vi = Vinv + 9*li;
+        const lm_entry *e = N->ent + N->ent_off[li]; int ne = N->ent_cnt[li];
+        for (int i = 0; i < ne; i++) {
+            double WV[18];
+            for (int a = 0; a < 6; a++) for (int c = 0; c < d; c++) { double s = 0; for (int k = 0; k < d; k++) s += sp[6*e[i].col + a]*e[i].W[3*a + k]*sl[3*li + k]*Vi[3*k + c]; WV[3*a + c] = s; }
+            for (int a = 0; a < 6; a++) { double s = 0; for (int c = 0; c < d; c++) s += WV[3*a + c]*bs[c]; g[6*e[i].col + a] -= s; }
+            for (int j = 0; j < ne; j++)
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { const int rr = 6*e[i].col + a, cc = 6*e[j].col + c; if (rr < cc) continue;
+                    double s = 0; for (int k = 0; k < d; k++) s += WV[3*a + k]*sp[cc]*e[j].W[3*c + k]*sl[3*li + k]; SB(rr, cc) -= s; }
+        }
+    }
+    if (!rc) {
+        for (int j = 0; j < n6 && !rc; j++) {                      /* band Cholesky, lower, in place */
+            double dj = SB(j, j);
+            for (int k = j - bw < 0 ? 0 : j - bw; k < j; k++) dj -= SB(j, k)*SB(j, k);
+            if (!(dj > 0)) { rc = -1; break; }
+            dj = sqrt(dj); SB(j, j) = dj;
+            const int iend = j + bw < n6 - 1 ? j + bw : n6 - 1;
+            for (int i = j + 1; i <= iend; i++) { double s = SB(i, j);
+                for (int k = i - bw < 0 ? 0 : i - bw; k < j; k++) s -= SB(i, k)*SB(j, k);
+                SB(i, j) = s/dj; }
+        }
+    }
+    if (!rc) {
+        for (int a = 0; a < n6; a++) yp[a] = -g[a];
+        for (int i = 0; i < n6; i++) { double s = yp[i]; for (int k = i - bw < 0 ? 0 : i - bw; k < i; k++) s -= SB(i, k)*yp[k]; yp[i] = s/SB(i, i); }
+        for (int i = n6 - 1; i >= 0; i--) { double s = yp[i]; const int kend = i + bw < n6 - 1 ? i + bw : n6 - 1; for (int k = i + 1; k <= kend; k++) s -= SB(k, i)*yp[k]; yp[i] = s/SB(i, i); }
+        for (int li = 0; li < N->nlm; li++) {
+            int d = N->dim[li]; if (d == 0) { yl[3*li] = yl[3*li+1] = yl[3*li+2] = 0; continue; }
+            double rhs[3];
+            for (int a = 0; a < d; a++) rhs[a] = -sl[3*li + a]*N->bl[3*li + a];
+            const lm_entry *e = N->ent + N->ent_off[li];
+            for (int i = 0; i < N->ent_cnt[li]; i++) for (int k = 0; k < d; k++) { double s = 0; for (int a = 0; a < 6; a++) s += sp[6*e[i].col + a]*e[i].W[3*a + k]*yp[6*e[i].col + a]; rhs[k] -= sl[3*li + k]*s; }
+            for (int a = 0; a < d; a++) { double s = 0; for (int c = 0; c < d; c++) s += Vinv[9*li + 3*a + c]*rhs[c]; yl[3*li + a] = s; }
+            for (int a = d; a < 3; a++) yl[3*li + a] = 0;
+        }
+    }
+    #undef SB
+    free(S); free(g); free(Vinv);
+    return rc;
+}
+
 static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* x (+) delta over the reduced program */
@@ -850,7 +970,7 @@ static double reduced_norm(const pass_t *P, const double *pose, const double *rh
 static void jacobi_and_diag(const neq_t *N, double *sp, double *sl, int compute_scale, double *dgp, double *dgl, const tsba_options *o) {
     int n6 = 6*N->nf;
     for (int a = 0; a < n6; a++) {
-        double h = N->Hpp[(size_t)a*n6 + a];
+        double h = hpp_diag(N, n6, a);
         if (compute_scale) sp[a] = 1.0/(1.0 + sqrt(h));
         dgp[a] = clampd(sp[a]*sp[a]*h, o->min_diagonal, o->max_diagonal);
     }
@@ -865,7 +985,7 @@ int tsba_oracle_reduced_system(const tsba_problem *p, const tsba_options *o, int
                                int32_t *free_idx, double *S, double *g, double *Hpp, double *bp, double *cost) {
     if (!p || !o || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
     pass_t P; pass_build(&P, p, o, level);
-    neq_t N; neq_alloc(&N, &P);
+    neq_t N; neq_alloc(&N, &P, 0);
     linearize(&P, p->pose, p->rho, p->theta, &N, NULL);
     int n6 = 6*N.nf;
     double *sp = (double *)malloc(sizeof(double)*(n6 + 1)), *dgp = (double *)malloc(sizeof(double)*(n6 + 1));
@@ -893,7 +1013,7 @@ int tsba_oracle_partial_system(const tsba_problem *p, const tsba_options *o, int
                                int32_t *free_idx, double *S, double *g, double *Hd, double *cost) {
     if (!p || !o || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
     pass_t P; pass_build(&P, p, o, level);
-    neq_t N; neq_alloc(&N, &P);
+    neq_t N; neq_alloc(&N, &P, 0);
     linearize(&P, p->pose, p->rho, p->theta, &N, NULL);
     int n6 = 6*N.nf;
     double *sp = (double *)malloc(sizeof(double)*(n6 + 1)), *dgp = (double *)calloc(n6 + 1, sizeof(double));
@@ -933,7 +1053,7 @@ int tsba_oracle_theta_cov(const tsba_problem *p, const tsba_options *o, int leve
 static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_report *rep, int cov_text, double *cov_out, int *cov_rc) {
     int level = o->levels[pass], max_it = o->its[pass];
     pass_t P; pass_build(&P, p, o, level);
-    neq_t N; neq_alloc(&N, &P);
+    neq_t N; neq_alloc(&N, &P, P.nf >= g_band_min_nf);
     int n6 = 6*N.nf; size_t nl3 = 3*(size_t)N.nlm;
     size_t npose = 7*(size_t)p->n_kf, nrho = (size_t)p->n_pt, nth = 3*(size_t)p->n_text;
     double *x_pose = (double *)malloc(sizeof(double)*(npose + 1)), *x_rho = (double *)malloc(sizeof(double)*(nrho + 1)), *x_th = (double *)malloc(sizeof(double)*(nth + 1));
@@ -962,7 +1082,7 @@ static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_repor
         if (radius < o->min_radius) { term = 4; break; }
         it++;
         if (!reuse_diag) jacobi_and_diag(&N, sp, sl, 0, dgp, dgl, o);
-        int rc = schur_solve(&N, sp, sl, dgp, dgl, radius, yp, yl, NULL, NULL);
+        int rc = N.bw < 0 ? schur_solve(&N, sp, sl, dgp, dgl, radius, yp, yl, NULL, NULL) : schur_solve_band(&N, sp, sl, dgp, dgl, radius, yp, yl);
         double model_change = -1;
         if (!rc) {
             for (int a = 0; a < n6; a++) dp[a] = sp[a]*yp[a];

@@ -1,0 +1,280 @@
+"""GPU parity tests of the global-BA paths (BASELINE configs 3 and 4) -- every solver the bench lines run through, under a checker.
+
+  * partitioned band solver with the separator system by block cyclic reduction (tsba_bandcr.h), forced through tsba_debug_set:
+    first LM step against scipy's banded Cholesky on the downloaded band, full trajectory against the sequential-separator and
+    the single-workgroup streaming solvers;
+  * config 4 at full size (5000 KF / ~500 k scene blocks): first step against scipy.linalg.solveh_banded, size-independent
+    properties of the solve (cost decrease, unit quaternions, gauge, bit-reproducibility);
+  * config 3 WITH text planes: parity with the oracle at 60 KF / 40 planes, properties at 500 KF x 50 k points x 1000 planes;
+  * the landmark shards of the multi-GPU path on ONE device: partial S, g of nshard = 2, 3 sum to the unsharded system, and the
+    whole N-rank solve (in-process communicator, one thread per rank) reproduces the 1-rank solve.
+"""
+import threading
+import numpy as np
+import pytest
+from scipy.linalg import solveh_banded
+
+from textslam_amd import synth, abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from textslam_amd.optimizer import Optimizer
+    g = Optimizer(0)
+    yield g
+    g.close()
+
+
+def _free_rows(free):
+    kf = np.nonzero(free)[0]
+    return np.concatenate([np.arange(6*k, 6*k + 6) for k in kf])
+
+
+def _check_first_step_banded(gpu, o):
+    rb = gpu.reduced_band(o.initial_radius)
+    assert np.abs(rb["ab"][0]).min() > 0                              # (the band solvers leave S intact)
+    ref = -solveh_banded(rb["ab"], rb["g"], lower=True)
+    got = rb["dp"][_free_rows(rb["free"])]
+    assert got.size == ref.size == rb["n"]
+    err = np.abs(got - ref).max()/np.abs(ref).max()
+    assert err <= 1e-8, err
+    return rb
+
+
+def _same_trajectory(rep1, rep2, G1, G2, atol=1e-9):
+    assert rep1["iters"] == rep2["iters"] and rep1["accepted"] == rep2["accepted"] and rep1["termination"] == rep2["termination"]
+    np.testing.assert_allclose(rep1["cost1"], rep2["cost1"], rtol=1e-9)
+    np.testing.assert_allclose(G1.pose, G2.pose, rtol=0, atol=atol)
+    np.testing.assert_allclose(G1.rho, G2.rho, rtol=0, atol=atol)
+
+
+@pytest.mark.parametrize("n_kf,band,parts", [(600, 6, 8), (900, 9, 17), (1100, 12, 11), (1500, 10, 27)])
+def test_cyclic_reduction_separator_solver(gpu, n_kf, band, parts):
+    """tsba_bandcr.h (k_cr_pivot / k_cr_update / k_cr_back) forced at sizes where the cost model would pick the sequential
+    separator solve: separators of 6 .. 12 pose blocks, 7 .. 26 of them (odd and even counts, not powers of two)."""
+    P = synth.config_global(n_kf=n_kf, n_pt=40*n_kf, band=band)
+    o = abi.options_global(); o.its[0] = 5
+    try:
+        gpu.debug_set(band_parts=parts, sep_solver=2)
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        assert info["band_stream"] == 1 and info["sep_cr"] == 1 and info["interiors"] == parts, info
+        _check_first_step_banded(gpu, o)
+        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+        assert rep1["accepted"][0] >= 3 and rep1["termination"][0] != 5 and rep1["cost1"][0] < rep1["cost0"][0]
+        gpu.debug_set(band_parts=parts, sep_solver=1)                   # same interiors, separator system by the streaming solver
+        gpu.upload(P, o); assert gpu.solver_info()["sep_cr"] == 0
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        _same_trajectory(rep1, rep2, G1, G2)
+        gpu.debug_set(band_parts=1)                                     # single-workgroup streaming solver
+        G3 = P.copy(); rep3 = gpu.GlobalBA(G3, options=o)
+        _same_trajectory(rep1, rep3, G1, G3)
+    finally:
+        gpu.debug_set()
+
+
+def test_small_pair_linearisation_variant(gpu):
+    """k_linearize<FULL, 4> (four (target, host) pairs per wave, chosen when a pair holds <= 24 scene blocks) against the
+    one-pair-per-wave kernel on the same map: the per-pair sums are formed in a different order, nothing else changes."""
+    P = synth.config_global(n_kf=400, n_pt=6000, band=10)
+    o = abi.options_global(); o.its[0] = 6
+    try:
+        gpu.upload(P, o)
+        assert gpu.solver_info()["small_pairs"] == 1
+        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+        gpu.debug_set(no_small_pairs=1)
+        gpu.upload(P, o); assert gpu.solver_info()["small_pairs"] == 0
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        _same_trajectory(rep1, rep2, G1, G2, atol=1e-10)
+    finally:
+        gpu.debug_set()
+
+
+def test_c6_full_size_global_ba(gpu):
+    """BASELINE config 4 on one GPU, the instance bench.py --workload global_ba times (5000 KF x 70 k points, ~500 k scene blocks):
+    the path the cost model picks (64 interiors, cyclic-reduction separator solve, one-wave Schur blocks, k_pose_sums,
+    k_gauge_par, four pairs per wave), first LM step against scipy's banded Cholesky, then size-independent properties."""
+    P = synth.config_global(n_kf=5000, n_pt=70000, band=10)
+    o = abi.options_global()
+    gpu.upload(P, o)
+    info = gpu.solver_info()
+    assert info["band_stream"] == 1 and info["sep_cr"] == 1 and info["interiors"] >= 32 and info["small_pairs"] == 1 and info["large_map"] == 1, info
+    rb = _check_first_step_banded(gpu, o)
+    assert rb["n"] == 6*(5000 - 2)                                    # gauge: the two initial keyframes are constant (optimizer.cc:1825-1830)
+    rep = gpu.solve(); A = gpu.download(P.copy())
+    assert rep["iters"][0] == 20 or rep["termination"][0] in (1, 2, 3)
+    assert rep["accepted"][0] >= 5 and rep["termination"][0] != 5
+    assert rep["cost1"][0] < 0.5*rep["cost0"][0]
+    assert 480000 < rep["n_sblock"][0] < 540000
+    q = A.pose.reshape(-1, 7)
+    assert np.allclose(np.linalg.norm(q[:, :4], axis=1), 1.0, atol=1e-12)
+    assert np.array_equal(q[:2], P.pose.reshape(-1, 7)[:2]) and not np.array_equal(q[2:], P.pose.reshape(-1, 7)[2:])
+    assert np.all(np.isfinite(A.rho)) and np.all(A.rho > 0)
+    # the solve moves towards the truth the generator perturbed away from
+    assert np.abs(A.pose - P.truth["pose"]).mean() < np.abs(P.pose - P.truth["pose"]).mean()
+    rep2 = gpu.solve(); B = gpu.download(P.copy())                     # restart from the uploaded state: bit-reproducible
+    assert rep2["iters"] == rep["iters"] and rep2["cost1"] == rep["cost1"]
+    assert np.array_equal(A.pose, B.pose) and np.array_equal(A.rho, B.rho)
+
+
+def _text_map(n_kf, n_pt, n_text, seed, feats, band, n_levels):
+    return synth.make_problem(n_kf=n_kf, n_pt=n_pt, n_text=n_text, seed=seed, feats=feats, max_targets=8, text_targets=5,
+                              frozen_frac=0.0, band=band, n_levels=n_levels, rot_deg=0.2, trans_m=0.01)
+
+
+def test_global_ba_with_text_planes_parity(gpu, oracle_lib):
+    """BASELINE config 3 keeps its 1 k text planes in the global BA (the reference's GlobalBA switches them off, optimizer.cc:1707:
+    options.use_text = 1 is the superset).  60 KF / 3000 points / 40 planes against the oracle: same LM trajectory."""
+    P = _text_map(60, 3000, 40, 5, (32, 16, 8), 10, 3)
+    o = abi.options_global(); o.use_text = 1; o.its[0] = 8
+    G, R = P.copy(), P.copy()
+    rg = gpu.GlobalBA(G, options=o)
+    ro = oracle_lib.solve(R, o)
+    assert rg["iters"] == ro["iters"] and rg["accepted"] == ro["accepted"] and rg["termination"] == ro["termination"]
+    assert rg["n_sblock"] == ro["n_sblock"] and rg["n_tblock"] == ro["n_tblock"] and rg["n_tblock"][0] > 1000
+    np.testing.assert_allclose(rg["cost0"], ro["cost0"], rtol=1e-11)
+    np.testing.assert_allclose(rg["cost1"], ro["cost1"], rtol=1e-9)
+    np.testing.assert_allclose(G.pose, R.pose, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(G.rho, R.rho, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(G.theta, R.theta, rtol=0, atol=1e-8)
+
+
+def test_c5_full_size_global_ba_with_text(gpu):
+    """BASELINE config 3 at full size: 500 KF x 50 k points x 1000 text planes, full Schur LM on one GPU (no oracle at this size:
+    first step against scipy's banded Cholesky + size-independent properties)."""
+    P = _text_map(500, 50000, 1000, 7, (64, 24, 12), 12, 1)
+    o = abi.options_global(); o.use_text = 1
+    gpu.upload(P, o)
+    info = gpu.solver_info()
+    assert info["band_stream"] == 1 and info["interiors"] > 1, info
+    _check_first_step_banded(gpu, o)
+    rep = gpu.solve(); A = gpu.download(P.copy())
+    assert rep["n_tblock"][0] > 200000 and rep["n_sblock"][0] > 250000
+    assert rep["accepted"][0] >= 5 and rep["termination"][0] != 5 and rep["cost1"][0] < 0.5*rep["cost0"][0]
+    assert np.allclose(np.linalg.norm(A.pose.reshape(-1, 7)[:, :4], axis=1), 1.0, atol=1e-12)
+    assert np.all(np.isfinite(A.theta)) and not np.array_equal(A.theta, P.theta)
+    assert np.abs(A.pose - P.truth["pose"]).mean() < np.abs(P.pose - P.truth["pose"]).mean()
+    rep2 = gpu.solve(); B = gpu.download(P.copy())
+    assert rep2["cost1"] == rep["cost1"] and np.array_equal(A.pose, B.pose) and np.array_equal(A.theta, B.theta)
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 on one device
+@pytest.mark.parametrize("nshard", [2, 3])
+@pytest.mark.parametrize("shape", ["dense", "band"])
+def test_device_landmark_striding_sums_to_unsharded_system(nshard, shape):
+    """tsba_upload with lm_nshard > 1 on the DEVICE path: each shard keeps the landmarks j = shard mod nshard, runs the split
+    (multi-GPU) kernel sequence and leaves its partial S, g before any exchange; the parts of all shards must sum to the
+    unsharded system, and every shard must derive the same band layout (the envelope comes from all observations)."""
+    from textslam_amd.optimizer import Optimizer
+    if shape == "dense":
+        P = synth.make_problem(n_kf=24, n_pt=900, n_text=12, seed=11, feats=(12, 8, 6), max_targets=6, text_targets=4, frozen_frac=0.1, band=8, n_levels=1)
+        o = abi.options_global(); o.use_text = 1
+    else:
+        P = synth.config_global(n_kf=300, n_pt=9000, band=8, far_frac=0.0)
+        o = abi.options_global()
+    radius = o.initial_radius
+
+    def system(shard, n):
+        g = Optimizer(0)
+        g.comm_init(None, 0, 1)                                       # split kernel sequence, no communicator
+        oo = abi.TsbaOptions.from_buffer_copy(o); oo.lm_shard, oo.lm_nshard = shard, n
+        g.upload(P, oo)
+        info = g.solver_info()
+        if shape == "dense":
+            r = g.reduced_system(radius); out = (r["S"].copy(), r["g"].copy(), r["free"].copy(), info)
+        else:
+            r = g.reduced_band(radius); out = (r["ab"].copy(), r["g"].copy(), r["free"].copy(), info)
+        g.close()
+        return out
+    S0, g0, free0, info0 = system(0, 1)
+    S = np.zeros_like(S0); gv = np.zeros_like(g0)
+    for r in range(nshard):
+        Sr, gr, fr, info = system(r, nshard)
+        assert Sr.shape == S0.shape and np.array_equal(fr, free0)
+        assert info["band_rows"] == info0["band_rows"] and info["band_storage"] == info0["band_storage"]
+        assert np.abs(Sr).max() > 0 and not np.allclose(Sr, S0)       # a proper part
+        S += Sr; gv += gr
+    scale = np.abs(S0).max()
+    if shape == "dense":                                              # (rows of constant poses: untouched storage on both sides)
+        rows = _free_rows(free0); m = rows.size
+        assert np.abs(S[:m, :m] - S0[:m, :m]).max() <= 1e-12*scale
+    else:
+        assert np.abs(S - S0).max() <= 1e-12*scale
+    assert np.abs(gv - g0).max() <= 1e-12*np.abs(g0).max()
+
+
+def _solve_on_ranks(P, o, world, call="GlobalBA"):
+    """The whole N-rank solve on one device: `world` contexts, one host thread each, collectives through the in-process group."""
+    from textslam_amd.optimizer import Optimizer, local_group_create, local_group_destroy
+    group = local_group_create(world)
+    out, err = [None]*world, [None]*world
+
+    def run(rank):
+        try:
+            g = Optimizer(0)
+            g.comm_init_local(group, rank, world)
+            G = P.copy()
+            rep = getattr(g, call)(G, options=o)
+            out[rank] = (G, rep, g.solver_info())
+            g.close()
+        except Exception as e:                                          # noqa: BLE001 -- reported below
+            err[rank] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    local_group_destroy(group)
+    assert all(e is None for e in err), err
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_global_ba_matches_single_rank(gpu, oracle_lib, world):
+    """The product's N > 1 path end to end -- sharded upload, split kernel sequence, all-reduce of S, g, the pose sums and the
+    landmark deltas, identical decisions on every rank -- against the 1-rank solve and the oracle."""
+    P = synth.config_global(n_kf=30, n_pt=1500, band=6)
+    o = abi.options_global()
+    G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+    ranks = _solve_on_ranks(P, o, world)
+    for G, rep, info in ranks:
+        assert info["world"] == world
+        _same_trajectory(rep1, rep, G1, G)
+        assert rep["n_sblock"] == rep1["n_sblock"]                      # block counts are global
+    for G, rep, _ in ranks[1:]:                                         # every rank ends with the same map
+        assert np.array_equal(G.pose, ranks[0][0].pose) and np.array_equal(G.rho, ranks[0][0].rho)
+    R = P.copy(); ro = oracle_lib.solve(R, o)
+    assert ranks[0][1]["iters"] == ro["iters"] and ranks[0][1]["accepted"] == ro["accepted"]
+    np.testing.assert_allclose(ranks[0][0].pose, R.pose, rtol=0, atol=1e-8)
+
+
+def test_multi_rank_band_solver_and_text(gpu):
+    """N = 2 on a map that takes the band path (300 KF: band storage of S is what the ranks exchange) and on a window with text."""
+    P = synth.config_global(n_kf=300, n_pt=9000, band=8)
+    o = abi.options_global(); o.its[0] = 6
+    G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+    for G, rep, info in _solve_on_ranks(P, o, 2):
+        assert info["band_storage"] == 1
+        _same_trajectory(rep1, rep, G1, G)
+    Q = synth.make_problem(n_kf=24, n_pt=900, n_text=12, seed=11, feats=(12, 8, 6), max_targets=6, text_targets=4, frozen_frac=0.1, band=8, n_levels=1)
+    o = abi.options_global(); o.use_text = 1; o.its[0] = 8
+    G1 = Q.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+    for G, rep, info in _solve_on_ranks(Q, o, 2):
+        _same_trajectory(rep1, rep, G1, G)
+        np.testing.assert_allclose(G.theta, G1.theta, rtol=0, atol=1e-9)
+
+
+def test_multi_gpu_rccl_two_ranks():
+    """Real RCCL over two devices (skipped on a one-GPU box): 2-rank solve against the 1-rank answer."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import subprocess, sys, os, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "global_ba", "--kf", "300", "--pts", "9000",
+                        "--steps", "2", "--warmup", "1", "--check-single"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["max_pose_diff_vs_single_rank"] <= 1e-9

@@ -288,8 +288,7 @@ def test_global_ba_band_cholesky_profiles(gpu, oracle_lib, n_kf, band, far):
 def test_global_ba_partitioned_band_solver(gpu, n_kf, n_pt, band):
     """Substructured band solver (tsba_bandp.h): at 300 keyframes the host picks several interiors + separators.  The LM step of
     the first linearisation against a dense numpy solve of the same reduced system, and the full GlobalBA against the
-    single-workgroup streaming solver (TSBA_BAND_PARTS=1): same LM trajectory, poses within 1e-9."""
-    import os
+    single-workgroup streaming solver (tsba_debug_set band_parts = 1): same LM trajectory, poses within 1e-9."""
     P = synth.config_global(n_kf=n_kf, n_pt=n_pt, band=band)          # band 12: border of 78 rows (two panel rounds, 3159 border-block tasks)
     o = abi.options_global(); o.its[0] = 6
     gpu.upload(P, o)
@@ -299,12 +298,14 @@ def test_global_ba_partitioned_band_solver(gpu, n_kf, n_pt, band):
     assert np.abs(S).sum() > 0                                     # (the band paths leave S intact)
     ref = -np.linalg.solve(S, rg["g"][:m])
     assert np.abs(rg["dp"][idx] - ref).max() <= 1e-8*np.abs(ref).max()
+    assert gpu.solver_info()["interiors"] > 1
     G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
-    os.environ["TSBA_BAND_PARTS"] = "1"
+    gpu.debug_set(band_parts=1)
     try:
         G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        assert gpu.solver_info()["interiors"] == 1
     finally:
-        del os.environ["TSBA_BAND_PARTS"]
+        gpu.debug_set()
     assert rep1["iters"] == rep2["iters"] and rep1["accepted"] == rep2["accepted"] and rep1["termination"] == rep2["termination"]
     assert rep1["accepted"][0] >= 3 and rep1["termination"][0] != 5
     np.testing.assert_allclose(G1.pose, G2.pose, rtol=0, atol=1e-9)

@@ -393,3 +393,20 @@ def test_lm_optimum_matches_scipy_least_squares(oracle_lib):
     # and the oracle's solution is stationary for the independent optimiser
     sol2 = least_squares(resid, pack(Q), method="trf", x_scale="jac", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=100)
     assert 0.5*np.sum(sol2.fun**2) >= c_oracle*(1 - 1e-7)
+
+
+def test_band_storage_solver_matches_dense(oracle_lib):
+    """Maps of thousands of keyframes go through band storage of H_pp / S and a band Cholesky (the dense reduced system would be 7 GB at
+    5000 keyframes -- what bench.py's cpu_baseline runs); forced here at 120 keyframes: same LM trajectory, same parameters to the bit."""
+    P = synth.config_global(n_kf=120, n_pt=4000, band=8)
+    o = abi.options_global(); o.its[0] = 5
+    A, B = P.copy(), P.copy()
+    ra = oracle_lib.solve(A, o)
+    oracle_lib.set_band_threshold(10)
+    try:
+        rb = oracle_lib.solve(B, o)
+    finally:
+        oracle_lib.set_band_threshold(400)
+    assert ra["iters"] == rb["iters"] and ra["accepted"] == rb["accepted"] and ra["cost1"] == rb["cost1"]
+    assert np.array_equal(A.pose, B.pose) and np.array_equal(A.rho, B.rho)
+    assert ra["accepted"][0] >= 3 and ra["cost1"][0] < ra["cost0"][0]

@@ -22,6 +22,8 @@
 #include <vector>
 #include <chrono>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types only: the library is dlopen()ed by tsba_comm_init, single-GPU use never touches RCCL
 #include "../../include/tsba.h"
@@ -1623,6 +1625,10 @@ struct Ctx {
     int run_slab = 0; size_t run_off = 0, run_len = 0;   // pending contiguous host-to-device range
     int cur_bw_rows = 1 << 30;                     // band bound of the level being solved (set by launch_pass_init)
     int rank = 0, world = 1; bool force_multi = false;
+    tsba_debug_options dbg{};                      // test / diagnostics switches (tsba_debug_set), all zero in production
+    struct LocalGroup *lgroup = nullptr;           // in-process communicator (tsba_comm_init_local)
+    size_t x_acc = 0, x_trial = 0, x_lin = 0, x_pass = 0;   // bytes handed to collectives: running total; last LM trial / linearisation / pass set-up
+    decltype(&ncclCommCount) p_count = nullptr;
     void *rccl_so = nullptr; ncclComm_t comm = nullptr;
     decltype(&ncclGetUniqueId) p_getid = nullptr; decltype(&ncclCommInitRank) p_init = nullptr;
     decltype(&ncclAllReduce) p_allreduce = nullptr; decltype(&ncclCommDestroy) p_destroy = nullptr;
@@ -1732,11 +1738,17 @@ int tsba_create(void **ctx, int device) {
     if (hipSetDevice(device) != hipSuccess) return TSBA_ERR_DEVICE;
     Ctx *c = new Ctx(); c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TSBA_ERR_DEVICE; }
-    hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
-    hipHostMalloc((void **)&c->st_host, sizeof(LmState)*TSBA_MAX_LEVELS, 0);
-    hipMalloc((void **)&c->st_log, sizeof(LmState)*TSBA_MAX_LEVELS);
-    if (hipHostMalloc((void **)&c->hprog, 64, hipHostMallocDefault) != hipSuccess) c->hprog = nullptr; else *c->hprog = 0;
-    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, device);
+    hipDeviceProp_t prop;
+    const bool ok = hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess
+        && hipHostMalloc((void **)&c->st_host, sizeof(LmState)*TSBA_MAX_LEVELS, 0) == hipSuccess
+        && hipMalloc((void **)&c->st_log, sizeof(LmState)*TSBA_MAX_LEVELS) == hipSuccess
+        && hipGetDeviceProperties(&prop, device) == hipSuccess;
+    if (!ok) {                                      // nothing half-built leaves this function
+        if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
+        if (c->st_host) hipHostFree(c->st_host); if (c->st_log) hipFree(c->st_log);
+        hipStreamDestroy(c->stream); delete c; return TSBA_ERR_DEVICE;
+    }
+    if (hipHostMalloc((void **)&c->hprog, 64, hipHostMallocDefault) != hipSuccess) c->hprog = nullptr; else *c->hprog = 0;   // (optional: early-exit polling only)
     c->lds_limit = prop.sharedMemPerBlock;       // 64 KiB default static limit; dynamic up to 160 KiB on gfx950
     if (c->lds_limit < 160*1024) c->lds_limit = 160*1024;
     *ctx = c; return TSBA_OK;
@@ -1756,14 +1768,66 @@ int tsba_destroy(void *ctx) {
 }
 const char *tsba_last_error(void *ctx) { return ctx ? ((Ctx *)ctx)->err.c_str() : "null ctx"; }
 
+// Every index the plan builder and the kernels dereference is range-checked here, once, in O(problem size): a bad index from the
+// adapter becomes TSBA_ERR_ARG instead of a host out-of-bounds read or a GPU memory fault (the library never aborts the process).
 static int check_problem(Ctx *c, const tsba_problem *p, const tsba_options *o) {
-    if (!p || !o) { set_err(c, "null problem/options"); return TSBA_ERR_ARG; }
-    if (p->n_kf <= 0 || p->n_levels < 1 || p->n_levels > TSBA_MAX_LEVELS) { set_err(c, "bad n_kf / n_levels"); return TSBA_ERR_ARG; }
-    if (o->n_passes < 1 || o->n_passes > TSBA_MAX_LEVELS) { set_err(c, "bad n_passes"); return TSBA_ERR_ARG; }
-    for (int i = 0; i < o->n_passes; i++) if (o->levels[i] < 0 || o->levels[i] >= p->n_levels) { set_err(c, "pass level out of range"); return TSBA_ERR_ARG; }
+    auto bad = [&](const char *what) { set_err(c, std::string("invalid problem: ") + what); return TSBA_ERR_ARG; };
+    if (!p || !o) return bad("null problem / options");
+    if (p->n_kf <= 0 || p->n_levels < 1 || p->n_levels > TSBA_MAX_LEVELS) return bad("n_kf / n_levels");
+    if (p->n_pt < 0 || p->n_text < 0 || p->n_tobs < 0 || p->n_sgood < 0) return bad("negative count");
+    if (o->n_passes < 1 || o->n_passes > TSBA_MAX_LEVELS) return bad("n_passes");
+    for (int i = 0; i < o->n_passes; i++) if (o->levels[i] < 0 || o->levels[i] >= p->n_levels) return bad("pass level out of range");
     if (o->text_jacobian != 0) { set_err(c, "text_jacobian=1 (numeric diff) is oracle-only"); return TSBA_ERR_ARG; }
-    if (o->use_text && p->n_tobs > 0) for (int i = 0; i < o->n_passes; i++) { int l = o->levels[i];
-        if (!p->img[l] || p->img_w[l]*p->img_h[l] > MS_MASK_WORDS*32) { set_err(c, "missing image level or image larger than 640x480"); return TSBA_ERR_ARG; } }
+    if (o->lm_nshard < 1 || o->lm_shard < 0 || o->lm_shard >= o->lm_nshard) return bad("lm_shard / lm_nshard");
+    if (!p->pose) return bad("pose is null");
+    if (p->n_pt > 0 && (!p->rho || !p->pt_ray || !p->pt_host)) return bad("null point array");
+    if (p->n_text > 0 && (!p->theta || !p->text_host || !p->text_box_ray)) return bad("null text-plane array");
+    if (p->n_sgood > 0 && !p->sgood) return bad("sgood is null");
+    bool frozen = false;
+    for (int j = 0; j < p->n_pt; j++) { const int h = p->pt_host[j]; if (h < -1 || h >= p->n_kf) return bad("pt_host out of range"); frozen |= h < 0; }
+    if (frozen && !p->pt_host_Trw) return bad("pt_host_Trw is null but a point has a frozen host");
+    frozen = false;
+    for (int j = 0; j < p->n_text; j++) { const int h = p->text_host[j]; if (h < -1 || h >= p->n_kf) return bad("text_host out of range"); frozen |= h < 0; }
+    if (frozen && !p->text_host_Twr) return bad("text_host_Twr is null but a plane has a frozen host");
+    if (p->n_tobs > 0) {
+        if (!p->tobs_kf || !p->tobs_text || !p->tobs_good || !p->tobs_fgood_off) return bad("null text-observation array");
+        if (p->tobs_fgood_off[0] < 0) return bad("tobs_fgood_off[0] < 0");
+        for (int t = 0; t < p->n_tobs; t++) {
+            if (p->tobs_kf[t] < 0 || p->tobs_kf[t] >= p->n_kf) return bad("tobs_kf out of range");
+            if (p->tobs_text[t] < 0 || p->tobs_text[t] >= p->n_text) return bad("tobs_text out of range");
+            if (p->tobs_fgood_off[t+1] < p->tobs_fgood_off[t]) return bad("tobs_fgood_off not monotone");
+        }
+        if (p->tobs_fgood_off[p->n_tobs] > 0 && !p->tfgood) return bad("tfgood is null");
+    }
+    std::vector<char> seen(p->n_levels, 0);
+    std::vector<int32_t> maxraw;
+    for (int i = 0; i < o->n_passes; i++) {
+        const int l = o->levels[i]; if (seen[l]) continue; seen[l] = 1;
+        const int ns = p->n_sobs[l];
+        if (ns < 0) return bad("n_sobs < 0");
+        if (ns > 0) {
+            if (!p->sobs_kf[l] || !p->sobs_pt[l] || !p->sobs_flag[l] || !p->sobs_uv0[l]) return bad("null scene-observation array");
+            const int32_t *kf = p->sobs_kf[l], *pt = p->sobs_pt[l], *fl = p->sobs_flag[l];
+            for (int s = 0; s < ns; s++) {
+                if ((unsigned)kf[s] >= (unsigned)p->n_kf) return bad("sobs_kf out of range");
+                if ((unsigned)pt[s] >= (unsigned)p->n_pt) return bad("sobs_pt out of range");
+                if ((unsigned)fl[s] >= (unsigned)p->n_sgood) return bad("sobs_flag out of range");
+            }
+        }
+        if (p->n_text > 0 && p->tfeat_off[l]) {             // (a level without text features passes tfeat_off = NULL)
+            const int32_t *off = p->tfeat_off[l]; const int nf = p->n_tfeat[l];
+            if (nf < 0 || off[0] < 0 || off[p->n_text] > nf) return bad("tfeat_off out of range");
+            for (int j = 0; j < p->n_text; j++) if (off[j+1] < off[j]) return bad("tfeat_off not monotone");
+            if (off[p->n_text] > off[0] && (!p->tfeat_raw[l] || !p->tfeat_uv[l] || !p->tfeat_ref[l])) return bad("null text-feature array");
+            maxraw.assign(p->n_text, -1);                  // a feature's flag is tfgood[tobs_fgood_off[t] + raw]: raw must fit every observation's span
+            for (int j = 0; j < p->n_text; j++) for (int f = off[j]; f < off[j+1]; f++) {
+                const int r = p->tfeat_raw[l][f]; if (r < 0) return bad("tfeat_raw < 0"); maxraw[j] = std::max(maxraw[j], (int32_t)r); }
+            for (int t = 0; t < p->n_tobs; t++)
+                if (maxraw[p->tobs_text[t]] >= p->tobs_fgood_off[t+1] - p->tobs_fgood_off[t]) return bad("tfeat_raw exceeds the observation's flag span");
+        }
+        if (o->use_text && p->n_tobs > 0)
+            if (!p->img[l] || p->img_w[l] <= 0 || p->img_h[l] <= 0 || p->img_w[l]*p->img_h[l] > MS_MASK_WORDS*32) { set_err(c, "missing image level or image larger than 640x480"); return TSBA_ERR_ARG; }
+    }
     return 0;
 }
 
@@ -1771,7 +1835,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
     hipSetDevice(c->device);
     int rc = check_problem(c, p, o); if (rc) return rc;
-    const bool tdbg = getenv("TSBA_DEBUG_TIMING") != nullptr;
+    const bool tdbg = c->dbg.verbose != 0;
     auto tu0 = std::chrono::steady_clock::now(); double t_plan = 0.0, t_img = 0.0;
     free_problem(c);
     auto tu1 = std::chrono::steady_clock::now();
@@ -1795,7 +1859,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         std::vector<char> seen(p->n_levels, 0);
         for (int ps = 0; ps < o->n_passes; ps++) { const int l = o->levels[ps]; if (seen[l]) continue; seen[l] = 1;
             HostPlan *H = &c->hplan[l];
-            planners[l] = std::thread([p, o, l, H]() { build_plan(p, o, l, *H); }); }
+            planners[l] = std::thread([p, o, l, H, tdbg]() { build_plan(p, o, l, *H, tdbg); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
 #define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
@@ -1868,7 +1932,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     {   bool po = p->n_kf == 1;
         for (int j = 0; po && j < p->n_pt; j++) po = p->pt_host[j] < 0;
         for (int j = 0; po && j < p->n_text; j++) po = p->text_host[j] < 0;
-        c->pose_only = po && !getenv("TSBA_NO_POSE_KERNEL");
+        c->pose_only = po && !c->dbg.no_pose_kernel;
         W.pst = nullptr; W.ppart = nullptr;
         if (c->pose_only) {
             size_t gmax = 1;
@@ -1895,7 +1959,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         if (use_lds_ || LDB >= (size_t)W.N) { c->S_count = (size_t)(W.N + 1)*W.N; AL(c->S_alloc, c->S_count); W.S = c->S_alloc; W.ldS = W.N; W.band = 0; }
         else { c->S_count = (size_t)W.N*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - CH_NB); W.ldS = (int)LDB - 1; W.band = 1; }
         c->Lcol = nullptr; c->band_stream = 0; c->sep_cr = false;
-        if (W.band && bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !getenv("TSBA_NO_BAND_STREAM")) {
+        if (W.band && bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !c->dbg.no_band_stream) {
             AL(c->Lcol, (size_t)p->n_kf*bwmax*6); c->band_stream = 1;
             // substructuring: P interiors on P workgroups + a separator system (again a band, 2 bw - 6 wide)
             // number of interiors: the interiors run in parallel (n_kf / P blocks each, ~3.5 us per block, 5 us once the border makes the
@@ -1905,7 +1969,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             const double t_f = bwmax > 57 ? 5.0 : 3.5, t_s = 2*bwmax - 6 > 115 ? 5.5 : 4.5;
             int P = (int)lround(sqrt((double)p->n_kf*t_f/((double)std::max(Bq, 1)*t_s)));
             bool want_cr = false;
-            if (bwmax <= CR_SMAX && !getenv("TSBA_NO_CR")) {
+            if (bwmax <= CR_SMAX && c->dbg.sep_solver != 1) {
                 // separator system by cyclic reduction (tsba_bandcr.h): its cost grows with log2(P) only (~130 us per level: pivot + update +
                 // back-substitution launches), so many more, shorter interiors pay
                 double best = 1e300; int bestP = P;
@@ -1920,8 +1984,8 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
                 const double cost_seq = (double)p->n_kf/Ps*t_f + (double)(Ps - 1)*Bq*t_s;
                 if (best < cost_seq) { P = bestP; want_cr = true; }
             }
-            if (getenv("TSBA_BAND_PARTS") && bwmax <= CR_SMAX && !getenv("TSBA_NO_CR")) want_cr = true;
-            if (const char *e = getenv("TSBA_BAND_PARTS")) P = atoi(e);
+            if (c->dbg.sep_solver == 2 && bwmax <= CR_SMAX) want_cr = true;
+            if (c->dbg.band_parts > 0) P = c->dbg.band_parts;
             P = std::max(1, std::min(P, BANDP_MAXP));
             while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < 4*Bq + 4) P--;                   // worth it only for interiors of a few bands
             if (P > 1 && bandp_chunk_blocks(bwmax) > 0 && 2*bwmax - 6 <= BAND_BW_MAX && band_chunk_blocks(2*bwmax - 6) > 0) {
@@ -1966,12 +2030,55 @@ static int reset_state(Ctx *c) {                 // one launch instead of ten sm
 }
 
 static bool is_multi(const Ctx *c) { return c->world > 1 || c->force_multi; }
+
+// In-process communicator (tsba_comm_init_local): `world` contexts of one process, one host thread each.  A collective is
+// stream-sync -> device-to-host -> barrier -> rank 0 reduces in rank order (deterministic) -> barrier -> host-to-device.
+// It exists so that the N > 1 code path -- sharded upload, split kernel sequence, every exchange -- runs under the test-suite on a
+// one-GPU box; production multi-GPU runs use RCCL (tsba_comm_init).
+struct LocalGroup {
+    int world = 1; bool broken = false;
+    std::mutex m; std::condition_variable cv; int arrived = 0; unsigned long long gen = 0;
+    std::vector<std::vector<char>> stage; std::vector<char> result;
+    bool barrier() {                               // false: a member never arrived (it failed before the collective) -- do not hang
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
+        const unsigned long long g = gen;
+        if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); return true; }
+        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || broken; })) { broken = true; cv.notify_all(); return false; }
+        return !broken;
+    }
+};
+static void local_allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op) {
+    LocalGroup *G = c->lgroup;
+    const size_t bytes = count*(dt == ncclDouble ? sizeof(double) : sizeof(int));
+    auto fail = [&](const char *what) { c->err = std::string("ncclAllReduce (local group): ") + what; };
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { fail("stream"); return; }
+    std::vector<char> &mine = G->stage[c->rank];
+    mine.resize(bytes);
+    if (hipMemcpy(mine.data(), buf, bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("device-to-host"); return; }
+    if (!G->barrier()) { fail("a rank did not arrive"); return; }
+    if (c->rank == 0) {
+        G->result = G->stage[0];
+        for (int r = 1; r < G->world; r++) {
+            if (G->stage[r].size() != bytes) { G->broken = true; break; }        // ranks disagree on the count: a layout bug, never sum garbage
+            if (dt == ncclDouble) { double *a = (double *)G->result.data(); const double *b = (const double *)G->stage[r].data();
+                if (op == ncclMax) for (size_t k = 0; k < count; k++) a[k] = a[k] > b[k] ? a[k] : b[k]; else for (size_t k = 0; k < count; k++) a[k] += b[k]; }
+            else { int *a = (int *)G->result.data(); const int *b = (const int *)G->stage[r].data(); for (size_t k = 0; k < count; k++) a[k] += b[k]; }
+        }
+    }
+    if (!G->barrier()) { fail("ranks disagree on the element count, or a rank did not arrive"); return; }
+    if (hipMemcpy(buf, G->result.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) fail("host-to-device");
+}
 static void allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op) {
+    c->x_acc += count*(dt == ncclDouble ? sizeof(double) : sizeof(int));
+    if (c->lgroup) { local_allreduce(c, buf, count, dt, op); return; }
     if (!c->comm) return;                          // force_multi without a communicator: exercises the split kernels only
     ncclResult_t r = c->p_allreduce(buf, buf, count, dt, op, c->comm, c->stream);
     if (r != ncclSuccess) c->err = std::string("ncclAllReduce: ") + c->p_errstr(r);
 }
 static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
+    const size_t x0 = c->x_acc;
+    struct XP { Ctx *c; size_t x0; ~XP() { c->x_pass = c->x_acc - x0; } } xp{c, x0};
     c->cur_bw_rows = D.bw_rows;
     c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
     Work &W = c->W; const tsba_options &o = c->opt;
@@ -1992,12 +2099,13 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
 }
 static int pose_parts(const Ctx *c) { return (c->n_kf > 126 && !is_multi(c)) ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
 // pairs with a dozen scene blocks (large maps): four pairs per wave
-static bool lin_small_pairs(const LevelDev &D) { static const bool off = getenv("TSBA_NO_SMALL_PAIRS") != nullptr; return !off && D.n_pair > 0 && (long long)D.n_sc <= 24LL*D.n_pair; }
+static bool lin_small_pairs(const Ctx *c, const LevelDev &D) { return !c->dbg.no_small_pairs && D.n_pair > 0 && (long long)D.n_sc <= 24LL*D.n_pair; }
 static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
+    struct XL { Ctx *c; size_t x0; ~XL() { c->x_lin = c->x_acc - x0; } } xl{c, c->x_acc};
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
     if (D.n_pair + D.n_tg > 0) {
-        if (lin_small_pairs(D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 7)/8 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
+        if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 7)/8 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
         else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
     }
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
@@ -2048,7 +2156,7 @@ static void launch_solve(Ctx *c) {
     Work &W = c->W;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) { hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0); return; }
-    if (c->band_stream && c->band_parts > 1 && !getenv("TSBA_NO_BAND_PARTS")) {      // partitioned: interiors in parallel + separator system (tsba_bandp.h)
+    if (c->band_stream && c->band_parts > 1) {      // partitioned: interiors in parallel + separator system (tsba_bandp.h)
         const int bwp = std::max(6, c->cur_bw_rows), cbp = bandp_chunk_blocks(bwp), P = c->band_parts;
         const int bwsep = 2*bwp - 6, cbs = band_chunk_blocks(bwsep);
         Work &Ws = c->Wsep; Ws.st = W.st; Ws.ldS = (P - 1)*bwp; Ws.N = (P - 1)*bwp;
@@ -2086,7 +2194,7 @@ static void launch_solve(Ctx *c) {
     }
     if (c->band_stream) {                                          // narrow band: one workgroup streams down the band (tsba_band.h)
         const int bws = std::max(6, c->cur_bw_rows), cb = band_chunk_blocks(bws);
-        if (getenv("TSBA_DEBUG_TIMING")) fprintf(stderr, "[launch_solve] band stream bw %d cb %d lds %zu B\n", bws, cb, band_lds_doubles(bws, cb)*sizeof(double));
+        if (c->dbg.verbose) fprintf(stderr, "[launch_solve] band stream bw %d cb %d lds %zu B\n", bws, cb, band_lds_doubles(bws, cb)*sizeof(double));
         hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(SOLVE_THREADS), (int)(band_lds_doubles(bws, cb)*sizeof(double)), c->stream, W, bws, cb, c->Lcol);
         const int nu = (bws + 63)/64, ldsb = (int)(band_lds_doubles(bws, cb)*sizeof(double));      // tasks per lane of the back substitution
         if (nu <= 1) hipLaunchKernelGGL(k_band_backsub<1>, dim3(1), dim3(BAND_BS_T), ldsb, c->stream, W, bws, (const double *)c->Lcol);
@@ -2109,12 +2217,13 @@ static void launch_solve(Ctx *c) {
         if (wr > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt*(nt + 1)/2), dim3(CH_T), lds_upd, c->stream, W, j0, bw);
     }
     const int lds_bs = (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double);
-    if (!getenv("TSBA_DEBUG_NO_BACKSUB")) hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, W, bw);
+    hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, W, bw);
 }
 
 // one LM iteration: reduced system -> pose step -> back-substitution / candidate -> speculative linearisation at the
 // candidate -> decision (on acceptance the speculative LinBuf simply becomes the current one)
 static void launch_step(Ctx *c, const LevelDev &D) {
+    struct XT { Ctx *c; size_t x0; ~XT() { c->x_trial = c->x_acc - x0; } } xt{c, c->x_acc};
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
@@ -2261,7 +2370,10 @@ int tsba_theta_optim(void *ctx, tsba_problem *p, const tsba_options *o, int text
     for (int k = 0; k < 6; k++) CK(hipMemcpy(&V[k], c->W.lb[st.lcur & 1].V_tx + (size_t)k*c->n_text + text, sizeof(double), hipMemcpyDeviceToHost));
     const double a = V[0], b = V[1], cc = V[2], e = V[3], f = V[4], i = V[5];
     const double A = e*i - f*f, B = -(b*i - cc*f), C = b*f - cc*e, det = a*A + b*B + cc*C;
-    if (!(det > 0.0) || !(a > 0.0) || !(a*e - b*b > 0.0)) { set_err(c, "theta information matrix is singular"); return TSBA_ERR_NUMERIC; }
+    // singular information matrix: as the reference (Covariance::Compute fails, thetaVariance keeps its value, PyrThetaOptim
+    // still returns true -- optimizer.cc:2224-2241): not an error, cov[] untouched, flagged in the report
+    if (!(det > 0.0) || !(a > 0.0) || !(a*e - b*b > 0.0)) { r->cov_valid = 0; return TSBA_OK; }
+    r->cov_valid = 1;
     const double id = 1.0/det;
     cov[0] = A*id; cov[1] = B*id; cov[2] = C*id; cov[3] = B*id; cov[4] = (a*i - cc*cc)*id; cov[5] = -(a*f - b*cc)*id;
     cov[6] = C*id; cov[7] = cov[5]; cov[8] = (a*e - b*b)*id;
@@ -2328,8 +2440,10 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     launch_linearize(c, D, 0);
     Work &W = c->W;
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream);
-    launch_schur(c, D, 0);
-    launch_solve(c);
+    // split (multi-GPU) sequence: this shard's PARTIAL S and g, before any exchange and without the pose damping (which is added
+    // once after the all-reduce) -- the parts of all shards sum to the unsharded system; dp is not computed
+    launch_schur(c, D, (int)is_multi(c));
+    if (!is_multi(c)) launch_solve(c); else hipMemsetAsync(W.dp, 0, sizeof(double)*W.N, c->stream);
     c->opt = saved;
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
     if (S) {
@@ -2349,6 +2463,29 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     return TSBA_OK;
 }
 
+// The same for LARGE maps, where the dense (6 n_kf)^2 copy is not an option (7.2 GB at 5000 keyframes): the band of the
+// compressed (free-pose) system in LAPACK lower-band storage, ab[(i - j)*n + j] = S(i, j) for j <= i <= j + bw -- what
+// scipy.linalg.solveh_banded(lower=True) takes.  Call once with ab = NULL to get n (rows) and bw, then with buffers.
+int tsba_debug_reduced_band(void *ctx, double radius, int32_t *n_out, int32_t *bw_out, double *ab, double *g, double *dp) {
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    if (!c->uploaded) return TSBA_ERR_STATE;
+    if (!c->W.band) { set_err(c, "the uploaded problem keeps a dense reduced system: use tsba_debug_reduced_system"); return TSBA_ERR_STATE; }
+    int rc = tsba_debug_reduced_system(ctx, radius, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
+    Work &W = c->W;
+    int nfree = 0; CK(hipMemcpy(&nfree, W.nfree, sizeof(int), hipMemcpyDeviceToHost));
+    const long long n = 6LL*nfree, LDB = W.ldS + 1, Wb = LDB - CH_NB;
+    const int bw = std::max(6, c->lev[c->opt.levels[0]].bw_rows) + 5;              // rows below the diagonal that can be non-zero (block-aligned band)
+    if (n_out) *n_out = (int32_t)n; if (bw_out) *bw_out = bw;
+    if (ab) {
+        std::vector<double> hb(c->S_count); CK(hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost));
+        for (long long d = 0; d <= bw; d++) for (long long j = 0; j < n; j++) { const long long i = j + d;
+            ab[d*n + j] = (i < n && j >= i - Wb) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
+    }
+    if (g) CK(hipMemcpy(g, W.g, sizeof(double)*n, hipMemcpyDeviceToHost));
+    if (dp) CK(hipMemcpy(dp, W.dp, sizeof(double)*W.N, hipMemcpyDeviceToHost));
+    return TSBA_OK;
+}
+
 int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *algo_bytes) {
     Ctx *c = (Ctx *)ctx; if (!c || n <= 0) return TSBA_ERR_ARG;
     if (!c->uploaded || level < 0 || level >= c->n_levels || !c->lev_built[level]) { set_err(c, "level not uploaded"); return TSBA_ERR_STATE; }
@@ -2364,7 +2501,7 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));   // k_linearize never clears need_lin itself
     CK(hipEventRecord(c->ev0, c->stream));
     for (int k = 0; k < n; k++) {
-        if (lin_small_pairs(D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 7)/8 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+        if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 7)/8 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
         else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
     }
     CK(hipEventRecord(c->ev1, c->stream));
@@ -2397,6 +2534,20 @@ int tsba_text_label_image(void *ctx, int kf, int level, float *out) {
     return TSBA_OK;
 }
 
+// which kernels the uploaded problem runs through (so that a test can assert that it exercises the path it means to):
+// out[0] reduced system in LDS (k_solve_t / k_solve_col)   [1] band storage   [2] streaming band solver   [3] interiors P
+// [4] separator system by cyclic reduction   [5] band rows   [6] four pairs per wave in the linearisation of the first pass's level
+// [7] fused pose-only kernel   [8] one-wave Schur blocks + k_pose_sums (large maps)   [9] world size   [10] small-system solver variant
+int tsba_debug_solver_info(void *ctx, int32_t *out, int n) {
+    Ctx *c = (Ctx *)ctx; if (!c || !out || n < 11) return TSBA_ERR_ARG;
+    if (!c->uploaded) return TSBA_ERR_STATE;
+    int use_lds; solve_lds_bytes(c, &use_lds);
+    int bwmax = 0; for (int l = 0; l < c->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
+    out[0] = use_lds; out[1] = c->W.band; out[2] = c->band_stream; out[3] = c->band_stream ? c->band_parts : 0; out[4] = c->sep_cr ? 1 : 0; out[5] = bwmax;
+    out[6] = lin_small_pairs(c, c->lev[c->opt.levels[0]]) ? 1 : 0; out[7] = c->pose_only ? 1 : 0; out[8] = c->n_kf > 126 ? 1 : 0;
+    out[9] = c->world; out[10] = c->dbg.small_solver;
+    return TSBA_OK;
+}
 int tsba_debug_plan_time(const tsba_problem *p, const tsba_options *o, int level, int reps, double *avg_ms) {   // host only: plan construction
     if (!p || !o || reps <= 0) return TSBA_ERR_ARG;
     auto t0 = std::chrono::steady_clock::now();
@@ -2461,6 +2612,7 @@ static int load_rccl(Ctx *c) {
     c->p_allreduce = (decltype(c->p_allreduce))dlsym(c->rccl_so, "ncclAllReduce");
     c->p_destroy = (decltype(c->p_destroy))dlsym(c->rccl_so, "ncclCommDestroy");
     c->p_errstr = (decltype(c->p_errstr))dlsym(c->rccl_so, "ncclGetErrorString");
+    c->p_count = (decltype(c->p_count))dlsym(c->rccl_so, "ncclCommCount");
     if (!c->p_getid || !c->p_init || !c->p_allreduce || !c->p_destroy || !c->p_errstr) { set_err(c, "librccl: missing symbols"); return TSBA_ERR_COMM; }
     return 0;
 }
@@ -2472,6 +2624,32 @@ int tsba_comm_unique_id(void *ctx, void *id128) {
     if (r != ncclSuccess) { set_err(c, std::string("ncclGetUniqueId: ") + c->p_errstr(r)); return TSBA_ERR_COMM; }
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     memcpy(id128, &id, 128);
+    return TSBA_OK;
+}
+void *tsba_local_group_create(int world) {
+    if (world < 1) return nullptr;
+    LocalGroup *G = new LocalGroup(); G->world = world; G->stage.resize(world); return G;
+}
+void tsba_local_group_destroy(void *group) { delete (LocalGroup *)group; }
+int tsba_comm_init_local(void *ctx, void *group, int rank, int world) {
+    Ctx *c = (Ctx *)ctx; LocalGroup *G = (LocalGroup *)group;
+    if (!c || !G || world != G->world || rank < 0 || rank >= world) return TSBA_ERR_ARG;
+    hipSetDevice(c->device);
+    free_problem(c);                               // any resident problem was sharded for the old world size
+    c->lgroup = G; c->rank = rank; c->world = world;
+    return TSBA_OK;
+}
+int tsba_comm_stats(void *ctx, int32_t *ranks, int64_t bytes[3]) {
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    if (ranks) { int n = c->lgroup ? c->lgroup->world : 1;
+        if (c->comm && c->p_count && c->p_count(c->comm, &n) != ncclSuccess) return TSBA_ERR_COMM;
+        *ranks = n; }
+    if (bytes) { bytes[0] = (int64_t)c->x_trial; bytes[1] = (int64_t)c->x_lin; bytes[2] = (int64_t)c->x_pass; }
+    return TSBA_OK;
+}
+int tsba_debug_set(void *ctx, const tsba_debug_options *d) {
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    if (d) c->dbg = *d; else memset(&c->dbg, 0, sizeof(c->dbg));
     return TSBA_OK;
 }
 int tsba_comm_init(void *ctx, const void *id128, int rank, int world) {

@@ -93,8 +93,7 @@ inline void bucket_order(const std::vector<int> &bucket, int n_bucket, std::vect
     for (size_t i = 0; i < bucket.size(); i++) order[(size_t)cur[bucket[i]]++] = (int)i;
 }
 
-inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P) {
-    static const bool dbg_plan = getenv("TSBA_DEBUG_PLAN") != nullptr;
+inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false) {
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
     P = HostPlan();
@@ -103,9 +102,19 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     struct Cand { int obs, kf, pt, host; };
     std::vector<Cand> cs;
     cs.reserve(p->n_sobs[L]);
+    // The envelope of the reduced camera matrix is a property of the WHOLE problem: every rank of a sharded solve must derive the
+    // same band (storage layout, solver choice, exchange counts) -- so it is taken from all observations, before the shard filter.
+    // A landmark couples every pair of its poses (observers + host): column lo = min pose reaches down to hi = max pose; the fill
+    // closure below (running maximum) covers the poses in between.
+    std::vector<int> reach(n_kf);
+    for (int a = 0; a < n_kf; a++) reach[a] = a;
+    std::vector<int> lm_lo((size_t)n_pt + n_text, n_kf), lm_hi((size_t)n_pt + n_text, -1);
+    auto touch = [&](int lm, int kf, int host) { if (host < 0) return;           // frozen landmark: no off-diagonal coupling
+        lm_lo[lm] = std::min(lm_lo[lm], std::min(kf, host)); lm_hi[lm] = std::max(lm_hi[lm], std::max(kf, host)); };
     for (int s = 0; s < p->n_sobs[L]; s++) {
         int kf = p->sobs_kf[L][s], pt = p->sobs_pt[L][s], host = p->pt_host[pt];
         if (host >= 0 && host == kf) continue;                    // optimizer.cc:1393 "Host != Target"
+        touch(pt, kf, host);
         if (o->lm_nshard > 1 && (pt % o->lm_nshard) != o->lm_shard) continue;   // multi-GPU: landmark shard
         cs.push_back({ s, kf, pt, host >= 0 ? host : -1 });
     }
@@ -114,9 +123,11 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     if (o->use_text) for (int t = 0; t < p->n_tobs; t++) {
         int kf = p->tobs_kf[t], j = p->tobs_text[t], host = p->text_host[j];
         if (host >= 0 && host == kf) continue;                    // optimizer.cc:1484
+        touch(n_pt + j, kf, host);
         if (o->lm_nshard > 1 && ((n_pt + j) % o->lm_nshard) != o->lm_shard) continue;
         gs.push_back({ t, kf, j, host >= 0 ? host : -1 });
     }
+    for (size_t lm = 0; lm < lm_lo.size(); lm++) if (lm_hi[lm] >= 0) reach[lm_lo[lm]] = std::max(reach[lm_lo[lm]], lm_hi[lm]);
     // ---- pairs: key = kf*(n_kf+1) + (host+1)
     auto key_of = [&](int kf, int host) { return (int64_t)kf*(n_kf + 1) + (host + 1); };
     KeyIndex pk; pk.begin((int64_t)n_kf*(n_kf + 1));
@@ -245,8 +256,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     {   // envelope of S: column a reaches down to its last coupled pose; Cholesky fill closes the profile under the running
         // maximum (a column inherits the reach of every earlier column that reaches it).  Compressing the fixed poses out
         // (device side) only shrinks distances, so this is an upper bound for the system that is actually factored.
-        std::vector<int> cm(n_kf);
-        for (int a = 0; a < n_kf; a++) cm[a] = a;
+        std::vector<int> &cm = reach;                             // (all ranks' observations: see the top of this function)
         for (int q = 0; q < n_sb; q++) cm[P.sb_a[q]] = std::max(cm[P.sb_a[q]], (int)P.sb_b[q]);
         int run = -1, bw = 0;
         for (int k = 0; k < n_kf; k++) { const int reach = (run >= k) ? std::max(cm[k], run) : cm[k]; run = std::max(run, reach); bw = std::max(bw, reach - k); }

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 import numpy as np
 
-from .abi import (TsbaProblem, TsbaOptions, TsbaReport, BAProblem, options_local, options_pose, options_global,
+from .abi import (TsbaProblem, TsbaOptions, TsbaReport, TsbaDebugOptions, BAProblem, options_local, options_pose, options_global,
                   options_init, options_landmarker, options_theta, STATE_LOCAL, STATE_NOTREACHWIN)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -43,8 +43,18 @@ def load_library():
                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tsba_time_linearize.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.tsba_debug_reduced_system.argtypes = [vp, C.c_double, dp, dp, dp, C.POINTER(C.c_int32), dp]
+    L.tsba_debug_reduced_band.argtypes = [vp, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, dp]
+    L.tsba_debug_solver_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
+    L.tsba_debug_time_solve.argtypes = [vp, C.c_int, dp]
+    L.tsba_comm_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.tsba_comm_unique_id.argtypes = [vp, vp]
     L.tsba_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.tsba_local_group_create.argtypes = [C.c_int]
+    L.tsba_local_group_create.restype = vp
+    L.tsba_local_group_destroy.argtypes = [vp]
+    L.tsba_local_group_destroy.restype = None
+    L.tsba_comm_init_local.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.tsba_debug_set.argtypes = [vp, C.POINTER(TsbaDebugOptions)]
     L.tsba_theta_optim.argtypes = [vp, C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, dp, C.POINTER(TsbaReport)]
     for name in ("tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global",
                  "tsba_default_options_init", "tsba_default_options_landmarker", "tsba_default_options_theta"):
@@ -60,12 +70,24 @@ EXPORTED_SYMBOLS = [
     "tsba_default_options_init", "tsba_default_options_landmarker", "tsba_default_options_theta",
     "tsba_local_ba", "tsba_pose_optim", "tsba_global_ba", "tsba_theta_optim", "tsba_text_label_image",
     "tsba_upload", "tsba_solve", "tsba_download", "tsba_eval", "tsba_time_linearize",
-    "tsba_comm_unique_id", "tsba_comm_init",
+    "tsba_comm_unique_id", "tsba_comm_init", "tsba_comm_init_local", "tsba_local_group_create", "tsba_local_group_destroy",
+    "tsba_debug_set", "tsba_debug_reduced_system",
 ]
 
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def local_group_create(world):
+    g = load_library().tsba_local_group_create(world)
+    if not g:
+        raise TsbaError("tsba_local_group_create failed")
+    return C.c_void_p(g)
+
+
+def local_group_destroy(group):
+    load_library().tsba_local_group_destroy(group)
 
 
 class Optimizer:
@@ -116,12 +138,14 @@ class Optimizer:
         """optimizer::OptimizeLandmarker(map): rho / theta refinement with every pose constant (kf_initial = all ones)."""
         return self._one_shot(self.lib.tsba_local_ba, prob, options or options_landmarker(), "tsba_local_ba(landmarker)")
 
-    def ThetaOptimMultiFs(self, prob: BAProblem, text: int = 0, options: TsbaOptions = None):
-        """optimizer::ThetaOptimMultiFs(F, obj): returns (report, 3x3 covariance of theta[text]); raises if it is singular."""
+    def ThetaOptimMultiFs(self, prob: BAProblem, text: int = 0, options: TsbaOptions = None, cov0=None):
+        """optimizer::ThetaOptimMultiFs(F, obj): returns (report, 3x3 covariance of theta[text]).  A singular information matrix is
+        not an error (the reference keeps obj->Covariance as it was, optimizer.cc:2224-2241): report["cov_valid"] == 0 and the
+        returned matrix is `cov0` (the caller's previous covariance, zeros if none was given)."""
         o = options or options_theta()
         s = prob.struct()
         rep = TsbaReport()
-        cov = np.zeros(9)
+        cov = np.zeros(9) if cov0 is None else np.ascontiguousarray(cov0, np.float64).reshape(9).copy()
         self._check(self.lib.tsba_theta_optim(self.ctx, C.byref(s), C.byref(o), text, _dp(cov), C.byref(rep)), "tsba_theta_optim")
         return rep.as_dict(), cov.reshape(3, 3)
 
@@ -186,6 +210,25 @@ class Optimizer:
                     "tsba_debug_reduced_system")
         return {"S": S, "g": g, "cost": cost.value, "free": free, "dp": dpv}
 
+    def solver_info(self):
+        """Which kernel paths the uploaded problem takes (tsba_debug_solver_info)."""
+        v = (C.c_int32 * 11)()
+        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 11), "tsba_debug_solver_info")
+        keys = ("lds_solver", "band_storage", "band_stream", "interiors", "sep_cr", "band_rows", "small_pairs", "pose_kernel", "large_map", "world", "small_solver")
+        return dict(zip(keys, [int(x) for x in v]))
+
+    def reduced_band(self, radius: float):
+        """Large maps: the reduced system of the first linearisation in LAPACK lower-band storage (scipy.linalg.solveh_banded,
+        lower=True) over the compressed free-pose rows, with g and the pose step dp (by keyframe)."""
+        n, bw = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.tsba_debug_reduced_band(self.ctx, radius, C.byref(n), C.byref(bw), None, None, None), "tsba_debug_reduced_band")
+        ab, g, dpv = np.zeros((bw.value + 1, n.value)), np.zeros(n.value), np.zeros(6*self._resident.n_kf)
+        self._check(self.lib.tsba_debug_reduced_band(self.ctx, radius, C.byref(n), C.byref(bw), _dp(ab), _dp(g), _dp(dpv)), "tsba_debug_reduced_band")
+        free = np.zeros(self._resident.n_kf, np.int32)
+        self._check(self.lib.tsba_debug_reduced_system(self.ctx, radius, None, None, None, free.ctypes.data_as(C.POINTER(C.c_int32)), None),
+                    "tsba_debug_reduced_system")
+        return {"ab": ab, "g": g, "dp": dpv, "n": n.value, "bw": bw.value, "free": free}
+
     # ---- multi-GPU (global BA): one process per GPU, RCCL communicator owned by the library
     def comm_unique_id(self):
         buf = (C.c_char * 128)()
@@ -194,6 +237,29 @@ class Optimizer:
 
     def comm_init(self, id128, rank, world):
         self._check(self.lib.tsba_comm_init(self.ctx, id128, rank, world), "tsba_comm_init")
+
+    def comm_init_local(self, group, rank, world):
+        """In-process communicator (test hook, include/tsba.h): `group` from local_group_create(world), one thread per rank."""
+        self._check(self.lib.tsba_comm_init_local(self.ctx, group, rank, world), "tsba_comm_init_local")
+
+    def debug_set(self, **kw):
+        """tsba_debug_set: solver-path switches for tests / diagnostics (no keyword = production behaviour)."""
+        d = TsbaDebugOptions()
+        for k, v in kw.items():
+            setattr(d, k, int(v))
+        self._check(self.lib.tsba_debug_set(self.ctx, C.byref(d) if kw else None), "tsba_debug_set")
+
+    def time_solve(self, n: int = 50):
+        """Average ms of the reduced-system solve on the S, g of the last solve (tsba_debug_time_solve)."""
+        ms = C.c_double(0)
+        self._check(self.lib.tsba_debug_time_solve(self.ctx, n, C.byref(ms)), "tsba_debug_time_solve")
+        return ms.value
+
+    def exchange_bytes(self):
+        """Communicator size and the bytes this rank handed to collectives per LM trial / linearisation / pass set-up."""
+        r = C.c_int32(0); b = (C.c_int64 * 3)()
+        self._check(self.lib.tsba_comm_stats(self.ctx, C.byref(r), b), "tsba_comm_stats")
+        return {"ranks": r.value, "per_trial": int(b[0]), "per_linearisation": int(b[1]), "per_pass": int(b[2])}
 
     def time_linearize(self, level: int, n: int = 50):
         ms, nbytes = C.c_double(0), C.c_double(0)

@@ -1,6 +1,6 @@
 """A/B timing of the resident C4 LocalBundleAdjustment solve (run twice in one gpurun call with different TSBA_* switches)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from textslam_amd import synth
 from textslam_amd.abi import options_local

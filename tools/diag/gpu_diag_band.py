@@ -1,7 +1,7 @@
 """GPU diagnostic (not a pytest): the streaming band solver's dp against numpy on the reduced system of the first linearisation."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer

@@ -1,7 +1,7 @@
 """GPU diagnostic (not a pytest): call latencies of the BA-pyramid front-end (640x480, 4 levels) next to the CPU restatement."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from textslam_amd.frame import Frame
 from textslam_amd.orbextractor import synthetic_frame

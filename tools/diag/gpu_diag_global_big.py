@@ -1,6 +1,6 @@
 """GPU diagnostic (not a pytest): C6-sized global BA (5000 KF, ~460k scene blocks, band covisibility) resident solve, for rocprofv3."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 nkf = int(sys.argv[1]) if len(sys.argv) > 1 else 5000

@@ -3,7 +3,7 @@ The reference's GlobalBA switches text off (optimizer.cc:1707); the kernels do n
 then the C5-sized timing."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 import oracle

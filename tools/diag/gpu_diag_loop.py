@@ -1,7 +1,7 @@
 """GPU diagnostic (not a pytest): call latencies of the loop-closure optimisers next to the CPU restatement."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from textslam_amd import synth
 from textslam_amd.loop import LoopOptimizer

@@ -1,7 +1,7 @@
 """GPU diagnostic (not a pytest): timing of the window search (grid build + search of 1000 queries in a 1000-feature frame) next to the CPU oracle."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd.orbextractor import ORBextractor, synthetic_frame
 import oracle
 ex = ORBextractor(1000, 1.2, 8, 20, 7)

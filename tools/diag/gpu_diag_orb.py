@@ -1,6 +1,6 @@
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd.orbextractor import ORBextractor, synthetic_frame
 import oracle
 n = 4

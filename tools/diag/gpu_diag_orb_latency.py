@@ -1,7 +1,7 @@
 """GPU diagnostic (not a pytest): ORB extraction latency for one frame (the per-frame call of the SLAM front-end) and for a batch."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd.orbextractor import ORBextractor, synthetic_frame
 ex = ORBextractor(1000, 1.2, 8, 20, 7)
 for n in (1, 2, 64):

@@ -1,6 +1,6 @@
 """GPU diagnostic (not a pytest): resident pose-only optimisation (C3) in a loop, for rocprofv3."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 opt = Optimizer(0)

@@ -1,6 +1,6 @@
 """GPU diagnostic (not a pytest): k_solve cycle stamps on the C4 window. Run with TSBA_LIB=textslam_amd/libtsba_stamps.so."""
 import sys, os, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 

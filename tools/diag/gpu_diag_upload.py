@@ -1,6 +1,6 @@
 """GPU diagnostic (not a pytest): where the time of a cold tsba_local_ba call goes (upload / plan construction vs solve)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 opt = Optimizer(0)
