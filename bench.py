@@ -53,14 +53,17 @@ def cpu_baseline_local(prob, opt_ref):
     o.text_jacobian = 1                       # NumericDiffCostFunction<CENTRAL>, nume_BAText.h:97-100
     cores = os.cpu_count() or 1
     res = {}
-    for nt in (1, cores):
+    for nt in sorted({1, min(16, cores), cores}):      # the restatement's accumulation is serial: a moderate team often beats all cores
         oracle.omp_set_threads(nt)
         q = prob.copy()
         t0 = time.perf_counter(); rep = oracle.solve(q, o, library=L); dt = time.perf_counter() - t0
         res[nt] = (rep["n_resid_evals"]/dt, dt)
-    return {"value": res[cores][0], "unit": "residuals/s", "cores": cores, "kind": "port",
-            "sample": "the full LocalBundleAdjustment call (3 passes) on the same window, numeric-diff text Jacobians, gcc -O3 -march=native -fopenmp",
-            "seconds": res[cores][1], "single_thread_value": res[1][0], "single_thread_seconds": res[1][1]}
+    best = max(res, key=lambda k: res[k][0])
+    return {"value": res[best][0], "unit": "residuals/s", "cores": best, "kind": "port",
+            "sample": "the full LocalBundleAdjustment call (3 passes) on the same window, numeric-diff text Jacobians, gcc -O3 -march=native -fopenmp; "
+                      "value = the best of the thread counts tried (1 = the reference's own num_threads setting, 16, all %d host cores)" % cores,
+            "seconds": res[best][1], "single_thread_value": res[1][0], "single_thread_seconds": res[1][1],
+            "all_core_value": res[cores][0], "all_cores": cores, "by_threads": {str(k): v[0] for k, v in res.items()}}
 
 
 def cpu_baseline_global(prob, opt):

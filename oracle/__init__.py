@@ -110,6 +110,7 @@ def baseline_lib():
     single-thread setting (num_threads = 1, optimizer.cc:1600).  Never used as a parity checker."""
     global _FAST
     if _FAST is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # idle workers sleep while the serial phases run (read when libgomp loads)
         d = os.path.join(_HERE, "_fast")
         os.makedirs(d, exist_ok=True)
         so = os.path.join(d, "libtsba_oracle_omp.so")

@@ -46,7 +46,7 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const uint8_t *const *img;      // [n_kf] device pointers
     const int *sc_obs, *sc_kf, *sc_pt, *sc_flag, *sc_slot; const double *sc_uv;
     const int *pair_i, *pair_h, *pair_hpos, *pair_sc_off, *pair_tg_off, *pair_tg;
-    const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot, *tg_rec, *tg_ppos, *pt_pose6;
+    const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot, *tg_rec, *tg_ppos, *pt_pose6, *pt_pair4;
     const int *pls_off, *pslot_pose, *pslot_pair, *pslot_lm, *tls_off, *tslot_pose, *tslot_pair, *tslot_lm;
     const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_pt_lm, *sb_tx_off, *sb_tx_s1, *sb_tx_s2, *sb_tx_lm;
     const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ps_lm, *pose_ts_off, *pose_ts, *pose_ts_lm;
@@ -54,13 +54,14 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const int *pf_g, *pf_f; int n_pf;   // pose-only path: flat (group, feature) list of the frame's text features
 };
 
-#define PT_REC 16
-#define TX_REC 48
+#define PT_REC 8
+#define TX_REC 28
 struct LinBuf {              // everything one linearisation produces
     double *pairM, *pairCost, *pairR, *pairOut, *tgM, *tgCost;
-    double *w_pt;                       // per point slot, one 128-byte record: w[0..5] | v | b | -Q^T w [8..13]   (PT_REC doubles)
+    double *w_pt;                       // per point slot, one 64-byte record: w[0..5] | v | b   (PT_REC doubles; the host slot of a landmark
+                                        // holds its host column -sum Q^T w in [0..5], formed by k_mid from w and the pair's R_cr)
     double *V_pt, *b_pt, *dgs_pt;       // per point: V, b, clamp(sigma^2 V)/sigma^2  (lambda = dgs / radius)
-    double *w_tx;                       // per plane slot, one 384-byte record: W[0..17] | V6 [18..23] | b3 [24..26] | -Q^T W [27..44]   (TX_REC doubles)
+    double *w_tx;                       // per plane slot, one 224-byte record: W[0..17] | V6 [18..23] | b3 [24..26]   (TX_REC doubles)
     double *V_tx, *b_tx, *dgs_tx;       // per plane: V [6][n], b [3][n], dgs [3][n]
     double *Hd, *bp, *dgs_p;            // per pose: diag(H_pp), gradient, dgs.  Hd | bp | scal[8] are one allocation (hb):
     double *bp_loc;                     // multi-GPU: this rank's part of bp (the reduced gradient is assembled from it)
@@ -517,6 +518,7 @@ __device__ __forceinline__ void wave_sum_groups16_mw(const double *acc, double *
 // observation with every feature on TWO lanes (4 taps each): the text lanes' instruction stream (~450 instructions per tap at
 // one instruction per ~4.5 cycles) is what bounds the kernel.  <= 256 VGPRs so that all ~730 workgroups of C4 are resident at once.
 #define LIN_T 128
+#define MID_U 4                          // slot records of a point that k_mid keeps in flight per round trip
 template <int MODE, int PPW = 1>
 __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int spec) {
     // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
@@ -557,9 +559,9 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
             const bool act = !fixed && (!W.filter_good || W.sgood[L.sc_flag[c]]);
             // the slot record of an inactive candidate is zeros: one store sequence for both cases (a second, branchy one
             // costs the kernel ~170 VGPRs of live ranges)
-            double wv[14];
+            double wv[8];
 #pragma unroll
-            for (int k = 0; k < 14; k++) wv[k] = 0.0;
+            for (int k = 0; k < 8; k++) wv[k] = 0.0;
             if (act) {
                 if (h < 0) pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
                 const double mx = W.pt_ray[2*pt], my = W.pt_ray[2*pt+1], rh = rho[pt];
@@ -578,13 +580,10 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
                 for (int a = 0; a < 6; a++) wv[a] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]);
                 wv[6] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
                 wv[7] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
-                double qa[3], qc[3]; mat3T_vec(T.Rcr, wv, qa); mat3T_vec(T.Rcr, wv + 3, qc);     // host column: -Q^T w
-#pragma unroll
-                for (int a = 0; a < 3; a++) { wv[8 + a] = -qa[a]; wv[11 + a] = -qc[a]; }
             }
-            if (slot >= 0) {
+            if (slot >= 0) {                         // (the host column -Q^T w is a function of w and the pair's R_cr: k_mid forms it)
 #pragma unroll
-                for (int k = 0; k < 14; k++) B.w_pt[(size_t)(slot)*PT_REC + k] = wv[k];
+                for (int k = 0; k < 8; k++) B.w_pt[(size_t)(slot)*PT_REC + k] = wv[k];
             }
         }
         if (MODE == MODE_COST) {
@@ -712,23 +711,10 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
         if (wave > 0) return;
         // wave 0 alone from here (LDS accesses of one wave are ordered; the fence keeps the compiler honest)
         if (lane < 27) B.tgM[(size_t)lane*L.n_tg + tgpp] = tot;          // pair-major rank: k_mid sums a contiguous range
-        else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; lds[lane - 27] = tot; }
+        else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; }
         else if (lane < 54) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + 18 + (lane - 45)] = tot; }
         else if (lane == 54) B.tgCost[g] = tot;
-        if (slot >= 0) {                    // host column of W: -blkdiag(R,R)^T W, rows (half, r), columns cc
-            if (lane < 9) {
-                double rv = T.Rcr[0];
-#pragma unroll
-                for (int q = 1; q < 9; q++) if (lane == q) rv = T.Rcr[q];
-                lds[32 + lane] = act_g ? rv : 0.0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < 18) {
-                const int half = lane/9, rr = (lane % 9)/3, cc = lane % 3;
-                double v = lds[32 + 0*3 + rr]*lds[(half*3 + 0)*3 + cc] + lds[32 + 1*3 + rr]*lds[(half*3 + 1)*3 + cc] + lds[32 + 2*3 + rr]*lds[(half*3 + 2)*3 + cc];
-                B.w_tx[(size_t)(slot)*TX_REC + 18 + (9 + lane)] = -v;
-            }
-        }
+        // (the host column of W, -blkdiag(R,R)^T W, is formed by k_mid from W and the pair's R_cr; an inactive group leaves W = 0)
     }
 }
 
@@ -738,8 +724,10 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
     const LmState *st = W.st;
     const int b = blockIdx.x;
     // static offsets of this thread's landmark / pair first: in flight together with the LM state
-    int o = 0, e = 0, tq0 = 0, tq1 = 0, ph_ = -1, hp_ = -1, act_ = 0;
-    if (b < nb_pt) { const int j = b*256 + threadIdx.x; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j]; } }
+    int o = 0, e = 0, tq0 = 0, tq1 = 0, ph_ = -1, hp_ = -1, act_ = 0, pr0[MID_U] = {0, 0, 0, 0};
+    if (b < nb_pt) { const int j = b*256 + threadIdx.x; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
+#pragma unroll
+        for (int u = 0; u < MID_U; u++) pr0[u] = L.pt_pair4[MID_U*(size_t)j + u]; } }
     else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + threadIdx.x; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
     else { const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x; if (p < L.n_pair) { tq0 = L.pair_tg_off[p]; tq1 = L.pair_tg_off[p+1]; ph_ = L.pair_h[p]; hp_ = L.pair_hpos[p]; } }
     if (st->done) return;
@@ -749,21 +737,30 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
     const int sel = spec ? (st->cur ^ 1) : st->cur;
     __shared__ double red[256];
     const double *rho_x = W.rho[sel], *theta_x = W.theta[sel];
+    const size_t np_ = L.n_pair;
     double gm = 0.0, xn = 0.0;
     if (b < nb_pt) {
         const int j = b*256 + threadIdx.x;
         if (e > o) {
-            double acc[8] = {0,0,0,0,0,0,0,0};
-            for (int s0 = o; s0 < e - 1; s0 += 6) {                  // 6 slot records in flight per round trip
-                double v[6][8];
+            double acc[8] = {0,0,0,0,0,0,0,0};                       // V, b, host column -sum Q^T w
+            for (int s0 = o; s0 < e - 1; s0 += MID_U) {              // MID_U slot records (and their pairs' R_cr) in flight per round trip
+                int pr[MID_U]; double v[MID_U][8], R[MID_U][9];
 #pragma unroll
-                for (int u = 0; u < 6; u++)
+                for (int u = 0; u < MID_U; u++) pr[u] = s0 == o ? pr0[u] : L.pslot_pair[min(s0 + u, e - 2)];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) v[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 2))*PT_REC + 6 + k];
+                for (int u = 0; u < MID_U; u++) {
 #pragma unroll
-                for (int u = 0; u < 6; u++)
+                    for (int k = 0; k < 8; k++) v[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 2))*PT_REC + k];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) acc[k] += s0 + u < e - 1 ? v[u][k] : 0.0;
+                    for (int k = 0; k < 9; k++) R[u][k] = B.pairR[(size_t)k*np_ + pr[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < MID_U; u++) if (s0 + u < e - 1) {
+                    double qa[3], qc[3]; mat3T_vec(R[u], v[u], qa); mat3T_vec(R[u], v[u] + 3, qc);
+                    acc[0] += v[u][6]; acc[1] += v[u][7];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) { acc[2 + a] += -qa[a]; acc[5 + a] += -qc[a]; }
+                }
             }
 #pragma unroll
             for (int k = 0; k < 6; k++) B.w_pt[(size_t)(e - 1)*PT_REC + k] = acc[2 + k];
@@ -777,19 +774,32 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
     } else if (b < nb_pt + nb_tx) {
         const int j = (b - nb_pt)*256 + threadIdx.x;
         if (e > o) {
-            double acc[27];
+            double acc[27];                                          // V6, b3, host column -blkdiag(R,R)^T W (18)
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = 0.0;
-            for (int s0 = o; s0 < e - 1; s0 += 3) {                  // 3 slot records in flight per round trip
-                double v[3][27];
+            for (int s0 = o; s0 < e - 1; s0 += 2) {                  // 2 slot records in flight per round trip
+                int pr[2]; double v[2][27], R[2][9];
 #pragma unroll
-                for (int u = 0; u < 3; u++)
+                for (int u = 0; u < 2; u++) pr[u] = L.tslot_pair[min(s0 + u, e - 2)];
 #pragma unroll
-                    for (int k = 0; k < 27; k++) v[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 2))*TX_REC + 18 + k];
+                for (int u = 0; u < 2; u++) {
 #pragma unroll
-                for (int u = 0; u < 3; u++)
+                    for (int k = 0; k < 27; k++) v[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 2))*TX_REC + k];
 #pragma unroll
-                    for (int k = 0; k < 27; k++) acc[k] += s0 + u < e - 1 ? v[u][k] : 0.0;
+                    for (int k = 0; k < 9; k++) R[u][k] = B.pairR[(size_t)k*np_ + pr[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) if (s0 + u < e - 1) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) acc[k] += v[u][18 + k];
+#pragma unroll
+                    for (int half = 0; half < 2; half++)
+#pragma unroll
+                        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                            for (int cc = 0; cc < 3; cc++)
+                                acc[9 + (half*3 + rr)*3 + cc] += -(R[u][0*3 + rr]*v[u][(half*3 + 0)*3 + cc] + R[u][1*3 + rr]*v[u][(half*3 + 1)*3 + cc] + R[u][2*3 + rr]*v[u][(half*3 + 2)*3 + cc]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 18; k++) B.w_tx[(size_t)(e - 1)*TX_REC + k] = acc[9 + k];
@@ -1900,7 +1910,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         D.img_w = p->img_w[l]; D.img_h = p->img_h[l];
 #define UV(field) do { rc = dev_upload_vec(c, &D.field, H.field); if (rc) return rc; } while (0)
         UV(sc_obs); UV(sc_kf); UV(sc_pt); UV(sc_flag); UV(sc_slot); UV(sc_uv);
-        UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
+        UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pt_pair4); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
         UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
         UV(pf_g); UV(pf_f); D.n_pf = (int)H.pf_g.size();
         UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
@@ -2120,6 +2130,7 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     if (npp) hipLaunchKernelGGL(k_pose_sums, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
     if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi, npp);
 }
+#define TSBA_SMALL_SOLVER_DEFAULT 1        // 1 blocked 6x6 LDL^T (k_solve_t), 2 column LDL^T (k_solve_col)
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
     size_t bytes = solve_lds_doubles(c->W.N)*sizeof(double);                                // worst case: every pose free
     *use_lds = bytes <= 160*1024 - 64;                                                      // gfx950: 160 KB of LDS per workgroup
@@ -2132,8 +2143,12 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
 static int set_solver_attrs(Ctx *c) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    else {
+    if (use_lds) {
+        CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipFuncSetAttribute((const void *)k_solve_col<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solvec_lds_doubles<4>(c->W.N)*sizeof(double))));
+        CK(hipFuncSetAttribute((const void *)k_solve_col<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solvec_lds_doubles<8>(c->W.N)*sizeof(double))));
+        CK(hipFuncSetAttribute((const void *)k_solve_col<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solvec_lds_doubles<12>(c->W.N)*sizeof(double))));
+    } else {
         CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cr_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -2155,7 +2170,15 @@ static int set_solver_attrs(Ctx *c) {
 static void launch_solve(Ctx *c) {
     Work &W = c->W;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) { hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0); return; }
+    if (use_lds) {
+        // small windows: column LDL^T with the matrix in registers (tsba_solve.h); tsba_debug_set small_solver = 1 keeps the blocked kernel
+        const int rows = W.N + 1, solver = c->dbg.small_solver ? c->dbg.small_solver : TSBA_SMALL_SOLVER_DEFAULT;
+        if (solver == 1) hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);
+        else if (rows <= 64) hipLaunchKernelGGL(k_solve_col<4>, dim3(1), dim3(SOLVEC_T), (int)(solvec_lds_doubles<4>(W.N)*sizeof(double)), c->stream, W);
+        else if (rows <= 128) hipLaunchKernelGGL(k_solve_col<8>, dim3(1), dim3(SOLVEC_T), (int)(solvec_lds_doubles<8>(W.N)*sizeof(double)), c->stream, W);
+        else hipLaunchKernelGGL(k_solve_col<12>, dim3(1), dim3(SOLVEC_T), (int)(solvec_lds_doubles<12>(W.N)*sizeof(double)), c->stream, W);
+        return;
+    }
     if (c->band_stream && c->band_parts > 1) {      // partitioned: interiors in parallel + separator system (tsba_bandp.h)
         const int bwp = std::max(6, c->cur_bw_rows), cbp = bandp_chunk_blocks(bwp), P = c->band_parts;
         const int bwsep = 2*bwp - 6, cbs = band_chunk_blocks(bwsep);
@@ -2604,9 +2627,20 @@ int tsba_debug_stamps(void *ctx, long long *out64) {
 
 static int load_rccl(Ctx *c) {
     if (c->rccl_so) return 0;
-    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-    for (const char *n : names) { c->rccl_so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (c->rccl_so) break; }
-    if (!c->rccl_so) { set_err(c, std::string("dlopen(librccl): ") + dlerror()); return TSBA_ERR_COMM; }
+    // RCCL must sit on the SAME HIP runtime as this library: streams and device pointers do not cross runtimes.  A process can hold
+    // two (a PyTorch wheel bundles its own libamdhip64 + librccl next to /opt/rocm's, and which one this library is bound to
+    // depends on the load order), and a bare dlopen("librccl.so.1") returns whichever copy was loaded first.  So: find the
+    // runtime our own HIP calls resolve to and take the librccl next to it, by full path.
+    std::string tried;
+    Dl_info di;
+    if (dladdr((void *)&hipStreamSynchronize, &di) && di.dli_fname) {
+        std::string dir(di.dli_fname); const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? std::string(".") : dir.substr(0, sl);
+        for (const char *n : { "/librccl.so.1", "/librccl.so" }) {
+            const std::string path = dir + n; tried += path + " ";
+            c->rccl_so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL); if (c->rccl_so) break; }
+    }
+    if (!c->rccl_so) for (const char *n : { "librccl.so.1", "librccl.so" }) { tried += std::string(n) + " "; c->rccl_so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (c->rccl_so) break; }
+    if (!c->rccl_so) { set_err(c, std::string("dlopen(librccl) failed, tried: ") + tried + ": " + dlerror()); return TSBA_ERR_COMM; }
     c->p_getid = (decltype(c->p_getid))dlsym(c->rccl_so, "ncclGetUniqueId");
     c->p_init = (decltype(c->p_init))dlsym(c->rccl_so, "ncclCommInitRank");
     c->p_allreduce = (decltype(c->p_allreduce))dlsym(c->rccl_so, "ncclAllReduce");

@@ -30,6 +30,7 @@ struct HostPlan {
     // text groups
     std::vector<int32_t> tg_tobs, tg_kf, tg_text, tg_pair, tg_slot;
     std::vector<int32_t> pt_pose6;      // poses of the first 6 slots of every point (clamped): k_back needs them one round trip earlier
+    std::vector<int32_t> pt_pair4;      // pairs of the first 4 observer slots of every point (clamped): k_mid fetches their R_cr together with the slot records
     std::vector<int32_t> tg_ppos;       // rank of the group in pair-major order (pair_tg is the inverse): k_mid sums contiguous ranges
     std::vector<int32_t> pf_g, pf_f;    // single-keyframe problems (pose-only path): flat list of (group, feature) over all groups
     std::vector<int32_t> tg_rec;        // per group, one 32-byte record: tobs, kf, text, host, slot, f0, f1, fgood offset (all static)
@@ -241,6 +242,9 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     P.pt_pose6.assign(6*(size_t)n_pt, 0);
     for (int j = 0; j < n_pt; j++) { const int o = P.pls_off[j], e = P.pls_off[j+1];
         for (int u = 0; u < 6; u++) P.pt_pose6[6*(size_t)j + u] = e > o ? P.pslot_pose[std::min(o + u, e - 1)] : 0; }
+    P.pt_pair4.assign(4*(size_t)n_pt, 0);
+    for (int j = 0; j < n_pt; j++) { const int o = P.pls_off[j], e = P.pls_off[j+1];       // observer slots [o, e-1), host slot e-1
+        for (int u = 0; u < 4; u++) P.pt_pair4[4*(size_t)j + u] = e - 1 > o ? P.pslot_pair[std::min(o + u, e - 2)] : 0; }
     P.tg_ppos.assign(n_tg, 0);
     for (size_t k = 0; k < P.pair_tg.size(); k++) P.tg_ppos[P.pair_tg[k]] = (int)k;
     P.tg_rec.resize(8*(size_t)n_tg);
