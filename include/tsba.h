@@ -220,7 +220,7 @@ int  tsba_debug_reduced_band(void *ctx, double radius, int32_t *n, int32_t *bw, 
 /* Which kernels the uploaded problem runs through, so that a test can assert it exercises the path it means to.  out[11]:
  * [0] reduced system solved in LDS  [1] band storage of S  [2] streaming band solver  [3] interiors P of the partitioned solver
  * [4] separator system by cyclic reduction  [5] band rows  [6] four (target, host) pairs per wave in the linearisation
- * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] small-system solver variant */
+ * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] reserved */
 int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
 
 /* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
@@ -240,9 +240,8 @@ typedef struct tsba_debug_options {
     int32_t no_band_stream;    /* 1: large systems through the wide-band multi-workgroup Cholesky even when the band is narrow */
     int32_t no_pose_kernel;    /* 1: PoseOptim through the general pipeline instead of the fused pose-only kernel */
     int32_t no_small_pairs;    /* 1: never put four (target, host) pairs on one wave of the linearisation */
-    int32_t small_solver;      /* reduced systems that fit the LDS: 0 default, 1 blocked 6x6 LDL^T (k_solve_t), 2 column LDL^T (k_solve_col) */
     int32_t verbose;           /* 1: host-side timing of upload / plan construction on stderr */
-    int32_t reserved[9];
+    int32_t reserved[10];
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

@@ -316,36 +316,21 @@ def test_global_ba_partitioned_band_solver(gpu, n_kf, n_pt, band):
 @pytest.mark.parametrize("n_kf,state", [(4, abi.STATE_NOTREACHWIN), (9, abi.STATE_LOCAL), (10, abi.STATE_NOTREACHWIN), (11, abi.STATE_LOCAL),
                                         (20, abi.STATE_LOCAL), (21, abi.STATE_NOTREACHWIN), (22, abi.STATE_NOTREACHWIN), (27, abi.STATE_LOCAL),
                                         (31, abi.STATE_NOTREACHWIN)])
-def test_small_system_solvers_agree(gpu, n_kf, state):
-    """The two solvers of reduced systems that fit the LDS -- blocked 6x6 LDL^T (k_solve_t) and column LDL^T with the matrix in
-    registers (k_solve_col<4 / 8 / 12>: 16-row block counts, free-pose counts on both sides of every block boundary) -- against a
-    dense numpy solve of the downloaded system, and against each other over a whole LocalBundleAdjustment."""
+def test_small_system_solver_sizes(gpu, oracle_lib, n_kf, state):
+    """The LDS solver of small reduced systems (k_solve_t: blocked 6x6 LDL^T, rhs as an extra row, back-substitution in one wave with
+    60 rows per register) over 2 .. 29 free poses -- both sides of every 10-block boundary of the back-substitution and of the 16-row
+    MFMA tile edges -- against a dense numpy solve of the downloaded system, and the whole LocalBundleAdjustment against the oracle."""
     P = synth.make_problem(n_kf=n_kf, n_pt=40*n_kf, n_text=3, seed=100 + n_kf, feats=(12, 8, 6), text_targets=3, max_targets=6, band=12)
     o = abi.options_local(state)
-    out = {}
-    try:
-        for solver in (1, 2):
-            gpu.debug_set(small_solver=solver)
-            gpu.upload(P, o)
-            info = gpu.solver_info()
-            assert info["lds_solver"] == 1 and info["small_solver"] == solver
-            rg = gpu.reduced_system(o.initial_radius)
-            idx = np.concatenate([np.arange(6*k, 6*k + 6) for k in np.nonzero(rg["free"])[0]]); m = len(idx)
-            S = rg["S"][:m, :m]; S = np.tril(S) + np.tril(S, -1).T
-            ref = -np.linalg.solve(S, rg["g"][:m])
-            assert np.abs(rg["dp"][idx] - ref).max() <= 1e-9*np.abs(ref).max(), (solver, m)
-            fixed = np.setdiff1d(np.arange(6*n_kf), idx)
-            assert np.all(rg["dp"][fixed] == 0.0)
-            G = P.copy(); rep = gpu.LocalBundleAdjustment(G, options=o)
-            out[solver] = (G, rep, rg["dp"].copy())
-    finally:
-        gpu.debug_set()
-    (G1, r1, d1), (G2, r2, d2) = out[1], out[2]
-    assert r1["iters"] == r2["iters"] and r1["accepted"] == r2["accepted"] and r1["termination"] == r2["termination"]
-    np.testing.assert_allclose(r1["cost1"], r2["cost1"], rtol=1e-9)
-    np.testing.assert_allclose(G1.pose, G2.pose, rtol=0, atol=1e-8)
-    np.testing.assert_allclose(G1.rho, G2.rho, rtol=0, atol=1e-8)
-    assert np.array_equal(G1.sgood, G2.sgood)
+    gpu.upload(P, o)
+    assert gpu.solver_info()["lds_solver"] == 1
+    rg = gpu.reduced_system(o.initial_radius)
+    idx = np.concatenate([np.arange(6*k, 6*k + 6) for k in np.nonzero(rg["free"])[0]]); m = len(idx)
+    S = rg["S"][:m, :m]; S = np.tril(S) + np.tril(S, -1).T
+    ref = -np.linalg.solve(S, rg["g"][:m])
+    assert np.abs(rg["dp"][idx] - ref).max() <= 1e-9*np.abs(ref).max(), m
+    assert np.all(rg["dp"][np.setdiff1d(np.arange(6*n_kf), idx)] == 0.0)
+    _check_solve(gpu, oracle_lib, P, o, lambda G, oo: gpu.LocalBundleAdjustment(G, options=oo), atol=1e-7)
 
 
 @pytest.mark.gpu

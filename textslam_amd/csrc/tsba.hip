@@ -2130,7 +2130,6 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     if (npp) hipLaunchKernelGGL(k_pose_sums, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
     if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi, npp);
 }
-#define TSBA_SMALL_SOLVER_DEFAULT 1        // 1 blocked 6x6 LDL^T (k_solve_t), 2 column LDL^T (k_solve_col)
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
     size_t bytes = solve_lds_doubles(c->W.N)*sizeof(double);                                // worst case: every pose free
     *use_lds = bytes <= 160*1024 - 64;                                                      // gfx950: 160 KB of LDS per workgroup
@@ -2143,12 +2142,8 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
 static int set_solver_attrs(Ctx *c) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) {
-        CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        CK(hipFuncSetAttribute((const void *)k_solve_col<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solvec_lds_doubles<4>(c->W.N)*sizeof(double))));
-        CK(hipFuncSetAttribute((const void *)k_solve_col<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solvec_lds_doubles<8>(c->W.N)*sizeof(double))));
-        CK(hipFuncSetAttribute((const void *)k_solve_col<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solvec_lds_doubles<12>(c->W.N)*sizeof(double))));
-    } else {
+    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    else {
         CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cr_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -2170,15 +2165,7 @@ static int set_solver_attrs(Ctx *c) {
 static void launch_solve(Ctx *c) {
     Work &W = c->W;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) {
-        // small windows: column LDL^T with the matrix in registers (tsba_solve.h); tsba_debug_set small_solver = 1 keeps the blocked kernel
-        const int rows = W.N + 1, solver = c->dbg.small_solver ? c->dbg.small_solver : TSBA_SMALL_SOLVER_DEFAULT;
-        if (solver == 1) hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);
-        else if (rows <= 64) hipLaunchKernelGGL(k_solve_col<4>, dim3(1), dim3(SOLVEC_T), (int)(solvec_lds_doubles<4>(W.N)*sizeof(double)), c->stream, W);
-        else if (rows <= 128) hipLaunchKernelGGL(k_solve_col<8>, dim3(1), dim3(SOLVEC_T), (int)(solvec_lds_doubles<8>(W.N)*sizeof(double)), c->stream, W);
-        else hipLaunchKernelGGL(k_solve_col<12>, dim3(1), dim3(SOLVEC_T), (int)(solvec_lds_doubles<12>(W.N)*sizeof(double)), c->stream, W);
-        return;
-    }
+    if (use_lds) { hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0); return; }
     if (c->band_stream && c->band_parts > 1) {      // partitioned: interiors in parallel + separator system (tsba_bandp.h)
         const int bwp = std::max(6, c->cur_bw_rows), cbp = bandp_chunk_blocks(bwp), P = c->band_parts;
         const int bwsep = 2*bwp - 6, cbs = band_chunk_blocks(bwsep);
@@ -2560,7 +2547,7 @@ int tsba_text_label_image(void *ctx, int kf, int level, float *out) {
 // which kernels the uploaded problem runs through (so that a test can assert that it exercises the path it means to):
 // out[0] reduced system in LDS (k_solve_t / k_solve_col)   [1] band storage   [2] streaming band solver   [3] interiors P
 // [4] separator system by cyclic reduction   [5] band rows   [6] four pairs per wave in the linearisation of the first pass's level
-// [7] fused pose-only kernel   [8] one-wave Schur blocks + k_pose_sums (large maps)   [9] world size   [10] small-system solver variant
+// [7] fused pose-only kernel   [8] one-wave Schur blocks + k_pose_sums (large maps)   [9] world size   [10] reserved
 int tsba_debug_solver_info(void *ctx, int32_t *out, int n) {
     Ctx *c = (Ctx *)ctx; if (!c || !out || n < 11) return TSBA_ERR_ARG;
     if (!c->uploaded) return TSBA_ERR_STATE;
@@ -2568,7 +2555,7 @@ int tsba_debug_solver_info(void *ctx, int32_t *out, int n) {
     int bwmax = 0; for (int l = 0; l < c->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
     out[0] = use_lds; out[1] = c->W.band; out[2] = c->band_stream; out[3] = c->band_stream ? c->band_parts : 0; out[4] = c->sep_cr ? 1 : 0; out[5] = bwmax;
     out[6] = lin_small_pairs(c, c->lev[c->opt.levels[0]]) ? 1 : 0; out[7] = c->pose_only ? 1 : 0; out[8] = c->n_kf > 126 ? 1 : 0;
-    out[9] = c->world; out[10] = c->dbg.small_solver;
+    out[9] = c->world; out[10] = 0;
     return TSBA_OK;
 }
 int tsba_debug_plan_time(const tsba_problem *p, const tsba_options *o, int level, int reps, double *avg_ms) {   // host only: plan construction
