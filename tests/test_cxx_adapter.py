@@ -1,0 +1,157 @@
+"""The C ABI from C++ through the adapter templates a TextSLAM maintainer compiles (adapter/tsba_gather.hpp), over plain structs
+with the shape of TextSLAM's object graph (tests/cxx/mock_textslam.hpp).
+
+CPU (no GPU needed): tests/cxx/abi_from_cxx builds the object graph of a synthetic problem -- keyframes with vObvPts /
+vSceneObv2d[level] / vObvGoodPts / vFrameImg, map points and text planes with their host keyframes, observations and flags --,
+runs the adapter's gather (rows B1 of SURVEY.md 8a: optimizer.cc:201-279, :1366-1557) and must reproduce every flat array.
+GPU: the same binary then calls the entry point, scatters the result back into the object graph (row O2: optimizer.cc:292-326) and
+the graph's parameters / flags must equal what the Python mirror gets from the same flat problem.
+"""
+import os
+import struct
+import subprocess
+import numpy as np
+import pytest
+
+from textslam_amd import synth, abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cxx", "abi_from_cxx")
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cxx")])
+
+
+def _write_dump(path, P, state=abi.STATE_LOCAL):
+    P.normalise()
+    rec = []
+
+    def put(name, a, dt):
+        a = np.ascontiguousarray(a, {0: np.float64, 1: np.int32, 2: np.uint8}[dt]).reshape(-1)
+        rec.append(struct.pack("<I", len(name)) + name.encode() + struct.pack("<BQ", dt, a.size) + a.tobytes())
+    n_kf = P.n_kf
+    put("n_levels", [P.n_levels], 1); put("state", [state], 1); put("K", P.K, 0)
+    for k in ("pose", "rho", "theta", "pt_ray", "pt_host_Trw", "text_host_Twr", "text_box_ray"):
+        put(k, getattr(P, k), 0)
+    for k in ("pt_host", "text_host", "tobs_kf", "tobs_text", "tobs_fgood_off"):
+        put(k, getattr(P, k), 1)
+    for k in ("kf_initial", "sgood", "tobs_good", "tfgood"):
+        put(k, getattr(P, k), 2)
+    # the keyframes' flag ranges: level 0 lists every raw observation of a keyframe, in order
+    cnt = np.bincount(P.sobs_kf[0], minlength=n_kf) if P.sobs_kf[0].size else np.zeros(n_kf, np.int64)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    assert off[-1] == P.sgood.size and np.array_equal(P.sobs_flag[0], np.arange(P.sgood.size))
+    put("kf_flag_off", off, 1)
+    for l in range(P.n_levels):
+        put("sobs_kf_%d" % l, P.sobs_kf[l], 1); put("sobs_pt_%d" % l, P.sobs_pt[l], 1); put("sobs_flag_%d" % l, P.sobs_flag[l], 1)
+        put("sobs_uv0_%d" % l, P.sobs_uv0[l], 0)
+        if P.n_text:
+            put("tfeat_off_%d" % l, P.tfeat_off[l], 1); put("tfeat_raw_%d" % l, P.tfeat_raw[l], 1)
+            put("tfeat_uv_%d" % l, P.tfeat_uv[l], 0); put("tfeat_ref_%d" % l, P.tfeat_ref[l], 0)
+        if P.img[l] is not None:
+            put("img_%d" % l, P.img[l], 2); put("img_wh_%d" % l, [P.img[l].shape[2], P.img[l].shape[1]], 1)
+    with open(path, "wb") as f:
+        f.write(b"".join(rec))
+
+
+def _read_out(path):
+    out, b = {}, open(path, "rb").read()
+    i = 0
+    while i < len(b):
+        nl, = struct.unpack_from("<I", b, i); i += 4
+        name = b[i:i + nl].decode(); i += nl
+        dt, cnt = struct.unpack_from("<BQ", b, i); i += 9
+        ty = {0: np.float64, 1: np.int32, 2: np.uint8}[dt]
+        out[name] = np.frombuffer(b, ty, cnt, i).copy(); i += cnt*np.dtype(ty).itemsize
+    return out
+
+
+def _observed_only(P, kf):
+    """PoseOptim / InitBA address the landmarks through the observing frame: F.vObvPts[i] IS observation i (optimizer.cc:1126-1131),
+    the planes are the frame's vObvText.  Re-index a synthetic problem that way: keep the points / planes keyframe `kf` observes, in
+    observation order."""
+    Q = P.copy()
+    sel = Q.sobs_kf[0] == kf
+    assert sel.all()
+    pts = Q.sobs_pt[0].copy()
+    assert len(np.unique(pts)) == len(pts)
+    new_of = -np.ones(P.n_pt, np.int64); new_of[pts] = np.arange(len(pts))
+    Q.rho, Q.pt_ray, Q.pt_host, Q.pt_host_Trw = P.rho[pts], P.pt_ray.reshape(-1, 2)[pts], P.pt_host[pts], P.pt_host_Trw.reshape(-1, 12)[pts]
+    for l in range(P.n_levels):
+        Q.sobs_pt[l] = new_of[P.sobs_pt[l]].astype(np.int32)
+    tx = P.tobs_text.copy()
+    assert len(np.unique(tx)) == len(tx) and (P.tobs_kf == kf).all()
+    Q.theta = P.theta.reshape(-1, 3)[tx]; Q.text_host = P.text_host[tx]; Q.text_host_Twr = P.text_host_Twr.reshape(-1, 12)[tx]
+    Q.text_box_ray = P.text_box_ray.reshape(-1, 8)[tx]
+    Q.tobs_text = np.arange(len(tx), dtype=np.int32)
+    for l in range(P.n_levels):
+        off = P.tfeat_off[l]
+        idx = np.concatenate([np.arange(off[j], off[j + 1]) for j in tx]) if len(tx) else np.zeros(0, np.int64)
+        Q.tfeat_off[l] = np.concatenate([[0], np.cumsum([off[j + 1] - off[j] for j in tx])]).astype(np.int32)
+        Q.tfeat_raw[l], Q.tfeat_uv[l], Q.tfeat_ref[l] = P.tfeat_raw[l][idx], P.tfeat_uv[l].reshape(-1, 2)[idx], P.tfeat_ref[l].reshape(-1, 8)[idx]
+    return Q.normalise()
+
+
+def _cases():
+    out = {}
+    out["local"] = (synth.tiny(seed=41, n_kf=6, n_pt=120, n_text=5), "local")
+    out["global"] = (synth.config_global(n_kf=12, n_pt=300, band=5), "global")
+    out["landmarker"] = (synth.landmark_refine(seed=9), "landmarker")
+    out["pose"] = (_observed_only(synth.make_problem(1, 200, 6, 13, feats=(8, 6, 4), frozen_frac=1.0, n_out=4, max_targets=1, text_targets=1), 0), "pose")
+    P = _observed_only(synth.init_pair(seed=5), 1)
+    P.sgood[:] = 1; P.tobs_good[:] = 1; P.tfgood[:] = 1                       # InitBA has no flags
+    out["init"] = (P, "init")
+    out["theta"] = (synth.landmark_refine(seed=3, n_pt=0, n_text=2), "theta")
+    return out
+
+
+@pytest.mark.parametrize("name", ["local", "global", "landmarker", "pose", "init", "theta"])
+def test_gather_reproduces_flat_problem(tmp_path, name):
+    _build()
+    P, mode = _cases()[name]
+    dump, out = str(tmp_path / "p.bin"), str(tmp_path / "o.bin")
+    _write_dump(dump, P)
+    r = subprocess.run([EXE, dump, mode, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 3), (r.returncode, r.stdout, r.stderr)
+    assert "gather identical" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["local", "global", "landmarker", "pose", "init", "theta"])
+def test_cxx_solve_and_scatter_matches_python_mirror(tmp_path, name):
+    from textslam_amd.optimizer import Optimizer
+    _build()
+    P, mode = _cases()[name]
+    dump, out = str(tmp_path / "p.bin"), str(tmp_path / "o.bin")
+    _write_dump(dump, P)
+    r = subprocess.run([EXE, dump, mode, out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "gather identical" in r.stdout and "solve + scatter done" in r.stdout
+    res = _read_out(out)
+    g = Optimizer(0)
+    G = P.copy()
+    if mode == "theta":
+        # the C++ side built its own flat problem (host first, observers, current frame): only the result is comparable
+        assert res["cov_valid"][0] == 1 and np.all(np.linalg.eigvalsh(res["cov"].reshape(3, 3)) > 0)
+        assert not np.array_equal(res["theta"], P.theta.reshape(-1, 3)[0])
+        return
+    if mode == "local":
+        rep = g.LocalBundleAdjustment(G)
+    elif mode == "global":
+        rep = g.GlobalBA(G)
+    elif mode == "landmarker":
+        rep = g.OptimizeLandmarker(G)
+    elif mode == "pose":
+        rep = g.PoseOptim(G)
+    else:
+        rep = g.InitBA(G)
+    assert res["iters"].tolist() == rep["iters"]
+    np.testing.assert_allclose(res["cost1"], rep["cost1"], rtol=1e-9)
+    # the graph stores poses as matrices: q -> R -> q costs a few ulp, and the q of the start pose went through the same round trip
+    np.testing.assert_allclose(res["pose"], G.pose, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res["rho"], G.rho, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res["theta"], G.theta, rtol=0, atol=1e-9)
+    if mode in ("local", "landmarker", "pose"):
+        assert np.array_equal(res["sgood"], G.sgood) and np.array_equal(res["tobs_good"], G.tobs_good) and np.array_equal(res["tfgood"], G.tfgood)
+    assert not np.array_equal(G.rho, P.rho) or mode == "pose"
