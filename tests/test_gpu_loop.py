@@ -77,3 +77,20 @@ def test_optimize_loop_edge_cases(lo):
     a = (g["pose"], g["fixed"], g["edge_i"][keep], g["edge_j"][keep], g["meas"][keep])
     x, rep = lo.OptimizeLoop(*a); xo, ro = oracle.optimize_loop(*a)
     assert rep["iters"] == ro["iters"] and rep["cost1"] <= rep["cost0"] and np.allclose(x, xo, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_kf", [12, 150])
+def test_optimize_loop_first_step_tight(lo, oracle_lib, n_kf):
+    """ONE LM iteration from the same start: the step is a function of the first linearisation only (numeric-diff Jacobians, gradient,
+    damped normal equations), before any divergence of the two LM trajectories can build up -- poses and cost within 1e-8 / 1e-9 where
+    the 20-iteration end state is only comparable to 1e-6."""
+    g = synth.pose_graph(seed=n_kf, n_kf=n_kf)
+    o = lo.default_options_loop(); o.max_it = 1
+    a = (g["pose"], g["fixed"], g["edge_i"], g["edge_j"], g["meas"])
+    xg, rg = lo.OptimizeLoop(*a, options=o)
+    xo, ro = oracle_lib.optimize_loop(*a, options=o)
+    assert (rg["iters"], rg["accepted"]) == (ro["iters"], ro["accepted"]) == (1, 1)
+    np.testing.assert_allclose(rg["cost0"], ro["cost0"], rtol=1e-12)
+    np.testing.assert_allclose(rg["cost1"], ro["cost1"], rtol=1e-9)
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-8)
+    assert np.abs(xg - g["pose"]).max() > 1e-4                              # a real step was taken

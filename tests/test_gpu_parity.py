@@ -233,6 +233,30 @@ def test_init_ba_parity(gpu, oracle_lib):
     assert rep["n_passes"] == 4 and np.array_equal(G.pose.reshape(-1, 7)[0], P.pose.reshape(-1, 7)[0])
 
 
+def test_init_ba_first_linearisation_and_gauge_invariants(gpu, oracle_lib):
+    """InitBA where it CAN be tight.  (1) Every pyramid level's residuals / Jacobians / mu, sigma, and the reduced system of the first
+    linearisation (S, g: 1e-9 -- the step itself is not compared, S is singular along the scale gauge up to the damping).
+    (2) The end state in the quantities the scale gauge cannot touch: rotation, translation DIRECTION, rho |t| and theta |t|."""
+    P = synth.init_pair(seed=5)
+    o = abi.options_init()
+    for l in range(4):
+        _check_eval(gpu, oracle_lib, P, o, l)
+    ro = oracle_lib.reduced_system(P, o, o.levels[0], o.initial_radius)
+    gpu.upload(P, o)
+    rg = gpu.reduced_system(o.initial_radius)
+    m = 6*ro["nf"]
+    assert m == 6 and _rel(rg["S"][:m, :m], ro["S"]) < 1e-9 and _rel(rg["g"][:m], ro["g"]) < 1e-9
+    assert rg["cost"] == pytest.approx(ro["cost"], rel=1e-12)
+    G, R = P.copy(), P.copy()
+    gpu.InitBA(G, options=o); oracle_lib.solve(R, o)
+
+    def invariants(Q):
+        pose = Q.pose.reshape(-1, 7)[1]; t = pose[4:]; s = np.linalg.norm(t)
+        return pose[:4], t/s, Q.rho*s, Q.theta*s
+    for a, b in zip(invariants(G), invariants(R)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+
+
 def test_landmarker_parity(gpu, oracle_lib):
     """optimizer::OptimizeLandmarker (rows R5 / R9): every pose constant, rho and theta refined, scene outlier pass."""
     P = synth.landmark_refine(seed=9)

@@ -1433,6 +1433,21 @@ __global__ void k_damp_multi(Work W) {
     int ia = W.fidx[a]; if (ia < 0) return;
     for (int k = 0; k < 6; k++) W.S[(size_t)(6*ia + k)*W.ldS + 6*ia + k] += B.dgs_p[6*a + k]*irad;
 }
+// Band storage keeps every row of S in a skewed window of LDB = band + 2 x 96 - 1 doubles (room for the wide-band Cholesky's diagonal
+// blocks): 251 columns at a band of 60 rows, of which a row holds at most band + 6 entries of the lower triangle.  The ranks exchange
+// only those: pack -> one all-reduce of N (band + 6) doubles (15.8 MB instead of 60 MB at 5000 keyframes) -> unpack.
+__global__ __launch_bounds__(256) void k_band_pack(Work W, double *buf, int wp, int unpack) {
+    const LmState *st = W.st;
+    if (st->done) return;
+    const int n = 6*(*W.nfree);
+    const long long tot = (long long)n*wp;
+    const size_t ldS = (size_t)W.ldS;
+    for (long long e = (long long)blockIdx.x*256 + threadIdx.x; e < tot; e += (long long)gridDim.x*256) {
+        const int i = (int)(e/wp), k = (int)(e - (long long)i*wp), c = i - wp + 1 + k;     // row i, columns i - wp + 1 .. i
+        if (c < 0) { if (!unpack) buf[e] = 0.0; continue; }
+        if (unpack) W.S[(size_t)i*ldS + c] = buf[e]; else buf[e] = W.S[(size_t)i*ldS + c];
+    }
+}
 // landmark parameters live on their owner: delta = x - x0 on the owner, 0 elsewhere (all-reduced, then x = x0 + delta)
 __global__ void k_delta_multi(Work W, const double *rho0, const double *theta0, int apply) {
     const int cur = W.st->cur;
@@ -1626,6 +1641,7 @@ struct Ctx {
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
     bool pose_only = false;                       // one keyframe, every landmark frozen in its host: the fused pose-only LM kernel applies
     double *S_alloc = nullptr; size_t S_count = 0;
+    double *S_xchg = nullptr; int xchg_wp = 0;      // multi-GPU, band storage: packed band rows for the exchange (k_band_pack)
     bool sep_cr = false;                  // separator system by cyclic reduction on the compact block pool (tsba_bandcr.h)
     int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Bpart = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
     double *Lcol = nullptr; int band_stream = 0;  // streaming band solver (tsba_band.h): L by block column; 1 = every built level fits it     // storage behind W.S (dense or band)
@@ -1646,6 +1662,7 @@ struct Ctx {
 };
 
 static void set_err(Ctx *c, const std::string &s) { c->err = s; }
+static bool is_multi(const Ctx *c);
 
 // Device memory comes from a few large slabs (bump allocation, 256-byte aligned) that persist across uploads: the ~200 arrays
 // of a problem cost no hipMalloc / hipFree / hipMemset each (one memset per slab and upload), and host data is staged through a
@@ -2013,6 +2030,8 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             } else c->band_parts = 1;
         }
         AL(W.Sy, W.N);
+        c->S_xchg = nullptr; c->xchg_wp = 0;
+        if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, (size_t)W.N*c->xchg_wp); }
     }
     AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
@@ -2240,7 +2259,12 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream);   // block-sparse S
     launch_schur(c, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
-        allreduce(c, c->S_alloc, c->S_count, ncclDouble, ncclSum);
+        if (c->S_xchg) {                           // band storage: only the band's entries travel
+            const int nbp = (int)std::min<size_t>(2048, ((size_t)W.N*c->xchg_wp + 255)/256);
+            hipLaunchKernelGGL(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 0);
+            allreduce(c, c->S_xchg, (size_t)W.N*c->xchg_wp, ncclDouble, ncclSum);
+            hipLaunchKernelGGL(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 1);
+        } else allreduce(c, c->S_alloc, c->S_count, ncclDouble, ncclSum);
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
         hipLaunchKernelGGL(k_damp_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
