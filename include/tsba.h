@@ -125,7 +125,9 @@ typedef struct tsba_options {
     double  min_relative_decrease;
     double  function_tolerance, gradient_tolerance, parameter_tolerance;
     double  min_diagonal, max_diagonal;
-    /* multi-GPU (global BA): this rank's share of the landmarks is [lm_shard, n) stride lm_nshard */
+    /* multi-GPU (global BA): this rank keeps the residual blocks of the landmarks hosted in keyframes [lm_shard, lm_shard + 1) * n_kf /
+     * lm_nshard (co-visibility is local in keyframe index: the rank's pairs and S blocks stay near its own range); the observations of
+     * a frozen landmark go with their target keyframe */
     int32_t lm_shard, lm_nshard;
     /* 1: the pointers in tsba_problem.img are DEVICE pointers on this context's GPU (tsframe_level_ptr planes, include/tsframe.h:
      * the pyramid frame::GetPyrMat left in HBM) -- the upload reads them in place, no host round trip; they must stay valid and
@@ -217,10 +219,11 @@ int  tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, d
  * system), g [n], dp [6 n_kf] (by keyframe, 0 for constant poses).  ab / g / dp may be NULL (first call: sizes only). */
 int  tsba_debug_reduced_band(void *ctx, double radius, int32_t *n, int32_t *bw, double *ab, double *g, double *dp);
 
-/* Which kernels the uploaded problem runs through, so that a test can assert it exercises the path it means to.  out[11]:
+/* Which kernels the uploaded problem runs through, so that a test can assert it exercises the path it means to.  out[15]:
  * [0] reduced system solved in LDS  [1] band storage of S  [2] streaming band solver  [3] interiors P of the partitioned solver
  * [4] separator system by cyclic reduction  [5] band rows  [6] four (target, host) pairs per wave in the linearisation
- * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] reserved */
+ * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] rank
+ * [11..14] this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots */
 int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
 
 /* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
@@ -247,8 +250,8 @@ int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: bac
 
 /* ---- multi-GPU: RCCL communicator for tsba_global_ba (one process per GPU) ---- */
 /* One process per GPU.  Rank 0 calls tsba_comm_unique_id and broadcasts the 128 bytes (e.g. torch.distributed); every rank
- * then calls tsba_comm_init.  Afterwards tsba_upload keeps only this rank's landmarks (j mod world == rank, all poses
- * replicated) and tsba_solve all-reduces the reduced normal equations S, g (and a few scalars) once per LM trial.
+ * then calls tsba_comm_init.  Afterwards tsba_upload keeps only this rank's landmarks (those hosted in its keyframe range, all
+ * poses replicated) and tsba_solve all-reduces the reduced normal equations S (its band), g and a few scalars once per LM trial.
  * id128 == NULL selects the split (multi-GPU) kernel sequence without a communicator (single-process test hook). */
 int  tsba_comm_unique_id(void *ctx, void *id128);
 int  tsba_comm_init(void *ctx, const void *id128, int rank, int world);

@@ -716,9 +716,9 @@ static void neq_free(neq_t *N) { free(N->Hpp); free(N->bp); free(N->V); free(N->
 static int blk_in_shard(const pass_t *P, const blk_t *b) {
     const tsba_options *o = P->o;
     if (o->lm_nshard <= 1) return 1;
-    int key;
-    if (b->type == BLK_SCENE_BA || b->type == BLK_SCENE_POSE) key = b->lm; else key = P->p->n_pt + b->lm;
-    return key % o->lm_nshard == o->lm_shard;
+    /* the rank whose keyframe range holds the landmark's host; the observations of a frozen landmark go with their target */
+    int k = b->host >= 0 ? b->host : b->kf;
+    return (int)(((long long)k*o->lm_nshard)/P->p->n_kf) == o->lm_shard;
 }
 
 /* linearise at (pose,rho,theta): loss-corrected J^T J, J^T r.  Optionally keep corrected (r,J) per block for the model-cost test. */

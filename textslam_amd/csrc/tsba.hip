@@ -1453,11 +1453,11 @@ __global__ void k_delta_multi(Work W, const double *rho0, const double *theta0, 
     const int cur = W.st->cur;
     int j = blockIdx.x*blockDim.x + threadIdx.x;
     if (j < W.n_pt) {
-        if (!apply) W.dl_pt[j] = (j % W.world == W.rank) ? W.rho[cur][j] - rho0[j] : 0.0;
+        if (!apply) W.dl_pt[j] = (W.pt_host[j] >= 0 && tsba_shard_of(W.pt_host[j], 0, W.n_kf, W.world) == W.rank) ? W.rho[cur][j] - rho0[j] : 0.0;   // (a frozen landmark does not move)
         else W.rho[cur][j] = rho0[j] + W.dl_pt[j];
     } else if (j < W.n_pt + 3*W.n_text) {
         int k = j - W.n_pt, t = k/3;
-        if (!apply) W.dl_tx[k] = ((W.n_pt + t) % W.world == W.rank) ? W.theta[cur][k] - theta0[k] : 0.0;
+        if (!apply) W.dl_tx[k] = (W.text_host[t] >= 0 && tsba_shard_of(W.text_host[t], 0, W.n_kf, W.world) == W.rank) ? W.theta[cur][k] - theta0[k] : 0.0;
         else W.theta[cur][k] = theta0[k] + W.dl_tx[k];
     }
 }
@@ -2571,15 +2571,17 @@ int tsba_text_label_image(void *ctx, int kf, int level, float *out) {
 // which kernels the uploaded problem runs through (so that a test can assert that it exercises the path it means to):
 // out[0] reduced system in LDS (k_solve_t / k_solve_col)   [1] band storage   [2] streaming band solver   [3] interiors P
 // [4] separator system by cyclic reduction   [5] band rows   [6] four pairs per wave in the linearisation of the first pass's level
-// [7] fused pose-only kernel   [8] one-wave Schur blocks + k_pose_sums (large maps)   [9] world size   [10] reserved
+// [7] fused pose-only kernel   [8] one-wave Schur blocks + k_pose_sums (large maps)   [9] world size   [10] rank
+// [11..14] size of this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots
 int tsba_debug_solver_info(void *ctx, int32_t *out, int n) {
-    Ctx *c = (Ctx *)ctx; if (!c || !out || n < 11) return TSBA_ERR_ARG;
+    Ctx *c = (Ctx *)ctx; if (!c || !out || n < 15) return TSBA_ERR_ARG;
     if (!c->uploaded) return TSBA_ERR_STATE;
     int use_lds; solve_lds_bytes(c, &use_lds);
     int bwmax = 0; for (int l = 0; l < c->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
     out[0] = use_lds; out[1] = c->W.band; out[2] = c->band_stream; out[3] = c->band_stream ? c->band_parts : 0; out[4] = c->sep_cr ? 1 : 0; out[5] = bwmax;
     out[6] = lin_small_pairs(c, c->lev[c->opt.levels[0]]) ? 1 : 0; out[7] = c->pose_only ? 1 : 0; out[8] = c->n_kf > 126 ? 1 : 0;
-    out[9] = c->world; out[10] = 0;
+    out[9] = c->world; out[10] = c->rank;
+    { const LevelDev &D0 = c->lev[c->opt.levels[0]]; out[11] = D0.n_pair; out[12] = D0.n_sb; out[13] = D0.n_sc; out[14] = D0.n_pslot; }
     return TSBA_OK;
 }
 int tsba_debug_plan_time(const tsba_problem *p, const tsba_options *o, int level, int reps, double *avg_ms) {   // host only: plan construction

@@ -94,6 +94,16 @@ inline void bucket_order(const std::vector<int> &bucket, int n_bucket, std::vect
     for (size_t i = 0; i < bucket.size(); i++) order[(size_t)cur[bucket[i]]++] = (int)i;
 }
 
+// Which rank of a sharded global BA keeps a residual block: the rank whose KEYFRAME RANGE holds the landmark's host (ranges of
+// n_kf / nshard consecutive keyframes).  Co-visibility is local in keyframe index, so a rank's blocks touch only the (target, host)
+// pairs and the 6x6 blocks of S near its own range -- its linearisation and Schur assembly shrink with 1 / nshard (a landmark-index
+// stride would leave every rank with every pair and every S block, each 1 / nshard full).  A frozen landmark (host outside the map)
+// couples nothing: each of its observations goes with its target keyframe.
+__host__ __device__ inline int tsba_shard_of(int host, int target_kf, int n_kf, int nshard) {
+    const int k = host >= 0 ? host : target_kf;
+    return (int)(((long long)k*nshard)/n_kf);
+}
+
 inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false) {
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
@@ -116,7 +126,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         int kf = p->sobs_kf[L][s], pt = p->sobs_pt[L][s], host = p->pt_host[pt];
         if (host >= 0 && host == kf) continue;                    // optimizer.cc:1393 "Host != Target"
         touch(pt, kf, host);
-        if (o->lm_nshard > 1 && (pt % o->lm_nshard) != o->lm_shard) continue;   // multi-GPU: landmark shard
+        if (o->lm_nshard > 1 && tsba_shard_of(host, kf, n_kf, o->lm_nshard) != o->lm_shard) continue;   // multi-GPU: landmark shard
         cs.push_back({ s, kf, pt, host >= 0 ? host : -1 });
     }
     struct Grp { int tobs, kf, text, host; };
@@ -125,7 +135,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         int kf = p->tobs_kf[t], j = p->tobs_text[t], host = p->text_host[j];
         if (host >= 0 && host == kf) continue;                    // optimizer.cc:1484
         touch(n_pt + j, kf, host);
-        if (o->lm_nshard > 1 && ((n_pt + j) % o->lm_nshard) != o->lm_shard) continue;
+        if (o->lm_nshard > 1 && tsba_shard_of(host, kf, n_kf, o->lm_nshard) != o->lm_shard) continue;
         gs.push_back({ t, kf, j, host >= 0 ? host : -1 });
     }
     for (size_t lm = 0; lm < lm_lo.size(); lm++) if (lm_hi[lm] >= 0) reach[lm_lo[lm]] = std::max(reach[lm_lo[lm]], lm_hi[lm]);

@@ -212,9 +212,10 @@ class Optimizer:
 
     def solver_info(self):
         """Which kernel paths the uploaded problem takes (tsba_debug_solver_info)."""
-        v = (C.c_int32 * 11)()
-        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 11), "tsba_debug_solver_info")
-        keys = ("lds_solver", "band_storage", "band_stream", "interiors", "sep_cr", "band_rows", "small_pairs", "pose_kernel", "large_map", "world", "reserved")
+        v = (C.c_int32 * 15)()
+        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 15), "tsba_debug_solver_info")
+        keys = ("lds_solver", "band_storage", "band_stream", "interiors", "sep_cr", "band_rows", "small_pairs", "pose_kernel", "large_map", "world", "rank",
+                "n_pair", "n_sblock", "n_scene_candidates", "n_point_slots")
         return dict(zip(keys, [int(x) for x in v]))
 
     def reduced_band(self, radius: float):
