@@ -147,11 +147,13 @@ def test_cxx_solve_and_scatter_matches_python_mirror(tmp_path, name):
     else:
         rep = g.InitBA(G)
     assert res["iters"].tolist() == rep["iters"]
-    np.testing.assert_allclose(res["cost1"], rep["cost1"], rtol=1e-9)
-    # the graph stores poses as matrices: q -> R -> q costs a few ulp, and the q of the start pose went through the same round trip
-    np.testing.assert_allclose(res["pose"], np.asarray(G.pose).reshape(-1), rtol=0, atol=1e-9)
-    np.testing.assert_allclose(res["rho"], np.asarray(G.rho).reshape(-1), rtol=0, atol=1e-9)
-    np.testing.assert_allclose(res["theta"], np.asarray(G.theta).reshape(-1), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res["cost1"], rep["cost1"], rtol=1e-5 if mode == "init" else 1e-9)
+    # the graph stores poses as matrices: q -> R -> q costs a few ulp on the START pose of the C++ run; two-view InitBA amplifies that
+    # along its free scale gauge (tests/test_gpu_parity.py::test_init_ba_first_linearisation_and_gauge_invariants)
+    tol = 2e-6 if mode == "init" else 1e-9
+    np.testing.assert_allclose(res["pose"], np.asarray(G.pose).reshape(-1), rtol=0, atol=tol)
+    np.testing.assert_allclose(res["rho"], np.asarray(G.rho).reshape(-1), rtol=0, atol=tol)
+    np.testing.assert_allclose(res["theta"], np.asarray(G.theta).reshape(-1), rtol=0, atol=tol)
     if mode in ("local", "landmarker", "pose"):
         assert np.array_equal(res["sgood"], G.sgood.reshape(-1)) and np.array_equal(res["tobs_good"], G.tobs_good.reshape(-1)) and np.array_equal(res["tfgood"], G.tfgood.reshape(-1))
     assert not np.array_equal(G.rho, P.rho) or mode == "pose"

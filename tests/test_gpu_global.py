@@ -158,52 +158,8 @@ def test_c5_full_size_global_ba_with_text(gpu):
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 on one device
-@pytest.mark.parametrize("nshard", [2, 3])
-@pytest.mark.parametrize("shape", ["dense", "band"])
-def test_device_landmark_striding_sums_to_unsharded_system(nshard, shape):
-    """tsba_upload with lm_nshard > 1 on the DEVICE path: each shard keeps the landmarks j = shard mod nshard, runs the split
-    (multi-GPU) kernel sequence and leaves its partial S, g before any exchange; the parts of all shards must sum to the
-    unsharded system, and every shard must derive the same band layout (the envelope comes from all observations)."""
-    from textslam_amd.optimizer import Optimizer
-    if shape == "dense":
-        P = synth.make_problem(n_kf=24, n_pt=900, n_text=12, seed=11, feats=(12, 8, 6), max_targets=6, text_targets=4, frozen_frac=0.1, band=8, n_levels=1)
-        o = abi.options_global(); o.use_text = 1
-    else:
-        P = synth.config_global(n_kf=300, n_pt=9000, band=8, far_frac=0.0)
-        o = abi.options_global()
-    radius = o.initial_radius
-
-    def system(shard, n):
-        g = Optimizer(0)
-        g.comm_init(None, 0, 1)                                       # split kernel sequence, no communicator
-        oo = abi.TsbaOptions.from_buffer_copy(o); oo.lm_shard, oo.lm_nshard = shard, n
-        g.upload(P, oo)
-        info = g.solver_info()
-        if shape == "dense":
-            r = g.reduced_system(radius); out = (r["S"].copy(), r["g"].copy(), r["free"].copy(), info)
-        else:
-            r = g.reduced_band(radius); out = (r["ab"].copy(), r["g"].copy(), r["free"].copy(), info)
-        g.close()
-        return out
-    S0, g0, free0, info0 = system(0, 1)
-    S = np.zeros_like(S0); gv = np.zeros_like(g0)
-    for r in range(nshard):
-        Sr, gr, fr, info = system(r, nshard)
-        assert Sr.shape == S0.shape and np.array_equal(fr, free0)
-        assert info["band_rows"] == info0["band_rows"] and info["band_storage"] == info0["band_storage"]
-        assert np.abs(Sr).max() > 0 and not np.allclose(Sr, S0)       # a proper part
-        S += Sr; gv += gr
-    scale = np.abs(S0).max()
-    if shape == "dense":                                              # (rows of constant poses: untouched storage on both sides)
-        rows = _free_rows(free0); m = rows.size
-        assert np.abs(S[:m, :m] - S0[:m, :m]).max() <= 1e-12*scale
-    else:
-        assert np.abs(S - S0).max() <= 1e-12*scale
-    assert np.abs(gv - g0).max() <= 1e-12*np.abs(g0).max()
-
-
-def _solve_on_ranks(P, o, world, call="GlobalBA"):
-    """The whole N-rank solve on one device: `world` contexts, one host thread each, collectives through the in-process group."""
+def _on_ranks(world, fn):
+    """Run fn(optimizer, rank) on `world` contexts of this process, one thread each, joined through the in-process communicator."""
     from textslam_amd.optimizer import Optimizer, local_group_create, local_group_destroy
     group = local_group_create(world)
     out, err = [None]*world, [None]*world
@@ -212,9 +168,7 @@ def _solve_on_ranks(P, o, world, call="GlobalBA"):
         try:
             g = Optimizer(0)
             g.comm_init_local(group, rank, world)
-            G = P.copy()
-            rep = getattr(g, call)(G, options=o)
-            out[rank] = (G, rep, g.solver_info())
+            out[rank] = fn(g, rank)
             g.close()
         except Exception as e:                                          # noqa: BLE001 -- reported below
             err[rank] = e
@@ -226,6 +180,57 @@ def _solve_on_ranks(P, o, world, call="GlobalBA"):
     local_group_destroy(group)
     assert all(e is None for e in err), err
     return out
+
+
+@pytest.mark.parametrize("nshard", [2, 3])
+@pytest.mark.parametrize("shape", ["dense", "band"])
+def test_device_landmark_shards_sum_to_unsharded_system(nshard, shape):
+    """The sharded upload on the DEVICE path: rank r keeps the landmarks hosted in its keyframe range, runs the split (multi-GPU) kernel
+    sequence -- participation flags and pose sums all-reduced -- and leaves its PARTIAL S, g before the exchange of the reduced system.
+    The parts of all ranks must sum to the unsharded system, every rank must derive the same band layout and the same free poses, and
+    the ranks' plans must be proper parts (pairs and S blocks local to the rank's keyframe range)."""
+    from textslam_amd.optimizer import Optimizer
+    if shape == "dense":
+        P = synth.make_problem(n_kf=24, n_pt=900, n_text=12, seed=11, feats=(12, 8, 6), max_targets=6, text_targets=4, frozen_frac=0.1, band=8, n_levels=1)
+        o = abi.options_global(); o.use_text = 1
+    else:
+        P = synth.config_global(n_kf=300, n_pt=9000, band=8, far_frac=0.0)
+        o = abi.options_global()
+    radius = o.initial_radius
+
+    def system(g, rank):
+        g.upload(P, o)
+        info = g.solver_info()
+        r = g.reduced_system(radius) if shape == "dense" else g.reduced_band(radius)
+        return (r["S"].copy() if shape == "dense" else r["ab"].copy()), r["g"].copy(), r["free"].copy(), info
+    g0 = Optimizer(0); g0.comm_init(None, 0, 1)                        # unsharded, split kernel sequence (S without the pose damping)
+    S0, gv0, free0, info0 = system(g0, 0); g0.close()
+    parts = _on_ranks(nshard, system)
+    S = np.zeros_like(S0); gv = np.zeros_like(gv0)
+    for Sr, gr, fr, info in parts:
+        assert Sr.shape == S0.shape and np.array_equal(fr, free0)
+        assert info["band_rows"] == info0["band_rows"] and info["band_storage"] == info0["band_storage"] and info["world"] == nshard
+        assert np.abs(Sr).max() > 0 and not np.allclose(Sr, S0)       # a proper part
+        S += Sr; gv += gr
+    assert sum(i["n_scene_candidates"] for _, _, _, i in parts) == info0["n_scene_candidates"]       # every block on exactly one rank
+    if shape == "band":                                                # keyframe-range ownership keeps the pairs / S blocks local
+        assert max(i["n_pair"] for _, _, _, i in parts) < 0.75*info0["n_pair"] and max(i["n_sblock"] for _, _, _, i in parts) < 0.75*info0["n_sblock"]
+    scale = np.abs(S0).max()
+    if shape == "dense":                                              # (rows of constant poses: untouched storage on both sides)
+        m = _free_rows(free0).size
+        assert np.abs(S[:m, :m] - S0[:m, :m]).max() <= 1e-12*scale
+    else:
+        assert np.abs(S - S0).max() <= 1e-12*scale
+    assert np.abs(gv - gv0).max() <= 1e-12*np.abs(gv0).max()
+
+
+def _solve_on_ranks(P, o, world, call="GlobalBA"):
+    """The whole N-rank solve on one device: `world` contexts, one host thread each, collectives through the in-process group."""
+    def solve(g, rank):
+        G = P.copy()
+        rep = getattr(g, call)(G, options=o)
+        return G, rep, g.solver_info()
+    return _on_ranks(world, solve)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -877,12 +877,12 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
 //   sums_local : pose diagonal / gradient from the pair sums (-> B.Hd, B.bp), landmark gradient max / |x|^2, cost
 //   pose_scale : Jacobi scaling, LM diagonal, gradient max and |x|^2 of the free poses (from the possibly all-reduced Hd / bp)
 __device__ void sums_local(const Work &W, const LevelDev &L, const LinBuf &B, double *dHd, double *dbp, int nb_lm, double *red,
-                           double &gmax_lm, double &xn_lm, double &cost) {
+                           double &gmax_lm, double &xn_lm, double &cost, bool skip_pose = false) {
     const int tid = threadIdx.x;
     gmax_lm = 0.0; xn_lm = 0.0; cost = 0.0;
     const double *out = B.pairOut;
     const size_t np = L.n_pair;
-    for (int task = tid; task < 12*W.n_kf; task += 256) {          // (pose, component): diag H (6) | b (6)
+    for (int task = tid; task < (skip_pose ? 0 : 12*W.n_kf); task += 256) {          // (pose, component): diag H (6) | b (6)   (large maps: k_pose_sums_raw did it)
         const int a = task/12, k = task - 12*a;
         const int t0 = L.pose_t_off[a], t1 = L.pose_t_off[a+1], h0 = L.pose_h_off[a], h1 = L.pose_h_off[a+1];
         if (k < 6) {
@@ -1051,6 +1051,56 @@ __global__ __launch_bounds__(256) void k_pose_sums(Work W, LevelDev L, int spec)
     gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red);
     if (tid == 0) { W.posepart[2*blockIdx.x] = gmax; W.posepart[2*blockIdx.x + 1] = xn; }
 }
+// The same in a sharded (multi-GPU) run, in two stages around the all-reduce of the exchange buffer cb = [Hd | bp | scalars]:
+//   k_pose_sums_raw    this rank's part of diag(H_pp) and of the pose gradient, 21 poses per workgroup  -> cb, B.bp_loc
+//   k_pose_scale_multi from the all-reduced cb: B.Hd / B.bp, Jacobi scale (first linearisation), LM diagonal, per-workgroup partials of
+//                      the gradient maximum and |x|^2 of the free poses -> W.posepart
+// (one workgroup walking 5000 poses cost 0.7 ms per linearisation: more than everything the sharding saves)
+__global__ __launch_bounds__(256) void k_pose_sums_raw(Work W, LevelDev L, int spec) {
+    const LmState *st = W.st;
+    if (st->done) return;
+    if (!spec && !st->need_lin) return;
+    if (spec && st->step_fail) return;
+    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
+    const int tid = threadIdx.x;
+    const double *out = B.pairOut; const size_t np = L.n_pair;
+    const int al = tid/12, k = tid - 12*al, a = blockIdx.x*21 + al;
+    if (tid >= 252 || a >= W.n_kf) return;
+    const int t0 = L.pose_t_off[a], t1 = L.pose_t_off[a+1], h0 = L.pose_h_off[a], h1 = L.pose_h_off[a+1];
+    const int kk = k < 6 ? k : k - 6;
+    const double *rt = out + (size_t)(k < 6 ? sym6(kk, kk) : 21 + kk)*np, *rh = out + (size_t)(k < 6 ? 63 + sym6(kk, kk) : 84 + kk)*np;
+    const double vt = range_sum<24>(rt, t0, t1), vh = range_sum<24>(rh, h0, h1);
+    if (k < 6) W.cb[6*a + kk] = vt + vh;
+    else { const double g = vt - vh; W.cb[W.N + 6*a + kk] = g; B.bp_loc[6*a + kk] = g; }
+}
+__global__ __launch_bounds__(256) void k_pose_scale_multi(Work W, int spec) {
+    const LmState *st = W.st;
+    if (st->done) return;
+    if (!spec && !st->need_lin) return;
+    if (spec && st->step_fail) return;
+    __shared__ double red[256];
+    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
+    const double *pose = W.pose[spec ? (st->cur ^ 1) : st->cur];
+    const bool first = !spec && st->first != 0;
+    const int tid = threadIdx.x, al = tid/6, k = tid - 6*al, a = blockIdx.x*21 + al;
+    double gmax = 0.0, xn = 0.0;
+    if (tid < 126 && a < W.n_kf) {
+        const double h = W.cb[6*a + k], g = W.cb[W.N + 6*a + k];
+        B.Hd[6*a + k] = h; B.bp[6*a + k] = g;
+        double sg;
+        if (first) { sg = 1.0/(1.0 + sqrt(h)); W.sig_p[6*a + k] = sg; } else sg = W.sig_p[6*a + k];
+        B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
+        if (W.fidx[a] >= 0) { gmax = fabs(g); const double px = pose[7*a + k]; xn = px*px; if (k == 0) { const double p6 = pose[7*a + 6]; xn += p6*p6; } }
+    }
+    gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red);
+    if (tid == 0) { W.posepart[2*blockIdx.x] = gmax; W.posepart[2*blockIdx.x + 1] = xn; }
+}
+// the pose part of k_postlin / k_decide in a sharded run on a large map: the partials k_pose_scale_multi left
+__device__ void pose_parts_multi(const Work &W, int npp, double *red, double &gmax_p, double &xn_p) {
+    gmax_p = 0.0; xn_p = 0.0;
+    for (int k = threadIdx.x; k < npp; k += 256) { gmax_p = fmax(gmax_p, W.posepart[2*k]); xn_p += W.posepart[2*k + 1]; }
+    gmax_p = block_max<256>(gmax_p, red); xn_p = block_sum<256>(xn_p, red);
+}
 __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm, int multi, int npp) {
     LmState *st = W.st;
     if (st->done || !st->need_lin) return;
@@ -1058,7 +1108,8 @@ __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad
     double gmax, xn, cost;
     const LinBuf &B = W.lb[st->lcur];
     if (!multi) { double o5[5]; postlin_fused(W, L, B, W.pose[st->cur], st->first != 0, nb_lm, 0, red, xch, o5, npp); gmax = o5[0]; xn = o5[1]; cost = o5[2]; }
-    else { double gp, xp; pose_scale(W, B, W.cb, W.cb + W.N, W.pose[st->cur], st->first != 0, red, gp, xp);
+    else { double gp, xp;
+           if (npp) pose_parts_multi(W, npp, red, gp, xp); else pose_scale(W, B, W.cb, W.cb + W.N, W.pose[st->cur], st->first != 0, red, gp, xp);
            const double *sc = W.cb + 2*(size_t)W.N; cost = sc[0]; xn = sc[1] + xp; gmax = fmax(W.cbm[0], gp); }
     if (threadIdx.x == 0) {
         st->x_cost = cost; st->x_norm = sqrt(xn); st->gmax = gmax;
@@ -1365,7 +1416,7 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
 #endif
     } else {                                      // k_sums_multi + all-reduce already produced the global sums
         double gp, xp;
-        pose_scale(W, Bc, W.cb, W.cb + W.N, W.pose[st->cur ^ 1], false, red, gp, xp);
+        if (npp) pose_parts_multi(W, npp, red, gp, xp); else pose_scale(W, Bc, W.cb, W.cb + W.N, W.pose[st->cur ^ 1], false, red, gp, xp);
         const double *sc = W.cb + 2*(size_t)W.N;
         cost = sc[0]; xn_c = sc[1] + xp; step2 = sc[2]; mcc = sc[3]; gmax_c = fmax(W.cbm[0], gp);
     }
@@ -1408,14 +1459,14 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
 // ================================================================== multi-GPU (global BA sharded by landmark over RCCL)
 // stage A: local sums into the all-reduce buffer hb = [Hd | bp | scal] and gm.  spec: candidate LinBuf (also folds the
 // k_back partial sums: landmark blocks are owned by exactly one rank, the replicated pose blocks count on rank 0 only)
-__global__ __launch_bounds__(256) void k_sums_multi(Work W, LevelDev L, int spec, int nb_lm, int nb_back, int nb_back_lm) {
+__global__ __launch_bounds__(256) void k_sums_multi(Work W, LevelDev L, int spec, int nb_lm, int nb_back, int nb_back_lm, int skip_pose) {
     LmState *st = W.st;
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     __shared__ double red[256];
     const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
     double gl, xl, cost;
-    sums_local(W, L, B, W.cb, W.cb + W.N, nb_lm, red, gl, xl, cost);
+    sums_local(W, L, B, W.cb, W.cb + W.N, nb_lm, red, gl, xl, cost, skip_pose != 0);
     double step2 = 0.0, mcc = 0.0;
     if (spec) for (int k = threadIdx.x; k < nb_back; k += 256)
         if (k < nb_back_lm || W.rank == 0) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
@@ -1653,6 +1704,7 @@ struct Ctx {
     int rank = 0, world = 1; bool force_multi = false;
     tsba_debug_options dbg{};                      // test / diagnostics switches (tsba_debug_set), all zero in production
     struct LocalGroup *lgroup = nullptr;           // in-process communicator (tsba_comm_init_local)
+    bool in_solve = false, has_token = false;      // local group: this rank is inside tsba_solve / holds the group's device token
     size_t x_acc = 0, x_trial = 0, x_lin = 0, x_pass = 0;   // bytes handed to collectives: running total; last LM trial / linearisation / pass set-up
     decltype(&ncclCommCount) p_count = nullptr;
     void *rccl_so = nullptr; ncclComm_t comm = nullptr;
@@ -2068,6 +2120,10 @@ struct LocalGroup {
     int world = 1; bool broken = false;
     std::mutex m; std::condition_variable cv; int arrived = 0; unsigned long long gen = 0;
     std::vector<std::vector<char>> stage; std::vector<char> result;
+    // The ranks of a group usually share ONE device.  A rank holds this token while it has kernels in flight (from the moment it leaves a
+    // collective until its stream has drained at the next one), so that the ranks' launches do not overlap on the device: kernel
+    // durations under a profiler are then those of a rank that has the GPU to itself, as in a real multi-GPU run.
+    std::mutex gpu_token;
     bool barrier() {                               // false: a member never arrived (it failed before the collective) -- do not hang
         std::unique_lock<std::mutex> lk(m);
         if (broken) return false;
@@ -2085,6 +2141,8 @@ static void local_allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, 
     std::vector<char> &mine = G->stage[c->rank];
     mine.resize(bytes);
     if (hipMemcpy(mine.data(), buf, bytes, hipMemcpyDeviceToHost) != hipSuccess) { fail("device-to-host"); return; }
+    if (c->has_token) { c->has_token = false; G->gpu_token.unlock(); }          // this rank's kernels have drained: the next rank may run
+    struct Retake { Ctx *c; LocalGroup *G; ~Retake() { if (c->in_solve && !c->has_token) { G->gpu_token.lock(); c->has_token = true; } } } retake{c, G};
     if (!G->barrier()) { fail("a rank did not arrive"); return; }
     if (c->rank == 0) {
         G->result = G->stage[0];
@@ -2126,7 +2184,7 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     else hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
-static int pose_parts(const Ctx *c) { return (c->n_kf > 126 && !is_multi(c)) ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
+static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
 // pairs with a dozen scene blocks (large maps): four pairs per wave
 static bool lin_small_pairs(const Ctx *c, const LevelDev &D) { return !c->dbg.no_small_pairs && D.n_pair > 0 && (long long)D.n_sc <= 24LL*D.n_pair; }
 static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
@@ -2139,14 +2197,15 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     }
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
+    const int npp = pose_parts(c);
     if (multi) {
         // local sums -> exchange buffer -> all-reduce; the consumer (k_postlin / k_decide) installs them into the right LinBuf
-        hipLaunchKernelGGL(k_sums_multi, dim3(1), dim3(256), 0, c->stream, W, D, spec, nb_pt + nb_tx + nb_pr, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx);
+        if (npp) hipLaunchKernelGGL(k_pose_sums_raw, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
+        hipLaunchKernelGGL(k_sums_multi, dim3(1), dim3(256), 0, c->stream, W, D, spec, nb_pt + nb_tx + nb_pr, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx, npp);
         allreduce(c, W.cb, 2*(size_t)W.N + 8, ncclDouble, ncclSum);
         allreduce(c, W.cbm, 1, ncclDouble, ncclMax);
-    }
-    const int npp = pose_parts(c);
-    if (npp) hipLaunchKernelGGL(k_pose_sums, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
+        if (npp) hipLaunchKernelGGL(k_pose_scale_multi, dim3(npp), dim3(256), 0, c->stream, W, spec);
+    } else if (npp) hipLaunchKernelGGL(k_pose_sums, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
     if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi, npp);
 }
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
@@ -2282,6 +2341,8 @@ int tsba_solve(void *ctx, tsba_report *r) {
     const tsba_options &o = c->opt;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     { int rca = set_solver_attrs(c); if (rca) return rca; }
+    struct Token { Ctx *c; Token(Ctx *c_) : c(c_) { if (c->lgroup) { c->in_solve = true; c->lgroup->gpu_token.lock(); c->has_token = true; } }
+                   ~Token() { if (c->lgroup) { c->in_solve = false; if (c->has_token) { hipStreamSynchronize(c->stream); c->has_token = false; c->lgroup->gpu_token.unlock(); } } } } token(c);
     auto t0 = std::chrono::steady_clock::now();
     int rc = reset_state(c); if (rc) return rc;
     for (int ps = 0; ps < o.n_passes; ps++) {
