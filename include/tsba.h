@@ -218,12 +218,16 @@ int  tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, d
  * bw = sub-diagonals kept, ab[(i - j)*n + j] = S(i, j) for j <= i <= j + bw (LAPACK lower band, rows of the COMPRESSED free-pose
  * system), g [n], dp [6 n_kf] (by keyframe, 0 for constant poses).  ab / g / dp may be NULL (first call: sizes only). */
 int  tsba_debug_reduced_band(void *ctx, double radius, int32_t *n, int32_t *bw, double *ab, double *g, double *dp);
+/* Row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating).  Not
+ * monotone in the keyframe index when the plan reordered the keyframes (solver_info [15]). */
+int  tsba_debug_row_of_kf(void *ctx, int32_t *rowblk);
 
-/* Which kernels the uploaded problem runs through, so that a test can assert it exercises the path it means to.  out[15]:
+/* Which kernels the uploaded problem runs through, so that a test can assert it exercises the path it means to.  out[16]:
  * [0] reduced system solved in LDS  [1] band storage of S  [2] streaming band solver  [3] interiors P of the partitioned solver
  * [4] separator system by cyclic reduction  [5] band rows  [6] four (target, host) pairs per wave in the linearisation
  * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] rank
- * [11..14] this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots */
+ * [11..14] this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots
+ * [15] rows of S in reverse Cuthill-McKee order of the keyframes (wide envelopes: loop closures) */
 int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
 
 /* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
@@ -244,7 +248,8 @@ typedef struct tsba_debug_options {
     int32_t no_pose_kernel;    /* 1: PoseOptim through the general pipeline instead of the fused pose-only kernel */
     int32_t no_small_pairs;    /* 1: never put four (target, host) pairs on one wave of the linearisation */
     int32_t verbose;           /* 1: host-side timing of upload / plan construction on stderr */
-    int32_t reserved[10];
+    int32_t no_kf_reorder;     /* 1: keep the rows of S in keyframe order even when the envelope is wide (loop closures) */
+    int32_t reserved[9];
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

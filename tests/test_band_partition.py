@@ -1,6 +1,7 @@
 """Host-side index arithmetic of the partitioned band solver (tsba_bandp.h / tsba_bandcr.h) through the library's debug hooks: no GPU
 needed.  The partition table every workgroup derives on the device, and the block pool of the cyclic-reduction separator solver."""
 import ctypes as C
+import numpy as np
 import os
 import pytest
 
@@ -63,3 +64,55 @@ def test_cyclic_reduction_block_pool(lib, mmax):
                 take(c, i)
                 take(c, a)                           # the new stride-2h coupling
         h *= 2
+
+
+def _plan_band(P, o, reorder):
+    import ctypes as C
+    from textslam_amd.optimizer import load_library
+    from textslam_amd import abi
+    L = load_library()
+    L.tsba_debug_plan_band.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    s = P.struct(); bw = C.c_int32(0); order = np.zeros(P.n_kf, np.int32)
+    assert L.tsba_debug_plan_band(C.byref(s), C.byref(o), 0, reorder, C.byref(bw), order.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    return bw.value, order
+
+
+def _envelope(P, order):
+    """Half bandwidth (pose blocks, Cholesky fill closed) of the reduced camera matrix under a row order, straight from the observations."""
+    n = P.n_kf
+    pos = np.empty(n, np.int64); pos[order] = np.arange(n)
+    kf, host = P.sobs_kf[0].astype(np.int64), P.pt_host[P.sobs_pt[0]].astype(np.int64)
+    m = (host >= 0) & (host != kf)
+    lo = np.full(P.n_pt, n, np.int64); hi = np.full(P.n_pt, -1, np.int64)
+    for a in (pos[kf[m]], pos[host[m]]):
+        np.minimum.at(lo, P.sobs_pt[0][m], a); np.maximum.at(hi, P.sobs_pt[0][m], a)
+    reach = np.arange(n)
+    ok = hi >= 0
+    np.maximum.at(reach, lo[ok], hi[ok])
+    run, bw = -1, 0
+    for k in range(n):
+        r = max(reach[k], run) if run >= k else reach[k]
+        run = max(run, r); bw = max(bw, r - k)
+    return bw
+
+
+def test_keyframe_reordering_of_a_loop_closure_map():
+    """Host side of the loop-closure handling (no GPU): on a ring map the keyframe-order envelope spans the matrix, the reverse
+    Cuthill-McKee order of the plan brings it to about twice the local band; the reported bound is the true envelope under that order;
+    a banded map keeps the keyframe order."""
+    from textslam_amd import synth, abi
+    o = abi.options_global()
+    P = synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True)
+    bw_id, order_id = _plan_band(P, o, 0)
+    bw_rcm, order = _plan_band(P, o, 1)
+    assert np.array_equal(order_id, np.arange(600)) and bw_id >= 590
+    assert sorted(order.tolist()) == list(range(600)) and not np.array_equal(order, np.arange(600))
+    assert bw_rcm <= 3*8 and bw_rcm == _envelope(P, order) and bw_id == _envelope(P, np.arange(600))
+    Q = synth.config_global(n_kf=300, n_pt=6000, band=8)
+    bw_b, order_b = _plan_band(Q, o, 1)
+    assert np.array_equal(order_b, np.arange(300)) and bw_b <= 9 and bw_b == _envelope(Q, np.arange(300))
+    # every rank of a sharded solve derives the same order and band (the graph comes from all observations)
+    for r in range(3):
+        oo = abi.options_global(); oo.lm_shard, oo.lm_nshard = r, 3
+        bw_r, order_r = _plan_band(P, oo, 1)
+        assert bw_r == bw_rcm and np.array_equal(order_r, order)

@@ -36,8 +36,8 @@ def _check_first_step_banded(gpu, o):
     rb = gpu.reduced_band(o.initial_radius)
     assert np.abs(rb["ab"][0]).min() > 0                              # (the band solvers leave S intact)
     ref = -solveh_banded(rb["ab"], rb["g"], lower=True)
-    got = rb["dp"][_free_rows(rb["free"])]
-    assert got.size == ref.size == rb["n"]
+    got = rb["dp_rows"]
+    assert got.size == ref.size == rb["n"] == 6*int(np.count_nonzero(rb["free"]))
     err = np.abs(got - ref).max()/np.abs(ref).max()
     assert err <= 1e-8, err
     return rb
@@ -155,6 +155,50 @@ def test_c5_full_size_global_ba_with_text(gpu):
     assert np.all(np.isfinite(A.theta)) and not np.array_equal(A.theta, P.theta)
     rep2 = gpu.solve(); B = gpu.download(P.copy())
     assert rep2["cost1"] == rep["cost1"] and np.array_equal(A.pose, B.pose) and np.array_equal(A.theta, B.theta)
+
+
+# ------------------------------------------------------------------------------------------------ loop closures
+def test_loop_closure_map_parity_with_keyframe_reordering(gpu, oracle_lib):
+    """GlobalBA runs right after a loop closure (loopClosing.cc:589): the last keyframes share landmarks with the first, the
+    co-visibility graph is a RING, and in keyframe order the envelope of S is the whole matrix.  The plan then orders the rows of S by
+    reverse Cuthill-McKee (band = twice the local one).  120-keyframe ring against the oracle (which knows nothing of orderings)."""
+    P = synth.config_global(n_kf=120, n_pt=4000, band=8, loop=True)
+    o = abi.options_global(); o.its[0] = 8
+    gpu.upload(P, o)
+    info = gpu.solver_info()
+    assert info["kf_reordered"] == 1 and info["band_storage"] == 1 and info["band_rows"] <= 6*3*8, info
+    G, R = P.copy(), P.copy()
+    rg = gpu.GlobalBA(G, options=o); ro = oracle_lib.solve(R, o)
+    assert rg["iters"] == ro["iters"] and rg["accepted"] == ro["accepted"] and rg["termination"] == ro["termination"]
+    np.testing.assert_allclose(rg["cost1"], ro["cost1"], rtol=1e-9)
+    np.testing.assert_allclose(G.pose, R.pose, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(G.rho, R.rho, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("n_kf,band", [(600, 8), (1500, 8)])
+def test_loop_closure_map_band_solvers(gpu, n_kf, band):
+    """The same on maps that take the partitioned band solver: first LM step against scipy's banded Cholesky in the reordered row space,
+    and (600 keyframes) the whole trajectory against the keyframe-order solve (tsba_debug_set no_kf_reorder: the wide-band /
+    dense multi-workgroup Cholesky on a (6 n_kf)^2 matrix -- what a loop closure cost before)."""
+    P = synth.config_global(n_kf=n_kf, n_pt=30*n_kf, band=band, loop=True)
+    o = abi.options_global(); o.its[0] = 5
+    try:
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        assert info["kf_reordered"] == 1 and info["band_stream"] == 1 and info["band_rows"] <= 6*3*band, info
+        rb = _check_first_step_banded(gpu, o)
+        assert not np.all(np.diff(rb["rowblk"][rb["rowblk"] >= 0]) > 0)       # the order really is not the keyframe order
+        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+        assert rep1["accepted"][0] >= 3 and rep1["termination"][0] != 5
+        if n_kf <= 600:
+            gpu.debug_set(no_kf_reorder=1)
+            gpu.upload(P, o)
+            info = gpu.solver_info()
+            assert info["kf_reordered"] == 0 and info["band_rows"] > 6*(n_kf - 40), info
+            G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+            _same_trajectory(rep1, rep2, G1, G2)
+    finally:
+        gpu.debug_set()
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 on one device

@@ -52,6 +52,7 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ps_lm, *pose_ts_off, *pose_ts, *pose_ts_lm;
     const int *tfeat_off, *tfeat_raw; const double *tfeat_uv, *tfeat_ref;
     const int *pf_g, *pf_f; int n_pf;   // pose-only path: flat (group, feature) list of the frame's text features
+    const int *kf_order;                // nullptr: the rows of S follow the keyframe index; else kf_order[i] = keyframe at position i (tsba_plan.h: rcm_order)
 };
 
 #define PT_REC 8
@@ -258,7 +259,7 @@ __device__ __forceinline__ void sum_counts(const Work &W, int ncp, int tid, int 
     if (b) atomicAdd(&lds2[1], b);
 }
 // gauge fixing, optimizer.cc:1562-1588 / :1825-1830
-__global__ void k_gauge(Work W, const uint8_t *kf_initial, int state, int ncp) {
+__global__ void k_gauge(Work W, const uint8_t *kf_initial, int state, int ncp, const int *order) {
     __shared__ int s_cnt2[2];
     if (threadIdx.x == 0) { s_cnt2[0] = 0; s_cnt2[1] = 0; }
     __syncthreads();
@@ -270,8 +271,8 @@ __global__ void k_gauge(Work W, const uint8_t *kf_initial, int state, int ncp) {
         int fixed = 0;
         for (int k = 0; k < W.n_kf && fixed < 3; k++) if (W.kf_in[k]) { W.kf_const[k] = 1; fixed++; }
     }
-    int nf = 0;
-    for (int k = 0; k < W.n_kf; k++) W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? nf++ : -1;
+    int nf = 0;                                                // rows of S: free poses in keyframe order, or in the plan's order
+    for (int i = 0; i < W.n_kf; i++) { const int k = order ? order[i] : i; W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? nf++ : -1; }
     *W.nfree = nf;
 }
 
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64) void k_gauge_wave(Work W, const uint8_t *kf_ini
 }
 // the same for large maps: 1024 threads, consecutive keyframes per thread, one block-wide exclusive scan for the compressed indices
 // (the single-thread walk above costs 1.4 ms at 5000 keyframes)
-__global__ __launch_bounds__(1024) void k_gauge_par(Work W, const uint8_t *kf_initial, int state, int ncp) {
+__global__ __launch_bounds__(1024) void k_gauge_par(Work W, const uint8_t *kf_initial, int state, int ncp, const int *order) {
     __shared__ int s_scan[1024]; __shared__ int s_first[3]; __shared__ int s_cnt; __shared__ int s_cnt2[2];
     if (threadIdx.x == 0) { s_cnt2[0] = 0; s_cnt2[1] = 0; }
     __syncthreads();
@@ -314,8 +315,9 @@ __global__ __launch_bounds__(1024) void k_gauge_par(Work W, const uint8_t *kf_in
     if (tid == 0) s_cnt = s_scan[0];
     __syncthreads();
     const bool fix3 = state == TSBA_STATE_LOCAL && s_cnt > 3;
-    int nfree = 0;
-    for (int k = k0; k < k1; k++) {
+    int nfree = 0;                                             // from here on a thread's range is a range of POSITIONS (= keyframes without a plan order)
+    for (int i = k0; i < k1; i++) {
+        const int k = order ? order[i] : i;
         int cst = (kf_initial[k] && W.kf_in[k]) ? 1 : 0;
         if (fix3 && (k == s_first[0] || k == s_first[1] || k == s_first[2])) cst = 1;
         W.kf_const[k] = cst;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_gauge_par(Work W, const uint8_t *kf_in
     s_scan[tid] = nfree; __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) { const int t = tid >= d ? s_scan[tid - d] : 0; __syncthreads(); s_scan[tid] += t; __syncthreads(); }
     int at = s_scan[tid] - nfree;                              // exclusive prefix
-    for (int k = k0; k < k1; k++) W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? at++ : -1;
+    for (int i = k0; i < k1; i++) { const int k = order ? order[i] : i; W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? at++ : -1; }
     if (tid == 1023) *W.nfree = s_scan[1023];
 }
 
@@ -1231,8 +1233,11 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             const int r = lane/6, cc = lane % 6;
             const double v = tail - tot;
             const size_t ldS = (size_t)W.ldS;                // (sb_a <= sb_b: the first store is the upper triangle, which band storage does not hold)
-            if (a == c || !W.band) W.S[(size_t)(6*ia + r)*ldS + 6*ic + cc] = v;
-            if (a != c) W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r] = v;
+            // band storage holds the lower triangle: the block goes to the row of the pose that comes LATER in S (with a plan order
+            // that need not be the larger keyframe index)
+            const bool a_later = ia > ic;
+            if (a == c || !W.band || a_later) W.S[(size_t)(6*ia + r)*ldS + 6*ic + cc] = v;
+            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r] = v;
         }
     } else {
         const int a = b - L.n_sb;
@@ -1938,7 +1943,8 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         std::vector<char> seen(p->n_levels, 0);
         for (int ps = 0; ps < o->n_passes; ps++) { const int l = o->levels[ps]; if (seen[l]) continue; seen[l] = 1;
             HostPlan *H = &c->hplan[l];
-            planners[l] = std::thread([p, o, l, H, tdbg]() { build_plan(p, o, l, *H, tdbg); }); }
+            const bool reorder = !c->dbg.no_kf_reorder;
+            planners[l] = std::thread([p, o, l, H, tdbg, reorder]() { build_plan(p, o, l, *H, tdbg, reorder); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
 #define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
@@ -1982,6 +1988,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pt_pair4); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
         UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
         UV(pf_g); UV(pf_f); D.n_pf = (int)H.pf_g.size();
+        if (!H.kf_order.empty()) UV(kf_order); else D.kf_order = nullptr;
         UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
         UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
         UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ps_lm); UV(pose_ts_off); UV(pose_ts); UV(pose_ts_lm);
@@ -2180,8 +2187,8 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
         hipLaunchKernelGGL(k_kfin_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
     if (c->n_kf <= 64) hipLaunchKernelGGL(k_gauge_wave, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
-    else if (c->n_kf > 256) hipLaunchKernelGGL(k_gauge_par, dim3(1), dim3(1024), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
-    else hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
+    else if (c->n_kf > 256) hipLaunchKernelGGL(k_gauge_par, dim3(1), dim3(1024), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp, D.kf_order);
+    else hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp, D.kf_order);
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
 static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
@@ -2634,15 +2641,34 @@ int tsba_text_label_image(void *ctx, int kf, int level, float *out) {
 // [4] separator system by cyclic reduction   [5] band rows   [6] four pairs per wave in the linearisation of the first pass's level
 // [7] fused pose-only kernel   [8] one-wave Schur blocks + k_pose_sums (large maps)   [9] world size   [10] rank
 // [11..14] size of this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots
+// [15] the rows of S follow a reverse Cuthill-McKee order of the keyframes instead of the keyframe index
 int tsba_debug_solver_info(void *ctx, int32_t *out, int n) {
-    Ctx *c = (Ctx *)ctx; if (!c || !out || n < 15) return TSBA_ERR_ARG;
+    Ctx *c = (Ctx *)ctx; if (!c || !out || n < 16) return TSBA_ERR_ARG;
     if (!c->uploaded) return TSBA_ERR_STATE;
     int use_lds; solve_lds_bytes(c, &use_lds);
     int bwmax = 0; for (int l = 0; l < c->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
     out[0] = use_lds; out[1] = c->W.band; out[2] = c->band_stream; out[3] = c->band_stream ? c->band_parts : 0; out[4] = c->sep_cr ? 1 : 0; out[5] = bwmax;
     out[6] = lin_small_pairs(c, c->lev[c->opt.levels[0]]) ? 1 : 0; out[7] = c->pose_only ? 1 : 0; out[8] = c->n_kf > 126 ? 1 : 0;
     out[9] = c->world; out[10] = c->rank;
-    { const LevelDev &D0 = c->lev[c->opt.levels[0]]; out[11] = D0.n_pair; out[12] = D0.n_sb; out[13] = D0.n_sc; out[14] = D0.n_pslot; }
+    { const LevelDev &D0 = c->lev[c->opt.levels[0]]; out[11] = D0.n_pair; out[12] = D0.n_sb; out[13] = D0.n_sc; out[14] = D0.n_pslot; out[15] = D0.kf_order ? 1 : 0; }
+    return TSBA_OK;
+}
+// row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating); with a
+// plan order (reverse Cuthill-McKee, tsba_plan.h) this is not monotone in the keyframe index
+int tsba_debug_row_of_kf(void *ctx, int32_t *rowblk) {
+    Ctx *c = (Ctx *)ctx; if (!c || !rowblk) return TSBA_ERR_ARG;
+    if (!c->uploaded) return TSBA_ERR_STATE;
+    hipSetDevice(c->device); CK(hipStreamSynchronize(c->stream));
+    CK(hipMemcpy(rowblk, c->W.fidx, sizeof(int32_t)*c->n_kf, hipMemcpyDeviceToHost));
+    return TSBA_OK;
+}
+// host only (no device needed): the plan's band bound of one level, with or without the keyframe reordering; order_out [n_kf] gets the
+// row order (identity when the plan keeps the keyframe order)
+int tsba_debug_plan_band(const tsba_problem *p, const tsba_options *o, int level, int reorder, int32_t *bw_pose, int32_t *order_out) {
+    if (!p || !o || !bw_pose || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
+    HostPlan H; build_plan(p, o, level, H, false, reorder != 0);
+    *bw_pose = H.bw_pose;
+    if (order_out) for (int k = 0; k < p->n_kf; k++) order_out[k] = H.kf_order.empty() ? k : H.kf_order[(size_t)k];
     return TSBA_OK;
 }
 int tsba_debug_plan_time(const tsba_problem *p, const tsba_options *o, int level, int reps, double *avg_ms) {   // host only: plan construction

@@ -22,6 +22,7 @@
 struct HostPlan {
     int level = 0;
     int bw_pose = 0;                            // half bandwidth of the reduced camera matrix in pose blocks, fill included
+    std::vector<int32_t> kf_order;              // empty: S is ordered by keyframe index; else kf_order[i] = keyframe at position i (reverse Cuthill-McKee)
     // scene candidates (sorted by pair)
     std::vector<int32_t> sc_obs, sc_kf, sc_pt, sc_flag, sc_slot;
     std::vector<double>  sc_uv;                 // [n_sc][2]
@@ -94,6 +95,36 @@ inline void bucket_order(const std::vector<int> &bucket, int n_bucket, std::vect
     for (size_t i = 0; i < bucket.size(); i++) order[(size_t)cur[bucket[i]]++] = (int)i;
 }
 
+// Reverse Cuthill-McKee ordering of the keyframe co-visibility graph (nb: adjacency lists, deduplicated).  After a loop closure the
+// graph is a ring -- keyframe n-1 shares landmarks with keyframe 0 -- and in keyframe order the envelope of S spans the whole matrix
+// (7.2 GB dense at 5000 keyframes); walked breadth-first from a peripheral keyframe the two arms of the ring interleave and the band
+// is twice the local one.  Components in turn, start = a pseudo-peripheral node (two breadth-first sweeps), neighbours by degree.
+inline void rcm_order(int n, const std::vector<std::vector<int> > &nb, std::vector<int32_t> &order) {
+    order.clear(); order.reserve(n);
+    std::vector<char> seen(n, 0); std::vector<int> level(n, 0), q;
+    auto bfs_last = [&](int s0) {                               // farthest node of minimum degree from s0 (within its component)
+        std::vector<int> fr(1, s0), mark; std::vector<char> vis(n, 0); vis[s0] = 1; int last = s0;
+        while (!fr.empty()) { std::vector<int> nx; int best = -1;
+            for (int u : fr) { if (best < 0 || nb[u].size() < nb[best].size()) best = u; for (int v : nb[u]) if (!vis[v] && !seen[v]) { vis[v] = 1; nx.push_back(v); } }
+            last = best; fr.swap(nx); }
+        return last;
+    };
+    for (int s0 = 0; s0 < n; s0++) {
+        if (seen[s0]) continue;
+        int start = s0;
+        if (!nb[s0].empty()) { start = bfs_last(s0); start = bfs_last(start); }
+        const size_t head0 = order.size();
+        order.push_back(start); seen[start] = 1;
+        for (size_t head = head0; head < order.size(); head++) {
+            const int u = order[head]; q.clear();
+            for (int v : nb[u]) if (!seen[v]) { seen[v] = 1; q.push_back(v); }
+            std::sort(q.begin(), q.end(), [&](int a, int b) { return nb[a].size() != nb[b].size() ? nb[a].size() < nb[b].size() : a < b; });
+            for (int v : q) order.push_back(v);
+        }
+        std::reverse(order.begin() + (long)head0, order.end());
+    }
+}
+
 // Which rank of a sharded global BA keeps a residual block: the rank whose KEYFRAME RANGE holds the landmark's host (ranges of
 // n_kf / nshard consecutive keyframes).  Co-visibility is local in keyframe index, so a rank's blocks touch only the (target, host)
 // pairs and the 6x6 blocks of S near its own range -- its linearisation and Schur assembly shrink with 1 / nshard (a landmark-index
@@ -104,7 +135,7 @@ __host__ __device__ inline int tsba_shard_of(int host, int target_kf, int n_kf, 
     return (int)(((long long)k*nshard)/n_kf);
 }
 
-inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false) {
+inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true) {
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
     P = HostPlan();
@@ -120,8 +151,11 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     std::vector<int> reach(n_kf);
     for (int a = 0; a < n_kf; a++) reach[a] = a;
     std::vector<int> lm_lo((size_t)n_pt + n_text, n_kf), lm_hi((size_t)n_pt + n_text, -1);
+    std::vector<int> lp_lm, lp_kf;                            // (landmark, pose) incidences of all observations: large maps only (reordering)
+    const bool keep_inc = n_kf > 64 && allow_reorder;
     auto touch = [&](int lm, int kf, int host) { if (host < 0) return;           // frozen landmark: no off-diagonal coupling
-        lm_lo[lm] = std::min(lm_lo[lm], std::min(kf, host)); lm_hi[lm] = std::max(lm_hi[lm], std::max(kf, host)); };
+        lm_lo[lm] = std::min(lm_lo[lm], std::min(kf, host)); lm_hi[lm] = std::max(lm_hi[lm], std::max(kf, host));
+        if (keep_inc) { lp_lm.push_back(lm); lp_kf.push_back(kf); lp_lm.push_back(lm); lp_kf.push_back(host); } };
     for (int s = 0; s < p->n_sobs[L]; s++) {
         int kf = p->sobs_kf[L][s], pt = p->sobs_pt[L][s], host = p->pt_host[pt];
         if (host >= 0 && host == kf) continue;                    // optimizer.cc:1393 "Host != Target"
@@ -272,9 +306,27 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         // (device side) only shrinks distances, so this is an upper bound for the system that is actually factored.
         std::vector<int> &cm = reach;                             // (all ranks' observations: see the top of this function)
         for (int q = 0; q < n_sb; q++) cm[P.sb_a[q]] = std::max(cm[P.sb_a[q]], (int)P.sb_b[q]);
-        int run = -1, bw = 0;
-        for (int k = 0; k < n_kf; k++) { const int reach = (run >= k) ? std::max(cm[k], run) : cm[k]; run = std::max(run, reach); bw = std::max(bw, reach - k); }
-        P.bw_pose = bw;
+        auto closed_bw = [&](const std::vector<int> &c) { int run = -1, bw = 0;
+            for (int k = 0; k < n_kf; k++) { const int reach = (run >= k) ? std::max(c[k], run) : c[k]; run = std::max(run, reach); bw = std::max(bw, reach - k); }
+            return bw; };
+        P.bw_pose = closed_bw(cm);
+        // A wide envelope (beyond the streaming band solvers: 26 pose blocks) on a large map: try the reverse Cuthill-McKee order of the
+        // co-visibility graph (all ranks' observations, so that every rank of a sharded solve derives the same order)
+        if (keep_inc && P.bw_pose > 26) {
+            std::vector<std::vector<int> > poses_of((size_t)n_pt + n_text), nb((size_t)n_kf);
+            for (size_t e = 0; e < lp_lm.size(); e++) poses_of[(size_t)lp_lm[e]].push_back(lp_kf[e]);
+            for (auto &v : poses_of) { if (v.size() < 2) continue; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+                for (size_t x = 0; x < v.size(); x++) for (size_t y = 0; y < v.size(); y++) if (x != y) nb[(size_t)v[x]].push_back(v[y]); }
+            for (auto &v : nb) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+            std::vector<int32_t> order; rcm_order(n_kf, nb, order);
+            std::vector<int> pos(n_kf), c2(n_kf);
+            for (int i = 0; i < n_kf; i++) { pos[order[i]] = i; c2[i] = i; }
+            for (const auto &v : poses_of) { if (v.size() < 2) continue; int lo = n_kf, hi = -1;
+                for (int k : v) { lo = std::min(lo, pos[k]); hi = std::max(hi, pos[k]); } c2[lo] = std::max(c2[lo], hi); }
+            for (int q = 0; q < n_sb; q++) { const int pa = pos[P.sb_a[q]], pb = pos[P.sb_b[q]]; c2[std::min(pa, pb)] = std::max(c2[std::min(pa, pb)], std::max(pa, pb)); }
+            const int bw2 = closed_bw(c2);
+            if (bw2*10 < P.bw_pose*7) { P.kf_order = order; P.bw_pose = bw2; }
+        }
     }
     std::vector<std::pair<int,int>> it_t, it_h, it_ps, it_ts;
     for (int q = 0; q < n_pair; q++) { it_t.push_back({ P.pair_i[q], q }); if (P.pair_h[q] >= 0) it_h.push_back({ P.pair_h[q], q }); }

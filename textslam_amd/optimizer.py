@@ -45,6 +45,7 @@ def load_library():
     L.tsba_debug_reduced_system.argtypes = [vp, C.c_double, dp, dp, dp, C.POINTER(C.c_int32), dp]
     L.tsba_debug_reduced_band.argtypes = [vp, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, dp]
     L.tsba_debug_solver_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
+    L.tsba_debug_row_of_kf.argtypes = [vp, C.POINTER(C.c_int32)]
     L.tsba_debug_time_solve.argtypes = [vp, C.c_int, dp]
     L.tsba_comm_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.tsba_comm_unique_id.argtypes = [vp, vp]
@@ -212,10 +213,10 @@ class Optimizer:
 
     def solver_info(self):
         """Which kernel paths the uploaded problem takes (tsba_debug_solver_info)."""
-        v = (C.c_int32 * 15)()
-        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 15), "tsba_debug_solver_info")
+        v = (C.c_int32 * 16)()
+        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 16), "tsba_debug_solver_info")
         keys = ("lds_solver", "band_storage", "band_stream", "interiors", "sep_cr", "band_rows", "small_pairs", "pose_kernel", "large_map", "world", "rank",
-                "n_pair", "n_sblock", "n_scene_candidates", "n_point_slots")
+                "n_pair", "n_sblock", "n_scene_candidates", "n_point_slots", "kf_reordered")
         return dict(zip(keys, [int(x) for x in v]))
 
     def reduced_band(self, radius: float):
@@ -228,7 +229,13 @@ class Optimizer:
         free = np.zeros(self._resident.n_kf, np.int32)
         self._check(self.lib.tsba_debug_reduced_system(self.ctx, radius, None, None, None, free.ctypes.data_as(C.POINTER(C.c_int32)), None),
                     "tsba_debug_reduced_system")
-        return {"ab": ab, "g": g, "dp": dpv, "n": n.value, "bw": bw.value, "free": free}
+        rowblk = np.zeros(self._resident.n_kf, np.int32)
+        self._check(self.lib.tsba_debug_row_of_kf(self.ctx, rowblk.ctypes.data_as(C.POINTER(C.c_int32))), "tsba_debug_row_of_kf")
+        # dp in the row order of S (the keyframe order unless the plan reordered the keyframes)
+        dp_rows = np.zeros(n.value)
+        for k in np.nonzero(rowblk >= 0)[0]:
+            dp_rows[6*rowblk[k]:6*rowblk[k] + 6] = dpv[6*k:6*k + 6]
+        return {"ab": ab, "g": g, "dp": dpv, "dp_rows": dp_rows, "n": n.value, "bw": bw.value, "free": free, "rowblk": rowblk}
 
     # ---- multi-GPU (global BA): one process per GPU, RCCL communicator owned by the library
     def comm_unique_id(self):

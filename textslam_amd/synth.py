@@ -60,6 +60,18 @@ def _cam(k, step=0.1, yaw_deg=0.35):
     return Rcw, -Rcw @ c
 
 
+def _cam_ring(k, n, step=0.1):
+    """T_cw of camera k of a CLOSED trajectory: n cameras on a circle (arc length `step` between neighbours) looking outward, so that
+    the last keyframes see what the first ones saw -- the map right after a loop closure, which is when TextSLAM runs GlobalBA
+    (loopClosing.cc:589)."""
+    phi = 2.0*np.pi*k/n
+    radius = step*n/(2.0*np.pi)
+    c = np.array([radius*np.sin(phi), 0.02*np.sin(0.3*k), radius*np.cos(phi)])
+    Rwc = _rot_y(phi)                       # optical axis (0,0,1) -> (sin phi, 0, cos phi): outward
+    Rcw = Rwc.T
+    return Rcw, -Rcw @ c
+
+
 def _bilinear(img, u, v):
     h, w = img.shape
     uf, vf = np.floor(u).astype(int), np.floor(v).astype(int)
@@ -106,7 +118,7 @@ class _Plane:
 
 def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), max_targets=5, text_targets=5,
                  frozen_frac=0.1, outlier_frac=0.05, noise_px=0.5, perturb=True, n_levels=3,
-                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None):
+                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None, loop=False):
     """Build a synthetic window (local BA / pose-only / global BA depending on the arguments).
 
     n_kf == 1 with frozen_frac == 1 gives the pose-only problem (every landmark hosted outside).
@@ -119,7 +131,7 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
     P.n_levels = n_levels if n_text > 0 else 1
     band = band or n_kf
     # cameras: window 0..n_kf-1, outside hosts -1..-n_out
-    cams = {k: _cam(k) for k in range(-n_out, n_kf)}
+    cams = {k: (_cam_ring(k, n_kf) if loop else _cam(k)) for k in range(-n_out, n_kf)}
     Rcw = np.stack([cams[k][0] for k in range(n_kf)])
     tcw = np.stack([cams[k][1] for k in range(n_kf)])
 
@@ -156,6 +168,8 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
         if far[j]:
             cand = rng.choice(n_kf, size=min(n_kf, 3 * max_targets), replace=False)
             cand.sort()
+        elif h >= 0 and loop:
+            cand = np.sort((h + 1 + np.arange(min(band, n_kf - 1))) % n_kf)      # the ring closes: the last keyframes observe the first ones' landmarks
         elif h >= 0:
             cand = np.arange(h + 1, min(n_kf, h + 1 + band))
         else:
@@ -418,10 +432,11 @@ def config_c4(seed=SEED):
     return make_problem(20, 5000, 100, seed)
 
 
-def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0):
-    """C5 / C6: scene-only global BA (the reference's GlobalBA ignores text, optimizer.cc:1707)."""
+def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0, loop=False):
+    """C5 / C6: scene-only global BA (the reference's GlobalBA ignores text, optimizer.cc:1707).  loop: closed trajectory (the map right
+    after a loop closure: the co-visibility graph is a ring, not a band)."""
     return make_problem(n_kf, n_pt, 0, seed, max_targets=max_targets, frozen_frac=0.0, band=band, far_frac=far_frac,
-                        n_levels=1, rot_deg=0.2, trans_m=0.01)
+                        n_levels=1, rot_deg=0.2, trans_m=0.01, loop=loop)
 
 
 def tiny(seed=7, n_kf=5, n_pt=60, n_text=4, **kw):
