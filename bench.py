@@ -271,7 +271,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL,4> (level 0, this rank's shard)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic if world == 1 else None, "traffic_source": src if world == 1 else None,
                                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3}
-            if sol_ms is not None:
+            if sol_ms is not None and not args.loop:
                 # the dominant phase of an LM trial: the band solve of the reduced camera system -- LDL^T of an n x n band of half width
                 # bw: n (bw^2 + 3 bw) flops + two triangular sweeps 4 n bw
                 bw = info["band_rows"] + 5

@@ -66,7 +66,7 @@ struct LinBuf {              // everything one linearisation produces
     double *V_tx, *b_tx, *dgs_tx;       // per plane: V [6][n], b [3][n], dgs [3][n]
     double *Hd, *bp, *dgs_p;            // per pose: diag(H_pp), gradient, dgs.  Hd | bp | scal[8] are one allocation (hb):
     double *bp_loc;                     // multi-GPU: this rank's part of bp (the reduced gradient is assembled from it)
-    double *lmpart;                     // per k_mid block: (gradient max, |x|^2) of its landmarks
+    double *lmpart;                     // per k_mid block: (gradient max, |x|^2) of its landmarks, cost of its pairs (+ their text groups)
 };
 
 struct PoseState;
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
         if (lane < 27) B.tgM[(size_t)lane*L.n_tg + tgpp] = tot;          // pair-major rank: k_mid sums a contiguous range
         else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; }
         else if (lane < 54) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + 18 + (lane - 45)] = tot; }
-        else if (lane == 54) B.tgCost[g] = tot;
+        else if (lane == 54) B.tgCost[tgpp] = tot;                       // pair-major rank as well: k_mid adds it to its pair's cost
         // (the host column of W, -blkdiag(R,R)^T W, is formed by k_mid from W and the pair's R_cr; an inactive group leaves W = 0)
     }
 }
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
     __shared__ double red[256];
     const double *rho_x = W.rho[sel], *theta_x = W.theta[sel];
     const size_t np_ = L.n_pair;
-    double gm = 0.0, xn = 0.0;
+    double gm = 0.0, xn = 0.0, cs = 0.0;                        // cs: cost of this thread's pair and of its text groups
     if (b < nb_pt) {
         const int j = b*256 + threadIdx.x;
         if (e > o) {
@@ -826,11 +826,13 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             for (int k = 0; k < 21; k++) M[k] = B.pairM[(size_t)k*L.n_pair + p];
 #pragma unroll
             for (int k = 0; k < 6; k++) c[k] = B.pairM[(size_t)(21 + k)*L.n_pair + p];
+            cs = B.pairCost[p];
             for (int q = tq0; q < tq1; q++) {          // (stored in pair-major order by k_linearize)
 #pragma unroll
                 for (int k = 0; k < 21; k++) M[k] += B.tgM[(size_t)k*L.n_tg + q];
 #pragma unroll
                 for (int k = 0; k < 6; k++) c[k] += B.tgM[(size_t)(21 + k)*L.n_tg + q];
+                cs += B.tgCost[q];
             }
             double *out = B.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) by pair | QMQ(21) Qc(6) by host-major rank
 #pragma unroll
@@ -872,7 +874,9 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
         }
     }
     gm = block_max<256>(gm, red); xn = block_sum<256>(xn, red);
-    if (threadIdx.x == 0) { B.lmpart[2*b] = gm; B.lmpart[2*b + 1] = xn; }
+    if (b >= nb_pt + nb_tx) cs = block_sum<256>(cs, red);       // (uniform) the cost as per-block partials: k_postlin / k_decide add a few hundred
+                                                                // numbers instead of walking 40 k pairs at 5000 keyframes (50 us of one workgroup)
+    if (threadIdx.x == 0) { B.lmpart[3*b] = gm; B.lmpart[3*b + 1] = xn; B.lmpart[3*b + 2] = cs; }
 }
 
 // ---- after a linearisation (256 threads of one block), in two stages so that a multi-GPU run can all-reduce in between:
@@ -896,9 +900,7 @@ __device__ void sums_local(const Work &W, const LevelDev &L, const LinBuf &B, do
         }
     }
     __threadfence_block();                                             // pose_scale reads these through other threads
-    for (int k = tid; k < nb_lm; k += 256) { gmax_lm = fmax(gmax_lm, B.lmpart[2*k]); xn_lm += B.lmpart[2*k + 1]; }
-    for (int p = tid; p < L.n_pair; p += 256) cost += B.pairCost[p];
-    for (int g = tid; g < L.n_tg; g += 256) cost += B.tgCost[g];
+    for (int k = tid; k < nb_lm; k += 256) { gmax_lm = fmax(gmax_lm, B.lmpart[3*k]); xn_lm += B.lmpart[3*k + 1]; cost += B.lmpart[3*k + 2]; }
     gmax_lm = block_max<256>(gmax_lm, red); xn_lm = block_sum<256>(xn_lm, red); cost = block_sum<256>(cost, red);
 }
 __device__ void pose_scale(const Work &W, const LinBuf &B, const double *sHd, const double *sbp, const double *pose, bool first,
@@ -931,27 +933,21 @@ __device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B,
 #ifdef TSBA_SOLVE_STAMPS
     long long q0_ = clock64(), q1_ = 0, q2_ = 0, q3_ = 0, q4_ = 0;
 #endif
-    {   // landmark / cost / step partials: three entries per thread in flight, the (rare) rest in a plain loop
-        double pc[3], tc[3], lg[3], lx[3], ps[3], pm[3];
+    {   // landmark / cost / step partials (one entry per k_mid / k_back workgroup): three per thread in flight, the (rare) rest in a plain loop
+        double lc[3], lg[3], lx[3], ps[3], pm[3];
 #pragma unroll
         for (int u = 0; u < 3; u++) {
             const int k = tid + 256*u;
-            pc[u] = B.pairCost[min(k, max(L.n_pair - 1, 0))]; tc[u] = B.tgCost[min(k, max(L.n_tg - 1, 0))];
-            lg[u] = B.lmpart[2*min(k, max(nb_lm - 1, 0))]; lx[u] = B.lmpart[2*min(k, max(nb_lm - 1, 0)) + 1];
+            lg[u] = B.lmpart[3*min(k, max(nb_lm - 1, 0))]; lx[u] = B.lmpart[3*min(k, max(nb_lm - 1, 0)) + 1]; lc[u] = B.lmpart[3*min(k, max(nb_lm - 1, 0)) + 2];
             ps[u] = W.partial[2*min(k, max(nb_back - 1, 0))]; pm[u] = W.partial[2*min(k, max(nb_back - 1, 0)) + 1];
         }
 #pragma unroll
         for (int u = 0; u < 3; u++) {
             const int k = tid + 256*u;
-            if (k < L.n_pair) cost += pc[u];
-            if (k < nb_lm) { gmax = fmax(gmax, lg[u]); xn += lx[u]; }
+            if (k < nb_lm) { gmax = fmax(gmax, lg[u]); xn += lx[u]; cost += lc[u]; }
             if (k < nb_back) { step2 += ps[u]; mcc += pm[u]; }
         }
-#pragma unroll
-        for (int u = 0; u < 3; u++) if (tid + 256*u < L.n_tg) cost += tc[u];
-        for (int k = tid + 768; k < L.n_pair; k += 256) cost += B.pairCost[k];
-        for (int k = tid + 768; k < L.n_tg; k += 256) cost += B.tgCost[k];
-        for (int k = tid + 768; k < nb_lm; k += 256) { gmax = fmax(gmax, B.lmpart[2*k]); xn += B.lmpart[2*k + 1]; }
+        for (int k = tid + 768; k < nb_lm; k += 256) { gmax = fmax(gmax, B.lmpart[3*k]); xn += B.lmpart[3*k + 1]; cost += B.lmpart[3*k + 2]; }
         for (int k = tid + 768; k < nb_back; k += 256) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
     }
 #ifdef TSBA_SOLVE_STAMPS
@@ -2032,7 +2028,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         AL(B.w_pt, PT_REC*mx_pslot); AL(B.V_pt, p->n_pt); AL(B.b_pt, p->n_pt); AL(B.dgs_pt, p->n_pt);
         AL(B.w_tx, TX_REC*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
         AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.bp_loc, W.N); AL(B.dgs_p, W.N);
-        AL(B.lmpart, 2*((size_t)c->nb_back_max + mx_pair/256 + 2));
+        AL(B.lmpart, 3*((size_t)c->nb_back_max + mx_pair/256 + 2));
     }
     AL(W.sig_pt, p->n_pt); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.sig_p, W.N);
     AL(W.cb, 2*(size_t)W.N + 8); AL(W.cbm, 1);
@@ -2230,7 +2226,8 @@ static int set_solver_attrs(Ctx *c) {
     if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     else {
         CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_bandp_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_bandp_factor<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_bandp_factor<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cr_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cr_update, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cr_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -2256,7 +2253,9 @@ static void launch_solve(Ctx *c) {
         const int bwsep = 2*bwp - 6, cbs = band_chunk_blocks(bwsep);
         Work &Ws = c->Wsep; Ws.st = W.st; Ws.ldS = (P - 1)*bwp; Ws.N = (P - 1)*bwp;
         if (!c->sep_cr) hipMemsetAsync(c->Ssep, 0, sizeof(double)*((size_t)Ws.ldS*Ws.ldS + Ws.ldS), c->stream);
-        hipLaunchKernelGGL(k_bandp_factor, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
+        // panel rows of a step: band + border (left separator) + rhs; two panel waves take 116 in one round, three 174
+        if (2*bwp + 1 > SOLVE_PW*SOLVE_PROWS && !c->dbg.two_panel_waves) hipLaunchKernelGGL(k_bandp_factor<3>, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
+        else hipLaunchKernelGGL(k_bandp_factor<2>, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
         hipMemsetAsync(c->Bpart, 0, sizeof(double)*(size_t)P*BANDP_NS*((size_t)bwp*bwp + bwp), c->stream);        // (slices of short interiors stay empty)
         hipLaunchKernelGGL(k_bandp_border, dim3(P, BANDP_NS), dim3(256), (int)((2*(size_t)BANDP_JC*bwp*6 + 6*BANDP_JC)*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Lb, c->Bpart);
         hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);

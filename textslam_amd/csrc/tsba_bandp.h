@@ -35,7 +35,7 @@ __device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax
 }
 static size_t bandp_lds_doubles(int bw, int cb) {               // window + border rows + rhs row, LD table, scratch
     const int rows = 6*cb + 2*bw;
-    return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*SOLVE_PW + 8 + 64;
+    return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*3 + 8 + 64;      // (scratch of up to three panel waves)
 }
 static int bandp_chunk_blocks(int bw) {
     for (int cb = 16; cb >= 4; cb--) if (bandp_lds_doubles(bw, cb)*sizeof(double) <= 152*1024) return cb;
@@ -43,12 +43,16 @@ static int bandp_chunk_blocks(int bw) {
 }
 
 // T_p layout: nT = nR + nL rows ([right separator rows; left separator rows]), dense nTmax x nTmax row-major (lower used) + gT
+// PW panel waves: a step's panel has bw band rows + bw border rows + the rhs row -- 121 rows at a band of 60, more than the 116 rows two
+// waves solve in one round (58 each); the second round doubled the latency chain of every step (4.3 us per pose block).  Three panel waves
+// (174 rows) take them in one round; the nine remaining update waves still cover the step's 26 MFMA tiles in three rounds.
+template <int PW>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, int CB, int Pmax, double *Lrow, double *Lb, double *Tbuf) {
     LmState *st = W.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NW = SOLVE_THREADS/64, NT = NW - SOLVE_PW;
+    constexpr int NW = SOLVE_THREADS/64, NT = NW - PW;
     if (st->done || st->step_fail) return;
     const int nb = *W.nfree, B = bw/6;
     if (nb == 0) return;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         for (int jb = jstart; jb < jend + (flush ? 1 : 0) && !fail; jb++) {
             const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
             const bool fl = jb == jend;                         // flush step: no factorisation, panel jb-1 onto everything right of it
-            if (wave < SOLVE_PW) {
+            if (wave < PW) {
                 double Lk[36], dprev[6];
                 if (jb > 0) {
                     ld6(LD + SOLVE_LD*(jb - 1) + LD_D, dprev);
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     };
                     if (lane >= 6) {
                         if (i0 < re + nx) solve_row(vrow(i0), a);
-                        for (int i = i0 + SOLVE_PW*SOLVE_PROWS; i < re + nx; i += SOLVE_PW*SOLVE_PROWS) { load_row(vrow(i), a); solve_row(vrow(i), a); }
+                        for (int i = i0 + PW*SOLVE_PROWS; i < re + nx; i += PW*SOLVE_PROWS) { load_row(vrow(i), a); solve_row(vrow(i), a); }
                     }
                 }
             } else if (jb > 0) {
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     const int k1 = min(4 + lk, 5);
                     const double dk0 = ldp[LD_D + lk], dk1 = lk < 2 ? ldp[LD_D + 4 + lk] : 0.0;
                     auto real = [&](int v) { return v < re ? v : n + (v - re); };
-                    for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
+                    for (int t = wave - PW; t < ntile; t += NT) {
                         int ti, tj;
                         if (t < ntri) { ti = tri_row(t); tj = t - tri(ti); } else { const int u = t - ntri; ti = ntcb + u/ntcb; tj = u - (ti - ntcb)*ntcb; }
                         const int r0v = Rs + 16*ti, c0v = Rs + 16*tj;

@@ -1,0 +1,12 @@
+"""GPU diagnostic (not a pytest): C6 resident solve A/B over tsba_debug_set switches."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from textslam_amd import synth, abi
+from textslam_amd.optimizer import Optimizer
+g = Optimizer(0)
+P = synth.config_global(n_kf=5000, n_pt=70000, band=10); o = abi.options_global()
+for name, kw in (("default", {}), ("two_panel_waves", {"two_panel_waves": 1}), ("default", {})):
+    g.debug_set(**kw); g.upload(P, o)
+    g.solve(); t = time.perf_counter(); n = 5
+    for _ in range(n): rep = g.solve()
+    print("%-16s solve %.2f ms  its %s acc %s cost1 %s  time_solve %.1f us" % (name, (time.perf_counter() - t)/n*1e3, rep["iters"], rep["accepted"], rep["cost1"], g.time_solve(20)*1e3), flush=True)
