@@ -249,8 +249,7 @@ typedef struct tsba_debug_options {
     int32_t no_small_pairs;    /* 1: never put four (target, host) pairs on one wave of the linearisation */
     int32_t verbose;           /* 1: host-side timing of upload / plan construction on stderr */
     int32_t no_kf_reorder;     /* 1: keep the rows of S in keyframe order even when the envelope is wide (loop closures) */
-    int32_t two_panel_waves;   /* 1: the interiors of the partitioned band solver with two panel waves even when a step's panel has > 116 rows */
-    int32_t reserved[8];
+    int32_t reserved[9];
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

@@ -43,9 +43,9 @@ static int bandp_chunk_blocks(int bw) {
 }
 
 // T_p layout: nT = nR + nL rows ([right separator rows; left separator rows]), dense nTmax x nTmax row-major (lower used) + gT
-// PW panel waves: a step's panel has bw band rows + bw border rows + the rhs row -- 121 rows at a band of 60, more than the 116 rows two
-// waves solve in one round (58 each); the second round doubled the latency chain of every step (4.3 us per pose block).  Three panel waves
-// (174 rows) take them in one round; the nine remaining update waves still cover the step's 26 MFMA tiles in three rounds.
+// PW panel waves (SOLVE_PW = 2 in the product).  A step's panel has bw band rows + bw border rows + the rhs row -- 121 rows at a band of
+// 60, which two panel waves (58 rows each) take in two rounds; three panel waves (one round, nine update waves) were measured in round 2
+// on the 5000-keyframe map: 1085 us per solve phase against 1064 us with two -- the second round is not what bounds the step.
 template <int PW>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, int CB, int Pmax, double *Lrow, double *Lb, double *Tbuf) {
     LmState *st = W.st;
