@@ -519,21 +519,24 @@ __device__ __forceinline__ void wave_sum_groups16_mw(const double *acc, double *
 // dozen scene blocks (thousands of keyframes: a 64-lane wave per pair was 85 % idle), eight pairs, one per 16-lane group; a text workgroup one (KF, text)
 // observation with every feature on TWO lanes (4 taps each): the text lanes' instruction stream (~450 instructions per tap at
 // one instruction per ~4.5 cycles) is what bounds the kernel.  <= 256 VGPRs so that all ~730 workgroups of C4 are resident at once.
-#define LIN_T 128
+#define LIN_TPL 2                        // photometric taps per lane: a feature's 8 taps sit on 8 / LIN_TPL neighbouring lanes
+#define LIN_T (64*(8/LIN_TPL))           // 64 features per text workgroup
+#define LIN_NWV (LIN_T/64)
 #define MID_U 4                          // slot records of a point that k_mid keeps in flight per round trip
 template <int MODE, int PPW = 1>
 __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int spec) {
     // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
     const LmState *st = W.st;
-    __shared__ double lds[2*28*65 + 2*64];
-    __shared__ int4 s_px[4*LIN_T];                          // the text path's pixel quads: indexed by tap at run time (not registers)
+    constexpr int NWV = LIN_T/64, TPL = LIN_TPL, LPF = 8/LIN_TPL;   // waves per workgroup; taps per lane; lanes per feature
+    __shared__ double lds[NWV*28*65 + NWV*64];
+    __shared__ unsigned s_px[TPL*LIN_T];                    // the text path's pixel quads (four bytes): indexed by tap at run time (not registers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *reg = lds + wave*28*65, *xw = lds + 2*28*65;
+    double *reg = lds + wave*28*65, *xw = lds + NWV*28*65;
     // static indices of this workgroup first: in flight together with the LM state
     constexpr int LPP = 64/PPW;                              // lanes per pair
-    const int nb_sc = (L.n_pair + 2*PPW - 1)/(2*PPW);
+    const int nb_sc = (L.n_pair + NWV*PPW - 1)/(NWV*PPW);
     const int sub = PPW == 1 ? lane : (lane & (LPP - 1));
-    const int bq = blockIdx.x, pr = (2*bq + wave)*PPW + (PPW == 1 ? 0 : lane/LPP), prc = min(pr, max(L.n_pair - 1, 0));
+    const int bq = blockIdx.x, pr = (NWV*bq + wave)*PPW + (PPW == 1 ? 0 : lane/LPP), prc = min(pr, max(L.n_pair - 1, 0));
     int pi = 0, ph = 0, pbeg = 0, pend = 0, tgpp = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
     if (bq < nb_sc) { pi = L.pair_i[prc]; ph = L.pair_h[prc]; pbeg = L.pair_sc_off[prc]; pend = pr < L.n_pair ? L.pair_sc_off[prc+1] : pbeg; }
     else { ra = ((const int4 *)L.tg_rec)[2*(bq - nb_sc)]; rb = ((const int4 *)L.tg_rec)[2*(bq - nb_sc) + 1]; tgpp = L.tg_ppos[bq - nb_sc]; }   // one static record per group
@@ -620,19 +623,21 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
             }
         }
     } else {
-        // ---------------- photometric blocks of one (KF, text) observation: thread = (feature tid >> 1, tap quad tid & 1)
+        // ---------------- photometric blocks of one (KF, text) observation: thread = (feature tid / LPF, tap group tid % LPF)
         const int g = b - nb_sc;
         const int tb = ra.x, i = ra.y, j = ra.z, h = ra.w, slot = rb.x, f0 = rb.y, f1 = rb.z, fg = rb.w;
         const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
         const bool act_g = (!W.filter_good || W.tobs_good[tb]) && !((h < 0) && W.kf_const[i]) && sigma != 0.0;
         // static data of this thread's first feature: fetched together with the level-2 operands, not after them
-        const int fl = tid >> 1, tp = tid & 1;
-        int f = f0 + fl, raw = 0; double fu = 0.0, fv = 0.0, refv[4] = {0, 0, 0, 0};
+        const int fl = tid/LPF, tp = tid % LPF;
+        int f = f0 + fl, raw = 0; double fu = 0.0, fv = 0.0, refv[TPL];
+#pragma unroll
+        for (int k = 0; k < TPL; k++) refv[k] = 0.0;
         if (f1 > f0) {
             const int fc = min(f, f1 - 1);
             raw = L.tfeat_raw[fc]; fu = L.tfeat_uv[2*fc]; fv = L.tfeat_uv[2*fc+1];
 #pragma unroll
-            for (int k = 0; k < 4; k++) refv[k] = L.tfeat_ref[8*(size_t)fc + 4*tp + k];
+            for (int k = 0; k < TPL; k++) refv[k] = L.tfeat_ref[8*(size_t)fc + TPL*tp + k];
         }
         PairT T;
         // poses / plane / image pointer do not wait for the activity test (h is known from the record)
@@ -655,26 +660,28 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
                 if (fb != f0 && in) {
                     raw = L.tfeat_raw[f]; fu = L.tfeat_uv[2*f]; fv = L.tfeat_uv[2*f+1];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) refv[k] = L.tfeat_ref[8*(size_t)f + 4*tp + k];
+                    for (int k = 0; k < TPL; k++) refv[k] = L.tfeat_ref[8*(size_t)f + TPL*tp + k];
                 }
                 const uint8_t good = in ? (W.filter_good ? W.tfgood[fg + raw] : (uint8_t)1) : (uint8_t)0;   // in flight with the pixel fetches
-                // the 8 pixel-pair fetches of the thread's 4 taps in flight before the first residual; the quads wait in LDS so that
+                // the pixel-pair fetches of all the thread's taps in flight before the first residual; the quads wait in LDS so that
                 // the residual loop can stay rolled (unrolled, its live state does not fit 256 VGPRs and spills to scratch)
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int kt = 4*tp + k;
+                for (int k = 0; k < TPL; k++) {
+                    const int kt = TPL*tp + k;
                     const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;   // tool.cc:1561
                     const TapPx q = tap_fetch(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h);
-                    s_px[k*LIN_T + tid] = make_int4(q.I00, q.I01, q.I10, q.I11);
+                    s_px[k*LIN_T + tid] = (unsigned)q.I00 | ((unsigned)q.I01 << 8) | ((unsigned)q.I10 << 16) | ((unsigned)q.I11 << 24);
                 }
                 double s = 0.0;
 #pragma unroll 1
-                for (int k = 0; k < 4; k++) {
-                    const int kt = 4*tp + k;
+                for (int k = 0; k < TPL; k++) {
+                    const int kt = TPL*tp + k;
                     const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;
-                    const int4 q4 = s_px[k*LIN_T + tid];
-                    const TapPx pxk = { q4.x, q4.y, q4.z, q4.w };
-                    const double rf = k == 0 ? refv[0] : k == 1 ? refv[1] : k == 2 ? refv[2] : refv[3];
+                    const unsigned q4 = s_px[k*LIN_T + tid];
+                    const TapPx pxk = { (int)(q4 & 0xff), (int)((q4 >> 8) & 0xff), (int)((q4 >> 16) & 0xff), (int)(q4 >> 24) };
+                    double rf = refv[0];
+#pragma unroll
+                    for (int q = 1; q < TPL; q++) if (k == q) rf = refv[q];
                     double jt[6], jl[3];
                     double r = text_tap_px(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], pxk, L.img_w, L.img_h,
                                            mu, sigma, inv_sigma, rf, W.w_t, true, jt, jl);
@@ -694,20 +701,25 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
                     blk[48] += jl[1]*jl[1]; blk[49] += jl[1]*jl[2]; blk[50] += jl[2]*jl[2];
                     blk[51] += jl[0]*r; blk[52] += jl[1]*r; blk[53] += jl[2]*r;
                 }
-                const double s8 = s + __shfl_xor(s, 1, 64);         // the block's squared norm: its 8 taps sit on 2 neighbouring lanes
+                double s8 = s;                                      // the block's squared norm: its 8 taps sit on LPF neighbouring lanes
+#pragma unroll
+                for (int q = 1; q < LPF; q <<= 1) s8 += __shfl_xor(s8, q, 64);
                 double wgt; const double rho_h = 0.5*huber(s8, W.huber_t, wgt);
                 const double wg = good ? wgt : 0.0;
 #pragma unroll
                 for (int k = 0; k < 54; k++) blk[k] *= wg;
                 blk[54] = (good && tp == 0) ? rho_h : 0.0;
             }
-            // 55 sums over the 128 threads: per wave two transposes (28 + 27 values), then the two waves
+            // 55 sums over the workgroup's threads: per wave two transposes (28 + 27 values), then the waves (fixed order)
             const double t0 = wave_sum_to_lane_mw<28>(blk, reg, lane);
             const double t1 = wave_sum_to_lane_mw<27>(blk + 28, reg, lane);
             if (lane < 28) xw[wave*64 + lane] = t0;
             if (lane < 27) xw[wave*64 + 28 + lane] = t1;
             __syncthreads();
-            if (lane < 55) tot += xw[lane] + xw[64 + lane];
+            if (lane < 55) { double part = xw[lane];
+#pragma unroll
+                for (int q = 1; q < NWV; q++) part += xw[q*64 + lane];
+                tot += part; }
             __syncthreads();
         }
         if (wave > 0) return;
@@ -2195,8 +2207,8 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
     if (D.n_pair + D.n_tg > 0) {
-        if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 7)/8 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
-        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
+        if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
+        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
     }
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
@@ -2599,8 +2611,8 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));   // k_linearize never clears need_lin itself
     CK(hipEventRecord(c->ev0, c->stream));
     for (int k = 0; k < n; k++) {
-        if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 7)/8 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
-        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + 1)/2 + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+        if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
     }
     CK(hipEventRecord(c->ev1, c->stream));
     CK(hipEventSynchronize(c->ev1));
