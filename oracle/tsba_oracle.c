@@ -219,9 +219,9 @@ void tsba_oracle_fillpoly4(int W, int H, const int *xy, uint8_t *mask) {
     const int XY_SHIFT = 16; const long long XY_ONE = 1 << 16;
     poly_edge edges[4]; int ne = 0;
     memset(mask, 0, (size_t)W*H);
-    long long p0x = (long long)xy[6] << XY_SHIFT, p0y = xy[7];
+    long long p0x = (long long)xy[6]*XY_ONE, p0y = xy[7];         /* (x * 2^16, not x << 16: vertices left of the image are negative) */
     for (int i = 0; i < 4; i++) {
-        long long p1x = (long long)xy[2*i] << XY_SHIFT, p1y = xy[2*i+1];
+        long long p1x = (long long)xy[2*i]*XY_ONE, p1y = xy[2*i+1];
         draw_line8(W, H, (p0x + (XY_ONE >> 1)) >> XY_SHIFT, p0y, (p1x + (XY_ONE >> 1)) >> XY_SHIFT, p1y, mask);
         if (p0y != p1y) {
             poly_edge e;
@@ -1058,7 +1058,9 @@ static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_repor
     size_t npose = 7*(size_t)p->n_kf, nrho = (size_t)p->n_pt, nth = 3*(size_t)p->n_text;
     double *x_pose = (double *)malloc(sizeof(double)*(npose + 1)), *x_rho = (double *)malloc(sizeof(double)*(nrho + 1)), *x_th = (double *)malloc(sizeof(double)*(nth + 1));
     double *c_pose = (double *)malloc(sizeof(double)*(npose + 1)), *c_rho = (double *)malloc(sizeof(double)*(nrho + 1)), *c_th = (double *)malloc(sizeof(double)*(nth + 1));
-    memcpy(x_pose, p->pose, sizeof(double)*npose); memcpy(x_rho, p->rho, sizeof(double)*nrho); memcpy(x_th, p->theta, sizeof(double)*nth);
+    memcpy(x_pose, p->pose, sizeof(double)*npose);
+    if (nrho) memcpy(x_rho, p->rho, sizeof(double)*nrho);                 /* (a problem without points / planes passes NULL: memcpy(…, NULL, 0) is undefined) */
+    if (nth) memcpy(x_th, p->theta, sizeof(double)*nth);
     double *sp = (double *)calloc(n6 + 1, sizeof(double)), *dgp = (double *)calloc(n6 + 1, sizeof(double)), *yp = (double *)calloc(n6 + 1, sizeof(double)), *dp = (double *)calloc(n6 + 1, sizeof(double));
     double *sl = (double *)calloc(nl3 + 1, sizeof(double)), *dgl = (double *)calloc(nl3 + 1, sizeof(double)), *yl = (double *)calloc(nl3 + 1, sizeof(double)), *dl = (double *)calloc(nl3 + 1, sizeof(double));
     double *keep = (double *)malloc(sizeof(double)*128*((size_t)P.nblk + 1));
@@ -1130,7 +1132,9 @@ static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_repor
 done:
     rep->iters[pass] = it; rep->accepted[pass] = accepted; rep->termination[pass] = term; rep->cost1[pass] = x_cost;
     rep->n_sblock[pass] = P.ns; rep->n_tblock[pass] = P.nt;
-    memcpy(p->pose, x_pose, sizeof(double)*npose); memcpy(p->rho, x_rho, sizeof(double)*nrho); memcpy(p->theta, x_th, sizeof(double)*nth);
+    memcpy(p->pose, x_pose, sizeof(double)*npose);
+    if (nrho) memcpy(p->rho, x_rho, sizeof(double)*nrho);
+    if (nth) memcpy(p->theta, x_th, sizeof(double)*nth);
 
     if (cov_out && cov_text >= 0 && cov_text < p->n_text) {      /* ceres::Covariance on the same problem (mu / sigma of this pass) */
         int li = P.tx_lm[cov_text];

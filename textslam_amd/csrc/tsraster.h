@@ -54,7 +54,7 @@ __device__ void raster_quad(unsigned *mask, const int *s_xy, int w, int hh, int 
         int y_min = 2147483647, y_max = -2147483647;
         for (int i = 0; i < 4; i++) {
             int i0 = (i + 3) & 3;
-            long long p0x = (long long)s_xy[2*i0] << 16, p0y = s_xy[2*i0+1], p1x = (long long)s_xy[2*i] << 16, p1y = s_xy[2*i+1];
+            long long p0x = (long long)s_xy[2*i0]*65536, p0y = s_xy[2*i0+1], p1x = (long long)s_xy[2*i]*65536, p1y = s_xy[2*i+1];   // (x * 2^16: negative x)
             if (p0y == p1y) continue;
             if (p0y < p1y) { ey0[ne] = (int)p0y; ey1[ne] = (int)p1y; ex[ne] = p0x; } else { ey0[ne] = (int)p1y; ey1[ne] = (int)p0y; ex[ne] = p1x; }
             edx[ne] = (p1x - p0x)/(p1y - p0y);

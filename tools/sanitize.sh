@@ -1,0 +1,51 @@
+#!/bin/bash
+# Sanitizer pass over this repository's own host code (aux row "race / memory checking"):
+#   1. the CPU oracle (plain C) under gcc ASan + UBSan, driven by its whole CPU test-suite;
+#   2. the adapter gather / scatter templates + the C++ ABI driver under g++ ASan + UBSan (six problem types);
+#   3. the HOST side of libtsba.so (plan builder, reordering, index validation, upload staging, C ABI) under clang ASan + UBSan --
+#      the CPU tests here; with a GPU (argument "gpu") also the GPU parity tests, i.e. real uploads / solves through the instrumented host
+#      code (device code is not instrumented: gfx950 ASan needs xnack, which this pool does not enable).
+# Usage: bash tools/sanitize.sh [gpu]   -> gpurun_out/r02_sanitizers.log (summary lines "SANITIZE <what>: <result>")
+set -u
+cd "$(dirname "$0")/.."
+OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/r02_sanitizers.log; : > $LOG
+GASAN=$(gcc -print-file-name=libasan.so); GUBSAN=$(gcc -print-file-name=libubsan.so)
+CASAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
+export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=0:halt_on_error=0
+say() { echo "SANITIZE $*" | tee -a $LOG; }
+
+# ---- 1. oracle
+mkdir -p /tmp/san_oracle && cp oracle/*.so /tmp/san_oracle/ 2>/dev/null
+for f in tsba tsorb tsframe tsloop; do gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o oracle/lib${f}_oracle.so oracle/${f}_oracle.c -lm || say "oracle build $f: FAILED"; done
+LD_PRELOAD="$GASAN $GUBSAN" python -m pytest tests/test_oracle.py tests/test_orb_oracle.py tests/test_frame_oracle.py tests/test_loop_oracle.py tests/test_golden.py tests/test_multi_gpu_sharding.py -q -s -p no:cacheprovider > /tmp/san_oracle.log 2>&1
+say "oracle (gcc ASan+UBSan, CPU suite): $(grep -E 'passed|failed' /tmp/san_oracle.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_oracle.log)"
+cp /tmp/san_oracle/*.so oracle/ 2>/dev/null; make -s -C oracle
+
+# ---- 2. adapter + C++ ABI driver
+g++ -std=c++11 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -Iadapter -o /tmp/abi_from_cxx_san tests/cxx/abi_from_cxx.cpp -Ltextslam_amd -ltsba -L/opt/rocm/lib -Wl,-rpath,$PWD/textslam_amd -Wl,-rpath,/opt/rocm/lib || say "adapter build: FAILED"
+python - > /tmp/san_adapter.log 2>&1 <<'PY'
+import subprocess, sys, os, tempfile
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import test_cxx_adapter as t
+bad = 0
+for name, (P, mode) in t._cases().items():
+    d = tempfile.mkdtemp(); dump, out = os.path.join(d, "p.bin"), os.path.join(d, "o.bin")
+    t._write_dump(dump, P)
+    r = subprocess.run(["/tmp/abi_from_cxx_san", dump, mode, out], capture_output=True, text=True)
+    ok = r.returncode in (0, 3) and "gather identical" in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr
+    print(name, "rc", r.returncode, "OK" if ok else "BAD\n" + r.stderr[-2000:]); bad += not ok
+print("bad", bad)
+PY
+say "adapter gather/scatter + C++ driver (g++ ASan+UBSan, 6 problem types): $(tail -1 /tmp/san_adapter.log)"
+
+# ---- 3. host side of libtsba
+(cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-unused-variable -o /tmp/libtsba_san.so tsba.hip) || say "libtsba build: FAILED"
+TSBA_LIB=/tmp/libtsba_san.so LD_PRELOAD="$CASAN" python -m pytest tests/test_band_partition.py tests/test_abi.py -q -s -p no:cacheprovider > /tmp/san_host.log 2>&1
+say "libtsba host code (clang ASan+UBSan), CPU tests (plan, reordering, partition tables, ABI): $(grep -E 'passed|failed' /tmp/san_host.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_host.log)"
+if [ "${1:-}" = "gpu" ]; then
+  TSBA_LIB=/tmp/libtsba_san.so LD_PRELOAD="$CASAN" timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_global.py tests/test_gpu_context_reuse.py -m gpu -q -s -p no:cacheprovider > /tmp/san_gpu.log 2>&1
+  say "libtsba host code (clang ASan+UBSan), GPU parity tests through the instrumented host side: $(grep -E 'passed|failed' /tmp/san_gpu.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log)"
+  grep -B2 -A12 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log | head -60 >> $LOG
+fi
+grep -B2 -A12 'ERROR: AddressSanitizer\|runtime error' /tmp/san_oracle.log /tmp/san_host.log 2>/dev/null | head -80 >> $LOG
+cat $LOG | grep SANITIZE
