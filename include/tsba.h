@@ -249,7 +249,8 @@ typedef struct tsba_debug_options {
     int32_t no_small_pairs;    /* 1: never put four (target, host) pairs on one wave of the linearisation */
     int32_t verbose;           /* 1: host-side timing of upload / plan construction on stderr */
     int32_t no_kf_reorder;     /* 1: keep the rows of S in keyframe order even when the envelope is wide (loop closures) */
-    int32_t reserved[9];
+    int32_t no_schur_quad;     /* 1: large maps assemble S with one wave per 6x6 block (k_schur_t<1>) instead of four blocks per wave */
+    int32_t reserved[8];
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

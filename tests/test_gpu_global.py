@@ -92,6 +92,28 @@ def test_small_pair_linearisation_variant(gpu):
         gpu.debug_set()
 
 
+def test_schur_four_blocks_per_wave_variant(gpu):
+    """k_schur_quad (large maps: four S blocks per wave, 16 lanes each) against one wave per block (k_schur_t<1>): the reduced system
+    of the first linearisation to 1e-13 (the partial sums are grouped differently), then the same LM trajectory -- on a scene-only map
+    and on a map with text planes (the 3 x 3 plane blocks take the second loop of the kernel)."""
+    cases = [(synth.config_global(n_kf=400, n_pt=8000, band=10), 0),
+             (_text_map(150, 3000, 60, 9, (24, 12, 8), 10, 1), 1)]
+    for P, use_text in cases:
+        o = abi.options_global(); o.its[0] = 6; o.use_text = use_text
+        try:
+            gpu.upload(P, o); ra = gpu.reduced_band(o.initial_radius)
+            G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+            gpu.debug_set(no_schur_quad=1)
+            gpu.upload(P, o); rb = gpu.reduced_band(o.initial_radius)
+            G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        finally:
+            gpu.debug_set()
+        assert np.abs(ra["ab"] - rb["ab"]).max() <= 1e-13*np.abs(rb["ab"]).max() and np.abs(ra["ab"]).max() > 0
+        np.testing.assert_allclose(ra["g"], rb["g"], rtol=0, atol=1e-13*np.abs(rb["g"]).max())
+        _same_trajectory(rep1, rep2, G1, G2, atol=1e-10)
+        assert rep1["accepted"][0] >= 3
+
+
 def test_c6_full_size_global_ba(gpu):
     """BASELINE config 4 on one GPU, the instance bench.py --workload global_ba times (5000 KF x 70 k points, ~500 k scene blocks):
     the path the cost model picks (64 interiors, cyclic-reduction separator solve, one-wave Schur blocks, k_pose_sums,

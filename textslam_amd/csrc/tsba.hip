@@ -1140,12 +1140,12 @@ __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad
 // SCHUR_NW waves per workgroup: 4 for windows (a diagonal block gathers ~1000 slot pairs), 1 for large maps (54 k blocks of ~60 slot
 // pairs each at 5000 keyframes: three idle waves per block and their hand-off were most of the 0.64 ms)
 template <int SCHUR_NW>
-__global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int multi) {
+__global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int multi, int b0) {
     constexpr int SCHUR_T = 64*SCHUR_NW;
     LmState *st = W.st;
     if (st->done) return;
     __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // (b0: large maps take the S blocks through k_schur_quad and only the gradient part here)
     const double radius = st->radius, irad = 1.0/radius;
     const LinBuf &B = W.lb[st->lcur];
     if (b < L.n_sb) {
@@ -1300,6 +1300,113 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         }
         __syncthreads();
         if (tid < 6) W.g[6*ia + tid] = bpv - (SCHUR_NW > 1 ? (((lds[tid] + lds[6 + tid]) + lds[12 + tid]) + lds[18 + tid]) : lds[tid]);
+    }
+}
+
+// Large maps: FOUR S blocks per wave, 16 lanes each.  At 5000 keyframes a block gathers ~70 slot pairs: a whole wave per block left most
+// load slots empty and paid a 64-lane reduction (36 LDS writes + 64 reads) per block; here a 16-lane group walks its block's list 64
+// entries per round trip (4 in flight per lane), the 36 sums of a group are transposed through a 36 x 17 LDS tile and every lane
+// finishes up to three entries of the block (tail: pose-pair products, damping) and stores them.  Same sums, same order within a lane;
+// the order ACROSS lanes differs from k_schur_t<1> (16 partial sums instead of 64), which the tests' tolerances cover.
+__global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi) {
+    LmState *st = W.st;
+    if (st->done) return;
+    __shared__ double lds[4*36*17];
+    const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
+    const int b = 4*(int)blockIdx.x + grp;
+    const bool have = b < L.n_sb;
+    const int bc = have ? b : L.n_sb - 1;
+    const double irad = 1.0/st->radius;
+    const LinBuf &B = W.lb[st->lcur];
+    const int a = L.sb_a[bc], c = L.sb_b[bc];
+    const int ia = W.fidx[a], ic = W.fidx[c];
+    const bool live = have && ia >= 0 && ic >= 0;               // rows / columns of S exist for free poses only
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+    const int pt0 = L.sb_pt_off[bc], pt1 = live ? L.sb_pt_off[bc+1] : pt0;
+    for (int base = pt0; base < pt1; base += 16*SCHUR_U) {
+        int s1[SCHUR_U], s2[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
+#pragma unroll
+        for (int u = 0; u < SCHUR_U; u++) {
+            const int q = base + u*16 + sub; ok[u] = q < pt1;
+            const int qc = min(q, pt1 - 1);
+            s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc];
+        }
+        double w1[SCHUR_U][6], w2[SCHUR_U][6], Vv[SCHUR_U], dg[SCHUR_U];
+#pragma unroll
+        for (int u = 0; u < SCHUR_U; u++) {
+            Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
+        }
+#pragma unroll
+        for (int u = 0; u < SCHUR_U; u++) {
+            const double vinv = ok[u] ? ts_rcp(Vv[u] + dg[u]*irad) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double wr = w1[u][r]*vinv;
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += wr*w2[u][cc];
+            }
+        }
+    }
+    if (live) for (int q = L.sb_tx_off[bc] + sub; q < L.sb_tx_off[bc+1]; q += 16) {
+        const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
+        double Vd[6], Vi[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+        Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
+        double W1[18], W2[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) { W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k]; W2[k] = B.w_tx[(size_t)(s2)*TX_REC + k]; }
+        if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double t0 = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
+            double t1 = W1[r*3]*Vi[1] + W1[r*3+1]*Vi[3] + W1[r*3+2]*Vi[4];
+            double t2 = W1[r*3]*Vi[2] + W1[r*3+1]*Vi[4] + W1[r*3+2]*Vi[5];
+#pragma unroll
+            for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += t0*W2[cc*3] + t1*W2[cc*3+1] + t2*W2[cc*3+2];
+        }
+    }
+    // tails of this lane's entries o = sub, sub + 16, sub + 32 (< 36), independent of the sums: issued before the reduction
+    double tail[3] = {0.0, 0.0, 0.0};
+    if (live) {
+        const double *out = B.pairOut;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int o = sub + 16*t; if (o >= 36) break;
+            const int r = o/6, cc = o - 6*r;
+            if (a == c) {
+                const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
+                tail[t] = range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
+                if (r == cc && !multi) tail[t] += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
+            } else {
+                const int pab = L.sb_pab[bc], pba = L.sb_pba[bc];
+                if (pab >= 0) tail[t] -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
+                if (pba >= 0) tail[t] -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
+            }
+        }
+    }
+    double *tile = lds + grp*36*17;
+#pragma unroll
+    for (int k = 0; k < 36; k++) tile[k*17 + sub] = acc[k];
+    __syncthreads();                                            // (one wave: an s_barrier of one wave)
+    if (!live) return;
+    const size_t ldS = (size_t)W.ldS;
+    const bool a_later = ia > ic;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int o = sub + 16*t; if (o >= 36) break;
+        const double *row = tile + o*17;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
+        const double v = tail[t] - ((s0 + s1) + (s2 + s3));
+        const int r = o/6, cc = o - 6*r;
+        if (a == c || !W.band || a_later) W.S[(size_t)(6*ia + r)*ldS + 6*ic + cc] = v;
+        if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r] = v;
     }
 }
 
@@ -2232,8 +2339,11 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
     return *use_lds ? (int)bytes : 0;
 }
 static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
-    if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi);      // large maps: one wave per block
-    else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi);
+    if (c->n_kf > 126 && !c->dbg.no_schur_quad) {               // large maps: four S blocks per wave, then one wave per pose for the reduced gradient
+        if (D.n_sb > 0) hipLaunchKernelGGL(k_schur_quad, dim3((D.n_sb + 3)/4), dim3(64), 0, c->stream, c->W, D, multi);
+        hipLaunchKernelGGL(k_schur_t<1>, dim3(c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, D.n_sb);
+    } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0);
+    else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0);
 }
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
 static int set_solver_attrs(Ctx *c) {
