@@ -35,7 +35,7 @@ __device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax
 }
 static size_t bandp_lds_doubles(int bw, int cb) {               // window + border rows + rhs row, LD table, scratch
     const int rows = 6*cb + 2*bw;
-    return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*3 + 8 + 64;      // (scratch of up to three panel waves)
+    return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*SOLVE_PW + 8 + 64;
 }
 static int bandp_chunk_blocks(int bw) {
     for (int cb = 16; cb >= 4; cb--) if (bandp_lds_doubles(bw, cb)*sizeof(double) <= 152*1024) return cb;
