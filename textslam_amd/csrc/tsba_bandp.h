@@ -43,16 +43,15 @@ static int bandp_chunk_blocks(int bw) {
 }
 
 // T_p layout: nT = nR + nL rows ([right separator rows; left separator rows]), dense nTmax x nTmax row-major (lower used) + gT
-// PW panel waves (SOLVE_PW = 2 in the product).  A step's panel has bw band rows + bw border rows + the rhs row -- 121 rows at a band of
+// SOLVE_PW = 2 panel waves.  A step's panel has bw band rows + bw border rows + the rhs row -- 121 rows at a band of
 // 60, which two panel waves (58 rows each) take in two rounds; three panel waves (one round, nine update waves) were measured in round 2
 // on the 5000-keyframe map: 1085 us per solve phase against 1064 us with two -- the second round is not what bounds the step.
-template <int PW>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, int CB, int Pmax, double *Lrow, double *Lb, double *Tbuf) {
     LmState *st = W.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NW = SOLVE_THREADS/64, NT = NW - PW;
+    constexpr int NW = SOLVE_THREADS/64, NT = NW - SOLVE_PW;
     if (st->done || st->step_fail) return;
     const int nb = *W.nfree, B = bw/6;
     if (nb == 0) return;
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         for (int jb = jstart; jb < jend + (flush ? 1 : 0) && !fail; jb++) {
             const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
             const bool fl = jb == jend;                         // flush step: no factorisation, panel jb-1 onto everything right of it
-            if (wave < PW) {
+            if (wave < SOLVE_PW) {
                 double Lk[36], dprev[6];
                 if (jb > 0) {
                     ld6(LD + SOLVE_LD*(jb - 1) + LD_D, dprev);
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     };
                     if (lane >= 6) {
                         if (i0 < re + nx) solve_row(vrow(i0), a);
-                        for (int i = i0 + PW*SOLVE_PROWS; i < re + nx; i += PW*SOLVE_PROWS) { load_row(vrow(i), a); solve_row(vrow(i), a); }
+                        for (int i = i0 + SOLVE_PW*SOLVE_PROWS; i < re + nx; i += SOLVE_PW*SOLVE_PROWS) { load_row(vrow(i), a); solve_row(vrow(i), a); }
                     }
                 }
             } else if (jb > 0) {
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     const int k1 = min(4 + lk, 5);
                     const double dk0 = ldp[LD_D + lk], dk1 = lk < 2 ? ldp[LD_D + 4 + lk] : 0.0;
                     auto real = [&](int v) { return v < re ? v : n + (v - re); };
-                    for (int t = wave - PW; t < ntile; t += NT) {
+                    for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
                         int ti, tj;
                         if (t < ntri) { ti = tri_row(t); tj = t - tri(ti); } else { const int u = t - ntri; ti = ntcb + u/ntcb; tj = u - (ti - ntcb)*ntcb; }
                         const int r0v = Rs + 16*ti, c0v = Rs + 16*tj;
