@@ -1415,6 +1415,7 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
 #include "tsba_band.h"
 #include "tsba_bandp.h"
 #include "tsba_bandcr.h"
+#include "tsba_bandcre.h"
 #include "tsba_pose.h"
 
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
@@ -1817,7 +1818,7 @@ struct Ctx {
     double *S_alloc = nullptr; size_t S_count = 0;
     double *S_xchg = nullptr; int xchg_wp = 0;      // multi-GPU, band storage: packed band rows for the exchange (k_band_pack)
     bool sep_cr = false;                  // separator system by cyclic reduction on the compact block pool (tsba_bandcr.h)
-    int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Bpart = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
+    int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Bpart = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr, *CRcontrib = nullptr, *CRfac = nullptr; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
     double *Lcol = nullptr; int band_stream = 0;  // streaming band solver (tsba_band.h): L by block column; 1 = every built level fits it     // storage behind W.S (dense or band)
     float *lbl_dev = nullptr, *lbl_host = nullptr; size_t lbl_cap = 0;   // text label image staging
     unsigned long long *hprog = nullptr; unsigned int pass_seq = 0;   // pinned progress word written by k_postlin / k_decide
@@ -2188,7 +2189,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
                 const double cost_seq = (double)p->n_kf/Ps*t_f + (double)(Ps - 1)*Bq*t_s;
                 if (best < cost_seq) { P = bestP; want_cr = true; }
             }
-            if (c->dbg.sep_solver == 2 && bwmax <= CR_SMAX) want_cr = true;
+            if (c->dbg.sep_solver >= 2 && bwmax <= CR_SMAX) want_cr = true;
             if (c->dbg.band_parts > 0) P = c->dbg.band_parts;
             P = std::max(1, std::min(P, BANDP_MAXP));
             while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < 4*Bq + 4) P--;                   // worth it only for interiors of a few bands
@@ -2198,7 +2199,8 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
                 AL(c->Lb, (size_t)p->n_kf*bwmax*6); AL(c->Tbuf, (size_t)P*((size_t)4*bwmax*bwmax + 2*bwmax));
                 AL(c->Bpart, (size_t)P*BANDP_NS*((size_t)bwmax*bwmax + bwmax));
                 c->sep_cr = want_cr && P >= 4;
-                if (c->sep_cr) AL(c->Ssep, cr_pool_blocks(P - 1)*(size_t)bwmax*bwmax); else AL(c->Ssep, (size_t)nsep*nsep + nsep);
+                if (c->sep_cr) { AL(c->Ssep, cr_pool_blocks(P - 1)*(size_t)bwmax*bwmax); AL(c->CRcontrib, (size_t)(P - 1)*cre_contrib_doubles(bwmax)); AL(c->CRfac, (size_t)(P - 1)*cre_rec_doubles(bwmax)); }
+                else AL(c->Ssep, (size_t)nsep*nsep + nsep);
                 AL(c->Lcol_sep, (size_t)(nsep/6 + 1)*bws*6);
                 Work &Ws = c->Wsep; memset(&Ws, 0, sizeof(Ws));
                 Ws.N = nsep; Ws.n_kf = 0; Ws.S = c->Ssep; Ws.ldS = nsep; Ws.band = 1; Ws.st = nullptr;       // (st is set at launch: W.st is allocated below)
@@ -2355,6 +2357,8 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_cr_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cr_update, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cr_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_cre_elim, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -2385,6 +2389,14 @@ static void launch_solve(Ctx *c) {
             const int mmax = P - 1;
             const int lp = (int)(cr_pivot_lds_doubles(bwp)*sizeof(double)), lu = (int)(cr_update_lds_doubles(bwp)*sizeof(double)), lb = (int)(cr_back_lds_doubles(bwp)*sizeof(double));
             int htop = 1;
+            if (c->dbg.sep_solver != 3) {      // one launch per level (tsba_bandcre.h); 3: the pivot / update / back kernels of tsba_bandcr.h
+                const int le = (int)(cre_elim_lds_doubles(bwp)*sizeof(double)), lbk = (int)(cre_back_lds_doubles(bwp)*sizeof(double));
+                for (int h = 1; h < mmax; h <<= 1) {
+                    const int npiv = (mmax + 2*h - 1)/(2*h), K = std::max(1, std::min(4, 224/npiv));     // workgroups per pivot (they share its product and stores)
+                    hipLaunchKernelGGL(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, c->CRcontrib, c->CRfac); htop = h; }
+                hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, 1, 1, c->CRcontrib, c->CRfac);
+                for (int h = htop; h >= 1; h >>= 1) hipLaunchKernelGGL(k_cre_back, dim3((mmax + 2*h - 1)/(2*h)), dim3(CRE_BT), lbk, c->stream, W, Ws, bwp, P, h, (const double *)c->CRfac);
+            } else {
             for (int h = 1; h < mmax; h <<= 1) {
                 const int npiv = (mmax + 2*h - 1)/(2*h);           // >= the pivots (2k + 1) h < m; workgroups past the end return
                 hipLaunchKernelGGL(k_cr_pivot, dim3(npiv), dim3(CR_T), lp, c->stream, W, Ws, bwp, P, h, 0);
@@ -2395,6 +2407,7 @@ static void launch_solve(Ctx *c) {
             hipLaunchKernelGGL(k_cr_back, dim3(1), dim3(CR_T), lb, c->stream, W, Ws, bwp, P, 0, 1);
             for (int h = htop; h >= 1; h >>= 1)
                 hipLaunchKernelGGL(k_cr_back, dim3((mmax + 2*h - 1)/(2*h)), dim3(CR_T), lb, c->stream, W, Ws, bwp, P, h, 0);
+            }
         } else {
         const int ldss = (int)(band_lds_doubles(bwsep, cbs)*sizeof(double)), nus = (bwsep + 63)/64;
         hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(SOLVE_THREADS), ldss, c->stream, Ws, bwsep, cbs, c->Lcol_sep);
