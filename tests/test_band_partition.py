@@ -30,14 +30,17 @@ def test_partition_covers_the_band(lib, nb, B, Pmax):
     P = _part(lib, nb, B, Pmax, 0)[0]
     assert 1 <= P <= Pmax
     pos = 0
+    sizes = []
     for p in range(P):
         Pp, a, b, hl, hr = _part(lib, nb, B, Pmax, p)
         assert Pp == P and a == pos and b > a
+        sizes.append(b - a)
         assert hl == (p > 0) and hr == (p < P - 1)
         if P > 1:
             assert b - a >= 2*B + 2
         pos = b + (B if hr else 0)
     assert pos == nb
+    assert max(sizes) - min(sizes) <= 1              # balanced: the launch lasts as long as its longest interior
     if P < Pmax:                                     # P shrank: one more interior would have been too short
         assert (nb - P*B)//(P + 1) < 2*B + 2
 

@@ -2175,13 +2175,15 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             int P = (int)lround(sqrt((double)p->n_kf*t_f/((double)std::max(Bq, 1)*t_s)));
             bool want_cr = false;
             if (bwmax <= CR_SMAX && c->dbg.sep_solver != 1) {
-                // separator system by cyclic reduction (tsba_bandcr.h): its cost grows with log2(P) only (~130 us per level: pivot + update +
-                // back-substitution launches), so many more, shorter interiors pay
+                // separator system by cyclic reduction (tsba_bandcre.h): its cost grows with log2(P) only (~45 us per level: one elimination
+                // and one back-substitution launch; 130 us with the three kernels of round 1), so many more, shorter interiors pay.
+                // Measured at 5000 keyframes / band 10 (ms per 20-iteration solve): P = 64 / 80 / 96 / 112 / 127 / 150 -> 20.6 / 20.3 / 19.4 /
+                // 18.6 / 18.0 / 18.8 (150: an eighth level)
                 double best = 1e300; int bestP = P;
                 for (int q = 4; q <= BANDP_MAXP; q++) {
-                    if ((p->n_kf - (q - 1)*Bq)/q < 6*Bq + 8) break;          // (shorter interiors no longer amortise a workgroup's fixed cost: measured)
+                    if ((p->n_kf - (q - 1)*Bq)/q < 2*Bq + 8) break;          // (the kernels need 2 B + 2 blocks per interior)
                     int lev = 1; for (int hh = 1; hh < q - 1; hh <<= 1) lev++;
-                    const double cost = (double)p->n_kf/q*t_f + 130.0*lev;
+                    const double cost = (double)p->n_kf/q*t_f + 45.0*lev;
                     if (cost < best) { best = cost; bestP = q; }
                 }
                 // (few, long interiors -- some hundred keyframes -- are still cheaper with the sequential separator solve: compare)
@@ -2192,7 +2194,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             if (c->dbg.sep_solver >= 2 && bwmax <= CR_SMAX) want_cr = true;
             if (c->dbg.band_parts > 0) P = c->dbg.band_parts;
             P = std::max(1, std::min(P, BANDP_MAXP));
-            while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < 4*Bq + 4) P--;                   // worth it only for interiors of a few bands
+            while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < ((c->dbg.band_parts > 0 || want_cr) ? 2*Bq + 2 : 4*Bq + 4)) P--;     // (2 B + 2: the least the kernels take; the sequential separator solve pays only for interiors of a few bands)
             if (P > 1 && bandp_chunk_blocks(bwmax) > 0 && 2*bwmax - 6 <= BAND_BW_MAX && band_chunk_blocks(2*bwmax - 6) > 0) {
                 const int nsep = (P - 1)*bwmax, bws = 2*bwmax - 6;
                 c->nsep_ld = nsep;

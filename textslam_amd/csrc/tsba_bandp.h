@@ -19,39 +19,183 @@
 // Every workgroup derives the same partition table from the number of free poses on the device (the host does not know it).
 #pragma once
 
-#define BANDP_MAXP 96
+#define BANDP_MAXP 160
+#ifndef BANDP_PW
+#define BANDP_PW 2                          // panel waves of k_bandp_factor
+#endif
 
 struct BandpPart { int P, a, b, has_left, has_right; };
-// interiors of q = (nb - (P - 1) B) / P blocks (the last takes the remainder), separators of B blocks between them; P shrinks
-// until an interior holds at least 2 B + 2 blocks
+// interiors of q = (nb - (P - 1) B) / P blocks -- the first `rem` of them one more: the launch lasts as long as its longest interior, and a
+// last interior that took the whole remainder was 85 blocks against 68 at 5000 keyframes / P = 64 --, separators of B blocks between
+// them; P shrinks until an interior holds at least 2 B + 2 blocks
 __device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax, int p) {
     int P = Pmax;
     while (P > 1 && (nb - (P - 1)*B)/P < 2*B + 2) P--;
     BandpPart r; r.P = P;
-    const int q = (nb - (P - 1)*B)/P;
-    r.a = p*(q + B); r.b = (p == P - 1) ? nb : r.a + q;
+    const int tot = nb - (P - 1)*B, q = tot/P, rem = tot - q*P;
+    r.a = p*(q + B) + (p < rem ? p : rem); r.b = r.a + q + (p < rem ? 1 : 0);
+    if (p == P - 1) r.b = nb;
     r.has_left = p > 0; r.has_right = p < P - 1;
     return r;
 }
 static size_t bandp_lds_doubles(int bw, int cb) {               // window + border rows + rhs row, LD table, scratch
     const int rows = 6*cb + 2*bw;
-    return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*SOLVE_PW + 8 + 64;
+    return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*BANDP_PW + 8 + 64;
 }
 static int bandp_chunk_blocks(int bw) {
     for (int cb = 16; cb >= 4; cb--) if (bandp_lds_doubles(bw, cb)*sizeof(double) <= 152*1024) return cb;
     return 0;
 }
 
+// ---- the cold phases of k_bandp_factor as functions of their own (NOT inlined): the kernel sits at its 168-register cap, and whatever these
+// phases keep live competes with the step loop -- inlined, the compiler spilled loop invariants and reloaded them from scratch inside
+// the copy loops (a scratch reload is a memory round trip).
+typedef __attribute__((address_space(3))) double lds_f64;
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global store in flight (vmcnt(0)) -- the write-out
+// of a chunk (130 KB per workgroup) would drain before the slide could start
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// rows [r0, n) of the window from HBM (band storage); for the border / rhs rows the columns [r0, n).  first: also the border-border
+// block and the couplings to the left separator.  Row-wise: a wave takes whole rows (row addresses on the scalar unit, no division
+// per element) and keeps the loads of LOAD_U rows in flight -- the element-wise loop waited for every load before it issued the next
+// (5 - 6 dependent HBM round trips per chunk).
+__device__ __noinline__ void bandp_load_rows(double *Ag, const double *S, size_t ld, const double *g, int r0_, int first_, int n_, int nbr_, int base_, int gl0_, int bw_) {
+    lds_f64 *A = (lds_f64 *)Ag;
+    // (arguments of a function arrive in vector registers: back to the scalar unit)
+    const int r0 = __builtin_amdgcn_readfirstlane(r0_), first = __builtin_amdgcn_readfirstlane(first_), n = __builtin_amdgcn_readfirstlane(n_), nbr = __builtin_amdgcn_readfirstlane(nbr_),
+              base = __builtin_amdgcn_readfirstlane(base_), gl0 = __builtin_amdgcn_readfirstlane(gl0_), bw = __builtin_amdgcn_readfirstlane(bw_);
+    constexpr int NW = SOLVE_THREADS/64, LOAD_U = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int k = wave; k < nbr; k += NW) { lds_f64 *row = A + rowoff(n + k);
+        for (int c = r0 + lane; c < n; c += 64) row[c] = 0.0;
+        if (first) for (int c = lane; c <= k; c += 64) row[n + c] = 0.0; }
+    if (first) __syncthreads();                              // (the band rows of the first chunk put the couplings into the border rows)
+    const int per = bw + 6;                                  // the band is block-aligned: row r reaches back to column 6 (r/6) - bw
+    lds_f64 *rhs = A + rowoff(n + nbr);
+    double gv[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) { const int c = r0 + tid + u*SOLVE_THREADS; gv[u] = c < n ? g[base + c] : 0.0; }
+    for (int rb = r0 + wave; rb < n; rb += NW*LOAD_U) {
+        double v[LOAD_U][2];
+#pragma unroll
+        for (int u = 0; u < LOAD_U; u++) {
+            const int r = rb + NW*u, gr = base + r, cmin = 6*(r/6) - bw;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const int k = 64*kk + lane, c = r - k;
+                v[u][kk] = 0.0;
+                if (r < n && k < per && c >= cmin && (c >= 0 || (first && nbr > 0 && base + c >= gl0))) v[u][kk] = S[(size_t)gr*ld + (base + c)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LOAD_U; u++) {
+            const int r = rb + NW*u, cmin = 6*(r/6) - bw;
+            if (r >= n) continue;
+            lds_f64 *row = A + rowoff(r);
+            for (int c = lane; c < cmin; c += 64) row[c] = 0.0;            // left of the band
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const int k = 64*kk + lane, c = r - k;
+                if (k < per && c >= cmin) {
+                    if (c >= 0) row[c] = v[u][kk];
+                    else if (first && nbr > 0 && base + c >= gl0) A[rowoff(n + (base + c - gl0)) + r] = v[u][kk];   // S(gr, gl) = border(gl, gr)
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) { const int c = r0 + tid + u*SOLVE_THREADS; if (c < n) rhs[c] = gv[u]; }
+    if (first) for (int k = tid; k < nbr; k += SOLVE_THREADS) rhs[n + k] = 0.0;
+    __syncthreads();
+}
+// slide by s rows.  Virtual index v: band rows 0 .. m-1, border rows m .. mv-1, rhs row mv.  Row-wise through registers: a wave takes the
+// virtual rows wave, wave + NW, ... (row addresses on the scalar unit, a lane a column of each 64-column chunk); ascending batches of SL_B
+// rows per wave, read - barrier - write - barrier: a destination lies at or below its own source and below every source of a later
+// batch.  (The element-wise version spent ~60 instructions of index arithmetic per element -- tri_row, two rowoff, four selects.)
+__device__ __noinline__ void bandp_slide(double *Ag, int n_, int n_new_, int m_, int s_, int mv_) {
+    lds_f64 *A = (lds_f64 *)Ag;
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    // (arguments of a function arrive in vector registers: back to the scalar unit)
+    const int n = __builtin_amdgcn_readfirstlane(n_), n_new = __builtin_amdgcn_readfirstlane(n_new_), m = __builtin_amdgcn_readfirstlane(m_),
+              s = __builtin_amdgcn_readfirstlane(s_), mv = __builtin_amdgcn_readfirstlane(mv_);
+    constexpr int NW = SOLVE_THREADS/64, SL_B = (2*(BAND_BW_MAX/2) + 6 + NW)/NW, SL_C = (2*(BAND_BW_MAX/2) + 6 + 127)/128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // two doubles per lane: rows start 16-byte aligned, s, m, n, n_new are even, so a pair never straddles the band / border boundary
+    // (the second slot of a row's last pair is the row's padding)
+    const int nch = (mv + 127) >> 7;
+    v2d sv[SL_B][SL_C];
+#pragma unroll
+    for (int u = 0; u < SL_B; u++) {
+        const int r = min(wave + NW*u, mv);
+        const lds_f64 *src = A + rowoff(r < m ? r + s : n + (r - m));
+        const int ncol = r < mv ? r + 1 : mv;
+#pragma unroll
+        for (int k = 0; k < SL_C; k++) if (k < nch) { const int c = min(128*k + 2*lane, (ncol - 1) & ~1); sv[u][k] = *(const lds_v2d *)(src + (c < m ? c + s : n + (c - m))); }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int u = 0; u < SL_B; u++) {
+        const int r = wave + NW*u;
+        if (r > mv) continue;
+        lds_f64 *dst = A + rowoff(r < m ? r : n_new + (r - m));
+        const int ncol = r < mv ? r + 1 : mv;
+#pragma unroll
+        for (int k = 0; k < SL_C; k++) { const int c = 128*k + 2*lane; if (c < ncol) *(lds_v2d *)(dst + (c < m ? c : n_new + (c - m))) = sv[u][k]; }
+    }
+    lds_barrier();
+}
+
+// finished column blocks jstart .. jend-1 of the window -> HBM.  A wave takes a column block, a lane one (row block b, column cc) of its L
+// panel -- six rows, i.e. 48 contiguous bytes of the [b][cc][ri] record -- and one border row (six contiguous columns): 16-byte stores,
+// no division per element (the element-wise loop: two run-time divisions and ~80 instructions per 8-byte store).
+__device__ __noinline__ void bandp_write_out(double *Ag, double *LDg, double *Lrow, double *Lb, double *LDbuf, double *Sy, int jstart_, int jend_, int base_, int n_, int nbr_, int bw_) {
+    lds_f64 *A = (lds_f64 *)Ag, *LD = (lds_f64 *)LDg;
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    const int jstart = __builtin_amdgcn_readfirstlane(jstart_), jend = __builtin_amdgcn_readfirstlane(jend_), base = __builtin_amdgcn_readfirstlane(base_),
+              n = __builtin_amdgcn_readfirstlane(n_), nbr = __builtin_amdgcn_readfirstlane(nbr_), bw = __builtin_amdgcn_readfirstlane(bw_);
+    constexpr int NW = SOLVE_THREADS/64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int REC = bw*6, NR = n + nbr;
+    for (int q = jstart + wave; q < jend; q += NW) {
+        const int gq = base/6 + q, c0 = 6*q;
+        for (int t = lane; t < REC/6; t += 64) {                 // (b, cc): rows 6 q + 6 + 6 b + ri
+            const int b = t/6, cc = t - 6*b, r0 = c0 + 6 + 6*b;
+            double v[6];
+#pragma unroll
+            for (int ri = 0; ri < 6; ri++) v[ri] = A[rowoff(min(r0 + ri, n - 1)) + c0 + cc];
+            double *o = Lrow + (size_t)(gq + 1 + b)*REC + b*36 + cc*6;
+            if (r0 + 5 < n) { ((v2d *)o)[0] = v2d{v[0], v[1]}; ((v2d *)o)[1] = v2d{v[2], v[3]}; ((v2d *)o)[2] = v2d{v[4], v[5]}; }
+            else {
+#pragma unroll
+                for (int ri = 0; ri < 6; ri++) if (r0 + ri < n) o[ri] = v[ri];
+            }
+        }
+        for (int br = lane; br < bw; br += 64) {                 // border panel of the column block: [border row][cc]
+            v2d x0 = {0.0, 0.0}, x1 = x0, x2 = x0;
+            if (br < nbr) { const lds_v2d *src = (const lds_v2d *)(A + rowoff(n + br) + c0); x0 = src[0]; x1 = src[1]; x2 = src[2]; }
+            v2d *o = (v2d *)(Lb + (size_t)gq*REC + 6*br);
+            o[0] = x0; o[1] = x1; o[2] = x2;
+        }
+        if (lane < 15) LDbuf[32*(size_t)gq + lane] = LD[SOLVE_LD*q + lane];
+        else if (lane >= 16 && lane < 22) LDbuf[32*(size_t)gq + lane] = LD[SOLVE_LD*q + LD_ID + (lane - 16)];
+        else if (lane >= 24 && lane < 30) Sy[6*gq + (lane - 24)] = A[rowoff(NR) + c0 + (lane - 24)];
+    }
+}
+
 // T_p layout: nT = nR + nL rows ([right separator rows; left separator rows]), dense nTmax x nTmax row-major (lower used) + gT
-// SOLVE_PW = 2 panel waves.  A step's panel has bw band rows + bw border rows + the rhs row -- 121 rows at a band of
-// 60, which two panel waves (58 rows each) take in two rounds; three panel waves (one round, nine update waves) were measured in round 2
-// on the 5000-keyframe map: 1085 us per solve phase against 1064 us with two -- the second round is not what bounds the step.
+// BANDP_PW = 2 panel waves.  A step's panel has bw band rows + bw border rows + the rhs row -- 121 rows at a band of 60, which two panel
+// waves (58 rows each) take in two rounds.  Three panel waves (ONE round, nine update waves), measured twice in round 2 on the
+// 5000-keyframe map (cycle stamps of the factor loops of one interior): 484 k cycles against 448 k with two -- the step is bound by
+// the update waves (a third panel wave takes a SIMD's issue slots from them), not by the second panel round.
 __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, int CB, int Pmax, double *Lrow, double *Lb, double *Tbuf) {
     LmState *st = W.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NW = SOLVE_THREADS/64, NT = NW - SOLVE_PW;
+    constexpr int NW = SOLVE_THREADS/64, NT = NW - BANDP_PW;
     if (st->done || st->step_fail) return;
     const int nb = *W.nfree, B = bw/6;
     if (nb == 0) return;
@@ -72,26 +216,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
     int base = 6*PT.a, n = min(Wn, row_lim - base);
     const int gl0 = 6*(PT.a - B);                               // first row of the left separator
     // rows [r0, n) of the window from HBM; for the border / rhs rows the columns [r0, n).  first: also the border-border block
-    auto load_rows = [&](int r0, bool first) {
-        for (int r = r0 + wave; r < n; r += NW) { double *row = A + rowoff(r); for (int c = lane; c <= r; c += 64) row[c] = 0.0; }
-        for (int k = wave; k < nbr; k += NW) { double *row = A + rowoff(n + k);
-            for (int c = r0 + lane; c < n; c += 64) row[c] = 0.0;
-            if (first) for (int c = lane; c <= k; c += 64) row[n + c] = 0.0; }
-        __syncthreads();
-        const int nr = n - r0, per = bw + 6;                   // the band is block-aligned: row r reaches back to column 6 (r/6) - bw
-        for (int e = tid; e < nr*per; e += SOLVE_THREADS) {
-            const int rr = e/per, k = e - rr*per, r = r0 + rr, c = r - k, gr = base + r;
-            if (c >= 0 && c >= 6*(r/6) - bw) A[rowoff(r) + c] = S[(size_t)gr*ld + (base + c)];
-            else if (first && nbr > 0 && c < 0) {               // left of the interior: the coupling to the left separator, S(gr, gl) = border(gl, gr)
-                const int gc = base + c;                         // global column < base
-                if (gc >= gl0 && gc >= 6*(gr/6) - bw) A[rowoff(n + (gc - gl0)) + r] = S[(size_t)gr*ld + gc];
-            }
-        }
-        double *rhs = A + rowoff(n + nbr);
-        for (int c = r0 + tid; c < n; c += SOLVE_THREADS) rhs[c] = W.g[base + c];
-        if (first) for (int k = tid; k < nbr; k += SOLVE_THREADS) rhs[n + k] = 0.0;
-        __syncthreads();
-    };
+    auto load_rows = [&](int r0, bool first) { bandp_load_rows(A, S, ld, W.g, r0, first ? 1 : 0, n, nbr, base, gl0, bw); };
     long long tF = 0, tW = 0, tS = 0, tL = 0, tx = clock64(); int nchunks = 0;       // phase stamps of interior 1 (-> W.dbg[32..36])
     load_rows(0, true);
     { const long long t_ = clock64(); tL += t_ - tx; tx = t_; }
@@ -104,7 +229,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         for (int jb = jstart; jb < jend + (flush ? 1 : 0) && !fail; jb++) {
             const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
             const bool fl = jb == jend;                         // flush step: no factorisation, panel jb-1 onto everything right of it
-            if (wave < SOLVE_PW) {
+            if (wave < BANDP_PW) {
                 double Lk[36], dprev[6];
                 if (jb > 0) {
                     ld6(LD + SOLVE_LD*(jb - 1) + LD_D, dprev);
@@ -166,7 +291,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     };
                     if (lane >= 6) {
                         if (i0 < re + nx) solve_row(vrow(i0), a);
-                        for (int i = i0 + SOLVE_PW*SOLVE_PROWS; i < re + nx; i += SOLVE_PW*SOLVE_PROWS) { load_row(vrow(i), a); solve_row(vrow(i), a); }
+                        for (int i = i0 + BANDP_PW*SOLVE_PROWS; i < re + nx; i += BANDP_PW*SOLVE_PROWS) { load_row(vrow(i), a); solve_row(vrow(i), a); }
                     }
                 }
             } else if (jb > 0) {
@@ -186,7 +311,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
                     const int k1 = min(4 + lk, 5);
                     const double dk0 = ldp[LD_D + lk], dk1 = lk < 2 ? ldp[LD_D + 4 + lk] : 0.0;
                     auto real = [&](int v) { return v < re ? v : n + (v - re); };
-                    for (int t = wave - SOLVE_PW; t < ntile; t += NT) {
+                    for (int t = wave - BANDP_PW; t < ntile; t += NT) {
                         int ti, tj;
                         if (t < ntri) { ti = tri_row(t); tj = t - tri(ti); } else { const int u = t - ntri; ti = ntcb + u/ntcb; tj = u - (ti - ntcb)*ntcb; }
                         const int r0v = Rs + 16*ti, c0v = Rs + 16*tj;
@@ -231,23 +356,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         { const long long t_ = clock64(); tF += t_ - tx; tx = t_; }
         if (fail) break;
         // ---------------- finished columns -> HBM: L by row block, the border panel, unit-lower diagonal factor + 1/d, v = D^-1 L^-1 g
-        {
-            const int nq = jend - jstart, per = 2*REC + 32;
-            for (int e = tid; e < nq*per; e += SOLVE_THREADS) {
-                const int qq = e/per, k = e - qq*per, q = jstart + qq, gq = base/6 + q;
-                if (k < REC) {                                   // L(r, 6 q + cc) -> row block gr, block b = gr - gq - 1, [b][cc][ri]
-                    const int dr = k/6, cc = k - 6*dr, r = 6*q + 6 + dr;
-                    if (r < n) { const int b = dr/6, ri = dr - 6*b;
-                        Lrow[(size_t)(gq + 1 + b)*REC + b*36 + cc*6 + ri] = A[rowoff(r) + 6*q + cc]; } }
-                else if (k < 2*REC) {                            // border panel of the column block: [border row][cc]
-                    const int kk = k - REC, br = kk/6, cc = kk - 6*br;
-                    Lb[(size_t)gq*REC + kk] = br < nbr ? A[rowoff(n + br) + 6*q + cc] : 0.0; }
-                else { const int u = k - 2*REC;
-                    if (u < 15) W.LDbuf[32*(size_t)gq + u] = LD[SOLVE_LD*q + u];
-                    else if (u >= 16 && u < 22) W.LDbuf[32*(size_t)gq + u] = LD[SOLVE_LD*q + LD_ID + (u - 16)];
-                    else if (u >= 24 && u < 30) W.Sy[6*gq + (u - 24)] = A[rowoff(NR) + 6*q + (u - 24)]; }
-            }
-        }
+        bandp_write_out(A, LD, Lrow, Lb, W.LDbuf, W.Sy, jstart, jend, base, n, nbr, bw);
         { const long long t_ = clock64(); tW += t_ - tx; tx = t_; nchunks++; }
         if (tid == 0 && W.dbg && blockIdx.x == 1) { W.dbg[32] = tF; W.dbg[33] = tW; W.dbg[34] = tS; W.dbg[35] = tL; W.dbg[19] = nchunks; }
         if (last) {
@@ -264,23 +373,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
         // packed order through registers: a destination lies at or below its own source and below every source not yet read
         {
             const int s = 6*(jend - 1), m = n - s, n_new = min(Wn, row_lim - (base + s)), mv = m + nbr, ne = tri(mv) + mv;
-            __syncthreads();
-            for (int e0 = 0; e0 < ne; e0 += 4*SOLVE_THREADS) {
-                double v[4]; int dst[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int e = e0 + u*SOLVE_THREADS + tid;
-                    dst[u] = -1;
-                    if (e < ne) { const int r = tri_row(e), c = e - tri(r);
-                        const int ro = r < m ? r + s : n + (r - m), co = c < m ? c + s : n + (c - m);
-                        const int rn = r < m ? r : n_new + (r - m), cn = c < m ? c : n_new + (c - m);
-                        v[u] = A[rowoff(ro) + co]; dst[u] = rowoff(rn) + cn; }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < 4; u++) if (dst[u] >= 0) A[dst[u]] = v[u];
-                __syncthreads();
-            }
+            lds_barrier();
+            (void)ne;
+            bandp_slide(A, n, n_new, m, s, mv);
             if (tid < SOLVE_LD) LD[tid] = LD[SOLVE_LD*(jend - 1) + tid];
             base += s; n = n_new;
             { const long long t_ = clock64(); tS += t_ - tx; tx = t_; }
