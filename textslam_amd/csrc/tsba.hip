@@ -1308,10 +1308,13 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
 // entries per round trip (4 in flight per lane), the 36 sums of a group are transposed through a 36 x 17 LDS tile and every lane
 // finishes up to three entries of the block (tail: pose-pair products, damping) and stores them.  Same sums, same order within a lane;
 // the order ACROSS lanes differs from k_schur_t<1> (16 partial sums instead of 64), which the tests' tolerances cover.
+#ifndef SCHURQ_U
+#define SCHURQ_U 2                          // list entries per lane in flight (k_schur_quad)
+#endif
 __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi) {
     LmState *st = W.st;
     if (st->done) return;
-    __shared__ double lds[4*36*17];
+    __shared__ double lds[4*12*17];                             // a third of a group's 36 sums at a time: 6.5 KB, the registers set the occupancy
     const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
     const int b = 4*(int)blockIdx.x + grp;
     const bool have = b < L.n_sb;
@@ -1325,23 +1328,23 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
     const int pt0 = L.sb_pt_off[bc], pt1 = live ? L.sb_pt_off[bc+1] : pt0;
-    for (int base = pt0; base < pt1; base += 16*SCHUR_U) {
-        int s1[SCHUR_U], s2[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
+    for (int base = pt0; base < pt1; base += 16*SCHURQ_U) {
+        int s1[SCHURQ_U], s2[SCHURQ_U], j[SCHURQ_U]; bool ok[SCHURQ_U];
 #pragma unroll
-        for (int u = 0; u < SCHUR_U; u++) {
+        for (int u = 0; u < SCHURQ_U; u++) {
             const int q = base + u*16 + sub; ok[u] = q < pt1;
             const int qc = min(q, pt1 - 1);
             s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc];
         }
-        double w1[SCHUR_U][6], w2[SCHUR_U][6], Vv[SCHUR_U], dg[SCHUR_U];
+        double w1[SCHURQ_U][6], w2[SCHURQ_U][6], Vv[SCHURQ_U], dg[SCHURQ_U];
 #pragma unroll
-        for (int u = 0; u < SCHUR_U; u++) {
+        for (int u = 0; u < SCHURQ_U; u++) {
             Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
 #pragma unroll
             for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
         }
 #pragma unroll
-        for (int u = 0; u < SCHUR_U; u++) {
+        for (int u = 0; u < SCHURQ_U; u++) {
             const double vinv = ok[u] ? ts_rcp(Vv[u] + dg[u]*irad) : 0.0;
 #pragma unroll
             for (int r = 0; r < 6; r++) {
@@ -1357,30 +1360,38 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
 #pragma unroll
         for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
         Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
-        double W1[18], W2[18];
+        // (t = W1 Vi first, then W2 three values at a time: W1, W2 and acc live together cost the kernel a wave per SIMD)
+        double tv[18];
+        {
+            double W1[18];
 #pragma unroll
-        for (int k = 0; k < 18; k++) { W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k]; W2[k] = B.w_tx[(size_t)(s2)*TX_REC + k]; }
-        if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
+            for (int k = 0; k < 18; k++) W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k];
+            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            double t0 = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
-            double t1 = W1[r*3]*Vi[1] + W1[r*3+1]*Vi[3] + W1[r*3+2]*Vi[4];
-            double t2 = W1[r*3]*Vi[2] + W1[r*3+1]*Vi[4] + W1[r*3+2]*Vi[5];
+            for (int r = 0; r < 6; r++) {
+                tv[r*3] = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
+                tv[r*3+1] = W1[r*3]*Vi[1] + W1[r*3+1]*Vi[3] + W1[r*3+2]*Vi[4];
+                tv[r*3+2] = W1[r*3]*Vi[2] + W1[r*3+1]*Vi[4] + W1[r*3+2]*Vi[5];
+            }
+        }
 #pragma unroll
-            for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += t0*W2[cc*3] + t1*W2[cc*3+1] + t2*W2[cc*3+2];
+        for (int cc = 0; cc < 6; cc++) {
+            const double x0 = B.w_tx[(size_t)(s2)*TX_REC + cc*3], x1 = B.w_tx[(size_t)(s2)*TX_REC + cc*3 + 1], x2 = B.w_tx[(size_t)(s2)*TX_REC + cc*3 + 2];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[r*6 + cc] += tv[r*3]*x0 + tv[r*3+1]*x1 + tv[r*3+2]*x2;
         }
     }
-    // tails of this lane's entries o = sub, sub + 16, sub + 32 (< 36), independent of the sums: issued before the reduction
+    // tails of this lane's entries o = sub, 12 + sub, 24 + sub (sub < 12), independent of the sums: issued before the reduction
     double tail[3] = {0.0, 0.0, 0.0};
-    if (live) {
+    if (live && sub < 12) {
         const double *out = B.pairOut;
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-            const int o = sub + 16*t; if (o >= 36) break;
+            const int o = sub + 12*t;
             const int r = o/6, cc = o - 6*r;
             if (a == c) {
                 const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
-                tail[t] = range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
+                tail[t] = range_sum<8>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<8>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);     // (8 in flight: a keyframe of a large map has ~8 pairs each way; 24 cost the kernel a wave per SIMD)
                 if (r == cc && !multi) tail[t] += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
             } else {
                 const int pab = L.sb_pab[bc], pba = L.sb_pba[bc];
@@ -1389,24 +1400,26 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
             }
         }
     }
-    double *tile = lds + grp*36*17;
-#pragma unroll
-    for (int k = 0; k < 36; k++) tile[k*17 + sub] = acc[k];
-    __syncthreads();                                            // (one wave: an s_barrier of one wave)
-    if (!live) return;
+    double *tile = lds + grp*12*17;
     const size_t ldS = (size_t)W.ldS;
     const bool a_later = ia > ic;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        const int o = sub + 16*t; if (o >= 36) break;
-        const double *row = tile + o*17;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-        for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
-        const double v = tail[t] - ((s0 + s1) + (s2 + s3));
-        const int r = o/6, cc = o - 6*r;
-        if (a == c || !W.band || a_later) W.S[(size_t)(6*ia + r)*ldS + 6*ic + cc] = v;
-        if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r] = v;
+        for (int k = 0; k < 12; k++) tile[k*17 + sub] = acc[12*t + k];
+        __syncthreads();                                        // (one wave: an s_barrier of one wave)
+        if (live && sub < 12) {
+            const int o = sub + 12*t;
+            const double *row = tile + sub*17;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
+            const double v = tail[t] - ((s0 + s1) + (s2 + s3));
+            const int r = o/6, cc = o - 6*r;
+            if (a == c || !W.band || a_later) W.S[(size_t)(6*ia + r)*ldS + 6*ic + cc] = v;
+            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -1816,6 +1829,7 @@ struct Ctx {
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
     bool pose_only = false;                       // one keyframe, every landmark frozen in its host: the fused pose-only LM kernel applies
     double *S_alloc = nullptr; size_t S_count = 0;
+    int S_up = CH_NB;                               // band storage: columns stored right of the diagonal + 1
     double *S_xchg = nullptr; int xchg_wp = 0;      // multi-GPU, band storage: packed band rows for the exchange (k_band_pack)
     bool sep_cr = false;                  // separator system by cyclic reduction on the compact block pool (tsba_bandcr.h)
     int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Bpart = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr, *CRcontrib = nullptr, *CRfac = nullptr; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
@@ -2160,11 +2174,17 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         // diagonal factors are kept) -- 80 MB instead of 7.2 GB at 5000 keyframes, and what the ranks all-reduce
         const int use_lds_ = solve_lds_doubles(W.N)*sizeof(double) <= 160*1024 - 64;        // (as solve_lds_bytes)
         int bwmax = 0; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
-        const size_t LDB = (size_t)bwmax + 2*CH_NB - 1;
-        if (use_lds_ || LDB >= (size_t)W.N) { c->S_count = (size_t)(W.N + 1)*W.N; AL(c->S_alloc, c->S_count); W.S = c->S_alloc; W.ldS = W.N; W.band = 0; }
-        else { c->S_count = (size_t)W.N*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - CH_NB); W.ldS = (int)LDB - 1; W.band = 1; }
+        // band storage: row i holds the columns [i - Wb, i + up) (skewed view S(i, j) = base[i (LDB - 1) + j]).  The blocked Cholesky of
+        // tsba_chol.h writes 96-wide blocks on both sides of the diagonal (up = CH_NB, Wb = band + CH_NB - 1); the streaming / partitioned
+        // solvers read the band only (up = 6: the diagonal pose block is stored square) -- 72 instead of 251 columns per row at a band of
+        // 60, and the band is cleared before every Schur assembly (60 MB per LM trial at 5000 keyframes with the wide rows)
+        const bool stream_ok = bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !c->dbg.no_band_stream;
+        c->S_up = stream_ok ? 6 : CH_NB;
+        const size_t LDB = stream_ok ? (size_t)bwmax + 12 : (size_t)bwmax + 2*CH_NB - 1;
+        if (use_lds_ || (size_t)bwmax + 2*CH_NB - 1 >= (size_t)W.N) { c->S_count = (size_t)(W.N + 1)*W.N; AL(c->S_alloc, c->S_count); W.S = c->S_alloc; W.ldS = W.N; W.band = 0; }
+        else { c->S_count = (size_t)W.N*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - c->S_up); W.ldS = (int)LDB - 1; W.band = 1; }
         c->Lcol = nullptr; c->band_stream = 0; c->sep_cr = false;
-        if (W.band && bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !c->dbg.no_band_stream) {
+        if (W.band && stream_ok) {
             AL(c->Lcol, (size_t)p->n_kf*bwmax*6); c->band_stream = 1;
             // substructuring: P interiors on P workgroups + a separator system (again a band, 2 bw - 6 wide)
             // number of interiors: the interiors run in parallel (n_kf / P blocks each, ~3.5 us per block, 5 us once the border makes the
@@ -2687,9 +2707,9 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     if (S) {
         if (!W.band) CK(hipMemcpy(S, W.S, sizeof(double)*(size_t)W.N*W.N, hipMemcpyDeviceToHost));
         else { std::vector<double> hb(c->S_count); CK(hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost));
-            const long long N = W.N, LDB = W.ldS + 1, Wb = LDB - CH_NB;                  // band -> dense (entries outside the band are zero)
+            const long long N = W.N, LDB = W.ldS + 1, Wb = LDB - c->S_up;                // band -> dense (entries outside the band are zero)
             for (long long i = 0; i < N; i++) for (long long j = 0; j < N; j++)
-                S[i*N + j] = (j >= i - Wb && j <= i + CH_NB - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
+                S[i*N + j] = (j >= i - Wb && j <= i + c->S_up - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
     }
     if (g) CK(hipMemcpy(g, W.g, sizeof(double)*W.N, hipMemcpyDeviceToHost));
     if (dp) CK(hipMemcpy(dp, W.dp, sizeof(double)*W.N, hipMemcpyDeviceToHost));
@@ -2711,7 +2731,7 @@ int tsba_debug_reduced_band(void *ctx, double radius, int32_t *n_out, int32_t *b
     int rc = tsba_debug_reduced_system(ctx, radius, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
     Work &W = c->W;
     int nfree = 0; CK(hipMemcpy(&nfree, W.nfree, sizeof(int), hipMemcpyDeviceToHost));
-    const long long n = 6LL*nfree, LDB = W.ldS + 1, Wb = LDB - CH_NB;
+    const long long n = 6LL*nfree, LDB = W.ldS + 1, Wb = LDB - c->S_up;
     const int bw = std::max(6, c->lev[c->opt.levels[0]].bw_rows) + 5;              // rows below the diagonal that can be non-zero (block-aligned band)
     if (n_out) *n_out = (int32_t)n; if (bw_out) *bw_out = bw;
     if (ab) {
@@ -2837,9 +2857,9 @@ int tsba_debug_copy_S(void *ctx, double *out) {      // (6 n_kf + 1) x (6 n_kf):
     const Work &W = c->W; const long long N = W.N;
     if (!W.band) { if (hipMemcpy(out, W.S, sizeof(double)*(size_t)N*N, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE; }
     else { std::vector<double> hb(c->S_count); if (hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE;
-        const long long LDB = W.ldS + 1, Wb = LDB - CH_NB;
+        const long long LDB = W.ldS + 1, Wb = LDB - c->S_up;
         for (long long i = 0; i < N; i++) for (long long j = 0; j < N; j++)
-            out[i*N + j] = (j >= i - Wb && j <= i + CH_NB - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
+            out[i*N + j] = (j >= i - Wb && j <= i + c->S_up - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
     // row N = the rhs row: of the large-system solver if that ran, else unused (the LDS solver keeps it on chip)
     return hipMemcpy(out + (size_t)N*N, W.Sy, sizeof(double)*(size_t)N, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
 }
