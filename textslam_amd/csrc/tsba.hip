@@ -1309,8 +1309,11 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
 // finishes up to three entries of the block (tail: pose-pair products, damping) and stores them.  Same sums, same order within a lane;
 // the order ACROSS lanes differs from k_schur_t<1> (16 partial sums instead of 64), which the tests' tolerances cover.
 #ifndef SCHURQ_U
-#define SCHURQ_U 2                          // list entries per lane in flight (k_schur_quad)
+#define SCHURQ_U 1                          // list entries per lane in flight (k_schur_quad): 1 -> 128 registers, four waves per SIMD (101 us with 2 / three waves, 97 us with 1 at 5000 keyframes; 113 us with 4 / two waves)
 #endif
+// TEXT = false: a level without text planes (the reference's GlobalBA) -- the plane part (3x3 inverse, 18-value records) sets the kernel's
+// register count (214: two waves per SIMD); without it three fit.
+template <bool TEXT>
 __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi) {
     LmState *st = W.st;
     if (st->done) return;
@@ -1354,7 +1357,7 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
             }
         }
     }
-    if (live) for (int q = L.sb_tx_off[bc] + sub; q < L.sb_tx_off[bc+1]; q += 16) {
+    if (TEXT && live) for (int q = L.sb_tx_off[bc] + sub; q < L.sb_tx_off[bc+1]; q += 16) {
         const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
         double Vd[6], Vi[6];
 #pragma unroll
@@ -2364,7 +2367,8 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
 }
 static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
     if (c->n_kf > 126 && !c->dbg.no_schur_quad) {               // large maps: four S blocks per wave, then one wave per pose for the reduced gradient
-        if (D.n_sb > 0) hipLaunchKernelGGL(k_schur_quad, dim3((D.n_sb + 3)/4), dim3(64), 0, c->stream, c->W, D, multi);
+        if (D.n_sb > 0) { if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3((D.n_sb + 3)/4), dim3(64), 0, c->stream, c->W, D, multi);
+            else hipLaunchKernelGGL(k_schur_quad<false>, dim3((D.n_sb + 3)/4), dim3(64), 0, c->stream, c->W, D, multi); }
         hipLaunchKernelGGL(k_schur_t<1>, dim3(c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, D.n_sb);
     } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0);
     else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0);
