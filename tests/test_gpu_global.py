@@ -50,14 +50,16 @@ def _same_trajectory(rep1, rep2, G1, G2, atol=1e-9):
     np.testing.assert_allclose(G1.rho, G2.rho, rtol=0, atol=atol)
 
 
-@pytest.mark.parametrize("n_kf,band,parts", [(600, 6, 8), (900, 9, 17), (1100, 12, 11), (1500, 10, 27)])
-def test_cyclic_reduction_separator_solver(gpu, n_kf, band, parts):
-    """tsba_bandcr.h (k_cr_pivot / k_cr_update / k_cr_back) forced at sizes where the cost model would pick the sequential
-    separator solve: separators of 6 .. 12 pose blocks, 7 .. 26 of them (odd and even counts, not powers of two)."""
+@pytest.mark.parametrize("n_kf,band,parts,cr", [(600, 6, 8, 2), (900, 9, 17, 2), (1100, 12, 11, 2), (1500, 10, 27, 2), (1300, 7, 40, 2), (1500, 13, 9, 2), (900, 9, 17, 3)])
+def test_cyclic_reduction_separator_solver(gpu, n_kf, band, parts, cr):
+    """The cyclic-reduction separator solver forced at sizes where the cost model would pick the sequential separator solve: separators of
+    6 .. 12 pose blocks, 7 .. 39 of them (odd and even counts, not powers of two).  cr = 2: one launch per level (tsba_bandcre.h:
+    k_cre_elim / k_cre_back, several workgroups per pivot at the lower levels); cr = 3: the pivot / update / back kernels of round 1
+    (tsba_bandcr.h), kept for A/B runs."""
     P = synth.config_global(n_kf=n_kf, n_pt=40*n_kf, band=band)
     o = abi.options_global(); o.its[0] = 5
     try:
-        gpu.debug_set(band_parts=parts, sep_solver=2)
+        gpu.debug_set(band_parts=parts, sep_solver=cr)
         gpu.upload(P, o)
         info = gpu.solver_info()
         assert info["band_stream"] == 1 and info["sep_cr"] == 1 and info["interiors"] == parts, info

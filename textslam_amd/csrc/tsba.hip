@@ -526,13 +526,14 @@ __device__ __forceinline__ void wave_sum_groups16_mw(const double *acc, double *
 #define LIN_T (64*(8/LIN_TPL))           // 64 features per text workgroup
 #define LIN_NWV (LIN_T/64)
 #define MID_U 4                          // slot records of a point that k_mid keeps in flight per round trip
-template <int MODE, int PPW = 1>
-__global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int spec) {
+// TEXT = false: levels without text planes (the reference's GlobalBA): the scene path alone needs far fewer registers than the text path.
+template <int MODE, int PPW = 1, bool TEXT = true>
+__global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, LevelDev L, int spec) {
     // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
     const LmState *st = W.st;
     constexpr int NWV = LIN_T/64, TPL = LIN_TPL, LPF = 8/LIN_TPL;   // waves per workgroup; taps per lane; lanes per feature
     __shared__ double lds[NWV*28*65 + NWV*64];
-    __shared__ unsigned s_px[TPL*LIN_T];                    // the text path's pixel quads (four bytes): indexed by tap at run time (not registers)
+    __shared__ unsigned s_px[TEXT ? TPL*LIN_T : 1];          // the text path's pixel quads (four bytes): indexed by tap at run time (not registers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *reg = lds + wave*28*65, *xw = lds + NWV*28*65;
     // static indices of this workgroup first: in flight together with the LM state
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
     const int bq = blockIdx.x, pr = (NWV*bq + wave)*PPW + (PPW == 1 ? 0 : lane/LPP), prc = min(pr, max(L.n_pair - 1, 0));
     int pi = 0, ph = 0, pbeg = 0, pend = 0, tgpp = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
     if (bq < nb_sc) { pi = L.pair_i[prc]; ph = L.pair_h[prc]; pbeg = L.pair_sc_off[prc]; pend = pr < L.n_pair ? L.pair_sc_off[prc+1] : pbeg; }
-    else { ra = ((const int4 *)L.tg_rec)[2*(bq - nb_sc)]; rb = ((const int4 *)L.tg_rec)[2*(bq - nb_sc) + 1]; tgpp = L.tg_ppos[bq - nb_sc]; }   // one static record per group
+    else if (TEXT) { ra = ((const int4 *)L.tg_rec)[2*(bq - nb_sc)]; rb = ((const int4 *)L.tg_rec)[2*(bq - nb_sc) + 1]; tgpp = L.tg_ppos[bq - nb_sc]; }   // one static record per group
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(LIN_T, 2) void k_linearize(Work W, LevelDev L, int 
                 }
             }
         }
-    } else {
+    } else if constexpr (TEXT) {
         // ---------------- photometric blocks of one (KF, text) observation: thread = (feature tid / LPF, tap group tid % LPF)
         const int g = b - nb_sc;
         const int tb = ra.x, i = ra.y, j = ra.z, h = ra.w, slot = rb.x, f0 = rb.y, f1 = rb.z, fg = rb.w;
@@ -2344,7 +2345,8 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
     if (D.n_pair + D.n_tg > 0) {
-        if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
+        if (lin_small_pairs(c, D) && D.n_tg == 0) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4, false>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV)), dim3(LIN_T), 0, c->stream, W, D, spec);
+        else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
         else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
     }
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
@@ -2763,7 +2765,8 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));   // k_linearize never clears need_lin itself
     CK(hipEventRecord(c->ev0, c->stream));
     for (int k = 0; k < n; k++) {
-        if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+        if (lin_small_pairs(c, D) && D.n_tg == 0) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4, false>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV)), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+        else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
         else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
     }
     CK(hipEventRecord(c->ev1, c->stream));
