@@ -295,30 +295,37 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
 }
 
 // x_i = L^-T (z_i - X_a^T x_a - X_c^T x_c) -> Ws.Sy
+// Every address is known from the launch arguments (the pool is laid out for the worst case mmax): all loads are issued before the solver
+// state and the number of separators are looked at -- one global round trip instead of two (-1.4 us per level).
 __global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, int Pmax, int h, const double *fac) {
     const LmState *st = W.st;
-    if (st->done || st->step_fail) return;
-    const int m = cr_nsep(W, bw, Pmax), s = bw, B = s/6, mmax = Pmax - 1, tid = threadIdx.x, lane = tid & 63;
+    const int s = bw, B = s/6, mmax = Pmax - 1, tid = threadIdx.x, lane = tid & 63;
     const int i = (2*(int)blockIdx.x + 1)*h;
-    if (i >= m) return;
-    const int a = i - h, c = i + h < m ? i + h : -1;
+    if (i >= mmax) return;
+    const int a = i - h, cmx = i + h < mmax ? i + h : -1;        // (c exists if cmx < m: decided below)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int xbase = rowoff(s);
     double *A = smem, *LD = A + rowoff(s + 1) + 16, *part = LD + SOLVE_LD*B, *xs = part + 4*128;
     const double *S = Ws.S; double *x = Ws.Sy;
     const double *rec = fac + (size_t)i*cre_rec_doubles(s);
-    const double *Xa = cr_blk(S, s, mmax, i, a), *Xc = c >= 0 ? cr_blk(S, s, mmax, c, i) : nullptr;
-    const int nx = c >= 0 ? 2*s : s;                             // rows of [X_a ; X_c]; a thread: column `col`, rows grp, grp + 4, ...
-    const int col = tid & 127, grp = tid >> 7;
-    for (int k = tid; k < nx; k += CRE_BT) xs[k] = k < s ? x[(size_t)a*s + k] : x[(size_t)c*s + k - s];
+    const double *Xa = cr_blk(S, s, mmax, i, a), *Xc = cmx >= 0 ? cr_blk(S, s, mmax, cmx, i) : Xa;
+    const int col = tid & 127, grp = tid >> 7;                   // a thread: column `col` of [X_a ; X_c], rows grp, grp + 4, ...
+    const int done = st->done, sfail = st->step_fail, nb = *W.nfree;
+    const double xin = tid < s ? x[(size_t)a*s + tid] : (tid < 2*s && cmx >= 0 ? x[(size_t)cmx*s + tid - s] : 0.0);      // (2 s <= 156 < CRE_BT)
     const double zc = (grp == 0 && col < s) ? rec[xbase + SOLVE_LD*B + col] : 0.0;
     auto xrow = [&](int r) { return r < s ? Xa + (size_t)r*s : Xc + (size_t)(r - s)*s; };
     constexpr int UB = 10;
+    const int nxm = cmx >= 0 ? 2*s : s;
     double xv[UB];
 #pragma unroll
-    for (int u = 0; u < UB; u++) { const int r = grp + 4*u; xv[u] = (col < s && r < nx) ? xrow(r)[col] : 0.0; }
+    for (int u = 0; u < UB; u++) { const int r = grp + 4*u; xv[u] = (col < s && r < nxm) ? xrow(r)[col] : 0.0; }
     cre_batched<CRE_BT, 8>(xbase, tid, [&](int e) { return rec[e]; }, [&](int e, double v) { A[e] = v; });
     for (int k = tid; k < SOLVE_LD*B; k += CRE_BT) LD[k] = rec[xbase + k];
+    if (done || sfail) return;
+    const int m = nb > 0 ? bandp_part(nb, s/6, Pmax, 0).P - 1 : 0;
+    if (i >= m) return;
+    const int nx = (cmx >= 0 && cmx < m) ? 2*s : s;              // rows of [X_a ; X_c]
+    if (tid < 2*s) xs[tid] = xin;
     __syncthreads();
     double acc = 0.0;
 #pragma unroll
@@ -338,3 +345,8 @@ __global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, in
     wave_lds_fence();
     for (int k = lane; k < s; k += 64) x[(size_t)i*s + k] = A[xbase + k];
 }
+
+// (All back-substitution levels in ONE launch -- a workgroup per separator, waiting on its neighbours' flags with agent-scope release /
+// acquire -- was built and measured in round 2: 91 us against 7 x 11.2 us for the launches per level.  A hop of the dependency tree
+// through flags costs more than a kernel boundary: the release writes back the XCD's L2, the acquire invalidates it, and the poll
+// adds its own round trips.  tools/experiments/cre_back_all.h)
