@@ -19,7 +19,9 @@
 #pragma once
 
 #define CRE_T 768
-#define CRE_PW 4                            // panel waves: up to s - 6 + 2 s + 1 rows below a diagonal block (229 at s = 78) in ONE round
+#ifndef CRE_PW
+#define CRE_PW 3                            // panel waves (58 rows each per round; up to s - 6 + 2 s + 1 = 229 rows below a diagonal block at s = 78). Measured at s = 60 (175 rows in the first step), 5000 keyframes, ms per solve: 2 waves 17.04 - 17.3, 3 waves 17.01, 4 waves (always one round) 17.26
+#endif
 #define CRE_BT 512
 __host__ __device__ __forceinline__ int cre_stride(int s) { return (s & 3) == 2 ? s : s + 2; }      // doubles; = 2 mod 4: b128 rows of 16 lanes hit 64 different banks
 __host__ __device__ __forceinline__ size_t cre_rec_doubles(int s) { return ((size_t)rowoff(s) + (size_t)SOLVE_LD*(s/6) + s + 1) & ~(size_t)1; }     // packed factor | LD table | z
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
                 st6(A + ir*sst + j0, av);
             };
             if (lane >= 6) {
-                if (i0 <= n) solve_row(i0, av);                  // (one round: at most 3 s - 5 = 229 rows below the block, 4 x 58 lanes)
+                if (i0 <= n) solve_row(i0, av);                  // (further rounds when more rows lie below the block than CRE_PW x 58 lanes hold)
+                for (int ir = i0 + CRE_PW*SOLVE_PROWS; ir <= n; ir += CRE_PW*SOLVE_PROWS) { load_row(ir, av); solve_row(ir, av); }
             }
             if (wave == 1 && jb == B - 1) {                      // inverse factor of the last block (the others: last update wave)
                 double mi[15];
