@@ -227,7 +227,8 @@ int  tsba_debug_row_of_kf(void *ctx, int32_t *rowblk);
  * [4] separator system by cyclic reduction  [5] band rows  [6] four (target, host) pairs per wave in the linearisation
  * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] rank
  * [11..14] this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots
- * [15] rows of S in reverse Cuthill-McKee order of the keyframes (wide envelopes: loop closures) */
+ * [15] rows of S in reverse Cuthill-McKee order of the keyframes (wide envelopes: loop closures)
+ * [16] (n >= 17) ring-shaped map solved with ghost rows for the first separator (one loop closure between the last and the first keyframes) */
 int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
 
 /* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
@@ -250,7 +251,8 @@ typedef struct tsba_debug_options {
     int32_t verbose;           /* 1: host-side timing of upload / plan construction on stderr */
     int32_t no_kf_reorder;     /* 1: keep the rows of S in keyframe order even when the envelope is wide (loop closures) */
     int32_t no_schur_quad;     /* 1: large maps assemble S with one wave per 6x6 block (k_schur_t<1>) instead of four blocks per wave */
-    int32_t reserved[8];
+    int32_t no_ring;           /* 1: a ring-shaped map (one loop closure between the last and the first keyframes) through the reordering path instead of the ghost-row partition */
+    int32_t reserved[7];
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

@@ -182,21 +182,31 @@ def test_c5_full_size_global_ba_with_text(gpu):
 
 
 # ------------------------------------------------------------------------------------------------ loop closures
-def test_loop_closure_map_parity_with_keyframe_reordering(gpu, oracle_lib):
+@pytest.mark.parametrize("mode", ["ring", "reorder"])
+def test_loop_closure_map_parity(gpu, oracle_lib, mode):
     """GlobalBA runs right after a loop closure (loopClosing.cc:589): the last keyframes share landmarks with the first, the
-    co-visibility graph is a RING, and in keyframe order the envelope of S is the whole matrix.  The plan then orders the rows of S by
-    reverse Cuthill-McKee (band = twice the local one).  120-keyframe ring against the oracle (which knows nothing of orderings)."""
+    co-visibility graph is a RING, and in keyframe order the envelope of S is the whole matrix.  Two ways through it: the ghost-row
+    partition (keyframe order, the closure blocks behind the last pose, band of the open chain) and the reverse Cuthill-McKee order of
+    the rows of S (band = twice the local one; what a closure that is not end-to-start takes).  120-keyframe ring against the oracle
+    (which knows nothing of either)."""
     P = synth.config_global(n_kf=120, n_pt=4000, band=8, loop=True)
     o = abi.options_global(); o.its[0] = 8
-    gpu.upload(P, o)
-    info = gpu.solver_info()
-    assert info["kf_reordered"] == 1 and info["band_storage"] == 1 and info["band_rows"] <= 6*3*8, info
-    G, R = P.copy(), P.copy()
-    rg = gpu.GlobalBA(G, options=o); ro = oracle_lib.solve(R, o)
-    assert rg["iters"] == ro["iters"] and rg["accepted"] == ro["accepted"] and rg["termination"] == ro["termination"]
-    np.testing.assert_allclose(rg["cost1"], ro["cost1"], rtol=1e-9)
-    np.testing.assert_allclose(G.pose, R.pose, rtol=0, atol=1e-8)
-    np.testing.assert_allclose(G.rho, R.rho, rtol=0, atol=1e-8)
+    try:
+        gpu.debug_set(no_ring=1 if mode == "reorder" else 0)
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        if mode == "ring":
+            assert info["ring"] == 1 and info["kf_reordered"] == 0 and info["band_rows"] <= 6*(8 + 3) and info["interiors"] == 4, info
+        else:
+            assert info["ring"] == 0 and info["kf_reordered"] == 1 and info["band_storage"] == 1 and info["band_rows"] <= 6*3*8, info
+        G, R = P.copy(), P.copy()
+        rg = gpu.GlobalBA(G, options=o); ro = oracle_lib.solve(R, o)
+        assert rg["iters"] == ro["iters"] and rg["accepted"] == ro["accepted"] and rg["termination"] == ro["termination"]
+        np.testing.assert_allclose(rg["cost1"], ro["cost1"], rtol=1e-9)
+        np.testing.assert_allclose(G.pose, R.pose, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(G.rho, R.rho, rtol=0, atol=1e-8)
+    finally:
+        gpu.debug_set()
 
 
 @pytest.mark.parametrize("n_kf,band", [(600, 8), (1500, 8)])
@@ -207,6 +217,7 @@ def test_loop_closure_map_band_solvers(gpu, n_kf, band):
     P = synth.config_global(n_kf=n_kf, n_pt=30*n_kf, band=band, loop=True)
     o = abi.options_global(); o.its[0] = 5
     try:
+        gpu.debug_set(no_ring=1)                                  # (the ghost-row partition of ring maps has its own test below)
         gpu.upload(P, o)
         info = gpu.solver_info()
         assert info["kf_reordered"] == 1 and info["band_stream"] == 1 and info["band_rows"] <= 6*3*band, info
@@ -221,6 +232,32 @@ def test_loop_closure_map_band_solvers(gpu, n_kf, band):
             assert info["kf_reordered"] == 0 and info["band_rows"] > 6*(n_kf - 40), info
             G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
             _same_trajectory(rep1, rep2, G1, G2)
+    finally:
+        gpu.debug_set()
+
+
+@pytest.mark.parametrize("n_kf,band,parts", [(600, 8, 0), (1500, 8, 0), (1500, 8, 8), (2400, 11, 0)])
+def test_loop_closure_ring_partition(gpu, n_kf, band, parts):
+    """One loop closure between the last and the first keyframes: the plan keeps the keyframe order, the closure blocks go to ghost rows behind
+    the last pose, the partition starts and ends with a copy of the first separator and the cyclic reduction merges the two at its root
+    (tsba_plan.h, tsba_bandp.h, tsba_bandcre.h) -- the band of the open chain instead of twice that under reverse Cuthill-McKee.
+    Against the reordering path on the same map: same LM trajectory, same poses."""
+    P = synth.config_global(n_kf=n_kf, n_pt=30*n_kf, band=band, loop=True)
+    o = abi.options_global(); o.its[0] = 6
+    try:
+        gpu.debug_set(band_parts=parts)
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        assert info["ring"] == 1 and info["kf_reordered"] == 0 and info["sep_cr"] == 1 and info["band_rows"] <= 6*(band + 3), info
+        assert info["interiors"] & (info["interiors"] - 1) == 0 and (parts == 0 or info["interiors"] == parts), info
+        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+        assert rep1["accepted"][0] >= 3 and rep1["termination"][0] != 5 and rep1["cost1"][0] < rep1["cost0"][0]
+        gpu.debug_set(no_ring=1)
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        assert info["ring"] == 0 and info["kf_reordered"] == 1, info
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        _same_trajectory(rep1, rep2, G1, G2)
     finally:
         gpu.debug_set()
 

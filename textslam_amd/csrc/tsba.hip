@@ -90,6 +90,8 @@ struct Work {                // device work buffers (sized for the largest level
     long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
     double *LDbuf;                      // diagonal of the inverse diagonal factors (large-system Cholesky)
     int ldS, band;                      // S(i,j) = S[i*ldS + j]; band: S holds only the band of the reduced camera matrix (large systems)
+    int ring;                           // 1: ring-shaped co-visibility (one loop closure, tsba_plan.h): the closure blocks -- first against last poses -- live
+                                        // in ghost rows behind the last free pose (row = nfree + row of the early pose)
     double *Sy;                         // right-hand-side row of the large-system solver (row n of the small one lives in LDS)
     unsigned long long *hprog;          // pinned host word (seq << 32 | it << 1 | done): lets the host stop enqueuing a converged pass
     unsigned int pass_seq;
@@ -1247,9 +1249,11 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             const size_t ldS = (size_t)W.ldS;                // (sb_a <= sb_b: the first store is the upper triangle, which band storage does not hold)
             // band storage holds the lower triangle: the block goes to the row of the pose that comes LATER in S (with a plan order
             // that need not be the larger keyframe index)
-            const bool a_later = ia > ic;
-            if (a == c || !W.band || a_later) W.S[(size_t)(6*ia + r)*ldS + 6*ic + cc] = v;
-            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r] = v;
+            int ja = ia, jc = ic;
+            if (W.ring) { const int nf = *W.nfree; if (ia - ic > nf/2) jc += nf; else if (ic - ia > nf/2) ja += nf; }     // closure block: the early pose's ghost row
+            const bool a_later = ja > jc;
+            if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
+            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
         }
     } else {
         const int a = b - L.n_sb;
@@ -1406,7 +1410,9 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
     }
     double *tile = lds + grp*12*17;
     const size_t ldS = (size_t)W.ldS;
-    const bool a_later = ia > ic;
+    int ja = ia, jc = ic;
+    if (W.ring) { const int nf = *W.nfree; if (ia - ic > nf/2) jc += nf; else if (ic - ia > nf/2) ja += nf; }     // closure block: the early pose's ghost row
+    const bool a_later = ja > jc;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
 #pragma unroll
@@ -1420,8 +1426,8 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
             for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
             const double v = tail[t] - ((s0 + s1) + (s2 + s3));
             const int r = o/6, cc = o - 6*r;
-            if (a == c || !W.band || a_later) W.S[(size_t)(6*ia + r)*ldS + 6*ic + cc] = v;
-            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r] = v;
+            if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
+            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
         }
         __syncthreads();
     }
@@ -2081,7 +2087,10 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         for (int ps = 0; ps < o->n_passes; ps++) { const int l = o->levels[ps]; if (seen[l]) continue; seen[l] = 1;
             HostPlan *H = &c->hplan[l];
             const bool reorder = !c->dbg.no_kf_reorder;
-            planners[l] = std::thread([p, o, l, H, tdbg, reorder]() { build_plan(p, o, l, *H, tdbg, reorder); }); }
+            // ring maps (one loop closure): a single-level, single-GPU solve through the partitioned solver with the cyclic-reduction separator tree
+            int n_lev = 0; { std::vector<char> sn(p->n_levels, 0); for (int q = 0; q < o->n_passes; q++) if (!sn[o->levels[q]]) { sn[o->levels[q]] = 1; n_lev++; } }
+            const int ring_max = (n_lev == 1 && !is_multi(c) && !c->dbg.no_ring && !c->dbg.no_band_stream && c->dbg.sep_solver != 1 && c->dbg.sep_solver != 3 && c->dbg.band_parts != 1) ? CR_SMAX/6 : 0;
+            planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
 #define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
@@ -2105,7 +2114,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     UP(W.tobs_kf, p->tobs_kf, p->n_tobs); UP(W.tobs_text, p->tobs_text, p->n_tobs); UP(W.tobs_fgood_off, p->tobs_fgood_off, (size_t)p->n_tobs + 1);
     AL(W.musig, 2*(size_t)p->n_tobs);
     AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
-    AL(W.fidx, p->n_kf); AL(W.nfree, 1); AL(W.dbg, 64); AL(W.LDbuf, 32*(size_t)p->n_kf);
+    AL(W.fidx, p->n_kf); AL(W.nfree, 1); AL(W.dbg, 64); AL(W.LDbuf, 32*((size_t)p->n_kf + BAND_BW_MAX/6 + 1));     // (+ the ghost blocks of a ring map)
     // ---- per-level plans
     size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1;
     for (int ps = 0; ps < o->n_passes; ps++) {
@@ -2183,13 +2192,16 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         // solvers read the band only (up = 6: the diagonal pose block is stored square) -- 72 instead of 251 columns per row at a band of
         // 60, and the band is cleared before every Schur assembly (60 MB per LM trial at 5000 keyframes with the wide rows)
         const bool stream_ok = bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !c->dbg.no_band_stream;
+        int ring = 0; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l] && c->hplan[l].ring) ring = 1;     // (a ring plan is only built for single-level solves)
+        const size_t nrow = (size_t)W.N + (ring ? bwmax : 0);                                                 // + the ghost rows of the first separator
         c->S_up = stream_ok ? 6 : CH_NB;
         const size_t LDB = stream_ok ? (size_t)bwmax + 12 : (size_t)bwmax + 2*CH_NB - 1;
         if (use_lds_ || (size_t)bwmax + 2*CH_NB - 1 >= (size_t)W.N) { c->S_count = (size_t)(W.N + 1)*W.N; AL(c->S_alloc, c->S_count); W.S = c->S_alloc; W.ldS = W.N; W.band = 0; }
-        else { c->S_count = (size_t)W.N*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - c->S_up); W.ldS = (int)LDB - 1; W.band = 1; }
+        else { c->S_count = nrow*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - c->S_up); W.ldS = (int)LDB - 1; W.band = 1; }
+        W.ring = 0;
         c->Lcol = nullptr; c->band_stream = 0; c->sep_cr = false;
         if (W.band && stream_ok) {
-            AL(c->Lcol, (size_t)p->n_kf*bwmax*6); c->band_stream = 1;
+            AL(c->Lcol, ((size_t)p->n_kf + bwmax/6 + 1)*bwmax*6); c->band_stream = 1;
             // substructuring: P interiors on P workgroups + a separator system (again a band, 2 bw - 6 wide)
             // number of interiors: the interiors run in parallel (n_kf / P blocks each, ~3.5 us per block, 5 us once the border makes the
             // panel waves take two rounds), the separator system is sequential again ((P - 1) B blocks at ~4.5 us, 5.5 us when its band
@@ -2218,23 +2230,31 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             if (c->dbg.sep_solver >= 2 && bwmax <= CR_SMAX) want_cr = true;
             if (c->dbg.band_parts > 0) P = c->dbg.band_parts;
             P = std::max(1, std::min(P, BANDP_MAXP));
-            while (P > 1 && (p->n_kf - (P - 1)*Bq)/P < ((c->dbg.band_parts > 0 || want_cr) ? 2*Bq + 2 : 4*Bq + 4)) P--;     // (2 B + 2: the least the kernels take; the sequential separator solve pays only for interiors of a few bands)
+            if (ring) {                       // ring: a power of two interiors (the separator tree ends in separator 0 and its ghost), cyclic reduction only
+                const int cap = c->dbg.band_parts > 0 ? c->dbg.band_parts : 128;
+                int Pr = 4; while (2*Pr <= cap && (p->n_kf + Bq - (2*Pr + 1)*Bq)/(2*Pr) >= 2*Bq + 8) Pr *= 2;
+                P = Pr; want_cr = true;
+            }
+            while (!ring && P > 1 && (p->n_kf - (P - 1)*Bq)/P < ((c->dbg.band_parts > 0 || want_cr) ? 2*Bq + 2 : 4*Bq + 4)) P--;     // (2 B + 2: the least the kernels take; the sequential separator solve pays only for interiors of a few bands)
             if (P > 1 && bandp_chunk_blocks(bwmax) > 0 && 2*bwmax - 6 <= BAND_BW_MAX && band_chunk_blocks(2*bwmax - 6) > 0) {
-                const int nsep = (P - 1)*bwmax, bws = 2*bwmax - 6;
+                const int nsepb = ring ? P + 1 : P - 1;                         // separators (ring: the last one is the ghost of the first)
+                const int nsep = nsepb*bwmax, bws = 2*bwmax - 6;
                 c->nsep_ld = nsep;
-                AL(c->Lb, (size_t)p->n_kf*bwmax*6); AL(c->Tbuf, (size_t)P*((size_t)4*bwmax*bwmax + 2*bwmax));
+                AL(c->Lb, ((size_t)p->n_kf + bwmax/6 + 1)*bwmax*6); AL(c->Tbuf, (size_t)P*((size_t)4*bwmax*bwmax + 2*bwmax));
                 AL(c->Bpart, (size_t)P*BANDP_NS*((size_t)bwmax*bwmax + bwmax));
                 c->sep_cr = want_cr && P >= 4;
-                if (c->sep_cr) { AL(c->Ssep, cr_pool_blocks(P - 1)*(size_t)bwmax*bwmax); AL(c->CRcontrib, (size_t)(P - 1)*cre_contrib_doubles(bwmax)); AL(c->CRfac, (size_t)(P - 1)*cre_rec_doubles(bwmax)); }
+                if (c->sep_cr) { AL(c->Ssep, cr_pool_blocks(nsepb)*(size_t)bwmax*bwmax); AL(c->CRcontrib, (size_t)nsepb*cre_contrib_doubles(bwmax)); AL(c->CRfac, (size_t)nsepb*cre_rec_doubles(bwmax)); }
                 else AL(c->Ssep, (size_t)nsep*nsep + nsep);
                 AL(c->Lcol_sep, (size_t)(nsep/6 + 1)*bws*6);
                 Work &Ws = c->Wsep; memset(&Ws, 0, sizeof(Ws));
                 Ws.N = nsep; Ws.n_kf = 0; Ws.S = c->Ssep; Ws.ldS = nsep; Ws.band = 1; Ws.st = nullptr;       // (st is set at launch: W.st is allocated below)
                 AL(Ws.Sy, nsep); AL(Ws.g, nsep); AL(Ws.dp, nsep); AL(Ws.LDbuf, 32*(size_t)(nsep/6 + 1)); AL(Ws.nfree, 1); AL(Ws.fidx, 1);
                 c->band_parts = P;
+                W.ring = (ring && c->sep_cr) ? 1 : 0;
             } else c->band_parts = 1;
         }
-        AL(W.Sy, W.N);
+        if (ring && !W.ring) { set_err(c, "ring-shaped map: the partitioned band solver is not available for this plan"); return TSBA_ERR_STATE; }
+        AL(W.Sy, W.N + BAND_BW_MAX);                            // (+ the ghost rows of a ring map)
         c->S_xchg = nullptr; c->xchg_wp = 0;
         if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, (size_t)W.N*c->xchg_wp); }
     }
@@ -2412,17 +2432,17 @@ static void launch_solve(Ctx *c) {
         hipLaunchKernelGGL(k_bandp_factor, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
         hipMemsetAsync(c->Bpart, 0, sizeof(double)*(size_t)P*BANDP_NS*((size_t)bwp*bwp + bwp), c->stream);        // (slices of short interiors stay empty)
         hipLaunchKernelGGL(k_bandp_border, dim3(P, BANDP_NS), dim3(256), (int)((2*(size_t)BANDP_JC*bwp*6 + 6*BANDP_JC)*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Lb, c->Bpart);
-        hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
+        hipLaunchKernelGGL(k_bandp_sep, dim3(W.ring ? P + 1 : P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
         if (c->sep_cr) {                  // separator system by block cyclic reduction (tsba_bandcr.h): log2(P - 1) levels
-            const int mmax = P - 1;
+            const int mmax = cr_mmax(W.ring, P), mlev = W.ring ? mmax - 1 : mmax;      // (ring: blocks 0 and mmax - 1 are merged at the root, no level for the ghost)
             const int lp = (int)(cr_pivot_lds_doubles(bwp)*sizeof(double)), lu = (int)(cr_update_lds_doubles(bwp)*sizeof(double)), lb = (int)(cr_back_lds_doubles(bwp)*sizeof(double));
             int htop = 1;
             if (c->dbg.sep_solver != 3) {      // one launch per level (tsba_bandcre.h); 3: the pivot / update / back kernels of tsba_bandcr.h
                 const int le = (int)(cre_elim_lds_doubles(bwp)*sizeof(double)), lbk = (int)(cre_back_lds_doubles(bwp)*sizeof(double));
-                for (int h = 1; h < mmax; h <<= 1) {
+                for (int h = 1; h < mlev; h <<= 1) {
                     const int npiv = (mmax + 2*h - 1)/(2*h), K = std::max(1, std::min(4, 224/npiv));     // workgroups per pivot (they share its product and stores)
                     hipLaunchKernelGGL(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, c->CRcontrib, c->CRfac); htop = h; }
-                hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, 1, 1, c->CRcontrib, c->CRfac);
+                hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, W.ring ? 2 : 1, 1, c->CRcontrib, c->CRfac);
                 for (int h = htop; h >= 1; h >>= 1) hipLaunchKernelGGL(k_cre_back, dim3((mmax + 2*h - 1)/(2*h)), dim3(CRE_BT), lbk, c->stream, W, Ws, bwp, P, h, (const double *)c->CRfac);
             } else {
             for (int h = 1; h < mmax; h <<= 1) {
@@ -2814,6 +2834,7 @@ int tsba_debug_solver_info(void *ctx, int32_t *out, int n) {
     out[6] = lin_small_pairs(c, c->lev[c->opt.levels[0]]) ? 1 : 0; out[7] = c->pose_only ? 1 : 0; out[8] = c->n_kf > 126 ? 1 : 0;
     out[9] = c->world; out[10] = c->rank;
     { const LevelDev &D0 = c->lev[c->opt.levels[0]]; out[11] = D0.n_pair; out[12] = D0.n_sb; out[13] = D0.n_sc; out[14] = D0.n_pslot; out[15] = D0.kf_order ? 1 : 0; }
+    if (n >= 17) out[16] = c->W.ring;
     return TSBA_OK;
 }
 // row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating); with a

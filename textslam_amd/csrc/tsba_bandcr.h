@@ -19,7 +19,9 @@
 static size_t cr_pivot_lds_doubles(int s) { return (size_t)s*(s + 1) + (size_t)s*(2*s + 1) + s; }
 static size_t cr_back_lds_doubles(int s) { return 3*(size_t)s*(s + 1) + 5*(size_t)s; }
 
-__device__ __forceinline__ int cr_nsep(const Work &W, int bw, int Pmax) { const int nb = *W.nfree; return nb > 0 ? bandp_part(nb, bw/6, Pmax, 0).P - 1 : 0; }
+__device__ __forceinline__ int cr_nsep(const Work &W, int bw, int Pmax) {      // separators of the system (ring: P + 1, the last one the ghost of the first)
+    const int nb = bandp_nb(W, bw/6); if (nb <= 0) return 0;
+    const int P = bandp_part(nb, bw/6, Pmax, 0, W.ring).P; return W.ring ? P + 1 : P - 1; }
 
 // n elements through f(index) -> value and st(index, value), 16 per thread in flight (a plain copy loop waits for every load before it
 // issues the next: ~0.6 us each)

@@ -47,10 +47,10 @@ __device__ __forceinline__ void cre_batched(int n, int tid, F f, G st) {
 __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int Pmax, int h, int root, int K, double *contrib, double *fac) {
     LmState *st = W.st;
     if (st->done || st->step_fail) return;
-    const int m = cr_nsep(W, bw, Pmax), s = bw, B = s/6, mmax = Pmax - 1;
+    const int m = cr_nsep(W, bw, Pmax), s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax);
     int i, a, c;
     if (root) { if (blockIdx.x > 0 || m <= 0) return; i = 0; a = -1; c = -1; }
-    else { i = (2*((int)blockIdx.x/K) + 1)*h; if (i >= m) return; a = i - h; c = i + h < m ? i + h : -1; }
+    else { i = (2*((int)blockIdx.x/K) + 1)*h; if (i >= m || (W.ring && i == m - 1)) return; a = i - h; c = i + h < m ? i + h : -1; }     // (ring: block m - 1 is the ghost of block 0, never a pivot)
     const int part = root ? 0 : (int)blockIdx.x % K;
     const int H = root ? (1 << 30) : h;                          // pending updates come from the pivots i -+ h', h' < H
     const int na = a >= 0 ? s : 0, nc = c >= 0 ? s : 0, ne = na + nc + 1, n = s + ne - 1;     // rows 0 .. n, row n = g_i
@@ -76,23 +76,38 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
     // ---- load: D_i and g_i minus their pending updates; the couplings as rows of a / rows of c
     {
         const double *Bii = cr_blk(S, s, mmax, i, i);
-        auto pending = [&](size_t offL, size_t offR, size_t idx, double v) {       // offL: what the LEFT pivots left for their right neighbour (cc / gc), offR: aa / ga
+        // pending updates of block `blk`: from the pivots blk - h' (their cc / gc slots, offL) and blk + h' (aa / ga, offR), h' < H
+        auto pending_of = [&](int blk, bool left, bool right, size_t offL, size_t offR, size_t idx, double v) {
             double p[16];
 #pragma unroll
             for (int l = 0; l < 8; l++) {
                 const int hp = 1 << l; const bool on = hp < H && hp < m;
-                p[2*l] = (on && !root) ? contrib[(size_t)(i - hp)*csz + offL + idx] : 0.0;
-                p[2*l + 1] = (on && i + hp < m) ? contrib[(size_t)(i + hp)*csz + offR + idx] : 0.0;
+                p[2*l] = (on && left && blk - hp > 0) ? contrib[(size_t)(blk - hp)*csz + offL + idx] : 0.0;
+                p[2*l + 1] = (on && right && blk + hp < m - (W.ring ? 1 : 0)) ? contrib[(size_t)(blk + hp)*csz + offR + idx] : 0.0;
             }
 #pragma unroll
             for (int l = 0; l < 16; l++) v -= p[l];
             return v;
         };
+        auto pending = [&](size_t offL, size_t offR, size_t idx, double v) { return pending_of(i, !root, true, offL, offR, idx, v); };
+        if (root == 2) {
+            // ring: blocks 0 and m - 1 are the same unknowns (m - 1 is the ghost of the first poses behind the last one): the root block is
+            // D_0 + D_{m-1} + S(m-1, 0) + S(m-1, 0)^T with both blocks' pending updates, the gradient the sum of both
+            const double *BiiP = cr_blk(S, s, mmax, m - 1, m - 1), *Bp0 = cr_blk(S, s, mmax, m - 1, 0);
+            for (int e = tid; e < tri(s); e += CRE_T) {
+                const int r = tri_row(e), q = e - tri(r); const size_t idx = (size_t)r*s + q;
+                const double v0 = pending_of(0, false, true, ss, 0, idx, Bii[idx]), v1 = pending_of(m - 1, true, false, ss, 0, idx, BiiP[idx]);
+                A[r*sst + q] = (v0 + v1) + (Bp0[idx] + Bp0[(size_t)q*s + r]);
+            }
+            for (int q = tid; q < s; q += CRE_T)
+                A[n*sst + q] = pending_of(0, false, true, 2*ss + s, 2*ss, (size_t)q, g[q]) + pending_of(m - 1, true, false, 2*ss + s, 2*ss, (size_t)q, g[(size_t)(m - 1)*s + q]);
+        } else {
         for (int e = tid; e < tri(s); e += CRE_T) {
             const int r = tri_row(e), q = e - tri(r); const size_t idx = (size_t)r*s + q;
             A[r*sst + q] = pending(ss, 0, idx, Bii[idx]);
         }
         for (int q = tid; q < s; q += CRE_T) A[n*sst + q] = pending(2*ss + s, 2*ss, (size_t)q, g[(size_t)i*s + q]);
+        }
         if (a >= 0) { const double *Bia = cr_blk(S, s, mmax, i, a);          // S(i, a)(r, t) -> row t of a, column r
             cre_batched<CRE_T, 8>(s*s, tid, [&](int e) { return Bia[e]; }, [&](int e, double v) { const int r = rowof(e), t = e - r*s; A[xbase + t*sst + r] = v; }); }
         if (c >= 0) { const double *Bci = cr_blk(S, s, mmax, c, i);          // S(c, i)(j, r) -> row j of c, column r
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
         if (wave == 0) {
             solve_backsub_wave(Pk, LD, s, B, lane);
             wave_lds_fence();
-            for (int k = lane; k < s; k += 64) Ws.Sy[k] = Pk[rowoff(s) + k];
+            for (int k = lane; k < s; k += 64) { Ws.Sy[k] = Pk[rowoff(s) + k]; if (root == 2) Ws.Sy[(size_t)(m - 1)*s + k] = Pk[rowoff(s) + k]; }
         }
         return;
     }
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
 // state and the number of separators are looked at -- one global round trip instead of two (-1.4 us per level).
 __global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, int Pmax, int h, const double *fac) {
     const LmState *st = W.st;
-    const int s = bw, B = s/6, mmax = Pmax - 1, tid = threadIdx.x, lane = tid & 63;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax), tid = threadIdx.x, lane = tid & 63;
     const int i = (2*(int)blockIdx.x + 1)*h;
     if (i >= mmax) return;
     const int a = i - h, cmx = i + h < mmax ? i + h : -1;        // (c exists if cmx < m: decided below)
@@ -325,8 +340,9 @@ __global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, in
     cre_batched<CRE_BT, 8>(xbase, tid, [&](int e) { return rec[e]; }, [&](int e, double v) { A[e] = v; });
     for (int k = tid; k < SOLVE_LD*B; k += CRE_BT) LD[k] = rec[xbase + k];
     if (done || sfail) return;
-    const int m = nb > 0 ? bandp_part(nb, s/6, Pmax, 0).P - 1 : 0;
-    if (i >= m) return;
+    int m = 0;
+    if (nb > 0) { const int P = bandp_part(W.ring ? nb + B : nb, B, Pmax, 0, W.ring).P; m = W.ring ? P + 1 : P - 1; }
+    if (i >= m || (W.ring && i == m - 1)) return;                // (ring: block m - 1 is the ghost of block 0, solved with it)
     const int nx = (cmx >= 0 && cmx < m) ? 2*s : s;              // rows of [X_a ; X_c]
     if (tid < 2*s) xs[tid] = xin;
     __syncthreads();

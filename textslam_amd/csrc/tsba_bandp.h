@@ -28,16 +28,33 @@ struct BandpPart { int P, a, b, has_left, has_right; };
 // interiors of q = (nb - (P - 1) B) / P blocks -- the first `rem` of them one more: the launch lasts as long as its longest interior, and a
 // last interior that took the whole remainder was 85 blocks against 68 at 5000 keyframes / P = 64 --, separators of B blocks between
 // them; P shrinks until an interior holds at least 2 B + 2 blocks
-__device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax, int p) {
+__device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax, int p, int ring = 0) {
+    BandpPart r;
+    if (ring) {
+        // ring (one loop closure, tsba_plan.h): nb counts the B ghost blocks behind the last pose.  [sep 0][interior 0][sep 1] ... [interior
+        // P-1][sep P = ghost of sep 0]: P interiors (a power of two: the separator tree ends in blocks 0 and P, which are the same
+        // unknowns), P + 1 separators, every interior has both neighbours
+        int P = Pmax;
+        while (P > 2 && (nb - (P + 1)*B)/P < 2*B + 2) P >>= 1;
+        r.P = P;
+        const int tot = nb - (P + 1)*B, q = tot/P, rem = tot - q*P;
+        r.a = B + p*(q + B) + (p < rem ? p : rem); r.b = r.a + q + (p < rem ? 1 : 0);
+        if (p == P - 1) r.b = nb - B;
+        r.has_left = 1; r.has_right = 1;
+        return r;
+    }
     int P = Pmax;
     while (P > 1 && (nb - (P - 1)*B)/P < 2*B + 2) P--;
-    BandpPart r; r.P = P;
+    r.P = P;
     const int tot = nb - (P - 1)*B, q = tot/P, rem = tot - q*P;
     r.a = p*(q + B) + (p < rem ? p : rem); r.b = r.a + q + (p < rem ? 1 : 0);
     if (p == P - 1) r.b = nb;
     r.has_left = p > 0; r.has_right = p < P - 1;
     return r;
 }
+// number of pose blocks the band solvers walk (ring: the ghost separator behind the last free pose), separators of the system, pool size
+__device__ __forceinline__ int bandp_nb(const Work &W, int B) { const int nf = *W.nfree; return nf > 0 && W.ring ? nf + B : nf; }
+__device__ __host__ __forceinline__ int cr_mmax(int ring, int Pmax) { return ring ? Pmax + 1 : Pmax - 1; }
 static size_t bandp_lds_doubles(int bw, int cb) {               // window + border rows + rhs row, LD table, scratch
     const int rows = 6*cb + 2*bw;
     return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*BANDP_PW + 8 + 64;
@@ -62,11 +79,11 @@ __device__ __forceinline__ void lds_barrier() {
 // block and the couplings to the left separator.  Row-wise: a wave takes whole rows (row addresses on the scalar unit, no division
 // per element) and keeps the loads of LOAD_U rows in flight -- the element-wise loop waited for every load before it issued the next
 // (5 - 6 dependent HBM round trips per chunk).
-__device__ __noinline__ void bandp_load_rows(double *Ag, const double *S, size_t ld, const double *g, int r0_, int first_, int n_, int nbr_, int base_, int gl0_, int bw_) {
+__device__ __noinline__ void bandp_load_rows(double *Ag, const double *S, size_t ld, const double *g, int r0_, int first_, int n_, int nbr_, int base_, int gl0_, int bw_, int glim_) {
     lds_f64 *A = (lds_f64 *)Ag;
     // (arguments of a function arrive in vector registers: back to the scalar unit)
     const int r0 = __builtin_amdgcn_readfirstlane(r0_), first = __builtin_amdgcn_readfirstlane(first_), n = __builtin_amdgcn_readfirstlane(n_), nbr = __builtin_amdgcn_readfirstlane(nbr_),
-              base = __builtin_amdgcn_readfirstlane(base_), gl0 = __builtin_amdgcn_readfirstlane(gl0_), bw = __builtin_amdgcn_readfirstlane(bw_);
+              base = __builtin_amdgcn_readfirstlane(base_), gl0 = __builtin_amdgcn_readfirstlane(gl0_), bw = __builtin_amdgcn_readfirstlane(bw_), glim = __builtin_amdgcn_readfirstlane(glim_);
     constexpr int NW = SOLVE_THREADS/64, LOAD_U = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int k = wave; k < nbr; k += NW) { lds_f64 *row = A + rowoff(n + k);
@@ -77,7 +94,7 @@ __device__ __noinline__ void bandp_load_rows(double *Ag, const double *S, size_t
     lds_f64 *rhs = A + rowoff(n + nbr);
     double gv[2];
 #pragma unroll
-    for (int u = 0; u < 2; u++) { const int c = r0 + tid + u*SOLVE_THREADS; gv[u] = c < n ? g[base + c] : 0.0; }
+    for (int u = 0; u < 2; u++) { const int c = r0 + tid + u*SOLVE_THREADS; gv[u] = (c < n && base + c < glim) ? g[base + c] : 0.0; }
     for (int rb = r0 + wave; rb < n; rb += NW*LOAD_U) {
         double v[LOAD_U][2];
 #pragma unroll
@@ -197,9 +214,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = SOLVE_THREADS/64, NT = NW - BANDP_PW;
     if (st->done || st->step_fail) return;
-    const int nb = *W.nfree, B = bw/6;
+    const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
-    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x);
+    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x, W.ring);
     if ((int)blockIdx.x >= PT.P) return;
     const int nbr = PT.has_left ? bw : 0;                       // border rows: the left separator
     const int row_lim = 6*(PT.has_right ? PT.b + B : PT.b);     // rows of the band this workgroup ever holds
@@ -216,7 +233,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
     int base = 6*PT.a, n = min(Wn, row_lim - base);
     const int gl0 = 6*(PT.a - B);                               // first row of the left separator
     // rows [r0, n) of the window from HBM; for the border / rhs rows the columns [r0, n).  first: also the border-border block
-    auto load_rows = [&](int r0, bool first) { bandp_load_rows(A, S, ld, W.g, r0, first ? 1 : 0, n, nbr, base, gl0, bw); };
+    const int glim = 6*(*W.nfree);                             // (ring: the ghost rows behind the last free pose have no gradient of their own)
+    auto load_rows = [&](int r0, bool first) { bandp_load_rows(A, S, ld, W.g, r0, first ? 1 : 0, n, nbr, base, gl0, bw, glim); };
     long long tF = 0, tW = 0, tS = 0, tL = 0, tx = clock64(); int nchunks = 0;       // phase stamps of interior 1 (-> W.dbg[32..36])
     load_rows(0, true);
     { const long long t_ = clock64(); tL += t_ - tx; tx = t_; }
@@ -394,9 +412,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
 __global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, const double *Lb, double *part) {
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
-    const int nb = *W.nfree, B = bw/6;
+    const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
-    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x);
+    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x, W.ring);
     if ((int)blockIdx.x >= PT.P || !PT.has_left) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int nbr = bw, REC = bw*6, tid = threadIdx.x;
@@ -450,9 +468,33 @@ static size_t cr_pool_blocks(int mmax) { size_t n = (size_t)mmax; for (int hh = 
 __global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, const double *Tbuf, const double *part, double *Ssep, int nsep_ld, double *gsep, int *nfree_sep, int blocked) {
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
-    const int nb = *W.nfree, B = bw/6;
-    const BandpPart P0 = bandp_part(nb, B, Pmax, 0);
+    const int B = bw/6, nb = bandp_nb(W, B);
+    const BandpPart P0 = bandp_part(nb, B, Pmax, 0, W.ring);
     const int P = P0.P, nS = bw, nTm = 2*bw;
+    const size_t tsz = (size_t)nTm*nTm + nTm, psz = (size_t)nS*nS + nS;
+    if (W.ring) {
+        // ring: separators 0 .. P, separator s LEFT of interior s and RIGHT of interior s - 1.  Separator 0 has no interior on its left (its
+        // diagonal block and gradient come straight from S, g), separator P -- the ghost rows -- none on its right; cyclic reduction ties
+        // the two together at the root.  Block pool only.
+        if (blockIdx.x == 0 && threadIdx.x == 0) *nfree_sep = (P + 1)*B;
+        const int s = blockIdx.x, mm = cr_mmax(1, Pmax);
+        if (s > P) return;
+        const double *Ta = s >= 1 ? Tbuf + (size_t)(s - 1)*tsz : nullptr;        // interior s - 1: this separator is its RIGHT one
+        const double *Tb = s < P ? Tbuf + (size_t)s*tsz : nullptr;                // interior s: this separator is its LEFT one (border rows of T)
+        const double *pp = part + (size_t)s*BANDP_NS*psz;
+        const size_t ldS = (size_t)W.ldS;
+        for (int e = threadIdx.x; e < nS*nS; e += 256) {
+            const int i = e/nS, j = e - i*nS;
+            if (j <= i) { double v = Ta ? Ta[(size_t)i*nTm + j] : W.S[(size_t)i*ldS + j];
+                if (Tb) for (int sl = 0; sl < BANDP_NS; sl++) v += pp[(size_t)sl*psz + (size_t)i*nS + j];
+                cr_blk(Ssep, nS, mm, s, s)[(size_t)i*nS + j] = v; }
+            if (Tb) cr_blk(Ssep, nS, mm, s + 1, s)[(size_t)j*nS + i] = Tb[(size_t)(nS + i)*nTm + j];     // T_s(border row i, right-separator column j) = S(sep s row i, sep s+1 col j)
+        }
+        for (int i = threadIdx.x; i < nS; i += 256) { double v = Ta ? (Ta + (size_t)nTm*nTm)[i] : W.g[i];
+            if (Tb) for (int sl = 0; sl < BANDP_NS; sl++) v += pp[(size_t)sl*psz + (size_t)nS*nS + i];
+            gsep[nS*s + i] = v; }
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) *nfree_sep = (P - 1)*B;
     const int s = blockIdx.x;                                    // separator s sits between interiors s and s + 1
     if (s >= P - 1) return;
@@ -481,18 +523,20 @@ __global__ __launch_bounds__(BAND_BS_T) void k_bandp_backsub(Work W, int bw, int
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (st->done || st->step_fail) return;
-    const int nb = *W.nfree, B = bw/6;
+    const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
-    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x);
+    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x, W.ring);
     if ((int)blockIdx.x >= PT.P) return;
     const int REC = bw*6, NTASK = 6*B, RECB = 2*REC + 32;
     const int r_lo = PT.a, r_hi = PT.has_right ? PT.b + B : PT.b;          // row blocks walked: [r_lo, r_hi), the top B of them given
     double *buf0 = smem, *buf1 = smem + (size_t)BAND_CK*RECB, *ring = buf1 + (size_t)BAND_CK*RECB, *xL = ring + 6*BAND_RINGB, *xR = xL + bw;
     for (int k = tid; k < 6*BAND_RINGB; k += BAND_BS_T) ring[k] = 0.0;
     for (int k = tid; k < bw; k += BAND_BS_T) {
-        xL[k] = PT.has_left ? xsep[(size_t)bw*(blockIdx.x - 1) + k] : 0.0;
-        xR[k] = PT.has_right ? xsep[(size_t)bw*blockIdx.x + k] : 0.0;
+        // (separator s lies LEFT of interior s in a ring -- where separator 0 comes first --, RIGHT of it otherwise)
+        xL[k] = PT.has_left ? xsep[(size_t)bw*(W.ring ? blockIdx.x : blockIdx.x - 1) + k] : 0.0;
+        xR[k] = PT.has_right ? xsep[(size_t)bw*(W.ring ? blockIdx.x + 1 : blockIdx.x) + k] : 0.0;
         if (PT.has_right) W.Sy[6*PT.b + k] = xR[k];              // the separator's solution goes to its rows of x
+        if (W.ring && blockIdx.x == 0) W.Sy[k] = xL[k];          // (ring: nobody has separator 0 on its right but the ghost rows)
     }
     const int nrows = r_hi - r_lo, nchunk = (nrows + BAND_CK - 1)/BAND_CK;
     auto stage = [&](int chunk, double *buf, int t0, int nt) {

@@ -22,6 +22,8 @@
 struct HostPlan {
     int level = 0;
     int bw_pose = 0;                            // half bandwidth of the reduced camera matrix in pose blocks, fill included
+    int ring = 0;                               // 1: the co-visibility graph is a RING (one loop closure between the last and the first keyframes): bw_pose is the band of
+                                                // the chain unrolled past its end -- the first bw_pose poses re-appear as ghost rows behind the last pose (tsba_bandp.h)
     std::vector<int32_t> kf_order;              // empty: S is ordered by keyframe index; else kf_order[i] = keyframe at position i (reverse Cuthill-McKee)
     // scene candidates (sorted by pair)
     std::vector<int32_t> sc_obs, sc_kf, sc_pt, sc_flag, sc_slot;
@@ -135,7 +137,7 @@ __host__ __device__ inline int tsba_shard_of(int host, int target_kf, int n_kf, 
     return (int)(((long long)k*nshard)/n_kf);
 }
 
-inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true) {
+inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true, int ring_max_blocks = 0) {
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
     P = HostPlan();
@@ -315,7 +317,30 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         if (keep_inc && P.bw_pose > 26) {
             std::vector<std::vector<int> > poses_of((size_t)n_pt + n_text), nb((size_t)n_kf);
             for (size_t e = 0; e < lp_lm.size(); e++) poses_of[(size_t)lp_lm[e]].push_back(lp_kf[e]);
-            for (auto &v : poses_of) { if (v.size() < 2) continue; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+            for (auto &v : poses_of) { if (v.size() < 2) continue; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+            // A single loop closure between the END and the START of the trajectory makes the graph a ring: every landmark's poses
+            // fit an arc of a few keyframes, some arcs wrap from the last keyframes to the first.  Unrolled past its end (a wrapping
+            // landmark's early poses k count as n_kf + k) the matrix is a band again -- bw_pose of the open chain, not twice that
+            // as under any reordering -- and the solver ties the ghost rows to the first poses at the root of its separator tree.
+            if (ring_max_blocks > 0) {
+                const int RB = ring_max_blocks, nu = n_kf + RB + 1;
+                std::vector<int> cu(nu); for (int k = 0; k < nu; k++) cu[k] = k;
+                bool ok = true, wraps = false;
+                for (const auto &v : poses_of) { if (v.size() < 2) continue;
+                    int best = v[0] + n_kf - v.back(); size_t at = 0;                 // largest cyclic gap (at = 0: the wrap between last and first)
+                    for (size_t x = 1; x < v.size(); x++) if (v[x] - v[x - 1] > best) { best = v[x] - v[x - 1]; at = x; }
+                    const int lo = at ? v[at] : v[0], hi = at ? v[at - 1] + n_kf : v.back();
+                    if (hi - lo > RB || hi >= n_kf + RB) { ok = false; break; }
+                    if (at) wraps = true;
+                    cu[lo] = std::max(cu[lo], hi); }
+                if (ok && wraps) {
+                    int run = -1, bwr = 0;
+                    for (int k = 0; k < nu; k++) { const int r = (run >= k) ? std::max(cu[k], run) : cu[k]; run = std::max(run, r); bwr = std::max(bwr, r - k); }
+                    if (bwr >= 1 && bwr <= RB && n_kf >= 4*(3*bwr + 2) + bwr) { P.ring = 1; P.bw_pose = bwr; }
+                }
+            }
+            if (!P.ring) {
+            for (auto &v : poses_of) { if (v.size() < 2) continue;
                 for (size_t x = 0; x < v.size(); x++) for (size_t y = 0; y < v.size(); y++) if (x != y) nb[(size_t)v[x]].push_back(v[y]); }
             for (auto &v : nb) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
             std::vector<int32_t> order; rcm_order(n_kf, nb, order);
@@ -326,6 +351,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             for (int q = 0; q < n_sb; q++) { const int pa = pos[P.sb_a[q]], pb = pos[P.sb_b[q]]; c2[std::min(pa, pb)] = std::max(c2[std::min(pa, pb)], std::max(pa, pb)); }
             const int bw2 = closed_bw(c2);
             if (bw2*10 < P.bw_pose*7) { P.kf_order = order; P.bw_pose = bw2; }
+            }
         }
     }
     std::vector<std::pair<int,int>> it_t, it_h, it_ps, it_ts;

@@ -213,10 +213,10 @@ class Optimizer:
 
     def solver_info(self):
         """Which kernel paths the uploaded problem takes (tsba_debug_solver_info)."""
-        v = (C.c_int32 * 16)()
-        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 16), "tsba_debug_solver_info")
+        v = (C.c_int32 * 17)()
+        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 17), "tsba_debug_solver_info")
         keys = ("lds_solver", "band_storage", "band_stream", "interiors", "sep_cr", "band_rows", "small_pairs", "pose_kernel", "large_map", "world", "rank",
-                "n_pair", "n_sblock", "n_scene_candidates", "n_point_slots", "kf_reordered")
+                "n_pair", "n_sblock", "n_scene_candidates", "n_point_slots", "kf_reordered", "ring")
         return dict(zip(keys, [int(x) for x in v]))
 
     def reduced_band(self, radius: float):
