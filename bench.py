@@ -260,7 +260,7 @@ def main():
                                           % (args.kf, args.pts, world), "lm_iterations": rep["iters"], "scene_blocks": rep["n_sblock"],
                               "reduced_system_dim": n6, "band_rows": info["band_rows"], "interiors": info["interiors"],
                               "separator_solver": "cyclic reduction" if info["sep_cr"] else "streaming", "far_frac": args.far,
-                              "loop_closure_map": bool(args.loop), "keyframes_reordered": bool(info["kf_reordered"]),
+                              "loop_closure_map": bool(args.loop), "keyframes_reordered": bool(info["kf_reordered"]), "ring_partition": bool(info.get("ring", 0)),
                               "rccl_ranks": ex["ranks"], "allreduce_bytes_per_lm_trial": ex["per_trial"],
                               "allreduce_bytes_per_linearisation": ex["per_linearisation"]}}
             if reference:

@@ -119,3 +119,44 @@ def test_keyframe_reordering_of_a_loop_closure_map():
         oo = abi.options_global(); oo.lm_shard, oo.lm_nshard = r, 3
         bw_r, order_r = _plan_band(P, oo, 1)
         assert bw_r == bw_rcm and np.array_equal(order_r, order)
+
+
+@pytest.mark.parametrize("nb,B,Pmax", [(5008, 10, 128), (608, 9, 16), (130, 9, 4), (1510, 8, 8), (2411, 11, 64)])
+def test_ring_partition_starts_and_ends_with_a_separator(lib, nb, B, Pmax):
+    """Ring maps (nb counts the B ghost blocks behind the last pose): [sep 0][interior 0][sep 1] ... [interior P-1][ghost of sep 0], P a
+    power of two, balanced interiors of at least 2 B + 2 blocks, every interior with both neighbours."""
+    lib.tsba_debug_bandp_part_ring.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]; lib.tsba_debug_bandp_part_ring.restype = None
+    def part(p):
+        o = (C.c_int*5)(); lib.tsba_debug_bandp_part_ring(nb, B, Pmax, p, o); return list(o)
+    P = part(0)[0]
+    assert 2 <= P <= Pmax and P & (P - 1) == 0
+    pos, sizes = B, []
+    for p in range(P):
+        Pp, a, b, hl, hr = part(p)
+        assert Pp == P and a == pos and b > a and hl == 1 and hr == 1
+        sizes.append(b - a); pos = b + B
+    assert pos == nb and max(sizes) - min(sizes) <= 1 and (min(sizes) >= 2*B + 2 or P == 2)
+
+
+def test_ring_plan_of_a_loop_closure_map():
+    """Host side of the ghost-row path (no GPU): a map whose last keyframes see the landmarks of the first is recognised as a ring and keeps
+    the band of the open chain; an open chain, a ring with a closure too wide for the separators, and a map with long-range
+    observations all over are not."""
+    from textslam_amd import synth, abi
+    from textslam_amd.optimizer import load_library
+    L = load_library()
+    L.tsba_debug_plan_ring.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int, C.POINTER(C.c_int32)]
+    o = abi.options_global()
+    def ring(P, mx):
+        s = P.struct(); bw = C.c_int32(0)
+        r = L.tsba_debug_plan_ring(C.byref(s), C.byref(o), 0, mx, C.byref(bw)); assert r >= 0
+        return r, bw.value
+    P = synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True)
+    r, bw = ring(P, 13)
+    assert r == 1 and 8 <= bw <= 11                          # the open chain's band (+ fill), not the 23 of the reordered rows
+    bw_rcm, _ = _plan_band(P, o, 1)
+    assert bw_rcm >= 2*bw - 4
+    assert ring(P, 6)[0] == 0                                 # separators of at most 6 pose blocks cannot hold a band of 8
+    assert ring(P, 0)[0] == 0                                 # not asked for (multi-GPU, several pyramid levels)
+    assert ring(synth.config_global(n_kf=600, n_pt=12000, band=8), 13)[0] == 0                  # open chain
+    assert ring(synth.config_global(n_kf=600, n_pt=12000, band=8, far_frac=0.02), 13)[0] == 0   # long-range observations: not a ring

@@ -2735,7 +2735,13 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
         else { std::vector<double> hb(c->S_count); CK(hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost));
             const long long N = W.N, LDB = W.ldS + 1, Wb = LDB - c->S_up;                // band -> dense (entries outside the band are zero)
             for (long long i = 0; i < N; i++) for (long long j = 0; j < N; j++)
-                S[i*N + j] = (j >= i - Wb && j <= i + c->S_up - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
+                S[i*N + j] = (j >= i - Wb && j <= i + c->S_up - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0;
+            if (W.ring) {                     // the loop-closure blocks: ghost row 6 nfree + r stands for row r of the first poses (lower triangle: (late pose, early pose))
+                int nf = 0; CK(hipMemcpy(&nf, W.nfree, sizeof(int), hipMemcpyDeviceToHost));
+                const long long n6 = 6LL*nf, ng = std::min<long long>(Wb, N);
+                for (long long r = 0; r < ng && n6 + r < (long long)(c->S_count/LDB); r++) for (long long j = std::max(0LL, n6 + r - Wb); j < n6; j++) {
+                    const double v = hb[(size_t)(Wb + (n6 + r)*(LDB - 1) + j)]; if (v != 0.0 && j > r) S[j*N + r] = v; }
+            } }
     }
     if (g) CK(hipMemcpy(g, W.g, sizeof(double)*W.N, hipMemcpyDeviceToHost));
     if (dp) CK(hipMemcpy(dp, W.dp, sizeof(double)*W.N, hipMemcpyDeviceToHost));
@@ -2754,6 +2760,7 @@ int tsba_debug_reduced_band(void *ctx, double radius, int32_t *n_out, int32_t *b
     Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
     if (!c->uploaded) return TSBA_ERR_STATE;
     if (!c->W.band) { set_err(c, "the uploaded problem keeps a dense reduced system: use tsba_debug_reduced_system"); return TSBA_ERR_STATE; }
+    if (c->W.ring) { set_err(c, "ring-shaped map: the loop-closure blocks live in ghost rows outside the band (tsba_debug_set no_ring for the reordered band)"); return TSBA_ERR_STATE; }
     int rc = tsba_debug_reduced_system(ctx, radius, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
     Work &W = c->W;
     int nfree = 0; CK(hipMemcpy(&nfree, W.nfree, sizeof(int), hipMemcpyDeviceToHost));
@@ -2900,6 +2907,15 @@ int tsba_debug_band_factor(void *ctx, double *lcol, long long n_lcol, double *ld
 }
 // host-side index arithmetic of the partitioned band solver, for the CPU test-suite (no device needed):
 // out5 = { P, a, b, has_left, has_right } of interior p;  block index of (br, bc) in the cyclic-reduction pool and the pool size
+// host-only: does the plan of `level` take the ring path (one loop closure between the last and the first keyframes) when separators of up
+// to ring_max_blocks pose blocks are allowed?  Returns 1 / 0 (< 0: error); *bw_pose = the band of the plan either way
+int tsba_debug_plan_ring(const tsba_problem *p, const tsba_options *o, int level, int ring_max_blocks, int32_t *bw_pose) {
+    if (!p || !o || !bw_pose || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
+    HostPlan H; build_plan(p, o, level, H, false, true, ring_max_blocks);
+    *bw_pose = H.bw_pose;
+    return H.ring;
+}
+void tsba_debug_bandp_part_ring(int nb, int B, int Pmax, int p, int *out5) { const BandpPart r = bandp_part(nb, B, Pmax, p, 1); out5[0] = r.P; out5[1] = r.a; out5[2] = r.b; out5[3] = r.has_left; out5[4] = r.has_right; }
 void tsba_debug_bandp_part(int nb, int B, int Pmax, int p, int *out5) { const BandpPart r = bandp_part(nb, B, Pmax, p); out5[0] = r.P; out5[1] = r.a; out5[2] = r.b; out5[3] = r.has_left; out5[4] = r.has_right; }
 long long tsba_debug_cr_blk_index(int mmax, int br, int bc) { return (long long)cr_blk_index(mmax, br, bc); }
 long long tsba_debug_cr_pool_blocks(int mmax) { return (long long)cr_pool_blocks(mmax); }
