@@ -373,6 +373,18 @@ def test_multi_rank_band_solver_and_text(gpu):
         np.testing.assert_allclose(G.theta, G1.theta, rtol=0, atol=1e-9)
 
 
+def test_multi_rank_ring_map(gpu):
+    """N = 2 on a loop-closure map: every rank recognises the ring from ALL observations, keeps its shard's closure blocks in the ghost
+    rows, and the ghost rows travel with the packed band."""
+    P = synth.config_global(n_kf=400, n_pt=12000, band=8, loop=True)
+    o = abi.options_global(); o.its[0] = 6
+    G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+    assert gpu.solver_info()["ring"] == 1
+    for G, rep, info in _solve_on_ranks(P, o, 2):
+        assert info["ring"] == 1 and info["world"] == 2 and info["band_storage"] == 1, info
+        _same_trajectory(rep1, rep, G1, G)
+
+
 def test_multi_gpu_rccl_two_ranks():
     """Real RCCL over two devices (skipped on a one-GPU box): 2-rank solve against the 1-rank answer."""
     import subprocess, sys, os, json

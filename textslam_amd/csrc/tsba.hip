@@ -1637,7 +1637,7 @@ __global__ void k_damp_multi(Work W) {
 __global__ __launch_bounds__(256) void k_band_pack(Work W, double *buf, int wp, int unpack) {
     const LmState *st = W.st;
     if (st->done) return;
-    const int n = 6*(*W.nfree);
+    const int n = 6*(*W.nfree) + (W.ring ? wp - 6 : 0);          // (ring: + the ghost rows behind the last free pose, wp = band + 6)
     const long long tot = (long long)n*wp;
     const size_t ldS = (size_t)W.ldS;
     for (long long e = (long long)blockIdx.x*256 + threadIdx.x; e < tot; e += (long long)gridDim.x*256) {
@@ -2089,7 +2089,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             const bool reorder = !c->dbg.no_kf_reorder;
             // ring maps (one loop closure): a single-level, single-GPU solve through the partitioned solver with the cyclic-reduction separator tree
             int n_lev = 0; { std::vector<char> sn(p->n_levels, 0); for (int q = 0; q < o->n_passes; q++) if (!sn[o->levels[q]]) { sn[o->levels[q]] = 1; n_lev++; } }
-            const int ring_max = (n_lev == 1 && !is_multi(c) && !c->dbg.no_ring && !c->dbg.no_band_stream && c->dbg.sep_solver != 1 && c->dbg.sep_solver != 3 && c->dbg.band_parts != 1) ? CR_SMAX/6 : 0;
+            const int ring_max = (n_lev == 1 && !c->dbg.no_ring && !c->dbg.no_band_stream && c->dbg.sep_solver != 1 && c->dbg.sep_solver != 3 && c->dbg.band_parts != 1) ? CR_SMAX/6 : 0;
             planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
@@ -2256,7 +2256,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         if (ring && !W.ring) { set_err(c, "ring-shaped map: the partitioned band solver is not available for this plan"); return TSBA_ERR_STATE; }
         AL(W.Sy, W.N + BAND_BW_MAX);                            // (+ the ghost rows of a ring map)
         c->S_xchg = nullptr; c->xchg_wp = 0;
-        if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, (size_t)W.N*c->xchg_wp); }
+        if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, ((size_t)W.N + bwmax)*c->xchg_wp); }
     }
     AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
@@ -2508,9 +2508,10 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     launch_schur(c, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
         if (c->S_xchg) {                           // band storage: only the band's entries travel
-            const int nbp = (int)std::min<size_t>(2048, ((size_t)W.N*c->xchg_wp + 255)/256);
+            const size_t nx = ((size_t)W.N + (W.ring ? c->xchg_wp - 6 : 0))*c->xchg_wp;
+            const int nbp = (int)std::min<size_t>(2048, (nx + 255)/256);
             hipLaunchKernelGGL(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 0);
-            allreduce(c, c->S_xchg, (size_t)W.N*c->xchg_wp, ncclDouble, ncclSum);
+            allreduce(c, c->S_xchg, nx, ncclDouble, ncclSum);
             hipLaunchKernelGGL(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 1);
         } else allreduce(c, c->S_alloc, c->S_count, ncclDouble, ncclSum);
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
