@@ -407,7 +407,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
 // ---- the deferred part of T_p: LL = -sum_j Lb_j D_j Lb_j^T and gL = -sum_j Lb_j D_j v_j over the interior's column blocks, from the border
 // panel in HBM.  grid (P, BANDP_NS): every workgroup takes a slice of the interior's blocks and writes its partial (summed in a
 // fixed order by k_bandp_sep: deterministic).  part layout per (p, slice): [nbr x nbr] (lower used) | [nbr]
-#define BANDP_NS 8
+#ifndef BANDP_NS
+#define BANDP_NS 4                          // slices of an interior in k_bandp_border (5000 keyframes, 127 interiors of 29 blocks: 8 slices 17.05 ms per solve, 4: 16.80, 2: 16.85)
+#endif
 #define BANDP_JC 8
 __global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, const double *Lb, double *part) {
     const LmState *st = W.st;
