@@ -160,3 +160,18 @@ def test_ring_plan_of_a_loop_closure_map():
     assert ring(P, 0)[0] == 0                                 # not asked for (multi-GPU, several pyramid levels)
     assert ring(synth.config_global(n_kf=600, n_pt=12000, band=8), 13)[0] == 0                  # open chain
     assert ring(synth.config_global(n_kf=600, n_pt=12000, band=8, far_frac=0.02), 13)[0] == 0   # long-range observations: not a ring
+
+
+def test_plan_does_not_depend_on_the_number_of_host_threads():
+    """The slot-pair lists of the Schur complement (2 M entries at 5000 keyframes) are placed by several host threads on large maps: the
+    lists must be the ones a single thread builds (block-major, landmark-major within a block)."""
+    from textslam_amd import synth, abi
+    from textslam_amd.optimizer import load_library
+    L = load_library()
+    L.tsba_debug_plan_checksum.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int]; L.tsba_debug_plan_checksum.restype = C.c_ulonglong
+    for P, o in ((synth.config_global(n_kf=700, n_pt=20000, band=9), abi.options_global()), (synth.tiny(seed=3, n_kf=8, n_pt=300, n_text=6), abi.options_local())):
+        s = P.struct()
+        ref = L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, 1)
+        assert ref != 0
+        for t in (2, 3, 7, 16):
+            assert L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, t) == ref, t

@@ -2908,6 +2908,18 @@ int tsba_debug_band_factor(void *ctx, double *lcol, long long n_lcol, double *ld
 }
 // host-side index arithmetic of the partitioned band solver, for the CPU test-suite (no device needed):
 // out5 = { P, a, b, has_left, has_right } of interior p;  block index of (br, bc) in the cyclic-reduction pool and the pool size
+// host-only: FNV-1a over the Schur slot-pair lists of the plan of `level`, built with `threads` host threads in the parallel sections
+// (0 = the production choice): the plan must not depend on the number of threads
+unsigned long long tsba_debug_plan_checksum(const tsba_problem *p, const tsba_options *o, int level, int threads) {
+    if (!p || !o || level < 0 || level >= p->n_levels) return 0;
+    const int saved = tsba_plan_threads; tsba_plan_threads = threads;
+    HostPlan H; build_plan(p, o, level, H);
+    tsba_plan_threads = saved;
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const std::vector<int32_t> &v) { for (int32_t x : v) { h ^= (unsigned int)x; h *= 1099511628211ull; } h ^= v.size(); h *= 1099511628211ull; };
+    mix(H.sb_a); mix(H.sb_b); mix(H.sb_pt_off); mix(H.sb_pt_s1); mix(H.sb_pt_s2); mix(H.sb_pt_lm); mix(H.sb_tx_off); mix(H.sb_tx_s1); mix(H.sb_tx_s2); mix(H.sb_tx_lm);
+    return h;
+}
 // host-only: does the plan of `level` take the ring path (one loop closure between the last and the first keyframes) when separators of up
 // to ring_max_blocks pose blocks are allowed?  Returns 1 / 0 (< 0: error); *bw_pose = the band of the plan either way
 int tsba_debug_plan_ring(const tsba_problem *p, const tsba_options *o, int level, int ring_max_blocks, int32_t *bw_pose) {

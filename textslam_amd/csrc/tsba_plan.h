@@ -12,12 +12,15 @@
 #pragma once
 #include <vector>
 #include <algorithm>
+#include <thread>
 #include <cstdint>
 #include <map>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include "../../include/tsba.h"
+
+static int tsba_plan_threads = 0;              // 0: by problem size; > 0: host threads of the plan builder's parallel sections (tests)
 
 struct HostPlan {
     int level = 0;
@@ -264,15 +267,46 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; if (h < 0) continue;
         int bl = blk_of(bkey(std::min(i, h), std::max(i, h)));
         if (i < h) P.sb_pab[bl] = q; else P.sb_pba[bl] = q; }     // pab: target = a, host = b;  pba: target = b, host = a
+    // Large maps (2 M slot pairs at 5000 keyframes: 31 ms of the 60 ms plan on one thread): T host threads take contiguous landmark ranges.
+    // Pass 1: a thread records the block of each of its pairs and counts per block; the block offsets and every thread's first position in
+    // every block follow from the counts (thread-major within a block = landmark-major: the same order as one thread produces); pass 2
+    // places.  The result does not depend on T.
     auto fill_tri = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, const std::vector<int32_t> &lm_of, int n_lm,
                         std::vector<int32_t> &off, std::vector<int32_t> &s1v, std::vector<int32_t> &s2v, std::vector<int32_t> &lmv) {
         off.assign((size_t)n_sb + 1, 0);                          // stable by block: the landmark-major generation order is kept
-        each_pair(loff, pose, n_lm, [&](int64_t k, int, int) { off[(size_t)blk_of(k) + 1]++; });
-        for (int q = 0; q < n_sb; q++) off[q+1] += off[q];
+        const size_t n_slot = n_lm > 0 ? (size_t)loff[n_lm] : 0;
+        int T = 1;
+        if (n_slot > 200000) { T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()/2)); }
+        if (tsba_plan_threads > 0) T = std::min(tsba_plan_threads, std::max(1, n_lm));
+        if (T <= 1) {
+            each_pair(loff, pose, n_lm, [&](int64_t k, int, int) { off[(size_t)blk_of(k) + 1]++; });
+            for (int q = 0; q < n_sb; q++) off[q+1] += off[q];
+            const size_t tot = (size_t)off[n_sb];
+            s1v.resize(tot); s2v.resize(tot); lmv.resize(tot);
+            std::vector<int32_t> cur(off.begin(), off.end() - 1);
+            each_pair(loff, pose, n_lm, [&](int64_t k, int s1, int s2) { const int at = cur[blk_of(k)]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; });
+            return;
+        }
+        std::vector<int> lo(T + 1, 0);                            // landmark ranges with about the same number of slots
+        for (int t = 1; t < T; t++) lo[t] = (int)(std::lower_bound(loff.begin(), loff.begin() + n_lm + 1, (int32_t)(n_slot*t/T)) - loff.begin());
+        lo[T] = n_lm;
+        auto range_pairs = [&](int j0, int j1, auto &&f) {
+            for (int j = j0; j < j1; j++) for (int s1 = loff[j]; s1 < loff[j+1]; s1++) for (int s2 = loff[j]; s2 < loff[j+1]; s2++) {
+                const int a = pose[s1], b2 = pose[s2]; if (a > b2) continue; f(bkey(a, b2), s1, s2); } };
+        std::vector<std::vector<int32_t> > blk(T), cnt(T);
+        {   std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back([&, t]() { cnt[t].assign((size_t)n_sb, 0); blk[t].reserve(4*n_slot/T + 1024);
+                range_pairs(lo[t], lo[t+1], [&](int64_t k, int, int) { const int q = blk_of(k); blk[t].push_back(q); cnt[t][(size_t)q]++; }); });
+            for (auto &x : th) x.join(); }
+        for (int q = 0; q < n_sb; q++) { int32_t run = off[q];    // off[q] is the start of block q; cnt[t][q] becomes thread t's first position in it
+            for (int t = 0; t < T; t++) { const int32_t c = cnt[t][(size_t)q]; cnt[t][(size_t)q] = run; run += c; }
+            off[q+1] = run; }
         const size_t tot = (size_t)off[n_sb];
         s1v.resize(tot); s2v.resize(tot); lmv.resize(tot);
-        std::vector<int32_t> cur(off.begin(), off.end() - 1);
-        each_pair(loff, pose, n_lm, [&](int64_t k, int s1, int s2) { const int at = cur[blk_of(k)]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; });
+        {   std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back([&, t]() { size_t e = 0;
+                range_pairs(lo[t], lo[t+1], [&](int64_t, int s1, int s2) { const int at = cnt[t][(size_t)blk[t][e++]]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; }); });
+            for (auto &x : th) x.join(); }
     };
     fill_tri(P.pls_off, P.pslot_pose, P.pslot_lm, n_pt, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2, P.sb_pt_lm);      // (lm: saves one dependent gather in k_schur)
     fill_tri(P.tls_off, P.tslot_pose, P.tslot_lm, n_text, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2, P.sb_tx_lm);
