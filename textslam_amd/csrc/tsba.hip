@@ -1324,7 +1324,11 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
     if (st->done) return;
     __shared__ double lds[4*12*17];                             // a third of a group's 36 sums at a time: 6.5 KB, the registers set the occupancy
     const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
-    const int b = 4*(int)blockIdx.x + grp;
+    // workgroups are handed to the 8 XCDs round-robin (workgroup i -> XCD i mod 8), and an XCD's L2 does not see the others': neighbouring S
+    // blocks read the same landmarks' records, so the workgroups of ONE XCD take a contiguous range of blocks (the kernel is bound by
+    // L2 -> L1 line fills; with neighbouring blocks on eight different XCDs every record crossed the fabric up to eight times)
+    const int per = (int)gridDim.x >> 3, wg = ((int)blockIdx.x & 7)*per + ((int)blockIdx.x >> 3);     // (the grid is a multiple of 8 workgroups)
+    const int b = 4*wg + grp;
     const bool have = b < L.n_sb;
     const int bc = have ? b : L.n_sb - 1;
     const double irad = 1.0/st->radius;
@@ -2389,8 +2393,9 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
 }
 static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
     if (c->n_kf > 126 && !c->dbg.no_schur_quad) {               // large maps: four S blocks per wave, then one wave per pose for the reduced gradient
-        if (D.n_sb > 0) { if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3((D.n_sb + 3)/4), dim3(64), 0, c->stream, c->W, D, multi);
-            else hipLaunchKernelGGL(k_schur_quad<false>, dim3((D.n_sb + 3)/4), dim3(64), 0, c->stream, c->W, D, multi); }
+        if (D.n_sb > 0) { const int nq = (((D.n_sb + 3)/4 + 7)/8)*8;           // (a multiple of 8 workgroups: the kernel's XCD-aware block mapping)
+            if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, D, multi);
+            else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, D, multi); }
         hipLaunchKernelGGL(k_schur_t<1>, dim3(c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, D.n_sb);
     } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0);
     else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0);
