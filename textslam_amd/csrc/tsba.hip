@@ -1148,7 +1148,11 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
     LmState *st = W.st;
     if (st->done) return;
     __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
-    const int b = blockIdx.x + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // (b0: large maps take the S blocks through k_schur_quad and only the gradient part here)
+    // (b0 > 0: large maps take the S blocks through k_schur_quad and only the gradient part here, a grid of a multiple of 8 workgroups in
+    // which the workgroups of ONE XCD -- workgroup i runs on XCD i mod 8 -- take neighbouring poses: the slot records of a landmark sit next
+    // to each other, one per observing pose, and neighbouring poses observe the same landmarks)
+    const int bx = b0 > 0 ? ((int)blockIdx.x & 7)*((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int b = bx + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double radius = st->radius, irad = 1.0/radius;
     const LinBuf &B = W.lb[st->lcur];
     if (b < L.n_sb) {
@@ -1257,6 +1261,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         }
     } else {
         const int a = b - L.n_sb;
+        if (a >= W.n_kf) return;                               // (the gradient-only grid is rounded up to a multiple of 8)
         const int ia = W.fidx[a];
         if (ia < 0) return;
         double acc[6] = {0,0,0,0,0,0};
@@ -2396,7 +2401,7 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
         if (D.n_sb > 0) { const int nq = (((D.n_sb + 3)/4 + 7)/8)*8;           // (a multiple of 8 workgroups: the kernel's XCD-aware block mapping)
             if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, D, multi);
             else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, D, multi); }
-        hipLaunchKernelGGL(k_schur_t<1>, dim3(c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, D.n_sb);
+        hipLaunchKernelGGL(k_schur_t<1>, dim3(((c->n_kf + 7)/8)*8), dim3(64), 0, c->stream, c->W, D, multi, D.n_sb);
     } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0);
     else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0);
 }
