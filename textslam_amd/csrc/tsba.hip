@@ -542,9 +542,13 @@ __global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, Level
     constexpr int LPP = 64/PPW;                              // lanes per pair
     const int nb_sc = (L.n_pair + NWV*PPW - 1)/(NWV*PPW);
     const int sub = PPW == 1 ? lane : (lane & (LPP - 1));
-    // (scene-only launches: a grid of a multiple of 8 workgroups in which the workgroups of ONE XCD -- workgroup i runs on XCD i mod 8 -- take
-    // neighbouring pairs: the 64-byte slot records of a landmark's observers share 128-byte lines, and neighbouring pairs observe the same landmarks)
+    // (scene-only launches: the workgroups of ONE XCD -- workgroup i runs on XCD i mod 8 -- take neighbouring pairs: the 64-byte slot records
+    // of a landmark's observers share 128-byte lines, and neighbouring pairs observe the same landmarks.  With text groups the same mapping
+    // was measured SLOWER on C4 (13.6 vs 13.0 us): the groups are the heavy workgroups and sit at the end of the index range -- contiguous
+    // ranges put all of them on the last two XCDs.)  The grid is a multiple of 8 workgroups either way.
+    // (Dispatching the text groups FIRST -- lowest workgroup indices -- was no better either: 13.2 us.)
     const int bq = TEXT ? (int)blockIdx.x : ((int)blockIdx.x & 7)*((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (bq >= nb_sc + (TEXT ? L.n_tg : 0)) return;
     const int pr = (NWV*bq + wave)*PPW + (PPW == 1 ? 0 : lane/LPP), prc = min(pr, max(L.n_pair - 1, 0));
     int pi = 0, ph = 0, pbeg = 0, pend = 0, tgpp = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
     if (bq < nb_sc) { pi = L.pair_i[prc]; ph = L.pair_h[prc]; pbeg = L.pair_sc_off[prc]; pend = pr < L.n_pair ? L.pair_sc_off[prc+1] : pbeg; }
@@ -2378,8 +2382,8 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
     if (D.n_pair + D.n_tg > 0) {
         if (lin_small_pairs(c, D) && D.n_tg == 0) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4, false>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
-        else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
-        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg), dim3(LIN_T), 0, c->stream, W, D, spec);
+        else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
+        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
     }
     hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
@@ -2807,8 +2811,8 @@ int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *alg
     CK(hipEventRecord(c->ev0, c->stream));
     for (int k = 0; k < n; k++) {
         if (lin_small_pairs(c, D) && D.n_tg == 0) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4, false>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + 7)/8)*8), dim3(LIN_T), 0, c->stream, c->W, D, 0);
-        else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
-        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+        else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, c->W, D, 0);
+        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, c->W, D, 0);
     }
     CK(hipEventRecord(c->ev1, c->stream));
     CK(hipEventSynchronize(c->ev1));
