@@ -298,11 +298,14 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             for (int t = 0; t < T; t++) th.emplace_back([&, t]() { cnt[t].assign((size_t)n_sb, 0); blk[t].reserve(4*n_slot/T + 1024);
                 range_pairs(lo[t], lo[t+1], [&](int64_t k, int, int) { const int q = blk_of(k); blk[t].push_back(q); cnt[t][(size_t)q]++; }); });
             for (auto &x : th) x.join(); }
+        lap("  slot pairs: pass 1 (threads)");
         for (int q = 0; q < n_sb; q++) { int32_t run = off[q];    // off[q] is the start of block q; cnt[t][q] becomes thread t's first position in it
             for (int t = 0; t < T; t++) { const int32_t c = cnt[t][(size_t)q]; cnt[t][(size_t)q] = run; run += c; }
             off[q+1] = run; }
         const size_t tot = (size_t)off[n_sb];
+        lap("  slot pairs: offsets");
         s1v.resize(tot); s2v.resize(tot); lmv.resize(tot);
+        lap("  slot pairs: resize");
         {   std::vector<std::thread> th;
             for (int t = 0; t < T; t++) th.emplace_back([&, t]() { size_t e = 0;
                 range_pairs(lo[t], lo[t+1], [&](int64_t, int s1, int s2) { const int at = cnt[t][(size_t)blk[t][e++]]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; }); });

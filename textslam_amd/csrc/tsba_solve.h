@@ -97,8 +97,9 @@ template <int w> struct IC { static constexpr int value = w; };
 // Back substitution L^T x = z for the factor in LDS (packed rows of the unit-lower L, row n = z = D^-1 L^-1 g, LD table with the
 // inverse 6x6 diagonal factors at LD_M), run by ONE wave with z in registers (60 rows per register: the register a block lives in
 // is a compile-time constant), x_block = L_jj^-T z_block, next block's operands prefetched.  The solution replaces the rhs row.
-__device__ __forceinline__ void solve_backsub_wave(double *A, double *LD, int n, int nfree, int lane) {
-    double *rhs = A + rowoff(n);
+template <class RO>
+__device__ __forceinline__ void solve_backsub_wave_ro(double *A, double *LD, int n, int nfree, int lane, RO ro) {
+    double *rhs = A + ro(n);
         // rows of blocks that were already consumed (and lanes 60..63) keep receiving updates: they are never read again, the
         // solution goes to the rhs row through lane 0
         double z[4];
@@ -112,7 +113,7 @@ __device__ __forceinline__ void solve_backsub_wave(double *A, double *LD, int n,
                 for (int u = 0; u <= w; u++) {
                     const int k = min(60*u + lane, j0);
 #pragma unroll
-                    for (int c = 0; c < 6; c++) col[u][c] = A[rowoff(j0 + c) + k];
+                    for (int c = 0; c < 6; c++) col[u][c] = A[ro(j0 + c) + k];
                 }
                 const double *o = LD + SOLVE_LD*(10*w + q) + LD_M;
                 double t[16];
@@ -157,6 +158,9 @@ __device__ __forceinline__ void solve_backsub_wave(double *A, double *LD, int n,
         if (nfree > 20) back(IC<2>{});
         if (nfree > 10) back(IC<1>{});
         back(IC<0>{});
+}
+__device__ __forceinline__ void solve_backsub_wave(double *A, double *LD, int n, int nfree, int lane) {
+    solve_backsub_wave_ro(A, LD, n, nfree, lane, [](int i) { return rowoff(i); });
 }
 
 #define SOLVE_DIAG_NB 96                     // diagonal block of the large-system Cholesky (tsba_chol.h)
@@ -398,3 +402,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
         for (int k = 0; k < 6; k++) W.dp[6*a + k] = ia >= 0 ? -rhs[6*ia + k] : 0.0;
     }
 }
+
+// (k_solve_r -- the same solver with every row at the same stride, update tiles with an unmasked path and scalar tile indices, optionally
+// only on the SIMDs without a panel wave -- was built and measured in round 2 on the C4 window: 34.95 us with ten update waves, 37.0 us
+// with the six of SIMD 2 and 3, against 33.5 us for this kernel.  What paid on the cyclic-reduction levels (tsba_bandcre.h), where the update
+// waves set the pace, does not here, where the panel chain does.  tools/experiments/solve_rect.h)
