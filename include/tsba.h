@@ -244,7 +244,7 @@ int  tsba_debug_time_solve(void *ctx, int n, double *avg_ms);
  * between solver paths that are all exact -- none of them changes what is computed, only by which kernels. */
 typedef struct tsba_debug_options {
     int32_t band_parts;        /* > 0: number of interiors of the partitioned band solver (1 = single-workgroup streaming solver) */
-    int32_t sep_solver;        /* separator system: 0 cost model, 1 sequential streaming solver, 2 block cyclic reduction (one launch per level), 3 cyclic reduction by the pivot / update / back kernels of round 1 */
+    int32_t sep_solver;        /* separator system: 0 cost model, 1 sequential streaming solver, 2 block cyclic reduction (one launch per level), 3 cyclic reduction by the pivot / update / back kernels of round 1, 4 as 2 with the separator system assembled by the border / sep kernels instead of the fused one */
     int32_t no_band_stream;    /* 1: large systems through the wide-band multi-workgroup Cholesky even when the band is narrow */
     int32_t no_pose_kernel;    /* 1: PoseOptim through the general pipeline instead of the fused pose-only kernel */
     int32_t no_small_pairs;    /* 1: never put four (target, host) pairs on one wave of the linearisation */

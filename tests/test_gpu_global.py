@@ -50,12 +50,13 @@ def _same_trajectory(rep1, rep2, G1, G2, atol=1e-9):
     np.testing.assert_allclose(G1.rho, G2.rho, rtol=0, atol=atol)
 
 
-@pytest.mark.parametrize("n_kf,band,parts,cr", [(600, 6, 8, 2), (900, 9, 17, 2), (1100, 12, 11, 2), (1500, 10, 27, 2), (1300, 7, 40, 2), (1500, 13, 9, 2), (900, 9, 17, 3)])
+@pytest.mark.parametrize("n_kf,band,parts,cr", [(600, 6, 8, 2), (900, 9, 17, 2), (1100, 12, 11, 2), (1500, 10, 27, 2), (1300, 7, 40, 2), (1500, 13, 9, 2), (900, 9, 17, 3), (900, 9, 17, 4)])
 def test_cyclic_reduction_separator_solver(gpu, n_kf, band, parts, cr):
     """The cyclic-reduction separator solver forced at sizes where the cost model would pick the sequential separator solve: separators of
     6 .. 12 pose blocks, 7 .. 39 of them (odd and even counts, not powers of two).  cr = 2: one launch per level (tsba_bandcre.h:
     k_cre_elim / k_cre_back, several workgroups per pivot at the lower levels); cr = 3: the pivot / update / back kernels of round 1
-    (tsba_bandcr.h), kept for A/B runs."""
+    (tsba_bandcr.h), kept for A/B runs; cr = 4: as 2 with the separator system assembled by k_bandp_border + k_bandp_sep
+    instead of the fused k_bandp_sepf."""
     P = synth.config_global(n_kf=n_kf, n_pt=40*n_kf, band=band)
     o = abi.options_global(); o.its[0] = 5
     try:

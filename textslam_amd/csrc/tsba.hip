@@ -2423,6 +2423,7 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_cr_update, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cr_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cre_elim, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_bandp_sepf, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -2447,9 +2448,13 @@ static void launch_solve(Ctx *c) {
         Work &Ws = c->Wsep; Ws.st = W.st; Ws.ldS = (P - 1)*bwp; Ws.N = (P - 1)*bwp;
         if (!c->sep_cr) hipMemsetAsync(c->Ssep, 0, sizeof(double)*((size_t)Ws.ldS*Ws.ldS + Ws.ldS), c->stream);
         hipLaunchKernelGGL(k_bandp_factor, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
+        if (c->sep_cr && c->dbg.sep_solver != 3 && c->dbg.sep_solver != 4)      // block pool: border products + separator assembly in one launch (4: the three launches, for A/B runs)
+            hipLaunchKernelGGL(k_bandp_sepf, dim3(W.ring ? P + 1 : P - 1), dim3(BSF_T), (int)(bandp_sepf_lds_doubles()*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Lb, c->Ssep, Ws.g, Ws.nfree);
+        else {
         hipMemsetAsync(c->Bpart, 0, sizeof(double)*(size_t)P*BANDP_NS*((size_t)bwp*bwp + bwp), c->stream);        // (slices of short interiors stay empty)
         hipLaunchKernelGGL(k_bandp_border, dim3(P, BANDP_NS), dim3(256), (int)((2*(size_t)BANDP_JC*bwp*6 + 6*BANDP_JC)*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Lb, c->Bpart);
         hipLaunchKernelGGL(k_bandp_sep, dim3(W.ring ? P + 1 : P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
+        }
         if (c->sep_cr) {                  // separator system by block cyclic reduction (tsba_bandcr.h): log2(P - 1) levels
             const int mmax = cr_mmax(W.ring, P), mlev = W.ring ? mmax - 1 : mmax;      // (ring: blocks 0 and mmax - 1 are merged at the root, no level for the ghost)
             const int lp = (int)(cr_pivot_lds_doubles(bwp)*sizeof(double)), lu = (int)(cr_update_lds_doubles(bwp)*sizeof(double)), lb = (int)(cr_back_lds_doubles(bwp)*sizeof(double));

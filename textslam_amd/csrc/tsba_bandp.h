@@ -518,6 +518,105 @@ __global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, con
     (void)gb;
 }
 
+// ---- separator system, block pool (cyclic reduction), in ONE launch: a workgroup per separator forms the deferred part of its right-hand
+// interior's T_p itself -- LL = -sum_j Lb_j D_j Lb_j^T, gL = -sum_j Lb_j D_j v_j from the border panel in HBM, as ONE product on the matrix
+// cores: rows = border rows (+ one row holding v), K = (column block, column) of the interior -- and adds the window part of its
+// left-hand interior.  (k_bandp_border on P x 4 workgroups + a clear of the partials + k_bandp_sep: 20 + 7 + 20 us per LM trial at
+// 5000 keyframes; the sequential separator solve keeps those kernels.)
+#define BSF_T 512
+#define BSF_JC 32                           // interior column blocks per staged chunk: K = 192
+#define BSF_LD (6*BSF_JC + 2)               // row stride of the staged panel (doubles; = 2 mod 4)
+#define BSF_XR 80                           // staged rows: up to 78 border rows + the v row
+static size_t bandp_sepf_lds_doubles() { return (size_t)BSF_XR*BSF_LD + 6*BSF_JC + 8; }
+__global__ __launch_bounds__(BSF_T) void k_bandp_sepf(Work W, int bw, int Pmax, const double *Tbuf, const double *Lb, double *Ssep, double *gsep, int *nfree_sep) {
+    const LmState *st = W.st;
+    if (st->done || st->step_fail) return;
+    const int B = bw/6, nb = bandp_nb(W, B);
+    if (nb == 0) return;
+    const BandpPart P0 = bandp_part(nb, B, Pmax, 0, W.ring);
+    const int P = P0.P, nS = bw, nTm = 2*bw, REC = bw*6;
+    const size_t tsz = (size_t)nTm*nTm + nTm;
+    const int s = blockIdx.x, nsep = W.ring ? P + 1 : P - 1, mm = cr_mmax(W.ring, Pmax);
+    if (s == 0 && threadIdx.x == 0) *nfree_sep = nsep*B;
+    if (s >= nsep) return;
+    // ir: the interior whose RIGHT separator this is (its window part RR of T), il: the one whose LEFT separator it is (border products, coupling)
+    const int ir = W.ring ? s - 1 : s, il = W.ring ? (s < P ? s : -1) : s + 1;
+    const double *Ta = ir >= 0 ? Tbuf + (size_t)ir*tsz : nullptr, *Tb = il >= 0 ? Tbuf + (size_t)il*tsz : nullptr;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *X = smem, *dK = smem + (size_t)BSF_XR*BSF_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
+    // tiles of [border rows x d] [border rows | v]^T: the lower triangle of the 4 x 4 row tiles + column tile 3 (it holds v in column 60 ... nS)
+    // -- for nS <= 48 the v row sits in an earlier tile: every (ti, tj) with tj <= ti or tj == tv is computed
+    const int nrt = (nS + 15) >> 4, tv = nS >> 4;                 // row tiles of the border; column tile that holds the v row (row index nS)
+    const int nct = tv + 1;
+    v4d acc[3] = { {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0} };
+    int tti[3], ttj[3], ntl = 0;
+    {   int cnt = 0;                                             // tile list in a fixed order, dealt to the 8 waves round-robin (<= 3 each: 19 tiles at nS = 78)
+        for (int ti = 0; ti < nrt; ti++) for (int tj = 0; tj < nct; tj++) { if (!(tj <= ti || tj == tv)) continue;
+            if ((cnt & 7) == wave && ntl < 3) { tti[ntl] = ti; ttj[ntl] = tj; ntl++; }
+            cnt++; }
+    }
+    if (il >= 0) {
+        const BandpPart PT = bandp_part(nb, B, Pmax, il, W.ring);
+        const int xrows = min(BSF_XR, 16*(tv + 1));              // rows any tile reads
+        for (int j0 = PT.a; j0 < PT.b; j0 += BSF_JC) {
+            const int nj = min(BSF_JC, PT.b - j0);
+            __syncthreads();
+            // stage: X[k][6 jj + cc] = Lb_j[k][cc] (k < nS), X[nS][.] = v_j, the other rows and the columns past 6 nj zero; dK = d_j[cc].
+            // Pairs of doubles, eight per thread in flight.
+            const int npair = xrows*(3*BSF_JC);
+            for (int e0 = tid; e0 < npair; e0 += 8*BSF_T) {
+                v2d v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u*BSF_T, k = e/(3*BSF_JC), q = e - k*(3*BSF_JC), jj = q/3, c2 = 2*(q - 3*jj);
+                    v[u] = v2d{0.0, 0.0};
+                    if (e < npair && jj < nj) { if (k < nS) v[u] = *(const v2d *)(Lb + (size_t)(j0 + jj)*REC + k*6 + c2);
+                                                else if (k == nS) v[u] = *(const v2d *)(W.Sy + 6*(size_t)(j0 + jj) + c2); }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u*BSF_T, k = e/(3*BSF_JC), q = e - k*(3*BSF_JC), jj = q/3, c2 = 2*(q - 3*jj);
+                    if (e < npair) *(v2d *)(X + (size_t)k*BSF_LD + 6*jj + c2) = v[u];
+                }
+            }
+            for (int e = tid; e < 6*BSF_JC; e += BSF_T) { const int jj = e/6, cc = e - 6*jj; dK[e] = jj < nj ? 1.0/W.LDbuf[32*(size_t)(j0 + jj) + 16 + cc] : 0.0; }
+            __syncthreads();
+            for (int u = 0; u < ntl; u++) {
+                const double *pa = X + (size_t)(16*tti[u] + lr)*BSF_LD, *pb = X + (size_t)(16*ttj[u] + lr)*BSF_LD;
+                for (int k0 = 0; k0 < 6*nj; k0 += 16) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) { const int k = k0 + 4*w + lk; av[w] = pa[k]*dK[k]; bv[w] = pb[k]; }
+#pragma unroll
+                    for (int w = 0; w < 4; w++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[w], bv[w], acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- D_s (lower), g_s: window part of interior ir (or, ring separator 0, the diagonal block and gradient of S, g themselves) minus the products
+    const size_t ldS = (size_t)W.ldS;
+    double *Dss = cr_blk(Ssep, nS, mm, s, s);
+    if (il >= 0) for (int u = 0; u < ntl; u++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int R = 16*tti[u] + lk + 4*r, Q = 16*ttj[u] + lr;
+            if (R >= nS) continue;
+            if (Q <= R) Dss[(size_t)R*nS + Q] = (Ta ? Ta[(size_t)R*nTm + Q] : W.S[(size_t)R*ldS + Q]) - acc[u][r];
+            else if (Q == nS) gsep[nS*s + R] = (Ta ? (Ta + (size_t)nTm*nTm)[R] : W.g[R]) - acc[u][r];
+        }
+    }
+    if (il < 0) {                                                // (ring: the ghost separator has no interior on its right)
+        for (int e = tid; e < nS*nS; e += BSF_T) { const int i = e/nS, j = e - i*nS; if (j <= i) Dss[e] = Ta[(size_t)i*nTm + j]; }
+        for (int i = tid; i < nS; i += BSF_T) gsep[nS*s + i] = (Ta + (size_t)nTm*nTm)[i];
+        return;
+    }
+    // coupling to the next separator through interior il: T_il(border row i, right-separator column j) = S(sep s row i, sep s+1 col j)
+    const bool has_r = W.ring || il < P - 1;
+    if (has_r) { double *Cn = cr_blk(Ssep, nS, mm, s + 1, s);
+        for (int e = tid; e < nS*nS; e += BSF_T) { const int i = e/nS, j = e - i*nS; Cn[(size_t)j*nS + i] = Tb[(size_t)(nS + i)*nTm + j]; } }
+}
+
 // ---- back substitution of the interiors (right-looking, as k_band_backsub), both separator solutions known
 template <int NU>
 __global__ __launch_bounds__(BAND_BS_T) void k_bandp_backsub(Work W, int bw, int Pmax, const double *Lrow, const double *Lb, const double *xsep) {

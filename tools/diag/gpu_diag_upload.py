@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 opt = Optimizer(0)
+if len(sys.argv) > 1 and sys.argv[1] == "verbose": opt.debug_set(verbose=1)
 P = synth.config_c4(); o = abi.options_local()
 for k in range(4):
     G = P.copy(); t = time.time(); rep = opt.LocalBundleAdjustment(G, options=o); dt = (time.time() - t)*1e3
