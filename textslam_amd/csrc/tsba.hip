@@ -1856,6 +1856,7 @@ struct Ctx {
     bool pose_only = false;                       // one keyframe, every landmark frozen in its host: the fused pose-only LM kernel applies
     double *S_alloc = nullptr; size_t S_count = 0;
     int S_up = CH_NB;                               // band storage: columns stored right of the diagonal + 1
+    bool S_stale = true;                            // band storage: entries of another pass may be left in S (cleared before the next assembly)
     double *S_xchg = nullptr; int xchg_wp = 0;      // multi-GPU, band storage: packed band rows for the exchange (k_band_pack)
     bool sep_cr = false;                  // separator system by cyclic reduction on the compact block pool (tsba_bandcr.h)
     int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Bpart = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr, *CRcontrib = nullptr, *CRfac = nullptr; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
@@ -2355,7 +2356,7 @@ static void allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRe
 static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     const size_t x0 = c->x_acc;
     struct XP { Ctx *c; size_t x0; ~XP() { c->x_pass = c->x_acc - x0; } } xp{c, x0};
-    c->cur_bw_rows = D.bw_rows;
+    c->cur_bw_rows = D.bw_rows; c->S_stale = true;             // (a new pass: other free poses, other entries of S)
     c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
     Work &W = c->W; const tsba_options &o = c->opt;
     hipLaunchKernelGGL(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
@@ -2526,7 +2527,11 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream);   // block-sparse S
+    // block-sparse S: what no block of the plan covers must read as zero.  The streaming / partitioned band solvers leave S intact and a pass
+    // writes the same entries in every trial (the free poses are fixed at its start), so the band is cleared once per pass; the in-place
+    // Cholesky of the wide-band path needs it before every assembly -- and so does a sharded run (a rank assembles only its own blocks; the
+    // other entries hold the sums the last exchange unpacked)
+    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2 && (!c->band_stream || c->S_stale || is_multi(c))) { hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream); c->S_stale = false; }
     launch_schur(c, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
         if (c->S_xchg) {                           // band storage: only the band's entries travel
@@ -2746,7 +2751,7 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     launch_pass_init(c, D, 0);
     launch_linearize(c, D, 0);
     Work &W = c->W;
-    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream);
+    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) { hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream); c->S_stale = false; }
     // split (multi-GPU) sequence: this shard's PARTIAL S and g, before any exchange and without the pose damping (which is added
     // once after the all-reduce) -- the parts of all shards sum to the unsharded system; dp is not computed
     launch_schur(c, D, (int)is_multi(c));
