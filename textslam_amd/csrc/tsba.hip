@@ -2463,7 +2463,7 @@ static void launch_solve(Ctx *c) {
             if (c->dbg.sep_solver != 3) {      // one launch per level (tsba_bandcre.h); 3: the pivot / update / back kernels of tsba_bandcr.h
                 const int le = (int)(cre_elim_lds_doubles(bwp)*sizeof(double)), lbk = (int)(cre_back_lds_doubles(bwp)*sizeof(double));
                 for (int h = 1; h < mlev; h <<= 1) {
-                    const int npiv = (mmax + 2*h - 1)/(2*h), K = std::max(1, std::min(4, 224/npiv));     // workgroups per pivot (they share its product and stores)
+                    const int npiv = (mmax + 2*h - 1)/(2*h), K = std::max(1, std::min(TSBA_CRE_KMAX, 224/npiv));     // workgroups per pivot (they share its product and stores)
                     hipLaunchKernelGGL(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, c->CRcontrib, c->CRfac); htop = h; }
                 hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, W.ring ? 2 : 1, 1, c->CRcontrib, c->CRfac);
                 for (int h = htop; h >= 1; h >>= 1) hipLaunchKernelGGL(k_cre_back, dim3((mmax + 2*h - 1)/(2*h)), dim3(CRE_BT), lbk, c->stream, W, Ws, bwp, P, h, (const double *)c->CRfac);

@@ -22,6 +22,9 @@
 #ifndef CRE_PW
 #define CRE_PW 3                            // panel waves (58 rows each per round; up to s - 6 + 2 s + 1 = 229 rows below a diagonal block at s = 78). Measured at s = 60 (175 rows in the first step), 5000 keyframes, ms per solve: 2 waves 17.04 - 17.3, 3 waves 17.01, 4 waves (always one round) 17.26
 #endif
+#ifndef TSBA_CRE_KMAX
+#define TSBA_CRE_KMAX 4                      // most workgroups per pivot (k_cre_elim: they share the product and the stores)
+#endif
 #define CRE_BT 512
 __host__ __device__ __forceinline__ int cre_stride(int s) { return (s & 3) == 2 ? s : s + 2; }      // doubles; = 2 mod 4: b128 rows of 16 lanes hit 64 different banks
 __host__ __device__ __forceinline__ size_t cre_rec_doubles(int s) { return ((size_t)rowoff(s) + (size_t)SOLVE_LD*(s/6) + s + 1) & ~(size_t)1; }     // packed factor | LD table | z
