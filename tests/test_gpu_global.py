@@ -263,6 +263,28 @@ def test_loop_closure_ring_partition(gpu, n_kf, band, parts):
         gpu.debug_set()
 
 
+@pytest.mark.parametrize("n_kf,band,seed", [(120, 8, 21), (200, 8, 4)])
+def test_loop_closure_ring_with_text_planes(gpu, n_kf, band, seed):
+    """The ghost-row path with text planes in the problem (their slot pairs take the second loop of the Schur kernels; 120 keyframes: one
+    workgroup per S block, 200: four blocks per wave) against the reordering path."""
+    P = synth.make_problem(n_kf=n_kf, n_pt=30*n_kf, n_text=n_kf//4, seed=seed, feats=(12, 8, 6), max_targets=6, text_targets=4, frozen_frac=0.0,
+                           band=band, n_levels=1, rot_deg=0.2, trans_m=0.01, loop=True)
+    o = abi.options_global(); o.use_text = 1; o.its[0] = 6
+    try:
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        assert info["ring"] == 1 and info["kf_reordered"] == 0, info
+        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+        assert rep1["accepted"][0] >= 2 and rep1["termination"][0] != 5
+        gpu.debug_set(no_ring=1)
+        gpu.upload(P, o); assert gpu.solver_info()["ring"] == 0
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        _same_trajectory(rep1, rep2, G1, G2)
+        np.testing.assert_allclose(G1.theta, G2.theta, rtol=0, atol=1e-8)
+    finally:
+        gpu.debug_set()
+
+
 # ------------------------------------------------------------------------------------------------ N > 1 on one device
 def _on_ranks(world, fn):
     """Run fn(optimizer, rank) on `world` contexts of this process, one thread each, joined through the in-process communicator."""
