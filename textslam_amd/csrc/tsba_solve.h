@@ -35,6 +35,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 __host__ __device__ __forceinline__ int tri(int i) { return (i*(i + 1)) >> 1; }
 // packed lower triangle with every row padded to an even length: rows start 16-byte aligned, so the 6-wide pose blocks
 // (even column offsets) move as ds_read_b128 / ds_write_b128
+// (Rows padded to a length = 2 mod 4 -- neighbouring rows an odd number of 16-byte slots apart: fewer LDS bank conflicts, which the counters
+// show at 1.7 cycles per LDS instruction in k_bandp_factor -- were measured in round 2: C4 3.03 vs 2.84 ms, C6 16.35 vs 15.8 ms.  The longer
+// address arithmetic costs more than the conflicts: these kernels are bound by instruction issue.)
 __host__ __device__ __forceinline__ int rowoff(int i) { return ((i + 1) >> 1)*((i >> 1) + 1)*2; }
 __device__ __forceinline__ int tri_row(int e) {          // largest i with tri(i) <= e   (e < 2^22)
     int i = (int)((__fsqrt_rn(8.f*(float)e + 1.f) - 1.f)*0.5f);
