@@ -263,6 +263,26 @@ def test_loop_closure_ring_partition(gpu, n_kf, band, parts):
         gpu.debug_set()
 
 
+def test_loop_closure_with_a_tail_takes_the_reordering_path(gpu):
+    """The loop starts at keyframe 200 of 600 (a tail before the loop): not a ring -- the rows of S are reordered (reverse Cuthill-McKee), and the
+    result is that of the keyframe-order solve on the wide-band path."""
+    P = synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True, loop_at=200)
+    o = abi.options_global(); o.its[0] = 5
+    try:
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        assert info["ring"] == 0 and info["kf_reordered"] == 1 and info["band_stream"] == 1 and info["band_rows"] <= 6*3*8, info
+        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+        assert rep1["accepted"][0] >= 3 and rep1["termination"][0] != 5
+        gpu.debug_set(no_kf_reorder=1)
+        gpu.upload(P, o)
+        assert gpu.solver_info()["kf_reordered"] == 0
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        _same_trajectory(rep1, rep2, G1, G2)
+    finally:
+        gpu.debug_set()
+
+
 @pytest.mark.parametrize("n_kf,band,seed", [(120, 8, 21), (200, 8, 4)])
 def test_loop_closure_ring_with_text_planes(gpu, n_kf, band, seed):
     """The ghost-row path with text planes in the problem (their slot pairs take the second loop of the Schur kernels; 120 keyframes: one

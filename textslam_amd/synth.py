@@ -72,6 +72,17 @@ def _cam_ring(k, n, step=0.1):
     return Rcw, -Rcw @ c
 
 
+def _cam_lollipop(k, n, k0, step=0.1):
+    """T_cw of camera k of a trajectory that runs straight for k0 keyframes and then once around a circle back to keyframe k0: a loop closure
+    with a TAIL before the loop (the usual case: the loop does not start at the first keyframe)."""
+    if k >= k0:
+        return _cam_ring(k - k0, n - k0, step)
+    R0, t0 = _cam_ring(0, n - k0, step)
+    c0 = -R0.T @ t0                         # centre of the loop's first camera; the tail arrives along the tangent (+x at phi = 0)
+    c = c0 + np.array([-(k0 - k)*step, 0.02*np.sin(0.3*k) - 0.02*np.sin(0.0), 0.0])
+    return R0, -R0 @ c
+
+
 def _bilinear(img, u, v):
     h, w = img.shape
     uf, vf = np.floor(u).astype(int), np.floor(v).astype(int)
@@ -118,7 +129,7 @@ class _Plane:
 
 def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), max_targets=5, text_targets=5,
                  frozen_frac=0.1, outlier_frac=0.05, noise_px=0.5, perturb=True, n_levels=3,
-                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None, loop=False):
+                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None, loop=False, loop_at=0):
     """Build a synthetic window (local BA / pose-only / global BA depending on the arguments).
 
     n_kf == 1 with frozen_frac == 1 gives the pose-only problem (every landmark hosted outside).
@@ -131,7 +142,7 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
     P.n_levels = n_levels if n_text > 0 else 1
     band = band or n_kf
     # cameras: window 0..n_kf-1, outside hosts -1..-n_out
-    cams = {k: (_cam_ring(k, n_kf) if loop else _cam(k)) for k in range(-n_out, n_kf)}
+    cams = {k: ((_cam_lollipop(k, n_kf, loop_at) if loop_at > 0 else _cam_ring(k, n_kf)) if loop else _cam(k)) for k in range(-n_out, n_kf)}
     Rcw = np.stack([cams[k][0] for k in range(n_kf)])
     tcw = np.stack([cams[k][1] for k in range(n_kf)])
 
@@ -169,7 +180,8 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
             cand = rng.choice(n_kf, size=min(n_kf, 3 * max_targets), replace=False)
             cand.sort()
         elif h >= 0 and loop:
-            cand = np.sort((h + 1 + np.arange(min(band, n_kf - 1))) % n_kf)      # the ring closes: the last keyframes observe the first ones' landmarks
+            nxt = h + 1 + np.arange(min(band, n_kf - loop_at - 1))                  # the ring closes: the last keyframes observe the first ones' landmarks
+            cand = np.sort(np.where(nxt < n_kf, nxt, loop_at + (nxt - n_kf)))      # (a loop that starts at keyframe loop_at: its end runs into keyframe loop_at)
         elif h >= 0:
             cand = np.arange(h + 1, min(n_kf, h + 1 + band))
         else:
@@ -432,11 +444,11 @@ def config_c4(seed=SEED):
     return make_problem(20, 5000, 100, seed)
 
 
-def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0, loop=False):
+def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0, loop=False, loop_at=0):
     """C5 / C6: scene-only global BA (the reference's GlobalBA ignores text, optimizer.cc:1707).  loop: closed trajectory (the map right
     after a loop closure: the co-visibility graph is a ring, not a band)."""
     return make_problem(n_kf, n_pt, 0, seed, max_targets=max_targets, frozen_frac=0.0, band=band, far_frac=far_frac,
-                        n_levels=1, rot_deg=0.2, trans_m=0.01, loop=loop)
+                        n_levels=1, rot_deg=0.2, trans_m=0.01, loop=loop, loop_at=loop_at)
 
 
 def tiny(seed=7, n_kf=5, n_pt=60, n_text=4, **kw):
