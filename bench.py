@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--pts", type=int, default=70000, help="global_ba: map points (70k points -> ~500k observations)")
     ap.add_argument("--far", type=float, default=0.0, help="global_ba: fraction of loop-closure-like long-range observations")
     ap.add_argument("--loop", action="store_true", help="global_ba: closed trajectory (the map right after a loop closure: ring-shaped co-visibility)")
+    ap.add_argument("--loop-at", type=int, default=0, help="global_ba --loop: the loop starts at this keyframe (a tail before the loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-single", action="store_true", help="global_ba, N > 1: compare the N-rank result with the 1-rank solve")
     args = ap.parse_args()
@@ -210,7 +211,7 @@ def main():
     reference, check = None, None
     if workload == "global_ba":
         # one global BA sharded by landmark over the ranks: poses replicated, reduced normal equations exchanged over RCCL
-        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=10, far_frac=args.far, loop=args.loop)      # identical on every rank
+        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=10, far_frac=args.far, loop=args.loop, loop_at=args.loop_at)      # identical on every rank
         opt = abi.options_global()
         if world > 1:
             if rank == 0:                                  # the 1-GPU time of the SAME map, same run: the strong-scaling reference

@@ -263,20 +263,28 @@ def test_loop_closure_ring_partition(gpu, n_kf, band, parts):
         gpu.debug_set()
 
 
-def test_loop_closure_with_a_tail_takes_the_reordering_path(gpu):
-    """The loop starts at keyframe 200 of 600 (a tail before the loop): not a ring -- the rows of S are reordered (reverse Cuthill-McKee), and the
-    result is that of the keyframe-order solve on the wide-band path."""
-    P = synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True, loop_at=200)
-    o = abi.options_global(); o.its[0] = 5
+@pytest.mark.parametrize("n_kf,k0,band,parts", [(600, 200, 8, 0), (900, 450, 8, 0), (1500, 300, 7, 0), (1500, 300, 7, 8), (700, 30, 8, 0)])
+def test_loop_closure_with_a_tail(gpu, n_kf, k0, band, parts):
+    """The usual loop closure: the last keyframes meet keyframe k0 > 0 -- a tail before the loop.  The rows stay in keyframe order, the loop's first
+    poses are a separator in the MIDDLE of the chain with their ghost behind the last pose; the separator labels count from that separator (the
+    tail's downwards), and the cyclic reduction ends with it and the ghost (tsba_bandp.h: bandp_part_ring).  Against the reordering path.
+    (k0 = 30: a tail too short for an interior -- the plan keeps the reordering.)"""
+    P = synth.config_global(n_kf=n_kf, n_pt=20*n_kf, band=band, loop=True, loop_at=k0)
+    o = abi.options_global(); o.its[0] = 6
     try:
+        gpu.debug_set(band_parts=parts)
         gpu.upload(P, o)
         info = gpu.solver_info()
-        assert info["ring"] == 0 and info["kf_reordered"] == 1 and info["band_stream"] == 1 and info["band_rows"] <= 6*3*8, info
+        if k0 < 40:
+            assert info["ring"] == 0 and info["kf_reordered"] == 1, info
+            return
+        assert info["ring"] == 1 and info["kf_reordered"] == 0 and info["sep_cr"] == 1 and info["band_rows"] <= 6*(band + 3), info
         G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
-        assert rep1["accepted"][0] >= 3 and rep1["termination"][0] != 5
-        gpu.debug_set(no_kf_reorder=1)
+        assert rep1["accepted"][0] >= 3 and rep1["termination"][0] != 5 and rep1["cost1"][0] < rep1["cost0"][0]
+        gpu.debug_set(no_ring=1)
         gpu.upload(P, o)
-        assert gpu.solver_info()["kf_reordered"] == 0
+        info = gpu.solver_info()
+        assert info["ring"] == 0 and info["kf_reordered"] == 1, info
         G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
         _same_trajectory(rep1, rep2, G1, G2)
     finally:

@@ -90,8 +90,9 @@ struct Work {                // device work buffers (sized for the largest level
     long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
     double *LDbuf;                      // diagonal of the inverse diagonal factors (large-system Cholesky)
     int ldS, band;                      // S(i,j) = S[i*ldS + j]; band: S holds only the band of the reduced camera matrix (large systems)
-    int ring;                           // 1: ring-shaped co-visibility (one loop closure, tsba_plan.h): the closure blocks -- first against last poses -- live
-                                        // in ghost rows behind the last free pose (row = nfree + row of the early pose)
+    int ring;                           // 1: ring-shaped co-visibility (one loop closure, tsba_plan.h): the closure blocks -- the loop's first poses S against its last --
+                                        // live in ghost rows behind the last free pose (row = nfree + row - first row of S; nfree[1] = first row of S)
+    int ring_g, ring_b, ring_k0;        // interiors of the loop (worst case, a power of two); band = separator size in pose blocks; first keyframe of the loop
     double *Sy;                         // right-hand-side row of the large-system solver (row n of the small one lives in LDS)
     unsigned long long *hprog;          // pinned host word (seq << 32 | it << 1 | done): lets the host stop enqueuing a converged pass
     unsigned int pass_seq;
@@ -274,8 +275,9 @@ __global__ void k_gauge(Work W, const uint8_t *kf_initial, int state, int ncp, c
         for (int k = 0; k < W.n_kf && fixed < 3; k++) if (W.kf_in[k]) { W.kf_const[k] = 1; fixed++; }
     }
     int nf = 0;                                                // rows of S: free poses in keyframe order, or in the plan's order
-    for (int i = 0; i < W.n_kf; i++) { const int k = order ? order[i] : i; W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? nf++ : -1; }
-    *W.nfree = nf;
+    int row0 = 0;
+    for (int i = 0; i < W.n_kf; i++) { const int k = order ? order[i] : i; if (i == W.ring_k0) row0 = nf; W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? nf++ : -1; }
+    W.nfree[0] = nf; W.nfree[1] = row0;                         // (ring maps: free poses before the loop's first keyframe)
 }
 
 // windows of up to 64 keyframes: one lane per keyframe, ballots instead of the serial walk (7.8 -> ~2 us per pass)
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(64) void k_gauge_wave(Work W, const uint8_t *kf_ini
     const bool fre = in && !cst;
     const unsigned long long m_free = __ballot(fre);
     if (on) { W.kf_const[k] = cst; W.fidx[k] = fre ? __popcll(m_free & ((1ull << k) - 1)) : -1; }
-    if (k == 0) *W.nfree = __popcll(m_free);
+    if (k == 0) { W.nfree[0] = __popcll(m_free); W.nfree[1] = 0; }
 }
 // the same for large maps: 1024 threads, consecutive keyframes per thread, one block-wide exclusive scan for the compressed indices
 // (the single-thread walk above costs 1.4 ms at 5000 keyframes)
@@ -329,8 +331,10 @@ __global__ __launch_bounds__(1024) void k_gauge_par(Work W, const uint8_t *kf_in
     s_scan[tid] = nfree; __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) { const int t = tid >= d ? s_scan[tid - d] : 0; __syncthreads(); s_scan[tid] += t; __syncthreads(); }
     int at = s_scan[tid] - nfree;                              // exclusive prefix
-    for (int i = k0; i < k1; i++) { const int k = order ? order[i] : i; W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? at++ : -1; }
-    if (tid == 1023) *W.nfree = s_scan[1023];
+    if (tid == 0) W.nfree[1] = 0;
+    __syncthreads();
+    for (int i = k0; i < k1; i++) { const int k = order ? order[i] : i; if (i == W.ring_k0 && i > 0) W.nfree[1] = at; W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? at++ : -1; }
+    if (tid == 1023) W.nfree[0] = s_scan[1023];
 }
 
 // ---- mu / sigma of a projected text box: tool::GetProjText x4 + tool::CalTextinfo (src/tool.cc:1178-1262,1655-1728)
@@ -1261,7 +1265,8 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             // band storage holds the lower triangle: the block goes to the row of the pose that comes LATER in S (with a plan order
             // that need not be the larger keyframe index)
             int ja = ia, jc = ic;
-            if (W.ring) { const int nf = *W.nfree; if (ia - ic > nf/2) jc += nf; else if (ic - ia > nf/2) ja += nf; }     // closure block: the early pose's ghost row
+            if (W.ring) { const int nf = W.nfree[0], r0 = W.nfree[1];       // closure block (a pose of the loop's first separator against a far one): the ghost row
+                if (ia - ic > W.ring_b && ic >= r0 && ic < r0 + W.ring_b) jc += nf - r0; else if (ic - ia > W.ring_b && ia >= r0 && ia < r0 + W.ring_b) ja += nf - r0; }
             const bool a_later = ja > jc;
             if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
             if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
@@ -1427,7 +1432,8 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
     double *tile = lds + grp*12*17;
     const size_t ldS = (size_t)W.ldS;
     int ja = ia, jc = ic;
-    if (W.ring) { const int nf = *W.nfree; if (ia - ic > nf/2) jc += nf; else if (ic - ia > nf/2) ja += nf; }     // closure block: the early pose's ghost row
+    if (W.ring) { const int nf = W.nfree[0], r0 = W.nfree[1];               // closure block (a pose of the loop's first separator against a far one): the ghost row
+        if (ia - ic > W.ring_b && ic >= r0 && ic < r0 + W.ring_b) jc += nf - r0; else if (ic - ia > W.ring_b && ia >= r0 && ia < r0 + W.ring_b) ja += nf - r0; }
     const bool a_later = ja > jc;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
@@ -2131,7 +2137,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     UP(W.tobs_kf, p->tobs_kf, p->n_tobs); UP(W.tobs_text, p->tobs_text, p->n_tobs); UP(W.tobs_fgood_off, p->tobs_fgood_off, (size_t)p->n_tobs + 1);
     AL(W.musig, 2*(size_t)p->n_tobs);
     AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
-    AL(W.fidx, p->n_kf); AL(W.nfree, 1); AL(W.dbg, 64); AL(W.LDbuf, 32*((size_t)p->n_kf + BAND_BW_MAX/6 + 1));     // (+ the ghost blocks of a ring map)
+    AL(W.fidx, p->n_kf); AL(W.nfree, 2); AL(W.dbg, 64); AL(W.LDbuf, 32*((size_t)p->n_kf + BAND_BW_MAX/6 + 1));     // (+ the ghost blocks of a ring map)
     // ---- per-level plans
     size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1;
     for (int ps = 0; ps < o->n_passes; ps++) {
@@ -2209,13 +2215,14 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         // solvers read the band only (up = 6: the diagonal pose block is stored square) -- 72 instead of 251 columns per row at a band of
         // 60, and the band is cleared before every Schur assembly (60 MB per LM trial at 5000 keyframes with the wide rows)
         const bool stream_ok = bwmax >= 6 && bwmax <= BAND_BW_MAX && band_chunk_blocks(bwmax) > 0 && !c->dbg.no_band_stream;
-        int ring = 0; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l] && c->hplan[l].ring) ring = 1;     // (a ring plan is only built for single-level solves)
+        int ring = 0, ring_k0 = 0; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l] && c->hplan[l].ring) { ring = 1; ring_k0 = c->hplan[l].ring_k0; }     // (a ring plan is only built for single-level solves)
+        int ring_G = 0;
         const size_t nrow = (size_t)W.N + (ring ? bwmax : 0);                                                 // + the ghost rows of the first separator
         c->S_up = stream_ok ? 6 : CH_NB;
         const size_t LDB = stream_ok ? (size_t)bwmax + 12 : (size_t)bwmax + 2*CH_NB - 1;
         if (use_lds_ || (size_t)bwmax + 2*CH_NB - 1 >= (size_t)W.N) { c->S_count = (size_t)(W.N + 1)*W.N; AL(c->S_alloc, c->S_count); W.S = c->S_alloc; W.ldS = W.N; W.band = 0; }
         else { c->S_count = nrow*LDB + LDB; AL(c->S_alloc, c->S_count); W.S = c->S_alloc + (LDB - c->S_up); W.ldS = (int)LDB - 1; W.band = 1; }
-        W.ring = 0;
+        W.ring = 0; W.ring_g = 0; W.ring_b = 0; W.ring_k0 = -1;
         c->Lcol = nullptr; c->band_stream = 0; c->sep_cr = false;
         if (W.band && stream_ok) {
             AL(c->Lcol, ((size_t)p->n_kf + bwmax/6 + 1)*bwmax*6); c->band_stream = 1;
@@ -2247,14 +2254,18 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             if (c->dbg.sep_solver >= 2 && bwmax <= CR_SMAX) want_cr = true;
             if (c->dbg.band_parts > 0) P = c->dbg.band_parts;
             P = std::max(1, std::min(P, BANDP_MAXP));
-            if (ring) {                       // ring: a power of two interiors (the separator tree ends in separator 0 and its ghost), cyclic reduction only
-                const int cap = c->dbg.band_parts > 0 ? c->dbg.band_parts : 128;
-                int Pr = 4; while (2*Pr <= cap && (p->n_kf + Bq - (2*Pr + 1)*Bq)/(2*Pr) >= 2*Bq + 8) Pr *= 2;
-                P = Pr; want_cr = true;
+            if (ring) {                       // ring: a power of two interiors in the loop (the separator tree ends in its first separator and the ghost), cyclic reduction only
+                const int cap = c->dbg.band_parts > 0 ? c->dbg.band_parts : 128, nloop = p->n_kf - ring_k0;
+                int Pr = 4; while (2*Pr <= cap && (nloop - 2*Pr*Bq)/(2*Pr) >= 2*Bq + 8) Pr *= 2;
+                ring_G = Pr;
+                int Pt = 0;                   // a tail before the loop: interiors of about the loop's size, at most as many as the loop has
+                if (ring_k0 > 0) { const int ql = (nloop - Pr*Bq)/Pr; Pt = std::max(1, std::min(Pr, (ring_k0 + ql/2)/(ql + Bq)));
+                    while (Pt > 1 && (ring_k0 - (Pt - 1)*Bq)/Pt < 2*Bq + 8) Pt--; }
+                P = Pr + Pt; want_cr = true;
             }
             while (!ring && P > 1 && (p->n_kf - (P - 1)*Bq)/P < ((c->dbg.band_parts > 0 || want_cr) ? 2*Bq + 2 : 4*Bq + 4)) P--;     // (2 B + 2: the least the kernels take; the sequential separator solve pays only for interiors of a few bands)
             if (P > 1 && bandp_chunk_blocks(bwmax) > 0 && 2*bwmax - 6 <= BAND_BW_MAX && band_chunk_blocks(2*bwmax - 6) > 0) {
-                const int nsepb = ring ? P + 1 : P - 1;                         // separators (ring: the last one is the ghost of the first)
+                const int nsepb = cr_mmax(ring, P, ring_G);                     // separator labels (ring: the last one is the ghost of the loop's first separator)
                 const int nsep = nsepb*bwmax, bws = 2*bwmax - 6;
                 c->nsep_ld = nsep;
                 AL(c->Lb, ((size_t)p->n_kf + bwmax/6 + 1)*bwmax*6); AL(c->Tbuf, (size_t)P*((size_t)4*bwmax*bwmax + 2*bwmax));
@@ -2267,7 +2278,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
                 Ws.N = nsep; Ws.n_kf = 0; Ws.S = c->Ssep; Ws.ldS = nsep; Ws.band = 1; Ws.st = nullptr;       // (st is set at launch: W.st is allocated below)
                 AL(Ws.Sy, nsep); AL(Ws.g, nsep); AL(Ws.dp, nsep); AL(Ws.LDbuf, 32*(size_t)(nsep/6 + 1)); AL(Ws.nfree, 1); AL(Ws.fidx, 1);
                 c->band_parts = P;
-                W.ring = (ring && c->sep_cr) ? 1 : 0;
+                W.ring = (ring && c->sep_cr) ? 1 : 0; W.ring_g = ring_G; W.ring_b = bwmax/6; W.ring_k0 = W.ring ? ring_k0 : -1;
             } else c->band_parts = 1;
         }
         if (ring && !W.ring) { set_err(c, "ring-shaped map: the partitioned band solver is not available for this plan"); return TSBA_ERR_STATE; }
@@ -2449,24 +2460,27 @@ static void launch_solve(Ctx *c) {
         Work &Ws = c->Wsep; Ws.st = W.st; Ws.ldS = (P - 1)*bwp; Ws.N = (P - 1)*bwp;
         if (!c->sep_cr) hipMemsetAsync(c->Ssep, 0, sizeof(double)*((size_t)Ws.ldS*Ws.ldS + Ws.ldS), c->stream);
         hipLaunchKernelGGL(k_bandp_factor, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
-        if (c->sep_cr && c->dbg.sep_solver != 3 && c->dbg.sep_solver != 4)      // block pool: border products + separator assembly in one launch (4: the three launches, for A/B runs)
+        if (c->sep_cr && (W.ring || (c->dbg.sep_solver != 3 && c->dbg.sep_solver != 4)))      // block pool: border products + separator assembly in one launch (4: the three launches, for A/B runs)
             hipLaunchKernelGGL(k_bandp_sepf, dim3(W.ring ? P + 1 : P - 1), dim3(BSF_T), (int)(bandp_sepf_lds_doubles()*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Lb, c->Ssep, Ws.g, Ws.nfree);
         else {
         hipMemsetAsync(c->Bpart, 0, sizeof(double)*(size_t)P*BANDP_NS*((size_t)bwp*bwp + bwp), c->stream);        // (slices of short interiors stay empty)
         hipLaunchKernelGGL(k_bandp_border, dim3(P, BANDP_NS), dim3(256), (int)((2*(size_t)BANDP_JC*bwp*6 + 6*BANDP_JC)*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Lb, c->Bpart);
-        hipLaunchKernelGGL(k_bandp_sep, dim3(W.ring ? P + 1 : P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
+        hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
         }
         if (c->sep_cr) {                  // separator system by block cyclic reduction (tsba_bandcr.h): log2(P - 1) levels
-            const int mmax = cr_mmax(W.ring, P), mlev = W.ring ? mmax - 1 : mmax;      // (ring: blocks 0 and mmax - 1 are merged at the root, no level for the ghost)
+            const int mmax = cr_mmax(W.ring, P, W.ring_g), mlev = W.ring ? W.ring_g : mmax;      // (ring: the root and the ghost are merged at the root, no level for them)
+            const int lab0 = W.ring && P > W.ring_g ? RING_OFF - (P - W.ring_g) + 1 : 0;          // lowest separator label (a ring with a tail counts down from RING_OFF)
             const int lp = (int)(cr_pivot_lds_doubles(bwp)*sizeof(double)), lu = (int)(cr_update_lds_doubles(bwp)*sizeof(double)), lb = (int)(cr_back_lds_doubles(bwp)*sizeof(double));
             int htop = 1;
-            if (c->dbg.sep_solver != 3) {      // one launch per level (tsba_bandcre.h); 3: the pivot / update / back kernels of tsba_bandcr.h
+            if (c->dbg.sep_solver != 3 || W.ring) {      // one launch per level (tsba_bandcre.h); 3: the pivot / update / back kernels of tsba_bandcr.h
                 const int le = (int)(cre_elim_lds_doubles(bwp)*sizeof(double)), lbk = (int)(cre_back_lds_doubles(bwp)*sizeof(double));
+                auto pivots = [&](int h, int &kb) { kb = lab0/(2*h); const int klast = (mmax - 1 - h)/(2*h); return std::max(0, klast - kb + 1); };     // pivots (2 k + 1) h, k = kb ..
                 for (int h = 1; h < mlev; h <<= 1) {
-                    const int npiv = (mmax + 2*h - 1)/(2*h), K = std::max(1, std::min(TSBA_CRE_KMAX, 224/npiv));     // workgroups per pivot (they share its product and stores)
-                    hipLaunchKernelGGL(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, c->CRcontrib, c->CRfac); htop = h; }
-                hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, W.ring ? 2 : 1, 1, c->CRcontrib, c->CRfac);
-                for (int h = htop; h >= 1; h >>= 1) hipLaunchKernelGGL(k_cre_back, dim3((mmax + 2*h - 1)/(2*h)), dim3(CRE_BT), lbk, c->stream, W, Ws, bwp, P, h, (const double *)c->CRfac);
+                    int kb; const int npiv = pivots(h, kb); if (npiv <= 0) { htop = h; continue; }
+                    const int K = std::max(1, std::min(TSBA_CRE_KMAX, 224/npiv));     // workgroups per pivot (they share its product and stores)
+                    hipLaunchKernelGGL(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, kb, c->CRcontrib, c->CRfac); htop = h; }
+                hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, W.ring ? 2 : 1, 1, 0, c->CRcontrib, c->CRfac);
+                for (int h = htop; h >= 1; h >>= 1) { int kb; const int npiv = pivots(h, kb); if (npiv > 0) hipLaunchKernelGGL(k_cre_back, dim3(npiv), dim3(CRE_BT), lbk, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac); }
             } else {
             for (int h = 1; h < mmax; h <<= 1) {
                 const int npiv = (mmax + 2*h - 1)/(2*h);           // >= the pivots (2k + 1) h < m; workgroups past the end return
@@ -2765,10 +2779,10 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
             for (long long i = 0; i < N; i++) for (long long j = 0; j < N; j++)
                 S[i*N + j] = (j >= i - Wb && j <= i + c->S_up - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0;
             if (W.ring) {                     // the loop-closure blocks: ghost row 6 nfree + r stands for row r of the first poses (lower triangle: (late pose, early pose))
-                int nf = 0; CK(hipMemcpy(&nf, W.nfree, sizeof(int), hipMemcpyDeviceToHost));
-                const long long n6 = 6LL*nf, ng = std::min<long long>(Wb, N);
+                int nfr[2] = {0, 0}; CK(hipMemcpy(nfr, W.nfree, 2*sizeof(int), hipMemcpyDeviceToHost));
+                const long long n6 = 6LL*nfr[0], r06 = 6LL*nfr[1], ng = std::min<long long>(6LL*W.ring_b, N);
                 for (long long r = 0; r < ng && n6 + r < (long long)(c->S_count/LDB); r++) for (long long j = std::max(0LL, n6 + r - Wb); j < n6; j++) {
-                    const double v = hb[(size_t)(Wb + (n6 + r)*(LDB - 1) + j)]; if (v != 0.0 && j > r) S[j*N + r] = v; }
+                    const double v = hb[(size_t)(Wb + (n6 + r)*(LDB - 1) + j)]; if (v != 0.0 && j > r06 + r) S[j*N + r06 + r] = v; }
             } }
     }
     if (g) CK(hipMemcpy(g, W.g, sizeof(double)*W.N, hipMemcpyDeviceToHost));
@@ -2953,9 +2967,12 @@ int tsba_debug_plan_ring(const tsba_problem *p, const tsba_options *o, int level
     if (!p || !o || !bw_pose || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
     HostPlan H; build_plan(p, o, level, H, false, true, ring_max_blocks);
     *bw_pose = H.bw_pose;
-    return H.ring;
+    return H.ring ? 1 + 16*H.ring_k0 : 0;     // (the first keyframe of the loop in the upper bits: 0 = the whole trajectory)
 }
-void tsba_debug_bandp_part_ring(int nb, int B, int Pmax, int p, int *out5) { const BandpPart r = bandp_part(nb, B, Pmax, p, 1); out5[0] = r.P; out5[1] = r.a; out5[2] = r.b; out5[3] = r.has_left; out5[4] = r.has_right; }
+void tsba_debug_bandp_part_ring(int nb, int B, int Pmax, int p, int *out5) { const BandpPart r = bandp_part_ring(nb - B, 0, B, Pmax, Pmax, p); out5[0] = r.P; out5[1] = r.a; out5[2] = r.b; out5[3] = r.has_left; out5[4] = r.has_right; }
+// ring with a tail: nf free poses, the loop starts at free row row0; out8 = P, a, b, has_left, has_right, G, Pt, label of the left separator
+void tsba_debug_bandp_part_ring2(int nf, int row0, int B, int Pmax, int Gmax, int p, int *out8) { const BandpPart r = bandp_part_ring(nf, row0, B, Pmax, Gmax, p);
+    out8[0] = r.P; out8[1] = r.a; out8[2] = r.b; out8[3] = r.has_left; out8[4] = r.has_right; out8[5] = r.G; out8[6] = r.Pt; out8[7] = r.lblL; }
 void tsba_debug_bandp_part(int nb, int B, int Pmax, int p, int *out5) { const BandpPart r = bandp_part(nb, B, Pmax, p); out5[0] = r.P; out5[1] = r.a; out5[2] = r.b; out5[3] = r.has_left; out5[4] = r.has_right; }
 long long tsba_debug_cr_blk_index(int mmax, int br, int bc) { return (long long)cr_blk_index(mmax, br, bc); }
 long long tsba_debug_cr_pool_blocks(int mmax) { return (long long)cr_pool_blocks(mmax); }

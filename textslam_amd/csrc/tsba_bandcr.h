@@ -19,9 +19,17 @@
 static size_t cr_pivot_lds_doubles(int s) { return (size_t)s*(s + 1) + (size_t)s*(2*s + 1) + s; }
 static size_t cr_back_lds_doubles(int s) { return 3*(size_t)s*(s + 1) + 5*(size_t)s; }
 
-__device__ __forceinline__ int cr_nsep(const Work &W, int bw, int Pmax) {      // separators of the system (ring: P + 1, the last one the ghost of the first)
-    const int nb = bandp_nb(W, bw/6); if (nb <= 0) return 0;
-    const int P = bandp_part(nb, bw/6, Pmax, 0, W.ring).P; return W.ring ? P + 1 : P - 1; }
+// separator labels of the system: lo .. m - 1, root r0 (ring maps: merged with label m - 1, the ghost of the loop's first separator)
+struct CrRange { int lo, m, r0; };
+__device__ __forceinline__ CrRange cr_range(const Work &W, int bw, int Pmax) {
+    CrRange r = {0, 0, 0};
+    const int nf = *W.nfree; if (nf <= 0) return r;
+    const BandpPart P0 = bandp_part_w(W, bw/6, Pmax, 0);
+    if (W.ring) { const int off = P0.Pt > 0 ? RING_OFF : 0; r.r0 = off; r.lo = P0.Pt > 0 ? off - P0.Pt + 1 : off; r.m = off + P0.G + 1; }
+    else r.m = P0.P - 1;
+    return r;
+}
+__device__ __forceinline__ int cr_nsep(const Work &W, int bw, int Pmax) { return cr_range(W, bw, Pmax).m; }      // (chain: the number of separators)
 
 // n elements through f(index) -> value and st(index, value), 16 per thread in flight (a plain copy loop waits for every load before it
 // issues the next: ~0.6 us each)

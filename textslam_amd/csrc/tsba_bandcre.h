@@ -47,13 +47,16 @@ __device__ __forceinline__ void cre_batched(int n, int tid, F f, G st) {
 // K workgroups per pivot: all of them run the same factorisation (bit-identical: same instruction sequence on the same data), then
 // share the product and the stores -- E D E^T is 36 tiles x 15 fp64 MFMA of 64 cycles at s = 60, 8.6 k cycles of ONE compute unit's four
 // matrix pipes, and three quarters of the chip idle next to the 32 pivots of the first level.
-__global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int Pmax, int h, int root, int K, double *contrib, double *fac) {
+__global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int Pmax, int h, int root, int K, int kb, double *contrib, double *fac) {
     LmState *st = W.st;
     if (st->done || st->step_fail) return;
-    const int m = cr_nsep(W, bw, Pmax), s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax);
+    const CrRange rg = cr_range(W, bw, Pmax);
+    const int m = rg.m, lo = rg.lo, r0 = rg.r0, s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
     int i, a, c;
-    if (root) { if (blockIdx.x > 0 || m <= 0) return; i = 0; a = -1; c = -1; }
-    else { i = (2*((int)blockIdx.x/K) + 1)*h; if (i >= m || (W.ring && i == m - 1)) return; a = i - h; c = i + h < m ? i + h : -1; }     // (ring: block m - 1 is the ghost of block 0, never a pivot)
+    if (root) { if (blockIdx.x > 0 || m <= 0) return; i = r0; a = -1; c = -1; }
+    else { i = (2*(kb + (int)blockIdx.x/K) + 1)*h;               // (kb: the first pivot the host launches -- labels of a ring with a tail do not start at 0)
+        if (i < lo || i >= m || (W.ring && i == m - 1)) return;  // (ring: label m - 1 is the ghost of the root, never a pivot)
+        a = i - h >= lo ? i - h : -1; c = i + h < m ? i + h : -1; }
     const int part = root ? 0 : (int)blockIdx.x % K;
     const int H = root ? (1 << 30) : h;                          // pending updates come from the pivots i -+ h', h' < H
     const int na = a >= 0 ? s : 0, nc = c >= 0 ? s : 0, ne = na + nc + 1, n = s + ne - 1;     // rows 0 .. n, row n = g_i
@@ -84,26 +87,27 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
             double p[16];
 #pragma unroll
             for (int l = 0; l < 8; l++) {
-                const int hp = 1 << l; const bool on = hp < H && hp < m;
-                p[2*l] = (on && left && blk - hp > 0) ? contrib[(size_t)(blk - hp)*csz + offL + idx] : 0.0;
-                p[2*l + 1] = (on && right && blk + hp < m - (W.ring ? 1 : 0)) ? contrib[(size_t)(blk + hp)*csz + offR + idx] : 0.0;
+                const int hp = 1 << l; const bool on = hp < H && hp < m - lo;
+                // (a producer is a pivot: not the root, not the ghost)
+                p[2*l] = (on && left && blk - hp >= lo && blk - hp != r0) ? contrib[(size_t)(blk - hp)*csz + offL + idx] : 0.0;
+                p[2*l + 1] = (on && right && blk + hp < m - (W.ring ? 1 : 0) && blk + hp != r0) ? contrib[(size_t)(blk + hp)*csz + offR + idx] : 0.0;
             }
 #pragma unroll
             for (int l = 0; l < 16; l++) v -= p[l];
             return v;
         };
-        auto pending = [&](size_t offL, size_t offR, size_t idx, double v) { return pending_of(i, !root, true, offL, offR, idx, v); };
+        auto pending = [&](size_t offL, size_t offR, size_t idx, double v) { return pending_of(i, true, true, offL, offR, idx, v); };
         if (root == 2) {
             // ring: blocks 0 and m - 1 are the same unknowns (m - 1 is the ghost of the first poses behind the last one): the root block is
             // D_0 + D_{m-1} + S(m-1, 0) + S(m-1, 0)^T with both blocks' pending updates, the gradient the sum of both
-            const double *BiiP = cr_blk(S, s, mmax, m - 1, m - 1), *Bp0 = cr_blk(S, s, mmax, m - 1, 0);
+            const double *BiiP = cr_blk(S, s, mmax, m - 1, m - 1), *Bp0 = cr_blk(S, s, mmax, m - 1, r0);
             for (int e = tid; e < tri(s); e += CRE_T) {
                 const int r = tri_row(e), q = e - tri(r); const size_t idx = (size_t)r*s + q;
-                const double v0 = pending_of(0, false, true, ss, 0, idx, Bii[idx]), v1 = pending_of(m - 1, true, false, ss, 0, idx, BiiP[idx]);
+                const double v0 = pending_of(r0, true, true, ss, 0, idx, Bii[idx]), v1 = pending_of(m - 1, true, false, ss, 0, idx, BiiP[idx]);
                 A[r*sst + q] = (v0 + v1) + (Bp0[idx] + Bp0[(size_t)q*s + r]);
             }
             for (int q = tid; q < s; q += CRE_T)
-                A[n*sst + q] = pending_of(0, false, true, 2*ss + s, 2*ss, (size_t)q, g[q]) + pending_of(m - 1, true, false, 2*ss + s, 2*ss, (size_t)q, g[(size_t)(m - 1)*s + q]);
+                A[n*sst + q] = pending_of(r0, true, true, 2*ss + s, 2*ss, (size_t)q, g[(size_t)r0*s + q]) + pending_of(m - 1, true, false, 2*ss + s, 2*ss, (size_t)q, g[(size_t)(m - 1)*s + q]);
         } else {
         for (int e = tid; e < tri(s); e += CRE_T) {
             const int r = tri_row(e), q = e - tri(r); const size_t idx = (size_t)r*s + q;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
         if (wave == 0) {
             solve_backsub_wave(Pk, LD, s, B, lane);
             wave_lds_fence();
-            for (int k = lane; k < s; k += 64) { Ws.Sy[k] = Pk[rowoff(s) + k]; if (root == 2) Ws.Sy[(size_t)(m - 1)*s + k] = Pk[rowoff(s) + k]; }
+            for (int k = lane; k < s; k += 64) { Ws.Sy[(size_t)r0*s + k] = Pk[rowoff(s) + k]; if (root == 2) Ws.Sy[(size_t)(m - 1)*s + k] = Pk[rowoff(s) + k]; }
         }
         return;
     }
@@ -318,10 +322,10 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
 // x_i = L^-T (z_i - X_a^T x_a - X_c^T x_c) -> Ws.Sy
 // Every address is known from the launch arguments (the pool is laid out for the worst case mmax): all loads are issued before the solver
 // state and the number of separators are looked at -- one global round trip instead of two (-1.4 us per level).
-__global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, int Pmax, int h, const double *fac) {
+__global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, int Pmax, int h, int kb, const double *fac) {
     const LmState *st = W.st;
-    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax), tid = threadIdx.x, lane = tid & 63;
-    const int i = (2*(int)blockIdx.x + 1)*h;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), tid = threadIdx.x, lane = tid & 63;
+    const int i = (2*(kb + (int)blockIdx.x) + 1)*h;
     if (i >= mmax) return;
     const int a = i - h, cmx = i + h < mmax ? i + h : -1;        // (c exists if cmx < m: decided below)
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -343,18 +347,22 @@ __global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, in
     cre_batched<CRE_BT, 8>(xbase, tid, [&](int e) { return rec[e]; }, [&](int e, double v) { A[e] = v; });
     for (int k = tid; k < SOLVE_LD*B; k += CRE_BT) LD[k] = rec[xbase + k];
     if (done || sfail) return;
-    int m = 0;
-    if (nb > 0) { const int P = bandp_part(W.ring ? nb + B : nb, B, Pmax, 0, W.ring).P; m = W.ring ? P + 1 : P - 1; }
-    if (i >= m || (W.ring && i == m - 1)) return;                // (ring: block m - 1 is the ghost of block 0, solved with it)
+    if (nb <= 0) return;
+    const CrRange rg = cr_range(W, bw, Pmax);
+    const int m = rg.m;
+    if (i < rg.lo || i >= m || (W.ring && i == m - 1)) return;   // (ring: label m - 1 is the ghost of the root, solved with it)
+    const bool has_a = a >= rg.lo;                               // (the first separator of a tail has no left neighbour)
     const int nx = (cmx >= 0 && cmx < m) ? 2*s : s;              // rows of [X_a ; X_c]
-    if (tid < 2*s) xs[tid] = xin;
+    if (tid < 2*s) xs[tid] = (tid < s && !has_a) ? 0.0 : xin;
+#pragma unroll
+    for (int u = 0; u < UB; u++) if (grp + 4*u < s && !has_a) xv[u] = 0.0;
     __syncthreads();
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < UB; u++) { const int r = grp + 4*u; if (r < nx) acc = fma(xv[u], xs[r], acc); }
     for (int r0 = grp + 4*UB; r0 < nx; r0 += 4*UB) {
 #pragma unroll
-        for (int u = 0; u < UB; u++) { const int r = r0 + 4*u; xv[u] = (col < s && r < nx) ? xrow(r)[col] : 0.0; }
+        for (int u = 0; u < UB; u++) { const int r = r0 + 4*u; xv[u] = (col < s && r < nx && (r >= s || has_a)) ? xrow(r)[col] : 0.0; }
 #pragma unroll
         for (int u = 0; u < UB; u++) { const int r = r0 + 4*u; if (r < nx) acc = fma(xv[u], xs[r], acc); }
     }

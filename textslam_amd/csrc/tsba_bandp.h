@@ -24,37 +24,56 @@
 #define BANDP_PW 2                          // panel waves of k_bandp_factor
 #endif
 
-struct BandpPart { int P, a, b, has_left, has_right; };
+struct BandpPart { int P, a, b, has_left, has_right, G, Pt, lblL; };      // ring maps: G interiors in the loop, Pt in the tail, label of the left separator (right = + 1)
+#define RING_OFF 128                        // ring with a tail: the loop's first separator has label RING_OFF, the tail's separators count down from it
 // interiors of q = (nb - (P - 1) B) / P blocks -- the first `rem` of them one more: the launch lasts as long as its longest interior, and a
 // last interior that took the whole remainder was 85 blocks against 68 at 5000 keyframes / P = 64 --, separators of B blocks between
 // them; P shrinks until an interior holds at least 2 B + 2 blocks
-__device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax, int p, int ring = 0) {
+__device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax, int p) {
     BandpPart r;
-    if (ring) {
-        // ring (one loop closure, tsba_plan.h): nb counts the B ghost blocks behind the last pose.  [sep 0][interior 0][sep 1] ... [interior
-        // P-1][sep P = ghost of sep 0]: P interiors (a power of two: the separator tree ends in blocks 0 and P, which are the same
-        // unknowns), P + 1 separators, every interior has both neighbours
-        int P = Pmax;
-        while (P > 2 && (nb - (P + 1)*B)/P < 2*B + 2) P >>= 1;
-        r.P = P;
-        const int tot = nb - (P + 1)*B, q = tot/P, rem = tot - q*P;
-        r.a = B + p*(q + B) + (p < rem ? p : rem); r.b = r.a + q + (p < rem ? 1 : 0);
-        if (p == P - 1) r.b = nb - B;
-        r.has_left = 1; r.has_right = 1;
-        return r;
-    }
     int P = Pmax;
     while (P > 1 && (nb - (P - 1)*B)/P < 2*B + 2) P--;
-    r.P = P;
+    r.P = P; r.G = 0; r.Pt = 0; r.lblL = p - 1;
     const int tot = nb - (P - 1)*B, q = tot/P, rem = tot - q*P;
     r.a = p*(q + B) + (p < rem ? p : rem); r.b = r.a + q + (p < rem ? 1 : 0);
     if (p == P - 1) r.b = nb;
     r.has_left = p > 0; r.has_right = p < P - 1;
     return r;
 }
+// Ring maps (one loop closure, tsba_plan.h).  nf free poses in keyframe order, the loop starts at free row row0 (0: the loop is the whole
+// trajectory), B ghost blocks follow the last pose:   [tail: interior, sep, ..., interior][S = first B rows of the loop][interior, sep, ...,
+// interior][ghost of S].   G interiors in the loop -- a power of two: the separator tree must end with S and its ghost, which are the
+// same unknowns --, Pt <= G in the tail (then no tail separator survives the level at which S and the ghost become neighbours).
+// Separator labels: S = off, the loop's separators off + 1 .. off + G - 1, the ghost off + G, the tail's off - 1, off - 2, ... towards the
+// start (off = RING_OFF with a tail, 0 without): interior p has the separators off - Pt + p and off - Pt + p + 1 on its sides.
+__device__ __host__ __forceinline__ BandpPart bandp_part_ring(int nf, int row0, int B, int Pmax, int Gmax, int p) {
+    BandpPart r;
+    const int na = nf - row0;                                    // S + the loop
+    int G = Gmax; while (G > 2 && (na - G*B)/G < 2*B + 2) G >>= 1;
+    int Pt = 0;
+    if (row0 > 0) { Pt = Pmax - Gmax < G ? Pmax - Gmax : G; if (Pt < 1) Pt = 1; while (Pt > 1 && (row0 - (Pt - 1)*B)/Pt < 2*B + 2) Pt--; }
+    r.G = G; r.Pt = Pt; r.P = G + Pt; r.lblL = (Pt > 0 ? RING_OFF : 0) - Pt + p;
+    if (p < Pt) {
+        const int tot = row0 - (Pt - 1)*B, q = tot/Pt, rem = tot - q*Pt;
+        r.a = p*(q + B) + (p < rem ? p : rem); r.b = r.a + q + (p < rem ? 1 : 0);
+        if (p == Pt - 1) r.b = row0;
+        r.has_left = p > 0; r.has_right = 1;
+    } else {
+        const int pp = p - Pt, tot = na - G*B, q = tot/G, rem = tot - q*G;
+        r.a = row0 + B + pp*(q + B) + (pp < rem ? pp : rem); r.b = r.a + q + (pp < rem ? 1 : 0);
+        if (pp == G - 1) r.b = nf;
+        r.has_left = 1; r.has_right = 1;
+    }
+    return r;
+}
 // number of pose blocks the band solvers walk (ring: the ghost separator behind the last free pose), separators of the system, pool size
 __device__ __forceinline__ int bandp_nb(const Work &W, int B) { const int nf = *W.nfree; return nf > 0 && W.ring ? nf + B : nf; }
-__device__ __host__ __forceinline__ int cr_mmax(int ring, int Pmax) { return ring ? Pmax + 1 : Pmax - 1; }
+__device__ __forceinline__ BandpPart bandp_part_w(const Work &W, int B, int Pmax, int p) {       // the partition every kernel of a launch derives
+    const int nf = *W.nfree;
+    return W.ring ? bandp_part_ring(nf, W.nfree[1], B, Pmax, W.ring_g, p) : bandp_part(nf, B, Pmax, p);
+}
+// separator labels run below this bound (pool, slots and solution are indexed by label)
+__device__ __host__ __forceinline__ int cr_mmax(int ring, int Pmax, int Gmax) { return ring ? (Pmax > Gmax ? RING_OFF : 0) + Gmax + 1 : Pmax - 1; }
 static size_t bandp_lds_doubles(int bw, int cb) {               // window + border rows + rhs row, LD table, scratch
     const int rows = 6*cb + 2*bw;
     return (size_t)rowoff(rows + 2) + 16 + (size_t)SOLVE_LD*((6*cb + bw)/6) + 36*BANDP_PW + 8 + 64;
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
     if (st->done || st->step_fail) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
-    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x, W.ring);
+    const BandpPart PT = bandp_part_w(W, B, Pmax, blockIdx.x);
     if ((int)blockIdx.x >= PT.P) return;
     const int nbr = PT.has_left ? bw : 0;                       // border rows: the left separator
     const int row_lim = 6*(PT.has_right ? PT.b + B : PT.b);     // rows of the band this workgroup ever holds
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, 
     if (st->done || st->step_fail) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
-    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x, W.ring);
+    const BandpPart PT = bandp_part_w(W, B, Pmax, blockIdx.x);
     if ((int)blockIdx.x >= PT.P || !PT.has_left) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int nbr = bw, REC = bw*6, tid = threadIdx.x;
@@ -471,32 +490,8 @@ __global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, con
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
     const int B = bw/6, nb = bandp_nb(W, B);
-    const BandpPart P0 = bandp_part(nb, B, Pmax, 0, W.ring);
+    const BandpPart P0 = bandp_part_w(W, B, Pmax, 0);
     const int P = P0.P, nS = bw, nTm = 2*bw;
-    const size_t tsz = (size_t)nTm*nTm + nTm, psz = (size_t)nS*nS + nS;
-    if (W.ring) {
-        // ring: separators 0 .. P, separator s LEFT of interior s and RIGHT of interior s - 1.  Separator 0 has no interior on its left (its
-        // diagonal block and gradient come straight from S, g), separator P -- the ghost rows -- none on its right; cyclic reduction ties
-        // the two together at the root.  Block pool only.
-        if (blockIdx.x == 0 && threadIdx.x == 0) *nfree_sep = (P + 1)*B;
-        const int s = blockIdx.x, mm = cr_mmax(1, Pmax);
-        if (s > P) return;
-        const double *Ta = s >= 1 ? Tbuf + (size_t)(s - 1)*tsz : nullptr;        // interior s - 1: this separator is its RIGHT one
-        const double *Tb = s < P ? Tbuf + (size_t)s*tsz : nullptr;                // interior s: this separator is its LEFT one (border rows of T)
-        const double *pp = part + (size_t)s*BANDP_NS*psz;
-        const size_t ldS = (size_t)W.ldS;
-        for (int e = threadIdx.x; e < nS*nS; e += 256) {
-            const int i = e/nS, j = e - i*nS;
-            if (j <= i) { double v = Ta ? Ta[(size_t)i*nTm + j] : W.S[(size_t)i*ldS + j];
-                if (Tb) for (int sl = 0; sl < BANDP_NS; sl++) v += pp[(size_t)sl*psz + (size_t)i*nS + j];
-                cr_blk(Ssep, nS, mm, s, s)[(size_t)i*nS + j] = v; }
-            if (Tb) cr_blk(Ssep, nS, mm, s + 1, s)[(size_t)j*nS + i] = Tb[(size_t)(nS + i)*nTm + j];     // T_s(border row i, right-separator column j) = S(sep s row i, sep s+1 col j)
-        }
-        for (int i = threadIdx.x; i < nS; i += 256) { double v = Ta ? (Ta + (size_t)nTm*nTm)[i] : W.g[i];
-            if (Tb) for (int sl = 0; sl < BANDP_NS; sl++) v += pp[(size_t)sl*psz + (size_t)nS*nS + i];
-            gsep[nS*s + i] = v; }
-        return;
-    }
     if (blockIdx.x == 0 && threadIdx.x == 0) *nfree_sep = (P - 1)*B;
     const int s = blockIdx.x;                                    // separator s sits between interiors s and s + 1
     if (s >= P - 1) return;
@@ -533,14 +528,19 @@ __global__ __launch_bounds__(BSF_T) void k_bandp_sepf(Work W, int bw, int Pmax, 
     if (st->done || st->step_fail) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
-    const BandpPart P0 = bandp_part(nb, B, Pmax, 0, W.ring);
+    const BandpPart P0 = bandp_part_w(W, B, Pmax, 0);
     const int P = P0.P, nS = bw, nTm = 2*bw, REC = bw*6;
     const size_t tsz = (size_t)nTm*nTm + nTm;
-    const int s = blockIdx.x, nsep = W.ring ? P + 1 : P - 1, mm = cr_mmax(W.ring, Pmax);
-    if (s == 0 && threadIdx.x == 0) *nfree_sep = nsep*B;
-    if (s >= nsep) return;
-    // ir: the interior whose RIGHT separator this is (its window part RR of T), il: the one whose LEFT separator it is (border products, coupling)
-    const int ir = W.ring ? s - 1 : s, il = W.ring ? (s < P ? s : -1) : s + 1;
+    // separator labels (pool, right-hand side and solution are indexed by label): chain s = 0 .. P - 2 between interiors s and s + 1; ring maps
+    // lo .. off + G (bandp_part_ring): ir = the interior whose RIGHT separator this is (its window part RR of T; none for a loop without a tail's
+    // first separator), il = the one whose LEFT separator it is (border products, coupling; none for the ghost)
+    const int mm = cr_mmax(W.ring, Pmax, W.ring_g);
+    const int off = W.ring && P0.Pt > 0 ? RING_OFF : 0, lo = W.ring ? (P0.Pt > 0 ? off - P0.Pt + 1 : off) : 0;
+    const int nsep = W.ring ? off + P0.G - lo + 1 : P - 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nfree_sep = nsep*B;
+    if ((int)blockIdx.x >= nsep) return;
+    const int s = lo + (int)blockIdx.x;
+    const int ir = W.ring ? s - off + P0.Pt - 1 : s, il = ir + 1 < P ? ir + 1 : -1;
     const double *Ta = ir >= 0 ? Tbuf + (size_t)ir*tsz : nullptr, *Tb = il >= 0 ? Tbuf + (size_t)il*tsz : nullptr;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *X = smem, *dK = smem + (size_t)BSF_XR*BSF_LD;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(BSF_T) void k_bandp_sepf(Work W, int bw, int Pmax, 
             cnt++; }
     }
     if (il >= 0) {
-        const BandpPart PT = bandp_part(nb, B, Pmax, il, W.ring);
+        const BandpPart PT = bandp_part_w(W, B, Pmax, il);
         const int xrows = min(BSF_XR, 16*(tv + 1));              // rows any tile reads
         for (int j0 = PT.a; j0 < PT.b; j0 += BSF_JC) {
             const int nj = min(BSF_JC, PT.b - j0);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(BSF_T) void k_bandp_sepf(Work W, int bw, int Pmax, 
         return;
     }
     // coupling to the next separator through interior il: T_il(border row i, right-separator column j) = S(sep s row i, sep s+1 col j)
-    const bool has_r = W.ring || il < P - 1;
+    const bool has_r = W.ring || il < P - 1;                   // (every interior of a ring map has a separator on its right)
     if (has_r) { double *Cn = cr_blk(Ssep, nS, mm, s + 1, s);
         for (int e = tid; e < nS*nS; e += BSF_T) { const int i = e/nS, j = e - i*nS; Cn[(size_t)j*nS + i] = Tb[(size_t)(nS + i)*nTm + j]; } }
 }
@@ -626,18 +626,17 @@ __global__ __launch_bounds__(BAND_BS_T) void k_bandp_backsub(Work W, int bw, int
     if (st->done || st->step_fail) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
-    const BandpPart PT = bandp_part(nb, B, Pmax, blockIdx.x, W.ring);
+    const BandpPart PT = bandp_part_w(W, B, Pmax, blockIdx.x);
     if ((int)blockIdx.x >= PT.P) return;
     const int REC = bw*6, NTASK = 6*B, RECB = 2*REC + 32;
     const int r_lo = PT.a, r_hi = PT.has_right ? PT.b + B : PT.b;          // row blocks walked: [r_lo, r_hi), the top B of them given
     double *buf0 = smem, *buf1 = smem + (size_t)BAND_CK*RECB, *ring = buf1 + (size_t)BAND_CK*RECB, *xL = ring + 6*BAND_RINGB, *xR = xL + bw;
     for (int k = tid; k < 6*BAND_RINGB; k += BAND_BS_T) ring[k] = 0.0;
     for (int k = tid; k < bw; k += BAND_BS_T) {
-        // (separator s lies LEFT of interior s in a ring -- where separator 0 comes first --, RIGHT of it otherwise)
-        xL[k] = PT.has_left ? xsep[(size_t)bw*(W.ring ? blockIdx.x : blockIdx.x - 1) + k] : 0.0;
-        xR[k] = PT.has_right ? xsep[(size_t)bw*(W.ring ? blockIdx.x + 1 : blockIdx.x) + k] : 0.0;
+        xL[k] = PT.has_left ? xsep[(size_t)bw*PT.lblL + k] : 0.0;
+        xR[k] = PT.has_right ? xsep[(size_t)bw*(PT.lblL + 1) + k] : 0.0;
         if (PT.has_right) W.Sy[6*PT.b + k] = xR[k];              // the separator's solution goes to its rows of x
-        if (W.ring && blockIdx.x == 0) W.Sy[k] = xL[k];          // (ring: nobody has separator 0 on its right but the ghost rows)
+        if (W.ring && PT.Pt == 0 && blockIdx.x == 0) W.Sy[k] = xL[k];     // (a loop without a tail: nobody has its first separator on its right but the ghost rows)
     }
     const int nrows = r_hi - r_lo, nchunk = (nrows + BAND_CK - 1)/BAND_CK;
     auto stage = [&](int chunk, double *buf, int t0, int nt) {

@@ -25,8 +25,9 @@ static int tsba_plan_threads = 0;              // 0: by problem size; > 0: host 
 struct HostPlan {
     int level = 0;
     int bw_pose = 0;                            // half bandwidth of the reduced camera matrix in pose blocks, fill included
-    int ring = 0;                               // 1: the co-visibility graph is a RING (one loop closure between the last and the first keyframes): bw_pose is the band of
-                                                // the chain unrolled past its end -- the first bw_pose poses re-appear as ghost rows behind the last pose (tsba_bandp.h)
+    int ring_k0 = 0;                            // ring: the loop starts at this keyframe (0: the whole trajectory is the loop; > 0: a tail before it)
+    int ring = 0;                               // 1: the co-visibility graph is a RING (one loop closure between the last keyframes and keyframe ring_k0): bw_pose is the band of
+                                                // the chain unrolled past its end -- the loop's first bw_pose poses re-appear as ghost rows behind the last pose (tsba_bandp.h)
     std::vector<int32_t> kf_order;              // empty: S is ordered by keyframe index; else kf_order[i] = keyframe at position i (reverse Cuthill-McKee)
     // scene candidates (sorted by pair)
     std::vector<int32_t> sc_obs, sc_kf, sc_pt, sc_flag, sc_slot;
@@ -373,7 +374,33 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 if (ok && wraps) {
                     int run = -1, bwr = 0;
                     for (int k = 0; k < nu; k++) { const int r = (run >= k) ? std::max(cu[k], run) : cu[k]; run = std::max(run, r); bwr = std::max(bwr, r - k); }
-                    if (bwr >= 1 && bwr <= RB && n_kf >= 4*(3*bwr + 2) + bwr) { P.ring = 1; P.bw_pose = bwr; }
+                    if (bwr >= 1 && bwr <= RB && n_kf >= 4*(3*bwr + 2) + bwr) { P.ring = 1; P.bw_pose = bwr; P.ring_k0 = 0; }
+                }
+                // The usual loop closure: the last keyframes meet keyframe k0 > 0 -- a ring with a tail.  The rows stay in keyframe order; a landmark that
+                // spans the closure counts its early poses (the loop's first ones) as n_kf + (k - k0): the ghost rows behind the last pose.
+                if (!P.ring) {
+                    int k0 = n_kf, klow = -1, ncl = 0; bool okc = true;
+                    for (const auto &v : poses_of) { if (v.size() < 2 || v.back() - v[0] <= RB) continue;
+                        size_t at = 1; for (size_t x = 2; x < v.size(); x++) if (v[x] - v[x - 1] > v[at] - v[at - 1]) at = x;
+                        if (v[at - 1] - v[0] > RB || v.back() - v[at] > RB || v[at] < n_kf - 2*RB) { okc = false; break; }
+                        k0 = std::min(k0, v[0]); klow = std::max(klow, v[at - 1]); ncl++; }
+                    if (okc && ncl > 0 && klow - k0 < RB && k0 >= 3*RB + 8 && n_kf - k0 >= 4*(3*RB + 2) + RB) {
+                        const int nu2 = n_kf + RB + 1;
+                        std::vector<int> c2(nu2); for (int k = 0; k < nu2; k++) c2[k] = k;
+                        bool ok2 = true; int gmax = -1;
+                        for (const auto &v : poses_of) { if (v.size() < 2) continue;
+                            int lo = v[0], hi = v.back();
+                            if (hi - lo > RB) { lo = nu2; hi = -1;                       // spans the closure: its early poses as ghosts
+                                for (int k : v) { const int u = (k >= k0 && k < k0 + RB) ? n_kf + (k - k0) : k; if (u != k) gmax = std::max(gmax, k - k0);
+                                    lo = std::min(lo, u); hi = std::max(hi, u); } }
+                            if (hi - lo > RB) { ok2 = false; break; }
+                            c2[lo] = std::max(c2[lo], hi); }
+                        if (ok2) {
+                            int run = -1, bwr = 0;
+                            for (int k = 0; k < nu2; k++) { const int r = (run >= k) ? std::max(c2[k], run) : c2[k]; run = std::max(run, r); bwr = std::max(bwr, r - k); }
+                            if (bwr >= 1 && bwr <= RB && gmax < bwr) { P.ring = 1; P.bw_pose = bwr; P.ring_k0 = k0; }
+                        }
+                    }
                 }
             }
             if (!P.ring) {
