@@ -153,12 +153,16 @@ def test_ring_plan_of_a_loop_closure_map():
         return r, bw.value
     P = synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True)
     r, bw = ring(P, 13)
-    assert r == 1 and 8 <= bw <= 11                          # the open chain's band (+ fill), not the 23 of the reordered rows
+    assert r == 1 and 8 <= bw <= 11                          # the open chain's band (+ fill), not the 23 of the reordered rows (upper bits: first keyframe of the loop = 0)
     bw_rcm, _ = _plan_band(P, o, 1)
     assert bw_rcm >= 2*bw - 4
     assert ring(P, 6)[0] == 0                                 # separators of at most 6 pose blocks cannot hold a band of 8
     assert ring(P, 0)[0] == 0                                 # not asked for (multi-GPU, several pyramid levels)
     assert ring(synth.config_global(n_kf=600, n_pt=12000, band=8), 13)[0] == 0                  # open chain
+    r, bw = ring(synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True, loop_at=200), 13) # a tail before the loop: keyframe order kept, the loop starts at 200
+    assert r & 15 == 1 and r >> 4 == 200 and 8 <= bw <= 11
+    assert ring(synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True, loop_at=30), 13)[0] == 0     # a tail too short for an interior
+    assert ring(synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True, loop_at=480), 13)[0] == 0    # a loop too short for four interiors
     assert ring(synth.config_global(n_kf=600, n_pt=12000, band=8, far_frac=0.02), 13)[0] == 0   # long-range observations: not a ring
 
 
@@ -175,3 +179,23 @@ def test_plan_does_not_depend_on_the_number_of_host_threads():
         assert ref != 0
         for t in (2, 3, 7, 16):
             assert L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, t) == ref, t
+
+
+@pytest.mark.parametrize("nf,row0,B,Gmax,Ptmax", [(598, 199, 8, 16, 8), (4998, 1499, 10, 128, 55), (1498, 299, 7, 64, 16), (898, 449, 8, 32, 32), (300, 60, 9, 8, 8)])
+def test_ring_partition_with_a_tail(lib, nf, row0, B, Gmax, Ptmax):
+    """[tail: interior, sep, ..., interior][S][loop: interior, sep, ..., interior][ghost of S]: the interiors and separators tile the rows, the
+    loop has a power of two of interiors, the tail at most as many, and the separator labels run upwards from the tail's first separator
+    through S = RING_OFF = 128 to the ghost."""
+    lib.tsba_debug_bandp_part_ring2.argtypes = [C.c_int]*6 + [C.POINTER(C.c_int)]; lib.tsba_debug_bandp_part_ring2.restype = None
+    def part(p):
+        o = (C.c_int*8)(); lib.tsba_debug_bandp_part_ring2(nf, row0, B, Gmax + Ptmax, Gmax, p, o); return list(o)
+    P, _, _, _, _, G, Pt, _ = part(0)
+    assert P == G + Pt and G & (G - 1) == 0 and 2 <= G <= Gmax and 1 <= Pt <= min(G, Ptmax)
+    pos = 0
+    for p in range(P):
+        Pp, a, b, hl, hr, Gp, Ptp, lbl = part(p)
+        assert (Pp, Gp, Ptp) == (P, G, Pt) and a == pos and b > a and hr == 1 and hl == (p > 0) and lbl == 128 - Pt + p
+        assert b - a >= 2*B + 2 or (p < Pt and Pt == 1) or G == 2
+        pos = b + B                                              # the separator on its right
+        if p == Pt - 1: assert b == row0                         # the tail ends where S begins
+    assert pos == nf + B                                         # the ghost of S behind the last pose

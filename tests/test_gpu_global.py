@@ -424,10 +424,11 @@ def test_multi_rank_band_solver_and_text(gpu):
         np.testing.assert_allclose(G.theta, G1.theta, rtol=0, atol=1e-9)
 
 
-def test_multi_rank_ring_map(gpu):
-    """N = 2 on a loop-closure map: every rank recognises the ring from ALL observations, keeps its shard's closure blocks in the ghost
-    rows, and the ghost rows travel with the packed band."""
-    P = synth.config_global(n_kf=400, n_pt=12000, band=8, loop=True)
+@pytest.mark.parametrize("k0", [0, 150])
+def test_multi_rank_ring_map(gpu, k0):
+    """N = 2 on a loop-closure map (k0 = 150: a tail before the loop): every rank recognises the ring from ALL observations, keeps its shard's
+    closure blocks in the ghost rows, and the ghost rows travel with the packed band."""
+    P = synth.config_global(n_kf=400, n_pt=12000, band=8, loop=True, loop_at=k0)
     o = abi.options_global(); o.its[0] = 6
     G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
     assert gpu.solver_info()["ring"] == 1
