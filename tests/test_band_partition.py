@@ -181,16 +181,16 @@ def test_plan_does_not_depend_on_the_number_of_host_threads():
             assert L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, t) == ref, t
 
 
-@pytest.mark.parametrize("nf,row0,B,Gmax,Ptmax", [(598, 199, 8, 16, 8), (4998, 1499, 10, 128, 55), (1498, 299, 7, 64, 16), (898, 449, 8, 32, 32), (300, 60, 9, 8, 8)])
+@pytest.mark.parametrize("nf,row0,B,Gmax,Ptmax", [(598, 199, 8, 16, 8), (4998, 1499, 10, 128, 55), (1498, 299, 7, 64, 16), (898, 449, 8, 32, 32), (300, 60, 9, 8, 8), (1498, 999, 7, 16, 40)])
 def test_ring_partition_with_a_tail(lib, nf, row0, B, Gmax, Ptmax):
     """[tail: interior, sep, ..., interior][S][loop: interior, sep, ..., interior][ghost of S]: the interiors and separators tile the rows, the
-    loop has a power of two of interiors, the tail at most as many, and the separator labels run upwards from the tail's first separator
+    loop has a power of two of interiors, the tail fewer than 128, and the separator labels run upwards from the tail's first separator
     through S = RING_OFF = 128 to the ghost."""
     lib.tsba_debug_bandp_part_ring2.argtypes = [C.c_int]*6 + [C.POINTER(C.c_int)]; lib.tsba_debug_bandp_part_ring2.restype = None
     def part(p):
         o = (C.c_int*8)(); lib.tsba_debug_bandp_part_ring2(nf, row0, B, Gmax + Ptmax, Gmax, p, o); return list(o)
     P, _, _, _, _, G, Pt, _ = part(0)
-    assert P == G + Pt and G & (G - 1) == 0 and 2 <= G <= Gmax and 1 <= Pt <= min(G, Ptmax)
+    assert P == G + Pt and G & (G - 1) == 0 and 2 <= G <= Gmax and 1 <= Pt <= min(127, Ptmax)
     pos = 0
     for p in range(P):
         Pp, a, b, hl, hr, Gp, Ptp, lbl = part(p)

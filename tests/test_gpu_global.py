@@ -263,7 +263,7 @@ def test_loop_closure_ring_partition(gpu, n_kf, band, parts):
         gpu.debug_set()
 
 
-@pytest.mark.parametrize("n_kf,k0,band,parts", [(600, 200, 8, 0), (900, 450, 8, 0), (1500, 300, 7, 0), (1500, 300, 7, 8), (700, 30, 8, 0)])
+@pytest.mark.parametrize("n_kf,k0,band,parts", [(600, 200, 8, 0), (900, 450, 8, 0), (1500, 300, 7, 0), (1500, 300, 7, 8), (1500, 1000, 7, 0), (700, 30, 8, 0)])
 def test_loop_closure_with_a_tail(gpu, n_kf, k0, band, parts):
     """The usual loop closure: the last keyframes meet keyframe k0 > 0 -- a tail before the loop.  The rows stay in keyframe order, the loop's first
     poses are a separator in the MIDDLE of the chain with their ghost behind the last pose; the separator labels count from that separator (the

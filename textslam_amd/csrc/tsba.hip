@@ -2258,8 +2258,8 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
                 const int cap = c->dbg.band_parts > 0 ? c->dbg.band_parts : 128, nloop = p->n_kf - ring_k0;
                 int Pr = 4; while (2*Pr <= cap && (nloop - 2*Pr*Bq)/(2*Pr) >= 2*Bq + 8) Pr *= 2;
                 ring_G = Pr;
-                int Pt = 0;                   // a tail before the loop: interiors of about the loop's size, at most as many as the loop has
-                if (ring_k0 > 0) { const int ql = (nloop - Pr*Bq)/Pr; Pt = std::max(1, std::min(Pr, (ring_k0 + ql/2)/(ql + Bq)));
+                int Pt = 0;                   // a tail before the loop: interiors of about the loop's size
+                if (ring_k0 > 0) { const int ql = (nloop - Pr*Bq)/Pr; Pt = std::max(1, std::min(std::min(RING_OFF - 1, BANDP_MAXP - Pr), (ring_k0 + ql/2)/(ql + Bq)));
                     while (Pt > 1 && (ring_k0 - (Pt - 1)*Bq)/Pt < 2*Bq + 8) Pt--; }
                 P = Pr + Pt; want_cr = true;
             }
@@ -2468,7 +2468,10 @@ static void launch_solve(Ctx *c) {
         hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
         }
         if (c->sep_cr) {                  // separator system by block cyclic reduction (tsba_bandcr.h): log2(P - 1) levels
-            const int mmax = cr_mmax(W.ring, P, W.ring_g), mlev = W.ring ? W.ring_g : mmax;      // (ring: the root and the ghost are merged at the root, no level for them)
+            const int mmax = cr_mmax(W.ring, P, W.ring_g);
+            int mlev = mmax;                  // levels h < mlev.  Ring: the loop's separators need h <= G/2 (the root and the ghost are merged at the root, no level for them),
+            if (W.ring) { mlev = W.ring_g;    // a tail's separator RING_OFF - j the level of the lowest set bit of j (j < the number of tail interiors)
+                for (int hh = 1; hh < P - W.ring_g; hh <<= 1) mlev = std::max(mlev, 2*hh); }
             const int lab0 = W.ring && P > W.ring_g ? RING_OFF - (P - W.ring_g) + 1 : 0;          // lowest separator label (a ring with a tail counts down from RING_OFF)
             const int lp = (int)(cr_pivot_lds_doubles(bwp)*sizeof(double)), lu = (int)(cr_update_lds_doubles(bwp)*sizeof(double)), lb = (int)(cr_back_lds_doubles(bwp)*sizeof(double));
             int htop = 1;

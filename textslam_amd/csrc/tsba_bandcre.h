@@ -88,9 +88,11 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
 #pragma unroll
             for (int l = 0; l < 8; l++) {
                 const int hp = 1 << l; const bool on = hp < H && hp < m - lo;
-                // (a producer is a pivot: not the root, not the ghost)
-                p[2*l] = (on && left && blk - hp >= lo && blk - hp != r0) ? contrib[(size_t)(blk - hp)*csz + offL + idx] : 0.0;
-                p[2*l + 1] = (on && right && blk + hp < m - (W.ring ? 1 : 0) && blk + hp != r0) ? contrib[(size_t)(blk + hp)*csz + offR + idx] : 0.0;
+                // (a producer is a pivot of level hp -- the lowest set bit of its label --: not the root, not the ghost; the ghost of a ring with a long
+                // tail is hp = 2 G away from a tail pivot of level G that is no neighbour of it)
+                const int pl = blk - hp, pr = blk + hp;
+                p[2*l] = (on && left && pl >= lo && pl != r0 && (pl & (2*hp - 1)) == hp) ? contrib[(size_t)pl*csz + offL + idx] : 0.0;
+                p[2*l + 1] = (on && right && pr < m - (W.ring ? 1 : 0) && pr != r0 && (pr & (2*hp - 1)) == hp) ? contrib[(size_t)pr*csz + offR + idx] : 0.0;
             }
 #pragma unroll
             for (int l = 0; l < 16; l++) v -= p[l];

@@ -19,7 +19,7 @@
 // Every workgroup derives the same partition table from the number of free poses on the device (the host does not know it).
 #pragma once
 
-#define BANDP_MAXP 160
+#define BANDP_MAXP 256
 #ifndef BANDP_PW
 #define BANDP_PW 2                          // panel waves of k_bandp_factor
 #endif
@@ -43,7 +43,8 @@ __device__ __host__ __forceinline__ BandpPart bandp_part(int nb, int B, int Pmax
 // Ring maps (one loop closure, tsba_plan.h).  nf free poses in keyframe order, the loop starts at free row row0 (0: the loop is the whole
 // trajectory), B ghost blocks follow the last pose:   [tail: interior, sep, ..., interior][S = first B rows of the loop][interior, sep, ...,
 // interior][ghost of S].   G interiors in the loop -- a power of two: the separator tree must end with S and its ghost, which are the
-// same unknowns --, Pt <= G in the tail (then no tail separator survives the level at which S and the ghost become neighbours).
+// same unknowns --, Pt < RING_OFF in the tail (its separators are eliminated at the levels of their labels like any other; the ghost is
+// never a pivot, S never an odd multiple of a level's stride below RING_OFF).
 // Separator labels: S = off, the loop's separators off + 1 .. off + G - 1, the ghost off + G, the tail's off - 1, off - 2, ... towards the
 // start (off = RING_OFF with a tail, 0 without): interior p has the separators off - Pt + p and off - Pt + p + 1 on its sides.
 __device__ __host__ __forceinline__ BandpPart bandp_part_ring(int nf, int row0, int B, int Pmax, int Gmax, int p) {
@@ -51,7 +52,7 @@ __device__ __host__ __forceinline__ BandpPart bandp_part_ring(int nf, int row0, 
     const int na = nf - row0;                                    // S + the loop
     int G = Gmax; while (G > 2 && (na - G*B)/G < 2*B + 2) G >>= 1;
     int Pt = 0;
-    if (row0 > 0) { Pt = Pmax - Gmax < G ? Pmax - Gmax : G; if (Pt < 1) Pt = 1; while (Pt > 1 && (row0 - (Pt - 1)*B)/Pt < 2*B + 2) Pt--; }
+    if (row0 > 0) { Pt = Pmax - Gmax < RING_OFF - 1 ? Pmax - Gmax : RING_OFF - 1; if (Pt < 1) Pt = 1; while (Pt > 1 && (row0 - (Pt - 1)*B)/Pt < 2*B + 2) Pt--; }
     r.G = G; r.Pt = Pt; r.P = G + Pt; r.lblL = (Pt > 0 ? RING_OFF : 0) - Pt + p;
     if (p < Pt) {
         const int tot = row0 - (Pt - 1)*B, q = tot/Pt, rem = tot - q*Pt;
@@ -71,6 +72,13 @@ __device__ __forceinline__ int bandp_nb(const Work &W, int B) { const int nf = *
 __device__ __forceinline__ BandpPart bandp_part_w(const Work &W, int B, int Pmax, int p) {       // the partition every kernel of a launch derives
     const int nf = *W.nfree;
     return W.ring ? bandp_part_ring(nf, W.nfree[1], B, Pmax, W.ring_g, p) : bandp_part(nf, B, Pmax, p);
+}
+// the same out of line, for k_bandp_factor: the kernel sits at its register cap, and the partition arithmetic inlined into it moved the
+// allocation of the step loop (+5 us per launch).  Returns (a, b, has_left | has_right << 1, P).
+__device__ __noinline__ int4 bandp_part_call(const int *nfree, int ring, int ring_g, int B, int Pmax, int p) {
+    const int nf = nfree[0];
+    const BandpPart r = ring ? bandp_part_ring(nf, nfree[1], B, Pmax, ring_g, p) : bandp_part(nf, B, Pmax, p);
+    return make_int4(r.a, r.b, r.has_left | (r.has_right << 1), r.P);
 }
 // separator labels run below this bound (pool, slots and solution are indexed by label)
 __device__ __host__ __forceinline__ int cr_mmax(int ring, int Pmax, int Gmax) { return ring ? (Pmax > Gmax ? RING_OFF : 0) + Gmax + 1 : Pmax - 1; }
@@ -235,7 +243,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
     if (st->done || st->step_fail) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
-    const BandpPart PT = bandp_part_w(W, B, Pmax, blockIdx.x);
+    BandpPart PT;
+    { const int4 q = bandp_part_call(W.nfree, W.ring, W.ring_g, B, Pmax, blockIdx.x); PT.a = q.x; PT.b = q.y; PT.has_left = q.z & 1; PT.has_right = q.z >> 1; PT.P = q.w; }
     if ((int)blockIdx.x >= PT.P) return;
     const int nbr = PT.has_left ? bw : 0;                       // border rows: the left separator
     const int row_lim = 6*(PT.has_right ? PT.b + B : PT.b);     // rows of the band this workgroup ever holds
