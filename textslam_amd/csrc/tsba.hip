@@ -1937,7 +1937,7 @@ static void free_problem(Ctx *c) {
     // the slabs stay (tsba_destroy frees them): zero what the last problem used, restart the bump allocation
     for (Slab &sl : c->slabs) { if (sl.used) hipMemsetAsync(sl.dev, 0, sl.used, c->stream); sl.used = 0; }
     c->cur_slab = 0; c->run_len = 0;
-    c->uploaded = false; c->hplan.clear(); c->lev.clear(); c->lev_built.clear();
+    c->uploaded = false; c->lev.clear(); c->lev_built.clear();      // (the host plans keep their storage for the next upload: HostPlan::recycle)
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) c->img_dev[l].clear();
 }
 

@@ -57,6 +57,17 @@ struct HostPlan {
     int n_pslot() const { return (int)pslot_pose.size(); }
     int n_tslot() const { return (int)tslot_pose.size(); }
     int n_sb() const { return (int)sb_a.size(); }
+    // a new plan into the same object (a context builds one per call: per keyframe for the local BA): scalars reset, every list emptied with its
+    // storage kept -- no allocation, no page faults for lists of the size the last call needed
+    void recycle() {
+        level = 0; bw_pose = 0; ring = 0; ring_k0 = 0;
+        for (std::vector<int32_t> *v : { &kf_order, &sc_obs, &sc_kf, &sc_pt, &sc_flag, &sc_slot, &pair_i, &pair_h, &pair_hpos, &pair_sc_off, &pair_tg_off, &pair_tg,
+                                         &tg_tobs, &tg_kf, &tg_text, &tg_pair, &tg_slot, &pt_pose6, &pt_pair4, &tg_ppos, &pf_g, &pf_f, &tg_rec,
+                                         &pls_off, &pslot_pose, &pslot_pair, &pslot_lm, &tls_off, &tslot_pose, &tslot_pair, &tslot_lm,
+                                         &sb_a, &sb_b, &sb_pab, &sb_pba, &sb_pt_off, &sb_pt_s1, &sb_pt_s2, &sb_pt_lm, &sb_tx_off, &sb_tx_s1, &sb_tx_s2, &sb_tx_lm,
+                                         &pose_t_off, &pose_t, &pose_h_off, &pose_h, &pose_ps_off, &pose_ps, &pose_ps_lm, &pose_ts_off, &pose_ts, &pose_ts_lm }) v->clear();
+        sc_uv.clear();
+    }
 };
 
 // Dense id of a sparse set of integer keys, ids in key order.  Small key ranges (a 20-keyframe window has 420 possible pairs)
@@ -144,7 +155,7 @@ __host__ __device__ inline int tsba_shard_of(int host, int target_kf, int n_kf, 
 inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true, int ring_max_blocks = 0) {
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
-    P = HostPlan();
+    P.recycle();
     P.level = L;
     const int n_kf = p->n_kf, n_pt = p->n_pt, n_text = p->n_text;
     struct Cand { int obs, kf, pt, host; };
