@@ -2908,9 +2908,12 @@ int tsba_debug_plan_band(const tsba_problem *p, const tsba_options *o, int level
     return TSBA_OK;
 }
 int tsba_debug_plan_time(const tsba_problem *p, const tsba_options *o, int level, int reps, double *avg_ms) {   // host only: plan construction
-    if (!p || !o || reps <= 0) return TSBA_ERR_ARG;
+    if (!p || !o || reps == 0) return TSBA_ERR_ARG;
+    const bool laps = reps < 0; if (laps) reps = -reps;           // reps < 0: one recycled plan object (as a context does), lap times of the last build on stderr
+    HostPlan R;
+    if (laps) build_plan(p, o, level, R, false, true, CR_SMAX/6);
     auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < reps; k++) { HostPlan H; build_plan(p, o, level, H); }
+    for (int k = 0; k < reps; k++) { if (laps) build_plan(p, o, level, R, k == reps - 1, true, CR_SMAX/6); else { HostPlan H; build_plan(p, o, level, H); } }
     *avg_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()/reps;
     return TSBA_OK;
 }
