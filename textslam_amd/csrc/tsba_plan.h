@@ -172,7 +172,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     const bool keep_inc = n_kf > 64 && allow_reorder;
     auto touch = [&](int lm, int kf, int host) { if (host < 0) return;           // frozen landmark: no off-diagonal coupling
         lm_lo[lm] = std::min(lm_lo[lm], std::min(kf, host)); lm_hi[lm] = std::max(lm_hi[lm], std::max(kf, host));
-        if (keep_inc) { lp_lm.push_back(lm); lp_kf.push_back(kf); lp_lm.push_back(lm); lp_kf.push_back(host); } };
+        if (keep_inc) { lp_lm.push_back(lm); lp_kf.push_back(kf); } };                   // (the host joins once per landmark, below)
     for (int s = 0; s < p->n_sobs[L]; s++) {
         int kf = p->sobs_kf[L][s], pt = p->sobs_pt[L][s], host = p->pt_host[pt];
         if (host >= 0 && host == kf) continue;                    // optimizer.cc:1393 "Host != Target"
@@ -364,9 +364,25 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         // A wide envelope (beyond the streaming band solvers: 26 pose blocks) on a large map: try the reverse Cuthill-McKee order of the
         // co-visibility graph (all ranks' observations, so that every rank of a sharded solve derives the same order)
         if (keep_inc && P.bw_pose > 26) {
-            std::vector<std::vector<int> > poses_of((size_t)n_pt + n_text), nb((size_t)n_kf);
-            for (size_t e = 0; e < lp_lm.size(); e++) poses_of[(size_t)lp_lm[e]].push_back(lp_kf[e]);
-            for (auto &v : poses_of) { if (v.size() < 2) continue; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+            // poses of every landmark (observers + host), sorted and distinct, as one CSR list (70 k small lists at 5000 keyframes: a
+            // vector per landmark spent more time in the allocator than in the loops below)
+            const size_t n_lm = (size_t)n_pt + n_text;
+            std::vector<int32_t> po_off(n_lm + 1, 0), po_n(n_lm, 0), po;
+            for (size_t e = 0; e < lp_lm.size(); e++) po_off[(size_t)lp_lm[e] + 1]++;
+            for (size_t j = 0; j < n_lm; j++) { if (lm_hi[j] >= 0) po_off[j + 1]++; po_off[j + 1] += po_off[j]; }
+            po.resize((size_t)po_off[n_lm]);
+            for (size_t j = 0; j < n_lm; j++) if (lm_hi[j] >= 0) po[(size_t)po_off[j] + po_n[j]++] = j < (size_t)n_pt ? p->pt_host[j] : p->text_host[j - n_pt];
+            for (size_t e = 0; e < lp_lm.size(); e++) { const size_t j = (size_t)lp_lm[e]; po[(size_t)po_off[j] + po_n[j]++] = lp_kf[e]; }
+            for (size_t j = 0; j < n_lm; j++) { if (po_n[j] < 2) continue; int32_t *b = &po[(size_t)po_off[j]];
+                std::sort(b, b + po_n[j]); po_n[j] = (int32_t)(std::unique(b, b + po_n[j]) - b); }
+            struct PoseList { const int32_t *p; size_t n; size_t size() const { return n; } int operator[](size_t i) const { return p[i]; } int back() const { return p[n - 1]; }
+                              const int32_t *begin() const { return p; } const int32_t *end() const { return p + n; } };
+            struct PoseLists { const std::vector<int32_t> &off, &cnt, &val;
+                struct It { const PoseLists *L; size_t j; bool operator!=(const It &o) const { return j != o.j; } void operator++() { j++; }
+                            PoseList operator*() const { return PoseList{ L->val.data() + L->off[j], (size_t)L->cnt[j] }; } };
+                It begin() const { return It{ this, 0 }; } It end() const { return It{ this, cnt.size() }; } };
+            const PoseLists poses_of{ po_off, po_n, po };
+            std::vector<std::vector<int> > nb((size_t)n_kf);
             // A single loop closure between the END and the START of the trajectory makes the graph a ring: every landmark's poses
             // fit an arc of a few keyframes, some arcs wrap from the last keyframes to the first.  Unrolled past its end (a wrapping
             // landmark's early poses k count as n_kf + k) the matrix is a band again -- bw_pose of the open chain, not twice that
@@ -375,7 +391,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 const int RB = ring_max_blocks, nu = n_kf + RB + 1;
                 std::vector<int> cu(nu); for (int k = 0; k < nu; k++) cu[k] = k;
                 bool ok = true, wraps = false;
-                for (const auto &v : poses_of) { if (v.size() < 2) continue;
+                for (const PoseList v : poses_of) { if (v.size() < 2) continue;
                     int best = v[0] + n_kf - v.back(); size_t at = 0;                 // largest cyclic gap (at = 0: the wrap between last and first)
                     for (size_t x = 1; x < v.size(); x++) if (v[x] - v[x - 1] > best) { best = v[x] - v[x - 1]; at = x; }
                     const int lo = at ? v[at] : v[0], hi = at ? v[at - 1] + n_kf : v.back();
@@ -391,7 +407,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 // spans the closure counts its early poses (the loop's first ones) as n_kf + (k - k0): the ghost rows behind the last pose.
                 if (!P.ring) {
                     int k0 = n_kf, klow = -1, ncl = 0; bool okc = true;
-                    for (const auto &v : poses_of) { if (v.size() < 2 || v.back() - v[0] <= RB) continue;
+                    for (const PoseList v : poses_of) { if (v.size() < 2 || v.back() - v[0] <= RB) continue;
                         size_t at = 1; for (size_t x = 2; x < v.size(); x++) if (v[x] - v[x - 1] > v[at] - v[at - 1]) at = x;
                         if (v[at - 1] - v[0] > RB || v.back() - v[at] > RB || v[at] < n_kf - 2*RB) { okc = false; break; }
                         k0 = std::min(k0, v[0]); klow = std::max(klow, v[at - 1]); ncl++; }
@@ -399,7 +415,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                         const int nu2 = n_kf + RB + 1;
                         std::vector<int> c2(nu2); for (int k = 0; k < nu2; k++) c2[k] = k;
                         bool ok2 = true; int gmax = -1;
-                        for (const auto &v : poses_of) { if (v.size() < 2) continue;
+                        for (const PoseList v : poses_of) { if (v.size() < 2) continue;
                             int lo = v[0], hi = v.back();
                             if (hi - lo > RB) { lo = nu2; hi = -1;                       // spans the closure: its early poses as ghosts
                                 for (int k : v) { const int u = (k >= k0 && k < k0 + RB) ? n_kf + (k - k0) : k; if (u != k) gmax = std::max(gmax, k - k0);
@@ -415,13 +431,21 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 }
             }
             if (!P.ring) {
-            for (auto &v : poses_of) { if (v.size() < 2) continue;
+            if ((int64_t)n_kf*n_kf <= ((int64_t)1 << 28)) {       // adjacency through a bitmap over pose pairs: set bits come out sorted and distinct
+                std::vector<uint64_t> bm((((size_t)n_kf*n_kf) >> 6) + 1, 0);
+                for (const PoseList v : poses_of) { if (v.size() < 2) continue;
+                    for (size_t x = 0; x < v.size(); x++) for (size_t y = 0; y < v.size(); y++) if (x != y) { const size_t k = (size_t)v[x]*n_kf + v[y]; bm[k >> 6] |= (uint64_t)1 << (k & 63); } }
+                for (size_t w = 0; w < bm.size(); w++) { uint64_t b = bm[w];
+                    while (b) { const size_t k = (w << 6) + (size_t)__builtin_ctzll(b); b &= b - 1; nb[k/n_kf].push_back((int)(k % n_kf)); } }
+            } else {
+            for (const PoseList v : poses_of) { if (v.size() < 2) continue;
                 for (size_t x = 0; x < v.size(); x++) for (size_t y = 0; y < v.size(); y++) if (x != y) nb[(size_t)v[x]].push_back(v[y]); }
             for (auto &v : nb) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+            }
             std::vector<int32_t> order; rcm_order(n_kf, nb, order);
             std::vector<int> pos(n_kf), c2(n_kf);
             for (int i = 0; i < n_kf; i++) { pos[order[i]] = i; c2[i] = i; }
-            for (const auto &v : poses_of) { if (v.size() < 2) continue; int lo = n_kf, hi = -1;
+            for (const PoseList v : poses_of) { if (v.size() < 2) continue; int lo = n_kf, hi = -1;
                 for (int k : v) { lo = std::min(lo, pos[k]); hi = std::max(hi, pos[k]); } c2[lo] = std::max(c2[lo], hi); }
             for (int q = 0; q < n_sb; q++) { const int pa = pos[P.sb_a[q]], pb = pos[P.sb_b[q]]; c2[std::min(pa, pb)] = std::max(c2[std::min(pa, pb)], std::max(pa, pb)); }
             const int bw2 = closed_bw(c2);
