@@ -2957,6 +2957,7 @@ int tsba_debug_band_factor(void *ctx, double *lcol, long long n_lcol, double *ld
 // out5 = { P, a, b, has_left, has_right } of interior p;  block index of (br, bc) in the cyclic-reduction pool and the pool size
 // host-only: FNV-1a over the Schur slot-pair lists of the plan of `level`, built with `threads` host threads in the parallel sections
 // (0 = the production choice): the plan must not depend on the number of threads
+void tsba_debug_plan_knob(int which, int value) { if (which == 0) tsba_plan_threads = value; else if (which == 1) tsba_plan_mark_mt = value; }   // host-only measurement knobs
 unsigned long long tsba_debug_plan_checksum(const tsba_problem *p, const tsba_options *o, int level, int threads) {
     if (!p || !o || level < 0 || level >= p->n_levels) return 0;
     const int saved = tsba_plan_threads; tsba_plan_threads = threads;

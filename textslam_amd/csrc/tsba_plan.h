@@ -21,6 +21,7 @@
 #include "../../include/tsba.h"
 
 static int tsba_plan_threads = 0;              // 0: by problem size; > 0: host threads of the plan builder's parallel sections (tests)
+static int tsba_plan_mark_mt = 1;              // S-block keys of the slot pairs marked by the same threads (0: by the calling thread; measurements)
 
 struct HostPlan {
     int level = 0;
@@ -86,6 +87,8 @@ struct KeyIndex {
         else if (range <= (int64_t)1 << 31) bits.assign((size_t)((range + 63) >> 6), 0);
     }
     void add(int64_t k) { if (dense()) table[(size_t)k] = 0; else if (bitmap()) bits[(size_t)(k >> 6)] |= (uint64_t)1 << (k & 63); else keys.push_back(k); }
+    bool concurrent() const { return dense() || bitmap(); }                           // add_mt may be called from several threads at once
+    void add_mt(int64_t k) { if (dense()) __atomic_store_n(&table[(size_t)k], 0, __ATOMIC_RELAXED); else __atomic_fetch_or(&bits[(size_t)(k >> 6)], (uint64_t)1 << (k & 63), __ATOMIC_RELAXED); }
     int finish() {                                                                   // returns the number of distinct keys
         if (dense()) { int n = 0; keys.clear(); for (int64_t k = 0; k < range; k++) if (table[(size_t)k] == 0) { table[(size_t)k] = n++; keys.push_back(k); } return n; }
         if (bitmap()) {
@@ -264,8 +267,26 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         for (int j = 0; j < n_lm; j++) for (int s1 = off[j]; s1 < off[j+1]; s1++) for (int s2 = off[j]; s2 < off[j+1]; s2++) {
             const int a = pose[s1], b = pose[s2]; if (a > b) continue; f(bkey(a, b), s1, s2); }
     };
-    each_pair(P.pls_off, P.pslot_pose, n_pt, [&](int64_t k, int, int) { bk.add(k); });
-    each_pair(P.tls_off, P.tslot_pose, n_text, [&](int64_t k, int, int) { bk.add(k); });
+    // large maps: T host threads over contiguous landmark ranges with about the same number of slots each
+    auto threads_for = [&](size_t n_slot, int n_lm) { int T = 1;
+        if (n_slot > 200000) T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()/2));
+        if (tsba_plan_threads > 0) T = std::min(tsba_plan_threads, std::max(1, n_lm));
+        return T; };
+    auto split_landmarks = [&](const std::vector<int32_t> &loff, int n_lm, int T) { std::vector<int> lo(T + 1, 0); const size_t n_slot = (size_t)loff[n_lm];
+        for (int t = 1; t < T; t++) lo[t] = (int)(std::lower_bound(loff.begin(), loff.begin() + n_lm + 1, (int32_t)(n_slot*t/T)) - loff.begin());
+        lo[T] = n_lm; return lo; };
+    auto range_pairs = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, int j0, int j1, auto &&f) {
+        for (int j = j0; j < j1; j++) for (int s1 = loff[j]; s1 < loff[j+1]; s1++) for (int s2 = loff[j]; s2 < loff[j+1]; s2++) {
+            const int a = pose[s1], b2 = pose[s2]; if (a > b2) continue; f(bkey(a, b2), s1, s2); } };
+    auto mark_blocks = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, int n_lm) {
+        const int T = (n_lm > 0 && bk.concurrent() && tsba_plan_mark_mt) ? threads_for((size_t)loff[n_lm], n_lm) : 1;
+        if (T <= 1) { each_pair(loff, pose, n_lm, [&](int64_t k, int, int) { bk.add(k); }); return; }
+        const std::vector<int> lo = split_landmarks(loff, n_lm, T);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back([&, t]() { range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t k, int, int) { bk.add_mt(k); }); });
+        for (auto &x : th) x.join(); };
+    mark_blocks(P.pls_off, P.pslot_pose, n_pt);
+    mark_blocks(P.tls_off, P.tslot_pose, n_text);
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bk.add(bkey(i, i));
         if (h >= 0) { bk.add(bkey(h, h)); bk.add(bkey(std::min(i, h), std::max(i, h))); } }
     if (n_kf <= 64) for (int a = 0; a < n_kf; a++) for (int b = a; b < n_kf; b++) bk.add(bkey(a, b));   // small windows: dense S, no memset
@@ -287,9 +308,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                         std::vector<int32_t> &off, std::vector<int32_t> &s1v, std::vector<int32_t> &s2v, std::vector<int32_t> &lmv) {
         off.assign((size_t)n_sb + 1, 0);                          // stable by block: the landmark-major generation order is kept
         const size_t n_slot = n_lm > 0 ? (size_t)loff[n_lm] : 0;
-        int T = 1;
-        if (n_slot > 200000) { T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()/2)); }
-        if (tsba_plan_threads > 0) T = std::min(tsba_plan_threads, std::max(1, n_lm));
+        const int T = threads_for(n_slot, n_lm);
         if (T <= 1) {
             each_pair(loff, pose, n_lm, [&](int64_t k, int, int) { off[(size_t)blk_of(k) + 1]++; });
             for (int q = 0; q < n_sb; q++) off[q+1] += off[q];
@@ -299,16 +318,11 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             each_pair(loff, pose, n_lm, [&](int64_t k, int s1, int s2) { const int at = cur[blk_of(k)]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; });
             return;
         }
-        std::vector<int> lo(T + 1, 0);                            // landmark ranges with about the same number of slots
-        for (int t = 1; t < T; t++) lo[t] = (int)(std::lower_bound(loff.begin(), loff.begin() + n_lm + 1, (int32_t)(n_slot*t/T)) - loff.begin());
-        lo[T] = n_lm;
-        auto range_pairs = [&](int j0, int j1, auto &&f) {
-            for (int j = j0; j < j1; j++) for (int s1 = loff[j]; s1 < loff[j+1]; s1++) for (int s2 = loff[j]; s2 < loff[j+1]; s2++) {
-                const int a = pose[s1], b2 = pose[s2]; if (a > b2) continue; f(bkey(a, b2), s1, s2); } };
+        const std::vector<int> lo = split_landmarks(loff, n_lm, T);
         std::vector<std::vector<int32_t> > blk(T), cnt(T);
         {   std::vector<std::thread> th;
             for (int t = 0; t < T; t++) th.emplace_back([&, t]() { cnt[t].assign((size_t)n_sb, 0); blk[t].reserve(4*n_slot/T + 1024);
-                range_pairs(lo[t], lo[t+1], [&](int64_t k, int, int) { const int q = blk_of(k); blk[t].push_back(q); cnt[t][(size_t)q]++; }); });
+                range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t k, int, int) { const int q = blk_of(k); blk[t].push_back(q); cnt[t][(size_t)q]++; }); });
             for (auto &x : th) x.join(); }
         lap("  slot pairs: pass 1 (threads)");
         for (int q = 0; q < n_sb; q++) { int32_t run = off[q];    // off[q] is the start of block q; cnt[t][q] becomes thread t's first position in it
@@ -320,7 +334,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         lap("  slot pairs: resize");
         {   std::vector<std::thread> th;
             for (int t = 0; t < T; t++) th.emplace_back([&, t]() { size_t e = 0;
-                range_pairs(lo[t], lo[t+1], [&](int64_t, int s1, int s2) { const int at = cnt[t][(size_t)blk[t][e++]]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; }); });
+                range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t, int s1, int s2) { const int at = cnt[t][(size_t)blk[t][e++]]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; }); });
             for (auto &x : th) x.join(); }
     };
     fill_tri(P.pls_off, P.pslot_pose, P.pslot_lm, n_pt, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2, P.sb_pt_lm);      // (lm: saves one dependent gather in k_schur)
