@@ -173,12 +173,37 @@ def test_plan_does_not_depend_on_the_number_of_host_threads():
     from textslam_amd.optimizer import load_library
     L = load_library()
     L.tsba_debug_plan_checksum.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int]; L.tsba_debug_plan_checksum.restype = C.c_ulonglong
-    for P, o in ((synth.config_global(n_kf=700, n_pt=20000, band=9), abi.options_global()), (synth.tiny(seed=3, n_kf=8, n_pt=300, n_text=6), abi.options_local())):
+    L.tsba_debug_plan_knob.argtypes = [C.c_int, C.c_int]; L.tsba_debug_plan_knob.restype = None
+    og3 = abi.options_global(); og3.lm_shard, og3.lm_nshard = 1, 3
+    sums = set()
+    for P, o, ring in ((synth.config_global(n_kf=700, n_pt=20000, band=9), abi.options_global(), 0), (synth.tiny(seed=3, n_kf=8, n_pt=300, n_text=6), abi.options_local(), 0),
+                       (synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True, loop_at=200), abi.options_global(), 13),      # ring plan (ghost rows)
+                       (synth.config_global(n_kf=600, n_pt=12000, band=8, loop=True), abi.options_global(), 0),                    # reordered plan
+                       (synth.config_global(n_kf=700, n_pt=20000, band=9), og3, 0)):                                               # one shard of three
         s = P.struct()
-        ref = L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, 1)
-        assert ref != 0
-        for t in (2, 3, 7, 16):
-            assert L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, t) == ref, t
+        L.tsba_debug_plan_knob(2, ring)                          # (ring_max_blocks of the hook's plan)
+        try:
+            ref = L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, 1)     # (a checksum over EVERY list of the plan)
+            assert ref != 0
+            for t in (2, 3, 7, 16):
+                assert L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, t) == ref, t
+        finally:
+            L.tsba_debug_plan_knob(2, 0)
+        sums.add(ref)
+    assert len(sums) == 5
+    # a context keeps its plan objects (lists and work lists) from call to call: a plan built into an object that held ANOTHER plan -- larger or
+    # smaller, built by more or fewer threads -- is the plan a fresh object gets
+    L.tsba_debug_plan_checksum_recycled.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int] * 2
+    L.tsba_debug_plan_checksum_recycled.restype = C.c_ulonglong
+    big, small, win = synth.config_global(n_kf=700, n_pt=20000, band=9), synth.config_global(n_kf=60, n_pt=3000, band=6), synth.tiny(seed=3, n_kf=8, n_pt=300, n_text=6)
+    og, ol = abi.options_global(), abi.options_local()
+    probs = [(big, og, 0), (small, og, 0), (win, ol, 0), (win, ol, 2)]
+    for (Pw, ow, lw) in probs:
+        for (Pn, on, ln) in probs:
+            sw, sn = Pw.struct(), Pn.struct()
+            fresh = L.tsba_debug_plan_checksum(C.byref(sn), C.byref(on), ln, 1)
+            for tw, tn in ((16, 1), (1, 5), (3, 16)):
+                assert L.tsba_debug_plan_checksum_recycled(C.byref(sw), C.byref(ow), lw, tw, C.byref(sn), C.byref(on), ln, tn) == fresh
 
 
 @pytest.mark.parametrize("nf,row0,B,Gmax,Ptmax", [(598, 199, 8, 16, 8), (4998, 1499, 10, 128, 55), (1498, 299, 7, 64, 16), (898, 449, 8, 32, 32), (300, 60, 9, 8, 8), (1498, 999, 7, 16, 40)])

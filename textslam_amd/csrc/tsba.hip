@@ -2957,16 +2957,39 @@ int tsba_debug_band_factor(void *ctx, double *lcol, long long n_lcol, double *ld
 // out5 = { P, a, b, has_left, has_right } of interior p;  block index of (br, bc) in the cyclic-reduction pool and the pool size
 // host-only: FNV-1a over the Schur slot-pair lists of the plan of `level`, built with `threads` host threads in the parallel sections
 // (0 = the production choice): the plan must not depend on the number of threads
-void tsba_debug_plan_knob(int which, int value) { if (which == 0) tsba_plan_threads = value; else if (which == 1) tsba_plan_mark_mt = value; }   // host-only measurement knobs
-unsigned long long tsba_debug_plan_checksum(const tsba_problem *p, const tsba_options *o, int level, int threads) {
-    if (!p || !o || level < 0 || level >= p->n_levels) return 0;
-    const int saved = tsba_plan_threads; tsba_plan_threads = threads;
-    HostPlan H; build_plan(p, o, level, H);
-    tsba_plan_threads = saved;
+static int tsba_plan_checksum_ring = 0;       // ring_max_blocks the checksum hook builds its plan with (knob 2)
+void tsba_debug_plan_knob(int which, int value) { if (which == 0) tsba_plan_threads = value; else if (which == 1) tsba_plan_mark_mt = value; else if (which == 2) tsba_plan_checksum_ring = value; else if (which == 3) tsba_plan_pin = value; }   // host-only measurement knobs
+} // extern "C"
+static unsigned long long plan_checksum(const HostPlan &H) {           // over EVERY list of the plan
     unsigned long long h = 1469598103934665603ull;
     auto mix = [&](const std::vector<int32_t> &v) { for (int32_t x : v) { h ^= (unsigned int)x; h *= 1099511628211ull; } h ^= v.size(); h *= 1099511628211ull; };
     mix(H.sb_a); mix(H.sb_b); mix(H.sb_pt_off); mix(H.sb_pt_s1); mix(H.sb_pt_s2); mix(H.sb_pt_lm); mix(H.sb_tx_off); mix(H.sb_tx_s1); mix(H.sb_tx_s2); mix(H.sb_tx_lm);
+    for (const std::vector<int32_t> *v : { &H.kf_order, &H.sc_obs, &H.sc_kf, &H.sc_pt, &H.sc_flag, &H.sc_slot, &H.pair_i, &H.pair_h, &H.pair_hpos, &H.pair_sc_off, &H.pair_tg_off, &H.pair_tg,
+                                           &H.tg_tobs, &H.tg_kf, &H.tg_text, &H.tg_pair, &H.tg_slot, &H.pt_pose6, &H.pt_pair4, &H.tg_ppos, &H.pf_g, &H.pf_f, &H.tg_rec,
+                                           &H.pls_off, &H.pslot_pose, &H.pslot_pair, &H.pslot_lm, &H.tls_off, &H.tslot_pose, &H.tslot_pair, &H.tslot_lm, &H.sb_pab, &H.sb_pba,
+                                           &H.pose_t_off, &H.pose_t, &H.pose_h_off, &H.pose_h, &H.pose_ps_off, &H.pose_ps, &H.pose_ps_lm, &H.pose_ts_off, &H.pose_ts, &H.pose_ts_lm }) mix(*v);
+    for (double x : H.sc_uv) { unsigned long long u; memcpy(&u, &x, 8); h ^= u; h *= 1099511628211ull; }
+    h ^= (unsigned long long)(H.bw_pose*4 + H.ring*2) + 8ull*(unsigned)H.ring_k0; h *= 1099511628211ull;
     return h;
+}
+extern "C" {
+unsigned long long tsba_debug_plan_checksum(const tsba_problem *p, const tsba_options *o, int level, int threads) {
+    if (!p || !o || level < 0 || level >= p->n_levels) return 0;
+    const int saved = tsba_plan_threads; tsba_plan_threads = threads;
+    HostPlan H; build_plan(p, o, level, H, false, true, tsba_plan_checksum_ring);
+    tsba_plan_threads = saved;
+    return plan_checksum(H);
+}
+// the plan of (p, o, level) built into a plan object that held the plan of (warm, ow, warm_level) before -- as a context does from call to call
+unsigned long long tsba_debug_plan_checksum_recycled(const tsba_problem *warm, const tsba_options *ow, int warm_level, int warm_threads,
+                                                     const tsba_problem *p, const tsba_options *o, int level, int threads) {
+    if (!warm || !ow || !p || !o || level < 0 || level >= p->n_levels || warm_level < 0 || warm_level >= warm->n_levels) return 0;
+    const int saved = tsba_plan_threads;
+    HostPlan H;
+    tsba_plan_threads = warm_threads; build_plan(warm, ow, warm_level, H, false, true, tsba_plan_checksum_ring);
+    tsba_plan_threads = threads; build_plan(p, o, level, H, false, true, tsba_plan_checksum_ring);
+    tsba_plan_threads = saved;
+    return plan_checksum(H);
 }
 // host-only: does the plan of `level` take the ring path (one loop closure between the last and the first keyframes) when separators of up
 // to ring_max_blocks pose blocks are allowed?  Returns 1 / 0 (< 0: error); *bw_pose = the band of the plan either way

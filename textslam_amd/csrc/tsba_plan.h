@@ -13,6 +13,10 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <atomic>
+#include <functional>
+#include <sched.h>
+#include <pthread.h>
 #include <cstdint>
 #include <map>
 #include <chrono>
@@ -21,9 +25,22 @@
 #include "../../include/tsba.h"
 
 static int tsba_plan_threads = 0;              // 0: by problem size; > 0: host threads of the plan builder's parallel sections (tests)
+static int tsba_plan_pin = 1;                  // the plan threads of a multi-threaded build (and its caller, for its duration) are pinned to the CPUs that share the caller's
+                                               // L3: every pass hands the lists the last pass wrote to other threads -- through one L3 that is a cache hit, across the
+                                               // 32 L3 domains of the GPU box's two sockets a remote-cache miss per line (5000 keyframes: 21.0 -> 13.3 ms); 0: scheduler's choice
 static int tsba_plan_mark_mt = 1;              // S-block keys of the slot pairs marked by the same threads (0: by the calling thread; measurements)
 
+struct PlanCand { int obs, kf, pt, host; };     // a scene candidate: observation, target keyframe, point, host keyframe (-1: frozen)
+// work lists of build_plan that live with the plan object: a context builds a plan per call, and 45 MB of fresh lists per build of a
+// 5000-keyframe map (page faults, unmapping under sixteen running threads) cost more than filling them
+struct PlanScratch {
+    std::vector<std::vector<PlanCand> > cs;     // per thread
+    std::vector<std::vector<int32_t> > hist, kc, tlo, thi;
+    std::vector<int32_t> sc_pair;
+    void threads(int T) { if ((int)cs.size() < T) { cs.resize((size_t)T); hist.resize((size_t)T); kc.resize((size_t)T); tlo.resize((size_t)T); thi.resize((size_t)T); } }
+};
 struct HostPlan {
+    PlanScratch scratch;                        // (kept by recycle())
     int level = 0;
     int bw_pose = 0;                            // half bandwidth of the reduced camera matrix in pose blocks, fill included
     int ring_k0 = 0;                            // ring: the loop starts at this keyframe (0: the whole trajectory is the loop; > 0: a tail before it)
@@ -88,7 +105,9 @@ struct KeyIndex {
     }
     void add(int64_t k) { if (dense()) table[(size_t)k] = 0; else if (bitmap()) bits[(size_t)(k >> 6)] |= (uint64_t)1 << (k & 63); else keys.push_back(k); }
     bool concurrent() const { return dense() || bitmap(); }                           // add_mt may be called from several threads at once
-    void add_mt(int64_t k) { if (dense()) __atomic_store_n(&table[(size_t)k], 0, __ATOMIC_RELAXED); else __atomic_fetch_or(&bits[(size_t)(k >> 6)], (uint64_t)1 << (k & 63), __ATOMIC_RELAXED); }
+    void add_mt(int64_t k) { if (dense()) { int32_t *e = &table[(size_t)k]; if (__atomic_load_n(e, __ATOMIC_RELAXED) != 0) __atomic_store_n(e, 0, __ATOMIC_RELAXED); }
+                             else { uint64_t *w = &bits[(size_t)(k >> 6)]; const uint64_t m = (uint64_t)1 << (k & 63);      // (test first: most slot pairs hit a bit that is set already, and a line that is only read stays shared)
+                                    if (!(__atomic_load_n(w, __ATOMIC_RELAXED) & m)) __atomic_fetch_or(w, m, __ATOMIC_RELAXED); } }
     int finish() {                                                                   // returns the number of distinct keys
         if (dense()) { int n = 0; keys.clear(); for (int64_t k = 0; k < range; k++) if (table[(size_t)k] == 0) { table[(size_t)k] = n++; keys.push_back(k); } return n; }
         if (bitmap()) {
@@ -155,49 +174,123 @@ __host__ __device__ inline int tsba_shard_of(int host, int target_kf, int n_kf, 
     return (int)(((long long)k*nshard)/n_kf);
 }
 
+// ---- host threads of the plan builder.  A 5000-keyframe map has 0.5 M observations and 2 M slot pairs, and its plan is 2/3 of a cold
+// tsba_global_ba call: every pass over them runs on a small fork-join pool (the calling thread is member 0; the others spin between the
+// parallel sections of ONE build_plan call -- they live for some ten milliseconds).  Every section is a contiguous split of its items and
+// every placement is a stable bucket sort, so the plan does not depend on the number of threads.
+// the CPUs that share the last-level cache with the CPU this thread runs on, within the process's affinity mask (false: unknown / fewer than 2)
+inline bool plan_l3_cpuset(cpu_set_t *set) {
+    const int cpu = sched_getcpu(); if (cpu < 0) return false;
+    char path[128]; snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE *f = fopen(path, "r"); if (!f) return false;
+    char buf[1024]; const bool got = fgets(buf, sizeof buf, f) != nullptr; fclose(f); if (!got) return false;
+    CPU_ZERO(set);
+    for (const char *q = buf; *q && *q != '\n'; ) { char *e; long a = strtol(q, &e, 10); if (e == q) break; long b = a; q = e;
+        if (*q == '-') { b = strtol(q + 1, &e, 10); q = e; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0) CPU_SET((int)c, set);
+        if (*q == ',') q++; }
+    cpu_set_t allowed; if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) CPU_AND(set, set, &allowed);
+    return CPU_COUNT(set) >= 2;
+}
+struct PlanPool {
+    int T; std::vector<std::thread> th; std::atomic<int> gen{0}, done{0}; std::atomic<bool> stop{false};
+    const std::function<void(int)> *job = nullptr;
+    bool pinned = false; cpu_set_t saved;
+    explicit PlanPool(int T_, bool pin = false) : T(std::max(1, T_)) {
+        cpu_set_t l3;
+        if (pin && T > 1 && plan_l3_cpuset(&l3) && pthread_getaffinity_np(pthread_self(), sizeof saved, &saved) == 0) {
+            T = std::min(T, CPU_COUNT(&l3)); pinned = pthread_setaffinity_np(pthread_self(), sizeof l3, &l3) == 0; }
+        for (int t = 1; t < T; t++) th.emplace_back([this, t]() { worker(t); });        // (threads inherit the creator's mask)
+    }
+    ~PlanPool() { stop.store(true); gen.fetch_add(1, std::memory_order_release); for (auto &x : th) x.join();
+                  if (pinned) pthread_setaffinity_np(pthread_self(), sizeof saved, &saved); }
+    PlanPool(const PlanPool &) = delete; PlanPool &operator=(const PlanPool &) = delete;
+    static void relax(int &spins) { if (++spins > 2048) std::this_thread::yield(); else __builtin_ia32_pause(); }
+    void worker(int t) { int seen = 0;
+        for (;;) { int spins = 0, g; while ((g = gen.load(std::memory_order_acquire)) == seen) relax(spins);
+            seen = g; if (stop.load()) return; (*job)(t); done.fetch_add(1, std::memory_order_release); } }
+    template <class F> void run(F &&f) {                                // f(t) for t = 0 .. T-1, returns when all are done
+        if (T <= 1) { f(0); return; }
+        const std::function<void(int)> fn = [&f](int t) { f(t); };
+        job = &fn; done.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release);
+        f(0);
+        int spins = 0; while (done.load(std::memory_order_acquire) != T - 1) relax(spins);
+    }
+    void range(size_t n, int t, size_t &a, size_t &b) const { a = n*(size_t)t/(size_t)T; b = n*(size_t)(t + 1)/(size_t)T; }
+};
+// Stable bucket placement in two passes over items the caller enumerates twice in the same order (thread t its own contiguous share):
+// pass 1 count(t, key) -- key < 0: the item takes no place --, offsets(), pass 2 next(t, e) = the item's position (e: the thread's running
+// item ordinal).  Thread-major within a bucket = item order, whatever the number of threads.
+struct BucketPlacer {
+    PlanPool &pool; int nb; std::vector<std::vector<int32_t> > &hist, &kc;       // (the plan's scratch lists: one placer at a time)
+    BucketPlacer(PlanPool &pl, int n_bucket, PlanScratch &sc) : pool(pl), nb(n_bucket), hist(sc.hist), kc(sc.kc) {}
+    void begin(int t, size_t expect) { hist[t].assign((size_t)nb, 0); kc[t].clear(); kc[t].reserve(expect); }
+    void count(int t, int key) { kc[t].push_back(key); if (key >= 0) hist[t][(size_t)key]++; }
+    // off[q] = start of bucket q (nb + 1 entries); a non-empty bucket is `extra` entries longer than its items (a landmark's host slot)
+    void offsets(std::vector<int32_t> &off, int extra = 0) {
+        const int T = pool.T; off.assign((size_t)nb + 1, 0);
+        pool.run([&](int t) { size_t a, b; pool.range((size_t)nb, t, a, b);
+            for (size_t q = a; q < b; q++) { int32_t tot = 0; for (int u = 0; u < T; u++) tot += hist[u][q]; off[q + 1] = tot > 0 ? tot + extra : 0; } });
+        for (int q = 0; q < nb; q++) off[(size_t)q + 1] += off[(size_t)q];
+        pool.run([&](int t) { size_t a, b; pool.range((size_t)nb, t, a, b);
+            for (size_t q = a; q < b; q++) { int32_t run = off[q]; for (int u = 0; u < T; u++) { const int32_t c = hist[u][q]; hist[u][q] = run; run += c; } } });
+    }
+    int key(int t, size_t e) const { return kc[t][e]; }
+    int next(int t, size_t &e) { const int k = kc[t][e++]; return k < 0 ? -1 : hist[t][(size_t)k]++; }
+};
+
 inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true, int ring_max_blocks = 0) {
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
     P.recycle();
     P.level = L;
-    const int n_kf = p->n_kf, n_pt = p->n_pt, n_text = p->n_text;
-    struct Cand { int obs, kf, pt, host; };
-    std::vector<Cand> cs;
-    cs.reserve(p->n_sobs[L]);
+    const int n_kf = p->n_kf, n_pt = p->n_pt, n_text = p->n_text, n_obs = p->n_sobs[L];
+    int T = 1;
+    if ((size_t)n_obs > 100000) T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()/2));
+    if (tsba_plan_threads > 0) T = tsba_plan_threads;
+    if ((int64_t)n_kf*(n_kf + 1) > ((int64_t)1 << 31)) T = 1;       // (the key sets below are shared bitmaps only up to 2^31 keys)
+    PlanPool pool(T, tsba_plan_pin != 0);
+    T = pool.T;
+    typedef PlanCand Cand;
+    PlanScratch &SC = P.scratch; SC.threads(T);
+    std::vector<std::vector<Cand> > &cs = SC.cs;                      // scene candidates in observation order, thread-major
+    for (auto &v : cs) v.clear();
     // The envelope of the reduced camera matrix is a property of the WHOLE problem: every rank of a sharded solve must derive the
     // same band (storage layout, solver choice, exchange counts) -- so it is taken from all observations, before the shard filter.
     // A landmark couples every pair of its poses (observers + host): column lo = min pose reaches down to hi = max pose; the fill
     // closure below (running maximum) covers the poses in between.
     std::vector<int> reach(n_kf);
     for (int a = 0; a < n_kf; a++) reach[a] = a;
-    std::vector<int> lm_lo((size_t)n_pt + n_text, n_kf), lm_hi((size_t)n_pt + n_text, -1);
-    std::vector<int> lp_lm, lp_kf;                            // (landmark, pose) incidences of all observations: large maps only (reordering)
-    const bool keep_inc = n_kf > 64 && allow_reorder;
-    auto touch = [&](int lm, int kf, int host) { if (host < 0) return;           // frozen landmark: no off-diagonal coupling
-        lm_lo[lm] = std::min(lm_lo[lm], std::min(kf, host)); lm_hi[lm] = std::max(lm_hi[lm], std::max(kf, host));
-        if (keep_inc) { lp_lm.push_back(lm); lp_kf.push_back(kf); } };                   // (the host joins once per landmark, below)
-    for (int s = 0; s < p->n_sobs[L]; s++) {
-        int kf = p->sobs_kf[L][s], pt = p->sobs_pt[L][s], host = p->pt_host[pt];
-        if (host >= 0 && host == kf) continue;                    // optimizer.cc:1393 "Host != Target"
-        touch(pt, kf, host);
-        if (o->lm_nshard > 1 && tsba_shard_of(host, kf, n_kf, o->lm_nshard) != o->lm_shard) continue;   // multi-GPU: landmark shard
-        cs.push_back({ s, kf, pt, host >= 0 ? host : -1 });
-    }
+    std::vector<int32_t> lm_lo((size_t)n_pt + n_text, n_kf), lm_hi((size_t)n_pt + n_text, -1);
+    std::vector<std::vector<int32_t> > &tlo = SC.tlo, &thi = SC.thi;  // per thread (points): a shared array would bounce its lines between the threads' caches on every observation
+    const bool keep_inc = n_kf > 64 && allow_reorder;                 // large maps: the landmarks' pose lists may be needed (reordering)
+    // ---- pairs: key = kf*(n_kf+1) + (host+1)
+    auto key_of = [&](int kf, int host) { return (int64_t)kf*(n_kf + 1) + (host + 1); };
+    KeyIndex pk; pk.begin((int64_t)n_kf*(n_kf + 1));
+    const bool sharded = o->lm_nshard > 1;
+    pool.run([&](int t) { size_t s0, s1; pool.range((size_t)n_obs, t, s0, s1); std::vector<Cand> &v = cs[(size_t)t]; v.reserve(s1 - s0);
+        int32_t *lo_t = lm_lo.data(), *hi_t = lm_hi.data();
+        if (T > 1) { tlo[(size_t)t].assign((size_t)n_pt, n_kf); thi[(size_t)t].assign((size_t)n_pt, -1); lo_t = tlo[(size_t)t].data(); hi_t = thi[(size_t)t].data(); }
+        for (size_t s = s0; s < s1; s++) {
+            const int kf = p->sobs_kf[L][s], pt = p->sobs_pt[L][s], host = p->pt_host[pt];
+            if (host >= 0 && host == kf) continue;                    // optimizer.cc:1393 "Host != Target"
+            if (host >= 0) { lo_t[pt] = std::min(lo_t[pt], std::min(kf, host)); hi_t[pt] = std::max(hi_t[pt], std::max(kf, host)); }   // (a frozen landmark couples nothing)
+            if (sharded && tsba_shard_of(host, kf, n_kf, o->lm_nshard) != o->lm_shard) continue;   // multi-GPU: landmark shard
+            v.push_back({ (int)s, kf, pt, host >= 0 ? host : -1 });
+            if (T > 1) pk.add_mt(key_of(kf, v.back().host)); else pk.add(key_of(kf, v.back().host)); } });
+    if (T > 1) pool.run([&](int t) { size_t j0, j1; pool.range((size_t)n_pt, t, j0, j1);
+        for (size_t j = j0; j < j1; j++) { int lo = n_kf, hi = -1; for (int u = 0; u < T; u++) { lo = std::min(lo, tlo[(size_t)u][j]); hi = std::max(hi, thi[(size_t)u][j]); } lm_lo[j] = lo; lm_hi[j] = hi; } });
     struct Grp { int tobs, kf, text, host; };
     std::vector<Grp> gs;
     if (o->use_text) for (int t = 0; t < p->n_tobs; t++) {
         int kf = p->tobs_kf[t], j = p->tobs_text[t], host = p->text_host[j];
         if (host >= 0 && host == kf) continue;                    // optimizer.cc:1484
-        touch(n_pt + j, kf, host);
-        if (o->lm_nshard > 1 && tsba_shard_of(host, kf, n_kf, o->lm_nshard) != o->lm_shard) continue;
+        if (host >= 0) { lm_lo[n_pt + j] = std::min(lm_lo[n_pt + j], std::min(kf, host)); lm_hi[n_pt + j] = std::max(lm_hi[n_pt + j], std::max(kf, host)); }
+        if (sharded && tsba_shard_of(host, kf, n_kf, o->lm_nshard) != o->lm_shard) continue;
         gs.push_back({ t, kf, j, host >= 0 ? host : -1 });
+        pk.add(key_of(kf, gs.back().host));
     }
     for (size_t lm = 0; lm < lm_lo.size(); lm++) if (lm_hi[lm] >= 0) reach[lm_lo[lm]] = std::max(reach[lm_lo[lm]], lm_hi[lm]);
-    // ---- pairs: key = kf*(n_kf+1) + (host+1)
-    auto key_of = [&](int kf, int host) { return (int64_t)kf*(n_kf + 1) + (host + 1); };
-    KeyIndex pk; pk.begin((int64_t)n_kf*(n_kf + 1));
-    for (auto &c : cs) pk.add(key_of(c.kf, c.host));
-    for (auto &g : gs) pk.add(key_of(g.kf, g.host));
     const int n_pair = pk.finish();
     const std::vector<int64_t> &keys = pk.keys;
     auto pair_of = [&](int kf, int host) { return pk.id(key_of(kf, host)); };
@@ -205,20 +298,18 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     for (int q = 0; q < n_pair; q++) { P.pair_i[q] = (int)(keys[q]/(n_kf + 1)); P.pair_h[q] = (int)(keys[q] % (n_kf + 1)) - 1; }
     lap("candidates + pair keys");
     // ---- sort scene candidates by pair (stable: keeps the reference order inside a pair)
-    std::vector<int> cpair(cs.size());
-    for (size_t i = 0; i < cs.size(); i++) cpair[i] = pair_of(cs[i].kf, cs[i].host);
-    std::vector<int> order; std::vector<int32_t> sc_off_tmp;
-    bucket_order(cpair, n_pair, order, sc_off_tmp);
-    const int n_sc = (int)cs.size();
-    P.sc_obs.resize(n_sc); P.sc_kf.resize(n_sc); P.sc_pt.resize(n_sc); P.sc_flag.resize(n_sc); P.sc_slot.assign(n_sc, -1); P.sc_uv.resize(2*(size_t)n_sc);
-    P.pair_sc_off.assign(n_pair + 1, 0);
-    for (int c = 0; c < n_sc; c++) {
-        const Cand &k = cs[order[c]];
-        P.sc_obs[c] = k.obs; P.sc_kf[c] = k.kf; P.sc_pt[c] = k.pt; P.sc_flag[c] = p->sobs_flag[L][k.obs];
-        P.sc_uv[2*c] = p->sobs_uv0[L][2*k.obs]; P.sc_uv[2*c+1] = p->sobs_uv0[L][2*k.obs+1];
-        P.pair_sc_off[cpair[order[c]] + 1]++;
+    size_t n_sc_ = 0; for (auto &v : cs) n_sc_ += v.size();
+    const int n_sc = (int)n_sc_;
+    std::vector<int32_t> &sc_pair = SC.sc_pair; sc_pair.resize((size_t)n_sc);      // pair of a sorted candidate
+    {   BucketPlacer bp(pool, n_pair, SC);
+        pool.run([&](int t) { const std::vector<Cand> &v = cs[(size_t)t]; bp.begin(t, v.size()); for (const Cand &k : v) bp.count(t, pair_of(k.kf, k.host)); });
+        bp.offsets(P.pair_sc_off);
+        P.sc_obs.resize(n_sc); P.sc_kf.resize(n_sc); P.sc_pt.resize(n_sc); P.sc_flag.resize(n_sc); P.sc_slot.assign(n_sc, -1); P.sc_uv.resize(2*(size_t)n_sc);
+        pool.run([&](int t) { size_t e = 0;
+            for (const Cand &k : cs[(size_t)t]) { const int q = bp.key(t, e); const int c = bp.next(t, e);
+                P.sc_obs[c] = k.obs; P.sc_kf[c] = k.kf; P.sc_pt[c] = k.pt; P.sc_flag[c] = p->sobs_flag[L][k.obs]; sc_pair[(size_t)c] = q;
+                P.sc_uv[2*(size_t)c] = p->sobs_uv0[L][2*(size_t)k.obs]; P.sc_uv[2*(size_t)c+1] = p->sobs_uv0[L][2*(size_t)k.obs+1]; } });
     }
-    for (int q = 0; q < n_pair; q++) P.pair_sc_off[q+1] += P.pair_sc_off[q];
     lap("candidate order");
     // ---- text groups and their pair CSR
     const int n_tg = (int)gs.size();
@@ -232,18 +323,18 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     P.pair_tg.resize(n_tg);
     { std::vector<int> cur(P.pair_tg_off.begin(), P.pair_tg_off.end() - 1);
       for (int g = 0; g < n_tg; g++) P.pair_tg[cur[P.tg_pair[g]]++] = g; }
-    // ---- landmark slots (landmark-major; last slot of a landmark = its host pose)
-    {
-        std::vector<int> cnt(n_pt + 1, 0);
-        for (int c = 0; c < n_sc; c++) if (p->pt_host[P.sc_pt[c]] >= 0) cnt[P.sc_pt[c]]++;
-        P.pls_off.assign(n_pt + 1, 0);
-        for (int j = 0; j < n_pt; j++) P.pls_off[j+1] = P.pls_off[j] + (cnt[j] > 0 ? cnt[j] + 1 : 0);
-        int ns = P.pls_off[n_pt];
+    // ---- landmark slots (landmark-major; last slot of a landmark = its host pose): the sorted candidates placed by point
+    {   BucketPlacer bl(pool, n_pt, SC);
+        pool.run([&](int t) { size_t c0, c1; pool.range((size_t)n_sc, t, c0, c1); bl.begin(t, c1 - c0);
+            for (size_t c = c0; c < c1; c++) { const int j = P.sc_pt[c]; bl.count(t, p->pt_host[j] >= 0 ? j : -1); } });
+        bl.offsets(P.pls_off, 1);
+        const int ns = P.pls_off[n_pt];
         P.pslot_pose.assign(ns, -1); P.pslot_pair.assign(ns, -1); P.pslot_lm.assign(ns, -1);
-        std::vector<int> cur(P.pls_off.begin(), P.pls_off.end() - 1);
-        for (int c = 0; c < n_sc; c++) { int j = P.sc_pt[c]; if (p->pt_host[j] < 0) continue;
-            int s = cur[j]++; P.sc_slot[c] = s; P.pslot_pose[s] = P.sc_kf[c]; P.pslot_pair[s] = pair_of(P.sc_kf[c], p->pt_host[j]); P.pslot_lm[s] = j; }
-        for (int j = 0; j < n_pt; j++) if (cnt[j] > 0) { int s = P.pls_off[j+1] - 1; P.pslot_pose[s] = p->pt_host[j]; P.pslot_lm[s] = j; }
+        pool.run([&](int t) { size_t c0, c1; pool.range((size_t)n_sc, t, c0, c1); size_t e = 0;
+            for (size_t c = c0; c < c1; c++) { const int s = bl.next(t, e); if (s < 0) continue;
+                P.sc_slot[c] = s; P.pslot_pose[s] = P.sc_kf[c]; P.pslot_pair[s] = sc_pair[c]; P.pslot_lm[s] = P.sc_pt[c]; } });
+        pool.run([&](int t) { size_t j0, j1; pool.range((size_t)n_pt, t, j0, j1);
+            for (size_t j = j0; j < j1; j++) if (P.pls_off[j+1] > P.pls_off[j]) { const int s = P.pls_off[j+1] - 1; P.pslot_pose[s] = p->pt_host[j]; P.pslot_lm[s] = (int)j; } });
     }
     {
         std::vector<int> cnt(n_text + 1, 0);
@@ -257,36 +348,42 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             int s = cur[j]++; P.tg_slot[g] = s; P.tslot_pose[s] = P.tg_kf[g]; P.tslot_pair[s] = P.tg_pair[g]; P.tslot_lm[s] = j; }
         for (int j = 0; j < n_text; j++) if (cnt[j] > 0) { int s = P.tls_off[j+1] - 1; P.tslot_pose[s] = p->text_host[j]; P.tslot_lm[s] = j; }
     }
+    {   // the point slots of every pose (0.57 M slots at 5000 keyframes)
+        const size_t n_ps = (size_t)P.n_pslot();
+        BucketPlacer bq(pool, n_kf, SC);
+        pool.run([&](int t) { size_t s0, s1; pool.range(n_ps, t, s0, s1); bq.begin(t, s1 - s0); for (size_t s = s0; s < s1; s++) bq.count(t, P.pslot_pose[s]); });
+        bq.offsets(P.pose_ps_off);
+        P.pose_ps.resize(n_ps); P.pose_ps_lm.resize(n_ps);
+        pool.run([&](int t) { size_t s0, s1; pool.range(n_ps, t, s0, s1); size_t e = 0;
+            for (size_t s = s0; s < s1; s++) { const int at = bq.next(t, e); P.pose_ps[at] = (int)s; P.pose_ps_lm[at] = P.pslot_lm[s]; } });
+    }
     lap("groups + landmark slots");
     // ---- reduced-system blocks: key = a*n_kf + b (a <= b)
     auto bkey = [&](int a, int b) { return (int64_t)a*n_kf + b; };
     KeyIndex bk; bk.begin((int64_t)n_kf*n_kf);
-    // slot pairs (s1, s2) of every landmark with pose(s1) <= pose(s2), in landmark-major generation order; they are visited twice
-    // (count per block, then place) instead of being materialised and sorted: 3 M pairs at 5000 keyframes
-    auto each_pair = [&](const std::vector<int32_t> &off, const std::vector<int32_t> &pose, int n_lm, auto &&f) {
-        for (int j = 0; j < n_lm; j++) for (int s1 = off[j]; s1 < off[j+1]; s1++) for (int s2 = off[j]; s2 < off[j+1]; s2++) {
-            const int a = pose[s1], b = pose[s2]; if (a > b) continue; f(bkey(a, b), s1, s2); }
-    };
-    // large maps: T host threads over contiguous landmark ranges with about the same number of slots each
-    auto threads_for = [&](size_t n_slot, int n_lm) { int T = 1;
-        if (n_slot > 200000) T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()/2));
-        if (tsba_plan_threads > 0) T = std::min(tsba_plan_threads, std::max(1, n_lm));
-        return T; };
-    auto split_landmarks = [&](const std::vector<int32_t> &loff, int n_lm, int T) { std::vector<int> lo(T + 1, 0); const size_t n_slot = (size_t)loff[n_lm];
+    // slot pairs (s1, s2) of every landmark with pose(s1) <= pose(s2), in landmark-major generation order; they are visited three times
+    // (mark the block, count per block, place) instead of being materialised and sorted: 2 M pairs at 5000 keyframes.  Thread t takes the
+    // landmarks [lo[t], lo[t+1]): about the same number of slots each.
+    auto split_landmarks = [&](const std::vector<int32_t> &loff, int n_lm) { std::vector<int> lo((size_t)T + 1, 0); const size_t n_slot = n_lm > 0 ? (size_t)loff[n_lm] : 0;
         for (int t = 1; t < T; t++) lo[t] = (int)(std::lower_bound(loff.begin(), loff.begin() + n_lm + 1, (int32_t)(n_slot*t/T)) - loff.begin());
         lo[T] = n_lm; return lo; };
     auto range_pairs = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, int j0, int j1, auto &&f) {
         for (int j = j0; j < j1; j++) for (int s1 = loff[j]; s1 < loff[j+1]; s1++) for (int s2 = loff[j]; s2 < loff[j+1]; s2++) {
             const int a = pose[s1], b2 = pose[s2]; if (a > b2) continue; f(bkey(a, b2), s1, s2); } };
-    auto mark_blocks = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, int n_lm) {
-        const int T = (n_lm > 0 && bk.concurrent() && tsba_plan_mark_mt) ? threads_for((size_t)loff[n_lm], n_lm) : 1;
-        if (T <= 1) { each_pair(loff, pose, n_lm, [&](int64_t k, int, int) { bk.add(k); }); return; }
-        const std::vector<int> lo = split_landmarks(loff, n_lm, T);
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++) th.emplace_back([&, t]() { range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t k, int, int) { bk.add_mt(k); }); });
-        for (auto &x : th) x.join(); };
-    mark_blocks(P.pls_off, P.pslot_pose, n_pt);
-    mark_blocks(P.tls_off, P.tslot_pose, n_text);
+    const std::vector<int> lo_pt = split_landmarks(P.pls_off, n_pt), lo_tx = split_landmarks(P.tls_off, n_text);
+    // marking the blocks of the point slots: by POSE (thread t the poses [a0, a1) with about the same number of slots: every slot of pose a, every
+    // slot of its landmark at a pose b >= a) -- a thread then writes its own rows of the key bitmap only; landmark-major, every thread wrote
+    // every row, and each of the 45 k first-time writes took the line out of fifteen other caches
+    if (T > 1 && tsba_plan_mark_mt) {
+        const size_t n_ps = (size_t)P.n_pslot();
+        pool.run([&](int t) {
+            const int a0 = (int)(std::lower_bound(P.pose_ps_off.begin(), P.pose_ps_off.end(), (int32_t)(n_ps*(size_t)t/(size_t)T)) - P.pose_ps_off.begin());
+            const int a1 = t + 1 == T ? n_kf : (int)(std::lower_bound(P.pose_ps_off.begin(), P.pose_ps_off.end(), (int32_t)(n_ps*(size_t)(t + 1)/(size_t)T)) - P.pose_ps_off.begin());
+            for (int a = std::min(a0, n_kf); a < std::min(a1, n_kf); a++)
+                for (int x = P.pose_ps_off[a]; x < P.pose_ps_off[a+1]; x++) { const int j = P.pose_ps_lm[x];
+                    for (int s2 = P.pls_off[j]; s2 < P.pls_off[j+1]; s2++) { const int b = P.pslot_pose[s2]; if (b >= a) bk.add_mt(bkey(a, b)); } } });
+    } else range_pairs(P.pls_off, P.pslot_pose, 0, n_pt, [&](int64_t k, int, int) { bk.add(k); });
+    range_pairs(P.tls_off, P.tslot_pose, 0, n_text, [&](int64_t k, int, int) { bk.add(k); });
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bk.add(bkey(i, i));
         if (h >= 0) { bk.add(bkey(h, h)); bk.add(bkey(std::min(i, h), std::max(i, h))); } }
     if (n_kf <= 64) for (int a = 0; a < n_kf; a++) for (int b = a; b < n_kf; b++) bk.add(bkey(a, b));   // small windows: dense S, no memset
@@ -300,45 +397,23 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; if (h < 0) continue;
         int bl = blk_of(bkey(std::min(i, h), std::max(i, h)));
         if (i < h) P.sb_pab[bl] = q; else P.sb_pba[bl] = q; }     // pab: target = a, host = b;  pba: target = b, host = a
-    // Large maps (2 M slot pairs at 5000 keyframes: 31 ms of the 60 ms plan on one thread): T host threads take contiguous landmark ranges.
-    // Pass 1: a thread records the block of each of its pairs and counts per block; the block offsets and every thread's first position in
-    // every block follow from the counts (thread-major within a block = landmark-major: the same order as one thread produces); pass 2
-    // places.  The result does not depend on T.
-    auto fill_tri = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, const std::vector<int32_t> &lm_of, int n_lm,
+    // the slot pairs placed by block, stable: the landmark-major generation order is kept within a block
+    auto fill_tri = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, const std::vector<int32_t> &lm_of, const std::vector<int> &lo,
                         std::vector<int32_t> &off, std::vector<int32_t> &s1v, std::vector<int32_t> &s2v, std::vector<int32_t> &lmv) {
-        off.assign((size_t)n_sb + 1, 0);                          // stable by block: the landmark-major generation order is kept
+        const int n_lm = lo[(size_t)T];
         const size_t n_slot = n_lm > 0 ? (size_t)loff[n_lm] : 0;
-        const int T = threads_for(n_slot, n_lm);
-        if (T <= 1) {
-            each_pair(loff, pose, n_lm, [&](int64_t k, int, int) { off[(size_t)blk_of(k) + 1]++; });
-            for (int q = 0; q < n_sb; q++) off[q+1] += off[q];
-            const size_t tot = (size_t)off[n_sb];
-            s1v.resize(tot); s2v.resize(tot); lmv.resize(tot);
-            std::vector<int32_t> cur(off.begin(), off.end() - 1);
-            each_pair(loff, pose, n_lm, [&](int64_t k, int s1, int s2) { const int at = cur[blk_of(k)]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; });
-            return;
-        }
-        const std::vector<int> lo = split_landmarks(loff, n_lm, T);
-        std::vector<std::vector<int32_t> > blk(T), cnt(T);
-        {   std::vector<std::thread> th;
-            for (int t = 0; t < T; t++) th.emplace_back([&, t]() { cnt[t].assign((size_t)n_sb, 0); blk[t].reserve(4*n_slot/T + 1024);
-                range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t k, int, int) { const int q = blk_of(k); blk[t].push_back(q); cnt[t][(size_t)q]++; }); });
-            for (auto &x : th) x.join(); }
-        lap("  slot pairs: pass 1 (threads)");
-        for (int q = 0; q < n_sb; q++) { int32_t run = off[q];    // off[q] is the start of block q; cnt[t][q] becomes thread t's first position in it
-            for (int t = 0; t < T; t++) { const int32_t c = cnt[t][(size_t)q]; cnt[t][(size_t)q] = run; run += c; }
-            off[q+1] = run; }
+        if (n_slot == 0) { off.assign((size_t)n_sb + 1, 0); return; }
+        BucketPlacer bp(pool, n_sb, SC);
+        pool.run([&](int t) { bp.begin(t, 4*n_slot/(size_t)T + 1024); range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t k, int, int) { bp.count(t, blk_of(k)); }); });
+        lap("  slot pairs: count");
+        bp.offsets(off);
         const size_t tot = (size_t)off[n_sb];
-        lap("  slot pairs: offsets");
         s1v.resize(tot); s2v.resize(tot); lmv.resize(tot);
-        lap("  slot pairs: resize");
-        {   std::vector<std::thread> th;
-            for (int t = 0; t < T; t++) th.emplace_back([&, t]() { size_t e = 0;
-                range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t, int s1, int s2) { const int at = cnt[t][(size_t)blk[t][e++]]++; s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; }); });
-            for (auto &x : th) x.join(); }
+        lap("  slot pairs: offsets + resize");
+        pool.run([&](int t) { size_t e = 0; range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t, int s1, int s2) { const int at = bp.next(t, e); s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; }); });
     };
-    fill_tri(P.pls_off, P.pslot_pose, P.pslot_lm, n_pt, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2, P.sb_pt_lm);      // (lm: saves one dependent gather in k_schur)
-    fill_tri(P.tls_off, P.tslot_pose, P.tslot_lm, n_text, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2, P.sb_tx_lm);
+    fill_tri(P.pls_off, P.pslot_pose, P.pslot_lm, lo_pt, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2, P.sb_pt_lm);      // (lm: saves one dependent gather in k_schur)
+    fill_tri(P.tls_off, P.tslot_pose, P.tslot_lm, lo_tx, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2, P.sb_tx_lm);
     lap("slot pairs by block");
     // ---- per-pose lists
     auto csr = [&](int n, const std::vector<std::pair<int,int>> &items, std::vector<int32_t> &off, std::vector<int32_t> &val) {
@@ -348,12 +423,11 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         std::vector<int> cur(off.begin(), off.end() - 1);
         for (auto &it : items) val[cur[it.first]++] = it.second;
     };
-    P.pt_pose6.assign(6*(size_t)n_pt, 0);
-    for (int j = 0; j < n_pt; j++) { const int o = P.pls_off[j], e = P.pls_off[j+1];
-        for (int u = 0; u < 6; u++) P.pt_pose6[6*(size_t)j + u] = e > o ? P.pslot_pose[std::min(o + u, e - 1)] : 0; }
-    P.pt_pair4.assign(4*(size_t)n_pt, 0);
-    for (int j = 0; j < n_pt; j++) { const int o = P.pls_off[j], e = P.pls_off[j+1];       // observer slots [o, e-1), host slot e-1
-        for (int u = 0; u < 4; u++) P.pt_pair4[4*(size_t)j + u] = e - 1 > o ? P.pslot_pair[std::min(o + u, e - 2)] : 0; }
+    P.pt_pose6.resize(6*(size_t)n_pt); P.pt_pair4.resize(4*(size_t)n_pt);
+    pool.run([&](int t) { size_t j0, j1; pool.range((size_t)n_pt, t, j0, j1);
+        for (size_t j = j0; j < j1; j++) { const int o = P.pls_off[j], e = P.pls_off[j+1];       // observer slots [o, e-1), host slot e-1
+            for (int u = 0; u < 6; u++) P.pt_pose6[6*j + u] = e > o ? P.pslot_pose[std::min(o + u, e - 1)] : 0;
+            for (int u = 0; u < 4; u++) P.pt_pair4[4*j + u] = e - 1 > o ? P.pslot_pair[std::min(o + u, e - 2)] : 0; } });
     P.tg_ppos.assign(n_tg, 0);
     for (size_t k = 0; k < P.pair_tg.size(); k++) P.tg_ppos[P.pair_tg[k]] = (int)k;
     P.tg_rec.resize(8*(size_t)n_tg);
@@ -378,15 +452,18 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         // A wide envelope (beyond the streaming band solvers: 26 pose blocks) on a large map: try the reverse Cuthill-McKee order of the
         // co-visibility graph (all ranks' observations, so that every rank of a sharded solve derives the same order)
         if (keep_inc && P.bw_pose > 26) {
-            // poses of every landmark (observers + host), sorted and distinct, as one CSR list (70 k small lists at 5000 keyframes: a
-            // vector per landmark spent more time in the allocator than in the loops below)
+            // poses of every landmark (observers + host), sorted and distinct, as one CSR list -- from ALL observations (a second pass over
+            // them: only maps with a wide envelope come here)
             const size_t n_lm = (size_t)n_pt + n_text;
             std::vector<int32_t> po_off(n_lm + 1, 0), po_n(n_lm, 0), po;
-            for (size_t e = 0; e < lp_lm.size(); e++) po_off[(size_t)lp_lm[e] + 1]++;
+            auto each_incidence = [&](auto &&f) {
+                for (int s = 0; s < n_obs; s++) { const int kf = p->sobs_kf[L][s], pt = p->sobs_pt[L][s], host = p->pt_host[pt]; if (host >= 0 && host != kf) f((size_t)pt, kf); }
+                if (o->use_text) for (int t = 0; t < p->n_tobs; t++) { const int kf = p->tobs_kf[t], j = p->tobs_text[t], host = p->text_host[j]; if (host >= 0 && host != kf) f((size_t)n_pt + j, kf); } };
+            each_incidence([&](size_t lm, int) { po_off[lm + 1]++; });
             for (size_t j = 0; j < n_lm; j++) { if (lm_hi[j] >= 0) po_off[j + 1]++; po_off[j + 1] += po_off[j]; }
             po.resize((size_t)po_off[n_lm]);
             for (size_t j = 0; j < n_lm; j++) if (lm_hi[j] >= 0) po[(size_t)po_off[j] + po_n[j]++] = j < (size_t)n_pt ? p->pt_host[j] : p->text_host[j - n_pt];
-            for (size_t e = 0; e < lp_lm.size(); e++) { const size_t j = (size_t)lp_lm[e]; po[(size_t)po_off[j] + po_n[j]++] = lp_kf[e]; }
+            each_incidence([&](size_t lm, int kf) { po[(size_t)po_off[lm] + po_n[lm]++] = kf; });
             for (size_t j = 0; j < n_lm; j++) { if (po_n[j] < 2) continue; int32_t *b = &po[(size_t)po_off[j]];
                 std::sort(b, b + po_n[j]); po_n[j] = (int32_t)(std::unique(b, b + po_n[j]) - b); }
             struct PoseList { const int32_t *p; size_t n; size_t size() const { return n; } int operator[](size_t i) const { return p[i]; } int back() const { return p[n - 1]; }
@@ -467,18 +544,16 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             }
         }
     }
-    std::vector<std::pair<int,int>> it_t, it_h, it_ps, it_ts;
+    std::vector<std::pair<int,int>> it_t, it_h, it_ts;
     for (int q = 0; q < n_pair; q++) { it_t.push_back({ P.pair_i[q], q }); if (P.pair_h[q] >= 0) it_h.push_back({ P.pair_h[q], q }); }
-    for (int s = 0; s < P.n_pslot(); s++) it_ps.push_back({ P.pslot_pose[s], s });
     for (int s = 0; s < P.n_tslot(); s++) it_ts.push_back({ P.tslot_pose[s], s });
     csr(n_kf, it_t, P.pose_t_off, P.pose_t); csr(n_kf, it_h, P.pose_h_off, P.pose_h);
     // pairs are sorted by (target, host): pose_t[k] == k, and the host-side products are stored host-major so that the per-pose
     // sums of both kinds read contiguous ranges
     P.pair_hpos.assign(n_pair, -1);
     for (size_t k = 0; k < P.pose_h.size(); k++) P.pair_hpos[P.pose_h[k]] = (int)k;
-    csr(n_kf, it_ps, P.pose_ps_off, P.pose_ps); csr(n_kf, it_ts, P.pose_ts_off, P.pose_ts);
-    P.pose_ps_lm.resize(P.pose_ps.size()); P.pose_ts_lm.resize(P.pose_ts.size());
-    for (size_t k = 0; k < P.pose_ps.size(); k++) P.pose_ps_lm[k] = P.pslot_lm[P.pose_ps[k]];
+    csr(n_kf, it_ts, P.pose_ts_off, P.pose_ts);
+    P.pose_ts_lm.resize(P.pose_ts.size());
     for (size_t k = 0; k < P.pose_ts.size(); k++) P.pose_ts_lm[k] = P.tslot_lm[P.pose_ts[k]];
     lap("per-pose lists");
 }

@@ -4,7 +4,8 @@
 #   2. the adapter gather / scatter templates + the C++ ABI driver under g++ ASan + UBSan (six problem types);
 #   3. the HOST side of libtsba.so (plan builder, reordering, index validation, upload staging, C ABI) under clang ASan + UBSan --
 #      the CPU tests here; with a GPU (argument "gpu") also the GPU parity tests, i.e. real uploads / solves through the instrumented host
-#      code (device code is not instrumented: gfx950 ASan needs xnack, which this pool does not enable).
+#      code (device code is not instrumented: gfx950 ASan needs xnack, which this pool does not enable);
+#   4. the plan builder's host threads under clang TSan.
 # Usage: bash tools/sanitize.sh [gpu]   -> gpurun_out/r02_sanitizers.log (summary lines "SANITIZE <what>: <result>")
 set -u
 cd "$(dirname "$0")/.."
@@ -52,5 +53,13 @@ if [ "${1:-}" = "gpu" ]; then
   say "libtsba host code (clang UBSan + bounds), GPU parity tests through the instrumented host side: $(grep -E 'passed|failed' /tmp/san_gpu.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log)"
   grep -B2 -A12 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log | head -60 >> $LOG
 fi
+# ---- 4. the plan builder's host threads (fork-join pool, shared key bitmaps, atomic min / max, stable bucket placement) under clang TSan:
+#         every plan of tools/diag/plan_checksums.py (windows, maps, loop closures, text planes, shards) built with 1, 3 and 16 threads
+CTSAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.tsan-x86_64.so)
+(cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=thread -fno-omit-frame-pointer -Wno-unused-variable -Wno-unused-value -o /tmp/libtsba_tsan.so tsba.hip 2>/dev/null) || say "libtsba TSan build: FAILED"
+TSBA_LIB=/tmp/libtsba_tsan.so LD_PRELOAD="$CTSAN" HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES=-1 TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" timeout 1500 python tools/diag/plan_checksums.py > /tmp/san_tsan.txt 2> /tmp/san_tsan.err
+python tools/diag/plan_checksums.py > /tmp/san_plain.txt 2>/dev/null
+say "libtsba plan builder (clang TSan, 1 / 3 / 16 host threads): $(wc -l < /tmp/san_tsan.txt) plans built, $(diff /tmp/san_plain.txt /tmp/san_tsan.txt | grep -c '^[<>]') checksum differences against the plain build ; reports: $(grep -c 'WARNING: ThreadSanitizer' /tmp/san_tsan.err)"
+grep -A12 'WARNING: ThreadSanitizer' /tmp/san_tsan.err | head -40 >> $LOG
 grep -B2 -A12 'ERROR: AddressSanitizer\|runtime error' /tmp/san_oracle.log /tmp/san_host.log 2>/dev/null | head -80 >> $LOG
 cat $LOG | grep SANITIZE
