@@ -224,3 +224,25 @@ def test_ring_partition_with_a_tail(lib, nf, row0, B, Gmax, Ptmax):
         pos = b + B                                              # the separator on its right
         if p == Pt - 1: assert b == row0                         # the tail ends where S begins
     assert pos == nf + B                                         # the ghost of S behind the last pose
+
+
+def test_plan_threads_leave_the_callers_cpu_affinity_alone():
+    """A multi-threaded plan build pins its threads -- and, for its duration, the calling thread -- to the CPUs that share the caller's L3
+    (tsba_plan.h: PlanPool).  Afterwards the caller's affinity mask is what it was, whether or not the pinning applied on this host."""
+    import os
+    from textslam_amd import synth, abi
+    from textslam_amd.optimizer import load_library
+    L = load_library()
+    L.tsba_debug_plan_checksum.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int]; L.tsba_debug_plan_checksum.restype = C.c_ulonglong
+    L.tsba_debug_plan_knob.argtypes = [C.c_int, C.c_int]; L.tsba_debug_plan_knob.restype = None
+    P = synth.config_global(n_kf=300, n_pt=8000, band=8); o = abi.options_global(); s = P.struct()
+    before = os.sched_getaffinity(0)
+    sums = []
+    try:
+        for pin in (1, 0, 1):
+            L.tsba_debug_plan_knob(3, pin)
+            sums.append(L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, 6))
+            assert os.sched_getaffinity(0) == before
+    finally:
+        L.tsba_debug_plan_knob(3, 1)
+    assert sums[0] == sums[1] == sums[2] != 0
