@@ -42,6 +42,30 @@ def _pmc_traffic(name):
     return None, None
 
 
+def usable_cores():
+    """CPUs this process can actually run on at once: the online CPUs, cut by the affinity mask and by the cgroup's CPU quota (the GPU
+    boxes of this pool show 256 CPUs under a quota of 16: an OpenMP team of 256 there is 16 CPUs' worth of time slices)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(float(quota)/float(period) + 0.5)))
+        except (OSError, ValueError):
+            pass
+    try:                                                  # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, int(q/per + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_local(prob, opt_ref):
     """The CPU restatement of the reference path (oracle source, Ceres-style central-difference text Jacobians) timed on this host:
     the full LocalBundleAdjustment call on the same window, once with the reference's own setting (1 thread: num_threads = 1,
@@ -51,7 +75,7 @@ def cpu_baseline_local(prob, opt_ref):
     L = oracle.baseline_lib()
     o = abi.TsbaOptions.from_buffer_copy(opt_ref)
     o.text_jacobian = 1                       # NumericDiffCostFunction<CENTRAL>, nume_BAText.h:97-100
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     res = {}
     for nt in sorted({1, min(16, cores), cores}):      # the restatement's accumulation is serial: a moderate team often beats all cores
         oracle.omp_set_threads(nt)
@@ -61,7 +85,8 @@ def cpu_baseline_local(prob, opt_ref):
     best = max(res, key=lambda k: res[k][0])
     return {"value": res[best][0], "unit": "residuals/s", "cores": best, "kind": "port",
             "sample": "the full LocalBundleAdjustment call (3 passes) on the same window, numeric-diff text Jacobians, gcc -O3 -march=native -fopenmp; "
-                      "value = the best of the thread counts tried (1 = the reference's own num_threads setting, 16, all %d host cores)" % cores,
+                      "value = the best of the thread counts tried (1 = the reference's own num_threads setting, 16, all %d CPUs this process may use: "
+                      "%d online, affinity mask and cgroup quota applied)" % (cores, os.cpu_count() or 1),
             "seconds": res[best][1], "single_thread_value": res[1][0], "single_thread_seconds": res[1][1],
             "all_core_value": res[cores][0], "all_cores": cores, "by_threads": {str(k): v[0] for k, v in res.items()}}
 
@@ -70,9 +95,9 @@ def cpu_baseline_global(prob, opt):
     """The same 5000-keyframe map through the CPU restatement (band storage of H_pp / S + band Cholesky), 1 thread and all cores."""
     import oracle
     L = oracle.baseline_lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     res = {}
-    for nt in (1, cores):
+    for nt in sorted({1, cores}):
         oracle.omp_set_threads(nt)
         t0 = time.perf_counter(); rep = oracle.solve(prob.copy(), opt, library=L); dt = time.perf_counter() - t0
         res[nt] = (rep["n_resid_evals"]/dt, dt)
