@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include "../../include/tsba.h"
 
 static int tsba_plan_threads = 0;              // 0: by problem size; > 0: host threads of the plan builder's parallel sections (tests)
@@ -192,6 +193,14 @@ inline bool plan_l3_cpuset(cpu_set_t *set) {
     cpu_set_t allowed; if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) CPU_AND(set, set, &allowed);
     return CPU_COUNT(set) >= 2;
 }
+// CPUs this process may run on at once: the affinity mask, cut by the cgroup's CPU quota (read once)
+inline int plan_usable_cpus() {
+    static const int n = []() { int c = (int)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t m; if (sched_getaffinity(0, sizeof m, &m) == 0) c = std::min(c, std::max(1, CPU_COUNT(&m)));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[64]; long per = 0; if (fscanf(f, "%63s %ld", q, &per) == 2 && per > 0 && strcmp(q, "max") != 0) c = std::min(c, std::max(1, (int)((atol(q) + per/2)/per))); fclose(f); }
+        return c; }();
+    return n;
+}
 struct PlanPool {
     int T; std::vector<std::thread> th; std::atomic<int> gen{0}, done{0}; std::atomic<bool> stop{false};
     const std::function<void(int)> *job = nullptr;
@@ -246,7 +255,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     P.level = L;
     const int n_kf = p->n_kf, n_pt = p->n_pt, n_text = p->n_text, n_obs = p->n_sobs[L];
     int T = 1;
-    if ((size_t)n_obs > 100000) T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()/2));
+    if ((size_t)n_obs > 100000) T = std::max(1, std::min(std::min(16, plan_usable_cpus()), (int)(std::thread::hardware_concurrency()/2)));
     if (tsba_plan_threads > 0) T = tsba_plan_threads;
     if ((int64_t)n_kf*(n_kf + 1) > ((int64_t)1 << 31)) T = 1;       // (the key sets below are shared bitmaps only up to 2^31 keys)
     PlanPool pool(T, tsba_plan_pin != 0);
