@@ -34,6 +34,22 @@ struct TextSlamTraits {
     }
     // optimizer.cc:321-325
     static void set_theta(MapText &obj, const double th[3]) { TextSLAM::Mat31 N(th[0], th[1], th[2]); obj.RefKF->SetN(N, obj.GetNidx()); }
+    // ---- loop closing (adapter/tsloop_gather.hpp): the reference's own Sim3_loop (setting.h:129-171) does the algebra
+    typedef TextSLAM::Sim3_loop Sim3;
+    static Sim3 sim_make(const double q[4], const double t[3], double s) {
+        Eigen::Quaterniond e(q[0], q[1], q[2], q[3]); e = e.normalized();
+        return Sim3(e, Eigen::Vector3d(t[0], t[1], t[2]), s);
+    }
+    static Sim3 sim_of_pose(const TextSLAM::Mat33 &R, const TextSLAM::Mat31 &t, double s) { return Sim3(R, t, s); }     // optimizer.cc:794-796
+    static void sim_get(const Sim3 &S, bool normalise, double out[8]) {
+        Eigen::Quaterniond e = S.r; if (normalise) e = e.normalized();
+        out[0] = e.w(); out[1] = e.x(); out[2] = e.y(); out[3] = e.z(); out[4] = S.t(0); out[5] = S.t(1); out[6] = S.t(2); out[7] = S.s;
+    }
+    // optimizer.cc:887-906: q normalised, T = [R(q) | t / s], SetPose(T)
+    static void set_pose_sim(KeyFrame &kf, const double pose[8]) {
+        const double p7[7] = { pose[0], pose[1], pose[2], pose[3], pose[4]/pose[7], pose[5]/pose[7], pose[6]/pose[7] };
+        set_pose(kf, p7);
+    }
     // nume_BAText.h:25: the cost functors index cv::Mat::data directly, i.e. continuous CV_8UC1 with step == cols
     static const uint8_t *img(const cv::Mat &im) { CV_Assert(im.type() == CV_8UC1 && im.isContinuous()); return im.data; }
     static int img_w(const cv::Mat &im) { return im.cols; }

@@ -95,6 +95,21 @@ inline void quat_to_R(const double q[4], Mat33 &R) {
     R(2, 0) = txz - twy; R(2, 1) = tyz + twx; R(2, 2) = 1 - (txx + tyy);
 }
 
+// ---- loop closing: setting.h:129-171 (Sim3_loop), :173-189 (FeatureConvert), cv::KeyPoint::pt
+struct Sim3_loop {
+    double r[4]; Vec3 t; double s;                                    // r = (w, x, y, z)
+    Sim3_loop() : s(1.0) { r[0] = 1; r[1] = r[2] = r[3] = 0; t(0) = t(1) = t(2) = 0; }
+    static void qmul(const double a[4], const double b[4], double o[4]) {
+        o[0] = a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3]; o[1] = a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2];
+        o[2] = a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1]; o[3] = a[0]*b[3] + a[1]*b[2] - a[2]*b[1] + a[3]*b[0]; }
+    static Vec3 rot(const double q[4], const Vec3 &v) { Mat33 R; quat_to_R(q, R); Vec3 o; for (int i = 0; i < 3; i++) o(i) = R(i, 0)*v(0) + R(i, 1)*v(1) + R(i, 2)*v(2); return o; }
+    Sim3_loop inverse() const { Sim3_loop o; o.r[0] = r[0]; o.r[1] = -r[1]; o.r[2] = -r[2]; o.r[3] = -r[3];
+        Vec3 u; for (int i = 0; i < 3; i++) u(i) = (-1.0/s)*t(i); o.t = rot(o.r, u); o.s = 1.0/s; return o; }       // (r*, r*((-1/s) t), 1/s)
+    Sim3_loop operator*(const Sim3_loop &b) const { Sim3_loop o; qmul(r, b.r, o.r); Vec3 u = rot(r, b.t); for (int i = 0; i < 3; i++) o.t(i) = s*u(i) + t(i); o.s = s*b.s; return o; }
+};
+struct KeyPoint { struct Pt { float x, y; } pt; };
+struct FeatureConvert { Mat31 posWorld, posObv; int FlagTS; mapText *obj; mapPts *pt; keyframe *KF; int idx2d; KeyPoint obv2d; Vec2 obv2dPred; };
+
 // The Traits adapter/tsba_gather.hpp asks for (adapter/textslam_traits.hpp is the same over the real types)
 struct Traits {
     typedef mock::map Map; typedef mock::keyframe KeyFrame; typedef mock::frame Frame; typedef mock::mapPts MapPt; typedef mock::mapText MapText;
@@ -117,6 +132,20 @@ struct Traits {
         kf.SetPose(Tcw);
     }
     static void set_theta(mapText &obj, const double th[3]) { Mat31 N; N(0) = th[0]; N(1) = th[1]; N(2) = th[2]; obj.RefKF->SetN(N, obj.GetNidx()); }
+    // loop closing (adapter/tsloop_gather.hpp)
+    typedef mock::Sim3_loop Sim3;
+    static Sim3 sim_make(const double q[4], const double t[3], double s) { Sim3 S; const double n = std::sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+        for (int a = 0; a < 4; a++) S.r[a] = q[a]/n;
+        for (int a = 0; a < 3; a++) S.t(a) = t[a];
+        S.s = s; return S; }
+    static Sim3 sim_of_pose(const Mat33 &R, const Mat31 &t, double s) { double q[4]; quat_of(R, q); const double tt[3] = { t(0), t(1), t(2) }; return sim_make(q, tt, s); }
+    static void sim_get(const Sim3 &S, bool normalise, double out[8]) { const double n = normalise ? std::sqrt(S.r[0]*S.r[0] + S.r[1]*S.r[1] + S.r[2]*S.r[2] + S.r[3]*S.r[3]) : 1.0;
+        for (int a = 0; a < 4; a++) out[a] = S.r[a]/n;
+        for (int a = 0; a < 3; a++) out[4 + a] = S.t(a);
+        out[7] = S.s; }
+    static void set_pose_sim(keyframe &kf, const double pose[8]) {                                  // optimizer.cc:887-906: T = [R(q / |q|) | t / s]
+        const double p7[7] = { pose[0], pose[1], pose[2], pose[3], pose[4]/pose[7], pose[5]/pose[7], pose[6]/pose[7] };
+        set_pose(kf, p7); }
     static const uint8_t *img(const Image &im) { return im.data.data(); }
     static int img_w(const Image &im) { return im.cols; }
     static int img_h(const Image &im) { return im.rows; }

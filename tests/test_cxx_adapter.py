@@ -157,3 +157,127 @@ def test_cxx_solve_and_scatter_matches_python_mirror(tmp_path, name):
     if mode in ("local", "landmarker", "pose"):
         assert np.array_equal(res["sgood"], G.sgood.reshape(-1)) and np.array_equal(res["tobs_good"], G.tobs_good.reshape(-1)) and np.array_equal(res["tfgood"], G.tfgood.reshape(-1))
     assert not np.array_equal(G.rho, P.rho) or mode == "pose"
+
+
+# ---- loop closing: optimizer::OptimizeSim3 / OptimizeLoop through adapter/tsloop_gather.hpp (tests/cxx/loop_from_cxx.cpp) -------------------
+LOOP_EXE = os.path.join(ROOT, "tests", "cxx", "loop_from_cxx")
+
+
+def _put_records(path, items):
+    rec = []
+    for name, a, dt in items:
+        a = np.ascontiguousarray(a, {0: np.float64, 1: np.int32, 2: np.uint8}[dt]).reshape(-1)
+        rec.append(struct.pack("<I", len(name)) + name.encode() + struct.pack("<BQ", dt, a.size) + a.tobytes())
+    with open(path, "wb") as f:
+        f.write(b"".join(rec))
+
+
+def _sim3_case():
+    m = synth.sim3_matches(seed=6, n=200, outlier_frac=0.15)
+    m["inliers"][::17] = 0                                                   # matches an earlier RANSAC pass already rejected
+    m["sim0"][:4] *= 1.7                                                     # Sim12.r as handed over is not normalised: the gather does it (optimizer.cc:637-638)
+    return m
+
+
+def _loop_case():
+    g = synth.pose_graph(seed=4, n_kf=40)
+    n_loop = g["n_loop_edges"]
+    rng = np.random.default_rng(11)
+    g["pt_host"] = rng.integers(0, 40, 25).astype(np.int32); g["rho"] = rng.uniform(0.1, 0.6, 25)
+    g["text_host"] = rng.integers(0, 40, 6).astype(np.int32); g["theta"] = rng.normal(0, 0.3, (6, 3))
+    g["norm"] = (g["edge_i"][:-n_loop], g["edge_j"][:-n_loop]); g["loop"] = (g["edge_i"][-n_loop:], g["edge_j"][-n_loop:])
+    return g
+
+
+def _write_loop_dump(path, g):
+    mScw = g["conn_sim"][list(g["conn_idx"]).index(g["kf_cur"])]
+    _put_records(path, [("est", g["est"], 0), ("conn_idx", g["conn_idx"], 1), ("conn_sim", g["conn_sim"], 0), ("mScw", mScw, 0),
+                        ("norm_i", g["norm"][0], 1), ("norm_j", g["norm"][1], 1), ("loop_i", g["loop"][0], 1), ("loop_j", g["loop"][1], 1),
+                        ("ids", [g["kf_cur"], g["kf_loop"]], 1), ("pt_host", g["pt_host"], 1), ("rho", g["rho"], 0),
+                        ("text_host", g["text_host"], 1), ("theta", g["theta"], 0)])
+
+
+def _same_sim3_rows(a, b, tol):
+    """rows (q | t | s): equal up to the sign of q (q and -q are one rotation; a pose that went through a rotation matrix comes back with w >= 0)"""
+    a, b = np.asarray(a).reshape(-1, 8), np.asarray(b).reshape(-1, 8)
+    sign = np.where(np.abs(a[:, :4] - b[:, :4]).max(1) <= np.abs(a[:, :4] + b[:, :4]).max(1), 1.0, -1.0)[:, None]
+    np.testing.assert_allclose(a[:, :4], sign*b[:, :4], rtol=0, atol=tol)
+    np.testing.assert_allclose(a[:, 4:], b[:, 4:], rtol=0, atol=tol)
+
+
+def _check_loop_gather(res, g):
+    """the arrays pack_loop built from the object graph against the flat problem of synth.pose_graph, connection by connection"""
+    n = len(g["pose"])
+    assert np.array_equal(res["g_fixed"], g["fixed"])
+    _same_sim3_rows(res["g_pose"], g["pose"], 1e-12)
+    key = lambda i, j: np.asarray(i, np.int64)*n + np.asarray(j, np.int64)
+    n_loop = g["n_loop_edges"]; n_norm = len(g["edge_i"]) - n_loop
+    assert len(res["g_edge_i"]) == len(g["edge_i"])
+    gm = res["g_meas"].reshape(-1, 8)
+    for sl in (slice(0, n_norm), slice(n_norm, None)):                       # the normal connections come first (optimizer.cc:788-858), each group in the map's order
+        ko, kg = key(g["edge_i"][sl], g["edge_j"][sl]), key(res["g_edge_i"][sl], res["g_edge_j"][sl])
+        assert len(np.unique(ko)) == len(ko) and np.array_equal(np.sort(ko), np.sort(kg))
+        _same_sim3_rows(gm[sl][np.argsort(kg)], g["meas"][sl][np.argsort(ko)], 1e-12)
+    # std::map<keyframe *, std::set<keyframe *>> order with the keyframes in one array: by first key, then by member
+    assert np.array_equal(key(res["g_edge_i"][:n_norm], res["g_edge_j"][:n_norm]), np.sort(key(res["g_edge_i"][:n_norm], res["g_edge_j"][:n_norm])))
+
+
+def test_loop_gather_reproduces_flat_problems(tmp_path):
+    _build()
+    m = _sim3_case()
+    dump, out = str(tmp_path / "s.bin"), str(tmp_path / "so.bin")
+    _put_records(dump, [("P1", m["P1"], 0), ("P2", m["P2"], 0), ("uv1", m["uv1"], 0), ("uv2", m["uv2"], 0), ("inliers", m["inliers"], 2), ("sim0", m["sim0"], 0), ("K", m["K"], 0)])
+    r = subprocess.run([LOOP_EXE, dump, "sim3", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 3), (r.returncode, r.stdout, r.stderr)
+    assert "gather identical" in r.stdout
+    g = _loop_case()
+    dump, out = str(tmp_path / "l.bin"), str(tmp_path / "lo.bin")
+    _write_loop_dump(dump, g)
+    r = subprocess.run([LOOP_EXE, dump, "loop", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 3), (r.returncode, r.stdout, r.stderr)
+    assert "gather done" in r.stdout
+    _check_loop_gather(_read_out(out), g)
+
+
+@pytest.mark.gpu
+def test_cxx_loop_closing_solve_and_scatter(tmp_path):
+    """OptimizeSim3 / OptimizeLoop from C++: gather -> tsloop_* -> scatter into the object graph, against the Python mirror on the same flat
+    arrays and against the reference's map update (optimizer.cc:884-956) done in numpy."""
+    from textslam_amd.loop import LoopOptimizer
+    _build()
+    lo = LoopOptimizer(0)
+    m = _sim3_case()
+    dump, out = str(tmp_path / "s.bin"), str(tmp_path / "so.bin")
+    _put_records(dump, [("P1", m["P1"], 0), ("P2", m["P2"], 0), ("uv1", m["uv1"], 0), ("uv2", m["uv2"], 0), ("inliers", m["inliers"], 2), ("sim0", m["sim0"], 0), ("K", m["K"], 0)])
+    r = subprocess.run([LOOP_EXE, dump, "sim3", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "solve + scatter done" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    res = _read_out(out)
+    n_in, sim, inl, rep = lo.OptimizeSim3(m["P1"], m["uv1"], m["P2"], m["uv2"], m["inliers"], m["sim0"], m["K"])
+    assert res["meta"].tolist() == [n_in, rep["iters"], rep["termination"]] and 0 < n_in < len(inl)
+    assert np.array_equal(res["inliers"].astype(bool), inl)
+    q = sim[:4]/np.linalg.norm(sim[:4])
+    np.testing.assert_allclose(res["sim"], np.concatenate([q, sim[4:]]), rtol=0, atol=1e-12)       # Sim12 = (q normalised, t, s), optimizer.cc:683-701
+    np.testing.assert_allclose(res["cost1"][0], rep["cost1"], rtol=1e-12)
+
+    g = _loop_case()
+    dump, out = str(tmp_path / "l.bin"), str(tmp_path / "lo.bin")
+    _write_loop_dump(dump, g)
+    r = subprocess.run([LOOP_EXE, dump, "loop", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "solve + scatter done" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    res = _read_out(out)
+    _check_loop_gather(res, g)
+    x, rep = lo.OptimizeLoop(res["g_pose"].reshape(-1, 8), res["g_fixed"], res["g_edge_i"], res["g_edge_j"], res["g_meas"].reshape(-1, 8))
+    assert res["meta"].tolist() == [rep["iters"], rep["termination"]] and rep["iters"] > 1
+    np.testing.assert_allclose(res["pose_solved"].reshape(-1, 8), x, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res["cost1"][0], rep["cost1"], rtol=1e-12)
+    assert rep["cost1"] < 0.1*rep["cost0"]
+    # the map update: T_cw = [R(q / |q|) | t / s], rho *= s(host), theta *= s(host)
+    for k in range(len(x)):
+        w, a, b, c = x[k, :4]/np.linalg.norm(x[k, :4])
+        R = np.array([[1 - 2*(b*b + c*c), 2*(a*b - w*c), 2*(a*c + w*b)], [2*(a*b + w*c), 1 - 2*(a*a + c*c), 2*(b*c - w*a)], [2*(a*c - w*b), 2*(b*c + w*a), 1 - 2*(a*a + b*b)]])
+        T = res["T34"].reshape(-1, 3, 4)[k]
+        np.testing.assert_allclose(T[:, :3], R, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(T[:, 3], x[k, 4:7]/x[k, 7], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res["rho"], g["rho"]*x[g["pt_host"], 7], rtol=1e-14)
+    np.testing.assert_allclose(res["theta"].reshape(-1, 3), g["theta"]*x[g["text_host"], 7][:, None], rtol=1e-14)
+    assert np.abs(x[:, 7] - 1).max() > 1e-3                                   # the scale drift was distributed over the loop

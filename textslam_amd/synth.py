@@ -548,4 +548,10 @@ def pose_graph(seed=SEED, n_kf=40, window=3, loop_at=2, scale_drift=1.06):
             ei.append(l); ej.append(c); meas.append(_sim_mul(corr[c], _sim_inv(ini[l])))
     fixed = np.zeros(n_kf, np.uint8); fixed[[0, 1, loop_at]] = 1                                    # optimizer.cc:861-869
     pose = np.array(ini) + 0.0
-    return {"pose": pose, "fixed": fixed, "edge_i": np.array(ei, np.int32), "edge_j": np.array(ej, np.int32), "meas": np.array(meas)}
+    n_loop = 3*3
+    return {"pose": pose, "fixed": fixed, "edge_i": np.array(ei, np.int32), "edge_j": np.array(ej, np.int32), "meas": np.array(meas),
+            # the object-graph form the reference's caller holds (loopClosing::CorrectLoop): the drifted keyframe poses (mTcw), the corrected
+            # Sim3 of the current keyframe's neighbourhood (vConnectKFs; mScw = the current keyframe's), the normal and the loop connections,
+            # KF = the last keyframe, LoopKF = keyframe loop_at
+            "est": np.array(est), "conn_idx": np.array(cur_group, np.int32), "conn_sim": np.array([corr[c] for c in cur_group]),
+            "n_loop_edges": n_loop, "kf_cur": n_kf - 1, "kf_loop": loop_at}

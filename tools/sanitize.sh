@@ -39,6 +39,23 @@ for name, (P, mode) in t._cases().items():
 print("bad", bad)
 PY
 say "adapter gather/scatter + C++ driver (g++ ASan+UBSan, 6 problem types): $(tail -1 /tmp/san_adapter.log)"
+g++ -std=c++11 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -Iadapter -o /tmp/loop_from_cxx_san tests/cxx/loop_from_cxx.cpp -Ltextslam_amd -ltsloop -L/opt/rocm/lib -Wl,-rpath,$PWD/textslam_amd -Wl,-rpath,/opt/rocm/lib || say "loop adapter build: FAILED"
+python - > /tmp/san_loop_adapter.log 2>&1 <<'PY'
+import subprocess, sys, os, tempfile
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import test_cxx_adapter as t
+d = tempfile.mkdtemp(); bad = 0
+m = t._sim3_case()
+t._put_records(os.path.join(d, "s.bin"), [("P1", m["P1"], 0), ("P2", m["P2"], 0), ("uv1", m["uv1"], 0), ("uv2", m["uv2"], 0), ("inliers", m["inliers"], 2), ("sim0", m["sim0"], 0), ("K", m["K"], 0)])
+g = t._loop_case(); t._write_loop_dump(os.path.join(d, "l.bin"), g)
+for mode, f in (("sim3", "s.bin"), ("loop", "l.bin")):
+    r = subprocess.run(["/tmp/loop_from_cxx_san", os.path.join(d, f), mode, os.path.join(d, "o.bin")], capture_output=True, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
+    ok = r.returncode in (0, 3) and "gather" in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr
+    print(mode, "rc", r.returncode, "OK" if ok else "BAD\n" + r.stderr[-2000:]); bad += not ok
+    if ok and mode == "loop": t._check_loop_gather(t._read_out(os.path.join(d, "o.bin")), g)
+print("bad", bad)
+PY
+say "loop-closing adapter gather + C++ driver (g++ ASan+UBSan, sim3 + pose graph): $(tail -1 /tmp/san_loop_adapter.log)"
 
 # ---- 3. host side of libtsba
 (cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-unused-variable -o /tmp/libtsba_san.so tsba.hip) || say "libtsba build: FAILED"
