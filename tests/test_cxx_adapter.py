@@ -281,3 +281,55 @@ def test_cxx_loop_closing_solve_and_scatter(tmp_path):
     np.testing.assert_allclose(res["rho"], g["rho"]*x[g["pt_host"], 7], rtol=1e-14)
     np.testing.assert_allclose(res["theta"].reshape(-1, 3), g["theta"]*x[g["text_host"], 7][:, None], rtol=1e-14)
     assert np.abs(x[:, 7] - 1).max() > 1e-3                                   # the scale drift was distributed over the loop
+
+
+# ---- ORBextractor: the adapter class (adapter/tsorb_extractor_core.hpp) from C++ (tests/cxx/orb_from_cxx.cpp) ------------------------------
+ORB_EXE = os.path.join(ROOT, "tests", "cxx", "orb_from_cxx")
+ORB_ARGS = (1000, 1.2, 8, 20, 7)                                              # tracking.cc:36: ORBextractor(1000, 1.2, 8, 20, 7)
+
+
+def _orb_dump(path, pad=0):
+    from textslam_amd.orbextractor import synthetic_frame
+    img = synthetic_frame(7)
+    h, w = img.shape
+    buf = np.zeros((h, w + pad), np.uint8); buf[:, :w] = img; buf[:, w:] = 255          # a cv::Mat ROI: step > cols, foreign bytes behind every row
+    _put_records(path, [("img", buf, 2), ("wh", [w, h, w + pad], 1), ("args", [ORB_ARGS[0], ORB_ARGS[2], ORB_ARGS[3], ORB_ARGS[4]], 1), ("scale", [ORB_ARGS[1]], 0)])
+    return img
+
+
+def _check_orb_tables(res):
+    """the constructor's tables as ORBextractor.cc:415-430 computes them: float entries, the scale factor a double member set from a float"""
+    n = ORB_ARGS[2]; s = np.float64(np.float32(ORB_ARGS[1]))
+    sf = np.ones(n, np.float32)
+    for i in range(1, n):
+        sf[i] = np.float32(np.float64(sf[i - 1])*s)
+    sig = sf*sf
+    expect = np.concatenate([sf, np.float32(1)/sf, sig, np.float32(1)/sig]).astype(np.float64)
+    assert np.array_equal(res["tables"], expect)
+    assert res["levels"][0] == n and res["scale_factor"][0] == np.float64(np.float32(ORB_ARGS[1]))
+
+
+def test_orb_adapter_class_tables(tmp_path):
+    _build()
+    dump, out = str(tmp_path / "o.bin"), str(tmp_path / "oo.bin")
+    _orb_dump(dump)
+    r = subprocess.run([ORB_EXE, dump, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 3), (r.returncode, r.stdout, r.stderr)
+    _check_orb_tables(_read_out(out))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pad", [0, 24])
+def test_cxx_orb_extractor_matches_python_mirror(tmp_path, pad):
+    """operator() of the adapter class from C++ (incl. an image with step > cols) against the Python mirror: bit-exact keypoints and descriptors"""
+    from textslam_amd.orbextractor import ORBextractor
+    _build()
+    dump, out = str(tmp_path / "o.bin"), str(tmp_path / "oo.bin")
+    img = _orb_dump(dump, pad)
+    r = subprocess.run([ORB_EXE, dump, out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "extract done" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    res = _read_out(out)
+    _check_orb_tables(res)
+    kp, desc = ORBextractor(*ORB_ARGS)(img)
+    assert res["n"][0] == len(kp) > 900
+    assert np.array_equal(res["kp"].reshape(-1, 6).astype(np.float32), kp) and np.array_equal(res["desc"].reshape(-1, 32), desc)
