@@ -228,8 +228,15 @@ int  tsba_debug_row_of_kf(void *ctx, int32_t *rowblk);
  * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] rank
  * [11..14] this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots
  * [15] rows of S in reverse Cuthill-McKee order of the keyframes (wide envelopes: loop closures)
- * [16] (n >= 17) ring-shaped map solved with ghost rows for the first separator (one loop closure between the last and the first keyframes) */
+ * [16] (n >= 17) ring-shaped map solved with ghost rows for the first separator (one loop closure between the last and the first keyframes)
+ * [17] (n >= 19) long-range coupling: band of the preconditioner in pose blocks (0: direct solve)  [18] 6x6 blocks outside the band */
 int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
+/* Maps with long-range coupling: the conjugate-gradient solves of the last tsba_solve.  out[0] iterations in total, [1] reduced systems
+ * solved (LM trials), [2] most iterations of one system, [3] systems that hit the iteration cap. */
+int  tsba_debug_pcg_stats(void *ctx, int32_t out[4]);
+/* The 6x6 blocks of the reduced system outside the band (solver_info [18] of them) as left by tsba_debug_reduced_system / the last solve:
+ * keyframes a < b of every block and its 36 values, row-major, rows = keyframe a.  Any output may be NULL. */
+int  tsba_debug_far_blocks(void *ctx, int32_t *a, int32_t *b, double *blocks);
 
 /* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
  * equation accumulation) over n launches on the library's stream, measured with HIP events.
@@ -252,7 +259,10 @@ typedef struct tsba_debug_options {
     int32_t no_kf_reorder;     /* 1: keep the rows of S in keyframe order even when the envelope is wide (loop closures) */
     int32_t no_schur_quad;     /* 1: large maps assemble S with one wave per 6x6 block (k_schur_t<1>) instead of four blocks per wave */
     int32_t no_ring;           /* 1: a ring-shaped map (one loop closure between the last and the first keyframes) through the reordering path instead of the ghost-row partition */
-    int32_t reserved[7];
+    int32_t far_solver;        // maps with long-range coupling (band + blocks outside it, conjugate gradients preconditioned with the band solver): 0 by the plan's rule (when no keyframe order brings the envelope within the band solvers' reach), 1 never (reordering / wide-band Cholesky as before), 2 whenever the map is eligible
+    int32_t pcg_max_it;        // > 0: iteration cap of the conjugate gradients (default 200)
+    int32_t pcg_tol_exp;       // > 0: relative tolerance 10^-pcg_tol_exp of the conjugate gradients in the M^-1 norm (default 10)
+    int32_t reserved[4];
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

@@ -1,0 +1,143 @@
+"""GPU parity tests of the global BA on maps with LONG-RANGE coupling (SURVEY 8d's C6 as written: band co-visibility + 1 % long-range
+observations; several loop closures in one session, loopClosing.cc:587-591): the reduced camera system is a band plus scattered 6x6 blocks,
+solved by conjugate gradients preconditioned with the band solver (csrc/tsba_pcg.h) -- no (6 n_kf)^2 matrix.
+
+  * first LM step: S dp = -g checked against the assembled matrix (band part M + the blocks of E) -- dense numpy solve at 600 / 900
+    keyframes, residual of the sparse system at 5000;
+  * whole solve: same LM trajectory (iterations, accepted steps, termination, cost, poses) as the direct solvers this replaces -- the
+    reordered band (reverse Cuthill-McKee) where that exists, the wide-band / dense Cholesky otherwise -- and as the CPU oracle;
+  * two ranks (in-process communicator): every rank derives the same block list, the blocks travel with the band.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from textslam_amd import synth, abi
+from test_gpu_global import _on_ranks, _same_trajectory
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from textslam_amd.optimizer import Optimizer
+    g = Optimizer(0)
+    yield g
+    g.close()
+
+
+def _sparse_system(gpu, radius):
+    """First linearisation: the reduced system as a scipy sparse matrix over the compressed free-pose rows, g, and the pose step by row."""
+    rb = gpu.reduced_band(radius)
+    n, bw, ab = rb["n"], rb["bw"], rb["ab"]
+    diags = [ab[0]] + [ab[d][:n - d] for d in range(1, bw + 1)]
+    A = sp.diags(diags, [-d for d in range(bw + 1)], shape=(n, n), format="lil")
+    a, b, v = gpu.far_blocks()
+    row = rb["rowblk"]
+    nblk = 0
+    for q in range(len(a)):
+        ia, ib = row[a[q]], row[b[q]]
+        if ia < 0 or ib < 0:
+            continue
+        A[6*ib:6*ib + 6, 6*ia:6*ia + 6] += v[q].T                 # lower triangle: rows of the later keyframe (a block of E may lie inside the band)
+        nblk += 1
+    A = sp.csr_matrix(A)
+    A = A + sp.tril(A, -1).T
+    return A, rb, nblk
+
+
+@pytest.mark.parametrize("n_kf,far,closures", [(600, 0.02, 0), (900, 0.0, 2), (900, 0.01, 3)])
+def test_first_step_against_the_assembled_system(gpu, n_kf, far, closures):
+    P = synth.config_global(n_kf=n_kf, n_pt=20*n_kf, band=8, far_frac=far, closures=closures)
+    o = abi.options_global()
+    try:
+        gpu.debug_set(far_solver=2)
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        assert info["far_band_blocks"] == 8 and info["far_blocks"] > 0 and info["band_storage"] == 1 and info["band_rows"] == 48 and info["kf_reordered"] == 0, info
+        A, rb, nblk = _sparse_system(gpu, o.initial_radius)
+        assert nblk > 0
+        ref = -np.linalg.solve(A.toarray(), rb["g"])
+        err = np.abs(rb["dp_rows"] - ref).max()/np.abs(ref).max()
+        assert err <= 1e-8, err
+    finally:
+        gpu.debug_set()
+
+
+@pytest.mark.parametrize("n_kf,far,closures", [(600, 0.02, 0), (900, 0.0, 2), (1500, 0.01, 2)])
+def test_same_trajectory_as_the_direct_solvers(gpu, n_kf, far, closures):
+    """The map through the conjugate gradients and through what it replaces (far_solver = 1: the reordered band where reverse Cuthill-McKee
+    finds one, the wide-band Cholesky on the dense matrix otherwise)."""
+    P = synth.config_global(n_kf=n_kf, n_pt=20*n_kf, band=8, far_frac=far, closures=closures)
+    o = abi.options_global(); o.its[0] = 8
+    try:
+        gpu.debug_set(far_solver=2)
+        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+        info, st = gpu.solver_info(), gpu.pcg_stats()
+        assert info["far_band_blocks"] == 8 and info["far_blocks"] > 0, info
+        assert st["systems"] >= rep1["iters"][0] and st["hit_cap"] == 0 and 0 < st["iterations"] and st["max_iterations"] <= 150, st
+        gpu.debug_set(far_solver=1)
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        assert gpu.solver_info()["far_band_blocks"] == 0
+        _same_trajectory(rep1, rep2, G1, G2, atol=1e-8)
+        assert rep1["cost1"][0] < 0.5*rep1["cost0"][0]
+    finally:
+        gpu.debug_set()
+
+
+def test_parity_with_the_oracle(gpu, oracle_lib):
+    """130 keyframes, 3 % long-range points, against the CPU oracle (which knows nothing of the split)."""
+    P = synth.config_global(n_kf=130, n_pt=4000, band=8, far_frac=0.03)
+    o = abi.options_global(); o.its[0] = 8
+    try:
+        gpu.debug_set(far_solver=2)
+        G, R = P.copy(), P.copy()
+        rg = gpu.GlobalBA(G, options=o)
+        assert gpu.solver_info()["far_band_blocks"] == 8
+        ro = oracle_lib.solve(R, o)
+        assert rg["iters"] == ro["iters"] and rg["accepted"] == ro["accepted"] and rg["termination"] == ro["termination"]
+        np.testing.assert_allclose(rg["cost1"], ro["cost1"], rtol=1e-9)
+        np.testing.assert_allclose(G.pose, R.pose, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(G.rho, R.rho, rtol=0, atol=1e-8)
+    finally:
+        gpu.debug_set()
+
+
+def test_two_ranks(gpu):
+    """N = 2: the ranks derive the same list of blocks outside the band from ALL observations, each assembles its landmarks' part, the
+    blocks are all-reduced next to the band and every rank iterates on the same summed system."""
+    P = synth.config_global(n_kf=600, n_pt=12000, band=8, far_frac=0.02)
+    o = abi.options_global(); o.its[0] = 6
+    G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+    info1 = gpu.solver_info()
+    assert info1["far_band_blocks"] == 8
+
+    def solve(g, rank):
+        G = P.copy()
+        rep = g.GlobalBA(G, options=o)
+        return G, rep, g.solver_info(), g.pcg_stats()
+    for G, rep, info, st in _on_ranks(2, solve):
+        assert info["world"] == 2 and info["far_band_blocks"] == 8 and info["far_blocks"] == info1["far_blocks"], info
+        assert st["hit_cap"] == 0
+        _same_trajectory(rep1, rep, G1, G, atol=1e-8)
+
+
+def test_c6_with_long_range_observations_full_size(gpu):
+    """SURVEY 8d's C6 as written: 5000 keyframes, ~500 k observations, band co-visibility + 1 % long-range points.  First step: residual of
+    the assembled sparse system; the solve: cost decrease, unit quaternions, no dense matrix (band storage), bit-reproducible."""
+    P = synth.config_global(n_kf=5000, n_pt=70000, band=10, far_frac=0.01)
+    o = abi.options_global()
+    gpu.upload(P, o)
+    info = gpu.solver_info()
+    assert info["far_band_blocks"] in (8, 10) and info["far_blocks"] > 5000 and info["band_storage"] == 1 and info["band_rows"] == 6*info["far_band_blocks"] and info["interiors"] > 32, info
+    A, rb, nblk = _sparse_system(gpu, o.initial_radius)
+    assert nblk > 5000
+    res = A @ rb["dp_rows"] + rb["g"]
+    assert np.abs(res).max() <= 1e-8*np.abs(rb["g"]).max(), (np.abs(res).max(), np.abs(rb["g"]).max())
+    rep = gpu.solve(); G = gpu.download(P.copy())
+    st = gpu.pcg_stats()
+    assert st["hit_cap"] == 0 and st["systems"] >= rep["iters"][0], st
+    assert rep["cost1"][0] < 0.05*rep["cost0"][0]
+    np.testing.assert_allclose(np.linalg.norm(G.pose[:, :4], axis=1), 1.0, atol=1e-12)
+    rep2 = gpu.solve(); G2 = gpu.download(P.copy())
+    assert rep2["iters"] == rep["iters"] and np.array_equal(G.pose, G2.pose) and np.array_equal(G.rho, G2.rho)

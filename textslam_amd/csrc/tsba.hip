@@ -34,7 +34,7 @@
 // ------------------------------------------------------------------------------------------------ device structs
 struct LmState {
     double radius, decrease_factor, x_cost, x_norm, cand_cost, model_change, step_norm, gmax, cost0;
-    int cur, done, need_lin, first, it, accepted, term, invalid, max_it, step_fail, lcur, pad1;
+    int cur, done, need_lin, first, it, accepted, term, invalid, max_it, step_fail, lcur, lin_done;      // lin_done: the iterative reduced-system solve of this trial has converged (tsba_pcg.h): the remaining preconditioner launches return at once
     int ns_active, nt_active, n_bad_scene, n_bad_tfeat, n_bad_text, pad2;
     long long n_lin, n_cost;
 };
@@ -53,6 +53,10 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const int *tfeat_off, *tfeat_raw; const double *tfeat_uv, *tfeat_ref;
     const int *pf_g, *pf_f; int n_pf;   // pose-only path: flat (group, feature) list of the frame's text features
     const int *kf_order;                // nullptr: the rows of S follow the keyframe index; else kf_order[i] = keyframe at position i (tsba_plan.h: rcm_order)
+    // band + long-range coupling (HostPlan::far_* / fb_*, tsba_pcg.h): nullptr / 0 unless the plan split the reduced system into M (the sb_* lists) + E.
+    // sb_far: nullptr in this view; in the view of E that launch_schur derives (sb_* = the fb_* lists) the index of every block in W.Sfar
+    const int *sb_far, *far_a, *far_b, *far_off, *far_ent; int n_far, far_B;
+    const int *fb_id, *fb_pab, *fb_pba, *fb_pt_off, *fb_pt_s1, *fb_pt_s2, *fb_pt_lm, *fb_tx_off, *fb_tx_s1, *fb_tx_s2, *fb_tx_lm;
 };
 
 #define PT_REC 8
@@ -105,6 +109,10 @@ struct Work {                // device work buffers (sized for the largest level
     double *posepart;                   // large maps: per k_pose_sums workgroup (21 poses): gradient max, |x|^2
     LmState *st;
     PoseState *pst; double *ppart;      // pose-only path (tsba_pose.h): double-buffered state, [2][G][28] partial sums
+    // band + long-range blocks, preconditioned conjugate gradients (tsba_pcg.h): the blocks outside the band [n_far][36] (rows: the earlier keyframe),
+    // the iteration's vectors in the compressed row space of S, per-workgroup partial sums [2][workgroups], double-buffered scalars, statistics
+    double *Sfar, *pc_x, *pc_r, *pc_p[2], *pc_q, *pc_g0, *pc_part;
+    struct PcgState *pcs; int *pc_stat;
 };
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(c, std::string(#x) + ": " + hipGetErrorString(e_)); return TSBA_ERR_DEVICE; } } while (0)
@@ -1268,8 +1276,12 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             if (W.ring) { const int nf = W.nfree[0], r0 = W.nfree[1];       // closure block (a pose of the loop's first separator against a far one): the ghost row
                 if (ia - ic > W.ring_b && ic >= r0 && ic < r0 + W.ring_b) jc += nf - r0; else if (ic - ia > W.ring_b && ia >= r0 && ia < r0 + W.ring_b) ja += nf - r0; }
             const bool a_later = ja > jc;
+            const int fq = L.sb_far ? L.sb_far[b] : -1;     // a block outside the band (long-range coupling): to the compact list, rows = the earlier keyframe a
+            if (fq >= 0) W.Sfar[(size_t)fq*36 + r*6 + cc] = v;
+            else {
             if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
             if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
+            }
         }
     } else {
         const int a = b - L.n_sb;
@@ -1435,6 +1447,7 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
     if (W.ring) { const int nf = W.nfree[0], r0 = W.nfree[1];               // closure block (a pose of the loop's first separator against a far one): the ghost row
         if (ia - ic > W.ring_b && ic >= r0 && ic < r0 + W.ring_b) jc += nf - r0; else if (ic - ia > W.ring_b && ia >= r0 && ia < r0 + W.ring_b) ja += nf - r0; }
     const bool a_later = ja > jc;
+    const int fq = (live && L.sb_far) ? L.sb_far[bc] : -1;     // a block outside the band (long-range coupling): to the compact list
 #pragma unroll
     for (int t = 0; t < 3; t++) {
 #pragma unroll
@@ -1448,8 +1461,11 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
             for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
             const double v = tail[t] - ((s0 + s1) + (s2 + s3));
             const int r = o/6, cc = o - 6*r;
+            if (fq >= 0) W.Sfar[(size_t)fq*36 + o] = v;
+            else {
             if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
             if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
+            }
         }
         __syncthreads();
     }
@@ -1461,6 +1477,7 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
 #include "tsba_bandp.h"
 #include "tsba_bandcr.h"
 #include "tsba_bandcre.h"
+#include "tsba_pcg.h"
 #include "tsba_pose.h"
 
 // ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
@@ -1872,6 +1889,7 @@ struct Ctx {
     std::vector<struct Slab> slabs; int cur_slab = 0;
     int run_slab = 0; size_t run_off = 0, run_len = 0;   // pending contiguous host-to-device range
     int cur_bw_rows = 1 << 30;                     // band bound of the level being solved (set by launch_pass_init)
+    int far_B = 0, n_far = 0, pcg_parts = 0; unsigned int pcg_seq = 0;      // band + long-range blocks (tsba_pcg.h): band of M in pose blocks, blocks outside it, partial sums per vector kernel
     int rank = 0, world = 1; bool force_multi = false;
     tsba_debug_options dbg{};                      // test / diagnostics switches (tsba_debug_set), all zero in production
     struct LocalGroup *lgroup = nullptr;           // in-process communicator (tsba_comm_init_local)
@@ -2113,7 +2131,10 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             // ring maps (one loop closure): a single-level, single-GPU solve through the partitioned solver with the cyclic-reduction separator tree
             int n_lev = 0; { std::vector<char> sn(p->n_levels, 0); for (int q = 0; q < o->n_passes; q++) if (!sn[o->levels[q]]) { sn[o->levels[q]] = 1; n_lev++; } }
             const int ring_max = (n_lev == 1 && !c->dbg.no_ring && !c->dbg.no_band_stream && c->dbg.sep_solver != 1 && c->dbg.sep_solver != 3 && c->dbg.band_parts != 1) ? CR_SMAX/6 : 0;
-            planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max); }); }
+            // maps with long-range coupling (several loop closures, points seen again much later): band + blocks outside it, preconditioned conjugate gradients
+            const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream) ? CR_SMAX/6 : 0;
+            const bool far_force = c->dbg.far_solver == 2;
+            planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max, far_max, far_force]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
 #define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
@@ -2158,6 +2179,10 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
         UV(pf_g); UV(pf_f); D.n_pf = (int)H.pf_g.size();
         if (!H.kf_order.empty()) UV(kf_order); else D.kf_order = nullptr;
+        D.far_B = H.far_B; D.n_far = H.n_far();
+        D.sb_far = nullptr;
+        if (H.far_B > 0) { UV(far_a); UV(far_b); UV(far_off); UV(far_ent); UV(fb_id); UV(fb_pab); UV(fb_pba); UV(fb_pt_off); UV(fb_pt_s1); UV(fb_pt_s2); UV(fb_pt_lm);
+            UV(fb_tx_off); UV(fb_tx_s1); UV(fb_tx_s2); UV(fb_tx_lm); }
         UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
         UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
         UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ps_lm); UV(pose_ts_off); UV(pose_ts); UV(pose_ts_lm);
@@ -2283,6 +2308,15 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
         }
         if (ring && !W.ring) { set_err(c, "ring-shaped map: the partitioned band solver is not available for this plan"); return TSBA_ERR_STATE; }
         AL(W.Sy, W.N + BAND_BW_MAX);                            // (+ the ghost rows of a ring map)
+        c->far_B = 0; c->n_far = 0; c->pcg_parts = 0;
+        for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l] && c->lev[l].far_B > 0) { c->far_B = c->lev[l].far_B; c->n_far = std::max(c->n_far, c->lev[l].n_far); }
+        if (c->far_B > 0) {
+            if (!W.band || !c->band_stream) { set_err(c, "map with long-range coupling: the band solvers are not available for this plan"); return TSBA_ERR_STATE; }
+            c->pcg_parts = (p->n_kf + 31)/32;
+            AL(W.Sfar, 36*(size_t)std::max(c->n_far, 1));
+            AL(W.pc_x, W.N); AL(W.pc_r, W.N); AL(W.pc_p[0], W.N); AL(W.pc_p[1], W.N); AL(W.pc_q, W.N); AL(W.pc_g0, W.N);
+            AL(W.pc_part, 2*(size_t)c->pcg_parts); AL(W.pcs, 2); AL(W.pc_stat, 4);
+        }
         c->S_xchg = nullptr; c->xchg_wp = 0;
         if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, ((size_t)W.N + bwmax)*c->xchg_wp); }
     }
@@ -2423,6 +2457,17 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
         hipLaunchKernelGGL(k_schur_t<1>, dim3(((c->n_kf + 7)/8)*8), dim3(64), 0, c->stream, c->W, D, multi, D.n_sb);
     } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0);
     else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0);
+    if (D.far_B > 0 && D.n_far > 0) {            // the blocks of E (what couples different clusters of a landmark): the same kernels on the fb_* lists, stored to W.Sfar
+        LevelDev E = D;
+        E.n_sb = D.n_far; E.sb_a = D.far_a; E.sb_b = D.far_b; E.sb_pab = D.fb_pab; E.sb_pba = D.fb_pba; E.sb_far = D.fb_id;
+        E.sb_pt_off = D.fb_pt_off; E.sb_pt_s1 = D.fb_pt_s1; E.sb_pt_s2 = D.fb_pt_s2; E.sb_pt_lm = D.fb_pt_lm;
+        E.sb_tx_off = D.fb_tx_off; E.sb_tx_s1 = D.fb_tx_s1; E.sb_tx_s2 = D.fb_tx_s2; E.sb_tx_lm = D.fb_tx_lm;
+        if (c->n_kf > 126 && !c->dbg.no_schur_quad) { const int nq = (((E.n_sb + 3)/4 + 7)/8)*8;
+            if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi);
+            else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi); }
+        else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(E.n_sb), dim3(64), 0, c->stream, c->W, E, multi, 0);
+        else hipLaunchKernelGGL(k_schur_t<4>, dim3(E.n_sb), dim3(256), 0, c->stream, c->W, E, multi, 0);
+    }
 }
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
 static int set_solver_attrs(Ctx *c) {
@@ -2537,6 +2582,38 @@ static void launch_solve(Ctx *c) {
     hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, W, bw);
 }
 
+// The reduced system of one LM trial: a direct solve, or -- band + long-range blocks -- conjugate gradients preconditioned with the band
+// solver (tsba_pcg.h).  The host enqueues iteration k only once the device has reached iteration k - 2 (pinned progress word), so a solve
+// that converges wastes two iterations of empty launches; every rank of a sharded run iterates on its own copy of the summed system.
+static void launch_solve_full(Ctx *c, const LevelDev &D) {
+    launch_solve(c);
+    if (D.far_B <= 0) return;
+    Work &W = c->W;
+    const int nbp = c->pcg_parts, B = std::max(6, c->cur_bw_rows)/6;
+    const int cap = c->dbg.pcg_max_it > 0 ? c->dbg.pcg_max_it : 200;
+    const double tol = c->dbg.pcg_tol_exp > 0 ? pow(10.0, -(double)c->dbg.pcg_tol_exp) : 1e-10, tol2 = tol*tol;
+    const unsigned int seq = ++c->pcg_seq;
+    hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W);
+    auto finished = [&](int it) {                                  // true: the device reported convergence (or the end of the pass); else waits until it is within two iterations
+        if (!c->hprog || it < 2) return false;
+        const auto tw = std::chrono::steady_clock::now();
+        for (int spin = 0;; spin++) {
+            const unsigned long long w = ((volatile unsigned long long *)c->hprog)[1];
+            if ((unsigned int)(w >> 32) == seq) { if (w & 1) return true; if ((int)((w & 0xffffffffu) >> 1) + 2 >= it) return false; }
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(5)) return false;      // never hang on it
+        }
+    };
+    int it = 0;
+    for (; it < cap; it++) {
+        if (finished(it)) break;
+        hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_T), 0, c->stream, W, D, it, seq, B, tol2, nbp);
+        hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp);
+        launch_solve(c);
+        hipLaunchKernelGGL(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W);
+    }
+    hipLaunchKernelGGL(k_pcg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
+}
+
 // one LM iteration: reduced system -> pose step -> back-substitution / candidate -> speculative linearisation at the
 // candidate -> decision (on acceptance the speculative LinBuf simply becomes the current one)
 static void launch_step(Ctx *c, const LevelDev &D) {
@@ -2548,7 +2625,9 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     // writes the same entries in every trial (the free poses are fixed at its start), so the band is cleared once per pass; the in-place
     // Cholesky of the wide-band path needs it before every assembly -- and so does a sharded run (a rank assembles only its own blocks; the
     // other entries hold the sums the last exchange unpacked)
-    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2 && (!c->band_stream || c->S_stale || is_multi(c))) { hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream); c->S_stale = false; }
+    if ((int64_t)D.n_sb < (int64_t)c->n_kf*(c->n_kf + 1)/2 && (!c->band_stream || c->S_stale || is_multi(c))) {
+        hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream); c->S_stale = false;
+        if (D.far_B > 0) hipMemsetAsync(W.Sfar, 0, sizeof(double)*36*(size_t)std::max(D.n_far, 1), c->stream); }
     launch_schur(c, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
         if (c->S_xchg) {                           // band storage: only the band's entries travel
@@ -2558,10 +2637,11 @@ static void launch_step(Ctx *c, const LevelDev &D) {
             allreduce(c, c->S_xchg, nx, ncclDouble, ncclSum);
             hipLaunchKernelGGL(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 1);
         } else allreduce(c, c->S_alloc, c->S_count, ncclDouble, ncclSum);
+        if (D.far_B > 0 && D.n_far > 0) allreduce(c, W.Sfar, 36*(size_t)D.n_far, ncclDouble, ncclSum);      // the blocks outside the band
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
         hipLaunchKernelGGL(k_damp_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
-    launch_solve(c);
+    launch_solve_full(c, D);
     hipLaunchKernelGGL(k_back, dim3(nb_pt + nb_tx + nb_kf), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
     launch_linearize(c, D, 1);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
@@ -2579,6 +2659,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
                    ~Token() { if (c->lgroup) { c->in_solve = false; if (c->has_token) { hipStreamSynchronize(c->stream); c->has_token = false; c->lgroup->gpu_token.unlock(); } } } } token(c);
     auto t0 = std::chrono::steady_clock::now();
     int rc = reset_state(c); if (rc) return rc;
+    if (c->far_B > 0) hipMemsetAsync(c->W.pc_stat, 0, 4*sizeof(int), c->stream);
     for (int ps = 0; ps < o.n_passes; ps++) {
         const LevelDev &D = c->lev[o.levels[ps]];
         const bool pose_path = c->pose_only && !is_multi(c);
@@ -2768,11 +2849,12 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
     launch_pass_init(c, D, 0);
     launch_linearize(c, D, 0);
     Work &W = c->W;
-    if (D.n_sb < c->n_kf*(c->n_kf + 1)/2) { hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream); c->S_stale = false; }
+    if ((int64_t)D.n_sb < (int64_t)c->n_kf*(c->n_kf + 1)/2) { hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream); c->S_stale = false;
+        if (D.far_B > 0) hipMemsetAsync(W.Sfar, 0, sizeof(double)*36*(size_t)std::max(D.n_far, 1), c->stream); }
     // split (multi-GPU) sequence: this shard's PARTIAL S and g, before any exchange and without the pose damping (which is added
     // once after the all-reduce) -- the parts of all shards sum to the unsharded system; dp is not computed
     launch_schur(c, D, (int)is_multi(c));
-    if (!is_multi(c)) launch_solve(c); else hipMemsetAsync(W.dp, 0, sizeof(double)*W.N, c->stream);
+    if (!is_multi(c)) launch_solve_full(c, D); else hipMemsetAsync(W.dp, 0, sizeof(double)*W.N, c->stream);
     c->opt = saved;
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
     if (S) {
@@ -2786,6 +2868,13 @@ int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, do
                 const long long n6 = 6LL*nfr[0], r06 = 6LL*nfr[1], ng = std::min<long long>(6LL*W.ring_b, N);
                 for (long long r = 0; r < ng && n6 + r < (long long)(c->S_count/LDB); r++) for (long long j = std::max(0LL, n6 + r - Wb); j < n6; j++) {
                     const double v = hb[(size_t)(Wb + (n6 + r)*(LDB - 1) + j)]; if (v != 0.0 && j > r06 + r) S[j*N + r06 + r] = v; }
+            }
+            if (D.far_B > 0 && D.n_far > 0) {        // the blocks outside the band (lower triangle: rows of the later keyframe)
+                const HostPlan &H = c->hplan[D.level];
+                std::vector<double> hf(36*(size_t)D.n_far); std::vector<int> fi(c->n_kf);
+                CK(hipMemcpy(hf.data(), W.Sfar, sizeof(double)*hf.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(fi.data(), W.fidx, sizeof(int)*c->n_kf, hipMemcpyDeviceToHost));
+                for (int q = 0; q < D.n_far; q++) { const long long ia = fi[H.far_a[q]], ic = fi[H.far_b[q]]; if (ia < 0 || ic < 0) continue;
+                    for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) S[(6*ic + cc)*N + 6*ia + r] = hf[36*(size_t)q + 6*r + cc]; }
             } }
     }
     if (g) CK(hipMemcpy(g, W.g, sizeof(double)*W.N, hipMemcpyDeviceToHost));
@@ -2887,6 +2976,30 @@ int tsba_debug_solver_info(void *ctx, int32_t *out, int n) {
     out[9] = c->world; out[10] = c->rank;
     { const LevelDev &D0 = c->lev[c->opt.levels[0]]; out[11] = D0.n_pair; out[12] = D0.n_sb; out[13] = D0.n_sc; out[14] = D0.n_pslot; out[15] = D0.kf_order ? 1 : 0; }
     if (n >= 17) out[16] = c->W.ring;
+    if (n >= 19) { out[17] = c->far_B; out[18] = c->n_far; }
+    return TSBA_OK;
+}
+// Iterative reduced-system solves of the last tsba_solve on a map with long-range coupling (tsba_pcg.h): out[0] conjugate-gradient iterations in
+// total, [1] reduced systems solved (LM trials), [2] most iterations of one system, [3] systems that hit the iteration cap.  Zeros otherwise.
+int tsba_debug_pcg_stats(void *ctx, int32_t out[4]) {
+    Ctx *c = (Ctx *)ctx; if (!c || !out) return TSBA_ERR_ARG;
+    if (!c->uploaded) return TSBA_ERR_STATE;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (c->far_B <= 0) return TSBA_OK;
+    hipSetDevice(c->device); CK(hipStreamSynchronize(c->stream));
+    CK(hipMemcpy(out, c->W.pc_stat, 4*sizeof(int32_t), hipMemcpyDeviceToHost));
+    return TSBA_OK;
+}
+// The 6x6 blocks outside the band after tsba_debug_reduced_system / a solve: keyframes a < b of block q and its 36 values (row-major, rows = a);
+// the number of blocks is solver_info [18].  Any output may be NULL.
+int tsba_debug_far_blocks(void *ctx, int32_t *a, int32_t *b, double *blocks) {
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    if (!c->uploaded || c->far_B <= 0) return TSBA_ERR_STATE;
+    const LevelDev &D = c->lev[c->opt.levels[0]]; const HostPlan &H = c->hplan[D.level];
+    hipSetDevice(c->device); CK(hipStreamSynchronize(c->stream));
+    if (a) memcpy(a, H.far_a.data(), sizeof(int32_t)*H.far_a.size());
+    if (b) memcpy(b, H.far_b.data(), sizeof(int32_t)*H.far_b.size());
+    if (blocks && D.n_far > 0) CK(hipMemcpy(blocks, c->W.Sfar, sizeof(double)*36*(size_t)D.n_far, hipMemcpyDeviceToHost));
     return TSBA_OK;
 }
 // row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating); with a
@@ -2968,6 +3081,8 @@ static unsigned long long plan_checksum(const HostPlan &H) {           // over E
                                            &H.tg_tobs, &H.tg_kf, &H.tg_text, &H.tg_pair, &H.tg_slot, &H.pt_pose6, &H.pt_pair4, &H.tg_ppos, &H.pf_g, &H.pf_f, &H.tg_rec,
                                            &H.pls_off, &H.pslot_pose, &H.pslot_pair, &H.pslot_lm, &H.tls_off, &H.tslot_pose, &H.tslot_pair, &H.tslot_lm, &H.sb_pab, &H.sb_pba,
                                            &H.pose_t_off, &H.pose_t, &H.pose_h_off, &H.pose_h, &H.pose_ps_off, &H.pose_ps, &H.pose_ps_lm, &H.pose_ts_off, &H.pose_ts, &H.pose_ts_lm }) mix(*v);
+    if (H.far_B > 0) { h ^= (unsigned long long)H.far_B; h *= 1099511628211ull;
+        for (const std::vector<int32_t> *v : { &H.far_a, &H.far_b, &H.far_off, &H.far_ent, &H.fb_id, &H.fb_pab, &H.fb_pba, &H.fb_pt_off, &H.fb_pt_s1, &H.fb_pt_s2, &H.fb_pt_lm, &H.fb_tx_off, &H.fb_tx_s1, &H.fb_tx_s2, &H.fb_tx_lm }) mix(*v); }
     for (double x : H.sc_uv) { unsigned long long u; memcpy(&u, &x, 8); h ^= u; h *= 1099511628211ull; }
     h ^= (unsigned long long)(H.bw_pose*4 + H.ring*2) + 8ull*(unsigned)H.ring_k0; h *= 1099511628211ull;
     return h;
@@ -2990,6 +3105,33 @@ unsigned long long tsba_debug_plan_checksum_recycled(const tsba_problem *warm, c
     tsba_plan_threads = threads; build_plan(p, o, level, H, false, true, tsba_plan_checksum_ring);
     tsba_plan_threads = saved;
     return plan_checksum(H);
+}
+// host-only: the band + long-range split of the plan of `level` (tsba_plan.h: HostPlan::far_* / fb_*) when bands of up to far_max_blocks pose blocks are allowed.
+// out[0] band of the preconditioner M in pose blocks (0: no split: ring, reordering or plain band), [1] 6x6 blocks of E (all ranks'), [2] those this rank
+// contributes to, [3] the plan's band bound, [4] ring, [5] keyframes reordered, [6] checksum of the block positions (low 31 bits), [7] slot pairs of E.
+// Checks what the split promises -- every block of M within the band, every slot pair of a landmark in exactly one of M / E, the positions of E
+// sorted -- and returns TSBA_ERR_STATE if not.
+int tsba_debug_plan_far(const tsba_problem *p, const tsba_options *o, int level, int far_max_blocks, int force, int ring_max_blocks, int32_t out[8]) {
+    if (!p || !o || !out || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
+    HostPlan H; build_plan(p, o, level, H, false, true, ring_max_blocks, far_max_blocks, force != 0);
+    int mine = 0; long long npairs = 0;
+    if (H.far_B > 0) {
+        for (int q = 0; q < H.n_sb(); q++) if (H.sb_b[q] - H.sb_a[q] > H.far_B) return TSBA_ERR_STATE;
+        for (int q = 0; q < H.n_far(); q++) { if (H.far_a[q] >= H.far_b[q]) return TSBA_ERR_STATE;
+            if (q > 0 && !(H.far_a[q-1] < H.far_a[q] || (H.far_a[q-1] == H.far_a[q] && H.far_b[q-1] < H.far_b[q]))) return TSBA_ERR_STATE;
+            const bool has = H.fb_pt_off[q+1] > H.fb_pt_off[q] || H.fb_tx_off[q+1] > H.fb_tx_off[q] || H.fb_pab[q] >= 0 || H.fb_pba[q] >= 0; mine += has;
+            for (int e = H.fb_pt_off[q]; e < H.fb_pt_off[q+1]; e++) if (H.pslot_pose[H.fb_pt_s1[e]] != H.far_a[q] || H.pslot_pose[H.fb_pt_s2[e]] != H.far_b[q] || H.pslot_lm[H.fb_pt_s1[e]] != H.pslot_lm[H.fb_pt_s2[e]]) return TSBA_ERR_STATE; }
+        npairs = (long long)H.fb_pt_s1.size() + (long long)H.fb_tx_s1.size();
+        // slot pairs with pose(s1) <= pose(s2): those of M + those of E = all of them
+        long long all = 0; for (int j = 0; j < p->n_pt; j++) { const long long n = H.pls_off[j+1] - H.pls_off[j]; all += n*(n + 1)/2; }
+        for (int j = 0; j < p->n_text; j++) { const long long n = H.tls_off[j+1] - H.tls_off[j]; all += n*(n + 1)/2; }
+        if ((long long)H.sb_pt_s1.size() + (long long)H.sb_tx_s1.size() + npairs != all) return TSBA_ERR_STATE;
+    }
+    unsigned long long h = 1469598103934665603ull;
+    for (const std::vector<int32_t> *v : { &H.far_a, &H.far_b, &H.far_off, &H.far_ent }) for (int32_t x : *v) { h ^= (unsigned int)x; h *= 1099511628211ull; }
+    out[0] = H.far_B; out[1] = H.n_far(); out[2] = mine; out[3] = H.bw_pose; out[4] = H.ring; out[5] = H.kf_order.empty() ? 0 : 1; out[6] = (int32_t)(h & 0x7fffffffu);
+    out[7] = (int32_t)npairs;
+    return TSBA_OK;
 }
 // host-only: does the plan of `level` take the ring path (one loop closure between the last and the first keyframes) when separators of up
 // to ring_max_blocks pose blocks are allowed?  Returns 1 / 0 (< 0: error); *bw_pose = the band of the plan either way

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(Work W, int bw, in
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = SOLVE_THREADS/64, NT = NW - SOLVE_PW;
-    if (st->done) return;
+    if (st->done | st->lin_done) return;
     const int nfree_all = *W.nfree, ntot = 6*nfree_all;
     if (st->step_fail || ntot == 0) { for (int k = tid; k < W.N; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
     const int Wn = 6*CB + bw;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BAND_BS_T) void k_band_backsub(Work W, int bw, cons
     LmState *st = W.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (st->done) return;
+    if (st->done | st->lin_done) return;
     const int nfree_all = *W.nfree;
     if (st->step_fail || nfree_all == 0) { for (int k = tid; k < W.N; k += BAND_BS_T) W.dp[k] = 0.0; return; }
     const int REC = bw*6, B = bw/6, NTASK = 6*B;

@@ -49,7 +49,7 @@ __device__ __forceinline__ void cre_batched(int n, int tid, F f, G st) {
 // matrix pipes, and three quarters of the chip idle next to the 32 pivots of the first level.
 __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int Pmax, int h, int root, int K, int kb, double *contrib, double *fac) {
     LmState *st = W.st;
-    if (st->done || st->step_fail) return;
+    if (st->done || st->step_fail || st->lin_done) return;
     const CrRange rg = cr_range(W, bw, Pmax);
     const int m = rg.m, lo = rg.lo, r0 = rg.r0, s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
     int i, a, c;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, in
     const double *rec = fac + (size_t)i*cre_rec_doubles(s);
     const double *Xa = cr_blk(S, s, mmax, i, a), *Xc = cmx >= 0 ? cr_blk(S, s, mmax, cmx, i) : Xa;
     const int col = tid & 127, grp = tid >> 7;                   // a thread: column `col` of [X_a ; X_c], rows grp, grp + 4, ...
-    const int done = st->done, sfail = st->step_fail, nb = *W.nfree;
+    const int done = st->done | st->lin_done, sfail = st->step_fail, nb = *W.nfree;
     const double xin = tid < s ? x[(size_t)a*s + tid] : (tid < 2*s && cmx >= 0 ? x[(size_t)cmx*s + tid - s] : 0.0);      // (2 s <= 156 < CRE_BT)
     const double zc = (grp == 0 && col < s) ? rec[xbase + SOLVE_LD*B + col] : 0.0;
     auto xrow = [&](int r) { return r < s ? Xa + (size_t)r*s : Xc + (size_t)(r - s)*s; };

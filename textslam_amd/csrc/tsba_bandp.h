@@ -240,7 +240,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = SOLVE_THREADS/64, NT = NW - BANDP_PW;
-    if (st->done || st->step_fail) return;
+    if (st->done || st->step_fail || st->lin_done) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
     BandpPart PT;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
 #define BANDP_JC 8
 __global__ __launch_bounds__(256) void k_bandp_border(Work W, int bw, int Pmax, const double *Lb, double *part) {
     const LmState *st = W.st;
-    if (st->done || st->step_fail) return;
+    if (st->done || st->step_fail || st->lin_done) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
     const BandpPart PT = bandp_part_w(W, B, Pmax, blockIdx.x);
@@ -497,7 +497,7 @@ static size_t cr_pool_blocks(int mmax) { size_t n = (size_t)mmax; for (int hh = 
 // blocks -> *nfree_sep (what k_band_solve reads)
 __global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, const double *Tbuf, const double *part, double *Ssep, int nsep_ld, double *gsep, int *nfree_sep, int blocked) {
     const LmState *st = W.st;
-    if (st->done || st->step_fail) return;
+    if (st->done || st->step_fail || st->lin_done) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     const BandpPart P0 = bandp_part_w(W, B, Pmax, 0);
     const int P = P0.P, nS = bw, nTm = 2*bw;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, con
 static size_t bandp_sepf_lds_doubles() { return (size_t)BSF_XR*BSF_LD + 6*BSF_JC + 8; }
 __global__ __launch_bounds__(BSF_T) void k_bandp_sepf(Work W, int bw, int Pmax, const double *Tbuf, const double *Lb, double *Ssep, double *gsep, int *nfree_sep) {
     const LmState *st = W.st;
-    if (st->done || st->step_fail) return;
+    if (st->done || st->step_fail || st->lin_done) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
     const BandpPart P0 = bandp_part_w(W, B, Pmax, 0);
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(BAND_BS_T) void k_bandp_backsub(Work W, int bw, int
     LmState *st = W.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (st->done || st->step_fail) return;
+    if (st->done || st->step_fail || st->lin_done) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
     const BandpPart PT = bandp_part_w(W, B, Pmax, blockIdx.x);
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(BAND_BS_T) void k_bandp_backsub(Work W, int bw, int
 
 __global__ void k_bandp_dp(Work W) {
     const LmState *st = W.st;
-    if (st->done) return;
+    if (st->done | st->lin_done) return;
     const int a = blockIdx.x*blockDim.x + threadIdx.x;
     if (a >= W.n_kf) return;
     const int ia = W.fidx[a];

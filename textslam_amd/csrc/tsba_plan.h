@@ -48,6 +48,18 @@ struct HostPlan {
     int ring = 0;                               // 1: the co-visibility graph is a RING (one loop closure between the last keyframes and keyframe ring_k0): bw_pose is the band of
                                                 // the chain unrolled past its end -- the loop's first bw_pose poses re-appear as ghost rows behind the last pose (tsba_bandp.h)
     std::vector<int32_t> kf_order;              // empty: S is ordered by keyframe index; else kf_order[i] = keyframe at position i (reverse Cuthill-McKee)
+    // Band + long-range coupling (far_B > 0): S = M + E.  Every landmark's poses fall into CLUSTERS that span at most far_B keyframes -- cluster 0: the
+    // host and the observers up to far_B keyframes after it, the other poses greedily in ascending order.  M takes a landmark's contribution
+    // restricted to each cluster (a principal submatrix of a positive semidefinite matrix: M stays positive definite whatever the map looks like
+    // -- simply cutting S off at a band does not), a band of far_B pose blocks in keyframe order: the sb_* lists below.  E takes what couples
+    // DIFFERENT clusters of a landmark (points seen again much later, loop closures; also the rare observer before its host): the far_* / fb_*
+    // lists.  The system is solved by conjugate gradients preconditioned with M (tsba_pcg.h).  The block positions far_a < far_b are a property of
+    // the WHOLE problem (every rank of a sharded solve derives the same list, sorted); fb_* are this rank's contributions in the layout of sb_*.
+    int far_B = 0;
+    std::vector<int32_t> far_a, far_b;          // [n_far] keyframes of a block of E
+    std::vector<int32_t> far_off, far_ent;      // per keyframe: its blocks of E as (index << 1 | 1 if the keyframe is far_b), ascending
+    std::vector<int32_t> fb_id, fb_pab, fb_pba, fb_pt_off, fb_pt_s1, fb_pt_s2, fb_pt_lm, fb_tx_off, fb_tx_s1, fb_tx_s2, fb_tx_lm;    // fb_id: 0 .. n_far - 1
+    int n_far() const { return (int)far_a.size(); }
     // scene candidates (sorted by pair)
     std::vector<int32_t> sc_obs, sc_kf, sc_pt, sc_flag, sc_slot;
     std::vector<double>  sc_uv;                 // [n_sc][2]
@@ -79,8 +91,8 @@ struct HostPlan {
     // a new plan into the same object (a context builds one per call: per keyframe for the local BA): scalars reset, every list emptied with its
     // storage kept -- no allocation, no page faults for lists of the size the last call needed
     void recycle() {
-        level = 0; bw_pose = 0; ring = 0; ring_k0 = 0;
-        for (std::vector<int32_t> *v : { &kf_order, &sc_obs, &sc_kf, &sc_pt, &sc_flag, &sc_slot, &pair_i, &pair_h, &pair_hpos, &pair_sc_off, &pair_tg_off, &pair_tg,
+        level = 0; bw_pose = 0; ring = 0; ring_k0 = 0; far_B = 0;
+        for (std::vector<int32_t> *v : { &far_a, &far_b, &far_off, &far_ent, &fb_id, &fb_pab, &fb_pba, &fb_pt_off, &fb_pt_s1, &fb_pt_s2, &fb_pt_lm, &fb_tx_off, &fb_tx_s1, &fb_tx_s2, &fb_tx_lm, &kf_order, &sc_obs, &sc_kf, &sc_pt, &sc_flag, &sc_slot, &pair_i, &pair_h, &pair_hpos, &pair_sc_off, &pair_tg_off, &pair_tg,
                                          &tg_tobs, &tg_kf, &tg_text, &tg_pair, &tg_slot, &pt_pose6, &pt_pair4, &tg_ppos, &pf_g, &pf_f, &tg_rec,
                                          &pls_off, &pslot_pose, &pslot_pair, &pslot_lm, &tls_off, &tslot_pose, &tslot_pair, &tslot_lm,
                                          &sb_a, &sb_b, &sb_pab, &sb_pba, &sb_pt_off, &sb_pt_s1, &sb_pt_s2, &sb_pt_lm, &sb_tx_off, &sb_tx_s1, &sb_tx_s2, &sb_tx_lm,
@@ -248,7 +260,10 @@ struct BucketPlacer {
     int next(int t, size_t &e) { const int k = kc[t][e++]; return k < 0 ? -1 : hist[t][(size_t)k]++; }
 };
 
-inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true, int ring_max_blocks = 0) {
+// far_max_blocks > 0: maps whose envelope no band solver reaches may be split into a band of at most far_max_blocks pose blocks + long-range
+// blocks (HostPlan::far_B); far_force: take the split whenever the map is eligible, without trying the keyframe reordering first
+inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true, int ring_max_blocks = 0,
+                       int far_max_blocks = 0, bool far_force = false) {
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
     P.recycle();
@@ -369,17 +384,20 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     lap("groups + landmark slots");
     // ---- reduced-system blocks: key = a*n_kf + b (a <= b)
     auto bkey = [&](int a, int b) { return (int64_t)a*n_kf + b; };
-    KeyIndex bk; bk.begin((int64_t)n_kf*n_kf);
     // slot pairs (s1, s2) of every landmark with pose(s1) <= pose(s2), in landmark-major generation order; they are visited three times
     // (mark the block, count per block, place) instead of being materialised and sorted: 2 M pairs at 5000 keyframes.  Thread t takes the
     // landmarks [lo[t], lo[t+1]): about the same number of slots each.
     auto split_landmarks = [&](const std::vector<int32_t> &loff, int n_lm) { std::vector<int> lo((size_t)T + 1, 0); const size_t n_slot = n_lm > 0 ? (size_t)loff[n_lm] : 0;
         for (int t = 1; t < T; t++) lo[t] = (int)(std::lower_bound(loff.begin(), loff.begin() + n_lm + 1, (int32_t)(n_slot*t/T)) - loff.begin());
         lo[T] = n_lm; return lo; };
-    auto range_pairs = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, int j0, int j1, auto &&f) {
+    // cl (may be null): cluster of every slot within its landmark (band + long-range split, below): only pairs of ONE cluster feed the band
+    auto range_pairs = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, const int32_t *cl, int j0, int j1, auto &&f) {
         for (int j = j0; j < j1; j++) for (int s1 = loff[j]; s1 < loff[j+1]; s1++) for (int s2 = loff[j]; s2 < loff[j+1]; s2++) {
-            const int a = pose[s1], b2 = pose[s2]; if (a > b2) continue; f(bkey(a, b2), s1, s2); } };
+            const int a = pose[s1], b2 = pose[s2]; if (a > b2 || (cl && cl[s1] != cl[s2])) continue; f(bkey(a, b2), s1, s2); } };
     const std::vector<int> lo_pt = split_landmarks(P.pls_off, n_pt), lo_tx = split_landmarks(P.tls_off, n_text);
+    // pair_far (may be null): (target, host) pairs whose cross term H_th lies outside the band part (the target is not in the host's cluster)
+    auto build_blocks = [&](const int32_t *cl_pt, const int32_t *cl_tx, const char *pair_far) {
+    KeyIndex bk; bk.begin((int64_t)n_kf*n_kf);
     // marking the blocks of the point slots: by POSE (thread t the poses [a0, a1) with about the same number of slots: every slot of pose a, every
     // slot of its landmark at a pose b >= a) -- a thread then writes its own rows of the key bitmap only; landmark-major, every thread wrote
     // every row, and each of the 45 k first-time writes took the line out of fifteen other caches
@@ -389,12 +407,12 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             const int a0 = (int)(std::lower_bound(P.pose_ps_off.begin(), P.pose_ps_off.end(), (int32_t)(n_ps*(size_t)t/(size_t)T)) - P.pose_ps_off.begin());
             const int a1 = t + 1 == T ? n_kf : (int)(std::lower_bound(P.pose_ps_off.begin(), P.pose_ps_off.end(), (int32_t)(n_ps*(size_t)(t + 1)/(size_t)T)) - P.pose_ps_off.begin());
             for (int a = std::min(a0, n_kf); a < std::min(a1, n_kf); a++)
-                for (int x = P.pose_ps_off[a]; x < P.pose_ps_off[a+1]; x++) { const int j = P.pose_ps_lm[x];
-                    for (int s2 = P.pls_off[j]; s2 < P.pls_off[j+1]; s2++) { const int b = P.pslot_pose[s2]; if (b >= a) bk.add_mt(bkey(a, b)); } } });
-    } else range_pairs(P.pls_off, P.pslot_pose, 0, n_pt, [&](int64_t k, int, int) { bk.add(k); });
-    range_pairs(P.tls_off, P.tslot_pose, 0, n_text, [&](int64_t k, int, int) { bk.add(k); });
+                for (int x = P.pose_ps_off[a]; x < P.pose_ps_off[a+1]; x++) { const int j = P.pose_ps_lm[x], sa = P.pose_ps[x];
+                    for (int s2 = P.pls_off[j]; s2 < P.pls_off[j+1]; s2++) { const int b = P.pslot_pose[s2]; if (b >= a && (!cl_pt || cl_pt[sa] == cl_pt[s2])) bk.add_mt(bkey(a, b)); } } });
+    } else range_pairs(P.pls_off, P.pslot_pose, cl_pt, 0, n_pt, [&](int64_t k, int, int) { bk.add(k); });
+    range_pairs(P.tls_off, P.tslot_pose, cl_tx, 0, n_text, [&](int64_t k, int, int) { bk.add(k); });
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bk.add(bkey(i, i));
-        if (h >= 0) { bk.add(bkey(h, h)); bk.add(bkey(std::min(i, h), std::max(i, h))); } }
+        if (h >= 0) { bk.add(bkey(h, h)); if (!pair_far || !pair_far[q]) bk.add(bkey(std::min(i, h), std::max(i, h))); } }
     if (n_kf <= 64) for (int a = 0; a < n_kf; a++) for (int b = a; b < n_kf; b++) bk.add(bkey(a, b));   // small windows: dense S, no memset
     lap("slot pair generation");
     const int n_sb = bk.finish();
@@ -403,27 +421,30 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     auto blk_of = [&](int64_t k) { return bk.id(k); };
     P.sb_a.resize(n_sb); P.sb_b.resize(n_sb); P.sb_pab.assign(n_sb, -1); P.sb_pba.assign(n_sb, -1);
     for (int q = 0; q < n_sb; q++) { P.sb_a[q] = (int)(bkeys[q]/n_kf); P.sb_b[q] = (int)(bkeys[q] % n_kf); }
-    for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; if (h < 0) continue;
+    for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; if (h < 0 || (pair_far && pair_far[q])) continue;
         int bl = blk_of(bkey(std::min(i, h), std::max(i, h)));
         if (i < h) P.sb_pab[bl] = q; else P.sb_pba[bl] = q; }     // pab: target = a, host = b;  pba: target = b, host = a
     // the slot pairs placed by block, stable: the landmark-major generation order is kept within a block
-    auto fill_tri = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, const std::vector<int32_t> &lm_of, const std::vector<int> &lo,
+    auto fill_tri = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, const int32_t *cl, const std::vector<int32_t> &lm_of, const std::vector<int> &lo,
                         std::vector<int32_t> &off, std::vector<int32_t> &s1v, std::vector<int32_t> &s2v, std::vector<int32_t> &lmv) {
         const int n_lm = lo[(size_t)T];
         const size_t n_slot = n_lm > 0 ? (size_t)loff[n_lm] : 0;
-        if (n_slot == 0) { off.assign((size_t)n_sb + 1, 0); return; }
+        if (n_slot == 0) { off.assign((size_t)n_sb + 1, 0); s1v.clear(); s2v.clear(); lmv.clear(); return; }
         BucketPlacer bp(pool, n_sb, SC);
-        pool.run([&](int t) { bp.begin(t, 4*n_slot/(size_t)T + 1024); range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t k, int, int) { bp.count(t, blk_of(k)); }); });
+        pool.run([&](int t) { bp.begin(t, 4*n_slot/(size_t)T + 1024); range_pairs(loff, pose, cl, lo[t], lo[t+1], [&](int64_t k, int, int) { bp.count(t, blk_of(k)); }); });
         lap("  slot pairs: count");
         bp.offsets(off);
         const size_t tot = (size_t)off[n_sb];
         s1v.resize(tot); s2v.resize(tot); lmv.resize(tot);
         lap("  slot pairs: offsets + resize");
-        pool.run([&](int t) { size_t e = 0; range_pairs(loff, pose, lo[t], lo[t+1], [&](int64_t, int s1, int s2) { const int at = bp.next(t, e); s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; }); });
+        pool.run([&](int t) { size_t e = 0; range_pairs(loff, pose, cl, lo[t], lo[t+1], [&](int64_t, int s1, int s2) { const int at = bp.next(t, e); s1v[at] = s1; s2v[at] = s2; lmv[at] = lm_of[s1]; }); });
     };
-    fill_tri(P.pls_off, P.pslot_pose, P.pslot_lm, lo_pt, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2, P.sb_pt_lm);      // (lm: saves one dependent gather in k_schur)
-    fill_tri(P.tls_off, P.tslot_pose, P.tslot_lm, lo_tx, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2, P.sb_tx_lm);
+    fill_tri(P.pls_off, P.pslot_pose, cl_pt, P.pslot_lm, lo_pt, P.sb_pt_off, P.sb_pt_s1, P.sb_pt_s2, P.sb_pt_lm);      // (lm: saves one dependent gather in k_schur)
+    fill_tri(P.tls_off, P.tslot_pose, cl_tx, P.tslot_lm, lo_tx, P.sb_tx_off, P.sb_tx_s1, P.sb_tx_s2, P.sb_tx_lm);
     lap("slot pairs by block");
+    };
+    build_blocks(nullptr, nullptr, nullptr);
+    const int n_sb = P.n_sb();
     // ---- per-pose lists
     auto csr = [&](int n, const std::vector<std::pair<int,int>> &items, std::vector<int32_t> &off, std::vector<int32_t> &val) {
         off.assign(n + 1, 0); val.resize(items.size());
@@ -530,7 +551,75 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                     }
                 }
             }
-            if (!P.ring) {
+            // Band + long-range blocks: most landmarks span a few consecutive keyframes (the local band), a small fraction couples keyframes far
+            // apart (points seen again much later, several loop closures) -- no order of the keyframes makes that a band.  The local band is the
+            // largest span that a noticeable share of the landmarks has; what lies outside goes to the long-range list.
+            int far_B = 0;
+            if (!P.ring && far_max_blocks > 0) {
+                std::vector<int64_t> hist((size_t)far_max_blocks + 2, 0); int64_t n_lm2 = 0;
+                for (const PoseList v : poses_of) { if (v.size() < 2) continue; n_lm2++; hist[(size_t)std::min(v.back() - v[0], far_max_blocks + 1)]++; }
+                int Bm = 0; for (int s = 1; s <= far_max_blocks; s++) if (hist[(size_t)s]*500 >= n_lm2) Bm = s;
+                int64_t n_wide = 0; for (int s = Bm + 1; s <= far_max_blocks + 1; s++) n_wide += hist[(size_t)s];
+                if (Bm >= 1 && n_wide*5 <= n_lm2 && n_kf >= 4*(3*Bm + 2) + Bm) far_B = Bm;
+            }
+            auto take_far = [&]() {
+                P.far_B = far_B; P.bw_pose = far_B; P.kf_order.clear();
+                // clusters of a landmark's poses (ascending; a host slot may come last): 0 = the host and what follows it within far_B keyframes
+                auto clusters = [&](auto &&pose_at, int n, int host, int32_t *cl) { int id = 0, start = 0;
+                    for (int x = 0; x < n; x++) { const int a = pose_at(x);
+                        if (a >= host && a - host <= far_B) { cl[x] = 0; continue; }
+                        if (id == 0 || a - start > far_B) { id++; start = a; }
+                        cl[x] = id; } };
+                // block positions of E: from ALL observations
+                KeyIndex fk; fk.begin((int64_t)n_kf*n_kf);
+                { std::vector<int32_t> cl; size_t lm = 0;
+                  for (const PoseList v : poses_of) { const size_t j = lm++; if (v.size() < 2) continue;
+                    const int host = j < (size_t)n_pt ? p->pt_host[j] : p->text_host[j - n_pt];
+                    cl.resize(v.size()); clusters([&](int x) { return v[(size_t)x]; }, (int)v.size(), host, cl.data());
+                    bool wide = false; for (size_t x = 0; x < v.size(); x++) wide |= cl[x] != 0;
+                    if (!wide) continue;
+                    for (size_t x = 0; x < v.size(); x++) for (size_t y = x + 1; y < v.size(); y++) if (cl[x] != cl[y]) fk.add(bkey(v[x], v[y])); } }
+                const int n_far = fk.finish();
+                P.far_a.resize((size_t)n_far); P.far_b.resize((size_t)n_far); P.fb_id.resize((size_t)n_far);
+                for (int q = 0; q < n_far; q++) { P.far_a[(size_t)q] = (int32_t)(fk.keys[(size_t)q]/n_kf); P.far_b[(size_t)q] = (int32_t)(fk.keys[(size_t)q] % n_kf); P.fb_id[(size_t)q] = q; }
+                P.far_off.assign((size_t)n_kf + 1, 0);
+                for (int q = 0; q < n_far; q++) { P.far_off[(size_t)P.far_a[(size_t)q] + 1]++; P.far_off[(size_t)P.far_b[(size_t)q] + 1]++; }
+                for (int k = 0; k < n_kf; k++) P.far_off[(size_t)k + 1] += P.far_off[(size_t)k];
+                P.far_ent.resize((size_t)P.far_off[(size_t)n_kf]);
+                { std::vector<int32_t> cur(P.far_off.begin(), P.far_off.end() - 1);
+                  for (int q = 0; q < n_far; q++) { P.far_ent[(size_t)cur[(size_t)P.far_a[(size_t)q]]++] = q << 1; P.far_ent[(size_t)cur[(size_t)P.far_b[(size_t)q]]++] = (q << 1) | 1; } }
+                // this rank's slots: cluster of every slot, the band part M rebuilt from the pairs within a cluster, E from the pairs across clusters
+                std::vector<int32_t> cl_pt((size_t)P.n_pslot(), 0), cl_tx((size_t)P.n_tslot(), 0);
+                std::vector<char> wide_pt((size_t)n_pt, 0), wide_tx((size_t)n_text, 0), pair_far((size_t)n_pair, 0);
+                pool.run([&](int t) { size_t j0, j1; pool.range((size_t)n_pt, t, j0, j1);
+                    for (size_t j = j0; j < j1; j++) { const int o0 = P.pls_off[j], n = P.pls_off[j + 1] - o0; if (n < 2) continue;
+                        clusters([&](int x) { return P.pslot_pose[(size_t)(o0 + x)]; }, n, p->pt_host[j], &cl_pt[(size_t)o0]);
+                        for (int x = 0; x < n; x++) if (cl_pt[(size_t)(o0 + x)]) wide_pt[j] = 1; } });
+                for (int j = 0; j < n_text; j++) { const int o0 = P.tls_off[j], n = P.tls_off[j + 1] - o0; if (n < 2) continue;
+                    clusters([&](int x) { return P.tslot_pose[(size_t)(o0 + x)]; }, n, p->text_host[j], &cl_tx[(size_t)o0]);
+                    for (int x = 0; x < n; x++) if (cl_tx[(size_t)(o0 + x)]) wide_tx[(size_t)j] = 1; }
+                for (int q = 0; q < n_pair; q++) { const int i = P.pair_i[q], h = P.pair_h[q]; pair_far[(size_t)q] = h >= 0 && !(i >= h && i - h <= far_B); }
+                build_blocks(cl_pt.data(), cl_tx.data(), pair_far.data());
+                P.fb_pab.assign((size_t)n_far, -1); P.fb_pba.assign((size_t)n_far, -1);
+                for (int q = 0; q < n_pair; q++) { if (!pair_far[(size_t)q]) continue; const int i = P.pair_i[q], h = P.pair_h[q];
+                    const int bl = fk.id(bkey(std::min(i, h), std::max(i, h)));
+                    if (i < h) P.fb_pab[(size_t)bl] = q; else P.fb_pba[(size_t)bl] = q; }
+                auto fill_far = [&](const std::vector<int32_t> &loff, const std::vector<int32_t> &pose, const std::vector<int32_t> &cl, const std::vector<char> &wide, int n_lm,
+                                    std::vector<int32_t> &off, std::vector<int32_t> &s1v, std::vector<int32_t> &s2v, std::vector<int32_t> &lmv) {
+                    off.assign((size_t)n_far + 1, 0);
+                    auto each = [&](auto &&f) { for (int j = 0; j < n_lm; j++) { if (!wide[(size_t)j]) continue;
+                        for (int s1 = loff[j]; s1 < loff[j + 1]; s1++) for (int s2 = loff[j]; s2 < loff[j + 1]; s2++)
+                            if (pose[s1] < pose[s2] && cl[(size_t)s1] != cl[(size_t)s2]) f(fk.id(bkey(pose[s1], pose[s2])), s1, s2, j); } };
+                    each([&](int id, int, int, int) { off[(size_t)id + 1]++; });
+                    for (int q = 0; q < n_far; q++) off[(size_t)q + 1] += off[(size_t)q];
+                    s1v.resize((size_t)off[(size_t)n_far]); s2v.resize(s1v.size()); lmv.resize(s1v.size());
+                    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+                    each([&](int id, int s1, int s2, int j) { const int at = cur[(size_t)id]++; s1v[(size_t)at] = s1; s2v[(size_t)at] = s2; lmv[(size_t)at] = j; }); };
+                fill_far(P.pls_off, P.pslot_pose, cl_pt, wide_pt, n_pt, P.fb_pt_off, P.fb_pt_s1, P.fb_pt_s2, P.fb_pt_lm);
+                fill_far(P.tls_off, P.tslot_pose, cl_tx, wide_tx, n_text, P.fb_tx_off, P.fb_tx_s1, P.fb_tx_s2, P.fb_tx_lm);
+            };
+            if (far_B > 0 && (far_force || n_kf > 2000)) take_far();       // (large maps: the reordering costs more host time than it can save)
+            if (!P.ring && !P.far_B) {
             if ((int64_t)n_kf*n_kf <= ((int64_t)1 << 28)) {       // adjacency through a bitmap over pose pairs: set bits come out sorted and distinct
                 std::vector<uint64_t> bm((((size_t)n_kf*n_kf) >> 6) + 1, 0);
                 for (const PoseList v : poses_of) { if (v.size() < 2) continue;
@@ -549,7 +638,8 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 for (int k : v) { lo = std::min(lo, pos[k]); hi = std::max(hi, pos[k]); } c2[lo] = std::max(c2[lo], hi); }
             for (int q = 0; q < n_sb; q++) { const int pa = pos[P.sb_a[q]], pb = pos[P.sb_b[q]]; c2[std::min(pa, pb)] = std::max(c2[std::min(pa, pb)], std::max(pa, pb)); }
             const int bw2 = closed_bw(c2);
-            if (bw2*10 < P.bw_pose*7) { P.kf_order = order; P.bw_pose = bw2; }
+            if (far_B > 0 && bw2 > 26) take_far();                 // no order of the keyframes brings the envelope within the band solvers' reach
+            else if (bw2*10 < P.bw_pose*7) { P.kf_order = order; P.bw_pose = bw2; }
             }
         }
     }

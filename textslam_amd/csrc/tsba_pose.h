@@ -301,7 +301,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_pose_begin(Work W, LevelDev L, d
         s->radius = radius0; s->decrease_factor = 2.0; s->x_cost = 0; s->x_norm = 0; s->cand_cost = 0; s->model_change = 0;
         s->step_norm = 0; s->gmax = 0; s->cost0 = 0;
         s->done = 0; s->need_lin = 1; s->first = 1; s->it = 0; s->accepted = 0; s->term = 0; s->invalid = 0; s->max_it = max_it;
-        s->step_fail = 0; s->lcur = 0; s->pad1 = 0; s->pad2 = 0;
+        s->step_fail = 0; s->lcur = 0; s->lin_done = 0; s->pad2 = 0;
         s->ns_active = cnt_s; s->nt_active = cnt_t; s->n_bad_scene = 0; s->n_bad_tfeat = 0; s->n_bad_text = 0;
         const int in = (cnt_s > 0 || cnt_t > 0) ? 1 : 0, cst = (kf_initial[0] && in) ? 1 : 0;    // optimizer.cc:1562-1588 for one keyframe
         W.kf_in[0] = in; W.kf_const[0] = cst;

@@ -45,6 +45,8 @@ def load_library():
     L.tsba_debug_reduced_system.argtypes = [vp, C.c_double, dp, dp, dp, C.POINTER(C.c_int32), dp]
     L.tsba_debug_reduced_band.argtypes = [vp, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, dp]
     L.tsba_debug_solver_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
+    L.tsba_debug_pcg_stats.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.tsba_debug_far_blocks.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
     L.tsba_debug_row_of_kf.argtypes = [vp, C.POINTER(C.c_int32)]
     L.tsba_debug_time_solve.argtypes = [vp, C.c_int, dp]
     L.tsba_comm_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
@@ -213,11 +215,25 @@ class Optimizer:
 
     def solver_info(self):
         """Which kernel paths the uploaded problem takes (tsba_debug_solver_info)."""
-        v = (C.c_int32 * 17)()
-        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 17), "tsba_debug_solver_info")
+        v = (C.c_int32 * 19)()
+        self._check(self.lib.tsba_debug_solver_info(self.ctx, v, 19), "tsba_debug_solver_info")
         keys = ("lds_solver", "band_storage", "band_stream", "interiors", "sep_cr", "band_rows", "small_pairs", "pose_kernel", "large_map", "world", "rank",
-                "n_pair", "n_sblock", "n_scene_candidates", "n_point_slots", "kf_reordered", "ring")
+                "n_pair", "n_sblock", "n_scene_candidates", "n_point_slots", "kf_reordered", "ring", "far_band_blocks", "far_blocks")
         return dict(zip(keys, [int(x) for x in v]))
+
+    def far_blocks(self):
+        """The 6x6 blocks outside the band (tsba_debug_far_blocks): keyframes a < b and values [n][6][6] (rows: keyframe a)."""
+        n = self.solver_info()["far_blocks"]
+        a, b, v = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros((n, 6, 6))
+        ip = C.POINTER(C.c_int32)
+        self._check(self.lib.tsba_debug_far_blocks(self.ctx, a.ctypes.data_as(ip), b.ctypes.data_as(ip), _dp(v)), "tsba_debug_far_blocks")
+        return a, b, v
+
+    def pcg_stats(self):
+        """Maps with long-range coupling: conjugate-gradient statistics of the last solve (tsba_debug_pcg_stats)."""
+        v = (C.c_int32 * 4)()
+        self._check(self.lib.tsba_debug_pcg_stats(self.ctx, v), "tsba_debug_pcg_stats")
+        return dict(zip(("iterations", "systems", "max_iterations", "hit_cap"), [int(x) for x in v]))
 
     def reduced_band(self, radius: float):
         """Large maps: the reduced system of the first linearisation in LAPACK lower-band storage (scipy.linalg.solveh_banded,

@@ -83,6 +83,38 @@ def _cam_lollipop(k, n, k0, step=0.1):
     return R0, -R0 @ c
 
 
+def _lobes(n, K):
+    """Keyframe ranges of a trajectory with K separate loop closures: a straight tail, then K loops, each closing on its own first keyframe,
+    joined by straight connectors.  Returns [(start, end)] of the loops."""
+    t = m = max(30, n//(4*K + 1))
+    l = (n - t - (K - 1)*m)//K
+    return [(t + i*(l + m), t + i*(l + m) + l) for i in range(K)]
+
+
+def _cam_lobes(k, n, K, step=0.1):
+    """T_cw of camera k of a trajectory that closes K separate loops (several loop closures in one session: the reference runs GlobalBA after
+    each, loopClosing.cc:587-591, on a map that keeps the earlier ones): tail -> loop 0 -> connector -> loop 1 -> ...; every loop is a circle
+    tangent to the base line at its junction, cameras looking outward as in _cam_ring; the connectors leave the junction along the tangent."""
+    lobes = _lobes(n, K)
+    l = lobes[0][1] - lobes[0][0]
+    radius = step*l/(2.0*np.pi)
+    m = lobes[1][0] - lobes[0][1] if K > 1 else 0
+    xj = lambda i: i*m*step                                   # junction of loop i on the base line (x axis, z = radius)
+    wob = 0.02*np.sin(0.3*k)
+    R0, _ = _cam_ring(0, l, step)
+    for i, (s, e) in enumerate(lobes):
+        if s <= k < e:
+            Rcw, t = _cam_ring(k - s, l, step)
+            c = -Rcw.T @ t + np.array([xj(i), 0.0, 0.0])
+            c[1] = wob
+            return Rcw, -Rcw @ c
+        if k < s:                                            # tail (i == 0) or the connector before loop i
+            c = np.array([xj(i) - (s - k)*step + (0.5*step if i > 0 else 0.0), wob, radius])
+            return R0, -R0 @ c
+    c = np.array([xj(K - 1) + (k - lobes[-1][1] + 0.5)*step, wob, radius])      # after the last loop
+    return R0, -R0 @ c
+
+
 def _bilinear(img, u, v):
     h, w = img.shape
     uf, vf = np.floor(u).astype(int), np.floor(v).astype(int)
@@ -129,7 +161,7 @@ class _Plane:
 
 def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), max_targets=5, text_targets=5,
                  frozen_frac=0.1, outlier_frac=0.05, noise_px=0.5, perturb=True, n_levels=3,
-                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None, loop=False, loop_at=0):
+                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None, loop=False, loop_at=0, closures=0):
     """Build a synthetic window (local BA / pose-only / global BA depending on the arguments).
 
     n_kf == 1 with frozen_frac == 1 gives the pose-only problem (every landmark hosted outside).
@@ -143,6 +175,9 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
     band = band or n_kf
     # cameras: window 0..n_kf-1, outside hosts -1..-n_out
     cams = {k: ((_cam_lollipop(k, n_kf, loop_at) if loop_at > 0 else _cam_ring(k, n_kf)) if loop else _cam(k)) for k in range(-n_out, n_kf)}
+    lobes = _lobes(n_kf, closures) if closures > 0 else []
+    if closures > 0:                                          # several separate loop closures (frozen hosts outside the map are not used with it)
+        cams = {k: _cam_lobes(max(k, 0), n_kf, closures) for k in range(-n_out, n_kf)}
     Rcw = np.stack([cams[k][0] for k in range(n_kf)])
     tcw = np.stack([cams[k][1] for k in range(n_kf)])
 
@@ -179,6 +214,12 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
         if far[j]:
             cand = rng.choice(n_kf, size=min(n_kf, 3 * max_targets), replace=False)
             cand.sort()
+        elif h >= 0 and closures > 0:
+            nxt = h + 1 + np.arange(band)
+            lo = [le for le in lobes if le[0] <= h < le[1] and h + band >= le[1]]
+            if lo and j % 2:                                  # the end of a loop: every second landmark is seen again by the loop's first keyframes (the closure),
+                nxt = np.where(nxt < lo[0][1], nxt, lo[0][0] + (nxt - lo[0][1]))     # the others by the keyframes that follow (the trajectory goes on)
+            cand = np.sort(nxt[nxt < n_kf])
         elif h >= 0 and loop:
             nxt = h + 1 + np.arange(min(band, n_kf - loop_at - 1))                  # the ring closes: the last keyframes observe the first ones' landmarks
             cand = np.sort(np.where(nxt < n_kf, nxt, loop_at + (nxt - n_kf)))      # (a loop that starts at keyframe loop_at: its end runs into keyframe loop_at)
@@ -444,11 +485,11 @@ def config_c4(seed=SEED):
     return make_problem(20, 5000, 100, seed)
 
 
-def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0, loop=False, loop_at=0):
+def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0, loop=False, loop_at=0, closures=0):
     """C5 / C6: scene-only global BA (the reference's GlobalBA ignores text, optimizer.cc:1707).  loop: closed trajectory (the map right
     after a loop closure: the co-visibility graph is a ring, not a band)."""
     return make_problem(n_kf, n_pt, 0, seed, max_targets=max_targets, frozen_frac=0.0, band=band, far_frac=far_frac,
-                        n_levels=1, rot_deg=0.2, trans_m=0.01, loop=loop, loop_at=loop_at)
+                        n_levels=1, rot_deg=0.2, trans_m=0.01, loop=loop, loop_at=loop_at, closures=closures)
 
 
 def tiny(seed=7, n_kf=5, n_pt=60, n_text=4, **kw):
