@@ -16,9 +16,14 @@ using tsba_adapter::Packed;
 typedef tsba_adapter::TextSlamTraits TT;
 
 namespace {
-// one context per optimizer object would be a member; a function-local static keeps this file free of header changes
-void *tsba_ctx() { static void *ctx = nullptr; if (!ctx && tsba_create(&ctx, 0) != TSBA_OK) { std::cerr << "tsba_create: no usable HIP device" << std::endl; exit(-1); } return ctx; }
+// One context per calling THREAD: TextSLAM's tracking, mapping and loop-closing threads call these methods concurrently (tracking.cc:447-561,
+// loopClosing.cc:589) and a tsba context serves one caller at a time (include/tsba.h).  thread_local keeps this file free of header changes;
+// with a header change the context would be a member of the optimizer object guarded like its other state.
+void *tsba_ctx() { static thread_local void *ctx = nullptr; if (!ctx && tsba_create(&ctx, 0) != TSBA_OK) { std::cerr << "tsba_create: no usable HIP device" << std::endl; exit(-1); } return ctx; }
 void k_of(const Mat33 &K, double out[4]) { out[0] = K(0, 0); out[1] = K(1, 1); out[2] = K(0, 2); out[3] = K(1, 2); }
+// TSBA_ERR_NUMERIC = the linear solver broke down in some LM trial (Ceres: termination FAILURE): the one-shot entry points have still
+// downloaded the LAST ACCEPTED state and the flags of the passes that ran (tsba.hip: one_shot returns the status after tsba_download), so
+// the scatter below writes a consistent state -- as Ceres leaves the parameter blocks at the best iterate.  Everything else is an error.
 bool failed(int rc, const char *what) { if (rc != TSBA_OK && rc != TSBA_ERR_NUMERIC) { std::cerr << what << ": " << tsba_last_error(tsba_ctx()) << std::endl; return true; } return false; }
 // label image of keyframe `kf` for the state left by the last solve: the TextLabelImg of ShowBAReproj_TextBox (optimizer.cc:2508-2582)
 cv::Mat label_image(int kf, const cv::Size &size) { cv::Mat lab(size, CV_32F); tsba_text_label_image(tsba_ctx(), kf, 0, (float *)lab.data); return lab; }
@@ -51,7 +56,8 @@ void optimizer::GlobalBA(map *mpMap) {
     tsba_adapter::pack_map<TT>(mpMap, vKFs, vMapPts, vMapTexts, /*global*/1, 1, K, /*FLAG_TEXT = false, :1707*/false, P);
     tsba_options o; tsba_default_options_global(&o);                                                                       // :411-414
     tsba_report rep;
-    if (failed(tsba_global_ba(tsba_ctx(), &P.p, &o, &rep), "tsba_global_ba")) exit(-1);                                    // (the reference exits on failure, :1842-1845)
+    const int rc_g = tsba_global_ba(tsba_ctx(), &P.p, &o, &rep);
+    if (failed(rc_g, "tsba_global_ba") || rc_g == TSBA_ERR_NUMERIC) exit(-1);                                              // (the reference exits when the solve is not usable, :1842-1845)
     tsba_adapter::scatter_map<TT>(P, vKFs, vMapPts, vMapTexts, true, false);                                              // :417-451
 }
 

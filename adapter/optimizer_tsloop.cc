@@ -15,7 +15,7 @@ namespace TextSLAM {
 typedef tsba_adapter::TextSlamTraits TT;
 
 namespace {
-void *tsloop_ctx() { static void *ctx = nullptr; if (!ctx && tsloop_create(0, &ctx) != TSLOOP_OK) { std::cerr << "tsloop_create: no usable HIP device" << std::endl; exit(-1); } return ctx; }
+void *tsloop_ctx() { static thread_local void *ctx = nullptr; if (!ctx && tsloop_create(0, &ctx) != TSLOOP_OK) { std::cerr << "tsloop_create: no usable HIP device" << std::endl; exit(-1); } return ctx; }
 }
 
 int optimizer::OptimizeSim3(vector<FeatureConvert> &vFeat1, vector<FeatureConvert> &vFeat2, vector<bool> &vbInliers, Sim3_loop &Sim12, const float th2) {

@@ -10,7 +10,9 @@
                     exchanges per LM trial.
   --workload local_ba | global_ba | orb selects explicitly (local BA and ORB at N > 1 are independent replicas).
 
-residuals/s = scalar residuals evaluated (once per linearisation and once per LM trial step) / wall time.
+residuals/s (`value`) = scalar residuals evaluated (once per linearisation and once per LM trial step) / wall time; `residuals_per_s_8d` counts
+SURVEY 8d's way (one residual + Jacobian evaluation per LM trial).  At N = 1 the local-BA line also carries `also`: the other BASELINE configs
+(C3, C5, C6 as an open chain / with 1 % long-range observations / after a loop closure, the ORB batch), each a few solves, no CPU leg.
 
 Launch: `python bench.py --gpus N` spawns the N ranks itself (one process per GPU, RCCL over xGMI); under a launcher that already
 set RANK / LOCAL_RANK / WORLD_SIZE (torch.distributed.run) it is one of the ranks -- --gpus must then agree with WORLD_SIZE.
@@ -173,6 +175,70 @@ def spawn_ranks(args):
         sys.exit("bench.py: rank exit codes %s" % rcs)
 
 
+def _evals_8d(rep):
+    """SURVEY 8d's residual count: every residual evaluated in a residual + Jacobian pass, once per LM trial step (the library's
+    n_resid_evals also counts the cost evaluation of every trial, which the same speculative launch produces: ~1.9 x)."""
+    return float(sum(it*(2*ns + 8*nt) for it, ns, nt in zip(rep["iters"], rep["n_sblock"], rep["n_tblock"])))
+
+
+def also_lines(gpu, local_rank, torch, steps=3):
+    """The other BASELINE configs on this GPU, without their CPU legs (a few hundred ms of GPU time each; the synthetic maps take longer to
+    build than to solve): C3 pose-only, C5 global BA 500 KF x 50 k points, C6 global BA 5000 KF / ~500 k observations as an open chain, with
+    SURVEY 8d's 1 % long-range observations, and right after a loop closure (ring), and the ORB batch of 64 frames."""
+    import numpy as np
+    from textslam_amd import synth, abi
+    out = {}
+
+    def run(name, prob, opt, extra=None, call=None):
+        t0 = time.perf_counter(); gpu.upload(prob, opt); up = (time.perf_counter() - t0)*1e3
+        rep = gpu.solve(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rep = gpu.solve()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0)/steps
+        e = {"ms_per_solve": dt*1e3, "residuals_per_s": float(rep["n_resid_evals"])/dt, "residuals_per_s_8d": _evals_8d(rep)/dt, "lm_iterations": rep["iters"],
+             "accepted": rep["accepted"], "scene_blocks": rep["n_sblock"][-1], "text_blocks": rep["n_tblock"][-1], "upload_plan_ms": up, "cost": [rep["cost0"][0], rep["cost1"][-1]]}
+        if extra:
+            e.update(extra(rep))
+        out[name] = e
+
+    def glob_extra(rep):
+        info = gpu.solver_info()
+        lin_ms, algo = gpu.time_linearize(0, 30)
+        e = {"band_rows": info["band_rows"], "interiors": info["interiors"], "ring_partition": info["ring"], "keyframes_reordered": info["kf_reordered"],
+             "roofline": {"bound": "hbm", "kernel": "k_linearize (level 0)", "achieved": algo/(lin_ms*1e-3)/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": algo/(lin_ms*1e-3)/1e9/HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo, "avg_launch_us": lin_ms*1e3}}
+        if info["far_band_blocks"]:
+            st = gpu.pcg_stats()
+            e.update({"long_range_blocks": info["far_blocks"], "preconditioner_band_blocks": info["far_band_blocks"], "pcg_iterations": st["iterations"],
+                      "pcg_systems": st["systems"], "pcg_max_iterations": st["max_iterations"], "pcg_hit_cap": st["hit_cap"]})
+        else:
+            e["solve_us_per_lm_trial"] = gpu.time_solve(10)*1e3
+        return e
+    run("c3_pose_only", synth.config_c3(), abi.options_pose())
+    og = abi.options_global()
+    run("c5_global_500kf_50kpts", synth.config_global(n_kf=500, n_pt=50000, band=12), og, glob_extra)
+    run("c6_global_5000kf_open_chain", synth.config_global(n_kf=5000, n_pt=70000, band=10), og, glob_extra)
+    run("c6_global_5000kf_1pct_long_range", synth.config_global(n_kf=5000, n_pt=70000, band=10, far_frac=0.01), og, glob_extra)
+    run("c6_global_5000kf_loop_closure_ring", synth.config_global(n_kf=5000, n_pt=70000, band=10, loop=True), og, glob_extra)
+    # ORB batch of 64 frames (BASELINE config 2)
+    from textslam_amd.orbextractor import ORBextractor, synthetic_frame
+    imgs = np.stack([synthetic_frame(s) for s in range(64)])
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device=local_rank)
+    ex.upload(imgs)
+    for _ in range(2):
+        ex.run()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        ex.run()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0)/10
+    nk = sum(len(k) for k, _ in ex.download())
+    out["c2_orb_64_frames"] = {"ms_per_batch": dt*1e3, "keypoints_per_s": nk/dt, "frames_per_s": 64/dt,
+                               "roofline": {"bound": "hbm", "kernel": "whole ORB pipeline", "achieved": 64*4.7e6/dt/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": 64*4.7e6/dt/1e9/HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 64*4.7e6}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +252,7 @@ def main():
     ap.add_argument("--loop", action="store_true", help="global_ba: closed trajectory (the map right after a loop closure: ring-shaped co-visibility)")
     ap.add_argument("--loop-at", type=int, default=0, help="global_ba --loop: the loop starts at this keyframe (a tail before the loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="local_ba at 1 GPU: skip the `also` object (the other BASELINE configs: C3, C5, C6 incl. long-range / loop-closure maps, ORB)")
     ap.add_argument("--check-single", action="store_true", help="global_ba, N > 1: compare the N-rank result with the 1-rank solve")
     args = ap.parse_args()
 
@@ -281,12 +348,13 @@ def main():
             n6 = 6*args.kf
             out = {"metric": "global_ba_residuals_per_s", "value": value, "unit": "residuals/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                   "dtype": "f64", "data": "synthetic",
+                   "dtype": "f64", "data": "synthetic", "residuals_per_s_8d": _evals_8d(rep)*args.steps/dt,
                    "config": {"workload": "C6 global BA: %d KF x %d pts (scene only, 20 LM its, level 0), landmarks sharded over %d GPU(s)"
                                           % (args.kf, args.pts, world), "lm_iterations": rep["iters"], "scene_blocks": rep["n_sblock"],
                               "reduced_system_dim": n6, "band_rows": info["band_rows"], "interiors": info["interiors"],
                               "separator_solver": "cyclic reduction" if info["sep_cr"] else "streaming", "far_frac": args.far,
                               "loop_closure_map": bool(args.loop), "keyframes_reordered": bool(info["kf_reordered"]), "ring_partition": bool(info.get("ring", 0)),
+                              "long_range_blocks": info.get("far_blocks", 0), "pcg": gpu.pcg_stats() if info.get("far_band_blocks") else None,
                               "rccl_ranks": ex["ranks"], "allreduce_bytes_per_lm_trial": ex["per_trial"],
                               "allreduce_bytes_per_linearisation": ex["per_linearisation"]}}
             if reference:
@@ -297,7 +365,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL,4> (level 0, this rank's shard)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic if world == 1 else None, "traffic_source": src if world == 1 else None,
                                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3}
-            if sol_ms is not None and not args.loop:
+            if sol_ms is not None and not args.loop and not info.get("far_band_blocks"):
                 # the dominant phase of an LM trial: the band solve of the reduced camera system -- LDL^T of an n x n band of half width
                 # bw: n (bw^2 + 3 bw) flops + two triangular sweeps 4 n bw
                 bw = info["band_rows"] + 5
@@ -337,6 +405,7 @@ def main():
                        "residual_blocks_level0": {"scene": rep["n_sblock"][-1], "text": rep["n_tblock"][-1]},
                        "lm_iterations": rep["iters"], "resid_evals_per_call": rep["n_resid_evals"]},
             "local_ba_wall_ms": ms_per_step,
+            "residuals_per_s_8d": _evals_8d(rep)*world/(dt/args.steps),      # SURVEY 8d's count: one per LM trial (`value` also counts the trial's cost evaluation)
             "local_ba_cold_call_ms": cold_ms,          # PCIe-inclusive: plan construction + upload + solve + download (never `value`)
             "roofline": {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -348,6 +417,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:        # (the CPU baseline is reported at N = 1 only)
             out["cpu_baseline"] = cpu_baseline_local(prob, opt)
+        if world == 1 and not args.no_also:                # the other BASELINE configs, outside the timed region of `value`
+            try:
+                out["also"] = also_lines(gpu, local_rank, torch)
+            except Exception as e:                         # noqa: BLE001 -- the headline line must not die with an extra
+                out["also"] = {"error": repr(e)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1137,8 +1137,8 @@ done:
     if (nth) memcpy(p->theta, x_th, sizeof(double)*nth);
 
     if (cov_out && cov_text >= 0 && cov_text < p->n_text) {      /* ceres::Covariance on the same problem (mu / sigma of this pass) */
-        int li = P.tx_lm[cov_text];
-        *cov_rc = (li >= 0 && !inv_sym(N.V + 9*li, 3, cov_out)) ? TSBA_OK : TSBA_ERR_NUMERIC;
+        int li = P.tx_lm[cov_text]; double ctmp[9];                /* the reference keeps the LAST pass whose Covariance::Compute succeeds, optimizer.cc:2224-2241 */
+        if (li >= 0 && !inv_sym(N.V + 9*li, 3, ctmp)) { memcpy(cov_out, ctmp, sizeof ctmp); *cov_rc = TSBA_OK; }
     }
     /* outlier pass on loss-corrected residuals, optimizer.cc:1609-1686 / :1228-1305 */
     if (o->outlier_scene || o->outlier_text) {
@@ -1183,7 +1183,7 @@ int tsba_oracle_solve(tsba_problem *p, const tsba_options *o, tsba_report *r) {
     return TSBA_OK;
 }
 
-/* optimizer::ThetaOptimMultiFs: the solve plus the covariance of theta[text] from the last pass (optimizer.cc:2219-2238) */
+/* optimizer::ThetaOptimMultiFs: the solve plus the covariance of theta[text] from the last pass whose information matrix is invertible (optimizer.cc:2219-2241) */
 int tsba_oracle_theta_optim(tsba_problem *p, const tsba_options *o, tsba_report *r, int text, double cov[9]) {
     if (!p || !o || !r || !cov) return TSBA_ERR_ARG;
     memset(r, 0, sizeof(*r));

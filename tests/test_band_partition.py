@@ -227,8 +227,8 @@ def test_ring_partition_with_a_tail(lib, nf, row0, B, Gmax, Ptmax):
 
 
 def test_plan_threads_leave_the_callers_cpu_affinity_alone():
-    """A multi-threaded plan build pins its threads -- and, for its duration, the calling thread -- to the CPUs that share the caller's L3
-    (tsba_plan.h: PlanPool).  Afterwards the caller's affinity mask is what it was, whether or not the pinning applied on this host."""
+    """Pinning of the plan threads is opt-in (tsba_options.host_plan_pin; debug knob 3) and applies to the WORKER threads of a multi-threaded
+    build only (tsba_plan.h: PlanPool): the calling thread's affinity mask is never touched, and the plan is the same either way."""
     import os
     from textslam_amd import synth, abi
     from textslam_amd.optimizer import load_library
@@ -236,6 +236,7 @@ def test_plan_threads_leave_the_callers_cpu_affinity_alone():
     L.tsba_debug_plan_checksum.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int]; L.tsba_debug_plan_checksum.restype = C.c_ulonglong
     L.tsba_debug_plan_knob.argtypes = [C.c_int, C.c_int]; L.tsba_debug_plan_knob.restype = None
     P = synth.config_global(n_kf=300, n_pt=8000, band=8); o = abi.options_global(); s = P.struct()
+    assert o.host_plan_pin == 0                                   # the default leaves scheduling alone
     before = os.sched_getaffinity(0)
     sums = []
     try:
@@ -243,6 +244,10 @@ def test_plan_threads_leave_the_callers_cpu_affinity_alone():
             L.tsba_debug_plan_knob(3, pin)
             sums.append(L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, 6))
             assert os.sched_getaffinity(0) == before
+        L.tsba_debug_plan_knob(3, 0)
+        o.host_plan_pin = 1                                       # the per-call option
+        sums.append(L.tsba_debug_plan_checksum(C.byref(s), C.byref(o), 0, 6))
+        assert os.sched_getaffinity(0) == before
     finally:
-        L.tsba_debug_plan_knob(3, 1)
-    assert sums[0] == sums[1] == sums[2] != 0
+        L.tsba_debug_plan_knob(3, 0)
+    assert sums[0] == sums[1] == sums[2] == sums[3] != 0

@@ -56,7 +56,7 @@ class TsbaOptions(C.Structure):
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("min_diagonal", C.c_double), ("max_diagonal", C.c_double),
         ("lm_shard", C.c_int32), ("lm_nshard", C.c_int32),
-        ("img_on_device", C.c_int32), ("reserved_", C.c_int32),
+        ("img_on_device", C.c_int32), ("host_plan_pin", C.c_int32),
     ]
 
 

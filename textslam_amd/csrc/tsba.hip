@@ -1788,6 +1788,12 @@ __global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_
     }
 }
 
+// ---- information matrix V (6 values) of one text plane at the end of a pass: ceres::Covariance runs after every pyramid pass of
+// PyrThetaOptim and the last successful one is kept (optimizer.cc:2219-2238)
+__global__ void k_record_vtx(Work W, int text, double *out6) {
+    const LinBuf &B = W.lb[W.st->lcur];
+    if (threadIdx.x < 6 && blockIdx.x == 0) out6[threadIdx.x] = B.V_tx[(size_t)threadIdx.x*W.n_text + text];
+}
 // ---- test hook: explicit residuals and Jacobians of every block, written at the reference's block order
 __global__ void k_eval_scene(Work W, LevelDev L, const int *out_idx, double *resid, double *jac) {
     int c = blockIdx.x*blockDim.x + threadIdx.x; if (c >= L.n_sc) return;
@@ -1889,6 +1895,7 @@ struct Ctx {
     std::vector<struct Slab> slabs; int cur_slab = 0;
     int run_slab = 0; size_t run_off = 0, run_len = 0;   // pending contiguous host-to-device range
     int cur_bw_rows = 1 << 30;                     // band bound of the level being solved (set by launch_pass_init)
+    int cov_text = -1; double *cov_log = nullptr;     // tsba_theta_optim: V of this plane at the end of every pass [TSBA_MAX_LEVELS][6]
     int far_B = 0, n_far = 0, pcg_parts = 0; unsigned int pcg_seq = 0;      // band + long-range blocks (tsba_pcg.h): band of M in pose blocks, blocks outside it, partial sums per vector kernel
     int rank = 0, world = 1; bool force_multi = false;
     tsba_debug_options dbg{};                      // test / diagnostics switches (tsba_debug_set), all zero in production
@@ -2021,9 +2028,11 @@ int tsba_create(void **ctx, int device) {
     if (c->lds_limit < 160*1024) c->lds_limit = 160*1024;
     *ctx = c; return TSBA_OK;
 }
+static void lgroup_forget(Ctx *c);              // (defined with LocalGroup below)
 int tsba_destroy(void *ctx) {
     Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
     hipSetDevice(c->device);
+    lgroup_forget(c);
     free_problem(c);
     hipStreamSynchronize(c->stream);
     for (Slab &sl : c->slabs) { hipFree(sl.dev); if (sl.host) hipHostFree(sl.host); }
@@ -2132,7 +2141,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
             int n_lev = 0; { std::vector<char> sn(p->n_levels, 0); for (int q = 0; q < o->n_passes; q++) if (!sn[o->levels[q]]) { sn[o->levels[q]] = 1; n_lev++; } }
             const int ring_max = (n_lev == 1 && !c->dbg.no_ring && !c->dbg.no_band_stream && c->dbg.sep_solver != 1 && c->dbg.sep_solver != 3 && c->dbg.band_parts != 1) ? CR_SMAX/6 : 0;
             // maps with long-range coupling (several loop closures, points seen again much later): band + blocks outside it, preconditioned conjugate gradients
-            const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream) ? CR_SMAX/6 : 0;
+            const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream && (!c->dbg.no_ring || c->dbg.far_solver == 2)) ? CR_SMAX/6 : 0;     // (no_ring asks for the reordering path)
             const bool far_force = c->dbg.far_solver == 2;
             planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max, far_max, far_force]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
@@ -2325,6 +2334,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     AL(W.posepart, 2*((size_t)p->n_kf/21 + 2));
     { size_t mxn = 1; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) mxn = std::max(mxn, (size_t)c->lev[l].n_sc + c->lev[l].n_tg); AL(W.cntpart, 2*(mxn/4 + mxn/256 + 4)); }
     AL(W.st, 1);
+    AL(c->cov_log, 6*TSBA_MAX_LEVELS);
     flush_run(c);
     auto tu2 = std::chrono::steady_clock::now();
     if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err(c, "upload sync failed"); return TSBA_ERR_DEVICE; }
@@ -2353,12 +2363,14 @@ static bool is_multi(const Ctx *c) { return c->world > 1 || c->force_multi; }
 // one-GPU box; production multi-GPU runs use RCCL (tsba_comm_init).
 struct LocalGroup {
     int world = 1; bool broken = false;
+    std::vector<Ctx *> members;                    // contexts that joined (tsba_comm_init_local): their lgroup is cleared when the group goes away
     std::mutex m; std::condition_variable cv; int arrived = 0; unsigned long long gen = 0;
     std::vector<std::vector<char>> stage; std::vector<char> result;
     // The ranks of a group usually share ONE device.  A rank holds this token while it has kernels in flight (from the moment it leaves a
     // collective until its stream has drained at the next one), so that the ranks' launches do not overlap on the device: kernel
     // durations under a profiler are then those of a rank that has the GPU to itself, as in a real multi-GPU run.
     std::mutex gpu_token;
+    void fail() { std::lock_guard<std::mutex> lk(m); broken = true; cv.notify_all(); }     // a member gives up: the others must not wait for it
     bool barrier() {                               // false: a member never arrived (it failed before the collective) -- do not hang
         std::unique_lock<std::mutex> lk(m);
         if (broken) return false;
@@ -2368,10 +2380,15 @@ struct LocalGroup {
         return !broken;
     }
 };
+static void lgroup_forget(Ctx *c) {              // the context leaves its in-process group (destroyed, or joined to an RCCL communicator)
+    if (!c->lgroup) return;
+    { std::lock_guard<std::mutex> lk(c->lgroup->m); for (Ctx *&m : c->lgroup->members) if (m == c) m = nullptr; }
+    c->lgroup = nullptr;
+}
 static void local_allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op) {
     LocalGroup *G = c->lgroup;
     const size_t bytes = count*(dt == ncclDouble ? sizeof(double) : sizeof(int));
-    auto fail = [&](const char *what) { c->err = std::string("ncclAllReduce (local group): ") + what; };
+    auto fail = [&](const char *what) { c->err = std::string("ncclAllReduce (local group): ") + what; G->fail(); };
     if (hipStreamSynchronize(c->stream) != hipSuccess) { fail("stream"); return; }
     std::vector<char> &mine = G->stage[c->rank];
     mine.resize(bytes);
@@ -2382,7 +2399,7 @@ static void local_allreduce(Ctx *c, void *buf, size_t count, ncclDataType_t dt, 
     if (c->rank == 0) {
         G->result = G->stage[0];
         for (int r = 1; r < G->world; r++) {
-            if (G->stage[r].size() != bytes) { G->broken = true; break; }        // ranks disagree on the count: a layout bug, never sum garbage
+            if (G->stage[r].size() != bytes) { G->fail(); break; }              // ranks disagree on the count: a layout bug, never sum garbage
             if (dt == ncclDouble) { double *a = (double *)G->result.data(); const double *b = (const double *)G->stage[r].data();
                 if (op == ncclMax) for (size_t k = 0; k < count; k++) a[k] = a[k] > b[k] ? a[k] : b[k]; else for (size_t k = 0; k < count; k++) a[k] += b[k]; }
             else { int *a = (int *)G->result.data(); const int *b = (const int *)G->stage[r].data(); for (size_t k = 0; k < count; k++) a[k] += b[k]; }
@@ -2704,6 +2721,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
         if (o.outlier_scene || o.outlier_text)
             if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
                                                           o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)nullptr);
+        if (c->cov_text >= 0 && c->cov_text < c->n_text && ps < TSBA_MAX_LEVELS) hipLaunchKernelGGL(k_record_vtx, dim3(1), dim3(64), 0, c->stream, c->W, c->cov_text, c->cov_log + 6*ps);
         CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
     }
     if (c->world > 1) {                           // every landmark was optimised by its owner only
@@ -2772,21 +2790,38 @@ int tsba_pose_optim(void *ctx, tsba_problem *p, const tsba_options *o, tsba_repo
 int tsba_global_ba(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r) { return one_shot(ctx, p, o, r); }
 int tsba_theta_optim(void *ctx, tsba_problem *p, const tsba_options *o, int text, double cov[9], tsba_report *r) {
     Ctx *c = (Ctx *)ctx;
-    if (!c || !p || !cov || text < 0 || text >= p->n_text) return TSBA_ERR_ARG;
-    int rc = one_shot(ctx, p, o, r); if (rc) return rc;
-    // information matrix of theta[text] at the solution = V of the current linearisation (undamped, loss-corrected J^T J)
-    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
-    double V[6];
-    for (int k = 0; k < 6; k++) CK(hipMemcpy(&V[k], c->W.lb[st.lcur & 1].V_tx + (size_t)k*c->n_text + text, sizeof(double), hipMemcpyDeviceToHost));
-    const double a = V[0], b = V[1], cc = V[2], e = V[3], f = V[4], i = V[5];
-    const double A = e*i - f*f, B = -(b*i - cc*f), C = b*f - cc*e, det = a*A + b*B + cc*C;
-    // singular information matrix: as the reference (Covariance::Compute fails, thetaVariance keeps its value, PyrThetaOptim
-    // still returns true -- optimizer.cc:2224-2241): not an error, cov[] untouched, flagged in the report
-    if (!(det > 0.0) || !(a > 0.0) || !(a*e - b*b > 0.0)) { r->cov_valid = 0; return TSBA_OK; }
-    r->cov_valid = 1;
-    const double id = 1.0/det;
-    cov[0] = A*id; cov[1] = B*id; cov[2] = C*id; cov[3] = B*id; cov[4] = (a*i - cc*cc)*id; cov[5] = -(a*f - b*cc)*id;
-    cov[6] = C*id; cov[7] = cov[5]; cov[8] = (a*e - b*b)*id;
+    if (!c || !p || !o || !cov || !r || text < 0 || text >= p->n_text) return TSBA_ERR_ARG;
+    c->cov_text = text;
+    int rc = one_shot(ctx, p, o, r);
+    c->cov_text = -1;
+    if (rc) return rc;
+    // Information matrix of theta[text] = V of the linearisation at the end of a pass (undamped, loss-corrected J^T J).  The reference
+    // runs ceres::Covariance after EVERY pyramid pass and keeps the last one that succeeds (optimizer.cc:2219-2238: thetaVariance is only
+    // overwritten when Compute returns true): the passes are tried from the last to the first.  A pass fails when V is not positive
+    // definite or its reciprocal condition number is below 1e-14 (Ceres' min_reciprocal_condition_number; recalled, oracle/RECALLED.md).
+    // No pass succeeds: as the reference (PyrThetaOptim still returns true, optimizer.cc:2224-2241) not an error, cov[] untouched.
+    double Vall[6*TSBA_MAX_LEVELS];
+    CK(hipMemcpy(Vall, c->cov_log, sizeof(Vall), hipMemcpyDeviceToHost));
+    r->cov_valid = 0;
+    for (int ps = std::min(o->n_passes, TSBA_MAX_LEVELS) - 1; ps >= 0; ps--) {
+        const double *V = Vall + 6*ps;
+        const double a = V[0], b = V[1], cc = V[2], e = V[3], f = V[4], i = V[5];
+        const double A = e*i - f*f, B = -(b*i - cc*f), C = b*f - cc*e, det = a*A + b*B + cc*C;
+        if (!(det > 0.0) || !(a > 0.0) || !(a*e - b*b > 0.0)) continue;
+        // eigenvalues of the symmetric 3x3 (trigonometric form): reciprocal condition number
+        const double q = (a + e + i)/3.0, p1 = b*b + cc*cc + f*f, p2 = (a - q)*(a - q) + (e - q)*(e - q) + (i - q)*(i - q) + 2.0*p1, pp = sqrt(p2/6.0);
+        double lmin = q, lmax = q;
+        if (pp > 0.0) { const double ip = 1.0/pp, b00 = (a - q)*ip, b01 = b*ip, b02 = cc*ip, b11 = (e - q)*ip, b12 = f*ip, b22 = (i - q)*ip;
+            double hr = 0.5*(b00*(b11*b22 - b12*b12) - b01*(b01*b22 - b12*b02) + b02*(b01*b12 - b11*b02));
+            hr = hr < -1.0 ? -1.0 : (hr > 1.0 ? 1.0 : hr);
+            const double phi = acos(hr)/3.0; lmax = q + 2.0*pp*cos(phi); lmin = q + 2.0*pp*cos(phi + 2.0943951023931953); }
+        if (!(lmin > 1e-14*lmax)) continue;
+        const double id = 1.0/det;
+        cov[0] = A*id; cov[1] = B*id; cov[2] = C*id; cov[3] = B*id; cov[4] = (a*i - cc*cc)*id; cov[5] = -(a*f - b*cc)*id;
+        cov[6] = C*id; cov[7] = cov[5]; cov[8] = (a*e - b*b)*id;
+        r->cov_valid = 1;
+        break;
+    }
     return TSBA_OK;
 }
 
@@ -3193,13 +3228,19 @@ void *tsba_local_group_create(int world) {
     if (world < 1) return nullptr;
     LocalGroup *G = new LocalGroup(); G->world = world; G->stage.resize(world); return G;
 }
-void tsba_local_group_destroy(void *group) { delete (LocalGroup *)group; }
+void tsba_local_group_destroy(void *group) {
+    LocalGroup *G = (LocalGroup *)group; if (!G) return;
+    G->fail();
+    for (Ctx *m : G->members) if (m && m->lgroup == G) { m->lgroup = nullptr; m->rank = 0; m->world = 1; m->uploaded = false; }   // (a resident problem was sharded for the group)
+    delete G;
+}
 int tsba_comm_init_local(void *ctx, void *group, int rank, int world) {
     Ctx *c = (Ctx *)ctx; LocalGroup *G = (LocalGroup *)group;
     if (!c || !G || world != G->world || rank < 0 || rank >= world) return TSBA_ERR_ARG;
     hipSetDevice(c->device);
     free_problem(c);                               // any resident problem was sharded for the old world size
     c->lgroup = G; c->rank = rank; c->world = world;
+    { std::lock_guard<std::mutex> lk(G->m); G->members.push_back(c); }
     return TSBA_OK;
 }
 int tsba_comm_stats(void *ctx, int32_t *ranks, int64_t bytes[3]) {
@@ -3218,6 +3259,7 @@ int tsba_debug_set(void *ctx, const tsba_debug_options *d) {
 int tsba_comm_init(void *ctx, const void *id128, int rank, int world) {
     Ctx *c = (Ctx *)ctx; if (!c || world < 1 || rank < 0 || rank >= world) return TSBA_ERR_ARG;
     hipSetDevice(c->device);
+    lgroup_forget(c);                              // (an RCCL communicator replaces an in-process group)
     if (!id128) { c->force_multi = world >= 1; c->rank = 0; c->world = 1; return TSBA_OK; }   // test hook: split kernels, no communicator
     int rc = load_rccl(c); if (rc) return rc;
     ncclUniqueId id; memcpy(&id, id128, 128);

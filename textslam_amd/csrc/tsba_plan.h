@@ -13,6 +13,8 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <atomic>
 #include <functional>
 #include <sched.h>
@@ -26,9 +28,10 @@
 #include "../../include/tsba.h"
 
 static int tsba_plan_threads = 0;              // 0: by problem size; > 0: host threads of the plan builder's parallel sections (tests)
-static int tsba_plan_pin = 1;                  // the plan threads of a multi-threaded build (and its caller, for its duration) are pinned to the CPUs that share the caller's
-                                               // L3: every pass hands the lists the last pass wrote to other threads -- through one L3 that is a cache hit, across the
-                                               // 32 L3 domains of the GPU box's two sockets a remote-cache miss per line (5000 keyframes: 21.0 -> 13.3 ms); 0: scheduler's choice
+static int tsba_plan_pin = 0;                  // 1 (debug knob; tsba_options.host_plan_pin per call): the WORKER threads of a multi-threaded build are pinned to the CPUs that share
+                                               // the caller's L3 -- every pass hands the lists the last pass wrote to other threads: through one L3 that is a cache hit, across the
+                                               // 32 L3 domains of the GPU box's two sockets a remote-cache miss per line (5000 keyframes: 21.0 -> 13.3 ms).  Off by default: a
+                                               // drop-in library does not touch scheduling unasked; the CALLING thread's affinity is never changed
 static int tsba_plan_mark_mt = 1;              // S-block keys of the slot pairs marked by the same threads (0: by the calling thread; measurements)
 
 struct PlanCand { int obs, kf, pt, host; };     // a scene candidate: observation, target keyframe, point, host keyframe (-1: frozen)
@@ -216,26 +219,37 @@ inline int plan_usable_cpus() {
 struct PlanPool {
     int T; std::vector<std::thread> th; std::atomic<int> gen{0}, done{0}; std::atomic<bool> stop{false};
     const std::function<void(int)> *job = nullptr;
-    bool pinned = false; cpu_set_t saved;
+    std::mutex m; std::condition_variable cv;          // workers park here after a short spin (several contexts may build plans at once: no indefinite busy-waiting)
     explicit PlanPool(int T_, bool pin = false) : T(std::max(1, T_)) {
-        cpu_set_t l3;
-        if (pin && T > 1 && plan_l3_cpuset(&l3) && pthread_getaffinity_np(pthread_self(), sizeof saved, &saved) == 0) {
-            T = std::min(T, CPU_COUNT(&l3)); pinned = pthread_setaffinity_np(pthread_self(), sizeof l3, &l3) == 0; }
-        for (int t = 1; t < T; t++) th.emplace_back([this, t]() { worker(t); });        // (threads inherit the creator's mask)
+        cpu_set_t l3; const bool pinned = pin && T > 1 && plan_l3_cpuset(&l3);
+        if (pinned) T = std::min(T, CPU_COUNT(&l3));
+        for (int t = 1; t < T; t++) { th.emplace_back([this, t]() { worker(t); });
+            if (pinned) pthread_setaffinity_np(th.back().native_handle(), sizeof l3, &l3); }       // the workers only: the caller keeps its own mask
     }
-    ~PlanPool() { stop.store(true); gen.fetch_add(1, std::memory_order_release); for (auto &x : th) x.join();
-                  if (pinned) pthread_setaffinity_np(pthread_self(), sizeof saved, &saved); }
+    ~PlanPool() { { std::lock_guard<std::mutex> lk(m); stop.store(true); gen.fetch_add(1, std::memory_order_release); } cv.notify_all(); for (auto &x : th) x.join(); }
     PlanPool(const PlanPool &) = delete; PlanPool &operator=(const PlanPool &) = delete;
-    static void relax(int &spins) { if (++spins > 2048) std::this_thread::yield(); else __builtin_ia32_pause(); }
+    static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        __asm__ __volatile__("yield");
+#else
+        std::this_thread::yield();
+#endif
+    }
     void worker(int t) { int seen = 0;
-        for (;;) { int spins = 0, g; while ((g = gen.load(std::memory_order_acquire)) == seen) relax(spins);
+        for (;;) { int spins = 0, g;
+            while ((g = gen.load(std::memory_order_acquire)) == seen) {
+                if (++spins < 4096) { cpu_relax(); continue; }
+                std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; }); }
             seen = g; if (stop.load()) return; (*job)(t); done.fetch_add(1, std::memory_order_release); } }
     template <class F> void run(F &&f) {                                // f(t) for t = 0 .. T-1, returns when all are done
         if (T <= 1) { f(0); return; }
         const std::function<void(int)> fn = [&f](int t) { f(t); };
-        job = &fn; done.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release);
+        job = &fn; done.store(0, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(m); gen.fetch_add(1, std::memory_order_release); } cv.notify_all();
         f(0);
-        int spins = 0; while (done.load(std::memory_order_acquire) != T - 1) relax(spins);
+        int spins = 0; while (done.load(std::memory_order_acquire) != T - 1) { if (++spins > 2048) std::this_thread::yield(); else cpu_relax(); }
     }
     void range(size_t n, int t, size_t &a, size_t &b) const { a = n*(size_t)t/(size_t)T; b = n*(size_t)(t + 1)/(size_t)T; }
 };
@@ -273,7 +287,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     if ((size_t)n_obs > 100000) T = std::max(1, std::min(std::min(16, plan_usable_cpus()), (int)(std::thread::hardware_concurrency()/2)));
     if (tsba_plan_threads > 0) T = tsba_plan_threads;
     if ((int64_t)n_kf*(n_kf + 1) > ((int64_t)1 << 31)) T = 1;       // (the key sets below are shared bitmaps only up to 2^31 keys)
-    PlanPool pool(T, tsba_plan_pin != 0);
+    PlanPool pool(T, tsba_plan_pin != 0 || o->host_plan_pin != 0);
     T = pool.T;
     typedef PlanCand Cand;
     PlanScratch &SC = P.scratch; SC.threads(T);
