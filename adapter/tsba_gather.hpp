@@ -42,6 +42,7 @@ struct Packed {
     std::vector<int32_t> tfeat_off[TSBA_MAX_LEVELS], tfeat_raw[TSBA_MAX_LEVELS], tobs_kf, tobs_text, tobs_fgood_off;
     std::vector<uint8_t> kf_initial, sgood, tobs_good, tfgood;
     std::vector<const uint8_t *> img[TSBA_MAX_LEVELS];
+    std::vector<int64_t> kf_id;             // keyframe::mnId of every keyframe (tsba_problem.kf_id: the context keeps the pyramid planes of keyframes it has seen)
     // bookkeeping for the scatter
     std::vector<int32_t> kf_flag_off;       // sgood offset of keyframe k's vObvGoodPts
     std::vector<int32_t> tobs_raw;          // index of text observation t in its keyframe's vObvText (vObvGoodTexts / vObvGoodTextFeats row)
@@ -60,6 +61,7 @@ struct Packed {
         p.n_tobs = (int32_t)tobs_kf.size(); p.tobs_kf = tobs_kf.data(); p.tobs_text = tobs_text.data(); p.tobs_good = tobs_good.data();
         if (tobs_fgood_off.empty()) tobs_fgood_off.push_back(0);
         p.tobs_fgood_off = tobs_fgood_off.data(); p.tfgood = tfgood.data();
+        p.kf_id = (kf_id.size() == pose.size()/7 && !kf_id.empty()) ? kf_id.data() : nullptr;
         for (int l = 0; l < n_levels; l++) {
             p.n_sobs[l] = (int32_t)sobs_kf[l].size();
             p.sobs_kf[l] = sobs_kf[l].data(); p.sobs_pt[l] = sobs_pt[l].data(); p.sobs_flag[l] = sobs_flag[l].data(); p.sobs_uv0[l] = sobs_uv0[l].data();
@@ -117,9 +119,22 @@ inline void pack_map(typename T::Map *mpMap, const std::vector<typename T::KeyFr
                      std::vector<int> *mnId2Pts_out = nullptr, std::vector<int> *mnId2Texts_out = nullptr) {
     std::vector<int> mnId2Pts((size_t)mpMap->imapPts, -1), mnId2Texts((size_t)mpMap->imapText, -1), mnId2KFs((size_t)mpMap->imapkfs, -1);
     for (size_t k = 0; k < vKFs.size(); k++) mnId2KFs[(size_t)vKFs[k]->mnId] = (int)k;                                 // :229-233
+    {   // one allocation per array instead of a doubling chain (this runs once per keyframe, on the caller's thread)
+        const size_t nk = vKFs.size(), np = vMapPts.size(), nt = vMapTexts.size();
+        P.pose.reserve(7*nk); P.kf_initial.reserve(nk); P.kf_id.reserve(nk); P.kf_flag_off.reserve(nk);
+        P.rho.reserve(np); P.pt_ray.reserve(2*np); P.pt_host.reserve(np); P.pt_Trw.reserve(12*np);
+        P.theta.reserve(3*nt); P.text_host.reserve(nt); P.text_Twr.reserve(12*nt); P.text_box.reserve(8*nt);
+        size_t nflag = 0; for (size_t k = 0; k < nk; k++) nflag += vKFs[k]->vObvGoodPts.size();
+        P.sgood.reserve(nflag);
+        for (int l = 0; l < n_levels; l++) { size_t n = 0; for (size_t k = 0; k < nk; k++) if ((size_t)l < vKFs[k]->vSceneObv2d.size()) n += vKFs[k]->vSceneObv2d[(size_t)l].size();
+            P.sobs_kf[l].reserve(n); P.sobs_pt[l].reserve(n); P.sobs_flag[l].reserve(n); P.sobs_uv0[l].reserve(2*n);
+            if (with_text) { size_t nf = 0; for (size_t j = 0; j < nt; j++) if ((size_t)l < vMapTexts[j]->vRefFeature.size()) nf += vMapTexts[j]->vRefFeature[(size_t)l].size();
+                P.tfeat_off[l].reserve(nt + 1); P.tfeat_raw[l].reserve(nf); P.tfeat_uv[l].reserve(2*nf); P.tfeat_ref[l].reserve(TSBA_NTAP*nf); } }
+    }
     // poses + gauge marks
     for (size_t k = 0; k < vKFs.size(); k++) {
         push_pose<T>(*vKFs[k], P.pose);
+        P.kf_id.push_back((int64_t)vKFs[k]->mnId);
         P.kf_initial.push_back(mode == 2 ? 1 : (vKFs[k]->mnId == 0 || vKFs[k]->mnId == 1) ? 1 : 0);                   // :274-275
     }
     // scene points: rho, ray, host (or the frozen host's T_rw)

@@ -385,6 +385,25 @@ def main():
         for _ in range(3):
             g2 = prob.copy(); tc = time.perf_counter(); gpu.LocalBundleAdjustment(g2, options=opt); cold.append((time.perf_counter() - tc)*1e3)
         cold_ms = min(cold)
+        # the call TextSLAM makes once per new keyframe: the window slides by one (tracking.cc:828-842), 19 of its 20 keyframes were in the last call --
+        # with the keyframes' identities (tsba_problem.kf_id) the context keeps their pyramid planes on the device and copies the new one only
+        import numpy as np
+        slide = []
+        for it in range(4):
+            g2 = prob.copy(); g2.kf_id = np.arange(20, dtype=np.int64) + 1000; g2.kf_id[19] = 5000 + it
+            tc = time.perf_counter(); gpu.LocalBundleAdjustment(g2, options=opt); slide.append((time.perf_counter() - tc)*1e3)
+        slide_ms = min(slide[1:])
+        # end to end as the adapter sees it: object graph -> gather (adapter/tsba_gather.hpp) -> tsba_local_ba -> scatter, from C++ (tests/cxx/abi_from_cxx)
+        adapter = None
+        exe = os.path.join(ROOT, "tests", "cxx", "abi_from_cxx")
+        if os.path.exists(exe):
+            import tempfile
+            from textslam_amd import abi as _abi
+            with tempfile.TemporaryDirectory() as td:
+                _abi.write_dump(os.path.join(td, "c4.bin"), prob.copy())
+                r = subprocess.run([exe, os.path.join(td, "c4.bin"), "time_local", os.path.join(td, "t.json"), "5"], capture_output=True, text=True, timeout=300)
+                if r.returncode == 0:
+                    adapter = json.load(open(os.path.join(td, "t.json")))
         gpu.upload(prob, opt)
         gpu.solve()
         # roofline of the linearisation kernel (residual + Jacobian + IRLS weight + J^T J / J^T r sums), level 0
@@ -407,6 +426,8 @@ def main():
             "local_ba_wall_ms": ms_per_step,
             "residuals_per_s_8d": _evals_8d(rep)*world/(dt/args.steps),      # SURVEY 8d's count: one per LM trial (`value` also counts the trial's cost evaluation)
             "local_ba_cold_call_ms": cold_ms,          # PCIe-inclusive: plan construction + upload + solve + download (never `value`)
+            "local_ba_sliding_call_ms": slide_ms,      # the same call with keyframe identities: 19 of the 20 keyframes' planes already on the device
+            "local_ba_adapter_call": adapter,          # C++: gather from the object graph + tsba_local_ba + scatter (what optimizer::LocalBundleAdjustment costs its caller)
             "roofline": {"bound": "hbm", "kernel": "k_linearize<FULL> (level 0)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": lin_ms*1e3},

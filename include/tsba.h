@@ -102,7 +102,15 @@ typedef struct tsba_problem {
     /* ---- images: level l of KF k = img[l][k], continuous uint8, img_w[l] x img_h[l] ---- */
     const uint8_t *const *img[TSBA_MAX_LEVELS]; /* img[l] = array of n_kf pointers (may be NULL if no text) */
     int32_t        img_w[TSBA_MAX_LEVELS], img_h[TSBA_MAX_LEVELS];
+
+    /* ---- optional: identity of the keyframes (keyframe::mnId).  A keyframe's pyramid planes never change after its creation, and
+     * LocalBundleAdjustment is called once per new keyframe on the last 20 (tracking.cc:828-842: 19 of them were in the last call).
+     * With kf_id != NULL the context keeps the planes of the keyframes it has seen on the device (up to TSBA_IMG_CACHE_KF of them, least
+     * recently used out first) and a call copies only the planes of keyframes it has not seen -- the caller promises that equal ids mean
+     * equal images at every level.  NULL: every call copies every plane.  Ignored with tsba_options.img_on_device. */
+    const int64_t *kf_id;             /* [n_kf] or NULL */
 } tsba_problem;
+#define TSBA_IMG_CACHE_KF 64
 
 typedef struct tsba_options {
     /* residual weights and robust kernels, optimizer.cc:1350-1351,1369,1454 */
@@ -238,6 +246,8 @@ int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
 /* Maps with long-range coupling: the conjugate-gradient solves of the last tsba_solve.  out[0] iterations in total, [1] reduced systems
  * solved (LM trials), [2] most iterations of one system, [3] systems that hit the iteration cap. */
 int  tsba_debug_pcg_stats(void *ctx, int32_t out[4]);
+/* Plane cache of the context (tsba_problem.kf_id): out[0] keyframes whose planes were found on the device, out[1] keyframes copied. */
+int  tsba_debug_img_cache_stats(void *ctx, int64_t out[2]);
 /* The 6x6 blocks of the reduced system outside the band (solver_info [18] of them) as left by tsba_debug_reduced_system / the last solve:
  * keyframes a < b of every block and its 36 values, row-major, rows = keyframe a.  Any output may be NULL. */
 int  tsba_debug_far_blocks(void *ctx, int32_t *a, int32_t *b, double *blocks);

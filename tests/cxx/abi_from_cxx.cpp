@@ -9,6 +9,12 @@
 //     4. if a HIP device is there: call the entry point of <mode> (local | global | landmarker | pose | init), scatter the result
 //        back into the object graph exactly as optimizer.cc does, and write the graph's parameters and flags to <out.bin>.
 //   exit code 0 = all of it, 3 = gather verified but no device (tsba_create returned TSBA_ERR_DEVICE), anything else = failure.
+//
+//   abi_from_cxx <dump.bin> time_local <out.json> [reps]
+//     what optimizer::LocalBundleAdjustment costs its caller end to end (optimizer.cc:197-331): gather (pack_map over ALL map points / texts)
+//     -> tsba_local_ba (plan + upload + solve + download) -> scatter_map, each phase timed; every repetition on a freshly built object graph
+//     (the scatter moves the poses: a second call on the same graph would converge in fewer iterations).  One JSON line to <out.json>.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -191,6 +197,41 @@ int main(int argc, char **argv) {
     if (argc < 4) { fprintf(stderr, "usage: %s dump.bin local|global|landmarker|pose|init out.bin\n", argv[0]); return 2; }
     Dump d; if (!read_dump(argv[1], d)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
     const std::string mode = argv[2];
+    if (mode == "time_local") {
+        const int reps = argc > 4 ? atoi(argv[4]) : 5;
+        void *cx = nullptr; int r0 = tsba_create(&cx, 0);
+        if (r0 == TSBA_ERR_DEVICE) { printf("no HIP device\n"); return 3; }
+        if (r0) return 1;
+        const bool wt = CNT(d, "tobs_kf") > 0;
+        std::vector<double> tg, ts, tc, tt; int its[TSBA_MAX_LEVELS] = {0}; double sol = 0, upl = 0, dwn = 0;
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        for (int rep_i = 0; rep_i < reps + 1; rep_i++) {                    // (the first call of a fresh context allocates: not counted)
+            Graph G; build_graph(d, "local", G);
+            G.kfs.back()->mnId = 100000 + (long unsigned)rep_i; G.M.imapkfs = 100000 + reps + 8;     // the window's newest keyframe is new to the context in every call: its planes cross the bus, the other 19 keyframes' do not
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<mapPts *> vP = G.M.GetAllMapPoints(); std::vector<mapText *> vT = G.M.GetAllMapTexts(TEXTGOOD);
+            Packed P; tsba_adapter::pack_map<Traits>(&G.M, G.kfs, vP, vT, 0, G.n_levels, G.K, wt, P);
+            const auto t1 = std::chrono::steady_clock::now();
+            tsba_options o; tsba_report rp; tsba_default_options_local(&o); o.state = I32(d, "state") ? I32(d, "state")[0] : TSBA_STATE_LOCAL;
+            const int rc = tsba_local_ba(cx, &P.p, &o, &rp);
+            const auto t2 = std::chrono::steady_clock::now();
+            if (rc) { fprintf(stderr, "tsba_local_ba: %d (%s)\n", rc, tsba_last_error(cx)); return 1; }
+            tsba_adapter::scatter_map<Traits>(P, G.kfs, vP, vT, true, true);
+            const auto t3 = std::chrono::steady_clock::now();
+            if (rep_i == 0) continue;
+            tg.push_back(ms(t0, t1)); tc.push_back(ms(t1, t2)); ts.push_back(ms(t2, t3)); tt.push_back(ms(t0, t3));
+            for (int k = 0; k < rp.n_passes; k++) its[k] = rp.iters[k];
+            sol = rp.t_solve_ms; upl = rp.t_upload_ms; dwn = rp.t_download_ms;
+        }
+        auto mn = [](std::vector<double> &v) { double m = v[0]; for (double x : v) m = x < m ? x : m; return m; };
+        FILE *f = fopen(argv[3], "w"); if (!f) return 2;
+        fprintf(f, "{\"local_ba_adapter_call_ms\": %.4f, \"gather_ms\": %.4f, \"tsba_local_ba_ms\": %.4f, \"scatter_ms\": %.4f, \"of_which_upload_plan_ms\": %.4f, \"solve_ms\": %.4f, \"download_ms\": %.4f, "
+                   "\"reps\": %d, \"lm_iterations\": [%d, %d, %d], \"keyframes\": %zu, \"map_points\": %zu, \"text_planes\": %zu}\n",
+                mn(tt), mn(tg), mn(tc), mn(ts), upl, sol, dwn, reps, its[0], its[1], its[2], CNT(d, "pose")/7, CNT(d, "rho"), CNT(d, "theta")/3);
+        fclose(f); tsba_destroy(cx);
+        printf("adapter call: %.3f ms (gather %.3f, tsba_local_ba %.3f, scatter %.3f)\n", mn(tt), mn(tg), mn(tc), mn(ts));
+        return 0;
+    }
     Graph G; build_graph(d, mode, G);
     const bool with_text = CNT(d, "tobs_kf") > 0;
     Packed P;

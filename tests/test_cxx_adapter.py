@@ -24,35 +24,7 @@ def _build():
 
 
 def _write_dump(path, P, state=abi.STATE_LOCAL):
-    P.normalise()
-    rec = []
-
-    def put(name, a, dt):
-        a = np.ascontiguousarray(a, {0: np.float64, 1: np.int32, 2: np.uint8}[dt]).reshape(-1)
-        rec.append(struct.pack("<I", len(name)) + name.encode() + struct.pack("<BQ", dt, a.size) + a.tobytes())
-    n_kf = P.n_kf
-    put("n_levels", [P.n_levels], 1); put("state", [state], 1); put("K", P.K, 0)
-    for k in ("pose", "rho", "theta", "pt_ray", "pt_host_Trw", "text_host_Twr", "text_box_ray"):
-        put(k, getattr(P, k), 0)
-    for k in ("pt_host", "text_host", "tobs_kf", "tobs_text", "tobs_fgood_off"):
-        put(k, getattr(P, k), 1)
-    for k in ("kf_initial", "sgood", "tobs_good", "tfgood"):
-        put(k, getattr(P, k), 2)
-    # the keyframes' flag ranges: level 0 lists every raw observation of a keyframe, in order
-    cnt = np.bincount(P.sobs_kf[0], minlength=n_kf) if P.sobs_kf[0].size else np.zeros(n_kf, np.int64)
-    off = np.concatenate([[0], np.cumsum(cnt)])
-    assert off[-1] == P.sgood.size and np.array_equal(P.sobs_flag[0], np.arange(P.sgood.size))
-    put("kf_flag_off", off, 1)
-    for l in range(P.n_levels):
-        put("sobs_kf_%d" % l, P.sobs_kf[l], 1); put("sobs_pt_%d" % l, P.sobs_pt[l], 1); put("sobs_flag_%d" % l, P.sobs_flag[l], 1)
-        put("sobs_uv0_%d" % l, P.sobs_uv0[l], 0)
-        if P.n_text:
-            put("tfeat_off_%d" % l, P.tfeat_off[l], 1); put("tfeat_raw_%d" % l, P.tfeat_raw[l], 1)
-            put("tfeat_uv_%d" % l, P.tfeat_uv[l], 0); put("tfeat_ref_%d" % l, P.tfeat_ref[l], 0)
-        if P.img[l] is not None:
-            put("img_%d" % l, P.img[l], 2); put("img_wh_%d" % l, [P.img[l].shape[2], P.img[l].shape[1]], 1)
-    with open(path, "wb") as f:
-        f.write(b"".join(rec))
+    abi.write_dump(path, P, state)
 
 
 def _read_out(path):

@@ -38,6 +38,7 @@ class TsbaProblem(C.Structure):
         ("tobs_fgood_off", c_ip), ("tfgood", c_up),
         ("img", c_upp * MAX_LEVELS),
         ("img_w", C.c_int32 * MAX_LEVELS), ("img_h", C.c_int32 * MAX_LEVELS),
+        ("kf_id", C.POINTER(C.c_int64)),
     ]
 
 
@@ -208,6 +209,7 @@ class BAProblem:
         self.img = [None] * MAX_LEVELS          # per level: uint8 array [n_kf, h, w]
         self.img_dev = [None] * MAX_LEVELS      # optional, per level: n_kf device addresses (Frame.level_device_ptr) -- handed over instead
                                                 # of the host arrays; pair with TsbaOptions.img_on_device = 1 (self.img keeps the shapes)
+        self.kf_id = None                        # optional int64 [n_kf]: identities of the keyframes (tsba_problem.kf_id: the context's plane cache)
         self.truth = {}                          # ground truth (synthetic problems only)
         self._keep = []
 
@@ -289,6 +291,11 @@ class BAProblem:
                 s.img_h[l], s.img_w[l] = im.shape[1], im.shape[2]
             else:
                 s.img[l] = C.cast(None, c_upp)
+        kid = getattr(self, "kf_id", None)
+        if kid is not None:
+            self.kf_id = np.ascontiguousarray(kid, np.int64)
+            assert self.kf_id.size == self.n_kf
+            s.kf_id = self.kf_id.ctypes.data_as(C.POINTER(C.c_int64))
         self._keep = keep
         return s
 
@@ -305,3 +312,37 @@ class BAProblem:
         """bytes one residual+Jacobian evaluation must move."""
         return (44 * n_sblock + 128 * n_tblock + 16 * n_pair
                 + 56 * self.n_kf + 8 * self.n_pt + 24 * self.n_text)
+
+
+def write_dump(path, P, state=STATE_LOCAL):
+    """A flat problem as the record file the C++ drivers of tests/cxx read (abi_from_cxx: object graph -> adapter gather -> C ABI -> scatter)."""
+    import struct
+    P.normalise()
+    rec = []
+
+    def put(name, a, dt):
+        a = np.ascontiguousarray(a, {0: np.float64, 1: np.int32, 2: np.uint8}[dt]).reshape(-1)
+        rec.append(struct.pack("<I", len(name)) + name.encode() + struct.pack("<BQ", dt, a.size) + a.tobytes())
+    n_kf = P.n_kf
+    put("n_levels", [P.n_levels], 1); put("state", [state], 1); put("K", P.K, 0)
+    for k in ("pose", "rho", "theta", "pt_ray", "pt_host_Trw", "text_host_Twr", "text_box_ray"):
+        put(k, getattr(P, k), 0)
+    for k in ("pt_host", "text_host", "tobs_kf", "tobs_text", "tobs_fgood_off"):
+        put(k, getattr(P, k), 1)
+    for k in ("kf_initial", "sgood", "tobs_good", "tfgood"):
+        put(k, getattr(P, k), 2)
+    # the keyframes' flag ranges: level 0 lists every raw observation of a keyframe, in order
+    cnt = np.bincount(P.sobs_kf[0], minlength=n_kf) if P.sobs_kf[0].size else np.zeros(n_kf, np.int64)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    assert off[-1] == P.sgood.size and np.array_equal(P.sobs_flag[0], np.arange(P.sgood.size))
+    put("kf_flag_off", off, 1)
+    for l in range(P.n_levels):
+        put("sobs_kf_%d" % l, P.sobs_kf[l], 1); put("sobs_pt_%d" % l, P.sobs_pt[l], 1); put("sobs_flag_%d" % l, P.sobs_flag[l], 1)
+        put("sobs_uv0_%d" % l, P.sobs_uv0[l], 0)
+        if P.n_text:
+            put("tfeat_off_%d" % l, P.tfeat_off[l], 1); put("tfeat_raw_%d" % l, P.tfeat_raw[l], 1)
+            put("tfeat_uv_%d" % l, P.tfeat_uv[l], 0); put("tfeat_ref_%d" % l, P.tfeat_ref[l], 0)
+        if P.img[l] is not None:
+            put("img_%d" % l, P.img[l], 2); put("img_wh_%d" % l, [P.img[l].shape[2], P.img[l].shape[1]], 1)
+    with open(path, "wb") as f:
+        f.write(b"".join(rec))

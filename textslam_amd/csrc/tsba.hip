@@ -24,6 +24,7 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
+#include <atomic>
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types only: the library is dlopen()ed by tsba_comm_init, single-GPU use never touches RCCL
 #include "../../include/tsba.h"
@@ -1871,7 +1872,15 @@ struct Ctx {
     Work W;
     std::vector<HostPlan> hplan;                  // per level (only levels used by the options are built)
     std::vector<LevelDev> lev;
-    std::vector<int> lev_built;
+    std::vector<int> lev_built;                   // level l is on the device (plan lists, reference features, image table)
+    // one-shot calls on small windows stage a level when its pass begins (the coarse passes run while the plan of level 0 is still being built)
+    std::vector<std::thread> planners;            // planners[l]: the host thread that builds level l's plan (joined by stage_level)
+    std::vector<int> lev_planned;                 // a plan of level l was started for this upload
+    const tsba_problem *stage_p = nullptr;        // the caller's problem while levels may still be staged from it (one-shot calls only)
+    std::vector<int> ic_slot; bool use_img_cache = false;      // plane cache: slot of every keyframe of this upload
+    std::atomic<int> plan_done[TSBA_MAX_LEVELS];  // set by a plan thread when its plan is complete: a level is staged ahead of its pass only when that costs no wait
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_stage[TSBA_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_async = false; int lev_wait[TSBA_MAX_LEVELS] = {0, 0, 0, 0};     // levels staged during a solve go over the copy stream; their pass waits for the event
     // restart copies
     double *pose0 = nullptr, *rho0 = nullptr, *theta0 = nullptr; uint8_t *sgood0 = nullptr, *tobs_good0 = nullptr, *tfgood0 = nullptr;
     uint8_t *kf_initial = nullptr;
@@ -1895,6 +1904,11 @@ struct Ctx {
     std::vector<struct Slab> slabs; int cur_slab = 0;
     int run_slab = 0; size_t run_off = 0, run_len = 0;   // pending contiguous host-to-device range
     int cur_bw_rows = 1 << 30;                     // band bound of the level being solved (set by launch_pass_init)
+    // device cache of keyframe pyramid planes (tsba_problem.kf_id): one slot per keyframe, all levels of a keyframe contiguous
+    struct ImgCache { uint8_t *dev = nullptr, *stage = nullptr; size_t stage_cap = 0, slot = 0, lvl_off[TSBA_MAX_LEVELS] = {0,0,0,0};
+                      int w[TSBA_MAX_LEVELS] = {0,0,0,0}, h[TSBA_MAX_LEVELS] = {0,0,0,0}; unsigned lvl_mask = 0;
+                      long long id[TSBA_IMG_CACHE_KF]; unsigned long long used[TSBA_IMG_CACHE_KF]; bool full[TSBA_IMG_CACHE_KF]; unsigned long long tick = 0;
+                      long long hits = 0, misses = 0; } ic;
     int cov_text = -1; double *cov_log = nullptr;     // tsba_theta_optim: V of this plane at the end of every pass [TSBA_MAX_LEVELS][6]
     int far_B = 0, n_far = 0, pcg_parts = 0; unsigned int pcg_seq = 0;      // band + long-range blocks (tsba_pcg.h): band of M in pose blocks, blocks outside it, partial sums per vector kernel
     int rank = 0, world = 1; bool force_multi = false;
@@ -1918,7 +1932,7 @@ static bool is_multi(const Ctx *c);
 struct Slab { char *dev = nullptr, *host = nullptr; size_t size = 0, used = 0; };
 static void flush_run(Ctx *c) {
     if (c->run_len) { Slab &sl = c->slabs[c->run_slab];
-        hipMemcpyAsync(sl.dev + c->run_off, sl.host + c->run_off, c->run_len, hipMemcpyHostToDevice, c->stream); c->run_len = 0; }
+        hipMemcpyAsync(sl.dev + c->run_off, sl.host + c->run_off, c->run_len, hipMemcpyHostToDevice, c->stage_async && c->copy_stream ? c->copy_stream : c->stream); c->run_len = 0; }
 }
 static int slab_take(Ctx *c, size_t bytes, int *slab, size_t *off) {
     for (;;) {
@@ -1929,6 +1943,7 @@ static int slab_take(Ctx *c, size_t bytes, int *slab, size_t *off) {
         hipError_t e = hipMalloc((void **)&sl.dev, sl.size);
         if (e != hipSuccess) { set_err(c, std::string("hipMalloc: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; }
         hipMemsetAsync(sl.dev, 0, sl.size, c->stream);
+        if (c->stage_async) hipStreamSynchronize(c->stream);     // (a slab born during a solve: the copy stream must not overtake its clearing)
         c->slabs.push_back(sl);
     }
 }
@@ -1957,7 +1972,9 @@ static int dev_upload(Ctx *c, const T **out, const T *src, size_t n) {
 template <typename T>
 static int dev_upload_vec(Ctx *c, const T **out, const std::vector<T> &v) { return dev_upload(c, out, v.data(), v.size()); }
 
+static void join_planners(Ctx *c) { for (auto &t : c->planners) if (t.joinable()) t.join(); c->planners.clear(); }
 static void free_problem(Ctx *c) {
+    join_planners(c); c->stage_p = nullptr;
     hipStreamSynchronize(c->stream);
     // the slabs stay (tsba_destroy frees them): zero what the last problem used, restart the bump allocation
     for (Slab &sl : c->slabs) { if (sl.used) hipMemsetAsync(sl.dev, 0, sl.used, c->stream); sl.used = 0; }
@@ -2013,6 +2030,9 @@ int tsba_create(void **ctx, int device) {
     if (hipSetDevice(device) != hipSuccess) return TSBA_ERR_DEVICE;
     Ctx *c = new Ctx(); c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TSBA_ERR_DEVICE; }
+    for (int l = 0; l < TSBA_MAX_LEVELS; l++) c->plan_done[l].store(0);
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) c->copy_stream = nullptr;     // (optional: staging then shares the compute stream)
+    for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (hipEventCreateWithFlags(&c->ev_stage[l], hipEventDisableTiming) != hipSuccess) c->ev_stage[l] = nullptr;
     hipDeviceProp_t prop;
     const bool ok = hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess
         && hipHostMalloc((void **)&c->st_host, sizeof(LmState)*TSBA_MAX_LEVELS, 0) == hipSuccess
@@ -2040,6 +2060,9 @@ int tsba_destroy(void *ctx) {
     if (c->comm && c->p_destroy) c->p_destroy(c->comm);
     hipHostFree(c->st_host); hipFree(c->st_log); if (c->hprog) hipHostFree(c->hprog);
     if (c->lbl_dev) hipFree(c->lbl_dev); if (c->lbl_host) hipHostFree(c->lbl_host);
+    if (c->ic.dev) hipFree(c->ic.dev); if (c->ic.stage) hipHostFree(c->ic.stage);
+    for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (c->ev_stage[l]) hipEventDestroy(c->ev_stage[l]);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
     delete c; return TSBA_OK;
 }
@@ -2108,7 +2131,11 @@ static int check_problem(Ctx *c, const tsba_problem *p, const tsba_options *o) {
     return 0;
 }
 
-int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
+static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, double *t_img);
+// lazy: the caller (a one-shot entry point) runs the solve right away and keeps *p alive until it returns -- on small windows only the first
+// pass's level is staged here, the others when their pass begins (tsba_solve), so that the coarse passes run on the device while the host
+// still builds and stages the plan of level 0 (the largest: ~1 ms of a 20-keyframe window's cold call)
+static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, bool lazy) {
     Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
     hipSetDevice(c->device);
     int rc = check_problem(c, p, o); if (rc) return rc;
@@ -2129,21 +2156,34 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     W.rank = c->rank; W.world = c->world;
     // the per-level plans are independent of each other and of the uploads below: one host thread per level builds them while this
     // thread stages the parameter / observation arrays (C4: 1.6 ms of plan construction in sequence -> the largest level, overlapped)
-    c->hplan.resize(p->n_levels); c->lev.resize(p->n_levels); c->lev_built.assign(p->n_levels, 0);
-    std::vector<std::thread> planners(p->n_levels);                 // planners[l]: the thread that builds level l's plan
-    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{planners};   // also on the error returns
+    c->hplan.resize(p->n_levels); c->lev.resize(p->n_levels); c->lev_built.assign(p->n_levels, 0); c->lev_planned.assign(p->n_levels, 0);
+    c->planners.clear(); c->planners.resize(p->n_levels);
+    std::vector<std::thread> &planners = c->planners;
+    struct Joiner { Ctx *c; bool armed; ~Joiner() { if (armed) join_planners(c); } } joiner{c, true};   // on the error returns
+    int n_lev_used = 0; { std::vector<char> sn(p->n_levels, 0); for (int q = 0; q < o->n_passes; q++) if (!sn[o->levels[q]]) { sn[o->levels[q]] = 1; n_lev_used++; } }
+    const bool small_window = solve_lds_doubles(W.N)*sizeof(double) <= 160*1024 - 64;
+    const bool defer = lazy && small_window && p->n_kf > 1 && n_lev_used > 1 && !is_multi(c);
+    for (int l = 0; l < TSBA_MAX_LEVELS; l++) { c->plan_done[l].store(0); c->lev_wait[l] = 0; }
     {   auto tp0 = std::chrono::steady_clock::now();
         std::vector<char> seen(p->n_levels, 0);
-        for (int ps = 0; ps < o->n_passes; ps++) { const int l = o->levels[ps]; if (seen[l]) continue; seen[l] = 1;
+        const int n_lev = n_lev_used;
+        const bool reorder = !c->dbg.no_kf_reorder;
+        // ring maps (one loop closure): a single-level, single-GPU solve through the partitioned solver with the cyclic-reduction separator tree
+        const int ring_max = (n_lev == 1 && !c->dbg.no_ring && !c->dbg.no_band_stream && c->dbg.sep_solver != 1 && c->dbg.sep_solver != 3 && c->dbg.band_parts != 1) ? CR_SMAX/6 : 0;
+        // maps with long-range coupling (several loop closures, points seen again much later): band + blocks outside it, preconditioned conjugate gradients
+        const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream && (!c->dbg.no_ring || c->dbg.far_solver == 2)) ? CR_SMAX/6 : 0;     // (no_ring asks for the reordering path)
+        const bool far_force = c->dbg.far_solver == 2;
+        for (int ps = o->n_passes - 1; ps >= 0; ps--) { const int l = o->levels[ps]; if (seen[l]) continue;
+            bool later = false; for (int q = 0; q < ps; q++) later |= o->levels[q] == l;       // (a level used by an earlier pass is started with that pass)
+            if (later) continue;
+            seen[l] = 1;
             HostPlan *H = &c->hplan[l];
-            const bool reorder = !c->dbg.no_kf_reorder;
-            // ring maps (one loop closure): a single-level, single-GPU solve through the partitioned solver with the cyclic-reduction separator tree
-            int n_lev = 0; { std::vector<char> sn(p->n_levels, 0); for (int q = 0; q < o->n_passes; q++) if (!sn[o->levels[q]]) { sn[o->levels[q]] = 1; n_lev++; } }
-            const int ring_max = (n_lev == 1 && !c->dbg.no_ring && !c->dbg.no_band_stream && c->dbg.sep_solver != 1 && c->dbg.sep_solver != 3 && c->dbg.band_parts != 1) ? CR_SMAX/6 : 0;
-            // maps with long-range coupling (several loop closures, points seen again much later): band + blocks outside it, preconditioned conjugate gradients
-            const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream && (!c->dbg.no_ring || c->dbg.far_solver == 2)) ? CR_SMAX/6 : 0;     // (no_ring asks for the reordering path)
-            const bool far_force = c->dbg.far_solver == 2;
-            planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max, far_max, far_force]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force); }); }
+            c->lev_planned[l] = 1;
+            std::atomic<int> *done = &c->plan_done[l];
+            // the levels of the later passes first (the largest plans); a deferring call builds the first pass's (small) plan on this thread:
+            // it is needed at once, and a thread's start costs as much as that plan
+            if (defer && ps == 0) { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force); done->store(1); continue; }
+            planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max, far_max, far_force, done]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force); done->store(1, std::memory_order_release); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
 #define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
@@ -2168,55 +2208,63 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     AL(W.musig, 2*(size_t)p->n_tobs);
     AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
     AL(W.fidx, p->n_kf); AL(W.nfree, 2); AL(W.dbg, 64); AL(W.LDbuf, 32*((size_t)p->n_kf + BAND_BW_MAX/6 + 1));     // (+ the ghost blocks of a ring map)
-    // ---- per-level plans
-    size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1;
-    for (int ps = 0; ps < o->n_passes; ps++) {
-        int l = o->levels[ps]; if (c->lev_built[l]) continue; c->lev_built[l] = 1;
-        {   auto tp0 = std::chrono::steady_clock::now();            // in pass order: the coarse levels are ready first and are staged while level 0 is still being built
-            if (planners[l].joinable()) planners[l].join();
-            t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); }
-        HostPlan &H = c->hplan[l];
-        LevelDev &D = c->lev[l]; memset(&D, 0, sizeof(D));
-        D.level = l; D.n_sc = H.n_sc(); D.n_pair = H.n_pair(); D.n_tg = H.n_tg(); D.n_pslot = H.n_pslot(); D.n_tslot = H.n_tslot(); D.n_sb = H.n_sb(); D.bw_rows = 6*H.bw_pose;
-        double sc = 1.0; for (int k = 0; k < l; k++) sc *= 0.5;
-        for (int k = 0; k < 4; k++) { double v = p->K[k]; for (int q = 0; q < l; q++) v *= 0.5; D.K[k] = v; }
-        (void)sc;
-        D.img_w = p->img_w[l]; D.img_h = p->img_h[l];
-#define UV(field) do { rc = dev_upload_vec(c, &D.field, H.field); if (rc) return rc; } while (0)
-        UV(sc_obs); UV(sc_kf); UV(sc_pt); UV(sc_flag); UV(sc_slot); UV(sc_uv);
-        UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pt_pair4); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
-        UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
-        UV(pf_g); UV(pf_f); D.n_pf = (int)H.pf_g.size();
-        if (!H.kf_order.empty()) UV(kf_order); else D.kf_order = nullptr;
-        D.far_B = H.far_B; D.n_far = H.n_far();
-        D.sb_far = nullptr;
-        if (H.far_B > 0) { UV(far_a); UV(far_b); UV(far_off); UV(far_ent); UV(fb_id); UV(fb_pab); UV(fb_pba); UV(fb_pt_off); UV(fb_pt_s1); UV(fb_pt_s2); UV(fb_pt_lm);
-            UV(fb_tx_off); UV(fb_tx_s1); UV(fb_tx_s2); UV(fb_tx_lm); }
-        UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
-        UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
-        UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ps_lm); UV(pose_ts_off); UV(pose_ts); UV(pose_ts_lm);
-        if (p->n_text > 0 && p->tfeat_off[l]) {
-            D.n_tfeat = p->n_tfeat[l];
-            UP(D.tfeat_off, p->tfeat_off[l], (size_t)p->n_text + 1); UP(D.tfeat_raw, p->tfeat_raw[l], p->n_tfeat[l]);
-            UP(D.tfeat_uv, p->tfeat_uv[l], 2*(size_t)p->n_tfeat[l]); UP(D.tfeat_ref, p->tfeat_ref[l], 8*(size_t)p->n_tfeat[l]);
-        } else { std::vector<int32_t> z((size_t)p->n_text + 1, 0); UP(D.tfeat_off, z.data(), z.size()); }
-        auto ti0 = std::chrono::steady_clock::now();
-        if (o->use_text && p->n_tobs > 0 && p->img[l]) {
-            std::vector<const uint8_t *> ptrs(p->n_kf, nullptr);
-            size_t npx = (size_t)p->img_w[l]*p->img_h[l];
-            for (int k = 0; k < p->n_kf; k++) {                 // through the pinned staging mirror: one copy for the whole level
-                if (!p->img[l][k]) { set_err(c, "null image pointer"); return TSBA_ERR_ARG; }
-                if (o->img_on_device) { ptrs[k] = p->img[l][k]; continue; }   // resident pyramid plane (tsframe_level_ptr): used in place
-                rc = dev_upload(c, &ptrs[k], p->img[l][k], npx); if (rc) return rc;
+    // ---- plane cache (tsba_problem.kf_id): the keyframes of this call get their slots; the planes of those not seen before are staged and copied
+    std::vector<int> &ic_slot = c->ic_slot; ic_slot.clear();
+    bool &use_img_cache = c->use_img_cache; use_img_cache = false;
+    if (p->kf_id && !o->img_on_device && o->use_text && p->n_tobs > 0 && p->n_kf <= TSBA_IMG_CACHE_KF) {
+        Ctx::ImgCache &IC = c->ic;
+        unsigned mask = 0; size_t off = 0, lo[TSBA_MAX_LEVELS] = {0,0,0,0}; bool same = IC.dev != nullptr;
+        { std::vector<char> seen(p->n_levels, 0);
+          for (int ps = 0; ps < o->n_passes; ps++) { const int l = o->levels[ps]; if (seen[l] || !p->img[l]) continue; seen[l] = 1; mask |= 1u << l; }
+          for (int l = 0; l < p->n_levels; l++) if (mask >> l & 1) { lo[l] = off; off += ((size_t)p->img_w[l]*p->img_h[l] + 255) & ~(size_t)255;
+              same = same && IC.w[l] == p->img_w[l] && IC.h[l] == p->img_h[l]; } }
+        same = same && IC.lvl_mask == mask && IC.slot == off;
+        if (mask && off) {
+            if (!same) {                                     // new geometry (or first use): an empty cache of TSBA_IMG_CACHE_KF slots
+                hipStreamSynchronize(c->stream);
+                if (IC.dev) { hipFree(IC.dev); IC.dev = nullptr; }
+                if (hipMalloc((void **)&IC.dev, off*TSBA_IMG_CACHE_KF) != hipSuccess) { IC.dev = nullptr; set_err(c, "hipMalloc (plane cache)"); return TSBA_ERR_DEVICE; }
+                IC.slot = off; IC.lvl_mask = mask;
+                for (int l = 0; l < TSBA_MAX_LEVELS; l++) { IC.lvl_off[l] = lo[l]; IC.w[l] = l < p->n_levels ? p->img_w[l] : 0; IC.h[l] = l < p->n_levels ? p->img_h[l] : 0; }
+                for (int q = 0; q < TSBA_IMG_CACHE_KF; q++) { IC.id[q] = 0; IC.used[q] = 0; IC.full[q] = false; }
             }
-            const uint8_t *const *dptr = nullptr;
-            rc = dev_upload(c, &dptr, (const uint8_t *const *)ptrs.data(), ptrs.size()); if (rc) return rc;
-            D.img = (const uint8_t *const *)dptr;
+            IC.tick++;
+            ic_slot.assign((size_t)p->n_kf, -1);
+            std::vector<int> miss;
+            for (int k = 0; k < p->n_kf; k++) { for (int q = 0; q < TSBA_IMG_CACHE_KF; q++) if (IC.full[q] && IC.id[q] == p->kf_id[k]) { ic_slot[(size_t)k] = q; IC.used[q] = IC.tick; break; }
+                if (ic_slot[(size_t)k] < 0) miss.push_back(k); }
+            for (int k : miss) { int best = -1;              // least recently used slot that this call does not use
+                for (int q = 0; q < TSBA_IMG_CACHE_KF; q++) if (IC.used[q] != IC.tick && (best < 0 || !IC.full[q] || (IC.full[best] && IC.used[q] < IC.used[best]))) { best = q; if (!IC.full[q]) break; }
+                IC.id[best] = p->kf_id[k]; IC.full[best] = true; IC.used[best] = IC.tick; ic_slot[(size_t)k] = best; }
+            IC.hits += p->n_kf - (long long)miss.size(); IC.misses += (long long)miss.size();
+            if (!miss.empty()) {
+                const size_t need = miss.size()*off;
+                if (IC.stage_cap < need) { if (IC.stage) hipHostFree(IC.stage); IC.stage = nullptr; IC.stage_cap = 0;
+                    if (hipHostMalloc((void **)&IC.stage, need, hipHostMallocDefault) != hipSuccess) { set_err(c, "hipHostMalloc (plane cache staging)"); return TSBA_ERR_DEVICE; }
+                    IC.stage_cap = need; }
+                for (size_t m = 0; m < miss.size(); m++) { const int k = miss[m];
+                    for (int l = 0; l < p->n_levels; l++) if (mask >> l & 1) { if (!p->img[l][k]) { set_err(c, "null image pointer"); return TSBA_ERR_ARG; }
+                        memcpy(IC.stage + m*off + lo[l], p->img[l][k], (size_t)p->img_w[l]*p->img_h[l]); }
+                    hipMemcpyAsync(IC.dev + (size_t)ic_slot[(size_t)k]*off, IC.stage + m*off, off, hipMemcpyHostToDevice, c->stream); }
+            }
+            use_img_cache = true;
         }
-        t_img += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
-        mx_pair = std::max(mx_pair, (size_t)D.n_pair); mx_tg = std::max(mx_tg, (size_t)D.n_tg);
-        mx_pslot = std::max(mx_pslot, (size_t)D.n_pslot); mx_tslot = std::max(mx_tslot, (size_t)D.n_tslot);
     }
+    // ---- per-level plans
+    size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1, mx_cnt = 1;
+    for (int ps = 0; ps < o->n_passes; ps++) {
+        const int l = o->levels[ps]; if (c->lev_built[l]) continue;
+        if (defer && ps > 0) {                     // staged when its pass begins: buffers by what the level can hold at most
+            const size_t nsc = (size_t)p->n_sobs[l], ntg = (size_t)p->n_tobs;
+            mx_pair = std::max(mx_pair, std::min((size_t)p->n_kf*((size_t)p->n_kf + 1), nsc + ntg)); mx_tg = std::max(mx_tg, ntg);
+            mx_pslot = std::max(mx_pslot, nsc + (size_t)p->n_pt); mx_tslot = std::max(mx_tslot, ntg + (size_t)p->n_text); mx_cnt = std::max(mx_cnt, nsc + ntg);
+            continue; }
+        rc = stage_level(c, p, l, &t_plan, &t_img); if (rc) return rc;
+        const LevelDev &D = c->lev[l];
+        mx_pair = std::max(mx_pair, (size_t)D.n_pair); mx_tg = std::max(mx_tg, (size_t)D.n_tg);
+        mx_pslot = std::max(mx_pslot, (size_t)D.n_pslot); mx_tslot = std::max(mx_tslot, (size_t)D.n_tslot); mx_cnt = std::max(mx_cnt, (size_t)D.n_sc + D.n_tg);
+    }
+    c->stage_p = defer ? p : nullptr;
     c->nb_back_max = (p->n_pt + 255)/256 + (p->n_text + 255)/256 + (p->n_kf + 255)/256;
     {   bool po = p->n_kf == 1;
         for (int j = 0; po && j < p->n_pt; j++) po = p->pt_host[j] < 0;
@@ -2332,7 +2380,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
     AL(W.posepart, 2*((size_t)p->n_kf/21 + 2));
-    { size_t mxn = 1; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) mxn = std::max(mxn, (size_t)c->lev[l].n_sc + c->lev[l].n_tg); AL(W.cntpart, 2*(mxn/4 + mxn/256 + 4)); }
+    AL(W.cntpart, 2*(mx_cnt/4 + mx_cnt/256 + 4));
     AL(W.st, 1);
     AL(c->cov_log, 6*TSBA_MAX_LEVELS);
     flush_run(c);
@@ -2341,6 +2389,71 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) {
     if (tdbg) { auto tu3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[tsba_upload] free %.2f ms, host total %.2f ms (waiting for the plan threads %.2f ms, image section %.2f ms), final sync %.2f ms\n", ms(tu0, tu1), ms(tu1, tu2), t_plan, t_img, ms(tu2, tu3)); }
     c->uploaded = true;
+    joiner.armed = false;                          // (deferred levels: their plan threads are joined by stage_level / free_problem)
+    if (!c->stage_p) join_planners(c);
+    return TSBA_OK;
+}
+int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) { return upload_impl(ctx, p, o, false); }
+
+// One pyramid level onto the device: the plan's lists (its host thread is joined here), the level's reference features, the table of image planes.
+static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, double *t_img) {
+    const tsba_options *o = &c->opt; int rc;
+    {   auto tp0 = std::chrono::steady_clock::now();            // in pass order: the coarse levels are ready first and are staged while level 0 is still being built
+        if (l < (int)c->planners.size() && c->planners[l].joinable()) c->planners[l].join();
+        if (t_plan) *t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); }
+    HostPlan &H = c->hplan[l];
+    LevelDev &D = c->lev[l]; memset(&D, 0, sizeof(D));
+    D.level = l; D.n_sc = H.n_sc(); D.n_pair = H.n_pair(); D.n_tg = H.n_tg(); D.n_pslot = H.n_pslot(); D.n_tslot = H.n_tslot(); D.n_sb = H.n_sb(); D.bw_rows = 6*H.bw_pose;
+    for (int k = 0; k < 4; k++) { double v = p->K[k]; for (int q = 0; q < l; q++) v *= 0.5; D.K[k] = v; }
+    D.img_w = p->img_w[l]; D.img_h = p->img_h[l];
+#define UV(field) do { rc = dev_upload_vec(c, &D.field, H.field); if (rc) return rc; } while (0)
+    UV(sc_obs); UV(sc_kf); UV(sc_pt); UV(sc_flag); UV(sc_slot); UV(sc_uv);
+    UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pt_pair4); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
+    UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
+    UV(pf_g); UV(pf_f); D.n_pf = (int)H.pf_g.size();
+    if (!H.kf_order.empty()) UV(kf_order); else D.kf_order = nullptr;
+    D.far_B = H.far_B; D.n_far = H.n_far();
+    D.sb_far = nullptr;
+    if (H.far_B > 0) { UV(far_a); UV(far_b); UV(far_off); UV(far_ent); UV(fb_id); UV(fb_pab); UV(fb_pba); UV(fb_pt_off); UV(fb_pt_s1); UV(fb_pt_s2); UV(fb_pt_lm);
+        UV(fb_tx_off); UV(fb_tx_s1); UV(fb_tx_s2); UV(fb_tx_lm); }
+    UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
+    UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
+    UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ps_lm); UV(pose_ts_off); UV(pose_ts); UV(pose_ts_lm);
+#undef UV
+    if (p->n_text > 0 && p->tfeat_off[l]) {
+        D.n_tfeat = p->n_tfeat[l];
+        UP(D.tfeat_off, p->tfeat_off[l], (size_t)p->n_text + 1); UP(D.tfeat_raw, p->tfeat_raw[l], p->n_tfeat[l]);
+        UP(D.tfeat_uv, p->tfeat_uv[l], 2*(size_t)p->n_tfeat[l]); UP(D.tfeat_ref, p->tfeat_ref[l], 8*(size_t)p->n_tfeat[l]);
+    } else { std::vector<int32_t> z((size_t)p->n_text + 1, 0); UP(D.tfeat_off, z.data(), z.size()); }
+    auto ti0 = std::chrono::steady_clock::now();
+    if (o->use_text && p->n_tobs > 0 && p->img[l]) {
+        std::vector<const uint8_t *> ptrs(p->n_kf, nullptr);
+        size_t npx = (size_t)p->img_w[l]*p->img_h[l];
+        const bool cached = c->use_img_cache;
+        for (int k = 0; k < p->n_kf; k++) {                 // through the pinned staging mirror: one copy for the whole level
+            if (!p->img[l][k]) { set_err(c, "null image pointer"); return TSBA_ERR_ARG; }
+            if (o->img_on_device) { ptrs[k] = p->img[l][k]; continue; }   // resident pyramid plane (tsframe_level_ptr): used in place
+            if (cached) { ptrs[k] = c->ic.dev + (size_t)c->ic_slot[(size_t)k]*c->ic.slot + c->ic.lvl_off[l]; continue; }   // the keyframe's slot of the plane cache (filled by the upload)
+            rc = dev_upload(c, &ptrs[k], p->img[l][k], npx); if (rc) return rc;
+        }
+        const uint8_t *const *dptr = nullptr;
+        rc = dev_upload(c, &dptr, (const uint8_t *const *)ptrs.data(), ptrs.size()); if (rc) return rc;
+        D.img = (const uint8_t *const *)dptr;
+    }
+    if (t_img) *t_img += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
+    flush_run(c);
+    if (c->stage_async && c->copy_stream && c->ev_stage[l]) { hipEventRecord(c->ev_stage[l], c->copy_stream); c->lev_wait[l] = 1; }      // the level's pass waits for this copy
+    c->lev_built[l] = 1;
+    return TSBA_OK;
+}
+// during a solve: levels of later passes whose plans are complete go to the device now, over the copy stream, next to the running pass
+static int stage_ahead(Ctx *c, int ps) {
+    if (!c->stage_p) return TSBA_OK;
+    for (int q = ps + 1; q < c->opt.n_passes; q++) { const int l = c->opt.levels[q];
+        if (c->lev_built[l] || !c->lev_planned[l]) continue;
+        if (!c->plan_done[l].load(std::memory_order_acquire)) break;           // in pass order
+        c->stage_async = true; const int rc = stage_level(c, c->stage_p, l, nullptr, nullptr); c->stage_async = false;
+        if (rc) return rc; }
     return TSBA_OK;
 }
 
@@ -2678,6 +2791,10 @@ int tsba_solve(void *ctx, tsba_report *r) {
     int rc = reset_state(c); if (rc) return rc;
     if (c->far_B > 0) hipMemsetAsync(c->W.pc_stat, 0, 4*sizeof(int), c->stream);
     for (int ps = 0; ps < o.n_passes; ps++) {
+        if (!c->lev_built[o.levels[ps]]) {            // a level the upload left for now (one-shot call on a small window): its plan is ready or nearly so
+            if (!c->stage_p) { set_err(c, "level not staged"); return TSBA_ERR_STATE; }
+            c->stage_async = true; rc = stage_level(c, c->stage_p, o.levels[ps], nullptr, nullptr); c->stage_async = false; if (rc) return rc; }
+        if (c->lev_wait[o.levels[ps]]) { hipStreamWaitEvent(c->stream, c->ev_stage[o.levels[ps]], 0); c->lev_wait[o.levels[ps]] = 0; }
         const LevelDev &D = c->lev[o.levels[ps]];
         const bool pose_path = c->pose_only && !is_multi(c);
         if (pose_path) {                                     // k_pass_reset + k_participation + k_gauge + k_musigma in one launch
@@ -2717,6 +2834,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
         for (int it = 0; it < o.its[ps]; it++) {
             if (converged(it)) break;
             launch_step(c, D);
+            if (it >= 1) { rc = stage_ahead(c, ps); if (rc) return rc; }      // (with two iterations queued the device does not run dry while the host stages)
         }
         if (o.outlier_scene || o.outlier_text)
             if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
@@ -2772,9 +2890,12 @@ int tsba_download(void *ctx, tsba_problem *p) {
 
 static int one_shot(void *ctx, tsba_problem *p, const tsba_options *o, tsba_report *r) {
     auto t0 = std::chrono::steady_clock::now();
-    int rc = tsba_upload(ctx, p, o); if (rc) return rc;
+    int rc = upload_impl(ctx, p, o, true); if (rc) return rc;
     auto t1 = std::chrono::steady_clock::now();
-    rc = tsba_solve(ctx, r); if (rc) return rc;
+    rc = tsba_solve(ctx, r);
+    { Ctx *c = (Ctx *)ctx; join_planners(c); c->stage_p = nullptr;      // (*p is the caller's: nothing may be staged from it after this call)
+      for (int l = 0; l < (int)c->lev_planned.size(); l++) if (c->lev_planned[l] && !c->lev_built[l]) c->uploaded = false; }   // a failed solve left a level unstaged: upload again before anything else
+    if (rc) return rc;
     auto t2 = std::chrono::steady_clock::now();
     rc = tsba_download(ctx, p); if (rc) return rc;
     auto t3 = std::chrono::steady_clock::now();
@@ -3036,6 +3157,11 @@ int tsba_debug_far_blocks(void *ctx, int32_t *a, int32_t *b, double *blocks) {
     if (b) memcpy(b, H.far_b.data(), sizeof(int32_t)*H.far_b.size());
     if (blocks && D.n_far > 0) CK(hipMemcpy(blocks, c->W.Sfar, sizeof(double)*36*(size_t)D.n_far, hipMemcpyDeviceToHost));
     return TSBA_OK;
+}
+// plane cache of the context (tsba_problem.kf_id): keyframes found on the device / copied, over the context's lifetime
+int tsba_debug_img_cache_stats(void *ctx, int64_t out[2]) {
+    Ctx *c = (Ctx *)ctx; if (!c || !out) return TSBA_ERR_ARG;
+    out[0] = c->ic.hits; out[1] = c->ic.misses; return TSBA_OK;
 }
 // row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating); with a
 // plan order (reverse Cuthill-McKee, tsba_plan.h) this is not monotone in the keyframe index

@@ -46,6 +46,7 @@ def load_library():
     L.tsba_debug_reduced_band.argtypes = [vp, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, dp]
     L.tsba_debug_solver_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
     L.tsba_debug_pcg_stats.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.tsba_debug_img_cache_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.tsba_debug_far_blocks.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
     L.tsba_debug_row_of_kf.argtypes = [vp, C.POINTER(C.c_int32)]
     L.tsba_debug_time_solve.argtypes = [vp, C.c_int, dp]
@@ -228,6 +229,12 @@ class Optimizer:
         ip = C.POINTER(C.c_int32)
         self._check(self.lib.tsba_debug_far_blocks(self.ctx, a.ctypes.data_as(ip), b.ctypes.data_as(ip), _dp(v)), "tsba_debug_far_blocks")
         return a, b, v
+
+    def img_cache_stats(self):
+        """Plane cache (tsba_problem.kf_id): (keyframes found on the device, keyframes copied) over the context's lifetime."""
+        v = (C.c_int64 * 2)()
+        self._check(self.lib.tsba_debug_img_cache_stats(self.ctx, v), "tsba_debug_img_cache_stats")
+        return int(v[0]), int(v[1])
 
     def pcg_stats(self):
         """Maps with long-range coupling: conjugate-gradient statistics of the last solve (tsba_debug_pcg_stats)."""

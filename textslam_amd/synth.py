@@ -596,3 +596,56 @@ def pose_graph(seed=SEED, n_kf=40, window=3, loop_at=2, scale_drift=1.06):
             # KF = the last keyframe, LoopKF = keyframe loop_at
             "est": np.array(est), "conn_idx": np.array(cur_group, np.int32), "conn_sim": np.array([corr[c] for c in cur_group]),
             "n_loop_edges": n_loop, "kf_cur": n_kf - 1, "kf_loop": loop_at}
+
+
+def _q_to_R(q):
+    w, x, y, z = q/np.linalg.norm(q)
+    return np.array([[1 - 2*(y*y + z*z), 2*(x*y - w*z), 2*(x*z + w*y)],
+                     [2*(x*y + w*z), 1 - 2*(x*x + z*z), 2*(y*z - w*x)],
+                     [2*(x*z - w*y), 2*(y*z + w*x), 1 - 2*(x*x + y*y)]])
+
+
+def window_of(Q, k0, n, kf_ids=None):
+    """The sliding window [k0, k0 + n) of a longer sequence Q (tracking.cc:828-842: LocalBundleAdjustment on the last 20 keyframes, once per new
+    keyframe): the window's keyframes with their observations; a landmark hosted in a keyframe outside the window is frozen in that host (its
+    pose taken from Q, as optimizer.cc:219-262 does); landmark indices stay those of Q.  kf_ids: identities of Q's keyframes (the plane cache
+    of the context, tsba_problem.kf_id)."""
+    Q.normalise()
+    W_ = Q.copy()
+    pose = Q.pose.reshape(-1, 7)
+    W_.pose = pose[k0:k0 + n].copy()
+    W_.kf_initial = Q.kf_initial[k0:k0 + n].copy()
+    inside = lambda h: (h >= k0) & (h < k0 + n)
+    # scene points
+    ph = Q.pt_host.astype(np.int64)
+    Trw = Q.pt_host_Trw.reshape(-1, 12).copy()
+    for j in np.nonzero((ph >= 0) & ~inside(ph))[0]:
+        R = _q_to_R(pose[ph[j], :4]); Trw[j] = np.concatenate([R, pose[ph[j], 4:7, None]], 1).reshape(-1)
+    W_.pt_host = np.where(inside(ph), ph - k0, -1).astype(np.int32)
+    W_.pt_host_Trw = Trw
+    kf0 = Q.sobs_kf[0]
+    f_lo, f_hi = int(np.searchsorted(kf0, k0, "left")), int(np.searchsorted(kf0, k0 + n, "left"))
+    assert np.array_equal(Q.sobs_flag[0], np.arange(Q.sgood.size)) and np.all(np.diff(kf0) >= 0)
+    W_.sgood = Q.sgood[f_lo:f_hi].copy()
+    for l in range(Q.n_levels):
+        m = inside(Q.sobs_kf[l].astype(np.int64))
+        W_.sobs_kf[l] = (Q.sobs_kf[l][m] - k0).astype(np.int32); W_.sobs_pt[l] = Q.sobs_pt[l][m].copy()
+        W_.sobs_flag[l] = (Q.sobs_flag[l][m] - f_lo).astype(np.int32); W_.sobs_uv0[l] = Q.sobs_uv0[l].reshape(-1, 2)[m].copy()
+        if Q.img[l] is not None:
+            W_.img[l] = Q.img[l][k0:k0 + n].copy()
+    # text planes
+    th = Q.text_host.astype(np.int64)
+    Twr = Q.text_host_Twr.reshape(-1, 12).copy()
+    for j in np.nonzero((th >= 0) & ~inside(th))[0]:
+        R = _q_to_R(pose[th[j], :4]); t = pose[th[j], 4:7]; Twr[j] = np.concatenate([R.T, (-R.T @ t)[:, None]], 1).reshape(-1)
+    W_.text_host = np.where(inside(th), th - k0, -1).astype(np.int32)
+    W_.text_host_Twr = Twr
+    m = inside(Q.tobs_kf.astype(np.int64))
+    W_.tobs_kf = (Q.tobs_kf[m] - k0).astype(np.int32); W_.tobs_text = Q.tobs_text[m].copy(); W_.tobs_good = Q.tobs_good[m].copy()
+    off = Q.tobs_fgood_off
+    keep = np.nonzero(m)[0]
+    W_.tobs_fgood_off = np.concatenate([[0], np.cumsum(off[keep + 1] - off[keep])]).astype(np.int32)
+    W_.tfgood = np.concatenate([Q.tfgood[off[t]:off[t + 1]] for t in keep]) if keep.size else np.zeros(0, np.uint8)
+    W_.kf_id = None if kf_ids is None else np.asarray(kf_ids, np.int64)[k0:k0 + n].copy()
+    W_.truth = {}
+    return W_.normalise()
