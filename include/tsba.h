@@ -246,6 +246,9 @@ int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
 /* Maps with long-range coupling: the conjugate-gradient solves of the last tsba_solve.  out[0] iterations in total, [1] reduced systems
  * solved (LM trials), [2] most iterations of one system, [3] systems that hit the iteration cap. */
 int  tsba_debug_pcg_stats(void *ctx, int32_t out[4]);
+/* Test hook: M X = R for T right-hand sides with the band factor of the last solve / tsba_debug_reduced_system (the solve phase that the
+ * iterative and low-rank solvers of maps with long-range coupling run on).  R, X: [6 x free poses][T], row-major. */
+int  tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X);
 /* Plane cache of the context (tsba_problem.kf_id): out[0] keyframes whose planes were found on the device, out[1] keyframes copied. */
 int  tsba_debug_img_cache_stats(void *ctx, int64_t out[2]);
 /* The 6x6 blocks of the reduced system outside the band (solver_info [18] of them) as left by tsba_debug_reduced_system / the last solve:
@@ -276,7 +279,8 @@ typedef struct tsba_debug_options {
     int32_t far_solver;        // maps with long-range coupling (band + blocks outside it, conjugate gradients preconditioned with the band solver): 0 by the plan's rule (when no keyframe order brings the envelope within the band solvers' reach), 1 never (reordering / wide-band Cholesky as before), 2 whenever the map is eligible
     int32_t pcg_max_it;        // > 0: iteration cap of the conjugate gradients (default 200)
     int32_t pcg_tol_exp;       // > 0: relative tolerance 10^-pcg_tol_exp of the conjugate gradients in the M^-1 norm (default 10)
-    int32_t reserved[4];
+    int32_t pcg_refactor;      // how the single-vector conjugate gradients apply the preconditioner: 0 / 1 by running the band factorisation again with the residual as right-hand side, 2 by the solve phase of tsba_bandms.h (one column of its 64: slower for one vector; A/B runs)
+    int32_t reserved[3];
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

@@ -85,6 +85,23 @@ def test_same_trajectory_as_the_direct_solvers(gpu, n_kf, far, closures):
         gpu.debug_set()
 
 
+def test_conjugate_gradients_on_the_solve_phase(gpu):
+    """The same conjugate gradients with the preconditioner applied by the solve phase (tsba_bandms.h) instead of a re-run of the factorisation:
+    same iteration counts, same LM trajectory."""
+    P = synth.config_global(n_kf=900, n_pt=18000, band=8, far_frac=0.01, closures=2)
+    o = abi.options_global(); o.its[0] = 5
+    try:
+        gpu.debug_set(far_solver=2, band_parts=16, sep_solver=2)
+        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o); st1 = gpu.pcg_stats()
+        assert gpu.solver_info()["far_band_blocks"] == 8 and gpu.solver_info()["sep_cr"] == 1
+        gpu.debug_set(far_solver=2, band_parts=16, sep_solver=2, pcg_refactor=2)
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o); st2 = gpu.pcg_stats()
+        _same_trajectory(rep1, rep2, G1, G2, atol=1e-8)
+        assert st1["hit_cap"] == 0 and st2["hit_cap"] == 0 and abs(st1["iterations"] - st2["iterations"]) <= st1["systems"], (st1, st2)
+    finally:
+        gpu.debug_set()
+
+
 def test_parity_with_the_oracle(gpu, oracle_lib):
     """130 keyframes, 3 % long-range points, against the CPU oracle (which knows nothing of the split)."""
     P = synth.config_global(n_kf=130, n_pt=4000, band=8, far_frac=0.03)
@@ -141,3 +158,29 @@ def test_c6_with_long_range_observations_full_size(gpu):
     np.testing.assert_allclose(np.linalg.norm(G.pose[:, :4], axis=1), 1.0, atol=1e-12)
     rep2 = gpu.solve(); G2 = gpu.download(P.copy())
     assert rep2["iters"] == rep["iters"] and np.array_equal(G.pose, G2.pose) and np.array_equal(G.rho, G2.rho)
+
+
+@pytest.mark.parametrize("n_kf,band,parts,T", [(900, 9, 17, 1), (900, 9, 17, 70), (1100, 12, 11, 5), (1500, 10, 27, 64), (600, 6, 8, 130), (1300, 7, 40, 3)])
+def test_multi_right_hand_side_solve_phase(gpu, n_kf, band, parts, T):
+    """The solve phase of the partitioned band solver on other right-hand sides (csrc/tsba_bandms.h: what the conjugate gradients apply as
+    preconditioner): M X = R for T random columns with the factor of the first linearisation, against scipy's banded Cholesky on the
+    downloaded band.  Open chains, separators of 6 .. 12 pose blocks, 7 .. 39 of them."""
+    from scipy.linalg import solveh_banded
+    P = synth.config_global(n_kf=n_kf, n_pt=40*n_kf, band=band)
+    o = abi.options_global()
+    try:
+        gpu.debug_set(band_parts=parts, sep_solver=2)
+        gpu.upload(P, o)
+        info = gpu.solver_info()
+        assert info["band_stream"] == 1 and info["interiors"] == parts and info["sep_cr"] == 1 and info["far_band_blocks"] == 0, info
+        rb = gpu.reduced_band(o.initial_radius)
+        rng = np.random.default_rng(5)
+        R = rng.standard_normal((rb["n"], T))*np.abs(rb["g"]).max()
+        R[:, 0] = -rb["g"]                                          # column 0: the system the factorisation itself solved
+        X = gpu.multi_solve(R)
+        ref = solveh_banded(rb["ab"], R, lower=True)
+        err = np.abs(X - ref).max(axis=0)/np.abs(ref).max(axis=0)
+        assert err.max() <= 1e-8, err
+        assert np.abs(X[:, 0] - rb["dp_rows"]).max() <= 1e-9*np.abs(rb["dp_rows"]).max()
+    finally:
+        gpu.debug_set()

@@ -1478,6 +1478,7 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
 #include "tsba_bandp.h"
 #include "tsba_bandcr.h"
 #include "tsba_bandcre.h"
+#include "tsba_bandms.h"
 #include "tsba_pcg.h"
 #include "tsba_pose.h"
 
@@ -1909,6 +1910,7 @@ struct Ctx {
                       int w[TSBA_MAX_LEVELS] = {0,0,0,0}, h[TSBA_MAX_LEVELS] = {0,0,0,0}; unsigned lvl_mask = 0;
                       long long id[TSBA_IMG_CACHE_KF]; unsigned long long used[TSBA_IMG_CACHE_KF]; bool full[TSBA_IMG_CACHE_KF]; unsigned long long tick = 0;
                       long long hits = 0, misses = 0; } ic;
+    MsBuf ms{}; double *ms_alloc = nullptr; size_t ms_bytes = 0; int ms_cap = 0;      // multi-right-hand-side solve phase of the partitioned band solver (tsba_bandms.h)
     int cov_text = -1; double *cov_log = nullptr;     // tsba_theta_optim: V of this plane at the end of every pass [TSBA_MAX_LEVELS][6]
     int far_B = 0, n_far = 0, pcg_parts = 0; unsigned int pcg_seq = 0;      // band + long-range blocks (tsba_pcg.h): band of M in pose blocks, blocks outside it, partial sums per vector kernel
     int rank = 0, world = 1; bool force_multi = false;
@@ -2061,6 +2063,7 @@ int tsba_destroy(void *ctx) {
     hipHostFree(c->st_host); hipFree(c->st_log); if (c->hprog) hipHostFree(c->hprog);
     if (c->lbl_dev) hipFree(c->lbl_dev); if (c->lbl_host) hipHostFree(c->lbl_host);
     if (c->ic.dev) hipFree(c->ic.dev); if (c->ic.stage) hipHostFree(c->ic.stage);
+    if (c->ms_alloc) hipFree(c->ms_alloc);
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (c->ev_stage[l]) hipEventDestroy(c->ev_stage[l]);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
@@ -2612,6 +2615,7 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_cre_elim, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_sepf, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_ms_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -2712,6 +2716,39 @@ static void launch_solve(Ctx *c) {
     hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, W, bw);
 }
 
+// ---- solve phase of the partitioned band solver for T right-hand sides (tsba_bandms.h): needs the factor of the last launch_solve of this level
+static bool ms_available(const Ctx *c) { return c->band_stream && c->band_parts > 1 && c->sep_cr && !c->W.ring && c->dbg.sep_solver != 3; }
+static int ms_reserve(Ctx *c, int T) {           // buffers for T columns (kept until a larger request or another problem size)
+    const size_t n6 = (size_t)c->W.N, labels = (size_t)cr_mmax(0, c->band_parts, 0) + 1, sdim = (size_t)std::max(6, c->cur_bw_rows);
+    const size_t per = 4*n6 + 5*labels*sdim, need = per*(size_t)T*sizeof(double);
+    if (need > c->ms_bytes) { if (c->ms_alloc) { hipStreamSynchronize(c->stream); hipFree(c->ms_alloc); } c->ms_alloc = nullptr; c->ms_bytes = 0;
+        if (hipMalloc((void **)&c->ms_alloc, need) != hipSuccess) { set_err(c, "hipMalloc (multi-right-hand-side buffers)"); return TSBA_ERR_DEVICE; }
+        c->ms_bytes = need; }
+    double *q = c->ms_alloc; MsBuf &M = c->ms; M.T = T;
+    M.R = q; q += n6*T; M.Wm = q; q += n6*T; M.V = q; q += n6*T; M.X = q; q += n6*T;
+    M.G = q; q += labels*sdim*T; M.Z = q; q += labels*sdim*T; M.Xs = q; q += labels*sdim*T; M.Cg = q;
+    c->ms_cap = T;
+    return TSBA_OK;
+}
+static void launch_ms_solve(Ctx *c) {            // M.R -> M.X
+    Work &W = c->W; const MsBuf &M = c->ms;
+    const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6, ncg = (M.T + 63)/64;
+    Work &Ws = c->Wsep; Ws.st = W.st;
+    const size_t lds1 = (size_t)bwp*64*sizeof(double);
+    hipLaunchKernelGGL(k_ms_fwd_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
+    hipLaunchKernelGGL(k_ms_sep_rhs, dim3((P - 1)*B, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
+    const int mmax = cr_mmax(0, P, 0);
+    auto pivots = [&](int h, int &kb) { kb = 0; const int klast = (mmax - 1 - h)/(2*h); return mmax - 1 - h < 0 ? 0 : std::max(0, klast + 1); };
+    int htop = 0;
+    for (int h = 1; h < mmax; h <<= 1) { int kb; const int npiv = pivots(h, kb); if (npiv <= 0) continue;
+        hipLaunchKernelGGL(k_ms_cre_fwd, dim3(npiv, ncg), dim3(MS_CT), lds1, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); htop = h; }
+    hipLaunchKernelGGL(k_ms_cre_root, dim3(1, ncg), dim3(64), lds1, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, M);
+    for (int h = htop; h >= 1; h >>= 1) { int kb; const int npiv = pivots(h, kb);
+        if (npiv > 0) hipLaunchKernelGGL(k_ms_cre_back, dim3(npiv, ncg), dim3(MS_CT), 3*lds1, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); }
+    hipLaunchKernelGGL(k_ms_back_border, dim3(c->n_kf, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lb, M);
+    hipLaunchKernelGGL(k_ms_back_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
+}
+
 // The reduced system of one LM trial: a direct solve, or -- band + long-range blocks -- conjugate gradients preconditioned with the band
 // solver (tsba_pcg.h).  The host enqueues iteration k only once the device has reached iteration k - 2 (pinned progress word), so a solve
 // that converges wastes two iterations of empty launches; every rank of a sharded run iterates on its own copy of the summed system.
@@ -2733,13 +2770,20 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
             if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(5)) return false;      // never hang on it
         }
     };
+    // M^-1 on the residual: the solve phase of the partitioned band solver on the factor this trial's first solve left (tsba_bandms.h); where
+    // that is not available (a single interior, the sequential separator solve) the factorisation is run again with the residual as right-hand side
+    // (measured at 5000 keyframes, one column: 1.3 ms per application against 0.57 ms for the factorisation re-run -- the solve phase pays for 64
+    // columns whether it has them or not; it is the default only for the block variants.  pcg_refactor = 2 selects it for the single-vector iteration)
+    const bool ms = ms_available(c) && c->dbg.pcg_refactor == 2 && ms_reserve(c, std::max(1, c->ms_cap)) == TSBA_OK;
+    const double *zp = W.Sy; double zs = -1.0;
     int it = 0;
     for (; it < cap; it++) {
         if (finished(it)) break;
-        hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_T), 0, c->stream, W, D, it, seq, B, tol2, nbp);
-        hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp);
-        launch_solve(c);
-        hipLaunchKernelGGL(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W);
+        hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_T), 0, c->stream, W, D, it, seq, B, tol2, nbp, zp, zs);
+        if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, c->ms.R, 1.0);
+            const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
+        else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, W.g, -1.0); launch_solve(c); }
+        hipLaunchKernelGGL(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, zp, zs);
     }
     hipLaunchKernelGGL(k_pcg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
 }
@@ -3162,6 +3206,24 @@ int tsba_debug_far_blocks(void *ctx, int32_t *a, int32_t *b, double *blocks) {
 int tsba_debug_img_cache_stats(void *ctx, int64_t out[2]) {
     Ctx *c = (Ctx *)ctx; if (!c || !out) return TSBA_ERR_ARG;
     out[0] = c->ic.hits; out[1] = c->ic.misses; return TSBA_OK;
+}
+// Test hook of the multi-right-hand-side solve phase (tsba_bandms.h): M X = R with the band factor the last tsba_debug_reduced_system / solve left
+// behind.  R, X: [6 nfree][T] row-major (compressed free-pose rows).  TSBA_ERR_STATE unless the problem runs through the partitioned band
+// solver with the cyclic-reduction separator system on a chain.
+int tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X) {
+    Ctx *c = (Ctx *)ctx; if (!c || T < 1 || !R || !X) return TSBA_ERR_ARG;
+    if (!c->uploaded || !ms_available(c)) { if (c) set_err(c, "multi-right-hand-side solve: needs the partitioned band solver with cyclic reduction on a chain"); return TSBA_ERR_STATE; }
+    hipSetDevice(c->device);
+    int nfree = 0; CK(hipMemcpy(&nfree, c->W.nfree, sizeof(int), hipMemcpyDeviceToHost));
+    int rc = ms_reserve(c, T); if (rc) return rc;
+    { int rca = set_solver_attrs(c); if (rca) return rca; }
+    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
+    st.done = 0; st.step_fail = 0; st.lin_done = 0; CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->ms.R, R, sizeof(double)*6*(size_t)nfree*T, hipMemcpyHostToDevice));
+    launch_ms_solve(c);
+    CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
+    CK(hipMemcpy(X, c->ms.X, sizeof(double)*6*(size_t)nfree*T, hipMemcpyDeviceToHost));
+    return TSBA_OK;
 }
 // row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating); with a
 // plan order (reverse Cuthill-McKee, tsba_plan.h) this is not monotone in the keyframe index

@@ -266,6 +266,10 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
         double *Pk = A + (size_t)(s + 1)*sst;
         for (int e = tid; e < tri(s); e += CRE_T) { const int r = tri_row(e), q = e - tri(r); Pk[rowoff(r) + q] = A[r*sst + q]; }
         for (int k = tid; k < s; k += CRE_T) Pk[rowoff(s) + k] = A[n*sst + k];
+        {   // the root's factor too (packed rows | LD table): the multi-right-hand-side solve phase (tsba_bandms.h) applies it to other vectors
+            double *recr = fac + (size_t)r0*cre_rec_doubles(s);
+            for (int e = tid; e < tri(s); e += CRE_T) { const int r = tri_row(e), q = e - tri(r); recr[rowoff(r) + q] = A[r*sst + q]; }
+            for (int k = tid; k < SOLVE_LD*B; k += CRE_T) recr[rowoff(s) + k] = LD[k]; }
         __syncthreads();
         if (wave == 0) {
             solve_backsub_wave(Pk, LD, s, B, lane);

@@ -1,0 +1,334 @@
+// Solve phase of the partitioned band solver for MANY right-hand sides: M X = R with the factor k_bandp_factor / k_bandp_sepf / k_cre_elim
+// left behind (tsba_bandp.h, tsba_bandcre.h) -- no factorisation, no S.  The factorisation carries ONE right-hand side (it rides along as
+// the last row); the iterative and low-rank solvers on top of it (tsba_pcg.h) need M^-1 applied to other vectors: a residual per
+// conjugate-gradient iteration, a few hundred unit-like columns for the loop-closure correction.
+//
+// Layout: a right-hand side block is [rows][T] (T columns, row-major): a LANE owns a COLUMN.  Everything a step needs from the factor
+// (a 6x6 block, a row of the packed triangle, a diagonal table) is the same for all lanes -- scalar / broadcast loads -- and every lane
+// runs the same recurrence on its own column: 64 columns cost what one costs.  The chain through an interior is one wave per (interior,
+// 64 columns); the dense parts of a separator pivot are dealt to 8 waves by rows.
+//
+//   k_ms_fwd_int     interiors forward:   w_q = l_q^-1 (r_q - sum_j L(q, j) w_j),  v = D^-1 w
+//   k_ms_sep_rhs     separator right-hand sides:  g_s = r_s - [rows of s below the interior on its left] w - [border rows of the interior on its right] w
+//   k_ms_cre_fwd     cyclic-reduction level h, forward:  z_i = D^-1 L_i^-1 (g_i - pending),  updates X_a w, X_c w for the neighbours' g
+//   k_ms_cre_root    the last block: forward and backward
+//   k_ms_cre_back    level h, backward:   x_i = L_i^-T (z_i - X_a^T x_a - X_c^T x_c)
+//   k_ms_back_border interiors, the part of the back substitution that does not depend on the running solution:  v_q -= Lb_q^T x_left
+//   k_ms_back_int    interiors backward:  x_q = l_q^-T (v_q - sum_R L(R, q)^T x_R)
+// Chain partitions only (no ring / ghost rows), separator system by cyclic reduction (tsba_bandcre.h).
+#pragma once
+
+#define MS_BMAX 13                          // widest separator in pose blocks (CR_SMAX / 6)
+#define MS_CT 512                           // workgroup of the separator kernels: 8 waves
+
+struct MsBuf {                              // device buffers of one multi-right-hand-side solve (sized for T_cap columns)
+    double *R, *Wm, *V, *X;                 // [6 nfree][T]: right-hand sides, w = L^-1 r (interior rows), v = D^-1 w, solution
+    double *G, *Z, *Xs, *Cg;                // [labels][s][T]: separator right-hand sides, z, solution; [labels][2][s][T] pending updates (for a | for c)
+    int T;                                  // columns (row stride)
+};
+
+__device__ __forceinline__ int ms_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- interiors, forward.  grid (Pmax, column groups), one wave.
+__global__ __launch_bounds__(64) void k_ms_fwd_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, MsBuf M) {
+    __shared__ double hist[MS_BMAX*6*64];
+    const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+    { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
+    const int B = bw/6, nf = ms_uni(*W.nfree);
+    if (nf <= 0) return;
+    const BandpPart PT = bandp_part(nf, B, Pmax, blockIdx.x);
+    const int a = ms_uni(PT.a), b = ms_uni(PT.b);
+    if ((int)blockIdx.x >= ms_uni(PT.P)) return;
+    const int REC = bw*6;
+    for (int q = a; q < b; q++) {
+        double t[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = on ? M.R[(size_t)(6*q + k)*T + cc_] : 0.0;
+        const double *rec = Lrow + (size_t)q*REC;
+        const int nbk = min(B, q - a);
+        for (int bb = 0; bb < nbk; bb++) {
+            const int j = q - 1 - bb; const double *Lb_ = rec + bb*36, *hj = hist + (j % B)*6*64 + lane;
+            double wj[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) wj[c] = hj[c*64];
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int r = 0; r < 6; r++) t[r] = fma(-Lb_[c*6 + r], wj[c], t[r]);
+        }
+        const double *ld = W.LDbuf + 32*(size_t)q;
+#pragma unroll
+        for (int r = 1; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < r; c++) t[r] = fma(-ld[tri(r - 1) + c], t[c], t[r]);
+        double *hq = hist + (q % B)*6*64 + lane;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { hq[k*64] = t[k];
+            if (on) { M.Wm[(size_t)(6*q + k)*T + cc_] = t[k]; M.V[(size_t)(6*q + k)*T + cc_] = t[k]*ld[16 + k]; } }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- separator right-hand sides.  grid ((P - 1) B, column groups), one wave: pose block jb of separator s.
+__global__ __launch_bounds__(64) void k_ms_sep_rhs(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M) {
+    const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+    { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
+    const int B = bw/6, nf = ms_uni(*W.nfree);
+    if (nf <= 0) return;
+    const int s = blockIdx.x/B, jb = blockIdx.x - s*B;
+    const BandpPart Pl = bandp_part(nf, B, Pmax, s);
+    if (s >= ms_uni(Pl.P) - 1) return;
+    const BandpPart Pr = bandp_part(nf, B, Pmax, s + 1);
+    const int la = ms_uni(Pl.a), lb = ms_uni(Pl.b), ra = ms_uni(Pr.a), rb = ms_uni(Pr.b), REC = bw*6;
+    const int gR = lb + jb;
+    double acc[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc[k] = on ? M.R[(size_t)(6*gR + k)*T + cc_] : 0.0;
+    for (int bb = 0; bb < B; bb++) {                           // the separator's rows below the interior on its left (its last B column blocks)
+        const int j = gR - 1 - bb;
+        if (j >= lb) continue;                                 // a column of the separator itself
+        if (j < la) break;
+        const double *Lk = Lrow + (size_t)gR*REC + bb*36;
+        double wj[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) wj[c] = M.Wm[(size_t)(6*j + c)*T + cc_];
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[r] = fma(-Lk[c*6 + r], wj[c], acc[r]);
+    }
+    for (int q = ra; q < rb; q++) {                            // its rows as the border of the interior on its right
+        const double *Lq = Lb + (size_t)q*REC + 6*(6*jb);
+        double wq[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) wq[c] = M.Wm[(size_t)(6*q + c)*T + cc_];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[r] = fma(-Lq[6*r + c], wq[c], acc[r]);
+    }
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) M.G[((size_t)s*bw + 6*jb + k)*T + cc_] = acc[k];
+    }
+}
+
+// forward / backward substitution with the packed factor of a separator block (rec: packed rows | LD table) on the columns of this wave; the
+// vector lives in LDS as v[row*64 + lane]
+__device__ __forceinline__ void ms_block_fwd(const double *__restrict__ rec, int s, int B, double *v, int lane) {
+    const double *LDt = rec + rowoff(s);
+    for (int jb = 0; jb < B; jb++) {
+        double t[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = v[(6*jb + k)*64 + lane];
+        for (int e = 0; e < jb; e++) {
+            double we[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) we[c] = v[(6*e + c)*64 + lane];
+#pragma unroll
+            for (int r = 0; r < 6; r++) { const double *row = rec + rowoff(6*jb + r) + 6*e;
+#pragma unroll
+                for (int c = 0; c < 6; c++) t[r] = fma(-row[c], we[c], t[r]); }
+        }
+        const double *ld = LDt + SOLVE_LD*jb;
+#pragma unroll
+        for (int r = 1; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < r; c++) t[r] = fma(-ld[tri(r - 1) + c], t[c], t[r]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) v[(6*jb + k)*64 + lane] = t[k];
+    }
+}
+__device__ __forceinline__ void ms_block_back(const double *__restrict__ rec, int s, int B, double *v, int lane) {      // L^T x = v in place
+    const double *LDt = rec + rowoff(s);
+    for (int jb = B - 1; jb >= 0; jb--) {
+        double t[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = v[(6*jb + k)*64 + lane];
+        for (int e = jb + 1; e < B; e++) {
+            double xe[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) xe[r] = v[(6*e + r)*64 + lane];
+#pragma unroll
+            for (int r = 0; r < 6; r++) { const double *row = rec + rowoff(6*e + r) + 6*jb;
+#pragma unroll
+                for (int c = 0; c < 6; c++) t[c] = fma(-row[c], xe[r], t[c]); }
+        }
+        const double *ld = LDt + SOLVE_LD*jb;
+#pragma unroll
+        for (int q = 4; q >= 0; q--)
+#pragma unroll
+            for (int k = q + 1; k < 6; k++) t[q] = fma(-ld[tri(k - 1) + q], t[k], t[q]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) v[(6*jb + k)*64 + lane] = t[k];
+    }
+}
+// g of block `blk` minus its pending updates (the producers of k_cre_elim's pending_of: pivots blk -+ h', h' < H, of level h')
+__device__ __forceinline__ double ms_pending(const MsBuf &M, int s, int blk, int H, int lo, int m, int r0, int row, int col, double v) {
+    const int T = M.T;
+    for (int l = 0; l < 8; l++) {
+        const int hp = 1 << l; if (!(hp < H && hp < m - lo)) break;
+        const int pl = blk - hp, pr = blk + hp;
+        if (pl >= lo && pl != r0 && (pl & (2*hp - 1)) == hp) v -= M.Cg[(((size_t)pl*2 + 1)*s + row)*T + col];     // blk is pl's right neighbour
+        if (pr < m && pr != r0 && (pr & (2*hp - 1)) == hp) v -= M.Cg[(((size_t)pr*2 + 0)*s + row)*T + col];       // blk is pr's left neighbour
+    }
+    return v;
+}
+
+// ---- cyclic reduction, level h, forward.  grid (pivots, column groups), 8 waves.
+__global__ __launch_bounds__(MS_CT) void k_ms_cre_fwd(Work W, Work Ws, int bw, int Pmax, int h, int kb, const double *__restrict__ fac, MsBuf M) {
+    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
+    double *v = ms_smem;                                       // [s][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6), col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+    { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
+    const CrRange rg = cr_range(W, bw, Pmax);
+    const int m = ms_uni(rg.m), lo = ms_uni(rg.lo), r0 = ms_uni(rg.r0), s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
+    const int i = (2*(kb + (int)blockIdx.x) + 1)*h;
+    if (i < lo || i >= m) return;
+    const int a = i - h >= lo ? i - h : -1, c = i + h < m ? i + h : -1;
+    for (int r = wave; r < s; r += MS_CT/64) v[r*64 + lane] = on ? ms_pending(M, s, i, h, lo, m, r0, r, cc_, M.G[((size_t)i*s + r)*T + cc_]) : 0.0;
+    __syncthreads();
+    const double *rec = fac + (size_t)i*cre_rec_doubles(s);
+    if (wave == 0) {
+        ms_block_fwd(rec, s, B, v, lane);
+        const double *LDt = rec + rowoff(s);
+        if (on) for (int r = 0; r < s; r++) M.Z[((size_t)i*s + r)*T + cc_] = v[r*64 + lane]*LDt[SOLVE_LD*(r/6) + LD_ID + r % 6];
+    }
+    __syncthreads();
+    // the neighbours' updates X_a w, X_c w: rows dealt to the waves
+    const double *Xa = a >= 0 ? cr_blk(Ws.S, s, mmax, i, a) : nullptr, *Xc = c >= 0 ? cr_blk(Ws.S, s, mmax, c, i) : nullptr;
+    for (int r = wave; r < 2*s; r += MS_CT/64) {
+        const double *X = r < s ? Xa : Xc; const int rr = r < s ? r : r - s;
+        double acc = 0.0;
+        if (X) { const double *row = X + (size_t)rr*s; for (int k = 0; k < s; k++) acc = fma(row[k], v[k*64 + lane], acc); }
+        if (on) M.Cg[(((size_t)i*2 + (r < s ? 0 : 1))*s + rr)*T + cc_] = acc;
+    }
+}
+
+// ---- the last block: forward and backward.  grid (1, column groups), one wave.
+__global__ __launch_bounds__(64) void k_ms_cre_root(Work W, Work Ws, int bw, int Pmax, const double *__restrict__ fac, MsBuf M) {
+    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
+    double *v = ms_smem;                                       // [s][64]
+    const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+    { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
+    const CrRange rg = cr_range(W, bw, Pmax);
+    const int m = ms_uni(rg.m), lo = ms_uni(rg.lo), r0 = ms_uni(rg.r0), s = bw, B = s/6;
+    if (m <= 0) return;
+    for (int r = 0; r < s; r++) v[r*64 + lane] = on ? ms_pending(M, s, r0, 1 << 30, lo, m, -1, r, cc_, M.G[((size_t)r0*s + r)*T + cc_]) : 0.0;
+    const double *rec = fac + (size_t)r0*cre_rec_doubles(s), *LDt = rec + rowoff(s);
+    ms_block_fwd(rec, s, B, v, lane);
+    for (int r = 0; r < s; r++) v[r*64 + lane] *= LDt[SOLVE_LD*(r/6) + LD_ID + r % 6];
+    ms_block_back(rec, s, B, v, lane);
+    if (on) for (int r = 0; r < s; r++) M.Xs[((size_t)r0*s + r)*T + cc_] = v[r*64 + lane];
+}
+
+// ---- cyclic reduction, level h, backward.  grid (pivots, column groups), 8 waves.
+__global__ __launch_bounds__(MS_CT) void k_ms_cre_back(Work W, Work Ws, int bw, int Pmax, int h, int kb, const double *__restrict__ fac, MsBuf M) {
+    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
+    double *v = ms_smem, *xa = ms_smem + (size_t)bw*64, *xc = ms_smem + 2*(size_t)bw*64;      // [s][64] each
+    const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6), col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+    { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
+    const CrRange rg = cr_range(W, bw, Pmax);
+    const int m = ms_uni(rg.m), lo = ms_uni(rg.lo), s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
+    const int i = (2*(kb + (int)blockIdx.x) + 1)*h;
+    if (i < lo || i >= m) return;
+    const int a = i - h >= lo ? i - h : -1, c = i + h < m ? i + h : -1;
+    for (int r = wave; r < s; r += MS_CT/64) {
+        xa[r*64 + lane] = (on && a >= 0) ? M.Xs[((size_t)a*s + r)*T + cc_] : 0.0;
+        xc[r*64 + lane] = (on && c >= 0) ? M.Xs[((size_t)c*s + r)*T + cc_] : 0.0; }
+    __syncthreads();
+    const double *Xa = a >= 0 ? cr_blk(Ws.S, s, mmax, i, a) : nullptr, *Xc = c >= 0 ? cr_blk(Ws.S, s, mmax, c, i) : nullptr;
+    for (int r = wave; r < s; r += MS_CT/64) {                 // (X_a^T x_a + X_c^T x_c)[r] = sum_t X_a[t][r] x_a[t] + X_c[t][r] x_c[t]
+        double acc = on ? M.Z[((size_t)i*s + r)*T + cc_] : 0.0;
+        if (Xa) for (int t = 0; t < s; t++) acc = fma(-Xa[(size_t)t*s + r], xa[t*64 + lane], acc);
+        if (Xc) for (int t = 0; t < s; t++) acc = fma(-Xc[(size_t)t*s + r], xc[t*64 + lane], acc);
+        v[r*64 + lane] = acc;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const double *rec = fac + (size_t)i*cre_rec_doubles(s);
+    ms_block_back(rec, s, B, v, lane);
+    if (on) for (int r = 0; r < s; r++) M.Xs[((size_t)i*s + r)*T + cc_] = v[r*64 + lane];
+}
+
+// ---- interiors: v_q -= Lb_q^T x_left for every column block (no chain).  grid (free pose blocks, column groups), one wave.  Also the
+// separators' solutions into their rows of X.
+__global__ __launch_bounds__(64) void k_ms_back_border(Work W, int bw, int Pmax, const double *__restrict__ Lb, MsBuf M) {
+    const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+    { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
+    const int B = bw/6, nf = ms_uni(*W.nfree), q = blockIdx.x;
+    if (q >= nf) return;
+    const BandpPart P0 = bandp_part(nf, B, Pmax, 0);
+    const int P = ms_uni(P0.P), REC = bw*6;
+    // the interior (or separator) of column block q: interiors have (almost) equal lengths -- walk the table
+    int p = 0; BandpPart PT = P0;
+    { const int tot = nf - (P - 1)*B, len = tot/P; p = min(P - 1, q/(len + B)); PT = bandp_part(nf, B, Pmax, p);
+      while (p > 0 && q < ms_uni(PT.a) - B) { p--; PT = bandp_part(nf, B, Pmax, p); }
+      while (p < P - 1 && q >= ms_uni(PT.b) + B) { p++; PT = bandp_part(nf, B, Pmax, p); } }
+    const int a = ms_uni(PT.a), b = ms_uni(PT.b);
+    if (q >= b) {                                              // a row block of the separator on p's right (label p): its solution
+        if (q < b + B && p < P - 1 && on) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) M.X[(size_t)(6*q + k)*T + cc_] = M.Xs[((size_t)p*bw + 6*(q - b) + k)*T + cc_]; }
+        return; }
+    if (q < a) {                                               // (the separator on p's left: label p - 1)
+        if (p > 0 && on) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) M.X[(size_t)(6*q + k)*T + cc_] = M.Xs[((size_t)(p - 1)*bw + 6*(q - (a - B)) + k)*T + cc_]; }
+        return; }
+    if (p == 0) return;                                        // no separator on the left
+    double acc[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc[k] = on ? M.V[(size_t)(6*q + k)*T + cc_] : 0.0;
+    const double *Lq = Lb + (size_t)q*REC;
+    for (int br = 0; br < bw; br++) {
+        const double xl = on ? M.Xs[((size_t)(p - 1)*bw + br)*T + cc_] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[c] = fma(-Lq[6*br + c], xl, acc[c]);
+    }
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) M.V[(size_t)(6*q + k)*T + cc_] = acc[k]; }
+}
+
+// ---- interiors, backward.  grid (Pmax, column groups), one wave.
+__global__ __launch_bounds__(64) void k_ms_back_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, MsBuf M) {
+    __shared__ double hist[MS_BMAX*6*64];
+    const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+    { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
+    const int B = bw/6, nf = ms_uni(*W.nfree);
+    if (nf <= 0) return;
+    const BandpPart PT = bandp_part(nf, B, Pmax, blockIdx.x);
+    const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P), p = blockIdx.x;
+    if (p >= P) return;
+    const int REC = bw*6, r_hi = p < P - 1 ? b + B : b;
+    for (int q = b - 1; q >= a; q--) {
+        double t[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = on ? M.V[(size_t)(6*q + k)*T + cc_] : 0.0;
+        const int Rend = min(q + B, r_hi - 1);
+        for (int R = q + 1; R <= Rend; R++) {
+            const double *Lk = Lrow + (size_t)R*REC + (R - 1 - q)*36;      // L(6 R + ri, 6 q + cc) at [cc*6 + ri]
+            double xr[6];
+            if (R >= b) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) xr[r] = on ? M.Xs[((size_t)p*bw + 6*(R - b) + r)*T + cc_] : 0.0;
+            } else { const double *hr = hist + (R % B)*6*64 + lane;
+#pragma unroll
+                for (int r = 0; r < 6; r++) xr[r] = hr[r*64]; }
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int r = 0; r < 6; r++) t[c] = fma(-Lk[c*6 + r], xr[r], t[c]);
+        }
+        const double *ld = W.LDbuf + 32*(size_t)q;
+#pragma unroll
+        for (int c = 4; c >= 0; c--)
+#pragma unroll
+            for (int k = c + 1; k < 6; k++) t[c] = fma(-ld[tri(k - 1) + c], t[k], t[c]);
+        double *hq = hist + (q % B)*6*64 + lane;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { hq[k*64] = t[k]; if (on) M.X[(size_t)(6*q + k)*T + cc_] = t[k]; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_begin(Work W) {
 }
 
 // launch `it`: beta from r.z, p = z + beta p, q = S p = (band + long-range blocks) p, partial p.q.  Also where convergence is noticed.
-__global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it, unsigned int seq, int B, double tol2, int nbp) {
+// zp, zs: where the last preconditioner application left z = zs * zp[] (the factorisation's own solve: -W.Sy; the solve phase: its X)
+__global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it, unsigned int seq, int B, double tol2, int nbp, const double *zp, double zs) {
     __shared__ double lds[4];
     LmState *st = W.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it
         return; }
     const double beta = it == 0 ? 0.0 : rz/rz_old;
     if (blockIdx.x == 0 && tid == 0) { sn->rz = rz; sn->rz0 = rz0; sn->it = it; pcg_publish(W, seq, it, 0); }
-    const double *po = W.pc_p[(it + 1) & 1], *Sy = W.Sy; double *pn = W.pc_p[it & 1];
-    auto pnew = [&](int i) { return fma(beta, po[i], -Sy[i]); };
+    const double *po = W.pc_p[(it + 1) & 1]; double *pn = W.pc_p[it & 1];
+    auto pnew = [&](int i) { return fma(beta, po[i], zs*zp[i]); };
     const int nfree = W.nfree[0]; const size_t ldS = (size_t)W.ldS;
     double pq = 0.0;
     for (int u = 0; u < PCG_PPW; u++) {
@@ -116,8 +117,9 @@ __global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it
     pcg_block_partial<PCG_T>(pq, W.pc_part + nbp, lds);
 }
 
-// alpha = r.z / p.q; x += alpha p; r -= alpha q; the next band solve's right-hand side g = -r (so that it returns M^-1 r)
-__global__ __launch_bounds__(PCG_ET) void k_pcg_update(Work W, int it, int nbp) {
+// alpha = r.z / p.q; x += alpha p; r -= alpha q; the next preconditioner application's right-hand side rhs = rs * r (the factorisation
+// path solves M y = -g: rs = -1 into W.g; the solve phase takes r itself)
+__global__ __launch_bounds__(PCG_ET) void k_pcg_update(Work W, int it, int nbp, double *rhs, double rs) {
     LmState *st = W.st;
     if (st->done || st->step_fail || st->lin_done) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,17 +132,17 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_update(Work W, int it, int nbp) 
     const int i = 6*ia + k;
     W.pc_x[i] = fma(alpha, W.pc_p[it & 1][i], W.pc_x[i]);
     const double r = fma(-alpha, W.pc_q[i], W.pc_r[i]);
-    W.pc_r[i] = r; W.g[i] = -r;
+    W.pc_r[i] = r; rhs[i] = rs*r;
 }
 
-// partial r.z after the band solve (z = -Sy)
-__global__ __launch_bounds__(PCG_ET) void k_pcg_dot(Work W) {
+// partial r.z after the preconditioner application
+__global__ __launch_bounds__(PCG_ET) void k_pcg_dot(Work W, const double *zp, double zs) {
     __shared__ double lds[4];
     const LmState *st = W.st;
     if (st->done || st->step_fail || st->lin_done) return;
     const int tid = threadIdx.x, a = blockIdx.x*32 + tid/6, k = tid % 6;
     double rzp = 0.0;
-    if (a < W.n_kf) { const int ia = W.fidx[a]; if (ia >= 0) rzp = -W.pc_r[6*ia + k]*W.Sy[6*ia + k]; }
+    if (a < W.n_kf) { const int ia = W.fidx[a]; if (ia >= 0) rzp = W.pc_r[6*ia + k]*(zs*zp[6*ia + k]); }
     pcg_block_partial<PCG_ET>(rzp, W.pc_part, lds);
 }
 

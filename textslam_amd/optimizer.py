@@ -47,6 +47,7 @@ def load_library():
     L.tsba_debug_solver_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
     L.tsba_debug_pcg_stats.argtypes = [vp, C.POINTER(C.c_int32)]
     L.tsba_debug_img_cache_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.tsba_debug_multi_solve.argtypes = [vp, C.c_int, dp, dp]
     L.tsba_debug_far_blocks.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
     L.tsba_debug_row_of_kf.argtypes = [vp, C.POINTER(C.c_int32)]
     L.tsba_debug_time_solve.argtypes = [vp, C.c_int, dp]
@@ -229,6 +230,12 @@ class Optimizer:
         ip = C.POINTER(C.c_int32)
         self._check(self.lib.tsba_debug_far_blocks(self.ctx, a.ctypes.data_as(ip), b.ctypes.data_as(ip), _dp(v)), "tsba_debug_far_blocks")
         return a, b, v
+
+    def multi_solve(self, R):
+        """M X = R with the band factor of the last solve (tsba_debug_multi_solve); R: [6 x free poses, T]."""
+        R = np.ascontiguousarray(R, np.float64); X = np.zeros_like(R)
+        self._check(self.lib.tsba_debug_multi_solve(self.ctx, R.shape[1], _dp(R), _dp(X)), "tsba_debug_multi_solve")
+        return X
 
     def img_cache_stats(self):
         """Plane cache (tsba_problem.kf_id): (keyframes found on the device, keyframes copied) over the context's lifetime."""
