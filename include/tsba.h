@@ -280,7 +280,8 @@ typedef struct tsba_debug_options {
     int32_t pcg_max_it;        // > 0: iteration cap of the conjugate gradients (default 200)
     int32_t pcg_tol_exp;       // > 0: relative tolerance 10^-pcg_tol_exp of the conjugate gradients in the M^-1 norm (default 10)
     int32_t pcg_refactor;      // how the single-vector conjugate gradients apply the preconditioner: 0 / 1 by running the band factorisation again with the residual as right-hand side, 2 by the solve phase of tsba_bandms.h (one column of its 64: slower for one vector; A/B runs)
-    int32_t reserved[3];
+    int32_t pcg_block;         // 0: enlarged conjugate gradients (32 columns per preconditioner application, tsba_pcg.h) where the solve phase of the band solver exists and the coupling outside the band is at most 4096 blocks (loop closures), 1: always the single-vector iteration, 2: enlarged wherever the solve phase exists
+    int32_t reserved[2];
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

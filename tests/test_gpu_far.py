@@ -85,19 +85,26 @@ def test_same_trajectory_as_the_direct_solvers(gpu, n_kf, far, closures):
         gpu.debug_set()
 
 
-def test_conjugate_gradients_on_the_solve_phase(gpu):
-    """The same conjugate gradients with the preconditioner applied by the solve phase (tsba_bandms.h) instead of a re-run of the factorisation:
-    same iteration counts, same LM trajectory."""
-    P = synth.config_global(n_kf=900, n_pt=18000, band=8, far_frac=0.01, closures=2)
+@pytest.mark.parametrize("far,closures", [(0.01, 2), (0.0, 3), (0.03, 0)])
+def test_conjugate_gradient_variants_agree(gpu, far, closures):
+    """Three ways through the same systems: the single-vector iteration with the preconditioner applied by re-running the factorisation, the
+    same on the solve phase (tsba_bandms.h), and the enlarged conjugate gradients (32 columns per application: the default where the solve
+    phase exists) -- same LM trajectory; the block variant needs fewer applications of M^-1."""
+    P = synth.config_global(n_kf=900, n_pt=18000, band=8, far_frac=far, closures=closures)
     o = abi.options_global(); o.its[0] = 5
     try:
-        gpu.debug_set(far_solver=2, band_parts=16, sep_solver=2)
-        G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o); st1 = gpu.pcg_stats()
-        assert gpu.solver_info()["far_band_blocks"] == 8 and gpu.solver_info()["sep_cr"] == 1
-        gpu.debug_set(far_solver=2, band_parts=16, sep_solver=2, pcg_refactor=2)
-        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o); st2 = gpu.pcg_stats()
-        _same_trajectory(rep1, rep2, G1, G2, atol=1e-8)
-        assert st1["hit_cap"] == 0 and st2["hit_cap"] == 0 and abs(st1["iterations"] - st2["iterations"]) <= st1["systems"], (st1, st2)
+        runs = []
+        for kw in (dict(pcg_block=1), dict(pcg_block=1, pcg_refactor=2), dict(pcg_block=2)):
+            gpu.debug_set(far_solver=2, band_parts=16, sep_solver=2, **kw)
+            G = P.copy(); rep = gpu.GlobalBA(G, options=o)
+            info = gpu.solver_info()
+            assert info["far_band_blocks"] == 8 and info["sep_cr"] == 1 and info["interiors"] == 16, info
+            runs.append((G, rep, gpu.pcg_stats()))
+        for G, rep, st in runs[1:]:
+            _same_trajectory(runs[0][1], rep, runs[0][0], G, atol=1e-8)
+            assert st["hit_cap"] == 0 and st["systems"] == runs[0][2]["systems"], st
+        assert abs(runs[0][2]["iterations"] - runs[1][2]["iterations"]) <= runs[0][2]["systems"]
+        assert runs[2][2]["iterations"] < runs[0][2]["iterations"], [r[2] for r in runs]
     finally:
         gpu.debug_set()
 

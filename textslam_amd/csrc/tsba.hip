@@ -1910,6 +1910,7 @@ struct Ctx {
                       int w[TSBA_MAX_LEVELS] = {0,0,0,0}, h[TSBA_MAX_LEVELS] = {0,0,0,0}; unsigned lvl_mask = 0;
                       long long id[TSBA_IMG_CACHE_KF]; unsigned long long used[TSBA_IMG_CACHE_KF]; bool full[TSBA_IMG_CACHE_KF]; unsigned long long tick = 0;
                       long long hits = 0, misses = 0; } ic;
+    EcgBuf ecg{}; double *ecg_alloc = nullptr; size_t ecg_bytes = 0;      // enlarged conjugate gradients (tsba_pcg.h)
     MsBuf ms{}; double *ms_alloc = nullptr; size_t ms_bytes = 0; int ms_cap = 0;      // multi-right-hand-side solve phase of the partitioned band solver (tsba_bandms.h)
     int cov_text = -1; double *cov_log = nullptr;     // tsba_theta_optim: V of this plane at the end of every pass [TSBA_MAX_LEVELS][6]
     int far_B = 0, n_far = 0, pcg_parts = 0; unsigned int pcg_seq = 0;      // band + long-range blocks (tsba_pcg.h): band of M in pose blocks, blocks outside it, partial sums per vector kernel
@@ -2064,6 +2065,7 @@ int tsba_destroy(void *ctx) {
     if (c->lbl_dev) hipFree(c->lbl_dev); if (c->lbl_host) hipHostFree(c->lbl_host);
     if (c->ic.dev) hipFree(c->ic.dev); if (c->ic.stage) hipHostFree(c->ic.stage);
     if (c->ms_alloc) hipFree(c->ms_alloc);
+    if (c->ecg_alloc) hipFree(c->ecg_alloc);
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (c->ev_stage[l]) hipEventDestroy(c->ev_stage[l]);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
@@ -2615,7 +2617,9 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_cre_elim, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_sepf, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_ms_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_ms_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 159*1024));
+        CK(hipFuncSetAttribute((const void *)k_ms_cre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
+        CK(hipFuncSetAttribute((const void *)k_ms_cre_root, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -2734,17 +2738,17 @@ static void launch_ms_solve(Ctx *c) {            // M.R -> M.X
     Work &W = c->W; const MsBuf &M = c->ms;
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6, ncg = (M.T + 63)/64;
     Work &Ws = c->Wsep; Ws.st = W.st;
-    const size_t lds1 = (size_t)bwp*64*sizeof(double);
+    const size_t ldsf = ms_cre_lds_doubles(bwp, 1)*sizeof(double), ldsb = (ms_cre_lds_doubles(bwp, 3) + 8*(size_t)(bwp + 2))*sizeof(double);
     hipLaunchKernelGGL(k_ms_fwd_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
     hipLaunchKernelGGL(k_ms_sep_rhs, dim3((P - 1)*B, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
     const int mmax = cr_mmax(0, P, 0);
     auto pivots = [&](int h, int &kb) { kb = 0; const int klast = (mmax - 1 - h)/(2*h); return mmax - 1 - h < 0 ? 0 : std::max(0, klast + 1); };
     int htop = 0;
     for (int h = 1; h < mmax; h <<= 1) { int kb; const int npiv = pivots(h, kb); if (npiv <= 0) continue;
-        hipLaunchKernelGGL(k_ms_cre_fwd, dim3(npiv, ncg), dim3(MS_CT), lds1, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); htop = h; }
-    hipLaunchKernelGGL(k_ms_cre_root, dim3(1, ncg), dim3(64), lds1, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, M);
+        hipLaunchKernelGGL(k_ms_cre_fwd, dim3(npiv, ncg), dim3(MS_CT), ldsf, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); htop = h; }
+    hipLaunchKernelGGL(k_ms_cre_root, dim3(1, ncg), dim3(256), ldsf, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, M);
     for (int h = htop; h >= 1; h >>= 1) { int kb; const int npiv = pivots(h, kb);
-        if (npiv > 0) hipLaunchKernelGGL(k_ms_cre_back, dim3(npiv, ncg), dim3(MS_CT), 3*lds1, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); }
+        if (npiv > 0) hipLaunchKernelGGL(k_ms_cre_back, dim3(npiv, ncg), dim3(MS_CT), ldsb, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); }
     hipLaunchKernelGGL(k_ms_back_border, dim3(c->n_kf, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lb, M);
     hipLaunchKernelGGL(k_ms_back_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
 }
@@ -2760,6 +2764,53 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     const int cap = c->dbg.pcg_max_it > 0 ? c->dbg.pcg_max_it : 200;
     const double tol = c->dbg.pcg_tol_exp > 0 ? pow(10.0, -(double)c->dbg.pcg_tol_exp) : 1e-10, tol2 = tol*tol;
     const unsigned int seq = ++c->pcg_seq;
+    // Enlarged conjugate gradients on the solve phase of the band solver (ECG_T columns per application of M^-1): the default where that phase exists
+    // (measured at 5000 keyframes, ms per solve, single vector / enlarged: two loop closures 410 / 303, three closures at 3000 keyframes 231 / 229, 1 % long-range
+    // points 247 / 320: the block iteration pays where the coupling outside the band is a few hundred blocks -- outlying eigenvalues, which it captures 32 at a
+    // time -- and loses where it is spread over the map)
+    const bool want_block = c->dbg.pcg_block == 2 || (c->dbg.pcg_block == 0 && D.n_far <= 4096);
+    if (ms_available(c) && want_block && ms_reserve(c, std::max(ECG_T, c->ms_cap)) == TSBA_OK) {
+        const int nch = (c->n_kf + ECG_CH - 1)/ECG_CH; const size_t n6 = (size_t)W.N;
+        const size_t need = (2*n6*ECG_T + (size_t)nch*2*(ECG_T*ECG_T + 1) + 4*(size_t)ECG_T*ECG_T + 4*ECG_T + 16)*sizeof(double);
+        bool ok = true;
+        if (need > c->ecg_bytes) { if (c->ecg_alloc) { hipStreamSynchronize(c->stream); hipFree(c->ecg_alloc); } c->ecg_alloc = nullptr; c->ecg_bytes = 0;
+            ok = hipMalloc((void **)&c->ecg_alloc, need) == hipSuccess; if (ok) c->ecg_bytes = need; }
+        if (ok) {
+            EcgBuf &E = c->ecg; double *q = c->ecg_alloc;
+            E.P = q; q += n6*ECG_T; E.Q = q; q += n6*ECG_T; E.part = q; q += (size_t)nch*2*(ECG_T*ECG_T + 1); E.Cm = q; q += ECG_T*ECG_T; E.Lm = q; q += ECG_T*ECG_T + ECG_T;
+            E.Y = q; q += ECG_T*ECG_T; E.y1 = q; q += ECG_T; E.scal = q; E.nchunk = nch;
+            const int Tk = c->ms.T; c->ms.T = ECG_T; const MsBuf M = c->ms;
+            auto finished_e = [&](int it) {
+                if (!c->hprog || it < 2) return false;
+                const auto tw = std::chrono::steady_clock::now();
+                for (int spin = 0;; spin++) {
+                    const unsigned long long w = ((volatile unsigned long long *)c->hprog)[1];
+                    if ((unsigned int)(w >> 32) == seq) { if (w & 1) return true; if ((int)((w & 0xffffffffu) >> 1) + 2 >= it) return false; }
+                    if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(5)) return false;
+                }
+            };
+            hipLaunchKernelGGL(k_ecg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, M);
+            launch_ms_solve(c);
+            hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)M.X, (const double *)M.X, (const double *)nullptr, (const double *)M.R, (const double *)M.X, E);
+            hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 0, 0, seq, tol2);
+            hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 2, 1);
+            int it = 0;
+            for (; it < cap; it++) {
+                if (finished_e(it)) break;
+                hipLaunchKernelGGL(k_ecg_matvec, dim3(nbp), dim3(256), 0, c->stream, W, D, B, E);
+                hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)E.P, (const double *)E.Q, (const double *)M.R, (const double *)nullptr, (const double *)nullptr, E);
+                hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 1, it, seq, tol2);
+                hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 1, 0);
+                launch_ms_solve(c);
+                hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)E.Q, (const double *)M.X, (const double *)nullptr, (const double *)M.R, (const double *)M.X, E);
+                hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 2, it, seq, tol2);
+                hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 2, 0);
+            }
+            hipLaunchKernelGGL(k_ecg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
+            c->ms.T = Tk;
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W);
     auto finished = [&](int it) {                                  // true: the device reported convergence (or the end of the pass); else waits until it is within two iterations
         if (!c->hprog || it < 2) return false;

@@ -29,9 +29,14 @@ struct MsBuf {                              // device buffers of one multi-right
 
 __device__ __forceinline__ int ms_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// ---- interiors, forward.  grid (Pmax, column groups), one wave.
+// ---- interiors, forward.  grid (Pmax, column groups), one wave.  The factor data of a step -- the row block's record (36 B doubles) and its
+// diagonal table -- is the same for every lane: it is fetched by the wave as ONE coalesced load a step ahead (registers), parked in LDS and
+// read back as broadcasts.  (As uniform scalar loads the compiler emits one s_load_dwordx16 and waits for it, 40 times per step: 8 us per
+// step, 240 us per interior; staged: ~1 us per step.)
+#define MS_RECMAX (36*MS_BMAX)
 __global__ __launch_bounds__(64) void k_ms_fwd_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, MsBuf M) {
-    __shared__ double hist[MS_BMAX*6*64];
+    __shared__ __attribute__((aligned(16))) double hist[MS_BMAX*6*64];
+    __shared__ __attribute__((aligned(16))) double recb[2][MS_RECMAX + 32];
     const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
     { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
     const int B = bw/6, nf = ms_uni(*W.nfree);
@@ -40,14 +45,30 @@ __global__ __launch_bounds__(64) void k_ms_fwd_int(Work W, int bw, int Pmax, con
     const int a = ms_uni(PT.a), b = ms_uni(PT.b);
     if ((int)blockIdx.x >= ms_uni(PT.P)) return;
     const int REC = bw*6;
+    constexpr int NL = (MS_RECMAX + 63)/64;
+    double pre[NL], preld, tn[6];
+    auto fetch = [&](int q) {                                   // operands of step q: issued one step ahead
+        const double *rec = Lrow + (size_t)q*REC; const int nv = 36*min(B, q - a);
+#pragma unroll
+        for (int k = 0; k < NL; k++) { const int e = lane + 64*k; pre[k] = e < nv ? rec[e] : 0.0; }
+        preld = lane < 22 ? W.LDbuf[32*(size_t)q + lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) tn[k] = on ? M.R[(size_t)(6*q + k)*T + cc_] : 0.0;
+    };
+    fetch(a);
     for (int q = a; q < b; q++) {
+        double *rb = recb[q & 1];
         double t[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) t[k] = on ? M.R[(size_t)(6*q + k)*T + cc_] : 0.0;
-        const double *rec = Lrow + (size_t)q*REC;
+        for (int k = 0; k < NL; k++) { const int e = lane + 64*k; if (e < MS_RECMAX) rb[e] = pre[k]; }
+        if (lane < 22) rb[MS_RECMAX + lane] = preld;
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = tn[k];
+        if (q + 1 < b) fetch(q + 1);
+        wave_lds_fence();
         const int nbk = min(B, q - a);
         for (int bb = 0; bb < nbk; bb++) {
-            const int j = q - 1 - bb; const double *Lb_ = rec + bb*36, *hj = hist + (j % B)*6*64 + lane;
+            const int j = q - 1 - bb; const double *Lb_ = rb + bb*36, *hj = hist + (j % B)*6*64 + lane;
             double wj[6];
 #pragma unroll
             for (int c = 0; c < 6; c++) wj[c] = hj[c*64];
@@ -56,7 +77,7 @@ __global__ __launch_bounds__(64) void k_ms_fwd_int(Work W, int bw, int Pmax, con
 #pragma unroll
                 for (int r = 0; r < 6; r++) t[r] = fma(-Lb_[c*6 + r], wj[c], t[r]);
         }
-        const double *ld = W.LDbuf + 32*(size_t)q;
+        const double *ld = rb + MS_RECMAX;
 #pragma unroll
         for (int r = 1; r < 6; r++)
 #pragma unroll
@@ -65,7 +86,7 @@ __global__ __launch_bounds__(64) void k_ms_fwd_int(Work W, int bw, int Pmax, con
 #pragma unroll
         for (int k = 0; k < 6; k++) { hq[k*64] = t[k];
             if (on) { M.Wm[(size_t)(6*q + k)*T + cc_] = t[k]; M.V[(size_t)(6*q + k)*T + cc_] = t[k]*ld[16 + k]; } }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_fence();
     }
 }
 
@@ -175,10 +196,23 @@ __device__ __forceinline__ double ms_pending(const MsBuf &M, int s, int blk, int
     return v;
 }
 
-// ---- cyclic reduction, level h, forward.  grid (pivots, column groups), 8 waves.
+// the factor record of a separator (packed rows | LD table | z) into LDS, all threads, coalesced
+template <int NT>
+__device__ __forceinline__ void ms_stage_rec(const double *__restrict__ rec, int s, double *dst, int tid) {
+    const int n = (int)cre_rec_doubles(s);
+    for (int e0 = tid; e0 < n; e0 += 8*NT) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int e = e0 + u*NT; v[u] = e < n ? rec[e] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int e = e0 + u*NT; if (e < n) dst[e] = v[u]; }
+    }
+}
+static size_t ms_cre_lds_doubles(int s, int nvec) { return (cre_rec_doubles(s) + 8) + (size_t)nvec*s*64 + 8*(size_t)(s + 2) + 16; }
+
+// ---- cyclic reduction, level h, forward.  grid (pivots, column groups), 8 waves.  LDS: the pivot's factor record | v [s][64] | a row buffer per wave.
 __global__ __launch_bounds__(MS_CT) void k_ms_cre_fwd(Work W, Work Ws, int bw, int Pmax, int h, int kb, const double *__restrict__ fac, MsBuf M) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
-    double *v = ms_smem;                                       // [s][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6), col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
     { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
     const CrRange rg = cr_range(W, bw, Pmax);
@@ -186,46 +220,58 @@ __global__ __launch_bounds__(MS_CT) void k_ms_cre_fwd(Work W, Work Ws, int bw, i
     const int i = (2*(kb + (int)blockIdx.x) + 1)*h;
     if (i < lo || i >= m) return;
     const int a = i - h >= lo ? i - h : -1, c = i + h < m ? i + h : -1;
+    double *recl = ms_smem, *v = recl + ((cre_rec_doubles(s) + 8) & ~(size_t)1), *rowb = v + (size_t)s*64 + wave*(s + 2);
+    const double *rec = fac + (size_t)i*cre_rec_doubles(s);
+    ms_stage_rec<MS_CT>(rec, s, recl, tid);
     for (int r = wave; r < s; r += MS_CT/64) v[r*64 + lane] = on ? ms_pending(M, s, i, h, lo, m, r0, r, cc_, M.G[((size_t)i*s + r)*T + cc_]) : 0.0;
     __syncthreads();
-    const double *rec = fac + (size_t)i*cre_rec_doubles(s);
     if (wave == 0) {
-        ms_block_fwd(rec, s, B, v, lane);
-        const double *LDt = rec + rowoff(s);
+        ms_block_fwd(recl, s, B, v, lane);
+        const double *LDt = recl + rowoff(s);
         if (on) for (int r = 0; r < s; r++) M.Z[((size_t)i*s + r)*T + cc_] = v[r*64 + lane]*LDt[SOLVE_LD*(r/6) + LD_ID + r % 6];
     }
     __syncthreads();
-    // the neighbours' updates X_a w, X_c w: rows dealt to the waves
+    // the neighbours' updates X_a w, X_c w: rows dealt to the waves; a row of X parked in the wave's row buffer (broadcast reads), the next one in flight
     const double *Xa = a >= 0 ? cr_blk(Ws.S, s, mmax, i, a) : nullptr, *Xc = c >= 0 ? cr_blk(Ws.S, s, mmax, c, i) : nullptr;
+    auto rowp = [&](int r) -> const double * { const double *X = r < s ? Xa : Xc; return X ? X + (size_t)(r < s ? r : r - s)*s : nullptr; };
+    double n0 = 0.0, n1 = 0.0;
+    { const double *rp = wave < 2*s ? rowp(wave) : nullptr; n0 = (rp && lane < s) ? rp[lane] : 0.0; n1 = (rp && lane + 64 < s) ? rp[lane + 64] : 0.0; }
     for (int r = wave; r < 2*s; r += MS_CT/64) {
-        const double *X = r < s ? Xa : Xc; const int rr = r < s ? r : r - s;
-        double acc = 0.0;
-        if (X) { const double *row = X + (size_t)rr*s; for (int k = 0; k < s; k++) acc = fma(row[k], v[k*64 + lane], acc); }
-        if (on) M.Cg[(((size_t)i*2 + (r < s ? 0 : 1))*s + rr)*T + cc_] = acc;
+        if (lane < s + 2) rowb[lane] = n0;                      // (s may be below 64: the buffers of the other waves follow this one)
+        if (lane + 64 < s + 2) rowb[lane + 64] = n1;
+        { const int rn = r + MS_CT/64; const double *rp = rn < 2*s ? rowp(rn) : nullptr; n0 = (rp && lane < s) ? rp[lane] : 0.0; n1 = (rp && lane + 64 < s) ? rp[lane + 64] : 0.0; }
+        wave_lds_fence();
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int k = 0; k + 1 < s; k += 2) { acc0 = fma(rowb[k], v[k*64 + lane], acc0); acc1 = fma(rowb[k + 1], v[(k + 1)*64 + lane], acc1); }
+        if (on) M.Cg[(((size_t)i*2 + (r < s ? 0 : 1))*s + (r < s ? r : r - s))*T + cc_] = rowp(r) ? acc0 + acc1 : 0.0;
+        wave_lds_fence();
     }
 }
 
-// ---- the last block: forward and backward.  grid (1, column groups), one wave.
-__global__ __launch_bounds__(64) void k_ms_cre_root(Work W, Work Ws, int bw, int Pmax, const double *__restrict__ fac, MsBuf M) {
+// ---- the last block: forward and backward.  grid (1, column groups), 4 waves stage the factor, wave 0 solves.
+__global__ __launch_bounds__(256) void k_ms_cre_root(Work W, Work Ws, int bw, int Pmax, const double *__restrict__ fac, MsBuf M) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
-    double *v = ms_smem;                                       // [s][64]
-    const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6), col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
     { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
     const CrRange rg = cr_range(W, bw, Pmax);
     const int m = ms_uni(rg.m), lo = ms_uni(rg.lo), r0 = ms_uni(rg.r0), s = bw, B = s/6;
     if (m <= 0) return;
-    for (int r = 0; r < s; r++) v[r*64 + lane] = on ? ms_pending(M, s, r0, 1 << 30, lo, m, -1, r, cc_, M.G[((size_t)r0*s + r)*T + cc_]) : 0.0;
-    const double *rec = fac + (size_t)r0*cre_rec_doubles(s), *LDt = rec + rowoff(s);
-    ms_block_fwd(rec, s, B, v, lane);
+    double *recl = ms_smem, *v = recl + ((cre_rec_doubles(s) + 8) & ~(size_t)1);
+    ms_stage_rec<256>(fac + (size_t)r0*cre_rec_doubles(s), s, recl, tid);
+    for (int r = wave; r < s; r += 4) v[r*64 + lane] = on ? ms_pending(M, s, r0, 1 << 30, lo, m, -1, r, cc_, M.G[((size_t)r0*s + r)*T + cc_]) : 0.0;
+    __syncthreads();
+    if (wave > 0) return;
+    const double *LDt = recl + rowoff(s);
+    ms_block_fwd(recl, s, B, v, lane);
     for (int r = 0; r < s; r++) v[r*64 + lane] *= LDt[SOLVE_LD*(r/6) + LD_ID + r % 6];
-    ms_block_back(rec, s, B, v, lane);
+    ms_block_back(recl, s, B, v, lane);
     if (on) for (int r = 0; r < s; r++) M.Xs[((size_t)r0*s + r)*T + cc_] = v[r*64 + lane];
+    (void)Ws;
 }
 
-// ---- cyclic reduction, level h, backward.  grid (pivots, column groups), 8 waves.
+// ---- cyclic reduction, level h, backward.  grid (pivots, column groups), 8 waves.  LDS: factor record | v | x_a | x_c | a column buffer per wave.
 __global__ __launch_bounds__(MS_CT) void k_ms_cre_back(Work W, Work Ws, int bw, int Pmax, int h, int kb, const double *__restrict__ fac, MsBuf M) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
-    double *v = ms_smem, *xa = ms_smem + (size_t)bw*64, *xc = ms_smem + 2*(size_t)bw*64;      // [s][64] each
     const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6), col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
     { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
     const CrRange rg = cr_range(W, bw, Pmax);
@@ -233,21 +279,33 @@ __global__ __launch_bounds__(MS_CT) void k_ms_cre_back(Work W, Work Ws, int bw, 
     const int i = (2*(kb + (int)blockIdx.x) + 1)*h;
     if (i < lo || i >= m) return;
     const int a = i - h >= lo ? i - h : -1, c = i + h < m ? i + h : -1;
+    double *recl = ms_smem, *v = recl + ((cre_rec_doubles(s) + 8) & ~(size_t)1), *xa = v + (size_t)s*64, *xc = xa + (size_t)s*64, *colb = xc + (size_t)s*64 + wave*2*(s + 2);
+    ms_stage_rec<MS_CT>(fac + (size_t)i*cre_rec_doubles(s), s, recl, tid);
     for (int r = wave; r < s; r += MS_CT/64) {
         xa[r*64 + lane] = (on && a >= 0) ? M.Xs[((size_t)a*s + r)*T + cc_] : 0.0;
         xc[r*64 + lane] = (on && c >= 0) ? M.Xs[((size_t)c*s + r)*T + cc_] : 0.0; }
     __syncthreads();
     const double *Xa = a >= 0 ? cr_blk(Ws.S, s, mmax, i, a) : nullptr, *Xc = c >= 0 ? cr_blk(Ws.S, s, mmax, c, i) : nullptr;
-    for (int r = wave; r < s; r += MS_CT/64) {                 // (X_a^T x_a + X_c^T x_c)[r] = sum_t X_a[t][r] x_a[t] + X_c[t][r] x_c[t]
-        double acc = on ? M.Z[((size_t)i*s + r)*T + cc_] : 0.0;
-        if (Xa) for (int t = 0; t < s; t++) acc = fma(-Xa[(size_t)t*s + r], xa[t*64 + lane], acc);
-        if (Xc) for (int t = 0; t < s; t++) acc = fma(-Xc[(size_t)t*s + r], xc[t*64 + lane], acc);
-        v[r*64 + lane] = acc;
+    // (X_a^T x_a + X_c^T x_c)[r] = sum_t X_a[t][r] x_a[t] + X_c[t][r] x_c[t]: column r of both blocks parked in the wave's buffer, the next column in flight
+    double na0 = 0.0, na1 = 0.0, nc0 = 0.0, nc1 = 0.0;
+    auto colfetch = [&](int r) { const bool okr = r < s;
+        na0 = (Xa && okr && lane < s) ? Xa[(size_t)lane*s + r] : 0.0; na1 = (Xa && okr && lane + 64 < s) ? Xa[(size_t)(lane + 64)*s + r] : 0.0;
+        nc0 = (Xc && okr && lane < s) ? Xc[(size_t)lane*s + r] : 0.0; nc1 = (Xc && okr && lane + 64 < s) ? Xc[(size_t)(lane + 64)*s + r] : 0.0; };
+    colfetch(wave);
+    for (int r = wave; r < s; r += MS_CT/64) {
+        if (lane < s + 2) { colb[lane] = na0; colb[s + 2 + lane] = nc0; }      // (s may be below 64: the buffers of the other waves follow this one)
+        if (lane + 64 < s + 2) { colb[lane + 64] = na1; colb[s + 2 + lane + 64] = nc1; }
+        const double z = on ? M.Z[((size_t)i*s + r)*T + cc_] : 0.0;
+        colfetch(r + MS_CT/64);
+        wave_lds_fence();
+        double acc0 = z, acc1 = 0.0;
+        for (int t = 0; t < s; t++) { acc0 = fma(-colb[t], xa[t*64 + lane], acc0); acc1 = fma(-colb[s + 2 + t], xc[t*64 + lane], acc1); }
+        v[r*64 + lane] = acc0 + acc1;
+        wave_lds_fence();
     }
     __syncthreads();
     if (wave > 0) return;
-    const double *rec = fac + (size_t)i*cre_rec_doubles(s);
-    ms_block_back(rec, s, B, v, lane);
+    ms_block_back(recl, s, B, v, lane);
     if (on) for (int r = 0; r < s; r++) M.Xs[((size_t)i*s + r)*T + cc_] = v[r*64 + lane];
 }
 
@@ -291,9 +349,12 @@ __global__ __launch_bounds__(64) void k_ms_back_border(Work W, int bw, int Pmax,
         for (int k = 0; k < 6; k++) M.V[(size_t)(6*q + k)*T + cc_] = acc[k]; }
 }
 
-// ---- interiors, backward.  grid (Pmax, column groups), one wave.
+// ---- interiors, backward.  grid (Pmax, column groups), one wave; factor data staged a step ahead as in k_ms_fwd_int (the B blocks
+// L(R, q), R = q + 1 .. q + B, sit in B different row records: 36 contiguous doubles each).
 __global__ __launch_bounds__(64) void k_ms_back_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, MsBuf M) {
-    __shared__ double hist[MS_BMAX*6*64];
+    __shared__ __attribute__((aligned(16))) double hist[MS_BMAX*6*64];
+    __shared__ __attribute__((aligned(16))) double xsep[MS_BMAX*6*64];
+    __shared__ __attribute__((aligned(16))) double recb[2][MS_RECMAX + 32];
     const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
     { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
     const int B = bw/6, nf = ms_uni(*W.nfree);
@@ -302,26 +363,41 @@ __global__ __launch_bounds__(64) void k_ms_back_int(Work W, int bw, int Pmax, co
     const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P), p = blockIdx.x;
     if (p >= P) return;
     const int REC = bw*6, r_hi = p < P - 1 ? b + B : b;
+    if (p < P - 1) for (int r = 0; r < bw; r++) xsep[r*64 + lane] = on ? M.Xs[((size_t)p*bw + r)*T + cc_] : 0.0;      // the separator on the right: its solution
+    constexpr int NL = (MS_RECMAX + 63)/64;
+    double pre[NL], preld, tn[6];
+    auto fetch = [&](int q) {
+        const int nv = 36*(min(q + B, r_hi - 1) - q);
+#pragma unroll
+        for (int k = 0; k < NL; k++) { const int e = lane + 64*k; pre[k] = e < nv ? Lrow[(size_t)(q + 1 + e/36)*REC + e] : 0.0; }
+        preld = lane < 22 ? W.LDbuf[32*(size_t)q + lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) tn[k] = on ? M.V[(size_t)(6*q + k)*T + cc_] : 0.0;
+    };
+    fetch(b - 1);
     for (int q = b - 1; q >= a; q--) {
+        double *rb = recb[q & 1];
         double t[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) t[k] = on ? M.V[(size_t)(6*q + k)*T + cc_] : 0.0;
+        for (int k = 0; k < NL; k++) { const int e = lane + 64*k; if (e < MS_RECMAX) rb[e] = pre[k]; }
+        if (lane < 22) rb[MS_RECMAX + lane] = preld;
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = tn[k];
+        if (q > a) fetch(q - 1);
+        wave_lds_fence();
         const int Rend = min(q + B, r_hi - 1);
         for (int R = q + 1; R <= Rend; R++) {
-            const double *Lk = Lrow + (size_t)R*REC + (R - 1 - q)*36;      // L(6 R + ri, 6 q + cc) at [cc*6 + ri]
+            const double *Lk = rb + (R - 1 - q)*36;            // L(6 R + ri, 6 q + cc) at [cc*6 + ri]
+            const double *xs = R >= b ? xsep + 6*(R - b)*64 + lane : hist + (R % B)*6*64 + lane;
             double xr[6];
-            if (R >= b) {
 #pragma unroll
-                for (int r = 0; r < 6; r++) xr[r] = on ? M.Xs[((size_t)p*bw + 6*(R - b) + r)*T + cc_] : 0.0;
-            } else { const double *hr = hist + (R % B)*6*64 + lane;
-#pragma unroll
-                for (int r = 0; r < 6; r++) xr[r] = hr[r*64]; }
+            for (int r = 0; r < 6; r++) xr[r] = xs[r*64];
 #pragma unroll
             for (int c = 0; c < 6; c++)
 #pragma unroll
                 for (int r = 0; r < 6; r++) t[c] = fma(-Lk[c*6 + r], xr[r], t[c]);
         }
-        const double *ld = W.LDbuf + 32*(size_t)q;
+        const double *ld = rb + MS_RECMAX;
 #pragma unroll
         for (int c = 4; c >= 0; c--)
 #pragma unroll
@@ -329,6 +405,6 @@ __global__ __launch_bounds__(64) void k_ms_back_int(Work W, int bw, int Pmax, co
         double *hq = hist + (q % B)*6*64 + lane;
 #pragma unroll
         for (int k = 0; k < 6; k++) { hq[k*64] = t[k]; if (on) M.X[(size_t)(6*q + k)*T + cc_] = t[k]; }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_fence();
     }
 }

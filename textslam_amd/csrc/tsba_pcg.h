@@ -20,7 +20,7 @@
 #define PCG_PPW 8
 #define PCG_ET 192                          // element-wise kernels: 32 poses x 6 rows per workgroup (the same number of workgroups, so one partial array serves all)
 
-struct PcgState { double rz, rz0; int it, pad; };
+struct PcgState { double rz, rz0, best; int it, since; };      // best: smallest r.z so far; since: iterations since it improved by a tenth (stagnation at the attainable accuracy)
 
 __device__ __forceinline__ double pcg_sum_parts(const double *part, int nb, int lane) {     // every lane gets the sum; fixed order
     double s = 0.0;
@@ -64,11 +64,15 @@ __global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it
     PcgState *so = W.pcs + ((it + 1) & 1), *sn = W.pcs + (it & 1);
     const double rz0 = it == 0 ? rz : so->rz0, rz_old = it == 0 ? 1.0 : so->rz;
     if (!(rz == rz)) { if (blockIdx.x == 0 && tid == 0) { st->step_fail = 1; pcg_publish(W, seq, it, 1); } return; }
-    if (!(rz > tol2*rz0)) {                                  // converged (every workgroup takes the same decision from the same partials)
+    // where M is so ill-conditioned that the tolerance lies below the rounding noise of M^-1 r (weakly damped trials of maps with loop closures:
+    // the drift modes) r.z stops falling: 12 iterations without a gain of a tenth end the solve with what it has -- the LM step test judges it
+    const double best_o = it == 0 ? rz : so->best; const int since_o = it == 0 ? 0 : so->since;
+    const bool gain = rz < 0.9*best_o; const double best = gain ? rz : best_o; const int since = gain ? 0 : since_o + 1;
+    if (!(rz > tol2*rz0) || since >= 12) {                   // converged (every workgroup takes the same decision from the same partials)
         if (blockIdx.x == 0 && tid == 0) { st->lin_done = 1; W.pc_stat[0] += it; W.pc_stat[1] += 1; if (it > W.pc_stat[2]) W.pc_stat[2] = it; pcg_publish(W, seq, it, 1); }
         return; }
     const double beta = it == 0 ? 0.0 : rz/rz_old;
-    if (blockIdx.x == 0 && tid == 0) { sn->rz = rz; sn->rz0 = rz0; sn->it = it; pcg_publish(W, seq, it, 0); }
+    if (blockIdx.x == 0 && tid == 0) { sn->rz = rz; sn->rz0 = rz0; sn->best = best; sn->since = since; sn->it = it; pcg_publish(W, seq, it, 0); }
     const double *po = W.pc_p[(it + 1) & 1]; double *pn = W.pc_p[it & 1];
     auto pnew = [&](int i) { return fma(beta, po[i], zs*zp[i]); };
     const int nfree = W.nfree[0]; const size_t ldS = (size_t)W.ldS;
@@ -156,6 +160,222 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_finish(Work W, int its_enqueued)
         W.dp[6*a + k] = (ia >= 0 && !fail) ? W.pc_x[6*ia + k] : 0.0;
         if (ia >= 0 && !fail) W.g[6*ia + k] = W.pc_g0[6*ia + k]; }
     __syncthreads();                                         // (every thread of workgroup 0 has read the flag)
+    if (blockIdx.x == 0 && tid == 0) {
+        if (!conv && !fail) { W.pc_stat[0] += its_enqueued; W.pc_stat[1] += 1; W.pc_stat[3] += 1; if (its_enqueued > W.pc_stat[2]) W.pc_stat[2] = its_enqueued; }
+        st->lin_done = 0; }
+}
+
+// =====================================================================================================================================
+// Enlarged conjugate gradients (Grigori, Moufawad, Nataf 2016): the residual is split into ECG_T vectors by pose (column c holds the rows of the
+// poses a with a mod ECG_T == c), the search space grows by ECG_T directions per iteration -- one application of M^-1 to ECG_T columns costs
+// what one column costs (tsba_bandms.h: a lane owns a column), and the outlying eigenvalues that a loop closure or the long-range points add
+// to M^-1 S are captured ECG_T at a time: 38 -> 6 iterations on a map with two closures, 25 -> 13 with 1 % long-range points (1500 keyframes).
+//   P~ (n x T) search directions (not orthonormalised: every use goes through C = P~^T S P~), Q~ = S P~, R residual block, Z = M^-1 R, x
+//   per iteration:  Q~ = S P~ | C = P~^T Q~, D = P~^T R | Y1 = C^-1 D | R -= Q~ Y1, x += P~ (Y1 1) | Z = M^-1 R | E = Q~^T Z, r.z |
+//                   Y2 = C^-1 E, convergence | P~ = Z - P~ Y2
+// C^-1 by a Cholesky factorisation with a pivot threshold (a direction that has become dependent is dropped for the iteration).  All sums in
+// fixed order (per-chunk partials, summed by one workgroup): deterministic.
+#define ECG_T 32
+#define ECG_CH 32                           // poses per chunk of the Gram kernels (192 rows)
+
+struct EcgBuf { double *P, *Q, *part, *Cm, *Lm, *Y, *y1, *scal; int nchunk; };      // part: [nchunk][2][T*T + 1]; scal: rz0, rz, flags
+
+// R = T(-g) (column = pose mod T), x = 0
+__global__ __launch_bounds__(PCG_ET) void k_ecg_begin(Work W, MsBuf M) {
+    const LmState *st = W.st;
+    if (st->done || st->step_fail) return;
+    const int tid = threadIdx.x, a = blockIdx.x*32 + tid/6, k = tid % 6;
+    if (a >= W.n_kf) return;
+    const int ia = W.fidx[a]; if (ia < 0) return;
+    const int i = 6*ia + k; const double gv = W.g[i];
+    W.pc_g0[i] = gv; W.pc_x[i] = 0.0;
+    for (int c = 0; c < ECG_T; c++) M.R[(size_t)i*ECG_T + c] = (ia % ECG_T) == c ? -gv : 0.0;
+}
+
+// Q~ = S P~ for ECG_T columns: one wave per pose, a lane per column; the pose's blocks of S staged in LDS by the wave (broadcast reads)
+__global__ __launch_bounds__(256) void k_ecg_matvec(Work W, LevelDev L, int B, EcgBuf E) {
+    __shared__ double blk[4][36];
+    const LmState *st = W.st;
+    if (st->done || st->step_fail || st->lin_done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & (ECG_T - 1), half = lane >> 5;      // two halves of a wave: two neighbour blocks at a time
+    const int nfree = W.nfree[0]; const size_t ldS = (size_t)W.ldS;
+    for (int u = 0; u < PCG_PPW; u++) {
+        const int a = (blockIdx.x*4 + wave)*PCG_PPW + u;
+        if (a >= W.n_kf) break;
+        const int ia = W.fidx[a];
+        if (ia < 0) continue;
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        // band: neighbour blocks ic = ia - B .. ia + B; lane (half, column): half 0 takes the even offsets, half 1 the odd ones
+        const int lo = max(ia - B, 0), hi = min(ia + B, nfree - 1);
+        for (int ic = lo + half; ic <= hi; ic += 2) {
+            double s[36];
+            if (ic <= ia) {
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) { const int col = 6*ic + cc, row = 6*ia + r;
+                        s[6*r + cc] = (ic < ia || col <= row) ? W.S[(size_t)row*ldS + col] : W.S[(size_t)col*ldS + row]; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) s[6*r + cc] = W.S[(size_t)(6*ic + cc)*ldS + 6*ia + r];
+            }
+            double p[6];
+#pragma unroll
+            for (int cc = 0; cc < 6; cc++) p[cc] = E.P[(size_t)(6*ic + cc)*ECG_T + c];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) acc[r] = fma(s[6*r + cc], p[cc], acc[r]);
+        }
+        // blocks of E of this keyframe
+        const int e0 = L.far_off[a], e1 = L.far_off[a + 1];
+        for (int e = e0 + half; e < e1; e += 2) {
+            const int ent = L.far_ent[e], fid = ent >> 1, side = ent & 1;
+            const int io = W.fidx[side ? L.far_a[fid] : L.far_b[fid]];
+            if (io < 0) continue;
+            const double *sb = W.Sfar + (size_t)fid*36;
+            double p[6];
+#pragma unroll
+            for (int cc = 0; cc < 6; cc++) p[cc] = E.P[(size_t)(6*io + cc)*ECG_T + c];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) acc[r] = fma(side ? sb[6*cc + r] : sb[6*r + cc], p[cc], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) { acc[r] += __shfl_xor(acc[r], 32, 64); if (half == 0) E.Q[(size_t)(6*ia + r)*ECG_T + c] = acc[r]; }
+    }
+    (void)blk;
+}
+
+// partial Gram matrices of a chunk of ECG_CH poses: out1 = A^T B1, out2 = A^T B2 (B2 may be null), and the partial of (R 1).(Z 1)
+__global__ __launch_bounds__(256) void k_ecg_gram(Work W, const double *A, const double *B1, const double *B2, const double *Rr, const double *Zz, EcgBuf E) {
+    __shared__ double sa[32*ECG_T], sb1[32*ECG_T], sb2[32*ECG_T], red[4];
+    const LmState *st = W.st;
+    if (st->done || st->step_fail || st->lin_done) return;
+    const int tid = threadIdx.x, i = tid >> 3, j0 = (tid & 7)*4;                  // thread: row i of the t x t result, columns j0 .. j0 + 3
+    double c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0}, rz = 0.0;
+    const int a0 = blockIdx.x*ECG_CH;
+    // the chunk's rows: the free poses among a0 .. a0 + ECG_CH - 1, 32 rows staged at a time
+    for (int sub = 0; sub < 6; sub++) {                                           // 32 poses x 6 rows = 6 slabs of 32 rows (row k of every pose of the chunk)
+        __syncthreads();
+        for (int e = tid; e < 32*ECG_T; e += 256) { const int p = e/ECG_T, col = e - p*ECG_T, a = a0 + p;
+            const int ia = a < W.n_kf ? W.fidx[a] : -1; const size_t idx = ia >= 0 ? (size_t)(6*ia + sub)*ECG_T + col : 0;
+            sa[e] = ia >= 0 ? A[idx] : 0.0; sb1[e] = ia >= 0 ? B1[idx] : 0.0; sb2[e] = (ia >= 0 && B2) ? B2[idx] : 0.0; }
+        if (Rr && tid < 32) { const int a = a0 + tid, ia = a < W.n_kf ? W.fidx[a] : -1;
+            if (ia >= 0) { double sr = 0.0, sz = 0.0; for (int col = 0; col < ECG_T; col++) { sr += Rr[(size_t)(6*ia + sub)*ECG_T + col]; sz += Zz[(size_t)(6*ia + sub)*ECG_T + col]; } rz += sr*sz; } }
+        __syncthreads();
+        for (int p = 0; p < 32; p++) { const double av = sa[p*ECG_T + i];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { c1[q] = fma(av, sb1[p*ECG_T + j0 + q], c1[q]); c2[q] = fma(av, sb2[p*ECG_T + j0 + q], c2[q]); } }
+    }
+    double *o = E.part + (size_t)blockIdx.x*2*(ECG_T*ECG_T + 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { o[i*ECG_T + j0 + q] = c1[q]; o[ECG_T*ECG_T + 1 + i*ECG_T + j0 + q] = c2[q]; }
+    rz = wave_sum1(tid < 64 ? rz : 0.0);
+    if (tid == 0) o[ECG_T*ECG_T] = rz;
+    (void)red;
+}
+
+// the t x t algebra, one workgroup of 1024 threads (thread = entry).  mode 1: C, D from the partials, Cholesky of C with a pivot threshold,
+// Y = C^-1 D, y1 = Y 1.  mode 2: E from the partials, r.z, convergence, Y = C^-1 E.  mode 0: only r.z of the start (rz0).
+__global__ __launch_bounds__(1024) void k_ecg_small(Work W, EcgBuf E, int mode, int it, unsigned int seq, double tol2) {
+    __shared__ double Cm[ECG_T*ECG_T], Dm[ECG_T*ECG_T], dinv[ECG_T]; __shared__ int dead[ECG_T];
+    LmState *st = W.st;
+    const int tid = threadIdx.x, i = tid/ECG_T, j = tid % ECG_T;
+    if (st->done || st->step_fail || st->lin_done) { if (tid == 0 && mode == 2) pcg_publish(W, seq, it, 1); return; }
+    const size_t ps = 2*(ECG_T*ECG_T + 1);
+    double c = 0.0, d = 0.0;
+    for (int k = 0; k < E.nchunk; k++) { c += E.part[(size_t)k*ps + tid]; d += E.part[(size_t)k*ps + ECG_T*ECG_T + 1 + tid]; }
+    if (mode != 1) {                                            // r.z in fixed order
+        double rz = 0.0; if (tid == 0) { for (int k = 0; k < E.nchunk; k++) rz += E.part[(size_t)k*ps + ECG_T*ECG_T]; }
+        __shared__ double srz; if (tid == 0) srz = rz; __syncthreads(); rz = srz;
+        if (mode == 0) { if (tid == 0) { E.scal[0] = rz; E.scal[1] = rz; E.scal[2] = rz; E.scal[3] = 0.0; } return; }
+        const double rz0 = E.scal[0], best_o = E.scal[2]; const int since_o = (int)E.scal[3];
+        const bool gain = rz < 0.9*best_o; const int since = gain ? 0 : since_o + 1;
+        if (!(rz == rz)) { if (tid == 0) { st->step_fail = 1; pcg_publish(W, seq, it, 1); } return; }
+        if (!(rz > tol2*rz0) || since >= 8) { if (tid == 0) { st->lin_done = 1; W.pc_stat[0] += it + 1; W.pc_stat[1] += 1; if (it + 1 > W.pc_stat[2]) W.pc_stat[2] = it + 1; pcg_publish(W, seq, it, 1); } return; }
+        __syncthreads();
+        if (tid == 0) { E.scal[1] = rz; if (gain) E.scal[2] = rz; E.scal[3] = (double)since; pcg_publish(W, seq, it, 0); }
+    }
+    if (mode == 1) {
+        Cm[tid] = c; Dm[tid] = d;
+        __syncthreads();
+        { const double cs = 0.5*(Cm[i*ECG_T + j] + Cm[j*ECG_T + i]); __syncthreads(); Cm[tid] = cs; }
+        __syncthreads();
+        double dmax = 0.0; for (int k = 0; k < ECG_T; k++) dmax = fmax(dmax, Cm[k*ECG_T + k]);
+        // right-looking Cholesky, lower triangle in place; a pivot below the threshold drops its direction
+        for (int k = 0; k < ECG_T; k++) {
+            const double piv = Cm[k*ECG_T + k];
+            const bool ok = piv > 1e-12*dmax;
+            __syncthreads();
+            if (tid == 0) { dead[k] = ok ? 0 : 1; dinv[k] = ok ? 1.0/sqrt(piv) : 0.0; }
+            __syncthreads();
+            if (j == k && i >= k) Cm[i*ECG_T + k] = i == k ? (ok ? sqrt(piv) : 1.0) : Cm[i*ECG_T + k]*dinv[k];
+            __syncthreads();
+            if (i > k && j > k && j <= i) Cm[i*ECG_T + j] -= Cm[i*ECG_T + k]*Cm[j*ECG_T + k];
+            __syncthreads();
+        }
+        E.Lm[tid] = Cm[tid];
+        if (tid < ECG_T) E.Lm[ECG_T*ECG_T + tid] = (double)dead[tid];
+    } else {
+        Cm[tid] = E.Lm[tid]; Dm[tid] = c;
+        if (tid < ECG_T) dead[tid] = E.Lm[ECG_T*ECG_T + tid] != 0.0;
+        __syncthreads();
+    }
+    // Y = C^-1 D: thread j < T takes right-hand side column j (forward, backward); dropped directions get 0
+    __syncthreads();
+    if (tid < ECG_T) {
+        const int col = tid; double y[ECG_T];
+        for (int r = 0; r < ECG_T; r++) { double v = Dm[r*ECG_T + col]; for (int k = 0; k < r; k++) v -= Cm[r*ECG_T + k]*y[k]; y[r] = dead[r] ? 0.0 : v/Cm[r*ECG_T + r]; }
+        for (int r = ECG_T - 1; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < ECG_T; k++) v -= Cm[k*ECG_T + r]*y[k]; y[r] = dead[r] ? 0.0 : v/Cm[r*ECG_T + r]; }
+        for (int r = 0; r < ECG_T; r++) E.Y[r*ECG_T + col] = y[r];
+    }
+    __syncthreads();
+    if (mode == 1 && tid < ECG_T) { double s = 0.0; for (int col = 0; col < ECG_T; col++) s += E.Y[tid*ECG_T + col]; E.y1[tid] = s; }
+}
+
+// mode 1: R -= Q~ Y, x += P~ y1.   mode 2: P~ = Z - P~ Y (first: P~ = Z).   One wave per row at a time, a lane per column.
+__global__ __launch_bounds__(256) void k_ecg_update(Work W, MsBuf M, EcgBuf E, int mode, int first) {
+    const LmState *st = W.st;
+    if (st->done || st->step_fail || st->lin_done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & (ECG_T - 1);
+    double y[ECG_T];
+#pragma unroll
+    for (int k = 0; k < ECG_T; k++) y[k] = first ? 0.0 : E.Y[k*ECG_T + c];
+    const double y1 = (mode == 1 && lane < ECG_T) ? E.y1[lane] : 0.0;
+    for (int u = 0; u < PCG_PPW; u++) {
+        const int a = (blockIdx.x*4 + wave)*PCG_PPW + u;
+        if (a >= W.n_kf) break;
+        const int ia = W.fidx[a];
+        if (ia < 0) continue;
+        for (int r = 0; r < 6; r++) {
+            const size_t row = (size_t)(6*ia + r)*ECG_T;
+            const double src = lane < ECG_T ? (mode == 1 ? E.Q[row + lane] : E.P[row + lane]) : 0.0;      // the row of Q~ / P~: lane k holds entry k
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < ECG_T; k++) acc = fma(readlane_f64(src, k), y[k], acc);
+            if (mode == 1) {
+                if (lane < ECG_T) M.R[row + c] -= acc;
+                const double px = lane < ECG_T ? E.P[row + lane]*y1 : 0.0;
+                const double s = wave_sum1(px);
+                if (lane == 0) W.pc_x[6*ia + r] += s;
+            } else if (lane < ECG_T) E.P[row + c] = M.X[row + c] - acc;
+        }
+    }
+}
+
+// dp = x by keyframe, g restored, flags cleared (as k_pcg_finish)
+__global__ __launch_bounds__(PCG_ET) void k_ecg_finish(Work W, int its_enqueued) {
+    LmState *st = W.st;
+    if (st->done) return;
+    const int tid = threadIdx.x, a = blockIdx.x*32 + tid/6, k = tid % 6;
+    const int fail = st->step_fail, conv = st->lin_done;
+    if (a < W.n_kf) { const int ia = W.fidx[a];
+        W.dp[6*a + k] = (ia >= 0 && !fail) ? W.pc_x[6*ia + k] : 0.0; }
+    __syncthreads();
     if (blockIdx.x == 0 && tid == 0) {
         if (!conv && !fail) { W.pc_stat[0] += its_enqueued; W.pc_stat[1] += 1; W.pc_stat[3] += 1; if (its_enqueued > W.pc_stat[2]) W.pc_stat[2] = its_enqueued; }
         st->lin_done = 0; }
