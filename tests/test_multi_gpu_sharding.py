@@ -1,8 +1,12 @@
-"""N > 1 path on CPU (gloo, world_size 2): the landmark sharding of the global BA and its one exchange step.
+"""N > 1 path on CPU (gloo, world_size 2): the arithmetic of the landmark sharding of the global BA and of its one exchange step.
 
-Every rank keeps the residual blocks of the landmarks j with j mod world == rank (all poses replicated), forms its part of
-the reduced normal equations, and the parts are all-reduced (sum).  Here the per-rank parts come from the CPU oracle and the
-collective is torch.distributed over gloo; the GPU path does exactly the same with libtsba kernels and RCCL."""
+Rank r keeps the residual blocks of the landmarks HOSTED in its keyframe range [r, r + 1) n_kf / world (tsba_shard_of, csrc/tsba_plan.h; the
+observations of a frozen landmark go with their target keyframe; all poses replicated), forms its part of the reduced normal equations, and the
+parts are all-reduced (sum).  Here the per-rank parts come from the CPU ORACLE (oracle/tsba_oracle.c: the same shard rule restated) and the
+collective is torch.distributed over gloo: this checks that the shards of the restatement sum to its unsharded system -- the exchange
+arithmetic -- not the product.  The product's own N > 1 path (sharded upload, split kernel sequence, every collective, ring maps, maps with
+long-range coupling) runs under `pytest -m gpu` through the in-process communicator: tests/test_gpu_global.py::test_multi_rank_*,
+test_device_landmark_shards_sum_to_unsharded_system, tests/test_gpu_far.py::test_two_ranks; over real RCCL in test_multi_gpu_rccl_two_ranks."""
 import os
 import sys
 import numpy as np

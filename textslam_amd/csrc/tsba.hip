@@ -32,1446 +32,9 @@
 #include "tsraster.h"
 #include "tsba_plan.h"
 
-// ------------------------------------------------------------------------------------------------ device structs
-struct LmState {
-    double radius, decrease_factor, x_cost, x_norm, cand_cost, model_change, step_norm, gmax, cost0;
-    int cur, done, need_lin, first, it, accepted, term, invalid, max_it, step_fail, lcur, lin_done;      // lin_done: the iterative reduced-system solve of this trial has converged (tsba_pcg.h): the remaining preconditioner launches return at once
-    int ns_active, nt_active, n_bad_scene, n_bad_tfeat, n_bad_text, pad2;
-    long long n_lin, n_cost;
-};
-
-struct LevelDev {            // device copies of HostPlan + per-level inputs
-    int level, n_sc, n_pair, n_tg, n_pslot, n_tslot, n_sb, n_tfeat, bw_rows;      // bw_rows: rows of S below a pose block that can be non-zero
-    double K[4];             // K_l
-    int img_w, img_h;
-    const uint8_t *const *img;      // [n_kf] device pointers
-    const int *sc_obs, *sc_kf, *sc_pt, *sc_flag, *sc_slot; const double *sc_uv;
-    const int *pair_i, *pair_h, *pair_hpos, *pair_sc_off, *pair_tg_off, *pair_tg;
-    const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot, *tg_rec, *tg_ppos, *pt_pose6, *pt_pair4;
-    const int *pls_off, *pslot_pose, *pslot_pair, *pslot_lm, *tls_off, *tslot_pose, *tslot_pair, *tslot_lm;
-    const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_pt_lm, *sb_tx_off, *sb_tx_s1, *sb_tx_s2, *sb_tx_lm;
-    const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ps_lm, *pose_ts_off, *pose_ts, *pose_ts_lm;
-    const int *tfeat_off, *tfeat_raw; const double *tfeat_uv, *tfeat_ref;
-    const int *pf_g, *pf_f; int n_pf;   // pose-only path: flat (group, feature) list of the frame's text features
-    const int *kf_order;                // nullptr: the rows of S follow the keyframe index; else kf_order[i] = keyframe at position i (tsba_plan.h: rcm_order)
-    // band + long-range coupling (HostPlan::far_* / fb_*, tsba_pcg.h): nullptr / 0 unless the plan split the reduced system into M (the sb_* lists) + E.
-    // sb_far: nullptr in this view; in the view of E that launch_schur derives (sb_* = the fb_* lists) the index of every block in W.Sfar
-    const int *sb_far, *far_a, *far_b, *far_off, *far_ent; int n_far, far_B;
-    const int *fb_id, *fb_pab, *fb_pba, *fb_pt_off, *fb_pt_s1, *fb_pt_s2, *fb_pt_lm, *fb_tx_off, *fb_tx_s1, *fb_tx_s2, *fb_tx_lm;
-};
-
-#define PT_REC 8
-#define TX_REC 28
-struct LinBuf {              // everything one linearisation produces
-    double *pairM, *pairCost, *pairR, *pairOut, *tgM, *tgCost;
-    double *w_pt;                       // per point slot, one 64-byte record: w[0..5] | v | b   (PT_REC doubles; the host slot of a landmark
-                                        // holds its host column -sum Q^T w in [0..5], formed by k_mid from w and the pair's R_cr)
-    double *V_pt, *b_pt, *dgs_pt;       // per point: V, b, clamp(sigma^2 V)/sigma^2  (lambda = dgs / radius)
-    double *w_tx;                       // per plane slot, one 224-byte record: W[0..17] | V6 [18..23] | b3 [24..26]   (TX_REC doubles)
-    double *V_tx, *b_tx, *dgs_tx;       // per plane: V [6][n], b [3][n], dgs [3][n]
-    double *Hd, *bp, *dgs_p;            // per pose: diag(H_pp), gradient, dgs.  Hd | bp | scal[8] are one allocation (hb):
-    double *bp_loc;                     // multi-GPU: this rank's part of bp (the reduced gradient is assembled from it)
-    double *lmpart;                     // per k_mid block: (gradient max, |x|^2) of its landmarks, cost of its pairs (+ their text groups)
-};
-
-struct PoseState;
-struct Work {                // device work buffers (sized for the largest level)
-    int n_kf, n_pt, n_text, n_tobs, N;      // N = 6 n_kf
-    int rank, world;                        // landmark shard of this process (global BA over RCCL), 0 / 1 otherwise
-    double K0[4];
-    double w_sx, w_sy, w_t, huber_s, huber_t;
-    int filter_good;
-    double min_diag, max_diag;
-    // parameters: double-buffered (x = buf[cur], candidate = buf[cur^1])
-    double *pose[2], *rho[2], *theta[2];
-    const double *pt_ray; const int *pt_host; const double *pt_Trw;
-    const int *text_host; const double *text_Twr; const double *text_box;
-    const int *tobs_kf, *tobs_text, *tobs_fgood_off;
-    uint8_t *sgood, *tobs_good, *tfgood;
-    double *musig;                      // [n_tobs][2]
-    int *kf_in, *kf_const, *act_pt, *act_tx;
-    int *fidx, *nfree;                  // compressed index of the free poses in S / g
-    double *cb, *cbm;                   // multi-GPU exchange buffers: cb = [Hd 6n | bp 6n | cost, |x_lm|^2, step^2, mcc] (sum), cbm = gradient max (max)
-    long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
-    double *LDbuf;                      // diagonal of the inverse diagonal factors (large-system Cholesky)
-    int ldS, band;                      // S(i,j) = S[i*ldS + j]; band: S holds only the band of the reduced camera matrix (large systems)
-    int ring;                           // 1: ring-shaped co-visibility (one loop closure, tsba_plan.h): the closure blocks -- the loop's first poses S against its last --
-                                        // live in ghost rows behind the last free pose (row = nfree + row - first row of S; nfree[1] = first row of S)
-    int ring_g, ring_b, ring_k0;        // interiors of the loop (worst case, a power of two); band = separator size in pose blocks; first keyframe of the loop
-    double *Sy;                         // right-hand-side row of the large-system solver (row n of the small one lives in LDS)
-    unsigned long long *hprog;          // pinned host word (seq << 32 | it << 1 | done): lets the host stop enqueuing a converged pass
-    unsigned int pass_seq;
-    // linearisation outputs, double-buffered: lb[lcur] belongs to x, lb[lcur^1] to the LM candidate (speculative)
-    LinBuf lb[2];
-    double *sig_pt, *sig_tx, *sig_p;    // Jacobi column scales, fixed at the first linearisation of a pass
-    double *S, *g, *dp, *dl_pt, *dl_tx;
-    double *partial;                    // [nblocks_back][2]
-    int *cntpart;                       // per k_participation workgroup: active scene blocks, active text blocks
-    double *posepart;                   // large maps: per k_pose_sums workgroup (21 poses): gradient max, |x|^2
-    LmState *st;
-    PoseState *pst; double *ppart;      // pose-only path (tsba_pose.h): double-buffered state, [2][G][28] partial sums
-    // band + long-range blocks, preconditioned conjugate gradients (tsba_pcg.h): the blocks outside the band [n_far][36] (rows: the earlier keyframe),
-    // the iteration's vectors in the compressed row space of S, per-workgroup partial sums [2][workgroups], double-buffered scalars, statistics
-    double *Sfar, *pc_x, *pc_r, *pc_p[2], *pc_q, *pc_g0, *pc_part;
-    struct PcgState *pcs; int *pc_stat;
-};
-
-#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(c, std::string(#x) + ": " + hipGetErrorString(e_)); return TSBA_ERR_DEVICE; } } while (0)
-
-// ------------------------------------------------------------------------------------------------ kernels
-__device__ __forceinline__ double wave_sum1(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-template <int NT>
-__device__ __forceinline__ double block_sum(double v, double *lds) {     // deterministic (fixed order), NT threads, all get the result
-    const int t = threadIdx.x;
-    lds[t] = v; __syncthreads();
-    if (t < 64) {
-        double s = lds[t];
-#pragma unroll
-        for (int k = 64; k < NT; k += 64) s += lds[t + k];
-        s = wave_sum1(s);
-        if (t == 0) lds[0] = s;
-    }
-    __syncthreads();
-    const double r = lds[0]; __syncthreads();
-    return r;
-}
-template <int NT>
-__device__ __forceinline__ double block_max(double v, double *lds) {
-    const int t = threadIdx.x;
-    lds[t] = v; __syncthreads();
-    if (t < 64) {
-        double s = lds[t];
-#pragma unroll
-        for (int k = 64; k < NT; k += 64) s = fmax(s, lds[t + k]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
-        if (t == 0) lds[0] = s;
-    }
-    __syncthreads();
-    const double r = lds[0]; __syncthreads();
-    return r;
-}
-
-// Sum over a variable-length gather list with U entries (index, then value) in flight per round trip instead of one:
-// val(idx) is evaluated for clamped indices and masked, the summation order is the list order.
-template <int U, class F>
-__device__ __forceinline__ double gather_sum(const int *list, int n, F &&val) {
-    double s = 0.0;
-    for (int base = 0; base < n; base += U) {
-        int idx[U]; double v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) idx[u] = list[min(base + u, n - 1)];
-#pragma unroll
-        for (int u = 0; u < U; u++) v[u] = val(idx[u]);
-#pragma unroll
-        for (int u = 0; u < U; u++) s += base + u < n ? v[u] : 0.0;
-    }
-    return s;
-}
-
-// contiguous range with U loads in flight per round trip, summed in index order
-template <int U>
-__device__ __forceinline__ double range_sum(const double *v, int i0, int i1) {
-    double s = 0.0;
-    for (int base = i0; base < i1; base += U) {
-        double x[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) x[u] = v[min(base + u, i1 - 1)];
-#pragma unroll
-        for (int u = 0; u < U; u++) s += base + u < i1 ? x[u] : 0.0;
-    }
-    return s;
-}
-
-// ---- start point of a solve: parameters (both buffers), inlier flags, LM state
-struct ResetSrc { const double *pose0, *rho0, *theta0; const uint8_t *sg0, *tg0, *tf0; long long n_pose, n_rho, n_theta, n_sg, n_tg, n_tf; };
-__global__ __launch_bounds__(256) void k_reset_state(Work W, ResetSrc A) {
-    const long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x, n = (long long)gridDim.x*blockDim.x;
-    for (long long k = t; k < A.n_pose; k += n) { const double v = A.pose0[k]; W.pose[0][k] = v; W.pose[1][k] = v; }
-    for (long long k = t; k < A.n_rho; k += n) { const double v = A.rho0[k]; W.rho[0][k] = v; W.rho[1][k] = v; }
-    for (long long k = t; k < A.n_theta; k += n) { const double v = A.theta0[k]; W.theta[0][k] = v; W.theta[1][k] = v; }
-    for (long long k = t; k < A.n_sg; k += n) W.sgood[k] = A.sg0[k];
-    for (long long k = t; k < A.n_tg; k += n) W.tobs_good[k] = A.tg0[k];
-    for (long long k = t; k < A.n_tf; k += n) W.tfgood[k] = A.tf0[k];
-    if (t == 0) memset(W.st, 0, sizeof(LmState));
-}
-
-// ---- pass initialisation
-__global__ void k_pass_reset(Work W, double radius0, int max_it) {
-    LmState *s = W.st;
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int cur = s->cur; long long nl = s->n_lin, nc = s->n_cost;
-        memset(s, 0, sizeof(LmState));
-        s->cur = cur; s->n_lin = nl; s->n_cost = nc;
-        s->radius = radius0; s->decrease_factor = 2.0; s->need_lin = 1; s->first = 1; s->max_it = max_it;
-        if (W.hprog) { *W.hprog = (unsigned long long)W.pass_seq << 32; __threadfence_system(); }
-    }
-    int t = blockIdx.x*blockDim.x + threadIdx.x, n = gridDim.x*blockDim.x;
-    for (int k = t; k < W.n_kf; k += n) { W.kf_in[k] = 0; W.kf_const[k] = 0; }
-    for (int k = t; k < W.n_pt; k += n) W.act_pt[k] = 0;
-    for (int k = t; k < W.n_text; k += n) W.act_tx[k] = 0;
-}
-
-// which candidates are active (good flags), which keyframes participate (FLAG_KFIN, optimizer.cc:1410-1411,1428,1514-1515)
-__global__ __launch_bounds__(256) void k_participation(Work W, LevelDev L, int partials) {
-    // workgroups 0 .. nb_sc-1: one scene candidate per thread; the rest: one (KF, text) group per WAVE, its features on the lanes
-    // (a thread walking the 64 features of a group alone was most of this kernel's 14 us)
-    __shared__ int cnt_s, cnt_t;
-    if (threadIdx.x == 0) { cnt_s = 0; cnt_t = 0; }
-    __syncthreads();
-    const int nb_sc = (L.n_sc + 255) >> 8, lane = threadIdx.x & 63;
-    if ((int)blockIdx.x < nb_sc) {
-        const int t = blockIdx.x*256 + threadIdx.x;
-        bool act = false;
-        if (t < L.n_sc) {
-            act = !W.filter_good || W.sgood[L.sc_flag[t]];
-            if (act) {
-                int pt = L.sc_pt[t], h = W.pt_host[pt];
-                W.kf_in[L.sc_kf[t]] = 1;
-                if (h >= 0) { W.kf_in[h] = 1; W.act_pt[pt] = 1; }
-            }
-        }
-        const int nw = __popcll(__ballot(act));
-        if (lane == 0 && nw) atomicAdd(&cnt_s, nw);
-    } else {
-        const int g = (blockIdx.x - nb_sc)*4 + (threadIdx.x >> 6);
-        if (g < L.n_tg) {
-            const int tb = L.tg_tobs[g], j = L.tg_text[g];
-            if (!W.filter_good || W.tobs_good[tb]) {
-                const int f0 = L.tfeat_off[j], f1 = L.tfeat_off[j+1], fg = W.tobs_fgood_off[tb];
-                int cnt = 0;
-                for (int f = f0 + lane; f < f1; f += 64) if (!W.filter_good || W.tfgood[fg + L.tfeat_raw[f]]) cnt++;
-                cnt = (int)wave_sum1((double)cnt);
-                if (lane == 0 && cnt > 0) {
-                    const int h = W.text_host[j];
-                    W.kf_in[L.tg_kf[g]] = 1;
-                    if (h >= 0) { W.kf_in[h] = 1; W.act_tx[j] = 1; }
-                    atomicAdd(&cnt_t, cnt);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // single GPU: per-workgroup partials, summed by the gauge kernel; multi-GPU: the counts are all-reduced before the gauge
-        // kernel runs, so they go straight to the state
-        if (partials) { W.cntpart[2*blockIdx.x] = cnt_s; W.cntpart[2*blockIdx.x + 1] = cnt_t; }
-        else { if (cnt_s) atomicAdd(&W.st->ns_active, cnt_s); if (cnt_t) atomicAdd(&W.st->nt_active, cnt_t); }
-    }
-}
-// block counts of k_participation -> LM state (called by the gauge kernels' first wave / all threads)
-__device__ __forceinline__ void sum_counts(const Work &W, int ncp, int tid, int nthreads, int *lds2 /* [2] zeroed */) {
-    int a = 0, b = 0;
-    for (int k = tid; k < ncp; k += nthreads) { a += W.cntpart[2*k]; b += W.cntpart[2*k + 1]; }
-    if (a) atomicAdd(&lds2[0], a);
-    if (b) atomicAdd(&lds2[1], b);
-}
-// gauge fixing, optimizer.cc:1562-1588 / :1825-1830
-__global__ void k_gauge(Work W, const uint8_t *kf_initial, int state, int ncp, const int *order) {
-    __shared__ int s_cnt2[2];
-    if (threadIdx.x == 0) { s_cnt2[0] = 0; s_cnt2[1] = 0; }
-    __syncthreads();
-    if (ncp) { sum_counts(W, ncp, threadIdx.x, blockDim.x, s_cnt2); __syncthreads(); if (threadIdx.x == 0) { W.st->ns_active = s_cnt2[0]; W.st->nt_active = s_cnt2[1]; } }
-    if (threadIdx.x || blockIdx.x) return;
-    int cnt = 0;
-    for (int k = 0; k < W.n_kf; k++) { if (kf_initial[k] && W.kf_in[k]) W.kf_const[k] = 1; cnt += W.kf_in[k]; }
-    if (state == TSBA_STATE_LOCAL && cnt > 3) {
-        int fixed = 0;
-        for (int k = 0; k < W.n_kf && fixed < 3; k++) if (W.kf_in[k]) { W.kf_const[k] = 1; fixed++; }
-    }
-    int nf = 0;                                                // rows of S: free poses in keyframe order, or in the plan's order
-    int row0 = 0;
-    for (int i = 0; i < W.n_kf; i++) { const int k = order ? order[i] : i; if (i == W.ring_k0) row0 = nf; W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? nf++ : -1; }
-    W.nfree[0] = nf; W.nfree[1] = row0;                         // (ring maps: free poses before the loop's first keyframe)
-}
-
-// windows of up to 64 keyframes: one lane per keyframe, ballots instead of the serial walk (7.8 -> ~2 us per pass)
-__global__ __launch_bounds__(64) void k_gauge_wave(Work W, const uint8_t *kf_initial, int state, int ncp) {
-    __shared__ int s_cnt2[2];
-    const int k = threadIdx.x;
-    if (k == 0) { s_cnt2[0] = 0; s_cnt2[1] = 0; }
-    __syncthreads();
-    if (ncp) { sum_counts(W, ncp, k, 64, s_cnt2); __syncthreads(); if (k == 0) { W.st->ns_active = s_cnt2[0]; W.st->nt_active = s_cnt2[1]; } }
-    const bool on = k < W.n_kf;
-    const int in = on ? W.kf_in[k] : 0, ini = on ? kf_initial[k] : 0;
-    const unsigned long long m_in = __ballot(in != 0);
-    int cst = (ini && in) ? 1 : 0;
-    if (state == TSBA_STATE_LOCAL && __popcll(m_in) > 3) {
-        const int before = __popcll(m_in & ((1ull << k) - 1));      // participating keyframes with a smaller index
-        if (in && before < 3) cst = 1;                               // the first three of them are held constant
-    }
-    const bool fre = in && !cst;
-    const unsigned long long m_free = __ballot(fre);
-    if (on) { W.kf_const[k] = cst; W.fidx[k] = fre ? __popcll(m_free & ((1ull << k) - 1)) : -1; }
-    if (k == 0) { W.nfree[0] = __popcll(m_free); W.nfree[1] = 0; }
-}
-// the same for large maps: 1024 threads, consecutive keyframes per thread, one block-wide exclusive scan for the compressed indices
-// (the single-thread walk above costs 1.4 ms at 5000 keyframes)
-__global__ __launch_bounds__(1024) void k_gauge_par(Work W, const uint8_t *kf_initial, int state, int ncp, const int *order) {
-    __shared__ int s_scan[1024]; __shared__ int s_first[3]; __shared__ int s_cnt; __shared__ int s_cnt2[2];
-    if (threadIdx.x == 0) { s_cnt2[0] = 0; s_cnt2[1] = 0; }
-    __syncthreads();
-    if (ncp) { sum_counts(W, ncp, threadIdx.x, 1024, s_cnt2); __syncthreads(); if (threadIdx.x == 0) { W.st->ns_active = s_cnt2[0]; W.st->nt_active = s_cnt2[1]; } }
-    const int tid = threadIdx.x, per = (W.n_kf + 1023)/1024, k0 = tid*per, k1 = min(W.n_kf, k0 + per);
-    if (tid == 0) {                                           // STATE_LOCAL: the first three participating keyframes are held constant
-        int f = 0; s_first[0] = s_first[1] = s_first[2] = -1;
-        if (state == TSBA_STATE_LOCAL) for (int k = 0; k < W.n_kf && f < 3; k++) if (W.kf_in[k]) s_first[f++] = k;
-    }
-    int cin = 0;
-    for (int k = k0; k < k1; k++) cin += W.kf_in[k];
-    s_scan[tid] = cin; __syncthreads();
-    for (int d = 512; d > 0; d >>= 1) { if (tid < d) s_scan[tid] += s_scan[tid + d]; __syncthreads(); }
-    if (tid == 0) s_cnt = s_scan[0];
-    __syncthreads();
-    const bool fix3 = state == TSBA_STATE_LOCAL && s_cnt > 3;
-    int nfree = 0;                                             // from here on a thread's range is a range of POSITIONS (= keyframes without a plan order)
-    for (int i = k0; i < k1; i++) {
-        const int k = order ? order[i] : i;
-        int cst = (kf_initial[k] && W.kf_in[k]) ? 1 : 0;
-        if (fix3 && (k == s_first[0] || k == s_first[1] || k == s_first[2])) cst = 1;
-        W.kf_const[k] = cst;
-        nfree += (W.kf_in[k] && !cst) ? 1 : 0;
-    }
-    __syncthreads();
-    s_scan[tid] = nfree; __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) { const int t = tid >= d ? s_scan[tid - d] : 0; __syncthreads(); s_scan[tid] += t; __syncthreads(); }
-    int at = s_scan[tid] - nfree;                              // exclusive prefix
-    if (tid == 0) W.nfree[1] = 0;
-    __syncthreads();
-    for (int i = k0; i < k1; i++) { const int k = order ? order[i] : i; if (i == W.ring_k0 && i > 0) W.nfree[1] = at; W.fidx[k] = (W.kf_in[k] && !W.kf_const[k]) ? at++ : -1; }
-    if (tid == 1023) W.nfree[0] = s_scan[1023];
-}
-
-// ---- mu / sigma of a projected text box: tool::GetProjText x4 + tool::CalTextinfo (src/tool.cc:1178-1262,1655-1728)
-// with cv::fillPoly's scan conversion (boundary Bresenham lines + 16.16 fixed-point scanline spans).  One workgroup per
-// (KF, text) observation; the polygon mask of the clamped bounding box lives in LDS as a bit field.
-#define MS_THREADS 256
-__device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, const int g, const double *pose, const double *theta) {
-    __shared__ unsigned mask[MS_MASK_WORDS];
-    __shared__ unsigned hist[256];
-    __shared__ int s_xy[8], s_bb[4];
-    __shared__ double s_red[MS_THREADS];
-    const int tid = threadIdx.x;
-    int tb = L.tg_tobs[g], kf = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
-    if (W.filter_good && !W.tobs_good[tb]) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
-    const int w = L.img_w, hh = L.img_h;
-    __shared__ int s_c[16];
-    if (tid < 4) {                                            // one box corner per lane (the serial walk over the four cost ~1.5 us of divisions)
-        const int b = tid;
-        Pose C; load_pose(pose + 7*kf, C);
-        PairT T;
-        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
-        else pair_from_Twr(C, W.text_Twr + 12*j, T);
-        double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-        double mx = W.text_box[(j*4 + b)*2], my = W.text_box[(j*4 + b)*2 + 1];
-        double invz = -(mx*th[0] + my*th[1] + th[2]);
-        double m[3] = { mx, my, 1.0 }, Rm[3]; mat3_vec(T.Rcr, m, Rm);
-        double X = Rm[0]/invz + T.tq[0] + C.t[0], Y = Rm[1]/invz + T.tq[1] + C.t[1], Z = Rm[2]/invz + T.tq[2] + C.t[2];
-        double cu = L.K[0]*X/Z + L.K[2], cv = L.K[1]*Y/Z + L.K[3];
-        s_xy[2*b] = (int)cu; s_xy[2*b+1] = (int)cv;
-        // the reference updates xMax / xMin only on strict improvement, starting from -1 / w + 1: a corner that does not improve
-        // contributes nothing -- the same as taking max / min over the corners that do
-        s_c[4*b] = cu > -1.0 ? (int)ceil(cu) : -1;            // candidate for xMax (initial value -1)
-        s_c[4*b + 1] = cu < (double)(w + 1) ? (int)floor(cu) : w + 1;
-        s_c[4*b + 2] = cv > -1.0 ? (int)ceil(cv) : -1;
-        s_c[4*b + 3] = cv < (double)(hh + 1) ? (int)floor(cv) : hh + 1;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int xMax = max(max(s_c[0], s_c[4]), max(s_c[8], s_c[12])), xMin = min(min(s_c[1], s_c[5]), min(s_c[9], s_c[13]));
-        int yMax = max(max(s_c[2], s_c[6]), max(s_c[10], s_c[14])), yMin = min(min(s_c[3], s_c[7]), min(s_c[11], s_c[15]));
-        if (xMin < 0) xMin = 0;
-        if (xMin >= w) xMin = w - 1;
-        if (yMin < 0) yMin = 0;
-        if (yMin >= hh) yMin = hh - 1;
-        if (xMax >= w) xMax = w - 1;
-        if (xMax < 0) xMax = 0;
-        if (yMax >= hh) yMax = hh - 1;
-        if (yMax < 0) yMax = 0;
-        s_bb[0] = xMin; s_bb[1] = xMax; s_bb[2] = yMin; s_bb[3] = yMax;
-    }
-    for (int k = tid; k < min((w*hh + 31) >> 5, MS_MASK_WORDS); k += MS_THREADS) mask[k] = 0;
-    hist[tid] = 0;
-    __syncthreads();
-    const int xMin = s_bb[0], xMax = s_bb[1], yMin = s_bb[2], yMax = s_bb[3];
-    raster_quad(mask, s_xy, w, hh, tid, MS_THREADS);
-    __syncthreads();
-    // histogram of masked pixels inside the clamped bounding box (tool.cc:1217-1232)
-    const uint8_t *img = L.img[kf];
-    int bw = xMax - xMin + 1, bh = yMax - yMin + 1;
-    {   // four pixels per thread and round with their loads in flight together; (x, y) advance without a division per pixel
-        const int npx = bw*bh, dx = MS_THREADS % bw, dy = MS_THREADS / bw;
-        int x = tid % bw, y = tid / bw;
-        for (int k0 = tid; k0 < npx; k0 += 4*MS_THREADS) {
-            int bit[4]; bool in[4]; unsigned px[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                bit[u] = (yMin + y)*w + xMin + x;
-                in[u] = k0 + u*MS_THREADS < npx && (mask[bit[u] >> 5] & (1u << (bit[u] & 31)));
-                x += dx; y += dy; if (x >= bw) { x -= bw; y++; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) px[u] = in[u] ? img[bit[u]] : 0u;
-#pragma unroll
-            for (int u = 0; u < 4; u++) if (in[u]) atomicAdd(&hist[px[u]], 1u);
-        }
-    }
-    __syncthreads();
-    double cnt = (double)hist[tid], sum = (double)hist[tid]*(double)tid;
-    double n = block_sum<MS_THREADS>(cnt, s_red), sm = block_sum<MS_THREADS>(sum, s_red);
-    if (n < 2.0) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
-    double mu = sm/n;
-    double d = (double)tid - mu;
-    double ss = block_sum<MS_THREADS>((double)hist[tid]*d*d, s_red);
-    if (tid == 0) { W.musig[2*tb] = mu; W.musig[2*tb+1] = sqrt(ss/(n - 1.0)); }
-}
-
-__global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
-    musigma_wg(W, L, blockIdx.x, W.pose[W.st->cur], W.theta[W.st->cur]);
-}
-
-// ---- text label image of one keyframe (optimizer::ShowBAReproj_TextBox -> tool::TextBoxWithFill, optimizer.cc:2508-2582,
-// tool.cc:2103-2166): background -1, then every text observation of the keyframe in observation order fills its projected quad
-// with its rank; later quads overwrite earlier ones, so ONE workgroup walks the observations sequentially (a keyframe sees a few
-// dozen planes) and only the rasterisation of each quad is parallel.
-#define LBL_THREADS 1024
-__global__ __launch_bounds__(LBL_THREADS) void k_label(Work W, int kf, int w, int hh, double fx, double fy, double cx, double cy, float *out) {
-    __shared__ unsigned mask[MS_MASK_WORDS];
-    __shared__ int s_xy[8], s_bb[4];
-    const int tid = threadIdx.x;
-    const double *pose = W.pose[W.st->cur], *theta = W.theta[W.st->cur];
-    for (int k = tid; k < w*hh; k += LBL_THREADS) out[k] = -1.0f;
-    int rank = 0;
-    for (int t = 0; t < W.n_tobs; t++) {
-        if (W.tobs_kf[t] != kf) continue;                   // (uniform)
-        const int j = W.tobs_text[t], h = W.text_host[j];
-        if (tid == 0) {
-            Pose C; load_pose(pose + 7*kf, C);
-            PairT T;
-            if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
-            else pair_from_Twr(C, W.text_Twr + 12*j, T);
-            const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-            int xMin = w, xMax = -1, yMin = hh, yMax = -1;
-            for (int b = 0; b < 4; b++) {
-                const double mx = W.text_box[(j*4 + b)*2], my = W.text_box[(j*4 + b)*2 + 1];
-                const double invz = -(mx*th[0] + my*th[1] + th[2]);
-                double m[3] = { mx, my, 1.0 }, Rm[3]; mat3_vec(T.Rcr, m, Rm);
-                const double X = Rm[0]/invz + T.tq[0] + C.t[0], Y = Rm[1]/invz + T.tq[1] + C.t[1], Z = Rm[2]/invz + T.tq[2] + C.t[2];
-                const double cu = fx*X/Z + cx, cv = fy*Y/Z + cy;
-                const int iu = (int)cu, iv = (int)cv;                 // cv::Point(double, double): truncation
-                s_xy[2*b] = iu; s_xy[2*b+1] = iv;
-                xMin = min(xMin, iu); xMax = max(xMax, iu); yMin = min(yMin, iv); yMax = max(yMax, iv);
-            }
-            s_bb[0] = max(xMin, 0); s_bb[1] = min(xMax, w - 1); s_bb[2] = max(yMin, 0); s_bb[3] = min(yMax, hh - 1);
-        }
-        for (int k = tid; k < MS_MASK_WORDS; k += LBL_THREADS) mask[k] = 0;
-        __syncthreads();
-        raster_quad(mask, s_xy, w, hh, tid, LBL_THREADS);
-        __syncthreads();
-        const int x0 = s_bb[0], x1 = s_bb[1], y0 = s_bb[2], y1 = s_bb[3];     // the filled set lies inside the corners' bounding box
-        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-        if (bw > 0 && bh > 0)
-            for (int k = tid; k < bw*bh; k += LBL_THREADS) {
-                const int x = x0 + k % bw, y = y0 + k / bw, bit = y*w + x;
-                if (mask[bit >> 5] & (1u << (bit & 31))) out[bit] = (float)rank;
-            }
-        rank++;
-        __syncthreads();
-    }
-}
-
-// ---- linearisation / cost.  grid = n_pair (scene waves) + n_tg (text waves), 64 threads each.
-#define MODE_FULL 0
-#define MODE_COST 1
-// transpose-sum of N <= 28 per-lane values of ONE wave inside a two-wave workgroup: lane l (< N) returns the total of acc[l].
-// reg: this wave's 28*65 doubles.  Both waves of the workgroup must call it (two workgroup barriers).
-template <int N>
-__device__ __forceinline__ double wave_sum_to_lane_mw(const double *acc, double *reg, int lane) {
-#pragma unroll
-    for (int i = 0; i < N; i++) reg[i*65 + lane] = acc[i];
-    __syncthreads();
-    double s = 0.0;
-    if (lane < N) {
-        const double *row = reg + lane*65;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 64; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
-        s = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    return s;
-}
-// the same for FOUR 16-lane groups per wave (small pairs share a wave): lane (group g, sub s) returns the group totals of acc[s] and
-// acc[s + 16] (the latter only for s + 16 < N).  Both waves of the workgroup must call it.
-template <int N>
-__device__ __forceinline__ void wave_sum_groups16_mw(const double *acc, double *reg, int lane, double &t0, double &t1) {
-#pragma unroll
-    for (int i = 0; i < N; i++) reg[i*65 + lane] = acc[i];
-    __syncthreads();
-    const int g16 = lane & 48, sub = lane & 15;
-    {
-        const double *row = reg + sub*65 + g16;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
-        t0 = (s0 + s1) + (s2 + s3);
-    }
-    t1 = 0.0;
-    if (sub + 16 < N) {
-        const double *row = reg + (sub + 16)*65 + g16;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
-        t1 = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-}
-// 128-thread workgroups: a scene workgroup takes two (target, host) pairs (one per wave) -- or, PPW = 4 for maps whose pairs hold a
-// dozen scene blocks (thousands of keyframes: a 64-lane wave per pair was 85 % idle), eight pairs, one per 16-lane group; a text workgroup one (KF, text)
-// observation with every feature on TWO lanes (4 taps each): the text lanes' instruction stream (~450 instructions per tap at
-// one instruction per ~4.5 cycles) is what bounds the kernel.  <= 256 VGPRs so that all ~730 workgroups of C4 are resident at once.
-#define LIN_TPL 4                        // photometric taps per lane: a feature's 8 taps sit on 8 / LIN_TPL neighbouring lanes.  4 = two lanes per
-                                         // feature, 128-thread workgroups.  2 (four lanes per feature, 256 threads) was measured in round 2: the C4
-                                         // level-0 launch went from 12.6 to 14.8 us -- the 55-value workgroup reduction is paid per wave, and
-                                         // halving a lane's tap loop does not pay for twice the waves
-#define LIN_T (64*(8/LIN_TPL))           // 64 features per text workgroup
-#define LIN_NWV (LIN_T/64)
-#define MID_U 4                          // slot records of a point that k_mid keeps in flight per round trip
-// TEXT = false: levels without text planes (the reference's GlobalBA): the scene path alone needs far fewer registers than the text path.
-template <int MODE, int PPW = 1, bool TEXT = true>
-__global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, LevelDev L, int spec) {
-    // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
-    const LmState *st = W.st;
-    constexpr int NWV = LIN_T/64, TPL = LIN_TPL, LPF = 8/LIN_TPL;   // waves per workgroup; taps per lane; lanes per feature
-    __shared__ double lds[NWV*28*65 + NWV*64];
-    __shared__ unsigned s_px[TEXT ? TPL*LIN_T : 1];          // the text path's pixel quads (four bytes): indexed by tap at run time (not registers)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *reg = lds + wave*28*65, *xw = lds + NWV*28*65;
-    // static indices of this workgroup first: in flight together with the LM state
-    constexpr int LPP = 64/PPW;                              // lanes per pair
-    const int nb_sc = (L.n_pair + NWV*PPW - 1)/(NWV*PPW);
-    const int sub = PPW == 1 ? lane : (lane & (LPP - 1));
-    // (scene-only launches: the workgroups of ONE XCD -- workgroup i runs on XCD i mod 8 -- take neighbouring pairs: the 64-byte slot records
-    // of a landmark's observers share 128-byte lines, and neighbouring pairs observe the same landmarks.  With text groups the same mapping
-    // was measured SLOWER on C4 (13.6 vs 13.0 us): the groups are the heavy workgroups and sit at the end of the index range -- contiguous
-    // ranges put all of them on the last two XCDs.)  The grid is a multiple of 8 workgroups either way.
-    // (Dispatching the text groups FIRST -- lowest workgroup indices -- was no better either: 13.2 us.)
-    const int bq = TEXT ? (int)blockIdx.x : ((int)blockIdx.x & 7)*((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
-    if (bq >= nb_sc + (TEXT ? L.n_tg : 0)) return;
-    const int pr = (NWV*bq + wave)*PPW + (PPW == 1 ? 0 : lane/LPP), prc = min(pr, max(L.n_pair - 1, 0));
-    int pi = 0, ph = 0, pbeg = 0, pend = 0, tgpp = 0; int4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
-    if (bq < nb_sc) { pi = L.pair_i[prc]; ph = L.pair_h[prc]; pbeg = L.pair_sc_off[prc]; pend = pr < L.n_pair ? L.pair_sc_off[prc+1] : pbeg; }
-    else if (TEXT) { ra = ((const int4 *)L.tg_rec)[2*(bq - nb_sc)]; rb = ((const int4 *)L.tg_rec)[2*(bq - nb_sc) + 1]; tgpp = L.tg_ppos[bq - nb_sc]; }   // one static record per group
-    if (st->done) return;
-    if (!spec && !st->need_lin) return;
-    if (spec && st->step_fail) return;
-    const int sel = spec ? (st->cur ^ 1) : st->cur;
-    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
-    const double *pose = W.pose[sel], *rho = W.rho[sel], *theta = W.theta[sel];
-    const int b = bq;
-    if (b < nb_sc) {
-        // ---------------- scene observations of pair (i, h)
-        const int i = pi, h = ph;
-        Pose C; load_pose(pose + 7*i, C);
-        PairT T;
-        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
-        const bool fixed = (h < 0) && W.kf_const[i];           // all parameter blocks constant: not in the reduced program
-        double acc[28];
-#pragma unroll
-        for (int k = 0; k < 28; k++) acc[k] = 0.0;
-        const int beg = pbeg, end = pend;
-#pragma unroll 1
-        for (int c = beg + sub; c < end; c += LPP) {
-            const int slot = L.sc_slot[c], pt = L.sc_pt[c];
-            const bool act = !fixed && (!W.filter_good || W.sgood[L.sc_flag[c]]);
-            // the slot record of an inactive candidate is zeros: one store sequence for both cases (a second, branchy one
-            // costs the kernel ~170 VGPRs of live ranges)
-            double wv[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) wv[k] = 0.0;
-            if (act) {
-                if (h < 0) pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
-                const double mx = W.pt_ray[2*pt], my = W.pt_ray[2*pt+1], rh = rho[pt];
-                const double uo = L.sc_uv[2*c], vo = L.sc_uv[2*c+1];
-                double r[2], jt[2][6], jl[2];
-                scene_block(T, C.t, mx, my, rh, uo, vo, W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r, jt, jl);
-                double wgt; acc[27] += 0.5*huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
-                int q = 0;
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int cc = a; cc < 6; cc++) { acc[q] += wgt*(jt[0][a]*jt[0][cc] + jt[1][a]*jt[1][cc]); q++; }
-#pragma unroll
-                for (int a = 0; a < 6; a++) acc[21 + a] += wgt*(jt[0][a]*r[0] + jt[1][a]*r[1]);
-#pragma unroll
-                for (int a = 0; a < 6; a++) wv[a] = wgt*(jt[0][a]*jl[0] + jt[1][a]*jl[1]);
-                wv[6] = wgt*(jl[0]*jl[0] + jl[1]*jl[1]);
-                wv[7] = wgt*(jl[0]*r[0] + jl[1]*r[1]);
-            }
-            if (slot >= 0) {                         // (the host column -Q^T w is a function of w and the pair's R_cr: k_mid forms it)
-#pragma unroll
-                for (int k = 0; k < 8; k++) B.w_pt[(size_t)(slot)*PT_REC + k] = wv[k];
-            }
-        }
-        if (MODE == MODE_COST) {
-            double cs = acc[27];
-            if (PPW == 1) cs = wave_sum1(cs);
-            else {
-#pragma unroll
-                for (int o = LPP/2; o > 0; o >>= 1) cs += __shfl_xor(cs, o, LPP);
-            }
-            if (sub == 0 && pr < L.n_pair) B.pairCost[pr] = cs;
-        } else if (PPW > 1) {
-            double t0, t1;
-            wave_sum_groups16_mw<28>(acc, reg, lane, t0, t1);
-            if (pr < L.n_pair) {
-                B.pairM[(size_t)sub*L.n_pair + pr] = t0;                       // values 0 .. 15
-                if (sub + 16 < 27) B.pairM[(size_t)(sub + 16)*L.n_pair + pr] = t1;
-                else if (sub + 16 == 27) B.pairCost[pr] = t1;
-                if (h >= 0 && sub == 0) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) B.pairR[(size_t)k*L.n_pair + pr] = T.Rcr[k];
-                }
-            }
-        } else {
-            double tot = wave_sum_to_lane_mw<28>(acc, reg, lane);
-            if (pr < L.n_pair) {
-                if (lane < 27) B.pairM[(size_t)lane*L.n_pair + pr] = tot;
-                else if (lane == 27) B.pairCost[pr] = tot;
-                if (h >= 0 && lane == 0) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) B.pairR[(size_t)k*L.n_pair + pr] = T.Rcr[k];
-                }
-            }
-        }
-    } else if constexpr (TEXT) {
-        // ---------------- photometric blocks of one (KF, text) observation: thread = (feature tid / LPF, tap group tid % LPF)
-        const int g = b - nb_sc;
-        const int tb = ra.x, i = ra.y, j = ra.z, h = ra.w, slot = rb.x, f0 = rb.y, f1 = rb.z, fg = rb.w;
-        const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
-        const bool act_g = (!W.filter_good || W.tobs_good[tb]) && !((h < 0) && W.kf_const[i]) && sigma != 0.0;
-        // static data of this thread's first feature: fetched together with the level-2 operands, not after them
-        const int fl = tid/LPF, tp = tid % LPF;
-        int f = f0 + fl, raw = 0; double fu = 0.0, fv = 0.0, refv[TPL];
-#pragma unroll
-        for (int k = 0; k < TPL; k++) refv[k] = 0.0;
-        if (f1 > f0) {
-            const int fc = min(f, f1 - 1);
-            raw = L.tfeat_raw[fc]; fu = L.tfeat_uv[2*fc]; fv = L.tfeat_uv[2*fc+1];
-#pragma unroll
-            for (int k = 0; k < TPL; k++) refv[k] = L.tfeat_ref[8*(size_t)fc + TPL*tp + k];
-        }
-        PairT T;
-        // poses / plane / image pointer do not wait for the activity test (h is known from the record)
-        Pose C; load_pose(pose + 7*i, C);
-        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
-        else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
-        const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-        const uint8_t *img = L.img[i];
-        const double inv_sigma = 1.0/sigma;
-        const double ifx = 1.0/L.K[0], ify = 1.0/L.K[1];
-        double tot = 0.0;                       // lane l < 55 of wave 0: running total of value l
-        // chunks of 64 features (one chunk unless the plane has more).  One accumulator set only: the weighted block of the
-        // thread's half feature is reduced per chunk, so that it stays inside the architectural VGPRs
-        for (int fb = f0; fb == f0 || fb < f1; fb += 64, f += 64) {
-            double blk[55];
-#pragma unroll
-            for (int k = 0; k < 55; k++) blk[k] = 0.0;
-            if (act_g) {                                               // (uniform; the shuffle below needs both lanes of a feature)
-                const bool in = f < f1;
-                if (fb != f0 && in) {
-                    raw = L.tfeat_raw[f]; fu = L.tfeat_uv[2*f]; fv = L.tfeat_uv[2*f+1];
-#pragma unroll
-                    for (int k = 0; k < TPL; k++) refv[k] = L.tfeat_ref[8*(size_t)f + TPL*tp + k];
-                }
-                const uint8_t good = in ? (W.filter_good ? W.tfgood[fg + raw] : (uint8_t)1) : (uint8_t)0;   // in flight with the pixel fetches
-                // the pixel-pair fetches of all the thread's taps in flight before the first residual; the quads wait in LDS so that
-                // the residual loop can stay rolled (unrolled, its live state does not fit 256 VGPRs and spills to scratch)
-#pragma unroll
-                for (int k = 0; k < TPL; k++) {
-                    const int kt = TPL*tp + k;
-                    const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;   // tool.cc:1561
-                    const TapPx q = tap_fetch(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h);
-                    s_px[k*LIN_T + tid] = (unsigned)q.I00 | ((unsigned)q.I01 << 8) | ((unsigned)q.I10 << 16) | ((unsigned)q.I11 << 24);
-                }
-                double s = 0.0;
-#pragma unroll 1
-                for (int k = 0; k < TPL; k++) {
-                    const int kt = TPL*tp + k;
-                    const double mx = (fu + TAP_DX[kt] - L.K[2])*ifx, my = (fv + TAP_DY[kt] - L.K[3])*ify;
-                    const unsigned q4 = s_px[k*LIN_T + tid];
-                    const TapPx pxk = { (int)(q4 & 0xff), (int)((q4 >> 8) & 0xff), (int)((q4 >> 16) & 0xff), (int)(q4 >> 24) };
-                    double rf = refv[0];
-#pragma unroll
-                    for (int q = 1; q < TPL; q++) if (k == q) rf = refv[q];
-                    double jt[6], jl[3];
-                    double r = text_tap_px(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], pxk, L.img_w, L.img_h,
-                                           mu, sigma, inv_sigma, rf, W.w_t, true, jt, jl);
-                    s += r*r;
-                    int q = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-#pragma unroll
-                        for (int cc = a; cc < 6; cc++) { blk[q] += jt[a]*jt[cc]; q++; }
-#pragma unroll
-                    for (int a = 0; a < 6; a++) blk[21 + a] += jt[a]*r;
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-#pragma unroll
-                        for (int cc = 0; cc < 3; cc++) blk[27 + a*3 + cc] += jt[a]*jl[cc];
-                    blk[45] += jl[0]*jl[0]; blk[46] += jl[0]*jl[1]; blk[47] += jl[0]*jl[2];
-                    blk[48] += jl[1]*jl[1]; blk[49] += jl[1]*jl[2]; blk[50] += jl[2]*jl[2];
-                    blk[51] += jl[0]*r; blk[52] += jl[1]*r; blk[53] += jl[2]*r;
-                }
-                double s8 = s;                                      // the block's squared norm: its 8 taps sit on LPF neighbouring lanes
-#pragma unroll
-                for (int q = 1; q < LPF; q <<= 1) s8 += __shfl_xor(s8, q, 64);
-                double wgt; const double rho_h = 0.5*huber(s8, W.huber_t, wgt);
-                const double wg = good ? wgt : 0.0;
-#pragma unroll
-                for (int k = 0; k < 54; k++) blk[k] *= wg;
-                blk[54] = (good && tp == 0) ? rho_h : 0.0;
-            }
-            // 55 sums over the workgroup's threads: per wave two transposes (28 + 27 values), then the waves (fixed order)
-            const double t0 = wave_sum_to_lane_mw<28>(blk, reg, lane);
-            const double t1 = wave_sum_to_lane_mw<27>(blk + 28, reg, lane);
-            if (lane < 28) xw[wave*64 + lane] = t0;
-            if (lane < 27) xw[wave*64 + 28 + lane] = t1;
-            __syncthreads();
-            if (lane < 55) { double part = xw[lane];
-#pragma unroll
-                for (int q = 1; q < NWV; q++) part += xw[q*64 + lane];
-                tot += part; }
-            __syncthreads();
-        }
-        if (wave > 0) return;
-        // wave 0 alone from here (LDS accesses of one wave are ordered; the fence keeps the compiler honest)
-        if (lane < 27) B.tgM[(size_t)lane*L.n_tg + tgpp] = tot;          // pair-major rank: k_mid sums a contiguous range
-        else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; }
-        else if (lane < 54) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + 18 + (lane - 45)] = tot; }
-        else if (lane == 54) B.tgCost[tgpp] = tot;                       // pair-major rank as well: k_mid adds it to its pair's cost
-        // (the host column of W, -blkdiag(R,R)^T W, is formed by k_mid from W and the pair's R_cr; an inactive group leaves W = 0)
-    }
-}
-
-// ---- per landmark: V, b, host column of W (= -sum Q^T w);  per pair: host-side products.  256-thread blocks.
-__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int spec) {
-    const LmState *st = W.st;
-    const int b = blockIdx.x;
-    // static offsets of this thread's landmark / pair first: in flight together with the LM state
-    int o = 0, e = 0, tq0 = 0, tq1 = 0, ph_ = -1, hp_ = -1, act_ = 0, pr0[MID_U] = {0, 0, 0, 0};
-    if (b < nb_pt) { const int j = b*256 + threadIdx.x; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
-#pragma unroll
-        for (int u = 0; u < MID_U; u++) pr0[u] = L.pt_pair4[MID_U*(size_t)j + u]; } }
-    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + threadIdx.x; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
-    else { const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x; if (p < L.n_pair) { tq0 = L.pair_tg_off[p]; tq1 = L.pair_tg_off[p+1]; ph_ = L.pair_h[p]; hp_ = L.pair_hpos[p]; } }
-    if (st->done) return;
-    if (!spec && !st->need_lin) return;
-    if (spec && st->step_fail) return;
-    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
-    const int sel = spec ? (st->cur ^ 1) : st->cur;
-    __shared__ double red[256];
-    const double *rho_x = W.rho[sel], *theta_x = W.theta[sel];
-    const size_t np_ = L.n_pair;
-    double gm = 0.0, xn = 0.0, cs = 0.0;                        // cs: cost of this thread's pair and of its text groups
-    if (b < nb_pt) {
-        const int j = b*256 + threadIdx.x;
-        if (e > o) {
-            double acc[8] = {0,0,0,0,0,0,0,0};                       // V, b, host column -sum Q^T w
-            for (int s0 = o; s0 < e - 1; s0 += MID_U) {              // MID_U slot records (and their pairs' R_cr) in flight per round trip
-                int pr[MID_U]; double v[MID_U][8], R[MID_U][9];
-#pragma unroll
-                for (int u = 0; u < MID_U; u++) pr[u] = s0 == o ? pr0[u] : L.pslot_pair[min(s0 + u, e - 2)];
-#pragma unroll
-                for (int u = 0; u < MID_U; u++) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) v[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 2))*PT_REC + k];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) R[u][k] = B.pairR[(size_t)k*np_ + pr[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < MID_U; u++) if (s0 + u < e - 1) {
-                    double qa[3], qc[3]; mat3T_vec(R[u], v[u], qa); mat3T_vec(R[u], v[u] + 3, qc);
-                    acc[0] += v[u][6]; acc[1] += v[u][7];
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { acc[2 + a] += -qa[a]; acc[5 + a] += -qc[a]; }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 6; k++) B.w_pt[(size_t)(e - 1)*PT_REC + k] = acc[2 + k];
-            const double V = acc[0];
-            B.V_pt[j] = V; B.b_pt[j] = acc[1];
-            if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
-            const double sg = W.sig_pt[j];
-            B.dgs_pt[j] = clampd(sg*sg*V, W.min_diag, W.max_diag)/(sg*sg);
-            if (act_) { gm = fabs(acc[1]); xn = rho_x[j]*rho_x[j]; }
-        }
-    } else if (b < nb_pt + nb_tx) {
-        const int j = (b - nb_pt)*256 + threadIdx.x;
-        if (e > o) {
-            double acc[27];                                          // V6, b3, host column -blkdiag(R,R)^T W (18)
-#pragma unroll
-            for (int k = 0; k < 27; k++) acc[k] = 0.0;
-            for (int s0 = o; s0 < e - 1; s0 += 2) {                  // 2 slot records in flight per round trip
-                int pr[2]; double v[2][27], R[2][9];
-#pragma unroll
-                for (int u = 0; u < 2; u++) pr[u] = L.tslot_pair[min(s0 + u, e - 2)];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-#pragma unroll
-                    for (int k = 0; k < 27; k++) v[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 2))*TX_REC + k];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) R[u][k] = B.pairR[(size_t)k*np_ + pr[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < 2; u++) if (s0 + u < e - 1) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) acc[k] += v[u][18 + k];
-#pragma unroll
-                    for (int half = 0; half < 2; half++)
-#pragma unroll
-                        for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                            for (int cc = 0; cc < 3; cc++)
-                                acc[9 + (half*3 + rr)*3 + cc] += -(R[u][0*3 + rr]*v[u][(half*3 + 0)*3 + cc] + R[u][1*3 + rr]*v[u][(half*3 + 1)*3 + cc] + R[u][2*3 + rr]*v[u][(half*3 + 2)*3 + cc]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 18; k++) B.w_tx[(size_t)(e - 1)*TX_REC + k] = acc[9 + k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) B.V_tx[(size_t)k*W.n_text + j] = acc[k];
-#pragma unroll
-            for (int k = 0; k < 3; k++) B.b_tx[(size_t)k*W.n_text + j] = acc[6 + k];
-            const double dv[3] = { acc[0], acc[3], acc[5] };
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (st->first) W.sig_tx[(size_t)k*W.n_text + j] = 1.0/(1.0 + sqrt(dv[k]));
-                const double sg = W.sig_tx[(size_t)k*W.n_text + j];
-                B.dgs_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag)/(sg*sg);
-            }
-            if (act_) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(acc[6 + k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
-        }
-    } else {
-        const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x;
-        if (p < L.n_pair) {
-            double M[21], c[6];
-#pragma unroll
-            for (int k = 0; k < 21; k++) M[k] = B.pairM[(size_t)k*L.n_pair + p];
-#pragma unroll
-            for (int k = 0; k < 6; k++) c[k] = B.pairM[(size_t)(21 + k)*L.n_pair + p];
-            cs = B.pairCost[p];
-            for (int q = tq0; q < tq1; q++) {          // (stored in pair-major order by k_linearize)
-#pragma unroll
-                for (int k = 0; k < 21; k++) M[k] += B.tgM[(size_t)k*L.n_tg + q];
-#pragma unroll
-                for (int k = 0; k < 6; k++) c[k] += B.tgM[(size_t)(21 + k)*L.n_tg + q];
-                cs += B.tgCost[q];
-            }
-            double *out = B.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) by pair | QMQ(21) Qc(6) by host-major rank
-#pragma unroll
-            for (int k = 0; k < 21; k++) out[(size_t)k*L.n_pair + p] = M[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) out[(size_t)(21 + k)*L.n_pair + p] = c[k];
-            if (ph_ >= 0) {
-                const int hp = hp_;                        // rows 63..89 are stored host-major
-                double R[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) R[k] = B.pairR[(size_t)k*L.n_pair + p];
-                double Mf[36];
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int cc = 0; cc < 6; cc++) Mf[r*6 + cc] = M[sym6(r, cc)];
-                double MQ[36];                         // M * blkdiag(R,R)
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int half = 0; half < 2; half++)
-#pragma unroll
-                        for (int cc = 0; cc < 3; cc++)
-                            MQ[r*6 + half*3 + cc] = Mf[r*6 + half*3]*R[cc] + Mf[r*6 + half*3 + 1]*R[3 + cc] + Mf[r*6 + half*3 + 2]*R[6 + cc];
-#pragma unroll
-                for (int k = 0; k < 36; k++) out[(size_t)(27 + k)*L.n_pair + p] = MQ[k];
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int cc = r; cc < 6; cc++) {
-                        const int hr = r/3, rr = r % 3;
-                        double v = R[0*3 + rr]*MQ[(hr*3 + 0)*6 + cc] + R[1*3 + rr]*MQ[(hr*3 + 1)*6 + cc] + R[2*3 + rr]*MQ[(hr*3 + 2)*6 + cc];
-                        out[(size_t)(63 + sym6(r, cc))*L.n_pair + hp] = v;
-                    }
-                double a[3], d[3]; mat3T_vec(R, c, a); mat3T_vec(R, c + 3, d);
-                out[(size_t)84*L.n_pair + hp] = a[0]; out[(size_t)85*L.n_pair + hp] = a[1]; out[(size_t)86*L.n_pair + hp] = a[2];
-                out[(size_t)87*L.n_pair + hp] = d[0]; out[(size_t)88*L.n_pair + hp] = d[1]; out[(size_t)89*L.n_pair + hp] = d[2];
-            }
-        }
-    }
-    gm = block_max<256>(gm, red); xn = block_sum<256>(xn, red);
-    if (b >= nb_pt + nb_tx) cs = block_sum<256>(cs, red);       // (uniform) the cost as per-block partials: k_postlin / k_decide add a few hundred
-                                                                // numbers instead of walking 40 k pairs at 5000 keyframes (50 us of one workgroup)
-    if (threadIdx.x == 0) { B.lmpart[3*b] = gm; B.lmpart[3*b + 1] = xn; B.lmpart[3*b + 2] = cs; }
-}
-
-// ---- after a linearisation (256 threads of one block), in two stages so that a multi-GPU run can all-reduce in between:
-//   sums_local : pose diagonal / gradient from the pair sums (-> B.Hd, B.bp), landmark gradient max / |x|^2, cost
-//   pose_scale : Jacobi scaling, LM diagonal, gradient max and |x|^2 of the free poses (from the possibly all-reduced Hd / bp)
-__device__ void sums_local(const Work &W, const LevelDev &L, const LinBuf &B, double *dHd, double *dbp, int nb_lm, double *red,
-                           double &gmax_lm, double &xn_lm, double &cost, bool skip_pose = false) {
-    const int tid = threadIdx.x;
-    gmax_lm = 0.0; xn_lm = 0.0; cost = 0.0;
-    const double *out = B.pairOut;
-    const size_t np = L.n_pair;
-    for (int task = tid; task < (skip_pose ? 0 : 12*W.n_kf); task += 256) {          // (pose, component): diag H (6) | b (6)   (large maps: k_pose_sums_raw did it)
-        const int a = task/12, k = task - 12*a;
-        const int t0 = L.pose_t_off[a], t1 = L.pose_t_off[a+1], h0 = L.pose_h_off[a], h1 = L.pose_h_off[a+1];
-        if (k < 6) {
-            const double h = range_sum<24>(out + (size_t)sym6(k, k)*np, t0, t1) + range_sum<24>(out + (size_t)(63 + sym6(k, k))*np, h0, h1);
-            dHd[6*a + k] = h;
-        } else {
-            const double g = range_sum<24>(out + (size_t)(21 + k - 6)*np, t0, t1) - range_sum<24>(out + (size_t)(84 + k - 6)*np, h0, h1);
-            dbp[6*a + k - 6] = g; B.bp_loc[6*a + k - 6] = g;
-        }
-    }
-    __threadfence_block();                                             // pose_scale reads these through other threads
-    for (int k = tid; k < nb_lm; k += 256) { gmax_lm = fmax(gmax_lm, B.lmpart[3*k]); xn_lm += B.lmpart[3*k + 1]; cost += B.lmpart[3*k + 2]; }
-    gmax_lm = block_max<256>(gmax_lm, red); xn_lm = block_sum<256>(xn_lm, red); cost = block_sum<256>(cost, red);
-}
-__device__ void pose_scale(const Work &W, const LinBuf &B, const double *sHd, const double *sbp, const double *pose, bool first,
-                           double *red, double &gmax_p, double &xn_p) {
-    const int tid = threadIdx.x;
-    gmax_p = 0.0; xn_p = 0.0;
-    for (int a = tid; a < W.n_kf; a += 256) {
-        const bool fre = W.fidx[a] >= 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const double h = sHd[6*a + k], g = sbp[6*a + k];
-            B.Hd[6*a + k] = h; B.bp[6*a + k] = g;                 // (multi-GPU: the all-reduced values replace the local ones)
-            if (first) W.sig_p[6*a + k] = 1.0/(1.0 + sqrt(h));
-            const double sg = W.sig_p[6*a + k];
-            B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
-            if (fre) gmax_p = fmax(gmax_p, fabs(g));
-        }
-        if (fre) for (int k = 0; k < 7; k++) xn_p += pose[7*a + k]*pose[7*a + k];
-    }
-    gmax_p = block_max<256>(gmax_p, red); xn_p = block_sum<256>(xn_p, red);
-}
-// Single-GPU path of k_postlin / k_decide: everything one linearisation contributes to the LM decision, with the independent
-// loads of all parts issued before the first wait and ONE five-value block reduction (a global round trip from this lone
-// workgroup costs ~0.6 us, a block reduction ~0.3 us: the old sequence had a dozen of the former and seven of the latter).
-//   out5 = { max |gradient|, |x|^2, cost, step^2 (nb_back partials), model cost change (nb_back partials) }   (thread 0)
-__device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm, int nb_back,
-                              double *red /*[5*256]*/, double *xch /*[252]*/, double out5[5], int npp = 0) {
-    const int tid = threadIdx.x;
-    double gmax = 0.0, xn = 0.0, cost = 0.0, step2 = 0.0, mcc = 0.0;
-#ifdef TSBA_SOLVE_STAMPS
-    long long q0_ = clock64(), q1_ = 0, q2_ = 0, q3_ = 0, q4_ = 0;
-#endif
-    {   // landmark / cost / step partials (one entry per k_mid / k_back workgroup): three per thread in flight, the (rare) rest in a plain loop
-        double lc[3], lg[3], lx[3], ps[3], pm[3];
-#pragma unroll
-        for (int u = 0; u < 3; u++) {
-            const int k = tid + 256*u;
-            lg[u] = B.lmpart[3*min(k, max(nb_lm - 1, 0))]; lx[u] = B.lmpart[3*min(k, max(nb_lm - 1, 0)) + 1]; lc[u] = B.lmpart[3*min(k, max(nb_lm - 1, 0)) + 2];
-            ps[u] = W.partial[2*min(k, max(nb_back - 1, 0))]; pm[u] = W.partial[2*min(k, max(nb_back - 1, 0)) + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 3; u++) {
-            const int k = tid + 256*u;
-            if (k < nb_lm) { gmax = fmax(gmax, lg[u]); xn += lx[u]; cost += lc[u]; }
-            if (k < nb_back) { step2 += ps[u]; mcc += pm[u]; }
-        }
-        for (int k = tid + 768; k < nb_lm; k += 256) { gmax = fmax(gmax, B.lmpart[3*k]); xn += B.lmpart[3*k + 1]; cost += B.lmpart[3*k + 2]; }
-        for (int k = tid + 768; k < nb_back; k += 256) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
-    }
-#ifdef TSBA_SOLVE_STAMPS
-    q1_ = clock64();
-#endif
-    // poses, 21 per round: thread (pose, component) sums one entry of diag(H_pp) (6) or of the gradient (6) over the pose's
-    // pairs -- target side by pair, host side host-major, both contiguous -- then the six diag threads finish the pose
-    const double *out = B.pairOut; const size_t np = L.n_pair;
-    // (large maps: k_pose_sums did the per-pose work on many workgroups; only its partials are left to add)
-    for (int k = tid; k < npp; k += 256) { gmax = fmax(gmax, W.posepart[2*k]); xn += W.posepart[2*k + 1]; }
-    for (int a0 = 0; a0 < (npp > 0 ? 0 : W.n_kf); a0 += 21) {
-        const int al = tid/12, k = tid - 12*al, a = a0 + al;
-        const bool on = tid < 252 && a < W.n_kf;
-        const int ac = min(a, W.n_kf - 1);
-        const int t0 = L.pose_t_off[ac], t1 = L.pose_t_off[ac+1], h0 = L.pose_h_off[ac], h1 = L.pose_h_off[ac+1];
-        const int kk = k < 6 ? k : k - 6;
-        const double sgp = first ? 0.0 : W.sig_p[6*ac + kk]; const int fre = W.fidx[ac];
-        const double px = pose[7*ac + kk], px6 = pose[7*ac + 6];
-        const double *rt = out + (size_t)(k < 6 ? sym6(kk, kk) : 21 + kk)*np, *rh = out + (size_t)(k < 6 ? 63 + sym6(kk, kk) : 84 + kk)*np;
-        const double vt = range_sum<24>(rt, t0, t1), vh = range_sum<24>(rh, h0, h1);
-        const double val = k < 6 ? vt + vh : vt - vh;
-#ifdef TSBA_SOLVE_STAMPS
-        q2_ = clock64();
-#endif
-        if (on) xch[tid] = val;
-        __syncthreads();
-        if (on && k < 6) {
-            const double h = val, g = xch[tid + 6];
-            B.Hd[6*a + k] = h; B.bp[6*a + k] = g; B.bp_loc[6*a + k] = g;
-            double sg = sgp;
-            if (first) { sg = 1.0/(1.0 + sqrt(h)); W.sig_p[6*a + k] = sg; }
-            B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
-            if (fre >= 0) { gmax = fmax(gmax, fabs(g)); xn += px*px + (k == 0 ? px6*px6 : 0.0); }
-        }
-        __syncthreads();
-    }
-#ifdef TSBA_SOLVE_STAMPS
-    q3_ = clock64();
-#endif
-    // one reduction for the five values: wave w reduces value w, wave 0 also value 4
-    red[tid] = gmax; red[256 + tid] = xn; red[512 + tid] = cost; red[768 + tid] = step2; red[1024 + tid] = mcc;
-    __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    auto reduce_one = [&](int v) -> double {
-        const double *r = red + 256*v;
-        double x;
-        if (v == 0) {
-            x = fmax(fmax(r[lane], r[lane + 64]), fmax(r[lane + 128], r[lane + 192]));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
-        } else { x = (r[lane] + r[lane + 64]) + (r[lane + 128] + r[lane + 192]); x = wave_sum1(x); }
-        return x;
-    };
-    const double x0 = reduce_one(wave), x4 = wave == 0 ? reduce_one(4) : 0.0;
-    __syncthreads();
-    if (lane == 0) { red[256*wave] = x0; if (wave == 0) red[1024] = x4; }
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < 5; v++) out5[v] = red[256*v];
-#ifdef TSBA_SOLVE_STAMPS
-    q4_ = clock64();
-    if (tid == 0) { W.dbg[40] = q1_ - q0_; W.dbg[41] = q2_ - q1_; W.dbg[42] = q3_ - q2_; W.dbg[43] = q4_ - q3_; }
-#endif
-}
-// The pose part of postlin_fused for large maps (hundreds of keyframes and more): 21 poses per workgroup instead of 21 per ROUND of
-// the single postlin / decide workgroup (238 rounds, 1.1 ms per LM iteration at 5000 keyframes).
-__global__ __launch_bounds__(256) void k_pose_sums(Work W, LevelDev L, int spec) {
-    const LmState *st = W.st;
-    if (st->done) return;
-    if (!spec && !st->need_lin) return;
-    if (spec && st->step_fail) return;
-    __shared__ double xch[256], red[256];
-    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
-    const double *pose = W.pose[spec ? (st->cur ^ 1) : st->cur];
-    const bool first = !spec && st->first != 0;
-    const int tid = threadIdx.x;
-    const double *out = B.pairOut; const size_t np = L.n_pair;
-    const int al = tid/12, k = tid - 12*al, a = blockIdx.x*21 + al;
-    const bool on = tid < 252 && a < W.n_kf;
-    const int ac = min(a, W.n_kf - 1);
-    const int t0 = L.pose_t_off[ac], t1 = L.pose_t_off[ac+1], h0 = L.pose_h_off[ac], h1 = L.pose_h_off[ac+1];
-    const int kk = k < 6 ? k : k - 6;
-    const double sgp = first ? 0.0 : W.sig_p[6*ac + kk]; const int fre = W.fidx[ac];
-    const double px = pose[7*ac + kk], px6 = pose[7*ac + 6];
-    const double *rt = out + (size_t)(k < 6 ? sym6(kk, kk) : 21 + kk)*np, *rh = out + (size_t)(k < 6 ? 63 + sym6(kk, kk) : 84 + kk)*np;
-    const double vt = range_sum<24>(rt, t0, t1), vh = range_sum<24>(rh, h0, h1);
-    const double val = k < 6 ? vt + vh : vt - vh;
-    if (on) xch[tid] = val;
-    __syncthreads();
-    double gmax = 0.0, xn = 0.0;
-    if (on && k < 6) {
-        const double h = val, g = xch[tid + 6];
-        B.Hd[6*a + k] = h; B.bp[6*a + k] = g; B.bp_loc[6*a + k] = g;
-        double sg = sgp;
-        if (first) { sg = 1.0/(1.0 + sqrt(h)); W.sig_p[6*a + k] = sg; }
-        B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
-        if (fre >= 0) { gmax = fabs(g); xn = px*px + (k == 0 ? px6*px6 : 0.0); }
-    }
-    gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red);
-    if (tid == 0) { W.posepart[2*blockIdx.x] = gmax; W.posepart[2*blockIdx.x + 1] = xn; }
-}
-// The same in a sharded (multi-GPU) run, in two stages around the all-reduce of the exchange buffer cb = [Hd | bp | scalars]:
-//   k_pose_sums_raw    this rank's part of diag(H_pp) and of the pose gradient, 21 poses per workgroup  -> cb, B.bp_loc
-//   k_pose_scale_multi from the all-reduced cb: B.Hd / B.bp, Jacobi scale (first linearisation), LM diagonal, per-workgroup partials of
-//                      the gradient maximum and |x|^2 of the free poses -> W.posepart
-// (one workgroup walking 5000 poses cost 0.7 ms per linearisation: more than everything the sharding saves)
-__global__ __launch_bounds__(256) void k_pose_sums_raw(Work W, LevelDev L, int spec) {
-    const LmState *st = W.st;
-    if (st->done) return;
-    if (!spec && !st->need_lin) return;
-    if (spec && st->step_fail) return;
-    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
-    const int tid = threadIdx.x;
-    const double *out = B.pairOut; const size_t np = L.n_pair;
-    const int al = tid/12, k = tid - 12*al, a = blockIdx.x*21 + al;
-    if (tid >= 252 || a >= W.n_kf) return;
-    const int t0 = L.pose_t_off[a], t1 = L.pose_t_off[a+1], h0 = L.pose_h_off[a], h1 = L.pose_h_off[a+1];
-    const int kk = k < 6 ? k : k - 6;
-    const double *rt = out + (size_t)(k < 6 ? sym6(kk, kk) : 21 + kk)*np, *rh = out + (size_t)(k < 6 ? 63 + sym6(kk, kk) : 84 + kk)*np;
-    const double vt = range_sum<24>(rt, t0, t1), vh = range_sum<24>(rh, h0, h1);
-    if (k < 6) W.cb[6*a + kk] = vt + vh;
-    else { const double g = vt - vh; W.cb[W.N + 6*a + kk] = g; B.bp_loc[6*a + kk] = g; }
-}
-__global__ __launch_bounds__(256) void k_pose_scale_multi(Work W, int spec) {
-    const LmState *st = W.st;
-    if (st->done) return;
-    if (!spec && !st->need_lin) return;
-    if (spec && st->step_fail) return;
-    __shared__ double red[256];
-    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
-    const double *pose = W.pose[spec ? (st->cur ^ 1) : st->cur];
-    const bool first = !spec && st->first != 0;
-    const int tid = threadIdx.x, al = tid/6, k = tid - 6*al, a = blockIdx.x*21 + al;
-    double gmax = 0.0, xn = 0.0;
-    if (tid < 126 && a < W.n_kf) {
-        const double h = W.cb[6*a + k], g = W.cb[W.N + 6*a + k];
-        B.Hd[6*a + k] = h; B.bp[6*a + k] = g;
-        double sg;
-        if (first) { sg = 1.0/(1.0 + sqrt(h)); W.sig_p[6*a + k] = sg; } else sg = W.sig_p[6*a + k];
-        B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
-        if (W.fidx[a] >= 0) { gmax = fabs(g); const double px = pose[7*a + k]; xn = px*px; if (k == 0) { const double p6 = pose[7*a + 6]; xn += p6*p6; } }
-    }
-    gmax = block_max<256>(gmax, red); xn = block_sum<256>(xn, red);
-    if (tid == 0) { W.posepart[2*blockIdx.x] = gmax; W.posepart[2*blockIdx.x + 1] = xn; }
-}
-// the pose part of k_postlin / k_decide in a sharded run on a large map: the partials k_pose_scale_multi left
-__device__ void pose_parts_multi(const Work &W, int npp, double *red, double &gmax_p, double &xn_p) {
-    gmax_p = 0.0; xn_p = 0.0;
-    for (int k = threadIdx.x; k < npp; k += 256) { gmax_p = fmax(gmax_p, W.posepart[2*k]); xn_p += W.posepart[2*k + 1]; }
-    gmax_p = block_max<256>(gmax_p, red); xn_p = block_sum<256>(xn_p, red);
-}
-__global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm, int multi, int npp) {
-    LmState *st = W.st;
-    if (st->done || !st->need_lin) return;
-    __shared__ double red[5*256], xch[256];
-    double gmax, xn, cost;
-    const LinBuf &B = W.lb[st->lcur];
-    if (!multi) { double o5[5]; postlin_fused(W, L, B, W.pose[st->cur], st->first != 0, nb_lm, 0, red, xch, o5, npp); gmax = o5[0]; xn = o5[1]; cost = o5[2]; }
-    else { double gp, xp;
-           if (npp) pose_parts_multi(W, npp, red, gp, xp); else pose_scale(W, B, W.cb, W.cb + W.N, W.pose[st->cur], st->first != 0, red, gp, xp);
-           const double *sc = W.cb + 2*(size_t)W.N; cost = sc[0]; xn = sc[1] + xp; gmax = fmax(W.cbm[0], gp); }
-    if (threadIdx.x == 0) {
-        st->x_cost = cost; st->x_norm = sqrt(xn); st->gmax = gmax;
-        if (st->first) st->cost0 = cost;
-        st->first = 0; st->need_lin = 0; st->n_lin++;
-        if (gmax <= grad_tol) { st->done = 1; st->term = 3; }
-        if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)st->it << 1) | (st->done ? 1u : 0u); __threadfence_system(); }
-    }
-}
-
-// ---- reduced camera system.  grid = n_sb (one workgroup per 6x6 block) + n_kf (reduced gradient), 256 threads.
-// The (slot, slot, landmark) gather lists of a diagonal block hold ~1000 entries: four waves, and per wave the indices and
-// operands of four entries in flight before the first multiply (two dependent global round trips per 1024 entries).
-#define SCHUR_U 4
-// SCHUR_NW waves per workgroup: 4 for windows (a diagonal block gathers ~1000 slot pairs), 1 for large maps (54 k blocks of ~60 slot
-// pairs each at 5000 keyframes: three idle waves per block and their hand-off were most of the 0.64 ms)
-template <int SCHUR_NW>
-__global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int multi, int b0) {
-    constexpr int SCHUR_T = 64*SCHUR_NW;
-    LmState *st = W.st;
-    if (st->done) return;
-    __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
-    // (b0 > 0: large maps take the S blocks through k_schur_quad and only the gradient part here, a grid of a multiple of 8 workgroups in
-    // which the workgroups of ONE XCD -- workgroup i runs on XCD i mod 8 -- take neighbouring poses: the slot records of a landmark sit next
-    // to each other, one per observing pose, and neighbouring poses observe the same landmarks)
-    const int bx = b0 > 0 ? ((int)blockIdx.x & 7)*((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
-    const int b = bx + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double radius = st->radius, irad = 1.0/radius;
-    const LinBuf &B = W.lb[st->lcur];
-    if (b < L.n_sb) {
-        const int a = L.sb_a[b], c = L.sb_b[b];
-        const int ia = W.fidx[a], ic = W.fidx[c];           // rows / columns of S exist for free poses only
-        if (ia < 0 || ic < 0) return;
-        double acc[36];
-#pragma unroll
-        for (int k = 0; k < 36; k++) acc[k] = 0.0;
-        const int pt0 = L.sb_pt_off[b], pt1 = L.sb_pt_off[b+1];
-        for (int base = pt0; base < pt1; base += SCHUR_T*SCHUR_U) {
-            int s1[SCHUR_U], s2[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
-#pragma unroll
-            for (int u = 0; u < SCHUR_U; u++) {
-                const int q = base + u*SCHUR_T + tid; ok[u] = q < pt1;
-                const int qc = min(q, pt1 - 1);
-                s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc];
-            }
-            double w1[SCHUR_U][6], w2[SCHUR_U][6], Vv[SCHUR_U], dg[SCHUR_U];
-#pragma unroll
-            for (int u = 0; u < SCHUR_U; u++) {
-                Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
-#pragma unroll
-                for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
-            }
-#pragma unroll
-            for (int u = 0; u < SCHUR_U; u++) {
-                const double vinv = ok[u] ? ts_rcp(Vv[u] + dg[u]*irad) : 0.0;     // (v_rcp + Newton: an IEEE division is ~35 instructions per slot pair)
-#pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    const double wr = w1[u][r]*vinv;
-#pragma unroll
-                    for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += wr*w2[u][cc];
-                }
-            }
-        }
-        for (int q = L.sb_tx_off[b] + tid; q < L.sb_tx_off[b+1]; q += SCHUR_T) {
-            const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
-            double Vd[6], Vi[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
-            Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
-            double W1[18], W2[18];
-#pragma unroll
-            for (int k = 0; k < 18; k++) { W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k]; W2[k] = B.w_tx[(size_t)(s2)*TX_REC + k]; }
-            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
-#pragma unroll
-            for (int r = 0; r < 6; r++) {
-                double t0 = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
-                double t1 = W1[r*3]*Vi[1] + W1[r*3+1]*Vi[3] + W1[r*3+2]*Vi[4];
-                double t2 = W1[r*3]*Vi[2] + W1[r*3+1]*Vi[4] + W1[r*3+2]*Vi[5];
-#pragma unroll
-                for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += t0*W2[cc*3] + t1*W2[cc*3+1] + t2*W2[cc*3+2];
-            }
-        }
-        // operands of the tail, independent of the sums: issued before the reduction
-        double tail = 0.0;
-        if (wave == 0 && lane < 36) {
-            const int r = lane/6, cc = lane % 6;
-            const double *out = B.pairOut;
-            if (a == c) {
-                const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
-                tail = range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
-                if (r == cc && !multi) tail += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
-            } else {
-                int pab = L.sb_pab[b], pba = L.sb_pba[b];
-                if (pab >= 0) tail -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
-                if (pba >= 0) tail -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
-            }
-        }
-        if (SCHUR_NW > 1) {
-            if (wave > 0) {
-#pragma unroll
-                for (int k = 0; k < 36; k++) lds[((wave - 1)*36 + k)*64 + lane] = acc[k];
-            }
-            __syncthreads();
-            if (wave == 0) {
-#pragma unroll
-                for (int k = 0; k < 36; k++) acc[k] += (lds[k*64 + lane] + lds[(36 + k)*64 + lane]) + lds[(72 + k)*64 + lane];
-            }
-            __syncthreads();
-        }
-        if (wave == 0) {
-#pragma unroll
-            for (int k = 0; k < 36; k++) lds[k*65 + lane] = acc[k];          // transpose: lane l < 36 sums entry l over the 64 lanes
-        }
-        __syncthreads();
-        if (wave > 0) return;
-        double tot = 0.0;
-        if (lane < 36) {
-            const double *row = lds + lane*65;
-#pragma unroll 16
-            for (int k = 0; k < 64; k++) tot += row[k];
-        }
-        if (lane < 36) {
-            const int r = lane/6, cc = lane % 6;
-            const double v = tail - tot;
-            const size_t ldS = (size_t)W.ldS;                // (sb_a <= sb_b: the first store is the upper triangle, which band storage does not hold)
-            // band storage holds the lower triangle: the block goes to the row of the pose that comes LATER in S (with a plan order
-            // that need not be the larger keyframe index)
-            int ja = ia, jc = ic;
-            if (W.ring) { const int nf = W.nfree[0], r0 = W.nfree[1];       // closure block (a pose of the loop's first separator against a far one): the ghost row
-                if (ia - ic > W.ring_b && ic >= r0 && ic < r0 + W.ring_b) jc += nf - r0; else if (ic - ia > W.ring_b && ia >= r0 && ia < r0 + W.ring_b) ja += nf - r0; }
-            const bool a_later = ja > jc;
-            const int fq = L.sb_far ? L.sb_far[b] : -1;     // a block outside the band (long-range coupling): to the compact list, rows = the earlier keyframe a
-            if (fq >= 0) W.Sfar[(size_t)fq*36 + r*6 + cc] = v;
-            else {
-            if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
-            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
-            }
-        }
-    } else {
-        const int a = b - L.n_sb;
-        if (a >= W.n_kf) return;                               // (the gradient-only grid is rounded up to a multiple of 8)
-        const int ia = W.fidx[a];
-        if (ia < 0) return;
-        double acc[6] = {0,0,0,0,0,0};
-        const int ps0 = L.pose_ps_off[a], ps1 = L.pose_ps_off[a+1];
-        for (int base = ps0; base < ps1; base += SCHUR_T*SCHUR_U) {
-            int s[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
-#pragma unroll
-            for (int u = 0; u < SCHUR_U; u++) {
-                const int q = base + u*SCHUR_T + tid; ok[u] = q < ps1;
-                const int qc = min(q, ps1 - 1);
-                s[u] = L.pose_ps[qc]; j[u] = L.pose_ps_lm[qc];
-            }
-            double w[SCHUR_U][6], bb[SCHUR_U], Vv[SCHUR_U], dg[SCHUR_U];
-#pragma unroll
-            for (int u = 0; u < SCHUR_U; u++) {
-                bb[u] = B.b_pt[j[u]]; Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
-#pragma unroll
-                for (int k = 0; k < 6; k++) w[u][k] = B.w_pt[(size_t)(s[u])*PT_REC + k];
-            }
-#pragma unroll
-            for (int u = 0; u < SCHUR_U; u++) {
-                const double f = ok[u] ? bb[u]*ts_rcp(Vv[u] + dg[u]*irad) : 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) acc[k] += w[u][k]*f;
-            }
-        }
-        for (int q = L.pose_ts_off[a] + tid; q < L.pose_ts_off[a+1]; q += SCHUR_T) {
-            const int s = L.pose_ts[q], j = L.pose_ts_lm[q];
-            double Vd[6], Vi[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
-            Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
-            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
-            double b0 = B.b_tx[j], b1 = B.b_tx[(size_t)W.n_text + j], b2 = B.b_tx[(size_t)2*W.n_text + j];
-            double f0 = Vi[0]*b0 + Vi[1]*b1 + Vi[2]*b2, f1 = Vi[1]*b0 + Vi[3]*b1 + Vi[4]*b2, f2 = Vi[2]*b0 + Vi[4]*b1 + Vi[5]*b2;
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                acc[k] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*f0 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*f1 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*f2;
-        }
-        const double bpv = tid < 6 ? (multi ? B.bp_loc[6*a + tid] : B.bp[6*a + tid]) : 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) acc[k] = wave_sum1(acc[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) lds[wave*6 + k] = acc[k];
-        }
-        __syncthreads();
-        if (tid < 6) W.g[6*ia + tid] = bpv - (SCHUR_NW > 1 ? (((lds[tid] + lds[6 + tid]) + lds[12 + tid]) + lds[18 + tid]) : lds[tid]);
-    }
-}
-
-// Large maps: FOUR S blocks per wave, 16 lanes each.  At 5000 keyframes a block gathers ~70 slot pairs: a whole wave per block left most
-// load slots empty and paid a 64-lane reduction (36 LDS writes + 64 reads) per block; here a 16-lane group walks its block's list 64
-// entries per round trip (4 in flight per lane), the 36 sums of a group are transposed through a 36 x 17 LDS tile and every lane
-// finishes up to three entries of the block (tail: pose-pair products, damping) and stores them.  Same sums, same order within a lane;
-// the order ACROSS lanes differs from k_schur_t<1> (16 partial sums instead of 64), which the tests' tolerances cover.
-#ifndef SCHURQ_U
-#define SCHURQ_U 1                          // list entries per lane in flight (k_schur_quad): 1 -> 128 registers, four waves per SIMD (101 us with 2 / three waves, 97 us with 1 at 5000 keyframes; 113 us with 4 / two waves)
-#endif
-// TEXT = false: a level without text planes (the reference's GlobalBA) -- the plane part (3x3 inverse, 18-value records) sets the kernel's
-// register count (214: two waves per SIMD); without it three fit.
-template <bool TEXT>
-__global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi) {
-    LmState *st = W.st;
-    if (st->done) return;
-    __shared__ double lds[4*12*17];                             // a third of a group's 36 sums at a time: 6.5 KB, the registers set the occupancy
-    const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
-    // workgroups are handed to the 8 XCDs round-robin (workgroup i -> XCD i mod 8), and an XCD's L2 does not see the others': neighbouring S
-    // blocks read the same landmarks' records, so the workgroups of ONE XCD take a contiguous range of blocks (the kernel is bound by
-    // L2 -> L1 line fills; with neighbouring blocks on eight different XCDs every record crossed the fabric up to eight times)
-    const int per = (int)gridDim.x >> 3, wg = ((int)blockIdx.x & 7)*per + ((int)blockIdx.x >> 3);     // (the grid is a multiple of 8 workgroups)
-    const int b = 4*wg + grp;
-    const bool have = b < L.n_sb;
-    const int bc = have ? b : L.n_sb - 1;
-    const double irad = 1.0/st->radius;
-    const LinBuf &B = W.lb[st->lcur];
-    const int a = L.sb_a[bc], c = L.sb_b[bc];
-    const int ia = W.fidx[a], ic = W.fidx[c];
-    const bool live = have && ia >= 0 && ic >= 0;               // rows / columns of S exist for free poses only
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    const int pt0 = L.sb_pt_off[bc], pt1 = live ? L.sb_pt_off[bc+1] : pt0;
-    for (int base = pt0; base < pt1; base += 16*SCHURQ_U) {
-        int s1[SCHURQ_U], s2[SCHURQ_U], j[SCHURQ_U]; bool ok[SCHURQ_U];
-#pragma unroll
-        for (int u = 0; u < SCHURQ_U; u++) {
-            const int q = base + u*16 + sub; ok[u] = q < pt1;
-            const int qc = min(q, pt1 - 1);
-            s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc];
-        }
-        double w1[SCHURQ_U][6], w2[SCHURQ_U][6], Vv[SCHURQ_U], dg[SCHURQ_U];
-#pragma unroll
-        for (int u = 0; u < SCHURQ_U; u++) {
-            Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
-        }
-#pragma unroll
-        for (int u = 0; u < SCHURQ_U; u++) {
-            const double vinv = ok[u] ? ts_rcp(Vv[u] + dg[u]*irad) : 0.0;
-#pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const double wr = w1[u][r]*vinv;
-#pragma unroll
-                for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += wr*w2[u][cc];
-            }
-        }
-    }
-    if (TEXT && live) for (int q = L.sb_tx_off[bc] + sub; q < L.sb_tx_off[bc+1]; q += 16) {
-        const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
-        double Vd[6], Vi[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
-        Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
-        // (t = W1 Vi first, then W2 three values at a time: W1, W2 and acc live together cost the kernel a wave per SIMD)
-        double tv[18];
-        {
-            double W1[18];
-#pragma unroll
-            for (int k = 0; k < 18; k++) W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k];
-            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
-#pragma unroll
-            for (int r = 0; r < 6; r++) {
-                tv[r*3] = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
-                tv[r*3+1] = W1[r*3]*Vi[1] + W1[r*3+1]*Vi[3] + W1[r*3+2]*Vi[4];
-                tv[r*3+2] = W1[r*3]*Vi[2] + W1[r*3+1]*Vi[4] + W1[r*3+2]*Vi[5];
-            }
-        }
-#pragma unroll
-        for (int cc = 0; cc < 6; cc++) {
-            const double x0 = B.w_tx[(size_t)(s2)*TX_REC + cc*3], x1 = B.w_tx[(size_t)(s2)*TX_REC + cc*3 + 1], x2 = B.w_tx[(size_t)(s2)*TX_REC + cc*3 + 2];
-#pragma unroll
-            for (int r = 0; r < 6; r++) acc[r*6 + cc] += tv[r*3]*x0 + tv[r*3+1]*x1 + tv[r*3+2]*x2;
-        }
-    }
-    // tails of this lane's entries o = sub, 12 + sub, 24 + sub (sub < 12), independent of the sums: issued before the reduction
-    double tail[3] = {0.0, 0.0, 0.0};
-    if (live && sub < 12) {
-        const double *out = B.pairOut;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int o = sub + 12*t;
-            const int r = o/6, cc = o - 6*r;
-            if (a == c) {
-                const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
-                tail[t] = range_sum<8>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<8>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);     // (8 in flight: a keyframe of a large map has ~8 pairs each way; 24 cost the kernel a wave per SIMD)
-                if (r == cc && !multi) tail[t] += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
-            } else {
-                const int pab = L.sb_pab[bc], pba = L.sb_pba[bc];
-                if (pab >= 0) tail[t] -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
-                if (pba >= 0) tail[t] -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
-            }
-        }
-    }
-    double *tile = lds + grp*12*17;
-    const size_t ldS = (size_t)W.ldS;
-    int ja = ia, jc = ic;
-    if (W.ring) { const int nf = W.nfree[0], r0 = W.nfree[1];               // closure block (a pose of the loop's first separator against a far one): the ghost row
-        if (ia - ic > W.ring_b && ic >= r0 && ic < r0 + W.ring_b) jc += nf - r0; else if (ic - ia > W.ring_b && ia >= r0 && ia < r0 + W.ring_b) ja += nf - r0; }
-    const bool a_later = ja > jc;
-    const int fq = (live && L.sb_far) ? L.sb_far[bc] : -1;     // a block outside the band (long-range coupling): to the compact list
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-#pragma unroll
-        for (int k = 0; k < 12; k++) tile[k*17 + sub] = acc[12*t + k];
-        __syncthreads();                                        // (one wave: an s_barrier of one wave)
-        if (live && sub < 12) {
-            const int o = sub + 12*t;
-            const double *row = tile + sub*17;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
-            const double v = tail[t] - ((s0 + s1) + (s2 + s3));
-            const int r = o/6, cc = o - 6*r;
-            if (fq >= 0) W.Sfar[(size_t)fq*36 + o] = v;
-            else {
-            if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
-            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
-            }
-        }
-        __syncthreads();
-    }
-}
-
+#include "tsba_types.h"
+#include "tsba_kernels_lin.h"
+#include "tsba_kernels_schur.h"
 #include "tsba_solve.h"
 #include "tsba_chol.h"
 #include "tsba_band.h"
@@ -1482,380 +45,7 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
 #include "tsba_pcg.h"
 #include "tsba_pose.h"
 
-// ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
-__global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
-    LmState *st = W.st;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    // static offsets / slot poses of this thread's landmark first: in flight together with the LM state
-    int o = 0, e = 0, act_ = 0, a0[6] = {0, 0, 0, 0, 0, 0};
-    if (b < nb_pt) { const int j = b*256 + tid; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
-#pragma unroll
-        for (int u = 0; u < 6; u++) a0[u] = L.pt_pose6[6*(size_t)j + u]; } }
-    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + tid; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
-    if (st->done) return;
-    __shared__ double red[256];
-    const int cur = st->cur;
-    const double irad = 1.0/st->radius;
-    const bool fail = st->step_fail;
-    const LinBuf &B = W.lb[st->lcur];
-    double step2 = 0.0, mcc = 0.0;
-    if (b < nb_pt) {
-        int j = b*256 + tid;
-        if (j < W.n_pt) {
-            double rh = W.rho[cur][j], d = 0.0;
-            if (!fail && e > o && act_) {
-                double acc = B.b_pt[j];
-                for (int s0 = o; s0 < e; s0 += 6) {                                 // 6 slots in flight; dp is 0 for constant / absent poses
-                    int a[6]; double w[6][6], dpv[6][6];
-#pragma unroll
-                    for (int u = 0; u < 6; u++) a[u] = s0 == o ? a0[u] : L.pslot_pose[min(s0 + u, e - 1)];
-#pragma unroll
-                    for (int u = 0; u < 6; u++)
-#pragma unroll
-                        for (int k = 0; k < 6; k++) { w[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 1))*PT_REC + k]; dpv[u][k] = W.dp[6*a[u] + k]; }
-#pragma unroll
-                    for (int u = 0; u < 6; u++)
-#pragma unroll
-                        for (int k = 0; k < 6; k++) acc += s0 + u < e ? w[u][k]*dpv[u][k] : 0.0;
-                }
-                const double lam = B.dgs_pt[j]*irad;
-                d = -acc/(B.V_pt[j] + lam);
-                step2 = d*d; mcc = lam*d*d - B.b_pt[j]*d;
-            }
-            W.rho[cur ^ 1][j] = rh + d;
-        }
-    } else if (b < nb_pt + nb_tx) {
-        int j = (b - nb_pt)*256 + tid;
-        if (j < W.n_text) {
-            double d[3] = {0,0,0};
-            if (!fail && e > o && act_) {
-                double acc[3] = { B.b_tx[j], B.b_tx[(size_t)W.n_text + j], B.b_tx[(size_t)2*W.n_text + j] };
-                for (int s0 = o; s0 < e; s0 += 3) {                                 // 3 slots in flight
-                    int a[3]; double w[3][18], dpv[3][6];
-#pragma unroll
-                    for (int u = 0; u < 3; u++) a[u] = L.tslot_pose[min(s0 + u, e - 1)];
-#pragma unroll
-                    for (int u = 0; u < 3; u++) {
-#pragma unroll
-                        for (int k = 0; k < 18; k++) w[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 1))*TX_REC + k];
-#pragma unroll
-                        for (int k = 0; k < 6; k++) dpv[u][k] = W.dp[6*a[u] + k];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 3; u++) if (s0 + u < e) {
-#pragma unroll
-                        for (int k = 0; k < 6; k++) { acc[0] += w[u][k*3]*dpv[u][k]; acc[1] += w[u][k*3 + 1]*dpv[u][k]; acc[2] += w[u][k*3 + 2]*dpv[u][k]; }
-                    }
-                }
-                double Vd[6], Vi[6], lam[3];
-#pragma unroll
-                for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
-#pragma unroll
-                for (int k = 0; k < 3; k++) lam[k] = B.dgs_tx[(size_t)k*W.n_text + j]*irad;
-                Vd[0] += lam[0]; Vd[3] += lam[1]; Vd[5] += lam[2];
-                if (inv_sym3(Vd, Vi)) {
-                    d[0] = -(Vi[0]*acc[0] + Vi[1]*acc[1] + Vi[2]*acc[2]);
-                    d[1] = -(Vi[1]*acc[0] + Vi[3]*acc[1] + Vi[4]*acc[2]);
-                    d[2] = -(Vi[2]*acc[0] + Vi[4]*acc[1] + Vi[5]*acc[2]);
-                    for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - B.b_tx[(size_t)k*W.n_text + j]*d[k]; }
-                }
-            }
-            for (int k = 0; k < 3; k++) W.theta[cur ^ 1][3*j + k] = W.theta[cur][3*j + k] + d[k];
-        }
-    } else {
-        int a = (b - nb_pt - nb_tx)*256 + tid;
-        if (a < W.n_kf) {
-            const double *x = W.pose[cur] + 7*a; double *c = W.pose[cur ^ 1] + 7*a;
-            if (!fail && W.fidx[a] >= 0) {
-                double d[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) d[k] = W.dp[6*a + k];
-                double q[4] = { x[0], x[1], x[2], x[3] }, qn[4];
-                quat_plus(q, d, qn);
-                for (int k = 0; k < 4; k++) { c[k] = qn[k]; step2 += (qn[k] - q[k])*(qn[k] - q[k]); }
-                for (int k = 0; k < 3; k++) { c[4 + k] = x[4 + k] + d[3 + k]; step2 += d[3 + k]*d[3 + k]; }
-                for (int k = 0; k < 6; k++) { const double lam = B.dgs_p[6*a + k]*irad; mcc += lam*d[k]*d[k] - B.bp[6*a + k]*d[k]; }
-            } else for (int k = 0; k < 7; k++) c[k] = x[k];
-        }
-    }
-    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
-    if (tid == 0) { W.partial[2*b] = step2; W.partial[2*b + 1] = mcc; }
-}
-
-// ---- step quality and trust-region update (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics)
-__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o, int multi, int npp) {
-    LmState *st = W.st;
-    if (st->done) return;
-    __shared__ double red[5*256], xch[256];
-    const int tid = threadIdx.x;
-    // the candidate was linearised speculatively into lb[lcur^1]: its cost, gradient and diagonals are already there
-    const LinBuf &Bc = W.lb[st->lcur ^ 1];
-    double gmax_c, xn_c, cost;
-    double step2 = 0.0, mcc = 0.0;
-#ifdef TSBA_SOLVE_STAMPS
-    const long long s0_ = clock64(); long long s1_ = 0, s2_ = 0, s3_ = 0;
-#endif
-    if (!multi) {
-        double o5[5];
-        postlin_fused(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, nb_back, red, xch, o5, npp);
-        gmax_c = o5[0]; xn_c = o5[1]; cost = o5[2]; step2 = o5[3]; mcc = o5[4];
-#ifdef TSBA_SOLVE_STAMPS
-        s1_ = s2_ = s3_ = clock64();
-#endif
-    } else {                                      // k_sums_multi + all-reduce already produced the global sums
-        double gp, xp;
-        if (npp) pose_parts_multi(W, npp, red, gp, xp); else pose_scale(W, Bc, W.cb, W.cb + W.N, W.pose[st->cur ^ 1], false, red, gp, xp);
-        const double *sc = W.cb + 2*(size_t)W.N;
-        cost = sc[0]; xn_c = sc[1] + xp; step2 = sc[2]; mcc = sc[3]; gmax_c = fmax(W.cbm[0], gp);
-    }
-    if (tid) return;
-    [&]() {
-    mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
-    st->it++;
-    st->cand_cost = cost; st->model_change = mcc; st->step_norm = sqrt(step2);
-    if (st->step_fail || !(mcc > 0.0)) {          // invalid step (LevenbergMarquardtStrategy::StepIsInvalid)
-        st->step_fail = 0;
-        if (++st->invalid >= 5) { st->done = 1; st->term = 5; return; }
-        st->radius *= 0.5;
-    } else {
-        st->invalid = 0; st->n_cost++;
-        if (!(cost == cost)) cost = 1.7976931348623157e308;
-        if (st->step_norm <= o.parameter_tolerance*(st->x_norm + o.parameter_tolerance)) { st->done = 1; st->term = 2; return; }
-        double cost_change = st->x_cost - cost;
-        if (fabs(cost_change) <= o.function_tolerance*st->x_cost) { st->done = 1; st->term = 1; return; }
-        double rel = cost_change/mcc;
-        if (rel > o.min_relative_decrease) {      // accept: the speculative linearisation becomes the current one
-            st->cur ^= 1; st->lcur ^= 1; st->accepted++; st->n_lin++;
-            st->x_cost = cost; st->x_norm = sqrt(xn_c); st->gmax = gmax_c;
-            double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
-            st->radius = fmin(st->radius/f, o.max_radius);
-            st->decrease_factor = 2.0;
-            if (gmax_c <= o.gradient_tolerance) { st->done = 1; st->term = 3; return; }
-        } else {
-            st->radius = st->radius/st->decrease_factor; st->decrease_factor *= 2.0;
-        }
-    }
-    if (st->it >= st->max_it) { st->done = 1; st->term = 0; }
-    else if (st->radius < o.min_radius) { st->done = 1; st->term = 4; }
-    }();
-    if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)st->it << 1) | (st->done ? 1u : 0u); __threadfence_system(); }
-#ifdef TSBA_SOLVE_STAMPS
-    W.dbg[32] = s1_ - s0_; W.dbg[33] = s2_ - s1_; W.dbg[34] = s3_ - s2_; W.dbg[35] = clock64() - s3_;
-#endif
-}
-
-// ================================================================== multi-GPU (global BA sharded by landmark over RCCL)
-// stage A: local sums into the all-reduce buffer hb = [Hd | bp | scal] and gm.  spec: candidate LinBuf (also folds the
-// k_back partial sums: landmark blocks are owned by exactly one rank, the replicated pose blocks count on rank 0 only)
-__global__ __launch_bounds__(256) void k_sums_multi(Work W, LevelDev L, int spec, int nb_lm, int nb_back, int nb_back_lm, int skip_pose) {
-    LmState *st = W.st;
-    if (st->done) return;
-    if (!spec && !st->need_lin) return;
-    __shared__ double red[256];
-    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
-    double gl, xl, cost;
-    sums_local(W, L, B, W.cb, W.cb + W.N, nb_lm, red, gl, xl, cost, skip_pose != 0);
-    double step2 = 0.0, mcc = 0.0;
-    if (spec) for (int k = threadIdx.x; k < nb_back; k += 256)
-        if (k < nb_back_lm || W.rank == 0) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
-    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
-    if (threadIdx.x == 0) { double *sc = W.cb + 2*(size_t)W.N; sc[0] = cost; sc[1] = xl; sc[2] = step2; sc[3] = mcc; W.cbm[0] = gl; }
-}
-// reduced camera system: add the pose damping once, after the all-reduce of the partial S
-__global__ void k_damp_multi(Work W) {
-    LmState *st = W.st;
-    if (st->done) return;
-    const LinBuf &B = W.lb[st->lcur];
-    const double irad = 1.0/st->radius;
-    int a = blockIdx.x*blockDim.x + threadIdx.x;
-    if (a >= W.n_kf) return;
-    int ia = W.fidx[a]; if (ia < 0) return;
-    for (int k = 0; k < 6; k++) W.S[(size_t)(6*ia + k)*W.ldS + 6*ia + k] += B.dgs_p[6*a + k]*irad;
-}
-// Band storage keeps every row of S in a skewed window of LDB = band + 2 x 96 - 1 doubles (room for the wide-band Cholesky's diagonal
-// blocks): 251 columns at a band of 60 rows, of which a row holds at most band + 6 entries of the lower triangle.  The ranks exchange
-// only those: pack -> one all-reduce of N (band + 6) doubles (15.8 MB instead of 60 MB at 5000 keyframes) -> unpack.
-__global__ __launch_bounds__(256) void k_band_pack(Work W, double *buf, int wp, int unpack) {
-    const LmState *st = W.st;
-    if (st->done) return;
-    const int n = 6*(*W.nfree) + (W.ring ? wp - 6 : 0);          // (ring: + the ghost rows behind the last free pose, wp = band + 6)
-    const long long tot = (long long)n*wp;
-    const size_t ldS = (size_t)W.ldS;
-    for (long long e = (long long)blockIdx.x*256 + threadIdx.x; e < tot; e += (long long)gridDim.x*256) {
-        const int i = (int)(e/wp), k = (int)(e - (long long)i*wp), c = i - wp + 1 + k;     // row i, columns i - wp + 1 .. i
-        if (c < 0) { if (!unpack) buf[e] = 0.0; continue; }
-        if (unpack) W.S[(size_t)i*ldS + c] = buf[e]; else buf[e] = W.S[(size_t)i*ldS + c];
-    }
-}
-// landmark parameters live on their owner: delta = x - x0 on the owner, 0 elsewhere (all-reduced, then x = x0 + delta)
-__global__ void k_delta_multi(Work W, const double *rho0, const double *theta0, int apply) {
-    const int cur = W.st->cur;
-    int j = blockIdx.x*blockDim.x + threadIdx.x;
-    if (j < W.n_pt) {
-        if (!apply) W.dl_pt[j] = (W.pt_host[j] >= 0 && tsba_shard_of(W.pt_host[j], 0, W.n_kf, W.world) == W.rank) ? W.rho[cur][j] - rho0[j] : 0.0;   // (a frozen landmark does not move)
-        else W.rho[cur][j] = rho0[j] + W.dl_pt[j];
-    } else if (j < W.n_pt + 3*W.n_text) {
-        int k = j - W.n_pt, t = k/3;
-        if (!apply) W.dl_tx[k] = (W.text_host[t] >= 0 && tsba_shard_of(W.text_host[t], 0, W.n_kf, W.world) == W.rank) ? W.theta[cur][k] - theta0[k] : 0.0;
-        else W.theta[cur][k] = theta0[k] + W.dl_tx[k];
-    }
-}
-__global__ void k_kfin_multi(Work W) {               // kf_in was summed over ranks: back to a flag
-    int k = blockIdx.x*blockDim.x + threadIdx.x;
-    if (k < W.n_kf) W.kf_in[k] = W.kf_in[k] != 0;
-}
-
-// ---- outlier pass on loss-corrected residuals, optimizer.cc:1609-1686 / :1228-1305
-// pfin != nullptr (pose-only path): the pass's result still lives in the PoseState -- pose from there, and one extra workgroup
-// installs it into W.st / W.pose (field by field: the counters of this very kernel are being updated by atomics)
-__global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_mono, double chi2_text, double bad_ratio,
-                                                int do_scene, int do_text, const PoseState *pfin) {
-    LmState *st = W.st;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int selc = pfin ? 0 : st->cur;
-    const double *pose = pfin ? pfin->x : W.pose[selc], *rho = W.rho[selc], *theta = W.theta[selc];
-    if (st->nt_active < 50) chi2_mono += 4.0;
-    const int nb_sc = (L.n_sc + 63) >> 6;
-    if (b < nb_sc) {
-        // scene: one candidate per lane (a frame's single (target, frozen host) pair would otherwise be one wave's serial loop)
-        if (!do_scene) return;
-        const int c = b*64 + lane;
-        int nbad = 0;
-        if (c < L.n_sc && (!W.filter_good || W.sgood[L.sc_flag[c]])) {
-            const int pt = L.sc_pt[c], i = L.sc_kf[c], h = W.pt_host[pt];
-            Pose C; load_pose(pose + 7*i, C);
-            PairT T;
-            if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
-            else pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
-            double r[2];
-            scene_residual(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1],
-                           W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r);
-            double wgt; huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
-            double sc = sqrt(wgt);
-            double ex = r[0]*sc/W.w_sx, ey = r[1]*sc/W.w_sy;
-            if (ex*ex > chi2_mono || ey*ey > chi2_mono) { W.sgood[L.sc_flag[c]] = 0; nbad++; }
-        }
-        nbad = (int)wave_sum1((double)nbad);
-        if (lane == 0 && nbad) atomicAdd(&st->n_bad_scene, nbad);
-    } else if (b < nb_sc + L.n_tg) {
-        // text: one (KF, text) observation per workgroup, lane = (feature lane >> 3, tap lane & 7), 8 features per round
-        if (!do_text) return;
-        const int g = b - nb_sc;
-        const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
-        if (W.filter_good && !W.tobs_good[tb]) return;
-        const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
-        Pose C; load_pose(pose + 7*i, C);
-        PairT T;
-        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
-        else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
-        const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-        const uint8_t *img = L.img[i];
-        const int fg = W.tobs_fgood_off[tb];
-        const int k = lane & 7, f0 = L.tfeat_off[j], f1 = L.tfeat_off[j+1];
-        int nblk = 0, nbad = 0;
-        for (int fb = f0; fb < f1; fb += 8) {                          // (uniform trip count: the shuffles need all 8 lanes of a feature)
-            const int f = fb + (lane >> 3);
-            const bool in = f < f1 && (!W.filter_good || W.tfgood[fg + L.tfeat_raw[min(f, f1 - 1)]]);
-            double r = 0.0;
-            if (in && sigma != 0.0) {                                   // sigma == 0: residuals are 0, never an outlier
-                const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
-                double jt[6], jl[3];
-                double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];
-                r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h, mu, sigma, 1.0/sigma,
-                             L.tfeat_ref[8*(size_t)f + k], W.w_t, false, jt, jl);
-            }
-            double s = r*r;
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            double wgt; huber(s, W.huber_t, wgt);
-            const double sc = sqrt(wgt);
-            int bad = (in && sigma != 0.0 && fabs(r*sc/W.w_t) > chi2_text) ? 1 : 0;
-            bad |= __shfl_xor(bad, 1, 64); bad |= __shfl_xor(bad, 2, 64); bad |= __shfl_xor(bad, 4, 64);
-            if (k == 0 && in) { nblk++; if (bad) { W.tfgood[fg + L.tfeat_raw[f]] = 0; nbad++; } }
-        }
-        nblk = (int)wave_sum1((double)nblk); nbad = (int)wave_sum1((double)nbad);
-        if (lane == 0 && nblk > 0) {
-            if (nbad) atomicAdd(&st->n_bad_tfeat, nbad);
-            if ((double)nbad/(double)nblk > bad_ratio) { W.tobs_good[tb] = 0; atomicAdd(&st->n_bad_text, 1); }
-        }
-    } else if (pfin) {
-        if (lane < 7) { W.pose[0][lane] = pfin->x[lane]; W.pose[1][lane] = pfin->x[lane]; }
-        if (lane == 0) {
-            const LmState &S = pfin->S;
-            st->radius = S.radius; st->decrease_factor = S.decrease_factor; st->x_cost = S.x_cost; st->x_norm = S.x_norm;
-            st->cand_cost = S.cand_cost; st->model_change = S.model_change; st->step_norm = S.step_norm; st->gmax = S.gmax; st->cost0 = S.cost0;
-            st->done = S.done; st->need_lin = S.need_lin; st->first = S.first; st->it = S.it; st->accepted = S.accepted;
-            st->term = S.term; st->invalid = S.invalid; st->max_it = S.max_it; st->step_fail = S.step_fail; st->lcur = S.lcur;
-            st->n_lin = S.n_lin; st->n_cost = S.n_cost;
-        }
-    }
-}
-
-// ---- information matrix V (6 values) of one text plane at the end of a pass: ceres::Covariance runs after every pyramid pass of
-// PyrThetaOptim and the last successful one is kept (optimizer.cc:2219-2238)
-__global__ void k_record_vtx(Work W, int text, double *out6) {
-    const LinBuf &B = W.lb[W.st->lcur];
-    if (threadIdx.x < 6 && blockIdx.x == 0) out6[threadIdx.x] = B.V_tx[(size_t)threadIdx.x*W.n_text + text];
-}
-// ---- test hook: explicit residuals and Jacobians of every block, written at the reference's block order
-__global__ void k_eval_scene(Work W, LevelDev L, const int *out_idx, double *resid, double *jac) {
-    int c = blockIdx.x*blockDim.x + threadIdx.x; if (c >= L.n_sc) return;
-    int oi = out_idx[c]; if (oi < 0) return;
-    const double *pose = W.pose[0], *rho = W.rho[0];
-    // pair of this candidate
-    int i = L.sc_kf[c], pt = L.sc_pt[c], h = W.pt_host[pt];
-    Pose C; load_pose(pose + 7*i, C);
-    PairT T;
-    if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); } else pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
-    double r[2], jt[2][6], jl[2];
-    scene_block(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1], W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r, jt, jl);
-    resid[2*oi] = r[0]; resid[2*oi+1] = r[1];
-    if (jac) for (int k = 0; k < 2; k++) {
-        double *row = jac + (size_t)oi*26 + k*13;
-        for (int a = 0; a < 6; a++) row[a] = jt[k][a];
-        if (h >= 0) {
-            for (int cc = 0; cc < 3; cc++) {
-                row[6 + cc] = -(jt[k][0]*T.Rcr[cc] + jt[k][1]*T.Rcr[3 + cc] + jt[k][2]*T.Rcr[6 + cc]);
-                row[9 + cc] = -(jt[k][3]*T.Rcr[cc] + jt[k][4]*T.Rcr[3 + cc] + jt[k][5]*T.Rcr[6 + cc]);
-            }
-            row[12] = jl[k];
-        } else for (int a = 6; a < 13; a++) row[a] = 0.0;
-    }
-}
-__global__ void k_eval_text(Work W, LevelDev L, int nblk, const int *blk_g, const int *blk_f, int ns, double *resid, double *jac) {
-    int q = blockIdx.x*blockDim.x + threadIdx.x; if (q >= nblk) return;
-    int g = blk_g[q], f = blk_f[q];
-    const double *pose = W.pose[0], *theta = W.theta[0];
-    const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
-    const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
-    Pose C; load_pose(pose + 7*i, C);
-    PairT T;
-    if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); } else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
-    const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-    const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
-    double *rout = resid + 2*(size_t)ns + 8*(size_t)q;
-    double *jout = jac ? jac + 26*(size_t)ns + 120*(size_t)q : nullptr;
-    for (int k = 0; k < 8; k++) {
-        double jt[6] = {0,0,0,0,0,0}, jl[3] = {0,0,0}, r = 0.0;
-        if (sigma != 0.0) {
-            double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];
-            r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], L.img[i], L.img_w, L.img_h, mu, sigma, 1.0/sigma,
-                         L.tfeat_ref[8*(size_t)f + k], W.w_t, true, jt, jl);
-        }
-        rout[k] = r;
-        if (jout) {
-            double *row = jout + k*15;
-            for (int a = 0; a < 6; a++) row[a] = jt[a];
-            if (h >= 0) {
-                for (int cc = 0; cc < 3; cc++) {
-                    row[6 + cc] = -(jt[0]*T.Rcr[cc] + jt[1]*T.Rcr[3 + cc] + jt[2]*T.Rcr[6 + cc]);
-                    row[9 + cc] = -(jt[3]*T.Rcr[cc] + jt[4]*T.Rcr[3 + cc] + jt[5]*T.Rcr[6 + cc]);
-                }
-                row[12] = jl[0]; row[13] = jl[1]; row[14] = jl[2];
-            } else for (int a = 6; a < 15; a++) row[a] = 0.0;
-        }
-    }
-}
-
+#include "tsba_kernels_step.h"
 // ------------------------------------------------------------------------------------------------ host side
 static int pose_grid(const LevelDev &D) { return std::max(1, (D.n_sc + 255)/256 + (D.n_pf + 31)/32); }    // workgroups of k_pose_iter
 struct DevBuf {
@@ -3088,264 +1278,7 @@ int tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int level
     return TSBA_OK;
 }
 
-// debug / test aid: first linearisation of pass 0 + reduced system for `radius`; copies S (N x N), g (N), cost, kf flags
-int tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, double *cost, int32_t *kf_free, double *dp) {
-    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
-    if (!c->uploaded) return TSBA_ERR_STATE;
-    hipSetDevice(c->device);
-    int rc = reset_state(c); if (rc) return rc;
-    tsba_options saved = c->opt; c->opt.initial_radius = radius;
-    const LevelDev &D = c->lev[c->opt.levels[0]];
-    { int rca = set_solver_attrs(c); if (rca) return rca; }
-    launch_pass_init(c, D, 0);
-    launch_linearize(c, D, 0);
-    Work &W = c->W;
-    if ((int64_t)D.n_sb < (int64_t)c->n_kf*(c->n_kf + 1)/2) { hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream); c->S_stale = false;
-        if (D.far_B > 0) hipMemsetAsync(W.Sfar, 0, sizeof(double)*36*(size_t)std::max(D.n_far, 1), c->stream); }
-    // split (multi-GPU) sequence: this shard's PARTIAL S and g, before any exchange and without the pose damping (which is added
-    // once after the all-reduce) -- the parts of all shards sum to the unsharded system; dp is not computed
-    launch_schur(c, D, (int)is_multi(c));
-    if (!is_multi(c)) launch_solve_full(c, D); else hipMemsetAsync(W.dp, 0, sizeof(double)*W.N, c->stream);
-    c->opt = saved;
-    CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
-    if (S) {
-        if (!W.band) CK(hipMemcpy(S, W.S, sizeof(double)*(size_t)W.N*W.N, hipMemcpyDeviceToHost));
-        else { std::vector<double> hb(c->S_count); CK(hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost));
-            const long long N = W.N, LDB = W.ldS + 1, Wb = LDB - c->S_up;                // band -> dense (entries outside the band are zero)
-            for (long long i = 0; i < N; i++) for (long long j = 0; j < N; j++)
-                S[i*N + j] = (j >= i - Wb && j <= i + c->S_up - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0;
-            if (W.ring) {                     // the loop-closure blocks: ghost row 6 nfree + r stands for row r of the first poses (lower triangle: (late pose, early pose))
-                int nfr[2] = {0, 0}; CK(hipMemcpy(nfr, W.nfree, 2*sizeof(int), hipMemcpyDeviceToHost));
-                const long long n6 = 6LL*nfr[0], r06 = 6LL*nfr[1], ng = std::min<long long>(6LL*W.ring_b, N);
-                for (long long r = 0; r < ng && n6 + r < (long long)(c->S_count/LDB); r++) for (long long j = std::max(0LL, n6 + r - Wb); j < n6; j++) {
-                    const double v = hb[(size_t)(Wb + (n6 + r)*(LDB - 1) + j)]; if (v != 0.0 && j > r06 + r) S[j*N + r06 + r] = v; }
-            }
-            if (D.far_B > 0 && D.n_far > 0) {        // the blocks outside the band (lower triangle: rows of the later keyframe)
-                const HostPlan &H = c->hplan[D.level];
-                std::vector<double> hf(36*(size_t)D.n_far); std::vector<int> fi(c->n_kf);
-                CK(hipMemcpy(hf.data(), W.Sfar, sizeof(double)*hf.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(fi.data(), W.fidx, sizeof(int)*c->n_kf, hipMemcpyDeviceToHost));
-                for (int q = 0; q < D.n_far; q++) { const long long ia = fi[H.far_a[q]], ic = fi[H.far_b[q]]; if (ia < 0 || ic < 0) continue;
-                    for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) S[(6*ic + cc)*N + 6*ia + r] = hf[36*(size_t)q + 6*r + cc]; }
-            } }
-    }
-    if (g) CK(hipMemcpy(g, W.g, sizeof(double)*W.N, hipMemcpyDeviceToHost));
-    if (dp) CK(hipMemcpy(dp, W.dp, sizeof(double)*W.N, hipMemcpyDeviceToHost));
-    LmState st; CK(hipMemcpy(&st, W.st, sizeof(st), hipMemcpyDeviceToHost));
-    if (cost) *cost = st.x_cost;
-    if (kf_free) { std::vector<int> in(c->n_kf), cs(c->n_kf);
-        CK(hipMemcpy(in.data(), W.kf_in, sizeof(int)*c->n_kf, hipMemcpyDeviceToHost)); CK(hipMemcpy(cs.data(), W.kf_const, sizeof(int)*c->n_kf, hipMemcpyDeviceToHost));
-        for (int k = 0; k < c->n_kf; k++) kf_free[k] = in[k] && !cs[k]; }
-    return TSBA_OK;
-}
-
-// The same for LARGE maps, where the dense (6 n_kf)^2 copy is not an option (7.2 GB at 5000 keyframes): the band of the
-// compressed (free-pose) system in LAPACK lower-band storage, ab[(i - j)*n + j] = S(i, j) for j <= i <= j + bw -- what
-// scipy.linalg.solveh_banded(lower=True) takes.  Call once with ab = NULL to get n (rows) and bw, then with buffers.
-int tsba_debug_reduced_band(void *ctx, double radius, int32_t *n_out, int32_t *bw_out, double *ab, double *g, double *dp) {
-    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
-    if (!c->uploaded) return TSBA_ERR_STATE;
-    if (!c->W.band) { set_err(c, "the uploaded problem keeps a dense reduced system: use tsba_debug_reduced_system"); return TSBA_ERR_STATE; }
-    if (c->W.ring) { set_err(c, "ring-shaped map: the loop-closure blocks live in ghost rows outside the band (tsba_debug_set no_ring for the reordered band)"); return TSBA_ERR_STATE; }
-    int rc = tsba_debug_reduced_system(ctx, radius, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
-    Work &W = c->W;
-    int nfree = 0; CK(hipMemcpy(&nfree, W.nfree, sizeof(int), hipMemcpyDeviceToHost));
-    const long long n = 6LL*nfree, LDB = W.ldS + 1, Wb = LDB - c->S_up;
-    const int bw = std::max(6, c->lev[c->opt.levels[0]].bw_rows) + 5;              // rows below the diagonal that can be non-zero (block-aligned band)
-    if (n_out) *n_out = (int32_t)n; if (bw_out) *bw_out = bw;
-    if (ab) {
-        std::vector<double> hb(c->S_count); CK(hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost));
-        for (long long d = 0; d <= bw; d++) for (long long j = 0; j < n; j++) { const long long i = j + d;
-            ab[d*n + j] = (i < n && j >= i - Wb) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
-    }
-    if (g) CK(hipMemcpy(g, W.g, sizeof(double)*n, hipMemcpyDeviceToHost));
-    if (dp) CK(hipMemcpy(dp, W.dp, sizeof(double)*W.N, hipMemcpyDeviceToHost));
-    return TSBA_OK;
-}
-
-int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *algo_bytes) {
-    Ctx *c = (Ctx *)ctx; if (!c || n <= 0) return TSBA_ERR_ARG;
-    if (!c->uploaded || level < 0 || level >= c->n_levels || !c->lev_built[level]) { set_err(c, "level not uploaded"); return TSBA_ERR_STATE; }
-    hipSetDevice(c->device);
-    int rc = reset_state(c); if (rc) return rc;
-    const LevelDev &D = c->lev[level];
-    int ps = 0; for (int k = 0; k < c->opt.n_passes; k++) if (c->opt.levels[k] == level) ps = k;
-    launch_pass_init(c, D, ps);
-    launch_linearize(c, D, 0);                                 // warm-up (also leaves need_lin = 0)
-    CK(hipStreamSynchronize(c->stream));
-    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
-    st.need_lin = 1; st.done = 0; st.first = 0;
-    CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));   // k_linearize never clears need_lin itself
-    CK(hipEventRecord(c->ev0, c->stream));
-    for (int k = 0; k < n; k++) {
-        if (lin_small_pairs(c, D) && D.n_tg == 0) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4, false>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + 7)/8)*8), dim3(LIN_T), 0, c->stream, c->W, D, 0);
-        else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, c->W, D, 0);
-        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, c->W, D, 0);
-    }
-    CK(hipEventRecord(c->ev1, c->stream));
-    CK(hipEventSynchronize(c->ev1));
-    float ms = 0; CK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    if (avg_ms) *avg_ms = (double)ms/n;
-    if (algo_bytes) {   // 44 B / scene block, 128 B / text block, 16 B / (KF,text) pair, parameters once
-        int npairs_text = 0; std::vector<int> kin;
-        (void)kin;
-        for (int g = 0; g < D.n_tg; g++) npairs_text++;
-        *algo_bytes = 44.0*st.ns_active + 128.0*st.nt_active + 16.0*npairs_text + 56.0*c->n_kf + 8.0*c->n_pt + 24.0*c->n_text;
-    }
-    return TSBA_OK;
-}
-
-int tsba_text_label_image(void *ctx, int kf, int level, float *out) {
-    Ctx *c = (Ctx *)ctx; if (!c || !out) return TSBA_ERR_ARG;
-    if (!c->uploaded) { set_err(c, "no problem uploaded"); return TSBA_ERR_STATE; }
-    if (kf < 0 || kf >= c->n_kf || level < 0 || level >= c->n_levels || !c->lev_built[level]) { set_err(c, "keyframe / level out of range or level not uploaded"); return TSBA_ERR_ARG; }
-    hipSetDevice(c->device);
-    const LevelDev &D = c->lev[level];
-    if (D.img_w <= 0 || D.img_h <= 0 || (size_t)D.img_w*D.img_h > (size_t)MS_MASK_WORDS*32) { set_err(c, "no image geometry for this level"); return TSBA_ERR_ARG; }
-    const size_t npx = (size_t)D.img_w*D.img_h;
-    if (c->lbl_cap < npx) { if (c->lbl_dev) hipFree(c->lbl_dev); if (c->lbl_host) hipHostFree(c->lbl_host); c->lbl_cap = 0;
-        CK(hipMalloc((void **)&c->lbl_dev, npx*sizeof(float))); CK(hipHostMalloc((void **)&c->lbl_host, npx*sizeof(float), hipHostMallocDefault)); c->lbl_cap = npx; }
-    hipLaunchKernelGGL(k_label, dim3(1), dim3(LBL_THREADS), 0, c->stream, c->W, kf, D.img_w, D.img_h, D.K[0], D.K[1], D.K[2], D.K[3], c->lbl_dev);
-    CK(hipMemcpyAsync(c->lbl_host, c->lbl_dev, npx*sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
-    memcpy(out, c->lbl_host, npx*sizeof(float));
-    return TSBA_OK;
-}
-
-// which kernels the uploaded problem runs through (so that a test can assert that it exercises the path it means to):
-// out[0] reduced system in LDS (k_solve_t / k_solve_col)   [1] band storage   [2] streaming band solver   [3] interiors P
-// [4] separator system by cyclic reduction   [5] band rows   [6] four pairs per wave in the linearisation of the first pass's level
-// [7] fused pose-only kernel   [8] one-wave Schur blocks + k_pose_sums (large maps)   [9] world size   [10] rank
-// [11..14] size of this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots
-// [15] the rows of S follow a reverse Cuthill-McKee order of the keyframes instead of the keyframe index
-int tsba_debug_solver_info(void *ctx, int32_t *out, int n) {
-    Ctx *c = (Ctx *)ctx; if (!c || !out || n < 16) return TSBA_ERR_ARG;
-    if (!c->uploaded) return TSBA_ERR_STATE;
-    int use_lds; solve_lds_bytes(c, &use_lds);
-    int bwmax = 0; for (int l = 0; l < c->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
-    out[0] = use_lds; out[1] = c->W.band; out[2] = c->band_stream; out[3] = c->band_stream ? c->band_parts : 0; out[4] = c->sep_cr ? 1 : 0; out[5] = bwmax;
-    out[6] = lin_small_pairs(c, c->lev[c->opt.levels[0]]) ? 1 : 0; out[7] = c->pose_only ? 1 : 0; out[8] = c->n_kf > 126 ? 1 : 0;
-    out[9] = c->world; out[10] = c->rank;
-    { const LevelDev &D0 = c->lev[c->opt.levels[0]]; out[11] = D0.n_pair; out[12] = D0.n_sb; out[13] = D0.n_sc; out[14] = D0.n_pslot; out[15] = D0.kf_order ? 1 : 0; }
-    if (n >= 17) out[16] = c->W.ring;
-    if (n >= 19) { out[17] = c->far_B; out[18] = c->n_far; }
-    return TSBA_OK;
-}
-// Iterative reduced-system solves of the last tsba_solve on a map with long-range coupling (tsba_pcg.h): out[0] conjugate-gradient iterations in
-// total, [1] reduced systems solved (LM trials), [2] most iterations of one system, [3] systems that hit the iteration cap.  Zeros otherwise.
-int tsba_debug_pcg_stats(void *ctx, int32_t out[4]) {
-    Ctx *c = (Ctx *)ctx; if (!c || !out) return TSBA_ERR_ARG;
-    if (!c->uploaded) return TSBA_ERR_STATE;
-    out[0] = out[1] = out[2] = out[3] = 0;
-    if (c->far_B <= 0) return TSBA_OK;
-    hipSetDevice(c->device); CK(hipStreamSynchronize(c->stream));
-    CK(hipMemcpy(out, c->W.pc_stat, 4*sizeof(int32_t), hipMemcpyDeviceToHost));
-    return TSBA_OK;
-}
-// The 6x6 blocks outside the band after tsba_debug_reduced_system / a solve: keyframes a < b of block q and its 36 values (row-major, rows = a);
-// the number of blocks is solver_info [18].  Any output may be NULL.
-int tsba_debug_far_blocks(void *ctx, int32_t *a, int32_t *b, double *blocks) {
-    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
-    if (!c->uploaded || c->far_B <= 0) return TSBA_ERR_STATE;
-    const LevelDev &D = c->lev[c->opt.levels[0]]; const HostPlan &H = c->hplan[D.level];
-    hipSetDevice(c->device); CK(hipStreamSynchronize(c->stream));
-    if (a) memcpy(a, H.far_a.data(), sizeof(int32_t)*H.far_a.size());
-    if (b) memcpy(b, H.far_b.data(), sizeof(int32_t)*H.far_b.size());
-    if (blocks && D.n_far > 0) CK(hipMemcpy(blocks, c->W.Sfar, sizeof(double)*36*(size_t)D.n_far, hipMemcpyDeviceToHost));
-    return TSBA_OK;
-}
-// plane cache of the context (tsba_problem.kf_id): keyframes found on the device / copied, over the context's lifetime
-int tsba_debug_img_cache_stats(void *ctx, int64_t out[2]) {
-    Ctx *c = (Ctx *)ctx; if (!c || !out) return TSBA_ERR_ARG;
-    out[0] = c->ic.hits; out[1] = c->ic.misses; return TSBA_OK;
-}
-// Test hook of the multi-right-hand-side solve phase (tsba_bandms.h): M X = R with the band factor the last tsba_debug_reduced_system / solve left
-// behind.  R, X: [6 nfree][T] row-major (compressed free-pose rows).  TSBA_ERR_STATE unless the problem runs through the partitioned band
-// solver with the cyclic-reduction separator system on a chain.
-int tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X) {
-    Ctx *c = (Ctx *)ctx; if (!c || T < 1 || !R || !X) return TSBA_ERR_ARG;
-    if (!c->uploaded || !ms_available(c)) { if (c) set_err(c, "multi-right-hand-side solve: needs the partitioned band solver with cyclic reduction on a chain"); return TSBA_ERR_STATE; }
-    hipSetDevice(c->device);
-    int nfree = 0; CK(hipMemcpy(&nfree, c->W.nfree, sizeof(int), hipMemcpyDeviceToHost));
-    int rc = ms_reserve(c, T); if (rc) return rc;
-    { int rca = set_solver_attrs(c); if (rca) return rca; }
-    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
-    st.done = 0; st.step_fail = 0; st.lin_done = 0; CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));
-    CK(hipMemcpy(c->ms.R, R, sizeof(double)*6*(size_t)nfree*T, hipMemcpyHostToDevice));
-    launch_ms_solve(c);
-    CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
-    CK(hipMemcpy(X, c->ms.X, sizeof(double)*6*(size_t)nfree*T, hipMemcpyDeviceToHost));
-    return TSBA_OK;
-}
-// row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating); with a
-// plan order (reverse Cuthill-McKee, tsba_plan.h) this is not monotone in the keyframe index
-int tsba_debug_row_of_kf(void *ctx, int32_t *rowblk) {
-    Ctx *c = (Ctx *)ctx; if (!c || !rowblk) return TSBA_ERR_ARG;
-    if (!c->uploaded) return TSBA_ERR_STATE;
-    hipSetDevice(c->device); CK(hipStreamSynchronize(c->stream));
-    CK(hipMemcpy(rowblk, c->W.fidx, sizeof(int32_t)*c->n_kf, hipMemcpyDeviceToHost));
-    return TSBA_OK;
-}
-// host only (no device needed): the plan's band bound of one level, with or without the keyframe reordering; order_out [n_kf] gets the
-// row order (identity when the plan keeps the keyframe order)
-int tsba_debug_plan_band(const tsba_problem *p, const tsba_options *o, int level, int reorder, int32_t *bw_pose, int32_t *order_out) {
-    if (!p || !o || !bw_pose || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
-    HostPlan H; build_plan(p, o, level, H, false, reorder != 0);
-    *bw_pose = H.bw_pose;
-    if (order_out) for (int k = 0; k < p->n_kf; k++) order_out[k] = H.kf_order.empty() ? k : H.kf_order[(size_t)k];
-    return TSBA_OK;
-}
-int tsba_debug_plan_time(const tsba_problem *p, const tsba_options *o, int level, int reps, double *avg_ms) {   // host only: plan construction
-    if (!p || !o || reps == 0) return TSBA_ERR_ARG;
-    const bool laps = reps < 0; if (laps) reps = -reps;           // reps < 0: one recycled plan object (as a context does), lap times of the last build on stderr
-    HostPlan R;
-    if (laps) build_plan(p, o, level, R, false, true, CR_SMAX/6);
-    auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < reps; k++) { if (laps) build_plan(p, o, level, R, k == reps - 1, true, CR_SMAX/6); else { HostPlan H; build_plan(p, o, level, H); } }
-    *avg_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()/reps;
-    return TSBA_OK;
-}
-int tsba_debug_time_solve(void *ctx, int n, double *avg_ms) {     // n back-to-back launches of the dense solve on the last S, g
-    Ctx *c = (Ctx *)ctx; if (!c || n <= 0 || !c->uploaded) return TSBA_ERR_ARG;
-    hipSetDevice(c->device);
-    CK(hipStreamSynchronize(c->stream));
-    LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
-    st.done = 0; st.step_fail = 0;
-    CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));
-    launch_solve(c);
-    CK(hipEventRecord(c->ev0, c->stream));
-    for (int k = 0; k < n; k++) launch_solve(c);
-    CK(hipEventRecord(c->ev1, c->stream));
-    CK(hipEventSynchronize(c->ev1));
-    float ms = 0; CK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    *avg_ms = (double)ms/n;
-    return TSBA_OK;
-}
-
-int tsba_debug_copy_S(void *ctx, double *out) {      // (6 n_kf + 1) x (6 n_kf): factored S and the rhs row after a solve
-    Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded) return TSBA_ERR_STATE;
-    hipSetDevice(c->device); hipStreamSynchronize(c->stream);
-    const Work &W = c->W; const long long N = W.N;
-    if (!W.band) { if (hipMemcpy(out, W.S, sizeof(double)*(size_t)N*N, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE; }
-    else { std::vector<double> hb(c->S_count); if (hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE;
-        const long long LDB = W.ldS + 1, Wb = LDB - c->S_up;
-        for (long long i = 0; i < N; i++) for (long long j = 0; j < N; j++)
-            out[i*N + j] = (j >= i - Wb && j <= i + c->S_up - 1) ? hb[(size_t)(Wb + i*(LDB - 1) + j)] : 0.0; }
-    // row N = the rhs row: of the large-system solver if that ran, else unused (the LDS solver keeps it on chip)
-    return hipMemcpy(out + (size_t)N*N, W.Sy, sizeof(double)*(size_t)N, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
-}
-
-int tsba_debug_band_factor(void *ctx, double *lcol, long long n_lcol, double *ldbuf, long long n_ld) {      // test hook: streaming band solver's factor
-    Ctx *c = (Ctx *)ctx; if (!c || !c->uploaded || !c->Lcol) return TSBA_ERR_STATE;
-    hipSetDevice(c->device); hipStreamSynchronize(c->stream);
-    if (hipMemcpy(lcol, c->Lcol, sizeof(double)*n_lcol, hipMemcpyDeviceToHost) != hipSuccess) return TSBA_ERR_DEVICE;
-    return hipMemcpy(ldbuf, c->W.LDbuf, sizeof(double)*n_ld, hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
-}
-// host-side index arithmetic of the partitioned band solver, for the CPU test-suite (no device needed):
-// out5 = { P, a, b, has_left, has_right } of interior p;  block index of (br, bc) in the cyclic-reduction pool and the pool size
-// host-only: FNV-1a over the Schur slot-pair lists of the plan of `level`, built with `threads` host threads in the parallel sections
-// (0 = the production choice): the plan must not depend on the number of threads
-static int tsba_plan_checksum_ring = 0;       // ring_max_blocks the checksum hook builds its plan with (knob 2)
-void tsba_debug_plan_knob(int which, int value) { if (which == 0) tsba_plan_threads = value; else if (which == 1) tsba_plan_mark_mt = value; else if (which == 2) tsba_plan_checksum_ring = value; else if (which == 3) tsba_plan_pin = value; }   // host-only measurement knobs
+#include "tsba_debug_abi.h"
 } // extern "C"
 static unsigned long long plan_checksum(const HostPlan &H) {           // over EVERY list of the plan
     unsigned long long h = 1469598103934665603ull;

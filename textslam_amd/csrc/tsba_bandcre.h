@@ -385,4 +385,4 @@ __global__ __launch_bounds__(CRE_BT) void k_cre_back(Work W, Work Ws, int bw, in
 // (All back-substitution levels in ONE launch -- a workgroup per separator, waiting on its neighbours' flags with agent-scope release /
 // acquire -- was built and measured in round 2: 91 us against 7 x 11.2 us for the launches per level.  A hop of the dependency tree
 // through flags costs more than a kernel boundary: the release writes back the XCD's L2, the acquire invalidates it, and the poll
-// adds its own round trips.  tools/experiments/cre_back_all.h)
+// adds its own round trips.  The experiment is in the history of this repository: tools/experiments/cre_back_all.h, removed in round 3.)

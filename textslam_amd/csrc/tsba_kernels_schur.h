@@ -1,0 +1,318 @@
+// Assembly of the reduced camera system: k_schur_t, k_schur_quad.  (part of the single translation unit tsba.hip: included there, in this order)
+#pragma once
+// ---- reduced camera system.  grid = n_sb (one workgroup per 6x6 block) + n_kf (reduced gradient), 256 threads.
+// The (slot, slot, landmark) gather lists of a diagonal block hold ~1000 entries: four waves, and per wave the indices and
+// operands of four entries in flight before the first multiply (two dependent global round trips per 1024 entries).
+#define SCHUR_U 4
+// SCHUR_NW waves per workgroup: 4 for windows (a diagonal block gathers ~1000 slot pairs), 1 for large maps (54 k blocks of ~60 slot
+// pairs each at 5000 keyframes: three idle waves per block and their hand-off were most of the 0.64 ms)
+template <int SCHUR_NW>
+__global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int multi, int b0) {
+    constexpr int SCHUR_T = 64*SCHUR_NW;
+    LmState *st = W.st;
+    if (st->done) return;
+    __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
+    // (b0 > 0: large maps take the S blocks through k_schur_quad and only the gradient part here, a grid of a multiple of 8 workgroups in
+    // which the workgroups of ONE XCD -- workgroup i runs on XCD i mod 8 -- take neighbouring poses: the slot records of a landmark sit next
+    // to each other, one per observing pose, and neighbouring poses observe the same landmarks)
+    const int bx = b0 > 0 ? ((int)blockIdx.x & 7)*((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int b = bx + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double radius = st->radius, irad = 1.0/radius;
+    const LinBuf &B = W.lb[st->lcur];
+    if (b < L.n_sb) {
+        const int a = L.sb_a[b], c = L.sb_b[b];
+        const int ia = W.fidx[a], ic = W.fidx[c];           // rows / columns of S exist for free poses only
+        if (ia < 0 || ic < 0) return;
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[k] = 0.0;
+        const int pt0 = L.sb_pt_off[b], pt1 = L.sb_pt_off[b+1];
+        for (int base = pt0; base < pt1; base += SCHUR_T*SCHUR_U) {
+            int s1[SCHUR_U], s2[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                const int q = base + u*SCHUR_T + tid; ok[u] = q < pt1;
+                const int qc = min(q, pt1 - 1);
+                s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc];
+            }
+            double w1[SCHUR_U][6], w2[SCHUR_U][6], Vv[SCHUR_U], dg[SCHUR_U];
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
+#pragma unroll
+                for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
+            }
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                const double vinv = ok[u] ? ts_rcp(Vv[u] + dg[u]*irad) : 0.0;     // (v_rcp + Newton: an IEEE division is ~35 instructions per slot pair)
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    const double wr = w1[u][r]*vinv;
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += wr*w2[u][cc];
+                }
+            }
+        }
+        for (int q = L.sb_tx_off[b] + tid; q < L.sb_tx_off[b+1]; q += SCHUR_T) {
+            const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
+            double Vd[6], Vi[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+            Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
+            double W1[18], W2[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) { W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k]; W2[k] = B.w_tx[(size_t)(s2)*TX_REC + k]; }
+            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                double t0 = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
+                double t1 = W1[r*3]*Vi[1] + W1[r*3+1]*Vi[3] + W1[r*3+2]*Vi[4];
+                double t2 = W1[r*3]*Vi[2] + W1[r*3+1]*Vi[4] + W1[r*3+2]*Vi[5];
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += t0*W2[cc*3] + t1*W2[cc*3+1] + t2*W2[cc*3+2];
+            }
+        }
+        // operands of the tail, independent of the sums: issued before the reduction
+        double tail = 0.0;
+        if (wave == 0 && lane < 36) {
+            const int r = lane/6, cc = lane % 6;
+            const double *out = B.pairOut;
+            if (a == c) {
+                const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
+                tail = range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
+                if (r == cc && !multi) tail += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
+            } else {
+                int pab = L.sb_pab[b], pba = L.sb_pba[b];
+                if (pab >= 0) tail -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
+                if (pba >= 0) tail -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
+            }
+        }
+        if (SCHUR_NW > 1) {
+            if (wave > 0) {
+#pragma unroll
+                for (int k = 0; k < 36; k++) lds[((wave - 1)*36 + k)*64 + lane] = acc[k];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int k = 0; k < 36; k++) acc[k] += (lds[k*64 + lane] + lds[(36 + k)*64 + lane]) + lds[(72 + k)*64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 36; k++) lds[k*65 + lane] = acc[k];          // transpose: lane l < 36 sums entry l over the 64 lanes
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        double tot = 0.0;
+        if (lane < 36) {
+            const double *row = lds + lane*65;
+#pragma unroll 16
+            for (int k = 0; k < 64; k++) tot += row[k];
+        }
+        if (lane < 36) {
+            const int r = lane/6, cc = lane % 6;
+            const double v = tail - tot;
+            const size_t ldS = (size_t)W.ldS;                // (sb_a <= sb_b: the first store is the upper triangle, which band storage does not hold)
+            // band storage holds the lower triangle: the block goes to the row of the pose that comes LATER in S (with a plan order
+            // that need not be the larger keyframe index)
+            int ja = ia, jc = ic;
+            if (W.ring) { const int nf = W.nfree[0], r0 = W.nfree[1];       // closure block (a pose of the loop's first separator against a far one): the ghost row
+                if (ia - ic > W.ring_b && ic >= r0 && ic < r0 + W.ring_b) jc += nf - r0; else if (ic - ia > W.ring_b && ia >= r0 && ia < r0 + W.ring_b) ja += nf - r0; }
+            const bool a_later = ja > jc;
+            const int fq = L.sb_far ? L.sb_far[b] : -1;     // a block outside the band (long-range coupling): to the compact list, rows = the earlier keyframe a
+            if (fq >= 0) W.Sfar[(size_t)fq*36 + r*6 + cc] = v;
+            else {
+            if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
+            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
+            }
+        }
+    } else {
+        const int a = b - L.n_sb;
+        if (a >= W.n_kf) return;                               // (the gradient-only grid is rounded up to a multiple of 8)
+        const int ia = W.fidx[a];
+        if (ia < 0) return;
+        double acc[6] = {0,0,0,0,0,0};
+        const int ps0 = L.pose_ps_off[a], ps1 = L.pose_ps_off[a+1];
+        for (int base = ps0; base < ps1; base += SCHUR_T*SCHUR_U) {
+            int s[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                const int q = base + u*SCHUR_T + tid; ok[u] = q < ps1;
+                const int qc = min(q, ps1 - 1);
+                s[u] = L.pose_ps[qc]; j[u] = L.pose_ps_lm[qc];
+            }
+            double w[SCHUR_U][6], bb[SCHUR_U], Vv[SCHUR_U], dg[SCHUR_U];
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                bb[u] = B.b_pt[j[u]]; Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
+#pragma unroll
+                for (int k = 0; k < 6; k++) w[u][k] = B.w_pt[(size_t)(s[u])*PT_REC + k];
+            }
+#pragma unroll
+            for (int u = 0; u < SCHUR_U; u++) {
+                const double f = ok[u] ? bb[u]*ts_rcp(Vv[u] + dg[u]*irad) : 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) acc[k] += w[u][k]*f;
+            }
+        }
+        for (int q = L.pose_ts_off[a] + tid; q < L.pose_ts_off[a+1]; q += SCHUR_T) {
+            const int s = L.pose_ts[q], j = L.pose_ts_lm[q];
+            double Vd[6], Vi[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+            Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
+            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
+            double b0 = B.b_tx[j], b1 = B.b_tx[(size_t)W.n_text + j], b2 = B.b_tx[(size_t)2*W.n_text + j];
+            double f0 = Vi[0]*b0 + Vi[1]*b1 + Vi[2]*b2, f1 = Vi[1]*b0 + Vi[3]*b1 + Vi[4]*b2, f2 = Vi[2]*b0 + Vi[4]*b1 + Vi[5]*b2;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                acc[k] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*f0 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*f1 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*f2;
+        }
+        const double bpv = tid < 6 ? (multi ? B.bp_loc[6*a + tid] : B.bp[6*a + tid]) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[k] = wave_sum1(acc[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) lds[wave*6 + k] = acc[k];
+        }
+        __syncthreads();
+        if (tid < 6) W.g[6*ia + tid] = bpv - (SCHUR_NW > 1 ? (((lds[tid] + lds[6 + tid]) + lds[12 + tid]) + lds[18 + tid]) : lds[tid]);
+    }
+}
+
+// Large maps: FOUR S blocks per wave, 16 lanes each.  At 5000 keyframes a block gathers ~70 slot pairs: a whole wave per block left most
+// load slots empty and paid a 64-lane reduction (36 LDS writes + 64 reads) per block; here a 16-lane group walks its block's list 64
+// entries per round trip (4 in flight per lane), the 36 sums of a group are transposed through a 36 x 17 LDS tile and every lane
+// finishes up to three entries of the block (tail: pose-pair products, damping) and stores them.  Same sums, same order within a lane;
+// the order ACROSS lanes differs from k_schur_t<1> (16 partial sums instead of 64), which the tests' tolerances cover.
+#ifndef SCHURQ_U
+#define SCHURQ_U 1                          // list entries per lane in flight (k_schur_quad): 1 -> 128 registers, four waves per SIMD (101 us with 2 / three waves, 97 us with 1 at 5000 keyframes; 113 us with 4 / two waves)
+#endif
+// TEXT = false: a level without text planes (the reference's GlobalBA) -- the plane part (3x3 inverse, 18-value records) sets the kernel's
+// register count (214: two waves per SIMD); without it three fit.
+template <bool TEXT>
+__global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi) {
+    LmState *st = W.st;
+    if (st->done) return;
+    __shared__ double lds[4*12*17];                             // a third of a group's 36 sums at a time: 6.5 KB, the registers set the occupancy
+    const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
+    // workgroups are handed to the 8 XCDs round-robin (workgroup i -> XCD i mod 8), and an XCD's L2 does not see the others': neighbouring S
+    // blocks read the same landmarks' records, so the workgroups of ONE XCD take a contiguous range of blocks (the kernel is bound by
+    // L2 -> L1 line fills; with neighbouring blocks on eight different XCDs every record crossed the fabric up to eight times)
+    const int per = (int)gridDim.x >> 3, wg = ((int)blockIdx.x & 7)*per + ((int)blockIdx.x >> 3);     // (the grid is a multiple of 8 workgroups)
+    const int b = 4*wg + grp;
+    const bool have = b < L.n_sb;
+    const int bc = have ? b : L.n_sb - 1;
+    const double irad = 1.0/st->radius;
+    const LinBuf &B = W.lb[st->lcur];
+    const int a = L.sb_a[bc], c = L.sb_b[bc];
+    const int ia = W.fidx[a], ic = W.fidx[c];
+    const bool live = have && ia >= 0 && ic >= 0;               // rows / columns of S exist for free poses only
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+    const int pt0 = L.sb_pt_off[bc], pt1 = live ? L.sb_pt_off[bc+1] : pt0;
+    for (int base = pt0; base < pt1; base += 16*SCHURQ_U) {
+        int s1[SCHURQ_U], s2[SCHURQ_U], j[SCHURQ_U]; bool ok[SCHURQ_U];
+#pragma unroll
+        for (int u = 0; u < SCHURQ_U; u++) {
+            const int q = base + u*16 + sub; ok[u] = q < pt1;
+            const int qc = min(q, pt1 - 1);
+            s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc];
+        }
+        double w1[SCHURQ_U][6], w2[SCHURQ_U][6], Vv[SCHURQ_U], dg[SCHURQ_U];
+#pragma unroll
+        for (int u = 0; u < SCHURQ_U; u++) {
+            Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
+        }
+#pragma unroll
+        for (int u = 0; u < SCHURQ_U; u++) {
+            const double vinv = ok[u] ? ts_rcp(Vv[u] + dg[u]*irad) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double wr = w1[u][r]*vinv;
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += wr*w2[u][cc];
+            }
+        }
+    }
+    if (TEXT && live) for (int q = L.sb_tx_off[bc] + sub; q < L.sb_tx_off[bc+1]; q += 16) {
+        const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
+        double Vd[6], Vi[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+        Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
+        // (t = W1 Vi first, then W2 three values at a time: W1, W2 and acc live together cost the kernel a wave per SIMD)
+        double tv[18];
+        {
+            double W1[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) W1[k] = B.w_tx[(size_t)(s1)*TX_REC + k];
+            if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                tv[r*3] = W1[r*3]*Vi[0] + W1[r*3+1]*Vi[1] + W1[r*3+2]*Vi[2];
+                tv[r*3+1] = W1[r*3]*Vi[1] + W1[r*3+1]*Vi[3] + W1[r*3+2]*Vi[4];
+                tv[r*3+2] = W1[r*3]*Vi[2] + W1[r*3+1]*Vi[4] + W1[r*3+2]*Vi[5];
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) {
+            const double x0 = B.w_tx[(size_t)(s2)*TX_REC + cc*3], x1 = B.w_tx[(size_t)(s2)*TX_REC + cc*3 + 1], x2 = B.w_tx[(size_t)(s2)*TX_REC + cc*3 + 2];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[r*6 + cc] += tv[r*3]*x0 + tv[r*3+1]*x1 + tv[r*3+2]*x2;
+        }
+    }
+    // tails of this lane's entries o = sub, 12 + sub, 24 + sub (sub < 12), independent of the sums: issued before the reduction
+    double tail[3] = {0.0, 0.0, 0.0};
+    if (live && sub < 12) {
+        const double *out = B.pairOut;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int o = sub + 12*t;
+            const int r = o/6, cc = o - 6*r;
+            if (a == c) {
+                const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
+                tail[t] = range_sum<8>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<8>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);     // (8 in flight: a keyframe of a large map has ~8 pairs each way; 24 cost the kernel a wave per SIMD)
+                if (r == cc && !multi) tail[t] += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
+            } else {
+                const int pab = L.sb_pab[bc], pba = L.sb_pba[bc];
+                if (pab >= 0) tail[t] -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
+                if (pba >= 0) tail[t] -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
+            }
+        }
+    }
+    double *tile = lds + grp*12*17;
+    const size_t ldS = (size_t)W.ldS;
+    int ja = ia, jc = ic;
+    if (W.ring) { const int nf = W.nfree[0], r0 = W.nfree[1];               // closure block (a pose of the loop's first separator against a far one): the ghost row
+        if (ia - ic > W.ring_b && ic >= r0 && ic < r0 + W.ring_b) jc += nf - r0; else if (ic - ia > W.ring_b && ia >= r0 && ia < r0 + W.ring_b) ja += nf - r0; }
+    const bool a_later = ja > jc;
+    const int fq = (live && L.sb_far) ? L.sb_far[bc] : -1;     // a block outside the band (long-range coupling): to the compact list
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) tile[k*17 + sub] = acc[12*t + k];
+        __syncthreads();                                        // (one wave: an s_barrier of one wave)
+        if (live && sub < 12) {
+            const int o = sub + 12*t;
+            const double *row = tile + sub*17;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) { s0 += row[q]; s1 += row[q + 1]; s2 += row[q + 2]; s3 += row[q + 3]; }
+            const double v = tail[t] - ((s0 + s1) + (s2 + s3));
+            const int r = o/6, cc = o - 6*r;
+            if (fq >= 0) W.Sfar[(size_t)fq*36 + o] = v;
+            else {
+            if (a == c || !W.band || a_later) W.S[(size_t)(6*ja + r)*ldS + 6*jc + cc] = v;
+            if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+

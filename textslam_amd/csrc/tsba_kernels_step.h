@@ -1,0 +1,376 @@
+// The rest of an LM trial: k_back, k_decide, the split (multi-GPU) kernels, the outlier pass, test-hook evaluation kernels.  (part of the single translation unit tsba.hip: included there, in this order)
+#pragma once
+// ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
+__global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
+    LmState *st = W.st;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // static offsets / slot poses of this thread's landmark first: in flight together with the LM state
+    int o = 0, e = 0, act_ = 0, a0[6] = {0, 0, 0, 0, 0, 0};
+    if (b < nb_pt) { const int j = b*256 + tid; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
+#pragma unroll
+        for (int u = 0; u < 6; u++) a0[u] = L.pt_pose6[6*(size_t)j + u]; } }
+    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + tid; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
+    if (st->done) return;
+    __shared__ double red[256];
+    const int cur = st->cur;
+    const double irad = 1.0/st->radius;
+    const bool fail = st->step_fail;
+    const LinBuf &B = W.lb[st->lcur];
+    double step2 = 0.0, mcc = 0.0;
+    if (b < nb_pt) {
+        int j = b*256 + tid;
+        if (j < W.n_pt) {
+            double rh = W.rho[cur][j], d = 0.0;
+            if (!fail && e > o && act_) {
+                double acc = B.b_pt[j];
+                for (int s0 = o; s0 < e; s0 += 6) {                                 // 6 slots in flight; dp is 0 for constant / absent poses
+                    int a[6]; double w[6][6], dpv[6][6];
+#pragma unroll
+                    for (int u = 0; u < 6; u++) a[u] = s0 == o ? a0[u] : L.pslot_pose[min(s0 + u, e - 1)];
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+#pragma unroll
+                        for (int k = 0; k < 6; k++) { w[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 1))*PT_REC + k]; dpv[u][k] = W.dp[6*a[u] + k]; }
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+#pragma unroll
+                        for (int k = 0; k < 6; k++) acc += s0 + u < e ? w[u][k]*dpv[u][k] : 0.0;
+                }
+                const double lam = B.dgs_pt[j]*irad;
+                d = -acc/(B.V_pt[j] + lam);
+                step2 = d*d; mcc = lam*d*d - B.b_pt[j]*d;
+            }
+            W.rho[cur ^ 1][j] = rh + d;
+        }
+    } else if (b < nb_pt + nb_tx) {
+        int j = (b - nb_pt)*256 + tid;
+        if (j < W.n_text) {
+            double d[3] = {0,0,0};
+            if (!fail && e > o && act_) {
+                double acc[3] = { B.b_tx[j], B.b_tx[(size_t)W.n_text + j], B.b_tx[(size_t)2*W.n_text + j] };
+                for (int s0 = o; s0 < e; s0 += 3) {                                 // 3 slots in flight
+                    int a[3]; double w[3][18], dpv[3][6];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) a[u] = L.tslot_pose[min(s0 + u, e - 1)];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+#pragma unroll
+                        for (int k = 0; k < 18; k++) w[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 1))*TX_REC + k];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) dpv[u][k] = W.dp[6*a[u] + k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) if (s0 + u < e) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) { acc[0] += w[u][k*3]*dpv[u][k]; acc[1] += w[u][k*3 + 1]*dpv[u][k]; acc[2] += w[u][k*3 + 2]*dpv[u][k]; }
+                    }
+                }
+                double Vd[6], Vi[6], lam[3];
+#pragma unroll
+                for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+#pragma unroll
+                for (int k = 0; k < 3; k++) lam[k] = B.dgs_tx[(size_t)k*W.n_text + j]*irad;
+                Vd[0] += lam[0]; Vd[3] += lam[1]; Vd[5] += lam[2];
+                if (inv_sym3(Vd, Vi)) {
+                    d[0] = -(Vi[0]*acc[0] + Vi[1]*acc[1] + Vi[2]*acc[2]);
+                    d[1] = -(Vi[1]*acc[0] + Vi[3]*acc[1] + Vi[4]*acc[2]);
+                    d[2] = -(Vi[2]*acc[0] + Vi[4]*acc[1] + Vi[5]*acc[2]);
+                    for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - B.b_tx[(size_t)k*W.n_text + j]*d[k]; }
+                }
+            }
+            for (int k = 0; k < 3; k++) W.theta[cur ^ 1][3*j + k] = W.theta[cur][3*j + k] + d[k];
+        }
+    } else {
+        int a = (b - nb_pt - nb_tx)*256 + tid;
+        if (a < W.n_kf) {
+            const double *x = W.pose[cur] + 7*a; double *c = W.pose[cur ^ 1] + 7*a;
+            if (!fail && W.fidx[a] >= 0) {
+                double d[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) d[k] = W.dp[6*a + k];
+                double q[4] = { x[0], x[1], x[2], x[3] }, qn[4];
+                quat_plus(q, d, qn);
+                for (int k = 0; k < 4; k++) { c[k] = qn[k]; step2 += (qn[k] - q[k])*(qn[k] - q[k]); }
+                for (int k = 0; k < 3; k++) { c[4 + k] = x[4 + k] + d[3 + k]; step2 += d[3 + k]*d[3 + k]; }
+                for (int k = 0; k < 6; k++) { const double lam = B.dgs_p[6*a + k]*irad; mcc += lam*d[k]*d[k] - B.bp[6*a + k]*d[k]; }
+            } else for (int k = 0; k < 7; k++) c[k] = x[k];
+        }
+    }
+    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+    if (tid == 0) { W.partial[2*b] = step2; W.partial[2*b + 1] = mcc; }
+}
+
+// ---- step quality and trust-region update (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics)
+__global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o, int multi, int npp) {
+    LmState *st = W.st;
+    if (st->done) return;
+    __shared__ double red[5*256], xch[256];
+    const int tid = threadIdx.x;
+    // the candidate was linearised speculatively into lb[lcur^1]: its cost, gradient and diagonals are already there
+    const LinBuf &Bc = W.lb[st->lcur ^ 1];
+    double gmax_c, xn_c, cost;
+    double step2 = 0.0, mcc = 0.0;
+#ifdef TSBA_SOLVE_STAMPS
+    const long long s0_ = clock64(); long long s1_ = 0, s2_ = 0, s3_ = 0;
+#endif
+    if (!multi) {
+        double o5[5];
+        postlin_fused(W, L, Bc, W.pose[st->cur ^ 1], false, nb_lm, nb_back, red, xch, o5, npp);
+        gmax_c = o5[0]; xn_c = o5[1]; cost = o5[2]; step2 = o5[3]; mcc = o5[4];
+#ifdef TSBA_SOLVE_STAMPS
+        s1_ = s2_ = s3_ = clock64();
+#endif
+    } else {                                      // k_sums_multi + all-reduce already produced the global sums
+        double gp, xp;
+        if (npp) pose_parts_multi(W, npp, red, gp, xp); else pose_scale(W, Bc, W.cb, W.cb + W.N, W.pose[st->cur ^ 1], false, red, gp, xp);
+        const double *sc = W.cb + 2*(size_t)W.N;
+        cost = sc[0]; xn_c = sc[1] + xp; step2 = sc[2]; mcc = sc[3]; gmax_c = fmax(W.cbm[0], gp);
+    }
+    if (tid) return;
+    [&]() {
+    mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
+    st->it++;
+    st->cand_cost = cost; st->model_change = mcc; st->step_norm = sqrt(step2);
+    if (st->step_fail || !(mcc > 0.0)) {          // invalid step (LevenbergMarquardtStrategy::StepIsInvalid)
+        st->step_fail = 0;
+        if (++st->invalid >= 5) { st->done = 1; st->term = 5; return; }
+        st->radius *= 0.5;
+    } else {
+        st->invalid = 0; st->n_cost++;
+        if (!(cost == cost)) cost = 1.7976931348623157e308;
+        if (st->step_norm <= o.parameter_tolerance*(st->x_norm + o.parameter_tolerance)) { st->done = 1; st->term = 2; return; }
+        double cost_change = st->x_cost - cost;
+        if (fabs(cost_change) <= o.function_tolerance*st->x_cost) { st->done = 1; st->term = 1; return; }
+        double rel = cost_change/mcc;
+        if (rel > o.min_relative_decrease) {      // accept: the speculative linearisation becomes the current one
+            st->cur ^= 1; st->lcur ^= 1; st->accepted++; st->n_lin++;
+            st->x_cost = cost; st->x_norm = sqrt(xn_c); st->gmax = gmax_c;
+            double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
+            st->radius = fmin(st->radius/f, o.max_radius);
+            st->decrease_factor = 2.0;
+            if (gmax_c <= o.gradient_tolerance) { st->done = 1; st->term = 3; return; }
+        } else {
+            st->radius = st->radius/st->decrease_factor; st->decrease_factor *= 2.0;
+        }
+    }
+    if (st->it >= st->max_it) { st->done = 1; st->term = 0; }
+    else if (st->radius < o.min_radius) { st->done = 1; st->term = 4; }
+    }();
+    if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)st->it << 1) | (st->done ? 1u : 0u); __threadfence_system(); }
+#ifdef TSBA_SOLVE_STAMPS
+    W.dbg[32] = s1_ - s0_; W.dbg[33] = s2_ - s1_; W.dbg[34] = s3_ - s2_; W.dbg[35] = clock64() - s3_;
+#endif
+}
+
+// ================================================================== multi-GPU (global BA sharded by landmark over RCCL)
+// stage A: local sums into the all-reduce buffer hb = [Hd | bp | scal] and gm.  spec: candidate LinBuf (also folds the
+// k_back partial sums: landmark blocks are owned by exactly one rank, the replicated pose blocks count on rank 0 only)
+__global__ __launch_bounds__(256) void k_sums_multi(Work W, LevelDev L, int spec, int nb_lm, int nb_back, int nb_back_lm, int skip_pose) {
+    LmState *st = W.st;
+    if (st->done) return;
+    if (!spec && !st->need_lin) return;
+    __shared__ double red[256];
+    const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
+    double gl, xl, cost;
+    sums_local(W, L, B, W.cb, W.cb + W.N, nb_lm, red, gl, xl, cost, skip_pose != 0);
+    double step2 = 0.0, mcc = 0.0;
+    if (spec) for (int k = threadIdx.x; k < nb_back; k += 256)
+        if (k < nb_back_lm || W.rank == 0) { step2 += W.partial[2*k]; mcc += W.partial[2*k + 1]; }
+    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
+    if (threadIdx.x == 0) { double *sc = W.cb + 2*(size_t)W.N; sc[0] = cost; sc[1] = xl; sc[2] = step2; sc[3] = mcc; W.cbm[0] = gl; }
+}
+// reduced camera system: add the pose damping once, after the all-reduce of the partial S
+__global__ void k_damp_multi(Work W) {
+    LmState *st = W.st;
+    if (st->done) return;
+    const LinBuf &B = W.lb[st->lcur];
+    const double irad = 1.0/st->radius;
+    int a = blockIdx.x*blockDim.x + threadIdx.x;
+    if (a >= W.n_kf) return;
+    int ia = W.fidx[a]; if (ia < 0) return;
+    for (int k = 0; k < 6; k++) W.S[(size_t)(6*ia + k)*W.ldS + 6*ia + k] += B.dgs_p[6*a + k]*irad;
+}
+// Band storage keeps every row of S in a skewed window of LDB = band + 2 x 96 - 1 doubles (room for the wide-band Cholesky's diagonal
+// blocks): 251 columns at a band of 60 rows, of which a row holds at most band + 6 entries of the lower triangle.  The ranks exchange
+// only those: pack -> one all-reduce of N (band + 6) doubles (15.8 MB instead of 60 MB at 5000 keyframes) -> unpack.
+__global__ __launch_bounds__(256) void k_band_pack(Work W, double *buf, int wp, int unpack) {
+    const LmState *st = W.st;
+    if (st->done) return;
+    const int n = 6*(*W.nfree) + (W.ring ? wp - 6 : 0);          // (ring: + the ghost rows behind the last free pose, wp = band + 6)
+    const long long tot = (long long)n*wp;
+    const size_t ldS = (size_t)W.ldS;
+    for (long long e = (long long)blockIdx.x*256 + threadIdx.x; e < tot; e += (long long)gridDim.x*256) {
+        const int i = (int)(e/wp), k = (int)(e - (long long)i*wp), c = i - wp + 1 + k;     // row i, columns i - wp + 1 .. i
+        if (c < 0) { if (!unpack) buf[e] = 0.0; continue; }
+        if (unpack) W.S[(size_t)i*ldS + c] = buf[e]; else buf[e] = W.S[(size_t)i*ldS + c];
+    }
+}
+// landmark parameters live on their owner: delta = x - x0 on the owner, 0 elsewhere (all-reduced, then x = x0 + delta)
+__global__ void k_delta_multi(Work W, const double *rho0, const double *theta0, int apply) {
+    const int cur = W.st->cur;
+    int j = blockIdx.x*blockDim.x + threadIdx.x;
+    if (j < W.n_pt) {
+        if (!apply) W.dl_pt[j] = (W.pt_host[j] >= 0 && tsba_shard_of(W.pt_host[j], 0, W.n_kf, W.world) == W.rank) ? W.rho[cur][j] - rho0[j] : 0.0;   // (a frozen landmark does not move)
+        else W.rho[cur][j] = rho0[j] + W.dl_pt[j];
+    } else if (j < W.n_pt + 3*W.n_text) {
+        int k = j - W.n_pt, t = k/3;
+        if (!apply) W.dl_tx[k] = (W.text_host[t] >= 0 && tsba_shard_of(W.text_host[t], 0, W.n_kf, W.world) == W.rank) ? W.theta[cur][k] - theta0[k] : 0.0;
+        else W.theta[cur][k] = theta0[k] + W.dl_tx[k];
+    }
+}
+__global__ void k_kfin_multi(Work W) {               // kf_in was summed over ranks: back to a flag
+    int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k < W.n_kf) W.kf_in[k] = W.kf_in[k] != 0;
+}
+
+// ---- outlier pass on loss-corrected residuals, optimizer.cc:1609-1686 / :1228-1305
+// pfin != nullptr (pose-only path): the pass's result still lives in the PoseState -- pose from there, and one extra workgroup
+// installs it into W.st / W.pose (field by field: the counters of this very kernel are being updated by atomics)
+__global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_mono, double chi2_text, double bad_ratio,
+                                                int do_scene, int do_text, const PoseState *pfin) {
+    LmState *st = W.st;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int selc = pfin ? 0 : st->cur;
+    const double *pose = pfin ? pfin->x : W.pose[selc], *rho = W.rho[selc], *theta = W.theta[selc];
+    if (st->nt_active < 50) chi2_mono += 4.0;
+    const int nb_sc = (L.n_sc + 63) >> 6;
+    if (b < nb_sc) {
+        // scene: one candidate per lane (a frame's single (target, frozen host) pair would otherwise be one wave's serial loop)
+        if (!do_scene) return;
+        const int c = b*64 + lane;
+        int nbad = 0;
+        if (c < L.n_sc && (!W.filter_good || W.sgood[L.sc_flag[c]])) {
+            const int pt = L.sc_pt[c], i = L.sc_kf[c], h = W.pt_host[pt];
+            Pose C; load_pose(pose + 7*i, C);
+            PairT T;
+            if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+            else pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+            double r[2];
+            scene_residual(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1],
+                           W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r);
+            double wgt; huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
+            double sc = sqrt(wgt);
+            double ex = r[0]*sc/W.w_sx, ey = r[1]*sc/W.w_sy;
+            if (ex*ex > chi2_mono || ey*ey > chi2_mono) { W.sgood[L.sc_flag[c]] = 0; nbad++; }
+        }
+        nbad = (int)wave_sum1((double)nbad);
+        if (lane == 0 && nbad) atomicAdd(&st->n_bad_scene, nbad);
+    } else if (b < nb_sc + L.n_tg) {
+        // text: one (KF, text) observation per workgroup, lane = (feature lane >> 3, tap lane & 7), 8 features per round
+        if (!do_text) return;
+        const int g = b - nb_sc;
+        const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
+        if (W.filter_good && !W.tobs_good[tb]) return;
+        const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
+        Pose C; load_pose(pose + 7*i, C);
+        PairT T;
+        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
+        else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
+        const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+        const uint8_t *img = L.img[i];
+        const int fg = W.tobs_fgood_off[tb];
+        const int k = lane & 7, f0 = L.tfeat_off[j], f1 = L.tfeat_off[j+1];
+        int nblk = 0, nbad = 0;
+        for (int fb = f0; fb < f1; fb += 8) {                          // (uniform trip count: the shuffles need all 8 lanes of a feature)
+            const int f = fb + (lane >> 3);
+            const bool in = f < f1 && (!W.filter_good || W.tfgood[fg + L.tfeat_raw[min(f, f1 - 1)]]);
+            double r = 0.0;
+            if (in && sigma != 0.0) {                                   // sigma == 0: residuals are 0, never an outlier
+                const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
+                double jt[6], jl[3];
+                double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];
+                r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h, mu, sigma, 1.0/sigma,
+                             L.tfeat_ref[8*(size_t)f + k], W.w_t, false, jt, jl);
+            }
+            double s = r*r;
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            double wgt; huber(s, W.huber_t, wgt);
+            const double sc = sqrt(wgt);
+            int bad = (in && sigma != 0.0 && fabs(r*sc/W.w_t) > chi2_text) ? 1 : 0;
+            bad |= __shfl_xor(bad, 1, 64); bad |= __shfl_xor(bad, 2, 64); bad |= __shfl_xor(bad, 4, 64);
+            if (k == 0 && in) { nblk++; if (bad) { W.tfgood[fg + L.tfeat_raw[f]] = 0; nbad++; } }
+        }
+        nblk = (int)wave_sum1((double)nblk); nbad = (int)wave_sum1((double)nbad);
+        if (lane == 0 && nblk > 0) {
+            if (nbad) atomicAdd(&st->n_bad_tfeat, nbad);
+            if ((double)nbad/(double)nblk > bad_ratio) { W.tobs_good[tb] = 0; atomicAdd(&st->n_bad_text, 1); }
+        }
+    } else if (pfin) {
+        if (lane < 7) { W.pose[0][lane] = pfin->x[lane]; W.pose[1][lane] = pfin->x[lane]; }
+        if (lane == 0) {
+            const LmState &S = pfin->S;
+            st->radius = S.radius; st->decrease_factor = S.decrease_factor; st->x_cost = S.x_cost; st->x_norm = S.x_norm;
+            st->cand_cost = S.cand_cost; st->model_change = S.model_change; st->step_norm = S.step_norm; st->gmax = S.gmax; st->cost0 = S.cost0;
+            st->done = S.done; st->need_lin = S.need_lin; st->first = S.first; st->it = S.it; st->accepted = S.accepted;
+            st->term = S.term; st->invalid = S.invalid; st->max_it = S.max_it; st->step_fail = S.step_fail; st->lcur = S.lcur;
+            st->n_lin = S.n_lin; st->n_cost = S.n_cost;
+        }
+    }
+}
+
+// ---- information matrix V (6 values) of one text plane at the end of a pass: ceres::Covariance runs after every pyramid pass of
+// PyrThetaOptim and the last successful one is kept (optimizer.cc:2219-2238)
+__global__ void k_record_vtx(Work W, int text, double *out6) {
+    const LinBuf &B = W.lb[W.st->lcur];
+    if (threadIdx.x < 6 && blockIdx.x == 0) out6[threadIdx.x] = B.V_tx[(size_t)threadIdx.x*W.n_text + text];
+}
+// ---- test hook: explicit residuals and Jacobians of every block, written at the reference's block order
+__global__ void k_eval_scene(Work W, LevelDev L, const int *out_idx, double *resid, double *jac) {
+    int c = blockIdx.x*blockDim.x + threadIdx.x; if (c >= L.n_sc) return;
+    int oi = out_idx[c]; if (oi < 0) return;
+    const double *pose = W.pose[0], *rho = W.rho[0];
+    // pair of this candidate
+    int i = L.sc_kf[c], pt = L.sc_pt[c], h = W.pt_host[pt];
+    Pose C; load_pose(pose + 7*i, C);
+    PairT T;
+    if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); } else pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+    double r[2], jt[2][6], jl[2];
+    scene_block(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1], W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r, jt, jl);
+    resid[2*oi] = r[0]; resid[2*oi+1] = r[1];
+    if (jac) for (int k = 0; k < 2; k++) {
+        double *row = jac + (size_t)oi*26 + k*13;
+        for (int a = 0; a < 6; a++) row[a] = jt[k][a];
+        if (h >= 0) {
+            for (int cc = 0; cc < 3; cc++) {
+                row[6 + cc] = -(jt[k][0]*T.Rcr[cc] + jt[k][1]*T.Rcr[3 + cc] + jt[k][2]*T.Rcr[6 + cc]);
+                row[9 + cc] = -(jt[k][3]*T.Rcr[cc] + jt[k][4]*T.Rcr[3 + cc] + jt[k][5]*T.Rcr[6 + cc]);
+            }
+            row[12] = jl[k];
+        } else for (int a = 6; a < 13; a++) row[a] = 0.0;
+    }
+}
+__global__ void k_eval_text(Work W, LevelDev L, int nblk, const int *blk_g, const int *blk_f, int ns, double *resid, double *jac) {
+    int q = blockIdx.x*blockDim.x + threadIdx.x; if (q >= nblk) return;
+    int g = blk_g[q], f = blk_f[q];
+    const double *pose = W.pose[0], *theta = W.theta[0];
+    const int tb = L.tg_tobs[g], i = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
+    const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
+    Pose C; load_pose(pose + 7*i, C);
+    PairT T;
+    if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); } else pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
+    const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
+    const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1];
+    double *rout = resid + 2*(size_t)ns + 8*(size_t)q;
+    double *jout = jac ? jac + 26*(size_t)ns + 120*(size_t)q : nullptr;
+    for (int k = 0; k < 8; k++) {
+        double jt[6] = {0,0,0,0,0,0}, jl[3] = {0,0,0}, r = 0.0;
+        if (sigma != 0.0) {
+            double mx = (fu + TAP_DX[k] - L.K[2])/L.K[0], my = (fv + TAP_DY[k] - L.K[3])/L.K[1];
+            r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], L.img[i], L.img_w, L.img_h, mu, sigma, 1.0/sigma,
+                         L.tfeat_ref[8*(size_t)f + k], W.w_t, true, jt, jl);
+        }
+        rout[k] = r;
+        if (jout) {
+            double *row = jout + k*15;
+            for (int a = 0; a < 6; a++) row[a] = jt[a];
+            if (h >= 0) {
+                for (int cc = 0; cc < 3; cc++) {
+                    row[6 + cc] = -(jt[0]*T.Rcr[cc] + jt[1]*T.Rcr[3 + cc] + jt[2]*T.Rcr[6 + cc]);
+                    row[9 + cc] = -(jt[3]*T.Rcr[cc] + jt[4]*T.Rcr[3 + cc] + jt[5]*T.Rcr[6 + cc]);
+                }
+                row[12] = jl[0]; row[13] = jl[1]; row[14] = jl[2];
+            } else for (int a = 6; a < 15; a++) row[a] = 0.0;
+        }
+    }
+}
+

@@ -409,4 +409,4 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
 // (k_solve_r -- the same solver with every row at the same stride, update tiles with an unmasked path and scalar tile indices, optionally
 // only on the SIMDs without a panel wave -- was built and measured in round 2 on the C4 window: 34.95 us with ten update waves, 37.0 us
 // with the six of SIMD 2 and 3, against 33.5 us for this kernel.  What paid on the cyclic-reduction levels (tsba_bandcre.h), where the update
-// waves set the pace, does not here, where the panel chain does.  tools/experiments/solve_rect.h)
+// waves set the pace, does not here, where the panel chain does.  In the history of this repository: tools/experiments/solve_rect.h, removed in round 3.)
