@@ -276,7 +276,7 @@ typedef struct tsba_debug_options {
     int32_t no_kf_reorder;     /* 1: keep the rows of S in keyframe order even when the envelope is wide (loop closures) */
     int32_t no_schur_quad;     /* 1: large maps assemble S with one wave per 6x6 block (k_schur_t<1>) instead of four blocks per wave */
     int32_t no_ring;           /* 1: a ring-shaped map (one loop closure between the last and the first keyframes) through the reordering path instead of the ghost-row partition */
-    int32_t far_solver;        // maps with long-range coupling (band + blocks outside it, conjugate gradients preconditioned with the band solver): 0 by the plan's rule (when no keyframe order brings the envelope within the band solvers' reach), 1 never (reordering / wide-band Cholesky as before), 2 whenever the map is eligible
+    int32_t far_solver;        // maps with long-range coupling (band part + blocks between a landmark's clusters, tsba_pcg.h): 0 by the plan's rule (when no keyframe order brings the envelope within the band solvers' reach), 1 never (reordering / wide-band Cholesky as before), 2 whenever the map is eligible, 3 as 2 without the low-rank correction for loop closures (tsba_wb.h: A/B runs of the plain iterations)
     int32_t pcg_max_it;        // > 0: iteration cap of the conjugate gradients (default 200)
     int32_t pcg_tol_exp;       // > 0: relative tolerance 10^-pcg_tol_exp of the conjugate gradients in the M^-1 norm (default 10)
     int32_t pcg_refactor;      // how the single-vector conjugate gradients apply the preconditioner: 0 / 1 by running the band factorisation again with the residual as right-hand side, 2 by the solve phase of tsba_bandms.h (one column of its 64: slower for one vector; A/B runs)

@@ -43,6 +43,7 @@
 #include "tsba_bandcre.h"
 #include "tsba_bandms.h"
 #include "tsba_pcg.h"
+#include "tsba_wb.h"
 #include "tsba_pose.h"
 
 #include "tsba_kernels_step.h"
@@ -100,6 +101,7 @@ struct Ctx {
                       int w[TSBA_MAX_LEVELS] = {0,0,0,0}, h[TSBA_MAX_LEVELS] = {0,0,0,0}; unsigned lvl_mask = 0;
                       long long id[TSBA_IMG_CACHE_KF]; unsigned long long used[TSBA_IMG_CACHE_KF]; bool full[TSBA_IMG_CACHE_KF]; unsigned long long tick = 0;
                       long long hits = 0, misses = 0; } ic;
+    WbBuf wb{}; Work Wk{}; double *wb_alloc = nullptr; size_t wb_bytes = 0;      // low-rank correction for loop closures (tsba_wb.h): its buffers, the k x k dense system as a second Work
     EcgBuf ecg{}; double *ecg_alloc = nullptr; size_t ecg_bytes = 0;      // enlarged conjugate gradients (tsba_pcg.h)
     MsBuf ms{}; double *ms_alloc = nullptr; size_t ms_bytes = 0; int ms_cap = 0;      // multi-right-hand-side solve phase of the partitioned band solver (tsba_bandms.h)
     int cov_text = -1; double *cov_log = nullptr;     // tsba_theta_optim: V of this plane at the end of every pass [TSBA_MAX_LEVELS][6]
@@ -256,6 +258,7 @@ int tsba_destroy(void *ctx) {
     if (c->ic.dev) hipFree(c->ic.dev); if (c->ic.stage) hipHostFree(c->ic.stage);
     if (c->ms_alloc) hipFree(c->ms_alloc);
     if (c->ecg_alloc) hipFree(c->ecg_alloc);
+    if (c->wb_alloc) hipFree(c->wb_alloc);
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (c->ev_stage[l]) hipEventDestroy(c->ev_stage[l]);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
@@ -366,8 +369,8 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         // ring maps (one loop closure): a single-level, single-GPU solve through the partitioned solver with the cyclic-reduction separator tree
         const int ring_max = (n_lev == 1 && !c->dbg.no_ring && !c->dbg.no_band_stream && c->dbg.sep_solver != 1 && c->dbg.sep_solver != 3 && c->dbg.band_parts != 1) ? CR_SMAX/6 : 0;
         // maps with long-range coupling (several loop closures, points seen again much later): band + blocks outside it, preconditioned conjugate gradients
-        const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream && (!c->dbg.no_ring || c->dbg.far_solver == 2)) ? CR_SMAX/6 : 0;     // (no_ring asks for the reordering path)
-        const bool far_force = c->dbg.far_solver == 2;
+        const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream && (!c->dbg.no_ring || c->dbg.far_solver >= 2)) ? CR_SMAX/6 : 0;     // (no_ring asks for the reordering path)
+        const bool far_force = c->dbg.far_solver == 2 || c->dbg.far_solver == 3;
         for (int ps = o->n_passes - 1; ps >= 0; ps--) { const int l = o->levels[ps]; if (seen[l]) continue;
             bool later = false; for (int q = 0; q < ps; q++) later |= o->levels[q] == l;       // (a level used by an earlier pass is started with that pass)
             if (later) continue;
@@ -609,6 +612,8 @@ static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, dou
     if (!H.kf_order.empty()) UV(kf_order); else D.kf_order = nullptr;
     D.far_B = H.far_B; D.n_far = H.n_far();
     D.sb_far = nullptr;
+    D.n_wb = (int)H.wb_kf.size(); D.wb_kf = nullptr; D.wb_idx = nullptr;
+    if (H.far_B > 0 && D.n_wb > 0) { UV(wb_kf); UV(wb_idx); }
     if (H.far_B > 0) { UV(far_a); UV(far_b); UV(far_off); UV(far_ent); UV(fb_id); UV(fb_pab); UV(fb_pba); UV(fb_pt_off); UV(fb_pt_s1); UV(fb_pt_s2); UV(fb_pt_lm);
         UV(fb_tx_off); UV(fb_tx_s1); UV(fb_tx_s2); UV(fb_tx_lm); }
     UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
@@ -822,6 +827,7 @@ static int set_solver_attrs(Ctx *c) {
     }
     return 0;
 }
+static void launch_dense_chol(Ctx *c, Work &W, int bw);
 // dense solve of the reduced camera system: LDS kernel for small windows, multi-workgroup blocked Cholesky otherwise
 static void launch_solve(Ctx *c) {
     Work &W = c->W;
@@ -892,8 +898,11 @@ static void launch_solve(Ctx *c) {
         else hipLaunchKernelGGL(k_band_backsub<3>, dim3(1), dim3(BAND_BS_T), ldsb, c->stream, W, bws, (const double *)c->Lcol);
         return;
     }
+    launch_dense_chol(c, W, std::min(c->cur_bw_rows, W.N));
+}
+// multi-workgroup blocked Cholesky (tsba_chol.h) of the system in `W` (band bound bw rows below a pose block; bw = N: dense)
+static void launch_dense_chol(Ctx *c, Work &W, int bw) {
     const int N = W.N;                                             // worst case: every keyframe free
-    const int bw = std::min(c->cur_bw_rows, N);                    // band of the reduced camera matrix (rows below a pose block)
     hipLaunchKernelGGL(k_chol_rhs, dim3((N + 255)/256), dim3(256), 0, c->stream, W);
     const int lds_diag = (int)(solve_diag_lds_doubles()*sizeof(double));
     const int lds_panel = (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double);
@@ -958,7 +967,8 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     // (measured at 5000 keyframes, ms per solve, single vector / enlarged: two loop closures 410 / 303, three closures at 3000 keyframes 231 / 229, 1 % long-range
     // points 247 / 320: the block iteration pays where the coupling outside the band is a few hundred blocks -- outlying eigenvalues, which it captures 32 at a
     // time -- and loses where it is spread over the map)
-    const bool want_block = c->dbg.pcg_block == 2 || (c->dbg.pcg_block == 0 && D.n_far <= 4096);
+    const bool closures = D.n_wb > 0 && c->dbg.far_solver != 3;       // (a few dozen keyframes touched: the low-rank correction below, not the block iteration)
+    const bool want_block = c->dbg.pcg_block == 2 || (c->dbg.pcg_block == 0 && D.n_far <= 4096 && !closures);
     if (ms_available(c) && want_block && ms_reserve(c, std::max(ECG_T, c->ms_cap)) == TSBA_OK) {
         const int nch = (c->n_kf + ECG_CH - 1)/ECG_CH; const size_t n6 = (size_t)W.N;
         const size_t need = (2*n6*ECG_T + (size_t)nch*2*(ECG_T*ECG_T + 1) + 4*(size_t)ECG_T*ECG_T + 4*ECG_T + 16)*sizeof(double);
@@ -1001,7 +1011,44 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
             return;
         }
     }
-    hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W);
+    // Loop closures (E touches a few dozen keyframes): the band solve corrected by the low-rank part exactly (tsba_wb.h) is the preconditioner --
+    // set up once per trial (one solve phase with k columns, the k x k matrix), then a band solve and a k x k Cholesky per application
+    bool wb = D.n_wb > 0 && ms_available(c) && c->dbg.far_solver != 3 && ms_reserve(c, std::max(6*D.n_wb, c->ms_cap)) == TSBA_OK;
+    const int kk = 6*D.n_wb;
+    if (wb) {
+        const size_t need = (3*(size_t)kk*kk + 2*(size_t)kk + (size_t)W.N + ((size_t)kk + 1)*kk + 4*(size_t)kk + 64 + 2*(size_t)D.n_wb + 16)*sizeof(double);
+        if (need > c->wb_bytes) { if (c->wb_alloc) { hipStreamSynchronize(c->stream); hipFree(c->wb_alloc); } c->wb_alloc = nullptr; c->wb_bytes = 0;
+            if (hipMalloc((void **)&c->wb_alloc, need) == hipSuccess) c->wb_bytes = need; else wb = false; }
+    }
+    double *K2 = nullptr;
+    if (wb) {
+        WbBuf &Bw = c->wb; double *q = c->wb_alloc;
+        Bw.k = kk; Bw.n_u = D.n_wb; Bw.wb_kf = D.wb_kf; Bw.wb_idx = D.wb_idx;
+        Bw.Gm = q; q += (size_t)kk*kk; Bw.T1 = q; q += (size_t)kk*kk; K2 = q; q += (size_t)kk*kk; Bw.xu = q; q += kk; Bw.vu = q; q += kk; Bw.z = q; q += W.N;
+        Work &Wk = c->Wk; memset(&Wk, 0, sizeof(Wk));
+        Wk.N = kk; Wk.n_kf = D.n_wb; Wk.ldS = kk; Wk.band = 0; Wk.st = W.st;
+        Wk.S = q; q += ((size_t)kk + 1)*kk; Wk.Sy = q; q += kk + 8; Wk.g = q; q += kk; Wk.dp = q; q += kk; Wk.LDbuf = q; q += kk + 8;
+        Wk.fidx = (int *)q; Wk.nfree = Wk.fidx + D.n_wb + 2;
+        const int Tk = c->ms.T; c->ms.T = kk; const MsBuf M = c->ms;
+        hipLaunchKernelGGL(k_wb_init, dim3(1), dim3(64), 0, c->stream, Wk.fidx, Wk.nfree, D.n_wb);
+        hipLaunchKernelGGL(k_wb_units, dim3(1024), dim3(256), 0, c->stream, W, M, Bw);
+        launch_ms_solve(c);
+        hipLaunchKernelGGL(k_wb_gather, dim3(std::min(1024, (kk*kk + 255)/256)), dim3(256), 0, c->stream, W, M, Bw);
+        hipLaunchKernelGGL(k_wb_EG, dim3(D.n_wb), dim3(256), 0, c->stream, W, D, Bw);
+        hipLaunchKernelGGL(k_wb_K2, dim3(std::min(2048, (kk*kk + 255)/256)), dim3(256), 0, c->stream, W, Bw, K2);
+        c->ms.T = Tk;
+    }
+    auto correct = [&](const double *yp, double ys) {              // z = M_W^-1 r from y = M^-1 r = ys * yp[]
+        WbBuf &Bw = c->wb; Work &Wk = c->Wk; MsBuf M = c->ms; M.T = kk;
+        hipLaunchKernelGGL(k_wb_rhs, dim3(1), dim3(512), 0, c->stream, W, Bw, yp, ys, Wk.g);
+        hipMemcpyAsync(Wk.S, K2, sizeof(double)*(size_t)kk*kk, hipMemcpyDeviceToDevice, c->stream);     // (the Cholesky works in place: a fresh copy per application)
+        launch_dense_chol(c, Wk, kk);
+        hipLaunchKernelGGL(k_wb_Gw, dim3(1), dim3(512), 0, c->stream, W, Bw, (const double *)Wk.dp);
+        hipLaunchKernelGGL(k_wb_Ex, dim3(D.n_wb), dim3(64), 0, c->stream, W, D, Bw, (const double *)Bw.xu);
+        hipLaunchKernelGGL(k_wb_apply, dim3(512), dim3(256), 0, c->stream, W, M, Bw, yp, ys);
+    };
+    if (wb) { correct(W.Sy, -1.0); hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, (const double *)c->wb.z, 1.0); }
+    else hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, (const double *)W.Sy, -1.0);
     auto finished = [&](int it) {                                  // true: the device reported convergence (or the end of the pass); else waits until it is within two iterations
         if (!c->hprog || it < 2) return false;
         const auto tw = std::chrono::steady_clock::now();
@@ -1015,15 +1062,16 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     // that is not available (a single interior, the sequential separator solve) the factorisation is run again with the residual as right-hand side
     // (measured at 5000 keyframes, one column: 1.3 ms per application against 0.57 ms for the factorisation re-run -- the solve phase pays for 64
     // columns whether it has them or not; it is the default only for the block variants.  pcg_refactor = 2 selects it for the single-vector iteration)
-    const bool ms = ms_available(c) && c->dbg.pcg_refactor == 2 && ms_reserve(c, std::max(1, c->ms_cap)) == TSBA_OK;
-    const double *zp = W.Sy; double zs = -1.0;
+    const bool ms = !wb && ms_available(c) && c->dbg.pcg_refactor == 2 && ms_reserve(c, std::max(1, c->ms_cap)) == TSBA_OK;
+    const double *zp = wb ? c->wb.z : W.Sy; double zs = wb ? 1.0 : -1.0;
     int it = 0;
     for (; it < cap; it++) {
         if (finished(it)) break;
         hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_T), 0, c->stream, W, D, it, seq, B, tol2, nbp, zp, zs);
         if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, c->ms.R, 1.0);
             const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
-        else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, W.g, -1.0); launch_solve(c); }
+        else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, W.g, -1.0); launch_solve(c);
+            if (wb) { correct(W.Sy, -1.0); zp = c->wb.z; zs = 1.0; } }
         hipLaunchKernelGGL(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, zp, zs);
     }
     hipLaunchKernelGGL(k_pcg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
@@ -1315,10 +1363,10 @@ unsigned long long tsba_debug_plan_checksum_recycled(const tsba_problem *warm, c
 }
 // host-only: the band + long-range split of the plan of `level` (tsba_plan.h: HostPlan::far_* / fb_*) when bands of up to far_max_blocks pose blocks are allowed.
 // out[0] band of the preconditioner M in pose blocks (0: no split: ring, reordering or plain band), [1] 6x6 blocks of E (all ranks'), [2] those this rank
-// contributes to, [3] the plan's band bound, [4] ring, [5] keyframes reordered, [6] checksum of the block positions (low 31 bits), [7] slot pairs of E.
+// contributes to, [3] the plan's band bound, [4] ring, [5] keyframes reordered, [6] checksum of the block positions (low 31 bits), [7] slot pairs of E, [8] keyframes touched by E when few enough for the low-rank correction (else 0).
 // Checks what the split promises -- every block of M within the band, every slot pair of a landmark in exactly one of M / E, the positions of E
 // sorted -- and returns TSBA_ERR_STATE if not.
-int tsba_debug_plan_far(const tsba_problem *p, const tsba_options *o, int level, int far_max_blocks, int force, int ring_max_blocks, int32_t out[8]) {
+int tsba_debug_plan_far(const tsba_problem *p, const tsba_options *o, int level, int far_max_blocks, int force, int ring_max_blocks, int32_t out[9]) {
     if (!p || !o || !out || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
     HostPlan H; build_plan(p, o, level, H, false, true, ring_max_blocks, far_max_blocks, force != 0);
     int mine = 0; long long npairs = 0;
@@ -1337,7 +1385,7 @@ int tsba_debug_plan_far(const tsba_problem *p, const tsba_options *o, int level,
     unsigned long long h = 1469598103934665603ull;
     for (const std::vector<int32_t> *v : { &H.far_a, &H.far_b, &H.far_off, &H.far_ent }) for (int32_t x : *v) { h ^= (unsigned int)x; h *= 1099511628211ull; }
     out[0] = H.far_B; out[1] = H.n_far(); out[2] = mine; out[3] = H.bw_pose; out[4] = H.ring; out[5] = H.kf_order.empty() ? 0 : 1; out[6] = (int32_t)(h & 0x7fffffffu);
-    out[7] = (int32_t)npairs;
+    out[7] = (int32_t)npairs; out[8] = (int32_t)H.wb_kf.size();
     return TSBA_OK;
 }
 // host-only: does the plan of `level` take the ring path (one loop closure between the last and the first keyframes) when separators of up

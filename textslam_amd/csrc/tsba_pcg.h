@@ -41,14 +41,14 @@ __device__ __forceinline__ void pcg_block_partial(double v, double *out, double 
 }
 
 // r_0 = -g, z_0 = M^-1 r_0 (the band solve that just ran), x = 0, p = 0 (beta_0 = 0), partial r.z
-__global__ __launch_bounds__(PCG_ET) void k_pcg_begin(Work W) {
+__global__ __launch_bounds__(PCG_ET) void k_pcg_begin(Work W, const double *zp, double zs) {
     __shared__ double lds[4];
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
     const int tid = threadIdx.x, a = blockIdx.x*32 + tid/6, k = tid % 6;
     double rzp = 0.0;
     if (a < W.n_kf) { const int ia = W.fidx[a];
-        if (ia >= 0) { const int i = 6*ia + k; const double gv = W.g[i], r = -gv, z = -W.Sy[i];
+        if (ia >= 0) { const int i = 6*ia + k; const double gv = W.g[i], r = -gv, z = zs*zp[i];
             W.pc_g0[i] = gv; W.pc_r[i] = r; W.pc_x[i] = 0.0; W.pc_p[0][i] = 0.0; W.pc_p[1][i] = 0.0; rzp = r*z; } }
     pcg_block_partial<PCG_ET>(rzp, W.pc_part, lds);
 }
@@ -65,10 +65,11 @@ __global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it
     const double rz0 = it == 0 ? rz : so->rz0, rz_old = it == 0 ? 1.0 : so->rz;
     if (!(rz == rz)) { if (blockIdx.x == 0 && tid == 0) { st->step_fail = 1; pcg_publish(W, seq, it, 1); } return; }
     // where M is so ill-conditioned that the tolerance lies below the rounding noise of M^-1 r (weakly damped trials of maps with loop closures:
-    // the drift modes) r.z stops falling: 12 iterations without a gain of a tenth end the solve with what it has -- the LM step test judges it
+    // the drift modes) r.z stops falling: 40 iterations without a gain of a tenth (r.z of conjugate gradients is not monotone: plateaus of a dozen
+    // iterations occur on the way down) end the solve with what it has -- the LM step test judges it
     const double best_o = it == 0 ? rz : so->best; const int since_o = it == 0 ? 0 : so->since;
     const bool gain = rz < 0.9*best_o; const double best = gain ? rz : best_o; const int since = gain ? 0 : since_o + 1;
-    if (!(rz > tol2*rz0) || since >= 12) {                   // converged (every workgroup takes the same decision from the same partials)
+    if (!(rz > tol2*rz0) || since >= 40) {                   // converged (every workgroup takes the same decision from the same partials)
         if (blockIdx.x == 0 && tid == 0) { st->lin_done = 1; W.pc_stat[0] += it; W.pc_stat[1] += 1; if (it > W.pc_stat[2]) W.pc_stat[2] = it; pcg_publish(W, seq, it, 1); }
         return; }
     const double beta = it == 0 ? 0.0 : rz/rz_old;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_ecg_small(Work W, EcgBuf E, int mode, 
         const double rz0 = E.scal[0], best_o = E.scal[2]; const int since_o = (int)E.scal[3];
         const bool gain = rz < 0.9*best_o; const int since = gain ? 0 : since_o + 1;
         if (!(rz == rz)) { if (tid == 0) { st->step_fail = 1; pcg_publish(W, seq, it, 1); } return; }
-        if (!(rz > tol2*rz0) || since >= 8) { if (tid == 0) { st->lin_done = 1; W.pc_stat[0] += it + 1; W.pc_stat[1] += 1; if (it + 1 > W.pc_stat[2]) W.pc_stat[2] = it + 1; pcg_publish(W, seq, it, 1); } return; }
+        if (!(rz > tol2*rz0) || since >= 16) { if (tid == 0) { st->lin_done = 1; W.pc_stat[0] += it + 1; W.pc_stat[1] += 1; if (it + 1 > W.pc_stat[2]) W.pc_stat[2] = it + 1; pcg_publish(W, seq, it, 1); } return; }
         __syncthreads();
         if (tid == 0) { E.scal[1] = rz; if (gain) E.scal[2] = rz; E.scal[3] = (double)since; pcg_publish(W, seq, it, 0); }
     }

@@ -61,6 +61,7 @@ struct HostPlan {
     int far_B = 0;
     std::vector<int32_t> far_a, far_b;          // [n_far] keyframes of a block of E
     std::vector<int32_t> far_off, far_ent;      // per keyframe: its blocks of E as (index << 1 | 1 if the keyframe is far_b), ascending
+    std::vector<int32_t> wb_kf, wb_idx;         // the keyframes a block of E touches, when they are few (<= 64: loop closures -- the low-rank correction of tsba_wb.h), and every keyframe's index in that list (-1)
     std::vector<int32_t> fb_id, fb_pab, fb_pba, fb_pt_off, fb_pt_s1, fb_pt_s2, fb_pt_lm, fb_tx_off, fb_tx_s1, fb_tx_s2, fb_tx_lm;    // fb_id: 0 .. n_far - 1
     int n_far() const { return (int)far_a.size(); }
     // scene candidates (sorted by pair)
@@ -95,7 +96,7 @@ struct HostPlan {
     // storage kept -- no allocation, no page faults for lists of the size the last call needed
     void recycle() {
         level = 0; bw_pose = 0; ring = 0; ring_k0 = 0; far_B = 0;
-        for (std::vector<int32_t> *v : { &far_a, &far_b, &far_off, &far_ent, &fb_id, &fb_pab, &fb_pba, &fb_pt_off, &fb_pt_s1, &fb_pt_s2, &fb_pt_lm, &fb_tx_off, &fb_tx_s1, &fb_tx_s2, &fb_tx_lm, &kf_order, &sc_obs, &sc_kf, &sc_pt, &sc_flag, &sc_slot, &pair_i, &pair_h, &pair_hpos, &pair_sc_off, &pair_tg_off, &pair_tg,
+        for (std::vector<int32_t> *v : { &wb_kf, &wb_idx, &far_a, &far_b, &far_off, &far_ent, &fb_id, &fb_pab, &fb_pba, &fb_pt_off, &fb_pt_s1, &fb_pt_s2, &fb_pt_lm, &fb_tx_off, &fb_tx_s1, &fb_tx_s2, &fb_tx_lm, &kf_order, &sc_obs, &sc_kf, &sc_pt, &sc_flag, &sc_slot, &pair_i, &pair_h, &pair_hpos, &pair_sc_off, &pair_tg_off, &pair_tg,
                                          &tg_tobs, &tg_kf, &tg_text, &tg_pair, &tg_slot, &pt_pose6, &pt_pair4, &tg_ppos, &pf_g, &pf_f, &tg_rec,
                                          &pls_off, &pslot_pose, &pslot_pair, &pslot_lm, &tls_off, &tslot_pose, &tslot_pair, &tslot_lm,
                                          &sb_a, &sb_b, &sb_pab, &sb_pba, &sb_pt_off, &sb_pt_s1, &sb_pt_s2, &sb_pt_lm, &sb_tx_off, &sb_tx_s1, &sb_tx_s2, &sb_tx_lm,
@@ -573,6 +574,10 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 std::vector<int64_t> hist((size_t)far_max_blocks + 2, 0); int64_t n_lm2 = 0;
                 for (const PoseList v : poses_of) { if (v.size() < 2) continue; n_lm2++; hist[(size_t)std::min(v.back() - v[0], far_max_blocks + 1)]++; }
                 int Bm = 0; for (int s = 1; s <= far_max_blocks; s++) if (hist[(size_t)s]*500 >= n_lm2) Bm = s;
+                // (a handful of landmarks just beyond that span -- an observer skipped here and there -- would scatter small blocks of E over the whole map: the
+                // band takes them in unless that costs more than one or two extra pose blocks)
+                for (int grow = 0; Bm >= 1 && Bm < far_max_blocks && grow < 2; grow++) { int64_t nbeyond = 0; for (int s = Bm + 1; s <= far_max_blocks; s++) nbeyond += hist[(size_t)s];
+                    if (nbeyond <= 4) break; Bm++; }
                 int64_t n_wide = 0; for (int s = Bm + 1; s <= far_max_blocks + 1; s++) n_wide += hist[(size_t)s];
                 if (Bm >= 1 && n_wide*5 <= n_lm2 && n_kf >= 4*(3*Bm + 2) + Bm) far_B = Bm;
             }
@@ -602,6 +607,9 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 P.far_ent.resize((size_t)P.far_off[(size_t)n_kf]);
                 { std::vector<int32_t> cur(P.far_off.begin(), P.far_off.end() - 1);
                   for (int q = 0; q < n_far; q++) { P.far_ent[(size_t)cur[(size_t)P.far_a[(size_t)q]]++] = q << 1; P.far_ent[(size_t)cur[(size_t)P.far_b[(size_t)q]]++] = (q << 1) | 1; } }
+                { int nu = 0; for (int k = 0; k < n_kf; k++) nu += P.far_off[(size_t)k + 1] > P.far_off[(size_t)k];
+                  if (nu > 0 && nu <= 64) { P.wb_idx.assign((size_t)n_kf, -1);
+                      for (int k = 0; k < n_kf; k++) if (P.far_off[(size_t)k + 1] > P.far_off[(size_t)k]) { P.wb_idx[(size_t)k] = (int32_t)P.wb_kf.size(); P.wb_kf.push_back(k); } } }
                 // this rank's slots: cluster of every slot, the band part M rebuilt from the pairs within a cluster, E from the pairs across clusters
                 std::vector<int32_t> cl_pt((size_t)P.n_pslot(), 0), cl_tx((size_t)P.n_tslot(), 0);
                 std::vector<char> wide_pt((size_t)n_pt, 0), wide_tx((size_t)n_text, 0), pair_far((size_t)n_pair, 0);

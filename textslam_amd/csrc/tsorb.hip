@@ -881,7 +881,6 @@ __global__ __launch_bounds__(128) void k_match(MatchDev M, int nq, const float *
 
 struct OCtx {
     int device = 0; hipStream_t stream = nullptr; std::string err;
-    hipStream_t stream2 = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // the blurred planes depend on the pyramid only: they are computed next to FAST / quadtree / orientation
     int nfeatures = 1000, nlevels = 8, ini_th = 20, min_th = 7; float scale = 1.2f;
     float sf[MAXL], isf[MAXL]; int nfl[MAXL], umax[16], gk[7];
     std::vector<void *> allocs; bool uploaded = false;
@@ -907,8 +906,6 @@ int tsorb_create(void **ctx, int nfeatures, float scale, int nlevels, int ini_th
     if (hipSetDevice(device) != hipSuccess) return TSORB_ERR_DEVICE;
     OCtx *c = new OCtx(); c->device = device; c->nfeatures = nfeatures; c->scale = scale; c->nlevels = nlevels; c->ini_th = ini_th; c->min_th = min_th;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TSORB_ERR_DEVICE; }
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) != hipSuccess
-        || hipEventCreateWithFlags(&c->ev_blur, hipEventDisableTiming) != hipSuccess) { if (c->stream2) hipStreamDestroy(c->stream2); c->stream2 = nullptr; }     // (optional: one stream then)
     // ORBextractor::ORBextractor, ORBextractor.cc:410-471 (fp32 arithmetic as there)
     c->sf[0] = 1.0f; for (int i = 1; i < nlevels; i++) c->sf[i] = c->sf[i-1]*scale;
     for (int i = 0; i < nlevels; i++) c->isf[i] = 1.0f/c->sf[i];
@@ -930,7 +927,6 @@ int tsorb_create(void **ctx, int nfeatures, float scale, int nlevels, int ini_th
 }
 int tsorb_destroy(void *ctx) { OCtx *c = (OCtx *)ctx; if (!c) return TSORB_ERR_ARG; hipSetDevice(c->device); ofree(c);
     if (c->m_buf) hipFree(c->m_buf); if (c->m_feat) hipFree(c->m_feat); if (c->mq_dev) hipFree(c->mq_dev); if (c->mq_host) hipHostFree(c->mq_host);
-    if (c->stream2) { hipStreamDestroy(c->stream2); if (c->ev_pyr) hipEventDestroy(c->ev_pyr); if (c->ev_blur) hipEventDestroy(c->ev_blur); }
     hipStreamDestroy(c->stream); delete c; return TSORB_OK; }
 const char *tsorb_last_error(void *ctx) { return ctx ? ((OCtx *)ctx)->err.c_str() : "null ctx"; }
 int tsorb_get_levels(void *ctx) { return ctx ? ((OCtx *)ctx)->nlevels : TSORB_ERR_ARG; }
@@ -999,17 +995,11 @@ int tsorb_run(void *ctx) {
     OrbDev &D = c->D;
     hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
     for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 127)/128, (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(128), 0, c->stream, D, l);
-    // The 7x7 blur reads the pyramid only and none of these kernels is bandwidth-bound (FAST: five dependent phases per cell; the quadtree: a wave
-    // per level): on a second stream the blur runs NEXT to FAST / quadtree / orientation instead of after them (108 of 606 us per batch of 64)
-    const bool two = c->stream2 != nullptr;
-    if (two) { hipEventRecord(c->ev_pyr, c->stream); hipStreamWaitEvent(c->stream2, c->ev_pyr, 0);
-        hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream2, D); hipEventRecord(c->ev_blur, c->stream2); }
     hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
     hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
-    if (two) hipStreamWaitEvent(c->stream, c->ev_blur, 0);
-    else hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D);
+    hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_pack, dim3(D.n), dim3(256), 0, c->stream, D);
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
