@@ -184,7 +184,7 @@ def _evals_8d(rep):
 def also_lines(gpu, local_rank, torch, steps=3):
     """The other BASELINE configs on this GPU, without their CPU legs (a few hundred ms of GPU time each; the synthetic maps take longer to
     build than to solve): C3 pose-only, C5 global BA 500 KF x 50 k points, C6 global BA 5000 KF / ~500 k observations as an open chain, with
-    SURVEY 8d's 1 % long-range observations, and right after a loop closure (ring), and the ORB batch of 64 frames."""
+    SURVEY 8d's 1 % long-range observations, right after a loop closure (ring) and with two separate closures, and the ORB batch of 64 frames."""
     import numpy as np
     from textslam_amd import synth, abi
     out = {}
@@ -221,6 +221,7 @@ def also_lines(gpu, local_rank, torch, steps=3):
     run("c6_global_5000kf_open_chain", synth.config_global(n_kf=5000, n_pt=70000, band=10), og, glob_extra)
     run("c6_global_5000kf_1pct_long_range", synth.config_global(n_kf=5000, n_pt=70000, band=10, far_frac=0.01), og, glob_extra)
     run("c6_global_5000kf_loop_closure_ring", synth.config_global(n_kf=5000, n_pt=70000, band=10, loop=True), og, glob_extra)
+    run("c6_global_5000kf_two_loop_closures", synth.config_global(n_kf=5000, n_pt=70000, band=10, closures=2), og, glob_extra)
     # ORB batch of 64 frames (BASELINE config 2)
     from textslam_amd.orbextractor import ORBextractor, synthetic_frame
     imgs = np.stack([synthetic_frame(s) for s in range(64)])

@@ -268,15 +268,22 @@ def test_loop_closure_with_a_tail(gpu, n_kf, k0, band, parts):
     """The usual loop closure: the last keyframes meet keyframe k0 > 0 -- a tail before the loop.  The rows stay in keyframe order, the loop's first
     poses are a separator in the MIDDLE of the chain with their ghost behind the last pose; the separator labels count from that separator (the
     tail's downwards), and the cyclic reduction ends with it and the ghost (tsba_bandp.h: bandp_part_ring).  Against the reordering path.
-    (k0 = 30: a tail too short for an interior -- the plan keeps the reordering.)"""
+    (k0 = 30: a tail too short for an interior -- not a ring for the partition; the closure goes through the low-rank correction of the band solve.)"""
     P = synth.config_global(n_kf=n_kf, n_pt=20*n_kf, band=band, loop=True, loop_at=k0)
     o = abi.options_global(); o.its[0] = 6
     try:
         gpu.debug_set(band_parts=parts)
         gpu.upload(P, o)
         info = gpu.solver_info()
-        if k0 < 40:
-            assert info["ring"] == 0 and info["kf_reordered"] == 1, info
+        if k0 < 40:                                                 # not a ring for the partition: the closure as a low-rank correction of the band solve (tsba_wb.h) ...
+            assert info["ring"] == 0 and info["kf_reordered"] == 0 and info["far_band_blocks"] == band, info
+            G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)
+            gpu.debug_set(band_parts=parts, far_solver=1)           # ... against the reordering path
+            gpu.upload(P, o)
+            info = gpu.solver_info()
+            assert info["ring"] == 0 and info["kf_reordered"] == 1 and info["far_band_blocks"] == 0, info
+            G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+            _same_trajectory(rep1, rep2, G1, G2, atol=1e-8)
             return
         assert info["ring"] == 1 and info["kf_reordered"] == 0 and info["sep_cr"] == 1 and info["band_rows"] <= 6*(band + 3), info
         G1 = P.copy(); rep1 = gpu.GlobalBA(G1, options=o)

@@ -570,7 +570,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
             c->pcg_parts = (p->n_kf + 31)/32;
             AL(W.Sfar, 36*(size_t)std::max(c->n_far, 1));
             AL(W.pc_x, W.N); AL(W.pc_r, W.N); AL(W.pc_p[0], W.N); AL(W.pc_p[1], W.N); AL(W.pc_q, W.N); AL(W.pc_g0, W.N);
-            AL(W.pc_part, 2*(size_t)c->pcg_parts); AL(W.pcs, 2); AL(W.pc_stat, 4);
+            AL(W.pc_part, 3*(size_t)c->pcg_parts + 8); AL(W.pcs, 2); AL(W.pc_stat, 4);
         }
         c->S_xchg = nullptr; c->xchg_wp = 0;
         if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, ((size_t)W.N + bwmax)*c->xchg_wp); }
@@ -1049,6 +1049,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     };
     if (wb) { correct(W.Sy, -1.0); hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, (const double *)c->wb.z, 1.0); }
     else hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, (const double *)W.Sy, -1.0);
+    if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, -1, nbp, 0.0);
     auto finished = [&](int it) {                                  // true: the device reported convergence (or the end of the pass); else waits until it is within two iterations
         if (!c->hprog || it < 2) return false;
         const auto tw = std::chrono::steady_clock::now();
@@ -1070,7 +1071,9 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
         hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_T), 0, c->stream, W, D, it, seq, B, tol2, nbp, zp, zs);
         if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, c->ms.R, 1.0);
             const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
-        else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, W.g, -1.0); launch_solve(c);
+        else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, W.g, -1.0);
+            if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
+            launch_solve(c);
             if (wb) { correct(W.Sy, -1.0); zp = c->wb.z; zs = 1.0; } }
         hipLaunchKernelGGL(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, zp, zs);
     }

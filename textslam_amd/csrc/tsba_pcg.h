@@ -46,11 +46,13 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_begin(Work W, const double *zp, 
     const LmState *st = W.st;
     if (st->done || st->step_fail) return;
     const int tid = threadIdx.x, a = blockIdx.x*32 + tid/6, k = tid % 6;
-    double rzp = 0.0;
+    double rzp = 0.0, rrp = 0.0;
     if (a < W.n_kf) { const int ia = W.fidx[a];
         if (ia >= 0) { const int i = 6*ia + k; const double gv = W.g[i], r = -gv, z = zs*zp[i];
-            W.pc_g0[i] = gv; W.pc_r[i] = r; W.pc_x[i] = 0.0; W.pc_p[0][i] = 0.0; W.pc_p[1][i] = 0.0; rzp = r*z; } }
+            W.pc_g0[i] = gv; W.pc_r[i] = r; W.pc_x[i] = 0.0; W.pc_p[0][i] = 0.0; W.pc_p[1][i] = 0.0; rzp = r*z; rrp = r*r; } }
     pcg_block_partial<PCG_ET>(rzp, W.pc_part, lds);
+    __syncthreads();
+    pcg_block_partial<PCG_ET>(rrp, W.pc_part + 2*gridDim.x, lds);
 }
 
 // launch `it`: beta from r.z, p = z + beta p, q = S p = (band + long-range blocks) p, partial p.q.  Also where convergence is noticed.
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it
 // alpha = r.z / p.q; x += alpha p; r -= alpha q; the next preconditioner application's right-hand side rhs = rs * r (the factorisation
 // path solves M y = -g: rs = -1 into W.g; the solve phase takes r itself)
 __global__ __launch_bounds__(PCG_ET) void k_pcg_update(Work W, int it, int nbp, double *rhs, double rs) {
+    __shared__ double lds[4];
     LmState *st = W.st;
     if (st->done || st->step_fail || st->lin_done) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -132,12 +135,23 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_update(Work W, int it, int nbp, 
     if (!(pq > 0.0)) { if (blockIdx.x == 0 && tid == 0) st->step_fail = 1; return; }       // S is positive definite (damped): a breakdown is a failed step
     const double alpha = W.pcs[it & 1].rz/pq;
     const int a = blockIdx.x*32 + tid/6, k = tid % 6;
-    if (a >= W.n_kf) return;
-    const int ia = W.fidx[a]; if (ia < 0) return;
-    const int i = 6*ia + k;
-    W.pc_x[i] = fma(alpha, W.pc_p[it & 1][i], W.pc_x[i]);
-    const double r = fma(-alpha, W.pc_q[i], W.pc_r[i]);
-    W.pc_r[i] = r; rhs[i] = rs*r;
+    double rrp = 0.0;
+    if (a < W.n_kf) { const int ia = W.fidx[a];
+        if (ia >= 0) { const int i = 6*ia + k;
+            W.pc_x[i] = fma(alpha, W.pc_p[it & 1][i], W.pc_x[i]);
+            const double r = fma(-alpha, W.pc_q[i], W.pc_r[i]);
+            W.pc_r[i] = r; rhs[i] = rs*r; rrp = r*r; } }
+    pcg_block_partial<PCG_ET>(rrp, W.pc_part + 2*nbp, lds);
+}
+// |r|^2 against |b|^2 right after the update: with an (almost) exact preconditioner -- the low-rank correction of tsba_wb.h -- the first step
+// already ends the solve, and the test on r.z would only notice after one more application of M^-1.  One wave.
+__global__ __launch_bounds__(64) void k_pcg_rcheck(Work W, int it, int nbp, double tolr2) {
+    LmState *st = W.st;
+    if (st->done || st->step_fail || st->lin_done) return;
+    const double rr = pcg_sum_parts(W.pc_part + 2*nbp, nbp, threadIdx.x);
+    if (threadIdx.x != 0) return;
+    if (it < 0) { W.pc_part[3*nbp] = rr; return; }             // |b|^2
+    if (rr <= tolr2*W.pc_part[3*nbp]) { st->lin_done = 1; W.pc_stat[0] += it + 1; W.pc_stat[1] += 1; if (it + 1 > W.pc_stat[2]) W.pc_stat[2] = it + 1; }
 }
 
 // partial r.z after the preconditioner application

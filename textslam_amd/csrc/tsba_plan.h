@@ -581,14 +581,22 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 int64_t n_wide = 0; for (int s = Bm + 1; s <= far_max_blocks + 1; s++) n_wide += hist[(size_t)s];
                 if (Bm >= 1 && n_wide*5 <= n_lm2 && n_kf >= 4*(3*Bm + 2) + Bm) far_B = Bm;
             }
+            // clusters of a landmark's poses (ascending; a host slot may come last): 0 = the host and what follows it within far_B keyframes
+            auto clusters = [&](auto &&pose_at, int n, int host, int32_t *cl) { int id = 0, start = 0;
+                for (int x = 0; x < n; x++) { const int a = pose_at(x);
+                    if (a >= host && a - host <= far_B) { cl[x] = 0; continue; }
+                    if (id == 0 || a - start > far_B) { id++; start = a; }
+                    cl[x] = id; } };
+            // keyframes that the coupling outside the band part would touch: a few dozen = loop closures (the low-rank correction of tsba_wb.h applies)
+            auto far_touched = [&]() { std::vector<char> hit((size_t)n_kf, 0); std::vector<int32_t> cl; size_t lm = 0; int n = 0;
+                for (const PoseList v : poses_of) { const size_t j = lm++; if (v.size() < 2) continue;
+                    const int host = j < (size_t)n_pt ? p->pt_host[j] : p->text_host[j - n_pt];
+                    cl.resize(v.size()); clusters([&](int x) { return v[(size_t)x]; }, (int)v.size(), host, cl.data());
+                    bool wide = false; for (size_t x = 0; x < v.size(); x++) wide |= cl[x] != 0;
+                    if (wide) for (size_t x = 0; x < v.size(); x++) if (!hit[(size_t)v[x]]) { hit[(size_t)v[x]] = 1; n++; } }
+                return n; };
             auto take_far = [&]() {
                 P.far_B = far_B; P.bw_pose = far_B; P.kf_order.clear();
-                // clusters of a landmark's poses (ascending; a host slot may come last): 0 = the host and what follows it within far_B keyframes
-                auto clusters = [&](auto &&pose_at, int n, int host, int32_t *cl) { int id = 0, start = 0;
-                    for (int x = 0; x < n; x++) { const int a = pose_at(x);
-                        if (a >= host && a - host <= far_B) { cl[x] = 0; continue; }
-                        if (id == 0 || a - start > far_B) { id++; start = a; }
-                        cl[x] = id; } };
                 // block positions of E: from ALL observations
                 KeyIndex fk; fk.begin((int64_t)n_kf*n_kf);
                 { std::vector<int32_t> cl; size_t lm = 0;
@@ -640,7 +648,9 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 fill_far(P.pls_off, P.pslot_pose, cl_pt, wide_pt, n_pt, P.fb_pt_off, P.fb_pt_s1, P.fb_pt_s2, P.fb_pt_lm);
                 fill_far(P.tls_off, P.tslot_pose, cl_tx, wide_tx, n_text, P.fb_tx_off, P.fb_tx_s1, P.fb_tx_s2, P.fb_tx_lm);
             };
-            if (far_B > 0 && (far_force || n_kf > 2000)) take_far();       // (large maps: the reordering costs more host time than it can save)
+            // (large maps: the reordering costs more host time than it can save; loop closures -- few keyframes touched -- are solved directly on the
+            // band of the keyframe order, which beats the doubled band of any reordering)
+            if (far_B > 0 && (far_force || n_kf > 2000 || (n_kf >= 600 && far_touched() <= 64))) take_far();
             if (!P.ring && !P.far_B) {
             if ((int64_t)n_kf*n_kf <= ((int64_t)1 << 28)) {       // adjacency through a bitmap over pose pairs: set bits come out sorted and distinct
                 std::vector<uint64_t> bm((((size_t)n_kf*n_kf) >> 6) + 1, 0);
