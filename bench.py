@@ -34,7 +34,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6      # dense fp64 matrix rate (= the fp64 vector rat
 def _pmc_traffic(name):
     """HBM bytes per launch of a kernel from the PMC passes committed under profiles/ (counters cannot be read from inside the
     process): 2 x FETCH_SIZE (gfx950 correction of the micro-architecture guide) + WRITE_SIZE."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, name))) as f:
                 pm = json.load(f)

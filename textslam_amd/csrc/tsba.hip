@@ -1068,7 +1068,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     int it = 0;
     for (; it < cap; it++) {
         if (finished(it)) break;
-        hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_T), 0, c->stream, W, D, it, seq, B, tol2, nbp, zp, zs);
+        hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_MT), 0, c->stream, W, D, it, seq, B, tol2, nbp, zp, zs);
         if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, c->ms.R, 1.0);
             const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
         else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, W.g, -1.0);

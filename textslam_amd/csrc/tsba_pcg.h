@@ -16,8 +16,10 @@
 // ahead of the device (pinned progress word), so a converged solve wastes two iterations of empty launches.
 #pragma once
 
-#define PCG_T 256                           // matvec workgroup: 4 waves, a wave takes PCG_PPW poses
+#define PCG_T 256                           // workgroups of the block kernels: 4 waves, a wave takes PCG_PPW poses
 #define PCG_PPW 8
+#define PCG_MT 1024                         // single-vector matvec: 16 waves x 2 poses (the same 32 poses per workgroup, so one partial array serves all; with 8 poses one
+#define PCG_MPW 2                           // after the other on a wave the kernel was a chain of dependent loads: 144 us at 5000 keyframes)
 #define PCG_ET 192                          // element-wise kernels: 32 poses x 6 rows per workgroup (the same number of workgroups, so one partial array serves all)
 
 struct PcgState { double rz, rz0, best; int it, since; };      // best: smallest r.z so far; since: iterations since it improved by a tenth (stagnation at the attainable accuracy)
@@ -57,8 +59,8 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_begin(Work W, const double *zp, 
 
 // launch `it`: beta from r.z, p = z + beta p, q = S p = (band + long-range blocks) p, partial p.q.  Also where convergence is noticed.
 // zp, zs: where the last preconditioner application left z = zs * zp[] (the factorisation's own solve: -W.Sy; the solve phase: its X)
-__global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it, unsigned int seq, int B, double tol2, int nbp, const double *zp, double zs) {
-    __shared__ double lds[4];
+__global__ __launch_bounds__(PCG_MT) void k_pcg_matvec(Work W, LevelDev L, int it, unsigned int seq, int B, double tol2, int nbp, const double *zp, double zs) {
+    __shared__ double lds[PCG_MT/64];
     LmState *st = W.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (st->done || st->step_fail || st->lin_done) { if (blockIdx.x == 0 && tid == 0) pcg_publish(W, seq, it, 1); return; }
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it
     auto pnew = [&](int i) { return fma(beta, po[i], zs*zp[i]); };
     const int nfree = W.nfree[0]; const size_t ldS = (size_t)W.ldS;
     double pq = 0.0;
-    for (int u = 0; u < PCG_PPW; u++) {
-        const int a = (blockIdx.x*4 + wave)*PCG_PPW + u;
+    for (int u = 0; u < PCG_MPW; u++) {
+        const int a = (blockIdx.x*(PCG_MT/64) + wave)*PCG_MPW + u;
         if (a >= W.n_kf) break;
         const int ia = W.fidx[a];
         if (ia < 0) continue;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(PCG_T) void k_pcg_matvec(Work W, LevelDev L, int it
         for (int j = 0; j < 6; j++) { g0 += __shfl(f0, 6*min(lane, 5) + j, 64); g1 += __shfl(f1, 6*j + min(lane, 5), 64); }
         if (lane < 6) { qk += g0 + g1; const int i = 6*ia + lane; const double pv = pnew(i); pn[i] = pv; W.pc_q[i] = qk; pq += pv*qk; }
     }
-    pcg_block_partial<PCG_T>(pq, W.pc_part + nbp, lds);
+    pcg_block_partial<PCG_MT>(pq, W.pc_part + nbp, lds);
 }
 
 // alpha = r.z / p.q; x += alpha p; r -= alpha q; the next preconditioner application's right-hand side rhs = rs * r (the factorisation
