@@ -192,5 +192,9 @@ def test_multi_right_hand_side_solve_phase(gpu, n_kf, band, parts, T):
         err = np.abs(X - ref).max(axis=0)/np.abs(ref).max(axis=0)
         assert err.max() <= 1e-8, err
         assert np.abs(X[:, 0] - rb["dp_rows"]).max() <= 1e-9*np.abs(rb["dp_rows"]).max()
+        # the single-vector solve phase (csrc/tsba_bandsv.h: a lane owns a row) on two of the columns
+        for k in (0, T - 1):
+            x1 = gpu.multi_solve(R[:, k:k + 1].copy(), single=True)[:, 0]
+            assert np.abs(x1 - ref[:, k]).max() <= 1e-8*np.abs(ref[:, k]).max(), (k, np.abs(x1 - ref[:, k]).max()/np.abs(ref[:, k]).max())
     finally:
         gpu.debug_set()

@@ -42,6 +42,7 @@
 #include "tsba_bandcr.h"
 #include "tsba_bandcre.h"
 #include "tsba_bandms.h"
+#include "tsba_bandsv.h"
 #include "tsba_pcg.h"
 #include "tsba_wb.h"
 #include "tsba_pose.h"
@@ -103,6 +104,7 @@ struct Ctx {
                       long long hits = 0, misses = 0; } ic;
     WbBuf wb{}; Work Wk{}; double *wb_alloc = nullptr; size_t wb_bytes = 0;      // low-rank correction for loop closures (tsba_wb.h): its buffers, the k x k dense system as a second Work
     EcgBuf ecg{}; double *ecg_alloc = nullptr; size_t ecg_bytes = 0;      // enlarged conjugate gradients (tsba_pcg.h)
+    MsBuf sv{}; double *sv_alloc = nullptr; size_t sv_bytes = 0;                      // single-vector solve phase (tsba_bandsv.h)
     MsBuf ms{}; double *ms_alloc = nullptr; size_t ms_bytes = 0; int ms_cap = 0;      // multi-right-hand-side solve phase of the partitioned band solver (tsba_bandms.h)
     int cov_text = -1; double *cov_log = nullptr;     // tsba_theta_optim: V of this plane at the end of every pass [TSBA_MAX_LEVELS][6]
     int far_B = 0, n_far = 0, pcg_parts = 0; unsigned int pcg_seq = 0;      // band + long-range blocks (tsba_pcg.h): band of M in pose blocks, blocks outside it, partial sums per vector kernel
@@ -257,6 +259,7 @@ int tsba_destroy(void *ctx) {
     if (c->lbl_dev) hipFree(c->lbl_dev); if (c->lbl_host) hipHostFree(c->lbl_host);
     if (c->ic.dev) hipFree(c->ic.dev); if (c->ic.stage) hipHostFree(c->ic.stage);
     if (c->ms_alloc) hipFree(c->ms_alloc);
+    if (c->sv_alloc) hipFree(c->sv_alloc);
     if (c->ecg_alloc) hipFree(c->ecg_alloc);
     if (c->wb_alloc) hipFree(c->wb_alloc);
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (c->ev_stage[l]) hipEventDestroy(c->ev_stage[l]);
@@ -815,6 +818,7 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_ms_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 159*1024));
         CK(hipFuncSetAttribute((const void *)k_ms_cre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
         CK(hipFuncSetAttribute((const void *)k_ms_cre_root, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
+        CK(hipFuncSetAttribute((const void *)k_sv_linv, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -923,13 +927,13 @@ static void launch_dense_chol(Ctx *c, Work &W, int bw) {
 static bool ms_available(const Ctx *c) { return c->band_stream && c->band_parts > 1 && c->sep_cr && !c->W.ring && c->dbg.sep_solver != 3; }
 static int ms_reserve(Ctx *c, int T) {           // buffers for T columns (kept until a larger request or another problem size)
     const size_t n6 = (size_t)c->W.N, labels = (size_t)cr_mmax(0, c->band_parts, 0) + 1, sdim = (size_t)std::max(6, c->cur_bw_rows);
-    const size_t per = 4*n6 + 5*labels*sdim, need = per*(size_t)T*sizeof(double);
+    const size_t per = 4*n6 + 6*labels*sdim, need = per*(size_t)T*sizeof(double);
     if (need > c->ms_bytes) { if (c->ms_alloc) { hipStreamSynchronize(c->stream); hipFree(c->ms_alloc); } c->ms_alloc = nullptr; c->ms_bytes = 0;
         if (hipMalloc((void **)&c->ms_alloc, need) != hipSuccess) { set_err(c, "hipMalloc (multi-right-hand-side buffers)"); return TSBA_ERR_DEVICE; }
         c->ms_bytes = need; }
     double *q = c->ms_alloc; MsBuf &M = c->ms; M.T = T;
     M.R = q; q += n6*T; M.Wm = q; q += n6*T; M.V = q; q += n6*T; M.X = q; q += n6*T;
-    M.G = q; q += labels*sdim*T; M.Z = q; q += labels*sdim*T; M.Xs = q; q += labels*sdim*T; M.Cg = q;
+    M.G = q; q += labels*sdim*T; M.Z = q; q += labels*sdim*T; M.Xs = q; q += labels*sdim*T; M.Cg = q; q += 2*labels*sdim*T; M.G2 = q;
     c->ms_cap = T;
     return TSBA_OK;
 }
@@ -950,6 +954,42 @@ static void launch_ms_solve(Ctx *c) {            // M.R -> M.X
         if (npiv > 0) hipLaunchKernelGGL(k_ms_cre_back, dim3(npiv, ncg), dim3(MS_CT), ldsb, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); }
     hipLaunchKernelGGL(k_ms_back_border, dim3(c->n_kf, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lb, M);
     hipLaunchKernelGGL(k_ms_back_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
+}
+
+// ---- the same for ONE right-hand side (tsba_bandsv.h): x = M^-1 (rs * r) into c->sv.X.  launch_sv_prepare once per factorisation (the
+// separators' inverse factors), then any number of launch_sv_solve
+static int sv_reserve(Ctx *c) {
+    const size_t n6 = ((size_t)c->W.N + 1) & ~(size_t)1, labels = (size_t)cr_mmax(0, c->band_parts, 0) + 1, sdim = (size_t)std::max(6, c->cur_bw_rows);
+    const size_t need = (4*n6 + 7*labels*sdim + labels*sdim*sdim)*sizeof(double);
+    if (need > c->sv_bytes) { if (c->sv_alloc) { hipStreamSynchronize(c->stream); hipFree(c->sv_alloc); } c->sv_alloc = nullptr; c->sv_bytes = 0;
+        if (hipMalloc((void **)&c->sv_alloc, need) != hipSuccess) { set_err(c, "hipMalloc (solve-phase buffers)"); return TSBA_ERR_DEVICE; }
+        c->sv_bytes = need; }
+    double *q = c->sv_alloc; MsBuf &M = c->sv; M.T = 1;
+    M.Li = q; q += labels*sdim*sdim;
+    M.R = q; q += n6; M.Wm = q; q += n6; M.V = q; q += n6; M.X = q; q += n6;
+    M.G = q; q += labels*sdim; M.Z = q; q += labels*sdim; M.Xs = q; q += labels*sdim; M.Cg = q; q += 2*labels*sdim; M.G2 = q; q += labels*sdim; M.Lid = q;
+    return TSBA_OK;
+}
+static void launch_sv_prepare(Ctx *c) {
+    const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, mmax = cr_mmax(0, P, 0);
+    if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(128), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, c->sv);
+}
+static void launch_sv_solve(Ctx *c, const double *r, double rs) {
+    Work &W = c->W; const MsBuf &M = c->sv;
+    const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6;
+    Work &Ws = c->Wsep; Ws.st = W.st;
+    if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M);
+    else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M);
+    const int mmax = cr_mmax(0, P, 0);
+    auto pivots = [&](int h) { const int klast = (mmax - 1 - h)/(2*h); return mmax - 1 - h < 0 ? 0 : std::max(0, klast + 1); };
+    int htop = 0;
+    for (int h = 1; h < mmax; h <<= 1) { const int npiv = pivots(h); if (npiv <= 0) continue;
+        hipLaunchKernelGGL(k_sv_cre_fwd, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); htop = h; }
+    hipLaunchKernelGGL(k_sv_cre_root, dim3(1), dim3(SV_CT), 0, c->stream, W, bwp, P, M);
+    for (int h = htop; h >= 1; h >>= 1) { const int npiv = pivots(h);
+        if (npiv > 0) hipLaunchKernelGGL(k_sv_cre_back, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
+    if (B <= 10) hipLaunchKernelGGL(k_sv_back_int<1>, dim3(P), dim3(SV_T), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
+    else hipLaunchKernelGGL(k_sv_back_int<2>, dim3(P), dim3(SV_T), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
 }
 
 // The reduced system of one LM trial: a direct solve, or -- band + long-range blocks -- conjugate gradients preconditioned with the band
@@ -1064,6 +1104,8 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     // (measured at 5000 keyframes, one column: 1.3 ms per application against 0.57 ms for the factorisation re-run -- the solve phase pays for 64
     // columns whether it has them or not; it is the default only for the block variants.  pcg_refactor = 2 selects it for the single-vector iteration)
     const bool ms = !wb && ms_available(c) && c->dbg.pcg_refactor == 2 && ms_reserve(c, std::max(1, c->ms_cap)) == TSBA_OK;
+    const bool sv = !ms && ms_available(c) && c->dbg.pcg_refactor == 0 && sv_reserve(c) == TSBA_OK;      // (the single-vector solve phase, tsba_bandsv.h: the default)
+    if (sv) launch_sv_prepare(c);
     const double *zp = wb ? c->wb.z : W.Sy; double zs = wb ? 1.0 : -1.0;
     int it = 0;
     for (; it < cap; it++) {
@@ -1071,6 +1113,10 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
         hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_MT), 0, c->stream, W, D, it, seq, B, tol2, nbp, zp, zs);
         if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, c->ms.R, 1.0);
             const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
+        else if (sv) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, c->sv.R, 1.0);
+            if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
+            launch_sv_solve(c, c->sv.R, 1.0); zp = c->sv.X; zs = 1.0;
+            if (wb) { correct(c->sv.X, 1.0); zp = c->wb.z; } }
         else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, W.g, -1.0);
             if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
             launch_solve(c);

@@ -1,0 +1,443 @@
+// Solve phase of the partitioned band solver for ONE right-hand side: M x = r with the factor k_bandp_factor / k_bandp_sepf / k_cre_elim left
+// behind (tsba_bandp.h, tsba_bandcre.h).  This is what a conjugate-gradient iteration applies as preconditioner (tsba_pcg.h); re-running the
+// factorisation with the residual as right-hand side costs 0.5 ms at 5000 keyframes, the many-column solve phase (tsba_bandms.h: a lane owns a
+// COLUMN) as much for one column as for 64.  Fifteen to twenty applications per LM trial: everything here is about latency.
+//
+//   interiors (a chain of pose blocks, one wave): a lane owns a ROW of the running right-hand side, the window of the B blocks after (before) the
+//     pivot.  A step: the pivot block's six values are broadcast (v_readlane), its 6 x 6 unit triangle is solved redundantly by every lane
+//     (15 FMAs on uniform values), every lane subtracts its six coefficients times the result -- no reduction across lanes anywhere, ~100
+//     instructions per pose block.  The chain wave never waits for memory: the other three waves of the workgroup stage what the next SV_K pivots
+//     need in LDS a chunk ahead and do the dense border work (the rows of the separator on the left) on the side.
+//   separators (cyclic reduction, a workgroup per pivot of a level): NO substitution at all -- k_sv_linv inverts every separator's unit-lower
+//     factor once per factorisation (a thread per column), after which a level is three small dense products (L^-1 v, X_a w, X_c w) whose
+//     operands are all requested up front, speculatively, and looked at after a single wait (a round trip to memory costs ~1.5 us; a kernel
+//     that asks for one thing after the other -- flags, number of free poses, record, neighbours, coupling blocks -- pays it six times).
+// Vectors: MsBuf with T = 1 (the right-hand side comes as rs * r[]).  Chain partitions only, cyclic-reduction separator system.
+#pragma once
+
+#define SV_T 256                            // interiors: chain wave + three staging waves
+#define SV_CT 512                           // separators: 8 waves
+#define SV_K 6                              // pivot blocks per staged chunk
+#define SV_TB (36*MS_BMAX)                  // staged pivot: [0, 36 B) coefficients | SV_TB + [0, 15) unit-lower l, [16, 22) 1/d | SV_TB + 22 + [0, 6) entering values
+#define SV_CS (SV_TB + 32)
+
+__device__ __forceinline__ double sv_bcast(double v, int lane) {           // lane: uniform
+    const int l = __builtin_amdgcn_readfirstlane(lane);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int NREG>
+__device__ __forceinline__ double sv_pivot(const double (&t)[NREG], int rho) {     // the value of window row rho (uniform)
+    if (NREG == 1) return sv_bcast(t[0], rho);
+    const double lo = sv_bcast(t[0], rho & 63), hi = sv_bcast(t[NREG - 1], rho & 63);
+    return rho >= 64 ? hi : lo;
+}
+__device__ __forceinline__ void sv_pin(double &x) { asm volatile("" : "+v"(x)); }     // the request for x is issued before this point (the compiler would sink it below
+__device__ __forceinline__ void sv_pin(v2d &x) { asm volatile("" : "+v"(x)); }        // the early-out branches, into the block that uses it: one more round trip)
+__device__ __forceinline__ int sv_nsep(int nf, int B, int Pmax) { return nf > 0 ? bandp_part(nf, B, Pmax, 0).P - 1 : 0; }      // chain: separators 0 .. m - 1, root 0 (cr_range)
+
+// ---- interiors, forward.  grid Pmax, SV_T threads.
+//   M.V = D^-1 w (L w = r), M.G [label][s] = rows of the separator on the right below this interior, M.G2 [label][s] = border rows of the separator on the left
+template <int NREG>
+__global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, const double *__restrict__ r, double rs, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double stg[2][SV_K][SV_CS];
+    __shared__ double wch[2][SV_K][6];
+    __shared__ double red[2][96];
+    const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6);
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = ms_uni(*W.nfree);
+    if (flags || nf <= 0) return;
+    const int B = bw/6, p = blockIdx.x;
+    const BandpPart PT = bandp_part(nf, B, Pmax, p);
+    const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P);
+    if (p >= P) return;
+    const int REC = bw*6, rend = p < P - 1 ? b + B : b, nch = (b - a + SV_K - 1)/SV_K;
+    const int ptid = tid - 64, pk = ptid >> 5, pj = ptid & 31, per = 36*B + 28;
+    auto stage = [&](int c) {                                   // producers: chunk c; thread (pivot pk, 32 threads across its record)
+        const int q = a + c*SV_K + pk;
+        if (q >= b) return;
+        double *dst = stg[c & 1][pk];
+        double vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int x = pj + 32*u; vv[u] = 0.0;
+            if (x < 36*B) { const int R = q + 1 + x/36; if (R < rend) vv[u] = Lrow[(size_t)R*REC + x]; }       // L(R, q), R = q + 1 .. q + B, at [(R - q - 1) 36 + 6 col + row]
+            else if (x < 36*B + 22) vv[u] = W.LDbuf[32*(size_t)q + (x - 36*B)];
+            else if (x < per) { const int Rn = q + B; if (Rn < rend) vv[u] = rs*r[6*(size_t)Rn + (x - 36*B - 22)]; } }     // the block entering the window after pivot q
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int x = pj + 32*u; if (x < per) dst[x < 36*B ? x : SV_TB + (x - 36*B)] = vv[u]; }
+    };
+    const int bbr = ptid % 96, bhalf = ptid/96;                 // border: row of the separator on the left, half of a chunk's pivots
+    double bacc = 0.0;
+    auto border = [&](int c) {                                  // - Lb_q w_q over the pivots of chunk c
+        if (bbr >= bw) return;
+        double lv[SV_K/2][6];
+#pragma unroll
+        for (int k = 0; k < SV_K/2; k++) { const int q = a + c*SV_K + bhalf*(SV_K/2) + k; const double *Lq = Lb + (size_t)q*REC + 6*bbr;
+#pragma unroll
+            for (int cc = 0; cc < 6; cc++) lv[k][cc] = q < b ? Lq[cc] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < SV_K/2; k++) {
+            if (a + c*SV_K + bhalf*(SV_K/2) + k >= b) break;     // (past the interior: nothing was written to wch)
+#pragma unroll
+            for (int cc = 0; cc < 6; cc++) bacc = fma(-lv[k][cc], wch[c & 1][bhalf*(SV_K/2) + k][cc], bacc); }
+    };
+    // window: the B blocks q .. q + B - 1 before a step, q + 1 .. q + B after it; block R in slot R mod B, row (slot, k) on lane / register (6 slot + k) mod 64, / 64
+    int slot[NREG], ri[NREG], dd[NREG]; bool rowok[NREG]; double t[NREG];
+#pragma unroll
+    for (int g = 0; g < NREG; g++) { const int rho = lane + 64*g; rowok[g] = rho < 6*B; slot[g] = rho/6; ri[g] = rho - 6*slot[g]; t[g] = 0.0; dd[g] = 1; }
+    int sq = a % B;
+    if (wave > 0) stage(0);
+    else {
+#pragma unroll
+        for (int g = 0; g < NREG; g++) { const int d = (slot[g] - sq + B) % B, R = a + d; t[g] = (rowok[g] && R < rend) ? rs*r[6*(size_t)R + ri[g]] : 0.0;
+            dd[g] = d == 0 ? B : d; }                           // distance to the pivot AFTER the pivot's slot has been handed to the entering block
+    }
+    __syncthreads();
+    for (int c = 0; c < nch; c++) {
+        if (wave > 0) { if (c + 1 < nch) stage(c + 1); if (p > 0 && c > 0) border(c - 1); }
+        else {
+            const int q0 = a + c*SV_K, nk = min(SV_K, b - q0);
+            for (int k = 0; k < nk; k++) {
+                const double *sk = stg[c & 1][k];
+                // requests of this step (none depends on the running solution)
+                double cf[NREG][6], ent[NREG], l[15];
+#pragma unroll
+                for (int g = 0; g < NREG; g++) { const double *cp = sk + (rowok[g] ? (dd[g] - 1)*36 + ri[g] : 0);
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) cf[g][cc] = cp[6*cc];
+                    ent[g] = sk[SV_TB + 22 + ri[g]]; }
+#pragma unroll
+                for (int e = 0; e < 15; e++) l[e] = sk[SV_TB + e];
+                const double idl = sk[SV_TB + 16 + (lane < 6 ? lane : 0)];
+                // the pivot block: broadcast, unit-lower solve on uniform values
+                double w[6];
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) w[cc] = sv_pivot<NREG>(t, 6*sq + cc);
+#pragma unroll
+                for (int i = 1; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < i; j++) w[i] = fma(-l[tri(i - 1) + j], w[j], w[i]);
+                if (lane < 6) { double wl = w[0];
+#pragma unroll
+                    for (int cc = 1; cc < 6; cc++) wl = lane == cc ? w[cc] : wl;
+                    wch[c & 1][k][lane] = wl; M.V[6*(size_t)(q0 + k) + lane] = wl*idl; }
+                // its slot goes to the entering block; every row of the window takes the pivot's contribution
+#pragma unroll
+                for (int g = 0; g < NREG; g++) {
+                    double tv = (rowok[g] && slot[g] == sq) ? ent[g] : t[g];
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) tv = fma(-cf[g][cc], w[cc], tv);
+                    t[g] = rowok[g] ? tv : 0.0;
+                    dd[g] = dd[g] == 1 ? B : dd[g] - 1;
+                }
+                sq = sq + 1 == B ? 0 : sq + 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && p < P - 1) {                               // what the window holds now: the separator's rows, minus this interior's part
+#pragma unroll
+        for (int g = 0; g < NREG; g++) { const int d = (slot[g] - b % B + B) % B;
+            if (rowok[g]) M.G[(size_t)p*bw + 6*d + ri[g]] = t[g]; }
+    }
+    if (p == 0) return;
+    if (wave > 0) { border(nch - 1); red[bhalf][bbr] = bacc; }
+    __syncthreads();
+    if (tid < bw) M.G2[(size_t)(p - 1)*bw + tid] = red[0][tid] + red[1][tid];
+}
+
+// ---- interiors, backward.  grid Pmax, SV_T threads: first the border part  v_q -= Lb_q^T x_left  (all threads), then the chain on wave 0 with the other waves
+// staging.  M.X = the solution (the rows of the separator on the right written along).
+template <int NREG>
+__global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double stg[2][SV_K][SV_CS];
+    __shared__ double xl[80];
+    const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6);
+    const int p = blockIdx.x;
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = ms_uni(*W.nfree);
+    double xlv = (p > 0 && tid < bw) ? M.Xs[(size_t)(p - 1)*bw + tid] : 0.0;      // (requested along with the flags: the address does not depend on them)
+    sv_pin(xlv);
+    if (flags || nf <= 0) return;
+    const int B = bw/6;
+    const BandpPart PT = bandp_part(nf, B, Pmax, p);
+    const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P);
+    if (p >= P) return;
+    const int REC = bw*6, rtop = p < P - 1 ? b + B : b;         // pivots rtop - 1 .. a (the separator on the right first: its solution is known)
+    if (p > 0) {
+        if (tid < 80) xl[tid] = xlv;
+        __syncthreads();
+        const int part = tid & 3, eo = tid >> 2, nout = 6*(b - a);
+        for (int e0 = 0; e0 < nout; e0 += 2*(SV_T/4)) {          // two passes of 64 outputs in flight
+            double lv[2][20], v0[2];
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) { const int e = e0 + ps*(SV_T/4) + eo; const bool ok = e < nout; const int q = a + e/6, cc = e % 6;
+                const double *Lq = Lb + (size_t)q*REC + cc;
+#pragma unroll
+                for (int j = 0; j < 20; j++) { const int br = part + 4*j; lv[ps][j] = (ok && br < bw) ? Lq[6*br] : 0.0; }
+                v0[ps] = (ok && part == 0) ? M.V[6*(size_t)q + cc] : 0.0; }
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) { const int e = e0 + ps*(SV_T/4) + eo; const bool ok = e < nout;
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 20; j++) { const int br = part + 4*j; if (br < bw) acc = fma(-lv[ps][j], xl[br], acc); }
+                acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+                if (ok && part == 0) M.V[6*(size_t)(a + e/6) + e % 6] = v0[ps] + acc; }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int ptid = tid - 64, pk = ptid >> 5, pj = ptid & 31, per = 36*B + 28;
+    // steps: the separator's blocks b + B - 1 .. b are pivots without a diagonal solve, then the interior's b - 1 .. a
+    const int nst = rtop - a, nch = (nst + SV_K - 1)/SV_K;
+    auto stage = [&](int c) {                                   // producers: chunk c = the pivots rtop - 1 - c SV_K - pk
+        const int R = rtop - 1 - c*SV_K - pk;
+        if (R < a) return;
+        double *dst = stg[c & 1][pk];
+        double vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int x = pj + 32*u; vv[u] = 0.0;
+            if (x < 36*B) vv[u] = Lrow[(size_t)R*REC + x];      // L(R, q), q = R - 1 .. R - B, at [(R - q - 1) 36 + 6 col + row]
+            else if (x < 36*B + 22) { if (R < b) vv[u] = W.LDbuf[32*(size_t)R + (x - 36*B)]; }
+            else if (x < per) { const int qn = R - B; if (qn >= a) vv[u] = M.V[6*(size_t)qn + (x - 36*B - 22)]; } }      // the block entering the window
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int x = pj + 32*u; if (x < per) dst[x < 36*B ? x : SV_TB + (x - 36*B)] = vv[u]; }
+    };
+    // window: the blocks R - B + 1 .. R before a step, R - B .. R - 1 after it; block q in slot q mod B
+    int slot[NREG], ri[NREG], dd[NREG]; bool rowok[NREG]; double t[NREG];
+#pragma unroll
+    for (int g = 0; g < NREG; g++) { const int rho = lane + 64*g; rowok[g] = rho < 6*B; slot[g] = rho/6; ri[g] = rho - 6*slot[g]; t[g] = 0.0; dd[g] = 1; }
+    int sR = (rtop - 1) % B;
+    if (wave > 0) stage(0);
+    else {
+#pragma unroll
+        for (int g = 0; g < NREG; g++) { const int d = (sR - slot[g] + B) % B, q = rtop - 1 - d;
+            t[g] = (rowok[g] && q >= a) ? (q >= b ? M.Xs[(size_t)p*bw + 6*(q - b) + ri[g]] : M.V[6*(size_t)q + ri[g]]) : 0.0;
+            dd[g] = d == 0 ? B : d; }
+    }
+    __syncthreads();
+    for (int c = 0; c < nch; c++) {
+        if (wave > 0) { if (c + 1 < nch) stage(c + 1); }
+        else {
+            const int R0 = rtop - 1 - c*SV_K, nk = min(SV_K, R0 - a + 1);
+            for (int k = 0; k < nk; k++) {
+                const double *sk = stg[c & 1][k]; const int R = R0 - k;
+                double cf[NREG][6], ent[NREG], l[15];
+#pragma unroll
+                for (int g = 0; g < NREG; g++) {
+                    const int q = R - dd[g]; const bool on = rowok[g] && q >= a && q < b;          // (rows of the separator itself take nothing)
+                    const double *cp = sk + (on ? (dd[g] - 1)*36 + 6*ri[g] : 0);
+#pragma unroll
+                    for (int k2 = 0; k2 < 6; k2++) { const double cv = cp[k2]; cf[g][k2] = on ? cv : 0.0; }
+                    ent[g] = sk[SV_TB + 22 + ri[g]]; }
+#pragma unroll
+                for (int e = 0; e < 15; e++) l[e] = sk[SV_TB + e];
+                double x[6];
+#pragma unroll
+                for (int k2 = 0; k2 < 6; k2++) x[k2] = sv_pivot<NREG>(t, 6*sR + k2);
+#pragma unroll
+                for (int i = 4; i >= 0; i--)
+#pragma unroll
+                    for (int j = i + 1; j < 6; j++) x[i] = fma(-l[tri(j - 1) + i], x[j], x[i]);
+                if (lane < 6) { double xo = x[0];
+#pragma unroll
+                    for (int k2 = 1; k2 < 6; k2++) xo = lane == k2 ? x[k2] : xo;
+                    M.X[6*(size_t)R + lane] = xo; }
+#pragma unroll
+                for (int g = 0; g < NREG; g++) {
+                    double tv = (rowok[g] && slot[g] == sR) ? ent[g] : t[g];
+#pragma unroll
+                    for (int k2 = 0; k2 < 6; k2++) tv = fma(-cf[g][k2], x[k2], tv);
+                    t[g] = rowok[g] ? tv : 0.0;
+                    dd[g] = dd[g] == 1 ? B : dd[g] - 1;
+                }
+                sR = sR == 0 ? B - 1 : sR - 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- the inverse of every separator's unit-lower factor, once per factorisation: M.Li [label][s][s] row-major (zeros above the diagonal), M.Lid [label][s] = 1/d.
+// grid labels, 128 threads: the packed record is unpacked into a dense triangle in LDS, then a thread per column j solves L y = e_j.
+static size_t sv_linv_lds_doubles(int s) { return (size_t)s*(s + 1) + (size_t)tri(s) + s; }
+__global__ __launch_bounds__(128) void k_sv_linv(Work W, int bw, int Pmax, const double *__restrict__ fac, MsBuf M) {
+    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
+    const int tid = threadIdx.x, s = bw, B = s/6, i = blockIdx.x;
+    const LmState *st_ = W.st; const int flags = st_->done | st_->step_fail, nf = ms_uni(*W.nfree);
+    if (flags) return;
+    if (i >= sv_nsep(nf, B, Pmax)) return;
+    double *Ld = ms_smem, *Y = Ld + (size_t)s*(s + 1);          // Ld [s][s + 1]; Y packed by rows: Y(k, j), j <= k, at tri(k) + j
+    const double *rec = fac + (size_t)i*cre_rec_doubles(s), *LDt = rec + rowoff(s);
+    for (int e = tid; e < s*s; e += 128) { const int rr = e/s, k = e - rr*s; double v = 0.0;
+        if (k < rr) v = (k/6 == rr/6) ? LDt[SOLVE_LD*(rr/6) + tri(rr % 6 - 1) + k % 6] : rec[rowoff(rr) + k];
+        Ld[rr*(s + 1) + k] = v; }
+    if (tid < s) M.Lid[(size_t)i*s + tid] = LDt[SOLVE_LD*(tid/6) + LD_ID + tid % 6];
+    __syncthreads();
+    const int j = tid;
+    double *out = M.Li + (size_t)i*s*s;
+    if (j < s) {
+        for (int rr = 0; rr < j; rr++) out[(size_t)rr*s + j] = 0.0;
+        Y[tri(j) + j] = 1.0; out[(size_t)j*s + j] = 1.0;
+        for (int rr = j + 1; rr < s; rr++) {
+            const double *Lr = Ld + rr*(s + 1);
+            double acc0 = 0.0, acc1 = 0.0; int k = j;
+            for (; k + 1 < rr; k += 2) { acc0 = fma(-Lr[k], Y[tri(k) + j], acc0); acc1 = fma(-Lr[k + 1], Y[tri(k + 1) + j], acc1); }
+            if (k < rr) acc0 = fma(-Lr[k], Y[tri(k) + j], acc0);
+            const double y = acc0 + acc1;
+            Y[tri(rr) + j] = y; out[(size_t)rr*s + j] = y;
+        }
+    }
+}
+
+// ---- the separator kernels: every operand requested at once, speculatively (every address is inside its allocation whatever the number of
+// separators turns out to be), one wait.
+// pending updates of block blk's right-hand side row `row` (the producers of ms_pending): pivots blk -+ 2^l of level 2^l, 2^l < H
+struct SvPend { double lo_[8], hi_[8]; };
+__device__ __forceinline__ void sv_pending_load(const MsBuf &M, int s, int blk, int mmax, int row, bool on, SvPend &P) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        const int hp = 1 << l, pl = blk - hp, pr = blk + hp;
+        P.lo_[l] = (on && pl >= 0) ? M.Cg[((size_t)pl*2 + 1)*s + row] : 0.0;
+        P.hi_[l] = (on && pr < mmax) ? M.Cg[((size_t)pr*2 + 0)*s + row] : 0.0;
+    }
+}
+__device__ __forceinline__ void sv_pin(SvPend &P) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) { sv_pin(P.lo_[l]); sv_pin(P.hi_[l]); }
+}
+__device__ __forceinline__ double sv_pending_sum(const SvPend &P, int blk, int H, int lo, int m, int r0, double v) {      // the order of ms_pending
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        const int hp = 1 << l; const bool lev = hp < H && hp < m - lo;
+        const int pl = blk - hp, pr = blk + hp;
+        if (lev && pl >= lo && pl != r0 && (pl & (2*hp - 1)) == hp) v -= P.lo_[l];
+        if (lev && pr < m && pr != r0 && (pr & (2*hp - 1)) == hp) v -= P.hi_[l];
+    }
+    return v;
+}
+// rows of a dense [.. ][s] block against a vector in LDS: four lanes per row (16-byte pieces 2 part + 8 j)
+struct SvRow { v2d x[10]; };
+__device__ __forceinline__ void sv_row_load(const double *row, int s, int part, bool on, SvRow &R) {
+#pragma unroll
+    for (int j = 0; j < 10; j++) { const int k = 2*part + 8*j; R.x[j] = (on && k < s) ? *(const v2d *)(row + k) : v2d{0.0, 0.0}; }
+}
+__device__ __forceinline__ void sv_pin(SvRow &R) {
+#pragma unroll
+    for (int j = 0; j < 10; j++) sv_pin(R.x[j]);
+}
+__device__ __forceinline__ double sv_row_dot(const SvRow &R, const double *v, int s, int part) {     // every lane of the wave takes part (shuffles)
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { const int k = 2*part + 8*j; if (k < s) acc = fma(R.x[j].x, v[k], fma(R.x[j].y, v[k + 1], acc)); }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+    return acc;
+}
+
+// ---- cyclic reduction, level h, forward.  grid pivots, SV_CT threads:  w = L^-1 (g - pending),  z = D^-1 w,  updates X_a w, X_c w for the neighbours
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_fwd(Work W, Work Ws, int bw, int Pmax, int h, int kb, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80], w[80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
+    const int i = (2*(kb + (int)blockIdx.x) + 1)*h, ia = i - h, ic = i + h;             // (i < mmax by the launch; ia >= 0)
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s;
+    double g0 = vrow ? M.G[(size_t)i*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)i*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)i*s + tid] : 0.0;
+    SvPend pd; sv_pending_load(M, s, i, mmax, tid, vrow, pd);
+    const int part = tid & 3, rq = tid >> 2;                    // 128 rows per pass
+    SvRow li, xr[2];
+    sv_row_load(M.Li + ((size_t)i*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
+    const double *Xa = cr_blk(Ws.S, s, mmax, i, ia), *Xc = cr_blk(Ws.S, s, mmax, ic, i);
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) { const int r = ps*(SV_CT/4) + rq; const bool rok = r < 2*s;
+        sv_row_load((r < s ? Xa : Xc) + (size_t)(rok ? (r < s ? r : r - s) : 0)*s, s, part, rok, xr[ps]); }
+    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(pd); sv_pin(li); sv_pin(xr[0]); sv_pin(xr[1]);
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0, r0 = 0;
+    if (i < lo || i >= m) return;
+    const bool has_a = ia >= lo, has_c = ic < m;
+    if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, g0 + g1);
+    __syncthreads();
+    { const double wv = sv_row_dot(li, v, s, part);
+      if (rq < s && part == 0) w[rq] = wv; }
+    __syncthreads();
+    if (vrow) M.Z[(size_t)i*s + tid] = w[tid]*idv;
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) { const int r = ps*(SV_CT/4) + rq; const bool rok = r < 2*s;
+        const double acc = sv_row_dot(xr[ps], w, s, part);
+        if (rok && part == 0) M.Cg[((size_t)i*2 + (r < s ? 0 : 1))*s + (r < s ? r : r - s)] = (r < s ? has_a : has_c) ? acc : 0.0;
+    }
+}
+
+// columns of a dense [s][s] block against a vector in LDS (the transposed product): six groups of rows t = g + 6 j, a thread per column
+struct SvCol { double x[13]; };
+__device__ __forceinline__ void sv_col_load(const double *X, int s, int g, int r, bool on, SvCol &C) {
+#pragma unroll
+    for (int j = 0; j < 13; j++) { const int t = g + 6*j; C.x[j] = (on && t < s) ? X[(size_t)t*s + r] : 0.0; }
+}
+__device__ __forceinline__ void sv_pin(SvCol &C) {
+#pragma unroll
+    for (int j = 0; j < 13; j++) sv_pin(C.x[j]);
+}
+__device__ __forceinline__ double sv_col_dot(const SvCol &C, const double *v, int s, int g) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 13; j++) { const int t = g + 6*j; if (t < s) acc = fma(C.x[j], v[t], acc); }
+    return acc;
+}
+
+// ---- the last block: forward and backward.  One workgroup.
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_root(Work W, int bw, int Pmax, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80], w[80], red[6*80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), r0 = 0;            // (chains: the root is label 0)
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s;
+    double g0 = vrow ? M.G[(size_t)r0*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)r0*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)r0*s + tid] : 0.0;
+    SvPend pd; sv_pending_load(M, s, r0, mmax, tid, vrow, pd);
+    const int part = tid & 3, rq = tid >> 2, g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    SvRow li; SvCol lc;
+    sv_row_load(M.Li + ((size_t)r0*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
+    sv_col_load(M.Li + (size_t)r0*s*s, s, g, con ? r : 0, con, lc);
+    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(pd); sv_pin(li); sv_pin(lc);
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0;
+    if (m <= 0) return;
+    if (vrow) v[tid] = sv_pending_sum(pd, r0, 1 << 30, lo, m, -1, g0 + g1);
+    __syncthreads();
+    { const double wv = sv_row_dot(li, v, s, part);
+      if (rq < s && part == 0) w[rq] = wv; }
+    __syncthreads();
+    if (vrow) v[tid] = w[tid]*idv;                              // z
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;       // x = L^-T z
+    __syncthreads();
+    if (vrow) M.Xs[(size_t)r0*s + tid] = ((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]);
+}
+
+// ---- cyclic reduction, level h, backward.  grid pivots, SV_CT threads:  x_i = L^-T (z_i - X_a^T x_a - X_c^T x_c)
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_back(Work W, Work Ws, int bw, int Pmax, int h, int kb, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double u[80], xa[80], xc[80], red[6*80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
+    const int i = (2*(kb + (int)blockIdx.x) + 1)*h, ia = i - h, ic = i + h;
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s, cin = ic < mmax;
+    double zv = vrow ? M.Z[(size_t)i*s + tid] : 0.0, xav = vrow ? M.Xs[(size_t)ia*s + tid] : 0.0, xcv = (vrow && cin) ? M.Xs[(size_t)ic*s + tid] : 0.0;
+    const double *Xa = cr_blk(Ws.S, s, mmax, i, ia), *Xc = cr_blk(Ws.S, s, mmax, ic, i);
+    const int g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    SvCol ca, cc_, lc;
+    sv_col_load(Xa, s, g, con ? r : 0, con, ca); sv_col_load(Xc, s, g, con ? r : 0, con, cc_);
+    sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con, lc);
+    sv_pin(zv); sv_pin(xav); sv_pin(xcv); sv_pin(ca); sv_pin(cc_); sv_pin(lc);
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0;
+    if (i < lo || i >= m) return;
+    const bool has_a = ia >= lo, has_c = ic < m;
+    if (vrow) { xa[tid] = has_a ? xav : 0.0; xc[tid] = has_c ? xcv : 0.0; }
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? (has_a ? sv_col_dot(ca, xa, s, g) : 0.0) + (has_c ? sv_col_dot(cc_, xc, s, g) : 0.0) : 0.0;
+    __syncthreads();
+    if (vrow) u[tid] = zv - (((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]));
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, u, s, g) : 0.0;
+    __syncthreads();
+    if (vrow) M.Xs[(size_t)i*s + tid] = ((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]);
+}

@@ -173,19 +173,21 @@ int tsba_debug_img_cache_stats(void *ctx, int64_t out[2]) {
 // Test hook of the multi-right-hand-side solve phase (tsba_bandms.h): M X = R with the band factor the last tsba_debug_reduced_system / solve left
 // behind.  R, X: [6 nfree][T] row-major (compressed free-pose rows).  TSBA_ERR_STATE unless the problem runs through the partitioned band
 // solver with the cyclic-reduction separator system on a chain.
-int tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X) {
-    Ctx *c = (Ctx *)ctx; if (!c || T < 1 || !R || !X) return TSBA_ERR_ARG;
+int tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X) {       // T = -1: one column through the single-vector solve phase (tsba_bandsv.h)
+    Ctx *c = (Ctx *)ctx; if (!c || (T < 1 && T != -1) || !R || !X) return TSBA_ERR_ARG;
     if (!c->uploaded || !ms_available(c)) { if (c) set_err(c, "multi-right-hand-side solve: needs the partitioned band solver with cyclic reduction on a chain"); return TSBA_ERR_STATE; }
     hipSetDevice(c->device);
     int nfree = 0; CK(hipMemcpy(&nfree, c->W.nfree, sizeof(int), hipMemcpyDeviceToHost));
-    int rc = ms_reserve(c, T); if (rc) return rc;
+    const bool single = T == -1; if (single) T = 1;
+    int rc = single ? sv_reserve(c) : ms_reserve(c, T); if (rc) return rc;
     { int rca = set_solver_attrs(c); if (rca) return rca; }
     LmState st; CK(hipMemcpy(&st, c->W.st, sizeof(st), hipMemcpyDeviceToHost));
     st.done = 0; st.step_fail = 0; st.lin_done = 0; CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));
-    CK(hipMemcpy(c->ms.R, R, sizeof(double)*6*(size_t)nfree*T, hipMemcpyHostToDevice));
-    launch_ms_solve(c);
+    const MsBuf &M = single ? c->sv : c->ms;
+    CK(hipMemcpy(M.R, R, sizeof(double)*6*(size_t)nfree*T, hipMemcpyHostToDevice));
+    if (single) { launch_sv_prepare(c); launch_sv_solve(c, M.R, 1.0); } else launch_ms_solve(c);
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
-    CK(hipMemcpy(X, c->ms.X, sizeof(double)*6*(size_t)nfree*T, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(X, M.X, sizeof(double)*6*(size_t)nfree*T, hipMemcpyDeviceToHost));
     return TSBA_OK;
 }
 // row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating); with a

@@ -231,10 +231,12 @@ class Optimizer:
         self._check(self.lib.tsba_debug_far_blocks(self.ctx, a.ctypes.data_as(ip), b.ctypes.data_as(ip), _dp(v)), "tsba_debug_far_blocks")
         return a, b, v
 
-    def multi_solve(self, R):
-        """M X = R with the band factor of the last solve (tsba_debug_multi_solve); R: [6 x free poses, T]."""
+    def multi_solve(self, R, single=False):
+        """M X = R with the band factor of the last solve (tsba_debug_multi_solve); R: [6 x free poses, T].  single: one column through the
+        single-vector solve phase (what a conjugate-gradient iteration applies)."""
         R = np.ascontiguousarray(R, np.float64); X = np.zeros_like(R)
-        self._check(self.lib.tsba_debug_multi_solve(self.ctx, R.shape[1], _dp(R), _dp(X)), "tsba_debug_multi_solve")
+        assert not single or R.shape[1] == 1
+        self._check(self.lib.tsba_debug_multi_solve(self.ctx, -1 if single else R.shape[1], _dp(R), _dp(X)), "tsba_debug_multi_solve")
         return X
 
     def img_cache_stats(self):

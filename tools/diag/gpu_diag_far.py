@@ -26,6 +26,8 @@ def mem_used_mb():
 
 
 opt = Optimizer(0)
+if os.environ.get("PCG_REFACTOR"):          # 1: the factorisation re-run as preconditioner, 2: the many-column solve phase (default: the single-vector solve phase)
+    opt.debug_set(pcg_refactor=int(os.environ["PCG_REFACTOR"])); print("pcg_refactor", os.environ["PCG_REFACTOR"])
 if tol_exp:
     opt.debug_set(pcg_tol_exp=tol_exp); print("pcg tolerance 1e-%d" % tol_exp)
 t = time.time()
