@@ -573,7 +573,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
             c->pcg_parts = (p->n_kf + 31)/32;
             AL(W.Sfar, 36*(size_t)std::max(c->n_far, 1));
             AL(W.pc_x, W.N); AL(W.pc_r, W.N); AL(W.pc_p[0], W.N); AL(W.pc_p[1], W.N); AL(W.pc_q, W.N); AL(W.pc_g0, W.N);
-            AL(W.pc_part, 3*(size_t)c->pcg_parts + 8); AL(W.pcs, 2); AL(W.pc_stat, 4);
+            AL(W.pc_part, 5*(size_t)c->pcg_parts + 16); AL(W.pcs, 2); AL(W.pc_stat, 4);
         }
         c->S_xchg = nullptr; c->xchg_wp = 0;
         if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, ((size_t)W.N + bwmax)*c->xchg_wp); }
@@ -819,6 +819,10 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_ms_cre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
         CK(hipFuncSetAttribute((const void *)k_ms_cre_root, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
         CK(hipFuncSetAttribute((const void *)k_sv_linv, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
+        CK(hipFuncSetAttribute((const void *)k_sv_fwd_int<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_sv_fwd_int<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_sv_back_int<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_sv_back_int<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -970,16 +974,20 @@ static int sv_reserve(Ctx *c) {
     M.G = q; q += labels*sdim; M.Z = q; q += labels*sdim; M.Xs = q; q += labels*sdim; M.Cg = q; q += 2*labels*sdim; M.G2 = q; q += labels*sdim; M.Lid = q;
     return TSBA_OK;
 }
+// bound of an interior's length in pose blocks (bandp_part: the device partitions the FREE poses -- at most n_kf -- into at most band_parts interiors of at
+// least 2 B + 2 blocks; where it has to take fewer interiors they stay below twice that)
+static int sv_lmax(const Ctx *c) { const int B = std::max(6, c->cur_bw_rows)/6, P = std::max(1, c->band_parts); return std::max(c->n_kf/P + 2, 5*B + 8); }
 static void launch_sv_prepare(Ctx *c) {
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, mmax = cr_mmax(0, P, 0);
     if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(128), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, c->sv);
 }
 static void launch_sv_solve(Ctx *c, const double *r, double rs) {
     Work &W = c->W; const MsBuf &M = c->sv;
-    const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6;
+    const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6, lmax = sv_lmax(c);
     Work &Ws = c->Wsep; Ws.st = W.st;
-    if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M);
-    else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M);
+    const size_t ldf = sv_fwd_lds_doubles(B)*sizeof(double), ldb = sv_back_lds_doubles(B, lmax)*sizeof(double);
+    if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M);
+    else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M);
     const int mmax = cr_mmax(0, P, 0);
     auto pivots = [&](int h) { const int klast = (mmax - 1 - h)/(2*h); return mmax - 1 - h < 0 ? 0 : std::max(0, klast + 1); };
     int htop = 0;
@@ -988,8 +996,8 @@ static void launch_sv_solve(Ctx *c, const double *r, double rs) {
     hipLaunchKernelGGL(k_sv_cre_root, dim3(1), dim3(SV_CT), 0, c->stream, W, bwp, P, M);
     for (int h = htop; h >= 1; h >>= 1) { const int npiv = pivots(h);
         if (npiv > 0) hipLaunchKernelGGL(k_sv_cre_back, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
-    if (B <= 10) hipLaunchKernelGGL(k_sv_back_int<1>, dim3(P), dim3(SV_T), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
-    else hipLaunchKernelGGL(k_sv_back_int<2>, dim3(P), dim3(SV_T), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
+    if (B <= 10) hipLaunchKernelGGL(k_sv_back_int<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M);
+    else hipLaunchKernelGGL(k_sv_back_int<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M);
 }
 
 // The reduced system of one LM trial: a direct solve, or -- band + long-range blocks -- conjugate gradients preconditioned with the band
@@ -1000,6 +1008,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     if (D.far_B <= 0) return;
     Work &W = c->W;
     const int nbp = c->pcg_parts, B = std::max(6, c->cur_bw_rows)/6;
+    const int nmv = (c->n_kf + PCG_MW - 1)/PCG_MW, pq_off = 3*nbp + 8;          // the matvec's workgroups (a wave per keyframe) and where their partial p.q go (nmv <= 2 nbp)
     const int cap = c->dbg.pcg_max_it > 0 ? c->dbg.pcg_max_it : 200;
     const double tol = c->dbg.pcg_tol_exp > 0 ? pow(10.0, -(double)c->dbg.pcg_tol_exp) : 1e-10, tol2 = tol*tol;
     const unsigned int seq = ++c->pcg_seq;
@@ -1110,14 +1119,14 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     int it = 0;
     for (; it < cap; it++) {
         if (finished(it)) break;
-        hipLaunchKernelGGL(k_pcg_matvec, dim3(nbp), dim3(PCG_MT), 0, c->stream, W, D, it, seq, B, tol2, nbp, zp, zs);
-        if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, c->ms.R, 1.0);
+        hipLaunchKernelGGL(k_pcg_matvec, dim3(nmv), dim3(64*PCG_MW), 0, c->stream, W, D, it, seq, B, tol2, nbp, pq_off, zp, zs);
+        if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->ms.R, 1.0);
             const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
-        else if (sv) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, c->sv.R, 1.0);
+        else if (sv) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->sv.R, 1.0);
             if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
             launch_sv_solve(c, c->sv.R, 1.0); zp = c->sv.X; zs = 1.0;
             if (wb) { correct(c->sv.X, 1.0); zp = c->wb.z; } }
-        else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, W.g, -1.0);
+        else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, W.g, -1.0);
             if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
             launch_solve(c);
             if (wb) { correct(W.Sy, -1.0); zp = c->wb.z; zs = 1.0; } }

@@ -15,11 +15,9 @@
 // Vectors: MsBuf with T = 1 (the right-hand side comes as rs * r[]).  Chain partitions only, cyclic-reduction separator system.
 #pragma once
 
-#define SV_T 256                            // interiors: chain wave + three staging waves
+#define SV_T 512                            // interiors: chain wave + seven staging waves
 #define SV_CT 512                           // separators: 8 waves
-#define SV_K 6                              // pivot blocks per staged chunk
-#define SV_TB (36*MS_BMAX)                  // staged pivot: [0, 36 B) coefficients | SV_TB + [0, 15) unit-lower l, [16, 22) 1/d | SV_TB + 22 + [0, 6) entering values
-#define SV_CS (SV_TB + 32)
+#define SV_K 16                             // pivot blocks per staged chunk (a chunk's chain time ~ one round trip to memory)
 
 __device__ __forceinline__ double sv_bcast(double v, int lane) {           // lane: uniform
     const int l = __builtin_amdgcn_readfirstlane(lane);
@@ -35,49 +33,70 @@ __device__ __forceinline__ void sv_pin(double &x) { asm volatile("" : "+v"(x)); 
 __device__ __forceinline__ void sv_pin(v2d &x) { asm volatile("" : "+v"(x)); }        // the early-out branches, into the block that uses it: one more round trip)
 __device__ __forceinline__ int sv_nsep(int nf, int B, int Pmax) { return nf > 0 ? bandp_part(nf, B, Pmax, 0).P - 1 : 0; }      // chain: separators 0 .. m - 1, root 0 (cr_range)
 
+// staged pivot record (CS = 36 B + 32 doubles): [0, 36 B) coefficients | 36 B + [0, 15) unit-lower l, [16, 22) 1/d | 36 B + 22 + [0, 6) entering values
+__host__ __device__ __forceinline__ int sv_cs(int B) { return 36*B + 32; }
+static size_t sv_fwd_lds_doubles(int B) { return 2*(size_t)SV_K*sv_cs(B) + 2*SV_K*6 + 4*96; }
+static size_t sv_back_lds_doubles(int B, int lmax) { return 2*(size_t)SV_K*sv_cs(B) + 6*(size_t)lmax + 80; }
+
+// producers (threads 64 .. 255): pivot records of a chunk, 6 pivots x 32 threads per round, every request of the chunk in flight at once
+#define SV_PT ((SV_T - 64)/SV_K)               // producer threads per pivot of a chunk
+#define SV_PU ((36*MS_BMAX + 28)/2/SV_PT + 1)  // 16-byte pieces per producer thread
+struct SvStage { v2d v[SV_PU]; };
+#define SV_BG 4                             // border: groups of 96 producer threads, SV_BQ pivots of a chunk each
+#define SV_BQ (SV_K/SV_BG)
+template <int NREG> struct SvStep { double cf[NREG][6], ent[NREG], l[15], idl; };
+
 // ---- interiors, forward.  grid Pmax, SV_T threads.
 //   M.V = D^-1 w (L w = r), M.G [label][s] = rows of the separator on the right below this interior, M.G2 [label][s] = border rows of the separator on the left
 template <int NREG>
 __global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, const double *__restrict__ r, double rs, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double stg[2][SV_K][SV_CS];
-    __shared__ double wch[2][SV_K][6];
-    __shared__ double red[2][96];
+    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6);
+#ifdef SV_STAMPS
+    long long stamps[8]; int nstamp = 0;
+#define SVS() do { if (nstamp < 8) stamps[nstamp++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SVS() do {} while (0)
+#endif
+    SVS();
     const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = ms_uni(*W.nfree);
     if (flags || nf <= 0) return;
-    const int B = bw/6, p = blockIdx.x;
+    SVS();
+    const int B = bw/6, p = blockIdx.x, CS = sv_cs(B), TB = 36*B;
+    double *stg = ms_smem, *wch = stg + 2*(size_t)SV_K*CS, *red = wch + 2*SV_K*6;       // stg [2][SV_K][CS], wch [2][SV_K][6], red [2][96]
     const BandpPart PT = bandp_part(nf, B, Pmax, p);
     const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P);
     if (p >= P) return;
     const int REC = bw*6, rend = p < P - 1 ? b + B : b, nch = (b - a + SV_K - 1)/SV_K;
-    const int ptid = tid - 64, pk = ptid >> 5, pj = ptid & 31, per = 36*B + 28;
-    auto stage = [&](int c) {                                   // producers: chunk c; thread (pivot pk, 32 threads across its record)
-        const int q = a + c*SV_K + pk;
-        if (q >= b) return;
-        double *dst = stg[c & 1][pk];
-        double vv[16];
+    const int ptid = tid - 64, pk = ptid & (SV_K - 1), pj = ptid/SV_K, perp = (TB + 28)/2;       // producers: (pivot of the chunk, SV_PT threads across its record, 16 bytes each)
+    auto stage = [&](int c) {                                   // producers: chunk c
+        const int q = a + c*SV_K + pk; const bool on = q < b;
+        const double *Lq = Lrow + (size_t)(q + 1)*REC, *ldq = W.LDbuf + 32*(size_t)q - TB, *rq = r + 6*(size_t)(q + B) - (TB + 22);
+        v2d vv[SV_PU];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int x = pj + 32*u; vv[u] = 0.0;
-            if (x < 36*B) { const int R = q + 1 + x/36; if (R < rend) vv[u] = Lrow[(size_t)R*REC + x]; }       // L(R, q), R = q + 1 .. q + B, at [(R - q - 1) 36 + 6 col + row]
-            else if (x < 36*B + 22) vv[u] = W.LDbuf[32*(size_t)q + (x - 36*B)];
-            else if (x < per) { const int Rn = q + B; if (Rn < rend) vv[u] = rs*r[6*(size_t)Rn + (x - 36*B - 22)]; } }     // the block entering the window after pivot q
+        for (int u = 0; u < SV_PU; u++) { const int x = 2*(pj + SV_PT*u); vv[u] = v2d{0.0, 0.0};
+            if (on && x < TB) { const int d1 = x/36; if (q + 1 + d1 < rend) vv[u] = *(const v2d *)(Lq + (size_t)d1*REC + x); }       // L(R, q), R = q + 1 .. q + B, at [(R - q - 1) 36 + 6 col + row]
+            else if (on && x < TB + 22) vv[u] = *(const v2d *)(ldq + x);
+            else if (on && x < TB + 28) { if (q + B < rend) { const v2d e = *(const v2d *)(rq + x); vv[u] = v2d{rs*e.x, rs*e.y}; } } }     // the block entering the window after pivot q
+        double *dst = stg + ((size_t)(c & 1)*SV_K + pk)*CS;
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int x = pj + 32*u; if (x < per) dst[x < 36*B ? x : SV_TB + (x - 36*B)] = vv[u]; }
+        for (int u = 0; u < SV_PU; u++) { const int xp = pj + SV_PT*u; if (on && xp < perp) *(v2d *)(dst + 2*xp) = vv[u]; }
     };
-    const int bbr = ptid % 96, bhalf = ptid/96;                 // border: row of the separator on the left, half of a chunk's pivots
+    const int bbr = ptid % 96, bhalf = ptid/96;                 // border: row of the separator on the left, a quarter of a chunk's pivots (SV_BQ of them)
     double bacc = 0.0;
     auto border = [&](int c) {                                  // - Lb_q w_q over the pivots of chunk c
-        if (bbr >= bw) return;
-        double lv[SV_K/2][6];
+        if (bbr >= bw || bhalf >= SV_BG) return;
+        v2d lv[SV_BQ][3];
 #pragma unroll
-        for (int k = 0; k < SV_K/2; k++) { const int q = a + c*SV_K + bhalf*(SV_K/2) + k; const double *Lq = Lb + (size_t)q*REC + 6*bbr;
+        for (int k = 0; k < SV_BQ; k++) { const int q = a + c*SV_K + bhalf*SV_BQ + k; const v2d *Lq = (const v2d *)(Lb + (size_t)q*REC + 6*bbr);
 #pragma unroll
-            for (int cc = 0; cc < 6; cc++) lv[k][cc] = q < b ? Lq[cc] : 0.0; }
+            for (int cc = 0; cc < 3; cc++) lv[k][cc] = q < b ? Lq[cc] : v2d{0.0, 0.0}; }
 #pragma unroll
-        for (int k = 0; k < SV_K/2; k++) {
-            if (a + c*SV_K + bhalf*(SV_K/2) + k >= b) break;     // (past the interior: nothing was written to wch)
+        for (int k = 0; k < SV_BQ; k++) {
+            if (a + c*SV_K + bhalf*SV_BQ + k >= b) break;        // (past the interior: nothing was written to wch)
+            const double *wk = wch + ((size_t)(c & 1)*SV_K + bhalf*SV_BQ + k)*6;
 #pragma unroll
-            for (int cc = 0; cc < 6; cc++) bacc = fma(-lv[k][cc], wch[c & 1][bhalf*(SV_K/2) + k][cc], bacc); }
+            for (int cc = 0; cc < 3; cc++) bacc = fma(-lv[k][cc].x, wk[2*cc], fma(-lv[k][cc].y, wk[2*cc + 1], bacc)); }
     };
     // window: the B blocks q .. q + B - 1 before a step, q + 1 .. q + B after it; block R in slot R mod B, row (slot, k) on lane / register (6 slot + k) mod 64, / 64
     int slot[NREG], ri[NREG], dd[NREG]; bool rowok[NREG]; double t[NREG];
@@ -91,164 +110,208 @@ __global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, c
             dd[g] = d == 0 ? B : d; }                           // distance to the pivot AFTER the pivot's slot has been handed to the entering block
     }
     __syncthreads();
+    SVS();
     for (int c = 0; c < nch; c++) {
         if (wave > 0) { if (c + 1 < nch) stage(c + 1); if (p > 0 && c > 0) border(c - 1); }
         else {
             const int q0 = a + c*SV_K, nk = min(SV_K, b - q0);
-            for (int k = 0; k < nk; k++) {
-                const double *sk = stg[c & 1][k];
-                // requests of this step (none depends on the running solution)
-                double cf[NREG][6], ent[NREG], l[15];
+            const double *sk0 = stg + (size_t)(c & 1)*SV_K*CS;
+            // the requests of a step do not depend on the running solution: those of step k + 1 are issued before the arithmetic of step k (two register sets)
+            auto load = [&](SvStep<NREG> &S, int k, const int (&dn)[NREG]) {
+                const double *sk = sk0 + (size_t)k*CS;
 #pragma unroll
-                for (int g = 0; g < NREG; g++) { const double *cp = sk + (rowok[g] ? (dd[g] - 1)*36 + ri[g] : 0);
+                for (int g = 0; g < NREG; g++) { const double *cp = sk + (rowok[g] ? (dn[g] - 1)*36 + ri[g] : 0);
 #pragma unroll
-                    for (int cc = 0; cc < 6; cc++) cf[g][cc] = cp[6*cc];
-                    ent[g] = sk[SV_TB + 22 + ri[g]]; }
+                    for (int cc = 0; cc < 6; cc++) S.cf[g][cc] = cp[6*cc];
+                    S.ent[g] = sk[TB + 22 + ri[g]]; }
 #pragma unroll
-                for (int e = 0; e < 15; e++) l[e] = sk[SV_TB + e];
-                const double idl = sk[SV_TB + 16 + (lane < 6 ? lane : 0)];
-                // the pivot block: broadcast, unit-lower solve on uniform values
-                double w[6];
+                for (int e = 0; e < 15; e++) S.l[e] = sk[TB + e];
+                S.idl = sk[TB + 16 + (lane < 6 ? lane : 0)];
+            };
+            auto exec = [&](const SvStep<NREG> &S, int k) {
+                double w[6];                                    // the pivot block: broadcast, unit-lower solve on uniform values
 #pragma unroll
                 for (int cc = 0; cc < 6; cc++) w[cc] = sv_pivot<NREG>(t, 6*sq + cc);
 #pragma unroll
                 for (int i = 1; i < 6; i++)
 #pragma unroll
-                    for (int j = 0; j < i; j++) w[i] = fma(-l[tri(i - 1) + j], w[j], w[i]);
+                    for (int j = 0; j < i; j++) w[i] = fma(-S.l[tri(i - 1) + j], w[j], w[i]);
                 if (lane < 6) { double wl = w[0];
 #pragma unroll
                     for (int cc = 1; cc < 6; cc++) wl = lane == cc ? w[cc] : wl;
-                    wch[c & 1][k][lane] = wl; M.V[6*(size_t)(q0 + k) + lane] = wl*idl; }
-                // its slot goes to the entering block; every row of the window takes the pivot's contribution
+                    wch[((size_t)(c & 1)*SV_K + k)*6 + lane] = wl; M.V[6*(size_t)(q0 + k) + lane] = wl*S.idl; }
 #pragma unroll
-                for (int g = 0; g < NREG; g++) {
-                    double tv = (rowok[g] && slot[g] == sq) ? ent[g] : t[g];
+                for (int g = 0; g < NREG; g++) {                // its slot goes to the entering block; every row of the window takes the pivot's contribution
+                    double tv = (rowok[g] && slot[g] == sq) ? S.ent[g] : t[g];
 #pragma unroll
-                    for (int cc = 0; cc < 6; cc++) tv = fma(-cf[g][cc], w[cc], tv);
+                    for (int cc = 0; cc < 6; cc++) tv = fma(-S.cf[g][cc], w[cc], tv);
                     t[g] = rowok[g] ? tv : 0.0;
                     dd[g] = dd[g] == 1 ? B : dd[g] - 1;
                 }
                 sq = sq + 1 == B ? 0 : sq + 1;
+            };
+            auto nextd = [&](int (&dn)[NREG]) {
+#pragma unroll
+                for (int g = 0; g < NREG; g++) dn[g] = dd[g] == 1 ? B : dd[g] - 1;
+            };
+            SvStep<NREG> S0, S1; int dn[NREG];
+            load(S0, 0, dd);
+            for (int k = 0; k < nk; k += 2) {
+                if (k + 1 < nk) { nextd(dn); load(S1, k + 1, dn); }
+                exec(S0, k);
+                if (k + 1 < nk) {
+                    if (k + 2 < nk) { nextd(dn); load(S0, k + 2, dn); }
+                    exec(S1, k + 1);
+                }
             }
+            SVS();
         }
         __syncthreads();
+        SVS();
     }
+#ifdef SV_STAMPS
+    if (tid == 0) for (int k = 0; k < 8; k++) M.Wm[8*(size_t)p + k] = k < nstamp ? (double)(stamps[k] - stamps[0]) : -1.0;
+#endif
     if (wave == 0 && p < P - 1) {                               // what the window holds now: the separator's rows, minus this interior's part
 #pragma unroll
         for (int g = 0; g < NREG; g++) { const int d = (slot[g] - b % B + B) % B;
             if (rowok[g]) M.G[(size_t)p*bw + 6*d + ri[g]] = t[g]; }
     }
     if (p == 0) return;
-    if (wave > 0) { border(nch - 1); red[bhalf][bbr] = bacc; }
+    if (wave > 0) { border(nch - 1); if (bhalf < SV_BG) red[bhalf*96 + bbr] = bacc; }
     __syncthreads();
-    if (tid < bw) M.G2[(size_t)(p - 1)*bw + tid] = red[0][tid] + red[1][tid];
+    if (tid < bw) M.G2[(size_t)(p - 1)*bw + tid] = (red[tid] + red[96 + tid]) + (red[192 + tid] + red[288 + tid]);
 }
 
-// ---- interiors, backward.  grid Pmax, SV_T threads: first the border part  v_q -= Lb_q^T x_left  (all threads), then the chain on wave 0 with the other waves
-// staging.  M.X = the solution (the rows of the separator on the right written along).
+// ---- interiors, backward.  grid Pmax, SV_T threads: the border part  v_q -= Lb_q^T x_left  by all threads into LDS (vc), then the chain on wave 0 with the
+// other waves staging.  M.X = the solution (the rows of the separator on the right written along).  lmax: bound of an interior's length (host).
 template <int NREG>
-__global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double stg[2][SV_K][SV_CS];
-    __shared__ double xl[80];
+__global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, int lmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M) {
+    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6);
     const int p = blockIdx.x;
     const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = ms_uni(*W.nfree);
     double xlv = (p > 0 && tid < bw) ? M.Xs[(size_t)(p - 1)*bw + tid] : 0.0;      // (requested along with the flags: the address does not depend on them)
     sv_pin(xlv);
     if (flags || nf <= 0) return;
-    const int B = bw/6;
+    const int B = bw/6, CS = sv_cs(B), TB = 36*B;
+    double *stg = ms_smem, *vc = stg + 2*(size_t)SV_K*CS, *xl = vc + 6*(size_t)lmax;     // stg [2][SV_K][CS], vc [6 lmax]: v of the interior's rows with the border part taken off, xl [80]
     const BandpPart PT = bandp_part(nf, B, Pmax, p);
     const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P);
-    if (p >= P) return;
+    if (p >= P || b - a > lmax) return;
     const int REC = bw*6, rtop = p < P - 1 ? b + B : b;         // pivots rtop - 1 .. a (the separator on the right first: its solution is known)
-    if (p > 0) {
+    const int ptid = tid - 64, pk = ptid & (SV_K - 1), pj = ptid/SV_K, perp = (TB + 22)/2;
+    const int nst = rtop - a, nch = (nst + SV_K - 1)/SV_K;
+    SvStage S;
+    auto stage_load = [&](int c) {                              // producers: chunk c = the pivots rtop - 1 - c SV_K - pk
+        const int R = rtop - 1 - c*SV_K - pk; const bool on = R >= a;
+        const double *LR = Lrow + (size_t)R*REC, *ldR = W.LDbuf + 32*(size_t)R - TB;
+#pragma unroll
+        for (int u = 0; u < SV_PU; u++) { const int x = 2*(pj + SV_PT*u); S.v[u] = v2d{0.0, 0.0};
+            if (on && x < TB) S.v[u] = *(const v2d *)(LR + x);  // L(R, q), q = R - 1 .. R - B, at [(R - q - 1) 36 + 6 col + row]
+            else if (on && x < TB + 22 && R < b) S.v[u] = *(const v2d *)(ldR + x); }
+    };
+    auto stage_store = [&](int c) {
+        const int R = rtop - 1 - c*SV_K - pk;
+        double *dst = stg + ((size_t)(c & 1)*SV_K + pk)*CS;
+#pragma unroll
+        for (int u = 0; u < SV_PU; u++) { const int xp = pj + SV_PT*u; if (R >= a && xp < perp) *(v2d *)(dst + 2*xp) = S.v[u]; }
+    };
+    // window: the blocks R - B + 1 .. R before a step, R - B .. R - 1 after it; block q in slot q mod B
+    int slot[NREG], ri[NREG], dd[NREG]; bool rowok[NREG]; double t[NREG], tsep[NREG];
+#pragma unroll
+    for (int g = 0; g < NREG; g++) { const int rho = lane + 64*g; rowok[g] = rho < 6*B; slot[g] = rho/6; ri[g] = rho - 6*slot[g]; t[g] = 0.0; dd[g] = 1; tsep[g] = 0.0; }
+    int sR = (rtop - 1) % B;
+    if (wave > 0) stage_load(0);
+    else {
+#pragma unroll
+        for (int g = 0; g < NREG; g++) { const int d = (sR - slot[g] + B) % B, q = rtop - 1 - d;
+            tsep[g] = (rowok[g] && q >= b) ? M.Xs[(size_t)p*bw + 6*(q - b) + ri[g]] : 0.0; }
+    }
+    {   // vc = v - Lb^T x_left: four lanes per output row, two passes of 128 outputs in flight
         if (tid < 80) xl[tid] = xlv;
-        __syncthreads();
         const int part = tid & 3, eo = tid >> 2, nout = 6*(b - a);
-        for (int e0 = 0; e0 < nout; e0 += 2*(SV_T/4)) {          // two passes of 64 outputs in flight
+        bool first = true;
+        for (int e0 = 0; e0 < nout; e0 += 2*(SV_T/4)) {
             double lv[2][20], v0[2];
 #pragma unroll
             for (int ps = 0; ps < 2; ps++) { const int e = e0 + ps*(SV_T/4) + eo; const bool ok = e < nout; const int q = a + e/6, cc = e % 6;
                 const double *Lq = Lb + (size_t)q*REC + cc;
 #pragma unroll
-                for (int j = 0; j < 20; j++) { const int br = part + 4*j; lv[ps][j] = (ok && br < bw) ? Lq[6*br] : 0.0; }
+                for (int j = 0; j < 20; j++) { const int br = part + 4*j; lv[ps][j] = (ok && p > 0 && br < bw) ? Lq[6*br] : 0.0; }
                 v0[ps] = (ok && part == 0) ? M.V[6*(size_t)q + cc] : 0.0; }
+            if (first) { __syncthreads(); first = false; }      // (xl)
 #pragma unroll
             for (int ps = 0; ps < 2; ps++) { const int e = e0 + ps*(SV_T/4) + eo; const bool ok = e < nout;
                 double acc = 0.0;
 #pragma unroll
                 for (int j = 0; j < 20; j++) { const int br = part + 4*j; if (br < bw) acc = fma(-lv[ps][j], xl[br], acc); }
                 acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
-                if (ok && part == 0) M.V[6*(size_t)(a + e/6) + e % 6] = v0[ps] + acc; }
+                if (ok && part == 0) vc[e] = v0[ps] + acc; }
         }
-        __threadfence_block();
-        __syncthreads();
+        if (first) __syncthreads();
     }
-    const int ptid = tid - 64, pk = ptid >> 5, pj = ptid & 31, per = 36*B + 28;
-    // steps: the separator's blocks b + B - 1 .. b are pivots without a diagonal solve, then the interior's b - 1 .. a
-    const int nst = rtop - a, nch = (nst + SV_K - 1)/SV_K;
-    auto stage = [&](int c) {                                   // producers: chunk c = the pivots rtop - 1 - c SV_K - pk
-        const int R = rtop - 1 - c*SV_K - pk;
-        if (R < a) return;
-        double *dst = stg[c & 1][pk];
-        double vv[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) { const int x = pj + 32*u; vv[u] = 0.0;
-            if (x < 36*B) vv[u] = Lrow[(size_t)R*REC + x];      // L(R, q), q = R - 1 .. R - B, at [(R - q - 1) 36 + 6 col + row]
-            else if (x < 36*B + 22) { if (R < b) vv[u] = W.LDbuf[32*(size_t)R + (x - 36*B)]; }
-            else if (x < per) { const int qn = R - B; if (qn >= a) vv[u] = M.V[6*(size_t)qn + (x - 36*B - 22)]; } }      // the block entering the window
-#pragma unroll
-        for (int u = 0; u < 16; u++) { const int x = pj + 32*u; if (x < per) dst[x < 36*B ? x : SV_TB + (x - 36*B)] = vv[u]; }
-    };
-    // window: the blocks R - B + 1 .. R before a step, R - B .. R - 1 after it; block q in slot q mod B
-    int slot[NREG], ri[NREG], dd[NREG]; bool rowok[NREG]; double t[NREG];
-#pragma unroll
-    for (int g = 0; g < NREG; g++) { const int rho = lane + 64*g; rowok[g] = rho < 6*B; slot[g] = rho/6; ri[g] = rho - 6*slot[g]; t[g] = 0.0; dd[g] = 1; }
-    int sR = (rtop - 1) % B;
-    if (wave > 0) stage(0);
-    else {
+    if (wave > 0) stage_store(0);
+    __syncthreads();
+    if (wave == 0) {
 #pragma unroll
         for (int g = 0; g < NREG; g++) { const int d = (sR - slot[g] + B) % B, q = rtop - 1 - d;
-            t[g] = (rowok[g] && q >= a) ? (q >= b ? M.Xs[(size_t)p*bw + 6*(q - b) + ri[g]] : M.V[6*(size_t)q + ri[g]]) : 0.0;
+            t[g] = (rowok[g] && q >= a) ? (q >= b ? tsep[g] : vc[6*(q - a) + ri[g]]) : 0.0;
             dd[g] = d == 0 ? B : d; }
     }
-    __syncthreads();
     for (int c = 0; c < nch; c++) {
-        if (wave > 0) { if (c + 1 < nch) stage(c + 1); }
+        if (wave > 0) { if (c + 1 < nch) { stage_load(c + 1); stage_store(c + 1); } }
         else {
             const int R0 = rtop - 1 - c*SV_K, nk = min(SV_K, R0 - a + 1);
-            for (int k = 0; k < nk; k++) {
-                const double *sk = stg[c & 1][k]; const int R = R0 - k;
-                double cf[NREG][6], ent[NREG], l[15];
+            const double *sk0 = stg + (size_t)(c & 1)*SV_K*CS;
+            auto load = [&](SvStep<NREG> &T, int k, const int (&dn)[NREG]) {
+                const double *sk = sk0 + (size_t)k*CS; const int R = R0 - k;
 #pragma unroll
                 for (int g = 0; g < NREG; g++) {
-                    const int q = R - dd[g]; const bool on = rowok[g] && q >= a && q < b;          // (rows of the separator itself take nothing)
-                    const double *cp = sk + (on ? (dd[g] - 1)*36 + 6*ri[g] : 0);
+                    const int q = R - dn[g]; const bool on = rowok[g] && q >= a && q < b;          // (rows of the separator itself take nothing)
+                    const double *cp = sk + (on ? (dn[g] - 1)*36 + 6*ri[g] : 0);
 #pragma unroll
-                    for (int k2 = 0; k2 < 6; k2++) { const double cv = cp[k2]; cf[g][k2] = on ? cv : 0.0; }
-                    ent[g] = sk[SV_TB + 22 + ri[g]]; }
+                    for (int k2 = 0; k2 < 6; k2++) { const double cv = cp[k2]; T.cf[g][k2] = on ? cv : 0.0; }
+                    const int qn = R - B; T.ent[g] = qn >= a ? vc[6*(qn - a) + ri[g]] : 0.0; }       // the block entering the window
 #pragma unroll
-                for (int e = 0; e < 15; e++) l[e] = sk[SV_TB + e];
+                for (int e = 0; e < 15; e++) T.l[e] = sk[TB + e];
+            };
+            auto exec = [&](const SvStep<NREG> &T, int k) {
+                const int R = R0 - k;
                 double x[6];
 #pragma unroll
                 for (int k2 = 0; k2 < 6; k2++) x[k2] = sv_pivot<NREG>(t, 6*sR + k2);
 #pragma unroll
                 for (int i = 4; i >= 0; i--)
 #pragma unroll
-                    for (int j = i + 1; j < 6; j++) x[i] = fma(-l[tri(j - 1) + i], x[j], x[i]);
+                    for (int j = i + 1; j < 6; j++) x[i] = fma(-T.l[tri(j - 1) + i], x[j], x[i]);
                 if (lane < 6) { double xo = x[0];
 #pragma unroll
                     for (int k2 = 1; k2 < 6; k2++) xo = lane == k2 ? x[k2] : xo;
                     M.X[6*(size_t)R + lane] = xo; }
 #pragma unroll
                 for (int g = 0; g < NREG; g++) {
-                    double tv = (rowok[g] && slot[g] == sR) ? ent[g] : t[g];
+                    double tv = (rowok[g] && slot[g] == sR) ? T.ent[g] : t[g];
 #pragma unroll
-                    for (int k2 = 0; k2 < 6; k2++) tv = fma(-cf[g][k2], x[k2], tv);
+                    for (int k2 = 0; k2 < 6; k2++) tv = fma(-T.cf[g][k2], x[k2], tv);
                     t[g] = rowok[g] ? tv : 0.0;
                     dd[g] = dd[g] == 1 ? B : dd[g] - 1;
                 }
                 sR = sR == 0 ? B - 1 : sR - 1;
+            };
+            auto nextd = [&](int (&dn)[NREG]) {
+#pragma unroll
+                for (int g = 0; g < NREG; g++) dn[g] = dd[g] == 1 ? B : dd[g] - 1;
+            };
+            SvStep<NREG> S0, S1; int dn[NREG];
+            load(S0, 0, dd);
+            for (int k = 0; k < nk; k += 2) {
+                if (k + 1 < nk) { nextd(dn); load(S1, k + 1, dn); }
+                exec(S0, k);
+                if (k + 1 < nk) {
+                    if (k + 2 < nk) { nextd(dn); load(S0, k + 2, dn); }
+                    exec(S1, k + 1);
+                }
             }
         }
         __syncthreads();

@@ -188,6 +188,10 @@ int tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X) {      
     if (single) { launch_sv_prepare(c); launch_sv_solve(c, M.R, 1.0); } else launch_ms_solve(c);
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
     CK(hipMemcpy(X, M.X, sizeof(double)*6*(size_t)nfree*T, hipMemcpyDeviceToHost));
+#ifdef SV_STAMPS
+    if (single) { std::vector<double> st(8*(size_t)c->band_parts); CK(hipMemcpy(st.data(), M.Wm, sizeof(double)*st.size(), hipMemcpyDeviceToHost));
+        for (int p : {0, 1, c->band_parts/2, c->band_parts - 1}) { fprintf(stderr, "sv stamps interior %d:", p); for (int k = 0; k < 8; k++) fprintf(stderr, " %.0f", st[8*(size_t)p + k]); fprintf(stderr, "\n"); } }
+#endif
     return TSBA_OK;
 }
 // row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating); with a

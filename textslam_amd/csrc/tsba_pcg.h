@@ -18,8 +18,6 @@
 
 #define PCG_T 256                           // workgroups of the block kernels: 4 waves, a wave takes PCG_PPW poses
 #define PCG_PPW 8
-#define PCG_MT 1024                         // single-vector matvec: 16 waves x 2 poses (the same 32 poses per workgroup, so one partial array serves all; with 8 poses one
-#define PCG_MPW 2                           // after the other on a wave the kernel was a chain of dependent loads: 144 us at 5000 keyframes)
 #define PCG_ET 192                          // element-wise kernels: 32 poses x 6 rows per workgroup (the same number of workgroups, so one partial array serves all)
 
 struct PcgState { double rz, rz0, best; int it, since; };      // best: smallest r.z so far; since: iterations since it improved by a tenth (stagnation at the attainable accuracy)
@@ -58,12 +56,21 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_begin(Work W, const double *zp, 
 }
 
 // launch `it`: beta from r.z, p = z + beta p, q = S p = (band + long-range blocks) p, partial p.q.  Also where convergence is noticed.
-// zp, zs: where the last preconditioner application left z = zs * zp[] (the factorisation's own solve: -W.Sy; the solve phase: its X)
-__global__ __launch_bounds__(PCG_MT) void k_pcg_matvec(Work W, LevelDev L, int it, unsigned int seq, int B, double tol2, int nbp, const double *zp, double zs) {
-    __shared__ double lds[PCG_MT/64];
+// zp, zs: where the last preconditioner application left z = zs * zp[] (the factorisation's own solve: -W.Sy; the solve phase: its X).
+// A wave per keyframe, PCG_MW keyframes per workgroup; the partial p.q of a workgroup goes to pc_part[pq_off + blockIdx.x].  The kernel is a chain
+// of memory round trips, not arithmetic (18 MB at 5000 keyframes): everything a keyframe needs is requested in as few rounds as its index chain allows
+// (row of the keyframe, its list of long-range blocks | band rows, columns, the vector, the list's entries | the blocks' other keyframes | their rows |
+// the blocks and the vector there) -- with two keyframes one after the other on a wave and the blocks of a keyframe one after the other on 36 lanes
+// this was 69 us per launch.
+#define PCG_MW 16
+__global__ __launch_bounds__(64*PCG_MW) void k_pcg_matvec(Work W, LevelDev L, int it, unsigned int seq, int B, double tol2, int nbp, int pq_off, const double *zp, double zs) {
+    __shared__ double lds[PCG_MW];
     LmState *st = W.st;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (st->done || st->step_fail || st->lin_done) { if (blockIdx.x == 0 && tid == 0) pcg_publish(W, seq, it, 1); return; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = blockIdx.x*PCG_MW + wave; const bool kf = a < W.n_kf;
+    // round 1
+    const int flags = st->done | st->step_fail | st->lin_done;
+    int ia = kf ? W.fidx[a] : -1; const int e0 = kf ? L.far_off[a] : 0, e1 = kf ? L.far_off[a + 1] : 0;
+    if (flags) { if (blockIdx.x == 0 && tid == 0) pcg_publish(W, seq, it, 1); return; }
     const double rz = pcg_sum_parts(W.pc_part, nbp, lane);
     PcgState *so = W.pcs + ((it + 1) & 1), *sn = W.pcs + (it & 1);
     const double rz0 = it == 0 ? rz : so->rz0, rz_old = it == 0 ? 1.0 : so->rz;
@@ -79,61 +86,76 @@ __global__ __launch_bounds__(PCG_MT) void k_pcg_matvec(Work W, LevelDev L, int i
     const double beta = it == 0 ? 0.0 : rz/rz_old;
     if (blockIdx.x == 0 && tid == 0) { sn->rz = rz; sn->rz0 = rz0; sn->best = best; sn->since = since; sn->it = it; pcg_publish(W, seq, it, 0); }
     const double *po = W.pc_p[(it + 1) & 1]; double *pn = W.pc_p[it & 1];
-    auto pnew = [&](int i) { return fma(beta, po[i], zs*zp[i]); };
     const int nfree = W.nfree[0]; const size_t ldS = (size_t)W.ldS;
-    double pq = 0.0;
-    for (int u = 0; u < PCG_MPW; u++) {
-        const int a = (blockIdx.x*(PCG_MT/64) + wave)*PCG_MPW + u;
-        if (a >= W.n_kf) break;
-        const int ia = W.fidx[a];
-        if (ia < 0) continue;
-        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        // lower part of the band incl. the (square) diagonal block: rows 6 ia .. 6 ia + 5, columns from pose block ia - B on
-        const int cl = 6*max(ia - B, 0), ncol = 6*ia + 6 - cl;
-        for (int cb = 0; cb < ncol; cb += 64) {
-            const bool ok = cb + lane < ncol; const int c = ok ? cl + cb + lane : cl;
-            const double pv = ok ? pnew(c) : 0.0;
+    double qk = 0.0, pvk = 0.0;
+    if (ia >= 0) {
+        // round 2: the band.  Lower part incl. the (square) diagonal block: rows 6 ia .. 6 ia + 5, columns from pose block ia - B on (lane: column, up to two);
+        // transposed part: rows of the pose blocks ia + 1 .. ia + B, columns 6 ia .. 6 ia + 5 (lane: row, up to two)
+        const int cl = 6*max(ia - B, 0), ncol = 6*ia + 6 - cl, r0 = 6*(ia + 1), nrow = 6*min(ia + B, nfree - 1) + 6 - r0;
+        double sl[2][6], pl_o[2], pl_z[2], pt_o[2], pt_z[2], st_[2][6];
 #pragma unroll
-            for (int r = 0; r < 6; r++) acc[r] += (c <= 6*ia + r ? W.S[(size_t)(6*ia + r)*ldS + c] : W.S[(size_t)c*ldS + 6*ia + r])*pv;     // (the diagonal block by its lower triangle: what a sharded run exchanges)
-        }
-        // the transposed part: rows of the pose blocks ia + 1 .. ia + B, columns 6 ia .. 6 ia + 5
-        const int r0 = 6*(ia + 1), nrow = 6*min(ia + B, nfree - 1) + 6 - r0;
-        for (int rb = 0; rb < nrow; rb += 64) {
-            const bool ok = rb + lane < nrow; const int j = ok ? r0 + rb + lane : r0;
-            const double pv = ok ? pnew(j) : 0.0;
+        for (int g = 0; g < 2; g++) {
+            const int cc = lane + 64*g; const bool ok = cc < ncol; const int c = cl + (ok ? cc : 0);
+            pl_o[g] = ok ? po[c] : 0.0; pl_z[g] = ok ? zp[c] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) sl[g][r] = !ok ? 0.0 : (c <= 6*ia + r ? W.S[(size_t)(6*ia + r)*ldS + c] : W.S[(size_t)c*ldS + 6*ia + r]);     // (the diagonal block by its lower triangle: what a sharded run exchanges)
+            const bool okr = cc < nrow; const int j = r0 + (okr ? cc : 0);
+            pt_o[g] = okr ? po[j] : 0.0; pt_z[g] = okr ? zp[j] : 0.0;
             const double *row = W.S + (size_t)j*ldS + 6*ia;
 #pragma unroll
-            for (int k = 0; k < 6; k++) acc[k] += row[k]*pv;
+            for (int k = 0; k < 6; k++) st_[g][k] = okr ? row[k] : 0.0;
         }
-        // long-range blocks of this keyframe: lane l < 36 holds entry (l / 6, l % 6) of a block (rows: far_a, columns: far_b)
-        double f0 = 0.0, f1 = 0.0;
-        const int e0 = L.far_off[a], e1 = L.far_off[a + 1], fr = lane < 36 ? lane/6 : 0, fc = lane < 36 ? lane % 6 : 0;
-        for (int e = e0; e < e1; e++) {
-            const int ent = L.far_ent[e], fid = ent >> 1, side = ent & 1;
-            const int io = W.fidx[side ? L.far_a[fid] : L.far_b[fid]];
-            if (io < 0) continue;
-            if (lane < 36) { const double v = W.Sfar[(size_t)fid*36 + lane];
-                if (!side) f0 += v*pnew(6*io + fc); else f1 += v*pnew(6*io + fr); }
+        // the long-range blocks of this keyframe, ten at a time: lane (slot, r) holds row r of q's contribution of block `slot`
+        const int es = lane/6, r6 = lane - 6*es;
+        double fsum = 0.0;
+        for (int eb = e0; eb < e1; eb += 10) {
+            const int e = eb + es; const bool on = es < 10 && e < e1;
+            const int ent = on ? L.far_ent[e] : 0, fid = ent >> 1, side = ent & 1;
+            const int oth = on ? (side ? L.far_a[fid] : L.far_b[fid]) : 0;
+            const int io = on ? W.fidx[oth] : -1;
+            double f = 0.0;
+            if (io >= 0) {                                      // side 0: this keyframe is far_a (rows of the block), side 1: far_b (columns)
+                const double *blk = W.Sfar + (size_t)fid*36 + (side ? r6 : 6*r6); const int stp = side ? 6 : 1;
+                double bv[6], xo[6], xz[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) { bv[c] = blk[c*stp]; xo[c] = po[6*io + c]; xz[c] = zp[6*io + c]; }
+#pragma unroll
+                for (int c = 0; c < 6; c++) f = fma(bv[c], fma(beta, xo[c], zs*xz[c]), f);
+            }
+            double gsum = 0.0;                                  // over the ten slots, in slot order
+#pragma unroll
+            for (int s2 = 0; s2 < 10; s2++) gsum += __shfl(f, 6*s2 + (lane < 6 ? lane : 0), 64);
+            fsum += gsum;
         }
-        double qk = 0.0;
+        double acc[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) acc[r] = 0.0;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const double pv = fma(beta, pl_o[g], zs*pl_z[g]), pt = fma(beta, pt_o[g], zs*pt_z[g]);
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[r] = fma(sl[g][r], pv, acc[r]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc[k] = fma(st_[g][k], pt, acc[k]);
+        }
 #pragma unroll
         for (int k = 0; k < 6; k++) { const double s = wave_sum1(acc[k]); if (lane == k) qk = s; }
-        double g0 = 0.0, g1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; j++) { g0 += __shfl(f0, 6*min(lane, 5) + j, 64); g1 += __shfl(f1, 6*j + min(lane, 5), 64); }
-        if (lane < 6) { qk += g0 + g1; const int i = 6*ia + lane; const double pv = pnew(i); pn[i] = pv; W.pc_q[i] = qk; pq += pv*qk; }
+        if (lane < 6) { qk += fsum; const int i = 6*ia + lane; pvk = fma(beta, po[i], zs*zp[i]); pn[i] = pvk; W.pc_q[i] = qk; }
     }
-    pcg_block_partial<PCG_MT>(pq, W.pc_part + nbp, lds);
+    const double pq = wave_sum1(lane < 6 ? pvk*qk : 0.0);
+    if (lane == 0) lds[wave] = pq;
+    __syncthreads();
+    if (tid == 0) { double s = 0.0; for (int k = 0; k < PCG_MW; k++) s += lds[k]; W.pc_part[pq_off + blockIdx.x] = s; }
 }
 
 // alpha = r.z / p.q; x += alpha p; r -= alpha q; the next preconditioner application's right-hand side rhs = rs * r (the factorisation
 // path solves M y = -g: rs = -1 into W.g; the solve phase takes r itself)
-__global__ __launch_bounds__(PCG_ET) void k_pcg_update(Work W, int it, int nbp, double *rhs, double rs) {
+__global__ __launch_bounds__(PCG_ET) void k_pcg_update(Work W, int it, int nbp, int pq_off, int npq, double *rhs, double rs) {
     __shared__ double lds[4];
     LmState *st = W.st;
     if (st->done || st->step_fail || st->lin_done) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const double pq = pcg_sum_parts(W.pc_part + nbp, nbp, lane);
+    const double pq = pcg_sum_parts(W.pc_part + pq_off, npq, lane);
     if (!(pq > 0.0)) { if (blockIdx.x == 0 && tid == 0) st->step_fail = 1; return; }       // S is positive definite (damped): a breakdown is a failed step
     const double alpha = W.pcs[it & 1].rz/pq;
     const int a = blockIdx.x*32 + tid/6, k = tid % 6;
