@@ -1012,12 +1012,11 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     const int cap = c->dbg.pcg_max_it > 0 ? c->dbg.pcg_max_it : 200;
     const double tol = c->dbg.pcg_tol_exp > 0 ? pow(10.0, -(double)c->dbg.pcg_tol_exp) : 1e-10, tol2 = tol*tol;
     const unsigned int seq = ++c->pcg_seq;
-    // Enlarged conjugate gradients on the solve phase of the band solver (ECG_T columns per application of M^-1): the default where that phase exists
-    // (measured at 5000 keyframes, ms per solve, single vector / enlarged: two loop closures 410 / 303, three closures at 3000 keyframes 231 / 229, 1 % long-range
-    // points 247 / 320: the block iteration pays where the coupling outside the band is a few hundred blocks -- outlying eigenvalues, which it captures 32 at a
-    // time -- and loses where it is spread over the map)
-    const bool closures = D.n_wb > 0 && c->dbg.far_solver != 3;       // (a few dozen keyframes touched: the low-rank correction below, not the block iteration)
-    const bool want_block = c->dbg.pcg_block == 2 || (c->dbg.pcg_block == 0 && D.n_far <= 4096 && !closures);
+    // Enlarged conjugate gradients on the many-column solve phase of the band solver (ECG_T columns per application of M^-1): an option (pcg_block = 2).
+    // It halves the iterations where the coupling outside the band is a few hundred blocks (outlying eigenvalues, captured 32 at a time), but an
+    // application costs 0.8 ms at 5000 keyframes against 0.13 ms of the single-vector solve phase (tsba_bandsv.h) -- measured when the single-vector
+    // iteration still re-ran the factorisation (0.57 ms), ms per solve single / enlarged: two loop closures 410 / 303, 1 % long-range points 247 / 320
+    const bool want_block = c->dbg.pcg_block == 2;
     if (ms_available(c) && want_block && ms_reserve(c, std::max(ECG_T, c->ms_cap)) == TSBA_OK) {
         const int nch = (c->n_kf + ECG_CH - 1)/ECG_CH; const size_t n6 = (size_t)W.N;
         const size_t need = (2*n6*ECG_T + (size_t)nch*2*(ECG_T*ECG_T + 1) + 4*(size_t)ECG_T*ECG_T + 4*ECG_T + 16)*sizeof(double);
