@@ -115,31 +115,63 @@ __global__ __launch_bounds__(256) void k_resize_tab(OrbDev D) {
         yt[y] = make_int4(min(max(sy, 0), S.h - 1), min(max(sy + 1, 0), S.h - 1), b0, b1);
     }
 }
-// grid (x chunks of 128, groups of RS_ROWS bordered rows, frames): a workgroup keeps its column terms in registers for RS_ROWS rows (one
-// row per workgroup meant 165 k two-wave workgroups for level 1 of a 64-frame batch: dispatch-bound); the row terms are uniform.
+// grid (x chunks of 4 x RS_T pixels, groups of RS_ROWS bordered rows, frames).  A thread produces FOUR neighbouring pixels of RS_ROWS rows: away from
+// the reflected columns their source columns are monotone and span at most 8 bytes, so a source row is one (unaligned) 8-byte load instead of
+// eight byte gathers, and the result one dword store instead of four byte stores (the byte version moved 1 byte per lane and instruction: 19 us
+// per level for 64 frames).  The column terms stay in registers for the row group; the row terms are uniform.
 #define RS_ROWS 8
-__global__ __launch_bounds__(128) void k_resize(OrbDev D, int l) {
+#define RS_T 64
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+__global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
     const LevelGeo &G = D.L[l], &S = D.L[l-1];
-    const int x = blockIdx.x*128 + threadIdx.x, y0 = blockIdx.y*RS_ROWS, f = blockIdx.z;
+    const int x = 4*(blockIdx.x*RS_T + threadIdx.x), y0 = blockIdx.y*RS_ROWS, f = blockIdx.z;
     if (x >= G.bw) return;
-    const int2 xt = ((const int2 *)(D.rtab + G.rx_off))[x];
+    const int2 *xtab = (const int2 *)(D.rtab + G.rx_off);
     const int4 *ytab = (const int4 *)(D.rtab + G.ry_off);
-    const int sx = xt.x & 0xffff, sx1 = xt.x >> 16, a0 = xt.y & 0xffff, a1 = xt.y >> 16;
     const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + S.pyr_off + (size_t)EDGE*S.bw + EDGE;
     uint8_t *dst = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + x;
     const int ny = min(RS_ROWS, G.bh - y0);
-    int p00[RS_ROWS], p01[RS_ROWS], p10[RS_ROWS], p11[RS_ROWS]; int4 yt[RS_ROWS];
+    int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
-    for (int r = 0; r < RS_ROWS; r++) {                          // all gathers of the row group in flight together
-        yt[r] = ytab[y0 + min(r, ny - 1)];
-        const uint8_t *r0 = src + yt[r].x*S.bw, *r1 = src + yt[r].y*S.bw;
-        p00[r] = r0[sx]; p01[r] = r0[sx1]; p10[r] = r1[sx]; p11[r] = r1[sx1];
-    }
+    for (int k = 0; k < 4; k++) { const int2 t = xtab[min(x + k, G.bw - 1)]; sx[k] = t.x & 0xffff; sx1[k] = t.x >> 16; a0[k] = t.y & 0xffff; a1[k] = t.y >> 16; }
+    const int base = min(min(sx[0], sx[1]), min(sx[2], sx[3])), top = max(max(sx1[0], sx1[1]), max(sx1[2], sx1[3]));
+    if (top - base <= 7) {                                      // (also across the reflected columns: the four source columns are neighbours in any order)
+        // byte o of the 8 loaded ones: word o >> 2, bits 8 (o & 3) .. -- 32-bit selects and field extracts (variable 64-bit shifts and 32-bit
+        // multiplies run at a quarter of the rate: the operands here are below 2^24, the products exact in 24-bit multiplies)
+        bool h0[4], h1[4]; int s0[4], s1[4];
 #pragma unroll
-    for (int r = 0; r < RS_ROWS; r++) {
-        if (r >= ny) break;
-        const int S0 = p00[r]*a0 + p01[r]*a1, S1 = p10[r]*a0 + p11[r]*a1;
-        dst[(size_t)(y0 + r)*G.bw] = (uint8_t)((((yt[r].z*(S0 >> 4)) >> 16) + ((yt[r].w*(S1 >> 4)) >> 16) + 2) >> 2);
+        for (int k = 0; k < 4; k++) { const int o0 = sx[k] - base, o1 = sx1[k] - base; h0[k] = o0 >= 4; h1[k] = o1 >= 4; s0[k] = 8*(o0 & 3); s1[k] = 8*(o1 & 3); }
+        uint2 q0[RS_ROWS], q1[RS_ROWS]; int4 yt[RS_ROWS];
+#pragma unroll
+        for (int r = 0; r < RS_ROWS; r++) {                      // all loads of the row group in flight together
+            yt[r] = ytab[y0 + min(r, ny - 1)];
+            const uint64_t u0 = *(const u64_unaligned *)(src + (size_t)yt[r].x*S.bw + base), u1 = *(const u64_unaligned *)(src + (size_t)yt[r].y*S.bw + base);
+            q0[r] = make_uint2((uint32_t)u0, (uint32_t)(u0 >> 32)); q1[r] = make_uint2((uint32_t)u1, (uint32_t)(u1 >> 32));
+        }
+#pragma unroll
+        for (int r = 0; r < RS_ROWS; r++) {
+            if (r >= ny) break;
+            uint32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t p00 = ((h0[k] ? q0[r].y : q0[r].x) >> s0[k]) & 255u, p01 = ((h1[k] ? q0[r].y : q0[r].x) >> s1[k]) & 255u;
+                const uint32_t p10 = ((h0[k] ? q1[r].y : q1[r].x) >> s0[k]) & 255u, p11 = ((h1[k] ? q1[r].y : q1[r].x) >> s1[k]) & 255u;
+                const uint32_t S0 = __umul24(p00, a0[k]) + __umul24(p01, a1[k]), S1 = __umul24(p10, a0[k]) + __umul24(p11, a1[k]);
+                o |= ((((__umul24(yt[r].z, S0 >> 4)) >> 16) + ((__umul24(yt[r].w, S1 >> 4)) >> 16) + 2) >> 2) << (8*k);
+            }
+            uint8_t *d = dst + (size_t)(y0 + r)*G.bw;
+            if (x + 3 < G.bw) *(u32_unaligned *)d = o;
+            else for (int k = 0; x + k < G.bw; k++) d[k] = (uint8_t)(o >> (8*k));     // (the last columns of a row)
+        }
+    } else {
+        for (int r = 0; r < ny; r++) {
+            const int4 yt = ytab[y0 + r];
+            const uint8_t *r0 = src + (size_t)yt.x*S.bw, *r1 = src + (size_t)yt.y*S.bw;
+            for (int k = 0; k < 4 && x + k < G.bw; k++) {
+                const int S0 = r0[sx[k]]*a0[k] + r0[sx1[k]]*a1[k], S1 = r1[sx[k]]*a0[k] + r1[sx1[k]]*a1[k];
+                dst[(size_t)(y0 + r)*G.bw + k] = (uint8_t)((((yt.z*(S0 >> 4)) >> 16) + ((yt.w*(S1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
     }
 }
 
@@ -238,7 +270,7 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     // list with every lane busy (the order of the list is irrelevant: scores go to the score map by position)
     for (int k = tid; k < npx; k += 256) { const int yy = (int)(((float)k + 0.5f)*inv_iw), pos = (3 + yy)*TILE_MAX + 3 + k - yy*iw;
         if (fast_maybe(tile + pos, TILE_MAX, D.min_th)) { const int i = atomicAdd(&s_ncand, 1);
-            if (i < FAST_CAND) s_cand[i] = (unsigned short)pos; else score[pos] = (uint8_t)fast_score(tile + pos, TILE_MAX, D.min_th); } }   // (list full: scored in place)
+            if (i < FAST_CAND) s_cand[i] = (unsigned short)pos; else score[pos] = (uint8_t)fast_score(tile + pos, TILE_MAX, D.min_th); } }   // (list full: scored in place; one atomic per wave through a ballot measured slower: 197 vs 185 us)
     __syncthreads();
     for (int k = tid; k < min(s_ncand, FAST_CAND); k += 256) { const int pos = s_cand[k]; score[pos] = (uint8_t)fast_score(tile + pos, TILE_MAX, D.min_th); }
     __syncthreads();
@@ -700,53 +732,68 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
 
 // ---------------------------------------------------------------- Gaussian blur 7x7, Q8 separable, reflect101 at the image edge
 #define BT_W 64
-#define BT_H 16
+#define BT_H 64
+#define BT_R 4                  // output rows per thread of the vertical pass
 __global__ __launch_bounds__(256) void k_blur(OrbDev D) {
     // one launch for all levels (the small levels do not fill the chip on their own): block -> (frame, level, tile)
     const int f = blockIdx.x / D.btiles_per_frame, bt = blockIdx.x % D.btiles_per_frame;
     int l = 0;
     while (l + 1 < D.nlevels && bt >= D.L[l+1].bt0) l++;
     const LevelGeo &G = D.L[l];
-    __shared__ __attribute__((aligned(16))) int rowf[(BT_H + 6)*BT_W];
+    // row sums of the horizontal pass as 16-bit values (256 x 255 at most).  The first version kept them as 32-bit words and had every thread of
+    // the vertical pass read its seven rows for ONE output row: 135 KB of LDS traffic per 1024 pixels -- the kernel ran at the LDS's rate (108 us),
+    // not at memory's.  16-bit sums and four output rows per thread (ten rows read for four written): 4.4 x less.
+    __shared__ __attribute__((aligned(16))) unsigned short rowf[(BT_H + 6)*BT_W];
     const int t = bt - G.bt0, ntx = (G.w + BT_W - 1)/BT_W, tx = t % ntx, ty = t / ntx;
     const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)EDGE*G.bw + EDGE;
     const int x0 = tx*BT_W, y0 = ty*BT_H, tid = threadIdx.x;
+    const int nrow = min(BT_H, G.h - y0) + 6;                   // rows of horizontal sums this tile needs
     int gk[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) gk[i] = D.gk[i];
-    // horizontal pass, four neighbouring outputs per thread from three (unaligned) dword loads.  The level sits in a 19-px REFLECT_101
-    // frame (ComputePyramid's copyMakeBorder) -- the blur's own border rule: the 3-px apron is read straight from the frame
-    for (int k = tid; k < (BT_H + 6)*(BT_W/4); k += 256) {
-        const int yy = k / (BT_W/4), xx = 4*(k % (BT_W/4));
-        const int y = min(y0 + yy - 3, G.h + 2), x = x0 + xx;
-        int4 s4 = make_int4(0, 0, 0, 0);
-        if (x < G.w) {
-            const uint8_t *r = src + (ptrdiff_t)y*G.bw + x - 3;         // bytes x-3 .. x+8 (x+6 is the last one used): inside the frame
-            const uint32_t w0 = *(const u32_unaligned *)r, w1 = *(const u32_unaligned *)(r + 4), w2 = *(const u32_unaligned *)(r + 8);
+    // horizontal pass, four neighbouring outputs per thread from three (unaligned) dword loads, two rows per thread in flight.  The level sits in a
+    // 19-px REFLECT_101 frame (ComputePyramid's copyMakeBorder) -- the blur's own border rule: the 3-px apron is read straight from the frame
+    for (int k0 = tid; k0 < nrow*(BT_W/4); k0 += 512) {
+        uint32_t w[2][3]; int yy[2], xx[2]; bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int k = k0 + 256*u; yy[u] = k / (BT_W/4); xx[u] = 4*(k % (BT_W/4)); on[u] = yy[u] < nrow && x0 + xx[u] < G.w;
+            const int y = min(y0 + yy[u] - 3, G.h + 2);
+            const uint8_t *r = src + (ptrdiff_t)y*G.bw + x0 + xx[u] - 3;         // bytes x-3 .. x+8 (x+6 is the last one used): inside the frame
+            w[u][0] = on[u] ? *(const u32_unaligned *)r : 0u; w[u][1] = on[u] ? *(const u32_unaligned *)(r + 4) : 0u; w[u][2] = on[u] ? *(const u32_unaligned *)(r + 8) : 0u; }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (yy[u] >= nrow) continue;
             int p[12];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { p[i] = (w0 >> (8*i)) & 255; p[4 + i] = (w1 >> (8*i)) & 255; p[8 + i] = (w2 >> (8*i)) & 255; }
+            for (int i = 0; i < 4; i++) { p[i] = (w[u][0] >> (8*i)) & 255; p[4 + i] = (w[u][1] >> (8*i)) & 255; p[8 + i] = (w[u][2] >> (8*i)) & 255; }
+            int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-            for (int i = 0; i < 7; i++) { s4.x += gk[i]*p[i]; s4.y += gk[i]*p[i + 1]; s4.z += gk[i]*p[i + 2]; s4.w += gk[i]*p[i + 3]; }
+            for (int i = 0; i < 7; i++) { s0 += __mul24(gk[i], p[i]); s1 += __mul24(gk[i], p[i + 1]); s2 += __mul24(gk[i], p[i + 2]); s3 += __mul24(gk[i], p[i + 3]); }     // (Q8 weights x bytes; v_mul_lo_u32 runs at a quarter of the rate)
+            *(uint2 *)&rowf[yy[u]*BT_W + xx[u]] = make_uint2((uint32_t)s0 | ((uint32_t)s1 << 16), (uint32_t)s2 | ((uint32_t)s3 << 16));
         }
-        *(int4 *)&rowf[yy*BT_W + xx] = s4;
     }
     __syncthreads();
     uint8_t *dst = D.blur + (size_t)f*D.blur_frame + G.blur_off;
-    {   // vertical pass: thread = (row, four neighbouring columns), one dword store where the four columns exist
-        const int yy = tid / (BT_W/4), xx = 4*(tid % (BT_W/4)), x = x0 + xx, y = y0 + yy;
-        if (x < G.w && y < G.h) {
-            int4 q[7];
+    {   // vertical pass: thread = (strip of BT_R rows, four neighbouring columns), one dword store per row where the four columns exist
+        const int ys = BT_R*(tid / (BT_W/4)), xx = 4*(tid % (BT_W/4)), x = x0 + xx;
+        if (x < G.w && y0 + ys < G.h) {
+            uint2 q[BT_R + 6];
 #pragma unroll
-            for (int i = 0; i < 7; i++) q[i] = *(const int4 *)&rowf[(yy + i)*BT_W + xx];
-            int4 s4 = make_int4(0, 0, 0, 0);
+            for (int i = 0; i < BT_R + 6; i++) q[i] = *(const uint2 *)&rowf[min(ys + i, nrow - 1)*BT_W + xx];
 #pragma unroll
-            for (int i = 0; i < 7; i++) { s4.x += gk[i]*q[i].x; s4.y += gk[i]*q[i].y; s4.z += gk[i]*q[i].z; s4.w += gk[i]*q[i].w; }
-            const int v0 = min(max((s4.x + (1 << 15)) >> 16, 0), 255), v1 = min(max((s4.y + (1 << 15)) >> 16, 0), 255);
-            const int v2 = min(max((s4.z + (1 << 15)) >> 16, 0), 255), v3 = min(max((s4.w + (1 << 15)) >> 16, 0), 255);
-            uint8_t *o = dst + (size_t)y*G.w + x;
-            if (x + 3 < G.w) *(u32_unaligned *)o = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
-            else { o[0] = (uint8_t)v0; if (x + 1 < G.w) o[1] = (uint8_t)v1; if (x + 2 < G.w) o[2] = (uint8_t)v2; }
+            for (int r = 0; r < BT_R; r++) {
+                const int y = y0 + ys + r;
+                if (y >= G.h) break;
+                int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) { const uint2 v = q[r + i];
+                    s0 += __mul24(gk[i], (int)(v.x & 0xffffu)); s1 += __mul24(gk[i], (int)(v.x >> 16)); s2 += __mul24(gk[i], (int)(v.y & 0xffffu)); s3 += __mul24(gk[i], (int)(v.y >> 16)); }
+                const int v0 = min(max((s0 + (1 << 15)) >> 16, 0), 255), v1 = min(max((s1 + (1 << 15)) >> 16, 0), 255);
+                const int v2 = min(max((s2 + (1 << 15)) >> 16, 0), 255), v3 = min(max((s3 + (1 << 15)) >> 16, 0), 255);
+                uint8_t *o = dst + (size_t)y*G.w + x;
+                if (x + 3 < G.w) *(u32_unaligned *)o = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+                else { o[0] = (uint8_t)v0; if (x + 1 < G.w) o[1] = (uint8_t)v1; if (x + 2 < G.w) o[2] = (uint8_t)v2; }
+            }
         }
     }
 }
@@ -994,7 +1041,7 @@ int tsorb_run(void *ctx) {
     hipSetDevice(c->device);
     OrbDev &D = c->D;
     hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
-    for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 127)/128, (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(128), 0, c->stream, D, l);
+    for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
     hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
