@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libtsorb.so")
+_LIBPATH = os.environ.get("TSORB_LIB", os.path.join(_HERE, "libtsorb.so"))     # TSORB_LIB: instrumented build for diagnostics
 _lib = None
 
 EXPORTED_SYMBOLS = ["tsorb_create", "tsorb_destroy", "tsorb_last_error", "tsorb_get_levels", "tsorb_get_scale_factors",
