@@ -81,11 +81,17 @@ __global__ __launch_bounds__(128) void k_level0(OrbDev D) {
         for (int r = 0; r < L0_ROWS; r++) v[r] = *(const u32_unaligned *)(src + (size_t)reflect101(y0 + min(r, ny - 1) - EDGE, G.h)*D.stride + (x - EDGE));
 #pragma unroll
         for (int r = 0; r < L0_ROWS; r++) { if (r >= ny) break; *(u32_unaligned *)(dst + (size_t)(y0 + r)*G.bw) = v[r]; }
-    } else {
-        for (int r = 0; r < ny; r++) {
-            const uint8_t *row = src + (size_t)reflect101(y0 + r - EDGE, G.h)*D.stride;
-            for (int i = 0; i < 4 && x + i < G.bw; i++) dst[(size_t)(y0 + r)*G.bw + i] = row[reflect101(x + i - EDGE, G.w)];
-        }
+    } else {                                                    // reflected columns: bytes, but all loads of the row group before the first store (source and
+        int cx[4]; uint32_t v[L0_ROWS];                         // destination may alias for the compiler: loads after a store wait for it -- eight round trips)
+#pragma unroll
+        for (int i = 0; i < 4; i++) cx[i] = reflect101(min(x + i, G.bw - 1) - EDGE, G.w);
+#pragma unroll
+        for (int r = 0; r < L0_ROWS; r++) { const uint8_t *row = src + (size_t)reflect101(y0 + min(r, ny - 1) - EDGE, G.h)*D.stride;
+            v[r] = (uint32_t)row[cx[0]] | ((uint32_t)row[cx[1]] << 8) | ((uint32_t)row[cx[2]] << 16) | ((uint32_t)row[cx[3]] << 24); }
+#pragma unroll
+        for (int r = 0; r < L0_ROWS; r++) { if (r >= ny) break;
+            uint8_t *d = dst + (size_t)(y0 + r)*G.bw;
+            if (x + 3 < G.bw) *(u32_unaligned *)d = v[r]; else for (int i = 0; x + i < G.bw; i++) d[i] = (uint8_t)(v[r] >> (8*i)); }
     }
 }
 // cv::resize(8UC1, INTER_LINEAR) from level l-1 to level l, evaluated at the reflected coordinate for border pixels.
