@@ -55,6 +55,7 @@ struct OrbDev {
     int *selcnt;                           // [n][nlevels]
     int *qfallback;                        // [n][nlevels] 1 = the LDS quadtree could not hold this level (serial kernel takes over)
     uint8_t *seldesc;                      // [n][slots][32]
+    float *selab;                          // [n][slots][2]  cos, sin of the keypoint angle (k_orient; read by k_describe)
     float *out_kp; uint8_t *out_desc; int *out_cnt;
     int umax[16]; int gk[7];
 };
@@ -736,7 +737,23 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 16); m01 += __shfl_xor(m01, o, 16); }
-    if (valid && v == 0) s[3] = fast_atan2f_dev((float)m01, (float)m10);
+    // the steering terms of rBRIEF, (float)cos((double)angle), (float)sin((double)angle): fp64 library code of a few hundred instructions that the
+    // descriptor kernel ran on every lane of every keypoint (32 lanes each: 21 of its 45 us) -- here once per keypoint, sixteen keypoints per wave pass
+    __shared__ float ang[16];
+    const int grp = threadIdx.x >> 4;
+    float angle = 0.f;
+    if (valid && v == 0) { angle = fast_atan2f_dev((float)m01, (float)m10); s[3] = angle; }
+    if (v == 0) ang[grp] = valid ? angle : -1.f;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const float an = ang[threadIdx.x];
+        if (an >= 0.f) {
+            const int g2 = (blockIdx.x*256 >> 4) + threadIdx.x;
+            const float factorPI = (float)(3.14159265358979323846/180.f);
+            const float rad = __fmul_rn(an, factorPI);
+            D.selab[2*(size_t)g2] = (float)cos((double)rad); D.selab[2*(size_t)g2 + 1] = (float)sin((double)rad);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- Gaussian blur 7x7, Q8 separable, reflect101 at the image edge
@@ -816,9 +833,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev D) {
     const LevelGeo &G = D.L[l];
     if ((slot - G.kp0) >= D.selcnt[(size_t)f*D.nlevels + l]) return;
     const float *s = D.sel + ((size_t)f*per + slot)*4;
-    const float factorPI = (float)(3.14159265358979323846/180.f);
-    const float angle = __fmul_rn(s[3], factorPI);
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const float a = D.selab[2*((size_t)f*per + slot)], b = D.selab[2*((size_t)f*per + slot) + 1];      // cos, sin of the angle (k_orient)
     const uint8_t *c = D.blur + (size_t)f*D.blur_frame + G.blur_off + (size_t)(int)rintf(s[1])*G.w + (int)rintf(s[0]);
     const int8_t *pat = d_pattern + 32*lane;
     int val = 0;
@@ -838,20 +853,21 @@ __global__ __launch_bounds__(256) void k_pack(OrbDev D) {
     __shared__ int off[MAXL + 1];
     if (tid == 0) { int o = 0; for (int l = 0; l < D.nlevels; l++) { off[l] = o; o += D.selcnt[(size_t)f*D.nlevels + l]; } off[D.nlevels] = o; D.out_cnt[f] = min(o, D.cap); }
     __syncthreads();
-    for (int l = 0; l < D.nlevels; l++) {
+    // one loop over the frame's keypoints (level by level it was eight rounds of count -> loads -> stores, each waiting for the one before: 20 us)
+    const int total = min(off[D.nlevels], D.cap);
+    for (int o = tid; o < total; o += 256) {
+        int l = 0;
+        while (l + 1 < D.nlevels && o >= off[l + 1]) l++;
         const LevelGeo &G = D.L[l];
-        const int n = D.selcnt[(size_t)f*D.nlevels + l];
-        for (int q = tid; q < n; q += 256) {
-            const int o = off[l] + q; if (o >= D.cap) continue;
-            const float *s = D.sel + ((size_t)f*D.slots_per_frame + G.kp0 + q)*4;
-            float *k = D.out_kp + ((size_t)f*D.cap + o)*6;
-            k[0] = l ? __fmul_rn(s[0], G.sf) : s[0]; k[1] = l ? __fmul_rn(s[1], G.sf) : s[1];
-            k[2] = (float)(int)__fmul_rn((float)PATCH_SIZE, G.sf); k[3] = s[3]; k[4] = s[2]; k[5] = (float)l;
-            const uint32_t *ds = (const uint32_t *)(D.seldesc + ((size_t)f*D.slots_per_frame + G.kp0 + q)*32);
-            uint32_t *dd = (uint32_t *)(D.out_desc + ((size_t)f*D.cap + o)*32);
-#pragma unroll
-            for (int w = 0; w < 8; w++) dd[w] = ds[w];
-        }
+        const int q = o - off[l];
+        const float *s = D.sel + ((size_t)f*D.slots_per_frame + G.kp0 + q)*4;
+        const uint32_t *ds = (const uint32_t *)(D.seldesc + ((size_t)f*D.slots_per_frame + G.kp0 + q)*32);
+        const float4 sv = *(const float4 *)s; const uint4 d0 = ((const uint4 *)ds)[0], d1 = ((const uint4 *)ds)[1];
+        float *k = D.out_kp + ((size_t)f*D.cap + o)*6;
+        k[0] = l ? __fmul_rn(sv.x, G.sf) : sv.x; k[1] = l ? __fmul_rn(sv.y, G.sf) : sv.y;
+        k[2] = (float)(int)__fmul_rn((float)PATCH_SIZE, G.sf); k[3] = sv.w; k[4] = sv.z; k[5] = (float)l;
+        uint2 *dd = (uint2 *)(D.out_desc + ((size_t)f*D.cap + o)*32);            // (the output block is 8-byte aligned for any n x cap)
+        dd[0] = make_uint2(d0.x, d0.y); dd[1] = make_uint2(d0.z, d0.w); dd[2] = make_uint2(d1.x, d1.y); dd[3] = make_uint2(d1.z, d1.w);
     }
 }
 
@@ -1034,7 +1050,7 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     if ((rc = oalloc(c, &D.cand, (size_t)n*c->nlevels*D.cand_cap*3))) return rc;
     if ((rc = oalloc(c, &D.nodes, (size_t)n*c->nlevels*D.node_cap*(sizeof(QNode)/sizeof(int)))) || (rc = oalloc(c, &D.pool, (size_t)n*c->nlevels*D.pool_cap)) ||
         (rc = oalloc(c, &D.snbuf, (size_t)n*c->nlevels*4*D.node_cap))) return rc;
-    if ((rc = oalloc(c, &D.sel, (size_t)n*kp0*4)) || (rc = oalloc(c, &D.selcnt, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.qfallback, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.seldesc, (size_t)n*kp0*32))) return rc;
+    if ((rc = oalloc(c, &D.sel, (size_t)n*kp0*4)) || (rc = oalloc(c, &D.selcnt, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.qfallback, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.seldesc, (size_t)n*kp0*32)) || (rc = oalloc(c, &D.selab, (size_t)n*kp0*2))) return rc;
     {   // the three outputs in one allocation (kp | count | desc): one device-to-host copy per call
         const size_t bkp = sizeof(float)*(size_t)n*cap*6, bcnt = ((sizeof(int)*(size_t)n + 15)/16)*16, bdesc = (size_t)n*cap*32;
         uint8_t *ob; if ((rc = oalloc(c, &ob, bkp + bcnt + bdesc))) return rc;
