@@ -198,7 +198,8 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
     double *stg = ms_smem, *vc = stg + 2*(size_t)SV_K*CS, *xl = vc + 6*(size_t)lmax;     // stg [2][SV_K][CS], vc [6 lmax]: v of the interior's rows with the border part taken off, xl [80]
     const BandpPart PT = bandp_part(nf, B, Pmax, p);
     const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P);
-    if (p >= P || b - a > lmax) return;
+    if (p >= P) return;
+    if (b - a > lmax) { if (tid == 0) W.st->step_fail = 1; return; }       // (cannot happen: sv_lmax bounds what bandp_part produces; a failed step, not a wrong one)
     const int REC = bw*6, rtop = p < P - 1 ? b + B : b;         // pivots rtop - 1 .. a (the separator on the right first: its solution is known)
     const int ptid = tid - 64, pk = ptid & (SV_K - 1), pj = ptid/SV_K, perp = (TB + 22)/2;
     const int nst = rtop - a, nch = (nst + SV_K - 1)/SV_K;

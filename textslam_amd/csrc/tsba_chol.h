@@ -187,6 +187,55 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(Work W, int bw) {
     }
 }
 
+// Forward substitution alone, for another right-hand side on the factor the kernels above left in S (the factorisation carries ITS right-hand side
+// along as an extra row; the low-rank correction of tsba_wb.h applies one k x k factor to several vectors per LM trial): y = L^-1 y in W.Sy, block
+// by block  y_J = W_J y_J (the stored inverse of the diagonal factor),  y_below -= L(below, J) y_J.  One workgroup, the mirror of k_chol_backsub
+// (which follows it unchanged).
+__global__ __launch_bounds__(1024) void k_chol_fwd(Work W, int bw) {
+    LmState *st = W.st;
+    if (st->done || st->step_fail) return;
+    const int n = 6 * *W.nfree;
+    const int tid = threadIdx.x, ld = W.ldS;
+    const double *A = W.S; double *y = W.Sy;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Wt = sm, *ys = sm + CH_NB*(CH_NB + 1), *xs = ys + CH_NB, *part = xs + CH_NB;      // Wt[c][r] = W[r][c]; part [8][96]
+    const int nblk = (n + CH_NB - 1)/CH_NB, Wb = bw + CH_NB - 1;
+    for (int jb = 0; jb < nblk; jb++) {
+        const int j0 = jb*CH_NB, nb = min(CH_NB, n - j0);
+        for (int k = tid; k < nb*nb; k += 1024) {
+            const int c = k / nb, r = k - c*nb;
+            Wt[c*(CH_NB + 1) + r] = r > c ? A[(size_t)(j0 + c)*ld + j0 + r] : (r == c ? W.LDbuf[j0 + r] : 0.0);
+        }
+        if (tid < nb) ys[tid] = y[j0 + tid];
+        __syncthreads();
+        if (tid < 8*CH_NB) {                                    // x[r] = sum_{c <= r} W[r][c] y[c], 8 partial sums per entry
+            const int r = tid >> 3, p = tid & 7;
+            double v = 0.0;
+            if (r < nb) for (int c = p; c <= r; c += 8) v = fma(Wt[c*(CH_NB + 1) + r], ys[c], v);
+            part[p*CH_NB + r] = v;
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < 8; p++) v += part[p*CH_NB + tid];
+            xs[tid] = v; y[j0 + tid] = v;
+        }
+        __syncthreads();
+        // rows below the block: L[i][k] is stored for i - k <= Wb
+        for (int i = j0 + nb + tid; i < min(n, j0 + nb + Wb); i += 1024) {
+            const int c0 = max(0, i - Wb - j0);
+            const double *row = A + (size_t)i*ld + j0;
+            double v0 = 0.0, v1 = 0.0;
+            int c = c0;
+            for (; c + 1 < nb; c += 2) { v0 = fma(row[c], xs[c], v0); v1 = fma(row[c + 1], xs[c + 1], v1); }
+            if (c < nb) v0 = fma(row[c], xs[c], v0);
+            y[i] -= v0 + v1;
+        }
+        __syncthreads();
+    }
+}
+
 // copies g into row n of S (the extra rhs row) -- the LDS solver does this itself
 __global__ void k_chol_rhs(Work W) {
     if (W.st->done) return;

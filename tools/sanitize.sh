@@ -6,10 +6,10 @@
 #      the CPU tests here; with a GPU (argument "gpu") also the GPU parity tests, i.e. real uploads / solves through the instrumented host
 #      code (device code is not instrumented: gfx950 ASan needs xnack, which this pool does not enable);
 #   4. the plan builder's host threads under clang TSan.
-# Usage: bash tools/sanitize.sh [gpu]   -> gpurun_out/r02_sanitizers.log (summary lines "SANITIZE <what>: <result>")
+# Usage: bash tools/sanitize.sh [gpu]   -> gpurun_out/r03_sanitizers.log (summary lines "SANITIZE <what>: <result>")
 set -u
 cd "$(dirname "$0")/.."
-OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/r02_sanitizers.log; : > $LOG
+OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/r03_sanitizers.log; : > $LOG
 GASAN=$(gcc -print-file-name=libasan.so); GUBSAN=$(gcc -print-file-name=libubsan.so)
 CASAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=0:halt_on_error=0
@@ -66,7 +66,7 @@ if [ "${1:-}" = "gpu" ]; then
   # allocation on a node without xnack ("out of memory: allocator is trying to allocate 0x400000 bytes")
   (cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=undefined,bounds -fno-omit-frame-pointer -Wno-unused-variable -o /tmp/libtsba_ubsan.so tsba.hip 2>/dev/null) || say "libtsba UBSan build: FAILED"
   CUBSAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.ubsan_standalone-x86_64.so)
-  TSBA_LIB=/tmp/libtsba_ubsan.so LD_PRELOAD="$CUBSAN" timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_global.py tests/test_gpu_context_reuse.py -m gpu -q -s -p no:cacheprovider > /tmp/san_gpu.log 2>&1
+  TSBA_LIB=/tmp/libtsba_ubsan.so LD_PRELOAD="$CUBSAN" timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_global.py tests/test_gpu_context_reuse.py tests/test_gpu_far.py -m gpu -q -s -p no:cacheprovider > /tmp/san_gpu.log 2>&1
   say "libtsba host code (clang UBSan + bounds), GPU parity tests through the instrumented host side: $(grep -E 'passed|failed' /tmp/san_gpu.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log)"
   grep -B2 -A12 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log | head -60 >> $LOG
 fi
