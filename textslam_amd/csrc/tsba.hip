@@ -43,6 +43,7 @@
 #include "tsba_bandcre.h"
 #include "tsba_bandms.h"
 #include "tsba_bandsv.h"
+#include "tsba_bandmx.h"
 #include "tsba_pcg.h"
 #include "tsba_wb.h"
 #include "tsba_pose.h"
@@ -822,6 +823,9 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_ms_cre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
         CK(hipFuncSetAttribute((const void *)k_ms_cre_root, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
         CK(hipFuncSetAttribute((const void *)k_sv_linv, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
+#define MX_ATTR(SS) CK(hipFuncSetAttribute((const void *)k_mx_cre_fwd<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024)); CK(hipFuncSetAttribute((const void *)k_mx_cre_root<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024)); CK(hipFuncSetAttribute((const void *)k_mx_cre_back<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        MX_ATTR(36) MX_ATTR(42) MX_ATTR(48) MX_ATTR(54) MX_ATTR(60) MX_ATTR(66)
+#undef MX_ATTR
         CK(hipFuncSetAttribute((const void *)k_sv_fwd_int<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_sv_fwd_int<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_sv_back_int<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -945,22 +949,41 @@ static int ms_reserve(Ctx *c, int T) {           // buffers for T columns (kept 
     c->ms_cap = T;
     return TSBA_OK;
 }
-static void launch_ms_solve(Ctx *c) {            // M.R -> M.X
+static void launch_ms_solve(Ctx *c, bool mx = false) {            // M.R -> M.X.  mx: the separators in product form (tsba_bandmx.h) -- c->sv holds the inverse factors of this factorisation
     Work &W = c->W; const MsBuf &M = c->ms;
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6, ncg = (M.T + 63)/64;
     Work &Ws = c->Wsep; Ws.st = W.st;
-    const size_t ldsf = ms_cre_lds_doubles(bwp, 1)*sizeof(double), ldsb = (ms_cre_lds_doubles(bwp, 3) + 8*(size_t)(bwp + 2))*sizeof(double);
+    mx = mx && bwp >= 36 && bwp <= MX_SMAX && bwp % 6 == 0;
+    const size_t ldsf = ms_cre_lds_doubles(bwp, 1)*sizeof(double), ldsb = (ms_cre_lds_doubles(bwp, 3) + 8*(size_t)(bwp + 2))*sizeof(double), ldsx = mx_lds_doubles(bwp)*sizeof(double);
     hipLaunchKernelGGL(k_ms_fwd_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
-    hipLaunchKernelGGL(k_ms_sep_rhs, dim3((P - 1)*B, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
+    hipLaunchKernelGGL(k_ms_sep_rhs, dim3(P - 1, ncg), dim3(64*B), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
     const int mmax = cr_mmax(0, P, 0);
     auto pivots = [&](int h, int &kb) { kb = 0; const int klast = (mmax - 1 - h)/(2*h); return mmax - 1 - h < 0 ? 0 : std::max(0, klast + 1); };
     int htop = 0;
+    const double *Li = c->sv.Li, *Lid = c->sv.Lid;
+    // (the product-form kernels are instantiated per separator size: compile-time loop bounds and LDS offsets)
+#define MX_CASES(CALL) switch (bwp) { case 36: CALL(36) break; case 42: CALL(42) break; case 48: CALL(48) break; case 54: CALL(54) break; case 60: CALL(60) break; case 66: CALL(66) break; default: break; }
     for (int h = 1; h < mmax; h <<= 1) { int kb; const int npiv = pivots(h, kb); if (npiv <= 0) continue;
-        hipLaunchKernelGGL(k_ms_cre_fwd, dim3(npiv, ncg), dim3(MS_CT), ldsf, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); htop = h; }
-    hipLaunchKernelGGL(k_ms_cre_root, dim3(1, ncg), dim3(256), ldsf, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, M);
+        if (mx) {
+#define MX_FWD(SS) hipLaunchKernelGGL(k_mx_cre_fwd<SS>, dim3(npiv, ncg), dim3(MX_T), ldsx, c->stream, W, Ws, bwp, P, h, kb, M, Li, Lid);
+            MX_CASES(MX_FWD)
+#undef MX_FWD
+        } else hipLaunchKernelGGL(k_ms_cre_fwd, dim3(npiv, ncg), dim3(MS_CT), ldsf, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M);
+        htop = h; }
+    if (mx) {
+#define MX_ROOT(SS) hipLaunchKernelGGL(k_mx_cre_root<SS>, dim3(1, ncg), dim3(MX_T), ldsx, c->stream, W, bwp, P, M, Li, Lid);
+        MX_CASES(MX_ROOT)
+#undef MX_ROOT
+    } else hipLaunchKernelGGL(k_ms_cre_root, dim3(1, ncg), dim3(256), ldsf, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, M);
     for (int h = htop; h >= 1; h >>= 1) { int kb; const int npiv = pivots(h, kb);
-        if (npiv > 0) hipLaunchKernelGGL(k_ms_cre_back, dim3(npiv, ncg), dim3(MS_CT), ldsb, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); }
-    hipLaunchKernelGGL(k_ms_back_border, dim3(c->n_kf, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lb, M);
+        if (npiv <= 0) continue;
+        if (mx) {
+#define MX_BACK(SS) hipLaunchKernelGGL(k_mx_cre_back<SS>, dim3(npiv, ncg), dim3(MX_T), ldsx, c->stream, W, Ws, bwp, P, h, kb, M, Li);
+            MX_CASES(MX_BACK)
+#undef MX_BACK
+        } else hipLaunchKernelGGL(k_ms_cre_back, dim3(npiv, ncg), dim3(MS_CT), ldsb, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); }
+#undef MX_CASES
+    hipLaunchKernelGGL(k_ms_back_border, dim3(P, ncg), dim3(BB_T), 0, c->stream, W, bwp, P, (const double *)c->Lb, M);
     hipLaunchKernelGGL(k_ms_back_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
 }
 
@@ -1016,6 +1039,9 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     const int cap = c->dbg.pcg_max_it > 0 ? c->dbg.pcg_max_it : 200;
     const double tol = c->dbg.pcg_tol_exp > 0 ? pow(10.0, -(double)c->dbg.pcg_tol_exp) : 1e-10, tol2 = tol*tol;
     const unsigned int seq = ++c->pcg_seq;
+    // the inverse factors of the separators (k_sv_linv), once per factorisation: the single-vector solve phase and the product form of the many-column one use them
+    const bool svok = ms_available(c) && c->dbg.pcg_refactor != 1 && sv_reserve(c) == TSBA_OK;
+    if (svok) launch_sv_prepare(c);
     // Enlarged conjugate gradients on the many-column solve phase of the band solver (ECG_T columns per application of M^-1): an option (pcg_block = 2).
     // It halves the iterations where the coupling outside the band is a few hundred blocks (outlying eigenvalues, captured 32 at a time), but an
     // application costs 0.8 ms at 5000 keyframes against 0.13 ms of the single-vector solve phase (tsba_bandsv.h) -- measured when the single-vector
@@ -1042,7 +1068,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
                 }
             };
             hipLaunchKernelGGL(k_ecg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, M);
-            launch_ms_solve(c);
+            launch_ms_solve(c, svok);
             hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)M.X, (const double *)M.X, (const double *)nullptr, (const double *)M.R, (const double *)M.X, E);
             hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 0, 0, seq, tol2);
             hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 2, 1);
@@ -1053,7 +1079,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
                 hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)E.P, (const double *)E.Q, (const double *)M.R, (const double *)nullptr, (const double *)nullptr, E);
                 hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 1, it, seq, tol2);
                 hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 1, 0);
-                launch_ms_solve(c);
+                launch_ms_solve(c, svok);
                 hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)E.Q, (const double *)M.X, (const double *)nullptr, (const double *)M.R, (const double *)M.X, E);
                 hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 2, it, seq, tol2);
                 hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 2, 0);
@@ -1084,7 +1110,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
         const int Tk = c->ms.T; c->ms.T = kk; const MsBuf M = c->ms;
         hipLaunchKernelGGL(k_wb_init, dim3(1), dim3(64), 0, c->stream, Wk.fidx, Wk.nfree, D.n_wb);
         hipLaunchKernelGGL(k_wb_units, dim3(1024), dim3(256), 0, c->stream, W, M, Bw);
-        launch_ms_solve(c);
+        launch_ms_solve(c, svok);
         hipLaunchKernelGGL(k_wb_gather, dim3(std::min(1024, (kk*kk + 255)/256)), dim3(256), 0, c->stream, W, M, Bw);
         hipLaunchKernelGGL(k_wb_EG, dim3(D.n_wb), dim3(256), 0, c->stream, W, D, Bw);
         hipLaunchKernelGGL(k_wb_K2, dim3(std::min(2048, (kk*kk + 255)/256)), dim3(256), 0, c->stream, W, Bw, K2);
@@ -1124,15 +1150,14 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     // (measured at 5000 keyframes, one column: 1.3 ms per application against 0.57 ms for the factorisation re-run -- the solve phase pays for 64
     // columns whether it has them or not; it is the default only for the block variants.  pcg_refactor = 2 selects it for the single-vector iteration)
     const bool ms = !wb && ms_available(c) && c->dbg.pcg_refactor == 2 && ms_reserve(c, std::max(1, c->ms_cap)) == TSBA_OK;
-    const bool sv = !ms && ms_available(c) && c->dbg.pcg_refactor == 0 && sv_reserve(c) == TSBA_OK;      // (the single-vector solve phase, tsba_bandsv.h: the default)
-    if (sv) launch_sv_prepare(c);
+    const bool sv = !ms && svok && c->dbg.pcg_refactor == 0;      // (the single-vector solve phase, tsba_bandsv.h: the default)
     const double *zp = wb ? c->wb.z : W.Sy; double zs = wb ? 1.0 : -1.0;
     int it = 0;
     for (; it < cap; it++) {
         if (finished(it)) break;
         hipLaunchKernelGGL(k_pcg_matvec, dim3(nmv), dim3(64*PCG_MW), 0, c->stream, W, D, it, seq, B, tol2, nbp, pq_off, zp, zs);
         if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->ms.R, 1.0);
-            const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
+            const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c, svok); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
         else if (sv) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->sv.R, 1.0);
             if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
             launch_sv_solve(c, c->sv.R, 1.0); zp = c->sv.X; zs = 1.0;

@@ -91,13 +91,15 @@ __global__ __launch_bounds__(64) void k_ms_fwd_int(Work W, int bw, int Pmax, con
     }
 }
 
-// ---- separator right-hand sides.  grid ((P - 1) B, column groups), one wave: pose block jb of separator s.
-__global__ __launch_bounds__(64) void k_ms_sep_rhs(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M) {
-    const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+// ---- separator right-hand sides.  grid (P - 1, column groups), a wave per pose block of separator s (B waves).  (One-wave workgroups per pose block
+// had every block of a separator fetch the w rows of the whole interior on the right from L2 / HBM: 456 MB per launch at 5000 keyframes and 210 columns;
+// as waves of one workgroup the other B - 1 reads are hits in the CU's cache.)
+__global__ __launch_bounds__(64*MS_BMAX) void k_ms_sep_rhs(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M) {
+    const int lane = threadIdx.x & 63, jb = ms_uni(threadIdx.x >> 6), col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
     { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
     const int B = bw/6, nf = ms_uni(*W.nfree);
-    if (nf <= 0) return;
-    const int s = blockIdx.x/B, jb = blockIdx.x - s*B;
+    if (nf <= 0 || jb >= B) return;
+    const int s = blockIdx.x;
     const BandpPart Pl = bandp_part(nf, B, Pmax, s);
     if (s >= ms_uni(Pl.P) - 1) return;
     const BandpPart Pr = bandp_part(nf, B, Pmax, s + 1);
@@ -310,51 +312,59 @@ __global__ __launch_bounds__(MS_CT) void k_ms_cre_back(Work W, Work Ws, int bw, 
     if (on) for (int r = 0; r < s; r++) M.Xs[((size_t)i*s + r)*T + cc_] = v[r*64 + lane];
 }
 
-// ---- interiors: v_q -= Lb_q^T x_left for every column block (no chain).  grid (free pose blocks, column groups), one wave.  Also the
-// separators' solutions into their rows of X.
-__global__ __launch_bounds__(64) void k_ms_back_border(Work W, int bw, int Pmax, const double *__restrict__ Lb, MsBuf M) {
-    const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
+// ---- interiors: v_q -= Lb_q^T x_left for every column block (no chain).  grid (Pmax, column groups), four waves: a lane keeps the solution of the
+// separator on the left (bw values of its column) in registers, wave w corrects the blocks a + w, a + w + 4, ... of the interior, their coefficient
+// records through LDS a block ahead.  (A workgroup per pose block re-read that solution for every block: 614 MB per launch at 5000 keyframes.)
+#define BB_T 256
+__global__ __launch_bounds__(BB_T) void k_ms_back_border(Work W, int bw, int Pmax, const double *__restrict__ Lb, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double cfs[BB_T/64][6*CR_SMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6), col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
     { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
-    const int B = bw/6, nf = ms_uni(*W.nfree), q = blockIdx.x;
-    if (q >= nf) return;
-    const BandpPart P0 = bandp_part(nf, B, Pmax, 0);
-    const int P = ms_uni(P0.P), REC = bw*6;
-    // the interior (or separator) of column block q: interiors have (almost) equal lengths -- walk the table
-    int p = 0; BandpPart PT = P0;
-    { const int tot = nf - (P - 1)*B, len = tot/P; p = min(P - 1, q/(len + B)); PT = bandp_part(nf, B, Pmax, p);
-      while (p > 0 && q < ms_uni(PT.a) - B) { p--; PT = bandp_part(nf, B, Pmax, p); }
-      while (p < P - 1 && q >= ms_uni(PT.b) + B) { p++; PT = bandp_part(nf, B, Pmax, p); } }
-    const int a = ms_uni(PT.a), b = ms_uni(PT.b);
-    if (q >= b) {                                              // a row block of the separator on p's right (label p): its solution
-        if (q < b + B && p < P - 1 && on) {
+    const int B = bw/6, nf = ms_uni(*W.nfree), p = blockIdx.x;
+    if (nf <= 0 || p == 0) return;                             // (the first interior has no separator on its left)
+    const BandpPart PT = bandp_part(nf, B, Pmax, p);
+    const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P), REC = bw*6;
+    if (p >= P) return;
+    double xl[CR_SMAX];
 #pragma unroll
-            for (int k = 0; k < 6; k++) M.X[(size_t)(6*q + k)*T + cc_] = M.Xs[((size_t)p*bw + 6*(q - b) + k)*T + cc_]; }
-        return; }
-    if (q < a) {                                               // (the separator on p's left: label p - 1)
-        if (p > 0 && on) {
+    for (int br = 0; br < CR_SMAX; br++) xl[br] = (on && br < bw) ? M.Xs[((size_t)(p - 1)*bw + br)*T + cc_] : 0.0;
+    constexpr int NC = (6*CR_SMAX + 63)/64;
+    double cl[NC], v6[6];
+    auto fetch = [&](int q) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) M.X[(size_t)(6*q + k)*T + cc_] = M.Xs[((size_t)(p - 1)*bw + 6*(q - (a - B)) + k)*T + cc_]; }
-        return; }
-    if (p == 0) return;                                        // no separator on the left
-    double acc[6];
+        for (int u = 0; u < NC; u++) { const int e = lane + 64*u; cl[u] = (q < b && e < REC) ? Lb[(size_t)q*REC + e] : 0.0; }
 #pragma unroll
-    for (int k = 0; k < 6; k++) acc[k] = on ? M.V[(size_t)(6*q + k)*T + cc_] : 0.0;
-    const double *Lq = Lb + (size_t)q*REC;
-    for (int br = 0; br < bw; br++) {
-        const double xl = on ? M.Xs[((size_t)(p - 1)*bw + br)*T + cc_] : 0.0;
+        for (int k = 0; k < 6; k++) v6[k] = (on && q < b) ? M.V[(size_t)(6*q + k)*T + cc_] : 0.0;
+    };
+    fetch(a + wave);
+    for (int q = a + wave; q < b; q += BB_T/64) {
+        double *cf = cfs[wave];
+        wave_lds_fence();                                       // (the previous block's reads)
 #pragma unroll
-        for (int c = 0; c < 6; c++) acc[c] = fma(-Lq[6*br + c], xl, acc[c]);
+        for (int u = 0; u < NC; u++) { const int e = lane + 64*u; if (e < REC) cf[e] = cl[u]; }
+        double acc[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[k] = v6[k];
+        fetch(q + BB_T/64);
+        wave_lds_fence();
+#pragma unroll
+        for (int br = 0; br < CR_SMAX; br++) {
+            if (br < bw) { const v2d c0 = *(const v2d *)(cf + 6*br), c1 = *(const v2d *)(cf + 6*br + 2), c2 = *(const v2d *)(cf + 6*br + 4);
+                acc[0] = fma(-c0.x, xl[br], acc[0]); acc[1] = fma(-c0.y, xl[br], acc[1]); acc[2] = fma(-c1.x, xl[br], acc[2]);
+                acc[3] = fma(-c1.y, xl[br], acc[3]); acc[4] = fma(-c2.x, xl[br], acc[4]); acc[5] = fma(-c2.y, xl[br], acc[5]); } }
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) M.V[(size_t)(6*q + k)*T + cc_] = acc[k]; }
     }
-    if (on) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) M.V[(size_t)(6*q + k)*T + cc_] = acc[k]; }
 }
 
-// ---- interiors, backward.  grid (Pmax, column groups), one wave; factor data staged a step ahead as in k_ms_fwd_int (the B blocks
-// L(R, q), R = q + 1 .. q + B, sit in B different row records: 36 contiguous doubles each).
+// ---- interiors, backward.  grid (Pmax, column groups), one wave.  Right-looking: once x_R is known, the B blocks before it take L(R, q)^T x_R --
+// the coefficients of a step are ONE row record (B x 36 contiguous doubles, staged a step ahead as in k_ms_fwd_int), the running right-hand sides of the
+// window live in LDS.  (Left-looking -- x_q = v_q - sum_R L(R, q)^T x_R -- gathers its B blocks from B different records: 288 us per launch at 5000
+// keyframes against 77 us of the forward kernel for the same arithmetic.)  The separator on the right comes first: its blocks are pivots whose
+// solution is known.
 __global__ __launch_bounds__(64) void k_ms_back_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double hist[MS_BMAX*6*64];
-    __shared__ __attribute__((aligned(16))) double xsep[MS_BMAX*6*64];
+    __shared__ __attribute__((aligned(16))) double vwin[MS_BMAX*6*64];
     __shared__ __attribute__((aligned(16))) double recb[2][MS_RECMAX + 32];
     const int lane = threadIdx.x, col = 64*blockIdx.y + lane, T = M.T; const bool on = col < T; const int cc_ = on ? col : 0;
     { const LmState *st_ = W.st; if (st_->done | st_->lin_done | st_->step_fail) return; }     // (a converged iterative solve: the launches the host still had in flight)
@@ -363,49 +373,68 @@ __global__ __launch_bounds__(64) void k_ms_back_int(Work W, int bw, int Pmax, co
     const BandpPart PT = bandp_part(nf, B, Pmax, blockIdx.x);
     const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P), p = blockIdx.x;
     if (p >= P) return;
-    const int REC = bw*6, r_hi = p < P - 1 ? b + B : b;
-    if (p < P - 1) for (int r = 0; r < bw; r++) xsep[r*64 + lane] = on ? M.Xs[((size_t)p*bw + r)*T + cc_] : 0.0;      // the separator on the right: its solution
+    const int REC = bw*6, rtop = p < P - 1 ? b + B : b;
     constexpr int NL = (MS_RECMAX + 63)/64;
     double pre[NL], preld, tn[6];
-    auto fetch = [&](int q) {
-        const int nv = 36*(min(q + B, r_hi - 1) - q);
+    auto fetch = [&](int R) {                                   // operands of pivot R: its row record, its diagonal table, the block R - B entering the window (or x of a separator block)
+        const int nv = 36*min(B, R - a);
+        const double *rec = Lrow + (size_t)R*REC;
 #pragma unroll
-        for (int k = 0; k < NL; k++) { const int e = lane + 64*k; pre[k] = e < nv ? Lrow[(size_t)(q + 1 + e/36)*REC + e] : 0.0; }
-        preld = lane < 22 ? W.LDbuf[32*(size_t)q + lane] : 0.0;
+        for (int k = 0; k < NL; k++) { const int e = lane + 64*k; pre[k] = e < nv ? rec[e] : 0.0; }
+        preld = (lane < 22 && R < b) ? W.LDbuf[32*(size_t)R + lane] : 0.0;
+        const int qn = R - B;
 #pragma unroll
-        for (int k = 0; k < 6; k++) tn[k] = on ? M.V[(size_t)(6*q + k)*T + cc_] : 0.0;
+        for (int k = 0; k < 6; k++) tn[k] = (on && qn >= a) ? M.V[(size_t)(6*qn + k)*T + cc_] : 0.0;
     };
-    fetch(b - 1);
-    for (int q = b - 1; q >= a; q--) {
-        double *rb = recb[q & 1];
-        double t[6];
+    // the window before the first pivot: blocks rtop - 1 .. rtop - B (interior blocks: v; separator blocks: x)
+    for (int d = 0; d < B; d++) { const int q = rtop - 1 - d; double v6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) v6[k] = (on && q >= a) ? (q >= b ? M.Xs[((size_t)p*bw + 6*(q - b) + k)*T + cc_] : M.V[(size_t)(6*q + k)*T + cc_]) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) vwin[((q % B + B) % B*6 + k)*64 + lane] = v6[k]; }
+    fetch(rtop - 1);
+    wave_lds_fence();
+    for (int R = rtop - 1; R >= a; R--) {
+        double *rb = recb[R & 1];
 #pragma unroll
         for (int k = 0; k < NL; k++) { const int e = lane + 64*k; if (e < MS_RECMAX) rb[e] = pre[k]; }
         if (lane < 22) rb[MS_RECMAX + lane] = preld;
+        double ent[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) t[k] = tn[k];
-        if (q > a) fetch(q - 1);
+        for (int k = 0; k < 6; k++) ent[k] = tn[k];
+        if (R > a) fetch(R - 1);
         wave_lds_fence();
-        const int Rend = min(q + B, r_hi - 1);
-        for (int R = q + 1; R <= Rend; R++) {
-            const double *Lk = rb + (R - 1 - q)*36;            // L(6 R + ri, 6 q + cc) at [cc*6 + ri]
-            const double *xs = R >= b ? xsep + 6*(R - b)*64 + lane : hist + (R % B)*6*64 + lane;
-            double xr[6];
+        // x_R: the window's values of block R with the diagonal block solved (separator blocks are solutions already: their table is zero)
+        double *wR = vwin + (R % B)*6*64 + lane;
+        double x[6];
 #pragma unroll
-            for (int r = 0; r < 6; r++) xr[r] = xs[r*64];
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-#pragma unroll
-                for (int r = 0; r < 6; r++) t[c] = fma(-Lk[c*6 + r], xr[r], t[c]);
-        }
+        for (int k = 0; k < 6; k++) x[k] = wR[k*64];
         const double *ld = rb + MS_RECMAX;
 #pragma unroll
         for (int c = 4; c >= 0; c--)
 #pragma unroll
-            for (int k = c + 1; k < 6; k++) t[c] = fma(-ld[tri(k - 1) + c], t[k], t[c]);
-        double *hq = hist + (q % B)*6*64 + lane;
+            for (int k = c + 1; k < 6; k++) x[c] = fma(-ld[tri(k - 1) + c], x[k], x[c]);
+        if (on) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) { hq[k*64] = t[k]; if (on) M.X[(size_t)(6*q + k)*T + cc_] = t[k]; }
+            for (int k = 0; k < 6; k++) M.X[(size_t)(6*R + k)*T + cc_] = x[k]; }
+        // its slot goes to the entering block R - B
+#pragma unroll
+        for (int k = 0; k < 6; k++) wR[k*64] = ent[k];
+        // the blocks before it (interior blocks only) take L(R, q)^T x_R
+        const int qlo = max(a, R - B);
+        for (int q = min(R - 1, b - 1); q >= qlo; q--) {
+            const double *Lk = rb + (R - 1 - q)*36;            // L(6 R + r, 6 q + c) at [c*6 + r]
+            double *wq = vwin + (q % B)*6*64 + lane;
+            double t[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) t[c] = wq[c*64];
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int r = 0; r < 6; r++) t[c] = fma(-Lk[c*6 + r], x[r], t[c]);
+#pragma unroll
+            for (int c = 0; c < 6; c++) wq[c*64] = t[c];
+        }
         wave_lds_fence();
     }
 }
