@@ -64,10 +64,11 @@ def test_first_step_against_the_assembled_system(gpu, n_kf, far, closures):
         gpu.debug_set()
 
 
-@pytest.mark.parametrize("n_kf,far,closures", [(600, 0.02, 0), (900, 0.0, 2), (1500, 0.01, 2)])
+@pytest.mark.parametrize("n_kf,far,closures", [(600, 0.02, 0), (900, 0.0, 2), (1500, 0.01, 2), (1500, 0.0, 6)])
 def test_same_trajectory_as_the_direct_solvers(gpu, n_kf, far, closures):
     """The map through the conjugate gradients and through what it replaces (far_solver = 1: the reordered band where reverse Cuthill-McKee
-    finds one, the wide-band Cholesky on the dense matrix otherwise)."""
+    finds one, the wide-band Cholesky on the dense matrix otherwise).  Six closures: more than 64 keyframes touched -- the low-rank correction
+    with k up to 768."""
     P = synth.config_global(n_kf=n_kf, n_pt=20*n_kf, band=8, far_frac=far, closures=closures)
     o = abi.options_global(); o.its[0] = 8
     try:
@@ -76,6 +77,8 @@ def test_same_trajectory_as_the_direct_solvers(gpu, n_kf, far, closures):
         info, st = gpu.solver_info(), gpu.pcg_stats()
         assert info["far_band_blocks"] == 8 and info["far_blocks"] > 0, info
         assert st["systems"] >= rep1["iters"][0] and st["hit_cap"] == 0 and 0 < st["iterations"] and st["max_iterations"] <= 150, st
+        if far == 0.0:                                              # closures only: the low-rank correction makes the band solve (nearly) exact
+            assert st["iterations"] <= 3*st["systems"], st
         gpu.debug_set(far_solver=1)
         G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
         assert gpu.solver_info()["far_band_blocks"] == 0

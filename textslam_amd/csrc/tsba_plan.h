@@ -43,6 +43,7 @@ struct PlanScratch {
     std::vector<int32_t> sc_pair;
     void threads(int T) { if ((int)cs.size() < T) { cs.resize((size_t)T); hist.resize((size_t)T); kc.resize((size_t)T); tlo.resize((size_t)T); thi.resize((size_t)T); } }
 };
+#define WB_MAXKF_PLAN 128                   // keyframes a loop closure's blocks may touch for the low-rank correction (tsba_wb.h: WB_MAXKF)
 struct HostPlan {
     PlanScratch scratch;                        // (kept by recycle())
     int level = 0;
@@ -61,7 +62,7 @@ struct HostPlan {
     int far_B = 0;
     std::vector<int32_t> far_a, far_b;          // [n_far] keyframes of a block of E
     std::vector<int32_t> far_off, far_ent;      // per keyframe: its blocks of E as (index << 1 | 1 if the keyframe is far_b), ascending
-    std::vector<int32_t> wb_kf, wb_idx;         // the keyframes a block of E touches, when they are few (<= 64: loop closures -- the low-rank correction of tsba_wb.h), and every keyframe's index in that list (-1)
+    std::vector<int32_t> wb_kf, wb_idx;         // the keyframes a block of E touches, when they are few (<= WB_MAXKF_PLAN: loop closures -- the low-rank correction of tsba_wb.h), and every keyframe's index in that list (-1)
     std::vector<int32_t> fb_id, fb_pab, fb_pba, fb_pt_off, fb_pt_s1, fb_pt_s2, fb_pt_lm, fb_tx_off, fb_tx_s1, fb_tx_s2, fb_tx_lm;    // fb_id: 0 .. n_far - 1
     int n_far() const { return (int)far_a.size(); }
     // scene candidates (sorted by pair)
@@ -616,7 +617,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 { std::vector<int32_t> cur(P.far_off.begin(), P.far_off.end() - 1);
                   for (int q = 0; q < n_far; q++) { P.far_ent[(size_t)cur[(size_t)P.far_a[(size_t)q]]++] = q << 1; P.far_ent[(size_t)cur[(size_t)P.far_b[(size_t)q]]++] = (q << 1) | 1; } }
                 { int nu = 0; for (int k = 0; k < n_kf; k++) nu += P.far_off[(size_t)k + 1] > P.far_off[(size_t)k];
-                  if (nu > 0 && nu <= 64) { P.wb_idx.assign((size_t)n_kf, -1);
+                  if (nu > 0 && nu <= WB_MAXKF_PLAN) { P.wb_idx.assign((size_t)n_kf, -1);
                       for (int k = 0; k < n_kf; k++) if (P.far_off[(size_t)k + 1] > P.far_off[(size_t)k]) { P.wb_idx[(size_t)k] = (int32_t)P.wb_kf.size(); P.wb_kf.push_back(k); } } }
                 // this rank's slots: cluster of every slot, the band part M rebuilt from the pairs within a cluster, E from the pairs across clusters
                 std::vector<int32_t> cl_pt((size_t)P.n_pslot(), 0), cl_tx((size_t)P.n_tslot(), 0);
@@ -650,7 +651,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             };
             // (large maps: the reordering costs more host time than it can save; loop closures -- few keyframes touched -- are solved directly on the
             // band of the keyframe order, which beats the doubled band of any reordering)
-            if (far_B > 0 && (far_force || n_kf > 2000 || (n_kf >= 600 && far_touched() <= 64))) take_far();
+            if (far_B > 0 && (far_force || n_kf > 2000 || (n_kf >= 600 && far_touched() <= WB_MAXKF_PLAN))) take_far();
             if (!P.ring && !P.far_B) {
             if ((int64_t)n_kf*n_kf <= ((int64_t)1 << 28)) {       // adjacency through a bitmap over pose pairs: set bits come out sorted and distinct
                 std::vector<uint64_t> bm((((size_t)n_kf*n_kf) >> 6) + 1, 0);

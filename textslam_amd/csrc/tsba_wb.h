@@ -11,7 +11,8 @@
 // (optimizer.cc:1727-1765, loopClosing.cc:587-591: GlobalBA after every closure).
 #pragma once
 
-#define WB_MAXKF 64                         // keyframes touched by E for this path (k <= 384)
+#define WB_MAXKF 128                        // keyframes touched by E for this path (k <= 768)
+static_assert(WB_MAXKF == WB_MAXKF_PLAN, "the plan builder (tsba_plan.h) and the kernels must agree on the size of the low-rank part");
 
 struct WbBuf {
     double *Gm, *T1, *xu, *vu, *z;          // [k][k], [k][k], x_U [k], v = E^ x_U [k], z = M_W^-1 r [6 n_kf] (compressed rows)

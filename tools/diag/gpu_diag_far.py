@@ -28,6 +28,8 @@ def mem_used_mb():
 opt = Optimizer(0)
 if os.environ.get("PCG_REFACTOR"):          # 1: the factorisation re-run as preconditioner, 2: the many-column solve phase (default: the single-vector solve phase)
     opt.debug_set(pcg_refactor=int(os.environ["PCG_REFACTOR"])); print("pcg_refactor", os.environ["PCG_REFACTOR"])
+if os.environ.get("FAR_SOLVER"):            # 3: conjugate gradients without the low-rank correction
+    opt.debug_set(far_solver=int(os.environ["FAR_SOLVER"])); print("far_solver", os.environ["FAR_SOLVER"])
 if tol_exp:
     opt.debug_set(pcg_tol_exp=tol_exp); print("pcg tolerance 1e-%d" % tol_exp)
 t = time.time()
