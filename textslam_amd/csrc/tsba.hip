@@ -1177,7 +1177,6 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     struct XT { Ctx *c; size_t x0; ~XT() { c->x_trial = c->x_acc - x0; } } xt{c, c->x_acc};
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
-    int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     // block-sparse S: what no block of the plan covers must read as zero.  The streaming / partitioned band solvers leave S intact and a pass
     // writes the same entries in every trial (the free poses are fixed at its start), so the band is cleared once per pass; the in-place
     // Cholesky of the wide-band path needs it before every assembly -- and so does a sharded run (a rank assembles only its own blocks; the
@@ -1210,7 +1209,6 @@ int tsba_solve(void *ctx, tsba_report *r) {
     hipSetDevice(c->device);
     memset(r, 0, sizeof(*r));
     const tsba_options &o = c->opt;
-    int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     { int rca = set_solver_attrs(c); if (rca) return rca; }
     struct Token { Ctx *c; Token(Ctx *c_) : c(c_) { if (c->lgroup) { c->in_solve = true; c->lgroup->gpu_token.lock(); c->has_token = true; } }
                    ~Token() { if (c->lgroup) { c->in_solve = false; if (c->has_token) { hipStreamSynchronize(c->stream); c->has_token = false; c->lgroup->gpu_token.unlock(); } } } } token(c);

@@ -255,7 +255,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
     double *A = smem;
     double *LD = A + rowoff(Wn + bw + 2) + 16;
     double *scr = LD + SOLVE_LD*(Wn/6);
-    const int REC = bw*6;
     if (tid == 0) fail = 0;
 
     int base = 6*PT.a, n = min(Wn, row_lim - base);
@@ -498,7 +497,7 @@ static size_t cr_pool_blocks(int mmax) { size_t n = (size_t)mmax; for (int hh = 
 __global__ __launch_bounds__(256) void k_bandp_sep(Work W, int bw, int Pmax, const double *Tbuf, const double *part, double *Ssep, int nsep_ld, double *gsep, int *nfree_sep, int blocked) {
     const LmState *st = W.st;
     if (st->done || st->step_fail || st->lin_done) return;
-    const int B = bw/6, nb = bandp_nb(W, B);
+    const int B = bw/6;
     const BandpPart P0 = bandp_part_w(W, B, Pmax, 0);
     const int P = P0.P, nS = bw, nTm = 2*bw;
     if (blockIdx.x == 0 && threadIdx.x == 0) *nfree_sep = (P - 1)*B;

@@ -532,7 +532,6 @@ __global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, Level
         }
     } else if constexpr (TEXT) {
         // ---------------- photometric blocks of one (KF, text) observation: thread = (feature tid / LPF, tap group tid % LPF)
-        const int g = b - nb_sc;
         const int tb = ra.x, i = ra.y, j = ra.z, h = ra.w, slot = rb.x, f0 = rb.y, f1 = rb.z, fg = rb.w;
         const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
         const bool act_g = (!W.filter_good || W.tobs_good[tb]) && !((h < 0) && W.kf_const[i]) && sigma != 0.0;
