@@ -476,6 +476,74 @@ __global__ __launch_bounds__(SV_CT) void k_sv_cre_root(Work W, int bw, int Pmax,
     if (vrow) M.Xs[(size_t)r0*s + tid] = ((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]);
 }
 
+// ---- the top of the tree in one launch: the single pivot of the highest level (i = h: its left neighbour is the root, it has no right one), the root,
+// and the pivot's back substitution -- three dependent launches of ~5 us as one workgroup's work, every operand of the three steps requested up front.
+// (With no pivot at that level, m <= h, this is the root kernel.)
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_top(Work W, Work Ws, int bw, int Pmax, int h, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], red[6*80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), i = h, r0 = 0;
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s;
+    double g0 = vrow ? M.G[(size_t)i*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)i*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)i*s + tid] : 0.0;
+    double g0r = vrow ? M.G[(size_t)r0*s + tid] : 0.0, g1r = vrow ? M.G2[(size_t)r0*s + tid] : 0.0, idr = vrow ? M.Lid[(size_t)r0*s + tid] : 0.0;
+    SvPend pd; sv_pending_load(M, s, i, mmax, tid, vrow, pd);
+    double pr_[8];                                              // the root's pending updates: the pivots 2^l of the levels below h (from the right only)
+#pragma unroll
+    for (int l = 0; l < 8; l++) { const int hp = 1 << l; pr_[l] = (vrow && hp < h && hp < mmax) ? M.Cg[((size_t)hp*2 + 0)*s + tid] : 0.0; sv_pin(pr_[l]); }
+    const int part = tid & 3, rq = tid >> 2, g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    const double *Xa = cr_blk(Ws.S, s, mmax, i, r0);
+    SvRow li, xar, lir; SvCol lcr;
+    sv_row_load(M.Li + ((size_t)i*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
+    sv_row_load(Xa + (size_t)(rq < s ? rq : 0)*s, s, part, rq < s, xar);
+    sv_row_load(M.Li + ((size_t)r0*s + (rq < s ? rq : 0))*s, s, part, rq < s, lir);
+    sv_col_load(M.Li + (size_t)r0*s*s, s, g, con ? r : 0, con, lcr);
+    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(g0r); sv_pin(g1r); sv_pin(idr); sv_pin(pd);
+    sv_pin(li); sv_pin(xar); sv_pin(lir); sv_pin(lcr);
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0;
+    if (m <= 0) return;
+    const bool piv = i < m;                                      // (uniform)
+    auto sum6 = [&](int k) { return ((red[k] + red[80 + k]) + (red[160 + k] + red[240 + k])) + (red[320 + k] + red[400 + k]); };
+    double zi = 0.0;
+    if (piv) {                                                  // forward step of the pivot: w = L^-1 (g - pending), z = D^-1 w, the root's update X_a w
+        if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, g0 + g1);
+        __syncthreads();
+        { const double wv = sv_row_dot(li, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
+        __syncthreads();
+        if (vrow) zi = w[tid]*idv;
+        { const double a = sv_row_dot(xar, w, s, part); if (rq < s && part == 0) cga[rq] = a; }
+        __syncthreads();
+    }
+    // (the operands of the pivot's back substitution are requested here: the registers of its forward step are free, the root's work hides the wait)
+    SvCol ca, lc;
+    sv_col_load(Xa, s, g, con ? r : 0, con && piv, ca);
+    sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con && piv, lc);
+    // the root: its pending updates of the levels below h as the root kernel takes them, the pivot's last
+    if (vrow) { double t = g0r + g1r;
+#pragma unroll
+        for (int l = 0; l < 8; l++) { const int hp = 1 << l; if (hp < h && hp < m) t -= pr_[l]; }
+        if (piv) t -= cga[tid];
+        v[tid] = t; }
+    __syncthreads();
+    { const double wv = sv_row_dot(lir, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
+    __syncthreads();
+    if (vrow) v[tid] = w[tid]*idr;                               // z of the root
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lcr, v, s, g) : 0.0;
+    __syncthreads();
+    if (vrow) { const double xv = sum6(tid); x0[tid] = xv; M.Xs[(size_t)r0*s + tid] = xv; }
+    if (!piv) return;
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(ca, x0, s, g) : 0.0;     // X_a^T x_0
+    __syncthreads();
+    if (vrow) v[tid] = zi - sum6(tid);
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;      // x_i = L^-T u
+    __syncthreads();
+    if (vrow) M.Xs[(size_t)i*s + tid] = sum6(tid);
+}
+
 // ---- cyclic reduction, level h, backward.  grid pivots, SV_CT threads:  x_i = L^-T (z_i - X_a^T x_a - X_c^T x_c)
 __global__ __launch_bounds__(SV_CT) void k_sv_cre_back(Work W, Work Ws, int bw, int Pmax, int h, int kb, MsBuf M) {
     __shared__ __attribute__((aligned(16))) double u[80], xa[80], xc[80], red[6*80];
