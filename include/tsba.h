@@ -279,7 +279,7 @@ typedef struct tsba_debug_options {
     int32_t far_solver;        // maps with long-range coupling (band part + blocks between a landmark's clusters, tsba_pcg.h): 0 by the plan's rule (when no keyframe order brings the envelope within the band solvers' reach), 1 never (reordering / wide-band Cholesky as before), 2 whenever the map is eligible, 3 as 2 without the low-rank correction for loop closures (tsba_wb.h: A/B runs of the plain iterations)
     int32_t pcg_max_it;        // > 0: iteration cap of the conjugate gradients (default 200)
     int32_t pcg_tol_exp;       // > 0: relative tolerance 10^-pcg_tol_exp of the conjugate gradients in the M^-1 norm (default 10)
-    int32_t pcg_refactor;      // preconditioner of the single-vector iteration: 0 the single-vector solve phase (tsba_bandsv.h) where it exists, else the factorisation re-run with the residual as right-hand side; 1: always the re-run; 2: the many-column solve phase with one column
+    int32_t pcg_refactor;      // preconditioner of the single-vector iteration: 0 the single-vector solve phase (tsba_bandsv.h) where it exists, else the factorisation re-run with the residual as right-hand side; 1: always the re-run; 2: the many-column solve phase with one column; 3: as 0 with r.z by its own kernel instead of inside the solve phase (A/B runs)
     int32_t pcg_block;         // 0 / 1: the single-vector iteration, 2: enlarged conjugate gradients (32 columns per preconditioner application, tsba_pcg.h) where the many-column solve phase of the band solver exists
     int32_t reserved[2];
 } tsba_debug_options;

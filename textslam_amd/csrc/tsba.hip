@@ -577,7 +577,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
             c->pcg_parts = (p->n_kf + 31)/32;
             AL(W.Sfar, 36*(size_t)std::max(c->n_far, 1));
             AL(W.pc_x, W.N); AL(W.pc_r, W.N); AL(W.pc_p[0], W.N); AL(W.pc_p[1], W.N); AL(W.pc_q, W.N); AL(W.pc_g0, W.N);
-            AL(W.pc_part, 5*(size_t)c->pcg_parts + 16); AL(W.pcs, 2); AL(W.pc_stat, 4);
+            AL(W.pc_part, 5*(size_t)c->pcg_parts + 16 + 144); AL(W.pcs, 2); AL(W.pc_stat, 4);       // (pc_part: + partial r.z per interior of the solve phase, tsba_bandsv.h)
         }
         c->S_xchg = nullptr; c->xchg_wp = 0;
         if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, ((size_t)W.N + bwmax)*c->xchg_wp); }
@@ -1008,7 +1008,7 @@ static void launch_sv_prepare(Ctx *c) {
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, mmax = cr_mmax(0, P, 0);
     if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(128), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, c->sv);
 }
-static void launch_sv_solve(Ctx *c, const double *r, double rs) {
+static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rdot = nullptr, double *rz_part = nullptr) {
     Work &W = c->W; const MsBuf &M = c->sv;
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6, lmax = sv_lmax(c);
     Work &Ws = c->Wsep; Ws.st = W.st;
@@ -1027,8 +1027,8 @@ static void launch_sv_solve(Ctx *c, const double *r, double rs) {
     else hipLaunchKernelGGL(k_sv_cre_root, dim3(1), dim3(SV_CT), 0, c->stream, W, bwp, P, M);
     for (int h = htop; h >= 1; h >>= 1) { const int npiv = pivots(h);
         if (npiv > 0 && !(fuse_top && h == htop)) hipLaunchKernelGGL(k_sv_cre_back, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
-    if (B <= 10) hipLaunchKernelGGL(k_sv_back_int<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M);
-    else hipLaunchKernelGGL(k_sv_back_int<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M);
+    if (B <= 10) hipLaunchKernelGGL(k_sv_back_int<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
+    else hipLaunchKernelGGL(k_sv_back_int<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
 }
 
 // The reduced system of one LM trial: a direct solve, or -- band + long-range blocks -- conjugate gradients preconditioned with the band
@@ -1044,7 +1044,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     const double tol = c->dbg.pcg_tol_exp > 0 ? pow(10.0, -(double)c->dbg.pcg_tol_exp) : 1e-10, tol2 = tol*tol;
     const unsigned int seq = ++c->pcg_seq;
     // the inverse factors of the separators (k_sv_linv), once per factorisation: the single-vector solve phase and the product form of the many-column one use them
-    const bool svok = ms_available(c) && c->dbg.pcg_refactor != 1 && sv_reserve(c) == TSBA_OK;
+    const bool svok = ms_available(c) && c->dbg.pcg_refactor != 1 && sv_reserve(c) == TSBA_OK;       // (pcg_refactor = 3: as 0 with r.z by its own kernel, for A/B runs)
     if (svok) launch_sv_prepare(c);
     // Enlarged conjugate gradients on the many-column solve phase of the band solver (ECG_T columns per application of M^-1): an option (pcg_block = 2).
     // It halves the iterations where the coupling outside the band is a few hundred blocks (outlying eigenvalues, captured 32 at a time), but an
@@ -1154,23 +1154,26 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     // (measured at 5000 keyframes, one column: 1.3 ms per application against 0.57 ms for the factorisation re-run -- the solve phase pays for 64
     // columns whether it has them or not; it is the default only for the block variants.  pcg_refactor = 2 selects it for the single-vector iteration)
     const bool ms = !wb && ms_available(c) && c->dbg.pcg_refactor == 2 && ms_reserve(c, std::max(1, c->ms_cap)) == TSBA_OK;
-    const bool sv = !ms && svok && c->dbg.pcg_refactor == 0;      // (the single-vector solve phase, tsba_bandsv.h: the default)
+    const bool sv = !ms && svok && (c->dbg.pcg_refactor == 0 || c->dbg.pcg_refactor == 3);      // (the single-vector solve phase, tsba_bandsv.h: the default)
+    const bool fused_dot = sv && !wb && c->band_parts <= 144 && c->dbg.pcg_refactor == 0; const int rz2_off = 5*nbp + 16;
     const double *zp = wb ? c->wb.z : W.Sy; double zs = wb ? 1.0 : -1.0;
     int it = 0;
     for (; it < cap; it++) {
         if (finished(it)) break;
-        hipLaunchKernelGGL(k_pcg_matvec, dim3(nmv), dim3(64*PCG_MW), 0, c->stream, W, D, it, seq, B, tol2, nbp, pq_off, zp, zs);
+        hipLaunchKernelGGL(k_pcg_matvec, dim3(nmv), dim3(64*PCG_MW), 0, c->stream, W, D, it, seq, B, tol2, (it > 0 && fused_dot) ? rz2_off : 0, (it > 0 && fused_dot) ? c->band_parts : nbp, pq_off, zp, zs);
         if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->ms.R, 1.0);
             const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c, svok); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
         else if (sv) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->sv.R, 1.0);
             if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
-            launch_sv_solve(c, c->sv.R, 1.0); zp = c->sv.X; zs = 1.0;
+            if (fused_dot) launch_sv_solve(c, c->sv.R, 1.0, c->sv.R, W.pc_part + rz2_off);      // (r.z comes along: no k_pcg_dot)
+            else launch_sv_solve(c, c->sv.R, 1.0);
+            zp = c->sv.X; zs = 1.0;
             if (wb) { correct(c->sv.X, 1.0); zp = c->wb.z; } }
         else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, W.g, -1.0);
             if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
             launch_solve(c);
             if (wb) { correct(W.Sy, -1.0); zp = c->wb.z; zs = 1.0; } }
-        hipLaunchKernelGGL(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, zp, zs);
+        if (!fused_dot) hipLaunchKernelGGL(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, zp, zs);
     }
     hipLaunchKernelGGL(k_pcg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
 }

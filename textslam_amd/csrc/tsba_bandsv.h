@@ -186,7 +186,7 @@ __global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, c
 // ---- interiors, backward.  grid Pmax, SV_T threads: the border part  v_q -= Lb_q^T x_left  by all threads into LDS (vc), then the chain on wave 0 with the
 // other waves staging.  M.X = the solution (the rows of the separator on the right written along).  lmax: bound of an interior's length (host).
 template <int NREG>
-__global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, int lmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M) {
+__global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, int lmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M, const double *__restrict__ rdot, double *__restrict__ rz_part) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6);
     const int p = blockIdx.x;
@@ -198,10 +198,10 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
     double *stg = ms_smem, *vc = stg + 2*(size_t)SV_K*CS, *xl = vc + 6*(size_t)lmax;     // stg [2][SV_K][CS], vc [6 lmax]: v of the interior's rows with the border part taken off, xl [80]
     const BandpPart PT = bandp_part(nf, B, Pmax, p);
     const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P);
-    if (p >= P) return;
+    if (p >= P) { if (rdot && tid == 0) rz_part[p] = 0.0; return; }
     if (b - a > lmax) { if (tid == 0) W.st->step_fail = 1; return; }       // (cannot happen: sv_lmax bounds what bandp_part produces; a failed step, not a wrong one)
     const int REC = bw*6, rtop = p < P - 1 ? b + B : b;         // pivots rtop - 1 .. a (the separator on the right first: its solution is known)
-    const int ptid = tid - 64, pk = ptid & (SV_K - 1), pj = ptid/SV_K, perp = (TB + 22)/2;
+    const int ptid = tid - 64, pk = ptid & (SV_K - 1), pj = ptid/SV_K, perp = (TB + (rdot ? 28 : 22))/2;
     const int nst = rtop - a, nch = (nst + SV_K - 1)/SV_K;
     SvStage S;
     auto stage_load = [&](int c) {                              // producers: chunk c = the pivots rtop - 1 - c SV_K - pk
@@ -210,7 +210,8 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
 #pragma unroll
         for (int u = 0; u < SV_PU; u++) { const int x = 2*(pj + SV_PT*u); S.v[u] = v2d{0.0, 0.0};
             if (on && x < TB) S.v[u] = *(const v2d *)(LR + x);  // L(R, q), q = R - 1 .. R - B, at [(R - q - 1) 36 + 6 col + row]
-            else if (on && x < TB + 22 && R < b) S.v[u] = *(const v2d *)(ldR + x); }
+            else if (on && x < TB + 22) { if (R < b) S.v[u] = *(const v2d *)(ldR + x); }
+            else if (on && rdot && x < TB + 28) S.v[u] = *(const v2d *)(rdot + 6*(size_t)R + (x - TB - 22)); }     // r of the pivot's rows (for r.z)
     };
     auto stage_store = [&](int c) {
         const int R = rtop - 1 - c*SV_K - pk;
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
             t[g] = (rowok[g] && q >= a) ? (q >= b ? tsep[g] : vc[6*(q - a) + ri[g]]) : 0.0;
             dd[g] = d == 0 ? B : d; }
     }
+    double racc = 0.0;
     for (int c = 0; c < nch; c++) {
         if (wave > 0) { if (c + 1 < nch) { stage_load(c + 1); stage_store(c + 1); } }
         else {
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
                     const int qn = R - B; T.ent[g] = qn >= a ? vc[6*(qn - a) + ri[g]] : 0.0; }       // the block entering the window
 #pragma unroll
                 for (int e = 0; e < 15; e++) T.l[e] = sk[TB + e];
+                T.idl = rdot ? sk[TB + 22 + (lane < 6 ? lane : 0)] : 0.0;      // (r of the pivot's row `lane`)
             };
             auto exec = [&](const SvStep<NREG> &T, int k) {
                 const int R = R0 - k;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
                 if (lane < 6) { double xo = x[0];
 #pragma unroll
                     for (int k2 = 1; k2 < 6; k2++) xo = lane == k2 ? x[k2] : xo;
-                    M.X[6*(size_t)R + lane] = xo; }
+                    M.X[6*(size_t)R + lane] = xo; racc = fma(T.idl, xo, racc); }
 #pragma unroll
                 for (int g = 0; g < NREG; g++) {
                     double tv = (rowok[g] && slot[g] == sR) ? T.ent[g] : t[g];
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
         }
         __syncthreads();
     }
+    if (rdot && wave == 0) { const double sr = wave_sum1(lane < 6 ? racc : 0.0); if (lane == 0) rz_part[p] = sr; }
 }
 
 // ---- the inverse of every separator's unit-lower factor, once per factorisation: M.Li [label][s][s] row-major (zeros above the diagonal), M.Lid [label][s] = 1/d.

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_begin(Work W, const double *zp, 
 // the blocks and the vector there) -- with two keyframes one after the other on a wave and the blocks of a keyframe one after the other on 36 lanes
 // this was 69 us per launch.
 #define PCG_MW 16
-__global__ __launch_bounds__(64*PCG_MW) void k_pcg_matvec(Work W, LevelDev L, int it, unsigned int seq, int B, double tol2, int nbp, int pq_off, const double *zp, double zs) {
+__global__ __launch_bounds__(64*PCG_MW) void k_pcg_matvec(Work W, LevelDev L, int it, unsigned int seq, int B, double tol2, int rz_off, int nrz, int pq_off, const double *zp, double zs) {
     __shared__ double lds[PCG_MW];
     LmState *st = W.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = blockIdx.x*PCG_MW + wave; const bool kf = a < W.n_kf;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64*PCG_MW) void k_pcg_matvec(Work W, LevelDev L, in
     const int flags = st->done | st->step_fail | st->lin_done;
     int ia = kf ? W.fidx[a] : -1; const int e0 = kf ? L.far_off[a] : 0, e1 = kf ? L.far_off[a + 1] : 0;
     if (flags) { if (blockIdx.x == 0 && tid == 0) pcg_publish(W, seq, it, 1); return; }
-    const double rz = pcg_sum_parts(W.pc_part, nbp, lane);
+    const double rz = pcg_sum_parts(W.pc_part + rz_off, nrz, lane);     // (partial r.z: of k_pcg_begin / k_pcg_dot, or of the interiors' kernel of the solve phase)
     PcgState *so = W.pcs + ((it + 1) & 1), *sn = W.pcs + (it & 1);
     const double rz0 = it == 0 ? rz : so->rz0, rz_old = it == 0 ? 1.0 : so->rz;
     if (!(rz == rz)) { if (blockIdx.x == 0 && tid == 0) { st->step_fail = 1; pcg_publish(W, seq, it, 1); } return; }
