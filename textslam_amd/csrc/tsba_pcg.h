@@ -67,18 +67,26 @@ __global__ __launch_bounds__(64*PCG_MW) void k_pcg_matvec(Work W, LevelDev L, in
     __shared__ double lds[PCG_MW];
     LmState *st = W.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = blockIdx.x*PCG_MW + wave; const bool kf = a < W.n_kf;
-    // round 1
+    // round 1: the flags, this keyframe's row and list, the partial sums of r.z and the state of the previous iteration -- requested together (pinned: the
+    // compiler would issue them one decision at a time)
     const int flags = st->done | st->step_fail | st->lin_done;
     int ia = kf ? W.fidx[a] : -1; const int e0 = kf ? L.far_off[a] : 0, e1 = kf ? L.far_off[a + 1] : 0;
-    if (flags) { if (blockIdx.x == 0 && tid == 0) pcg_publish(W, seq, it, 1); return; }
-    const double rz = pcg_sum_parts(W.pc_part + rz_off, nrz, lane);     // (partial r.z: of k_pcg_begin / k_pcg_dot, or of the interiors' kernel of the solve phase)
     PcgState *so = W.pcs + ((it + 1) & 1), *sn = W.pcs + (it & 1);
-    const double rz0 = it == 0 ? rz : so->rz0, rz_old = it == 0 ? 1.0 : so->rz;
+    double pp[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { pp[k] = lane + 64*k < nrz ? W.pc_part[rz_off + lane + 64*k] : 0.0; sv_pin(pp[k]); }
+    double so_rz0 = it == 0 ? 0.0 : so->rz0, so_rz = it == 0 ? 1.0 : so->rz, so_best = it == 0 ? 0.0 : so->best; int so_since = it == 0 ? 0 : so->since;
+    sv_pin(so_rz0); sv_pin(so_rz); sv_pin(so_best); asm volatile("" : "+v"(so_since)); asm volatile("" : "+v"(ia));
+    if (flags) { if (blockIdx.x == 0 && tid == 0) pcg_publish(W, seq, it, 1); return; }
+    double rzs = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+    for (int k = lane + 256; k < nrz; k += 64) rzs += W.pc_part[rz_off + k];       // (more than 256 partial sums: not with today's sizes)
+    const double rz = wave_sum1(rzs);
+    const double rz0 = it == 0 ? rz : so_rz0, rz_old = so_rz;
     if (!(rz == rz)) { if (blockIdx.x == 0 && tid == 0) { st->step_fail = 1; pcg_publish(W, seq, it, 1); } return; }
     // where M is so ill-conditioned that the tolerance lies below the rounding noise of M^-1 r (weakly damped trials of maps with loop closures:
     // the drift modes) r.z stops falling: 40 iterations without a gain of a tenth (r.z of conjugate gradients is not monotone: plateaus of a dozen
     // iterations occur on the way down) end the solve with what it has -- the LM step test judges it
-    const double best_o = it == 0 ? rz : so->best; const int since_o = it == 0 ? 0 : so->since;
+    const double best_o = it == 0 ? rz : so_best; const int since_o = so_since;
     const bool gain = rz < 0.9*best_o; const double best = gain ? rz : best_o; const int since = gain ? 0 : since_o + 1;
     if (!(rz > tol2*rz0) || since >= 40) {                   // converged (every workgroup takes the same decision from the same partials)
         if (blockIdx.x == 0 && tid == 0) { st->lin_done = 1; W.pc_stat[0] += it; W.pc_stat[1] += 1; if (it > W.pc_stat[2]) W.pc_stat[2] = it; pcg_publish(W, seq, it, 1); }
