@@ -248,7 +248,8 @@ int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
 int  tsba_debug_pcg_stats(void *ctx, int32_t out[4]);
 /* Test hook: M X = R for T right-hand sides with the band factor of the last solve / tsba_debug_reduced_system (the solve phase that the
  * iterative and low-rank solvers of maps with long-range coupling run on).  R, X: [6 x free poses][T], row-major. */
-int  tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X);
+int  tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X);   /* T = -1: one column through the single-vector solve phase */
+int  tsba_debug_sv_lmax(int n_kf, int B, int Pmax);                          /* host only: the bound on an interior's length the solve phase sizes its LDS with */
 /* Plane cache of the context (tsba_problem.kf_id): out[0] keyframes whose planes were found on the device, out[1] keyframes copied. */
 int  tsba_debug_img_cache_stats(void *ctx, int64_t out[2]);
 /* The 6x6 blocks of the reduced system outside the band (solver_info [18] of them) as left by tsba_debug_reduced_system / the last solve:

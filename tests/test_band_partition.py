@@ -17,6 +17,7 @@ def lib():
     L.tsba_debug_bandp_part.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]; L.tsba_debug_bandp_part.restype = None
     L.tsba_debug_cr_blk_index.argtypes = [C.c_int, C.c_int, C.c_int]; L.tsba_debug_cr_blk_index.restype = C.c_longlong
     L.tsba_debug_cr_pool_blocks.argtypes = [C.c_int]; L.tsba_debug_cr_pool_blocks.restype = C.c_longlong
+    L.tsba_debug_sv_lmax.argtypes = [C.c_int, C.c_int, C.c_int]; L.tsba_debug_sv_lmax.restype = C.c_int
     return L
 
 
@@ -43,6 +44,20 @@ def test_partition_covers_the_band(lib, nb, B, Pmax):
     assert max(sizes) - min(sizes) <= 1              # balanced: the launch lasts as long as its longest interior
     if P < Pmax:                                     # P shrank: one more interior would have been too short
         assert (nb - P*B)//(P + 1) < 2*B + 2
+
+
+def test_solve_phase_bound_on_an_interiors_length(lib):
+    """The single-vector solve phase (csrc/tsba_bandsv.h) keeps one value per row of an interior in LDS, sized on the host from the number of keyframes
+    and the number of interiors asked for -- while the device partitions the FREE poses, of which there may be fewer, into possibly fewer interiors:
+    no interior of any such partition is longer than the bound."""
+    rng = np.random.default_rng(3)
+    for _ in range(400):
+        B = int(rng.integers(1, 14)); Pmax = int(rng.integers(2, 130)); n_kf = int(rng.integers(2*B + 4, 6000))
+        lmax = lib.tsba_debug_sv_lmax(n_kf, B, Pmax)
+        for nf in {n_kf, max(1, n_kf - 1), max(1, n_kf//2), max(1, int(rng.integers(1, n_kf + 1))), min(n_kf, 3*B + 3)}:
+            P = _part(lib, nf, B, Pmax, 0)[0]
+            longest = max(_part(lib, nf, B, Pmax, p)[2] - _part(lib, nf, B, Pmax, p)[1] for p in range(P))
+            assert longest <= lmax, (n_kf, nf, B, Pmax, P, longest, lmax)
 
 
 @pytest.mark.parametrize("mmax", [1, 2, 3, 4, 5, 7, 8, 20, 31, 63, 95])

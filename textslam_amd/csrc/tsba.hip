@@ -1003,7 +1003,8 @@ static int sv_reserve(Ctx *c) {
 }
 // bound of an interior's length in pose blocks (bandp_part: the device partitions the FREE poses -- at most n_kf -- into at most band_parts interiors of at
 // least 2 B + 2 blocks; where it has to take fewer interiors they stay below twice that)
-static int sv_lmax(const Ctx *c) { const int B = std::max(6, c->cur_bw_rows)/6, P = std::max(1, c->band_parts); return std::max(c->n_kf/P + 2, 5*B + 8); }
+static int sv_lmax_of(int n_kf, int B, int P) { return std::max(n_kf/std::max(1, P) + 2, 5*B + 8); }
+static int sv_lmax(const Ctx *c) { return sv_lmax_of(c->n_kf, std::max(6, c->cur_bw_rows)/6, c->band_parts); }
 static void launch_sv_prepare(Ctx *c) {
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, mmax = cr_mmax(0, P, 0);
     if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(128), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, c->sv);
@@ -1532,6 +1533,7 @@ void tsba_debug_bandp_part_ring(int nb, int B, int Pmax, int p, int *out5) { con
 // ring with a tail: nf free poses, the loop starts at free row row0; out8 = P, a, b, has_left, has_right, G, Pt, label of the left separator
 void tsba_debug_bandp_part_ring2(int nf, int row0, int B, int Pmax, int Gmax, int p, int *out8) { const BandpPart r = bandp_part_ring(nf, row0, B, Pmax, Gmax, p);
     out8[0] = r.P; out8[1] = r.a; out8[2] = r.b; out8[3] = r.has_left; out8[4] = r.has_right; out8[5] = r.G; out8[6] = r.Pt; out8[7] = r.lblL; }
+int tsba_debug_sv_lmax(int n_kf, int B, int Pmax) { return sv_lmax_of(n_kf, B, Pmax); }      // the bound the solve phase sizes its LDS with (tests/test_band_partition.py)
 void tsba_debug_bandp_part(int nb, int B, int Pmax, int p, int *out5) { const BandpPart r = bandp_part(nb, B, Pmax, p); out5[0] = r.P; out5[1] = r.a; out5[2] = r.b; out5[3] = r.has_left; out5[4] = r.has_right; }
 long long tsba_debug_cr_blk_index(int mmax, int br, int bc) { return (long long)cr_blk_index(mmax, br, bc); }
 long long tsba_debug_cr_pool_blocks(int mmax) { return (long long)cr_pool_blocks(mmax); }
