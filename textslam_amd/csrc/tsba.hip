@@ -1007,7 +1007,7 @@ static int sv_lmax_of(int n_kf, int B, int P) { return std::max(n_kf/std::max(1,
 static int sv_lmax(const Ctx *c) { return sv_lmax_of(c->n_kf, std::max(6, c->cur_bw_rows)/6, c->band_parts); }
 static void launch_sv_prepare(Ctx *c) {
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, mmax = cr_mmax(0, P, 0);
-    if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(128), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, c->sv);
+    if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(SV_LT), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, c->sv);
 }
 static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rdot = nullptr, double *rz_part = nullptr) {
     Work &W = c->W; const MsBuf &M = c->sv;

@@ -9,7 +9,7 @@
 //     instructions per pose block.  The chain wave never waits for memory: the other three waves of the workgroup stage what the next SV_K pivots
 //     need in LDS a chunk ahead and do the dense border work (the rows of the separator on the left) on the side.
 //   separators (cyclic reduction, a workgroup per pivot of a level): NO substitution at all -- k_sv_linv inverts every separator's unit-lower
-//     factor once per factorisation (a thread per column), after which a level is three small dense products (L^-1 v, X_a w, X_c w) whose
+//     factor once per factorisation (block recursion, six threads per column), after which a level is three small dense products (L^-1 v, X_a w, X_c w) whose
 //     operands are all requested up front, speculatively, and looked at after a single wait (a round trip to memory costs ~1.5 us; a kernel
 //     that asks for one thing after the other -- flags, number of free poses, record, neighbours, coupling blocks -- pays it six times).
 // Vectors: MsBuf with T = 1 (the right-hand side comes as rs * r[]).  Chain partitions only, cyclic-reduction separator system.
@@ -324,35 +324,52 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
 }
 
 // ---- the inverse of every separator's unit-lower factor, once per factorisation: M.Li [label][s][s] row-major (zeros above the diagonal), M.Lid [label][s] = 1/d.
-// grid labels, 128 threads: the packed record is unpacked into a dense triangle in LDS, then a thread per column j solves L y = e_j.
-static size_t sv_linv_lds_doubles(int s) { return (size_t)s*(s + 1) + (size_t)tri(s) + s; }
-__global__ __launch_bounds__(128) void k_sv_linv(Work W, int bw, int Pmax, const double *__restrict__ fac, MsBuf M) {
+// grid labels, SV_LT threads = six per column (one per row of a pose block).  Block recursion on the packed record (in LDS) with the 6 x 6 inverses
+// of the diagonal blocks that the factorisation already left in the record's table:
+//   Linv(I, I) = inv(l_I),   Linv(I, J) = - inv(l_I) sum_{K = J .. I-1} L(I, K) Linv(K, J)   for the block rows I = 1, 2, ... in turn
+// -- 300 FMAs per thread and two barriers per block row (a thread per column solving L y = e_j row by row: 1800 dependent FMAs, 64 us per launch).
+#define SV_LT 512
+static size_t sv_linv_lds_doubles(int s) { return ((cre_rec_doubles(s) + 8) & ~(size_t)1) + (size_t)s*(s + 1) + 6*(size_t)(s + 2); }
+__global__ __launch_bounds__(SV_LT) void k_sv_linv(Work W, int bw, int Pmax, const double *__restrict__ fac, MsBuf M) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, s = bw, B = s/6, i = blockIdx.x;
     const LmState *st_ = W.st; const int flags = st_->done | st_->step_fail, nf = ms_uni(*W.nfree);
     if (flags) return;
     if (i >= sv_nsep(nf, B, Pmax)) return;
-    double *Ld = ms_smem, *Y = Ld + (size_t)s*(s + 1);          // Ld [s][s + 1]; Y packed by rows: Y(k, j), j <= k, at tri(k) + j
-    const double *rec = fac + (size_t)i*cre_rec_doubles(s), *LDt = rec + rowoff(s);
-    for (int e = tid; e < s*s; e += 128) { const int rr = e/s, k = e - rr*s; double v = 0.0;
-        if (k < rr) v = (k/6 == rr/6) ? LDt[SOLVE_LD*(rr/6) + tri(rr % 6 - 1) + k % 6] : rec[rowoff(rr) + k];
-        Ld[rr*(s + 1) + k] = v; }
-    if (tid < s) M.Lid[(size_t)i*s + tid] = LDt[SOLVE_LD*(tid/6) + LD_ID + tid % 6];
+    const size_t nrec = cre_rec_doubles(s);
+    double *recl = ms_smem, *Y = recl + ((nrec + 8) & ~(size_t)1), *T = Y + (size_t)s*(s + 1);      // packed record | Linv [s][s + 1] | T [6][s + 2]
+    const double *rec = fac + (size_t)i*nrec;
+    for (size_t e = tid; e < nrec; e += SV_LT) recl[e] = rec[e];
     __syncthreads();
-    const int j = tid;
-    double *out = M.Li + (size_t)i*s*s;
-    if (j < s) {
-        for (int rr = 0; rr < j; rr++) out[(size_t)rr*s + j] = 0.0;
-        Y[tri(j) + j] = 1.0; out[(size_t)j*s + j] = 1.0;
-        for (int rr = j + 1; rr < s; rr++) {
-            const double *Lr = Ld + rr*(s + 1);
-            double acc0 = 0.0, acc1 = 0.0; int k = j;
-            for (; k + 1 < rr; k += 2) { acc0 = fma(-Lr[k], Y[tri(k) + j], acc0); acc1 = fma(-Lr[k + 1], Y[tri(k + 1) + j], acc1); }
-            if (k < rr) acc0 = fma(-Lr[k], Y[tri(k) + j], acc0);
-            const double y = acc0 + acc1;
-            Y[tri(rr) + j] = y; out[(size_t)rr*s + j] = y;
+    const double *LDt = recl + rowoff(s);
+    if (tid < s) M.Lid[(size_t)i*s + tid] = LDt[SOLVE_LD*(tid/6) + LD_ID + tid % 6];
+    const int j = tid/6, r = tid - 6*j, J = j/6, q = j - 6*J; const bool on = j < s;
+    // diagonal blocks (and zeros everywhere else of this thread's column)
+    if (on) for (int I = 0; I < B; I++) Y[(size_t)(6*I + r)*(s + 1) + j] = I != J ? 0.0 : (r == q ? 1.0 : (r > q ? LDt[SOLVE_LD*I + LD_M + tri(r - 1) + q] : 0.0));
+    __syncthreads();
+    for (int I = 1; I < B; I++) {
+        const bool act = on && J < I;
+        if (act) {
+            const double *Lr = recl + rowoff(6*I + r);          // row 6 I + r of the packed factor: entries of the blocks K < I
+            double a0 = 0.0, a1 = 0.0;
+            for (int K = J; K < I; K++) {
+                const double *yk = Y + (size_t)(6*K)*(s + 1) + j;
+#pragma unroll
+                for (int c = 0; c < 6; c += 2) { a0 = fma(Lr[6*K + c], yk[(size_t)c*(s + 1)], a0); a1 = fma(Lr[6*K + c + 1], yk[(size_t)(c + 1)*(s + 1)], a1); }
+            }
+            T[r*(s + 2) + j] = a0 + a1;
         }
+        __syncthreads();
+        if (act) {
+            const double *mi = LDt + SOLVE_LD*I + LD_M;
+            double y = T[r*(s + 2) + j];
+            for (int q2 = 0; q2 < r; q2++) y = fma(mi[tri(r - 1) + q2], T[q2*(s + 2) + j], y);
+            Y[(size_t)(6*I + r)*(s + 1) + j] = -y;
+        }
+        __syncthreads();
     }
+    double *out = M.Li + (size_t)i*s*s;
+    for (int e = tid; e < s*s; e += SV_LT) { const int rr = e/s, cc = e - rr*s; out[e] = cc <= rr ? Y[(size_t)rr*(s + 1) + cc] : 0.0; }
 }
 
 // ---- the separator kernels: every operand requested at once, speculatively (every address is inside its allocation whatever the number of
