@@ -182,6 +182,7 @@ __global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, c
     __syncthreads();
     if (tid < bw) M.G2[(size_t)(p - 1)*bw + tid] = (red[tid] + red[96 + tid]) + (red[192 + tid] + red[288 + tid]);
 }
+#undef SVS
 
 // ---- interiors, backward.  grid Pmax, SV_T threads: the border part  v_q -= Lb_q^T x_left  by all threads into LDS (vc), then the chain on wave 0 with the
 // other waves staging.  M.X = the solution (the rows of the separator on the right written along).  lmax: bound of an interior's length (host).
