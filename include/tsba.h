@@ -221,70 +221,8 @@ int  tsba_download(void *ctx, tsba_problem *p);       /* parameters + good flags
 int  tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int level,
                double *resid, double *jac, double *musigma, int64_t *ns, int64_t *nt);
 
-/* Debug aid: first linearisation of pass 0 of the uploaded problem and the damped reduced camera system for
- * `radius`: S [(6 n_kf)^2] (identity rows for constant / absent poses), g [6 n_kf], cost, kf_free [n_kf], dp [6 n_kf]
- * (the pose step S dp = -g).  Any output may be NULL. */
-int  tsba_debug_reduced_system(void *ctx, double radius, double *S, double *g, double *cost, int32_t *kf_free, double *dp);
-
-/* The same for large maps (band storage of the reduced system; the dense copy would be 7.2 GB at 5000 keyframes): n = 6 x free poses,
- * bw = sub-diagonals kept, ab[(i - j)*n + j] = S(i, j) for j <= i <= j + bw (LAPACK lower band, rows of the COMPRESSED free-pose
- * system), g [n], dp [6 n_kf] (by keyframe, 0 for constant poses).  ab / g / dp may be NULL (first call: sizes only). */
-int  tsba_debug_reduced_band(void *ctx, double radius, int32_t *n, int32_t *bw, double *ab, double *g, double *dp);
-/* Row block of every keyframe in the compressed reduced system of the last pass set-up (-1: constant / not participating).  Not
- * monotone in the keyframe index when the plan reordered the keyframes (solver_info [15]). */
-int  tsba_debug_row_of_kf(void *ctx, int32_t *rowblk);
-
-/* Which kernels the uploaded problem runs through, so that a test can assert it exercises the path it means to.  out[16]:
- * [0] reduced system solved in LDS  [1] band storage of S  [2] streaming band solver  [3] interiors P of the partitioned solver
- * [4] separator system by cyclic reduction  [5] band rows  [6] four (target, host) pairs per wave in the linearisation
- * [7] fused pose-only kernel  [8] large-map Schur / pose-sum kernels  [9] world size  [10] rank
- * [11..14] this rank's plan of the first pass's level: (target, host) pairs, S blocks, scene candidates, point slots
- * [15] rows of S in reverse Cuthill-McKee order of the keyframes (wide envelopes: loop closures)
- * [16] (n >= 17) ring-shaped map solved with ghost rows for the first separator (one loop closure between the last and the first keyframes)
- * [17] (n >= 19) long-range coupling: band of the preconditioner in pose blocks (0: direct solve)  [18] 6x6 blocks outside the band */
-int  tsba_debug_solver_info(void *ctx, int32_t *out, int n);
-/* Maps with long-range coupling: the conjugate-gradient solves of the last tsba_solve.  out[0] iterations in total, [1] reduced systems
- * solved (LM trials), [2] most iterations of one system, [3] systems that hit the iteration cap. */
-int  tsba_debug_pcg_stats(void *ctx, int32_t out[4]);
-/* Test hook: M X = R for T right-hand sides with the band factor of the last solve / tsba_debug_reduced_system (the solve phase that the
- * iterative and low-rank solvers of maps with long-range coupling run on).  R, X: [6 x free poses][T], row-major. */
-int  tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X);   /* T = -1: one column through the single-vector solve phase */
-int  tsba_debug_sv_lmax(int n_kf, int B, int Pmax);                          /* host only: the bound on an interior's length the solve phase sizes its LDS with */
-/* Plane cache of the context (tsba_problem.kf_id): out[0] keyframes whose planes were found on the device, out[1] keyframes copied. */
-int  tsba_debug_img_cache_stats(void *ctx, int64_t out[2]);
-/* The 6x6 blocks of the reduced system outside the band (solver_info [18] of them) as left by tsba_debug_reduced_system / the last solve:
- * keyframes a < b of every block and its 36 values, row-major, rows = keyframe a.  Any output may be NULL. */
-int  tsba_debug_far_blocks(void *ctx, int32_t *a, int32_t *b, double *blocks);
-
-/* Average duration (ms) of the linearisation kernel (residual + Jacobian + robust weight + normal-
- * equation accumulation) over n launches on the library's stream, measured with HIP events.
- * Requires an uploaded problem; `level` selects the pass.  Also returns the algorithmic bytes of one launch. */
-int  tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *algo_bytes);
-
-/* Average duration (ms) of the reduced-system solve (every kernel between the Schur complement and the landmark back-substitution)
- * over n repetitions on the S, g left by the last solve / tsba_debug_reduced_system; HIP events on the library's stream. */
-int  tsba_debug_time_solve(void *ctx, int n, double *avg_ms);
-
-/* Test / diagnostics switches of one context (never read from the environment; all zero = production behaviour).  They select
- * between solver paths that are all exact -- none of them changes what is computed, only by which kernels. */
-typedef struct tsba_debug_options {
-    int32_t band_parts;        /* > 0: number of interiors of the partitioned band solver (1 = single-workgroup streaming solver) */
-    int32_t sep_solver;        /* separator system: 0 cost model, 1 sequential streaming solver, 2 block cyclic reduction (one launch per level), 3 cyclic reduction by the pivot / update / back kernels of round 1, 4 as 2 with the separator system assembled by the border / sep kernels instead of the fused one */
-    int32_t no_band_stream;    /* 1: large systems through the wide-band multi-workgroup Cholesky even when the band is narrow */
-    int32_t no_pose_kernel;    /* 1: PoseOptim through the general pipeline instead of the fused pose-only kernel */
-    int32_t no_small_pairs;    /* 1: never put four (target, host) pairs on one wave of the linearisation */
-    int32_t verbose;           /* 1: host-side timing of upload / plan construction on stderr */
-    int32_t no_kf_reorder;     /* 1: keep the rows of S in keyframe order even when the envelope is wide (loop closures) */
-    int32_t no_schur_quad;     /* 1: large maps assemble S with one wave per 6x6 block (k_schur_t<1>) instead of four blocks per wave */
-    int32_t no_ring;           /* 1: a ring-shaped map (one loop closure between the last and the first keyframes) through the reordering path instead of the ghost-row partition */
-    int32_t far_solver;        // maps with long-range coupling (band part + blocks between a landmark's clusters, tsba_pcg.h): 0 by the plan's rule (when no keyframe order brings the envelope within the band solvers' reach), 1 never (reordering / wide-band Cholesky as before), 2 whenever the map is eligible, 3 as 2 without the low-rank correction for loop closures (tsba_wb.h: A/B runs of the plain iterations)
-    int32_t pcg_max_it;        // > 0: iteration cap of the conjugate gradients (default 200)
-    int32_t pcg_tol_exp;       // > 0: relative tolerance 10^-pcg_tol_exp of the conjugate gradients in the M^-1 norm (default 10)
-    int32_t pcg_refactor;      // preconditioner of the single-vector iteration: 0 the single-vector solve phase (tsba_bandsv.h) where it exists, else the factorisation re-run with the residual as right-hand side; 1: always the re-run; 2: the many-column solve phase with one column; 3: as 0 with r.z by its own kernel instead of inside the solve phase (A/B runs)
-    int32_t pcg_block;         // 0 / 1: the single-vector iteration, 2: enlarged conjugate gradients (32 columns per preconditioner application, tsba_pcg.h) where the many-column solve phase of the band solver exists
-    int32_t reserved[2];
-} tsba_debug_options;
-int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
+/* Test hooks that look inside a solve (reduced system, solver-path switches, kernel timing) are declared in tsba_debug.h; nothing of
+ * the reference's surface needs them. */
 
 /* ---- multi-GPU: RCCL communicator for tsba_global_ba (one process per GPU) ---- */
 /* One process per GPU.  Rank 0 calls tsba_comm_unique_id and broadcasts the 128 bytes (e.g. torch.distributed); every rank

@@ -161,6 +161,143 @@ def reduced_system(prob: BAProblem, opt: TsbaOptions, level: int, radius: float)
             "bp": bp[:m], "cost": cost.value}
 
 
+def reduced_blocks(prob: BAProblem, opt: TsbaOptions, level: int, radius: float):
+    """The reduced camera system of the first linearisation as 6x6 blocks (tsba_oracle_reduced_blocks): any map size / co-visibility graph.
+    -> dict(nf, free_idx [n_kf], br, bc (free-pose block indices, br >= bc), val [n][6][6] (rows: pose br), g [6 nf], cost)."""
+    L = lib(); ip = C.POINTER(C.c_int32)
+    L.tsba_oracle_reduced_blocks.argtypes = [C.POINTER(TsbaProblem), C.POINTER(TsbaOptions), C.c_int, C.c_double, ip, ip, ip,
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.tsba_oracle_reduced_blocks.restype = C.c_int
+    s = prob.struct()
+    free = np.zeros(prob.n_kf, np.int32); cost = C.c_double(0)
+    n = L.tsba_oracle_reduced_blocks(C.byref(s), C.byref(opt), level, radius, free.ctypes.data_as(ip), None, None, None, None, None)
+    assert n >= 0, n
+    nf = int((free >= 0).sum())
+    br, bc, val, g = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros((n, 6, 6)), np.zeros(6*nf)
+    n2 = L.tsba_oracle_reduced_blocks(C.byref(s), C.byref(opt), level, radius, free.ctypes.data_as(ip), br.ctypes.data_as(ip), bc.ctypes.data_as(ip),
+                                      _dp(val), _dp(g), C.byref(cost))
+    assert n2 == n, (n, n2)
+    return {"nf": nf, "free_idx": free, "br": br, "bc": bc, "val": val, "g": g, "cost": cost.value}
+
+
+def blocks_to_sparse(n, br, bc, val):
+    """scipy CSC matrix (n x n, both triangles) of a symmetric matrix given by 6x6 blocks of its lower block triangle (diagonal blocks in full)."""
+    import scipy.sparse as sp
+    br = np.asarray(br, np.int64); bc = np.asarray(bc, np.int64); val = np.array(val, np.float64).reshape(-1, 6, 6)
+    dg = br == bc                                                      # diagonal blocks come in full, symmetric up to rounding: take their lower triangle
+    val[dg] = np.tril(val[dg]) + np.transpose(np.tril(val[dg], -1), (0, 2, 1))
+    r = (6*br[:, None, None] + np.arange(6)[None, :, None] + np.zeros((1, 1, 6), np.int64)).ravel()
+    c = (6*bc[:, None, None] + np.arange(6)[None, None, :] + np.zeros((1, 6, 1), np.int64)).ravel()
+    A = sp.coo_matrix((val.ravel(), (r, c)), shape=(n, n)).tocsc()
+    off = br != bc
+    ro = (6*br[off][:, None, None] + np.arange(6)[None, :, None] + np.zeros((1, 1, 6), np.int64)).ravel()
+    co = (6*bc[off][:, None, None] + np.arange(6)[None, None, :] + np.zeros((1, 6, 1), np.int64)).ravel()
+    return (A + sp.coo_matrix((val[off].ravel(), (co, ro)), shape=(n, n)).tocsc()).tocsc()
+
+
+_SOLVER_KEEP = []
+
+
+def set_sparse_solver(fn):
+    """Route the LM loop of solve() through block-sparse normal equations with `fn(A, rhs) -> y` as the linear solver (A: scipy CSC, symmetric
+    positive definite) -- the stand-in for the reference's exact sparse Cholesky on maps that are neither small nor banded.  fn = None: back
+    to the dense / band storage with the built-in Cholesky."""
+    L = lib()
+    CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+    L.tsba_oracle_set_sparse_solver.restype = None
+    if fn is None:
+        L.tsba_oracle_set_sparse_solver.argtypes = [C.c_void_p]
+        L.tsba_oracle_set_sparse_solver(None); _SOLVER_KEEP.clear(); return
+
+    def cb(n, nblk, br, bc, val, rhs, y):
+        try:
+            A = blocks_to_sparse(n, np.ctypeslib.as_array(br, (nblk,)), np.ctypeslib.as_array(bc, (nblk,)), np.ctypeslib.as_array(val, (nblk*36,)))
+            x = np.asarray(fn(A, np.ctypeslib.as_array(rhs, (n,)).copy()), np.float64)
+            if not np.all(np.isfinite(x)):
+                return 1
+            np.ctypeslib.as_array(y, (n,))[:] = x
+            return 0
+        except Exception:
+            import traceback; traceback.print_exc()
+            return 1
+    f = CB(cb); _SOLVER_KEEP[:] = [f]
+    L.tsba_oracle_set_sparse_solver.argtypes = [CB]
+    L.tsba_oracle_set_sparse_solver(f)
+
+
+def sparse_direct_solver(A, rhs):
+    """Exact sparse factorisation (SuperLU, minimum-degree ordering on A + A^T)."""
+    from scipy.sparse.linalg import splu
+    return splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)).solve(rhs)
+
+
+SOLVER_LOG = []          # one entry per linear solve of sparse_solver: ("banded", bandwidth) or ("gmres", iterations, relative residual)
+
+
+def sparse_solver(A, rhs, band_limit=700, tol=1e-13):
+    """The plug for set_sparse_solver on maps of thousands of keyframes: S y = rhs to working accuracy, by whichever exact method is affordable.
+      * maps whose graph has a narrow band under a reverse Cuthill-McKee order (open chains, one or a few loop closures): LAPACK's banded
+        Cholesky on the permuted matrix -- a direct solve;
+      * otherwise (scattered long-range observations: the Cholesky factor of such a graph fills to a dense 30 000 x 30 000 matrix at 5000
+        keyframes): an iterative solve to a relative residual of 1e-13 (below).  Nothing here knows how the product splits the system; the
+        result is checked by its true residual."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    from scipy.linalg import solveh_banded
+    n = A.shape[0]
+
+    def band_of(M, bw):
+        ab = np.zeros((bw + 1, n))
+        for d in range(bw + 1):
+            ab[d, :n - d] = M.diagonal(-d)
+        return ab
+    perm = reverse_cuthill_mckee(A, symmetric_mode=True)
+    Ap = A[perm][:, perm].tocoo()
+    bw = int(np.abs(Ap.row - Ap.col).max()) if Ap.nnz else 0
+    if bw <= band_limit:
+        x = np.zeros(n)
+        x[perm] = solveh_banded(band_of(Ap.tocsc(), bw), rhs[perm], lower=True)
+        SOLVER_LOG.append(("banded", bw))
+        return x
+    # no narrow band under any order: GMRES (full orthogonalisation, restart 250) on A, right-hand side to a relative residual of 1e-13,
+    # preconditioned with a sparse LU of A's own block band in keyframe order -- the band ends where the number of 6x6 blocks per block
+    # distance falls below 1 % of all blocks (the local co-visibility).  The truncated band need not be positive definite (with weak damping
+    # it is not): GMRES does not ask for that.
+    from scipy.sparse.linalg import splu, gmres, LinearOperator
+    C0 = A.tocoo()
+    bd = np.abs(C0.row//6 - C0.col//6)
+    cnt = np.bincount(bd, minlength=41)[:41]/36.0
+    dense = np.nonzero(cnt >= 0.01*(C0.nnz/36.0))[0]
+    B = int(dense.max()) if dense.size else 0
+    inb = bd <= B
+    lu = splu(sp.coo_matrix((C0.data[inb], (C0.row[inb], C0.col[inb])), shape=(n, n)).tocsc(), permc_spec="NATURAL")
+    its = [0]
+
+    def count(_):
+        its[0] += 1
+    x, info = gmres(A, rhs, rtol=tol, atol=0.0, restart=250, maxiter=8, M=LinearOperator((n, n), matvec=lu.solve), callback=count, callback_type="pr_norm")
+    nb = np.linalg.norm(rhs)
+    rel = float(np.linalg.norm(rhs - A @ x)/max(nb, 1e-300))
+    SOLVER_LOG.append(("gmres", its[0], rel))
+    if not rel <= 1e-11:
+        raise np.linalg.LinAlgError("GMRES did not converge: relative residual %g after %d iterations" % (rel, its[0]))
+    return x
+
+
+def solve_traced(prob: BAProblem, opt: TsbaOptions, cap=64):
+    """solve() + the per-trial record of every pass: list over passes of arrays [trials][4] =
+    (candidate cost, model cost change, radius after the decision, 1 accepted / 0 rejected / -1 invalid step / 2 tolerance exit)."""
+    L = lib()
+    L.tsba_oracle_set_trace.argtypes = [C.POINTER(C.c_double), C.c_int]; L.tsba_oracle_set_trace.restype = None
+    buf = np.full((4, cap, 4), np.nan)
+    L.tsba_oracle_set_trace(_dp(buf), cap)
+    try:
+        rep = solve(prob, opt)
+    finally:
+        L.tsba_oracle_set_trace(None, 0)
+    return rep, [buf[k, :min(rep["iters"][k], cap)].copy() for k in range(rep["n_passes"])]
+
+
 def partial_system(prob: BAProblem, opt: TsbaOptions, level: int, radius: float):
     """One rank's (opt.lm_shard of opt.lm_nshard) contribution to S, g, diag(H_pp) before the all-reduce."""
     n6 = 6 * prob.n_kf

@@ -656,10 +656,43 @@ int tsba_oracle_eval(const tsba_problem *p, const tsba_options *o, int level,
 
 /* ------------------------------------------------------------------ normal equations */
 typedef struct { int col; double W[18]; } lm_entry;     /* 6 x d block of J_pose^T J_lm, row-major 6 x 3 */
+/* 6x6 blocks of a symmetric block-sparse matrix (lower triangle incl. the diagonal blocks), found through an open-addressing hash on
+ * (block row, block column): the storage of H_pp / S for maps whose co-visibility graph is neither small nor a band (loop closures,
+ * long-range observations at thousands of keyframes).  Blocks keep the order in which they were first touched. */
+typedef struct { int nb, cap; long long *key; int *slot; int nblk, cblk; int *br, *bc; double *val; } bsp_t;
+static void bsp_init(bsp_t *B, int nb) { memset(B, 0, sizeof(*B)); B->nb = nb; B->cap = 1 << 12; B->key = (long long *)malloc(sizeof(long long)*(size_t)B->cap); B->slot = (int *)malloc(sizeof(int)*(size_t)B->cap);
+    for (int i = 0; i < B->cap; i++) B->key[i] = -1;
+    B->cblk = 1 << 10; B->br = (int *)malloc(sizeof(int)*(size_t)B->cblk); B->bc = (int *)malloc(sizeof(int)*(size_t)B->cblk); B->val = (double *)malloc(sizeof(double)*36*(size_t)B->cblk); }
+static void bsp_free(bsp_t *B) { free(B->key); free(B->slot); free(B->br); free(B->bc); free(B->val); memset(B, 0, sizeof(*B)); }
+static void bsp_rehash(bsp_t *B) {
+    int ncap = B->cap*2; long long *nk = (long long *)malloc(sizeof(long long)*(size_t)ncap); int *ns = (int *)malloc(sizeof(int)*(size_t)ncap);
+    for (int i = 0; i < ncap; i++) nk[i] = -1;
+    for (int i = 0; i < B->cap; i++) if (B->key[i] >= 0) { unsigned long long h = (unsigned long long)B->key[i]*0x9E3779B97F4A7C15ull; int q = (int)(h >> 40) & (ncap - 1);
+        while (nk[q] >= 0) q = (q + 1) & (ncap - 1);
+        nk[q] = B->key[i]; ns[q] = B->slot[i]; }
+    free(B->key); free(B->slot); B->key = nk; B->slot = ns; B->cap = ncap;
+}
+static double *bsp_block(bsp_t *B, int r, int c, int create) {      /* block (r, c), r >= c; NULL if absent and !create */
+    const long long k = (long long)r*B->nb + c; unsigned long long h = (unsigned long long)k*0x9E3779B97F4A7C15ull; int q = (int)(h >> 40) & (B->cap - 1);
+    while (B->key[q] >= 0) { if (B->key[q] == k) return B->val + 36*(size_t)B->slot[q]; q = (q + 1) & (B->cap - 1); }
+    if (!create) return NULL;
+    if (B->nblk == B->cblk) { B->cblk *= 2; B->br = (int *)realloc(B->br, sizeof(int)*(size_t)B->cblk); B->bc = (int *)realloc(B->bc, sizeof(int)*(size_t)B->cblk); B->val = (double *)realloc(B->val, sizeof(double)*36*(size_t)B->cblk); }
+    const int id = B->nblk++; B->br[id] = r; B->bc[id] = c; memset(B->val + 36*(size_t)id, 0, sizeof(double)*36);
+    B->key[q] = k; B->slot[q] = id;
+    if (2*(size_t)B->nblk > (size_t)B->cap) bsp_rehash(B);
+    return B->val + 36*(size_t)id;
+}
+static void bsp_copy(bsp_t *D, const bsp_t *S) {                     /* same blocks, same order */
+    bsp_init(D, S->nb);
+    for (int i = 0; i < S->nblk; i++) memcpy(bsp_block(D, S->br[i], S->bc[i], 1), S->val + 36*(size_t)i, sizeof(double)*36);
+}
+
 typedef struct {
     int nf, nlm;
     int bw;                            /* -1: Hpp dense (6nf)^2; >= 0: lower band, Hpp[a*(bw+1) + (a-c)] = H(a, c) for a-bw <= c <= a
-                                          (maps of thousands of keyframes: the dense matrix would be 7 GB at 5000 keyframes) */
+                                          (maps of thousands of keyframes: the dense matrix would be 7 GB at 5000 keyframes);
+                                          -2: block-sparse (hs): any co-visibility graph, the linear solve is handed to g_sparse_solver */
+    bsp_t hs;
     double *Hpp, *bp;                  /* (6nf)^2 or 6nf x (bw+1), 6nf */
     double *V, *bl; int *dim;          /* per landmark: 3x3, 3, d */
     lm_entry *ent; int *ent_off, *ent_cnt;
@@ -677,16 +710,20 @@ static int g_band_min_nf = 400;
 void tsba_oracle_set_band_threshold(int nf) { g_band_min_nf = nf; }
 
 static inline void hpp_add(neq_t *N, int n6, int r, int c, double v) {
-    if (N->bw < 0) N->Hpp[(size_t)r*n6 + c] += v;
+    if (N->bw == -2) { if (r/6 >= c/6) bsp_block(&N->hs, r/6, c/6, 1)[6*(r % 6) + (c % 6)] += v; }     /* block-sparse: the lower block triangle (diagonal blocks in full) */
+    else if (N->bw < 0) N->Hpp[(size_t)r*n6 + c] += v;
     else if (r >= c) N->Hpp[(size_t)r*(N->bw + 1) + (r - c)] += v;        /* band: the lower triangle only */
 }
-static inline double hpp_diag(const neq_t *N, int n6, int a) { return N->bw < 0 ? N->Hpp[(size_t)a*n6 + a] : N->Hpp[(size_t)a*(N->bw + 1)]; }
+static inline double hpp_diag(const neq_t *N, int n6, int a) {
+    if (N->bw == -2) { const double *b = bsp_block((bsp_t *)&N->hs, a/6, a/6, 0); return b ? b[7*(a % 6)] : 0.0; }
+    return N->bw < 0 ? N->Hpp[(size_t)a*n6 + a] : N->Hpp[(size_t)a*(N->bw + 1)]; }
 
 static void neq_alloc(neq_t *N, const pass_t *P, int band) {
     memset(N, 0, sizeof(*N));
     N->nf = P->nf; N->nlm = P->nlm; int n6 = 6*N->nf;
     N->bw = -1;
-    if (band) {      /* half bandwidth: a landmark couples every pair of its free poses (Cholesky without pivoting keeps the band) */
+    if (band == 2) { N->bw = -2; bsp_init(&N->hs, N->nf); }
+    else if (band) {      /* half bandwidth: a landmark couples every pair of its free poses (Cholesky without pivoting keeps the band) */
         int *lo = (int *)malloc(sizeof(int)*((size_t)N->nlm + 1)), *hi = (int *)malloc(sizeof(int)*((size_t)N->nlm + 1)), bwb = 0;
         for (int i = 0; i < N->nlm; i++) { lo[i] = N->nf; hi[i] = -1; }
         for (int i = 0; i < P->nblk; i++) { const blk_t *b = &P->blk[i];
@@ -699,7 +736,7 @@ static void neq_alloc(neq_t *N, const pass_t *P, int band) {
         free(lo); free(hi);
         N->bw = 6*bwb + 5;
     }
-    N->Hpp = (double *)calloc((N->bw < 0 ? (size_t)n6*n6 : (size_t)n6*(N->bw + 1)) + 1, sizeof(double)); N->bp = (double *)calloc((size_t)n6 + 1, sizeof(double));
+    N->Hpp = (double *)calloc((N->bw == -2 ? 0 : N->bw < 0 ? (size_t)n6*n6 : (size_t)n6*(N->bw + 1)) + 1, sizeof(double)); N->bp = (double *)calloc((size_t)n6 + 1, sizeof(double));
     N->V = (double *)calloc((size_t)9*N->nlm + 1, sizeof(double)); N->bl = (double *)calloc((size_t)3*N->nlm + 1, sizeof(double));
     N->dim = (int *)calloc((size_t)N->nlm + 1, sizeof(int));
     N->ent_off = (int *)calloc((size_t)N->nlm + 1, sizeof(int)); N->ent_cnt = (int *)calloc((size_t)N->nlm + 1, sizeof(int));
@@ -710,7 +747,7 @@ static void neq_alloc(neq_t *N, const pass_t *P, int band) {
     N->ent = (lm_entry *)calloc((size_t)tot + 1, sizeof(lm_entry));
     free(cnt);
 }
-static void neq_free(neq_t *N) { free(N->Hpp); free(N->bp); free(N->V); free(N->bl); free(N->dim); free(N->ent); free(N->ent_off); free(N->ent_cnt); }
+static void neq_free(neq_t *N) { if (N->bw == -2) bsp_free(&N->hs); free(N->Hpp); free(N->bp); free(N->V); free(N->bl); free(N->dim); free(N->ent); free(N->ent_off); free(N->ent_cnt); }
 
 /* shard filter for the multi-GPU restatement: a block belongs to the rank that owns its landmark */
 static int blk_in_shard(const pass_t *P, const blk_t *b) {
@@ -724,7 +761,9 @@ static int blk_in_shard(const pass_t *P, const blk_t *b) {
 /* linearise at (pose,rho,theta): loss-corrected J^T J, J^T r.  Optionally keep corrected (r,J) per block for the model-cost test. */
 static void linearize(const pass_t *P, const double *pose, const double *rho, const double *theta, neq_t *N, double *keep) {
     int n6 = 6*N->nf;
-    memset(N->Hpp, 0, sizeof(double)*(N->bw < 0 ? (size_t)n6*n6 : (size_t)n6*(N->bw + 1))); memset(N->bp, 0, sizeof(double)*(size_t)n6);
+    if (N->bw == -2) memset(N->hs.val, 0, sizeof(double)*36*(size_t)N->hs.nblk);        /* (the blocks of an earlier linearisation stay, as zeros) */
+    else memset(N->Hpp, 0, sizeof(double)*(N->bw < 0 ? (size_t)n6*n6 : (size_t)n6*(N->bw + 1)));
+    memset(N->bp, 0, sizeof(double)*(size_t)n6);
     memset(N->V, 0, sizeof(double)*9*(size_t)N->nlm); memset(N->bl, 0, sizeof(double)*3*(size_t)N->nlm);
     memset(N->ent_cnt, 0, sizeof(int)*(size_t)N->nlm);
     N->cost = 0;
@@ -945,6 +984,74 @@ static int schur_solve_band(const neq_t *N, const double *sp, const double *sl, 
     return rc;
 }
 
+
+/* The same for a block-sparse H_pp (N->bw == -2): S as hashed 6x6 blocks of the lower block triangle, the sums over exactly the terms of the
+ * dense variant in the same order (the blocks agree with the dense S to the last bit), and the linear solve S y = -g handed to
+ * g_sparse_solver -- the reference's SPARSE_NORMAL_CHOLESKY is an exact sparse factorisation (optimizer.cc:1833-1840); the tests plug
+ * scipy's sparse direct solver in here (a converged iterative solve where the factor would fill).  With yp == NULL the blocks are
+ * only exported: S_out takes the hashed store (caller frees with bsp_free), g_out the reduced gradient. */
+typedef int (*tsba_oracle_sparse_solver)(int n, int nblk, const int *br, const int *bc, const double *val, const double *rhs, double *y);
+static tsba_oracle_sparse_solver g_sparse_solver = NULL;
+void tsba_oracle_set_sparse_solver(tsba_oracle_sparse_solver f) { g_sparse_solver = f; }
+
+static int schur_solve_sparse(const neq_t *N, const double *sp, const double *sl, const double *dgp, const double *dgl, double radius,
+                              double *yp, double *yl, bsp_t *S_out, double *g_out) {
+    const int n6 = 6*N->nf;
+    bsp_t S; bsp_copy(&S, &N->hs);
+    double *g = (double *)malloc(sizeof(double)*((size_t)n6 + 1));
+    for (int i = 0; i < S.nblk; i++) { double *v = S.val + 36*(size_t)i; const int r0 = 6*S.br[i], c0 = 6*S.bc[i];
+        for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) v[6*a + c] *= sp[r0 + a]*sp[c0 + c]; }
+    for (int a = 0; a < n6; a++) { bsp_block(&S, a/6, a/6, 1)[7*(a % 6)] += dgp[a]/radius; g[a] = sp[a]*N->bp[a]; }
+    double *Vinv = (double *)malloc(sizeof(double)*(9*(size_t)N->nlm + 1));
+    int rc = 0;
+    for (int li = 0; li < N->nlm && !rc; li++) {
+        int d = N->dim[li]; if (d == 0) continue;
+        double Vs[9] = {0}, bs[3];
+        for (int a = 0; a < d; a++) { for (int c = 0; c < d; c++) Vs[3*a + c] = sl[3*li + a]*sl[3*li + c]*N->V[9*li + 3*a + c]; Vs[3*a + a] += dgl[3*li + a]/radius; bs[a] = sl[3*li + a]*N->bl[3*li + a]; }
+        if (inv_sym(Vs, d, Vinv + 9*li)) { rc = -1; break; }
+        const double *Vi = Vinv + 9*li;
+        const lm_entry *e = N->ent + N->ent_off[li]; int ne = N->ent_cnt[li];
+        for (int i = 0; i < ne; i++) {
+            double WV[18];
+            for (int a = 0; a < 6; a++) for (int c = 0; c < d; c++) { double s = 0; for (int k = 0; k < d; k++) s += sp[6*e[i].col + a]*e[i].W[3*a + k]*sl[3*li + k]*Vi[3*k + c]; WV[3*a + c] = s; }
+            for (int a = 0; a < 6; a++) { double s = 0; for (int c = 0; c < d; c++) s += WV[3*a + c]*bs[c]; g[6*e[i].col + a] -= s; }
+            for (int j = 0; j < ne; j++) { if (e[i].col < e[j].col) continue;
+                double *blk = bsp_block(&S, e[i].col, e[j].col, 1);
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
+                    double s = 0; for (int k = 0; k < d; k++) s += WV[3*a + k]*sp[6*e[j].col + c]*e[j].W[3*c + k]*sl[3*li + k]; blk[6*a + c] -= s; } }
+        }
+    }
+    if (g_out) memcpy(g_out, g, sizeof(double)*(size_t)n6);
+    if (!rc && yp) {
+        if (!g_sparse_solver) rc = -1;
+        else {
+            double *rhs = (double *)malloc(sizeof(double)*((size_t)n6 + 1));
+            for (int a = 0; a < n6; a++) rhs[a] = -g[a];
+            if (n6 > 0 && g_sparse_solver(n6, S.nblk, S.br, S.bc, S.val, rhs, yp)) rc = -1;
+            free(rhs);
+        }
+        if (!rc) for (int li = 0; li < N->nlm; li++) {
+            int d = N->dim[li]; if (d == 0) { yl[3*li] = yl[3*li+1] = yl[3*li+2] = 0; continue; }
+            double rhs[3];
+            for (int a = 0; a < d; a++) rhs[a] = -sl[3*li + a]*N->bl[3*li + a];
+            const lm_entry *e = N->ent + N->ent_off[li];
+            for (int i = 0; i < N->ent_cnt[li]; i++) for (int k = 0; k < d; k++) { double s = 0; for (int a = 0; a < 6; a++) s += sp[6*e[i].col + a]*e[i].W[3*a + k]*yp[6*e[i].col + a]; rhs[k] -= sl[3*li + k]*s; }
+            for (int a = 0; a < d; a++) { double s = 0; for (int c = 0; c < d; c++) s += Vinv[9*li + 3*a + c]*rhs[c]; yl[3*li + a] = s; }
+            for (int a = d; a < 3; a++) yl[3*li + a] = 0;
+        }
+    }
+    if (S_out) *S_out = S; else bsp_free(&S);
+    free(g); free(Vinv);
+    return rc;
+}
+
+/* Per-trial record of the LM loop for the parity tests of long runs (where do two correct implementations part?):
+ * trace[4*k] = candidate cost (NaN: invalid step), [4*k+1] = model cost change, [4*k+2] = radius after the decision,
+ * [4*k+3] = 1 accepted / 0 rejected / -1 invalid step / 2 terminated by a tolerance on this trial.  cap trials per pass, pass-major. */
+static double *g_trace = NULL; static int g_trace_cap = 0;
+void tsba_oracle_set_trace(double *buf, int cap_per_pass) { g_trace = buf; g_trace_cap = cap_per_pass; }
+#define TRACE(pass, it, c, m, r, f) do { if (g_trace && (it) >= 1 && (it) <= g_trace_cap) { double *t_ = g_trace + 4*((size_t)(pass)*g_trace_cap + (it) - 1); t_[0] = (c); t_[1] = (m); t_[2] = (r); t_[3] = (f); } } while (0)
+
 static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* x (+) delta over the reduced program */
@@ -1005,6 +1112,35 @@ int tsba_oracle_reduced_system(const tsba_problem *p, const tsba_options *o, int
     return rc ? TSBA_ERR_NUMERIC : nf;
 }
 
+
+/* The reduced camera system of the first linearisation as 6x6 blocks, for maps where the dense (6 nf)^2 copy is not an option: block q
+ * couples free poses br[q] >= bc[q] (column-block indices as in free_idx), val[36 q ..] row-major with rows = pose br[q]; UNSCALED
+ * coordinates, pose damping for `radius` included, as tsba_oracle_reduced_system.  Call with br == NULL for the number of blocks
+ * (return value); then with buffers of that size.  g [6 nf], cost, free_idx [n_kf] as there. */
+int tsba_oracle_reduced_blocks(const tsba_problem *p, const tsba_options *o, int level, double radius,
+                               int32_t *free_idx, int32_t *br, int32_t *bc, double *val, double *g, double *cost) {
+    if (!p || !o || level < 0 || level >= p->n_levels) return TSBA_ERR_ARG;
+    pass_t P; pass_build(&P, p, o, level);
+    neq_t N; neq_alloc(&N, &P, 2);
+    linearize(&P, p->pose, p->rho, p->theta, &N, NULL);
+    int n6 = 6*N.nf;
+    double *sp = (double *)malloc(sizeof(double)*(n6 + 1)), *dgp = (double *)malloc(sizeof(double)*(n6 + 1));
+    double *sl = (double *)malloc(sizeof(double)*(3*(size_t)N.nlm + 1)), *dgl = (double *)malloc(sizeof(double)*(3*(size_t)N.nlm + 1));
+    jacobi_and_diag(&N, sp, sl, 1, dgp, dgl, o);
+    bsp_t S; double *gs = (double *)malloc(sizeof(double)*(n6 + 1));
+    int rc = schur_solve_sparse(&N, sp, sl, dgp, dgl, radius, NULL, NULL, &S, gs);
+    int nblk = S.nblk;
+    if (br && bc && val) for (int i = 0; i < S.nblk; i++) { br[i] = S.br[i]; bc[i] = S.bc[i];
+        for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) val[36*(size_t)i + 6*a + c] = S.val[36*(size_t)i + 6*a + c]/(sp[6*S.br[i] + a]*sp[6*S.bc[i] + c]); }
+    if (g) for (int a = 0; a < n6; a++) g[a] = gs[a]/sp[a];
+    if (cost) *cost = N.cost;
+    if (free_idx) for (int k = 0; k < p->n_kf; k++) free_idx[k] = P.free_idx[k];
+    bsp_free(&S);
+    free(sp); free(dgp); free(sl); free(dgl); free(gs);
+    neq_free(&N); pass_free(&P);
+    return rc ? TSBA_ERR_NUMERIC : nblk;
+}
+
 /* Multi-GPU restatement: what ONE rank (options.lm_shard of lm_nshard) contributes to the reduced normal equations before the
  * all-reduce: S_part = H_pp,part - sum_{own landmarks} W (V + Lambda_l)^-1 W^T (no pose damping, unscaled pose coordinates),
  * g_part, diag(H_pp,part) and the partial cost.  Summing the parts over the ranks and adding the pose damping
@@ -1053,7 +1189,7 @@ int tsba_oracle_theta_cov(const tsba_problem *p, const tsba_options *o, int leve
 static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_report *rep, int cov_text, double *cov_out, int *cov_rc) {
     int level = o->levels[pass], max_it = o->its[pass];
     pass_t P; pass_build(&P, p, o, level);
-    neq_t N; neq_alloc(&N, &P, P.nf >= g_band_min_nf);
+    neq_t N; neq_alloc(&N, &P, g_sparse_solver ? 2 : P.nf >= g_band_min_nf);
     int n6 = 6*N.nf; size_t nl3 = 3*(size_t)N.nlm;
     size_t npose = 7*(size_t)p->n_kf, nrho = (size_t)p->n_pt, nth = 3*(size_t)p->n_text;
     double *x_pose = (double *)malloc(sizeof(double)*(npose + 1)), *x_rho = (double *)malloc(sizeof(double)*(nrho + 1)), *x_th = (double *)malloc(sizeof(double)*(nth + 1));
@@ -1084,7 +1220,7 @@ static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_repor
         if (radius < o->min_radius) { term = 4; break; }
         it++;
         if (!reuse_diag) jacobi_and_diag(&N, sp, sl, 0, dgp, dgl, o);
-        int rc = N.bw < 0 ? schur_solve(&N, sp, sl, dgp, dgl, radius, yp, yl, NULL, NULL) : schur_solve_band(&N, sp, sl, dgp, dgl, radius, yp, yl);
+        int rc = N.bw == -2 ? schur_solve_sparse(&N, sp, sl, dgp, dgl, radius, yp, yl, NULL, NULL) : N.bw < 0 ? schur_solve(&N, sp, sl, dgp, dgl, radius, yp, yl, NULL, NULL) : schur_solve_band(&N, sp, sl, dgp, dgl, radius, yp, yl);
         double model_change = -1;
         if (!rc) {
             for (int a = 0; a < n6; a++) dp[a] = sp[a]*yp[a];
@@ -1101,8 +1237,8 @@ static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_repor
                     model_change -= jd*(kp[k] + jd/2); } }
         }
         if (rc || !(model_change > 0)) {           /* invalid step: StepIsInvalid() */
-            if (++invalid >= 5) { term = 5; break; }
-            radius *= 0.5; reuse_diag = 1; continue;
+            if (++invalid >= 5) { term = 5; TRACE(pass, it, NAN, model_change, radius, -1.0); break; }
+            radius *= 0.5; reuse_diag = 1; TRACE(pass, it, NAN, model_change, radius, -1.0); continue;
         }
         invalid = 0;
         apply_step(&P, x_pose, x_rho, x_th, dp, dl, c_pose, c_rho, c_th);
@@ -1110,9 +1246,9 @@ static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_repor
         rep->n_resid_evals += nres_blk;
         if (!(c_cost == c_cost)) c_cost = DBL_MAX;
         double step_norm = reduced_norm(&P, x_pose, x_rho, x_th, c_pose, c_rho, c_th);
-        if (step_norm <= o->parameter_tolerance*(x_norm + o->parameter_tolerance)) { term = 2; break; }
+        if (step_norm <= o->parameter_tolerance*(x_norm + o->parameter_tolerance)) { term = 2; TRACE(pass, it, c_cost, model_change, radius, 2.0); break; }
         double cost_change = x_cost - c_cost;
-        if (fabs(cost_change) <= o->function_tolerance*x_cost) { term = 1; break; }
+        if (fabs(cost_change) <= o->function_tolerance*x_cost) { term = 1; TRACE(pass, it, c_cost, model_change, radius, 2.0); break; }
         double rel = cost_change/model_change;
         if (rel > o->min_relative_decrease) {
             memcpy(x_pose, c_pose, sizeof(double)*npose); memcpy(x_rho, c_rho, sizeof(double)*nrho); memcpy(x_th, c_th, sizeof(double)*nth);
@@ -1123,10 +1259,12 @@ static int run_pass(tsba_problem *p, const tsba_options *o, int pass, tsba_repor
             double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
             radius = radius/f; if (radius > o->max_radius) radius = o->max_radius;
             decrease_factor = 2.0; reuse_diag = 0;
+            TRACE(pass, it, c_cost, model_change, radius, 1.0);
             GRAD_MAX(gmax);
             if (gmax <= o->gradient_tolerance) { term = 3; break; }
         } else {
             radius = radius/decrease_factor; decrease_factor *= 2.0; reuse_diag = 1;
+            TRACE(pass, it, c_cost, model_change, radius, 0.0);
         }
     }
 done:

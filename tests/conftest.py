@@ -16,3 +16,22 @@ def oracle_lib():
     import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(scope="session")
+def map_cache():
+    """Synthetic maps of thousands of keyframes take ~10 s to build: the full-size tests of several modules share them (read-only: every
+    solve works on a copy)."""
+    from textslam_amd import synth
+    cache = {}
+
+    def get(**kw):
+        key = tuple(sorted(kw.items()))
+        if key not in cache:
+            text = kw.pop("n_text", 0)
+            if text:
+                cache[key] = synth.make_problem(n_text=text, max_targets=8, text_targets=5, frozen_frac=0.0, rot_deg=0.2, trans_m=0.01, **kw)
+            else:
+                cache[key] = synth.config_global(**kw)
+        return cache[key]
+    return get

@@ -27,9 +27,15 @@ def test_exports_every_declared_symbol(lib):
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/tsba.h but not exported"
+    # the drop-in header carries the reference's surface only: the test / diagnostics hooks live in tsba_debug.h
+    assert not [n for n in names if n.startswith(("tsba_debug_", "tsba_time_"))]
+    dbg = sorted(set(re.findall(r"\b(tsba_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "tsba_debug.h")).read())))
+    assert len(dbg) >= 12
+    for n in dbg:
+        assert hasattr(lib, n), f"{n} declared in include/tsba_debug.h but not exported"
     from textslam_amd import optimizer
     for n in optimizer.EXPORTED_SYMBOLS:
-        assert n in names
+        assert n in names or n in dbg
 
 
 def test_struct_layout_matches_ctypes(tmp_path):

@@ -1,0 +1,202 @@
+"""Full-size global-BA configurations against the CPU ORACLE (not against the GPU's own downloaded system): BASELINE config 4 (C5: 500 KF x
+50 k points x 1000 text planes) and every 5000-keyframe variant of config 5 (C6: open chain, SURVEY 8d's 1 % long-range points, the ring
+right after a loop closure, two separate closures).  Reference: PyrGlobalBA, /root/reference/src/optimizer.cc:1701-1851 (Ceres LM over
+SPARSE_NORMAL_CHOLESKY, :1833-1840).
+
+Per configuration:
+  * first linearisation: cost0 (rtol 1e-11), the reduced gradient g and every 6x6 block of the reduced camera system S -- band, ghost rows and
+    the blocks outside the band alike, compared by keyframe pair -- against the oracle's block-sparse restatement (rel 1e-9);
+  * first LM step: the pose step of the GPU solves the ORACLE's system (direct sparse solve where the factor stays sparse, residual of the
+    oracle's system on the map with long-range points);
+  * the LM prefix: the oracle's trust-region loop on block-sparse normal equations with an exact linear solve (oracle.sparse_solver) against
+    the GPU's trace, trial by trial: K = number of leading trials with the same decision and the same candidate cost.  On maps of this size
+    the trajectory is NOT a function of the algorithm alone: two exact solvers inside the oracle itself (band Cholesky / SuperLU) part at
+    K(1e-9) = 4, K(1e-6) = 6 on the open chain -- rounding differences of 1e-16 in the step grow by ~30 x per LM iteration.  The test
+    asserts a floor for K and records the measured values in gpurun_out/lm_prefix.json.
+  * N = 2 / 8 in-process ranks at 5000 keyframes: the same prefix statement for the sharded solve against the single-rank GPU trace.
+"""
+import json
+import os
+import numpy as np
+import pytest
+
+from textslam_amd import abi
+from test_gpu_global import _on_ranks
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONFIGS = {
+    "c5_text":       dict(n_kf=500, n_pt=50000, n_text=1000, seed=7, feats=(64, 24, 12), band=12, n_levels=1),
+    "c6_open_chain": dict(n_kf=5000, n_pt=70000, band=10),
+    "c6_long_range": dict(n_kf=5000, n_pt=70000, band=10, far_frac=0.01),
+    "c6_ring":       dict(n_kf=5000, n_pt=70000, band=10, loop=True),
+    "c6_closures2":  dict(n_kf=5000, n_pt=70000, band=10, closures=2),
+}
+PREFIX_ITS = 12          # LM trials compared (the trajectories of two exact implementations part well before)
+# floors for (K at 1e-9, K at 1e-6, trials with the same decision), set below the measured values: C5 12 / 12 / 12, ring 11 / 11 / 11 and two
+# closures 10 / 10 / 10 (the whole run, costs to 1e-13: closed loops pin the drift modes), open chain 1 / 5 / 12 (its free end makes S ill-conditioned:
+# two backward-stable solvers differ by cond x eps in the step), long-range points 0 / 3 / 12 with the product's 1e-10 conjugate-gradient tolerance
+K_FLOOR = {"c5_text": (10, 12, 12), "c6_open_chain": (1, 4, 8), "c6_long_range": (0, 3, 8), "c6_ring": (9, 10, 10), "c6_closures2": (8, 9, 9)}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from textslam_amd.optimizer import Optimizer
+    g = Optimizer(0)
+    yield g
+    g.close()
+
+
+def _options(name):
+    o = abi.options_global()
+    if name == "c5_text":
+        o.use_text = 1
+    return o
+
+
+def prefix_length(tr_a, tr_b, rtol):
+    """Leading LM trials with the same decision and candidate costs within rtol."""
+    K = 0
+    for a, b in zip(tr_a, tr_b):
+        if a[3] != b[3]:
+            break
+        if np.isnan(a[0]) != np.isnan(b[0]) or (not np.isnan(a[0]) and not abs(a[0] - b[0]) <= rtol*abs(b[0])):
+            break
+        K += 1
+    return K
+
+
+def _record(name, **kw):
+    path = os.path.join(ROOT, "gpurun_out", "lm_prefix.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data.setdefault(name, {}).update(kw)
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_first_linearisation_and_lm_prefix_against_the_oracle(gpu, oracle_lib, map_cache, name):
+    import scipy.sparse.linalg as spl
+    P = map_cache(**CONFIGS[name]); o = _options(name)
+    nk = P.n_kf
+    # ---- the oracle's system
+    ob = oracle_lib.reduced_blocks(P, o, 0, o.initial_radius)
+    kf_of = np.nonzero(ob["free_idx"] >= 0)[0]                       # free-pose block -> keyframe (keyframe order)
+    n = 6*ob["nf"]
+    # ---- the GPU's
+    gpu.upload(P, o)
+    info = gpu.solver_info()
+    assert info["band_storage"] == 1, info
+    if name == "c6_long_range":
+        assert info["far_blocks"] > 5000 and info["far_band_blocks"] > 0, info
+    if name == "c6_closures2":
+        assert info["far_blocks"] > 0, info
+    if name == "c6_ring":
+        assert info["ring"] == 1, info
+    gb = gpu.reduced_blocks(o.initial_radius)
+    # cost and gradient
+    assert abs(gb["cost"] - ob["cost"]) <= 1e-11*ob["cost"], (gb["cost"], ob["cost"])
+    g_or = np.zeros(6*nk)
+    for q, k in enumerate(kf_of):
+        g_or[6*k:6*k + 6] = ob["g"][6*q:6*q + 6]
+    gscale = np.abs(g_or).max()
+    assert np.abs(gb["g"] - g_or).max() <= 1e-9*gscale, np.abs(gb["g"] - g_or).max()/gscale
+    # every block of S, by keyframe pair (the oracle's blocks are in keyframe order: rows = the later keyframe)
+    sscale = np.abs(ob["val"]).max()
+    seen, worst = set(), 0.0
+    for q in range(len(ob["br"])):
+        key = (int(kf_of[ob["br"][q]]), int(kf_of[ob["bc"][q]]))
+        blk = gb["blocks"].get(key)
+        ref = ob["val"][q]
+        if blk is None:
+            assert np.abs(ref).max() <= 1e-9*sscale, (key, np.abs(ref).max())     # (structurally present in the oracle, numerically nothing)
+            continue
+        seen.add(key)
+        bscale = max(np.abs(ref).max(), 1e-6*sscale)
+        worst = max(worst, float(np.abs(blk - ref).max()/bscale))
+    assert worst <= 1e-9, worst
+    for key, blk in gb["blocks"].items():                             # nothing on the GPU that the oracle does not have
+        assert key in seen or np.abs(blk).max() <= 1e-9*sscale, key
+    # ---- first LM step: the GPU's pose step solves the oracle's system
+    A = oracle_lib.blocks_to_sparse(n, ob["br"], ob["bc"], ob["val"])
+    dp = np.concatenate([gb["dp"][6*k:6*k + 6] for k in kf_of])
+    res = A @ dp + ob["g"]
+    assert np.abs(res).max() <= 1e-8*np.abs(ob["g"]).max(), np.abs(res).max()/np.abs(ob["g"]).max()
+    if name != "c6_long_range":                                       # (there the sparse factor fills: the residual above is the statement)
+        ref = oracle_lib.sparse_solver(A.tocsc(), -ob["g"])
+        assert np.abs(dp - ref).max() <= 1e-8*np.abs(ref).max(), np.abs(dp - ref).max()/np.abs(ref).max()
+    _record(name, n_blocks=len(ob["br"]), worst_block_rel=worst, cost0=ob["cost"], first_step_residual=float(np.abs(res).max()/np.abs(ob["g"]).max()))
+    # ---- the LM prefix
+    o.its[0] = PREFIX_ITS
+    gpu.upload(P, o); rep_g = gpu.solve(); tr_g = gpu.lm_trace(0)
+    st = gpu.pcg_stats()
+    assert st["hit_cap"] == 0, st
+    R = P.copy()
+    if name in ("c5_text", "c6_open_chain"):                          # a band in keyframe order: the oracle's own band Cholesky
+        rep_o, tr_o = oracle_lib.solve_traced(R, o)
+    else:
+        oracle_lib.SOLVER_LOG.clear()
+        oracle_lib.set_sparse_solver(oracle_lib.sparse_solver)
+        try:
+            rep_o, tr_o = oracle_lib.solve_traced(R, o)
+        finally:
+            oracle_lib.set_sparse_solver(None)
+        assert oracle_lib.SOLVER_LOG and oracle_lib.SOLVER_LOG[0][0] == ("gmres" if name == "c6_long_range" else "banded"), oracle_lib.SOLVER_LOG[:2]
+    tr_o = tr_o[0]
+    assert abs(rep_g["cost0"][0] - rep_o["cost0"][0]) <= 1e-11*rep_o["cost0"][0]
+    K9, K6, K3 = (prefix_length(tr_g, tr_o, t) for t in (1e-9, 1e-6, 1e-3))
+    Kdec = 0
+    for a, b in zip(tr_g, tr_o):                                      # decisions only
+        if a[3] != b[3]:
+            break
+        Kdec += 1
+    rel = [float(abs(a[0] - b[0])/abs(b[0])) if not (np.isnan(a[0]) or np.isnan(b[0])) else None for a, b in zip(tr_g, tr_o)]
+    print(f"\n{name}: LM prefix K(1e-9) = {K9}, K(1e-6) = {K6}, K(1e-3) = {K3}, decisions agree for {Kdec} of {min(len(tr_g), len(tr_o))} trials; "
+          f"final cost GPU {rep_g['cost1'][0]:.6g} / oracle {rep_o['cost1'][0]:.6g}")
+    _record(name, K_1e9=K9, K_1e6=K6, K_1e3=K3, K_decisions=Kdec, trials=int(min(len(tr_g), len(tr_o))), rel_cost_by_trial=rel,
+            cost1_gpu=rep_g["cost1"][0], cost1_oracle=rep_o["cost1"][0], iters_gpu=rep_g["iters"][0], iters_oracle=rep_o["iters"][0],
+            accepted_gpu=rep_g["accepted"][0], accepted_oracle=rep_o["accepted"][0])
+    f9, f6, fd = K_FLOOR[name]
+    assert K9 >= f9 and K6 >= f6 and Kdec >= fd, (K9, K6, Kdec, rel)
+    assert tr_g[0][3] == tr_o[0][3] and abs(tr_g[0][0] - tr_o[0][0]) <= (1e-8 if name == "c6_long_range" else 1e-10)*tr_o[0][0]     # the first trial: cost at x0 + dx
+    if name == "c6_long_range":
+        # the prefix is limited by the inexact linear solve, not by the assembly: with the conjugate gradients run to 1e-13 the first trial agrees
+        # with the oracle as on the open chain
+        try:
+            gpu.debug_set(pcg_tol_exp=13, pcg_max_it=400)
+            gpu.upload(P, o); rep_t = gpu.solve(); tr_t = gpu.lm_trace(0)
+            assert gpu.pcg_stats()["hit_cap"] == 0
+        finally:
+            gpu.debug_set()
+        K9t, K6t = prefix_length(tr_t, tr_o, 1e-9), prefix_length(tr_t, tr_o, 1e-6)
+        rel_t = [float(abs(a[0] - b[0])/abs(b[0])) if not (np.isnan(a[0]) or np.isnan(b[0])) else None for a, b in zip(tr_t, tr_o)]
+        print(f"{name}, conjugate gradients to 1e-13: K(1e-9) = {K9t}, K(1e-6) = {K6t}; first trial {rel_t[0]:.1e}")
+        _record(name, K_1e9_tight=K9t, K_1e6_tight=K6t, rel_cost_by_trial_tight=rel_t)
+        assert rel_t[0] <= 1e-9 and K6t >= 3, (K9t, K6t, rel_t)
+    # both end far below the start (the two trajectories are both valid LM runs)
+    assert rep_g["cost1"][0] < 0.2*rep_g["cost0"][0] and abs(rep_g["cost1"][0] - rep_o["cost1"][0]) <= 0.1*rep_o["cost1"][0]
+
+
+@pytest.mark.parametrize("name", ["c6_open_chain", "c6_long_range"])
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_lm_prefix_at_5000_keyframes(gpu, map_cache, name, world):
+    """N in-process ranks (the product's own N > 1 path: sharded upload, split kernels, every collective) against the single-rank GPU trace
+    on the 5000-keyframe maps: first trial to 1e-10, then the prefix length."""
+    P = map_cache(**CONFIGS[name]); o = _options(name); o.its[0] = PREFIX_ITS
+    gpu.upload(P, o); rep1 = gpu.solve(); tr1 = gpu.lm_trace(0)
+
+    def solve(g, rank):
+        g.upload(P, o); rep = g.solve()
+        return rep, g.lm_trace(0), g.solver_info()
+    outs = _on_ranks(world, solve)
+    for rep, tr, info in outs:
+        assert info["world"] == world
+        assert np.array_equal(tr, outs[0][1], equal_nan=True)           # every rank takes the same decisions on the same sums
+    tr = outs[0][1]
+    K9, K6 = prefix_length(tr, tr1, 1e-9), prefix_length(tr, tr1, 1e-6)
+    print(f"\n{name}, {world} ranks against 1: LM prefix K(1e-9) = {K9}, K(1e-6) = {K6} of {len(tr1)} trials; final cost {outs[0][0]['cost1'][0]:.6g} / {rep1['cost1'][0]:.6g}")
+    _record(f"{name}_ranks{world}", K_1e9=K9, K_1e6=K6, trials=int(len(tr1)), cost1=outs[0][0]["cost1"][0], cost1_single=rep1["cost1"][0])
+    assert abs(outs[0][0]["cost0"][0] - rep1["cost0"][0]) <= 1e-12*rep1["cost0"][0]
+    assert tr[0][3] == tr1[0][3] and abs(tr[0][0] - tr1[0][0]) <= 1e-10*tr1[0][0]
+    assert K9 >= 1 and K6 >= 3, (K9, K6)             # measured: 1-2 / 3-7 (the sharded sums differ from the unsharded ones in the last bits)

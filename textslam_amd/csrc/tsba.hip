@@ -28,6 +28,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types only: the library is dlopen()ed by tsba_comm_init, single-GPU use never touches RCCL
 #include "../../include/tsba.h"
+#include "../../include/tsba_debug.h"
 #include "tsba_device.h"
 #include "tsraster.h"
 #include "tsba_plan.h"
@@ -108,6 +109,7 @@ struct Ctx {
     unsigned char *dl_dev = nullptr, *dl_host = nullptr; size_t dl_bytes = 0;       // results of a solve as one block (k_pack_results): one device-to-host copy per download
     MsBuf sv{}; double *sv_alloc = nullptr; size_t sv_bytes = 0;                      // single-vector solve phase (tsba_bandsv.h)
     MsBuf ms{}; double *ms_alloc = nullptr; size_t ms_bytes = 0; int ms_cap = 0;      // multi-right-hand-side solve phase of the partitioned band solver (tsba_bandms.h)
+    std::vector<int32_t> rb_r, rb_c; std::vector<double> rb_v;      // tsba_debug_reduced_blocks: the blocks between its two calls
     int cov_text = -1; double *cov_log = nullptr;     // tsba_theta_optim: V of this plane at the end of every pass [TSBA_MAX_LEVELS][6]
     int far_B = 0, n_far = 0, pcg_parts = 0; unsigned int pcg_seq = 0;      // band + long-range blocks (tsba_pcg.h): band of M in pose blocks, blocks outside it, partial sums per vector kernel
     int rank = 0, world = 1; bool force_multi = false;
@@ -412,7 +414,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     UP(W.tobs_kf, p->tobs_kf, p->n_tobs); UP(W.tobs_text, p->tobs_text, p->n_tobs); UP(W.tobs_fgood_off, p->tobs_fgood_off, (size_t)p->n_tobs + 1);
     AL(W.musig, 2*(size_t)p->n_tobs);
     AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
-    AL(W.fidx, p->n_kf); AL(W.nfree, 2); AL(W.dbg, 64); AL(W.LDbuf, 32*((size_t)p->n_kf + BAND_BW_MAX/6 + 1));     // (+ the ghost blocks of a ring map)
+    AL(W.fidx, p->n_kf); AL(W.nfree, 2); AL(W.dbg, 64); AL(W.trace, 4*(size_t)TSBA_TRACE_CAP*TSBA_MAX_LEVELS); AL(W.LDbuf, 32*((size_t)p->n_kf + BAND_BW_MAX/6 + 1));     // (+ the ghost blocks of a ring map)
     // ---- plane cache (tsba_problem.kf_id): the keyframes of this call get their slots; the planes of those not seen before are staged and copied
     std::vector<int> &ic_slot = c->ic_slot; ic_slot.clear();
     bool &use_img_cache = c->use_img_cache; use_img_cache = false;
@@ -739,7 +741,7 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     const size_t x0 = c->x_acc;
     struct XP { Ctx *c; size_t x0; ~XP() { c->x_pass = c->x_acc - x0; } } xp{c, x0};
     c->cur_bw_rows = D.bw_rows; c->S_stale = true;             // (a new pass: other free poses, other entries of S)
-    c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
+    c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq; c->W.trace_pass = pass;
     Work &W = c->W; const tsba_options &o = c->opt;
     hipLaunchKernelGGL(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
     int n = D.n_sc + D.n_tg;

@@ -74,6 +74,79 @@ int tsba_debug_reduced_band(void *ctx, double radius, int32_t *n_out, int32_t *b
     return TSBA_OK;
 }
 
+
+// The reduced system of the first linearisation as 6x6 blocks keyed by KEYFRAME pairs, whatever the storage behind it (band rows in any keyframe
+// order, the ghost rows of a ring map, the blocks outside the band of a map with long-range coupling): block q couples keyframes kf_r[q], kf_c[q]
+// and holds S(rows of kf_r, columns of kf_c), row-major.  A keyframe pair may appear more than once (a block of E inside the band): the parts add.
+// First call with kf_r == NULL: *nblk = number of blocks (the system is assembled, solved and downloaded then and kept until the second call).
+// g_kf, dp_kf [6 n_kf] by keyframe (0 for constant poses), cost = the cost at the linearisation point.  Band storage only.
+int tsba_debug_reduced_blocks(void *ctx, double radius, int32_t *nblk, int32_t *kf_r, int32_t *kf_c, double *val, double *g_kf, double *dp_kf, double *cost) {
+    Ctx *c = (Ctx *)ctx; if (!c || !nblk) return TSBA_ERR_ARG;
+    if (!c->uploaded) return TSBA_ERR_STATE;
+    if (!c->W.band) { set_err(c, "the uploaded problem keeps a dense reduced system: use tsba_debug_reduced_system"); return TSBA_ERR_STATE; }
+    if (!kf_r) {
+        int rc = tsba_debug_reduced_system(ctx, radius, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
+        Work &W = c->W; const LevelDev &D = c->lev[c->opt.levels[0]];
+        c->rb_r.clear(); c->rb_c.clear(); c->rb_v.clear();
+        int nfr[2] = {0, 0}; CK(hipMemcpy(nfr, W.nfree, 2*sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> fi(c->n_kf), kf_of(std::max(1, nfr[0]), -1);
+        CK(hipMemcpy(fi.data(), W.fidx, sizeof(int)*c->n_kf, hipMemcpyDeviceToHost));
+        for (int k = 0; k < c->n_kf; k++) if (fi[k] >= 0 && fi[k] < nfr[0]) kf_of[fi[k]] = k;
+        std::vector<double> hb(c->S_count); CK(hipMemcpy(hb.data(), c->S_alloc, sizeof(double)*c->S_count, hipMemcpyDeviceToHost));
+        const long long LDB = W.ldS + 1, Wb = LDB - c->S_up, nrows = (long long)(c->S_count/LDB);
+        auto at = [&](long long i, long long j) { return hb[(size_t)(Wb + i*(LDB - 1) + j)]; };
+        auto emit = [&](int kr, int kc, const double *b) { c->rb_r.push_back(kr); c->rb_c.push_back(kc); c->rb_v.insert(c->rb_v.end(), b, b + 36); };
+        const int wbb = (int)(Wb/6);                                   // block columns left of the diagonal block a row block can reach
+        for (int rb = 0; rb < nfr[0]; rb++) for (int cb = std::max(0, rb - wbb); cb <= rb; cb++) {
+            double b[36]; bool nz = false;
+            for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) { const long long i = 6LL*rb + r, j = 6LL*cb + q;
+                const double v = (j <= i && j >= i - Wb) ? at(i, j) : (j > i && cb == rb ? at(j, i) : 0.0); b[6*r + q] = v; nz |= v != 0.0; }
+            if (nz) emit(kf_of[rb], kf_of[cb], b);
+        }
+        if (W.ring) {                                                  // ghost row 6 nfree + r = row r of the loop's first poses: the closure blocks (late pose, early pose)
+            const long long n6 = 6LL*nfr[0]; const int eb0 = nfr[1];
+            for (int g = 0; g < W.ring_b && n6 + 6LL*g + 5 < nrows; g++) for (int cb = 0; cb < nfr[0]; cb++) {
+                if (cb <= eb0 + g) continue;
+                double b[36]; bool nz = false;
+                for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) { const long long i = n6 + 6LL*g + r, j = 6LL*cb + q;     // S(j, first + r): rows of the late pose cb
+                    const double v = (j >= i - Wb && j >= 0) ? at(i, j) : 0.0; b[6*q + r] = v; nz |= v != 0.0; }
+                if (nz) emit(kf_of[cb], kf_of[eb0 + g], b);
+            }
+        }
+        if (D.far_B > 0 && D.n_far > 0) {                              // the blocks outside the band: stored with rows = the earlier keyframe a
+            const HostPlan &H = c->hplan[D.level];
+            std::vector<double> hf(36*(size_t)D.n_far); CK(hipMemcpy(hf.data(), W.Sfar, sizeof(double)*hf.size(), hipMemcpyDeviceToHost));
+            for (int q = 0; q < D.n_far; q++) { if (fi[H.far_a[q]] < 0 || fi[H.far_b[q]] < 0) continue;
+                bool nz = false; for (int e = 0; e < 36; e++) nz |= hf[36*(size_t)q + e] != 0.0;
+                if (nz) emit(H.far_a[q], H.far_b[q], hf.data() + 36*(size_t)q); }
+        }
+        *nblk = (int32_t)c->rb_r.size();
+        return TSBA_OK;
+    }
+    if ((size_t)*nblk != c->rb_r.size()) { set_err(c, "tsba_debug_reduced_blocks: call with kf_r == NULL first"); return TSBA_ERR_STATE; }
+    memcpy(kf_r, c->rb_r.data(), sizeof(int32_t)*c->rb_r.size()); memcpy(kf_c, c->rb_c.data(), sizeof(int32_t)*c->rb_c.size());
+    if (val) memcpy(val, c->rb_v.data(), sizeof(double)*c->rb_v.size());
+    Work &W = c->W;
+    std::vector<int> fi(c->n_kf); CK(hipMemcpy(fi.data(), W.fidx, sizeof(int)*c->n_kf, hipMemcpyDeviceToHost));
+    if (g_kf) { std::vector<double> gr(W.N); CK(hipMemcpy(gr.data(), W.g, sizeof(double)*W.N, hipMemcpyDeviceToHost));
+        for (int k = 0; k < c->n_kf; k++) for (int e = 0; e < 6; e++) g_kf[6*k + e] = fi[k] >= 0 ? gr[6*(size_t)fi[k] + e] : 0.0; }
+    if (dp_kf) CK(hipMemcpy(dp_kf, W.dp, sizeof(double)*W.N, hipMemcpyDeviceToHost));
+    if (cost) { LmState st; CK(hipMemcpy(&st, W.st, sizeof(st), hipMemcpyDeviceToHost)); *cost = st.x_cost; }
+    c->rb_r.clear(); c->rb_c.clear(); c->rb_v.clear(); c->rb_r.shrink_to_fit(); c->rb_c.shrink_to_fit(); c->rb_v.shrink_to_fit();
+    return TSBA_OK;
+}
+// Per LM trial of pass `pass` of the last solve: out[4 k] = candidate cost (NaN: invalid step), [4 k + 1] = model cost change, [4 k + 2] = radius
+// after the decision, [4 k + 3] = 1 accepted / 0 rejected / -1 invalid step / 2 tolerance exit on this trial.  Returns the number of trials
+// recorded (min(iterations of the pass, cap, TSBA_TRACE_CAP)) or a negative error.  (The fused pose-only kernel keeps no trace.)
+int tsba_debug_lm_trace(void *ctx, int pass, double *out, int cap) {
+    Ctx *c = (Ctx *)ctx; if (!c || !out || pass < 0 || pass >= TSBA_MAX_LEVELS || cap <= 0) return TSBA_ERR_ARG;
+    if (!c->uploaded || !c->W.trace) return TSBA_ERR_STATE;
+    hipSetDevice(c->device); CK(hipStreamSynchronize(c->stream));
+    const int n = std::min({cap, TSBA_TRACE_CAP, (int)c->st_host[pass].it});
+    if (n > 0) CK(hipMemcpy(out, c->W.trace + 4*(size_t)pass*TSBA_TRACE_CAP, sizeof(double)*4*(size_t)n, hipMemcpyDeviceToHost));
+    return n;
+}
+
 int tsba_time_linearize(void *ctx, int level, int n, double *avg_ms, double *algo_bytes) {
     Ctx *c = (Ctx *)ctx; if (!c || n <= 0) return TSBA_ERR_ARG;
     if (!c->uploaded || level < 0 || level >= c->n_levels || !c->lev_built[level]) { set_err(c, "level not uploaded"); return TSBA_ERR_STATE; }

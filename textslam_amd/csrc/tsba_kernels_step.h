@@ -127,27 +127,28 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
         cost = sc[0]; xn_c = sc[1] + xp; step2 = sc[2]; mcc = sc[3]; gmax_c = fmax(W.cbm[0], gp);
     }
     if (tid) return;
+    double verdict = 0.0;                         // trace: 1 accepted / 0 rejected / -1 invalid step / 2 tolerance exit on this trial
     [&]() {
     mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
     st->it++;
     st->cand_cost = cost; st->model_change = mcc; st->step_norm = sqrt(step2);
     if (st->step_fail || !(mcc > 0.0)) {          // invalid step (LevenbergMarquardtStrategy::StepIsInvalid)
-        st->step_fail = 0;
+        st->step_fail = 0; verdict = -1.0;
         if (++st->invalid >= 5) { st->done = 1; st->term = 5; return; }
         st->radius *= 0.5;
     } else {
         st->invalid = 0; st->n_cost++;
         if (!(cost == cost)) cost = 1.7976931348623157e308;
-        if (st->step_norm <= o.parameter_tolerance*(st->x_norm + o.parameter_tolerance)) { st->done = 1; st->term = 2; return; }
+        if (st->step_norm <= o.parameter_tolerance*(st->x_norm + o.parameter_tolerance)) { st->done = 1; st->term = 2; verdict = 2.0; return; }
         double cost_change = st->x_cost - cost;
-        if (fabs(cost_change) <= o.function_tolerance*st->x_cost) { st->done = 1; st->term = 1; return; }
+        if (fabs(cost_change) <= o.function_tolerance*st->x_cost) { st->done = 1; st->term = 1; verdict = 2.0; return; }
         double rel = cost_change/mcc;
         if (rel > o.min_relative_decrease) {      // accept: the speculative linearisation becomes the current one
             st->cur ^= 1; st->lcur ^= 1; st->accepted++; st->n_lin++;
             st->x_cost = cost; st->x_norm = sqrt(xn_c); st->gmax = gmax_c;
             double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
             st->radius = fmin(st->radius/f, o.max_radius);
-            st->decrease_factor = 2.0;
+            st->decrease_factor = 2.0; verdict = 1.0;
             if (gmax_c <= o.gradient_tolerance) { st->done = 1; st->term = 3; return; }
         } else {
             st->radius = st->radius/st->decrease_factor; st->decrease_factor *= 2.0;
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
     if (st->it >= st->max_it) { st->done = 1; st->term = 0; }
     else if (st->radius < o.min_radius) { st->done = 1; st->term = 4; }
     }();
+    if (W.trace && st->it >= 1 && st->it <= TSBA_TRACE_CAP) {     // test hook (tsba_debug_lm_trace): 32 bytes per trial
+        double *t = W.trace + 4*((size_t)W.trace_pass*TSBA_TRACE_CAP + st->it - 1);
+        t[0] = verdict < 0.0 ? __longlong_as_double(0x7ff8000000000000LL) : cost; t[1] = mcc; t[2] = st->radius; t[3] = verdict; }
     if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)st->it << 1) | (st->done ? 1u : 0u); __threadfence_system(); }
 #ifdef TSBA_SOLVE_STAMPS
     W.dbg[32] = s1_ - s0_; W.dbg[33] = s2_ - s1_; W.dbg[34] = s3_ - s2_; W.dbg[35] = clock64() - s3_;

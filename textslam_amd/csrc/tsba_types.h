@@ -29,6 +29,7 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const int *fb_id, *fb_pab, *fb_pba, *fb_pt_off, *fb_pt_s1, *fb_pt_s2, *fb_pt_lm, *fb_tx_off, *fb_tx_s1, *fb_tx_s2, *fb_tx_lm;
 };
 
+#define TSBA_TRACE_CAP 64
 #define PT_REC 8
 #define TX_REC 28
 struct LinBuf {              // everything one linearisation produces
@@ -62,6 +63,7 @@ struct Work {                // device work buffers (sized for the largest level
     int *fidx, *nfree;                  // compressed index of the free poses in S / g
     double *cb, *cbm;                   // multi-GPU exchange buffers: cb = [Hd 6n | bp 6n | cost, |x_lm|^2, step^2, mcc] (sum), cbm = gradient max (max)
     long long *dbg;                     // [64] cycle stamps of instrumented kernels (debug)
+    double *trace; int trace_pass;      // per LM trial of the pass being solved: candidate cost, model cost change, radius after the decision, decision (tsba_debug_lm_trace; [TSBA_MAX_LEVELS][TSBA_TRACE_CAP][4])
     double *LDbuf;                      // diagonal of the inverse diagonal factors (large-system Cholesky)
     int ldS, band;                      // S(i,j) = S[i*ldS + j]; band: S holds only the band of the reduced camera matrix (large systems)
     int ring;                           // 1: ring-shaped co-visibility (one loop closure, tsba_plan.h): the closure blocks -- the loop's first poses S against its last --

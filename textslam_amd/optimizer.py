@@ -51,6 +51,9 @@ def load_library():
     L.tsba_debug_far_blocks.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
     L.tsba_debug_row_of_kf.argtypes = [vp, C.POINTER(C.c_int32)]
     L.tsba_debug_time_solve.argtypes = [vp, C.c_int, dp]
+    ip32 = C.POINTER(C.c_int32)
+    L.tsba_debug_reduced_blocks.argtypes = [vp, C.c_double, ip32, ip32, ip32, dp, dp, dp, dp]
+    L.tsba_debug_lm_trace.argtypes = [vp, C.c_int, dp, C.c_int]
     L.tsba_comm_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.tsba_comm_unique_id.argtypes = [vp, vp]
     L.tsba_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -268,6 +271,35 @@ class Optimizer:
         for k in np.nonzero(rowblk >= 0)[0]:
             dp_rows[6*rowblk[k]:6*rowblk[k] + 6] = dpv[6*k:6*k + 6]
         return {"ab": ab, "g": g, "dp": dpv, "dp_rows": dp_rows, "n": n.value, "bw": bw.value, "free": free, "rowblk": rowblk}
+
+    def reduced_blocks(self, radius: float):
+        """Large maps, any co-visibility graph: the reduced system of the first linearisation as 6x6 blocks keyed by keyframe pairs
+        (tsba_debug_reduced_blocks).  -> dict(blocks {(kf_hi, kf_lo): 6x6 with rows = kf_hi}, g [6 n_kf], dp [6 n_kf], cost)."""
+        n = C.c_int32(0); ip = C.POINTER(C.c_int32)
+        self._check(self.lib.tsba_debug_reduced_blocks(self.ctx, radius, C.byref(n), None, None, None, None, None, None), "tsba_debug_reduced_blocks")
+        nk = self._resident.n_kf
+        kr, kc, v = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32), np.zeros((n.value, 6, 6))
+        g, dpv, cost = np.zeros(6*nk), np.zeros(6*nk), C.c_double(0)
+        self._check(self.lib.tsba_debug_reduced_blocks(self.ctx, radius, C.byref(n), kr.ctypes.data_as(ip), kc.ctypes.data_as(ip), _dp(v), _dp(g), _dp(dpv), C.byref(cost)),
+                    "tsba_debug_reduced_blocks")
+        blocks = {}
+        for q in range(n.value):
+            r, c_ = int(kr[q]), int(kc[q])
+            key, b = ((r, c_), v[q]) if r >= c_ else ((c_, r), v[q].T)
+            if key in blocks:
+                blocks[key] = blocks[key] + b
+            else:
+                blocks[key] = b.copy()
+        return {"blocks": blocks, "g": g, "dp": dpv, "cost": cost.value}
+
+    def lm_trace(self, ps: int = 0, cap: int = 64):
+        """Per LM trial of pass `ps` of the last solve: [trials][4] = candidate cost (NaN: invalid step), model cost change, radius after
+        the decision, 1 accepted / 0 rejected / -1 invalid / 2 tolerance exit (tsba_debug_lm_trace)."""
+        out = np.full((cap, 4), np.nan)
+        n = self.lib.tsba_debug_lm_trace(self.ctx, int(ps), _dp(out), cap)
+        if n < 0:
+            self._check(n, "tsba_debug_lm_trace")
+        return out[:n].copy()
 
     # ---- multi-GPU (global BA): one process per GPU, RCCL communicator owned by the library
     def comm_unique_id(self):
