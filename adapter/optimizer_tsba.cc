@@ -19,7 +19,10 @@ namespace {
 // One context per calling THREAD: TextSLAM's tracking, mapping and loop-closing threads call these methods concurrently (tracking.cc:447-561,
 // loopClosing.cc:589) and a tsba context serves one caller at a time (include/tsba.h).  thread_local keeps this file free of header changes;
 // with a header change the context would be a member of the optimizer object guarded like its other state.
-void *tsba_ctx() { static thread_local void *ctx = nullptr; if (!ctx && tsba_create(&ctx, 0) != TSBA_OK) { std::cerr << "tsba_create: no usable HIP device" << std::endl; exit(-1); } return ctx; }
+// The holder destroys the context when its thread exits (slabs, plane cache of 64 pyramid slots and streams go with it).  The label image below
+// reads the state of the last solve OF THE CALLING THREAD: UpdateTrackedTextBA runs on the thread that ran the BA (optimizer.cc:322-326), as here.
+struct CtxHolder { void *ctx = nullptr; ~CtxHolder() { if (ctx) tsba_destroy(ctx); } };
+void *tsba_ctx() { static thread_local CtxHolder h; if (!h.ctx && tsba_create(&h.ctx, 0) != TSBA_OK) { std::cerr << "tsba_create: no usable HIP device" << std::endl; exit(-1); } return h.ctx; }
 void k_of(const Mat33 &K, double out[4]) { out[0] = K(0, 0); out[1] = K(1, 1); out[2] = K(0, 2); out[3] = K(1, 2); }
 // TSBA_ERR_NUMERIC = the linear solver broke down in some LM trial (Ceres: termination FAILURE): the one-shot entry points have still
 // downloaded the LAST ACCEPTED state and the flags of the passes that ran (tsba.hip: one_shot returns the status after tsba_download), so

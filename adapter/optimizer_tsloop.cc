@@ -15,7 +15,8 @@ namespace TextSLAM {
 typedef tsba_adapter::TextSlamTraits TT;
 
 namespace {
-void *tsloop_ctx() { static thread_local void *ctx = nullptr; if (!ctx && tsloop_create(0, &ctx) != TSLOOP_OK) { std::cerr << "tsloop_create: no usable HIP device" << std::endl; exit(-1); } return ctx; }
+struct CtxHolder { void *ctx = nullptr; ~CtxHolder() { if (ctx) tsloop_destroy(ctx); } };          // one context per calling thread, destroyed with it
+void *tsloop_ctx() { static thread_local CtxHolder h; if (!h.ctx && tsloop_create(0, &h.ctx) != TSLOOP_OK) { std::cerr << "tsloop_create: no usable HIP device" << std::endl; exit(-1); } return h.ctx; }
 }
 
 int optimizer::OptimizeSim3(vector<FeatureConvert> &vFeat1, vector<FeatureConvert> &vFeat2, vector<bool> &vbInliers, Sim3_loop &Sim12, const float th2) {

@@ -159,8 +159,27 @@ typedef struct tsba_report {
     int32_t n_bad_scene[TSBA_MAX_LEVELS], n_bad_tfeat[TSBA_MAX_LEVELS], n_bad_text[TSBA_MAX_LEVELS];
     double  t_upload_ms, t_solve_ms, t_download_ms;
     int32_t cov_valid;                     /* tsba_theta_optim: 1 = cov[] was written, 0 = singular information matrix (cov untouched) */
-    int32_t reserved_;
+    /* How the reduced camera system S dx = -g was solved (the reference hands it to Ceres' sparse Cholesky, optimizer.cc:1833-1840, which
+     * either solves it or fails the step).  Every path below is an exact solve except TSBA_SOLVER_BAND_PCG, which iterates to a relative
+     * tolerance of 1e-10; an iterative solve that does not get there is treated as a FAILED linear solve (the LM loop shrinks the trust
+     * region, as Ceres does on LINEAR_SOLVER_FAILURE) and counted in pcg_unconverged -- an unconverged step is never accepted. */
+    int32_t solver_path;                   /* TSBA_SOLVER_* of the last pass */
+    int32_t pcg_iterations;                /* TSBA_SOLVER_BAND_PCG / _BAND_LOWRANK: conjugate-gradient iterations over all LM trials */
+    int32_t pcg_systems;                   /* reduced systems solved iteratively (LM trials) */
+    int32_t pcg_max_iterations;            /* most iterations one system took */
+    int32_t pcg_unconverged;               /* systems that hit the iteration cap: their LM trial was rejected as an invalid step */
+    int32_t pcg_stagnated;                 /* systems that ended at the attainable accuracy (rounding noise of M^-1 r) short of the tolerance */
+    int32_t reserved_[3];
 } tsba_report;
+#define TSBA_SOLVER_LDS          0   /* window of <= 31 keyframes: blocked LDL^T in one workgroup's LDS */
+#define TSBA_SOLVER_DENSE        1   /* multi-workgroup blocked Cholesky on the dense / wide-band matrix */
+#define TSBA_SOLVER_BAND         2   /* streaming band solver, one workgroup */
+#define TSBA_SOLVER_BAND_PART    3   /* partitioned band solver, separator system sequential */
+#define TSBA_SOLVER_BAND_CR      4   /* partitioned band solver, separator system by block cyclic reduction */
+#define TSBA_SOLVER_RING         5   /* as 4 on a ring (one loop closure): ghost rows, merged root */
+#define TSBA_SOLVER_BAND_LOWRANK 6   /* band part + exact low-rank correction for a few loop closures (one or two refinement iterations) */
+#define TSBA_SOLVER_BAND_PCG     7   /* band part as preconditioner of conjugate gradients (scattered long-range observations) */
+#define TSBA_SOLVER_POSE         8   /* one free pose: 6x6 in registers (tsba_pose_optim) */
 
 /* Reference defaults for the three public methods. */
 void tsba_default_options_local (tsba_options *o);   /* levels 2,1,0 x10, chi2 12.25 / .5 .5 .5(.95 at 0) */

@@ -204,3 +204,43 @@ def test_multi_right_hand_side_solve_phase(gpu, n_kf, band, parts, T):
             assert np.abs(x1 - ref[:, k]).max() <= 1e-8*np.abs(ref[:, k]).max(), (k, np.abs(x1 - ref[:, k]).max()/np.abs(ref[:, k]).max())
     finally:
         gpu.debug_set()
+
+
+def test_solver_status_in_the_report(gpu):
+    """tsba_report says which solver ran and whether the iterative one converged (the reference's sparse Cholesky either solves the system or the
+    step fails, optimizer.cc:1833-1845): an iteration cap that is hit makes the LM trial an INVALID step (trust region halved), never an accepted one."""
+    P = synth.config_global(n_kf=600, n_pt=12000, band=8, far_frac=0.02)
+    o = abi.options_global(); o.its[0] = 6
+    try:
+        gpu.debug_set(far_solver=2)
+        G = P.copy(); rep = gpu.GlobalBA(G, options=o)
+        assert rep["solver_path"] == 7 and rep["pcg_systems"] >= rep["iters"][0] and rep["pcg_iterations"] > 0, rep
+        assert rep["pcg_unconverged"] == 0 and rep["pcg_max_iterations"] <= 150 and rep["status"] == 0, rep
+        st = gpu.pcg_stats()
+        assert st["iterations"] == rep["pcg_iterations"] and st["systems"] == rep["pcg_systems"] and st["hit_cap"] == 0
+        gpu.debug_set(far_solver=2, pcg_max_it=3)                     # three iterations cannot reach 1e-10
+        G2 = P.copy(); rep2 = gpu.GlobalBA(G2, options=o)
+        tr = gpu.lm_trace(0)
+        assert rep2["pcg_unconverged"] >= 1, rep2
+        bad = tr[:, 3] == -1.0
+        assert bad.sum() >= rep2["pcg_unconverged"] - 1 and np.all(np.isnan(tr[bad, 0])), tr       # (a solve cut off by the end of the pass has no trial)
+        assert rep2["accepted"][0] == int((tr[:, 3] == 1.0).sum())
+        if rep2["termination"][0] == 5:
+            assert rep2["status"] == -3 and np.array_equal(G2.pose, P.pose)      # five invalid steps in a row: TSBA_ERR_NUMERIC, the parameters stay at the last accepted state
+    finally:
+        gpu.debug_set()
+    # the other paths name themselves too
+    Q = synth.config_global(n_kf=900, n_pt=18000, band=8, closures=2)
+    try:
+        gpu.debug_set(far_solver=2)
+        rq = gpu.GlobalBA(Q.copy(), options=o)
+        assert rq["solver_path"] == 6 and rq["pcg_unconverged"] == 0, rq
+    finally:
+        gpu.debug_set()
+    R = synth.config_global(n_kf=600, n_pt=12000, band=8)
+    rr = gpu.GlobalBA(R.copy(), options=o)
+    assert rr["solver_path"] in (3, 4) and rr["pcg_systems"] == 0, rr
+    rl = gpu.LocalBundleAdjustment(synth.tiny().copy())
+    assert rl["solver_path"] == 0, rl
+    rp = gpu.PoseOptim(synth.config_c3().copy())
+    assert rp["solver_path"] == 8, rp

@@ -70,13 +70,17 @@ class TsbaReport(C.Structure):
         ("n_resid_evals", C.c_int64),
         ("n_bad_scene", C.c_int32 * MAX_LEVELS), ("n_bad_tfeat", C.c_int32 * MAX_LEVELS), ("n_bad_text", C.c_int32 * MAX_LEVELS),
         ("t_upload_ms", C.c_double), ("t_solve_ms", C.c_double), ("t_download_ms", C.c_double),
-        ("cov_valid", C.c_int32), ("reserved_", C.c_int32),
+        ("cov_valid", C.c_int32), ("solver_path", C.c_int32),
+        ("pcg_iterations", C.c_int32), ("pcg_systems", C.c_int32), ("pcg_max_iterations", C.c_int32), ("pcg_unconverged", C.c_int32), ("pcg_stagnated", C.c_int32),
+        ("reserved_", C.c_int32 * 3),
     ]
 
     def as_dict(self):
         n = self.n_passes
         d = {"status": self.status, "n_passes": n, "n_resid_evals": self.n_resid_evals, "cov_valid": self.cov_valid,
-             "t_upload_ms": self.t_upload_ms, "t_solve_ms": self.t_solve_ms, "t_download_ms": self.t_download_ms}
+             "t_upload_ms": self.t_upload_ms, "t_solve_ms": self.t_solve_ms, "t_download_ms": self.t_download_ms,
+             "solver_path": self.solver_path, "pcg_iterations": self.pcg_iterations, "pcg_systems": self.pcg_systems,
+             "pcg_max_iterations": self.pcg_max_iterations, "pcg_unconverged": self.pcg_unconverged, "pcg_stagnated": self.pcg_stagnated}
         for k in ("iters", "accepted", "termination", "cost0", "cost1", "n_sblock", "n_tblock",
                   "n_bad_scene", "n_bad_tfeat", "n_bad_text"):
             d[k] = list(getattr(self, k))[:n]
@@ -84,7 +88,7 @@ class TsbaReport(C.Structure):
 
 
 class TsbaDebugOptions(C.Structure):
-    """tsba_debug_options (include/tsba.h): test / diagnostics switches of one context; all zero = production behaviour."""
+    """tsba_debug_options (include/tsba_debug.h): test / diagnostics switches of one context; all zero = production behaviour."""
     _fields_ = [
         ("band_parts", C.c_int32), ("sep_solver", C.c_int32), ("no_band_stream", C.c_int32), ("no_pose_kernel", C.c_int32),
         ("no_small_pairs", C.c_int32), ("verbose", C.c_int32), ("no_kf_reorder", C.c_int32), ("no_schur_quad", C.c_int32), ("no_ring", C.c_int32),

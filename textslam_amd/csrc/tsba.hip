@@ -177,6 +177,8 @@ static void join_planners(Ctx *c) { for (auto &t : c->planners) if (t.joinable()
 static void free_problem(Ctx *c) {
     join_planners(c); c->stage_p = nullptr;
     hipStreamSynchronize(c->stream);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);       // (a level staged ahead of a pass that a failed solve never reached: its copy reads the slabs' pinned mirror)
+    for (int l = 0; l < TSBA_MAX_LEVELS; l++) c->lev_wait[l] = 0;
     // the slabs stay (tsba_destroy frees them): zero what the last problem used, restart the bump allocation
     for (Slab &sl : c->slabs) { if (sl.used) hipMemsetAsync(sl.dev, 0, sl.used, c->stream); sl.used = 0; }
     c->cur_slab = 0; c->run_len = 0;
@@ -236,7 +238,7 @@ int tsba_create(void **ctx, int device) {
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (hipEventCreateWithFlags(&c->ev_stage[l], hipEventDisableTiming) != hipSuccess) c->ev_stage[l] = nullptr;
     hipDeviceProp_t prop;
     const bool ok = hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess
-        && hipHostMalloc((void **)&c->st_host, sizeof(LmState)*TSBA_MAX_LEVELS, 0) == hipSuccess
+        && hipHostMalloc((void **)&c->st_host, sizeof(LmState)*TSBA_MAX_LEVELS + 64, 0) == hipSuccess
         && hipMalloc((void **)&c->st_log, sizeof(LmState)*TSBA_MAX_LEVELS) == hipSuccess
         && hipGetDeviceProperties(&prop, device) == hipSuccess;
     if (!ok) {                                      // nothing half-built leaves this function
@@ -244,7 +246,7 @@ int tsba_create(void **ctx, int device) {
         if (c->st_host) hipHostFree(c->st_host); if (c->st_log) hipFree(c->st_log);
         hipStreamDestroy(c->stream); delete c; return TSBA_ERR_DEVICE;
     }
-    if (hipHostMalloc((void **)&c->hprog, 64, hipHostMallocDefault) != hipSuccess) c->hprog = nullptr; else *c->hprog = 0;   // (optional: early-exit polling only)
+    if (hipHostMalloc((void **)&c->hprog, 64, hipHostMallocDefault) != hipSuccess) c->hprog = nullptr; else memset(c->hprog, 0, 64);   // (optional: early-exit polling only)
     c->lds_limit = prop.sharedMemPerBlock;       // 64 KiB default static limit; dynamic up to 160 KiB on gfx950
     if (c->lds_limit < 160*1024) c->lds_limit = 160*1024;
     *ctx = c; return TSBA_OK;
@@ -435,6 +437,8 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
                 for (int l = 0; l < TSBA_MAX_LEVELS; l++) { IC.lvl_off[l] = lo[l]; IC.w[l] = l < p->n_levels ? p->img_w[l] : 0; IC.h[l] = l < p->n_levels ? p->img_h[l] : 0; }
                 for (int q = 0; q < TSBA_IMG_CACHE_KF; q++) { IC.id[q] = 0; IC.used[q] = 0; IC.full[q] = false; }
             }
+            for (int l = 0; l < p->n_levels; l++) if (mask >> l & 1) for (int k = 0; k < p->n_kf; k++)      // before any slot changes hands: a failed call must not leave a slot marked full without its planes
+                if (!p->img[l][k]) { set_err(c, "null image pointer"); return TSBA_ERR_ARG; }
             IC.tick++;
             ic_slot.assign((size_t)p->n_kf, -1);
             std::vector<int> miss;
@@ -447,11 +451,12 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
             if (!miss.empty()) {
                 const size_t need = miss.size()*off;
                 if (IC.stage_cap < need) { if (IC.stage) hipHostFree(IC.stage); IC.stage = nullptr; IC.stage_cap = 0;
-                    if (hipHostMalloc((void **)&IC.stage, need, hipHostMallocDefault) != hipSuccess) { set_err(c, "hipHostMalloc (plane cache staging)"); return TSBA_ERR_DEVICE; }
+                    if (hipHostMalloc((void **)&IC.stage, need, hipHostMallocDefault) != hipSuccess) { IC.stage = nullptr;
+                        for (int k : miss) IC.full[ic_slot[(size_t)k]] = false;          // (their planes were never copied)
+                        set_err(c, "hipHostMalloc (plane cache staging)"); return TSBA_ERR_DEVICE; }
                     IC.stage_cap = need; }
                 for (size_t m = 0; m < miss.size(); m++) { const int k = miss[m];
-                    for (int l = 0; l < p->n_levels; l++) if (mask >> l & 1) { if (!p->img[l][k]) { set_err(c, "null image pointer"); return TSBA_ERR_ARG; }
-                        memcpy(IC.stage + m*off + lo[l], p->img[l][k], (size_t)p->img_w[l]*p->img_h[l]); }
+                    for (int l = 0; l < p->n_levels; l++) if (mask >> l & 1) memcpy(IC.stage + m*off + lo[l], p->img[l][k], (size_t)p->img_w[l]*p->img_h[l]);
                     hipMemcpyAsync(IC.dev + (size_t)ic_slot[(size_t)k]*off, IC.stage + m*off, off, hipMemcpyHostToDevice, c->stream); }
             }
             use_img_cache = true;
@@ -579,7 +584,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
             c->pcg_parts = (p->n_kf + 31)/32;
             AL(W.Sfar, 36*(size_t)std::max(c->n_far, 1));
             AL(W.pc_x, W.N); AL(W.pc_r, W.N); AL(W.pc_p[0], W.N); AL(W.pc_p[1], W.N); AL(W.pc_q, W.N); AL(W.pc_g0, W.N);
-            AL(W.pc_part, 5*(size_t)c->pcg_parts + 16 + 144); AL(W.pcs, 2); AL(W.pc_stat, 4);       // (pc_part: + partial r.z per interior of the solve phase, tsba_bandsv.h)
+            AL(W.pc_part, 5*(size_t)c->pcg_parts + 16 + 144); AL(W.pcs, 2); AL(W.pc_stat, 8);       // (pc_part: + partial r.z per interior of the solve phase, tsba_bandsv.h)
         }
         c->S_xchg = nullptr; c->xchg_wp = 0;
         if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, ((size_t)W.N + bwmax)*c->xchg_wp); }
@@ -1071,6 +1076,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
                 for (int spin = 0;; spin++) {
                     const unsigned long long w = ((volatile unsigned long long *)c->hprog)[1];
                     if ((unsigned int)(w >> 32) == seq) { if (w & 1) return true; if ((int)((w & 0xffffffffu) >> 1) + 2 >= it) return false; }
+                    PlanPool::cpu_relax();
                     if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(5)) return false;
                 }
             };
@@ -1149,6 +1155,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
         for (int spin = 0;; spin++) {
             const unsigned long long w = ((volatile unsigned long long *)c->hprog)[1];
             if ((unsigned int)(w >> 32) == seq) { if (w & 1) return true; if ((int)((w & 0xffffffffu) >> 1) + 2 >= it) return false; }
+            PlanPool::cpu_relax();
             if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(5)) return false;      // never hang on it
         }
     };
@@ -1224,7 +1231,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
                    ~Token() { if (c->lgroup) { c->in_solve = false; if (c->has_token) { hipStreamSynchronize(c->stream); c->has_token = false; c->lgroup->gpu_token.unlock(); } } } } token(c);
     auto t0 = std::chrono::steady_clock::now();
     int rc = reset_state(c); if (rc) return rc;
-    if (c->far_B > 0) hipMemsetAsync(c->W.pc_stat, 0, 4*sizeof(int), c->stream);
+    if (c->far_B > 0) hipMemsetAsync(c->W.pc_stat, 0, 8*sizeof(int), c->stream);
     for (int ps = 0; ps < o.n_passes; ps++) {
         if (!c->lev_built[o.levels[ps]]) {            // a level the upload left for now (one-shot call on a small window): its plan is ready or nearly so
             if (!c->stage_p) { set_err(c, "level not staged"); return TSBA_ERR_STATE; }
@@ -1246,6 +1253,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
                 const unsigned long long w = *(volatile unsigned long long *)c->hprog;
                 if ((unsigned int)(w >> 32) == c->W.pass_seq) { if (w & 1) return true; if ((int)((w & 0xffffffffu) >> 1) + 2 > it) break; }
                 else if (it < 2) break;                              // the device has not reached this pass yet
+                PlanPool::cpu_relax();
                 if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(2)) break;   // never hang on it
             }
             return false;
@@ -1287,6 +1295,8 @@ int tsba_solve(void *ctx, tsba_report *r) {
         }
     }
     CK(hipMemcpyAsync(c->st_host, c->st_log, sizeof(LmState)*o.n_passes, hipMemcpyDeviceToHost, c->stream));
+    int *pcg_host = (int *)(c->st_host + TSBA_MAX_LEVELS);          // (the pinned block has room for 8 ints behind the pass snapshots)
+    if (c->far_B > 0) CK(hipMemcpyAsync(pcg_host, c->W.pc_stat, 8*sizeof(int), hipMemcpyDeviceToHost, c->stream));
     CK(hipStreamSynchronize(c->stream));
     CK(hipGetLastError());
     if (!c->err.empty() && c->err.rfind("ncclAllReduce", 0) == 0) return TSBA_ERR_COMM;
@@ -1305,6 +1315,11 @@ int tsba_solve(void *ctx, tsba_report *r) {
         prev_lin = s.n_lin; prev_cost = s.n_cost;
         if (s.term == 5) r->status = TSBA_ERR_NUMERIC;
     }
+    { int use_lds; solve_lds_bytes(c, &use_lds); const LevelDev &Dl = c->lev[o.levels[o.n_passes - 1]];
+      r->solver_path = (c->pose_only && !is_multi(c)) ? TSBA_SOLVER_POSE : use_lds ? TSBA_SOLVER_LDS
+          : Dl.far_B > 0 ? (Dl.n_wb > 0 && ms_available(c) && c->dbg.far_solver != 3 ? TSBA_SOLVER_BAND_LOWRANK : TSBA_SOLVER_BAND_PCG)
+          : !c->band_stream ? TSBA_SOLVER_DENSE : c->band_parts <= 1 ? TSBA_SOLVER_BAND : c->W.ring ? TSBA_SOLVER_RING : c->sep_cr ? TSBA_SOLVER_BAND_CR : TSBA_SOLVER_BAND_PART; }
+    if (c->far_B > 0) { r->pcg_iterations = pcg_host[0]; r->pcg_systems = pcg_host[1]; r->pcg_max_iterations = pcg_host[2]; r->pcg_unconverged = pcg_host[3]; r->pcg_stagnated = pcg_host[4]; }
     return TSBA_OK;
 }
 

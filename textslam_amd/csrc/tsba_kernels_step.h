@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
         cost = sc[0]; xn_c = sc[1] + xp; step2 = sc[2]; mcc = sc[3]; gmax_c = fmax(W.cbm[0], gp);
     }
     if (tid) return;
+    st->lin_done = 0;                             // (the iterative reduced-system solve of this trial is over: tsba_pcg.h)
     double verdict = 0.0;                         // trace: 1 accepted / 0 rejected / -1 invalid step / 2 tolerance exit on this trial
     [&]() {
     mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)

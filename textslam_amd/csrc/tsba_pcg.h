@@ -82,14 +82,17 @@ __global__ __launch_bounds__(64*PCG_MW) void k_pcg_matvec(Work W, LevelDev L, in
     for (int k = lane + 256; k < nrz; k += 64) rzs += W.pc_part[rz_off + k];       // (more than 256 partial sums: not with today's sizes)
     const double rz = wave_sum1(rzs);
     const double rz0 = it == 0 ? rz : so_rz0, rz_old = so_rz;
-    if (!(rz == rz)) { if (blockIdx.x == 0 && tid == 0) { st->step_fail = 1; pcg_publish(W, seq, it, 1); } return; }
+    if (!(rz == rz) || rz < 0.0) {                       // NaN, or r.M^-1 r < 0: the preconditioner is numerically indefinite -- a failed linear solve, the LM loop raises the damping
+        if (blockIdx.x == 0 && tid == 0) { st->step_fail = 1; W.pc_stat[5] += 1; pcg_publish(W, seq, it, 1); } return; }
     // where M is so ill-conditioned that the tolerance lies below the rounding noise of M^-1 r (weakly damped trials of maps with loop closures:
     // the drift modes) r.z stops falling: 40 iterations without a gain of a tenth (r.z of conjugate gradients is not monotone: plateaus of a dozen
     // iterations occur on the way down) end the solve with what it has -- the LM step test judges it
     const double best_o = it == 0 ? rz : so_best; const int since_o = so_since;
     const bool gain = rz < 0.9*best_o; const double best = gain ? rz : best_o; const int since = gain ? 0 : since_o + 1;
     if (!(rz > tol2*rz0) || since >= 40) {                   // converged (every workgroup takes the same decision from the same partials)
-        if (blockIdx.x == 0 && tid == 0) { st->lin_done = 1; W.pc_stat[0] += it; W.pc_stat[1] += 1; if (it > W.pc_stat[2]) W.pc_stat[2] = it; pcg_publish(W, seq, it, 1); }
+        if (blockIdx.x == 0 && tid == 0) { st->lin_done = 1; W.pc_stat[0] += it; W.pc_stat[1] += 1; if (it > W.pc_stat[2]) W.pc_stat[2] = it;
+            if (rz > tol2*rz0) W.pc_stat[4] += 1;          // ended by stagnation at the attainable accuracy, not by the tolerance
+            pcg_publish(W, seq, it, 1); }
         return; }
     const double beta = it == 0 ? 0.0 : rz/rz_old;
     if (blockIdx.x == 0 && tid == 0) { sn->rz = rz; sn->rz0 = rz0; sn->best = best; sn->since = since; sn->it = it; pcg_publish(W, seq, it, 0); }
@@ -197,19 +200,21 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_dot(Work W, const double *zp, do
     pcg_block_partial<PCG_ET>(rzp, W.pc_part, lds);
 }
 
-// dp = x by keyframe (0 for constant poses / failed steps), g restored, the trial's flag cleared
+// dp = x by keyframe (0 for constant poses / failed steps), g restored.  A solve that ran into the iteration cap without converging is a FAILED
+// linear solve: the reference's sparse Cholesky either solves the system or the step is invalid (Ceres: LINEAR_SOLVER_FAILURE -> the trust region
+// shrinks; optimizer.cc:1833-1845) -- the trial is flagged step_fail, k_decide halves the radius, and the count goes to tsba_report.pcg_unconverged.
+// (lin_done is cleared by k_decide: every workgroup of this kernel reads it.)
 __global__ __launch_bounds__(PCG_ET) void k_pcg_finish(Work W, int its_enqueued) {
     LmState *st = W.st;
     if (st->done) return;
     const int tid = threadIdx.x, a = blockIdx.x*32 + tid/6, k = tid % 6;
-    const int fail = st->step_fail, conv = st->lin_done;
+    const int conv = st->lin_done, fail0 = st->step_fail, fail = fail0 | !conv;
     if (a < W.n_kf) { const int ia = W.fidx[a];
         W.dp[6*a + k] = (ia >= 0 && !fail) ? W.pc_x[6*ia + k] : 0.0;
-        if (ia >= 0 && !fail) W.g[6*ia + k] = W.pc_g0[6*ia + k]; }
-    __syncthreads();                                         // (every thread of workgroup 0 has read the flag)
-    if (blockIdx.x == 0 && tid == 0) {
-        if (!conv && !fail) { W.pc_stat[0] += its_enqueued; W.pc_stat[1] += 1; W.pc_stat[3] += 1; if (its_enqueued > W.pc_stat[2]) W.pc_stat[2] = its_enqueued; }
-        st->lin_done = 0; }
+        if (ia >= 0 && !fail0) W.g[6*ia + k] = W.pc_g0[6*ia + k]; }
+    if (blockIdx.x == 0 && tid == 0 && !conv && !fail0) {
+        W.pc_stat[0] += its_enqueued; W.pc_stat[1] += 1; W.pc_stat[3] += 1; if (its_enqueued > W.pc_stat[2]) W.pc_stat[2] = its_enqueued;
+        st->step_fail = 1; }
 }
 
 // =====================================================================================================================================
