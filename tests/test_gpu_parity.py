@@ -368,3 +368,30 @@ def test_theta_optim_singular_information_is_not_an_error(gpu):
     assert rep["cov_valid"] == 0 and rep["status"] == 0 and np.array_equal(cov, prev)
     rep, cov = gpu.ThetaOptimMultiFs(P.copy(), text=0, options=abi.options_theta(), cov0=prev)
     assert rep["cov_valid"] == 1 and np.all(np.linalg.eigvalsh(cov) > 0)
+
+
+@pytest.mark.parametrize("n_kf", [4, 5, 7, 20, 31])
+def test_small_window_solver_schedules_agree(gpu, n_kf):
+    """The reduced system of a small window through its two schedules (tsba_debug_options.solve_variant): the production kernel (two panel waves:
+    look-ahead, 6x6 LDL^T and panel solve on the same wave) and the round-4 experiment with a separate wave that factors the next diagonal block
+    while the panel is solved (tsba_solve_la.h; measured slower, kept for A/B runs) -- same LM trajectory, first step to 1e-11.  1, 2, 4, 17 and
+    28 free poses (the LOCAL gauge fixes three keyframes)."""
+    P = synth.config_c4() if n_kf == 20 else synth.make_problem(n_kf=n_kf, n_pt=60*n_kf, n_text=max(2, n_kf//2), seed=40 + n_kf, feats=(16, 8, 6))
+    o = abi.options_local()
+    runs = []
+    try:
+        for var in (0, 1, 2):
+            gpu.debug_set(solve_variant=var)
+            gpu.upload(P, o)
+            rs = gpu.reduced_system(o.initial_radius)
+            rep = gpu.solve(); G = gpu.download(P.copy())
+            runs.append((rs["dp"].copy(), rep, G))
+    finally:
+        gpu.debug_set()
+    ref = runs[0]
+    assert np.abs(ref[0]).max() > 0
+    for dp, rep, G in runs[1:]:
+        assert np.abs(dp - ref[0]).max() <= 1e-11*np.abs(ref[0]).max()
+        assert rep["iters"] == ref[1]["iters"] and rep["accepted"] == ref[1]["accepted"] and rep["termination"] == ref[1]["termination"]
+        np.testing.assert_allclose(rep["cost1"], ref[1]["cost1"], rtol=1e-10)
+        np.testing.assert_allclose(G.pose, ref[2].pose, rtol=0, atol=1e-9)

@@ -37,6 +37,7 @@
 #include "tsba_kernels_lin.h"
 #include "tsba_kernels_schur.h"
 #include "tsba_solve.h"
+#include "tsba_solve_la.h"
 #include "tsba_chol.h"
 #include "tsba_band.h"
 #include "tsba_bandp.h"
@@ -816,7 +817,8 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
 static int set_solver_attrs(Ctx *c) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (use_lds) { CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipFuncSetAttribute((const void *)k_solve_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(solve_la_lds_doubles(c->W.N)*sizeof(double), 160*1024 - 64))); }
     else {
         CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -855,7 +857,11 @@ static void launch_dense_chol(Ctx *c, Work &W, int bw);
 static void launch_solve(Ctx *c) {
     Work &W = c->W;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) { hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0); return; }
+    if (use_lds) {                                  // small windows: one workgroup, S in LDS.  solve_variant 1: the two-panel-wave schedule of tsba_solve.h (A/B runs)
+        const size_t la = solve_la_lds_doubles(W.N)*sizeof(double);
+        if ((c->dbg.solve_variant == 1 || c->dbg.solve_variant == 2) && la <= 160*1024 - 64) hipLaunchKernelGGL(k_solve_la, dim3(1), dim3(SOLVE_THREADS), (int)la, c->stream, W, c->dbg.solve_variant == 2 ? 0 : 1);
+        else hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);
+        return; }
     if (c->band_stream && c->band_parts > 1) {      // partitioned: interiors in parallel + separator system (tsba_bandp.h)
         const int bwp = std::max(6, c->cur_bw_rows), cbp = bandp_chunk_blocks(bwp), P = c->band_parts;
         const int bwsep = 2*bwp - 6, cbs = band_chunk_blocks(bwsep);
@@ -1559,6 +1565,13 @@ int tsba_debug_stamps(void *ctx, long long *out64) {
     hipSetDevice(c->device); hipStreamSynchronize(c->stream);
     return hipMemcpy(out64, c->W.dbg, 64*sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
 }
+#ifdef TSBA_SOLVE_STAMPS
+int tsba_debug_step_stamps(void *ctx, long long *out128) {      // stamps build only: per factorisation step of the last k_solve_t launch
+    Ctx *c = (Ctx *)ctx; if (!c) return TSBA_ERR_ARG;
+    hipSetDevice(c->device); hipStreamSynchronize(c->stream);
+    return hipMemcpyFromSymbol(out128, HIP_SYMBOL(ts_step_stamps), 128*sizeof(long long)) == hipSuccess ? 0 : TSBA_ERR_DEVICE;
+}
+#endif
 
 static int load_rccl(Ctx *c) {
     if (c->rccl_so) return 0;

@@ -21,6 +21,7 @@
 #define SOLVE_PW 2                          // panel waves
 #define SOLVE_PROWS (64 - 6)                // panel rows per wave and chunk
 #ifdef TSBA_SOLVE_STAMPS                    // make stamps: cycle stamps into W.dbg (tsba_debug_stamps), perturbs the timing
+__device__ long long ts_step_stamps[4*32];  // per factorisation step: panel wave 0 (load+apply | ldl | solve), update wave 2 (tiles)
 #define STAMP(v) do { long long t_ = clock64(); v += t_ - tx; tx = t_; } while (0)
 #else
 #define STAMP(v) do { } while (0)
@@ -228,6 +229,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
 #endif
     for (int jb = 0; jb < nfree && !fail; jb++) {
         const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
+#ifdef TSBA_SOLVE_STAMPS
+        const long long tx0_ = clock64();
+#endif
         if (wave < SOLVE_PW) {
             double Lk[36], dprev[6];
             if (jb > 0) {
@@ -258,6 +262,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
             if (lane < 6) st6(scr + wave*36 + lane*6, a);
             wave_lds_fence();
             STAMP(ta);
+#ifdef TSBA_SOLVE_STAMPS
+            const long long sa_ = clock64();
+#endif
             double s[21], l[15], d[6], id[6]; bool bad = false;
             {
                 double t[36];
@@ -277,6 +284,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
                 if (bad) { fail = 1; st->step_fail = 1; }
             }
             STAMP(tb);
+#ifdef TSBA_SOLVE_STAMPS
+            const long long sb_ = clock64();
+#endif
             auto solve_row = [&](int i, double a[6]) {           // x L^T = a (right-looking: 5-deep chain), stored row = x D^-1
 #pragma unroll
                 for (int c = 0; c < 5; c++)
@@ -290,6 +300,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
                 if (i0 <= n) solve_row(i0, a);
                 for (int i = i0 + SOLVE_PW*SOLVE_PROWS; i <= n; i += SOLVE_PW*SOLVE_PROWS) { load_row(i, a); solve_row(i, a); }
             }
+#ifdef TSBA_SOLVE_STAMPS
+            if (!DIAG && wave == 0 && lane == 0 && jb < 32) { const long long se_ = clock64(); ts_step_stamps[jb] = sa_ - tx0_; ts_step_stamps[32 + jb] = sb_ - sa_; ts_step_stamps[64 + jb] = se_ - sb_; }
+#endif
             if (wave == 1 && jb == nfree - 1) {                  // inverse factor of the last block (the others: last T wave)
                 double m[15];
                 inv_unit_lower6(l, m);
@@ -343,6 +356,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
             }
         }
         STAMP(tc);
+#ifdef TSBA_SOLVE_STAMPS
+        if (!DIAG && lane == 0 && jb < 32) { const long long se_ = clock64();
+            if (wave == 2) ts_step_stamps[3*32 + jb] = se_ - tx0_; }
+#endif
         __syncthreads();                       // panel jb complete, trailing update with panel jb-1 complete
         STAMP(td);
     }

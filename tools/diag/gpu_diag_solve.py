@@ -5,6 +5,7 @@ from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 
 opt = Optimizer(0)
+opt.debug_set(solve_variant=int(os.environ.get("SOLVE_VARIANT", "0")))
 P = synth.config_c4(); o = abi.options_local()
 opt.upload(P, o)
 for _ in range(3):
@@ -22,3 +23,10 @@ ms = ctypes.c_double()
 opt.lib.tsba_debug_time_solve.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
 rc = opt.lib.tsba_debug_time_solve(opt.ctx, 200, ctypes.byref(ms))
 print("k_solve back-to-back: rc %d, %.2f us per launch" % (rc, ms.value*1e3))
+
+if hasattr(opt.lib, "tsba_debug_step_stamps"):
+    ss = (ctypes.c_longlong * 128)()
+    opt.lib.tsba_debug_step_stamps(opt.ctx, ss)
+    print("per step (cycles): jb | P0 load+apply+scratch (D: apply+solve) | P0 scratch-read+ldl (D: diag update) | P0 solve+store (D: ldl) | T wave2 tiles; P wave (look-ahead schedule) steps 0-3:", list(st[44:48]))
+    for jb in range(int(st[6]) or 17):
+        print("   %2d | %5d | %5d | %5d | %5d" % (jb, ss[jb], ss[32 + jb], ss[64 + jb], ss[96 + jb]))
