@@ -493,7 +493,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         LinBuf &B = W.lb[b];
         AL(B.pairM, 27*mx_pair); AL(B.pairCost, mx_pair); AL(B.pairR, 9*mx_pair); AL(B.pairOut, 90*mx_pair);
         AL(B.tgM, 27*mx_tg); AL(B.tgCost, mx_tg);
-        AL(B.w_pt, PT_REC*mx_pslot); AL(B.V_pt, p->n_pt); AL(B.b_pt, p->n_pt); AL(B.dgs_pt, p->n_pt);
+        AL(B.w_pt, PT_REC*mx_pslot); AL(B.vdb_pt, PT_VDB*(size_t)p->n_pt);
         AL(B.w_tx, TX_REC*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
         AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.bp_loc, W.N); AL(B.dgs_p, W.N);
         AL(B.lmpart, 3*((size_t)c->nb_back_max + mx_pair/256 + 2));
@@ -796,10 +796,9 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
 }
 static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
     if (c->n_kf > 126 && !c->dbg.no_schur_quad) {               // large maps: four S blocks per wave, then one wave per pose for the reduced gradient
-        if (D.n_sb > 0) { const int nq = (((D.n_sb + 3)/4 + 7)/8)*8;           // (a multiple of 8 workgroups: the kernel's XCD-aware block mapping)
-            if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, D, multi);
-            else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, D, multi); }
-        hipLaunchKernelGGL(k_schur_t<1>, dim3(((c->n_kf + 7)/8)*8), dim3(64), 0, c->stream, c->W, D, multi, D.n_sb);
+        const int nq = D.n_sb > 0 ? (((D.n_sb + 3)/4 + 7)/8)*8 : 0, ng = ((c->n_kf + 7)/8)*8;           // (multiples of 8 workgroups: the kernel's XCD-aware mappings)
+        if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq + ng), dim3(64), 0, c->stream, c->W, D, multi, nq, ng);
+        else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq + ng), dim3(64), 0, c->stream, c->W, D, multi, nq, ng);
     } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0);
     else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0);
     if (D.far_B > 0 && D.n_far > 0) {            // the blocks of E (what couples different clusters of a landmark): the same kernels on the fb_* lists, stored to W.Sfar
@@ -808,8 +807,8 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
         E.sb_pt_off = D.fb_pt_off; E.sb_pt_s1 = D.fb_pt_s1; E.sb_pt_s2 = D.fb_pt_s2; E.sb_pt_lm = D.fb_pt_lm;
         E.sb_tx_off = D.fb_tx_off; E.sb_tx_s1 = D.fb_tx_s1; E.sb_tx_s2 = D.fb_tx_s2; E.sb_tx_lm = D.fb_tx_lm;
         if (c->n_kf > 126 && !c->dbg.no_schur_quad) { const int nq = (((E.n_sb + 3)/4 + 7)/8)*8;
-            if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi);
-            else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi); }
+            if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi, nq, 0);
+            else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi, nq, 0); }
         else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(E.n_sb), dim3(64), 0, c->stream, c->W, E, multi, 0);
         else hipLaunchKernelGGL(k_schur_t<4>, dim3(E.n_sb), dim3(256), 0, c->stream, c->W, E, multi, 0);
     }

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, Level
                 else if (sub + 16 == 27) B.pairCost[pr] = t1;
                 if (h >= 0 && sub == 0) {
 #pragma unroll
-                    for (int k = 0; k < 9; k++) B.pairR[(size_t)k*L.n_pair + pr] = T.Rcr[k];
+                    for (int k = 0; k < 9; k++) PAIRR(B, pr, k, L.n_pair) = T.Rcr[k];      // [pair][9]: k_mid reads a pair's rotation per landmark slot -- nine scattered loads with [9][pair]
                 }
             }
         } else {
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, Level
                 else if (lane == 27) B.pairCost[pr] = tot;
                 if (h >= 0 && lane == 0) {
 #pragma unroll
-                    for (int k = 0; k < 9; k++) B.pairR[(size_t)k*L.n_pair + pr] = T.Rcr[k];
+                    for (int k = 0; k < 9; k++) PAIRR(B, pr, k, L.n_pair) = T.Rcr[k];      // [pair][9]: k_mid reads a pair's rotation per landmark slot -- nine scattered loads with [9][pair]
                 }
             }
         }
@@ -658,7 +658,6 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
     const int sel = spec ? (st->cur ^ 1) : st->cur;
     __shared__ double red[256];
     const double *rho_x = W.rho[sel], *theta_x = W.theta[sel];
-    const size_t np_ = L.n_pair;
     double gm = 0.0, xn = 0.0, cs = 0.0;                        // cs: cost of this thread's pair and of its text groups
     if (b < nb_pt) {
         const int j = b*256 + threadIdx.x;
@@ -673,7 +672,7 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
 #pragma unroll
                     for (int k = 0; k < 8; k++) v[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 2))*PT_REC + k];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) R[u][k] = B.pairR[(size_t)k*np_ + pr[u]];
+                    for (int k = 0; k < 9; k++) R[u][k] = PAIRR(B, pr[u], k, L.n_pair);
                 }
 #pragma unroll
                 for (int u = 0; u < MID_U; u++) if (s0 + u < e - 1) {
@@ -686,10 +685,9 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
 #pragma unroll
             for (int k = 0; k < 6; k++) B.w_pt[(size_t)(e - 1)*PT_REC + k] = acc[2 + k];
             const double V = acc[0];
-            B.V_pt[j] = V; B.b_pt[j] = acc[1];
             if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
             const double sg = W.sig_pt[j];
-            B.dgs_pt[j] = clampd(sg*sg*V, W.min_diag, W.max_diag)/(sg*sg);
+            VDB_STORE(B, j, W.n_pt, V, clampd(sg*sg*V, W.min_diag, W.max_diag)/(sg*sg), acc[1]);
             if (act_) { gm = fabs(acc[1]); xn = rho_x[j]*rho_x[j]; }
         }
     } else if (b < nb_pt + nb_tx) {
@@ -707,7 +705,7 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
 #pragma unroll
                     for (int k = 0; k < 27; k++) v[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 2))*TX_REC + k];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) R[u][k] = B.pairR[(size_t)k*np_ + pr[u]];
+                    for (int k = 0; k < 9; k++) R[u][k] = PAIRR(B, pr[u], k, L.n_pair);
                 }
 #pragma unroll
                 for (int u = 0; u < 2; u++) if (s0 + u < e - 1) {
@@ -762,7 +760,7 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
                 const int hp = hp_;                        // rows 63..89 are stored host-major
                 double R[9];
 #pragma unroll
-                for (int k = 0; k < 9; k++) R[k] = B.pairR[(size_t)k*L.n_pair + p];
+                for (int k = 0; k < 9; k++) R[k] = PAIRR(B, p, k, L.n_pair);
                 double Mf[36];
 #pragma unroll
                 for (int r = 0; r < 6; r++)

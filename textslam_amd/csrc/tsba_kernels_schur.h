@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             double w1[SCHUR_U][6], w2[SCHUR_U][6], Vv[SCHUR_U], dg[SCHUR_U];
 #pragma unroll
             for (int u = 0; u < SCHUR_U; u++) {
-                Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
+                VDB_LOAD(B, j[u], W.n_pt, Vv[u], dg[u]);
 #pragma unroll
                 for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
             }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             double w[SCHUR_U][6], bb[SCHUR_U], Vv[SCHUR_U], dg[SCHUR_U];
 #pragma unroll
             for (int u = 0; u < SCHUR_U; u++) {
-                bb[u] = B.b_pt[j[u]]; Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
+                VDB_LOADB(B, j[u], W.n_pt, Vv[u], dg[u], bb[u]);
 #pragma unroll
                 for (int k = 0; k < 6; k++) w[u][k] = B.w_pt[(size_t)(s[u])*PT_REC + k];
             }
@@ -192,16 +192,68 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
 #endif
 // TEXT = false: a level without text planes (the reference's GlobalBA) -- the plane part (3x3 inverse, 18-value records) sets the kernel's
 // register count (214: two waves per SIMD); without it three fit.
+// The reduced gradient of one pose by one wave (the gradient branch of k_schur_t<1>): g_a = b_a - sum_j W_aj (V_j + lambda_j)^-1 b_j over the pose's slots.
 template <bool TEXT>
-__global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi) {
+__device__ __forceinline__ void schur_grad_wave(const Work &W, const LevelDev &L, LmState *st, const LinBuf &B, double irad, int multi, int a, int lane) {
+    const int ia = W.fidx[a];
+    if (ia < 0) return;
+    double acc[6] = {0,0,0,0,0,0};
+    const int ps0 = L.pose_ps_off[a], ps1 = L.pose_ps_off[a+1];
+    for (int base = ps0; base < ps1; base += 64*SCHUR_U) {
+        int s[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
+#pragma unroll
+        for (int u = 0; u < SCHUR_U; u++) { const int q = base + u*64 + lane; ok[u] = q < ps1; const int qc = min(q, ps1 - 1); s[u] = L.pose_ps[qc]; j[u] = L.pose_ps_lm[qc]; }
+        double w[SCHUR_U][6], bb[SCHUR_U], Vv[SCHUR_U], dg[SCHUR_U];
+#pragma unroll
+        for (int u = 0; u < SCHUR_U; u++) {
+            VDB_LOADB(B, j[u], W.n_pt, Vv[u], dg[u], bb[u]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) w[u][k] = B.w_pt[(size_t)(s[u])*PT_REC + k];
+        }
+#pragma unroll
+        for (int u = 0; u < SCHUR_U; u++) {
+            const double f = ok[u] ? bb[u]*ts_rcp(Vv[u] + dg[u]*irad) : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc[k] += w[u][k]*f;
+        }
+    }
+    if (TEXT) for (int q = L.pose_ts_off[a] + lane; q < L.pose_ts_off[a+1]; q += 64) {
+        const int s = L.pose_ts[q], j = L.pose_ts_lm[q];
+        double Vd[6], Vi[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+        Vd[0] += B.dgs_tx[j]*irad; Vd[3] += B.dgs_tx[(size_t)W.n_text + j]*irad; Vd[5] += B.dgs_tx[(size_t)2*W.n_text + j]*irad;
+        if (!inv_sym3(Vd, Vi)) { st->step_fail = 1; continue; }
+        double b0 = B.b_tx[j], b1 = B.b_tx[(size_t)W.n_text + j], b2 = B.b_tx[(size_t)2*W.n_text + j];
+        double f0 = Vi[0]*b0 + Vi[1]*b1 + Vi[2]*b2, f1 = Vi[1]*b0 + Vi[3]*b1 + Vi[4]*b2, f2 = Vi[2]*b0 + Vi[4]*b1 + Vi[5]*b2;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            acc[k] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*f0 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*f1 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*f2;
+    }
+    const double bpv = lane < 6 ? (multi ? B.bp_loc[6*a + lane] : B.bp[6*a + lane]) : 0.0;
+    double mine = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const double sk = wave_sum1(acc[k]); if (lane == k) mine = sk; }
+    if (lane < 6) W.g[6*ia + lane] = bpv - mine;
+}
+
+// grid = nq workgroups for the S blocks (four per wave) + ng for the reduced gradient (one pose per wave), both multiples of 8: blocks and gradient
+// are independent, and as two launches the second (22 us at 5000 keyframes) waited for the first (85 us)
+template <bool TEXT>
+__global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi, int nq, int ng) {
     LmState *st = W.st;
     if (st->done) return;
     __shared__ double lds[4*12*17];                             // a third of a group's 36 sums at a time: 6.5 KB, the registers set the occupancy
+    if ((int)blockIdx.x >= nq) {                                // gradient part: the workgroups of ONE XCD take neighbouring poses (as k_schur_t with b0 > 0)
+        const int i = (int)blockIdx.x - nq, a = (i & 7)*(ng >> 3) + (i >> 3);
+        if (a < W.n_kf) schur_grad_wave<TEXT>(W, L, st, W.lb[st->lcur], 1.0/st->radius, multi, a, (int)threadIdx.x);
+        return;
+    }
     const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
     // workgroups are handed to the 8 XCDs round-robin (workgroup i -> XCD i mod 8), and an XCD's L2 does not see the others': neighbouring S
     // blocks read the same landmarks' records, so the workgroups of ONE XCD take a contiguous range of blocks (the kernel is bound by
     // L2 -> L1 line fills; with neighbouring blocks on eight different XCDs every record crossed the fabric up to eight times)
-    const int per = (int)gridDim.x >> 3, wg = ((int)blockIdx.x & 7)*per + ((int)blockIdx.x >> 3);     // (the grid is a multiple of 8 workgroups)
+    const int per = nq >> 3, wg = ((int)blockIdx.x & 7)*per + ((int)blockIdx.x >> 3);     // (nq is a multiple of 8 workgroups)
     const int b = 4*wg + grp;
     const bool have = b < L.n_sb;
     const int bc = have ? b : L.n_sb - 1;
@@ -225,7 +277,7 @@ __global__ __launch_bounds__(64) void k_schur_quad(Work W, LevelDev L, int multi
         double w1[SCHURQ_U][6], w2[SCHURQ_U][6], Vv[SCHURQ_U], dg[SCHURQ_U];
 #pragma unroll
         for (int u = 0; u < SCHURQ_U; u++) {
-            Vv[u] = B.V_pt[j[u]]; dg[u] = B.dgs_pt[j[u]];
+            VDB_LOAD(B, j[u], W.n_pt, Vv[u], dg[u]);
 #pragma unroll
             for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
         }

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
         if (j < W.n_pt) {
             double rh = W.rho[cur][j], d = 0.0;
             if (!fail && e > o && act_) {
-                double acc = B.b_pt[j];
+                double Vj, Dj, bj; VDB_LOADB(B, j, W.n_pt, Vj, Dj, bj);
+                double acc = bj;
                 for (int s0 = o; s0 < e; s0 += 6) {                                 // 6 slots in flight; dp is 0 for constant / absent poses
                     int a[6]; double w[6][6], dpv[6][6];
 #pragma unroll
@@ -36,9 +37,9 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
 #pragma unroll
                         for (int k = 0; k < 6; k++) acc += s0 + u < e ? w[u][k]*dpv[u][k] : 0.0;
                 }
-                const double lam = B.dgs_pt[j]*irad;
-                d = -acc/(B.V_pt[j] + lam);
-                step2 = d*d; mcc = lam*d*d - B.b_pt[j]*d;
+                const double lam = Dj*irad;
+                d = -acc/(Vj + lam);
+                step2 = d*d; mcc = lam*d*d - bj*d;
             }
             W.rho[cur ^ 1][j] = rh + d;
         }

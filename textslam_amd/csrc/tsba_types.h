@@ -1,5 +1,6 @@
 // Device-side structs of libtsba.so: LM state, per-level plan views, linearisation buffers, work buffers.  (part of the single translation unit tsba.hip: included there, in this order)
 #pragma once
+typedef double v2d __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------ device structs
 struct LmState {
     double radius, decrease_factor, x_cost, x_norm, cand_cost, model_change, step_norm, gmax, cost0;
@@ -31,12 +32,29 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
 
 #define TSBA_TRACE_CAP 64
 #define PT_REC 8
+#define PT_VDB 4
+// layout experiments (A/B builds): -DTSBA_VDB_SOA keeps V | dgs | b as three arrays [3][n_pt], -DTSBA_PAIRR_SOA keeps the pair rotations as [9][n_pair]
+#ifdef TSBA_VDB_SOA
+#define VDB_LOAD(B, j, npt, V_, D_) do { V_ = (B).vdb_pt[(size_t)(j)]; D_ = (B).vdb_pt[(size_t)(npt) + (j)]; } while (0)
+#define VDB_LOADB(B, j, npt, V_, D_, B_) do { V_ = (B).vdb_pt[(size_t)(j)]; D_ = (B).vdb_pt[(size_t)(npt) + (j)]; B_ = (B).vdb_pt[2*(size_t)(npt) + (j)]; } while (0)
+#define VDB_STORE(B, j, npt, V_, D_, B_) do { (B).vdb_pt[(size_t)(j)] = V_; (B).vdb_pt[(size_t)(npt) + (j)] = D_; (B).vdb_pt[2*(size_t)(npt) + (j)] = B_; } while (0)
+#else
+#define VDB_LOAD(B, j, npt, V_, D_) do { const v2d vd_ = *(const v2d *)((B).vdb_pt + PT_VDB*(size_t)(j)); V_ = vd_.x; D_ = vd_.y; } while (0)
+#define VDB_LOADB(B, j, npt, V_, D_, B_) do { const double *rec_ = (B).vdb_pt + PT_VDB*(size_t)(j); const v2d vd_ = *(const v2d *)rec_; V_ = vd_.x; D_ = vd_.y; B_ = rec_[2]; } while (0)
+#define VDB_STORE(B, j, npt, V_, D_, B_) do { double *rec_ = (B).vdb_pt + PT_VDB*(size_t)(j); ((v2d *)rec_)[0] = v2d{V_, D_}; rec_[2] = B_; } while (0)
+#endif
+#ifdef TSBA_PAIRR_SOA
+#define PAIRR(B, p, k, np) (B).pairR[(size_t)(k)*(np) + (p)]
+#else
+#define PAIRR(B, p, k, np) (B).pairR[9*(size_t)(p) + (k)]
+#endif
 #define TX_REC 28
 struct LinBuf {              // everything one linearisation produces
     double *pairM, *pairCost, *pairR, *pairOut, *tgM, *tgCost;
     double *w_pt;                       // per point slot, one 64-byte record: w[0..5] | v | b   (PT_REC doubles; the host slot of a landmark
                                         // holds its host column -sum Q^T w in [0..5], formed by k_mid from w and the pair's R_cr)
-    double *V_pt, *b_pt, *dgs_pt;       // per point: V, b, clamp(sigma^2 V)/sigma^2  (lambda = dgs / radius)
+    double *vdb_pt;                     // per point ONE 32-byte record: V | clamp(sigma^2 V)/sigma^2 (lambda = that / radius) | b | -   (three separate arrays were three gathers
+                                        // per slot pair in the Schur kernels, which are bound by the number of lines they pull)
     double *w_tx;                       // per plane slot, one 224-byte record: W[0..17] | V6 [18..23] | b3 [24..26]   (TX_REC doubles)
     double *V_tx, *b_tx, *dgs_tx;       // per plane: V [6][n], b [3][n], dgs [3][n]
     double *Hd, *bp, *dgs_p;            // per pose: diag(H_pp), gradient, dgs.  Hd | bp | scal[8] are one allocation (hb):
