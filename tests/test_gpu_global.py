@@ -458,3 +458,25 @@ def test_multi_gpu_rccl_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["max_pose_diff_vs_single_rank"] <= 1e-9
+
+
+@pytest.mark.parametrize("kw", [dict(n_kf=600, n_pt=12000, band=8), dict(n_kf=900, n_pt=18000, band=9, loop=True), dict(n_kf=900, n_pt=18000, band=8, closures=2),
+                                dict(n_kf=700, n_pt=14000, band=8, far_frac=0.02), dict(n_kf=1500, n_pt=30000, band=7, loop=True, loop_at=300)])
+def test_schur_lists_built_on_the_device_equal_the_host_lists(gpu, kw):
+    """Large maps build the slot pairs of the S blocks on the device (csrc/tsba_devplan.h: a wave per block walks pose a's slots and looks for pose b among
+    each landmark's slots) instead of in two host passes over 2 M pairs.  Same entries in the same (landmark) order, so the Schur sums -- and with them the
+    whole solve -- are bit-identical to the host-built lists: open chain, ring, ring with a tail, two closures and scattered long-range points (the
+    band / long-range split restricts the pairs to one cluster of a landmark)."""
+    P = synth.config_global(**kw)
+    o = abi.options_global(); o.its[0] = 6
+    try:
+        gpu.debug_set(host_pair_lists=1, far_solver=2 if (kw.get("far_frac") or kw.get("closures")) else 0)
+        G1 = P.copy(); r1 = gpu.GlobalBA(G1, options=o); i1 = gpu.solver_info()
+        gpu.debug_set(far_solver=2 if (kw.get("far_frac") or kw.get("closures")) else 0)
+        G2 = P.copy(); r2 = gpu.GlobalBA(G2, options=o); i2 = gpu.solver_info()
+    finally:
+        gpu.debug_set()
+    assert i1 == i2 and i1["band_storage"] == 1, (i1, i2)
+    assert r1["iters"] == r2["iters"] and r1["accepted"] == r2["accepted"] and r1["cost0"] == r2["cost0"] and r1["cost1"] == r2["cost1"]
+    assert np.array_equal(G1.pose, G2.pose) and np.array_equal(G1.rho, G2.rho)
+    assert r1["cost1"][0] < 0.5*r1["cost0"][0]

@@ -51,6 +51,7 @@
 #include "tsba_pose.h"
 
 #include "tsba_kernels_step.h"
+#include "tsba_devplan.h"
 // ------------------------------------------------------------------------------------------------ host side
 static int pose_grid(const LevelDev &D) { return std::max(1, (D.n_sc + 255)/256 + (D.n_pf + 31)/32); }    // workgroups of k_pose_iter
 struct DevBuf {
@@ -383,6 +384,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         // maps with long-range coupling (several loop closures, points seen again much later): band + blocks outside it, preconditioned conjugate gradients
         const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream && (!c->dbg.no_ring || c->dbg.far_solver >= 2)) ? CR_SMAX/6 : 0;     // (no_ring asks for the reordering path)
         const bool far_force = c->dbg.far_solver == 2 || c->dbg.far_solver == 3;
+        const bool dev_pairs = p->n_kf > 126 && !c->dbg.host_pair_lists;      // large maps: the point slot pairs by S block are built on the device (tsba_devplan.h)
         for (int ps = o->n_passes - 1; ps >= 0; ps--) { const int l = o->levels[ps]; if (seen[l]) continue;
             bool later = false; for (int q = 0; q < ps; q++) later |= o->levels[q] == l;       // (a level used by an earlier pass is started with that pass)
             if (later) continue;
@@ -392,8 +394,8 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
             std::atomic<int> *done = &c->plan_done[l];
             // the levels of the later passes first (the largest plans); a deferring call builds the first pass's (small) plan on this thread:
             // it is needed at once, and a thread's start costs as much as that plan
-            if (defer && ps == 0) { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force); done->store(1); continue; }
-            planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max, far_max, far_force, done]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force); done->store(1, std::memory_order_release); }); }
+            if (defer && ps == 0) { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs); done->store(1); continue; }
+            planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs, done]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs); done->store(1, std::memory_order_release); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
 #define UP(dst, src, n) do { rc = dev_upload(c, &(dst), (src), (size_t)(n)); if (rc) return rc; } while (0)
@@ -632,7 +634,15 @@ static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, dou
     if (H.far_B > 0) { UV(far_a); UV(far_b); UV(far_off); UV(far_ent); UV(fb_id); UV(fb_pab); UV(fb_pba); UV(fb_pt_off); UV(fb_pt_s1); UV(fb_pt_s2); UV(fb_pt_lm);
         UV(fb_tx_off); UV(fb_tx_s1); UV(fb_tx_s2); UV(fb_tx_lm); }
     UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
-    UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
+    UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
+    int *dp_off = nullptr, *dp_s1 = nullptr, *dp_s2 = nullptr, *dp_lm = nullptr; const int32_t *dp_cl = nullptr;
+    if (H.dev_pt_pairs >= 0) {                                     // large maps: the point slot pairs by block are built on the device (tsba_devplan.h)
+        rc = dev_alloc(c, &dp_off, (size_t)D.n_sb + 2); if (rc) return rc;
+        const size_t tot = (size_t)std::max<int64_t>(H.dev_pt_pairs, 1);
+        rc = dev_alloc(c, &dp_s1, tot); if (rc) return rc; rc = dev_alloc(c, &dp_s2, tot); if (rc) return rc; rc = dev_alloc(c, &dp_lm, tot); if (rc) return rc;
+        if (!H.cl_pt_dev.empty()) { rc = dev_upload_vec(c, &dp_cl, H.cl_pt_dev); if (rc) return rc; }
+        D.sb_pt_off = dp_off; D.sb_pt_s1 = dp_s1; D.sb_pt_s2 = dp_s2; D.sb_pt_lm = dp_lm;
+    } else { UV(sb_pt_off); UV(sb_pt_s1); UV(sb_pt_s2); UV(sb_pt_lm); }
     UV(pose_t_off); UV(pose_t); UV(pose_h_off); UV(pose_h); UV(pose_ps_off); UV(pose_ps); UV(pose_ps_lm); UV(pose_ts_off); UV(pose_ts); UV(pose_ts_lm);
 #undef UV
     if (p->n_text > 0 && p->tfeat_off[l]) {
@@ -657,6 +667,13 @@ static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, dou
     }
     if (t_img) *t_img += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
     flush_run(c);
+    if (H.dev_pt_pairs >= 0 && D.n_sb > 0) {                       // (after the copies it reads, on the stream they went over)
+        hipStream_t sq = c->stage_async && c->copy_stream ? c->copy_stream : c->stream;
+        hipMemsetAsync(dp_off, 0, sizeof(int)*((size_t)D.n_sb + 2), sq);
+        hipLaunchKernelGGL(k_sb_pairs<0>, dim3(D.n_sb), dim3(64), 0, sq, D.n_sb, D.sb_a, D.sb_b, D.pose_ps_off, D.pose_ps, D.pose_ps_lm, D.pls_off, D.pslot_pose, (const int *)dp_cl, dp_off, dp_s1, dp_s2, dp_lm);
+        hipLaunchKernelGGL(k_sb_scan, dim3(1), dim3(1024), 0, sq, D.n_sb, dp_off);
+        hipLaunchKernelGGL(k_sb_pairs<1>, dim3(D.n_sb), dim3(64), 0, sq, D.n_sb, D.sb_a, D.sb_b, D.pose_ps_off, D.pose_ps, D.pose_ps_lm, D.pls_off, D.pslot_pose, (const int *)dp_cl, dp_off, dp_s1, dp_s2, dp_lm);
+    }
     if (c->stage_async && c->copy_stream && c->ev_stage[l]) { hipEventRecord(c->ev_stage[l], c->copy_stream); c->lev_wait[l] = 1; }      // the level's pass waits for this copy
     c->lev_built[l] = 1;
     return TSBA_OK;

@@ -65,6 +65,10 @@ struct HostPlan {
     std::vector<int32_t> wb_kf, wb_idx;         // the keyframes a block of E touches, when they are few (<= WB_MAXKF_PLAN: loop closures -- the low-rank correction of tsba_wb.h), and every keyframe's index in that list (-1)
     std::vector<int32_t> fb_id, fb_pab, fb_pba, fb_pt_off, fb_pt_s1, fb_pt_s2, fb_pt_lm, fb_tx_off, fb_tx_s1, fb_tx_s2, fb_tx_lm;    // fb_id: 0 .. n_far - 1
     int n_far() const { return (int)far_a.size(); }
+    // Large maps: the slot pairs of the POINT landmarks by S block (sb_pt_off / _s1 / _s2 / _lm: 2 M entries at 5000 keyframes, 9 of the plan's 21 ms
+    // on sixteen host threads) are built on the device by tsba_devplan.h from lists that are uploaded anyway; the host then only counts them.
+    // dev_pt_pairs >= 0: their number (the four host lists stay empty); cl_pt_dev: cluster of every point slot when the band / long-range split is on
+    int64_t dev_pt_pairs = -1; std::vector<int32_t> cl_pt_dev;
     // scene candidates (sorted by pair)
     std::vector<int32_t> sc_obs, sc_kf, sc_pt, sc_flag, sc_slot;
     std::vector<double>  sc_uv;                 // [n_sc][2]
@@ -102,7 +106,7 @@ struct HostPlan {
                                          &pls_off, &pslot_pose, &pslot_pair, &pslot_lm, &tls_off, &tslot_pose, &tslot_pair, &tslot_lm,
                                          &sb_a, &sb_b, &sb_pab, &sb_pba, &sb_pt_off, &sb_pt_s1, &sb_pt_s2, &sb_pt_lm, &sb_tx_off, &sb_tx_s1, &sb_tx_s2, &sb_tx_lm,
                                          &pose_t_off, &pose_t, &pose_h_off, &pose_h, &pose_ps_off, &pose_ps, &pose_ps_lm, &pose_ts_off, &pose_ts, &pose_ts_lm }) v->clear();
-        sc_uv.clear();
+        sc_uv.clear(); dev_pt_pairs = -1; cl_pt_dev.clear();
     }
 };
 
@@ -279,7 +283,7 @@ struct BucketPlacer {
 // far_max_blocks > 0: maps whose envelope no band solver reaches may be split into a band of at most far_max_blocks pose blocks + long-range
 // blocks (HostPlan::far_B); far_force: take the split whenever the map is eligible, without trying the keyframe reordering first
 inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true, int ring_max_blocks = 0,
-                       int far_max_blocks = 0, bool far_force = false) {
+                       int far_max_blocks = 0, bool far_force = false, bool dev_pairs = false) {
     auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!dbg_plan) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[build_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
     P.recycle();
@@ -446,6 +450,14 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         const int n_lm = lo[(size_t)T];
         const size_t n_slot = n_lm > 0 ? (size_t)loff[n_lm] : 0;
         if (n_slot == 0) { off.assign((size_t)n_sb + 1, 0); s1v.clear(); s2v.clear(); lmv.clear(); return; }
+        if (dev_pairs && &off == &P.sb_pt_off) {                       // the device builds these lists (tsba_devplan.h): count only
+            std::vector<int64_t> part((size_t)T, 0);
+            pool.run([&](int t) { int64_t n = 0; range_pairs(loff, pose, cl, lo[t], lo[t+1], [&](int64_t, int, int) { n++; }); part[(size_t)t] = n; });
+            int64_t tot = 0; for (int64_t v : part) tot += v;
+            P.dev_pt_pairs = tot; off.clear(); s1v.clear(); s2v.clear(); lmv.clear();
+            if (cl) P.cl_pt_dev.assign(cl, cl + n_slot); else P.cl_pt_dev.clear();
+            lap("  slot pairs: counted for the device build");
+            return; }
         BucketPlacer bp(pool, n_sb, SC);
         pool.run([&](int t) { bp.begin(t, 4*n_slot/(size_t)T + 1024); range_pairs(loff, pose, cl, lo[t], lo[t+1], [&](int64_t k, int, int) { bp.count(t, blk_of(k)); }); });
         lap("  slot pairs: count");
