@@ -58,6 +58,43 @@ def main():
         print(name, rep["iters"], rep["cost1"])
 
 
+# global BA on maps whose reduced system is not a plain band: the LM run trial by trial (candidate cost, model cost change, radius, decision), the final
+# parameters and the reduced gradient of the first linearisation -- for the CPU suite (oracle regression) and for the GPU suite (every solver path of
+# tsba_global_ba against a COMMITTED vector, not only against the oracle built on the test box)
+GLOBAL_CASES = {
+    "mid_global_long_range": dict(n_kf=130, n_pt=4000, band=8, far_frac=0.03),
+    "mid_global_ring": dict(n_kf=150, n_pt=3600, band=8, loop=True),
+    "mid_global_two_closures": dict(n_kf=160, n_pt=4000, band=8, closures=2),
+}
+
+
+def make_global_case(name):
+    P = synth.config_global(**GLOBAL_CASES[name])
+    o = abi.options_global(); o.its[0] = 10
+    return P, o
+
+
+def global_digest(P):
+    h = hashlib.sha256()
+    for a in (P.pose, P.rho, P.pt_ray, P.sobs_uv0[0], P.sobs_kf[0], P.sobs_pt[0], P.pt_host):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def make_global():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for name in GLOBAL_CASES:
+        P, o = make_global_case(name)
+        rb = oracle.reduced_blocks(P, o, 0, o.initial_radius)
+        Q = P.copy()
+        rep, tr = oracle.solve_traced(Q, o)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), digest=global_digest(P), trace=tr[0], pose=Q.pose, rho=Q.rho,
+                            g=rb["g"], free_idx=rb["free_idx"], cost_lin=rb["cost"], n_blocks=len(rb["br"]), abs_sum_S=float(np.abs(rb["val"]).sum()),
+                            iters=np.array(rep["iters"]), accepted=np.array(rep["accepted"]), termination=np.array(rep["termination"]),
+                            cost0=np.array(rep["cost0"]), cost1=np.array(rep["cost1"]))
+        print(name, rep["iters"], rep["accepted"], rep["cost1"], len(rb["br"]))
+
+
 def make_orb():
     from textslam_amd.orbextractor import synthetic_frame
     seed = 77
@@ -68,4 +105,5 @@ def make_orb():
 
 if __name__ == "__main__":
     main()
+    make_global()
     make_orb()

@@ -10,6 +10,8 @@
     whole N-rank solve (in-process communicator, one thread per rank) reproduces the 1-rank solve.
 """
 import threading
+import os
+import sys
 import numpy as np
 import pytest
 from scipy.linalg import solveh_banded
@@ -480,3 +482,36 @@ def test_schur_lists_built_on_the_device_equal_the_host_lists(gpu, kw):
     assert r1["iters"] == r2["iters"] and r1["accepted"] == r2["accepted"] and r1["cost0"] == r2["cost0"] and r1["cost1"] == r2["cost1"]
     assert np.array_equal(G1.pose, G2.pose) and np.array_equal(G1.rho, G2.rho)
     assert r1["cost1"][0] < 0.5*r1["cost0"][0]
+
+
+@pytest.mark.parametrize("name,variants", [
+    ("mid_global_long_range", [dict(far_solver=2), dict(far_solver=3, pcg_block=1), dict(far_solver=1), dict(far_solver=1, no_band_stream=1)]),
+    ("mid_global_ring", [dict(), dict(no_ring=1), dict(no_ring=1, no_kf_reorder=1)]),
+    ("mid_global_two_closures", [dict(far_solver=2), dict(far_solver=3), dict(far_solver=1)]),
+])
+def test_global_ba_against_the_committed_fixtures(gpu, name, variants):
+    """tsba_global_ba against COMMITTED vectors (tests/golden/mid_global_*.npz: the oracle's LM trace, final parameters and first-linearisation
+    gradient on a map with 3 % long-range points, on a ring and on a map with two closures), through every solver path that can take the map:
+    conjugate gradients with and without the low-rank correction, the reordered band, the wide-band / dense Cholesky, the ghost-row partition."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    P, o = make_golden.make_global_case(name)
+    assert make_golden.global_digest(P) == str(g["digest"])
+    paths = set()
+    try:
+        for kw in variants:
+            gpu.debug_set(**kw)
+            G = P.copy(); rep = gpu.GlobalBA(G, options=o); tr = gpu.lm_trace(0)
+            paths.add(rep["solver_path"])
+            assert rep["iters"] == g["iters"].tolist() and rep["accepted"] == g["accepted"].tolist() and rep["termination"] == g["termination"].tolist(), (kw, rep)
+            assert np.array_equal(tr[:, 3], g["trace"][:, 3]), kw
+            np.testing.assert_allclose(tr[:, 0], g["trace"][:, 0], rtol=1e-9, err_msg=str(kw))
+            np.testing.assert_allclose(tr[:, 2], g["trace"][:, 2], rtol=1e-7, err_msg=str(kw))       # (the radius follows the gain ratio, a ratio of differences)
+            np.testing.assert_allclose(rep["cost1"], g["cost1"], rtol=1e-9)
+            np.testing.assert_allclose(G.pose, g["pose"], rtol=0, atol=1e-8)
+            np.testing.assert_allclose(G.rho, g["rho"], rtol=0, atol=1e-8)
+            assert rep["pcg_unconverged"] == 0
+    finally:
+        gpu.debug_set()
+    assert len(paths) >= 2, paths                                       # (the variants really went through different solvers)
