@@ -199,7 +199,7 @@ def test_first_linearisation_and_lm_prefix_against_the_oracle(gpu, oracle_lib, m
             accepted_gpu=rep_g["accepted"][0], accepted_oracle=rep_o["accepted"][0])
     f9, f6, fd = K_FLOOR[name]
     assert K9 >= f9 and K6 >= f6 and Kdec >= fd, (K9, K6, Kdec, rel)
-    assert tr_g[0][3] == tr_o[0][3] and abs(tr_g[0][0] - tr_o[0][0]) <= (1e-8 if name == "c6_long_range" else 1e-10)*tr_o[0][0]     # the first trial: cost at x0 + dx
+    assert tr_g[0][3] == tr_o[0][3] and abs(tr_g[0][0] - tr_o[0][0]) <= (1e-8 if name == "c6_long_range" else 1e-9)*tr_o[0][0]     # the first trial: cost at x0 + dx (measured: 6e-11 on the open chain, <= 1e-12 elsewhere, 5e-9 with the 1e-10 iterative solve)
     if name == "c6_long_range":
         # the prefix is limited by the inexact linear solve, not by the assembly: with the conjugate gradients run to 1e-13 the first trial agrees
         # with the oracle as on the open chain
@@ -238,5 +238,5 @@ def test_sharded_lm_prefix_at_5000_keyframes(gpu, map_cache, name, world):
     print(f"\n{name}, {world} ranks against 1: LM prefix K(1e-9) = {K9}, K(1e-6) = {K6} of {len(tr1)} trials; final cost {outs[0][0]['cost1'][0]:.6g} / {rep1['cost1'][0]:.6g}")
     _record(f"{name}_ranks{world}", K_1e9=K9, K_1e6=K6, trials=int(len(tr1)), cost1=outs[0][0]["cost1"][0], cost1_single=rep1["cost1"][0])
     assert abs(outs[0][0]["cost0"][0] - rep1["cost0"][0]) <= 1e-12*rep1["cost0"][0]
-    assert tr[0][3] == tr1[0][3] and abs(tr[0][0] - tr1[0][0]) <= 1e-10*tr1[0][0]
+    assert tr[0][3] == tr1[0][3] and abs(tr[0][0] - tr1[0][0]) <= 1e-9*tr1[0][0]
     assert K9 >= 1 and K6 >= 2, (K9, K6)             # measured: 1-2 / 3-7 (the sharded sums differ from the unsharded ones in the last bits)
