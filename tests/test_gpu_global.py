@@ -515,3 +515,23 @@ def test_global_ba_against_the_committed_fixtures(gpu, name, variants):
     finally:
         gpu.debug_set()
     assert len(paths) >= 2, paths                                       # (the variants really went through different solvers)
+
+
+def test_a_landmark_listed_twice_at_a_keyframe_keeps_the_host_lists(gpu, oracle_lib):
+    """The device build of the S blocks' slot-pair lists relies on one slot per (landmark, keyframe) -- what the reference's maps have.  An input that lists
+    an observation twice is still a valid problem (two residual blocks): the plan notices and keeps the host lists; the solve matches the oracle."""
+    P = synth.config_global(n_kf=200, n_pt=5000, band=8)
+    kf, pt, fl, uv = P.sobs_kf[0], P.sobs_pt[0], P.sobs_flag[0], P.sobs_uv0[0]
+    pick = np.arange(50, len(kf), len(kf)//40)[:40]                  # forty observations listed twice (next to the original: the lists stay keyframe-major)
+    pick = pick[P.pt_host[pt[pick]] != kf[pick]]
+    rep_idx = np.sort(np.concatenate([np.arange(len(kf)), pick]))
+    P.sobs_kf[0], P.sobs_pt[0], P.sobs_flag[0] = kf[rep_idx].copy(), pt[rep_idx].copy(), fl[rep_idx].copy()
+    P.sobs_uv0[0] = (uv[rep_idx] + 0.25*(np.arange(len(rep_idx)) % 2)[:, None]).copy()       # (the second listing with a slightly different pixel)
+    o = abi.options_global(); o.its[0] = 5
+    G, R = P.copy(), P.copy()
+    rg = gpu.GlobalBA(G, options=o)
+    ro = oracle_lib.solve(R, o)
+    assert rg["n_sblock"] == ro["n_sblock"] and rg["iters"] == ro["iters"] and rg["accepted"] == ro["accepted"]
+    np.testing.assert_allclose(rg["cost0"], ro["cost0"], rtol=1e-11)
+    np.testing.assert_allclose(rg["cost1"], ro["cost1"], rtol=1e-9)
+    np.testing.assert_allclose(G.pose, R.pose, rtol=0, atol=1e-8)

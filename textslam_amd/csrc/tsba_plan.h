@@ -451,13 +451,19 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         const size_t n_slot = n_lm > 0 ? (size_t)loff[n_lm] : 0;
         if (n_slot == 0) { off.assign((size_t)n_sb + 1, 0); s1v.clear(); s2v.clear(); lmv.clear(); return; }
         if (dev_pairs && &off == &P.sb_pt_off) {                       // the device builds these lists (tsba_devplan.h): count only
-            std::vector<int64_t> part((size_t)T, 0);
-            pool.run([&](int t) { int64_t n = 0; range_pairs(loff, pose, cl, lo[t], lo[t+1], [&](int64_t, int, int) { n++; }); part[(size_t)t] = n; });
-            int64_t tot = 0; for (int64_t v : part) tot += v;
-            P.dev_pt_pairs = tot; off.clear(); s1v.clear(); s2v.clear(); lmv.clear();
-            if (cl) P.cl_pt_dev.assign(cl, cl + n_slot); else P.cl_pt_dev.clear();
-            lap("  slot pairs: counted for the device build");
-            return; }
+            std::vector<int64_t> part((size_t)T, 0); std::vector<char> dup((size_t)T, 0);
+            pool.run([&](int t) { int64_t n = 0; range_pairs(loff, pose, cl, lo[t], lo[t+1], [&](int64_t, int, int) { n++; }); part[(size_t)t] = n;
+                // the device walk relies on ONE slot per (landmark, pose) -- what the reference's maps have; a landmark listed twice at a keyframe
+                // (two slots at one pose) keeps the host lists, which take any input
+                for (int j = lo[t]; j < lo[t+1] && !dup[(size_t)t]; j++) for (int s1 = loff[j]; s1 < loff[j+1]; s1++) for (int s2 = s1 + 1; s2 < loff[j+1]; s2++) if (pose[s1] == pose[s2]) dup[(size_t)t] = 1; });
+            bool any_dup = false; for (char d : dup) any_dup |= d != 0;
+            if (!any_dup) {
+                int64_t tot = 0; for (int64_t v : part) tot += v;
+                P.dev_pt_pairs = tot; off.clear(); s1v.clear(); s2v.clear(); lmv.clear();
+                if (cl) P.cl_pt_dev.assign(cl, cl + n_slot); else P.cl_pt_dev.clear();
+                lap("  slot pairs: counted for the device build");
+                return; }
+            P.dev_pt_pairs = -1; P.cl_pt_dev.clear(); }
         BucketPlacer bp(pool, n_sb, SC);
         pool.run([&](int t) { bp.begin(t, 4*n_slot/(size_t)T + 1024); range_pairs(loff, pose, cl, lo[t], lo[t+1], [&](int64_t k, int, int) { bp.count(t, blk_of(k)); }); });
         lap("  slot pairs: count");
