@@ -98,7 +98,8 @@ def test_conjugate_gradient_variants_agree(gpu, far, closures):
     o = abi.options_global(); o.its[0] = 5
     try:
         runs = []
-        for kw in (dict(far_solver=3, pcg_block=1), dict(far_solver=3, pcg_block=1, pcg_refactor=1), dict(far_solver=3, pcg_block=1, pcg_refactor=2), dict(far_solver=3, pcg_block=2), dict(far_solver=2)):
+        for kw in (dict(far_solver=3, pcg_block=1), dict(far_solver=3, pcg_block=1, pcg_refactor=1), dict(far_solver=3, pcg_block=1, pcg_refactor=2), dict(far_solver=3, pcg_block=2), dict(far_solver=2),
+                   dict(far_solver=3, pcg_block=1, sv_per_level=1)):
             gpu.debug_set(band_parts=16, sep_solver=2, **kw)
             G = P.copy(); rep = gpu.GlobalBA(G, options=o)
             info = gpu.solver_info()
@@ -110,6 +111,8 @@ def test_conjugate_gradient_variants_agree(gpu, far, closures):
         for k in (1, 2):
             assert abs(runs[0][2]["iterations"] - runs[k][2]["iterations"]) <= runs[0][2]["systems"], [r[2] for r in runs]
         assert runs[3][2]["iterations"] < runs[0][2]["iterations"], [r[2] for r in runs]
+        # the separator tree of the solve phase as a launch per level (the sixth run) instead of one launch: the same bits all the way
+        assert np.array_equal(runs[5][0].pose, runs[0][0].pose) and np.array_equal(runs[5][0].rho, runs[0][0].rho) and runs[5][2]["iterations"] == runs[0][2]["iterations"]
         if far == 0.0:                                              # loop closures only: the low-rank correction makes the band solve (nearly) exact
             assert runs[4][2]["iterations"] <= 3*runs[4][2]["systems"], runs[4][2]
     finally:
@@ -202,6 +205,12 @@ def test_multi_right_hand_side_solve_phase(gpu, n_kf, band, parts, T):
         for k in (0, T - 1):
             x1 = gpu.multi_solve(R[:, k:k + 1].copy(), single=True)[:, 0]
             assert np.abs(x1 - ref[:, k]).max() <= 1e-8*np.abs(ref[:, k]).max(), (k, np.abs(x1 - ref[:, k]).max()/np.abs(ref[:, k]).max())
+            # the separator tree as ONE launch (workgroups polling each other's results, k_sv_cre_tree: production) and as a launch per level: the same bits
+            gpu.debug_set(band_parts=abs(parts), sep_solver=2, sv_per_level=1)
+            x2 = gpu.multi_solve(R[:, k:k + 1].copy(), single=True)[:, 0]
+            gpu.debug_set(band_parts=abs(parts), sep_solver=2)
+            x3 = gpu.multi_solve(R[:, k:k + 1].copy(), single=True)[:, 0]
+            assert np.array_equal(x1, x2) and np.array_equal(x1, x3)
     finally:
         gpu.debug_set()
 

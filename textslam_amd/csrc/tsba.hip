@@ -1043,20 +1043,24 @@ static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rd
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6, lmax = sv_lmax(c);
     Work &Ws = c->Wsep; Ws.st = W.st;
     const size_t ldf = sv_fwd_lds_doubles(B)*sizeof(double), ldb = sv_back_lds_doubles(B, lmax)*sizeof(double);
-    if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M);
-    else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M);
     const int mmax = cr_mmax(0, P, 0);
     auto pivots = [&](int h) { const int klast = (mmax - 1 - h)/(2*h); return mmax - 1 - h < 0 ? 0 : std::max(0, klast + 1); };
     int htop = 0;
     for (int h = 1; h < mmax; h <<= 1) if (pivots(h) > 0) htop = h;
-    // the highest level has one pivot (3 h >= 2 h >= the number of separators): its forward step, the root and its back substitution are one launch
+    // the highest level has one pivot (3 h >= 2 h >= the number of separators): its forward step, the root and its back substitution are one workgroup's work
     const bool fuse_top = htop > 0 && pivots(htop) == 1;
-    for (int h = 1; h <= htop; h <<= 1) { const int npiv = pivots(h); if (npiv <= 0 || (fuse_top && h == htop)) continue;
-        hipLaunchKernelGGL(k_sv_cre_fwd, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
-    if (fuse_top) hipLaunchKernelGGL(k_sv_cre_top, dim3(1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
-    else hipLaunchKernelGGL(k_sv_cre_root, dim3(1), dim3(SV_CT), 0, c->stream, W, bwp, P, M);
-    for (int h = htop; h >= 1; h >>= 1) { const int npiv = pivots(h);
-        if (npiv > 0 && !(fuse_top && h == htop)) hipLaunchKernelGGL(k_sv_cre_back, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
+    const int tree = fuse_top && !c->dbg.sv_per_level;           // the whole tree in one launch (k_sv_cre_tree)
+    if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree);
+    else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree);
+    if (tree) hipLaunchKernelGGL(k_sv_cre_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
+    else {
+        for (int h = 1; h <= htop; h <<= 1) { const int npiv = pivots(h); if (npiv <= 0 || (fuse_top && h == htop)) continue;
+            hipLaunchKernelGGL(k_sv_cre_fwd, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
+        if (fuse_top) hipLaunchKernelGGL(k_sv_cre_top, dim3(1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
+        else hipLaunchKernelGGL(k_sv_cre_root, dim3(1), dim3(SV_CT), 0, c->stream, W, bwp, P, M);
+        for (int h = htop; h >= 1; h >>= 1) { const int npiv = pivots(h);
+            if (npiv > 0 && !(fuse_top && h == htop)) hipLaunchKernelGGL(k_sv_cre_back, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
+    }
     if (B <= 10) hipLaunchKernelGGL(k_sv_back_int<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
     else hipLaunchKernelGGL(k_sv_back_int<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
 }

@@ -49,7 +49,7 @@ template <int NREG> struct SvStep { double cf[NREG][6], ent[NREG], l[15], idl; }
 // ---- interiors, forward.  grid Pmax, SV_T threads.
 //   M.V = D^-1 w (L w = r), M.G [label][s] = rows of the separator on the right below this interior, M.G2 [label][s] = border rows of the separator on the left
 template <int NREG>
-__global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, const double *__restrict__ r, double rs, MsBuf M) {
+__global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, const double *__restrict__ r, double rs, MsBuf M, int tree) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6);
 #ifdef SV_STAMPS
@@ -67,6 +67,9 @@ __global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, c
     const BandpPart PT = bandp_part(nf, B, Pmax, p);
     const int a = ms_uni(PT.a), b = ms_uni(PT.b), P = ms_uni(PT.P);
     if (p >= P) return;
+    // (k_sv_cre_tree polls these slots: this application's values have not arrived while they hold a NaN)
+    if (tree && tid >= SV_T - 3*bw) { const int e = tid - (SV_T - 3*bw), row = e % bw, which = e/bw; const double qn = __builtin_nan("");
+        if (which < 2) M.Cg[((size_t)p*2 + which)*bw + row] = qn; else M.Xs[(size_t)p*bw + row] = qn; }
     const int REC = bw*6, rend = p < P - 1 ? b + B : b, nch = (b - a + SV_K - 1)/SV_K;
     const int ptid = tid - 64, pk = ptid & (SV_K - 1), pj = ptid/SV_K, perp = (TB + 28)/2;       // producers: (pivot of the chunk, SV_PT threads across its record, 16 bytes each)
     auto stage = [&](int c) {                                   // producers: chunk c
@@ -594,4 +597,165 @@ __global__ __launch_bounds__(SV_CT) void k_sv_cre_back(Work W, Work Ws, int bw, 
     if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, u, s, g) : 0.0;
     __syncthreads();
     if (vrow) M.Xs[(size_t)i*s + tid] = ((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]);
+}
+
+// ---- the whole separator tree in ONE launch: forward steps of every level, the root, back substitution of every level.
+// A level of the tree is ~1 us of work behind a launch of ~6 us, twelve levels and the top per application, fifteen to twenty applications per LM
+// trial.  Here every pivot has its workgroup for the whole application (grid = labels 1 .. mmax - 1; the workgroup of the top pivot also does the
+// root): it requests its matrix operands, then POLLS the vector entries it needs -- the pending updates of the lower levels going up, the
+// solution of its neighbours coming down -- until they are no longer the NaN that k_sv_fwd_int left in those slots for this application.  A value
+// travels from its producer to a polling consumer on another XCD in ~0.65 us (tools/handover_bench.hip: flag + data 1.2 - 2 us, a dependent
+// launch 2.8 us at best), and nothing else is handed over: every other operand was written by an earlier launch.  Producers never publish a
+// NaN (a NaN result goes out as +inf: the iteration above sees it in r.z) and polling is bounded, so a broken factor cannot park the device.
+// All workgroups are resident at once (at most 127 of them on 256 CUs), and a waiting workgroup holds nothing its producers need.
+// Same arithmetic in the same order as k_sv_cre_fwd / _top / _back: the result is bit-identical to the launch-per-level path.
+#define SV_SPIN_MAX (1 << 15)
+__device__ __forceinline__ double sv_ld_co(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sv_st_co(double *p, double v) { __hip_atomic_store(p, v == v ? v : __builtin_inf(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sv_pending_poll(const MsBuf &M, int s, int blk, int H, int m, int row, bool on, SvPend &P) {
+    unsigned need = 0;                                          // bit l: from blk - 2^l, bit 8 + l: from blk + 2^l (the terms sv_pending_sum takes, lo = r0 = 0)
+#pragma unroll
+    for (int l = 0; l < 8; l++) { const int hp = 1 << l, pl = blk - hp, pr = blk + hp; const bool lev = on && hp < H && hp < m;
+        if (lev && pl >= 1 && (pl & (2*hp - 1)) == hp) need |= 1u << l;
+        if (lev && pr < m && (pr & (2*hp - 1)) == hp) need |= 1u << (8 + l);
+        P.lo_[l] = 0.0; P.hi_[l] = 0.0; }
+    for (int spins = 0; need && spins < SV_SPIN_MAX; spins++) {  // every outstanding request of a round in flight at once; a slot is final once it is not a NaN
+#pragma unroll
+        for (int l = 0; l < 8; l++) { const int hp = 1 << l;
+            if (need >> l & 1) P.lo_[l] = sv_ld_co(&M.Cg[((size_t)(blk - hp)*2 + 1)*s + row]);
+            if (need >> (8 + l) & 1) P.hi_[l] = sv_ld_co(&M.Cg[((size_t)(blk + hp)*2 + 0)*s + row]); }
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            if ((need >> l & 1) && P.lo_[l] == P.lo_[l]) need &= ~(1u << l);
+            if ((need >> (8 + l) & 1) && P.hi_[l] == P.hi_[l]) need &= ~(1u << (8 + l)); }
+        if (need) __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int l = 0; l < 8; l++) { if (need >> l & 1) P.lo_[l] = __builtin_inf(); if (need >> (8 + l) & 1) P.hi_[l] = __builtin_inf(); }     // (gave up: the result is not finite)
+}
+__device__ __forceinline__ void sv_poll2(const double *pa, bool on_a, const double *pc, bool on_c, double &va, double &vc) {      // both requests in one round trip
+    va = 0.0; vc = 0.0;
+    bool na = on_a, nc = on_c;
+    for (int spins = 0; (na || nc) && spins < SV_SPIN_MAX; spins++) {
+        const double ta = na ? sv_ld_co(pa) : 0.0, tc = nc ? sv_ld_co(pc) : 0.0;
+        if (na && ta == ta) { va = ta; na = false; }
+        if (nc && tc == tc) { vc = tc; nc = false; }
+        if (na || nc) __builtin_amdgcn_s_sleep(1);
+    }
+    if (na) va = __builtin_inf();
+    if (nc) vc = __builtin_inf();
+}
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_tree(Work W, Work Ws, int bw, int Pmax, int htop, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], xc[80], red[6*80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), i = (int)blockIdx.x + 1, r0 = 0, lo = 0;
+    const bool top = i == htop;
+    const int h = i & -i, ia = i - h, ic = i + h;               // (the top pivot: ia = 0 is the root, ic >= mmax)
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s;
+    double g0 = vrow ? M.G[(size_t)i*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)i*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)i*s + tid] : 0.0;
+    const int part = tid & 3, rq = tid >> 2, g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    const double *Xa = cr_blk(Ws.S, s, mmax, i, ia), *Xc = cr_blk(Ws.S, s, mmax, ic < mmax ? ic : i, i);
+    SvRow li; sv_row_load(M.Li + ((size_t)i*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
+    auto sum6 = [&](int k) { return ((red[k] + red[80 + k]) + (red[160 + k] + red[240 + k])) + (red[320 + k] + red[400 + k]); };
+    if (top) {                                                  // ---- the top pivot and the root (k_sv_cre_top)
+        double g0r = vrow ? M.G[(size_t)r0*s + tid] : 0.0, g1r = vrow ? M.G2[(size_t)r0*s + tid] : 0.0, idr = vrow ? M.Lid[(size_t)r0*s + tid] : 0.0;
+        SvRow xar, lir; SvCol lcr;
+        sv_row_load(Xa + (size_t)(rq < s ? rq : 0)*s, s, part, rq < s, xar);
+        sv_row_load(M.Li + ((size_t)r0*s + (rq < s ? rq : 0))*s, s, part, rq < s, lir);
+        sv_col_load(M.Li + (size_t)r0*s*s, s, g, con ? r : 0, con, lcr);
+        sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(g0r); sv_pin(g1r); sv_pin(idr); sv_pin(li); sv_pin(xar); sv_pin(lir); sv_pin(lcr);
+        if (flags) return;
+        const int m = ms_uni(sv_nsep(nf, B, Pmax));
+        if (m <= 0) return;
+        const bool piv = i < m;                                  // (uniform)
+        SvPend pd; sv_pending_poll(M, s, i, piv ? h : 0, m, tid, vrow, pd);
+        double pr_[8];                                          // the root's pending updates: the pivots 2^l of the levels below h (from the right only)
+#pragma unroll
+        for (int l = 0; l < 8; l++) pr_[l] = 0.0;
+        { unsigned need = 0;
+#pragma unroll
+          for (int l = 0; l < 8; l++) { const int hp = 1 << l; if (vrow && hp < h && hp < m) need |= 1u << l; }
+          for (int spins = 0; need && spins < SV_SPIN_MAX; spins++) {
+#pragma unroll
+              for (int l = 0; l < 8; l++) if (need >> l & 1) pr_[l] = sv_ld_co(&M.Cg[((size_t)(1 << l)*2 + 0)*s + tid]);
+#pragma unroll
+              for (int l = 0; l < 8; l++) if ((need >> l & 1) && pr_[l] == pr_[l]) need &= ~(1u << l);
+              if (need) __builtin_amdgcn_s_sleep(1); }
+#pragma unroll
+          for (int l = 0; l < 8; l++) if (need >> l & 1) pr_[l] = __builtin_inf(); }
+        double zi = 0.0;
+        if (piv) {
+            if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, g0 + g1);
+            __syncthreads();
+            { const double wv = sv_row_dot(li, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
+            __syncthreads();
+            if (vrow) zi = w[tid]*idv;
+            { const double a = sv_row_dot(xar, w, s, part); if (rq < s && part == 0) cga[rq] = a; }
+            __syncthreads();
+        }
+        SvCol ca, lc;
+        sv_col_load(Xa, s, g, con ? r : 0, con && piv, ca);
+        sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con && piv, lc);
+        if (vrow) { double t = g0r + g1r;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { const int hp = 1 << l; if (hp < h && hp < m) t -= pr_[l]; }
+            if (piv) t -= cga[tid];
+            v[tid] = t; }
+        __syncthreads();
+        { const double wv = sv_row_dot(lir, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
+        __syncthreads();
+        if (vrow) v[tid] = w[tid]*idr;
+        __syncthreads();
+        if (g < 6) red[g*80 + r] = con ? sv_col_dot(lcr, v, s, g) : 0.0;
+        __syncthreads();
+        if (vrow) { const double xv = sum6(tid); x0[tid] = xv; sv_st_co(&M.Xs[(size_t)r0*s + tid], xv); }
+        if (!piv) return;
+        __syncthreads();
+        if (g < 6) red[g*80 + r] = con ? sv_col_dot(ca, x0, s, g) : 0.0;
+        __syncthreads();
+        if (vrow) v[tid] = zi - sum6(tid);
+        __syncthreads();
+        if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;
+        __syncthreads();
+        if (vrow) sv_st_co(&M.Xs[(size_t)i*s + tid], sum6(tid));
+        return;
+    }
+    // ---- a pivot below the top: forward step (k_sv_cre_fwd) ...
+    SvRow xr[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) { const int rr = ps*(SV_CT/4) + rq; const bool rok = rr < 2*s;
+        sv_row_load((rr < s ? Xa : Xc) + (size_t)(rok ? (rr < s ? rr : rr - s) : 0)*s, s, part, rok, xr[ps]); }
+    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(li); sv_pin(xr[0]); sv_pin(xr[1]);
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax));
+    if (i >= m) return;
+    const bool has_a = ia >= lo, has_c = ic < m;
+    SvPend pd; sv_pending_poll(M, s, i, h, m, tid, vrow, pd);
+    if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, g0 + g1);
+    __syncthreads();
+    { const double wv = sv_row_dot(li, v, s, part);
+      if (rq < s && part == 0) w[rq] = wv; }
+    __syncthreads();
+    const double zv = vrow ? w[tid]*idv : 0.0;
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) { const int rr = ps*(SV_CT/4) + rq; const bool rok = rr < 2*s;
+        const double acc = sv_row_dot(xr[ps], w, s, part);
+        if (rok && part == 0) sv_st_co(&M.Cg[((size_t)i*2 + (rr < s ? 0 : 1))*s + (rr < s ? rr : rr - s)], (rr < s ? has_a : has_c) ? acc : 0.0);
+    }
+    // ---- ... and, once both neighbours are solved, its back substitution (k_sv_cre_back): the operands travel while the levels above work
+    SvCol ca, cc_, lc;
+    sv_col_load(Xa, s, g, con ? r : 0, con, ca); sv_col_load(Xc, s, g, con ? r : 0, con && has_c, cc_);
+    sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con, lc);
+    sv_pin(ca); sv_pin(cc_); sv_pin(lc);
+    double xav, xcv; sv_poll2(&M.Xs[(size_t)ia*s + tid], vrow && has_a, &M.Xs[(size_t)ic*s + tid], vrow && has_c, xav, xcv);
+    if (vrow) { x0[tid] = xav; xc[tid] = xcv; }
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? (has_a ? sv_col_dot(ca, x0, s, g) : 0.0) + (has_c ? sv_col_dot(cc_, xc, s, g) : 0.0) : 0.0;
+    __syncthreads();
+    if (vrow) v[tid] = zv - sum6(tid);
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;
+    __syncthreads();
+    if (vrow) sv_st_co(&M.Xs[(size_t)i*s + tid], sum6(tid));
 }

@@ -1,0 +1,23 @@
+"""GPU diagnostic (not a pytest): resident solve of C6 with 1 % long-range points, the separator tree of the solve phase as one launch (production)
+against a launch per level (tsba_debug_options.sv_per_level = 1)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from textslam_amd import synth, abi
+from textslam_amd.optimizer import Optimizer
+opt = Optimizer(0)
+far = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
+P = synth.config_global(n_kf=5000, n_pt=70000, band=10, far_frac=far); o = abi.options_global()
+res = {}
+for mode in (0, 1, 0, 1):
+    opt.debug_set(sv_per_level=mode)
+    opt.upload(P, o)
+    ts = []
+    for _ in range(4):
+        rep = opt.solve(); ts.append(rep["t_solve_ms"])
+    G = P.copy(); opt.download(G)
+    print("tree %s: min %.3f ms  iters %s accepted %s cost1 %.12g  pcg %d its / %d systems, unconverged %d" % ("per level " if mode else "one launch", min(ts), rep["iters"], rep["accepted"],
+          rep["cost1"][0], rep["pcg_iterations"], rep["pcg_systems"], rep["pcg_unconverged"]), flush=True)
+    if mode in res: assert np.array_equal(res[mode], G.pose)
+    res[mode] = G.pose.copy()
+print("bit-identical:", np.array_equal(res[0], res[1]))
