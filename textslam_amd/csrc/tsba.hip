@@ -847,7 +847,7 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_ms_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 159*1024));
         CK(hipFuncSetAttribute((const void *)k_ms_cre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
         CK(hipFuncSetAttribute((const void *)k_ms_cre_root, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
-        CK(hipFuncSetAttribute((const void *)k_sv_linv, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
+        CK(hipFuncSetAttribute((const void *)k_sv_linv, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
 #define MX_ATTR(SS) CK(hipFuncSetAttribute((const void *)k_mx_cre_fwd<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024)); CK(hipFuncSetAttribute((const void *)k_mx_cre_root<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024)); CK(hipFuncSetAttribute((const void *)k_mx_cre_back<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         MX_ATTR(36) MX_ATTR(42) MX_ATTR(48) MX_ATTR(54) MX_ATTR(60) MX_ATTR(66)
 #undef MX_ATTR
@@ -1020,12 +1020,12 @@ static void launch_ms_solve(Ctx *c, bool mx = false) {            // M.R -> M.X.
 // separators' inverse factors), then any number of launch_sv_solve
 static int sv_reserve(Ctx *c) {
     const size_t n6 = ((size_t)c->W.N + 1) & ~(size_t)1, labels = (size_t)cr_mmax(0, c->band_parts, 0) + 1, sdim = (size_t)std::max(6, c->cur_bw_rows);
-    const size_t need = (4*n6 + 7*labels*sdim + labels*sdim*sdim)*sizeof(double);
+    const size_t need = (4*n6 + 7*labels*sdim + 3*labels*sdim*sdim)*sizeof(double);
     if (need > c->sv_bytes) { if (c->sv_alloc) { hipStreamSynchronize(c->stream); hipFree(c->sv_alloc); } c->sv_alloc = nullptr; c->sv_bytes = 0;
         if (hipMalloc((void **)&c->sv_alloc, need) != hipSuccess) { set_err(c, "hipMalloc (solve-phase buffers)"); return TSBA_ERR_DEVICE; }
         c->sv_bytes = need; }
     double *q = c->sv_alloc; MsBuf &M = c->sv; M.T = 1;
-    M.Li = q; q += labels*sdim*sdim;
+    M.Li = q; q += labels*sdim*sdim; M.Pp = q; q += 2*labels*sdim*sdim;
     M.R = q; q += n6; M.Wm = q; q += n6; M.V = q; q += n6; M.X = q; q += n6;
     M.G = q; q += labels*sdim; M.Z = q; q += labels*sdim; M.Xs = q; q += labels*sdim; M.Cg = q; q += 2*labels*sdim; M.G2 = q; q += labels*sdim; M.Lid = q;
     return TSBA_OK;
@@ -1036,7 +1036,7 @@ static int sv_lmax_of(int n_kf, int B, int P) { return std::max(n_kf/std::max(1,
 static int sv_lmax(const Ctx *c) { return sv_lmax_of(c->n_kf, std::max(6, c->cur_bw_rows)/6, c->band_parts); }
 static void launch_sv_prepare(Ctx *c) {
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, mmax = cr_mmax(0, P, 0);
-    if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(SV_LT), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, c->sv);
+    if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(SV_LT), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, (const double *)c->Ssep, c->sv);
 }
 static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rdot = nullptr, double *rz_part = nullptr) {
     Work &W = c->W; const MsBuf &M = c->sv;

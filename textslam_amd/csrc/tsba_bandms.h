@@ -25,6 +25,7 @@ struct MsBuf {                              // device buffers of one multi-right
     double *R, *Wm, *V, *X;                 // [6 nfree][T]: right-hand sides, w = L^-1 r (interior rows), v = D^-1 w, solution
     double *G, *Z, *Xs, *Cg;                // [labels][s][T]: separator right-hand sides, z, solution; [labels][2][s][T] pending updates (for a | for c)
     double *G2, *Li, *Lid;                  // single-vector solve phase (tsba_bandsv.h): [labels][s] border part of a separator's right-hand side; [labels][s][s] inverse unit-lower factors, [labels][s] 1/d
+    double *Pp;                             // [labels][2][s][s]: the couplings of a pivot to its two neighbours times its inverse factor (k_sv_linv)
     int T;                                  // columns (row stride)
 };
 

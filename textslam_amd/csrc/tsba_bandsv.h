@@ -333,8 +333,8 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
 //   Linv(I, I) = inv(l_I),   Linv(I, J) = - inv(l_I) sum_{K = J .. I-1} L(I, K) Linv(K, J)   for the block rows I = 1, 2, ... in turn
 // -- 300 FMAs per thread and two barriers per block row (a thread per column solving L y = e_j row by row: 1800 dependent FMAs, 64 us per launch).
 #define SV_LT 512
-static size_t sv_linv_lds_doubles(int s) { return ((cre_rec_doubles(s) + 8) & ~(size_t)1) + (size_t)s*(s + 1) + 6*(size_t)(s + 2); }
-__global__ __launch_bounds__(SV_LT) void k_sv_linv(Work W, int bw, int Pmax, const double *__restrict__ fac, MsBuf M) {
+static size_t sv_linv_lds_doubles(int s) { return ((cre_rec_doubles(s) + 8) & ~(size_t)1) + (size_t)s*(s + 1) + std::max(6*(size_t)(s + 2), (size_t)s*(s + 1)); }
+__global__ __launch_bounds__(SV_LT) void k_sv_linv(Work W, int bw, int Pmax, const double *__restrict__ fac, const double *__restrict__ pool, MsBuf M) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, s = bw, B = s/6, i = blockIdx.x;
     const LmState *st_ = W.st; const int flags = st_->done | st_->step_fail, nf = ms_uni(*W.nfree);
@@ -374,6 +374,31 @@ __global__ __launch_bounds__(SV_LT) void k_sv_linv(Work W, int bw, int Pmax, con
     }
     double *out = M.Li + (size_t)i*s*s;
     for (int e = tid; e < s*s; e += SV_LT) { const int rr = e/s, cc = e - rr*s; out[e] = cc <= rr ? Y[(size_t)rr*(s + 1) + cc] : 0.0; }
+    // the products the separator steps apply (M.Pp [label][2][s][s]): P_a = X_a L^-1, P_c = X_c L^-1 with the couplings X of this pivot to its neighbours
+    // a = i - h, c = i + h as the elimination left them in the pool.  One block at a time through LDS (T's place), four threads per row, every fourth column each.
+    if (i == 0) return;                                         // (the root has no neighbours)
+    const int h = i & -i, ia = i - h, ic = i + h, mmax = cr_mmax(W.ring, Pmax, W.ring_g), m = sv_nsep(nf, B, Pmax);
+    double *XS = T;                                             // [s][s + 1]
+    const int rw = tid >> 2, kg = tid & 3;
+    for (int which = 0; which < 2; which++) {
+        const bool have = which == 0 || ic < m;                 // (uniform)
+        const double *X = cr_blk(pool, s, mmax, which && have ? ic : i, which && have ? i : ia);
+        __syncthreads();
+        for (int e = tid; e < s*s; e += SV_LT) { const int rr = e/s, cc = e - rr*s; XS[(size_t)rr*(s + 1) + cc] = have ? X[e] : 0.0; }
+        __syncthreads();
+        for (int row = rw; row < s; row += SV_LT/4) {
+            double acc[20];
+#pragma unroll
+            for (int c = 0; c < 20; c++) acc[c] = 0.0;
+            const double *xr = XS + (size_t)row*(s + 1);
+            for (int t = 0; t < s; t++) { const double x = xr[t]; const double *yr = Y + (size_t)t*(s + 1) + kg;
+#pragma unroll
+                for (int c = 0; c < 20; c++) if (kg + 4*c < s) acc[c] = fma(x, yr[4*c], acc[c]); }
+            double *o = M.Pp + (((size_t)i*2 + which)*s + row)*s + kg;
+#pragma unroll
+            for (int c = 0; c < 20; c++) if (kg + 4*c < s) o[4*c] = acc[c];
+        }
+    }
 }
 
 // ---- the separator kernels: every operand requested at once, speculatively (every address is inside its allocation whatever the number of
@@ -420,41 +445,6 @@ __device__ __forceinline__ double sv_row_dot(const SvRow &R, const double *v, in
     return acc;
 }
 
-// ---- cyclic reduction, level h, forward.  grid pivots, SV_CT threads:  w = L^-1 (g - pending),  z = D^-1 w,  updates X_a w, X_c w for the neighbours
-__global__ __launch_bounds__(SV_CT) void k_sv_cre_fwd(Work W, Work Ws, int bw, int Pmax, int h, int kb, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double v[80], w[80];
-    const int tid = threadIdx.x;
-    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
-    const int i = (2*(kb + (int)blockIdx.x) + 1)*h, ia = i - h, ic = i + h;             // (i < mmax by the launch; ia >= 0)
-    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
-    const bool vrow = tid < s;
-    double g0 = vrow ? M.G[(size_t)i*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)i*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)i*s + tid] : 0.0;
-    SvPend pd; sv_pending_load(M, s, i, mmax, tid, vrow, pd);
-    const int part = tid & 3, rq = tid >> 2;                    // 128 rows per pass
-    SvRow li, xr[2];
-    sv_row_load(M.Li + ((size_t)i*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
-    const double *Xa = cr_blk(Ws.S, s, mmax, i, ia), *Xc = cr_blk(Ws.S, s, mmax, ic, i);
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) { const int r = ps*(SV_CT/4) + rq; const bool rok = r < 2*s;
-        sv_row_load((r < s ? Xa : Xc) + (size_t)(rok ? (r < s ? r : r - s) : 0)*s, s, part, rok, xr[ps]); }
-    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(pd); sv_pin(li); sv_pin(xr[0]); sv_pin(xr[1]);
-    if (flags) return;
-    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0, r0 = 0;
-    if (i < lo || i >= m) return;
-    const bool has_a = ia >= lo, has_c = ic < m;
-    if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, g0 + g1);
-    __syncthreads();
-    { const double wv = sv_row_dot(li, v, s, part);
-      if (rq < s && part == 0) w[rq] = wv; }
-    __syncthreads();
-    if (vrow) M.Z[(size_t)i*s + tid] = w[tid]*idv;
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) { const int r = ps*(SV_CT/4) + rq; const bool rok = r < 2*s;
-        const double acc = sv_row_dot(xr[ps], w, s, part);
-        if (rok && part == 0) M.Cg[((size_t)i*2 + (r < s ? 0 : 1))*s + (r < s ? r : r - s)] = (r < s ? has_a : has_c) ? acc : 0.0;
-    }
-}
-
 // columns of a dense [s][s] block against a vector in LDS (the transposed product): six groups of rows t = g + 6 j, a thread per column
 struct SvCol { double x[13]; };
 __device__ __forceinline__ void sv_col_load(const double *X, int s, int g, int r, bool on, SvCol &C) {
@@ -472,143 +462,7 @@ __device__ __forceinline__ double sv_col_dot(const SvCol &C, const double *v, in
     return acc;
 }
 
-// ---- the last block: forward and backward.  One workgroup.
-__global__ __launch_bounds__(SV_CT) void k_sv_cre_root(Work W, int bw, int Pmax, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double v[80], w[80], red[6*80];
-    const int tid = threadIdx.x;
-    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), r0 = 0;            // (chains: the root is label 0)
-    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
-    const bool vrow = tid < s;
-    double g0 = vrow ? M.G[(size_t)r0*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)r0*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)r0*s + tid] : 0.0;
-    SvPend pd; sv_pending_load(M, s, r0, mmax, tid, vrow, pd);
-    const int part = tid & 3, rq = tid >> 2, g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
-    SvRow li; SvCol lc;
-    sv_row_load(M.Li + ((size_t)r0*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
-    sv_col_load(M.Li + (size_t)r0*s*s, s, g, con ? r : 0, con, lc);
-    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(pd); sv_pin(li); sv_pin(lc);
-    if (flags) return;
-    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0;
-    if (m <= 0) return;
-    if (vrow) v[tid] = sv_pending_sum(pd, r0, 1 << 30, lo, m, -1, g0 + g1);
-    __syncthreads();
-    { const double wv = sv_row_dot(li, v, s, part);
-      if (rq < s && part == 0) w[rq] = wv; }
-    __syncthreads();
-    if (vrow) v[tid] = w[tid]*idv;                              // z
-    __syncthreads();
-    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;       // x = L^-T z
-    __syncthreads();
-    if (vrow) M.Xs[(size_t)r0*s + tid] = ((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]);
-}
 
-// ---- the top of the tree in one launch: the single pivot of the highest level (i = h: its left neighbour is the root, it has no right one), the root,
-// and the pivot's back substitution -- three dependent launches of ~5 us as one workgroup's work, every operand of the three steps requested up front.
-// (With no pivot at that level, m <= h, this is the root kernel.)
-__global__ __launch_bounds__(SV_CT) void k_sv_cre_top(Work W, Work Ws, int bw, int Pmax, int h, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], red[6*80];
-    const int tid = threadIdx.x;
-    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), i = h, r0 = 0;
-    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
-    const bool vrow = tid < s;
-    double g0 = vrow ? M.G[(size_t)i*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)i*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)i*s + tid] : 0.0;
-    double g0r = vrow ? M.G[(size_t)r0*s + tid] : 0.0, g1r = vrow ? M.G2[(size_t)r0*s + tid] : 0.0, idr = vrow ? M.Lid[(size_t)r0*s + tid] : 0.0;
-    SvPend pd; sv_pending_load(M, s, i, mmax, tid, vrow, pd);
-    double pr_[8];                                              // the root's pending updates: the pivots 2^l of the levels below h (from the right only)
-#pragma unroll
-    for (int l = 0; l < 8; l++) { const int hp = 1 << l; pr_[l] = (vrow && hp < h && hp < mmax) ? M.Cg[((size_t)hp*2 + 0)*s + tid] : 0.0; sv_pin(pr_[l]); }
-    const int part = tid & 3, rq = tid >> 2, g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
-    const double *Xa = cr_blk(Ws.S, s, mmax, i, r0);
-    SvRow li, xar, lir; SvCol lcr;
-    sv_row_load(M.Li + ((size_t)i*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
-    sv_row_load(Xa + (size_t)(rq < s ? rq : 0)*s, s, part, rq < s, xar);
-    sv_row_load(M.Li + ((size_t)r0*s + (rq < s ? rq : 0))*s, s, part, rq < s, lir);
-    sv_col_load(M.Li + (size_t)r0*s*s, s, g, con ? r : 0, con, lcr);
-    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(g0r); sv_pin(g1r); sv_pin(idr); sv_pin(pd);
-    sv_pin(li); sv_pin(xar); sv_pin(lir); sv_pin(lcr);
-    if (flags) return;
-    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0;
-    if (m <= 0) return;
-    const bool piv = i < m;                                      // (uniform)
-    auto sum6 = [&](int k) { return ((red[k] + red[80 + k]) + (red[160 + k] + red[240 + k])) + (red[320 + k] + red[400 + k]); };
-    double zi = 0.0;
-    if (piv) {                                                  // forward step of the pivot: w = L^-1 (g - pending), z = D^-1 w, the root's update X_a w
-        if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, g0 + g1);
-        __syncthreads();
-        { const double wv = sv_row_dot(li, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
-        __syncthreads();
-        if (vrow) zi = w[tid]*idv;
-        { const double a = sv_row_dot(xar, w, s, part); if (rq < s && part == 0) cga[rq] = a; }
-        __syncthreads();
-    }
-    // (the operands of the pivot's back substitution are requested here: the registers of its forward step are free, the root's work hides the wait)
-    SvCol ca, lc;
-    sv_col_load(Xa, s, g, con ? r : 0, con && piv, ca);
-    sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con && piv, lc);
-    // the root: its pending updates of the levels below h as the root kernel takes them, the pivot's last
-    if (vrow) { double t = g0r + g1r;
-#pragma unroll
-        for (int l = 0; l < 8; l++) { const int hp = 1 << l; if (hp < h && hp < m) t -= pr_[l]; }
-        if (piv) t -= cga[tid];
-        v[tid] = t; }
-    __syncthreads();
-    { const double wv = sv_row_dot(lir, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
-    __syncthreads();
-    if (vrow) v[tid] = w[tid]*idr;                               // z of the root
-    __syncthreads();
-    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lcr, v, s, g) : 0.0;
-    __syncthreads();
-    if (vrow) { const double xv = sum6(tid); x0[tid] = xv; M.Xs[(size_t)r0*s + tid] = xv; }
-    if (!piv) return;
-    __syncthreads();
-    if (g < 6) red[g*80 + r] = con ? sv_col_dot(ca, x0, s, g) : 0.0;     // X_a^T x_0
-    __syncthreads();
-    if (vrow) v[tid] = zi - sum6(tid);
-    __syncthreads();
-    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;      // x_i = L^-T u
-    __syncthreads();
-    if (vrow) M.Xs[(size_t)i*s + tid] = sum6(tid);
-}
-
-// ---- cyclic reduction, level h, backward.  grid pivots, SV_CT threads:  x_i = L^-T (z_i - X_a^T x_a - X_c^T x_c)
-__global__ __launch_bounds__(SV_CT) void k_sv_cre_back(Work W, Work Ws, int bw, int Pmax, int h, int kb, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double u[80], xa[80], xc[80], red[6*80];
-    const int tid = threadIdx.x;
-    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
-    const int i = (2*(kb + (int)blockIdx.x) + 1)*h, ia = i - h, ic = i + h;
-    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
-    const bool vrow = tid < s, cin = ic < mmax;
-    double zv = vrow ? M.Z[(size_t)i*s + tid] : 0.0, xav = vrow ? M.Xs[(size_t)ia*s + tid] : 0.0, xcv = (vrow && cin) ? M.Xs[(size_t)ic*s + tid] : 0.0;
-    const double *Xa = cr_blk(Ws.S, s, mmax, i, ia), *Xc = cr_blk(Ws.S, s, mmax, ic, i);
-    const int g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
-    SvCol ca, cc_, lc;
-    sv_col_load(Xa, s, g, con ? r : 0, con, ca); sv_col_load(Xc, s, g, con ? r : 0, con, cc_);
-    sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con, lc);
-    sv_pin(zv); sv_pin(xav); sv_pin(xcv); sv_pin(ca); sv_pin(cc_); sv_pin(lc);
-    if (flags) return;
-    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0;
-    if (i < lo || i >= m) return;
-    const bool has_a = ia >= lo, has_c = ic < m;
-    if (vrow) { xa[tid] = has_a ? xav : 0.0; xc[tid] = has_c ? xcv : 0.0; }
-    __syncthreads();
-    if (g < 6) red[g*80 + r] = con ? (has_a ? sv_col_dot(ca, xa, s, g) : 0.0) + (has_c ? sv_col_dot(cc_, xc, s, g) : 0.0) : 0.0;
-    __syncthreads();
-    if (vrow) u[tid] = zv - (((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]));
-    __syncthreads();
-    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, u, s, g) : 0.0;
-    __syncthreads();
-    if (vrow) M.Xs[(size_t)i*s + tid] = ((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]);
-}
-
-// ---- the whole separator tree in ONE launch: forward steps of every level, the root, back substitution of every level.
-// A level of the tree is ~1 us of work behind a launch of ~6 us, twelve levels and the top per application, fifteen to twenty applications per LM
-// trial.  Here every pivot has its workgroup for the whole application (grid = labels 1 .. mmax - 1; the workgroup of the top pivot also does the
-// root): it requests its matrix operands, then POLLS the vector entries it needs -- the pending updates of the lower levels going up, the
-// solution of its neighbours coming down -- until they are no longer the NaN that k_sv_fwd_int left in those slots for this application.  A value
-// travels from its producer to a polling consumer on another XCD in ~0.65 us (tools/handover_bench.hip: flag + data 1.2 - 2 us, a dependent
-// launch 2.8 us at best), and nothing else is handed over: every other operand was written by an earlier launch.  Producers never publish a
-// NaN (a NaN result goes out as +inf: the iteration above sees it in r.z) and polling is bounded, so a broken factor cannot park the device.
-// All workgroups are resident at once (at most 127 of them on 256 CUs), and a waiting workgroup holds nothing its producers need.
-// Same arithmetic in the same order as k_sv_cre_fwd / _top / _back: the result is bit-identical to the launch-per-level path.
 #define SV_SPIN_MAX (1 << 15)
 __device__ __forceinline__ double sv_ld_co(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sv_st_co(double *p, double v) { __hip_atomic_store(p, v == v ? v : __builtin_inf(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -645,117 +499,243 @@ __device__ __forceinline__ void sv_poll2(const double *pa, bool on_a, const doub
     if (na) va = __builtin_inf();
     if (nc) vc = __builtin_inf();
 }
-__global__ __launch_bounds__(SV_CT) void k_sv_cre_tree(Work W, Work Ws, int bw, int Pmax, int htop, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], xc[80], red[6*80];
+
+// ---- the separator steps.  With the products P_a = X_a L^-1, P_c = X_c L^-1 that k_sv_linv leaves next to L^-1 (once per factorisation), a pivot's
+// forward step has ONE product on the path to its neighbours -- [P_a; P_c] v, v = g - pending -- and z = D^-1 L^-1 v beside it; its back substitution is
+//   x_i = L^-T z - P_a^T x_a - P_c^T x_c:   L^-T z before the neighbours' solutions arrive, one product after.
+// (X_a (L^-1 v) and L^-T (z - X_a^T x_a - X_c^T x_c): two products and four barriers in sequence on each way -- 2.3 us per level by wall-clock stamps.)
+struct SvFwd { double g0, g1, idq[2]; SvRow row[2]; };          // rows of [P_a; P_c; L^-1] (3 s <= 234 of them), 128 per pass, four lanes each
+__device__ __forceinline__ void sv_fwd_load(const MsBuf &M, int s, int i, int tid, SvFwd &F) {
+    const bool vrow = tid < s; const int part = tid & 3, rq = tid >> 2;
+    F.g0 = vrow ? M.G[(size_t)i*s + tid] : 0.0; F.g1 = vrow ? M.G2[(size_t)i*s + tid] : 0.0;
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) { const int R = ps*(SV_CT/4) + rq; const bool isp = R < 2*s, isl = !isp && R < 3*s;
+        const double *row = isp ? M.Pp + ((size_t)i*2*s + R)*s : M.Li + ((size_t)i*s + (isl ? R - 2*s : 0))*s;      // rows 0 .. 2 s - 1 of [label][2][s][s]: P_a, then P_c
+        F.idq[ps] = isl ? M.Lid[(size_t)i*s + R - 2*s] : 0.0;
+        sv_row_load(row, s, part, isp || isl, F.row[ps]); }
+    sv_pin(F.g0); sv_pin(F.g1); sv_pin(F.idq[0]); sv_pin(F.idq[1]); sv_pin(F.row[0]); sv_pin(F.row[1]);
+}
+// the products of a forward step with v (LDS): f(R, value) for this thread's rows R < 2 s of [P_a; P_c] v, z[r] = (L^-1 v)[r] / d[r] into zz (LDS)
+template <class F2>
+__device__ __forceinline__ void sv_fwd_products(const SvFwd &F, const double *v, int s, int tid, double *zz, F2 f) {
+    const int part = tid & 3, rq = tid >> 2;
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) { const int R = ps*(SV_CT/4) + rq;
+        const double d = sv_row_dot(F.row[ps], v, s, part);
+        if (part == 0) { if (R < 2*s) f(R, d); else if (R < 3*s) zz[R - 2*s] = d*F.idq[ps]; } }
+}
+struct SvBack { SvCol ca, cc, lc; };
+__device__ __forceinline__ void sv_back_load(const MsBuf &M, int s, int i, int g, int r, bool con, bool has_c, SvBack &K) {
+    sv_col_load(M.Pp + ((size_t)i*2 + 0)*s*s, s, g, con ? r : 0, con, K.ca); sv_col_load(M.Pp + ((size_t)i*2 + 1)*s*s, s, g, con ? r : 0, con && has_c, K.cc);
+    sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con, K.lc);
+    sv_pin(K.ca); sv_pin(K.cc); sv_pin(K.lc);
+}
+#define SV_SUM6(red, k) (((red[k] + red[80 + (k)]) + (red[160 + (k)] + red[240 + (k)])) + (red[320 + (k)] + red[400 + (k)]))
+
+// ---- cyclic reduction, level h, forward.  grid pivots, SV_CT threads:  updates [P_a; P_c] v for the neighbours, z = D^-1 L^-1 v,  v = g - pending
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_fwd(Work W, Work Ws, int bw, int Pmax, int h, int kb, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80];
     const int tid = threadIdx.x;
-    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), i = (int)blockIdx.x + 1, r0 = 0, lo = 0;
-    const bool top = i == htop;
-    const int h = i & -i, ia = i - h, ic = i + h;               // (the top pivot: ia = 0 is the root, ic >= mmax)
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
+    const int i = (2*(kb + (int)blockIdx.x) + 1)*h, ia = i - h, ic = i + h;             // (i < mmax by the launch; ia >= 0)
     const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
     const bool vrow = tid < s;
-    double g0 = vrow ? M.G[(size_t)i*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)i*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)i*s + tid] : 0.0;
-    const int part = tid & 3, rq = tid >> 2, g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
-    const double *Xa = cr_blk(Ws.S, s, mmax, i, ia), *Xc = cr_blk(Ws.S, s, mmax, ic < mmax ? ic : i, i);
-    SvRow li; sv_row_load(M.Li + ((size_t)i*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
-    auto sum6 = [&](int k) { return ((red[k] + red[80 + k]) + (red[160 + k] + red[240 + k])) + (red[320 + k] + red[400 + k]); };
-    if (top) {                                                  // ---- the top pivot and the root (k_sv_cre_top)
-        double g0r = vrow ? M.G[(size_t)r0*s + tid] : 0.0, g1r = vrow ? M.G2[(size_t)r0*s + tid] : 0.0, idr = vrow ? M.Lid[(size_t)r0*s + tid] : 0.0;
-        SvRow xar, lir; SvCol lcr;
-        sv_row_load(Xa + (size_t)(rq < s ? rq : 0)*s, s, part, rq < s, xar);
-        sv_row_load(M.Li + ((size_t)r0*s + (rq < s ? rq : 0))*s, s, part, rq < s, lir);
-        sv_col_load(M.Li + (size_t)r0*s*s, s, g, con ? r : 0, con, lcr);
-        sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(g0r); sv_pin(g1r); sv_pin(idr); sv_pin(li); sv_pin(xar); sv_pin(lir); sv_pin(lcr);
-        if (flags) return;
-        const int m = ms_uni(sv_nsep(nf, B, Pmax));
-        if (m <= 0) return;
-        const bool piv = i < m;                                  // (uniform)
-        SvPend pd; sv_pending_poll(M, s, i, piv ? h : 0, m, tid, vrow, pd);
-        double pr_[8];                                          // the root's pending updates: the pivots 2^l of the levels below h (from the right only)
-#pragma unroll
-        for (int l = 0; l < 8; l++) pr_[l] = 0.0;
-        { unsigned need = 0;
-#pragma unroll
-          for (int l = 0; l < 8; l++) { const int hp = 1 << l; if (vrow && hp < h && hp < m) need |= 1u << l; }
-          for (int spins = 0; need && spins < SV_SPIN_MAX; spins++) {
-#pragma unroll
-              for (int l = 0; l < 8; l++) if (need >> l & 1) pr_[l] = sv_ld_co(&M.Cg[((size_t)(1 << l)*2 + 0)*s + tid]);
-#pragma unroll
-              for (int l = 0; l < 8; l++) if ((need >> l & 1) && pr_[l] == pr_[l]) need &= ~(1u << l);
-              if (need) __builtin_amdgcn_s_sleep(1); }
-#pragma unroll
-          for (int l = 0; l < 8; l++) if (need >> l & 1) pr_[l] = __builtin_inf(); }
-        double zi = 0.0;
-        if (piv) {
-            if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, g0 + g1);
-            __syncthreads();
-            { const double wv = sv_row_dot(li, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
-            __syncthreads();
-            if (vrow) zi = w[tid]*idv;
-            { const double a = sv_row_dot(xar, w, s, part); if (rq < s && part == 0) cga[rq] = a; }
-            __syncthreads();
-        }
-        SvCol ca, lc;
-        sv_col_load(Xa, s, g, con ? r : 0, con && piv, ca);
-        sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con && piv, lc);
-        if (vrow) { double t = g0r + g1r;
-#pragma unroll
-            for (int l = 0; l < 8; l++) { const int hp = 1 << l; if (hp < h && hp < m) t -= pr_[l]; }
-            if (piv) t -= cga[tid];
-            v[tid] = t; }
-        __syncthreads();
-        { const double wv = sv_row_dot(lir, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
-        __syncthreads();
-        if (vrow) v[tid] = w[tid]*idr;
-        __syncthreads();
-        if (g < 6) red[g*80 + r] = con ? sv_col_dot(lcr, v, s, g) : 0.0;
-        __syncthreads();
-        if (vrow) { const double xv = sum6(tid); x0[tid] = xv; sv_st_co(&M.Xs[(size_t)r0*s + tid], xv); }
-        if (!piv) return;
-        __syncthreads();
-        if (g < 6) red[g*80 + r] = con ? sv_col_dot(ca, x0, s, g) : 0.0;
-        __syncthreads();
-        if (vrow) v[tid] = zi - sum6(tid);
-        __syncthreads();
-        if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;
-        __syncthreads();
-        if (vrow) sv_st_co(&M.Xs[(size_t)i*s + tid], sum6(tid));
-        return;
-    }
-    // ---- a pivot below the top: forward step (k_sv_cre_fwd) ...
-    SvRow xr[2];
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) { const int rr = ps*(SV_CT/4) + rq; const bool rok = rr < 2*s;
-        sv_row_load((rr < s ? Xa : Xc) + (size_t)(rok ? (rr < s ? rr : rr - s) : 0)*s, s, part, rok, xr[ps]); }
-    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(li); sv_pin(xr[0]); sv_pin(xr[1]);
+    SvFwd F; sv_fwd_load(M, s, i, tid, F);
+    SvPend pd; sv_pending_load(M, s, i, mmax, tid, vrow, pd); sv_pin(pd);
     if (flags) return;
-    const int m = ms_uni(sv_nsep(nf, B, Pmax));
-    if (i >= m) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0, r0 = 0;
+    if (i < lo || i >= m) return;
     const bool has_a = ia >= lo, has_c = ic < m;
-    SvPend pd; sv_pending_poll(M, s, i, h, m, tid, vrow, pd);
-    if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, g0 + g1);
+    if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, F.g0 + F.g1);
+    __syncthreads();
+    sv_fwd_products(F, v, s, tid, M.Z + (size_t)i*s, [&](int R, double acc) { M.Cg[((size_t)i*2 + (R < s ? 0 : 1))*s + (R < s ? R : R - s)] = (R < s ? has_a : has_c) ? acc : 0.0; });
+}
+
+// ---- the last block: forward and backward.  One workgroup.
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_root(Work W, int bw, int Pmax, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80], w[80], red[6*80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), r0 = 0;            // (chains: the root is label 0)
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s;
+    double g0 = vrow ? M.G[(size_t)r0*s + tid] : 0.0, g1 = vrow ? M.G2[(size_t)r0*s + tid] : 0.0, idv = vrow ? M.Lid[(size_t)r0*s + tid] : 0.0;
+    SvPend pd; sv_pending_load(M, s, r0, mmax, tid, vrow, pd);
+    const int part = tid & 3, rq = tid >> 2, g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    SvRow li; SvCol lc;
+    sv_row_load(M.Li + ((size_t)r0*s + (rq < s ? rq : 0))*s, s, part, rq < s, li);
+    sv_col_load(M.Li + (size_t)r0*s*s, s, g, con ? r : 0, con, lc);
+    sv_pin(g0); sv_pin(g1); sv_pin(idv); sv_pin(pd); sv_pin(li); sv_pin(lc);
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0;
+    if (m <= 0) return;
+    if (vrow) v[tid] = sv_pending_sum(pd, r0, 1 << 30, lo, m, -1, g0 + g1);
     __syncthreads();
     { const double wv = sv_row_dot(li, v, s, part);
       if (rq < s && part == 0) w[rq] = wv; }
     __syncthreads();
-    const double zv = vrow ? w[tid]*idv : 0.0;
+    if (vrow) v[tid] = w[tid]*idv;                              // z
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;       // x = L^-T z
+    __syncthreads();
+    if (vrow) M.Xs[(size_t)r0*s + tid] = ((red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid])) + (red[320 + tid] + red[400 + tid]);
+}
+
+// ---- the top of the tree in one launch: the single pivot of the highest level (i = h: its left neighbour is the root, it has no right one), the root,
+// and the pivot's back substitution -- three dependent launches of ~5 us as one workgroup's work, every operand of the three steps requested up front.
+// (With no pivot at that level, m <= h, this is the root kernel.)  TREE: as a workgroup of k_sv_cre_tree -- pending updates polled, results published.
+template <bool TREE>
+__device__ __forceinline__ void sv_top_body(const Work &W, int s, int B, int Pmax, int mmax, int h, const MsBuf &M, double *v, double *w, double *cga, double *x0, double *zz, double *red) {
+    const int tid = threadIdx.x, i = h, r0 = 0, lo = 0;
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s;
+    const int part = tid & 3, rq = tid >> 2, g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    SvFwd F; sv_fwd_load(M, s, i, tid, F);
+    double g0r = vrow ? M.G[(size_t)r0*s + tid] : 0.0, g1r = vrow ? M.G2[(size_t)r0*s + tid] : 0.0, idr = vrow ? M.Lid[(size_t)r0*s + tid] : 0.0;
+    SvRow lir; SvCol lcr;
+    sv_row_load(M.Li + ((size_t)r0*s + (rq < s ? rq : 0))*s, s, part, rq < s, lir);
+    sv_col_load(M.Li + (size_t)r0*s*s, s, g, con ? r : 0, con, lcr);
+    sv_pin(g0r); sv_pin(g1r); sv_pin(idr); sv_pin(lir); sv_pin(lcr);
+    SvPend pd; double pr_[8];                                  // pr_: the root's pending updates -- the pivots 2^l of the levels below h (from the right only)
+    if (!TREE) { sv_pending_load(M, s, i, mmax, tid, vrow, pd); sv_pin(pd);
 #pragma unroll
-    for (int ps = 0; ps < 2; ps++) { const int rr = ps*(SV_CT/4) + rq; const bool rok = rr < 2*s;
-        const double acc = sv_row_dot(xr[ps], w, s, part);
-        if (rok && part == 0) sv_st_co(&M.Cg[((size_t)i*2 + (rr < s ? 0 : 1))*s + (rr < s ? rr : rr - s)], (rr < s ? has_a : has_c) ? acc : 0.0);
+        for (int l = 0; l < 8; l++) { const int hp = 1 << l; pr_[l] = (vrow && hp < h && hp < mmax) ? M.Cg[((size_t)hp*2 + 0)*s + tid] : 0.0; sv_pin(pr_[l]); } }
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax));
+    if (m <= 0) return;
+    const bool piv = i < m;                                      // (uniform)
+    if (TREE) { sv_pending_poll(M, s, i, piv ? h : 0, m, tid, vrow, pd);
+        unsigned need = 0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) { const int hp = 1 << l; pr_[l] = 0.0; if (vrow && hp < h && hp < m) need |= 1u << l; }
+        for (int spins = 0; need && spins < SV_SPIN_MAX; spins++) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) if (need >> l & 1) pr_[l] = sv_ld_co(&M.Cg[((size_t)(1 << l)*2 + 0)*s + tid]);
+#pragma unroll
+            for (int l = 0; l < 8; l++) if ((need >> l & 1) && pr_[l] == pr_[l]) need &= ~(1u << l);
+            if (need) __builtin_amdgcn_s_sleep(1); }
+#pragma unroll
+        for (int l = 0; l < 8; l++) if (need >> l & 1) pr_[l] = __builtin_inf(); }
+    if (piv) {                                                  // forward step of the pivot: the root's update P_a v, z = D^-1 L^-1 v
+        if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, F.g0 + F.g1);
+        __syncthreads();
+        sv_fwd_products(F, v, s, tid, zz, [&](int R, double acc) { if (R < s) cga[R] = acc; });
+        __syncthreads();
     }
-    // ---- ... and, once both neighbours are solved, its back substitution (k_sv_cre_back): the operands travel while the levels above work
-    SvCol ca, cc_, lc;
-    sv_col_load(Xa, s, g, con ? r : 0, con, ca); sv_col_load(Xc, s, g, con ? r : 0, con && has_c, cc_);
-    sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con, lc);
-    sv_pin(ca); sv_pin(cc_); sv_pin(lc);
+    // (the operands of the pivot's back substitution are requested here: the registers of its forward step are free, the root's work hides the wait)
+    SvCol ca, lc;
+    sv_col_load(M.Pp + ((size_t)i*2 + 0)*s*s, s, g, con ? r : 0, con && piv, ca);
+    sv_col_load(M.Li + (size_t)i*s*s, s, g, con ? r : 0, con && piv, lc);
+    // the root: its pending updates of the levels below h as the root kernel takes them, the pivot's last
+    if (vrow) { double t = g0r + g1r;
+#pragma unroll
+        for (int l = 0; l < 8; l++) { const int hp = 1 << l; if (hp < h && hp < m) t -= pr_[l]; }
+        if (piv) t -= cga[tid];
+        v[tid] = t; }
+    __syncthreads();
+    { const double wv = sv_row_dot(lir, v, s, part); if (rq < s && part == 0) w[rq] = wv; }
+    __syncthreads();
+    if (vrow) v[tid] = w[tid]*idr;                               // z of the root
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lcr, v, s, g) : 0.0;
+    __syncthreads();
+    if (vrow) { const double xv = SV_SUM6(red, tid); x0[tid] = xv; if (TREE) sv_st_co(&M.Xs[(size_t)r0*s + tid], xv); else M.Xs[(size_t)r0*s + tid] = xv; }
+    if (!piv) return;
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, zz, s, g) : 0.0;     // L^-T z
+    __syncthreads();
+    const double u0 = vrow ? SV_SUM6(red, tid) : 0.0;
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(ca, x0, s, g) : 0.0;     // P_a^T x_0
+    __syncthreads();
+    if (vrow) { const double xv = u0 - SV_SUM6(red, tid); if (TREE) sv_st_co(&M.Xs[(size_t)i*s + tid], xv); else M.Xs[(size_t)i*s + tid] = xv; }
+}
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_top(Work W, Work Ws, int bw, int Pmax, int h, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], zz[80], red[6*80];
+    sv_top_body<false>(W, bw, bw/6, Pmax, cr_mmax(W.ring, Pmax, W.ring_g), h, M, v, w, cga, x0, zz, red);
+    (void)Ws;
+}
+
+// ---- cyclic reduction, level h, backward.  grid pivots, SV_CT threads:  x_i = L^-T z_i - P_a^T x_a - P_c^T x_c
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_back(Work W, Work Ws, int bw, int Pmax, int h, int kb, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double zz[80], xa[80], xc[80], red[6*80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g);
+    const int i = (2*(kb + (int)blockIdx.x) + 1)*h, ia = i - h, ic = i + h;
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s, cin = ic < mmax;
+    double zv = vrow ? M.Z[(size_t)i*s + tid] : 0.0, xav = vrow ? M.Xs[(size_t)ia*s + tid] : 0.0, xcv = (vrow && cin) ? M.Xs[(size_t)ic*s + tid] : 0.0;
+    const int g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    SvBack K; sv_back_load(M, s, i, g, r, con, true, K);
+    sv_pin(zv); sv_pin(xav); sv_pin(xcv);
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax)), lo = 0;
+    if (i < lo || i >= m) return;
+    const bool has_a = ia >= lo, has_c = ic < m;
+    if (vrow) { zz[tid] = zv; xa[tid] = has_a ? xav : 0.0; xc[tid] = has_c ? xcv : 0.0; }
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(K.lc, zz, s, g) : 0.0;
+    __syncthreads();
+    const double u0 = vrow ? SV_SUM6(red, tid) : 0.0;
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? (has_a ? sv_col_dot(K.ca, xa, s, g) : 0.0) + (has_c ? sv_col_dot(K.cc, xc, s, g) : 0.0) : 0.0;
+    __syncthreads();
+    if (vrow) M.Xs[(size_t)i*s + tid] = u0 - SV_SUM6(red, tid);
+    (void)Ws;
+}
+
+// ---- the whole separator tree in ONE launch: forward steps of every level, the root, back substitution of every level.
+// A level of the tree is ~1 us of work behind a launch of ~6 us, twelve levels and the top per application, fifteen to twenty applications per LM
+// trial.  Here every pivot has its workgroup for the whole application (grid = labels 1 .. mmax - 1; the workgroup of the top pivot also does the
+// root): it requests its matrix operands, then POLLS the vector entries it needs -- the pending updates of the lower levels going up, the
+// solution of its neighbours coming down -- until they are no longer the NaN that k_sv_fwd_int left in those slots for this application.  A value
+// travels from its producer to a polling consumer on another XCD in ~0.65 us (tools/handover_bench.hip: flag + data 1.2 - 2 us, a dependent
+// launch 2.8 us at best), and nothing else is handed over: every other operand was written by an earlier launch.  Producers never publish a
+// NaN (a NaN result goes out as +inf: the iteration above sees it in r.z) and polling is bounded, so a broken factor cannot park the device.
+// All workgroups are resident at once (at most 127 of them on 256 CUs), and a waiting workgroup holds nothing its producers need.
+// Same arithmetic in the same order as k_sv_cre_fwd / _top / _back: the result is bit-identical to the launch-per-level path.
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_tree(Work W, Work Ws, int bw, int Pmax, int htop, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], xc[80], red[6*80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), i = (int)blockIdx.x + 1, lo = 0, r0 = 0;
+    if (i == htop) { sv_top_body<true>(W, s, B, Pmax, mmax, htop, M, v, w, cga, x0, xc, red); return; }
+#ifdef TSBA_SOLVE_STAMPS
+    // wall-clock stamps (10 ns ticks, one clock for the whole device) of pivot 1 and of the pivot below the top: W.dbg[0 / 8 ..]
+    const int sslot = i == 1 ? 0 : i == htop/2 ? 8 : -1; int sn = 0;
+#define TREE_STAMP() do { if (sslot >= 0 && tid == 0 && sn < 8) W.dbg[sslot + sn++] = wall_clock64(); } while (0)
+#else
+#define TREE_STAMP() do { } while (0)
+#endif
+    TREE_STAMP();
+    const int h = i & -i, ia = i - h, ic = i + h;
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s;
+    const int g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    SvFwd F; sv_fwd_load(M, s, i, tid, F);
+    if (flags) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax));
+    if (i >= m) return;
+    const bool has_a = ia >= lo, has_c = ic < m;
+    TREE_STAMP();
+    // ---- forward step (k_sv_cre_fwd) ...
+    SvPend pd; sv_pending_poll(M, s, i, h, m, tid, vrow, pd);
+    TREE_STAMP();
+    if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, F.g0 + F.g1);
+    __syncthreads();
+    sv_fwd_products(F, v, s, tid, w, [&](int R, double acc) { sv_st_co(&M.Cg[((size_t)i*2 + (R < s ? 0 : 1))*s + (R < s ? R : R - s)], (R < s ? has_a : has_c) ? acc : 0.0); });     // (w: z)
+    TREE_STAMP();
+    // ---- ... and its back substitution (k_sv_cre_back): the operands and L^-T z while the levels above work, one product once both neighbours are solved
+    SvBack K; sv_back_load(M, s, i, g, r, con, has_c, K);
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(K.lc, w, s, g) : 0.0;
+    __syncthreads();
+    const double u0 = vrow ? SV_SUM6(red, tid) : 0.0;
     double xav, xcv; sv_poll2(&M.Xs[(size_t)ia*s + tid], vrow && has_a, &M.Xs[(size_t)ic*s + tid], vrow && has_c, xav, xcv);
+    TREE_STAMP();
     if (vrow) { x0[tid] = xav; xc[tid] = xcv; }
     __syncthreads();
-    if (g < 6) red[g*80 + r] = con ? (has_a ? sv_col_dot(ca, x0, s, g) : 0.0) + (has_c ? sv_col_dot(cc_, xc, s, g) : 0.0) : 0.0;
+    if (g < 6) red[g*80 + r] = con ? (has_a ? sv_col_dot(K.ca, x0, s, g) : 0.0) + (has_c ? sv_col_dot(K.cc, xc, s, g) : 0.0) : 0.0;
     __syncthreads();
-    if (vrow) v[tid] = zv - sum6(tid);
-    __syncthreads();
-    if (g < 6) red[g*80 + r] = con ? sv_col_dot(lc, v, s, g) : 0.0;
-    __syncthreads();
-    if (vrow) sv_st_co(&M.Xs[(size_t)i*s + tid], sum6(tid));
+    if (vrow) sv_st_co(&M.Xs[(size_t)i*s + tid], u0 - SV_SUM6(red, tid));
+    TREE_STAMP();
+    (void)Ws;
 }
