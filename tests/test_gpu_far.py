@@ -253,3 +253,30 @@ def test_solver_status_in_the_report(gpu):
     assert rl["solver_path"] == 0, rl
     rp = gpu.PoseOptim(synth.config_c3().copy())
     assert rp["solver_path"] == 8, rp
+
+
+@pytest.mark.parametrize("n_kf,band,parts", [(900, 9, 17), (1100, 12, 11), (600, 8, -30), (1500, 10, 27)])
+def test_separator_back_substitution_in_one_launch(gpu, n_kf, band, parts):
+    """The direct solve of a chain map: the separators' back substitution as ONE launch through the inverse factors and products of the solve phase
+    (k_sv_linv + k_cre_back_tree, workgroups polling their neighbours' solutions: production) against a substitution launch per level (k_cre_back,
+    tsba_debug_options.sv_per_level = 2), on maps with long-range blocks (where the iterative path builds those operands anyway) -- the first step against
+    scipy's sparse solve of the assembled system and against each other, the same LM run."""
+    from scipy.sparse.linalg import spsolve
+    P = synth.config_global(n_kf=n_kf, n_pt=40*n_kf, band=band, far_frac=0.01)      # (the one-launch form runs where the iterative path needs its operands anyway: maps with long-range blocks)
+    o = abi.options_global(); o.its[0] = 6
+    runs = []
+    try:
+        for per_level in (0, 2):
+            gpu.debug_set(band_parts=abs(parts), sep_solver=2, sv_per_level=per_level, far_solver=3, pcg_block=1)
+            gpu.upload(P, o)
+            info = gpu.solver_info()
+            assert info["band_stream"] == 1 and info["sep_cr"] == 1 and info["far_band_blocks"] > 0, info
+            A, rb, nblk = _sparse_system(gpu, o.initial_radius)
+            ref = spsolve(sp.csc_matrix(A), -rb["g"])
+            assert nblk > 0 and np.abs(rb["dp_rows"] - ref).max() <= 1e-7*np.abs(ref).max(), (per_level, np.abs(rb["dp_rows"] - ref).max()/np.abs(ref).max())     # (conjugate gradients to 1e-10 in the M^-1 norm)
+            rep = gpu.solve(); G = gpu.download(P.copy())
+            runs.append((rb["dp_rows"].copy(), rep, G))
+    finally:
+        gpu.debug_set()
+    assert np.abs(runs[0][0] - runs[1][0]).max() <= 1e-7*np.abs(runs[1][0]).max()
+    _same_trajectory(runs[1][1], runs[0][1], runs[1][2], runs[0][2], atol=1e-7)

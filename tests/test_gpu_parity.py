@@ -372,7 +372,7 @@ def test_theta_optim_singular_information_is_not_an_error(gpu):
 
 @pytest.mark.parametrize("n_kf", [4, 5, 7, 20, 31])
 def test_small_window_solver_schedules_agree(gpu, n_kf):
-    """The reduced system of a small window through its two schedules (tsba_debug_options.solve_variant): the production kernel (two panel waves:
+    """The reduced system of a small window through its schedules (tsba_debug_options.solve_variant): the production kernel (two panel waves:
     look-ahead, 6x6 LDL^T and panel solve on the same wave) and the round-4 experiment with a separate wave that factors the next diagonal block
     while the panel is solved (tsba_solve_la.h; measured slower, kept for A/B runs) -- same LM trajectory, first step to 1e-11.  1, 2, 4, 17 and
     28 free poses (the LOCAL gauge fixes three keyframes)."""
@@ -380,7 +380,7 @@ def test_small_window_solver_schedules_agree(gpu, n_kf):
     o = abi.options_local()
     runs = []
     try:
-        for var in (0, 1, 2):
+        for var in (0, 1, 2, 3):
             gpu.debug_set(solve_variant=var)
             gpu.upload(P, o)
             rs = gpu.reduced_system(o.initial_radius)
@@ -395,3 +395,7 @@ def test_small_window_solver_schedules_agree(gpu, n_kf):
         assert rep["iters"] == ref[1]["iters"] and rep["accepted"] == ref[1]["accepted"] and rep["termination"] == ref[1]["termination"]
         np.testing.assert_allclose(rep["cost1"], ref[1]["cost1"], rtol=1e-10)
         np.testing.assert_allclose(G.pose, ref[2].pose, rtol=0, atol=1e-9)
+    # variant 3 = the production solver with the back-substitution as a launch of its own; production (0) runs both in one launch (k_solve_back: the
+    # back-substitution blocks poll the pose step): the same arithmetic in the same order, the same bits
+    assert np.array_equal(runs[3][2].pose, ref[2].pose) and np.array_equal(runs[3][2].rho, ref[2].rho) and np.array_equal(runs[3][2].theta, ref[2].theta)
+    assert runs[3][1]["cost1"] == ref[1]["cost1"]

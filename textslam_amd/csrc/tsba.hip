@@ -109,7 +109,7 @@ struct Ctx {
     WbBuf wb{}; Work Wk{}; double *wb_alloc = nullptr; size_t wb_bytes = 0;      // low-rank correction for loop closures (tsba_wb.h): its buffers, the k x k dense system as a second Work
     EcgBuf ecg{}; double *ecg_alloc = nullptr; size_t ecg_bytes = 0;      // enlarged conjugate gradients (tsba_pcg.h)
     unsigned char *dl_dev = nullptr, *dl_host = nullptr; size_t dl_bytes = 0;       // results of a solve as one block (k_pack_results): one device-to-host copy per download
-    MsBuf sv{}; double *sv_alloc = nullptr; size_t sv_bytes = 0;                      // single-vector solve phase (tsba_bandsv.h)
+    MsBuf sv{}; double *sv_alloc = nullptr; size_t sv_bytes = 0; bool sv_prepared = false;      // single-vector solve phase (tsba_bandsv.h); sv_prepared: k_sv_linv has run on the current factorisation
     MsBuf ms{}; double *ms_alloc = nullptr; size_t ms_bytes = 0; int ms_cap = 0;      // multi-right-hand-side solve phase of the partitioned band solver (tsba_bandms.h)
     std::vector<int32_t> rb_r, rb_c; std::vector<double> rb_v;      // tsba_debug_reduced_blocks: the blocks between its two calls
     int cov_text = -1; double *cov_log = nullptr;     // tsba_theta_optim: V of this plane at the end of every pass [TSBA_MAX_LEVELS][6]
@@ -480,7 +480,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         mx_pslot = std::max(mx_pslot, (size_t)D.n_pslot); mx_tslot = std::max(mx_tslot, (size_t)D.n_tslot); mx_cnt = std::max(mx_cnt, (size_t)D.n_sc + D.n_tg);
     }
     c->stage_p = defer ? p : nullptr;
-    c->nb_back_max = (p->n_pt + 255)/256 + (p->n_text + 255)/256 + (p->n_kf + 255)/256;
+    c->nb_back_max = back_blocks_pt(p->n_pt) + back_blocks_tx(p->n_text) + (p->n_kf + 255)/256;      // k_back's blocks (at least k_mid's landmark blocks)
     {   bool po = p->n_kf == 1;
         for (int j = 0; po && j < p->n_pt; j++) po = p->pt_host[j] < 0;
         for (int j = 0; po && j < p->n_text; j++) po = p->text_host[j] < 0;
@@ -506,6 +506,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         // view: S(i,j) = base[i*(LDB-1) + j], LDB = band + 96 columns of the diagonal block's upper triangle, where the inverse
         // diagonal factors are kept) -- 80 MB instead of 7.2 GB at 5000 keyframes, and what the ranks all-reduce
         const int use_lds_ = solve_lds_doubles(W.N)*sizeof(double) <= 160*1024 - 64;        // (as solve_lds_bytes)
+        W.dp_poll = use_lds_ && !is_multi(c) && !c->pose_only && c->dbg.solve_variant == 0;        // solver and back-substitution in one launch (k_solve_back)
         int bwmax = 0; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
         // band storage: row i holds the columns [i - Wb, i + up) (skewed view S(i, j) = base[i (LDB - 1) + j]).  The blocked Cholesky of
         // tsba_chol.h writes 96-wide blocks on both sides of the diagonal (up = CH_NB, Wb = band + CH_NB - 1); the streaming / partitioned
@@ -592,7 +593,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         c->S_xchg = nullptr; c->xchg_wp = 0;
         if (W.band && is_multi(c)) { c->xchg_wp = std::min(W.N, bwmax + 6); AL(c->S_xchg, ((size_t)W.N + bwmax)*c->xchg_wp); }
     }
-    AL(W.g, W.N); AL(W.dp, W.N); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
+    AL(W.g, W.N); AL(W.dp, W.N + 2); AL(W.dl_pt, p->n_pt); AL(W.dl_tx, 3*(size_t)p->n_text);
     AL(W.partial, 2*(size_t)c->nb_back_max);
     AL(W.posepart, 2*((size_t)p->n_kf/21 + 2));
     AL(W.cntpart, 2*(mx_cnt/4 + mx_cnt/256 + 4));
@@ -799,7 +800,7 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     if (multi) {
         // local sums -> exchange buffer -> all-reduce; the consumer (k_postlin / k_decide) installs them into the right LinBuf
         if (npp) hipLaunchKernelGGL(k_pose_sums_raw, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
-        hipLaunchKernelGGL(k_sums_multi, dim3(1), dim3(256), 0, c->stream, W, D, spec, nb_pt + nb_tx + nb_pr, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx, npp);
+        hipLaunchKernelGGL(k_sums_multi, dim3(1), dim3(256), 0, c->stream, W, D, spec, nb_pt + nb_tx + nb_pr, back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text) + nb_kf, back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text), npp);      // (k_back's blocks: its partial sums)
         allreduce(c, W.cb, 2*(size_t)W.N + 8, ncclDouble, ncclSum);
         allreduce(c, W.cbm, 1, ncclDouble, ncclMax);
         if (npp) hipLaunchKernelGGL(k_pose_scale_multi, dim3(npp), dim3(256), 0, c->stream, W, spec);
@@ -834,6 +835,7 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
 static int set_solver_attrs(Ctx *c) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) { CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipFuncSetAttribute((const void *)k_solve_back, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, (int)((768 + c->W.N + 2)*sizeof(double)))));
         CK(hipFuncSetAttribute((const void *)k_solve_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(solve_la_lds_doubles(c->W.N)*sizeof(double), 160*1024 - 64))); }
     else {
         CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -870,8 +872,12 @@ static int set_solver_attrs(Ctx *c) {
 }
 static void launch_dense_chol(Ctx *c, Work &W, int bw);
 // dense solve of the reduced camera system: LDS kernel for small windows, multi-workgroup blocked Cholesky otherwise
+static bool ms_available(const Ctx *c);
+static int sv_reserve(Ctx *c);
+static void launch_sv_prepare(Ctx *c, double *xreset);
 static void launch_solve(Ctx *c) {
     Work &W = c->W;
+    c->sv_prepared = false;
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) {                                  // small windows: one workgroup, S in LDS.  solve_variant 1: the two-panel-wave schedule of tsba_solve.h (A/B runs)
         const size_t la = solve_la_lds_doubles(W.N)*sizeof(double);
@@ -907,6 +913,13 @@ static void launch_solve(Ctx *c) {
                     const int K = std::max(1, std::min(TSBA_CRE_KMAX, 224/npiv));     // workgroups per pivot (they share its product and stores)
                     hipLaunchKernelGGL(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, kb, c->CRcontrib, c->CRfac); htop = h; }
                 hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, W.ring ? 2 : 1, 1, 0, c->CRcontrib, c->CRfac);
+                // back substitution: a launch per level -- or, where the iterative path needs the inverse factors and products of the solve phase anyway (maps with
+                // long-range blocks), one launch through them (k_sv_linv + k_cre_back_tree).  For a plain direct solve k_sv_linv costs more than the six launches
+                // it saves (5000-keyframe chain 15.4 against 14.9 ms, C5 with 72-row separators 10.4 against 9.3 ms)
+                if (c->far_B > 0 && ms_available(c) && !(c->dbg.sv_per_level & 2) && c->dbg.pcg_refactor != 1 && mmax >= 2 && sv_reserve(c) == TSBA_OK) {
+                    launch_sv_prepare(c, Ws.Sy);
+                    hipLaunchKernelGGL(k_cre_back_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, c->sv);
+                } else
                 for (int h = htop; h >= 1; h >>= 1) { int kb; const int npiv = pivots(h, kb); if (npiv > 0) hipLaunchKernelGGL(k_cre_back, dim3(npiv), dim3(CRE_BT), lbk, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac); }
             } else {
             for (int h = 1; h < mmax; h <<= 1) {
@@ -1034,9 +1047,10 @@ static int sv_reserve(Ctx *c) {
 // least 2 B + 2 blocks; where it has to take fewer interiors they stay below twice that)
 static int sv_lmax_of(int n_kf, int B, int P) { return std::max(n_kf/std::max(1, P) + 2, 5*B + 8); }
 static int sv_lmax(const Ctx *c) { return sv_lmax_of(c->n_kf, std::max(6, c->cur_bw_rows)/6, c->band_parts); }
-static void launch_sv_prepare(Ctx *c) {
+static void launch_sv_prepare(Ctx *c, double *xreset) {
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, mmax = cr_mmax(0, P, 0);
-    if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(SV_LT), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, (const double *)c->Ssep, c->sv);
+    if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(SV_LT), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, (const double *)c->Ssep, c->sv, xreset);
+    c->sv_prepared = true;
 }
 static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rdot = nullptr, double *rz_part = nullptr) {
     Work &W = c->W; const MsBuf &M = c->sv;
@@ -1049,7 +1063,7 @@ static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rd
     for (int h = 1; h < mmax; h <<= 1) if (pivots(h) > 0) htop = h;
     // the highest level has one pivot (3 h >= 2 h >= the number of separators): its forward step, the root and its back substitution are one workgroup's work
     const bool fuse_top = htop > 0 && pivots(htop) == 1;
-    const int tree = fuse_top && !c->dbg.sv_per_level;           // the whole tree in one launch (k_sv_cre_tree)
+    const int tree = fuse_top && !(c->dbg.sv_per_level & 1);           // the whole tree in one launch (k_sv_cre_tree)
     if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree);
     else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree);
     if (tree) hipLaunchKernelGGL(k_sv_cre_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
@@ -1079,7 +1093,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     const unsigned int seq = ++c->pcg_seq;
     // the inverse factors of the separators (k_sv_linv), once per factorisation: the single-vector solve phase and the product form of the many-column one use them
     const bool svok = ms_available(c) && c->dbg.pcg_refactor != 1 && sv_reserve(c) == TSBA_OK;       // (pcg_refactor = 3: as 0 with r.z by its own kernel, for A/B runs)
-    if (svok) launch_sv_prepare(c);
+    if (svok && !c->sv_prepared) launch_sv_prepare(c, nullptr);       // (the direct solve of a chain has run it already: its back substitution uses the same products)
     // Enlarged conjugate gradients on the many-column solve phase of the band solver (ECG_T columns per application of M^-1): an option (pcg_block = 2).
     // It halves the iterations where the coupling outside the band is a few hundred blocks (outlying eigenvalues, captured 32 at a time), but an
     // application costs 0.8 ms at 5000 keyframes against 0.13 ms of the single-vector solve phase (tsba_bandsv.h) -- measured when the single-vector
@@ -1240,10 +1254,16 @@ static void launch_step(Ctx *c, const LevelDev &D) {
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
         hipLaunchKernelGGL(k_damp_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
-    launch_solve_full(c, D);
-    hipLaunchKernelGGL(k_back, dim3(nb_pt + nb_tx + nb_kf), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx);
+    const int bb_pt = back_blocks_pt(c->n_pt), bb_tx = back_blocks_tx(c->n_text), nb_all = bb_pt + bb_tx + nb_kf;      // k_back's blocks
+    if (W.dp_poll && D.far_B <= 0) {               // small window: solver (workgroup 0) and back-substitution (three blocks per workgroup, polling the step) in one launch
+        int use_lds; const int lds = solve_lds_bytes(c, &use_lds);
+        hipLaunchKernelGGL(k_solve_back, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), std::max(lds, (int)((768 + W.N + 2)*sizeof(double))), c->stream, W, D, bb_pt, bb_tx, nb_all);
+    } else {
+        launch_solve_full(c, D);
+        hipLaunchKernelGGL(k_back, dim3(nb_all), dim3(256), 0, c->stream, W, D, bb_pt, bb_tx);
+    }
     launch_linearize(c, D, 1);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_pt + nb_tx + nb_kf, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_all, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
 }
 
 int tsba_solve(void *ctx, tsba_report *r) {

@@ -334,12 +334,13 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
 // -- 300 FMAs per thread and two barriers per block row (a thread per column solving L y = e_j row by row: 1800 dependent FMAs, 64 us per launch).
 #define SV_LT 512
 static size_t sv_linv_lds_doubles(int s) { return ((cre_rec_doubles(s) + 8) & ~(size_t)1) + (size_t)s*(s + 1) + std::max(6*(size_t)(s + 2), (size_t)s*(s + 1)); }
-__global__ __launch_bounds__(SV_LT) void k_sv_linv(Work W, int bw, int Pmax, const double *__restrict__ fac, const double *__restrict__ pool, MsBuf M) {
+__global__ __launch_bounds__(SV_LT) void k_sv_linv(Work W, int bw, int Pmax, const double *__restrict__ fac, const double *__restrict__ pool, MsBuf M, double *xreset) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, s = bw, B = s/6, i = blockIdx.x;
     const LmState *st_ = W.st; const int flags = st_->done | st_->step_fail, nf = ms_uni(*W.nfree);
     if (flags) return;
     if (i >= sv_nsep(nf, B, Pmax)) return;
+    if (xreset && i > 0 && tid < s) xreset[(size_t)i*s + tid] = __builtin_nan("");       // (k_cre_back_tree polls the separators' solution: not there yet)
     const size_t nrec = cre_rec_doubles(s);
     double *recl = ms_smem, *Y = recl + ((nrec + 8) & ~(size_t)1), *T = Y + (size_t)s*(s + 1);      // packed record | Linv [s][s + 1] | T [6][s + 2]
     const double *rec = fac + (size_t)i*nrec;
@@ -738,4 +739,36 @@ __global__ __launch_bounds__(SV_CT) void k_sv_cre_tree(Work W, Work Ws, int bw, 
     if (vrow) sv_st_co(&M.Xs[(size_t)i*s + tid], u0 - SV_SUM6(red, tid));
     TREE_STAMP();
     (void)Ws;
+}
+
+// ---- the back substitution of the factorisation's OWN right-hand side through the same products, in one launch: x_i = L^-T z_i - P_a^T x_a - P_c^T x_c with z_i
+// from the pivot's record (k_cre_elim carries the right-hand side along), the root's x from the root launch, every other separator polled as in
+// k_sv_cre_tree (k_sv_linv, the launch before, leaves the NaNs in Ws.Sy).  Replaces the six k_cre_back launches of a 5000-keyframe chain (10.5 us each:
+// a substitution on one wave behind its launch) by k_sv_linv (which the iterative path runs anyway) + ~15 us.
+__global__ __launch_bounds__(SV_CT) void k_cre_back_tree(Work W, Work Ws, int bw, int Pmax, const double *__restrict__ fac, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double zz[80], xa[80], xc[80], red[6*80];
+    const int tid = threadIdx.x;
+    const int s = bw, B = s/6, i = (int)blockIdx.x + 1, h = i & -i, ia = i - h, ic = i + h;
+    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = *W.nfree;
+    const bool vrow = tid < s;
+    double zv = vrow ? fac[(size_t)i*cre_rec_doubles(s) + rowoff(s) + SOLVE_LD*B + tid] : 0.0;
+    const int g = tid/80, r = tid - 80*g; const bool con = g < 6 && r < s;
+    SvBack K; sv_back_load(M, s, i, g, r, con, true, K);
+    sv_pin(zv);
+    if (flags || nf <= 0) return;
+    const int m = ms_uni(sv_nsep(nf, B, Pmax));
+    if (i >= m) return;
+    const bool has_c = ic < m;
+    double *x = Ws.Sy;
+    if (vrow) zz[tid] = zv;
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(K.lc, zz, s, g) : 0.0;
+    __syncthreads();
+    const double u0 = vrow ? SV_SUM6(red, tid) : 0.0;
+    double xav, xcv; sv_poll2(&x[(size_t)ia*s + tid], vrow, &x[(size_t)ic*s + tid], vrow && has_c, xav, xcv);
+    if (vrow) { xa[tid] = xav; xc[tid] = xcv; }
+    __syncthreads();
+    if (g < 6) red[g*80 + r] = con ? sv_col_dot(K.ca, xa, s, g) + (has_c ? sv_col_dot(K.cc, xc, s, g) : 0.0) : 0.0;
+    __syncthreads();
+    if (vrow) sv_st_co(&x[(size_t)i*s + tid], u0 - SV_SUM6(red, tid));
 }

@@ -258,8 +258,8 @@ int tsba_debug_multi_solve(void *ctx, int T, const double *R, double *X) {      
     st.done = 0; st.step_fail = 0; st.lin_done = 0; CK(hipMemcpy(c->W.st, &st, sizeof(st), hipMemcpyHostToDevice));
     const MsBuf &M = single ? c->sv : c->ms;
     CK(hipMemcpy(M.R, R, sizeof(double)*6*(size_t)nfree*T, hipMemcpyHostToDevice));
-    if (single) { launch_sv_prepare(c); launch_sv_solve(c, M.R, 1.0); }
-    else { const bool mx = sv_reserve(c) == TSBA_OK; if (mx) launch_sv_prepare(c); launch_ms_solve(c, mx); }
+    if (single) { launch_sv_prepare(c, nullptr); launch_sv_solve(c, M.R, 1.0); }
+    else { const bool mx = sv_reserve(c) == TSBA_OK; if (mx) launch_sv_prepare(c, nullptr); launch_ms_solve(c, mx); }
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
     CK(hipMemcpy(X, M.X, sizeof(double)*6*(size_t)nfree*T, hipMemcpyDeviceToHost));
 #ifdef SV_STAMPS

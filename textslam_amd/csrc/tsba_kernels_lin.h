@@ -1018,6 +1018,7 @@ __device__ void pose_parts_multi(const Work &W, int npp, double *red, double &gm
 }
 __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm, int multi, int npp) {
     LmState *st = W.st;
+    if (W.dp_poll) for (int k = threadIdx.x; k <= W.N; k += 256) W.dp[k] = __builtin_nan("");       // (k_solve_back: "not there yet" for the blocks that poll the step)
     if (st->done || !st->need_lin) return;
     __shared__ double red[5*256], xch[256];
     double gmax, xn, cost;

@@ -1,71 +1,145 @@
 // The rest of an LM trial: k_back, k_decide, the split (multi-GPU) kernels, the outlier pass, test-hook evaluation kernels.  (part of the single translation unit tsba.hip: included there, in this order)
 #pragma once
-// ---- landmark back-substitution + candidate parameters.  256-thread blocks: points | texts | poses
-__global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
+// ---- landmark back-substitution + candidate parameters.  256-thread blocks: BK_PT points (four threads each) | BK_TX texts (sixteen threads each) | 256 poses.
+// The threads of a landmark take its slots in turn (slot o + t, o + t + T, ...), so a point of up to 24 slots and a text of up to 32 (48 where three are in flight) are
+// one round of requests; the partial sums meet in a fixed order (xor shuffles: every thread of the landmark gets the same bits) and the landmark's
+// first thread writes the result.  (One thread per landmark walked a text's twenty slots three at a time: seven dependent rounds.)
+// POLL (k_solve_back): the block runs in the launch that solves the reduced system.  Everything that does not depend on the pose step -- offsets, state,
+// the landmark's own terms and the records of its first round -- is requested first; then the block polls the step (W.dp, NaN until the solver
+// workgroup publishes it; W.dp[N]: 0 solved / 1 failed) into LDS and goes on from there.  Same arithmetic in the same order either way.
+#define BK_TP 4                             // threads of a point / of a text
+#define BK_TT 16
+#define BK_PT (256/BK_TP)
+#define BK_TX (256/BK_TT)
+static inline int back_blocks_pt(int n_pt) { return (n_pt + BK_PT - 1)/BK_PT; }
+static inline int back_blocks_tx(int n_text) { return (n_text + BK_TX - 1)/BK_TX; }
+template <bool POLL>
+__device__ __forceinline__ void back_body(const Work &W, const LevelDev &L, int nb_pt, int nb_tx, int b, int tid, bool live, double *red, double *dps) {
     LmState *st = W.st;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool is_pt = live && b < nb_pt, is_tx = live && !is_pt && b < nb_pt + nb_tx;
+    const int T = is_pt ? BK_TP : BK_TT, part = is_pt ? tid % BK_TP : tid % BK_TT;           // threads of a landmark, this thread's place among them
+    const int j = is_pt ? b*BK_PT + tid/BK_TP : is_tx ? (b - nb_pt)*BK_TX + tid/BK_TT : 0;
+    const bool lm = (is_pt && j < W.n_pt) || (is_tx && j < W.n_text);
     // static offsets / slot poses of this thread's landmark first: in flight together with the LM state
-    int o = 0, e = 0, act_ = 0, a0[6] = {0, 0, 0, 0, 0, 0};
-    if (b < nb_pt) { const int j = b*256 + tid; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
+    int o = 0, e = 0, act_ = 0, a0[3] = {0, 0, 0};
+    if (lm && is_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
 #pragma unroll
-        for (int u = 0; u < 6; u++) a0[u] = L.pt_pose6[6*(size_t)j + u]; } }
-    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + tid; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
+        for (int u = 0; u < 3; u++) a0[u] = part + BK_TP*u < 6 ? L.pt_pose6[6*(size_t)j + part + BK_TP*u] : 0; }       // (the poses of a point's first six slots: this thread's share of them)
+    else if (lm) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; }
     if (st->done) return;
-    __shared__ double red[256];
     const int cur = st->cur;
     const double irad = 1.0/st->radius;
-    const bool fail = st->step_fail;
+    bool fail = st->step_fail;
     const LinBuf &B = W.lb[st->lcur];
+    const double *dp = W.dp;
+    const bool on = lm && e > o && act_;
+    auto slot_of = [&](int k) { return o + part + T*k; };        // this thread's k-th slot (valid while < e)
+    // POLL: the first round of records (a point's six, a text's two), then the step
+    double wq[6][6], rh0 = 0.0, Vj0 = 0.0, Dj0 = 0.0, bj0 = 0.0; int aq[6] = {0, 0, 0, 0, 0, 0};
+    if (POLL) {
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) wq[u][k] = 0.0;
+        if (is_pt && lm) { rh0 = W.rho[cur][j];
+            if (on) { VDB_LOADB(B, j, W.n_pt, Vj0, Dj0, bj0);
+#pragma unroll
+                for (int u = 0; u < 6; u++) { const int sl = min(slot_of(u), e - 1); aq[u] = part + BK_TP*u < 6 ? a0[u < 3 ? u : 0] : L.pslot_pose[sl];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) wq[u][k] = B.w_pt[(size_t)sl*PT_REC + k]; } } }
+        else if (is_tx && on) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const int sl = min(slot_of(u), e - 1); aq[u] = L.tslot_pose[sl];
+#pragma unroll
+                for (int k = 0; k < 18; k++) wq[3*u + k/6][k % 6] = B.w_tx[(size_t)sl*TX_REC + k]; } }
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) asm volatile("" : "+v"(wq[u][k]));
+            asm volatile("" : "+v"(aq[u])); }
+        asm volatile("" : "+v"(rh0)); asm volatile("" : "+v"(Vj0)); asm volatile("" : "+v"(Dj0)); asm volatile("" : "+v"(bj0));
+        const int nd = W.N + 1, t768 = threadIdx.x;
+        for (int k0 = 0; k0 < nd; k0 += (int)blockDim.x) { const int k = k0 + t768;
+            if (k < nd) { double v = co_load(&W.dp[k]);
+                for (int spins = 0; v != v && spins < (1 << 16); spins++) { __builtin_amdgcn_s_sleep(1); v = co_load(&W.dp[k]); }
+                dps[k] = v == v ? v : __builtin_inf(); } }
+        __syncthreads();
+        fail = dps[W.N] != 0.0;
+        dp = dps;
+    }
     double step2 = 0.0, mcc = 0.0;
-    if (b < nb_pt) {
-        int j = b*256 + tid;
-        if (j < W.n_pt) {
-            double rh = W.rho[cur][j], d = 0.0;
-            if (!fail && e > o && act_) {
-                double Vj, Dj, bj; VDB_LOADB(B, j, W.n_pt, Vj, Dj, bj);
-                double acc = bj;
-                for (int s0 = o; s0 < e; s0 += 6) {                                 // 6 slots in flight; dp is 0 for constant / absent poses
-                    int a[6]; double w[6][6], dpv[6][6];
+    if (is_pt) {
+        if (lm) {
+            double rh = POLL ? rh0 : W.rho[cur][j], d = 0.0;
+            if (!fail && on) {
+                double Vj, Dj, bj;
+                if (POLL) { Vj = Vj0; Dj = Dj0; bj = bj0; } else VDB_LOADB(B, j, W.n_pt, Vj, Dj, bj);
+                double acc = 0.0;
+                auto pt_round = [&](int k0, const int (&a)[6], const double (&w)[6][6]) {     // six of this thread's slots; dp is 0 for constant / absent poses
+                    if (POLL) {                                                     // (the step is in LDS: no batch of requests to keep in registers)
 #pragma unroll
-                    for (int u = 0; u < 6; u++) a[u] = s0 == o ? a0[u] : L.pslot_pose[min(s0 + u, e - 1)];
+                        for (int u = 0; u < 6; u++) { const double *du = dp + 6*a[u];
+#pragma unroll
+                            for (int k = 0; k < 6; k++) acc = slot_of(k0 + u) < e ? fma(w[u][k], du[k], acc) : acc; }
+                        return; }
+                    double dpv[6][6];
 #pragma unroll
                     for (int u = 0; u < 6; u++)
 #pragma unroll
-                        for (int k = 0; k < 6; k++) { w[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 1))*PT_REC + k]; dpv[u][k] = W.dp[6*a[u] + k]; }
+                        for (int k = 0; k < 6; k++) dpv[u][k] = dp[6*a[u] + k];
 #pragma unroll
                     for (int u = 0; u < 6; u++)
 #pragma unroll
-                        for (int k = 0; k < 6; k++) acc += s0 + u < e ? w[u][k]*dpv[u][k] : 0.0;
+                        for (int k = 0; k < 6; k++) acc = slot_of(k0 + u) < e ? fma(w[u][k], dpv[u][k], acc) : acc; };
+                if (POLL) pt_round(0, aq, wq);
+                for (int k0 = POLL ? 6 : 0; slot_of(k0) < e; k0 += 6) {
+                    int a[6]; double w[6][6];
+#pragma unroll
+                    for (int u = 0; u < 6; u++) a[u] = part + BK_TP*(k0 + u) < 6 ? a0[(k0 + u) % 3] : L.pslot_pose[min(slot_of(k0 + u), e - 1)];
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+#pragma unroll
+                        for (int k = 0; k < 6; k++) w[u][k] = B.w_pt[(size_t)(min(slot_of(k0 + u), e - 1))*PT_REC + k];
+                    pt_round(k0, a, w);
                 }
+#pragma unroll
+                for (int x = 1; x < BK_TP; x <<= 1) acc += __shfl_xor(acc, x, 64);  // the threads' sums: the same bits in every one of them
+                acc = bj + acc;
                 const double lam = Dj*irad;
                 d = -acc/(Vj + lam);
-                step2 = d*d; mcc = lam*d*d - bj*d;
+                if (part == 0) { step2 = d*d; mcc = lam*d*d - bj*d; }
             }
-            W.rho[cur ^ 1][j] = rh + d;
+            if (part == 0) W.rho[cur ^ 1][j] = rh + d;
         }
-    } else if (b < nb_pt + nb_tx) {
-        int j = (b - nb_pt)*256 + tid;
-        if (j < W.n_text) {
+    } else if (is_tx) {
+        if (lm) {
             double d[3] = {0,0,0};
-            if (!fail && e > o && act_) {
-                double acc[3] = { B.b_tx[j], B.b_tx[(size_t)W.n_text + j], B.b_tx[(size_t)2*W.n_text + j] };
-                for (int s0 = o; s0 < e; s0 += 3) {                                 // 3 slots in flight
-                    int a[3]; double w[3][18], dpv[3][6];
+            if (!fail && on) {
+                double acc[3] = { 0.0, 0.0, 0.0 };
+                auto tx_slot = [&](int a, const double *w) {
 #pragma unroll
-                    for (int u = 0; u < 3; u++) a[u] = L.tslot_pose[min(s0 + u, e - 1)];
+                    for (int k = 0; k < 6; k++) { const double dk = dp[6*a + k]; acc[0] = fma(w[k*3], dk, acc[0]); acc[1] = fma(w[k*3 + 1], dk, acc[1]); acc[2] = fma(w[k*3 + 2], dk, acc[2]); } };
+                if (POLL) {
 #pragma unroll
-                    for (int u = 0; u < 3; u++) {
+                    for (int u = 0; u < 2; u++) if (slot_of(u) < e) { double w[18];
 #pragma unroll
-                        for (int k = 0; k < 18; k++) w[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 1))*TX_REC + k];
+                        for (int k = 0; k < 18; k++) w[k] = wq[3*u + k/6][k % 6];
+                        tx_slot(aq[u], w); } }
+                constexpr int TB = POLL ? 2 : 3;                                    // slots in flight (the sums run slot by slot either way)
+                for (int k0 = POLL ? 2 : 0; slot_of(k0) < e; k0 += TB) {
+                    int a[TB]; double w[TB][18];
 #pragma unroll
-                        for (int k = 0; k < 6; k++) dpv[u][k] = W.dp[6*a[u] + k];
-                    }
+                    for (int u = 0; u < TB; u++) { const int sl = min(slot_of(k0 + u), e - 1); a[u] = L.tslot_pose[sl];
 #pragma unroll
-                    for (int u = 0; u < 3; u++) if (s0 + u < e) {
+                        for (int k = 0; k < 18; k++) w[u][k] = B.w_tx[(size_t)sl*TX_REC + k]; }
 #pragma unroll
-                        for (int k = 0; k < 6; k++) { acc[0] += w[u][k*3]*dpv[u][k]; acc[1] += w[u][k*3 + 1]*dpv[u][k]; acc[2] += w[u][k*3 + 2]*dpv[u][k]; }
-                    }
+                    for (int u = 0; u < TB; u++) if (slot_of(k0 + u) < e) tx_slot(a[u], w[u]);
                 }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { double t = acc[k];
+#pragma unroll
+                    for (int x = 1; x < BK_TT; x <<= 1) t += __shfl_xor(t, x, 64);              // the threads' sums
+                    acc[k] = B.b_tx[(size_t)k*W.n_text + j] + t; }
                 double Vd[6], Vi[6], lam[3];
 #pragma unroll
                 for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
@@ -76,19 +150,19 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
                     d[0] = -(Vi[0]*acc[0] + Vi[1]*acc[1] + Vi[2]*acc[2]);
                     d[1] = -(Vi[1]*acc[0] + Vi[3]*acc[1] + Vi[4]*acc[2]);
                     d[2] = -(Vi[2]*acc[0] + Vi[4]*acc[1] + Vi[5]*acc[2]);
-                    for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - B.b_tx[(size_t)k*W.n_text + j]*d[k]; }
+                    if (part == 0) for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - B.b_tx[(size_t)k*W.n_text + j]*d[k]; }
                 }
             }
-            for (int k = 0; k < 3; k++) W.theta[cur ^ 1][3*j + k] = W.theta[cur][3*j + k] + d[k];
+            if (part == 0) for (int k = 0; k < 3; k++) W.theta[cur ^ 1][3*j + k] = W.theta[cur][3*j + k] + d[k];
         }
-    } else {
+    } else if (live) {
         int a = (b - nb_pt - nb_tx)*256 + tid;
         if (a < W.n_kf) {
             const double *x = W.pose[cur] + 7*a; double *c = W.pose[cur ^ 1] + 7*a;
             if (!fail && W.fidx[a] >= 0) {
                 double d[6];
 #pragma unroll
-                for (int k = 0; k < 6; k++) d[k] = W.dp[6*a + k];
+                for (int k = 0; k < 6; k++) d[k] = dp[6*a + k];
                 double q[4] = { x[0], x[1], x[2], x[3] }, qn[4];
                 quat_plus(q, d, qn);
                 for (int k = 0; k < 4; k++) { c[k] = qn[k]; step2 += (qn[k] - q[k])*(qn[k] - q[k]); }
@@ -97,13 +171,33 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
             } else for (int k = 0; k < 7; k++) c[k] = x[k];
         }
     }
-    step2 = block_sum<256>(step2, red); mcc = block_sum<256>(mcc, red);
-    if (tid == 0) { W.partial[2*b] = step2; W.partial[2*b + 1] = mcc; }
+    // the block's two partial sums: 256 values each, in block_sum<256>'s order (a block is four waves of its workgroup)
+    red[tid] = step2; __syncthreads();
+    if (tid < 64) { double sv = ((red[tid] + red[tid + 64]) + red[tid + 128]) + red[tid + 192]; sv = wave_sum1(sv); if (tid == 0 && live) W.partial[2*b] = sv; }
+    __syncthreads();
+    red[tid] = mcc; __syncthreads();
+    if (tid < 64) { double sv = ((red[tid] + red[tid + 64]) + red[tid + 128]) + red[tid + 192]; sv = wave_sum1(sv); if (tid == 0 && live) W.partial[2*b + 1] = sv; }
+}
+__global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int nb_tx) {
+    __shared__ double red[256];
+    back_body<false>(W, L, nb_pt, nb_tx, blockIdx.x, threadIdx.x, true, red, nullptr);
+}
+// ---- the reduced system of a small window and the back-substitution in ONE launch: workgroup 0 is k_solve_t, every other workgroup three blocks of k_back
+// that wait for the pose step where k_back would wait for its launch (6.97 us per trial on C4, most of it the launch, the state round trip and the
+// records' round trip behind it).  The step reaches the waiting blocks ~0.65 us after the solver stores it (tools/handover_bench.hip).
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_back(Work W, LevelDev L, int nb_pt, int nb_tx, int nb_all) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (blockIdx.x != 0) {
+        const int sub = threadIdx.x >> 8, b = 3*((int)blockIdx.x - 1) + sub;
+        back_body<true>(W, L, nb_pt, nb_tx, b, threadIdx.x & 255, b < nb_all, smem + 256*sub, smem + 768);
+        return; }
+    solve_body<false, true>(W, 0, smem);
 }
 
 // ---- step quality and trust-region update (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics)
 __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o, int multi, int npp) {
     LmState *st = W.st;
+    if (W.dp_poll) for (int k = threadIdx.x; k <= W.N; k += 256) W.dp[k] = __builtin_nan("");       // (k_solve_back: "not there yet" for the blocks that poll the next step)
     if (st->done) return;
     __shared__ double red[5*256], xch[256];
     const int tid = threadIdx.x;

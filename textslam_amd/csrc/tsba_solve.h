@@ -176,10 +176,13 @@ static size_t solve_diag_lds_doubles() { return solve_lds_doubles(SOLVE_DIAG_NB)
 // DIAG = true : the 96x96 (or shorter, last) diagonal block at (B0, B0) of a LARGE system (tsba_chol.h): same factorisation, then
 //               the inverse of the factor; written back as Cholesky factor L D^1/2 (lower triangle), its inverse transposed
 //               (strict upper triangle) and the inverse's diagonal (W.LDbuf).
-template <bool DIAG>
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
+// PUB: the result is published for workgroups of the SAME launch that poll it (k_solve_back, tsba_kernels_step.h): dp and, behind it, the failure flag
+// go out as device-coherent stores of values that are never NaN (the slots hold NaN until then)
+__device__ __forceinline__ double co_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void co_store(double *p, double v) { __hip_atomic_store(p, v == v ? v : __builtin_inf(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool DIAG, bool PUB>
+__device__ __forceinline__ void solve_body(const Work &W, int B0, double *smem) {
     LmState *st = W.st;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = SOLVE_THREADS/64, NT = NW - SOLVE_PW;
@@ -409,7 +412,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
         }
         return;
     }
-    if (fail || nfree == 0) { for (int k = tid; k < Nmax; k += SOLVE_THREADS) W.dp[k] = 0.0; return; }
+    if (fail || nfree == 0) {
+        for (int k = tid; k < Nmax; k += SOLVE_THREADS) { if (PUB) co_store(&W.dp[k], 0.0); else W.dp[k] = 0.0; }
+        if (PUB && tid == 0) co_store(&W.dp[Nmax], fail ? 1.0 : 0.0);
+        return; }
     double *rhs = A + rowoff(n);
     if (wave == 0) solve_backsub_wave(A, LD, n, nfree, lane);
     __syncthreads();
@@ -419,8 +425,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
     for (int a = tid; a < W.n_kf; a += SOLVE_THREADS) {
         int ia = W.fidx[a];
 #pragma unroll
-        for (int k = 0; k < 6; k++) W.dp[6*a + k] = ia >= 0 ? -rhs[6*ia + k] : 0.0;
+        for (int k = 0; k < 6; k++) { const double d = ia >= 0 ? -rhs[6*ia + k] : 0.0; if (PUB) co_store(&W.dp[6*a + k], d); else W.dp[6*a + k] = d; }
     }
+    if (PUB && tid == 0) co_store(&W.dp[Nmax], 0.0);
+}
+template <bool DIAG>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    solve_body<DIAG, false>(W, B0, smem);
 }
 
 // (k_solve_r -- the same solver with every row at the same stride, update tiles with an unmasked path and scalar tile indices, optionally

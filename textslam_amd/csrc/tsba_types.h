@@ -94,6 +94,7 @@ struct Work {                // device work buffers (sized for the largest level
     LinBuf lb[2];
     double *sig_pt, *sig_tx, *sig_p;    // Jacobi column scales, fixed at the first linearisation of a pass
     double *S, *g, *dp, *dl_pt, *dl_tx;
+    int dp_poll;                        // small windows: the back-substitution runs in the solver's launch and polls dp [N] + the failure flag dp[N] (k_solve_back); k_postlin / k_decide leave NaN there
     double *partial;                    // [nblocks_back][2]
     int *cntpart;                       // per k_participation workgroup: active scene blocks, active text blocks
     double *posepart;                   // large maps: per k_pose_sums workgroup (21 poses): gradient max, |x|^2

@@ -1,5 +1,6 @@
 """GPU diagnostic (not a pytest): resident solve of C6 with 1 % long-range points, the separator tree of the solve phase as one launch (production)
-against a launch per level (tsba_debug_options.sv_per_level = 1)."""
+and the back substitution of the factorisation's own solve as one launch each
+(production) against a launch per level (tsba_debug_options.sv_per_level = 3)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -9,7 +10,7 @@ opt = Optimizer(0)
 far = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
 P = synth.config_global(n_kf=5000, n_pt=70000, band=10, far_frac=far); o = abi.options_global()
 res = {}
-for mode in (0, 1, 0, 1):
+for mode in (0, 3, 0, 3):
     opt.debug_set(sv_per_level=mode)
     opt.upload(P, o)
     ts = []
@@ -20,4 +21,4 @@ for mode in (0, 1, 0, 1):
           rep["cost1"][0], rep["pcg_iterations"], rep["pcg_systems"], rep["pcg_unconverged"]), flush=True)
     if mode in res: assert np.array_equal(res[mode], G.pose)
     res[mode] = G.pose.copy()
-print("bit-identical:", np.array_equal(res[0], res[1]))
+print("same bits (not expected: the two back substitutions round differently):", np.array_equal(res[0], res[3]))
