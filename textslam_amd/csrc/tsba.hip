@@ -913,10 +913,10 @@ static void launch_solve(Ctx *c) {
                     const int K = std::max(1, std::min(TSBA_CRE_KMAX, 224/npiv));     // workgroups per pivot (they share its product and stores)
                     hipLaunchKernelGGL(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, kb, c->CRcontrib, c->CRfac); htop = h; }
                 hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, W.ring ? 2 : 1, 1, 0, c->CRcontrib, c->CRfac);
-                // back substitution: a launch per level -- or, where the iterative path needs the inverse factors and products of the solve phase anyway (maps with
-                // long-range blocks), one launch through them (k_sv_linv + k_cre_back_tree).  For a plain direct solve k_sv_linv costs more than the six launches
-                // it saves (5000-keyframe chain 15.4 against 14.9 ms, C5 with 72-row separators 10.4 against 9.3 ms)
-                if (c->far_B > 0 && ms_available(c) && !(c->dbg.sv_per_level & 2) && c->dbg.pcg_refactor != 1 && mmax >= 2 && sv_reserve(c) == TSBA_OK) {
+                // back substitution: a launch per level -- or one launch through the inverse factors and products of the solve phase (k_sv_linv + k_cre_back_tree)
+                // where the iterative path needs those anyway (maps with long-range blocks) or the tree is deep enough to pay for k_sv_linv (28 us at 48-row
+                // separators against 10.5 us per level)
+                if ((c->far_B > 0 || (htop >= 32 && bwp <= 60)) && ms_available(c) && !(c->dbg.sv_per_level & 2) && c->dbg.pcg_refactor != 1 && mmax >= 2 && sv_reserve(c) == TSBA_OK) {
                     launch_sv_prepare(c, Ws.Sy);
                     hipLaunchKernelGGL(k_cre_back_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, c->sv);
                 } else

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
 //   Linv(I, I) = inv(l_I),   Linv(I, J) = - inv(l_I) sum_{K = J .. I-1} L(I, K) Linv(K, J)   for the block rows I = 1, 2, ... in turn
 // -- 300 FMAs per thread and two barriers per block row (a thread per column solving L y = e_j row by row: 1800 dependent FMAs, 64 us per launch).
 #define SV_LT 512
-static size_t sv_linv_lds_doubles(int s) { return ((cre_rec_doubles(s) + 8) & ~(size_t)1) + (size_t)s*(s + 1) + std::max(6*(size_t)(s + 2), (size_t)s*(s + 1)); }
+static size_t sv_linv_lds_doubles(int s) { return ((cre_rec_doubles(s) + 8) & ~(size_t)1) + (size_t)s*(s + 1) + std::max(6*(size_t)(s + 2), (size_t)16*((s + 15)/16)*(s + 3)); }
 __global__ __launch_bounds__(SV_LT) void k_sv_linv(Work W, int bw, int Pmax, const double *__restrict__ fac, const double *__restrict__ pool, MsBuf M, double *xreset) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, s = bw, B = s/6, i = blockIdx.x;
@@ -376,28 +376,36 @@ __global__ __launch_bounds__(SV_LT) void k_sv_linv(Work W, int bw, int Pmax, con
     double *out = M.Li + (size_t)i*s*s;
     for (int e = tid; e < s*s; e += SV_LT) { const int rr = e/s, cc = e - rr*s; out[e] = cc <= rr ? Y[(size_t)rr*(s + 1) + cc] : 0.0; }
     // the products the separator steps apply (M.Pp [label][2][s][s]): P_a = X_a L^-1, P_c = X_c L^-1 with the couplings X of this pivot to its neighbours
-    // a = i - h, c = i + h as the elimination left them in the pool.  One block at a time through LDS (T's place), four threads per row, every fourth column each.
+    // a = i - h, c = i + h as the elimination left them in the pool.  One block at a time: X through LDS (T's place, [rows padded to 16][s + 3] with the
+    // pad columns zero), 16 x 16 tiles of X Y on the matrix cores (v_mfma_f64_16x16x4: lane (lr, lk) feeds X[16 ti + lr][t + lk] and Y[t + lk][16 tj + lr]
+    // and holds P[16 ti + lk + 4 r][16 tj + lr], r = 0 .. 3).  (A thread per four columns of a row with the sums in registers: 72 of the kernel's 86 us.)
     if (i == 0) return;                                         // (the root has no neighbours)
     const int h = i & -i, ia = i - h, ic = i + h, mmax = cr_mmax(W.ring, Pmax, W.ring_g), m = sv_nsep(nf, B, Pmax);
-    double *XS = T;                                             // [s][s + 1]
-    const int rw = tid >> 2, kg = tid & 3;
+    double *XS = T;
+    const int SX = s + 3, nt = (s + 15)/16, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
     for (int which = 0; which < 2; which++) {
         const bool have = which == 0 || ic < m;                 // (uniform)
         const double *X = cr_blk(pool, s, mmax, which && have ? ic : i, which && have ? i : ia);
         __syncthreads();
-        for (int e = tid; e < s*s; e += SV_LT) { const int rr = e/s, cc = e - rr*s; XS[(size_t)rr*(s + 1) + cc] = have ? X[e] : 0.0; }
+        for (int e0 = 0; e0 < 16*nt*SX; e0 += 6*SV_LT) {        // rows >= s and the pad columns: zero
+            double xv[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) { const int e = e0 + u*SV_LT + tid, rr = e/SX, cc = e - rr*SX; xv[u] = (have && rr < s && cc < s) ? X[(size_t)rr*s + cc] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 6; u++) { const int e = e0 + u*SV_LT + tid; if (e < 16*nt*SX) XS[e] = xv[u]; }
+        }
         __syncthreads();
-        for (int row = rw; row < s; row += SV_LT/4) {
-            double acc[20];
+        double *o = M.Pp + ((size_t)i*2 + which)*s*s;
+        for (int tile = wave; tile < nt*nt; tile += SV_LT/64) {
+            const int ti = tile/nt, tj = tile - ti*nt;
+            v4d c = {0.0, 0.0, 0.0, 0.0};
+            const double *pa = XS + (size_t)(16*ti + lr)*SX + lk;
+            const int col = 16*tj + lr;
+            for (int t0 = 0; t0 < s; t0 += 4) { const int t = t0 + lk;
+                const double av = pa[t0], bv = (t < s && col < s) ? Y[(size_t)t*(s + 1) + col] : 0.0;
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0); }
 #pragma unroll
-            for (int c = 0; c < 20; c++) acc[c] = 0.0;
-            const double *xr = XS + (size_t)row*(s + 1);
-            for (int t = 0; t < s; t++) { const double x = xr[t]; const double *yr = Y + (size_t)t*(s + 1) + kg;
-#pragma unroll
-                for (int c = 0; c < 20; c++) if (kg + 4*c < s) acc[c] = fma(x, yr[4*c], acc[c]); }
-            double *o = M.Pp + (((size_t)i*2 + which)*s + row)*s + kg;
-#pragma unroll
-            for (int c = 0; c < 20; c++) if (kg + 4*c < s) o[4*c] = acc[c];
+            for (int r = 0; r < 4; r++) { const int R = 16*ti + lk + 4*r; if (R < s && col < s) o[(size_t)R*s + col] = c[r]; }
         }
     }
 }
