@@ -99,7 +99,7 @@ def test_conjugate_gradient_variants_agree(gpu, far, closures):
     try:
         runs = []
         for kw in (dict(far_solver=3, pcg_block=1), dict(far_solver=3, pcg_block=1, pcg_refactor=1), dict(far_solver=3, pcg_block=1, pcg_refactor=2), dict(far_solver=3, pcg_block=2), dict(far_solver=2),
-                   dict(far_solver=3, pcg_block=1, sv_per_level=1)):
+                   dict(far_solver=3, pcg_block=1, sv_per_level=1), dict(far_solver=3, pcg_block=1, sv_per_level=4)):
             gpu.debug_set(band_parts=16, sep_solver=2, **kw)
             G = P.copy(); rep = gpu.GlobalBA(G, options=o)
             info = gpu.solver_info()
@@ -113,6 +113,8 @@ def test_conjugate_gradient_variants_agree(gpu, far, closures):
         assert runs[3][2]["iterations"] < runs[0][2]["iterations"], [r[2] for r in runs]
         # the separator tree of the solve phase as a launch per level (the sixth run) instead of one launch: the same bits all the way
         assert np.array_equal(runs[5][0].pose, runs[0][0].pose) and np.array_equal(runs[5][0].rho, runs[0][0].rho) and runs[5][2]["iterations"] == runs[0][2]["iterations"]
+        # ... and the iteration's update step as a launch of its own (the seventh) instead of inside the first kernel of the preconditioner application
+        assert np.array_equal(runs[6][0].pose, runs[0][0].pose) and np.array_equal(runs[6][0].rho, runs[0][0].rho) and runs[6][2]["iterations"] == runs[0][2]["iterations"]
         if far == 0.0:                                              # loop closures only: the low-rank correction makes the band solve (nearly) exact
             assert runs[4][2]["iterations"] <= 3*runs[4][2]["systems"], runs[4][2]
     finally:

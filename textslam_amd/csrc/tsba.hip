@@ -1052,7 +1052,7 @@ static void launch_sv_prepare(Ctx *c, double *xreset) {
     if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(SV_LT), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, (const double *)c->Ssep, c->sv, xreset);
     c->sv_prepared = true;
 }
-static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rdot = nullptr, double *rz_part = nullptr) {
+static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rdot = nullptr, double *rz_part = nullptr, SvUpd upd = SvUpd{0, 0, 0, 0}) {
     Work &W = c->W; const MsBuf &M = c->sv;
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, B = bwp/6, lmax = sv_lmax(c);
     Work &Ws = c->Wsep; Ws.st = W.st;
@@ -1064,8 +1064,8 @@ static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rd
     // the highest level has one pivot (3 h >= 2 h >= the number of separators): its forward step, the root and its back substitution are one workgroup's work
     const bool fuse_top = htop > 0 && pivots(htop) == 1;
     const int tree = fuse_top && !(c->dbg.sv_per_level & 1);           // the whole tree in one launch (k_sv_cre_tree)
-    if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree);
-    else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree);
+    if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
+    else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
     if (tree) hipLaunchKernelGGL(k_sv_cre_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
     else {
         for (int h = 1; h <= htop; h <<= 1) { const int npiv = pivots(h); if (npiv <= 0 || (fuse_top && h == htop)) continue;
@@ -1213,6 +1213,9 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
         hipLaunchKernelGGL(k_pcg_matvec, dim3(nmv), dim3(64*PCG_MW), 0, c->stream, W, D, it, seq, B, tol2, (it > 0 && fused_dot) ? rz2_off : 0, (it > 0 && fused_dot) ? c->band_parts : nbp, pq_off, zp, zs);
         if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->ms.R, 1.0);
             const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c, svok); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
+        else if (sv && fused_dot && !(c->dbg.sv_per_level & 4)) {      // the iteration's update step (alpha; x, r) inside the first kernel of the preconditioner application
+            launch_sv_solve(c, W.pc_r, 1.0, W.pc_r, W.pc_part + rz2_off, SvUpd{1, it, nmv, pq_off});
+            zp = c->sv.X; zs = 1.0; }
         else if (sv) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->sv.R, 1.0);
             if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
             if (fused_dot) launch_sv_solve(c, c->sv.R, 1.0, c->sv.R, W.pc_part + rz2_off);      // (r.z comes along: no k_pcg_dot)

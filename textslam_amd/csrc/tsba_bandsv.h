@@ -48,8 +48,11 @@ template <int NREG> struct SvStep { double cf[NREG][6], ent[NREG], l[15], idl; }
 
 // ---- interiors, forward.  grid Pmax, SV_T threads.
 //   M.V = D^-1 w (L w = r), M.G [label][s] = rows of the separator on the right below this interior, M.G2 [label][s] = border rows of the separator on the left
+// upd (conjugate gradients, tsba_pcg.h): the step of the iteration that leads to this application -- alpha = r.z / p.q from the partial sums,
+// x += alpha p, r -= alpha q -- is taken HERE on this interior's rows before anything else (k_pcg_update as a launch of its own: 5.3 us + a gap per iteration)
+struct SvUpd { int on, it, npq, pq_off; };
 template <int NREG>
-__global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, const double *__restrict__ r, double rs, MsBuf M, int tree) {
+__global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, const double *r, double rs, MsBuf M, int tree, SvUpd upd) {
     extern __shared__ __attribute__((aligned(16))) double ms_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6);
 #ifdef SV_STAMPS
@@ -59,7 +62,9 @@ __global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, c
 #define SVS() do {} while (0)
 #endif
     SVS();
-    const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = ms_uni(*W.nfree);
+    LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = ms_uni(*W.nfree);
+    double pqs = 0.0, rz_u = 0.0;
+    if (upd.on) { for (int k = lane; k < upd.npq; k += 64) pqs += W.pc_part[upd.pq_off + k]; rz_u = W.pcs[upd.it & 1].rz; }     // (pcg_sum_parts: requested with the state)
     if (flags || nf <= 0) return;
     SVS();
     const int B = bw/6, p = blockIdx.x, CS = sv_cs(B), TB = 36*B;
@@ -71,6 +76,16 @@ __global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, c
     if (tree && tid >= SV_T - 3*bw) { const int e = tid - (SV_T - 3*bw), row = e % bw, which = e/bw; const double qn = __builtin_nan("");
         if (which < 2) M.Cg[((size_t)p*2 + which)*bw + row] = qn; else M.Xs[(size_t)p*bw + row] = qn; }
     const int REC = bw*6, rend = p < P - 1 ? b + B : b, nch = (b - a + SV_K - 1)/SV_K;
+    if (upd.on) {                                               // this interior's rows 6 a .. 6 rend - 1 (the interiors' ranges tile the system)
+        const double pq = wave_sum1(pqs);
+        if (!(pq > 0.0)) { if (p == 0 && tid == 0) st_->step_fail = 1; return; }       // S is positive definite (damped): a breakdown is a failed step
+        const double alpha = rz_u/pq;
+        const double *pp = W.pc_p[upd.it & 1];
+        for (int i = 6*a + tid; i < 6*rend; i += SV_T) {
+            W.pc_x[i] = fma(alpha, pp[i], W.pc_x[i]);
+            W.pc_r[i] = fma(-alpha, W.pc_q[i], W.pc_r[i]); }
+        __syncthreads();                                        // (r below is W.pc_r: this workgroup reads only rows it has just written)
+    }
     const int ptid = tid - 64, pk = ptid & (SV_K - 1), pj = ptid/SV_K, perp = (TB + 28)/2;       // producers: (pivot of the chunk, SV_PT threads across its record, 16 bytes each)
     auto stage = [&](int c) {                                   // producers: chunk c
         const int q = a + c*SV_K + pk; const bool on = q < b;

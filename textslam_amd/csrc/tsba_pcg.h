@@ -20,7 +20,7 @@
 #define PCG_PPW 8
 #define PCG_ET 192                          // element-wise kernels: 32 poses x 6 rows per workgroup (the same number of workgroups, so one partial array serves all)
 
-struct PcgState { double rz, rz0, best; int it, since; };      // best: smallest r.z so far; since: iterations since it improved by a tenth (stagnation at the attainable accuracy)
+// (struct PcgState: tsba_types.h)
 
 __device__ __forceinline__ double pcg_sum_parts(const double *part, int nb, int lane) {     // every lane gets the sum; fixed order
     double s = 0.0;

@@ -63,6 +63,8 @@ struct LinBuf {              // everything one linearisation produces
 };
 
 struct PoseState;
+// state of the conjugate-gradient iteration (tsba_pcg.h), double-buffered by the iteration's parity
+struct PcgState { double rz, rz0, best; int it, since; };      // best: smallest r.z so far; since: iterations since it improved by a tenth (stagnation at the attainable accuracy)
 struct Work {                // device work buffers (sized for the largest level)
     int n_kf, n_pt, n_text, n_tobs, N;      // N = 6 n_kf
     int rank, world;                        // landmark shard of this process (global BA over RCCL), 0 / 1 otherwise

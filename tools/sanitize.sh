@@ -6,15 +6,18 @@
 #      the CPU tests here; with a GPU (argument "gpu") also the GPU parity tests, i.e. real uploads / solves through the instrumented host
 #      code (device code is not instrumented: gfx950 ASan needs xnack, which this pool does not enable);
 #   4. the plan builder's host threads under clang TSan.
-# Usage: bash tools/sanitize.sh [gpu]   -> gpurun_out/r04_sanitizers.log (summary lines "SANITIZE <what>: <result>")
+# Usage: bash tools/sanitize.sh [gpu | gpuonly]   -> gpurun_out/r04_sanitizers.log (summary lines "SANITIZE <what>: <result>"); gpuonly: just the GPU leg
+# of part 3 into gpurun_out/r04_sanitizers_gpu.log (the CPU parts do not need the GPU box)
 set -u
 cd "$(dirname "$0")/.."
-OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/r04_sanitizers.log; : > $LOG
+MODE=${1:-}
+OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/r04_sanitizers.log; [ "$MODE" = "gpuonly" ] && LOG=$OUT/r04_sanitizers_gpu.log; : > $LOG
 GASAN=$(gcc -print-file-name=libasan.so); GUBSAN=$(gcc -print-file-name=libubsan.so)
 CASAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=0:halt_on_error=0
 say() { echo "SANITIZE $*" | tee -a $LOG; }
 
+if [ "$MODE" != "gpuonly" ]; then
 # ---- 1. oracle
 mkdir -p /tmp/san_oracle && cp oracle/*.so /tmp/san_oracle/ 2>/dev/null
 for f in tsba tsorb tsframe tsloop; do gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o oracle/lib${f}_oracle.so oracle/${f}_oracle.c -lm || say "oracle build $f: FAILED"; done
@@ -58,10 +61,13 @@ PY
 say "loop-closing adapter gather + C++ driver (g++ ASan+UBSan, sim3 + pose graph): $(tail -1 /tmp/san_loop_adapter.log)"
 
 # ---- 3. host side of libtsba
+fi
+if [ "$MODE" != "gpuonly" ]; then
 (cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-unused-variable -o /tmp/libtsba_san.so tsba.hip) || say "libtsba build: FAILED"
 TSBA_LIB=/tmp/libtsba_san.so LD_PRELOAD="$CASAN" HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES=-1 python -m pytest tests/test_band_partition.py tests/test_abi.py -q -s -p no:cacheprovider > /tmp/san_host.log 2>&1
 say "libtsba host code (clang ASan+UBSan), CPU tests (plan, reordering, partition tables, ABI): $(grep -E 'passed|failed' /tmp/san_host.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_host.log)"
-if [ "${1:-}" = "gpu" ]; then
+fi
+if [ "$MODE" = "gpu" ] || [ "$MODE" = "gpuonly" ]; then
   # with a live device: UBSan only -- the ROCm ASan runtime intercepts hsa_amd_memory_pool_allocate for device-side ASan and aborts the first
   # allocation on a node without xnack ("out of memory: allocator is trying to allocate 0x400000 bytes")
   (cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=undefined,bounds -fno-omit-frame-pointer -Wno-unused-variable -o /tmp/libtsba_ubsan.so tsba.hip 2>/dev/null) || say "libtsba UBSan build: FAILED"
@@ -70,6 +76,7 @@ if [ "${1:-}" = "gpu" ]; then
   say "libtsba host code (clang UBSan + bounds), GPU parity tests through the instrumented host side: $(grep -E 'passed|failed' /tmp/san_gpu.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log)"
   grep -B2 -A12 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log | head -60 >> $LOG
 fi
+if [ "$MODE" != "gpuonly" ]; then
 # ---- 4. the plan builder's host threads (fork-join pool, shared key bitmaps, atomic min / max, stable bucket placement) under clang TSan:
 #         every plan of tools/diag/plan_checksums.py (windows, maps, loop closures, text planes, shards) built with 1, 3 and 16 threads
 CTSAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.tsan-x86_64.so)
@@ -79,4 +86,5 @@ python tools/diag/plan_checksums.py > /tmp/san_plain.txt 2>/dev/null
 say "libtsba plan builder (clang TSan, 1 / 3 / 16 host threads): $(wc -l < /tmp/san_tsan.txt) plans built, $(diff /tmp/san_plain.txt /tmp/san_tsan.txt | grep -c '^[<>]') checksum differences against the plain build ; reports: $(grep -c 'WARNING: ThreadSanitizer' /tmp/san_tsan.err)"
 grep -A12 'WARNING: ThreadSanitizer' /tmp/san_tsan.err | head -40 >> $LOG
 grep -B2 -A12 'ERROR: AddressSanitizer\|runtime error' /tmp/san_oracle.log /tmp/san_host.log 2>/dev/null | head -80 >> $LOG
+fi
 cat $LOG | grep SANITIZE
