@@ -35,12 +35,14 @@ __device__ __forceinline__ void back_body(const Work &W, const LevelDev &L, int 
     const bool on = lm && e > o && act_;
     auto slot_of = [&](int k) { return o + part + T*k; };        // this thread's k-th slot (valid while < e)
     // POLL: the first round of records (a point's six, a text's two), then the step
-    double wq[6][6], rh0 = 0.0, Vj0 = 0.0, Dj0 = 0.0, bj0 = 0.0; int aq[6] = {0, 0, 0, 0, 0, 0};
+    double wq[6][6], tq[12], rh0 = 0.0, Vj0 = 0.0, Dj0 = 0.0, bj0 = 0.0; int aq[6] = {0, 0, 0, 0, 0, 0}, pfi = -1;      // (tq: a text's b | V | damping, a pose's parameters)
     if (POLL) {
 #pragma unroll
         for (int u = 0; u < 6; u++)
 #pragma unroll
             for (int k = 0; k < 6; k++) wq[u][k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) tq[k] = 0.0;
         if (is_pt && lm) { rh0 = W.rho[cur][j];
             if (on) { VDB_LOADB(B, j, W.n_pt, Vj0, Dj0, bj0);
 #pragma unroll
@@ -51,7 +53,19 @@ __device__ __forceinline__ void back_body(const Work &W, const LevelDev &L, int 
 #pragma unroll
             for (int u = 0; u < 2; u++) { const int sl = min(slot_of(u), e - 1); aq[u] = L.tslot_pose[sl];
 #pragma unroll
-                for (int k = 0; k < 18; k++) wq[3*u + k/6][k % 6] = B.w_tx[(size_t)sl*TX_REC + k]; } }
+                for (int k = 0; k < 18; k++) wq[3*u + k/6][k % 6] = B.w_tx[(size_t)sl*TX_REC + k]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { tq[k] = B.b_tx[(size_t)k*W.n_text + j]; tq[9 + k] = B.dgs_tx[(size_t)k*W.n_text + j]; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) tq[3 + k] = B.V_tx[(size_t)k*W.n_text + j]; }
+        else if (live && !is_pt && !is_tx) { const int a = (b - nb_pt - nb_tx)*256 + tid;          // a pose: its parameters, damping and gradient rows
+            if (a < W.n_kf) { pfi = W.fidx[a];
+#pragma unroll
+                for (int k = 0; k < 7; k++) tq[k] = W.pose[cur][7*a + k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) { wq[0][k] = B.dgs_p[6*a + k]; wq[1][k] = B.bp[6*a + k]; } } }
+#pragma unroll
+        for (int k = 0; k < 12; k++) asm volatile("" : "+v"(tq[k]));
 #pragma unroll
         for (int u = 0; u < 6; u++) {
 #pragma unroll
@@ -139,18 +153,18 @@ __device__ __forceinline__ void back_body(const Work &W, const LevelDev &L, int 
                 for (int k = 0; k < 3; k++) { double t = acc[k];
 #pragma unroll
                     for (int x = 1; x < BK_TT; x <<= 1) t += __shfl_xor(t, x, 64);              // the threads' sums
-                    acc[k] = B.b_tx[(size_t)k*W.n_text + j] + t; }
+                    acc[k] = (POLL ? tq[k] : B.b_tx[(size_t)k*W.n_text + j]) + t; }
                 double Vd[6], Vi[6], lam[3];
 #pragma unroll
-                for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
+                for (int k = 0; k < 6; k++) Vd[k] = POLL ? tq[3 + k] : B.V_tx[(size_t)k*W.n_text + j];
 #pragma unroll
-                for (int k = 0; k < 3; k++) lam[k] = B.dgs_tx[(size_t)k*W.n_text + j]*irad;
+                for (int k = 0; k < 3; k++) lam[k] = (POLL ? tq[9 + k] : B.dgs_tx[(size_t)k*W.n_text + j])*irad;
                 Vd[0] += lam[0]; Vd[3] += lam[1]; Vd[5] += lam[2];
                 if (inv_sym3(Vd, Vi)) {
                     d[0] = -(Vi[0]*acc[0] + Vi[1]*acc[1] + Vi[2]*acc[2]);
                     d[1] = -(Vi[1]*acc[0] + Vi[3]*acc[1] + Vi[4]*acc[2]);
                     d[2] = -(Vi[2]*acc[0] + Vi[4]*acc[1] + Vi[5]*acc[2]);
-                    if (part == 0) for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - B.b_tx[(size_t)k*W.n_text + j]*d[k]; }
+                    if (part == 0) for (int k = 0; k < 3; k++) { step2 += d[k]*d[k]; mcc += lam[k]*d[k]*d[k] - (POLL ? tq[k] : B.b_tx[(size_t)k*W.n_text + j])*d[k]; }
                 }
             }
             if (part == 0) for (int k = 0; k < 3; k++) W.theta[cur ^ 1][3*j + k] = W.theta[cur][3*j + k] + d[k];
@@ -158,8 +172,11 @@ __device__ __forceinline__ void back_body(const Work &W, const LevelDev &L, int 
     } else if (live) {
         int a = (b - nb_pt - nb_tx)*256 + tid;
         if (a < W.n_kf) {
-            const double *x = W.pose[cur] + 7*a; double *c = W.pose[cur ^ 1] + 7*a;
-            if (!fail && W.fidx[a] >= 0) {
+            double xl[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) xl[k] = POLL ? tq[k] : W.pose[cur][7*a + k];
+            const double *x = xl; double *c = W.pose[cur ^ 1] + 7*a;
+            if (!fail && (POLL ? pfi : W.fidx[a]) >= 0) {
                 double d[6];
 #pragma unroll
                 for (int k = 0; k < 6; k++) d[k] = dp[6*a + k];
@@ -167,7 +184,7 @@ __device__ __forceinline__ void back_body(const Work &W, const LevelDev &L, int 
                 quat_plus(q, d, qn);
                 for (int k = 0; k < 4; k++) { c[k] = qn[k]; step2 += (qn[k] - q[k])*(qn[k] - q[k]); }
                 for (int k = 0; k < 3; k++) { c[4 + k] = x[4 + k] + d[3 + k]; step2 += d[3 + k]*d[3 + k]; }
-                for (int k = 0; k < 6; k++) { const double lam = B.dgs_p[6*a + k]*irad; mcc += lam*d[k]*d[k] - B.bp[6*a + k]*d[k]; }
+                for (int k = 0; k < 6; k++) { const double lam = (POLL ? wq[0][k] : B.dgs_p[6*a + k])*irad; mcc += lam*d[k]*d[k] - (POLL ? wq[1][k] : B.bp[6*a + k])*d[k]; }
             } else for (int k = 0; k < 7; k++) c[k] = x[k];
         }
     }
