@@ -84,6 +84,7 @@ struct Ctx {
     LmState *st_host = nullptr;                   // pinned: per-pass snapshots
     LmState *st_log = nullptr;                    // device [MAX passes]
     int nb_back_max = 0;
+    LmState *st_base = nullptr;                   // W.st / W.st_next are st_base and st_base + 1 in the order of the moment
     size_t lds_limit = 0;
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -597,7 +598,8 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     AL(W.partial, 2*(size_t)c->nb_back_max);
     AL(W.posepart, 2*((size_t)p->n_kf/21 + 2));
     AL(W.cntpart, 2*(mx_cnt/4 + mx_cnt/256 + 4));
-    AL(W.st, 1);
+    AL(W.st, 2); c->st_base = W.st;
+    W.st_next = (W.dp_poll && p->n_kf <= 126) ? W.st + 1 : nullptr;        // windows on one GPU: k_schur_t takes the previous trial's decision itself (the two copies of the state swap roles after that launch)
     AL(c->cov_log, 6*TSBA_MAX_LEVELS);
     flush_run(c);
     auto tu2 = std::chrono::steady_clock::now();
@@ -812,13 +814,13 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
     *use_lds = bytes <= 160*1024 - 64;                                                      // gfx950: 160 KB of LDS per workgroup
     return *use_lds ? (int)bytes : 0;
 }
-static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
+static void launch_schur(Ctx *c, const LevelDev &D, int multi, SchurDec dec = SchurDec{0, 0, 0, tsba_options{}}) {
     if (c->n_kf > 126 && !c->dbg.no_schur_quad) {               // large maps: four S blocks per wave, then one wave per pose for the reduced gradient
         const int nq = D.n_sb > 0 ? (((D.n_sb + 3)/4 + 7)/8)*8 : 0, ng = ((c->n_kf + 7)/8)*8;           // (multiples of 8 workgroups: the kernel's XCD-aware mappings)
         if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq + ng), dim3(64), 0, c->stream, c->W, D, multi, nq, ng);
         else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq + ng), dim3(64), 0, c->stream, c->W, D, multi, nq, ng);
-    } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0);
-    else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0);
+    } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
+    else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0, dec);
     if (D.far_B > 0 && D.n_far > 0) {            // the blocks of E (what couples different clusters of a landmark): the same kernels on the fb_* lists, stored to W.Sfar
         LevelDev E = D;
         E.n_sb = D.n_far; E.sb_a = D.far_a; E.sb_b = D.far_b; E.sb_pab = D.fb_pab; E.sb_pba = D.fb_pba; E.sb_far = D.fb_id;
@@ -827,8 +829,8 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi) {
         if (c->n_kf > 126 && !c->dbg.no_schur_quad) { const int nq = (((E.n_sb + 3)/4 + 7)/8)*8;
             if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi, nq, 0);
             else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi, nq, 0); }
-        else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(E.n_sb), dim3(64), 0, c->stream, c->W, E, multi, 0);
-        else hipLaunchKernelGGL(k_schur_t<4>, dim3(E.n_sb), dim3(256), 0, c->stream, c->W, E, multi, 0);
+        else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(E.n_sb), dim3(64), 0, c->stream, c->W, E, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
+        else hipLaunchKernelGGL(k_schur_t<4>, dim3(E.n_sb), dim3(256), 0, c->stream, c->W, E, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
     }
 }
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
@@ -1231,9 +1233,15 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     hipLaunchKernelGGL(k_pcg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
 }
 
+static void launch_decide(Ctx *c, const LevelDev &D) {
+    Work &W = c->W;
+    const int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
+    const int nb_all = back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text) + nb_kf;
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_all, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
+}
 // one LM iteration: reduced system -> pose step -> back-substitution / candidate -> speculative linearisation at the
 // candidate -> decision (on acceptance the speculative LinBuf simply becomes the current one)
-static void launch_step(Ctx *c, const LevelDev &D) {
+static void launch_step(Ctx *c, const LevelDev &D, bool decide_prev = false) {
     struct XT { Ctx *c; size_t x0; ~XT() { c->x_trial = c->x_acc - x0; } } xt{c, c->x_acc};
     Work &W = c->W;
     int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
@@ -1244,7 +1252,12 @@ static void launch_step(Ctx *c, const LevelDev &D) {
     if ((int64_t)D.n_sb < (int64_t)c->n_kf*(c->n_kf + 1)/2 && (!c->band_stream || c->S_stale || is_multi(c))) {
         hipMemsetAsync(c->S_alloc, 0, sizeof(double)*c->S_count, c->stream); c->S_stale = false;
         if (D.far_B > 0) hipMemsetAsync(W.Sfar, 0, sizeof(double)*36*(size_t)std::max(D.n_far, 1), c->stream); }
-    launch_schur(c, D, (int)is_multi(c));
+    const int bb_pt = back_blocks_pt(c->n_pt), bb_tx = back_blocks_tx(c->n_text), nb_all = bb_pt + bb_tx + nb_kf;      // k_back's blocks
+    const bool fused_decide = W.st_next != nullptr && D.far_B <= 0;       // the decision on a trial is taken by the NEXT trial's k_schur_t (the last trial's by k_decide after the loop)
+    if (fused_decide && decide_prev) {
+        launch_schur(c, D, 0, SchurDec{1, nb_all, nb_pt + nb_tx + nb_pr, c->opt});
+        std::swap(W.st, W.st_next);                 // from here on the launches see the state that launch wrote
+    } else launch_schur(c, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
         if (c->S_xchg) {                           // band storage: only the band's entries travel
             const size_t nx = ((size_t)W.N + (W.ring ? c->xchg_wp - 6 : 0))*c->xchg_wp;
@@ -1257,7 +1270,6 @@ static void launch_step(Ctx *c, const LevelDev &D) {
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
         hipLaunchKernelGGL(k_damp_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
-    const int bb_pt = back_blocks_pt(c->n_pt), bb_tx = back_blocks_tx(c->n_text), nb_all = bb_pt + bb_tx + nb_kf;      // k_back's blocks
     if (W.dp_poll && D.far_B <= 0) {               // small window: solver (workgroup 0) and back-substitution (three blocks per workgroup, polling the step) in one launch
         int use_lds; const int lds = solve_lds_bytes(c, &use_lds);
         hipLaunchKernelGGL(k_solve_back, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), std::max(lds, (int)((768 + W.N + 2)*sizeof(double))), c->stream, W, D, bb_pt, bb_tx, nb_all);
@@ -1266,7 +1278,7 @@ static void launch_step(Ctx *c, const LevelDev &D) {
         hipLaunchKernelGGL(k_back, dim3(nb_all), dim3(256), 0, c->stream, W, D, bb_pt, bb_tx);
     }
     launch_linearize(c, D, 1);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_all, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
+    if (!fused_decide) launch_decide(c, D);
 }
 
 int tsba_solve(void *ctx, tsba_report *r) {
@@ -1323,11 +1335,13 @@ int tsba_solve(void *ctx, tsba_report *r) {
             continue;
         }
         launch_linearize(c, D, 0);
+        int n_trials = 0;
         for (int it = 0; it < o.its[ps]; it++) {
             if (converged(it)) break;
-            launch_step(c, D);
+            launch_step(c, D, n_trials > 0); n_trials++;
             if (it >= 1) { rc = stage_ahead(c, ps); if (rc) return rc; }      // (with two iterations queued the device does not run dry while the host stages)
         }
+        if (n_trials > 0 && c->W.st_next != nullptr && D.far_B <= 0) launch_decide(c, D);      // windows: the decision on the last trial (the others were taken by the following trial's k_schur_t)
         if (o.outlier_scene || o.outlier_text)
             if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
                                                           o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)nullptr);

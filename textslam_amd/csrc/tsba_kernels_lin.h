@@ -651,6 +651,7 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
         for (int u = 0; u < MID_U; u++) pr0[u] = L.pt_pair4[MID_U*(size_t)j + u]; } }
     else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + threadIdx.x; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
     else { const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x; if (p < L.n_pair) { tq0 = L.pair_tg_off[p]; tq1 = L.pair_tg_off[p+1]; ph_ = L.pair_h[p]; hp_ = L.pair_hpos[p]; } }
+    if (W.st_next && b == 0 && threadIdx.x == 0) W.st_next->step_fail = 0;      // (the next trial's k_schur_t takes this trial's decision into that copy of the state, every field but this one: its own workgroups may raise it)
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
@@ -843,8 +844,10 @@ __device__ void pose_scale(const Work &W, const LinBuf &B, const double *sHd, co
 // loads of all parts issued before the first wait and ONE five-value block reduction (a global round trip from this lone
 // workgroup costs ~0.6 us, a block reduction ~0.3 us: the old sequence had a dozen of the former and seven of the latter).
 //   out5 = { max |gradient|, |x|^2, cost, step^2 (nb_back partials), model cost change (nb_back partials) }   (thread 0)
+// write: this workgroup stores the poses' diagonal / gradient / damping rows (every workgroup of a launch that takes the decision redundantly computes
+// them; one stores); keep (may be null): [2][6 n_kf] in LDS, the damping rows and the gradient rows for the caller's own use
 __device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm, int nb_back,
-                              double *red /*[5*256]*/, double *xch /*[252]*/, double out5[5], int npp = 0) {
+                              double *red /*[5*256]*/, double *xch /*[252]*/, double out5[5], int npp = 0, bool write = true, double *keep = nullptr) {
     const int tid = threadIdx.x;
     double gmax = 0.0, xn = 0.0, cost = 0.0, step2 = 0.0, mcc = 0.0;
 #ifdef TSBA_SOLVE_STAMPS
@@ -893,10 +896,12 @@ __device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B,
         __syncthreads();
         if (on && k < 6) {
             const double h = val, g = xch[tid + 6];
-            B.Hd[6*a + k] = h; B.bp[6*a + k] = g; B.bp_loc[6*a + k] = g;
+            if (write) { B.Hd[6*a + k] = h; B.bp[6*a + k] = g; B.bp_loc[6*a + k] = g; }
             double sg = sgp;
-            if (first) { sg = 1.0/(1.0 + sqrt(h)); W.sig_p[6*a + k] = sg; }
-            B.dgs_p[6*a + k] = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
+            if (first) { sg = 1.0/(1.0 + sqrt(h)); if (write) W.sig_p[6*a + k] = sg; }
+            const double dgv = clampd(sg*sg*h, W.min_diag, W.max_diag)/(sg*sg);
+            if (write) B.dgs_p[6*a + k] = dgv;
+            if (keep) { keep[6*a + k] = dgv; keep[6*W.n_kf + 6*a + k] = g; }
             if (fre >= 0) { gmax = fmax(gmax, fabs(g)); xn += px*px + (k == 0 ? px6*px6 : 0.0); }
         }
         __syncthreads();
@@ -1019,6 +1024,7 @@ __device__ void pose_parts_multi(const Work &W, int npp, double *red, double &gm
 __global__ __launch_bounds__(256) void k_postlin(Work W, LevelDev L, double grad_tol, int nb_lm, int multi, int npp) {
     LmState *st = W.st;
     if (W.dp_poll) for (int k = threadIdx.x; k <= W.N; k += 256) W.dp[k] = __builtin_nan("");       // (k_solve_back: "not there yet" for the blocks that poll the step)
+    if (W.st_next && threadIdx.x == 0) W.st_next->step_fail = 0;
     if (st->done || !st->need_lin) return;
     __shared__ double red[5*256], xch[256];
     double gmax, xn, cost;

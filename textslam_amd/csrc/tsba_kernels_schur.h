@@ -6,19 +6,58 @@
 #define SCHUR_U 4
 // SCHUR_NW waves per workgroup: 4 for windows (a diagonal block gathers ~1000 slot pairs), 1 for large maps (54 k blocks of ~60 slot
 // pairs each at 5000 keyframes: three idle waves per block and their hand-off were most of the 0.64 ms)
+// dec (windows on one GPU, SCHUR_NW = 4: 256 threads as k_decide): the launch takes the DECISION on the previous trial first -- every workgroup,
+// redundantly and bit-identically, sums what the candidate's linearisation left (postlin_fused: cost, step, model cost change, the poses' diagonal and
+// gradient rows), applies the Ceres rules to its private copy of the state and goes on with the outcome; workgroup 0 also stores the rows and writes the
+// new state to W.st_next (the host passes that copy as W.st from the next launch on).  k_decide as a launch of its own was 9.0 us + a gap per trial;
+// inside this launch its round trip runs next to the list fetches of the assembly.
+struct SchurDec { int on, nb_back, nb_lm; tsba_options o; };
+template <class S> __device__ __forceinline__ double lm_decide(S &s, double cost, double step2, double mcc, double gmax_c, double xn_c, const tsba_options &o);
+__device__ __forceinline__ void lm_decide_publish(const Work &W, const LmState &s, double cost, double mcc_half, double verdict);
+__device__ __forceinline__ void lm_state_store(LmState *n, const LmState &s) {       // every field but step_fail
+    n->radius = s.radius; n->decrease_factor = s.decrease_factor; n->x_cost = s.x_cost; n->x_norm = s.x_norm; n->cand_cost = s.cand_cost;
+    n->model_change = s.model_change; n->step_norm = s.step_norm; n->gmax = s.gmax; n->cost0 = s.cost0;
+    n->cur = s.cur; n->done = s.done; n->need_lin = s.need_lin; n->first = s.first; n->it = s.it; n->accepted = s.accepted; n->term = s.term;
+    n->invalid = s.invalid; n->max_it = s.max_it; n->lcur = s.lcur; n->lin_done = s.lin_done;
+    n->ns_active = s.ns_active; n->nt_active = s.nt_active; n->n_bad_scene = s.n_bad_scene; n->n_bad_tfeat = s.n_bad_tfeat; n->n_bad_text = s.n_bad_text; n->pad2 = s.pad2;
+    n->n_lin = s.n_lin; n->n_cost = s.n_cost;
+}
 template <int SCHUR_NW>
-__global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int multi, int b0) {
+__global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int multi, int b0, SchurDec dec) {
     constexpr int SCHUR_T = 64*SCHUR_NW;
     LmState *st = W.st;
-    if (st->done) return;
+    if (st->done) {                                             // (a finished pass: the launches the host still had in flight -- the other copy of the state has to say so too)
+        if (SCHUR_NW == 4 && dec.on && blockIdx.x == 0 && threadIdx.x == 0) { const LmState s = *st; lm_state_store(W.st_next, s); }
+        return; }
     __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
+    __shared__ double keep[SCHUR_NW == 4 ? 2*6*32 : 1]; __shared__ double dsh_r; __shared__ int dsh_i[3];
+    int lcur_ = st->lcur; double radius_ = st->radius; bool fresh = false;      // fresh: the current linearisation is the candidate this launch has just accepted
+    if constexpr (SCHUR_NW == 4) if (dec.on) {
+        double o5[5];
+        postlin_fused(W, L, W.lb[lcur_ ^ 1], W.pose[st->cur ^ 1], false, dec.nb_lm, dec.nb_back, lds, lds + 5*256, o5, 0, blockIdx.x == 0, keep);
+        if (blockIdx.x == 0 && W.dp_poll) for (int k = threadIdx.x; k <= W.N; k += SCHUR_T) W.dp[k] = __builtin_nan("");     // (k_solve_back: "not there yet")
+        if (threadIdx.x == 0) {
+            LmState s = *st;
+            s.lin_done = 0;
+            const double verdict = lm_decide(s, o5[2], o5[3], o5[4], o5[0], o5[1], dec.o);
+            dsh_i[0] = s.done; dsh_i[1] = s.lcur; dsh_i[2] = s.lcur != lcur_; dsh_r = s.radius;
+            if (blockIdx.x == 0) {                               // the new state, every field but step_fail (zero since k_mid of the last trial; the workgroups of this launch may raise it)
+                lm_state_store(W.st_next, s);
+                lm_decide_publish(W, s, o5[2], s.model_change, verdict);
+            }
+        }
+        __syncthreads();
+        if (dsh_i[0]) return;
+        lcur_ = dsh_i[1]; radius_ = dsh_r; fresh = dsh_i[2] != 0;
+        st = W.st_next;                                         // (where this trial's failure flag lives)
+    }
     // (b0 > 0: large maps take the S blocks through k_schur_quad and only the gradient part here, a grid of a multiple of 8 workgroups in
     // which the workgroups of ONE XCD -- workgroup i runs on XCD i mod 8 -- take neighbouring poses: the slot records of a landmark sit next
     // to each other, one per observing pose, and neighbouring poses observe the same landmarks)
     const int bx = b0 > 0 ? ((int)blockIdx.x & 7)*((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int b = bx + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double radius = st->radius, irad = 1.0/radius;
-    const LinBuf &B = W.lb[st->lcur];
+    const double radius = radius_, irad = 1.0/radius;
+    const LinBuf &B = W.lb[lcur_];
     if (b < L.n_sb) {
         const int a = L.sb_a[b], c = L.sb_b[b];
         const int ia = W.fidx[a], ic = W.fidx[c];           // rows / columns of S exist for free poses only
@@ -80,7 +119,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             if (a == c) {
                 const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
                 tail = range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
-                if (r == cc && !multi) tail += B.dgs_p[6*a + r]*irad;      // multi-GPU: added once after the all-reduce
+                if (r == cc && !multi) tail += (SCHUR_NW == 4 && fresh ? keep[6*a + r] : B.dgs_p[6*a + r])*irad;      // multi-GPU: added once after the all-reduce
             } else {
                 int pab = L.sb_pab[b], pba = L.sb_pba[b];
                 if (pab >= 0) tail -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
@@ -170,7 +209,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             for (int k = 0; k < 6; k++)
                 acc[k] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*f0 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*f1 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*f2;
         }
-        const double bpv = tid < 6 ? (multi ? B.bp_loc[6*a + tid] : B.bp[6*a + tid]) : 0.0;
+        const double bpv = tid < 6 ? (multi ? B.bp_loc[6*a + tid] : (SCHUR_NW == 4 && fresh ? keep[6*W.n_kf + 6*a + tid] : B.bp[6*a + tid])) : 0.0;
 #pragma unroll
         for (int k = 0; k < 6; k++) acc[k] = wave_sum1(acc[k]);
         if (lane == 0) {

@@ -211,6 +211,48 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_back(Work W, LevelDev L
     solve_body<false, true>(W, 0, smem);
 }
 
+// ---- the decision on one LM trial (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics) on the state s -- the state in device memory
+// (k_decide) or a workgroup's private copy of it (k_schur_t with the decision of the previous trial inside, tsba_kernels_schur.h).
+// Returns the trace verdict: 1 accepted / 0 rejected / -1 invalid step / 2 tolerance exit on this trial.
+template <class S>
+__device__ __forceinline__ double lm_decide(S &s, double cost, double step2, double mcc, double gmax_c, double xn_c, const tsba_options &o) {
+    double verdict = 0.0;
+    mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
+    s.it++;
+    s.cand_cost = cost; s.model_change = mcc; s.step_norm = sqrt(step2);
+    if (s.step_fail || !(mcc > 0.0)) {            // invalid step (LevenbergMarquardtStrategy::StepIsInvalid)
+        s.step_fail = 0; verdict = -1.0;
+        if (++s.invalid >= 5) { s.done = 1; s.term = 5; return verdict; }
+        s.radius *= 0.5;
+    } else {
+        s.invalid = 0; s.n_cost++;
+        if (!(cost == cost)) cost = 1.7976931348623157e308;
+        if (s.step_norm <= o.parameter_tolerance*(s.x_norm + o.parameter_tolerance)) { s.done = 1; s.term = 2; return 2.0; }
+        double cost_change = s.x_cost - cost;
+        if (fabs(cost_change) <= o.function_tolerance*s.x_cost) { s.done = 1; s.term = 1; return 2.0; }
+        double rel = cost_change/mcc;
+        if (rel > o.min_relative_decrease) {      // accept: the speculative linearisation becomes the current one
+            s.cur ^= 1; s.lcur ^= 1; s.accepted++; s.n_lin++;
+            s.x_cost = cost; s.x_norm = sqrt(xn_c); s.gmax = gmax_c;
+            double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
+            s.radius = fmin(s.radius/f, o.max_radius);
+            s.decrease_factor = 2.0; verdict = 1.0;
+            if (gmax_c <= o.gradient_tolerance) { s.done = 1; s.term = 3; return verdict; }
+        } else {
+            s.radius = s.radius/s.decrease_factor; s.decrease_factor *= 2.0;
+        }
+    }
+    if (s.it >= s.max_it) { s.done = 1; s.term = 0; }
+    else if (s.radius < o.min_radius) { s.done = 1; s.term = 4; }
+    return verdict;
+}
+// what a decision leaves for the host and the tests: the trace record of the trial (tsba_debug_lm_trace: 32 bytes) and the pinned progress word
+__device__ __forceinline__ void lm_decide_publish(const Work &W, const LmState &s, double cost, double mcc_half, double verdict) {
+    if (W.trace && s.it >= 1 && s.it <= TSBA_TRACE_CAP) {
+        double *t = W.trace + 4*((size_t)W.trace_pass*TSBA_TRACE_CAP + s.it - 1);
+        t[0] = verdict < 0.0 ? __longlong_as_double(0x7ff8000000000000LL) : (cost == cost ? cost : 1.7976931348623157e308); t[1] = mcc_half; t[2] = s.radius; t[3] = verdict; }
+    if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)s.it << 1) | (s.done ? 1u : 0u); __threadfence_system(); }
+}
 // ---- step quality and trust-region update (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics)
 __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back, int nb_lm, tsba_options o, int multi, int npp) {
     LmState *st = W.st;
@@ -240,40 +282,8 @@ __global__ __launch_bounds__(256) void k_decide(Work W, LevelDev L, int nb_back,
     }
     if (tid) return;
     st->lin_done = 0;                             // (the iterative reduced-system solve of this trial is over: tsba_pcg.h)
-    double verdict = 0.0;                         // trace: 1 accepted / 0 rejected / -1 invalid step / 2 tolerance exit on this trial
-    [&]() {
-    mcc *= 0.5;                                   // model_cost_change = 1/2 dx^T (Lambda dx - g)
-    st->it++;
-    st->cand_cost = cost; st->model_change = mcc; st->step_norm = sqrt(step2);
-    if (st->step_fail || !(mcc > 0.0)) {          // invalid step (LevenbergMarquardtStrategy::StepIsInvalid)
-        st->step_fail = 0; verdict = -1.0;
-        if (++st->invalid >= 5) { st->done = 1; st->term = 5; return; }
-        st->radius *= 0.5;
-    } else {
-        st->invalid = 0; st->n_cost++;
-        if (!(cost == cost)) cost = 1.7976931348623157e308;
-        if (st->step_norm <= o.parameter_tolerance*(st->x_norm + o.parameter_tolerance)) { st->done = 1; st->term = 2; verdict = 2.0; return; }
-        double cost_change = st->x_cost - cost;
-        if (fabs(cost_change) <= o.function_tolerance*st->x_cost) { st->done = 1; st->term = 1; verdict = 2.0; return; }
-        double rel = cost_change/mcc;
-        if (rel > o.min_relative_decrease) {      // accept: the speculative linearisation becomes the current one
-            st->cur ^= 1; st->lcur ^= 1; st->accepted++; st->n_lin++;
-            st->x_cost = cost; st->x_norm = sqrt(xn_c); st->gmax = gmax_c;
-            double t = 2.0*rel - 1.0, f = 1.0 - t*t*t; if (f < 1.0/3.0) f = 1.0/3.0;
-            st->radius = fmin(st->radius/f, o.max_radius);
-            st->decrease_factor = 2.0; verdict = 1.0;
-            if (gmax_c <= o.gradient_tolerance) { st->done = 1; st->term = 3; return; }
-        } else {
-            st->radius = st->radius/st->decrease_factor; st->decrease_factor *= 2.0;
-        }
-    }
-    if (st->it >= st->max_it) { st->done = 1; st->term = 0; }
-    else if (st->radius < o.min_radius) { st->done = 1; st->term = 4; }
-    }();
-    if (W.trace && st->it >= 1 && st->it <= TSBA_TRACE_CAP) {     // test hook (tsba_debug_lm_trace): 32 bytes per trial
-        double *t = W.trace + 4*((size_t)W.trace_pass*TSBA_TRACE_CAP + st->it - 1);
-        t[0] = verdict < 0.0 ? __longlong_as_double(0x7ff8000000000000LL) : cost; t[1] = mcc; t[2] = st->radius; t[3] = verdict; }
-    if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)st->it << 1) | (st->done ? 1u : 0u); __threadfence_system(); }
+    const double verdict = lm_decide(*st, cost, step2, mcc, gmax_c, xn_c, o);
+    lm_decide_publish(W, *st, cost, st->model_change, verdict);
 #ifdef TSBA_SOLVE_STAMPS
     W.dbg[32] = s1_ - s0_; W.dbg[33] = s2_ - s1_; W.dbg[34] = s3_ - s2_; W.dbg[35] = clock64() - s3_;
 #endif

@@ -100,7 +100,7 @@ struct Work {                // device work buffers (sized for the largest level
     double *partial;                    // [nblocks_back][2]
     int *cntpart;                       // per k_participation workgroup: active scene blocks, active text blocks
     double *posepart;                   // large maps: per k_pose_sums workgroup (21 poses): gradient max, |x|^2
-    LmState *st;
+    LmState *st, *st_next;              // st_next (windows, single GPU; else null): the copy of the state that k_schur_t writes when it takes the previous trial's decision itself -- the host swaps the two after that launch
     PoseState *pst; double *ppart;      // pose-only path (tsba_pose.h): double-buffered state, [2][G][28] partial sums
     // band + long-range blocks, preconditioned conjugate gradients (tsba_pcg.h): the blocks outside the band [n_far][36] (rows: the earlier keyframe),
     // the iteration's vectors in the compressed row space of S, per-workgroup partial sums [2][workgroups], double-buffered scalars, statistics
