@@ -859,6 +859,8 @@ static int set_solver_attrs(Ctx *c) {
         CK(hipFuncSetAttribute((const void *)k_sv_fwd_int<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_sv_back_int<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_sv_back_int<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        CK(hipFuncSetAttribute((const void *)k_sv_tree_back<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150*1024));
+        CK(hipFuncSetAttribute((const void *)k_sv_tree_back<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -1068,6 +1070,11 @@ static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rd
     const int tree = fuse_top && !(c->dbg.sv_per_level & 1);           // the whole tree in one launch (k_sv_cre_tree)
     if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
     else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
+    const bool tree_back = tree && !(c->dbg.sv_per_level & 8);        // ... and the interiors' back substitution in the tree's launch (k_sv_tree_back)
+    if (tree_back) {
+        if (B <= 10) hipLaunchKernelGGL(k_sv_tree_back<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, htop, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
+        else hipLaunchKernelGGL(k_sv_tree_back<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, htop, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
+        return; }
     if (tree) hipLaunchKernelGGL(k_sv_cre_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
     else {
         for (int h = 1; h <= htop; h <<= 1) { const int npiv = pivots(h); if (npiv <= 0 || (fuse_top && h == htop)) continue;

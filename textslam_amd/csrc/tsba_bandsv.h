@@ -204,13 +204,20 @@ __global__ __launch_bounds__(SV_T) void k_sv_fwd_int(Work W, int bw, int Pmax, c
 
 // ---- interiors, backward.  grid Pmax, SV_T threads: the border part  v_q -= Lb_q^T x_left  by all threads into LDS (vc), then the chain on wave 0 with the
 // other waves staging.  M.X = the solution (the rows of the separator on the right written along).  lmax: bound of an interior's length (host).
-template <int NREG>
-__global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, int lmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M, const double *__restrict__ rdot, double *__restrict__ rz_part) {
-    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
+// POLL (k_sv_tree_back): the interior runs in the launch of the separator tree -- the solutions of its two separators (M.Xs) are polled where the
+// kernel of its own reads them, after everything that does not depend on them has been requested
+__device__ __forceinline__ double sv_poll1(const double *p, bool on) {
+    double v = 0.0;
+    if (on) { v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spins = 0; v != v && spins < (1 << 15); spins++) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (v != v) v = __builtin_inf(); }
+    return v;
+}
+template <int NREG, bool POLL>
+__device__ __forceinline__ void sv_back_int_body(const Work &W, int bw, int Pmax, int lmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, const MsBuf &M, const double *__restrict__ rdot, double *__restrict__ rz_part, double *ms_smem, int p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = ms_uni(tid >> 6);
-    const int p = blockIdx.x;
     const LmState *st_ = W.st; const int flags = st_->done | st_->lin_done | st_->step_fail, nf = ms_uni(*W.nfree);
-    double xlv = (p > 0 && tid < bw) ? M.Xs[(size_t)(p - 1)*bw + tid] : 0.0;      // (requested along with the flags: the address does not depend on them)
+    double xlv = (!POLL && p > 0 && tid < bw) ? M.Xs[(size_t)(p - 1)*bw + tid] : 0.0;      // (requested along with the flags: the address does not depend on them)
     sv_pin(xlv);
     if (flags || nf <= 0) return;
     const int B = bw/6, CS = sv_cs(B), TB = 36*B;
@@ -247,10 +254,10 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
     else {
 #pragma unroll
         for (int g = 0; g < NREG; g++) { const int d = (sR - slot[g] + B) % B, q = rtop - 1 - d;
-            tsep[g] = (rowok[g] && q >= b) ? M.Xs[(size_t)p*bw + 6*(q - b) + ri[g]] : 0.0; }
+            tsep[g] = (!POLL && rowok[g] && q >= b) ? M.Xs[(size_t)p*bw + 6*(q - b) + ri[g]] : 0.0; }
     }
     {   // vc = v - Lb^T x_left: four lanes per output row, two passes of 128 outputs in flight
-        if (tid < 80) xl[tid] = xlv;
+        if (!POLL && tid < 80) xl[tid] = xlv;
         const int part = tid & 3, eo = tid >> 2, nout = 6*(b - a);
         bool first = true;
         for (int e0 = 0; e0 < nout; e0 += 2*(SV_T/4)) {
@@ -261,7 +268,8 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
 #pragma unroll
                 for (int j = 0; j < 20; j++) { const int br = part + 4*j; lv[ps][j] = (ok && p > 0 && br < bw) ? Lq[6*br] : 0.0; }
                 v0[ps] = (ok && part == 0) ? M.V[6*(size_t)q + cc] : 0.0; }
-            if (first) { __syncthreads(); first = false; }      // (xl)
+            if (first) { if (POLL && tid < 80) xl[tid] = sv_poll1(&M.Xs[(size_t)max(p - 1, 0)*bw + tid], p > 0 && tid < bw);
+                __syncthreads(); first = false; }      // (xl)
 #pragma unroll
             for (int ps = 0; ps < 2; ps++) { const int e = e0 + ps*(SV_T/4) + eo; const bool ok = e < nout;
                 double acc = 0.0;
@@ -273,6 +281,11 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
         if (first) __syncthreads();
     }
     if (wave > 0) stage_store(0);
+    if (POLL && wave == 0) {
+#pragma unroll
+        for (int g = 0; g < NREG; g++) { const int d = (sR - slot[g] + B) % B, q = rtop - 1 - d; const bool on = rowok[g] && q >= b;
+            tsep[g] = sv_poll1(&M.Xs[(size_t)p*bw + (on ? 6*(q - b) + ri[g] : 0)], on); }
+    }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
@@ -340,6 +353,11 @@ __global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, 
         __syncthreads();
     }
     if (rdot && wave == 0) { const double sr = wave_sum1(lane < 6 ? racc : 0.0); if (lane == 0) rz_part[p] = sr; }
+}
+template <int NREG>
+__global__ __launch_bounds__(SV_T) void k_sv_back_int(Work W, int bw, int Pmax, int lmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M, const double *__restrict__ rdot, double *__restrict__ rz_part) {
+    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
+    sv_back_int_body<NREG, false>(W, bw, Pmax, lmax, Lrow, Lb, M, rdot, rz_part, ms_smem, (int)blockIdx.x);
 }
 
 // ---- the inverse of every separator's unit-lower factor, once per factorisation: M.Li [label][s][s] row-major (zeros above the diagonal), M.Lid [label][s] = 1/d.
@@ -717,11 +735,9 @@ __global__ __launch_bounds__(SV_CT) void k_sv_cre_back(Work W, Work Ws, int bw, 
 // NaN (a NaN result goes out as +inf: the iteration above sees it in r.z) and polling is bounded, so a broken factor cannot park the device.
 // All workgroups are resident at once (at most 127 of them on 256 CUs), and a waiting workgroup holds nothing its producers need.
 // Same arithmetic in the same order as k_sv_cre_fwd / _top / _back: the result is bit-identical to the launch-per-level path.
-__global__ __launch_bounds__(SV_CT) void k_sv_cre_tree(Work W, Work Ws, int bw, int Pmax, int htop, MsBuf M) {
-    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], xc[80], red[6*80];
-    const int tid = threadIdx.x;
-    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), i = (int)blockIdx.x + 1, lo = 0, r0 = 0;
-    if (i == htop) { sv_top_body<true>(W, s, B, Pmax, mmax, htop, M, v, w, cga, x0, xc, red); return; }
+// a pivot below the top: its forward step, then -- once both neighbours are solved -- its back substitution
+__device__ __forceinline__ void sv_tree_node_body(const Work &W, int s, int B, int Pmax, int i, int htop, const MsBuf &M, double *v, double *w, double *x0, double *xc, double *red) {
+    const int tid = threadIdx.x, lo = 0, r0 = 0;
 #ifdef TSBA_SOLVE_STAMPS
     // wall-clock stamps (10 ns ticks, one clock for the whole device) of pivot 1 and of the pivot below the top: W.dbg[0 / 8 ..]
     const int sslot = i == 1 ? 0 : i == htop/2 ? 8 : -1; int sn = 0;
@@ -761,7 +777,28 @@ __global__ __launch_bounds__(SV_CT) void k_sv_cre_tree(Work W, Work Ws, int bw, 
     __syncthreads();
     if (vrow) sv_st_co(&M.Xs[(size_t)i*s + tid], u0 - SV_SUM6(red, tid));
     TREE_STAMP();
+}
+__global__ __launch_bounds__(SV_CT) void k_sv_cre_tree(Work W, Work Ws, int bw, int Pmax, int htop, MsBuf M) {
+    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], xc[80], red[6*80];
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), i = (int)blockIdx.x + 1;
+    if (i == htop) sv_top_body<true>(W, s, B, Pmax, mmax, htop, M, v, w, cga, x0, xc, red);
+    else sv_tree_node_body(W, s, B, Pmax, i, htop, M, v, w, x0, xc, red);
     (void)Ws;
+}
+// ---- the tree and the interiors' back substitution in one launch: workgroup p is the pivot of label p (the top pivot's also the root; workgroups 0 and P - 1
+// have no pivot) and then interior p, which polls the solutions of its two separators where k_sv_back_int reads them -- with the records of its first
+// chunk and the border rows already requested.  (k_sv_back_int behind its own launch: 20.9 us per application.)
+template <int NREG>
+__global__ __launch_bounds__(SV_T) void k_sv_tree_back(Work W, int bw, int Pmax, int htop, int lmax, const double *__restrict__ Lrow, const double *__restrict__ Lb, MsBuf M, const double *__restrict__ rdot, double *__restrict__ rz_part) {
+    extern __shared__ __attribute__((aligned(16))) double ms_smem[];
+    __shared__ __attribute__((aligned(16))) double v[80], w[80], cga[80], x0[80], xc[80], red[6*80];
+    const int s = bw, B = s/6, mmax = cr_mmax(W.ring, Pmax, W.ring_g), i = (int)blockIdx.x;
+    if (i >= 1 && i < mmax) {
+        if (i == htop) sv_top_body<true>(W, s, B, Pmax, mmax, htop, M, v, w, cga, x0, xc, red);
+        else sv_tree_node_body(W, s, B, Pmax, i, htop, M, v, w, x0, xc, red);
+    }
+    __syncthreads();
+    sv_back_int_body<NREG, true>(W, bw, Pmax, lmax, Lrow, Lb, M, rdot, rz_part, ms_smem, i);
 }
 
 // ---- the back substitution of the factorisation's OWN right-hand side through the same products, in one launch: x_i = L^-T z_i - P_a^T x_a - P_c^T x_c with z_i
