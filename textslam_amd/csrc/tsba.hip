@@ -634,6 +634,8 @@ static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, dou
     D.sb_far = nullptr;
     D.n_wb = (int)H.wb_kf.size(); D.wb_kf = nullptr; D.wb_idx = nullptr;
     if (H.far_B > 0 && D.n_wb > 0) { UV(wb_kf); UV(wb_idx); }
+    D.far_rec = nullptr; D.n_far_ent = H.far_B > 0 ? (int)H.far_ent.size() : 0;
+    if (H.far_B > 0) { rc = dev_alloc(c, &D.far_rec, std::max<size_t>(1, H.far_ent.size())); if (rc) return rc; }
     if (H.far_B > 0) { UV(far_a); UV(far_b); UV(far_off); UV(far_ent); UV(fb_id); UV(fb_pab); UV(fb_pba); UV(fb_pt_off); UV(fb_pt_s1); UV(fb_pt_s2); UV(fb_pt_lm);
         UV(fb_tx_off); UV(fb_tx_s1); UV(fb_tx_s2); UV(fb_tx_lm); }
     UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
@@ -782,6 +784,8 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     if (c->n_kf <= 64) hipLaunchKernelGGL(k_gauge_wave, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
     else if (c->n_kf > 256) hipLaunchKernelGGL(k_gauge_par, dim3(1), dim3(1024), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp, D.kf_order);
     else hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp, D.kf_order);
+    if (D.far_B > 0 && D.far_rec) { const int ne = D.n_far_ent;      // the blocks outside the band by keyframe, with the other keyframe's row (the gauge is fixed now)
+        if (ne > 0) hipLaunchKernelGGL(k_far_rows, dim3((ne + 255)/256), dim3(256), 0, c->stream, W, D, ne); }
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
 static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)

@@ -55,6 +55,14 @@ __global__ __launch_bounds__(PCG_ET) void k_pcg_begin(Work W, const double *zp, 
     pcg_block_partial<PCG_ET>(rrp, W.pc_part + 2*gridDim.x, lds);
 }
 
+// per pass, after the gauge: far_rec[e] = (far_ent[e], row of the entry's other keyframe among the free poses | -1)
+__global__ __launch_bounds__(256) void k_far_rows(Work W, LevelDev L, int ne) {
+    const int e = blockIdx.x*256 + threadIdx.x;
+    if (e >= ne) return;
+    const int ent = L.far_ent[e], fid = ent >> 1, oth = (ent & 1) ? L.far_a[fid] : L.far_b[fid];
+    L.far_rec[e] = make_int2(ent, W.fidx[oth]);
+}
+
 // launch `it`: beta from r.z, p = z + beta p, q = S p = (band + long-range blocks) p, partial p.q.  Also where convergence is noticed.
 // zp, zs: where the last preconditioner application left z = zs * zp[] (the factorisation's own solve: -W.Sy; the solve phase: its X).
 // A wave per keyframe, PCG_MW keyframes per workgroup; the partial p.q of a workgroup goes to pc_part[pq_off + blockIdx.x].  The kernel is a chain
@@ -121,9 +129,8 @@ __global__ __launch_bounds__(64*PCG_MW) void k_pcg_matvec(Work W, LevelDev L, in
         double fsum = 0.0;
         for (int eb = e0; eb < e1; eb += 10) {
             const int e = eb + es; const bool on = es < 10 && e < e1;
-            const int ent = on ? L.far_ent[e] : 0, fid = ent >> 1, side = ent & 1;
-            const int oth = on ? (side ? L.far_a[fid] : L.far_b[fid]) : 0;
-            const int io = on ? W.fidx[oth] : -1;
+            const int2 rec = on ? L.far_rec[e] : make_int2(0, -1);      // (entry, row of the other keyframe: k_far_rows)
+            const int ent = rec.x, fid = ent >> 1, side = ent & 1, io = rec.y;
             double f = 0.0;
             if (io >= 0) {                                      // side 0: this keyframe is far_a (rows of the block), side 1: far_b (columns)
                 const double *blk = W.Sfar + (size_t)fid*36 + (side ? r6 : 6*r6); const int stp = side ? 6 : 1;

@@ -26,6 +26,7 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     // band + long-range coupling (HostPlan::far_* / fb_*, tsba_pcg.h): nullptr / 0 unless the plan split the reduced system into M (the sb_* lists) + E.
     // sb_far: nullptr in this view; in the view of E that launch_schur derives (sb_* = the fb_* lists) the index of every block in W.Sfar
     const int *sb_far, *far_a, *far_b, *far_off, *far_ent; int n_far, far_B;
+    int n_far_ent; int2 *far_rec;       // [n_far_ent = entries of far_ent]: (the entry, the row of the block's OTHER keyframe among the free poses or -1): filled by k_far_rows once the pass's gauge is fixed, so that the matrix-vector product of tsba_pcg.h finds a block in one hop instead of three
     const int *wb_kf, *wb_idx; int n_wb;   // keyframes touched by E when they are few (tsba_wb.h)
     const int *fb_id, *fb_pab, *fb_pba, *fb_pt_off, *fb_pt_s1, *fb_pt_s2, *fb_pt_lm, *fb_tx_off, *fb_tx_s1, *fb_tx_s2, *fb_tx_lm;
 };
