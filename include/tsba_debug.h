@@ -71,7 +71,7 @@ typedef struct tsba_debug_options {
     int32_t pcg_tol_exp;       // > 0: relative tolerance 10^-pcg_tol_exp of the conjugate gradients in the M^-1 norm (default 10)
     int32_t pcg_refactor;      // preconditioner of the single-vector iteration: 0 the single-vector solve phase (tsba_bandsv.h) where it exists, else the factorisation re-run with the residual as right-hand side; 1: always the re-run; 2: the many-column solve phase with one column; 3: as 0 with r.z by its own kernel instead of inside the solve phase (A/B runs)
     int32_t pcg_block;         // 0 / 1: the single-vector iteration, 2: enlarged conjugate gradients (32 columns per preconditioner application, tsba_pcg.h) where the many-column solve phase of the band solver exists
-    int32_t solve_variant;     // reduced system of a small window (one workgroup, S in LDS): 0 the two-panel-wave schedule (tsba_solve.h), 1 the look-ahead schedule with a separate diagonal wave (tsba_solve_la.h: built in round 4 and measured SLOWER, 39.3 against 33.2 us on C4; kept for A/B runs), 2 as 1 with the update tiles handed out in wave order, 3 the production solver with the back-substitution as a launch of its own (k_solve_t + k_back, production until round 4) instead of in the solver's launch (k_solve_back)
+    int32_t solve_variant;     // reduced system of a small window (one workgroup, S in LDS): 0 the two-panel-wave schedule (tsba_solve.h), 1 the look-ahead schedule with a separate diagonal wave (tsba_solve_la.h: built in round 4 and measured SLOWER, 39.3 against 33.2 us on C4; kept for A/B runs), 2 as 1 with the update tiles handed out in wave order, 3 the production solver with the back-substitution and the step decision as launches of their own (k_solve_t + k_back + k_decide per trial, production until round 4) instead of in the solver's launch (k_solve_back) and in the next trial's k_schur_t
     int32_t sv_per_level;      // bit 0: the separator tree of the single-vector solve phase as one launch per level (k_sv_cre_fwd / _top / _back, production until round 4) instead of one launch for the whole tree (k_sv_cre_tree); bit 1: the back substitution of the factorisation's own solve on maps with long-range blocks as a launch per level (k_cre_back) instead of one launch through the solve phase's products (k_cre_back_tree); bit 2: the update step of a conjugate-gradient iteration (alpha; x, r) as a launch of its own (k_pcg_update) instead of inside the first kernel of the preconditioner application; bit 3: the interiors' back substitution of the solve phase as a launch of its own (k_sv_back_int) instead of in the tree's launch (k_sv_tree_back): A/B runs, bit-identity / parity tests
     int32_t host_pair_lists;   // 1: large maps build the slot pairs of the S blocks on the host (as every map did until round 4) instead of on the device (tsba_devplan.h): A/B runs, list comparison
 } tsba_debug_options;
