@@ -22,7 +22,12 @@ namespace {
 // The holder destroys the context when its thread exits (slabs, plane cache of 64 pyramid slots and streams go with it).  The label image below
 // reads the state of the last solve OF THE CALLING THREAD: UpdateTrackedTextBA runs on the thread that ran the BA (optimizer.cc:322-326), as here.
 struct CtxHolder { void *ctx = nullptr; ~CtxHolder() { if (ctx) tsba_destroy(ctx); } };
-void *tsba_ctx() { static thread_local CtxHolder h; if (!h.ctx && tsba_create(&h.ctx, 0) != TSBA_OK) { std::cerr << "tsba_create: no usable HIP device" << std::endl; exit(-1); } return h.ctx; }
+void *tsba_ctx() { static thread_local CtxHolder h;
+    if (!h.ctx && tsba_abi_version() != TSBA_ABI_VERSION) { std::cerr << "libtsba.so: ABI version " << tsba_abi_version() << ", this adapter was built against " << TSBA_ABI_VERSION << std::endl; exit(-1); }
+    if (!h.ctx && tsba_create(&h.ctx, 0) != TSBA_OK) { std::cerr << "tsba_create: no usable HIP device" << std::endl; exit(-1); } return h.ctx; }
+// what the window's keyframes and planes contributed to the last calls of THIS thread (adapter/tsba_gather.hpp: GatherCache).  Cleared by the entry points
+// that run where observations are re-targeted without their lists changing length (loop closing: mapPts::Replace before GlobalBA, loopClosing.cc:560-591)
+tsba_adapter::GatherCache &gather_cache() { static thread_local tsba_adapter::GatherCache c; return c; }
 void k_of(const Mat33 &K, double out[4]) { out[0] = K(0, 0); out[1] = K(1, 1); out[2] = K(0, 2); out[3] = K(1, 2); }
 // TSBA_ERR_NUMERIC = the linear solver broke down in some LM trial (Ceres: termination FAILURE): the one-shot entry points have still
 // downloaded the LAST ACCEPTED state and the flags of the passes that ran (tsba.hip: one_shot returns the status after tsba_download), so
@@ -37,7 +42,7 @@ void optimizer::LocalBundleAdjustment(map *mpMap, vector<keyframe *> vKFs, const
     vector<mapText *> vMapTexts = mpMap->GetAllMapTexts(TEXTGOOD);
     double K[4]; k_of(vK[0], K);
     Packed P;
-    tsba_adapter::pack_map<TT>(mpMap, vKFs, vMapPts, vMapTexts, /*local*/0, /*levels 0..2*/3, K, !bFlag_noText, P);           // optimizer.cc:201-279, :1366-1557
+    tsba_adapter::pack_map<TT>(mpMap, vKFs, vMapPts, vMapTexts, /*local*/0, /*levels 0..2*/3, K, !bFlag_noText, P, nullptr, nullptr, &gather_cache());           // optimizer.cc:201-279, :1366-1557
     tsba_options o; tsba_default_options_local(&o);                                                                        // :282-289
     o.state = STATE == LOCAL ? TSBA_STATE_LOCAL : STATE == GLOBAL ? TSBA_STATE_GLOBAL : TSBA_STATE_NOTREACHWIN;              // :1571-1588
     o.use_text = !bFlag_noText; o.outlier_scene = o.outlier_text = !bFlag_rapid;                                             // :1339-1345
@@ -56,6 +61,7 @@ void optimizer::GlobalBA(map *mpMap) {
     vector<mapText *> vMapTexts = mpMap->GetAllMapTexts(TEXTGOOD);
     double K[4]; k_of(vK[0], K);
     Packed P;
+    gather_cache().invalidate();                                                                                           // (a loop closure re-targets observations: what the local windows cached is stale)
     tsba_adapter::pack_map<TT>(mpMap, vKFs, vMapPts, vMapTexts, /*global*/1, 1, K, /*FLAG_TEXT = false, :1707*/false, P);
     tsba_options o; tsba_default_options_global(&o);                                                                       // :411-414
     tsba_report rep;

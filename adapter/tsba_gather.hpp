@@ -73,6 +73,73 @@ struct Packed {
     }
 };
 
+// ---- what a keyframe / a text plane contributes to EVERY window it is part of, kept between calls -----------------------------------
+// optimizer::LocalBundleAdjustment runs once per new keyframe on a window that slid by one (tracking.cc:826-842): 19 of its 20 keyframes were in the
+// last call, and walking their observation lists again -- obs[s]->IdxToRaw, vObvPts[raw]->pt->mnId, vSceneObv2d[0][raw]->feature: three dependent
+// pointer hops per observation and level -- is most of the gather's time (1.1 ms of a 4.6 ms call at 20 keyframes x 5000 points).  A keyframe's
+// observation lists are append-only in the reference (keyframe::AddSceneObserv, keyframe.cc:96-114: the only writers besides the constructor; called
+// by loop closing, loopClosing.cc:1259), and a plane's reference features are fixed when the plane is created (mapText.cc:64-107).  So a segment is
+// cached under the object's mnId and reused while the lengths of the lists it was built from are unchanged; what a call still does per observation
+// is one table lookup (map point id -> index in THIS call's point list) and four stores.  Point / plane parameters, poses and every flag are read
+// from the object graph in every call -- only topology is kept.  invalidate() after anything that re-targets observations without changing the lists'
+// lengths (mapPts::Replace at a loop closure, mapPts.cc:170-190): the adapter's GlobalBA / loop entry points call it.
+// The arrays a cached gather produces are the arrays pack_map produces without a cache, element for element (tests/cxx: slide_check).
+struct GatherCache {
+    struct KfSeg { size_t n_obvpts; std::vector<size_t> n_obs; std::vector<std::vector<int32_t> > raw, ptid; std::vector<std::vector<double> > uv0; unsigned long long used; };
+    struct TextSeg { std::vector<size_t> n_feat; std::vector<std::vector<int32_t> > raw; std::vector<std::vector<double> > uv, ref; unsigned long long used; };
+    std::map<long long, KfSeg> kf; std::map<long long, TextSeg> text;
+    unsigned long long tick; long long hits, misses;
+    GatherCache() : tick(0), hits(0), misses(0) {}
+    void invalidate() { kf.clear(); text.clear(); }
+    // entries no call has used for `keep` calls leave (the window moved on)
+    void begin_call(unsigned long long keep = 4) { tick++;
+        for (std::map<long long, KfSeg>::iterator it = kf.begin(); it != kf.end();) { if (it->second.used + keep < tick) kf.erase(it++); else ++it; }
+        for (std::map<long long, TextSeg>::iterator it = text.begin(); it != text.end();) { if (it->second.used + keep < tick) text.erase(it++); else ++it; } }
+    template <class KeyFrameT>
+    const KfSeg &scene(const KeyFrameT &K, int n_levels) {
+        KfSeg &S = kf[(long long)K.mnId];
+        bool ok = S.n_obs.size() == (size_t)n_levels && S.n_obvpts == K.vObvPts.size();
+        for (int l = 0; ok && l < n_levels; l++) ok = S.n_obs[(size_t)l] == ((size_t)l < K.vSceneObv2d.size() ? K.vSceneObv2d[(size_t)l].size() : 0);
+        S.used = tick;
+        if (ok) { hits++; return S; }
+        misses++;
+        S.n_obvpts = K.vObvPts.size(); S.n_obs.assign((size_t)n_levels, 0); S.raw.assign((size_t)n_levels, std::vector<int32_t>()); S.ptid = S.raw; S.uv0.assign((size_t)n_levels, std::vector<double>());
+        for (int l = 0; l < n_levels; l++) {
+            if ((size_t)l >= K.vSceneObv2d.size()) continue;
+            const auto &obs = K.vSceneObv2d[(size_t)l];
+            S.n_obs[(size_t)l] = obs.size(); S.raw[(size_t)l].reserve(obs.size()); S.ptid[(size_t)l].reserve(obs.size()); S.uv0[(size_t)l].reserve(2*obs.size());
+            for (size_t s = 0; s < obs.size(); s++) {
+                const int raw = obs[s]->IdxToRaw;
+                S.raw[(size_t)l].push_back(raw); S.ptid[(size_t)l].push_back((int32_t)K.vObvPts[(size_t)raw]->pt->mnId);
+                const auto uv0 = K.vSceneObv2d[0][(size_t)raw]->feature;
+                S.uv0[(size_t)l].push_back(uv0(0)); S.uv0[(size_t)l].push_back(uv0(1));
+            }
+        }
+        return S;
+    }
+    template <class MapTextT>
+    const TextSeg &features(const MapTextT &Tx, int n_levels) {
+        TextSeg &S = text[(long long)Tx.mnId];
+        bool ok = S.n_feat.size() == (size_t)n_levels;
+        for (int l = 0; ok && l < n_levels; l++) ok = S.n_feat[(size_t)l] == ((size_t)l < Tx.vRefFeature.size() ? Tx.vRefFeature[(size_t)l].size() : 0);
+        S.used = tick;
+        if (ok) { hits++; return S; }
+        misses++;
+        S.n_feat.assign((size_t)n_levels, 0); S.raw.assign((size_t)n_levels, std::vector<int32_t>()); S.uv.assign((size_t)n_levels, std::vector<double>()); S.ref = S.uv;
+        for (int l = 0; l < n_levels; l++) {
+            if ((size_t)l >= Tx.vRefFeature.size()) continue;
+            const auto &feats = Tx.vRefFeature[(size_t)l];
+            S.n_feat[(size_t)l] = feats.size();
+            for (size_t f = 0; f < feats.size(); f++) {
+                S.raw[(size_t)l].push_back((int32_t)feats[f]->IdxToRaw);
+                S.uv[(size_t)l].push_back(feats[f]->u); S.uv[(size_t)l].push_back(feats[f]->v);
+                for (int k = 0; k < TSBA_NTAP; k++) S.ref[(size_t)l].push_back(feats[f]->neighbourNInten[k]);
+            }
+        }
+        return S;
+    }
+};
+
 // ---- small pieces shared by every problem type -----------------------------------------------------------------------------
 template <class T, class PoseHolder>
 inline void push_pose(const PoseHolder &kf, std::vector<double> &pose) {                // optimizer.cc:84-90, :264-271
@@ -90,10 +157,15 @@ inline void push_zero12(std::vector<double> &out) { out.insert(out.end(), 12, 0.
 // normalised host intensities (neighbourNInten).  The 8 tap rays are not shipped: the library rebuilds them from the centre with the
 // reference's own expression (tool.cc:1550-1566) -- 16 B instead of 192 B per feature.
 template <class MapTextT>
-inline void push_text_features(const std::vector<MapTextT *> &texts, int level, Packed &P) {
+inline void push_text_features(const std::vector<MapTextT *> &texts, int level, Packed &P, GatherCache *cache = nullptr, int n_levels = 0) {
     P.tfeat_off[level].assign(1, 0);
     for (size_t j = 0; j < texts.size(); j++) {
-        if ((size_t)level < texts[j]->vRefFeature.size()) {
+        if (cache) {                                                 // the plane's features of this level as three block copies
+            const GatherCache::TextSeg &S = cache->features(*texts[j], n_levels);
+            P.tfeat_raw[level].insert(P.tfeat_raw[level].end(), S.raw[(size_t)level].begin(), S.raw[(size_t)level].end());
+            P.tfeat_uv[level].insert(P.tfeat_uv[level].end(), S.uv[(size_t)level].begin(), S.uv[(size_t)level].end());
+            P.tfeat_ref[level].insert(P.tfeat_ref[level].end(), S.ref[(size_t)level].begin(), S.ref[(size_t)level].end());
+        } else if ((size_t)level < texts[j]->vRefFeature.size()) {
             const auto &feats = texts[j]->vRefFeature[level];
             for (size_t f = 0; f < feats.size(); f++) {
                 P.tfeat_raw[level].push_back((int32_t)feats[f]->IdxToRaw);
@@ -116,7 +188,8 @@ template <class T>
 inline void pack_map(typename T::Map *mpMap, const std::vector<typename T::KeyFrame *> &vKFs,
                      const std::vector<typename T::MapPt *> &vMapPts, const std::vector<typename T::MapText *> &vMapTexts,
                      int mode, int n_levels, const double K[4], bool with_text, Packed &P,
-                     std::vector<int> *mnId2Pts_out = nullptr, std::vector<int> *mnId2Texts_out = nullptr) {
+                     std::vector<int> *mnId2Pts_out = nullptr, std::vector<int> *mnId2Texts_out = nullptr, GatherCache *cache = nullptr) {
+    if (cache) cache->begin_call();
     std::vector<int> mnId2Pts((size_t)mpMap->imapPts, -1), mnId2Texts((size_t)mpMap->imapText, -1), mnId2KFs((size_t)mpMap->imapkfs, -1);
     for (size_t k = 0; k < vKFs.size(); k++) mnId2KFs[(size_t)vKFs[k]->mnId] = (int)k;                                 // :229-233
     {   // one allocation per array instead of a doubling chain (this runs once per keyframe, on the caller's thread)
@@ -169,6 +242,18 @@ inline void pack_map(typename T::Map *mpMap, const std::vector<typename T::KeyFr
     for (int l = 0; l < n_levels; l++)
         for (size_t k = 0; k < vKFs.size(); k++) {
             if ((size_t)l >= vKFs[k]->vSceneObv2d.size()) continue;
+            if (cache) {                                               // the keyframe's cached segment: one lookup and four stores per observation
+                const GatherCache::KfSeg &S = cache->scene(*vKFs[k], n_levels);
+                const std::vector<int32_t> &raws = S.raw[(size_t)l], &ids = S.ptid[(size_t)l]; const std::vector<double> &uv = S.uv0[(size_t)l];
+                const int32_t f0 = P.kf_flag_off[k];
+                for (size_t s = 0; s < raws.size(); s++) {
+                    const int j = mnId2Pts[(size_t)ids[s]];
+                    if (j < 0) continue;
+                    P.sobs_kf[l].push_back((int32_t)k); P.sobs_pt[l].push_back(j); P.sobs_flag[l].push_back(f0 + raws[s]);
+                    P.sobs_uv0[l].push_back(uv[2*s]); P.sobs_uv0[l].push_back(uv[2*s + 1]);
+                }
+                continue;
+            }
             const auto &obs = vKFs[k]->vSceneObv2d[l];
             for (size_t s = 0; s < obs.size(); s++) {
                 const int raw = obs[s]->IdxToRaw;
@@ -181,7 +266,7 @@ inline void pack_map(typename T::Map *mpMap, const std::vector<typename T::KeyFr
         }
     int iw[TSBA_MAX_LEVELS] = {0, 0, 0, 0}, ih[TSBA_MAX_LEVELS] = {0, 0, 0, 0};
     if (with_text) {
-        for (int l = 0; l < n_levels; l++) push_text_features(vMapTexts, l, P);
+        for (int l = 0; l < n_levels; l++) push_text_features(vMapTexts, l, P, cache, n_levels);
         // text observations, keyframe-major over GetStateTextObvs(TEXTGOOD) (:1462-1475): good flag of the observation and one flag
         // per LEVEL-0 feature of the plane (vObvGoodTextFeats[raw], indexed by IdxToRaw)
         P.tobs_fgood_off.assign(1, 0);

@@ -34,7 +34,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6      # dense fp64 matrix rate (= the fp64 vector rat
 def _pmc_traffic(name):
     """HBM bytes per launch of a kernel from the PMC passes committed under profiles/ (counters cannot be read from inside the
     process): 2 x FETCH_SIZE (gfx950 correction of the micro-architecture guide) + WRITE_SIZE."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, name))) as f:
                 pm = json.load(f)
@@ -185,7 +185,7 @@ def _evals_8d(rep):
     return float(sum(it*(2*ns + 8*nt) for it, ns, nt in zip(rep["iters"], rep["n_sblock"], rep["n_tblock"])))
 
 
-def also_lines(gpu, local_rank, torch, steps=3):
+def also_lines(gpu, local_rank, torch, steps=10):
     """The other BASELINE configs on this GPU, without their CPU legs (a few hundred ms of GPU time each; the synthetic maps take longer to
     build than to solve): C3 pose-only, C5 global BA 500 KF x 50 k points, C6 global BA 5000 KF / ~500 k observations as an open chain, with
     SURVEY 8d's 1 % long-range observations, right after a loop closure (ring) and with two separate closures, and the ORB batch of 64 frames."""
@@ -196,11 +196,12 @@ def also_lines(gpu, local_rank, torch, steps=3):
     def run(name, prob, opt, extra=None, call=None):
         t0 = time.perf_counter(); gpu.upload(prob, opt); up = (time.perf_counter() - t0)*1e3
         rep = gpu.solve(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        ts = []                                            # every solve timed on its own (tsba_solve returns after its last kernel): median, min and max of `steps`
         for _ in range(steps):
-            rep = gpu.solve()
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0)/steps
-        e = {"ms_per_solve": dt*1e3, "residuals_per_s": float(rep["n_resid_evals"])/dt, "residuals_per_s_8d": _evals_8d(rep)/dt, "lm_iterations": rep["iters"],
+            t0 = time.perf_counter(); rep = gpu.solve(); ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize(); dt = float(np.median(ts))
+        e = {"ms_per_solve": dt*1e3, "ms_per_solve_min": min(ts)*1e3, "ms_per_solve_max": max(ts)*1e3, "timed_solves": steps, "poll_timeouts": rep["poll_timeouts"],
+             "residuals_per_s": float(rep["n_resid_evals"])/dt, "residuals_per_s_8d": _evals_8d(rep)/dt, "lm_iterations": rep["iters"],
              "accepted": rep["accepted"], "scene_blocks": rep["n_sblock"][-1], "text_blocks": rep["n_tblock"][-1], "upload_plan_ms": up, "cost": [rep["cost0"][0], rep["cost1"][-1]],
              "solver_path": SOLVER_PATHS.get(rep["solver_path"], rep["solver_path"])}
         if extra:
@@ -215,9 +216,10 @@ def also_lines(gpu, local_rank, torch, steps=3):
     def glob_extra(rep):
         info = gpu.solver_info()
         lin_ms, algo = gpu.time_linearize(0, 30)
+        traffic, src = _pmc_traffic("c6_linearize") if gpu._resident.n_kf == 5000 else (None, None)      # (the PMC pass was taken on the 5000-keyframe chain)
         e = {"band_rows": info["band_rows"], "interiors": info["interiors"], "ring_partition": info["ring"], "keyframes_reordered": info["kf_reordered"],
              "roofline": {"bound": "hbm", "kernel": "k_linearize (level 0)", "achieved": algo/(lin_ms*1e-3)/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": algo/(lin_ms*1e-3)/1e9/HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo, "avg_launch_us": lin_ms*1e3}}
+                          "frac": algo/(lin_ms*1e-3)/1e9/HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": algo, "avg_launch_us": lin_ms*1e3}}
         if info["far_band_blocks"]:
             e.update({"long_range_blocks": info["far_blocks"], "preconditioner_band_blocks": info["far_band_blocks"], "pcg_iterations": rep["pcg_iterations"],
                       "pcg_systems": rep["pcg_systems"], "pcg_max_iterations": rep["pcg_max_iterations"], "pcg_unconverged": rep["pcg_unconverged"],

@@ -169,7 +169,10 @@ typedef struct tsba_report {
     int32_t pcg_max_iterations;            /* most iterations one system took */
     int32_t pcg_unconverged;               /* systems that hit the iteration cap: their LM trial was rejected as an invalid step */
     int32_t pcg_stagnated;                 /* systems that ended at the attainable accuracy (rounding noise of M^-1 r) short of the tolerance */
-    int32_t reserved_[3];
+    int32_t poll_timeouts;                 /* threads of kernels whose workgroups hand results over inside one launch (k_solve_back, the separator tree of the solve
+                                            * phase) that gave up waiting: each fails the linear solve of its LM trial (the trial is rejected as an invalid step, as
+                                            * LINEAR_SOLVER_FAILURE in Ceres) -- 0 unless the device was kept from running the launch's workgroups for tens of ms */
+    int32_t reserved_[2];
 } tsba_report;
 #define TSBA_SOLVER_LDS          0   /* window of <= 31 keyframes: blocked LDL^T in one workgroup's LDS */
 #define TSBA_SOLVER_DENSE        1   /* multi-workgroup blocked Cholesky on the dense / wide-band matrix */
@@ -198,6 +201,11 @@ void tsba_default_options_landmarker(tsba_options *o);
 void tsba_default_options_theta     (tsba_options *o);
 
 /* ---- context ---- */
+/* The layout of tsba_problem / tsba_options / tsba_report this header describes.  A caller built against another header must not hand its structs to the
+ * library: compare tsba_abi_version() with TSBA_ABI_VERSION once at start-up (adapter/tsba_gather.hpp does).  Bumped whenever a struct changes size or a
+ * field changes meaning (round 5: 5 -- tsba_report.poll_timeouts took one of the reserved words, the size is unchanged). */
+#define TSBA_ABI_VERSION 5
+int  tsba_abi_version(void);
 int  tsba_create (void **ctx, int device);   /* TSBA_ERR_DEVICE if no gfx950 device is usable */
 int  tsba_destroy(void *ctx);
 const char *tsba_last_error(void *ctx);

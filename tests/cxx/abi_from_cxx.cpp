@@ -204,13 +204,15 @@ int main(int argc, char **argv) {
         if (r0) return 1;
         const bool wt = CNT(d, "tobs_kf") > 0;
         std::vector<double> tg, ts, tc, tt; int its[TSBA_MAX_LEVELS] = {0}; double sol = 0, upl = 0, dwn = 0;
+        tsba_adapter::GatherCache cache;                                      // as the adapter's: what the 19 keyframes that stay contributed to the last call
+        const bool use_cache = !(argc > 5 && std::string(argv[5]) == "nocache");
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         for (int rep_i = 0; rep_i < reps + 1; rep_i++) {                    // (the first call of a fresh context allocates: not counted)
             Graph G; build_graph(d, "local", G);
             G.kfs.back()->mnId = 100000 + (long unsigned)rep_i; G.M.imapkfs = 100000 + reps + 8;     // the window's newest keyframe is new to the context in every call: its planes cross the bus, the other 19 keyframes' do not
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<mapPts *> vP = G.M.GetAllMapPoints(); std::vector<mapText *> vT = G.M.GetAllMapTexts(TEXTGOOD);
-            Packed P; tsba_adapter::pack_map<Traits>(&G.M, G.kfs, vP, vT, 0, G.n_levels, G.K, wt, P);
+            Packed P; tsba_adapter::pack_map<Traits>(&G.M, G.kfs, vP, vT, 0, G.n_levels, G.K, wt, P, nullptr, nullptr, use_cache ? &cache : nullptr);
             const auto t1 = std::chrono::steady_clock::now();
             tsba_options o; tsba_report rp; tsba_default_options_local(&o); o.state = I32(d, "state") ? I32(d, "state")[0] : TSBA_STATE_LOCAL;
             const int rc = tsba_local_ba(cx, &P.p, &o, &rp);
@@ -226,10 +228,57 @@ int main(int argc, char **argv) {
         auto mn = [](std::vector<double> &v) { double m = v[0]; for (double x : v) m = x < m ? x : m; return m; };
         FILE *f = fopen(argv[3], "w"); if (!f) return 2;
         fprintf(f, "{\"local_ba_adapter_call_ms\": %.4f, \"gather_ms\": %.4f, \"tsba_local_ba_ms\": %.4f, \"scatter_ms\": %.4f, \"of_which_upload_plan_ms\": %.4f, \"solve_ms\": %.4f, \"download_ms\": %.4f, "
-                   "\"reps\": %d, \"lm_iterations\": [%d, %d, %d], \"keyframes\": %zu, \"map_points\": %zu, \"text_planes\": %zu}\n",
-                mn(tt), mn(tg), mn(tc), mn(ts), upl, sol, dwn, reps, its[0], its[1], its[2], CNT(d, "pose")/7, CNT(d, "rho"), CNT(d, "theta")/3);
+                   "\"reps\": %d, \"lm_iterations\": [%d, %d, %d], \"keyframes\": %zu, \"map_points\": %zu, \"text_planes\": %zu, \"gather_cache\": %s, \"gather_cache_hits\": %lld, \"gather_cache_misses\": %lld}\n",
+                mn(tt), mn(tg), mn(tc), mn(ts), upl, sol, dwn, reps, its[0], its[1], its[2], CNT(d, "pose")/7, CNT(d, "rho"), CNT(d, "theta")/3, use_cache ? "true" : "false", cache.hits, cache.misses);
         fclose(f); tsba_destroy(cx);
         printf("adapter call: %.3f ms (gather %.3f, tsba_local_ba %.3f, scatter %.3f)\n", mn(tt), mn(tg), mn(tc), mn(ts));
+        return 0;
+    }
+    if (mode == "slide_check") {
+        // A window that slides: sub-windows of W keyframes of the dump's map, moved on by one keyframe per call (tracking.cc:826-842), gathered (a) from
+        // scratch and (b) with ONE GatherCache kept over the calls -- every flat array of (b) has to equal (a)'s, element for element; then the same after
+        // the graph changed in the ways the reference allows between two calls: a keyframe gained an observation (keyframe::AddSceneObserv, the lists grow),
+        // flags flipped, parameters moved, a plane left the TEXTGOOD set.  CPU only.
+        Graph G; build_graph(d, "local", G);
+        const bool wt = CNT(d, "tobs_kf") > 0;
+        const size_t nk = G.kfs.size(), Wn = nk > 6 ? nk - 5 : nk;
+        tsba_adapter::GatherCache cache; int calls = 0;
+        auto same = [&](const Packed &A, const Packed &B) {
+            bool ok = A.pose == B.pose && A.rho == B.rho && A.theta == B.theta && A.pt_ray == B.pt_ray && A.pt_Trw == B.pt_Trw && A.text_Twr == B.text_Twr && A.text_box == B.text_box
+                && A.pt_host == B.pt_host && A.text_host == B.text_host && A.tobs_kf == B.tobs_kf && A.tobs_text == B.tobs_text && A.tobs_fgood_off == B.tobs_fgood_off
+                && A.kf_initial == B.kf_initial && A.sgood == B.sgood && A.tobs_good == B.tobs_good && A.tfgood == B.tfgood && A.kf_id == B.kf_id && A.kf_flag_off == B.kf_flag_off && A.tobs_raw == B.tobs_raw;
+            for (int l = 0; l < TSBA_MAX_LEVELS; l++) ok = ok && A.sobs_uv0[l] == B.sobs_uv0[l] && A.tfeat_uv[l] == B.tfeat_uv[l] && A.tfeat_ref[l] == B.tfeat_ref[l] && A.sobs_kf[l] == B.sobs_kf[l]
+                && A.sobs_pt[l] == B.sobs_pt[l] && A.sobs_flag[l] == B.sobs_flag[l] && A.tfeat_off[l] == B.tfeat_off[l] && A.tfeat_raw[l] == B.tfeat_raw[l] && A.img[l] == B.img[l];
+            return ok && A.p.n_kf == B.p.n_kf && A.p.n_pt == B.p.n_pt && A.p.n_text == B.p.n_text && A.p.n_tobs == B.p.n_tobs && A.p.n_sgood == B.p.n_sgood;
+        };
+        auto check = [&](size_t w0, const char *what) {
+            std::vector<keyframe *> win(G.kfs.begin() + (long)w0, G.kfs.begin() + (long)(w0 + Wn));
+            std::vector<mapPts *> vP = G.M.GetAllMapPoints(); std::vector<mapText *> vT = G.M.GetAllMapTexts(TEXTGOOD);
+            Packed A, B;
+            tsba_adapter::pack_map<Traits>(&G.M, win, vP, vT, 0, G.n_levels, G.K, wt, A);
+            tsba_adapter::pack_map<Traits>(&G.M, win, vP, vT, 0, G.n_levels, G.K, wt, B, nullptr, nullptr, &cache);
+            calls++;
+            if (!same(A, B)) { fprintf(stderr, "slide_check: cached gather differs from a fresh one (%s, window at %zu)\n", what, w0); return false; }
+            return true;
+        };
+        for (size_t w0 = 0; w0 + Wn <= nk; w0++) if (!check(w0, "slide")) return 1;
+        const long long hits_slide = cache.hits, miss_slide = cache.misses;
+        // the graph moves on between calls
+        keyframe *kf = G.kfs[nk - 2];
+        if (!G.pts.empty()) {                                                   // keyframe::AddSceneObserv (keyframe.cc:96-114): one more entry of vObvPts / vObvGoodPts and one feature per pyramid level
+            kf->vObvPts.push_back(new SceneObservation{G.pts[0], 0}); kf->vObvGoodPts.push_back(true);
+            const int raw = (int)kf->vObvPts.size() - 1;
+            for (size_t l = 0; l < kf->vSceneObv2d.size(); l++) { const double sc = 1.0/(double)(1 << l); Vec2 f; f(0) = 101.5*sc; f(1) = 77.25*sc;
+                kf->vSceneObv2d[l].push_back(new SceneFeature{f(0), f(1), f, (int)l, raw}); } }
+        for (size_t i = 0; i < kf->vObvGoodPts.size(); i += 7) kf->vObvGoodPts[i] = !kf->vObvGoodPts[i];
+        for (size_t j = 0; j < G.pts.size(); j += 3) { double r = G.pts[j]->GetInverD()*1.01; G.pts[j]->SetRho(r); }
+        if (G.texts.size() > 1) G.texts[1]->STATE = TEXTIMMATURE;
+        if (!check(nk - Wn, "after the graph changed")) return 1;
+        if (!check(nk - Wn, "the same window again")) return 1;
+        cache.invalidate();
+        if (!check(nk - Wn, "after invalidate()")) return 1;
+        printf("slide_check: %d gathers identical with and without the cache; while sliding %lld segments reused, %lld built\n", calls, hits_slide, miss_slide);
+        if (!(hits_slide > miss_slide)) { fprintf(stderr, "slide_check: the cache was not used\n"); return 1; }
         return 0;
     }
     Graph G; build_graph(d, mode, G);

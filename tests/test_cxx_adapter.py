@@ -89,6 +89,21 @@ def test_gather_reproduces_flat_problem(tmp_path, name):
     assert "gather identical" in r.stdout
 
 
+@pytest.mark.parametrize("case", ["small", "c4"])
+def test_sliding_window_gather_with_the_segment_cache_equals_a_fresh_gather(tmp_path, case):
+    """optimizer::LocalBundleAdjustment runs on a window that slid by one keyframe (tracking.cc:826-842).  The adapter keeps what every keyframe / text
+    plane contributed to the last call (adapter/tsba_gather.hpp: GatherCache -- topology only; parameters and flags are read every call): over a six-window
+    slide, after a keyframe gained an observation (keyframe::AddSceneObserv), after flags / parameters / a plane's state changed, and after invalidate(),
+    EVERY flat array of the cached gather equals the fresh gather's element for element (so the plan the library builds from them is the same plan)."""
+    _build()
+    P = synth.config_c4() if case == "c4" else synth.make_problem(n_kf=9, n_pt=400, n_text=8, seed=77, feats=(16, 8, 6))
+    dump = tmp_path / "p.bin"
+    _write_dump(str(dump), P)
+    r = subprocess.run([EXE, str(dump), "slide_check", str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "gathers identical with and without the cache" in r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["local", "global", "landmarker", "pose", "init", "theta"])
 def test_cxx_solve_and_scatter_matches_python_mirror(tmp_path, name):

@@ -37,7 +37,10 @@ PREFIX_ITS = 12          # LM trials compared (the trajectories of two exact imp
 # floors for (K at 1e-9, K at 1e-6, trials with the same decision), set below the measured values: C5 12 / 12 / 12, ring 11 / 11 / 11 and two
 # closures 10 / 10 / 10 (the whole run, costs to 1e-13: closed loops pin the drift modes), open chain 1 / 5 / 12 (its free end makes S ill-conditioned:
 # two backward-stable solvers differ by cond x eps in the step), long-range points 0 / 3 / 12 with the product's 1e-10 conjugate-gradient tolerance
-K_FLOOR = {"c5_text": (10, 12, 12), "c6_open_chain": (1, 3, 8), "c6_long_range": (0, 2, 8), "c6_ring": (9, 10, 10), "c6_closures2": (8, 9, 9)}
+# Round 5: every floor is (measured in rounds 4 and 5) - 1, so that a regression of two trials fails; the 1e-9 floor of the open chain stays at its
+# measured 1 (the first trial has agreed to 6e-11 on every box so far) and that of the long-range map at 0 -- there the first step is checked directly
+# instead (its residual in the oracle's system <= 1e-9, no unconverged solve, first trial <= 1e-8; with the iteration run to 1e-13: <= 1e-9).
+K_FLOOR = {"c5_text": (11, 11, 11), "c6_open_chain": (1, 4, 11), "c6_long_range": (0, 2, 11), "c6_ring": (10, 10, 10), "c6_closures2": (9, 9, 9)}
 
 
 @pytest.fixture(scope="module")
@@ -199,6 +202,9 @@ def test_first_linearisation_and_lm_prefix_against_the_oracle(gpu, oracle_lib, m
             accepted_gpu=rep_g["accepted"][0], accepted_oracle=rep_o["accepted"][0])
     f9, f6, fd = K_FLOOR[name]
     assert K9 >= f9 and K6 >= f6 and Kdec >= fd, (K9, K6, Kdec, rel)
+    assert rep_g["poll_timeouts"] == 0 and rep_g["pcg_unconverged"] == 0, rep_g
+    if name == "c6_long_range":
+        assert rres <= 1e-9, rres                                 # the first step solves the ORACLE's system (measured 2e-12)
     assert tr_g[0][3] == tr_o[0][3] and abs(tr_g[0][0] - tr_o[0][0]) <= (1e-8 if name == "c6_long_range" else 1e-9)*tr_o[0][0]     # the first trial: cost at x0 + dx (measured: 6e-11 on the open chain, <= 1e-12 elsewhere, 5e-9 with the 1e-10 iterative solve)
     if name == "c6_long_range":
         # the prefix is limited by the inexact linear solve, not by the assembly: with the conjugate gradients run to 1e-13 the first trial agrees
@@ -240,3 +246,83 @@ def test_sharded_lm_prefix_at_5000_keyframes(gpu, map_cache, name, world):
     assert abs(outs[0][0]["cost0"][0] - rep1["cost0"][0]) <= 1e-12*rep1["cost0"][0]
     assert tr[0][3] == tr1[0][3] and abs(tr[0][0] - tr1[0][0]) <= 1e-9*tr1[0][0]
     assert K9 >= 1 and K6 >= 2, (K9, K6)             # measured: 1-2 / 3-7 (the sharded sums differ from the unsharded ones in the last bits)
+
+
+CONVERGED_ITS = 600
+
+
+def _gauge_aligned_pose_gap(Pa, Pb):
+    """Largest camera-centre distance between two solutions of one map after the best rigid + scale alignment of the centres (a global BA without
+    fixed scale leaves a similarity free along nearly flat directions; the first keyframe is held, the rest can drift together)."""
+    def centres(pose):
+        q, t = pose[:, :4]/np.linalg.norm(pose[:, :4], axis=1, keepdims=True), pose[:, 4:]
+        w, x, y, z = q.T
+        R = np.stack([1 - 2*(y*y + z*z), 2*(x*y - w*z), 2*(x*z + w*y), 2*(x*y + w*z), 1 - 2*(x*x + z*z), 2*(y*z - w*x),
+                      2*(x*z - w*y), 2*(y*z + w*x), 1 - 2*(x*x + y*y)], axis=1).reshape(-1, 3, 3)
+        return -np.einsum("nji,nj->ni", R, t)                       # c = -R^T t  (T_cw)
+    A, B = centres(Pa), centres(Pb)
+    ma, mb = A.mean(0), B.mean(0)
+    H = (A - ma).T @ (B - mb)
+    U, S, Vt = np.linalg.svd(H)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    Rm = Vt.T @ D @ U.T
+    sc = np.trace(np.diag(S) @ D)/((A - ma)**2).sum()
+    Aal = sc*(A - ma) @ Rm.T + mb
+    extent = np.linalg.norm(B - mb, axis=1).max()
+    return float(np.linalg.norm(Aal - B, axis=1).max()/extent), float(np.linalg.norm(A - B, axis=1).max()/extent)
+
+
+@pytest.mark.parametrize("name", ["c6_open_chain", "c6_long_range"])
+def test_converged_answers_against_the_oracle(gpu, oracle_lib, map_cache, name):
+    """SURVEY 8d's tolerance is stated on CONVERGED answers, and the reference runs one deterministic solve to Ceres' exit (optimizer.cc:1833-1846).  The
+    12-trial prefix above cannot say whether GPU and oracle arrive at the same answer on the two maps where their trajectories part (cond x eps, DESIGN 7 /
+    13.1): here both run until the function tolerance ends them (oracle: 231 / 129 iterations, tests/golden/make_converged.py; end states committed).
+
+      (a) AT the oracle's converged answer the two implementations agree on everything the next iteration is made of: cost (1e-11), reduced gradient and
+          every 6x6 block of S (1e-9), and the GPU's pose step solves the oracle's system -- the full first-linearisation comparison, at the END state;
+      (b) both runs from the common start end by the same criterion; the final costs are compared, recorded, and asserted against the sharpness of that
+          criterion on this map.  A function-tolerance exit is taken where ONE step improves the cost by less than 1e-6: that is not a distance to a minimum.
+          The oracle itself, started again at its own answer, runs on for dozens of iterations and lowers the cost by `again` (4.5e-4 on the open chain,
+          fixture) before the tolerance ends it a second time: the reference's own exit defines the converged cost of these maps to no better than that.
+          The GPU's converged cost has to lie within 3 x that of the oracle's; the camera centres' gap after similarity alignment is recorded next to it;
+      (c) the GPU started at the oracle's answer against the oracle started there (same state, same initial trust region): the LM prefix again."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", f"converged_{name}.npz"))
+    assert int(fx["term"]) == 1 and int(fx["again_term"]) == 1
+    again = (float(fx["cost1"]) - float(fx["again_cost1"]))/float(fx["cost1"])
+    P = map_cache(**CONFIGS[name]); o = _options(name); o.its[0] = CONVERGED_ITS
+    # (b) from the common start
+    gpu.upload(P, o); rep_g = gpu.solve(); G = gpu.download(P.copy())
+    assert rep_g["poll_timeouts"] == 0 and rep_g["pcg_unconverged"] == 0, rep_g
+    assert abs(rep_g["cost0"][0] - float(fx["cost0"])) <= 1e-11*float(fx["cost0"])
+    assert rep_g["termination"][0] == 1, rep_g                       # the function tolerance, as the oracle
+    rel_cost = abs(rep_g["cost1"][0] - float(fx["cost1"]))/float(fx["cost1"])
+    gap_al, gap_raw = _gauge_aligned_pose_gap(G.pose, fx["pose"])
+    # (a) at the oracle's end state
+    Q = P.copy(); Q.pose[:] = fx["pose"]; Q.rho[:] = fx["rho"]
+    o1 = _options(name)
+    gpu.upload(Q, o1)
+    ob, worst, rres = compare_first_linearisation(gpu, oracle_lib, Q, o1, direct=name != "c6_long_range")
+    assert abs(ob["cost"] - float(fx["cost1"])) <= 1e-12*float(fx["cost1"])
+    # (c) both started again there
+    o2 = _options(name); o2.its[0] = 200
+    gpu.upload(Q, o2); rep_a = gpu.solve(); tr_a = gpu.lm_trace(0)
+    tr_o = fx["again_trace"]
+    K9, K6 = prefix_length(tr_a, tr_o, 1e-9), prefix_length(tr_a, tr_o, 1e-6)
+    Kdec = 0
+    for a, b in zip(tr_a, tr_o):
+        if a[3] != b[3]:
+            break
+        Kdec += 1
+    moved = (rep_a["cost0"][0] - rep_a["cost1"][0])/rep_a["cost0"][0]
+    print(f"\n{name}: converged GPU {rep_g['cost1'][0]:.9g} in {rep_g['iters'][0]} iterations / oracle {float(fx['cost1']):.9g} in {int(fx['iters'])}: rel {rel_cost:.2e} "
+          f"(the oracle started again at its answer: {int(fx['again_iters'])} iterations, cost lower by {again:.2e}); camera centres {gap_al:.2e} of the map's extent after "
+          f"similarity alignment ({gap_raw:.2e} before); at the oracle's answer: S blocks {worst:.1e}, step residual {rres:.1e}; started again there: GPU {rep_a['iters'][0]} "
+          f"iterations, cost lower by {moved:.2e}, prefix K(1e-9) = {K9}, K(1e-6) = {K6}, decisions {Kdec} of {min(len(tr_a), len(tr_o))}")
+    _record(name, converged=dict(cost1_gpu=rep_g["cost1"][0], cost1_oracle=float(fx["cost1"]), rel_cost=rel_cost, iters_gpu=rep_g["iters"][0], iters_oracle=int(fx["iters"]),
+                                 accepted_gpu=rep_g["accepted"][0], accepted_oracle=int(fx["accepted"]), oracle_again_rel=again, oracle_again_iters=int(fx["again_iters"]),
+                                 centre_gap_aligned=gap_al, centre_gap_raw=gap_raw,
+                                 at_oracle_answer=dict(worst_block_rel=worst, first_step_residual=rres, gpu_again_iters=rep_a["iters"][0], gpu_again_rel=moved,
+                                                       K_1e9=K9, K_1e6=K6, K_decisions=Kdec, trials=int(min(len(tr_a), len(tr_o))))))
+    assert rep_a["termination"][0] == 1 and rep_a["poll_timeouts"] == 0
+    assert tr_a[0][3] == tr_o[0][3] and Kdec >= 3, (Kdec, tr_a[:4], tr_o[:4])
+    assert rel_cost <= 3.0*again, (rel_cost, again)

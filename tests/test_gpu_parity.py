@@ -380,7 +380,7 @@ def test_small_window_solver_schedules_agree(gpu, n_kf):
     o = abi.options_local()
     runs = []
     try:
-        for var in (0, 1, 2, 3):
+        for var in (0, 1, 2, 3, 4):
             gpu.debug_set(solve_variant=var)
             gpu.upload(P, o)
             rs = gpu.reduced_system(o.initial_radius)
@@ -399,3 +399,62 @@ def test_small_window_solver_schedules_agree(gpu, n_kf):
     # back-substitution blocks poll the pose step): the same arithmetic in the same order, the same bits
     assert np.array_equal(runs[3][2].pose, ref[2].pose) and np.array_equal(runs[3][2].rho, ref[2].rho) and np.array_equal(runs[3][2].theta, ref[2].theta)
     assert runs[3][1]["cost1"] == ref[1]["cost1"]
+    # variant 4 = variant 3 with the 6x6 diagonal blocks factored from an LDS scratch copy in every lane (production until round 5) instead of in
+    # place across lanes 0..5 with v_readlane broadcasts: the same operations on the same operands
+    assert np.array_equal(runs[4][0], runs[3][0])
+    assert np.array_equal(runs[4][2].pose, ref[2].pose) and np.array_equal(runs[4][2].rho, ref[2].rho) and np.array_equal(runs[4][2].theta, ref[2].theta)
+    assert runs[4][1]["cost1"] == ref[1]["cost1"]
+
+
+def _full_state(gpu, rep, G):
+    return (rep["iters"], rep["accepted"], rep["termination"], rep["cost0"], rep["cost1"], rep["n_sblock"], rep["n_tblock"],
+            rep["n_bad_scene"], rep["n_bad_tfeat"], rep["n_bad_text"])
+
+
+@pytest.mark.parametrize("case", ["tiny", "c4", "c4_oneshot", "init", "landmarker", "no_text", "no_outlier"])
+def test_pass_boundaries_in_one_launch_agree(gpu, case):
+    """A window's pass begins with k_pass_begin (participation + gauge + LM state reset + mu / sigma) and ends with k_pass_end (outlier pass + the next
+    level's mu / sigma + clearing), its final state reaches the report through k_solve_end (tsba_kernels_pass.h); tsba_debug_options.pass_launches = 1
+    keeps the launches of rounds 1-4 (k_pass_reset, k_participation, k_gauge_wave, k_musigma | k_outlier, state copies).  Same arithmetic: the
+    reports (every per-pass field), the parameters, the flags and the LM traces are bit-identical -- resident solves, solves repeated on one upload
+    and one-shot calls (levels staged while the first pass runs) alike."""
+    oneshot = None
+    if case == "tiny":
+        P, o = synth.tiny(), abi.options_local()
+    elif case in ("c4", "c4_oneshot"):
+        P, o = synth.config_c4(), abi.options_local()
+        if case == "c4_oneshot":
+            oneshot = lambda Q: gpu.LocalBundleAdjustment(Q, options=o)
+    elif case == "init":
+        P, o = synth.init_pair(), abi.options_init()
+    elif case == "landmarker":
+        P, o = synth.landmark_refine(), abi.options_landmarker()
+    elif case == "no_text":
+        P, o = synth.make_problem(n_kf=9, n_pt=700, n_text=0, seed=91, feats=(16, 8, 6)), abi.options_local()
+    else:
+        P, o = synth.make_problem(n_kf=12, n_pt=900, n_text=6, seed=92, feats=(16, 8, 6)), abi.options_local()
+        o.outlier_scene = o.outlier_text = 0
+    runs = []
+    try:
+        for old in (0, 1, 0):
+            gpu.debug_set(pass_launches=old)
+            for rep_no in range(2):                              # twice on one upload: tsba_solve restarts from the uploaded parameters
+                G = P.copy()
+                if oneshot:
+                    rep = oneshot(G)
+                else:
+                    if rep_no == 0:
+                        gpu.upload(P, o)
+                    rep = gpu.solve(); gpu.download(G)
+                traces = [gpu.lm_trace(ps) for ps in range(o.n_passes)]
+                runs.append((_full_state(gpu, rep, G), G, traces))
+    finally:
+        gpu.debug_set()
+    ref = runs[2]                                                # (the launches of rounds 1-4)
+    assert sum(ref[0][0]) > 0
+    for st, G, tr in runs:
+        assert st == ref[0], (st, ref[0])
+        assert np.array_equal(G.pose, ref[1].pose) and np.array_equal(G.rho, ref[1].rho) and np.array_equal(G.theta, ref[1].theta)
+        assert np.array_equal(G.sgood, ref[1].sgood) and np.array_equal(G.tobs_good, ref[1].tobs_good) and np.array_equal(G.tfgood, ref[1].tfgood)
+        for a, b in zip(tr, ref[2]):
+            assert np.array_equal(a, b, equal_nan=True)

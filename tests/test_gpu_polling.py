@@ -1,0 +1,130 @@
+"""The kernels whose workgroups hand results over INSIDE one launch (value polling: k_solve_back on windows, k_sv_cre_tree / k_sv_tree_back /
+k_cre_back_tree on large maps, the k_lin_mid roles) -- made safe and observable:
+
+  * they are chosen only where the whole grid is resident at once (occupancy x compute units, checked per context); a device too small for the grid
+    (tsba_debug_options.assume_cus) takes the launch-per-step path and computes the same bits;
+  * a wait that runs into its bound is counted (tsba_report.poll_timeouts) on top of failing the linear solve;
+  * a second context that keeps the device busy (an ORB extractor looping on a 16-frame batch from another host thread, as TextSLAM's tracking thread does
+    beside a local / global BA) changes nothing: identical LM traces, identical parameters, zero time-outs.
+
+The reference is deterministic (optimizer.cc:1599,1838: num_threads = 1)."""
+import threading
+import numpy as np
+import pytest
+
+from textslam_amd import synth, abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from textslam_amd.optimizer import Optimizer
+    g = Optimizer(0)
+    yield g
+    g.close()
+
+
+def _solve(gpu, P, o, n_passes):
+    gpu.upload(P, o)
+    rep = gpu.solve()
+    G = gpu.download(P.copy())
+    return rep, G, [gpu.lm_trace(ps) for ps in range(n_passes)]
+
+
+def _same(a, b):
+    ra, Ga, ta = a; rb, Gb, tb = b
+    assert ra["iters"] == rb["iters"] and ra["accepted"] == rb["accepted"] and ra["termination"] == rb["termination"]
+    assert ra["cost1"] == rb["cost1"]
+    assert np.array_equal(Ga.pose, Gb.pose) and np.array_equal(Ga.rho, Gb.rho) and np.array_equal(Ga.theta, Gb.theta)
+    for x, y in zip(ta, tb):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
+class _Busy:
+    """An ORB extractor of its own context (own stream) running batches back to back on another host thread."""
+    def __init__(self, n_frames=16):
+        from textslam_amd.orbextractor import ORBextractor, synthetic_frame
+        self.ex = ORBextractor(device=0)
+        self.ex.upload(np.stack([synthetic_frame(s) for s in range(n_frames)]))
+        self.stop = threading.Event(); self.runs = 0
+        self.th = threading.Thread(target=self._loop, daemon=True)
+
+    def _loop(self):
+        while not self.stop.is_set():
+            self.ex.run(); self.runs += 1
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set(); self.th.join(timeout=30)
+        self.ex.close()
+
+
+def test_window_solve_beside_a_busy_context(gpu):
+    P, o = synth.config_c4(), abi.options_local()
+    alone = _solve(gpu, P, o, o.n_passes)
+    assert alone[0]["poll_timeouts"] == 0 and alone[0]["solver_path"] == 0
+    with _Busy() as busy:
+        while busy.runs < 2:
+            pass
+        for _ in range(20):
+            r0 = busy.runs
+            beside = _solve(gpu, P, o, o.n_passes)
+            assert beside[0]["poll_timeouts"] == 0, beside[0]
+            _same(beside, alone)
+        assert busy.runs > r0 or busy.runs > 2                      # (the other context did run meanwhile)
+
+
+def test_long_range_map_beside_a_busy_context(gpu, map_cache):
+    P = map_cache(n_kf=5000, n_pt=70000, band=10, far_frac=0.01); o = abi.options_global(); o.its[0] = 6
+    alone = _solve(gpu, P, o, 1)
+    assert alone[0]["poll_timeouts"] == 0 and alone[0]["pcg_unconverged"] == 0 and alone[0]["pcg_iterations"] > 0
+    with _Busy() as busy:
+        while busy.runs < 2:
+            pass
+        for _ in range(3):
+            beside = _solve(gpu, P, o, 1)
+            assert beside[0]["poll_timeouts"] == 0 and beside[0]["pcg_unconverged"] == 0, beside[0]
+            _same(beside, alone)
+        assert busy.runs > 2
+
+
+def test_open_chain_beside_a_busy_context(gpu, map_cache):
+    """The direct solve of a 5000-keyframe chain: its separator back-substitution is one polling launch (k_cre_back_tree)."""
+    P = map_cache(n_kf=5000, n_pt=70000, band=10); o = abi.options_global(); o.its[0] = 6
+    alone = _solve(gpu, P, o, 1)
+    assert alone[0]["poll_timeouts"] == 0
+    with _Busy() as busy:
+        while busy.runs < 2:
+            pass
+        for _ in range(3):
+            beside = _solve(gpu, P, o, 1)
+            assert beside[0]["poll_timeouts"] == 0, beside[0]
+            _same(beside, alone)
+
+
+@pytest.mark.parametrize("case", ["window", "long_range", "open_chain"])
+def test_a_device_too_small_for_the_grid_takes_the_launch_per_step_path(gpu, map_cache, case):
+    """assume_cus = 4: no polling launch fits (30 workgroups of k_solve_back, 127 + 128 of the separator tree) -- the solves go through k_solve_t + k_back +
+    k_decide / the launch per level and give the same bits (windows) / the same LM run to the tolerance the per-level tests state (maps: the product form
+    of the separator back substitution rounds differently from the substitution, tests/test_gpu_global.py)."""
+    if case == "window":
+        P, o, npass = synth.config_c4(), abi.options_local(), 3
+    else:
+        P = map_cache(n_kf=5000, n_pt=70000, band=10, **({"far_frac": 0.01} if case == "long_range" else {})); o = abi.options_global(); o.its[0] = 4; npass = 1
+    ref = _solve(gpu, P, o, npass)
+    try:
+        gpu.debug_set(assume_cus=4)
+        small = _solve(gpu, P, o, npass)
+    finally:
+        gpu.debug_set()
+    assert small[0]["poll_timeouts"] == 0
+    if case == "window":
+        _same(small, ref)
+    else:
+        assert small[0]["iters"] == ref[0]["iters"] and small[0]["accepted"] == ref[0]["accepted"]
+        assert abs(small[0]["cost1"][0] - ref[0]["cost1"][0]) <= 1e-6*ref[0]["cost1"][0]
+        assert np.array_equal(small[2][0][:, 3], ref[2][0][:, 3])                     # the same decisions

@@ -72,7 +72,7 @@ class TsbaReport(C.Structure):
         ("t_upload_ms", C.c_double), ("t_solve_ms", C.c_double), ("t_download_ms", C.c_double),
         ("cov_valid", C.c_int32), ("solver_path", C.c_int32),
         ("pcg_iterations", C.c_int32), ("pcg_systems", C.c_int32), ("pcg_max_iterations", C.c_int32), ("pcg_unconverged", C.c_int32), ("pcg_stagnated", C.c_int32),
-        ("reserved_", C.c_int32 * 3),
+        ("poll_timeouts", C.c_int32), ("reserved_", C.c_int32 * 2),
     ]
 
     def as_dict(self):
@@ -80,7 +80,8 @@ class TsbaReport(C.Structure):
         d = {"status": self.status, "n_passes": n, "n_resid_evals": self.n_resid_evals, "cov_valid": self.cov_valid,
              "t_upload_ms": self.t_upload_ms, "t_solve_ms": self.t_solve_ms, "t_download_ms": self.t_download_ms,
              "solver_path": self.solver_path, "pcg_iterations": self.pcg_iterations, "pcg_systems": self.pcg_systems,
-             "pcg_max_iterations": self.pcg_max_iterations, "pcg_unconverged": self.pcg_unconverged, "pcg_stagnated": self.pcg_stagnated}
+             "pcg_max_iterations": self.pcg_max_iterations, "pcg_unconverged": self.pcg_unconverged, "pcg_stagnated": self.pcg_stagnated,
+             "poll_timeouts": self.poll_timeouts}
         for k in ("iters", "accepted", "termination", "cost0", "cost1", "n_sblock", "n_tblock",
                   "n_bad_scene", "n_bad_tfeat", "n_bad_text"):
             d[k] = list(getattr(self, k))[:n]
@@ -93,6 +94,7 @@ class TsbaDebugOptions(C.Structure):
         ("band_parts", C.c_int32), ("sep_solver", C.c_int32), ("no_band_stream", C.c_int32), ("no_pose_kernel", C.c_int32),
         ("no_small_pairs", C.c_int32), ("verbose", C.c_int32), ("no_kf_reorder", C.c_int32), ("no_schur_quad", C.c_int32), ("no_ring", C.c_int32),
         ("far_solver", C.c_int32), ("pcg_max_it", C.c_int32), ("pcg_tol_exp", C.c_int32), ("pcg_refactor", C.c_int32), ("pcg_block", C.c_int32), ("solve_variant", C.c_int32), ("sv_per_level", C.c_int32), ("host_pair_lists", C.c_int32),
+        ("pass_launches", C.c_int32), ("trial_launches", C.c_int32), ("assume_cus", C.c_int32),
     ]
 
 

@@ -51,6 +51,7 @@
 #include "tsba_pose.h"
 
 #include "tsba_kernels_step.h"
+#include "tsba_kernels_pass.h"
 #include "tsba_devplan.h"
 // ------------------------------------------------------------------------------------------------ host side
 static int pose_grid(const LevelDev &D) { return std::max(1, (D.n_sc + 255)/256 + (D.n_pf + 31)/32); }    // workgroups of k_pose_iter
@@ -85,7 +86,11 @@ struct Ctx {
     LmState *st_log = nullptr;                    // device [MAX passes]
     int nb_back_max = 0;
     LmState *st_base = nullptr;                   // W.st / W.st_next are st_base and st_base + 1 in the order of the moment
+    double *musig2[2] = {nullptr, nullptr}; int musig_sel = 0;      // mu / sigma of the text observations, two buffers: k_pass_end fills the next pass's while the outlier pass reads this one's
+    int *ticket = nullptr;                        // k_pass_begin: arrival counter of its participation workgroups (zero between launches)
     size_t lds_limit = 0;
+    int n_cu = 0;                                 // compute units of the device
+    std::vector<std::pair<std::pair<const void *, size_t>, int>> occ_cache;      // (kernel, dynamic LDS) -> workgroups of it one compute unit holds
     std::vector<uint8_t *> img_dev[TSBA_MAX_LEVELS];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // RCCL (global BA sharded over the GPUs of one node): one process per GPU, communicator created by tsba_comm_init
@@ -129,6 +134,18 @@ struct Ctx {
 
 static void set_err(Ctx *c, const std::string &s) { c->err = s; }
 static bool is_multi(const Ctx *c);
+// Kernels whose workgroups wait for each other inside ONE launch (value polling: k_solve_back, k_sv_cre_tree, k_sv_tree_back, k_cre_back_tree) make progress
+// only if every workgroup of the launch has a compute unit.  They are chosen only where the whole grid fits the device at once (occupancy of that kernel
+// with its dynamic LDS x compute units); otherwise the launch-per-step path that they replaced runs.  Other work on the device (a second context's
+// kernels) can only DELAY the dispatch of a workgroup -- it ends without waiting for anything here -- and a wait that outlasts the polling bound is counted
+// (ts_poll_giveups -> tsba_report.poll_timeouts) on top of failing the linear solve.
+static bool grid_resident(Ctx *c, const void *fn, int threads, size_t lds, int grid) {
+    int nb = -1;
+    for (auto &e : c->occ_cache) if (e.first.first == fn && e.first.second == lds) nb = e.second;
+    if (nb < 0) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess) nb = 0;
+        c->occ_cache.push_back({{fn, lds}, nb}); }
+    return (long long)nb*(c->dbg.assume_cus > 0 ? c->dbg.assume_cus : c->n_cu) >= grid;
+}
 
 // Device memory comes from a few large slabs (bump allocation, 256-byte aligned) that persist across uploads: the ~200 arrays
 // of a problem cost no hipMalloc / hipFree / hipMemset each (one memset per slab and upload), and host data is staged through a
@@ -250,6 +267,7 @@ int tsba_create(void **ctx, int device) {
         hipStreamDestroy(c->stream); delete c; return TSBA_ERR_DEVICE;
     }
     if (hipHostMalloc((void **)&c->hprog, 64, hipHostMallocDefault) != hipSuccess) c->hprog = nullptr; else memset(c->hprog, 0, 64);   // (optional: early-exit polling only)
+    c->n_cu = prop.multiProcessorCount;
     c->lds_limit = prop.sharedMemPerBlock;       // 64 KiB default static limit; dynamic up to 160 KiB on gfx950
     if (c->lds_limit < 160*1024) c->lds_limit = 160*1024;
     *ctx = c; return TSBA_OK;
@@ -278,6 +296,7 @@ int tsba_destroy(void *ctx) {
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
     delete c; return TSBA_OK;
 }
+int tsba_abi_version(void) { return TSBA_ABI_VERSION; }
 const char *tsba_last_error(void *ctx) { return ctx ? ((Ctx *)ctx)->err.c_str() : "null ctx"; }
 
 // Every index the plan builder and the kernels dereference is range-checked here, once, in O(problem size): a bad index from the
@@ -418,7 +437,8 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     { std::vector<double> z; const double *src = p->text_host_Twr; if (!src) { z.assign(12*(size_t)p->n_text, 0.0); src = z.data(); } UP(W.text_Twr, src, 12*(size_t)p->n_text); }
     UP(W.text_box, p->text_box_ray, 8*(size_t)p->n_text);
     UP(W.tobs_kf, p->tobs_kf, p->n_tobs); UP(W.tobs_text, p->tobs_text, p->n_tobs); UP(W.tobs_fgood_off, p->tobs_fgood_off, (size_t)p->n_tobs + 1);
-    AL(W.musig, 2*(size_t)p->n_tobs);
+    AL(c->musig2[0], 2*(size_t)p->n_tobs); AL(c->musig2[1], 2*(size_t)p->n_tobs); c->musig_sel = 0; W.musig = c->musig2[0];
+    AL(c->ticket, 4); W.poll0 = (unsigned int *)(c->ticket + 1);
     AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
     AL(W.fidx, p->n_kf); AL(W.nfree, 2); AL(W.dbg, 64); AL(W.trace, 4*(size_t)TSBA_TRACE_CAP*TSBA_MAX_LEVELS); AL(W.LDbuf, 32*((size_t)p->n_kf + BAND_BW_MAX/6 + 1));     // (+ the ghost blocks of a ring map)
     // ---- plane cache (tsba_problem.kf_id): the keyframes of this call get their slots; the planes of those not seen before are staged and copied
@@ -507,7 +527,13 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         // view: S(i,j) = base[i*(LDB-1) + j], LDB = band + 96 columns of the diagonal block's upper triangle, where the inverse
         // diagonal factors are kept) -- 80 MB instead of 7.2 GB at 5000 keyframes, and what the ranks all-reduce
         const int use_lds_ = solve_lds_doubles(W.N)*sizeof(double) <= 160*1024 - 64;        // (as solve_lds_bytes)
-        W.dp_poll = use_lds_ && !is_multi(c) && !c->pose_only && c->dbg.solve_variant == 0;        // solver and back-substitution in one launch (k_solve_back)
+        W.dp_poll = use_lds_ && !is_multi(c) && !c->pose_only && (c->dbg.solve_variant == 0 || c->dbg.solve_variant == 5);        // solver and back-substitution in one launch (k_solve_back)
+        if (W.dp_poll) {                           // ... whose workgroups poll the solver's: only where the whole grid is resident at once (else k_solve_t + k_back + k_decide)
+            const int nb_all_ = back_blocks_pt(p->n_pt) + back_blocks_tx(p->n_text) + (p->n_kf + 255)/256;
+            const int ldsb_ = std::max((int)(solve_lds_doubles(W.N)*sizeof(double)), (int)((768 + W.N + 2)*sizeof(double)));
+            CK(hipFuncSetAttribute((const void *)k_solve_back<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb_));
+            if (!grid_resident(c, (const void *)k_solve_back<true>, SOLVE_THREADS, (size_t)ldsb_, 1 + (nb_all_ + 2)/3)) W.dp_poll = 0;
+        }
         int bwmax = 0; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
         // band storage: row i holds the columns [i - Wb, i + up) (skewed view S(i, j) = base[i (LDB - 1) + j]).  The blocked Cholesky of
         // tsba_chol.h writes 96-wide blocks on both sides of the diagonal (up = CH_NB, Wb = band + CH_NB - 1); the streaming / partitioned
@@ -599,7 +625,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     AL(W.posepart, 2*((size_t)p->n_kf/21 + 2));
     AL(W.cntpart, 2*(mx_cnt/4 + mx_cnt/256 + 4));
     AL(W.st, 2); c->st_base = W.st;
-    W.st_next = (W.dp_poll && p->n_kf <= 126) ? W.st + 1 : nullptr;        // windows on one GPU: k_schur_t takes the previous trial's decision itself (the two copies of the state swap roles after that launch)
+    W.st_next = (W.dp_poll && p->n_kf <= SCHUR_KEEP_KF) ? W.st + 1 : nullptr;        // windows on one GPU: k_schur_t takes the previous trial's decision itself (the two copies of the state swap roles after that launch)
     AL(c->cov_log, 6*TSBA_MAX_LEVELS);
     flush_run(c);
     auto tu2 = std::chrono::steady_clock::now();
@@ -841,7 +867,9 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi, SchurDec dec = Sc
 static int set_solver_attrs(Ctx *c) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) { CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        CK(hipFuncSetAttribute((const void *)k_solve_back, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, (int)((768 + c->W.N + 2)*sizeof(double)))));
+        CK(hipFuncSetAttribute((const void *)k_solve_t<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipFuncSetAttribute((const void *)k_solve_back<true>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, (int)((768 + c->W.N + 2)*sizeof(double)))));
+        CK(hipFuncSetAttribute((const void *)k_solve_back<false>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, (int)((768 + c->W.N + 2)*sizeof(double)))));
         CK(hipFuncSetAttribute((const void *)k_solve_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(solve_la_lds_doubles(c->W.N)*sizeof(double), 160*1024 - 64))); }
     else {
         CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
@@ -890,6 +918,7 @@ static void launch_solve(Ctx *c) {
     if (use_lds) {                                  // small windows: one workgroup, S in LDS.  solve_variant 1: the two-panel-wave schedule of tsba_solve.h (A/B runs)
         const size_t la = solve_la_lds_doubles(W.N)*sizeof(double);
         if ((c->dbg.solve_variant == 1 || c->dbg.solve_variant == 2) && la <= 160*1024 - 64) hipLaunchKernelGGL(k_solve_la, dim3(1), dim3(SOLVE_THREADS), (int)la, c->stream, W, c->dbg.solve_variant == 2 ? 0 : 1);
+        else if (c->dbg.solve_variant == 4) hipLaunchKernelGGL((k_solve_t<false, false>), dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);      // (the diagonal blocks through the LDS scratch: A/B and bit-identity runs)
         else hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);
         return; }
     if (c->band_stream && c->band_parts > 1) {      // partitioned: interiors in parallel + separator system (tsba_bandp.h)
@@ -924,7 +953,7 @@ static void launch_solve(Ctx *c) {
                 // back substitution: a launch per level -- or one launch through the inverse factors and products of the solve phase (k_sv_linv + k_cre_back_tree)
                 // where the iterative path needs those anyway (maps with long-range blocks) or the tree is deep enough to pay for k_sv_linv (28 us at 48-row
                 // separators against 10.5 us per level)
-                if ((c->far_B > 0 || (htop >= 32 && bwp <= 60)) && ms_available(c) && !(c->dbg.sv_per_level & 2) && c->dbg.pcg_refactor != 1 && mmax >= 2 && sv_reserve(c) == TSBA_OK) {
+                if ((c->far_B > 0 || (htop >= 32 && bwp <= 60)) && ms_available(c) && !(c->dbg.sv_per_level & 2) && c->dbg.pcg_refactor != 1 && mmax >= 2 && grid_resident(c, (const void *)k_cre_back_tree, SV_CT, 0, mmax - 1) && sv_reserve(c) == TSBA_OK) {
                     launch_sv_prepare(c, Ws.Sy);
                     hipLaunchKernelGGL(k_cre_back_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, c->sv);
                 } else
@@ -1071,10 +1100,11 @@ static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rd
     for (int h = 1; h < mmax; h <<= 1) if (pivots(h) > 0) htop = h;
     // the highest level has one pivot (3 h >= 2 h >= the number of separators): its forward step, the root and its back substitution are one workgroup's work
     const bool fuse_top = htop > 0 && pivots(htop) == 1;
-    const int tree = fuse_top && !(c->dbg.sv_per_level & 1);           // the whole tree in one launch (k_sv_cre_tree)
+    const bool tb_fits = B <= 10 ? grid_resident(c, (const void *)k_sv_tree_back<1>, SV_T, ldb, P) : grid_resident(c, (const void *)k_sv_tree_back<2>, SV_T, ldb, P);
+    const int tree = fuse_top && !(c->dbg.sv_per_level & 1) && grid_resident(c, (const void *)k_sv_cre_tree, SV_CT, 0, mmax - 1);           // the whole tree in one launch (k_sv_cre_tree): its workgroups poll each other
     if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
     else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
-    const bool tree_back = tree && !(c->dbg.sv_per_level & 8);        // ... and the interiors' back substitution in the tree's launch (k_sv_tree_back)
+    const bool tree_back = tree && !(c->dbg.sv_per_level & 8) && tb_fits;        // ... and the interiors' back substitution in the tree's launch (k_sv_tree_back)
     if (tree_back) {
         if (B <= 10) hipLaunchKernelGGL(k_sv_tree_back<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, htop, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
         else hipLaunchKernelGGL(k_sv_tree_back<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, htop, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
@@ -1283,7 +1313,9 @@ static void launch_step(Ctx *c, const LevelDev &D, bool decide_prev = false) {
     }
     if (W.dp_poll && D.far_B <= 0) {               // small window: solver (workgroup 0) and back-substitution (three blocks per workgroup, polling the step) in one launch
         int use_lds; const int lds = solve_lds_bytes(c, &use_lds);
-        hipLaunchKernelGGL(k_solve_back, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), std::max(lds, (int)((768 + W.N + 2)*sizeof(double))), c->stream, W, D, bb_pt, bb_tx, nb_all);
+        const int ldsb = std::max(lds, (int)((768 + W.N + 2)*sizeof(double)));
+        if (c->dbg.solve_variant == 5) hipLaunchKernelGGL(k_solve_back<false>, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), ldsb, c->stream, W, D, bb_pt, bb_tx, nb_all);      // (A/B: the diagonal blocks through the LDS scratch)
+        else hipLaunchKernelGGL(k_solve_back<true>, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), ldsb, c->stream, W, D, bb_pt, bb_tx, nb_all);
     } else {
         launch_solve_full(c, D);
         hipLaunchKernelGGL(k_back, dim3(nb_all), dim3(256), 0, c->stream, W, D, bb_pt, bb_tx);
@@ -1304,6 +1336,11 @@ int tsba_solve(void *ctx, tsba_report *r) {
     auto t0 = std::chrono::steady_clock::now();
     int rc = reset_state(c); if (rc) return rc;
     if (c->far_B > 0) hipMemsetAsync(c->W.pc_stat, 0, 8*sizeof(int), c->stream);
+    // windows on one GPU (the same contexts that take a trial's decision inside the next trial's assembly): a pass begins and ends with one launch each
+    auto fastp = [&](const LevelDev &D) { return c->W.st_next != nullptr && c->n_kf <= 64 && D.far_B <= 0 && !is_multi(c) && !c->pose_only && !c->dbg.pass_launches && D.n_sc + D.n_tg > 0; };
+    bool fast_any = false; for (int ps = 0; ps < o.n_passes; ps++) if (c->lev_built[o.levels[ps]] ? fastp(c->lev[o.levels[ps]]) : (c->W.st_next != nullptr && c->n_kf <= 64 && !c->dbg.pass_launches)) fast_any = true;
+    bool log_pending = false;                     // the pass before this one left its final state in W.st only
+    int ms_ahead = -1;                            // the pass whose mu / sigma the previous pass's k_pass_end has computed
     for (int ps = 0; ps < o.n_passes; ps++) {
         if (!c->lev_built[o.levels[ps]]) {            // a level the upload left for now (one-shot call on a small window): its plan is ready or nearly so
             if (!c->stage_p) { set_err(c, "level not staged"); return TSBA_ERR_STATE; }
@@ -1314,7 +1351,19 @@ int tsba_solve(void *ctx, tsba_report *r) {
         if (pose_path) {                                     // k_pass_reset + k_participation + k_gauge + k_musigma in one launch
             c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
             hipLaunchKernelGGL(k_pose_begin, dim3(D.n_tg + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial);
-        } else launch_pass_init(c, D, ps);
+        } else if (fastp(D)) {
+            // windows: k_pass_begin (tsba_kernels_pass.h).  The participation arrays are clear (k_reset_state / the last pass's k_pass_end); the text
+            // observations' mu / sigma are there already if the last pass's k_pass_end computed them for this level
+            c->cur_bw_rows = D.bw_rows; c->S_stale = true; c->x_pass = 0;
+            c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq; c->W.trace_pass = ps;
+            const int npb = (D.n_sc + 255)/256 + (D.n_tg + 3)/4, n_ms = ms_ahead == ps ? 0 : D.n_tg;
+            hipLaunchKernelGGL(k_pass_begin, dim3(npb + n_ms), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial, o.state,
+                               npb, n_ms, log_pending ? c->st_log + ps - 1 : (LmState *)nullptr, c->ticket);
+            log_pending = false;
+        } else {
+            if (log_pending) { CK(hipMemcpyAsync(c->st_log + ps - 1, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream)); log_pending = false; }
+            launch_pass_init(c, D, ps);
+        }
         // The kernels of an LM iteration return at once when the pass has converged, but each still costs a launch (~4 us):
         // the host reads the pinned progress word and stays at most two iterations ahead of the device -- no API call, no
         // synchronisation -- so a pass that converges early wastes two iterations of empty launches instead of all the rest.
@@ -1353,11 +1402,29 @@ int tsba_solve(void *ctx, tsba_report *r) {
             if (it >= 1) { rc = stage_ahead(c, ps); if (rc) return rc; }      // (with two iterations queued the device does not run dry while the host stages)
         }
         if (n_trials > 0 && c->W.st_next != nullptr && D.far_B <= 0) launch_decide(c, D);      // windows: the decision on the last trial (the others were taken by the following trial's k_schur_t)
+        if (fastp(D)) {
+            // windows: the outlier pass, the NEXT pass's mu / sigma (when its level is on the device already) and the clearing of the participation arrays
+            // in one launch; this pass's final state is kept by the next pass's k_pass_begin (or by k_solve_end)
+            const bool outl = (o.outlier_scene || o.outlier_text) && D.n_sc + D.n_tg > 0;
+            const int nb_out = outl ? (D.n_sc + 63)/64 + D.n_tg : 0;
+            const LevelDev *Dn = nullptr;
+            if (ps + 1 < o.n_passes && c->lev_built[o.levels[ps + 1]] && fastp(c->lev[o.levels[ps + 1]]) && c->lev[o.levels[ps + 1]].n_tg > 0) { const int ln = o.levels[ps + 1];
+                if (c->lev_wait[ln]) { hipStreamWaitEvent(c->stream, c->ev_stage[ln], 0); c->lev_wait[ln] = 0; }      // (staged over the copy stream during this pass's trials: long since there)
+                Dn = &c->lev[ln]; }
+            const int n_ms = Dn ? Dn->n_tg : 0;
+            hipLaunchKernelGGL(k_pass_end, dim3((nb_out + 3)/4 + n_ms + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, Dn ? *Dn : D, nb_out, n_ms, c->musig2[c->musig_sel ^ 1],
+                               o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
+            if (Dn) { c->musig_sel ^= 1; c->W.musig = c->musig2[c->musig_sel]; ms_ahead = ps + 1; }
+            if (c->cov_text >= 0 && c->cov_text < c->n_text && ps < TSBA_MAX_LEVELS) hipLaunchKernelGGL(k_record_vtx, dim3(1), dim3(64), 0, c->stream, c->W, c->cov_text, c->cov_log + 6*ps);
+            log_pending = true;
+            continue;
+        }
         if (o.outlier_scene || o.outlier_text)
             if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
                                                           o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)nullptr);
         if (c->cov_text >= 0 && c->cov_text < c->n_text && ps < TSBA_MAX_LEVELS) hipLaunchKernelGGL(k_record_vtx, dim3(1), dim3(64), 0, c->stream, c->W, c->cov_text, c->cov_log + 6*ps);
         CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
+        if (fast_any) hipLaunchKernelGGL(k_part_clear, dim3(8), dim3(256), 0, c->stream, c->W);       // (a later pass may begin with k_pass_begin)
     }
     if (c->world > 1) {                           // every landmark was optimised by its owner only
         int nl = c->n_pt + 3*c->n_text;
@@ -1368,7 +1435,8 @@ int tsba_solve(void *ctx, tsba_report *r) {
             hipLaunchKernelGGL(k_delta_multi, dim3((nl + 255)/256), dim3(256), 0, c->stream, c->W, (const double *)c->rho0, (const double *)c->theta0, 1);
         }
     }
-    CK(hipMemcpyAsync(c->st_host, c->st_log, sizeof(LmState)*o.n_passes, hipMemcpyDeviceToHost, c->stream));
+    // the passes' final states straight into pinned host memory (a kernel's stores: no copy engine, no staging)
+    hipLaunchKernelGGL(k_solve_end, dim3(1), dim3(64), 0, c->stream, c->W, c->st_log, o.n_passes, log_pending ? 1 : 0, c->st_host, (unsigned int *)(c->st_host + TSBA_MAX_LEVELS) + 8);
     int *pcg_host = (int *)(c->st_host + TSBA_MAX_LEVELS);          // (the pinned block has room for 8 ints behind the pass snapshots)
     if (c->far_B > 0) CK(hipMemcpyAsync(pcg_host, c->W.pc_stat, 8*sizeof(int), hipMemcpyDeviceToHost, c->stream));
     CK(hipStreamSynchronize(c->stream));
@@ -1393,6 +1461,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
       r->solver_path = (c->pose_only && !is_multi(c)) ? TSBA_SOLVER_POSE : use_lds ? TSBA_SOLVER_LDS
           : Dl.far_B > 0 ? (Dl.n_wb > 0 && ms_available(c) && c->dbg.far_solver != 3 ? TSBA_SOLVER_BAND_LOWRANK : TSBA_SOLVER_BAND_PCG)
           : !c->band_stream ? TSBA_SOLVER_DENSE : c->band_parts <= 1 ? TSBA_SOLVER_BAND : c->W.ring ? TSBA_SOLVER_RING : c->sep_cr ? TSBA_SOLVER_BAND_CR : TSBA_SOLVER_BAND_PART; }
+    r->poll_timeouts = (int32_t)((const unsigned int *)pcg_host)[8];
     if (c->far_B > 0) { r->pcg_iterations = pcg_host[0]; r->pcg_systems = pcg_host[1]; r->pcg_max_iterations = pcg_host[2]; r->pcg_unconverged = pcg_host[3]; r->pcg_stagnated = pcg_host[4]; }
     return TSBA_OK;
 }

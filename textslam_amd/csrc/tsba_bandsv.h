@@ -210,7 +210,7 @@ __device__ __forceinline__ double sv_poll1(const double *p, bool on) {
     double v = 0.0;
     if (on) { v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int spins = 0; v != v && spins < (1 << 15); spins++) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        if (v != v) v = __builtin_inf(); }
+        if (v != v) { v = __builtin_inf(); atomicAdd(&ts_poll_giveups, 1u); } }
     return v;
 }
 template <int NREG, bool POLL>
@@ -528,6 +528,7 @@ __device__ __forceinline__ void sv_pending_poll(const MsBuf &M, int s, int blk, 
     }
 #pragma unroll
     for (int l = 0; l < 8; l++) { if (need >> l & 1) P.lo_[l] = __builtin_inf(); if (need >> (8 + l) & 1) P.hi_[l] = __builtin_inf(); }     // (gave up: the result is not finite)
+    if (need) atomicAdd(&ts_poll_giveups, 1u);
 }
 __device__ __forceinline__ void sv_poll2(const double *pa, bool on_a, const double *pc, bool on_c, double &va, double &vc) {      // both requests in one round trip
     va = 0.0; vc = 0.0;
@@ -540,6 +541,7 @@ __device__ __forceinline__ void sv_poll2(const double *pa, bool on_a, const doub
     }
     if (na) va = __builtin_inf();
     if (nc) vc = __builtin_inf();
+    if (na || nc) atomicAdd(&ts_poll_giveups, 1u);
 }
 
 // ---- the separator steps.  With the products P_a = X_a L^-1, P_c = X_c L^-1 that k_sv_linv leaves next to L^-1 (once per factorisation), a pivot's
@@ -656,7 +658,8 @@ __device__ __forceinline__ void sv_top_body(const Work &W, int s, int B, int Pma
             for (int l = 0; l < 8; l++) if ((need >> l & 1) && pr_[l] == pr_[l]) need &= ~(1u << l);
             if (need) __builtin_amdgcn_s_sleep(1); }
 #pragma unroll
-        for (int l = 0; l < 8; l++) if (need >> l & 1) pr_[l] = __builtin_inf(); }
+        for (int l = 0; l < 8; l++) if (need >> l & 1) pr_[l] = __builtin_inf();
+        if (need) atomicAdd(&ts_poll_giveups, 1u); }
     if (piv) {                                                  // forward step of the pivot: the root's update P_a v, z = D^-1 L^-1 v
         if (vrow) v[tid] = sv_pending_sum(pd, i, h, lo, m, r0, F.g0 + F.g1);
         __syncthreads();

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void k_reset_state(Work W, ResetSrc A) {
     for (long long k = t; k < A.n_sg; k += n) W.sgood[k] = A.sg0[k];
     for (long long k = t; k < A.n_tg; k += n) W.tobs_good[k] = A.tg0[k];
     for (long long k = t; k < A.n_tf; k += n) W.tfgood[k] = A.tf0[k];
-    if (t == 0) memset(W.st, 0, sizeof(LmState));
+    for (long long k = t; k < W.n_kf; k += n) W.kf_in[k] = 0;             // (what k_pass_reset clears: the first pass of a window starts with k_pass_begin, tsba_kernels_pass.h)
+    for (long long k = t; k < W.n_pt; k += n) W.act_pt[k] = 0;
+    for (long long k = t; k < W.n_text; k += n) W.act_tx[k] = 0;
+    if (t == 0) { memset(W.st, 0, sizeof(LmState)); if (W.poll0) *W.poll0 = ts_poll_giveups; }
 }
 
 // ---- pass initialisation
@@ -99,15 +102,15 @@ __global__ void k_pass_reset(Work W, double radius0, int max_it) {
 }
 
 // which candidates are active (good flags), which keyframes participate (FLAG_KFIN, optimizer.cc:1410-1411,1428,1514-1515)
-__global__ __launch_bounds__(256) void k_participation(Work W, LevelDev L, int partials) {
+__device__ __forceinline__ void participation_wg(const Work &W, const LevelDev &L, const int bid, int partials) {
     // workgroups 0 .. nb_sc-1: one scene candidate per thread; the rest: one (KF, text) group per WAVE, its features on the lanes
     // (a thread walking the 64 features of a group alone was most of this kernel's 14 us)
     __shared__ int cnt_s, cnt_t;
     if (threadIdx.x == 0) { cnt_s = 0; cnt_t = 0; }
     __syncthreads();
     const int nb_sc = (L.n_sc + 255) >> 8, lane = threadIdx.x & 63;
-    if ((int)blockIdx.x < nb_sc) {
-        const int t = blockIdx.x*256 + threadIdx.x;
+    if (bid < nb_sc) {
+        const int t = bid*256 + threadIdx.x;
         bool act = false;
         if (t < L.n_sc) {
             act = !W.filter_good || W.sgood[L.sc_flag[t]];
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void k_participation(Work W, LevelDev L, int p
         const int nw = __popcll(__ballot(act));
         if (lane == 0 && nw) atomicAdd(&cnt_s, nw);
     } else {
-        const int g = (blockIdx.x - nb_sc)*4 + (threadIdx.x >> 6);
+        const int g = (bid - nb_sc)*4 + (threadIdx.x >> 6);
         if (g < L.n_tg) {
             const int tb = L.tg_tobs[g], j = L.tg_text[g];
             if (!W.filter_good || W.tobs_good[tb]) {
@@ -141,10 +144,11 @@ __global__ __launch_bounds__(256) void k_participation(Work W, LevelDev L, int p
     if (threadIdx.x == 0) {
         // single GPU: per-workgroup partials, summed by the gauge kernel; multi-GPU: the counts are all-reduced before the gauge
         // kernel runs, so they go straight to the state
-        if (partials) { W.cntpart[2*blockIdx.x] = cnt_s; W.cntpart[2*blockIdx.x + 1] = cnt_t; }
+        if (partials) { W.cntpart[2*bid] = cnt_s; W.cntpart[2*bid + 1] = cnt_t; }
         else { if (cnt_s) atomicAdd(&W.st->ns_active, cnt_s); if (cnt_t) atomicAdd(&W.st->nt_active, cnt_t); }
     }
 }
+__global__ __launch_bounds__(256) void k_participation(Work W, LevelDev L, int partials) { participation_wg(W, L, (int)blockIdx.x, partials); }
 // block counts of k_participation -> LM state (called by the gauge kernels' first wave / all threads)
 __device__ __forceinline__ void sum_counts(const Work &W, int ncp, int tid, int nthreads, int *lds2 /* [2] zeroed */) {
     int a = 0, b = 0;

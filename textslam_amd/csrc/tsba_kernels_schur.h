@@ -4,6 +4,7 @@
 // The (slot, slot, landmark) gather lists of a diagonal block hold ~1000 entries: four waves, and per wave the indices and
 // operands of four entries in flight before the first multiply (two dependent global round trips per 1024 entries).
 #define SCHUR_U 4
+#define SCHUR_KEEP_KF 32                    // keyframes whose damping / gradient rows a workgroup of k_schur_t<4> keeps in LDS when it takes the previous trial's decision itself
 // SCHUR_NW waves per workgroup: 4 for windows (a diagonal block gathers ~1000 slot pairs), 1 for large maps (54 k blocks of ~60 slot
 // pairs each at 5000 keyframes: three idle waves per block and their hand-off were most of the 0.64 ms)
 // dec (windows on one GPU, SCHUR_NW = 4: 256 threads as k_decide): the launch takes the DECISION on the previous trial first -- every workgroup,
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         if (SCHUR_NW == 4 && dec.on && blockIdx.x == 0 && threadIdx.x == 0) { const LmState s = *st; lm_state_store(W.st_next, s); }
         return; }
     __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
-    __shared__ double keep[SCHUR_NW == 4 ? 2*6*32 : 1]; __shared__ double dsh_r; __shared__ int dsh_i[3];
+    __shared__ double keep[SCHUR_NW == 4 ? 2*6*SCHUR_KEEP_KF : 1]; __shared__ double dsh_r; __shared__ int dsh_i[3];      // (keep: damping | gradient rows of up to SCHUR_KEEP_KF poses -- the host enables `dec` only for windows of at most that many)
     int lcur_ = st->lcur; double radius_ = st->radius; bool fresh = false;      // fresh: the current linearisation is the candidate this launch has just accepted
     if constexpr (SCHUR_NW == 4) if (dec.on) {
         double o5[5];

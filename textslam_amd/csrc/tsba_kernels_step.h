@@ -76,9 +76,10 @@ __device__ __forceinline__ void back_body(const Work &W, const LevelDev &L, int 
         for (int k0 = 0; k0 < nd; k0 += (int)blockDim.x) { const int k = k0 + t768;
             if (k < nd) { double v = co_load(&W.dp[k]);
                 for (int spins = 0; v != v && spins < (1 << 16); spins++) { __builtin_amdgcn_s_sleep(1); v = co_load(&W.dp[k]); }
+                if (v != v) atomicAdd(&ts_poll_giveups, 1u);
                 dps[k] = v == v ? v : __builtin_inf(); } }
         __syncthreads();
-        fail = dps[W.N] != 0.0;
+        fail = fail || dps[W.N] != 0.0;                         // (the assembly's flag, read with the state, or the solver's: what k_back reads after both launches)
         dp = dps;
     }
     double step2 = 0.0, mcc = 0.0;
@@ -202,13 +203,14 @@ __global__ __launch_bounds__(256) void k_back(Work W, LevelDev L, int nb_pt, int
 // ---- the reduced system of a small window and the back-substitution in ONE launch: workgroup 0 is k_solve_t, every other workgroup three blocks of k_back
 // that wait for the pose step where k_back would wait for its launch (6.97 us per trial on C4, most of it the launch, the state round trip and the
 // records' round trip behind it).  The step reaches the waiting blocks ~0.65 us after the solver stores it (tools/handover_bench.hip).
+template <bool RL = true>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_back(Work W, LevelDev L, int nb_pt, int nb_tx, int nb_all) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (blockIdx.x != 0) {
         const int sub = threadIdx.x >> 8, b = 3*((int)blockIdx.x - 1) + sub;
         back_body<true>(W, L, nb_pt, nb_tx, b, threadIdx.x & 255, b < nb_all, smem + 256*sub, smem + 768);
         return; }
-    solve_body<false, true>(W, 0, smem);
+    solve_body<false, true, RL>(W, 0, smem);
 }
 
 // ---- the decision on one LM trial (Ceres 1.x TrustRegionMinimizer / LevenbergMarquardtStrategy semantics) on the state s -- the state in device memory
@@ -353,10 +355,11 @@ __global__ void k_kfin_multi(Work W) {               // kf_in was summed over ra
 // ---- outlier pass on loss-corrected residuals, optimizer.cc:1609-1686 / :1228-1305
 // pfin != nullptr (pose-only path): the pass's result still lives in the PoseState -- pose from there, and one extra workgroup
 // installs it into W.st / W.pose (field by field: the counters of this very kernel are being updated by atomics)
-__global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_mono, double chi2_text, double bad_ratio,
-                                                int do_scene, int do_text, const PoseState *pfin) {
+// (one wave of 64 lanes per block b: k_outlier launches a workgroup per wave, k_pass_end -- tsba_kernels_pass.h -- four waves per workgroup next to
+// other roles)
+__device__ __forceinline__ void outlier_wave(const Work &W, const LevelDev &L, const int b, const int lane, double chi2_mono, double chi2_text, double bad_ratio,
+                                             int do_scene, int do_text, const PoseState *pfin) {
     LmState *st = W.st;
-    const int b = blockIdx.x, lane = threadIdx.x;
     const int selc = pfin ? 0 : st->cur;
     const double *pose = pfin ? pfin->x : W.pose[selc], *rho = W.rho[selc], *theta = W.theta[selc];
     if (st->nt_active < 50) chi2_mono += 4.0;
@@ -433,6 +436,11 @@ __global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_
             st->n_lin = S.n_lin; st->n_cost = S.n_cost;
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_outlier(Work W, LevelDev L, double chi2_mono, double chi2_text, double bad_ratio,
+                                                int do_scene, int do_text, const PoseState *pfin) {
+    outlier_wave(W, L, blockIdx.x, threadIdx.x, chi2_mono, chi2_text, bad_ratio, do_scene, do_text, pfin);
 }
 
 // ---- information matrix V (6 values) of one text plane at the end of a pass: ceres::Covariance runs after every pyramid pass of

@@ -180,7 +180,11 @@ static size_t solve_diag_lds_doubles() { return solve_lds_doubles(SOLVE_DIAG_NB)
 // go out as device-coherent stores of values that are never NaN (the slots hold NaN until then)
 __device__ __forceinline__ double co_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void co_store(double *p, double v) { __hip_atomic_store(p, v == v ? v : __builtin_inf(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool DIAG, bool PUB>
+// RL: the 6x6 diagonal block is factored where it already lives -- row r in lane r of the panel wave -- with the pivot and the column below it
+// broadcast by v_readlane (uniform operands), instead of going through a wave-private LDS scratch to every lane and being factored there from a
+// private copy: same operations on the same operands in the same order (bit-identical: RL = false is kept for that comparison,
+// tsba_debug_options.solve_variant = 4), ~120 instructions on the chain of a block step instead of ~9 LDS reads + ~110 + the scratch hand-over
+template <bool DIAG, bool PUB, bool RL = true>
 __device__ __forceinline__ void solve_body(const Work &W, int B0, double *smem) {
     LmState *st = W.st;
     __shared__ int fail;
@@ -262,13 +266,40 @@ __device__ __forceinline__ void solve_body(const Work &W, int B0, double *smem) 
             const int i0 = lane < 6 ? j0 + lane : R0 + wave*SOLVE_PROWS + lane - 6;
             double a[6];
             load_row(min(i0, n), a);
+            double l[15], d[6], id[6]; bool bad = false;
+#ifdef TSBA_SOLVE_STAMPS
+            long long sa_ = 0;
+#endif
+            if constexpr (RL) {
+                STAMP(ta);
+#ifdef TSBA_SOLVE_STAMPS
+                sa_ = clock64();
+#endif
+                double sd[6];                                     // lanes 0..5: row `lane` of the diagonal block (entries 0..lane); other lanes: not used
+#pragma unroll
+                for (int c = 0; c < 6; c++) sd[c] = a[c];
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double dc = readlane_f64(sd[c], c);
+                    if (!(dc > 0.0)) { bad = true; dc = 1.0; }
+                    d[c] = dc; id[c] = rcp_nr(dc);
+                    double col[6];
+#pragma unroll
+                    for (int r = c + 1; r < 6; r++) col[r] = readlane_f64(sd[c], r);       // column c below the diagonal (not yet scaled)
+#pragma unroll
+                    for (int r = c + 1; r < 6; r++) l[tri(r - 1) + c] = col[r]*id[c];
+                    const double lr = sd[c]*id[c];                // this lane's own row: l(lane, c)
+#pragma unroll
+                    for (int q = c + 1; q < 6; q++) sd[q] = fma(-lr, col[q], sd[q]);       // (entries right of the lane's diagonal are never read)
+                }
+            } else {
             if (lane < 6) st6(scr + wave*36 + lane*6, a);
             wave_lds_fence();
             STAMP(ta);
 #ifdef TSBA_SOLVE_STAMPS
-            const long long sa_ = clock64();
+            sa_ = clock64();
 #endif
-            double s[21], l[15], d[6], id[6]; bool bad = false;
+            double s[21];
             {
                 double t[36];
 #pragma unroll
@@ -279,6 +310,7 @@ __device__ __forceinline__ void solve_body(const Work &W, int B0, double *smem) 
                     for (int c = 0; c <= r; c++) s[tri(r) + c] = t[6*r + c];
             }
             ldl6(s, l, d, id, bad);
+            }
             if (wave == 0 && lane == 0) {
                 double *o = LD + SOLVE_LD*jb;
 #pragma unroll
@@ -429,10 +461,10 @@ __device__ __forceinline__ void solve_body(const Work &W, int B0, double *smem) 
     }
     if (PUB && tid == 0) co_store(&W.dp[Nmax], 0.0);
 }
-template <bool DIAG>
+template <bool DIAG, bool RL = true>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_t(Work W, int B0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    solve_body<DIAG, false>(W, B0, smem);
+    solve_body<DIAG, false, RL>(W, B0, smem);
 }
 
 // (k_solve_r -- the same solver with every row at the same stride, update tiles with an unmasked path and scalar tile indices, optionally

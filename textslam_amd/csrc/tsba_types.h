@@ -1,6 +1,10 @@
 // Device-side structs of libtsba.so: LM state, per-level plan views, linearisation buffers, work buffers.  (part of the single translation unit tsba.hip: included there, in this order)
 #pragma once
 typedef double v2d __attribute__((ext_vector_type(2)));
+// Kernels whose workgroups poll values that other workgroups of the same launch publish (k_solve_back, k_sv_cre_tree, k_sv_tree_back, k_cre_back_tree, and the
+// roles of k_lin_mid) bound their polling; a thread that gives up counts itself here.  A solve reports the difference over its duration
+// (tsba_report.poll_timeouts): a give-up fails the linear solve of its LM trial -- this says that it was a wait and not the numbers.
+__device__ unsigned int ts_poll_giveups;
 // ------------------------------------------------------------------------------------------------ device structs
 struct LmState {
     double radius, decrease_factor, x_cost, x_norm, cand_cost, model_change, step_norm, gmax, cost0;
@@ -101,6 +105,7 @@ struct Work {                // device work buffers (sized for the largest level
     double *partial;                    // [nblocks_back][2]
     int *cntpart;                       // per k_participation workgroup: active scene blocks, active text blocks
     double *posepart;                   // large maps: per k_pose_sums workgroup (21 poses): gradient max, |x|^2
+    unsigned int *poll0;                // ts_poll_giveups at the start of the solve (k_reset_state)
     LmState *st, *st_next;              // st_next (windows, single GPU; else null): the copy of the state that k_schur_t writes when it takes the previous trial's decision itself -- the host swaps the two after that launch
     PoseState *pst; double *ppart;      // pose-only path (tsba_pose.h): double-buffered state, [2][G][28] partial sums
     // band + long-range blocks, preconditioned conjugate gradients (tsba_pcg.h): the blocks outside the band [n_far][36] (rows: the earlier keyframe),

@@ -72,9 +72,10 @@ def load_library():
     return L
 
 
+ABI_VERSION = 5                                   # TSBA_ABI_VERSION of include/tsba.h
 EXPORTED_SYMBOLS = [
     "tsba_default_options_local", "tsba_default_options_pose", "tsba_default_options_global",
-    "tsba_create", "tsba_destroy", "tsba_last_error",
+    "tsba_abi_version", "tsba_create", "tsba_destroy", "tsba_last_error",
     "tsba_default_options_init", "tsba_default_options_landmarker", "tsba_default_options_theta",
     "tsba_local_ba", "tsba_pose_optim", "tsba_global_ba", "tsba_theta_optim", "tsba_text_label_image",
     "tsba_upload", "tsba_solve", "tsba_download", "tsba_eval", "tsba_time_linearize",
@@ -103,6 +104,8 @@ class Optimizer:
 
     def __init__(self, device=0):
         self.lib = load_library()
+        if self.lib.tsba_abi_version() != ABI_VERSION:           # (the ctypes mirrors in abi.py describe exactly one layout)
+            raise TsbaError(f"libtsba.so has ABI version {self.lib.tsba_abi_version()}, abi.py mirrors {ABI_VERSION}")
         self.ctx = C.c_void_p()
         rc = self.lib.tsba_create(C.byref(self.ctx), device)
         if rc != 0:
