@@ -84,6 +84,29 @@ __device__ __forceinline__ void ldl6(double s[21], double l[15], double d[6], do
         }
     }
 }
+// The same factorisation of a 6x6 block whose row r (entries 0..r) sits in lane r of the calling wave (a[], lanes 0..5; what the other lanes hold is not
+// used): the pivot and the column below it are broadcast by v_readlane, every lane gets l, d, 1/d as uniform values and updates its own row.  Operation
+// for operation what ldl6 does on a private copy of the block -- l(r,c) = s(r,c) * 1/d(c), s(r,q) -= l(r,c) s(q,c) in the same order -- so the
+// results are the same bits; what it saves is the hand-over of the six rows through LDS to all 64 lanes.
+__device__ __forceinline__ void ldl6_lanes(const double a[6], double l[15], double d[6], double id[6], bool &bad) {
+    double sd[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) sd[c] = a[c];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double dc = readlane_f64(sd[c], c);
+        if (!(dc > 0.0)) { bad = true; dc = 1.0; }
+        d[c] = dc; id[c] = rcp_nr(dc);
+        double col[6];
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) col[r] = readlane_f64(sd[c], r);       // column c below the diagonal (not yet scaled)
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) l[tri(r - 1) + c] = col[r]*id[c];
+        const double lr = sd[c]*id[c];                            // this lane's own row: l(lane, c)
+#pragma unroll
+        for (int q = c + 1; q < 6; q++) sd[q] = fma(-lr, col[q], sd[q]);       // (entries right of the lane's diagonal are never read)
+    }
+}
 // M = L^-1 for unit-lower L (both packed strictly-lower)
 __device__ __forceinline__ void inv_unit_lower6(const double l[15], double m[15]) {
 #pragma unroll
@@ -275,23 +298,7 @@ __device__ __forceinline__ void solve_body(const Work &W, int B0, double *smem) 
 #ifdef TSBA_SOLVE_STAMPS
                 sa_ = clock64();
 #endif
-                double sd[6];                                     // lanes 0..5: row `lane` of the diagonal block (entries 0..lane); other lanes: not used
-#pragma unroll
-                for (int c = 0; c < 6; c++) sd[c] = a[c];
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    double dc = readlane_f64(sd[c], c);
-                    if (!(dc > 0.0)) { bad = true; dc = 1.0; }
-                    d[c] = dc; id[c] = rcp_nr(dc);
-                    double col[6];
-#pragma unroll
-                    for (int r = c + 1; r < 6; r++) col[r] = readlane_f64(sd[c], r);       // column c below the diagonal (not yet scaled)
-#pragma unroll
-                    for (int r = c + 1; r < 6; r++) l[tri(r - 1) + c] = col[r]*id[c];
-                    const double lr = sd[c]*id[c];                // this lane's own row: l(lane, c)
-#pragma unroll
-                    for (int q = c + 1; q < 6; q++) sd[q] = fma(-lr, col[q], sd[q]);       // (entries right of the lane's diagonal are never read)
-                }
+                ldl6_lanes(a, l, d, id, bad);
             } else {
             if (lane < 6) st6(scr + wave*36 + lane*6, a);
             wave_lds_fence();
