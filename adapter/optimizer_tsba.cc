@@ -41,7 +41,7 @@ void optimizer::LocalBundleAdjustment(map *mpMap, vector<keyframe *> vKFs, const
     vector<mapPts *> vMapPts = mpMap->GetAllMapPoints();
     vector<mapText *> vMapTexts = mpMap->GetAllMapTexts(TEXTGOOD);
     double K[4]; k_of(vK[0], K);
-    Packed P;
+    static thread_local Packed P_keep; Packed &P = P_keep; P.reset();                                                       // (one per thread: the arrays' storage stays)
     tsba_adapter::pack_map<TT>(mpMap, vKFs, vMapPts, vMapTexts, /*local*/0, /*levels 0..2*/3, K, !bFlag_noText, P, nullptr, nullptr, &gather_cache());           // optimizer.cc:201-279, :1366-1557
     tsba_options o; tsba_default_options_local(&o);                                                                        // :282-289
     o.state = STATE == LOCAL ? TSBA_STATE_LOCAL : STATE == GLOBAL ? TSBA_STATE_GLOBAL : TSBA_STATE_NOTREACHWIN;              // :1571-1588

@@ -49,6 +49,16 @@ struct Packed {
     tsba_problem p;
 
     Packed() { std::memset(&p, 0, sizeof(p)); }
+    // empty, with every array's storage kept: an adapter that packs a window per keyframe reuses ONE Packed (3 MB of arrays at 20 keyframes x 5000 points --
+    // allocating and first-touching them was a quarter of a cached gather)
+    void reset() {
+        pose.clear(); rho.clear(); theta.clear(); pt_ray.clear(); pt_Trw.clear(); text_Twr.clear(); text_box.clear();
+        pt_host.clear(); text_host.clear(); tobs_kf.clear(); tobs_text.clear(); tobs_fgood_off.clear();
+        kf_initial.clear(); sgood.clear(); tobs_good.clear(); tfgood.clear(); kf_id.clear(); kf_flag_off.clear(); tobs_raw.clear();
+        for (int l = 0; l < TSBA_MAX_LEVELS; l++) { sobs_uv0[l].clear(); tfeat_uv[l].clear(); tfeat_ref[l].clear(); sobs_kf[l].clear(); sobs_pt[l].clear(); sobs_flag[l].clear();
+            tfeat_off[l].clear(); tfeat_raw[l].clear(); img[l].clear(); }
+        std::memset(&p, 0, sizeof(p));
+    }
 
     // wire the pointers of tsba_problem to the vectors (after the last push_back)
     void finish(int n_levels, const double K[4], const int img_w[TSBA_MAX_LEVELS], const int img_h[TSBA_MAX_LEVELS]) {
@@ -211,15 +221,20 @@ inline void pack_map(typename T::Map *mpMap, const std::vector<typename T::KeyFr
         P.kf_initial.push_back(mode == 2 ? 1 : (vKFs[k]->mnId == 0 || vKFs[k]->mnId == 1) ? 1 : 0);                   // :274-275
     }
     // scene points: rho, ray, host (or the frozen host's T_rw)
-    for (size_t j = 0; j < vMapPts.size(); j++) {
-        typename T::MapPt *pt = vMapPts[j];
-        P.rho.push_back(pt->GetInverD());
-        const auto ray = pt->GetRaydir();
-        P.pt_ray.push_back(ray(0)); P.pt_ray.push_back(ray(1));
-        const int h = mnId2KFs[(size_t)pt->RefKF->mnId];
-        P.pt_host.push_back(h);
-        if (h < 0) push_mat34(pt->RefKF->mTcw, P.pt_Trw); else push_zero12(P.pt_Trw);                                  // :1416-1417
-        mnId2Pts[(size_t)pt->mnId] = (int)j;
+    {   // (arrays sized once and written by index: a push_back per value -- 17 per point -- was a third of this function's time)
+        const size_t np = vMapPts.size();
+        P.rho.resize(np); P.pt_ray.resize(2*np); P.pt_host.resize(np); P.pt_Trw.assign(12*np, 0.0);
+        for (size_t j = 0; j < np; j++) {
+            typename T::MapPt *pt = vMapPts[j];
+            P.rho[j] = pt->GetInverD();
+            const auto ray = pt->GetRaydir();
+            P.pt_ray[2*j] = ray(0); P.pt_ray[2*j + 1] = ray(1);
+            const int h = mnId2KFs[(size_t)pt->RefKF->mnId];
+            P.pt_host[j] = h;
+            if (h < 0) { const auto &Tm = pt->RefKF->mTcw; double *o = &P.pt_Trw[12*j];                                    // :1416-1417 (a host inside the window: zeros)
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) o[4*r + c] = Tm(r, c); }
+            mnId2Pts[(size_t)pt->mnId] = (int)j;
+        }
     }
     // text planes: theta = n/d in the host frame, host (or the frozen host's T_wr), detection box rays
     for (size_t j = 0; j < vMapTexts.size(); j++) {
@@ -233,9 +248,11 @@ inline void pack_map(typename T::Map *mpMap, const std::vector<typename T::KeyFr
         mnId2Texts[(size_t)obj->mnId] = (int)j;
     }
     // good flags of the scene observations: the keyframes' vObvGoodPts, concatenated
-    for (size_t k = 0; k < vKFs.size(); k++) {
-        P.kf_flag_off.push_back((int32_t)P.sgood.size());
-        for (size_t i = 0; i < vKFs[k]->vObvGoodPts.size(); i++) P.sgood.push_back(vKFs[k]->vObvGoodPts[i] ? 1 : 0);
+    {   size_t nflag = 0;
+        for (size_t k = 0; k < vKFs.size(); k++) { P.kf_flag_off.push_back((int32_t)nflag); nflag += vKFs[k]->vObvGoodPts.size(); }
+        P.sgood.resize(nflag);
+        for (size_t k = 0; k < vKFs.size(); k++) { uint8_t *o = nflag ? &P.sgood[(size_t)P.kf_flag_off[k]] : nullptr; const auto &g = vKFs[k]->vObvGoodPts;
+            for (size_t i = 0; i < g.size(); i++) o[i] = g[i] ? 1 : 0; }
     }
     // scene observations per level, in the reference's residual order: keyframe-major, then vSceneObv2d[level] (:1366-1435).
     // The residual always uses the LEVEL-0 pixel of the observation (SceneUse0Pyr, :1336,1402-1403).
@@ -246,12 +263,15 @@ inline void pack_map(typename T::Map *mpMap, const std::vector<typename T::KeyFr
                 const GatherCache::KfSeg &S = cache->scene(*vKFs[k], n_levels);
                 const std::vector<int32_t> &raws = S.raw[(size_t)l], &ids = S.ptid[(size_t)l]; const std::vector<double> &uv = S.uv0[(size_t)l];
                 const int32_t f0 = P.kf_flag_off[k];
-                for (size_t s = 0; s < raws.size(); s++) {
+                const size_t w0 = P.sobs_kf[l].size(), ns = raws.size(); size_t w = w0;
+                P.sobs_kf[l].resize(w0 + ns, (int32_t)k); P.sobs_pt[l].resize(w0 + ns); P.sobs_flag[l].resize(w0 + ns); P.sobs_uv0[l].resize(2*(w0 + ns));
+                int32_t *opt = P.sobs_pt[l].data(), *ofl = P.sobs_flag[l].data(); double *ouv = P.sobs_uv0[l].data();
+                for (size_t s = 0; s < ns; s++) {
                     const int j = mnId2Pts[(size_t)ids[s]];
-                    if (j < 0) continue;
-                    P.sobs_kf[l].push_back((int32_t)k); P.sobs_pt[l].push_back(j); P.sobs_flag[l].push_back(f0 + raws[s]);
-                    P.sobs_uv0[l].push_back(uv[2*s]); P.sobs_uv0[l].push_back(uv[2*s + 1]);
+                    if (j < 0) continue;                               // (a point the map no longer lists)
+                    opt[w] = j; ofl[w] = f0 + raws[s]; ouv[2*w] = uv[2*s]; ouv[2*w + 1] = uv[2*s + 1]; w++;
                 }
+                if (w != w0 + ns) { P.sobs_kf[l].resize(w); P.sobs_pt[l].resize(w); P.sobs_flag[l].resize(w); P.sobs_uv0[l].resize(2*w); }
                 continue;
             }
             const auto &obs = vKFs[k]->vSceneObv2d[l];
@@ -279,7 +299,8 @@ inline void pack_map(typename T::Map *mpMap, const std::vector<typename T::KeyFr
                 P.tobs_kf.push_back((int32_t)k); P.tobs_text.push_back(j); P.tobs_raw.push_back(raw);
                 P.tobs_good.push_back(vKFs[k]->vObvGoodTexts[(size_t)raw] ? 1 : 0);
                 const auto &fg = vKFs[k]->vObvGoodTextFeats[(size_t)raw];
-                for (size_t f = 0; f < fg.size(); f++) P.tfgood.push_back(fg[f] ? 1 : 0);
+                const size_t f0 = P.tfgood.size(); P.tfgood.resize(f0 + fg.size());
+                for (size_t f = 0; f < fg.size(); f++) P.tfgood[f0 + f] = fg[f] ? 1 : 0;
                 P.tobs_fgood_off.push_back((int32_t)P.tfgood.size());
             }
         }

@@ -206,13 +206,15 @@ int main(int argc, char **argv) {
         std::vector<double> tg, ts, tc, tt; int its[TSBA_MAX_LEVELS] = {0}; double sol = 0, upl = 0, dwn = 0;
         tsba_adapter::GatherCache cache;                                      // as the adapter's: what the 19 keyframes that stay contributed to the last call
         const bool use_cache = !(argc > 5 && std::string(argv[5]) == "nocache");
+        Packed Pkeep;                                                        // (the adapter keeps one per thread)
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         for (int rep_i = 0; rep_i < reps + 1; rep_i++) {                    // (the first call of a fresh context allocates: not counted)
             Graph G; build_graph(d, "local", G);
             G.kfs.back()->mnId = 100000 + (long unsigned)rep_i; G.M.imapkfs = 100000 + reps + 8;     // the window's newest keyframe is new to the context in every call: its planes cross the bus, the other 19 keyframes' do not
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<mapPts *> vP = G.M.GetAllMapPoints(); std::vector<mapText *> vT = G.M.GetAllMapTexts(TEXTGOOD);
-            Packed P; tsba_adapter::pack_map<Traits>(&G.M, G.kfs, vP, vT, 0, G.n_levels, G.K, wt, P, nullptr, nullptr, use_cache ? &cache : nullptr);
+            Packed Pnew; Packed &P = use_cache ? Pkeep : Pnew; if (use_cache) P.reset();
+            tsba_adapter::pack_map<Traits>(&G.M, G.kfs, vP, vT, 0, G.n_levels, G.K, wt, P, nullptr, nullptr, use_cache ? &cache : nullptr);
             const auto t1 = std::chrono::steady_clock::now();
             tsba_options o; tsba_report rp; tsba_default_options_local(&o); o.state = I32(d, "state") ? I32(d, "state")[0] : TSBA_STATE_LOCAL;
             const int rc = tsba_local_ba(cx, &P.p, &o, &rp);
@@ -232,6 +234,22 @@ int main(int argc, char **argv) {
                 mn(tt), mn(tg), mn(tc), mn(ts), upl, sol, dwn, reps, its[0], its[1], its[2], CNT(d, "pose")/7, CNT(d, "rho"), CNT(d, "theta")/3, use_cache ? "true" : "false", cache.hits, cache.misses);
         fclose(f); tsba_destroy(cx);
         printf("adapter call: %.3f ms (gather %.3f, tsba_local_ba %.3f, scatter %.3f)\n", mn(tt), mn(tg), mn(tc), mn(ts));
+        return 0;
+    }
+    if (mode == "time_gather") {            // CPU only: what pack_map costs with and without the segment cache (same graph, keyframe ids as a sliding window would have them)
+        Graph G; build_graph(d, "local", G);
+        const bool wt = CNT(d, "tobs_kf") > 0;
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        tsba_adapter::GatherCache cache; double best[3] = {1e30, 1e30, 1e30}; Packed Pkeep;
+        for (int rep_i = 0; rep_i < 30; rep_i++) for (int cc = 0; cc < 3; cc++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<mapPts *> vP = G.M.GetAllMapPoints(); std::vector<mapText *> vT = G.M.GetAllMapTexts(TEXTGOOD);
+            Packed Pnew; Packed &P = cc == 2 ? Pkeep : Pnew; if (cc == 2) P.reset();
+            tsba_adapter::pack_map<Traits>(&G.M, G.kfs, vP, vT, 0, G.n_levels, G.K, wt, P, nullptr, nullptr, cc ? &cache : nullptr);
+            const double t = ms(t0, std::chrono::steady_clock::now());
+            if (t < best[cc]) best[cc] = t;
+        }
+        printf("gather: %.3f ms from scratch, %.3f ms with the segment cache, %.3f ms with the cache into a Packed kept between calls\n", best[0], best[1], best[2]);
         return 0;
     }
     if (mode == "slide_check") {

@@ -78,7 +78,7 @@ def _record(name, **kw):
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 
 
-def compare_first_linearisation(gpu, oracle_lib, P, o, direct=True):
+def compare_first_linearisation(gpu, oracle_lib, P, o, direct=True, measure_only=False):
     """cost, reduced gradient, every 6x6 block of S by keyframe pair and the first pose step of the uploaded problem against the oracle's block-sparse
     restatement.  -> (oracle blocks, worst block difference relative to the block's scale, relative residual of the oracle's system at the GPU's step)"""
     nk = P.n_kf
@@ -91,7 +91,17 @@ def compare_first_linearisation(gpu, oracle_lib, P, o, direct=True):
     for q, k in enumerate(kf_of):
         g_or[6*k:6*k + 6] = ob["g"][6*q:6*q + 6]
     gscale = np.abs(g_or).max()
-    assert np.abs(gb["g"] - g_or).max() <= 1e-9*gscale, np.abs(gb["g"] - g_or).max()/gscale
+    g_gap = float(np.abs(gb["g"] - g_or).max()/gscale)
+    if measure_only:                                                  # (a state where the reduction is ill-conditioned: the caller asserts what the measurements support)
+        sscale = np.abs(ob["val"]).max(); worst = 0.0
+        for q in range(len(ob["br"])):
+            blk = gb["blocks"].get((int(kf_of[ob["br"][q]]), int(kf_of[ob["bc"][q]])))
+            if blk is not None:
+                worst = max(worst, float(np.abs(blk - ob["val"][q]).max()/max(np.abs(ob["val"][q]).max(), 1e-6*sscale)))
+        A = oracle_lib.blocks_to_sparse(n, ob["br"], ob["bc"], ob["val"])
+        dp = np.concatenate([gb["dp"][6*k:6*k + 6] for k in kf_of])
+        return ob, worst, float(np.abs(A @ dp + ob["g"]).max()/np.abs(ob["g"]).max()), g_gap
+    assert g_gap <= 1e-9, g_gap
     # every block of S, by keyframe pair (the oracle's blocks are in keyframe order: rows = the later keyframe)
     sscale = np.abs(ob["val"]).max()
     seen, worst = set(), 0.0
@@ -297,12 +307,20 @@ def test_converged_answers_against_the_oracle(gpu, oracle_lib, map_cache, name):
     assert rep_g["termination"][0] == 1, rep_g                       # the function tolerance, as the oracle
     rel_cost = abs(rep_g["cost1"][0] - float(fx["cost1"]))/float(fx["cost1"])
     gap_al, gap_raw = _gauge_aligned_pose_gap(G.pose, fx["pose"])
-    # (a) at the oracle's end state
+    # (a) at the oracle's end state: every residual and every Jacobian entry (tsba_eval, the reference's block order), the cost; the REDUCED system is
+    # measured and recorded -- after 231 iterations some landmarks are barely constrained (V_j near the LM floor), and W V^-1 b amplifies the last bits
+    # of V_j by 1/V_j: the reduced gradient agrees to ~1e-4 of its scale where it agreed to 1e-9 at the start (the amplification that parts the trajectories)
     Q = P.copy(); Q.pose[:] = fx["pose"]; Q.rho[:] = fx["rho"]
     o1 = _options(name)
+    eo, eg = oracle_lib.evaluate(Q, o1, 0), gpu.evaluate(Q, o1, 0)
+    assert (eo["ns"], eo["nt"]) == (eg["ns"], eg["nt"]) and eo["ns"] > 400000
+    resid_gap = float(np.abs(eg["resid"] - eo["resid"]).max())
+    jac_gap = float(np.abs(eg["jac_scene"] - eo["jac_scene"]).max()/np.abs(eo["jac_scene"]).max())
+    assert resid_gap <= 1e-9 and jac_gap <= 1e-10, (resid_gap, jac_gap)
     gpu.upload(Q, o1)
-    ob, worst, rres = compare_first_linearisation(gpu, oracle_lib, Q, o1, direct=name != "c6_long_range")
+    ob, worst, rres, g_gap = compare_first_linearisation(gpu, oracle_lib, Q, o1, direct=False, measure_only=True)
     assert abs(ob["cost"] - float(fx["cost1"])) <= 1e-12*float(fx["cost1"])
+    assert g_gap <= 1e-2 and worst <= 1e-2 and rres <= 1e-6, (g_gap, worst, rres)
     # (c) both started again there
     o2 = _options(name); o2.its[0] = 200
     gpu.upload(Q, o2); rep_a = gpu.solve(); tr_a = gpu.lm_trace(0)
@@ -316,12 +334,12 @@ def test_converged_answers_against_the_oracle(gpu, oracle_lib, map_cache, name):
     moved = (rep_a["cost0"][0] - rep_a["cost1"][0])/rep_a["cost0"][0]
     print(f"\n{name}: converged GPU {rep_g['cost1'][0]:.9g} in {rep_g['iters'][0]} iterations / oracle {float(fx['cost1']):.9g} in {int(fx['iters'])}: rel {rel_cost:.2e} "
           f"(the oracle started again at its answer: {int(fx['again_iters'])} iterations, cost lower by {again:.2e}); camera centres {gap_al:.2e} of the map's extent after "
-          f"similarity alignment ({gap_raw:.2e} before); at the oracle's answer: S blocks {worst:.1e}, step residual {rres:.1e}; started again there: GPU {rep_a['iters'][0]} "
+          f"similarity alignment ({gap_raw:.2e} before); at the oracle's answer: residuals {resid_gap:.1e}, Jacobians {jac_gap:.1e}, reduced gradient {g_gap:.1e}, S blocks {worst:.1e}, step residual {rres:.1e}; started again there: GPU {rep_a['iters'][0]} "
           f"iterations, cost lower by {moved:.2e}, prefix K(1e-9) = {K9}, K(1e-6) = {K6}, decisions {Kdec} of {min(len(tr_a), len(tr_o))}")
     _record(name, converged=dict(cost1_gpu=rep_g["cost1"][0], cost1_oracle=float(fx["cost1"]), rel_cost=rel_cost, iters_gpu=rep_g["iters"][0], iters_oracle=int(fx["iters"]),
                                  accepted_gpu=rep_g["accepted"][0], accepted_oracle=int(fx["accepted"]), oracle_again_rel=again, oracle_again_iters=int(fx["again_iters"]),
                                  centre_gap_aligned=gap_al, centre_gap_raw=gap_raw,
-                                 at_oracle_answer=dict(worst_block_rel=worst, first_step_residual=rres, gpu_again_iters=rep_a["iters"][0], gpu_again_rel=moved,
+                                 at_oracle_answer=dict(residual_gap=resid_gap, jacobian_gap_rel=jac_gap, reduced_gradient_gap_rel=g_gap, worst_block_rel=worst, first_step_residual=rres, gpu_again_iters=rep_a["iters"][0], gpu_again_rel=moved,
                                                        K_1e9=K9, K_1e6=K6, K_decisions=Kdec, trials=int(min(len(tr_a), len(tr_o))))))
     assert rep_a["termination"][0] == 1 and rep_a["poll_timeouts"] == 0
     assert tr_a[0][3] == tr_o[0][3] and Kdec >= 3, (Kdec, tr_a[:4], tr_o[:4])

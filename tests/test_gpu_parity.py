@@ -411,13 +411,16 @@ def _full_state(gpu, rep, G):
             rep["n_bad_scene"], rep["n_bad_tfeat"], rep["n_bad_text"])
 
 
+@pytest.mark.parametrize("knob", ["pass_launches", "trial_launches"])
 @pytest.mark.parametrize("case", ["tiny", "c4", "c4_oneshot", "init", "landmarker", "no_text", "no_outlier"])
-def test_pass_boundaries_in_one_launch_agree(gpu, case):
+def test_pass_boundaries_in_one_launch_agree(gpu, case, knob):
     """A window's pass begins with k_pass_begin (participation + gauge + LM state reset + mu / sigma) and ends with k_pass_end (outlier pass + the next
     level's mu / sigma + clearing), its final state reaches the report through k_solve_end (tsba_kernels_pass.h); tsba_debug_options.pass_launches = 1
     keeps the launches of rounds 1-4 (k_pass_reset, k_participation, k_gauge_wave, k_musigma | k_outlier, state copies).  Same arithmetic: the
     reports (every per-pass field), the parameters, the flags and the LM traces are bit-identical -- resident solves, solves repeated on one upload
-    and one-shot calls (levels staged while the first pass runs) alike."""
+    and one-shot calls (levels staged while the first pass runs) alike.
+    knob = trial_launches: the same statement for k_mid inside the speculative linearisation's launch (k_lin_mid: the last workgroups of the linearisation to
+    finish take the k_mid blocks) against k_mid as a launch of its own."""
     oneshot = None
     if case == "tiny":
         P, o = synth.tiny(), abi.options_local()
@@ -431,13 +434,14 @@ def test_pass_boundaries_in_one_launch_agree(gpu, case):
         P, o = synth.landmark_refine(), abi.options_landmarker()
     elif case == "no_text":
         P, o = synth.make_problem(n_kf=9, n_pt=700, n_text=0, seed=91, feats=(16, 8, 6)), abi.options_local()
+        o.n_passes = 2; o.levels[0] = 0; o.levels[1] = 0          # (a scene-only synthetic problem has one pyramid level: two passes on it)
     else:
         P, o = synth.make_problem(n_kf=12, n_pt=900, n_text=6, seed=92, feats=(16, 8, 6)), abi.options_local()
         o.outlier_scene = o.outlier_text = 0
     runs = []
     try:
         for old in (0, 1, 0):
-            gpu.debug_set(pass_launches=old)
+            gpu.debug_set(**{knob: old})
             for rep_no in range(2):                              # twice on one upload: tsba_solve restarts from the uploaded parameters
                 G = P.copy()
                 if oneshot:
@@ -447,12 +451,12 @@ def test_pass_boundaries_in_one_launch_agree(gpu, case):
                         gpu.upload(P, o)
                     rep = gpu.solve(); gpu.download(G)
                 traces = [gpu.lm_trace(ps) for ps in range(o.n_passes)]
-                runs.append((_full_state(gpu, rep, G), G, traces))
+                runs.append((_full_state(gpu, rep, G), G, traces, rep["poll_timeouts"]))
     finally:
         gpu.debug_set()
     ref = runs[2]                                                # (the launches of rounds 1-4)
-    assert sum(ref[0][0]) > 0
-    for st, G, tr in runs:
+    assert sum(ref[0][0]) > 0 and all(r[3] == 0 for r in runs)   # (no poll ran into its bound)
+    for st, G, tr, _ in runs:
         assert st == ref[0], (st, ref[0])
         assert np.array_equal(G.pose, ref[1].pose) and np.array_equal(G.rho, ref[1].rho) and np.array_equal(G.theta, ref[1].theta)
         assert np.array_equal(G.sgood, ref[1].sgood) and np.array_equal(G.tobs_good, ref[1].tobs_good) and np.array_equal(G.tfgood, ref[1].tfgood)

@@ -88,6 +88,7 @@ struct Ctx {
     LmState *st_base = nullptr;                   // W.st / W.st_next are st_base and st_base + 1 in the order of the moment
     double *musig2[2] = {nullptr, nullptr}; int musig_sel = 0;      // mu / sigma of the text observations, two buffers: k_pass_end fills the next pass's while the outlier pass reads this one's
     int *ticket = nullptr;                        // k_pass_begin: arrival counter of its participation workgroups (zero between launches)
+    unsigned long long *lin_ticket = nullptr, lin_base = 0;      // k_lin_mid: arrivals of its workgroups over all launches since the upload (device), the same count on the host
     size_t lds_limit = 0;
     int n_cu = 0;                                 // compute units of the device
     std::vector<std::pair<std::pair<const void *, size_t>, int>> occ_cache;      // (kernel, dynamic LDS) -> workgroups of it one compute unit holds
@@ -439,6 +440,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     UP(W.tobs_kf, p->tobs_kf, p->n_tobs); UP(W.tobs_text, p->tobs_text, p->n_tobs); UP(W.tobs_fgood_off, p->tobs_fgood_off, (size_t)p->n_tobs + 1);
     AL(c->musig2[0], 2*(size_t)p->n_tobs); AL(c->musig2[1], 2*(size_t)p->n_tobs); c->musig_sel = 0; W.musig = c->musig2[0];
     AL(c->ticket, 4); W.poll0 = (unsigned int *)(c->ticket + 1);
+    AL(c->lin_ticket, 2); c->lin_base = 0;                         // (slab memory: zero)
     AL(W.kf_in, p->n_kf); AL(W.kf_const, p->n_kf); AL(W.act_pt, p->n_pt); AL(W.act_tx, p->n_text);
     AL(W.fidx, p->n_kf); AL(W.nfree, 2); AL(W.dbg, 64); AL(W.trace, 4*(size_t)TSBA_TRACE_CAP*TSBA_MAX_LEVELS); AL(W.LDbuf, 32*((size_t)p->n_kf + BAND_BW_MAX/6 + 1));     // (+ the ghost blocks of a ring map)
     // ---- plane cache (tsba_problem.kf_id): the keyframes of this call get their slots; the planes of those not seen before are staged and copied
@@ -519,7 +521,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         AL(B.w_pt, PT_REC*mx_pslot); AL(B.vdb_pt, PT_VDB*(size_t)p->n_pt);
         AL(B.w_tx, TX_REC*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
         AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.bp_loc, W.N); AL(B.dgs_p, W.N);
-        AL(B.lmpart, 3*((size_t)c->nb_back_max + mx_pair/256 + 2));
+        AL(B.lmpart, 3*((size_t)c->nb_back_max + mx_pair/MID_TW + 4));      // (one partial per k_mid block: at most n_pt / 128 + n_text / 128 + pairs / 128 + 3, and nb_back_max >= n_pt / 64 + n_text / 16)
     }
     AL(W.sig_pt, p->n_pt); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.sig_p, W.N);
     AL(W.cb, 2*(size_t)W.N + 8); AL(W.cbm, 1);
@@ -814,19 +816,32 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
         if (ne > 0) hipLaunchKernelGGL(k_far_rows, dim3((ne + 255)/256), dim3(256), 0, c->stream, W, D, ne); }
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
+// k_mid's blocks: 256 landmarks / pairs each; windows 128 (MID_TW: what a workgroup of the linearisation can take over, k_lin_mid) -- by the window's size alone,
+// so that every solver variant of a window sums the same partials
+static int mid_threads(const Ctx *c) { return c->n_kf <= SCHUR_KEEP_KF ? MID_TW : 256; }
+static void mid_blocks(const Ctx *c, const LevelDev &D, int &nb_pt, int &nb_tx, int &nb_pr) { const int t = mid_threads(c);
+    nb_pt = (c->n_pt + t - 1)/t; nb_tx = (c->n_text + t - 1)/t; nb_pr = (D.n_pair + t - 1)/t; }
 static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
 // pairs with a dozen scene blocks (large maps): four pairs per wave
 static bool lin_small_pairs(const Ctx *c, const LevelDev &D) { return !c->dbg.no_small_pairs && D.n_pair > 0 && (long long)D.n_sc <= 24LL*D.n_pair; }
 static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     struct XL { Ctx *c; size_t x0; ~XL() { c->x_lin = c->x_acc - x0; } } xl{c, c->x_acc};
     Work &W = c->W;
-    int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_pr = (D.n_pair + 255)/256, nb_kf = (c->n_kf + 255)/256;
+    int nb_pt, nb_tx, nb_pr; mid_blocks(c, D, nb_pt, nb_tx, nb_pr); const int nb_kf = (c->n_kf + 255)/256;
+    // windows, the speculative linearisation of a trial: k_mid inside the linearisation's launch (k_lin_mid: its last workgroups to finish take the k_mid blocks)
+    if (spec && W.st_next && c->lin_ticket && !c->dbg.trial_launches && !is_multi(c) && mid_threads(c) == MID_TW && D.n_pair + D.n_tg > 0 && !lin_small_pairs(c, D)) {
+        const unsigned grid = (unsigned)((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8);
+        hipLaunchKernelGGL(k_lin_mid, dim3(grid), dim3(LIN_T), 0, c->stream, W, D, nb_pt, nb_tx, nb_pt + nb_tx + nb_pr, c->lin_ticket, c->lin_base);
+        c->lin_base += grid;
+        return;
+    }
     if (D.n_pair + D.n_tg > 0) {
         if (lin_small_pairs(c, D) && D.n_tg == 0) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4, false>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
         else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
         else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
     }
-    hipLaunchKernelGGL(k_mid, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    if (mid_threads(c) == MID_TW) hipLaunchKernelGGL(k_mid<MID_TW>, dim3(nb_pt + nb_tx + nb_pr), dim3(MID_TW), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    else hipLaunchKernelGGL(k_mid<256>, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
     const int npp = pose_parts(c);
     if (multi) {
@@ -1276,7 +1291,7 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
 
 static void launch_decide(Ctx *c, const LevelDev &D) {
     Work &W = c->W;
-    const int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
+    int nb_pt, nb_tx, nb_pr; mid_blocks(c, D, nb_pt, nb_tx, nb_pr); const int nb_kf = (c->n_kf + 255)/256;
     const int nb_all = back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text) + nb_kf;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_all, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
 }
@@ -1285,7 +1300,7 @@ static void launch_decide(Ctx *c, const LevelDev &D) {
 static void launch_step(Ctx *c, const LevelDev &D, bool decide_prev = false) {
     struct XT { Ctx *c; size_t x0; ~XT() { c->x_trial = c->x_acc - x0; } } xt{c, c->x_acc};
     Work &W = c->W;
-    int nb_pt = (c->n_pt + 255)/256, nb_tx = (c->n_text + 255)/256, nb_kf = (c->n_kf + 255)/256, nb_pr = (D.n_pair + 255)/256;
+    int nb_pt, nb_tx, nb_pr; mid_blocks(c, D, nb_pt, nb_tx, nb_pr); const int nb_kf = (c->n_kf + 255)/256;
     // block-sparse S: what no block of the plan covers must read as zero.  The streaming / partitioned band solvers leave S intact and a pass
     // writes the same entries in every trial (the free poses are fixed at its start), so the band is cleared once per pass; the in-place
     // Cholesky of the wide-band path needs it before every assembly -- and so does a sharded run (a rank assembles only its own blocks; the

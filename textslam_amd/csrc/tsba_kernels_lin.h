@@ -429,7 +429,7 @@ __device__ __forceinline__ void wave_sum_groups16_mw(const double *acc, double *
 #define MID_U 4                          // slot records of a point that k_mid keeps in flight per round trip
 // TEXT = false: levels without text planes (the reference's GlobalBA): the scene path alone needs far fewer registers than the text path.
 template <int MODE, int PPW = 1, bool TEXT = true>
-__global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, LevelDev L, int spec) {
+__device__ __forceinline__ void lin_body(const Work &W, const LevelDev &L, const int spec) {
     // spec = 0: linearise at x (pass start); spec = 1: speculative linearisation at the LM candidate, into the other LinBuf
     const LmState *st = W.st;
     constexpr int NWV = LIN_T/64, TPL = LIN_TPL, LPF = 8/LIN_TPL;   // waves per workgroup; taps per lane; lanes per feature
@@ -643,29 +643,33 @@ __global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, Level
     }
 }
 
+template <int MODE, int PPW = 1, bool TEXT = true>
+__global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, LevelDev L, int spec) { lin_body<MODE, PPW, TEXT>(W, L, spec); }
+
 // ---- per landmark: V, b, host column of W (= -sum Q^T w);  per pair: host-side products.  256-thread blocks.
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int spec) {
+// NT threads per block (256; windows: 128 -- MID_TW -- so that a block is what a workgroup of k_linearize can take over, k_lin_mid below): block b takes NT
+// points / planes / pairs and leaves one partial (gradient max, |x|^2, cost) in B.lmpart.  clear_next: the block also zeroes the next trial's failure flag.
+template <int NT>
+__device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, const int nb_pt, const int nb_tx, const int spec, const int b, const bool clear_next, double *red /* [NT] */) {
     const LmState *st = W.st;
-    const int b = blockIdx.x;
     // static offsets of this thread's landmark / pair first: in flight together with the LM state
     int o = 0, e = 0, tq0 = 0, tq1 = 0, ph_ = -1, hp_ = -1, act_ = 0, pr0[MID_U] = {0, 0, 0, 0};
-    if (b < nb_pt) { const int j = b*256 + threadIdx.x; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
+    if (b < nb_pt) { const int j = b*NT + threadIdx.x; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
 #pragma unroll
         for (int u = 0; u < MID_U; u++) pr0[u] = L.pt_pair4[MID_U*(size_t)j + u]; } }
-    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*256 + threadIdx.x; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
-    else { const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x; if (p < L.n_pair) { tq0 = L.pair_tg_off[p]; tq1 = L.pair_tg_off[p+1]; ph_ = L.pair_h[p]; hp_ = L.pair_hpos[p]; } }
-    if (W.st_next && b == 0 && threadIdx.x == 0) W.st_next->step_fail = 0;      // (the next trial's k_schur_t takes this trial's decision into that copy of the state, every field but this one: its own workgroups may raise it)
+    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*NT + threadIdx.x; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
+    else { const int p = (b - nb_pt - nb_tx)*NT + threadIdx.x; if (p < L.n_pair) { tq0 = L.pair_tg_off[p]; tq1 = L.pair_tg_off[p+1]; ph_ = L.pair_h[p]; hp_ = L.pair_hpos[p]; } }
+    if (clear_next && W.st_next && b == 0 && threadIdx.x == 0) W.st_next->step_fail = 0;      // (the next trial's k_schur_t takes this trial's decision into that copy of the state, every field but this one: its own workgroups may raise it)
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
     const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
     const int sel = spec ? (st->cur ^ 1) : st->cur;
-    __shared__ double red[256];
     const double *rho_x = W.rho[sel], *theta_x = W.theta[sel];
     double gm = 0.0, xn = 0.0, cs = 0.0;                        // cs: cost of this thread's pair and of its text groups
     if (b < nb_pt) {
-        const int j = b*256 + threadIdx.x;
+        const int j = b*NT + threadIdx.x;
         if (e > o) {
             double acc[8] = {0,0,0,0,0,0,0,0};                       // V, b, host column -sum Q^T w
             for (int s0 = o; s0 < e - 1; s0 += MID_U) {              // MID_U slot records (and their pairs' R_cr) in flight per round trip
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             if (act_) { gm = fabs(acc[1]); xn = rho_x[j]*rho_x[j]; }
         }
     } else if (b < nb_pt + nb_tx) {
-        const int j = (b - nb_pt)*256 + threadIdx.x;
+        const int j = (b - nb_pt)*NT + threadIdx.x;
         if (e > o) {
             double acc[27];                                          // V6, b3, host column -blkdiag(R,R)^T W (18)
 #pragma unroll
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             if (act_) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(acc[6 + k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
         }
     } else {
-        const int p = (b - nb_pt - nb_tx)*256 + threadIdx.x;
+        const int p = (b - nb_pt - nb_tx)*NT + threadIdx.x;
         if (p < L.n_pair) {
             double M[21], c[6];
 #pragma unroll
@@ -795,10 +799,46 @@ __global__ __launch_bounds__(256) void k_mid(Work W, LevelDev L, int nb_pt, int 
             }
         }
     }
-    gm = block_max<256>(gm, red); xn = block_sum<256>(xn, red);
-    if (b >= nb_pt + nb_tx) cs = block_sum<256>(cs, red);       // (uniform) the cost as per-block partials: k_postlin / k_decide add a few hundred
+    gm = block_max<NT>(gm, red); xn = block_sum<NT>(xn, red);
+    if (b >= nb_pt + nb_tx) cs = block_sum<NT>(cs, red);       // (uniform) the cost as per-block partials: k_postlin / k_decide add a few hundred
                                                                 // numbers instead of walking 40 k pairs at 5000 keyframes (50 us of one workgroup)
     if (threadIdx.x == 0) { B.lmpart[3*b] = gm; B.lmpart[3*b + 1] = xn; B.lmpart[3*b + 2] = cs; }
+}
+#define MID_TW 128
+template <int NT>
+__global__ __launch_bounds__(NT) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int spec) {
+    __shared__ double red[NT];
+    mid_block<NT>(W, L, nb_pt, nb_tx, spec, (int)blockIdx.x, true, red);
+}
+
+// ---- windows: the speculative linearisation of an LM trial and k_mid in ONE launch.  k_mid as a launch of its own was 10.6 us per trial on C4: a launch, the
+// state's round trip, the offsets' round trip, and only then its two rounds of records.  Here every workgroup of the linearisation takes a ticket when its
+// outputs are stored (fence, then one atomic on a counter that only ever grows: `base` is its value before this launch -- the host keeps count --, so nothing is
+// ever reset); the LAST nb_lm arrivals stay: each requests the static offsets of "its" k_mid block, waits until the counter says that all n workgroups have
+// stored (they are its own launch's earlier finishers: running or done, whatever the dispatch order -- nobody waits for a workgroup that has not started),
+// fences and runs the block.  Same block size as k_mid<MID_TW>, same sums in the same order: bit-identical to the two launches
+// (tsba_debug_options.trial_launches = 1).  A wait that outlasts its bound (other work holding the last workgroups off the device for tens of ms) is
+// counted and fails the step, as every give-up does.
+#define LM_SPIN_MAX (1 << 16)
+__global__ __launch_bounds__(LIN_T, 2) void k_lin_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int nb_lm, unsigned long long *ticket, unsigned long long base) {
+    static_assert(LIN_T == MID_TW, "a workgroup of the linearisation takes over a k_mid block");
+    __shared__ double red[MID_TW]; __shared__ long long s_rank;
+    const int tid = threadIdx.x;
+    if (W.st_next && blockIdx.x == 0 && tid == 0) W.st_next->step_fail = 0;      // (what k_mid's block 0 does: the next trial's failure flag starts clear)
+    lin_body<MODE_FULL, 1, true>(W, L, 1);
+    __syncthreads();                                            // (every wave's stores are issued; a wave that left lin_body early is here too)
+    if (tid == 0) { __threadfence(); s_rank = (long long)(atomicAdd(ticket, 1ull) - base); }
+    __syncthreads();
+    const long long n = gridDim.x, m = nb_lm < n ? nb_lm : n, first = s_rank - (n - m);
+    if (first < 0) return;
+    if (tid == 0) {
+        unsigned long long v = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spins = 0; v - base < (unsigned long long)n && spins < LM_SPIN_MAX; spins++) { __builtin_amdgcn_s_sleep(2); v = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (v - base < (unsigned long long)n) { atomicAdd(&ts_poll_giveups, 1u); if (W.st_next) W.st_next->step_fail = 1; }
+    }
+    __syncthreads();
+    __threadfence();                                            // (the other workgroups' records)
+    for (long long b = first; b < nb_lm; b += m) { mid_block<MID_TW>(W, L, nb_pt, nb_tx, 1, (int)b, false, red); __syncthreads(); }
 }
 
 // ---- after a linearisation (256 threads of one block), in two stages so that a multi-GPU run can all-reduce in between:
