@@ -75,7 +75,7 @@ typedef struct tsba_debug_options {
     int32_t sv_per_level;      // bit 0: the separator tree of the single-vector solve phase as one launch per level (k_sv_cre_fwd / _top / _back, production until round 4) instead of one launch for the whole tree (k_sv_cre_tree); bit 1: the back substitution of the factorisation's own solve on maps with long-range blocks as a launch per level (k_cre_back) instead of one launch through the solve phase's products (k_cre_back_tree); bit 2: the update step of a conjugate-gradient iteration (alpha; x, r) as a launch of its own (k_pcg_update) instead of inside the first kernel of the preconditioner application; bit 3: the interiors' back substitution of the solve phase as a launch of its own (k_sv_back_int) instead of in the tree's launch (k_sv_tree_back): A/B runs, bit-identity / parity tests
     int32_t host_pair_lists;   // 1: large maps build the slot pairs of the S blocks on the host (as every map did until round 4) instead of on the device (tsba_devplan.h): A/B runs, list comparison
     int32_t pass_launches;     // 1: a window's pass begins and ends with the launches of rounds 1-4 (k_pass_reset, k_participation, k_gauge_wave, k_musigma | k_outlier, state copy) instead of k_pass_begin | k_pass_end (tsba_kernels_pass.h): A/B runs, bit-identity tests
-    int32_t trial_launches;    // windows: 0 production; 1: k_mid as a launch of its own (production until round 5) instead of in k_linearize's launch, polling that launch's records (bit-identical)
+    int32_t trial_launches;    // windows: 0 production (k_linearize, k_mid<256> as two launches); 2: the round-5 experiment k_lin_mid -- k_mid inside the speculative linearisation's launch, its last workgroups to finish taking k_mid's blocks of 128 -- measured SLOWER (40.7 against 13.4 + 10.6 us: 736 workgroups signalling completion cost more than the kernel boundary); 1: the two launches with k_mid's blocks of 128 (the experiment's bit-identical comparison partner)
     int32_t assume_cus;        // > 0: the residency test of the kernels whose workgroups poll each other (k_solve_back, k_sv_cre_tree, k_sv_tree_back, k_cre_back_tree) assumes a device of this many compute units (tests: a device too small for the grid takes the launch-per-step path)
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */

@@ -314,9 +314,20 @@ def test_converged_answers_against_the_oracle(gpu, oracle_lib, map_cache, name):
     o1 = _options(name)
     eo, eg = oracle_lib.evaluate(Q, o1, 0), gpu.evaluate(Q, o1, 0)
     assert (eo["ns"], eo["nt"]) == (eg["ns"], eg["nt"]) and eo["ns"] > 400000
-    resid_gap = float(np.abs(eg["resid"] - eo["resid"]).max())
-    jac_gap = float(np.abs(eg["jac_scene"] - eo["jac_scene"]).max()/np.abs(eo["jac_scene"]).max())
-    assert resid_gap <= 1e-9 and jac_gap <= 1e-10, (resid_gap, jac_gap)
+    # Block by block, relative to the block's own magnitude.  After 231 iterations the 5 % outlier observations have pushed a handful of points to where one of
+    # their cameras sees them at almost zero depth AND almost on the optical axis: Jacobian entries of 1e9 .. 1e12 on a residual of 1e-5 .. 1e3 pixels (open
+    # chain: one block at 1.2e12, its residual moves by 8e-6 when the translations are scaled by 1 + 2e-16).  Those blocks -- max |J| > 1e6, counted and
+    # recorded -- are compared to 1e-3; every other block to 1e-9.
+    ro, rg = eo["resid"].reshape(-1, 2), eg["resid"].reshape(-1, 2)
+    Jo, Jg = eo["jac_scene"].reshape(eo["ns"], -1), eg["jac_scene"].reshape(eo["ns"], -1)
+    jmax = np.abs(Jo).max(1); ill = jmax > 1e6
+    rgap = np.abs(rg - ro).max(1)/np.maximum(1.0, np.abs(ro).max(1)); jgap = np.abs(Jg - Jo).max(1)/np.maximum(1.0, jmax)
+    resid_gap, jac_gap = float(rgap[~ill].max()), float(jgap[~ill].max())
+    ill_resid_gap, ill_jac_gap = (float(rgap[ill].max()), float(jgap[ill].max())) if ill.any() else (0.0, 0.0)
+    print(f"\n{name}: at the oracle's answer {int(ill.sum())} of {len(ill)} blocks have Jacobian entries above 1e6 (largest {jmax.max():.3g}): residuals {ill_resid_gap:.1e}, Jacobians {ill_jac_gap:.1e}; "
+          f"all other blocks: residuals {resid_gap:.1e}, Jacobians {jac_gap:.1e}")
+    assert resid_gap <= 1e-9 and jac_gap <= 1e-9, (resid_gap, jac_gap)
+    assert int(ill.sum()) <= 100 and ill_resid_gap <= 1e-3 and ill_jac_gap <= 1e-3, (int(ill.sum()), ill_resid_gap, ill_jac_gap)
     gpu.upload(Q, o1)
     ob, worst, rres, g_gap = compare_first_linearisation(gpu, oracle_lib, Q, o1, direct=False, measure_only=True)
     assert abs(ob["cost"] - float(fx["cost1"])) <= 1e-12*float(fx["cost1"])
@@ -339,7 +350,7 @@ def test_converged_answers_against_the_oracle(gpu, oracle_lib, map_cache, name):
     _record(name, converged=dict(cost1_gpu=rep_g["cost1"][0], cost1_oracle=float(fx["cost1"]), rel_cost=rel_cost, iters_gpu=rep_g["iters"][0], iters_oracle=int(fx["iters"]),
                                  accepted_gpu=rep_g["accepted"][0], accepted_oracle=int(fx["accepted"]), oracle_again_rel=again, oracle_again_iters=int(fx["again_iters"]),
                                  centre_gap_aligned=gap_al, centre_gap_raw=gap_raw,
-                                 at_oracle_answer=dict(residual_gap=resid_gap, jacobian_gap_rel=jac_gap, reduced_gradient_gap_rel=g_gap, worst_block_rel=worst, first_step_residual=rres, gpu_again_iters=rep_a["iters"][0], gpu_again_rel=moved,
+                                 at_oracle_answer=dict(residual_gap=resid_gap, jacobian_gap_rel=jac_gap, ill_conditioned_blocks=int(ill.sum()), ill_residual_gap=ill_resid_gap, ill_jacobian_gap_rel=ill_jac_gap, reduced_gradient_gap_rel=g_gap, worst_block_rel=worst, first_step_residual=rres, gpu_again_iters=rep_a["iters"][0], gpu_again_rel=moved,
                                                        K_1e9=K9, K_1e6=K6, K_decisions=Kdec, trials=int(min(len(tr_a), len(tr_o))))))
     assert rep_a["termination"][0] == 1 and rep_a["poll_timeouts"] == 0
     assert tr_a[0][3] == tr_o[0][3] and Kdec >= 3, (Kdec, tr_a[:4], tr_o[:4])

@@ -419,8 +419,8 @@ def test_pass_boundaries_in_one_launch_agree(gpu, case, knob):
     keeps the launches of rounds 1-4 (k_pass_reset, k_participation, k_gauge_wave, k_musigma | k_outlier, state copies).  Same arithmetic: the
     reports (every per-pass field), the parameters, the flags and the LM traces are bit-identical -- resident solves, solves repeated on one upload
     and one-shot calls (levels staged while the first pass runs) alike.
-    knob = trial_launches: the same statement for k_mid inside the speculative linearisation's launch (k_lin_mid: the last workgroups of the linearisation to
-    finish take the k_mid blocks) against k_mid as a launch of its own."""
+    knob = trial_launches: the same statement for the round-5 experiment k_lin_mid (k_mid inside the speculative linearisation's launch: the last workgroups of the
+    linearisation to finish take the k_mid blocks; measured slower and off by default) against k_mid as a launch of its own with the same block size."""
     oneshot = None
     if case == "tiny":
         P, o = synth.tiny(), abi.options_local()
@@ -441,7 +441,7 @@ def test_pass_boundaries_in_one_launch_agree(gpu, case, knob):
     runs = []
     try:
         for old in (0, 1, 0):
-            gpu.debug_set(**{knob: old})
+            gpu.debug_set(**{knob: (old if knob == "pass_launches" else 2 - old)})       # (trial_launches: 2 = the k_lin_mid experiment, 1 = its two-launch partner)
             for rep_no in range(2):                              # twice on one upload: tsba_solve restarts from the uploaded parameters
                 G = P.copy()
                 if oneshot:

@@ -816,9 +816,9 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
         if (ne > 0) hipLaunchKernelGGL(k_far_rows, dim3((ne + 255)/256), dim3(256), 0, c->stream, W, D, ne); }
     if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
-// k_mid's blocks: 256 landmarks / pairs each; windows 128 (MID_TW: what a workgroup of the linearisation can take over, k_lin_mid) -- by the window's size alone,
-// so that every solver variant of a window sums the same partials
-static int mid_threads(const Ctx *c) { return c->n_kf <= SCHUR_KEEP_KF ? MID_TW : 256; }
+// k_mid's blocks: 256 landmarks / pairs each.  tsba_debug_options.trial_launches = 1 / 2 (the k_lin_mid experiment and its comparison partner): 128 (MID_TW: what a
+// workgroup of the linearisation can take over)
+static int mid_threads(const Ctx *c) { return (c->dbg.trial_launches == 1 || c->dbg.trial_launches == 2) && c->n_kf <= SCHUR_KEEP_KF ? MID_TW : 256; }
 static void mid_blocks(const Ctx *c, const LevelDev &D, int &nb_pt, int &nb_tx, int &nb_pr) { const int t = mid_threads(c);
     nb_pt = (c->n_pt + t - 1)/t; nb_tx = (c->n_text + t - 1)/t; nb_pr = (D.n_pair + t - 1)/t; }
 static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
@@ -828,8 +828,10 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     struct XL { Ctx *c; size_t x0; ~XL() { c->x_lin = c->x_acc - x0; } } xl{c, c->x_acc};
     Work &W = c->W;
     int nb_pt, nb_tx, nb_pr; mid_blocks(c, D, nb_pt, nb_tx, nb_pr); const int nb_kf = (c->n_kf + 255)/256;
-    // windows, the speculative linearisation of a trial: k_mid inside the linearisation's launch (k_lin_mid: its last workgroups to finish take the k_mid blocks)
-    if (spec && W.st_next && c->lin_ticket && !c->dbg.trial_launches && !is_multi(c) && mid_threads(c) == MID_TW && D.n_pair + D.n_tg > 0 && !lin_small_pairs(c, D)) {
+    // EXPERIMENT, off by default (trial_launches = 2): k_mid inside the speculative linearisation's launch (k_lin_mid: its last workgroups to finish take the k_mid
+    // blocks).  Measured in round 5: 40.7 us per launch against 13.4 + 10.6 us for the two launches -- 736 workgroups telling each other that they are done costs
+    // more than the kernel boundary it replaces (tools/ticket_bench.hip)
+    if (spec && W.st_next && c->lin_ticket && c->dbg.trial_launches == 2 && !is_multi(c) && mid_threads(c) == MID_TW && D.n_pair + D.n_tg > 0 && !lin_small_pairs(c, D)) {
         const unsigned grid = (unsigned)((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8);
         hipLaunchKernelGGL(k_lin_mid, dim3(grid), dim3(LIN_T), 0, c->stream, W, D, nb_pt, nb_tx, nb_pt + nb_tx + nb_pr, c->lin_ticket, c->lin_base);
         c->lin_base += grid;
@@ -1371,9 +1373,11 @@ int tsba_solve(void *ctx, tsba_report *r) {
             // observations' mu / sigma are there already if the last pass's k_pass_end computed them for this level
             c->cur_bw_rows = D.bw_rows; c->S_stale = true; c->x_pass = 0;
             c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq; c->W.trace_pass = ps;
-            const int npb = (D.n_sc + 255)/256 + (D.n_tg + 3)/4, n_ms = ms_ahead == ps ? 0 : D.n_tg;
-            hipLaunchKernelGGL(k_pass_begin, dim3(npb + n_ms), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial, o.state,
-                               npb, n_ms, log_pending ? c->st_log + ps - 1 : (LmState *)nullptr, c->ticket);
+            // (at most PB_WG workgroups walk k_participation's npb blocks: every arrival at the ticket is a device-wide fence and an atomic on one word --
+            // 30 - 40 ns each, one after the other: tools/ticket_bench.hip)
+            const int npb = (D.n_sc + 255)/256 + (D.n_tg + 3)/4, nwg = std::min(npb, PB_WG), n_ms = ms_ahead == ps ? 0 : D.n_tg;
+            hipLaunchKernelGGL(k_pass_begin, dim3(nwg + n_ms), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial, o.state,
+                               npb, nwg, n_ms, log_pending ? c->st_log + ps - 1 : (LmState *)nullptr, c->ticket);
             log_pending = false;
         } else {
             if (log_pending) { CK(hipMemcpyAsync(c->st_log + ps - 1, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream)); log_pending = false; }

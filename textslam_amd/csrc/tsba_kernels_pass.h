@@ -4,9 +4,9 @@
 // k_gauge_wave, k_musigma -- and to end with k_outlier and a device-to-device copy of the LM state; the solve ended with a device-to-host copy.  On a
 // 20-keyframe window each of them is a launch, a round trip or two and no work to speak of (41 + 20 us per pass, three passes per solve).  Here:
 //
-//   k_pass_begin   workgroups [0, npb): k_participation's (good flags -> which landmarks / keyframes take part, block counts); the LAST of them to finish
+//   k_pass_begin   workgroups [0, nwg): k_participation's blocks, taken in turn (good flags -> which landmarks / keyframes take part, block counts); the LAST of them to finish
 //                  (ticket) keeps the previous pass's final state for the report, resets the LM state and fixes the gauge (k_gauge_wave's ballots);
-//                  workgroups [npb, npb + n_ms): the text observations' mu / sigma (k_musigma) -- unless the previous pass's k_pass_end has computed them
+//                  workgroups [nwg, nwg + n_ms): the text observations' mu / sigma (k_musigma) -- unless the previous pass's k_pass_end has computed them
 //   k_pass_end     the outlier pass (four of k_outlier's waves per workgroup)  |  mu / sigma of the NEXT pass's level at the final parameters of this one
 //                  (into the other of two buffers: the outlier pass still reads this level's)  |  one workgroup that clears the participation arrays
 //   k_solve_end    the passes' final states -> pinned host memory (no copy engine, no staging)
@@ -32,13 +32,14 @@ __device__ __forceinline__ void gauge_wave_body(const Work &W, const uint8_t *kf
     if (k == 0) { W.nfree[0] = __popcll(m_free); W.nfree[1] = 0; }
 }
 
+#define PB_WG 24                            // workgroups that walk k_participation's blocks in k_pass_begin
 __global__ __launch_bounds__(MS_THREADS) void k_pass_begin(Work W, LevelDev L, double radius0, int max_it, const uint8_t *kf_initial, int state,
-                                                           int npb, int n_ms, LmState *log_prev, int *ticket) {
+                                                           int npb, int nwg, int n_ms, LmState *log_prev, int *ticket) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (b >= npb) { if (b - npb < n_ms) musigma_wg(W, L, b - npb, W.pose[W.st->cur], W.theta[W.st->cur]); return; }
-    participation_wg(W, L, b, 1);
+    if (b >= nwg) { if (b - nwg < n_ms) musigma_wg(W, L, b - nwg, W.pose[W.st->cur], W.theta[W.st->cur]); return; }
+    for (int vb = b; vb < npb; vb += nwg) { participation_wg(W, L, vb, 1); __syncthreads(); }       // (k_participation's block vb: its partial counts go to cntpart[vb])
     __shared__ int s_last; __shared__ int s_cnt2[2];
-    if (tid == 0) { __threadfence(); s_last = atomicAdd(ticket, 1) == npb - 1; s_cnt2[0] = 0; s_cnt2[1] = 0; }
+    if (tid == 0) { __threadfence(); s_last = atomicAdd(ticket, 1) == nwg - 1; s_cnt2[0] = 0; s_cnt2[1] = 0; }
     __syncthreads();
     if (!s_last) return;
     __threadfence();                                              // (the other workgroups' flags and counts)

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from textslam_amd import synth, abi
 from textslam_amd.optimizer import Optimizer
 
-DEFAULT = ["production=", "ldl_scratch=solve_variant:5", "pass_launches=pass_launches:1", "mid_own_launch=trial_launches:1", "round4=solve_variant:5,pass_launches:1,trial_launches:1",
+DEFAULT = ["production=", "ldl_scratch=solve_variant:5", "pass_launches=pass_launches:1", "lin_mid_fused=trial_launches:2", "round4=solve_variant:5,pass_launches:1",
            "separate_launches=solve_variant:3"]
 
 
