@@ -77,6 +77,7 @@ typedef struct tsba_debug_options {
     int32_t pass_launches;     // 1: a window's pass begins and ends with the launches of rounds 1-4 (k_pass_reset, k_participation, k_gauge_wave, k_musigma | k_outlier, state copy) instead of k_pass_begin | k_pass_end (tsba_kernels_pass.h): A/B runs, bit-identity tests
     int32_t trial_launches;    // windows: 0 production (k_linearize, k_mid<256> as two launches); 2: the round-5 experiment k_lin_mid -- k_mid inside the speculative linearisation's launch, its last workgroups to finish taking k_mid's blocks of 128 -- measured SLOWER (40.7 against 13.4 + 10.6 us: 736 workgroups signalling completion cost more than the kernel boundary); 1: the two launches with k_mid's blocks of 128 (the experiment's bit-identical comparison partner)
     int32_t assume_cus;        // > 0: the residency test of the kernels whose workgroups poll each other (k_solve_back, k_sv_cre_tree, k_sv_tree_back, k_cre_back_tree) assumes a device of this many compute units (tests: a device too small for the grid takes the launch-per-step path)
+    int32_t lds_poison;        // 1 / 2 / 3: before every launch of tsba_solve the LDS of every compute unit is filled with NaNs / 1e300 / 0x5a bytes (what another context's kernels may leave there): results must not change
 } tsba_debug_options;
 int  tsba_debug_set(void *ctx, const tsba_debug_options *d);   /* d == NULL: back to production behaviour; applies to the next upload */
 

@@ -100,10 +100,43 @@ def test_open_chain_beside_a_busy_context(gpu, map_cache):
     with _Busy() as busy:
         while busy.runs < 2:
             pass
-        for _ in range(3):
+        for _ in range(25):                                          # (round 5: 1 run in 15 differed before the siblings of a cyclic-reduction pivot waited for each other's loads, k_cre_elim)
             beside = _solve(gpu, P, o, 1)
             assert beside[0]["poll_timeouts"] == 0, beside[0]
             _same(beside, alone)
+
+
+@pytest.mark.parametrize("case", ["c4", "window_31", "pose", "open_chain", "long_range", "ring", "c5", "dense_100"])
+def test_results_do_not_depend_on_what_other_kernels_left_in_lds(gpu, map_cache, case):
+    """What a kernel finds in LDS is whatever the last workgroup on that compute unit left there: this context's own kernels when the device is otherwise idle
+    (the same bytes every run -- a read of never-written LDS goes unnoticed), another context's next to it.  tsba_debug_options.lds_poison fills the LDS of every
+    compute unit with NaNs / 1e300 / 0x5a bytes before EVERY launch of the solve: same traces, same parameters, bit for bit."""
+    its = None
+    if case == "c4":
+        P, o = synth.config_c4(), abi.options_local()
+    elif case == "window_31":
+        P, o = synth.make_problem(n_kf=31, n_pt=1800, n_text=15, seed=71, feats=(16, 8, 6)), abi.options_local()
+    elif case == "pose":
+        P, o = synth.config_c3(), abi.options_pose()
+    elif case == "c5":
+        P, o, its = map_cache(n_kf=500, n_pt=50000, band=12), abi.options_global(), 4
+    elif case == "dense_100":
+        P, o, its = synth.config_global(n_kf=100, n_pt=3000, band=100), abi.options_global(), 4
+    else:
+        kw = dict(open_chain={}, long_range=dict(far_frac=0.01), ring=dict(loop=True))[case]
+        P, o, its = map_cache(n_kf=5000, n_pt=70000, band=10, **kw), abi.options_global(), 3
+    if its:
+        o.its[0] = its
+    runs = []
+    try:
+        for pz in (0, 1, 2, 3):
+            gpu.debug_set(lds_poison=pz)
+            runs.append(_solve(gpu, P, o, o.n_passes))
+    finally:
+        gpu.debug_set()
+    for r in runs[1:]:
+        assert r[0]["poll_timeouts"] == 0
+        _same(r, runs[0])
 
 
 @pytest.mark.parametrize("case", ["window", "long_range", "open_chain"])

@@ -94,7 +94,7 @@ class TsbaDebugOptions(C.Structure):
         ("band_parts", C.c_int32), ("sep_solver", C.c_int32), ("no_band_stream", C.c_int32), ("no_pose_kernel", C.c_int32),
         ("no_small_pairs", C.c_int32), ("verbose", C.c_int32), ("no_kf_reorder", C.c_int32), ("no_schur_quad", C.c_int32), ("no_ring", C.c_int32),
         ("far_solver", C.c_int32), ("pcg_max_it", C.c_int32), ("pcg_tol_exp", C.c_int32), ("pcg_refactor", C.c_int32), ("pcg_block", C.c_int32), ("solve_variant", C.c_int32), ("sv_per_level", C.c_int32), ("host_pair_lists", C.c_int32),
-        ("pass_launches", C.c_int32), ("trial_launches", C.c_int32), ("assume_cus", C.c_int32),
+        ("pass_launches", C.c_int32), ("trial_launches", C.c_int32), ("assume_cus", C.c_int32), ("lds_poison", C.c_int32),
     ]
 
 

@@ -53,6 +53,24 @@
 #include "tsba_kernels_step.h"
 #include "tsba_kernels_pass.h"
 #include "tsba_devplan.h"
+// ---- LDS hygiene (tests): what a kernel finds in LDS is whatever the last workgroup on that compute unit left -- its own context's kernels when the device is
+// otherwise idle (the same bytes every run: a read of never-written LDS goes unnoticed), another context's next to it (TextSLAM extracts ORB features while
+// a bundle adjustment runs).  tsba_debug_options.lds_poison = 1 / 2 / 3 fills the LDS of every compute unit with NaNs / 1e300 / 0x5a bytes before EVERY launch
+// of a solve: a kernel that reads what it has not written shows up as a changed result (tests/test_gpu_polling.py).
+__global__ __launch_bounds__(256) void k_lds_poison(int pattern, int ndbl) {
+    extern __shared__ __attribute__((aligned(16))) double pz[];
+    const double v = pattern == 1 ? __longlong_as_double(0x7ff8000000000000LL) : pattern == 2 ? 1e300 : __longlong_as_double(0x5a5a5a5a5a5a5a5aLL);
+    for (int k = threadIdx.x; k < ndbl; k += 256) pz[k] = v;
+    __syncthreads();
+    for (int k = 0; k < 40; k++) __builtin_amdgcn_s_sleep(127);      // (~2 us: long enough for every compute unit to be handed one of the workgroups)
+}
+static thread_local int g_lds_poison = 0;
+static void lds_poison_hook(hipStream_t st) {
+    if (!g_lds_poison) return;
+    static std::once_flag once; std::call_once(once, [] { hipFuncSetAttribute((const void *)k_lds_poison, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256); });
+    hipLaunchKernelGGL(k_lds_poison, dim3(1024), dim3(256), 160*1024 - 256, st, g_lds_poison, (160*1024 - 256)/8);
+}
+#define LAUNCHK(kern, grid, block, lds, st, ...) do { lds_poison_hook(st); hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__); } while (0)
 // ------------------------------------------------------------------------------------------------ host side
 static int pose_grid(const LevelDev &D) { return std::max(1, (D.n_sc + 255)/256 + (D.n_pf + 31)/32); }    // workgroups of k_pose_iter
 struct DevBuf {
@@ -101,7 +119,7 @@ struct Ctx {
     bool S_stale = true;                            // band storage: entries of another pass may be left in S (cleared before the next assembly)
     double *S_xchg = nullptr; int xchg_wp = 0;      // multi-GPU, band storage: packed band rows for the exchange (k_band_pack)
     bool sep_cr = false;                  // separator system by cyclic reduction on the compact block pool (tsba_bandcr.h)
-    int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Bpart = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr, *CRcontrib = nullptr, *CRfac = nullptr; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
+    int band_parts = 1; double *Lb = nullptr, *Tbuf = nullptr, *Bpart = nullptr, *Ssep = nullptr, *Lcol_sep = nullptr, *CRcontrib = nullptr, *CRfac = nullptr; int *CRgate = nullptr; int cre_epoch = 0; int nsep_ld = 0; Work Wsep;   // partitioned band solver (tsba_bandp.h)
     double *Lcol = nullptr; int band_stream = 0;  // streaming band solver (tsba_band.h): L by block column; 1 = every built level fits it     // storage behind W.S (dense or band)
     float *lbl_dev = nullptr, *lbl_host = nullptr; size_t lbl_cap = 0;   // text label image staging
     unsigned long long *hprog = nullptr; unsigned int pass_seq = 0;   // pinned progress word written by k_postlin / k_decide
@@ -598,7 +616,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
                 AL(c->Lb, ((size_t)p->n_kf + bwmax/6 + 1)*bwmax*6); AL(c->Tbuf, (size_t)P*((size_t)4*bwmax*bwmax + 2*bwmax));
                 AL(c->Bpart, (size_t)P*BANDP_NS*((size_t)bwmax*bwmax + bwmax));
                 c->sep_cr = want_cr && P >= 4;
-                if (c->sep_cr) { AL(c->Ssep, cr_pool_blocks(nsepb)*(size_t)bwmax*bwmax); AL(c->CRcontrib, (size_t)nsepb*cre_contrib_doubles(bwmax)); AL(c->CRfac, (size_t)nsepb*cre_rec_doubles(bwmax)); }
+                if (c->sep_cr) { AL(c->Ssep, cr_pool_blocks(nsepb)*(size_t)bwmax*bwmax); AL(c->CRcontrib, (size_t)nsepb*cre_contrib_doubles(bwmax)); AL(c->CRfac, (size_t)nsepb*cre_rec_doubles(bwmax)); AL(c->CRgate, (size_t)(nsepb + 2)*TSBA_CRE_KMAX); c->cre_epoch = 0; }
                 else AL(c->Ssep, (size_t)nsep*nsep + nsep);
                 AL(c->Lcol_sep, (size_t)(nsep/6 + 1)*bws*6);
                 Work &Ws = c->Wsep; memset(&Ws, 0, sizeof(Ws));
@@ -703,9 +721,9 @@ static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, dou
     if (H.dev_pt_pairs >= 0 && D.n_sb > 0) {                       // (after the copies it reads, on the stream they went over)
         hipStream_t sq = c->stage_async && c->copy_stream ? c->copy_stream : c->stream;
         hipMemsetAsync(dp_off, 0, sizeof(int)*((size_t)D.n_sb + 2), sq);
-        hipLaunchKernelGGL(k_sb_pairs<0>, dim3(D.n_sb), dim3(64), 0, sq, D.n_sb, D.sb_a, D.sb_b, D.pose_ps_off, D.pose_ps, D.pose_ps_lm, D.pls_off, D.pslot_pose, (const int *)dp_cl, dp_off, dp_s1, dp_s2, dp_lm);
-        hipLaunchKernelGGL(k_sb_scan, dim3(1), dim3(1024), 0, sq, D.n_sb, dp_off);
-        hipLaunchKernelGGL(k_sb_pairs<1>, dim3(D.n_sb), dim3(64), 0, sq, D.n_sb, D.sb_a, D.sb_b, D.pose_ps_off, D.pose_ps, D.pose_ps_lm, D.pls_off, D.pslot_pose, (const int *)dp_cl, dp_off, dp_s1, dp_s2, dp_lm);
+        LAUNCHK(k_sb_pairs<0>, dim3(D.n_sb), dim3(64), 0, sq, D.n_sb, D.sb_a, D.sb_b, D.pose_ps_off, D.pose_ps, D.pose_ps_lm, D.pls_off, D.pslot_pose, (const int *)dp_cl, dp_off, dp_s1, dp_s2, dp_lm);
+        LAUNCHK(k_sb_scan, dim3(1), dim3(1024), 0, sq, D.n_sb, dp_off);
+        LAUNCHK(k_sb_pairs<1>, dim3(D.n_sb), dim3(64), 0, sq, D.n_sb, D.sb_a, D.sb_b, D.pose_ps_off, D.pose_ps, D.pose_ps_lm, D.pls_off, D.pslot_pose, (const int *)dp_cl, dp_off, dp_s1, dp_s2, dp_lm);
     }
     if (c->stage_async && c->copy_stream && c->ev_stage[l]) { hipEventRecord(c->ev_stage[l], c->copy_stream); c->lev_wait[l] = 1; }      // the level's pass waits for this copy
     c->lev_built[l] = 1;
@@ -729,7 +747,7 @@ static int reset_state(Ctx *c) {                 // one launch instead of ten sm
                    (long long)7*c->n_kf, (long long)c->n_pt, (long long)3*c->n_text, (long long)c->n_sgood, (long long)c->n_tobs, (long long)c->n_tfgood };
     long long mx = std::max(std::max(A.n_pose, A.n_rho), std::max(std::max(A.n_theta, A.n_sg), std::max(A.n_tg, A.n_tf)));
     const int nb = (int)std::min<long long>(1024, std::max<long long>(1, (mx + 255)/256));
-    hipLaunchKernelGGL(k_reset_state, dim3(nb), dim3(256), 0, c->stream, W, A);
+    LAUNCHK(k_reset_state, dim3(nb), dim3(256), 0, c->stream, W, A);
     return 0;
 }
 
@@ -799,22 +817,22 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
     c->cur_bw_rows = D.bw_rows; c->S_stale = true;             // (a new pass: other free poses, other entries of S)
     c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq; c->W.trace_pass = pass;
     Work &W = c->W; const tsba_options &o = c->opt;
-    hipLaunchKernelGGL(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
+    LAUNCHK(k_pass_reset, dim3(64), dim3(256), 0, c->stream, W, o.initial_radius, o.its[pass]);
     int n = D.n_sc + D.n_tg;
     const int npb = (D.n_sc + 255)/256 + (D.n_tg + 3)/4;                    // k_participation workgroups: scene candidates | text groups
     const int ncp = (n > 0 && !is_multi(c)) ? npb : 0;                      // count partials (single GPU)
-    if (n > 0) hipLaunchKernelGGL(k_participation, dim3(npb), dim3(256), 0, c->stream, W, D, ncp ? 1 : 0);
+    if (n > 0) LAUNCHK(k_participation, dim3(npb), dim3(256), 0, c->stream, W, D, ncp ? 1 : 0);
     if (is_multi(c)) {                             // participation and block counts are global properties
         allreduce(c, W.kf_in, c->n_kf, ncclInt32, ncclSum);
         allreduce(c, &W.st->ns_active, 2, ncclInt32, ncclSum);
-        hipLaunchKernelGGL(k_kfin_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
+        LAUNCHK(k_kfin_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
-    if (c->n_kf <= 64) hipLaunchKernelGGL(k_gauge_wave, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
-    else if (c->n_kf > 256) hipLaunchKernelGGL(k_gauge_par, dim3(1), dim3(1024), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp, D.kf_order);
-    else hipLaunchKernelGGL(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp, D.kf_order);
+    if (c->n_kf <= 64) LAUNCHK(k_gauge_wave, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp);
+    else if (c->n_kf > 256) LAUNCHK(k_gauge_par, dim3(1), dim3(1024), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp, D.kf_order);
+    else LAUNCHK(k_gauge, dim3(1), dim3(64), 0, c->stream, W, (const uint8_t *)c->kf_initial, o.state, ncp, D.kf_order);
     if (D.far_B > 0 && D.far_rec) { const int ne = D.n_far_ent;      // the blocks outside the band by keyframe, with the other keyframe's row (the gauge is fixed now)
-        if (ne > 0) hipLaunchKernelGGL(k_far_rows, dim3((ne + 255)/256), dim3(256), 0, c->stream, W, D, ne); }
-    if (D.n_tg > 0) hipLaunchKernelGGL(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
+        if (ne > 0) LAUNCHK(k_far_rows, dim3((ne + 255)/256), dim3(256), 0, c->stream, W, D, ne); }
+    if (D.n_tg > 0) LAUNCHK(k_musigma, dim3(D.n_tg), dim3(MS_THREADS), 0, c->stream, W, D);
 }
 // k_mid's blocks: 256 landmarks / pairs each.  tsba_debug_options.trial_launches = 1 / 2 (the k_lin_mid experiment and its comparison partner): 128 (MID_TW: what a
 // workgroup of the linearisation can take over)
@@ -833,28 +851,28 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     // more than the kernel boundary it replaces (tools/ticket_bench.hip)
     if (spec && W.st_next && c->lin_ticket && c->dbg.trial_launches == 2 && !is_multi(c) && mid_threads(c) == MID_TW && D.n_pair + D.n_tg > 0 && !lin_small_pairs(c, D)) {
         const unsigned grid = (unsigned)((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8);
-        hipLaunchKernelGGL(k_lin_mid, dim3(grid), dim3(LIN_T), 0, c->stream, W, D, nb_pt, nb_tx, nb_pt + nb_tx + nb_pr, c->lin_ticket, c->lin_base);
+        LAUNCHK(k_lin_mid, dim3(grid), dim3(LIN_T), 0, c->stream, W, D, nb_pt, nb_tx, nb_pt + nb_tx + nb_pr, c->lin_ticket, c->lin_base);
         c->lin_base += grid;
         return;
     }
     if (D.n_pair + D.n_tg > 0) {
-        if (lin_small_pairs(c, D) && D.n_tg == 0) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4, false>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
-        else if (lin_small_pairs(c, D)) hipLaunchKernelGGL((k_linearize<MODE_FULL, 4>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
-        else hipLaunchKernelGGL((k_linearize<MODE_FULL, 1>), dim3((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
+        if (lin_small_pairs(c, D) && D.n_tg == 0) LAUNCHK((k_linearize<MODE_FULL, 4, false>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
+        else if (lin_small_pairs(c, D)) LAUNCHK((k_linearize<MODE_FULL, 4>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
+        else LAUNCHK((k_linearize<MODE_FULL, 1>), dim3((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
     }
-    if (mid_threads(c) == MID_TW) hipLaunchKernelGGL(k_mid<MID_TW>, dim3(nb_pt + nb_tx + nb_pr), dim3(MID_TW), 0, c->stream, W, D, nb_pt, nb_tx, spec);
-    else hipLaunchKernelGGL(k_mid<256>, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    if (mid_threads(c) == MID_TW) LAUNCHK(k_mid<MID_TW>, dim3(nb_pt + nb_tx + nb_pr), dim3(MID_TW), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    else LAUNCHK(k_mid<256>, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
     const int npp = pose_parts(c);
     if (multi) {
         // local sums -> exchange buffer -> all-reduce; the consumer (k_postlin / k_decide) installs them into the right LinBuf
-        if (npp) hipLaunchKernelGGL(k_pose_sums_raw, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
-        hipLaunchKernelGGL(k_sums_multi, dim3(1), dim3(256), 0, c->stream, W, D, spec, nb_pt + nb_tx + nb_pr, back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text) + nb_kf, back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text), npp);      // (k_back's blocks: its partial sums)
+        if (npp) LAUNCHK(k_pose_sums_raw, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
+        LAUNCHK(k_sums_multi, dim3(1), dim3(256), 0, c->stream, W, D, spec, nb_pt + nb_tx + nb_pr, back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text) + nb_kf, back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text), npp);      // (k_back's blocks: its partial sums)
         allreduce(c, W.cb, 2*(size_t)W.N + 8, ncclDouble, ncclSum);
         allreduce(c, W.cbm, 1, ncclDouble, ncclMax);
-        if (npp) hipLaunchKernelGGL(k_pose_scale_multi, dim3(npp), dim3(256), 0, c->stream, W, spec);
-    } else if (npp) hipLaunchKernelGGL(k_pose_sums, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
-    if (!spec) hipLaunchKernelGGL(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi, npp);
+        if (npp) LAUNCHK(k_pose_scale_multi, dim3(npp), dim3(256), 0, c->stream, W, spec);
+    } else if (npp) LAUNCHK(k_pose_sums, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
+    if (!spec) LAUNCHK(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi, npp);
 }
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
     size_t bytes = solve_lds_doubles(c->W.N)*sizeof(double);                                // worst case: every pose free
@@ -864,20 +882,20 @@ static int solve_lds_bytes(Ctx *c, int *use_lds) {
 static void launch_schur(Ctx *c, const LevelDev &D, int multi, SchurDec dec = SchurDec{0, 0, 0, tsba_options{}}) {
     if (c->n_kf > 126 && !c->dbg.no_schur_quad) {               // large maps: four S blocks per wave, then one wave per pose for the reduced gradient
         const int nq = D.n_sb > 0 ? (((D.n_sb + 3)/4 + 7)/8)*8 : 0, ng = ((c->n_kf + 7)/8)*8;           // (multiples of 8 workgroups: the kernel's XCD-aware mappings)
-        if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq + ng), dim3(64), 0, c->stream, c->W, D, multi, nq, ng);
-        else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq + ng), dim3(64), 0, c->stream, c->W, D, multi, nq, ng);
-    } else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
-    else hipLaunchKernelGGL(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0, dec);
+        if (D.n_tg > 0) LAUNCHK(k_schur_quad<true>, dim3(nq + ng), dim3(64), 0, c->stream, c->W, D, multi, nq, ng);
+        else LAUNCHK(k_schur_quad<false>, dim3(nq + ng), dim3(64), 0, c->stream, c->W, D, multi, nq, ng);
+    } else if (c->n_kf > 126) LAUNCHK(k_schur_t<1>, dim3(D.n_sb + c->n_kf), dim3(64), 0, c->stream, c->W, D, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
+    else LAUNCHK(k_schur_t<4>, dim3(D.n_sb + c->n_kf), dim3(256), 0, c->stream, c->W, D, multi, 0, dec);
     if (D.far_B > 0 && D.n_far > 0) {            // the blocks of E (what couples different clusters of a landmark): the same kernels on the fb_* lists, stored to W.Sfar
         LevelDev E = D;
         E.n_sb = D.n_far; E.sb_a = D.far_a; E.sb_b = D.far_b; E.sb_pab = D.fb_pab; E.sb_pba = D.fb_pba; E.sb_far = D.fb_id;
         E.sb_pt_off = D.fb_pt_off; E.sb_pt_s1 = D.fb_pt_s1; E.sb_pt_s2 = D.fb_pt_s2; E.sb_pt_lm = D.fb_pt_lm;
         E.sb_tx_off = D.fb_tx_off; E.sb_tx_s1 = D.fb_tx_s1; E.sb_tx_s2 = D.fb_tx_s2; E.sb_tx_lm = D.fb_tx_lm;
         if (c->n_kf > 126 && !c->dbg.no_schur_quad) { const int nq = (((E.n_sb + 3)/4 + 7)/8)*8;
-            if (D.n_tg > 0) hipLaunchKernelGGL(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi, nq, 0);
-            else hipLaunchKernelGGL(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi, nq, 0); }
-        else if (c->n_kf > 126) hipLaunchKernelGGL(k_schur_t<1>, dim3(E.n_sb), dim3(64), 0, c->stream, c->W, E, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
-        else hipLaunchKernelGGL(k_schur_t<4>, dim3(E.n_sb), dim3(256), 0, c->stream, c->W, E, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
+            if (D.n_tg > 0) LAUNCHK(k_schur_quad<true>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi, nq, 0);
+            else LAUNCHK(k_schur_quad<false>, dim3(nq), dim3(64), 0, c->stream, c->W, E, multi, nq, 0); }
+        else if (c->n_kf > 126) LAUNCHK(k_schur_t<1>, dim3(E.n_sb), dim3(64), 0, c->stream, c->W, E, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
+        else LAUNCHK(k_schur_t<4>, dim3(E.n_sb), dim3(256), 0, c->stream, c->W, E, multi, 0, SchurDec{0, 0, 0, tsba_options{}});
     }
 }
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
@@ -934,22 +952,22 @@ static void launch_solve(Ctx *c) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
     if (use_lds) {                                  // small windows: one workgroup, S in LDS.  solve_variant 1: the two-panel-wave schedule of tsba_solve.h (A/B runs)
         const size_t la = solve_la_lds_doubles(W.N)*sizeof(double);
-        if ((c->dbg.solve_variant == 1 || c->dbg.solve_variant == 2) && la <= 160*1024 - 64) hipLaunchKernelGGL(k_solve_la, dim3(1), dim3(SOLVE_THREADS), (int)la, c->stream, W, c->dbg.solve_variant == 2 ? 0 : 1);
-        else if (c->dbg.solve_variant == 4) hipLaunchKernelGGL((k_solve_t<false, false>), dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);      // (the diagonal blocks through the LDS scratch: A/B and bit-identity runs)
-        else hipLaunchKernelGGL(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);
+        if ((c->dbg.solve_variant == 1 || c->dbg.solve_variant == 2) && la <= 160*1024 - 64) LAUNCHK(k_solve_la, dim3(1), dim3(SOLVE_THREADS), (int)la, c->stream, W, c->dbg.solve_variant == 2 ? 0 : 1);
+        else if (c->dbg.solve_variant == 4) LAUNCHK((k_solve_t<false, false>), dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);      // (the diagonal blocks through the LDS scratch: A/B and bit-identity runs)
+        else LAUNCHK(k_solve_t<false>, dim3(1), dim3(SOLVE_THREADS), lds, c->stream, W, 0);
         return; }
     if (c->band_stream && c->band_parts > 1) {      // partitioned: interiors in parallel + separator system (tsba_bandp.h)
         const int bwp = std::max(6, c->cur_bw_rows), cbp = bandp_chunk_blocks(bwp), P = c->band_parts;
         const int bwsep = 2*bwp - 6, cbs = band_chunk_blocks(bwsep);
         Work &Ws = c->Wsep; Ws.st = W.st; Ws.ldS = (P - 1)*bwp; Ws.N = (P - 1)*bwp;
         if (!c->sep_cr) hipMemsetAsync(c->Ssep, 0, sizeof(double)*((size_t)Ws.ldS*Ws.ldS + Ws.ldS), c->stream);
-        hipLaunchKernelGGL(k_bandp_factor, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
+        LAUNCHK(k_bandp_factor, dim3(P), dim3(SOLVE_THREADS), (int)(bandp_lds_doubles(bwp, cbp)*sizeof(double)), c->stream, W, bwp, cbp, P, c->Lcol, c->Lb, c->Tbuf);
         if (c->sep_cr && (W.ring || (c->dbg.sep_solver != 3 && c->dbg.sep_solver != 4)))      // block pool: border products + separator assembly in one launch (4: the three launches, for A/B runs)
-            hipLaunchKernelGGL(k_bandp_sepf, dim3(W.ring ? P + 1 : P - 1), dim3(BSF_T), (int)(bandp_sepf_lds_doubles()*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Lb, c->Ssep, Ws.g, Ws.nfree);
+            LAUNCHK(k_bandp_sepf, dim3(W.ring ? P + 1 : P - 1), dim3(BSF_T), (int)(bandp_sepf_lds_doubles()*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Lb, c->Ssep, Ws.g, Ws.nfree);
         else {
         hipMemsetAsync(c->Bpart, 0, sizeof(double)*(size_t)P*BANDP_NS*((size_t)bwp*bwp + bwp), c->stream);        // (slices of short interiors stay empty)
-        hipLaunchKernelGGL(k_bandp_border, dim3(P, BANDP_NS), dim3(256), (int)((2*(size_t)BANDP_JC*bwp*6 + 6*BANDP_JC)*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Lb, c->Bpart);
-        hipLaunchKernelGGL(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
+        LAUNCHK(k_bandp_border, dim3(P, BANDP_NS), dim3(256), (int)((2*(size_t)BANDP_JC*bwp*6 + 6*BANDP_JC)*sizeof(double)), c->stream, W, bwp, P, (const double *)c->Lb, c->Bpart);
+        LAUNCHK(k_bandp_sep, dim3(P - 1), dim3(256), 0, c->stream, W, bwp, P, (const double *)c->Tbuf, (const double *)c->Bpart, c->Ssep, Ws.ldS, Ws.g, Ws.nfree, (int)c->sep_cr);
         }
         if (c->sep_cr) {                  // separator system by block cyclic reduction (tsba_bandcr.h): log2(P - 1) levels
             const int mmax = cr_mmax(W.ring, P, W.ring_g);
@@ -961,53 +979,54 @@ static void launch_solve(Ctx *c) {
             int htop = 1;
             if (c->dbg.sep_solver != 3 || W.ring) {      // one launch per level (tsba_bandcre.h); 3: the pivot / update / back kernels of tsba_bandcr.h
                 const int le = (int)(cre_elim_lds_doubles(bwp)*sizeof(double)), lbk = (int)(cre_back_lds_doubles(bwp)*sizeof(double));
+                c->cre_epoch++;                                   // (this factorisation's ordinal: what the K workgroups of a pivot tell each other they have loaded for, k_cre_elim)
                 auto pivots = [&](int h, int &kb) { kb = lab0/(2*h); const int klast = (mmax - 1 - h)/(2*h); return std::max(0, klast - kb + 1); };     // pivots (2 k + 1) h, k = kb ..
                 for (int h = 1; h < mlev; h <<= 1) {
                     int kb; const int npiv = pivots(h, kb); if (npiv <= 0) { htop = h; continue; }
                     const int K = std::max(1, std::min(TSBA_CRE_KMAX, 224/npiv));     // workgroups per pivot (they share its product and stores)
-                    hipLaunchKernelGGL(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, kb, c->CRcontrib, c->CRfac); htop = h; }
-                hipLaunchKernelGGL(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, W.ring ? 2 : 1, 1, 0, c->CRcontrib, c->CRfac);
+                    LAUNCHK(k_cre_elim, dim3(npiv*K), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, h, 0, K, kb, c->CRcontrib, c->CRfac, c->CRgate, c->cre_epoch); htop = h; }
+                LAUNCHK(k_cre_elim, dim3(1), dim3(CRE_T), le, c->stream, W, Ws, bwp, P, 0, W.ring ? 2 : 1, 1, 0, c->CRcontrib, c->CRfac, c->CRgate, c->cre_epoch);
                 // back substitution: a launch per level -- or one launch through the inverse factors and products of the solve phase (k_sv_linv + k_cre_back_tree)
                 // where the iterative path needs those anyway (maps with long-range blocks) or the tree is deep enough to pay for k_sv_linv (28 us at 48-row
                 // separators against 10.5 us per level)
                 if ((c->far_B > 0 || (htop >= 32 && bwp <= 60)) && ms_available(c) && !(c->dbg.sv_per_level & 2) && c->dbg.pcg_refactor != 1 && mmax >= 2 && grid_resident(c, (const void *)k_cre_back_tree, SV_CT, 0, mmax - 1) && sv_reserve(c) == TSBA_OK) {
                     launch_sv_prepare(c, Ws.Sy);
-                    hipLaunchKernelGGL(k_cre_back_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, c->sv);
+                    LAUNCHK(k_cre_back_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, c->sv);
                 } else
-                for (int h = htop; h >= 1; h >>= 1) { int kb; const int npiv = pivots(h, kb); if (npiv > 0) hipLaunchKernelGGL(k_cre_back, dim3(npiv), dim3(CRE_BT), lbk, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac); }
+                for (int h = htop; h >= 1; h >>= 1) { int kb; const int npiv = pivots(h, kb); if (npiv > 0) LAUNCHK(k_cre_back, dim3(npiv), dim3(CRE_BT), lbk, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac); }
             } else {
             for (int h = 1; h < mmax; h <<= 1) {
                 const int npiv = (mmax + 2*h - 1)/(2*h);           // >= the pivots (2k + 1) h < m; workgroups past the end return
-                hipLaunchKernelGGL(k_cr_pivot, dim3(npiv), dim3(CR_T), lp, c->stream, W, Ws, bwp, P, h, 0);
-                hipLaunchKernelGGL(k_cr_update, dim3(2*npiv + 1), dim3(CR_T), lu, c->stream, W, Ws, bwp, P, h, npiv);
+                LAUNCHK(k_cr_pivot, dim3(npiv), dim3(CR_T), lp, c->stream, W, Ws, bwp, P, h, 0);
+                LAUNCHK(k_cr_update, dim3(2*npiv + 1), dim3(CR_T), lu, c->stream, W, Ws, bwp, P, h, npiv);
                 htop = h;
             }
-            hipLaunchKernelGGL(k_cr_pivot, dim3(1), dim3(CR_T), lp, c->stream, W, Ws, bwp, P, 0, 1);
-            hipLaunchKernelGGL(k_cr_back, dim3(1), dim3(CR_T), lb, c->stream, W, Ws, bwp, P, 0, 1);
+            LAUNCHK(k_cr_pivot, dim3(1), dim3(CR_T), lp, c->stream, W, Ws, bwp, P, 0, 1);
+            LAUNCHK(k_cr_back, dim3(1), dim3(CR_T), lb, c->stream, W, Ws, bwp, P, 0, 1);
             for (int h = htop; h >= 1; h >>= 1)
-                hipLaunchKernelGGL(k_cr_back, dim3((mmax + 2*h - 1)/(2*h)), dim3(CR_T), lb, c->stream, W, Ws, bwp, P, h, 0);
+                LAUNCHK(k_cr_back, dim3((mmax + 2*h - 1)/(2*h)), dim3(CR_T), lb, c->stream, W, Ws, bwp, P, h, 0);
             }
         } else {
         const int ldss = (int)(band_lds_doubles(bwsep, cbs)*sizeof(double)), nus = (bwsep + 63)/64;
-        hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(SOLVE_THREADS), ldss, c->stream, Ws, bwsep, cbs, c->Lcol_sep);
-        if (nus <= 1) hipLaunchKernelGGL(k_band_backsub<1>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
-        else if (nus == 2) hipLaunchKernelGGL(k_band_backsub<2>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
-        else hipLaunchKernelGGL(k_band_backsub<3>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
+        LAUNCHK(k_band_solve, dim3(1), dim3(SOLVE_THREADS), ldss, c->stream, Ws, bwsep, cbs, c->Lcol_sep);
+        if (nus <= 1) LAUNCHK(k_band_backsub<1>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
+        else if (nus == 2) LAUNCHK(k_band_backsub<2>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
+        else LAUNCHK(k_band_backsub<3>, dim3(1), dim3(BAND_BS_T), ldss, c->stream, Ws, bwsep, (const double *)c->Lcol_sep);
         }
         const int nup = (bwp + 63)/64, ldsp = (int)((2*(size_t)BAND_CK*(2*(size_t)bwp*6 + 32) + 6*BAND_RINGB + 2*bwp + 64)*sizeof(double));
-        if (nup <= 1) hipLaunchKernelGGL(k_bandp_backsub<1>, dim3(P), dim3(BAND_BS_T), ldsp, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, (const double *)Ws.Sy);
-        else hipLaunchKernelGGL(k_bandp_backsub<2>, dim3(P), dim3(BAND_BS_T), ldsp, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, (const double *)Ws.Sy);
-        hipLaunchKernelGGL(k_bandp_dp, dim3((W.n_kf + 255)/256), dim3(256), 0, c->stream, W);
+        if (nup <= 1) LAUNCHK(k_bandp_backsub<1>, dim3(P), dim3(BAND_BS_T), ldsp, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, (const double *)Ws.Sy);
+        else LAUNCHK(k_bandp_backsub<2>, dim3(P), dim3(BAND_BS_T), ldsp, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, (const double *)Ws.Sy);
+        LAUNCHK(k_bandp_dp, dim3((W.n_kf + 255)/256), dim3(256), 0, c->stream, W);
         return;
     }
     if (c->band_stream) {                                          // narrow band: one workgroup streams down the band (tsba_band.h)
         const int bws = std::max(6, c->cur_bw_rows), cb = band_chunk_blocks(bws);
         if (c->dbg.verbose) fprintf(stderr, "[launch_solve] band stream bw %d cb %d lds %zu B\n", bws, cb, band_lds_doubles(bws, cb)*sizeof(double));
-        hipLaunchKernelGGL(k_band_solve, dim3(1), dim3(SOLVE_THREADS), (int)(band_lds_doubles(bws, cb)*sizeof(double)), c->stream, W, bws, cb, c->Lcol);
+        LAUNCHK(k_band_solve, dim3(1), dim3(SOLVE_THREADS), (int)(band_lds_doubles(bws, cb)*sizeof(double)), c->stream, W, bws, cb, c->Lcol);
         const int nu = (bws + 63)/64, ldsb = (int)(band_lds_doubles(bws, cb)*sizeof(double));      // tasks per lane of the back substitution
-        if (nu <= 1) hipLaunchKernelGGL(k_band_backsub<1>, dim3(1), dim3(BAND_BS_T), ldsb, c->stream, W, bws, (const double *)c->Lcol);
-        else if (nu == 2) hipLaunchKernelGGL(k_band_backsub<2>, dim3(1), dim3(BAND_BS_T), ldsb, c->stream, W, bws, (const double *)c->Lcol);
-        else hipLaunchKernelGGL(k_band_backsub<3>, dim3(1), dim3(BAND_BS_T), ldsb, c->stream, W, bws, (const double *)c->Lcol);
+        if (nu <= 1) LAUNCHK(k_band_backsub<1>, dim3(1), dim3(BAND_BS_T), ldsb, c->stream, W, bws, (const double *)c->Lcol);
+        else if (nu == 2) LAUNCHK(k_band_backsub<2>, dim3(1), dim3(BAND_BS_T), ldsb, c->stream, W, bws, (const double *)c->Lcol);
+        else LAUNCHK(k_band_backsub<3>, dim3(1), dim3(BAND_BS_T), ldsb, c->stream, W, bws, (const double *)c->Lcol);
         return;
     }
     launch_dense_chol(c, W, std::min(c->cur_bw_rows, W.N));
@@ -1015,20 +1034,20 @@ static void launch_solve(Ctx *c) {
 // multi-workgroup blocked Cholesky (tsba_chol.h) of the system in `W` (band bound bw rows below a pose block; bw = N: dense)
 static void launch_dense_chol(Ctx *c, Work &W, int bw) {
     const int N = W.N;                                             // worst case: every keyframe free
-    hipLaunchKernelGGL(k_chol_rhs, dim3((N + 255)/256), dim3(256), 0, c->stream, W);
+    LAUNCHK(k_chol_rhs, dim3((N + 255)/256), dim3(256), 0, c->stream, W);
     const int lds_diag = (int)(solve_diag_lds_doubles()*sizeof(double));
     const int lds_panel = (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double);
     const int lds_upd = 2*64*(CH_NB + 1)*(int)sizeof(double);
     for (int j0 = 0; j0 < N; j0 += CH_NB) {
-        hipLaunchKernelGGL(k_solve_t<true>, dim3(1), dim3(SOLVE_THREADS), lds_diag, c->stream, W, j0);
+        LAUNCHK(k_solve_t<true>, dim3(1), dim3(SOLVE_THREADS), lds_diag, c->stream, W, j0);
         // the host only knows the worst case n = N; a shorter last block (nb < NB) still has the rhs row below it
         const int wr = std::max(0, std::min(bw, N - (j0 + 6)));        // band rows below the block, + 1 for the rhs row
-        hipLaunchKernelGGL(k_chol_panel, dim3(wr/64 + 1), dim3(CH_T), lds_panel, c->stream, W, j0, bw);
+        LAUNCHK(k_chol_panel, dim3(wr/64 + 1), dim3(CH_T), lds_panel, c->stream, W, j0, bw);
         const int nt = (wr + 1 + 63)/64;
-        if (wr > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt*(nt + 1)/2), dim3(CH_T), lds_upd, c->stream, W, j0, bw);
+        if (wr > 0) LAUNCHK(k_chol_update, dim3(nt*(nt + 1)/2), dim3(CH_T), lds_upd, c->stream, W, j0, bw);
     }
     const int lds_bs = (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double);
-    hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, W, bw);
+    LAUNCHK(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, W, bw);
 }
 
 // ---- solve phase of the partitioned band solver for T right-hand sides (tsba_bandms.h): needs the factor of the last launch_solve of this level
@@ -1051,8 +1070,8 @@ static void launch_ms_solve(Ctx *c, bool mx = false) {            // M.R -> M.X.
     Work &Ws = c->Wsep; Ws.st = W.st;
     mx = mx && bwp >= 36 && bwp <= MX_SMAX && bwp % 6 == 0;
     const size_t ldsf = ms_cre_lds_doubles(bwp, 1)*sizeof(double), ldsb = (ms_cre_lds_doubles(bwp, 3) + 8*(size_t)(bwp + 2))*sizeof(double), ldsx = mx_lds_doubles(bwp)*sizeof(double);
-    hipLaunchKernelGGL(k_ms_fwd_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
-    hipLaunchKernelGGL(k_ms_sep_rhs, dim3(P - 1, ncg), dim3(64*B), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
+    LAUNCHK(k_ms_fwd_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
+    LAUNCHK(k_ms_sep_rhs, dim3(P - 1, ncg), dim3(64*B), 0, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, M);
     const int mmax = cr_mmax(0, P, 0);
     auto pivots = [&](int h, int &kb) { kb = 0; const int klast = (mmax - 1 - h)/(2*h); return mmax - 1 - h < 0 ? 0 : std::max(0, klast + 1); };
     int htop = 0;
@@ -1061,26 +1080,26 @@ static void launch_ms_solve(Ctx *c, bool mx = false) {            // M.R -> M.X.
 #define MX_CASES(CALL) switch (bwp) { case 36: CALL(36) break; case 42: CALL(42) break; case 48: CALL(48) break; case 54: CALL(54) break; case 60: CALL(60) break; case 66: CALL(66) break; default: break; }
     for (int h = 1; h < mmax; h <<= 1) { int kb; const int npiv = pivots(h, kb); if (npiv <= 0) continue;
         if (mx) {
-#define MX_FWD(SS) hipLaunchKernelGGL(k_mx_cre_fwd<SS>, dim3(npiv, ncg), dim3(MX_T), ldsx, c->stream, W, Ws, bwp, P, h, kb, M, Li, Lid);
+#define MX_FWD(SS) LAUNCHK(k_mx_cre_fwd<SS>, dim3(npiv, ncg), dim3(MX_T), ldsx, c->stream, W, Ws, bwp, P, h, kb, M, Li, Lid);
             MX_CASES(MX_FWD)
 #undef MX_FWD
-        } else hipLaunchKernelGGL(k_ms_cre_fwd, dim3(npiv, ncg), dim3(MS_CT), ldsf, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M);
+        } else LAUNCHK(k_ms_cre_fwd, dim3(npiv, ncg), dim3(MS_CT), ldsf, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M);
         htop = h; }
     if (mx) {
-#define MX_ROOT(SS) hipLaunchKernelGGL(k_mx_cre_root<SS>, dim3(1, ncg), dim3(MX_T), ldsx, c->stream, W, bwp, P, M, Li, Lid);
+#define MX_ROOT(SS) LAUNCHK(k_mx_cre_root<SS>, dim3(1, ncg), dim3(MX_T), ldsx, c->stream, W, bwp, P, M, Li, Lid);
         MX_CASES(MX_ROOT)
 #undef MX_ROOT
-    } else hipLaunchKernelGGL(k_ms_cre_root, dim3(1, ncg), dim3(256), ldsf, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, M);
+    } else LAUNCHK(k_ms_cre_root, dim3(1, ncg), dim3(256), ldsf, c->stream, W, Ws, bwp, P, (const double *)c->CRfac, M);
     for (int h = htop; h >= 1; h >>= 1) { int kb; const int npiv = pivots(h, kb);
         if (npiv <= 0) continue;
         if (mx) {
-#define MX_BACK(SS) hipLaunchKernelGGL(k_mx_cre_back<SS>, dim3(npiv, ncg), dim3(MX_T), ldsx, c->stream, W, Ws, bwp, P, h, kb, M, Li);
+#define MX_BACK(SS) LAUNCHK(k_mx_cre_back<SS>, dim3(npiv, ncg), dim3(MX_T), ldsx, c->stream, W, Ws, bwp, P, h, kb, M, Li);
             MX_CASES(MX_BACK)
 #undef MX_BACK
-        } else hipLaunchKernelGGL(k_ms_cre_back, dim3(npiv, ncg), dim3(MS_CT), ldsb, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); }
+        } else LAUNCHK(k_ms_cre_back, dim3(npiv, ncg), dim3(MS_CT), ldsb, c->stream, W, Ws, bwp, P, h, kb, (const double *)c->CRfac, M); }
 #undef MX_CASES
-    hipLaunchKernelGGL(k_ms_back_border, dim3(P, ncg), dim3(BB_T), 0, c->stream, W, bwp, P, (const double *)c->Lb, M);
-    hipLaunchKernelGGL(k_ms_back_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
+    LAUNCHK(k_ms_back_border, dim3(P, ncg), dim3(BB_T), 0, c->stream, W, bwp, P, (const double *)c->Lb, M);
+    LAUNCHK(k_ms_back_int, dim3(P, ncg), dim3(64), 0, c->stream, W, bwp, P, (const double *)c->Lcol, M);
 }
 
 // ---- the same for ONE right-hand side (tsba_bandsv.h): x = M^-1 (rs * r) into c->sv.X.  launch_sv_prepare once per factorisation (the
@@ -1103,7 +1122,7 @@ static int sv_lmax_of(int n_kf, int B, int P) { return std::max(n_kf/std::max(1,
 static int sv_lmax(const Ctx *c) { return sv_lmax_of(c->n_kf, std::max(6, c->cur_bw_rows)/6, c->band_parts); }
 static void launch_sv_prepare(Ctx *c, double *xreset) {
     const int bwp = std::max(6, c->cur_bw_rows), P = c->band_parts, mmax = cr_mmax(0, P, 0);
-    if (mmax > 0) hipLaunchKernelGGL(k_sv_linv, dim3(mmax), dim3(SV_LT), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, (const double *)c->Ssep, c->sv, xreset);
+    if (mmax > 0) LAUNCHK(k_sv_linv, dim3(mmax), dim3(SV_LT), sv_linv_lds_doubles(bwp)*sizeof(double), c->stream, c->W, bwp, P, (const double *)c->CRfac, (const double *)c->Ssep, c->sv, xreset);
     c->sv_prepared = true;
 }
 static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rdot = nullptr, double *rz_part = nullptr, SvUpd upd = SvUpd{0, 0, 0, 0}) {
@@ -1119,24 +1138,24 @@ static void launch_sv_solve(Ctx *c, const double *r, double rs, const double *rd
     const bool fuse_top = htop > 0 && pivots(htop) == 1;
     const bool tb_fits = B <= 10 ? grid_resident(c, (const void *)k_sv_tree_back<1>, SV_T, ldb, P) : grid_resident(c, (const void *)k_sv_tree_back<2>, SV_T, ldb, P);
     const int tree = fuse_top && !(c->dbg.sv_per_level & 1) && grid_resident(c, (const void *)k_sv_cre_tree, SV_CT, 0, mmax - 1);           // the whole tree in one launch (k_sv_cre_tree): its workgroups poll each other
-    if (B <= 10) hipLaunchKernelGGL(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
-    else hipLaunchKernelGGL(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
+    if (B <= 10) LAUNCHK(k_sv_fwd_int<1>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
+    else LAUNCHK(k_sv_fwd_int<2>, dim3(P), dim3(SV_T), ldf, c->stream, W, bwp, P, (const double *)c->Lcol, (const double *)c->Lb, r, rs, M, tree, upd);
     const bool tree_back = tree && !(c->dbg.sv_per_level & 8) && tb_fits;        // ... and the interiors' back substitution in the tree's launch (k_sv_tree_back)
     if (tree_back) {
-        if (B <= 10) hipLaunchKernelGGL(k_sv_tree_back<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, htop, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
-        else hipLaunchKernelGGL(k_sv_tree_back<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, htop, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
+        if (B <= 10) LAUNCHK(k_sv_tree_back<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, htop, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
+        else LAUNCHK(k_sv_tree_back<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, htop, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
         return; }
-    if (tree) hipLaunchKernelGGL(k_sv_cre_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
+    if (tree) LAUNCHK(k_sv_cre_tree, dim3(mmax - 1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
     else {
         for (int h = 1; h <= htop; h <<= 1) { const int npiv = pivots(h); if (npiv <= 0 || (fuse_top && h == htop)) continue;
-            hipLaunchKernelGGL(k_sv_cre_fwd, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
-        if (fuse_top) hipLaunchKernelGGL(k_sv_cre_top, dim3(1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
-        else hipLaunchKernelGGL(k_sv_cre_root, dim3(1), dim3(SV_CT), 0, c->stream, W, bwp, P, M);
+            LAUNCHK(k_sv_cre_fwd, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
+        if (fuse_top) LAUNCHK(k_sv_cre_top, dim3(1), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, htop, M);
+        else LAUNCHK(k_sv_cre_root, dim3(1), dim3(SV_CT), 0, c->stream, W, bwp, P, M);
         for (int h = htop; h >= 1; h >>= 1) { const int npiv = pivots(h);
-            if (npiv > 0 && !(fuse_top && h == htop)) hipLaunchKernelGGL(k_sv_cre_back, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
+            if (npiv > 0 && !(fuse_top && h == htop)) LAUNCHK(k_sv_cre_back, dim3(npiv), dim3(SV_CT), 0, c->stream, W, Ws, bwp, P, h, 0, M); }
     }
-    if (B <= 10) hipLaunchKernelGGL(k_sv_back_int<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
-    else hipLaunchKernelGGL(k_sv_back_int<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
+    if (B <= 10) LAUNCHK(k_sv_back_int<1>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
+    else LAUNCHK(k_sv_back_int<2>, dim3(P), dim3(SV_T), ldb, c->stream, W, bwp, P, lmax, (const double *)c->Lcol, (const double *)c->Lb, M, rdot, rz_part);
 }
 
 // The reduced system of one LM trial: a direct solve, or -- band + long-range blocks -- conjugate gradients preconditioned with the band
@@ -1180,24 +1199,24 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
                     if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - tw > std::chrono::seconds(5)) return false;
                 }
             };
-            hipLaunchKernelGGL(k_ecg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, M);
+            LAUNCHK(k_ecg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, M);
             launch_ms_solve(c, svok);
-            hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)M.X, (const double *)M.X, (const double *)nullptr, (const double *)M.R, (const double *)M.X, E);
-            hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 0, 0, seq, tol2);
-            hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 2, 1);
+            LAUNCHK(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)M.X, (const double *)M.X, (const double *)nullptr, (const double *)M.R, (const double *)M.X, E);
+            LAUNCHK(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 0, 0, seq, tol2);
+            LAUNCHK(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 2, 1);
             int it = 0;
             for (; it < cap; it++) {
                 if (finished_e(it)) break;
-                hipLaunchKernelGGL(k_ecg_matvec, dim3(nbp), dim3(256), 0, c->stream, W, D, B, E);
-                hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)E.P, (const double *)E.Q, (const double *)M.R, (const double *)nullptr, (const double *)nullptr, E);
-                hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 1, it, seq, tol2);
-                hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 1, 0);
+                LAUNCHK(k_ecg_matvec, dim3(nbp), dim3(256), 0, c->stream, W, D, B, E);
+                LAUNCHK(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)E.P, (const double *)E.Q, (const double *)M.R, (const double *)nullptr, (const double *)nullptr, E);
+                LAUNCHK(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 1, it, seq, tol2);
+                LAUNCHK(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 1, 0);
                 launch_ms_solve(c, svok);
-                hipLaunchKernelGGL(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)E.Q, (const double *)M.X, (const double *)nullptr, (const double *)M.R, (const double *)M.X, E);
-                hipLaunchKernelGGL(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 2, it, seq, tol2);
-                hipLaunchKernelGGL(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 2, 0);
+                LAUNCHK(k_ecg_gram, dim3(nch), dim3(256), 0, c->stream, W, (const double *)E.Q, (const double *)M.X, (const double *)nullptr, (const double *)M.R, (const double *)M.X, E);
+                LAUNCHK(k_ecg_small, dim3(1), dim3(1024), 0, c->stream, W, E, 2, it, seq, tol2);
+                LAUNCHK(k_ecg_update, dim3(nbp), dim3(256), 0, c->stream, W, M, E, 2, 0);
             }
-            hipLaunchKernelGGL(k_ecg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
+            LAUNCHK(k_ecg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
             c->ms.T = Tk;
             return;
         }
@@ -1221,34 +1240,34 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
         Wk.S = q; q += ((size_t)kk + 1)*kk; Wk.Sy = q; q += kk + 8; Wk.g = q; q += kk; Wk.dp = q; q += kk; Wk.LDbuf = q; q += kk + 8;
         Wk.fidx = (int *)q; Wk.nfree = Wk.fidx + D.n_wb + 2;
         const int Tk = c->ms.T; c->ms.T = kk; const MsBuf M = c->ms;
-        hipLaunchKernelGGL(k_wb_init, dim3(1), dim3(64), 0, c->stream, Wk.fidx, Wk.nfree, D.n_wb);
-        hipLaunchKernelGGL(k_wb_units, dim3(1024), dim3(256), 0, c->stream, W, M, Bw);
+        LAUNCHK(k_wb_init, dim3(1), dim3(64), 0, c->stream, Wk.fidx, Wk.nfree, D.n_wb);
+        LAUNCHK(k_wb_units, dim3(1024), dim3(256), 0, c->stream, W, M, Bw);
         launch_ms_solve(c, svok);
-        hipLaunchKernelGGL(k_wb_gather, dim3(std::min(1024, (kk*kk + 255)/256)), dim3(256), 0, c->stream, W, M, Bw);
-        hipLaunchKernelGGL(k_wb_EG, dim3(D.n_wb), dim3(256), 0, c->stream, W, D, Bw);
-        hipLaunchKernelGGL(k_wb_K2, dim3(std::min(2048, (kk*kk + 255)/256)), dim3(256), 0, c->stream, W, Bw, K2);
+        LAUNCHK(k_wb_gather, dim3(std::min(1024, (kk*kk + 255)/256)), dim3(256), 0, c->stream, W, M, Bw);
+        LAUNCHK(k_wb_EG, dim3(D.n_wb), dim3(256), 0, c->stream, W, D, Bw);
+        LAUNCHK(k_wb_K2, dim3(std::min(2048, (kk*kk + 255)/256)), dim3(256), 0, c->stream, W, Bw, K2);
         c->ms.T = Tk;
     }
     bool wb_factored = false;
     auto correct = [&](const double *yp, double ys) {              // z = M_W^-1 r from y = M^-1 r = ys * yp[]
         WbBuf &Bw = c->wb; Work &Wk = c->Wk; MsBuf M = c->ms; M.T = kk;
-        hipLaunchKernelGGL(k_wb_rhs, dim3(1), dim3(512), 0, c->stream, W, Bw, yp, ys, Wk.g);
+        LAUNCHK(k_wb_rhs, dim3(1), dim3(512), 0, c->stream, W, Bw, yp, ys, Wk.g);
         if (!wb_factored) {                                        // once per LM trial: the k x k factor (in place, over a copy), with this right-hand side riding along
             hipMemcpyAsync(Wk.S, K2, sizeof(double)*(size_t)kk*kk, hipMemcpyDeviceToDevice, c->stream);
             launch_dense_chol(c, Wk, kk); wb_factored = true;
         } else {                                                   // later applications: the two substitutions on that factor (0.28 ms of factorisation each before)
             const int lds_bs = (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double);
-            hipLaunchKernelGGL(k_chol_rhs, dim3((kk + 255)/256), dim3(256), 0, c->stream, Wk);
-            hipLaunchKernelGGL(k_chol_fwd, dim3(1), dim3(1024), lds_bs, c->stream, Wk, kk);
-            hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, Wk, kk);
+            LAUNCHK(k_chol_rhs, dim3((kk + 255)/256), dim3(256), 0, c->stream, Wk);
+            LAUNCHK(k_chol_fwd, dim3(1), dim3(1024), lds_bs, c->stream, Wk, kk);
+            LAUNCHK(k_chol_backsub, dim3(1), dim3(1024), lds_bs, c->stream, Wk, kk);
         }
-        hipLaunchKernelGGL(k_wb_Gw, dim3(1), dim3(512), 0, c->stream, W, Bw, (const double *)Wk.dp);
-        hipLaunchKernelGGL(k_wb_Ex, dim3(D.n_wb), dim3(64), 0, c->stream, W, D, Bw, (const double *)Bw.xu);
-        hipLaunchKernelGGL(k_wb_apply, dim3(512), dim3(256), 0, c->stream, W, M, Bw, yp, ys);
+        LAUNCHK(k_wb_Gw, dim3(1), dim3(512), 0, c->stream, W, Bw, (const double *)Wk.dp);
+        LAUNCHK(k_wb_Ex, dim3(D.n_wb), dim3(64), 0, c->stream, W, D, Bw, (const double *)Bw.xu);
+        LAUNCHK(k_wb_apply, dim3(512), dim3(256), 0, c->stream, W, M, Bw, yp, ys);
     };
-    if (wb) { correct(W.Sy, -1.0); hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, (const double *)c->wb.z, 1.0); }
-    else hipLaunchKernelGGL(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, (const double *)W.Sy, -1.0);
-    if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, -1, nbp, 0.0);
+    if (wb) { correct(W.Sy, -1.0); LAUNCHK(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, (const double *)c->wb.z, 1.0); }
+    else LAUNCHK(k_pcg_begin, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, (const double *)W.Sy, -1.0);
+    if (wb) LAUNCHK(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, -1, nbp, 0.0);
     auto finished = [&](int it) {                                  // true: the device reported convergence (or the end of the pass); else waits until it is within two iterations
         if (!c->hprog || it < 2) return false;
         const auto tw = std::chrono::steady_clock::now();
@@ -1270,32 +1289,32 @@ static void launch_solve_full(Ctx *c, const LevelDev &D) {
     int it = 0;
     for (; it < cap; it++) {
         if (finished(it)) break;
-        hipLaunchKernelGGL(k_pcg_matvec, dim3(nmv), dim3(64*PCG_MW), 0, c->stream, W, D, it, seq, B, tol2, (it > 0 && fused_dot) ? rz2_off : 0, (it > 0 && fused_dot) ? c->band_parts : nbp, pq_off, zp, zs);
-        if (ms) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->ms.R, 1.0);
+        LAUNCHK(k_pcg_matvec, dim3(nmv), dim3(64*PCG_MW), 0, c->stream, W, D, it, seq, B, tol2, (it > 0 && fused_dot) ? rz2_off : 0, (it > 0 && fused_dot) ? c->band_parts : nbp, pq_off, zp, zs);
+        if (ms) { LAUNCHK(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->ms.R, 1.0);
             const int Tk = c->ms.T; c->ms.T = 1; launch_ms_solve(c, svok); c->ms.T = Tk; zp = c->ms.X; zs = 1.0; }
         else if (sv && fused_dot && !(c->dbg.sv_per_level & 4)) {      // the iteration's update step (alpha; x, r) inside the first kernel of the preconditioner application
             launch_sv_solve(c, W.pc_r, 1.0, W.pc_r, W.pc_part + rz2_off, SvUpd{1, it, nmv, pq_off});
             zp = c->sv.X; zs = 1.0; }
-        else if (sv) { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->sv.R, 1.0);
-            if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
+        else if (sv) { LAUNCHK(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, c->sv.R, 1.0);
+            if (wb) LAUNCHK(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
             if (fused_dot) launch_sv_solve(c, c->sv.R, 1.0, c->sv.R, W.pc_part + rz2_off);      // (r.z comes along: no k_pcg_dot)
             else launch_sv_solve(c, c->sv.R, 1.0);
             zp = c->sv.X; zs = 1.0;
             if (wb) { correct(c->sv.X, 1.0); zp = c->wb.z; } }
-        else { hipLaunchKernelGGL(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, W.g, -1.0);
-            if (wb) hipLaunchKernelGGL(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
+        else { LAUNCHK(k_pcg_update, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it, nbp, pq_off, nmv, W.g, -1.0);
+            if (wb) LAUNCHK(k_pcg_rcheck, dim3(1), dim3(64), 0, c->stream, W, it, nbp, 1e-20);      // |r| <= 1e-10 |b|
             launch_solve(c);
             if (wb) { correct(W.Sy, -1.0); zp = c->wb.z; zs = 1.0; } }
-        if (!fused_dot) hipLaunchKernelGGL(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, zp, zs);
+        if (!fused_dot) LAUNCHK(k_pcg_dot, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, zp, zs);
     }
-    hipLaunchKernelGGL(k_pcg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
+    LAUNCHK(k_pcg_finish, dim3(nbp), dim3(PCG_ET), 0, c->stream, W, it);
 }
 
 static void launch_decide(Ctx *c, const LevelDev &D) {
     Work &W = c->W;
     int nb_pt, nb_tx, nb_pr; mid_blocks(c, D, nb_pt, nb_tx, nb_pr); const int nb_kf = (c->n_kf + 255)/256;
     const int nb_all = back_blocks_pt(c->n_pt) + back_blocks_tx(c->n_text) + nb_kf;
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_all, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
+    LAUNCHK(k_decide, dim3(1), dim3(256), 0, c->stream, W, D, nb_all, nb_pt + nb_tx + nb_pr, c->opt, (int)is_multi(c), pose_parts(c));
 }
 // one LM iteration: reduced system -> pose step -> back-substitution / candidate -> speculative linearisation at the
 // candidate -> decision (on acceptance the speculative LinBuf simply becomes the current one)
@@ -1320,22 +1339,22 @@ static void launch_step(Ctx *c, const LevelDev &D, bool decide_prev = false) {
         if (c->S_xchg) {                           // band storage: only the band's entries travel
             const size_t nx = ((size_t)W.N + (W.ring ? c->xchg_wp - 6 : 0))*c->xchg_wp;
             const int nbp = (int)std::min<size_t>(2048, (nx + 255)/256);
-            hipLaunchKernelGGL(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 0);
+            LAUNCHK(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 0);
             allreduce(c, c->S_xchg, nx, ncclDouble, ncclSum);
-            hipLaunchKernelGGL(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 1);
+            LAUNCHK(k_band_pack, dim3(nbp), dim3(256), 0, c->stream, W, c->S_xchg, c->xchg_wp, 1);
         } else allreduce(c, c->S_alloc, c->S_count, ncclDouble, ncclSum);
         if (D.far_B > 0 && D.n_far > 0) allreduce(c, W.Sfar, 36*(size_t)D.n_far, ncclDouble, ncclSum);      // the blocks outside the band
         allreduce(c, W.g, W.N, ncclDouble, ncclSum);
-        hipLaunchKernelGGL(k_damp_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
+        LAUNCHK(k_damp_multi, dim3((c->n_kf + 255)/256), dim3(256), 0, c->stream, W);
     }
     if (W.dp_poll && D.far_B <= 0) {               // small window: solver (workgroup 0) and back-substitution (three blocks per workgroup, polling the step) in one launch
         int use_lds; const int lds = solve_lds_bytes(c, &use_lds);
         const int ldsb = std::max(lds, (int)((768 + W.N + 2)*sizeof(double)));
-        if (c->dbg.solve_variant == 5) hipLaunchKernelGGL(k_solve_back<false>, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), ldsb, c->stream, W, D, bb_pt, bb_tx, nb_all);      // (A/B: the diagonal blocks through the LDS scratch)
-        else hipLaunchKernelGGL(k_solve_back<true>, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), ldsb, c->stream, W, D, bb_pt, bb_tx, nb_all);
+        if (c->dbg.solve_variant == 5) LAUNCHK(k_solve_back<false>, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), ldsb, c->stream, W, D, bb_pt, bb_tx, nb_all);      // (A/B: the diagonal blocks through the LDS scratch)
+        else LAUNCHK(k_solve_back<true>, dim3(1 + (nb_all + 2)/3), dim3(SOLVE_THREADS), ldsb, c->stream, W, D, bb_pt, bb_tx, nb_all);
     } else {
         launch_solve_full(c, D);
-        hipLaunchKernelGGL(k_back, dim3(nb_all), dim3(256), 0, c->stream, W, D, bb_pt, bb_tx);
+        LAUNCHK(k_back, dim3(nb_all), dim3(256), 0, c->stream, W, D, bb_pt, bb_tx);
     }
     launch_linearize(c, D, 1);
     if (!fused_decide) launch_decide(c, D);
@@ -1348,6 +1367,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
     memset(r, 0, sizeof(*r));
     const tsba_options &o = c->opt;
     { int rca = set_solver_attrs(c); if (rca) return rca; }
+    struct Poison { Poison(int v) { g_lds_poison = v; } ~Poison() { g_lds_poison = 0; } } poison(c->dbg.lds_poison);
     struct Token { Ctx *c; Token(Ctx *c_) : c(c_) { if (c->lgroup) { c->in_solve = true; c->lgroup->gpu_token.lock(); c->has_token = true; } }
                    ~Token() { if (c->lgroup) { c->in_solve = false; if (c->has_token) { hipStreamSynchronize(c->stream); c->has_token = false; c->lgroup->gpu_token.unlock(); } } } } token(c);
     auto t0 = std::chrono::steady_clock::now();
@@ -1367,7 +1387,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
         const bool pose_path = c->pose_only && !is_multi(c);
         if (pose_path) {                                     // k_pass_reset + k_participation + k_gauge + k_musigma in one launch
             c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
-            hipLaunchKernelGGL(k_pose_begin, dim3(D.n_tg + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial);
+            LAUNCHK(k_pose_begin, dim3(D.n_tg + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial);
         } else if (fastp(D)) {
             // windows: k_pass_begin (tsba_kernels_pass.h).  The participation arrays are clear (k_reset_state / the last pass's k_pass_end); the text
             // observations' mu / sigma are there already if the last pass's k_pass_end computed them for this level
@@ -1376,7 +1396,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
             // (at most PB_WG workgroups walk k_participation's npb blocks: every arrival at the ticket is a device-wide fence and an atomic on one word --
             // 30 - 40 ns each, one after the other: tools/ticket_bench.hip)
             const int npb = (D.n_sc + 255)/256 + (D.n_tg + 3)/4, nwg = std::min(npb, PB_WG), n_ms = ms_ahead == ps ? 0 : D.n_tg;
-            hipLaunchKernelGGL(k_pass_begin, dim3(nwg + n_ms), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial, o.state,
+            LAUNCHK(k_pass_begin, dim3(nwg + n_ms), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial, o.state,
                                npb, nwg, n_ms, log_pending ? c->st_log + ps - 1 : (LmState *)nullptr, c->ticket);
             log_pending = false;
         } else {
@@ -1400,15 +1420,15 @@ int tsba_solve(void *ctx, tsba_report *r) {
         };
         if (pose_path) {                                     // PoseOptim: one launch per LM iteration (tsba_pose.h)
             const int G = pose_grid(D);
-            hipLaunchKernelGGL(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, -1, G);
+            LAUNCHK(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, -1, G);
             int k_last = 0;
             for (int k = 0; k <= o.its[ps]; k++) {           // launch k decides trial k - 1 and prepares trial k
                 if (k >= 1 && converged(k - 1)) break;
-                hipLaunchKernelGGL(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, k, G);
+                LAUNCHK(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, k, G);
                 k_last = k;
             }
             // outlier pass + installation of the pass's result (one extra workgroup) in one launch
-            hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg + 1), dim3(64), 0, c->stream, c->W, D, o.chi2_mono[ps], o.chi2_text[ps],
+            LAUNCHK(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg + 1), dim3(64), 0, c->stream, c->W, D, o.chi2_mono[ps], o.chi2_text[ps],
                                o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)(c->W.pst + ((k_last + 1) & 1)));
             CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
             continue;
@@ -1431,31 +1451,31 @@ int tsba_solve(void *ctx, tsba_report *r) {
                 if (c->lev_wait[ln]) { hipStreamWaitEvent(c->stream, c->ev_stage[ln], 0); c->lev_wait[ln] = 0; }      // (staged over the copy stream during this pass's trials: long since there)
                 Dn = &c->lev[ln]; }
             const int n_ms = Dn ? Dn->n_tg : 0;
-            hipLaunchKernelGGL(k_pass_end, dim3((nb_out + 3)/4 + n_ms + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, Dn ? *Dn : D, nb_out, n_ms, c->musig2[c->musig_sel ^ 1],
+            LAUNCHK(k_pass_end, dim3((nb_out + 3)/4 + n_ms + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, Dn ? *Dn : D, nb_out, n_ms, c->musig2[c->musig_sel ^ 1],
                                o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text);
             if (Dn) { c->musig_sel ^= 1; c->W.musig = c->musig2[c->musig_sel]; ms_ahead = ps + 1; }
-            if (c->cov_text >= 0 && c->cov_text < c->n_text && ps < TSBA_MAX_LEVELS) hipLaunchKernelGGL(k_record_vtx, dim3(1), dim3(64), 0, c->stream, c->W, c->cov_text, c->cov_log + 6*ps);
+            if (c->cov_text >= 0 && c->cov_text < c->n_text && ps < TSBA_MAX_LEVELS) LAUNCHK(k_record_vtx, dim3(1), dim3(64), 0, c->stream, c->W, c->cov_text, c->cov_log + 6*ps);
             log_pending = true;
             continue;
         }
         if (o.outlier_scene || o.outlier_text)
-            if (D.n_sc + D.n_tg > 0) hipLaunchKernelGGL(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
+            if (D.n_sc + D.n_tg > 0) LAUNCHK(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg), dim3(64), 0, c->stream, c->W, D,
                                                           o.chi2_mono[ps], o.chi2_text[ps], o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)nullptr);
-        if (c->cov_text >= 0 && c->cov_text < c->n_text && ps < TSBA_MAX_LEVELS) hipLaunchKernelGGL(k_record_vtx, dim3(1), dim3(64), 0, c->stream, c->W, c->cov_text, c->cov_log + 6*ps);
+        if (c->cov_text >= 0 && c->cov_text < c->n_text && ps < TSBA_MAX_LEVELS) LAUNCHK(k_record_vtx, dim3(1), dim3(64), 0, c->stream, c->W, c->cov_text, c->cov_log + 6*ps);
         CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
-        if (fast_any) hipLaunchKernelGGL(k_part_clear, dim3(8), dim3(256), 0, c->stream, c->W);       // (a later pass may begin with k_pass_begin)
+        if (fast_any) LAUNCHK(k_part_clear, dim3(8), dim3(256), 0, c->stream, c->W);       // (a later pass may begin with k_pass_begin)
     }
     if (c->world > 1) {                           // every landmark was optimised by its owner only
         int nl = c->n_pt + 3*c->n_text;
         if (nl > 0) {
-            hipLaunchKernelGGL(k_delta_multi, dim3((nl + 255)/256), dim3(256), 0, c->stream, c->W, (const double *)c->rho0, (const double *)c->theta0, 0);
+            LAUNCHK(k_delta_multi, dim3((nl + 255)/256), dim3(256), 0, c->stream, c->W, (const double *)c->rho0, (const double *)c->theta0, 0);
             if (c->n_pt) allreduce(c, c->W.dl_pt, c->n_pt, ncclDouble, ncclSum);
             if (c->n_text) allreduce(c, c->W.dl_tx, 3*(size_t)c->n_text, ncclDouble, ncclSum);
-            hipLaunchKernelGGL(k_delta_multi, dim3((nl + 255)/256), dim3(256), 0, c->stream, c->W, (const double *)c->rho0, (const double *)c->theta0, 1);
+            LAUNCHK(k_delta_multi, dim3((nl + 255)/256), dim3(256), 0, c->stream, c->W, (const double *)c->rho0, (const double *)c->theta0, 1);
         }
     }
     // the passes' final states straight into pinned host memory (a kernel's stores: no copy engine, no staging)
-    hipLaunchKernelGGL(k_solve_end, dim3(1), dim3(64), 0, c->stream, c->W, c->st_log, o.n_passes, log_pending ? 1 : 0, c->st_host, (unsigned int *)(c->st_host + TSBA_MAX_LEVELS) + 8);
+    LAUNCHK(k_solve_end, dim3(1), dim3(64), 0, c->stream, c->W, c->st_log, o.n_passes, log_pending ? 1 : 0, c->st_host, (unsigned int *)(c->st_host + TSBA_MAX_LEVELS) + 8);
     int *pcg_host = (int *)(c->st_host + TSBA_MAX_LEVELS);          // (the pinned block has room for 8 ints behind the pass snapshots)
     if (c->far_B > 0) CK(hipMemcpyAsync(pcg_host, c->W.pc_stat, 8*sizeof(int), hipMemcpyDeviceToHost, c->stream));
     CK(hipStreamSynchronize(c->stream));
@@ -1521,7 +1541,7 @@ int tsba_download(void *ctx, tsba_problem *p) {
         CK(hipMalloc((void **)&c->dl_dev, cap)); CK(hipHostMalloc((void **)&c->dl_host, cap, hipHostMallocDefault)); c->dl_bytes = cap;
     }
     const size_t work = std::max<size_t>({7*(size_t)c->n_kf, (size_t)c->n_pt, 3*(size_t)c->n_text, (size_t)c->n_sgood, (size_t)c->n_tobs, (size_t)c->n_tfgood, 64});
-    hipLaunchKernelGGL(k_pack_results, dim3((unsigned)std::min<size_t>(1024, (work + 255)/256)), dim3(256), 0, c->stream, c->W, L, c->dl_dev, c->n_kf, c->n_pt, c->n_text, c->n_sgood, c->n_tobs, c->n_tfgood);
+    LAUNCHK(k_pack_results, dim3((unsigned)std::min<size_t>(1024, (work + 255)/256)), dim3(256), 0, c->stream, c->W, L, c->dl_dev, c->n_kf, c->n_pt, c->n_text, c->n_sgood, c->n_tobs, c->n_tfgood);
     CK(hipMemcpyAsync(c->dl_host, c->dl_dev, L.total, hipMemcpyDeviceToHost, c->stream));
     CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
     memcpy(p->pose, c->dl_host + L.o_pose, sizeof(double)*7*(size_t)c->n_kf);
@@ -1627,8 +1647,8 @@ int tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int level
         rc = dev_alloc(c, &d_r, (size_t)(2*ns + 8*nt)); if (rc) return rc;
         if (jac) { rc = dev_alloc(c, &d_j, (size_t)(26*ns + 120*nt)); if (rc) return rc; }
         flush_run(c);                                  // staged uploads leave as one copy
-        if (H.n_sc() > 0) hipLaunchKernelGGL(k_eval_scene, dim3((H.n_sc() + 255)/256), dim3(256), 0, c->stream, c->W, D, d_oi, d_r, d_j);
-        if (nt > 0) hipLaunchKernelGGL(k_eval_text, dim3(((int)nt + 255)/256), dim3(256), 0, c->stream, c->W, D, (int)nt, d_bg, d_bf, (int)ns, d_r, d_j);
+        if (H.n_sc() > 0) LAUNCHK(k_eval_scene, dim3((H.n_sc() + 255)/256), dim3(256), 0, c->stream, c->W, D, d_oi, d_r, d_j);
+        if (nt > 0) LAUNCHK(k_eval_text, dim3(((int)nt + 255)/256), dim3(256), 0, c->stream, c->W, D, (int)nt, d_bg, d_bf, (int)ns, d_r, d_j);
         CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
         if (resid) CK(hipMemcpy(resid, d_r, sizeof(double)*(size_t)(2*ns + 8*nt), hipMemcpyDeviceToHost));
         if (jac) CK(hipMemcpy(jac, d_j, sizeof(double)*(size_t)(26*ns + 120*nt), hipMemcpyDeviceToHost));

@@ -47,7 +47,15 @@ __device__ __forceinline__ void cre_batched(int n, int tid, F f, G st) {
 // K workgroups per pivot: all of them run the same factorisation (bit-identical: same instruction sequence on the same data), then
 // share the product and the stores -- E D E^T is 36 tiles x 15 fp64 MFMA of 64 cycles at s = 60, 8.6 k cycles of ONE compute unit's four
 // matrix pipes, and three quarters of the chip idle next to the 32 pivots of the first level.
-__global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int Pmax, int h, int root, int K, int kb, double *contrib, double *fac) {
+// The K workgroups of a pivot overwrite the couplings S(i, a), S(c, i) IN PLACE with X_a, X_c (what the back substitution reads) -- the very blocks every one
+// of them loads first.  Started together they are 25 us past their loads when the first of them stores; with another context on the device (TextSLAM extracts
+// ORB features while a bundle adjustment runs) one of the K can be dispatched that much later and load a mix of S and X: found in round 5 by running the
+// 5000-keyframe solves beside a busy context (1 run in 15 ended with other numbers, some with a failed step).  `gate` [label][K]: workgroup `part` counts its
+// completed load phases there (its own word: a plain counter, one writer); before the first store every workgroup makes sure its K - 1 siblings' counters
+// have reached its own -- checked by an update wave during the last factorisation step, where it costs nothing; a sibling that is late is waited for
+// (not for ever, and not once the step has failed anyway).  The counter is the factorisation's ordinal `epoch` (host), so a label that sits a pass out, or
+// a workgroup that left early, leaves nothing behind.
+__global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int Pmax, int h, int root, int K, int kb, double *contrib, double *fac, int *gate, int epoch) {
     LmState *st = W.st;
     if (st->done || st->step_fail || st->lin_done) return;
     const CrRange rg = cr_range(W, bw, Pmax);
@@ -58,6 +66,9 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
         if (i < lo || i >= m || (W.ring && i == m - 1)) return;  // (ring: label m - 1 is the ghost of the root, never a pivot)
         a = i - h >= lo ? i - h : -1; c = i + h < m ? i + h : -1; }
     const int part = root ? 0 : (int)blockIdx.x % K;
+    int *gate_i = gate + (size_t)i*TSBA_CRE_KMAX;
+    const int my_gen = epoch;
+    __shared__ int gate_ok;
     const int H = root ? (1 << 30) : h;                          // pending updates come from the pivots i -+ h', h' < H
     const int na = a >= 0 ? s : 0, nc = c >= 0 ? s : 0, ne = na + nc + 1, n = s + ne - 1;     // rows 0 .. n, row n = g_i
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -122,8 +133,9 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
         if (c >= 0) { const double *Bci = cr_blk(S, s, mmax, c, i);          // S(c, i)(j, r) -> row j of c, column r
             cre_batched<CRE_T, 8>(s*s, tid, [&](int e) { return Bci[e]; }, [&](int e, double v) { const int j = rowof(e), r = e - j*s; A[xbase + (na + j)*sst + r] = v; }); }
     }
-    if (tid == 0) fail = 0;
+    if (tid == 0) { fail = 0; gate_ok = K > 1 ? 0 : 1; }
     __syncthreads();
+    if (K > 1 && tid == CRE_T - 64) __hip_atomic_store(gate_i + part, my_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // this workgroup has loaded (the barrier: every thread's loads have returned)
     CRE_STAMP(q1_);
     for (int jb = 0; jb < B && !fail; jb++) {
         const int j0 = 6*jb, R0 = j0 + 6, p0 = j0 - 6;
@@ -244,6 +256,11 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
                     }
                 }
             }
+            if (K > 1 && jb == B - 1 && tid == CRE_T - 64) {      // have the siblings loaded?  (normally long ago: one round trip beside this step's tiles)
+                bool ok = true;
+                for (int p2 = 0; p2 < K; p2++) if (p2 != part) ok = ok && __hip_atomic_load(gate_i + p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - my_gen >= 0;
+                gate_ok = ok ? 1 : 0;
+            }
             if (wave == NW - 1) {                                // inverse of the unit-lower factor of block jb-1
                 double l[15], mi[15];
 #pragma unroll
@@ -277,6 +294,17 @@ __global__ __launch_bounds__(CRE_T) void k_cre_elim(Work W, Work Ws, int bw, int
             for (int k = lane; k < s; k += 64) { Ws.Sy[(size_t)r0*s + k] = Pk[rowoff(s) + k]; if (root == 2) Ws.Sy[(size_t)(m - 1)*s + k] = Pk[rowoff(s) + k]; }
         }
         return;
+    }
+    if (!gate_ok) {                                              // (uniform) a sibling had not loaded yet: wait for it -- bounded, counted, and the step fails if it never comes
+        if (tid == CRE_T - 64) {
+            bool ok = false;
+            for (int spins = 0; !ok && spins < (1 << 16); spins++) { ok = true;
+                for (int p2 = 0; p2 < K; p2++) if (p2 != part) ok = ok && __hip_atomic_load(gate_i + p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - my_gen >= 0;
+                if (!ok && __hip_atomic_load(&st->step_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;      // (the step has failed elsewhere: a sibling may have left at once)
+                if (!ok) __builtin_amdgcn_s_sleep(8); }
+            if (!ok && !__hip_atomic_load(&st->step_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&ts_poll_giveups, 1u); st->step_fail = 1; }
+        }
+        __syncthreads();
     }
     // ---- the factor for the back substitution (packed rows), X_a / X_c over the couplings, z over g
     double *rec = fac + (size_t)i*cre_rec_doubles(s);
