@@ -92,9 +92,12 @@ def test_long_range_map_beside_a_busy_context(gpu, map_cache):
         assert busy.runs > 2
 
 
-def test_open_chain_beside_a_busy_context(gpu, map_cache):
-    """The direct solve of a 5000-keyframe chain: its separator back-substitution is one polling launch (k_cre_back_tree)."""
-    P = map_cache(n_kf=5000, n_pt=70000, band=10); o = abi.options_global(); o.its[0] = 6
+@pytest.mark.parametrize("kw", [dict(n_kf=5000, n_pt=70000, band=10), dict(n_kf=5000, n_pt=70000, band=10, loop=True), dict(n_kf=5000, n_pt=70000, band=10, closures=2),
+                                dict(n_kf=500, n_pt=50000, band=12)], ids=["open_chain", "ring", "two_closures", "c5"])
+def test_direct_map_solves_beside_a_busy_context(gpu, map_cache, kw):
+    """The direct solves of the large maps (partitioned band solver + cyclic reduction; on the 5000-keyframe chain the separator back-substitution is one polling
+    launch, k_cre_back_tree; two closures: + the low-rank correction)."""
+    P = map_cache(**kw); o = abi.options_global(); o.its[0] = 6
     alone = _solve(gpu, P, o, 1)
     assert alone[0]["poll_timeouts"] == 0
     with _Busy() as busy:
