@@ -46,9 +46,6 @@ int tsorb_download(void *ctx, float *kp, uint8_t *desc, int32_t *count);
 /* Test hook: pyramid level `level` (with its 19-px BORDER_REFLECT_101 frame) of frame f after a run: (h_l + 38) x (w_l + 38) bytes;
  * blurred = 1 returns the 7x7 Gaussian-blurred level (no frame): h_l x w_l. */
 int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out, int32_t *w_out, int32_t *h_out);
-/* Test / diagnostics switch (applies to the next upload of a new geometry): pyramid_launches = 1 computes every pyramid level in a launch of its own (as
- * until round 5) instead of the upper levels in one launch by a workgroup per frame (k_resize_tail); same pixels either way. */
-int tsorb_debug_set(void *ctx, int pyramid_launches);
 
 /* ---- Window / projection search: the step between the extractor and PoseOptim.
  *   tsorb_match_set_frame / _set_features  <- frame::AssignFeaturesToGrid + PosInGrid                       src/frame.cc:372-407

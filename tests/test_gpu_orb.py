@@ -106,27 +106,3 @@ def test_match_search_parity_on_resident_frames(orb, oracle_lib):
     got2 = ex.match_search(qxy, qr, None, dA, max_cand=32)
     for k in ("cand_cnt", "best_idx", "best_dist", "best_dist2", "cand_idx", "cand_dist"):
         assert np.array_equal(got2[k], ref2[k]), k
-
-
-@pytest.mark.parametrize("shape", [(480, 640), (480, 752), (241, 322), (96, 128)])
-def test_upper_pyramid_levels_in_one_launch_equal_the_launch_per_level(oracle_lib, shape):
-    """k_resize_tail (one workgroup per frame computes the pyramid from the first level whose predecessor fits its LDS) against a launch per level
-    (tsorb_debug_set(1), the pipeline until round 5): every level with its border, and the extractor's output, byte for byte -- 640 x 480 (levels 3 .. 7 fused),
-    752 x 480 (4 .. 7), and two small frames where the whole pyramid above level 0 is one launch; the first size also against the oracle."""
-    from textslam_amd.orbextractor import ORBextractor
-    h, w = shape
-    imgs = np.stack([np.ascontiguousarray(np.tile(synthetic_frame(60 + s), (1, 2))[:h, :w]) for s in range(3)])
-    ex = ORBextractor(1000, 1.2, 8, 20, 7, device=0)
-    out = {}
-    for mode in (0, 1):
-        ex.debug_set(pyramid_launches=mode)
-        res = ex.extract_batch(imgs)
-        out[mode] = (res, [[ex.debug_level(f, l) for l in range(8)] for f in range(len(imgs))])
-    ex.debug_set()
-    for f in range(len(imgs)):
-        _same(out[0][0][f], out[1][0][f])
-        for l in range(8):
-            assert np.array_equal(out[0][1][f][l], out[1][1][f][l]), (f, l)
-    if shape == (480, 640):
-        for l in range(8):
-            assert np.array_equal(out[0][1][0][l], oracle_lib.orb_level(imgs[0], l))

@@ -182,60 +182,6 @@ __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
     }
 }
 
-// The upper levels of the pyramid in ONE launch: level l is cv::resize of level l - 1 (ORBextractor::ComputePyramid, ORBextractor.cc:1118-1143), so the
-// levels are dependent launches -- seven of them, 12.7 us each on a batch of 64 frames, and from the fourth on a launch has less work than its own
-// latency.  Here one workgroup per frame walks the levels l0 .. nlevels - 1: the INTERIOR of level l - 1 (all a resize reads: border pixels are evaluated at
-// reflected coordinates) is staged in LDS -- 148 KB for level 2 of a 640 x 480 frame: l0 is the first level whose predecessor fits --, every thread takes
-// quads of four neighbouring bordered pixels (column terms in registers for all rows, row terms uniform per wave), and the bordered level goes to the
-// pyramid in HBM, from where the next stage reloads its interior (same workgroup: a barrier orders it).  Pixel for pixel k_resize's arithmetic
-// (cv::resize INTER_LINEAR, 11-bit weights): the bit-exact tests are the guard.
-#define RT_T 1024
-#define RT_LDS_MAX (150*1024)
-__global__ __launch_bounds__(RT_T) void k_resize_tail(OrbDev D, int l0) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t sprev[];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int l = l0; l < D.nlevels; l++) {
-        const LevelGeo &G = D.L[l], &S = D.L[l-1];
-        const int sw4 = (S.w + 3) & ~3;                        // LDS row stride (dword stores)
-        const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + S.pyr_off + (size_t)EDGE*S.bw + EDGE;
-        {   // stage the interior of level l - 1: (unaligned) dwords, four in flight per thread
-            const int qw = sw4 >> 2, nq = qw*S.h; const float inv_qw = 1.0f/(float)qw;
-            for (int q0 = tid; q0 < nq; q0 += 4*RT_T) {
-                uint32_t v[4]; int at[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const int q = min(q0 + u*RT_T, nq - 1), y = (int)(((float)q + 0.5f)*inv_qw), x = 4*(q - y*qw);
-                    at[u] = y*sw4 + x; v[u] = *(const u32_unaligned *)(src + (size_t)y*S.bw + x); }      // (up to 3 bytes past the interior: still inside the level's frame)
-#pragma unroll
-                for (int u = 0; u < 4; u++) if (q0 + u*RT_T < nq) *(uint32_t *)(sprev + at[u]) = v[u];
-            }
-        }
-        __syncthreads();
-        const int2 *xtab = (const int2 *)(D.rtab + G.rx_off);
-        const int4 *ytab = (const int4 *)(D.rtab + G.ry_off);
-        uint8_t *dst = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off;
-        const int gq = (G.bw + 3) >> 2;                         // quads per bordered row
-        for (int xq0 = 0; xq0 < gq; xq0 += 64) {
-            const int xq = xq0 + lane, x = 4*xq;
-            int sx[4], sx1[4], a0[4], a1[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const int2 t = xtab[min(x + k, G.bw - 1)]; sx[k] = t.x & 0xffff; sx1[k] = t.x >> 16; a0[k] = t.y & 0xffff; a1[k] = t.y >> 16; }
-            for (int y = wave; y < G.bh; y += RT_T/64) {
-                const int4 yt = ytab[y];
-                const uint8_t *r0 = sprev + yt.x*sw4, *r1 = sprev + yt.y*sw4;
-                uint32_t o = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t S0 = __umul24((uint32_t)r0[sx[k]], a0[k]) + __umul24((uint32_t)r0[sx1[k]], a1[k]), S1 = __umul24((uint32_t)r1[sx[k]], a0[k]) + __umul24((uint32_t)r1[sx1[k]], a1[k]);
-                    o |= ((((__umul24(yt.z, S0 >> 4)) >> 16) + ((__umul24(yt.w, S1 >> 4)) >> 16) + 2) >> 2) << (8*k);
-                }
-                if (xq < gq) { uint8_t *d = dst + (size_t)y*G.bw + x;
-                    if (x + 3 < G.bw) *(u32_unaligned *)d = o; else for (int k = 0; x + k < G.bw; k++) d[k] = (uint8_t)(o >> (8*k)); }
-            }
-        }
-        __syncthreads();                                        // level l is in HBM (this workgroup's stores: visible to its own loads after the barrier) and sprev is free
-    }
-}
-
 // ---------------------------------------------------------------- FAST per cell
 // quick reject: 9 contiguous ring pixels always contain at least two of the four compass points
 __device__ __forceinline__ bool fast_maybe(const uint8_t *p, int stride, int threshold) {
@@ -1014,8 +960,6 @@ struct OCtx {
     // the SLAM front-end calls once per frame with the same geometry: buffers and pinned staging are kept between calls
     MatchDev M; bool m_set = false; void *m_buf = nullptr; size_t m_cap = 0; void *m_feat = nullptr; size_t m_feat_cap = 0;   // search grid of the current frame
     void *mq_dev = nullptr, *mq_host = nullptr; size_t mq_cap = 0;
-    bool no_tail = false;                       // tsorb_debug_set: 1 = every level as a launch of its own (A/B runs, bit-identity test)
-    int tail_l0 = 0, tail_lds = 0;              // k_resize_tail: first level it computes (0: none), dynamic LDS (the largest staged interior)
     int key[5] = {0, 0, 0, 0, 0}; uint8_t *h_img = nullptr; void *h_out = nullptr; size_t h_img_sz = 0, h_out_sz = 0;
 };
 static int cv_round_f(float v) { return (int)lrintf(v); }
@@ -1115,11 +1059,6 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     }
     c->key[0] = n; c->key[1] = w; c->key[2] = h; c->key[3] = stride; c->key[4] = cap;
     if (c->nlevels > 1) hipLaunchKernelGGL(k_resize_tab, dim3(c->nlevels - 1), dim3(256), 0, c->stream, D);
-    // the pyramid's tail: from the first level whose predecessor's interior fits the LDS of one workgroup, when at least two levels are left to fuse
-    c->tail_l0 = 0; c->tail_lds = 0;
-    if (!c->no_tail) for (int l = 1; l < c->nlevels; l++) { const size_t need = (size_t)((D.L[l-1].w + 3) & ~3)*D.L[l-1].h + 16;
-        if (need <= RT_LDS_MAX && c->nlevels - l >= 2) { c->tail_l0 = l; c->tail_lds = (int)need; break; } }
-    if (c->tail_l0) OCK(hipFuncSetAttribute((const void *)k_resize_tail, hipFuncAttributeMaxDynamicSharedMemorySize, c->tail_lds));
     c->uploaded = true; return TSORB_OK;
 }
 int tsorb_run(void *ctx) {
@@ -1127,10 +1066,7 @@ int tsorb_run(void *ctx) {
     hipSetDevice(c->device);
     OrbDev &D = c->D;
     hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
-    // levels 1 .. tail_l0 - 1 as launches of their own (the whole chip per level), the rest by one workgroup per frame in one launch (k_resize_tail)
-    const int l_tail = c->tail_l0 > 0 ? c->tail_l0 : D.nlevels;
-    for (int l = 1; l < l_tail; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
-    if (l_tail < D.nlevels) hipLaunchKernelGGL(k_resize_tail, dim3(D.n), dim3(RT_T), c->tail_lds, c->stream, D, l_tail);
+    for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
     hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
@@ -1159,7 +1095,6 @@ int tsorb_extract_batch(void *ctx, const uint8_t *imgs, int n, int w, int h, int
     rc = tsorb_run(ctx); if (rc) return rc;
     return tsorb_download(ctx, kp, desc, count);
 }
-int tsorb_debug_set(void *ctx, int pyramid_launches) { OCtx *c = (OCtx *)ctx; if (!c) return TSORB_ERR_ARG; hipSetDevice(c->device); c->no_tail = pyramid_launches != 0; ofree(c); return TSORB_OK; }      // (the next upload lays the buffers out again)
 int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out, int32_t *w_out, int32_t *h_out) {
     OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded || !out) return TSORB_ERR_ARG;
     OrbDev &D = c->D; if (frame < 0 || frame >= D.n || level < 0 || level >= D.nlevels) return TSORB_ERR_ARG;
