@@ -63,6 +63,76 @@ class _Busy:
         self.ex.close()
 
 
+class _BusyBA:
+    """A second bundle-adjustment context solving a 700-keyframe map over and over on another host thread (TextSLAM's loop-closing thread runs GlobalBA while
+    the mapping thread runs local windows, loopClosing.cc:587-591 / tracking.cc:826-842): workgroups of 768 threads with 100+ KB of LDS, the kind that keeps
+    a polling launch's workgroups off the device."""
+    def __init__(self):
+        from textslam_amd.optimizer import Optimizer
+        self.g = Optimizer(0)
+        P = synth.config_global(n_kf=700, n_pt=14000, band=8); o = abi.options_global(); o.its[0] = 20
+        self.g.upload(P, o)
+        self.stop = threading.Event(); self.runs = 0; self.reps = set()
+        self.th = threading.Thread(target=self._loop, daemon=True)
+
+    def _loop(self):
+        while not self.stop.is_set():
+            rep = self.g.solve(); self.runs += 1
+            self.reps.add((tuple(rep["iters"]), tuple(rep["accepted"]), tuple(rep["cost1"]), rep["poll_timeouts"]))
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set(); self.th.join(timeout=60)
+        self.g.close()
+
+
+def test_window_and_maps_beside_a_second_bundle_adjustment(gpu, map_cache):
+    """Local windows and 5000-keyframe maps on one context while a second context solves a 700-keyframe map in a loop: both sides bit-identical to their runs
+    alone, no time-outs."""
+    Pw, ow = synth.config_c4(), abi.options_local()
+    alone_w = _solve(gpu, Pw, ow, ow.n_passes)
+    maps = {}
+    for name, kw in (("open_chain", {}), ("long_range", dict(far_frac=0.01))):
+        P = map_cache(n_kf=5000, n_pt=70000, band=10, **kw); o = abi.options_global(); o.its[0] = 5
+        maps[name] = (P, o, _solve(gpu, P, o, 1))
+    with _BusyBA() as busy:
+        while busy.runs < 2:
+            pass
+        for _ in range(15):
+            r = _solve(gpu, Pw, ow, ow.n_passes)
+            assert r[0]["poll_timeouts"] == 0
+            _same(r, alone_w)
+        for name, (P, o, alone) in maps.items():
+            for _ in range(6):
+                r = _solve(gpu, P, o, 1)
+                assert r[0]["poll_timeouts"] == 0 and r[0]["pcg_unconverged"] == 0, (name, r[0])
+                _same(r, alone)
+        n = busy.runs
+    assert n > 4 and len(busy.reps) == 1 and next(iter(busy.reps))[3] == 0, (n, busy.reps)      # the other side: one and the same result every time
+
+
+def test_orb_extraction_beside_a_busy_bundle_adjustment(oracle_lib):
+    """The other direction: the ORB extractor's output while a bundle adjustment loops on the device -- keypoints and descriptors bit-exact (vs the oracle)."""
+    from textslam_amd.orbextractor import ORBextractor, synthetic_frame
+    imgs = np.stack([synthetic_frame(80 + s) for s in range(8)])
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device=0)
+    ref = ex.extract_batch(imgs)
+    kp_o, d_o = oracle_lib.orb_extract(imgs[0])
+    assert np.array_equal(ref[0][0][:, :2], kp_o[:, :2]) and np.array_equal(ref[0][1], d_o)
+    with _BusyBA() as busy:
+        while busy.runs < 2:
+            pass
+        for _ in range(25):
+            res = ex.extract_batch(imgs)
+            for (ka, da), (kb, db) in zip(res, ref):
+                assert np.array_equal(ka, kb) and np.array_equal(da, db)
+        assert busy.runs > 4
+    ex.close()
+
+
 def test_window_solve_beside_a_busy_context(gpu):
     P, o = synth.config_c4(), abi.options_local()
     alone = _solve(gpu, P, o, o.n_passes)
