@@ -11,7 +11,7 @@ Per configuration:
   * the LM prefix: the oracle's trust-region loop on block-sparse normal equations with an exact linear solve (oracle.sparse_solver) against
     the GPU's trace, trial by trial: K = number of leading trials with the same decision and the same candidate cost.  On maps of this size
     the trajectory is NOT a function of the algorithm alone: two exact solvers inside the oracle itself (band Cholesky / SuperLU) part at
-    K(1e-9) = 4, K(1e-6) = 6 on the open chain -- rounding differences of 1e-16 in the step grow by ~30 x per LM iteration.  The test
+    K(1e-9) = 4, K(1e-6) = 6 on the open chain (docs/ledger_r04.md 13.1) -- rounding differences of 1e-16 in the step grow by ~30 x per LM iteration.  The test
     asserts a floor for K and records the measured values in gpurun_out/lm_prefix.json.
   * N = 2 / 8 in-process ranks at 5000 keyframes: the same prefix statement for the sharded solve against the single-rank GPU trace.
 """
@@ -34,7 +34,7 @@ CONFIGS = {
     "c6_closures2":  dict(n_kf=5000, n_pt=70000, band=10, closures=2),
 }
 PREFIX_ITS = 12          # LM trials compared (the trajectories of two exact implementations part well before)
-# floors for (K at 1e-9, K at 1e-6, trials with the same decision), set below the measured values: C5 12 / 12 / 12, ring 11 / 11 / 11 and two
+# floors for (K at 1e-9, K at 1e-6, trials with the same decision), set below the measured values (docs/ledger_r04.md 13.1): C5 12 / 12 / 12, ring 11 / 11 / 11 and two
 # closures 10 / 10 / 10 (the whole run, costs to 1e-13: closed loops pin the drift modes), open chain 1 / 5 / 12 (its free end makes S ill-conditioned:
 # two backward-stable solvers differ by cond x eps in the step), long-range points 0 / 3 / 12 with the product's 1e-10 conjugate-gradient tolerance
 # Round 5: every floor is (measured in rounds 4 and 5) - 1, so that a regression of two trials fails; the 1e-9 floor of the open chain stays at its
@@ -285,7 +285,7 @@ def _gauge_aligned_pose_gap(Pa, Pb):
 @pytest.mark.parametrize("name", ["c6_open_chain", "c6_long_range"])
 def test_converged_answers_against_the_oracle(gpu, oracle_lib, map_cache, name):
     """SURVEY 8d's tolerance is stated on CONVERGED answers, and the reference runs one deterministic solve to Ceres' exit (optimizer.cc:1833-1846).  The
-    12-trial prefix above cannot say whether GPU and oracle arrive at the same answer on the two maps where their trajectories part (cond x eps, DESIGN 7 /
+    12-trial prefix above cannot say whether GPU and oracle arrive at the same answer on the two maps where their trajectories part (cond x eps, docs/ledger_r04.md
     13.1): here both run until the function tolerance ends them (oracle: 231 / 129 iterations, tests/golden/make_converged.py; end states committed).
 
       (a) AT the oracle's converged answer the two implementations agree on everything the next iteration is made of: cost (1e-11), reduced gradient and

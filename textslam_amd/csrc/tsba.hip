@@ -848,7 +848,7 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
     int nb_pt, nb_tx, nb_pr; mid_blocks(c, D, nb_pt, nb_tx, nb_pr); const int nb_kf = (c->n_kf + 255)/256;
     // EXPERIMENT, off by default (trial_launches = 2): k_mid inside the speculative linearisation's launch (k_lin_mid: its last workgroups to finish take the k_mid
     // blocks).  Measured in round 5: 40.7 us per launch against 13.4 + 10.6 us for the two launches -- 736 workgroups telling each other that they are done costs
-    // more than the kernel boundary it replaces (tools/ticket_bench.hip)
+    // more than the kernel boundary it replaces (tools/ticket_bench.hip, docs/ledger_r05.md 14.2)
     if (spec && W.st_next && c->lin_ticket && c->dbg.trial_launches == 2 && !is_multi(c) && mid_threads(c) == MID_TW && D.n_pair + D.n_tg > 0 && !lin_small_pairs(c, D)) {
         const unsigned grid = (unsigned)((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8);
         LAUNCHK(k_lin_mid, dim3(grid), dim3(LIN_T), 0, c->stream, W, D, nb_pt, nb_tx, nb_pt + nb_tx + nb_pr, c->lin_ticket, c->lin_base);
