@@ -42,6 +42,18 @@ for name, (P, mode) in t._cases().items():
 print("bad", bad)
 PY
 say "adapter gather/scatter + C++ driver (g++ ASan+UBSan, 6 problem types): $(tail -1 /tmp/san_adapter.log)"
+# the sliding-window gather with the segment cache (round 5): six windows, a mutated graph, invalidate() -- C4-sized
+python - > /tmp/san_slide.log 2>&1 <<'PY'
+import subprocess, sys, os, tempfile
+sys.path.insert(0, ".")
+from textslam_amd import synth, abi
+d = tempfile.mkdtemp(); dump = os.path.join(d, "c4.bin")
+abi.write_dump(dump, synth.config_c4())
+r = subprocess.run(["/tmp/abi_from_cxx_san", dump, "slide_check", os.path.join(d, "o.bin")], capture_output=True, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
+ok = r.returncode == 0 and "gathers identical" in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr
+print(r.stdout.strip()); print("OK" if ok else "BAD\n" + r.stderr[-2000:])
+PY
+say "adapter gather cache, sliding window + mutated graph (g++ ASan+UBSan): $(tail -1 /tmp/san_slide.log)"
 g++ -std=c++11 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -Iadapter -o /tmp/loop_from_cxx_san tests/cxx/loop_from_cxx.cpp -Ltextslam_amd -ltsloop -L/opt/rocm/lib -Wl,-rpath,$PWD/textslam_amd -Wl,-rpath,/opt/rocm/lib || say "loop adapter build: FAILED"
 python - > /tmp/san_loop_adapter.log 2>&1 <<'PY'
 import subprocess, sys, os, tempfile
