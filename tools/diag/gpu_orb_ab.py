@@ -1,0 +1,12 @@
+import os, sys, time, numpy as np
+sys.path.insert(0, os.getcwd())
+from textslam_amd.orbextractor import ORBextractor, synthetic_frame
+imgs = np.stack([synthetic_frame(s) for s in range(64)])
+for n in (64, 1):
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device=0); ex.upload(imgs[:n])
+    for _ in range(5): ex.run()
+    ts = []
+    for _ in range(40):
+        t0 = time.perf_counter(); ex.run(); ts.append((time.perf_counter() - t0)*1e3)
+    print(os.environ.get("TSORB_LIB", "default"), f"frames {n:2d}: median {np.median(ts):.4f} ms  min {min(ts):.4f} ms", flush=True)
+    ex.close()
