@@ -67,7 +67,9 @@ __device__ __forceinline__ uint8_t *lev_ptr(const OrbDev &D, uint8_t *base, int 
 // ---------------------------------------------------------------- pyramid
 // level 0 = the input inside its REFLECT_101 frame.  grid (x chunks of 4 x 128 pixels, groups of L0_ROWS bordered rows, frames); a thread
 // moves four neighbouring pixels as one (unaligned) dword where they do not touch the reflected columns.
+#ifndef L0_ROWS
 #define L0_ROWS 8
+#endif
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __global__ __launch_bounds__(128) void k_level0(OrbDev D) {
     const LevelGeo &G = D.L[0];
@@ -126,8 +128,12 @@ __global__ __launch_bounds__(256) void k_resize_tab(OrbDev D) {
 // the reflected columns their source columns are monotone and span at most 8 bytes, so a source row is one (unaligned) 8-byte load instead of
 // eight byte gathers, and the result one dword store instead of four byte stores (the byte version moved 1 byte per lane and instruction: 19 us
 // per level for 64 frames).  The column terms stay in registers for the row group; the row terms are uniform.
+#ifndef RS_ROWS
 #define RS_ROWS 8
+#endif
+#ifndef RS_T
 #define RS_T 64
+#endif
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
     const LevelGeo &G = D.L[l], &S = D.L[l-1];
