@@ -421,7 +421,8 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     // marking the blocks of the point slots: by POSE (thread t the poses [a0, a1) with about the same number of slots: every slot of pose a, every
     // slot of its landmark at a pose b >= a) -- a thread then writes its own rows of the key bitmap only; landmark-major, every thread wrote
     // every row, and each of the 45 k first-time writes took the line out of fifteen other caches
-    if (T > 1 && tsba_plan_mark_mt) {
+    if (n_kf <= 64) { /* small windows: every (a, b) is a block (added below) -- nothing to mark */ }
+    else if (T > 1 && tsba_plan_mark_mt) {
         const size_t n_ps = (size_t)P.n_pslot();
         pool.run([&](int t) {
             const int a0 = (int)(std::lower_bound(P.pose_ps_off.begin(), P.pose_ps_off.end(), (int32_t)(n_ps*(size_t)t/(size_t)T)) - P.pose_ps_off.begin());
@@ -430,7 +431,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
                 for (int x = P.pose_ps_off[a]; x < P.pose_ps_off[a+1]; x++) { const int j = P.pose_ps_lm[x], sa = P.pose_ps[x];
                     for (int s2 = P.pls_off[j]; s2 < P.pls_off[j+1]; s2++) { const int b = P.pslot_pose[s2]; if (b >= a && (!cl_pt || cl_pt[sa] == cl_pt[s2])) bk.add_mt(bkey(a, b)); } } });
     } else range_pairs(P.pls_off, P.pslot_pose, cl_pt, 0, n_pt, [&](int64_t k, int, int) { bk.add(k); });
-    range_pairs(P.tls_off, P.tslot_pose, cl_tx, 0, n_text, [&](int64_t k, int, int) { bk.add(k); });
+    if (n_kf > 64) range_pairs(P.tls_off, P.tslot_pose, cl_tx, 0, n_text, [&](int64_t k, int, int) { bk.add(k); });
     for (int q = 0; q < n_pair; q++) { int i = P.pair_i[q], h = P.pair_h[q]; bk.add(bkey(i, i));
         if (h >= 0) { bk.add(bkey(h, h)); if (!pair_far || !pair_far[q]) bk.add(bkey(std::min(i, h), std::max(i, h))); } }
     if (n_kf <= 64) for (int a = 0; a < n_kf; a++) for (int b = a; b < n_kf; b++) bk.add(bkey(a, b));   // small windows: dense S, no memset
