@@ -125,3 +125,26 @@ def test_orb_library_exports_and_refuses_without_device():
         pytest.skip("a HIP device is present here")
     assert rc == -2
     assert L.tsorb_create(C.byref(ctx), 1000, 0.9, 8, 20, 7, 0) == -1          # bad scale factor
+
+
+def test_abi_version_is_the_headers(lib):
+    """tsba_abi_version() (what the adapter and the Python mirror check before they hand a struct to the library) equals TSBA_ABI_VERSION of include/tsba.h
+    and the mirror's constant."""
+    from textslam_amd import optimizer
+    m = re.search(r"#define\s+TSBA_ABI_VERSION\s+(\d+)", open(HDR).read())
+    assert m and lib.tsba_abi_version() == int(m.group(1)) == optimizer.ABI_VERSION
+
+
+def test_report_keeps_its_size_and_the_new_counter_sits_in_a_reserved_word(tmp_path):
+    """tsba_report.poll_timeouts (round 5) took one of the three reserved words: the struct a caller built against the round-4 header passes is as long as
+    the one the library writes."""
+    from textslam_amd import abi
+    src = tmp_path / "r.c"
+    src.write_text('#include "tsba.h"\n#include <stddef.h>\nunsigned long a(void){return sizeof(tsba_report);}\nunsigned long b(void){return offsetof(tsba_report, poll_timeouts);}\n'
+                   'unsigned long c(void){return offsetof(tsba_report, pcg_stagnated);}\n')
+    so = tmp_path / "r.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-o", str(so), str(src)])
+    L = C.CDLL(str(so))
+    for f in ("a", "b", "c"):
+        getattr(L, f).restype = C.c_ulong
+    assert L.a() == C.sizeof(abi.TsbaReport) and L.b() == L.c() + 4 == abi.TsbaReport.poll_timeouts.offset and L.a() == L.b() + 4 + 8
