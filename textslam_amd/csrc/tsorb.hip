@@ -206,15 +206,9 @@ __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int thre
     for (int k = 0; k < 16; k++) d[k] = v - p[cy[k]*stride + cx[k]];
 #pragma unroll
     for (int k = 16; k < 25; k++) d[k] = d[k - 16];
-    // 9 contiguous darker / brighter: run-length over the doubled ring, as bit masks
-    unsigned mp = 0, mn = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mp |= (d[k] > threshold ? 1u : 0u) << k; mn |= (d[k] < -threshold ? 1u : 0u) << k; }
-    mp |= mp << 16; mn |= mn << 16;
-    unsigned rp = mp, rn = mn;
-#pragma unroll
-    for (int k = 1; k < 9; k++) { rp &= mp >> k; rn &= mn >> k; }
-    if (((rp | rn) & 0xffffu) == 0) return 0;
+    // No separate arc test: the ladders below start at the threshold, so what they return is the largest threshold the pixel is still a corner at
+    // (minus one) when it is one at `threshold` -- an arc of 9 with every |difference| above it -- and threshold - 1 when it is not.  (The bit-mask
+    // run-length test this replaces cost a third of the instructions of a survivor and saved the ladders only for a wave without a single corner.)
     int a0 = threshold;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
@@ -233,7 +227,8 @@ __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int thre
         b0 = min(b0, max(b, d[k]));
         b0 = min(b0, max(b, d[k+9]));
     }
-    return -b0 - 1;
+    const int r = -b0 - 1;
+    return r >= threshold ? r : 0;
 }
 #ifndef FAST_TU
 #define FAST_TU 2                       // tile dwords per thread in flight (measured on a batch of 64: 1 -> 0.494, 2 -> 0.490, 3 -> 0.494, 4 -> 0.497, 6 -> 0.505 ms: more requests per thread cost occupancy)
@@ -292,14 +287,26 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     // (measured, phases of the 187 us: tile 46, quick reject 45, arc test + cornerScore of the survivors 70, non-maximum suppression + ordering 22;
     // the survivors in two steps -- arc test on all, the score ladders on the compacted corners only -- was slower, 201 us: two more barriers, and
     // the 16 ring reads, not the ladders, are what a survivor costs)
-    for (int k = tid; k < min(s_ncand, FAST_CAND); k += 256) { const int pos = s_cand[k]; score[pos] = (uint8_t)fast_score(tile + pos, TILE_MAX, D.min_th); }
+    // (a thread scores at most FAST_CAND / 256 = 8 survivors: which of them came out as corners stays in a bit mask, the suppression pass below looks at
+    // those positions only instead of at every pixel of the cell again -- 22 us of the 187 were that second sweep)
+    const int ncand = s_ncand;
+    unsigned mine = 0;
+    for (int k = tid, m = 0; k < min(ncand, FAST_CAND); k += 256, m++) { const int pos = s_cand[k], sc = fast_score(tile + pos, TILE_MAX, D.min_th); score[pos] = (uint8_t)sc; mine |= (sc > 0 ? 1u : 0u) << m; }
     __syncthreads();
     // 3x3 non-maximum suppression.  The survivors are few (a handful per cell): appended in any order, then put into the reference's
     // row-major order by a rank sort on the pixel index -- two barriers per pass instead of a ballot scan over every 256-pixel chunk
     int n = 0;
     for (int pass = 0; pass < 2; pass++) {
         const int th = pass == 0 ? D.ini_th : 1;
-        for (int k = tid; k < npx; k += 256) {
+        if (ncand <= FAST_CAND) {                   // uniform: every scored pixel is on the list
+            for (unsigned left = mine; left; left &= left - 1) {
+                const int pos = s_cand[tid + 256*(__ffs(left) - 1)], y = pos/TILE_MAX, x = pos - y*TILE_MAX;
+                const uint8_t *q = score + pos; const int sc = q[0];
+                if (sc >= th && sc > q[-TILE_MAX-1] && sc > q[-TILE_MAX] && sc > q[-TILE_MAX+1] && sc > q[-1] && sc > q[1] &&
+                    sc > q[TILE_MAX-1] && sc > q[TILE_MAX] && sc > q[TILE_MAX+1]) { const int i = atomicAdd(&s_nkeep, 1); if (i < CELL_CAP) s_keep[i] = (unsigned int)((y - 3)*iw + x - 3) | ((unsigned int)sc << 16); }
+            }
+        } else
+        for (int k = tid; k < npx; k += 256) {      // (list full: some pixels were scored in place)
             const int yy = (int)(((float)k + 0.5f)*inv_iw), y = 3 + yy, x = 3 + k - yy*iw;
             const uint8_t *q = score + y*TILE_MAX + x; const int sc = q[0];
             if (sc >= th && sc > q[-TILE_MAX-1] && sc > q[-TILE_MAX] && sc > q[-TILE_MAX+1] && sc > q[-1] && sc > q[1] &&
