@@ -191,42 +191,38 @@ __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
 // ---------------------------------------------------------------- FAST per cell
 // quick reject: 9 contiguous ring pixels always contain at least two of the four compass points
 __device__ __forceinline__ bool fast_maybe(const uint8_t *p, int stride, int threshold) {
-    const int v = p[0];
-    const int d0 = v - p[3*stride], d4 = v - p[3], d8 = v - p[-3*stride], d12 = v - p[-3];
-    const int nb = (d0 > threshold) + (d4 > threshold) + (d8 > threshold) + (d12 > threshold);
-    const int nd = (d0 < -threshold) + (d4 < -threshold) + (d8 < -threshold) + (d12 < -threshold);
-    return nb >= 2 || nd >= 2;
+    // "at least two of the four darker than v - t" is "the second smallest of the four is", likewise the second largest against v + t: eight min / max
+    // on the pixel values instead of eight compares and their sums on the differences
+    const int v = p[0], a = p[3*stride], b = p[-3*stride], c = p[3], d = p[-3];
+    const int mn1 = min(a, b), mx1 = max(a, b), mn2 = min(c, d), mx2 = max(c, d);
+    const int second_smallest = min(max(mn1, mn2), min(mx1, mx2)), second_largest = max(min(mx1, mx2), max(mn1, mn2));
+    return second_smallest < v - threshold || second_largest > v + threshold;
 }
 __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int threshold) {     // 0 = not a corner
     const int cx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
     const int cy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
     const int v = p[0];
-    int d[25];
+    int q[18];
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - p[cy[k]*stride + cx[k]];
+    for (int k = 0; k < 16; k++) q[k] = p[cy[k]*stride + cx[k]];
+    q[16] = q[0]; q[17] = q[1];
+    // cornerScore (OpenCV fast_score.cpp, called at ORBextractor.cc:808-812 through cv::FAST): with d_k = v - q_k, a0 = max(threshold, the largest over
+    // the 16 arcs of 9 of the arc's smallest d), b0 = min(-a0, the smallest over the arcs of the arc's largest d), score = -b0 - 1.  No separate arc
+    // test: a pixel is a corner at `threshold` (an arc with every |d| above it) exactly when that score reaches the threshold; otherwise it is
+    // threshold - 1.  (The bit-mask run-length test this replaces cost a third of a survivor's instructions and spared the rest only to a wave without
+    // a single corner.)  The arcs' extrema as a sliding window over the ring -- threes, then three threes -- on the pixel values themselves
+    // (min d = v - max q): the numbers of OpenCV's ladders, whose early-outs only skip arcs that cannot change the result, in under half the
+    // instructions and without a branch.
+    int lo3[16], hi3[16];
 #pragma unroll
-    for (int k = 16; k < 25; k++) d[k] = d[k - 16];
-    // No separate arc test: the ladders below start at the threshold, so what they return is the largest threshold the pixel is still a corner at
-    // (minus one) when it is one at `threshold` -- an arc of 9 with every |difference| above it -- and threshold - 1 when it is not.  (The bit-mask
-    // run-length test this replaces cost a third of the instructions of a survivor and saved the ladders only for a wave without a single corner.)
-    int a0 = threshold;
+    for (int k = 0; k < 16; k++) { lo3[k] = min(min(q[k], q[k+1]), q[k+2]); hi3[k] = max(max(q[k], q[k+1]), q[k+2]); }
+    int arc_hi = 255, arc_lo = 0;               // the smallest of the arcs' maxima, the largest of their minima
 #pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-        int a = min(min(d[k+1], d[k+2]), d[k+3]);
-        if (a <= a0) continue;
-        a = min(a, min(min(d[k+4], d[k+5]), min(min(d[k+6], d[k+7]), d[k+8])));
-        a0 = max(a0, min(a, d[k]));
-        a0 = max(a0, min(a, d[k+9]));
+    for (int k = 0; k < 16; k++) {
+        arc_hi = min(arc_hi, max(max(hi3[k], hi3[(k+3) & 15]), hi3[(k+6) & 15]));
+        arc_lo = max(arc_lo, min(min(lo3[k], lo3[(k+3) & 15]), lo3[(k+6) & 15]));
     }
-    int b0 = -a0;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-        int b = max(max(max(d[k+1], d[k+2]), max(d[k+3], d[k+4])), d[k+5]);
-        if (b >= b0) continue;
-        b = max(b, max(max(d[k+6], d[k+7]), d[k+8]));
-        b0 = min(b0, max(b, d[k]));
-        b0 = min(b0, max(b, d[k+9]));
-    }
+    const int a0 = max(threshold, v - arc_hi), b0 = min(-a0, v - arc_lo);
     const int r = -b0 - 1;
     return r >= threshold ? r : 0;
 }
