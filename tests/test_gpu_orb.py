@@ -80,6 +80,21 @@ def test_full_batch_properties(orb):
         assert 990 <= len(kp) <= 1040 and np.all(np.diff(kp[:, 5]) >= 0)
 
 
+def test_large_batches_take_the_split_detector_and_agree(orb, oracle_lib):
+    """From 24 frames on the detector runs as two launches (levels with cells up to 34 px: two waves per cell on a 40 x 40 tile; the others through the
+    general instance); below, one launch of the general instance.  Same keypoints and descriptors either way, and against the oracle -- including a frame
+    of noise (candidate lists full) and a low-contrast one (the per-cell fallback threshold)."""
+    imgs = [synthetic_frame(300 + s) for s in range(30)]
+    imgs.append(np.random.default_rng(6).integers(0, 256, (480, 640)).astype(np.uint8))
+    imgs.append((synthetic_frame(331).astype(np.int32) // 12 + 100).astype(np.uint8))
+    imgs = np.stack(imgs)
+    res = orb.extract_batch(imgs)
+    for f in (0, 13, 29, 30, 31):
+        _same(res[f], orb.extract_batch(imgs[f:f + 1])[0])
+    for f in (5, 30, 31):
+        _same(res[f], oracle_lib.orb_extract(imgs[f], cap=8192))
+
+
 @pytest.mark.gpu
 def test_match_search_parity_on_resident_frames(orb, oracle_lib):
     """tsorb_match_* vs the oracle, bit-exact: candidates in the reference's order, Hamming distances, best / second best --

@@ -45,6 +45,7 @@ struct OrbDev {
     int n, nlevels, ini_th, min_th, w, h, stride;
     LevelGeo L[MAXL];
     int cells_per_frame, slots_per_frame, btiles_per_frame, cand_cap, node_cap, pool_cap, cap;
+    int fast_nl[2], fast_cells[2], fast_c0[2][MAXL]; signed char fast_lv[2][MAXL];     // k_fast's two launches: [0] the levels whose cell ROIs fit a 40 x 40 tile, [1] the others; c0: a level's first cell inside its launch
     size_t pyr_frame, blur_frame;          // bytes per frame
     const uint8_t *img; uint8_t *pyr, *blur;
     int *rtab;                             // cv::resize coordinate / weight tables of levels 1.. (k_resize_tab, once per geometry)
@@ -229,18 +230,27 @@ __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int thre
 #ifndef FAST_TU
 #define FAST_TU 2                       // tile dwords per thread in flight (measured on a batch of 64: 1 -> 0.494, 2 -> 0.490, 3 -> 0.494, 4 -> 0.497, 6 -> 0.505 ms: more requests per thread cost occupancy)
 #endif
-#define FAST_CAND 2048          // quick-reject survivors listed per cell (a typical cell has ~1000 inner pixels, 10-30 % survive); the rest are scored in place
-__global__ __launch_bounds__(256) void k_fast(OrbDev D) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_MAX*TILE_MAX];
-    __shared__ __attribute__((aligned(16))) uint8_t score[TILE_MAX*TILE_MAX];      // cornerScore <= 255
+// S: row stride of the LDS tile (>= the widest cell ROI of the geometry, a multiple of 4), NC: quick-reject survivors listed per cell (a typical cell has
+// ~1000 inner pixels, 10-30 % survive; the rest are scored in place), NK: corners a cell can keep (one per 2 x 2 inner pixels after the strict 3 x 3
+// suppression), T: threads.  Two instances: <40, 1024, 320, 128> for geometries whose cells are 30 - 34 px (every level of a 752 x 480 frame; 6.4 KB of
+// LDS: sixteen workgroups = all 32 wave slots of a compute unit), <72, 2048, 1024, 256> for anything up to the 59-px cell the grid rule allows.
+// A workgroup lives for one cell: it asks memory for its tile, waits (~2 us), computes (a few hundred ns of issue time).  With four waves per cell a
+// SIMD's eight waves spend 90 % of their lives in that wait and the kernel ran at the latency's pace, 133 us; two waves per cell double the arithmetic
+// behind every wait (an empty launch of the 84 k workgroups alone takes 42 us: the floor of this shape).
+template <int S, int NC, int NK, int T, int GRP>
+__global__ __launch_bounds__(T) void k_fast(OrbDev D) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[S*S];
+    __shared__ __attribute__((aligned(16))) uint8_t score[S*S];      // cornerScore <= 255
     __shared__ int s_ncand, s_nkeep;
-    __shared__ unsigned short s_cand[FAST_CAND];     // 18 KB of LDS per workgroup: eight workgroups (all 32 wave slots) per CU
-    __shared__ unsigned int s_keep[CELL_CAP];
-    const int f = blockIdx.x / D.cells_per_frame, cidx = blockIdx.x % D.cells_per_frame, tid = threadIdx.x;
-    int l = 0;
-    while (l + 1 < D.nlevels && cidx >= D.L[l+1].cell0) l++;
-    const LevelGeo &G = D.L[l];
-    const int cc = cidx - G.cell0, i = cc / G.nCols, j = cc % G.nCols;
+    __shared__ unsigned short s_cand[NC];
+    __shared__ unsigned int s_keep[NK];
+    const int f = blockIdx.x / D.fast_cells[GRP], tid = threadIdx.x;
+    int cc = blockIdx.x % D.fast_cells[GRP], c0 = 0, lv = D.fast_lv[GRP][0];      // the cell inside this launch's levels (every offset into the kernel arguments static: one batch of scalar loads)
+#pragma unroll
+    for (int k = 1; k < MAXL; k++) { const bool in = k < D.fast_nl[GRP] && cc >= D.fast_c0[GRP][k]; c0 = in ? D.fast_c0[GRP][k] : c0; lv = in ? D.fast_lv[GRP][k] : lv; }
+    cc -= c0;
+    const LevelGeo &G = D.L[lv];
+    const int cidx = G.cell0 + cc, i = cc / G.nCols, j = cc % G.nCols;
     int *cnt_out = D.cellcnt + (size_t)f*D.cells_per_frame + cidx;
     // cell ROI, ORBextractor.cc:790-806 (float arithmetic on small integers is exact)
     const int iniY = G.minB + i*G.hCell, iniX = G.minB + j*G.wCell;
@@ -256,13 +266,13 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     const int iw = rw - 6, ih = rh - 6;             // inner pixels (3-px margin)
     {
         const int rw4 = (rw + 3) >> 2, n4 = rw4*rh; const float inv_rw4 = 1.0f/(float)rw4;
-        for (int k0 = tid; k0 < n4; k0 += FAST_TU*256) {       // FAST_TU dwords per thread in flight
+        for (int k0 = tid; k0 < n4; k0 += FAST_TU*T) {       // FAST_TU dwords per thread in flight
             uint32_t v[FAST_TU]; int at[FAST_TU];
 #pragma unroll
-            for (int u = 0; u < FAST_TU; u++) { const int k = min(k0 + 256*u, n4 - 1), y = (int)(((float)k + 0.5f)*inv_rw4), x = 4*(k - y*rw4);
-                at[u] = y*TILE_MAX + x; v[u] = *(const u32_unaligned *)(src + (size_t)y*G.bw + x); }
+            for (int u = 0; u < FAST_TU; u++) { const int k = min(k0 + T*u, n4 - 1), y = (int)(((float)k + 0.5f)*inv_rw4), x = 4*(k - y*rw4);
+                at[u] = y*S + x; v[u] = *(const u32_unaligned *)(src + (size_t)y*G.bw + x); }
 #pragma unroll
-            for (int u = 0; u < FAST_TU; u++) if (k0 + 256*u < n4) { *(uint32_t *)&tile[at[u]] = v[u]; *(uint32_t *)&score[at[u]] = 0u; }
+            for (int u = 0; u < FAST_TU; u++) if (k0 + T*u < n4) { *(uint32_t *)&tile[at[u]] = v[u]; *(uint32_t *)&score[at[u]] = 0u; }
         }
         if (tid == 0) { s_ncand = 0; s_nkeep = 0; }
     }
@@ -276,43 +286,43 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev D) {
     // the full arc test + cornerScore are ~200 instructions and a wave runs them for all 64 lanes if one needs them: first a
     // 4-pixel quick reject over all inner pixels, the survivors' tile positions compacted into a list, then the full test on the
     // list with every lane busy (the order of the list is irrelevant: scores go to the score map by position)
-    for (int k = tid; k < npx; k += 256) { const int yy = (int)(((float)k + 0.5f)*inv_iw), pos = (3 + yy)*TILE_MAX + 3 + k - yy*iw;
-        if (fast_maybe(tile + pos, TILE_MAX, D.min_th)) { const int i = atomicAdd(&s_ncand, 1);
-            if (i < FAST_CAND) s_cand[i] = (unsigned short)pos; else score[pos] = (uint8_t)fast_score(tile + pos, TILE_MAX, D.min_th); } }   // (list full: scored in place; one atomic per wave through a ballot measured slower: 197 vs 185 us)
+    for (int k = tid; k < npx; k += T) { const int yy = (int)(((float)k + 0.5f)*inv_iw), pos = (3 + yy)*S + 3 + k - yy*iw;
+        if (fast_maybe(tile + pos, S, D.min_th)) { const int i = atomicAdd(&s_ncand, 1);
+            if (i < NC) s_cand[i] = (unsigned short)pos; else score[pos] = (uint8_t)fast_score(tile + pos, S, D.min_th); } }   // (list full: scored in place; one atomic per wave through a ballot measured slower: 197 vs 185 us)
     __syncthreads();
     // (measured, phases of the 187 us: tile 46, quick reject 45, arc test + cornerScore of the survivors 70, non-maximum suppression + ordering 22;
     // the survivors in two steps -- arc test on all, the score ladders on the compacted corners only -- was slower, 201 us: two more barriers, and
     // the 16 ring reads, not the ladders, are what a survivor costs)
-    // (a thread scores at most FAST_CAND / 256 = 8 survivors: which of them came out as corners stays in a bit mask, the suppression pass below looks at
+    // (a thread scores at most NC / T = 8 survivors: which of them came out as corners stays in a bit mask, the suppression pass below looks at
     // those positions only instead of at every pixel of the cell again -- 22 us of the 187 were that second sweep)
     const int ncand = s_ncand;
     unsigned mine = 0;
-    for (int k = tid, m = 0; k < min(ncand, FAST_CAND); k += 256, m++) { const int pos = s_cand[k], sc = fast_score(tile + pos, TILE_MAX, D.min_th); score[pos] = (uint8_t)sc; mine |= (sc > 0 ? 1u : 0u) << m; }
+    for (int k = tid, m = 0; k < min(ncand, NC); k += T, m++) { const int pos = s_cand[k], sc = fast_score(tile + pos, S, D.min_th); score[pos] = (uint8_t)sc; mine |= (sc > 0 ? 1u : 0u) << m; }
     __syncthreads();
     // 3x3 non-maximum suppression.  The survivors are few (a handful per cell): appended in any order, then put into the reference's
     // row-major order by a rank sort on the pixel index -- two barriers per pass instead of a ballot scan over every 256-pixel chunk
     int n = 0;
     for (int pass = 0; pass < 2; pass++) {
         const int th = pass == 0 ? D.ini_th : 1;
-        if (ncand <= FAST_CAND) {                   // uniform: every scored pixel is on the list
+        if (ncand <= NC) {                   // uniform: every scored pixel is on the list
             for (unsigned left = mine; left; left &= left - 1) {
-                const int pos = s_cand[tid + 256*(__ffs(left) - 1)], y = pos/TILE_MAX, x = pos - y*TILE_MAX;
+                const int pos = s_cand[tid + T*(__ffs(left) - 1)], y = pos/S, x = pos - y*S;
                 const uint8_t *q = score + pos; const int sc = q[0];
-                if (sc >= th && sc > q[-TILE_MAX-1] && sc > q[-TILE_MAX] && sc > q[-TILE_MAX+1] && sc > q[-1] && sc > q[1] &&
-                    sc > q[TILE_MAX-1] && sc > q[TILE_MAX] && sc > q[TILE_MAX+1]) { const int i = atomicAdd(&s_nkeep, 1); if (i < CELL_CAP) s_keep[i] = (unsigned int)((y - 3)*iw + x - 3) | ((unsigned int)sc << 16); }
+                if (sc >= th && sc > q[-S-1] && sc > q[-S] && sc > q[-S+1] && sc > q[-1] && sc > q[1] &&
+                    sc > q[S-1] && sc > q[S] && sc > q[S+1]) { const int i = atomicAdd(&s_nkeep, 1); if (i < NK) s_keep[i] = (unsigned int)((y - 3)*iw + x - 3) | ((unsigned int)sc << 16); }
             }
         } else
-        for (int k = tid; k < npx; k += 256) {      // (list full: some pixels were scored in place)
+        for (int k = tid; k < npx; k += T) {      // (list full: some pixels were scored in place)
             const int yy = (int)(((float)k + 0.5f)*inv_iw), y = 3 + yy, x = 3 + k - yy*iw;
-            const uint8_t *q = score + y*TILE_MAX + x; const int sc = q[0];
-            if (sc >= th && sc > q[-TILE_MAX-1] && sc > q[-TILE_MAX] && sc > q[-TILE_MAX+1] && sc > q[-1] && sc > q[1] &&
-                sc > q[TILE_MAX-1] && sc > q[TILE_MAX] && sc > q[TILE_MAX+1]) { const int i = atomicAdd(&s_nkeep, 1); if (i < CELL_CAP) s_keep[i] = (unsigned int)k | ((unsigned int)sc << 16); }
+            const uint8_t *q = score + y*S + x; const int sc = q[0];
+            if (sc >= th && sc > q[-S-1] && sc > q[-S] && sc > q[-S+1] && sc > q[-1] && sc > q[1] &&
+                sc > q[S-1] && sc > q[S] && sc > q[S+1]) { const int i = atomicAdd(&s_nkeep, 1); if (i < NK) s_keep[i] = (unsigned int)k | ((unsigned int)sc << 16); }
         }
         __syncthreads();
-        n = min(s_nkeep, CELL_CAP);
+        n = min(s_nkeep, NK);
         if (n > 0) break;                           // uniform (nothing at iniTh: the cell is searched again at the fallback threshold)
     }
-    for (int a = tid; a < n; a += 256) {
+    for (int a = tid; a < n; a += T) {
         const unsigned int e = s_keep[a]; const int ka = (int)(e & 0xffffu); int rank = 0;
         for (int b2 = 0; b2 < n; b2++) rank += (int)(s_keep[b2] & 0xffffu) < ka;
         const int yy = (int)(((float)ka + 0.5f)*inv_iw), y = 3 + yy, x = 3 + ka - yy*iw;
@@ -1042,6 +1052,13 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
         if (G.nCols < 1 || G.nRows < 1) { c->err = "image too small for the requested pyramid"; return TSORB_ERR_ARG; }
         G.wCell = (int)ceilf(width/G.nCols); G.hCell = (int)ceilf(height/G.nRows);
         if (G.wCell + 6 > TILE_MAX || G.hCell + 6 > TILE_MAX) { c->err = "cell larger than the LDS tile"; return TSORB_ERR_ARG; }
+        { static const int shape = [] { const char *e = getenv("TSORB_FAST_SHAPE"); return e ? atoi(e) : -1; }();      // (diagnostics: 0 every level through the general instance, 1 - 3 the split at any batch size)
+          // below ~24 frames the device is not full and a cell's own time counts: four waves per cell, one launch (measured: 1 frame 0.144 against 0.157 ms
+          // split, 16 frames equal, 32 frames 0.299 against 0.292, 64 frames 0.446 against 0.426)
+          const bool one_group = shape == 0 || (shape < 0 && n < 24);
+          const int g = (G.wCell + 6 > 40 || G.hCell + 6 > 40 || one_group) ? 1 : 0;          // (rows are staged as dwords: up to 3 bytes past the ROI, still inside a stride of 40)
+          if (l == 0) { D.fast_nl[0] = D.fast_nl[1] = D.fast_cells[0] = D.fast_cells[1] = 0; }
+          D.fast_c0[g][D.fast_nl[g]] = D.fast_cells[g]; D.fast_lv[g][D.fast_nl[g]++] = (signed char)l; D.fast_cells[g] += G.nCols*G.nRows; }
         G.cell0 = cell0; cell0 += G.nCols*G.nRows;
         G.nfeat = c->nfl[l]; G.capL = c->nfl[l] + 8; G.kp0 = kp0; kp0 += G.capL; G.sf = c->sf[l];
         G.pyr_off = po; po += (size_t)G.bw*G.bh; G.blur_off = bo; bo += (size_t)G.w*G.h;
@@ -1080,7 +1097,13 @@ int tsorb_run(void *ctx) {
     OrbDev &D = c->D;
     hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
     for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
-    hipLaunchKernelGGL(k_fast, dim3(D.n*D.cells_per_frame), dim3(256), 0, c->stream, D);
+    static const int fast_shape = [] { const char *e = getenv("TSORB_FAST_SHAPE"); return e ? atoi(e) : 2; }();      // (diagnostics: 1 / 3 the small tile with 256 / 64 threads)
+    if (D.fast_cells[0] > 0) {
+        if (fast_shape == 1) hipLaunchKernelGGL((k_fast<40, 1024, 320, 256, 0>), dim3(D.n*D.fast_cells[0]), dim3(256), 0, c->stream, D);
+        else if (fast_shape == 3) hipLaunchKernelGGL((k_fast<40, 1024, 320, 64, 0>), dim3(D.n*D.fast_cells[0]), dim3(64), 0, c->stream, D);
+        else hipLaunchKernelGGL((k_fast<40, 1024, 320, 128, 0>), dim3(D.n*D.fast_cells[0]), dim3(128), 0, c->stream, D);
+    }
+    if (D.fast_cells[1] > 0) hipLaunchKernelGGL((k_fast<TILE_MAX, 2048, CELL_CAP, 256, 1>), dim3(D.n*D.fast_cells[1]), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
     hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);

@@ -1,8 +1,8 @@
 import os, sys, time, numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from textslam_amd.orbextractor import ORBextractor, synthetic_frame
 imgs = np.stack([synthetic_frame(s) for s in range(64)])
-for n in (64, 1):
+for n in [int(x) for x in os.environ.get("ORB_AB_FRAMES", "64,1").split(",")]:
     ex = ORBextractor(1000, 1.2, 8, 20, 7, device=0); ex.upload(imgs[:n])
     for _ in range(5): ex.run()
     ts = []
