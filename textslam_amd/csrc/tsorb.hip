@@ -228,15 +228,16 @@ __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int thre
     return r >= threshold ? r : 0;
 }
 #ifndef FAST_TU
-#define FAST_TU 2                       // tile dwords per thread in flight (measured on a batch of 64: 1 -> 0.494, 2 -> 0.490, 3 -> 0.494, 4 -> 0.497, 6 -> 0.505 ms: more requests per thread cost occupancy)
+#define FAST_TU 2                       // tile dwords per thread in flight (measured on a batch of 64, four waves per cell: 1 -> 0.494, 2 -> 0.490, 3 -> 0.494, 4 -> 0.497, 6 -> 0.505 ms: more requests per thread cost occupancy)
 #endif
 // S: row stride of the LDS tile (>= the widest cell ROI of the geometry, a multiple of 4), NC: quick-reject survivors listed per cell (a typical cell has
 // ~1000 inner pixels, 10-30 % survive; the rest are scored in place), NK: corners a cell can keep (one per 2 x 2 inner pixels after the strict 3 x 3
 // suppression), T: threads.  Two instances: <40, 1024, 320, 128> for geometries whose cells are 30 - 34 px (every level of a 752 x 480 frame; 6.4 KB of
 // LDS: sixteen workgroups = all 32 wave slots of a compute unit), <72, 2048, 1024, 256> for anything up to the 59-px cell the grid rule allows.
-// A workgroup lives for one cell: it asks memory for its tile, waits (~2 us), computes (a few hundred ns of issue time).  With four waves per cell a
-// SIMD's eight waves spend 90 % of their lives in that wait and the kernel ran at the latency's pace, 133 us; two waves per cell double the arithmetic
-// behind every wait (an empty launch of the 84 k workgroups alone takes 42 us: the floor of this shape).
+// Measured on a batch of 64 (rocprofv3, phases by elimination, round 5): four waves per cell on the 72 x 72 tile 133 us; two waves per cell on the 40 x 40
+// tile 101 us + 9 us for the levels with larger cells = an empty launch of the 51 k workgroups 26 (42 with four waves each), tiles 18, quick reject 22,
+// scores 25, suppression + ordering + output 10.  One wave per cell, two cells per workgroup with both tiles requested together, the blur on a second
+// stream beside the detector or the quadtree (events, or hipExtAnyOrderLaunch, which gfx9 ignores): all measured, none faster (docs/ledger_r05.md).
 template <int S, int NC, int NK, int T, int GRP>
 __global__ __launch_bounds__(T) void k_fast(OrbDev D) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[S*S];
@@ -283,16 +284,15 @@ __global__ __launch_bounds__(T) void k_fast(OrbDev D) {
     // iniTh) -- the 3x3 maximum test on the full score map selects exactly what cv::FAST(iniTh) + NMS selects.
     const float inv_iw = 1.0f/(float)iw;
     const int npx = iw*ih;
-    // the full arc test + cornerScore are ~200 instructions and a wave runs them for all 64 lanes if one needs them: first a
-    // 4-pixel quick reject over all inner pixels, the survivors' tile positions compacted into a list, then the full test on the
-    // list with every lane busy (the order of the list is irrelevant: scores go to the score map by position)
+    // the cornerScore is ~100 instructions and a wave runs them for all 64 lanes if one needs them: first a 4-pixel quick reject over all
+    // inner pixels, the survivors' tile positions compacted into a list, then the score on the list with every lane busy (the order of the
+    // list is irrelevant: scores go to the score map by position)
     for (int k = tid; k < npx; k += T) { const int yy = (int)(((float)k + 0.5f)*inv_iw), pos = (3 + yy)*S + 3 + k - yy*iw;
         if (fast_maybe(tile + pos, S, D.min_th)) { const int i = atomicAdd(&s_ncand, 1);
             if (i < NC) s_cand[i] = (unsigned short)pos; else score[pos] = (uint8_t)fast_score(tile + pos, S, D.min_th); } }   // (list full: scored in place; one atomic per wave through a ballot measured slower: 197 vs 185 us)
     __syncthreads();
-    // (measured, phases of the 187 us: tile 46, quick reject 45, arc test + cornerScore of the survivors 70, non-maximum suppression + ordering 22;
-    // the survivors in two steps -- arc test on all, the score ladders on the compacted corners only -- was slower, 201 us: two more barriers, and
-    // the 16 ring reads, not the ladders, are what a survivor costs)
+    // (the survivors in two steps -- arc test on all, the score on the compacted corners only -- was slower: two more barriers, and the 16 ring
+    // reads are what a survivor costs)
     // (a thread scores at most NC / T = 8 survivors: which of them came out as corners stays in a bit mask, the suppression pass below looks at
     // those positions only instead of at every pixel of the cell again -- 22 us of the 187 were that second sweep)
     const int ncand = s_ncand;
@@ -1105,7 +1105,7 @@ int tsorb_run(void *ctx) {
     }
     if (D.fast_cells[1] > 0) hipLaunchKernelGGL((k_fast<TILE_MAX, 2048, CELL_CAP, 256, 1>), dim3(D.n*D.fast_cells[1]), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
-    hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
+    hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged (4.7 us to find none; as a call from k_octree's thread 0 it cost that kernel 48 VGPRs and 1.2 KB of scratch per lane: 0.449 against 0.424 ms)
     hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
