@@ -72,6 +72,20 @@ __device__ __forceinline__ uint8_t *lev_ptr(const OrbDev &D, uint8_t *base, int 
 #define L0_ROWS 8
 #endif
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+// Workgroup b of a launch runs on XCD b mod 8, each XCD behind an L2 of its own: neighbours in a launch's work order (cells of one row, tiles of one
+// level, keypoints of one frame) share cache lines, and in launch order every one of them would sit behind a different L2 -- each line fetched up to eight
+// times (measured: k_fast 2.2 x its tiles' bytes, k_blur 2.1 x).  xcd_order gives XCD x the x-th contiguous eighth of the work instead.
+#ifndef TSORB_XCD_ORDER
+#define TSORB_XCD_ORDER 1
+#endif
+__device__ __forceinline__ int xcd_order(int b, int n) {
+#if TSORB_XCD_ORDER
+    const int q = n >> 3, rem = n & 7, x = b & 7;
+    return x*q + min(x, rem) + (b >> 3);
+#else
+    return b;
+#endif
+}
 __global__ __launch_bounds__(128) void k_level0(OrbDev D) {
     const LevelGeo &G = D.L[0];
     const int x = 4*(blockIdx.x*128 + threadIdx.x), y0 = blockIdx.y*L0_ROWS, f = blockIdx.z;
@@ -245,8 +259,9 @@ __global__ __launch_bounds__(T) void k_fast(OrbDev D) {
     __shared__ int s_ncand, s_nkeep;
     __shared__ unsigned short s_cand[NC];
     __shared__ unsigned int s_keep[NK];
-    const int f = blockIdx.x / D.fast_cells[GRP], tid = threadIdx.x;
-    int cc = blockIdx.x % D.fast_cells[GRP], c0 = 0, lv = D.fast_lv[GRP][0];      // the cell inside this launch's levels (every offset into the kernel arguments static: one batch of scalar loads)
+    const int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int f = bid / D.fast_cells[GRP], tid = threadIdx.x;
+    int cc = bid % D.fast_cells[GRP], c0 = 0, lv = D.fast_lv[GRP][0];      // the cell inside this launch's levels (every offset into the kernel arguments static: one batch of scalar loads)
 #pragma unroll
     for (int k = 1; k < MAXL; k++) { const bool in = k < D.fast_nl[GRP] && cc >= D.fast_c0[GRP][k]; c0 = in ? D.fast_c0[GRP][k] : c0; lv = in ? D.fast_lv[GRP][k] : lv; }
     cc -= c0;
@@ -731,7 +746,8 @@ __device__ __forceinline__ float fast_atan2f_dev(float y, float x) {     // cv::
     return a;
 }
 __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
-    const int g = (blockIdx.x*256 + threadIdx.x) >> 4, v = threadIdx.x & 15;
+    const int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int g = (bid*256 + threadIdx.x) >> 4, v = threadIdx.x & 15;
     const int per = D.slots_per_frame, f = g / per, slot = g % per;
     if (f >= D.n) return;
     int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;
@@ -771,7 +787,7 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
     if (threadIdx.x < 16) {
         const float an = ang[threadIdx.x];
         if (an >= 0.f) {
-            const int g2 = (blockIdx.x*256 >> 4) + threadIdx.x;
+            const int g2 = (bid*256 >> 4) + threadIdx.x;
             const float factorPI = (float)(3.14159265358979323846/180.f);
             const float rad = __fmul_rn(an, factorPI);
             D.selab[2*(size_t)g2] = (float)cos((double)rad); D.selab[2*(size_t)g2 + 1] = (float)sin((double)rad);
@@ -785,7 +801,8 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
 #define BT_R 4                  // output rows per thread of the vertical pass
 __global__ __launch_bounds__(256) void k_blur(OrbDev D) {
     // one launch for all levels (the small levels do not fill the chip on their own): block -> (frame, level, tile)
-    const int f = blockIdx.x / D.btiles_per_frame, bt = blockIdx.x % D.btiles_per_frame;
+    const int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int f = bid / D.btiles_per_frame, bt = bid % D.btiles_per_frame;
     int l = 0;
     while (l + 1 < D.nlevels && bt >= D.L[l+1].bt0) l++;
     const LevelGeo &G = D.L[l];
@@ -849,7 +866,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev D) {
 
 // ---------------------------------------------------------------- descriptors: 32 lanes per keypoint, lane i -> byte i
 __global__ __launch_bounds__(256) void k_describe(OrbDev D) {
-    const int g = (blockIdx.x*256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;      // 32 lanes per keypoint: two keypoints per wave
+    const int g = (xcd_order(blockIdx.x, gridDim.x)*256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;      // 32 lanes per keypoint: two keypoints per wave
     const int per = D.slots_per_frame, f = g / per, slot = g % per;
     if (f >= D.n) return;
     int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;

@@ -21,15 +21,20 @@ pmc() {     # name, counter, kernel filter, bench args...
   rm -rf /tmp/pmc_$name; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$name -o $name -- python $OLDPWD/bench.py "$@" --no-cpu-baseline --no-also > /dev/null 2> /tmp/pmc_$name.err )
   python profiles/rocpd_pmc_by_kernel.py $(find /tmp/pmc_$name -name "*.db" | head -1) $filt > $OUT/r05_${name}.txt 2>&1
 }
+ONLY=${1:-all}      # "orb": just the ORB legs (after a change of that pipeline)
+if [ "$ONLY" = all ]; then
 stats c4_local_ba --steps 20 --warmup 3
 stats c6_global_ba --workload global_ba --steps 3 --warmup 1
+fi
 stats orb_batch64 --workload orb --steps 20 --warmup 3
+if [ "$ONLY" = all ]; then
 diag c6_long_range 5000 70000 0.01 2
 diag c6_two_closures 5000 70000 0.0 2 2
 pmc c4_pmc_fetch FETCH_SIZE k_linearize --steps 3 --warmup 1
 pmc c4_pmc_write WRITE_SIZE k_linearize --steps 3 --warmup 1
 pmc c6_pmc_fetch FETCH_SIZE k_linearize --workload global_ba --steps 2 --warmup 1
 pmc c6_pmc_write WRITE_SIZE k_linearize --workload global_ba --steps 2 --warmup 1
+fi
 pmc orb_pmc_fetch FETCH_SIZE "" --workload orb --steps 2 --warmup 1
 pmc orb_pmc_write WRITE_SIZE "" --workload orb --steps 2 --warmup 1
 ls -la $OUT/r05_* | head -60
