@@ -412,7 +412,7 @@ def _full_state(gpu, rep, G):
 
 
 @pytest.mark.parametrize("knob", ["pass_launches", "trial_launches"])
-@pytest.mark.parametrize("case", ["tiny", "c4", "c4_oneshot", "init", "landmarker", "no_text", "no_outlier"])
+@pytest.mark.parametrize("case", ["tiny", "c4", "c4_oneshot", "init", "landmarker", "no_text", "no_outlier", "pose_c3", "pose_oneshot", "pose_no_text"])
 def test_pass_boundaries_in_one_launch_agree(gpu, case, knob):
     """A window's pass begins with k_pass_begin (participation + gauge + LM state reset + mu / sigma) and ends with k_pass_end (outlier pass + the next
     level's mu / sigma + clearing), its final state reaches the report through k_solve_end (tsba_kernels_pass.h); tsba_debug_options.pass_launches = 1
@@ -420,8 +420,12 @@ def test_pass_boundaries_in_one_launch_agree(gpu, case, knob):
     reports (every per-pass field), the parameters, the flags and the LM traces are bit-identical -- resident solves, solves repeated on one upload
     and one-shot calls (levels staged while the first pass runs) alike.
     knob = trial_launches: the same statement for the round-5 experiment k_lin_mid (k_mid inside the speculative linearisation's launch: the last workgroups of the
-    linearisation to finish take the k_mid blocks; measured slower and off by default) against k_mid as a launch of its own with the same block size."""
+    linearisation to finish take the k_mid blocks; measured slower and off by default) against k_mid as a launch of its own with the same block size.
+    pose_*: PoseOptim -- all LM steps of a pass in one launch (k_pose_pass: a barrier across its workgroups where the launches were) against a launch per
+    step (k_pose_iter, pass_launches = 1)."""
     oneshot = None
+    if case.startswith("pose") and knob != "pass_launches":
+        pytest.skip("the pose-only path has no k_mid")
     if case == "tiny":
         P, o = synth.tiny(), abi.options_local()
     elif case in ("c4", "c4_oneshot"):
@@ -430,6 +434,13 @@ def test_pass_boundaries_in_one_launch_agree(gpu, case, knob):
             oneshot = lambda Q: gpu.LocalBundleAdjustment(Q, options=o)
     elif case == "init":
         P, o = synth.init_pair(), abi.options_init()
+    elif case in ("pose_c3", "pose_oneshot"):
+        P, o = synth.config_c3(), abi.options_pose()
+        if case == "pose_oneshot":
+            oneshot = lambda Q: gpu.PoseOptim(Q, options=o)
+    elif case == "pose_no_text":
+        P, o = synth.config_c3(), abi.options_pose()
+        o.use_text = 0
     elif case == "landmarker":
         P, o = synth.landmark_refine(), abi.options_landmarker()
     elif case == "no_text":
@@ -457,6 +468,16 @@ def test_pass_boundaries_in_one_launch_agree(gpu, case, knob):
     ref = runs[2]                                                # (the launches of rounds 1-4)
     assert sum(ref[0][0]) > 0 and all(r[3] == 0 for r in runs)   # (no poll ran into its bound)
     for st, G, tr, _ in runs:
+        if case.startswith("pose"):
+            assert runs[0][0] == runs[1][0] == runs[4][0] == runs[5][0] and np.array_equal(runs[0][1].pose, runs[5][1].pose)      # (the one-launch path: the same bits every time)
+            # two kernels, one arithmetic -- but not one compilation of it: the compiler contracts the sweep's multiply-adds differently inside k_pose_pass's loop
+            # and inside k_pose_iter, sums differ in the last bit (observed 2e-16 relative).  Decisions, counts and flags identical; costs and the pose to 1e-12
+            assert st[:3] == ref[0][:3] and st[5:] == ref[0][5:], (st, ref[0])
+            np.testing.assert_allclose(st[3], ref[0][3], rtol=1e-12); np.testing.assert_allclose(st[4], ref[0][4], rtol=1e-12)
+            np.testing.assert_allclose(G.pose, ref[1].pose, rtol=0, atol=1e-12)
+            assert np.array_equal(G.rho, ref[1].rho) and np.array_equal(G.theta, ref[1].theta)
+            assert np.array_equal(G.sgood, ref[1].sgood) and np.array_equal(G.tobs_good, ref[1].tobs_good) and np.array_equal(G.tfgood, ref[1].tfgood)
+            continue
         assert st == ref[0], (st, ref[0])
         assert np.array_equal(G.pose, ref[1].pose) and np.array_equal(G.rho, ref[1].rho) and np.array_equal(G.theta, ref[1].theta)
         assert np.array_equal(G.sgood, ref[1].sgood) and np.array_equal(G.tobs_good, ref[1].tobs_good) and np.array_equal(G.tfgood, ref[1].tfgood)

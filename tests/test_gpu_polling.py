@@ -179,6 +179,30 @@ def test_direct_map_solves_beside_a_busy_context(gpu, map_cache, kw):
             _same(beside, alone)
 
 
+def test_pose_optim_beside_busy_contexts(gpu):
+    """PoseOptim (tracking, once per frame) runs a pass's LM steps in ONE launch whose workgroups poll each other's sums (k_pose_pass): beside an ORB extractor
+    and beside a second bundle adjustment looping on other host threads -- what TextSLAM's mapping and loop-closing threads do to the tracking thread -- the
+    same bits as alone, no time-outs; with a device assumed too small for the launch (assume_cus = 1) the launch-per-step path takes over."""
+    P, o = synth.config_c3(), abi.options_pose()
+    alone = _solve(gpu, P, o, o.n_passes)
+    assert alone[0]["poll_timeouts"] == 0 and sum(alone[0]["iters"]) > 0
+    for busy_cls in (_Busy, _BusyBA):
+        with busy_cls() as busy:
+            while busy.runs < 2:
+                pass
+            for _ in range(40):
+                r = _solve(gpu, P, o, o.n_passes)
+                assert r[0]["poll_timeouts"] == 0, r[0]
+                _same(r, alone)
+    try:
+        gpu.debug_set(assume_cus=1)
+        small = _solve(gpu, P, o, o.n_passes)
+    finally:
+        gpu.debug_set()
+    assert small[0]["poll_timeouts"] == 0 and small[0]["iters"] == alone[0]["iters"] and small[0]["accepted"] == alone[0]["accepted"]
+    np.testing.assert_allclose(small[1].pose, alone[1].pose, rtol=0, atol=1e-12)       # (another compilation of the same arithmetic: last-bit differences in the sums)
+
+
 @pytest.mark.parametrize("case", ["c4", "window_31", "pose", "open_chain", "long_range", "ring", "c5", "dense_100"])
 def test_results_do_not_depend_on_what_other_kernels_left_in_lds(gpu, map_cache, case):
     """What a kernel finds in LDS is whatever the last workgroup on that compute unit left there: this context's own kernels when the device is otherwise idle

@@ -530,7 +530,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         if (c->pose_only) {
             size_t gmax = 1;
             for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) gmax = std::max(gmax, (size_t)pose_grid(c->lev[l]));
-            AL(W.pst, 2); AL(W.ppart, 2*28*gmax);
+            AL(W.pst, 2); AL(W.ppart, 3*28*gmax);
         } }
     for (int b = 0; b < 2; b++) {
         LinBuf &B = W.lb[b];
@@ -1385,9 +1385,12 @@ int tsba_solve(void *ctx, tsba_report *r) {
         if (c->lev_wait[o.levels[ps]]) { hipStreamWaitEvent(c->stream, c->ev_stage[o.levels[ps]], 0); c->lev_wait[o.levels[ps]] = 0; }
         const LevelDev &D = c->lev[o.levels[ps]];
         const bool pose_path = c->pose_only && !is_multi(c);
+        // PoseOptim: the pass's LM steps in one launch (k_pose_pass) where its workgroups are all resident at once, otherwise a launch per step
+        const bool pose_one_launch = pose_path && !c->dbg.pass_launches && grid_resident(c, (const void *)k_pose_pass, POSE_WG, 0, pose_grid(D));
         if (pose_path) {                                     // k_pass_reset + k_participation + k_gauge + k_musigma in one launch
             c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
-            LAUNCHK(k_pose_begin, dim3(D.n_tg + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial);
+            LAUNCHK(k_pose_begin, dim3(D.n_tg + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial,
+                    pose_one_launch ? c->W.ppart : (double *)nullptr, 3*28*pose_grid(D));
         } else if (fastp(D)) {
             // windows: k_pass_begin (tsba_kernels_pass.h).  The participation arrays are clear (k_reset_state / the last pass's k_pass_end); the text
             // observations' mu / sigma are there already if the last pass's k_pass_end computed them for this level
@@ -1420,12 +1423,16 @@ int tsba_solve(void *ctx, tsba_report *r) {
         };
         if (pose_path) {                                     // PoseOptim: one launch per LM iteration (tsba_pose.h)
             const int G = pose_grid(D);
-            LAUNCHK(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, -1, G);
-            int k_last = 0;
-            for (int k = 0; k <= o.its[ps]; k++) {           // launch k decides trial k - 1 and prepares trial k
-                if (k >= 1 && converged(k - 1)) break;
-                LAUNCHK(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, k, G);
-                k_last = k;
+            int k_last = -1;                                 // (k_pose_pass leaves the final state in pst[0])
+            if (pose_one_launch) LAUNCHK(k_pose_pass, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, G, o.its[ps]);
+            else {
+                LAUNCHK(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, -1, G);
+                for (int k = 0; k <= o.its[ps]; k++) {       // launch k decides trial k - 1 and prepares trial k
+                    if (k >= 1 && converged(k - 1)) break;
+                    LAUNCHK(k_pose_iter, dim3(G), dim3(POSE_WG), 0, c->stream, c->W, D, o, k, G);
+                    k_last = k;
+                }
+                if (k_last < 0) k_last = 0;
             }
             // outlier pass + installation of the pass's result (one extra workgroup) in one launch
             LAUNCHK(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg + 1), dim3(64), 0, c->stream, c->W, D, o.chi2_mono[ps], o.chi2_text[ps],

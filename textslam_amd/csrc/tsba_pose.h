@@ -104,48 +104,43 @@ __device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L
     return tot;
 }
 
-// k = -1: linearisation at the start point (into part[1]); k >= 0: see the header
-__global__ __launch_bounds__(POSE_WG) void k_pose_iter(Work W, LevelDev L, tsba_options o, int k, int G) {
-    __shared__ double lds[POSE_LDS];                        // the sweep's transposes; before it, the staged partial sums
-    __shared__ double s_ps[8*28];
-    __shared__ double s_sum[32];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int nb_sc = (L.n_sc + POSE_WG - 1)/POSE_WG;
-    const bool is_free = W.fidx[0] >= 0;                    // (a constant pose leaves every block out of the reduced program)
-    if (k < 0) {
-        const LmState *st = W.st;
-        if (st->done) return;
-        const int cur = st->cur;
-        double tot = 0.0;
-        if (is_free) tot = pose_sweep_wg(W, L, W.pose[cur], W.rho[cur], W.theta[cur], b, nb_sc, lds);
-        if (tid < 28) W.ppart[(size_t)(1*G + b)*28 + tid] = tot;
-        return;
-    }
-    // ---- state
-    PoseState P;
-    if (k == 0) {
-        P.S = *W.st;
+// the state a pass starts from (k = 0)
+__device__ __forceinline__ void pose_state_init(const Work &W, PoseState &P) {
+    P.S = *W.st;
 #pragma unroll
-        for (int q = 0; q < 7; q++) { P.x[q] = W.pose[P.S.cur][q]; P.cand[q] = P.x[q]; }
+    for (int q = 0; q < 7; q++) { P.x[q] = W.pose[P.S.cur][q]; P.cand[q] = P.x[q]; }
 #pragma unroll
-        for (int q = 0; q < 21; q++) P.M[q] = 0.0;
+    for (int q = 0; q < 21; q++) P.M[q] = 0.0;
 #pragma unroll
-        for (int q = 0; q < 6; q++) { P.c[q] = 0.0; P.sig[q] = 1.0; P.dgs[q] = 0.0; }
-        P.mcc = 0.0; P.step2 = 0.0; P.fail = 0; P.pad = 0;
-    } else P = W.pst[k & 1];
-    PoseState *Pn = W.pst + ((k + 1) & 1);
+    for (int q = 0; q < 6; q++) { P.c[q] = 0.0; P.sig[q] = 1.0; P.dgs[q] = 0.0; }
+    P.mcc = 0.0; P.step2 = 0.0; P.fail = 0; P.pad = 0;
+}
+// One step of the state machine, executed redundantly and bit-identically by every workgroup: the sums of the last sweep (src: [G][28]), the Ceres decision for
+// the trial they belong to (k = 0: scaling + gradient test of the first linearisation), then the next trial's 6 x 6 solve and candidate.  POLLED: the sums are
+// being written by the other workgroups of THIS launch (k_pose_pass): every value is read with device-coherent loads until it is there (NaN = not yet).
+__device__ __forceinline__ double pose_poll(const double *p) {
+    double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spins = 0; v != v && spins < (1 << 17); spins++) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (v != v) { v = __builtin_inf(); atomicAdd(&ts_poll_giveups, 1u); }      // (counted: tsba_report.poll_timeouts; an infinite sum fails the trial)
+    return v;
+}
+__device__ __forceinline__ void pose_publish(double *p, double v) { __hip_atomic_store(p, v == v ? v : __builtin_inf(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool POLLED>
+__device__ __forceinline__ void pose_step(const Work &W, const tsba_options &o, int k, int G, const double *src, bool is_free, PoseState &P, double *lds, double *s_ps, double *s_sum) {
+    const int tid = threadIdx.x;
     LmState &S = P.S;
-    if (S.done) { if (b == 0 && tid == 0) *Pn = P; return; }
     // ---- sums of the last sweep: 28 values x G workgroups.  All loads in flight at once (staged through LDS), then eight
     // partial sums per value in a fixed order
     {
-        const double *src = W.ppart + (size_t)((k + 1) & 1)*G*28;
         const int i = tid % 28, h = tid / 28;                // h < 8 for tid < 224
         double part = 0.0;
         for (int g0 = 0; g0 < G; g0 += POSE_TILE) {
             const int ng = min(POSE_TILE, G - g0);
             const double2 *s2 = (const double2 *)(src + (size_t)g0*28);
-            for (int e = tid; e < ng*14; e += POSE_WG) ((double2 *)lds)[e] = s2[e];
+            for (int e = tid; e < ng*14; e += POSE_WG) {
+                if (POLLED) { const double *sd = (const double *)(s2 + e); ((double2 *)lds)[e] = make_double2(pose_poll(sd), pose_poll(sd + 1)); }
+                else ((double2 *)lds)[e] = s2[e];
+            }
             __syncthreads();
             if (h < 8) for (int g = h; g < ng; g += 8) part += lds[g*28 + i];
             __syncthreads();
@@ -269,6 +264,33 @@ __global__ __launch_bounds__(POSE_WG) void k_pose_iter(Work W, LevelDev L, tsba_
         }
         P.mcc = mcc; P.step2 = step2; P.fail = fail ? 1 : 0;
     }
+}
+
+// k = -1: linearisation at the start point (into part[1]); k >= 0: see the header
+__global__ __launch_bounds__(POSE_WG) void k_pose_iter(Work W, LevelDev L, tsba_options o, int k, int G) {
+    __shared__ double lds[POSE_LDS];                        // the sweep's transposes; before it, the staged partial sums
+    __shared__ double s_ps[8*28];
+    __shared__ double s_sum[32];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int nb_sc = (L.n_sc + POSE_WG - 1)/POSE_WG;
+    const bool is_free = W.fidx[0] >= 0;                    // (a constant pose leaves every block out of the reduced program)
+    if (k < 0) {
+        const LmState *st = W.st;
+        if (st->done) return;
+        const int cur = st->cur;
+        double tot = 0.0;
+        if (is_free) tot = pose_sweep_wg(W, L, W.pose[cur], W.rho[cur], W.theta[cur], b, nb_sc, lds);
+        if (tid < 28) W.ppart[(size_t)(1*G + b)*28 + tid] = tot;
+        return;
+    }
+    // ---- state
+    PoseState P;
+    if (k == 0) pose_state_init(W, P);
+    else P = W.pst[k & 1];
+    PoseState *Pn = W.pst + ((k + 1) & 1);
+    LmState &S = P.S;
+    if (S.done) { if (b == 0 && tid == 0) *Pn = P; return; }
+    pose_step<false>(W, o, k, G, W.ppart + (size_t)((k + 1) & 1)*G*28, is_free, P, lds, s_ps, s_sum);
     if (b == 0 && tid == 0) {
         *Pn = P;
         if (W.hprog) *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)(unsigned)S.it << 1) | (unsigned long long)(S.done != 0);
@@ -279,12 +301,54 @@ __global__ __launch_bounds__(POSE_WG) void k_pose_iter(Work W, LevelDev L, tsba_
     if (tid < 28) W.ppart[(size_t)((k & 1)*G + b)*28 + tid] = tot;
 }
 
+
+// The whole pass in ONE launch (round 5): the steps of k_pose_iter in a loop, and where the launches were, nothing but the sums themselves.  Every workgroup
+// carries the state in registers -- they all compute the same bits, so they all leave the loop in the same iteration without telling each other --; the sums of
+// step k go to buffer k mod 3 of W.ppart as device-coherent stores and are read by polling every value until it is no longer NaN (a NaN sum is published as
+// +inf: the trial fails either way).  A workgroup in step k has seen every other workgroup's sums of step k - 1, so all of them have finished reading the
+// buffer of step k - 2: that is the one it resets (its own 28 values) for step k + 1; k_pose_begin fills all three with NaNs before the pass.  A wait that runs
+// into its bound is counted (tsba_report.poll_timeouts) and fails the trial; the launch is used only where all G workgroups (a few tens: 256 scene blocks or
+// 32 text features each) are resident at once (tsba.hip: grid_resident).  Saved: a launch boundary per LM step and the two steps of empty launches the host
+// stays ahead -- C3 0.28 -> 0.2x ms; a counter barrier (fence + atomic + polling the counter, then reading the sums) in the same place gave 0.232.
+__global__ __launch_bounds__(POSE_WG) void k_pose_pass(Work W, LevelDev L, tsba_options o, int G, int max_k) {
+    __shared__ double lds[POSE_LDS];
+    __shared__ double s_ps[8*28];
+    __shared__ double s_sum[32];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int nb_sc = (L.n_sc + POSE_WG - 1)/POSE_WG;
+    const bool is_free = W.fidx[0] >= 0;
+    if (W.st->done) return;                                  // (uniform: written before this launch)
+    const int cur = W.st->cur;
+    {   // linearisation at the start point ("step -1": buffer 2)
+        double tot = 0.0;
+        if (is_free) tot = pose_sweep_wg(W, L, W.pose[cur], W.rho[cur], W.theta[cur], b, nb_sc, lds);
+        if (tid < 28) pose_publish(&W.ppart[(size_t)(2*G + b)*28 + tid], tot);
+    }
+    PoseState P;
+    pose_state_init(W, P);
+    LmState &S = P.S;
+    for (int k = 0; k <= max_k; k++) {
+        __syncthreads();                                     // (lds / s_sum of the last sweep and step are free)
+        pose_step<true>(W, o, k, G, W.ppart + (size_t)((k + 2) % 3)*G*28, is_free, P, lds, s_ps, s_sum);
+        if (b == 0 && tid == 0 && W.hprog) *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)(unsigned)S.it << 1) | (unsigned long long)(S.done != 0);
+        if (S.done) break;
+        if (tid < 28) __hip_atomic_store(&W.ppart[(size_t)(((k + 1) % 3)*G + b)*28 + tid], __builtin_nan(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (step k - 2's: read by everybody)
+        __syncthreads();
+        // speculative linearisation at the candidate; after a failed step (no candidate) nobody looks at the sums, but everybody waits for them: zeros
+        double tot = 0.0;
+        if (!P.fail) tot = pose_sweep_wg(W, L, P.cand, W.rho[cur], W.theta[cur], b, nb_sc, lds);
+        if (tid < 28) pose_publish(&W.ppart[(size_t)((k % 3)*G + b)*28 + tid], tot);
+    }
+    if (b == 0 && tid == 0) W.pst[0] = P;                    // (k_outlier installs it)
+}
+
 // pass start of the pose-only path in one launch: workgroups 0 .. n_tg-1 = k_musigma (the pose is the same in both parameter
 // buffers here); workgroup n_tg = k_pass_reset + k_participation + k_gauge for one keyframe
-__global__ __launch_bounds__(MS_THREADS) void k_pose_begin(Work W, LevelDev L, double radius0, int max_it, const uint8_t *kf_initial) {
+__global__ __launch_bounds__(MS_THREADS) void k_pose_begin(Work W, LevelDev L, double radius0, int max_it, const uint8_t *kf_initial, double *sums_nan, int n_nan) {
     if ((int)blockIdx.x < L.n_tg) { musigma_wg(W, L, blockIdx.x, W.pose[0], W.theta[0]); return; }
     __shared__ int cnt_s, cnt_t;
     const int tid = threadIdx.x;
+    if (sums_nan) for (int e = tid; e < n_nan; e += MS_THREADS) sums_nan[e] = __builtin_nan("");      // k_pose_pass: "not there yet"
     if (tid == 0) { cnt_s = 0; cnt_t = 0; }
     __syncthreads();
     int ns = 0, nt = 0;
