@@ -1390,7 +1390,8 @@ int tsba_solve(void *ctx, tsba_report *r) {
         if (pose_path) {                                     // k_pass_reset + k_participation + k_gauge + k_musigma in one launch
             c->W.hprog = c->hprog; c->W.pass_seq = ++c->pass_seq;
             LAUNCHK(k_pose_begin, dim3(D.n_tg + 1), dim3(MS_THREADS), 0, c->stream, c->W, D, o.initial_radius, o.its[ps], (const uint8_t *)c->kf_initial,
-                    pose_one_launch ? c->W.ppart : (double *)nullptr, 3*28*pose_grid(D));
+                    pose_one_launch ? c->W.ppart : (double *)nullptr, 3*28*pose_grid(D), log_pending ? c->st_log + ps - 1 : (LmState *)nullptr);
+            log_pending = false;
         } else if (fastp(D)) {
             // windows: k_pass_begin (tsba_kernels_pass.h).  The participation arrays are clear (k_reset_state / the last pass's k_pass_end); the text
             // observations' mu / sigma are there already if the last pass's k_pass_end computed them for this level
@@ -1437,7 +1438,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
             // outlier pass + installation of the pass's result (one extra workgroup) in one launch
             LAUNCHK(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg + 1), dim3(64), 0, c->stream, c->W, D, o.chi2_mono[ps], o.chi2_text[ps],
                                o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)(c->W.pst + ((k_last + 1) & 1)));
-            CK(hipMemcpyAsync(c->st_log + ps, c->W.st, sizeof(LmState), hipMemcpyDeviceToDevice, c->stream));
+            log_pending = true;                              // (kept by the next pass's k_pose_begin, or by k_solve_end)
             continue;
         }
         launch_linearize(c, D, 0);

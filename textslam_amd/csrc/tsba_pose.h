@@ -30,10 +30,45 @@ struct PoseState {
     int fail, pad;
 };
 
+// What a thread's observation needs besides the pose -- constant over a pass (the landmarks are frozen, the flags change in the outlier pass only): loaded once
+// per launch.  Scene block: T12 = T_rw of the point's host, v = ray (2), rho, u, v.  Text tap: T12 = T_wr of the plane's host, v = mu, sigma, feature u, v,
+// reference intensity, theta (3).
+struct PoseObs { bool on; double T12[12], v[8]; const uint8_t *img; };
+__device__ __forceinline__ void pose_obs_load(const Work &W, const LevelDev &L, const double *rho, const double *theta, int b, int nb_sc, PoseObs &O) {
+    const int tid = threadIdx.x;
+    O.on = false; O.img = nullptr;
+#pragma unroll
+    for (int q = 0; q < 12; q++) O.T12[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) O.v[q] = 0.0;
+    if (b < nb_sc) {
+        const int c = b*POSE_WG + tid;
+        if (c < L.n_sc && (!W.filter_good || W.sgood[L.sc_flag[c]])) {
+            const int pt = L.sc_pt[c];
+            O.on = true;
+#pragma unroll
+            for (int q = 0; q < 12; q++) O.T12[q] = W.pt_Trw[12*(size_t)pt + q];
+            O.v[0] = W.pt_ray[2*pt]; O.v[1] = W.pt_ray[2*pt+1]; O.v[2] = rho[pt]; O.v[3] = L.sc_uv[2*c]; O.v[4] = L.sc_uv[2*c+1];
+        }
+    } else {
+        const int fi = (b - nb_sc)*(POSE_WG/8) + (tid >> 3), kt = tid & 7;
+        if (fi < L.n_pf) {
+            const int g = L.pf_g[fi], f = L.pf_f[fi];
+            const int4 ra = ((const int4 *)L.tg_rec)[2*g], rb = ((const int4 *)L.tg_rec)[2*g + 1];
+            const int tb = ra.x, j = ra.z, fg = rb.w;
+            O.v[0] = W.musig[2*tb]; O.v[1] = W.musig[2*tb+1];
+            O.v[2] = L.tfeat_uv[2*f]; O.v[3] = L.tfeat_uv[2*f+1]; O.v[4] = L.tfeat_ref[8*(size_t)f + kt];
+            O.img = L.img[ra.y];
+#pragma unroll
+            for (int q = 0; q < 12; q++) O.T12[q] = W.text_Twr[12*(size_t)j + q];
+            O.v[5] = theta[3*j]; O.v[6] = theta[3*j+1]; O.v[7] = theta[3*j+2];
+            O.on = (!W.filter_good || (W.tobs_good[tb] && W.tfgood[fg + L.tfeat_raw[f]])) && O.v[1] != 0.0;
+        }
+    }
+}
 // this workgroup's share of the observations at pose p7 -- 256 scene blocks, or 32 text features x 8 taps: thread t < 28 returns
 // the workgroup total of value t (0..20 = sum w J^T J upper / sym6 order, 21..26 = sum w J^T r, 27 = sum rho / 2)
-__device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L, const double *p7, const double *rho, const double *theta,
-                                                int b, int nb_sc, double *lds) {
+__device__ __forceinline__ double pose_sweep_obs(const Work &W, const LevelDev &L, const double *p7, const PoseObs &O, int b, int nb_sc, double *lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[28];
 #pragma unroll
@@ -41,12 +76,10 @@ __device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L
     Pose C; load_pose(p7, C);
     if (b < nb_sc) {
         // ---- scene blocks (R3), one per thread: frozen host, T_rw stored with the point
-        const int c = b*POSE_WG + tid;
-        if (c < L.n_sc && (!W.filter_good || W.sgood[L.sc_flag[c]])) {
-            const int pt = L.sc_pt[c];
-            PairT T; pair_from_Trw(C, W.pt_Trw + 12*(size_t)pt, T);
+        if (O.on) {
+            PairT T; pair_from_Trw(C, O.T12, T);
             double r[2], jt[2][6], jl[2];
-            scene_block(T, C.t, W.pt_ray[2*pt], W.pt_ray[2*pt+1], rho[pt], L.sc_uv[2*c], L.sc_uv[2*c+1],
+            scene_block(T, C.t, O.v[0], O.v[1], O.v[2], O.v[3], O.v[4],
                         W.K0[0], W.K0[1], W.K0[2], W.K0[3], W.w_sx, W.w_sy, r, jt, jl);
             double wgt; acc[27] = 0.5*huber(r[0]*r[0] + r[1]*r[1], W.huber_s, wgt);
             int q = 0;
@@ -59,24 +92,15 @@ __device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L
         }
     } else {
         // ---- photometric blocks (R7): thread = (feature, tap); (group, feature) from the frame's flat feature list
-        const int fi = (b - nb_sc)*(POSE_WG/8) + (tid >> 3), kt = tid & 7;
-        double r = 0.0, jt[6] = {0, 0, 0, 0, 0, 0}; bool good = false;
-        if (fi < L.n_pf) {
-            const int g = L.pf_g[fi], f = L.pf_f[fi];
-            const int4 ra = ((const int4 *)L.tg_rec)[2*g], rb = ((const int4 *)L.tg_rec)[2*g + 1];
-            const int tb = ra.x, j = ra.z, fg = rb.w;
-            const double mu = W.musig[2*tb], sigma = W.musig[2*tb+1];
-            const double fu = L.tfeat_uv[2*f], fv = L.tfeat_uv[2*f+1], rf = L.tfeat_ref[8*(size_t)f + kt];
-            const uint8_t *img = L.img[ra.y];
-            PairT T; pair_from_Twr(C, W.text_Twr + 12*(size_t)j, T);
-            const double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-            good = (!W.filter_good || (W.tobs_good[tb] && W.tfgood[fg + L.tfeat_raw[f]])) && sigma != 0.0;
-            if (good) {
-                const double mx = (fu + TAP_DX[kt] - L.K[2])/L.K[0], my = (fv + TAP_DY[kt] - L.K[3])/L.K[1];   // tool.cc:1561
-                double jl[3];
-                r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h,
-                             mu, sigma, 1.0/sigma, rf, W.w_t, true, jt, jl);
-            }
+        const int kt = tid & 7;
+        double r = 0.0, jt[6] = {0, 0, 0, 0, 0, 0}; const bool good = O.on;
+        if (good) {
+            PairT T; pair_from_Twr(C, O.T12, T);
+            const double th[3] = { O.v[5], O.v[6], O.v[7] };
+            const double mx = (O.v[2] + TAP_DX[kt] - L.K[2])/L.K[0], my = (O.v[3] + TAP_DY[kt] - L.K[3])/L.K[1];   // tool.cc:1561
+            double jl[3];
+            r = text_tap(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], O.img, L.img_w, L.img_h,
+                         O.v[0], O.v[1], 1.0/O.v[1], O.v[4], W.w_t, true, jt, jl);
         }
         double s8 = r*r;                                        // the block's squared norm: its 8 taps sit on 8 neighbouring lanes
         s8 += __shfl_xor(s8, 1, 64); s8 += __shfl_xor(s8, 2, 64); s8 += __shfl_xor(s8, 4, 64);
@@ -102,6 +126,10 @@ __device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L
         for (int w = 0; w < POSE_NW; w++) tot += xw[w*32 + tid];
     }
     return tot;
+}
+__device__ __forceinline__ double pose_sweep_wg(const Work &W, const LevelDev &L, const double *p7, const double *rho, const double *theta, int b, int nb_sc, double *lds) {
+    PoseObs O; pose_obs_load(W, L, rho, theta, b, nb_sc, O);
+    return pose_sweep_obs(W, L, p7, O, b, nb_sc, lds);
 }
 
 // the state a pass starts from (k = 0)
@@ -319,9 +347,10 @@ __global__ __launch_bounds__(POSE_WG) void k_pose_pass(Work W, LevelDev L, tsba_
     const bool is_free = W.fidx[0] >= 0;
     if (W.st->done) return;                                  // (uniform: written before this launch)
     const int cur = W.st->cur;
+    PoseObs O; pose_obs_load(W, L, W.rho[cur], W.theta[cur], b, nb_sc, O);      // (once: every step's sweep runs from registers; a text tap still fetches its pixels)
     {   // linearisation at the start point ("step -1": buffer 2)
         double tot = 0.0;
-        if (is_free) tot = pose_sweep_wg(W, L, W.pose[cur], W.rho[cur], W.theta[cur], b, nb_sc, lds);
+        if (is_free) tot = pose_sweep_obs(W, L, W.pose[cur], O, b, nb_sc, lds);
         if (tid < 28) pose_publish(&W.ppart[(size_t)(2*G + b)*28 + tid], tot);
     }
     PoseState P;
@@ -336,7 +365,7 @@ __global__ __launch_bounds__(POSE_WG) void k_pose_pass(Work W, LevelDev L, tsba_
         __syncthreads();
         // speculative linearisation at the candidate; after a failed step (no candidate) nobody looks at the sums, but everybody waits for them: zeros
         double tot = 0.0;
-        if (!P.fail) tot = pose_sweep_wg(W, L, P.cand, W.rho[cur], W.theta[cur], b, nb_sc, lds);
+        if (!P.fail) tot = pose_sweep_obs(W, L, P.cand, O, b, nb_sc, lds);
         if (tid < 28) pose_publish(&W.ppart[(size_t)((k % 3)*G + b)*28 + tid], tot);
     }
     if (b == 0 && tid == 0) W.pst[0] = P;                    // (k_outlier installs it)
@@ -344,7 +373,7 @@ __global__ __launch_bounds__(POSE_WG) void k_pose_pass(Work W, LevelDev L, tsba_
 
 // pass start of the pose-only path in one launch: workgroups 0 .. n_tg-1 = k_musigma (the pose is the same in both parameter
 // buffers here); workgroup n_tg = k_pass_reset + k_participation + k_gauge for one keyframe
-__global__ __launch_bounds__(MS_THREADS) void k_pose_begin(Work W, LevelDev L, double radius0, int max_it, const uint8_t *kf_initial, double *sums_nan, int n_nan) {
+__global__ __launch_bounds__(MS_THREADS) void k_pose_begin(Work W, LevelDev L, double radius0, int max_it, const uint8_t *kf_initial, double *sums_nan, int n_nan, LmState *log_prev) {
     if ((int)blockIdx.x < L.n_tg) { musigma_wg(W, L, blockIdx.x, W.pose[0], W.theta[0]); return; }
     __shared__ int cnt_s, cnt_t;
     const int tid = threadIdx.x;
@@ -362,6 +391,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_pose_begin(Work W, LevelDev L, d
     __syncthreads();
     if (tid == 0) {
         LmState *s = W.st;                                   // (every field but cur / n_lin / n_cost, which carry over)
+        if (log_prev) *log_prev = *s;                        // the pass before this one left its final state here only (its outlier counts were still being added when it was installed)
         s->radius = radius0; s->decrease_factor = 2.0; s->x_cost = 0; s->x_norm = 0; s->cand_cost = 0; s->model_change = 0;
         s->step_norm = 0; s->gmax = 0; s->cost0 = 0;
         s->done = 0; s->need_lin = 1; s->first = 1; s->it = 0; s->accepted = 0; s->term = 0; s->invalid = 0; s->max_it = max_it;
