@@ -46,6 +46,11 @@ int tsorb_download(void *ctx, float *kp, uint8_t *desc, int32_t *count);
 /* Test hook: pyramid level `level` (with its 19-px BORDER_REFLECT_101 frame) of frame f after a run: (h_l + 38) x (w_l + 38) bytes;
  * blurred = 1 returns the 7x7 Gaussian-blurred level (no frame): h_l x w_l. */
 int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out, int32_t *w_out, int32_t *h_out);
+/* Test / diagnostics hook: the shape of the FAST launch(es).  -1 (default): chosen by the batch size -- from 24 frames on, the levels whose cells fit a 40 x 40
+ * tile run two waves per cell in a launch of their own, the others (and every level of a smaller batch) four waves per cell on a 72 x 72 tile; 0: every level through
+ * the general instance whatever the batch size; 2: the split whatever the batch size; 1 / 3: the split with four waves / one wave per cell on the small tile (A/B runs).
+ * The output does not depend on it (tests/test_gpu_orb.py).  Takes effect at the next upload. */
+int tsorb_debug_fast_shape(void *ctx, int shape);
 
 /* ---- Window / projection search: the step between the extractor and PoseOptim.
  *   tsorb_match_set_frame / _set_features  <- frame::AssignFeaturesToGrid + PosInGrid                       src/frame.cc:372-407

@@ -93,6 +93,15 @@ def test_large_batches_take_the_split_detector_and_agree(orb, oracle_lib):
         _same(res[f], orb.extract_batch(imgs[f:f + 1])[0])
     for f in (5, 30, 31):
         _same(res[f], oracle_lib.orb_extract(imgs[f], cap=8192))
+    try:                                                          # the shapes kept for A/B runs (tsorb_debug_fast_shape): the same output
+        for shape in (0, 1, 3, 2):
+            orb.debug_fast_shape(shape)
+            alt = orb.extract_batch(imgs)
+            for f in (0, 7, 30, 31):
+                _same(alt[f], res[f])
+            _same(orb.extract_batch(imgs[3:4])[0], res[3])        # (the split on a single frame)
+    finally:
+        orb.debug_fast_shape(-1)
 
 
 @pytest.mark.gpu

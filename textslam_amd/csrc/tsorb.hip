@@ -995,7 +995,7 @@ struct OCtx {
     int device = 0; hipStream_t stream = nullptr; std::string err;
     int nfeatures = 1000, nlevels = 8, ini_th = 20, min_th = 7; float scale = 1.2f;
     float sf[MAXL], isf[MAXL]; int nfl[MAXL], umax[16], gk[7];
-    std::vector<void *> allocs; bool uploaded = false;
+    std::vector<void *> allocs; bool uploaded = false; int fast_shape = -1;       // (tsorb_debug_fast_shape)
     OrbDev D;
     // the SLAM front-end calls once per frame with the same geometry: buffers and pinned staging are kept between calls
     MatchDev M; bool m_set = false; void *m_buf = nullptr; size_t m_cap = 0; void *m_feat = nullptr; size_t m_feat_cap = 0;   // search grid of the current frame
@@ -1069,7 +1069,7 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
         if (G.nCols < 1 || G.nRows < 1) { c->err = "image too small for the requested pyramid"; return TSORB_ERR_ARG; }
         G.wCell = (int)ceilf(width/G.nCols); G.hCell = (int)ceilf(height/G.nRows);
         if (G.wCell + 6 > TILE_MAX || G.hCell + 6 > TILE_MAX) { c->err = "cell larger than the LDS tile"; return TSORB_ERR_ARG; }
-        { static const int shape = [] { const char *e = getenv("TSORB_FAST_SHAPE"); return e ? atoi(e) : -1; }();      // (diagnostics: 0 every level through the general instance, 1 - 3 the split at any batch size)
+        { const int shape = c->fast_shape;                   // (tsorb_debug_fast_shape: 0 every level through the general instance, 1 - 3 the split at any batch size)
           // below ~24 frames the device is not full and a cell's own time counts: four waves per cell, one launch (measured: 1 frame 0.144 against 0.157 ms
           // split, 16 frames equal, 32 frames 0.299 against 0.292, 64 frames 0.446 against 0.426)
           const bool one_group = shape == 0 || (shape < 0 && n < 24);
@@ -1114,7 +1114,7 @@ int tsorb_run(void *ctx) {
     OrbDev &D = c->D;
     hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
     for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
-    static const int fast_shape = [] { const char *e = getenv("TSORB_FAST_SHAPE"); return e ? atoi(e) : 2; }();      // (diagnostics: 1 / 3 the small tile with 256 / 64 threads)
+    const int fast_shape = c->fast_shape < 0 ? 2 : c->fast_shape;      // (diagnostics: 1 / 3 the small tile with 256 / 64 threads)
     if (D.fast_cells[0] > 0) {
         if (fast_shape == 1) hipLaunchKernelGGL((k_fast<40, 1024, 320, 256, 0>), dim3(D.n*D.fast_cells[0]), dim3(256), 0, c->stream, D);
         else if (fast_shape == 3) hipLaunchKernelGGL((k_fast<40, 1024, 320, 64, 0>), dim3(D.n*D.fast_cells[0]), dim3(64), 0, c->stream, D);
@@ -1148,6 +1148,7 @@ int tsorb_extract_batch(void *ctx, const uint8_t *imgs, int n, int w, int h, int
     rc = tsorb_run(ctx); if (rc) return rc;
     return tsorb_download(ctx, kp, desc, count);
 }
+int tsorb_debug_fast_shape(void *ctx, int shape) { OCtx *c = (OCtx *)ctx; if (!c || shape < -1 || shape > 3) return TSORB_ERR_ARG; c->fast_shape = shape; c->key[0] = 0; return TSORB_OK; }      // (key: the next upload sets the geometry up again)
 int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out, int32_t *w_out, int32_t *h_out) {
     OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded || !out) return TSORB_ERR_ARG;
     OrbDev &D = c->D; if (frame < 0 || frame >= D.n || level < 0 || level >= D.nlevels) return TSORB_ERR_ARG;
