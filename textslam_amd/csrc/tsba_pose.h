@@ -1,21 +1,26 @@
 // Pose-only optimisation (optimizer::PoseOptim -> PyrPoseOptim, optimizer.cc:1060-1327: one free pose, every landmark frozen in its
-// host keyframe -- residual rows R3 / R7) with ONE kernel per LM iteration.  Included by tsba.hip after tsba_solve.h.
+// host keyframe -- residual rows R3 / R7).  Included by tsba.hip after tsba_solve.h.
 //
-// The general pipeline spends seven dependent launches per LM iteration (schur, solve, back, linearize, mid, decide ...) and gives
-// the single (target, host = frozen) pair of a frame to ONE wave: 3000 scene blocks = 47 serial rounds.  With 6 unknowns there is
-// nothing to schedule between the sweeps, so here every LM iteration is one launch of ~60 workgroups of 256 threads:
+// The general pipeline spends several dependent launches per LM iteration (schur, solve + back, linearize, mid) and gives the single
+// (target, host = frozen) pair of a frame to ONE wave: 3000 scene blocks = 47 serial rounds.  With 6 unknowns there is nothing to
+// schedule between the sweeps: an LM step is "sum the sweep's partial sums, decide, solve 6 x 6, sweep at the candidate", run by 7 - 18
+// workgroups of 256 threads (256 scene blocks or 32 text features x 8 taps each).
 //
-//   k_pose_iter(k):   every workgroup, redundantly and bit-identically:
+//   k_pose_pass (round 5, the path taken where the grid is resident at once): ALL steps of a pass in one launch; the state lives in
+//                     every workgroup's registers, the sums are exchanged by polling their values (three buffers; see the kernel).
+//   k_pose_iter(k) (one launch per step: devices too small for the grid, tsba_debug_options.pass_launches, rounds 1 - 4):
+//                     every workgroup, redundantly and bit-identically:
 //                       state_k   <- pst[k & 1]                                      (k = 0: built from W.st / W.pose)
 //                       sums(cand) <- sum over workgroups of part[(k + 1) & 1]       (fixed order: deterministic)
 //                       Ceres decision for trial k-1 (k = 0: Jacobi scaling + gradient test of the first linearisation)
 //                       (M + D/radius) dp = -c  by 6x6 LDL^T in registers, candidate on the quaternion manifold
 //                     workgroup 0 writes state_{k+1} -> pst[(k + 1) & 1] and the pinned progress word;
-//                     every workgroup then sweeps ITS 256 scene blocks / 32 text features x 8 taps at the candidate -> part[k & 1].
+//                     every workgroup then sweeps ITS observations at the candidate -> part[k & 1].
+//                     State and partial sums are double-buffered by the launch ordinal, so no workgroup reads what another one writes in
+//                     the same launch; a converged pass copies its state forward.
 //
-// State and partial sums are double-buffered by the launch ordinal, so no workgroup reads what another one writes in the same
-// launch; a converged pass copies its state forward, and k_pose_finish(k_last) installs it into W.st / W.pose.  mu / sigma
-// (k_musigma), participation, gauge and the outlier pass stay the kernels of the general path.
+// Both share pose_step / pose_sweep_obs.  k_outlier's extra workgroup installs the final state into W.st / W.pose; mu / sigma, participation
+// and gauge are k_pose_begin (one launch), the outlier pass is the general path's kernel.
 #pragma once
 
 #define POSE_WG 256
