@@ -368,3 +368,62 @@ def test_converged_answers_against_the_oracle(gpu, oracle_lib, map_cache, name):
 #   these valleys is path-dependent (the oracle itself moves on by 4.5e-4 / 4.1e-3 when started again at its answer).
 CONVERGED_FLOOR = {"c6_open_chain": dict(K9=26, K6=27, Kdec=28, rel_cost=4e-3), "c6_long_range": dict(K9=0, K6=56, Kdec=60, rel_cost=6e-2)}
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+# Round 6: SURVEY 8d's "converged parameters rel 1e-6" on the 5000-keyframe open chain and the map with long-range points AS THE REFERENCE HANDS THEM TO GlobalBA
+# (tests/golden/make_converged.py): no point that a local BA has flagged (map::GetAllMapPoints(false), src/optimizer.cc:337-341, src/map.cc:36-47,
+# src/tracking.cc:2215-2230) and every camera near its place (GlobalBA runs after the loop correction, loopClosing.cc:587-591).  The gauge is fixed by the two
+# constant keyframes (optimizer.cc:405-406), so the parameters are compared directly -- no similarity alignment.
+HANDED_OVER = {
+    "c6_open_chain_handed_over": dict(n_kf=5000, n_pt=105000, band=10, drop_outlier_points=True, perturb_in_camera=True),
+    "c6_long_range_handed_over": dict(n_kf=5000, n_pt=105000, band=10, far_frac=0.01, drop_outlier_points=True, perturb_in_camera=True),
+}
+SURVEY_8D_CONVERGED = 1e-6
+
+
+def _parameter_gaps(G, pose_ref, rho_ref):
+    """-> (quaternion gap, translation gap relative to the map's extent, camera-centre gap relative to the extent, inverse-depth gap relative to the value)"""
+    qa = G.pose[:, :4]/np.linalg.norm(G.pose[:, :4], axis=1, keepdims=True); qb = pose_ref[:, :4]/np.linalg.norm(pose_ref[:, :4], axis=1, keepdims=True)
+    qa = qa*np.sign((qa*qb).sum(1, keepdims=True))
+    extent = float(np.abs(pose_ref[:, 4:]).max())
+    _, raw = _gauge_aligned_pose_gap(G.pose, pose_ref)             # (the gauge is fixed: the RAW gap of the camera centres, no alignment)
+    return (float(np.abs(qa - qb).max()), float(np.abs(G.pose[:, 4:] - pose_ref[:, 4:]).max()/extent), raw,
+            float((np.abs(G.rho - rho_ref)/np.abs(rho_ref)).max()))
+
+
+@pytest.mark.parametrize("name", list(HANDED_OVER))
+def test_converged_parameters_on_the_map_as_the_reference_hands_it_over(gpu, name):
+    """(A) both sides run the reference's solve to Ceres' own exit (function tolerance 1e-6, optimizer.cc:1833-1846) from the common start: same number of
+    iterations and accepted steps, final cost and final parameters within SURVEY 8d's 1e-6.
+    (B) both sides with function_tolerance = parameter_tolerance = gradient_tolerance = 0 until no step changes the cost any more -- a true stationary point,
+    where the answer does not depend on the iteration an exit test fires in: cost to 1e-9, parameters to 1e-6."""
+    from textslam_amd import synth
+    fx = np.load(os.path.join(ROOT, "tests", "golden", f"converged_{name}.npz"))
+    P = synth.config_global(**HANDED_OVER[name])
+    # (A) Ceres' exit
+    o = abi.options_global(); o.its[0] = CONVERGED_ITS
+    gpu.upload(P, o); rep = gpu.solve(); G = gpu.download(P.copy())
+    assert rep["poll_timeouts"] == 0 and rep["pcg_unconverged"] == 0, rep
+    assert abs(rep["cost0"][0] - float(fx["cost0"])) <= 1e-11*float(fx["cost0"])
+    relA = abs(rep["cost1"][0] - float(fx["cost1"]))/float(fx["cost1"])
+    gq, gt, gc, gr = _parameter_gaps(G, fx["pose"], fx["rho"])
+    print(f"\n{name} (A) Ceres' exit: GPU {rep['iters'][0]} iterations / {rep['accepted'][0]} accepted, cost {rep['cost1'][0]!r}; oracle {int(fx['iters'])} / {int(fx['accepted'])}, "
+          f"cost {float(fx['cost1'])!r}: rel {relA:.2e}; quaternions {gq:.2e}, translations {gt:.2e} and camera centres {gc:.2e} of the map's extent, inverse depths rel {gr:.2e}")
+    # (B) a stationary point
+    o3 = abi.options_global(); o3.its[0] = 600; o3.function_tolerance = 0.0; o3.parameter_tolerance = 0.0; o3.gradient_tolerance = 0.0
+    gpu.upload(P, o3); rep3 = gpu.solve(); G3 = gpu.download(P.copy())
+    assert rep3["poll_timeouts"] == 0 and rep3["pcg_unconverged"] == 0, rep3
+    relB = abs(rep3["cost1"][0] - float(fx["stationary_cost1"]))/float(fx["stationary_cost1"])
+    sq, st, sc, sr = _parameter_gaps(G3, fx["stationary_pose"], fx["stationary_rho"])
+    print(f"{name} (B) zero tolerances: GPU {rep3['iters'][0]} iterations / {rep3['accepted'][0]} accepted, termination {rep3['termination'][0]}, cost {rep3['cost1'][0]!r}; oracle "
+          f"{int(fx['stationary_iters'])} / {int(fx['stationary_accepted'])}, cost {float(fx['stationary_cost1'])!r}: rel {relB:.2e}; quaternions {sq:.2e}, translations {st:.2e} and "
+          f"camera centres {sc:.2e} of the map's extent, inverse depths rel {sr:.2e}")
+    _record(name, ceres_exit=dict(iters_gpu=rep["iters"][0], iters_oracle=int(fx["iters"]), accepted_gpu=rep["accepted"][0], accepted_oracle=int(fx["accepted"]),
+                                  cost1_gpu=rep["cost1"][0], cost1_oracle=float(fx["cost1"]), rel_cost=relA, quaternion_gap=gq, translation_gap=gt, centre_gap=gc, rho_gap_rel=gr),
+            stationary=dict(iters_gpu=rep3["iters"][0], iters_oracle=int(fx["stationary_iters"]), termination_gpu=rep3["termination"][0], cost1_gpu=rep3["cost1"][0],
+                            cost1_oracle=float(fx["stationary_cost1"]), rel_cost=relB, quaternion_gap=sq, translation_gap=st, centre_gap=sc, rho_gap_rel=sr))
+    assert rep["termination"][0] == 1 and rep["iters"][0] == int(fx["iters"]) and rep["accepted"][0] == int(fx["accepted"]), rep
+    assert relA <= SURVEY_8D_CONVERGED and max(gq, gt, gc, gr) <= SURVEY_8D_CONVERGED, (relA, gq, gt, gc, gr)
+    assert rep3["iters"][0] < 600, rep3                              # (it ended because no step changes the cost any more, not on the iteration cap)
+    assert relB <= 1e-9 and max(sq, st, sc, sr) <= SURVEY_8D_CONVERGED, (relB, sq, st, sc, sr)

@@ -96,6 +96,7 @@ struct Ctx {
     std::vector<int> ic_slot; bool use_img_cache = false;      // plane cache: slot of every keyframe of this upload
     std::atomic<int> plan_done[TSBA_MAX_LEVELS];  // set by a plan thread when its plan is complete: a level is staged ahead of its pass only when that costs no wait
     hipStream_t copy_stream = nullptr; hipEvent_t ev_stage[TSBA_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_upload = nullptr; bool upload_pending = false;      // one-shot calls end their upload without a synchronisation: the copy stream's first staging waits for this event (the slabs' clearing runs on the compute stream)
     bool stage_async = false; int lev_wait[TSBA_MAX_LEVELS] = {0, 0, 0, 0};     // levels staged during a solve go over the copy stream; their pass waits for the event
     // restart copies
     double *pose0 = nullptr, *rho0 = nullptr, *theta0 = nullptr; uint8_t *sgood0 = nullptr, *tobs_good0 = nullptr, *tfgood0 = nullptr;
@@ -133,6 +134,7 @@ struct Ctx {
                       long long hits = 0, misses = 0; } ic;
     WbBuf wb{}; Work Wk{}; double *wb_alloc = nullptr; size_t wb_bytes = 0;      // low-rank correction for loop closures (tsba_wb.h): its buffers, the k x k dense system as a second Work
     EcgBuf ecg{}; double *ecg_alloc = nullptr; size_t ecg_bytes = 0;      // enlarged conjugate gradients (tsba_pcg.h)
+    bool pack_in_solve = false, packed = false;   // one-shot calls: tsba_solve packs the results behind its last kernel (enqueue_pack); packed: the block in dl_host is that solve's
     unsigned char *dl_dev = nullptr, *dl_host = nullptr; size_t dl_bytes = 0;       // results of a solve as one block (k_pack_results): one device-to-host copy per download
     MsBuf sv{}; double *sv_alloc = nullptr; size_t sv_bytes = 0; bool sv_prepared = false;      // single-vector solve phase (tsba_bandsv.h); sv_prepared: k_sv_linv has run on the current factorisation
     MsBuf ms{}; double *ms_alloc = nullptr; size_t ms_bytes = 0; int ms_cap = 0;      // multi-right-hand-side solve phase of the partitioned band solver (tsba_bandms.h)
@@ -275,6 +277,7 @@ int tsba_create(void **ctx, int device) {
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) c->plan_done[l].store(0);
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) c->copy_stream = nullptr;     // (optional: staging then shares the compute stream)
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (hipEventCreateWithFlags(&c->ev_stage[l], hipEventDisableTiming) != hipSuccess) c->ev_stage[l] = nullptr;
+    if (hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming) != hipSuccess) c->ev_upload = nullptr;
     hipDeviceProp_t prop;
     const bool ok = hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess
         && hipHostMalloc((void **)&c->st_host, sizeof(LmState)*TSBA_MAX_LEVELS + 64, 0) == hipSuccess
@@ -311,6 +314,7 @@ int tsba_destroy(void *ctx) {
     if (c->ecg_alloc) hipFree(c->ecg_alloc);
     if (c->wb_alloc) hipFree(c->wb_alloc);
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) if (c->ev_stage[l]) hipEventDestroy(c->ev_stage[l]);
+    if (c->ev_upload) hipEventDestroy(c->ev_upload);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipStreamDestroy(c->stream);
     delete c; return TSBA_OK;
@@ -412,7 +416,8 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     struct Joiner { Ctx *c; bool armed; ~Joiner() { if (armed) join_planners(c); } } joiner{c, true};   // on the error returns
     int n_lev_used = 0; { std::vector<char> sn(p->n_levels, 0); for (int q = 0; q < o->n_passes; q++) if (!sn[o->levels[q]]) { sn[o->levels[q]] = 1; n_lev_used++; } }
     const bool small_window = solve_lds_doubles(W.N)*sizeof(double) <= 160*1024 - 64;
-    const bool defer = lazy && small_window && p->n_kf > 1 && n_lev_used > 1 && !is_multi(c);
+    // (round 6: also the single-frame problems of tsba_pose_optim -- the plans of the later passes' levels are built and staged while the first pass runs)
+    const bool defer = lazy && small_window && n_lev_used > 1 && !is_multi(c);
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) { c->plan_done[l].store(0); c->lev_wait[l] = 0; }
     {   auto tp0 = std::chrono::steady_clock::now();
         std::vector<char> seen(p->n_levels, 0);
@@ -529,7 +534,12 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         W.pst = nullptr; W.ppart = nullptr;
         if (c->pose_only) {
             size_t gmax = 1;
-            for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) gmax = std::max(gmax, (size_t)pose_grid(c->lev[l]));
+            for (int l = 0; l < p->n_levels; l++) {
+                if (c->lev_built[l]) gmax = std::max(gmax, (size_t)pose_grid(c->lev[l]));
+                else if (c->lev_planned[l]) {                // a level staged later (deferred): its grid is bounded by what the level can hold
+                    size_t npf = 0;
+                    if (p->tfeat_off[l]) for (int q = 0; q < p->n_tobs; q++) { const int j = p->tobs_text[q]; npf += (size_t)(p->tfeat_off[l][j + 1] - p->tfeat_off[l][j]); }
+                    gmax = std::max(gmax, ((size_t)p->n_sobs[l] + 255)/256 + (npf + 31)/32 + 1); } }
             AL(W.pst, 2); AL(W.ppart, 3*28*gmax);
         } }
     for (int b = 0; b < 2; b++) {
@@ -649,7 +659,10 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     AL(c->cov_log, 6*TSBA_MAX_LEVELS);
     flush_run(c);
     auto tu2 = std::chrono::steady_clock::now();
-    if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err(c, "upload sync failed"); return TSBA_ERR_DEVICE; }
+    // (a one-shot call goes straight on to the solve on the same stream: nothing touches the staged bytes before free_problem's synchronisation at the next upload)
+    c->upload_pending = false;
+    if (lazy && c->ev_upload && (!c->stage_p || c->copy_stream)) { if (c->stage_p) { hipEventRecord(c->ev_upload, c->stream); c->upload_pending = true; } }
+    else if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err(c, "upload sync failed"); return TSBA_ERR_DEVICE; }
     if (tdbg) { auto tu3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[tsba_upload] free %.2f ms, host total %.2f ms (waiting for the plan threads %.2f ms, image section %.2f ms), final sync %.2f ms\n", ms(tu0, tu1), ms(tu1, tu2), t_plan, t_img, ms(tu2, tu3)); }
     c->uploaded = true;
@@ -662,6 +675,7 @@ int tsba_upload(void *ctx, const tsba_problem *p, const tsba_options *o) { retur
 // One pyramid level onto the device: the plan's lists (its host thread is joined here), the level's reference features, the table of image planes.
 static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, double *t_img) {
     const tsba_options *o = &c->opt; int rc;
+    if (c->stage_async && c->copy_stream && c->upload_pending) { hipStreamWaitEvent(c->copy_stream, c->ev_upload, 0); c->upload_pending = false; }
     {   auto tp0 = std::chrono::steady_clock::now();            // in pass order: the coarse levels are ready first and are staged while level 0 is still being built
         if (l < (int)c->planners.size() && c->planners[l].joinable()) c->planners[l].join();
         if (t_plan) *t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); }
@@ -1360,8 +1374,10 @@ static void launch_step(Ctx *c, const LevelDev &D, bool decide_prev = false) {
     if (!fused_decide) launch_decide(c, D);
 }
 
+static int enqueue_pack(Ctx *c);
 int tsba_solve(void *ctx, tsba_report *r) {
     Ctx *c = (Ctx *)ctx; if (!c || !r) return TSBA_ERR_ARG;
+    if (c) c->packed = false;
     if (!c->uploaded) { set_err(c, "no problem uploaded"); return TSBA_ERR_STATE; }
     hipSetDevice(c->device);
     memset(r, 0, sizeof(*r));
@@ -1439,6 +1455,7 @@ int tsba_solve(void *ctx, tsba_report *r) {
             LAUNCHK(k_outlier, dim3((D.n_sc + 63)/64 + D.n_tg + 1), dim3(64), 0, c->stream, c->W, D, o.chi2_mono[ps], o.chi2_text[ps],
                                o.text_bad_ratio, o.outlier_scene, o.outlier_text, (const PoseState *)(c->W.pst + ((k_last + 1) & 1)));
             log_pending = true;                              // (kept by the next pass's k_pose_begin, or by k_solve_end)
+            rc = stage_ahead(c, ps); if (rc) return rc;      // (one-shot calls: the later passes' levels, over the copy stream while this pass runs)
             continue;
         }
         launch_linearize(c, D, 0);
@@ -1486,8 +1503,10 @@ int tsba_solve(void *ctx, tsba_report *r) {
     LAUNCHK(k_solve_end, dim3(1), dim3(64), 0, c->stream, c->W, c->st_log, o.n_passes, log_pending ? 1 : 0, c->st_host, (unsigned int *)(c->st_host + TSBA_MAX_LEVELS) + 8);
     int *pcg_host = (int *)(c->st_host + TSBA_MAX_LEVELS);          // (the pinned block has room for 8 ints behind the pass snapshots)
     if (c->far_B > 0) CK(hipMemcpyAsync(pcg_host, c->W.pc_stat, 8*sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (c->pack_in_solve) { rc = enqueue_pack(c); if (rc) return rc; }
     CK(hipStreamSynchronize(c->stream));
     CK(hipGetLastError());
+    c->packed = c->pack_in_solve;
     if (!c->err.empty() && c->err.rfind("ncclAllReduce", 0) == 0) return TSBA_ERR_COMM;
     auto t1 = std::chrono::steady_clock::now();
     r->t_solve_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -1535,12 +1554,11 @@ __global__ __launch_bounds__(256) void k_pack_results(Work W, DlLayout L, unsign
     for (size_t k = t; k < (size_t)n_to; k += nt) out[L.o_to + k] = W.tobs_good[k];
     for (size_t k = t; k < (size_t)n_tf; k += nt) out[L.o_tf + k] = W.tfgood[k];
 }
-int tsba_download(void *ctx, tsba_problem *p) {
-    Ctx *c = (Ctx *)ctx; if (!c || !p) return TSBA_ERR_ARG;
-    if (!c->uploaded) { set_err(c, "no problem uploaded"); return TSBA_ERR_STATE; }
-    hipSetDevice(c->device);
-    static_assert(sizeof(LmState) % 4 == 0, "LmState is copied as words");
-    const DlLayout L = dl_layout(c);
+// The one-shot entry points (round 6) pack the results INSIDE the solve, behind its last kernel and before its one synchronisation -- small blocks (a pose-only
+// call: 5 KB, a window: 60 KB) as the kernel's own stores into pinned host memory, larger ones through the device block and one copy: tsba_download then
+// only copies out of the pinned block (no launch, no second synchronisation: 0.06 ms of a 0.66 ms tsba_pose_optim call).
+#define TSBA_PACK_DIRECT_MAX ((size_t)256 << 10)
+static int dl_reserve(Ctx *c, const DlLayout &L) {
     if (L.total > c->dl_bytes) {
         CK(hipStreamSynchronize(c->stream));
         if (c->dl_dev) hipFree(c->dl_dev); if (c->dl_host) hipHostFree(c->dl_host);
@@ -1548,10 +1566,26 @@ int tsba_download(void *ctx, tsba_problem *p) {
         const size_t cap = L.total + L.total/4;
         CK(hipMalloc((void **)&c->dl_dev, cap)); CK(hipHostMalloc((void **)&c->dl_host, cap, hipHostMallocDefault)); c->dl_bytes = cap;
     }
+    return TSBA_OK;
+}
+static int enqueue_pack(Ctx *c) {                 // (no synchronisation: the caller's)
+    const DlLayout L = dl_layout(c);
+    int rc = dl_reserve(c, L); if (rc) return rc;
+    const bool direct = L.total <= TSBA_PACK_DIRECT_MAX;
     const size_t work = std::max<size_t>({7*(size_t)c->n_kf, (size_t)c->n_pt, 3*(size_t)c->n_text, (size_t)c->n_sgood, (size_t)c->n_tobs, (size_t)c->n_tfgood, 64});
-    LAUNCHK(k_pack_results, dim3((unsigned)std::min<size_t>(1024, (work + 255)/256)), dim3(256), 0, c->stream, c->W, L, c->dl_dev, c->n_kf, c->n_pt, c->n_text, c->n_sgood, c->n_tobs, c->n_tfgood);
-    CK(hipMemcpyAsync(c->dl_host, c->dl_dev, L.total, hipMemcpyDeviceToHost, c->stream));
-    CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
+    LAUNCHK(k_pack_results, dim3((unsigned)std::min<size_t>(direct ? 64 : 1024, (work + 255)/256)), dim3(256), 0, c->stream, c->W, L, direct ? c->dl_host : c->dl_dev, c->n_kf, c->n_pt, c->n_text, c->n_sgood, c->n_tobs, c->n_tfgood);
+    if (!direct) CK(hipMemcpyAsync(c->dl_host, c->dl_dev, L.total, hipMemcpyDeviceToHost, c->stream));
+    return TSBA_OK;
+}
+int tsba_download(void *ctx, tsba_problem *p) {
+    Ctx *c = (Ctx *)ctx; if (!c || !p) return TSBA_ERR_ARG;
+    if (!c->uploaded) { set_err(c, "no problem uploaded"); return TSBA_ERR_STATE; }
+    hipSetDevice(c->device);
+    static_assert(sizeof(LmState) % 4 == 0, "LmState is copied as words");
+    const DlLayout L = dl_layout(c);
+    if (c->packed) c->packed = false;             // (the solve that has just ended left the block in pinned memory)
+    else { int rc = enqueue_pack(c); if (rc) return rc;
+        CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError()); }
     memcpy(p->pose, c->dl_host + L.o_pose, sizeof(double)*7*(size_t)c->n_kf);
     if (c->n_pt) memcpy(p->rho, c->dl_host + L.o_rho, sizeof(double)*(size_t)c->n_pt);
     if (c->n_text) memcpy(p->theta, c->dl_host + L.o_theta, sizeof(double)*3*(size_t)c->n_text);
@@ -1565,7 +1599,9 @@ static int one_shot(void *ctx, tsba_problem *p, const tsba_options *o, tsba_repo
     auto t0 = std::chrono::steady_clock::now();
     int rc = upload_impl(ctx, p, o, true); if (rc) return rc;
     auto t1 = std::chrono::steady_clock::now();
+    ((Ctx *)ctx)->pack_in_solve = true;
     rc = tsba_solve(ctx, r);
+    ((Ctx *)ctx)->pack_in_solve = false;
     { Ctx *c = (Ctx *)ctx; join_planners(c); c->stage_p = nullptr;      // (*p is the caller's: nothing may be staged from it after this call)
       for (int l = 0; l < (int)c->lev_planned.size(); l++) if (c->lev_planned[l] && !c->lev_built[l]) c->uploaded = false; }   // a failed solve left a level unstaged: upload again before anything else
     if (rc) return rc;

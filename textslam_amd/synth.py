@@ -161,11 +161,20 @@ class _Plane:
 
 def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), max_targets=5, text_targets=5,
                  frozen_frac=0.1, outlier_frac=0.05, noise_px=0.5, perturb=True, n_levels=3,
-                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None, loop=False, loop_at=0, closures=0):
+                 band=None, far_frac=0.0, n_out=3, rot_deg=0.5, trans_m=0.02, lm_rel=0.05, self_obs=True, n_fixed=3, kf_initial=None, loop=False, loop_at=0, closures=0,
+                 drop_outlier_points=False, perturb_in_camera=False):
     """Build a synthetic window (local BA / pose-only / global BA depending on the arguments).
 
     n_kf == 1 with frozen_frac == 1 gives the pose-only problem (every landmark hosted outside).
     n_text == 0 skips image synthesis (global BA, scene points only, as the reference's GlobalBA).
+    drop_outlier_points: the map as the reference hands it to GlobalBA -- optimizer::GlobalBA takes map::GetAllMapPoints(false)
+    (src/optimizer.cc:337-341, src/map.cc:36-47: only points with FLAG_BAD == false) and every local BA has set FLAG_BAD on a point with ANY
+    observation it flagged (tracking::mpPtsCondUpdate, src/tracking.cc:2215-2230): every point with a gross-outlier observation or an
+    observation whose good flag is already down leaves the problem with all its observations (PyrGlobalBA skips them: IdxRho < 0,
+    optimizer.cc:1738-1743).  The random stream is the same with and without it.
+    perturb_in_camera: the pose perturbation as a motion of the CAMERA, T_cw' = (dR, dt) T_cw: the camera centre moves by ~trans_m wherever the keyframe is.  The
+    default perturbs R_cw and t_cw separately, which turns a camera 500 m from the origin around the ORIGIN (0.2 degrees = 1.7 m at keyframe 5000 against a
+    step of 0.1 m between keyframes): a start no loop correction would leave behind, and the reason the 5000-keyframe chains need hundreds of LM iterations.
     """
     rng = np.random.default_rng(seed)
     fx, fy, cx, cy = K_GENERAL_MOTION
@@ -208,6 +217,7 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
         R, t = cams[int(k)]
         Xw[m] = (Xh[m] - t) @ R          # X_w = R^T (X_c - t)
     per_kf = [[] for _ in range(n_kf)]    # (pt, u, v)
+    gross = np.zeros(n_pt, bool)          # points with a gross-outlier observation (what a local BA's outlier pass flags)
     order = np.arange(n_pt)
     for j in order:
         h = int(host[j])
@@ -239,6 +249,7 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
                 if rng.random() < outlier_frac:
                     nu += rng.choice([-1, 1]) * rng.uniform(8, 20)
                     nv += rng.choice([-1, 1]) * rng.uniform(8, 20)
+                    gross[j] = True
                 per_kf[int(k)].append((j, u + nu, v + nv))
                 got += 1
                 if got >= max_targets:
@@ -249,11 +260,19 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
     P.sgood = np.ones(int(kf_off[-1]), np.uint8)
     if P.sgood.size > 10:
         P.sgood[rng.integers(0, P.sgood.size, max(1, P.sgood.size // 100))] = 0
+    bad_pt = gross.copy()
+    if drop_outlier_points:
+        for k in range(n_kf):
+            for i, (j, u, v) in enumerate(per_kf[k]):
+                if not P.sgood[kf_off[k] + i]:
+                    bad_pt[j] = True
     for l in range(P.n_levels):
         kk, pp, ff, uv = [], [], [], []
         for k in range(n_kf):
             for i, (j, u, v) in enumerate(per_kf[k]):
                 if l > 0 and (i % (2 ** l)) != 0:      # coarser levels see a subset (tool::GetPyramidPts)
+                    continue
+                if drop_outlier_points and bad_pt[j]:  # FLAG_BAD points are not in GetAllMapPoints(false)
                     continue
                 kk.append(k); pp.append(j); ff.append(kf_off[k] + i); uv.append((u, v))
         P.sobs_kf[l], P.sobs_pt[l], P.sobs_flag[l] = np.array(kk, np.int32), np.array(pp, np.int32), np.array(ff, np.int32)
@@ -456,7 +475,7 @@ def make_problem(n_kf=20, n_pt=5000, n_text=100, seed=SEED, feats=(64, 24, 12), 
             dR = _rodrigues(np.deg2rad(rot_deg) * ax)
             pose[k, :4] = _R_to_q(dR @ Rcw[k])
             dv = rng.normal(size=3)
-            pose[k, 4:] = tcw[k] + trans_m * dv / np.linalg.norm(dv)
+            pose[k, 4:] = (dR @ tcw[k] if perturb_in_camera else tcw[k]) + trans_m * dv / np.linalg.norm(dv)
         movable = P.pt_host >= 0
         rho_i[movable] *= 1 + rng.uniform(-lm_rel, lm_rel, movable.sum())
         if n_text > 0:
@@ -485,11 +504,12 @@ def config_c4(seed=SEED):
     return make_problem(20, 5000, 100, seed)
 
 
-def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0, loop=False, loop_at=0, closures=0):
+def config_global(n_kf=500, n_pt=50000, seed=SEED, max_targets=8, band=12, far_frac=0.0, loop=False, loop_at=0, closures=0, drop_outlier_points=False, perturb_in_camera=False):
     """C5 / C6: scene-only global BA (the reference's GlobalBA ignores text, optimizer.cc:1707).  loop: closed trajectory (the map right
     after a loop closure: the co-visibility graph is a ring, not a band)."""
     return make_problem(n_kf, n_pt, 0, seed, max_targets=max_targets, frozen_frac=0.0, band=band, far_frac=far_frac,
-                        n_levels=1, rot_deg=0.2, trans_m=0.01, loop=loop, loop_at=loop_at, closures=closures)
+                        n_levels=1, rot_deg=0.2, trans_m=0.01, loop=loop, loop_at=loop_at, closures=closures,
+                        drop_outlier_points=drop_outlier_points, perturb_in_camera=perturb_in_camera)
 
 
 def tiny(seed=7, n_kf=5, n_pt=60, n_text=4, **kw):
