@@ -549,7 +549,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         AL(B.w_pt, PT_REC*mx_pslot); AL(B.vdb_pt, PT_VDB*(size_t)p->n_pt);
         AL(B.w_tx, TX_REC*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
         AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.bp_loc, W.N); AL(B.dgs_p, W.N);
-        AL(B.lmpart, 3*((size_t)c->nb_back_max + mx_pair/MID_TW + 4));      // (one partial per k_mid block: at most n_pt / 128 + n_text / 128 + pairs / 128 + 3, and nb_back_max >= n_pt / 64 + n_text / 16)
+        AL(B.lmpart, 3*((size_t)p->n_pt/64 + (size_t)p->n_text/(64/MID_PL) + mx_pair/(64/16) + 8));      // (one partial per k_mid block, at its smallest block size)      // (one partial per k_mid block: at most n_pt / 128 + n_text / 128 + pairs / 128 + 3, and nb_back_max >= n_pt / 64 + n_text / 16)
     }
     AL(W.sig_pt, p->n_pt); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.sig_p, W.N);
     AL(W.cb, 2*(size_t)W.N + 8); AL(W.cbm, 1);
@@ -686,7 +686,7 @@ static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, dou
     D.img_w = p->img_w[l]; D.img_h = p->img_h[l];
 #define UV(field) do { rc = dev_upload_vec(c, &D.field, H.field); if (rc) return rc; } while (0)
     UV(sc_obs); UV(sc_kf); UV(sc_pt); UV(sc_flag); UV(sc_slot); UV(sc_uv);
-    UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pt_pair4); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
+    UV(tg_rec); UV(tg_ppos); UV(pt_pose6); UV(pt_pair4); UV(tx_pair8); UV(pair_i); UV(pair_h); UV(pair_hpos); UV(pair_sc_off); UV(pair_tg_off); UV(pair_tg);
     UV(tg_tobs); UV(tg_kf); UV(tg_text); UV(tg_pair); UV(tg_slot);
     UV(pf_g); UV(pf_f); D.n_pf = (int)H.pf_g.size();
     if (!H.kf_order.empty()) UV(kf_order); else D.kf_order = nullptr;
@@ -850,9 +850,14 @@ static void launch_pass_init(Ctx *c, const LevelDev &D, int pass) {
 }
 // k_mid's blocks: 256 landmarks / pairs each.  tsba_debug_options.trial_launches = 1 / 2 (the k_lin_mid experiment and its comparison partner): 128 (MID_TW: what a
 // workgroup of the linearisation can take over)
-static int mid_threads(const Ctx *c) { return (c->dbg.trial_launches == 1 || c->dbg.trial_launches == 2) && c->n_kf <= SCHUR_KEEP_KF ? MID_TW : 256; }
+// Windows (round 6): ONE wave per block -- what bounds a block is the number of cache lines its gathers pull through its compute unit's vector cache (256 points x 5 slots
+// x (a 64-byte record + a 72-byte rotation) took ~10 k cycles on each of 20 compute units); 64-thread blocks put the same gathers on four times as many
+static int mid_threads(const Ctx *c) { return c->n_kf <= SCHUR_KEEP_KF ? ((c->dbg.trial_launches == 1 || c->dbg.trial_launches == 2) ? MID_TW : 64) : 256; }
+// (round 6: a plane has MID_PL = 8 lanes, one slot record each, a pair MID_PR = 4 lanes that share its text groups: the three kinds of block each end after
+// two dependent round trips instead of up to eight)
 static void mid_blocks(const Ctx *c, const LevelDev &D, int &nb_pt, int &nb_tx, int &nb_pr) { const int t = mid_threads(c);
-    nb_pt = (c->n_pt + t - 1)/t; nb_tx = (c->n_text + t - 1)/t; nb_pr = (D.n_pair + t - 1)/t; }
+    const int pr = t == 256 ? MID_PR_MIN : 16;
+    nb_pt = (c->n_pt + t - 1)/t; nb_tx = (c->n_text + t/MID_PL - 1)/(t/MID_PL); nb_pr = (D.n_pair + t/pr - 1)/(t/pr); }
 static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
 // pairs with a dozen scene blocks (large maps): four pairs per wave
 static bool lin_small_pairs(const Ctx *c, const LevelDev &D) { return !c->dbg.no_small_pairs && D.n_pair > 0 && (long long)D.n_sc <= 24LL*D.n_pair; }
@@ -874,8 +879,9 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
         else if (lin_small_pairs(c, D)) LAUNCHK((k_linearize<MODE_FULL, 4>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
         else LAUNCHK((k_linearize<MODE_FULL, 1>), dim3((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
     }
-    if (mid_threads(c) == MID_TW) LAUNCHK(k_mid<MID_TW>, dim3(nb_pt + nb_tx + nb_pr), dim3(MID_TW), 0, c->stream, W, D, nb_pt, nb_tx, spec);
-    else LAUNCHK(k_mid<256>, dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    if (mid_threads(c) == MID_TW) LAUNCHK((k_mid<MID_TW, 6, 16>), dim3(nb_pt + nb_tx + nb_pr), dim3(MID_TW), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    else if (mid_threads(c) == 64) LAUNCHK((k_mid<64, 6, 16>), dim3(nb_pt + nb_tx + nb_pr), dim3(64), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    else LAUNCHK((k_mid<256, 4, MID_PR_MIN>), dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
     const int npp = pose_parts(c);
     if (multi) {
@@ -1709,7 +1715,7 @@ static unsigned long long plan_checksum(const HostPlan &H) {           // over E
     auto mix = [&](const std::vector<int32_t> &v) { for (int32_t x : v) { h ^= (unsigned int)x; h *= 1099511628211ull; } h ^= v.size(); h *= 1099511628211ull; };
     mix(H.sb_a); mix(H.sb_b); mix(H.sb_pt_off); mix(H.sb_pt_s1); mix(H.sb_pt_s2); mix(H.sb_pt_lm); mix(H.sb_tx_off); mix(H.sb_tx_s1); mix(H.sb_tx_s2); mix(H.sb_tx_lm);
     for (const std::vector<int32_t> *v : { &H.kf_order, &H.sc_obs, &H.sc_kf, &H.sc_pt, &H.sc_flag, &H.sc_slot, &H.pair_i, &H.pair_h, &H.pair_hpos, &H.pair_sc_off, &H.pair_tg_off, &H.pair_tg,
-                                           &H.tg_tobs, &H.tg_kf, &H.tg_text, &H.tg_pair, &H.tg_slot, &H.pt_pose6, &H.pt_pair4, &H.tg_ppos, &H.pf_g, &H.pf_f, &H.tg_rec,
+                                           &H.tg_tobs, &H.tg_kf, &H.tg_text, &H.tg_pair, &H.tg_slot, &H.pt_pose6, &H.pt_pair4, &H.tx_pair8, &H.tg_ppos, &H.pf_g, &H.pf_f, &H.tg_rec,
                                            &H.pls_off, &H.pslot_pose, &H.pslot_pair, &H.pslot_lm, &H.tls_off, &H.tslot_pose, &H.tslot_pair, &H.tslot_lm, &H.sb_pab, &H.sb_pba,
                                            &H.pose_t_off, &H.pose_t, &H.pose_h_off, &H.pose_h, &H.pose_ps_off, &H.pose_ps, &H.pose_ps_lm, &H.pose_ts_off, &H.pose_ts, &H.pose_ts_lm }) mix(*v);
     if (H.far_B > 0) { h ^= (unsigned long long)H.far_B; h *= 1099511628211ull;

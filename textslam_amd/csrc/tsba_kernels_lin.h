@@ -648,43 +648,70 @@ __global__ __launch_bounds__(LIN_T, TEXT ? 2 : 3) void k_linearize(Work W, Level
 
 // ---- per landmark: V, b, host column of W (= -sum Q^T w);  per pair: host-side products.  256-thread blocks.
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
-// NT threads per block (256; windows: 128 -- MID_TW -- so that a block is what a workgroup of k_linearize can take over, k_lin_mid below): block b takes NT
-// points / planes / pairs and leaves one partial (gradient max, |x|^2, cost) in B.lmpart.  clear_next: the block also zeroes the next trial's failure flag.
-template <int NT>
+// NT threads per block (256; windows of the k_lin_mid experiment: 128 -- MID_TW -- so that a block is what a workgroup of k_linearize can take over): block b takes
+// NT points / NT/8 planes / NT/4 pairs and leaves one partial (gradient max, |x|^2, cost) in B.lmpart.  clear_next: the block also zeroes the next trial's failure flag.
+// Round 6 (stamps: tools/mid_stamps.sh, docs/ledger_r06.md): the kernel was the sum of its dependent round trips -- a point with more than four observers took
+// three after its offsets (records | the fifth slot's pair | its record), a plane six (pair, record: two slots at a time), a pair one per text group -- 21.8 k
+// cycles for the pair blocks, 20.4 k for the plane blocks, 16.1 k for the point blocks of C4.  Now every kind has TWO: the static offsets (with the LM state),
+// then everything else at once -- U = 6 slot records of a point in flight (windows; maps keep 4: there the kernel is a throughput kernel and registers are
+// occupancy), a plane on MID_PL = 8 lanes with one slot record each, a pair on MID_PR = 4 lanes that share its text groups; the lanes' sums meet by xor shuffles
+// (a fixed order), the block's three partials in one reduction.
+#define MID_PL 8
+#define MID_PR_MIN 4
+#define PT_PAIRN 6                          // entries of L.pt_pair4 per point
+// MID_PR lanes per pair: 16 on windows (C4: ~90 pairs at a level with up to ~20 text groups each -- the groups are the round trips), 4 on maps
+template <int NT, int U, int MID_PR>
 __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, const int nb_pt, const int nb_tx, const int spec, const int b, const bool clear_next, double *red /* [NT] */) {
+    static_assert(U <= PT_PAIRN && NT % 64 == 0, "k_mid: the static pair list holds PT_PAIRN entries per point");
     const LmState *st = W.st;
+#ifdef MID_STAMPS                           // (make-time experiment, tools/mid_stamps.sh: cycles a block of each kind spends in the kernel, summed over blocks and launches into W.dbg)
+    const long long ms_t0 = clock64(); const int ms_kind = b < nb_pt ? 0 : b < nb_pt + nb_tx ? 1 : 2;
+#define MID_STAMP(slot) do { if (threadIdx.x == 0 && spec) atomicAdd((unsigned long long *)&W.dbg[16 + 8*ms_kind + (slot)], (unsigned long long)(clock64() - ms_t0)); } while (0)
+#else
+#define MID_STAMP(slot) do { } while (0)
+#endif
+    const int tid = threadIdx.x;
     // static offsets of this thread's landmark / pair first: in flight together with the LM state
-    int o = 0, e = 0, tq0 = 0, tq1 = 0, ph_ = -1, hp_ = -1, act_ = 0, pr0[MID_U] = {0, 0, 0, 0};
-    if (b < nb_pt) { const int j = b*NT + threadIdx.x; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j];
+    int o = 0, e = 0, tq0 = 0, tq1 = 0, ph_ = -1, hp_ = -1, act_ = 0, pr0[U], prt = 0;
+    double sg0 = 1.0, sgt[3] = {1.0, 1.0, 1.0};             // the Jacobi scales as they are (a first linearisation replaces them below)
 #pragma unroll
-        for (int u = 0; u < MID_U; u++) pr0[u] = L.pt_pair4[MID_U*(size_t)j + u]; } }
-    else if (b < nb_pt + nb_tx) { const int j = (b - nb_pt)*NT + threadIdx.x; if (j < W.n_text) { o = L.tls_off[j]; e = L.tls_off[j+1]; act_ = W.act_tx[j]; } }
-    else { const int p = (b - nb_pt - nb_tx)*NT + threadIdx.x; if (p < L.n_pair) { tq0 = L.pair_tg_off[p]; tq1 = L.pair_tg_off[p+1]; ph_ = L.pair_h[p]; hp_ = L.pair_hpos[p]; } }
-    if (clear_next && W.st_next && b == 0 && threadIdx.x == 0) W.st_next->step_fail = 0;      // (the next trial's k_schur_t takes this trial's decision into that copy of the state, every field but this one: its own workgroups may raise it)
+    for (int u = 0; u < U; u++) pr0[u] = 0;
+    const int jt = (b - nb_pt)*(NT/MID_PL) + (tid >> 3), ut = tid & (MID_PL - 1);            // plane blocks: plane, lane
+    const int pp = (b - nb_pt - nb_tx)*(NT/MID_PR) + tid/MID_PR, up = tid & (MID_PR - 1);    // pair blocks: pair, lane
+    if (b < nb_pt) { const int j = b*NT + tid; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j]; sg0 = W.sig_pt[j];
+#pragma unroll
+        for (int u = 0; u < U; u++) pr0[u] = L.pt_pair4[PT_PAIRN*(size_t)j + u]; } }
+    else if (b < nb_pt + nb_tx) { if (jt < W.n_text) { o = L.tls_off[jt]; e = L.tls_off[jt+1]; act_ = W.act_tx[jt]; prt = L.tx_pair8[MID_PL*(size_t)jt + ut];
+#pragma unroll
+        for (int k = 0; k < 3; k++) sgt[k] = W.sig_tx[(size_t)k*W.n_text + jt]; } }
+    else { if (pp < L.n_pair) { tq0 = L.pair_tg_off[pp]; tq1 = L.pair_tg_off[pp+1]; ph_ = L.pair_h[pp]; hp_ = L.pair_hpos[pp]; } }
+    if (clear_next && W.st_next && b == 0 && tid == 0) W.st_next->step_fail = 0;      // (the next trial's k_schur_t takes this trial's decision into that copy of the state, every field but this one: its own workgroups may raise it)
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
     const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
     const int sel = spec ? (st->cur ^ 1) : st->cur;
     const double *rho_x = W.rho[sel], *theta_x = W.theta[sel];
+    const bool first = st->first != 0;
     double gm = 0.0, xn = 0.0, cs = 0.0;                        // cs: cost of this thread's pair and of its text groups
+    MID_STAMP(0);                                               // (the state and the static offsets are here)
     if (b < nb_pt) {
-        const int j = b*NT + threadIdx.x;
+        const int j = b*NT + tid;
         if (e > o) {
             double acc[8] = {0,0,0,0,0,0,0,0};                       // V, b, host column -sum Q^T w
-            for (int s0 = o; s0 < e - 1; s0 += MID_U) {              // MID_U slot records (and their pairs' R_cr) in flight per round trip
-                int pr[MID_U]; double v[MID_U][8], R[MID_U][9];
+            for (int s0 = o; s0 < e - 1; s0 += U) {                  // U slot records (and their pairs' R_cr) in flight per round trip
+                int pr[U]; double v[U][8], R[U][9];
 #pragma unroll
-                for (int u = 0; u < MID_U; u++) pr[u] = s0 == o ? pr0[u] : L.pslot_pair[min(s0 + u, e - 2)];
+                for (int u = 0; u < U; u++) pr[u] = s0 == o ? pr0[u] : L.pslot_pair[min(s0 + u, e - 2)];
 #pragma unroll
-                for (int u = 0; u < MID_U; u++) {
+                for (int u = 0; u < U; u++) {
 #pragma unroll
                     for (int k = 0; k < 8; k++) v[u][k] = B.w_pt[(size_t)(min(s0 + u, e - 2))*PT_REC + k];
 #pragma unroll
                     for (int k = 0; k < 9; k++) R[u][k] = PAIRR(B, pr[u], k, L.n_pair);
                 }
 #pragma unroll
-                for (int u = 0; u < MID_U; u++) if (s0 + u < e - 1) {
+                for (int u = 0; u < U; u++) if (s0 + u < e - 1) {
                     double qa[3], qc[3]; mat3T_vec(R[u], v[u], qa); mat3T_vec(R[u], v[u] + 3, qc);
                     acc[0] += v[u][6]; acc[1] += v[u][7];
 #pragma unroll
@@ -694,82 +721,107 @@ __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, cons
 #pragma unroll
             for (int k = 0; k < 6; k++) B.w_pt[(size_t)(e - 1)*PT_REC + k] = acc[2 + k];
             const double V = acc[0];
-            if (st->first) W.sig_pt[j] = 1.0/(1.0 + sqrt(V));
-            const double sg = W.sig_pt[j];
+            double sg = sg0;
+            if (first) { sg = 1.0/(1.0 + sqrt(V)); W.sig_pt[j] = sg; }
             VDB_STORE(B, j, W.n_pt, V, clampd(sg*sg*V, W.min_diag, W.max_diag)/(sg*sg), acc[1]);
             if (act_) { gm = fabs(acc[1]); xn = rho_x[j]*rho_x[j]; }
         }
     } else if (b < nb_pt + nb_tx) {
-        const int j = (b - nb_pt)*NT + threadIdx.x;
-        if (e > o) {
-            double acc[27];                                          // V6, b3, host column -blkdiag(R,R)^T W (18)
+        const int j = jt;
+        if (e > o) {                                                  // (uniform over a plane's eight lanes)
+            double acc[27];                                          // V6, b3, host column -blkdiag(R,R)^T W (18): this lane's slots
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = 0.0;
-            for (int s0 = o; s0 < e - 1; s0 += 2) {                  // 2 slot records in flight per round trip
-                int pr[2]; double v[2][27], R[2][9];
+            for (int s0 = o; s0 < e - 1; s0 += MID_PL) {             // one slot record per lane and round trip (a plane seen from more than eight keyframes goes round again)
+                const int sc = min(s0 + ut, e - 2);
+                const int pr = s0 == o ? prt : L.tslot_pair[sc];
+                double v[27], R[9];
 #pragma unroll
-                for (int u = 0; u < 2; u++) pr[u] = L.tslot_pair[min(s0 + u, e - 2)];
+                for (int k = 0; k < 27; k++) v[k] = B.w_tx[(size_t)sc*TX_REC + k];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int k = 0; k < 9; k++) R[k] = PAIRR(B, pr, k, L.n_pair);
+                if (s0 + ut < e - 1) {
 #pragma unroll
-                    for (int k = 0; k < 27; k++) v[u][k] = B.w_tx[(size_t)(min(s0 + u, e - 2))*TX_REC + k];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) R[u][k] = PAIRR(B, pr[u], k, L.n_pair);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; u++) if (s0 + u < e - 1) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) acc[k] += v[u][18 + k];
+                    for (int k = 0; k < 9; k++) acc[k] += v[18 + k];
 #pragma unroll
                     for (int half = 0; half < 2; half++)
 #pragma unroll
                         for (int rr = 0; rr < 3; rr++)
 #pragma unroll
                             for (int cc = 0; cc < 3; cc++)
-                                acc[9 + (half*3 + rr)*3 + cc] += -(R[u][0*3 + rr]*v[u][(half*3 + 0)*3 + cc] + R[u][1*3 + rr]*v[u][(half*3 + 1)*3 + cc] + R[u][2*3 + rr]*v[u][(half*3 + 2)*3 + cc]);
+                                acc[9 + (half*3 + rr)*3 + cc] += -(R[0*3 + rr]*v[(half*3 + 0)*3 + cc] + R[1*3 + rr]*v[(half*3 + 1)*3 + cc] + R[2*3 + rr]*v[(half*3 + 2)*3 + cc]);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 18; k++) B.w_tx[(size_t)(e - 1)*TX_REC + k] = acc[9 + k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) B.V_tx[(size_t)k*W.n_text + j] = acc[k];
-#pragma unroll
-            for (int k = 0; k < 3; k++) B.b_tx[(size_t)k*W.n_text + j] = acc[6 + k];
-            const double dv[3] = { acc[0], acc[3], acc[5] };
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (st->first) W.sig_tx[(size_t)k*W.n_text + j] = 1.0/(1.0 + sqrt(dv[k]));
-                const double sg = W.sig_tx[(size_t)k*W.n_text + j];
-                B.dgs_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag)/(sg*sg);
+            for (int k = 0; k < 27; k++) {                           // the eight lanes' sums (lanes 8 q .. 8 q + 7 of a wave), fixed order
+                acc[k] += __shfl_xor(acc[k], 1, 64); acc[k] += __shfl_xor(acc[k], 2, 64); acc[k] += __shfl_xor(acc[k], 4, 64);
             }
-            if (act_) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(acc[6 + k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
+            if (ut == 0) {
+#pragma unroll
+                for (int k = 0; k < 18; k++) B.w_tx[(size_t)(e - 1)*TX_REC + k] = acc[9 + k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) B.V_tx[(size_t)k*W.n_text + j] = acc[k];
+#pragma unroll
+                for (int k = 0; k < 3; k++) B.b_tx[(size_t)k*W.n_text + j] = acc[6 + k];
+                const double dv[3] = { acc[0], acc[3], acc[5] };
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double sg = sgt[k];
+                    if (first) { sg = 1.0/(1.0 + sqrt(dv[k])); W.sig_tx[(size_t)k*W.n_text + j] = sg; }
+                    B.dgs_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag)/(sg*sg);
+                }
+                if (act_) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(acc[6 + k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
+            }
         }
     } else {
-        const int p = (b - nb_pt - nb_tx)*NT + threadIdx.x;
+        const int p = pp;
         if (p < L.n_pair) {
-            double M[21], c[6];
+            double M[27];                                            // M (21) | c (6): lane 0 starts from the scene blocks' sums, every lane adds its share of the pair's text groups
+            double R[9];
+            // every load of the pair issued before the first use (a load under a lane-dependent branch is waited for at the end of that branch: the scene sums,
+            // the rotation and each text group were a round trip each): the four lanes read the same scene sums and rotation, masked afterwards; a lane's first
+            // two text groups (clamped, masked) ride along -- a pair with more than eight text groups goes round again
+            const int ntg = L.n_tg, q1 = tq0 + up, q2 = q1 + MID_PR;
+            double m0[27], g1[27], g2[27], c0, c1 = 0.0, c2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < 21; k++) M[k] = B.pairM[(size_t)k*L.n_pair + p];
+            for (int k = 0; k < 27; k++) m0[k] = B.pairM[(size_t)k*L.n_pair + p];
+            c0 = B.pairCost[p];
 #pragma unroll
-            for (int k = 0; k < 6; k++) c[k] = B.pairM[(size_t)(21 + k)*L.n_pair + p];
-            cs = B.pairCost[p];
-            for (int q = tq0; q < tq1; q++) {          // (stored in pair-major order by k_linearize)
+            for (int k = 0; k < 9; k++) R[k] = PAIRR(B, p, k, L.n_pair);
+            if (ntg > 0) {                                           // (uniform)
+                const int q1c = min(q1, ntg - 1), q2c = min(q2, ntg - 1);
 #pragma unroll
-                for (int k = 0; k < 21; k++) M[k] += B.tgM[(size_t)k*L.n_tg + q];
+                for (int k = 0; k < 27; k++) { g1[k] = B.tgM[(size_t)k*ntg + q1c]; g2[k] = B.tgM[(size_t)k*ntg + q2c]; }
+                c1 = B.tgCost[q1c]; c2 = B.tgCost[q2c];
+            } else {
 #pragma unroll
-                for (int k = 0; k < 6; k++) c[k] += B.tgM[(size_t)(21 + k)*L.n_tg + q];
+                for (int k = 0; k < 27; k++) { g1[k] = 0.0; g2[k] = 0.0; }
+            }
+            const bool h1 = q1 < tq1, h2 = q2 < tq1;
+#pragma unroll
+            for (int k = 0; k < 27; k++) M[k] = ((up == 0 ? m0[k] : 0.0) + (h1 ? g1[k] : 0.0)) + (h2 ? g2[k] : 0.0);
+            MID_STAMP(3);
+            cs = ((up == 0 ? c0 : 0.0) + (h1 ? c1 : 0.0)) + (h2 ? c2 : 0.0);
+            for (int q = q2 + MID_PR; q < tq1; q += MID_PR) {
+#pragma unroll
+                for (int k = 0; k < 27; k++) M[k] += B.tgM[(size_t)k*ntg + q];
                 cs += B.tgCost[q];
             }
-            double *out = B.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) by pair | QMQ(21) Qc(6) by host-major rank
 #pragma unroll
-            for (int k = 0; k < 21; k++) out[(size_t)k*L.n_pair + p] = M[k];
+            for (int k = 0; k < 27; k++)
 #pragma unroll
-            for (int k = 0; k < 6; k++) out[(size_t)(21 + k)*L.n_pair + p] = c[k];
+                for (int of = 1; of < MID_PR; of <<= 1) M[k] += __shfl_xor(M[k], of, 64);      // all lanes of the pair hold its sums
+            double cs_pair = cs;
+#pragma unroll
+            for (int of = 1; of < MID_PR; of <<= 1) cs_pair += __shfl_xor(cs_pair, of, 64);
+            cs = up == 0 ? cs_pair : 0.0;                       // (counted once per pair)
+            MID_STAMP(4);
+            const double *c = M + 21;
+            double *out = B.pairOut;      // [90][n_pair]: M(21) c(6) MQ(36) by pair | QMQ(21) Qc(6) by host-major rank.  Every lane forms everything; lane u stores entries k = u mod MID_PR
+#pragma unroll
+            for (int k = 0; k < 27; k++) if ((k & (MID_PR - 1)) == up) out[(size_t)k*L.n_pair + p] = M[k];
             if (ph_ >= 0) {
                 const int hp = hp_;                        // rows 63..89 are stored host-major
-                double R[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) R[k] = PAIRR(B, p, k, L.n_pair);
                 double Mf[36];
 #pragma unroll
                 for (int r = 0; r < 6; r++)
@@ -784,31 +836,44 @@ __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, cons
                         for (int cc = 0; cc < 3; cc++)
                             MQ[r*6 + half*3 + cc] = Mf[r*6 + half*3]*R[cc] + Mf[r*6 + half*3 + 1]*R[3 + cc] + Mf[r*6 + half*3 + 2]*R[6 + cc];
 #pragma unroll
-                for (int k = 0; k < 36; k++) out[(size_t)(27 + k)*L.n_pair + p] = MQ[k];
+                for (int k = 0; k < 36; k++) if ((k & (MID_PR - 1)) == up) out[(size_t)(27 + k)*L.n_pair + p] = MQ[k];
 #pragma unroll
                 for (int r = 0; r < 6; r++)
 #pragma unroll
                     for (int cc = r; cc < 6; cc++) {
                         const int hr = r/3, rr = r % 3;
                         double v = R[0*3 + rr]*MQ[(hr*3 + 0)*6 + cc] + R[1*3 + rr]*MQ[(hr*3 + 1)*6 + cc] + R[2*3 + rr]*MQ[(hr*3 + 2)*6 + cc];
-                        out[(size_t)(63 + sym6(r, cc))*L.n_pair + hp] = v;
+                        if ((sym6(r, cc) & (MID_PR - 1)) == up) out[(size_t)(63 + sym6(r, cc))*L.n_pair + hp] = v;
                     }
+                MID_STAMP(5);
                 double a[3], d[3]; mat3T_vec(R, c, a); mat3T_vec(R, c + 3, d);
-                out[(size_t)84*L.n_pair + hp] = a[0]; out[(size_t)85*L.n_pair + hp] = a[1]; out[(size_t)86*L.n_pair + hp] = a[2];
-                out[(size_t)87*L.n_pair + hp] = d[0]; out[(size_t)88*L.n_pair + hp] = d[1]; out[(size_t)89*L.n_pair + hp] = d[2];
+                if (up == MID_PR - 1) { out[(size_t)84*L.n_pair + hp] = a[0]; out[(size_t)85*L.n_pair + hp] = a[1]; out[(size_t)86*L.n_pair + hp] = a[2]; }
+                if (up == MID_PR - 2) { out[(size_t)87*L.n_pair + hp] = d[0]; out[(size_t)88*L.n_pair + hp] = d[1]; out[(size_t)89*L.n_pair + hp] = d[2]; }
             }
         }
     }
-    gm = block_max<NT>(gm, red); xn = block_sum<NT>(xn, red);
-    if (b >= nb_pt + nb_tx) cs = block_sum<NT>(cs, red);       // (uniform) the cost as per-block partials: k_postlin / k_decide add a few hundred
-                                                                // numbers instead of walking 40 k pairs at 5000 keyframes (50 us of one workgroup)
-    if (threadIdx.x == 0) { B.lmpart[3*b] = gm; B.lmpart[3*b + 1] = xn; B.lmpart[3*b + 2] = cs; }
+    MID_STAMP(1);                                               // (this thread's records summed and stored)
+    // the block's partials in ONE reduction: waves by shuffles, the NT / 64 waves' results through LDS, fixed order (the cost as per-block partials: k_postlin /
+    // k_decide add a few hundred numbers instead of walking 40 k pairs at 5000 keyframes)
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) { gm = fmax(gm, __shfl_xor(gm, of, 64)); xn += __shfl_xor(xn, of, 64); cs += __shfl_xor(cs, of, 64); }
+    if ((tid & 63) == 0) { red[3*(tid >> 6)] = gm; red[3*(tid >> 6) + 1] = xn; red[3*(tid >> 6) + 2] = cs; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < NT/64; w++) { gm = fmax(gm, red[3*w]); xn += red[3*w + 1]; cs += red[3*w + 2]; }
+        B.lmpart[3*b] = gm; B.lmpart[3*b + 1] = xn; B.lmpart[3*b + 2] = cs;
+    }
+    MID_STAMP(2);
+#ifdef MID_STAMPS
+    if (tid == 0 && spec) atomicAdd((unsigned long long *)&W.dbg[16 + 8*ms_kind + 7], 1ull);      // blocks counted
+#endif
 }
 #define MID_TW 128
-template <int NT>
+template <int NT, int U, int PR>
 __global__ __launch_bounds__(NT) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int spec) {
     __shared__ double red[NT];
-    mid_block<NT>(W, L, nb_pt, nb_tx, spec, (int)blockIdx.x, true, red);
+    mid_block<NT, U, PR>(W, L, nb_pt, nb_tx, spec, (int)blockIdx.x, true, red);
 }
 
 // ---- windows: the speculative linearisation of an LM trial and k_mid in ONE launch.  k_mid as a launch of its own was 10.6 us per trial on C4: a launch, the
@@ -838,7 +903,7 @@ __global__ __launch_bounds__(LIN_T, 2) void k_lin_mid(Work W, LevelDev L, int nb
     }
     __syncthreads();
     __threadfence();                                            // (the other workgroups' records)
-    for (long long b = first; b < nb_lm; b += m) { mid_block<MID_TW>(W, L, nb_pt, nb_tx, 1, (int)b, false, red); __syncthreads(); }
+    for (long long b = first; b < nb_lm; b += m) { mid_block<MID_TW, 6, 16>(W, L, nb_pt, nb_tx, 1, (int)b, false, red); __syncthreads(); }
 }
 
 // ---- after a linearisation (256 threads of one block), in two stages so that a multi-GPU run can all-reduce in between:

@@ -77,7 +77,8 @@ struct HostPlan {
     // text groups
     std::vector<int32_t> tg_tobs, tg_kf, tg_text, tg_pair, tg_slot;
     std::vector<int32_t> pt_pose6;      // poses of the first 6 slots of every point (clamped): k_back needs them one round trip earlier
-    std::vector<int32_t> pt_pair4;      // pairs of the first 4 observer slots of every point (clamped): k_mid fetches their R_cr together with the slot records
+    std::vector<int32_t> pt_pair4;      // pairs of the first PT_PAIRN (6) observer slots of every point (clamped): k_mid fetches their R_cr together with the slot records
+    std::vector<int32_t> tx_pair8;      // pairs of the first 8 observer slots of every plane (clamped): k_mid gives a plane eight lanes, one slot record each
     std::vector<int32_t> tg_ppos;       // rank of the group in pair-major order (pair_tg is the inverse): k_mid sums contiguous ranges
     std::vector<int32_t> pf_g, pf_f;    // single-keyframe problems (pose-only path): flat list of (group, feature) over all groups
     std::vector<int32_t> tg_rec;        // per group, one 32-byte record: tobs, kf, text, host, slot, f0, f1, fgood offset (all static)
@@ -102,7 +103,7 @@ struct HostPlan {
     void recycle() {
         level = 0; bw_pose = 0; ring = 0; ring_k0 = 0; far_B = 0;
         for (std::vector<int32_t> *v : { &wb_kf, &wb_idx, &far_a, &far_b, &far_off, &far_ent, &fb_id, &fb_pab, &fb_pba, &fb_pt_off, &fb_pt_s1, &fb_pt_s2, &fb_pt_lm, &fb_tx_off, &fb_tx_s1, &fb_tx_s2, &fb_tx_lm, &kf_order, &sc_obs, &sc_kf, &sc_pt, &sc_flag, &sc_slot, &pair_i, &pair_h, &pair_hpos, &pair_sc_off, &pair_tg_off, &pair_tg,
-                                         &tg_tobs, &tg_kf, &tg_text, &tg_pair, &tg_slot, &pt_pose6, &pt_pair4, &tg_ppos, &pf_g, &pf_f, &tg_rec,
+                                         &tg_tobs, &tg_kf, &tg_text, &tg_pair, &tg_slot, &pt_pose6, &pt_pair4, &tx_pair8, &tg_ppos, &pf_g, &pf_f, &tg_rec,
                                          &pls_off, &pslot_pose, &pslot_pair, &pslot_lm, &tls_off, &tslot_pose, &tslot_pair, &tslot_lm,
                                          &sb_a, &sb_b, &sb_pab, &sb_pba, &sb_pt_off, &sb_pt_s1, &sb_pt_s2, &sb_pt_lm, &sb_tx_off, &sb_tx_s1, &sb_tx_s2, &sb_tx_lm,
                                          &pose_t_off, &pose_t, &pose_h_off, &pose_h, &pose_ps_off, &pose_ps, &pose_ps_lm, &pose_ts_off, &pose_ts, &pose_ts_lm }) v->clear();
@@ -488,11 +489,14 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         std::vector<int> cur(off.begin(), off.end() - 1);
         for (auto &it : items) val[cur[it.first]++] = it.second;
     };
-    P.pt_pose6.resize(6*(size_t)n_pt); P.pt_pair4.resize(4*(size_t)n_pt);
+    P.pt_pose6.resize(6*(size_t)n_pt); P.pt_pair4.resize(6*(size_t)n_pt);
     pool.run([&](int t) { size_t j0, j1; pool.range((size_t)n_pt, t, j0, j1);
         for (size_t j = j0; j < j1; j++) { const int o = P.pls_off[j], e = P.pls_off[j+1];       // observer slots [o, e-1), host slot e-1
             for (int u = 0; u < 6; u++) P.pt_pose6[6*j + u] = e > o ? P.pslot_pose[std::min(o + u, e - 1)] : 0;
-            for (int u = 0; u < 4; u++) P.pt_pair4[4*j + u] = e - 1 > o ? P.pslot_pair[std::min(o + u, e - 2)] : 0; } });
+            for (int u = 0; u < 6; u++) P.pt_pair4[6*j + u] = e - 1 > o ? P.pslot_pair[std::min(o + u, e - 2)] : 0; } });
+    P.tx_pair8.resize(8*P.tls_off.size() > 8 ? 8*(P.tls_off.size() - 1) : 0);
+    for (size_t j = 0; j + 1 < P.tls_off.size(); j++) { const int o = P.tls_off[j], e = P.tls_off[j+1];
+        for (int u = 0; u < 8; u++) P.tx_pair8[8*j + u] = e - 1 > o ? P.tslot_pair[std::min(o + u, e - 2)] : 0; }
     P.tg_ppos.assign(n_tg, 0);
     for (size_t k = 0; k < P.pair_tg.size(); k++) P.tg_ppos[P.pair_tg[k]] = (int)k;
     P.tg_rec.resize(8*(size_t)n_tg);

@@ -1,0 +1,21 @@
+"""GPU diagnostic (not a pytest; needs the -DMID_STAMPS build copied over textslam_amd/libtsba.so, tools/mid_stamps.sh): cycles the blocks of k_mid spend per kind."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from textslam_amd import synth, abi
+from textslam_amd.optimizer import Optimizer
+opt = Optimizer(0)
+P = synth.config_c4(); o = abi.options_local()
+opt.upload(P, o)
+for k in range(5): rep = opt.solve()
+v = (C.c_longlong*64)()
+opt.lib.tsba_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+assert opt.lib.tsba_debug_stamps(opt.ctx, v) == 0
+v = np.array(list(v), dtype=np.int64)
+print("k_mid (speculative launches of 5 C4 solves; level mix 2,1,0), mean cycles per block from its start, by kind:")
+for kind, name in enumerate(("point blocks", "plane blocks", "pair blocks")):
+    s = v[16 + 8*kind: 24 + 8*kind]; n = max(int(s[7]), 1)
+    print("  %-13s blocks %6d   state + offsets there %7.0f   records summed and stored %7.0f   end (after the block reductions) %7.0f" % (name, n, s[0]/n, s[1]/n, s[2]/n))
+s = v[32:40]; n = max(int(s[7]), 1)
+print("  pair blocks in detail: loads there %7.0f   lanes' sums met %7.0f   products formed and stored (host pairs) %7.0f" % (s[3]/n, s[4]/n, s[5]/n))
+print("(clock64 at 100 MHz on gfx950? compare with the kernel's 10.4 us)")
