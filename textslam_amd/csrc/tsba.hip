@@ -549,7 +549,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         AL(B.w_pt, PT_REC*mx_pslot); AL(B.vdb_pt, PT_VDB*(size_t)p->n_pt);
         AL(B.w_tx, TX_REC*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
         AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.bp_loc, W.N); AL(B.dgs_p, W.N);
-        AL(B.lmpart, 3*((size_t)p->n_pt/64 + (size_t)p->n_text/(64/MID_PL) + mx_pair/(64/16) + 8));      // (one partial per k_mid block, at its smallest block size)      // (one partial per k_mid block: at most n_pt / 128 + n_text / 128 + pairs / 128 + 3, and nb_back_max >= n_pt / 64 + n_text / 16)
+        AL(B.lmpart, 3*((size_t)p->n_pt/64 + (size_t)p->n_text/(64/MID_PL) + mx_pair/(64/MID_PR_MIN) + 8));      // (one partial per k_mid block, at its smallest block size)      // (one partial per k_mid block: at most n_pt / 128 + n_text / 128 + pairs / 128 + 3, and nb_back_max >= n_pt / 64 + n_text / 16)
     }
     AL(W.sig_pt, p->n_pt); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.sig_p, W.N);
     AL(W.cb, 2*(size_t)W.N + 8); AL(W.cbm, 1);
@@ -856,7 +856,7 @@ static int mid_threads(const Ctx *c) { return c->n_kf <= SCHUR_KEEP_KF ? ((c->db
 // (round 6: a plane has MID_PL = 8 lanes, one slot record each, a pair MID_PR = 4 lanes that share its text groups: the three kinds of block each end after
 // two dependent round trips instead of up to eight)
 static void mid_blocks(const Ctx *c, const LevelDev &D, int &nb_pt, int &nb_tx, int &nb_pr) { const int t = mid_threads(c);
-    const int pr = t == 256 ? MID_PR_MIN : 16;
+    const int pr = MID_PR_MIN;
     nb_pt = (c->n_pt + t - 1)/t; nb_tx = (c->n_text + t/MID_PL - 1)/(t/MID_PL); nb_pr = (D.n_pair + t/pr - 1)/(t/pr); }
 static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
 // pairs with a dozen scene blocks (large maps): four pairs per wave
@@ -879,8 +879,8 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
         else if (lin_small_pairs(c, D)) LAUNCHK((k_linearize<MODE_FULL, 4>), dim3((((D.n_pair + 4*LIN_NWV - 1)/(4*LIN_NWV) + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
         else LAUNCHK((k_linearize<MODE_FULL, 1>), dim3((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8), dim3(LIN_T), 0, c->stream, W, D, spec);
     }
-    if (mid_threads(c) == MID_TW) LAUNCHK((k_mid<MID_TW, 6, 16>), dim3(nb_pt + nb_tx + nb_pr), dim3(MID_TW), 0, c->stream, W, D, nb_pt, nb_tx, spec);
-    else if (mid_threads(c) == 64) LAUNCHK((k_mid<64, 6, 16>), dim3(nb_pt + nb_tx + nb_pr), dim3(64), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    if (mid_threads(c) == MID_TW) LAUNCHK((k_mid<MID_TW, 6, MID_PR_MIN>), dim3(nb_pt + nb_tx + nb_pr), dim3(MID_TW), 0, c->stream, W, D, nb_pt, nb_tx, spec);
+    else if (mid_threads(c) == 64) LAUNCHK((k_mid<64, 6, MID_PR_MIN>), dim3(nb_pt + nb_tx + nb_pr), dim3(64), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     else LAUNCHK((k_mid<256, 4, MID_PR_MIN>), dim3(nb_pt + nb_tx + nb_pr), dim3(256), 0, c->stream, W, D, nb_pt, nb_tx, spec);
     const int multi = is_multi(c);
     const int npp = pose_parts(c);

@@ -659,7 +659,8 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 #define MID_PL 8
 #define MID_PR_MIN 4
 #define PT_PAIRN 6                          // entries of L.pt_pair4 per point
-// MID_PR lanes per pair: 16 on windows (C4: ~90 pairs at a level with up to ~20 text groups each -- the groups are the round trips), 4 on maps
+// MID_PR lanes per pair (4.  16 was measured on C4 -- ~90 pairs at a level, up to ~20 text groups each --: 8.65 against 7.63 us: two more shuffle steps over 27 values and
+// stores predicated sixteen ways cost a lone wave more than the group loop's extra round trip; tools/mid_stamps.sh)
 template <int NT, int U, int MID_PR>
 __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, const int nb_pt, const int nb_tx, const int spec, const int b, const bool clear_next, double *red /* [NT] */) {
     static_assert(U <= PT_PAIRN && NT % 64 == 0, "k_mid: the static pair list holds PT_PAIRN entries per point");
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(LIN_T, 2) void k_lin_mid(Work W, LevelDev L, int nb
     }
     __syncthreads();
     __threadfence();                                            // (the other workgroups' records)
-    for (long long b = first; b < nb_lm; b += m) { mid_block<MID_TW, 6, 16>(W, L, nb_pt, nb_tx, 1, (int)b, false, red); __syncthreads(); }
+    for (long long b = first; b < nb_lm; b += m) { mid_block<MID_TW, 6, MID_PR_MIN>(W, L, nb_pt, nb_tx, 1, (int)b, false, red); __syncthreads(); }
 }
 
 // ---- after a linearisation (256 threads of one block), in two stages so that a multi-GPU run can all-reduce in between:
