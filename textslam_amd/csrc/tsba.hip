@@ -699,7 +699,7 @@ static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, dou
     if (H.far_B > 0) { UV(far_a); UV(far_b); UV(far_off); UV(far_ent); UV(fb_id); UV(fb_pab); UV(fb_pba); UV(fb_pt_off); UV(fb_pt_s1); UV(fb_pt_s2); UV(fb_pt_lm);
         UV(fb_tx_off); UV(fb_tx_s1); UV(fb_tx_s2); UV(fb_tx_lm); }
     UV(pls_off); UV(pslot_pose); UV(pslot_pair); UV(pslot_lm); UV(tls_off); UV(tslot_pose); UV(tslot_pair); UV(tslot_lm);
-    UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
+    UV(sb_a); UV(sb_b); UV(sb_pab); UV(sb_pba); UV(sb_rng); UV(sb_tx_off); UV(sb_tx_s1); UV(sb_tx_s2); UV(sb_tx_lm);
     int *dp_off = nullptr, *dp_s1 = nullptr, *dp_s2 = nullptr, *dp_lm = nullptr; const int32_t *dp_cl = nullptr;
     if (H.dev_pt_pairs >= 0) {                                     // large maps: the point slot pairs by block are built on the device (tsba_devplan.h)
         rc = dev_alloc(c, &dp_off, (size_t)D.n_sb + 2); if (rc) return rc;

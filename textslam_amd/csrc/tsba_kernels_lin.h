@@ -956,8 +956,10 @@ __device__ void pose_scale(const Work &W, const LinBuf &B, const double *sHd, co
 //   out5 = { max |gradient|, |x|^2, cost, step^2 (nb_back partials), model cost change (nb_back partials) }   (thread 0)
 // write: this workgroup stores the poses' diagonal / gradient / damping rows (every workgroup of a launch that takes the decision redundantly computes
 // them; one stores); keep (may be null): [2][6 n_kf] in LDS, the damping rows and the gradient rows for the caller's own use
+// light (round 6): only the partials of cost / step / model cost change -- what the accept / reject decision and the trust region are made of; the poses' sums
+// (gradient max and |x|^2: the tolerance exits, kept by the one workgroup that runs the full version) are skipped and out5[0], out5[1] are not meaningful
 __device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B, const double *pose, bool first, int nb_lm, int nb_back,
-                              double *red /*[5*256]*/, double *xch /*[252]*/, double out5[5], int npp = 0, bool write = true, double *keep = nullptr) {
+                              double *red /*[5*256]*/, double *xch /*[252]*/, double out5[5], int npp = 0, bool write = true, double *keep = nullptr, bool light = false) {
     const int tid = threadIdx.x;
     double gmax = 0.0, xn = 0.0, cost = 0.0, step2 = 0.0, mcc = 0.0;
 #ifdef TSBA_SOLVE_STAMPS
@@ -988,7 +990,7 @@ __device__ void postlin_fused(const Work &W, const LevelDev &L, const LinBuf &B,
     const double *out = B.pairOut; const size_t np = L.n_pair;
     // (large maps: k_pose_sums did the per-pose work on many workgroups; only its partials are left to add)
     for (int k = tid; k < npp; k += 256) { gmax = fmax(gmax, W.posepart[2*k]); xn += W.posepart[2*k + 1]; }
-    for (int a0 = 0; a0 < (npp > 0 ? 0 : W.n_kf); a0 += 21) {
+    for (int a0 = 0; a0 < (npp > 0 || light ? 0 : W.n_kf); a0 += 21) {
         const int al = tid/12, k = tid - 12*al, a = a0 + al;
         const bool on = tid < 252 && a < W.n_kf;
         const int ac = min(a, W.n_kf - 1);

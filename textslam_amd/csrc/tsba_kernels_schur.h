@@ -26,21 +26,71 @@ __device__ __forceinline__ void lm_state_store(LmState *n, const LmState &s) {  
 template <int SCHUR_NW>
 __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int multi, int b0, SchurDec dec) {
     constexpr int SCHUR_T = 64*SCHUR_NW;
+#ifdef MID_STAMPS                           // (make-time experiment, tools/mid_stamps.sh: cycles of a workgroup by kind -- diagonal S block, off-diagonal S block, gradient -- into W.dbg[40..63])
+    const long long ss_t0 = clock64(); int ss_kind = 2;
+#define SCHUR_STAMP(slot) do { if (threadIdx.x == 0) atomicAdd((unsigned long long *)&W.dbg[40 + 8*ss_kind + (slot)], (unsigned long long)(clock64() - ss_t0)); } while (0)
+#else
+#define SCHUR_STAMP(slot) do { } while (0)
+#endif
+    // Round 6 (stamps, tools/mid_stamps.sh: a diagonal block's workgroup spent 18 k cycles on the decision and then walked NINE dependent round trips -- block ->
+    // offsets / rows -> slot-pair indices -> records, the same again for the planes' slot pairs, offsets -> ranges for the tail): everything that does not depend
+    // on the decision (the static lists of the plan, the rows of the free poses) is requested BEFORE it -- the block's own entries with the LM state, what hangs
+    // off them with the decision's first loads -- and is there when the decision is.
+    struct Pre { int a, c, ia, ic, pt0, pt1, tx0, tx1, pab, pba, t0, t1, h0, h1, ps0, ps1, ts0, ts1; int s1[2*SCHUR_U], s2[2*SCHUR_U], j[2*SCHUR_U], xs1, xs2, xj; } pre;      // (two rounds of a diagonal block's slot pairs: ~1100 entries on 256 threads)
+    constexpr bool PRE = SCHUR_NW == 4;
+    const int pre_kind = !PRE || b0 != 0 ? 0 : ((int)blockIdx.x < L.n_sb ? 1 : ((int)blockIdx.x - L.n_sb < W.n_kf ? 2 : 0));
+    if constexpr (PRE) {
+        const int b = (int)blockIdx.x;                             // (windows: b0 == 0, no XCD remapping)
+        if (pre_kind == 1) {
+            pre.a = L.sb_a[b]; pre.c = L.sb_b[b]; pre.pt0 = L.sb_pt_off[b]; pre.pt1 = L.sb_pt_off[b+1]; pre.tx0 = L.sb_tx_off[b]; pre.tx1 = L.sb_tx_off[b+1];
+            pre.pab = L.sb_pab[b]; pre.pba = L.sb_pba[b];
+            pre.t0 = L.sb_rng[4*b]; pre.t1 = L.sb_rng[4*b + 1]; pre.h0 = L.sb_rng[4*b + 2]; pre.h1 = L.sb_rng[4*b + 3];
+        } else if (pre_kind == 2) {
+            pre.a = b - L.n_sb; pre.ia = W.fidx[pre.a];
+            pre.ps0 = L.pose_ps_off[pre.a]; pre.ps1 = L.pose_ps_off[pre.a+1]; pre.ts0 = L.pose_ts_off[pre.a]; pre.ts1 = L.pose_ts_off[pre.a+1];
+            pre.t0 = L.pose_t_off[pre.a]; pre.t1 = L.pose_t_off[pre.a+1]; pre.h0 = L.pose_h_off[pre.a]; pre.h1 = L.pose_h_off[pre.a+1];
+        }
+    }
     LmState *st = W.st;
     if (st->done) {                                             // (a finished pass: the launches the host still had in flight -- the other copy of the state has to say so too)
         if (SCHUR_NW == 4 && dec.on && blockIdx.x == 0 && threadIdx.x == 0) { const LmState s = *st; lm_state_store(W.st_next, s); }
         return; }
     __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
-    __shared__ double keep[SCHUR_NW == 4 ? 2*6*SCHUR_KEEP_KF : 1]; __shared__ double dsh_r; __shared__ int dsh_i[3];      // (keep: damping | gradient rows of up to SCHUR_KEEP_KF poses -- the host enables `dec` only for windows of at most that many)
+    __shared__ double dsh_r; __shared__ int dsh_i[3];
     int lcur_ = st->lcur; double radius_ = st->radius; bool fresh = false;      // fresh: the current linearisation is the candidate this launch has just accepted
+    if constexpr (PRE) {                                            // (second stage: in flight together with the decision's first loads)
+        const int tid = threadIdx.x;
+        if (pre_kind == 1) {
+            pre.ia = W.fidx[pre.a]; pre.ic = W.fidx[pre.c];
+#pragma unroll
+            for (int u = 0; u < 2*SCHUR_U; u++) { const int qc = max(min(pre.pt0 + u*SCHUR_T + tid, pre.pt1 - 1), 0);
+                pre.s1[u] = L.sb_pt_s1[qc]; pre.s2[u] = L.sb_pt_s2[qc]; pre.j[u] = L.sb_pt_lm[qc]; }
+            { const int qc = max(min(pre.tx0 + tid, pre.tx1 - 1), 0); pre.xs1 = L.sb_tx_s1[qc]; pre.xs2 = L.sb_tx_s2[qc]; pre.xj = L.sb_tx_lm[qc]; }
+        } else if (pre_kind == 2) {
+#pragma unroll
+            for (int u = 0; u < 2*SCHUR_U; u++) { const int qc = max(min(pre.ps0 + u*SCHUR_T + tid, pre.ps1 - 1), 0); pre.s1[u] = L.pose_ps[qc]; pre.j[u] = L.pose_ps_lm[qc]; }
+            { const int qc = max(min(pre.ts0 + tid, pre.ts1 - 1), 0); pre.xs1 = L.pose_ts[qc]; pre.xj = L.pose_ts_lm[qc]; }
+        }
+    }
+    const bool use_pre = PRE && b0 == 0;
     if constexpr (SCHUR_NW == 4) if (dec.on) {
+        // Round 6: workgroup 0 takes the FULL decision (and stores the state, the poses' rows, the trace); every other workgroup takes it from the partials of
+        // cost / step / model cost change alone -- the same sums in the same order, so accept / reject, the trust region and the buffer that becomes current
+        // come out the same bits; what it skips (the poses' gradient max and |x|^2 over 75 KB of pair products that 230 workgroups were all pulling through the
+        // L2 at once: 18 - 24 k cycles of a 38 k-cycle kernel, tools/mid_stamps.sh) only decides the gradient-tolerance exit, which workgroup 0 keeps -- a
+        // workgroup that misses it assembles a block nobody reads.  The rows a workgroup needs of the accepted candidate (its pose's damping / gradient) it
+        // forms itself from the ranges it reads anyway, with the arithmetic of postlin_fused.
         double o5[5];
-        postlin_fused(W, L, W.lb[lcur_ ^ 1], W.pose[st->cur ^ 1], false, dec.nb_lm, dec.nb_back, lds, lds + 5*256, o5, 0, blockIdx.x == 0, keep);
+        const bool full = blockIdx.x == 0;
+        // (Measured and dropped: the block's tail -- pose-pair products / gradient row -- formed for BOTH outcomes before the decision, in flight with its partials.
+        // A diagonal block's 36 lanes read 36 different rows of the pair products with every request: 2 x 48 requests x 36 cache lines through one compute
+        // unit's vector cache cost 9 k cycles in front of the decision against the 4.5 k they take behind the gather: 15.9 against 14.0 us.)
+        postlin_fused(W, L, W.lb[lcur_ ^ 1], W.pose[st->cur ^ 1], false, dec.nb_lm, dec.nb_back, lds, lds + 5*256, o5, 0, full, nullptr, !full);
         if (blockIdx.x == 0 && W.dp_poll) for (int k = threadIdx.x; k <= W.N; k += SCHUR_T) W.dp[k] = __builtin_nan("");     // (k_solve_back: "not there yet")
         if (threadIdx.x == 0) {
             LmState s = *st;
             s.lin_done = 0;
-            const double verdict = lm_decide(s, o5[2], o5[3], o5[4], o5[0], o5[1], dec.o);
+            const double verdict = lm_decide(s, o5[2], o5[3], o5[4], full ? o5[0] : __builtin_inf(), full ? o5[1] : 0.0, dec.o);      // (no gradient-tolerance exit from the light decision)
             dsh_i[0] = s.done; dsh_i[1] = s.lcur; dsh_i[2] = s.lcur != lcur_; dsh_r = s.radius;
             if (blockIdx.x == 0) {                               // the new state, every field but step_fail (zero since k_mid of the last trial; the workgroups of this launch may raise it)
                 lm_state_store(W.st_next, s);
@@ -57,23 +107,29 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
     // to each other, one per observing pose, and neighbouring poses observe the same landmarks)
     const int bx = b0 > 0 ? ((int)blockIdx.x & 7)*((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int b = bx + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MID_STAMPS
+    ss_kind = b < L.n_sb ? (L.sb_a[b] == L.sb_b[b] ? 0 : 1) : 2;
+#endif
+    SCHUR_STAMP(0);                                             // (the decision on the previous trial is taken)
     const double radius = radius_, irad = 1.0/radius;
     const LinBuf &B = W.lb[lcur_];
     if (b < L.n_sb) {
-        const int a = L.sb_a[b], c = L.sb_b[b];
-        const int ia = W.fidx[a], ic = W.fidx[c];           // rows / columns of S exist for free poses only
+        const int a = use_pre ? pre.a : L.sb_a[b], c = use_pre ? pre.c : L.sb_b[b];
+        const int ia = use_pre ? pre.ia : W.fidx[a], ic = use_pre ? pre.ic : W.fidx[c];           // rows / columns of S exist for free poses only
         if (ia < 0 || ic < 0) return;
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
-        const int pt0 = L.sb_pt_off[b], pt1 = L.sb_pt_off[b+1];
+        const int pt0 = use_pre ? pre.pt0 : L.sb_pt_off[b], pt1 = use_pre ? pre.pt1 : L.sb_pt_off[b+1];
         for (int base = pt0; base < pt1; base += SCHUR_T*SCHUR_U) {
             int s1[SCHUR_U], s2[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
 #pragma unroll
             for (int u = 0; u < SCHUR_U; u++) {
                 const int q = base + u*SCHUR_T + tid; ok[u] = q < pt1;
                 const int qc = min(q, pt1 - 1);
-                s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc];
+                if (use_pre && base == pt0) { s1[u] = pre.s1[u]; s2[u] = pre.s2[u]; j[u] = pre.j[u]; }
+                else if (use_pre && base == pt0 + SCHUR_T*SCHUR_U) { s1[u] = pre.s1[SCHUR_U + u]; s2[u] = pre.s2[SCHUR_U + u]; j[u] = pre.j[SCHUR_U + u]; }
+                else { s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc]; }
             }
             double w1[SCHUR_U][6], w2[SCHUR_U][6], Vv[SCHUR_U], dg[SCHUR_U];
 #pragma unroll
@@ -93,8 +149,10 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
                 }
             }
         }
-        for (int q = L.sb_tx_off[b] + tid; q < L.sb_tx_off[b+1]; q += SCHUR_T) {
-            const int s1 = L.sb_tx_s1[q], s2 = L.sb_tx_s2[q], j = L.sb_tx_lm[q];
+        const int tx0 = use_pre ? pre.tx0 : L.sb_tx_off[b], tx1 = use_pre ? pre.tx1 : L.sb_tx_off[b+1];
+        for (int q = tx0 + tid; q < tx1; q += SCHUR_T) {
+            const bool fq = use_pre && q == tx0 + tid;
+            const int s1 = fq ? pre.xs1 : L.sb_tx_s1[q], s2 = fq ? pre.xs2 : L.sb_tx_s2[q], j = fq ? pre.xj : L.sb_tx_lm[q];
             double Vd[6], Vi[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
@@ -112,6 +170,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
                 for (int cc = 0; cc < 6; cc++) acc[r*6 + cc] += t0*W2[cc*3] + t1*W2[cc*3+1] + t2*W2[cc*3+2];
             }
         }
+        SCHUR_STAMP(1);                                         // (the slot pairs gathered and multiplied)
         // operands of the tail, independent of the sums: issued before the reduction
         double tail = 0.0;
         if (wave == 0 && lane < 36) {
@@ -119,10 +178,13 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             const double *out = B.pairOut;
             if (a == c) {
                 const double *rt = out + (size_t)sym6(r, cc)*L.n_pair, *rh = out + (size_t)(63 + sym6(r, cc))*L.n_pair;
-                tail = range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
-                if (r == cc && !multi) tail += (SCHUR_NW == 4 && fresh ? keep[6*a + r] : B.dgs_p[6*a + r])*irad;      // multi-GPU: added once after the all-reduce
+                const double sgd = r == cc ? W.sig_p[6*a + r] : 1.0, dgm = r == cc ? B.dgs_p[6*a + r] : 0.0;      // (requested with the ranges)
+                tail = use_pre ? range_sum<24>(rt, pre.t0, pre.t1) + range_sum<24>(rh, pre.h0, pre.h1)
+                               : range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
+                // the damping of a candidate this launch has just accepted: postlin_fused's expression on this block's own diagonal sums (workgroup 0 stores the same values for the launches to come)
+                if (r == cc && !multi) tail += (SCHUR_NW == 4 && fresh ? clampd(sgd*sgd*tail, W.min_diag, W.max_diag)/(sgd*sgd) : dgm)*irad;      // multi-GPU: added once after the all-reduce
             } else {
-                int pab = L.sb_pab[b], pba = L.sb_pba[b];
+                int pab = use_pre ? pre.pab : L.sb_pab[b], pba = use_pre ? pre.pba : L.sb_pba[b];
                 if (pab >= 0) tail -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
                 if (pba >= 0) tail -= out[(size_t)(27 + cc*6 + r)*L.n_pair + pba];        // -(M Q)^T     target c, host a
             }
@@ -145,6 +207,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         }
         __syncthreads();
         if (wave > 0) return;
+        SCHUR_STAMP(2);                                         // (tail operands there, the four waves' sums met)
         double tot = 0.0;
         if (lane < 36) {
             const double *row = lds + lane*65;
@@ -168,20 +231,26 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             if (a != c && (!W.band || !a_later)) W.S[(size_t)(6*jc + cc)*ldS + 6*ja + r] = v;
             }
         }
+        SCHUR_STAMP(3);
+#ifdef MID_STAMPS
+        if (threadIdx.x == 0) atomicAdd((unsigned long long *)&W.dbg[40 + 8*ss_kind + 7], 1ull);
+#endif
     } else {
         const int a = b - L.n_sb;
         if (a >= W.n_kf) return;                               // (the gradient-only grid is rounded up to a multiple of 8)
-        const int ia = W.fidx[a];
+        const int ia = use_pre ? pre.ia : W.fidx[a];
         if (ia < 0) return;
         double acc[6] = {0,0,0,0,0,0};
-        const int ps0 = L.pose_ps_off[a], ps1 = L.pose_ps_off[a+1];
+        const int ps0 = use_pre ? pre.ps0 : L.pose_ps_off[a], ps1 = use_pre ? pre.ps1 : L.pose_ps_off[a+1];
         for (int base = ps0; base < ps1; base += SCHUR_T*SCHUR_U) {
             int s[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
 #pragma unroll
             for (int u = 0; u < SCHUR_U; u++) {
                 const int q = base + u*SCHUR_T + tid; ok[u] = q < ps1;
                 const int qc = min(q, ps1 - 1);
-                s[u] = L.pose_ps[qc]; j[u] = L.pose_ps_lm[qc];
+                if (use_pre && base == ps0) { s[u] = pre.s1[u]; j[u] = pre.j[u]; }
+                else if (use_pre && base == ps0 + SCHUR_T*SCHUR_U) { s[u] = pre.s1[SCHUR_U + u]; j[u] = pre.j[SCHUR_U + u]; }
+                else { s[u] = L.pose_ps[qc]; j[u] = L.pose_ps_lm[qc]; }
             }
             double w[SCHUR_U][6], bb[SCHUR_U], Vv[SCHUR_U], dg[SCHUR_U];
 #pragma unroll
@@ -197,8 +266,10 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
                 for (int k = 0; k < 6; k++) acc[k] += w[u][k]*f;
             }
         }
-        for (int q = L.pose_ts_off[a] + tid; q < L.pose_ts_off[a+1]; q += SCHUR_T) {
-            const int s = L.pose_ts[q], j = L.pose_ts_lm[q];
+        const int ts0 = use_pre ? pre.ts0 : L.pose_ts_off[a], ts1 = use_pre ? pre.ts1 : L.pose_ts_off[a+1];
+        for (int q = ts0 + tid; q < ts1; q += SCHUR_T) {
+            const bool fq = use_pre && q == ts0 + tid;
+            const int s = fq ? pre.xs1 : L.pose_ts[q], j = fq ? pre.xj : L.pose_ts_lm[q];
             double Vd[6], Vi[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) Vd[k] = B.V_tx[(size_t)k*W.n_text + j];
@@ -210,7 +281,14 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             for (int k = 0; k < 6; k++)
                 acc[k] += B.w_tx[(size_t)(s)*TX_REC + (k*3)]*f0 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 1)]*f1 + B.w_tx[(size_t)(s)*TX_REC + (k*3 + 2)]*f2;
         }
-        const double bpv = tid < 6 ? (multi ? B.bp_loc[6*a + tid] : (SCHUR_NW == 4 && fresh ? keep[6*W.n_kf + 6*a + tid] : B.bp[6*a + tid])) : 0.0;
+        double bpv = 0.0;
+        if (tid < 6) {
+            if (multi) bpv = B.bp_loc[6*a + tid];
+            else if (SCHUR_NW == 4 && fresh) {              // the gradient row of a candidate this launch has just accepted: postlin_fused's sums for this pose
+                const double *out = B.pairOut; const size_t np = L.n_pair;
+                bpv = range_sum<24>(out + (size_t)(21 + tid)*np, L.pose_t_off[a], L.pose_t_off[a+1]) - range_sum<24>(out + (size_t)(84 + tid)*np, L.pose_h_off[a], L.pose_h_off[a+1]);
+            } else bpv = B.bp[6*a + tid];
+        }
 #pragma unroll
         for (int k = 0; k < 6; k++) acc[k] = wave_sum1(acc[k]);
         if (lane == 0) {
@@ -219,6 +297,10 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         }
         __syncthreads();
         if (tid < 6) W.g[6*ia + tid] = bpv - (SCHUR_NW > 1 ? (((lds[tid] + lds[6 + tid]) + lds[12 + tid]) + lds[18 + tid]) : lds[tid]);
+        SCHUR_STAMP(3);
+#ifdef MID_STAMPS
+        if (threadIdx.x == 0) atomicAdd((unsigned long long *)&W.dbg[40 + 8*ss_kind + 7], 1ull);
+#endif
     }
 }
 

@@ -87,6 +87,7 @@ struct HostPlan {
     std::vector<int32_t> tls_off, tslot_pose, tslot_pair, tslot_lm;     // text planes
     // reduced-system blocks
     std::vector<int32_t> sb_a, sb_b, sb_pab, sb_pba;
+    std::vector<int32_t> sb_rng;       // per block, four entries: a diagonal block's ranges of pair products (pose_t_off[a], pose_t_off[a+1], pose_h_off[a], pose_h_off[a+1]) -- k_schur_t requests them with the block itself
     std::vector<int32_t> sb_pt_off, sb_pt_s1, sb_pt_s2, sb_pt_lm, sb_tx_off, sb_tx_s1, sb_tx_s2, sb_tx_lm;
     // per pose: pairs where it is target / host; slots it owns
     std::vector<int32_t> pose_t_off, pose_t, pose_h_off, pose_h;
@@ -105,7 +106,7 @@ struct HostPlan {
         for (std::vector<int32_t> *v : { &wb_kf, &wb_idx, &far_a, &far_b, &far_off, &far_ent, &fb_id, &fb_pab, &fb_pba, &fb_pt_off, &fb_pt_s1, &fb_pt_s2, &fb_pt_lm, &fb_tx_off, &fb_tx_s1, &fb_tx_s2, &fb_tx_lm, &kf_order, &sc_obs, &sc_kf, &sc_pt, &sc_flag, &sc_slot, &pair_i, &pair_h, &pair_hpos, &pair_sc_off, &pair_tg_off, &pair_tg,
                                          &tg_tobs, &tg_kf, &tg_text, &tg_pair, &tg_slot, &pt_pose6, &pt_pair4, &tx_pair8, &tg_ppos, &pf_g, &pf_f, &tg_rec,
                                          &pls_off, &pslot_pose, &pslot_pair, &pslot_lm, &tls_off, &tslot_pose, &tslot_pair, &tslot_lm,
-                                         &sb_a, &sb_b, &sb_pab, &sb_pba, &sb_pt_off, &sb_pt_s1, &sb_pt_s2, &sb_pt_lm, &sb_tx_off, &sb_tx_s1, &sb_tx_s2, &sb_tx_lm,
+                                         &sb_a, &sb_b, &sb_pab, &sb_pba, &sb_rng, &sb_pt_off, &sb_pt_s1, &sb_pt_s2, &sb_pt_lm, &sb_tx_off, &sb_tx_s1, &sb_tx_s2, &sb_tx_lm,
                                          &pose_t_off, &pose_t, &pose_h_off, &pose_h, &pose_ps_off, &pose_ps, &pose_ps_lm, &pose_ts_off, &pose_ts, &pose_ts_lm }) v->clear();
         sc_uv.clear(); dev_pt_pairs = -1; cl_pt_dev.clear();
     }
@@ -707,6 +708,9 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     // sums of both kinds read contiguous ranges
     P.pair_hpos.assign(n_pair, -1);
     for (size_t k = 0; k < P.pose_h.size(); k++) P.pair_hpos[P.pose_h[k]] = (int)k;
+    P.sb_rng.assign(4*(size_t)P.n_sb(), 0);
+    for (int b = 0; b < P.n_sb(); b++) if (P.sb_a[b] == P.sb_b[b]) { const int a = P.sb_a[b];
+        P.sb_rng[4*b] = P.pose_t_off[a]; P.sb_rng[4*b + 1] = P.pose_t_off[a+1]; P.sb_rng[4*b + 2] = P.pose_h_off[a]; P.sb_rng[4*b + 3] = P.pose_h_off[a+1]; }
     csr(n_kf, it_ts, P.pose_ts_off, P.pose_ts);
     P.pose_ts_lm.resize(P.pose_ts.size());
     for (size_t k = 0; k < P.pose_ts.size(); k++) P.pose_ts_lm[k] = P.tslot_lm[P.pose_ts[k]];

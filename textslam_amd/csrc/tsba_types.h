@@ -22,6 +22,7 @@ struct LevelDev {            // device copies of HostPlan + per-level inputs
     const int *pair_i, *pair_h, *pair_hpos, *pair_sc_off, *pair_tg_off, *pair_tg;
     const int *tg_tobs, *tg_kf, *tg_text, *tg_pair, *tg_slot, *tg_rec, *tg_ppos, *pt_pose6, *pt_pair4, *tx_pair8;      // pt_pair4: PT_PAIRN (6) entries per point
     const int *pls_off, *pslot_pose, *pslot_pair, *pslot_lm, *tls_off, *tslot_pose, *tslot_pair, *tslot_lm;
+    const int *sb_rng;       // [n_sb][4]: a diagonal block's (pose_t_off[a], pose_t_off[a+1], pose_h_off[a], pose_h_off[a+1])
     const int *sb_a, *sb_b, *sb_pab, *sb_pba, *sb_pt_off, *sb_pt_s1, *sb_pt_s2, *sb_pt_lm, *sb_tx_off, *sb_tx_s1, *sb_tx_s2, *sb_tx_lm;
     const int *pose_t_off, *pose_t, *pose_h_off, *pose_h, *pose_ps_off, *pose_ps, *pose_ps_lm, *pose_ts_off, *pose_ts, *pose_ts_lm;
     const int *tfeat_off, *tfeat_raw; const double *tfeat_uv, *tfeat_ref;
