@@ -377,7 +377,7 @@ CONVERGED_FLOOR = {"c6_open_chain": dict(K9=26, K6=27, Kdec=28, rel_cost=4e-3), 
 # constant keyframes (optimizer.cc:405-406), so the parameters are compared directly -- no similarity alignment.
 HANDED_OVER = {
     "c6_open_chain_handed_over": dict(n_kf=5000, n_pt=105000, band=10, drop_outlier_points=True, perturb_in_camera=True),
-    "c6_long_range_handed_over": dict(n_kf=5000, n_pt=105000, band=10, far_frac=0.01, drop_outlier_points=True, perturb_in_camera=True),
+    "c6_long_range_handed_over": dict(n_kf=2000, n_pt=42000, band=10, far_frac=0.01, drop_outlier_points=True, perturb_in_camera=True),      # (2000 keyframes: where the oracle's system has an exact -- dense -- solve; make_converged.py)
 }
 SURVEY_8D_CONVERGED = 1e-6
 

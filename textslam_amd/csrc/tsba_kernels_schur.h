@@ -57,6 +57,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         return; }
     __shared__ double lds[SCHUR_NW > 1 ? 3*36*64 : 36*65];     // waves 1..3 hand their partial blocks to wave 0, which then transposes (36*65 <= 3*36*64)
     __shared__ double dsh_r; __shared__ int dsh_i[3];
+    __shared__ double tls[SCHUR_NW == 4 ? 21*65 : 1];          // a diagonal block's tail: the 21 distinct entries x (target range | host range), see below
     int lcur_ = st->lcur; double radius_ = st->radius; bool fresh = false;      // fresh: the current linearisation is the candidate this launch has just accepted
     if constexpr (PRE) {                                            // (second stage: in flight together with the decision's first loads)
         const int tid = threadIdx.x;
@@ -121,6 +122,28 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
 #pragma unroll
         for (int k = 0; k < 36; k++) acc[k] = 0.0;
         const int pt0 = use_pre ? pre.pt0 : L.sb_pt_off[b], pt1 = use_pre ? pre.pt1 : L.sb_pt_off[b+1];
+        // Round 6: the TAIL's operands are requested here, in flight with the gather, laid out so that a request touches a few cache lines instead of 36: a
+        // diagonal block's 36 lanes used to read 36 different rows of the pair products with every one of 48 requests (1700 line accesses through one
+        // vector cache, 4.5 k cycles behind the gather).  Now lane q of waves 1 - 3 reads element q of the pose's target range (lanes 0 - 31) or host range
+        // (32 - 63) of seven of the 21 distinct rows each -- contiguous: 2 + 2 lines per request --, the values cross through LDS, and lane (r, c) of wave 0
+        // adds its row up in index order: the same sums in the same order as range_sum<24>(target) + range_sum<24>(host).
+        bool tq = false; double tl[7] = {0,0,0,0,0,0,0}, tsg = 1.0, tdg = 0.0, to0 = 0.0, to1 = 0.0; bool t_on = false;
+        if constexpr (SCHUR_NW == 4) if (use_pre && pre.t1 - pre.t0 <= 32 && pre.h1 - pre.h0 <= 32) {      // (uniform: windows of at most 32 keyframes)
+            tq = true;
+            const double *out = B.pairOut;
+            if (a == c) {
+                if (wave > 0) {
+                    const bool ht = lane < 32; const int pos = ht ? lane : lane - 32;
+                    t_on = ht ? pos < pre.t1 - pre.t0 : pos < pre.h1 - pre.h0;
+                    const size_t q = t_on ? (size_t)((ht ? pre.t0 : pre.h0) + pos) : 0;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) tl[i] = out[(size_t)((ht ? 0 : 63) + 7*(wave - 1) + i)*L.n_pair + q];
+                } else if (lane < 36 && lane/6 == lane % 6) { tsg = W.sig_p[6*a + lane/6]; tdg = B.dgs_p[6*a + lane/6]; }
+            } else if (wave == 0 && lane < 36) {
+                const int r = lane/6, cc = lane % 6;
+                to0 = out[(size_t)(27 + r*6 + cc)*L.n_pair + max(pre.pab, 0)]; to1 = out[(size_t)(27 + cc*6 + r)*L.n_pair + max(pre.pba, 0)];
+            }
+        }
         for (int base = pt0; base < pt1; base += SCHUR_T*SCHUR_U) {
             int s1[SCHUR_U], s2[SCHUR_U], j[SCHUR_U]; bool ok[SCHUR_U];
 #pragma unroll
@@ -132,11 +155,31 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
                 else { s1[u] = L.sb_pt_s1[qc]; s2[u] = L.sb_pt_s2[qc]; j[u] = L.sb_pt_lm[qc]; }
             }
             double w1[SCHUR_U][6], w2[SCHUR_U][6], Vv[SCHUR_U], dg[SCHUR_U];
+            if (SCHUR_NW == 4 && a == c) {                      // a diagonal block: both slots of an entry are the landmark's ONE slot at this pose -- one record, not
+                                                                // two requests for it (a third of the block's cache-line accesses; a second slot at the same pose is read on its own)
+#pragma unroll
+                for (int u = 0; u < SCHUR_U; u++) {
+                    VDB_LOAD(B, j[u], W.n_pt, Vv[u], dg[u]);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k];
+                }
+#pragma unroll
+                for (int u = 0; u < SCHUR_U; u++) {
+                    if (s2[u] != s1[u]) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) w2[u][k] = w1[u][k];
+                    }
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < SCHUR_U; u++) {
                 VDB_LOAD(B, j[u], W.n_pt, Vv[u], dg[u]);
 #pragma unroll
                 for (int k = 0; k < 6; k++) { w1[u][k] = B.w_pt[(size_t)(s1[u])*PT_REC + k]; w2[u][k] = B.w_pt[(size_t)(s2[u])*PT_REC + k]; }
+            }
             }
 #pragma unroll
             for (int u = 0; u < SCHUR_U; u++) {
@@ -173,7 +216,15 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         SCHUR_STAMP(1);                                         // (the slot pairs gathered and multiplied)
         // operands of the tail, independent of the sums: issued before the reduction
         double tail = 0.0;
-        if (wave == 0 && lane < 36) {
+        if (tq) {
+            if (a == c && wave > 0) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) tls[(7*(wave - 1) + i)*65 + lane] = t_on ? tl[i] : 0.0;
+            } else if (a != c && wave == 0 && lane < 36) {
+                if (pre.pab >= 0) tail -= to0;
+                if (pre.pba >= 0) tail -= to1;
+            }
+        } else if (wave == 0 && lane < 36) {
             const int r = lane/6, cc = lane % 6;
             const double *out = B.pairOut;
             if (a == c) {
@@ -198,6 +249,17 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
             if (wave == 0) {
 #pragma unroll
                 for (int k = 0; k < 36; k++) acc[k] += (lds[k*64 + lane] + lds[(36 + k)*64 + lane]) + lds[(72 + k)*64 + lane];
+                if (tq && a == c && lane < 36) {                // the diagonal block's tail from the values waves 1 - 3 left in LDS
+                    const int r = lane/6, cc = lane % 6;
+                    const double *row = tls + sym6(r, cc)*65;
+                    double st_ = 0.0, sh_ = 0.0;
+#pragma unroll 8
+                    for (int q = 0; q < 32; q++) st_ += row[q];
+#pragma unroll 8
+                    for (int q = 0; q < 32; q++) sh_ += row[32 + q];
+                    tail = st_ + sh_;
+                    if (r == cc && !multi) tail += (fresh ? clampd(tsg*tsg*tail, W.min_diag, W.max_diag)/(tsg*tsg) : tdg)*irad;
+                }
             }
             __syncthreads();
         }
