@@ -861,7 +861,7 @@ static void mid_blocks(const Ctx *c, const LevelDev &D, int &nb_pt, int &nb_tx, 
 static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
 // pairs with a dozen scene blocks (large maps): four pairs per wave
 static bool lin_small_pairs(const Ctx *c, const LevelDev &D) { return !c->dbg.no_small_pairs && D.n_pair > 0 && (long long)D.n_sc <= 24LL*D.n_pair; }
-static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
+static void launch_linearize(Ctx *c, const LevelDev &D, int spec, bool skip_postlin = false) {      // skip_postlin: windows -- the first k_schur_t of the pass does k_postlin's work (SchurDec.on = 2)
     struct XL { Ctx *c; size_t x0; ~XL() { c->x_lin = c->x_acc - x0; } } xl{c, c->x_acc};
     Work &W = c->W;
     int nb_pt, nb_tx, nb_pr; mid_blocks(c, D, nb_pt, nb_tx, nb_pr); const int nb_kf = (c->n_kf + 255)/256;
@@ -892,7 +892,7 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec) {
         allreduce(c, W.cbm, 1, ncclDouble, ncclMax);
         if (npp) LAUNCHK(k_pose_scale_multi, dim3(npp), dim3(256), 0, c->stream, W, spec);
     } else if (npp) LAUNCHK(k_pose_sums, dim3(npp), dim3(256), 0, c->stream, W, D, spec);
-    if (!spec) LAUNCHK(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi, npp);
+    if (!spec && !skip_postlin) LAUNCHK(k_postlin, dim3(1), dim3(256), 0, c->stream, W, D, c->opt.gradient_tolerance, nb_pt + nb_tx + nb_pr, multi, npp);
 }
 static int solve_lds_bytes(Ctx *c, int *use_lds) {
     size_t bytes = solve_lds_doubles(c->W.N)*sizeof(double);                                // worst case: every pose free
@@ -1338,7 +1338,7 @@ static void launch_decide(Ctx *c, const LevelDev &D) {
 }
 // one LM iteration: reduced system -> pose step -> back-substitution / candidate -> speculative linearisation at the
 // candidate -> decision (on acceptance the speculative LinBuf simply becomes the current one)
-static void launch_step(Ctx *c, const LevelDev &D, bool decide_prev = false) {
+static void launch_step(Ctx *c, const LevelDev &D, bool decide_prev = false, bool first_fused = false) {
     struct XT { Ctx *c; size_t x0; ~XT() { c->x_trial = c->x_acc - x0; } } xt{c, c->x_acc};
     Work &W = c->W;
     int nb_pt, nb_tx, nb_pr; mid_blocks(c, D, nb_pt, nb_tx, nb_pr); const int nb_kf = (c->n_kf + 255)/256;
@@ -1351,8 +1351,8 @@ static void launch_step(Ctx *c, const LevelDev &D, bool decide_prev = false) {
         if (D.far_B > 0) hipMemsetAsync(W.Sfar, 0, sizeof(double)*36*(size_t)std::max(D.n_far, 1), c->stream); }
     const int bb_pt = back_blocks_pt(c->n_pt), bb_tx = back_blocks_tx(c->n_text), nb_all = bb_pt + bb_tx + nb_kf;      // k_back's blocks
     const bool fused_decide = W.st_next != nullptr && D.far_B <= 0;       // the decision on a trial is taken by the NEXT trial's k_schur_t (the last trial's by k_decide after the loop)
-    if (fused_decide && decide_prev) {
-        launch_schur(c, D, 0, SchurDec{1, nb_all, nb_pt + nb_tx + nb_pr, c->opt});
+    if (fused_decide && (decide_prev || first_fused)) {     // (first_fused: the pass's first trial -- workgroup 0 of the assembly does k_postlin's work on the first linearisation, nobody decides anything)
+        launch_schur(c, D, 0, SchurDec{decide_prev ? 1 : 2, nb_all, nb_pt + nb_tx + nb_pr, c->opt});
         std::swap(W.st, W.st_next);                 // from here on the launches see the state that launch wrote
     } else launch_schur(c, D, (int)is_multi(c));
     if (is_multi(c)) {                             // one exchange per LM trial: the reduced normal equations
@@ -1464,11 +1464,13 @@ int tsba_solve(void *ctx, tsba_report *r) {
             rc = stage_ahead(c, ps); if (rc) return rc;      // (one-shot calls: the later passes' levels, over the copy stream while this pass runs)
             continue;
         }
-        launch_linearize(c, D, 0);
+        // windows: k_postlin (the first linearisation's scaling, cost, gradient test: 8.6 us of one workgroup) inside the first trial's assembly
+        const bool fuse_first = fastp(D) && o.its[ps] > 0 && c->dbg.trial_launches != 3;
+        launch_linearize(c, D, 0, fuse_first);
         int n_trials = 0;
         for (int it = 0; it < o.its[ps]; it++) {
-            if (converged(it)) break;
-            launch_step(c, D, n_trials > 0); n_trials++;
+            if (converged(it) && !(fuse_first && n_trials == 0)) break;
+            launch_step(c, D, n_trials > 0, fuse_first && n_trials == 0); n_trials++;
             if (it >= 1) { rc = stage_ahead(c, ps); if (rc) return rc; }      // (with two iterations queued the device does not run dry while the host stages)
         }
         if (n_trials > 0 && c->W.st_next != nullptr && D.far_B <= 0) launch_decide(c, D);      // windows: the decision on the last trial (the others were taken by the following trial's k_schur_t)

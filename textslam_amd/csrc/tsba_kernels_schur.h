@@ -74,7 +74,34 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         }
     }
     const bool use_pre = PRE && b0 == 0;
-    if constexpr (SCHUR_NW == 4) if (dec.on) {
+    bool first_ = false;                                        // dec.on == 2: this is the pass's first linearisation (the Jacobi scales are being fixed by it)
+    if constexpr (SCHUR_NW == 4) if (dec.on == 2) {
+        // The first trial of a pass (round 6): no decision to take -- workgroup 0 does what k_postlin did as a launch of its own on the first linearisation
+        // (the poses' rows and Jacobi scales, cost, gradient test, the state into the other copy); every workgroup forms the rows it needs of its own pose itself
+        first_ = st->first != 0;
+        if (blockIdx.x == 0) {
+            double o5[5];
+            const bool lin = st->need_lin != 0;
+            if (lin) postlin_fused(W, L, W.lb[lcur_], W.pose[st->cur], first_, dec.nb_lm, 0, lds, lds + 5*256, o5, 0, true, nullptr, false);
+            if (W.dp_poll) for (int k = threadIdx.x; k <= W.N; k += SCHUR_T) W.dp[k] = __builtin_nan("");     // (k_solve_back: "not there yet")
+            if (threadIdx.x == 0) {
+                LmState s = *st;
+                if (lin) {
+                    s.x_cost = o5[2]; s.x_norm = sqrt(o5[1]); s.gmax = o5[0];
+                    if (s.first) s.cost0 = o5[2];
+                    s.first = 0; s.need_lin = 0; s.n_lin++;
+                    if (s.gmax <= dec.o.gradient_tolerance) { s.done = 1; s.term = 3; }
+                }
+                lm_state_store(W.st_next, s);
+                if (W.hprog) { *W.hprog = ((unsigned long long)W.pass_seq << 32) | ((unsigned long long)s.it << 1) | (s.done ? 1u : 0u); __threadfence_system(); }
+                dsh_i[0] = s.done;
+            }
+            __syncthreads();
+            if (dsh_i[0]) return;
+        }
+        fresh = true;
+        st = W.st_next;                                         // (where this trial's failure flag lives)
+    } else if (dec.on) {
         // Round 6: workgroup 0 takes the FULL decision (and stores the state, the poses' rows, the trace); every other workgroup takes it from the partials of
         // cost / step / model cost change alone -- the same sums in the same order, so accept / reject, the trust region and the buffer that becomes current
         // come out the same bits; what it skips (the poses' gradient max and |x|^2 over 75 KB of pair products that 230 workgroups were all pulling through the
@@ -233,7 +260,8 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
                 tail = use_pre ? range_sum<24>(rt, pre.t0, pre.t1) + range_sum<24>(rh, pre.h0, pre.h1)
                                : range_sum<24>(rt, L.pose_t_off[a], L.pose_t_off[a+1]) + range_sum<24>(rh, L.pose_h_off[a], L.pose_h_off[a+1]);
                 // the damping of a candidate this launch has just accepted: postlin_fused's expression on this block's own diagonal sums (workgroup 0 stores the same values for the launches to come)
-                if (r == cc && !multi) tail += (SCHUR_NW == 4 && fresh ? clampd(sgd*sgd*tail, W.min_diag, W.max_diag)/(sgd*sgd) : dgm)*irad;      // multi-GPU: added once after the all-reduce
+                if (r == cc && !multi) { const double sg_ = first_ ? 1.0/(1.0 + sqrt(tail)) : sgd;
+                    tail += (SCHUR_NW == 4 && fresh ? clampd(sg_*sg_*tail, W.min_diag, W.max_diag)/(sg_*sg_) : dgm)*irad; }      // multi-GPU: added once after the all-reduce
             } else {
                 int pab = use_pre ? pre.pab : L.sb_pab[b], pba = use_pre ? pre.pba : L.sb_pba[b];
                 if (pab >= 0) tail -= out[(size_t)(27 + r*6 + cc)*L.n_pair + pab];        // -(M Q)       target a, host c
@@ -258,7 +286,8 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
 #pragma unroll 8
                     for (int q = 0; q < 32; q++) sh_ += row[32 + q];
                     tail = st_ + sh_;
-                    if (r == cc && !multi) tail += (fresh ? clampd(tsg*tsg*tail, W.min_diag, W.max_diag)/(tsg*tsg) : tdg)*irad;
+                    if (r == cc && !multi) { const double sg_ = first_ ? 1.0/(1.0 + sqrt(tail)) : tsg;      // (postlin_fused's expressions)
+                        tail += (fresh ? clampd(sg_*sg_*tail, W.min_diag, W.max_diag)/(sg_*sg_) : tdg)*irad; }
                 }
             }
             __syncthreads();
