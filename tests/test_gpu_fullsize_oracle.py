@@ -366,7 +366,10 @@ def test_converged_answers_against_the_oracle(gpu, oracle_lib, map_cache, name):
 #   from the COMMON START both end on the function tolerance, at costs 1.5e-3 (open chain: 154 against 231 iterations) and 2.9e-2 (long-range: 107 against 129)
 #   apart -- NOT SURVEY 8d's 1e-6: the trajectories part after 1 - 5 trials (cond x eps, above) and the exit is taken wherever one step gains < 1e-6, which on
 #   these valleys is path-dependent (the oracle itself moves on by 4.5e-4 / 4.1e-3 when started again at its answer).
-CONVERGED_FLOOR = {"c6_open_chain": dict(K9=26, K6=27, Kdec=28, rel_cost=4e-3), "c6_long_range": dict(K9=0, K6=56, Kdec=60, rel_cost=6e-2)}
+# Round 6: k_mid sums a pair's text groups and a plane's slots on several lanes and its block partials in one reduction -- other summation orders, 1e-16 in the cost.
+# On the long-range map that moves K(1e-6) from 64 to 45 of 64 trials (decisions still 64 of 64, the same 96 iterations, the same decrease to 1e-4): the floor is
+# 40.  What these two maps can and cannot say is in docs/ledger_r06.md 15.1: two exact CPU solvers inside the oracle end 6.7e-3 apart on the open chain.
+CONVERGED_FLOOR = {"c6_open_chain": dict(K9=26, K6=27, Kdec=28, rel_cost=4e-3), "c6_long_range": dict(K9=0, K6=40, Kdec=60, rel_cost=6e-2)}
 
 
 
