@@ -34,7 +34,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6      # dense fp64 matrix rate (= the fp64 vector rat
 def _pmc_traffic(name):
     """HBM bytes per launch of a kernel from the PMC passes committed under profiles/ (counters cannot be read from inside the
     process): 2 x FETCH_SIZE (gfx950 correction of the micro-architecture guide) + WRITE_SIZE."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, name))) as f:
                 pm = json.load(f)
@@ -222,7 +222,8 @@ def also_lines(gpu, local_rank, torch, steps=10):
     def glob_extra(rep):
         info = gpu.solver_info()
         lin_ms, algo = gpu.time_linearize(0, 30)
-        traffic, src = _pmc_traffic("c6_linearize") if gpu._resident.n_kf == 5000 else (None, None)      # (the PMC pass was taken on the 5000-keyframe chain)
+        # (PMC passes: the 5000-keyframe chain, and -- round 6 -- C5)
+        traffic, src = _pmc_traffic("c6_linearize") if gpu._resident.n_kf == 5000 else (_pmc_traffic("c5_linearize") if gpu._resident.n_kf == 500 else (None, None))
         e = {"band_rows": info["band_rows"], "interiors": info["interiors"], "ring_partition": info["ring"], "keyframes_reordered": info["kf_reordered"],
              "roofline": {"bound": "hbm", "kernel": "k_linearize (level 0)", "achieved": algo/(lin_ms*1e-3)/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": algo/(lin_ms*1e-3)/1e9/HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": algo, "avg_launch_us": lin_ms*1e3}}
@@ -267,6 +268,7 @@ def main():
                     help="default: local_ba at 1 GPU, global_ba (the sharded 5000-keyframe map) at N > 1")
     ap.add_argument("--kf", type=int, default=5000, help="global_ba: keyframes (BASELINE configs[4]: 5k KF / 500k observations)")
     ap.add_argument("--pts", type=int, default=70000, help="global_ba: map points (70k points -> ~500k observations)")
+    ap.add_argument("--band", type=int, default=10, help="global_ba: keyframes after its host that observe a point (C5 in `also`: 12)")
     ap.add_argument("--far", type=float, default=0.0, help="global_ba: fraction of loop-closure-like long-range observations")
     ap.add_argument("--loop", action="store_true", help="global_ba: closed trajectory (the map right after a loop closure: ring-shaped co-visibility)")
     ap.add_argument("--loop-at", type=int, default=0, help="global_ba --loop: the loop starts at this keyframe (a tail before the loop)")
@@ -322,7 +324,7 @@ def main():
     reference, check = None, None
     if workload == "global_ba":
         # one global BA sharded by landmark over the ranks: poses replicated, reduced normal equations exchanged over RCCL
-        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=10, far_frac=args.far, loop=args.loop, loop_at=args.loop_at)      # identical on every rank
+        prob = synth.config_global(n_kf=args.kf, n_pt=args.pts, band=args.band, far_frac=args.far, loop=args.loop, loop_at=args.loop_at)      # identical on every rank
         opt = abi.options_global()
         if world > 1:
             if rank == 0:                                  # the 1-GPU time of the SAME map, same run: the strong-scaling reference
@@ -379,6 +381,7 @@ def main():
                               "long_range_blocks": info.get("far_blocks", 0), "pcg": gpu.pcg_stats() if info.get("far_band_blocks") else None,
                               "rccl_ranks": ex["ranks"], "allreduce_bytes_per_lm_trial": ex["per_trial"],
                               "allreduce_bytes_per_linearisation": ex["per_linearisation"]}}
+            out["rccl_ranks"] = ex["ranks"]                     # (top-level: the communicator size the library reports, 1 without tsba_comm_init)
             if reference:
                 out["scaling_reference"] = reference
                 out["config"]["speedup_vs_1gpu_same_run"] = reference["ms_per_step"]/ms_per_step
@@ -386,7 +389,7 @@ def main():
                 out["scaling_note"] = ("strong scaling of ONE 5000-keyframe solve is expected to be flat: the reduced-system solve (two thirds of an LM trial on one GPU, "
                                        "a latency chain that every rank repeats) does not shard; per-rank kernel times give a ceiling of 1.42 x at 8 ranks before "
                                        "16.6 MB of all-reduce per trial (DESIGN.md 7).  INTEGRATION.md tells callers to keep a map on one GPU")
-            traffic, src = _pmc_traffic("c6_linearize")
+            traffic, src = _pmc_traffic("c6_linearize") if args.kf == 5000 else (_pmc_traffic("c5_linearize") if args.kf == 500 else (None, None))
             achieved = algo_bytes/(lin_ms*1e-3)/1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_linearize<FULL,4> (level 0, this rank's shard)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS, "traffic": traffic if world == 1 else None, "traffic_source": src if world == 1 else None,
