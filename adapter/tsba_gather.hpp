@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <vector>
 #include "tsba.h"
 
@@ -94,15 +95,22 @@ struct Packed {
 // from the object graph in every call -- only topology is kept.  invalidate() after anything that re-targets observations without changing the lists'
 // lengths (mapPts::Replace at a loop closure, mapPts.cc:170-190): the adapter's GlobalBA / loop entry points call it.
 // The arrays a cached gather produces are the arrays pack_map produces without a cache, element for element (tests/cxx: slide_check).
+// A process-wide topology epoch: whatever re-targets observations WITHOUT changing list lengths (mapPts::Replace / keyframe::ReplaceMapPt at a loop closure, on
+// whichever thread it runs) bumps it once; every thread's cache compares it in begin_call() and drops what it holds (round-5 advisor: a thread_local cache
+// invalidated only on the thread that ran GlobalBA would keep packing stale point ids on another).
+inline std::atomic<unsigned long long> &gather_topology_epoch() { static std::atomic<unsigned long long> e(0); return e; }
+inline void gather_topology_changed() { gather_topology_epoch().fetch_add(1, std::memory_order_acq_rel); }
 struct GatherCache {
+    unsigned long long seen_epoch = 0;
     struct KfSeg { size_t n_obvpts; std::vector<size_t> n_obs; std::vector<std::vector<int32_t> > raw, ptid; std::vector<std::vector<double> > uv0; unsigned long long used; };
     struct TextSeg { std::vector<size_t> n_feat; std::vector<std::vector<int32_t> > raw; std::vector<std::vector<double> > uv, ref; unsigned long long used; };
     std::map<long long, KfSeg> kf; std::map<long long, TextSeg> text;
     unsigned long long tick; long long hits, misses;
     GatherCache() : tick(0), hits(0), misses(0) {}
-    void invalidate() { kf.clear(); text.clear(); }
+    void invalidate() { kf.clear(); text.clear(); gather_topology_changed(); seen_epoch = gather_topology_epoch().load(std::memory_order_acquire); }      // (also tells every other thread's cache)
     // entries no call has used for `keep` calls leave (the window moved on)
     void begin_call(unsigned long long keep = 4) { tick++;
+        { const unsigned long long e = gather_topology_epoch().load(std::memory_order_acquire); if (e != seen_epoch) { kf.clear(); text.clear(); seen_epoch = e; } }
         for (std::map<long long, KfSeg>::iterator it = kf.begin(); it != kf.end();) { if (it->second.used + keep < tick) kf.erase(it++); else ++it; }
         for (std::map<long long, TextSeg>::iterator it = text.begin(); it != text.end();) { if (it->second.used + keep < tick) text.erase(it++); else ++it; } }
     template <class KeyFrameT>

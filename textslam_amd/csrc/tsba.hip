@@ -134,6 +134,7 @@ struct Ctx {
                       long long hits = 0, misses = 0; } ic;
     WbBuf wb{}; Work Wk{}; double *wb_alloc = nullptr; size_t wb_bytes = 0;      // low-rank correction for loop closures (tsba_wb.h): its buffers, the k x k dense system as a second Work
     EcgBuf ecg{}; double *ecg_alloc = nullptr; size_t ecg_bytes = 0;      // enlarged conjugate gradients (tsba_pcg.h)
+    bool pose_retry = false;                      // tsba_solve is running the pose-only solve again with a launch per LM step (after a poll give-up in k_pose_pass)
     bool pack_in_solve = false, packed = false;   // one-shot calls: tsba_solve packs the results behind its last kernel (enqueue_pack); packed: the block in dl_host is that solve's
     unsigned char *dl_dev = nullptr, *dl_host = nullptr; size_t dl_bytes = 0;       // results of a solve as one block (k_pack_results): one device-to-host copy per download
     MsBuf sv{}; double *sv_alloc = nullptr; size_t sv_bytes = 0; bool sv_prepared = false;      // single-vector solve phase (tsba_bandsv.h); sv_prepared: k_sv_linv has run on the current factorisation
@@ -868,8 +869,10 @@ static void launch_linearize(Ctx *c, const LevelDev &D, int spec, bool skip_post
     // EXPERIMENT, off by default (trial_launches = 2): k_mid inside the speculative linearisation's launch (k_lin_mid: its last workgroups to finish take the k_mid
     // blocks).  Measured in round 5: 40.7 us per launch against 13.4 + 10.6 us for the two launches -- 736 workgroups telling each other that they are done costs
     // more than the kernel boundary it replaces (tools/ticket_bench.hip, docs/ledger_r05.md 14.2)
-    if (spec && W.st_next && c->lin_ticket && c->dbg.trial_launches == 2 && !is_multi(c) && mid_threads(c) == MID_TW && D.n_pair + D.n_tg > 0 && !lin_small_pairs(c, D)) {
-        const unsigned grid = (unsigned)((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8);
+    const unsigned lm_grid = (unsigned)((((D.n_pair + LIN_NWV - 1)/LIN_NWV + D.n_tg + 7)/8)*8);
+    if (spec && W.st_next && c->lin_ticket && c->dbg.trial_launches == 2 && !is_multi(c) && mid_threads(c) == MID_TW && D.n_pair + D.n_tg > 0 && !lin_small_pairs(c, D)
+        && grid_resident(c, (const void *)k_lin_mid, LIN_T, 0, (int)lm_grid)) {      // (its retained workgroups wait for every arrival: only where the whole grid is resident, as every launch that waits)
+        const unsigned grid = lm_grid;
         LAUNCHK(k_lin_mid, dim3(grid), dim3(LIN_T), 0, c->stream, W, D, nb_pt, nb_tx, nb_pt + nb_tx + nb_pr, c->lin_ticket, c->lin_base);
         c->lin_base += grid;
         return;
@@ -1536,6 +1539,17 @@ int tsba_solve(void *ctx, tsba_report *r) {
           : Dl.far_B > 0 ? (Dl.n_wb > 0 && ms_available(c) && c->dbg.far_solver != 3 ? TSBA_SOLVER_BAND_LOWRANK : TSBA_SOLVER_BAND_PCG)
           : !c->band_stream ? TSBA_SOLVER_DENSE : c->band_parts <= 1 ? TSBA_SOLVER_BAND : c->W.ring ? TSBA_SOLVER_RING : c->sep_cr ? TSBA_SOLVER_BAND_CR : TSBA_SOLVER_BAND_PART; }
     r->poll_timeouts = (int32_t)((const unsigned int *)pcg_host)[8];
+    // PoseOptim in one launch per pass (k_pose_pass): every workgroup keeps the LM state redundantly and assumes that all of them read the same polled sums -- a poll that ran
+    // into its bound in ONE workgroup (a dispatch stall of ~100 ms beside another context) would let the copies part silently (round-5 advisor).  A give-up anywhere
+    // during such a solve: the answer is not used, the solve runs again from its start point with a launch per LM step (k_pose_iter: no workgroup waits for another)
+    if (c->pose_only && !is_multi(c) && r->poll_timeouts != 0 && !c->dbg.pass_launches && !c->pose_retry) {
+        c->pose_retry = true; c->dbg.pass_launches = 1;
+        const int32_t gave_up = r->poll_timeouts;
+        const int rc2 = tsba_solve(ctx, r);
+        c->dbg.pass_launches = 0; c->pose_retry = false;
+        if (rc2 == TSBA_OK) r->poll_timeouts += gave_up;       // (reported: the caller sees that the first attempt was abandoned)
+        return rc2;
+    }
     if (c->far_B > 0) { r->pcg_iterations = pcg_host[0]; r->pcg_systems = pcg_host[1]; r->pcg_max_iterations = pcg_host[2]; r->pcg_unconverged = pcg_host[3]; r->pcg_stagnated = pcg_host[4]; }
     return TSBA_OK;
 }

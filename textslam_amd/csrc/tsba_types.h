@@ -3,7 +3,9 @@
 typedef double v2d __attribute__((ext_vector_type(2)));
 // Kernels whose workgroups poll values that other workgroups of the same launch publish (k_solve_back, k_sv_cre_tree, k_sv_tree_back, k_cre_back_tree, and the
 // roles of k_lin_mid) bound their polling; a thread that gives up counts itself here.  A solve reports the difference over its duration
-// (tsba_report.poll_timeouts): a give-up fails the linear solve of its LM trial -- this says that it was a wait and not the numbers.
+// (tsba_report.poll_timeouts): a give-up fails the linear solve of its LM trial -- this says that it was a wait and not the numbers.  ONE counter per process:
+// a solve's figure also counts the give-ups of other contexts that solved at the same time (tracking's PoseOptim beside a mapping BA), and it counts threads,
+// not events -- it answers "did anything give up while this solve ran", which is what the callers (and the pose-only retry in tsba_solve) ask.
 __device__ unsigned int ts_poll_giveups;
 // ------------------------------------------------------------------------------------------------ device structs
 struct LmState {
