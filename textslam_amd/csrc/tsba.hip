@@ -550,7 +550,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         AL(B.w_pt, PT_REC*mx_pslot); AL(B.vdb_pt, PT_VDB*(size_t)p->n_pt);
         AL(B.w_tx, TX_REC*mx_tslot); AL(B.V_tx, 6*(size_t)p->n_text); AL(B.b_tx, 3*(size_t)p->n_text); AL(B.dgs_tx, 3*(size_t)p->n_text);
         AL(B.Hd, W.N); AL(B.bp, W.N); AL(B.bp_loc, W.N); AL(B.dgs_p, W.N);
-        AL(B.lmpart, 3*((size_t)p->n_pt/64 + (size_t)p->n_text/(64/MID_PL) + mx_pair/(64/MID_PR_MIN) + 8));      // (one partial per k_mid block, at its smallest block size)      // (one partial per k_mid block: at most n_pt / 128 + n_text / 128 + pairs / 128 + 3, and nb_back_max >= n_pt / 64 + n_text / 16)
+        AL(B.lmpart, 3*((size_t)p->n_pt/64 + (size_t)p->n_text/2 + mx_pair + 8));      // (one partial per k_mid block, at its smallest block size)      // (one partial per k_mid block: at most n_pt / 128 + n_text / 128 + pairs / 128 + 3, and nb_back_max >= n_pt / 64 + n_text / 16)
     }
     AL(W.sig_pt, p->n_pt); AL(W.sig_tx, 3*(size_t)p->n_text); AL(W.sig_p, W.N);
     AL(W.cb, 2*(size_t)W.N + 8); AL(W.cbm, 1);
@@ -858,7 +858,9 @@ static int mid_threads(const Ctx *c) { return c->n_kf <= SCHUR_KEEP_KF ? ((c->db
 // two dependent round trips instead of up to eight)
 static void mid_blocks(const Ctx *c, const LevelDev &D, int &nb_pt, int &nb_tx, int &nb_pr) { const int t = mid_threads(c);
     const int pr = MID_PR_MIN;
-    nb_pt = (c->n_pt + t - 1)/t; nb_tx = (c->n_text + t/MID_PL - 1)/(t/MID_PL); nb_pr = (D.n_pair + t/pr - 1)/(t/pr); }
+    nb_pt = (c->n_pt + t - 1)/t;
+    if (t == 64) { nb_tx = (c->n_text + 1)/2; nb_pr = D.n_pair; }      // one-wave blocks: a plane on 32 lanes, a pair on the whole wave (a lane per value / output)
+    else { nb_tx = (c->n_text + t/MID_PL - 1)/(t/MID_PL); nb_pr = (D.n_pair + t/pr - 1)/(t/pr); } }
 static int pose_parts(const Ctx *c) { return c->n_kf > 126 ? (c->n_kf + 20)/21 : 0; }    // k_pose_sums workgroups (0: the pose sums stay in k_postlin / k_decide)
 // pairs with a dozen scene blocks (large maps): four pairs per wave
 static bool lin_small_pairs(const Ctx *c, const LevelDev &D) { return !c->dbg.no_small_pairs && D.n_pair > 0 && (long long)D.n_sc <= 24LL*D.n_pair; }

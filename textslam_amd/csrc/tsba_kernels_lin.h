@@ -658,6 +658,11 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 // (a fixed order), the block's three partials in one reduction.
 #define MID_PL 8
 #define MID_PR_MIN 4
+__device__ __forceinline__ void mid_lds_fence() {           // order this wave's LDS writes before its following LDS reads (one-wave blocks: no barrier needed)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #define PT_PAIRN 6                          // entries of L.pt_pair4 per point
 // MID_PR lanes per pair (4.  16 was measured on C4 -- ~90 pairs at a level, up to ~20 text groups each --: 8.65 against 7.63 us: two more shuffle steps over 27 values and
 // stores predicated sixteen ways cost a lone wave more than the group loop's extra round trip; tools/mid_stamps.sh)
@@ -677,14 +682,23 @@ __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, cons
     double sg0 = 1.0, sgt[3] = {1.0, 1.0, 1.0};             // the Jacobi scales as they are (a first linearisation replaces them below)
 #pragma unroll
     for (int u = 0; u < U; u++) pr0[u] = 0;
-    const int jt = (b - nb_pt)*(NT/MID_PL) + (tid >> 3), ut = tid & (MID_PL - 1);            // plane blocks: plane, lane
-    const int pp = (b - nb_pt - nb_tx)*(NT/MID_PR) + tid/MID_PR, up = tid & (MID_PR - 1);    // pair blocks: pair, lane
+    // One-wave blocks (windows, NT == 64) give a plane 32 lanes and a pair the whole wave, a lane per VALUE (the 27 of a plane / a pair, then a lane per output):
+    // no cross-lane sums, no predicated stores -- see the two W1 branches below.  Wider blocks (maps: throughput kernels) keep a plane on 8 and a pair on 4 lanes.
+    constexpr bool W1 = NT == 64;
+    const int jt = W1 ? (b - nb_pt)*2 + (tid >> 5) : (b - nb_pt)*(NT/MID_PL) + (tid >> 3), ut = W1 ? (tid & 31) : (tid & (MID_PL - 1));            // plane blocks: plane, lane
+    const int pp = W1 ? b - nb_pt - nb_tx : (b - nb_pt - nb_tx)*(NT/MID_PR) + tid/MID_PR, up = W1 ? tid : (tid & (MID_PR - 1));    // pair blocks: pair, lane
+    int prs[6] = {0, 0, 0, 0, 0, 0};
     if (b < nb_pt) { const int j = b*NT + tid; if (j < W.n_pt) { o = L.pls_off[j]; e = L.pls_off[j+1]; act_ = W.act_pt[j]; sg0 = W.sig_pt[j];
 #pragma unroll
         for (int u = 0; u < U; u++) pr0[u] = L.pt_pair4[PT_PAIRN*(size_t)j + u]; } }
-    else if (b < nb_pt + nb_tx) { if (jt < W.n_text) { o = L.tls_off[jt]; e = L.tls_off[jt+1]; act_ = W.act_tx[jt]; prt = L.tx_pair8[MID_PL*(size_t)jt + ut];
+    else if (b < nb_pt + nb_tx) { if (jt < W.n_text) { o = L.tls_off[jt]; e = L.tls_off[jt+1]; act_ = W.act_tx[jt];
+        if constexpr (W1) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) sgt[k] = W.sig_tx[(size_t)k*W.n_text + jt]; } }
+            for (int u = 0; u < 6; u++) prs[u] = L.tx_pair8[MID_PL*(size_t)jt + u];
+            if (ut == 18 || ut == 21 || ut == 23) sgt[0] = W.sig_tx[(size_t)(ut == 18 ? 0 : ut == 21 ? 1 : 2)*W.n_text + jt];
+        } else { prt = L.tx_pair8[MID_PL*(size_t)jt + ut];
+#pragma unroll
+        for (int k = 0; k < 3; k++) sgt[k] = W.sig_tx[(size_t)k*W.n_text + jt]; } } }
     else { if (pp < L.n_pair) { tq0 = L.pair_tg_off[pp]; tq1 = L.pair_tg_off[pp+1]; ph_ = L.pair_h[pp]; hp_ = L.pair_hpos[pp]; } }
     if (clear_next && W.st_next && b == 0 && tid == 0) W.st_next->step_fail = 0;      // (the next trial's k_schur_t takes this trial's decision into that copy of the state, every field but this one: its own workgroups may raise it)
     if (st->done) return;
@@ -726,6 +740,38 @@ __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, cons
             if (first) { sg = 1.0/(1.0 + sqrt(V)); W.sig_pt[j] = sg; }
             VDB_STORE(B, j, W.n_pt, V, clampd(sg*sg*V, W.min_diag, W.max_diag)/(sg*sg), acc[1]);
             if (act_) { gm = fabs(acc[1]); xn = rho_x[j]*rho_x[j]; }
+        }
+    } else if (W1 && b < nb_pt + nb_tx) {
+        // a plane on 32 lanes, lane k < 27 = value k of its record (W 0..17 | V6 18..23 | b3 24..26): the V / b lanes add the slots' values up, a W lane (half, rr, cc)
+        // forms its entry of the host column -blkdiag(R,R)^T W from three values and three rotation entries per slot -- six slots in flight, nothing crosses lanes
+        const int j = jt, k = ut;
+        if (e > o && k < 27) {
+            const int hr_ = k/3, cc_ = k - 3*hr_, half_ = hr_/3, rr_ = hr_ - 3*half_;      // (W lanes)
+            double acc = 0.0;
+            for (int s0 = o; s0 < e - 1; s0 += 6) {
+                double x[6][3], Rv[6][3];
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int sc = min(s0 + u, e - 2);
+                    const int pr = s0 == o ? prs[u] : L.tslot_pair[sc];
+                    // (the same requests on every lane, the V / b lanes' at addresses they do not use: a request under a lane-dependent branch is waited for at the end
+                    // of that branch -- two kinds of lane were two round trips)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { x[u][q] = B.w_tx[(size_t)sc*TX_REC + (k >= 18 ? k : (half_*3 + q)*3 + cc_)]; Rv[u][q] = PAIRR(B, pr, k >= 18 ? 0 : q*3 + rr_, L.n_pair); }
+                }
+#pragma unroll
+                for (int u = 0; u < 6; u++) if (s0 + u < e - 1) acc += k >= 18 ? x[u][0] : -(Rv[u][0]*x[u][0] + Rv[u][1]*x[u][1] + Rv[u][2]*x[u][2]);
+            }
+            if (k < 18) B.w_tx[(size_t)(e - 1)*TX_REC + k] = acc;
+            else if (k < 24) B.V_tx[(size_t)(k - 18)*W.n_text + j] = acc;
+            else B.b_tx[(size_t)(k - 24)*W.n_text + j] = acc;
+            if (k == 18 || k == 21 || k == 23) {                     // the diagonal of V: Jacobi scale and LM diagonal of the plane's three parameters
+                const int kd = k == 18 ? 0 : k == 21 ? 1 : 2;
+                double sg = sgt[0];
+                if (first) { sg = 1.0/(1.0 + sqrt(acc)); W.sig_tx[(size_t)kd*W.n_text + j] = sg; }
+                B.dgs_tx[(size_t)kd*W.n_text + j] = clampd(sg*sg*acc, W.min_diag, W.max_diag)/(sg*sg);
+            }
+            if (act_ && k >= 24) { gm = fabs(acc); const double tv = theta_x[3*j + (k - 24)]; xn = tv*tv; }
         }
     } else if (b < nb_pt + nb_tx) {
         const int j = jt;
@@ -772,6 +818,55 @@ __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, cons
                     B.dgs_tx[(size_t)k*W.n_text + j] = clampd(sg*sg*dv[k], W.min_diag, W.max_diag)/(sg*sg);
                 }
                 if (act_) for (int k = 0; k < 3; k++) { gm = fmax(gm, fabs(acc[6 + k])); xn += theta_x[3*j + k]*theta_x[3*j + k]; }
+            }
+        }
+    } else if (W1) {
+        // a pair on one wave: lane k < 27 = row k of its sums M (21) | c (6), lane 27 its cost -- the scene blocks' sums plus the pair's text groups IN ORDER, eight groups
+        // in flight; then a lane per OUTPUT: 27 copies, 36 entries of M Q, 21 of Q^T M Q, 6 of Q^T c, the operands crossing through 80 doubles of LDS
+        const int p = pp, k = tid;
+        double *xs = red;                                           // [0..26] M | c, [32..40] R, [44..79] M Q
+        if (p < L.n_pair) {
+            const int ntg = L.n_tg;
+            // every lane makes the same nine requests (lanes 28..63 at addresses whose values they do not use, lanes 32..40 the rotation in place of the scene sums):
+            // a request under a lane-dependent branch is waited for at the end of that branch, and the sums and the rotation were two round trips
+            const bool isM = k < 27, isS = k < 28, isR = k >= 32 && k < 41;
+            const double *row = isM ? B.tgM + (size_t)k*ntg : B.tgCost;
+            const double *a0 = isM ? B.pairM + (size_t)k*L.n_pair + p : (isR ? &PAIRR(B, p, k - 32, L.n_pair) : B.pairCost + p);
+            double g8[8];
+            const double m0 = *a0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) g8[u] = ntg > 0 ? row[min(tq0 + u, ntg - 1)] : 0.0;
+            double m = m0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) m += (isS && tq0 + u < tq1) ? g8[u] : 0.0;
+            for (int q0 = tq0 + 8; q0 < tq1; q0 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) g8[u] = row[min(q0 + u, ntg - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) m += (isS && q0 + u < tq1) ? g8[u] : 0.0;
+            }
+            if (k == 27) cs = m;
+            if (k < 27) { xs[k] = m; B.pairOut[(size_t)k*L.n_pair + p] = m; }
+            if (isR) xs[k] = ph_ >= 0 ? m : 0.0;
+            if (ph_ >= 0) {                                          // (uniform)
+                double *out = B.pairOut;
+                const double *Rs = xs + 32; double *MQs = xs + 44;
+                mid_lds_fence();
+                if (k < 36) {                                        // M * blkdiag(R,R), entry (r, half*3 + cc)
+                    const int r = k/6, col = k - 6*r, half = col/3, cc = col - 3*half;
+                    const double mq = xs[sym6(r, half*3)]*Rs[cc] + xs[sym6(r, half*3 + 1)]*Rs[3 + cc] + xs[sym6(r, half*3 + 2)]*Rs[6 + cc];
+                    MQs[k] = mq; out[(size_t)(27 + k)*L.n_pair + p] = mq;
+                } else if (k < 42) {                                 // Q^T c
+                    const int e6 = k - 36, half = e6/3, a = e6 - 3*half;
+                    const double *c = xs + 21 + 3*half;
+                    out[(size_t)(84 + e6)*L.n_pair + hp_] = Rs[a]*c[0] + Rs[3 + a]*c[1] + Rs[6 + a]*c[2];
+                }
+                mid_lds_fence();
+                if (k < 36) {                                        // Q^T (M Q): upper triangle, rows 63.. stored host-major
+                    const int r = k/6, cc = k - 6*r, hr = r/3, rr = r - 3*hr;
+                    if (cc >= r) out[(size_t)(63 + sym6(r, cc))*L.n_pair + hp_] = Rs[rr]*MQs[(hr*3)*6 + cc] + Rs[3 + rr]*MQs[(hr*3 + 1)*6 + cc] + Rs[6 + rr]*MQs[(hr*3 + 2)*6 + cc];
+                }
+                mid_lds_fence();                                    // (the block's partials go through the same LDS words below)
             }
         }
     } else {
@@ -873,7 +968,7 @@ __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, cons
 #define MID_TW 128
 template <int NT, int U, int PR>
 __global__ __launch_bounds__(NT) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int spec) {
-    __shared__ double red[NT];
+    __shared__ double red[NT < 80 ? 80 : NT];
     mid_block<NT, U, PR>(W, L, nb_pt, nb_tx, spec, (int)blockIdx.x, true, red);
 }
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
     }
     const bool use_pre = PRE && b0 == 0;
     bool first_ = false;                                        // dec.on == 2: this is the pass's first linearisation (the Jacobi scales are being fixed by it)
-    if constexpr (SCHUR_NW == 4) if (dec.on == 2) {
+    if constexpr (SCHUR_NW == 4) { if (dec.on == 2) {
         // The first trial of a pass (round 6): no decision to take -- workgroup 0 does what k_postlin did as a launch of its own on the first linearisation
         // (the poses' rows and Jacobi scales, cost, gradient test, the state into the other copy); every workgroup forms the rows it needs of its own pose itself
         first_ = st->first != 0;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
         if (dsh_i[0]) return;
         lcur_ = dsh_i[1]; radius_ = dsh_r; fresh = dsh_i[2] != 0;
         st = W.st_next;                                         // (where this trial's failure flag lives)
-    }
+    } }
     // (b0 > 0: large maps take the S blocks through k_schur_quad and only the gradient part here, a grid of a multiple of 8 workgroups in
     // which the workgroups of ONE XCD -- workgroup i runs on XCD i mod 8 -- take neighbouring poses: the slot records of a landmark sit next
     // to each other, one per observing pose, and neighbouring poses observe the same landmarks)
