@@ -242,18 +242,32 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
     __shared__ int s_xy[8], s_bb[4];
     __shared__ double s_red[MS_THREADS];
     const int tid = threadIdx.x;
-    int tb = L.tg_tobs[g], kf = L.tg_kf[g], j = L.tg_text[g], h = W.text_host[j];
-    if (W.filter_good && !W.tobs_good[tb]) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
+    // (round 6) the group's static record (tobs, keyframe, text, host: one 16-byte load) instead of three lists and then the host; what hangs off it -- the good
+    // flag, both poses, the plane, the corner, the keyframe's image pointer -- requested together by every thread BEFORE the flag is looked at (a request under a
+    // lane-dependent branch is waited for at the end of that branch): one dependent round trip where there were three, and the image pointer is there when the
+    // histogram needs it
+    const int4 ra = ((const int4 *)L.tg_rec)[2*g];
+    const int tb = ra.x, kf = ra.y, j = ra.z, h = ra.w;
+    const uint8_t good_t = W.tobs_good[tb];
+    const uint8_t *img = L.img[kf];
+    const int bq_ = tid & 3;
+    double pc[7], ph[12], th[3], mx, my;
+#pragma unroll
+    for (int k = 0; k < 7; k++) pc[k] = pose[7*kf + k];
+#pragma unroll
+    for (int k = 0; k < 12; k++) ph[k] = h >= 0 ? (k < 7 ? pose[7*h + k] : 0.0) : W.text_Twr[12*(size_t)j + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) th[k] = theta[3*j + k];
+    mx = W.text_box[(j*4 + bq_)*2]; my = W.text_box[(j*4 + bq_)*2 + 1];
+    if (W.filter_good && !good_t) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
     const int w = L.img_w, hh = L.img_h;
     __shared__ int s_c[16];
     if (tid < 4) {                                            // one box corner per lane (the serial walk over the four cost ~1.5 us of divisions)
         const int b = tid;
-        Pose C; load_pose(pose + 7*kf, C);
+        Pose C; load_pose(pc, C);
         PairT T;
-        if (h >= 0) { Pose Hs; load_pose(pose + 7*h, Hs); pair_from_poses(C, Hs, T); }
-        else pair_from_Twr(C, W.text_Twr + 12*j, T);
-        double th[3] = { theta[3*j], theta[3*j+1], theta[3*j+2] };
-        double mx = W.text_box[(j*4 + b)*2], my = W.text_box[(j*4 + b)*2 + 1];
+        if (h >= 0) { Pose Hs; load_pose(ph, Hs); pair_from_poses(C, Hs, T); }
+        else pair_from_Twr(C, ph, T);
         double invz = -(mx*th[0] + my*th[1] + th[2]);
         double m[3] = { mx, my, 1.0 }, Rm[3]; mat3_vec(T.Rcr, m, Rm);
         double X = Rm[0]/invz + T.tq[0] + C.t[0], Y = Rm[1]/invz + T.tq[1] + C.t[1], Z = Rm[2]/invz + T.tq[2] + C.t[2];
@@ -287,7 +301,6 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
     raster_quad(mask, s_xy, w, hh, tid, MS_THREADS);
     __syncthreads();
     // histogram of masked pixels inside the clamped bounding box (tool.cc:1217-1232)
-    const uint8_t *img = L.img[kf];
     int bw = xMax - xMin + 1, bh = yMax - yMin + 1;
     {   // four pixels per thread and round with their loads in flight together; (x, y) advance without a division per pixel
         const int npx = bw*bh, dx = MS_THREADS % bw, dy = MS_THREADS / bw;
@@ -455,6 +468,12 @@ __device__ __forceinline__ void lin_body(const Work &W, const LevelDev &L, const
     if (st->done) return;
     if (!spec && !st->need_lin) return;
     if (spec && st->step_fail) return;
+#ifdef MID_STAMPS                           // (tools/mid_stamps.sh: cycles of a workgroup of the linearisation by kind -- scene pairs / text group -- into W.dbg[0..15])
+    const long long ls_t0 = clock64(); const int ls_kind = bq < nb_sc ? 0 : 1;
+#define LIN_STAMP(slot) do { if (threadIdx.x == 0 && spec) atomicAdd((unsigned long long *)&W.dbg[8*ls_kind + (slot)], (unsigned long long)(clock64() - ls_t0)); } while (0)
+#else
+#define LIN_STAMP(slot) do { } while (0)
+#endif
     const int sel = spec ? (st->cur ^ 1) : st->cur;
     const LinBuf &B = W.lb[spec ? (st->lcur ^ 1) : st->lcur];
     const double *pose = W.pose[sel], *rho = W.rho[sel], *theta = W.theta[sel];
@@ -503,6 +522,7 @@ __device__ __forceinline__ void lin_body(const Work &W, const LevelDev &L, const
                 for (int k = 0; k < 8; k++) B.w_pt[(size_t)(slot)*PT_REC + k] = wv[k];
             }
         }
+        LIN_STAMP(1);                                           // (the pair's candidates evaluated, slot records stored)
         if (MODE == MODE_COST) {
             double cs = acc[27];
             if (PPW == 1) cs = wave_sum1(cs);
@@ -534,6 +554,10 @@ __device__ __forceinline__ void lin_body(const Work &W, const LevelDev &L, const
                 }
             }
         }
+        LIN_STAMP(3);
+#ifdef MID_STAMPS
+        if (threadIdx.x == 0 && spec) atomicAdd((unsigned long long *)&W.dbg[8*ls_kind + 7], 1ull);
+#endif
     } else if constexpr (TEXT) {
         // ---------------- photometric blocks of one (KF, text) observation: thread = (feature tid / LPF, tap group tid % LPF)
         const int tb = ra.x, i = ra.y, j = ra.z, h = ra.w, slot = rb.x, f0 = rb.y, f1 = rb.z, fg = rb.w;
@@ -583,6 +607,7 @@ __device__ __forceinline__ void lin_body(const Work &W, const LevelDev &L, const
                     const TapPx q = tap_fetch(T, C.t, th, mx, my, L.K[0], L.K[1], L.K[2], L.K[3], img, L.img_w, L.img_h);
                     s_px[k*LIN_T + tid] = (unsigned)q.I00 | ((unsigned)q.I01 << 8) | ((unsigned)q.I10 << 16) | ((unsigned)q.I11 << 24);
                 }
+                LIN_STAMP(1);                                   // (operands there, the taps' pixel quads requested)
                 double s = 0.0;
 #pragma unroll 1
                 for (int k = 0; k < TPL; k++) {
@@ -621,6 +646,7 @@ __device__ __forceinline__ void lin_body(const Work &W, const LevelDev &L, const
                 for (int k = 0; k < 54; k++) blk[k] *= wg;
                 blk[54] = (good && tp == 0) ? rho_h : 0.0;
             }
+            LIN_STAMP(2);                                       // (the thread's taps evaluated and weighted)
             // 55 sums over the workgroup's threads: per wave two transposes (28 + 27 values), then the waves (fixed order)
             const double t0 = wave_sum_to_lane_mw<28>(blk, reg, lane);
             const double t1 = wave_sum_to_lane_mw<27>(blk + 28, reg, lane);
@@ -634,6 +660,10 @@ __device__ __forceinline__ void lin_body(const Work &W, const LevelDev &L, const
             __syncthreads();
         }
         if (wave > 0) return;
+        LIN_STAMP(3);
+#ifdef MID_STAMPS
+        if (threadIdx.x == 0 && spec) atomicAdd((unsigned long long *)&W.dbg[8*ls_kind + 7], 1ull);
+#endif
         // wave 0 alone from here (LDS accesses of one wave are ordered; the fence keeps the compiler honest)
         if (lane < 27) B.tgM[(size_t)lane*L.n_tg + tgpp] = tot;          // pair-major rank: k_mid sums a contiguous range
         else if (lane < 45) { if (slot >= 0) B.w_tx[(size_t)(slot)*TX_REC + (lane - 27)] = tot; }

@@ -12,6 +12,10 @@ v = (C.c_longlong*64)()
 opt.lib.tsba_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 assert opt.lib.tsba_debug_stamps(opt.ctx, v) == 0
 v = np.array(list(v), dtype=np.int64)
+print("k_linearize (speculative launches), mean cycles per workgroup from the arrival of the LM state, by kind:")
+for kind, name in enumerate(("scene pairs (2 per workgroup)", "text group")):
+    s_ = v[8*kind: 8*kind + 8]; n = max(int(s_[7]), 1)
+    print("  %-30s workgroups %6d   [1] %7.0f   [2] %7.0f   end %7.0f    (scene: [1] = candidates evaluated; text: [1] = operands there, taps requested, [2] = taps evaluated)" % (name, n, s_[1]/n, s_[2]/n, s_[3]/n))
 print("k_mid (speculative launches of 5 C4 solves; level mix 2,1,0), mean cycles per block from its start, by kind:")
 for kind, name in enumerate(("point blocks", "plane blocks", "pair blocks")):
     s = v[16 + 8*kind: 24 + 8*kind]; n = max(int(s[7]), 1)
