@@ -246,6 +246,12 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
     // flag, both poses, the plane, the corner, the keyframe's image pointer -- requested together by every thread BEFORE the flag is looked at (a request under a
     // lane-dependent branch is waited for at the end of that branch): one dependent round trip where there were three, and the image pointer is there when the
     // histogram needs it
+#ifdef MID_STAMPS                           // (tools/mid_stamps.sh: cycles of a mu / sigma workgroup by phase into W.dbg[56..63] -- the slots of k_schur_t's gradient rows in that build)
+    const long long us_t0 = clock64();
+#define MS_STAMP(slot) do { if (threadIdx.x == 0) atomicAdd((unsigned long long *)&W.dbg[56 + (slot)], (unsigned long long)(clock64() - us_t0)); } while (0)
+#else
+#define MS_STAMP(slot) do { } while (0)
+#endif
     const int4 ra = ((const int4 *)L.tg_rec)[2*g];
     const int tb = ra.x, kf = ra.y, j = ra.z, h = ra.w;
     const uint8_t good_t = W.tobs_good[tb];
@@ -260,6 +266,7 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
     for (int k = 0; k < 3; k++) th[k] = theta[3*j + k];
     mx = W.text_box[(j*4 + bq_)*2]; my = W.text_box[(j*4 + bq_)*2 + 1];
     if (W.filter_good && !good_t) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
+    MS_STAMP(0);                                              // (operands there)
     const int w = L.img_w, hh = L.img_h;
     __shared__ int s_c[16];
     if (tid < 4) {                                            // one box corner per lane (the serial walk over the four cost ~1.5 us of divisions)
@@ -294,12 +301,15 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
         if (yMax < 0) yMax = 0;
         s_bb[0] = xMin; s_bb[1] = xMax; s_bb[2] = yMin; s_bb[3] = yMax;
     }
+    MS_STAMP(1);                                              // (corners projected)
     for (int k = tid; k < min((w*hh + 31) >> 5, MS_MASK_WORDS); k += MS_THREADS) mask[k] = 0;
     hist[tid] = 0;
     __syncthreads();
     const int xMin = s_bb[0], xMax = s_bb[1], yMin = s_bb[2], yMax = s_bb[3];
+    MS_STAMP(2);                                              // (mask cleared)
     raster_quad(mask, s_xy, w, hh, tid, MS_THREADS);
     __syncthreads();
+    MS_STAMP(3);                                              // (quad rasterised)
     // histogram of masked pixels inside the clamped bounding box (tool.cc:1217-1232)
     int bw = xMax - xMin + 1, bh = yMax - yMin + 1;
     {   // four pixels per thread and round with their loads in flight together; (x, y) advance without a division per pixel
@@ -320,6 +330,7 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
         }
     }
     __syncthreads();
+    MS_STAMP(4);                                              // (histogram)
     double cnt = (double)hist[tid], sum = (double)hist[tid]*(double)tid;
     double n = block_sum<MS_THREADS>(cnt, s_red), sm = block_sum<MS_THREADS>(sum, s_red);
     if (n < 2.0) { if (tid == 0) { W.musig[2*tb] = 0; W.musig[2*tb+1] = 0; } return; }
@@ -327,6 +338,10 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
     double d = (double)tid - mu;
     double ss = block_sum<MS_THREADS>((double)hist[tid]*d*d, s_red);
     if (tid == 0) { W.musig[2*tb] = mu; W.musig[2*tb+1] = sqrt(ss/(n - 1.0)); }
+    MS_STAMP(5);
+#ifdef MID_STAMPS
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)&W.dbg[63], 1ull);
+#endif
 }
 
 __global__ __launch_bounds__(MS_THREADS) void k_musigma(Work W, LevelDev L) {
