@@ -307,7 +307,11 @@ __device__ __forceinline__ void musigma_wg(const Work &W, const LevelDev &L, con
     __syncthreads();
     const int xMin = s_bb[0], xMax = s_bb[1], yMin = s_bb[2], yMax = s_bb[3];
     MS_STAMP(2);                                              // (mask cleared)
+#ifdef MID_STAMPS
+    raster_quad(mask, s_xy, w, hh, tid, MS_THREADS, W.dbg + 48);
+#else
     raster_quad(mask, s_xy, w, hh, tid, MS_THREADS);
+#endif
     __syncthreads();
     MS_STAMP(3);                                              // (quad rasterised)
     // histogram of masked pixels inside the clamped bounding box (tool.cc:1217-1232)

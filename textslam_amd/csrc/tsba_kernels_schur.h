@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64*SCHUR_NW) void k_schur_t(Work W, LevelDev L, int
     constexpr int SCHUR_T = 64*SCHUR_NW;
 #ifdef MID_STAMPS                           // (make-time experiment, tools/mid_stamps.sh: cycles of a workgroup by kind -- diagonal S block, off-diagonal S block, gradient -- into W.dbg[40..63])
     const long long ss_t0 = clock64(); int ss_kind = 2;      // (kind 2's slots are shared with k_musigma's stamps: not recorded)
-#define SCHUR_STAMP(slot) do { if (threadIdx.x == 0 && ss_kind < 2) atomicAdd((unsigned long long *)&W.dbg[40 + 8*ss_kind + (slot)], (unsigned long long)(clock64() - ss_t0)); } while (0)
+#define SCHUR_STAMP(slot) do { if (threadIdx.x == 0 && ss_kind < 1) atomicAdd((unsigned long long *)&W.dbg[40 + 8*ss_kind + (slot)], (unsigned long long)(clock64() - ss_t0)); } while (0)
 #else
 #define SCHUR_STAMP(slot) do { } while (0)
 #endif

@@ -25,7 +25,8 @@ print("  pair blocks in detail: loads there %7.0f   lanes' sums met %7.0f   prod
 print("k_schur_t<4> (all launches), mean cycles per workgroup from its start, by kind:")
 s = v[56:64]; n = max(int(s[7]), 1)
 print("mu / sigma of a text observation (k_pass_begin / k_pass_end), mean cycles per workgroup: operands there %6.0f   corners projected %6.0f   mask cleared %6.0f   quad rasterised %6.0f   histogram %6.0f   end %6.0f   (%d workgroups)" % (s[0]/n, s[1]/n, s[2]/n, s[3]/n, s[4]/n, s[5]/n, n))
-for kind, name in enumerate(("diagonal S blocks", "off-diagonal S blocks")):
+print("   inside the quad's rasterisation (thread 0, cycles from its start): boundary lines %6.0f   edge slopes %6.0f   end of the scanline fill %6.0f" % (v[48]/n, v[49]/n, v[50]/n))
+for kind, name in enumerate(("diagonal S blocks",)):
     s = v[40 + 8*kind: 48 + 8*kind]; n = max(int(s[7]), 1)
     print("  %-22s workgroups %6d   decision taken %7.0f   slot pairs gathered %7.0f   waves' sums met %7.0f   end %7.0f" % (name, n, s[0]/n, s[1]/n, s[2]/n, s[3]/n))
 print("(clock64 at 100 MHz on gfx950? compare with the kernel's 10.4 us)")
