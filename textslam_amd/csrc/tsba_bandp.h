@@ -20,6 +20,9 @@
 #pragma once
 
 #define BANDP_MAXP 256
+#ifndef BANDP_T
+#define BANDP_T SOLVE_THREADS               // threads of k_bandp_factor (round 6: 512 = two waves per SIMD = 256 registers was tried against the 248 bytes per lane this kernel spills at 768 / 168 registers)
+#endif
 #ifndef BANDP_PW
 #define BANDP_PW 2                          // panel waves of k_bandp_factor
 #endif
@@ -111,7 +114,7 @@ __device__ __noinline__ void bandp_load_rows(double *Ag, const double *S, size_t
     // (arguments of a function arrive in vector registers: back to the scalar unit)
     const int r0 = __builtin_amdgcn_readfirstlane(r0_), first = __builtin_amdgcn_readfirstlane(first_), n = __builtin_amdgcn_readfirstlane(n_), nbr = __builtin_amdgcn_readfirstlane(nbr_),
               base = __builtin_amdgcn_readfirstlane(base_), gl0 = __builtin_amdgcn_readfirstlane(gl0_), bw = __builtin_amdgcn_readfirstlane(bw_), glim = __builtin_amdgcn_readfirstlane(glim_);
-    constexpr int NW = SOLVE_THREADS/64, LOAD_U = 4;
+    constexpr int NW = BANDP_T/64, LOAD_U = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int k = wave; k < nbr; k += NW) { lds_f64 *row = A + rowoff(n + k);
         for (int c = r0 + lane; c < n; c += 64) row[c] = 0.0;
@@ -121,7 +124,7 @@ __device__ __noinline__ void bandp_load_rows(double *Ag, const double *S, size_t
     lds_f64 *rhs = A + rowoff(n + nbr);
     double gv[2];
 #pragma unroll
-    for (int u = 0; u < 2; u++) { const int c = r0 + tid + u*SOLVE_THREADS; gv[u] = (c < n && base + c < glim) ? g[base + c] : 0.0; }
+    for (int u = 0; u < 2; u++) { const int c = r0 + tid + u*BANDP_T; gv[u] = (c < n && base + c < glim) ? g[base + c] : 0.0; }
     for (int rb = r0 + wave; rb < n; rb += NW*LOAD_U) {
         double v[LOAD_U][2];
 #pragma unroll
@@ -151,8 +154,8 @@ __device__ __noinline__ void bandp_load_rows(double *Ag, const double *S, size_t
         }
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) { const int c = r0 + tid + u*SOLVE_THREADS; if (c < n) rhs[c] = gv[u]; }
-    if (first) for (int k = tid; k < nbr; k += SOLVE_THREADS) rhs[n + k] = 0.0;
+    for (int u = 0; u < 2; u++) { const int c = r0 + tid + u*BANDP_T; if (c < n) rhs[c] = gv[u]; }
+    if (first) for (int k = tid; k < nbr; k += BANDP_T) rhs[n + k] = 0.0;
     __syncthreads();
 }
 // slide by s rows.  Virtual index v: band rows 0 .. m-1, border rows m .. mv-1, rhs row mv.  Row-wise through registers: a wave takes the
@@ -165,7 +168,7 @@ __device__ __noinline__ void bandp_slide(double *Ag, int n_, int n_new_, int m_,
     // (arguments of a function arrive in vector registers: back to the scalar unit)
     const int n = __builtin_amdgcn_readfirstlane(n_), n_new = __builtin_amdgcn_readfirstlane(n_new_), m = __builtin_amdgcn_readfirstlane(m_),
               s = __builtin_amdgcn_readfirstlane(s_), mv = __builtin_amdgcn_readfirstlane(mv_);
-    constexpr int NW = SOLVE_THREADS/64, SL_B = (2*(BAND_BW_MAX/2) + 6 + NW)/NW, SL_C = (2*(BAND_BW_MAX/2) + 6 + 127)/128;
+    constexpr int NW = BANDP_T/64, SL_B = (2*(BAND_BW_MAX/2) + 6 + NW)/NW, SL_C = (2*(BAND_BW_MAX/2) + 6 + 127)/128;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // two doubles per lane: rows start 16-byte aligned, s, m, n, n_new are even, so a pair never straddles the band / border boundary
     // (the second slot of a row's last pair is the row's padding)
@@ -200,7 +203,7 @@ __device__ __noinline__ void bandp_write_out(double *Ag, double *LDg, double *Lr
     typedef __attribute__((address_space(3))) v2d lds_v2d;
     const int jstart = __builtin_amdgcn_readfirstlane(jstart_), jend = __builtin_amdgcn_readfirstlane(jend_), base = __builtin_amdgcn_readfirstlane(base_),
               n = __builtin_amdgcn_readfirstlane(n_), nbr = __builtin_amdgcn_readfirstlane(nbr_), bw = __builtin_amdgcn_readfirstlane(bw_);
-    constexpr int NW = SOLVE_THREADS/64;
+    constexpr int NW = BANDP_T/64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int REC = bw*6, NR = n + nbr;
     for (int q = jstart + wave; q < jend; q += NW) {
@@ -234,12 +237,12 @@ __device__ __noinline__ void bandp_write_out(double *Ag, double *LDg, double *Lr
 // waves (58 rows each) take in two rounds.  Three panel waves (ONE round, nine update waves), measured twice in round 2 on the
 // 5000-keyframe map (cycle stamps of the factor loops of one interior): 484 k cycles against 448 k with two -- the step is bound by
 // the update waves (a third panel wave takes a SIMD's issue slots from them), not by the second panel round.
-__global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, int CB, int Pmax, double *Lrow, double *Lb, double *Tbuf) {
+__global__ __launch_bounds__(BANDP_T) void k_bandp_factor(Work W, int bw, int CB, int Pmax, double *Lrow, double *Lb, double *Tbuf) {
     LmState *st = W.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NW = SOLVE_THREADS/64, NT = NW - BANDP_PW;
+    constexpr int NW = BANDP_T/64, NT = NW - BANDP_PW;
     if (st->done || st->step_fail || st->lin_done) return;
     const int B = bw/6, nb = bandp_nb(W, B);
     if (nb == 0) return;
@@ -410,8 +413,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_bandp_factor(Work W, int bw, 
             double *T = Tbuf + (size_t)blockIdx.x*((size_t)nTm*nTm + nTm), *gT = T + (size_t)nTm*nTm;
             __syncthreads();
             auto realT = [&](int v) { return v < nR ? 6*jend + v : n + (v - nR); };
-            for (int e = tid; e < nT*nT; e += SOLVE_THREADS) { const int i = e/nT, j = e - i*nT; if (j <= i) T[(size_t)i*nTm + j] = A[rowoff(realT(i)) + realT(j)]; }
-            for (int i = tid; i < nT; i += SOLVE_THREADS) gT[i] = A[rowoff(NR) + realT(i)];
+            for (int e = tid; e < nT*nT; e += BANDP_T) { const int i = e/nT, j = e - i*nT; if (j <= i) T[(size_t)i*nTm + j] = A[rowoff(realT(i)) + realT(j)]; }
+            for (int i = tid; i < nT; i += BANDP_T) gT[i] = A[rowoff(NR) + realT(i)];
             break;
         }
         // ---------------- slide by s rows.  Virtual index v: band rows 0 .. m-1, border rows m .. m+nbr-1, rhs row m+nbr; ascending
