@@ -32,7 +32,9 @@ __device__ __forceinline__ void gauge_wave_body(const Work &W, const uint8_t *kf
     if (k == 0) { W.nfree[0] = __popcll(m_free); W.nfree[1] = 0; }
 }
 
+#ifndef PB_WG
 #define PB_WG 24                            // workgroups that walk k_participation's blocks in k_pass_begin
+#endif
 __global__ __launch_bounds__(MS_THREADS) void k_pass_begin(Work W, LevelDev L, double radius0, int max_it, const uint8_t *kf_initial, int state,
                                                            int npb, int nwg, int n_ms, LmState *log_prev, int *ticket) {
     const int b = blockIdx.x, tid = threadIdx.x;

@@ -1,0 +1,10 @@
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+cp textslam_amd/libtsba.so /tmp/libtsba_prod.so
+for v in prod pb48 pb72 pb128; do
+  if [ $v = prod ]; then cp /tmp/libtsba_prod.so textslam_amd/libtsba.so; else cp tools/bin/libtsba_$v.so textslam_amd/libtsba.so; fi
+  rm -rf /tmp/prof_$v; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o $v -- python $OLDPWD/tools/diag/gpu_c4_loop.py 20 > /tmp/run_$v.txt 2> /tmp/prof_$v.err )
+  echo "== $v: $(cat /tmp/run_$v.txt)"
+  python profiles/rocpd_top_kernels.py $(find /tmp/prof_$v -name "*.db" | head -1) 2>&1 | grep -E "k_pass_begin|k_pass_end"
+done
+cp /tmp/libtsba_prod.so textslam_amd/libtsba.so
