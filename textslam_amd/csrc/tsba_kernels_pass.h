@@ -33,7 +33,8 @@ __device__ __forceinline__ void gauge_wave_body(const Work &W, const uint8_t *kf
 }
 
 #ifndef PB_WG
-#define PB_WG 24                            // workgroups that walk k_participation's blocks in k_pass_begin
+#define PB_WG 128                           // workgroups that walk k_participation's blocks in k_pass_begin.  Round 6: 24 -> 128 (C4 level 0: 215 blocks, nine in turn per workgroup at ~2 us
+                                            // each were the kernel once mu / sigma stopped being it: 20.7 us at 24, 15.9 at 48, 14.4 at 72, 13.6 at 128; the ticket's 128 arrivals cost ~4 us of that)
 #endif
 __global__ __launch_bounds__(MS_THREADS) void k_pass_begin(Work W, LevelDev L, double radius0, int max_it, const uint8_t *kf_initial, int state,
                                                            int npb, int nwg, int n_ms, LmState *log_prev, int *ticket) {
