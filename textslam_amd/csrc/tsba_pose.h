@@ -371,7 +371,9 @@ __global__ __launch_bounds__(POSE_WG) void k_pose_pass(Work W, LevelDev L, tsba_
         // speculative linearisation at the candidate; after a failed step (no candidate) nobody looks at the sums, but everybody waits for them: zeros
         double tot = 0.0;
         if (!P.fail) tot = pose_sweep_obs(W, L, P.cand, O, b, nb_sc, lds);
-        if (tid < 28) pose_publish(&W.ppart[(size_t)((k % 3)*G + b)*28 + tid], tot);
+        // (release: this thread's NaN reset of the NEXT-BUT-ONE buffer above is visible before these sums are -- a reader that has seen everybody's sums of step k
+        // may then rely on the reset: nothing but timing ordered the two relaxed stores before; round-5 advisor.  The reset was issued a whole sweep ago: the fence waits for nothing)
+        if (tid < 28) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); pose_publish(&W.ppart[(size_t)((k % 3)*G + b)*28 + tid], tot); }
     }
     if (b == 0 && tid == 0) W.pst[0] = P;                    // (k_outlier installs it)
 }
