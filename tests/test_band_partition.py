@@ -221,6 +221,34 @@ def test_plan_does_not_depend_on_the_number_of_host_threads():
                 assert L.tsba_debug_plan_checksum_recycled(C.byref(sw), C.byref(ow), lw, tw, C.byref(sn), C.byref(on), ln, tn) == fresh
 
 
+def test_single_frame_plan_is_the_generic_plan():
+    """tsba_pose_optim's problems (one frame, every landmark frozen in a host outside it) get their plan from build_plan_single_frame -- the lists written
+    down directly on the calling thread -- instead of build_plan's generic passes on plan threads: every list must be the one the generic builder makes
+    (checksum over every list of the plan, per level; with / without text planes, without scene observations, into a recycled plan object)."""
+    from textslam_amd import synth, abi
+    from textslam_amd.optimizer import load_library
+    L = load_library()
+    L.tsba_debug_plan_checksum.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int]; L.tsba_debug_plan_checksum.restype = C.c_ulonglong
+    L.tsba_debug_plan_checksum_single_frame.argtypes = [C.POINTER(abi.TsbaProblem), C.POINTER(abi.TsbaOptions), C.c_int, C.c_int]; L.tsba_debug_plan_checksum_single_frame.restype = C.c_ulonglong
+    o = abi.options_pose(); o_nt = abi.options_pose(); o_nt.use_text = 0
+    cases = [(synth.config_c3(), o), (synth.config_c3(seed=5), o_nt),
+             (synth.make_problem(1, 40, 3, 11, feats=(8, 6, 4), frozen_frac=1.0, n_out=2, max_targets=1, text_targets=1), o),
+             (synth.make_problem(1, 200, 0, 12, frozen_frac=1.0, max_targets=1), o)]
+    seen = set()
+    for P, oo in cases:
+        s = P.struct()
+        for lvl in range(P.n_levels):
+            ref = L.tsba_debug_plan_checksum(C.byref(s), C.byref(oo), lvl, 1)
+            assert ref != 0
+            for recycled in (0, 1):
+                assert L.tsba_debug_plan_checksum_single_frame(C.byref(s), C.byref(oo), lvl, recycled) == ref, (lvl, recycled)
+            seen.add(ref)
+    assert len(seen) >= 9
+    # not such a problem: a window, a frame with a landmark hosted in it
+    W = synth.tiny(); sw = W.struct()
+    assert L.tsba_debug_plan_checksum_single_frame(C.byref(sw), C.byref(abi.options_local()), 0, 0) == 0
+
+
 @pytest.mark.parametrize("nf,row0,B,Gmax,Ptmax", [(598, 199, 8, 16, 8), (4998, 1499, 10, 128, 55), (1498, 299, 7, 64, 16), (898, 449, 8, 32, 32), (300, 60, 9, 8, 8), (1498, 999, 7, 16, 40)])
 def test_ring_partition_with_a_tail(lib, nf, row0, B, Gmax, Ptmax):
     """[tail: interior, sep, ..., interior][S][loop: interior, sep, ..., interior][ghost of S]: the interiors and separators tile the rows, the

@@ -190,11 +190,20 @@ static int slab_take(Ctx *c, size_t bytes, int *slab, size_t *off) {
         c->slabs.push_back(sl);
     }
 }
+// A piece that receives no host data (an allocation, an empty list) right behind the pending run of staged bytes: when it is small the run goes on across it --
+// zeros in the pinned mirror, which is what the slab's clearing left on the device -- instead of ending there.  Round 6 (rocprofv3 timeline of a one-shot
+// tsba_pose_optim call): a single-frame plan has some thirty empty lists, each of them cut the run, and the call left as ~30 copies of a few hundred bytes
+// (3 - 4 us of host time and 5 - 10 us of device time EACH, one after the other in front of the first kernel) instead of three.
+#define RUN_BRIDGE ((size_t)32 << 10)
+static void run_bridge(Ctx *c, int si, size_t off, size_t bytes) {
+    Slab &sl = c->slabs[si];
+    if (c->run_len && c->run_slab == si && c->run_off + c->run_len == off && bytes <= RUN_BRIDGE && sl.host) { memset(sl.host + off, 0, bytes); c->run_len += bytes; }
+}
 template <typename T>
 static int dev_alloc(Ctx *c, T **out, size_t n) {
     const size_t bytes = (std::max<size_t>(n, 1)*sizeof(T) + 255) & ~(size_t)255;
     int si; size_t off; int rc = slab_take(c, bytes, &si, &off); if (rc) return rc;
-    *out = (T *)(c->slabs[si].dev + off); return 0;
+    *out = (T *)(c->slabs[si].dev + off); run_bridge(c, si, off, bytes); return 0;
 }
 template <typename T>
 static int dev_upload(Ctx *c, const T **out, const T *src, size_t n) {
@@ -202,7 +211,7 @@ static int dev_upload(Ctx *c, const T **out, const T *src, size_t n) {
     int si; size_t off; int rc = slab_take(c, bytes, &si, &off); if (rc) return rc;
     Slab &sl = c->slabs[si];
     *out = (const T *)(sl.dev + off);
-    if (!n || !src) return 0;
+    if (!n || !src) { run_bridge(c, si, off, bytes); return 0; }
     if (!sl.host) { hipError_t e = hipHostMalloc((void **)&sl.host, sl.size, hipHostMallocDefault);
         if (e != hipSuccess) { set_err(c, std::string("hipHostMalloc: ") + hipGetErrorString(e)); return TSBA_ERR_DEVICE; } }
     if (c->run_len && (c->run_slab != si || c->run_off + c->run_len != off)) flush_run(c);
@@ -418,7 +427,10 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     int n_lev_used = 0; { std::vector<char> sn(p->n_levels, 0); for (int q = 0; q < o->n_passes; q++) if (!sn[o->levels[q]]) { sn[o->levels[q]] = 1; n_lev_used++; } }
     const bool small_window = solve_lds_doubles(W.N)*sizeof(double) <= 160*1024 - 64;
     // (round 6: also the single-frame problems of tsba_pose_optim -- the plans of the later passes' levels are built and staged while the first pass runs)
-    const bool defer = lazy && small_window && n_lev_used > 1 && !is_multi(c);
+    // (round 6: a single-frame problem with every landmark frozen -- tsba_pose_optim, per frame -- has a plan that is a copy of its input: written down directly
+    // on this thread for every level (build_plan_single_frame, microseconds), no plan threads, every level staged before the solve)
+    const bool single_frame = plan_is_single_frame(p, o) && c->dbg.host_pair_lists != 1;
+    const bool defer = lazy && small_window && n_lev_used > 1 && !is_multi(c) && !single_frame;
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) { c->plan_done[l].store(0); c->lev_wait[l] = 0; }
     {   auto tp0 = std::chrono::steady_clock::now();
         std::vector<char> seen(p->n_levels, 0);
@@ -439,6 +451,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
             std::atomic<int> *done = &c->plan_done[l];
             // the levels of the later passes first (the largest plans); a deferring call builds the first pass's (small) plan on this thread:
             // it is needed at once, and a thread's start costs as much as that plan
+            if (single_frame) { build_plan_single_frame(p, o, l, *H); done->store(1); continue; }
             if (defer && ps == 0) { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs); done->store(1); continue; }
             planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs, done]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs); done->store(1, std::memory_order_release); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
@@ -732,7 +745,7 @@ static int stage_level(Ctx *c, const tsba_problem *p, int l, double *t_plan, dou
         D.img = (const uint8_t *const *)dptr;
     }
     if (t_img) *t_img += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
-    flush_run(c);
+    if (c->stage_async || H.dev_pt_pairs >= 0) flush_run(c);        // (a level staged with the upload: its bytes leave with the upload's last copy -- one copy for all levels of a single-frame call)
     if (H.dev_pt_pairs >= 0 && D.n_sb > 0) {                       // (after the copies it reads, on the stream they went over)
         hipStream_t sq = c->stage_async && c->copy_stream ? c->copy_stream : c->stream;
         hipMemsetAsync(dp_off, 0, sizeof(int)*((size_t)D.n_sb + 2), sq);
@@ -1735,7 +1748,7 @@ static unsigned long long plan_checksum(const HostPlan &H) {           // over E
     for (const std::vector<int32_t> *v : { &H.kf_order, &H.sc_obs, &H.sc_kf, &H.sc_pt, &H.sc_flag, &H.sc_slot, &H.pair_i, &H.pair_h, &H.pair_hpos, &H.pair_sc_off, &H.pair_tg_off, &H.pair_tg,
                                            &H.tg_tobs, &H.tg_kf, &H.tg_text, &H.tg_pair, &H.tg_slot, &H.pt_pose6, &H.pt_pair4, &H.tx_pair8, &H.tg_ppos, &H.pf_g, &H.pf_f, &H.tg_rec,
                                            &H.pls_off, &H.pslot_pose, &H.pslot_pair, &H.pslot_lm, &H.tls_off, &H.tslot_pose, &H.tslot_pair, &H.tslot_lm, &H.sb_pab, &H.sb_pba,
-                                           &H.pose_t_off, &H.pose_t, &H.pose_h_off, &H.pose_h, &H.pose_ps_off, &H.pose_ps, &H.pose_ps_lm, &H.pose_ts_off, &H.pose_ts, &H.pose_ts_lm }) mix(*v);
+                                           &H.pose_t_off, &H.pose_t, &H.pose_h_off, &H.pose_h, &H.pose_ps_off, &H.pose_ps, &H.pose_ps_lm, &H.pose_ts_off, &H.pose_ts, &H.pose_ts_lm, &H.sb_rng }) mix(*v);
     if (H.far_B > 0) { h ^= (unsigned long long)H.far_B; h *= 1099511628211ull;
         for (const std::vector<int32_t> *v : { &H.far_a, &H.far_b, &H.far_off, &H.far_ent, &H.fb_id, &H.fb_pab, &H.fb_pba, &H.fb_pt_off, &H.fb_pt_s1, &H.fb_pt_s2, &H.fb_pt_lm, &H.fb_tx_off, &H.fb_tx_s1, &H.fb_tx_s2, &H.fb_tx_lm }) mix(*v); }
     for (double x : H.sc_uv) { unsigned long long u; memcpy(&u, &x, 8); h ^= u; h *= 1099511628211ull; }
@@ -1748,6 +1761,14 @@ unsigned long long tsba_debug_plan_checksum(const tsba_problem *p, const tsba_op
     const int saved = tsba_plan_threads; tsba_plan_threads = threads;
     HostPlan H; build_plan(p, o, level, H, false, true, tsba_plan_checksum_ring);
     tsba_plan_threads = saved;
+    return plan_checksum(H);
+}
+// the plan of a single-frame problem (every landmark frozen) as build_plan_single_frame writes it down: the same checksum as tsba_debug_plan_checksum's; 0: not such a problem.
+// recycled != 0: into a plan object that held the generic plan of the same problem's level 0 before
+unsigned long long tsba_debug_plan_checksum_single_frame(const tsba_problem *p, const tsba_options *o, int level, int recycled) {
+    if (!p || !o || level < 0 || level >= p->n_levels || !plan_is_single_frame(p, o)) return 0;
+    HostPlan H; if (recycled) build_plan(p, o, 0, H);
+    build_plan_single_frame(p, o, level, H);
     return plan_checksum(H);
 }
 // the plan of (p, o, level) built into a plan object that held the plan of (warm, ow, warm_level) before -- as a context does from call to call

@@ -452,10 +452,12 @@ __device__ __forceinline__ void wave_sum_groups16_mw(const double *acc, double *
 // dozen scene blocks (thousands of keyframes: a 64-lane wave per pair was 85 % idle), eight pairs, one per 16-lane group; a text workgroup one (KF, text)
 // observation with every feature on TWO lanes (4 taps each): the text lanes' instruction stream (~450 instructions per tap at
 // one instruction per ~4.5 cycles) is what bounds the kernel.  <= 256 VGPRs so that all ~730 workgroups of C4 are resident at once.
+#ifndef LIN_TPL
 #define LIN_TPL 4                        // photometric taps per lane: a feature's 8 taps sit on 8 / LIN_TPL neighbouring lanes.  4 = two lanes per
                                          // feature, 128-thread workgroups.  2 (four lanes per feature, 256 threads) was measured in round 2: the C4
                                          // level-0 launch went from 12.6 to 14.8 us -- the 55-value workgroup reduction is paid per wave, and
                                          // halving a lane's tap loop does not pay for twice the waves
+#endif
 #define LIN_T (64*(8/LIN_TPL))           // 64 features per text workgroup
 #define LIN_NWV (LIN_T/64)
 #define MID_U 4                          // slot records of a point that k_mid keeps in flight per round trip
@@ -1014,7 +1016,7 @@ __device__ __forceinline__ void mid_block(const Work &W, const LevelDev &L, cons
     if (tid == 0 && spec) atomicAdd((unsigned long long *)&W.dbg[16 + 8*ms_kind + 7], 1ull);      // blocks counted
 #endif
 }
-#define MID_TW 128
+#define MID_TW LIN_T                         // (128 with LIN_TPL = 4)
 template <int NT, int U, int PR>
 __global__ __launch_bounds__(NT) void k_mid(Work W, LevelDev L, int nb_pt, int nb_tx, int spec) {
     __shared__ double red[NT < 80 ? 80 : NT];

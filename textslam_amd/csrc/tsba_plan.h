@@ -282,6 +282,43 @@ struct BucketPlacer {
     int next(int t, size_t &e) { const int k = kc[t][e++]; return k < 0 ? -1 : hist[t][(size_t)k]++; }
 };
 
+// The plan of a SINGLE-FRAME problem whose landmarks are all frozen in hosts outside it (optimizer::PoseOptim, optimizer.cc:135-195 -- the call the tracking
+// thread makes per frame): one (target, frozen host) pair, every observation a candidate in its own order, no landmark slot, one diagonal block.  build_plan
+// arrives at exactly these lists through its generic passes (candidate keys, bucket placements, slot pairs: 0.03 - 0.07 ms per level, on threads of their own in
+// a one-shot call); here they are written down directly -- a copy of the input arrays -- in a few microseconds on the calling thread, so that a one-shot
+// tsba_pose_optim call plans and stages all its levels before the solve (round 6; tests/test_band_partition.py compares the checksum over every list with build_plan's).
+inline bool plan_is_single_frame(const tsba_problem *p, const tsba_options *o) {
+    if (p->n_kf != 1 || o->lm_nshard > 1) return false;
+    for (int j = 0; j < p->n_pt; j++) if (p->pt_host[j] >= 0) return false;
+    for (int j = 0; j < p->n_text; j++) if (p->text_host[j] >= 0) return false;
+    return true;
+}
+inline void build_plan_single_frame(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P) {
+    P.recycle(); P.level = L;
+    const int n_pt = p->n_pt, n_text = p->n_text, n_sc = p->n_sobs[L], n_tg = o->use_text ? p->n_tobs : 0, n_pair = (n_sc > 0 || n_tg > 0) ? 1 : 0;
+    if (n_pair) { P.pair_i.assign(1, 0); P.pair_h.assign(1, -1); P.pair_hpos.assign(1, -1); }
+    P.pair_sc_off.assign((size_t)n_pair + 1, 0); P.pair_tg_off.assign((size_t)n_pair + 1, 0);
+    if (n_pair) { P.pair_sc_off[1] = n_sc; P.pair_tg_off[1] = n_tg; }
+    P.sc_obs.resize((size_t)n_sc); P.sc_kf.resize((size_t)n_sc); P.sc_pt.resize((size_t)n_sc); P.sc_flag.resize((size_t)n_sc); P.sc_slot.assign((size_t)n_sc, -1); P.sc_uv.resize(2*(size_t)n_sc);
+    for (int c = 0; c < n_sc; c++) { P.sc_obs[(size_t)c] = c; P.sc_kf[(size_t)c] = p->sobs_kf[L][c]; P.sc_pt[(size_t)c] = p->sobs_pt[L][c]; P.sc_flag[(size_t)c] = p->sobs_flag[L][c]; }
+    if (n_sc > 0) memcpy(P.sc_uv.data(), p->sobs_uv0[L], 2*(size_t)n_sc*sizeof(double));
+    P.tg_tobs.resize((size_t)n_tg); P.tg_kf.resize((size_t)n_tg); P.tg_text.resize((size_t)n_tg); P.tg_pair.assign((size_t)n_tg, 0); P.tg_slot.assign((size_t)n_tg, -1);
+    P.pair_tg.resize((size_t)n_tg); P.tg_ppos.resize((size_t)n_tg); P.tg_rec.resize(8*(size_t)n_tg);
+    for (int g = 0; g < n_tg; g++) { const int j = p->tobs_text[g];
+        P.tg_tobs[(size_t)g] = g; P.tg_kf[(size_t)g] = p->tobs_kf[g]; P.tg_text[(size_t)g] = j; P.pair_tg[(size_t)g] = g; P.tg_ppos[(size_t)g] = g;
+        int32_t *r = &P.tg_rec[8*(size_t)g];
+        r[0] = g; r[1] = p->tobs_kf[g]; r[2] = j; r[3] = p->text_host[j]; r[4] = -1;
+        r[5] = p->tfeat_off[L] ? p->tfeat_off[L][j] : 0; r[6] = p->tfeat_off[L] ? p->tfeat_off[L][j+1] : 0; r[7] = p->tobs_fgood_off[g];
+        for (int f = r[5]; f < r[6]; f++) { P.pf_g.push_back(g); P.pf_f.push_back(f); } }
+    P.pls_off.assign((size_t)n_pt + 1, 0); P.tls_off.assign((size_t)n_text + 1, 0);
+    P.pt_pose6.assign(6*(size_t)n_pt, 0); P.pt_pair4.assign(6*(size_t)n_pt, 0); P.tx_pair8.assign(8*(size_t)n_text, 0);
+    P.sb_a.assign(1, 0); P.sb_b.assign(1, 0); P.sb_pab.assign(1, -1); P.sb_pba.assign(1, -1);
+    P.sb_pt_off.assign(2, 0); P.sb_tx_off.assign(2, 0);
+    P.pose_t_off.assign(2, 0); P.pose_t_off[1] = n_pair; if (n_pair) P.pose_t.assign(1, 0);
+    P.pose_h_off.assign(2, 0); P.pose_ps_off.assign(2, 0); P.pose_ts_off.assign(2, 0);
+    P.sb_rng.assign(4, 0); P.sb_rng[1] = n_pair;
+}
+
 // far_max_blocks > 0: maps whose envelope no band solver reaches may be split into a band of at most far_max_blocks pose blocks + long-range
 // blocks (HostPlan::far_B); far_force: take the split whenever the map is eligible, without trying the keyframe reordering first
 inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, HostPlan &P, bool dbg_plan = false, bool allow_reorder = true, int ring_max_blocks = 0,
