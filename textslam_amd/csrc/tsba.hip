@@ -432,6 +432,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
     const bool single_frame = plan_is_single_frame(p, o) && c->dbg.host_pair_lists != 1;
     const bool defer = lazy && small_window && n_lev_used > 1 && !is_multi(c) && !single_frame;
     for (int l = 0; l < TSBA_MAX_LEVELS; l++) { c->plan_done[l].store(0); c->lev_wait[l] = 0; }
+    std::function<void()> first_plan;
     {   auto tp0 = std::chrono::steady_clock::now();
         std::vector<char> seen(p->n_levels, 0);
         const int n_lev = n_lev_used;
@@ -452,7 +453,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
             // the levels of the later passes first (the largest plans); a deferring call builds the first pass's (small) plan on this thread:
             // it is needed at once, and a thread's start costs as much as that plan
             if (single_frame) { build_plan_single_frame(p, o, l, *H); done->store(1); continue; }
-            if (defer && ps == 0) { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs); done->store(1); continue; }
+            if (defer && ps == 0) { first_plan = [=]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs); done->store(1); }; continue; }    // (built below, behind the problem arrays' copy)
             planners[l] = std::thread([p, o, l, H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs, done]() { build_plan(p, o, l, *H, tdbg, reorder, ring_max, far_max, far_force, dev_pairs); done->store(1, std::memory_order_release); }); }
         t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     }
@@ -526,6 +527,10 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         }
     }
     // ---- per-level plans
+    if (first_plan) {                              // a deferring call: the first pass's plan on this thread, while the problem arrays (and a new keyframe's planes) cross the bus
+        flush_run(c);
+        auto tp0 = std::chrono::steady_clock::now(); first_plan();
+        t_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); }
     size_t mx_pair = 1, mx_tg = 1, mx_pslot = 1, mx_tslot = 1, mx_cnt = 1;
     for (int ps = 0; ps < o->n_passes; ps++) {
         const int l = o->levels[ps]; if (c->lev_built[l]) continue;
