@@ -615,7 +615,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
                 // 18.6 / 18.0 / 18.8 (150: an eighth level)
                 double best = 1e300; int bestP = P;
                 for (int q = 4; q <= BANDP_MAXP; q++) {
-                    if ((p->n_kf - (q - 1)*Bq)/q < 2*Bq + 8) break;          // (the kernels need 2 B + 2 blocks per interior)
+                    if ((p->n_kf - (q - 1)*Bq)/q < 2*Bq + 2) break;          // (the kernels need 2 B + 2 blocks per interior; until round 6 this loop stopped at 2 B + 8 -- C5: 11 interiors, 9.39 ms; 13: 8.76 ms, tools/diag/gpu_sweep_parts.py)
                     int lev = 1; for (int hh = 1; hh < q - 1; hh <<= 1) lev++;
                     const double cost = (double)p->n_kf/q*t_f + 45.0*lev;
                     if (cost < best) { best = cost; bestP = q; }
