@@ -6,12 +6,12 @@
 #      the CPU tests here; with a GPU (argument "gpu") also the GPU parity tests, i.e. real uploads / solves through the instrumented host
 #      code (device code is not instrumented: gfx950 ASan needs xnack, which this pool does not enable);
 #   4. the plan builder's host threads under clang TSan.
-# Usage: bash tools/sanitize.sh [gpu | gpuonly]   -> gpurun_out/r05_sanitizers.log (summary lines "SANITIZE <what>: <result>"); gpuonly: just the GPU leg
-# of part 3 into gpurun_out/r05_sanitizers_gpu.log (the CPU parts do not need the GPU box)
+# Usage: bash tools/sanitize.sh [gpu | gpuonly]   -> gpurun_out/r06_sanitizers.log (summary lines "SANITIZE <what>: <result>"); gpuonly: just the GPU leg
+# of part 3 into gpurun_out/r06_sanitizers_gpu.log (the CPU parts do not need the GPU box)
 set -u
 cd "$(dirname "$0")/.."
 MODE=${1:-}
-OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/r05_sanitizers.log; [ "$MODE" = "gpuonly" ] && LOG=$OUT/r05_sanitizers_gpu.log; : > $LOG
+OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/r06_sanitizers.log; [ "$MODE" = "gpuonly" ] && LOG=$OUT/r06_sanitizers_gpu.log; : > $LOG
 GASAN=$(gcc -print-file-name=libasan.so); GUBSAN=$(gcc -print-file-name=libubsan.so)
 CASAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=0:halt_on_error=0
