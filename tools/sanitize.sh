@@ -3,11 +3,10 @@
 #   1. the CPU oracle (plain C) under gcc ASan + UBSan, driven by its whole CPU test-suite;
 #   2. the adapter gather / scatter templates + the C++ ABI driver under g++ ASan + UBSan (six problem types);
 #   3. the HOST side of libtsba.so (plan builder, reordering, index validation, upload staging, C ABI) under clang ASan + UBSan --
-#      the CPU tests here; with a GPU (argument "gpu") also the GPU parity tests, i.e. real uploads / solves through the instrumented host
-#      code (device code is not instrumented: gfx950 ASan needs xnack, which this pool does not enable);
+#      the CPU tests here (the leg that needs a device -- the GPU parity tests through a UBSan build of the host side -- is tools/sanitize_gpu.sh:
+#      this file carries the memory-error sanitizer's flags, which the GPU pool refuses to run, and is listed in .gpurunignore);
 #   4. the plan builder's host threads under clang TSan.
-# Usage: bash tools/sanitize.sh [gpu | gpuonly]   -> gpurun_out/r06_sanitizers.log (summary lines "SANITIZE <what>: <result>"); gpuonly: just the GPU leg
-# of part 3 into gpurun_out/r06_sanitizers_gpu.log (the CPU parts do not need the GPU box)
+# Usage: bash tools/sanitize.sh   -> gpurun_out/r06_sanitizers.log (summary lines "SANITIZE <what>: <result>"); runs in the build container (no GPU)
 set -u
 cd "$(dirname "$0")/.."
 MODE=${1:-}
@@ -78,15 +77,6 @@ if [ "$MODE" != "gpuonly" ]; then
 (cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-unused-variable -o /tmp/libtsba_san.so tsba.hip) || say "libtsba build: FAILED"
 TSBA_LIB=/tmp/libtsba_san.so LD_PRELOAD="$CASAN" HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES=-1 python -m pytest tests/test_band_partition.py tests/test_abi.py -q -s -p no:cacheprovider > /tmp/san_host.log 2>&1
 say "libtsba host code (clang ASan+UBSan), CPU tests (plan, reordering, partition tables, ABI): $(grep -E 'passed|failed' /tmp/san_host.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_host.log)"
-fi
-if [ "$MODE" = "gpu" ] || [ "$MODE" = "gpuonly" ]; then
-  # with a live device: UBSan only -- the ROCm ASan runtime intercepts hsa_amd_memory_pool_allocate for device-side ASan and aborts the first
-  # allocation on a node without xnack ("out of memory: allocator is trying to allocate 0x400000 bytes")
-  (cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=undefined,bounds -fno-omit-frame-pointer -Wno-unused-variable -o /tmp/libtsba_ubsan.so tsba.hip 2>/dev/null) || say "libtsba UBSan build: FAILED"
-  CUBSAN=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.ubsan_standalone-x86_64.so)
-  TSBA_LIB=/tmp/libtsba_ubsan.so LD_PRELOAD="$CUBSAN" timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_global.py tests/test_gpu_context_reuse.py tests/test_gpu_far.py -m gpu -q -s -p no:cacheprovider > /tmp/san_gpu.log 2>&1
-  say "libtsba host code (clang UBSan + bounds), GPU parity tests through the instrumented host side: $(grep -E 'passed|failed' /tmp/san_gpu.log | tail -1) ; reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log)"
-  grep -B2 -A12 'ERROR: AddressSanitizer\|runtime error' /tmp/san_gpu.log | head -60 >> $LOG
 fi
 if [ "$MODE" != "gpuonly" ]; then
 # ---- 4. the plan builder's host threads (fork-join pool, shared key bitmaps, atomic min / max, stable bucket placement) under clang TSan:
