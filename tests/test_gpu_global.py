@@ -484,6 +484,29 @@ def test_schur_lists_built_on_the_device_equal_the_host_lists(gpu, kw):
     assert r1["cost1"][0] < 0.5*r1["cost0"][0]
 
 
+@pytest.mark.parametrize("shape", ["c4", "tiny", "init_pair", "window31"])
+def test_schur_lists_built_on_the_device_equal_the_host_lists_on_windows(gpu, shape):
+    """Round 6: windows take the device-built slot pairs as well (they are the largest part of the plan a one-shot tsba_local_ba call builds on its calling thread).  Same entries
+    in the same order as the host lists: the whole three-pass solve -- poses, inverse depths, planes, flags, costs -- is the same bits, through the one-shot call (levels of the
+    later passes staged over the copy stream while the first pass runs) and through upload + solve."""
+    P = {"c4": synth.config_c4, "tiny": synth.tiny, "init_pair": synth.init_pair, "window31": lambda: synth.make_problem(31, 2500, 20, 77, feats=(16, 8, 6))}[shape]()
+    o = abi.options_init() if shape == "init_pair" else abi.options_local()
+    outs = []
+    try:
+        for mode in (1, 0):
+            gpu.debug_set(host_pair_lists=mode)
+            G = P.copy(); r = gpu.LocalBundleAdjustment(G, options=o)
+            gpu.upload(P, o); r2 = gpu.solve(); G2 = gpu.download(P.copy())
+            outs.append((G, r, G2, r2))
+    finally:
+        gpu.debug_set()
+    (Ga, ra, Ga2, ra2), (Gb, rb, Gb2, rb2) = outs
+    for X, Y in ((Ga, Gb), (Ga2, Gb2), (Ga, Gb2)):
+        assert np.array_equal(X.pose, Y.pose) and np.array_equal(X.rho, Y.rho) and np.array_equal(X.theta, Y.theta)
+        assert np.array_equal(X.sgood, Y.sgood) and np.array_equal(X.tobs_good, Y.tobs_good) and np.array_equal(X.tfgood, Y.tfgood)
+    assert ra["iters"] == rb["iters"] == rb2["iters"] and ra["cost1"] == rb["cost1"] == rb2["cost1"] and ra["accepted"] == rb["accepted"]
+
+
 @pytest.mark.parametrize("name,variants", [
     ("mid_global_long_range", [dict(far_solver=2), dict(far_solver=3, pcg_block=1), dict(far_solver=1), dict(far_solver=1, no_band_stream=1)]),
     ("mid_global_ring", [dict(), dict(no_ring=1), dict(no_ring=1, no_kf_reorder=1)]),

@@ -442,7 +442,10 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         // maps with long-range coupling (several loop closures, points seen again much later): band + blocks outside it, preconditioned conjugate gradients
         const int far_max = (n_lev == 1 && c->dbg.far_solver != 1 && !c->dbg.no_band_stream && (!c->dbg.no_ring || c->dbg.far_solver >= 2)) ? CR_SMAX/6 : 0;     // (no_ring asks for the reordering path)
         const bool far_force = c->dbg.far_solver == 2 || c->dbg.far_solver == 3;
-        const bool dev_pairs = p->n_kf > (c->dbg.host_pair_lists == 2 ? 1 : 126) && c->dbg.host_pair_lists != 1;      // large maps: the point slot pairs by S block are built on the device (tsba_devplan.h)
+        // the point slot pairs by S block are built on the device (tsba_devplan.h) -- since round 4 on maps of more than 126 keyframes (2 M pairs: 9 of the plan's 21 ms), since round 6 on
+        // windows as well: they are the largest part of a window's plan (C4 level 2: 0.18 of 0.5 ms on the calling thread of a one-shot call, level 0: 0.7 of 1.5 ms), the three small
+        // launches that build them cost the pass ~15 us, the lists are the same entries in the same order (same bits: test_schur_lists_built_on_the_device_equal_the_host_lists)
+        const bool dev_pairs = p->n_kf > 1 && c->dbg.host_pair_lists != 1;
         for (int ps = o->n_passes - 1; ps >= 0; ps--) { const int l = o->levels[ps]; if (seen[l]) continue;
             bool later = false; for (int q = 0; q < ps; q++) later |= o->levels[q] == l;       // (a level used by an earlier pass is started with that pass)
             if (later) continue;
