@@ -286,13 +286,14 @@ int tsba_debug_plan_band(const tsba_problem *p, const tsba_options *o, int level
     if (order_out) for (int k = 0; k < p->n_kf; k++) order_out[k] = H.kf_order.empty() ? k : H.kf_order[(size_t)k];
     return TSBA_OK;
 }
+static int tsba_plan_time_dev_pairs = 0;    // (tsba_debug_plan_knob 4) tsba_debug_plan_time builds the plan as an upload does since round 6: the point slot pairs left to the device
 int tsba_debug_plan_time(const tsba_problem *p, const tsba_options *o, int level, int reps, double *avg_ms) {   // host only: plan construction
     if (!p || !o || reps == 0) return TSBA_ERR_ARG;
     const bool laps = reps < 0; if (laps) reps = -reps;           // reps < 0: one recycled plan object (as a context does), lap times of the last build on stderr
     HostPlan R;
     if (laps) build_plan(p, o, level, R, false, true, CR_SMAX/6);
     auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < reps; k++) { if (laps) build_plan(p, o, level, R, k == reps - 1, true, CR_SMAX/6); else { HostPlan H; build_plan(p, o, level, H); } }
+    for (int k = 0; k < reps; k++) { if (laps) build_plan(p, o, level, R, k == reps - 1, true, CR_SMAX/6, 0, false, tsba_plan_time_dev_pairs != 0); else { HostPlan H; build_plan(p, o, level, H, false, true, 0, 0, false, tsba_plan_time_dev_pairs != 0); } }
     *avg_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()/reps;
     return TSBA_OK;
 }
@@ -337,4 +338,4 @@ int tsba_debug_band_factor(void *ctx, double *lcol, long long n_lcol, double *ld
 // host-only: FNV-1a over the Schur slot-pair lists of the plan of `level`, built with `threads` host threads in the parallel sections
 // (0 = the production choice): the plan must not depend on the number of threads
 static int tsba_plan_checksum_ring = 0;       // ring_max_blocks the checksum hook builds its plan with (knob 2)
-void tsba_debug_plan_knob(int which, int value) { if (which == 0) tsba_plan_threads = value; else if (which == 1) tsba_plan_mark_mt = value; else if (which == 2) tsba_plan_checksum_ring = value; else if (which == 3) tsba_plan_pin = value; }   // host-only measurement knobs
+void tsba_debug_plan_knob(int which, int value) { if (which == 0) tsba_plan_threads = value; else if (which == 1) tsba_plan_mark_mt = value; else if (which == 2) tsba_plan_checksum_ring = value; else if (which == 3) tsba_plan_pin = value; else if (which == 4) tsba_plan_time_dev_pairs = value; }   // host-only measurement knobs
