@@ -119,6 +119,32 @@ def test_pose_optim_parity_c3(gpu, oracle_lib):
     assert np.abs(G.pose - P.truth["pose"]).max() < np.abs(P.pose - P.truth["pose"]).max()
 
 
+@pytest.mark.parametrize("shape", ["c3", "no_text", "no_text_planes", "small"])
+def test_pose_optim_call_with_the_single_frame_plan_agrees(gpu, oracle_lib, shape):
+    """The per-frame tsba_pose_optim call writes its plan down on the calling thread (build_plan_single_frame), stages every level with the upload and leaves as one
+    host-to-device copy (round 6); tsba_debug_options.host_pair_lists = 1 takes the generic builder on plan threads with the later levels staged during the solve (until
+    round 6).  Same lists (tests/test_band_partition.py compares their checksums on the CPU), so the same bits -- one-shot, repeated on the same context, and against the oracle."""
+    if shape == "c3": P, o = synth.config_c3(), abi.options_pose()
+    elif shape == "no_text": P, o = synth.config_c3(seed=5), abi.options_pose(); o.use_text = 0
+    elif shape == "no_text_planes":
+        P, o = synth.make_problem(1, 400, 0, 12, frozen_frac=1.0, max_targets=1), abi.options_pose()
+        if P.n_levels < 3: o.n_passes = 1; o.levels[0] = 0                     # (a map without planes is built with one level)
+    else: P, o = synth.make_problem(1, 40, 3, 11, feats=(8, 6, 4), frozen_frac=1.0, n_out=2, max_targets=1, text_targets=1), abi.options_pose()
+    outs = []
+    try:
+        for mode in (1, 0, 0):
+            gpu.debug_set(host_pair_lists=mode)
+            G = P.copy(); r = gpu.PoseOptim(G, options=o); outs.append((G, r))
+    finally:
+        gpu.debug_set()
+    for G, r in outs[1:]:
+        assert np.array_equal(G.pose, outs[0][0].pose) and np.array_equal(G.sgood, outs[0][0].sgood) and np.array_equal(G.tfgood, outs[0][0].tfgood)
+        assert r["iters"] == outs[0][1]["iters"] and r["cost1"] == outs[0][1]["cost1"] and r["accepted"] == outs[0][1]["accepted"]
+    R = P.copy(); ro = oracle_lib.solve(R, o)
+    assert outs[1][1]["iters"] == ro["iters"]
+    np.testing.assert_allclose(outs[1][0].pose, R.pose, rtol=0, atol=1e-7)
+
+
 def test_scene_only_global_style(gpu, oracle_lib):
     P = synth.config_global(n_kf=12, n_pt=600, band=6)
     _check_solve(gpu, oracle_lib, P, abi.options_global(), lambda G, o: gpu.GlobalBA(G, options=o))
