@@ -32,6 +32,28 @@ def test_stages_bit_exact(orb, oracle_lib):
         assert np.array_equal(orb.debug_level(0, l, True), oracle_lib.orb_level(img, l, blurred=True))      # S5 blur
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (480, 752)])
+def test_pyramid_in_one_launch_is_the_chained_pyramid(oracle_lib, shape):
+    """Up to four frames take k_pyramid_one (a level's tile formed inside one workgroup from a base level several levels up: two launches, or one for
+    every level from the input image), larger batches a launch per level (tsorb_debug_pyramid forces any of them, and moves the split level): the same
+    bytes on every level, frame included, and the same features."""
+    from textslam_amd.orbextractor import ORBextractor
+    h, w = shape
+    imgs = np.stack([np.ascontiguousarray(np.tile(synthetic_frame(60 + s), (1, 2))[:h, :w]) for s in range(6)])
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device=0)
+    try:
+        for mode, batch in ((1, imgs[:1]), (1, imgs), (2, imgs[:1]), (2, imgs[:3]), (0, imgs[:1]), (-1, imgs[:2]), (-1, imgs), (102, imgs[:1]), (105, imgs[:2]), (103, imgs[:1])):
+            ex.debug_pyramid(mode)                  # (100 + s: the split level of the two launches; the shape stays as set before)
+            if mode >= 100: ex.debug_pyramid(1)
+            res = ex.extract_batch(batch)
+            for f in sorted({0, len(batch) - 1}):
+                for l in range(8):
+                    assert np.array_equal(ex.debug_level(f, l), oracle_lib.orb_level(batch[f], l)), (mode, len(batch), f, l)
+                _same(res[f], oracle_lib.orb_extract(batch[f]))
+    finally:
+        ex.close()
+
+
 def test_batch_matches_oracle(orb, oracle_lib):
     imgs = np.stack([synthetic_frame(30 + s) for s in range(6)])
     res = orb.extract_batch(imgs)

@@ -8,8 +8,8 @@
 //   k_octree              one workgroup per (frame, level): DistributeOctTree (serial list surgery, thread 0)      :540-764
 //   k_orient              16 lanes per keypoint: intensity-centroid moments + fastAtan2                         :77-104
 //   k_blur                7x7 sigma-2 Gaussian, Q8 fixed point separable, LDS tiled                            :1096-1097
-//   k_describe            one wave per keypoint: 256 steered BRIEF tests, one byte per lane                     :108-147
-//   k_pack                level-major concatenation, coordinates scaled back to level 0                         :1106-1112
+//   k_describe            32 lanes per keypoint: 256 steered BRIEF tests, one byte per lane, written straight into the
+//                         level-major output (coordinates scaled back to level 0)                               :108-147, :1106-1112
 // Integer / fp32 arithmetic is written so that every rounding matches the CPU oracle: no FMA contraction where the
 // reference has separate multiplies and adds (__fmul_rn / __fadd_rn / __dmul_rn ...), rintf = cvRound (half to even).
 #include <hip/hip_runtime.h>
@@ -49,13 +49,13 @@ struct OrbDev {
     size_t pyr_frame, blur_frame;          // bytes per frame
     const uint8_t *img; uint8_t *pyr, *blur;
     int *rtab;                             // cv::resize coordinate / weight tables of levels 1.. (k_resize_tab, once per geometry)
+    double rsx[MAXL], rsy[MAXL];           // cv::resize's inverse scales of level l against level l-1 (1 / (w_l / w_{l-1}): IEEE divisions, formed once on the host)
     uint32_t *cellkp; int *cellcnt;        // [n][cells][CELL_CAP] packed (x | y<<8 | score<<16), [n][cells]
     float *cand;                           // [n][nlevels][cand_cap][3]  x, y, response (relative to minBorder)
     int *nodes, *pool, *snbuf;             // quadtree scratch per (frame, level)
     float *sel;                            // [n][slots][4]  x, y (level coords incl. border offset), response, angle
     int *selcnt;                           // [n][nlevels]
     int *qfallback;                        // [n][nlevels] 1 = the LDS quadtree could not hold this level (serial kernel takes over)
-    uint8_t *seldesc;                      // [n][slots][32]
     float *selab;                          // [n][slots][2]  cos, sin of the keypoint angle (k_orient; read by k_describe)
     float *out_kp; uint8_t *out_desc; int *out_cnt;
     int umax[16]; int gk[7];
@@ -86,9 +86,9 @@ __device__ __forceinline__ int xcd_order(int b, int n) {
     return b;
 #endif
 }
-__global__ __launch_bounds__(128) void k_level0(OrbDev D) {
+// four neighbouring pixels (bordered column x ..) of the L0_ROWS bordered rows from y0 of frame f
+__device__ __forceinline__ void level0_item(const OrbDev &D, int x, int y0, int f) {
     const LevelGeo &G = D.L[0];
-    const int x = 4*(blockIdx.x*128 + threadIdx.x), y0 = blockIdx.y*L0_ROWS, f = blockIdx.z;
     if (x >= G.bw) return;
     const uint8_t *src = D.img + (size_t)f*D.h*D.stride;
     uint8_t *dst = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + x;
@@ -112,32 +112,34 @@ __global__ __launch_bounds__(128) void k_level0(OrbDev D) {
             if (x + 3 < G.bw) *(u32_unaligned *)d = v[r]; else for (int i = 0; x + i < G.bw; i++) d[i] = (uint8_t)(v[r] >> (8*i)); }
     }
 }
+__global__ __launch_bounds__(128) void k_level0(OrbDev D) { level0_item(D, 4*(blockIdx.x*128 + threadIdx.x), blockIdx.y*L0_ROWS, blockIdx.z); }
 // cv::resize(8UC1, INTER_LINEAR) from level l-1 to level l, evaluated at the reflected coordinate for border pixels.
 // The source coordinates and the 11-bit weights depend on the geometry only: k_resize_tab fills them once per upload (the per-pixel
 // version spent ~150 instructions per pixel on fp64 coordinate arithmetic, conversions and 64-bit index products).
 //   column x: { sx | sx1 << 16, a0 | a1 << 16 }     row y: { sy0, sy1, b0, b1 }
+// one column / row of cv::resize's tables: dx, dy = destination coordinate inside the level (after the frame's reflection), Sw, Sh = source size
+__device__ __forceinline__ int2 resize_xent(int dx, double scale_x, int Sw) {
+    float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scale_x), 0.5);
+    int sx = (int)floorf(fx); fx = __fsub_rn(fx, (float)sx);
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= Sw - 1) { fx = 0.f; sx = Sw - 1; }
+    const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f)), a1 = (int)rintf(__fmul_rn(fx, 2048.f));
+    const int sx1 = sx + 1 < Sw ? sx + 1 : sx;
+    return make_int2(sx | (sx1 << 16), a0 | (a1 << 16));
+}
+__device__ __forceinline__ int4 resize_yent(int dy, double scale_y, int Sh) {
+    float fy = (float)__dsub_rn(__dmul_rn((double)dy + 0.5, scale_y), 0.5);
+    int sy = (int)floorf(fy); fy = __fsub_rn(fy, (float)sy);
+    const int b0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fy), 2048.f)), b1 = (int)rintf(__fmul_rn(fy, 2048.f));
+    return make_int4(min(max(sy, 0), Sh - 1), min(max(sy + 1, 0), Sh - 1), b0, b1);
+}
 __global__ __launch_bounds__(256) void k_resize_tab(OrbDev D) {
     const int l = blockIdx.x + 1;
     const LevelGeo &G = D.L[l], &S = D.L[l-1];
-    const double scale_x = 1.0/((double)G.w/(double)S.w), scale_y = 1.0/((double)G.h/(double)S.h);
+    const double scale_x = D.rsx[l], scale_y = D.rsy[l];
     int2 *xt = (int2 *)(D.rtab + G.rx_off); int4 *yt = (int4 *)(D.rtab + G.ry_off);
-    for (int x = threadIdx.x; x < G.bw; x += 256) {
-        const int dx = reflect101(x - EDGE, G.w);
-        float fx = (float)__dsub_rn(__dmul_rn((double)dx + 0.5, scale_x), 0.5);
-        int sx = (int)floorf(fx); fx = __fsub_rn(fx, (float)sx);
-        if (sx < 0) { fx = 0.f; sx = 0; }
-        if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
-        const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f)), a1 = (int)rintf(__fmul_rn(fx, 2048.f));
-        const int sx1 = sx + 1 < S.w ? sx + 1 : sx;
-        xt[x] = make_int2(sx | (sx1 << 16), a0 | (a1 << 16));
-    }
-    for (int y = threadIdx.x; y < G.bh; y += 256) {
-        const int dy = reflect101(y - EDGE, G.h);
-        float fy = (float)__dsub_rn(__dmul_rn((double)dy + 0.5, scale_y), 0.5);
-        int sy = (int)floorf(fy); fy = __fsub_rn(fy, (float)sy);
-        const int b0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fy), 2048.f)), b1 = (int)rintf(__fmul_rn(fy, 2048.f));
-        yt[y] = make_int4(min(max(sy, 0), S.h - 1), min(max(sy + 1, 0), S.h - 1), b0, b1);
-    }
+    for (int x = threadIdx.x; x < G.bw; x += 256) xt[x] = resize_xent(reflect101(x - EDGE, G.w), scale_x, S.w);
+    for (int y = threadIdx.x; y < G.bh; y += 256) yt[y] = resize_yent(reflect101(y - EDGE, G.h), scale_y, S.h);
 }
 // grid (x chunks of 4 x RS_T pixels, groups of RS_ROWS bordered rows, frames).  A thread produces FOUR neighbouring pixels of RS_ROWS rows: away from
 // the reflected columns their source columns are monotone and span at most 8 bytes, so a source row is one (unaligned) 8-byte load instead of
@@ -200,6 +202,131 @@ __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
                 dst[(size_t)(y0 + r)*G.bw + k] = (uint8_t)((((yt.z*(S0 >> 4)) >> 16) + ((yt.w*(S1 >> 4)) >> 16) + 2) >> 2);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------- the pyramid of a FEW frames in one or two launches
+// k_level0 + seven k_resize are eight dependent launches: 52 of the 132 us the per-frame call of the SLAM front-end takes on the device (frame.cc:328-331 extracts
+// one frame at a time), each a table round trip, a pixel round trip and a launch for a few hundred KB.  Here a workgroup owns one tile of ONE level l and forms it
+// from a BASE level several levels up (the input image, or a level an earlier launch wrote): the base region under the tile -> LDS, then the levels between, of
+// exactly the pixels the next level asks for, LDS to LDS, then the tile.  Every intermediate pixel is cv::resize's fixed-point result from the same four source
+// pixels with the same weights as k_resize's (the same table entries: resize_xent / resize_yent), so the levels are the same bytes; what is paid is arithmetic --
+// a 16 x 16 tile seven levels below its base forms 13.7 k intermediate pixels, four levels below 2.7 k -- on a device that one frame leaves idle.  tsorb_run
+// takes this path for up to P1_MAX_N frames (a batch loses: 64 frames would do several times the work of a pipeline that takes 106 us), as two launches:
+// levels 0 .. P1_SPLIT from the input image, the rest from level P1_SPLIT (tsorb_debug_pyramid: 0 = always the chain, 1 = always this, 2 = one launch for all levels).
+// Needed pixels: the tile's bordered columns reflect to an interior range of level l; an interior range [a, b] of level k reads the columns sx(a) .. sx1(b) of
+// level k-1 (the tables are monotone) -- lanes 0..3 walk the four range ends up the levels.  Level 0 (the input inside its reflected frame) is a copy by
+// workgroups of its own in the first launch.  The deepest level's tiles come first in a launch: they are the longest.
+#define P1_L0_ROWS 16
+#ifndef P1_MAX_N
+#define P1_MAX_N 8
+#endif
+#ifndef P1_SPLIT
+#define P1_SPLIT 3
+#endif
+struct PyrOne { int base, top, nl, t0[MAXL + 1], ncol[MAXL], tw[MAXL], th[MAXL], per_frame; };     // levels base+1 .. top from level base (+ level 0's copy when base = 0); t0[i]: first workgroup (inside a frame) of level top - i
+__device__ __forceinline__ void reflect_range(int lo, int hi, int n, int &rlo, int &rhi) {       // the interior coordinates that lo .. hi (bordered coordinate minus EDGE) reflect to
+    const int a = reflect101(lo, n), b = reflect101(hi, n);
+    rlo = min(a, b); rhi = max(a, b);
+    if (lo <= 0 && hi >= 0) rlo = 0;
+    if (lo <= n - 1 && hi >= n - 1) rhi = n - 1;
+}
+// four neighbouring destination pixels from the LDS region src (pitch, origin ox, oy): xt = the destination columns' entries, ye = the row's
+__device__ __forceinline__ uint32_t p1_quad(const uint8_t *src, int pitch, int ox, int oy, const int2 *xt, int x, int n, const int4 ye) {
+    const int base0 = (ye.x - oy)*pitch - ox, base1 = (ye.y - oy)*pitch - ox;
+    uint32_t o = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int2 xe = xt[min(x + j, n - 1)];
+        const int sx = xe.x & 0xffff, sx1 = xe.x >> 16, a0 = xe.y & 0xffff, a1 = xe.y >> 16;
+        const int S0 = (int)src[base0 + sx]*a0 + (int)src[base0 + sx1]*a1, S1 = (int)src[base1 + sx]*a0 + (int)src[base1 + sx1]*a1;
+        o |= (uint32_t)(((((ye.z*(S0 >> 4)) >> 16) + ((ye.w*(S1 >> 4)) >> 16) + 2) >> 2) & 255) << (8*j);
+    }
+    return o;
+}
+// BUF: bytes per LDS region buffer (two: a stage reads one and writes the other), ENT: table entries (columns, rows) of all stages of a tile, T: threads.
+// Two instances: <4096, 192, 256> for tiles up to four levels below their base, <16384, 512, 512> for any depth (the host sizes the tiles and picks)
+template <int BUF, int ENT, int T>
+__global__ __launch_bounds__(T) void k_pyramid_one(OrbDev D, PyrOne Q) {
+    __shared__ __attribute__((aligned(16))) uint8_t buf[2][BUF];
+    __shared__ int2 s_xt[ENT];
+    __shared__ int4 s_yt[ENT];
+    __shared__ int s_rng[MAXL][4];                          // level k < l: the interior columns lo, hi and rows lo, hi the tile needs of it
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x / Q.per_frame; int r = blockIdx.x - f*Q.per_frame, i = 0;
+#pragma unroll
+    for (int k = 1; k < MAXL; k++) if (k < Q.nl && r >= Q.t0[k]) i = k;
+    const int l = Q.top - i, B = Q.base; r -= Q.t0[i];
+    if (l == 0) {                                           // level 0: P1_L0_ROWS bordered rows per workgroup
+        const int nx4 = (D.L[0].bw + 3) >> 2;
+        for (int it = tid; it < nx4*(P1_L0_ROWS/L0_ROWS); it += T) { const int g = it/nx4, y0 = r*P1_L0_ROWS + g*L0_ROWS; if (y0 < D.L[0].bh) level0_item(D, 4*(it - g*nx4), y0, f); }
+        return;
+    }
+    const LevelGeo &G = D.L[l];
+    const int ty = r/Q.ncol[l], tx = r - ty*Q.ncol[l];
+    const int X0 = tx*Q.tw[l], Y0 = ty*Q.th[l], TW = min(Q.tw[l], G.bw - X0), TH = min(Q.th[l], G.bh - Y0);
+    if (tid < 4) {                                          // lane: axis (x, y) and end (lo, hi) of the needed range, level by level
+        const int ax = tid >> 1, hi_end = tid & 1;
+        int rlo, rhi;
+        if (ax == 0) reflect_range(X0 - EDGE, X0 + TW - 1 - EDGE, G.w, rlo, rhi); else reflect_range(Y0 - EDGE, Y0 + TH - 1 - EDGE, G.h, rlo, rhi);
+        int v = hi_end ? rhi : rlo;
+        for (int k = l; k > B; k--) {
+            if (ax == 0) { const int2 e = resize_xent(v, D.rsx[k], D.L[k-1].w); v = hi_end ? (e.x >> 16) : (e.x & 0xffff); }
+            else { const int4 e = resize_yent(v, D.rsy[k], D.L[k-1].h); v = hi_end ? e.y : e.x; }
+            s_rng[k-1][tid] = v;
+        }
+    }
+    __syncthreads();
+    // ---- the base level's region under the tile: requested now, stored behind the tables' arithmetic
+    const int ax0 = s_rng[B][0], ay0 = s_rng[B][2], dpr0 = (s_rng[B][1] - ax0 + 4) >> 2, nd0 = dpr0*(s_rng[B][3] - ay0 + 1);
+    if (nd0*4 > BUF) return;                                // (never: the host sized the tiles against the buffers)
+    uint32_t v[BUF/4/T];
+    {   const uint8_t *img = B == 0 ? D.img + (size_t)f*D.h*D.stride : D.pyr + (size_t)f*D.pyr_frame + D.L[B].pyr_off + (size_t)EDGE*D.L[B].bw + EDGE;
+        const int stride = B == 0 ? D.stride : D.L[B].bw, w0 = D.L[B].w;
+        const float inv = 1.0f/(float)dpr0;
+#pragma unroll
+        for (int u = 0; u < BUF/4/T; u++) {
+            const int d = min(tid + u*T, nd0 - 1), y = (int)(((float)d + 0.5f)*inv), x = ax0 + 4*(d - y*dpr0);
+            const uint8_t *row = img + (size_t)(ay0 + y)*stride;
+            if (x + 3 < w0) v[u] = *(const u32_unaligned *)(row + x);
+            else v[u] = (uint32_t)row[min(x, w0 - 1)] | ((uint32_t)row[min(x + 1, w0 - 1)] << 8) | ((uint32_t)row[min(x + 2, w0 - 1)] << 16) | ((uint32_t)row[min(x + 3, w0 - 1)] << 24);
+        }
+    }
+    // ---- the table entries of every stage: a thread finds the stage of its entry (levels B+1 .. l-1: the needed interior columns / rows; level l: the tile's bordered ones)
+    for (int e0 = tid; e0 < 2*ENT; e0 += T) {
+        int e = e0, xo = 0, yo = 0;
+        for (int k = B + 1; k <= l; k++) {
+            const int lo = k < l ? s_rng[k][0] : X0, n = k < l ? s_rng[k][1] - lo + 1 : TW, loy = k < l ? s_rng[k][2] : Y0, ny = k < l ? s_rng[k][3] - loy + 1 : TH;
+            if (e < n) { if (xo + e < ENT) s_xt[xo + e] = resize_xent(k < l ? lo + e : reflect101(lo + e - EDGE, G.w), D.rsx[k], D.L[k-1].w); break; }
+            e -= n;
+            if (e < ny) { if (yo + e < ENT) s_yt[yo + e] = resize_yent(k < l ? loy + e : reflect101(loy + e - EDGE, G.h), D.rsy[k], D.L[k-1].h); break; }
+            e -= ny; xo += n; yo += ny;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < BUF/4/T; u++) if (tid + u*T < nd0) ((uint32_t *)buf[0])[tid + u*T] = v[u];
+    __syncthreads();
+    // ---- the levels between, of the needed pixels, LDS to LDS, four neighbouring pixels per thread
+    int cur = 0, ox = ax0, oy = ay0, pitch = 4*dpr0, xo = 0, yo = 0;
+    for (int k = B + 1; k < l; k++) {
+        const int lo = s_rng[k][0], n = s_rng[k][1] - lo + 1, loy = s_rng[k][2], ny = s_rng[k][3] - loy + 1, qpr = (n + 3) >> 2, nq = qpr*ny;
+        if (4*nq > BUF || xo + n > ENT || yo + ny > ENT) return;        // (never)
+        const uint8_t *src = buf[cur]; uint32_t *dst = (uint32_t *)buf[cur ^ 1];
+        const float inv = 1.0f/(float)qpr;
+        for (int q = tid; q < nq; q += T) { const int y = (int)(((float)q + 0.5f)*inv), x = 4*(q - y*qpr); dst[q] = p1_quad(src, pitch, ox, oy, s_xt + xo, x, n, s_yt[yo + y]); }
+        __syncthreads();
+        cur ^= 1; ox = lo; oy = loy; pitch = 4*qpr; xo += n; yo += ny;
+    }
+    // ---- the tile itself
+    {   const int qpr = (TW + 3) >> 2, nq = qpr*TH;
+        if (xo + TW > ENT || yo + TH > ENT) return;                      // (never)
+        const uint8_t *src = buf[cur];
+        uint8_t *out = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)Y0*G.bw + X0;
+        const float inv = 1.0f/(float)qpr;
+        for (int q = tid; q < nq; q += T) { const int y = (int)(((float)q + 0.5f)*inv), x = 4*(q - y*qpr);
+            const uint32_t o = p1_quad(src, pitch, ox, oy, s_xt + xo, x, TW, s_yt[yo + y]);
+            uint8_t *d = out + (size_t)y*G.bw + x;
+            if (x + 3 < TW) *(u32_unaligned *)d = o; else for (int j = 0; x + j < TW; j++) d[j] = (uint8_t)(o >> (8*j)); }
     }
 }
 
@@ -375,14 +502,13 @@ __device__ void q_divide(QList &L, int src, int c[4], int node_cap, int pool_cap
     for (int i = 0; i < s.nk; i++) { int key = L.pool[s.key0 + i]; const float *kp = L.kp + 3*key;
         int q = (kp[0] < ux) ? ((kp[1] < by) ? 0 : 2) : ((kp[1] < by) ? 1 : 3); L.pool[w[q]++] = key; }
 }
-__global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) {
-    const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, tid = threadIdx.x;
-    if (!D.qfallback[blockIdx.x]) return;
+// (one thread: the (frame, level) problems the LDS version cannot hold -- none on camera images)
+__device__ __noinline__ void octree_serial(const OrbDev &D, int f, int l) {
     const LevelGeo &G = D.L[l];
     float *cand = D.cand + ((size_t)f*D.nlevels + l)*D.cand_cap*3;
-    __shared__ int s_nc;
+    int s_nc;
     // 1. gather the cells of this level in the reference's order (rows of cells, then columns; row-major inside a cell)
-    if (tid == 0) {
+    {
         int nc = 0;
         const int *cnt = D.cellcnt + (size_t)f*D.cells_per_frame + G.cell0;
         const uint32_t *ck = D.cellkp + ((size_t)f*D.cells_per_frame + G.cell0)*CELL_CAP;
@@ -396,8 +522,6 @@ __global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) {
         }
         s_nc = nc;
     }
-    __syncthreads();
-    if (tid != 0) return;
     const int nk = s_nc;
     int *selcnt = D.selcnt + (size_t)f*D.nlevels + l;
     float *sel = D.sel + ((size_t)f*D.slots_per_frame + G.kp0)*4;
@@ -467,6 +591,7 @@ __global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) {
     }
     *selcnt = ns;
 }
+__global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) { if (threadIdx.x == 0 && D.qfallback[blockIdx.x]) octree_serial(D, blockIdx.x / D.nlevels, blockIdx.x % D.nlevels); }
 
 
 // ---------------------------------------------------------------- quadtree, wave-cooperative, everything in LDS.
@@ -504,7 +629,18 @@ __device__ __forceinline__ void qscan4(const int v[4], int *s_w, int tid, int ex
 // (compaction / rank sort) -> child counts (one wave per node) -> scan + cut -> stable 4-way partition of the keys (one wave per node)
 // -> child records + new list (scans).  Nodes live in a pool indexed by the list: the first non-empty child takes its parent's slot, so
 // the pool never holds more than the list.  Levels that do not fit (candidates, nodes) fall back to k_octree_serial.
+// (A problem that does not fit is flagged for k_octree_serial, a launch of its own: 4.8 us to find none.  Solved on the spot by thread 0 instead, the serial code's
+// registers and scratch cost this kernel more than that launch -- 64 frames: 0.449 against 0.424 ms; one frame: 54.4 us against 44.8 + 4.8.)
+#define Q_FALLBACK() do { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; } while (0)
+#ifdef Q_STAMPS       // (tools/diag/octree_stamps.sh) thread 0's cycles by phase into D.snbuf: gather, first nodes, per pass: order / counts / cut / partition / lists, arg-max
+#define QS(i) do { if (tid == 0) { const long long t1_ = clock64(); q_acc[i] += (int)(t1_ - q_t0); q_t0 = t1_; } } while (0)
+#else
+#define QS(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
+#ifdef Q_STAMPS
+    int q_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q_pass = 0; long long q_t0 = clock64();
+#endif
     const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const LevelGeo &G = D.L[l];
     // 16-bit candidates / keys (pixel coordinates and FAST scores are small integers): 78 KB of LDS, two workgroups per CU
@@ -523,7 +659,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     const int ncell = G.nCols*G.nRows;
     const int *cnt = D.cellcnt + (size_t)f*D.cells_per_frame + G.cell0;
     const uint32_t *ck = D.cellkp + ((size_t)f*D.cells_per_frame + G.cell0)*CELL_CAP;
-    if (ncell > QL_CELLS) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
+    if (ncell > QL_CELLS) Q_FALLBACK();
     int nk = 0;
     {   // thread t owns cells 4t .. 4t+3 (QL_CELLS = 4 QT): one scan, the four counts in flight together
         int v[4], ex[4];
@@ -535,7 +671,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     }
     if (tid == 0) D.qfallback[blockIdx.x] = 0;
     if (nk == 0) { if (tid == 0) *selcnt = 0; return; }
-    if (nk > QL_CAND) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
+    if (nk > QL_CAND) Q_FALLBACK();
     __syncthreads();
     for (int k0 = tid; k0 < nk; k0 += 8*QT) {            // eight entries per thread and round: their loads are in flight together
         int cell[8]; uint32_t p[8];
@@ -555,10 +691,11 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
             cx[k] = (unsigned short)((int)(p[u] & 255u) + j*G.wCell); cy[k] = (unsigned short)((int)((p[u] >> 8) & 255u) + i*G.hCell); cr[k] = (unsigned short)(p[u] >> 16);
         }
     }
+    QS(0);
     const int minX = G.minB, maxX = G.maxBX, minY = G.minB, maxY = G.maxBY, N = G.nfeat;
     const int nIni = (int)roundf((float)(maxX - minX)/(float)(maxY - minY));
     const float hX = (float)(maxX - minX)/(float)nIni;
-    if (nIni < 1 || nIni > 16) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
+    if (nIni < 1 || nIni > 16) Q_FALLBACK();
     // ---- initial nodes (ORBextractor.cc:544-573): empty ones are dropped, the list keeps the rest in order
     for (int k = tid; k < nk; k += QT) keys[k] = (unsigned short)k;
     __syncthreads();
@@ -581,6 +718,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     int size = s_front, next_id = nIni, cur = 0;
     bool phase2 = false, overflow = false;
     __syncthreads();
+    QS(1);
     for (;;) {
         const int prevSize = size;
         unsigned short *L = lst[cur], *Ln = lst[cur ^ 1];
@@ -608,6 +746,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
                 __syncthreads();
             }
         }
+        QS(2);
         if (np == 0) break;                                                   // nothing left to split: size == prevSize
         // ---- 2. child counts, one wave per node
         // (a pass with ONE node -- the first generation: all candidates of the level -- is shared by the waves: wave w takes the w-th
@@ -635,6 +774,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         if (tid == 0) { s_cut = np; s_nexp = 0; }
         for (int p = tid; p < size; p += QT) fsplit[p] = 0;
         __syncthreads();
+        QS(3);
         // ---- 3. cut (phase 2) and offsets: thread t owns processing ranks 4t .. 4t+3
         int m[4], mex[4], mtot;
 #pragma unroll
@@ -652,6 +792,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         __syncthreads();
         const int front = s_front, newSize = front + size - S;
         if (newSize > QL_NODES || next_id + 4*S > 65000) { overflow = true; break; }
+        QS(4);
         // ---- 4. stable 4-way partition of the split nodes' keys, one wave per node (tmpk at the node's own key positions)
         for (int r0 = one ? 0 : wv*gpw; r0 < S; r0 += (QT/64)*gpw) {
             const int r = r0 + grp; const bool act = r < S;
@@ -676,6 +817,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
                 run0 += __popcll(m0); run1 += __popcll(m1); run2 += __popcll(m2); run3 += __popcll(m3);
             }
         }
+        QS(5);
         // ---- 5. the kept part of the list (order preserved) behind the new front
         {
             int v[4], ex[4], tot;
@@ -716,10 +858,14 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         size = newSize; next_id += 4*S; cur ^= 1;
         const int nToExpand = s_nexp;
         __syncthreads();                                     // (s_nexp / s_cut are reset by the next pass)
+        QS(6);
+#ifdef Q_STAMPS
+        q_pass++;
+#endif
         if (size >= N || size == prevSize) break;
         if (!phase2 && size + nToExpand*3 > N) phase2 = true;
     }
-    if (overflow) { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; }
+    if (overflow) Q_FALLBACK();
     // ---- best response per node, in list order
     const unsigned short *L = lst[cur];
     const int ns = min(size, G.capL);
@@ -730,6 +876,10 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         sel[4*q] = (float)cx[best] + (float)minX; sel[4*q+1] = (float)cy[best] + (float)minY; sel[4*q+2] = (float)mr; sel[4*q+3] = 0.f;
     }
     if (tid == 0) *selcnt = ns;
+    QS(7);
+#ifdef Q_STAMPS
+    if (tid == 0) { int *o = D.snbuf + 16*blockIdx.x; for (int i = 0; i < 8; i++) o[i] = q_acc[i]; o[8] = q_pass; o[9] = nk; o[10] = size; }
+#endif
 }
 
 // ---------------------------------------------------------------- orientation: 16 lanes per keypoint
@@ -864,17 +1014,26 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev D) {
     }
 }
 
-// ---------------------------------------------------------------- descriptors: 32 lanes per keypoint, lane i -> byte i
+// ---------------------------------------------------------------- descriptors: 32 lanes per keypoint, lane i -> byte i; straight into the level-major output
+// (ORBextractor.cc:1106-1112: coordinates scaled back to level 0).  A keypoint's place is its level's first place -- the counts of the levels before it -- plus
+// its place in the level: the separate packing launch (a frame's keypoints and descriptors read back and written again, 4.7 us of the 107 of a per-frame call)
+// is gone since round 6.
 __global__ __launch_bounds__(256) void k_describe(OrbDev D) {
     const int g = (xcd_order(blockIdx.x, gridDim.x)*256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;      // 32 lanes per keypoint: two keypoints per wave
     const int per = D.slots_per_frame, f = g / per, slot = g % per;
     if (f >= D.n) return;
     int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;
     const LevelGeo &G = D.L[l];
-    if ((slot - G.kp0) >= D.selcnt[(size_t)f*D.nlevels + l]) return;
-    const float *s = D.sel + ((size_t)f*per + slot)*4;
+    const int *sc = D.selcnt + (size_t)f*D.nlevels;
+    int before = 0, total = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < MAXL; k++) { const int cnt = k < D.nlevels ? sc[k] : 0; before += k < l ? cnt : 0; mine = k == l ? cnt : mine; total += cnt; }
+    if (slot == 0 && lane == 0) D.out_cnt[f] = min(total, D.cap);
+    const int o = before + slot - G.kp0;
+    if ((slot - G.kp0) >= mine || o >= D.cap) return;
+    const float4 sv = *(const float4 *)(D.sel + ((size_t)f*per + slot)*4);
     const float a = D.selab[2*((size_t)f*per + slot)], b = D.selab[2*((size_t)f*per + slot) + 1];      // cos, sin of the angle (k_orient)
-    const uint8_t *c = D.blur + (size_t)f*D.blur_frame + G.blur_off + (size_t)(int)rintf(s[1])*G.w + (int)rintf(s[0]);
+    const uint8_t *c = D.blur + (size_t)f*D.blur_frame + G.blur_off + (size_t)(int)rintf(sv.y)*G.w + (int)rintf(sv.x);
     const int8_t *pat = d_pattern + 32*lane;
     int val = 0;
 #pragma unroll
@@ -884,30 +1043,10 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev D) {
         const int t1 = c[(int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)))*G.w + (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)))];
         val |= (t0 < t1) << t;
     }
-    D.seldesc[((size_t)f*per + slot)*32 + lane] = (uint8_t)val;
-}
-
-// ---------------------------------------------------------------- level-major packing, coordinates back to level 0
-__global__ __launch_bounds__(256) void k_pack(OrbDev D) {
-    const int f = blockIdx.x, tid = threadIdx.x;
-    __shared__ int off[MAXL + 1];
-    if (tid == 0) { int o = 0; for (int l = 0; l < D.nlevels; l++) { off[l] = o; o += D.selcnt[(size_t)f*D.nlevels + l]; } off[D.nlevels] = o; D.out_cnt[f] = min(o, D.cap); }
-    __syncthreads();
-    // one loop over the frame's keypoints (level by level it was eight rounds of count -> loads -> stores, each waiting for the one before: 20 us)
-    const int total = min(off[D.nlevels], D.cap);
-    for (int o = tid; o < total; o += 256) {
-        int l = 0;
-        while (l + 1 < D.nlevels && o >= off[l + 1]) l++;
-        const LevelGeo &G = D.L[l];
-        const int q = o - off[l];
-        const float *s = D.sel + ((size_t)f*D.slots_per_frame + G.kp0 + q)*4;
-        const uint32_t *ds = (const uint32_t *)(D.seldesc + ((size_t)f*D.slots_per_frame + G.kp0 + q)*32);
-        const float4 sv = *(const float4 *)s; const uint4 d0 = ((const uint4 *)ds)[0], d1 = ((const uint4 *)ds)[1];
-        float *k = D.out_kp + ((size_t)f*D.cap + o)*6;
-        k[0] = l ? __fmul_rn(sv.x, G.sf) : sv.x; k[1] = l ? __fmul_rn(sv.y, G.sf) : sv.y;
-        k[2] = (float)(int)__fmul_rn((float)PATCH_SIZE, G.sf); k[3] = sv.w; k[4] = sv.z; k[5] = (float)l;
-        uint2 *dd = (uint2 *)(D.out_desc + ((size_t)f*D.cap + o)*32);            // (the output block is 8-byte aligned for any n x cap)
-        dd[0] = make_uint2(d0.x, d0.y); dd[1] = make_uint2(d0.z, d0.w); dd[2] = make_uint2(d1.x, d1.y); dd[3] = make_uint2(d1.z, d1.w);
+    D.out_desc[((size_t)f*D.cap + o)*32 + lane] = (uint8_t)val;
+    if (lane < 6) {                                             // x, y, size, angle, response, octave
+        const float kx = l ? __fmul_rn(sv.x, G.sf) : sv.x, ky = l ? __fmul_rn(sv.y, G.sf) : sv.y, ks = (float)(int)__fmul_rn((float)PATCH_SIZE, G.sf);
+        D.out_kp[((size_t)f*D.cap + o)*6 + lane] = lane == 0 ? kx : lane == 1 ? ky : lane == 2 ? ks : lane == 3 ? sv.w : lane == 4 ? sv.z : (float)l;
     }
 }
 
@@ -996,6 +1135,7 @@ struct OCtx {
     int nfeatures = 1000, nlevels = 8, ini_th = 20, min_th = 7; float scale = 1.2f;
     float sf[MAXL], isf[MAXL]; int nfl[MAXL], umax[16], gk[7];
     std::vector<void *> allocs; bool uploaded = false; int fast_shape = -1;       // (tsorb_debug_fast_shape)
+    int pyr_shape = -1, pyr_split = P1_SPLIT; PyrOne Q[3]; int q_inst[3];           // (tsorb_debug_pyramid) k_pyramid_one's launches: [0] levels 0 .. split from the image, [1] the rest from level split, [2] every level from the image; instance 0 = small buffers, 1 = large, -1 = does not fit
     OrbDev D;
     // the SLAM front-end calls once per frame with the same geometry: buffers and pinned staging are kept between calls
     MatchDev M; bool m_set = false; void *m_buf = nullptr; size_t m_cap = 0; void *m_feat = nullptr; size_t m_feat_cap = 0;   // search grid of the current frame
@@ -1084,6 +1224,31 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     { int bt = 0; for (int l = 0; l < c->nlevels; l++) { LevelGeo &G = D.L[l]; G.bt0 = bt; bt += ((G.w + BT_W - 1)/BT_W)*((G.h + BT_H - 1)/BT_H); } D.btiles_per_frame = bt; }
     int rt = 0;
     for (int l = 1; l < c->nlevels; l++) { LevelGeo &G = D.L[l]; G.rx_off = rt; rt += 2*((G.bw + 1) & ~1); G.ry_off = rt; rt += 4*G.bh; }
+    for (int l = 1; l < c->nlevels; l++) { D.rsx[l] = 1.0/((double)D.L[l].w/(double)D.L[l-1].w); D.rsy[l] = 1.0/((double)D.L[l].h/(double)D.L[l-1].h); }
+    {   // k_pyramid_one's tilings: 64 x 16 one or two levels below the base, 32 x 16 three, 16 x 16 further down (a tile's cost grows with its depth), halved until
+        // every stage's region (bounded from above: a range of n pixels reads at most ceil(n scale) + 3 of the level before; + 4 taken) fits the LDS buffers and tables
+        const int NL = c->nlevels, sp = std::min(std::max(c->pyr_split, 0), NL - 1);
+        const int bases[3] = { 0, sp, 0 }, tops[3] = { sp, NL - 1, NL - 1 };
+        for (int q = 0; q < 3; q++) {
+            PyrOne &Q = c->Q[q]; memset(&Q, 0, sizeof(Q)); Q.base = bases[q]; Q.top = tops[q]; c->q_inst[q] = 0;
+            for (int l = Q.base + 1; l <= Q.top; l++) {
+                const int dep = l - Q.base; int tw = dep <= 2 ? 64 : dep == 3 ? 32 : 16, th = 16;
+                for (;;) {
+                    int wk = tw, hk = th, sw = tw, sh = th, need = 0;
+                    for (int k = l; k > Q.base; k--) { wk = std::min((int)ceil(wk*D.rsx[k]) + 4, D.L[k-1].w); hk = std::min((int)ceil(hk*D.rsy[k]) + 4, D.L[k-1].h);
+                        need = std::max(need, 4*((wk + 3)/4)*hk); if (k > Q.base + 1) { sw += wk; sh += hk; } }
+                    const int inst = (need <= 4096 && sw <= 192 && sh <= 192) ? 0 : (need <= 16384 && sw <= 512 && sh <= 512) ? 1 : -1;
+                    if (inst >= 0) { c->q_inst[q] = c->q_inst[q] < 0 ? -1 : std::max(c->q_inst[q], inst); break; }
+                    if (tw > 8) tw /= 2; else if (th > 4) th /= 2; else { c->q_inst[q] = -1; break; }
+                }
+                Q.tw[l] = tw; Q.th[l] = th; Q.ncol[l] = (D.L[l].bw + tw - 1)/tw;
+            }
+            int t = 0; Q.nl = Q.top - Q.base + (Q.base == 0 ? 1 : 0);
+            for (int i = 0; i < Q.nl; i++) { const int l = Q.top - i; Q.t0[i] = t;
+                t += l == 0 ? (D.L[0].bh + P1_L0_ROWS - 1)/P1_L0_ROWS : Q.ncol[l]*((D.L[l].bh + Q.th[l] - 1)/Q.th[l]); }
+            Q.t0[Q.nl] = t; Q.per_frame = t;
+        }
+    }
     // strict 3x3 NMS leaves at most one corner per 2x2 block: the level-0 search area bounds every level's candidate count
     D.cand_cap = ((D.L[0].maxBX - D.L[0].minB)*(D.L[0].maxBY - D.L[0].minB))/4 + 64; D.node_cap = 64*(c->nfl[0] + 64); D.pool_cap = 16*D.cand_cap;
     int rc;
@@ -1097,7 +1262,7 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     if ((rc = oalloc(c, &D.cand, (size_t)n*c->nlevels*D.cand_cap*3))) return rc;
     if ((rc = oalloc(c, &D.nodes, (size_t)n*c->nlevels*D.node_cap*(sizeof(QNode)/sizeof(int)))) || (rc = oalloc(c, &D.pool, (size_t)n*c->nlevels*D.pool_cap)) ||
         (rc = oalloc(c, &D.snbuf, (size_t)n*c->nlevels*4*D.node_cap))) return rc;
-    if ((rc = oalloc(c, &D.sel, (size_t)n*kp0*4)) || (rc = oalloc(c, &D.selcnt, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.qfallback, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.seldesc, (size_t)n*kp0*32)) || (rc = oalloc(c, &D.selab, (size_t)n*kp0*2))) return rc;
+    if ((rc = oalloc(c, &D.sel, (size_t)n*kp0*4)) || (rc = oalloc(c, &D.selcnt, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.qfallback, (size_t)n*c->nlevels)) || (rc = oalloc(c, &D.selab, (size_t)n*kp0*2))) return rc;
     {   // the three outputs in one allocation (kp | count | desc): one device-to-host copy per call
         const size_t bkp = sizeof(float)*(size_t)n*cap*6, bcnt = ((sizeof(int)*(size_t)n + 15)/16)*16, bdesc = (size_t)n*cap*32;
         uint8_t *ob; if ((rc = oalloc(c, &ob, bkp + bcnt + bdesc))) return rc;
@@ -1112,8 +1277,16 @@ int tsorb_run(void *ctx) {
     OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG;
     hipSetDevice(c->device);
     OrbDev &D = c->D;
-    hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
-    for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
+    const bool few = c->pyr_shape == 1 || c->pyr_shape == 2 || (c->pyr_shape < 0 && D.n <= P1_MAX_N);
+    auto pyr_launch = [&](const PyrOne &Q, int inst) { if (Q.per_frame <= 0) return;
+        if (inst == 0) hipLaunchKernelGGL((k_pyramid_one<4096, 192, 256>), dim3(D.n*Q.per_frame), dim3(256), 0, c->stream, D, Q);
+        else hipLaunchKernelGGL((k_pyramid_one<16384, 512, 512>), dim3(D.n*Q.per_frame), dim3(512), 0, c->stream, D, Q); };
+    if (few && c->pyr_shape != 2 && c->q_inst[0] >= 0 && c->q_inst[1] >= 0) { pyr_launch(c->Q[0], c->q_inst[0]); pyr_launch(c->Q[1], c->q_inst[1]); }     // a few frames: two launches
+    else if (few && c->q_inst[2] >= 0) pyr_launch(c->Q[2], c->q_inst[2]);                                                                                    // (or one)
+    else {
+        hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
+        for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
+    }
     const int fast_shape = c->fast_shape < 0 ? 2 : c->fast_shape;      // (diagnostics: 1 / 3 the small tile with 256 / 64 threads)
     if (D.fast_cells[0] > 0) {
         if (fast_shape == 1) hipLaunchKernelGGL((k_fast<40, 1024, 320, 256, 0>), dim3(D.n*D.fast_cells[0]), dim3(256), 0, c->stream, D);
@@ -1122,11 +1295,10 @@ int tsorb_run(void *ctx) {
     }
     if (D.fast_cells[1] > 0) hipLaunchKernelGGL((k_fast<TILE_MAX, 2048, CELL_CAP, 256, 1>), dim3(D.n*D.fast_cells[1]), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
-    hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged (4.7 us to find none; as a call from k_octree's thread 0 it cost that kernel 48 VGPRs and 1.2 KB of scratch per lane: 0.449 against 0.424 ms)
+    hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
     hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D);
     hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
-    hipLaunchKernelGGL(k_pack, dim3(D.n), dim3(256), 0, c->stream, D);
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
     return TSORB_OK;
 }
@@ -1149,6 +1321,12 @@ int tsorb_extract_batch(void *ctx, const uint8_t *imgs, int n, int w, int h, int
     return tsorb_download(ctx, kp, desc, count);
 }
 int tsorb_debug_fast_shape(void *ctx, int shape) { OCtx *c = (OCtx *)ctx; if (!c || shape < -1 || shape > 3) return TSORB_ERR_ARG; c->fast_shape = shape; c->key[0] = 0; return TSORB_OK; }      // (key: the next upload sets the geometry up again)
+int tsorb_debug_pyramid(void *ctx, int shape) { OCtx *c = (OCtx *)ctx; if (!c || shape < -1 || (shape > 2 && shape < 100) || shape >= 100 + MAXL) return TSORB_ERR_ARG;
+    if (shape >= 100) { c->pyr_split = shape - 100; c->key[0] = 0; } else c->pyr_shape = shape; return TSORB_OK; }      // (100 + s: the split level of the two launches, at the next upload)
+#ifdef Q_STAMPS
+int tsorb_debug_stamps(void *ctx, int32_t *out, int n) { OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG; hipSetDevice(c->device);
+    return hipMemcpy(out, c->D.snbuf, sizeof(int32_t)*(size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? TSORB_OK : TSORB_ERR_DEVICE; }
+#endif
 int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out, int32_t *w_out, int32_t *h_out) {
     OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded || !out) return TSORB_ERR_ARG;
     OrbDev &D = c->D; if (frame < 0 || frame >= D.n || level < 0 || level >= D.nlevels) return TSORB_ERR_ARG;

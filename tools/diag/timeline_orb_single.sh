@@ -10,7 +10,8 @@ ev = []
 for f in glob.glob("/tmp/prof_os/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:50]))
 ev.sort()
-starts = [i for i, e in enumerate(ev) if e[2].startswith("k_level0")]
+first = lambda n: n.startswith("k_level0") or "k_pyramid_one" in n
+starts = [i for i, e in enumerate(ev) if first(e[2]) and (i == 0 or not first(ev[i-1][2]))]
 i0, i1 = starts[12], starts[13]
 base = ev[i0][0]; prev = base
 for s, e, n in ev[i0:i1]:
