@@ -57,6 +57,9 @@ int tsorb_debug_fast_shape(void *ctx, int shape);
  * the input image in ONE launch (when the geometry fits the kernel's buffers; a launch per level otherwise); 100 + s: the two launches split at level s (takes effect at
  * the next upload).  The pyramid is the same bytes every way (tests/test_gpu_orb.py). */
 int tsorb_debug_pyramid(void *ctx, int shape);
+/* Test hook: the number of runs of this context in which a (frame, level) did not fit the LDS quadtree (more than 4096 candidates, 1024 nodes) and the serial pass
+ * (k_octree_serial, then orientation and descriptors once more) was launched behind the first synchronisation. */
+int tsorb_debug_fallbacks(void *ctx);
 
 /* ---- Window / projection search: the step between the extractor and PoseOptim.
  *   tsorb_match_set_frame / _set_features  <- frame::AssignFeaturesToGrid + PosInGrid                       src/frame.cc:372-407

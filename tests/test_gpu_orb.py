@@ -81,7 +81,11 @@ def test_edge_cases(orb, oracle_lib):
     small = np.ascontiguousarray(synthetic_frame(51)[:240, :320])   # another resolution
     _same(orb(small), oracle_lib.orb_extract(small))
     noise = np.random.default_rng(5).integers(0, 256, (480, 640)).astype(np.uint8)        # corners everywhere: quadtree under load
+    before = orb.debug_fallbacks()
     _same(orb(noise), oracle_lib.orb_extract(noise, cap=8192))
+    assert orb.debug_fallbacks() == before + 1          # more candidates than the LDS quadtree holds: the serial pass behind the first synchronisation
+    _same(orb(small), oracle_lib.orb_extract(small))    # (and the next frame is none the worse for it)
+    assert orb.debug_fallbacks() == before + 1
 
 
 def test_against_golden_fixture(orb):

@@ -56,6 +56,7 @@ struct OrbDev {
     float *sel;                            // [n][slots][4]  x, y (level coords incl. border offset), response, angle
     int *selcnt;                           // [n][nlevels]
     int *qfallback;                        // [n][nlevels] 1 = the LDS quadtree could not hold this level (serial kernel takes over)
+    int *h_fallback;                       // (pinned host memory) set when any level of the run was flagged: the host launches the serial pass only then
     float *selab;                          // [n][slots][2]  cos, sin of the keypoint angle (k_orient; read by k_describe)
     float *out_kp; uint8_t *out_desc; int *out_cnt;
     int umax[16]; int gk[7];
@@ -380,13 +381,13 @@ __device__ __forceinline__ int fast_score(const uint8_t *p, int stride, int thre
 // scores 25, suppression + ordering + output 10.  One wave per cell, two cells per workgroup with both tiles requested together, the blur on a second
 // stream beside the detector or the quadtree (events, or hipExtAnyOrderLaunch, which gfx9 ignores): all measured, none faster (docs/ledger_r05.md).
 template <int S, int NC, int NK, int T, int GRP>
-__global__ __launch_bounds__(T) void k_fast(OrbDev D) {
+__device__ __forceinline__ void fast_body(const OrbDev &D, const int block, const int nblocks) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[S*S];
     __shared__ __attribute__((aligned(16))) uint8_t score[S*S];      // cornerScore <= 255
     __shared__ int s_ncand, s_nkeep;
     __shared__ unsigned short s_cand[NC];
     __shared__ unsigned int s_keep[NK];
-    const int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int bid = xcd_order(block, nblocks);
     const int f = bid / D.fast_cells[GRP], tid = threadIdx.x;
     int cc = bid % D.fast_cells[GRP], c0 = 0, lv = D.fast_lv[GRP][0];      // the cell inside this launch's levels (every offset into the kernel arguments static: one batch of scalar loads)
 #pragma unroll
@@ -472,6 +473,8 @@ __global__ __launch_bounds__(T) void k_fast(OrbDev D) {
     }
     if (tid == 0) *cnt_out = n;
 }
+template <int S, int NC, int NK, int T, int GRP>
+__global__ __launch_bounds__(T) void k_fast(OrbDev D) { fast_body<S, NC, NK, T, GRP>(D, blockIdx.x, gridDim.x); }
 
 // ---------------------------------------------------------------- quadtree (DistributeOctTree), one workgroup per (frame, level)
 struct QNode { int ulx, uly, urx, ury, blx, bly, brx, bry, key0, nk, nomore, prev, next; };
@@ -601,7 +604,9 @@ __global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) { if (threadIdx.
 #define QL_CAND 4096
 #define QL_NODES 1024
 struct QN { short x0, y0, x1, y1; unsigned short key0, nk, id, pad; };     // 16 bytes: box, key range, creation number
-#define QT 256
+#ifndef QT
+#define QT 512                  // (one frame: 256 threads 0.0938 ms, 512 0.0903, 1024 0.0901; 64 frames: 0.424, 0.424, 0.458)
+#endif
 #define QL_CELLS (4*QT)
 // exclusive block scan of 4 values per thread (thread t owns elements 4t .. 4t+3): ex[j] = sum of everything before element 4t+j
 __device__ __forceinline__ void qscan4(const int v[4], int *s_w, int tid, int ex[4], int &total) {
@@ -629,9 +634,11 @@ __device__ __forceinline__ void qscan4(const int v[4], int *s_w, int tid, int ex
 // (compaction / rank sort) -> child counts (one wave per node) -> scan + cut -> stable 4-way partition of the keys (one wave per node)
 // -> child records + new list (scans).  Nodes live in a pool indexed by the list: the first non-empty child takes its parent's slot, so
 // the pool never holds more than the list.  Levels that do not fit (candidates, nodes) fall back to k_octree_serial.
-// (A problem that does not fit is flagged for k_octree_serial, a launch of its own: 4.8 us to find none.  Solved on the spot by thread 0 instead, the serial code's
-// registers and scratch cost this kernel more than that launch -- 64 frames: 0.449 against 0.424 ms; one frame: 54.4 us against 44.8 + 4.8.)
-#define Q_FALLBACK() do { if (tid == 0) D.qfallback[blockIdx.x] = 1; return; } while (0)
+// A problem that does not fit is flagged for k_octree_serial and, in pinned host memory, for the host: tsorb_run looks at that word after its synchronisation and only then
+// launches the serial pass and the orientation / descriptor kernels a second time (never on camera images; until round 6 k_octree_serial was launched every time: 4.8 us
+// to find nothing).  Solved on the spot by thread 0 instead, the serial code's registers and scratch cost this kernel more than that launch -- 64 frames: 0.449 against
+// 0.424 ms; one frame: 54.4 us against 44.8 + 4.8.
+#define Q_FALLBACK() do { if (tid == 0) { D.qfallback[blockIdx.x] = 1; *selcnt = 0; *D.h_fallback = 1; } return; } while (0)     // (the level counts as empty until the serial pass has run)
 #ifdef Q_STAMPS       // (tools/diag/octree_stamps.sh) thread 0's cycles by phase into D.snbuf: gather, first nodes, per pass: order / counts / cut / partition / lists, arg-max
 #define QS(i) do { if (tid == 0) { const long long t1_ = clock64(); q_acc[i] += (int)(t1_ - q_t0); q_t0 = t1_; } } while (0)
 #else
@@ -673,21 +680,24 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     if (nk == 0) { if (tid == 0) *selcnt = 0; return; }
     if (nk > QL_CAND) Q_FALLBACK();
     __syncthreads();
+    const float inv_ncols = 1.0f/(float)G.nCols;
     for (int k0 = tid; k0 < nk; k0 += 8*QT) {            // eight entries per thread and round: their loads are in flight together
         int cell[8]; uint32_t p[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = min(k0 + u*QT, nk - 1);
-            int lo = 0, hi = ncell;                      // the last cell whose offset is <= k (an empty cell shares its successor's offset)
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= k) lo = mid; else hi = mid; }
-            cell[u] = lo;
+        for (int u = 0; u < 8; u++) cell[u] = 0;
+        // the last cell whose offset is <= k (an empty cell shares its successor's offset): a fixed number of steps, the eight searches' LDS reads of a step in
+        // flight together (a while loop per entry was eight times ten dependent reads: 8 k of the 18 k cycles this gather took)
+        for (int step = QL_CELLS/2; step > 0; step >>= 1) {
+            if (step >= ncell) continue;
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int k = min(k0 + u*QT, nk - 1), c = cell[u] + step; if (c < ncell && coff[min(c, QL_CELLS - 1)] <= k) cell[u] = c; }
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) { const int k = min(k0 + u*QT, nk - 1); p[u] = ck[(size_t)cell[u]*CELL_CAP + (k - coff[cell[u]])]; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int k = k0 + u*QT; if (k >= nk) break;
-            const int i = cell[u] / G.nCols, j = cell[u] - i*G.nCols;
+            const int i = (int)(((float)cell[u] + 0.5f)*inv_ncols), j = cell[u] - i*G.nCols;          // (cell / nCols: exact for these sizes, a tenth of the division's instructions)
             cx[k] = (unsigned short)((int)(p[u] & 255u) + j*G.wCell); cy[k] = (unsigned short)((int)((p[u] >> 8) & 255u) + i*G.hCell); cr[k] = (unsigned short)(p[u] >> 16);
         }
     }
@@ -762,7 +772,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
             const int ux = q.x0 + ((q.x1 - q.x0 + 1) >> 1), by = q.y0 + ((q.y1 - q.y0 + 1) >> 1);     // ceil(half extent), ORBextractor.cc:496-497
             const int seg = one ? (((q.nk + QT/64 - 1)/(QT/64) + 63) & ~63) : q.nk, k_lo = one ? min(wv*seg, (int)q.nk) : 0, k_hi = one ? min(k_lo + seg, (int)q.nk) : q.nk;
             int c0 = 0, c1 = 0, c2 = 0;
-            for (int b2 = k_lo; __any(b2 < k_hi); b2 += lpn) {
+            for (int b2 = k_lo; __any(b2 < k_hi); b2 += lpn) {            // (four rounds' reads in flight together: measured slower -- most nodes take one round, and a lone wave pays for the other three's ballots)
                 const int k = b2 + sub; int z = -1;
                 if (k < k_hi) { const int key = keys[q.key0 + k]; z = (cx[key] < ux) ? ((cy[key] < by) ? 0 : 2) : ((cy[key] < by) ? 1 : 3); }
                 c0 += __popcll(__ballot(z == 0) & gmask); c1 += __popcll(__ballot(z == 1) & gmask); c2 += __popcll(__ballot(z == 2) & gmask);
@@ -895,6 +905,26 @@ __device__ __forceinline__ float fast_atan2f_dev(float y, float x) {     // cv::
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
 }
+// rows +v / -v of a keypoint's circular patch (lane v of its sixteen): the lane's share of the moments m10, m01 (ORBextractor.cc:77-104)
+__device__ __forceinline__ void orient_rows(const OrbDev &D, const LevelGeo &G, int f, float kx, float ky, int v, int &m10, int &m01) {
+    // as 8 + 8 unaligned dwords (columns -16 .. 15; a keypoint is >= 16 px inside the level, the level sits in a 19-px frame), the columns beyond
+    // umax[v] masked out: 16 loads in flight instead of up to 62 dependent byte loads
+    const uint8_t *c = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)(EDGE + (int)rintf(ky))*G.bw + EDGE + (int)rintf(kx);
+    const int d = v == 0 ? HALF_PATCH : D.umax[v];
+    const uint8_t *rp = c + (ptrdiff_t)v*G.bw - 16, *rm = c - (ptrdiff_t)v*G.bw - 16;
+    uint32_t wp[8], wm[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) { wp[w] = *(const u32_unaligned *)(rp + 4*w); wm[w] = *(const u32_unaligned *)(rm + 4*w); }
+    int vs = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int u = 4*w + b - 16;
+            if (u >= -d && u <= d) { const int vp = (wp[w] >> (8*b)) & 255, vm = (wm[w] >> (8*b)) & 255; vs += vp - vm; m10 += u*(v == 0 ? vp : vp + vm); }
+        }
+    m01 = v*vs;
+}
 __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
     const int bid = xcd_order(blockIdx.x, gridDim.x);
     const int g = (bid*256 + threadIdx.x) >> 4, v = threadIdx.x & 15;
@@ -905,25 +935,7 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
     const bool valid = (slot - G.kp0) < D.selcnt[(size_t)f*D.nlevels + l];
     float *s = D.sel + ((size_t)f*per + slot)*4;
     int m10 = 0, m01 = 0;
-    if (valid) {
-        // rows +v / -v of the circular patch as 8 + 8 unaligned dwords (columns -16 .. 15; a keypoint is >= 16 px inside the level, the level
-        // sits in a 19-px frame), the columns beyond umax[v] masked out: 16 loads in flight instead of up to 62 dependent byte loads
-        const uint8_t *c = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + (size_t)(EDGE + (int)rintf(s[1]))*G.bw + EDGE + (int)rintf(s[0]);
-        const int d = v == 0 ? HALF_PATCH : D.umax[v];
-        const uint8_t *rp = c + (ptrdiff_t)v*G.bw - 16, *rm = c - (ptrdiff_t)v*G.bw - 16;
-        uint32_t wp[8], wm[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) { wp[w] = *(const u32_unaligned *)(rp + 4*w); wm[w] = *(const u32_unaligned *)(rm + 4*w); }
-        int vs = 0;
-#pragma unroll
-        for (int w = 0; w < 8; w++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int u = 4*w + b - 16;
-                if (u >= -d && u <= d) { const int vp = (wp[w] >> (8*b)) & 255, vm = (wm[w] >> (8*b)) & 255; vs += vp - vm; m10 += u*(v == 0 ? vp : vp + vm); }
-            }
-        m01 = v*vs;
-    }
+    if (valid) orient_rows(D, G, f, s[0], s[1], v, m10, m01);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 16); m01 += __shfl_xor(m01, o, 16); }
     // the steering terms of rBRIEF, (float)cos((double)angle), (float)sin((double)angle): fp64 library code of a few hundred instructions that the
@@ -949,9 +961,9 @@ __global__ __launch_bounds__(256) void k_orient(OrbDev D) {
 #define BT_W 64
 #define BT_H 64
 #define BT_R 4                  // output rows per thread of the vertical pass
-__global__ __launch_bounds__(256) void k_blur(OrbDev D) {
+__device__ __forceinline__ void blur_body(const OrbDev &D, const int block, const int nblocks) {
     // one launch for all levels (the small levels do not fill the chip on their own): block -> (frame, level, tile)
-    const int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int bid = xcd_order(block, nblocks);
     const int f = bid / D.btiles_per_frame, bt = bid % D.btiles_per_frame;
     int l = 0;
     while (l + 1 < D.nlevels && bt >= D.L[l+1].bt0) l++;
@@ -1014,25 +1026,20 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev D) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_blur(OrbDev D) { blur_body(D, blockIdx.x, gridDim.x); }
+// A few frames: the blur's tiles ride in the detector's launch (both read the pyramid only; the blur as a launch of its own is 6.7 us of the ~100 of a per-frame
+// call, 1.7 of them work) -- the detector's workgroups first.  On a batch the two stay apart (k_fast's small-tile instance has half the threads and a third of the LDS).
+__global__ __launch_bounds__(256) void k_fast_blur(OrbDev D, int nfast) {
+    if ((int)blockIdx.x < nfast) fast_body<TILE_MAX, 2048, CELL_CAP, 256, 1>(D, blockIdx.x, nfast);
+    else blur_body(D, blockIdx.x - nfast, gridDim.x - nfast);
+}
+
 // ---------------------------------------------------------------- descriptors: 32 lanes per keypoint, lane i -> byte i; straight into the level-major output
 // (ORBextractor.cc:1106-1112: coordinates scaled back to level 0).  A keypoint's place is its level's first place -- the counts of the levels before it -- plus
 // its place in the level: the separate packing launch (a frame's keypoints and descriptors read back and written again, 4.7 us of the 107 of a per-frame call)
 // is gone since round 6.
-__global__ __launch_bounds__(256) void k_describe(OrbDev D) {
-    const int g = (xcd_order(blockIdx.x, gridDim.x)*256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;      // 32 lanes per keypoint: two keypoints per wave
-    const int per = D.slots_per_frame, f = g / per, slot = g % per;
-    if (f >= D.n) return;
-    int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;
-    const LevelGeo &G = D.L[l];
-    const int *sc = D.selcnt + (size_t)f*D.nlevels;
-    int before = 0, total = 0, mine = 0;
-#pragma unroll
-    for (int k = 0; k < MAXL; k++) { const int cnt = k < D.nlevels ? sc[k] : 0; before += k < l ? cnt : 0; mine = k == l ? cnt : mine; total += cnt; }
-    if (slot == 0 && lane == 0) D.out_cnt[f] = min(total, D.cap);
-    const int o = before + slot - G.kp0;
-    if ((slot - G.kp0) >= mine || o >= D.cap) return;
-    const float4 sv = *(const float4 *)(D.sel + ((size_t)f*per + slot)*4);
-    const float a = D.selab[2*((size_t)f*per + slot)], b = D.selab[2*((size_t)f*per + slot) + 1];      // cos, sin of the angle (k_orient)
+// byte `lane` of the descriptor of the keypoint sv = (x, y, response, angle) with a, b = cos, sin of its angle, and the keypoint's six output values, at place o of frame f
+__device__ __forceinline__ void describe_out(const OrbDev &D, const LevelGeo &G, int f, int l, int o, int lane, const float4 sv, const float a, const float b) {
     const uint8_t *c = D.blur + (size_t)f*D.blur_frame + G.blur_off + (size_t)(int)rintf(sv.y)*G.w + (int)rintf(sv.x);
     const int8_t *pat = d_pattern + 32*lane;
     int val = 0;
@@ -1048,6 +1055,53 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev D) {
         const float kx = l ? __fmul_rn(sv.x, G.sf) : sv.x, ky = l ? __fmul_rn(sv.y, G.sf) : sv.y, ks = (float)(int)__fmul_rn((float)PATCH_SIZE, G.sf);
         D.out_kp[((size_t)f*D.cap + o)*6 + lane] = lane == 0 ? kx : lane == 1 ? ky : lane == 2 ? ks : lane == 3 ? sv.w : lane == 4 ? sv.z : (float)l;
     }
+}
+__global__ __launch_bounds__(256) void k_describe(OrbDev D) {
+    const int g = (xcd_order(blockIdx.x, gridDim.x)*256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;      // 32 lanes per keypoint: two keypoints per wave
+    const int per = D.slots_per_frame, f = g / per, slot = g % per;
+    if (f >= D.n) return;
+    int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;
+    const LevelGeo &G = D.L[l];
+    const int *sc = D.selcnt + (size_t)f*D.nlevels;
+    int before = 0, total = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < MAXL; k++) { const int cnt = k < D.nlevels ? sc[k] : 0; before += k < l ? cnt : 0; mine = k == l ? cnt : mine; total += cnt; }
+    if (slot == 0 && lane == 0) D.out_cnt[f] = min(total, D.cap);
+    const int o = before + slot - G.kp0;
+    if ((slot - G.kp0) >= mine || o >= D.cap) return;
+    const float4 sv = *(const float4 *)(D.sel + ((size_t)f*per + slot)*4);
+    const float a = D.selab[2*((size_t)f*per + slot)], b = D.selab[2*((size_t)f*per + slot) + 1];      // cos, sin of the angle (k_orient)
+    describe_out(D, G, f, l, o, lane, sv, a, b);
+}
+// A few frames: orientation and descriptor in one launch (each launch of the per-frame chain costs ~5 us before its first instruction).  The keypoint's 32 lanes: sixteen
+// take the patch's rows, lane 0 the angle and its cosine / sine (fp64 library code: on a batch that is why k_orient does them sixteen keypoints per wave pass, not two).
+__global__ __launch_bounds__(256) void k_orient_describe(OrbDev D) {
+    const int g = (xcd_order(blockIdx.x, gridDim.x)*256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;
+    const int per = D.slots_per_frame, f = g / per, slot = g % per;
+    if (f >= D.n) return;
+    int l = 0; while (l + 1 < D.nlevels && slot >= D.L[l+1].kp0) l++;
+    const LevelGeo &G = D.L[l];
+    const int *sc = D.selcnt + (size_t)f*D.nlevels;
+    int before = 0, total = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < MAXL; k++) { const int cnt = k < D.nlevels ? sc[k] : 0; before += k < l ? cnt : 0; mine = k == l ? cnt : mine; total += cnt; }
+    if (slot == 0 && lane == 0) D.out_cnt[f] = min(total, D.cap);
+    const int o = before + slot - G.kp0;
+    if ((slot - G.kp0) >= mine || o >= D.cap) return;
+    float4 sv = *(const float4 *)(D.sel + ((size_t)f*per + slot)*4);
+    int m10 = 0, m01 = 0;
+    if (lane < 16) orient_rows(D, G, f, sv.x, sv.y, lane, m10, m01);
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1) { m10 += __shfl_xor(m10, w, 16); m01 += __shfl_xor(m01, w, 16); }
+    float angle = 0.f, a = 0.f, b = 0.f;
+    if (lane == 0) {
+        angle = fast_atan2f_dev((float)m01, (float)m10);
+        const float factorPI = (float)(3.14159265358979323846/180.f);
+        const float rad = __fmul_rn(angle, factorPI);
+        a = (float)cos((double)rad); b = (float)sin((double)rad);
+    }
+    sv.w = __shfl(angle, 0, 32); a = __shfl(a, 0, 32); b = __shfl(b, 0, 32);
+    describe_out(D, G, f, l, o, lane, sv, a, b);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1135,6 +1189,7 @@ struct OCtx {
     int nfeatures = 1000, nlevels = 8, ini_th = 20, min_th = 7; float scale = 1.2f;
     float sf[MAXL], isf[MAXL]; int nfl[MAXL], umax[16], gk[7];
     std::vector<void *> allocs; bool uploaded = false; int fast_shape = -1;       // (tsorb_debug_fast_shape)
+    int *h_fb = nullptr; int fallbacks = 0;                                     // the run's fallback word (pinned), runs that took the serial pass
     int pyr_shape = -1, pyr_split = P1_SPLIT; PyrOne Q[3]; int q_inst[3];           // (tsorb_debug_pyramid) k_pyramid_one's launches: [0] levels 0 .. split from the image, [1] the rest from level split, [2] every level from the image; instance 0 = small buffers, 1 = large, -1 = does not fit
     OrbDev D;
     // the SLAM front-end calls once per frame with the same geometry: buffers and pinned staging are kept between calls
@@ -1158,6 +1213,8 @@ int tsorb_create(void **ctx, int nfeatures, float scale, int nlevels, int ini_th
     if (hipSetDevice(device) != hipSuccess) return TSORB_ERR_DEVICE;
     OCtx *c = new OCtx(); c->device = device; c->nfeatures = nfeatures; c->scale = scale; c->nlevels = nlevels; c->ini_th = ini_th; c->min_th = min_th;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TSORB_ERR_DEVICE; }
+    if (hipHostMalloc((void **)&c->h_fb, 64, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return TSORB_ERR_DEVICE; }
+    *c->h_fb = 0;
     // ORBextractor::ORBextractor, ORBextractor.cc:410-471 (fp32 arithmetic as there)
     c->sf[0] = 1.0f; for (int i = 1; i < nlevels; i++) c->sf[i] = c->sf[i-1]*scale;
     for (int i = 0; i < nlevels; i++) c->isf[i] = 1.0f/c->sf[i];
@@ -1178,6 +1235,7 @@ int tsorb_create(void **ctx, int nfeatures, float scale, int nlevels, int ini_th
     *ctx = c; return TSORB_OK;
 }
 int tsorb_destroy(void *ctx) { OCtx *c = (OCtx *)ctx; if (!c) return TSORB_ERR_ARG; hipSetDevice(c->device); ofree(c);
+    if (c->h_fb) hipHostFree(c->h_fb);
     if (c->m_buf) hipFree(c->m_buf); if (c->m_feat) hipFree(c->m_feat); if (c->mq_dev) hipFree(c->mq_dev); if (c->mq_host) hipHostFree(c->mq_host);
     hipStreamDestroy(c->stream); delete c; return TSORB_OK; }
 const char *tsorb_last_error(void *ctx) { return ctx ? ((OCtx *)ctx)->err.c_str() : "null ctx"; }
@@ -1197,6 +1255,7 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     }
     ofree(c);
     OrbDev &D = c->D; memset(&D, 0, sizeof(D));
+    { void *dp = nullptr; if (hipHostGetDevicePointer(&dp, c->h_fb, 0) != hipSuccess) { c->err = "hipHostGetDevicePointer failed"; return TSORB_ERR_DEVICE; } D.h_fallback = (int *)dp; }
     D.n = n; D.nlevels = c->nlevels; D.ini_th = c->ini_th; D.min_th = c->min_th; D.w = w; D.h = h; D.stride = stride; D.cap = cap;
     memcpy(D.umax, c->umax, sizeof(D.umax)); memcpy(D.gk, c->gk, sizeof(D.gk));
     size_t po = 0, bo = 0; int cell0 = 0, kp0 = 0;
@@ -1293,13 +1352,24 @@ int tsorb_run(void *ctx) {
         else if (fast_shape == 3) hipLaunchKernelGGL((k_fast<40, 1024, 320, 64, 0>), dim3(D.n*D.fast_cells[0]), dim3(64), 0, c->stream, D);
         else hipLaunchKernelGGL((k_fast<40, 1024, 320, 128, 0>), dim3(D.n*D.fast_cells[0]), dim3(128), 0, c->stream, D);
     }
-    if (D.fast_cells[1] > 0) hipLaunchKernelGGL((k_fast<TILE_MAX, 2048, CELL_CAP, 256, 1>), dim3(D.n*D.fast_cells[1]), dim3(256), 0, c->stream, D);
+    const bool blur_rides = few && D.fast_cells[1] > 0;
+    if (blur_rides) hipLaunchKernelGGL(k_fast_blur, dim3(D.n*D.fast_cells[1] + D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D, D.n*D.fast_cells[1]);
+    else if (D.fast_cells[1] > 0) hipLaunchKernelGGL((k_fast<TILE_MAX, 2048, CELL_CAP, 256, 1>), dim3(D.n*D.fast_cells[1]), dim3(256), 0, c->stream, D);
+    *c->h_fb = 0;                                                                             // (the previous run has been waited for)
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
-    hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);     // only levels the LDS version flagged
-    hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
-    hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D);
-    hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
+    if (!few) hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
+    if (!blur_rides) hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D);
+    if (few) hipLaunchKernelGGL(k_orient_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);      // a few frames: orientation inside the descriptor launch
+    else hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
+    if (*(volatile int *)c->h_fb) {             // a level the LDS quadtree could not hold (counted as empty so far): the serial pass, then orientation and descriptors again with its keypoints in place
+        c->fallbacks++;
+        hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);
+        if (few) hipLaunchKernelGGL(k_orient_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
+        else { hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
+               hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D); }
+        OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
+    }
     return TSORB_OK;
 }
 int tsorb_download(void *ctx, float *kp, uint8_t *desc, int32_t *count) {
@@ -1321,6 +1391,7 @@ int tsorb_extract_batch(void *ctx, const uint8_t *imgs, int n, int w, int h, int
     return tsorb_download(ctx, kp, desc, count);
 }
 int tsorb_debug_fast_shape(void *ctx, int shape) { OCtx *c = (OCtx *)ctx; if (!c || shape < -1 || shape > 3) return TSORB_ERR_ARG; c->fast_shape = shape; c->key[0] = 0; return TSORB_OK; }      // (key: the next upload sets the geometry up again)
+int tsorb_debug_fallbacks(void *ctx) { OCtx *c = (OCtx *)ctx; return c ? c->fallbacks : TSORB_ERR_ARG; }
 int tsorb_debug_pyramid(void *ctx, int shape) { OCtx *c = (OCtx *)ctx; if (!c || shape < -1 || (shape > 2 && shape < 100) || shape >= 100 + MAXL) return TSORB_ERR_ARG;
     if (shape >= 100) { c->pyr_split = shape - 100; c->key[0] = 0; } else c->pyr_shape = shape; return TSORB_OK; }      // (100 + s: the split level of the two launches, at the next upload)
 #ifdef Q_STAMPS

@@ -12,7 +12,7 @@ _lib = None
 
 EXPORTED_SYMBOLS = ["tsorb_create", "tsorb_destroy", "tsorb_last_error", "tsorb_get_levels", "tsorb_get_scale_factors",
                     "tsorb_get_features_per_level", "tsorb_extract_batch", "tsorb_upload", "tsorb_run", "tsorb_download",
-                    "tsorb_debug_level", "tsorb_debug_fast_shape", "tsorb_debug_pyramid", "tsorb_match_set_frame", "tsorb_match_set_features", "tsorb_match_search"]
+                    "tsorb_debug_level", "tsorb_debug_fast_shape", "tsorb_debug_pyramid", "tsorb_debug_fallbacks", "tsorb_match_set_frame", "tsorb_match_set_features", "tsorb_match_search"]
 
 
 class TsorbError(RuntimeError):
@@ -39,6 +39,7 @@ def load_library():
         L.tsorb_debug_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, up, ip, ip]
         L.tsorb_debug_fast_shape.argtypes = [vp, C.c_int]
         L.tsorb_debug_pyramid.argtypes = [vp, C.c_int]
+        L.tsorb_debug_fallbacks.argtypes = [vp]
         L.tsorb_match_set_frame.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.tsorb_match_set_features.argtypes = [vp, fp, up, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.tsorb_match_search.argtypes = [vp, C.c_int, fp, fp, ip, up, C.c_int, ip, ip, ip, ip, ip, ip]
@@ -145,6 +146,10 @@ class ORBextractor:
     def debug_pyramid(self, shape=-1):
         """Diagnostics: how the pyramid is formed (include/tsorb.h): 0 a launch per level, 1 every level from the input image in one launch, -1 by the batch size."""
         self._check(self.lib.tsorb_debug_pyramid(self.ctx, int(shape)), "tsorb_debug_pyramid")
+
+    def debug_fallbacks(self):
+        """Runs of this extractor that took the serial quadtree pass (include/tsorb.h)."""
+        return int(self.lib.tsorb_debug_fallbacks(self.ctx))
 
     def debug_level(self, frame, level, blurred=False):
         n, h, w = self._shape
