@@ -256,6 +256,18 @@ def also_lines(gpu, local_rank, torch, steps=10):
     out["c2_orb_64_frames"] = {"ms_per_batch": dt*1e3, "ms_per_batch_min": min(ts)*1e3, "ms_per_batch_max": max(ts)*1e3, "timed_batches": 20, "keypoints_per_s": nk/dt, "frames_per_s": 64/dt,
                                "roofline": {"bound": "hbm", "kernel": "whole ORB pipeline", "achieved": 64*4.7e6/dt/1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": 64*4.7e6/dt/1e9/HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 64*4.7e6}}
+    # ORB, ONE frame: the call frame.cc:328-331 makes per camera image (resident: the device chain alone; call: upload + chain + download)
+    ex.upload(imgs[:1])
+    for _ in range(5):
+        ex.run()
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter(); ex.run(); ts.append(time.perf_counter() - t0)
+    tc = []
+    for _ in range(20):
+        t0 = time.perf_counter(); ex.extract_batch(imgs[:1]); tc.append(time.perf_counter() - t0)
+    out["orb_one_frame"] = {"ms_resident": float(np.median(ts))*1e3, "ms_resident_min": min(ts)*1e3, "ms_resident_max": max(ts)*1e3,
+                            "ms_call": float(np.median(tc))*1e3, "ms_call_min": min(tc)*1e3, "ms_call_max": max(tc)*1e3, "timed": 20, "keypoints": int(len(ex.download()[0][0]))}
     return out
 
 

@@ -42,7 +42,7 @@ def test_pyramid_in_one_launch_is_the_chained_pyramid(oracle_lib, shape):
     imgs = np.stack([np.ascontiguousarray(np.tile(synthetic_frame(60 + s), (1, 2))[:h, :w]) for s in range(6)])
     ex = ORBextractor(1000, 1.2, 8, 20, 7, device=0)
     try:
-        for mode, batch in ((1, imgs[:1]), (1, imgs), (2, imgs[:1]), (2, imgs[:3]), (0, imgs[:1]), (-1, imgs[:2]), (-1, imgs), (102, imgs[:1]), (105, imgs[:2]), (103, imgs[:1])):
+        for mode, batch in ((1, imgs[:1]), (1, imgs), (2, imgs[:1]), (2, imgs[:3]), (3, imgs[:1]), (3, imgs), (0, imgs[:1]), (-1, imgs[:2]), (-1, imgs), (102, imgs[:1]), (105, imgs[:2]), (103, imgs[:1])):
             ex.debug_pyramid(mode)                  # (100 + s: the split level of the two launches; the shape stays as set before)
             if mode >= 100: ex.debug_pyramid(1)
             res = ex.extract_batch(batch)
@@ -126,8 +126,13 @@ def test_large_batches_take_the_split_detector_and_agree(orb, oracle_lib):
             for f in (0, 7, 30, 31):
                 _same(alt[f], res[f])
             _same(orb.extract_batch(imgs[3:4])[0], res[3])        # (the split on a single frame)
-    finally:
         orb.debug_fast_shape(-1)
+        orb.debug_pyramid(200)                                    # orientation and blur as launches of their own (one launch by default on a batch)
+        apart = orb.extract_batch(imgs)
+        for f in (0, 7, 30, 31):
+            _same(apart[f], res[f])
+    finally:
+        orb.debug_fast_shape(-1); orb.debug_pyramid(201)
 
 
 @pytest.mark.gpu

@@ -925,8 +925,8 @@ __device__ __forceinline__ void orient_rows(const OrbDev &D, const LevelGeo &G, 
         }
     m01 = v*vs;
 }
-__global__ __launch_bounds__(256) void k_orient(OrbDev D) {
-    const int bid = xcd_order(blockIdx.x, gridDim.x);
+__device__ __forceinline__ void orient_body(const OrbDev &D, const int block, const int nblocks) {
+    const int bid = xcd_order(block, nblocks);
     const int g = (bid*256 + threadIdx.x) >> 4, v = threadIdx.x & 15;
     const int per = D.slots_per_frame, f = g / per, slot = g % per;
     if (f >= D.n) return;
@@ -1027,6 +1027,13 @@ __device__ __forceinline__ void blur_body(const OrbDev &D, const int block, cons
 }
 
 __global__ __launch_bounds__(256) void k_blur(OrbDev D) { blur_body(D, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void k_orient(OrbDev D) { orient_body(D, blockIdx.x, gridDim.x); }
+// A batch: orientation (waits for the pyramid's lines around 1000 keypoints per frame: latency) and blur (every pixel once: bandwidth) need different things of the device
+// and nothing of each other: one launch, the orientation's workgroups first.
+__global__ __launch_bounds__(256) void k_orient_blur(OrbDev D, int norient) {
+    if ((int)blockIdx.x < norient) orient_body(D, blockIdx.x, norient);
+    else blur_body(D, blockIdx.x - norient, gridDim.x - norient);
+}
 // A few frames: the blur's tiles ride in the detector's launch (both read the pyramid only; the blur as a launch of its own is 6.7 us of the ~100 of a per-frame
 // call, 1.7 of them work) -- the detector's workgroups first.  On a batch the two stay apart (k_fast's small-tile instance has half the threads and a third of the LDS).
 __global__ __launch_bounds__(256) void k_fast_blur(OrbDev D, int nfast) {
@@ -1189,8 +1196,9 @@ struct OCtx {
     int nfeatures = 1000, nlevels = 8, ini_th = 20, min_th = 7; float scale = 1.2f;
     float sf[MAXL], isf[MAXL]; int nfl[MAXL], umax[16], gk[7];
     std::vector<void *> allocs; bool uploaded = false; int fast_shape = -1;       // (tsorb_debug_fast_shape)
+    int merge_ob = 1;                                                           // (tsorb_debug_pyramid 200 / 201) a batch's orientation and blur in one launch
     int *h_fb = nullptr; int fallbacks = 0;                                     // the run's fallback word (pinned), runs that took the serial pass
-    int pyr_shape = -1, pyr_split = P1_SPLIT; PyrOne Q[3]; int q_inst[3];           // (tsorb_debug_pyramid) k_pyramid_one's launches: [0] levels 0 .. split from the image, [1] the rest from level split, [2] every level from the image; instance 0 = small buffers, 1 = large, -1 = does not fit
+    int pyr_shape = -1, pyr_split = P1_SPLIT; PyrOne Q[3 + MAXL/2 + 1]; int q_inst[3 + MAXL/2 + 1], n_pairs = 0;           // (tsorb_debug_pyramid) k_pyramid_one's launches: [0] levels 0 .. split from the image, [1] the rest from level split, [2] every level from the image; instance 0 = small buffers, 1 = large, -1 = does not fit
     OrbDev D;
     // the SLAM front-end calls once per frame with the same geometry: buffers and pinned staging are kept between calls
     MatchDev M; bool m_set = false; void *m_buf = nullptr; size_t m_cap = 0; void *m_feat = nullptr; size_t m_feat_cap = 0;   // search grid of the current frame
@@ -1287,9 +1295,8 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     {   // k_pyramid_one's tilings: 64 x 16 one or two levels below the base, 32 x 16 three, 16 x 16 further down (a tile's cost grows with its depth), halved until
         // every stage's region (bounded from above: a range of n pixels reads at most ceil(n scale) + 3 of the level before; + 4 taken) fits the LDS buffers and tables
         const int NL = c->nlevels, sp = std::min(std::max(c->pyr_split, 0), NL - 1);
-        const int bases[3] = { 0, sp, 0 }, tops[3] = { sp, NL - 1, NL - 1 };
-        for (int q = 0; q < 3; q++) {
-            PyrOne &Q = c->Q[q]; memset(&Q, 0, sizeof(Q)); Q.base = bases[q]; Q.top = tops[q]; c->q_inst[q] = 0;
+        auto tiling = [&](int base, int top, PyrOne &Q, int &qi) {
+            memset(&Q, 0, sizeof(Q)); Q.base = base; Q.top = top; qi = 0;
             for (int l = Q.base + 1; l <= Q.top; l++) {
                 const int dep = l - Q.base; int tw = dep <= 2 ? 64 : dep == 3 ? 32 : 16, th = 16;
                 for (;;) {
@@ -1297,8 +1304,8 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
                     for (int k = l; k > Q.base; k--) { wk = std::min((int)ceil(wk*D.rsx[k]) + 4, D.L[k-1].w); hk = std::min((int)ceil(hk*D.rsy[k]) + 4, D.L[k-1].h);
                         need = std::max(need, 4*((wk + 3)/4)*hk); if (k > Q.base + 1) { sw += wk; sh += hk; } }
                     const int inst = (need <= 4096 && sw <= 192 && sh <= 192) ? 0 : (need <= 16384 && sw <= 512 && sh <= 512) ? 1 : -1;
-                    if (inst >= 0) { c->q_inst[q] = c->q_inst[q] < 0 ? -1 : std::max(c->q_inst[q], inst); break; }
-                    if (tw > 8) tw /= 2; else if (th > 4) th /= 2; else { c->q_inst[q] = -1; break; }
+                    if (inst >= 0) { qi = qi < 0 ? -1 : std::max(qi, inst); break; }
+                    if (tw > 8) tw /= 2; else if (th > 4) th /= 2; else { qi = -1; break; }
                 }
                 Q.tw[l] = tw; Q.th[l] = th; Q.ncol[l] = (D.L[l].bw + tw - 1)/tw;
             }
@@ -1306,7 +1313,10 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
             for (int i = 0; i < Q.nl; i++) { const int l = Q.top - i; Q.t0[i] = t;
                 t += l == 0 ? (D.L[0].bh + P1_L0_ROWS - 1)/P1_L0_ROWS : Q.ncol[l]*((D.L[l].bh + Q.th[l] - 1)/Q.th[l]); }
             Q.t0[Q.nl] = t; Q.per_frame = t;
-        }
+        };
+        tiling(0, sp, c->Q[0], c->q_inst[0]); tiling(sp, NL - 1, c->Q[1], c->q_inst[1]); tiling(0, NL - 1, c->Q[2], c->q_inst[2]);
+        c->n_pairs = 0;                                       // (tsorb_debug_pyramid 3) two levels per launch: 0 - 1 from the image, 2 - 3 from level 1, ..
+        for (int b0 = 0; b0 < NL; b0 += 2) { const int q = 3 + c->n_pairs++; tiling(b0 == 0 ? 0 : b0 - 1, std::min(b0 + 1, NL - 1), c->Q[q], c->q_inst[q]); }
     }
     // strict 3x3 NMS leaves at most one corner per 2x2 block: the level-0 search area bounds every level's candidate count
     D.cand_cap = ((D.L[0].maxBX - D.L[0].minB)*(D.L[0].maxBY - D.L[0].minB))/4 + 64; D.node_cap = 64*(c->nfl[0] + 64); D.pool_cap = 16*D.cand_cap;
@@ -1342,6 +1352,8 @@ int tsorb_run(void *ctx) {
         else hipLaunchKernelGGL((k_pyramid_one<16384, 512, 512>), dim3(D.n*Q.per_frame), dim3(512), 0, c->stream, D, Q); };
     if (few && c->pyr_shape != 2 && c->q_inst[0] >= 0 && c->q_inst[1] >= 0) { pyr_launch(c->Q[0], c->q_inst[0]); pyr_launch(c->Q[1], c->q_inst[1]); }     // a few frames: two launches
     else if (few && c->q_inst[2] >= 0) pyr_launch(c->Q[2], c->q_inst[2]);                                                                                    // (or one)
+    else if (c->pyr_shape == 3 && [&] { for (int q = 0; q < c->n_pairs; q++) if (c->q_inst[3 + q] < 0) return false; return true; }())
+        for (int q = 0; q < c->n_pairs; q++) pyr_launch(c->Q[3 + q], c->q_inst[3 + q]);                                                                    // (experiment: two levels per launch, any batch)
     else {
         hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
         for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
@@ -1357,8 +1369,12 @@ int tsorb_run(void *ctx) {
     else if (D.fast_cells[1] > 0) hipLaunchKernelGGL((k_fast<TILE_MAX, 2048, CELL_CAP, 256, 1>), dim3(D.n*D.fast_cells[1]), dim3(256), 0, c->stream, D);
     *c->h_fb = 0;                                                                             // (the previous run has been waited for)
     hipLaunchKernelGGL(k_octree, dim3(D.n*D.nlevels), dim3(QT), 0, c->stream, D);
+    if (!few && !blur_rides && c->merge_ob) { const int no = (D.n*D.slots_per_frame*16 + 255)/256;
+        hipLaunchKernelGGL(k_orient_blur, dim3(no + D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D, no); }
+    else {
     if (!few) hipLaunchKernelGGL(k_orient, dim3((D.n*D.slots_per_frame*16 + 255)/256), dim3(256), 0, c->stream, D);
     if (!blur_rides) hipLaunchKernelGGL(k_blur, dim3(D.n*D.btiles_per_frame), dim3(256), 0, c->stream, D);
+    }
     if (few) hipLaunchKernelGGL(k_orient_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);      // a few frames: orientation inside the descriptor launch
     else hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
@@ -1392,7 +1408,8 @@ int tsorb_extract_batch(void *ctx, const uint8_t *imgs, int n, int w, int h, int
 }
 int tsorb_debug_fast_shape(void *ctx, int shape) { OCtx *c = (OCtx *)ctx; if (!c || shape < -1 || shape > 3) return TSORB_ERR_ARG; c->fast_shape = shape; c->key[0] = 0; return TSORB_OK; }      // (key: the next upload sets the geometry up again)
 int tsorb_debug_fallbacks(void *ctx) { OCtx *c = (OCtx *)ctx; return c ? c->fallbacks : TSORB_ERR_ARG; }
-int tsorb_debug_pyramid(void *ctx, int shape) { OCtx *c = (OCtx *)ctx; if (!c || shape < -1 || (shape > 2 && shape < 100) || shape >= 100 + MAXL) return TSORB_ERR_ARG;
+int tsorb_debug_pyramid(void *ctx, int shape) { OCtx *c = (OCtx *)ctx; if (!c || shape < -1 || (shape > 3 && shape < 100) || (shape >= 100 + MAXL && shape != 200 && shape != 201)) return TSORB_ERR_ARG;
+    if (shape == 200 || shape == 201) { c->merge_ob = shape - 200; return TSORB_OK; }
     if (shape >= 100) { c->pyr_split = shape - 100; c->key[0] = 0; } else c->pyr_shape = shape; return TSORB_OK; }      // (100 + s: the split level of the two launches, at the next upload)
 #ifdef Q_STAMPS
 int tsorb_debug_stamps(void *ctx, int32_t *out, int n) { OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG; hipSetDevice(c->device);
