@@ -59,6 +59,7 @@ struct OrbDev {
     int *h_fallback;                       // (pinned host memory) set when any level of the run was flagged: the host launches the serial pass only then
     float *selab;                          // [n][slots][2]  cos, sin of the keypoint angle (k_orient; read by k_describe)
     float *out_kp; uint8_t *out_desc; int *out_cnt;
+    float *h_kp; uint8_t *h_desc; int *h_cnt;     // the same three blocks in the pinned host buffer tsorb_download hands out: a few frames' results are stored there as well (no copy back)
     int umax[16]; int gk[7];
 };
 __device__ __constant__ int8_t d_pattern[1024];
@@ -1046,6 +1047,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(OrbDev D, int nfast) {
 // its place in the level: the separate packing launch (a frame's keypoints and descriptors read back and written again, 4.7 us of the 107 of a per-frame call)
 // is gone since round 6.
 // byte `lane` of the descriptor of the keypoint sv = (x, y, response, angle) with a, b = cos, sin of its angle, and the keypoint's six output values, at place o of frame f
+template <bool HOST>
 __device__ __forceinline__ void describe_out(const OrbDev &D, const LevelGeo &G, int f, int l, int o, int lane, const float4 sv, const float a, const float b) {
     const uint8_t *c = D.blur + (size_t)f*D.blur_frame + G.blur_off + (size_t)(int)rintf(sv.y)*G.w + (int)rintf(sv.x);
     const int8_t *pat = d_pattern + 32*lane;
@@ -1058,9 +1060,12 @@ __device__ __forceinline__ void describe_out(const OrbDev &D, const LevelGeo &G,
         val |= (t0 < t1) << t;
     }
     D.out_desc[((size_t)f*D.cap + o)*32 + lane] = (uint8_t)val;
+    if (HOST) D.h_desc[((size_t)f*D.cap + o)*32 + lane] = (uint8_t)val;
     if (lane < 6) {                                             // x, y, size, angle, response, octave
         const float kx = l ? __fmul_rn(sv.x, G.sf) : sv.x, ky = l ? __fmul_rn(sv.y, G.sf) : sv.y, ks = (float)(int)__fmul_rn((float)PATCH_SIZE, G.sf);
-        D.out_kp[((size_t)f*D.cap + o)*6 + lane] = lane == 0 ? kx : lane == 1 ? ky : lane == 2 ? ks : lane == 3 ? sv.w : lane == 4 ? sv.z : (float)l;
+        const float kv = lane == 0 ? kx : lane == 1 ? ky : lane == 2 ? ks : lane == 3 ? sv.w : lane == 4 ? sv.z : (float)l;
+        D.out_kp[((size_t)f*D.cap + o)*6 + lane] = kv;
+        if (HOST) D.h_kp[((size_t)f*D.cap + o)*6 + lane] = kv;
     }
 }
 __global__ __launch_bounds__(256) void k_describe(OrbDev D) {
@@ -1078,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev D) {
     if ((slot - G.kp0) >= mine || o >= D.cap) return;
     const float4 sv = *(const float4 *)(D.sel + ((size_t)f*per + slot)*4);
     const float a = D.selab[2*((size_t)f*per + slot)], b = D.selab[2*((size_t)f*per + slot) + 1];      // cos, sin of the angle (k_orient)
-    describe_out(D, G, f, l, o, lane, sv, a, b);
+    describe_out<false>(D, G, f, l, o, lane, sv, a, b);
 }
 // A few frames: orientation and descriptor in one launch (each launch of the per-frame chain costs ~5 us before its first instruction).  The keypoint's 32 lanes: sixteen
 // take the patch's rows, lane 0 the angle and its cosine / sine (fp64 library code: on a batch that is why k_orient does them sixteen keypoints per wave pass, not two).
@@ -1092,7 +1097,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbDev D) {
     int before = 0, total = 0, mine = 0;
 #pragma unroll
     for (int k = 0; k < MAXL; k++) { const int cnt = k < D.nlevels ? sc[k] : 0; before += k < l ? cnt : 0; mine = k == l ? cnt : mine; total += cnt; }
-    if (slot == 0 && lane == 0) D.out_cnt[f] = min(total, D.cap);
+    if (slot == 0 && lane == 0) { D.out_cnt[f] = min(total, D.cap); D.h_cnt[f] = min(total, D.cap); }
     const int o = before + slot - G.kp0;
     if ((slot - G.kp0) >= mine || o >= D.cap) return;
     float4 sv = *(const float4 *)(D.sel + ((size_t)f*per + slot)*4);
@@ -1108,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbDev D) {
         a = (float)cos((double)rad); b = (float)sin((double)rad);
     }
     sv.w = __shfl(angle, 0, 32); a = __shfl(a, 0, 32); b = __shfl(b, 0, 32);
-    describe_out(D, G, f, l, o, lane, sv, a, b);
+    describe_out<true>(D, G, f, l, o, lane, sv, a, b);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1196,6 +1201,7 @@ struct OCtx {
     int nfeatures = 1000, nlevels = 8, ini_th = 20, min_th = 7; float scale = 1.2f;
     float sf[MAXL], isf[MAXL]; int nfl[MAXL], umax[16], gk[7];
     std::vector<void *> allocs; bool uploaded = false; int fast_shape = -1;       // (tsorb_debug_fast_shape)
+    bool out_on_host = false;                                                   // the last run stored its results in h_out itself (a few frames)
     int merge_ob = 1;                                                           // (tsorb_debug_pyramid 200 / 201) a batch's orientation and blur in one launch
     int *h_fb = nullptr; int fallbacks = 0;                                     // the run's fallback word (pinned), runs that took the serial pass
     int pyr_shape = -1, pyr_split = P1_SPLIT; PyrOne Q[3 + MAXL/2 + 1]; int q_inst[3 + MAXL/2 + 1], n_pairs = 0;           // (tsorb_debug_pyramid) k_pyramid_one's launches: [0] levels 0 .. split from the image, [1] the rest from level split, [2] every level from the image; instance 0 = small buffers, 1 = large, -1 = does not fit
@@ -1337,6 +1343,8 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
         uint8_t *ob; if ((rc = oalloc(c, &ob, bkp + bcnt + bdesc))) return rc;
         D.out_kp = (float *)ob; D.out_cnt = (int *)(ob + bkp); D.out_desc = ob + bkp + bcnt;
         c->h_out_sz = bkp + bcnt + bdesc; OCK(hipHostMalloc(&c->h_out, c->h_out_sz, hipHostMallocDefault));
+        void *hd = nullptr; OCK(hipHostGetDevicePointer(&hd, c->h_out, 0));
+        D.h_kp = (float *)hd; D.h_cnt = (int *)((uint8_t *)hd + bkp); D.h_desc = (uint8_t *)hd + bkp + bcnt;
     }
     c->key[0] = n; c->key[1] = w; c->key[2] = h; c->key[3] = stride; c->key[4] = cap;
     if (c->nlevels > 1) hipLaunchKernelGGL(k_resize_tab, dim3(c->nlevels - 1), dim3(256), 0, c->stream, D);
@@ -1378,6 +1386,7 @@ int tsorb_run(void *ctx) {
     if (few) hipLaunchKernelGGL(k_orient_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);      // a few frames: orientation inside the descriptor launch
     else hipLaunchKernelGGL(k_describe, dim3((D.n*D.slots_per_frame*32 + 255)/256), dim3(256), 0, c->stream, D);
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
+    c->out_on_host = few;
     if (*(volatile int *)c->h_fb) {             // a level the LDS quadtree could not hold (counted as empty so far): the serial pass, then orientation and descriptors again with its keypoints in place
         c->fallbacks++;
         hipLaunchKernelGGL(k_octree_serial, dim3(D.n*D.nlevels), dim3(64), 0, c->stream, D);
@@ -1393,8 +1402,10 @@ int tsorb_download(void *ctx, float *kp, uint8_t *desc, int32_t *count) {
     hipSetDevice(c->device); OrbDev &D = c->D;
     const size_t bkp = sizeof(float)*(size_t)D.n*D.cap*6, bcnt = ((sizeof(int)*(size_t)D.n + 15)/16)*16, bdesc = (size_t)D.n*D.cap*32;
     const size_t bytes = desc ? bkp + bcnt + bdesc : bkp + bcnt;
-    OCK(hipMemcpyAsync(c->h_out, D.out_kp, bytes, hipMemcpyDeviceToHost, c->stream));
-    OCK(hipStreamSynchronize(c->stream));
+    if (!c->out_on_host) {                  // (a few frames: k_orient_describe stored them in h_out as well, and tsorb_run has waited for it)
+        OCK(hipMemcpyAsync(c->h_out, D.out_kp, bytes, hipMemcpyDeviceToHost, c->stream));
+        OCK(hipStreamSynchronize(c->stream));
+    }
     const uint8_t *hb = (const uint8_t *)c->h_out;
     if (kp) memcpy(kp, hb, bkp);
     if (count) memcpy(count, hb + bkp, sizeof(int)*(size_t)D.n);

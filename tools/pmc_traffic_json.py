@@ -24,6 +24,17 @@ def main():
     fr, wr = rows(fetch, pat), rows(write, pat)
     if not fr or not wr:
         raise SystemExit("no rows for %r in %s / %s" % (pat, fetch, write))
+    if len(sys.argv) > 6 and sys.argv[6] == "sum":          # the whole pipeline: every kernel dispatched once per batch (n = the number of batches of the run), copies left out
+        def total(rs):
+            nb = max(r[3] for r in rs)
+            return sum(r[4] for r in rs if r[3] == nb and "copyBuffer" not in r[0]), {("%s grid %d" % (r[0], r[1])): round(r[4]/1024.0, 2) for r in rs if r[3] == nb and "copyBuffer" not in r[0]}
+        f, fk = total(fr); w, wk = total(wr)
+        json.dump({"kernel": label, "fetch_size_kb_raw_max": f, "write_size_kb_raw_max": w,
+                   "correction": "guide (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request on gfx950 -> x2; WRITE_SIZE taken as reported; narrow gather "
+                                 "accesses are uncalibrated (orientation, descriptors).  Sum over the pipeline's kernels of the mean per dispatch",
+                   "source": "%s, %s" % (fetch, write), "per_kernel_fetch_mb_raw": fk, "per_kernel_write_mb_raw": wk}, open(dst, "w"), indent=1)
+        print(dst, f, w)
+        return
     g = max(r[1] for r in fr)
     f = max(r[6] for r in fr if r[1] == g); w = max(r[6] for r in wr if r[1] == max(x[1] for x in wr))
     json.dump({"kernel": label, "fetch_size_kb_raw_max": f, "write_size_kb_raw_max": w, "grid": g,

@@ -46,4 +46,8 @@ sed -i 's#gpurun_out/#profiles/#g' $OUT/r06_*_pmc_traffic.json
 fi
 pmc orb_pmc_fetch FETCH_SIZE "" --workload orb --steps 2 --warmup 1
 pmc orb_pmc_write WRITE_SIZE "" --workload orb --steps 2 --warmup 1
+python tools/pmc_traffic_json.py $OUT/r06_orb_pmc_fetch.txt $OUT/r06_orb_pmc_write.txt "" $OUT/r06_orb_pmc_traffic.json "whole ORB pipeline, one batch of 64 frames (sum over its kernels' mean per dispatch)" sum
+sed -i 's#gpurun_out/#profiles/#g' $OUT/r06_orb_pmc_traffic.json
+# the per-frame call: kernel timeline of ONE resident frame
+bash tools/diag/timeline_orb_single.sh > $OUT/r06_orb_one_frame_timeline.txt 2>&1
 ls -la $OUT/r06_* | head -60
