@@ -23,6 +23,7 @@
 #include <chrono>
 #include <thread>
 #include <mutex>
+#include <map>
 #include <condition_variable>
 #include <atomic>
 #include <dlfcn.h>
@@ -155,6 +156,25 @@ struct Ctx {
 };
 
 static void set_err(Ctx *c, const std::string &s) { c->err = s; }
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, once per (kernel, device) and size class instead of before every solve (a global-BA solve made ~45 of these
+// calls).  And with a retry: beside another host thread that was initialising an RCCL communicator the call has been seen to fail with "invalid device function" for a
+// kernel it had accepted a thousand times (the runtime's function table while another library's code objects are being registered; the busy-context suite of round 6's
+// final tree, profiles/r06_gpu_suite_beside_busy_contexts_final.txt) -- a transient of the runtime must not fail a solve.
+static int set_attr_cached(Ctx *c, const void *fn, int bytes, const char *what) {
+    static std::mutex mu; static std::map<std::pair<const void *, int>, int> granted;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(fn, c->device); const auto it = granted.find(key);
+    if (it != granted.end() && it->second >= bytes) return 0;
+    hipError_t e = hipSuccess;
+    for (int t = 0; t < 6; t++) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError(); std::this_thread::sleep_for(std::chrono::microseconds(100 << t));
+    }
+    if (e != hipSuccess) { set_err(c, std::string("hipFuncSetAttribute(") + what + "): " + hipGetErrorString(e)); return TSBA_ERR_DEVICE; }
+    granted[key] = bytes; return 0;
+}
+#define ATTR(fn, bytes) do { const int rc_ = set_attr_cached(c, (const void *)(fn), (int)(bytes), #fn); if (rc_) return rc_; } while (0)
 static bool is_multi(const Ctx *c);
 // Kernels whose workgroups wait for each other inside ONE launch (value polling: k_solve_back, k_sv_cre_tree, k_sv_tree_back, k_cre_back_tree) make progress
 // only if every workgroup of the launch has a compute unit.  They are chosen only where the whole grid fits the device at once (occupancy of that kernel
@@ -583,7 +603,7 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         if (W.dp_poll) {                           // ... whose workgroups poll the solver's: only where the whole grid is resident at once (else k_solve_t + k_back + k_decide)
             const int nb_all_ = back_blocks_pt(p->n_pt) + back_blocks_tx(p->n_text) + (p->n_kf + 255)/256;
             const int ldsb_ = std::max((int)(solve_lds_doubles(W.N)*sizeof(double)), (int)((768 + W.N + 2)*sizeof(double)));
-            CK(hipFuncSetAttribute((const void *)k_solve_back<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb_));
+            ATTR(k_solve_back<true>, ldsb_);
             if (!grid_resident(c, (const void *)k_solve_back<true>, SOLVE_THREADS, (size_t)ldsb_, 1 + (nb_all_ + 2)/3)) W.dp_poll = 0;
         }
         int bwmax = 0; for (int l = 0; l < p->n_levels; l++) if (c->lev_built[l]) bwmax = std::max(bwmax, c->lev[l].bw_rows);
@@ -947,43 +967,43 @@ static void launch_schur(Ctx *c, const LevelDev &D, int multi, SchurDec dec = Sc
 // kernels with more than 64 KB of dynamic LDS need the attribute once per process
 static int set_solver_attrs(Ctx *c) {
     int use_lds; int lds = solve_lds_bytes(c, &use_lds);
-    if (use_lds) { CK(hipFuncSetAttribute((const void *)k_solve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        CK(hipFuncSetAttribute((const void *)k_solve_t<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        CK(hipFuncSetAttribute((const void *)k_solve_back<true>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, (int)((768 + c->W.N + 2)*sizeof(double)))));
-        CK(hipFuncSetAttribute((const void *)k_solve_back<false>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds, (int)((768 + c->W.N + 2)*sizeof(double)))));
-        CK(hipFuncSetAttribute((const void *)k_solve_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(solve_la_lds_doubles(c->W.N)*sizeof(double), 160*1024 - 64))); }
+    if (use_lds) { ATTR(k_solve_t<false>, lds);
+        ATTR((k_solve_t<false, false>), lds);
+        ATTR(k_solve_back<true>, std::max(lds, (int)((768 + c->W.N + 2)*sizeof(double))));
+        ATTR(k_solve_back<false>, std::max(lds, (int)((768 + c->W.N + 2)*sizeof(double))));
+        ATTR(k_solve_la, (int)std::min<size_t>(solve_la_lds_doubles(c->W.N)*sizeof(double), 160*1024 - 64)); }
     else {
-        CK(hipFuncSetAttribute((const void *)k_band_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_bandp_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_cr_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_cr_update, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_cr_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_cre_elim, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_bandp_sepf, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_ms_cre_back, hipFuncAttributeMaxDynamicSharedMemorySize, 159*1024));
-        CK(hipFuncSetAttribute((const void *)k_ms_cre_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
-        CK(hipFuncSetAttribute((const void *)k_ms_cre_root, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
-        CK(hipFuncSetAttribute((const void *)k_sv_linv, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-#define MX_ATTR(SS) CK(hipFuncSetAttribute((const void *)k_mx_cre_fwd<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024)); CK(hipFuncSetAttribute((const void *)k_mx_cre_root<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024)); CK(hipFuncSetAttribute((const void *)k_mx_cre_back<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        ATTR(k_band_solve, 156*1024);
+        ATTR(k_bandp_factor, 156*1024);
+        ATTR(k_cr_pivot, 156*1024);
+        ATTR(k_cr_update, 156*1024);
+        ATTR(k_cr_back, 156*1024);
+        ATTR(k_cre_elim, 156*1024);
+        ATTR(k_bandp_sepf, 156*1024);
+        ATTR(k_cre_back, 156*1024);
+        ATTR(k_ms_cre_back, 159*1024);
+        ATTR(k_ms_cre_fwd, 100*1024);
+        ATTR(k_ms_cre_root, 100*1024);
+        ATTR(k_sv_linv, 156*1024);
+#define MX_ATTR(SS) ATTR(k_mx_cre_fwd<SS>, 156*1024); ATTR(k_mx_cre_root<SS>, 156*1024); ATTR(k_mx_cre_back<SS>, 156*1024);
         MX_ATTR(36) MX_ATTR(42) MX_ATTR(48) MX_ATTR(54) MX_ATTR(60) MX_ATTR(66)
 #undef MX_ATTR
-        CK(hipFuncSetAttribute((const void *)k_sv_fwd_int<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_sv_fwd_int<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_sv_back_int<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_sv_back_int<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_sv_tree_back<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150*1024));
-        CK(hipFuncSetAttribute((const void *)k_sv_tree_back<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150*1024));
-        CK(hipFuncSetAttribute((const void *)k_bandp_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_bandp_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_band_backsub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_band_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_band_backsub<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        CK(hipFuncSetAttribute((const void *)k_solve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(solve_diag_lds_doubles()*sizeof(double))));
-        CK(hipFuncSetAttribute((const void *)k_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double)));
-        CK(hipFuncSetAttribute((const void *)k_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2*64*(CH_NB + 1)*(int)sizeof(double)));
-        CK(hipFuncSetAttribute((const void *)k_chol_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double)));
-        CK(hipFuncSetAttribute((const void *)k_chol_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double)));
+        ATTR(k_sv_fwd_int<1>, 156*1024);
+        ATTR(k_sv_fwd_int<2>, 156*1024);
+        ATTR(k_sv_back_int<1>, 156*1024);
+        ATTR(k_sv_back_int<2>, 156*1024);
+        ATTR(k_sv_tree_back<1>, 150*1024);
+        ATTR(k_sv_tree_back<2>, 150*1024);
+        ATTR(k_bandp_backsub<1>, 156*1024);
+        ATTR(k_bandp_backsub<2>, 156*1024);
+        ATTR(k_band_backsub<1>, 156*1024);
+        ATTR(k_band_backsub<2>, 156*1024);
+        ATTR(k_band_backsub<3>, 156*1024);
+        ATTR(k_solve_t<true>, (int)(solve_diag_lds_doubles()*sizeof(double)));
+        ATTR(k_chol_panel, (CH_NB + 64)*(CH_NB + 1)*(int)sizeof(double));
+        ATTR(k_chol_update, 2*64*(CH_NB + 1)*(int)sizeof(double));
+        ATTR(k_chol_backsub, (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double));
+        ATTR(k_chol_fwd, (CH_NB*(CH_NB + 1) + 2*CH_NB + 8*CH_NB)*(int)sizeof(double));
     }
     return 0;
 }

@@ -623,6 +623,30 @@ __device__ __forceinline__ void qscan4(const int v[4], int *s_w, int tid, int ex
     __syncthreads();
     ex[0] = base + incl - t; ex[1] = ex[0] + v[0]; ex[2] = ex[1] + v[1]; ex[3] = ex[2] + v[2];
 }
+// exclusive block scan of two values per thread (one entry each)
+__device__ __forceinline__ void qscan1x2(const int a, const int b, int *s_w2, int tid, int &ea, int &eb) {
+    const int lane = tid & 63, wv = tid >> 6;
+    int ia = a, ib = b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64); if (lane >= o) { ia += ua; ib += ub; } }
+    if (lane == 63) { s_w2[2*wv] = ia; s_w2[2*wv + 1] = ib; }
+    __syncthreads();
+    int ba = 0, bb = 0;
+#pragma unroll
+    for (int q = 0; q < QT/64; q++) if (q < wv) { ba += s_w2[2*q]; bb += s_w2[2*q + 1]; }
+    __syncthreads();
+    ea = ba + ia - a; eb = bb + ib - b;
+}
+#ifndef Q_FF
+#define Q_FF (QT >= 512)        // the generations of full passes in one step (below); needs a thread per cell of the four levels (340)
+#endif
+#define FF_D 4                  // generations it can take at once (4^4 = 256 cells at the deepest)
+__device__ __forceinline__ int ff_base(int g) { return ((1 << (2*g)) - 1)/3; }      // cells of the depths before g, the root included: 0, 1, 5, 21, 85, 341
+// position digits <-> path digits of a generation-g node: digit i (1 = the root's child) runs backwards where g - i is even (an involution)
+__device__ __forceinline__ int ff_flip(int code, int g) { int out = 0;
+#pragma unroll
+    for (int i = 1; i <= FF_D; i++) if (i <= g) { const int d = (code >> (2*(g - i))) & 3; out |= (((g - i) & 1) ? d : 3 - d) << (2*(g - i)); }
+    return out; }
 // DistributeOctTree (ORBextractor.cc:537-753) for one (frame, level), one generation of splits at a time.  The reference walks a
 // std::list and splits node after node; what a pass does to the list is nevertheless a function of the pass's processing order only:
 //   * phase 1 (a full pass): every expandable node (more than one key) of the list, in list order, is split; children are pushed to the
@@ -727,9 +751,96 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     __syncthreads();
     if (nIni > 1) { for (int k = tid; k < nk; k += QT) keys[k] = tmpk[k]; __syncthreads(); }
     int size = s_front, next_id = nIni, cur = 0;
-    bool phase2 = false, overflow = false;
+    bool phase2 = false, overflow = false, ff_done = false;
     __syncthreads();
     QS(1);
+    // ---- the generations of FULL passes in one step.  While every expandable node is split (until size + 3 nToExpand > N) the tree after g passes is a function of the
+    // keys' coordinates alone: a key's path is four box halvings in registers, a cell's key count a histogram, and the list after pass g is
+    //   [generation g] ++ [the one-key nodes of generation g-1] ++ .. ++ [.. of generation 1],
+    // a generation ordered by its path digits with digit i running backwards where g - i is even (children go to the FRONT in order 0..3, parents are visited front to
+    // back: every pass reverses the order of the one before and appends a backwards digit).  Creation numbers (phase 2's tie-break): 4 per split node in the order of
+    // the pass = the parent's rank among the expandable nodes of its generation.  Keys: stable by path = a counting sort by the deepest cell.  One step instead of three
+    // passes of five barrier-separated phases each (~20 k cycles a pass, whatever the number of keys); the loop below goes on from there (phase 2, or further full passes).
+    if (Q_FF && nIni == 1 && nk > 1) {
+        int *hist = (int *)cnt4, *pref = hist + 340;          // keys per cell, depth g = 1..4 at ff_base(g) - 1; exclusive prefix over the deepest cells (then the scatter's cursors)
+        __shared__ int s_ff[FF_D + 1][2], s_w2[2*(QT/64)];
+        unsigned short *rk = mexs;                            // per scan entry: expandable nodes before it
+        for (int i = tid; i < 340 + 256; i += QT) hist[i] = 0;
+        if (tid < 2*(FF_D + 1)) s_ff[tid >> 1][tid & 1] = 0;
+        const QN root = nd[0];
+        __syncthreads();
+        for (int k = tid; k < nk; k += QT) {
+            int x0 = root.x0, y0 = root.y0, x1 = root.x1, y1 = root.y1, code = 0; const int X = cx[k], Y = cy[k];
+#pragma unroll
+            for (int g = 1; g <= FF_D; g++) {
+                const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1, zx = X < x0 + hx ? 0 : 1, zy = Y < y0 + hy ? 0 : 1;
+                if (zx) x0 += hx; else x1 = x0 + hx;
+                if (zy) y0 += hy; else y1 = y0 + hy;
+                code = 4*code + zx + 2*zy;
+                atomicAdd(&hist[ff_base(g) - 1 + code], 1);
+            }
+        }
+        __syncthreads();
+        // a cell is a node of its generation when it holds keys and every cell above it holds more than one
+        auto cnt_of = [&](int g, int c) { return g == 0 ? nk : hist[ff_base(g) - 1 + c]; };
+        auto exists = [&](int g, int c) { if (cnt_of(g, c) == 0) return false; for (int a = g - 1; a >= 1; a--) if (hist[ff_base(a) - 1 + (c >> (2*(g - a)))] <= 1) return false; return true; };
+        if (tid >= 1 && tid < 341) { int g = 1; while (tid >= ff_base(g + 1)) g++; const int c = tid - ff_base(g);
+            if (exists(g, c)) { atomicAdd(&s_ff[g][0], 1); if (hist[ff_base(g) - 1 + c] > 1) atomicAdd(&s_ff[g][1], 1); } }
+        __syncthreads();
+        int G = FF_D, sizeG = 1, nid = nIni; bool stop = false;
+        {   int sz = 1, nexp_prev = 1;                        // generation 0: the root, expandable
+            for (int g = 1; g <= FF_D; g++) {
+                const int szg = sz - nexp_prev + s_ff[g][0], nexp = s_ff[g][1];
+                nid += 4*nexp_prev;
+                G = g; sizeG = szg;
+                if (szg >= N || szg == sz) { stop = true; break; }
+                if (szg + 3*nexp > N) { phase2 = true; break; }
+                sz = szg; nexp_prev = nexp;
+            }
+        }
+        // scan entries: [generation G by position] [generation G-1] .. [generation 1]; a thread per entry
+        int g = 0, pos = 0, c = 0; bool fin = false, expd = false;
+        {   int e = tid;
+            for (int gg = G; gg >= 1; gg--) { const int n = 1 << (2*gg); if (e < n) { g = gg; pos = e; break; } e -= n; }
+            if (g) { c = ff_flip(pos, g); if (exists(g, c)) { const int cn = hist[ff_base(g) - 1 + c]; fin = g == G || cn == 1; expd = cn > 1; } }
+        }
+        int eA, eP;
+        qscan1x2((fin ? 1 : 0) | (expd ? 1 << 16 : 0), tid < (1 << (2*G)) ? hist[ff_base(G) - 1 + tid] : 0, s_w2, tid, eA, eP);
+        if (tid < (1 << (2*G))) pref[tid] = eP;
+        if (tid < 340) rk[tid] = (unsigned short)(eA >> 16);
+        __syncthreads();
+        if (fin) {                                            // the node's record at its list position (pool slot = list position)
+            const int P = eA & 0xffff;
+            int x0 = root.x0, y0 = root.y0, x1 = root.x1, y1 = root.y1;
+            for (int i = 1; i <= g; i++) { const int z = (c >> (2*(g - i))) & 3, hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+                if (z & 1) x0 += hx; else x1 = x0 + hx;
+                if (z & 2) y0 += hy; else y1 = y0 + hy; }
+            // creation number: 4 x the parent's rank among the expandable nodes of ITS generation (in that generation's order) + the quadrant, behind the numbers of the passes before
+            int id0 = nIni, blk = 0, prank = 0;
+            for (int gg = 1; gg < g; gg++) id0 += 4*(gg == 1 ? 1 : s_ff[gg - 1][1]);
+            if (g > 1) { for (int gg = G; gg > g - 1; gg--) blk += 1 << (2*gg); prank = rk[blk + ff_flip(c >> 2, g - 1)] - rk[blk]; }
+            QN q; q.x0 = (short)x0; q.y0 = (short)y0; q.x1 = (short)x1; q.y1 = (short)y1;
+            q.key0 = (unsigned short)pref[c << (2*(G - g))]; q.nk = (unsigned short)hist[ff_base(g) - 1 + c]; q.id = (unsigned short)(id0 + 4*prank + (c & 3)); q.pad = 0;
+            nd[P] = q; lst[0][P] = (unsigned short)P;
+        }
+        __syncthreads();
+        // keys: stable by the deepest cell -- any order into the cell's range first (cursor = the prefix), then every key to its rank inside the cell
+        auto code_of = [&](int k) { int x0 = root.x0, y0 = root.y0, x1 = root.x1, y1 = root.y1, code = 0; const int X = cx[k], Y = cy[k];
+            for (int gg = 1; gg <= G; gg++) { const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1, zx = X < x0 + hx ? 0 : 1, zy = Y < y0 + hy ? 0 : 1;
+                if (zx) x0 += hx; else x1 = x0 + hx;
+                if (zy) y0 += hy; else y1 = y0 + hy;
+                code = 4*code + zx + 2*zy; }
+            return code; };
+        for (int k = tid; k < nk; k += QT) tmpk[atomicAdd(&pref[code_of(k)], 1)] = (unsigned short)k;
+        __syncthreads();
+        for (int p = tid; p < nk; p += QT) { const int key = tmpk[p], cd = code_of(key), end = pref[cd], start = end - hist[ff_base(G) - 1 + cd];
+            int r = 0; for (int q2 = start; q2 < end; q2++) r += tmpk[q2] < key;
+            keys[start + r] = (unsigned short)key; }
+        __syncthreads();
+        size = sizeG; next_id = nid; cur = 0; ff_done = stop;
+    }
+    QS(2);
+    if (!ff_done)
     for (;;) {
         const int prevSize = size;
         unsigned short *L = lst[cur], *Ln = lst[cur ^ 1];
