@@ -664,14 +664,14 @@ __device__ __forceinline__ int ff_flip(int code, int g) { int out = 0;
 // to find nothing).  Solved on the spot by thread 0 instead, the serial code's registers and scratch cost this kernel more than that launch -- 64 frames: 0.449 against
 // 0.424 ms; one frame: 54.4 us against 44.8 + 4.8.
 #define Q_FALLBACK() do { if (tid == 0) { D.qfallback[blockIdx.x] = 1; *selcnt = 0; *D.h_fallback = 1; } return; } while (0)     // (the level counts as empty until the serial pass has run)
-#ifdef Q_STAMPS       // (tools/diag/octree_stamps.sh) thread 0's cycles by phase into D.snbuf: gather, first nodes, per pass: order / counts / cut / partition / lists, arg-max
+#ifdef Q_STAMPS       // (tools/diag/octree_stamps.sh) thread 0's cycles by phase into D.snbuf: gather, first nodes, per pass: order / counts / cut / partition / lists, arg-max; 8 .. 13: the phases of the full generations' step
 #define QS(i) do { if (tid == 0) { const long long t1_ = clock64(); q_acc[i] += (int)(t1_ - q_t0); q_t0 = t1_; } } while (0)
 #else
 #define QS(i) do { } while (0)
 #endif
 __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
 #ifdef Q_STAMPS
-    int q_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q_pass = 0; long long q_t0 = clock64();
+    int q_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, q_pass = 0; long long q_t0 = clock64();
 #endif
     const int f = blockIdx.x / D.nlevels, l = blockIdx.x % D.nlevels, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const LevelGeo &G = D.L[l];
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     //   [generation g] ++ [the one-key nodes of generation g-1] ++ .. ++ [.. of generation 1],
     // a generation ordered by its path digits with digit i running backwards where g - i is even (children go to the FRONT in order 0..3, parents are visited front to
     // back: every pass reverses the order of the one before and appends a backwards digit).  Creation numbers (phase 2's tie-break): 4 per split node in the order of
-    // the pass = the parent's rank among the expandable nodes of its generation.  Keys: stable by path = a counting sort by the deepest cell.  One step instead of three
+    // the pass = the parent's rank among the expandable nodes of its generation.  Keys: grouped by path = a counting sort by the deepest cell.  One step instead of three
     // passes of five barrier-separated phases each (~20 k cycles a pass, whatever the number of keys); the loop below goes on from there (phase 2, or further full passes).
     if (Q_FF && nIni == 1 && nk > 1) {
         int *hist = (int *)cnt4, *pref = hist + 340;          // keys per cell, depth g = 1..4 at ff_base(g) - 1; exclusive prefix over the deepest cells (then the scatter's cursors)
@@ -781,12 +781,14 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
             }
         }
         __syncthreads();
+        QS(8);
         // a cell is a node of its generation when it holds keys and every cell above it holds more than one
         auto cnt_of = [&](int g, int c) { return g == 0 ? nk : hist[ff_base(g) - 1 + c]; };
         auto exists = [&](int g, int c) { if (cnt_of(g, c) == 0) return false; for (int a = g - 1; a >= 1; a--) if (hist[ff_base(a) - 1 + (c >> (2*(g - a)))] <= 1) return false; return true; };
         if (tid >= 1 && tid < 341) { int g = 1; while (tid >= ff_base(g + 1)) g++; const int c = tid - ff_base(g);
             if (exists(g, c)) { atomicAdd(&s_ff[g][0], 1); if (hist[ff_base(g) - 1 + c] > 1) atomicAdd(&s_ff[g][1], 1); } }
         __syncthreads();
+        QS(9);
         int G = FF_D, sizeG = 1, nid = nIni; bool stop = false;
         {   int sz = 1, nexp_prev = 1;                        // generation 0: the root, expandable
             for (int g = 1; g <= FF_D; g++) {
@@ -809,6 +811,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         if (tid < (1 << (2*G))) pref[tid] = eP;
         if (tid < 340) rk[tid] = (unsigned short)(eA >> 16);
         __syncthreads();
+        QS(10);
         if (fin) {                                            // the node's record at its list position (pool slot = list position)
             const int P = eA & 0xffff;
             int x0 = root.x0, y0 = root.y0, x1 = root.x1, y1 = root.y1;
@@ -824,19 +827,18 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
             nd[P] = q; lst[0][P] = (unsigned short)P;
         }
         __syncthreads();
-        // keys: stable by the deepest cell -- any order into the cell's range first (cursor = the prefix), then every key to its rank inside the cell
+        QS(11);
+        // keys: into their deepest cell's range, in any order (cursor = the prefix): the order of a node's keys matters to nothing but the arg-max's ties, and those go by
+        // candidate number (the stable order cost 6 k cycles: a rank inside the cell per key)
         auto code_of = [&](int k) { int x0 = root.x0, y0 = root.y0, x1 = root.x1, y1 = root.y1, code = 0; const int X = cx[k], Y = cy[k];
             for (int gg = 1; gg <= G; gg++) { const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1, zx = X < x0 + hx ? 0 : 1, zy = Y < y0 + hy ? 0 : 1;
                 if (zx) x0 += hx; else x1 = x0 + hx;
                 if (zy) y0 += hy; else y1 = y0 + hy;
                 code = 4*code + zx + 2*zy; }
             return code; };
-        for (int k = tid; k < nk; k += QT) tmpk[atomicAdd(&pref[code_of(k)], 1)] = (unsigned short)k;
+        for (int k = tid; k < nk; k += QT) keys[atomicAdd(&pref[code_of(k)], 1)] = (unsigned short)k;
         __syncthreads();
-        for (int p = tid; p < nk; p += QT) { const int key = tmpk[p], cd = code_of(key), end = pref[cd], start = end - hist[ff_base(G) - 1 + cd];
-            int r = 0; for (int q2 = start; q2 < end; q2++) r += tmpk[q2] < key;
-            keys[start + r] = (unsigned short)key; }
-        __syncthreads();
+        QS(12);
         size = sizeG; next_id = nid; cur = 0; ff_done = stop;
     }
     QS(2);
@@ -994,13 +996,13 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     for (int q = tid; q < ns; q += QT) {
         const QN n = nd[L[q]];
         int best = keys[n.key0]; int mr = cr[best];
-        for (int k = 1; k < n.nk; k++) { const int key = keys[n.key0 + k]; if ((int)cr[key] > mr) { best = key; mr = cr[key]; } }
+        for (int k = 1; k < n.nk; k++) { const int key = keys[n.key0 + k]; const int r = cr[key]; if (r > mr || (r == mr && key < best)) { best = key; mr = r; } }      // (ties: the reference keeps the FIRST key of the node = the smallest candidate number, whatever order the node's keys are in here)
         sel[4*q] = (float)cx[best] + (float)minX; sel[4*q+1] = (float)cy[best] + (float)minY; sel[4*q+2] = (float)mr; sel[4*q+3] = 0.f;
     }
     if (tid == 0) *selcnt = ns;
     QS(7);
 #ifdef Q_STAMPS
-    if (tid == 0) { int *o = D.snbuf + 16*blockIdx.x; for (int i = 0; i < 8; i++) o[i] = q_acc[i]; o[8] = q_pass; o[9] = nk; o[10] = size; }
+    if (tid == 0) { int *o = D.snbuf + 32*blockIdx.x; for (int i = 0; i < 8; i++) o[i] = q_acc[i]; o[8] = q_pass; o[9] = nk; o[10] = size; for (int i = 8; i < 16; i++) o[16 + i - 8] = q_acc[i]; }
 #endif
 }
 
