@@ -806,15 +806,20 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
             for (int gg = G; gg >= 1; gg--) { const int n = 1 << (2*gg); if (e < n) { g = gg; pos = e; break; } e -= n; }
             if (g) { c = ff_flip(pos, g); if (exists(g, c)) { const int cn = hist[ff_base(g) - 1 + c]; fin = g == G || cn == 1; expd = cn > 1; } }
         }
+        // the first pass of phase 2 as well where the cells one level further down are counted (G < FF_D): the expandable nodes of generation G, largest first
+        // (ties: the later creation number), are split until the list holds N nodes -- a rank sort over at most 64 keys, the non-empty children of each from the
+        // histogram, the cut from their running sum; the list is [children of the split nodes, last split first, quadrant 3 first] ++ [the others in order]
+        const bool p2 = phase2 && !stop && G < FF_D;
+        const int GK = p2 ? G + 1 : G;                        // depth of the cells the keys are grouped by
         int eA, eP;
-        qscan1x2((fin ? 1 : 0) | (expd ? 1 << 16 : 0), tid < (1 << (2*G)) ? hist[ff_base(G) - 1 + tid] : 0, s_w2, tid, eA, eP);
-        if (tid < (1 << (2*G))) pref[tid] = eP;
+        qscan1x2((fin ? 1 : 0) | (expd ? 1 << 16 : 0), tid < (1 << (2*GK)) ? hist[ff_base(GK) - 1 + tid] : 0, s_w2, tid, eA, eP);
+        if (tid < (1 << (2*GK))) pref[tid] = eP;
         if (tid < 340) rk[tid] = (unsigned short)(eA >> 16);
+        if (tid == 0) s_cut = s_ff[G][1];
         __syncthreads();
         QS(10);
-        if (fin) {                                            // the node's record at its list position (pool slot = list position)
-            const int P = eA & 0xffff;
-            int x0 = root.x0, y0 = root.y0, x1 = root.x1, y1 = root.y1;
+        int P = eA & 0xffff, myid = 0, x0 = root.x0, y0 = root.y0, x1 = root.x1, y1 = root.y1;
+        if (fin) {                                            // box and creation number of the node
             for (int i = 1; i <= g; i++) { const int z = (c >> (2*(g - i))) & 3, hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
                 if (z & 1) x0 += hx; else x1 = x0 + hx;
                 if (z & 2) y0 += hy; else y1 = y0 + hy; }
@@ -822,8 +827,41 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
             int id0 = nIni, blk = 0, prank = 0;
             for (int gg = 1; gg < g; gg++) id0 += 4*(gg == 1 ? 1 : s_ff[gg - 1][1]);
             if (g > 1) { for (int gg = G; gg > g - 1; gg--) blk += 1 << (2*gg); prank = rk[blk + ff_flip(c >> 2, g - 1)] - rk[blk]; }
+            myid = id0 + 4*prank + (c & 3);
+        }
+        bool split = false; int r2 = 0, mex2 = 0, m2 = 0, front = 0, newSize = sizeG;
+        if (p2) {
+            unsigned int *ck = (unsigned int *)tmpk;          // (at most 64 keys)
+            const int np2 = s_ff[G][1]; const bool cand = g == G && expd;
+            const unsigned int mykey = cand ? ((unsigned int)hist[ff_base(G) - 1 + c] << 16) | (unsigned int)myid : 0u;
+            if (cand) { ck[eA >> 16] = mykey;                 // (generation G is the first block of the scan: the count of expandable entries before this one is its index)
+#pragma unroll
+                for (int z = 0; z < 4; z++) m2 += hist[ff_base(G + 1) - 1 + 4*c + z] > 0; }
+            __syncthreads();
+            if (cand) { for (int b2 = 0; b2 < np2; b2++) r2 += ck[b2] > mykey; proc[r2] = (unsigned short)m2; }
+            __syncthreads();
+            if (cand) { for (int b2 = 0; b2 < r2; b2++) mex2 += proc[b2];
+                if (sizeG + mex2 + m2 - (r2 + 1) >= N) atomicMin(&s_cut, r2 + 1); }
+            __syncthreads();
+            const int S = s_cut;
+            split = cand && r2 < S;
+            if (cand && r2 == S - 1) s_front = mex2 + m2;
+            int eS, e0;
+            qscan1x2(split ? 1 : 0, 0, s_w2, tid, eS, e0);    // (its barriers publish s_front)
+            front = s_front; newSize = front + sizeG - S; nid += 4*S;
+            P = front + P - eS;                               // a kept node: behind the new front, in the old order
+            if (split) {                                      // the children's records: quadrant z of the r-th split node at front - 1 - (children before it)
+                const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1; int jj = 0;
+#pragma unroll
+                for (int z = 0; z < 4; z++) { const int cn = hist[ff_base(G + 1) - 1 + 4*c + z];
+                    if (cn > 0) { QN q; q.x0 = (short)((z & 1) ? x0 + hx : x0); q.x1 = (short)((z & 1) ? x1 : x0 + hx); q.y0 = (short)((z & 2) ? y0 + hy : y0); q.y1 = (short)((z & 2) ? y1 : y0 + hy);
+                        q.key0 = (unsigned short)pref[4*c + z]; q.nk = (unsigned short)cn; q.id = (unsigned short)(nid - 4*S + 4*r2 + z); q.pad = 0;
+                        const int at = front - 1 - (mex2 + jj); nd[at] = q; lst[0][at] = (unsigned short)at; jj++; } }
+            }
+        }
+        if (fin && !split) {                                  // the node's record at its list position (pool slot = list position)
             QN q; q.x0 = (short)x0; q.y0 = (short)y0; q.x1 = (short)x1; q.y1 = (short)y1;
-            q.key0 = (unsigned short)pref[c << (2*(G - g))]; q.nk = (unsigned short)hist[ff_base(g) - 1 + c]; q.id = (unsigned short)(id0 + 4*prank + (c & 3)); q.pad = 0;
+            q.key0 = (unsigned short)pref[c << (2*(GK - g))]; q.nk = (unsigned short)hist[ff_base(g) - 1 + c]; q.id = (unsigned short)myid; q.pad = 0;
             nd[P] = q; lst[0][P] = (unsigned short)P;
         }
         __syncthreads();
@@ -831,7 +869,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         // keys: into their deepest cell's range, in any order (cursor = the prefix): the order of a node's keys matters to nothing but the arg-max's ties, and those go by
         // candidate number (the stable order cost 6 k cycles: a rank inside the cell per key)
         auto code_of = [&](int k) { int x0 = root.x0, y0 = root.y0, x1 = root.x1, y1 = root.y1, code = 0; const int X = cx[k], Y = cy[k];
-            for (int gg = 1; gg <= G; gg++) { const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1, zx = X < x0 + hx ? 0 : 1, zy = Y < y0 + hy ? 0 : 1;
+            for (int gg = 1; gg <= GK; gg++) { const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1, zx = X < x0 + hx ? 0 : 1, zy = Y < y0 + hy ? 0 : 1;
                 if (zx) x0 += hx; else x1 = x0 + hx;
                 if (zy) y0 += hy; else y1 = y0 + hy;
                 code = 4*code + zx + 2*zy; }
@@ -839,6 +877,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
         for (int k = tid; k < nk; k += QT) keys[atomicAdd(&pref[code_of(k)], 1)] = (unsigned short)k;
         __syncthreads();
         QS(12);
+        if (p2) { if (newSize >= N || newSize == sizeG) stop = true; sizeG = newSize; }
         size = sizeG; next_id = nid; cur = 0; ff_done = stop;
     }
     QS(2);
