@@ -5,7 +5,8 @@
 //                         fused in (a border pixel is the resize result at the reflected coordinate)        ORBextractor.cc:1118-1143
 //   k_fast                one workgroup per 30-px cell: ROI tile in LDS, FAST-9/16 + cornerScore + 3x3 NMS at threshold 20,
 //                         per-cell fallback to 7, row-major ordered compaction                               :766-830
-//   k_octree              one workgroup per (frame, level): DistributeOctTree (serial list surgery, thread 0)      :540-764
+//   k_octree              one workgroup per (frame, level): DistributeOctTree -- the full passes and the first pass of phase 2 in
+//                         closed form from the keys' coordinates, whatever is left one generation of splits at a time      :540-764
 //   k_orient              16 lanes per keypoint: intensity-centroid moments + fastAtan2                         :77-104
 //   k_blur                7x7 sigma-2 Gaussian, Q8 fixed point separable, LDS tiled                            :1096-1097
 //   k_describe            32 lanes per keypoint: 256 steered BRIEF tests, one byte per lane, written straight into the
@@ -647,13 +648,15 @@ __device__ __forceinline__ int ff_flip(int code, int g) { int out = 0;
 #pragma unroll
     for (int i = 1; i <= FF_D; i++) if (i <= g) { const int d = (code >> (2*(g - i))) & 3; out |= (((g - i) & 1) ? d : 3 - d) << (2*(g - i)); }
     return out; }
-// DistributeOctTree (ORBextractor.cc:537-753) for one (frame, level), one generation of splits at a time.  The reference walks a
+// DistributeOctTree (ORBextractor.cc:537-753) for one (frame, level).  The loop below takes one generation of splits at a time; since the last session of round 6 the
+// generations of full passes and the first pass of phase 2 are taken in ONE step before it (further down: "the generations of FULL passes in one step"), after which
+// the loop has nothing left to do on camera images (it still runs for two initial nodes, for more than four full generations, for a second pass of phase 2).  The reference walks a
 // std::list and splits node after node; what a pass does to the list is nevertheless a function of the pass's processing order only:
 //   * phase 1 (a full pass): every expandable node (more than one key) of the list, in list order, is split; children are pushed to the
 //     FRONT (so they are not visited in the same pass) and the parent is erased;
 //   * phase 2 (once size + 3 nToExpand > N): the expandable nodes sorted by (size, creation order), largest first, are split until the list
-//     holds N nodes -- the cut is a prefix sum over "non-empty children - 1", found before any key moves (a node that is not split must
-//     keep its key order: ties in the final arg-max go to the first key).
+//     holds N nodes -- the cut is a prefix sum over "non-empty children - 1", found before any key moves (ties in the final arg-max go to the
+//     node's first key in the reference = its smallest candidate number here, whatever order the node's keys are in).
 // New list = reverse(non-empty children in processing order) ++ (old list without the split nodes); creation numbers = 4 per split in
 // processing order (they break the ties of phase 2's sort, as the node addresses do in the reference).  So a pass is: processing order
 // (compaction / rank sort) -> child counts (one wave per node) -> scan + cut -> stable 4-way partition of the keys (one wave per node)
@@ -838,9 +841,14 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
 #pragma unroll
                 for (int z = 0; z < 4; z++) m2 += hist[ff_base(G + 1) - 1 + 4*c + z] > 0; }
             __syncthreads();
-            if (cand) { for (int b2 = 0; b2 < np2; b2++) r2 += ck[b2] > mykey; proc[r2] = (unsigned short)m2; }
+            if (cand) {
+#pragma unroll 8
+                for (int b2 = 0; b2 < np2; b2++) r2 += ck[b2] > mykey;
+                proc[r2] = (unsigned short)m2; }
             __syncthreads();
-            if (cand) { for (int b2 = 0; b2 < r2; b2++) mex2 += proc[b2];
+            if (cand) {
+#pragma unroll 8
+                for (int b2 = 0; b2 < r2; b2++) mex2 += proc[b2];
                 if (sizeG + mex2 + m2 - (r2 + 1) >= N) atomicMin(&s_cut, r2 + 1); }
             __syncthreads();
             const int S = s_cut;
