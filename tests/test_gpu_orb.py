@@ -80,6 +80,13 @@ def test_edge_cases(orb, oracle_lib):
     _same(orb(low), oracle_lib.orb_extract(low))
     small = np.ascontiguousarray(synthetic_frame(51)[:240, :320])   # another resolution
     _same(orb(small), oracle_lib.orb_extract(small))
+    # a handful of corners, some of them alone in their quarter of the image, clusters that stay together for several splits: the quadtree's closed-form
+    # generations end early (a pass that changes nothing, one-key nodes at every depth) -- and one corner only, and two
+    for k, boxes in enumerate(([(100, 100), (104, 300), (400, 500), (404, 508), (408, 516), (60, 600)], [(200, 320)], [(200, 320), (206, 330)])):
+        sparse = np.full((480, 640), 40, np.uint8)
+        for (y, x) in boxes:
+            sparse[y:y + 9, x:x + 9] = 220
+        _same(orb(sparse), oracle_lib.orb_extract(sparse))
     noise = np.random.default_rng(5).integers(0, 256, (480, 640)).astype(np.uint8)        # corners everywhere: quadtree under load
     before = orb.debug_fallbacks()
     _same(orb(noise), oracle_lib.orb_extract(noise, cap=8192))

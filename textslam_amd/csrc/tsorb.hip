@@ -21,6 +21,7 @@
 #include <cfloat>
 #include <string>
 #include <vector>
+#include <type_traits>
 #include "../../include/tsorb.h"
 #include "../../include/orb_pattern.h"
 
@@ -709,26 +710,32 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
     if (nk > QL_CAND) Q_FALLBACK();
     __syncthreads();
     const float inv_ncols = 1.0f/(float)G.nCols;
-    for (int k0 = tid; k0 < nk; k0 += 8*QT) {            // eight entries per thread and round: their loads are in flight together
-        int cell[8]; uint32_t p[8];
+    // U entries per thread and round: their loads are in flight together (eight for a level that needs them; a camera frame's level has two per thread: the eight searches of a
+    // round were mostly clamped duplicates)
+    auto gather = [&](auto utag) {
+        constexpr int U = decltype(utag)::value;
+        for (int k0 = tid; k0 < nk; k0 += U*QT) {
+            int cell[U]; uint32_t p[U];
 #pragma unroll
-        for (int u = 0; u < 8; u++) cell[u] = 0;
-        // the last cell whose offset is <= k (an empty cell shares its successor's offset): a fixed number of steps, the eight searches' LDS reads of a step in
-        // flight together (a while loop per entry was eight times ten dependent reads: 8 k of the 18 k cycles this gather took)
-        for (int step = QL_CELLS/2; step > 0; step >>= 1) {
-            if (step >= ncell) continue;
+            for (int u = 0; u < U; u++) cell[u] = 0;
+            // the last cell whose offset is <= k (an empty cell shares its successor's offset): a fixed number of steps, the searches' LDS reads of a step in
+            // flight together (a while loop per entry was eight times ten dependent reads: 8 k of the 18 k cycles this gather took)
+            for (int step = QL_CELLS/2; step > 0; step >>= 1) {
+                if (step >= ncell) continue;
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int k = min(k0 + u*QT, nk - 1), c = cell[u] + step; if (c < ncell && coff[min(c, QL_CELLS - 1)] <= k) cell[u] = c; }
+                for (int u = 0; u < U; u++) { const int k = min(k0 + u*QT, nk - 1), c = cell[u] + step; if (c < ncell && coff[min(c, QL_CELLS - 1)] <= k) cell[u] = c; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int k = min(k0 + u*QT, nk - 1); p[u] = ck[(size_t)cell[u]*CELL_CAP + (k - coff[cell[u]])]; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = k0 + u*QT; if (k >= nk) break;
+                const int i = (int)(((float)cell[u] + 0.5f)*inv_ncols), j = cell[u] - i*G.nCols;          // (cell / nCols: exact for these sizes, a tenth of the division's instructions)
+                cx[k] = (unsigned short)((int)(p[u] & 255u) + j*G.wCell); cy[k] = (unsigned short)((int)((p[u] >> 8) & 255u) + i*G.hCell); cr[k] = (unsigned short)(p[u] >> 16);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int k = min(k0 + u*QT, nk - 1); p[u] = ck[(size_t)cell[u]*CELL_CAP + (k - coff[cell[u]])]; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = k0 + u*QT; if (k >= nk) break;
-            const int i = (int)(((float)cell[u] + 0.5f)*inv_ncols), j = cell[u] - i*G.nCols;          // (cell / nCols: exact for these sizes, a tenth of the division's instructions)
-            cx[k] = (unsigned short)((int)(p[u] & 255u) + j*G.wCell); cy[k] = (unsigned short)((int)((p[u] >> 8) & 255u) + i*G.hCell); cr[k] = (unsigned short)(p[u] >> 16);
-        }
-    }
+    };
+    if (nk <= 2*QT) gather(std::integral_constant<int, 2>()); else gather(std::integral_constant<int, 8>());
     QS(0);
     const int minX = G.minB, maxX = G.maxBX, minY = G.minB, maxY = G.maxBY, N = G.nfeat;
     const int nIni = (int)roundf((float)(maxX - minX)/(float)(maxY - minY));
