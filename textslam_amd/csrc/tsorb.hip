@@ -856,7 +856,7 @@ __global__ __launch_bounds__(QT) void k_octree(OrbDev D) {
             if (cand) {
 #pragma unroll 8
                 for (int b2 = 0; b2 < r2; b2++) mex2 += proc[b2];
-                if (sizeG + mex2 + m2 - (r2 + 1) >= N) atomicMin(&s_cut, r2 + 1); }
+                if (sizeG + mex2 + m2 - (r2 + 1) >= N && !(r2 > 0 && sizeG + mex2 - r2 >= N)) s_cut = r2 + 1; }      // (the running size never falls: ONE rank is the first to reach N -- an atomicMin by every rank behind it was up to 60 atomics on one word)
             __syncthreads();
             const int S = s_cut;
             split = cand && r2 < S;
