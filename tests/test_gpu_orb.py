@@ -72,6 +72,26 @@ def test_init_frame_extractor_3000(oracle_lib):
     assert ex.GetFeaturesPerLevel().sum() == 3000 and ex.GetLevels() == 8
 
 
+@pytest.mark.parametrize("nfeatures,scale,nlevels,shape", [(500, 1.5, 5, (480, 640)), (2000, 1.1, 8, (480, 640)), (1200, 1.2, 8, (720, 1280)), (300, 2.0, 3, (360, 480)), (1000, 1.2, 1, (480, 640))])
+def test_other_extractor_parameters(oracle_lib, nfeatures, scale, nlevels, shape):
+    """Other pyramids and feature counts than TextSLAM's yaml files use -- the tile sizes of the few-frames pyramid, its split level, the quadtree's closed-form
+    generations (their number follows the level's feature count; a 16:9 frame starts from two nodes and takes the loop) all depend on them: a single frame
+    (the few-frames launch plan) and the same frame as a launch per stage and level, both against the oracle, pyramid levels included."""
+    from textslam_amd.orbextractor import ORBextractor
+    h, w = shape
+    img = np.ascontiguousarray(np.tile(synthetic_frame(90 + nlevels), (2, 3))[:h, :w])
+    ref = oracle_lib.orb_extract(img, nfeatures=nfeatures, scale=scale, nlevels=nlevels, cap=8192)
+    ex = ORBextractor(nfeatures, scale, nlevels, 20, 7, device=0)
+    try:
+        for mode in (-1, 0):
+            ex.debug_pyramid(mode)
+            _same(ex(img), ref)
+            for l in range(nlevels):
+                assert np.array_equal(ex.debug_level(0, l), oracle_lib.orb_level(img, l, scale=scale, nlevels=nlevels)), (mode, l)
+    finally:
+        ex.close()
+
+
 def test_edge_cases(orb, oracle_lib):
     flat = np.full((480, 640), 128, np.uint8)                      # no corners anywhere: empty output
     kp, desc = orb(flat)

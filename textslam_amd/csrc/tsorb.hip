@@ -1525,7 +1525,7 @@ int tsorb_run(void *ctx) {
     auto pyr_launch = [&](const PyrOne &Q, int inst) { if (Q.per_frame <= 0) return;
         if (inst == 0) hipLaunchKernelGGL((k_pyramid_one<4096, 192, 256>), dim3(D.n*Q.per_frame), dim3(256), 0, c->stream, D, Q);
         else hipLaunchKernelGGL((k_pyramid_one<16384, 512, 512>), dim3(D.n*Q.per_frame), dim3(512), 0, c->stream, D, Q); };
-    if (few && c->pyr_shape != 2 && c->q_inst[0] >= 0 && c->q_inst[1] >= 0) { pyr_launch(c->Q[0], c->q_inst[0]); pyr_launch(c->Q[1], c->q_inst[1]); }     // a few frames: two launches
+    if (few && c->pyr_shape != 2 && c->q_inst[0] >= 0 && c->q_inst[1] >= 0) { pyr_launch(c->Q[0], c->q_inst[0]); if (c->Q[1].top > c->Q[1].base) pyr_launch(c->Q[1], c->q_inst[1]); }     // a few frames: two launches
     else if (few && c->q_inst[2] >= 0) pyr_launch(c->Q[2], c->q_inst[2]);                                                                                    // (or one)
     else if (c->pyr_shape == 3 && [&] { for (int q = 0; q < c->n_pairs; q++) if (c->q_inst[3 + q] < 0) return false; return true; }())
         for (int q = 0; q < c->n_pairs; q++) pyr_launch(c->Q[3 + q], c->q_inst[3 + q]);                                                                    // (experiment: two levels per launch, any batch)
