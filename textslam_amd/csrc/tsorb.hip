@@ -1214,16 +1214,33 @@ __global__ __launch_bounds__(256) void k_fast_blur(OrbDev D, int nfast) {
 // its place in the level: the separate packing launch (a frame's keypoints and descriptors read back and written again, 4.7 us of the 107 of a per-frame call)
 // is gone since round 6.
 // byte `lane` of the descriptor of the keypoint sv = (x, y, response, angle) with a, b = cos, sin of its angle, and the keypoint's six output values, at place o of frame f
+#define DW_R 18                 // the descriptor's window: rows / columns -18 .. 18 around the keypoint
+#define DW_H (2*DW_R + 1)
+#define DW_P 40                 // bytes per window row in LDS (ten dwords)
 template <bool HOST>
 __device__ __forceinline__ void describe_out(const OrbDev &D, const LevelGeo &G, int f, int l, int o, int lane, const float4 sv, const float a, const float b) {
-    const uint8_t *c = D.blur + (size_t)f*D.blur_frame + G.blur_off + (size_t)(int)rintf(sv.y)*G.w + (int)rintf(sv.x);
+    // The 512 taps of a keypoint lie within 18 px of it (the pattern's coordinates are at most 13 on either axis: 13 sqrt 2 = 18.4, rounded 18).  Straight from the blurred level they
+    // were 16 byte loads per lane, each a wave instruction that touches up to 64 different cache lines: the kernel ran at the rate its compute unit's vector cache looks lines up
+    // (45 us for 64 frames, the lines of 64 k windows several times over).  The window once, as rows of ten dwords, into LDS (37 rows x 40 bytes; a keypoint is at least 19 px inside
+    // its level, the three bytes past the window's right edge at worst the start of the next row), the taps from there.
+    __shared__ __attribute__((aligned(4))) uint8_t s_win[8][DW_H*DW_P];
+    uint8_t *win = s_win[threadIdx.x >> 5];
+    {   const uint8_t *c = D.blur + (size_t)f*D.blur_frame + G.blur_off + (size_t)((int)rintf(sv.y) - DW_R)*G.w + (int)rintf(sv.x) - DW_R;
+        uint32_t v[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) { const int idx = min(lane + 32*k, DW_H*(DW_P/4) - 1), row = idx/(DW_P/4), col = idx - row*(DW_P/4); v[k] = *(const u32_unaligned *)(c + (size_t)row*G.w + 4*col); }
+#pragma unroll
+        for (int k = 0; k < 12; k++) if (lane + 32*k < DW_H*(DW_P/4)) ((uint32_t *)win)[lane + 32*k] = v[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (a keypoint's 32 lanes are one half of a wave: its LDS accesses are in order)
+    const uint8_t *c = win + DW_R*DW_P + DW_R;
     const int8_t *pat = d_pattern + 32*lane;
     int val = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const float x0 = pat[4*t], y0 = pat[4*t+1], x1 = pat[4*t+2], y1 = pat[4*t+3];
-        const int t0 = c[(int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)))*G.w + (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)))];
-        const int t1 = c[(int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)))*G.w + (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)))];
+        const int t0 = c[(int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)))*DW_P + (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)))];
+        const int t1 = c[(int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)))*DW_P + (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)))];
         val |= (t0 < t1) << t;
     }
     D.out_desc[((size_t)f*D.cap + o)*32 + lane] = (uint8_t)val;
