@@ -172,9 +172,13 @@ __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
     if (top - base <= 7) {                                      // (also across the reflected columns: the four source columns are neighbours in any order)
         // byte o of the 8 loaded ones: word o >> 2, bits 8 (o & 3) .. -- 32-bit selects and field extracts (variable 64-bit shifts and 32-bit
         // multiplies run at a quarter of the rate: the operands here are below 2^24, the products exact in 24-bit multiplies)
-        bool h0[4], h1[4]; int s0[4], s1[4];
+        // (round 6: a column's two source bytes as ONE byte permute of the 8 loaded ones -> (p0 | p1 << 16), its horizontal term as one 16-bit dot product with the
+        // table's packed weights (a0 | a1 << 16): 2 + 2 instructions per pixel where selects, shifts, masks and two multiply-adds were 16)
+        typedef unsigned short __attribute__((ext_vector_type(2))) us2;
+        uint32_t psel[4]; us2 wts[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const int o0 = sx[k] - base, o1 = sx1[k] - base; h0[k] = o0 >= 4; h1[k] = o1 >= 4; s0[k] = 8*(o0 & 3); s1[k] = 8*(o1 & 3); }
+        for (int k = 0; k < 4; k++) { const int o0 = sx[k] - base, o1 = sx1[k] - base; psel[k] = (uint32_t)o0 | (0x0cu << 8) | ((uint32_t)o1 << 16) | (0x0cu << 24);
+            wts[k] = __builtin_bit_cast(us2, (uint32_t)a0[k] | ((uint32_t)a1[k] << 16)); }
         uint2 q0[RS_ROWS], q1[RS_ROWS]; int4 yt[RS_ROWS];
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++) {                      // all loads of the row group in flight together
@@ -188,9 +192,8 @@ __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
             uint32_t o = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t p00 = ((h0[k] ? q0[r].y : q0[r].x) >> s0[k]) & 255u, p01 = ((h1[k] ? q0[r].y : q0[r].x) >> s1[k]) & 255u;
-                const uint32_t p10 = ((h0[k] ? q1[r].y : q1[r].x) >> s0[k]) & 255u, p11 = ((h1[k] ? q1[r].y : q1[r].x) >> s1[k]) & 255u;
-                const uint32_t S0 = __umul24(p00, a0[k]) + __umul24(p01, a1[k]), S1 = __umul24(p10, a0[k]) + __umul24(p11, a1[k]);
+                const uint32_t S0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(q0[r].y, q0[r].x, psel[k])), wts[k], 0u, false);
+                const uint32_t S1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(q1[r].y, q1[r].x, psel[k])), wts[k], 0u, false);
                 o |= ((((__umul24(yt[r].z, S0 >> 4)) >> 16) + ((__umul24(yt[r].w, S1 >> 4)) >> 16) + 2) >> 2) << (8*k);
             }
             uint8_t *d = dst + (size_t)(y0 + r)*G.bw;
