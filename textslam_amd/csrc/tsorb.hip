@@ -156,13 +156,17 @@ __global__ __launch_bounds__(256) void k_resize_tab(OrbDev D) {
 #define RS_T 64
 #endif
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-__global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
+// nyb0 > 0 (level 1 only): the launch also carries level 0's copy -- level 1 is formed from the INPUT image (the bytes of level 0's interior), so the copy is no longer a launch
+// in front of the chain but the row groups blockIdx.y >= gridDim.y - nyb0 of this one (two bandwidth-bound launches of a batch side by side instead of one after the other)
+__global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l, int nyb0) {
     const LevelGeo &G = D.L[l], &S = D.L[l-1];
+    if (nyb0 > 0 && (int)blockIdx.y >= (int)gridDim.y - nyb0) { level0_item(D, 4*(blockIdx.x*RS_T + threadIdx.x), ((int)blockIdx.y - ((int)gridDim.y - nyb0))*L0_ROWS, blockIdx.z); return; }
     const int x = 4*(blockIdx.x*RS_T + threadIdx.x), y0 = blockIdx.y*RS_ROWS, f = blockIdx.z;
     if (x >= G.bw) return;
     const int2 *xtab = (const int2 *)(D.rtab + G.rx_off);
     const int4 *ytab = (const int4 *)(D.rtab + G.ry_off);
-    const uint8_t *src = D.pyr + (size_t)f*D.pyr_frame + S.pyr_off + (size_t)EDGE*S.bw + EDGE;
+    const uint8_t *src = nyb0 > 0 ? D.img + (size_t)f*D.h*D.stride : D.pyr + (size_t)f*D.pyr_frame + S.pyr_off + (size_t)EDGE*S.bw + EDGE;
+    const int spitch = nyb0 > 0 ? D.stride : S.bw;
     uint8_t *dst = D.pyr + (size_t)f*D.pyr_frame + G.pyr_off + x;
     const int ny = min(RS_ROWS, G.bh - y0);
     int sx[4], sx1[4], a0[4], a1[4];
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++) {                      // all loads of the row group in flight together
             yt[r] = ytab[y0 + min(r, ny - 1)];
-            const uint64_t u0 = *(const u64_unaligned *)(src + (size_t)yt[r].x*S.bw + base), u1 = *(const u64_unaligned *)(src + (size_t)yt[r].y*S.bw + base);
+            const uint64_t u0 = *(const u64_unaligned *)(src + (size_t)yt[r].x*spitch + base), u1 = *(const u64_unaligned *)(src + (size_t)yt[r].y*spitch + base);
             q0[r] = make_uint2((uint32_t)u0, (uint32_t)(u0 >> 32)); q1[r] = make_uint2((uint32_t)u1, (uint32_t)(u1 >> 32));
         }
 #pragma unroll
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l) {
     } else {
         for (int r = 0; r < ny; r++) {
             const int4 yt = ytab[y0 + r];
-            const uint8_t *r0 = src + (size_t)yt.x*S.bw, *r1 = src + (size_t)yt.y*S.bw;
+            const uint8_t *r0 = src + (size_t)yt.x*spitch, *r1 = src + (size_t)yt.y*spitch;
             for (int k = 0; k < 4 && x + k < G.bw; k++) {
                 const int S0 = r0[sx[k]]*a0[k] + r0[sx1[k]]*a1[k], S1 = r1[sx[k]]*a0[k] + r1[sx1[k]]*a1[k];
                 dst[(size_t)(y0 + r)*G.bw + k] = (uint8_t)((((yt.z*(S0 >> 4)) >> 16) + ((yt.w*(S1 >> 4)) >> 16) + 2) >> 2);
@@ -1514,7 +1518,7 @@ int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride
     // strict 3x3 NMS leaves at most one corner per 2x2 block: the level-0 search area bounds every level's candidate count
     D.cand_cap = ((D.L[0].maxBX - D.L[0].minB)*(D.L[0].maxBY - D.L[0].minB))/4 + 64; D.node_cap = 64*(c->nfl[0] + 64); D.pool_cap = 16*D.cand_cap;
     int rc;
-    uint8_t *img; if ((rc = oalloc(c, &img, (size_t)n*h*stride))) return rc; D.img = img;
+    uint8_t *img; if ((rc = oalloc(c, &img, (size_t)n*h*stride + 8))) return rc; D.img = img;        // (+ 8: level 1's 8-byte source loads at the end of the last row)
     c->h_img_sz = (size_t)n*h*stride; OCK(hipHostMalloc((void **)&c->h_img, c->h_img_sz, hipHostMallocDefault));
     memcpy(c->h_img, imgs, c->h_img_sz);
     OCK(hipMemcpyAsync(img, c->h_img, c->h_img_sz, hipMemcpyHostToDevice, c->stream));
@@ -1550,8 +1554,9 @@ int tsorb_run(void *ctx) {
     else if (c->pyr_shape == 3 && [&] { for (int q = 0; q < c->n_pairs; q++) if (c->q_inst[3 + q] < 0) return false; return true; }())
         for (int q = 0; q < c->n_pairs; q++) pyr_launch(c->Q[3 + q], c->q_inst[3 + q]);                                                                    // (experiment: two levels per launch, any batch)
     else {
-        hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
-        for (int l = 1; l < D.nlevels; l++) hipLaunchKernelGGL(k_resize, dim3((D.L[l].bw + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS, D.n), dim3(RS_T), 0, c->stream, D, l);
+        if (D.nlevels == 1) hipLaunchKernelGGL(k_level0, dim3((D.L[0].bw + 511)/512, (D.L[0].bh + L0_ROWS - 1)/L0_ROWS, D.n), dim3(128), 0, c->stream, D);
+        for (int l = 1; l < D.nlevels; l++) { const int nyb0 = l == 1 ? (D.L[0].bh + L0_ROWS - 1)/L0_ROWS : 0;        // (level 0's copy rides in level 1's launch)
+            hipLaunchKernelGGL(k_resize, dim3((std::max(D.L[l].bw, nyb0 ? D.L[0].bw : 0) + 4*RS_T - 1)/(4*RS_T), (D.L[l].bh + RS_ROWS - 1)/RS_ROWS + nyb0, D.n), dim3(RS_T), 0, c->stream, D, l, nyb0); }
     }
     const int fast_shape = c->fast_shape < 0 ? 2 : c->fast_shape;      // (diagnostics: 1 / 3 the small tile with 256 / 64 threads)
     if (D.fast_cells[0] > 0) {
