@@ -611,7 +611,9 @@ __global__ __launch_bounds__(64) void k_octree_serial(OrbDev D) { if (threadIdx.
 // One wave per (frame, level).  Candidates (x, y, response), the per-node key lists and the node pool live in LDS; the list
 // surgery is executed redundantly by all 64 lanes (uniform control flow, lane 0 writes), the 4-way stable partition of a
 // node's keys and the final arg-max are spread over the lanes.  Levels that do not fit fall back to k_octree_serial.
+#ifndef QL_CAND
 #define QL_CAND 4096
+#endif
 #define QL_NODES 1024
 struct QN { short x0, y0, x1, y1; unsigned short key0, nk, id, pad; };     // 16 bytes: box, key range, creation number
 #ifndef QT
