@@ -51,11 +51,12 @@ int tsorb_debug_level(void *ctx, int frame, int level, int blurred, uint8_t *out
  * the general instance whatever the batch size; 2: the split whatever the batch size; 1 / 3: the split with four waves / one wave per cell on the small tile (A/B runs).
  * The output does not depend on it (tests/test_gpu_orb.py).  Takes effect at the next upload. */
 int tsorb_debug_fast_shape(void *ctx, int shape);
-/* Test / diagnostics hook: how the pyramid is formed.  -1 (default): chosen by the batch size -- up to 4 frames a tile of a level is formed from a base level several
+/* Test / diagnostics hook: how the pyramid is formed.  -1 (default): chosen by the batch size -- for a few frames a tile of a level is formed from a base level several
  * levels up inside one workgroup (k_pyramid_one: two launches, levels 0 .. 3 from the input image and levels 4 .. from level 3; the per-frame call of frame.cc:328-331 is
  * a chain of eight dependent launches otherwise), larger batches take a launch per level; 0: always a launch per level; 1: always the two launches; 2: every level from
- * the input image in ONE launch (when the geometry fits the kernel's buffers; a launch per level otherwise); 100 + s: the two launches split at level s (takes effect at
- * the next upload).  The pyramid is the same bytes every way (tests/test_gpu_orb.py). */
+ * the input image in ONE launch (when the geometry fits the kernel's buffers; a launch per level otherwise); 3: two levels per launch at any batch size (an experiment:
+ * slower on a batch); 100 + s: the two launches split at level s (takes effect at the next upload); 200 / 201: a batch's orientation and blur as two launches / one (default).
+ * Up to 8 frames (not 4) take the few-frames plan since the quadtree and the descriptors joined it.  The output is the same bytes every way (tests/test_gpu_orb.py). */
 int tsorb_debug_pyramid(void *ctx, int shape);
 /* Test hook: the number of runs of this context in which a (frame, level) did not fit the LDS quadtree (more than 4096 candidates, 1024 nodes) and the serial pass
  * (k_octree_serial, then orientation and descriptors once more) was launched behind the first synchronisation. */
