@@ -13,3 +13,8 @@ export UBSAN_OPTIONS=print_stacktrace=0:halt_on_error=0
 TSBA_LIB=/tmp/libtsba_ubsan.so LD_PRELOAD="$CUBSAN" timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_global.py tests/test_gpu_context_reuse.py tests/test_gpu_far.py -m gpu -q -s -p no:cacheprovider > /tmp/san_gpu.log 2>&1
 say "libtsba host code (clang UBSan + bounds), GPU parity tests through the instrumented host side: $(grep -E 'passed|failed' /tmp/san_gpu.log | tail -1) ; reports: $(grep -c 'runtime error' /tmp/san_gpu.log)"
 grep -B2 -A12 'runtime error' /tmp/san_gpu.log | head -60 >> $LOG
+# libtsorb.so's host side the same way (round 6's last session rewrote its launch plans: the few-frames pyramid's tilings, the fallback word in pinned memory, the results' pinned copy)
+(cd textslam_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fsanitize=undefined,bounds -fno-omit-frame-pointer -Wno-unused-variable -o /tmp/libtsorb_ubsan.so tsorb.hip 2>/dev/null) || say "libtsorb UBSan build: FAILED"
+TSORB_LIB=/tmp/libtsorb_ubsan.so LD_PRELOAD="$CUBSAN" timeout 900 python -m pytest tests/test_gpu_orb.py -m gpu -q -s -p no:cacheprovider > /tmp/san_gpu_orb.log 2>&1
+say "libtsorb host code (clang UBSan + bounds), the ORB GPU tests through the instrumented host side: $(grep -E 'passed|failed' /tmp/san_gpu_orb.log | tail -1) ; reports: $(grep -c 'runtime error' /tmp/san_gpu_orb.log)"
+grep -B2 -A12 'runtime error' /tmp/san_gpu_orb.log | head -40 >> $LOG
