@@ -56,7 +56,7 @@ int tsorb_debug_fast_shape(void *ctx, int shape);
  * a chain of eight dependent launches otherwise), larger batches take a launch per level; 0: always a launch per level; 1: always the two launches; 2: every level from
  * the input image in ONE launch (when the geometry fits the kernel's buffers; a launch per level otherwise); 3: two levels per launch at any batch size (an experiment:
  * slower on a batch); 100 + s: the two launches split at level s (takes effect at the next upload); 200 / 201: a batch's orientation and blur as two launches / one (default).
- * Up to 8 frames (not 4) take the few-frames plan since the quadtree and the descriptors joined it.  The output is the same bytes every way (tests/test_gpu_orb.py). */
+ * Up to 5 frames take the few-frames plan (where it still beats the batch plan, which gained from the same session's work).  The output is the same bytes every way (tests/test_gpu_orb.py). */
 int tsorb_debug_pyramid(void *ctx, int shape);
 /* Test hook: the number of runs of this context in which a (frame, level) did not fit the LDS quadtree (more than 4096 candidates, 1024 nodes) and the serial pass
  * (k_octree_serial, then orientation and descriptors once more) was launched behind the first synchronisation. */

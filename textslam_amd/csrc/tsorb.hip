@@ -230,7 +230,7 @@ __global__ __launch_bounds__(RS_T) void k_resize(OrbDev D, int l, int nyb0) {
 // workgroups of its own in the first launch.  The deepest level's tiles come first in a launch: they are the longest.
 #define P1_L0_ROWS 16
 #ifndef P1_MAX_N
-#define P1_MAX_N 8
+#define P1_MAX_N 5                    // (ms per call, few-frames plan / a launch per stage and level, final tree: 1: 0.063 / 0.087, 2: 0.070 / 0.096, 4: 0.097 / 0.109, 5: 0.109 / 0.112, 6: 0.118 / 0.119, 8: 0.139 / 0.126)
 #endif
 #ifndef P1_SPLIT
 #define P1_SPLIT 3
