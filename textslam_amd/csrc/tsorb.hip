@@ -1345,18 +1345,36 @@ __global__ __launch_bounds__(1024) void k_mg_scan(MatchDev M) {          // incl
     for (int k = 0; k < 3; k++) { run += v[k]; M.off[1 + 3*t + k] = run; }
 }
 __global__ __launch_bounds__(256) void k_mg_place(MatchDev M) {           // rank inside the cell = features of the cell with a smaller index
-    const int i = blockIdx.x*256 + threadIdx.x;
-    if (i >= M.n) return;
-    const int c = M.cell[i];
-    if (c < 0) return;
+    // (64 features per workgroup, four threads each: the features before the workgroup's last one through LDS, 1024 at a time, a quarter of a tile per thread -- every thread
+    // walking all of them in global memory was 40 us for 1000 features)
+    __shared__ int s_cell[1024];
+    const int i = blockIdx.x*64 + (threadIdx.x >> 2), part = threadIdx.x & 3, iend = min((int)(blockIdx.x + 1)*64, M.n);
+    const int c = i < M.n ? M.cell[i] : -1;
     int rank = 0;
-    for (int j = 0; j < i; j++) rank += M.cell[j] == c;
-    M.list[M.off[c] + rank] = i;
+    for (int t0 = 0; t0 < iend; t0 += 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = t0 + threadIdx.x + 256*u; s_cell[threadIdx.x + 256*u] = j < iend ? M.cell[j] : -2; }
+        __syncthreads();
+        const int n = min(1024, i - t0), j0 = 256*part, j1 = min(n, j0 + 256);         // the features of this tile before feature i; this thread's quarter of the tile
+        if (c >= 0) for (int j = j0; j < j1; j += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) rank += (j + u < j1 && s_cell[j + u] == c) ? 1 : 0; }
+        __syncthreads();
+    }
+    rank += __shfl_xor(rank, 1, 4); rank += __shfl_xor(rank, 2, 4);
+    if (c >= 0 && part == 0) M.list[M.off[c] + rank] = i;
 }
-__global__ __launch_bounds__(128) void k_match(MatchDev M, int nq, const float *qxy, const float *qr, const int *qlev, const uint8_t *qdesc, int max_cand,
+// One WAVE per query (until round 6: one thread per query walking its window's cells one after the other -- two dependent loads per cell, two more per feature, 81 cells for a
+// 40-px radius: 289 us for 1000 queries, 0.37 ms per call of tracking::SearchFrom3D's search).  The window's cells on the lanes in the reference's order (column by column,
+// frame.cc:415-468), their feature counts as a wave scan; then the window's features on the lanes, again in that order (a lane finds its feature's cell in the scan), the
+// reference's filters and the Hamming distance per lane; the survivors keep their order through a ballot, best / second best as the two smallest of the multiset with the
+// first minimum's index (what the reference's sequential scan ends with).
+__global__ __launch_bounds__(256) void k_match(MatchDev M, int nq, const float *qxy, const float *qr, const int *qlev, const uint8_t *qdesc, int max_cand,
                                                int *cand_idx, int *cand_dist, int *cand_cnt, int *best_idx, int *best_dist, int *best_dist2) {
-    const int q = blockIdx.x*128 + threadIdx.x;
-    if (q >= nq) return;
+    __shared__ int s_inc[4][64], s_o0[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = blockIdx.x*4 + wv;
+    if (q >= nq) return;                                     // (a whole wave)
+    int *inc = s_inc[wv], *o0s = s_o0[wv];
     const float x = qxy[2*q], y = qxy[2*q+1], r = qr[q];
     const int minLevel = qlev ? qlev[2*q] : -1, maxLevel = qlev ? qlev[2*q+1] : -1;
     uint32_t qd[8];
@@ -1367,26 +1385,60 @@ __global__ __launch_bounds__(128) void k_match(MatchDev M, int nq, const float *
     const int c0y = max(0, (int)floor(((double)y - M.min_y - (double)r)*M.ih)), c1y = min(MG_ROWS - 1, (int)ceil(((double)y - M.min_y + (double)r)*M.ih));
     if (!(c0x >= MG_COLS || c1x < 0 || c0y >= MG_ROWS || c1y < 0)) {
         const bool check = (minLevel > 0) || (maxLevel >= 0);
-        for (int ix = c0x; ix <= c1x; ix++) for (int iy = c0y; iy <= c1y; iy++) {
-            const int c = ix*MG_ROWS + iy;
-            for (int k = M.off[c]; k < M.off[c+1]; k++) {
-                const int i = M.list[k];
-                const float fx = M.kp[6*i], fy = M.kp[6*i+1]; const int oct = (int)M.kp[6*i+5];
-                if (check) { if (oct < minLevel) continue; if (maxLevel >= 0 && oct > maxLevel) continue; }
-                const float dx = fx - x, dy = fy - y;
-                if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
-                const uint32_t *fd = (const uint32_t *)(M.desc + 32*(size_t)i);
-                int d = 0;
+        const int ny = c1y - c0y + 1, ncell = (c1x - c0x + 1)*ny;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int e0 = 0; e0 < ncell; e0 += 64) {             // 64 cells of the window at a time
+            const int e = e0 + lane; int o0 = 0, cnt = 0;
+            if (e < ncell) { const int ix = c0x + e/ny, iy = c0y + e - (e/ny)*ny, c = ix*MG_ROWS + iy; o0 = M.off[c]; cnt = M.off[c+1] - o0; }
+            int incl = cnt;
 #pragma unroll
-                for (int w = 0; w < 8; w++) d += __popc(qd[w] ^ fd[w]);
-                if (nc < max_cand) { cand_idx[(size_t)q*max_cand + nc] = i; cand_dist[(size_t)q*max_cand + nc] = d; }
-                nc++;
-                if (d < bd) { bd2 = bd; bd = d; bi = i; } else if (d < bd2) bd2 = d;
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+            const int tot = __shfl(incl, 63, 64);
+            inc[lane] = incl; o0s[lane] = o0 - (incl - cnt);                                 // (list position of the cell's first feature minus the features before the cell)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int j0 = 0; j0 < tot; j0 += 64) {            // 64 features of those cells at a time, in order
+                const int j = j0 + lane; bool pass = false; int i = 0, d = 0;
+                if (j < tot) {
+                    int lo = 0;                                // the first cell whose inclusive count exceeds j
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1) if (inc[lo + step - 1] <= j) lo += step;
+                    i = M.list[o0s[lo] + j];
+                    const float fx = M.kp[6*i], fy = M.kp[6*i+1]; const int oct = (int)M.kp[6*i+5];
+                    const uint32_t *fd = (const uint32_t *)(M.desc + 32*(size_t)i);
+                    uint32_t f8[8];
+#pragma unroll
+                    for (int w = 0; w < 8; w++) f8[w] = fd[w];
+                    pass = true;
+                    if (check) { if (oct < minLevel) pass = false; if (maxLevel >= 0 && oct > maxLevel) pass = false; }
+                    const float dx = fx - x, dy = fy - y;
+                    if (!(fabsf(dx) < r && fabsf(dy) < r)) pass = false;
+#pragma unroll
+                    for (int w = 0; w < 8; w++) d += __popc(qd[w] ^ f8[w]);
+                }
+                const unsigned long long pm = __ballot(pass);
+                if (pm) {
+                    const int rank = nc + __popcll(pm & lt);
+                    if (pass && rank < max_cand) { cand_idx[(size_t)q*max_cand + rank] = i; cand_dist[(size_t)q*max_cand + rank] = d; }
+                    nc += __popcll(pm);
+                    // the chunk's two smallest distances and the first lane of the smallest
+                    int m1 = pass ? d : 2147483647;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m1 = min(m1, __shfl_xor(m1, o, 64));
+                    const unsigned long long at1 = __ballot(pass && d == m1);
+                    const int first = __ffsll((long long)at1) - 1;
+                    int m2 = (pass && lane != first) ? d : 2147483647;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m2 = min(m2, __shfl_xor(m2, o, 64));
+                    const int i1 = __shfl(i, first, 64);
+                    // merged behind what came before (a later equal minimum does not take the index: strict < in the reference)
+                    if (m1 < bd) { bd2 = min(bd, m2); bd = m1; bi = i1; } else bd2 = min(bd2, m1);
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (the next 64 cells overwrite the scan)
         }
     }
-    for (int k = nc; k < max_cand; k++) { cand_idx[(size_t)q*max_cand + k] = -1; cand_dist[(size_t)q*max_cand + k] = -1; }     // unused slots
-    cand_cnt[q] = nc; best_idx[q] = bi; best_dist[q] = bd; best_dist2[q] = bd2;
+    for (int k = nc + lane; k < max_cand; k += 64) { cand_idx[(size_t)q*max_cand + k] = -1; cand_dist[(size_t)q*max_cand + k] = -1; }     // unused slots
+    if (lane == 0) { cand_cnt[q] = nc; best_idx[q] = bi; best_dist[q] = bd; best_dist2[q] = bd2; }
 }
 
 struct OCtx {
@@ -1643,7 +1695,7 @@ static int match_build(OCtx *c, const float *kp_dev, const uint8_t *desc_dev, in
     OCK(hipMemsetAsync(M.off, 0, sizeof(int)*(MG_CELLS + 1), c->stream));
     if (n > 0) hipLaunchKernelGGL(k_mg_cell, dim3((n + 255)/256), dim3(256), 0, c->stream, M);
     hipLaunchKernelGGL(k_mg_scan, dim3(1), dim3(1024), 0, c->stream, M);
-    if (n > 0) hipLaunchKernelGGL(k_mg_place, dim3((n + 255)/256), dim3(256), 0, c->stream, M);
+    if (n > 0) hipLaunchKernelGGL(k_mg_place, dim3((n + 63)/64), dim3(256), 0, c->stream, M);
     c->m_set = true; return TSORB_OK;
 }
 int tsorb_match_set_frame(void *ctx, int frame, double min_x, double max_x, double min_y, double max_y) {
@@ -1678,7 +1730,7 @@ int tsorb_match_search(void *ctx, int nq, const float *qxy, const float *qr, con
     memcpy(h + b_xy + b_r + b_lev, qdesc, b_d);
     OCK(hipMemcpyAsync(d, h, in_sz, hipMemcpyHostToDevice, c->stream));
     int *o_ci = (int *)(d + in_sz), *o_cd = o_ci + (size_t)nq*max_cand, *o_cnt = o_cd + (size_t)nq*max_cand, *o_bi = o_cnt + nq, *o_bd = o_bi + nq, *o_bd2 = o_bd + nq;
-    hipLaunchKernelGGL(k_match, dim3((nq + 127)/128), dim3(128), 0, c->stream, c->M, nq, (const float *)d, (const float *)(d + b_xy), (const int *)(d + b_xy + b_r),
+    hipLaunchKernelGGL(k_match, dim3((nq + 3)/4), dim3(256), 0, c->stream, c->M, nq, (const float *)d, (const float *)(d + b_xy), (const int *)(d + b_xy + b_r),
                        (const uint8_t *)(d + b_xy + b_r + b_lev), max_cand, o_ci, o_cd, o_cnt, o_bi, o_bd, o_bd2);
     OCK(hipMemcpyAsync(h + in_sz, d + in_sz, out_sz, hipMemcpyDeviceToHost, c->stream));
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
