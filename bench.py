@@ -268,6 +268,16 @@ def also_lines(gpu, local_rank, torch, steps=10):
         t0 = time.perf_counter(); ex.extract_batch(imgs[:1]); tc.append(time.perf_counter() - t0)
     out["orb_one_frame"] = {"ms_resident": float(np.median(ts))*1e3, "ms_resident_min": min(ts)*1e3, "ms_resident_max": max(ts)*1e3,
                             "ms_call": float(np.median(tc))*1e3, "ms_call_min": min(tc)*1e3, "ms_call_max": max(tc)*1e3, "timed": 20, "keypoints": int(len(ex.download()[0][0]))}
+    # the tracking thread's window search (tracking::SearchFrom3D*: frame::GetFeaturesInArea + DescriptorDistance): every keypoint of one frame searched in the next, 40-px radius
+    (kpA, dA), (kpB, dB) = ex.extract_batch(imgs[:2])
+    nq = kpA.shape[0]
+    qxy = kpA[:, :2].copy(); qr = np.full(nq, 40.0, np.float32); oct_ = kpA[:, 5].astype(np.int32); qlev = np.stack([oct_ - 1, oct_ + 1], 1).astype(np.int32)
+    tg, tq = [], []
+    for _ in range(23):
+        t0 = time.perf_counter(); ex.match_set_frame(1, (0.0, 640.0, 0.0, 480.0)); t1 = time.perf_counter(); res = ex.match_search(qxy, qr, qlev, dA, 32); t2 = time.perf_counter()
+        tg.append(t1 - t0); tq.append(t2 - t1)
+    out["orb_window_search"] = {"ms_search_call": float(np.median(tq[3:]))*1e3, "ms_search_call_min": min(tq[3:])*1e3, "ms_search_call_max": max(tq[3:])*1e3,
+                                "ms_grid_per_frame": float(np.median(tg[3:]))*1e3, "queries": int(nq), "radius_px": 40, "mean_candidates": float(res["cand_cnt"].mean()), "timed": 20}
     return out
 
 
