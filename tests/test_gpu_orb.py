@@ -182,6 +182,15 @@ def test_match_search_parity_on_resident_frames(orb, oracle_lib):
     for k in ("cand_cnt", "best_idx", "best_dist", "best_dist2", "cand_idx", "cand_dist"):
         assert np.array_equal(got[k], ref[k]), k
     assert (ref["cand_cnt"] > 0).mean() > 0.5 and ref["cand_cnt"].max() > 8        # both the common and the truncated case occur
+    # windows of many cells and many features (a wave takes 64 cells, then 64 features at a time), a window that leaves the grid, truncated candidate lists, no lists at all
+    qxy2 = qxy[:96].copy(); qxy2[:8] = [[-500.0, -500.0], [5.0, 5.0], [639.0, 479.0], [320.0, 240.0], [2000.0, 100.0], [0.0, 479.0], [639.0, 0.0], [320.0, -30.0]]
+    qr2 = np.where(np.arange(96) % 3 == 0, 300.0, 120.0).astype(np.float32)
+    for mc in (4, 0, 256):
+        ref3 = oracle.orb_match(kpB, dB, bounds, qxy2, qr2, qlev[:96], dA[:96], max_cand=mc)
+        got3 = ex.match_search(qxy2, qr2, qlev[:96], dA[:96], max_cand=mc)
+        for k in ("cand_cnt", "best_idx", "best_dist", "best_dist2", "cand_idx", "cand_dist"):
+            assert np.array_equal(got3[k], ref3[k]), (mc, k)
+    assert ref3["cand_cnt"].max() > 128                                                # more features than two rounds of a wave
     # explicit feature set, no level check (keyframe::GetFeaturesInArea)
     ref2 = oracle.orb_match(kpA, dA, bounds, qxy, qr, np.full((nq, 2), -1, np.int32), dA, max_cand=32)
     ex.match_set_features(kpA, dA, bounds)
