@@ -73,7 +73,7 @@ typedef struct tsba_debug_options {
     int32_t pcg_block;         // 0 / 1: the single-vector iteration, 2: enlarged conjugate gradients (32 columns per preconditioner application, tsba_pcg.h) where the many-column solve phase of the band solver exists
     int32_t solve_variant;     // reduced system of a small window (one workgroup, S in LDS): 0 the two-panel-wave schedule (tsba_solve.h), 1 the look-ahead schedule with a separate diagonal wave (tsba_solve_la.h: built in round 4 and measured SLOWER, 39.3 against 33.2 us on C4; kept for A/B runs), 2 as 1 with the update tiles handed out in wave order, 3 the production solver with the back-substitution and the step decision as launches of their own (k_solve_t + k_back + k_decide per trial, production until round 4) instead of in the solver's launch (k_solve_back) and in the next trial's k_schur_t, 4 as 3 with every 6x6 diagonal block factored from a scratch copy in LDS by every lane of the panel waves (production until round 5) instead of in place across six lanes with v_readlane broadcasts (bit-identical), 5 as 0 (production) with that scratch-copy factorisation
     int32_t sv_per_level;      // bit 0: the separator tree of the single-vector solve phase as one launch per level (k_sv_cre_fwd / _top / _back, production until round 4) instead of one launch for the whole tree (k_sv_cre_tree); bit 1: the back substitution of the factorisation's own solve on maps with long-range blocks as a launch per level (k_cre_back) instead of one launch through the solve phase's products (k_cre_back_tree); bit 2: the update step of a conjugate-gradient iteration (alpha; x, r) as a launch of its own (k_pcg_update) instead of inside the first kernel of the preconditioner application; bit 3: the interiors' back substitution of the solve phase as a launch of its own (k_sv_back_int) instead of in the tree's launch (k_sv_tree_back): A/B runs, bit-identity / parity tests
-    int32_t host_pair_lists;   // 1: the slot pairs of the S blocks are built on the host (as every map did until round 4 and every window until round 6) instead of on the device (tsba_devplan.h): A/B runs, list comparison; and single-frame problems (tsba_pose_optim) get their plan from the generic builder on plan threads, the later passes' levels staged during the solve (until round 6), instead of build_plan_single_frame on the calling thread
+    int32_t host_pair_lists;   // 0: on the device for problems of at least 4096 scene observations, on the host below; 2: on the device at any size; 1: the slot pairs of the S blocks are built on the host (as every map did until round 4 and every window until round 6) instead of on the device (tsba_devplan.h): A/B runs, list comparison; and single-frame problems (tsba_pose_optim) get their plan from the generic builder on plan threads, the later passes' levels staged during the solve (until round 6), instead of build_plan_single_frame on the calling thread
     int32_t pass_launches;     // 1: a window's pass begins and ends with the launches of rounds 1-4 (k_pass_reset, k_participation, k_gauge_wave, k_musigma | k_outlier, state copy) instead of k_pass_begin | k_pass_end (tsba_kernels_pass.h); PoseOptim: a launch per LM step (k_pose_iter) instead of one per pass (k_pose_pass): A/B runs, agreement tests
     int32_t trial_launches;    // windows: 0 production (k_linearize, k_mid<256> as two launches); 2: the round-5 experiment k_lin_mid -- k_mid inside the speculative linearisation's launch, its last workgroups to finish taking k_mid's blocks of 128 -- measured SLOWER (40.7 against 13.4 + 10.6 us: 736 workgroups signalling completion cost more than the kernel boundary); 1: the two launches with k_mid's blocks of 128 (the experiment's bit-identical comparison partner)
     int32_t assume_cus;        // > 0: the residency test of the kernels whose workgroups poll each other (k_solve_back, k_sv_cre_tree, k_sv_tree_back, k_cre_back_tree) assumes a device of this many compute units (tests: a device too small for the grid takes the launch-per-step path)

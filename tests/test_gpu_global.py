@@ -493,7 +493,7 @@ def test_schur_lists_built_on_the_device_equal_the_host_lists_on_windows(gpu, sh
     o = abi.options_init() if shape == "init_pair" else abi.options_local()
     outs = []
     try:
-        for mode in (1, 0):
+        for mode in (1, 2):                                   # (2: the device lists at any size; by default only from 4096 scene observations on)
             gpu.debug_set(host_pair_lists=mode)
             G = P.copy(); r = gpu.LocalBundleAdjustment(G, options=o)
             gpu.upload(P, o); r2 = gpu.solve(); G2 = gpu.download(P.copy())

@@ -465,7 +465,9 @@ static int upload_impl(void *ctx, const tsba_problem *p, const tsba_options *o, 
         // the point slot pairs by S block are built on the device (tsba_devplan.h) -- since round 4 on maps of more than 126 keyframes (2 M pairs: 9 of the plan's 21 ms), since round 6 on
         // windows as well: they are the largest part of a window's plan (C4 level 2: 0.18 of 0.5 ms on the calling thread of a one-shot call, level 0: 0.7 of 1.5 ms), the three small
         // launches that build them cost the pass ~15 us, the lists are the same entries in the same order (same bits: test_schur_lists_built_on_the_device_equal_the_host_lists)
-        const bool dev_pairs = p->n_kf > 1 && c->dbg.host_pair_lists != 1;
+        // (... on problems of at least 4096 scene observations: below, the three launches cost a level more than the host's lists -- InitBA's pair, a landmark's refinement, a plane's:
+        // 15 us per level of calls that take 1.3 - 2.3 ms in launch-bound trials of ~32 us; tsba_debug_options.host_pair_lists = 2 asks for the device lists at any size)
+        const bool dev_pairs = p->n_kf > 1 && c->dbg.host_pair_lists != 1 && (c->dbg.host_pair_lists == 2 || p->n_sobs[0] >= 4096);
         for (int ps = o->n_passes - 1; ps >= 0; ps--) { const int l = o->levels[ps]; if (seen[l]) continue;
             bool later = false; for (int q = 0; q < ps; q++) later |= o->levels[q] == l;       // (a level used by an earlier pass is started with that pass)
             if (later) continue;
