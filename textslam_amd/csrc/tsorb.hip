@@ -1722,17 +1722,18 @@ int tsorb_match_search(void *ctx, int nq, const float *qxy, const float *qr, con
     // one pinned staging block in, one out: [qxy | qr | qlev | qdesc]  ->  [cand_idx | cand_dist | cnt | best | dist | dist2]
     const size_t b_xy = 8*(size_t)nq, b_r = 4*(size_t)nq, b_lev = 8*(size_t)nq, b_d = 32*(size_t)nq, in_sz = b_xy + b_r + b_lev + b_d;
     const size_t b_c = 4*(size_t)nq*max_cand, out_sz = 2*b_c + 16*(size_t)nq, tot = in_sz + out_sz;
-    if (c->mq_cap < tot) { if (c->mq_dev) hipFree(c->mq_dev); if (c->mq_host) hipHostFree(c->mq_host); c->mq_cap = 0;
-        OCK(hipMalloc(&c->mq_dev, tot)); OCK(hipHostMalloc(&c->mq_host, tot, hipHostMallocDefault)); c->mq_cap = tot; }
-    char *h = (char *)c->mq_host, *d = (char *)c->mq_dev;
+    if (c->mq_cap < tot) { if (c->mq_host) hipHostFree(c->mq_host); c->mq_cap = 0;
+        OCK(hipHostMalloc(&c->mq_host, tot, hipHostMallocDefault)); c->mq_cap = tot; }
+    char *h = (char *)c->mq_host, *d = nullptr;
     memcpy(h, qxy, b_xy); memcpy(h + b_xy, qr, b_r);
     if (qlev) memcpy(h + b_xy + b_r, qlev, b_lev); else for (size_t k = 0; k < 2*(size_t)nq; k++) ((int32_t *)(h + b_xy + b_r))[k] = -1;
     memcpy(h + b_xy + b_r + b_lev, qdesc, b_d);
-    OCK(hipMemcpyAsync(d, h, in_sz, hipMemcpyHostToDevice, c->stream));
+    // (round 6: the kernel reads the queries from, and stores the results into, the pinned block itself -- a wave reads its query's 52 bytes once, the results are a few KB (or
+    // the candidate lists' 8 bytes per entry): two copies on the stream cost the call more than the bus does; d = the block's device address)
+    { void *hd = nullptr; OCK(hipHostGetDevicePointer(&hd, c->mq_host, 0)); d = (char *)hd; }
     int *o_ci = (int *)(d + in_sz), *o_cd = o_ci + (size_t)nq*max_cand, *o_cnt = o_cd + (size_t)nq*max_cand, *o_bi = o_cnt + nq, *o_bd = o_bi + nq, *o_bd2 = o_bd + nq;
     hipLaunchKernelGGL(k_match, dim3((nq + 3)/4), dim3(256), 0, c->stream, c->M, nq, (const float *)d, (const float *)(d + b_xy), (const int *)(d + b_xy + b_r),
                        (const uint8_t *)(d + b_xy + b_r + b_lev), max_cand, o_ci, o_cd, o_cnt, o_bi, o_bd, o_bd2);
-    OCK(hipMemcpyAsync(h + in_sz, d + in_sz, out_sz, hipMemcpyDeviceToHost, c->stream));
     OCK(hipStreamSynchronize(c->stream)); OCK(hipGetLastError());
     const char *ho = h + in_sz;
     if (cand_idx) memcpy(cand_idx, ho, b_c);
