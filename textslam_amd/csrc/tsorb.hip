@@ -1506,6 +1506,7 @@ int tsorb_get_features_per_level(void *ctx, int32_t *n) { OCtx *c = (OCtx *)ctx;
 int tsorb_upload(void *ctx, const uint8_t *imgs, int n, int w, int h, int stride, int cap) {
     OCtx *c = (OCtx *)ctx; if (!c || !imgs || n < 1 || w < 64 || h < 64 || stride < w || cap < 1) return TSORB_ERR_ARG;
     hipSetDevice(c->device);
+    c->out_on_host = false;                                  // (until the next run)
     if (c->uploaded && c->key[0] == n && c->key[1] == w && c->key[2] == h && c->key[3] == stride && c->key[4] == cap) {
         // same geometry as the previous call: only the pixels travel (pinned staging, one asynchronous copy)
         memcpy(c->h_img, imgs, (size_t)n*h*stride);
@@ -1702,7 +1703,9 @@ int tsorb_match_set_frame(void *ctx, int frame, double min_x, double max_x, doub
     OCtx *c = (OCtx *)ctx; if (!c || !c->uploaded) return TSORB_ERR_ARG;
     OrbDev &D = c->D; if (frame < 0 || frame >= D.n) return TSORB_ERR_ARG;
     hipSetDevice(c->device);
-    int cnt = 0; OCK(hipMemcpyAsync(&cnt, D.out_cnt + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream)); OCK(hipStreamSynchronize(c->stream));
+    int cnt = 0;
+    if (c->out_on_host) cnt = ((const int *)((const uint8_t *)c->h_out + sizeof(float)*(size_t)D.n*D.cap*6))[frame];       // (a few frames: the run stored the counts in the pinned block and waited for it -- no copy, no synchronisation: 0.035 -> ~0.01 ms)
+    else { OCK(hipMemcpyAsync(&cnt, D.out_cnt + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream)); OCK(hipStreamSynchronize(c->stream)); }
     return match_build(c, D.out_kp + (size_t)frame*D.cap*6, D.out_desc + (size_t)frame*D.cap*32, cnt, min_x, max_x, min_y, max_y);
 }
 int tsorb_match_set_features(void *ctx, const float *kp6, const uint8_t *desc, int n, double min_x, double max_x, double min_y, double max_y) {
