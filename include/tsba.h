@@ -257,6 +257,10 @@ int  tsba_eval(void *ctx, const tsba_problem *p, const tsba_options *o, int leve
  * poses replicated) and tsba_solve all-reduces the reduced normal equations S (its band), g and a few scalars once per LM trial.
  * id128 == NULL selects the split (multi-GPU) kernel sequence without a communicator (single-process test hook). */
 int  tsba_comm_unique_id(void *ctx, void *id128);
+/* Loads RCCL into the process (once; tsba_comm_unique_id / tsba_comm_init do it themselves otherwise).  Call it at start-up, BEFORE other host threads launch kernels, in a process
+ * that will use a communicator: loading a HIP library registers its code objects with the runtime, and a launch on another thread at that moment is not safe (observed beside a looping
+ * extractor and a looping bundle adjustment: "invalid device function", a segmentation fault inside the other thread's launch).  TSBA_OK, or TSBA_ERR_COMM when no librccl is found. */
+int  tsba_comm_load(void);
 int  tsba_comm_init(void *ctx, const void *id128, int rank, int world);
 /* What the last solve handed to collectives on this rank: ranks = size of the communicator (ncclCommCount; 1 without one),
  * bytes[0] per LM trial (reduced normal equations + the sums of the speculative linearisation), bytes[1] per linearisation,

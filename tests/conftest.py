@@ -48,6 +48,8 @@ def busy_device():
         return
     import threading
     import numpy as np
+    from textslam_amd.optimizer import load_library
+    load_library().tsba_comm_load()                 # (include/tsba.h: RCCL's code objects are registered before the busy threads launch kernels, not under them by the communicator tests)
     stop = threading.Event(); threads = []; counts = {"orb": 0, "ba": 0}
     if mode in ("orb", "both"):
         from textslam_amd.orbextractor import ORBextractor, synthetic_frame

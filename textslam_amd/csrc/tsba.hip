@@ -1868,22 +1868,33 @@ int tsba_debug_step_stamps(void *ctx, long long *out128) {      // stamps build 
 }
 #endif
 
-static int load_rccl(Ctx *c) {
-    if (c->rccl_so) return 0;
+// The library is loaded ONCE per process, under a lock -- and should be loaded (tsba_comm_load) before other host threads launch kernels: loading a HIP library registers its code
+// objects with the runtime, and a kernel launch or hipFuncSetAttribute on another thread at that moment has been seen to fail ("invalid device function") and to crash (a segmentation
+// fault inside another library's launch): the busy-context suite of round 6, test_multi_gpu_kernel_sequence_single_process beside an ORB extractor and a bundle adjustment looping on
+// their own threads, once in about five runs (docs/ledger_r06.md 15.14).
+static std::mutex g_rccl_mu; static void *g_rccl_so = nullptr; static std::string g_rccl_tried;
+static void *rccl_handle() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl_so) return g_rccl_so;
     // RCCL must sit on the SAME HIP runtime as this library: streams and device pointers do not cross runtimes.  A process can hold
     // two (a PyTorch wheel bundles its own libamdhip64 + librccl next to /opt/rocm's, and which one this library is bound to
     // depends on the load order), and a bare dlopen("librccl.so.1") returns whichever copy was loaded first.  So: find the
     // runtime our own HIP calls resolve to and take the librccl next to it, by full path.
-    std::string tried;
+    g_rccl_tried.clear();
     Dl_info di;
     if (dladdr((void *)&hipStreamSynchronize, &di) && di.dli_fname) {
         std::string dir(di.dli_fname); const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? std::string(".") : dir.substr(0, sl);
         for (const char *n : { "/librccl.so.1", "/librccl.so" }) {
-            const std::string path = dir + n; tried += path + " ";
-            c->rccl_so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL); if (c->rccl_so) break; }
+            const std::string path = dir + n; g_rccl_tried += path + " ";
+            g_rccl_so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL); if (g_rccl_so) break; }
     }
-    if (!c->rccl_so) for (const char *n : { "librccl.so.1", "librccl.so" }) { tried += std::string(n) + " "; c->rccl_so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (c->rccl_so) break; }
-    if (!c->rccl_so) { set_err(c, std::string("dlopen(librccl) failed, tried: ") + tried + ": " + dlerror()); return TSBA_ERR_COMM; }
+    if (!g_rccl_so) for (const char *n : { "librccl.so.1", "librccl.so" }) { g_rccl_tried += std::string(n) + " "; g_rccl_so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl_so) break; }
+    return g_rccl_so;
+}
+static int load_rccl(Ctx *c) {
+    if (c->rccl_so) return 0;
+    c->rccl_so = rccl_handle();
+    if (!c->rccl_so) { const char *e = dlerror(); set_err(c, std::string("dlopen(librccl) failed, tried: ") + g_rccl_tried + ": " + (e ? e : "")); return TSBA_ERR_COMM; }
     c->p_getid = (decltype(c->p_getid))dlsym(c->rccl_so, "ncclGetUniqueId");
     c->p_init = (decltype(c->p_init))dlsym(c->rccl_so, "ncclCommInitRank");
     c->p_allreduce = (decltype(c->p_allreduce))dlsym(c->rccl_so, "ncclAllReduce");
@@ -1893,6 +1904,7 @@ static int load_rccl(Ctx *c) {
     if (!c->p_getid || !c->p_init || !c->p_allreduce || !c->p_destroy || !c->p_errstr) { set_err(c, "librccl: missing symbols"); return TSBA_ERR_COMM; }
     return 0;
 }
+int tsba_comm_load(void) { return rccl_handle() ? TSBA_OK : TSBA_ERR_COMM; }
 int tsba_comm_unique_id(void *ctx, void *id128) {
     Ctx *c = (Ctx *)ctx; if (!c || !id128) return TSBA_ERR_ARG;
     int rc = load_rccl(c); if (rc) return rc;

@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "tsba_default_options_init", "tsba_default_options_landmarker", "tsba_default_options_theta",
     "tsba_local_ba", "tsba_pose_optim", "tsba_global_ba", "tsba_theta_optim", "tsba_text_label_image",
     "tsba_upload", "tsba_solve", "tsba_download", "tsba_eval", "tsba_time_linearize",
-    "tsba_comm_unique_id", "tsba_comm_init", "tsba_comm_init_local", "tsba_local_group_create", "tsba_local_group_destroy",
+    "tsba_comm_unique_id", "tsba_comm_load", "tsba_comm_init", "tsba_comm_init_local", "tsba_local_group_create", "tsba_local_group_destroy",
     "tsba_debug_set", "tsba_debug_reduced_system",
 ]
 
