@@ -1,8 +1,9 @@
 // libtsorb.so -- MI355X (gfx950) ORB front-end for TextSLAM's ORBextractor hot path.  C ABI in include/tsorb.h.
 //
 // Batch of n frames, every stage one launch over (frame, level, ...):
-//   k_level0 / k_resize   pyramid: 8 levels x1.2, cv::resize INTER_LINEAR fixed point (11-bit weights), 19-px REFLECT_101 frame
-//                         fused in (a border pixel is the resize result at the reflected coordinate)        ORBextractor.cc:1118-1143
+//   k_resize              pyramid: 8 levels x1.2, cv::resize INTER_LINEAR fixed point (11-bit weights), 19-px REFLECT_101 frame
+//                         fused in (a border pixel is the resize result at the reflected coordinate); level 1 from the input image,
+//                         level 0's copy inside its launch                                                 ORBextractor.cc:1118-1143
 //   k_fast                one workgroup per 30-px cell: ROI tile in LDS, FAST-9/16 + cornerScore + 3x3 NMS at threshold 20,
 //                         per-cell fallback to 7, row-major ordered compaction                               :766-830
 //   k_octree              one workgroup per (frame, level): DistributeOctTree -- the full passes and the first pass of phase 2 in
@@ -11,6 +12,12 @@
 //   k_blur                7x7 sigma-2 Gaussian, Q8 fixed point separable, LDS tiled                            :1096-1097
 //   k_describe            32 lanes per keypoint: 256 steered BRIEF tests, one byte per lane, written straight into the
 //                         level-major output (coordinates scaled back to level 0)                               :108-147, :1106-1112
+//   (k_orient and k_blur share a launch: k_orient_blur.)
+// Up to P1_MAX_N frames -- the per-frame call of frame.cc:328-331 -- take a launch plan of their own, five launches: k_pyramid_one x 2 (a level's tile formed
+// inside one workgroup from the input image / from level 3), k_fast_blur (the blur's tiles behind the detector's workgroups), k_octree, k_orient_describe
+// (orientation inside the descriptor's launch, results also stored in the pinned block the download hands out).  Levels the LDS quadtree cannot hold are
+// flagged in pinned memory and redone by k_octree_serial behind the run's synchronisation.
+// Window search (tracking::SearchFrom3D*): k_mg_cell / k_mg_scan / k_mg_place build a frame's 64 x 48 grid, k_match searches it, a wave per query.
 // Integer / fp32 arithmetic is written so that every rounding matches the CPU oracle: no FMA contraction where the
 // reference has separate multiplies and adds (__fmul_rn / __fadd_rn / __dmul_rn ...), rintf = cvRound (half to even).
 #include <hip/hip_runtime.h>
