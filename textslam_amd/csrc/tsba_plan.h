@@ -406,6 +406,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
     P.pair_tg.resize(n_tg);
     { std::vector<int> cur(P.pair_tg_off.begin(), P.pair_tg_off.end() - 1);
       for (int g = 0; g < n_tg; g++) P.pair_tg[cur[P.tg_pair[g]]++] = g; }
+    lap("  text groups");
     // ---- landmark slots (landmark-major; last slot of a landmark = its host pose): the sorted candidates placed by point
     {   BucketPlacer bl(pool, n_pt, SC);
         pool.run([&](int t) { size_t c0, c1; pool.range((size_t)n_sc, t, c0, c1); bl.begin(t, c1 - c0);
@@ -419,6 +420,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
         pool.run([&](int t) { size_t j0, j1; pool.range((size_t)n_pt, t, j0, j1);
             for (size_t j = j0; j < j1; j++) if (P.pls_off[j+1] > P.pls_off[j]) { const int s = P.pls_off[j+1] - 1; P.pslot_pose[s] = p->pt_host[j]; P.pslot_lm[s] = (int)j; } });
     }
+    lap("  point slots");
     {
         std::vector<int> cnt(n_text + 1, 0);
         for (int g = 0; g < n_tg; g++) if (p->text_host[P.tg_text[g]] >= 0) cnt[P.tg_text[g]]++;
@@ -431,6 +433,7 @@ inline void build_plan(const tsba_problem *p, const tsba_options *o, int L, Host
             int s = cur[j]++; P.tg_slot[g] = s; P.tslot_pose[s] = P.tg_kf[g]; P.tslot_pair[s] = P.tg_pair[g]; P.tslot_lm[s] = j; }
         for (int j = 0; j < n_text; j++) if (cnt[j] > 0) { int s = P.tls_off[j+1] - 1; P.tslot_pose[s] = p->text_host[j]; P.tslot_lm[s] = j; }
     }
+    lap("  text slots");
     {   // the point slots of every pose (0.57 M slots at 5000 keyframes)
         const size_t n_ps = (size_t)P.n_pslot();
         BucketPlacer bq(pool, n_kf, SC);
